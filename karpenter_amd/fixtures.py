@@ -1,0 +1,367 @@
+"""Problem builders: synthetic instance types, NodePools and pods, as the JSON problem document both the product host
+library (karpenter_amd/host) and the test oracle read.
+
+Each builder mirrors a fixture of the reference so parity tests read like the reference's own tests:
+  fake_instance_type / fake_instance_types / fake_default_instance_types / fake_instance_types_assorted
+      -> pkg/cloudprovider/fake/instancetype.go:99-205, :411-439, :369-409 ; fake/cloudprovider.go:220-267
+  kwok_instance_types   -> kwok/tools/gen_instance_types.go:36-113 + kwok/cloudprovider/helpers.go:125-214
+  pod(...)              -> pkg/test/pods.go:88 (test.Pod / PodOptions)
+  node_pool(...)        -> pkg/test/nodepool.go:35 (test.NodePool)
+Quantities are Kubernetes quantity strings ("100m", "4Gi", "1.8G").
+"""
+from __future__ import annotations
+
+import copy
+import math
+import random
+import re
+
+ZONE = "topology.kubernetes.io/zone"
+HOSTNAME = "kubernetes.io/hostname"
+ARCH = "kubernetes.io/arch"
+OS = "kubernetes.io/os"
+INSTANCE_TYPE = "node.kubernetes.io/instance-type"
+CAPACITY_TYPE = "karpenter.sh/capacity-type"
+NODEPOOL = "karpenter.sh/nodepool"
+
+# pkg/cloudprovider/fake/instancetype.go:36-52
+FAKE_LABEL_INSTANCE_SIZE = "size"
+FAKE_EXOTIC_LABEL = "special"
+FAKE_INTEGER_LABEL = "integer"
+FAKE_WELL_KNOWN = [FAKE_LABEL_INSTANCE_SIZE, FAKE_EXOTIC_LABEL, FAKE_INTEGER_LABEL, "karpenter.sh/reservation-id"]
+GPU_VENDOR_A = "fake.com/vendor-a"
+GPU_VENDOR_B = "fake.com/vendor-b"
+
+# kwok/apis/v1alpha1/labels.go:25-46
+KWOK_SIZE = "karpenter.kwok.sh/instance-size"
+KWOK_FAMILY = "karpenter.kwok.sh/instance-family"
+KWOK_MEMORY = "karpenter.kwok.sh/instance-memory"
+KWOK_CPU = "karpenter.kwok.sh/instance-cpu"
+KWOK_WELL_KNOWN = [KWOK_SIZE, KWOK_FAMILY, KWOK_CPU, KWOK_MEMORY]
+KWOK_ZONES = ["test-zone-a", "test-zone-b", "test-zone-c", "test-zone-d"]
+
+_SUFFIX = {"": 1.0, "m": 1e-3, "k": 1e3, "M": 1e6, "G": 1e9, "T": 1e12, "Ki": 2.0**10, "Mi": 2.0**20, "Gi": 2.0**30, "Ti": 2.0**40}
+
+
+def quantity_float(q) -> float:
+    """resource.Quantity.AsApproximateFloat64 for the quantities the fixtures use."""
+    m = re.fullmatch(r"([0-9.]+)([a-zA-Z]*)", str(q))
+    return float(m.group(1)) * _SUFFIX[m.group(2)]
+
+
+def req(key, operator, *values, min_values=None):
+    r = {"key": key, "operator": operator, "values": [str(v) for v in values]}
+    if min_values is not None:
+        r["minValues"] = min_values
+    return r
+
+
+def offering(capacity_type, zone, price, available=True, reservation_id=None, reservation_capacity=0):
+    reqs = [req(CAPACITY_TYPE, "In", capacity_type), req(ZONE, "In", zone)]
+    if reservation_id is not None:
+        reqs.append(req("karpenter.sh/reservation-id", "In", reservation_id))
+    o = {"requirements": reqs, "price": price, "available": available}
+    if reservation_capacity:
+        o["reservationCapacity"] = reservation_capacity
+    return o
+
+
+def fake_price(resources) -> float:
+    """fake.PriceFromResources — fake/instancetype.go:426-439."""
+    price = 0.0
+    for k, v in resources.items():
+        if k == "cpu":
+            price += 0.1 * quantity_float(v)
+        elif k == "memory":
+            price += 0.1 * quantity_float(v) / 1e9
+        elif k in (GPU_VENDOR_A, GPU_VENDOR_B):
+            price += 1.0
+    return price
+
+
+def fake_instance_type(name, resources=None, offerings=None, architecture=None, operating_systems=None, requirements=None):
+    """fake.NewInstanceType — fake/instancetype.go:99-205."""
+    res = dict(resources or {})
+    res.setdefault("cpu", "4")
+    res.setdefault("memory", "4Gi")
+    res.setdefault("pods", "5")
+    if not offerings:
+        p = fake_price(res)
+        offerings = [offering("spot", "test-zone-1", p), offering("spot", "test-zone-2", p), offering("on-demand", "test-zone-1", p),
+                     offering("on-demand", "test-zone-2", p), offering("on-demand", "test-zone-3", p)]
+    arch = architecture or "amd64"
+    oses = sorted(operating_systems) if operating_systems else sorted(["linux", "windows", "darwin"])
+    avail = [o for o in offerings if o.get("available", True)]
+
+    def off_val(o, key):
+        return next(r["values"][0] for r in o["requirements"] if r["key"] == key)
+
+    cpu_val = int(quantity_float(res["cpu"]))  # Quantity.Value() rounds up; fixtures use whole CPUs
+    reqs = [
+        req(INSTANCE_TYPE, "In", name),
+        req(ARCH, "In", arch),
+        req(OS, "In", *oses),
+        req(ZONE, "In", *[off_val(o, ZONE) for o in avail]),
+        req(CAPACITY_TYPE, "In", *[off_val(o, CAPACITY_TYPE) for o in avail]),
+        req(FAKE_INTEGER_LABEL, "In", cpu_val),
+    ]
+    large = quantity_float(res["cpu"]) > 4 and quantity_float(res["memory"]) > 8 * 2.0**30
+    if large:
+        reqs += [req(FAKE_LABEL_INSTANCE_SIZE, "In", "large"), req(FAKE_EXOTIC_LABEL, "In", "optional")]
+    else:
+        reqs += [req(FAKE_LABEL_INSTANCE_SIZE, "In", "small"), req(FAKE_EXOTIC_LABEL, "DoesNotExist")]
+    # NOTE the reference builds size/special as DoesNotExist and then Insert()s a value, which turns them into In
+    # (complement stays false, instancetype.go:170-185); extra requirements are intersected in before that.
+    reqs += list(requirements or [])
+    return {"name": name, "requirements": reqs, "capacity": res, "overhead": {"cpu": "100m", "memory": "10Mi"}, "offerings": offerings}
+
+
+def fake_instance_types(total):
+    """fake.InstanceTypes — fake/instancetype.go:411-424."""
+    return [fake_instance_type(f"fake-it-{i}", {"cpu": str(i + 1), "memory": f"{(i + 1) * 2}Gi", "pods": str((i + 1) * 10)}) for i in range(total)]
+
+
+def fake_default_instance_types():
+    """fake CloudProvider default catalogue — fake/cloudprovider.go:232-262."""
+    return [
+        fake_instance_type("default-instance-type"),
+        fake_instance_type("small-instance-type", {"cpu": "2", "memory": "2Gi"}),
+        fake_instance_type("gpu-vendor-instance-type", {GPU_VENDOR_A: "2"}),
+        fake_instance_type("gpu-vendor-b-instance-type", {GPU_VENDOR_B: "2"}),
+        fake_instance_type("arm-instance-type", {"cpu": "16", "memory": "128Gi"}, architecture="arm64", operating_systems=["ios", "linux", "windows", "darwin"]),
+        fake_instance_type("single-pod-instance-type", {"pods": "1"}),
+    ]
+
+
+def fake_instance_types_assorted():
+    """fake.InstanceTypesAssorted — fake/instancetype.go:369-409."""
+    out = []
+    for cpu in [1, 2, 4, 8, 16, 32, 64]:
+        for mem in [1, 2, 4, 8, 16, 32, 64, 128]:
+            for zone in ["test-zone-1", "test-zone-2", "test-zone-3"]:
+                for ct in ["spot", "on-demand"]:
+                    for os_ in ["linux", "windows"]:
+                        for arch in ["amd64", "arm64"]:
+                            res = {"cpu": str(cpu), "memory": f"{mem}Gi"}
+                            out.append(fake_instance_type(f"{cpu}-cpu-{mem}-mem-{arch}-{os_}-{zone}-{ct}", res, [offering(ct, zone, fake_price(res))], arch, [os_]))
+    return out
+
+
+def kwok_instance_types(cpus=(1, 2, 4, 8, 16, 32, 48, 64, 96, 128, 192, 256), mem_factors=(2, 4, 8), oses=("linux", "windows"),
+                        archs=("amd64", "arm64"), zones=KWOK_ZONES, limit=None):
+    """kwok generic catalogue — gen_instance_types.go:68-113 through helpers.go:125-214 (newInstanceType).
+
+    The stock grid gives 144 types. Wider grids (more cpu sizes / memory factors) keep the same naming and price rule
+    and are used for the 500- and 1000-type configurations.
+    """
+    out = []
+    for cpu in cpus:
+        for mf in mem_factors:
+            for os_ in oses:
+                for arch in archs:
+                    family = {2: "c", 4: "s", 8: "m"}.get(mf, "e")
+                    name = f"{family}-{cpu}x-{arch}-{os_}" if mf in (2, 4, 8) else f"e{mf}-{cpu}x-{arch}-{os_}"
+                    mem = cpu * mf
+                    pods = max(0, min(cpu * 16, 1024))
+                    res = {"cpu": str(cpu), "memory": f"{mem}Gi", "pods": str(pods), "ephemeral-storage": "20Gi"}
+                    price = 0.025 * cpu + 0.001 * (mem * 2.0**30) / 1e9
+                    offs = []
+                    for z in zones:
+                        for ct in ["spot", "on-demand"]:
+                            offs.append(offering(ct, z, price * 0.7 if ct == "spot" else price))
+                    fam = re.split(r"[.-]", name, maxsplit=1)[0]
+                    reqs = [req(INSTANCE_TYPE, "In", name), req(ARCH, "In", arch), req(OS, "In", os_), req(ZONE, "In", *zones),
+                            req(CAPACITY_TYPE, "In", "spot", "on-demand"), req(KWOK_SIZE, "In", str(cpu)), req(KWOK_FAMILY, "In", fam),
+                            req(KWOK_CPU, "In", str(cpu)), req(KWOK_MEMORY, "In", f"{mem}Gi")]
+                    out.append({"name": name, "requirements": reqs, "capacity": res, "overhead": {"cpu": "100m", "memory": "10Mi"}, "offerings": offs})
+                    if limit and len(out) >= limit:
+                        return out
+    return out
+
+
+def kwok_catalog(n):
+    """The N-type kwok-style catalogues of BASELINE.json's configs: 50 -> first 50 linux types of the stock grid,
+    144 -> stock grid, 500 / 1000 -> widened cpu grid x memory factors (names stay unique)."""
+    if n <= 72:
+        return kwok_instance_types(oses=("linux",))[:n]
+    if n <= 144:
+        return kwok_instance_types()[:n]
+    cpus = (1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256)
+    mfs = (2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32)
+    out = []
+    for mf in mfs:
+        out += kwok_instance_types(cpus=cpus, mem_factors=(mf,))
+    if n > len(out):
+        out += kwok_instance_types(cpus=(3, 6, 10, 20, 40, 80, 160, 224), mem_factors=mfs)
+    assert len(out) >= n, (len(out), n)
+    assert len({t["name"] for t in out}) == len(out)
+    return out[:n]
+
+
+_uid_counter = [0]
+
+
+def pod(uid=None, name=None, namespace="default", labels=None, requests=None, node_selector=None, node_requirements=None,
+        node_preferences=None, tolerations=None, topology_spread=None, pod_requirements=None, pod_preferences=None,
+        pod_anti_requirements=None, pod_anti_preferences=None, creation=0, phase="Pending", node_name=""):
+    """test.Pod — pkg/test/pods.go:88. node_requirements: list of NodeSelectorRequirement (one term) or list of terms."""
+    if uid is None:
+        _uid_counter[0] += 1
+        uid = f"00000000-0000-0000-0000-{_uid_counter[0]:012d}"
+    p = {"uid": uid, "name": name or uid, "namespace": namespace, "labels": dict(labels or {}), "requests": dict(requests or {}),
+         "creationTimestamp": creation, "phase": phase, "nodeName": node_name}
+    if node_selector:
+        p["nodeSelector"] = dict(node_selector)
+    if node_requirements or node_preferences:
+        na = {}
+        if node_requirements:
+            terms = node_requirements if isinstance(node_requirements[0], list) else [node_requirements]
+            na["required"] = terms
+        if node_preferences:
+            prefs = node_preferences
+            if prefs and "matchExpressions" not in prefs[0]:
+                prefs = [{"weight": 1, "matchExpressions": prefs}]
+            na["preferred"] = prefs
+        p["nodeAffinity"] = na
+    if tolerations:
+        p["tolerations"] = [dict({"key": "", "operator": "", "value": "", "effect": ""}, **t) for t in tolerations]
+    if topology_spread:
+        p["topologySpreadConstraints"] = topology_spread
+    if pod_requirements or pod_preferences:
+        p["podAffinity"] = {"required": pod_requirements or [], "preferred": pod_preferences or []}
+    if pod_anti_requirements or pod_anti_preferences:
+        p["podAntiAffinity"] = {"required": pod_anti_requirements or [], "preferred": pod_anti_preferences or []}
+    return p
+
+
+def spread(key, labels, max_skew=1, when="DoNotSchedule", min_domains=None, taints_policy=None, affinity_policy=None):
+    c = {"maxSkew": max_skew, "topologyKey": key, "whenUnsatisfiable": when, "labelSelector": {"matchLabels": dict(labels)}}
+    if min_domains is not None:
+        c["minDomains"] = min_domains
+    if taints_policy:
+        c["nodeTaintsPolicy"] = taints_policy
+    if affinity_policy:
+        c["nodeAffinityPolicy"] = affinity_policy
+    return c
+
+
+def affinity_term(key, labels, namespaces=None):
+    t = {"labelSelector": {"matchLabels": dict(labels)}, "topologyKey": key}
+    if namespaces:
+        t["namespaces"] = list(namespaces)
+    return t
+
+
+def node_pool(name="default", weight=0, requirements=None, labels=None, taints=None, limits=None, instance_types=None):
+    """test.NodePool — pkg/test/nodepool.go:35 (node class label as the test fixtures produce it)."""
+    np = {"name": name, "weight": weight, "requirements": list(requirements or []), "labels": dict(labels or {}),
+          "taints": [dict({"key": "", "value": "", "effect": ""}, **t) for t in (taints or [])],
+          "nodeClassLabelKey": "karpenter.test.sh/testnodeclass", "nodeClassName": "default"}
+    if limits is not None:
+        np["limits"] = dict(limits)
+    if instance_types is not None:
+        np["instanceTypes"] = list(instance_types)
+    return np
+
+
+def problem(instance_types, node_pools, pods=None, pod_groups=None, well_known=FAKE_WELL_KNOWN, state_nodes=None, cluster_pods=None,
+            daemonset_pods=None, options=None, deleting_node_names=None):
+    return {"wellKnownLabels": list(well_known), "options": dict(options or {}), "instanceTypes": instance_types, "nodePools": node_pools,
+            "stateNodes": list(state_nodes or []), "pods": list(pods or []), "podGroups": list(pod_groups or []),
+            "daemonSetPods": list(daemonset_pods or []), "clusterPods": list(cluster_pods or []),
+            "deletingNodeNames": list(deleting_node_names or [])}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json configurations. Pods are emitted as podGroups: {count, uidSeed, template}; the host
+# library (and the oracle) expand a group into `count` pods whose uids come from splitmix64(uidSeed, i), so a
+# million-pod problem is a few hundred JSON objects. Because queue order breaks (cpu, memory) ties by uid
+# (queue.go:98-107), pods of different groups interleave pseudo-randomly exactly like uuid.NewUUID() pods do in
+# scheduling_benchmark_test.go.
+# ---------------------------------------------------------------------------------------------------------------
+BENCH_CPU_M = [100, 250, 500, 1000, 1500]        # scheduling_benchmark_test.go:451-455
+BENCH_MEM_MI = [100, 256, 512, 1024, 2048, 4096]  # :447-450
+
+
+def _split_counts(total, weights, rng):
+    """Deterministic multinomial-ish split of `total` over len(weights) groups (largest remainder)."""
+    s = float(sum(weights))
+    raw = [total * w / s for w in weights]
+    base = [int(math.floor(x)) for x in raw]
+    rem = total - sum(base)
+    order = sorted(range(len(weights)), key=lambda i: (raw[i] - base[i], i), reverse=True)
+    for i in order[:rem]:
+        base[i] += 1
+    return base
+
+
+def config1(pods=5000, n_types=50, seed=42):
+    """C1: KWOK provider, cpu+mem requests only, 50 instance types, 1 NodePool."""
+    rng = random.Random(seed)
+    combos = [(c, m) for c in BENCH_CPU_M for m in BENCH_MEM_MI]
+    counts = _split_counts(pods, [1 + rng.random() for _ in combos], rng)
+    groups = []
+    for gi, ((c, m), n) in enumerate(zip(combos, counts)):
+        if n:
+            groups.append({"count": n, "uidSeed": seed * 100003 + gi, "template": pod(uid="t", requests={"cpu": f"{c}m", "memory": f"{m}Mi"}, labels={"my-label": "abcdefg"[gi % 7]})})
+    np_ = node_pool("default", limits={"cpu": "10000000", "memory": "10000000Gi"})
+    np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    return problem(kwok_catalog(n_types), [np_], pod_groups=groups, well_known=KWOK_WELL_KNOWN)
+
+
+def config2(pods=1_000_000, n_types=500, seed=42, tolerating_fraction=0.25):
+    """C2: nodeSelector + taint/toleration constraints, 500 instance types.
+
+    Two NodePools: `dedicated` (weight 10, taint dedicated=batch:NoSchedule) and `default` (weight 0, untainted).
+    A quarter of the pods tolerate the taint (Exists) and therefore try `dedicated` first. nodeSelectors are drawn
+    from the instance-type universe: arch, os, zone, capacity-type, each either unset or one value.
+    """
+    rng = random.Random(seed)
+    combos = [(c, m) for c in BENCH_CPU_M for m in BENCH_MEM_MI]
+    selectors = [{}]
+    for arch in ("amd64", "arm64"):
+        selectors.append({ARCH: arch})
+    for z in KWOK_ZONES:
+        selectors.append({ZONE: z})
+    selectors.append({CAPACITY_TYPE: "spot"})
+    selectors.append({CAPACITY_TYPE: "on-demand"})
+    for arch in ("amd64", "arm64"):
+        for z in KWOK_ZONES[:2]:
+            selectors.append({ARCH: arch, ZONE: z})
+    selectors.append({OS: "linux", ARCH: "arm64", CAPACITY_TYPE: "spot"})
+    selectors.append({OS: "linux", ZONE: KWOK_ZONES[3], CAPACITY_TYPE: "on-demand"})
+    classes = []
+    for (c, m) in combos:
+        for si, sel in enumerate(selectors):
+            for tol in (False, True):
+                w = (3.0 if not sel else 1.0) * (tolerating_fraction if tol else 1 - tolerating_fraction) * (1 + rng.random())
+                classes.append((c, m, si, sel, tol, w))
+    counts = _split_counts(pods, [k[5] for k in classes], rng)
+    groups = []
+    for gi, ((c, m, si, sel, tol, _), n) in enumerate(zip(classes, counts)):
+        if not n:
+            continue
+        sel2 = dict(sel)
+        if not tol and OS not in sel2 and si % 3 == 0:
+            sel2[OS] = "linux"
+        t = pod(uid="t", requests={"cpu": f"{c}m", "memory": f"{m}Mi"}, node_selector=sel2,
+                tolerations=[{"key": "dedicated", "operator": "Exists", "effect": "NoSchedule"}] if tol else None)
+        groups.append({"count": n, "uidSeed": seed * 100003 + gi, "template": t})
+    dedicated = node_pool("dedicated", weight=10, taints=[{"key": "dedicated", "value": "batch", "effect": "NoSchedule"}],
+                          requirements=[req(OS, "In", "linux")])
+    default = node_pool("default", weight=0)
+    for np_ in (dedicated, default):
+        np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    return problem(kwok_catalog(n_types), [dedicated, default], pod_groups=groups, well_known=KWOK_WELL_KNOWN)
+
+
+def scale_problem(prob, pods):
+    """Same problem with the pod groups rescaled to `pods` total (keeps the class mix)."""
+    p = copy.deepcopy(prob)
+    total = sum(g["count"] for g in p["podGroups"])
+    counts = _split_counts(pods, [g["count"] for g in p["podGroups"]], None)
+    for g, n in zip(p["podGroups"], counts):
+        g["count"] = n
+    p["podGroups"] = [g for g in p["podGroups"] if g["count"]]
+    assert sum(g["count"] for g in p["podGroups"]) == pods, total
+    return p

@@ -1,0 +1,718 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Never linked into or called by the product path.
+//
+// Restatement of pkg/controllers/provisioning/scheduling/{scheduler.go, nodeclaim.go, existingnode.go, queue.go,
+// nodeclaimtemplate.go, preferences.go, reservationmanager.go} and pkg/cloudprovider/types.go (price/minValues helpers).
+// Single-threaded: parallelizeUntil (scheduler.go:939-961) only fans out candidate checks and always keeps the
+// lowest index (:639,:674,:759), so a sequential first-success scan is equivalent.
+#pragma once
+#include "topology.hpp"
+
+namespace oracle {
+
+// ---- cloudprovider helpers -------------------------------------------------------------------------------------
+// Offerings.HasCompatible / Compatible — types.go:553-570
+inline bool offering_compatible(const Requirements& reqs, const Offering& o) { return reqs.compatible(o.reqs, true); }
+
+// InstanceTypes.SatisfiesMinValues — types.go:399-433
+inline int satisfies_min_values(const std::vector<const InstanceType*>& its, const Requirements& reqs, std::map<std::string, int>* unsat, bool* ok) {
+  *ok = true;
+  if (!reqs.has_min_values()) return 0;
+  std::map<std::string, int> incompatible;
+  std::map<std::string, std::set<std::string>> values_for_key;
+  for (size_t i = 0; i < its.size(); ++i) {
+    for (auto& kv : reqs.m) if (kv.second.min_values) {
+      Requirement r = its[i]->reqs.get(kv.first);
+      values_for_key[kv.first].insert(r.values.begin(), r.values.end());
+    }
+    for (auto& kv : values_for_key) {
+      int mv = *reqs.get(kv.first).min_values;
+      if ((int)kv.second.size() < mv) incompatible[kv.first] = (int)kv.second.size();
+      else incompatible.erase(kv.first);
+    }
+    if (incompatible.empty()) return (int)i + 1;
+  }
+  if (!incompatible.empty()) { *ok = false; if (unsat) *unsat = incompatible; return (int)its.size(); }
+  return (int)its.size();
+}
+// cheapest compatible available offering price (the comparator key of OrderByPrice, types.go:336-355)
+inline double min_compatible_price(const InstanceType& it, const Requirements& reqs) {
+  double p = DBL_MAX;
+  for (auto& o : it.offerings) if (o.available && offering_compatible(reqs, o) && o.price < p) p = o.price;
+  return p;
+}
+// InstanceTypes.OrderByPrice — types.go:336-355 (sort.Slice, unstable; Go pdqsort restated in pdqsort.hpp)
+inline void order_by_price(std::vector<const InstanceType*>& its, const Requirements& reqs) {
+  go_sort_slice(its, [&](const InstanceType* a, const InstanceType* b) { return min_compatible_price(*a, reqs) < min_compatible_price(*b, reqs); });
+}
+// Offerings.WorstLaunchPrice — types.go:587-598
+inline double worst_launch_price(const InstanceType& it, const Requirements& reqs) {
+  for (const char* ct : {"reserved", "spot", "on-demand"}) {
+    Requirements ctr;
+    ctr.add(Requirement::make(kCapacityTypeLabel, Op::In, {ct}));
+    double worst = -1;
+    bool any = false;
+    for (auto& o : it.offerings) {
+      if (!o.available) continue;
+      if (!offering_compatible(reqs, o)) continue;
+      if (!ctr.compatible(o.reqs, true)) continue;
+      if (!any || o.price > worst) worst = o.price;  // MostExpensive: lo.MaxBy keeps the first maximum
+      any = true;
+    }
+    if (any) return worst;
+  }
+  return DBL_MAX;
+}
+
+// ---- ReservationManager — reservationmanager.go:28-110 ---------------------------------------------------------
+struct ReservationManager {
+  std::map<std::string, std::set<std::string>> reservations;  // hostname -> reservation ids
+  std::map<std::string, int> capacity;                        // reservation id -> remaining
+  void init(const Problem& pr, const std::vector<const NodePool*>& pools) {
+    for (auto* np : pools)
+      for (int idx : np->instance_types)
+        for (auto& o : pr.catalog[idx].offerings) {
+          if (o.capacity_type() != "reserved") continue;
+          std::string id = o.reservation_id();
+          auto it = capacity.find(id);
+          if (it == capacity.end()) capacity[id] = o.reservation_capacity;
+          else if (o.reservation_capacity < it->second) it->second = o.reservation_capacity;  // keep the most pessimistic
+        }
+  }
+  bool has_reservation(const std::string& host, const std::string& id) const {
+    auto it = reservations.find(host);
+    return it != reservations.end() && it->second.count(id);
+  }
+  bool can_reserve(const std::string& host, const Offering& o) const {
+    std::string id = o.reservation_id();
+    if (has_reservation(host, id)) return true;
+    auto it = capacity.find(id);
+    return it != capacity.end() && it->second > 0;
+  }
+  void reserve(const std::string& host, const std::vector<const Offering*>& ofs) {
+    for (auto* o : ofs) {
+      std::string id = o->reservation_id();
+      if (has_reservation(host, id)) continue;
+      capacity[id] -= 1;
+      reservations[host].insert(id);
+    }
+  }
+  void release(const std::string& host, const Offering& o) {
+    std::string id = o.reservation_id();
+    auto it = reservations.find(host);
+    if (it != reservations.end() && it->second.count(id)) { it->second.erase(id); capacity[id] += 1; }
+  }
+};
+
+// ---- scheduling types ------------------------------------------------------------------------------------------
+struct DaemonOverheadGroup {  // scheduler.go:963-967 (host ports are out of the problem format)
+  std::set<const InstanceType*> its;
+  std::vector<const InstanceType*> its_ordered;
+  ResourceList overhead;
+};
+
+// NodeClaimTemplate — nodeclaimtemplate.go:55-94
+struct NodeClaimTemplate {
+  const NodePool* np = nullptr;
+  std::string nodepool_name;
+  int weight = 0;
+  std::vector<const InstanceType*> its;
+  Requirements reqs;
+  std::vector<Taint> taints;
+  std::vector<DaemonOverheadGroup> daemon_groups;
+  int index = 0;
+};
+
+enum ErrCode {
+  ERR_NONE = 0,
+  ERR_TAINTS = 1,            // did not tolerate taint (taints.go:91)
+  ERR_INCOMPATIBLE = 2,      // incompatible requirements (nodeclaim.go:134)
+  ERR_TOPOLOGY = 3,          // unsatisfiable topology constraint (topology.go:241)
+  ERR_INSTANCE_TYPES = 4,    // InstanceTypeFilterError (nodeclaim.go:437)
+  ERR_RESOURCES = 5,         // exceeds node resources (existingnode.go:97)
+  ERR_NO_TEMPLATES = 6,      // nodepool requirements filtered out all available instance types (scheduler.go:605)
+  ERR_LIMITS = 7,            // all available instance types exceed limits / node limits exhausted (scheduler.go:713,718)
+  ERR_RESERVED = 8,          // ReservedOfferingError (nodeclaim.go:341,346)
+  ERR_EXISTING = 9,          // failed scheduling pod to existing nodes
+  ERR_MIN_VALUES = 10,       // minValues requirement is not met (types.go:430)
+};
+
+struct FilterDiag {  // InstanceTypeFilterError flags — nodeclaim.go:437-459
+  bool requirements_met = false, fits = false, has_offering = false;
+  bool requirements_and_fits = false, requirements_and_offering = false, fits_and_offering = false;
+  bool min_values_incompatible = false;
+  int bits() const {
+    return (requirements_met ? 1 : 0) | (fits ? 2 : 0) | (has_offering ? 4 : 0) | (requirements_and_fits ? 8 : 0) |
+           (requirements_and_offering ? 16 : 0) | (fits_and_offering ? 32 : 0) | (min_values_incompatible ? 64 : 0);
+  }
+};
+
+struct Counters {
+  long long bin_evaluations = 0;       // V: CanAdd calls on in-flight claims + new-claim attempts + existing nodes
+  long long it_evaluations = 0;        // instance types visited in filterInstanceTypesByRequirements
+  long long sorts = 0, pops = 0, relaxations = 0;
+};
+
+struct PodData {  // scheduler.go:217-229
+  ResourceList requests;
+  Requirements reqs, strict_reqs;
+};
+
+// compatible / fits — nodeclaim.go:620-638
+inline bool it_compatible(const InstanceType& it, const Requirements& reqs) { return it.reqs.intersects(reqs); }
+inline void it_fits(const InstanceType& it, const ResourceList& requests, const Requirements& reqs, bool& fits, bool& has_offering) {
+  fits = false; has_offering = false;
+  for (auto& g : it.groups) {
+    bool resource_fit = res_fits(requests, g.allocatable);
+    for (auto* of : g.offerings) {
+      if (offering_compatible(reqs, *of)) {
+        has_offering = true;
+        if (resource_fit) { fits = true; return; }
+        break;
+      }
+    }
+  }
+}
+
+// filterInstanceTypesByRequirements — nodeclaim.go:541-618
+inline bool filter_instance_types(const std::vector<const InstanceType*>& its, Requirements& reqs, const std::vector<DaemonOverheadGroup>& groups,
+                                  const ResourceList& total_requests, bool relax_min_values, std::vector<const InstanceType*>& remaining,
+                                  std::map<std::string, int>& unsat, FilterDiag& d, Counters* ctr) {
+  remaining.clear();
+  std::set<const InstanceType*> eligible(its.begin(), its.end());
+  for (auto& g : groups) {
+    ResourceList total = g.overhead.empty() ? total_requests : res_merge(total_requests, g.overhead);
+    for (auto* it : g.its_ordered) {
+      if (!eligible.count(it)) continue;
+      if (ctr) ctr->it_evaluations++;
+      bool compat = it_compatible(*it, reqs);
+      bool fits, has_off;
+      it_fits(*it, total, reqs, fits, has_off);
+      d.requirements_met |= compat; d.fits |= fits; d.has_offering |= has_off;
+      d.requirements_and_fits |= (compat && fits && !has_off);
+      d.requirements_and_offering |= (compat && has_off && !fits);
+      d.fits_and_offering |= (fits && has_off && !compat);
+      if (compat && fits && has_off) remaining.push_back(it);
+    }
+  }
+  if (reqs.has_min_values()) {
+    bool ok;
+    std::map<std::string, int> u;
+    satisfies_min_values(remaining, reqs, &u, &ok);
+    if (!ok) {
+      unsat = u;
+      if (!relax_min_values) { remaining.clear(); d.min_values_incompatible = true; }
+    }
+  }
+  return !remaining.empty();
+}
+
+struct Scheduler;
+
+// NodeClaim — nodeclaim.go:43-119
+struct NodeClaim {
+  const NodeClaimTemplate* tmpl = nullptr;
+  Requirements reqs;
+  std::vector<const InstanceType*> its;
+  ResourceList requests;
+  std::vector<Pod*> pods;
+  std::string hostname;
+  std::map<std::string, std::string> annotations;
+  std::vector<const Offering*> reserved_offerings;
+  int id = 0;  // creation order
+};
+
+// ExistingNode — existingnode.go:32-75
+struct ExistingNode {
+  const StateNode* node = nullptr;
+  std::vector<Pod*> pods;
+  ResourceList remaining;
+  Requirements reqs;
+  bool under_consolidate_after = false;
+};
+
+struct Results {
+  std::vector<NodeClaim*> new_node_claims;
+  std::vector<ExistingNode*> existing_nodes;
+  std::map<std::string, std::pair<int, int>> pod_errors;  // uid -> (code, diag bits)
+  bool timed_out = false;
+};
+
+struct Scheduler {
+  const Problem* pr = nullptr;
+  Options opts;
+  std::vector<Pod> pods;          // working copies ("original" pods held by the queue)
+  std::vector<const NodePool*> pools;
+  std::vector<NodeClaimTemplate> templates;
+  std::vector<std::unique_ptr<NodeClaim>> claim_store;
+  std::vector<NodeClaim*> new_node_claims;   // s.newNodeClaims: physically re-sorted in place (scheduler.go:598)
+  std::vector<std::unique_ptr<ExistingNode>> existing_store;
+  std::vector<ExistingNode*> existing_nodes;
+  std::map<std::string, ResourceList> remaining_resources;  // nodepool -> remaining (only pools present in the map count)
+  std::map<std::string, PodData> cached;                    // by uid
+  Topology topology;
+  ReservationManager reservations;
+  bool tolerate_prefer_no_schedule = false;
+  long long node_id = 0;  // hostname-placeholder counter (nodeclaim.go:83,93); per-solve in the oracle
+  Counters ctr;
+  int last_err = 0, last_diag = 0;
+
+  // ---- pod requirement derivation: requirements.go:74-118 --------------------------------------------------
+  static Requirements pod_requirements(Pod& p, bool required_only) {
+    Requirements r = label_requirements(p.node_selector);
+    if (!p.has_node_affinity) return r;
+    if (!required_only && !p.preferred_terms.empty()) {
+      // sort.Slice(preferred, weight desc) — mutates the pod's slice in place (requirements.go:102)
+      go_sort_slice(p.preferred_terms, [](const PreferredSchedulingTerm& a, const PreferredSchedulingTerm& b) { return a.weight > b.weight; });
+      r.add_all(exprs_to_requirements(p.preferred_terms[0].preference));
+    }
+    if (p.has_required && !p.required_terms.empty()) r.add_all(exprs_to_requirements(p.required_terms[0]));
+    return r;
+  }
+  // updateCachedPodData — scheduler.go:554-580
+  void update_cached_pod_data(Pod& p) {
+    PodData d;
+    d.reqs = pod_requirements(p, opts.ignore_preferences);
+    d.strict_reqs = d.reqs;
+    if (p.has_node_affinity && !p.preferred_terms.empty()) d.strict_reqs = pod_requirements(p, true);
+    d.requests = p.requests;                       // RequestsForPods — resources.go:30-38
+    d.requests["pods"] = (i128)1 * 1000000000;
+    cached[p.uid] = d;
+  }
+
+  // ---- Preferences — preferences.go:38-146 -----------------------------------------------------------------
+  static bool remove_required_node_affinity_term(Pod& p) {
+    if (!p.has_node_affinity || !p.has_required || p.required_terms.empty()) return false;
+    if (p.required_terms.size() > 1) { p.required_terms.erase(p.required_terms.begin()); return true; }
+    return false;
+  }
+  template <class T> static void stable_by_weight_desc(std::vector<T>& v) {
+    std::stable_sort(v.begin(), v.end(), [](const T& a, const T& b) { return a.weight > b.weight; });  // sort.SliceStable
+  }
+  static bool remove_preferred_pod_affinity_term(Pod& p) {
+    if (!p.has_pod_affinity || p.affinity_preferred.empty()) return false;
+    stable_by_weight_desc(p.affinity_preferred);
+    p.affinity_preferred.erase(p.affinity_preferred.begin());
+    return true;
+  }
+  static bool remove_preferred_pod_anti_affinity_term(Pod& p) {
+    if (!p.has_pod_anti_affinity || p.anti_preferred.empty()) return false;
+    stable_by_weight_desc(p.anti_preferred);
+    p.anti_preferred.erase(p.anti_preferred.begin());
+    return true;
+  }
+  static bool remove_preferred_node_affinity_term(Pod& p) {
+    if (!p.has_node_affinity || p.preferred_terms.empty()) return false;
+    stable_by_weight_desc(p.preferred_terms);
+    p.preferred_terms.erase(p.preferred_terms.begin());
+    return true;
+  }
+  static bool remove_topology_spread_schedule_anyway(Pod& p) {
+    for (size_t i = 0; i < p.tscs.size(); ++i)
+      if (p.tscs[i].when_unsatisfiable == "ScheduleAnyway") {
+        p.tscs[i] = p.tscs.back();
+        p.tscs.pop_back();
+        return true;
+      }
+    return false;
+  }
+  static bool tolerate_prefer_no_schedule_taints(Pod& p) {
+    // MatchToleration: key, operator, value, effect all equal
+    for (auto& t : p.tolerations) if (t.key.empty() && t.op == "Exists" && t.value.empty() && t.effect == "PreferNoSchedule") return false;
+    p.tolerations.push_back({"", "Exists", "", "PreferNoSchedule"});
+    return true;
+  }
+  bool relax(Pod& p) {
+    if (remove_required_node_affinity_term(p)) return true;
+    if (remove_preferred_pod_affinity_term(p)) return true;
+    if (remove_preferred_pod_anti_affinity_term(p)) return true;
+    if (remove_preferred_node_affinity_term(p)) return true;
+    if (remove_topology_spread_schedule_anyway(p)) return true;
+    if (tolerate_prefer_no_schedule && tolerate_prefer_no_schedule_taints(p)) return true;
+    return false;
+  }
+
+  // ---- daemon overhead: scheduler.go:972-1043 --------------------------------------------------------------
+  bool daemon_pod_compatible(const NodeClaimTemplate& nct, const InstanceType& it, const Pod& pod_in) {
+    Pod p = pod_in;
+    tolerate_prefer_no_schedule_taints(p);
+    if (!taints_tolerated(nct.taints, p.tolerations)) return false;
+    for (;;) {
+      Requirements pr_ = pod_requirements(p, true);
+      if (nct.reqs.compatible(pr_, true) && it.reqs.intersects(pr_)) return true;
+      if (!remove_required_node_affinity_term(p)) return false;
+    }
+  }
+  void build_daemon_overhead_groups(NodeClaimTemplate& nct) {
+    // groups keyed by the sorted set of compatible daemon pods (podSetKey). lo.Values(groups) randomises group order in
+    // the reference (scheduler.go:1001); canonicalised here to order of first appearance.
+    std::vector<std::pair<std::string, DaemonOverheadGroup>> groups;
+    for (auto* it : nct.its) {
+      std::vector<const Pod*> compat;
+      for (auto& dp : pr->daemonset_pods) if (daemon_pod_compatible(nct, *it, dp)) compat.push_back(&dp);
+      std::vector<std::string> keys;
+      for (auto* p : compat) keys.push_back(p->ns + "/" + p->name);
+      std::sort(keys.begin(), keys.end());
+      std::string key;
+      for (auto& k : keys) { if (!key.empty()) key += ","; key += k; }
+      DaemonOverheadGroup* g = nullptr;
+      for (auto& e : groups) if (e.first == key) { g = &e.second; break; }
+      if (!g) {
+        DaemonOverheadGroup ng;
+        if (!compat.empty()) {
+          for (auto* p : compat) ng.overhead = res_merge(ng.overhead, p->requests);
+          ng.overhead["pods"] = (i128)compat.size() * 1000000000;
+        }
+        groups.push_back({key, ng});
+        g = &groups.back().second;
+      }
+      g->its.insert(it);
+      g->its_ordered.push_back(it);
+    }
+    for (auto& e : groups) nct.daemon_groups.push_back(e.second);
+  }
+
+  // ---- NewScheduler — scheduler.go:127-215 (+ Provisioner.NewScheduler ordering, provisioner.go:293) --------
+  void init(const Problem& problem) {
+    pr = &problem;
+    opts = problem.opts;
+    pods = problem.pods;
+    for (auto& np : problem.node_pools) if (!np.is_static) pools.push_back(&np);
+    // OrderByWeight — pkg/utils/nodepool/nodepool.go:161-171 (total order: weight desc, name desc)
+    std::sort(pools.begin(), pools.end(), [](const NodePool* a, const NodePool* b) { return a->weight != b->weight ? a->weight > b->weight : a->name > b->name; });
+    for (auto* np : pools) for (auto& t : np->taints) if (t.effect == "PreferNoSchedule") tolerate_prefer_no_schedule = true;
+
+    std::vector<const StateNode*> snodes;
+    for (auto& n : problem.state_nodes) snodes.push_back(&n);
+    topology.init(problem, pools, snodes, pods, opts.ignore_preferences);
+
+    for (auto* np : pools) {
+      if (np->instance_types.empty()) continue;  // provisioner.go:311-314 skips pools with no resolved instance types
+      // NewNodeClaimTemplate — nodeclaimtemplate.go:66-94
+      NodeClaimTemplate nct;
+      nct.np = np; nct.nodepool_name = np->name; nct.weight = np->weight; nct.taints = np->taints;
+      nct.reqs.add_all(exprs_to_requirements(np->requirements));
+      std::map<std::string, std::string> labels = np->labels;
+      labels[kNodePoolLabel] = np->name;
+      labels[np->node_class_label_key] = np->node_class_name;
+      nct.reqs.add_all(label_requirements(labels));
+      nct.reqs.add(Requirement::make(kNodeRegisteredLabel, Op::In, {"true"}));
+      nct.reqs.add(Requirement::make(kNodeInitializedLabel, Op::In, {"true"}));
+      // prefilter — scheduler.go:159
+      std::vector<const InstanceType*> all;
+      for (int idx : np->instance_types) all.push_back(&problem.catalog[idx]);
+      DaemonOverheadGroup g0;
+      g0.its.insert(all.begin(), all.end());
+      g0.its_ordered = all;
+      std::map<std::string, int> unsat;
+      FilterDiag d;
+      ResourceList none;
+      std::vector<const InstanceType*> remaining;
+      filter_instance_types(all, nct.reqs, {g0}, none, opts.min_values_best_effort, remaining, unsat, d, nullptr);
+      if (remaining.empty()) continue;
+      nct.its = remaining;
+      templates.push_back(nct);
+    }
+    for (size_t i = 0; i < templates.size(); ++i) { templates[i].index = (int)i; build_daemon_overhead_groups(templates[i]); }
+    for (auto* np : pools) if (np->has_limits) remaining_resources[np->name] = np->limits;
+    // NOTE scheduler.go:183 builds the map for every NodePool (nil limits => empty ResourceList, which never filters);
+    // only pools with limits can change behaviour, so only those are kept.
+    reservations.init(problem, pools);
+    // calculateExistingNodeClaims — scheduler.go:792-802
+    for (auto& n : problem.state_nodes) {
+      auto en = std::make_unique<ExistingNode>();
+      en->node = &n;
+      // daemons compatible with the node (scheduler.go:805-832) minus what already runs there (existingnode.go:50-60)
+      ResourceList daemon;
+      int ndaemons = 0;
+      for (auto& dp : problem.daemonset_pods) {
+        Pod p = dp;
+        if (!taints_tolerated(n.taints, p.tolerations)) continue;
+        if (!label_requirements(n.labels).compatible(pod_requirements(p, true), false)) continue;
+        daemon = res_merge(daemon, p.requests);
+        ndaemons++;
+      }
+      daemon["pods"] = (i128)ndaemons * 1000000000;
+      res_subtract_from(daemon, n.daemonset_requests);
+      for (auto& kv : daemon) if (kv.second < 0) kv.second = 0;
+      en->remaining = res_subtract(n.available, daemon);
+      en->reqs = label_requirements(n.labels);
+      en->reqs.add(Requirement::make(kLabelHostname, Op::In, {n.hostname}));
+      en->under_consolidate_after = opts.enforce_consolidate_after && n.under_consolidate_after;
+      topology.reg(kLabelHostname, n.hostname);
+      // updateRemainingResources — scheduler.go:835-842
+      auto npit = n.labels.find(kNodePoolLabel);
+      if (npit != n.labels.end()) {
+        auto rr = remaining_resources.find(npit->second);
+        if (rr != remaining_resources.end()) rr->second = res_subtract(rr->second, n.capacity);
+      }
+      existing_nodes.push_back(en.get());
+      existing_store.push_back(std::move(en));
+    }
+    // sortExistingNodes — scheduler.go:845-858 (SliceStable; total order)
+    std::stable_sort(existing_nodes.begin(), existing_nodes.end(), [](const ExistingNode* a, const ExistingNode* b) {
+      if (a->node->initialized != b->node->initialized) return a->node->initialized;
+      return a->node->name < b->node->name;
+    });
+  }
+
+  // ---- ExistingNode.CanAdd / Add — existingnode.go:81-185 --------------------------------------------------
+  bool existing_can_add(ExistingNode& n, const Pod& pod, const PodData& pd, Requirements& out) {
+    ctr.bin_evaluations++;
+    if (!taints_tolerated(n.node->taints, pod.tolerations)) { last_err = ERR_TAINTS; return false; }
+    if (!res_fits(pd.requests, n.remaining)) { last_err = ERR_RESOURCES; return false; }
+    if (!n.reqs.compatible(pd.reqs, false)) { last_err = ERR_INCOMPATIBLE; return false; }
+    Requirements base = n.reqs;
+    base.add_all(pd.reqs);
+    Requirements topo;
+    if (!topology.add_requirements(pod, n.node->taints, pd.strict_reqs, base, topo)) { last_err = ERR_TOPOLOGY; return false; }
+    if (!base.compatible(topo, false)) { last_err = ERR_TOPOLOGY; return false; }
+    base.add_all(topo);
+    out = base;
+    return true;
+  }
+  void existing_add(ExistingNode& n, Pod* pod, const PodData& pd, const Requirements& reqs) {
+    n.pods.push_back(pod);
+    res_subtract_from(n.remaining, pd.requests);
+    n.reqs = reqs;
+    topology.record(*pod, n.node->taints, reqs);
+  }
+
+  // ---- NodeClaim — nodeclaim.go:85-350 ---------------------------------------------------------------------
+  std::unique_ptr<NodeClaim> new_node_claim(const NodeClaimTemplate& t, const std::vector<const InstanceType*>& its) {
+    auto nc = std::make_unique<NodeClaim>();
+    char buf[64];
+    snprintf(buf, sizeof buf, "hostname-placeholder-%04lld", ++node_id);
+    nc->hostname = buf;
+    nc->tmpl = &t;
+    nc->reqs = t.reqs;
+    nc->reqs.add(Requirement::make(kLabelHostname, Op::In, {nc->hostname}));
+    nc->its = its;
+    return nc;
+  }
+  // offeringsToReserve — nodeclaim.go:303-350
+  bool offerings_to_reserve(NodeClaim& n, const std::vector<const InstanceType*>& its, const Requirements& reqs, std::vector<const Offering*>& out) {
+    out.clear();
+    if (!opts.reserved_capacity) return true;
+    bool has_compatible = false;
+    for (auto* it : its)
+      for (auto& o : it->offerings) {
+        if (o.capacity_type() != "reserved" || !o.available) continue;
+        if (!reqs.compatible(o.reqs, true)) continue;
+        has_compatible = true;
+        if (reservations.can_reserve(n.hostname, o)) out.push_back(&o);
+      }
+    if (opts.reserved_offering_strict) {
+      if (has_compatible && out.empty()) return false;
+      if (!n.reserved_offerings.empty() && out.empty()) return false;
+    }
+    return true;
+  }
+  // CanAdd — nodeclaim.go:124-242 (single volume alternative: nil)
+  bool claim_can_add(NodeClaim& n, const Pod& pod, const PodData& pd, bool relax_min_values, Requirements& out_reqs,
+                     std::vector<const InstanceType*>& out_its, std::vector<const Offering*>& out_ofs) {
+    ctr.bin_evaluations++;
+    last_diag = 0;
+    if (!taints_tolerated(n.tmpl->taints, pod.tolerations)) { last_err = ERR_TAINTS; return false; }
+    Requirements base = n.reqs;
+    if (!base.compatible(pd.reqs, true)) { last_err = ERR_INCOMPATIBLE; return false; }
+    base.add_all(pd.reqs);
+    Requirements topo;
+    if (!topology.add_requirements(pod, n.tmpl->taints, pd.strict_reqs, base, topo)) { last_err = ERR_TOPOLOGY; return false; }
+    if (!base.compatible(topo, true)) { last_err = ERR_TOPOLOGY; return false; }
+    base.add_all(topo);
+    ResourceList requests = res_merge(n.requests, pd.requests);
+    std::map<std::string, int> unsat;
+    FilterDiag d;
+    bool ok = filter_instance_types(n.its, base, n.tmpl->daemon_groups, requests, relax_min_values, out_its, unsat, d, &ctr);
+    if (relax_min_values) for (auto& kv : unsat) base.m[kv.first].min_values = kv.second;
+    if (!ok) { last_err = d.min_values_incompatible ? ERR_MIN_VALUES : ERR_INSTANCE_TYPES; last_diag = d.bits(); return false; }
+    if (!offerings_to_reserve(n, out_its, base, out_ofs)) { last_err = ERR_RESERVED; return false; }
+    out_reqs = base;
+    return true;
+  }
+  // Add — nodeclaim.go:247-263
+  void claim_add(NodeClaim& n, Pod* pod, const PodData& pd, const Requirements& reqs, const std::vector<const InstanceType*>& its, const std::vector<const Offering*>& ofs) {
+    n.pods.push_back(pod);
+    n.its = its;
+    n.requests = res_merge(n.requests, pd.requests);
+    n.reqs = reqs;
+    topology.reg(kLabelHostname, n.hostname);
+    topology.record(*pod, n.tmpl->taints, reqs);
+    reservations.reserve(n.hostname, ofs);
+    std::set<std::string> updated;
+    for (auto* o : ofs) updated.insert(o->reservation_id());
+    for (auto* o : n.reserved_offerings) if (!updated.count(o->reservation_id())) reservations.release(n.hostname, *o);
+    n.reserved_offerings = ofs;
+  }
+
+  // ---- add — scheduler.go:582-790 --------------------------------------------------------------------------
+  // subtractMax — scheduler.go:1049-1066 ; filterByRemainingResources — :1069-1085
+  static ResourceList subtract_max(const ResourceList& remaining, const std::vector<const InstanceType*>& its) {
+    if (its.empty()) return remaining;
+    std::vector<const ResourceList*> caps;
+    for (auto* it : its) caps.push_back(&it->capacity);
+    ResourceList mx = res_max(caps), out;
+    for (auto& kv : remaining) { auto f = mx.find(kv.first); out[kv.first] = kv.second - (f == mx.end() ? 0 : f->second); }
+    return out;
+  }
+  static std::vector<const InstanceType*> filter_by_remaining(const std::vector<const InstanceType*>& its, const ResourceList& remaining) {
+    std::vector<const InstanceType*> out;
+    for (auto* it : its) {
+      bool viable = true;
+      for (auto& kv : remaining) { auto f = it->capacity.find(kv.first); i128 c = f == it->capacity.end() ? 0 : f->second; if (c > kv.second) viable = false; }
+      if (viable) out.push_back(it);
+    }
+    return out;
+  }
+  bool add_to_new_claim(Pod& pod, Pod* queue_pod) {
+    const PodData& pd = cached[pod.uid];
+    int first_err = 0, first_diag = 0;
+    for (auto& t : templates) {
+      std::vector<const InstanceType*> its = t.its;
+      auto rr = remaining_resources.find(t.nodepool_name);
+      if (rr != remaining_resources.end()) {
+        auto nodes = rr->second.find("nodes");
+        if (nodes != rr->second.end() && nodes->second == 0) { if (!first_err) first_err = ERR_LIMITS; continue; }
+        its = filter_by_remaining(its, rr->second);
+        if (its.empty()) { if (!first_err) first_err = ERR_LIMITS; continue; }
+      }
+      std::unique_ptr<NodeClaim> nc = new_node_claim(t, its);
+      Requirements r; std::vector<const InstanceType*> rem; std::vector<const Offering*> ofs;
+      if (!claim_can_add(*nc, pod, pd, opts.min_values_best_effort, r, rem, ofs)) {
+        if (!first_err) { first_err = last_err; first_diag = last_diag; }
+        if (last_err == ERR_RESERVED) { last_err = ERR_RESERVED; last_diag = 0; return false; }  // :736-751: voids later templates
+        continue;
+      }
+      // minValuesRelaxed annotation — scheduler.go:763-772
+      bool relaxed = false;
+      for (auto& kv : nc->reqs.m) {
+        auto upd = r.get(kv.first).min_values;
+        auto orig = kv.second.min_values;
+        if (orig && upd && *upd < *orig) relaxed = true;
+      }
+      nc->annotations[kMinValuesRelaxedAnnotation] = relaxed ? "true" : "false";
+      claim_add(*nc, queue_pod, pd, r, rem, ofs);
+      nc->id = (int)claim_store.size();
+      new_node_claims.push_back(nc.get());
+      if (rr != remaining_resources.end()) rr->second = subtract_max(rr->second, nc->its);
+      claim_store.push_back(std::move(nc));
+      return true;
+    }
+    last_err = first_err ? first_err : ERR_NO_TEMPLATES;
+    last_diag = first_diag;
+    return false;
+  }
+  bool add(Pod& pod, Pod* queue_pod) {
+    if (add_to_existing(pod, queue_pod)) return true;
+    // sort.Slice(s.newNodeClaims, len(Pods) asc) — scheduler.go:598, Go pdqsort (unstable)
+    ctr.sorts++;
+    go_sort_slice(new_node_claims, [](const NodeClaim* a, const NodeClaim* b) { return a->pods.size() < b->pods.size(); });
+    if (add_to_inflight(pod, queue_pod)) return true;
+    if (templates.empty()) { last_err = ERR_NO_TEMPLATES; last_diag = 0; return false; }
+    return add_to_new_claim(pod, queue_pod);
+  }
+  // The reference appends the *relaxed copy* it was handed to Pods; results are reported by uid so the distinction is
+  // invisible. queue_pod keeps the pointer stable.
+  bool add_to_existing(Pod& pod, Pod* queue_pod) {
+    const PodData& pd = cached[pod.uid];
+    for (auto* en : existing_nodes) {
+      if (en->under_consolidate_after && (pod.phase != "Pending" && !pr->deleting_node_names.count(pod.node_name))) continue;
+      Requirements r;
+      if (existing_can_add(*en, pod, pd, r)) { existing_add(*en, queue_pod, pd, r); return true; }
+    }
+    return false;
+  }
+  bool add_to_inflight(Pod& pod, Pod* queue_pod) {
+    const PodData& pd = cached[pod.uid];
+    for (auto* nc : new_node_claims) {
+      Requirements r; std::vector<const InstanceType*> its; std::vector<const Offering*> ofs;
+      if (claim_can_add(*nc, pod, pd, false, r, its, ofs)) { claim_add(*nc, queue_pod, pd, r, its, ofs); return true; }
+    }
+    return false;
+  }
+
+  // trySchedule — scheduler.go:521-552 (p is the DeepCopy)
+  bool try_schedule(Pod& copy, Pod* queue_pod) {
+    for (;;) {
+      if (add(copy, queue_pod)) return true;
+      if (last_err == ERR_RESERVED) return false;
+      int err = last_err, diag = last_diag;
+      if (!relax(copy)) { last_err = err; last_diag = diag; return false; }
+      ctr.relaxations++;
+      topology.update(copy);
+      update_cached_pod_data(copy);
+    }
+  }
+
+  // Solve — scheduler.go:440-519 ; Queue — queue.go:31-108
+  Results solve() {
+    Results res;
+    for (auto& p : pods) update_cached_pod_data(p);
+    std::vector<Pod*> q;
+    for (auto& p : pods) q.push_back(&p);
+    // NewQueue: sort.Slice(byCPUAndMemoryDescending) — total order, any sort gives the same result (queue.go:37-41,72-108)
+    std::sort(q.begin(), q.end(), [&](Pod* a, Pod* b) {
+      const ResourceList& l = cached[a->uid].requests; const ResourceList& r = cached[b->uid].requests;
+      auto get = [](const ResourceList& m, const char* k) { auto it = m.find(k); return it == m.end() ? (i128)0 : it->second; };
+      i128 lc = get(l, "cpu"), rc = get(r, "cpu");
+      if (lc != rc) return lc > rc;
+      i128 lm = get(l, "memory"), rm = get(r, "memory");
+      if (lm != rm) return lm > rm;
+      if (a->creation != b->creation) return a->creation < b->creation;
+      return a->uid < b->uid;
+    });
+    std::map<std::string, size_t> last_len;
+    size_t head = 0;
+    long long steps = 0;
+    for (;;) {
+      size_t qlen = q.size() - head;
+      if (qlen == 0) break;
+      Pod* p = q[head];
+      auto ll = last_len.find(p->uid);
+      if (ll != last_len.end() && ll->second == qlen) break;   // queue.go:52-56 (checked before popping)
+      if (opts.max_steps >= 0 && steps >= opts.max_steps) { res.timed_out = true; break; }  // ctx deadline stand-in
+      head++;
+      steps++;
+      ctr.pops++;
+      Pod copy = *p;  // pod.DeepCopy()
+      if (try_schedule(copy, p)) {
+        res.pod_errors.erase(p->uid);
+      } else {
+        res.pod_errors[p->uid] = {last_err, last_diag};
+        topology.update(*p);
+        update_cached_pod_data(*p);
+        q.push_back(p);
+        last_len[p->uid] = q.size() - head;   // queue.go:63-66
+      }
+    }
+    // FinalizeScheduling — nodeclaim.go:383-409
+    for (auto* nc : new_node_claims) {
+      nc->reqs.m.erase(kLabelHostname);
+      if (!nc->reserved_offerings.empty()) {
+        nc->reqs.m[kCapacityTypeLabel] = Requirement::make(kCapacityTypeLabel, Op::In, {"reserved"});
+        std::vector<std::string> ids;
+        for (auto* o : nc->reserved_offerings) ids.push_back(o->reservation_id());
+        nc->reqs.add(Requirement::make(kReservationIDLabel, Op::In, ids));
+      }
+      // addDaemonRequests — nodeclaim.go:353-377
+      std::set<const InstanceType*> remaining(nc->its.begin(), nc->its.end());
+      ResourceList min_overhead;
+      bool have = false;
+      for (auto& g : nc->tmpl->daemon_groups) {
+        bool has_remaining = false;
+        for (auto* it : g.its_ordered) if (remaining.count(it)) { has_remaining = true; break; }
+        if (!has_remaining) continue;
+        if (min_overhead.empty()) min_overhead = g.overhead;
+        else min_overhead = res_min({&min_overhead, &g.overhead});
+        have = true;
+      }
+      (void)have;
+      if (!min_overhead.empty()) nc->requests = res_merge(nc->requests, min_overhead);
+    }
+    res.new_node_claims = new_node_claims;
+    res.existing_nodes = existing_nodes;
+    return res;
+  }
+};
+
+}  // namespace oracle

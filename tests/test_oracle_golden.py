@@ -1,0 +1,119 @@
+"""Pins the CPU oracle against the reference's own truth tables (tests/golden/, transcribed by make_golden.py from
+pkg/scheduling/requirement_test.go and requirements_test.go)."""
+import json
+import os
+
+import pytest
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+TABLES = json.load(open(os.path.join(G, "requirement_tables.json")))
+COMPAT = json.load(open(os.path.join(G, "requirements_compatible.json")))
+DEFS = TABLES["definitions"]
+
+
+def canon(r):
+    """canonical struct view of a requirement as the oracle reports it"""
+    return {"key": r["key"], "complement": r["complement"], "values": sorted(r["values"]), "gte": r["gte"], "lte": r["lte"], "minValues": r["minValues"]}
+
+
+def expected_struct(oracle, exp):
+    if isinstance(exp, dict):
+        return {k: exp[k] for k in ("key", "complement", "values", "gte", "lte", "minValues")}
+    return canon(oracle.evaluate({"fn": "describe", "a": DEFS[exp]}))
+
+
+def test_intersection_tables(oracle):
+    # requirement_test.go:103-747 — Expect(a.Intersection(b)).To(Equal(expected)), struct equality incl. minValues/bounds
+    assert len(TABLES["intersection"]) == 590
+    for a, b, exp in TABLES["intersection"]:
+        got = canon(oracle.evaluate({"fn": "intersection", "a": DEFS[a], "b": DEFS[b]}))
+        assert got == expected_struct(oracle, exp), (a, b, exp, got)
+
+
+def test_has_intersection_agrees_with_intersection(oracle):
+    # HasIntersection (requirement.go:220) must agree with Intersection().Len() != 0 on every table row
+    for a, b, _ in TABLES["intersection"]:
+        inter = oracle.evaluate({"fn": "intersection", "a": DEFS[a], "b": DEFS[b]})
+        d = oracle.evaluate({"fn": "describe", "a": {"key": "key", "operator": "In", "values": []}})
+        nonempty = inter["complement"] or len(inter["values"]) > 0
+        assert oracle.evaluate({"fn": "has_intersection", "a": DEFS[a], "b": DEFS[b]}) == nonempty, (a, b)
+
+
+def test_has_operator_len(oracle):
+    for name, value, exp in TABLES["has"]:
+        assert oracle.evaluate({"fn": "has", "a": DEFS[name], "value": value}) == exp, (name, value)
+    for name, op in TABLES["operator"]:
+        assert oracle.evaluate({"fn": "describe", "a": DEFS[name]})["operator"] == op, name
+    for name, ln in TABLES["len"]:
+        assert oracle.evaluate({"fn": "describe", "a": DEFS[name]})["len"] == ln, name
+
+
+@pytest.mark.parametrize("mode", ["loose", "strict"])
+def test_compatible_tables(oracle, mode):
+    # requirements_test.go:57-543 — 15x15, zone key (well-known): loose allows undefined well-known labels, strict does not
+    defs = COMPAT["definitions"]
+    assert len(COMPAT[mode]) == 225
+    for a, b, exp in COMPAT[mode]:
+        qa = [] if defs[a] is None else [defs[a]]
+        qb = [] if defs[b] is None else [defs[b]]
+        got = oracle.evaluate({"fn": "compatible", "a": qa, "b": qb, "allowUndefinedWellKnown": mode == "loose"})
+        assert got == exp, (mode, a, b)
+
+
+def test_gte_lte_operators(oracle):
+    # requirement_test.go:953-1084
+    gte = lambda n: {"key": "key", "operator": "Gte", "values": [str(n)]}
+    lte = lambda n: {"key": "key", "operator": "Lte", "values": [str(n)]}
+    gt = lambda n: {"key": "key", "operator": "Gt", "values": [str(n)]}
+    lt = lambda n: {"key": "key", "operator": "Lt", "values": [str(n)]}
+    has = lambda r, v: oracle.evaluate({"fn": "has", "a": r, "value": v})
+    assert has(gte(5), "5") and has(gte(5), "6") and not has(gte(5), "4")
+    assert has(lte(5), "5") and has(lte(5), "4") and not has(lte(5), "6")
+    r = oracle.evaluate({"fn": "intersection", "a": gte(3), "b": lte(7)})
+    assert (r["gte"], r["lte"], r["complement"]) == (3, 7, True)
+    assert canon(oracle.evaluate({"fn": "describe", "a": gt(4)})) == canon(oracle.evaluate({"fn": "describe", "a": gte(5)}))
+    assert canon(oracle.evaluate({"fn": "describe", "a": lt(6)})) == canon(oracle.evaluate({"fn": "describe", "a": lte(5)}))
+    r = oracle.evaluate({"fn": "intersection", "a": gte(3), "b": gt(5)})
+    assert r["gte"] == 6
+    r = oracle.evaluate({"fn": "intersection", "a": gte(8), "b": gt(5)})
+    assert r["gte"] == 8
+    r = oracle.evaluate({"fn": "intersection", "a": lte(3), "b": lt(9)})
+    assert r["lte"] == 3
+    assert has(gte(0), "0") and not has(gte(0), "-1")
+    assert has(lte(0), "0") and not has(lte(0), "1")
+    assert oracle.evaluate({"fn": "describe", "a": gt(2**63 - 1)})["operator"] == "DoesNotExist"
+    assert not has(gte(1), "abc")  # non-integers are out of bounds (requirement.go:339-342)
+
+
+def test_label_normalisation(oracle):
+    # requirements_test.go:34-38 / requirement_test.go:66-101
+    r = oracle.evaluate({"fn": "describe", "a": {"key": "failure-domain.beta.kubernetes.io/zone", "operator": "In", "values": ["test"]}})
+    assert r["key"] == "topology.kubernetes.io/zone"
+    for alias, key in {"beta.kubernetes.io/arch": "kubernetes.io/arch", "beta.kubernetes.io/os": "kubernetes.io/os",
+                       "beta.kubernetes.io/instance-type": "node.kubernetes.io/instance-type",
+                       "failure-domain.beta.kubernetes.io/region": "topology.kubernetes.io/region"}.items():
+        assert oracle.evaluate({"fn": "describe", "a": {"key": alias, "operator": "In", "values": ["x"]}})["key"] == key
+
+
+def test_resources(oracle):
+    # pkg/utils/resources/suite_test.go:651-714
+    ev = lambda op, *lists: oracle.evaluate({"fn": "resources", "op": op, "lists": list(lists)})
+    q = lambda s: oracle.evaluate({"fn": "quantity", "value": s})
+    assert ev("max") == {}
+    assert ev("max", {"cpu": "1", "memory": "4Gi"}, {"cpu": "3", "memory": "2Gi"}, {"cpu": "2", "memory": "8Gi"}) == {"cpu": q("3"), "memory": q("8Gi")}
+    assert ev("max", {"cpu": "1"}, {"memory": "2Gi"}, {"cpu": "3"}) == {"cpu": q("3"), "memory": q("2Gi")}
+    assert ev("min") == {}
+    assert ev("min", {"cpu": "4", "memory": "8Gi"}, {"cpu": "2", "memory": "6Gi"}, {"cpu": "3", "memory": "1Gi"}) == {"cpu": q("2"), "memory": q("1Gi")}
+    assert ev("min", {"cpu": "1", "memory": "4Gi"}, {"cpu": "3"}, {"cpu": "2", "memory": "1Gi"}) == {"cpu": q("1")}
+    assert ev("fits", {"cpu": "1"}, {"cpu": "1"}) is True
+    assert ev("fits", {"cpu": "1001m"}, {"cpu": "1"}) is False
+    assert ev("fits", {"foo": "0"}, {"cpu": "1"}) is True          # zero request of an unknown resource fits (suite_test.go:1667)
+    assert ev("fits", {"cpu": "1"}, {"cpu": "2", "memory": "-1"}) is False  # any negative total never fits (resources.go:190)
+    assert q("1.8G") == str(18 * 10**17) and q("100m") == str(10**8) and q("4Gi") == str(4 * 2**30 * 10**9)
+
+
+def test_go_sort_slice_small_is_insertion_sort(oracle):
+    # n <= 12 -> insertionSort_func: stable
+    keys = [3, 1, 2, 1, 3, 2, 1]
+    perm = oracle.evaluate({"fn": "sort_by_key", "keys": keys})
+    assert perm == sorted(range(len(keys)), key=lambda i: (keys[i], i))
