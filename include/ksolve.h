@@ -1,0 +1,217 @@
+/*
+ * ksolve.h — C ABI of the MI355X-native provisioning solver.
+ *
+ * This is the drop-in boundary for ONE path of kubernetes-sigs/karpenter: the provisioning scheduler's
+ *   scheduling.NewScheduler(...)            pkg/controllers/provisioning/scheduling/scheduler.go:127-215
+ *   (*Scheduler).Solve(ctx, pods)           pkg/controllers/provisioning/scheduling/scheduler.go:440-519
+ * as called from Provisioner.Schedule (provisioner.go:359,430) and disruption.SimulateScheduling (helpers.go:113,128).
+ * The reference is pure Go and has no FFI for this path; these are the entry points a cgo shim binds instead
+ * (go/ksolve_shim.go). Plain pointers and sizes only: no Go pointers are retained after a call
+ * returns, inputs are caller-owned and read-only for the duration of the call, outputs are library-owned and
+ * released with ksolve_results_free.
+ *
+ * Data model ("KSP", flat SoA): label keys and values are dictionary-encoded by the caller. A requirement
+ * (pkg/scheduling/requirement.go:36-43) on key k is {complement bit, u64 value-bitmask words over k's dictionary,
+ * optional inclusive int bounds, optional minValues}; a requirement set (requirements.go:34) is one such slot per key.
+ * Resources (pkg/utils/resources) are int64 in a per-dimension scale chosen by the caller so every quantity is exact.
+ */
+#ifndef KSOLVE_H
+#define KSOLVE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KSOLVE_ABI_VERSION 1
+#define KSOLVE_MAX_KEYS 32        /* requirement keys per problem (one bit each in the u32 flag words) */
+#define KSOLVE_MAX_RES 8          /* resource dimensions */
+#define KSOLVE_MAX_TEMPLATES 32   /* NodeClaimTemplates (NodePools that survived prefiltering) */
+#define KSOLVE_MAX_ITWORDS 32     /* ceil(n_instance_types / 64) */
+#define KSOLVE_MAX_ZONES 16       /* distinct offering zones  */
+#define KSOLVE_MAX_CAPTYPES 4     /* distinct offering capacity types */
+#define KSOLVE_MAX_TOPO_GROUPS 64
+
+typedef enum {
+  KSOLVE_OK = 0,
+  KSOLVE_ERR_INVALID = 1,      /* malformed problem description */
+  KSOLVE_ERR_UNSUPPORTED = 2,  /* valid Karpenter input outside what this build solves on the device (never a CPU fallback) */
+  KSOLVE_ERR_DEVICE = 3,       /* HIP runtime failure; see ksolve_last_error */
+  KSOLVE_ERR_NO_DEVICE = 4,    /* no gfx950 device / HIP runtime not usable */
+  KSOLVE_ERR_CANCELLED = 5,    /* deadline or ksolve_cancel: results are partial but valid (scheduler.go:477-480,:518) */
+  KSOLVE_ERR_CAPACITY = 6      /* a fixed device-side capacity (claims) was exceeded */
+} ksolve_status;
+
+/* Per-pod error codes (Results.PodErrors, scheduler.go:284). */
+typedef enum {
+  KSOLVE_POD_OK = 0,
+  KSOLVE_POD_TAINTS = 1,          /* did not tolerate taint                         taints.go:91 */
+  KSOLVE_POD_INCOMPATIBLE = 2,    /* incompatible requirements                      nodeclaim.go:134 */
+  KSOLVE_POD_TOPOLOGY = 3,        /* unsatisfiable topology constraint              topology.go:241 */
+  KSOLVE_POD_INSTANCE_TYPES = 4,  /* InstanceTypeFilterError (+6 diagnostic bits)   nodeclaim.go:437-459 */
+  KSOLVE_POD_RESOURCES = 5,       /* exceeds node resources                         existingnode.go:97 */
+  KSOLVE_POD_NO_TEMPLATES = 6,    /* nodepool requirements filtered out all types   scheduler.go:605 */
+  KSOLVE_POD_LIMITS = 7,          /* nodepool limits                                scheduler.go:713,718 */
+  KSOLVE_POD_RESERVED = 8,        /* ReservedOfferingError                          nodeclaim.go:341,346 */
+  KSOLVE_POD_EXISTING = 9,
+  KSOLVE_POD_MIN_VALUES = 10      /* minValues requirement is not met               types.go:430 */
+} ksolve_pod_error;
+
+/* A table of requirement sets, SoA over `n` entities. words_per_set = problem.req_words (sum over keys of the
+ * key's dictionary words). mask[e * req_words + key_word_off[k] + w]. Flag words carry one bit per key. */
+typedef struct {
+  uint32_t n;
+  const uint64_t* mask;       /* n * req_words */
+  const uint32_t* defined;    /* n : key present in the set (requirements.go Has) */
+  const uint32_t* complement; /* n : requirement.complement */
+  const uint32_t* has_gte;    /* n */
+  const uint32_t* has_lte;    /* n */
+  const int64_t* gte;         /* n * n_keys, may be NULL when no entity has bounds */
+  const int64_t* lte;         /* n * n_keys, may be NULL */
+  const int32_t* min_values;  /* n * n_keys, -1 = nil; may be NULL */
+} ksolve_reqsets;
+
+/* Topology groups (topologygroup.go:55-77), pre-deduplicated by the caller with TopologyGroup.Hash() semantics. */
+typedef struct {
+  uint32_t n;
+  const uint8_t* type;         /* 0 spread, 1 pod affinity, 2 pod anti-affinity (topologygroup.go:35-41) */
+  const uint8_t* inverse;      /* 1 = member of Topology.inverseTopologyGroups (topology.go:56) */
+  const int32_t* key;          /* requirement key index, or -1 for kubernetes.io/hostname */
+  const int32_t* max_skew;
+  const int32_t* min_domains;  /* -1 = nil */
+  const uint64_t* domains;     /* n * key dictionary words: registered domains of a dictionary key (topologygroup.go:103-107) */
+  const int32_t* init_counts;  /* n * 64 * words : pre-counted pods per domain value (topology.go:361-459), may be NULL */
+  const uint8_t* filter_affinity_honor; /* nodeAffinityPolicy == Honor */
+  const uint8_t* filter_taint_honor;    /* nodeTaintsPolicy == Honor */
+  const uint32_t* filter_first;         /* n+1 : CSR into filter_reqs (TopologyNodeFilter.Requirements, OR'd) */
+  ksolve_reqsets filter_reqs;
+  const uint64_t* filter_tolerates;     /* n : distinct-taint mask the owner pod tolerates */
+} ksolve_topology;
+
+typedef struct {
+  uint32_t abi_version;
+
+  /* ---- dictionaries ---- */
+  uint32_t n_keys;                 /* <= KSOLVE_MAX_KEYS */
+  const uint32_t* key_word_off;    /* n_keys+1 : first mask word of each key; req_words = key_word_off[n_keys] */
+  uint32_t well_known_mask;        /* v1.WellKnownLabels as key bits (labels.go:75-84 plus provider additions) */
+  int32_t key_instance_type;       /* key index of node.kubernetes.io/instance-type; its dictionary IS the instance type list */
+  int32_t key_zone, key_capacity_type;
+  int32_t key_hostname;            /* key index of kubernetes.io/hostname when some pod/node requirement mentions it, else -1 */
+  const int64_t* value_int;        /* req_words*64 : strconv.Atoi(value) */
+  const uint64_t* value_is_int;    /* req_words : bit set when the value parses as an integer (requirement.go:339) */
+
+  /* ---- resources ---- */
+  uint32_t n_res;                  /* dims; 0 = cpu, 1 = memory (queue.go:72-90 sorts on these two) */
+
+  /* ---- instance types: cloudprovider.InstanceType (types.go:123-142) ---- */
+  uint32_t n_its;
+  const int64_t* it_allocatable;   /* n_res * n_its (SoA): Allocatable() = capacity - overhead  (types.go:271-294) */
+  const int64_t* it_capacity;      /* n_res * n_its */
+  ksolve_reqsets it_reqs;          /* InstanceType.Requirements */
+  const uint64_t* it_offering_avail; /* n_its : bit (zone_idx*4 + ct_idx) set for an Available offering (types.go:470-486) */
+  const double* it_offering_price;   /* n_its * 64 */
+  uint32_t n_zones, n_captypes;    /* zone_idx / ct_idx are value indices in key_zone / key_capacity_type dictionaries */
+
+  /* ---- templates: NodeClaimTemplate per NodePool, in OrderByWeight order (nodepool.go:161-171) ---- */
+  uint32_t n_templates;
+  ksolve_reqsets tmpl_reqs;        /* nodeclaimtemplate.go:66-94 */
+  const uint64_t* tmpl_taints;     /* n_templates : mask over the problem's distinct taints */
+  const uint64_t* tmpl_its;        /* n_templates * it_words : instance types offered by the pool (GetInstanceTypes) */
+  const uint32_t* tmpl_limit_mask; /* n_templates : bit r set => limits[r] applies; bit n_res => "nodes" limit */
+  const int64_t* tmpl_limits;      /* n_templates * (n_res+1) : remaining = limits - existing capacity (scheduler.go:183,835) */
+
+  /* ---- pods (one row per pod *variant*: row p < n_pods is the pod as submitted; rows >= n_pods are the
+   *      pre-computed results of Preferences.Relax (preferences.go:38-57), chained through pod_next_variant) ---- */
+  uint32_t n_pods;
+  uint32_t n_pod_rows;
+  const int64_t* pod_requests;     /* n_res * n_pod_rows (SoA) : RequestsForPods incl. pods=1 (resources.go:30-38) */
+  ksolve_reqsets pod_reqs;         /* PodData.Requirements  (scheduler.go:554-580) */
+  ksolve_reqsets pod_strict_reqs;  /* PodData.StrictRequirements; mask may alias pod_reqs when identical */
+  const uint64_t* pod_tolerates;   /* n_pod_rows : bit i set when the pod tolerates distinct taint i (taints.go:83-95) */
+  const int32_t* pod_next_variant; /* n_pod_rows : row of the next relaxation, -1 = none */
+  const uint64_t* pod_topo_owned;  /* n_pod_rows : topology groups the pod owns (topology.go:187) */
+  const uint64_t* pod_topo_selected; /* n_pod_rows : groups whose selector matches the pod (topologygroup.go:442) */
+  const int64_t* pod_creation;     /* n_pods : CreationTimestamp seconds */
+  const uint64_t* pod_uid_hi;      /* n_pods : (hi,lo) compare like the UID strings (queue.go:107) */
+  const uint64_t* pod_uid_lo;
+  const uint8_t* pod_is_pending;   /* n_pods : Status.Phase == Pending (scheduler.go:628) */
+  const uint8_t* pod_from_deleting_node; /* n_pods */
+
+  /* ---- existing nodes, already in sortExistingNodes order (scheduler.go:845-858) ---- */
+  uint32_t n_nodes;
+  ksolve_reqsets node_reqs;        /* labels + hostname (existingnode.go:66-70); hostname value index in node_hostname */
+  const uint64_t* node_taints;
+  const int64_t* node_remaining;   /* n_res * n_nodes : Available - daemon overhead (existingnode.go:47-64) */
+  const uint8_t* node_initialized;
+  const uint8_t* node_under_consolidate_after;
+
+  ksolve_topology topo;
+
+  /* ---- distinct taints of the problem (for filter_taint_honor only the masks matter) ---- */
+  uint32_t n_taints;
+} ksolve_problem_desc;
+
+typedef struct {
+  uint32_t min_values_best_effort; /* MinValuesPolicyBestEffort (scheduler.go:117) */
+  uint32_t max_claims;             /* device capacity for in-flight NodeClaims; 0 = n_pods */
+  int64_t max_steps;               /* stand-in for the ctx deadline: stop after this many queue pops, -1 = none */
+  uint32_t device;                 /* HIP device ordinal */
+  uint32_t reserved;
+} ksolve_options;
+
+/* One NodeClaim of Results.NewNodeClaims (scheduler.go:282, nodeclaim.go:43-62), in the order the reference's
+ * s.newNodeClaims slice ends in. */
+typedef struct {
+  uint32_t n_claims;
+  uint32_t it_words, req_words, n_keys, n_res;
+  const int32_t* template_idx;   /* n_claims */
+  const uint32_t* pod_count;     /* n_claims */
+  const uint64_t* it_mask;       /* n_claims * it_words : InstanceTypeOptions */
+  const int64_t* requests;       /* n_claims * n_res : Spec.Resources.Requests */
+  const uint64_t* req_mask;      /* n_claims * req_words : Requirements after FinalizeScheduling */
+  const uint32_t* req_defined, *req_complement, *req_has_gte, *req_has_lte;
+  const int64_t* req_gte, *req_lte;     /* n_claims * n_keys */
+  const int32_t* req_min_values;        /* n_claims * n_keys */
+  const uint8_t* min_values_relaxed;    /* n_claims : annotation nodeclaim-min-values-relaxed (scheduler.go:763-772) */
+  const double* cheapest_price;         /* n_claims : cheapest compatible available offering over InstanceTypeOptions */
+  const uint32_t* hostname_seq;         /* n_claims : N of hostname-placeholder-%04d (nodeclaim.go:93) */
+} ksolve_claims;
+
+typedef struct {
+  ksolve_status status;
+  uint32_t n_pods;
+  const int32_t* pod_assignment;   /* n_pods : >=0 index into claims; <= -2 existing node (-2 - node index); -1 unscheduled */
+  const uint8_t* pod_error;        /* n_pods : ksolve_pod_error */
+  const uint8_t* pod_error_diag;   /* n_pods : InstanceTypeFilterError bits (requirementsMet|fits<<1|hasOffering<<2|...) */
+  const uint32_t* pod_slot;        /* n_pods : position of the pod inside its claim's / node's Pods slice */
+  ksolve_claims claims;
+  /* counters: V = candidate-bin evaluations, plus timing of the device phases in microseconds */
+  uint64_t bin_evaluations, it_evaluations, queue_pops, sorts, slow_sorts, relaxations;
+  double us_upload, us_prepass, us_pack, us_finalize, us_download;
+  double packing_cost;
+  void* impl;
+} ksolve_results;
+
+typedef struct ksolve_handle ksolve_handle;
+
+/* Validates and uploads a problem: device buffers + a HIP stream owned by the handle (NewScheduler). */
+ksolve_status ksolve_create(const ksolve_problem_desc* desc, const ksolve_options* opts, ksolve_handle** out);
+/* Runs Solve() on the device. One in-flight solve per handle; distinct handles are independent and thread-safe. */
+ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out);
+/* Asks a running ksolve_solve on another thread to stop at the next pod boundary (ctx cancellation). */
+ksolve_status ksolve_cancel(ksolve_handle* h);
+void ksolve_results_free(ksolve_results* r);
+void ksolve_destroy(ksolve_handle* h);
+const char* ksolve_last_error(const ksolve_handle* h);
+/* ABI version of the loaded library, and whether a gfx950 device is usable (0/1). */
+uint32_t ksolve_abi_version(void);
+int ksolve_device_available(void);
+/* Time of the most recent pack kernel launch measured with HIP events on the handle's stream (milliseconds). */
+double ksolve_last_kernel_ms(const ksolve_handle* h, const char* kernel_name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KSOLVE_H */

@@ -1,0 +1,274 @@
+// kernels.h — the data-parallel kernels around the pack engine (bodies; the __global__ wrappers are in ksolve.hip).
+//
+//   it_index_*   : inverts InstanceType.Requirements into per-(key,value) instance-type bitmasks, so that
+//                  "which instance types intersect this requirement set" is a handful of ORs (engine.h compat_mask)
+//   row_hash / row_insert / row_verify / class_number / row_class / class_gather :
+//                  pod equivalence classes. Streams the per-pod SoA rows (requests, requirement masks, toleration and
+//                  topology masks) once from HBM, hashes each row, and deduplicates through an open-addressing table so
+//                  that requirement algebra and pruning state are kept per class, not per pod. HBM-bound.
+//   sort_key_*   : queue order keys (queue.go:72-108): cpu desc, memory desc, creationTimestamp asc, uid asc
+//   finalize     : per claim cheapest compatible available offering (the packing-cost estimator)
+#pragma once
+#include "ksp.h"
+
+namespace ks {
+
+#if KS_DEVICE
+KS_FN uint64_t atomic_cas_u64(uint64_t* p, uint64_t expect, uint64_t v) { return (uint64_t)atomicCAS((unsigned long long*)p, (unsigned long long)expect, (unsigned long long)v); }
+KS_FN void atomic_min_u32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+KS_FN uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+KS_FN void atomic_min_i64(int64_t* p, int64_t v) { atomicMin((long long*)p, (long long)v); }
+KS_FN void atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
+KS_FN void atomic_or_u32(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+#else
+inline uint64_t atomic_cas_u64(uint64_t* p, uint64_t expect, uint64_t v) { uint64_t o = *p; if (o == expect) *p = v; return o; }
+inline void atomic_min_u32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
+inline uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p += v; return o; }
+inline void atomic_min_i64(int64_t* p, int64_t v) { if (v < *p) *p = v; }
+inline void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
+inline void atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
+#endif
+
+// ------------------------------------------------------------------------------------------------ instance types
+struct ItIndexArgs {
+  Dict dict;
+  int n_its, it_words, n_res;
+  ReqTable it_reqs;
+  const int64_t* it_alloc;
+  uint64_t* kv_has;      // [req_words*64][it_words]
+  uint64_t* key_undef;   // [n_keys][it_words]
+  uint64_t* key_compl;
+  uint64_t* key_neg;
+  uint64_t* it_alloc_ok; // [it_words]
+  uint32_t* error;       // bit0: an instance type does not require In [own name] on the instance-type key; bit1: bounds on an instance type
+};
+// one thread per instance type
+KS_FN void it_index_body(int it, const ItIndexArgs& a) {
+  const Dict& d = a.dict;
+  ReqRef r = a.it_reqs.at(d, it);
+  const int iw = a.it_words;
+  const uint64_t bitv = 1ull << (it & 63);
+  const int word = it >> 6;
+  if (r.has_gte | r.has_lte) atomic_or_u32(a.error, 2u);
+  bool ok = true;
+  for (int x = 0; x < a.n_res; ++x) ok = ok && a.it_alloc[(size_t)x * a.n_its + it] >= 0;
+  if (ok) atomic_or_u64(&a.it_alloc_ok[word], bitv);
+  for (int k = 0; k < d.n_keys; ++k) {
+    uint32_t w0 = d.key_word_off[k], w1 = d.key_word_off[k + 1];
+    if (k == d.key_it) {
+      // must be exactly In [own name]: engine.h relies on dictionary index == instance type index
+      bool good = bit(r.defined, k) && !bit(r.complement, k);
+      for (uint32_t w = w0; w < w1 && good; ++w) good = r.mask[w] == (((int)(w - w0) == word) ? bitv : 0ull);
+      if (!good) atomic_or_u32(a.error, 1u);
+      continue;
+    }
+    if (!bit(r.defined, k)) { atomic_or_u64(&a.key_undef[(size_t)k * iw + word], bitv); continue; }
+    bool comp = bit(r.complement, k);
+    if (comp) atomic_or_u64(&a.key_compl[(size_t)k * iw + word], bitv);
+    if (op_negative(req_op(d, r, k))) atomic_or_u64(&a.key_neg[(size_t)k * iw + word], bitv);
+    for (uint32_t w = w0; w < w1; ++w) {
+      uint64_t has = comp ? (~r.mask[w] & d.value_valid[w]) : r.mask[w];  // Requirement.Has(value) over the dictionary
+      while (has) {
+        int b = ctz64(has);
+        has &= has - 1;
+        atomic_or_u64(&a.kv_has[((size_t)w * 64 + b) * iw + word], bitv);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ pod classes
+struct RowArgs {
+  Dict dict;
+  int n_rows, n_res;
+  const int64_t* requests;  // [n_res][n_rows]
+  ReqTable reqs, strict;
+  const uint64_t* tolerates;
+  const uint64_t* topo_owned;
+  const uint64_t* topo_selected;
+  // table
+  uint64_t seed;
+  uint32_t table_size;      // power of two
+  uint64_t* table_hash;     // 0 = empty
+  uint32_t* table_rep;      // smallest row with that hash
+  uint32_t* table_class;
+  uint64_t* row_hash;
+  uint32_t* row_slot;
+  uint32_t* row_class;
+  uint32_t* n_classes;
+  uint32_t* collision;
+  // class tables
+  uint32_t* class_rep;
+  int64_t* cls_requests;    // [n_classes][n_res]
+  MutReqTable cls_reqs, cls_strict;
+  uint64_t* cls_tolerates;
+  int64_t* min_request;     // [n_res]
+};
+KS_FN uint64_t mix64(uint64_t h, uint64_t v) {
+  h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+  h *= 0xBF58476D1CE4E5B9ull;
+  h ^= h >> 29;
+  return h;
+}
+KS_FN uint64_t hash_reqset(const Dict& d, uint64_t h, const ReqRef& r) {
+  h = mix64(h, ((uint64_t)r.defined << 32) | r.complement);
+  h = mix64(h, ((uint64_t)r.has_gte << 32) | r.has_lte);
+  uint32_t keys = r.defined;
+  while (keys) {
+    int k = __builtin_ctz(keys);
+    keys &= keys - 1;
+    for (uint32_t w = d.key_word_off[k]; w < d.key_word_off[k + 1]; ++w) h = mix64(h, r.mask[w]);
+    if (bit(r.has_gte, k)) h = mix64(h, (uint64_t)r.gte[k]);
+    if (bit(r.has_lte, k)) h = mix64(h, (uint64_t)r.lte[k]);
+    if (r.minv) h = mix64(h, (uint64_t)(int64_t)r.minv[k]);
+  }
+  return h;
+}
+KS_FN bool equal_reqset(const Dict& d, const ReqRef& a, const ReqRef& b) {
+  if (a.defined != b.defined || a.complement != b.complement || a.has_gte != b.has_gte || a.has_lte != b.has_lte) return false;
+  uint32_t keys = a.defined;
+  while (keys) {
+    int k = __builtin_ctz(keys);
+    keys &= keys - 1;
+    for (uint32_t w = d.key_word_off[k]; w < d.key_word_off[k + 1]; ++w) if (a.mask[w] != b.mask[w]) return false;
+    if (bit(a.has_gte, k) && a.gte[k] != b.gte[k]) return false;
+    if (bit(a.has_lte, k) && a.lte[k] != b.lte[k]) return false;
+    int32_t am = a.minv ? a.minv[k] : -1, bm = b.minv ? b.minv[k] : -1;
+    if (am != bm) return false;
+  }
+  return true;
+}
+KS_FN void row_hash_body(int row, const RowArgs& a) {
+  uint64_t h = a.seed;
+  for (int r = 0; r < a.n_res; ++r) h = mix64(h, (uint64_t)a.requests[(size_t)r * a.n_rows + row]);
+  h = hash_reqset(a.dict, h, a.reqs.at(a.dict, row));
+  h = hash_reqset(a.dict, h, a.strict.at(a.dict, row));
+  h = mix64(h, a.tolerates[row]);
+  h = mix64(h, a.topo_owned ? a.topo_owned[row] : 0);
+  h = mix64(h, a.topo_selected ? a.topo_selected[row] : 0);
+  if (h == 0) h = 1;
+  a.row_hash[row] = h;
+  uint32_t slot = (uint32_t)(h >> 17) & (a.table_size - 1);
+  for (;;) {
+    uint64_t prev = atomic_cas_u64(&a.table_hash[slot], 0ull, h);
+    if (prev == 0ull || prev == h) break;
+    slot = (slot + 1) & (a.table_size - 1);
+  }
+  atomic_min_u32(&a.table_rep[slot], (uint32_t)row);
+  a.row_slot[row] = slot;
+}
+KS_FN bool rows_equal(const RowArgs& a, int x, int y) {
+  for (int r = 0; r < a.n_res; ++r) if (a.requests[(size_t)r * a.n_rows + x] != a.requests[(size_t)r * a.n_rows + y]) return false;
+  if (!equal_reqset(a.dict, a.reqs.at(a.dict, x), a.reqs.at(a.dict, y))) return false;
+  if (!equal_reqset(a.dict, a.strict.at(a.dict, x), a.strict.at(a.dict, y))) return false;
+  if (a.tolerates[x] != a.tolerates[y]) return false;
+  if (a.topo_owned && a.topo_owned[x] != a.topo_owned[y]) return false;
+  if (a.topo_selected && a.topo_selected[x] != a.topo_selected[y]) return false;
+  return true;
+}
+// verify against the representative (a 64-bit hash collision between different rows is reported, the host re-seeds) and
+// let each representative draw a class id
+KS_FN void row_verify_body(int row, const RowArgs& a) {
+  uint32_t slot = a.row_slot[row];
+  uint32_t rep = a.table_rep[slot];
+  if (rep == (uint32_t)row) {
+    uint32_t id = atomic_add_u32(a.n_classes, 1u);
+    a.table_class[slot] = id;
+  } else if (!rows_equal(a, row, (int)rep)) {
+    *a.collision = 1;
+  }
+}
+KS_FN void row_class_body(int row, const RowArgs& a) {
+  uint32_t slot = a.row_slot[row];
+  uint32_t id = a.table_class[slot];
+  a.row_class[row] = id;
+  if (a.table_rep[slot] == (uint32_t)row) a.class_rep[id] = (uint32_t)row;
+}
+KS_FN void copy_reqset(const Dict& d, const MutReqTable& dst, uint32_t di, const ReqRef& s) {
+  uint64_t* m = dst.mask + (size_t)di * d.req_words;
+  for (int w = 0; w < d.req_words; ++w) m[w] = s.mask[w];
+  dst.defined[di] = s.defined; dst.complement[di] = s.complement; dst.has_gte[di] = s.has_gte; dst.has_lte[di] = s.has_lte;
+  for (int k = 0; k < d.n_keys; ++k) {
+    dst.gte[(size_t)di * d.n_keys + k] = (s.gte && bit(s.has_gte, k)) ? s.gte[k] : 0;
+    dst.lte[(size_t)di * d.n_keys + k] = (s.lte && bit(s.has_lte, k)) ? s.lte[k] : 0;
+    dst.minv[(size_t)di * d.n_keys + k] = s.minv ? s.minv[k] : -1;
+  }
+}
+KS_FN void class_gather_body(int cls, const RowArgs& a) {
+  int row = (int)a.class_rep[cls];
+  for (int r = 0; r < a.n_res; ++r) {
+    int64_t v = a.requests[(size_t)r * a.n_rows + row];
+    a.cls_requests[(size_t)cls * a.n_res + r] = v;
+    atomic_min_i64(&a.min_request[r], v);
+  }
+  copy_reqset(a.dict, a.cls_reqs, cls, a.reqs.at(a.dict, row));
+  copy_reqset(a.dict, a.cls_strict, cls, a.strict.at(a.dict, row));
+  a.cls_tolerates[cls] = a.tolerates[row];
+}
+
+// ------------------------------------------------------------------------------------------------ queue order
+struct SortKeyArgs {
+  int n_pods, n_rows;
+  const int64_t* requests;   // [n_res][n_rows]; dim 0 = cpu, dim 1 = memory
+  const int64_t* creation;
+  const uint64_t *uid_hi, *uid_lo;
+  const uint32_t* idx_in;    // current permutation
+  uint64_t* key_out;
+  int pass;                  // 0 uid_lo, 1 uid_hi, 2 creation, 3 memory (desc), 4 cpu (desc)
+};
+KS_FN void sort_key_body(int i, const SortKeyArgs& a) {
+  uint32_t p = a.idx_in ? a.idx_in[i] : (uint32_t)i;
+  uint64_t k;
+  switch (a.pass) {
+    case 0: k = a.uid_lo[p]; break;
+    case 1: k = a.uid_hi[p]; break;
+    case 2: k = (uint64_t)a.creation[p] ^ 0x8000000000000000ull; break;
+    case 3: k = ~((uint64_t)a.requests[(size_t)1 * a.n_rows + p] ^ 0x8000000000000000ull); break;
+    default: k = ~((uint64_t)a.requests[(size_t)0 * a.n_rows + p] ^ 0x8000000000000000ull); break;
+  }
+  a.key_out[i] = k;
+}
+
+// ------------------------------------------------------------------------------------------------ finalize
+struct FinalizeArgs {
+  Dict dict;
+  int n_its, it_words, n_zones, n_cts;
+  const uint64_t* it_off_avail;
+  const double* it_off_price;
+  const uint64_t* c_its;
+  MutReqTable c_reqs;
+  double* cheapest;
+};
+// one thread per claim: min over InstanceTypeOptions of the cheapest available offering compatible with the claim's
+// requirements (the comparator key of OrderByPrice, types.go:336-355)
+KS_FN void finalize_body(int c, const FinalizeArgs& a) {
+  const Dict& d = a.dict;
+  ReqRef r = a.c_reqs.at(d, c);
+  uint32_t zones = 0, cts = 0;
+  if (d.key_zone >= 0 && bit(r.defined, d.key_zone)) { for (int z = 0; z < a.n_zones; ++z) if (req_has(d, r, d.key_zone, d.key_word_off[d.key_zone], z)) zones |= 1u << z; }
+  else zones = (1u << a.n_zones) - 1;
+  if (d.key_ct >= 0 && bit(r.defined, d.key_ct)) { for (int t = 0; t < a.n_cts; ++t) if (req_has(d, r, d.key_ct, d.key_word_off[d.key_ct], t)) cts |= 1u << t; }
+  else cts = (1u << a.n_cts) - 1;
+  uint64_t cells = 0;
+  for (uint32_t zz = zones; zz; zz &= zz - 1) cells |= (uint64_t)cts << (__builtin_ctz(zz) * 4);
+  double best = 1.7976931348623157e308;
+  const uint64_t* its = a.c_its + (size_t)c * a.it_words;
+  for (int w = 0; w < a.it_words; ++w) {
+    uint64_t m = its[w];
+    while (m) {
+      int b = ctz64(m);
+      m &= m - 1;
+      int it = w * 64 + b;
+      uint64_t av = a.it_off_avail[it] & cells;
+      while (av) {
+        int cell = ctz64(av);
+        av &= av - 1;
+        double p = a.it_off_price[(size_t)it * 64 + cell];
+        if (p < best) best = p;
+      }
+    }
+  }
+  a.cheapest[c] = best;
+}
+
+}  // namespace ks

@@ -1,0 +1,437 @@
+// ksolve_impl.h — implementation of the C ABI (include/ksolve.h) on top of a tiny backend layer.
+// Included by exactly one translation unit per build:
+//   ksolve.hip      (product): HIP backend — device arena, one stream per handle, HIP events around every phase
+//   tests/emu/ksolve_emu.cpp (TEST ONLY): host emulation of the same kernels, to fuzz the device algorithm against the
+//                              oracle on machines without a GPU. Never built into, or loaded by, the product.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ksolve.h"
+#include "engine.h"
+#include "kernels.h"
+
+// Backend contract (provided by the including TU):
+//   void* be_alloc(ksolve_handle*, size_t bytes)  — zero-initialised device memory owned by the handle
+//   void  be_h2d(ksolve_handle*, void* dst, const void* src, size_t), be_d2h(...), be_fill(ksolve_handle*, void*, int byte, size_t)
+//   void  be_sync(ksolve_handle*)
+//   launchers: be_launch_it_index, be_launch_row_hash, ..., be_launch_pack, be_sort_pods
+//   timers: be_tic(h, slot), be_toc(h, slot) -> accumulate milliseconds per named phase
+struct ksolve_handle;
+
+namespace ksi {
+
+using namespace ks;
+
+struct HostReqTable {  // device pointers of an uploaded ksolve_reqsets
+  ReqTable t{};
+};
+
+struct Timers {
+  double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+enum { T_UPLOAD = 0, T_INDEX = 1, T_CLASSIFY = 2, T_SORT = 3, T_PACK = 4, T_FINALIZE = 5, T_DOWNLOAD = 6 };
+
+}  // namespace ksi
+
+struct ksolve_handle {
+  std::string error;
+  ksolve_options opts{};
+  ksi::Timers timers;
+  // problem sizes
+  uint32_t n_keys = 0, req_words = 0, n_res = 0, n_its = 0, it_words = 0, n_templates = 0, n_pods = 0, n_rows = 0, n_classes = 0;
+  uint32_t max_claims = 0, claim_words = 0, class_capacity = 0;
+  ks::ProblemView pv{};
+  ks::Workspace ws{};
+  // device buffers needed by the host between phases
+  ks::ItIndexArgs it_args{};
+  ks::RowArgs row_args{};
+  ks::SortKeyArgs sort_args{};
+  uint32_t *d_idx_a = nullptr, *d_idx_b = nullptr;
+  uint64_t *d_key_a = nullptr, *d_key_b = nullptr;
+  double* d_cheapest = nullptr;
+  int* d_cancel = nullptr;
+  ks::MutReqTable d_cls_reqs{}, d_cls_strict{};
+  std::vector<void*> allocations;
+  void* backend = nullptr;
+  volatile int cancel_requested = 0;
+  bool has_topology = false;
+};
+
+// ---- backend hooks (defined by the including TU before this point is instantiated) ----
+static void* be_alloc(ksolve_handle* h, size_t bytes);
+static void be_h2d(ksolve_handle* h, void* dst, const void* src, size_t bytes);
+static void be_d2h(ksolve_handle* h, void* dst, const void* src, size_t bytes);
+static void be_fill(ksolve_handle* h, void* dst, int byte, size_t bytes);
+static void be_sync(ksolve_handle* h);
+static bool be_ok(ksolve_handle* h);
+static void be_tic(ksolve_handle* h, int slot);
+static void be_toc(ksolve_handle* h, int slot);
+static void be_launch_it_index(ksolve_handle* h, int n, const ks::ItIndexArgs& a);
+static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a);
+static void be_launch_row_verify(ksolve_handle* h, int n, const ks::RowArgs& a);
+static void be_launch_row_class(ksolve_handle* h, int n, const ks::RowArgs& a);
+static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a);
+static void be_sort_pods(ksolve_handle* h);  // fills ws/pv.sorted_pods
+static void be_launch_pack(ksolve_handle* h);
+static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a);
+static int be_device_available();
+
+namespace ksi {
+
+template <class T>
+static T* up(ksolve_handle* h, const T* src, size_t n) {
+  if (n == 0) n = 1;
+  T* d = (T*)be_alloc(h, n * sizeof(T));
+  if (src) be_h2d(h, d, src, n * sizeof(T));
+  return d;
+}
+template <class T>
+static T* dz(ksolve_handle* h, size_t n) { return (T*)be_alloc(h, (n ? n : 1) * sizeof(T)); }
+
+static ReqTable upload_reqs(ksolve_handle* h, const ksolve_reqsets& r, uint32_t n, uint32_t req_words, uint32_t n_keys) {
+  ReqTable t{};
+  t.mask = up(h, r.mask, (size_t)n * req_words);
+  t.defined = up(h, r.defined, n);
+  t.complement = up(h, r.complement, n);
+  t.has_gte = r.has_gte ? up(h, r.has_gte, n) : dz<uint32_t>(h, n);
+  t.has_lte = r.has_lte ? up(h, r.has_lte, n) : dz<uint32_t>(h, n);
+  t.gte = r.gte ? up(h, r.gte, (size_t)n * n_keys) : dz<int64_t>(h, (size_t)n * n_keys);
+  t.lte = r.lte ? up(h, r.lte, (size_t)n * n_keys) : dz<int64_t>(h, (size_t)n * n_keys);
+  if (r.min_values) t.minv = up(h, r.min_values, (size_t)n * n_keys);
+  else { int32_t* m = dz<int32_t>(h, (size_t)n * n_keys); be_fill(h, m, 0xFF, (size_t)n * n_keys * sizeof(int32_t)); t.minv = m; }
+  return t;
+}
+static MutReqTable alloc_reqs(ksolve_handle* h, uint32_t n, uint32_t req_words, uint32_t n_keys) {
+  MutReqTable t{};
+  t.mask = dz<uint64_t>(h, (size_t)n * req_words);
+  t.defined = dz<uint32_t>(h, n); t.complement = dz<uint32_t>(h, n); t.has_gte = dz<uint32_t>(h, n); t.has_lte = dz<uint32_t>(h, n);
+  t.gte = dz<int64_t>(h, (size_t)n * n_keys); t.lte = dz<int64_t>(h, (size_t)n * n_keys); t.minv = dz<int32_t>(h, (size_t)n * n_keys);
+  return t;
+}
+static ReqTable as_const(const MutReqTable& m) {
+  ReqTable t{};
+  t.mask = m.mask; t.defined = m.defined; t.complement = m.complement; t.has_gte = m.has_gte; t.has_lte = m.has_lte;
+  t.gte = m.gte; t.lte = m.lte; t.minv = m.minv;
+  return t;
+}
+
+static ksolve_status fail(ksolve_handle* h, ksolve_status s, const std::string& msg) {
+  h->error = msg;
+  return s;
+}
+
+static bool any_nonzero(const uint32_t* p, uint32_t n) {
+  if (!p) return false;
+  for (uint32_t i = 0; i < n; ++i) if (p[i]) return true;
+  return false;
+}
+
+static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* o, ksolve_handle* h) {
+  if (!d || d->abi_version != KSOLVE_ABI_VERSION) return fail(h, KSOLVE_ERR_INVALID, "abi version mismatch");
+  if (d->n_keys == 0 || d->n_keys > KSOLVE_MAX_KEYS) return fail(h, KSOLVE_ERR_INVALID, "n_keys out of range");
+  if (d->n_res < 2 || d->n_res > KSOLVE_MAX_RES) return fail(h, KSOLVE_ERR_INVALID, "n_res must be in [2,8] (cpu, memory first)");
+  if (d->n_templates > KSOLVE_MAX_TEMPLATES) return fail(h, KSOLVE_ERR_UNSUPPORTED, "more than 32 NodeClaimTemplates");
+  if (d->n_zones > KSOLVE_MAX_ZONES || d->n_captypes > KSOLVE_MAX_CAPTYPES) return fail(h, KSOLVE_ERR_UNSUPPORTED, "more than 16 offering zones or 4 capacity types");
+  if (d->n_its == 0 && d->n_templates) return fail(h, KSOLVE_ERR_INVALID, "templates without instance types");
+  const uint32_t req_words = d->key_word_off[d->n_keys];
+  if (req_words > (uint32_t)ks::kMaxReqWords) return fail(h, KSOLVE_ERR_UNSUPPORTED, "requirement dictionaries need more than 96 mask words");
+  const uint32_t it_words = (d->n_its + 63) / 64;
+  if (it_words > (uint32_t)ks::kMaxItWords) return fail(h, KSOLVE_ERR_UNSUPPORTED, "more than 2048 instance types");
+  if (d->key_instance_type < 0) return fail(h, KSOLVE_ERR_INVALID, "key_instance_type required");
+  if (d->key_word_off[d->key_instance_type + 1] - d->key_word_off[d->key_instance_type] != it_words)
+    return fail(h, KSOLVE_ERR_INVALID, "instance-type key dictionary must be the instance type list");
+  if (d->n_nodes) return fail(h, KSOLVE_ERR_UNSUPPORTED, "existing nodes are not solved on the device in this build");
+  if (d->topo.n) return fail(h, KSOLVE_ERR_UNSUPPORTED, "topology groups are not solved on the device in this build");
+  if (d->tmpl_reqs.min_values) {
+    for (size_t i = 0; i < (size_t)d->n_templates * d->n_keys; ++i)
+      if (d->tmpl_reqs.min_values[i] >= 0) return fail(h, KSOLVE_ERR_UNSUPPORTED, "minValues are not solved on the device in this build");
+  }
+  for (uint32_t i = 0; i < d->n_its; ++i) {
+    // reserved offerings would need the ReservationManager; capacity type index >= n_captypes never occurs by construction
+    (void)i;
+  }
+  if (o) h->opts = *o;
+  else { h->opts = ksolve_options{}; h->opts.max_steps = -1; }
+  h->n_keys = d->n_keys; h->req_words = req_words; h->n_res = d->n_res; h->n_its = d->n_its; h->it_words = it_words;
+  h->n_templates = d->n_templates; h->n_pods = d->n_pods; h->n_rows = d->n_pod_rows;
+  if (h->n_rows < h->n_pods) return fail(h, KSOLVE_ERR_INVALID, "n_pod_rows < n_pods");
+
+  be_tic(h, T_UPLOAD);
+  ks::ProblemView& P = h->pv;
+  ks::Dict& dict = P.dict;
+  dict.n_keys = d->n_keys; dict.req_words = req_words;
+  for (uint32_t k = 0; k <= d->n_keys; ++k) dict.key_word_off[k] = d->key_word_off[k];
+  dict.well_known_mask = d->well_known_mask;
+  dict.key_it = d->key_instance_type; dict.key_zone = d->key_zone; dict.key_ct = d->key_capacity_type; dict.key_hostname = d->key_hostname;
+  dict.value_int = up(h, d->value_int, (size_t)req_words * 64);
+  dict.value_is_int = up(h, d->value_is_int, req_words);
+  // valid dictionary bits are not part of the ABI: a value is valid when some entity mentions it; complements
+  // enumerate the dictionary, so derive validity from the union of every uploaded mask.
+  {
+    std::vector<uint64_t> valid(req_words, 0);
+    auto acc = [&](const ksolve_reqsets& r, uint32_t n) { if (r.mask) for (size_t i = 0; i < (size_t)n * req_words; ++i) valid[i % req_words] |= r.mask[i]; };
+    acc(d->it_reqs, d->n_its); acc(d->tmpl_reqs, d->n_templates); acc(d->pod_reqs, d->n_pod_rows); acc(d->pod_strict_reqs, d->n_pod_rows);
+    // every instance type name is a valid value of the instance-type key
+    for (uint32_t i = 0; i < d->n_its; ++i) valid[d->key_word_off[d->key_instance_type] + i / 64] |= 1ull << (i % 64);
+    dict.value_valid = up(h, valid.data(), req_words);
+  }
+  P.n_res = d->n_res; P.n_its = d->n_its; P.it_words = it_words;
+  P.it_alloc = up(h, d->it_allocatable, (size_t)d->n_res * d->n_its);
+  P.it_cap = up(h, d->it_capacity, (size_t)d->n_res * d->n_its);
+  P.it_off_avail = up(h, d->it_offering_avail, d->n_its);
+  P.it_off_price = up(h, d->it_offering_price, (size_t)d->n_its * 64);
+  P.n_zones = d->n_zones; P.n_cts = d->n_captypes;
+  P.it_reqs = upload_reqs(h, d->it_reqs, d->n_its, req_words, d->n_keys);
+  uint64_t* kv_has = dz<uint64_t>(h, (size_t)req_words * 64 * it_words);
+  uint64_t* key_undef = dz<uint64_t>(h, (size_t)d->n_keys * it_words);
+  uint64_t* key_compl = dz<uint64_t>(h, (size_t)d->n_keys * it_words);
+  uint64_t* key_neg = dz<uint64_t>(h, (size_t)d->n_keys * it_words);
+  uint64_t* alloc_ok = dz<uint64_t>(h, it_words);
+  P.kv_has = kv_has; P.key_undef = key_undef; P.key_compl = key_compl; P.key_neg = key_neg; P.it_alloc_ok = alloc_ok;
+  h->it_args = ks::ItIndexArgs{dict, (int)d->n_its, (int)it_words, (int)d->n_res, P.it_reqs, P.it_alloc, kv_has, key_undef, key_compl, key_neg, alloc_ok, dz<uint32_t>(h, 1)};
+
+  P.n_templates = d->n_templates;
+  P.tmpl_reqs = upload_reqs(h, d->tmpl_reqs, d->n_templates, req_words, d->n_keys);
+  P.tmpl_taints = up(h, d->tmpl_taints, d->n_templates);
+  P.tmpl_its = up(h, d->tmpl_its, (size_t)d->n_templates * it_words);
+  P.tmpl_limit_mask = up(h, d->tmpl_limit_mask, d->n_templates);
+  P.tmpl_limits = up(h, d->tmpl_limits, (size_t)d->n_templates * (d->n_res + 1));
+
+  P.n_pods = d->n_pods; P.n_rows = d->n_pod_rows;
+  P.row_next = up(h, d->pod_next_variant, d->n_pod_rows);
+  P.pod_is_pending = up(h, d->pod_is_pending, d->n_pods);
+  ks::RowArgs& R = h->row_args;
+  R.dict = dict; R.n_rows = d->n_pod_rows; R.n_res = d->n_res;
+  R.requests = up(h, d->pod_requests, (size_t)d->n_res * d->n_pod_rows);
+  R.reqs = upload_reqs(h, d->pod_reqs, d->n_pod_rows, req_words, d->n_keys);
+  if (d->pod_strict_reqs.mask == d->pod_reqs.mask || d->pod_strict_reqs.mask == nullptr) R.strict = R.reqs;
+  else R.strict = upload_reqs(h, d->pod_strict_reqs, d->n_pod_rows, req_words, d->n_keys);
+  R.tolerates = up(h, d->pod_tolerates, d->n_pod_rows);
+  R.topo_owned = nullptr; R.topo_selected = nullptr;
+  uint32_t ts = 64;
+  while (ts < 2 * d->n_pod_rows) ts <<= 1;
+  R.table_size = ts; R.seed = 0x6b73703176310a01ull;
+  R.table_hash = dz<uint64_t>(h, ts); R.table_rep = dz<uint32_t>(h, ts); R.table_class = dz<uint32_t>(h, ts);
+  R.row_hash = dz<uint64_t>(h, d->n_pod_rows); R.row_slot = dz<uint32_t>(h, d->n_pod_rows);
+  uint32_t* row_class = dz<uint32_t>(h, d->n_pod_rows);
+  R.row_class = row_class; P.row_class = row_class;
+  R.n_classes = dz<uint32_t>(h, 1); R.collision = dz<uint32_t>(h, 1);
+  int64_t* minreq = dz<int64_t>(h, d->n_res);
+  R.min_request = minreq; P.min_request = minreq;
+
+  ks::SortKeyArgs& S = h->sort_args;
+  S.n_pods = d->n_pods; S.n_rows = d->n_pod_rows; S.requests = R.requests;
+  S.creation = up(h, d->pod_creation, d->n_pods);
+  S.uid_hi = up(h, d->pod_uid_hi, d->n_pods); S.uid_lo = up(h, d->pod_uid_lo, d->n_pods);
+  h->d_idx_a = dz<uint32_t>(h, d->n_pods); h->d_idx_b = dz<uint32_t>(h, d->n_pods);
+  h->d_key_a = dz<uint64_t>(h, d->n_pods); h->d_key_b = dz<uint64_t>(h, d->n_pods);
+
+  // workspace
+  uint32_t mc = h->opts.max_claims ? h->opts.max_claims : d->n_pods;
+  if (mc > d->n_pods) mc = d->n_pods;
+  if (mc == 0) mc = 1;
+  h->max_claims = mc; h->claim_words = (mc + 63) / 64;
+  ks::Workspace& W = h->ws;
+  W.max_claims = (int)mc; W.claim_words = (int)h->claim_words;
+  W.c_tmpl = dz<int32_t>(h, mc); W.c_total = dz<int64_t>(h, (size_t)mc * d->n_res); W.c_head = dz<int64_t>(h, (size_t)mc * d->n_res);
+  W.c_its = dz<uint64_t>(h, (size_t)mc * it_words);
+  W.c_reqs = alloc_reqs(h, mc, req_words, d->n_keys);
+  W.c_host_seq = dz<uint32_t>(h, mc); W.c_relaxed = dz<uint8_t>(h, mc); W.c_npods = dz<uint32_t>(h, mc);
+  W.o_key = dz<uint32_t>(h, mc); W.o_ord = dz<uint32_t>(h, mc); W.o_pos = dz<uint32_t>(h, mc);
+  W.closed = dz<uint64_t>(h, h->claim_words);
+  W.queue = dz<uint32_t>(h, (size_t)d->n_pods + 1); W.last_len = dz<uint32_t>(h, d->n_pods);
+  W.t_its = dz<uint64_t>(h, (size_t)d->n_templates * it_words);
+  W.t_remaining = dz<int64_t>(h, (size_t)d->n_templates * (d->n_res + 1));
+  W.assign = dz<int32_t>(h, d->n_pods); W.err = dz<uint8_t>(h, d->n_pods); W.diag = dz<uint8_t>(h, d->n_pods); W.slot = dz<uint32_t>(h, d->n_pods);
+  W.n_claims_out = dz<int>(h, 1); W.status_out = dz<int>(h, 1);
+  h->d_cancel = dz<int>(h, 1);
+  W.cancel_flag = h->d_cancel;
+  W.max_steps = h->opts.max_steps;
+  W.counters = dz<ks::Counters>(h, 1);
+  h->d_cheapest = dz<double>(h, mc);
+  be_sync(h);
+  be_toc(h, T_UPLOAD);
+  if (!be_ok(h)) return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "device allocation/upload failed" : h->error);
+  return KSOLVE_OK;
+}
+
+struct ResultsImpl {
+  std::vector<int32_t> assign, tmpl;
+  std::vector<uint8_t> err, diag, relaxed;
+  std::vector<uint32_t> slot, npods, defined, complement, has_gte, has_lte, host_seq, ord;
+  std::vector<uint64_t> its, mask;
+  std::vector<int64_t> requests, gte, lte;
+  std::vector<int32_t> minv;
+  std::vector<double> cheapest;
+};
+
+static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
+  memset(out, 0, sizeof(*out));
+  ks::ProblemView& P = h->pv;
+  ks::Workspace& W = h->ws;
+  const uint32_t n_pods = h->n_pods, n_rows = h->n_rows, n_res = h->n_res;
+
+  // ---- phase 1: instance-type requirement index ----
+  be_tic(h, T_INDEX);
+  be_fill(h, (void*)P.kv_has, 0, (size_t)h->req_words * 64 * h->it_words * 8);
+  be_fill(h, (void*)P.key_undef, 0, (size_t)h->n_keys * h->it_words * 8);
+  be_fill(h, (void*)P.key_compl, 0, (size_t)h->n_keys * h->it_words * 8);
+  be_fill(h, (void*)P.key_neg, 0, (size_t)h->n_keys * h->it_words * 8);
+  be_fill(h, (void*)P.it_alloc_ok, 0, (size_t)h->it_words * 8);
+  be_fill(h, h->it_args.error, 0, 4);
+  if (h->n_its) be_launch_it_index(h, (int)h->n_its, h->it_args);
+  be_toc(h, T_INDEX);
+
+  // ---- phase 2: pod equivalence classes ----
+  be_tic(h, T_CLASSIFY);
+  ks::RowArgs& R = h->row_args;
+  uint32_t n_classes = 0;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    be_fill(h, R.table_hash, 0, (size_t)R.table_size * 8);
+    be_fill(h, R.table_rep, 0xFF, (size_t)R.table_size * 4);
+    be_fill(h, R.n_classes, 0, 4);
+    be_fill(h, R.collision, 0, 4);
+    if (n_rows) { be_launch_row_hash(h, (int)n_rows, R); be_launch_row_verify(h, (int)n_rows, R); }
+    uint32_t coll = 0;
+    be_d2h(h, &n_classes, R.n_classes, 4);
+    be_d2h(h, &coll, R.collision, 4);
+    be_sync(h);
+    if (!coll) break;
+    R.seed = R.seed * 6364136223846793005ull + 1442695040888963407ull;  // a 64-bit collision between different rows: re-seed
+    if (attempt == 3) return fail(h, KSOLVE_ERR_DEVICE, "row hash collisions persist");
+  }
+  uint32_t it_err = 0;
+  be_d2h(h, &it_err, h->it_args.error, 4);
+  be_sync(h);
+  if (it_err & 1) return fail(h, KSOLVE_ERR_UNSUPPORTED, "an instance type does not carry `node.kubernetes.io/instance-type In [own name]`");
+  if (it_err & 2) return fail(h, KSOLVE_ERR_UNSUPPORTED, "instance types with Gt/Lt requirements are not supported");
+  h->n_classes = n_classes;
+  if (n_classes > h->class_capacity) {
+    // class tables are sized once the class count is known (and kept for later solves on the same handle)
+    h->class_capacity = n_classes;
+    R.class_rep = dz<uint32_t>(h, n_classes);
+    R.cls_requests = dz<int64_t>(h, (size_t)n_classes * n_res);
+    h->d_cls_reqs = alloc_reqs(h, n_classes, h->req_words, h->n_keys);
+    h->d_cls_strict = alloc_reqs(h, n_classes, h->req_words, h->n_keys);
+    R.cls_reqs = h->d_cls_reqs; R.cls_strict = h->d_cls_strict;
+    R.cls_tolerates = dz<uint64_t>(h, n_classes);
+    h->ws.dead = dz<uint64_t>(h, (size_t)n_classes * h->claim_words);
+  }
+  if (n_classes > 0) {
+    be_fill(h, R.min_request, 0x7F, (size_t)n_res * 8);
+    be_launch_row_class(h, (int)n_rows, R);
+    be_launch_class_gather(h, (int)n_classes, R);
+  }
+  P.n_classes = (int)n_classes;
+  P.cls_requests = R.cls_requests; P.cls_reqs = as_const(h->d_cls_reqs); P.cls_strict = as_const(h->d_cls_strict);
+  P.cls_tolerates = R.cls_tolerates;
+  if (n_classes) be_fill(h, W.dead, 0, (size_t)n_classes * h->claim_words * 8);
+  be_toc(h, T_CLASSIFY);
+
+  // ---- phase 3: queue order ----
+  be_tic(h, T_SORT);
+  be_sort_pods(h);
+  be_toc(h, T_SORT);
+
+  // ---- phase 4: pack ----
+  be_fill(h, W.closed, 0, (size_t)h->claim_words * 8);
+  be_fill(h, W.last_len, 0, (size_t)n_pods * 4);
+  be_fill(h, W.assign, 0xFF, (size_t)n_pods * 4);
+  be_fill(h, W.err, 0, n_pods); be_fill(h, W.diag, 0, n_pods);
+  be_fill(h, W.n_claims_out, 0, 4); be_fill(h, W.status_out, 0, 4);
+  be_fill(h, h->d_cancel, 0, 4);
+  be_tic(h, T_PACK);
+  if (n_pods) be_launch_pack(h);
+  be_toc(h, T_PACK);
+
+  int n_claims = 0, status = 0;
+  be_d2h(h, &n_claims, W.n_claims_out, 4);
+  be_d2h(h, &status, W.status_out, 4);
+  be_sync(h);
+  if (!be_ok(h)) return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "pack kernel failed" : h->error);
+  if (status == 1) return fail(h, KSOLVE_ERR_CAPACITY, "claim capacity exceeded (ksolve_options.max_claims)");
+
+  // ---- phase 5: finalize ----
+  be_tic(h, T_FINALIZE);
+  ks::FinalizeArgs F{P.dict, (int)h->n_its, (int)h->it_words, P.n_zones, P.n_cts, P.it_off_avail, P.it_off_price, W.c_its, W.c_reqs, h->d_cheapest};
+  if (n_claims) be_launch_finalize(h, n_claims, F);
+  be_toc(h, T_FINALIZE);
+
+  // ---- phase 6: download ----
+  be_tic(h, T_DOWNLOAD);
+  ResultsImpl* im = new ResultsImpl();
+  im->assign.resize(n_pods); im->err.resize(n_pods); im->diag.resize(n_pods); im->slot.resize(n_pods);
+  if (n_pods) {
+    be_d2h(h, im->assign.data(), W.assign, (size_t)n_pods * 4);
+    be_d2h(h, im->err.data(), W.err, n_pods); be_d2h(h, im->diag.data(), W.diag, n_pods);
+    be_d2h(h, im->slot.data(), W.slot, (size_t)n_pods * 4);
+  }
+  const uint32_t C = (uint32_t)n_claims;
+  std::vector<int32_t> tmpl(C);
+  std::vector<uint32_t> npods(C), defined(C), complement(C), has_gte(C), has_lte(C), host_seq(C), ord(C);
+  std::vector<uint8_t> relaxed(C);
+  std::vector<uint64_t> its((size_t)C * h->it_words), mask((size_t)C * h->req_words);
+  std::vector<int64_t> requests((size_t)C * n_res), gte((size_t)C * h->n_keys), lte((size_t)C * h->n_keys);
+  std::vector<int32_t> minv((size_t)C * h->n_keys);
+  std::vector<double> cheapest(C);
+  if (C) {
+    be_d2h(h, tmpl.data(), W.c_tmpl, (size_t)C * 4); be_d2h(h, npods.data(), W.c_npods, (size_t)C * 4);
+    be_d2h(h, its.data(), W.c_its, its.size() * 8); be_d2h(h, mask.data(), W.c_reqs.mask, mask.size() * 8);
+    be_d2h(h, defined.data(), W.c_reqs.defined, (size_t)C * 4); be_d2h(h, complement.data(), W.c_reqs.complement, (size_t)C * 4);
+    be_d2h(h, has_gte.data(), W.c_reqs.has_gte, (size_t)C * 4); be_d2h(h, has_lte.data(), W.c_reqs.has_lte, (size_t)C * 4);
+    be_d2h(h, gte.data(), W.c_reqs.gte, gte.size() * 8); be_d2h(h, lte.data(), W.c_reqs.lte, lte.size() * 8);
+    be_d2h(h, minv.data(), W.c_reqs.minv, minv.size() * 4);
+    be_d2h(h, requests.data(), W.c_total, requests.size() * 8);
+    be_d2h(h, host_seq.data(), W.c_host_seq, (size_t)C * 4); be_d2h(h, relaxed.data(), W.c_relaxed, C);
+    be_d2h(h, cheapest.data(), h->d_cheapest, (size_t)C * 8);
+    be_d2h(h, ord.data(), W.o_ord, (size_t)C * 4);
+  }
+  ks::Counters ctr{};
+  be_d2h(h, &ctr, W.counters, sizeof(ctr));
+  be_sync(h);
+  be_toc(h, T_DOWNLOAD);
+  if (!be_ok(h)) { delete im; return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "download failed" : h->error); }
+
+  // Report claims in the order the reference's s.newNodeClaims slice ends in (position order), so claim index i in the
+  // results is position i; pod assignments are remapped accordingly.
+  std::vector<uint32_t> newidx(C);
+  for (uint32_t i = 0; i < C; ++i) newidx[ord[i]] = i;
+  auto permute = [&](auto& dst, const auto& src, size_t width) {
+    dst.resize((size_t)C * width);
+    for (uint32_t i = 0; i < C; ++i) for (size_t w = 0; w < width; ++w) dst[(size_t)i * width + w] = src[(size_t)ord[i] * width + w];
+  };
+  permute(im->tmpl, tmpl, 1); permute(im->npods, npods, 1); permute(im->its, its, h->it_words); permute(im->mask, mask, h->req_words);
+  permute(im->defined, defined, 1); permute(im->complement, complement, 1); permute(im->has_gte, has_gte, 1); permute(im->has_lte, has_lte, 1);
+  permute(im->gte, gte, h->n_keys); permute(im->lte, lte, h->n_keys); permute(im->minv, minv, h->n_keys);
+  permute(im->requests, requests, n_res); permute(im->host_seq, host_seq, 1); permute(im->relaxed, relaxed, 1); permute(im->cheapest, cheapest, 1);
+  for (uint32_t p = 0; p < n_pods; ++p) if (im->assign[p] >= 0) im->assign[p] = (int32_t)newidx[im->assign[p]];
+  double cost = 0;
+  for (uint32_t i = 0; i < C; ++i) if (im->cheapest[i] < 1e300) cost += im->cheapest[i];
+
+  out->status = status == 2 ? KSOLVE_ERR_CANCELLED : KSOLVE_OK;
+  out->n_pods = n_pods;
+  out->pod_assignment = im->assign.data(); out->pod_error = im->err.data(); out->pod_error_diag = im->diag.data(); out->pod_slot = im->slot.data();
+  ksolve_claims& cl = out->claims;
+  cl.n_claims = C; cl.it_words = h->it_words; cl.req_words = h->req_words; cl.n_keys = h->n_keys; cl.n_res = n_res;
+  cl.template_idx = im->tmpl.data(); cl.pod_count = im->npods.data(); cl.it_mask = im->its.data(); cl.requests = im->requests.data();
+  cl.req_mask = im->mask.data(); cl.req_defined = im->defined.data(); cl.req_complement = im->complement.data();
+  cl.req_has_gte = im->has_gte.data(); cl.req_has_lte = im->has_lte.data(); cl.req_gte = im->gte.data(); cl.req_lte = im->lte.data();
+  cl.req_min_values = im->minv.data(); cl.min_values_relaxed = im->relaxed.data(); cl.cheapest_price = im->cheapest.data();
+  cl.hostname_seq = im->host_seq.data();
+  out->bin_evaluations = ctr.bin_evaluations; out->it_evaluations = ctr.it_evaluations; out->queue_pops = ctr.queue_pops;
+  out->sorts = ctr.sorts; out->slow_sorts = ctr.slow_sorts; out->relaxations = ctr.relaxations;
+  out->us_upload = h->timers.ms[T_UPLOAD] * 1e3;
+  out->us_prepass = (h->timers.ms[T_INDEX] + h->timers.ms[T_CLASSIFY] + h->timers.ms[T_SORT]) * 1e3;
+  out->us_pack = h->timers.ms[T_PACK] * 1e3; out->us_finalize = h->timers.ms[T_FINALIZE] * 1e3; out->us_download = h->timers.ms[T_DOWNLOAD] * 1e3;
+  out->packing_cost = cost;
+  out->impl = im;
+  return out->status;
+}
+
+}  // namespace ksi

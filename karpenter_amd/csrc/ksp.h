@@ -1,0 +1,115 @@
+// ksp.h — device-side view of a flattened scheduling problem and of the solver workspace.
+// Plain pointers into device memory (or host memory in the test-only emulation build). Layouts are SoA where a
+// kernel streams over many entities (pods) and AoS-by-entity where one wave touches one entity at a time (claims).
+#pragma once
+#include "reqalg.h"
+
+namespace ks {
+
+struct ReqTable {  // n requirement sets, SoA (ksolve_reqsets)
+  const uint64_t* mask;
+  const uint32_t *defined, *complement, *has_gte, *has_lte;
+  const int64_t *gte, *lte;
+  const int32_t* minv;
+  KS_FN ReqRef at(const Dict& d, uint32_t e) const {
+    ReqRef r;
+    r.mask = mask + (size_t)e * d.req_words;
+    r.defined = defined[e]; r.complement = complement[e];
+    r.has_gte = has_gte ? has_gte[e] : 0; r.has_lte = has_lte ? has_lte[e] : 0;
+    r.gte = gte ? gte + (size_t)e * d.n_keys : nullptr;
+    r.lte = lte ? lte + (size_t)e * d.n_keys : nullptr;
+    r.minv = minv ? minv + (size_t)e * d.n_keys : nullptr;
+    return r;
+  }
+};
+
+struct MutReqTable {  // claims: same layout, writable
+  uint64_t* mask;
+  uint32_t *defined, *complement, *has_gte, *has_lte;
+  int64_t *gte, *lte;
+  int32_t* minv;
+  KS_FN ReqRef at(const Dict& d, uint32_t e) const {
+    ReqRef r;
+    r.mask = mask + (size_t)e * d.req_words;
+    r.defined = defined[e]; r.complement = complement[e]; r.has_gte = has_gte[e]; r.has_lte = has_lte[e];
+    r.gte = gte + (size_t)e * d.n_keys; r.lte = lte + (size_t)e * d.n_keys; r.minv = minv + (size_t)e * d.n_keys;
+    return r;
+  }
+};
+
+struct ProblemView {
+  Dict dict;
+  int n_res, n_its, it_words;
+  const int64_t* it_alloc;       // [n_res][n_its]
+  const int64_t* it_cap;         // [n_res][n_its]
+  const uint64_t* it_alloc_ok;   // [it_words] instance types whose allocatable has no negative dimension (resources.go:190)
+  const uint64_t* it_off_avail;  // [n_its] bit zone*4+ct
+  const double* it_off_price;    // [n_its][64]
+  int n_zones, n_cts;
+  // instance-type requirement index, built by the prepass kernel (k_build_it_index):
+  const uint64_t* kv_has;        // [req_words*64][it_words] ITs whose requirement on the value's key Has(value) (incl. complements)
+  const uint64_t* key_undef;     // [n_keys][it_words] ITs that do not define the key
+  const uint64_t* key_compl;     // [n_keys][it_words] ITs whose requirement on the key is a complement (NotIn/Exists)
+  const uint64_t* key_neg;       // [n_keys][it_words] ITs whose operator on the key is NotIn or DoesNotExist
+  ReqTable it_reqs;
+
+  int n_templates;
+  ReqTable tmpl_reqs;
+  const uint64_t* tmpl_taints;
+  const uint64_t* tmpl_its;      // [n_templates][it_words]
+  const uint32_t* tmpl_limit_mask;
+  const int64_t* tmpl_limits;    // [n_templates][n_res+1]
+
+  int n_pods, n_rows;
+  const int32_t* row_next;       // [n_rows] relaxation chain
+  const uint32_t* row_class;     // [n_rows] class id (k_classify)
+  const uint8_t* pod_is_pending;
+
+  int n_classes;
+  const int64_t* cls_requests;   // [n_classes][n_res]
+  ReqTable cls_reqs, cls_strict;
+  const uint64_t* cls_tolerates; // [n_classes]
+  const int64_t* min_request;    // [n_res] min over classes (for the closed-claim test)
+
+  const uint32_t* sorted_pods;   // [n_pods] queue order (k_sort)
+};
+
+struct Counters {
+  unsigned long long bin_evaluations, full_evaluations, it_evaluations, queue_pops, sorts, slow_sorts, relaxations, column_resets, walk_scans;
+};
+
+struct Workspace {
+  int max_claims, claim_words;   // claim_words = ceil(max_claims/64)
+  // claims (AoS by claim)
+  int32_t* c_tmpl;               // [max_claims]
+  int64_t* c_total;              // [max_claims][n_res]   Spec.Resources.Requests
+  int64_t* c_head;               // [max_claims][n_res]   max allocatable over remaining instance types - total
+  uint64_t* c_its;               // [max_claims][it_words] InstanceTypeOptions
+  MutReqTable c_reqs;            // Requirements
+  uint32_t* c_host_seq;          // hostname-placeholder sequence number
+  uint8_t* c_relaxed;
+  uint32_t* c_npods;             // pod count by claim id
+  // order (pdq_emul.h)
+  uint32_t *o_key, *o_ord, *o_pos;
+  // first-fit pruning
+  uint64_t* dead;                // [n_classes][claim_words] bit set = claim known infeasible for the class
+  uint64_t* closed;              // [claim_words] claim cannot take any pod any more
+  // queue (queue.go): circular buffer of pod ids + lastLen
+  uint32_t* queue;               // [n_pods+1]
+  uint32_t* last_len;            // [n_pods] 0 = never pushed
+  // template state
+  uint64_t* t_its;               // [n_templates][it_words] prefiltered instance types (scheduler.go:159)
+  int64_t* t_remaining;          // [n_templates][n_res+1]
+  // results
+  int32_t* assign;               // [n_pods]
+  uint8_t *err, *diag;           // [n_pods]
+  uint32_t* slot;                // [n_pods]
+  // scalars
+  int* n_claims_out;
+  int* status_out;               // 0 ok, 1 capacity exceeded, 2 cancelled/timed out
+  volatile int* cancel_flag;
+  long long max_steps;
+  Counters* counters;
+};
+
+}  // namespace ks

@@ -1,0 +1,301 @@
+// pdq_emul.h — bit-exact emulation of the claim ordering the reference maintains with
+//     sort.Slice(s.newNodeClaims, func(a, b int) bool { return len(a.Pods) < len(b.Pods) })     scheduler.go:598
+// which runs before every in-flight scan and is Go's UNSTABLE pattern-defeating quicksort (go1.26 sort/zsortfunc.go:
+// insertion sort <= 12, ninther pivot, partialInsertionSort, partitionEqual, breakPatterns xorshift, heapsort
+// fallback). Which of two equally-full claims a pod lands in depends on the permutation that algorithm leaves, so
+// the device keeps the claims in exactly that permutation.
+//
+// The array is always "sorted except for the one claim the previous step touched" (its count went up by one, or it
+// was appended with count 1). For that input pdqsort almost always takes the partialInsertionSort path, whose effect
+// is a stable move of one element; that case is handled with a vector search + rotate (O(distance/64) wave steps).
+// Every other path (pivot samples that see the defect, 12 < n < 50, ...) runs the full algorithm below with its
+// sequential scans replaced by ballot searches. Keys are the per-position pod counts; `ord` holds the claim id at
+// each position and `pos` its inverse.
+#pragma once
+#include "wave.h"
+
+namespace ks {
+
+template <class W>
+struct ClaimOrder {
+  uint32_t* key;   // [cap] pod count of the claim at position i
+  uint32_t* ord;   // [cap] claim id at position i
+  uint32_t* pos;   // [cap] position of claim id
+  int n = 0;
+  int defect = -1;        // position whose key changed since the array was last sorted, -1 = sorted
+  bool defect_append = false;
+  uint64_t slow_sorts = 0;
+
+  // ---- element access (uniform) ----
+  KS_FN bool less(int i, int j) const { return key[i] < key[j]; }
+  KS_FN void swap(int i, int j) {
+    if (i == j) return;
+    uint32_t ki = key[i], kj = key[j], oi = ord[i], oj = ord[j];
+    W::store(&key[i], kj); W::store(&key[j], ki);
+    W::store(&ord[i], oj); W::store(&ord[j], oi);
+    W::store(&pos[oj], (uint32_t)i); W::store(&pos[oi], (uint32_t)j);
+    W::sync();
+  }
+  // move element at `from` to `to` (to < from), shifting [to, from) right by one
+  KS_FN void rotate_right(int to, int from) {
+    if (to >= from) return;
+    uint32_t mk = key[from], mo = ord[from];
+    for (int top = from; top > to; top -= 64) {  // high to low so a round never reads what an earlier round wrote
+      int lo = top - 64 > to ? top - 64 : to;
+      shift_round(lo, top, +1);
+    }
+    W::store(&key[to], mk); W::store(&ord[to], mo); W::store(&pos[mo], (uint32_t)to);
+    W::sync();
+  }
+  // move element at `from` to `to` (to > from), shifting (from, to] left by one
+  KS_FN void rotate_left(int from, int to) {
+    if (to <= from) return;
+    uint32_t mk = key[from], mo = ord[from];
+    for (int lo = from + 1; lo <= to; lo += 64) {
+      int hi = lo + 64 <= to + 1 ? lo + 64 : to + 1;
+      shift_round(lo, hi, -1);
+    }
+    W::store(&key[to], mk); W::store(&ord[to], mo); W::store(&pos[mo], (uint32_t)to);
+    W::sync();
+  }
+  // elements [lo,hi) (at most 64) move by delta (+1 / -1): all reads of the round precede its writes
+  KS_FN void shift_round(int lo, int hi, int delta) {
+#if KS_DEVICE
+    int i = lo + W::lane();
+    uint32_t k = 0, o = 0;
+    bool act = i < hi;
+    if (act) { k = key[i]; o = ord[i]; }
+    W::sync();
+    if (act) { key[i + delta] = k; ord[i + delta] = o; pos[o] = (uint32_t)(i + delta); }
+    W::sync();
+#else
+    if (delta > 0) for (int i = hi - 1; i >= lo; --i) { key[i + 1] = key[i]; ord[i + 1] = ord[i]; pos[ord[i + 1]] = i + 1; }
+    else for (int i = lo; i < hi; ++i) { key[i - 1] = key[i]; ord[i - 1] = ord[i]; pos[ord[i - 1]] = i - 1; }
+#endif
+  }
+
+  // ---- mutation by the scheduler ----
+  KS_FN void increment(int claim) {  // a pod was added to an in-flight claim (nodeclaim.go:249)
+    int p = (int)pos[claim];
+    W::store(&key[p], key[p] + 1);
+    W::sync();
+    defect = p; defect_append = false;
+  }
+  KS_FN void append(int claim) {     // a new claim with its first pod (scheduler.go:785)
+    W::store(&key[n], 1u); W::store(&ord[n], (uint32_t)claim); W::store(&pos[claim], (uint32_t)n);
+    W::sync();
+    defect = n; defect_append = true;
+    n++;
+  }
+
+  // ---- Go pdqsort pieces ----
+  static KS_FN int bits_len(unsigned x) { return x ? 32 - __builtin_clz(x) : 0; }
+
+  KS_FN void insertion_sort(int a, int b) {
+    for (int i = a + 1; i < b; i++)
+      for (int j = i; j > a && less(j, j - 1); j--) swap(j, j - 1);
+  }
+  KS_FN void sift_down(int lo, int hi, int first) {
+    int root = lo;
+    for (;;) {
+      int child = 2 * root + 1;
+      if (child >= hi) return;
+      if (child + 1 < hi && less(first + child, first + child + 1)) child++;
+      if (!less(first + root, first + child)) return;
+      swap(first + root, first + child);
+      root = child;
+    }
+  }
+  KS_FN void heap_sort(int a, int b) {
+    int first = a, lo = 0, hi = b - a;
+    for (int i = (hi - 1) / 2; i >= 0; i--) sift_down(i, hi, first);
+    for (int i = hi - 1; i >= 0; i--) { swap(first, first + i); sift_down(lo, i, first); }
+  }
+  // order2/median on preloaded keys: indices are permuted, data is not touched
+  static KS_FN void order2(int& a, int& b, uint32_t& ka, uint32_t& kb, int& swaps) {
+    if (kb < ka) { swaps++; int t = a; a = b; b = t; uint32_t tk = ka; ka = kb; kb = tk; }
+  }
+  static KS_FN void median3(int a, int b, int c, uint32_t ka, uint32_t kb, uint32_t kc, int& swaps, int& out, uint32_t& kout) {
+    order2(a, b, ka, kb, swaps); order2(b, c, kb, kc, swaps); order2(a, b, ka, kb, swaps);
+    out = b; kout = kb;
+  }
+  KS_FN int choose_pivot(int a, int b, int& hint) {  // hint: 0 unknown, 1 increasing, 2 decreasing
+    int l = b - a, swaps = 0;
+    int i = a + l / 4 * 1, j = a + l / 4 * 2, k = a + l / 4 * 3;
+    if (l >= 8) {
+      uint32_t ki, kj, kk;
+      if (l >= 50) {
+        uint32_t s0 = key[i - 1], s1 = key[i], s2 = key[i + 1], s3 = key[j - 1], s4 = key[j], s5 = key[j + 1], s6 = key[k - 1], s7 = key[k], s8 = key[k + 1];
+        int oi, oj, ok;
+        median3(i - 1, i, i + 1, s0, s1, s2, swaps, oi, ki);
+        median3(j - 1, j, j + 1, s3, s4, s5, swaps, oj, kj);
+        median3(k - 1, k, k + 1, s6, s7, s8, swaps, ok, kk);
+        i = oi; j = oj; k = ok;
+      } else { ki = key[i]; kj = key[j]; kk = key[k]; }
+      int oj2; uint32_t dummy;
+      median3(i, j, k, ki, kj, kk, swaps, oj2, dummy);
+      j = oj2;
+    }
+    hint = swaps == 0 ? 1 : (swaps == 12 ? 2 : 0);
+    return j;
+  }
+  KS_FN void reverse_range(int a, int b) { int i = a, j = b - 1; while (i < j) { swap(i, j); i++; j--; } }
+
+  // first x in [i,b) with key[x] < key[x-1]; at the top level the only possible descents are at the defect
+  KS_FN int next_descent(int i, int b, bool top) {
+    if (top) {
+      if (defect < 0) return b;
+      for (int x = defect; x <= defect + 1; ++x) if (x >= i && x >= 1 && x < b && key[x] < key[x - 1]) return x;
+      return b;
+    }
+    const uint32_t* kp = key;
+    return W::find_first(i, b, [kp](int x) { return kp[x] < kp[x - 1]; });
+  }
+  KS_FN bool partial_insertion_sort(int a, int b, bool top) {
+    int i = a + 1;
+    for (int step = 0; step < 5; step++) {
+      i = next_descent(i, b, top);
+      if (i == b) return true;
+      if (b - a < 50) return false;
+      swap(i, i - 1);
+      if (i - a >= 2) {  // shift the smaller one to the left (Go uses the absolute bound j >= 1)
+        uint32_t mv = key[i - 1];
+        const uint32_t* kp = key;
+        int t = W::find_last(0, i - 1, [kp, mv](int x) { return !(mv < kp[x]); });
+        rotate_right(t + 1, i - 1);
+      }
+      if (b - i >= 2) {  // shift the greater one to the right
+        uint32_t mv = key[i];
+        const uint32_t* kp = key;
+        int e = W::find_first(i + 1, b, [kp, mv](int x) { return !(kp[x] < mv); });
+        rotate_left(i, e - 1);
+      }
+      if (top) defect = -1;  // the single defect is repaired: the rest of the array is known sorted
+    }
+    return false;
+  }
+  KS_FN void break_patterns(int a, int b) {
+    int length = b - a;
+    if (length >= 8) {
+      uint64_t r = (uint64_t)length;
+      unsigned modulus = 1u << bits_len((unsigned)length);
+      int idx = a + (length / 4) * 2 - 1;
+      for (int t = 0; t < 3; t++) {
+        r ^= r << 13; r ^= r >> 7; r ^= r << 17;
+        int other = (int)((unsigned)r & (modulus - 1));
+        if (other >= length) other -= length;
+        swap(idx - 1 + t, a + other);
+      }
+    }
+  }
+  KS_FN int partition_equal(int a, int b, int pivot) {
+    swap(a, pivot);
+    uint32_t pv = key[a];
+    const uint32_t* kp = key;
+    int i = a + 1, j = b - 1;
+    for (;;) {
+      i = W::find_first(i, j + 1, [kp, pv](int x) { return pv < kp[x]; });
+      j = W::find_last(i, j + 1, [kp, pv](int x) { return !(pv < kp[x]); });
+      if (i > j) break;
+      swap(i, j); i++; j--;
+    }
+    return i;
+  }
+  KS_FN int partition(int a, int b, int pivot, bool& already) {
+    swap(a, pivot);
+    uint32_t pv = key[a];
+    const uint32_t* kp = key;
+    int i = a + 1, j = b - 1;
+    i = W::find_first(i, j + 1, [kp, pv](int x) { return !(kp[x] < pv); });
+    j = W::find_last(i, j + 1, [kp, pv](int x) { return kp[x] < pv; });
+    if (i > j) { swap(j, a); already = true; return j; }
+    swap(i, j); i++; j--;
+    for (;;) {
+      i = W::find_first(i, j + 1, [kp, pv](int x) { return !(kp[x] < pv); });
+      j = W::find_last(i, j + 1, [kp, pv](int x) { return kp[x] < pv; });
+      if (i > j) break;
+      swap(i, j); i++; j--;
+    }
+    swap(j, a);
+    already = false;
+    return j;
+  }
+
+  struct Frame { int a, b, limit; bool was_balanced, was_partitioned; };
+
+  // pdqsort_func with the recursion turned into an explicit stack (the recursive call always takes the smaller
+  // side, so the depth is bounded by log2 n).
+  KS_FN void pdqsort(int a0, int b0, int limit0) {
+    Frame stack[40];
+    int sp = 0;
+    Frame cur{a0, b0, limit0, true, true};
+    bool top = true;  // still the outermost call, nothing swapped yet
+    for (;;) {
+      bool done = false;
+      for (;;) {
+        int a = cur.a, b = cur.b;
+        int length = b - a;
+        if (length <= 12) { insertion_sort(a, b); done = true; break; }
+        if (cur.limit == 0) { heap_sort(a, b); done = true; break; }
+        if (!cur.was_balanced) { break_patterns(a, b); cur.limit--; }
+        int hint;
+        int pivot = choose_pivot(a, b, hint);
+        if (hint == 2) { reverse_range(a, b); pivot = (b - 1) - (pivot - a); hint = 1; top = false; }
+        if (cur.was_balanced && cur.was_partitioned && hint == 1) {
+          if (partial_insertion_sort(a, b, top)) { done = true; break; }
+        }
+        top = false;
+        if (a > 0 && !less(a - 1, pivot)) { cur.a = partition_equal(a, b, pivot); continue; }
+        bool already;
+        int mid = partition(a, b, pivot, already);
+        cur.was_partitioned = already;
+        int left_len = mid - a, right_len = b - mid;
+        int balance_threshold = length / 8;
+        Frame child;
+        if (left_len < right_len) {
+          cur.was_balanced = left_len >= balance_threshold;
+          child = Frame{a, mid, cur.limit, true, true};
+          cur.a = mid + 1;
+        } else {
+          cur.was_balanced = right_len >= balance_threshold;
+          child = Frame{mid + 1, b, cur.limit, true, true};
+          cur.b = mid;
+        }
+        stack[sp++] = cur;  // the parent continues after the child has run to completion
+        cur = child;
+      }
+      (void)done;
+      if (sp == 0) break;
+      cur = stack[--sp];
+    }
+  }
+
+  // sort.Slice on the current array
+  KS_FN void sort() {
+    if (defect < 0 || n <= 1) { defect = -1; return; }  // sorted input: pdqsort performs no swap
+    if (n <= 12) {
+      // insertionSort_func is a stable sort; with a single defect that is one stable move
+      if (defect_append) {
+        uint32_t mv = key[n - 1];
+        const uint32_t* kp = key;
+        int t = W::find_last(0, n - 1, [kp, mv](int x) { return !(mv < kp[x]); });
+        rotate_right(t + 1, n - 1);
+      } else {
+        int p = defect;
+        uint32_t mv = key[p];
+        const uint32_t* kp = key;
+        int e = W::find_first(p + 1, n, [kp, mv](int x) { return !(kp[x] < mv); });
+        rotate_left(p, e - 1);
+      }
+      defect = -1;
+      return;
+    }
+    int saved = defect;
+    pdqsort(0, n, bits_len((unsigned)n));
+    if (defect >= 0 || saved < 0) {}  // (defect is cleared by the fast path; any other path leaves the array sorted too)
+    if (defect >= 0) slow_sorts++;
+    defect = -1;
+  }
+};
+
+}  // namespace ks

@@ -1,0 +1,845 @@
+// ksched.cpp — host side of the solver above the C ABI: the part of NewScheduler/Solve that is object wrangling rather
+// than compute. It mirrors what the Go shim (go/ksolve_shim.go) does inside Karpenter:
+//   1. NewScheduler inputs (provisioner.go:265-360): NodePools ordered by weight (nodepool.go:161-171), one
+//      NodeClaimTemplate per pool (nodeclaimtemplate.go:66-94), instance types, pods;
+//   2. flatten them into the KSP arrays of include/ksolve.h (dictionary-encode labels, exact integer resources,
+//      PodData requirement sets — requirements.go:74-118, scheduler.go:554-580 —, toleration masks, the
+//      Preferences.Relax ladder — preferences.go:38-57);
+//   3. ksolve_create / ksolve_solve on the device library;
+//   4. rehydrate Results (scheduler.go:281-286) from the flat results.
+// Input and output are JSON documents (schema: karpenter_amd/fixtures.py) so that Python tests can read like the
+// reference's Go tests. There is NO scheduling logic here: requirement intersection reuses the same flat algebra the
+// kernels use (csrc/reqalg.h), and anything the device build cannot solve is reported as "unsupported", never solved
+// on the CPU.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstring>
+#include <map>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ksolve.h"
+#include "../csrc/reqalg.h"
+#include "json_mini.hpp"
+
+namespace ks {
+// ReqBuf::ref() hides minv when no key has minValues; the flattener always wants it.
+inline ReqRef reqbuf_ref_with_minv(const ReqBuf& b) { ReqRef r = b.ref(); r.minv = b.minv; return r; }
+}  // namespace ks
+
+namespace {
+
+typedef __int128 i128;
+using kj::Value;
+
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// ---- resource.Quantity -> exact int128 nano-units ----
+i128 parse_quantity(const std::string& s) {
+  if (s.empty()) throw std::runtime_error("quantity: empty");
+  size_t i = 0;
+  bool neg = false;
+  if (s[i] == '+' || s[i] == '-') { neg = s[i] == '-'; ++i; }
+  i128 mant = 0;
+  int frac = 0;
+  bool dot = false, any = false;
+  for (; i < s.size(); ++i) {
+    char c = s[i];
+    if (c >= '0' && c <= '9') { mant = mant * 10 + (c - '0'); if (dot) ++frac; any = true; }
+    else if (c == '.' && !dot) dot = true;
+    else break;
+  }
+  if (!any) throw std::runtime_error("quantity: '" + s + "'");
+  std::string suf = s.substr(i);
+  static const std::map<std::string, int> dec = {{"", 0}, {"n", -9}, {"u", -6}, {"m", -3}, {"k", 3}, {"M", 6}, {"G", 9}, {"T", 12}, {"P", 15}, {"E", 18}};
+  static const std::map<std::string, int> bin = {{"Ki", 10}, {"Mi", 20}, {"Gi", 30}, {"Ti", 40}, {"Pi", 50}, {"Ei", 60}};
+  int e = 0;
+  i128 v = mant;
+  auto d = dec.find(suf);
+  if (d != dec.end()) e = d->second;
+  else if (bin.count(suf)) v *= (i128)1 << bin.at(suf);
+  else if (!suf.empty() && (suf[0] == 'e' || suf[0] == 'E')) e = atoi(suf.c_str() + 1);
+  else throw std::runtime_error("quantity suffix: '" + s + "'");
+  e += 9 - frac;
+  for (; e > 0; --e) v *= 10;
+  for (; e < 0; ++e) { if (v % 10) throw Unsupported("quantity finer than nano: " + s); v /= 10; }
+  return neg ? -v : v;
+}
+std::string i128_str(i128 v) {
+  if (v == 0) return "0";
+  bool neg = v < 0;
+  unsigned __int128 u = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
+  std::string s;
+  while (u) { s += (char)('0' + (int)(u % 10)); u /= 10; }
+  if (neg) s += '-';
+  std::reverse(s.begin(), s.end());
+  return s;
+}
+bool go_atoi(const std::string& s, long long& out) {  // strconv.Atoi
+  if (s.empty()) return false;
+  size_t i = 0;
+  bool neg = false;
+  if (s[0] == '+' || s[0] == '-') { neg = s[0] == '-'; i = 1; }
+  if (i == s.size()) return false;
+  unsigned long long v = 0;
+  for (; i < s.size(); ++i) {
+    if (s[i] < '0' || s[i] > '9') return false;
+    unsigned d = s[i] - '0';
+    if (v > (ULLONG_MAX - d) / 10) return false;
+    v = v * 10 + d;
+  }
+  if (!neg && v > (unsigned long long)LLONG_MAX) return false;
+  if (neg && v > (unsigned long long)LLONG_MAX + 1ULL) return false;
+  out = neg ? (long long)(0 - v) : (long long)v;
+  return true;
+}
+
+const char* kHostname = "kubernetes.io/hostname";
+const char* kZone = "topology.kubernetes.io/zone";
+const char* kInstanceType = "node.kubernetes.io/instance-type";
+const char* kCapacityType = "karpenter.sh/capacity-type";
+const char* kNodePool = "karpenter.sh/nodepool";
+
+std::string normalize_key(const std::string& k) {  // v1.NormalizedLabels — labels.go:121-127
+  static const std::map<std::string, std::string> n = {{"failure-domain.beta.kubernetes.io/zone", kZone},
+                                                       {"beta.kubernetes.io/arch", "kubernetes.io/arch"},
+                                                       {"beta.kubernetes.io/os", "kubernetes.io/os"},
+                                                       {"beta.kubernetes.io/instance-type", kInstanceType},
+                                                       {"failure-domain.beta.kubernetes.io/region", "topology.kubernetes.io/region"}};
+  auto it = n.find(k);
+  return it == n.end() ? k : it->second;
+}
+
+struct Expr { std::string key, op; std::vector<std::string> values; int min_values = -1; };
+Expr parse_expr(const Value& v) {
+  Expr e;
+  e.key = normalize_key(v.at("key").s());
+  e.op = v.at("operator").s();
+  for (auto& x : v.at("values").items()) e.values.push_back(x.s());
+  if (v.has("minValues") && !v.at("minValues").is_null()) e.min_values = (int)v.at("minValues").i();
+  return e;
+}
+std::vector<Expr> parse_exprs(const Value& v) { std::vector<Expr> out; for (auto& e : v.items()) out.push_back(parse_expr(e)); return out; }
+std::vector<Expr> label_exprs(const Value& labels) {
+  std::vector<Expr> out;
+  for (auto& kv : labels.members()) out.push_back(Expr{normalize_key(kv.first), "In", {kv.second.s()}, -1});
+  return out;
+}
+
+struct Taint { std::string key, value, effect; bool operator<(const Taint& o) const { return std::tie(key, value, effect) < std::tie(o.key, o.value, o.effect); } };
+struct Toleration { std::string key, op, value, effect; };
+// corev1.Toleration.ToleratesTaint(logger, taint, enableComparisonOperators=true) — called at taints.go:89
+bool tolerates(const Toleration& t, const Taint& x) {
+  if (!t.effect.empty() && t.effect != x.effect) return false;
+  if (!t.key.empty() && t.key != x.key) return false;
+  if (t.op.empty() || t.op == "Equal") return t.value == x.value;
+  if (t.op == "Exists") return true;
+  if (t.op == "Lt" || t.op == "Gt") {
+    long long tv, xv;
+    if (!go_atoi(t.value, tv) || !go_atoi(x.value, xv)) return false;
+    return t.op == "Lt" ? xv < tv : xv > tv;
+  }
+  return false;
+}
+
+// ---- dictionaries ----
+struct Dictionary {
+  std::vector<std::string> keys;
+  std::map<std::string, int> key_index;
+  std::vector<std::vector<std::string>> values;             // per key
+  std::vector<std::map<std::string, int>> value_index;
+  int key(const std::string& k) {
+    auto it = key_index.find(k);
+    if (it != key_index.end()) return it->second;
+    int i = (int)keys.size();
+    keys.push_back(k); key_index[k] = i; values.emplace_back(); value_index.emplace_back();
+    return i;
+  }
+  int value(int k, const std::string& v) {
+    auto it = value_index[k].find(v);
+    if (it != value_index[k].end()) return it->second;
+    int i = (int)values[k].size();
+    values[k].push_back(v); value_index[k][v] = i;
+    return i;
+  }
+  void note(const Expr& e) { int k = key(e.key); if (e.op == "In" || e.op == "NotIn") for (auto& v : e.values) value(k, v); }
+};
+
+// A table of requirement sets under construction (host memory, ABI layout).
+struct ReqTableBuilder {
+  int n = 0, req_words = 0, n_keys = 0;
+  std::vector<uint64_t> mask;
+  std::vector<uint32_t> defined, complement, has_gte, has_lte;
+  std::vector<int64_t> gte, lte;
+  std::vector<int32_t> minv;
+  void init(int n_, int rw, int nk) {
+    n = n_; req_words = rw; n_keys = nk;
+    mask.assign((size_t)n * rw, 0); defined.assign(n, 0); complement.assign(n, 0); has_gte.assign(n, 0); has_lte.assign(n, 0);
+    gte.assign((size_t)n * nk, 0); lte.assign((size_t)n * nk, 0); minv.assign((size_t)n * nk, -1);
+  }
+  void put(int e, const ks::ReqBuf& b) {
+    for (int w = 0; w < req_words; ++w) mask[(size_t)e * req_words + w] = b.mask[w];
+    defined[e] = b.defined; complement[e] = b.complement; has_gte[e] = b.has_gte; has_lte[e] = b.has_lte;
+    for (int k = 0; k < n_keys; ++k) { gte[(size_t)e * n_keys + k] = b.gte[k]; lte[(size_t)e * n_keys + k] = b.lte[k]; minv[(size_t)e * n_keys + k] = b.minv[k]; }
+  }
+  ksolve_reqsets view() const {
+    ksolve_reqsets r{};
+    r.n = (uint32_t)n; r.mask = mask.data(); r.defined = defined.data(); r.complement = complement.data();
+    r.has_gte = has_gte.data(); r.has_lte = has_lte.data(); r.gte = gte.data(); r.lte = lte.data(); r.min_values = minv.data();
+    return r;
+  }
+};
+
+struct Flattener {
+  Dictionary dict;
+  ks::Dict kd{};
+  std::vector<uint32_t> key_word_off;
+  std::vector<int64_t> value_int;
+  std::vector<uint64_t> value_is_int, value_valid;
+  std::set<std::string> well_known;
+
+  void finalize_dictionary(int n_its_words_min) {
+    int nk = (int)dict.keys.size();
+    if (nk > KSOLVE_MAX_KEYS) throw Unsupported("more than 32 distinct requirement keys");
+    key_word_off.assign(nk + 1, 0);
+    for (int k = 0; k < nk; ++k) {
+      int words = std::max(1, ((int)dict.values[k].size() + 63) / 64);
+      if (dict.keys[k] == kInstanceType) words = std::max(words, n_its_words_min);
+      key_word_off[k + 1] = key_word_off[k] + words;
+    }
+    int rw = key_word_off[nk];
+    if (rw > ks::kMaxReqWords) throw Unsupported("requirement dictionaries need more than 96 mask words");
+    value_int.assign((size_t)rw * 64, 0); value_is_int.assign(rw, 0); value_valid.assign(rw, 0);
+    for (int k = 0; k < nk; ++k)
+      for (size_t v = 0; v < dict.values[k].size(); ++v) {
+        size_t bitpos = (size_t)key_word_off[k] * 64 + v;
+        value_valid[bitpos / 64] |= 1ull << (bitpos % 64);
+        long long iv;
+        if (go_atoi(dict.values[k][v], iv)) { value_int[bitpos] = iv; value_is_int[bitpos / 64] |= 1ull << (bitpos % 64); }
+      }
+    kd.n_keys = nk; kd.req_words = rw;
+    for (int k = 0; k <= nk; ++k) kd.key_word_off[k] = key_word_off[k];
+    kd.well_known_mask = 0;
+    for (int k = 0; k < nk; ++k) if (well_known.count(dict.keys[k])) kd.well_known_mask |= 1u << k;
+    auto find = [&](const char* name) { auto it = dict.key_index.find(name); return it == dict.key_index.end() ? -1 : it->second; };
+    kd.key_it = find(kInstanceType); kd.key_zone = find(kZone); kd.key_ct = find(kCapacityType); kd.key_hostname = find(kHostname);
+    kd.value_int = value_int.data(); kd.value_is_int = value_is_int.data(); kd.value_valid = value_valid.data();
+  }
+  // NewRequirementWithFlexibility (requirement.go:48-110) in flat form
+  void encode(const Expr& e, ks::ReqBuf& b) {
+    memset(&b, 0, sizeof(b));
+    for (int k = 0; k < ks::kMaxKeys; ++k) b.minv[k] = -1;
+    int k = dict.key_index.at(e.key);
+    uint32_t kb = 1u << k;
+    b.defined = kb;
+    auto set_vals = [&]() { for (auto& v : e.values) { size_t pos = (size_t)key_word_off[k] * 64 + dict.value_index[k].at(v); b.mask[pos / 64] |= 1ull << (pos % 64); } };
+    auto atoi0 = [&](const std::string& s) { long long v = 0; go_atoi(s, v); return v; };
+    if (e.min_values >= 0) { b.minv[k] = e.min_values; b.has_minv = kb; }
+    if (e.op == "In") { set_vals(); return; }
+    if (e.op == "DoesNotExist") return;
+    b.complement = kb;
+    if (e.op == "NotIn") { set_vals(); return; }
+    if (e.op == "Exists") return;
+    long long v = e.values.empty() ? 0 : atoi0(e.values[0]);
+    if (e.op == "Gt") {
+      if (v == LLONG_MAX) { b.complement = 0; b.minv[k] = -1; b.has_minv = 0; return; }  // Gt MaxInt matches nothing (requirement.go:85-88)
+      b.has_gte = kb; b.gte[k] = v + 1;
+    } else if (e.op == "Lt") { b.has_lte = kb; b.lte[k] = v - 1; }
+    else if (e.op == "Gte") { b.has_gte = kb; b.gte[k] = v; }
+    else if (e.op == "Lte") { b.has_lte = kb; b.lte[k] = v; }
+    else throw std::runtime_error("bad operator " + e.op);
+  }
+  static void clear(ks::ReqBuf& b) { memset(&b, 0, sizeof(b)); for (int k = 0; k < ks::kMaxKeys; ++k) b.minv[k] = -1; }
+};
+
+// ---- pod model (only what the flattener needs) ----
+struct PodSpec {
+  std::string uid;
+  long long creation = 0;
+  bool pending = true;
+  std::map<std::string, i128> requests;
+  Value node_selector;
+  bool has_node_affinity = false, has_required = false;
+  std::vector<std::vector<Expr>> required_terms;
+  std::vector<std::pair<int, std::vector<Expr>>> preferred;  // (weight, exprs)
+  std::vector<Toleration> tolerations;
+};
+
+// Go's insertion sort (sort.Slice on <= 12 elements is a stable insertion sort; pods with more than 12 preferred
+// node-affinity terms are rejected so the unstable pdqsort path is never needed here) — requirements.go:102
+template <class T, class L>
+void small_stable_sort(std::vector<T>& v, L less) {
+  if (v.size() > 12) throw Unsupported("more than 12 preferred node affinity terms");
+  std::stable_sort(v.begin(), v.end(), less);
+}
+
+struct Api {
+  void* lib = nullptr;
+  decltype(&ksolve_create) create = nullptr;
+  decltype(&ksolve_solve) solve = nullptr;
+  decltype(&ksolve_results_free) results_free = nullptr;
+  decltype(&ksolve_destroy) destroy = nullptr;
+  decltype(&ksolve_last_error) last_error = nullptr;
+  decltype(&ksolve_last_kernel_ms) kernel_ms = nullptr;
+  bool load(const char* path, std::string& err) {
+    lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { err = std::string("cannot load solver library: ") + dlerror(); return false; }
+    create = (decltype(create))dlsym(lib, "ksolve_create");
+    solve = (decltype(solve))dlsym(lib, "ksolve_solve");
+    results_free = (decltype(results_free))dlsym(lib, "ksolve_results_free");
+    destroy = (decltype(destroy))dlsym(lib, "ksolve_destroy");
+    last_error = (decltype(last_error))dlsym(lib, "ksolve_last_error");
+    kernel_ms = (decltype(kernel_ms))dlsym(lib, "ksolve_last_kernel_ms");
+    if (!create || !solve || !results_free || !destroy || !last_error) { err = "solver library lacks ksolve_* symbols"; return false; }
+    return true;
+  }
+};
+
+std::map<std::string, i128> parse_resources(const Value& v) {
+  std::map<std::string, i128> r;
+  for (auto& kv : v.members()) {
+    if (kv.second.kind == Value::Str) r[kv.first] = parse_quantity(kv.second.str);
+    else if (kv.second.kind == Value::Num && kv.second.is_int) r[kv.first] = (i128)kv.second.inum * 1000000000;
+    else throw std::runtime_error("resource quantity must be a string or an integer");
+  }
+  return r;
+}
+
+uint64_t splitmix64(uint64_t& x) {
+  uint64_t z = (x += 0x9E3779B97F4A7C15ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+// uid of pod i of a podGroup (fixtures.py): 128 bits from splitmix64, printed as a UUID
+void group_uid(uint64_t seed, uint64_t i, uint64_t& hi, uint64_t& lo, std::string* text) {
+  uint64_t st = seed * 0x9E3779B97F4A7C15ULL + i * 0xD1B54A32D192ED03ULL + 0x2545F4914F6CDD1DULL;
+  uint64_t a = splitmix64(st), b = splitmix64(st);
+  hi = a; lo = b;
+  if (text) {
+    char buf[40];
+    snprintf(buf, sizeof buf, "%08x-%04x-%04x-%04x-%012llx", (unsigned)(a >> 32), (unsigned)((a >> 16) & 0xffff), (unsigned)(a & 0xffff),
+             (unsigned)(b >> 48), (unsigned long long)(b & 0xffffffffffffULL));
+    *text = buf;
+  }
+}
+bool parse_uuid(const std::string& s, uint64_t& hi, uint64_t& lo) {
+  if (s.size() != 36) return false;
+  uint64_t v[2] = {0, 0};
+  int nib = 0;
+  for (size_t i = 0; i < 36; ++i) {
+    char c = s[i];
+    if (i == 8 || i == 13 || i == 18 || i == 23) { if (c != '-') return false; continue; }
+    int d;
+    if (c >= '0' && c <= '9') d = c - '0';
+    else if (c >= 'a' && c <= 'f') d = c - 'a' + 10;
+    else return false;  // upper-case hex sorts differently as a string: use the rank fallback
+    v[nib / 16] = (v[nib / 16] << 4) | (unsigned)d;
+    nib++;
+  }
+  hi = v[0]; lo = v[1];
+  return true;
+}
+
+}  // namespace
+
+
+// ---------------------------------------------------------------------------------------------------------------
+static PodSpec parse_pod(const Value& v) {
+  PodSpec p;
+  p.uid = v.at("uid").s();
+  p.creation = v.at("creationTimestamp").i(0);
+  p.pending = v.at("phase").s("Pending") == "Pending";
+  p.requests = parse_resources(v.at("requests"));
+  p.node_selector = v.at("nodeSelector");
+  const Value& na = v.at("nodeAffinity");
+  if (!na.is_null()) {
+    p.has_node_affinity = true;
+    if (na.has("required") && !na.at("required").is_null()) {
+      p.has_required = true;
+      for (auto& t : na.at("required").items()) p.required_terms.push_back(parse_exprs(t));
+    }
+    for (auto& t : na.at("preferred").items()) p.preferred.push_back({(int)t.at("weight").i(), parse_exprs(t.at("matchExpressions"))});
+  }
+  for (auto& t : v.at("tolerations").items()) p.tolerations.push_back({t.at("key").s(), t.at("operator").s(), t.at("value").s(), t.at("effect").s()});
+  if (v.at("topologySpreadConstraints").items().size()) throw Unsupported("topologySpreadConstraints are not solved on the device in this build");
+  if (!v.at("podAffinity").is_null() || !v.at("podAntiAffinity").is_null()) throw Unsupported("pod (anti-)affinity is not solved on the device in this build");
+  return p;
+}
+
+static char* dup_json(const Value& v) {
+  std::string s;
+  kj::write(v, s);
+  char* out = (char*)malloc(s.size() + 1);
+  memcpy(out, s.c_str(), s.size() + 1);
+  return out;
+}
+static char* error_json(const char* kind, const std::string& msg) {
+  Value o = Value::object();
+  o.set("error", Value::string(msg));
+  o.set("kind", Value::string(kind));
+  return dup_json(o);
+}
+
+extern "C" void ksched_free(char* p) { free(p); }
+
+// Solve a problem document on the device library at `solver_lib`. `repeat` > 1 re-runs ksolve_solve on the same handle
+// (inputs stay resident in HBM) and reports every run's timings — used by bench.py.
+extern "C" char* ksched_solve_json(const char* problem_json, const char* solver_lib, int repeat, int want_results) {
+  Api api;
+  std::string err;
+  if (!api.load(solver_lib, err)) return error_json("load", err);
+  ksolve_handle* handle = nullptr;
+  try {
+    Value root = kj::Parser(problem_json).parse();
+    Flattener fl;
+    for (const char* k : {kNodePool, kZone, "topology.kubernetes.io/region", kInstanceType, "kubernetes.io/arch", "kubernetes.io/os", kCapacityType, "node.kubernetes.io/windows-build"}) fl.well_known.insert(k);
+    for (auto& k : root.at("wellKnownLabels").items()) fl.well_known.insert(k.s());
+    const Value& opts = root.at("options");
+    bool ignore_prefs = opts.at("preferencePolicy").s("Respect") == "Ignore";
+    if (opts.at("reservedCapacity").boolean_or(false)) throw Unsupported("reserved capacity is not solved on the device in this build");
+    if (root.at("stateNodes").items().size()) throw Unsupported("existing nodes are not solved on the device in this build");
+    if (root.at("daemonSetPods").items().size()) throw Unsupported("daemonset overhead is not solved on the device in this build");
+
+    // ---- instance types ----
+    const auto& its_json = root.at("instanceTypes").items();
+    const int n_its = (int)its_json.size();
+    std::map<std::string, int> it_index;
+    Dictionary& D = fl.dict;
+    int k_it = D.key(kInstanceType), k_zone = D.key(kZone), k_ct = D.key(kCapacityType);
+    for (int i = 0; i < n_its; ++i) {
+      const std::string name = its_json[i].at("name").s();
+      if (it_index.count(name)) throw std::runtime_error("duplicate instance type " + name);
+      it_index[name] = i;
+      D.value(k_it, name);
+    }
+    // offering zones / capacity types first so their value indices are the offering cell coordinates
+    std::vector<std::vector<Expr>> it_exprs(n_its);
+    struct Off { int zone, ct; double price; bool available; };
+    std::vector<std::vector<Off>> it_offs(n_its);
+    for (int i = 0; i < n_its; ++i)
+      for (auto& of : its_json[i].at("offerings").items()) {
+        std::string zone, ct;
+        for (auto& e : of.at("requirements").items()) {
+          Expr x = parse_expr(e);
+          if (x.op != "In" || x.values.size() != 1) throw Unsupported("offering requirements must be single-valued In");
+          if (x.key == kZone) zone = x.values[0];
+          else if (x.key == kCapacityType) ct = x.values[0];
+          else throw Unsupported("offering requirement on " + x.key + " (reserved offerings) is not solved on the device in this build");
+        }
+        if (zone.empty() || ct.empty()) throw std::runtime_error("offering without zone/capacity-type");
+        if (ct == "reserved") throw Unsupported("reserved offerings are not solved on the device in this build");
+        if (of.has("capacityOverride") || of.has("overheadOverride")) throw Unsupported("offering overrides");
+        it_offs[i].push_back({D.value(k_zone, zone), D.value(k_ct, ct), of.at("price").d(), of.at("available").boolean_or(true)});
+      }
+    const int n_zones = (int)D.values[k_zone].size(), n_cts = (int)D.values[k_ct].size();
+    if (n_zones > KSOLVE_MAX_ZONES || n_cts > KSOLVE_MAX_CAPTYPES) throw Unsupported("more than 16 offering zones or 4 capacity types");
+    for (int i = 0; i < n_its; ++i) { it_exprs[i] = parse_exprs(its_json[i].at("requirements")); for (auto& e : it_exprs[i]) D.note(e); }
+
+    // ---- node pools -> templates (OrderByWeight; static pools and pools without instance types are skipped) ----
+    struct Pool { const Value* v; std::string name; int weight; };
+    std::vector<Pool> pools;
+    for (auto& np : root.at("nodePools").items()) {
+      if (np.at("static").boolean_or(false)) continue;
+      if (np.has("instanceTypes") && !np.at("instanceTypes").is_null() && np.at("instanceTypes").items().empty()) continue;
+      pools.push_back({&np, np.at("name").s(), (int)np.at("weight").i(0)});
+    }
+    std::sort(pools.begin(), pools.end(), [](const Pool& a, const Pool& b) { return a.weight != b.weight ? a.weight > b.weight : a.name > b.name; });
+    const int n_templates = (int)pools.size();
+    if (n_templates > KSOLVE_MAX_TEMPLATES) throw Unsupported("more than 32 NodePools");
+    std::vector<std::vector<Expr>> tmpl_exprs(n_templates);
+    std::vector<Taint> distinct_taints;
+    auto taint_id = [&](const Taint& t) {
+      for (size_t i = 0; i < distinct_taints.size(); ++i) if (!(distinct_taints[i] < t) && !(t < distinct_taints[i])) return (int)i;
+      distinct_taints.push_back(t);
+      if (distinct_taints.size() > 64) throw Unsupported("more than 64 distinct taints");
+      return (int)distinct_taints.size() - 1;
+    };
+    std::vector<uint64_t> tmpl_taints(n_templates, 0);
+    bool tolerate_prefer_no_schedule = false;
+    for (int t = 0; t < n_templates; ++t) {
+      const Value& np = *pools[t].v;
+      tmpl_exprs[t] = parse_exprs(np.at("requirements"));
+      for (auto& e : label_exprs(np.at("labels"))) tmpl_exprs[t].push_back(e);
+      tmpl_exprs[t].push_back(Expr{kNodePool, "In", {pools[t].name}, -1});
+      tmpl_exprs[t].push_back(Expr{np.at("nodeClassLabelKey").s("karpenter.test.sh/testnodeclass"), "In", {np.at("nodeClassName").s("default")}, -1});
+      tmpl_exprs[t].push_back(Expr{"karpenter.sh/registered", "In", {"true"}, -1});
+      tmpl_exprs[t].push_back(Expr{"karpenter.sh/initialized", "In", {"true"}, -1});
+      for (auto& e : tmpl_exprs[t]) { D.note(e); if (e.min_values >= 0) throw Unsupported("minValues are not solved on the device in this build"); }
+      for (auto& tv : np.at("taints").items()) {
+        Taint x{tv.at("key").s(), tv.at("value").s(), tv.at("effect").s()};
+        tmpl_taints[t] |= 1ull << taint_id(x);
+        if (x.effect == "PreferNoSchedule") tolerate_prefer_no_schedule = true;
+      }
+    }
+
+    // ---- pods (explicit list + deterministic groups) ----
+    struct Row { int spec; };  // index into specs
+    std::vector<PodSpec> specs;           // distinct pod templates (each explicit pod is its own spec)
+    std::vector<int> pod_spec;            // per pod -> spec
+    std::vector<uint64_t> uid_hi, uid_lo;
+    std::vector<std::string> uid_text;    // explicit pods only ("" for group pods: regenerated on demand)
+    std::vector<std::pair<uint64_t, uint64_t>> group_of_pod;  // (seed, index) for group pods
+    bool all_uuid = true;
+    for (auto& pv : root.at("pods").items()) {
+      specs.push_back(parse_pod(pv));
+      pod_spec.push_back((int)specs.size() - 1);
+      uint64_t hi = 0, lo = 0;
+      if (!parse_uuid(specs.back().uid, hi, lo)) all_uuid = false;
+      uid_hi.push_back(hi); uid_lo.push_back(lo); uid_text.push_back(specs.back().uid); group_of_pod.push_back({0, 0});
+    }
+    for (auto& g : root.at("podGroups").items()) {
+      specs.push_back(parse_pod(g.at("template")));
+      int si = (int)specs.size() - 1;
+      uint64_t seed = (uint64_t)g.at("uidSeed").i(0);
+      long long cnt = g.at("count").i(0);
+      for (long long i = 0; i < cnt; ++i) {
+        uint64_t hi, lo;
+        group_uid(seed, (uint64_t)i, hi, lo, nullptr);
+        pod_spec.push_back(si); uid_hi.push_back(hi); uid_lo.push_back(lo); uid_text.push_back(std::string()); group_of_pod.push_back({seed, (uint64_t)i});
+      }
+    }
+    const int n_pods = (int)pod_spec.size();
+    if (!all_uuid) {
+      // UIDs that are not lower-case UUIDs: order them as strings on the host and hand the device their rank
+      std::vector<int> order(n_pods);
+      for (int i = 0; i < n_pods; ++i) order[i] = i;
+      auto text = [&](int i) { if (!uid_text[i].empty()) return uid_text[i]; std::string s; uint64_t a, b; group_uid(group_of_pod[i].first, group_of_pod[i].second, a, b, &s); return s; };
+      std::vector<std::string> texts(n_pods);
+      for (int i = 0; i < n_pods; ++i) texts[i] = text(i);
+      std::sort(order.begin(), order.end(), [&](int a, int b) { return texts[a] < texts[b]; });
+      for (int r = 0; r < n_pods; ++r) { uid_hi[order[r]] = 0; uid_lo[order[r]] = (uint64_t)r; }
+    }
+    // requirement ladders per spec: row 0 = as submitted, then one row per Preferences.Relax step (preferences.go:38-57)
+    struct Variant { std::vector<Expr> reqs, strict; std::vector<Toleration> tolerations; };
+    std::vector<std::vector<Variant>> ladders(specs.size());
+    for (size_t si = 0; si < specs.size(); ++si) {
+      PodSpec p = specs[si];
+      for (;;) {
+        // newPodRequirements — requirements.go:91-118
+        auto build = [&](bool required_only) {
+          std::vector<Expr> out = label_exprs(p.node_selector);
+          if (!p.has_node_affinity) return out;
+          if (!required_only && !p.preferred.empty()) {
+            small_stable_sort(p.preferred, [](const std::pair<int, std::vector<Expr>>& a, const std::pair<int, std::vector<Expr>>& b) { return a.first > b.first; });
+            for (auto& e : p.preferred[0].second) out.push_back(e);
+          }
+          if (p.has_required && !p.required_terms.empty()) for (auto& e : p.required_terms[0]) out.push_back(e);
+          return out;
+        };
+        Variant v;
+        v.reqs = build(ignore_prefs);
+        v.strict = (p.has_node_affinity && !p.preferred.empty()) ? build(true) : v.reqs;   // scheduler.go:561-566
+        v.tolerations = p.tolerations;
+        for (auto& e : v.reqs) D.note(e);
+        for (auto& e : v.strict) D.note(e);
+        ladders[si].push_back(v);
+        // Relax: first relaxation that applies
+        if (p.has_node_affinity && p.has_required && p.required_terms.size() > 1) { p.required_terms.erase(p.required_terms.begin()); continue; }
+        if (p.has_node_affinity && !p.preferred.empty()) {
+          std::stable_sort(p.preferred.begin(), p.preferred.end(), [](const std::pair<int, std::vector<Expr>>& a, const std::pair<int, std::vector<Expr>>& b) { return a.first > b.first; });
+          p.preferred.erase(p.preferred.begin());
+          continue;
+        }
+        if (tolerate_prefer_no_schedule) {
+          bool have = false;
+          for (auto& t : p.tolerations) if (t.key.empty() && t.op == "Exists" && t.value.empty() && t.effect == "PreferNoSchedule") have = true;
+          if (!have) { p.tolerations.push_back({"", "Exists", "", "PreferNoSchedule"}); continue; }
+        }
+        break;
+      }
+    }
+    if (D.key_index.count(kHostname)) throw Unsupported("requirements on kubernetes.io/hostname are not solved on the device in this build");
+
+    // ---- resources: dimensions and exact scales ----
+    std::vector<std::string> res_names = {"cpu", "memory"};
+    auto add_res = [&](const std::string& r) { if (r == "nodes") return; if (std::find(res_names.begin(), res_names.end(), r) == res_names.end()) res_names.push_back(r); };
+    add_res("pods");
+    std::vector<std::map<std::string, i128>> it_cap(n_its), it_over(n_its);
+    for (int i = 0; i < n_its; ++i) {
+      it_cap[i] = parse_resources(its_json[i].at("capacity")); it_over[i] = parse_resources(its_json[i].at("overhead"));
+      for (auto& kv : it_cap[i]) { if (kv.first.rfind("hugepages-", 0) == 0) throw Unsupported("hugepages"); add_res(kv.first); }
+    }
+    for (auto& s : specs) for (auto& kv : s.requests) add_res(kv.first);
+    std::vector<std::map<std::string, i128>> tmpl_limits(n_templates);
+    std::vector<bool> tmpl_has_limits(n_templates, false);
+    for (int t = 0; t < n_templates; ++t) {
+      const Value& np = *pools[t].v;
+      if (np.has("limits") && !np.at("limits").is_null()) { tmpl_has_limits[t] = true; tmpl_limits[t] = parse_resources(np.at("limits")); for (auto& kv : tmpl_limits[t]) add_res(kv.first); }
+    }
+    const int n_res = (int)res_names.size();
+    if (n_res > KSOLVE_MAX_RES) throw Unsupported("more than 8 resource dimensions");
+    std::vector<i128> scale(n_res, 1000000000);  // nano-units per device unit; shrink until every quantity divides
+    auto consider = [&](const std::map<std::string, i128>& m) {
+      for (auto& kv : m) {
+        if (kv.first == "nodes") continue;
+        int r = (int)(std::find(res_names.begin(), res_names.end(), kv.first) - res_names.begin());
+        i128 v = kv.second < 0 ? -kv.second : kv.second;
+        while (scale[r] > 1 && v % scale[r] != 0) scale[r] /= 10;
+      }
+    };
+    for (int i = 0; i < n_its; ++i) { consider(it_cap[i]); consider(it_over[i]); }
+    for (auto& s : specs) consider(s.requests);
+    for (int t = 0; t < n_templates; ++t) consider(tmpl_limits[t]);
+    auto to_dev = [&](int r, i128 nano) {
+      i128 v = nano / scale[r];
+      if (v > (i128)(INT64_MAX / 4) || v < -(i128)(INT64_MAX / 4)) throw Unsupported("resource quantity does not fit the device's exact int64 encoding");
+      return (int64_t)v;
+    };
+    auto res_get = [&](const std::map<std::string, i128>& m, const std::string& k) { auto it = m.find(k); return it == m.end() ? (i128)0 : it->second; };
+
+    // ---- dictionary is complete ----
+    const int it_words = std::max(1, (n_its + 63) / 64);
+    fl.finalize_dictionary(it_words);
+    const int nk = fl.kd.n_keys, rw = fl.kd.req_words;
+
+    // instance type tables
+    std::vector<int64_t> it_alloc((size_t)n_res * n_its), it_capv((size_t)n_res * n_its);
+    std::vector<uint64_t> it_avail(n_its, 0);
+    std::vector<double> it_price((size_t)n_its * 64, 0.0);
+    ReqTableBuilder it_reqs;
+    it_reqs.init(n_its, rw, nk);
+    for (int i = 0; i < n_its; ++i) {
+      for (int r = 0; r < n_res; ++r) {
+        i128 cap = res_get(it_cap[i], res_names[r]);
+        i128 alloc = it_cap[i].count(res_names[r]) ? cap - res_get(it_over[i], res_names[r]) : 0;  // resources.Subtract keeps capacity's keys (resources.go:83-97)
+        it_capv[(size_t)r * n_its + i] = to_dev(r, cap);
+        it_alloc[(size_t)r * n_its + i] = to_dev(r, alloc);
+      }
+      for (auto& o : it_offs[i]) {
+        int cell = o.zone * 4 + o.ct;
+        if (o.available) {
+          if ((it_avail[i] >> cell) & 1) { if (o.price < it_price[(size_t)i * 64 + cell]) it_price[(size_t)i * 64 + cell] = o.price; }
+          else { it_avail[i] |= 1ull << cell; it_price[(size_t)i * 64 + cell] = o.price; }
+        }
+      }
+      ks::ReqBuf b;
+      Flattener::clear(b);
+      for (auto& e : it_exprs[i]) { ks::ReqBuf one; fl.encode(e, one); ks::reqbuf_add(fl.kd, b, ks::reqbuf_ref_with_minv(one)); }
+      it_reqs.put(i, b);
+    }
+    // templates
+    ReqTableBuilder tmpl_reqs;
+    tmpl_reqs.init(n_templates, rw, nk);
+    std::vector<uint64_t> tmpl_its((size_t)n_templates * it_words, 0);
+    std::vector<uint32_t> tmpl_limit_mask(n_templates, 0);
+    std::vector<int64_t> tmpl_lim((size_t)n_templates * (n_res + 1), 0);
+    for (int t = 0; t < n_templates; ++t) {
+      ks::ReqBuf b;
+      Flattener::clear(b);
+      for (auto& e : tmpl_exprs[t]) { ks::ReqBuf one; fl.encode(e, one); ks::reqbuf_add(fl.kd, b, ks::reqbuf_ref_with_minv(one)); }
+      tmpl_reqs.put(t, b);
+      const Value& np = *pools[t].v;
+      if (np.has("instanceTypes") && !np.at("instanceTypes").is_null()) {
+        int prev = -1;
+        for (auto& n : np.at("instanceTypes").items()) {
+          auto f = it_index.find(n.s());
+          if (f == it_index.end()) throw std::runtime_error("unknown instance type " + n.s());
+          if (f->second < prev) throw Unsupported("NodePool instance types must be listed in catalogue order");
+          prev = f->second;
+          tmpl_its[(size_t)t * it_words + f->second / 64] |= 1ull << (f->second % 64);
+        }
+      } else for (int i = 0; i < n_its; ++i) tmpl_its[(size_t)t * it_words + i / 64] |= 1ull << (i % 64);
+      if (tmpl_has_limits[t]) {
+        for (auto& kv : tmpl_limits[t]) {
+          if (kv.first == "nodes") { tmpl_limit_mask[t] |= 1u << n_res; tmpl_lim[(size_t)t * (n_res + 1) + n_res] = (int64_t)(kv.second / 1000000000); continue; }
+          int r = (int)(std::find(res_names.begin(), res_names.end(), kv.first) - res_names.begin());
+          tmpl_limit_mask[t] |= 1u << r;
+          tmpl_lim[(size_t)t * (n_res + 1) + r] = to_dev(r, kv.second);
+        }
+      }
+    }
+    // pod rows: rows [0,n_pods) are the pods; ladder rows are shared per spec and appended after
+    std::vector<int> spec_first_extra(specs.size(), -1);
+    int n_rows = n_pods;
+    for (size_t si = 0; si < specs.size(); ++si) if (ladders[si].size() > 1) { spec_first_extra[si] = n_rows; n_rows += (int)ladders[si].size() - 1; }
+    std::vector<int64_t> pod_requests((size_t)n_res * n_rows);
+    ReqTableBuilder pod_reqs, pod_strict;
+    pod_reqs.init(n_rows, rw, nk); pod_strict.init(n_rows, rw, nk);
+    std::vector<uint64_t> pod_tol(n_rows, 0);
+    std::vector<int32_t> pod_next(n_rows, -1);
+    std::vector<int64_t> pod_creation(n_pods);
+    std::vector<uint8_t> pod_pending(n_pods);
+    // encode each (spec, variant) once, then replicate to its rows
+    struct Enc { ks::ReqBuf reqs, strict; uint64_t tol; std::vector<int64_t> req; };
+    std::vector<std::vector<Enc>> enc(specs.size());
+    for (size_t si = 0; si < specs.size(); ++si) {
+      std::vector<int64_t> req(n_res);
+      for (int r = 0; r < n_res; ++r) req[r] = to_dev(r, res_names[r] == "pods" ? (i128)1000000000 : res_get(specs[si].requests, res_names[r]));
+      for (auto& v : ladders[si]) {
+        Enc e;
+        Flattener::clear(e.reqs); Flattener::clear(e.strict);
+        for (auto& x : v.reqs) { ks::ReqBuf one; fl.encode(x, one); ks::reqbuf_add(fl.kd, e.reqs, ks::reqbuf_ref_with_minv(one)); }
+        for (auto& x : v.strict) { ks::ReqBuf one; fl.encode(x, one); ks::reqbuf_add(fl.kd, e.strict, ks::reqbuf_ref_with_minv(one)); }
+        e.tol = 0;
+        for (size_t ti = 0; ti < distinct_taints.size(); ++ti) for (auto& t : v.tolerations) if (tolerates(t, distinct_taints[ti])) { e.tol |= 1ull << ti; break; }
+        e.req = req;
+        enc[si].push_back(e);
+      }
+    }
+    auto put_row = [&](int row, const Enc& e) {
+      for (int r = 0; r < n_res; ++r) pod_requests[(size_t)r * n_rows + row] = e.req[r];
+      pod_reqs.put(row, e.reqs); pod_strict.put(row, e.strict); pod_tol[row] = e.tol;
+    };
+    for (int p = 0; p < n_pods; ++p) {
+      int si = pod_spec[p];
+      put_row(p, enc[si][0]);
+      pod_next[p] = spec_first_extra[si];
+      pod_creation[p] = specs[si].creation;
+      pod_pending[p] = specs[si].pending ? 1 : 0;
+    }
+    for (size_t si = 0; si < specs.size(); ++si) if (spec_first_extra[si] >= 0)
+      for (size_t vi = 1; vi < ladders[si].size(); ++vi) {
+        int row = spec_first_extra[si] + (int)vi - 1;
+        put_row(row, enc[si][vi]);
+        pod_next[row] = vi + 1 < ladders[si].size() ? row + 1 : -1;
+      }
+
+    // ---- describe & solve ----
+    ksolve_problem_desc d{};
+    d.abi_version = KSOLVE_ABI_VERSION;
+    d.n_keys = (uint32_t)nk; d.key_word_off = fl.key_word_off.data(); d.well_known_mask = fl.kd.well_known_mask;
+    d.key_instance_type = fl.kd.key_it; d.key_zone = fl.kd.key_zone; d.key_capacity_type = fl.kd.key_ct; d.key_hostname = -1;
+    d.value_int = fl.value_int.data(); d.value_is_int = fl.value_is_int.data();
+    d.n_res = (uint32_t)n_res;
+    d.n_its = (uint32_t)n_its; d.it_allocatable = it_alloc.data(); d.it_capacity = it_capv.data(); d.it_reqs = it_reqs.view();
+    d.it_offering_avail = it_avail.data(); d.it_offering_price = it_price.data(); d.n_zones = (uint32_t)n_zones; d.n_captypes = (uint32_t)n_cts;
+    d.n_templates = (uint32_t)n_templates; d.tmpl_reqs = tmpl_reqs.view(); d.tmpl_taints = tmpl_taints.data(); d.tmpl_its = tmpl_its.data();
+    d.tmpl_limit_mask = tmpl_limit_mask.data(); d.tmpl_limits = tmpl_lim.data();
+    d.n_pods = (uint32_t)n_pods; d.n_pod_rows = (uint32_t)n_rows; d.pod_requests = pod_requests.data();
+    d.pod_reqs = pod_reqs.view(); d.pod_strict_reqs = pod_strict.view(); d.pod_tolerates = pod_tol.data(); d.pod_next_variant = pod_next.data();
+    d.pod_creation = pod_creation.data(); d.pod_uid_hi = uid_hi.data(); d.pod_uid_lo = uid_lo.data(); d.pod_is_pending = pod_pending.data();
+    d.n_taints = (uint32_t)distinct_taints.size();
+    ksolve_options ko{};
+    ko.min_values_best_effort = opts.at("minValuesPolicy").s("Strict") == "BestEffort";
+    ko.max_claims = (uint32_t)opts.at("maxClaims").i(0);
+    ko.max_steps = opts.at("maxSteps").i(-1);
+    ko.device = (uint32_t)opts.at("device").i(0);
+
+    ksolve_status st = api.create(&d, &ko, &handle);
+    if (st != KSOLVE_OK) {
+      std::string msg = handle ? api.last_error(handle) : "ksolve_create failed";
+      if (handle) api.destroy(handle);
+      return error_json(st == KSOLVE_ERR_UNSUPPORTED ? "unsupported" : st == KSOLVE_ERR_NO_DEVICE ? "no_device" : "create", msg);
+    }
+    Value timings = Value::array();
+    ksolve_results res{};
+    for (int it = 0; it < std::max(1, repeat); ++it) {
+      if (it) api.results_free(&res);
+      st = api.solve(handle, &res);
+      if (st != KSOLVE_OK && st != KSOLVE_ERR_CANCELLED) {
+        std::string msg = api.last_error(handle);
+        api.destroy(handle);
+        return error_json(st == KSOLVE_ERR_UNSUPPORTED ? "unsupported" : st == KSOLVE_ERR_CAPACITY ? "capacity" : "solve", msg);
+      }
+      Value t = Value::object();
+      t.set("upload_us", Value::number(res.us_upload)); t.set("prepass_us", Value::number(res.us_prepass)); t.set("pack_us", Value::number(res.us_pack));
+      t.set("finalize_us", Value::number(res.us_finalize)); t.set("download_us", Value::number(res.us_download));
+      if (api.kernel_ms) {
+        t.set("pack_kernel_ms", Value::number(api.kernel_ms(handle, "ksolve_pack")));
+        t.set("classify_ms", Value::number(api.kernel_ms(handle, "classify")));
+        t.set("sort_ms", Value::number(api.kernel_ms(handle, "sort")));
+        t.set("it_index_ms", Value::number(api.kernel_ms(handle, "it_index")));
+      }
+      timings.push(t);
+    }
+
+    // ---- rehydrate Results ----
+    Value out = Value::object();
+    auto uid_of = [&](int p) { if (!uid_text[p].empty()) return uid_text[p]; std::string s; uint64_t a, b; group_uid(group_of_pod[p].first, group_of_pod[p].second, a, b, &s); return s; };
+    const ksolve_claims& cl = res.claims;
+    Value counters = Value::object();
+    counters.set("binEvaluations", Value::integer((int64_t)res.bin_evaluations));
+    counters.set("instanceTypeEvaluations", Value::integer((int64_t)res.it_evaluations));
+    counters.set("pops", Value::integer((int64_t)res.queue_pops)); counters.set("sorts", Value::integer((int64_t)res.sorts));
+    counters.set("slowSorts", Value::integer((int64_t)res.slow_sorts)); counters.set("relaxations", Value::integer((int64_t)res.relaxations));
+    counters.set("pods", Value::integer(n_pods)); counters.set("claims", Value::integer(cl.n_claims));
+    counters.set("rows", Value::integer(n_rows)); counters.set("instanceTypes", Value::integer(n_its));
+    counters.set("reqWords", Value::integer(rw)); counters.set("itWords", Value::integer(it_words)); counters.set("keys", Value::integer(nk)); counters.set("resources", Value::integer(n_res));
+    out.set("counters", counters);
+    out.set("timings", timings);
+    out.set("timedOut", Value::boolean(st == KSOLVE_ERR_CANCELLED));
+    out.set("packingCost", Value::number(res.packing_cost));
+    int unscheduled = 0;
+    for (int p = 0; p < n_pods; ++p) if (res.pod_assignment[p] == -1) unscheduled++;
+    out.set("scheduledPods", Value::integer(n_pods - unscheduled));
+    if (want_results) {
+      std::vector<std::vector<std::pair<uint32_t, int>>> members(cl.n_claims);
+      Value errs = Value::object();
+      for (int p = 0; p < n_pods; ++p) {
+        int a = res.pod_assignment[p];
+        if (a >= 0) members[a].push_back({res.pod_slot[p], p});
+        else { Value e = Value::object(); e.set("code", Value::integer(res.pod_error[p])); e.set("diag", Value::integer(res.pod_error_diag[p])); errs.set(uid_of(p), e); }
+      }
+      Value claims = Value::array();
+      for (uint32_t c = 0; c < cl.n_claims; ++c) {
+        Value cj = Value::object();
+        int t = cl.template_idx[c];
+        cj.set("nodePool", Value::string(pools[t].name));
+        char hb[64];
+        snprintf(hb, sizeof hb, "hostname-placeholder-%04u", cl.hostname_seq[c]);
+        cj.set("hostname", Value::string(hb));
+        std::sort(members[c].begin(), members[c].end());
+        Value pj = Value::array();
+        for (auto& m : members[c]) pj.push(Value::string(uid_of(m.second)));
+        cj.set("pods", pj);
+        Value itj = Value::array();
+        for (int i = 0; i < n_its; ++i) if ((cl.it_mask[(size_t)c * cl.it_words + i / 64] >> (i % 64)) & 1) itj.push(Value::string(its_json[i].at("name").s()));
+        cj.set("instanceTypes", itj);
+        Value rj = Value::array();
+        // requirements in key-name order, like the oracle's std::map
+        std::vector<std::pair<std::string, int>> keys;
+        for (int k = 0; k < nk; ++k) if ((cl.req_defined[c] >> k) & 1) keys.push_back({D.keys[k], k});
+        std::sort(keys.begin(), keys.end());
+        for (auto& kk : keys) {
+          int k = kk.second;
+          Value r = Value::object();
+          r.set("key", Value::string(kk.first));
+          bool comp = (cl.req_complement[c] >> k) & 1;
+          r.set("complement", Value::boolean(comp));
+          std::vector<std::string> vals;
+          for (size_t v = 0; v < D.values[k].size(); ++v) { size_t pos = (size_t)fl.key_word_off[k] * 64 + v; if ((cl.req_mask[(size_t)c * cl.req_words + pos / 64] >> (pos % 64)) & 1) vals.push_back(D.values[k][v]); }
+          std::sort(vals.begin(), vals.end());
+          Value vj = Value::array();
+          for (auto& v : vals) vj.push(Value::string(v));
+          r.set("values", vj);
+          r.set("gte", ((cl.req_has_gte[c] >> k) & 1) ? Value::integer(cl.req_gte[(size_t)c * nk + k]) : Value());
+          r.set("lte", ((cl.req_has_lte[c] >> k) & 1) ? Value::integer(cl.req_lte[(size_t)c * nk + k]) : Value());
+          int mv = cl.req_min_values[(size_t)c * nk + k];
+          r.set("minValues", mv >= 0 ? Value::integer(mv) : Value());
+          r.set("operator", Value::string(comp ? (vals.empty() ? "Exists" : "NotIn") : (vals.empty() ? "DoesNotExist" : "In")));
+          rj.push(r);
+        }
+        cj.set("requirements", rj);
+        Value qj = Value::object();
+        for (int r = 0; r < n_res; ++r) {
+          int64_t v = cl.requests[(size_t)c * n_res + r];
+          if (v != 0 || res_names[r] == "pods") qj.set(res_names[r], Value::string(i128_str((i128)v * scale[r])));
+        }
+        cj.set("requests", qj);
+        Value ann = Value::object();
+        ann.set("karpenter.sh/nodeclaim-min-values-relaxed", Value::string(cl.min_values_relaxed[c] ? "true" : "false"));
+        cj.set("annotations", ann);
+        cj.set("reservedOfferings", Value::array());
+        cj.set("cheapestPrice", Value::number(cl.cheapest_price[c] < 1e300 ? cl.cheapest_price[c] : -1.0));
+        claims.push(cj);
+      }
+      out.set("newNodeClaims", claims);
+      out.set("existingNodes", Value::array());
+      out.set("podErrors", errs);
+    }
+    api.results_free(&res);
+    api.destroy(handle);
+    return dup_json(out);
+  } catch (const Unsupported& e) {
+    if (handle) api.destroy(handle);
+    return error_json("unsupported", e.what());
+  } catch (const std::exception& e) {
+    if (handle) api.destroy(handle);
+    return error_json("invalid", e.what());
+  }
+}

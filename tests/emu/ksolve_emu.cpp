@@ -1,0 +1,85 @@
+// TEST INFRASTRUCTURE ONLY — host emulation of the device solver.
+//
+// Compiles the product's device algorithm (karpenter_amd/csrc/{engine,pdq_emul,reqalg,kernels}.h) for the host with
+// KSOLVE_HOST_EMULATION, where a wavefront is a loop over 64 lanes and a kernel launch is a loop over its grid. It
+// exists so that `pytest -m "not gpu"` can fuzz the device algorithm against the oracle on machines without a GPU.
+// It is built only by tests/ (into tests/emu/), is never built by __graft_entry__.build() as part of the product, and
+// the product's Python host (karpenter_amd/scheduling.py) refuses to load it unless a test passes it explicitly.
+#define KSOLVE_HOST_EMULATION 1
+#include "../../karpenter_amd/csrc/ksolve_impl.h"
+
+struct EmuBackend { std::chrono::steady_clock::time_point t0[8]; };
+
+static void* be_alloc(ksolve_handle* h, size_t bytes) { void* p = calloc(1, bytes ? bytes : 1); h->allocations.push_back(p); return p; }
+static void be_h2d(ksolve_handle*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
+static void be_d2h(ksolve_handle*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
+static void be_fill(ksolve_handle*, void* dst, int byte, size_t bytes) { memset(dst, byte, bytes); }
+static void be_sync(ksolve_handle*) {}
+static bool be_ok(ksolve_handle*) { return true; }
+static void be_tic(ksolve_handle* h, int slot) { ((EmuBackend*)h->backend)->t0[slot] = std::chrono::steady_clock::now(); }
+static void be_toc(ksolve_handle* h, int slot) {
+  h->timers.ms[slot] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ((EmuBackend*)h->backend)->t0[slot]).count();
+}
+static void be_launch_it_index(ksolve_handle*, int n, const ks::ItIndexArgs& a) { for (int i = 0; i < n; ++i) ks::it_index_body(i, a); }
+static void be_launch_row_hash(ksolve_handle*, int n, const ks::RowArgs& a) { for (int i = 0; i < n; ++i) ks::row_hash_body(i, a); }
+static void be_launch_row_verify(ksolve_handle*, int n, const ks::RowArgs& a) { for (int i = 0; i < n; ++i) ks::row_verify_body(i, a); }
+static void be_launch_row_class(ksolve_handle*, int n, const ks::RowArgs& a) { for (int i = 0; i < n; ++i) ks::row_class_body(i, a); }
+static void be_launch_class_gather(ksolve_handle*, int n, const ks::RowArgs& a) { for (int i = 0; i < n; ++i) ks::class_gather_body(i, a); }
+static void be_launch_finalize(ksolve_handle*, int n, const ks::FinalizeArgs& a) { for (int i = 0; i < n; ++i) ks::finalize_body(i, a); }
+static void be_sort_pods(ksolve_handle* h) {
+  // same LSD structure as the device path: five stable passes over 64-bit keys
+  const int n = (int)h->n_pods;
+  uint32_t* idx = h->d_idx_a;
+  for (int i = 0; i < n; ++i) idx[i] = (uint32_t)i;
+  for (int pass = 0; pass < 5; ++pass) {
+    ks::SortKeyArgs a = h->sort_args;
+    a.idx_in = idx; a.key_out = h->d_key_a; a.pass = pass;
+    for (int i = 0; i < n; ++i) ks::sort_key_body(i, a);
+    std::vector<uint32_t> perm(n);
+    for (int i = 0; i < n; ++i) perm[i] = (uint32_t)i;
+    const uint64_t* key = h->d_key_a;
+    std::stable_sort(perm.begin(), perm.end(), [key](uint32_t x, uint32_t y) { return key[x] < key[y]; });
+    std::vector<uint32_t> out(n);
+    for (int i = 0; i < n; ++i) out[i] = idx[perm[i]];
+    memcpy(idx, out.data(), (size_t)n * 4);
+  }
+  h->pv.sorted_pods = idx;
+}
+static void be_launch_pack(ksolve_handle* h) {
+  static thread_local ks::Scratch scratch;
+  ks::Engine<ks::Wave> eng(h->pv, h->ws, scratch);
+  eng.solve();
+}
+static int be_device_available() { return 1; }
+
+extern "C" {
+ksolve_status ksolve_create(const ksolve_problem_desc* desc, const ksolve_options* opts, ksolve_handle** out) {
+  ksolve_handle* h = new ksolve_handle();
+  h->backend = new EmuBackend();
+  ksolve_status s = ksi::create(desc, opts, h);
+  *out = h;  // returned even on failure so the caller can read ksolve_last_error
+  return s;
+}
+ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out) { return ksi::solve(h, out); }
+ksolve_status ksolve_cancel(ksolve_handle* h) { if (h->d_cancel) *h->d_cancel = 1; return KSOLVE_OK; }
+void ksolve_results_free(ksolve_results* r) { if (r && r->impl) { delete (ksi::ResultsImpl*)r->impl; r->impl = nullptr; } }
+void ksolve_destroy(ksolve_handle* h) {
+  if (!h) return;
+  for (void* p : h->allocations) free(p);
+  delete (EmuBackend*)h->backend;
+  delete h;
+}
+const char* ksolve_last_error(const ksolve_handle* h) { return h ? h->error.c_str() : "null handle"; }
+uint32_t ksolve_abi_version(void) { return KSOLVE_ABI_VERSION; }
+int ksolve_device_available(void) { return 0; }  // the emulation is not a device
+double ksolve_last_kernel_ms(const ksolve_handle* h, const char* name) {
+  if (!h) return -1;
+  std::string n(name ? name : "");
+  if (n == "ksolve_pack") return h->timers.ms[ksi::T_PACK];
+  if (n == "classify") return h->timers.ms[ksi::T_CLASSIFY];
+  if (n == "sort") return h->timers.ms[ksi::T_SORT];
+  if (n == "it_index") return h->timers.ms[ksi::T_INDEX];
+  return -1;
+}
+int ksolve_is_emulation(void) { return 1; }
+}

@@ -1,0 +1,45 @@
+"""Shared helpers for parity tests: canonical comparison of a product Results document with the oracle's."""
+import os
+
+EMU_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libksolve_emu.so")
+
+
+def build_emu():
+    """Builds the TEST-ONLY host emulation of the device solver (tests/emu/ksolve_emu.cpp)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "emu", "ksolve_emu.cpp")
+    deps = [src] + [os.path.join(root, "karpenter_amd", "csrc", f) for f in os.listdir(os.path.join(root, "karpenter_amd", "csrc")) if f.endswith(".h")]
+    deps.append(os.path.join(root, "include", "ksolve.h"))
+    if not os.path.exists(EMU_LIB) or any(os.path.getmtime(d) > os.path.getmtime(EMU_LIB) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", EMU_LIB, src])
+    return EMU_LIB
+
+
+def canon_req(r):
+    return (r["key"], r["complement"], tuple(sorted(r["values"])), r["gte"], r["lte"], r["minValues"])
+
+
+def canon_claim(c):
+    reqs = tuple(sorted(canon_req(r) for r in c["requirements"]))
+    requests = tuple(sorted((k, int(v)) for k, v in c["requests"].items() if int(v) != 0))
+    return {"nodePool": c["nodePool"], "pods": list(c["pods"]), "instanceTypes": list(c["instanceTypes"]), "requirements": reqs,
+            "requests": requests, "hostname": c["hostname"]}
+
+
+def assert_same_results(got, want, check_price=True):
+    """L1-strict parity: same claims in the same order, same pod identities in the same slot order, same instance
+    type options, requirements and requests; same existing-node assignments; same pod errors."""
+    assert len(got["newNodeClaims"]) == len(want["newNodeClaims"]), (len(got["newNodeClaims"]), len(want["newNodeClaims"]))
+    for i, (g, w) in enumerate(zip(got["newNodeClaims"], want["newNodeClaims"])):
+        cg, cw = canon_claim(g), canon_claim(w)
+        for field in cw:
+            assert cg[field] == cw[field], (i, field, cg[field], cw[field])
+        if check_price:
+            assert g["cheapestPrice"] == w["cheapestPrice"], (i, g["cheapestPrice"], w["cheapestPrice"])
+    ge = {e["name"]: e["pods"] for e in got.get("existingNodes", []) if e["pods"]}
+    we = {e["name"]: e["pods"] for e in want.get("existingNodes", []) if e["pods"]}
+    assert ge == we
+    gerr = {u: (e["code"], e["diag"]) for u, e in got["podErrors"].items()}
+    werr = {u: (e["code"], e["diag"]) for u, e in want["podErrors"].items()}
+    assert gerr == werr, (sorted(gerr.items())[:5], sorted(werr.items())[:5])
