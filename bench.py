@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""bench.py — pods scheduled/sec through Solve() on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path — ksolve_solve(): pod classing, queue sort, the pack engine, finalize, results
+download — over one batch of synthetic pods whose flattened problem is already resident in HBM (ksolve_create is
+outside the timed region, like b.ResetTimer() after setupScheduler in scheduling_benchmark_test.go:166-169).
+
+  N = 1 : BASELINE.json configs[1] — 1M pods, 500 instance types, nodeSelector + taint/toleration constraints.
+  N > 1 : weak scaling. Solve() is a serial chain inside one coupled problem, so the path shards across INDEPENDENT
+          scheduling problems (NodePool components): rank r solves its own configs[1]-shaped problem
+          (different seed), no collective on the data path; after the timed solves one RCCL all-reduce over the
+          per-instance-type option-count / cost vector gives the global packing summary (north_star).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(c):
+    """bytes = P*B_pod + V*B_bin + P*B_bin(writeback) + N_it*T*B_it with the record sizes of the
+    layouts actually used (DESIGN.md §Data layout)."""
+    R, RW, IW, K = c["resources"], c["reqWords"], c["itWords"], c["keys"]
+    b_pod = 8 * R + 2 * (8 * RW + 16) + 8 + 4 + 8 + 16 + 1
+    b_bin = 8 * RW + 16 + 8 * IW + 16 * R + 20 * K + 16
+    b_it = 16 * R + 8 * RW + 16 + 8 + 512
+    total = c["pods"] * b_pod + c["referenceBinEvaluations"] * b_bin + c["pods"] * b_bin + c["instanceTypes"] * c.get("templates", 1) * b_it
+    return total, {"B_pod": b_pod, "B_bin": b_bin, "B_it": b_it}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pods", type=int, default=1_000_000, help="pods per GPU (configs[1] = 1M)")
+    ap.add_argument("--types", type=int, default=500)
+    ap.add_argument("--cpu-sample", type=int, default=40_000, help="pods in the bounded cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if dist is not None:
+        dist.barrier()
+    from karpenter_amd import fixtures as fx
+    from karpenter_amd.scheduling import NewScheduler
+
+    prob = fx.config2(pods=args.pods, n_types=args.types, seed=42 + rank)
+    prob["options"]["device"] = local_rank
+    sched = NewScheduler(prob)  # flatten + upload: inputs resident in HBM before the timed region
+
+    def sync():
+        if torch is not None:
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sched.Solve(want_results=False)
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    timings = []
+    for _ in range(args.steps):
+        last = sched.Solve(want_results=False)  # synchronous: returns after the device finished and results are on the host
+        timings += last["timings"]
+    sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    scheduled = last["scheduledPods"]
+    cost = last["packingCost"]
+    claims = last["counters"]["claims"]
+
+    if dist is not None:
+        # max over ranks of the timed region; whole-job pods; global packing summary over xGMI (RCCL all-reduce)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        v = torch.tensor([float(scheduled), float(cost), float(claims)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        scheduled, cost, claims = int(v[0].item()), float(v[1].item()), int(v[2].item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = scheduled / (elapsed / args.steps)
+    c = dict(last["counters"])
+    c["templates"] = len(prob["nodePools"])
+    abytes, rec = algorithmic_bytes(c)
+    pack_ms = sum(t["pack_kernel_ms"] for t in timings) / len(timings)
+    cls_ms = sum(t["classify_ms"] for t in timings) / len(timings)
+    achieved = abytes / (pack_ms * 1e-3) / 1e9
+    stream_bytes = c["rows"] * rec["B_pod"]
+    out = {
+        "metric": "pods scheduled/sec (Solve())", "value": value, "unit": "pods/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: {args.pods} pods/GPU x {args.types} kwok instance types, nodeSelector + taint/toleration, 2 NodePools",
+                   "pods_per_gpu": args.pods, "instance_types": args.types, "sharding": "one independent scheduling problem per GPU" if world > 1 else "single problem"},
+        "packing": {"node_claims": claims, "packing_cost_per_hour": cost, "pods_scheduled": scheduled},
+        "roofline": {"kernel": "ksolve_pack", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes": abytes, "avg_kernel_ms": pack_ms, "records": rec,
+                     "note": "serial first-fit chain: latency-bound, one wavefront per problem; V = referenceBinEvaluations"},
+        "roofline_stream": {"kernel": "ksolve_row_hash+verify+class (pod classing)", "bound": "hbm", "bytes": stream_bytes, "avg_ms": cls_ms,
+                            "achieved": stream_bytes / (cls_ms * 1e-3) / 1e9 if cls_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+        "phases_ms": {k: sum(t[k] for t in timings) / len(timings) for k in ("pack_kernel_ms", "classify_ms", "sort_ms", "it_index_ms")},
+        "counters": c,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        import oracle  # the checker, used here only as the reported CPU baseline
+        sample = fx.config2(pods=args.cpu_sample, n_types=args.types, seed=42)
+        r = oracle.solve(sample)
+        secs = r["counters"]["solveSeconds"]
+        out["cpu_baseline"] = {"value": args.cpu_sample / secs, "unit": "pods/s", "cores": 1, "kind": "port",
+                               "sample": f"{args.cpu_sample} pods of the same configs[1] mix x {args.types} instance types, fresh scheduler, oracle C++ restatement of the Go Solve() ({secs:.1f} s)",
+                               "seconds": secs, "bin_evaluations": r["counters"]["binEvaluations"]}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

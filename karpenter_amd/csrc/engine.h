@@ -248,6 +248,7 @@ struct Engine {
                      P.tmpl_taints[S.c_tmpl[c]], false, &changed);
     if (rc != E_OK) { mark_dead(k, c); return rc; }
     uint32_t np = S.c_npods[c];
+    ctr.ref_bin_evaluations += (unsigned long long)order.pos[c] + 1;   // the reference walked every claim up to this position
     write_claim(c, S.c_tmpl[c], false);
     W::store(&S.c_npods[c], np + 1);
     order.increment(c);
@@ -326,6 +327,7 @@ struct Engine {
     const Dict& d = P.dict;
     const int nr = P.n_res, iw = P.it_words, n_its = P.n_its;
     int first_err = 0, first_diag = 0;
+    ctr.ref_bin_evaluations += (unsigned long long)n_claims;  // the reference tried every in-flight claim before coming here
     for (int t = 0; t < P.n_templates; ++t) {
       if (!((active_templates >> t) & 1)) continue;
       const uint64_t* its = S.t_its + (size_t)t * iw;
@@ -357,6 +359,7 @@ struct Engine {
       int64_t zero[kMaxRes];
       for (int r = 0; r < nr; ++r) zero[r] = 0;
       bool changed;
+      ctr.ref_bin_evaluations++;
       int rc = can_add(k, P.tmpl_reqs.at(d, t), its, zero, nullptr, P.tmpl_taints[t], first_err == 0, &changed);
       if (rc != E_OK) { if (!first_err) { first_err = rc; first_diag = rc == E_INSTANCE_TYPES ? last_diag : 0; } continue; }
       if (n_claims >= S.max_claims) { W::store(S.status_out, 1); return -1; }

@@ -14,12 +14,12 @@
 namespace ks {
 
 #if KS_DEVICE
-KS_FN uint64_t atomic_cas_u64(uint64_t* p, uint64_t expect, uint64_t v) { return (uint64_t)atomicCAS((unsigned long long*)p, (unsigned long long)expect, (unsigned long long)v); }
-KS_FN void atomic_min_u32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
-KS_FN uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
-KS_FN void atomic_min_i64(int64_t* p, int64_t v) { atomicMin((long long*)p, (long long)v); }
-KS_FN void atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
-KS_FN void atomic_or_u32(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+KS_DEV uint64_t atomic_cas_u64(uint64_t* p, uint64_t expect, uint64_t v) { return (uint64_t)atomicCAS((unsigned long long*)p, (unsigned long long)expect, (unsigned long long)v); }
+KS_DEV void atomic_min_u32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+KS_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+KS_DEV void atomic_min_i64(int64_t* p, int64_t v) { atomicMin((long long*)p, (long long)v); }
+KS_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
+KS_DEV void atomic_or_u32(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 #else
 inline uint64_t atomic_cas_u64(uint64_t* p, uint64_t expect, uint64_t v) { uint64_t o = *p; if (o == expect) *p = v; return o; }
 inline void atomic_min_u32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }

@@ -1,0 +1,206 @@
+// ksolve.hip — HIP backend of the C ABI (include/ksolve.h) for MI355X (gfx950, wave64).
+//
+// Kernels (names as they appear in rocprofv3 traces):
+//   ksolve_it_index      one thread per instance type: inverts InstanceType.Requirements into per-(key,value) bitmasks
+//   ksolve_row_hash      one thread per pod row: streams the pod SoA from HBM, hashes, inserts into the class table
+//   ksolve_row_verify    exact compare against the class representative, class numbering
+//   ksolve_row_class / ksolve_class_gather   class ids per row, class tables
+//   ksolve_sort_key      queue-order key extraction (5 stable LSD passes with rocprim::radix_sort_pairs)
+//   ksolve_pack          the pack engine: ONE wavefront per scheduling problem (engine.h)
+//   ksolve_finalize      one thread per claim: cheapest compatible available offering
+// Each handle owns a stream; every phase is bracketed by HIP events recorded on that stream.
+#include <cstring>
+#include <hip/hip_runtime.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "ksolve_impl.h"
+
+struct HipBackend {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0[8], ev1[8];
+  bool failed = false;
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  int device = 0;
+};
+#define HB(h) ((HipBackend*)(h)->backend)
+static bool hip_check(ksolve_handle* h, hipError_t e, const char* what) {
+  if (e == hipSuccess) return true;
+  HB(h)->failed = true;
+  if (h->error.empty()) h->error = std::string(what) + ": " + hipGetErrorString(e);
+  return false;
+}
+
+static void* be_alloc(ksolve_handle* h, size_t bytes) {
+  void* p = nullptr;
+  if (!hip_check(h, hipMalloc(&p, bytes ? bytes : 8), "hipMalloc")) return nullptr;
+  h->allocations.push_back(p);
+  hip_check(h, hipMemsetAsync(p, 0, bytes ? bytes : 8, HB(h)->stream), "hipMemsetAsync");
+  return p;
+}
+static void be_h2d(ksolve_handle* h, void* dst, const void* src, size_t bytes) {
+  if (!dst || !bytes) return;
+  hip_check(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, HB(h)->stream), "hipMemcpy H2D");
+  // source buffers are caller-owned and only guaranteed for the duration of the call
+  hip_check(h, hipStreamSynchronize(HB(h)->stream), "hipStreamSynchronize");
+}
+static void be_d2h(ksolve_handle* h, void* dst, const void* src, size_t bytes) {
+  if (!src || !bytes) return;
+  hip_check(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, HB(h)->stream), "hipMemcpy D2H");
+}
+static void be_fill(ksolve_handle* h, void* dst, int byte, size_t bytes) {
+  if (!dst || !bytes) return;
+  hip_check(h, hipMemsetAsync(dst, byte, bytes, HB(h)->stream), "hipMemsetAsync");
+}
+static void be_sync(ksolve_handle* h) { hip_check(h, hipStreamSynchronize(HB(h)->stream), "hipStreamSynchronize"); }
+static bool be_ok(ksolve_handle* h) { return !HB(h)->failed; }
+static void be_tic(ksolve_handle* h, int slot) { hip_check(h, hipEventRecord(HB(h)->ev0[slot], HB(h)->stream), "hipEventRecord"); }
+static void be_toc(ksolve_handle* h, int slot) {
+  hip_check(h, hipEventRecord(HB(h)->ev1[slot], HB(h)->stream), "hipEventRecord");
+  hip_check(h, hipEventSynchronize(HB(h)->ev1[slot]), "hipEventSynchronize");
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, HB(h)->ev0[slot], HB(h)->ev1[slot]) == hipSuccess) h->timers.ms[slot] = ms;
+}
+
+// ---- kernels ----
+__global__ void ksolve_it_index(int n, ks::ItIndexArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ks::it_index_body(i, a);
+}
+__global__ void ksolve_row_hash(int n, ks::RowArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ks::row_hash_body(i, a);
+}
+__global__ void ksolve_row_verify(int n, ks::RowArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ks::row_verify_body(i, a);
+}
+__global__ void ksolve_row_class(int n, ks::RowArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ks::row_class_body(i, a);
+}
+__global__ void ksolve_class_gather(int n, ks::RowArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ks::class_gather_body(i, a);
+}
+__global__ void ksolve_sort_key(int n, ks::SortKeyArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ks::sort_key_body(i, a);
+}
+__global__ void ksolve_iota(int n, uint32_t* idx) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] = (uint32_t)i;
+}
+__global__ void ksolve_finalize(int n, ks::FinalizeArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ks::finalize_body(i, a);
+}
+// One wavefront (64 threads) per problem; the working requirement set and candidate lists live in LDS.
+__global__ void __launch_bounds__(64) ksolve_pack(ks::ProblemView pv, ks::Workspace ws) {
+  __shared__ ks::Scratch scratch;
+  ks::Engine<ks::Wave> eng(pv, ws, scratch);
+  eng.solve();
+}
+
+static dim3 grid_for(int n) { return dim3((unsigned)((n + 255) / 256)); }
+static void be_launch_it_index(ksolve_handle* h, int n, const ks::ItIndexArgs& a) { hipLaunchKernelGGL(ksolve_it_index, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
+static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_row_hash, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
+static void be_launch_row_verify(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_row_verify, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
+static void be_launch_row_class(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_row_class, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
+static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_class_gather, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
+static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a) { hipLaunchKernelGGL(ksolve_finalize, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
+static void be_launch_pack(ksolve_handle* h) {
+  hipLaunchKernelGGL(ksolve_pack, dim3(1), dim3(64), 0, HB(h)->stream, h->pv, h->ws);
+  hip_check(h, hipGetLastError(), "ksolve_pack launch");
+}
+
+// queue order (queue.go:72-108): five stable LSD radix passes over 64-bit keys, least significant criterion first
+static void be_sort_pods(ksolve_handle* h) {
+  const int n = (int)h->n_pods;
+  HipBackend* b = HB(h);
+  uint32_t *in = h->d_idx_a, *out = h->d_idx_b;
+  h->pv.sorted_pods = in;
+  if (n == 0) return;
+  hipLaunchKernelGGL(ksolve_iota, grid_for(n), dim3(256), 0, b->stream, n, in);
+  for (int pass = 0; pass < 5; ++pass) {
+    ks::SortKeyArgs a = h->sort_args;
+    a.idx_in = in; a.key_out = h->d_key_a; a.pass = pass;
+    hipLaunchKernelGGL(ksolve_sort_key, grid_for(n), dim3(256), 0, b->stream, n, a);
+    size_t need = 0;
+    hip_check(h, rocprim::radix_sort_pairs(nullptr, need, h->d_key_a, h->d_key_b, in, out, (size_t)n, 0, 64, b->stream), "radix_sort_pairs(size)");
+    if (need > b->sort_tmp_bytes) {
+      if (b->sort_tmp) hipFree(b->sort_tmp);
+      b->sort_tmp = nullptr;
+      if (!hip_check(h, hipMalloc(&b->sort_tmp, need), "hipMalloc(sort)")) return;
+      b->sort_tmp_bytes = need;
+    }
+    hip_check(h, rocprim::radix_sort_pairs(b->sort_tmp, need, h->d_key_a, h->d_key_b, in, out, (size_t)n, 0, 64, b->stream), "radix_sort_pairs");
+    std::swap(in, out);
+  }
+  h->pv.sorted_pods = in;
+}
+
+static int be_device_available() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, 0) != hipSuccess) return 0;
+  return std::string(p.gcnArchName).rfind("gfx950", 0) == 0 ? 1 : 0;
+}
+
+extern "C" {
+
+ksolve_status ksolve_create(const ksolve_problem_desc* desc, const ksolve_options* opts, ksolve_handle** out) {
+  ksolve_handle* h = new ksolve_handle();
+  HipBackend* b = new HipBackend();
+  h->backend = b;
+  *out = h;
+  if (!be_device_available()) { h->error = "no usable gfx950 device (hipGetDeviceCount/hipGetDeviceProperties)"; return KSOLVE_ERR_NO_DEVICE; }
+  b->device = opts ? (int)opts->device : 0;
+  if (!hip_check(h, hipSetDevice(b->device), "hipSetDevice")) return KSOLVE_ERR_DEVICE;
+  if (!hip_check(h, hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate")) return KSOLVE_ERR_DEVICE;
+  for (int i = 0; i < 8; ++i) { hip_check(h, hipEventCreate(&b->ev0[i]), "hipEventCreate"); hip_check(h, hipEventCreate(&b->ev1[i]), "hipEventCreate"); }
+  return ksi::create(desc, opts, h);
+}
+ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out) {
+  if (!h || !h->backend) return KSOLVE_ERR_INVALID;
+  if (hipSetDevice(HB(h)->device) != hipSuccess) return KSOLVE_ERR_DEVICE;
+  return ksi::solve(h, out);
+}
+ksolve_status ksolve_cancel(ksolve_handle* h) {
+  if (!h || !h->d_cancel) return KSOLVE_ERR_INVALID;
+  int one = 1;
+  // written from another thread while the pack kernel polls the flag between pods
+  hipMemcpy(h->d_cancel, &one, sizeof(int), hipMemcpyHostToDevice);
+  return KSOLVE_OK;
+}
+void ksolve_results_free(ksolve_results* r) {
+  if (r && r->impl) { delete (ksi::ResultsImpl*)r->impl; r->impl = nullptr; }
+}
+void ksolve_destroy(ksolve_handle* h) {
+  if (!h) return;
+  HipBackend* b = HB(h);
+  if (b) {
+    if (b->stream) hipStreamSynchronize(b->stream);
+    for (void* p : h->allocations) hipFree(p);
+    if (b->sort_tmp) hipFree(b->sort_tmp);
+    if (b->stream) { for (int i = 0; i < 8; ++i) { hipEventDestroy(b->ev0[i]); hipEventDestroy(b->ev1[i]); } hipStreamDestroy(b->stream); }
+    delete b;
+  }
+  delete h;
+}
+const char* ksolve_last_error(const ksolve_handle* h) { return h ? h->error.c_str() : "null handle"; }
+uint32_t ksolve_abi_version(void) { return KSOLVE_ABI_VERSION; }
+int ksolve_device_available(void) { return be_device_available(); }
+double ksolve_last_kernel_ms(const ksolve_handle* h, const char* name) {
+  if (!h) return -1;
+  std::string n(name ? name : "");
+  if (n == "ksolve_pack") return h->timers.ms[ksi::T_PACK];
+  if (n == "classify") return h->timers.ms[ksi::T_CLASSIFY];
+  if (n == "sort") return h->timers.ms[ksi::T_SORT];
+  if (n == "it_index") return h->timers.ms[ksi::T_INDEX];
+  return -1;
+}
+
+}  // extern "C"

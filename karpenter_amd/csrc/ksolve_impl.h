@@ -426,6 +426,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   cl.hostname_seq = im->host_seq.data();
   out->bin_evaluations = ctr.bin_evaluations; out->it_evaluations = ctr.it_evaluations; out->queue_pops = ctr.queue_pops;
   out->sorts = ctr.sorts; out->slow_sorts = ctr.slow_sorts; out->relaxations = ctr.relaxations;
+  out->ref_bin_evaluations = ctr.ref_bin_evaluations;
   out->us_upload = h->timers.ms[T_UPLOAD] * 1e3;
   out->us_prepass = (h->timers.ms[T_INDEX] + h->timers.ms[T_CLASSIFY] + h->timers.ms[T_SORT]) * 1e3;
   out->us_pack = h->timers.ms[T_PACK] * 1e3; out->us_finalize = h->timers.ms[T_FINALIZE] * 1e3; out->us_download = h->timers.ms[T_DOWNLOAD] * 1e3;

@@ -76,6 +76,7 @@ struct ProblemView {
 
 struct Counters {
   unsigned long long bin_evaluations, full_evaluations, it_evaluations, queue_pops, sorts, slow_sorts, relaxations, column_resets, walk_scans;
+  unsigned long long ref_bin_evaluations;  // V: candidate bins the reference would have evaluated
 };
 
 struct Workspace {

@@ -244,6 +244,7 @@ struct ClaimOrder {
         if (cur.was_balanced && cur.was_partitioned && hint == 1) {
           if (partial_insertion_sort(a, b, top)) { done = true; break; }
         }
+        if (top) slow_sorts++;  // the outermost call leaves the single-defect fast path: full pdqsort from here on
         top = false;
         if (a > 0 && !less(a - 1, pivot)) { cur.a = partition_equal(a, b, pivot); continue; }
         bool already;
@@ -290,10 +291,7 @@ struct ClaimOrder {
       defect = -1;
       return;
     }
-    int saved = defect;
     pdqsort(0, n, bits_len((unsigned)n));
-    if (defect >= 0 || saved < 0) {}  // (defect is cleared by the fast path; any other path leaves the array sorted too)
-    if (defect >= 0) slow_sorts++;
     defect = -1;
   }
 };

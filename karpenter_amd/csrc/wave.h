@@ -11,12 +11,14 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define KS_DEVICE 1
-#define KS_FN __device__ __forceinline__
+#if defined(__HIPCC__) && !defined(KSOLVE_HOST_EMULATION)
+#define KS_DEVICE 1   // compiled by hipcc: the Wave below is the real 64-lane wavefront
+#define KS_FN __host__ __device__ __forceinline__
+#define KS_DEV __device__ __forceinline__
 #else
-#define KS_DEVICE 0
+#define KS_DEVICE 0   // g++ (host flattener, test-only emulation): a wave is a loop over 64 lanes
 #define KS_FN inline
+#define KS_DEV inline
 #endif
 
 namespace ks {
@@ -24,23 +26,23 @@ namespace ks {
 #if KS_DEVICE
 
 struct Wave {
-  KS_FN static int lane() { return (int)(threadIdx.x & 63); }
+  KS_DEV static int lane() { return (int)(threadIdx.x & 63); }
   // Orders this wave's LDS/global accesses; the wave executes in lockstep so this is a compiler + counter fence only.
-  KS_FN static void sync() {
+  KS_DEV static void sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
   template <class F>
-  KS_FN static uint64_t ballot(F f) { return __ballot(f(lane()) ? 1 : 0); }
+  KS_DEV static uint64_t ballot(F f) { return __ballot(f(lane()) ? 1 : 0); }
   // f(i) for i in [0,n), striped over lanes
   template <class F>
-  KS_FN static void for_n(int n, F f) {
+  KS_DEV static void for_n(int n, F f) {
     for (int i = lane(); i < n; i += 64) f(i);
     sync();
   }
   // smallest i in [lo,hi) with pred(i), else hi
   template <class F>
-  KS_FN static int find_first(int lo, int hi, F pred) {
+  KS_DEV static int find_first(int lo, int hi, F pred) {
     for (int base = lo; base < hi; base += 64) {
       int i = base + lane();
       uint64_t m = __ballot((i < hi && pred(i)) ? 1 : 0);
@@ -50,7 +52,7 @@ struct Wave {
   }
   // largest i in [lo,hi) with pred(i), else lo-1
   template <class F>
-  KS_FN static int find_last(int lo, int hi, F pred) {
+  KS_DEV static int find_last(int lo, int hi, F pred) {
     for (int top = hi; top > lo; top -= 64) {
       int i = top - 64 + lane();
       uint64_t m = __ballot((i >= lo && pred(i)) ? 1 : 0);
@@ -60,7 +62,7 @@ struct Wave {
   }
   // min over i in [0,n) of f(i) (u64); identity = ~0
   template <class F>
-  KS_FN static uint64_t reduce_min(int n, F f) {
+  KS_DEV static uint64_t reduce_min(int n, F f) {
     uint64_t v = ~0ull;
     for (int i = lane(); i < n; i += 64) { uint64_t x = f(i); v = x < v ? x : v; }
     for (int off = 32; off > 0; off >>= 1) {
@@ -70,7 +72,7 @@ struct Wave {
     return v;
   }
   template <class F>
-  KS_FN static int64_t reduce_max_i64(int n, F f) {
+  KS_DEV static int64_t reduce_max_i64(int n, F f) {
     int64_t v = INT64_MIN;
     for (int i = lane(); i < n; i += 64) { int64_t x = f(i); v = x > v ? x : v; }
     for (int off = 32; off > 0; off >>= 1) {
@@ -80,7 +82,7 @@ struct Wave {
     return v;
   }
   template <class F>
-  KS_FN static uint64_t reduce_or(int n, F f) {
+  KS_DEV static uint64_t reduce_or(int n, F f) {
     uint64_t v = 0;
     for (int i = lane(); i < n; i += 64) v |= f(i);
     for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
@@ -88,10 +90,10 @@ struct Wave {
   }
   // scalar store: one lane writes, every lane may read it back afterwards (same wave, program order)
   template <class T>
-  KS_FN static void store(T* p, T v) {
+  KS_DEV static void store(T* p, T v) {
     if (lane() == 0) *p = v;
   }
-  KS_FN static bool leader() { return lane() == 0; }
+  KS_DEV static bool leader() { return lane() == 0; }
 };
 
 #else  // host emulation (tests only)

@@ -387,16 +387,33 @@ static char* error_json(const char* kind, const std::string& msg) {
 
 extern "C" void ksched_free(char* p) { free(p); }
 
-// Solve a problem document on the device library at `solver_lib`. `repeat` > 1 re-runs ksolve_solve on the same handle
-// (inputs stay resident in HBM) and reports every run's timings — used by bench.py.
-extern "C" char* ksched_solve_json(const char* problem_json, const char* solver_lib, int repeat, int want_results) {
+// A problem flattened and resident on the device: what NewScheduler returns.
+struct Session {
   Api api;
-  std::string err;
-  if (!api.load(solver_lib, err)) return error_json("load", err);
   ksolve_handle* handle = nullptr;
+  Value root;
+  Flattener fl;
+  std::vector<std::string> pool_names, uid_text, res_names, it_names;
+  std::vector<std::pair<uint64_t, uint64_t>> group_of_pod;
+  std::vector<i128> scale;
+  int n_pods = 0, n_rows = 0, n_its = 0, n_res = 0, it_words = 0;
+  std::string error_kind, error;
+};
+
+static char* session_error(Session* s) { char* r = error_json(s->error_kind.c_str(), s->error); return r; }
+
+// NewScheduler: parse + flatten the problem document and upload it through ksolve_create. Returns a session handle
+// (never null); ksched_error(session) is non-null when it failed.
+extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
+  Session* S = new Session();
+  Api& api = S->api;
+  std::string err;
+  if (!api.load(solver_lib, err)) { S->error_kind = "load"; S->error = err; return S; }
+  ksolve_handle*& handle = S->handle;
   try {
-    Value root = kj::Parser(problem_json).parse();
-    Flattener fl;
+    S->root = kj::Parser(problem_json).parse();
+    Value& root = S->root;
+    Flattener& fl = S->fl;
     for (const char* k : {kNodePool, kZone, "topology.kubernetes.io/region", kInstanceType, "kubernetes.io/arch", "kubernetes.io/os", kCapacityType, "node.kubernetes.io/windows-build"}) fl.well_known.insert(k);
     for (auto& k : root.at("wellKnownLabels").items()) fl.well_known.insert(k.s());
     const Value& opts = root.at("options");
@@ -722,18 +739,65 @@ extern "C" char* ksched_solve_json(const char* problem_json, const char* solver_
 
     ksolve_status st = api.create(&d, &ko, &handle);
     if (st != KSOLVE_OK) {
-      std::string msg = handle ? api.last_error(handle) : "ksolve_create failed";
-      if (handle) api.destroy(handle);
-      return error_json(st == KSOLVE_ERR_UNSUPPORTED ? "unsupported" : st == KSOLVE_ERR_NO_DEVICE ? "no_device" : "create", msg);
+      S->error = handle ? api.last_error(handle) : "ksolve_create failed";
+      S->error_kind = st == KSOLVE_ERR_UNSUPPORTED ? "unsupported" : st == KSOLVE_ERR_NO_DEVICE ? "no_device" : "create";
+      if (handle) { api.destroy(handle); handle = nullptr; }
+      return S;
     }
+    for (auto& p : pools) S->pool_names.push_back(p.name);
+    S->uid_text = uid_text; S->group_of_pod = group_of_pod; S->res_names = res_names; S->scale = scale;
+    for (int i = 0; i < n_its; ++i) S->it_names.push_back(its_json[i].at("name").s());
+    S->n_pods = n_pods; S->n_rows = n_rows; S->n_its = n_its; S->n_res = n_res; S->it_words = it_words;
+    return S;
+  } catch (const Unsupported& e) {
+    if (S->handle) { api.destroy(S->handle); S->handle = nullptr; }
+    S->error_kind = "unsupported"; S->error = e.what();
+    return S;
+  } catch (const std::exception& e) {
+    if (S->handle) { api.destroy(S->handle); S->handle = nullptr; }
+    S->error_kind = "invalid"; S->error = e.what();
+    return S;
+  }
+}
+
+extern "C" const char* ksched_error(void* session) {
+  Session* S = (Session*)session;
+  return (S && !S->error_kind.empty()) ? S->error.c_str() : nullptr;
+}
+extern "C" const char* ksched_error_kind(void* session) {
+  Session* S = (Session*)session;
+  return (S && !S->error_kind.empty()) ? S->error_kind.c_str() : nullptr;
+}
+extern "C" void ksched_close(void* session) {
+  Session* S = (Session*)session;
+  if (!S) return;
+  if (S->handle) S->api.destroy(S->handle);
+  delete S;
+}
+
+// Solve(): one pass of the hot path on the device with the inputs already resident in HBM. want_results = 0 skips
+// the rehydration of NodeClaims (counters, timings and packing cost are always returned).
+extern "C" char* ksched_solve(void* session, int want_results) {
+  Session* S = (Session*)session;
+  if (!S || !S->handle) return S ? session_error(S) : error_json("invalid", "null session");
+  Api& api = S->api;
+  ksolve_handle* handle = S->handle;
+  Flattener& fl = S->fl;
+  Dictionary& D = fl.dict;
+  const int n_pods = S->n_pods, n_rows = S->n_rows, n_its = S->n_its, n_res = S->n_res, it_words = S->it_words;
+  const int nk = fl.kd.n_keys, rw = fl.kd.req_words;
+  const std::vector<std::string>& uid_text = S->uid_text;
+  const std::vector<std::pair<uint64_t, uint64_t>>& group_of_pod = S->group_of_pod;
+  const std::vector<std::string>& res_names = S->res_names;
+  const std::vector<i128>& scale = S->scale;
+  try {
     Value timings = Value::array();
     ksolve_results res{};
-    for (int it = 0; it < std::max(1, repeat); ++it) {
-      if (it) api.results_free(&res);
+    ksolve_status st;
+    {
       st = api.solve(handle, &res);
       if (st != KSOLVE_OK && st != KSOLVE_ERR_CANCELLED) {
         std::string msg = api.last_error(handle);
-        api.destroy(handle);
         return error_json(st == KSOLVE_ERR_UNSUPPORTED ? "unsupported" : st == KSOLVE_ERR_CAPACITY ? "capacity" : "solve", msg);
       }
       Value t = Value::object();
@@ -755,6 +819,7 @@ extern "C" char* ksched_solve_json(const char* problem_json, const char* solver_
     Value counters = Value::object();
     counters.set("binEvaluations", Value::integer((int64_t)res.bin_evaluations));
     counters.set("instanceTypeEvaluations", Value::integer((int64_t)res.it_evaluations));
+    counters.set("referenceBinEvaluations", Value::integer((int64_t)res.ref_bin_evaluations));
     counters.set("pops", Value::integer((int64_t)res.queue_pops)); counters.set("sorts", Value::integer((int64_t)res.sorts));
     counters.set("slowSorts", Value::integer((int64_t)res.slow_sorts)); counters.set("relaxations", Value::integer((int64_t)res.relaxations));
     counters.set("pods", Value::integer(n_pods)); counters.set("claims", Value::integer(cl.n_claims));
@@ -779,7 +844,7 @@ extern "C" char* ksched_solve_json(const char* problem_json, const char* solver_
       for (uint32_t c = 0; c < cl.n_claims; ++c) {
         Value cj = Value::object();
         int t = cl.template_idx[c];
-        cj.set("nodePool", Value::string(pools[t].name));
+        cj.set("nodePool", Value::string(S->pool_names[t]));
         char hb[64];
         snprintf(hb, sizeof hb, "hostname-placeholder-%04u", cl.hostname_seq[c]);
         cj.set("hostname", Value::string(hb));
@@ -788,7 +853,7 @@ extern "C" char* ksched_solve_json(const char* problem_json, const char* solver_
         for (auto& m : members[c]) pj.push(Value::string(uid_of(m.second)));
         cj.set("pods", pj);
         Value itj = Value::array();
-        for (int i = 0; i < n_its; ++i) if ((cl.it_mask[(size_t)c * cl.it_words + i / 64] >> (i % 64)) & 1) itj.push(Value::string(its_json[i].at("name").s()));
+        for (int i = 0; i < n_its; ++i) if ((cl.it_mask[(size_t)c * cl.it_words + i / 64] >> (i % 64)) & 1) itj.push(Value::string(S->it_names[i]));
         cj.set("instanceTypes", itj);
         Value rj = Value::array();
         // requirements in key-name order, like the oracle's std::map
@@ -833,13 +898,35 @@ extern "C" char* ksched_solve_json(const char* problem_json, const char* solver_
       out.set("podErrors", errs);
     }
     api.results_free(&res);
-    api.destroy(handle);
     return dup_json(out);
-  } catch (const Unsupported& e) {
-    if (handle) api.destroy(handle);
-    return error_json("unsupported", e.what());
   } catch (const std::exception& e) {
-    if (handle) api.destroy(handle);
     return error_json("invalid", e.what());
   }
+}
+
+// Convenience: open + solve (repeat times, last result returned with every run's timings) + close.
+extern "C" char* ksched_solve_json(const char* problem_json, const char* solver_lib, int repeat, int want_results) {
+  void* s = ksched_open(problem_json, solver_lib);
+  if (ksched_error(s)) { char* e = session_error((Session*)s); ksched_close(s); return e; }
+  char* out = nullptr;
+  std::vector<std::string> timings;
+  for (int i = 0; i < std::max(1, repeat); ++i) {
+    if (out) free(out);
+    out = ksched_solve(s, want_results);
+    Value v = kj::Parser(out).parse();
+    if (v.has("error")) break;
+    std::string t;
+    kj::write(v.at("timings").items()[0], t);
+    timings.push_back(t);
+  }
+  ksched_close(s);
+  Value v = kj::Parser(out).parse();
+  if (!v.has("error")) {
+    Value all = Value::array();
+    for (auto& t : timings) all.push(kj::Parser(t.c_str()).parse());
+    v.set("timings", all);
+    free(out);
+    out = dup_json(v);
+  }
+  return out;
 }

@@ -45,8 +45,15 @@ def _load_ksched():
         if not os.path.exists(KSCHED_LIB):
             raise SolverUnavailable(f"{KSCHED_LIB} is not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
         lib = ctypes.CDLL(KSCHED_LIB)
-        lib.ksched_solve_json.restype = ctypes.c_void_p
-        lib.ksched_solve_json.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+        lib.ksched_open.restype = ctypes.c_void_p
+        lib.ksched_open.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        lib.ksched_solve.restype = ctypes.c_void_p
+        lib.ksched_solve.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.ksched_error.restype = ctypes.c_char_p
+        lib.ksched_error.argtypes = [ctypes.c_void_p]
+        lib.ksched_error_kind.restype = ctypes.c_char_p
+        lib.ksched_error_kind.argtypes = [ctypes.c_void_p]
+        lib.ksched_close.argtypes = [ctypes.c_void_p]
         lib.ksched_free.argtypes = [ctypes.c_void_p]
         _ksched = lib
     return _ksched
@@ -67,28 +74,58 @@ class Results(dict):
         return not self["podErrors"]
 
 
+def _raise(kind, msg):
+    if kind == "unsupported":
+        raise Unsupported(msg)
+    if kind in ("no_device", "load"):
+        raise SolverUnavailable(msg)
+    raise RuntimeError(f"ksolve {kind}: {msg}")
+
+
 class Scheduler:
+    """scheduling.Scheduler: the problem flattened and resident in HBM (ksolve_create); Solve() runs the hot path."""
+
     def __init__(self, problem: dict, solver_lib: str | None = None):
         self.problem = problem
         self._solver_lib = solver_lib or KSOLVE_LIB
-
-    def Solve(self, repeat: int = 1, want_results: bool = True) -> Results:
-        """Runs Solve() on the device. `repeat` re-solves on the same handle (inputs stay resident in HBM)."""
         if not os.path.exists(self._solver_lib):
             raise SolverUnavailable(f"{self._solver_lib} is not built (hipcc --offload-arch=gfx950; see __graft_entry__.build)")
-        lib = _load_ksched()
-        ptr = lib.ksched_solve_json(json.dumps(self.problem).encode(), self._solver_lib.encode(), int(repeat), 1 if want_results else 0)
+        self._lib = _load_ksched()
+        self._session = self._lib.ksched_open(json.dumps(problem).encode(), self._solver_lib.encode())
+        err = self._lib.ksched_error(self._session)
+        if err is not None:
+            kind = self._lib.ksched_error_kind(self._session).decode()
+            msg = err.decode()
+            self.close()
+            _raise(kind, msg)
+
+    def close(self):
+        if getattr(self, "_session", None):
+            self._lib.ksched_close(self._session)
+            self._session = None
+
+    def __del__(self):
         try:
-            out = json.loads(ctypes.string_at(ptr).decode())
-        finally:
-            lib.ksched_free(ptr)
-        if "error" in out:
-            kind = out.get("kind")
-            if kind == "unsupported":
-                raise Unsupported(out["error"])
-            if kind in ("no_device", "load"):
-                raise SolverUnavailable(out["error"])
-            raise RuntimeError(f"ksolve {kind}: {out['error']}")
+            self.close()
+        except Exception:
+            pass
+
+    def Solve(self, repeat: int = 1, want_results: bool = True) -> Results:
+        """Runs Solve() on the device; `repeat` re-solves on the same resident inputs and collects every run's timings."""
+        if not self._session:
+            raise RuntimeError("scheduler is closed")
+        timings = []
+        out = None
+        for _ in range(max(1, int(repeat))):
+            ptr = self._lib.ksched_solve(self._session, 1 if want_results else 0)
+            try:
+                out = json.loads(ctypes.string_at(ptr).decode())
+            finally:
+                self._lib.ksched_free(ptr)
+            if "error" in out:
+                _raise(out.get("kind"), out["error"])
+            timings += out["timings"]
+        out["timings"] = timings
         return Results(out)
 
 

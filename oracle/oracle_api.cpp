@@ -221,6 +221,20 @@ char* oracle_eval_json(const char* query_json) {
       oj::Value perm = oj::Value::array();
       for (auto& e : v) perm.push(oj::Value::integer(e.second));
       out.set("result", perm);
+    } else if (fn == "order_trace") {
+      // ops: -1 = append a new claim (count 1), i >= 0 = add one pod to claim id i. Before every op the claims are
+      // re-sorted with Go's sort.Slice on the pod count, exactly like scheduler.go:598. Returns the final id order.
+      std::vector<std::pair<long long, int>> v;
+      for (auto& o : q.at("ops").items()) {
+        go_sort_slice(v, [](const std::pair<long long, int>& a, const std::pair<long long, int>& b) { return a.first < b.first; });
+        long long op = o.i();
+        if (op < 0) v.push_back({1, (int)v.size()});
+        else for (auto& e : v) if (e.second == (int)op) { e.first++; break; }
+      }
+      go_sort_slice(v, [](const std::pair<long long, int>& a, const std::pair<long long, int>& b) { return a.first < b.first; });
+      oj::Value perm = oj::Value::array();
+      for (auto& e : v) perm.push(oj::Value::integer(e.second));
+      out.set("result", perm);
     } else if (fn == "quantity") {
       out.set("result", oj::Value::string(i128_to_string(parse_quantity(q.at("value").s()))));
     } else {

@@ -82,4 +82,20 @@ double ksolve_last_kernel_ms(const ksolve_handle* h, const char* name) {
   return -1;
 }
 int ksolve_is_emulation(void) { return 1; }
+// Drives the device's claim-order emulation (pdq_emul.h) with a trace of commits; out_ids receives the final order.
+int ksolve_emu_order_trace(const int* ops, int n_ops, int* out_ids, unsigned long long* slow_sorts) {
+  std::vector<uint32_t> key(n_ops + 1), ord(n_ops + 1), pos(n_ops + 1);
+  ks::ClaimOrder<ks::Wave> o;
+  o.key = key.data(); o.ord = ord.data(); o.pos = pos.data();
+  int n_claims = 0;
+  for (int i = 0; i < n_ops; ++i) {
+    o.sort();
+    if (ops[i] < 0) o.append(n_claims++);
+    else o.increment(ops[i]);
+  }
+  o.sort();
+  for (int i = 0; i < o.n; ++i) out_ids[i] = (int)ord[i];
+  if (slow_sorts) *slow_sorts = o.slow_sorts;
+  return o.n;
+}
 }

@@ -1,0 +1,65 @@
+"""The C-ABI libraries load and export every symbol include/ksolve.h declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__
+    __graft_entry__.build()
+    return True
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "ksolve.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ksolve_[a-z_]+)\s*\(", src)))
+
+
+def test_header_declares_the_boundary():
+    fns = declared_functions()
+    for f in ("ksolve_create", "ksolve_solve", "ksolve_cancel", "ksolve_results_free", "ksolve_destroy", "ksolve_last_error"):
+        assert f in fns
+
+
+def test_libksolve_exports_every_declared_symbol(built):
+    lib = ctypes.CDLL(os.path.join(ROOT, "karpenter_amd", "libksolve.so"))
+    for f in declared_functions():
+        assert hasattr(lib, f), f
+    lib.ksolve_abi_version.restype = ctypes.c_uint32
+    assert lib.ksolve_abi_version() == 1
+    assert not hasattr(lib, "ksolve_is_emulation")  # the product library is the HIP build, never the test emulation
+
+
+def test_product_refuses_to_run_without_a_gpu(built):
+    """No CPU fallback: on a machine without a gfx950 device the product path raises instead of solving."""
+    from karpenter_amd import fixtures as fx
+    from karpenter_amd.scheduling import NewScheduler, SolverUnavailable, device_available
+    if device_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(SolverUnavailable):
+        NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], [fx.pod()])).Solve()
+
+
+def test_host_library_symbols(built):
+    lib = ctypes.CDLL(os.path.join(ROOT, "karpenter_amd", "libksched.so"))
+    for f in ("ksched_open", "ksched_solve", "ksched_close", "ksched_error", "ksched_error_kind", "ksched_free", "ksched_solve_json"):
+        assert hasattr(lib, f), f
+
+
+def test_product_never_references_the_oracle():
+    """oracle/ is test infrastructure: nothing under karpenter_amd/ or include/ may import, include or link it."""
+    bad = []
+    for base in ("karpenter_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip")):
+                    text = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"^\s*(import|from)\s+oracle\b", text, re.M) or re.search(r"#include\s+\"[^\"]*oracle/", text) or "liboracle" in text:
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,170 @@
+"""CPU tests of the DEVICE ALGORITHM: the product's engine / Go-pdqsort emulation / flat requirement algebra compiled
+for the host (tests/emu/ksolve_emu.cpp, test infrastructure only) and driven through the real C ABI and the real host
+flattener (karpenter_amd/libksched.so), compared with the oracle claim by claim (L1-strict: same claims in the same
+order with the same pod identities, instance types, requirements and requests). The GPU run of the same comparisons
+is tests/test_gpu_parity.py."""
+import ctypes
+import random
+
+import pytest
+
+import parity
+from karpenter_amd import fixtures as fx
+from karpenter_amd.scheduling import NewScheduler, Unsupported
+
+AMD = {fx.ARCH: "amd64"}
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import __graft_entry__  # builds libksched.so (host flattener); the HIP library is not needed for these tests
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ksched = os.path.join(root, "karpenter_amd", "libksched.so")
+    host = os.path.join(root, "karpenter_amd", "host", "ksched.cpp")
+    if not os.path.exists(ksched) or os.path.getmtime(host) > os.path.getmtime(ksched):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", ksched, host, "-ldl"])
+    return parity.build_emu()
+
+
+def check(oracle, emu, prob):
+    want = oracle.solve(prob)
+    got = NewScheduler(prob, solver_lib=emu).Solve()
+    parity.assert_same_results(got, want)
+    assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]  # V
+    assert abs(got["packingCost"] - want["packingCost"]) < 1e-9 * max(1.0, want["packingCost"])
+    return got, want
+
+
+def test_config1_kwok_5000_pods(oracle, emu):
+    got, _ = check(oracle, emu, fx.config1())
+    assert got["scheduledPods"] == 5000 and not got["podErrors"]
+
+
+@pytest.mark.parametrize("pods,types,seed", [(3000, 100, 7), (12000, 500, 42), (800, 144, 1)])
+def test_config2_selectors_taints(oracle, emu, pods, types, seed):
+    got, _ = check(oracle, emu, fx.config2(pods=pods, n_types=types, seed=seed))
+    assert got["scheduledPods"] == pods
+
+
+def test_reference_binpacking_cases(oracle, emu):
+    its = fx.fake_default_instance_types()
+    pods = [fx.pod(requests={"memory": "1.8G"}, node_selector=AMD) for _ in range(40)] + [fx.pod(requests={"memory": "400M"}, node_selector=AMD) for _ in range(20)]
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], pods))
+    assert len(got["newNodeClaims"]) == 20
+    check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(requests={"cpu": "1m", "memory": "1m"}, node_selector=AMD) for _ in range(25)]))
+    check(oracle, emu, fx.problem(fx.fake_instance_types(5), [fx.node_pool()], [fx.pod(requests={"cpu": "4.5"}), fx.pod(requests={"cpu": "1"})]))
+
+
+def test_unschedulable_pods_requeue_and_error_codes(oracle, emu):
+    its = fx.fake_default_instance_types()
+    pods = [fx.pod(requests={"memory": "2Ti"}), fx.pod(requests={"cpu": "1"}), fx.pod(node_selector={fx.ZONE: "nowhere"}),
+            fx.pod(node_requirements=[fx.req("undefined-key", "In", "x")]), fx.pod(requests={"cpu": "100"}), fx.pod(requests={"cpu": "2"})]
+    got, want = check(oracle, emu, fx.problem(its, [fx.node_pool()], pods))
+    assert len(got["podErrors"]) == 4
+    codes = {e["code"] for e in got["podErrors"].values()}
+    assert codes == {2, 4}  # incompatible requirements / InstanceTypeFilterError
+
+
+def test_custom_label_operators_and_gt_lt(oracle, emu):
+    key = "test-key"
+    for expr in (fx.req(key, "In", "test-value"), fx.req(key, "NotIn", "test-value"), fx.req(key, "Exists"), fx.req(key, "DoesNotExist"),
+                 fx.req(key, "In", "another-value"), fx.req(key, "NotIn", "another-value")):
+        for labels in ({}, {key: "test-value"}):
+            check(oracle, emu, fx.problem(fx.fake_default_instance_types(), [fx.node_pool(labels=labels)], [fx.pod(node_requirements=[expr])]))
+    its = fx.fake_instance_types(8)
+    for expr in (fx.req(fx.FAKE_INTEGER_LABEL, "Gt", "6"), fx.req(fx.FAKE_INTEGER_LABEL, "Lt", "3"), fx.req(fx.FAKE_INTEGER_LABEL, "Gt", "100"),
+                 fx.req(fx.FAKE_INTEGER_LABEL, "NotIn", "2", "3"), fx.req(fx.FAKE_EXOTIC_LABEL, "Exists"), fx.req(fx.FAKE_EXOTIC_LABEL, "DoesNotExist")):
+        check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(node_requirements=[expr]), fx.pod(requests={"cpu": "1"})]))
+    # NodePool with a Gt requirement narrowing the integer label, pods with Lt: bounds intersect on the claim
+    pool = fx.node_pool(requirements=[fx.req(fx.FAKE_INTEGER_LABEL, "Gt", "2")])
+    pods = [fx.pod(node_requirements=[fx.req(fx.FAKE_INTEGER_LABEL, "Lt", "6")]), fx.pod(node_requirements=[fx.req(fx.FAKE_INTEGER_LABEL, "Lt", "3")])]
+    check(oracle, emu, fx.problem(its, [pool], pods))
+
+
+def test_preference_relaxation_ladder(oracle, emu):
+    its = fx.fake_default_instance_types()
+    pods = [fx.pod(node_requirements=[fx.req(fx.ZONE, "In", "test-zone-3")], node_preferences=[fx.req(fx.ZONE, "In", "invalid")]),
+            fx.pod(node_requirements=[[fx.req(fx.ZONE, "In", "invalid")], [fx.req(fx.ZONE, "In", "test-zone-2")]]),
+            fx.pod(node_preferences=[{"weight": 1, "matchExpressions": [fx.req(fx.ARCH, "In", "arm64")]}, {"weight": 5, "matchExpressions": [fx.req(fx.ARCH, "In", "sparc")]}]),
+            fx.pod(node_requirements=[[fx.req(fx.ZONE, "In", "invalid")], [fx.req(fx.ZONE, "In", "invalid-2")]])]
+    got, want = check(oracle, emu, fx.problem(its, [fx.node_pool()], pods))
+    assert got["counters"]["relaxations"] == want["counters"]["relaxations"] > 0
+    check(oracle, emu, fx.problem(its, [fx.node_pool()], pods, options={"preferencePolicy": "Ignore"}))
+    # PreferNoSchedule taints are tolerated only after relaxation (preferences.go:133-146)
+    pool = fx.node_pool(taints=[{"key": "soft", "value": "x", "effect": "PreferNoSchedule"}])
+    check(oracle, emu, fx.problem(its, [pool], [fx.pod(), fx.pod(requests={"cpu": "1"})]))
+
+
+def test_taints_weights_and_limits(oracle, emu):
+    its = fx.fake_default_instance_types()
+    pools = [fx.node_pool("tainted", weight=10, taints=[{"key": "dedicated", "value": "x", "effect": "NoSchedule"}]), fx.node_pool("plain", weight=1)]
+    tol = [{"key": "dedicated", "operator": "Exists"}]
+    pods = [fx.pod(requests={"cpu": "1"}, tolerations=tol if i % 3 == 0 else None) for i in range(30)]
+    got, _ = check(oracle, emu, fx.problem(its, pools, pods))
+    assert {c["nodePool"] for c in got["newNodeClaims"]} == {"tainted", "plain"}
+    pools = [fx.node_pool("low", weight=1), fx.node_pool("high", weight=10, limits={"cpu": "20"})]
+    pods = [fx.pod(requests={"cpu": "3"}, node_selector=AMD) for _ in range(12)]
+    check(oracle, emu, fx.problem(its, pools, pods))
+    pools = [fx.node_pool("only", limits={"cpu": "8", "memory": "1Ti"})]
+    got, _ = check(oracle, emu, fx.problem(its, pools, pods))
+    assert any(e["code"] == 7 for e in got["podErrors"].values())  # nodepool limits
+    check(oracle, emu, fx.problem(its, [fx.node_pool("n", limits={"nodes": "0"})], pods[:2]))
+
+
+def test_empty_and_degenerate_inputs(oracle, emu):
+    its = fx.fake_default_instance_types()
+    check(oracle, emu, fx.problem(its, [fx.node_pool()], []))
+    check(oracle, emu, fx.problem(its, [fx.node_pool(requirements=[fx.req(fx.ARCH, "In", "sparc")])], [fx.pod()]))   # template filtered out: no templates
+    check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(uid="not-a-uuid-b"), fx.pod(uid="not-a-uuid-a"), fx.pod(uid="Z")]))  # rank fallback for uid order
+
+
+def test_unsupported_is_loud_not_cpu(emu):
+    lab = {"a": "b"}
+    with pytest.raises(Unsupported):
+        NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], [fx.pod(labels=lab, topology_spread=[fx.spread(fx.ZONE, lab)])]), solver_lib=emu)
+    with pytest.raises(Unsupported):
+        NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "Exists", min_values=2)])], [fx.pod()]), solver_lib=emu)
+
+
+def test_random_problems_fuzz(oracle, emu):
+    rng = random.Random(2024)
+    for trial in range(25):
+        n_types = rng.choice([6, 20, 70, 144])
+        its = fx.kwok_catalog(n_types) if rng.random() < 0.6 else fx.fake_instance_types(n_types)
+        wk = fx.KWOK_WELL_KNOWN if "kwok" in str(its[0]["requirements"]) else fx.FAKE_WELL_KNOWN
+        zones = sorted({z for t in its for r in t["requirements"] if r["key"] == fx.ZONE for z in r["values"]})
+        pools = []
+        for i in range(rng.choice([1, 1, 2, 3])):
+            taints = [{"key": "team", "value": str(i), "effect": "NoSchedule"}] if rng.random() < 0.4 else None
+            reqs = [fx.req(fx.ZONE, rng.choice(["In", "NotIn"]), rng.choice(zones))] if rng.random() < 0.3 else None
+            limits = {"cpu": str(rng.choice([4, 64, 1000]))} if rng.random() < 0.3 else None
+            pools.append(fx.node_pool(f"np-{i}", weight=rng.choice([0, 5, 5, 9]), taints=taints, requirements=reqs, limits=limits, labels={"team": str(i)} if rng.random() < 0.5 else None))
+        pods = []
+        for j in range(rng.choice([5, 40, 300])):
+            sel = {}
+            if rng.random() < 0.3: sel[fx.ZONE] = rng.choice(zones + ["nowhere"])
+            if rng.random() < 0.2: sel[fx.ARCH] = rng.choice(["amd64", "arm64"])
+            if rng.random() < 0.1: sel["team"] = rng.choice(["0", "1", "9"])
+            tol = [{"key": "team", "operator": "Exists"}] if rng.random() < 0.5 else None
+            nreq = [fx.req(fx.CAPACITY_TYPE, rng.choice(["In", "NotIn"]), rng.choice(["spot", "on-demand"]))] if rng.random() < 0.2 else None
+            pods.append(fx.pod(requests={"cpu": f"{rng.choice([100, 250, 1000, 3500])}m", "memory": f"{rng.choice([128, 512, 4096])}Mi"}, node_selector=sel, tolerations=tol,
+                               node_requirements=nreq, creation=rng.choice([0, 0, 5])))
+        check(oracle, emu, fx.problem(its, pools, pods, well_known=wk))
+
+
+def test_claim_order_emulation_matches_go_pdqsort(oracle, emu):
+    """pdq_emul.h against the oracle's literal pdqsort port on random commit traces (ties everywhere, n up to 4000)."""
+    lib = ctypes.CDLL(emu)
+    rng = random.Random(11)
+    for trial in range(40):
+        ops, n = [], 0
+        for _ in range(rng.choice([15, 49, 51, 130, 700, 4000])):
+            if n == 0 or rng.random() < rng.choice([0.02, 0.2, 0.7]):
+                ops.append(-1); n += 1
+            else:
+                ops.append(rng.randrange(n) if rng.random() < 0.5 else max(0, n - 1 - int(rng.expovariate(0.2))))
+        arr = (ctypes.c_int * len(ops))(*ops)
+        out = (ctypes.c_int * (len(ops) + 1))()
+        got_n = lib.ksolve_emu_order_trace(arr, len(ops), out, None)
+        assert list(out[:got_n]) == oracle.evaluate({"fn": "order_trace", "ops": ops}), trial

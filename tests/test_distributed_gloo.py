@@ -1,0 +1,69 @@
+"""N>1 path on CPU: world_size-2 gloo. Each rank solves its own independent scheduling problem (one NodePool component
+per rank) with the test emulation of the device solver, then the per-instance-type option-count / cost
+vector is summed with an all-reduce exactly like bench.py does over RCCL. Rank 0 checks the reduced vector against the
+oracle's solution of each shard."""
+import json
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, emu, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from karpenter_amd import fixtures as fx
+    from karpenter_amd.scheduling import NewScheduler
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob = fx.config2(pods=1500, n_types=60, seed=100 + rank)
+    res = NewScheduler(prob, solver_lib=emu).Solve()
+    names = [t["name"] for t in prob["instanceTypes"]]
+    vec = torch.zeros(len(names) + 3, dtype=torch.float64)
+    for c in res["newNodeClaims"]:
+        for t in c["instanceTypes"]:
+            vec[names.index(t)] += 1
+    vec[-3], vec[-2], vec[-1] = res["scheduledPods"], res["packingCost"], len(res["newNodeClaims"])
+    dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        q.put({"vec": vec.tolist(), "max": t.item()})
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_solve_and_allreduce():
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    import parity
+    from karpenter_amd import fixtures as fx
+    emu = parity.build_emu()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, emu, q)) for r in range(2)]
+    for p in procs: p.start()
+    out = q.get(timeout=240)
+    for p in procs: p.join(60)
+    assert all(p.exitcode == 0 for p in procs)
+    want_sched = want_cost = want_claims = 0
+    hist = None
+    for r in range(2):
+        prob = fx.config2(pods=1500, n_types=60, seed=100 + r)
+        res = oracle.solve(prob)
+        names = [t["name"] for t in prob["instanceTypes"]]
+        hist = hist or [0] * len(names)
+        for c in res["newNodeClaims"]:
+            for t in c["instanceTypes"]:
+                hist[names.index(t)] += 1
+        want_sched += 1500 - len(res["podErrors"]); want_cost += res["packingCost"]; want_claims += len(res["newNodeClaims"])
+    assert out["max"] == 2.0
+    assert [int(x) for x in out["vec"][:-3]] == hist
+    assert int(out["vec"][-3]) == want_sched and int(out["vec"][-1]) == want_claims
+    assert abs(out["vec"][-2] - want_cost) < 1e-9 * max(1.0, want_cost)

@@ -1,0 +1,90 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the product path — karpenter_amd/libksolve.so (HIP) through the C ABI
+— against the oracle on the same seeded inputs, bit-exact (L1-strict), plus size-independent properties at full size."""
+import collections
+import os
+
+import pytest
+
+import parity
+from karpenter_amd import fixtures as fx
+from karpenter_amd.scheduling import NewScheduler, device_available
+
+pytestmark = pytest.mark.gpu
+AMD = {fx.ARCH: "amd64"}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    import __graft_entry__
+    __graft_entry__.build()
+    assert device_available(), "GPU tests need a usable gfx950 device and karpenter_amd/libksolve.so (no CPU fallback)"
+
+
+def check(oracle, prob):
+    want = oracle.solve(prob)
+    got = NewScheduler(prob).Solve()
+    parity.assert_same_results(got, want)
+    assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
+    return got, want
+
+
+def test_config1_5000_pods_50_types(oracle):
+    got, _ = check(oracle, fx.config1())
+    assert got["scheduledPods"] == 5000
+
+
+@pytest.mark.parametrize("pods,types,seed", [(20000, 500, 42), (6000, 144, 3), (2000, 1000, 9)])
+def test_config2_scaled(oracle, pods, types, seed):
+    got, _ = check(oracle, fx.config2(pods=pods, n_types=types, seed=seed))
+    assert got["scheduledPods"] == pods
+
+
+def test_reference_known_answers(oracle):
+    its = fx.fake_default_instance_types()
+    pods = [fx.pod(requests={"memory": "1.8G"}, node_selector=AMD) for _ in range(40)] + [fx.pod(requests={"memory": "400M"}, node_selector=AMD) for _ in range(20)]
+    got, _ = check(oracle, fx.problem(its, [fx.node_pool()], pods))
+    assert len(got["newNodeClaims"]) == 20                                            # suite_test.go:1613-1644
+    got, _ = check(oracle, fx.problem(its, [fx.node_pool()], [fx.pod(requests={"cpu": "1m", "memory": "1m"}, node_selector=AMD) for _ in range(25)]))
+    assert len(got["newNodeClaims"]) == 5                                             # suite_test.go:1694-1715
+
+
+def test_edge_cases(oracle):
+    its = fx.fake_default_instance_types()
+    check(oracle, fx.problem(its, [fx.node_pool()], []))
+    pods = [fx.pod(requests={"memory": "2Ti"}), fx.pod(requests={"cpu": "1"}), fx.pod(node_selector={fx.ZONE: "nowhere"}),
+            fx.pod(node_requirements=[fx.req("undefined-key", "In", "x")]), fx.pod(requests={"cpu": "100"}), fx.pod(requests={"cpu": "2"})]
+    got, _ = check(oracle, fx.problem(its, [fx.node_pool()], pods))
+    assert len(got["podErrors"]) == 4
+    pools = [fx.node_pool("tainted", weight=10, taints=[{"key": "dedicated", "value": "x", "effect": "NoSchedule"}]), fx.node_pool("plain", weight=1, limits={"cpu": "12"})]
+    pods = [fx.pod(requests={"cpu": "1"}, tolerations=[{"key": "dedicated", "operator": "Exists"}] if i % 3 == 0 else None) for i in range(40)]
+    check(oracle, fx.problem(its, pools, pods))
+    its8 = fx.fake_instance_types(8)
+    for expr in (fx.req(fx.FAKE_INTEGER_LABEL, "Gt", "6"), fx.req(fx.FAKE_INTEGER_LABEL, "Lt", "3"), fx.req(fx.FAKE_EXOTIC_LABEL, "DoesNotExist")):
+        check(oracle, fx.problem(its8, [fx.node_pool()], [fx.pod(node_requirements=[expr]), fx.pod(requests={"cpu": "1"})]))
+    pods = [fx.pod(node_requirements=[fx.req(fx.ZONE, "In", "test-zone-3")], node_preferences=[fx.req(fx.ZONE, "In", "invalid")]),
+            fx.pod(node_requirements=[[fx.req(fx.ZONE, "In", "invalid")], [fx.req(fx.ZONE, "In", "test-zone-2")]])]
+    check(oracle, fx.problem(its, [fx.node_pool()], pods))
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] scale (the oracle cannot run this in seconds): properties that hold for any correct packing."""
+    n = int(os.environ.get("KSOLVE_FULL_PODS", "200000"))
+    prob = fx.config2(pods=n)
+    s = NewScheduler(prob)
+    a = s.Solve()
+    b = s.Solve()  # idempotence: a second Solve on the same resident inputs gives the same packing
+    assert a["scheduledPods"] == n and not a["podErrors"]
+    assert a["counters"]["claims"] == b["counters"]["claims"] and a["packingCost"] == b["packingCost"]
+    seen = collections.Counter()
+    catalog = {t["name"]: t for t in prob["instanceTypes"]}
+    for c, c2 in zip(a["newNodeClaims"], b["newNodeClaims"]):
+        assert c["pods"] == c2["pods"] and c["instanceTypes"] == c2["instanceTypes"]
+        seen.update(c["pods"])
+        assert c["instanceTypes"], "a claim without a surviving instance type"
+        cpu = int(c["requests"]["cpu"]); pods = int(c["requests"]["pods"]) // 10**9
+        assert pods == len(c["pods"])
+        # some surviving type must hold the claim's total (kwok allocatable = capacity - 100m cpu)
+        assert any(cpu <= int(catalog[t]["capacity"]["cpu"]) * 10**9 - 10**8 and pods <= int(catalog[t]["capacity"]["pods"]) for t in c["instanceTypes"])
+    assert len(seen) == n and set(seen.values()) == {1}  # every pod placed exactly once
+    counts = [len(c["pods"]) for c in a["newNodeClaims"]]
+    assert counts == sorted(counts)  # Results keep the reference's final claim order: sorted by pod count (scheduler.go:598)
