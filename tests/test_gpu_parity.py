@@ -86,5 +86,8 @@ def test_full_size_properties():
         # some surviving type must hold the claim's total (kwok allocatable = capacity - 100m cpu)
         assert any(cpu <= int(catalog[t]["capacity"]["cpu"]) * 10**9 - 10**8 and pods <= int(catalog[t]["capacity"]["pods"]) for t in c["instanceTypes"])
     assert len(seen) == n and set(seen.values()) == {1}  # every pod placed exactly once
+    # Results keep the reference's final s.newNodeClaims order: sorted by pod count (scheduler.go:598) except for the one
+    # claim the last pod touched (no sort runs after the final commit)
     counts = [len(c["pods"]) for c in a["newNodeClaims"]]
-    assert counts == sorted(counts)  # Results keep the reference's final claim order: sorted by pod count (scheduler.go:598)
+    drops = [i for i in range(1, len(counts)) if counts[i] < counts[i - 1]]
+    assert len(drops) <= 1
