@@ -4,13 +4,18 @@
 // Why one wave: first-fit-decreasing is a serial chain — every commit changes the claim it lands on, the claim order
 // (scheduler.go:598) and the NodePool limits the next pod sees — so control is wave-uniform scalar code. The 64 lanes
 // are the vector unit for what IS parallel inside a step:
-//   * instance-type filtering (filterInstanceTypesByRequirements, nodeclaim.go:541-618): one lane per instance type,
-//     requirement compatibility from precomputed per-(key,value) instance-type bitmasks, resource fit and offering
-//     availability per lane, __ballot -> one u64 word of the surviving InstanceTypeOptions mask;
+//   * requirement-set intersection (Requirements.Compatible / Add, requirements.go:181-197,133-140): one lane per
+//     dictionary mask word, three ballots give per-key "has intersection / non-empty" for all keys at once;
+//   * instance-type filtering (filterInstanceTypesByRequirements, nodeclaim.go:541-618): requirement compatibility from
+//     per-(key,value) instance-type bitmasks, resource fit and offering availability one lane per instance type,
+//     __ballot -> one u64 word of the surviving InstanceTypeOptions mask;
 //   * first-fit selection over the in-flight claims in the reference's order with "lowest index wins"
-//     (scheduler.go:667-686): ballot + ffs over candidate lists;
-//   * the claim re-ordering (pdq_emul.h) and bulk state moves.
-// Independent problems (NodePool components, consolidation probes) run as independent waves on other CUs.
+//     (scheduler.go:667-686): ballot over the class's dead row, gather, reduce_min on (position, claim);
+//   * the claim re-ordering (pdq_emul.h) and record moves.
+// Latency discipline (a single wave cannot hide a dependent HBM/L2 round trip): instance-type tables, templates and
+// the claim order live in LDS; a claim / class is moved as ONE contiguous record with one coalesced load (lane i moves
+// word i); queue entries are fetched 64 at a time. Independent problems (NodePool components, consolidation probes)
+// run as independent waves.
 //
 // Exact pruning: dead[class][claim] caches "CanAdd(claim, pod of this class) failed". Between two changes of a
 // claim's requirement set that verdict is monotone (requests only grow, InstanceTypeOptions only shrink), so the bit
@@ -26,73 +31,163 @@ enum {
   E_LIMITS = 7, E_RESERVED = 8, E_EXISTING = 9, E_MIN_VALUES = 10
 };
 
+constexpr int kMaxHot = kMaxReqWords + kMaxItWords + 2 * kMaxRes + 4;
+constexpr int kMaxCold = 2 * kMaxKeys + (kMaxKeys + 1) / 2;
+
 struct Scratch {
-  ReqBuf merged;
-  uint64_t cm[kMaxItWords];    // instance types compatible with `merged`
-  uint64_t its[kMaxItWords];   // surviving InstanceTypeOptions
-  uint64_t lim[kMaxItWords];   // instance types within NodePool limits
-  uint64_t cand[64];           // candidate list: (position << 32 | claim)
+  ReqBuf merged;                    // slow-path working set (bounds / minValues / very wide dictionaries)
+  uint64_t cm[kMaxItWords];         // instance types compatible with the merged requirements
+  uint64_t its[kMaxItWords];        // surviving InstanceTypeOptions
+  uint64_t lim[kMaxItWords];        // instance types within NodePool limits
+  uint64_t cand[64];                // candidate list: (position << 32 | claim)
+  uint64_t stage[64];               // live words of the class's dead row
   int64_t total[kMaxRes];
-  int64_t head[kMaxRes];
+  uint64_t claim[kMaxHot];          // candidate bin, hot record
+  uint64_t claim_cold[kMaxCold];
+  uint64_t cls[kMaxReqWords + kMaxRes + 4];
+  uint64_t cls_cold[kMaxCold];
+  uint64_t out[kMaxHot];            // record being committed
+  uint64_t out_cold[kMaxCold];
+  uint32_t blk_pod[64], blk_class[64], blk_last[64];
+  uint8_t word_key[kMaxReqWords];   // dictionary word -> key
+};
+
+struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host buffer (test emulation)
+  int64_t* alloc;       // [nr][iw*64]
+  uint64_t* avail;      // [iw*64]
+  uint64_t* kv;         // [n_kv][iw]
+  uint64_t* keymask;    // [3][nk][iw]
+  uint64_t* allocok;    // [iw]
+  uint16_t* kvslot;     // [rw*64]
+  uint64_t* tmpl;       // [T][c_hot_words]
+  uint64_t* tmpl_cold;  // [T][cold_words]
+  uint32_t *okey, *oord, *opos;
+  Scratch* scratch;
+  KS_FN void bind(char* base, const LdsPlan& p) {
+    alloc = (int64_t*)(base + p.off_alloc); avail = (uint64_t*)(base + p.off_avail); kv = (uint64_t*)(base + p.off_kv);
+    keymask = (uint64_t*)(base + p.off_keymask); allocok = (uint64_t*)(base + p.off_allocok); kvslot = (uint16_t*)(base + p.off_kvslot);
+    tmpl = (uint64_t*)(base + p.off_tmpl); tmpl_cold = (uint64_t*)(base + p.off_tmplcold);
+    okey = (uint32_t*)(base + p.off_order); oord = okey + p.order_cap; opos = oord + p.order_cap;
+    scratch = (Scratch*)(base + p.off_scratch);
+  }
 };
 
 template <class W>
 struct Engine {
   const ProblemView& P;
   Workspace& S;
+  LdsTables L;
   Scratch& sc;
+  const RecLayout lay;
   ClaimOrder<W> order;
   int n_claims = 0;
+  bool order_in_lds = true;
   uint32_t host_seq = 0;
   uint32_t active_templates = 0;
   int last_err = 0, last_diag = 0;
   Counters ctr{};
 
-  KS_FN Engine(const ProblemView& p, Workspace& s, Scratch& scratch) : P(p), S(s), sc(scratch) {
-    order.key = s.o_key; order.ord = s.o_ord; order.pos = s.o_pos;
+  KS_DEV Engine(const ProblemView& p, Workspace& s, const LdsTables& l) : P(p), S(s), L(l), sc(*l.scratch), lay(p.lay) {
+    order.key = L.okey; order.ord = L.oord; order.pos = L.opos;
+  }
+
+  // ------------------------------------------------------------------------------------------------------------
+  // record helpers
+  KS_DEV void load_words(uint64_t* dst, const uint64_t* src, int n) {
+    W::for_n(n, [&](int i) { dst[i] = src[i]; });
+  }
+  KS_DEV static uint32_t lo32(uint64_t v) { return (uint32_t)v; }
+  KS_DEV static uint32_t hi32(uint64_t v) { return (uint32_t)(v >> 32); }
+  KS_DEV ReqRef claim_ref(const uint64_t* hot, const uint64_t* cold) const {
+    ReqRef r;
+    uint64_t f0 = hot[lay.c_f0()], f1 = hot[lay.c_f1()];
+    r.mask = hot + lay.c_mask(); r.defined = lo32(f0); r.complement = hi32(f0); r.has_gte = lo32(f1); r.has_lte = hi32(f1);
+    r.gte = (const int64_t*)cold; r.lte = (const int64_t*)(cold + lay.nk);
+    r.minv = (hi32(hot[lay.c_meta2()]) & 2u) ? (const int32_t*)(cold + 2 * lay.nk) : nullptr;
+    return r;
+  }
+  KS_DEV ReqRef class_ref(const uint64_t* hot, const uint64_t* cold) const {
+    ReqRef r;
+    uint64_t f0 = hot[lay.k_f0()], f1 = hot[lay.k_f1()];
+    r.mask = hot + lay.k_mask(); r.defined = lo32(f0); r.complement = hi32(f0); r.has_gte = lo32(f1); r.has_lte = hi32(f1);
+    r.gte = (const int64_t*)cold; r.lte = (const int64_t*)(cold + lay.nk);
+    r.minv = (lo32(hot[lay.k_meta()]) & 1u) ? (const int32_t*)(cold + 2 * lay.nk) : nullptr;
+    return r;
+  }
+
+  // ------------------------------------------------------------------------------------------------------------
+  // one-time: instance-type tables, dictionary helpers and templates into LDS
+  KS_DEV void load_tables() {
+    const Dict& d = P.dict;
+    const int nr = P.n_res, iw = P.it_words, n_its = P.n_its, np = iw * 64;
+    const ProblemView& Pv = P;
+    LdsTables& Lt = L;
+    for (int r = 0; r < nr; ++r)
+      W::for_n(np, [&](int it) { Lt.alloc[(size_t)r * np + it] = it < n_its ? Pv.it_alloc[(size_t)r * n_its + it] : INT64_MIN; });
+    W::for_n(np, [&](int it) { Lt.avail[it] = it < n_its ? Pv.it_off_avail[it] : 0; });
+    W::for_n(iw, [&](int w) { Lt.allocok[w] = Pv.it_alloc_ok[w]; });
+    const int nki = d.n_keys * iw;
+    W::for_n(3 * nki, [&](int i) {
+      int which = i / nki, rest = i % nki;
+      const uint64_t* src = which == 0 ? Pv.key_undef : which == 1 ? Pv.key_compl : Pv.key_neg;
+      Lt.keymask[i] = src[rest];
+    });
+    W::for_n(d.req_words * 64, [&](int v) {
+      uint16_t slot = Pv.kv_slot[v];
+      Lt.kvslot[v] = slot;
+      if (slot != 0xFFFF) for (int w = 0; w < iw; ++w) Lt.kv[(size_t)slot * iw + w] = Pv.kv_has[(size_t)v * iw + w];
+    });
+    uint8_t* wk = sc.word_key;
+    if (W::leader())
+      for (int k = 0; k < d.n_keys; ++k)
+        for (uint32_t w = d.key_word_off[k]; w < d.key_word_off[k + 1]; ++w) wk[w] = (uint8_t)k;
+    W::sync();
   }
 
   // ------------------------------------------------------------------------------------------------------------
   // Instance types compatible with a requirement set: InstanceType.Requirements.Intersects(reqs) == nil for every
-  // instance type at once (nodeclaim.go:620-622, requirements.go:254-274), one u64 word per 64 instance types.
-  KS_FN void compat_mask(const ReqBuf& m) {
+  // type at once (nodeclaim.go:620-622, requirements.go:254-274). Only keys that some instance type defines can
+  // exclude a type.
+  KS_DEV void compat_mask(const ReqRef& q) {
     const Dict& d = P.dict;
-    const ProblemView& Pv = P;
+    const LdsTables& Lt = L;
     uint64_t* cm = sc.cm;
-    const int iw = P.it_words;
+    const uint64_t* m = q.mask;
+    const int iw = P.it_words, nk = d.n_keys;
+    const uint32_t keys0 = q.defined & (P.it_keys | (d.key_it >= 0 ? (1u << d.key_it) : 0u));
     W::for_n(iw, [&](int w) {
       uint64_t acc = ~0ull;
-      uint32_t keys = m.defined;
+      uint32_t keys = keys0;
       while (keys) {
         int k = __builtin_ctz(keys);
         keys &= keys - 1;
         uint32_t w0 = d.key_word_off[k], w1 = d.key_word_off[k + 1];
-        bool comp = bit(m.complement, k);
-        bool hg = bit(m.has_gte, k), hl = bit(m.has_lte, k);
+        bool comp = bit(q.complement, k);
+        bool hg = bit(q.has_gte, k), hl = bit(q.has_lte, k);
+        int64_t g = hg ? q.gte[k] : 0, l = hl ? q.lte[k] : 0;
         if (k == d.key_it) {
           // the instance-type key's dictionary IS the instance-type list and every type requires In [own name]
-          uint64_t mm = m.mask[w0 + w];
-          uint64_t v = comp ? inbounds_word(d, w0 + w, ~mm, hg, m.gte[k], hl, m.lte[k]) : mm;
-          acc &= v;
+          uint64_t mm = m[w0 + w];
+          acc &= comp ? inbounds_word(d, w0 + w, ~mm, hg, g, hl, l) : mm;
           continue;
         }
-        uint64_t r = Pv.key_undef[(size_t)k * iw + w];
+        uint64_t r = Lt.keymask[(size_t)k * iw + w];                                  // key_undef
         bool nonempty = false;
         if (!comp) {
           for (uint32_t x = w0; x < w1; ++x) {
-            uint64_t bits = m.mask[x];
+            uint64_t bits = m[x];
             if (bits) nonempty = true;
-            while (bits) { int b = ctz64(bits); bits &= bits - 1; r |= Pv.kv_has[((size_t)x * 64 + b) * iw + w]; }
+            while (bits) { int b = ctz64(bits); bits &= bits - 1; uint16_t s = Lt.kvslot[x * 64 + b]; if (s != 0xFFFF) r |= Lt.kv[(size_t)s * iw + w]; }
           }
-          if (!nonempty) r |= Pv.key_neg[(size_t)k * iw + w];  // DoesNotExist vs {NotIn, DoesNotExist}: requirements.go:260-265
+          if (!nonempty) r |= Lt.keymask[(size_t)(2 * nk + k) * iw + w];             // DoesNotExist vs {NotIn, DoesNotExist}: requirements.go:260-265
         } else {
-          r |= Pv.key_compl[(size_t)k * iw + w];               // two complements always intersect: requirement.go:226-228
+          r |= Lt.keymask[(size_t)(nk + k) * iw + w];                                 // two complements always intersect: requirement.go:226-228
           for (uint32_t x = w0; x < w1; ++x) {
-            if (m.mask[x]) nonempty = true;
-            uint64_t bits = inbounds_word(d, x, ~m.mask[x] & d.value_valid[x], hg, m.gte[k], hl, m.lte[k]);
-            while (bits) { int b = ctz64(bits); bits &= bits - 1; r |= Pv.kv_has[((size_t)x * 64 + b) * iw + w]; }
+            if (m[x]) nonempty = true;
+            uint64_t bits = inbounds_word(d, x, ~m[x] & d.value_valid[x], hg, g, hl, l);
+            while (bits) { int b = ctz64(bits); bits &= bits - 1; uint16_t s = Lt.kvslot[x * 64 + b]; if (s != 0xFFFF) r |= Lt.kv[(size_t)s * iw + w]; }
           }
-          if (nonempty) r |= Pv.key_neg[(size_t)k * iw + w];   // NotIn vs {NotIn, DoesNotExist}
+          if (nonempty) r |= Lt.keymask[(size_t)(2 * nk + k) * iw + w];              // NotIn vs {NotIn, DoesNotExist}
         }
         acc &= r;
       }
@@ -100,16 +195,15 @@ struct Engine {
     });
   }
 
-  // zone x capacity-type cells an offering may sit in to be compatible with `m` (types.go:553-570:
+  // zone x capacity-type cells an offering may sit in to be compatible with the requirements (types.go:553-570:
   // reqs.IsCompatible(offering.Requirements, AllowUndefinedWellKnownLabels); offerings carry single In values).
-  KS_FN uint64_t offering_cells(const ReqBuf& m) {
+  KS_DEV uint64_t offering_cells(const ReqRef& r) {
     const Dict& d = P.dict;
-    ReqRef r = m.ref();
     uint32_t zones = 0, cts = 0;
-    if (d.key_zone >= 0 && bit(m.defined, d.key_zone)) {
+    if (d.key_zone >= 0 && bit(r.defined, d.key_zone)) {
       for (int z = 0; z < P.n_zones; ++z) if (req_has(d, r, d.key_zone, d.key_word_off[d.key_zone], z)) zones |= 1u << z;
     } else zones = (1u << P.n_zones) - 1;
-    if (d.key_ct >= 0 && bit(m.defined, d.key_ct)) {
+    if (d.key_ct >= 0 && bit(r.defined, d.key_ct)) {
       for (int c = 0; c < P.n_cts; ++c) if (req_has(d, r, d.key_ct, d.key_word_off[d.key_ct], c)) cts |= 1u << c;
     } else cts = (1u << P.n_cts) - 1;
     uint64_t cells = 0;
@@ -118,32 +212,32 @@ struct Engine {
   }
 
   // filterInstanceTypesByRequirements for one candidate bin: its' = its ∩ compatible ∩ fits ∩ hasOffering.
-  // Returns whether any instance type survives; fills sc.its. diag (InstanceTypeFilterError flags) only if asked.
-  KS_FN bool filter_instance_types(const uint64_t* bin_its, const int64_t* total, bool want_diag) {
-    compat_mask(sc.merged);
-    uint64_t cells = offering_cells(sc.merged);
-    const ProblemView& Pv = P;
-    const int nr = P.n_res, n_its = P.n_its;
+  // `full` = the requirement set differs from the bin's own, so compatibility and offerings must be re-evaluated; when
+  // the requirements are unchanged the bin's instance types already satisfy both (they were filtered by these very
+  // requirements at the last commit, nodeclaim.go:250-253) and only the resource fit can drop types.
+  KS_DEV bool filter_instance_types(const uint64_t* bin_its, const int64_t* total, bool full, const ReqRef& reqs, bool want_diag) {
+    uint64_t cells = ~0ull;
+    if (full) {
+      compat_mask(reqs);
+      cells = offering_cells(reqs);
+    }
+    const LdsTables& Lt = L;
+    const int nr = P.n_res, np = P.it_words * 64;
     uint64_t any = 0;
     bool d_req = false, d_fit = false, d_off = false, d_ro = false, d_fo = false;
     for (int w = 0; w < P.it_words; ++w) {
       uint64_t in = bin_its[w];
-      if (!in) { W::store(&sc.its[w], (uint64_t)0); continue; }
-      uint64_t cm = sc.cm[w];
-      if (!want_diag && !(in & cm)) { W::store(&sc.its[w], (uint64_t)0); continue; }
-      uint64_t aok = Pv.it_alloc_ok[w];
+      uint64_t cm = full ? sc.cm[w] : ~0ull;
+      if (!in || (!want_diag && !(in & cm))) { W::store(&sc.its[w], (uint64_t)0); continue; }
+      uint64_t aok = Lt.allocok[w];
       uint64_t fit = W::ballot([&](int l) {
+        if (!((in >> l) & 1)) return false;
         int it = w * 64 + l;
-        if (it >= n_its || !((in >> l) & 1)) return false;
         bool f = (aok >> l) & 1;
-        for (int r = 0; r < nr; ++r) f = f && total[r] <= Pv.it_alloc[(size_t)r * n_its + it];
+        for (int r = 0; r < nr; ++r) f = f && total[r] <= Lt.alloc[(size_t)r * np + it];
         return f;
       });
-      uint64_t off = W::ballot([&](int l) {
-        int it = w * 64 + l;
-        if (it >= n_its || !((in >> l) & 1)) return false;
-        return (Pv.it_off_avail[it] & cells) != 0;
-      });
+      uint64_t off = full ? W::ballot([&](int l) { return ((in >> l) & 1) && (Lt.avail[w * 64 + l] & cells) != 0; }) : in;
       ctr.it_evaluations += popc64(in);
       uint64_t itfits = fit & off;  // fits() reports itFits only together with a compatible offering (nodeclaim.go:624-638)
       uint64_t keep = in & cm & itfits;
@@ -160,67 +254,188 @@ struct Engine {
   }
 
   // ------------------------------------------------------------------------------------------------------------
-  // NodeClaim.CanAdd (nodeclaim.go:124-242) for a pod of class k on a bin described by (reqs, its, total, taints).
-  // On success sc.merged / sc.its / sc.total hold the updated requirements, instance types and requests.
-  KS_FN int can_add(int k, const ReqRef& bin_reqs, const uint64_t* bin_its, const int64_t* bin_total, const int64_t* bin_head,
-                    uint64_t bin_taints, bool want_diag, bool* reqs_changed) {
+  // Requirements.Compatible + Add for a bin record against the class record in sc.cls, both without bounds, one lane
+  // per dictionary word. Writes the merged masks + flag words into sc.out. Returns false when incompatible.
+  KS_DEV bool fast_compat_merge(const uint64_t* bin, uint32_t kdef, bool* changed) {
     const Dict& d = P.dict;
+    const int rw = lay.rw;
+    const uint64_t f0 = bin[lay.c_f0()];
+    const uint32_t cdef = lo32(f0), ccomp = hi32(f0);
+    const uint32_t kcomp = hi32(sc.cls[lay.k_f0()]) & kdef;
+    const uint64_t* a = bin + lay.c_mask();
+    const uint64_t* b = sc.cls + lay.k_mask();
+    const uint8_t* wk = sc.word_key;
+    const uint32_t both = cdef & kdef;
+    uint32_t undef = kdef & ~cdef & ~d.well_known_mask;
+    uint64_t NA = 0, NB = 0, H = 0;
+    if (both | undef) {
+      NB = W::ballot([&](int l) { return l < rw && b[l] != 0; });
+      if (both) {
+        NA = W::ballot([&](int l) { return l < rw && a[l] != 0; });
+        H = W::ballot([&](int l) {
+          if (l >= rw) return false;
+          int k = wk[l];
+          bool ca = (ccomp >> k) & 1, cb = (kcomp >> k) & 1;
+          uint64_t x = a[l], y = b[l];
+          return (ca ? (cb ? ~0ull : (y & ~x)) : (cb ? (x & ~y) : (x & y))) != 0;
+        });
+      }
+    }
+    auto lanes_of = [&](int k) { uint32_t w0 = d.key_word_off[k], n = d.key_word_off[k + 1] - w0; return (n >= 64 ? ~0ull : ((1ull << n) - 1)) << w0; };
+    while (undef) {  // a key the bin does not define: only NotIn / DoesNotExist may pass (requirements.go:185-193)
+      int k = __builtin_ctz(undef);
+      undef &= undef - 1;
+      bool ne = (NB & lanes_of(k)) != 0;
+      bool comp = (kcomp >> k) & 1;
+      if (!(comp ? ne : !ne)) return false;
+    }
+    uint32_t bk = both;
+    while (bk) {  // Intersects — requirements.go:254-274
+      int k = __builtin_ctz(bk);
+      bk &= bk - 1;
+      uint64_t ln = lanes_of(k);
+      bool ca = (ccomp >> k) & 1, cb = (kcomp >> k) & 1;
+      if ((ca && cb) || (H & ln)) continue;
+      bool nea = (NA & ln) != 0, neb = (NB & ln) != 0;
+      bool nega = ca ? nea : !nea, negb = cb ? neb : !neb;
+      if (nega && negb) continue;
+      return false;
+    }
+    // merge (Requirement.Intersection per key, requirement.go:181-214 without bounds)
+    uint64_t* o = sc.out + lay.c_mask();
+    uint64_t diff = 0;
+    if (kdef) {
+      diff = W::ballot([&](int l) {
+        if (l >= rw) return false;
+        int k = wk[l];
+        uint64_t x = a[l], v = x;
+        if ((kdef >> k) & 1) {
+          uint64_t y = b[l];
+          if (!((cdef >> k) & 1)) v = y;
+          else {
+            bool ca = (ccomp >> k) & 1, cb = (kcomp >> k) & 1;
+            v = ca ? (cb ? (x | y) : (y & ~x)) : (cb ? (x & ~y) : (x & y));
+          }
+        }
+        o[l] = v;
+        return v != x;
+      });
+    } else {
+      W::for_n(rw, [&](int l) { o[l] = a[l]; });
+    }
+    const uint32_t ndef = cdef | kdef;
+    const uint32_t ncomp = (ccomp & ~kdef) | (ccomp & kcomp & both) | (kcomp & ~cdef);
+    if (W::leader()) { sc.out[lay.c_f0()] = (uint64_t)ndef | ((uint64_t)ncomp << 32); sc.out[lay.c_f1()] = 0; }
+    W::sync();
+    *changed = diff != 0 || ndef != cdef || ncomp != ccomp;
+    return true;
+  }
+
+  // NodeClaim.CanAdd (nodeclaim.go:124-242) for a pod of the class in sc.cls on the bin record `bin`/`bin_cold`.
+  // On success sc.out holds the committed record's masks and flag words, sc.its / sc.total the new instance types and
+  // requests (finish_record completes head/meta and writes the record).
+  KS_DEV int can_add(const uint64_t* bin, const uint64_t* bin_cold, bool fresh, bool want_diag, bool* reqs_changed, bool* its_changed) {
+    const Dict& d = P.dict;
+    const int nr = lay.nr;
     ctr.bin_evaluations++;
-    if (bin_taints & ~P.cls_tolerates[k]) return E_TAINTS;                       // Taints.ToleratesPod — nodeclaim.go:126
-    const int64_t* req = P.cls_requests + (size_t)k * P.n_res;
-    if (bin_head) for (int r = 0; r < P.n_res; ++r) if (req[r] > bin_head[r]) return E_INSTANCE_TYPES;  // no remaining type can hold it
-    ReqRef q = P.cls_reqs.at(d, k);
+    const uint64_t bin_taints = P.tmpl_taints[lo32(bin[lay.c_meta()])];
+    if (bin_taints & ~sc.cls[lay.k_tol()]) return E_TAINTS;                              // Taints.ToleratesPod — nodeclaim.go:126
+    const int64_t* req = (const int64_t*)(sc.cls + lay.k_req());
+    const int64_t* head = (const int64_t*)(bin + lay.c_head());
+    const int64_t* tot = (const int64_t*)(bin + lay.c_total());
+    for (int r = 0; r < nr; ++r) if (req[r] > head[r]) return E_INSTANCE_TYPES;           // no remaining instance type can hold it
+    uint32_t kdef = lo32(sc.cls[lay.k_f0()]);
     int hn = d.key_hostname;
-    if (hn >= 0 && bit(q.defined, hn)) {
+    if (hn >= 0 && ((kdef >> hn) & 1)) {
       // the claim's own hostname requirement is In [hostname-placeholder-N] (nodeclaim.go:97), a value outside every
       // dictionary: only an unbounded complement (NotIn / Exists) on the pod side intersects it.
-      if (!bit(q.complement, hn) || bit(q.has_gte | q.has_lte, hn)) return E_INCOMPATIBLE;
-      q.defined &= ~(1u << hn);
+      uint32_t kc = hi32(sc.cls[lay.k_f0()]);
+      uint64_t kf1 = sc.cls[lay.k_f1()];
+      if (!((kc >> hn) & 1) || (((lo32(kf1) | hi32(kf1)) >> hn) & 1)) return E_INCOMPATIBLE;
+      kdef &= ~(1u << hn);
     }
-    if (reqs_compatible(d, bin_reqs, q, true) != COMPAT_OK) return E_INCOMPATIBLE;  // nodeclaim.go:133
+    const bool bin_minv = (hi32(bin[lay.c_meta2()]) & 2u) != 0, cls_minv = (lo32(sc.cls[lay.k_meta()]) & 1u) != 0;
+    const bool slow = bin[lay.c_f1()] != 0 || sc.cls[lay.k_f1()] != 0 || cls_minv || lay.rw > 64;
+    bool changed = false;
+    ReqRef merged;
+    if (!slow) {
+      if (!fast_compat_merge(bin, kdef, &changed)) return E_INCOMPATIBLE;               // nodeclaim.go:133-136
+      merged.mask = sc.out + lay.c_mask(); merged.defined = lo32(sc.out[lay.c_f0()]); merged.complement = hi32(sc.out[lay.c_f0()]);
+      merged.has_gte = merged.has_lte = 0; merged.gte = merged.lte = nullptr; merged.minv = nullptr;
+      if (bin_minv) {  // minValues of the bin carry over (pods cannot add any)
+        const uint64_t* bc = bin_cold; uint64_t* oc = sc.out_cold;
+        W::for_n(lay.cold_words(), [&](int i) { oc[i] = bc[i]; });
+      }
+    } else {
+      ReqRef br = claim_ref(bin, bin_cold);
+      ReqRef q = class_ref(sc.cls, sc.cls_cold);
+      q.defined = kdef;
+      if (reqs_compatible(d, br, q, true) != COMPAT_OK) return E_INCOMPATIBLE;
+      reqbuf_load(d, sc.merged, br);
+      changed = reqbuf_add(d, sc.merged, q);
+      const ReqBuf& m = sc.merged;
+      uint64_t* o = sc.out;
+      W::for_n(lay.rw, [&](int w) { o[w] = m.mask[w]; });
+      if (W::leader()) {
+        o[lay.c_f0()] = (uint64_t)m.defined | ((uint64_t)m.complement << 32);
+        o[lay.c_f1()] = (uint64_t)m.has_gte | ((uint64_t)m.has_lte << 32);
+      }
+      int64_t* cg = (int64_t*)sc.out_cold; int64_t* cl = cg + lay.nk; int32_t* cv = (int32_t*)(sc.out_cold + 2 * lay.nk);
+      W::for_n(lay.nk, [&](int k) { cg[k] = m.gte[k]; cl[k] = m.lte[k]; cv[k] = m.minv[k]; });
+      merged.mask = sc.out + lay.c_mask(); merged.defined = m.defined; merged.complement = m.complement;
+      merged.has_gte = m.has_gte; merged.has_lte = m.has_lte; merged.gte = cg; merged.lte = cl; merged.minv = cv;
+    }
     ctr.full_evaluations++;
-    reqbuf_load(d, sc.merged, bin_reqs);
-    bool changed = reqbuf_add(d, sc.merged, q);                                      // nodeclaim.go:136
     if (reqs_changed) *reqs_changed = changed;
-    for (int r = 0; r < P.n_res; ++r) W::store(&sc.total[r], bin_total[r] + req[r]);  // resources.Merge — nodeclaim.go:211
-    W::sync();
-    if (!filter_instance_types(bin_its, sc.total, want_diag)) return E_INSTANCE_TYPES;  // nodeclaim.go:213
+    int64_t* ntot = sc.total;
+    W::for_n(nr, [&](int r) { ntot[r] = tot[r] + req[r]; });                               // resources.Merge — nodeclaim.go:211
+    const bool full = changed || fresh;
+    if (!filter_instance_types(bin + lay.c_its(), sc.total, full, merged, want_diag)) return E_INSTANCE_TYPES;  // nodeclaim.go:213
+    if (its_changed) {
+      const uint64_t* bi = bin + lay.c_its();
+      const uint64_t* ni = sc.its;
+      const int iw = lay.iw;
+      *its_changed = W::ballot([&](int l) { return l < iw && bi[l] != ni[l]; }) != 0;
+    }
     return E_OK;
   }
 
-  // ---- claim state ------------------------------------------------------------------------------------------
-  KS_FN void write_claim(int c, int tmpl, bool fresh) {
-    const Dict& d = P.dict;
-    const int nr = P.n_res, iw = P.it_words;
-    if (fresh) { W::store(&S.c_tmpl[c], (int32_t)tmpl); W::store(&S.c_host_seq[c], host_seq); W::store(&S.c_relaxed[c], (uint8_t)0); }
-    uint64_t* cits = S.c_its + (size_t)c * iw;
+  // completes sc.out (its, total, head, meta words) and writes the record to HBM
+  KS_DEV void finish_record(int c, const uint64_t* bin, bool recompute_head, uint32_t tmpl, uint32_t npods, uint32_t seq, uint32_t flags_hi, bool write_cold) {
+    const int nr = lay.nr, iw = lay.iw, np = iw * 64;
+    uint64_t* o = sc.out;
     const uint64_t* sits = sc.its;
-    W::for_n(iw, [&](int w) { cits[w] = sits[w]; });
-    uint64_t* cm = S.c_reqs.mask + (size_t)c * d.req_words;
-    const ReqBuf& m = sc.merged;
-    W::for_n(d.req_words, [&](int w) { cm[w] = m.mask[w]; });
-    W::store(&S.c_reqs.defined[c], m.defined); W::store(&S.c_reqs.complement[c], m.complement);
-    W::store(&S.c_reqs.has_gte[c], m.has_gte); W::store(&S.c_reqs.has_lte[c], m.has_lte);
-    int64_t* cg = S.c_reqs.gte + (size_t)c * d.n_keys; int64_t* cl = S.c_reqs.lte + (size_t)c * d.n_keys;
-    int32_t* cv = S.c_reqs.minv + (size_t)c * d.n_keys;
-    W::for_n(d.n_keys, [&](int k) { cg[k] = m.gte[k]; cl[k] = m.lte[k]; cv[k] = m.minv[k]; });
-    // headroom = max allocatable over the surviving instance types - total
-    int64_t* tot = S.c_total + (size_t)c * nr;
-    int64_t* head = S.c_head + (size_t)c * nr;
-    const ProblemView& Pv = P;
-    const int n_its = P.n_its;
+    const RecLayout ly = lay;
+    W::for_n(iw, [&](int w) { o[ly.c_its() + w] = sits[w]; });
+    const LdsTables& Lt = L;
     bool is_closed = false;
     for (int r = 0; r < nr; ++r) {
-      int64_t mx = W::reduce_max_i64(n_its, [&](int it) { return ((sits[it >> 6] >> (it & 63)) & 1) ? Pv.it_alloc[(size_t)r * n_its + it] : INT64_MIN; });
-      int64_t h = mx - sc.total[r];
-      W::store(&tot[r], sc.total[r]);
-      W::store(&head[r], h);
+      int64_t h;
+      if (recompute_head) {
+        // headroom = max allocatable over the surviving instance types - total
+        int64_t mx = W::reduce_max_i64(np, [&](int it) { return ((sits[it >> 6] >> (it & 63)) & 1) ? Lt.alloc[(size_t)r * np + it] : INT64_MIN; });
+        h = mx - sc.total[r];
+      } else {
+        h = ((const int64_t*)(bin + ly.c_head()))[r] - (sc.total[r] - ((const int64_t*)(bin + ly.c_total()))[r]);  // same types, same maximum
+      }
+      if (W::leader()) { o[ly.c_total() + r] = (uint64_t)sc.total[r]; o[ly.c_head() + r] = (uint64_t)h; }
       if (P.min_request[r] > 0 && h < P.min_request[r]) is_closed = true;
     }
-    if (is_closed) W::store(&S.closed[c >> 6], (uint64_t)(S.closed[c >> 6] | (1ull << (c & 63))));
+    if (W::leader()) {
+      o[ly.c_meta()] = (uint64_t)tmpl | ((uint64_t)npods << 32);
+      o[ly.c_meta2()] = (uint64_t)seq | ((uint64_t)flags_hi << 32);
+    }
     W::sync();
+    uint64_t* dst = S.c_hot + (size_t)c * ly.c_hot_words();
+    W::for_n(ly.c_hot_words(), [&](int i) { dst[i] = o[i]; });
+    if (write_cold) {
+      uint64_t* dc = S.c_cold + (size_t)c * ly.cold_words();
+      const uint64_t* oc = sc.out_cold;
+      W::for_n(ly.cold_words(), [&](int i) { dc[i] = oc[i]; });
+    }
+    if (is_closed) W::store(&S.closed[c >> 6], (uint64_t)(S.closed[c >> 6] | (1ull << (c & 63))));
   }
-  KS_FN void reset_column(int c) {
+  KS_DEV void reset_column(int c) {
     ctr.column_resets++;
     uint64_t* dead = S.dead;
     const int cw = S.claim_words;
@@ -228,62 +443,83 @@ struct Engine {
     const int word = c >> 6;
     W::for_n(P.n_classes, [&](int k) { dead[(size_t)k * cw + word] &= clr; });
   }
-  KS_FN void mark_dead(int k, int c) {
+  KS_DEV void mark_dead(int k, int c) {
     uint64_t* p = &S.dead[(size_t)k * S.claim_words + (c >> 6)];
     W::store(p, (uint64_t)(*p | (1ull << (c & 63))));
-    W::sync();
   }
-  KS_FN void commit_pod(int pod, int claim, uint32_t slot) {
+  KS_DEV void commit_pod(int pod, int claim, uint32_t slot) {
     W::store(&S.assign[pod], (int32_t)claim);
     W::store(&S.slot[pod], slot);
   }
+  // the claim order moves to HBM once it no longer fits the LDS budget
+  KS_DEV void spill_order_if_full() {
+    if (!order_in_lds || n_claims < P.lds.order_cap) return;
+    uint32_t *gk = S.o_key, *go = S.o_ord, *gp = S.o_pos;
+    const uint32_t *lk = L.okey, *lo_ = L.oord, *lp = L.opos;
+    W::for_n(n_claims, [&](int i) { gk[i] = lk[i]; go[i] = lo_[i]; gp[i] = lp[i]; });
+    order.key = gk; order.ord = go; order.pos = gp;
+    order_in_lds = false;
+  }
 
   // ---- in-flight scan: addToInflightNode (scheduler.go:658-692) ---------------------------------------------
-  // returns E_OK when the pod was committed to some claim
-  KS_FN int try_claim(int k, int c, int pod) {
-    const Dict& d = P.dict;
-    ReqRef cr = S.c_reqs.at(d, c);
-    bool changed = false;
-    int rc = can_add(k, cr, S.c_its + (size_t)c * P.it_words, S.c_total + (size_t)c * P.n_res, S.c_head + (size_t)c * P.n_res,
-                     P.tmpl_taints[S.c_tmpl[c]], false, &changed);
+  KS_DEV int try_claim(int k, int c, int pod) {
+    const uint64_t* src = S.c_hot + (size_t)c * lay.c_hot_words();
+    load_words(sc.claim, src, lay.c_hot_words());
+    const uint64_t f1 = sc.claim[lay.c_f1()];
+    const uint32_t m2 = hi32(sc.claim[lay.c_meta2()]);
+    if (f1 != 0 || (m2 & 2u)) load_words(sc.claim_cold, S.c_cold + (size_t)c * lay.cold_words(), lay.cold_words());
+    bool changed = false, its_changed = false;
+    int rc = can_add(sc.claim, sc.claim_cold, false, false, &changed, &its_changed);
     if (rc != E_OK) { mark_dead(k, c); return rc; }
-    uint32_t np = S.c_npods[c];
+    const uint32_t tmpl = lo32(sc.claim[lay.c_meta()]), np = hi32(sc.claim[lay.c_meta()]);
     ctr.ref_bin_evaluations += (unsigned long long)order.pos[c] + 1;   // the reference walked every claim up to this position
-    write_claim(c, S.c_tmpl[c], false);
-    W::store(&S.c_npods[c], np + 1);
+    if (!changed) {
+      // requirements untouched: carry masks and flags over from the bin record
+      uint64_t* o = sc.out;
+      const uint64_t* b = sc.claim;
+      const RecLayout ly = lay;
+      W::for_n(ly.rw, [&](int w) { o[w] = b[w]; });
+      if (W::leader()) { o[ly.c_f0()] = b[ly.c_f0()]; o[ly.c_f1()] = b[ly.c_f1()]; }
+      W::sync();
+    }
+    const bool out_cold = changed && (sc.out[lay.c_f1()] != 0 || (m2 & 2u));
+    finish_record(c, sc.claim, its_changed, tmpl, np + 1, lo32(sc.claim[lay.c_meta2()]), m2, out_cold);
     order.increment(c);
     if (changed) reset_column(c);
     commit_pod(pod, c, np);
     return E_OK;
   }
-  KS_FN bool scan_inflight(int k, int pod) {
+  KS_DEV bool scan_inflight(int k, int pod) {
     if (n_claims == 0) return false;
     const int words = (n_claims + 63) >> 6;
     const uint64_t* drow = S.dead + (size_t)k * S.claim_words;
     const uint64_t* closed = S.closed;
     const int nc = n_claims;
-    // Steady state: only a handful of claims are not yet known infeasible for this class. Find the words of the
-    // class's dead row that still have live bits (one ballot per 64 words), gather those claims and probe them in
-    // position order (lowest position wins, scheduler.go:673-676).
+    // Steady state: only a handful of claims are not yet known infeasible for this class. One coalesced load of the
+    // class's dead row (64 words = 4096 claims per step), ballot the words with live bits, gather those claims and
+    // probe them in position order (lowest position wins, scheduler.go:673-676).
     int ncand = 0;
     bool overflow = false;
+    uint64_t* stage = sc.stage;
     for (int w0 = 0; w0 < words && !overflow; w0 += 64) {
       int wn = words - w0 < 64 ? words - w0 : 64;
       uint64_t any = W::ballot([&](int l) {
         if (l >= wn) return false;
         int w = w0 + l;
         uint64_t valid = (w == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
-        return (~drow[w] & ~closed[w] & valid) != 0;
-      });
-      while (any && !overflow) {
-        int w = w0 + ctz64(any);
-        any &= any - 1;
-        uint64_t valid = (w == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
         uint64_t a = ~drow[w] & ~closed[w] & valid;
+        stage[l] = a;
+        return a != 0;
+      });
+      W::sync();
+      while (any && !overflow) {
+        int l = ctz64(any);
+        any &= any - 1;
+        uint64_t a = stage[l];
         while (a) {
           int b = ctz64(a); a &= a - 1;
           if (ncand >= 64) { overflow = true; break; }
-          int c = w * 64 + b;
+          int c = (w0 + l) * 64 + b;
           W::store(&sc.cand[ncand], ((uint64_t)order.pos[c] << 32) | (uint32_t)c);
           ncand++;
         }
@@ -323,21 +559,24 @@ struct Engine {
   }
 
   // ---- new claim: addToNewNodeClaim (scheduler.go:695-790) --------------------------------------------------
-  KS_FN int add_to_new_claim(int k, int pod) {
-    const Dict& d = P.dict;
-    const int nr = P.n_res, iw = P.it_words, n_its = P.n_its;
+  KS_DEV int add_to_new_claim(int k, int pod) {
+    const int nr = lay.nr, iw = lay.iw, n_its = P.n_its;
+    const RecLayout ly = lay;
     int first_err = 0, first_diag = 0;
     ctr.ref_bin_evaluations += (unsigned long long)n_claims;  // the reference tried every in-flight claim before coming here
     for (int t = 0; t < P.n_templates; ++t) {
       if (!((active_templates >> t) & 1)) continue;
-      const uint64_t* its = S.t_its + (size_t)t * iw;
+      const uint64_t* trec = L.tmpl + (size_t)t * ly.c_hot_words();
+      const uint64_t* tcold = L.tmpl_cold + (size_t)t * ly.cold_words();
       uint32_t lm = P.tmpl_limit_mask[t];
+      const uint64_t* bin = trec;
       if (lm) {
         int64_t* rem = S.t_remaining + (size_t)t * (nr + 1);
         if (((lm >> nr) & 1) && rem[nr] == 0) { if (!first_err) first_err = E_LIMITS; continue; }   // node limit — scheduler.go:711-715
-        // filterByRemainingResources — scheduler.go:1069-1085
-        uint64_t any = 0;
+        // filterByRemainingResources — scheduler.go:1069-1085 (instance types carry no "nodes" capacity, :1076)
         const ProblemView& Pv = P;
+        const uint64_t* its = trec + ly.c_its();
+        uint64_t any = 0;
         for (int w = 0; w < iw; ++w) {
           uint64_t in = its[w];
           uint64_t ok = in ? W::ballot([&](int l) {
@@ -345,7 +584,7 @@ struct Engine {
             if (it >= n_its || !((in >> l) & 1)) return false;
             bool v = true;
             for (int r = 0; r < nr; ++r) if ((lm >> r) & 1) v = v && Pv.it_cap[(size_t)r * n_its + it] <= rem[r];
-            if ((lm >> nr) & 1) v = v && 0 <= rem[nr];  // instance types carry no "nodes" capacity (scheduler.go:1076)
+            if ((lm >> nr) & 1) v = v && 0 <= rem[nr];
             return v;
           }) : 0;
           W::store(&sc.lim[w], ok);
@@ -353,19 +592,31 @@ struct Engine {
         }
         W::sync();
         if (!any) { if (!first_err) first_err = E_LIMITS; continue; }
-        its = sc.lim;
+        // a copy of the template record with the limited instance types
+        uint64_t* cl = sc.claim;
+        const uint64_t* lim = sc.lim;
+        W::for_n(ly.c_hot_words(), [&](int i) { cl[i] = (i >= ly.c_its() && i < ly.c_its() + iw) ? lim[i - ly.c_its()] : trec[i]; });
+        bin = sc.claim;
       }
       host_seq++;  // NewNodeClaim draws a hostname-placeholder number for every attempt (nodeclaim.go:93)
-      int64_t zero[kMaxRes];
-      for (int r = 0; r < nr; ++r) zero[r] = 0;
-      bool changed;
+      bool changed = false;
       ctr.ref_bin_evaluations++;
-      int rc = can_add(k, P.tmpl_reqs.at(d, t), its, zero, nullptr, P.tmpl_taints[t], first_err == 0, &changed);
+      int rc = can_add(bin, tcold, true, first_err == 0, &changed, nullptr);
       if (rc != E_OK) { if (!first_err) { first_err = rc; first_diag = rc == E_INSTANCE_TYPES ? last_diag : 0; } continue; }
       if (n_claims >= S.max_claims) { W::store(S.status_out, 1); return -1; }
+      spill_order_if_full();
       int c = n_claims++;
-      write_claim(c, t, true);
-      W::store(&S.c_npods[c], 1u);
+      const uint32_t tm2 = hi32(trec[ly.c_meta2()]);
+      uint64_t* o = sc.out;
+      uint64_t* oc = sc.out_cold;
+      if (!changed) {
+        W::for_n(ly.rw, [&](int w) { o[w] = bin[w]; });
+        if (W::leader()) { o[ly.c_f0()] = bin[ly.c_f0()]; o[ly.c_f1()] = bin[ly.c_f1()]; }
+        W::for_n(ly.cold_words(), [&](int i) { oc[i] = tcold[i]; });
+      }
+      W::sync();
+      const bool cold = sc.out[ly.c_f1()] != 0 || (tm2 & 2u);
+      finish_record(c, bin, true, (uint32_t)t, 1u, host_seq, tm2 & 2u, cold);
       order.append(c);
       if (lm) {
         // subtractMax — scheduler.go:1049-1066 : remaining -= max capacity over the claim's instance types
@@ -385,51 +636,79 @@ struct Engine {
     return first_err ? first_err : E_NO_TEMPLATES;
   }
 
+  // ---- class record of the pod being placed ----------------------------------------------------------------
+  KS_DEV void fetch_class(int k) {
+    const int hw = lay.k_hot_words();
+    load_words(sc.cls, P.cls_hot + (size_t)k * hw, hw);
+    if (sc.cls[lay.k_f1()] != 0 || (lo32(sc.cls[lay.k_meta()]) & 1u)) load_words(sc.cls_cold, P.cls_cold + (size_t)k * lay.cold_words(), lay.cold_words());
+  }
+
   // add — scheduler.go:582-612
-  KS_FN int add(int row, int pod) {
-    int k = (int)P.row_class[row];
+  KS_DEV int add_class(int k, int pod) {
     ctr.sorts++;
     order.sort();                                      // scheduler.go:598
     if (scan_inflight(k, pod)) return E_OK;            // scheduler.go:601
     if (active_templates == 0) { last_diag = 0; return E_NO_TEMPLATES; }   // scheduler.go:604-606
     return add_to_new_claim(k, pod);                   // scheduler.go:607
   }
-  // trySchedule — scheduler.go:521-552 ; the relaxation ladder (preferences.go:38-57) is precomputed as row chain
-  KS_FN int try_schedule(int pod) {
+  // trySchedule — scheduler.go:521-552 ; the relaxation ladder (preferences.go:38-57) is precomputed as a row chain
+  KS_DEV int try_schedule(int pod, int k0) {
     int row = pod;
+    int k = k0;
     for (;;) {
-      int rc = add(row, pod);
+      fetch_class(k);
+      int rc = add_class(k, pod);
       if (rc == E_OK || rc < 0) return rc;
       if (rc == E_RESERVED) return rc;
       int nxt = P.row_next[row];
       if (nxt < 0) return rc;
       row = nxt;
+      k = (int)P.row_class[row];
       ctr.relaxations++;
     }
   }
 
   // NewScheduler's per-template prefilter (scheduler.go:156-171): instance types compatible with the template's own
-  // requirements, with non-negative allocatable and a compatible available offering.
-  KS_FN void prefilter_templates() {
+  // requirements, with non-negative allocatable and a compatible available offering. Templates become claim-shaped
+  // records in LDS (total 0, unlimited headroom).
+  KS_DEV void prefilter_templates() {
     const Dict& d = P.dict;
     active_templates = 0;
-    int64_t zero[kMaxRes];
-    for (int r = 0; r < P.n_res; ++r) zero[r] = 0;
+    const int nr = lay.nr, iw = lay.iw;
+    const RecLayout ly = lay;
+    for (int r = 0; r < nr; ++r) W::store(&sc.total[r], (int64_t)0);
+    W::sync();
     for (int t = 0; t < P.n_templates; ++t) {
-      reqbuf_load(d, sc.merged, P.tmpl_reqs.at(d, t));
-      bool any = filter_instance_types(P.tmpl_its + (size_t)t * P.it_words, zero, false);
-      uint64_t* dst = S.t_its + (size_t)t * P.it_words;
+      ReqRef tr = P.tmpl_reqs.at(d, t);
+      uint64_t* rec = L.tmpl + (size_t)t * ly.c_hot_words();
+      uint64_t* cold = L.tmpl_cold + (size_t)t * ly.cold_words();
+      W::for_n(ly.rw, [&](int w) { rec[w] = tr.mask[w]; });
+      int64_t* cg = (int64_t*)cold; int64_t* cl = cg + ly.nk; int32_t* cv = (int32_t*)(cold + 2 * ly.nk);
+      bool has_minv = false;
+      for (int k = 0; k < ly.nk; ++k) if (tr.minv && tr.minv[k] >= 0) has_minv = true;
+      W::for_n(ly.nk, [&](int k) { cg[k] = (tr.gte && bit(tr.has_gte, k)) ? tr.gte[k] : 0; cl[k] = (tr.lte && bit(tr.has_lte, k)) ? tr.lte[k] : 0; cv[k] = tr.minv ? tr.minv[k] : -1; });
+      if (W::leader()) {
+        rec[ly.c_f0()] = (uint64_t)tr.defined | ((uint64_t)tr.complement << 32);
+        rec[ly.c_f1()] = (uint64_t)tr.has_gte | ((uint64_t)tr.has_lte << 32);
+        rec[ly.c_meta()] = (uint64_t)(uint32_t)t;
+        rec[ly.c_meta2()] = (uint64_t)(has_minv ? 2u : 0u) << 32;
+        for (int r = 0; r < nr; ++r) { rec[ly.c_total() + r] = 0; rec[ly.c_head() + r] = (uint64_t)INT64_MAX; }
+      }
+      W::sync();
+      ReqRef rr = claim_ref(rec, cold);
+      bool any = filter_instance_types(P.tmpl_its + (size_t)t * iw, sc.total, true, rr, false);
       const uint64_t* sits = sc.its;
-      W::for_n(P.it_words, [&](int w) { dst[w] = sits[w]; });
+      W::for_n(iw, [&](int w) { rec[ly.c_its() + w] = sits[w]; });
       if (any) active_templates |= 1u << t;
-      int64_t* rem = S.t_remaining + (size_t)t * (P.n_res + 1);
-      const int64_t* lim = P.tmpl_limits + (size_t)t * (P.n_res + 1);
-      W::for_n(P.n_res + 1, [&](int r) { rem[r] = lim[r]; });
+      int64_t* rem = S.t_remaining + (size_t)t * (nr + 1);
+      const int64_t* lim = P.tmpl_limits + (size_t)t * (nr + 1);
+      W::for_n(nr + 1, [&](int r) { rem[r] = lim[r]; });
     }
   }
 
   // Solve — scheduler.go:440-519 with Queue (queue.go:31-108)
-  KS_FN void solve() {
+  KS_DEV void solve() {
+    load_tables();
     prefilter_templates();
     const int np = P.n_pods;
     const uint32_t cap = (uint32_t)np + 1;
@@ -439,14 +718,29 @@ struct Engine {
     uint32_t head = 0, tail = (uint32_t)np % cap, qlen = (uint32_t)np;
     long long steps = 0;
     int status = 0;
+    int blk_n = 0, blk_i = 0;
     while (qlen > 0) {
-      int pod = (int)S.queue[head];
-      if (S.last_len[pod] == qlen) break;                                   // queue.go:52-56
+      if (blk_i >= blk_n) {
+        // fetch the next (up to) 64 queue entries with their class ids and lastLen in two coalesced round trips
+        blk_n = qlen < 64 ? (int)qlen : 64;
+        blk_i = 0;
+        uint32_t* bp = sc.blk_pod; uint32_t* bc = sc.blk_class; uint32_t* bl = sc.blk_last;
+        const uint32_t* rc_ = P.row_class; const uint32_t* ll = S.last_len;
+        const int bn = blk_n;
+        const uint32_t h0 = head;
+        W::for_n(64, [&](int l) {
+          if (l < bn) { uint32_t p = queue[(h0 + (uint32_t)l) % cap]; bp[l] = p; bc[l] = rc_[p]; bl[l] = ll[p]; }
+        });
+      }
+      int pod = (int)sc.blk_pod[blk_i];
+      if (sc.blk_last[blk_i] == qlen) break;                                // queue.go:52-56
       if ((S.max_steps >= 0 && steps >= S.max_steps) || (S.cancel_flag && *S.cancel_flag)) { status = 2; break; }
+      int k0 = (int)sc.blk_class[blk_i];
+      blk_i++;
       head = (head + 1) % cap; qlen--;
       steps++;
       ctr.queue_pops++;
-      int rc = try_schedule(pod);
+      int rc = try_schedule(pod, k0);
       if (rc < 0) { status = 1; break; }
       if (rc != E_OK) {
         W::store(&S.err[pod], (uint8_t)rc);
@@ -461,6 +755,12 @@ struct Engine {
       }
     }
     ctr.slow_sorts = order.slow_sorts;
+    if (order_in_lds) {
+      // results read the final order from HBM
+      uint32_t* go = S.o_ord;
+      const uint32_t* lo_ = L.oord;
+      W::for_n(n_claims, [&](int i) { go[i] = lo_[i]; });
+    }
     W::store(S.n_claims_out, n_claims);
     if (status) W::store(S.status_out, status);
     if (W::leader()) *S.counters = ctr;

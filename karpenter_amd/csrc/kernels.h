@@ -103,6 +103,9 @@ struct RowArgs {
   MutReqTable cls_reqs, cls_strict;
   uint64_t* cls_tolerates;
   int64_t* min_request;     // [n_res]
+  uint64_t* cls_hot;        // [n_classes][k_hot_words]
+  uint64_t* cls_cold;       // [n_classes][cold_words]
+  RecLayout lay;
 };
 KS_FN uint64_t mix64(uint64_t h, uint64_t v) {
   h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
@@ -204,6 +207,26 @@ KS_FN void class_gather_body(int cls, const RowArgs& a) {
   copy_reqset(a.dict, a.cls_reqs, cls, a.reqs.at(a.dict, row));
   copy_reqset(a.dict, a.cls_strict, cls, a.strict.at(a.dict, row));
   a.cls_tolerates[cls] = a.tolerates[row];
+  // packed records for the pack engine (RecLayout)
+  const RecLayout& ly = a.lay;
+  ReqRef q = a.reqs.at(a.dict, row);
+  uint64_t* hot = a.cls_hot + (size_t)cls * ly.k_hot_words();
+  uint64_t* cold = a.cls_cold + (size_t)cls * ly.cold_words();
+  for (int w = 0; w < ly.rw; ++w) hot[ly.k_mask() + w] = q.mask[w];
+  for (int r = 0; r < a.n_res; ++r) hot[ly.k_req() + r] = (uint64_t)a.requests[(size_t)r * a.n_rows + row];
+  hot[ly.k_f0()] = (uint64_t)q.defined | ((uint64_t)q.complement << 32);
+  hot[ly.k_f1()] = (uint64_t)q.has_gte | ((uint64_t)q.has_lte << 32);
+  hot[ly.k_tol()] = a.tolerates[row];
+  bool has_minv = false;
+  int64_t* cg = (int64_t*)cold; int64_t* cl = cg + ly.nk; int32_t* cv = (int32_t*)(cold + 2 * ly.nk);
+  for (int k = 0; k < ly.nk; ++k) {
+    cg[k] = (q.gte && bit(q.has_gte, k)) ? q.gte[k] : 0;
+    cl[k] = (q.lte && bit(q.has_lte, k)) ? q.lte[k] : 0;
+    int32_t mv = q.minv ? q.minv[k] : -1;
+    cv[k] = mv;
+    if (mv >= 0 && bit(q.defined, k)) has_minv = true;
+  }
+  hot[ly.k_meta()] = has_minv ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------ queue order
@@ -235,15 +258,23 @@ struct FinalizeArgs {
   int n_its, it_words, n_zones, n_cts;
   const uint64_t* it_off_avail;
   const double* it_off_price;
-  const uint64_t* c_its;
-  MutReqTable c_reqs;
+  const uint64_t* c_hot;
+  const uint64_t* c_cold;
+  RecLayout lay;
   double* cheapest;
 };
 // one thread per claim: min over InstanceTypeOptions of the cheapest available offering compatible with the claim's
 // requirements (the comparator key of OrderByPrice, types.go:336-355)
 KS_FN void finalize_body(int c, const FinalizeArgs& a) {
   const Dict& d = a.dict;
-  ReqRef r = a.c_reqs.at(d, c);
+  const RecLayout& ly = a.lay;
+  const uint64_t* hot = a.c_hot + (size_t)c * ly.c_hot_words();
+  const uint64_t* cold = a.c_cold + (size_t)c * ly.cold_words();
+  ReqRef r;
+  r.mask = hot + ly.c_mask();
+  r.defined = (uint32_t)hot[ly.c_f0()]; r.complement = (uint32_t)(hot[ly.c_f0()] >> 32);
+  r.has_gte = (uint32_t)hot[ly.c_f1()]; r.has_lte = (uint32_t)(hot[ly.c_f1()] >> 32);
+  r.gte = (const int64_t*)cold; r.lte = (const int64_t*)(cold + ly.nk); r.minv = nullptr;
   uint32_t zones = 0, cts = 0;
   if (d.key_zone >= 0 && bit(r.defined, d.key_zone)) { for (int z = 0; z < a.n_zones; ++z) if (req_has(d, r, d.key_zone, d.key_word_off[d.key_zone], z)) zones |= 1u << z; }
   else zones = (1u << a.n_zones) - 1;
@@ -252,7 +283,7 @@ KS_FN void finalize_body(int c, const FinalizeArgs& a) {
   uint64_t cells = 0;
   for (uint32_t zz = zones; zz; zz &= zz - 1) cells |= (uint64_t)cts << (__builtin_ctz(zz) * 4);
   double best = 1.7976931348623157e308;
-  const uint64_t* its = a.c_its + (size_t)c * a.it_words;
+  const uint64_t* its = hot + ly.c_its();
   for (int w = 0; w < a.it_words; ++w) {
     uint64_t m = its[w];
     while (m) {

@@ -98,8 +98,10 @@ __global__ void ksolve_finalize(int n, ks::FinalizeArgs a) {
 }
 // One wavefront (64 threads) per problem; the working requirement set and candidate lists live in LDS.
 __global__ void __launch_bounds__(64) ksolve_pack(ks::ProblemView pv, ks::Workspace ws) {
-  __shared__ ks::Scratch scratch;
-  ks::Engine<ks::Wave> eng(pv, ws, scratch);
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  ks::LdsTables tables;
+  tables.bind(lds, pv.lds);
+  ks::Engine<ks::Wave> eng(pv, ws, tables);
   eng.solve();
 }
 
@@ -111,7 +113,9 @@ static void be_launch_row_class(ksolve_handle* h, int n, const ks::RowArgs& a) {
 static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_class_gather, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
 static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a) { hipLaunchKernelGGL(ksolve_finalize, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
 static void be_launch_pack(ksolve_handle* h) {
-  hipLaunchKernelGGL(ksolve_pack, dim3(1), dim3(64), 0, HB(h)->stream, h->pv, h->ws);
+  const int lds_bytes = h->pv.lds.total_bytes;
+  if (!hip_check(h, hipFuncSetAttribute((const void*)ksolve_pack, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
+  hipLaunchKernelGGL(ksolve_pack, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, h->pv, h->ws);
   hip_check(h, hipGetLastError(), "ksolve_pack launch");
 }
 

@@ -46,6 +46,7 @@ struct ksolve_handle {
   // problem sizes
   uint32_t n_keys = 0, req_words = 0, n_res = 0, n_its = 0, it_words = 0, n_templates = 0, n_pods = 0, n_rows = 0, n_classes = 0;
   uint32_t max_claims = 0, claim_words = 0, class_capacity = 0;
+  int n_kv = 0;
   ks::ProblemView pv{};
   ks::Workspace ws{};
   // device buffers needed by the host between phases
@@ -196,6 +197,32 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   P.kv_has = kv_has; P.key_undef = key_undef; P.key_compl = key_compl; P.key_neg = key_neg; P.it_alloc_ok = alloc_ok;
   h->it_args = ks::ItIndexArgs{dict, (int)d->n_its, (int)it_words, (int)d->n_res, P.it_reqs, P.it_alloc, kv_has, key_undef, key_compl, key_neg, alloc_ok, dz<uint32_t>(h, 1)};
 
+  {
+    // keys some instance type defines, and a compact row index for every dictionary value of those keys
+    uint32_t it_keys = 0;
+    for (uint32_t i = 0; i < d->n_its; ++i) it_keys |= d->it_reqs.defined[i];
+    if (d->key_instance_type >= 0) it_keys &= ~(1u << d->key_instance_type);
+    P.it_keys = it_keys;
+    std::vector<uint16_t> slot((size_t)req_words * 64, 0xFFFF);
+    std::vector<uint64_t> used(req_words, 0);
+    for (uint32_t i = 0; i < d->n_its; ++i) for (uint32_t x = 0; x < req_words; ++x) used[x] |= d->it_reqs.mask[(size_t)i * req_words + x];
+    int n_kv = 0;
+    for (uint32_t k = 0; k < d->n_keys; ++k) {
+      if (!((it_keys >> k) & 1)) continue;
+      // complements on the instance-type side "have" every dictionary value they do not exclude: give every valid value a row
+      bool any_compl = false;
+      for (uint32_t i = 0; i < d->n_its; ++i) if ((d->it_reqs.complement[i] >> k) & 1) any_compl = true;
+      for (uint32_t x = d->key_word_off[k]; x < d->key_word_off[k + 1]; ++x)
+        for (int b = 0; b < 64; ++b) {
+          bool want = (used[x] >> b) & 1;
+          if (any_compl) want = true;
+          if (want) { if (n_kv >= 0xFFFE) return fail(h, KSOLVE_ERR_UNSUPPORTED, "too many instance-type label values"); slot[(size_t)x * 64 + b] = (uint16_t)n_kv++; }
+        }
+    }
+    P.kv_slot = up(h, slot.data(), slot.size());
+    h->n_kv = n_kv;
+  }
+
   P.n_templates = d->n_templates;
   P.tmpl_reqs = upload_reqs(h, d->tmpl_reqs, d->n_templates, req_words, d->n_keys);
   P.tmpl_taints = up(h, d->tmpl_taints, d->n_templates);
@@ -239,10 +266,10 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   h->max_claims = mc; h->claim_words = (mc + 63) / 64;
   ks::Workspace& W = h->ws;
   W.max_claims = (int)mc; W.claim_words = (int)h->claim_words;
-  W.c_tmpl = dz<int32_t>(h, mc); W.c_total = dz<int64_t>(h, (size_t)mc * d->n_res); W.c_head = dz<int64_t>(h, (size_t)mc * d->n_res);
-  W.c_its = dz<uint64_t>(h, (size_t)mc * it_words);
-  W.c_reqs = alloc_reqs(h, mc, req_words, d->n_keys);
-  W.c_host_seq = dz<uint32_t>(h, mc); W.c_relaxed = dz<uint8_t>(h, mc); W.c_npods = dz<uint32_t>(h, mc);
+  ks::RecLayout lay{(int)req_words, (int)it_words, (int)d->n_res, (int)d->n_keys};
+  P.lay = lay;
+  W.c_hot = dz<uint64_t>(h, (size_t)mc * lay.c_hot_words());
+  W.c_cold = dz<uint64_t>(h, (size_t)mc * lay.cold_words());
   W.o_key = dz<uint32_t>(h, mc); W.o_ord = dz<uint32_t>(h, mc); W.o_pos = dz<uint32_t>(h, mc);
   W.closed = dz<uint64_t>(h, h->claim_words);
   W.queue = dz<uint32_t>(h, (size_t)d->n_pods + 1); W.last_len = dz<uint32_t>(h, d->n_pods);
@@ -255,6 +282,31 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   W.max_steps = h->opts.max_steps;
   W.counters = dz<ks::Counters>(h, 1);
   h->d_cheapest = dz<double>(h, mc);
+  {
+    // LDS plan of the pack kernel: tables first, the claim order gets what is left of the 160 KiB
+    ks::LdsPlan& lp = P.lds;
+    auto align = [](int x) { return (x + 15) & ~15; };
+    const int np = (int)it_words * 64;
+    int off = 0;
+    lp.off_alloc = off; off = align(off + (int)d->n_res * np * 8);
+    lp.off_avail = off; off = align(off + np * 8);
+    lp.n_kv = h->n_kv;
+    lp.off_kv = off; off = align(off + std::max(1, h->n_kv) * (int)it_words * 8);
+    lp.off_keymask = off; off = align(off + 3 * (int)d->n_keys * (int)it_words * 8);
+    lp.off_allocok = off; off = align(off + (int)it_words * 8);
+    lp.off_kvslot = off; off = align(off + (int)req_words * 64 * 2);
+    lp.off_tmpl = off; off = align(off + std::max(1u, d->n_templates) * lay.c_hot_words() * 8);
+    lp.off_tmplcold = off; off = align(off + std::max(1u, d->n_templates) * lay.cold_words() * 8);
+    lp.off_scratch = off; off = align(off + (int)sizeof(ks::Scratch));
+    const int budget = 160 * 1024 - 512;
+    if (off + 12 * 64 > budget) return fail(h, KSOLVE_ERR_UNSUPPORTED, "instance-type tables do not fit the 160 KiB LDS of one CU");
+    int cap = (budget - off) / 12;
+    cap &= ~63;
+    if (cap > (int)mc) cap = ((int)mc + 63) & ~63;
+    lp.off_order = off; lp.order_cap = cap;
+    off += cap * 12;
+    lp.total_bytes = off;
+  }
   be_sync(h);
   be_toc(h, T_UPLOAD);
   if (!be_ok(h)) return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "device allocation/upload failed" : h->error);
@@ -321,6 +373,9 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
     h->d_cls_strict = alloc_reqs(h, n_classes, h->req_words, h->n_keys);
     R.cls_reqs = h->d_cls_reqs; R.cls_strict = h->d_cls_strict;
     R.cls_tolerates = dz<uint64_t>(h, n_classes);
+    R.cls_hot = dz<uint64_t>(h, (size_t)n_classes * P.lay.k_hot_words());
+    R.cls_cold = dz<uint64_t>(h, (size_t)n_classes * P.lay.cold_words());
+    R.lay = P.lay;
     h->ws.dead = dz<uint64_t>(h, (size_t)n_classes * h->claim_words);
   }
   if (n_classes > 0) {
@@ -331,6 +386,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   P.n_classes = (int)n_classes;
   P.cls_requests = R.cls_requests; P.cls_reqs = as_const(h->d_cls_reqs); P.cls_strict = as_const(h->d_cls_strict);
   P.cls_tolerates = R.cls_tolerates;
+  P.cls_hot = R.cls_hot; P.cls_cold = R.cls_cold;
   if (n_classes) be_fill(h, W.dead, 0, (size_t)n_classes * h->claim_words * 8);
   be_toc(h, T_CLASSIFY);
 
@@ -359,7 +415,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
 
   // ---- phase 5: finalize ----
   be_tic(h, T_FINALIZE);
-  ks::FinalizeArgs F{P.dict, (int)h->n_its, (int)h->it_words, P.n_zones, P.n_cts, P.it_off_avail, P.it_off_price, W.c_its, W.c_reqs, h->d_cheapest};
+  ks::FinalizeArgs F{P.dict, (int)h->n_its, (int)h->it_words, P.n_zones, P.n_cts, P.it_off_avail, P.it_off_price, W.c_hot, W.c_cold, P.lay, h->d_cheapest};
   if (n_claims) be_launch_finalize(h, n_claims, F);
   be_toc(h, T_FINALIZE);
 
@@ -373,6 +429,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
     be_d2h(h, im->slot.data(), W.slot, (size_t)n_pods * 4);
   }
   const uint32_t C = (uint32_t)n_claims;
+  const ks::RecLayout ly = P.lay;
   std::vector<int32_t> tmpl(C);
   std::vector<uint32_t> npods(C), defined(C), complement(C), has_gte(C), has_lte(C), host_seq(C), ord(C);
   std::vector<uint8_t> relaxed(C);
@@ -380,15 +437,10 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   std::vector<int64_t> requests((size_t)C * n_res), gte((size_t)C * h->n_keys), lte((size_t)C * h->n_keys);
   std::vector<int32_t> minv((size_t)C * h->n_keys);
   std::vector<double> cheapest(C);
+  std::vector<uint64_t> hot((size_t)C * ly.c_hot_words()), cold((size_t)C * ly.cold_words());
   if (C) {
-    be_d2h(h, tmpl.data(), W.c_tmpl, (size_t)C * 4); be_d2h(h, npods.data(), W.c_npods, (size_t)C * 4);
-    be_d2h(h, its.data(), W.c_its, its.size() * 8); be_d2h(h, mask.data(), W.c_reqs.mask, mask.size() * 8);
-    be_d2h(h, defined.data(), W.c_reqs.defined, (size_t)C * 4); be_d2h(h, complement.data(), W.c_reqs.complement, (size_t)C * 4);
-    be_d2h(h, has_gte.data(), W.c_reqs.has_gte, (size_t)C * 4); be_d2h(h, has_lte.data(), W.c_reqs.has_lte, (size_t)C * 4);
-    be_d2h(h, gte.data(), W.c_reqs.gte, gte.size() * 8); be_d2h(h, lte.data(), W.c_reqs.lte, lte.size() * 8);
-    be_d2h(h, minv.data(), W.c_reqs.minv, minv.size() * 4);
-    be_d2h(h, requests.data(), W.c_total, requests.size() * 8);
-    be_d2h(h, host_seq.data(), W.c_host_seq, (size_t)C * 4); be_d2h(h, relaxed.data(), W.c_relaxed, C);
+    be_d2h(h, hot.data(), W.c_hot, hot.size() * 8);
+    be_d2h(h, cold.data(), W.c_cold, cold.size() * 8);
     be_d2h(h, cheapest.data(), h->d_cheapest, (size_t)C * 8);
     be_d2h(h, ord.data(), W.o_ord, (size_t)C * 4);
   }
@@ -397,6 +449,25 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   be_sync(h);
   be_toc(h, T_DOWNLOAD);
   if (!be_ok(h)) { delete im; return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "download failed" : h->error); }
+  for (uint32_t c = 0; c < C; ++c) {
+    const uint64_t* hr = hot.data() + (size_t)c * ly.c_hot_words();
+    const uint64_t* cr = cold.data() + (size_t)c * ly.cold_words();
+    for (uint32_t x = 0; x < h->req_words; ++x) mask[(size_t)c * h->req_words + x] = hr[ly.c_mask() + x];
+    for (uint32_t x = 0; x < h->it_words; ++x) its[(size_t)c * h->it_words + x] = hr[ly.c_its() + x];
+    for (uint32_t r = 0; r < n_res; ++r) requests[(size_t)c * n_res + r] = (int64_t)hr[ly.c_total() + r];
+    defined[c] = (uint32_t)hr[ly.c_f0()]; complement[c] = (uint32_t)(hr[ly.c_f0()] >> 32);
+    has_gte[c] = (uint32_t)hr[ly.c_f1()]; has_lte[c] = (uint32_t)(hr[ly.c_f1()] >> 32);
+    tmpl[c] = (int32_t)(uint32_t)hr[ly.c_meta()]; npods[c] = (uint32_t)(hr[ly.c_meta()] >> 32);
+    host_seq[c] = (uint32_t)hr[ly.c_meta2()];
+    const uint32_t fl = (uint32_t)(hr[ly.c_meta2()] >> 32);
+    relaxed[c] = fl & 1u;
+    const bool cold_valid = hr[ly.c_f1()] != 0 || (fl & 2u);
+    for (uint32_t k = 0; k < h->n_keys; ++k) {
+      gte[(size_t)c * h->n_keys + k] = cold_valid ? ((const int64_t*)cr)[k] : 0;
+      lte[(size_t)c * h->n_keys + k] = cold_valid ? ((const int64_t*)cr)[h->n_keys + k] : 0;
+      minv[(size_t)c * h->n_keys + k] = (fl & 2u) ? ((const int32_t*)(cr + 2 * h->n_keys))[k] : -1;
+    }
+  }
 
   // Report claims in the order the reference's s.newNodeClaims slice ends in (position order), so claim index i in the
   // results is position i; pod assignments are remapped accordingly.

@@ -37,6 +37,52 @@ struct MutReqTable {  // claims: same layout, writable
   }
 };
 
+// Record layouts (u64 words). A claim / class / template is moved between HBM and LDS as ONE contiguous record with a
+// single coalesced wave load (lane i moves word i), instead of many dependent scalar loads.
+//   hot  claim record : masks[rw] | its[iw] | total[nr] | head[nr] | f0 | f1 | meta | meta2
+//                       f0 = defined | complement<<32 ; f1 = has_gte | has_lte<<32 ; meta = template | npods<<32 ;
+//                       meta2 = hostname seq | flags<<32 (bit0 min-values-relaxed, bit1 has_minv)
+//   cold claim record : gte[nk] | lte[nk] | minv[nk] as packed i32               — only touched when bounds/minValues exist
+//   hot  class record : masks[rw] | requests[nr] | f0 | f1 | tolerates | meta(has_minv bit0)
+//   cold class record : gte[nk] | lte[nk] | minv[nk]
+struct RecLayout {
+  int rw, iw, nr, nk;
+  KS_FN int c_mask() const { return 0; }
+  KS_FN int c_its() const { return rw; }
+  KS_FN int c_total() const { return rw + iw; }
+  KS_FN int c_head() const { return rw + iw + nr; }
+  KS_FN int c_f0() const { return rw + iw + 2 * nr; }
+  KS_FN int c_f1() const { return c_f0() + 1; }
+  KS_FN int c_meta() const { return c_f0() + 2; }
+  KS_FN int c_meta2() const { return c_f0() + 3; }
+  KS_FN int c_hot_words() const { return c_f0() + 4; }
+  KS_FN int cold_words() const { return 2 * nk + (nk + 1) / 2; }
+  KS_FN int k_mask() const { return 0; }
+  KS_FN int k_req() const { return rw; }
+  KS_FN int k_f0() const { return rw + nr; }
+  KS_FN int k_f1() const { return rw + nr + 1; }
+  KS_FN int k_tol() const { return rw + nr + 2; }
+  KS_FN int k_meta() const { return rw + nr + 3; }
+  KS_FN int k_hot_words() const { return rw + nr + 4; }
+};
+
+// LDS plan of the pack kernel (byte offsets into the dynamic shared segment), computed by the host.
+struct LdsPlan {
+  int total_bytes;
+  int off_alloc;      // i64 [nr][iw*64]      allocatable, SoA
+  int off_avail;      // u64 [iw*64]          offering availability cells
+  int off_kv;         // u64 [n_kv][iw]       compact kv_has rows (only values of keys some instance type defines)
+  int off_keymask;    // u64 [3][nk][iw]      key_undef | key_compl | key_neg
+  int off_allocok;    // u64 [iw]
+  int off_kvslot;     // u16 [rw*64]          dictionary (word,bit) -> compact kv row, 0xFFFF = none
+  int off_tmpl;       // u64 [T][c_hot_words] template records (claim-shaped: prefiltered its, total 0, head +inf)
+  int off_tmplcold;   // u64 [T][cold_words]
+  int off_order;      // u32 key[cap] | ord[cap] | pos[cap]
+  int order_cap;
+  int off_scratch;    // Scratch
+  int n_kv;
+};
+
 struct ProblemView {
   Dict dict;
   int n_res, n_its, it_words;
@@ -70,6 +116,12 @@ struct ProblemView {
   ReqTable cls_reqs, cls_strict;
   const uint64_t* cls_tolerates; // [n_classes]
   const int64_t* min_request;    // [n_res] min over classes (for the closed-claim test)
+  const uint64_t* cls_hot;       // [n_classes][k_hot_words]  (class_gather)
+  const uint64_t* cls_cold;      // [n_classes][cold_words]
+  RecLayout lay;
+  LdsPlan lds;
+  const uint16_t* kv_slot;       // [req_words*64] compact kv row of a dictionary value (host-built)
+  uint32_t it_keys;              // keys that at least one instance type defines
 
   const uint32_t* sorted_pods;   // [n_pods] queue order (k_sort)
 };
@@ -81,16 +133,10 @@ struct Counters {
 
 struct Workspace {
   int max_claims, claim_words;   // claim_words = ceil(max_claims/64)
-  // claims (AoS by claim)
-  int32_t* c_tmpl;               // [max_claims]
-  int64_t* c_total;              // [max_claims][n_res]   Spec.Resources.Requests
-  int64_t* c_head;               // [max_claims][n_res]   max allocatable over remaining instance types - total
-  uint64_t* c_its;               // [max_claims][it_words] InstanceTypeOptions
-  MutReqTable c_reqs;            // Requirements
-  uint32_t* c_host_seq;          // hostname-placeholder sequence number
-  uint8_t* c_relaxed;
-  uint32_t* c_npods;             // pod count by claim id
-  // order (pdq_emul.h)
+  // claims (AoS by claim; see RecLayout)
+  uint64_t* c_hot;               // [max_claims][c_hot_words]
+  uint64_t* c_cold;              // [max_claims][cold_words]
+  // order (pdq_emul.h): lives in LDS while it fits (LdsPlan.order_cap), these are the HBM spill arrays
   uint32_t *o_key, *o_ord, *o_pos;
   // first-fit pruning
   uint64_t* dead;                // [n_classes][claim_words] bit set = claim known infeasible for the class

@@ -46,8 +46,10 @@ static void be_sort_pods(ksolve_handle* h) {
   h->pv.sorted_pods = idx;
 }
 static void be_launch_pack(ksolve_handle* h) {
-  static thread_local ks::Scratch scratch;
-  ks::Engine<ks::Wave> eng(h->pv, h->ws, scratch);
+  std::vector<char> lds((size_t)h->pv.lds.total_bytes + 64);  // stands in for the CU's LDS segment
+  ks::LdsTables tables;
+  tables.bind(lds.data(), h->pv.lds);
+  ks::Engine<ks::Wave> eng(h->pv, h->ws, tables);
   eng.solve();
 }
 static int be_device_available() { return 1; }
