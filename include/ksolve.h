@@ -190,6 +190,7 @@ typedef struct {
   /* counters: V = candidate-bin evaluations, plus timing of the device phases in microseconds */
   uint64_t bin_evaluations, it_evaluations, queue_pops, sorts, slow_sorts, relaxations;
   uint64_t ref_bin_evaluations;    /* V as the reference algorithm would count it: every claim up to the accepting one */
+  uint64_t phase_cycles[24];       /* shader clocks per pack-engine phase: queue, class fetch, sort, scan, record load, CanAdd, commit, new claim, dead mark, trySchedule, total */
   double us_upload, us_prepass, us_pack, us_finalize, us_download;
   double packing_cost;
   void* impl;

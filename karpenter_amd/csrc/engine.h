@@ -49,6 +49,9 @@ struct Scratch {
   uint64_t out[kMaxHot];            // record being committed
   uint64_t out_cold[kMaxCold];
   uint32_t blk_pod[64], blk_class[64], blk_last[64];
+  uint64_t tmpl_taints[32];         // template taint masks
+  int64_t min_request[kMaxRes];     // min over classes per dimension (closed-claim test)
+  int32_t cache_tag[32];            // claim id held by each record-cache line, -1 = empty
   uint8_t word_key[kMaxReqWords];   // dictionary word -> key
 };
 
@@ -61,13 +64,16 @@ struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host b
   uint16_t* kvslot;     // [rw*64]
   uint64_t* tmpl;       // [T][c_hot_words]
   uint64_t* tmpl_cold;  // [T][cold_words]
-  uint32_t *okey, *oord, *opos;
+  KS_LDS uint32_t *okey, *oord, *opos;   // claim order (pdq_emul.h)
+  uint64_t* closed;     // [order_cap/64] claims that cannot take any pod any more
+  uint64_t* cache;      // [32][c_hot_words] direct-mapped cache of hot claim records
   Scratch* scratch;
   KS_FN void bind(char* base, const LdsPlan& p) {
     alloc = (int64_t*)(base + p.off_alloc); avail = (uint64_t*)(base + p.off_avail); kv = (uint64_t*)(base + p.off_kv);
     keymask = (uint64_t*)(base + p.off_keymask); allocok = (uint64_t*)(base + p.off_allocok); kvslot = (uint16_t*)(base + p.off_kvslot);
     tmpl = (uint64_t*)(base + p.off_tmpl); tmpl_cold = (uint64_t*)(base + p.off_tmplcold);
-    okey = (uint32_t*)(base + p.off_order); oord = okey + p.order_cap; opos = oord + p.order_cap;
+    okey = (KS_LDS uint32_t*)(base + p.off_order); oord = okey + p.order_cap; opos = oord + p.order_cap;
+    closed = (uint64_t*)(base + p.off_closed); cache = (uint64_t*)(base + p.off_cache);
     scratch = (Scratch*)(base + p.off_scratch);
   }
 };
@@ -81,7 +87,6 @@ struct Engine {
   const RecLayout lay;
   ClaimOrder<W> order;
   int n_claims = 0;
-  bool order_in_lds = true;
   uint32_t host_seq = 0;
   uint32_t active_templates = 0;
   int last_err = 0, last_diag = 0;
@@ -141,6 +146,10 @@ struct Engine {
     if (W::leader())
       for (int k = 0; k < d.n_keys; ++k)
         for (uint32_t w = d.key_word_off[k]; w < d.key_word_off[k + 1]; ++w) wk[w] = (uint8_t)k;
+    uint64_t* tt = sc.tmpl_taints; int64_t* mr = sc.min_request; int32_t* tag = sc.cache_tag;
+    W::for_n(32, [&](int t) { tt[t] = t < Pv.n_templates ? Pv.tmpl_taints[t] : 0; tag[t] = -1; });
+    W::for_n(nr, [&](int r) { mr[r] = Pv.min_request[r]; });
+    W::for_n(Pv.lds.order_cap / 64, [&](int w) { Lt.closed[w] = 0; });
     W::sync();
   }
 
@@ -222,31 +231,51 @@ struct Engine {
       cells = offering_cells(reqs);
     }
     const LdsTables& Lt = L;
-    const int nr = P.n_res, np = P.it_words * 64;
+    const int nr = P.n_res, iw = P.it_words, np = iw * 64;
     uint64_t any = 0;
     bool d_req = false, d_fit = false, d_off = false, d_ro = false, d_fo = false;
-    for (int w = 0; w < P.it_words; ++w) {
-      uint64_t in = bin_its[w];
-      uint64_t cm = full ? sc.cm[w] : ~0ull;
-      if (!in || (!want_diag && !(in & cm))) { W::store(&sc.its[w], (uint64_t)0); continue; }
-      uint64_t aok = Lt.allocok[w];
-      uint64_t fit = W::ballot([&](int l) {
-        if (!((in >> l) & 1)) return false;
-        int it = w * 64 + l;
-        bool f = (aok >> l) & 1;
-        for (int r = 0; r < nr; ++r) f = f && total[r] <= Lt.alloc[(size_t)r * np + it];
-        return f;
+    for (int w0 = 0; w0 < iw; w0 += 8) {
+      const int n = iw - w0 < 8 ? iw - w0 : 8;
+      // one lane per instance type, eight mask words per step; every allocatable / availability load of the step is in
+      // flight at once (resource fit AND a compatible offering: fits() reports itFits only with one, nodeclaim.go:624-638)
+      uint64_t* its_out = sc.its;
+      const uint64_t* cmw = sc.cm;
+      W::ballots8(n, [&](int l, int j) {
+        int it = (w0 + j) * 64 + l;
+        int f = full ? (int)((Lt.avail[it] & cells) != 0) : 1;
+        for (int r = 0; r < nr; ++r) f &= (int)(total[r] <= Lt.alloc[(size_t)r * np + it]);
+        return f != 0;
+      }, [&](int j, uint64_t fit_and_off) {
+        const int w = w0 + j;
+        const uint64_t in = bin_its[w];
+        const uint64_t cm = full ? cmw[w] : ~0ull;
+        const uint64_t itfits = in & Lt.allocok[w] & fit_and_off;
+        const uint64_t keep = cm & itfits;
+        ctr.it_evaluations += popc64(in);
+        if (want_diag) { d_req |= (in & cm) != 0; d_fit |= itfits != 0; d_fo |= (itfits & ~cm) != 0; }
+        W::store(&its_out[w], keep);
+        any |= keep;
       });
-      uint64_t off = full ? W::ballot([&](int l) { return ((in >> l) & 1) && (Lt.avail[w * 64 + l] & cells) != 0; }) : in;
-      ctr.it_evaluations += popc64(in);
-      uint64_t itfits = fit & off;  // fits() reports itFits only together with a compatible offering (nodeclaim.go:624-638)
-      uint64_t keep = in & cm & itfits;
       if (want_diag) {
-        d_req |= (in & cm) != 0; d_fit |= itfits != 0; d_off |= off != 0;
-        d_ro |= (in & cm & off & ~itfits) != 0; d_fo |= (itfits & ~cm) != 0;
+        // InstanceTypeFilterError flags (nodeclaim.go:585-592) need resource fit and offering separately (failure path only)
+        W::ballots8(n, [&](int l, int j) { return (Lt.avail[(w0 + j) * 64 + l] & cells) != 0; },
+                    [&](int j, uint64_t offb) { W::store(&sc.lim[w0 + j], offb); });
+        W::sync();
+        W::ballots8(n, [&](int l, int j) {
+          int it = (w0 + j) * 64 + l;
+          int f = 1;
+          for (int r = 0; r < nr; ++r) f &= (int)(total[r] <= Lt.alloc[(size_t)r * np + it]);
+          return f != 0;
+        }, [&](int j, uint64_t fitb) {
+          const int w = w0 + j;
+          const uint64_t in = bin_its[w];
+          const uint64_t cm = full ? cmw[w] : ~0ull;
+          const uint64_t off = full ? (in & sc.lim[w]) : in;
+          const uint64_t itfits = in & Lt.allocok[w] & fitb & off;
+          d_off |= off != 0;
+          d_ro |= (in & cm & off & ~itfits) != 0;
+        });
       }
-      W::store(&sc.its[w], keep);
-      any |= keep;
     }
     W::sync();
     if (want_diag) last_diag = (d_req ? 1 : 0) | (d_fit ? 2 : 0) | (d_off ? 4 : 0) | (d_ro ? 16 : 0) | (d_fo ? 32 : 0);
@@ -338,12 +367,13 @@ struct Engine {
     const Dict& d = P.dict;
     const int nr = lay.nr;
     ctr.bin_evaluations++;
-    const uint64_t bin_taints = P.tmpl_taints[lo32(bin[lay.c_meta()])];
+    unsigned long long ta = W::clock();
+    const uint64_t bin_taints = sc.tmpl_taints[lo32(bin[lay.c_meta()]) & 31u];
     if (bin_taints & ~sc.cls[lay.k_tol()]) return E_TAINTS;                              // Taints.ToleratesPod — nodeclaim.go:126
     const int64_t* req = (const int64_t*)(sc.cls + lay.k_req());
     const int64_t* head = (const int64_t*)(bin + lay.c_head());
     const int64_t* tot = (const int64_t*)(bin + lay.c_total());
-    for (int r = 0; r < nr; ++r) if (req[r] > head[r]) return E_INSTANCE_TYPES;           // no remaining instance type can hold it
+    if (W::ballot([&](int l) { return l < nr && req[l] > head[l]; })) return E_INSTANCE_TYPES;   // no remaining instance type can hold it
     uint32_t kdef = lo32(sc.cls[lay.k_f0()]);
     int hn = d.key_hostname;
     if (hn >= 0 && ((kdef >> hn) & 1)) {
@@ -358,6 +388,8 @@ struct Engine {
     const bool slow = bin[lay.c_f1()] != 0 || sc.cls[lay.k_f1()] != 0 || cls_minv || lay.rw > 64;
     bool changed = false;
     ReqRef merged;
+    unsigned long long tb = W::clock();
+    ctr.cycles[11] += tb - ta;
     if (!slow) {
       if (!fast_compat_merge(bin, kdef, &changed)) return E_INCOMPATIBLE;               // nodeclaim.go:133-136
       merged.mask = sc.out + lay.c_mask(); merged.defined = lo32(sc.out[lay.c_f0()]); merged.complement = hi32(sc.out[lay.c_f0()]);
@@ -386,11 +418,17 @@ struct Engine {
       merged.has_gte = m.has_gte; merged.has_lte = m.has_lte; merged.gte = cg; merged.lte = cl; merged.minv = cv;
     }
     ctr.full_evaluations++;
+    unsigned long long tc = W::clock();
+    ctr.cycles[12] += tc - tb;
     if (reqs_changed) *reqs_changed = changed;
     int64_t* ntot = sc.total;
     W::for_n(nr, [&](int r) { ntot[r] = tot[r] + req[r]; });                               // resources.Merge — nodeclaim.go:211
     const bool full = changed || fresh;
-    if (!filter_instance_types(bin + lay.c_its(), sc.total, full, merged, want_diag)) return E_INSTANCE_TYPES;  // nodeclaim.go:213
+    unsigned long long td = W::clock();
+    ctr.cycles[13] += td - tc;
+    const bool any_it = filter_instance_types(bin + lay.c_its(), sc.total, full, merged, want_diag);
+    ctr.cycles[14] += W::clock() - td;
+    if (!any_it) return E_INSTANCE_TYPES;  // nodeclaim.go:213
     if (its_changed) {
       const uint64_t* bi = bin + lay.c_its();
       const uint64_t* ni = sc.its;
@@ -400,40 +438,48 @@ struct Engine {
     return E_OK;
   }
 
-  // completes sc.out (its, total, head, meta words) and writes the record to HBM
+  // completes sc.out (its, total, head, meta words) and writes the record to HBM (and the record cache)
   KS_DEV void finish_record(int c, const uint64_t* bin, bool recompute_head, uint32_t tmpl, uint32_t npods, uint32_t seq, uint32_t flags_hi, bool write_cold) {
     const int nr = lay.nr, iw = lay.iw, np = iw * 64;
     uint64_t* o = sc.out;
     const uint64_t* sits = sc.its;
     const RecLayout ly = lay;
-    W::for_n(iw, [&](int w) { o[ly.c_its() + w] = sits[w]; });
     const LdsTables& Lt = L;
-    bool is_closed = false;
-    for (int r = 0; r < nr; ++r) {
-      int64_t h;
-      if (recompute_head) {
-        // headroom = max allocatable over the surviving instance types - total
+    const int64_t* ntot = sc.total;
+    if (recompute_head) {
+      // headroom = max allocatable over the surviving instance types - total
+      for (int r = 0; r < nr; ++r) {
         int64_t mx = W::reduce_max_i64(np, [&](int it) { return ((sits[it >> 6] >> (it & 63)) & 1) ? Lt.alloc[(size_t)r * np + it] : INT64_MIN; });
-        h = mx - sc.total[r];
-      } else {
-        h = ((const int64_t*)(bin + ly.c_head()))[r] - (sc.total[r] - ((const int64_t*)(bin + ly.c_total()))[r]);  // same types, same maximum
+        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(mx - ntot[r]);
       }
-      if (W::leader()) { o[ly.c_total() + r] = (uint64_t)sc.total[r]; o[ly.c_head() + r] = (uint64_t)h; }
-      if (P.min_request[r] > 0 && h < P.min_request[r]) is_closed = true;
+    } else {
+      const int64_t* bh = (const int64_t*)(bin + ly.c_head());
+      const int64_t* bt = (const int64_t*)(bin + ly.c_total());
+      W::for_n(nr, [&](int r) { o[ly.c_head() + r] = (uint64_t)(bh[r] - (ntot[r] - bt[r])); });  // same types, same maximum
     }
+    W::for_n(iw > nr ? iw : nr, [&](int i) {
+      if (i < iw) o[ly.c_its() + i] = sits[i];
+      if (i < nr) o[ly.c_total() + i] = (uint64_t)ntot[i];
+    });
     if (W::leader()) {
       o[ly.c_meta()] = (uint64_t)tmpl | ((uint64_t)npods << 32);
       o[ly.c_meta2()] = (uint64_t)seq | ((uint64_t)flags_hi << 32);
     }
     W::sync();
+    const int64_t* mr = sc.min_request;
+    const int64_t* oh = (const int64_t*)(o + ly.c_head());
+    const bool is_closed = W::ballot([&](int l) { return l < nr && mr[l] > 0 && oh[l] < mr[l]; }) != 0;
     uint64_t* dst = S.c_hot + (size_t)c * ly.c_hot_words();
-    W::for_n(ly.c_hot_words(), [&](int i) { dst[i] = o[i]; });
+    uint64_t* line = L.cache + (size_t)(c & 31) * ly.c_hot_words();
+    W::for_n(ly.c_hot_words(), [&](int i) { uint64_t v = o[i]; dst[i] = v; line[i] = v; });
+    if (W::leader()) sc.cache_tag[c & 31] = c;
     if (write_cold) {
       uint64_t* dc = S.c_cold + (size_t)c * ly.cold_words();
       const uint64_t* oc = sc.out_cold;
       W::for_n(ly.cold_words(), [&](int i) { dc[i] = oc[i]; });
     }
-    if (is_closed) W::store(&S.closed[c >> 6], (uint64_t)(S.closed[c >> 6] | (1ull << (c & 63))));
+    if (is_closed && W::leader()) L.closed[c >> 6] |= 1ull << (c & 63);
+    W::sync();
   }
   KS_DEV void reset_column(int c) {
     ctr.column_resets++;
@@ -443,106 +489,105 @@ struct Engine {
     const int word = c >> 6;
     W::for_n(P.n_classes, [&](int k) { dead[(size_t)k * cw + word] &= clr; });
   }
-  KS_DEV void mark_dead(int k, int c) {
-    uint64_t* p = &S.dead[(size_t)k * S.claim_words + (c >> 6)];
-    W::store(p, (uint64_t)(*p | (1ull << (c & 63))));
-  }
   KS_DEV void commit_pod(int pod, int claim, uint32_t slot) {
     W::store(&S.assign[pod], (int32_t)claim);
     W::store(&S.slot[pod], slot);
   }
-  // the claim order moves to HBM once it no longer fits the LDS budget
-  KS_DEV void spill_order_if_full() {
-    if (!order_in_lds || n_claims < P.lds.order_cap) return;
-    uint32_t *gk = S.o_key, *go = S.o_ord, *gp = S.o_pos;
-    const uint32_t *lk = L.okey, *lo_ = L.oord, *lp = L.opos;
-    W::for_n(n_claims, [&](int i) { gk[i] = lk[i]; go[i] = lo_[i]; gp[i] = lp[i]; });
-    order.key = gk; order.ord = go; order.pos = gp;
-    order_in_lds = false;
-  }
 
   // ---- in-flight scan: addToInflightNode (scheduler.go:658-692) ---------------------------------------------
-  KS_DEV int try_claim(int k, int c, int pod) {
-    const uint64_t* src = S.c_hot + (size_t)c * lay.c_hot_words();
-    load_words(sc.claim, src, lay.c_hot_words());
-    const uint64_t f1 = sc.claim[lay.c_f1()];
-    const uint32_t m2 = hi32(sc.claim[lay.c_meta2()]);
-    if (f1 != 0 || (m2 & 2u)) load_words(sc.claim_cold, S.c_cold + (size_t)c * lay.cold_words(), lay.cold_words());
+  // dead_word_on_failure = what the class's dead-row word of claim c becomes when the probe fails
+  KS_DEV int try_claim(int k, int c, int pod, uint64_t dead_word_on_failure) {
+    unsigned long long t0 = W::clock();
+    const RecLayout ly = lay;
+    // hot record: from the LDS record cache when this claim was the last one committed to its line, else one coalesced load
+    if (sc.cache_tag[c & 31] == c) load_words(sc.claim, L.cache + (size_t)(c & 31) * ly.c_hot_words(), ly.c_hot_words());
+    else load_words(sc.claim, S.c_hot + (size_t)c * ly.c_hot_words(), ly.c_hot_words());
+    const uint64_t f1 = sc.claim[ly.c_f1()];
+    const uint32_t m2 = hi32(sc.claim[ly.c_meta2()]);
+    if (f1 != 0 || (m2 & 2u)) load_words(sc.claim_cold, S.c_cold + (size_t)c * ly.cold_words(), ly.cold_words());
     bool changed = false, its_changed = false;
+    unsigned long long t1 = W::clock();
+    ctr.cycles[4] += t1 - t0;
     int rc = can_add(sc.claim, sc.claim_cold, false, false, &changed, &its_changed);
-    if (rc != E_OK) { mark_dead(k, c); return rc; }
-    const uint32_t tmpl = lo32(sc.claim[lay.c_meta()]), np = hi32(sc.claim[lay.c_meta()]);
+    unsigned long long t2 = W::clock();
+    ctr.cycles[5] += t2 - t1;
+    if (rc != E_OK) {
+      W::store(&S.dead[(size_t)k * S.claim_words + (c >> 6)], dead_word_on_failure);
+      ctr.cycles[8] += W::clock() - t2;
+      return rc;
+    }
+    const uint32_t tmpl = lo32(sc.claim[ly.c_meta()]), np = hi32(sc.claim[ly.c_meta()]);
     ctr.ref_bin_evaluations += (unsigned long long)order.pos[c] + 1;   // the reference walked every claim up to this position
     if (!changed) {
       // requirements untouched: carry masks and flags over from the bin record
       uint64_t* o = sc.out;
       const uint64_t* b = sc.claim;
-      const RecLayout ly = lay;
-      W::for_n(ly.rw, [&](int w) { o[w] = b[w]; });
-      if (W::leader()) { o[ly.c_f0()] = b[ly.c_f0()]; o[ly.c_f1()] = b[ly.c_f1()]; }
-      W::sync();
+      W::for_n(ly.rw + 2, [&](int w) { int i = w < ly.rw ? w : ly.c_f0() + (w - ly.rw); o[i] = b[i]; });
     }
-    const bool out_cold = changed && (sc.out[lay.c_f1()] != 0 || (m2 & 2u));
-    finish_record(c, sc.claim, its_changed, tmpl, np + 1, lo32(sc.claim[lay.c_meta2()]), m2, out_cold);
+    const bool out_cold = changed && (sc.out[ly.c_f1()] != 0 || (m2 & 2u));
+    finish_record(c, sc.claim, its_changed, tmpl, np + 1, lo32(sc.claim[ly.c_meta2()]), m2, out_cold);
     order.increment(c);
     if (changed) reset_column(c);
     commit_pod(pod, c, np);
+    ctr.cycles[6] += W::clock() - t2;
     return E_OK;
   }
   KS_DEV bool scan_inflight(int k, int pod) {
     if (n_claims == 0) return false;
     const int words = (n_claims + 63) >> 6;
-    const uint64_t* drow = S.dead + (size_t)k * S.claim_words;
-    const uint64_t* closed = S.closed;
+    if (words > 64) return scan_inflight_walk(k, pod);
+    uint64_t* drow = S.dead + (size_t)k * S.claim_words;
+    const uint64_t* closed = L.closed;
     const int nc = n_claims;
-    // Steady state: only a handful of claims are not yet known infeasible for this class. One coalesced load of the
-    // class's dead row (64 words = 4096 claims per step), ballot the words with live bits, gather those claims and
-    // probe them in position order (lowest position wins, scheduler.go:673-676).
-    int ncand = 0;
-    bool overflow = false;
     uint64_t* stage = sc.stage;
-    for (int w0 = 0; w0 < words && !overflow; w0 += 64) {
-      int wn = words - w0 < 64 ? words - w0 : 64;
-      uint64_t any = W::ballot([&](int l) {
-        if (l >= wn) return false;
-        int w = w0 + l;
-        uint64_t valid = (w == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
-        uint64_t a = ~drow[w] & ~closed[w] & valid;
-        stage[l] = a;
-        return a != 0;
-      });
-      W::sync();
-      while (any && !overflow) {
-        int l = ctz64(any);
-        any &= any - 1;
-        uint64_t a = stage[l];
-        while (a) {
-          int b = ctz64(a); a &= a - 1;
-          if (ncand >= 64) { overflow = true; break; }
-          int c = (w0 + l) * 64 + b;
-          W::store(&sc.cand[ncand], ((uint64_t)order.pos[c] << 32) | (uint32_t)c);
-          ncand++;
-        }
+    // One coalesced load of the class's dead row (lane l holds word l: up to 4096 claims), live = not dead, not closed,
+    // staged in LDS so that everything after it is LDS-only.
+    uint64_t any = W::ballot([&](int l) {
+      uint64_t a = 0;
+      if (l < words) {
+        uint64_t valid = (l == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
+        a = ~drow[l] & ~closed[l] & valid;
       }
-    }
+      stage[l] = a;
+      return a != 0;
+    });
     W::sync();
-    if (!overflow) {
-      if (ncand == 0) return false;
-      for (;;) {
-        const uint64_t* cand = sc.cand;
-        uint64_t best = W::reduce_min(ncand, [&](int i) { return cand[i]; });
-        if (best == ~0ull) return false;
-        int c = (int)(uint32_t)best;
-        if (try_claim(k, c, pod) == E_OK) return true;
-        for (int i = 0; i < ncand; ++i) if (sc.cand[i] == best) W::store(&sc.cand[i], (uint64_t)~0ull);
+    if (!any) return false;
+    // Walk the claims in the reference's order (addToInflightNode, scheduler.go:667-686), 64 positions per ballot, testing
+    // the staged live bits: the first live position is the first candidate; a failed probe clears its bit.
+    const KS_LDS uint32_t* ord = order.ord;
+    for (int base = 0; base < nc; base += 64) {
+      uint64_t m = W::ballot([&](int l) {
+        int i = base + l;
+        if (i >= nc) return false;
+        uint32_t c = ord[i];
+        return ((stage[c >> 6] >> (c & 63)) & 1) != 0;
+      });
+      while (m) {
+        int i = base + ctz64(m);
+        m &= m - 1;
+        const int c = (int)ord[i];
+        const int l = c >> 6;
+        const uint64_t valid = (l == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
+        const uint64_t live = stage[l] & ~(1ull << (c & 63));
+        // on failure the class's dead word becomes: everything not live any more (closed claims may be recorded as dead
+        // too — both are permanent until the column is reset), never touching bits of claims that do not exist yet
+        if (try_claim(k, c, pod, ~live & valid) == E_OK) return true;
+        W::store(&stage[l], live);
         W::sync();
       }
     }
-    // Many live claims (a class seen for the first time, or very many open bins): walk the claims in the reference's
-    // order, 64 positions per step, ballot the live ones and probe them lowest position first.
+    return false;
+  }
+  // Ordered walk (more than 4096 claims with live ones in several blocks, or a class seen for the first time with very
+  // many open bins): 64 positions per step, ballot the live ones and probe them lowest position first.
+  KS_DEV bool scan_inflight_walk(int k, int pod) {
     ctr.walk_scans++;
+    uint64_t* drow = S.dead + (size_t)k * S.claim_words;
+    const uint64_t* closed = L.closed;
+    const int nc = n_claims;
     for (int base = 0; base < nc; base += 64) {
-      const uint32_t* ord = order.ord;
+      const KS_LDS uint32_t* ord = order.ord;
       uint64_t m = W::ballot([&](int l) {
         int i = base + l;
         if (i >= nc) return false;
@@ -552,7 +597,7 @@ struct Engine {
       while (m) {
         int l = ctz64(m); m &= m - 1;
         int c = (int)order.ord[base + l];
-        if (try_claim(k, c, pod) == E_OK) return true;
+        if (try_claim(k, c, pod, drow[c >> 6] | (1ull << (c & 63))) == E_OK) return true;
       }
     }
     return false;
@@ -603,8 +648,7 @@ struct Engine {
       ctr.ref_bin_evaluations++;
       int rc = can_add(bin, tcold, true, first_err == 0, &changed, nullptr);
       if (rc != E_OK) { if (!first_err) { first_err = rc; first_diag = rc == E_INSTANCE_TYPES ? last_diag : 0; } continue; }
-      if (n_claims >= S.max_claims) { W::store(S.status_out, 1); return -1; }
-      spill_order_if_full();
+      if (n_claims >= S.max_claims || n_claims >= P.lds.order_cap) { W::store(S.status_out, 1); return -1; }
       int c = n_claims++;
       const uint32_t tm2 = hi32(trec[ly.c_meta2()]);
       uint64_t* o = sc.out;
@@ -646,17 +690,27 @@ struct Engine {
   // add — scheduler.go:582-612
   KS_DEV int add_class(int k, int pod) {
     ctr.sorts++;
+    unsigned long long t0 = W::clock();
     order.sort();                                      // scheduler.go:598
-    if (scan_inflight(k, pod)) return E_OK;            // scheduler.go:601
+    unsigned long long t1 = W::clock();
+    ctr.cycles[2] += t1 - t0;
+    bool ok = scan_inflight(k, pod);                   // scheduler.go:601
+    ctr.cycles[3] += W::clock() - t1;
+    if (ok) return E_OK;
     if (active_templates == 0) { last_diag = 0; return E_NO_TEMPLATES; }   // scheduler.go:604-606
-    return add_to_new_claim(k, pod);                   // scheduler.go:607
+    t1 = W::clock();
+    int rc = add_to_new_claim(k, pod);                 // scheduler.go:607
+    ctr.cycles[7] += W::clock() - t1;
+    return rc;
   }
   // trySchedule — scheduler.go:521-552 ; the relaxation ladder (preferences.go:38-57) is precomputed as a row chain
   KS_DEV int try_schedule(int pod, int k0) {
     int row = pod;
     int k = k0;
     for (;;) {
+      unsigned long long t0 = W::clock();
       fetch_class(k);
+      ctr.cycles[1] += W::clock() - t0;
       int rc = add_class(k, pod);
       if (rc == E_OK || rc < 0) return rc;
       if (rc == E_RESERVED) return rc;
@@ -708,6 +762,7 @@ struct Engine {
 
   // Solve — scheduler.go:440-519 with Queue (queue.go:31-108)
   KS_DEV void solve() {
+    const unsigned long long t_begin = W::clock();
     load_tables();
     prefilter_templates();
     const int np = P.n_pods;
@@ -720,6 +775,7 @@ struct Engine {
     int status = 0;
     int blk_n = 0, blk_i = 0;
     while (qlen > 0) {
+      unsigned long long tq = W::clock();
       if (blk_i >= blk_n) {
         // fetch the next (up to) 64 queue entries with their class ids and lastLen in two coalesced round trips
         blk_n = qlen < 64 ? (int)qlen : 64;
@@ -731,16 +787,20 @@ struct Engine {
         W::for_n(64, [&](int l) {
           if (l < bn) { uint32_t p = queue[(h0 + (uint32_t)l) % cap]; bp[l] = p; bc[l] = rc_[p]; bl[l] = ll[p]; }
         });
+        if (S.cancel_flag && *S.cancel_flag) { status = 2; break; }   // ctx cancellation, polled once per 64 pods
       }
       int pod = (int)sc.blk_pod[blk_i];
       if (sc.blk_last[blk_i] == qlen) break;                                // queue.go:52-56
-      if ((S.max_steps >= 0 && steps >= S.max_steps) || (S.cancel_flag && *S.cancel_flag)) { status = 2; break; }
+      if (S.max_steps >= 0 && steps >= S.max_steps) { status = 2; break; }
       int k0 = (int)sc.blk_class[blk_i];
       blk_i++;
       head = (head + 1) % cap; qlen--;
       steps++;
       ctr.queue_pops++;
+      ctr.cycles[0] += W::clock() - tq;
+      unsigned long long ts = W::clock();
       int rc = try_schedule(pod, k0);
+      ctr.cycles[9] += W::clock() - ts;
       if (rc < 0) { status = 1; break; }
       if (rc != E_OK) {
         W::store(&S.err[pod], (uint8_t)rc);
@@ -755,10 +815,11 @@ struct Engine {
       }
     }
     ctr.slow_sorts = order.slow_sorts;
-    if (order_in_lds) {
+    ctr.cycles[10] = W::clock() - t_begin;
+    {
       // results read the final order from HBM
       uint32_t* go = S.o_ord;
-      const uint32_t* lo_ = L.oord;
+      const KS_LDS uint32_t* lo_ = L.oord;
       W::for_n(n_claims, [&](int i) { go[i] = lo_[i]; });
     }
     W::store(S.n_claims_out, n_claims);

@@ -298,13 +298,17 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     lp.off_tmpl = off; off = align(off + std::max(1u, d->n_templates) * lay.c_hot_words() * 8);
     lp.off_tmplcold = off; off = align(off + std::max(1u, d->n_templates) * lay.cold_words() * 8);
     lp.off_scratch = off; off = align(off + (int)sizeof(ks::Scratch));
+    lp.off_cache = off; off = align(off + 32 * lay.c_hot_words() * 8);
     const int budget = 160 * 1024 - 512;
-    if (off + 12 * 64 > budget) return fail(h, KSOLVE_ERR_UNSUPPORTED, "instance-type tables do not fit the 160 KiB LDS of one CU");
-    int cap = (budget - off) / 12;
+    if (off + 13 * 64 > budget) return fail(h, KSOLVE_ERR_UNSUPPORTED, "instance-type tables do not fit the 160 KiB LDS of one CU");
+    // the claim order (12 B per claim) and the closed bitmap (1 bit per claim) get what is left
+    int cap = (int)(((long long)(budget - off) * 8) / (12 * 8 + 1));
     cap &= ~63;
+    if (cap > 4096) cap = 4096;   // one dead-row word per lane in the first-fit scan
     if (cap > (int)mc) cap = ((int)mc + 63) & ~63;
     lp.off_order = off; lp.order_cap = cap;
-    off += cap * 12;
+    off = align(off + cap * 12);
+    lp.off_closed = off; off = align(off + cap / 8 + 8);
     lp.total_bytes = off;
   }
   be_sync(h);
@@ -411,7 +415,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   be_d2h(h, &status, W.status_out, 4);
   be_sync(h);
   if (!be_ok(h)) return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "pack kernel failed" : h->error);
-  if (status == 1) return fail(h, KSOLVE_ERR_CAPACITY, "claim capacity exceeded (ksolve_options.max_claims)");
+  if (status == 1) return fail(h, KSOLVE_ERR_CAPACITY, "more in-flight NodeClaims than this build keeps resident (ksolve_options.max_claims / 4096 per problem)");
 
   // ---- phase 5: finalize ----
   be_tic(h, T_FINALIZE);
@@ -498,6 +502,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   out->bin_evaluations = ctr.bin_evaluations; out->it_evaluations = ctr.it_evaluations; out->queue_pops = ctr.queue_pops;
   out->sorts = ctr.sorts; out->slow_sorts = ctr.slow_sorts; out->relaxations = ctr.relaxations;
   out->ref_bin_evaluations = ctr.ref_bin_evaluations;
+  for (int i = 0; i < 24; ++i) out->phase_cycles[i] = ctr.cycles[i];
   out->us_upload = h->timers.ms[T_UPLOAD] * 1e3;
   out->us_prepass = (h->timers.ms[T_INDEX] + h->timers.ms[T_CLASSIFY] + h->timers.ms[T_SORT]) * 1e3;
   out->us_pack = h->timers.ms[T_PACK] * 1e3; out->us_finalize = h->timers.ms[T_FINALIZE] * 1e3; out->us_download = h->timers.ms[T_DOWNLOAD] * 1e3;

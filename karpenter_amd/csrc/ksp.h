@@ -79,6 +79,8 @@ struct LdsPlan {
   int off_tmplcold;   // u64 [T][cold_words]
   int off_order;      // u32 key[cap] | ord[cap] | pos[cap]
   int order_cap;
+  int off_closed;     // u64 [cap/64]
+  int off_cache;      // u64 [32][c_hot_words] record cache
   int off_scratch;    // Scratch
   int n_kv;
 };
@@ -129,6 +131,7 @@ struct ProblemView {
 struct Counters {
   unsigned long long bin_evaluations, full_evaluations, it_evaluations, queue_pops, sorts, slow_sorts, relaxations, column_resets, walk_scans;
   unsigned long long ref_bin_evaluations;  // V: candidate bins the reference would have evaluated
+  unsigned long long cycles[24];           // shader clock spent per engine phase (profiling aid)
 };
 
 struct Workspace {

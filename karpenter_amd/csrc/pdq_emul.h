@@ -18,9 +18,9 @@ namespace ks {
 
 template <class W>
 struct ClaimOrder {
-  uint32_t* key;   // [cap] pod count of the claim at position i
-  uint32_t* ord;   // [cap] claim id at position i
-  uint32_t* pos;   // [cap] position of claim id
+  KS_LDS uint32_t* key;   // [cap] pod count of the claim at position i   (LDS resident)
+  KS_LDS uint32_t* ord;   // [cap] claim id at position i
+  KS_LDS uint32_t* pos;   // [cap] position of claim id
   int n = 0;
   int defect = -1;        // position whose key changed since the array was last sorted, -1 = sorted
   bool defect_append = false;
@@ -148,7 +148,7 @@ struct ClaimOrder {
       for (int x = defect; x <= defect + 1; ++x) if (x >= i && x >= 1 && x < b && key[x] < key[x - 1]) return x;
       return b;
     }
-    const uint32_t* kp = key;
+    const KS_LDS uint32_t* kp = key;
     return W::find_first(i, b, [kp](int x) { return kp[x] < kp[x - 1]; });
   }
   KS_FN bool partial_insertion_sort(int a, int b, bool top) {
@@ -157,16 +157,32 @@ struct ClaimOrder {
       i = next_descent(i, b, top);
       if (i == b) return true;
       if (b - a < 50) return false;
+      if (top) {
+        // Single known defect: Go's swap(i,i-1) + the two shift loops amount to ONE rotation of the touched claim to
+        // its stable place (see the derivation in DESIGN.md §4); do it with one search + one rotate.
+        const KS_LDS uint32_t* kq = key;
+        if (defect_append) {           // i == n-1: the new claim moves left behind the last claim with <= its count
+          uint32_t mv = key[i];
+          int t = W::find_last(0, i, [kq, mv](int x) { return !(mv < kq[x]); });
+          rotate_right(t + 1, i);
+        } else {                       // i == p+1: the incremented claim at p moves right past the claims with a smaller count
+          uint32_t mv = key[i - 1];
+          int e = W::find_first(i, b, [kq, mv](int x) { return !(kq[x] < mv); });
+          rotate_left(i - 1, e - 1);
+        }
+        defect = -1;
+        return true;
+      }
       swap(i, i - 1);
       if (i - a >= 2) {  // shift the smaller one to the left (Go uses the absolute bound j >= 1)
         uint32_t mv = key[i - 1];
-        const uint32_t* kp = key;
+        const KS_LDS uint32_t* kp = key;
         int t = W::find_last(0, i - 1, [kp, mv](int x) { return !(mv < kp[x]); });
         rotate_right(t + 1, i - 1);
       }
       if (b - i >= 2) {  // shift the greater one to the right
         uint32_t mv = key[i];
-        const uint32_t* kp = key;
+        const KS_LDS uint32_t* kp = key;
         int e = W::find_first(i + 1, b, [kp, mv](int x) { return !(kp[x] < mv); });
         rotate_left(i, e - 1);
       }
@@ -191,7 +207,7 @@ struct ClaimOrder {
   KS_FN int partition_equal(int a, int b, int pivot) {
     swap(a, pivot);
     uint32_t pv = key[a];
-    const uint32_t* kp = key;
+    const KS_LDS uint32_t* kp = key;
     int i = a + 1, j = b - 1;
     for (;;) {
       i = W::find_first(i, j + 1, [kp, pv](int x) { return pv < kp[x]; });
@@ -204,7 +220,7 @@ struct ClaimOrder {
   KS_FN int partition(int a, int b, int pivot, bool& already) {
     swap(a, pivot);
     uint32_t pv = key[a];
-    const uint32_t* kp = key;
+    const KS_LDS uint32_t* kp = key;
     int i = a + 1, j = b - 1;
     i = W::find_first(i, j + 1, [kp, pv](int x) { return !(kp[x] < pv); });
     j = W::find_last(i, j + 1, [kp, pv](int x) { return kp[x] < pv; });
@@ -278,13 +294,13 @@ struct ClaimOrder {
       // insertionSort_func is a stable sort; with a single defect that is one stable move
       if (defect_append) {
         uint32_t mv = key[n - 1];
-        const uint32_t* kp = key;
+        const KS_LDS uint32_t* kp = key;
         int t = W::find_last(0, n - 1, [kp, mv](int x) { return !(mv < kp[x]); });
         rotate_right(t + 1, n - 1);
       } else {
         int p = defect;
         uint32_t mv = key[p];
-        const uint32_t* kp = key;
+        const KS_LDS uint32_t* kp = key;
         int e = W::find_first(p + 1, n, [kp, mv](int x) { return !(kp[x] < mv); });
         rotate_left(p, e - 1);
       }

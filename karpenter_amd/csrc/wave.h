@@ -15,10 +15,12 @@
 #define KS_DEVICE 1   // compiled by hipcc: the Wave below is the real 64-lane wavefront
 #define KS_FN __host__ __device__ __forceinline__
 #define KS_DEV __device__ __forceinline__
+#define KS_LDS __attribute__((address_space(3)))   // pointers known to point into the CU's LDS: ds_* instead of flat_*
 #else
 #define KS_DEVICE 0   // g++ (host flattener, test-only emulation): a wave is a loop over 64 lanes
 #define KS_FN inline
 #define KS_DEV inline
+#define KS_LDS
 #endif
 
 namespace ks {
@@ -34,6 +36,16 @@ struct Wave {
   }
   template <class F>
   KS_DEV static uint64_t ballot(F f) { return __ballot(f(lane()) ? 1 : 0); }
+  // g(j, ballot(f(lane, j))) for j < n <= 8: all predicates (and their loads) are evaluated before the first ballot, so
+  // eight words cost one LDS latency instead of eight. No arrays: everything stays in registers.
+  template <class F, class G>
+  KS_DEV static void ballots8(int n, F f, G g) {
+    const int l = lane();
+    int p0 = 0 < n ? (int)f(l, 0) : 0, p1 = 1 < n ? (int)f(l, 1) : 0, p2 = 2 < n ? (int)f(l, 2) : 0, p3 = 3 < n ? (int)f(l, 3) : 0;
+    int p4 = 4 < n ? (int)f(l, 4) : 0, p5 = 5 < n ? (int)f(l, 5) : 0, p6 = 6 < n ? (int)f(l, 6) : 0, p7 = 7 < n ? (int)f(l, 7) : 0;
+    if (0 < n) g(0, (uint64_t)__ballot(p0)); if (1 < n) g(1, (uint64_t)__ballot(p1)); if (2 < n) g(2, (uint64_t)__ballot(p2)); if (3 < n) g(3, (uint64_t)__ballot(p3));
+    if (4 < n) g(4, (uint64_t)__ballot(p4)); if (5 < n) g(5, (uint64_t)__ballot(p5)); if (6 < n) g(6, (uint64_t)__ballot(p6)); if (7 < n) g(7, (uint64_t)__ballot(p7));
+  }
   // f(i) for i in [0,n), striped over lanes
   template <class F>
   KS_DEV static void for_n(int n, F f) {
@@ -93,7 +105,35 @@ struct Wave {
   KS_DEV static void store(T* p, T v) {
     if (lane() == 0) *p = v;
   }
+  template <class T>
+  KS_DEV static void store(KS_LDS T* p, T v) {
+    if (lane() == 0) *p = v;
+  }
   KS_DEV static bool leader() { return lane() == 0; }
+  KS_DEV static unsigned long long clock() { return __builtin_readcyclecounter(); }
+  // min over the 64 lanes of a u32 with DPP row operations (no LDS traffic): quad swaps, row rotates, row broadcasts;
+  // the full result lands in lane 63.
+  KS_DEV static uint32_t min_u32(uint32_t v) {
+    int x = (int)v;
+#define KS_DPP_MIN(ctrl, row_mask) { int o = __builtin_amdgcn_update_dpp(-1, x, ctrl, row_mask, 0xf, false); x = ((uint32_t)o < (uint32_t)x) ? o : x; }
+    KS_DPP_MIN(0xB1, 0xf)    // quad_perm [1,0,3,2]
+    KS_DPP_MIN(0x4E, 0xf)    // quad_perm [2,3,0,1]
+    KS_DPP_MIN(0x124, 0xf)   // row_ror:4
+    KS_DPP_MIN(0x128, 0xf)   // row_ror:8
+    KS_DPP_MIN(0x142, 0xa)   // row_bcast:15 -> rows 1,3
+    KS_DPP_MIN(0x143, 0xc)   // row_bcast:31 -> rows 2,3
+#undef KS_DPP_MIN
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+  }
+  // smallest f(lane) over the lanes with valid(lane), as (value, lane); value = ~0u when none
+  template <class F>
+  KS_DEV static uint32_t argmin_u32(F f, int* lane_out) {
+    uint32_t mine = f(lane());
+    uint32_t m = min_u32(mine);
+    uint64_t who = __ballot(mine == m ? 1 : 0);
+    *lane_out = m == 0xFFFFFFFFu ? -1 : (int)__builtin_ctzll(who);
+    return m;
+  }
 };
 
 #else  // host emulation (tests only)
@@ -106,6 +146,10 @@ struct Wave {
     uint64_t m = 0;
     for (int l = 0; l < 64; ++l) if (f(l)) m |= 1ull << l;
     return m;
+  }
+  template <class F, class G>
+  static void ballots8(int n, F f, G g) {
+    for (int j = 0; j < n; ++j) { uint64_t m = 0; for (int l = 0; l < 64; ++l) if (f(l, j)) m |= 1ull << l; g(j, m); }
   }
   template <class F>
   static void for_n(int n, F f) { for (int i = 0; i < n; ++i) f(i); }
@@ -122,6 +166,14 @@ struct Wave {
   template <class T>
   static void store(T* p, T v) { *p = v; }
   static bool leader() { return true; }
+  static unsigned long long clock() { return 0; }
+  template <class F>
+  static uint32_t argmin_u32(F f, int* lane_out) {
+    uint32_t m = 0xFFFFFFFFu; int who = -1;
+    for (int l = 0; l < 64; ++l) { uint32_t x = f(l); if (x < m) { m = x; who = l; } }
+    *lane_out = who;
+    return m;
+  }
 };
 
 #endif

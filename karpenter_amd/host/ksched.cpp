@@ -825,6 +825,7 @@ extern "C" char* ksched_solve(void* session, int want_results) {
     counters.set("pods", Value::integer(n_pods)); counters.set("claims", Value::integer(cl.n_claims));
     counters.set("rows", Value::integer(n_rows)); counters.set("instanceTypes", Value::integer(n_its));
     counters.set("reqWords", Value::integer(rw)); counters.set("itWords", Value::integer(it_words)); counters.set("keys", Value::integer(nk)); counters.set("resources", Value::integer(n_res));
+    { Value pc = Value::array(); for (int i = 0; i < 24; ++i) pc.push(Value::integer((int64_t)res.phase_cycles[i])); counters.set("phaseCycles", pc); }
     out.set("counters", counters);
     out.set("timings", timings);
     out.set("timedOut", Value::boolean(st == KSOLVE_ERR_CANCELLED));
