@@ -556,25 +556,39 @@ struct Engine {
     // Walk the claims in the reference's order (addToInflightNode, scheduler.go:667-686), 64 positions per ballot, testing
     // the staged live bits: the first live position is the first candidate; a failed probe clears its bit.
     const KS_LDS uint32_t* ord = order.ord;
-    for (int base = 0; base < nc; base += 64) {
-      uint64_t m = W::ballot([&](int l) {
-        int i = base + l;
+    for (int base0 = 0; base0 < nc; base0 += 512) {
+      // 512 positions per step: eight independent (ord -> live bit) gathers in flight, then eight ballots
+      const int nchunks = (nc - base0 + 63) / 64 < 8 ? (nc - base0 + 63) / 64 : 8;
+      uint64_t found = 0;   // first chunk with a live position
+      int found_j = -1;
+      W::ballots8(nchunks, [&](int l, int j) {
+        int i = base0 + j * 64 + l;
         if (i >= nc) return false;
         uint32_t c = ord[i];
         return ((stage[c >> 6] >> (c & 63)) & 1) != 0;
-      });
-      while (m) {
-        int i = base + ctz64(m);
-        m &= m - 1;
-        const int c = (int)ord[i];
-        const int l = c >> 6;
-        const uint64_t valid = (l == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
-        const uint64_t live = stage[l] & ~(1ull << (c & 63));
-        // on failure the class's dead word becomes: everything not live any more (closed claims may be recorded as dead
-        // too — both are permanent until the column is reset), never touching bits of claims that do not exist yet
-        if (try_claim(k, c, pod, ~live & valid) == E_OK) return true;
-        W::store(&stage[l], live);
-        W::sync();
+      }, [&](int j, uint64_t m) { if (m && found_j < 0) { found_j = j; found = m; } });
+      if (found_j < 0) continue;
+      // probe from the first live position on, chunk by chunk (re-ballot after a failed probe: stage changed)
+      for (int base = base0 + found_j * 64; base < nc && base < base0 + 512; base += 64) {
+        uint64_t m = base == base0 + found_j * 64 ? found : W::ballot([&](int l) {
+          int i = base + l;
+          if (i >= nc) return false;
+          uint32_t c = ord[i];
+          return ((stage[c >> 6] >> (c & 63)) & 1) != 0;
+        });
+        while (m) {
+          int i = base + ctz64(m);
+          m &= m - 1;
+          const int c = (int)ord[i];
+          const int l = c >> 6;
+          const uint64_t valid = (l == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
+          const uint64_t live = stage[l] & ~(1ull << (c & 63));
+          // on failure the class's dead word becomes: everything not live any more (closed claims may be recorded as
+          // dead too — both are permanent until the column is reset), never touching bits of claims that do not exist yet
+          if (try_claim(k, c, pod, ~live & valid) == E_OK) return true;
+          W::store(&stage[l], live);
+          W::sync();
+        }
       }
     }
     return false;
@@ -680,6 +694,114 @@ struct Engine {
     return first_err ? first_err : E_NO_TEMPLATES;
   }
 
+  // ---- existing nodes: addToExistingNode (scheduler.go:614-656), ExistingNode.CanAdd/Add (existingnode.go:81-185) ----
+  // 64 nodes per step, one lane per node, SoA loads coalesced across lanes; the lowest passing index wins
+  // (scheduler.go:639). Strict Compatible (no AllowUndefinedWellKnownLabels, existingnode.go:100).
+  KS_DEV bool add_to_existing(int k, int pod) {
+    const int ne = P.n_nodes;
+    if (ne == 0) return false;
+    const Dict& d = P.dict;
+    const RecLayout ly = lay;
+    const int nr = ly.nr;
+    const Workspace& Sw = S;
+    const ProblemView& Pv = P;
+    const uint64_t* cls = sc.cls;
+    const uint64_t* cls_cold = sc.cls_cold;
+    const uint32_t kdef = lo32(cls[ly.k_f0()]), kcomp = hi32(cls[ly.k_f0()]);
+    const uint32_t khg = lo32(cls[ly.k_f1()]), khl = hi32(cls[ly.k_f1()]);
+    const uint64_t ktol = cls[ly.k_tol()];
+    const int64_t* req = (const int64_t*)(cls + ly.k_req());
+    // keys on which the pod's operator is NotIn / DoesNotExist (may be undefined on the node, requirements.go:188)
+    uint32_t kneg = 0;
+    for (uint32_t ks_ = kdef; ks_; ks_ &= ks_ - 1) {
+      int key = __builtin_ctz(ks_);
+      bool ne_ = false;
+      for (uint32_t w = d.key_word_off[key]; w < d.key_word_off[key + 1]; ++w) ne_ = ne_ || cls[ly.k_mask() + w] != 0;
+      if (((kcomp >> key) & 1) ? ne_ : !ne_) kneg |= 1u << key;
+    }
+    const bool exempt_pod = Pv.pod_is_pending[pod] != 0 || (Pv.pod_from_deleting && Pv.pod_from_deleting[pod] != 0);
+    uint64_t* ndead = S.n_dead + (size_t)k * P.node_words;
+    for (int base = 0; base < ne; base += 64) {
+      const uint64_t deadw = ndead[base >> 6];
+      const int cnt = ne - base < 64 ? ne - base : 64;
+      const uint64_t validm = cnt == 64 ? ~0ull : ((1ull << cnt) - 1);
+      // nodes under consolidateAfter are skipped for non-pending pods that do not come from a deleting node (:628)
+      const uint64_t skipped = exempt_pod ? 0ull : W::ballot([&](int l) { return l < cnt && (Pv.node_flags[base + l] & 2) != 0; });
+      uint64_t todo = validm & ~deadw & ~skipped;
+      if (!todo) { ctr.ref_bin_evaluations += popc64(validm & ~skipped); continue; }
+      const uint64_t ok = W::ballot([&](int l) {
+        if (!((todo >> l) & 1)) return false;
+        const int e_ = base + l;
+        if (Pv.node_taints[e_] & ~ktol) return false;                                    // taints — existingnode.go:83
+        bool fit = true;                                                                   // resources.Fits — :96
+        for (int r = 0; r < nr; ++r) { int64_t rem = Sw.n_remaining[(size_t)r * ne + e_]; fit = fit && rem >= 0 && req[r] <= rem; }
+        if (!fit) return false;
+        const uint32_t ndef = Sw.n_defined[e_], ncomp = Sw.n_complement[e_];
+        if (kdef & ~ndef & ~kneg) return false;                                           // undefined key — requirements.go:185-193
+        for (uint32_t both = kdef & ndef; both; both &= both - 1) {                       // Intersects — requirements.go:254-274
+          const int key = __builtin_ctz(both);
+          const bool ca = (ncomp >> key) & 1, cb = (kcomp >> key) & 1;
+          if (ca && cb) continue;
+          const bool hg = (khg >> key) & 1, hl = (khl >> key) & 1;
+          bool hit = false, nonempty_n = false;
+          for (uint32_t w = d.key_word_off[key]; w < d.key_word_off[key + 1]; ++w) {
+            const uint64_t a = Sw.n_mask[(size_t)w * ne + e_], b = cls[ly.k_mask() + w];
+            nonempty_n = nonempty_n || a != 0;
+            uint64_t c = ca ? (b & ~a) : cb ? (a & ~b) : (a & b);
+            if (c && (hg || hl)) c = inbounds_word(d, w, c, hg, hg ? ((const int64_t*)cls_cold)[key] : 0, hl, hl ? ((const int64_t*)cls_cold)[ly.nk + key] : 0);
+            hit = hit || c != 0;
+          }
+          if (hit) continue;
+          const bool neg_n = ca ? nonempty_n : !nonempty_n;
+          if (neg_n && ((kneg >> key) & 1)) continue;
+          return false;
+        }
+        return true;
+      });
+      if (!ok) {
+        // every probed node of this block failed: remember it (monotone until the node's requirements change)
+        W::store(&ndead[base >> 6], (uint64_t)(deadw | todo));
+        ctr.ref_bin_evaluations += popc64(validm & ~skipped);
+        continue;
+      }
+      const int l = ctz64(ok);
+      const int en = base + l;
+      const uint64_t below = (l == 0) ? 0ull : ((1ull << l) - 1);
+      W::store(&ndead[base >> 6], (uint64_t)(deadw | (todo & below)));
+      ctr.ref_bin_evaluations += popc64(validm & ~skipped & (below | (1ull << l)));
+      ctr.bin_evaluations += popc64(todo & (below | (1ull << l)));
+      // ---- ExistingNode.Add (existingnode.go:172-185): requirements <- node ∧ pod, remaining -= requests
+      ReqBuf& m = sc.merged;
+      uint64_t* nm = S.n_mask;
+      W::for_n(ly.rw, [&](int w) { m.mask[w] = nm[(size_t)w * ne + en]; });
+      if (W::leader()) {
+        m.defined = Sw.n_defined[en]; m.complement = Sw.n_complement[en]; m.has_gte = m.has_lte = m.has_minv = 0;
+        for (int kk = 0; kk < ly.nk; ++kk) { m.gte[kk] = 0; m.lte[kk] = 0; m.minv[kk] = -1; }
+      }
+      W::sync();
+      ReqRef q = class_ref(sc.cls, sc.cls_cold);
+      const bool changed = reqbuf_add(d, sc.merged, q);
+      if (changed) {
+        W::for_n(ly.rw, [&](int w) { nm[(size_t)w * ne + en] = m.mask[w]; });
+        W::store(&S.n_defined[en], m.defined);
+        W::store(&S.n_complement[en], m.complement);
+        uint64_t* nd = S.n_dead;
+        const int nwd = P.node_words;
+        const uint64_t clr = ~(1ull << (en & 63));
+        W::for_n(P.n_classes, [&](int kk) { nd[(size_t)kk * nwd + (en >> 6)] &= clr; });
+      }
+      int64_t* nrem = S.n_remaining;
+      W::for_n(nr, [&](int r) { nrem[(size_t)r * ne + en] -= req[r]; });                  // resources.SubtractFrom — existingnode.go:175
+      const uint32_t np_ = S.n_npods[en];
+      W::store(&S.n_npods[en], np_ + 1);
+      W::store(&S.assign[pod], (int32_t)(-2 - en));
+      W::store(&S.slot[pod], np_);
+      W::sync();
+      return true;
+    }
+    return false;
+  }
+
   // ---- class record of the pod being placed ----------------------------------------------------------------
   KS_DEV void fetch_class(int k) {
     const int hw = lay.k_hot_words();
@@ -689,6 +811,7 @@ struct Engine {
 
   // add — scheduler.go:582-612
   KS_DEV int add_class(int k, int pod) {
+    if (add_to_existing(k, pod)) return E_OK;          // scheduler.go:594
     ctr.sorts++;
     unsigned long long t0 = W::clock();
     order.sort();                                      // scheduler.go:598
@@ -763,6 +886,14 @@ struct Engine {
   // Solve — scheduler.go:440-519 with Queue (queue.go:31-108)
   KS_DEV void solve() {
     const unsigned long long t_begin = W::clock();
+    if (P.n_nodes) {
+      // ExistingNodes are mutated by Solve: start from the pristine copies
+      const int ne = P.n_nodes;
+      Workspace& Sw = S;
+      W::for_n(lay.rw * ne, [&](int i) { Sw.n_mask[i] = Sw.n_mask0[i]; });
+      W::for_n(lay.nr * ne, [&](int i) { Sw.n_remaining[i] = Sw.n_remaining0[i]; });
+      W::for_n(ne, [&](int i) { Sw.n_defined[i] = Sw.n_defined0[i]; Sw.n_complement[i] = Sw.n_complement0[i]; Sw.n_npods[i] = 0; });
+    }
     load_tables();
     prefilter_templates();
     const int np = P.n_pods;

@@ -45,7 +45,7 @@ struct ksolve_handle {
   ksi::Timers timers;
   // problem sizes
   uint32_t n_keys = 0, req_words = 0, n_res = 0, n_its = 0, it_words = 0, n_templates = 0, n_pods = 0, n_rows = 0, n_classes = 0;
-  uint32_t max_claims = 0, claim_words = 0, class_capacity = 0;
+  uint32_t max_claims = 0, claim_words = 0, class_capacity = 0, n_nodes = 0;
   int n_kv = 0;
   ks::ProblemView pv{};
   ks::Workspace ws{};
@@ -147,7 +147,9 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   if (d->key_instance_type < 0) return fail(h, KSOLVE_ERR_INVALID, "key_instance_type required");
   if (d->key_word_off[d->key_instance_type + 1] - d->key_word_off[d->key_instance_type] != it_words)
     return fail(h, KSOLVE_ERR_INVALID, "instance-type key dictionary must be the instance type list");
-  if (d->n_nodes) return fail(h, KSOLVE_ERR_UNSUPPORTED, "existing nodes are not solved on the device in this build");
+  if (d->n_nodes) {
+    if (any_nonzero(d->node_reqs.has_gte, d->n_nodes) || any_nonzero(d->node_reqs.has_lte, d->n_nodes)) return fail(h, KSOLVE_ERR_INVALID, "existing-node requirements are label sets: no bounds");
+  }
   if (d->topo.n) return fail(h, KSOLVE_ERR_UNSUPPORTED, "topology groups are not solved on the device in this build");
   if (d->tmpl_reqs.min_values) {
     for (size_t i = 0; i < (size_t)d->n_templates * d->n_keys; ++i)
@@ -252,6 +254,30 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   int64_t* minreq = dz<int64_t>(h, d->n_res);
   R.min_request = minreq; P.min_request = minreq;
 
+  // existing nodes: SoA (word-major masks, dimension-major remaining) so that 64 lanes probe 64 nodes coalesced
+  {
+    const uint32_t ne = d->n_nodes;
+    P.n_nodes = (int)ne; P.node_words = (int)((ne + 63) / 64);
+    h->n_nodes = ne;
+    if (ne) {
+      std::vector<uint64_t> tm((size_t)req_words * ne);
+      for (uint32_t e = 0; e < ne; ++e) for (uint32_t x = 0; x < req_words; ++x) tm[(size_t)x * ne + e] = d->node_reqs.mask[(size_t)e * req_words + x];
+      h->ws.n_mask0 = up(h, tm.data(), tm.size());
+      h->ws.n_defined0 = up(h, d->node_reqs.defined, ne);
+      h->ws.n_complement0 = up(h, d->node_reqs.complement, ne);
+      h->ws.n_remaining0 = up(h, d->node_remaining, (size_t)d->n_res * ne);
+      h->ws.n_mask = dz<uint64_t>(h, tm.size());
+      h->ws.n_defined = dz<uint32_t>(h, ne); h->ws.n_complement = dz<uint32_t>(h, ne);
+      h->ws.n_remaining = dz<int64_t>(h, (size_t)d->n_res * ne);
+      h->ws.n_npods = dz<uint32_t>(h, ne);
+      P.node_taints = up(h, d->node_taints, ne);
+      std::vector<uint8_t> fl(ne);
+      for (uint32_t e = 0; e < ne; ++e) fl[e] = (uint8_t)((d->node_initialized && d->node_initialized[e] ? 1 : 0) | (d->node_under_consolidate_after && d->node_under_consolidate_after[e] ? 2 : 0));
+      P.node_flags = up(h, fl.data(), ne);
+    }
+    P.pod_from_deleting = d->pod_from_deleting_node ? up(h, d->pod_from_deleting_node, d->n_pods) : nullptr;
+  }
+
   ks::SortKeyArgs& S = h->sort_args;
   S.n_pods = d->n_pods; S.n_rows = d->n_pod_rows; S.requests = R.requests;
   S.creation = up(h, d->pod_creation, d->n_pods);
@@ -325,6 +351,7 @@ struct ResultsImpl {
   std::vector<int64_t> requests, gte, lte;
   std::vector<int32_t> minv;
   std::vector<double> cheapest;
+  std::vector<uint32_t> node_npods;
 };
 
 static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
@@ -381,6 +408,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
     R.cls_cold = dz<uint64_t>(h, (size_t)n_classes * P.lay.cold_words());
     R.lay = P.lay;
     h->ws.dead = dz<uint64_t>(h, (size_t)n_classes * h->claim_words);
+    if (h->n_nodes) h->ws.n_dead = dz<uint64_t>(h, (size_t)n_classes * P.node_words);
   }
   if (n_classes > 0) {
     be_fill(h, R.min_request, 0x7F, (size_t)n_res * 8);
@@ -392,6 +420,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   P.cls_tolerates = R.cls_tolerates;
   P.cls_hot = R.cls_hot; P.cls_cold = R.cls_cold;
   if (n_classes) be_fill(h, W.dead, 0, (size_t)n_classes * h->claim_words * 8);
+  if (n_classes && h->n_nodes) be_fill(h, W.n_dead, 0, (size_t)n_classes * P.node_words * 8);
   be_toc(h, T_CLASSIFY);
 
   // ---- phase 3: queue order ----
@@ -448,6 +477,8 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
     be_d2h(h, cheapest.data(), h->d_cheapest, (size_t)C * 8);
     be_d2h(h, ord.data(), W.o_ord, (size_t)C * 4);
   }
+  im->node_npods.resize(h->n_nodes);
+  if (h->n_nodes) be_d2h(h, im->node_npods.data(), W.n_npods, (size_t)h->n_nodes * 4);
   ks::Counters ctr{};
   be_d2h(h, &ctr, W.counters, sizeof(ctr));
   be_sync(h);

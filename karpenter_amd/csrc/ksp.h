@@ -126,6 +126,12 @@ struct ProblemView {
   uint32_t it_keys;              // keys that at least one instance type defines
 
   const uint32_t* sorted_pods;   // [n_pods] queue order (k_sort)
+
+  // existing nodes in sortExistingNodes order (scheduler.go:845-858); SoA so that 64 lanes probe 64 nodes coalesced
+  int n_nodes, node_words;       // node_words = ceil(n_nodes/64)
+  const uint64_t* node_taints;   // [n_nodes]
+  const uint8_t* node_flags;     // [n_nodes] bit0 initialized, bit1 under consolidateAfter
+  const uint8_t* pod_from_deleting; // [n_pods]
 };
 
 struct Counters {
@@ -144,6 +150,14 @@ struct Workspace {
   // first-fit pruning
   uint64_t* dead;                // [n_classes][claim_words] bit set = claim known infeasible for the class
   uint64_t* closed;              // [claim_words] claim cannot take any pod any more
+  // existing nodes (mutable part): ExistingNode.requirements / remainingResources / Pods (existingnode.go:32-45)
+  uint64_t* n_mask;              // [req_words][n_nodes]
+  uint32_t *n_defined, *n_complement; // [n_nodes]
+  int64_t* n_remaining;          // [n_res][n_nodes]
+  uint32_t* n_npods;             // [n_nodes]
+  uint64_t* n_dead;              // [n_classes][node_words] node known infeasible for the class
+  // pristine copies restored at the start of every solve
+  const uint64_t* n_mask0; const uint32_t *n_defined0, *n_complement0; const int64_t* n_remaining0;
   // queue (queue.go): circular buffer of pod ids + lastLen
   uint32_t* queue;               // [n_pods+1]
   uint32_t* last_len;            // [n_pods] 0 = never pushed

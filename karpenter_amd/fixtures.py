@@ -264,6 +264,32 @@ def node_pool(name="default", weight=0, requirements=None, labels=None, taints=N
     return np
 
 
+def state_node(name, instance_type, zone, capacity_type="on-demand", nodepool="default", used=None, taints=None, initialized=True,
+               extra_labels=None, under_consolidate_after=False):
+    """A state.StateNode as the scheduler reads it (existingnode.go:47-75): labels of a node launched from `instance_type`
+    in `zone` (single-valued instance-type requirements become labels, like the fake/KWOK providers do on Create),
+    Available() = allocatable - used, Capacity() incl. nodes: 1 (statenode.go:370-374)."""
+    labels = {}
+    for r in instance_type["requirements"]:
+        if r["operator"] == "In" and len(r["values"]) == 1:
+            labels[r["key"]] = r["values"][0]
+    labels.update({ZONE: zone, CAPACITY_TYPE: capacity_type, NODEPOOL: nodepool, HOSTNAME: name,
+                   "karpenter.sh/registered": "true", "karpenter.sh/initialized": "true"})
+    labels.update(extra_labels or {})
+    from decimal import Decimal
+    def nano(q):
+        m = re.fullmatch(r"([0-9.]+)([a-zA-Z]*)", str(q))
+        mult = {"": 1, "m": Decimal("0.001"), "k": 10**3, "M": 10**6, "G": 10**9, "T": 10**12, "Ki": 2**10, "Mi": 2**20, "Gi": 2**30, "Ti": 2**40}[m.group(2)]
+        return int(Decimal(m.group(1)) * mult * 10**9)
+    avail = {}
+    for k, v in instance_type["capacity"].items():
+        a = nano(v) - nano(instance_type["overhead"].get(k, "0")) - nano((used or {}).get(k, "0"))
+        avail[k] = f"{a}n"
+    cap = dict(instance_type["capacity"]); cap["nodes"] = "1"
+    return {"name": name, "labels": labels, "taints": [dict({"key": "", "value": "", "effect": ""}, **t) for t in (taints or [])],
+            "available": avail, "capacity": cap, "initialized": initialized, "managed": True, "underConsolidateAfter": under_consolidate_after}
+
+
 def problem(instance_types, node_pools, pods=None, pod_groups=None, well_known=FAKE_WELL_KNOWN, state_nodes=None, cluster_pods=None,
             daemonset_pods=None, options=None, deleting_node_names=None):
     return {"wellKnownLabels": list(well_known), "options": dict(options or {}), "instanceTypes": instance_types, "nodePools": node_pools,

@@ -261,6 +261,7 @@ struct PodSpec {
   std::string uid;
   long long creation = 0;
   bool pending = true;
+  std::string node_name;
   std::map<std::string, i128> requests;
   Value node_selector;
   bool has_node_affinity = false, has_required = false;
@@ -354,6 +355,7 @@ static PodSpec parse_pod(const Value& v) {
   p.uid = v.at("uid").s();
   p.creation = v.at("creationTimestamp").i(0);
   p.pending = v.at("phase").s("Pending") == "Pending";
+  p.node_name = v.at("nodeName").s("");
   p.requests = parse_resources(v.at("requests"));
   p.node_selector = v.at("nodeSelector");
   const Value& na = v.at("nodeAffinity");
@@ -393,7 +395,8 @@ struct Session {
   ksolve_handle* handle = nullptr;
   Value root;
   Flattener fl;
-  std::vector<std::string> pool_names, uid_text, res_names, it_names;
+  std::vector<std::string> pool_names, uid_text, res_names, it_names, node_names;
+  std::vector<uint8_t> node_initialized;
   std::vector<std::pair<uint64_t, uint64_t>> group_of_pod;
   std::vector<i128> scale;
   int n_pods = 0, n_rows = 0, n_its = 0, n_res = 0, it_words = 0;
@@ -419,7 +422,6 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     const Value& opts = root.at("options");
     bool ignore_prefs = opts.at("preferencePolicy").s("Respect") == "Ignore";
     if (opts.at("reservedCapacity").boolean_or(false)) throw Unsupported("reserved capacity is not solved on the device in this build");
-    if (root.at("stateNodes").items().size()) throw Unsupported("existing nodes are not solved on the device in this build");
     if (root.at("daemonSetPods").items().size()) throw Unsupported("daemonset overhead is not solved on the device in this build");
 
     // ---- instance types ----
@@ -570,7 +572,28 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         break;
       }
     }
-    if (D.key_index.count(kHostname)) throw Unsupported("requirements on kubernetes.io/hostname are not solved on the device in this build");
+    // ---- existing nodes (state.StateNode read accessors): sortExistingNodes order (scheduler.go:845-858) ----
+    struct NodeIn { const Value* v; std::string name, hostname; bool initialized; };
+    std::vector<NodeIn> nodes;
+    for (auto& nv : root.at("stateNodes").items()) {
+      NodeIn n{&nv, nv.at("name").s(), "", nv.at("initialized").boolean_or(true)};
+      n.hostname = nv.has("hostname") ? nv.at("hostname").s() : (nv.at("labels").has(kHostname) ? nv.at("labels").at(kHostname).s() : n.name);
+      if (nv.at("daemonSetRequests").members().size()) throw Unsupported("daemonset requests on existing nodes");
+      nodes.push_back(n);
+    }
+    std::stable_sort(nodes.begin(), nodes.end(), [](const NodeIn& a, const NodeIn& b) { if (a.initialized != b.initialized) return a.initialized; return a.name < b.name; });
+    const int n_nodes = (int)nodes.size();
+    std::vector<std::vector<Expr>> node_exprs(n_nodes);
+    std::vector<uint64_t> node_taints(n_nodes, 0);
+    for (int e = 0; e < n_nodes; ++e) {
+      node_exprs[e] = label_exprs(nodes[e].v->at("labels"));
+      // NewExistingNode adds hostname In [HostName()] (existingnode.go:72); drop a hostname label so it is not intersected twice
+      node_exprs[e].erase(std::remove_if(node_exprs[e].begin(), node_exprs[e].end(), [](const Expr& x) { return x.key == kHostname; }), node_exprs[e].end());
+      if (nodes[e].v->at("labels").has(kHostname)) node_exprs[e].push_back(Expr{kHostname, "In", {nodes[e].v->at("labels").at(kHostname).s()}, -1});
+      node_exprs[e].push_back(Expr{kHostname, "In", {nodes[e].hostname}, -1});
+      for (auto& x : node_exprs[e]) D.note(x);
+      for (auto& tv : nodes[e].v->at("taints").items()) node_taints[e] |= 1ull << taint_id(Taint{tv.at("key").s(), tv.at("value").s(), tv.at("effect").s()});
+    }
 
     // ---- resources: dimensions and exact scales ----
     std::vector<std::string> res_names = {"cpu", "memory"};
@@ -588,6 +611,11 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       const Value& np = *pools[t].v;
       if (np.has("limits") && !np.at("limits").is_null()) { tmpl_has_limits[t] = true; tmpl_limits[t] = parse_resources(np.at("limits")); for (auto& kv : tmpl_limits[t]) add_res(kv.first); }
     }
+    std::vector<std::map<std::string, i128>> node_avail(n_nodes), node_cap(n_nodes);
+    for (int e = 0; e < n_nodes; ++e) {
+      node_avail[e] = parse_resources(nodes[e].v->at("available")); node_cap[e] = parse_resources(nodes[e].v->at("capacity"));
+      for (auto& kv : node_avail[e]) add_res(kv.first);
+    }
     const int n_res = (int)res_names.size();
     if (n_res > KSOLVE_MAX_RES) throw Unsupported("more than 8 resource dimensions");
     std::vector<i128> scale(n_res, 1000000000);  // nano-units per device unit; shrink until every quantity divides
@@ -602,6 +630,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     for (int i = 0; i < n_its; ++i) { consider(it_cap[i]); consider(it_over[i]); }
     for (auto& s : specs) consider(s.requests);
     for (int t = 0; t < n_templates; ++t) consider(tmpl_limits[t]);
+    for (int e = 0; e < n_nodes; ++e) { consider(node_avail[e]); consider(node_cap[e]); }
     auto to_dev = [&](int r, i128 nano) {
       i128 v = nano / scale[r];
       if (v > (i128)(INT64_MAX / 4) || v < -(i128)(INT64_MAX / 4)) throw Unsupported("resource quantity does not fit the device's exact int64 encoding");
@@ -662,6 +691,12 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         }
       } else for (int i = 0; i < n_its; ++i) tmpl_its[(size_t)t * it_words + i / 64] |= 1ull << (i % 64);
       if (tmpl_has_limits[t]) {
+        // updateRemainingResources (scheduler.go:835-842): limits minus the capacity of the pool's existing nodes
+        for (int e = 0; e < n_nodes; ++e) {
+          const Value& nl = nodes[e].v->at("labels");
+          if (!nl.has(kNodePool) || nl.at(kNodePool).s() != pools[t].name) continue;
+          for (auto& kv : tmpl_limits[t]) { auto f = node_cap[e].find(kv.first); if (f != node_cap[e].end()) kv.second -= f->second; }
+        }
         for (auto& kv : tmpl_limits[t]) {
           if (kv.first == "nodes") { tmpl_limit_mask[t] |= 1u << n_res; tmpl_lim[(size_t)t * (n_res + 1) + n_res] = (int64_t)(kv.second / 1000000000); continue; }
           int r = (int)(std::find(res_names.begin(), res_names.end(), kv.first) - res_names.begin());
@@ -669,6 +704,20 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
           tmpl_lim[(size_t)t * (n_res + 1) + r] = to_dev(r, kv.second);
         }
       }
+    }
+    // existing node tables
+    ReqTableBuilder node_reqs;
+    node_reqs.init(n_nodes, rw, nk);
+    std::vector<int64_t> node_remaining((size_t)n_res * std::max(1, n_nodes), 0);
+    std::vector<uint8_t> node_init(std::max(1, n_nodes), 0), node_uca(std::max(1, n_nodes), 0);
+    for (int e = 0; e < n_nodes; ++e) {
+      ks::ReqBuf b;
+      Flattener::clear(b);
+      for (auto& x : node_exprs[e]) { ks::ReqBuf one; fl.encode(x, one); ks::reqbuf_add(fl.kd, b, ks::reqbuf_ref_with_minv(one)); }
+      node_reqs.put(e, b);
+      for (int r = 0; r < n_res; ++r) node_remaining[(size_t)r * n_nodes + e] = to_dev(r, res_get(node_avail[e], res_names[r]));
+      node_init[e] = nodes[e].initialized ? 1 : 0;
+      node_uca[e] = (opts.at("consolidationSimulation").boolean_or(false) && nodes[e].v->at("underConsolidateAfter").boolean_or(false)) ? 1 : 0;
     }
     // pod rows: rows [0,n_pods) are the pods; ladder rows are shared per spec and appended after
     std::vector<int> spec_first_extra(specs.size(), -1);
@@ -720,7 +769,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     ksolve_problem_desc d{};
     d.abi_version = KSOLVE_ABI_VERSION;
     d.n_keys = (uint32_t)nk; d.key_word_off = fl.key_word_off.data(); d.well_known_mask = fl.kd.well_known_mask;
-    d.key_instance_type = fl.kd.key_it; d.key_zone = fl.kd.key_zone; d.key_capacity_type = fl.kd.key_ct; d.key_hostname = -1;
+    d.key_instance_type = fl.kd.key_it; d.key_zone = fl.kd.key_zone; d.key_capacity_type = fl.kd.key_ct;
     d.value_int = fl.value_int.data(); d.value_is_int = fl.value_is_int.data();
     d.n_res = (uint32_t)n_res;
     d.n_its = (uint32_t)n_its; d.it_allocatable = it_alloc.data(); d.it_capacity = it_capv.data(); d.it_reqs = it_reqs.view();
@@ -731,6 +780,16 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     d.pod_reqs = pod_reqs.view(); d.pod_strict_reqs = pod_strict.view(); d.pod_tolerates = pod_tol.data(); d.pod_next_variant = pod_next.data();
     d.pod_creation = pod_creation.data(); d.pod_uid_hi = uid_hi.data(); d.pod_uid_lo = uid_lo.data(); d.pod_is_pending = pod_pending.data();
     d.n_taints = (uint32_t)distinct_taints.size();
+    d.key_hostname = fl.kd.key_hostname;
+    d.n_nodes = (uint32_t)n_nodes; d.node_reqs = node_reqs.view(); d.node_taints = node_taints.data(); d.node_remaining = node_remaining.data();
+    d.node_initialized = node_init.data(); d.node_under_consolidate_after = node_uca.data();
+    std::vector<uint8_t> pod_from_deleting(std::max(1, n_pods), 0);
+    {
+      std::set<std::string> deleting;
+      for (auto& nn : root.at("deletingNodeNames").items()) deleting.insert(nn.s());
+      if (!deleting.empty()) for (int p = 0; p < n_pods; ++p) if (deleting.count(specs[pod_spec[p]].node_name)) pod_from_deleting[p] = 1;
+    }
+    d.pod_from_deleting_node = pod_from_deleting.data();
     ksolve_options ko{};
     ko.min_values_best_effort = opts.at("minValuesPolicy").s("Strict") == "BestEffort";
     ko.max_claims = (uint32_t)opts.at("maxClaims").i(0);
@@ -745,6 +804,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       return S;
     }
     for (auto& p : pools) S->pool_names.push_back(p.name);
+    for (auto& n : nodes) { S->node_names.push_back(n.name); S->node_initialized.push_back(n.initialized ? 1 : 0); }
     S->uid_text = uid_text; S->group_of_pod = group_of_pod; S->res_names = res_names; S->scale = scale;
     for (int i = 0; i < n_its; ++i) S->it_names.push_back(its_json[i].at("name").s());
     S->n_pods = n_pods; S->n_rows = n_rows; S->n_its = n_its; S->n_res = n_res; S->it_words = it_words;
@@ -832,13 +892,16 @@ extern "C" char* ksched_solve(void* session, int want_results) {
     out.set("packingCost", Value::number(res.packing_cost));
     int unscheduled = 0;
     for (int p = 0; p < n_pods; ++p) if (res.pod_assignment[p] == -1) unscheduled++;
+    counters.set("existingNodes", Value::integer((int64_t)S->node_names.size()));
     out.set("scheduledPods", Value::integer(n_pods - unscheduled));
     if (want_results) {
       std::vector<std::vector<std::pair<uint32_t, int>>> members(cl.n_claims);
+      std::vector<std::vector<std::pair<uint32_t, int>>> node_members(S->node_names.size());
       Value errs = Value::object();
       for (int p = 0; p < n_pods; ++p) {
         int a = res.pod_assignment[p];
         if (a >= 0) members[a].push_back({res.pod_slot[p], p});
+        else if (a <= -2) node_members[-2 - a].push_back({res.pod_slot[p], p});
         else { Value e = Value::object(); e.set("code", Value::integer(res.pod_error[p])); e.set("diag", Value::integer(res.pod_error_diag[p])); errs.set(uid_of(p), e); }
       }
       Value claims = Value::array();
@@ -895,7 +958,18 @@ extern "C" char* ksched_solve(void* session, int want_results) {
         claims.push(cj);
       }
       out.set("newNodeClaims", claims);
-      out.set("existingNodes", Value::array());
+      Value ens = Value::array();
+      for (size_t e = 0; e < S->node_names.size(); ++e) {
+        Value ej = Value::object();
+        ej.set("name", Value::string(S->node_names[e]));
+        std::sort(node_members[e].begin(), node_members[e].end());
+        Value pj = Value::array();
+        for (auto& m : node_members[e]) pj.push(Value::string(uid_of(m.second)));
+        ej.set("pods", pj);
+        ej.set("initialized", Value::boolean(S->node_initialized[e] != 0));
+        ens.push(ej);
+      }
+      out.set("existingNodes", ens);
       out.set("podErrors", errs);
     }
     api.results_free(&res);

@@ -112,6 +112,56 @@ def test_taints_weights_and_limits(oracle, emu):
     check(oracle, emu, fx.problem(its, [fx.node_pool("n", limits={"nodes": "0"})], pods[:2]))
 
 
+def _cluster(its, rng, n_nodes, pools=("default",)):
+    nodes = []
+    zones = sorted({z for t in its for r in t["requirements"] if r["key"] == fx.ZONE for z in r["values"]})
+    for i in range(n_nodes):
+        t = rng.choice(its)
+        tz = [z for r in t["requirements"] if r["key"] == fx.ZONE for z in r["values"]] or zones
+        used = {"cpu": f"{rng.choice([0, 100, 500, 1500])}m", "pods": str(rng.choice([0, 1, 3]))}
+        taints = [{"key": "team", "value": "0", "effect": "NoSchedule"}] if rng.random() < 0.2 else None
+        nodes.append(fx.state_node(f"node-{rng.randrange(10**6):06d}-{i}", t, rng.choice(tz), rng.choice(["spot", "on-demand"]), rng.choice(pools), used=used,
+                                   taints=taints, initialized=rng.random() < 0.8, under_consolidate_after=rng.random() < 0.2))
+    return nodes
+
+
+def test_existing_nodes_first_fit(oracle, emu):
+    # suite_test.go "Existing Nodes" :2606-2727 / "In-Flight Nodes" :1829-2016: existing capacity is used before new claims,
+    # initialized nodes first then by name (scheduler.go:845-858), strict requirement compatibility (existingnode.go:100)
+    its = fx.fake_default_instance_types()
+    by = {t["name"]: t for t in its}
+    nodes = [fx.state_node("node-b", by["default-instance-type"], "test-zone-1", used={"cpu": "1"}),
+             fx.state_node("node-a", by["small-instance-type"], "test-zone-2"),
+             fx.state_node("node-c", by["default-instance-type"], "test-zone-3", initialized=False),
+             fx.state_node("node-t", by["arm-instance-type"], "test-zone-1", taints=[{"key": "k", "value": "v", "effect": "NoSchedule"}])]
+    pods = ([fx.pod(requests={"cpu": "1"}) for _ in range(8)] + [fx.pod(requests={"cpu": "500m"}, node_selector={fx.ZONE: "test-zone-3"}) for _ in range(3)]
+            + [fx.pod(requests={"cpu": "3"}, tolerations=[{"key": "k", "operator": "Exists"}]) for _ in range(4)] + [fx.pod(requests={"cpu": "1"}, node_selector={"custom": "x"})]
+            + [fx.pod(node_selector={fx.HOSTNAME: "node-a"}), fx.pod(node_requirements=[fx.req(fx.HOSTNAME, "NotIn", "node-a", "node-b")])])
+    got, want = check(oracle, emu, fx.problem(its, [fx.node_pool(limits={"cpu": "100"})], pods, state_nodes=nodes))
+    assert [e["name"] for e in got["existingNodes"]] == ["node-a", "node-b", "node-t", "node-c"]
+    assert sum(len(e["pods"]) for e in got["existingNodes"]) > 0 and len(got["newNodeClaims"]) >= 1
+
+
+def test_existing_nodes_consolidation_simulation_fuzz(oracle, emu):
+    # disruption.SimulateScheduling (helpers.go:53-155) shapes: non-pending pods from candidate nodes, nodes under
+    # consolidateAfter are skipped unless the pod is pending or comes from a deleting node (scheduler.go:628)
+    rng = random.Random(77)
+    for trial in range(12):
+        its = fx.kwok_catalog(rng.choice([12, 40, 144]))
+        nodes = _cluster(its, rng, rng.choice([3, 40, 150]))
+        pods = []
+        for j in range(rng.choice([10, 120])):
+            sel = {fx.ZONE: rng.choice(fx.KWOK_ZONES)} if rng.random() < 0.3 else {}
+            pods.append(fx.pod(requests={"cpu": f"{rng.choice([100, 500, 2000])}m", "memory": f"{rng.choice([256, 2048])}Mi"}, node_selector=sel,
+                               tolerations=[{"key": "team", "operator": "Exists"}] if rng.random() < 0.4 else None,
+                               phase=rng.choice(["Pending", "Running"]), node_name=rng.choice(["", "gone-node"])))
+        np_ = fx.node_pool("default", limits={"cpu": str(rng.choice([8, 200, 100000]))})
+        np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+        prob = fx.problem(its, [np_], pods, well_known=fx.KWOK_WELL_KNOWN, state_nodes=nodes, options={"consolidationSimulation": True},
+                          deleting_node_names=["gone-node"] if rng.random() < 0.5 else [])
+        check(oracle, emu, prob)
+
+
 def test_empty_and_degenerate_inputs(oracle, emu):
     its = fx.fake_default_instance_types()
     check(oracle, emu, fx.problem(its, [fx.node_pool()], []))

@@ -66,6 +66,23 @@ def test_edge_cases(oracle):
     check(oracle, fx.problem(its, [fx.node_pool()], pods))
 
 
+def test_existing_nodes(oracle):
+    import random
+    rng = random.Random(5)
+    its = fx.kwok_catalog(144)
+    nodes = []
+    for i in range(300):
+        it = rng.choice(its)
+        nodes.append(fx.state_node(f"node-{i:04d}", it, rng.choice(fx.KWOK_ZONES), rng.choice(["spot", "on-demand"]), "default",
+                                   used={"cpu": f"{rng.choice([0, 500, 1500])}m"}, initialized=rng.random() < 0.9, under_consolidate_after=rng.random() < 0.2))
+    pods = [fx.pod(requests={"cpu": f"{rng.choice([100, 500, 2000])}m", "memory": f"{rng.choice([256, 2048])}Mi"},
+                   node_selector={fx.ZONE: rng.choice(fx.KWOK_ZONES)} if rng.random() < 0.3 else {}, phase=rng.choice(["Pending", "Running"])) for _ in range(3000)]
+    np_ = fx.node_pool("default")
+    np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    got, _ = check(oracle, fx.problem(its, [np_], pods, well_known=fx.KWOK_WELL_KNOWN, state_nodes=nodes, options={"consolidationSimulation": True}))
+    assert sum(len(e["pods"]) for e in got["existingNodes"]) > 100
+
+
 def test_full_size_properties():
     """BASELINE configs[1] scale (the oracle cannot run this in seconds): properties that hold for any correct packing."""
     n = int(os.environ.get("KSOLVE_FULL_PODS", "200000"))
