@@ -51,11 +51,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
+    device_index = local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        ngpu = torch.cuda.device_count()
+        if ngpu >= world:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+            reduce_device = "cuda"
+        else:
+            # fewer GPUs than ranks (smoke-testing the launcher on a 1-GPU box): ranks share GPUs, collectives on gloo
+            device_index = local_rank % max(1, ngpu)
+            torch.cuda.set_device(device_index)
+            dist.init_process_group(backend="gloo")
+            reduce_device = "cpu"
 
     import __graft_entry__
     if rank == 0:
@@ -66,7 +76,7 @@ def main():
     from karpenter_amd.scheduling import NewScheduler
 
     prob = fx.config2(pods=args.pods, n_types=args.types, seed=42 + rank)
-    prob["options"]["device"] = local_rank
+    prob["options"]["device"] = device_index
     sched = NewScheduler(prob)  # flatten + upload: inputs resident in HBM before the timed region
 
     def sync():
@@ -94,10 +104,10 @@ def main():
 
     if dist is not None:
         # max over ranks of the timed region; whole-job pods; global packing summary over xGMI (RCCL all-reduce)
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        v = torch.tensor([float(scheduled), float(cost), float(claims)], dtype=torch.float64, device="cuda")
+        v = torch.tensor([float(scheduled), float(cost), float(claims)], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
         scheduled, cost, claims = int(v[0].item()), float(v[1].item()), int(v[2].item())
 

@@ -1,0 +1,64 @@
+"""Consolidation simulator: decisions from the device algorithm (host emulation here, GPU in
+test_gpu_parity.py) must equal the decisions derived from the oracle's Solve() on every probe."""
+import pytest
+
+import parity
+from karpenter_amd import disruption as dz
+from karpenter_amd import fixtures as fx
+from karpenter_amd.scheduling import NewScheduler
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import __graft_entry__  # noqa: F401
+    return parity.build_emu()
+
+
+def strip(cmd):
+    return {k: cmd.get(k) for k in ("decision", "candidates", "replacement", "replacementCapacityType")}
+
+
+def test_simulate_scheduling_delete_replace_noop(oracle, emu):
+    # consolidation_test.go Delete :2396-, Replace :1005-, "can't remove without creating N candidates"
+    its = fx.kwok_catalog(144)
+    by = {t["name"]: t for t in its}
+    np_ = fx.node_pool("default"); np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    def node(name, it, pods_cpu, ct="on-demand"):
+        pods = [fx.pod(requests={"cpu": c, "memory": "128Mi"}, phase="Running", node_name=name) for c in pods_cpu]
+        used = {"cpu": f"{sum(int(float(c[:-1])) if c.endswith('m') else int(float(c) * 1000) for c in pods_cpu)}m", "pods": str(len(pods))}
+        n = fx.state_node(name, by[it], "test-zone-a", ct, "default", used=used)
+        n["pods"] = pods
+        return n
+    big_empty = node("big", "s-16x-amd64-linux", [])
+    small_full = node("small", "c-2x-amd64-linux", ["500m", "500m"])
+    oversized = node("oversized", "m-32x-amd64-linux", ["1000m"])
+    cluster = {"instanceTypes": its, "nodePools": [np_], "nodes": [big_empty, small_full, oversized], "pendingPods": [], "wellKnownLabels": fx.KWOK_WELL_KNOWN}
+    dev = lambda p: NewScheduler(p, solver_lib=emu).Solve()
+    # the small node's pods fit on the big one: DELETE
+    a, b = dz.compute_consolidation(cluster, [small_full], dev), dz.compute_consolidation(cluster, [small_full], oracle.solve)
+    assert strip(a) == strip(b) and a["decision"] == dz.DELETE
+    # without spare capacity the oversized node is REPLACED by something cheaper
+    cluster2 = dict(cluster, nodes=[oversized])
+    a, b = dz.compute_consolidation(cluster2, [oversized], dev), dz.compute_consolidation(cluster2, [oversized], oracle.solve)
+    assert strip(a) == strip(b) and a["decision"] == dz.REPLACE and "m-64x-amd64-linux" not in a["replacement"] and a["replacementCapacityType"] == "spot"
+    # a node that is already the cheapest fit: no-op
+    tight = node("tight", "c-1x-amd64-linux", ["800m"], ct="spot")
+    cluster3 = dict(cluster, nodes=[tight])
+    a, b = dz.compute_consolidation(cluster3, [tight], dev), dz.compute_consolidation(cluster3, [tight], oracle.solve)
+    assert strip(a) == strip(b) and a["decision"] == dz.NOOP
+
+
+def test_sweep_and_binary_search_match_oracle(oracle, emu):
+    cluster = dz.make_cluster(n_nodes=40, pods_per_node=5, seed=3)
+    cands = dz.sort_candidates(cluster, cluster["nodes"])
+    dev = lambda p: NewScheduler(p, solver_lib=emu).Solve()
+    got = dz.sweep(cluster, cands[:15], dev, workers=4)
+    want = dz.sweep(cluster, cands[:15], oracle.solve)
+    assert [strip(c) for c in got] == [strip(c) for c in want]
+    assert any(c["decision"] != dz.NOOP for c in got)
+    for g, w in zip(got, want):
+        parity.assert_same_results(g["results"], w["results"])
+    a, pa = dz.first_n_consolidation_option(cluster, cands, dev)
+    b, pb = dz.first_n_consolidation_option(cluster, cands, oracle.solve)
+    assert pa == pb and strip(a) == strip(b)   # same probe sequence, same command (multinodeconsolidation.go:136-199)
+    assert strip(dz.single_node_consolidation(cluster, cands, dev)) == strip(dz.single_node_consolidation(cluster, cands, oracle.solve))

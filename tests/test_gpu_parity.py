@@ -108,3 +108,20 @@ def test_full_size_properties():
     counts = [len(c["pods"]) for c in a["newNodeClaims"]]
     drops = [i for i in range(1, len(counts)) if counts[i] < counts[i - 1]]
     assert len(drops) <= 1
+
+
+def test_consolidation_sweep(oracle):
+    """SURVEY §8 a20 on the GPU: every probe of a single-node consolidation sweep (independent Solve() calls, run on four
+    concurrent device sessions) gives the oracle's decision and the oracle's Results."""
+    from karpenter_amd import disruption as dz
+    cluster = dz.make_cluster(n_nodes=80, pods_per_node=6, seed=9)
+    cands = dz.sort_candidates(cluster, cluster["nodes"])[:24]
+    got = dz.sweep(cluster, cands, lambda p: NewScheduler(p).Solve(), workers=4)
+    want = dz.sweep(cluster, cands, oracle.solve)
+    keys = ("decision", "candidates", "replacement", "replacementCapacityType")
+    assert [{k: c.get(k) for k in keys} for c in got] == [{k: c.get(k) for k in keys} for c in want]
+    for g, w in zip(got, want):
+        parity.assert_same_results(g["results"], w["results"])
+    a, pa = dz.first_n_consolidation_option(cluster, cands, lambda p: NewScheduler(p).Solve())
+    b, pb = dz.first_n_consolidation_option(cluster, cands, oracle.solve)
+    assert pa == pb and a["decision"] == b["decision"] and a["candidates"] == b["candidates"]
