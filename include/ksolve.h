@@ -31,7 +31,7 @@ extern "C" {
 #define KSOLVE_MAX_ITWORDS 32     /* ceil(n_instance_types / 64) */
 #define KSOLVE_MAX_ZONES 16       /* distinct offering zones  */
 #define KSOLVE_MAX_CAPTYPES 4     /* distinct offering capacity types */
-#define KSOLVE_MAX_TOPO_GROUPS 64
+#define KSOLVE_MAX_TOPO_GROUPS 1024 /* topology groups per problem; pod group masks take ceil(n/64) words */
 
 typedef enum {
   KSOLVE_OK = 0,
@@ -72,21 +72,32 @@ typedef struct {
   const int32_t* min_values;  /* n * n_keys, -1 = nil; may be NULL */
 } ksolve_reqsets;
 
-/* Topology groups (topologygroup.go:55-77), pre-deduplicated by the caller with TopologyGroup.Hash() semantics. */
+/* Topology groups (topologygroup.go:55-77): Topology.topologyGroups then Topology.inverseTopologyGroups
+ * (topology.go:52-56), pre-deduplicated by the caller with TopologyGroup.Hash() semantics (topologygroup.go:188-222).
+ * A group on a dictionary key counts pods per dictionary value of that key; a kubernetes.io/hostname group (key = -1)
+ * counts pods per bin (existing node / in-flight NodeClaim) — the solver owns those domains. */
 typedef struct {
-  uint32_t n;
+  uint32_t n;                  /* <= KSOLVE_MAX_TOPO_GROUPS */
   const uint8_t* type;         /* 0 spread, 1 pod affinity, 2 pod anti-affinity (topologygroup.go:35-41) */
   const uint8_t* inverse;      /* 1 = member of Topology.inverseTopologyGroups (topology.go:56) */
+  const uint8_t* initially_active; /* 1 = created by NewTopology (topology.go:68-103); 0 = created when a pod relaxes into a
+                                    * variant that owns it (topology.go:162-194): it sees no Record before that moment */
   const int32_t* key;          /* requirement key index, or -1 for kubernetes.io/hostname */
   const int32_t* max_skew;
   const int32_t* min_domains;  /* -1 = nil */
-  const uint64_t* domains;     /* n * key dictionary words: registered domains of a dictionary key (topologygroup.go:103-107) */
-  const int32_t* init_counts;  /* n * 64 * words : pre-counted pods per domain value (topology.go:361-459), may be NULL */
-  const uint8_t* filter_affinity_honor; /* nodeAffinityPolicy == Honor */
+  uint32_t domain_words;       /* mask words per group in `domains` / 64 counters each in `init_counts` */
+  const uint64_t* domains;     /* n * domain_words : registered domains of a dictionary key (topologygroup.go:103-107) */
+  const int32_t* init_counts;  /* n * domain_words * 64 : pods pre-counted per domain value (topology.go:361-459) */
+  const int32_t* init_node_counts; /* n * n_nodes : hostname groups, pods pre-counted per existing node; may be NULL */
+  const uint8_t* filter_affinity_honor; /* TopologyNodeFilter: nodeAffinityPolicy == Honor (topologynodefilter.go:68-79) */
   const uint8_t* filter_taint_honor;    /* nodeTaintsPolicy == Honor */
   const uint32_t* filter_first;         /* n+1 : CSR into filter_reqs (TopologyNodeFilter.Requirements, OR'd) */
   ksolve_reqsets filter_reqs;
-  const uint64_t* filter_tolerates;     /* n : distinct-taint mask the owner pod tolerates */
+  const uint64_t* filter_tolerates;     /* n : distinct-taint mask the creating pod tolerates */
+  const uint16_t* value_rank;  /* req_words*64 : rank of a dictionary value's name among its key's values (Go map iteration
+                                * order is undefined where the reference breaks ties, topologygroup.go:259,355,372; ties go
+                                * to the lexicographically smallest domain) */
+  const int32_t* node_hostname_value;   /* n_nodes : value index of the node's hostname in key_hostname's dictionary, -1 = none */
 } ksolve_topology;
 
 typedef struct {
@@ -131,8 +142,9 @@ typedef struct {
   ksolve_reqsets pod_strict_reqs;  /* PodData.StrictRequirements; mask may alias pod_reqs when identical */
   const uint64_t* pod_tolerates;   /* n_pod_rows : bit i set when the pod tolerates distinct taint i (taints.go:83-95) */
   const int32_t* pod_next_variant; /* n_pod_rows : row of the next relaxation, -1 = none */
-  const uint64_t* pod_topo_owned;  /* n_pod_rows : topology groups the pod owns (topology.go:187) */
-  const uint64_t* pod_topo_selected; /* n_pod_rows : groups whose selector matches the pod (topologygroup.go:442) */
+  const uint64_t* pod_topo_owned;  /* n_pod_rows * topo_words, topo_words = ceil(topo.n / 64): topology groups the pod variant
+                                    * owns (topology.go:187, :352); NULL when topo.n == 0 */
+  const uint64_t* pod_topo_selected; /* n_pod_rows * topo_words : groups whose namespaces + selector match the pod (topologygroup.go:442) */
   const int64_t* pod_creation;     /* n_pods : CreationTimestamp seconds */
   const uint64_t* pod_uid_hi;      /* n_pods : (hi,lo) compare like the UID strings (queue.go:107) */
   const uint64_t* pod_uid_lo;

@@ -36,6 +36,11 @@ constexpr int kMaxCold = 2 * kMaxKeys + (kMaxKeys + 1) / 2;
 
 struct Scratch {
   ReqBuf merged;                    // slow-path working set (bounds / minValues / very wide dictionaries)
+  ReqBuf topo;                      // nodeRequirements ∧ topology domains (Topology.AddRequirements, topology.go:226-250)
+  uint64_t tq[kMaxReqWords];        // next-domain set of one topology group (only the group key's words are used)
+  uint64_t t_owned[kMaxTopoWords], t_sel[kMaxTopoWords];   // topology groups the class being placed owns / is selected by
+  uint64_t t_match[kMaxTopoWords];  // getMatchingTopologies (topology.go:561-574)
+  uint64_t t_active[kMaxTopoWords]; // groups created so far
   uint64_t cm[kMaxItWords];         // instance types compatible with the merged requirements
   uint64_t its[kMaxItWords];        // surviving InstanceTypeOptions
   uint64_t lim[kMaxItWords];        // instance types within NodePool limits
@@ -91,6 +96,11 @@ struct Engine {
   uint32_t active_templates = 0;
   int last_err = 0, last_diag = 0;
   Counters ctr{};
+  // topology: groups that exist so far, and the masks of the class being placed
+  bool cur_M = false;               // the class being placed has matching topology groups
+  bool cur_rec = false;             // ... or is counted by some group when it is committed
+  int cur_class = 0;
+  bool topo_reached = false;        // the last can_add got as far as the topology stage (its verdict is not cacheable)
 
   KS_DEV Engine(const ProblemView& p, Workspace& s, const LdsTables& l) : P(p), S(s), L(l), sc(*l.scratch), lay(p.lay) {
     order.key = L.okey; order.ord = L.oord; order.pos = L.opos;
@@ -360,13 +370,278 @@ struct Engine {
     return true;
   }
 
+  // ------------------------------------------------------------------------------------------------------------
+  // Topology (topology.go, topologygroup.go, topologynodefilter.go). A group keyed on a dictionary key keeps one
+  // counter per dictionary value; a kubernetes.io/hostname group keeps one counter per bin (existing node / claim):
+  // a bin's hostname requirement is always the single value In [its own hostname] (nodeclaim.go:97, existingnode.go:72),
+  // so only the single-domain branches of nextDomain* (topologygroup.go:236-249,331-343,407-415) can run for it.
+  // One lane per domain value: Has() tests, min/arg-min over counters and the resulting In-set are ballots/reductions.
+  static constexpr uint64_t NONE = ~(uint64_t)0;
+  KS_DEV bool topo_has(const ReqRef& r, int key, uint32_t w, int b) const {   // r.Get(key).Has(value); undefined key = Exists
+    if (!bit(r.defined, key)) return true;
+    return req_has(P.dict, r, key, w, b);
+  }
+  // podDomains.Has(bin's hostname)
+  KS_DEV bool pod_has_host(const ReqRef& pod, int bin_kind, int bin) const {
+    const int hn = P.dict.key_hostname;
+    if (hn < 0 || !bit(pod.defined, hn)) return true;
+    const bool open = bit(pod.complement, hn) && !bit(pod.has_gte, hn) && !bit(pod.has_lte, hn);
+    if (bin_kind == 0) return open;   // hostname-placeholder-N: outside every dictionary and not an integer
+    const int v = P.topo.node_host_value[bin];
+    if (v < 0) return open;
+    return req_has(P.dict, pod, hn, P.dict.key_word_off[hn] + (uint32_t)(v >> 6), v & 63);
+  }
+  KS_DEV int32_t* host_counter(int g, int bin_kind, int bin) const {
+    const int hs = P.topo.host_slot[g];
+    return bin_kind == 0 ? S.tg_claim_counts + (size_t)hs * S.max_claims + bin : S.tg_node_counts + (size_t)hs * P.n_nodes + bin;
+  }
+  // anyCompatiblePodDomain for a hostname group — topologygroup.go:393-400
+  KS_DEV bool topo_any_compatible_host(int g, const ReqRef& pod) {
+    const int hs = P.topo.host_slot[g];
+    const int32_t* nc = S.tg_node_counts + (size_t)hs * P.n_nodes;
+    const int32_t* cc = S.tg_claim_counts + (size_t)hs * S.max_claims;
+    const int ne = P.n_nodes, ncl = n_claims;
+    if (W::find_first(0, ne, [&](int e) { return nc[e] > 0 && pod_has_host(pod, 1, e); }) < ne) return true;
+    if (!pod_has_host(pod, 0, 0)) return false;
+    return W::find_first(0, ncl, [&](int c) { return cc[c] > 0; }) < ncl;
+  }
+  // the hostname groups of the class on bin `bin` (-1 = a claim that does not exist yet: count 0)
+  KS_DEV bool topo_hostname_ok(int g, bool self, const ReqRef& pod, int bin_kind, int bin) {
+    const TopoView& T = P.topo;
+    const int cnt = bin >= 0 ? *host_counter(g, bin_kind, bin) : 0;
+    switch (T.type[g]) {
+      case 0: return (long long)cnt + (self ? 1 : 0) <= (long long)T.max_skew[g];       // topologygroup.go:240-247
+      case 2: return cnt == 0;                                                            // :409-414
+      default:                                                                            // :331-343
+        if (!pod_has_host(pod, bin_kind, bin)) return false;
+        if (cnt > 0) return true;
+        if (!self) return false;
+        if (S.tg_nonzero[g] == 0) return true;
+        return !topo_any_compatible_host(g, pod);
+    }
+  }
+  // nextDomainTopologySpread / nextDomainAffinity / nextDomainAntiAffinity for a group on a dictionary key. Writes the
+  // chosen domain set into sc.tq (words of the key). false = no domain satisfies the constraint.
+  KS_DEV bool topo_next_domain(int g, bool self, const ReqRef& pod, const ReqRef& node) {
+    const TopoView& T = P.topo;
+    const Dict& d = P.dict;
+    const int key = T.key[g], type = T.type[g];
+    const uint32_t w0 = d.key_word_off[key], nw = d.key_word_off[key + 1] - w0;
+    const uint64_t* D = S.tg_domains + (size_t)g * T.dom_words;
+    const int32_t* cnt = S.tg_counts + (size_t)g * T.dom_words * 64;
+    const uint16_t* rank = T.value_rank + (size_t)w0 * 64;
+    uint64_t* tq = sc.tq;
+    uint64_t any = 0;
+    if (type == 0) {
+      // domainMinCount — topologygroup.go:300-322
+      long long mn = INT32_MAX;
+      int supported = 0;
+      for (uint32_t x = 0; x < nw; ++x) {
+        const uint64_t dw = D[x];
+        const uint64_t sup = W::ballot([&](int b) { return ((dw >> b) & 1) != 0 && topo_has(pod, key, w0 + x, b); });
+        supported += popc64(sup);
+        const uint64_t m = W::reduce_min(64, [&](int b) -> uint64_t { return ((sup >> b) & 1) ? (uint64_t)(uint32_t)cnt[x * 64 + b] : NONE; });
+        if (m != NONE && (long long)m < mn) mn = (long long)m;
+      }
+      if (T.min_domains[g] >= 0 && supported < T.min_domains[g]) mn = 0;
+      // the valid domain with the fewest pods, the smallest name among equals — topologygroup.go:251-297
+      const long long skew = T.max_skew[g];
+      uint64_t best = NONE;
+      for (uint32_t x = 0; x < nw; ++x) {
+        const uint64_t dw = D[x];
+        const uint64_t m = W::reduce_min(64, [&](int b) -> uint64_t {
+          if (!((dw >> b) & 1) || !topo_has(node, key, w0 + x, b)) return NONE;
+          const long long c = (long long)cnt[x * 64 + b] + (self ? 1 : 0);
+          if (c - mn > skew) return NONE;
+          return ((uint64_t)c << 32) | ((uint64_t)rank[x * 64 + b] << 16) | (uint64_t)(x * 64 + b);
+        });
+        best = m < best ? m : best;
+      }
+      if (best == NONE) return false;
+      const uint32_t v = (uint32_t)(best & 0xFFFF);
+      W::for_n((int)nw, [&](int x) { tq[w0 + x] = ((uint32_t)x == (v >> 6)) ? (1ull << (v & 63)) : 0ull; });
+      return true;
+    }
+    if (type == 2) {
+      // empty domains the node and the pod admit — topologygroup.go:417-438
+      for (uint32_t x = 0; x < nw; ++x) {
+        const uint64_t dw = D[x];
+        const uint64_t opt = W::ballot([&](int b) { return ((dw >> b) & 1) != 0 && cnt[x * 64 + b] == 0 && topo_has(node, key, w0 + x, b) && topo_has(pod, key, w0 + x, b); });
+        W::store(&tq[w0 + x], opt);
+        any |= opt;
+      }
+      W::sync();
+      return any != 0;
+    }
+    // affinity — topologygroup.go:345-388
+    uint64_t any_pod_nonzero = 0;
+    for (uint32_t x = 0; x < nw; ++x) {
+      const uint64_t dw = D[x];
+      const uint64_t pn = W::ballot([&](int b) { return ((dw >> b) & 1) != 0 && cnt[x * 64 + b] > 0 && topo_has(pod, key, w0 + x, b); });
+      const uint64_t opt = pn & W::ballot([&](int b) { return topo_has(node, key, w0 + x, b); });
+      W::store(&tq[w0 + x], opt);
+      any |= opt;
+      any_pod_nonzero |= pn;
+    }
+    W::sync();
+    if (any) return true;
+    if (!self || !(S.tg_nonzero[g] == 0 || any_pod_nonzero == 0)) return false;
+    // nothing to be affine to yet and the pod matches its own selector: bootstrap a domain (:372-386)
+    uint64_t b1 = NONE, b2 = NONE;
+    for (uint32_t x = 0; x < nw; ++x) {
+      const uint64_t dw = D[x];
+      const uint64_t ph = W::ballot([&](int b) { return ((dw >> b) & 1) != 0 && topo_has(pod, key, w0 + x, b); });
+      const uint64_t nh = ph & W::ballot([&](int b) { return topo_has(node, key, w0 + x, b); });
+      const uint64_t m1 = W::reduce_min(64, [&](int b) -> uint64_t { return ((nh >> b) & 1) ? (((uint64_t)rank[x * 64 + b] << 16) | (uint64_t)(x * 64 + b)) : NONE; });
+      const uint64_t m2 = W::reduce_min(64, [&](int b) -> uint64_t { return ((ph >> b) & 1) ? (((uint64_t)rank[x * 64 + b] << 16) | (uint64_t)(x * 64 + b)) : NONE; });
+      b1 = m1 < b1 ? m1 : b1;
+      b2 = m2 < b2 ? m2 : b2;
+    }
+    if (b1 == NONE && b2 == NONE) return false;
+    W::for_n((int)nw, [&](int x) {
+      uint64_t v = 0;
+      if (b1 != NONE && ((uint32_t)(b1 & 0xFFFF) >> 6) == (uint32_t)x) v |= 1ull << (b1 & 63);
+      if (b2 != NONE && ((uint32_t)(b2 & 0xFFFF) >> 6) == (uint32_t)x) v |= 1ull << (b2 & 63);
+      tq[w0 + x] = v;
+    });
+    return true;
+  }
+  // Topology.AddRequirements + the Compatible check that follows it (topology.go:226-250, nodeclaim.go:195-206,
+  // existingnode.go:111-122). `base` = the bin's requirements already intersected with the pod's. On success sc.topo
+  // holds base ∧ every matching group's next domain and *changed tells whether that differs from base.
+  KS_DEV bool topo_apply(const ReqRef& base, int bin_kind, int bin, bool allow_undefined, bool* changed) {
+    const TopoView& T = P.topo;
+    const Dict& d = P.dict;
+    const ReqRef pod = P.cls_strict.at(d, (uint32_t)cur_class);
+    ReqBuf& tb = sc.topo;
+    W::for_n(d.req_words, [&](int w) { tb.mask[w] = base.mask[w]; });
+    W::for_n(d.n_keys, [&](int k) {
+      tb.gte[k] = (base.gte && bit(base.has_gte, k)) ? base.gte[k] : 0;
+      tb.lte[k] = (base.lte && bit(base.has_lte, k)) ? base.lte[k] : 0;
+      tb.minv[k] = base.minv ? base.minv[k] : -1;
+    });
+    uint32_t hm = 0;
+    if (base.minv) for (int k = 0; k < d.n_keys; ++k) if (base.minv[k] >= 0) hm |= 1u << k;
+    if (W::leader()) { tb.defined = base.defined; tb.complement = base.complement; tb.has_gte = base.has_gte; tb.has_lte = base.has_lte; tb.has_minv = hm; }
+    W::sync();
+    bool any_change = false;
+    for (int tw = 0; tw < T.words; ++tw) for (uint64_t m = sc.t_match[tw]; m; m &= m - 1) {
+      const int g = tw * 64 + ctz64(m);
+      const bool self = (sc.t_sel[tw] >> (g & 63)) & 1;
+      const int key = T.key[g];
+      if (key < 0) {
+        if (!topo_hostname_ok(g, self, pod, bin_kind, bin)) return false;
+        continue;   // In [bin's hostname] ∧ the bin's own hostname requirement: nothing changes
+      }
+      if (!topo_next_domain(g, self, pod, base)) return false;
+      ReqRef q;
+      q.mask = sc.tq; q.defined = 1u << key; q.complement = 0; q.has_gte = q.has_lte = 0; q.gte = q.lte = nullptr; q.minv = nullptr;
+      any_change = reqbuf_add(d, tb, q) || any_change;
+      W::sync();
+    }
+    *changed = any_change;
+    if (any_change) {
+      ReqRef tr = tb.ref();
+      if (reqs_compatible(d, base, tr, allow_undefined) != COMPAT_OK) return false;
+    }
+    return true;
+  }
+  // TopologyNodeFilter.Matches(taints, requirements) — topologynodefilter.go:68-96 (strict Compatible, :71)
+  KS_DEV bool topo_filter_matches(int g, uint64_t taints, const ReqRef& fin, int bin_kind) {
+    const TopoView& T = P.topo;
+    const Dict& d = P.dict;
+    if (T.f_taint[g] && (taints & ~T.f_tolerates[g])) return false;
+    if (!T.f_affinity[g]) return true;
+    const uint32_t a = T.f_first[g], b = T.f_first[g + 1];
+    if (a == b) return true;
+    const int hn = d.key_hostname;
+    for (uint32_t i = a; i < b; ++i) {
+      ReqRef r = T.f_reqs.at(d, i);
+      if (bin_kind == 0 && hn >= 0 && bit(r.defined, hn)) {
+        // a claim's hostname requirement (In [placeholder]) is kept implicit: only an open complement intersects it
+        if (!(bit(r.complement, hn) && !bit(r.has_gte, hn) && !bit(r.has_lte, hn))) continue;
+        r.defined &= ~(1u << hn);
+      }
+      if (reqs_compatible(d, fin, r, false) == COMPAT_OK) return true;
+    }
+    return false;
+  }
+  // Topology.Record — topology.go:197-220
+  KS_DEV void topo_record(uint64_t taints, const ReqRef& fin, int bin_kind, int bin) {
+    const TopoView& T = P.topo;
+    const Dict& d = P.dict;
+    for (int tw = 0; tw < T.words; ++tw)
+    for (uint64_t todo = (sc.t_active[tw] & ~T.inverse_mask[tw] & sc.t_sel[tw]) | (T.inverse_mask[tw] & sc.t_owned[tw]); todo; todo &= todo - 1) {
+      const int g = tw * 64 + ctz64(todo);
+      const bool inv = (T.inverse_mask[tw] >> (g & 63)) & 1;
+      if (!inv && !topo_filter_matches(g, taints, fin, bin_kind)) continue;
+      const int key = T.key[g];
+      if (key < 0) {
+        int32_t* p = host_counter(g, bin_kind, bin);
+        const int32_t c = *p;
+        W::store(p, c + 1);
+        if (c == 0) W::store(&S.tg_nonzero[g], S.tg_nonzero[g] + 1);
+        W::sync();
+        continue;
+      }
+      if (!bit(fin.defined, key)) continue;   // Exists: no values
+      const uint32_t w0 = d.key_word_off[key], nw = d.key_word_off[key + 1] - w0;
+      const bool anti = inv || T.type[g] == 2;
+      int nvals = 0;
+      for (uint32_t x = 0; x < nw; ++x) nvals += popc64(fin.mask[w0 + x]);
+      // anti-affinity blocks every stored value (domains.Values(), also for a NotIn set); the others count a pod only
+      // once its domain is decided (topology.go:203-211)
+      if (!anti && (bit(fin.complement, key) || nvals != 1)) continue;
+      uint64_t* D = S.tg_domains + (size_t)g * T.dom_words;
+      int32_t* cnt = S.tg_counts + (size_t)g * T.dom_words * 64;
+      int fresh = 0;
+      for (uint32_t x = 0; x < nw; ++x) {
+        const uint64_t mk = fin.mask[w0 + x];
+        if (!mk) continue;
+        const uint64_t was_zero = W::ballot([&](int b) {
+          if (!((mk >> b) & 1)) return false;
+          const int32_t c = cnt[x * 64 + b];
+          cnt[x * 64 + b] = c + 1;
+          return c == 0;
+        });
+        fresh += popc64(was_zero);
+        W::store(&D[x], (uint64_t)(D[x] | mk));
+      }
+      if (fresh) W::store(&S.tg_nonzero[g], S.tg_nonzero[g] + fresh);
+      W::sync();
+    }
+  }
+  KS_DEV ReqRef out_ref(const uint64_t* cold) const {   // the record being committed (sc.out) as a requirement set
+    ReqRef r;
+    const uint64_t f0 = sc.out[lay.c_f0()], f1 = sc.out[lay.c_f1()];
+    r.mask = sc.out + lay.c_mask(); r.defined = lo32(f0); r.complement = hi32(f0); r.has_gte = lo32(f1); r.has_lte = hi32(f1);
+    r.gte = (const int64_t*)cold; r.lte = (const int64_t*)(cold + lay.nk); r.minv = nullptr;
+    return r;
+  }
+
   // NodeClaim.CanAdd (nodeclaim.go:124-242) for a pod of the class in sc.cls on the bin record `bin`/`bin_cold`.
   // On success sc.out holds the committed record's masks and flag words, sc.its / sc.total the new instance types and
   // requests (finish_record completes head/meta and writes the record).
-  KS_DEV int can_add(const uint64_t* bin, const uint64_t* bin_cold, bool fresh, bool want_diag, bool* reqs_changed, bool* its_changed) {
+  // the merged requirement set `m` becomes the record being built (sc.out / sc.out_cold)
+  KS_DEV ReqRef reqbuf_to_out(const ReqBuf& m) {
+    uint64_t* o = sc.out;
+    W::for_n(lay.rw, [&](int w) { o[w] = m.mask[w]; });
+    if (W::leader()) {
+      o[lay.c_f0()] = (uint64_t)m.defined | ((uint64_t)m.complement << 32);
+      o[lay.c_f1()] = (uint64_t)m.has_gte | ((uint64_t)m.has_lte << 32);
+    }
+    int64_t* cg = (int64_t*)sc.out_cold; int64_t* cl = cg + lay.nk; int32_t* cv = (int32_t*)(sc.out_cold + 2 * lay.nk);
+    W::for_n(lay.nk, [&](int k) { cg[k] = m.gte[k]; cl[k] = m.lte[k]; cv[k] = m.minv[k]; });
+    ReqRef r;
+    r.mask = sc.out + lay.c_mask(); r.defined = m.defined; r.complement = m.complement;
+    r.has_gte = m.has_gte; r.has_lte = m.has_lte; r.gte = cg; r.lte = cl; r.minv = cv;
+    return r;
+  }
+  KS_DEV int can_add(const uint64_t* bin, const uint64_t* bin_cold, bool fresh, bool want_diag, bool* reqs_changed, bool* its_changed, int claim_id) {
     const Dict& d = P.dict;
     const int nr = lay.nr;
     ctr.bin_evaluations++;
+    topo_reached = false;
     unsigned long long ta = W::clock();
     const uint64_t bin_taints = sc.tmpl_taints[lo32(bin[lay.c_meta()]) & 31u];
     if (bin_taints & ~sc.cls[lay.k_tol()]) return E_TAINTS;                              // Taints.ToleratesPod — nodeclaim.go:126
@@ -405,17 +680,14 @@ struct Engine {
       if (reqs_compatible(d, br, q, true) != COMPAT_OK) return E_INCOMPATIBLE;
       reqbuf_load(d, sc.merged, br);
       changed = reqbuf_add(d, sc.merged, q);
-      const ReqBuf& m = sc.merged;
-      uint64_t* o = sc.out;
-      W::for_n(lay.rw, [&](int w) { o[w] = m.mask[w]; });
-      if (W::leader()) {
-        o[lay.c_f0()] = (uint64_t)m.defined | ((uint64_t)m.complement << 32);
-        o[lay.c_f1()] = (uint64_t)m.has_gte | ((uint64_t)m.has_lte << 32);
-      }
-      int64_t* cg = (int64_t*)sc.out_cold; int64_t* cl = cg + lay.nk; int32_t* cv = (int32_t*)(sc.out_cold + 2 * lay.nk);
-      W::for_n(lay.nk, [&](int k) { cg[k] = m.gte[k]; cl[k] = m.lte[k]; cv[k] = m.minv[k]; });
-      merged.mask = sc.out + lay.c_mask(); merged.defined = m.defined; merged.complement = m.complement;
-      merged.has_gte = m.has_gte; merged.has_lte = m.has_lte; merged.gte = cg; merged.lte = cl; merged.minv = cv;
+      merged = reqbuf_to_out(sc.merged);
+    }
+    if (cur_M) {
+      // topology: nodeclaim.go:195-208
+      topo_reached = true;
+      bool tchanged = false;
+      if (!topo_apply(merged, 0, claim_id, true, &tchanged)) return E_TOPOLOGY;
+      if (tchanged) { merged = reqbuf_to_out(sc.topo); changed = true; }
     }
     ctr.full_evaluations++;
     unsigned long long tc = W::clock();
@@ -495,8 +767,9 @@ struct Engine {
   }
 
   // ---- in-flight scan: addToInflightNode (scheduler.go:658-692) ---------------------------------------------
-  // dead_word_on_failure = what the class's dead-row word of claim c becomes when the probe fails
-  KS_DEV int try_claim(int k, int c, int pod, uint64_t dead_word_on_failure) {
+  // One probe of claim c. On failure the caller records the verdict in the class's dead row — unless the probe got as
+  // far as the topology stage: domain counters move with every commit anywhere, so that verdict cannot be cached.
+  KS_DEV int try_claim(int k, int c, int pod) {
     unsigned long long t0 = W::clock();
     const RecLayout ly = lay;
     // hot record: from the LDS record cache when this claim was the last one committed to its line, else one coalesced load
@@ -508,14 +781,10 @@ struct Engine {
     bool changed = false, its_changed = false;
     unsigned long long t1 = W::clock();
     ctr.cycles[4] += t1 - t0;
-    int rc = can_add(sc.claim, sc.claim_cold, false, false, &changed, &its_changed);
+    int rc = can_add(sc.claim, sc.claim_cold, false, false, &changed, &its_changed, c);
     unsigned long long t2 = W::clock();
     ctr.cycles[5] += t2 - t1;
-    if (rc != E_OK) {
-      W::store(&S.dead[(size_t)k * S.claim_words + (c >> 6)], dead_word_on_failure);
-      ctr.cycles[8] += W::clock() - t2;
-      return rc;
-    }
+    if (rc != E_OK) return rc;
     const uint32_t tmpl = lo32(sc.claim[ly.c_meta()]), np = hi32(sc.claim[ly.c_meta()]);
     ctr.ref_bin_evaluations += (unsigned long long)order.pos[c] + 1;   // the reference walked every claim up to this position
     if (!changed) {
@@ -525,6 +794,7 @@ struct Engine {
       W::for_n(ly.rw + 2, [&](int w) { int i = w < ly.rw ? w : ly.c_f0() + (w - ly.rw); o[i] = b[i]; });
     }
     const bool out_cold = changed && (sc.out[ly.c_f1()] != 0 || (m2 & 2u));
+    if (cur_rec) topo_record(sc.tmpl_taints[tmpl & 31u], out_ref(changed ? sc.out_cold : sc.claim_cold), 0, c);   // nodeclaim.go:252-253
     finish_record(c, sc.claim, its_changed, tmpl, np + 1, lo32(sc.claim[ly.c_meta2()]), m2, out_cold);
     order.increment(c);
     if (changed) reset_column(c);
@@ -583,11 +853,16 @@ struct Engine {
           const int l = c >> 6;
           const uint64_t valid = (l == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
           const uint64_t live = stage[l] & ~(1ull << (c & 63));
-          // on failure the class's dead word becomes: everything not live any more (closed claims may be recorded as
-          // dead too — both are permanent until the column is reset), never touching bits of claims that do not exist yet
-          if (try_claim(k, c, pod, ~live & valid) == E_OK) return true;
+          if (try_claim(k, c, pod) == E_OK) return true;
+          unsigned long long tf = W::clock();
+          // the class's dead word becomes: everything not live any more (closed claims may be recorded as dead too —
+          // both are permanent until the column is reset), never touching bits of claims that do not exist yet. Classes
+          // under topology constraints only record the failures that did not depend on domain counters.
+          if (!cur_M) W::store(&drow[l], (uint64_t)(~live & valid));
+          else if (!topo_reached) W::store(&drow[l], (uint64_t)(drow[l] | (1ull << (c & 63))));
           W::store(&stage[l], live);
           W::sync();
+          ctr.cycles[8] += W::clock() - tf;
         }
       }
     }
@@ -611,7 +886,9 @@ struct Engine {
       while (m) {
         int l = ctz64(m); m &= m - 1;
         int c = (int)order.ord[base + l];
-        if (try_claim(k, c, pod, drow[c >> 6] | (1ull << (c & 63))) == E_OK) return true;
+        if (try_claim(k, c, pod) == E_OK) return true;
+        if (!topo_reached) W::store(&drow[c >> 6], (uint64_t)(drow[c >> 6] | (1ull << (c & 63))));
+        W::sync();
       }
     }
     return false;
@@ -660,7 +937,7 @@ struct Engine {
       host_seq++;  // NewNodeClaim draws a hostname-placeholder number for every attempt (nodeclaim.go:93)
       bool changed = false;
       ctr.ref_bin_evaluations++;
-      int rc = can_add(bin, tcold, true, first_err == 0, &changed, nullptr);
+      int rc = can_add(bin, tcold, true, first_err == 0, &changed, nullptr, -1);
       if (rc != E_OK) { if (!first_err) { first_err = rc; first_diag = rc == E_INSTANCE_TYPES ? last_diag : 0; } continue; }
       if (n_claims >= S.max_claims || n_claims >= P.lds.order_cap) { W::store(S.status_out, 1); return -1; }
       int c = n_claims++;
@@ -674,6 +951,7 @@ struct Engine {
       }
       W::sync();
       const bool cold = sc.out[ly.c_f1()] != 0 || (tm2 & 2u);
+      if (cur_rec) topo_record(sc.tmpl_taints[t & 31], out_ref(sc.out_cold), 0, c);
       finish_record(c, bin, true, (uint32_t)t, 1u, host_seq, tm2 & 2u, cold);
       order.append(c);
       if (lm) {
@@ -758,29 +1036,35 @@ struct Engine {
         }
         return true;
       });
-      if (!ok) {
-        // every probed node of this block failed: remember it (monotone until the node's requirements change)
-        W::store(&ndead[base >> 6], (uint64_t)(deadw | todo));
-        ctr.ref_bin_evaluations += popc64(validm & ~skipped);
-        continue;
+      int l = -1;
+      bool changed = false;
+      ReqBuf* fin = &sc.merged;
+      if (!cur_M) {
+        if (ok) l = ctz64(ok);
+        if (l >= 0) changed = node_merge(base + l);
+      } else {
+        // topology decides among the nodes that passed everything else (existingnode.go:111-122), lowest index first
+        for (uint64_t cand = ok; cand; cand &= cand - 1) {
+          const int cl_ = ctz64(cand);
+          const bool ch = node_merge(base + cl_);
+          bool tch = false;
+          ctr.bin_evaluations++;
+          if (!topo_apply(sc.merged.ref(), 1, base + cl_, false, &tch)) continue;
+          l = cl_; changed = ch || tch;
+          if (tch) fin = &sc.topo;
+          break;
+        }
       }
-      const int l = ctz64(ok);
+      // nodes that failed a check that does not involve topology stay failed until their requirements change
+      const uint64_t below = l < 0 ? ~0ull : (l == 0 ? 0ull : ((1ull << l) - 1));
+      W::store(&ndead[base >> 6], (uint64_t)(deadw | (todo & ~ok & below)));
+      if (l < 0) { ctr.ref_bin_evaluations += popc64(validm & ~skipped); continue; }
       const int en = base + l;
-      const uint64_t below = (l == 0) ? 0ull : ((1ull << l) - 1);
-      W::store(&ndead[base >> 6], (uint64_t)(deadw | (todo & below)));
       ctr.ref_bin_evaluations += popc64(validm & ~skipped & (below | (1ull << l)));
       ctr.bin_evaluations += popc64(todo & (below | (1ull << l)));
-      // ---- ExistingNode.Add (existingnode.go:172-185): requirements <- node ∧ pod, remaining -= requests
-      ReqBuf& m = sc.merged;
+      // ---- ExistingNode.Add (existingnode.go:172-185): requirements <- node ∧ pod ∧ topology, remaining -= requests
+      const ReqBuf& m = *fin;
       uint64_t* nm = S.n_mask;
-      W::for_n(ly.rw, [&](int w) { m.mask[w] = nm[(size_t)w * ne + en]; });
-      if (W::leader()) {
-        m.defined = Sw.n_defined[en]; m.complement = Sw.n_complement[en]; m.has_gte = m.has_lte = m.has_minv = 0;
-        for (int kk = 0; kk < ly.nk; ++kk) { m.gte[kk] = 0; m.lte[kk] = 0; m.minv[kk] = -1; }
-      }
-      W::sync();
-      ReqRef q = class_ref(sc.cls, sc.cls_cold);
-      const bool changed = reqbuf_add(d, sc.merged, q);
       if (changed) {
         W::for_n(ly.rw, [&](int w) { nm[(size_t)w * ne + en] = m.mask[w]; });
         W::store(&S.n_defined[en], m.defined);
@@ -790,6 +1074,7 @@ struct Engine {
         const uint64_t clr = ~(1ull << (en & 63));
         W::for_n(P.n_classes, [&](int kk) { nd[(size_t)kk * nwd + (en >> 6)] &= clr; });
       }
+      if (cur_rec) topo_record(Pv.node_taints[en], m.ref(), 1, en);              // existingnode.go:184
       int64_t* nrem = S.n_remaining;
       W::for_n(nr, [&](int r) { nrem[(size_t)r * ne + en] -= req[r]; });                  // resources.SubtractFrom — existingnode.go:175
       const uint32_t np_ = S.n_npods[en];
@@ -801,12 +1086,45 @@ struct Engine {
     }
     return false;
   }
+  // sc.merged <- ExistingNode.requirements ∧ the pod's (existingnode.go:105-108); true when that differs from the node's
+  KS_DEV bool node_merge(int en) {
+    const Dict& d = P.dict;
+    const int ne = P.n_nodes;
+    ReqBuf& m = sc.merged;
+    const uint64_t* nm = S.n_mask;
+    W::for_n(lay.rw, [&](int w) { m.mask[w] = nm[(size_t)w * ne + en]; });
+    if (W::leader()) {
+      m.defined = S.n_defined[en]; m.complement = S.n_complement[en]; m.has_gte = m.has_lte = m.has_minv = 0;
+      for (int kk = 0; kk < lay.nk; ++kk) { m.gte[kk] = 0; m.lte[kk] = 0; m.minv[kk] = -1; }
+    }
+    W::sync();
+    ReqRef q = class_ref(sc.cls, sc.cls_cold);
+    return reqbuf_add(d, sc.merged, q);
+  }
 
   // ---- class record of the pod being placed ----------------------------------------------------------------
   KS_DEV void fetch_class(int k) {
     const int hw = lay.k_hot_words();
     load_words(sc.cls, P.cls_hot + (size_t)k * hw, hw);
     if (sc.cls[lay.k_f1()] != 0 || (lo32(sc.cls[lay.k_meta()]) & 1u)) load_words(sc.cls_cold, P.cls_cold + (size_t)k * lay.cold_words(), lay.cold_words());
+    cur_class = k;
+    if (P.topo.n_groups) {
+      const TopoView& T = P.topo;
+      const uint64_t* ct = T.cls_topo + (size_t)k * 2 * T.words;
+      Scratch& s_ = sc;
+      // getMatchingTopologies — topology.go:561-574: groups the pod owns + inverse anti-affinity groups that select it;
+      // Topology.Update creates the groups of a relaxed pod (topology.go:162-194)
+      const uint64_t anyM = W::ballot([&](int w) {
+        if (w >= T.words) return false;
+        const uint64_t ow = ct[w], se = ct[T.words + w], inv = T.inverse_mask[w];
+        const uint64_t mt = (ow & ~inv) | (se & inv);
+        s_.t_owned[w] = ow; s_.t_sel[w] = se; s_.t_match[w] = mt; s_.t_active[w] |= ow & ~inv;
+        return mt != 0;
+      });
+      const uint64_t anyR = W::ballot([&](int w) { return w < T.words && (ct[w] | ct[T.words + w]) != 0; });
+      W::sync();
+      cur_M = anyM != 0; cur_rec = anyR != 0;
+    }
   }
 
   // add — scheduler.go:582-612
@@ -893,6 +1211,16 @@ struct Engine {
       W::for_n(lay.rw * ne, [&](int i) { Sw.n_mask[i] = Sw.n_mask0[i]; });
       W::for_n(lay.nr * ne, [&](int i) { Sw.n_remaining[i] = Sw.n_remaining0[i]; });
       W::for_n(ne, [&](int i) { Sw.n_defined[i] = Sw.n_defined0[i]; Sw.n_complement[i] = Sw.n_complement0[i]; Sw.n_npods[i] = 0; });
+    }
+    if (P.topo.n_groups) {
+      const TopoView& T = P.topo;
+      Workspace& Sw = S;
+      const int G = T.n_groups, dv = T.dom_words * 64;
+      W::for_n(G * T.dom_words, [&](int i) { Sw.tg_domains[i] = T.domains0[i]; });
+      W::for_n(G * dv, [&](int i) { Sw.tg_counts[i] = T.counts0[i]; });
+      W::for_n(T.n_host_groups * P.n_nodes, [&](int i) { Sw.tg_node_counts[i] = T.node_counts0[i]; });
+      W::for_n(G, [&](int i) { Sw.tg_nonzero[i] = T.nonzero0[i]; });
+      W::for_n(T.words, [&](int w) { sc.t_active[w] = T.initially_active[w]; });
     }
     load_tables();
     prefilter_templates();

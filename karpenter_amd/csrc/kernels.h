@@ -84,8 +84,9 @@ struct RowArgs {
   const int64_t* requests;  // [n_res][n_rows]
   ReqTable reqs, strict;
   const uint64_t* tolerates;
-  const uint64_t* topo_owned;
+  const uint64_t* topo_owned;     // [n_rows][topo_words] or nullptr
   const uint64_t* topo_selected;
+  int topo_words;
   // table
   uint64_t seed;
   uint32_t table_size;      // power of two
@@ -105,6 +106,7 @@ struct RowArgs {
   int64_t* min_request;     // [n_res]
   uint64_t* cls_hot;        // [n_classes][k_hot_words]
   uint64_t* cls_cold;       // [n_classes][cold_words]
+  uint64_t* cls_topo;       // [n_classes][2*topo_words] topology groups owned | selected
   RecLayout lay;
 };
 KS_FN uint64_t mix64(uint64_t h, uint64_t v) {
@@ -147,8 +149,7 @@ KS_FN void row_hash_body(int row, const RowArgs& a) {
   h = hash_reqset(a.dict, h, a.reqs.at(a.dict, row));
   h = hash_reqset(a.dict, h, a.strict.at(a.dict, row));
   h = mix64(h, a.tolerates[row]);
-  h = mix64(h, a.topo_owned ? a.topo_owned[row] : 0);
-  h = mix64(h, a.topo_selected ? a.topo_selected[row] : 0);
+  if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) { h = mix64(h, a.topo_owned[(size_t)row * a.topo_words + w]); h = mix64(h, a.topo_selected[(size_t)row * a.topo_words + w]); }
   if (h == 0) h = 1;
   a.row_hash[row] = h;
   uint32_t slot = (uint32_t)(h >> 17) & (a.table_size - 1);
@@ -165,8 +166,10 @@ KS_FN bool rows_equal(const RowArgs& a, int x, int y) {
   if (!equal_reqset(a.dict, a.reqs.at(a.dict, x), a.reqs.at(a.dict, y))) return false;
   if (!equal_reqset(a.dict, a.strict.at(a.dict, x), a.strict.at(a.dict, y))) return false;
   if (a.tolerates[x] != a.tolerates[y]) return false;
-  if (a.topo_owned && a.topo_owned[x] != a.topo_owned[y]) return false;
-  if (a.topo_selected && a.topo_selected[x] != a.topo_selected[y]) return false;
+  if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) {
+    if (a.topo_owned[(size_t)x * a.topo_words + w] != a.topo_owned[(size_t)y * a.topo_words + w]) return false;
+    if (a.topo_selected[(size_t)x * a.topo_words + w] != a.topo_selected[(size_t)y * a.topo_words + w]) return false;
+  }
   return true;
 }
 // verify against the representative (a 64-bit hash collision between different rows is reported, the host re-seeds) and
@@ -227,6 +230,10 @@ KS_FN void class_gather_body(int cls, const RowArgs& a) {
     if (mv >= 0 && bit(q.defined, k)) has_minv = true;
   }
   hot[ly.k_meta()] = has_minv ? 1u : 0u;
+  if (a.cls_topo) for (int w = 0; w < a.topo_words; ++w) {
+    a.cls_topo[(size_t)cls * 2 * a.topo_words + w] = a.topo_owned[(size_t)row * a.topo_words + w];
+    a.cls_topo[(size_t)cls * 2 * a.topo_words + a.topo_words + w] = a.topo_selected[(size_t)row * a.topo_words + w];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ queue order

@@ -150,7 +150,8 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   if (d->n_nodes) {
     if (any_nonzero(d->node_reqs.has_gte, d->n_nodes) || any_nonzero(d->node_reqs.has_lte, d->n_nodes)) return fail(h, KSOLVE_ERR_INVALID, "existing-node requirements are label sets: no bounds");
   }
-  if (d->topo.n) return fail(h, KSOLVE_ERR_UNSUPPORTED, "topology groups are not solved on the device in this build");
+  if (d->topo.n > KSOLVE_MAX_TOPO_GROUPS) return fail(h, KSOLVE_ERR_UNSUPPORTED, "more than 1024 topology groups");
+  if (d->topo.n && (!d->pod_topo_owned || !d->pod_topo_selected)) return fail(h, KSOLVE_ERR_INVALID, "topology groups without pod_topo_owned / pod_topo_selected");
   if (d->tmpl_reqs.min_values) {
     for (size_t i = 0; i < (size_t)d->n_templates * d->n_keys; ++i)
       if (d->tmpl_reqs.min_values[i] >= 0) return fail(h, KSOLVE_ERR_UNSUPPORTED, "minValues are not solved on the device in this build");
@@ -180,6 +181,14 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     std::vector<uint64_t> valid(req_words, 0);
     auto acc = [&](const ksolve_reqsets& r, uint32_t n) { if (r.mask) for (size_t i = 0; i < (size_t)n * req_words; ++i) valid[i % req_words] |= r.mask[i]; };
     acc(d->it_reqs, d->n_its); acc(d->tmpl_reqs, d->n_templates); acc(d->pod_reqs, d->n_pod_rows); acc(d->pod_strict_reqs, d->n_pod_rows);
+    acc(d->node_reqs, d->n_nodes);
+    if (d->topo.n) {
+      acc(d->topo.filter_reqs, d->topo.filter_first[d->topo.n]);
+      for (uint32_t g = 0; g < d->topo.n; ++g) if (d->topo.key[g] >= 0) {
+        const uint32_t w0 = d->key_word_off[d->topo.key[g]], nw = d->key_word_off[d->topo.key[g] + 1] - w0;
+        for (uint32_t x = 0; x < nw && x < d->topo.domain_words; ++x) valid[w0 + x] |= d->topo.domains[(size_t)g * d->topo.domain_words + x];
+      }
+    }
     // every instance type name is a valid value of the instance-type key
     for (uint32_t i = 0; i < d->n_its; ++i) valid[d->key_word_off[d->key_instance_type] + i / 64] |= 1ull << (i % 64);
     dict.value_valid = up(h, valid.data(), req_words);
@@ -242,7 +251,10 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   if (d->pod_strict_reqs.mask == d->pod_reqs.mask || d->pod_strict_reqs.mask == nullptr) R.strict = R.reqs;
   else R.strict = upload_reqs(h, d->pod_strict_reqs, d->n_pod_rows, req_words, d->n_keys);
   R.tolerates = up(h, d->pod_tolerates, d->n_pod_rows);
-  R.topo_owned = nullptr; R.topo_selected = nullptr;
+  R.topo_words = (int)((d->topo.n + 63) / 64);
+  R.topo_owned = d->topo.n ? up(h, d->pod_topo_owned, (size_t)d->n_pod_rows * R.topo_words) : nullptr;
+  R.topo_selected = d->topo.n ? up(h, d->pod_topo_selected, (size_t)d->n_pod_rows * R.topo_words) : nullptr;
+  h->has_topology = d->topo.n != 0;
   uint32_t ts = 64;
   while (ts < 2 * d->n_pod_rows) ts <<= 1;
   R.table_size = ts; R.seed = 0x6b73703176310a01ull;
@@ -308,6 +320,55 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   W.max_steps = h->opts.max_steps;
   W.counters = dz<ks::Counters>(h, 1);
   h->d_cheapest = dz<double>(h, mc);
+  {
+    // topology groups
+    ks::TopoView& T = P.topo;
+    const ksolve_topology& t = d->topo;
+    const uint32_t G = t.n;
+    T.n_groups = (int)G; T.dom_words = (int)std::max(1u, t.domain_words);
+    T.words = (int)((G + 63) / 64);
+    for (int w = 0; w < ks::kMaxTopoWords; ++w) { T.inverse_mask[w] = 0; T.initially_active[w] = 0; }
+    T.n_host_groups = 0;
+    if (G) {
+      std::vector<int16_t> host_slot(G, -1);
+      std::vector<int32_t> nonzero(G, 0);
+      const size_t dv = (size_t)T.dom_words * 64;
+      for (uint32_t g = 0; g < G; ++g) {
+        if (t.type[g] > 2) return fail(h, KSOLVE_ERR_INVALID, "topology group type out of range");
+        if (t.key[g] >= (int32_t)d->n_keys) return fail(h, KSOLVE_ERR_INVALID, "topology group key out of range");
+        if (t.key[g] >= 0 && d->key_word_off[t.key[g] + 1] - d->key_word_off[t.key[g]] > t.domain_words) return fail(h, KSOLVE_ERR_INVALID, "topology domain_words too small for a group key");
+        if (t.inverse[g]) T.inverse_mask[g >> 6] |= 1ull << (g & 63);
+        if (t.initially_active[g] || t.inverse[g]) T.initially_active[g >> 6] |= 1ull << (g & 63);
+        if (t.key[g] < 0) {
+          host_slot[g] = (int16_t)T.n_host_groups++;
+          if (t.init_node_counts) for (uint32_t e = 0; e < d->n_nodes; ++e) if (t.init_node_counts[(size_t)g * d->n_nodes + e] > 0) nonzero[g]++;
+        } else if (t.init_counts) {
+          for (size_t v = 0; v < dv; ++v) if (t.init_counts[(size_t)g * dv + v] > 0) nonzero[g]++;
+        }
+      }
+      T.type = up(h, t.type, G); T.key = up(h, t.key, G); T.host_slot = up(h, host_slot.data(), G);
+      T.max_skew = up(h, t.max_skew, G); T.min_domains = up(h, t.min_domains, G);
+      T.domains0 = up(h, t.domains, (size_t)G * T.dom_words);
+      T.counts0 = t.init_counts ? up(h, t.init_counts, (size_t)G * dv) : dz<int32_t>(h, (size_t)G * dv);
+      std::vector<int32_t> nc((size_t)std::max(1, T.n_host_groups) * std::max(1u, d->n_nodes), 0);
+      if (t.init_node_counts) for (uint32_t g = 0; g < G; ++g) if (host_slot[g] >= 0)
+        for (uint32_t e = 0; e < d->n_nodes; ++e) nc[(size_t)host_slot[g] * d->n_nodes + e] = t.init_node_counts[(size_t)g * d->n_nodes + e];
+      T.node_counts0 = up(h, nc.data(), nc.size());
+      T.nonzero0 = up(h, nonzero.data(), G);
+      T.f_affinity = up(h, t.filter_affinity_honor, G); T.f_taint = up(h, t.filter_taint_honor, G);
+      T.f_first = up(h, t.filter_first, G + 1);
+      T.f_reqs = upload_reqs(h, t.filter_reqs, t.filter_first[G], req_words, d->n_keys);
+      T.f_tolerates = up(h, t.filter_tolerates, G);
+      T.value_rank = up(h, t.value_rank, (size_t)req_words * 64);
+      T.node_host_value = d->n_nodes ? (t.node_hostname_value ? up(h, t.node_hostname_value, d->n_nodes) : nullptr) : nullptr;
+      if (d->n_nodes && !t.node_hostname_value) return fail(h, KSOLVE_ERR_INVALID, "topology with existing nodes needs node_hostname_value");
+      W.tg_domains = dz<uint64_t>(h, (size_t)G * T.dom_words);
+      W.tg_counts = dz<int32_t>(h, (size_t)G * dv);
+      W.tg_node_counts = dz<int32_t>(h, nc.size());
+      W.tg_claim_counts = dz<int32_t>(h, (size_t)std::max(1, T.n_host_groups) * mc);
+      W.tg_nonzero = dz<int32_t>(h, G);
+    }
+  }
   {
     // LDS plan of the pack kernel: tables first, the claim order gets what is left of the 160 KiB
     ks::LdsPlan& lp = P.lds;
@@ -406,6 +467,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
     R.cls_tolerates = dz<uint64_t>(h, n_classes);
     R.cls_hot = dz<uint64_t>(h, (size_t)n_classes * P.lay.k_hot_words());
     R.cls_cold = dz<uint64_t>(h, (size_t)n_classes * P.lay.cold_words());
+    R.cls_topo = h->has_topology ? dz<uint64_t>(h, (size_t)n_classes * 2 * R.topo_words) : nullptr;
     R.lay = P.lay;
     h->ws.dead = dz<uint64_t>(h, (size_t)n_classes * h->claim_words);
     if (h->n_nodes) h->ws.n_dead = dz<uint64_t>(h, (size_t)n_classes * P.node_words);
@@ -419,6 +481,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   P.cls_requests = R.cls_requests; P.cls_reqs = as_const(h->d_cls_reqs); P.cls_strict = as_const(h->d_cls_strict);
   P.cls_tolerates = R.cls_tolerates;
   P.cls_hot = R.cls_hot; P.cls_cold = R.cls_cold;
+  P.topo.cls_topo = R.cls_topo;
   if (n_classes) be_fill(h, W.dead, 0, (size_t)n_classes * h->claim_words * 8);
   if (n_classes && h->n_nodes) be_fill(h, W.n_dead, 0, (size_t)n_classes * P.node_words * 8);
   be_toc(h, T_CLASSIFY);
@@ -435,6 +498,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   be_fill(h, W.err, 0, n_pods); be_fill(h, W.diag, 0, n_pods);
   be_fill(h, W.n_claims_out, 0, 4); be_fill(h, W.status_out, 0, 4);
   be_fill(h, h->d_cancel, 0, 4);
+  if (P.topo.n_host_groups) be_fill(h, W.tg_claim_counts, 0, (size_t)P.topo.n_host_groups * h->max_claims * 4);
   be_tic(h, T_PACK);
   if (n_pods) be_launch_pack(h);
   be_toc(h, T_PACK);

@@ -85,6 +85,30 @@ struct LdsPlan {
   int n_kv;
 };
 
+// Topology groups (topologygroup.go:55-77), regular groups then inverse anti-affinity groups; group sets are bit masks of
+// `words` u64 words.
+constexpr int kMaxTopoWords = 16;
+struct TopoView {
+  int n_groups, dom_words, words;
+  uint64_t inverse_mask[kMaxTopoWords], initially_active[kMaxTopoWords];
+  const uint8_t* type;           // [G] 0 spread, 1 affinity, 2 anti-affinity
+  const int32_t* key;            // [G] dictionary key, -1 = kubernetes.io/hostname (domains are the bins)
+  const int16_t* host_slot;       // [G] row of a hostname group in the per-bin counters, -1 for dictionary keys
+  int n_host_groups;
+  const int32_t *max_skew, *min_domains;
+  const uint64_t* domains0;      // [G][dom_words] registered domains at creation
+  const int32_t* counts0;        // [G][dom_words*64]
+  const int32_t* node_counts0;   // [n_host_groups][n_nodes]
+  const int32_t* nonzero0;       // [G] domains with a positive count at creation
+  const uint8_t *f_affinity, *f_taint;   // [G] TopologyNodeFilter policies == Honor
+  const uint32_t* f_first;       // [G+1]
+  ReqTable f_reqs;
+  const uint64_t* f_tolerates;   // [G]
+  const uint16_t* value_rank;    // [req_words*64]
+  const int32_t* node_host_value;  // [n_nodes]
+  const uint64_t* cls_topo;      // [n_classes][2*words] owned | selected (class_gather)
+};
+
 struct ProblemView {
   Dict dict;
   int n_res, n_its, it_words;
@@ -132,6 +156,7 @@ struct ProblemView {
   const uint64_t* node_taints;   // [n_nodes]
   const uint8_t* node_flags;     // [n_nodes] bit0 initialized, bit1 under consolidateAfter
   const uint8_t* pod_from_deleting; // [n_pods]
+  TopoView topo;
 };
 
 struct Counters {
@@ -158,6 +183,12 @@ struct Workspace {
   uint64_t* n_dead;              // [n_classes][node_words] node known infeasible for the class
   // pristine copies restored at the start of every solve
   const uint64_t* n_mask0; const uint32_t *n_defined0, *n_complement0; const int64_t* n_remaining0;
+  // topology group state (TopologyGroup.domains / emptyDomains, topologygroup.go:74-76)
+  uint64_t* tg_domains;          // [G][dom_words] registered domains (Record can add one, topologygroup.go:143-150)
+  int32_t* tg_counts;            // [G][dom_words*64]
+  int32_t* tg_node_counts;       // [n_host_groups][n_nodes]      hostname groups: pods per existing node
+  int32_t* tg_claim_counts;      // [n_host_groups][max_claims]   hostname groups: pods per in-flight claim
+  int32_t* tg_nonzero;           // [G] number of domains with a positive count
   // queue (queue.go): circular buffer of pod ids + lastLen
   uint32_t* queue;               // [n_pods+1]
   uint32_t* last_len;            // [n_pods] 0 = never pushed

@@ -252,6 +252,11 @@ def affinity_term(key, labels, namespaces=None):
     return t
 
 
+def weighted(weight, term):
+    """WeightedPodAffinityTerm."""
+    return {"weight": weight, "term": term}
+
+
 def node_pool(name="default", weight=0, requirements=None, labels=None, taints=None, limits=None, instance_types=None):
     """test.NodePool — pkg/test/nodepool.go:35 (node class label as the test fixtures produce it)."""
     np = {"name": name, "weight": weight, "requirements": list(requirements or []), "labels": dict(labels or {}),

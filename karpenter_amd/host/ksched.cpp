@@ -256,8 +256,60 @@ struct Flattener {
   static void clear(ks::ReqBuf& b) { memset(&b, 0, sizeof(b)); for (int k = 0; k < ks::kMaxKeys; ++k) b.minv[k] = -1; }
 };
 
+// metav1.LabelSelector as labels.Selector: nil matches nothing, empty matches everything (topologygroup.go:101-104,:443)
+struct SelExpr {
+  std::string key, op;
+  std::set<std::string> values;
+  bool operator<(const SelExpr& o) const { return std::tie(key, op, values) < std::tie(o.key, o.op, o.values); }
+};
+struct Selector {
+  bool nil = true;
+  std::map<std::string, std::string> match_labels;
+  std::vector<SelExpr> exprs;
+  bool valid() const {
+    for (auto& e : exprs) {
+      if (e.op == "In" || e.op == "NotIn") { if (e.values.empty()) return false; }
+      else if (e.op == "Exists" || e.op == "DoesNotExist") { if (!e.values.empty()) return false; }
+      else return false;
+    }
+    return true;
+  }
+  bool matches(const std::map<std::string, std::string>& labels) const {
+    if (nil || !valid()) return false;
+    for (auto& kv : match_labels) { auto it = labels.find(kv.first); if (it == labels.end() || it->second != kv.second) return false; }
+    for (auto& e : exprs) {
+      auto it = labels.find(e.key);
+      if (e.op == "In") { if (it == labels.end() || !e.values.count(it->second)) return false; }
+      else if (e.op == "NotIn") { if (it != labels.end() && e.values.count(it->second)) return false; }
+      else if (e.op == "Exists") { if (it == labels.end()) return false; }
+      else if (e.op == "DoesNotExist") { if (it != labels.end()) return false; }
+    }
+    return true;
+  }
+  std::string canon() const {   // what TopologyGroup.Hash() sees of the selector (slices hashed as sets)
+    std::string out = nil ? "nil;" : "sel;";
+    for (auto& kv : match_labels) out += kv.first + "=" + kv.second + ",";
+    out += ";";
+    std::set<SelExpr> ex(exprs.begin(), exprs.end());
+    for (auto& e : ex) { out += e.key + " " + e.op + " ["; for (auto& v : e.values) out += v + ","; out += "];"; }
+    return out;
+  }
+};
+struct Tsc {
+  int max_skew = 1, min_domains = -1;
+  std::string key, when = "DoNotSchedule", taint_policy, affinity_policy;   // policies: "" = nil
+  Selector sel;
+};
+struct AffTerm { Selector sel; std::string key; std::vector<std::string> namespaces; };
+
 // ---- pod model (only what the flattener needs) ----
 struct PodSpec {
+  std::string ns = "default", phase = "Pending";
+  std::map<std::string, std::string> labels;
+  std::vector<Tsc> tscs;
+  bool has_pod_affinity = false, has_pod_anti = false;
+  std::vector<AffTerm> aff_required, anti_required;
+  std::vector<std::pair<int, AffTerm>> aff_preferred, anti_preferred;
   std::string uid;
   long long creation = 0;
   bool pending = true;
@@ -350,6 +402,27 @@ bool parse_uuid(const std::string& s, uint64_t& hi, uint64_t& lo) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
+static Selector parse_selector(const Value& v) {
+  Selector s;
+  if (v.is_null()) return s;
+  s.nil = false;
+  for (auto& kv : v.at("matchLabels").members()) s.match_labels[kv.first] = kv.second.s();
+  for (auto& e : v.at("matchExpressions").items()) {
+    SelExpr x;
+    x.key = e.at("key").s(); x.op = e.at("operator").s();
+    for (auto& val : e.at("values").items()) x.values.insert(val.s());
+    s.exprs.push_back(x);
+  }
+  return s;
+}
+static AffTerm parse_aff_term(const Value& v) {
+  AffTerm t;
+  t.sel = parse_selector(v.at("labelSelector"));
+  t.key = v.at("topologyKey").s();
+  for (auto& n : v.at("namespaces").items()) t.namespaces.push_back(n.s());
+  if (v.has("namespaceSelector") && !v.at("namespaceSelector").is_null()) throw Unsupported("namespaceSelector needs a namespace lister");
+  return t;
+}
 static PodSpec parse_pod(const Value& v) {
   PodSpec p;
   p.uid = v.at("uid").s();
@@ -368,8 +441,37 @@ static PodSpec parse_pod(const Value& v) {
     for (auto& t : na.at("preferred").items()) p.preferred.push_back({(int)t.at("weight").i(), parse_exprs(t.at("matchExpressions"))});
   }
   for (auto& t : v.at("tolerations").items()) p.tolerations.push_back({t.at("key").s(), t.at("operator").s(), t.at("value").s(), t.at("effect").s()});
-  if (v.at("topologySpreadConstraints").items().size()) throw Unsupported("topologySpreadConstraints are not solved on the device in this build");
-  if (!v.at("podAffinity").is_null() || !v.at("podAntiAffinity").is_null()) throw Unsupported("pod (anti-)affinity is not solved on the device in this build");
+  p.ns = v.at("namespace").s("default");
+  p.phase = v.at("phase").s("Pending");
+  for (auto& kv : v.at("labels").members()) p.labels[kv.first] = kv.second.s();
+  for (auto& c : v.at("topologySpreadConstraints").items()) {
+    Tsc t;
+    t.max_skew = (int)c.at("maxSkew").i(1);
+    t.key = c.at("topologyKey").s();
+    t.when = c.at("whenUnsatisfiable").s("DoNotSchedule");
+    t.sel = parse_selector(c.at("labelSelector"));
+    if (c.has("minDomains") && !c.at("minDomains").is_null()) t.min_domains = (int)c.at("minDomains").i();
+    if (c.has("nodeTaintsPolicy") && !c.at("nodeTaintsPolicy").is_null()) t.taint_policy = c.at("nodeTaintsPolicy").s();
+    if (c.has("nodeAffinityPolicy") && !c.at("nodeAffinityPolicy").is_null()) t.affinity_policy = c.at("nodeAffinityPolicy").s();
+    // matchLabelKeys are merged into the selector (topology.go:470-478)
+    for (auto& k : c.at("matchLabelKeys").items()) {
+      auto it = p.labels.find(k.s());
+      if (it != p.labels.end()) { t.sel.nil = false; t.sel.exprs.push_back(SelExpr{k.s(), "In", {it->second}}); }
+    }
+    p.tscs.push_back(t);
+  }
+  const Value& pa = v.at("podAffinity");
+  if (!pa.is_null()) {
+    p.has_pod_affinity = true;
+    for (auto& t : pa.at("required").items()) p.aff_required.push_back(parse_aff_term(t));
+    for (auto& t : pa.at("preferred").items()) p.aff_preferred.push_back({(int)t.at("weight").i(), parse_aff_term(t.at("term"))});
+  }
+  const Value& paa = v.at("podAntiAffinity");
+  if (!paa.is_null()) {
+    p.has_pod_anti = true;
+    for (auto& t : paa.at("required").items()) p.anti_required.push_back(parse_aff_term(t));
+    for (auto& t : paa.at("preferred").items()) p.anti_preferred.push_back({(int)t.at("weight").i(), parse_aff_term(t.at("term"))});
+  }
   return p;
 }
 
@@ -480,6 +582,20 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     };
     std::vector<uint64_t> tmpl_taints(n_templates, 0);
     bool tolerate_prefer_no_schedule = false;
+    struct AnyPool { const Value* v; uint64_t taints; };
+    std::vector<AnyPool> all_pools;   // every non-static NodePool, also those without instance types (topology.go:105-146, scheduler.go:139-147)
+    for (auto& np : root.at("nodePools").items()) {
+      if (np.at("static").boolean_or(false)) continue;
+      uint64_t m = 0;
+      for (auto& tv : np.at("taints").items()) {
+        Taint x{tv.at("key").s(), tv.at("value").s(), tv.at("effect").s()};
+        m |= 1ull << taint_id(x);
+        if (x.effect == "PreferNoSchedule") tolerate_prefer_no_schedule = true;
+      }
+      for (auto& e : parse_exprs(np.at("requirements"))) D.note(e);
+      for (auto& e : label_exprs(np.at("labels"))) D.note(e);
+      all_pools.push_back({&np, m});
+    }
     for (int t = 0; t < n_templates; ++t) {
       const Value& np = *pools[t].v;
       tmpl_exprs[t] = parse_exprs(np.at("requirements"));
@@ -534,7 +650,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       for (int r = 0; r < n_pods; ++r) { uid_hi[order[r]] = 0; uid_lo[order[r]] = (uint64_t)r; }
     }
     // requirement ladders per spec: row 0 = as submitted, then one row per Preferences.Relax step (preferences.go:38-57)
-    struct Variant { std::vector<Expr> reqs, strict; std::vector<Toleration> tolerations; };
+    struct Variant { std::vector<Expr> reqs, strict; std::vector<Toleration> tolerations; PodSpec pod; };
     std::vector<std::vector<Variant>> ladders(specs.size());
     for (size_t si = 0; si < specs.size(); ++si) {
       PodSpec p = specs[si];
@@ -554,15 +670,38 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         v.reqs = build(ignore_prefs);
         v.strict = (p.has_node_affinity && !p.preferred.empty()) ? build(true) : v.reqs;   // scheduler.go:561-566
         v.tolerations = p.tolerations;
+        v.pod = p;
         for (auto& e : v.reqs) D.note(e);
         for (auto& e : v.strict) D.note(e);
+        for (auto& term : p.required_terms) for (auto& e : term) D.note(e);   // every term feeds the TopologyNodeFilter (topologynodefilter.go:50-62)
+        for (auto& t : p.tscs) if (t.key != kHostname) D.key(t.key);
+        for (auto* list : {&p.aff_required, &p.anti_required}) for (auto& t : *list) if (t.key != kHostname) D.key(t.key);
+        for (auto* list : {&p.aff_preferred, &p.anti_preferred}) for (auto& t : *list) if (t.second.key != kHostname) D.key(t.second.key);
         ladders[si].push_back(v);
-        // Relax: first relaxation that applies
+        // Relax: first relaxation that applies (preferences.go:38-57)
         if (p.has_node_affinity && p.has_required && p.required_terms.size() > 1) { p.required_terms.erase(p.required_terms.begin()); continue; }
+        auto by_weight = [](const std::pair<int, AffTerm>& a, const std::pair<int, AffTerm>& b) { return a.first > b.first; };
+        if (p.has_pod_affinity && !p.aff_preferred.empty()) {     // removePreferredPodAffinityTerm — preferences.go:89-101
+          std::stable_sort(p.aff_preferred.begin(), p.aff_preferred.end(), by_weight);
+          p.aff_preferred.erase(p.aff_preferred.begin());
+          continue;
+        }
+        if (p.has_pod_anti && !p.anti_preferred.empty()) {        // removePreferredPodAntiAffinityTerm — preferences.go:103-115
+          std::stable_sort(p.anti_preferred.begin(), p.anti_preferred.end(), by_weight);
+          p.anti_preferred.erase(p.anti_preferred.begin());
+          continue;
+        }
         if (p.has_node_affinity && !p.preferred.empty()) {
           std::stable_sort(p.preferred.begin(), p.preferred.end(), [](const std::pair<int, std::vector<Expr>>& a, const std::pair<int, std::vector<Expr>>& b) { return a.first > b.first; });
           p.preferred.erase(p.preferred.begin());
           continue;
+        }
+        {
+          // removeTopologySpreadScheduleAnyway — preferences.go:59-73 (swap with the last element, then truncate)
+          bool removed = false;
+          for (size_t i = 0; i < p.tscs.size(); ++i)
+            if (p.tscs[i].when == "ScheduleAnyway") { p.tscs[i] = p.tscs.back(); p.tscs.pop_back(); removed = true; break; }
+          if (removed) continue;
         }
         if (tolerate_prefer_no_schedule) {
           bool have = false;
@@ -765,6 +904,318 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         pod_next[row] = vi + 1 < ladders[si].size() ? row + 1 : -1;
       }
 
+    // ---- topology groups (NewTopology, topology.go:68-103; Update, :162-194) --------------------------------
+    // The device keeps one counter per (group, domain); which groups exist, what they select and what each pod variant
+    // owns is object wrangling done here. Group identity follows TopologyGroup.Hash() (topologygroup.go:188-222):
+    // key, type, namespaces, selector, maxSkew and — of the node filter — only what hashstructure can see (requirement
+    // KEYS and minValues, policies, tolerations); minDomains and requirement values are not part of it.
+    struct HGroup {
+      int type = 0; std::string key; bool inverse = false, initial = false;
+      std::set<std::string> namespaces; Selector sel; int max_skew = 0, min_domains = -1;
+      std::string taint_policy, affinity_policy;
+      std::vector<std::vector<Expr>> freqs; uint64_t ftol = 0;
+      std::string identity;
+      std::set<std::string> domains; std::map<std::string, int> counts;
+      std::string content() const {
+        std::string c = identity + "|md" + std::to_string(min_domains) + "|tol" + std::to_string(ftol) + "|";
+        for (auto& d : domains) c += d + ",";
+        c += "|";
+        for (auto& r : freqs) { for (auto& e : r) { c += e.key + " " + e.op + " ["; for (auto& v : e.values) c += v + ","; c += "];"; } c += "/"; }
+        return c;
+      }
+    };
+    std::vector<HGroup> groups;
+    std::vector<std::vector<std::vector<int>>> variant_owned(specs.size());   // group ids per (spec, variant)
+    std::vector<std::vector<int>> spec_inverse_owned(specs.size());
+    bool any_topology = false;
+    for (auto& sp : specs) if (!sp.tscs.empty() || sp.has_pod_affinity || sp.has_pod_anti) any_topology = true;
+    std::vector<PodSpec> cluster_pods;
+    for (auto& cv : root.at("clusterPods").items()) cluster_pods.push_back(parse_pod(cv));
+    for (auto& cp : cluster_pods) if (cp.has_pod_anti && !cp.anti_required.empty()) any_topology = true;
+    auto tol_mask = [&](const std::vector<Toleration>& tols) {
+      uint64_t m = 0;
+      for (size_t ti = 0; ti < distinct_taints.size(); ++ti) for (auto& t : tols) if (tolerates(t, distinct_taints[ti])) { m |= 1ull << ti; break; }
+      return m;
+    };
+    if (any_topology) {
+      // buildDomainGroups — topology.go:105-146 ; TopologyDomainGroup.Insert — topologydomaingroup.go:36-57
+      std::map<std::string, std::map<std::string, std::vector<uint64_t>>> dg;
+      auto dg_insert = [&](const std::string& key, const std::string& dom, uint64_t taints) {
+        auto& m = dg[key];
+        auto it = m.find(dom);
+        if (it == m.end() || taints == 0) { m[dom] = {taints}; return; }
+        if (it->second[0] == 0) return;
+        it->second.push_back(taints);
+      };
+      for (auto& ap : all_pools) {
+        const Value& np = *ap.v;
+        std::vector<Expr> pe = parse_exprs(np.at("requirements"));
+        for (auto& e : label_exprs(np.at("labels"))) pe.push_back(e);
+        ks::ReqBuf pb;
+        Flattener::clear(pb);
+        for (auto& e : pe) { ks::ReqBuf one; fl.encode(e, one); ks::reqbuf_add(fl.kd, pb, ks::reqbuf_ref_with_minv(one)); }
+        auto each_value = [&](const ks::ReqBuf& b, bool only_in, uint64_t taints) {
+          for (int k = 0; k < nk; ++k) {
+            if (!((b.defined >> k) & 1)) continue;
+            if (only_in && (((b.complement >> k) & 1) || !ks::key_nonempty(fl.kd, b.mask, k))) continue;
+            for (size_t v = 0; v < D.values[k].size(); ++v) {
+              size_t pos = (size_t)fl.key_word_off[k] * 64 + v;
+              if ((b.mask[pos / 64] >> (pos % 64)) & 1) dg_insert(D.keys[k], D.values[k][v], taints);   // requirement.Values(): the stored set
+            }
+          }
+        };
+        std::vector<int> members;
+        if (np.has("instanceTypes") && !np.at("instanceTypes").is_null()) { for (auto& n : np.at("instanceTypes").items()) members.push_back(it_index.at(n.s())); }
+        else for (int i = 0; i < n_its; ++i) members.push_back(i);
+        for (int i : members) {
+          ks::ReqBuf b = pb;
+          ks::ReqRef ir; ir.mask = it_reqs.mask.data() + (size_t)i * rw; ir.defined = it_reqs.defined[i]; ir.complement = it_reqs.complement[i];
+          ir.has_gte = it_reqs.has_gte[i]; ir.has_lte = it_reqs.has_lte[i]; ir.gte = it_reqs.gte.data() + (size_t)i * nk; ir.lte = it_reqs.lte.data() + (size_t)i * nk; ir.minv = it_reqs.minv.data() + (size_t)i * nk;
+          ks::reqbuf_add(fl.kd, b, ir);
+          each_value(b, false, ap.taints);
+        }
+        each_value(pb, true, ap.taints);
+      }
+      // state-node label sets (countDomains uses the raw labels, topology.go:376,441)
+      std::vector<ks::ReqBuf> node_label_reqs(n_nodes);
+      std::vector<std::map<std::string, std::string>> node_labels(n_nodes);
+      for (int e = 0; e < n_nodes; ++e) {
+        Flattener::clear(node_label_reqs[e]);
+        for (auto& x : label_exprs(nodes[e].v->at("labels"))) { ks::ReqBuf one; fl.encode(x, one); ks::reqbuf_add(fl.kd, node_label_reqs[e], ks::reqbuf_ref_with_minv(one)); node_labels[e][x.key] = x.values[0]; }
+      }
+      std::map<std::string, int> node_by_name;
+      for (int e = 0; e < n_nodes; ++e) node_by_name[nodes[e].name] = e;
+      std::set<std::string> excluded;   // pods being scheduled are not counted from the cluster (topology.go:92-94)
+      if (!cluster_pods.empty()) for (int p = 0; p < n_pods; ++p) {
+        if (!uid_text[p].empty()) excluded.insert(uid_text[p]);
+        else { std::string t; uint64_t a, b; group_uid(group_of_pod[p].first, group_of_pod[p].second, a, b, &t); excluded.insert(t); }
+      }
+      auto filter_matches = [&](const HGroup& g, uint64_t taints, const ks::ReqBuf& reqs) {   // topologynodefilter.go:68-96
+        if (g.taint_policy == "Honor" && (taints & ~g.ftol)) return false;
+        if (g.affinity_policy != "Honor" || g.freqs.empty()) return true;
+        for (auto& r : g.freqs) {
+          ks::ReqBuf b;
+          Flattener::clear(b);
+          for (auto& e : r) { ks::ReqBuf one; fl.encode(e, one); ks::reqbuf_add(fl.kd, b, ks::reqbuf_ref_with_minv(one)); }
+          if (ks::reqs_compatible(fl.kd, ks::reqbuf_ref_with_minv(reqs), ks::reqbuf_ref_with_minv(b), false) == ks::COMPAT_OK) return true;
+        }
+        return false;
+      };
+      // NewTopologyGroup — topologygroup.go:79-126
+      auto make_group = [&](int type, const std::string& key, const PodSpec& pod, const std::set<std::string>& namespaces, const Selector& sel,
+                            int max_skew, int min_domains, const std::string& taint_policy, const std::string& affinity_policy) {
+        HGroup g;
+        g.type = type; g.key = key; g.namespaces = namespaces; g.sel = sel; g.max_skew = max_skew; g.min_domains = min_domains;
+        std::string fview;
+        if (type == 0) {
+          g.taint_policy = taint_policy.empty() ? "Ignore" : taint_policy;
+          g.affinity_policy = affinity_policy.empty() ? "Honor" : affinity_policy;
+          g.ftol = tol_mask(pod.tolerations);
+          std::vector<Expr> selx = label_exprs(pod.node_selector);
+          if (!pod.has_node_affinity || !pod.has_required) g.freqs.push_back(selx);
+          else for (auto& term : pod.required_terms) { std::vector<Expr> r = selx; for (auto& e : term) r.push_back(e); g.freqs.push_back(r); }
+          std::set<std::set<std::string>> rv;
+          for (auto& r : g.freqs) { std::set<std::string> ks_; for (auto& e : r) ks_.insert(e.key); rv.insert(ks_); }
+          for (auto& r : rv) { for (auto& k : r) fview += k + ","; fview += "/"; }
+          std::set<std::tuple<std::string, std::string, std::string, std::string>> tv;
+          for (auto& t : pod.tolerations) tv.insert({t.key, t.op, t.value, t.effect});
+          fview += "|";
+          for (auto& t : tv) fview += std::get<0>(t) + ":" + std::get<1>(t) + ":" + std::get<2>(t) + ":" + std::get<3>(t) + ",";
+        }
+        g.identity = key + "|" + std::to_string(type) + "|";
+        for (auto& n : namespaces) g.identity += n + ",";
+        g.identity += "|" + std::to_string(max_skew) + "|" + g.taint_policy + "|" + g.affinity_policy + "|" + fview + "|" + sel.canon();
+        // ForEachDomain — topologydomaingroup.go:61-72
+        const uint64_t ptol = tol_mask(pod.tolerations);
+        auto dgi = dg.find(key);
+        if (dgi != dg.end()) for (auto& kv : dgi->second) {
+          bool ok = g.taint_policy == "Ignore";
+          if (!ok) for (uint64_t taints : kv.second) if (!(taints & ~ptol)) { ok = true; break; }
+          if (ok) g.domains.insert(kv.first);
+        }
+        return g;
+      };
+      // countDomains — topology.go:361-459
+      auto count_domains = [&](HGroup& g) {
+        for (int e = 0; e < n_nodes; ++e) {
+          if (!nodes[e].v->at("hasNode").boolean_or(true)) continue;
+          if (!filter_matches(g, node_taints[e], node_label_reqs[e])) continue;
+          auto it = node_labels[e].find(g.key);
+          if (it != node_labels[e].end()) g.domains.insert(it->second);
+        }
+        for (auto& cp : cluster_pods) {
+          if (!g.namespaces.count(cp.ns)) continue;
+          if (!g.sel.nil && !g.sel.matches(cp.labels)) continue;
+          if (cp.node_name.empty() || cp.phase == "Failed" || cp.phase == "Succeeded") continue;
+          if (excluded.count(cp.uid)) continue;
+          auto nf = node_by_name.find(cp.node_name);
+          if (nf == node_by_name.end()) continue;
+          const int e = nf->second;
+          std::string dom;
+          auto it = node_labels[e].find(g.key);
+          if (it != node_labels[e].end()) dom = it->second;
+          else if (g.key == kHostname) dom = nodes[e].name;
+          else continue;
+          if (!filter_matches(g, node_taints[e], node_label_reqs[e])) continue;
+          g.counts[dom]++; g.domains.insert(dom);
+        }
+      };
+      auto namespace_list = [](const std::string& ns, const std::vector<std::string>& list) {
+        return list.empty() ? std::set<std::string>{ns} : std::set<std::string>(list.begin(), list.end());
+      };
+      // inverse anti-affinity groups — topology.go:310-355
+      std::vector<HGroup> inverse;
+      auto inverse_for = [&](const PodSpec& pod, int node) {
+        std::vector<int> owned;
+        for (auto& term : pod.anti_required) {
+          HGroup g = make_group(2, term.key, pod, namespace_list(pod.ns, term.namespaces), term.sel, INT32_MAX, -1, "", "");
+          int id = -1;
+          for (size_t i = 0; i < inverse.size(); ++i) if (inverse[i].identity == g.identity) { id = (int)i; break; }
+          if (id < 0) { g.inverse = true; g.initial = true; inverse.push_back(g); id = (int)inverse.size() - 1; }
+          if (node >= 0) { auto it = node_labels[node].find(inverse[id].key); if (it != node_labels[node].end()) { inverse[id].counts[it->second]++; inverse[id].domains.insert(it->second); } }
+          owned.push_back(id);
+        }
+        return owned;
+      };
+      for (auto& cp : cluster_pods) {
+        if (!(cp.has_pod_anti && !cp.anti_required.empty())) continue;
+        if (excluded.count(cp.uid)) continue;
+        auto nf = node_by_name.find(cp.node_name);
+        if (nf == node_by_name.end()) continue;
+        inverse_for(cp, nf->second);
+      }
+      std::vector<std::vector<std::vector<int>>> variant_groups(specs.size());
+      std::map<std::string, int> group_by_identity;
+      for (int pass = 0; pass < 2; ++pass) {   // pass 0: NewTopology sees every pod as submitted; pass 1: groups that only relaxed variants own
+        for (size_t si = 0; si < specs.size(); ++si) {
+          if (pass == 0) {
+            variant_groups[si].resize(ladders[si].size());
+            const PodSpec& p0 = ladders[si][0].pod;
+            const bool any_anti = p0.has_pod_anti && (!p0.anti_required.empty() || !p0.anti_preferred.empty());
+            const bool req_anti = any_anti && !p0.anti_required.empty();
+            if ((ignore_prefs && req_anti) || (!ignore_prefs && any_anti)) spec_inverse_owned[si] = inverse_for(p0, -1);
+          }
+          for (size_t vi = pass == 0 ? 0 : 1; vi < (pass == 0 ? 1 : ladders[si].size()); ++vi) {
+            const PodSpec& p = ladders[si][vi].pod;
+            std::vector<HGroup> tgs;
+            for (auto& t : p.tscs) {   // newForTopologies — topology.go:461-495
+              if (ignore_prefs && t.when != "DoNotSchedule") continue;
+              tgs.push_back(make_group(0, t.key, p, {p.ns}, t.sel, t.max_skew, t.min_domains, t.taint_policy, t.affinity_policy));
+            }
+            if (p.has_pod_affinity) {  // newForAffinities — topology.go:498-538
+              for (auto& t : p.aff_required) tgs.push_back(make_group(1, t.key, p, namespace_list(p.ns, t.namespaces), t.sel, INT32_MAX, -1, "", ""));
+              if (!ignore_prefs) for (auto& t : p.aff_preferred) tgs.push_back(make_group(1, t.second.key, p, namespace_list(p.ns, t.second.namespaces), t.second.sel, INT32_MAX, -1, "", ""));
+            }
+            if (p.has_pod_anti) {
+              for (auto& t : p.anti_required) tgs.push_back(make_group(2, t.key, p, namespace_list(p.ns, t.namespaces), t.sel, INT32_MAX, -1, "", ""));
+              if (!ignore_prefs) for (auto& t : p.anti_preferred) tgs.push_back(make_group(2, t.second.key, p, namespace_list(p.ns, t.second.namespaces), t.second.sel, INT32_MAX, -1, "", ""));
+            }
+            for (auto& tg : tgs) {
+              auto found = group_by_identity.find(tg.identity);
+              int id = found == group_by_identity.end() ? -1 : found->second;
+              if (id < 0) {
+                count_domains(tg);
+                tg.initial = pass == 0;
+                groups.push_back(tg);
+                id = (int)groups.size() - 1;
+                group_by_identity[tg.identity] = id;
+              } else if (!groups[id].initial) {
+                // a group that first appears when some pod relaxes is created by whichever pod relaxes first; that is only
+                // well-defined without running the solve when every candidate creator would build the same group
+                count_domains(tg);
+                if (tg.content() != groups[id].content()) throw Unsupported("relaxation would create a topology group whose contents depend on scheduling order");
+              }
+              variant_groups[si][vi].push_back(id);
+            }
+          }
+        }
+      }
+      if (groups.size() + inverse.size() > KSOLVE_MAX_TOPO_GROUPS) throw Unsupported("more than 1024 topology groups");
+      const size_t n_regular = groups.size();
+      for (auto& g : inverse) groups.push_back(g);
+      for (size_t si = 0; si < specs.size(); ++si) {
+        variant_owned[si].resize(ladders[si].size());
+        for (size_t vi = 0; vi < ladders[si].size(); ++vi) {
+          variant_owned[si][vi] = variant_groups[si][vi];
+          for (int id : spec_inverse_owned[si]) variant_owned[si][vi].push_back((int)n_regular + id);
+        }
+      }
+    }
+    const int G = (int)groups.size();
+    std::vector<uint8_t> tg_type(G), tg_inverse(G), tg_initial(G), tg_fa(G), tg_ft(G);
+    std::vector<int32_t> tg_key(G), tg_skew(G), tg_mind(G);
+    std::vector<uint32_t> tg_ffirst(G + 1, 0);
+    std::vector<uint64_t> tg_ftol(G), tg_domains;
+    std::vector<int32_t> tg_counts, tg_node_counts;
+    std::vector<uint16_t> value_rank((size_t)rw * 64, 0);
+    std::vector<int32_t> node_host_value(std::max(1, n_nodes), -1);
+    std::vector<uint64_t> pod_topo_owned, pod_topo_selected;
+    ReqTableBuilder tg_freqs;
+    uint32_t dom_words = 1;
+    if (G) {
+      for (auto& g : groups) if (g.key != kHostname) { int k = D.key_index.at(g.key); dom_words = std::max(dom_words, fl.key_word_off[k + 1] - fl.key_word_off[k]); }
+      tg_domains.assign((size_t)G * dom_words, 0); tg_counts.assign((size_t)G * dom_words * 64, 0); tg_node_counts.assign((size_t)G * std::max(1, n_nodes), 0);
+      int n_f = 0;
+      for (auto& g : groups) n_f += (int)g.freqs.size();
+      tg_freqs.init(std::max(1, n_f), rw, nk);
+      int fi = 0;
+      for (int gi = 0; gi < G; ++gi) {
+        const HGroup& g = groups[gi];
+        tg_type[gi] = (uint8_t)g.type; tg_inverse[gi] = g.inverse; tg_initial[gi] = g.initial;
+        tg_skew[gi] = g.max_skew; tg_mind[gi] = g.min_domains;
+        tg_fa[gi] = g.affinity_policy == "Honor"; tg_ft[gi] = g.taint_policy == "Honor"; tg_ftol[gi] = g.ftol;
+        tg_ffirst[gi] = (uint32_t)fi;
+        for (auto& r : g.freqs) {
+          ks::ReqBuf b;
+          Flattener::clear(b);
+          for (auto& e : r) { ks::ReqBuf one; fl.encode(e, one); ks::reqbuf_add(fl.kd, b, ks::reqbuf_ref_with_minv(one)); }
+          tg_freqs.put(fi++, b);
+        }
+        if (g.key == kHostname) {
+          tg_key[gi] = -1;
+          for (auto& kv : g.counts) {
+            int found = -1;
+            for (int e = 0; e < n_nodes; ++e) if (nodes[e].hostname == kv.first) { found = e; break; }
+            if (found < 0) throw Unsupported("pods counted on a hostname that is not a state node");
+            tg_node_counts[(size_t)gi * n_nodes + found] += kv.second;
+          }
+          continue;
+        }
+        const int k = D.key_index.at(g.key);
+        tg_key[gi] = k;
+        for (auto& dom : g.domains) {
+          auto vi = D.value_index[k].find(dom);
+          if (vi == D.value_index[k].end()) throw std::runtime_error("topology domain " + dom + " missing from the dictionary");
+          tg_domains[(size_t)gi * dom_words + vi->second / 64] |= 1ull << (vi->second % 64);
+        }
+        for (auto& kv : g.counts) tg_counts[(size_t)gi * dom_words * 64 + D.value_index[k].at(kv.first)] = kv.second;
+      }
+      tg_ffirst[G] = (uint32_t)fi;
+      for (int k = 0; k < nk; ++k) {
+        std::vector<int> order(D.values[k].size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return D.values[k][a] < D.values[k][b]; });
+        if (order.size() > 65535) throw Unsupported("more than 65535 values under one label key");
+        for (size_t r = 0; r < order.size(); ++r) value_rank[(size_t)fl.key_word_off[k] * 64 + order[r]] = (uint16_t)r;
+      }
+      if (fl.kd.key_hostname >= 0) for (int e = 0; e < n_nodes; ++e) {
+        auto vi = D.value_index[fl.kd.key_hostname].find(nodes[e].hostname);
+        if (vi != D.value_index[fl.kd.key_hostname].end()) node_host_value[e] = vi->second;
+      }
+      const int tw = (G + 63) / 64;
+      pod_topo_owned.assign((size_t)n_rows * tw, 0); pod_topo_selected.assign((size_t)n_rows * tw, 0);
+      std::vector<std::vector<uint64_t>> spec_selected(specs.size(), std::vector<uint64_t>(tw, 0));
+      for (size_t si = 0; si < specs.size(); ++si)
+        for (int gi = 0; gi < G; ++gi) if (groups[gi].namespaces.count(specs[si].ns) && groups[gi].sel.matches(specs[si].labels)) spec_selected[si][gi / 64] |= 1ull << (gi % 64);
+      auto put_masks = [&](int row, size_t si, size_t vi) {
+        for (int id : variant_owned[si][vi]) pod_topo_owned[(size_t)row * tw + id / 64] |= 1ull << (id % 64);
+        for (int w = 0; w < tw; ++w) pod_topo_selected[(size_t)row * tw + w] = spec_selected[si][w];
+      };
+      for (int p = 0; p < n_pods; ++p) put_masks(p, (size_t)pod_spec[p], 0);
+      for (size_t si = 0; si < specs.size(); ++si) if (spec_first_extra[si] >= 0)
+        for (size_t vi = 1; vi < ladders[si].size(); ++vi) put_masks(spec_first_extra[si] + (int)vi - 1, si, vi);
+    }
+
     // ---- describe & solve ----
     ksolve_problem_desc d{};
     d.abi_version = KSOLVE_ABI_VERSION;
@@ -790,6 +1241,15 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       if (!deleting.empty()) for (int p = 0; p < n_pods; ++p) if (deleting.count(specs[pod_spec[p]].node_name)) pod_from_deleting[p] = 1;
     }
     d.pod_from_deleting_node = pod_from_deleting.data();
+    if (G) {
+      ksolve_topology& t = d.topo;
+      t.n = (uint32_t)G; t.type = tg_type.data(); t.inverse = tg_inverse.data(); t.initially_active = tg_initial.data(); t.key = tg_key.data();
+      t.max_skew = tg_skew.data(); t.min_domains = tg_mind.data(); t.domain_words = dom_words; t.domains = tg_domains.data();
+      t.init_counts = tg_counts.data(); t.init_node_counts = tg_node_counts.data();
+      t.filter_affinity_honor = tg_fa.data(); t.filter_taint_honor = tg_ft.data(); t.filter_first = tg_ffirst.data(); t.filter_reqs = tg_freqs.view();
+      t.filter_tolerates = tg_ftol.data(); t.value_rank = value_rank.data(); t.node_hostname_value = node_host_value.data();
+      d.pod_topo_owned = pod_topo_owned.data(); d.pod_topo_selected = pod_topo_selected.data();
+    }
     ksolve_options ko{};
     ko.min_values_best_effort = opts.at("minValuesPolicy").s("Strict") == "BestEffort";
     ko.max_claims = (uint32_t)opts.at("maxClaims").i(0);

@@ -170,9 +170,8 @@ def test_empty_and_degenerate_inputs(oracle, emu):
 
 
 def test_unsupported_is_loud_not_cpu(emu):
-    lab = {"a": "b"}
     with pytest.raises(Unsupported):
-        NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], [fx.pod(labels=lab, topology_spread=[fx.spread(fx.ZONE, lab)])]), solver_lib=emu)
+        NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], [fx.pod()], daemonset_pods=[fx.pod(requests={"cpu": "100m"})]), solver_lib=emu)
     with pytest.raises(Unsupported):
         NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "Exists", min_values=2)])], [fx.pod()]), solver_lib=emu)
 
