@@ -823,6 +823,26 @@ struct Engine {
     });
     W::sync();
     if (!any) return false;
+    if (cur_M) {
+      // Hostname spread / anti-affinity groups of the class: a claim whose per-claim counter already rules it out
+      // (topologygroup.go:240-247,409-414) cannot pass CanAdd, whatever else holds. One lane per claim, counters coalesced.
+      const TopoView& T = P.topo;
+      for (int tw = 0; tw < T.words; ++tw) for (uint64_t m = sc.t_match[tw]; m; m &= m - 1) {
+        const int g = tw * 64 + ctz64(m);
+        if (T.key[g] >= 0 || T.type[g] == 1) continue;
+        const bool self = (sc.t_sel[tw] >> (g & 63)) & 1;
+        const long long limit = T.type[g] == 2 ? 0 : (long long)T.max_skew[g] - (self ? 1 : 0);
+        const int32_t* cc = S.tg_claim_counts + (size_t)T.host_slot[g] * S.max_claims;
+        any = 0;
+        for (int w0 = 0; w0 < words; w0 += 8) {
+          const int n = words - w0 < 8 ? words - w0 : 8;
+          W::ballots8(n, [&](int l, int j) { const int c = (w0 + j) * 64 + l; return c < nc && (long long)cc[c] <= limit; },
+                      [&](int j, uint64_t ok) { const uint64_t v = stage[w0 + j] & ok; W::store(&stage[w0 + j], v); any |= v; });
+        }
+        W::sync();
+        if (!any) return false;
+      }
+    }
     // Walk the claims in the reference's order (addToInflightNode, scheduler.go:667-686), 64 positions per ballot, testing
     // the staged live bits: the first live position is the first candidate; a failed probe clears its bit.
     const KS_LDS uint32_t* ord = order.ord;

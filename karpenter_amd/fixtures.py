@@ -386,6 +386,44 @@ def config2(pods=1_000_000, n_types=500, seed=42, tolerating_fraction=0.25):
     return problem(kwok_catalog(n_types), [dedicated, default], pod_groups=groups, well_known=KWOK_WELL_KNOWN)
 
 
+def config3(pods=1_000_000, n_types=500, seed=42, anti_affinity_pods=None):
+    """C3: podAntiAffinity + 3-zone topologySpreadConstraints, the reference benchmark's diverse mix
+    (scheduling_benchmark_test.go:259-272): one fifth each of generic pods, zonal spread (maxSkew 1), hostname spread,
+    zonal self-affinity and hostname anti-affinity (app=nginx pods repel each other: one node each), labels and spread
+    selectors drawn from my-label in a..g (randomLabels, :430-436), NodePool limited to three zones.
+    anti_affinity_pods overrides the size of the anti-affinity fifth (every such pod needs its own NodeClaim)."""
+    rng = random.Random(seed)
+    combos = [(c, m) for c in BENCH_CPU_M for m in BENCH_MEM_MI]
+    letters = "abcdefg"
+    fifth = pods // 5
+    n_anti = fifth if anti_affinity_pods is None else min(anti_affinity_pods, pods)
+    rest = pods - n_anti
+    kinds = []   # (weight, template kwargs)
+    for lab in letters:
+        kinds.append(("generic", 1.0 + pods % 5, dict(labels={"my-label": lab})))
+        for sel in letters:
+            kinds.append(("zonal", 1.0 / 7, dict(labels={"my-label": lab}, topology_spread=[spread(ZONE, {"my-label": sel})])))
+            kinds.append(("host", 1.0 / 7, dict(labels={"my-label": lab}, topology_spread=[spread(HOSTNAME, {"my-label": sel})])))
+        kinds.append(("affinity", 1.0, dict(labels={"my-affininity": lab}, pod_requirements=[affinity_term(ZONE, {"my-affininity": lab})])))
+    classes = [(k, w * (1 + 0.2 * rng.random()), kw, c, m) for (k, w, kw) in kinds for (c, m) in combos]
+    counts = _split_counts(rest, [k[1] for k in classes], rng)
+    groups = []
+    gi = 0
+    for (kind, _, kw, c, m), n in zip(classes, counts):
+        gi += 1
+        if n:
+            groups.append({"count": n, "uidSeed": seed * 100003 + gi, "template": pod(uid="t", requests={"cpu": f"{c}m", "memory": f"{m}Mi"}, **kw)})
+    nginx = {"app": "nginx"}
+    for (c, m), n in zip(combos, _split_counts(n_anti, [1 + rng.random() for _ in combos], rng)):
+        gi += 1
+        if n:
+            groups.append({"count": n, "uidSeed": seed * 100003 + gi,
+                           "template": pod(uid="t", requests={"cpu": f"{c}m", "memory": f"{m}Mi"}, labels=nginx, pod_anti_requirements=[affinity_term(HOSTNAME, nginx)])})
+    np_ = node_pool("default", requirements=[req(ZONE, "In", *KWOK_ZONES[:3])])
+    np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    return problem(kwok_catalog(n_types), [np_], pod_groups=groups, well_known=KWOK_WELL_KNOWN)
+
+
 def scale_problem(prob, pods):
     """Same problem with the pod groups rescaled to `pods` total (keeps the class mix)."""
     p = copy.deepcopy(prob)

@@ -125,3 +125,50 @@ def test_consolidation_sweep(oracle):
     a, pa = dz.first_n_consolidation_option(cluster, cands, lambda p: NewScheduler(p).Solve())
     b, pb = dz.first_n_consolidation_option(cluster, cands, oracle.solve)
     assert pa == pb and a["decision"] == b["decision"] and a["candidates"] == b["candidates"]
+
+
+# ---- topology ---------------------------------------------------------------------------
+def test_topology_reference_cases(oracle):
+    lab = {"test": "test"}
+    base = lambda pods, **kw: fx.problem(fx.fake_default_instance_types(), kw.pop("pools", [fx.node_pool()]), pods, **kw)
+    got, _ = check(oracle, base([fx.pod(labels=lab, topology_spread=[fx.spread(fx.ZONE, lab)]) for _ in range(4)]))   # topology_test.go:110-124
+    cnt = collections.Counter()
+    for c in got["newNodeClaims"]:
+        cnt[[q for q in c["requirements"] if q["key"] == fx.ZONE][0]["values"][0]] += len(c["pods"])
+    assert sorted(cnt.values()) == [1, 1, 2]
+    got, _ = check(oracle, base([fx.pod(labels=lab, topology_spread=[fx.spread(fx.HOSTNAME, lab)]) for _ in range(4)]))  # :547-560
+    assert sorted(len(c["pods"]) for c in got["newNodeClaims"]) == [1, 1, 1, 1]
+    got, _ = check(oracle, base([fx.pod(labels=lab, pod_anti_requirements=[fx.affinity_term(fx.ZONE, lab)]) for _ in range(5)]))  # :2502-2531
+    assert len(got["newNodeClaims"]) == 1 and len(got["podErrors"]) == 4
+    aff = {"security": "s2"}
+    zp = [fx.pod(requests={"cpu": "2"}, pod_anti_requirements=[fx.affinity_term(fx.ZONE, aff)], node_selector={fx.ZONE: f"test-zone-{i}"}) for i in (1, 2, 3)]
+    victim = fx.pod(labels=aff)
+    got, _ = check(oracle, base(zp + [victim]))                                                                        # :2466-2500
+    assert list(got["podErrors"]) == [victim["uid"]]
+    a = {"app": "a"}
+    got, _ = check(oracle, base([fx.pod(labels=a, requests={"cpu": "1"}, pod_requirements=[fx.affinity_term(fx.ZONE, a)]) for _ in range(6)]))
+    assert not got["podErrors"]
+    check(oracle, base([fx.pod(labels=a, pod_preferences=[fx.weighted(10, fx.affinity_term(fx.ZONE, {"app": "nope"}))],
+                               pod_anti_preferences=[fx.weighted(5, fx.affinity_term(fx.HOSTNAME, a))]) for _ in range(4)]))
+
+
+def test_topology_with_existing_nodes_and_cluster_pods(oracle):
+    lab = {"test": "test"}
+    its = fx.fake_default_instance_types()
+    nodes, cluster = [], []
+    for i, zone in enumerate(["test-zone-1", "test-zone-1", "test-zone-2"]):
+        nodes.append(fx.state_node(f"node-{i}", its[2], zone, "on-demand", "default", used={"cpu": "1", "pods": "1"}))
+        cluster.append(fx.pod(labels=lab, phase="Running", node_name=f"node-{i}", requests={"cpu": "1"}))
+    cluster.append(fx.pod(labels={"role": "guard"}, phase="Running", node_name="node-2", pod_anti_requirements=[fx.affinity_term(fx.ZONE, {"role": "intruder"})]))
+    pods = [fx.pod(labels=lab, topology_spread=[fx.spread(fx.ZONE, lab)]) for _ in range(5)]
+    pods += [fx.pod(labels=lab, topology_spread=[fx.spread(fx.HOSTNAME, lab, max_skew=2)]) for _ in range(4)]
+    pods += [fx.pod(labels={"role": "intruder"}) for _ in range(2)]
+    check(oracle, fx.problem(its, [fx.node_pool()], pods, state_nodes=nodes, cluster_pods=cluster))
+
+
+@pytest.mark.parametrize("pods,types,anti,seed", [(3000, 144, None, 3), (12000, 500, 700, 42)])
+def test_config3_topology_mix(oracle, pods, types, anti, seed):
+    """BASELINE configs[2] shape (anti-affinity + 3-zone spread, the reference benchmark's diverse mix) at sizes the
+    oracle finishes in seconds."""
+    got, _ = check(oracle, fx.config3(pods=pods, n_types=types, seed=seed, anti_affinity_pods=anti))
+    assert got["scheduledPods"] == pods
