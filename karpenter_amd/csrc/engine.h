@@ -97,6 +97,22 @@ struct Engine {
   int last_err = 0, last_diag = 0;
   Counters ctr{};
   // topology: groups that exist so far, and the masks of the class being placed
+  // Instance-type tables in registers: lane l owns instance types {j*64 + l}; with up to kRegIw mask words and kRegNr
+  // resource dimensions (512 types x 4 dims: every KWOK / benchmark catalogue) the resource-fit test of
+  // filterInstanceTypesByRequirements is pure VALU compares on registers, no LDS traffic. Larger problems use the LDS tables.
+  static constexpr int kRegIw = 8, kRegNr = 4;
+#if KS_DEVICE
+  int64_t ra_[kRegIw][kRegNr];
+  uint64_t rav_[kRegIw];
+  KS_DEV int64_t& RA(int, int j, int r) { return ra_[j][r]; }
+  KS_DEV uint64_t& RAV(int, int j) { return rav_[j]; }
+#else
+  int64_t ra_[64][kRegIw][kRegNr];
+  uint64_t rav_[64][kRegIw];
+  int64_t& RA(int l, int j, int r) { return ra_[l][j][r]; }
+  uint64_t& RAV(int l, int j) { return rav_[l][j]; }
+#endif
+  bool regs_ok = false;
   bool cur_M = false;               // the class being placed has matching topology groups
   bool cur_rec = false;             // ... or is counted by some group when it is committed
   int cur_class = 0;
@@ -161,6 +177,19 @@ struct Engine {
     W::for_n(nr, [&](int r) { mr[r] = Pv.min_request[r]; });
     W::for_n(Pv.lds.order_cap / 64, [&](int w) { Lt.closed[w] = 0; });
     W::sync();
+    regs_ok = iw <= kRegIw && nr <= kRegNr;
+    if (regs_ok) {
+      W::ballot([&](int l) {
+#pragma unroll
+        for (int j = 0; j < kRegIw; ++j) {
+          const int it = j * 64 + l;
+          RAV(l, j) = (j < iw && it < n_its) ? Pv.it_off_avail[it] : 0ull;
+#pragma unroll
+          for (int r = 0; r < kRegNr; ++r) RA(l, j, r) = (j < iw && r < nr && it < n_its) ? Pv.it_alloc[(size_t)r * n_its + it] : INT64_MIN;
+        }
+        return false;
+      });
+    }
   }
 
   // ------------------------------------------------------------------------------------------------------------
@@ -237,12 +266,43 @@ struct Engine {
   KS_DEV bool filter_instance_types(const uint64_t* bin_its, const int64_t* total, bool full, const ReqRef& reqs, bool want_diag) {
     uint64_t cells = ~0ull;
     if (full) {
+      ctr.full_filters++;
       compat_mask(reqs);
       cells = offering_cells(reqs);
     }
     const LdsTables& Lt = L;
     const int nr = P.n_res, iw = P.it_words, np = iw * 64;
     uint64_t any = 0;
+    if (regs_ok && !want_diag) {
+      // register tables: every compare of the step is VALU work on this lane's own instance types
+      unsigned long long q0 = W::clock();
+      int64_t tt[kRegNr];
+#pragma unroll
+      for (int r = 0; r < kRegNr; ++r) tt[r] = r < nr ? total[r] : INT64_MIN;
+      uint64_t* its_out = sc.its;
+      const uint64_t* cmw = sc.cm;
+      // eight fit ballots (words past it_words hold padding and are ignored below), each written into its lane of one
+      // vector register; then ONE round of LDS traffic: lane j combines word j (its ∩ allocatable-ok ∩ compatible ∩ fits)
+      LaneVec64 fitv;
+      W::ballots8(8, [&](int l, int j) {
+        int f = full ? (int)((RAV(l, j) & cells) != 0) : 1;
+#pragma unroll
+        for (int r = 0; r < kRegNr; ++r) f &= (int)(tt[r] <= RA(l, j, r));
+        return f != 0;
+      }, [&](int j, uint64_t fit_and_off) { fitv.set(j, fit_and_off); });
+      unsigned long long q1 = W::clock();
+      ctr.cycles[15] += q1 - q0;
+      const uint64_t nonempty = W::ballot([&](int l) {
+        if (l >= iw) return false;
+        const uint64_t fw = fitv.get(l);
+        const uint64_t keep = (full ? cmw[l] : ~0ull) & bin_its[l] & Lt.allocok[l] & fw;
+        its_out[l] = keep;
+        return keep != 0;
+      });
+      W::sync();
+      ctr.cycles[16] += W::clock() - q1;
+      return nonempty != 0;
+    }
     bool d_req = false, d_fit = false, d_off = false, d_ro = false, d_fo = false;
     for (int w0 = 0; w0 < iw; w0 += 8) {
       const int n = iw - w0 < 8 ? iw - w0 : 8;
@@ -718,7 +778,23 @@ struct Engine {
     const RecLayout ly = lay;
     const LdsTables& Lt = L;
     const int64_t* ntot = sc.total;
-    if (recompute_head) {
+    if (recompute_head && regs_ok) {
+      // headroom = max allocatable over the surviving instance types - total, from the register tables
+      uint64_t sw[kRegIw];
+#pragma unroll
+      for (int j = 0; j < kRegIw; ++j) sw[j] = j < iw ? sits[j] : 0ull;
+#pragma unroll
+      for (int r = 0; r < kRegNr; ++r) {
+        if (r >= nr) break;
+        int64_t mx = W::lanes_max_i64([&](int l) {
+          int64_t m = INT64_MIN;
+#pragma unroll
+          for (int j = 0; j < kRegIw; ++j) { const int64_t a = ((sw[j] >> l) & 1) ? RA(l, j, r) : INT64_MIN; m = a > m ? a : m; }
+          return m;
+        });
+        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(mx - ntot[r]);
+      }
+    } else if (recompute_head) {
       // headroom = max allocatable over the surviving instance types - total
       for (int r = 0; r < nr; ++r) {
         int64_t mx = W::reduce_max_i64(np, [&](int it) { return ((sits[it >> 6] >> (it & 63)) & 1) ? Lt.alloc[(size_t)r * np + it] : INT64_MIN; });
@@ -744,6 +820,7 @@ struct Engine {
     uint64_t* dst = S.c_hot + (size_t)c * ly.c_hot_words();
     uint64_t* line = L.cache + (size_t)(c & 31) * ly.c_hot_words();
     W::for_n(ly.c_hot_words(), [&](int i) { uint64_t v = o[i]; dst[i] = v; line[i] = v; });
+    { int64_t* hd = S.c_headroom; const int mc = S.max_claims; W::for_n(nr, [&](int r) { hd[(size_t)r * mc + c] = oh[r]; }); }
     if (W::leader()) sc.cache_tag[c & 31] = c;
     if (write_cold) {
       uint64_t* dc = S.c_cold + (size_t)c * ly.cold_words();
@@ -843,9 +920,75 @@ struct Engine {
         if (!any) return false;
       }
     }
-    // Walk the claims in the reference's order (addToInflightNode, scheduler.go:667-686), 64 positions per ballot, testing
-    // the staged live bits: the first live position is the first candidate; a failed probe clears its bit.
+    {
+      // Headroom prefilter: CanAdd's first resource test — a request larger than what the largest surviving instance type
+      // still has free (nodeclaim.go:213 can only fail) — for 64 claims per ballot from the SoA headroom table, only over
+      // the words that still have live claims. These failures are exact and permanent until the claim's column resets.
+      const int64_t* hd = S.c_headroom;
+      const int mc = S.max_claims;
+      const int nr = lay.nr;
+      const int64_t* req = (const int64_t*)(sc.cls + lay.k_req());
+      uint64_t nz = W::ballot([&](int l) { return l < words && stage[l] != 0; });
+      if (popc64(nz) > 8) nz = 0;   // many live words: one round of loads would not cover them; the probes decide
+      else any = 0;
+      while (nz) {
+        int wj[8];
+        int n = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { wj[q] = 0; if (nz) { wj[q] = ctz64(nz); nz &= nz - 1; n = q + 1; } }
+        W::ballots8(n, [&](int l, int j) {
+          const int c = wj[j] * 64 + l;
+          int ok = 1;
+          for (int r = 0; r < nr; ++r) ok &= (int)(req[r] <= hd[(size_t)r * mc + c]);
+          return ok != 0;
+        }, [&](int j, uint64_t okm) {
+          const int w = wj[j];
+          const uint64_t before = stage[w], v = before & okm;
+          if (v != before) { W::store(&stage[w], v); W::store(&drow[w], (uint64_t)(drow[w] | (before & ~okm))); }
+          any |= v;
+        });
+      }
+      W::sync();
+      if (!any) return false;
+    }
     const KS_LDS uint32_t* ord = order.ord;
+    {
+      // Few live claims (the usual case once the dead row has filled in): the candidate the reference reaches first is
+      // the live claim with the smallest position in its order (addToInflightNode, scheduler.go:667-686). Lane l owns
+      // word l of the live set and takes the minimum of (position, claim) over its bits; one DPP reduction picks the
+      // winner. No walk over the order at all.
+      const KS_LDS uint32_t* pos = order.pos;
+      int who0;
+      const int densest = 64 - (int)W::argmin_u32([&](int l) { return (uint32_t)(64 - (l < words ? popc64(stage[l]) : 0)); }, &who0);
+      if (densest <= 12) {   // the per-lane loop below runs `densest` times
+        for (;;) {
+          int who;
+          const uint32_t best = W::argmin_u32([&](int l) {
+            uint32_t mine = 0xFFFFFFFFu;
+            if (l < words) for (uint64_t b = stage[l]; b; b &= b - 1) {
+              const uint32_t c = (uint32_t)(l * 64 + ctz64(b));
+              const uint32_t key = (pos[c] << 12) | c;
+              mine = key < mine ? key : mine;
+            }
+            return mine;
+          }, &who);
+          if (best == 0xFFFFFFFFu) return false;
+          const int c = (int)(best & 0xFFFu);
+          const int l = c >> 6;
+          const uint64_t valid = (l == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
+          const uint64_t live = stage[l] & ~(1ull << (c & 63));
+          if (try_claim(k, c, pod) == E_OK) return true;
+          unsigned long long tf = W::clock();
+          if (!cur_M) W::store(&drow[l], (uint64_t)(~live & valid));
+          else if (!topo_reached) W::store(&drow[l], (uint64_t)(drow[l] | (1ull << (c & 63))));
+          W::store(&stage[l], live);
+          W::sync();
+          ctr.cycles[8] += W::clock() - tf;
+        }
+      }
+    }
+    // Many live claims: walk the claims in the reference's order, 64 positions per ballot, testing the staged live bits:
+    // the first live position is the first candidate; a failed probe clears its bit.
     for (int base0 = 0; base0 < nc; base0 += 512) {
       // 512 positions per step: eight independent (ord -> live bit) gathers in flight, then eight ballots
       const int nchunks = (nc - base0 + 63) / 64 < 8 ? (nc - base0 + 63) / 64 : 8;

@@ -308,6 +308,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   P.lay = lay;
   W.c_hot = dz<uint64_t>(h, (size_t)mc * lay.c_hot_words());
   W.c_cold = dz<uint64_t>(h, (size_t)mc * lay.cold_words());
+  W.c_headroom = dz<int64_t>(h, (size_t)mc * d->n_res);
   W.o_key = dz<uint32_t>(h, mc); W.o_ord = dz<uint32_t>(h, mc); W.o_pos = dz<uint32_t>(h, mc);
   W.closed = dz<uint64_t>(h, h->claim_words);
   W.queue = dz<uint32_t>(h, (size_t)d->n_pods + 1); W.last_len = dz<uint32_t>(h, d->n_pods);
@@ -598,6 +599,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   out->sorts = ctr.sorts; out->slow_sorts = ctr.slow_sorts; out->relaxations = ctr.relaxations;
   out->ref_bin_evaluations = ctr.ref_bin_evaluations;
   for (int i = 0; i < 24; ++i) out->phase_cycles[i] = ctr.cycles[i];
+  out->phase_cycles[23] = ctr.full_filters; out->phase_cycles[22] = ctr.column_resets; out->phase_cycles[21] = ctr.full_evaluations;
   out->us_upload = h->timers.ms[T_UPLOAD] * 1e3;
   out->us_prepass = (h->timers.ms[T_INDEX] + h->timers.ms[T_CLASSIFY] + h->timers.ms[T_SORT]) * 1e3;
   out->us_pack = h->timers.ms[T_PACK] * 1e3; out->us_finalize = h->timers.ms[T_FINALIZE] * 1e3; out->us_download = h->timers.ms[T_DOWNLOAD] * 1e3;

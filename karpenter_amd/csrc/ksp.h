@@ -163,6 +163,7 @@ struct Counters {
   unsigned long long bin_evaluations, full_evaluations, it_evaluations, queue_pops, sorts, slow_sorts, relaxations, column_resets, walk_scans;
   unsigned long long ref_bin_evaluations;  // V: candidate bins the reference would have evaluated
   unsigned long long cycles[24];           // shader clock spent per engine phase (profiling aid)
+  unsigned long long full_filters;         // filterInstanceTypesByRequirements runs that had to re-evaluate compatibility + offerings
 };
 
 struct Workspace {
@@ -170,6 +171,7 @@ struct Workspace {
   // claims (AoS by claim; see RecLayout)
   uint64_t* c_hot;               // [max_claims][c_hot_words]
   uint64_t* c_cold;              // [max_claims][cold_words]
+  int64_t* c_headroom;           // [n_res][max_claims] SoA copy of the records' headroom: lane-per-claim prefilter of the scan
   // order (pdq_emul.h): lives in LDS while it fits (LdsPlan.order_cap), these are the HBM spill arrays
   uint32_t *o_key, *o_ord, *o_pos;
   // first-fit pruning

@@ -93,6 +93,16 @@ struct Wave {
     }
     return v;
   }
+  // max over the 64 lanes of f(lane)
+  template <class F>
+  KS_DEV static int64_t lanes_max_i64(F f) {
+    int64_t v = f(lane());
+    for (int off = 32; off > 0; off >>= 1) {
+      int64_t o = __shfl_xor(v, off, 64);
+      v = o > v ? o : v;
+    }
+    return v;
+  }
   template <class F>
   KS_DEV static uint64_t reduce_or(int n, F f) {
     uint64_t v = 0;
@@ -162,6 +172,8 @@ struct Wave {
   template <class F>
   static int64_t reduce_max_i64(int n, F f) { int64_t v = INT64_MIN; for (int i = 0; i < n; ++i) { int64_t x = f(i); if (x > v) v = x; } return v; }
   template <class F>
+  static int64_t lanes_max_i64(F f) { int64_t v = INT64_MIN; for (int l = 0; l < 64; ++l) { int64_t x = f(l); if (x > v) v = x; } return v; }
+  template <class F>
   static uint64_t reduce_or(int n, F f) { uint64_t v = 0; for (int i = 0; i < n; ++i) v |= f(i); return v; }
   template <class T>
   static void store(T* p, T v) { *p = v; }
@@ -177,6 +189,25 @@ struct Wave {
 };
 
 #endif
+
+// One u64 per lane, written from wave-uniform values (v_writelane: no LDS, no exec-mask juggling).
+struct LaneVec64 {
+#if KS_DEVICE
+  uint64_t v = 0;
+  KS_DEV void set(int lane, uint64_t x) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    // one SGPR operand per VOP3 (constant bus): the lane select goes through m0
+    asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(lo), "+v"(hi) : "s"(xl), "s"(lane), "s"(xh) : "m0");
+    v = (uint64_t)lo | ((uint64_t)hi << 32);
+  }
+  KS_DEV uint64_t get(int) const { return v; }
+#else
+  uint64_t v[64] = {};
+  void set(int lane, uint64_t x) { v[lane] = x; }
+  uint64_t get(int l) const { return v[l]; }
+#endif
+};
 
 KS_FN int popc64(uint64_t x) { return __builtin_popcountll(x); }
 KS_FN int ctz64(uint64_t x) { return __builtin_ctzll(x); }

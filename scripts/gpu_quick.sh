@@ -1,13 +1,13 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python - <<'PY'
+timeout 900 python - <<'PY'
 import sys, time, json
 from karpenter_amd import fixtures as fx
 from karpenter_amd.scheduling import NewScheduler
-prob = fx.config2(pods=200000)
-s = NewScheduler(prob)
-r = s.Solve(repeat=2, want_results=False)
-c = r["counters"]; pc = c["phaseCycles"]
-names = ["queue","class_fetch","sort","scan","rec_load","can_add","commit","new_claim","dead_mark","try_sched","total","ca_pre","ca_merge","ca_total","ca_filter"]
-print("pack ms", [t["pack_kernel_ms"] for t in r["timings"]], "pods", c["pods"], "evals", c["binEvaluations"])
-for n, v in zip(names, pc): print("%-12s %12d cycles  %8.0f /pod" % (n, v, v / c["pods"]))
+names = ["queue","class_fetch","sort","scan","rec_load","can_add","commit","new_claim","dead_mark","try_sched","total","ca_pre","ca_merge","ca_total","ca_filter","f_ballots","f_combine","x17","x18","x19","x20","merge_reached","col_resets","full_filters"]
+for label, prob in (("config2 200k", fx.config2(pods=200000)), ("config3 100k", fx.config3(pods=100000, n_types=500, seed=42, anti_affinity_pods=3000))):
+    s = NewScheduler(prob)
+    r = s.Solve(repeat=2, want_results=False)
+    c = r["counters"]; pc = c["phaseCycles"]
+    print(label, "pack ms", [t["pack_kernel_ms"] for t in r["timings"]], "pods", c["pods"], "claims", c["claims"], "evals", c["binEvaluations"], "V", c["referenceBinEvaluations"])
+    for n, v in zip(names, pc): print("%-12s %14d cycles  %9.0f /pod" % (n, v, v / c["pods"]))
 PY
