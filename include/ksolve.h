@@ -133,6 +133,15 @@ typedef struct {
   const uint32_t* tmpl_limit_mask; /* n_templates : bit r set => limits[r] applies; bit n_res => "nodes" limit */
   const int64_t* tmpl_limits;      /* n_templates * (n_res+1) : remaining = limits - existing capacity (scheduler.go:183,835) */
 
+  /* ---- daemonset overhead (scheduler.go:963-1043): the instance types of a template are partitioned into groups that
+   *      share the same set of compatible daemonset pods; a type must fit requests + its group's overhead
+   *      (nodeclaim.go:558-566) and FinalizeScheduling adds the smallest overhead to the claim's requests
+   *      (nodeclaim.go:353-377). NULL tmpl_daemon_first = no daemonsets. At most 64 groups per problem. ---- */
+  const uint32_t* tmpl_daemon_first;     /* n_templates+1 : CSR into the group arrays */
+  const uint64_t* daemon_group_its;      /* n_groups * it_words */
+  const int64_t* daemon_group_overhead;  /* n_groups * n_res, incl. pods = number of daemon pods */
+  const uint8_t* daemon_group_nonempty;  /* n_groups : at least one daemon pod is compatible with the group */
+
   /* ---- pods (one row per pod *variant*: row p < n_pods is the pod as submitted; rows >= n_pods are the
    *      pre-computed results of Preferences.Relax (preferences.go:38-57), chained through pod_next_variant) ---- */
   uint32_t n_pods;

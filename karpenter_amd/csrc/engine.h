@@ -38,6 +38,9 @@ struct Scratch {
   ReqBuf merged;                    // slow-path working set (bounds / minValues / very wide dictionaries)
   ReqBuf topo;                      // nodeRequirements ∧ topology domains (Topology.AddRequirements, topology.go:226-250)
   uint64_t tq[kMaxReqWords];        // next-domain set of one topology group (only the group key's words are used)
+  int64_t gtot[kMaxRes];            // requests + the daemon overhead of the group being filtered
+  uint64_t gin[kMaxItWords];        // the bin's instance types that belong to that group
+  int dg_first[33];   // daemon-overhead groups of each template (CSR)
   uint64_t t_owned[kMaxTopoWords], t_sel[kMaxTopoWords];   // topology groups the class being placed owns / is selected by
   uint64_t t_match[kMaxTopoWords];  // getMatchingTopologies (topology.go:561-574)
   uint64_t t_active[kMaxTopoWords]; // groups created so far
@@ -72,6 +75,8 @@ struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host b
   KS_LDS uint32_t *okey, *oord, *opos;   // claim order (pdq_emul.h)
   uint64_t* closed;     // [order_cap/64] claims that cannot take any pod any more
   uint64_t* cache;      // [32][c_hot_words] direct-mapped cache of hot claim records
+  int64_t* dg_ov;       // [n_dg][nr] daemon overhead per group (scheduler.go:963-1043)
+  uint64_t* dg_its;     // [n_dg][iw] instance types of the group
   Scratch* scratch;
   KS_FN void bind(char* base, const LdsPlan& p) {
     alloc = (int64_t*)(base + p.off_alloc); avail = (uint64_t*)(base + p.off_avail); kv = (uint64_t*)(base + p.off_kv);
@@ -79,6 +84,7 @@ struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host b
     tmpl = (uint64_t*)(base + p.off_tmpl); tmpl_cold = (uint64_t*)(base + p.off_tmplcold);
     okey = (KS_LDS uint32_t*)(base + p.off_order); oord = okey + p.order_cap; opos = oord + p.order_cap;
     closed = (uint64_t*)(base + p.off_closed); cache = (uint64_t*)(base + p.off_cache);
+    dg_ov = (int64_t*)(base + p.off_dgov); dg_its = (uint64_t*)(base + p.off_dgits);
     scratch = (Scratch*)(base + p.off_scratch);
   }
 };
@@ -177,6 +183,9 @@ struct Engine {
     W::for_n(nr, [&](int r) { mr[r] = Pv.min_request[r]; });
     W::for_n(Pv.lds.order_cap / 64, [&](int w) { Lt.closed[w] = 0; });
     W::sync();
+    W::for_n(Pv.n_templates + 1, [&](int t) { sc.dg_first[t] = Pv.dg_first[t]; });
+    W::for_n(Pv.n_dg * nr, [&](int i) { Lt.dg_ov[i] = Pv.dg_ov[i]; });
+    W::for_n(Pv.n_dg * iw, [&](int i) { Lt.dg_its[i] = Pv.dg_its[i]; });
     regs_ok = iw <= kRegIw && nr <= kRegNr;
     if (regs_ok) {
       W::ballot([&](int l) {
@@ -263,13 +272,50 @@ struct Engine {
   // `full` = the requirement set differs from the bin's own, so compatibility and offerings must be re-evaluated; when
   // the requirements are unchanged the bin's instance types already satisfy both (they were filtered by these very
   // requirements at the last commit, nodeclaim.go:250-253) and only the resource fit can drop types.
-  KS_DEV bool filter_instance_types(const uint64_t* bin_its, const int64_t* total, bool full, const ReqRef& reqs, bool want_diag) {
+  // `tmpl` selects the daemon-overhead groups (instance types of a template that share the same set of compatible
+  // daemonset pods, scheduler.go:963-1043): an instance type must fit requests + its group's overhead
+  // (nodeclaim.go:558-566). tmpl < 0: no overhead (NewScheduler's prefilter, scheduler.go:159).
+  struct FilterDiagAcc { bool d_req = false, d_fit = false, d_off = false, d_ro = false, d_fo = false; };
+  KS_DEV bool filter_instance_types(const uint64_t* bin_its, const int64_t* total, bool full, const ReqRef& reqs, bool want_diag, int tmpl) {
     uint64_t cells = ~0ull;
     if (full) {
       ctr.full_filters++;
       compat_mask(reqs);
       cells = offering_cells(reqs);
     }
+    FilterDiagAcc acc;
+    const int nr = P.n_res, iw = P.it_words;
+    const int g0 = tmpl < 0 ? 0 : sc.dg_first[tmpl], g1 = tmpl < 0 ? 1 : sc.dg_first[tmpl + 1];
+    bool any;
+    if (g1 - g0 == 1) {
+      const int64_t* tot = total;
+      if (tmpl >= 0 && ((P.dg_nonzero >> g0) & 1)) {
+        const int64_t* ov = L.dg_ov + (size_t)g0 * nr;
+        int64_t* gt = sc.gtot;
+        W::for_n(nr, [&](int r) { gt[r] = total[r] + ov[r]; });
+        tot = sc.gtot;
+      }
+      any = filter_core(bin_its, tot, full, cells, want_diag, false, acc);
+    } else {
+      uint64_t* its_out = sc.its;
+      W::for_n(iw, [&](int w) { its_out[w] = 0; });
+      any = false;
+      for (int g = g0; g < g1; ++g) {
+        const uint64_t* gm = L.dg_its + (size_t)g * iw;
+        const int64_t* ov = L.dg_ov + (size_t)g * nr;
+        uint64_t* gin = sc.gin;
+        const uint64_t some = W::ballot([&](int w) { if (w >= iw) return false; const uint64_t v = bin_its[w] & gm[w]; gin[w] = v; return v != 0; });
+        if (!some) continue;
+        int64_t* gt = sc.gtot;
+        W::for_n(nr, [&](int r) { gt[r] = total[r] + ov[r]; });
+        any = filter_core(sc.gin, sc.gtot, full, cells, want_diag, true, acc) || any;
+      }
+    }
+    if (want_diag) last_diag = (acc.d_req ? 1 : 0) | (acc.d_fit ? 2 : 0) | (acc.d_off ? 4 : 0) | (acc.d_ro ? 16 : 0) | (acc.d_fo ? 32 : 0);
+    return any;
+  }
+  // one group: its_out (sc.its) = / |= in ∩ compatible ∩ fits ∩ hasOffering
+  KS_DEV bool filter_core(const uint64_t* bin_its, const int64_t* total, bool full, uint64_t cells, bool want_diag, bool accumulate, FilterDiagAcc& acc) {
     const LdsTables& Lt = L;
     const int nr = P.n_res, iw = P.it_words, np = iw * 64;
     uint64_t any = 0;
@@ -296,14 +342,14 @@ struct Engine {
         if (l >= iw) return false;
         const uint64_t fw = fitv.get(l);
         const uint64_t keep = (full ? cmw[l] : ~0ull) & bin_its[l] & Lt.allocok[l] & fw;
-        its_out[l] = keep;
+        its_out[l] = accumulate ? (its_out[l] | keep) : keep;
         return keep != 0;
       });
       W::sync();
       ctr.cycles[16] += W::clock() - q1;
       return nonempty != 0;
     }
-    bool d_req = false, d_fit = false, d_off = false, d_ro = false, d_fo = false;
+    bool& d_req = acc.d_req; bool& d_fit = acc.d_fit; bool& d_off = acc.d_off; bool& d_ro = acc.d_ro; bool& d_fo = acc.d_fo;
     for (int w0 = 0; w0 < iw; w0 += 8) {
       const int n = iw - w0 < 8 ? iw - w0 : 8;
       // one lane per instance type, eight mask words per step; every allocatable / availability load of the step is in
@@ -323,7 +369,7 @@ struct Engine {
         const uint64_t keep = cm & itfits;
         ctr.it_evaluations += popc64(in);
         if (want_diag) { d_req |= (in & cm) != 0; d_fit |= itfits != 0; d_fo |= (itfits & ~cm) != 0; }
-        W::store(&its_out[w], keep);
+        W::store(&its_out[w], (uint64_t)(accumulate ? (its_out[w] | keep) : keep));
         any |= keep;
       });
       if (want_diag) {
@@ -348,7 +394,6 @@ struct Engine {
       }
     }
     W::sync();
-    if (want_diag) last_diag = (d_req ? 1 : 0) | (d_fit ? 2 : 0) | (d_off ? 4 : 0) | (d_ro ? 16 : 0) | (d_fo ? 32 : 0);
     return any != 0;
   }
 
@@ -758,7 +803,7 @@ struct Engine {
     const bool full = changed || fresh;
     unsigned long long td = W::clock();
     ctr.cycles[13] += td - tc;
-    const bool any_it = filter_instance_types(bin + lay.c_its(), sc.total, full, merged, want_diag);
+    const bool any_it = filter_instance_types(bin + lay.c_its(), sc.total, full, merged, want_diag, (int)(lo32(bin[lay.c_meta()]) & 31u));
     ctr.cycles[14] += W::clock() - td;
     if (!any_it) return E_INSTANCE_TYPES;  // nodeclaim.go:213
     if (its_changed) {
@@ -778,7 +823,19 @@ struct Engine {
     const RecLayout ly = lay;
     const LdsTables& Lt = L;
     const int64_t* ntot = sc.total;
-    if (recompute_head && regs_ok) {
+    const int hg0 = sc.dg_first[tmpl & 31u], hg1 = sc.dg_first[(tmpl & 31u) + 1];
+    if (recompute_head && hg1 - hg0 > 1) {
+      // several daemon-overhead groups: headroom = max over groups of (max allocatable in the group - its overhead) - total
+      for (int r = 0; r < nr; ++r) {
+        int64_t best = INT64_MIN;
+        for (int g = hg0; g < hg1; ++g) {
+          const uint64_t* gm = Lt.dg_its + (size_t)g * iw;
+          int64_t mx = W::reduce_max_i64(np, [&](int it) { return ((sits[it >> 6] & gm[it >> 6]) >> (it & 63)) & 1 ? Lt.alloc[(size_t)r * np + it] : INT64_MIN; });
+          if (mx != INT64_MIN && mx - Lt.dg_ov[(size_t)g * nr + r] > best) best = mx - Lt.dg_ov[(size_t)g * nr + r];
+        }
+        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(best - ntot[r]);
+      }
+    } else if (recompute_head && regs_ok) {
       // headroom = max allocatable over the surviving instance types - total, from the register tables
       uint64_t sw[kRegIw];
 #pragma unroll
@@ -792,13 +849,13 @@ struct Engine {
           for (int j = 0; j < kRegIw; ++j) { const int64_t a = ((sw[j] >> l) & 1) ? RA(l, j, r) : INT64_MIN; m = a > m ? a : m; }
           return m;
         });
-        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(mx - ntot[r]);
+        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(mx - Lt.dg_ov[(size_t)hg0 * nr + r] - ntot[r]);
       }
     } else if (recompute_head) {
       // headroom = max allocatable over the surviving instance types - total
       for (int r = 0; r < nr; ++r) {
         int64_t mx = W::reduce_max_i64(np, [&](int it) { return ((sits[it >> 6] >> (it & 63)) & 1) ? Lt.alloc[(size_t)r * np + it] : INT64_MIN; });
-        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(mx - ntot[r]);
+        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(mx - Lt.dg_ov[(size_t)hg0 * nr + r] - ntot[r]);
       }
     } else {
       const int64_t* bh = (const int64_t*)(bin + ly.c_head());
@@ -1354,9 +1411,10 @@ struct Engine {
       }
       W::sync();
       ReqRef rr = claim_ref(rec, cold);
-      bool any = filter_instance_types(P.tmpl_its + (size_t)t * iw, sc.total, true, rr, false);
+      bool any = filter_instance_types(P.tmpl_its + (size_t)t * iw, sc.total, true, rr, false, -1);
       const uint64_t* sits = sc.its;
-      W::for_n(iw, [&](int w) { rec[ly.c_its() + w] = sits[w]; });
+      uint64_t* tits = S.t_its + (size_t)t * iw;
+      W::for_n(iw, [&](int w) { rec[ly.c_its() + w] = sits[w]; tits[w] = sits[w]; });
       if (any) active_templates |= 1u << t;
       int64_t* rem = S.t_remaining + (size_t)t * (nr + 1);
       const int64_t* lim = P.tmpl_limits + (size_t)t * (nr + 1);

@@ -269,6 +269,13 @@ struct FinalizeArgs {
   const uint64_t* c_cold;
   RecLayout lay;
   double* cheapest;
+  // addDaemonRequests — nodeclaim.go:353-377
+  const int* dg_first;
+  const int64_t* dg_ov;
+  const uint64_t* dg_its;
+  uint64_t dg_nonempty;
+  const uint64_t* t_its;     // [n_templates][it_words] prefiltered instance types: daemonOverheadGroups are built over them, in their order
+  int64_t* daemon_requests;  // [n_claims][n_res]
 };
 // one thread per claim: min over InstanceTypeOptions of the cheapest available offering compatible with the claim's
 // requirements (the comparator key of OrderByPrice, types.go:336-355)
@@ -307,6 +314,36 @@ KS_FN void finalize_body(int c, const FinalizeArgs& a) {
     }
   }
   a.cheapest[c] = best;
+  // The smallest daemon overhead over the groups that still have an instance type on the claim. Groups are visited in
+  // the order NewScheduler built them (first appearance over the template's prefiltered types, scheduler.go:985-1003;
+  // the reference's own order is a Go map iteration). MinResources keeps the intersection of keys: a group without any
+  // daemon pod empties the running minimum, and an empty minimum is overwritten by the next group (nodeclaim.go:368-372).
+  {
+    const int nr = ly.nr, iw = a.it_words;
+    const int t = (int)((uint32_t)hot[ly.c_meta()] & 31u);
+    const int g0 = a.dg_first[t], g1 = a.dg_first[t + 1];
+    int64_t cur[kMaxRes];
+    bool cur_empty = true;
+    uint64_t visited = 0;
+    for (int step = g0; step < g1; ++step) {
+      int pick = -1, pick_first = 0x7FFFFFFF;
+      for (int g = g0; g < g1; ++g) {
+        if ((visited >> (g - g0)) & 1) continue;
+        int first = 0x7FFFFFFE;
+        for (int w = 0; w < iw; ++w) { uint64_t m = a.dg_its[(size_t)g * iw + w] & a.t_its[(size_t)t * iw + w]; if (m) { first = w * 64 + ctz64(m); break; } }
+        if (first < pick_first) { pick_first = first; pick = g; }
+      }
+      if (pick < 0) break;
+      visited |= 1ull << (pick - g0);
+      bool remaining = false;
+      for (int w = 0; w < iw; ++w) if (a.dg_its[(size_t)pick * iw + w] & its[w]) remaining = true;
+      if (!remaining) continue;
+      const bool g_empty = !((a.dg_nonempty >> pick) & 1);
+      if (cur_empty) { for (int r = 0; r < nr; ++r) cur[r] = a.dg_ov[(size_t)pick * nr + r]; cur_empty = g_empty; }
+      else { for (int r = 0; r < nr; ++r) { int64_t v = a.dg_ov[(size_t)pick * nr + r]; cur[r] = v < cur[r] ? v : cur[r]; } cur_empty = g_empty; }
+    }
+    for (int r = 0; r < nr; ++r) a.daemon_requests[(size_t)c * nr + r] = cur_empty ? 0 : cur[r];
+  }
 }
 
 }  // namespace ks

@@ -56,6 +56,7 @@ struct ksolve_handle {
   uint32_t *d_idx_a = nullptr, *d_idx_b = nullptr;
   uint64_t *d_key_a = nullptr, *d_key_b = nullptr;
   double* d_cheapest = nullptr;
+  int64_t* d_daemon_requests = nullptr;   // [max_claims][n_res] addDaemonRequests, by the finalize kernel
   int* d_cancel = nullptr;
   ks::MutReqTable d_cls_reqs{}, d_cls_strict{};
   std::vector<void*> allocations;
@@ -241,6 +242,36 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   P.tmpl_limit_mask = up(h, d->tmpl_limit_mask, d->n_templates);
   P.tmpl_limits = up(h, d->tmpl_limits, (size_t)d->n_templates * (d->n_res + 1));
 
+  {
+    // daemon-overhead groups; without daemonsets every template is one group with no overhead
+    std::vector<int> first(d->n_templates + 1, 0);
+    std::vector<int64_t> ov;
+    std::vector<uint64_t> gits;
+    uint64_t nonzero = 0, nonempty = 0;
+    if (d->tmpl_daemon_first) {
+      const uint32_t ng = d->tmpl_daemon_first[d->n_templates];
+      if (ng > 64) return fail(h, KSOLVE_ERR_UNSUPPORTED, "more than 64 daemon-overhead groups");
+      for (uint32_t t = 0; t <= d->n_templates; ++t) first[t] = (int)d->tmpl_daemon_first[t];
+      for (uint32_t t = 0; t < d->n_templates; ++t) if (first[t + 1] <= first[t]) return fail(h, KSOLVE_ERR_INVALID, "every template needs at least one daemon-overhead group");
+      ov.assign(d->daemon_group_overhead, d->daemon_group_overhead + (size_t)ng * d->n_res);
+      gits.assign(d->daemon_group_its, d->daemon_group_its + (size_t)ng * it_words);
+      for (uint32_t g = 0; g < ng; ++g) {
+        for (uint32_t r = 0; r < d->n_res; ++r) { if (ov[(size_t)g * d->n_res + r] < 0) return fail(h, KSOLVE_ERR_INVALID, "negative daemon overhead"); if (ov[(size_t)g * d->n_res + r]) nonzero |= 1ull << g; }
+        if (d->daemon_group_nonempty && d->daemon_group_nonempty[g]) nonempty |= 1ull << g;
+      }
+    } else {
+      for (uint32_t t = 0; t <= d->n_templates; ++t) first[t] = (int)t;
+      ov.assign((size_t)std::max(1u, d->n_templates) * d->n_res, 0);
+      gits.assign(d->tmpl_its, d->tmpl_its + (size_t)d->n_templates * it_words);
+      if (gits.empty()) gits.assign(it_words, 0);
+    }
+    P.n_dg = first[d->n_templates];
+    P.dg_first = up(h, first.data(), first.size());
+    P.dg_ov = up(h, ov.data(), ov.size());
+    P.dg_its = up(h, gits.data(), gits.size());
+    P.dg_nonzero = nonzero; P.dg_nonempty = nonempty;
+  }
+
   P.n_pods = d->n_pods; P.n_rows = d->n_pod_rows;
   P.row_next = up(h, d->pod_next_variant, d->n_pod_rows);
   P.pod_is_pending = up(h, d->pod_is_pending, d->n_pods);
@@ -321,6 +352,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   W.max_steps = h->opts.max_steps;
   W.counters = dz<ks::Counters>(h, 1);
   h->d_cheapest = dz<double>(h, mc);
+  h->d_daemon_requests = dz<int64_t>(h, (size_t)mc * d->n_res);
   {
     // topology groups
     ks::TopoView& T = P.topo;
@@ -386,6 +418,8 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     lp.off_tmpl = off; off = align(off + std::max(1u, d->n_templates) * lay.c_hot_words() * 8);
     lp.off_tmplcold = off; off = align(off + std::max(1u, d->n_templates) * lay.cold_words() * 8);
     lp.off_scratch = off; off = align(off + (int)sizeof(ks::Scratch));
+    lp.off_dgov = off; off = align(off + std::max(1, P.n_dg) * (int)d->n_res * 8);
+    lp.off_dgits = off; off = align(off + std::max(1, P.n_dg) * (int)it_words * 8);
     lp.off_cache = off; off = align(off + 32 * lay.c_hot_words() * 8);
     const int budget = 160 * 1024 - 512;
     if (off + 13 * 64 > budget) return fail(h, KSOLVE_ERR_UNSUPPORTED, "instance-type tables do not fit the 160 KiB LDS of one CU");
@@ -513,7 +547,8 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
 
   // ---- phase 5: finalize ----
   be_tic(h, T_FINALIZE);
-  ks::FinalizeArgs F{P.dict, (int)h->n_its, (int)h->it_words, P.n_zones, P.n_cts, P.it_off_avail, P.it_off_price, W.c_hot, W.c_cold, P.lay, h->d_cheapest};
+  ks::FinalizeArgs F{P.dict, (int)h->n_its, (int)h->it_words, P.n_zones, P.n_cts, P.it_off_avail, P.it_off_price, W.c_hot, W.c_cold, P.lay, h->d_cheapest,
+                     P.dg_first, P.dg_ov, P.dg_its, P.dg_nonempty, W.t_its, h->d_daemon_requests};
   if (n_claims) be_launch_finalize(h, n_claims, F);
   be_toc(h, T_FINALIZE);
 
@@ -535,11 +570,14 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   std::vector<int64_t> requests((size_t)C * n_res), gte((size_t)C * h->n_keys), lte((size_t)C * h->n_keys);
   std::vector<int32_t> minv((size_t)C * h->n_keys);
   std::vector<double> cheapest(C);
+  std::vector<int64_t> daemon_req;
   std::vector<uint64_t> hot((size_t)C * ly.c_hot_words()), cold((size_t)C * ly.cold_words());
   if (C) {
     be_d2h(h, hot.data(), W.c_hot, hot.size() * 8);
     be_d2h(h, cold.data(), W.c_cold, cold.size() * 8);
     be_d2h(h, cheapest.data(), h->d_cheapest, (size_t)C * 8);
+    daemon_req.resize((size_t)C * n_res);
+    be_d2h(h, daemon_req.data(), h->d_daemon_requests, (size_t)C * n_res * 8);
     be_d2h(h, ord.data(), W.o_ord, (size_t)C * 4);
   }
   im->node_npods.resize(h->n_nodes);
@@ -554,7 +592,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
     const uint64_t* cr = cold.data() + (size_t)c * ly.cold_words();
     for (uint32_t x = 0; x < h->req_words; ++x) mask[(size_t)c * h->req_words + x] = hr[ly.c_mask() + x];
     for (uint32_t x = 0; x < h->it_words; ++x) its[(size_t)c * h->it_words + x] = hr[ly.c_its() + x];
-    for (uint32_t r = 0; r < n_res; ++r) requests[(size_t)c * n_res + r] = (int64_t)hr[ly.c_total() + r];
+    for (uint32_t r = 0; r < n_res; ++r) requests[(size_t)c * n_res + r] = (int64_t)hr[ly.c_total() + r] + daemon_req[(size_t)c * n_res + r];   // FinalizeScheduling, nodeclaim.go:405-408
     defined[c] = (uint32_t)hr[ly.c_f0()]; complement[c] = (uint32_t)(hr[ly.c_f0()] >> 32);
     has_gte[c] = (uint32_t)hr[ly.c_f1()]; has_lte[c] = (uint32_t)(hr[ly.c_f1()] >> 32);
     tmpl[c] = (int32_t)(uint32_t)hr[ly.c_meta()]; npods[c] = (uint32_t)(hr[ly.c_meta()] >> 32);

@@ -82,6 +82,8 @@ struct LdsPlan {
   int off_closed;     // u64 [cap/64]
   int off_cache;      // u64 [32][c_hot_words] record cache
   int off_scratch;    // Scratch
+  int off_dgov;       // i64 [n_dg][nr]       daemon overhead per group
+  int off_dgits;      // u64 [n_dg][iw]       group membership
   int n_kv;
 };
 
@@ -131,6 +133,13 @@ struct ProblemView {
   const uint64_t* tmpl_its;      // [n_templates][it_words]
   const uint32_t* tmpl_limit_mask;
   const int64_t* tmpl_limits;    // [n_templates][n_res+1]
+  // daemon-overhead groups (scheduler.go:963-1043): every template has at least one group; its groups partition its types
+  int n_dg;
+  const int* dg_first;           // [n_templates+1]
+  const int64_t* dg_ov;          // [n_dg][n_res]
+  const uint64_t* dg_its;        // [n_dg][it_words]
+  uint64_t dg_nonzero;           // group has a non-zero overhead vector
+  uint64_t dg_nonempty;          // group has at least one compatible daemon pod (addDaemonRequests, nodeclaim.go:353-377)
 
   int n_pods, n_rows;
   const int32_t* row_next;       // [n_rows] relaxation chain

@@ -524,7 +524,6 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     const Value& opts = root.at("options");
     bool ignore_prefs = opts.at("preferencePolicy").s("Respect") == "Ignore";
     if (opts.at("reservedCapacity").boolean_or(false)) throw Unsupported("reserved capacity is not solved on the device in this build");
-    if (root.at("daemonSetPods").items().size()) throw Unsupported("daemonset overhead is not solved on the device in this build");
 
     // ---- instance types ----
     const auto& its_json = root.at("instanceTypes").items();
@@ -711,13 +710,21 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         break;
       }
     }
+    // ---- daemonset pods: only their scheduling constraints and requests matter (scheduler.go:972-1043) ----
+    std::vector<PodSpec> daemons;
+    for (auto& dv : root.at("daemonSetPods").items()) {
+      daemons.push_back(parse_pod(dv));
+      const PodSpec& dp = daemons.back();
+      for (auto& e : label_exprs(dp.node_selector)) D.note(e);
+      for (auto& term : dp.required_terms) for (auto& e : term) D.note(e);
+    }
+    if (daemons.size() > 64) throw Unsupported("more than 64 daemonset pods");
     // ---- existing nodes (state.StateNode read accessors): sortExistingNodes order (scheduler.go:845-858) ----
     struct NodeIn { const Value* v; std::string name, hostname; bool initialized; };
     std::vector<NodeIn> nodes;
     for (auto& nv : root.at("stateNodes").items()) {
       NodeIn n{&nv, nv.at("name").s(), "", nv.at("initialized").boolean_or(true)};
       n.hostname = nv.has("hostname") ? nv.at("hostname").s() : (nv.at("labels").has(kHostname) ? nv.at("labels").at(kHostname).s() : n.name);
-      if (nv.at("daemonSetRequests").members().size()) throw Unsupported("daemonset requests on existing nodes");
       nodes.push_back(n);
     }
     std::stable_sort(nodes.begin(), nodes.end(), [](const NodeIn& a, const NodeIn& b) { if (a.initialized != b.initialized) return a.initialized; return a.name < b.name; });
@@ -744,15 +751,17 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       for (auto& kv : it_cap[i]) { if (kv.first.rfind("hugepages-", 0) == 0) throw Unsupported("hugepages"); add_res(kv.first); }
     }
     for (auto& s : specs) for (auto& kv : s.requests) add_res(kv.first);
+    for (auto& dp : daemons) for (auto& kv : dp.requests) add_res(kv.first);
     std::vector<std::map<std::string, i128>> tmpl_limits(n_templates);
     std::vector<bool> tmpl_has_limits(n_templates, false);
     for (int t = 0; t < n_templates; ++t) {
       const Value& np = *pools[t].v;
       if (np.has("limits") && !np.at("limits").is_null()) { tmpl_has_limits[t] = true; tmpl_limits[t] = parse_resources(np.at("limits")); for (auto& kv : tmpl_limits[t]) add_res(kv.first); }
     }
-    std::vector<std::map<std::string, i128>> node_avail(n_nodes), node_cap(n_nodes);
+    std::vector<std::map<std::string, i128>> node_avail(n_nodes), node_cap(n_nodes), node_ds(n_nodes);
     for (int e = 0; e < n_nodes; ++e) {
       node_avail[e] = parse_resources(nodes[e].v->at("available")); node_cap[e] = parse_resources(nodes[e].v->at("capacity"));
+      node_ds[e] = parse_resources(nodes[e].v->at("daemonSetRequests"));
       for (auto& kv : node_avail[e]) add_res(kv.first);
     }
     const int n_res = (int)res_names.size();
@@ -768,6 +777,8 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     };
     for (int i = 0; i < n_its; ++i) { consider(it_cap[i]); consider(it_over[i]); }
     for (auto& s : specs) consider(s.requests);
+    for (auto& dp : daemons) consider(dp.requests);
+    for (int e = 0; e < n_nodes; ++e) consider(node_ds[e]);
     for (int t = 0; t < n_templates; ++t) consider(tmpl_limits[t]);
     for (int e = 0; e < n_nodes; ++e) { consider(node_avail[e]); consider(node_cap[e]); }
     auto to_dev = [&](int r, i128 nano) {
@@ -782,6 +793,15 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     fl.finalize_dictionary(it_words);
     const int nk = fl.kd.n_keys, rw = fl.kd.req_words;
 
+    // newPodRequirements(pod, required only) of a daemonset pod — requirements.go:74-118
+    auto daemon_reqs = [&](const PodSpec& dp) {
+      ks::ReqBuf b;
+      Flattener::clear(b);
+      std::vector<Expr> ex = label_exprs(dp.node_selector);
+      if (dp.has_node_affinity && dp.has_required && !dp.required_terms.empty()) for (auto& e : dp.required_terms[0]) ex.push_back(e);
+      for (auto& e : ex) { ks::ReqBuf one; fl.encode(e, one); ks::reqbuf_add(fl.kd, b, ks::reqbuf_ref_with_minv(one)); }
+      return b;
+    };
     // instance type tables
     std::vector<int64_t> it_alloc((size_t)n_res * n_its), it_capv((size_t)n_res * n_its);
     std::vector<uint64_t> it_avail(n_its, 0);
@@ -844,6 +864,73 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         }
       }
     }
+    // daemon-overhead groups per template (scheduler.go:972-1043): instance types keyed by the set of daemonset pods that
+    // could run on a node of that type from that NodePool
+    std::vector<uint32_t> dg_first;
+    std::vector<uint64_t> dg_its;
+    std::vector<int64_t> dg_ov;
+    std::vector<uint8_t> dg_nonempty;
+    if (!daemons.empty()) {
+      struct DTerm { std::vector<ks::ReqBuf> reqs; };
+      std::vector<DTerm> dterms(daemons.size());
+      for (size_t di = 0; di < daemons.size(); ++di) {
+        PodSpec p = daemons[di];
+        for (;;) {   // isDaemonPodCompatible relaxes required node-affinity terms one by one (scheduler.go:1029-1043)
+          dterms[di].reqs.push_back(daemon_reqs(p));
+          if (p.has_node_affinity && p.has_required && p.required_terms.size() > 1) { p.required_terms.erase(p.required_terms.begin()); continue; }
+          break;
+        }
+      }
+      dg_first.push_back(0);
+      for (int t = 0; t < n_templates; ++t) {
+        ks::ReqRef tr;
+        tr.mask = tmpl_reqs.mask.data() + (size_t)t * rw; tr.defined = tmpl_reqs.defined[t]; tr.complement = tmpl_reqs.complement[t];
+        tr.has_gte = tmpl_reqs.has_gte[t]; tr.has_lte = tmpl_reqs.has_lte[t]; tr.gte = tmpl_reqs.gte.data() + (size_t)t * nk; tr.lte = tmpl_reqs.lte.data() + (size_t)t * nk; tr.minv = nullptr;
+        std::vector<uint64_t> tolerated(daemons.size(), 0);
+        for (size_t di = 0; di < daemons.size(); ++di) {
+          std::vector<Toleration> tols = daemons[di].tolerations;
+          tols.push_back({"", "Exists", "", "PreferNoSchedule"});
+          bool ok = true;
+          for (size_t ti = 0; ti < distinct_taints.size(); ++ti) if ((tmpl_taints[t] >> ti) & 1) {
+            bool one = false;
+            for (auto& tl : tols) one = one || tolerates(tl, distinct_taints[ti]);
+            ok = ok && one;
+          }
+          tolerated[di] = ok;
+        }
+        std::vector<uint64_t> keys;   // group key = mask of compatible daemons, in order of first appearance
+        const size_t base = dg_nonempty.size();
+        for (int i = 0; i < n_its; ++i) {
+          if (!((tmpl_its[(size_t)t * it_words + i / 64] >> (i % 64)) & 1)) continue;
+          ks::ReqRef ir; ir.mask = it_reqs.mask.data() + (size_t)i * rw; ir.defined = it_reqs.defined[i]; ir.complement = it_reqs.complement[i];
+          ir.has_gte = it_reqs.has_gte[i]; ir.has_lte = it_reqs.has_lte[i]; ir.gte = it_reqs.gte.data() + (size_t)i * nk; ir.lte = it_reqs.lte.data() + (size_t)i * nk; ir.minv = nullptr;
+          uint64_t key = 0;
+          for (size_t di = 0; di < daemons.size(); ++di) {
+            if (!tolerated[di]) continue;
+            for (auto& rq : dterms[di].reqs) {
+              ks::ReqRef q = ks::reqbuf_ref_with_minv(rq);
+              if (ks::reqs_compatible(fl.kd, tr, q, true) == ks::COMPAT_OK && ks::reqs_intersect(fl.kd, ir, q)) { key |= 1ull << di; break; }
+            }
+          }
+          size_t gi = 0;
+          for (; gi < keys.size(); ++gi) if (keys[gi] == key) break;
+          if (gi == keys.size()) {
+            keys.push_back(key);
+            dg_its.resize(dg_its.size() + it_words, 0);
+            dg_nonempty.push_back(key != 0);
+            for (int r = 0; r < n_res; ++r) {
+              i128 sum = 0;
+              for (size_t di = 0; di < daemons.size(); ++di) if ((key >> di) & 1) sum += res_names[r] == "pods" ? (i128)1000000000 : res_get(daemons[di].requests, res_names[r]);
+              dg_ov.push_back(to_dev(r, sum));
+            }
+          }
+          dg_its[(base + gi) * it_words + i / 64] |= 1ull << (i % 64);
+        }
+        if (keys.empty()) { dg_its.resize(dg_its.size() + it_words, 0); dg_nonempty.push_back(0); for (int r = 0; r < n_res; ++r) dg_ov.push_back(0); }
+        dg_first.push_back((uint32_t)dg_nonempty.size());
+      }
+      if (dg_nonempty.size() > 64) throw Unsupported("more than 64 daemon-overhead groups");
+    }
     // existing node tables
     ReqTableBuilder node_reqs;
     node_reqs.init(n_nodes, rw, nk);
@@ -854,7 +941,34 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       Flattener::clear(b);
       for (auto& x : node_exprs[e]) { ks::ReqBuf one; fl.encode(x, one); ks::reqbuf_add(fl.kd, b, ks::reqbuf_ref_with_minv(one)); }
       node_reqs.put(e, b);
-      for (int r = 0; r < n_res; ++r) node_remaining[(size_t)r * n_nodes + e] = to_dev(r, res_get(node_avail[e], res_names[r]));
+      // daemons that would run on the node minus what already runs there (scheduler.go:805-832, existingnode.go:50-64)
+      std::map<std::string, i128> daemon;
+      int n_daemons = 0;
+      if (!daemons.empty()) {
+        ks::ReqBuf lb;
+        Flattener::clear(lb);
+        for (auto& x : label_exprs(nodes[e].v->at("labels"))) { ks::ReqBuf one; fl.encode(x, one); ks::reqbuf_add(fl.kd, lb, ks::reqbuf_ref_with_minv(one)); }
+        for (auto& dp : daemons) {
+          bool tolerated = true;
+          for (size_t ti = 0; ti < distinct_taints.size(); ++ti) if ((node_taints[e] >> ti) & 1) {
+            bool ok = false;
+            for (auto& t : dp.tolerations) ok = ok || tolerates(t, distinct_taints[ti]);
+            tolerated = tolerated && ok;
+          }
+          if (!tolerated) continue;
+          ks::ReqBuf pr = daemon_reqs(dp);
+          if (ks::reqs_compatible(fl.kd, ks::reqbuf_ref_with_minv(lb), ks::reqbuf_ref_with_minv(pr), false) != ks::COMPAT_OK) continue;
+          for (auto& kv : dp.requests) daemon[kv.first] += kv.second;
+          n_daemons++;
+        }
+      }
+      daemon["pods"] = (i128)n_daemons * 1000000000;
+      for (auto& kv : node_ds[e]) daemon[kv.first] -= kv.second;
+      for (int r = 0; r < n_res; ++r) {
+        i128 dmn = res_get(daemon, res_names[r]);
+        if (dmn < 0) dmn = 0;
+        node_remaining[(size_t)r * n_nodes + e] = to_dev(r, res_get(node_avail[e], res_names[r]) - dmn);
+      }
       node_init[e] = nodes[e].initialized ? 1 : 0;
       node_uca[e] = (opts.at("consolidationSimulation").boolean_or(false) && nodes[e].v->at("underConsolidateAfter").boolean_or(false)) ? 1 : 0;
     }
@@ -1227,6 +1341,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     d.it_offering_avail = it_avail.data(); d.it_offering_price = it_price.data(); d.n_zones = (uint32_t)n_zones; d.n_captypes = (uint32_t)n_cts;
     d.n_templates = (uint32_t)n_templates; d.tmpl_reqs = tmpl_reqs.view(); d.tmpl_taints = tmpl_taints.data(); d.tmpl_its = tmpl_its.data();
     d.tmpl_limit_mask = tmpl_limit_mask.data(); d.tmpl_limits = tmpl_lim.data();
+    if (!dg_first.empty()) { d.tmpl_daemon_first = dg_first.data(); d.daemon_group_its = dg_its.data(); d.daemon_group_overhead = dg_ov.data(); d.daemon_group_nonempty = dg_nonempty.data(); }
     d.n_pods = (uint32_t)n_pods; d.n_pod_rows = (uint32_t)n_rows; d.pod_requests = pod_requests.data();
     d.pod_reqs = pod_reqs.view(); d.pod_strict_reqs = pod_strict.view(); d.pod_tolerates = pod_tol.data(); d.pod_next_variant = pod_next.data();
     d.pod_creation = pod_creation.data(); d.pod_uid_hi = uid_hi.data(); d.pod_uid_lo = uid_lo.data(); d.pod_is_pending = pod_pending.data();

@@ -22,7 +22,8 @@ def emu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ksched = os.path.join(root, "karpenter_amd", "libksched.so")
     host = os.path.join(root, "karpenter_amd", "host", "ksched.cpp")
-    if not os.path.exists(ksched) or os.path.getmtime(host) > os.path.getmtime(ksched):
+    deps = [host, os.path.join(root, "include", "ksolve.h"), os.path.join(root, "karpenter_amd", "csrc", "reqalg.h")]
+    if not os.path.exists(ksched) or any(os.path.getmtime(d) > os.path.getmtime(ksched) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", ksched, host, "-ldl"])
     return parity.build_emu()
 
@@ -171,9 +172,75 @@ def test_empty_and_degenerate_inputs(oracle, emu):
 
 def test_unsupported_is_loud_not_cpu(emu):
     with pytest.raises(Unsupported):
-        NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], [fx.pod()], daemonset_pods=[fx.pod(requests={"cpu": "100m"})]), solver_lib=emu)
+        NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], [fx.pod()], options={"reservedCapacity": True}), solver_lib=emu)
     with pytest.raises(Unsupported):
         NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "Exists", min_values=2)])], [fx.pod()]), solver_lib=emu)
+
+
+def sorted_its(res):
+    """Daemon-overhead groups are visited in Go map order by the reference (scheduler.go:1001), so the order of
+    InstanceTypeOptions across groups is not defined: compare them as sets."""
+    for c in res["newNodeClaims"]:
+        c["instanceTypes"] = sorted(c["instanceTypes"])
+    return res
+
+
+def check_daemons(oracle, emu, prob):
+    want = sorted_its(oracle.solve(prob))
+    got = sorted_its(NewScheduler(prob, solver_lib=emu).Solve())
+    parity.assert_same_results(got, want)
+    assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
+    return got
+
+
+def test_daemonset_overhead(oracle, emu):
+    """suite_test.go "Daemonsets" (:2143-2460): overhead is added per instance type when fitting, and the smallest overhead
+    is added to the NodeClaim's requests by FinalizeScheduling (nodeclaim.go:353-377)."""
+    its = fx.fake_default_instance_types()
+    ds = [fx.pod(requests={"cpu": "1", "memory": "1Gi"})]
+    got = check_daemons(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(requests={"cpu": "1", "memory": "1Gi"})], daemonset_pods=ds))
+    req = got["newNodeClaims"][0]["requests"]
+    assert int(req["cpu"]) == 2 * 10**9 and int(req["pods"]) == 2 * 10**9                 # suite_test.go:2155-2172
+    # a daemonset restricted to arm64 splits a template's instance types into two overhead groups
+    ds2 = ds + [fx.pod(requests={"cpu": "2"}, node_selector={fx.ARCH: "arm64"})]
+    pods = [fx.pod(requests={"cpu": f"{c}m"}) for c in (500, 900, 1500, 2500, 3500) for _ in range(4)]
+    check_daemons(oracle, emu, fx.problem(its, [fx.node_pool()], pods, daemonset_pods=ds2))
+    check_daemons(oracle, emu, fx.problem(its, [fx.node_pool()], pods + [fx.pod(node_selector={fx.ARCH: "arm64"}, requests={"cpu": "3"})], daemonset_pods=ds2))
+    # daemonset that does not tolerate the NodePool's taint is not counted; one with a node affinity term that has to relax is
+    pools = [fx.node_pool(taints=[{"key": "k", "value": "v", "effect": "NoSchedule"}])]
+    tol = [{"key": "k", "operator": "Exists"}]
+    ds3 = [fx.pod(requests={"cpu": "1"}), fx.pod(requests={"cpu": "500m"}, tolerations=tol,
+                                                   node_requirements=[[fx.req(fx.ZONE, "In", "nowhere")], [fx.req(fx.ZONE, "In", "test-zone-2")]])]
+    check_daemons(oracle, emu, fx.problem(its, pools, [fx.pod(requests={"cpu": "1"}, tolerations=tol) for _ in range(6)], daemonset_pods=ds3))
+    # existing nodes: expected daemons minus what already runs there (existingnode.go:50-64)
+    nodes = [fx.state_node(f"node-{i}", its[2], "test-zone-1", "on-demand", "default", used={"cpu": "500m", "pods": "1"}) for i in range(3)]
+    nodes[0]["daemonSetRequests"] = {"cpu": "1", "memory": "1Gi", "pods": "1"}
+    check_daemons(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(requests={"cpu": "900m"}) for _ in range(8)], daemonset_pods=ds, state_nodes=nodes))
+
+
+def test_daemonset_fuzz(oracle, emu):
+    rng = random.Random(77)
+    for trial in range(20):
+        its = fx.kwok_catalog(rng.choice([20, 70, 144])) if trial % 2 else fx.fake_instance_types(rng.choice([6, 20]))
+        wk = fx.KWOK_WELL_KNOWN if trial % 2 else fx.FAKE_WELL_KNOWN
+        zones = fx.KWOK_ZONES if trial % 2 else ["test-zone-1", "test-zone-2", "test-zone-3"]
+        ds = []
+        for _ in range(rng.randrange(1, 4)):
+            kw = dict(requests={"cpu": f"{rng.choice([50, 100, 250])}m", "memory": f"{rng.choice([64, 128])}Mi"})
+            pick = rng.random()
+            if pick < 0.3:
+                kw["node_selector"] = {fx.ARCH: rng.choice(["amd64", "arm64"])}
+            elif pick < 0.5:
+                kw["node_selector"] = {fx.ZONE: rng.choice(zones)}
+            elif pick < 0.6:
+                kw["node_requirements"] = [[fx.req(fx.OS, "In", "plan9")], [fx.req(fx.OS, "In", "linux")]]
+            ds.append(fx.pod(**kw))
+        pods = [fx.pod(requests={"cpu": f"{rng.choice(fx.BENCH_CPU_M)}m", "memory": f"{rng.choice(fx.BENCH_MEM_MI)}Mi"},
+                       node_selector=rng.choice([None, None, {fx.ARCH: "arm64"}, {fx.ZONE: rng.choice(zones)}])) for _ in range(rng.randrange(20, 150))]
+        np_ = fx.node_pool()
+        if trial % 2:
+            np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+        check_daemons(oracle, emu, fx.problem(its, [np_], pods, daemonset_pods=ds, well_known=wk))
 
 
 def test_random_problems_fuzz(oracle, emu):
