@@ -119,6 +119,8 @@ struct Engine {
   uint64_t& RAV(int l, int j) { return rav_[l][j]; }
 #endif
   bool regs_ok = false;
+  bool min_values_best_effort = false;   // MinValuesPolicyBestEffort (scheduler.go:117)
+  bool minv_lowered = false;        // the last can_add lowered a minValues requirement (BestEffort)
   bool cur_M = false;               // the class being placed has matching topology groups
   bool cur_rec = false;             // ... or is counted by some group when it is committed
   int cur_class = 0;
@@ -126,6 +128,7 @@ struct Engine {
 
   KS_DEV Engine(const ProblemView& p, Workspace& s, const LdsTables& l) : P(p), S(s), L(l), sc(*l.scratch), lay(p.lay) {
     order.key = L.okey; order.ord = L.oord; order.pos = L.opos;
+    min_values_best_effort = s.min_values_best_effort != 0;
   }
 
   // ------------------------------------------------------------------------------------------------------------
@@ -727,6 +730,48 @@ struct Engine {
   // NodeClaim.CanAdd (nodeclaim.go:124-242) for a pod of the class in sc.cls on the bin record `bin`/`bin_cold`.
   // On success sc.out holds the committed record's masks and flag words, sc.its / sc.total the new instance types and
   // requests (finish_record completes head/meta and writes the record).
+  // Number of distinct values the instance types in `its` carry on `key` (InstanceTypes.SatisfiesMinValues,
+  // types.go:399-433: the union of requirement.Values() over the types). One lane per dictionary value; a value counts
+  // when some surviving type lists it (per-value instance-type bitmasks from the it_index kernel).
+  KS_DEV int distinct_values(int key, const uint64_t* its) {
+    const Dict& d = P.dict;
+    const LdsTables& Lt = L;
+    const int iw = lay.iw;
+    int total = 0;
+    if (key == d.key_it) {   // every type requires In [own name]
+      for (int w = 0; w < iw; ++w) total += popc64(its[w]);
+      return total;
+    }
+    for (uint32_t x = d.key_word_off[key]; x < d.key_word_off[key + 1]; ++x) {
+      const uint64_t vb = d.value_valid[x];
+      total += popc64(W::ballot([&](int b) {
+        if (!((vb >> b) & 1)) return false;
+        const uint16_t sl = Lt.kvslot[x * 64 + b];
+        if (sl == 0xFFFF) return false;
+        uint64_t any = 0;
+        for (int w = 0; w < iw; ++w) any |= Lt.kv[(size_t)sl * iw + w] & its[w];
+        return any != 0;
+      }));
+    }
+    return total;
+  }
+  // minValues of the requirement set (mv, one per key, -1 = nil) against the surviving instance types (sc.its):
+  // nodeclaim.go:602-613. Strict policy: unmet => false. BestEffort (relax): the requirement is lowered to what the types
+  // offer (nodeclaim.go:224-229) and *lowered is set.
+  KS_DEV bool min_values_ok(int32_t* mv, bool relax, bool* lowered) {
+    bool ok = true;
+    for (int k = 0; k < lay.nk; ++k) {
+      const int32_t want = mv[k];
+      if (want < 0) continue;
+      const int have = distinct_values(k, sc.its);
+      if (have >= want) continue;
+      if (!relax) { ok = false; continue; }
+      W::store(&mv[k], (int32_t)have);
+      *lowered = true;
+    }
+    W::sync();
+    return ok;
+  }
   // the merged requirement set `m` becomes the record being built (sc.out / sc.out_cold)
   KS_DEV ReqRef reqbuf_to_out(const ReqBuf& m) {
     uint64_t* o = sc.out;
@@ -806,6 +851,13 @@ struct Engine {
     const bool any_it = filter_instance_types(bin + lay.c_its(), sc.total, full, merged, want_diag, (int)(lo32(bin[lay.c_meta()]) & 31u));
     ctr.cycles[14] += W::clock() - td;
     if (!any_it) return E_INSTANCE_TYPES;  // nodeclaim.go:213
+    minv_lowered = false;
+    if (bin_minv) {
+      // SatisfiesMinValues over the remaining types (nodeclaim.go:602-613); only a new NodeClaim may relax (scheduler.go:731)
+      bool lowered = false;
+      if (!min_values_ok((int32_t*)(sc.out_cold + 2 * lay.nk), fresh && min_values_best_effort, &lowered)) { last_diag |= 64; return E_MIN_VALUES; }
+      if (lowered) { minv_lowered = true; if (reqs_changed) *reqs_changed = true; }
+    }
     if (its_changed) {
       const uint64_t* bi = bin + lay.c_its();
       const uint64_t* ni = sc.its;
@@ -1158,7 +1210,7 @@ struct Engine {
       bool changed = false;
       ctr.ref_bin_evaluations++;
       int rc = can_add(bin, tcold, true, first_err == 0, &changed, nullptr, -1);
-      if (rc != E_OK) { if (!first_err) { first_err = rc; first_diag = rc == E_INSTANCE_TYPES ? last_diag : 0; } continue; }
+      if (rc != E_OK) { if (!first_err) { first_err = rc; first_diag = (rc == E_INSTANCE_TYPES || rc == E_MIN_VALUES) ? last_diag : 0; } continue; }
       if (n_claims >= S.max_claims || n_claims >= P.lds.order_cap) { W::store(S.status_out, 1); return -1; }
       int c = n_claims++;
       const uint32_t tm2 = hi32(trec[ly.c_meta2()]);
@@ -1172,7 +1224,14 @@ struct Engine {
       W::sync();
       const bool cold = sc.out[ly.c_f1()] != 0 || (tm2 & 2u);
       if (cur_rec) topo_record(sc.tmpl_taints[t & 31], out_ref(sc.out_cold), 0, c);
-      finish_record(c, bin, true, (uint32_t)t, 1u, host_seq, tm2 & 2u, cold);
+      uint32_t relaxed = 0;
+      if (minv_lowered) {
+        // karpenter.sh/nodeclaim-min-values-relaxed — scheduler.go:763-772
+        const int32_t* nv = (const int32_t*)(sc.out_cold + 2 * ly.nk);
+        const int32_t* ov_ = (const int32_t*)(tcold + 2 * ly.nk);
+        for (int k = 0; k < ly.nk; ++k) if (ov_[k] >= 0 && nv[k] >= 0 && nv[k] < ov_[k]) relaxed = 1;
+      }
+      finish_record(c, bin, true, (uint32_t)t, 1u, host_seq, (tm2 & 2u) | relaxed, cold);
       order.append(c);
       if (lm) {
         // subtractMax — scheduler.go:1049-1066 : remaining -= max capacity over the claim's instance types
@@ -1412,6 +1471,13 @@ struct Engine {
       W::sync();
       ReqRef rr = claim_ref(rec, cold);
       bool any = filter_instance_types(P.tmpl_its + (size_t)t * iw, sc.total, true, rr, false, -1);
+      if (any && has_minv) {
+        // scheduler.go:159: the prefilter applies minValues too; BestEffort keeps the template without touching its requirements
+        int32_t* tmp = (int32_t*)(sc.out_cold + 2 * ly.nk);
+        W::for_n(ly.nk, [&](int k) { tmp[k] = cv[k]; });
+        bool lowered = false;
+        if (!min_values_ok(tmp, min_values_best_effort, &lowered)) any = false;
+      }
       const uint64_t* sits = sc.its;
       uint64_t* tits = S.t_its + (size_t)t * iw;
       W::for_n(iw, [&](int w) { rec[ly.c_its() + w] = sits[w]; tits[w] = sits[w]; });

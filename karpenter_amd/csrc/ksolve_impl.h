@@ -154,8 +154,12 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   if (d->topo.n > KSOLVE_MAX_TOPO_GROUPS) return fail(h, KSOLVE_ERR_UNSUPPORTED, "more than 1024 topology groups");
   if (d->topo.n && (!d->pod_topo_owned || !d->pod_topo_selected)) return fail(h, KSOLVE_ERR_INVALID, "topology groups without pod_topo_owned / pod_topo_selected");
   if (d->tmpl_reqs.min_values) {
-    for (size_t i = 0; i < (size_t)d->n_templates * d->n_keys; ++i)
-      if (d->tmpl_reqs.min_values[i] >= 0) return fail(h, KSOLVE_ERR_UNSUPPORTED, "minValues are not solved on the device in this build");
+    // distinct-value counting uses the instance types' value lists: a NotIn/Exists instance-type requirement on a
+    // minValues key has no such list (its Values() are the excluded ones)
+    for (uint32_t t = 0; t < d->n_templates; ++t) for (uint32_t k = 0; k < d->n_keys; ++k) {
+      if (d->tmpl_reqs.min_values[(size_t)t * d->n_keys + k] < 0 || (int32_t)k == d->key_instance_type) continue;
+      for (uint32_t i = 0; i < d->n_its; ++i) if ((d->it_reqs.complement[i] >> k) & 1) return fail(h, KSOLVE_ERR_UNSUPPORTED, "minValues on a key that an instance type constrains with NotIn/Exists");
+    }
   }
   for (uint32_t i = 0; i < d->n_its; ++i) {
     // reserved offerings would need the ReservationManager; capacity type index >= n_captypes never occurs by construction
@@ -350,6 +354,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   h->d_cancel = dz<int>(h, 1);
   W.cancel_flag = h->d_cancel;
   W.max_steps = h->opts.max_steps;
+  W.min_values_best_effort = h->opts.min_values_best_effort ? 1 : 0;
   W.counters = dz<ks::Counters>(h, 1);
   h->d_cheapest = dz<double>(h, mc);
   h->d_daemon_requests = dz<int64_t>(h, (size_t)mc * d->n_res);

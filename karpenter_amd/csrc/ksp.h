@@ -215,6 +215,7 @@ struct Workspace {
   int* status_out;               // 0 ok, 1 capacity exceeded, 2 cancelled/timed out
   volatile int* cancel_flag;
   long long max_steps;
+  int min_values_best_effort;
   Counters* counters;
 };
 

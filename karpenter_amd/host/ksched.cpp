@@ -603,7 +603,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       tmpl_exprs[t].push_back(Expr{np.at("nodeClassLabelKey").s("karpenter.test.sh/testnodeclass"), "In", {np.at("nodeClassName").s("default")}, -1});
       tmpl_exprs[t].push_back(Expr{"karpenter.sh/registered", "In", {"true"}, -1});
       tmpl_exprs[t].push_back(Expr{"karpenter.sh/initialized", "In", {"true"}, -1});
-      for (auto& e : tmpl_exprs[t]) { D.note(e); if (e.min_values >= 0) throw Unsupported("minValues are not solved on the device in this build"); }
+      for (auto& e : tmpl_exprs[t]) D.note(e);
       for (auto& tv : np.at("taints").items()) {
         Taint x{tv.at("key").s(), tv.at("value").s(), tv.at("effect").s()};
         tmpl_taints[t] |= 1ull << taint_id(x);

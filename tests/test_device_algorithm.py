@@ -243,6 +243,46 @@ def test_daemonset_fuzz(oracle, emu):
         check_daemons(oracle, emu, fx.problem(its, [np_], pods, daemonset_pods=ds, well_known=wk))
 
 
+def _mv_types():
+    off = [fx.offering("spot", "test-zone-1-spot", 0.52)]
+    small = fx.fake_instance_type("instance-type-1", resources={"cpu": "1", "memory": "1Gi"}, offerings=off, architecture="arm64", operating_systems=["linux"])
+    big = fx.fake_instance_type("instance-type-2", resources={"cpu": "4", "memory": "4Gi"}, offerings=[fx.offering("spot", "test-zone-1-spot", 1.0)], architecture="arm64", operating_systems=["linux"])
+    return [small, big]
+
+
+def test_min_values(oracle, emu):
+    """instance_selection_test.go "MinValues" (:620-1500): a claim must keep at least minValues distinct values of the key
+    among its instance types, so two pods that only fit together on the big type go to two nodes."""
+    its = _mv_types()
+    two = [fx.pod(requests={"cpu": "0.9", "memory": "0.9Gi"}) for _ in range(2)]
+    pool = fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "In", "instance-type-1", "instance-type-2", min_values=2)])
+    got, _ = check(oracle, emu, fx.problem(its, [pool], two))
+    assert len(got["newNodeClaims"]) == 2 and all(len(c["instanceTypes"]) == 2 for c in got["newNodeClaims"])      # :621-691
+    # without minValues both share the big type
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "In", "instance-type-1", "instance-type-2")])], two))
+    assert len(got["newNodeClaims"]) == 1
+    # more values required than exist: strict policy fails the pods (:1234-1259), BestEffort relaxes and annotates
+    pool3 = fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "In", "instance-type-1", "instance-type-2", min_values=3)])
+    got, _ = check(oracle, emu, fx.problem(its, [pool3], two))
+    assert len(got["podErrors"]) == 2 and not got["newNodeClaims"]
+    got, _ = check(oracle, emu, fx.problem(its, [pool3], two, options={"minValuesPolicy": "BestEffort"}))
+    assert not got["podErrors"]
+    assert all(c["annotations"]["karpenter.sh/nodeclaim-min-values-relaxed"] == "true" for c in got["newNodeClaims"])
+    # a pod that only fits the big type cannot keep two values: strict = error code MIN_VALUES on the new claim
+    big_pod = [fx.pod(requests={"cpu": "3"})]
+    got, _ = check(oracle, emu, fx.problem(its, [pool], big_pod))
+    assert list(got["podErrors"].values())[0]["code"] == 10
+    got, _ = check(oracle, emu, fx.problem(its, [pool], big_pod, options={"minValuesPolicy": "BestEffort"}))
+    assert not got["podErrors"]
+    # minValues on a label other than the instance type, several keys, and Exists with minValues
+    kw = fx.kwok_catalog(144)
+    np_ = fx.node_pool(requirements=[fx.req("karpenter.kwok.sh/instance-family", "Exists", min_values=3), fx.req(fx.INSTANCE_TYPE, "Exists", min_values=10)])
+    np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    pods = [fx.pod(requests={"cpu": f"{c}m", "memory": f"{m}Mi"}) for c in (500, 4000, 30000, 120000) for m in (512, 8192, 65536) for _ in range(3)]
+    for policy in ("Strict", "BestEffort"):
+        check(oracle, emu, fx.problem(kw, [np_], pods, well_known=fx.KWOK_WELL_KNOWN, options={"minValuesPolicy": policy}))
+
+
 def test_random_problems_fuzz(oracle, emu):
     rng = random.Random(2024)
     for trial in range(25):
