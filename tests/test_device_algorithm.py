@@ -173,8 +173,10 @@ def test_empty_and_degenerate_inputs(oracle, emu):
 def test_unsupported_is_loud_not_cpu(emu):
     with pytest.raises(Unsupported):
         NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], [fx.pod()], options={"reservedCapacity": True}), solver_lib=emu)
-    with pytest.raises(Unsupported):
-        NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "Exists", min_values=2)])], [fx.pod()]), solver_lib=emu)
+    with pytest.raises(Unsupported):   # reserved offerings need the ReservationManager (reservationmanager.go), not on the device yet
+        its = fx.fake_default_instance_types()
+        its[0]["offerings"].append(fx.offering("reserved", "test-zone-1", 0.01, reservation_id="r-1", reservation_capacity=2))
+        NewScheduler(fx.problem(its, [fx.node_pool()], [fx.pod()]), solver_lib=emu)
 
 
 def sorted_its(res):
