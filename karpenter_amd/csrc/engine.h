@@ -48,7 +48,7 @@ struct Scratch {
   uint64_t its[kMaxItWords];        // surviving InstanceTypeOptions
   uint64_t lim[kMaxItWords];        // instance types within NodePool limits
   uint64_t cand[64];                // candidate list: (position << 32 | claim)
-  uint64_t stage[64];               // live words of the class's dead row
+  uint64_t stage[128];              // live words of the class's dead row (two per lane: up to 8192 claims)
   int64_t total[kMaxRes];
   uint64_t claim[kMaxHot];          // candidate bin, hot record
   uint64_t claim_cold[kMaxCold];
@@ -991,21 +991,25 @@ struct Engine {
   KS_DEV bool scan_inflight(int k, int pod) {
     if (n_claims == 0) return false;
     const int words = (n_claims + 63) >> 6;
-    if (words > 64) return scan_inflight_walk(k, pod);
+    if (words > 128) return scan_inflight_walk(k, pod);
     uint64_t* drow = S.dead + (size_t)k * S.claim_words;
     const uint64_t* closed = L.closed;
     const int nc = n_claims;
     uint64_t* stage = sc.stage;
-    // One coalesced load of the class's dead row (lane l holds word l: up to 4096 claims), live = not dead, not closed,
-    // staged in LDS so that everything after it is LDS-only.
+    // One coalesced load of the class's dead row (lane l holds words l and l + 64: up to 8192 claims), live = not dead,
+    // not closed, staged in LDS so that everything after it is LDS-only.
     uint64_t any = W::ballot([&](int l) {
-      uint64_t a = 0;
+      uint64_t a = 0, b = 0;
       if (l < words) {
         uint64_t valid = (l == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
         a = ~drow[l] & ~closed[l] & valid;
       }
-      stage[l] = a;
-      return a != 0;
+      if (l + 64 < words) {
+        uint64_t valid = (l + 64 == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
+        b = ~drow[l + 64] & ~closed[l + 64] & valid;
+      }
+      stage[l] = a; stage[l + 64] = b;
+      return (a | b) != 0;
     });
     W::sync();
     if (!any) return false;
@@ -1038,13 +1042,18 @@ struct Engine {
       const int nr = lay.nr;
       const int64_t* req = (const int64_t*)(sc.cls + lay.k_req());
       uint64_t nz = W::ballot([&](int l) { return l < words && stage[l] != 0; });
-      if (popc64(nz) > 8) nz = 0;   // many live words: one round of loads would not cover them; the probes decide
+      uint64_t nz_hi = words > 64 ? W::ballot([&](int l) { return l + 64 < words && stage[l + 64] != 0; }) : 0ull;
+      if (popc64(nz) + popc64(nz_hi) > 8) nz = nz_hi = 0;   // many live words: one round of loads would not cover them; the probes decide
       else any = 0;
-      while (nz) {
+      while (nz | nz_hi) {
         int wj[8];
         int n = 0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { wj[q] = 0; if (nz) { wj[q] = ctz64(nz); nz &= nz - 1; n = q + 1; } }
+        for (int q = 0; q < 8; ++q) {
+          wj[q] = 0;
+          if (nz) { wj[q] = ctz64(nz); nz &= nz - 1; n = q + 1; }
+          else if (nz_hi) { wj[q] = 64 + ctz64(nz_hi); nz_hi &= nz_hi - 1; n = q + 1; }
+        }
         W::ballots8(n, [&](int l, int j) {
           const int c = wj[j] * 64 + l;
           int ok = 1;
@@ -1068,21 +1077,21 @@ struct Engine {
       // winner. No walk over the order at all.
       const KS_LDS uint32_t* pos = order.pos;
       int who0;
-      const int densest = 64 - (int)W::argmin_u32([&](int l) { return (uint32_t)(64 - (l < words ? popc64(stage[l]) : 0)); }, &who0);
+      const int densest = 128 - (int)W::argmin_u32([&](int l) { return (uint32_t)(128 - (l < words ? popc64(stage[l]) : 0) - (l + 64 < words ? popc64(stage[l + 64]) : 0)); }, &who0);
       if (densest <= 12) {   // the per-lane loop below runs `densest` times
         for (;;) {
           int who;
           const uint32_t best = W::argmin_u32([&](int l) {
             uint32_t mine = 0xFFFFFFFFu;
-            if (l < words) for (uint64_t b = stage[l]; b; b &= b - 1) {
-              const uint32_t c = (uint32_t)(l * 64 + ctz64(b));
-              const uint32_t key = (pos[c] << 12) | c;
+            for (int w = l; w < words; w += 64) for (uint64_t b = stage[w]; b; b &= b - 1) {
+              const uint32_t c = (uint32_t)(w * 64 + ctz64(b));
+              const uint32_t key = (pos[c] << 13) | c;
               mine = key < mine ? key : mine;
             }
             return mine;
           }, &who);
           if (best == 0xFFFFFFFFu) return false;
-          const int c = (int)(best & 0xFFFu);
+          const int c = (int)(best & 0x1FFFu);
           const int l = c >> 6;
           const uint64_t valid = (l == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
           const uint64_t live = stage[l] & ~(1ull << (c & 63));

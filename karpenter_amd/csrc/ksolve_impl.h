@@ -431,7 +431,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     // the claim order (12 B per claim) and the closed bitmap (1 bit per claim) get what is left
     int cap = (int)(((long long)(budget - off) * 8) / (12 * 8 + 1));
     cap &= ~63;
-    if (cap > 4096) cap = 4096;   // one dead-row word per lane in the first-fit scan
+    if (cap > 8192) cap = 8192;   // two dead-row words per lane in the first-fit scan
     if (cap > (int)mc) cap = ((int)mc + 63) & ~63;
     lp.off_order = off; lp.order_cap = cap;
     off = align(off + cap * 12);
@@ -548,7 +548,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   be_d2h(h, &status, W.status_out, 4);
   be_sync(h);
   if (!be_ok(h)) return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "pack kernel failed" : h->error);
-  if (status == 1) return fail(h, KSOLVE_ERR_CAPACITY, "more in-flight NodeClaims than this build keeps resident (ksolve_options.max_claims / 4096 per problem)");
+  if (status == 1) return fail(h, KSOLVE_ERR_CAPACITY, "more in-flight NodeClaims than this build keeps resident (ksolve_options.max_claims / up to 8192 per problem, bounded by the 160 KiB LDS)");
 
   // ---- phase 5: finalize ----
   be_tic(h, T_FINALIZE);

@@ -326,3 +326,15 @@ def test_claim_order_emulation_matches_go_pdqsort(oracle, emu):
         out = (ctypes.c_int * (len(ops) + 1))()
         got_n = lib.ksolve_emu_order_trace(arr, len(ops), out, None)
         assert list(out[:got_n]) == oracle.evaluate({"fn": "order_trace", "ops": ops}), trial
+
+
+def test_more_than_4096_claims(oracle, emu):
+    """The staged first-fit scan keeps two dead-row words per lane: up to 8192 in-flight NodeClaims per problem."""
+    its = fx.fake_default_instance_types()
+    pods = [fx.pod(requests={"cpu": "9"}) for _ in range(4300)] + [fx.pod(requests={"cpu": "200m"}) for _ in range(900)]
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], pods))
+    assert len(got["newNodeClaims"]) > 4096
+    lab = {"app": "nginx"}
+    pods = [fx.pod(labels=lab, requests={"cpu": "100m"}, pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, lab)]) for _ in range(4200)]
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], pods + [fx.pod(requests={"cpu": "1"}) for _ in range(300)]))
+    assert len(got["newNodeClaims"]) > 4096
