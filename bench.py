@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--types", type=int, default=500)
     ap.add_argument("--cpu-sample", type=int, default=40_000, help="pods in the bounded cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-problems", type=int, default=256, help="independent problems solved with ONE batched launch (reported beside the headline, 0 = skip)")
+    ap.add_argument("--batch-pods", type=int, default=20_000, help="pods per problem of the batched measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,6 +141,21 @@ def main():
         "phases_ms": {k: sum(t[k] for t in timings) / len(timings) for k in ("pack_kernel_ms", "classify_ms", "sort_ms", "it_index_ms")},
         "counters": c,
     }
+    if args.batch_problems > 0 and world == 1:
+        # Independent problems (NodePool components / consolidation probes) in ONE launch of the pack kernel:
+        # block b = the wavefront of problem b. Reported beside the headline, never part of `value`.
+        from karpenter_amd.scheduling import SolveBatch
+        scheds = [NewScheduler(dict(fx.config2(pods=args.batch_pods, n_types=args.types, seed=1000 + i), options={"device": device_index})) for i in range(args.batch_problems)]
+        SolveBatch(scheds, want_results=False)   # warm-up
+        tb = time.perf_counter()
+        rs = SolveBatch(scheds, want_results=False)
+        dt = time.perf_counter() - tb
+        out["batched"] = {"problems": args.batch_problems, "pods_each": args.batch_pods, "seconds": dt,
+                          "value": sum(r["scheduledPods"] for r in rs) / dt, "unit": "pods/s",
+                          "pack_kernel_ms": rs[0]["timings"][0]["pack_kernel_ms"],
+                          "note": "ksolve_solve_batch: one wavefront per independent problem, one kernel launch; includes prepass and result download of every problem"}
+        for sc_ in scheds:
+            sc_.close()
     if not args.no_cpu_baseline and world == 1:
         import oracle  # the checker, used here only as the reported CPU baseline
         sample = fx.config2(pods=args.cpu_sample, n_types=args.types, seed=42)

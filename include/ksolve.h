@@ -223,6 +223,11 @@ typedef struct ksolve_handle ksolve_handle;
 ksolve_status ksolve_create(const ksolve_problem_desc* desc, const ksolve_options* opts, ksolve_handle** out);
 /* Runs Solve() on the device. One in-flight solve per handle; distinct handles are independent and thread-safe. */
 ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out);
+/* Solves n independent problems (handles on the same device) with ONE launch of the pack kernel: block b is the
+ * wavefront of problem b. Results are identical to n ksolve_solve calls; outs[i].status carries each problem's status.
+ * This is the entry point for consolidation sweeps (disruption/helpers.go:53-155 runs one Solve() per candidate set)
+ * and for NodePool components of one provisioning pass. */
+ksolve_status ksolve_solve_batch(ksolve_handle** handles, uint32_t n, ksolve_results* outs);
 /* Asks a running ksolve_solve on another thread to stop at the next pod boundary (ctx cancellation). */
 ksolve_status ksolve_cancel(ksolve_handle* h);
 void ksolve_results_free(ksolve_results* r);

@@ -105,6 +105,15 @@ __global__ void __launch_bounds__(64) ksolve_pack(ks::ProblemView pv, ks::Worksp
   eng.solve();
 }
 
+// Batched form: block b solves problem b (its view and workspace are read from HBM instead of the kernel arguments).
+__global__ void __launch_bounds__(64) ksolve_pack_batch(ks::BatchItem* items) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  ks::BatchItem& it = items[blockIdx.x];
+  ks::LdsTables tables;
+  tables.bind(lds, it.pv.lds);
+  ks::Engine<ks::Wave> eng(it.pv, it.ws, tables);
+  eng.solve();
+}
 static dim3 grid_for(int n) { return dim3((unsigned)((n + 255) / 256)); }
 static void be_launch_it_index(ksolve_handle* h, int n, const ks::ItIndexArgs& a) { hipLaunchKernelGGL(ksolve_it_index, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
 static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_row_hash, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
@@ -119,6 +128,24 @@ static void be_launch_pack(ksolve_handle* h) {
   hip_check(h, hipGetLastError(), "ksolve_pack launch");
 }
 
+static void be_launch_pack_batch(ksolve_handle** hs, int n) {
+  ksolve_handle* h0 = hs[0];
+  HipBackend* b = HB(h0);
+  std::vector<ks::BatchItem> items((size_t)n);
+  int lds_bytes = 0;
+  for (int i = 0; i < n; ++i) { items[i].pv = hs[i]->pv; items[i].ws = hs[i]->ws; lds_bytes = std::max(lds_bytes, hs[i]->pv.lds.total_bytes); }
+  ks::BatchItem* d_items = nullptr;
+  if (!hip_check(h0, hipMalloc((void**)&d_items, items.size() * sizeof(ks::BatchItem)), "hipMalloc(batch)")) return;
+  hip_check(h0, hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(ks::BatchItem), hipMemcpyHostToDevice, b->stream), "hipMemcpy(batch)");
+  if (hip_check(h0, hipFuncSetAttribute((const void*)ksolve_pack_batch, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) {
+    be_tic(h0, ksi::T_PACK);
+    hipLaunchKernelGGL(ksolve_pack_batch, dim3((unsigned)n), dim3(64), (size_t)lds_bytes, b->stream, d_items);
+    hip_check(h0, hipGetLastError(), "ksolve_pack_batch launch");
+    be_toc(h0, ksi::T_PACK);
+    for (int i = 1; i < n; ++i) { hs[i]->timers.ms[ksi::T_PACK] = h0->timers.ms[ksi::T_PACK]; if (b->failed) { HB(hs[i])->failed = true; hs[i]->error = h0->error; } }
+  }
+  hipFree(d_items);
+}
 // queue order (queue.go:72-108): five stable LSD radix passes over 64-bit keys, least significant criterion first
 static void be_sort_pods(ksolve_handle* h) {
   const int n = (int)h->n_pods;
@@ -171,6 +198,12 @@ ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out) {
   if (!h || !h->backend) return KSOLVE_ERR_INVALID;
   if (hipSetDevice(HB(h)->device) != hipSuccess) return KSOLVE_ERR_DEVICE;
   return ksi::solve(h, out);
+}
+ksolve_status ksolve_solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) {
+  if (!hs || !outs || n == 0) return KSOLVE_ERR_INVALID;
+  for (uint32_t i = 0; i < n; ++i) if (!hs[i] || !hs[i]->backend || HB(hs[i])->device != HB(hs[0])->device) return KSOLVE_ERR_INVALID;
+  if (hipSetDevice(HB(hs[0])->device) != hipSuccess) return KSOLVE_ERR_DEVICE;
+  return ksi::solve_batch(hs, n, outs);
 }
 ksolve_status ksolve_cancel(ksolve_handle* h) {
   if (!h || !h->d_cancel) return KSOLVE_ERR_INVALID;

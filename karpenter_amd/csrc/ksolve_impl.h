@@ -81,6 +81,7 @@ static void be_launch_row_class(ksolve_handle* h, int n, const ks::RowArgs& a);
 static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a);
 static void be_sort_pods(ksolve_handle* h);  // fills ws/pv.sorted_pods
 static void be_launch_pack(ksolve_handle* h);
+static void be_launch_pack_batch(ksolve_handle** hs, int n);   // one block per handle; sets every handle's T_PACK timer
 static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a);
 static int be_device_available();
 
@@ -455,8 +456,8 @@ struct ResultsImpl {
   std::vector<uint32_t> node_npods;
 };
 
-static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
-  memset(out, 0, sizeof(*out));
+// Phases 1-3 (instance-type index, pod classes, queue order) and the resets the pack kernel needs.
+static ksolve_status solve_prepare(ksolve_handle* h) {
   ks::ProblemView& P = h->pv;
   ks::Workspace& W = h->ws;
   const uint32_t n_pods = h->n_pods, n_rows = h->n_rows, n_res = h->n_res;
@@ -539,10 +540,15 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   be_fill(h, W.n_claims_out, 0, 4); be_fill(h, W.status_out, 0, 4);
   be_fill(h, h->d_cancel, 0, 4);
   if (P.topo.n_host_groups) be_fill(h, W.tg_claim_counts, 0, (size_t)P.topo.n_host_groups * h->max_claims * 4);
-  be_tic(h, T_PACK);
-  if (n_pods) be_launch_pack(h);
-  be_toc(h, T_PACK);
+  return KSOLVE_OK;
+}
 
+// Phases 5-6 (finalize, download) after the pack kernel has run.
+static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
+  memset(out, 0, sizeof(*out));
+  ks::ProblemView& P = h->pv;
+  ks::Workspace& W = h->ws;
+  const uint32_t n_pods = h->n_pods, n_res = h->n_res;
   int n_claims = 0, status = 0;
   be_d2h(h, &n_claims, W.n_claims_out, 4);
   be_d2h(h, &status, W.status_out, 4);
@@ -649,6 +655,36 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   out->packing_cost = cost;
   out->impl = im;
   return out->status;
+}
+
+static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
+  memset(out, 0, sizeof(*out));
+  ksolve_status st = solve_prepare(h);
+  if (st != KSOLVE_OK) return st;
+  be_tic(h, T_PACK);
+  if (h->n_pods) be_launch_pack(h);
+  be_toc(h, T_PACK);
+  return solve_finish(h, out);
+}
+
+// Many independent problems, one launch: block b of the pack kernel is the wavefront of problem b. This is how
+// consolidation sweeps (helpers.go:53-155: one Solve() per candidate set) and NodePool components fill the chip.
+static ksolve_status solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) {
+  for (uint32_t i = 0; i < n; ++i) memset(&outs[i], 0, sizeof(outs[i]));
+  std::vector<ksolve_status> st(n, KSOLVE_OK);
+  std::vector<ksolve_handle*> run;
+  for (uint32_t i = 0; i < n; ++i) {
+    st[i] = solve_prepare(hs[i]);
+    outs[i].status = st[i];
+    if (st[i] == KSOLVE_OK) { be_sync(hs[i]); if (hs[i]->n_pods) run.push_back(hs[i]); }
+  }
+  if (!run.empty()) be_launch_pack_batch(run.data(), (int)run.size());
+  ksolve_status worst = KSOLVE_OK;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (st[i] == KSOLVE_OK) st[i] = solve_finish(hs[i], &outs[i]);
+    if (st[i] != KSOLVE_OK && st[i] != KSOLVE_ERR_CANCELLED) worst = st[i];
+  }
+  return worst;
 }
 
 }  // namespace ksi

@@ -219,4 +219,9 @@ struct Workspace {
   Counters* counters;
 };
 
+struct BatchItem {  // one scheduling problem of a batched pack launch
+  ProblemView pv;
+  Workspace ws;
+};
+
 }  // namespace ks

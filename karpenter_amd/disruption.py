@@ -178,6 +178,39 @@ def single_node_consolidation(cluster, candidates, solver):
     return {"decision": NOOP, "candidates": []}
 
 
+class _Recorder:
+    """Collects the problems a decision procedure wants solved / replays their results, so that all probes of a sweep can
+    go to the device as ONE batched launch."""
+
+    def __init__(self):
+        self.problems, self.results, self.replay = [], None, 0
+
+    def __call__(self, prob):
+        if self.results is None:
+            self.problems.append(prob)
+            raise _Deferred()
+        r = self.results[self.replay]
+        self.replay += 1
+        return r
+
+
+class _Deferred(Exception):
+    pass
+
+
+def sweep_batched(cluster, candidates, batch_solver):
+    """Single-node consolidation sweep with every probe in one device launch: `batch_solver(list of problems) -> list of
+    Results` (the product passes SolveBatch over NewScheduler sessions: one wavefront per probe)."""
+    rec = _Recorder()
+    for c in candidates:
+        try:
+            compute_consolidation(cluster, [c], rec)
+        except _Deferred:
+            pass
+    rec.results = batch_solver(rec.problems)
+    return [compute_consolidation(cluster, [c], rec) for c in candidates]
+
+
 def sweep(cluster, candidates, solver, workers=1):
     """Evaluates computeConsolidation for every single-node candidate. Probes are independent Solve() calls; with
     workers > 1 they run concurrently (each device session owns a stream, each pack kernel is one wavefront on its own

@@ -1412,9 +1412,8 @@ extern "C" void ksched_close(void* session) {
 
 // Solve(): one pass of the hot path on the device with the inputs already resident in HBM. want_results = 0 skips
 // the rehydration of NodeClaims (counters, timings and packing cost are always returned).
-extern "C" char* ksched_solve(void* session, int want_results) {
-  Session* S = (Session*)session;
-  if (!S || !S->handle) return S ? session_error(S) : error_json("invalid", "null session");
+// Results of one finished device solve as a JSON document (takes ownership of `res`).
+static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int want_results) {
   Api& api = S->api;
   ksolve_handle* handle = S->handle;
   Flattener& fl = S->fl;
@@ -1427,10 +1426,7 @@ extern "C" char* ksched_solve(void* session, int want_results) {
   const std::vector<i128>& scale = S->scale;
   try {
     Value timings = Value::array();
-    ksolve_results res{};
-    ksolve_status st;
     {
-      st = api.solve(handle, &res);
       if (st != KSOLVE_OK && st != KSOLVE_ERR_CANCELLED) {
         std::string msg = api.last_error(handle);
         return error_json(st == KSOLVE_ERR_UNSUPPORTED ? "unsupported" : st == KSOLVE_ERR_CAPACITY ? "capacity" : "solve", msg);
@@ -1552,6 +1548,34 @@ extern "C" char* ksched_solve(void* session, int want_results) {
   } catch (const std::exception& e) {
     return error_json("invalid", e.what());
   }
+}
+
+extern "C" char* ksched_solve(void* session, int want_results) {
+  Session* S = (Session*)session;
+  if (!S || !S->handle) return S ? session_error(S) : error_json("invalid", "null session");
+  ksolve_results res{};
+  ksolve_status st = S->api.solve(S->handle, &res);
+  return results_json(S, res, st, want_results);
+}
+
+// Solve() for n sessions with ONE launch of the pack kernel (ksolve_solve_batch): every probe of a consolidation sweep
+// is its own wavefront. outs receives n result documents (each to be released with ksched_free). Returns 0 on success.
+extern "C" int ksched_solve_batch(void** sessions, int n, int want_results, char** outs) {
+  if (!sessions || n <= 0 || !outs) return 1;
+  std::vector<ksolve_handle*> hs;
+  for (int i = 0; i < n; ++i) {
+    Session* S = (Session*)sessions[i];
+    outs[i] = nullptr;
+    if (!S || !S->handle) { for (int j = 0; j < n; ++j) outs[j] = S ? session_error(S) : error_json("invalid", "null session"); return 1; }
+    hs.push_back(S->handle);
+  }
+  Session* S0 = (Session*)sessions[0];
+  auto batch = (decltype(&ksolve_solve_batch))dlsym(S0->api.lib, "ksolve_solve_batch");
+  if (!batch) { for (int j = 0; j < n; ++j) outs[j] = error_json("load", "solver library lacks ksolve_solve_batch"); return 1; }
+  std::vector<ksolve_results> res((size_t)n);
+  batch(hs.data(), (uint32_t)n, res.data());
+  for (int i = 0; i < n; ++i) outs[i] = results_json((Session*)sessions[i], res[i], res[i].status, want_results);
+  return 0;
 }
 
 // Convenience: open + solve (repeat times, last result returned with every run's timings) + close.

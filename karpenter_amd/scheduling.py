@@ -55,6 +55,8 @@ def _load_ksched():
         lib.ksched_error_kind.argtypes = [ctypes.c_void_p]
         lib.ksched_close.argtypes = [ctypes.c_void_p]
         lib.ksched_free.argtypes = [ctypes.c_void_p]
+        lib.ksched_solve_batch.restype = ctypes.c_int
+        lib.ksched_solve_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         _ksched = lib
     return _ksched
 
@@ -131,6 +133,31 @@ class Scheduler:
 
 def NewScheduler(problem: dict, solver_lib: str | None = None) -> Scheduler:
     return Scheduler(problem, solver_lib)
+
+
+def SolveBatch(schedulers, want_results: bool = True):
+    """Solve() for many independent Schedulers with ONE launch of the pack kernel (ksolve_solve_batch): each problem is
+    its own wavefront on its own CU. Same Results as calling Solve() on each; this is how a consolidation pass
+    (disruption/helpers.go:53-155: one simulation per candidate set) or the NodePool components of a provisioning pass
+    fill the GPU."""
+    schedulers = list(schedulers)
+    if not schedulers:
+        return []
+    lib = schedulers[0]._lib
+    n = len(schedulers)
+    sessions = (ctypes.c_void_p * n)(*[s._session for s in schedulers])
+    outs = (ctypes.c_void_p * n)()
+    lib.ksched_solve_batch(sessions, n, 1 if want_results else 0, outs)
+    results = []
+    for i in range(n):
+        try:
+            doc = json.loads(ctypes.string_at(outs[i]).decode())
+        finally:
+            lib.ksched_free(outs[i])
+        if "error" in doc:
+            _raise(doc.get("kind"), doc["error"])
+        results.append(Results(doc))
+    return results
 
 
 def device_available() -> bool:

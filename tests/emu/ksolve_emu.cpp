@@ -52,6 +52,9 @@ static void be_launch_pack(ksolve_handle* h) {
   ks::Engine<ks::Wave> eng(h->pv, h->ws, tables);
   eng.solve();
 }
+static void be_launch_pack_batch(ksolve_handle** hs, int n) {
+  for (int i = 0; i < n; ++i) { be_tic(hs[i], ksi::T_PACK); be_launch_pack(hs[i]); be_toc(hs[i], ksi::T_PACK); }
+}
 static int be_device_available() { return 1; }
 
 extern "C" {
@@ -63,6 +66,7 @@ ksolve_status ksolve_create(const ksolve_problem_desc* desc, const ksolve_option
   return s;
 }
 ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out) { return ksi::solve(h, out); }
+ksolve_status ksolve_solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) { return ksi::solve_batch(hs, n, outs); }
 ksolve_status ksolve_cancel(ksolve_handle* h) { if (h->d_cancel) *h->d_cancel = 1; return KSOLVE_OK; }
 void ksolve_results_free(ksolve_results* r) { if (r && r->impl) { delete (ksi::ResultsImpl*)r->impl; r->impl = nullptr; } }
 void ksolve_destroy(ksolve_handle* h) {

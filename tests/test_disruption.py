@@ -62,3 +62,20 @@ def test_sweep_and_binary_search_match_oracle(oracle, emu):
     b, pb = dz.first_n_consolidation_option(cluster, cands, oracle.solve)
     assert pa == pb and strip(a) == strip(b)   # same probe sequence, same command (multinodeconsolidation.go:136-199)
     assert strip(dz.single_node_consolidation(cluster, cands, dev)) == strip(dz.single_node_consolidation(cluster, cands, oracle.solve))
+
+
+def test_batched_sweep_matches_sequential(oracle, emu):
+    """Every probe of the sweep in one ksolve_solve_batch launch gives the same decisions as probe-by-probe solving."""
+    from karpenter_amd.scheduling import NewScheduler, SolveBatch
+    cluster = dz.make_cluster(n_nodes=40, pods_per_node=5, seed=5)
+    cands = dz.sort_candidates(cluster, cluster["nodes"])[:12]
+
+    def batch(problems):
+        return SolveBatch([NewScheduler(p, solver_lib=emu) for p in problems])
+
+    got = dz.sweep_batched(cluster, cands, batch)
+    want = dz.sweep(cluster, cands, oracle.solve)
+    keys = ("decision", "candidates", "replacement", "replacementCapacityType")
+    assert [{k: c.get(k) for k in keys} for c in got] == [{k: c.get(k) for k in keys} for c in want]
+    for g, w in zip(got, want):
+        parity.assert_same_results(g["results"], w["results"])

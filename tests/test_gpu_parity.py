@@ -172,3 +172,21 @@ def test_config3_topology_mix(oracle, pods, types, anti, seed):
     oracle finishes in seconds."""
     got, _ = check(oracle, fx.config3(pods=pods, n_types=types, seed=seed, anti_affinity_pods=anti))
     assert got["scheduledPods"] == pods
+
+
+def test_batched_launch_equals_individual_solves(oracle):
+    """ksolve_solve_batch: n problems, one pack launch (block b = problem b) — same Results as n ksolve_solve calls."""
+    from karpenter_amd.scheduling import SolveBatch
+    from karpenter_amd import disruption as dz
+    probs = [fx.config2(pods=1500 + 300 * i, n_types=144, seed=50 + i) for i in range(6)]
+    probs.append(fx.config3(pods=1200, n_types=144, seed=7))
+    probs.append(fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], []))
+    got = SolveBatch([NewScheduler(p) for p in probs])
+    for g, p in zip(got, probs):
+        parity.assert_same_results(g, oracle.solve(p))
+    cluster = dz.make_cluster(n_nodes=60, pods_per_node=6, seed=11)
+    cands = dz.sort_candidates(cluster, cluster["nodes"])[:32]
+    a = dz.sweep_batched(cluster, cands, lambda ps: SolveBatch([NewScheduler(p) for p in ps]))
+    b = dz.sweep(cluster, cands, oracle.solve)
+    keys = ("decision", "candidates", "replacement", "replacementCapacityType")
+    assert [{k: c.get(k) for k in keys} for c in a] == [{k: c.get(k) for k in keys} for c in b]
