@@ -142,6 +142,17 @@ typedef struct {
   const int64_t* daemon_group_overhead;  /* n_groups * n_res, incl. pods = number of daemon pods */
   const uint8_t* daemon_group_nonempty;  /* n_groups : at least one daemon pod is compatible with the group */
 
+  /* ---- reserved offerings (capacity type "reserved", types.go:470-486) and the ReservationManager
+   *      (reservationmanager.go:28-110). Only consulted when ksolve_options.reserved_capacity is set. ---- */
+  uint32_t n_reservations;               /* distinct reservation ids, <= 64 */
+  const int32_t* reservation_capacity;   /* n_reservations : smallest ReservationCapacity over the id's offerings (reservationmanager.go:45-60) */
+  int32_t key_reservation_id;            /* key index of cloudprovider.ReservationIDLabel; value index == reservation index; -1 = none */
+  int32_t captype_reserved;              /* value index of "reserved" in key_capacity_type's dictionary, -1 = none */
+  const uint32_t* it_reserved_first;     /* n_its+1 : CSR over the AVAILABLE reserved offerings of each instance type */
+  const uint8_t* reserved_zone;          /* per reserved offering: zone value index */
+  const uint8_t* reserved_id;            /* per reserved offering: reservation index */
+  const double* reserved_price;          /* per reserved offering */
+
   /* ---- pods (one row per pod *variant*: row p < n_pods is the pod as submitted; rows >= n_pods are the
    *      pre-computed results of Preferences.Relax (preferences.go:38-57), chained through pod_next_variant) ---- */
   uint32_t n_pods;
@@ -179,7 +190,8 @@ typedef struct {
   uint32_t max_claims;             /* device capacity for in-flight NodeClaims; 0 = n_pods */
   int64_t max_steps;               /* stand-in for the ctx deadline: stop after this many queue pops, -1 = none */
   uint32_t device;                 /* HIP device ordinal */
-  uint32_t reserved;
+  uint32_t reserved_capacity;      /* FeatureGates.ReservedCapacity (nodeclaim.go:308) */
+  uint32_t reserved_offering_strict; /* DisableReservedCapacityFallback / ReservedOfferingModeStrict (scheduler.go:103, nodeclaim.go:339-348) */
 } ksolve_options;
 
 /* One NodeClaim of Results.NewNodeClaims (scheduler.go:282, nodeclaim.go:43-62), in the order the reference's
@@ -198,6 +210,7 @@ typedef struct {
   const uint8_t* min_values_relaxed;    /* n_claims : annotation nodeclaim-min-values-relaxed (scheduler.go:763-772) */
   const double* cheapest_price;         /* n_claims : cheapest compatible available offering over InstanceTypeOptions */
   const uint32_t* hostname_seq;         /* n_claims : N of hostname-placeholder-%04d (nodeclaim.go:93) */
+  const uint64_t* reserved_mask;        /* n_claims : reservation ids held by the claim (NodeClaim.reservedOfferings, nodeclaim.go:60) */
 } ksolve_claims;
 
 typedef struct {

@@ -40,6 +40,7 @@ struct Scratch {
   uint64_t tq[kMaxReqWords];        // next-domain set of one topology group (only the group key's words are used)
   int64_t gtot[kMaxRes];            // requests + the daemon overhead of the group being filtered
   uint64_t gin[kMaxItWords];        // the bin's instance types that belong to that group
+  int32_t resv_cap[64];             // ReservationManager.capacity (reservationmanager.go:31)
   int dg_first[33];   // daemon-overhead groups of each template (CSR)
   uint64_t t_owned[kMaxTopoWords], t_sel[kMaxTopoWords];   // topology groups the class being placed owns / is selected by
   uint64_t t_match[kMaxTopoWords];  // getMatchingTopologies (topology.go:561-574)
@@ -119,6 +120,7 @@ struct Engine {
   uint64_t& RAV(int l, int j) { return rav_[l][j]; }
 #endif
   bool regs_ok = false;
+  uint64_t pending_reserved = 0;    // offerings the last successful can_add wants reserved (offeringsToReserve, nodeclaim.go:303-350)
   bool min_values_best_effort = false;   // MinValuesPolicyBestEffort (scheduler.go:117)
   bool minv_lowered = false;        // the last can_add lowered a minValues requirement (BestEffort)
   bool cur_M = false;               // the class being placed has matching topology groups
@@ -772,6 +774,41 @@ struct Engine {
     W::sync();
     return ok;
   }
+  // Reservation ids of the available reserved offerings of the surviving instance types (sc.its) that are compatible
+  // with the requirements (reqs.IsCompatible(offering.Requirements, AllowUndefinedWellKnownLabels), nodeclaim.go:318-321).
+  // One lane per instance type.
+  KS_DEV uint64_t reservable_ids(const ReqRef& r) {
+    const Dict& d = P.dict;
+    const ProblemView& Pv = P;
+    if (Pv.ct_reserved < 0 || Pv.key_rid < 0) return 0;
+    if (d.key_ct >= 0 && bit(r.defined, d.key_ct) && !req_has(d, r, d.key_ct, d.key_word_off[d.key_ct], Pv.ct_reserved)) return 0;
+    uint32_t zones = 0;
+    if (d.key_zone >= 0 && bit(r.defined, d.key_zone)) { for (int z = 0; z < P.n_zones; ++z) if (req_has(d, r, d.key_zone, d.key_word_off[d.key_zone], z)) zones |= 1u << z; }
+    else zones = (1u << P.n_zones) - 1;
+    uint64_t ids_ok = 0;   // reservation ids the requirement on the reservation-id key admits
+    const bool rid_defined = bit(r.defined, Pv.key_rid);
+    if (!rid_defined) { if (bit(d.well_known_mask, Pv.key_rid)) ids_ok = ~0ull; }
+    else for (int i = 0; i < Pv.n_resv; ++i) if (req_has(d, r, Pv.key_rid, d.key_word_off[Pv.key_rid] + (uint32_t)(i >> 6), i & 63)) ids_ok |= 1ull << i;
+    if (!ids_ok) return 0;
+    const uint64_t* sits = sc.its;
+    return W::reduce_or(P.n_its, [&](int it) -> uint64_t {
+      if (!((sits[it >> 6] >> (it & 63)) & 1)) return 0;
+      uint64_t m = 0;
+      for (uint32_t o = Pv.it_resv_first[it]; o < Pv.it_resv_first[it + 1]; ++o) if ((zones >> Pv.resv_zone[o]) & 1) m |= 1ull << Pv.resv_id[o];
+      return m & ids_ok;
+    });
+  }
+  // NodeClaim.Add's reservation bookkeeping (nodeclaim.go:255-262): reserve what is new, release what is no longer held
+  KS_DEV void commit_reservations(int c, bool fresh) {
+    const uint64_t held = fresh ? 0ull : S.c_reserved[c];
+    const uint64_t now = pending_reserved;
+    if (W::leader()) {
+      for (uint64_t m = now & ~held; m; m &= m - 1) sc.resv_cap[ctz64(m)] -= 1;
+      for (uint64_t m = held & ~now; m; m &= m - 1) sc.resv_cap[ctz64(m)] += 1;
+    }
+    W::store(&S.c_reserved[c], now);
+    W::sync();
+  }
   // the merged requirement set `m` becomes the record being built (sc.out / sc.out_cold)
   KS_DEV ReqRef reqbuf_to_out(const ReqBuf& m) {
     uint64_t* o = sc.out;
@@ -857,6 +894,16 @@ struct Engine {
       bool lowered = false;
       if (!min_values_ok((int32_t*)(sc.out_cold + 2 * lay.nk), fresh && min_values_best_effort, &lowered)) { last_diag |= 64; return E_MIN_VALUES; }
       if (lowered) { minv_lowered = true; if (reqs_changed) *reqs_changed = true; }
+    }
+    if (P.reserved_on) {
+      // offeringsToReserve — nodeclaim.go:303-350
+      const uint64_t held = claim_id >= 0 ? S.c_reserved[claim_id] : 0ull;
+      const uint64_t cand = reservable_ids(merged);
+      uint64_t open_ids = 0;
+      for (int i = 0; i < P.n_resv; ++i) if (sc.resv_cap[i] > 0) open_ids |= 1ull << i;
+      const uint64_t out_ids = cand & (held | open_ids);               // ReservationManager.CanReserve (reservationmanager.go:62-72)
+      if (P.reserved_strict && out_ids == 0 && (cand != 0 || held != 0)) { topo_reached = true; return E_RESERVED; }
+      pending_reserved = out_ids;
     }
     if (its_changed) {
       const uint64_t* bi = bin + lay.c_its();
@@ -981,6 +1028,7 @@ struct Engine {
     }
     const bool out_cold = changed && (sc.out[ly.c_f1()] != 0 || (m2 & 2u));
     if (cur_rec) topo_record(sc.tmpl_taints[tmpl & 31u], out_ref(changed ? sc.out_cold : sc.claim_cold), 0, c);   // nodeclaim.go:252-253
+    if (P.reserved_on) commit_reservations(c, false);
     finish_record(c, sc.claim, its_changed, tmpl, np + 1, lo32(sc.claim[ly.c_meta2()]), m2, out_cold);
     order.increment(c);
     if (changed) reset_column(c);
@@ -1219,6 +1267,7 @@ struct Engine {
       bool changed = false;
       ctr.ref_bin_evaluations++;
       int rc = can_add(bin, tcold, true, first_err == 0, &changed, nullptr, -1);
+      if (rc == E_RESERVED) { last_diag = 0; return E_RESERVED; }   // voids the lower-weight templates (scheduler.go:736-751)
       if (rc != E_OK) { if (!first_err) { first_err = rc; first_diag = (rc == E_INSTANCE_TYPES || rc == E_MIN_VALUES) ? last_diag : 0; } continue; }
       if (n_claims >= S.max_claims || n_claims >= P.lds.order_cap) { W::store(S.status_out, 1); return -1; }
       int c = n_claims++;
@@ -1233,6 +1282,7 @@ struct Engine {
       W::sync();
       const bool cold = sc.out[ly.c_f1()] != 0 || (tm2 & 2u);
       if (cur_rec) topo_record(sc.tmpl_taints[t & 31], out_ref(sc.out_cold), 0, c);
+      if (P.reserved_on) commit_reservations(c, true);
       uint32_t relaxed = 0;
       if (minv_lowered) {
         // karpenter.sh/nodeclaim-min-values-relaxed — scheduler.go:763-772
@@ -1519,6 +1569,7 @@ struct Engine {
       W::for_n(T.words, [&](int w) { sc.t_active[w] = T.initially_active[w]; });
     }
     load_tables();
+    if (P.reserved_on) W::for_n(P.n_resv, [&](int i) { sc.resv_cap[i] = P.resv_cap0[i]; });
     prefilter_templates();
     const int np = P.n_pods;
     const uint32_t cap = (uint32_t)np + 1;

@@ -276,6 +276,11 @@ struct FinalizeArgs {
   uint64_t dg_nonempty;
   const uint64_t* t_its;     // [n_templates][it_words] prefiltered instance types: daemonOverheadGroups are built over them, in their order
   int64_t* daemon_requests;  // [n_claims][n_res]
+  // reserved offerings: a claim that holds reservations launches only into them (nodeclaim.go:391-403)
+  const uint64_t* c_reserved;    // [n_claims] or nullptr
+  const uint32_t* it_resv_first;
+  const uint8_t *resv_zone, *resv_id;
+  const double* resv_price;
 };
 // one thread per claim: min over InstanceTypeOptions of the cheapest available offering compatible with the claim's
 // requirements (the comparator key of OrderByPrice, types.go:336-355)
@@ -311,6 +316,15 @@ KS_FN void finalize_body(int c, const FinalizeArgs& a) {
         double p = a.it_off_price[(size_t)it * 64 + cell];
         if (p < best) best = p;
       }
+    }
+  }
+  if (a.c_reserved && a.c_reserved[c]) {
+    const uint64_t held = a.c_reserved[c];
+    best = 1.7976931348623157e308;
+    for (int w = 0; w < a.it_words; ++w) for (uint64_t m = its[w]; m; m &= m - 1) {
+      const int it = w * 64 + ctz64(m);
+      for (uint32_t o = a.it_resv_first[it]; o < a.it_resv_first[it + 1]; ++o)
+        if (((held >> a.resv_id[o]) & 1) && ((zones >> a.resv_zone[o]) & 1) && a.resv_price[o] < best) best = a.resv_price[o];
     }
   }
   a.cheapest[c] = best;

@@ -277,6 +277,21 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     P.dg_nonzero = nonzero; P.dg_nonempty = nonempty;
   }
 
+  {
+    // reserved offerings
+    P.n_resv = (int)d->n_reservations; P.key_rid = d->key_reservation_id; P.ct_reserved = d->captype_reserved;
+    P.reserved_strict = h->opts.reserved_offering_strict ? 1 : 0;
+    P.reserved_on = (h->opts.reserved_capacity && d->n_reservations > 0) ? 1 : 0;
+    if (d->n_reservations > 64) return fail(h, KSOLVE_ERR_UNSUPPORTED, "more than 64 capacity reservations");
+    if (P.reserved_on) {
+      if (!d->it_reserved_first || !d->reservation_capacity || d->key_reservation_id < 0 || d->captype_reserved < 0) return fail(h, KSOLVE_ERR_INVALID, "reserved offerings need it_reserved_first, reservation_capacity, key_reservation_id and captype_reserved");
+      const uint32_t no = d->it_reserved_first[d->n_its];
+      P.resv_cap0 = up(h, d->reservation_capacity, d->n_reservations);
+      P.it_resv_first = up(h, d->it_reserved_first, (size_t)d->n_its + 1);
+      P.resv_zone = up(h, d->reserved_zone, no); P.resv_id = up(h, d->reserved_id, no); P.resv_price = up(h, d->reserved_price, no);
+    }
+  }
+
   P.n_pods = d->n_pods; P.n_rows = d->n_pod_rows;
   P.row_next = up(h, d->pod_next_variant, d->n_pod_rows);
   P.pod_is_pending = up(h, d->pod_is_pending, d->n_pods);
@@ -345,6 +360,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   W.c_hot = dz<uint64_t>(h, (size_t)mc * lay.c_hot_words());
   W.c_cold = dz<uint64_t>(h, (size_t)mc * lay.cold_words());
   W.c_headroom = dz<int64_t>(h, (size_t)mc * d->n_res);
+  W.c_reserved = dz<uint64_t>(h, mc);
   W.o_key = dz<uint32_t>(h, mc); W.o_ord = dz<uint32_t>(h, mc); W.o_pos = dz<uint32_t>(h, mc);
   W.closed = dz<uint64_t>(h, h->claim_words);
   W.queue = dz<uint32_t>(h, (size_t)d->n_pods + 1); W.last_len = dz<uint32_t>(h, d->n_pods);
@@ -449,7 +465,7 @@ struct ResultsImpl {
   std::vector<int32_t> assign, tmpl;
   std::vector<uint8_t> err, diag, relaxed;
   std::vector<uint32_t> slot, npods, defined, complement, has_gte, has_lte, host_seq, ord;
-  std::vector<uint64_t> its, mask;
+  std::vector<uint64_t> its, mask, reserved;
   std::vector<int64_t> requests, gte, lte;
   std::vector<int32_t> minv;
   std::vector<double> cheapest;
@@ -559,7 +575,8 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   // ---- phase 5: finalize ----
   be_tic(h, T_FINALIZE);
   ks::FinalizeArgs F{P.dict, (int)h->n_its, (int)h->it_words, P.n_zones, P.n_cts, P.it_off_avail, P.it_off_price, W.c_hot, W.c_cold, P.lay, h->d_cheapest,
-                     P.dg_first, P.dg_ov, P.dg_its, P.dg_nonempty, W.t_its, h->d_daemon_requests};
+                     P.dg_first, P.dg_ov, P.dg_its, P.dg_nonempty, W.t_its, h->d_daemon_requests,
+                     P.reserved_on ? W.c_reserved : nullptr, P.it_resv_first, P.resv_zone, P.resv_id, P.resv_price};
   if (n_claims) be_launch_finalize(h, n_claims, F);
   be_toc(h, T_FINALIZE);
 
@@ -582,11 +599,14 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   std::vector<int32_t> minv((size_t)C * h->n_keys);
   std::vector<double> cheapest(C);
   std::vector<int64_t> daemon_req;
+  std::vector<uint64_t> reserved;
   std::vector<uint64_t> hot((size_t)C * ly.c_hot_words()), cold((size_t)C * ly.cold_words());
   if (C) {
     be_d2h(h, hot.data(), W.c_hot, hot.size() * 8);
     be_d2h(h, cold.data(), W.c_cold, cold.size() * 8);
     be_d2h(h, cheapest.data(), h->d_cheapest, (size_t)C * 8);
+    reserved.resize(C);
+    be_d2h(h, reserved.data(), W.c_reserved, (size_t)C * 8);
     daemon_req.resize((size_t)C * n_res);
     be_d2h(h, daemon_req.data(), h->d_daemon_requests, (size_t)C * n_res * 8);
     be_d2h(h, ord.data(), W.o_ord, (size_t)C * 4);
@@ -606,6 +626,19 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
     for (uint32_t r = 0; r < n_res; ++r) requests[(size_t)c * n_res + r] = (int64_t)hr[ly.c_total() + r] + daemon_req[(size_t)c * n_res + r];   // FinalizeScheduling, nodeclaim.go:405-408
     defined[c] = (uint32_t)hr[ly.c_f0()]; complement[c] = (uint32_t)(hr[ly.c_f0()] >> 32);
     has_gte[c] = (uint32_t)hr[ly.c_f1()]; has_lte[c] = (uint32_t)(hr[ly.c_f1()] >> 32);
+    if (P.reserved_on && reserved[c]) {
+      // FinalizeScheduling pins the claim to its reservations (nodeclaim.go:391-403): capacity-type = reserved,
+      // reservation-id In [held ids]
+      const uint32_t kc = (uint32_t)P.dict.key_ct, kr = (uint32_t)P.key_rid;
+      uint64_t* mk = mask.data() + (size_t)c * h->req_words;
+      for (uint32_t x = P.dict.key_word_off[kc]; x < P.dict.key_word_off[kc + 1]; ++x) mk[x] = 0;
+      mk[P.dict.key_word_off[kc] + (uint32_t)P.ct_reserved / 64] = 1ull << (P.ct_reserved % 64);
+      defined[c] |= 1u << kc; complement[c] &= ~(1u << kc); has_gte[c] &= ~(1u << kc); has_lte[c] &= ~(1u << kc);
+      const uint32_t rx = P.dict.key_word_off[kr];
+      if ((defined[c] >> kr) & 1) mk[rx] = ((complement[c] >> kr) & 1) ? (reserved[c] & ~mk[rx]) : (reserved[c] & mk[rx]);
+      else mk[rx] = reserved[c];
+      defined[c] |= 1u << kr; complement[c] &= ~(1u << kr);
+    }
     tmpl[c] = (int32_t)(uint32_t)hr[ly.c_meta()]; npods[c] = (uint32_t)(hr[ly.c_meta()] >> 32);
     host_seq[c] = (uint32_t)hr[ly.c_meta2()];
     const uint32_t fl = (uint32_t)(hr[ly.c_meta2()] >> 32);
@@ -629,6 +662,8 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   permute(im->tmpl, tmpl, 1); permute(im->npods, npods, 1); permute(im->its, its, h->it_words); permute(im->mask, mask, h->req_words);
   permute(im->defined, defined, 1); permute(im->complement, complement, 1); permute(im->has_gte, has_gte, 1); permute(im->has_lte, has_lte, 1);
   permute(im->gte, gte, h->n_keys); permute(im->lte, lte, h->n_keys); permute(im->minv, minv, h->n_keys);
+  if (reserved.empty()) reserved.assign(C, 0);
+  permute(im->reserved, reserved, 1);
   permute(im->requests, requests, n_res); permute(im->host_seq, host_seq, 1); permute(im->relaxed, relaxed, 1); permute(im->cheapest, cheapest, 1);
   for (uint32_t p = 0; p < n_pods; ++p) if (im->assign[p] >= 0) im->assign[p] = (int32_t)newidx[im->assign[p]];
   double cost = 0;
@@ -643,7 +678,7 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   cl.req_mask = im->mask.data(); cl.req_defined = im->defined.data(); cl.req_complement = im->complement.data();
   cl.req_has_gte = im->has_gte.data(); cl.req_has_lte = im->has_lte.data(); cl.req_gte = im->gte.data(); cl.req_lte = im->lte.data();
   cl.req_min_values = im->minv.data(); cl.min_values_relaxed = im->relaxed.data(); cl.cheapest_price = im->cheapest.data();
-  cl.hostname_seq = im->host_seq.data();
+  cl.hostname_seq = im->host_seq.data(); cl.reserved_mask = im->reserved.data();
   out->bin_evaluations = ctr.bin_evaluations; out->it_evaluations = ctr.it_evaluations; out->queue_pops = ctr.queue_pops;
   out->sorts = ctr.sorts; out->slow_sorts = ctr.slow_sorts; out->relaxations = ctr.relaxations;
   out->ref_bin_evaluations = ctr.ref_bin_evaluations;

@@ -140,6 +140,12 @@ struct ProblemView {
   const uint64_t* dg_its;        // [n_dg][it_words]
   uint64_t dg_nonzero;           // group has a non-zero overhead vector
   uint64_t dg_nonempty;          // group has at least one compatible daemon pod (addDaemonRequests, nodeclaim.go:353-377)
+  // reserved offerings + ReservationManager (reservationmanager.go:28-110); reserved_on = feature gate and any reservation
+  int reserved_on, reserved_strict, n_resv, key_rid, ct_reserved;
+  const int32_t* resv_cap0;      // [n_resv]
+  const uint32_t* it_resv_first; // [n_its+1]
+  const uint8_t *resv_zone, *resv_id;
+  const double* resv_price;
 
   int n_pods, n_rows;
   const int32_t* row_next;       // [n_rows] relaxation chain
@@ -180,6 +186,7 @@ struct Workspace {
   // claims (AoS by claim; see RecLayout)
   uint64_t* c_hot;               // [max_claims][c_hot_words]
   uint64_t* c_cold;              // [max_claims][cold_words]
+  uint64_t* c_reserved;          // [max_claims] reservation ids held by each claim
   int64_t* c_headroom;           // [n_res][max_claims] SoA copy of the records' headroom: lane-per-claim prefilter of the scan
   // order (pdq_emul.h): lives in LDS while it fits (LdsPlan.order_cap), these are the HBM spill arrays
   uint32_t *o_key, *o_ord, *o_pos;

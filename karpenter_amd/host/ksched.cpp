@@ -501,7 +501,7 @@ struct Session {
   std::vector<uint8_t> node_initialized;
   std::vector<std::pair<uint64_t, uint64_t>> group_of_pod;
   std::vector<i128> scale;
-  int n_pods = 0, n_rows = 0, n_its = 0, n_res = 0, it_words = 0;
+  int n_pods = 0, n_rows = 0, n_its = 0, n_res = 0, it_words = 0, k_rid = -1;
   std::string error_kind, error;
 };
 
@@ -523,7 +523,6 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     for (auto& k : root.at("wellKnownLabels").items()) fl.well_known.insert(k.s());
     const Value& opts = root.at("options");
     bool ignore_prefs = opts.at("preferencePolicy").s("Respect") == "Ignore";
-    if (opts.at("reservedCapacity").boolean_or(false)) throw Unsupported("reserved capacity is not solved on the device in this build");
 
     // ---- instance types ----
     const auto& its_json = root.at("instanceTypes").items();
@@ -539,23 +538,37 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     }
     // offering zones / capacity types first so their value indices are the offering cell coordinates
     std::vector<std::vector<Expr>> it_exprs(n_its);
-    struct Off { int zone, ct; double price; bool available; };
+    struct Off { int zone, ct; double price; bool available; int rid; };
     std::vector<std::vector<Off>> it_offs(n_its);
+    const char* kReservationID = "karpenter.sh/reservation-id";   // cloudprovider.ReservationIDLabel
+    int k_rid = -1;
+    std::vector<int32_t> resv_capacity;   // per reservation id: the most pessimistic ReservationCapacity (reservationmanager.go:45-60)
     for (int i = 0; i < n_its; ++i)
       for (auto& of : its_json[i].at("offerings").items()) {
-        std::string zone, ct;
+        std::string zone, ct, rid;
         for (auto& e : of.at("requirements").items()) {
           Expr x = parse_expr(e);
           if (x.op != "In" || x.values.size() != 1) throw Unsupported("offering requirements must be single-valued In");
           if (x.key == kZone) zone = x.values[0];
           else if (x.key == kCapacityType) ct = x.values[0];
-          else throw Unsupported("offering requirement on " + x.key + " (reserved offerings) is not solved on the device in this build");
+          else if (x.key == kReservationID) rid = x.values[0];
+          else throw Unsupported("offering requirement on " + x.key);
         }
         if (zone.empty() || ct.empty()) throw std::runtime_error("offering without zone/capacity-type");
-        if (ct == "reserved") throw Unsupported("reserved offerings are not solved on the device in this build");
         if (of.has("capacityOverride") || of.has("overheadOverride")) throw Unsupported("offering overrides");
-        it_offs[i].push_back({D.value(k_zone, zone), D.value(k_ct, ct), of.at("price").d(), of.at("available").boolean_or(true)});
+        int ridx = -1;
+        if (ct == "reserved") {
+          if (rid.empty()) throw std::runtime_error("reserved offering without a reservation id");
+          if (k_rid < 0) k_rid = D.key(kReservationID);
+          ridx = D.value(k_rid, rid);
+          const int cap = (int)of.at("reservationCapacity").i(0);
+          if (ridx >= (int)resv_capacity.size()) resv_capacity.resize(ridx + 1, INT32_MAX);
+          if (cap < resv_capacity[ridx]) resv_capacity[ridx] = cap;
+        } else if (!rid.empty()) throw Unsupported("reservation id on a non-reserved offering");
+        it_offs[i].push_back({D.value(k_zone, zone), D.value(k_ct, ct), of.at("price").d(), of.at("available").boolean_or(true), ridx});
       }
+    const int n_resv = (int)resv_capacity.size();
+    if (n_resv > 64) throw Unsupported("more than 64 capacity reservations");
     const int n_zones = (int)D.values[k_zone].size(), n_cts = (int)D.values[k_ct].size();
     if (n_zones > KSOLVE_MAX_ZONES || n_cts > KSOLVE_MAX_CAPTYPES) throw Unsupported("more than 16 offering zones or 4 capacity types");
     for (int i = 0; i < n_its; ++i) { it_exprs[i] = parse_exprs(its_json[i].at("requirements")); for (auto& e : it_exprs[i]) D.note(e); }
@@ -827,6 +840,14 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       for (auto& e : it_exprs[i]) { ks::ReqBuf one; fl.encode(e, one); ks::reqbuf_add(fl.kd, b, ks::reqbuf_ref_with_minv(one)); }
       it_reqs.put(i, b);
     }
+    std::vector<uint32_t> it_resv_first(n_its + 1, 0);
+    std::vector<uint8_t> resv_zone, resv_id;
+    std::vector<double> resv_price;
+    for (int i = 0; i < n_its; ++i) {
+      for (auto& o : it_offs[i]) if (o.rid >= 0 && o.available) { resv_zone.push_back((uint8_t)o.zone); resv_id.push_back((uint8_t)o.rid); resv_price.push_back(o.price); }
+      it_resv_first[i + 1] = (uint32_t)resv_zone.size();
+    }
+    if (resv_zone.empty()) { resv_zone.push_back(0); resv_id.push_back(0); resv_price.push_back(0); }
     // templates
     ReqTableBuilder tmpl_reqs;
     tmpl_reqs.init(n_templates, rw, nk);
@@ -1341,6 +1362,9 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     d.it_offering_avail = it_avail.data(); d.it_offering_price = it_price.data(); d.n_zones = (uint32_t)n_zones; d.n_captypes = (uint32_t)n_cts;
     d.n_templates = (uint32_t)n_templates; d.tmpl_reqs = tmpl_reqs.view(); d.tmpl_taints = tmpl_taints.data(); d.tmpl_its = tmpl_its.data();
     d.tmpl_limit_mask = tmpl_limit_mask.data(); d.tmpl_limits = tmpl_lim.data();
+    d.n_reservations = (uint32_t)n_resv; d.reservation_capacity = resv_capacity.data(); d.key_reservation_id = k_rid;
+    d.captype_reserved = D.value_index[k_ct].count("reserved") ? D.value_index[k_ct].at("reserved") : -1;
+    d.it_reserved_first = it_resv_first.data(); d.reserved_zone = resv_zone.data(); d.reserved_id = resv_id.data(); d.reserved_price = resv_price.data();
     if (!dg_first.empty()) { d.tmpl_daemon_first = dg_first.data(); d.daemon_group_its = dg_its.data(); d.daemon_group_overhead = dg_ov.data(); d.daemon_group_nonempty = dg_nonempty.data(); }
     d.n_pods = (uint32_t)n_pods; d.n_pod_rows = (uint32_t)n_rows; d.pod_requests = pod_requests.data();
     d.pod_reqs = pod_reqs.view(); d.pod_strict_reqs = pod_strict.view(); d.pod_tolerates = pod_tol.data(); d.pod_next_variant = pod_next.data();
@@ -1370,6 +1394,8 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     ko.max_claims = (uint32_t)opts.at("maxClaims").i(0);
     ko.max_steps = opts.at("maxSteps").i(-1);
     ko.device = (uint32_t)opts.at("device").i(0);
+    ko.reserved_capacity = opts.at("reservedCapacity").boolean_or(false) ? 1 : 0;
+    ko.reserved_offering_strict = opts.at("reservedOfferingMode").s("Fallback") == "Strict" ? 1 : 0;
 
     ksolve_status st = api.create(&d, &ko, &handle);
     if (st != KSOLVE_OK) {
@@ -1382,6 +1408,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     for (auto& n : nodes) { S->node_names.push_back(n.name); S->node_initialized.push_back(n.initialized ? 1 : 0); }
     S->uid_text = uid_text; S->group_of_pod = group_of_pod; S->res_names = res_names; S->scale = scale;
     for (int i = 0; i < n_its; ++i) S->it_names.push_back(its_json[i].at("name").s());
+    S->k_rid = k_rid;
     S->n_pods = n_pods; S->n_rows = n_rows; S->n_its = n_its; S->n_res = n_res; S->it_words = it_words;
     return S;
   } catch (const Unsupported& e) {
@@ -1524,7 +1551,11 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
         Value ann = Value::object();
         ann.set("karpenter.sh/nodeclaim-min-values-relaxed", Value::string(cl.min_values_relaxed[c] ? "true" : "false"));
         cj.set("annotations", ann);
-        cj.set("reservedOfferings", Value::array());
+        {
+          Value ro = Value::array();
+          if (cl.reserved_mask && S->k_rid >= 0) for (int i = 0; i < 64; ++i) if ((cl.reserved_mask[c] >> i) & 1) ro.push(Value::string(D.values[S->k_rid][i]));
+          cj.set("reservedOfferings", ro);
+        }
         cj.set("cheapestPrice", Value::number(cl.cheapest_price[c] < 1e300 ? cl.cheapest_price[c] : -1.0));
         claims.push(cj);
       }

@@ -171,11 +171,13 @@ def test_empty_and_degenerate_inputs(oracle, emu):
 
 
 def test_unsupported_is_loud_not_cpu(emu):
-    with pytest.raises(Unsupported):
-        NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], [fx.pod()], options={"reservedCapacity": True}), solver_lib=emu)
-    with pytest.raises(Unsupported):   # reserved offerings need the ReservationManager (reservationmanager.go), not on the device yet
+    with pytest.raises(Unsupported):   # namespaceSelector needs a namespace lister (topology.go:526-550)
+        term = fx.affinity_term(fx.ZONE, {"a": "b"})
+        term["namespaceSelector"] = {"matchLabels": {"team": "x"}}
+        NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], [fx.pod(pod_requirements=[term])]), solver_lib=emu)
+    with pytest.raises(Unsupported):   # hugepages change the allocatable memory per offering group (types.go:271-294)
         its = fx.fake_default_instance_types()
-        its[0]["offerings"].append(fx.offering("reserved", "test-zone-1", 0.01, reservation_id="r-1", reservation_capacity=2))
+        its[0]["capacity"]["hugepages-2Mi"] = "1Gi"
         NewScheduler(fx.problem(its, [fx.node_pool()], [fx.pod()]), solver_lib=emu)
 
 
@@ -283,6 +285,69 @@ def test_min_values(oracle, emu):
     pods = [fx.pod(requests={"cpu": f"{c}m", "memory": f"{m}Mi"}) for c in (500, 4000, 30000, 120000) for m in (512, 8192, 65536) for _ in range(3)]
     for policy in ("Strict", "BestEffort"):
         check(oracle, emu, fx.problem(kw, [np_], pods, well_known=fx.KWOK_WELL_KNOWN, options={"minValuesPolicy": policy}))
+
+
+def reserved_types(capacity=1):
+    """suite_test.go "Reserved Instance Types" BeforeEach (:4677-4714): medium and small carry a reserved offering each."""
+    its = [fx.fake_instance_type(n, resources={"cpu": str(c), "memory": f"{c}Gi"}) for n, c in (("large-instance-type", 6), ("medium-instance-type", 3), ("small-instance-type", 2))]
+    for it in its[1:]:
+        for r in it["requirements"]:
+            if r["key"] == fx.CAPACITY_TYPE:
+                r["values"].append("reserved")
+        it["offerings"].append(fx.offering("reserved", "test-zone-1", fx.fake_price(it["capacity"]) / 100000.0, reservation_id="r-" + it["name"], reservation_capacity=capacity))
+    return its
+
+
+def test_reserved_offerings(oracle, emu):
+    strict = {"reservedCapacity": True, "reservedOfferingMode": "Strict"}
+    fallback = {"reservedCapacity": True, "reservedOfferingMode": "Fallback"}
+    pods = lambda n, cpu="1800m": [fx.pod(requests={"cpu": cpu}) for _ in range(n)]
+    # suite_test.go:4715-4765: the first claim reserves both offerings, so only one pod schedules per loop
+    got, _ = check(oracle, emu, fx.problem(reserved_types(), [fx.node_pool()], pods(3), options=strict))
+    assert len(got["newNodeClaims"]) == 1 and len(got["newNodeClaims"][0]["pods"]) == 1
+    assert sorted(e["code"] for e in got["podErrors"].values()) == [8, 8]
+    claim = got["newNodeClaims"][0]
+    assert sorted(claim["reservedOfferings"]) == ["r-medium-instance-type", "r-small-instance-type"]
+    assert [q["values"] for q in claim["requirements"] if q["key"] == fx.CAPACITY_TYPE] == [["reserved"]]
+    # Fallback mode (the consolidation simulator's, helpers.go:106-112) may use on-demand / spot instead
+    got, _ = check(oracle, emu, fx.problem(reserved_types(), [fx.node_pool()], pods(3), options=fallback))
+    assert not got["podErrors"]
+    # feature gate off: reserved offerings are ordinary offerings
+    check(oracle, emu, fx.problem(reserved_types(), [fx.node_pool()], pods(3)))
+    # more capacity, more pods, several NodePools sharing the reservations (suite_test.go:4767-4822)
+    for opts in (strict, fallback):
+        check(oracle, emu, fx.problem(reserved_types(3), [fx.node_pool("np-1", weight=2), fx.node_pool("np-2")], pods(7, "900m") + pods(4, "2500m"), options=opts))
+        sel = [fx.pod(requests={"cpu": "1"}, node_selector={fx.CAPACITY_TYPE: ct}) for ct in ("reserved", "reserved", "on-demand", "spot", "reserved")]
+        check(oracle, emu, fx.problem(reserved_types(2), [fx.node_pool()], sel + pods(5, "600m"), options=opts))
+        check(oracle, emu, fx.problem(reserved_types(2), [fx.node_pool()], [fx.pod(requests={"cpu": "500m"}, node_selector={fx.ZONE: z}) for z in ("test-zone-1", "test-zone-2", "test-zone-1", "test-zone-3")], options=opts))
+
+
+def test_reserved_offerings_fuzz(oracle, emu):
+    rng = random.Random(4242)
+    for trial in range(25):
+        its = fx.fake_instance_types(rng.choice([4, 8, 12]))
+        n_res = rng.randrange(1, 5)
+        for i in range(n_res):
+            for it in rng.sample(its, rng.randrange(1, 3)):
+                for r in it["requirements"]:
+                    if r["key"] == fx.CAPACITY_TYPE and "reserved" not in r["values"]:
+                        r["values"].append("reserved")
+                it["offerings"].append(fx.offering("reserved", rng.choice(["test-zone-1", "test-zone-2"]), 0.001 * (i + 1), reservation_id=f"cr-{i}",
+                                                   reservation_capacity=rng.randrange(1, 4), available=rng.random() < 0.9))
+        pods = []
+        for _ in range(rng.randrange(5, 40)):
+            kw = dict(requests={"cpu": f"{rng.choice([250, 500, 1000, 2000])}m", "memory": f"{rng.choice([128, 512, 1024])}Mi"})
+            pick = rng.random()
+            if pick < 0.2:
+                kw["node_selector"] = {fx.CAPACITY_TYPE: rng.choice(["reserved", "on-demand", "spot"])}
+            elif pick < 0.35:
+                kw["node_selector"] = {fx.ZONE: rng.choice(["test-zone-1", "test-zone-2", "test-zone-3"])}
+            elif pick < 0.45:
+                kw["node_preferences"] = [fx.req(fx.CAPACITY_TYPE, "In", "reserved")]
+            pods.append(fx.pod(**kw))
+        opts = {"reservedCapacity": True, "reservedOfferingMode": rng.choice(["Strict", "Fallback"])}
+        pools = [fx.node_pool()] if trial % 3 else [fx.node_pool("a", weight=5, limits={"cpu": "20"}), fx.node_pool("b")]
+        check(oracle, emu, fx.problem(its, pools, pods, options=opts))
 
 
 def test_random_problems_fuzz(oracle, emu):

@@ -193,3 +193,28 @@ def test_benchmark_diverse_pods_all_schedule(oracle):
     pods += [fx.pod(labels={"app": "nginx"}, requests=res(), pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, {"app": "nginx"})]) for _ in range(60)]
     r = oracle.solve(fx.problem(fx.fake_instance_types(400), [fx.node_pool(limits={"cpu": "10000000", "memory": "10000000Gi"})], pods))
     assert not r["podErrors"] and len(r["newNodeClaims"]) >= 60
+
+
+def test_reserved_instance_types(oracle):
+    # suite_test.go:4715-4765: a claim compatible with both reserved types reserves both, so one pod schedules per loop;
+    # once both reservations are used up the last pod falls back to on-demand/spot
+    def types(cap_medium, cap_small):
+        its = [fx.fake_instance_type(n, resources={"cpu": str(c), "memory": f"{c}Gi"}) for n, c in (("large-instance-type", 6), ("medium-instance-type", 3), ("small-instance-type", 2))]
+        for it, cap in ((its[1], cap_medium), (its[2], cap_small)):
+            for r in it["requirements"]:
+                if r["key"] == fx.CAPACITY_TYPE:
+                    r["values"].append("reserved")
+            it["offerings"].append(fx.offering("reserved", "test-zone-1", fx.fake_price(it["capacity"]) / 100000.0, reservation_id="r-" + it["name"],
+                                               reservation_capacity=max(cap, 0), available=cap > 0))
+        return its
+    opts = {"reservedCapacity": True, "reservedOfferingMode": "Strict"}
+    pods = [fx.pod(requests={"cpu": "1800m"}) for _ in range(3)]
+    r = oracle.solve(fx.problem(types(1, 1), [fx.node_pool()], pods, options=opts))
+    assert len(r["newNodeClaims"]) == 1 and len(r["newNodeClaims"][0]["pods"]) == 1 and len(r["podErrors"]) == 2
+    assert sorted(r["newNodeClaims"][0]["reservedOfferings"]) == ["r-medium-instance-type", "r-small-instance-type"]
+    # second loop: the small reservation is gone (unavailable), the claim reserves the medium one
+    r = oracle.solve(fx.problem(types(1, 0), [fx.node_pool()], pods[1:], options=opts))
+    assert len(r["newNodeClaims"]) == 1 and r["newNodeClaims"][0]["reservedOfferings"] == ["r-medium-instance-type"] and len(r["podErrors"]) == 1
+    # third loop: no reservation left, falls back to on-demand / spot
+    r = oracle.solve(fx.problem(types(0, 0), [fx.node_pool()], pods[2:], options=opts))
+    assert len(r["newNodeClaims"]) == 1 and not r["newNodeClaims"][0]["reservedOfferings"] and not r["podErrors"]
