@@ -190,3 +190,28 @@ def test_batched_launch_equals_individual_solves(oracle):
     b = dz.sweep(cluster, cands, oracle.solve)
     keys = ("decision", "candidates", "replacement", "replacementCapacityType")
     assert [{k: c.get(k) for k in keys} for c in a] == [{k: c.get(k) for k in keys} for c in b]
+
+
+def test_daemons_min_values_reservations(oracle):
+    """SURVEY §8 rows a17 (daemon overhead), a11/a14 (minValues), a18 (reservations) through the HIP path."""
+    import random
+    from test_device_algorithm import _mv_types, reserved_types, sorted_its
+    its = fx.fake_default_instance_types()
+    ds = [fx.pod(requests={"cpu": "1", "memory": "1Gi"}), fx.pod(requests={"cpu": "2"}, node_selector={fx.ARCH: "arm64"})]
+    pods = [fx.pod(requests={"cpu": f"{c}m"}) for c in (500, 900, 1500, 2500, 3500) for _ in range(4)] + [fx.pod(node_selector={fx.ARCH: "arm64"}, requests={"cpu": "3"})]
+    prob = fx.problem(its, [fx.node_pool()], pods, daemonset_pods=ds)
+    parity.assert_same_results(sorted_its(NewScheduler(prob).Solve()), sorted_its(oracle.solve(prob)))
+    two = [fx.pod(requests={"cpu": "0.9", "memory": "0.9Gi"}) for _ in range(2)]
+    for mv, policy in ((2, "Strict"), (3, "Strict"), (3, "BestEffort")):
+        pool = fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "In", "instance-type-1", "instance-type-2", min_values=mv)])
+        check(oracle, fx.problem(_mv_types(), [pool], two, options={"minValuesPolicy": policy}))
+    kw = fx.kwok_catalog(144)
+    np_ = fx.node_pool(requirements=[fx.req("karpenter.kwok.sh/instance-family", "Exists", min_values=3), fx.req(fx.INSTANCE_TYPE, "Exists", min_values=10)])
+    np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    pods = [fx.pod(requests={"cpu": f"{c}m", "memory": f"{m}Mi"}) for c in (500, 4000, 30000, 120000) for m in (512, 8192, 65536) for _ in range(3)]
+    check(oracle, fx.problem(kw, [np_], pods, well_known=fx.KWOK_WELL_KNOWN))
+    rng = random.Random(5)
+    for mode in ("Strict", "Fallback"):
+        pods = [fx.pod(requests={"cpu": f"{rng.choice([300, 900, 1800, 2500])}m"}, node_selector=rng.choice([None, None, {fx.CAPACITY_TYPE: "reserved"}, {fx.ZONE: "test-zone-1"}])) for _ in range(25)]
+        got, _ = check(oracle, fx.problem(reserved_types(2) + fx.fake_instance_types(4), [fx.node_pool()], pods, options={"reservedCapacity": True, "reservedOfferingMode": mode}))
+        assert any(c["reservedOfferings"] for c in got["newNodeClaims"])
