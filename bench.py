@@ -126,6 +126,16 @@ def main():
     pack_ms = sum(t["pack_kernel_ms"] for t in timings) / len(timings)
     cls_ms = sum(t["classify_ms"] for t in timings) / len(timings)
     achieved = abytes / (pack_ms * 1e-3) / 1e9
+    traffic = None
+    try:
+        # HBM bytes of one ksolve_pack launch from the TCC counters (rocprofv3 --pmc, separate passes; scripts/gpu_pmc.sh).
+        # Collected on this workload in its own profiling run and committed under profiles/; not measurable from inside.
+        with open(os.path.join(ROOT, "profiles", "round1", "pmc_pack_traffic.json")) as f:
+            pmc = json.load(f)
+        if args.pods == 1_000_000 and args.types == 500:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
     stream_bytes = c["rows"] * rec["B_pod"]
     out = {
         "metric": "pods scheduled/sec (Solve())", "value": value, "unit": "pods/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -134,8 +144,8 @@ def main():
                    "pods_per_gpu": args.pods, "instance_types": args.types, "sharding": "one independent scheduling problem per GPU" if world > 1 else "single problem"},
         "packing": {"node_claims": claims, "packing_cost_per_hour": cost, "pods_scheduled": scheduled},
         "roofline": {"kernel": "ksolve_pack", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes": abytes, "avg_kernel_ms": pack_ms, "records": rec,
-                     "note": "serial first-fit chain: latency-bound, one wavefront per problem; V = referenceBinEvaluations"},
+                     "traffic": traffic, "algorithmic_bytes": abytes, "avg_kernel_ms": pack_ms, "records": rec,
+                     "note": "serial first-fit chain: latency-bound, one wavefront per problem; V = referenceBinEvaluations; traffic = 2*FETCH_SIZE + WRITE_SIZE of one launch (profiles/round1/pmc_pack_traffic.json): the working set stays in L2/Infinity Cache and exact pruning evaluates 1.1 of the reference's ~1009 bins per pod"},
         "roofline_stream": {"kernel": "ksolve_row_hash+verify+class (pod classing)", "bound": "hbm", "bytes": stream_bytes, "avg_ms": cls_ms,
                             "achieved": stream_bytes / (cls_ms * 1e-3) / 1e9 if cls_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s"},
         "phases_ms": {k: sum(t[k] for t in timings) / len(timings) for k in ("pack_kernel_ms", "classify_ms", "sort_ms", "it_index_ms")},
