@@ -836,6 +836,8 @@ struct Engine {
     const int64_t* head = (const int64_t*)(bin + lay.c_head());
     const int64_t* tot = (const int64_t*)(bin + lay.c_total());
     if (W::ballot([&](int l) { return l < nr && req[l] > head[l]; })) return E_INSTANCE_TYPES;   // no remaining instance type can hold it
+    const bool bin_minv = (hi32(bin[lay.c_meta2()]) & 2u) != 0, cls_minv = (lo32(sc.cls[lay.k_meta()]) & 1u) != 0;
+    const bool slow = bin[lay.c_f1()] != 0 || sc.cls[lay.k_f1()] != 0 || cls_minv || lay.rw > 64;
     uint32_t kdef = lo32(sc.cls[lay.k_f0()]);
     int hn = d.key_hostname;
     if (hn >= 0 && ((kdef >> hn) & 1)) {
@@ -846,8 +848,6 @@ struct Engine {
       if (!((kc >> hn) & 1) || (((lo32(kf1) | hi32(kf1)) >> hn) & 1)) return E_INCOMPATIBLE;
       kdef &= ~(1u << hn);
     }
-    const bool bin_minv = (hi32(bin[lay.c_meta2()]) & 2u) != 0, cls_minv = (lo32(sc.cls[lay.k_meta()]) & 1u) != 0;
-    const bool slow = bin[lay.c_f1()] != 0 || sc.cls[lay.k_f1()] != 0 || cls_minv || lay.rw > 64;
     bool changed = false;
     ReqRef merged;
     unsigned long long tb = W::clock();
@@ -1291,6 +1291,7 @@ struct Engine {
         for (int k = 0; k < ly.nk; ++k) if (ov_[k] >= 0 && nv[k] >= 0 && nv[k] < ov_[k]) relaxed = 1;
       }
       finish_record(c, bin, true, (uint32_t)t, 1u, host_seq, (tm2 & 2u) | relaxed, cold);
+
       order.append(c);
       if (lm) {
         // subtractMax — scheduler.go:1049-1066 : remaining -= max capacity over the claim's instance types
@@ -1446,6 +1447,7 @@ struct Engine {
     load_words(sc.cls, P.cls_hot + (size_t)k * hw, hw);
     if (sc.cls[lay.k_f1()] != 0 || (lo32(sc.cls[lay.k_meta()]) & 1u)) load_words(sc.cls_cold, P.cls_cold + (size_t)k * lay.cold_words(), lay.cold_words());
     cur_class = k;
+
     if (P.topo.n_groups) {
       const TopoView& T = P.topo;
       const uint64_t* ct = T.cls_topo + (size_t)k * 2 * T.words;

@@ -120,7 +120,14 @@ struct Wave {
     if (lane() == 0) *p = v;
   }
   KS_DEV static bool leader() { return lane() == 0; }
+  // Shader clock for the per-phase counters of a profiling build (-DKSOLVE_PHASE_TIMERS, scripts/gpu_quick.sh). The
+  // product build compiles the timers out: 24 live 64-bit accumulators and an s_memtime + s_waitcnt per phase boundary
+  // cost a single wavefront ~10% and a lot of register pressure.
+#ifdef KSOLVE_PHASE_TIMERS
   KS_DEV static unsigned long long clock() { return __builtin_readcyclecounter(); }
+#else
+  KS_DEV static unsigned long long clock() { return 0ull; }
+#endif
   // min over the 64 lanes of a u32 with DPP row operations (no LDS traffic): quad swaps, row rotates, row broadcasts;
   // the full result lands in lane 63.
   KS_DEV static uint32_t min_u32(uint32_t v) {
