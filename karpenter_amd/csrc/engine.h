@@ -90,7 +90,9 @@ struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host b
   }
 };
 
-template <class W>
+// FULL = false compiles the engine for problems without topology groups, existing nodes, daemonset overhead, minValues
+// and reservations (C1/C2-shaped provisioning batches): those code paths and their live state drop out of the kernel.
+template <class W, bool FULL = true>
 struct Engine {
   const ProblemView& P;
   Workspace& S;
@@ -191,7 +193,7 @@ struct Engine {
     W::for_n(Pv.n_templates + 1, [&](int t) { sc.dg_first[t] = Pv.dg_first[t]; });
     W::for_n(Pv.n_dg * nr, [&](int i) { Lt.dg_ov[i] = Pv.dg_ov[i]; });
     W::for_n(Pv.n_dg * iw, [&](int i) { Lt.dg_its[i] = Pv.dg_its[i]; });
-    regs_ok = iw <= kRegIw && nr <= kRegNr;
+    regs_ok = !FULL || (iw <= kRegIw && nr <= kRegNr);   // lite problems fit the register tables by definition
     if (regs_ok) {
       W::ballot([&](int l) {
 #pragma unroll
@@ -290,11 +292,11 @@ struct Engine {
     }
     FilterDiagAcc acc;
     const int nr = P.n_res, iw = P.it_words;
-    const int g0 = tmpl < 0 ? 0 : sc.dg_first[tmpl], g1 = tmpl < 0 ? 1 : sc.dg_first[tmpl + 1];
+    const int g0 = (!FULL || tmpl < 0) ? 0 : sc.dg_first[tmpl], g1 = (!FULL || tmpl < 0) ? 1 : sc.dg_first[tmpl + 1];
     bool any;
-    if (g1 - g0 == 1) {
+    if (!FULL || g1 - g0 == 1) {
       const int64_t* tot = total;
-      if (tmpl >= 0 && ((P.dg_nonzero >> g0) & 1)) {
+      if (FULL && tmpl >= 0 && ((P.dg_nonzero >> g0) & 1)) {
         const int64_t* ov = L.dg_ov + (size_t)g0 * nr;
         int64_t* gt = sc.gtot;
         W::for_n(nr, [&](int r) { gt[r] = total[r] + ov[r]; });
@@ -836,8 +838,8 @@ struct Engine {
     const int64_t* head = (const int64_t*)(bin + lay.c_head());
     const int64_t* tot = (const int64_t*)(bin + lay.c_total());
     if (W::ballot([&](int l) { return l < nr && req[l] > head[l]; })) return E_INSTANCE_TYPES;   // no remaining instance type can hold it
-    const bool bin_minv = (hi32(bin[lay.c_meta2()]) & 2u) != 0, cls_minv = (lo32(sc.cls[lay.k_meta()]) & 1u) != 0;
-    const bool slow = bin[lay.c_f1()] != 0 || sc.cls[lay.k_f1()] != 0 || cls_minv || lay.rw > 64;
+    const bool bin_minv = FULL && (hi32(bin[lay.c_meta2()]) & 2u) != 0, cls_minv = FULL && (lo32(sc.cls[lay.k_meta()]) & 1u) != 0;
+    const bool slow = FULL && (bin[lay.c_f1()] != 0 || sc.cls[lay.k_f1()] != 0 || cls_minv || lay.rw > 64);   // lite: no bounds anywhere, rw <= 64
     uint32_t kdef = lo32(sc.cls[lay.k_f0()]);
     int hn = d.key_hostname;
     if (hn >= 0 && ((kdef >> hn) & 1)) {
@@ -869,7 +871,7 @@ struct Engine {
       changed = reqbuf_add(d, sc.merged, q);
       merged = reqbuf_to_out(sc.merged);
     }
-    if (cur_M) {
+    if (FULL && cur_M) {
       // topology: nodeclaim.go:195-208
       topo_reached = true;
       bool tchanged = false;
@@ -895,7 +897,7 @@ struct Engine {
       if (!min_values_ok((int32_t*)(sc.out_cold + 2 * lay.nk), fresh && min_values_best_effort, &lowered)) { last_diag |= 64; return E_MIN_VALUES; }
       if (lowered) { minv_lowered = true; if (reqs_changed) *reqs_changed = true; }
     }
-    if (P.reserved_on) {
+    if (FULL && P.reserved_on) {
       // offeringsToReserve — nodeclaim.go:303-350
       const uint64_t held = claim_id >= 0 ? S.c_reserved[claim_id] : 0ull;
       const uint64_t cand = reservable_ids(merged);
@@ -922,8 +924,8 @@ struct Engine {
     const RecLayout ly = lay;
     const LdsTables& Lt = L;
     const int64_t* ntot = sc.total;
-    const int hg0 = sc.dg_first[tmpl & 31u], hg1 = sc.dg_first[(tmpl & 31u) + 1];
-    if (recompute_head && hg1 - hg0 > 1) {
+    const int hg0 = FULL ? sc.dg_first[tmpl & 31u] : 0, hg1 = FULL ? sc.dg_first[(tmpl & 31u) + 1] : 1;
+    if (FULL && recompute_head && hg1 - hg0 > 1) {
       // several daemon-overhead groups: headroom = max over groups of (max allocatable in the group - its overhead) - total
       for (int r = 0; r < nr; ++r) {
         int64_t best = INT64_MIN;
@@ -948,13 +950,13 @@ struct Engine {
           for (int j = 0; j < kRegIw; ++j) { const int64_t a = ((sw[j] >> l) & 1) ? RA(l, j, r) : INT64_MIN; m = a > m ? a : m; }
           return m;
         });
-        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(mx - Lt.dg_ov[(size_t)hg0 * nr + r] - ntot[r]);
+        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(mx - (FULL ? Lt.dg_ov[(size_t)hg0 * nr + r] : 0) - ntot[r]);
       }
     } else if (recompute_head) {
       // headroom = max allocatable over the surviving instance types - total
       for (int r = 0; r < nr; ++r) {
         int64_t mx = W::reduce_max_i64(np, [&](int it) { return ((sits[it >> 6] >> (it & 63)) & 1) ? Lt.alloc[(size_t)r * np + it] : INT64_MIN; });
-        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(mx - Lt.dg_ov[(size_t)hg0 * nr + r] - ntot[r]);
+        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(mx - (FULL ? Lt.dg_ov[(size_t)hg0 * nr + r] : 0) - ntot[r]);
       }
     } else {
       const int64_t* bh = (const int64_t*)(bin + ly.c_head());
@@ -1010,7 +1012,7 @@ struct Engine {
     else load_words(sc.claim, S.c_hot + (size_t)c * ly.c_hot_words(), ly.c_hot_words());
     const uint64_t f1 = sc.claim[ly.c_f1()];
     const uint32_t m2 = hi32(sc.claim[ly.c_meta2()]);
-    if (f1 != 0 || (m2 & 2u)) load_words(sc.claim_cold, S.c_cold + (size_t)c * ly.cold_words(), ly.cold_words());
+    if (FULL && (f1 != 0 || (m2 & 2u))) load_words(sc.claim_cold, S.c_cold + (size_t)c * ly.cold_words(), ly.cold_words());
     bool changed = false, its_changed = false;
     unsigned long long t1 = W::clock();
     ctr.cycles[4] += t1 - t0;
@@ -1026,9 +1028,9 @@ struct Engine {
       const uint64_t* b = sc.claim;
       W::for_n(ly.rw + 2, [&](int w) { int i = w < ly.rw ? w : ly.c_f0() + (w - ly.rw); o[i] = b[i]; });
     }
-    const bool out_cold = changed && (sc.out[ly.c_f1()] != 0 || (m2 & 2u));
-    if (cur_rec) topo_record(sc.tmpl_taints[tmpl & 31u], out_ref(changed ? sc.out_cold : sc.claim_cold), 0, c);   // nodeclaim.go:252-253
-    if (P.reserved_on) commit_reservations(c, false);
+    const bool out_cold = FULL && changed && (sc.out[ly.c_f1()] != 0 || (m2 & 2u));
+    if (FULL && cur_rec) topo_record(sc.tmpl_taints[tmpl & 31u], out_ref(changed ? sc.out_cold : sc.claim_cold), 0, c);   // nodeclaim.go:252-253
+    if (FULL && P.reserved_on) commit_reservations(c, false);
     finish_record(c, sc.claim, its_changed, tmpl, np + 1, lo32(sc.claim[ly.c_meta2()]), m2, out_cold);
     order.increment(c);
     if (changed) reset_column(c);
@@ -1039,7 +1041,7 @@ struct Engine {
   KS_DEV bool scan_inflight(int k, int pod) {
     if (n_claims == 0) return false;
     const int words = (n_claims + 63) >> 6;
-    if (words > 128) return scan_inflight_walk(k, pod);
+    // n_claims <= LdsPlan::order_cap <= 8192, so the live set always fits two words per lane
     uint64_t* drow = S.dead + (size_t)k * S.claim_words;
     const uint64_t* closed = L.closed;
     const int nc = n_claims;
@@ -1061,7 +1063,7 @@ struct Engine {
     });
     W::sync();
     if (!any) return false;
-    if (cur_M) {
+    if (FULL && cur_M) {
       // Hostname spread / anti-affinity groups of the class: a claim whose per-claim counter already rules it out
       // (topologygroup.go:240-247,409-414) cannot pass CanAdd, whatever else holds. One lane per claim, counters coalesced.
       const TopoView& T = P.topo;
@@ -1145,7 +1147,7 @@ struct Engine {
           const uint64_t live = stage[l] & ~(1ull << (c & 63));
           if (try_claim(k, c, pod) == E_OK) return true;
           unsigned long long tf = W::clock();
-          if (!cur_M) W::store(&drow[l], (uint64_t)(~live & valid));
+          if (!FULL || !cur_M) W::store(&drow[l], (uint64_t)(~live & valid));
           else if (!topo_reached) W::store(&drow[l], (uint64_t)(drow[l] | (1ull << (c & 63))));
           W::store(&stage[l], live);
           W::sync();
@@ -1187,7 +1189,7 @@ struct Engine {
           // the class's dead word becomes: everything not live any more (closed claims may be recorded as dead too —
           // both are permanent until the column is reset), never touching bits of claims that do not exist yet. Classes
           // under topology constraints only record the failures that did not depend on domain counters.
-          if (!cur_M) W::store(&drow[l], (uint64_t)(~live & valid));
+          if (!FULL || !cur_M) W::store(&drow[l], (uint64_t)(~live & valid));
           else if (!topo_reached) W::store(&drow[l], (uint64_t)(drow[l] | (1ull << (c & 63))));
           W::store(&stage[l], live);
           W::sync();
@@ -1197,32 +1199,6 @@ struct Engine {
     }
     return false;
   }
-  // Ordered walk (more than 4096 claims with live ones in several blocks, or a class seen for the first time with very
-  // many open bins): 64 positions per step, ballot the live ones and probe them lowest position first.
-  KS_DEV bool scan_inflight_walk(int k, int pod) {
-    ctr.walk_scans++;
-    uint64_t* drow = S.dead + (size_t)k * S.claim_words;
-    const uint64_t* closed = L.closed;
-    const int nc = n_claims;
-    for (int base = 0; base < nc; base += 64) {
-      const KS_LDS uint32_t* ord = order.ord;
-      uint64_t m = W::ballot([&](int l) {
-        int i = base + l;
-        if (i >= nc) return false;
-        uint32_t c = ord[i];
-        return !(((drow[c >> 6] | closed[c >> 6]) >> (c & 63)) & 1);
-      });
-      while (m) {
-        int l = ctz64(m); m &= m - 1;
-        int c = (int)order.ord[base + l];
-        if (try_claim(k, c, pod) == E_OK) return true;
-        if (!topo_reached) W::store(&drow[c >> 6], (uint64_t)(drow[c >> 6] | (1ull << (c & 63))));
-        W::sync();
-      }
-    }
-    return false;
-  }
-
   // ---- new claim: addToNewNodeClaim (scheduler.go:695-790) --------------------------------------------------
   KS_DEV int add_to_new_claim(int k, int pod) {
     const int nr = lay.nr, iw = lay.iw, n_its = P.n_its;
@@ -1281,8 +1257,8 @@ struct Engine {
       }
       W::sync();
       const bool cold = sc.out[ly.c_f1()] != 0 || (tm2 & 2u);
-      if (cur_rec) topo_record(sc.tmpl_taints[t & 31], out_ref(sc.out_cold), 0, c);
-      if (P.reserved_on) commit_reservations(c, true);
+      if (FULL && cur_rec) topo_record(sc.tmpl_taints[t & 31], out_ref(sc.out_cold), 0, c);
+      if (FULL && P.reserved_on) commit_reservations(c, true);
       uint32_t relaxed = 0;
       if (minv_lowered) {
         // karpenter.sh/nodeclaim-min-values-relaxed — scheduler.go:763-772
@@ -1445,7 +1421,7 @@ struct Engine {
   KS_DEV void fetch_class(int k) {
     const int hw = lay.k_hot_words();
     load_words(sc.cls, P.cls_hot + (size_t)k * hw, hw);
-    if (sc.cls[lay.k_f1()] != 0 || (lo32(sc.cls[lay.k_meta()]) & 1u)) load_words(sc.cls_cold, P.cls_cold + (size_t)k * lay.cold_words(), lay.cold_words());
+    if (FULL && (sc.cls[lay.k_f1()] != 0 || (lo32(sc.cls[lay.k_meta()]) & 1u))) load_words(sc.cls_cold, P.cls_cold + (size_t)k * lay.cold_words(), lay.cold_words());
     cur_class = k;
 
     if (P.topo.n_groups) {
@@ -1469,7 +1445,7 @@ struct Engine {
 
   // add — scheduler.go:582-612
   KS_DEV int add_class(int k, int pod) {
-    if (add_to_existing(k, pod)) return E_OK;          // scheduler.go:594
+    if (FULL && add_to_existing(k, pod)) return E_OK;  // scheduler.go:594
     ctr.sorts++;
     unsigned long long t0 = W::clock();
     order.sort();                                      // scheduler.go:598
@@ -1532,7 +1508,7 @@ struct Engine {
       W::sync();
       ReqRef rr = claim_ref(rec, cold);
       bool any = filter_instance_types(P.tmpl_its + (size_t)t * iw, sc.total, true, rr, false, -1);
-      if (any && has_minv) {
+      if (FULL && any && has_minv) {
         // scheduler.go:159: the prefilter applies minValues too; BestEffort keeps the template without touching its requirements
         int32_t* tmp = (int32_t*)(sc.out_cold + 2 * ly.nk);
         W::for_n(ly.nk, [&](int k) { tmp[k] = cv[k]; });
@@ -1552,7 +1528,7 @@ struct Engine {
   // Solve — scheduler.go:440-519 with Queue (queue.go:31-108)
   KS_DEV void solve() {
     const unsigned long long t_begin = W::clock();
-    if (P.n_nodes) {
+    if (FULL && P.n_nodes) {
       // ExistingNodes are mutated by Solve: start from the pristine copies
       const int ne = P.n_nodes;
       Workspace& Sw = S;
@@ -1560,7 +1536,7 @@ struct Engine {
       W::for_n(lay.nr * ne, [&](int i) { Sw.n_remaining[i] = Sw.n_remaining0[i]; });
       W::for_n(ne, [&](int i) { Sw.n_defined[i] = Sw.n_defined0[i]; Sw.n_complement[i] = Sw.n_complement0[i]; Sw.n_npods[i] = 0; });
     }
-    if (P.topo.n_groups) {
+    if (FULL && P.topo.n_groups) {
       const TopoView& T = P.topo;
       Workspace& Sw = S;
       const int G = T.n_groups, dv = T.dom_words * 64;
@@ -1571,7 +1547,7 @@ struct Engine {
       W::for_n(T.words, [&](int w) { sc.t_active[w] = T.initially_active[w]; });
     }
     load_tables();
-    if (P.reserved_on) W::for_n(P.n_resv, [&](int i) { sc.resv_cap[i] = P.resv_cap0[i]; });
+    if (FULL && P.reserved_on) W::for_n(P.n_resv, [&](int i) { sc.resv_cap[i] = P.resv_cap0[i]; });
     prefilter_templates();
     const int np = P.n_pods;
     const uint32_t cap = (uint32_t)np + 1;

@@ -101,7 +101,16 @@ __global__ void __launch_bounds__(64) ksolve_pack(ks::ProblemView pv, ks::Worksp
   extern __shared__ __attribute__((aligned(16))) char lds[];
   ks::LdsTables tables;
   tables.bind(lds, pv.lds);
-  ks::Engine<ks::Wave> eng(pv, ws, tables);
+  ks::Engine<ks::Wave, true> eng(pv, ws, tables);
+  eng.solve();
+}
+// The same engine compiled without topology / existing nodes / daemon overhead / minValues / reservations, for problems
+// that use none of them (ProblemView::lite): less code and far less live state around the hot loop.
+__global__ void __launch_bounds__(64) ksolve_pack_lite(ks::ProblemView pv, ks::Workspace ws) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  ks::LdsTables tables;
+  tables.bind(lds, pv.lds);
+  ks::Engine<ks::Wave, false> eng(pv, ws, tables);
   eng.solve();
 }
 
@@ -111,8 +120,8 @@ __global__ void __launch_bounds__(64) ksolve_pack_batch(ks::BatchItem* items) {
   ks::BatchItem& it = items[blockIdx.x];
   ks::LdsTables tables;
   tables.bind(lds, it.pv.lds);
-  ks::Engine<ks::Wave> eng(it.pv, it.ws, tables);
-  eng.solve();
+  if (it.pv.lite) { ks::Engine<ks::Wave, false> eng(it.pv, it.ws, tables); eng.solve(); }
+  else { ks::Engine<ks::Wave, true> eng(it.pv, it.ws, tables); eng.solve(); }
 }
 static dim3 grid_for(int n) { return dim3((unsigned)((n + 255) / 256)); }
 static void be_launch_it_index(ksolve_handle* h, int n, const ks::ItIndexArgs& a) { hipLaunchKernelGGL(ksolve_it_index, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
@@ -123,8 +132,10 @@ static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a
 static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a) { hipLaunchKernelGGL(ksolve_finalize, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
 static void be_launch_pack(ksolve_handle* h) {
   const int lds_bytes = h->pv.lds.total_bytes;
-  if (!hip_check(h, hipFuncSetAttribute((const void*)ksolve_pack, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
-  hipLaunchKernelGGL(ksolve_pack, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, h->pv, h->ws);
+  const void* fn = h->pv.lite ? (const void*)ksolve_pack_lite : (const void*)ksolve_pack;
+  if (!hip_check(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
+  if (h->pv.lite) hipLaunchKernelGGL(ksolve_pack_lite, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, h->pv, h->ws);
+  else hipLaunchKernelGGL(ksolve_pack, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, h->pv, h->ws);
   hip_check(h, hipGetLastError(), "ksolve_pack launch");
 }
 

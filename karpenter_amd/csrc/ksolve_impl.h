@@ -455,6 +455,17 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     lp.off_closed = off; off = align(off + cap / 8 + 8);
     lp.total_bytes = off;
   }
+  {
+    bool any_minv = false;
+    if (d->tmpl_reqs.min_values) for (size_t i = 0; i < (size_t)d->n_templates * d->n_keys; ++i) if (d->tmpl_reqs.min_values[i] >= 0) any_minv = true;
+    const bool bounds = any_nonzero(d->pod_reqs.has_gte, d->n_pod_rows) || any_nonzero(d->pod_reqs.has_lte, d->n_pod_rows) ||
+                        any_nonzero(d->tmpl_reqs.has_gte, d->n_templates) || any_nonzero(d->tmpl_reqs.has_lte, d->n_templates);
+    P.lite = (d->topo.n == 0 && d->n_nodes == 0 && !d->tmpl_daemon_first && !any_minv && !P.reserved_on && !bounds && req_words <= 64 &&
+              it_words <= 8 && d->n_res <= 4) ? 1 : 0;
+#ifdef KSOLVE_NO_LITE
+    P.lite = 0;   // A/B builds only
+#endif
+  }
   be_sync(h);
   be_toc(h, T_UPLOAD);
   if (!be_ok(h)) return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "device allocation/upload failed" : h->error);

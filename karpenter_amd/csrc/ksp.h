@@ -172,6 +172,7 @@ struct ProblemView {
   const uint8_t* node_flags;     // [n_nodes] bit0 initialized, bit1 under consolidateAfter
   const uint8_t* pod_from_deleting; // [n_pods]
   TopoView topo;
+  int lite;                      // no topology groups, existing nodes, daemon overhead, minValues or reservations: Engine<W, false>
 };
 
 struct Counters {

@@ -49,8 +49,8 @@ static void be_launch_pack(ksolve_handle* h) {
   std::vector<char> lds((size_t)h->pv.lds.total_bytes + 64);  // stands in for the CU's LDS segment
   ks::LdsTables tables;
   tables.bind(lds.data(), h->pv.lds);
-  ks::Engine<ks::Wave> eng(h->pv, h->ws, tables);
-  eng.solve();
+  if (h->pv.lite) { ks::Engine<ks::Wave, false> eng(h->pv, h->ws, tables); eng.solve(); }
+  else { ks::Engine<ks::Wave, true> eng(h->pv, h->ws, tables); eng.solve(); }
 }
 static void be_launch_pack_batch(ksolve_handle** hs, int n) {
   for (int i = 0; i < n; ++i) { be_tic(hs[i], ksi::T_PACK); be_launch_pack(hs[i]); be_toc(hs[i], ksi::T_PACK); }
