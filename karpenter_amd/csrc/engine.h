@@ -618,6 +618,40 @@ struct Engine {
     });
     return true;
   }
+  // Domain values of group g's key for which the group's own nextDomain* would find a domain on a bin that admits the
+  // value — as far as that can be said without looking at the bin (~0 = cannot tell). Used only to skip claims that
+  // certainly fail; the winner still goes through topo_apply.
+  KS_DEV uint64_t topo_ok_mask(int g, bool self, const ReqRef& pod) {
+    const TopoView& T = P.topo;
+    const Dict& d = P.dict;
+    const int key = T.key[g], type = T.type[g];
+    const uint32_t w0 = d.key_word_off[key];
+    const uint64_t dw = S.tg_domains[(size_t)g * T.dom_words];
+    const int32_t* cnt = S.tg_counts + (size_t)g * T.dom_words * 64;
+    // the pod's own requirement on the key narrows the bin's domains (nodeRequirements = bin ∧ pod, nodeclaim.go:137-140)
+    uint64_t podreq = ~0ull;
+    {
+      const uint32_t kdef = lo32(sc.cls[lay.k_f0()]), kc = hi32(sc.cls[lay.k_f0()]);
+      const uint32_t kb = lo32(sc.cls[lay.k_f1()]) | hi32(sc.cls[lay.k_f1()]);
+      if ((kb >> key) & 1) return ~0ull;
+      if ((kdef >> key) & 1) podreq = ((kc >> key) & 1) ? (~sc.cls[lay.k_mask() + w0] & d.value_valid[w0]) : sc.cls[lay.k_mask() + w0];
+    }
+    if (type == 0) {
+      const uint64_t sup = W::ballot([&](int b) { return ((dw >> b) & 1) != 0 && topo_has(pod, key, w0, b); });
+      long long mn = INT32_MAX;
+      const uint64_t m = W::reduce_min(64, [&](int b) -> uint64_t { return ((sup >> b) & 1) ? (uint64_t)(uint32_t)cnt[b] : NONE; });
+      if (m != NONE) mn = (long long)m;
+      if (T.min_domains[g] >= 0 && popc64(sup) < T.min_domains[g]) mn = 0;
+      const long long skew = T.max_skew[g];
+      const uint64_t valid = W::ballot([&](int b) { return ((dw >> b) & 1) != 0 && (long long)cnt[b] + (self ? 1 : 0) - mn <= skew; });
+      return valid & podreq;
+    }
+    const uint64_t ph = W::ballot([&](int b) { return ((dw >> b) & 1) != 0 && topo_has(pod, key, w0, b); });
+    if (type == 2) return ph & podreq & W::ballot([&](int b) { return cnt[b] == 0; });
+    const uint64_t pn = ph & W::ballot([&](int b) { return cnt[b] > 0; });
+    if (pn == 0 && self) return ~0ull;   // bootstrap path of nextDomainAffinity (:372-386): decided per bin
+    return pn & podreq;
+  }
   // Topology.AddRequirements + the Compatible check that follows it (topology.go:226-250, nodeclaim.go:195-206,
   // existingnode.go:111-122). `base` = the bin's requirements already intersected with the pod's. On success sc.topo
   // holds base ∧ every matching group's next domain and *changed tells whether that differs from base.
@@ -979,6 +1013,21 @@ struct Engine {
     uint64_t* line = L.cache + (size_t)(c & 31) * ly.c_hot_words();
     W::for_n(ly.c_hot_words(), [&](int i) { uint64_t v = o[i]; dst[i] = v; line[i] = v; });
     { int64_t* hd = S.c_headroom; const int mc = S.max_claims; W::for_n(nr, [&](int r) { hd[(size_t)r * mc + c] = oh[r]; }); }
+    if (FULL && P.topo.n_key_slots) {
+      // values the claim still admits on each topology key (undefined key or bounds: everything)
+      const TopoView& T = P.topo;
+      const Dict& d = P.dict;
+      uint64_t* km = S.c_keymask;
+      const int mc = S.max_claims;
+      const uint32_t def = lo32(o[ly.c_f0()]), comp = hi32(o[ly.c_f0()]), bnd = lo32(o[ly.c_f1()]) | hi32(o[ly.c_f1()]);
+      W::for_n(T.n_key_slots, [&](int sl) {
+        const int key = T.slot_key[sl];
+        const uint32_t x = d.key_word_off[key];
+        uint64_t v = ~0ull;
+        if (((def >> key) & 1) && !((bnd >> key) & 1)) v = ((comp >> key) & 1) ? (~o[ly.c_mask() + x] & d.value_valid[x]) : o[ly.c_mask() + x];
+        km[(size_t)sl * mc + c] = v;
+      });
+    }
     if (W::leader()) sc.cache_tag[c & 31] = c;
     if (write_cold) {
       uint64_t* dc = S.c_cold + (size_t)c * ly.cold_words();
@@ -1069,8 +1118,25 @@ struct Engine {
       const TopoView& T = P.topo;
       for (int tw = 0; tw < T.words; ++tw) for (uint64_t m = sc.t_match[tw]; m; m &= m - 1) {
         const int g = tw * 64 + ctz64(m);
-        if (T.key[g] >= 0 || T.type[g] == 1) continue;
         const bool self = (sc.t_sel[tw] >> (g & 63)) & 1;
+        if (T.key[g] >= 0) {
+          // dictionary key: skip the claims whose admitted values miss every domain the group could pick
+          const int sl = T.key_slot[g];
+          if (sl < 0) continue;
+          const uint64_t okv = topo_ok_mask(g, self, P.cls_strict.at(P.dict, (uint32_t)cur_class));
+          if (okv == ~0ull) continue;
+          const uint64_t* km = S.c_keymask + (size_t)sl * S.max_claims;
+          any = 0;
+          for (int w0 = 0; w0 < words; w0 += 8) {
+            const int n = words - w0 < 8 ? words - w0 : 8;
+            W::ballots8(n, [&](int l, int j) { const int c = (w0 + j) * 64 + l; return c < nc && (km[c] & okv) != 0; },
+                        [&](int j, uint64_t ok) { const uint64_t v = stage[w0 + j] & ok; W::store(&stage[w0 + j], v); any |= v; });
+          }
+          W::sync();
+          if (!any) return false;
+          continue;
+        }
+        if (T.type[g] == 1) continue;
         const long long limit = T.type[g] == 2 ? 0 : (long long)T.max_skew[g] - (self ? 1 : 0);
         const int32_t* cc = S.tg_claim_counts + (size_t)T.host_slot[g] * S.max_claims;
         any = 0;

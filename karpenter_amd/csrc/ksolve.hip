@@ -120,8 +120,16 @@ __global__ void __launch_bounds__(64) ksolve_pack_batch(ks::BatchItem* items) {
   ks::BatchItem& it = items[blockIdx.x];
   ks::LdsTables tables;
   tables.bind(lds, it.pv.lds);
-  if (it.pv.lite) { ks::Engine<ks::Wave, false> eng(it.pv, it.ws, tables); eng.solve(); }
-  else { ks::Engine<ks::Wave, true> eng(it.pv, it.ws, tables); eng.solve(); }
+  ks::Engine<ks::Wave, true> eng(it.pv, it.ws, tables);
+  eng.solve();
+}
+__global__ void __launch_bounds__(64) ksolve_pack_batch_lite(ks::BatchItem* items) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  ks::BatchItem& it = items[blockIdx.x];
+  ks::LdsTables tables;
+  tables.bind(lds, it.pv.lds);
+  ks::Engine<ks::Wave, false> eng(it.pv, it.ws, tables);
+  eng.solve();
 }
 static dim3 grid_for(int n) { return dim3((unsigned)((n + 255) / 256)); }
 static void be_launch_it_index(ksolve_handle* h, int n, const ks::ItIndexArgs& a) { hipLaunchKernelGGL(ksolve_it_index, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
@@ -139,23 +147,47 @@ static void be_launch_pack(ksolve_handle* h) {
   hip_check(h, hipGetLastError(), "ksolve_pack launch");
 }
 
-static void be_launch_pack_batch(ksolve_handle** hs, int n) {
-  ksolve_handle* h0 = hs[0];
+// One launch per engine flavour (lite / full problems of the batch), each on the stream of its first handle so that the
+// two launches overlap; every handle's T_PACK timer gets the time of its own launch.
+static void launch_batch_group(std::vector<ksolve_handle*>& g, bool lite, ks::BatchItem** d_items_out) {
+  *d_items_out = nullptr;
+  if (g.empty()) return;
+  ksolve_handle* h0 = g[0];
   HipBackend* b = HB(h0);
-  std::vector<ks::BatchItem> items((size_t)n);
+  std::vector<ks::BatchItem> items(g.size());
   int lds_bytes = 0;
-  for (int i = 0; i < n; ++i) { items[i].pv = hs[i]->pv; items[i].ws = hs[i]->ws; lds_bytes = std::max(lds_bytes, hs[i]->pv.lds.total_bytes); }
+  for (size_t i = 0; i < g.size(); ++i) { items[i].pv = g[i]->pv; items[i].ws = g[i]->ws; lds_bytes = std::max(lds_bytes, g[i]->pv.lds.total_bytes); }
   ks::BatchItem* d_items = nullptr;
   if (!hip_check(h0, hipMalloc((void**)&d_items, items.size() * sizeof(ks::BatchItem)), "hipMalloc(batch)")) return;
+  *d_items_out = d_items;
   hip_check(h0, hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(ks::BatchItem), hipMemcpyHostToDevice, b->stream), "hipMemcpy(batch)");
-  if (hip_check(h0, hipFuncSetAttribute((const void*)ksolve_pack_batch, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) {
-    be_tic(h0, ksi::T_PACK);
-    hipLaunchKernelGGL(ksolve_pack_batch, dim3((unsigned)n), dim3(64), (size_t)lds_bytes, b->stream, d_items);
-    hip_check(h0, hipGetLastError(), "ksolve_pack_batch launch");
-    be_toc(h0, ksi::T_PACK);
-    for (int i = 1; i < n; ++i) { hs[i]->timers.ms[ksi::T_PACK] = h0->timers.ms[ksi::T_PACK]; if (b->failed) { HB(hs[i])->failed = true; hs[i]->error = h0->error; } }
-  }
-  hipFree(d_items);
+  hip_check(h0, hipStreamSynchronize(b->stream), "hipStreamSynchronize");   // `items` is a local
+  const void* fn = lite ? (const void*)ksolve_pack_batch_lite : (const void*)ksolve_pack_batch;
+  if (!hip_check(h0, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
+  hip_check(h0, hipEventRecord(b->ev0[ksi::T_PACK], b->stream), "hipEventRecord");
+  if (lite) hipLaunchKernelGGL(ksolve_pack_batch_lite, dim3((unsigned)g.size()), dim3(64), (size_t)lds_bytes, b->stream, d_items);
+  else hipLaunchKernelGGL(ksolve_pack_batch, dim3((unsigned)g.size()), dim3(64), (size_t)lds_bytes, b->stream, d_items);
+  hip_check(h0, hipGetLastError(), "ksolve_pack_batch launch");
+  hip_check(h0, hipEventRecord(b->ev1[ksi::T_PACK], b->stream), "hipEventRecord");
+}
+static void finish_batch_group(std::vector<ksolve_handle*>& g, ks::BatchItem* d_items) {
+  if (g.empty()) return;
+  ksolve_handle* h0 = g[0];
+  HipBackend* b = HB(h0);
+  hip_check(h0, hipEventSynchronize(b->ev1[ksi::T_PACK]), "hipEventSynchronize");
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, b->ev0[ksi::T_PACK], b->ev1[ksi::T_PACK]) == hipSuccess) h0->timers.ms[ksi::T_PACK] = ms;
+  for (size_t i = 1; i < g.size(); ++i) { g[i]->timers.ms[ksi::T_PACK] = h0->timers.ms[ksi::T_PACK]; if (b->failed) { HB(g[i])->failed = true; g[i]->error = h0->error; } }
+  if (d_items) hipFree(d_items);
+}
+static void be_launch_pack_batch(ksolve_handle** hs, int n) {
+  std::vector<ksolve_handle*> lite, full;
+  for (int i = 0; i < n; ++i) (hs[i]->pv.lite ? lite : full).push_back(hs[i]);
+  ks::BatchItem *dl = nullptr, *df = nullptr;
+  launch_batch_group(lite, true, &dl);
+  launch_batch_group(full, false, &df);
+  finish_batch_group(lite, dl);
+  finish_batch_group(full, df);
 }
 // queue order (queue.go:72-108): five stable LSD radix passes over 64-bit keys, least significant criterion first
 static void be_sort_pods(ksolve_handle* h) {

@@ -401,6 +401,18 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
           for (size_t v = 0; v < dv; ++v) if (t.init_counts[(size_t)g * dv + v] > 0) nonzero[g]++;
         }
       }
+      // topology keys whose dictionary fits one mask word get a per-claim "values still admitted" table for the scan prefilter
+      std::vector<int8_t> key_slot(G, -1);
+      T.n_key_slots = 0;
+      for (uint32_t g = 0; g < G; ++g) {
+        if (t.key[g] < 0 || d->key_word_off[t.key[g] + 1] - d->key_word_off[t.key[g]] != 1) continue;
+        int sl = -1;
+        for (int i = 0; i < T.n_key_slots; ++i) if (T.slot_key[i] == t.key[g]) sl = i;
+        if (sl < 0 && T.n_key_slots < 4) { sl = T.n_key_slots++; T.slot_key[sl] = t.key[g]; }
+        key_slot[g] = (int8_t)sl;
+      }
+      T.key_slot = up(h, key_slot.data(), G);
+      W.c_keymask = dz<uint64_t>(h, (size_t)std::max(1, T.n_key_slots) * mc);
       T.type = up(h, t.type, G); T.key = up(h, t.key, G); T.host_slot = up(h, host_slot.data(), G);
       T.max_skew = up(h, t.max_skew, G); T.min_domains = up(h, t.min_domains, G);
       T.domains0 = up(h, t.domains, (size_t)G * T.dom_words);

@@ -95,6 +95,9 @@ struct TopoView {
   uint64_t inverse_mask[kMaxTopoWords], initially_active[kMaxTopoWords];
   const uint8_t* type;           // [G] 0 spread, 1 affinity, 2 anti-affinity
   const int32_t* key;            // [G] dictionary key, -1 = kubernetes.io/hostname (domains are the bins)
+  const int8_t* key_slot;        // [G] row of the group's key in the per-claim domain masks (keys of one dictionary word), -1 = none
+  int n_key_slots;
+  int slot_key[4];               // dictionary key of each slot
   const int16_t* host_slot;       // [G] row of a hostname group in the per-bin counters, -1 for dictionary keys
   int n_host_groups;
   const int32_t *max_skew, *min_domains;
@@ -187,6 +190,7 @@ struct Workspace {
   // claims (AoS by claim; see RecLayout)
   uint64_t* c_hot;               // [max_claims][c_hot_words]
   uint64_t* c_cold;              // [max_claims][cold_words]
+  uint64_t* c_keymask;           // [n_key_slots][max_claims] values each claim still admits on a topology key (lane-per-claim prefilter)
   uint64_t* c_reserved;          // [max_claims] reservation ids held by each claim
   int64_t* c_headroom;           // [n_res][max_claims] SoA copy of the records' headroom: lane-per-claim prefilter of the scan
   // order (pdq_emul.h): lives in LDS while it fits (LdsPlan.order_cap), these are the HBM spill arrays
