@@ -307,6 +307,31 @@ struct ClaimOrder {
       defect = -1;
       return;
     }
+    if (n >= 50) {
+      // The outermost pdqsort call on "sorted except position p": choosePivot samples the keys around n/4, n/2 and 3n/4
+      // (zsortfunc.go choosePivot_func); unless p is one of those nine positions every sampled comparison sees sorted
+      // data, so swaps == 0, the hint is "increasing" and the call goes straight to partialInsertionSort, which repairs
+      // the single defect with one stable move (see partial_insertion_sort). Skip the sampling in that case.
+      const int q = n / 4, p = defect;
+      const bool sampled = (p >= q - 1 && p <= q + 1) || (p >= 2 * q - 1 && p <= 2 * q + 1) || (p >= 3 * q - 1 && p <= 3 * q + 1);
+      if (!sampled) {
+        const KS_LDS uint32_t* kq = key;
+        if (defect_append) {
+          const int i = n - 1;
+          if (i >= 1 && key[i] < key[i - 1]) {
+            uint32_t mv = key[i];
+            int t = W::find_last(0, i, [kq, mv](int x) { return !(mv < kq[x]); });
+            rotate_right(t + 1, i);
+          }
+        } else if (p + 1 < n && key[p + 1] < key[p]) {
+          uint32_t mv = key[p];
+          int e = W::find_first(p + 1, n, [kq, mv](int x) { return !(kq[x] < mv); });
+          rotate_left(p, e - 1);
+        }
+        defect = -1;
+        return;
+      }
+    }
     pdqsort(0, n, bits_len((unsigned)n));
     defect = -1;
   }
