@@ -418,20 +418,22 @@ struct Engine {
     const uint8_t* wk = sc.word_key;
     const uint32_t both = cdef & kdef;
     uint32_t undef = kdef & ~cdef & ~d.well_known_mask;
-    uint64_t NA = 0, NB = 0, H = 0;
-    if (both | undef) {
-      NB = W::ballot([&](int l) { return l < rw && b[l] != 0; });
-      if (both) {
-        NA = W::ballot([&](int l) { return l < rw && a[l] != 0; });
-        H = W::ballot([&](int l) {
-          if (l >= rw) return false;
-          int k = wk[l];
-          bool ca = (ccomp >> k) & 1, cb = (kcomp >> k) & 1;
-          uint64_t x = a[l], y = b[l];
-          return (ca ? (cb ? ~0ull : (y & ~x)) : (cb ? (x & ~y) : (x & y))) != 0;
-        });
-      }
-    }
+    // One pass over the words: non-empty (bin), non-empty (pod), has-intersection, and — optimistically, it is only used
+    // when the sets turn out compatible — the merged word (Requirement.Intersection, requirement.go:181-214 without
+    // bounds) and whether it differs from the bin's.
+    uint64_t NA = 0, NB = 0, H = 0, diff = 0;
+    uint64_t* o = sc.out + lay.c_mask();
+    W::ballot4([&](int l) {
+      if (l >= rw) return 0;
+      const int k = wk[l];
+      const bool ca = (ccomp >> k) & 1, cb = (kcomp >> k) & 1;
+      const uint64_t x = a[l], y = b[l];
+      const uint64_t inter = ca ? (cb ? ~0ull : (y & ~x)) : (cb ? (x & ~y) : (x & y));
+      uint64_t v = x;
+      if ((kdef >> k) & 1) v = !((cdef >> k) & 1) ? y : (ca ? (cb ? (x | y) : (y & ~x)) : (cb ? (x & ~y) : (x & y)));
+      o[l] = v;
+      return (x != 0 ? 1 : 0) | (y != 0 ? 2 : 0) | (inter != 0 ? 4 : 0) | (v != x ? 8 : 0);
+    }, NA, NB, H, diff);
     auto lanes_of = [&](int k) { uint32_t w0 = d.key_word_off[k], n = d.key_word_off[k + 1] - w0; return (n >= 64 ? ~0ull : ((1ull << n) - 1)) << w0; };
     while (undef) {  // a key the bin does not define: only NotIn / DoesNotExist may pass (requirements.go:185-193)
       int k = __builtin_ctz(undef);
@@ -451,28 +453,6 @@ struct Engine {
       bool nega = ca ? nea : !nea, negb = cb ? neb : !neb;
       if (nega && negb) continue;
       return false;
-    }
-    // merge (Requirement.Intersection per key, requirement.go:181-214 without bounds)
-    uint64_t* o = sc.out + lay.c_mask();
-    uint64_t diff = 0;
-    if (kdef) {
-      diff = W::ballot([&](int l) {
-        if (l >= rw) return false;
-        int k = wk[l];
-        uint64_t x = a[l], v = x;
-        if ((kdef >> k) & 1) {
-          uint64_t y = b[l];
-          if (!((cdef >> k) & 1)) v = y;
-          else {
-            bool ca = (ccomp >> k) & 1, cb = (kcomp >> k) & 1;
-            v = ca ? (cb ? (x | y) : (y & ~x)) : (cb ? (x & ~y) : (x & y));
-          }
-        }
-        o[l] = v;
-        return v != x;
-      });
-    } else {
-      W::for_n(rw, [&](int l) { o[l] = a[l]; });
     }
     const uint32_t ndef = cdef | kdef;
     const uint32_t ncomp = (ccomp & ~kdef) | (ccomp & kcomp & both) | (kcomp & ~cdef);

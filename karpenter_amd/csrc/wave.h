@@ -36,6 +36,12 @@ struct Wave {
   }
   template <class F>
   KS_DEV static uint64_t ballot(F f) { return __ballot(f(lane()) ? 1 : 0); }
+  // four ballots from ONE evaluation of f(lane) (bits 0..3 of its result): the loads behind the predicates happen once
+  template <class F>
+  KS_DEV static void ballot4(F f, uint64_t& m0, uint64_t& m1, uint64_t& m2, uint64_t& m3) {
+    const int v = f(lane());
+    m0 = __ballot(v & 1); m1 = __ballot(v & 2); m2 = __ballot(v & 4); m3 = __ballot(v & 8);
+  }
   // g(j, ballot(f(lane, j))) for j < n <= 8: all predicates (and their loads) are evaluated before the first ballot, so
   // eight words cost one LDS latency instead of eight. No arrays: everything stays in registers.
   template <class F, class G>
@@ -163,6 +169,11 @@ struct Wave {
     uint64_t m = 0;
     for (int l = 0; l < 64; ++l) if (f(l)) m |= 1ull << l;
     return m;
+  }
+  template <class F>
+  static void ballot4(F f, uint64_t& m0, uint64_t& m1, uint64_t& m2, uint64_t& m3) {
+    m0 = m1 = m2 = m3 = 0;
+    for (int l = 0; l < 64; ++l) { const int v = f(l); if (v & 1) m0 |= 1ull << l; if (v & 2) m1 |= 1ull << l; if (v & 4) m2 |= 1ull << l; if (v & 8) m3 |= 1ull << l; }
   }
   template <class F, class G>
   static void ballots8(int n, F f, G g) {
