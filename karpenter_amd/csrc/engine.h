@@ -24,6 +24,13 @@
 #include "ksp.h"
 #include "pdq_emul.h"
 
+// diagnostic counters that only the profiling build keeps (every live 64-bit counter costs the lone wave registers)
+#ifdef KSOLVE_PHASE_TIMERS
+#define KS_DIAG(x) x
+#else
+#define KS_DIAG(x) ((void)0)
+#endif
+
 namespace ks {
 
 enum {
@@ -286,7 +293,7 @@ struct Engine {
   KS_DEV bool filter_instance_types(const uint64_t* bin_its, const int64_t* total, bool full, const ReqRef& reqs, bool want_diag, int tmpl) {
     uint64_t cells = ~0ull;
     if (full) {
-      ctr.full_filters++;
+      KS_DIAG(ctr.full_filters++);
       compat_mask(reqs);
       cells = offering_cells(reqs);
     }
@@ -374,7 +381,7 @@ struct Engine {
         const uint64_t cm = full ? cmw[w] : ~0ull;
         const uint64_t itfits = in & Lt.allocok[w] & fit_and_off;
         const uint64_t keep = cm & itfits;
-        ctr.it_evaluations += popc64(in);
+        KS_DIAG(ctr.it_evaluations += popc64(in));
         if (want_diag) { d_req |= (in & cm) != 0; d_fit |= itfits != 0; d_fo |= (itfits & ~cm) != 0; }
         W::store(&its_out[w], (uint64_t)(accumulate ? (its_out[w] | keep) : keep));
         any |= keep;
@@ -892,7 +899,7 @@ struct Engine {
       if (!topo_apply(merged, 0, claim_id, true, &tchanged)) return E_TOPOLOGY;
       if (tchanged) { merged = reqbuf_to_out(sc.topo); changed = true; }
     }
-    ctr.full_evaluations++;
+    KS_DIAG(ctr.full_evaluations++);
     unsigned long long tc = W::clock();
     ctr.cycles[12] += tc - tb;
     if (reqs_changed) *reqs_changed = changed;
@@ -1018,7 +1025,7 @@ struct Engine {
     W::sync();
   }
   KS_DEV void reset_column(int c) {
-    ctr.column_resets++;
+    KS_DIAG(ctr.column_resets++);
     uint64_t* dead = S.dead;
     const int cw = S.claim_words;
     const uint64_t clr = ~(1ull << (c & 63));
