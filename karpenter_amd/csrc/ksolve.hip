@@ -53,6 +53,7 @@ static void be_fill(ksolve_handle* h, void* dst, int byte, size_t bytes) {
   if (!dst || !bytes) return;
   hip_check(h, hipMemsetAsync(dst, byte, bytes, HB(h)->stream), "hipMemsetAsync");
 }
+static void be_thread_init(ksolve_handle* h) { hipSetDevice(HB(h)->device); }
 static void be_sync(ksolve_handle* h) { hip_check(h, hipStreamSynchronize(HB(h)->stream), "hipStreamSynchronize"); }
 static bool be_ok(ksolve_handle* h) { return !HB(h)->failed; }
 static void be_tic(ksolve_handle* h, int slot) { hip_check(h, hipEventRecord(HB(h)->ev0[slot], HB(h)->stream), "hipEventRecord"); }

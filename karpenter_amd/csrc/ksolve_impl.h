@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ksolve.h"
@@ -81,7 +82,8 @@ static void be_launch_row_class(ksolve_handle* h, int n, const ks::RowArgs& a);
 static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a);
 static void be_sort_pods(ksolve_handle* h);  // fills ws/pv.sorted_pods
 static void be_launch_pack(ksolve_handle* h);
-static void be_launch_pack_batch(ksolve_handle** hs, int n);   // one block per handle; sets every handle's T_PACK timer
+static void be_launch_pack_batch(ksolve_handle** hs, int n);
+static void be_thread_init(ksolve_handle* h);   // makes the handle's device current on a worker thread   // one block per handle; sets every handle's T_PACK timer
 static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a);
 static int be_device_available();
 
@@ -730,18 +732,22 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
 static ksolve_status solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) {
   for (uint32_t i = 0; i < n; ++i) memset(&outs[i], 0, sizeof(outs[i]));
   std::vector<ksolve_status> st(n, KSOLVE_OK);
+  // The prepass (classes, queue order) and the result download of different problems are independent: a few host
+  // threads drive them on the problems' own streams so that the launches and copies of different problems overlap.
+  const uint32_t n_threads = std::min<uint32_t>(n, std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+  auto parallel = [&](auto&& fn) {
+    if (n_threads <= 1) { for (uint32_t i = 0; i < n; ++i) fn(i); return; }
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < n_threads; ++t) pool.emplace_back([&, t]() { be_thread_init(hs[0]); for (uint32_t i = t; i < n; i += n_threads) fn(i); });
+    for (auto& th : pool) th.join();
+  };
+  parallel([&](uint32_t i) { st[i] = solve_prepare(hs[i]); outs[i].status = st[i]; if (st[i] == KSOLVE_OK) be_sync(hs[i]); });
   std::vector<ksolve_handle*> run;
-  for (uint32_t i = 0; i < n; ++i) {
-    st[i] = solve_prepare(hs[i]);
-    outs[i].status = st[i];
-    if (st[i] == KSOLVE_OK) { be_sync(hs[i]); if (hs[i]->n_pods) run.push_back(hs[i]); }
-  }
+  for (uint32_t i = 0; i < n; ++i) if (st[i] == KSOLVE_OK && hs[i]->n_pods) run.push_back(hs[i]);
   if (!run.empty()) be_launch_pack_batch(run.data(), (int)run.size());
+  parallel([&](uint32_t i) { if (st[i] == KSOLVE_OK) st[i] = solve_finish(hs[i], &outs[i]); });
   ksolve_status worst = KSOLVE_OK;
-  for (uint32_t i = 0; i < n; ++i) {
-    if (st[i] == KSOLVE_OK) st[i] = solve_finish(hs[i], &outs[i]);
-    if (st[i] != KSOLVE_OK && st[i] != KSOLVE_ERR_CANCELLED) worst = st[i];
-  }
+  for (uint32_t i = 0; i < n; ++i) if (st[i] != KSOLVE_OK && st[i] != KSOLVE_ERR_CANCELLED) worst = st[i];
   return worst;
 }
 

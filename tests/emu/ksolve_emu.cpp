@@ -15,6 +15,7 @@ static void be_h2d(ksolve_handle*, void* dst, const void* src, size_t bytes) { m
 static void be_d2h(ksolve_handle*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
 static void be_fill(ksolve_handle*, void* dst, int byte, size_t bytes) { memset(dst, byte, bytes); }
 static void be_sync(ksolve_handle*) {}
+static void be_thread_init(ksolve_handle*) {}
 static bool be_ok(ksolve_handle*) { return true; }
 static void be_tic(ksolve_handle* h, int slot) { ((EmuBackend*)h->backend)->t0[slot] = std::chrono::steady_clock::now(); }
 static void be_toc(ksolve_handle* h, int slot) {

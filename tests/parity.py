@@ -12,7 +12,7 @@ def build_emu():
     deps = [src] + [os.path.join(root, "karpenter_amd", "csrc", f) for f in os.listdir(os.path.join(root, "karpenter_amd", "csrc")) if f.endswith(".h")]
     deps.append(os.path.join(root, "include", "ksolve.h"))
     if not os.path.exists(EMU_LIB) or any(os.path.getmtime(d) > os.path.getmtime(EMU_LIB) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", EMU_LIB, src])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", EMU_LIB, src])
     return EMU_LIB
 
 
