@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--types", type=int, default=500)
     ap.add_argument("--cpu-sample", type=int, default=40_000, help="pods in the bounded cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch-problems", type=int, default=256, help="independent problems solved with ONE batched launch (reported beside the headline, 0 = skip)")
+    ap.add_argument("--batch-problems", type=int, default=512, help="independent problems solved with ONE batched launch (reported beside the headline, 0 = skip)")
     ap.add_argument("--batch-pods", type=int, default=20_000, help="pods per problem of the batched measurement")
     args = ap.parse_args()
 
@@ -155,7 +155,7 @@ def main():
         # Independent problems (NodePool components / consolidation probes) in ONE launch of the pack kernel:
         # block b = the wavefront of problem b. Reported beside the headline, never part of `value`.
         from karpenter_amd.scheduling import SolveBatch
-        scheds = [NewScheduler(dict(fx.config2(pods=args.batch_pods, n_types=args.types, seed=1000 + i), options={"device": device_index})) for i in range(args.batch_problems)]
+        scheds = [NewScheduler(dict(fx.config2(pods=args.batch_pods, n_types=args.types, seed=1000 + i), options={"device": device_index, "maxClaims": 1024})) for i in range(args.batch_problems)]   # 1024 in-flight claims per problem keep the LDS plan under 80 KB: two problems per CU
         SolveBatch(scheds, want_results=False)   # warm-up
         tb = time.perf_counter()
         rs = SolveBatch(scheds, want_results=False)
