@@ -779,22 +779,29 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     }
     const int n_res = (int)res_names.size();
     if (n_res > KSOLVE_MAX_RES) throw Unsupported("more than 8 resource dimensions");
-    std::vector<i128> scale(n_res, 1000000000);  // nano-units per device unit; shrink until every quantity divides
+    // nano-units per device unit: the greatest common divisor of every quantity of the dimension, so that the device
+    // integers are exact and as small as possible (with Mi-granular memory and milli-cpu they fit 32 bits, which lets the
+    // lite engine keep its instance-type tables as int32 registers)
+    std::vector<i128> scale(n_res, 0);
+    auto gcd128 = [](i128 a, i128 b) { while (b) { i128 t = a % b; a = b; b = t; } return a; };
     auto consider = [&](const std::map<std::string, i128>& m) {
       for (auto& kv : m) {
         if (kv.first == "nodes") continue;
         int r = (int)(std::find(res_names.begin(), res_names.end(), kv.first) - res_names.begin());
         i128 v = kv.second < 0 ? -kv.second : kv.second;
-        while (scale[r] > 1 && v % scale[r] != 0) scale[r] /= 10;
+        if (v) scale[r] = gcd128(scale[r], v);
       }
     };
+    consider({{"pods", (i128)1000000000}});   // every pod requests pods: 1 (resources.go:30-38)
     for (int i = 0; i < n_its; ++i) { consider(it_cap[i]); consider(it_over[i]); }
     for (auto& s : specs) consider(s.requests);
     for (auto& dp : daemons) consider(dp.requests);
     for (int e = 0; e < n_nodes; ++e) consider(node_ds[e]);
     for (int t = 0; t < n_templates; ++t) consider(tmpl_limits[t]);
     for (int e = 0; e < n_nodes; ++e) { consider(node_avail[e]); consider(node_cap[e]); }
+    for (int r = 0; r < n_res; ++r) if (scale[r] == 0) scale[r] = 1000000000;
     auto to_dev = [&](int r, i128 nano) {
+      if (nano % scale[r] != 0) throw std::runtime_error("internal: a quantity of " + res_names[r] + " was not part of the scale computation");
       i128 v = nano / scale[r];
       if (v > (i128)(INT64_MAX / 4) || v < -(i128)(INT64_MAX / 4)) throw Unsupported("resource quantity does not fit the device's exact int64 encoding");
       return (int64_t)v;
