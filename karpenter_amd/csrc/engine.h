@@ -1082,6 +1082,7 @@ struct Engine {
     const uint64_t* closed = L.closed;
     const int nc = n_claims;
     uint64_t* stage = sc.stage;
+    unsigned long long ts0 = W::clock();
     // One coalesced load of the class's dead row (lane l holds words l and l + 64: up to 8192 claims), live = not dead,
     // not closed, staged in LDS so that everything after it is LDS-only.
     uint64_t any = W::ballot([&](int l) {
@@ -1136,42 +1137,20 @@ struct Engine {
         if (!any) return false;
       }
     }
-    {
-      // Headroom prefilter: CanAdd's first resource test — a request larger than what the largest surviving instance type
-      // still has free (nodeclaim.go:213 can only fail) — for 64 claims per ballot from the SoA headroom table, only over
-      // the words that still have live claims. These failures are exact and permanent until the claim's column resets.
-      const int64_t* hd = S.c_headroom;
-      const int mc = S.max_claims;
-      const int nr = lay.nr;
-      const int64_t* req = (const int64_t*)(sc.cls + lay.k_req());
-      uint64_t nz = W::ballot([&](int l) { return l < words && stage[l] != 0; });
-      uint64_t nz_hi = words > 64 ? W::ballot([&](int l) { return l + 64 < words && stage[l + 64] != 0; }) : 0ull;
-      if (popc64(nz) + popc64(nz_hi) > 8) nz = nz_hi = 0;   // many live words: one round of loads would not cover them; the probes decide
-      else any = 0;
-      while (nz | nz_hi) {
-        int wj[8];
-        int n = 0;
+    unsigned long long ts1 = W::clock();
+    ctr.cycles[17] += ts1 - ts0;
+    // CanAdd's first resource test — a request larger than what the largest surviving instance type still has free
+    // (nodeclaim.go:213 can only fail) — is folded into the selection below from the SoA headroom table: these failures
+    // are exact and permanent until the claim's column resets.
+    const int64_t* hd = S.c_headroom;
+    const int mc = S.max_claims;
+    const int nr = lay.nr;
+    const int64_t* req = (const int64_t*)(sc.cls + lay.k_req());
+    int64_t rq[kRegNr];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          wj[q] = 0;
-          if (nz) { wj[q] = ctz64(nz); nz &= nz - 1; n = q + 1; }
-          else if (nz_hi) { wj[q] = 64 + ctz64(nz_hi); nz_hi &= nz_hi - 1; n = q + 1; }
-        }
-        W::ballots8(n, [&](int l, int j) {
-          const int c = wj[j] * 64 + l;
-          int ok = 1;
-          for (int r = 0; r < nr; ++r) ok &= (int)(req[r] <= hd[(size_t)r * mc + c]);
-          return ok != 0;
-        }, [&](int j, uint64_t okm) {
-          const int w = wj[j];
-          const uint64_t before = stage[w], v = before & okm;
-          if (v != before) { W::store(&stage[w], v); W::store(&drow[w], (uint64_t)(drow[w] | (before & ~okm))); }
-          any |= v;
-        });
-      }
-      W::sync();
-      if (!any) return false;
-    }
+    for (int r = 0; r < kRegNr; ++r) rq[r] = r < nr ? req[r] : INT64_MIN;
+    unsigned long long ts2 = W::clock();
+    ctr.cycles[18] += ts2 - ts1;
     const KS_LDS uint32_t* ord = order.ord;
     {
       // Few live claims (the usual case once the dead row has filled in): the candidate the reference reaches first is
@@ -1180,6 +1159,34 @@ struct Engine {
       // winner. No walk over the order at all.
       const KS_LDS uint32_t* pos = order.pos;
       int who0;
+      {
+        // Headroom prefilter, one lane per claim, 64 claims per ballot, over the words that still have live claims.
+        uint64_t nz = W::ballot([&](int l) { return l < words && stage[l] != 0; });
+        uint64_t nz_hi = words > 64 ? W::ballot([&](int l) { return l + 64 < words && stage[l + 64] != 0; }) : 0ull;
+        if (popc64(nz) + popc64(nz_hi) <= 8) {   // more live words than that: the probes decide
+          any = 0;
+          while (nz | nz_hi) {
+            int w;
+            if (nz) { w = ctz64(nz); nz &= nz - 1; } else { w = 64 + ctz64(nz_hi); nz_hi &= nz_hi - 1; }
+            const uint64_t okm = W::ballot([&](int l) {
+              const int c = w * 64 + l;
+              int64_t h[kRegNr];
+#pragma unroll
+              for (int r = 0; r < kRegNr; ++r) h[r] = r < nr ? hd[(size_t)r * mc + c] : INT64_MAX;
+              int ok = 1;
+#pragma unroll
+              for (int r = 0; r < kRegNr; ++r) ok &= (int)(rq[r] <= h[r]);
+              for (int r = kRegNr; r < nr; ++r) ok &= (int)(req[r] <= hd[(size_t)r * mc + c]);
+              return ok != 0;
+            });
+            const uint64_t before = stage[w], v = before & okm;
+            if (v != before) { W::store(&stage[w], v); W::store(&drow[w], (uint64_t)(drow[w] | (before & ~okm))); }
+            any |= v;
+          }
+          W::sync();
+          if (!any) return false;
+        }
+      }
       const int densest = 128 - (int)W::argmin_u32([&](int l) { return (uint32_t)(128 - (l < words ? popc64(stage[l]) : 0) - (l + 64 < words ? popc64(stage[l + 64]) : 0)); }, &who0);
       if (densest <= 12) {   // the per-lane loop below runs `densest` times
         for (;;) {
@@ -1194,6 +1201,7 @@ struct Engine {
             return mine;
           }, &who);
           if (best == 0xFFFFFFFFu) return false;
+          ctr.cycles[19] += W::clock() - ts2;
           const int c = (int)(best & 0x1FFFu);
           const int l = c >> 6;
           const uint64_t valid = (l == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;

@@ -3,7 +3,7 @@ timeout 900 python - <<'PY'
 import sys, time, json, os
 from karpenter_amd import fixtures as fx
 from karpenter_amd.scheduling import NewScheduler
-names = ["queue","class_fetch","sort","scan","rec_load","can_add","commit","new_claim","dead_mark","try_sched","total","ca_pre","ca_merge","ca_total","ca_filter","f_ballots","f_combine","x17","x18","x19","x20","merge_reached","col_resets","full_filters"]
+names = ["queue","class_fetch","sort","scan","rec_load","can_add","commit","new_claim","dead_mark","try_sched","total","ca_pre","ca_merge","ca_total","ca_filter","f_ballots","f_combine","s_stage","s_headroom","s_select","x20","merge_reached","col_resets","full_filters"]
 for label, prob in (("config2 200k", fx.config2(pods=200000)), ("config3 100k", fx.config3(pods=100000, n_types=500, seed=42, anti_affinity_pods=3000))):
     s = NewScheduler(prob, solver_lib=os.path.abspath("karpenter_amd/variants/libksolve_timers.so"))
     r = s.Solve(repeat=2, want_results=False)
