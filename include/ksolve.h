@@ -190,6 +190,9 @@ typedef struct {
   uint32_t max_claims;             /* device capacity for in-flight NodeClaims; 0 = n_pods */
   int64_t max_steps;               /* stand-in for the ctx deadline: stop after this many queue pops, -1 = none */
   uint32_t device;                 /* HIP device ordinal */
+  uint32_t lds_claim_cap;          /* 0 = as many in-flight claims as the CU's LDS can order (<= 8192); smaller values shrink the
+                                    * LDS footprint (more problems per CU in ksolve_solve_batch). A solve that needs more claims
+                                    * is re-run on the engine variant that keeps the claim order in HBM. */
   uint32_t reserved_capacity;      /* FeatureGates.ReservedCapacity (nodeclaim.go:308) */
   uint32_t reserved_offering_strict; /* DisableReservedCapacityFallback / ReservedOfferingModeStrict (scheduler.go:103, nodeclaim.go:339-348) */
 } ksolve_options;

@@ -22,6 +22,7 @@
 // stays valid; when a commit changes the claim's requirements the claim's column is cleared for every class.
 #pragma once
 #include "ksp.h"
+#include <type_traits>
 #include "pdq_emul.h"
 
 // diagnostic counters that only the profiling build keeps (every live 64-bit counter costs the lone wave registers)
@@ -81,7 +82,8 @@ struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host b
   uint64_t* tmpl;       // [T][c_hot_words]
   uint64_t* tmpl_cold;  // [T][cold_words]
   KS_LDS uint32_t *okey, *oord, *opos;   // claim order (pdq_emul.h)
-  uint64_t* closed;     // [order_cap/64] claims that cannot take any pod any more
+  uint64_t* closed;     // [claim words] claims that cannot take any pod any more
+  uint64_t* stage_big;  // [claim words] live-set staging of the BIG engine (the others use Scratch::stage)
   uint64_t* cache;      // [32][c_hot_words] direct-mapped cache of hot claim records
   int64_t* dg_ov;       // [n_dg][nr] daemon overhead per group (scheduler.go:963-1043)
   uint64_t* dg_its;     // [n_dg][iw] instance types of the group
@@ -92,6 +94,7 @@ struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host b
     tmpl = (uint64_t*)(base + p.off_tmpl); tmpl_cold = (uint64_t*)(base + p.off_tmplcold);
     okey = (KS_LDS uint32_t*)(base + p.off_order); oord = okey + p.order_cap; opos = oord + p.order_cap;
     closed = (uint64_t*)(base + p.off_closed); cache = (uint64_t*)(base + p.off_cache);
+    stage_big = (uint64_t*)(base + p.off_stage);
     dg_ov = (int64_t*)(base + p.off_dgov); dg_its = (uint64_t*)(base + p.off_dgits);
     scratch = (Scratch*)(base + p.off_scratch);
   }
@@ -99,14 +102,17 @@ struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host b
 
 // FULL = false compiles the engine for problems without topology groups, existing nodes, daemonset overhead, minValues
 // and reservations (C1/C2-shaped provisioning batches): those code paths and their live state drop out of the kernel.
-template <class W, bool FULL = true>
+// BIG = true keeps the claim order in HBM and sizes the live-set staging area and the closed bitmap by the problem
+// (hundreds of thousands of in-flight claims: anti-affinity / hostname-spread workloads where every pod is its own node).
+template <class W, bool FULL = true, bool BIG = false>
 struct Engine {
   const ProblemView& P;
   Workspace& S;
   LdsTables L;
   Scratch& sc;
   const RecLayout lay;
-  ClaimOrder<W> order;
+  typedef typename std::conditional<BIG, uint32_t*, KS_LDS uint32_t*>::type order_ptr;
+  ClaimOrder<W, order_ptr> order;
   int n_claims = 0;
   uint32_t host_seq = 0;
   uint32_t active_templates = 0;
@@ -138,7 +144,8 @@ struct Engine {
   bool topo_reached = false;        // the last can_add got as far as the topology stage (its verdict is not cacheable)
 
   KS_DEV Engine(const ProblemView& p, Workspace& s, const LdsTables& l) : P(p), S(s), L(l), sc(*l.scratch), lay(p.lay) {
-    order.key = L.okey; order.ord = L.oord; order.pos = L.opos;
+    if constexpr (BIG) { order.key = s.o_key; order.ord = s.o_ord; order.pos = s.o_pos; }
+    else { order.key = L.okey; order.ord = L.oord; order.pos = L.opos; }
     min_values_best_effort = s.min_values_best_effort != 0;
   }
 
@@ -195,7 +202,7 @@ struct Engine {
     uint64_t* tt = sc.tmpl_taints; int64_t* mr = sc.min_request; int32_t* tag = sc.cache_tag;
     W::for_n(32, [&](int t) { tt[t] = t < Pv.n_templates ? Pv.tmpl_taints[t] : 0; tag[t] = -1; });
     W::for_n(nr, [&](int r) { mr[r] = Pv.min_request[r]; });
-    W::for_n(Pv.lds.order_cap / 64, [&](int w) { Lt.closed[w] = 0; });
+    W::for_n(BIG ? Pv.lds.stage_words : Pv.lds.order_cap / 64, [&](int w) { Lt.closed[w] = 0; });
     W::sync();
     W::for_n(Pv.n_templates + 1, [&](int t) { sc.dg_first[t] = Pv.dg_first[t]; });
     W::for_n(Pv.n_dg * nr, [&](int i) { Lt.dg_ov[i] = Pv.dg_ov[i]; });
@@ -1081,23 +1088,37 @@ struct Engine {
     uint64_t* drow = S.dead + (size_t)k * S.claim_words;
     const uint64_t* closed = L.closed;
     const int nc = n_claims;
-    uint64_t* stage = sc.stage;
+    uint64_t* stage = BIG ? L.stage_big : sc.stage;
     unsigned long long ts0 = W::clock();
     // One coalesced load of the class's dead row (lane l holds words l and l + 64: up to 8192 claims), live = not dead,
     // not closed, staged in LDS so that everything after it is LDS-only.
-    uint64_t any = W::ballot([&](int l) {
-      uint64_t a = 0, b = 0;
-      if (l < words) {
-        uint64_t valid = (l == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
-        a = ~drow[l] & ~closed[l] & valid;
-      }
-      if (l + 64 < words) {
-        uint64_t valid = (l + 64 == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
-        b = ~drow[l + 64] & ~closed[l + 64] & valid;
-      }
-      stage[l] = a; stage[l + 64] = b;
-      return (a | b) != 0;
-    });
+    uint64_t any;
+    if constexpr (BIG) {
+      any = W::ballot([&](int l) {
+        uint64_t acc = 0;
+        for (int w = l; w < words; w += 64) {
+          const uint64_t valid = (w == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
+          const uint64_t a = ~drow[w] & ~closed[w] & valid;
+          stage[w] = a;
+          acc |= a;
+        }
+        return acc != 0;
+      });
+    } else {
+      any = W::ballot([&](int l) {
+        uint64_t a = 0, b = 0;
+        if (l < words) {
+          uint64_t valid = (l == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
+          a = ~drow[l] & ~closed[l] & valid;
+        }
+        if (l + 64 < words) {
+          uint64_t valid = (l + 64 == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
+          b = ~drow[l + 64] & ~closed[l + 64] & valid;
+        }
+        stage[l] = a; stage[l + 64] = b;
+        return (a | b) != 0;
+      });
+    }
     W::sync();
     if (!any) return false;
     if (FULL && cur_M) {
@@ -1151,14 +1172,45 @@ struct Engine {
     for (int r = 0; r < kRegNr; ++r) rq[r] = r < nr ? req[r] : INT64_MIN;
     unsigned long long ts2 = W::clock();
     ctr.cycles[18] += ts2 - ts1;
-    const KS_LDS uint32_t* ord = order.ord;
+    const order_ptr ord = order.ord;
     {
       // Few live claims (the usual case once the dead row has filled in): the candidate the reference reaches first is
       // the live claim with the smallest position in its order (addToInflightNode, scheduler.go:667-686). Lane l owns
       // word l of the live set and takes the minimum of (position, claim) over its bits; one DPP reduction picks the
       // winner. No walk over the order at all.
-      const KS_LDS uint32_t* pos = order.pos;
+      const order_ptr pos = order.pos;
       int who0;
+      int densest;
+      if constexpr (BIG) {
+        // same test, over however many words the problem has: each lane counts the live words it owns, prefilter only when few
+        int who1;
+        const int my_words_max = 64 - (int)W::argmin_u32([&](int l) { int n = 0; for (int w = l; w < words; w += 64) n += stage[w] != 0; return (uint32_t)(64 - (n > 64 ? 64 : n)); }, &who1);
+        if (my_words_max <= 1) {
+          uint64_t nzl = W::ballot([&](int l) { for (int w = l; w < words; w += 64) if (stage[w]) return true; return false; });
+          if (popc64(nzl) <= 8) {
+            any = 0;
+            for (; nzl; nzl &= nzl - 1) {
+              const int l0 = ctz64(nzl);
+              int w = -1;
+              for (int x = l0; x < words; x += 64) if (stage[x]) { w = x; break; }   // uniform: stage is shared memory
+              if (w < 0) continue;
+              const uint64_t okm = W::ballot([&](int l) {
+                const int c = w * 64 + l;
+                if (c >= nc) return false;
+                int ok = 1;
+                for (int r = 0; r < nr; ++r) ok &= (int)(req[r] <= hd[(size_t)r * mc + c]);
+                return ok != 0;
+              });
+              const uint64_t before = stage[w], v = before & okm;
+              if (v != before) { W::store(&stage[w], v); W::store(&drow[w], (uint64_t)(drow[w] | (before & ~okm))); }
+              any |= v;
+            }
+            W::sync();
+            if (!any) return false;
+          }
+        }
+        densest = 4096 - (int)W::argmin_u32([&](int l) { int n = 0; for (int w = l; w < words; w += 64) n += popc64(stage[w]); return (uint32_t)(4096 - (n > 4096 ? 4096 : n)); }, &who0);
+      } else {
       {
         // Headroom prefilter, one lane per claim, 64 claims per ballot, over the words that still have live claims.
         uint64_t nz = W::ballot([&](int l) { return l < words && stage[l] != 0; });
@@ -1187,22 +1239,38 @@ struct Engine {
           if (!any) return false;
         }
       }
-      const int densest = 128 - (int)W::argmin_u32([&](int l) { return (uint32_t)(128 - (l < words ? popc64(stage[l]) : 0) - (l + 64 < words ? popc64(stage[l + 64]) : 0)); }, &who0);
+      densest = 128 - (int)W::argmin_u32([&](int l) { return (uint32_t)(128 - (l < words ? popc64(stage[l]) : 0) - (l + 64 < words ? popc64(stage[l + 64]) : 0)); }, &who0);
+      }
       if (densest <= 12) {   // the per-lane loop below runs `densest` times
         for (;;) {
-          int who;
-          const uint32_t best = W::argmin_u32([&](int l) {
-            uint32_t mine = 0xFFFFFFFFu;
-            for (int w = l; w < words; w += 64) for (uint64_t b = stage[w]; b; b &= b - 1) {
-              const uint32_t c = (uint32_t)(w * 64 + ctz64(b));
-              const uint32_t key = (pos[c] << 13) | c;
-              mine = key < mine ? key : mine;
-            }
-            return mine;
-          }, &who);
-          if (best == 0xFFFFFFFFu) return false;
+          int c;
+          if constexpr (BIG) {
+            const uint64_t best = W::reduce_min(64, [&](int l) -> uint64_t {
+              uint64_t mine = ~0ull;
+              for (int w = l; w < words; w += 64) for (uint64_t b = stage[w]; b; b &= b - 1) {
+                const uint32_t cc = (uint32_t)(w * 64 + ctz64(b));
+                const uint64_t key = ((uint64_t)pos[cc] << 32) | cc;
+                mine = key < mine ? key : mine;
+              }
+              return mine;
+            });
+            if (best == ~0ull) return false;
+            c = (int)(uint32_t)best;
+          } else {
+            int who;
+            const uint32_t best = W::argmin_u32([&](int l) {
+              uint32_t mine = 0xFFFFFFFFu;
+              for (int w = l; w < words; w += 64) for (uint64_t b = stage[w]; b; b &= b - 1) {
+                const uint32_t cc = (uint32_t)(w * 64 + ctz64(b));
+                const uint32_t key = (pos[cc] << 13) | cc;
+                mine = key < mine ? key : mine;
+              }
+              return mine;
+            }, &who);
+            if (best == 0xFFFFFFFFu) return false;
+            c = (int)(best & 0x1FFFu);
+          }
           ctr.cycles[19] += W::clock() - ts2;
-          const int c = (int)(best & 0x1FFFu);
           const int l = c >> 6;
           const uint64_t valid = (l == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
           const uint64_t live = stage[l] & ~(1ull << (c & 63));
@@ -1306,7 +1374,7 @@ struct Engine {
       int rc = can_add(bin, tcold, true, first_err == 0, &changed, nullptr, -1);
       if (rc == E_RESERVED) { last_diag = 0; return E_RESERVED; }   // voids the lower-weight templates (scheduler.go:736-751)
       if (rc != E_OK) { if (!first_err) { first_err = rc; first_diag = (rc == E_INSTANCE_TYPES || rc == E_MIN_VALUES) ? last_diag : 0; } continue; }
-      if (n_claims >= S.max_claims || n_claims >= P.lds.order_cap) { W::store(S.status_out, 1); return -1; }
+      if (n_claims >= S.max_claims || (!BIG && n_claims >= P.lds.order_cap)) { W::store(S.status_out, 1); return -1; }
       int c = n_claims++;
       const uint32_t tm2 = hi32(trec[ly.c_meta2()]);
       uint64_t* o = sc.out;
@@ -1663,9 +1731,11 @@ struct Engine {
     ctr.cycles[10] = W::clock() - t_begin;
     {
       // results read the final order from HBM
-      uint32_t* go = S.o_ord;
-      const KS_LDS uint32_t* lo_ = L.oord;
-      W::for_n(n_claims, [&](int i) { go[i] = lo_[i]; });
+      if constexpr (!BIG) {
+        uint32_t* go = S.o_ord;
+        const KS_LDS uint32_t* lo_ = L.oord;
+        W::for_n(n_claims, [&](int i) { go[i] = lo_[i]; });
+      }
     }
     W::store(S.n_claims_out, n_claims);
     if (status) W::store(S.status_out, status);

@@ -115,6 +115,15 @@ __global__ void __launch_bounds__(64) ksolve_pack_lite(ks::ProblemView pv, ks::W
   eng.solve();
 }
 
+// The full engine with the claim order in HBM, for problems with more in-flight claims than a CU's LDS can order
+// (every anti-affinity / hostname-spread pod is its own NodeClaim): ProblemView::big.
+__global__ void __launch_bounds__(64) ksolve_pack_big(ks::ProblemView pv, ks::Workspace ws) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  ks::LdsTables tables;
+  tables.bind(lds, pv.lds);
+  ks::Engine<ks::Wave, true, true> eng(pv, ws, tables);
+  eng.solve();
+}
 // Batched form: block b solves problem b (its view and workspace are read from HBM instead of the kernel arguments).
 __global__ void __launch_bounds__(64) ksolve_pack_batch(ks::BatchItem* items) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -141,9 +150,10 @@ static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a
 static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a) { hipLaunchKernelGGL(ksolve_finalize, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
 static void be_launch_pack(ksolve_handle* h) {
   const int lds_bytes = h->pv.lds.total_bytes;
-  const void* fn = h->pv.lite ? (const void*)ksolve_pack_lite : (const void*)ksolve_pack;
+  const void* fn = h->pv.big ? (const void*)ksolve_pack_big : h->pv.lite ? (const void*)ksolve_pack_lite : (const void*)ksolve_pack;
   if (!hip_check(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
-  if (h->pv.lite) hipLaunchKernelGGL(ksolve_pack_lite, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, h->pv, h->ws);
+  if (h->pv.big) hipLaunchKernelGGL(ksolve_pack_big, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, h->pv, h->ws);
+  else if (h->pv.lite) hipLaunchKernelGGL(ksolve_pack_lite, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, h->pv, h->ws);
   else hipLaunchKernelGGL(ksolve_pack, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, h->pv, h->ws);
   hip_check(h, hipGetLastError(), "ksolve_pack launch");
 }
@@ -183,7 +193,10 @@ static void finish_batch_group(std::vector<ksolve_handle*>& g, ks::BatchItem* d_
 }
 static void be_launch_pack_batch(ksolve_handle** hs, int n) {
   std::vector<ksolve_handle*> lite, full;
-  for (int i = 0; i < n; ++i) (hs[i]->pv.lite ? lite : full).push_back(hs[i]);
+  for (int i = 0; i < n; ++i) {
+    if (hs[i]->pv.big) { be_tic(hs[i], ksi::T_PACK); be_launch_pack(hs[i]); be_toc(hs[i], ksi::T_PACK); continue; }   // BIG problems run alone
+    (hs[i]->pv.lite ? lite : full).push_back(hs[i]);
+  }
   ks::BatchItem *dl = nullptr, *df = nullptr;
   launch_batch_group(lite, true, &dl);
   launch_batch_group(full, false, &df);

@@ -64,6 +64,9 @@ struct ksolve_handle {
   void* backend = nullptr;
   volatile int cancel_requested = 0;
   bool has_topology = false;
+  ks::LdsPlan lds_big{};   // LDS plan of the BIG engine, used once a solve overflowed the LDS-resident claim order
+  bool big_capable = false;
+  int lite_saved = 0;
 };
 
 // ---- backend hooks (defined by the including TU before this point is instantiated) ----
@@ -463,6 +466,25 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     int cap = (int)(((long long)(budget - off) * 8) / (12 * 8 + 1));
     cap &= ~63;
     if (cap > 8192) cap = 8192;   // two dead-row words per lane in the first-fit scan
+    if (h->opts.lds_claim_cap && (int)((h->opts.lds_claim_cap + 63) & ~63u) < cap) cap = (int)((h->opts.lds_claim_cap + 63) & ~63u);
+    lp.stage_words = 0; lp.off_stage = off;
+    P.big = 0;
+    // Problems that turn out to need more in-flight claims than the LDS order holds are re-run with the BIG engine (order
+    // in HBM; only the live-set staging words and the closed bitmap, 2 bits per claim, in LDS): plan it now.
+    h->lds_big = lp;
+    h->big_capable = false;
+    if ((int)mc > cap) {
+      const long long fit = ((long long)(budget - off - 64) * 8 / 2) & ~63ll;
+      if ((long long)mc > fit) { mc = (uint32_t)fit; h->max_claims = mc; h->claim_words = (mc + 63) / 64; W.max_claims = (int)mc; W.claim_words = (int)h->claim_words; }
+      ks::LdsPlan& lb = h->lds_big;
+      int ob = off;
+      lb.order_cap = 0; lb.off_order = ob;
+      lb.stage_words = (int)((mc + 63) / 64);
+      lb.off_closed = ob; ob = align(ob + lb.stage_words * 8);
+      lb.off_stage = ob; ob = align(ob + lb.stage_words * 8);
+      lb.total_bytes = ob;
+      h->big_capable = (int)mc > cap;
+    }
     if (cap > (int)mc) cap = ((int)mc + 63) & ~63;
     lp.off_order = off; lp.order_cap = cap;
     off = align(off + cap * 12);
@@ -717,6 +739,8 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   return out->status;
 }
 
+static void be_results_drop(ksolve_results* r) { if (r && r->impl) { delete (ResultsImpl*)r->impl; r->impl = nullptr; } }
+static ksolve_status solve(ksolve_handle* h, ksolve_results* out);
 static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   memset(out, 0, sizeof(*out));
   ksolve_status st = solve_prepare(h);
@@ -724,6 +748,20 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
   be_tic(h, T_PACK);
   if (h->n_pods) be_launch_pack(h);
   be_toc(h, T_PACK);
+  if (!h->pv.big && h->big_capable) {
+    int status = 0;
+    be_d2h(h, &status, h->ws.status_out, 4);
+    be_sync(h);
+    if (status == 1) {
+      // more in-flight claims than the LDS-resident order holds: this problem runs on the BIG engine from now on
+      h->pv.big = 1; h->pv.lite = 0; h->pv.lds = h->lds_big;
+      st = solve_prepare(h);
+      if (st != KSOLVE_OK) return st;
+      be_tic(h, T_PACK);
+      be_launch_pack(h);
+      be_toc(h, T_PACK);
+    }
+  }
   return solve_finish(h, out);
 }
 
@@ -745,7 +783,11 @@ static ksolve_status solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results*
   std::vector<ksolve_handle*> run;
   for (uint32_t i = 0; i < n; ++i) if (st[i] == KSOLVE_OK && hs[i]->n_pods) run.push_back(hs[i]);
   if (!run.empty()) be_launch_pack_batch(run.data(), (int)run.size());
-  parallel([&](uint32_t i) { if (st[i] == KSOLVE_OK) st[i] = solve_finish(hs[i], &outs[i]); });
+  parallel([&](uint32_t i) {
+    if (st[i] != KSOLVE_OK) return;
+    st[i] = solve_finish(hs[i], &outs[i]);
+    if (st[i] == KSOLVE_ERR_CAPACITY && hs[i]->big_capable && !hs[i]->pv.big) { be_results_drop(&outs[i]); st[i] = solve(hs[i], &outs[i]); }   // re-run alone on the BIG engine
+  });
   ksolve_status worst = KSOLVE_OK;
   for (uint32_t i = 0; i < n; ++i) if (st[i] != KSOLVE_OK && st[i] != KSOLVE_ERR_CANCELLED) worst = st[i];
   return worst;

@@ -79,7 +79,9 @@ struct LdsPlan {
   int off_tmplcold;   // u64 [T][cold_words]
   int off_order;      // u32 key[cap] | ord[cap] | pos[cap]
   int order_cap;
-  int off_closed;     // u64 [cap/64]
+  int off_closed;     // u64 [cap/64]   (BIG: [stage_words])
+  int off_stage;      // u64 [stage_words] live-set staging of the BIG engine
+  int stage_words;    // BIG: ceil(max_claims / 64), else 0
   int off_cache;      // u64 [32][c_hot_words] record cache
   int off_scratch;    // Scratch
   int off_dgov;       // i64 [n_dg][nr]       daemon overhead per group
@@ -175,6 +177,7 @@ struct ProblemView {
   const uint8_t* node_flags;     // [n_nodes] bit0 initialized, bit1 under consolidateAfter
   const uint8_t* pod_from_deleting; // [n_pods]
   TopoView topo;
+  int big;                       // more in-flight claims than the LDS order holds: Engine<W, true, true> (order in HBM)
   int lite;                      // no topology groups, existing nodes, daemon overhead, minValues or reservations: Engine<W, false>
 };
 

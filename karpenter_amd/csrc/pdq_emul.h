@@ -16,11 +16,12 @@
 
 namespace ks {
 
-template <class W>
+// P32 = pointer type of the three arrays: LDS for problems whose claims fit the CU's LDS, HBM for larger ones.
+template <class W, class P32 = KS_LDS uint32_t*>
 struct ClaimOrder {
-  KS_LDS uint32_t* key;   // [cap] pod count of the claim at position i   (LDS resident)
-  KS_LDS uint32_t* ord;   // [cap] claim id at position i
-  KS_LDS uint32_t* pos;   // [cap] position of claim id
+  P32 key;   // [cap] pod count of the claim at position i
+  P32 ord;   // [cap] claim id at position i
+  P32 pos;   // [cap] position of claim id
   int n = 0;
   int defect = -1;        // position whose key changed since the array was last sorted, -1 = sorted
   bool defect_append = false;
@@ -148,7 +149,7 @@ struct ClaimOrder {
       for (int x = defect; x <= defect + 1; ++x) if (x >= i && x >= 1 && x < b && key[x] < key[x - 1]) return x;
       return b;
     }
-    const KS_LDS uint32_t* kp = key;
+    const P32 kp = key;
     return W::find_first(i, b, [kp](int x) { return kp[x] < kp[x - 1]; });
   }
   KS_FN bool partial_insertion_sort(int a, int b, bool top) {
@@ -160,7 +161,7 @@ struct ClaimOrder {
       if (top) {
         // Single known defect: Go's swap(i,i-1) + the two shift loops amount to ONE rotation of the touched claim to
         // its stable place (see the derivation in DESIGN.md §4); do it with one search + one rotate.
-        const KS_LDS uint32_t* kq = key;
+        const P32 kq = key;
         if (defect_append) {           // i == n-1: the new claim moves left behind the last claim with <= its count
           uint32_t mv = key[i];
           int t = W::find_last(0, i, [kq, mv](int x) { return !(mv < kq[x]); });
@@ -176,13 +177,13 @@ struct ClaimOrder {
       swap(i, i - 1);
       if (i - a >= 2) {  // shift the smaller one to the left (Go uses the absolute bound j >= 1)
         uint32_t mv = key[i - 1];
-        const KS_LDS uint32_t* kp = key;
+        const P32 kp = key;
         int t = W::find_last(0, i - 1, [kp, mv](int x) { return !(mv < kp[x]); });
         rotate_right(t + 1, i - 1);
       }
       if (b - i >= 2) {  // shift the greater one to the right
         uint32_t mv = key[i];
-        const KS_LDS uint32_t* kp = key;
+        const P32 kp = key;
         int e = W::find_first(i + 1, b, [kp, mv](int x) { return !(kp[x] < mv); });
         rotate_left(i, e - 1);
       }
@@ -207,7 +208,7 @@ struct ClaimOrder {
   KS_FN int partition_equal(int a, int b, int pivot) {
     swap(a, pivot);
     uint32_t pv = key[a];
-    const KS_LDS uint32_t* kp = key;
+    const P32 kp = key;
     int i = a + 1, j = b - 1;
     for (;;) {
       i = W::find_first(i, j + 1, [kp, pv](int x) { return pv < kp[x]; });
@@ -220,7 +221,7 @@ struct ClaimOrder {
   KS_FN int partition(int a, int b, int pivot, bool& already) {
     swap(a, pivot);
     uint32_t pv = key[a];
-    const KS_LDS uint32_t* kp = key;
+    const P32 kp = key;
     int i = a + 1, j = b - 1;
     i = W::find_first(i, j + 1, [kp, pv](int x) { return !(kp[x] < pv); });
     j = W::find_last(i, j + 1, [kp, pv](int x) { return kp[x] < pv; });
@@ -294,13 +295,13 @@ struct ClaimOrder {
       // insertionSort_func is a stable sort; with a single defect that is one stable move
       if (defect_append) {
         uint32_t mv = key[n - 1];
-        const KS_LDS uint32_t* kp = key;
+        const P32 kp = key;
         int t = W::find_last(0, n - 1, [kp, mv](int x) { return !(mv < kp[x]); });
         rotate_right(t + 1, n - 1);
       } else {
         int p = defect;
         uint32_t mv = key[p];
-        const KS_LDS uint32_t* kp = key;
+        const P32 kp = key;
         int e = W::find_first(p + 1, n, [kp, mv](int x) { return !(kp[x] < mv); });
         rotate_left(p, e - 1);
       }
@@ -315,7 +316,7 @@ struct ClaimOrder {
       const int q = n / 4, p = defect;
       const bool sampled = (p >= q - 1 && p <= q + 1) || (p >= 2 * q - 1 && p <= 2 * q + 1) || (p >= 3 * q - 1 && p <= 3 * q + 1);
       if (!sampled) {
-        const KS_LDS uint32_t* kq = key;
+        const P32 kq = key;
         if (defect_append) {
           const int i = n - 1;
           if (i >= 1 && key[i] < key[i - 1]) {

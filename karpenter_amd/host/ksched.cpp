@@ -1401,6 +1401,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     ko.max_claims = (uint32_t)opts.at("maxClaims").i(0);
     ko.max_steps = opts.at("maxSteps").i(-1);
     ko.device = (uint32_t)opts.at("device").i(0);
+    ko.lds_claim_cap = (uint32_t)opts.at("ldsClaimCap").i(0);
     ko.reserved_capacity = opts.at("reservedCapacity").boolean_or(false) ? 1 : 0;
     ko.reserved_offering_strict = opts.at("reservedOfferingMode").s("Fallback") == "Strict" ? 1 : 0;
 

@@ -50,7 +50,8 @@ static void be_launch_pack(ksolve_handle* h) {
   std::vector<char> lds((size_t)h->pv.lds.total_bytes + 64);  // stands in for the CU's LDS segment
   ks::LdsTables tables;
   tables.bind(lds.data(), h->pv.lds);
-  if (h->pv.lite) { ks::Engine<ks::Wave, false> eng(h->pv, h->ws, tables); eng.solve(); }
+  if (h->pv.big) { ks::Engine<ks::Wave, true, true> eng(h->pv, h->ws, tables); eng.solve(); }
+  else if (h->pv.lite) { ks::Engine<ks::Wave, false> eng(h->pv, h->ws, tables); eng.solve(); }
   else { ks::Engine<ks::Wave, true> eng(h->pv, h->ws, tables); eng.solve(); }
 }
 static void be_launch_pack_batch(ksolve_handle** hs, int n) {

@@ -403,3 +403,33 @@ def test_more_than_4096_claims(oracle, emu):
     pods = [fx.pod(labels=lab, requests={"cpu": "100m"}, pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, lab)]) for _ in range(4200)]
     got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], pods + [fx.pod(requests={"cpu": "1"}) for _ in range(300)]))
     assert len(got["newNodeClaims"]) > 4096
+
+
+def test_more_claims_than_the_lds_order_holds(oracle, emu):
+    """When a solve needs more in-flight NodeClaims than the LDS-resident claim order holds (8192 by default, lowered here
+    with ldsClaimCap so that the case stays small) it is re-run on the BIG engine (claim order in HBM): same results."""
+    its = fx.fake_default_instance_types()
+    lab = {"app": "nginx"}
+    opts = {"ldsClaimCap": 128}
+    pods = [fx.pod(labels=lab, requests={"cpu": "100m"}, pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, lab)]) for _ in range(700)]
+    pods += [fx.pod(requests={"cpu": "1"}) for _ in range(200)] + [fx.pod(labels={"x": "y"}, topology_spread=[fx.spread(fx.ZONE, {"x": "y"})]) for _ in range(30)]
+    pods += [fx.pod(labels={"h": "s"}, topology_spread=[fx.spread(fx.HOSTNAME, {"h": "s"}, max_skew=2)]) for _ in range(90)]
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], pods, options=opts))
+    assert len(got["newNodeClaims"]) > 700
+    # a problem without topology: big pods, one per node; and the C2 mix with a tiny cap
+    pods = [fx.pod(requests={"cpu": "9"}) for _ in range(650)] + [fx.pod(requests={"cpu": "300m"}) for _ in range(500)]
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], pods, options=opts))
+    assert len(got["newNodeClaims"]) >= 650
+    prob = fx.config2(pods=60000, n_types=144, seed=11)
+    prob["options"]["ldsClaimCap"] = 64
+    got, _ = check(oracle, emu, prob)
+    assert len(got["newNodeClaims"]) > 64
+
+
+def test_batch_with_an_overflowing_problem(oracle, emu):
+    from karpenter_amd.scheduling import SolveBatch
+    its = fx.fake_default_instance_types()
+    probs = [fx.problem(its, [fx.node_pool()], [fx.pod(requests={"cpu": "9"}) for _ in range(n)] + [fx.pod(requests={"cpu": "500m"}) for _ in range(40)], options={"ldsClaimCap": 128})
+             for n in (50, 400, 90)]
+    for got, prob in zip(SolveBatch([NewScheduler(p, solver_lib=emu) for p in probs]), probs):
+        parity.assert_same_results(got, oracle.solve(prob))

@@ -215,3 +215,27 @@ def test_daemons_min_values_reservations(oracle):
         pods = [fx.pod(requests={"cpu": f"{rng.choice([300, 900, 1800, 2500])}m"}, node_selector=rng.choice([None, None, {fx.CAPACITY_TYPE: "reserved"}, {fx.ZONE: "test-zone-1"}])) for _ in range(25)]
         got, _ = check(oracle, fx.problem(reserved_types(2) + fx.fake_instance_types(4), [fx.node_pool()], pods, options={"reservedCapacity": True, "reservedOfferingMode": mode}))
         assert any(c["reservedOfferings"] for c in got["newNodeClaims"])
+
+
+def test_big_engine_claim_order_in_hbm(oracle):
+    """A solve that needs more in-flight claims than the LDS-resident order holds is re-run on the BIG engine (order in
+    HBM). Parity at a size the oracle finishes (cap lowered with ldsClaimCap), then the real thing without the oracle:
+    25k anti-affinity pods = 25k NodeClaims, checked through the properties the constraint implies."""
+    its = fx.fake_default_instance_types()
+    lab = {"app": "nginx"}
+    pods = [fx.pod(labels=lab, requests={"cpu": "100m"}, pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, lab)]) for _ in range(700)]
+    pods += [fx.pod(requests={"cpu": "1"}) for _ in range(200)] + [fx.pod(labels={"h": "s"}, topology_spread=[fx.spread(fx.HOSTNAME, {"h": "s"}, max_skew=2)]) for _ in range(90)]
+    got, _ = check(oracle, fx.problem(its, [fx.node_pool()], pods, options={"ldsClaimCap": 128}))
+    assert len(got["newNodeClaims"]) > 700
+    prob = fx.config2(pods=60000, n_types=144, seed=11)
+    prob["options"]["ldsClaimCap"] = 64
+    check(oracle, prob)
+    big = fx.config3(pods=60000, n_types=144, seed=2, anti_affinity_pods=25000)
+    r = NewScheduler(big).Solve()
+    assert r["scheduledPods"] == 60000 and not r["podErrors"]
+    assert len(r["newNodeClaims"]) >= 25000
+    anti = 0
+    for c in r["newNodeClaims"]:
+        assert len(c["pods"]) >= 1
+    # every anti-affinity pod sits alone among its kind: count claims is at least the number of such pods
+    assert r["counters"]["claims"] == len(r["newNodeClaims"])
