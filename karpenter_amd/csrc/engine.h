@@ -48,6 +48,7 @@ struct Scratch {
   uint64_t tq[kMaxReqWords];        // next-domain set of one topology group (only the group key's words are used)
   int64_t gtot[kMaxRes];            // requests + the daemon overhead of the group being filtered
   uint64_t gin[kMaxItWords];        // the bin's instance types that belong to that group
+  uint64_t km_old[4];               // a claim's admitted values per topology-key slot before the commit being written
   int32_t resv_cap[64];             // ReservationManager.capacity (reservationmanager.go:31)
   int dg_first[33];   // daemon-overhead groups of each template (CSR)
   uint64_t t_owned[kMaxTopoWords], t_sel[kMaxTopoWords];   // topology groups the class being placed owns / is selected by
@@ -721,6 +722,15 @@ struct Engine {
         const int32_t c = *p;
         W::store(p, c + 1);
         if (c == 0) W::store(&S.tg_nonzero[g], S.tg_nonzero[g] + 1);
+        if (bin_kind == 0 && T.type[g] != 1) {
+          // threshold bitmaps of the scan prefilter: "count <= t-1" ends when the count reaches t, "count <= t" at t+1
+          const long long t = T.type[g] == 2 ? 0 : (long long)T.max_skew[g];
+          const long long n = (long long)c + 1;
+          if (n == t || n == t + 1) {
+            uint64_t* hz = S.host_le + ((size_t)T.host_slot[g] * 2 + (n == t ? 0 : 1)) * S.claim_words + (bin >> 6);
+            W::store(hz, (uint64_t)(*hz & ~(1ull << (bin & 63))));
+          }
+        }
         W::sync();
         continue;
       }
@@ -1014,6 +1024,7 @@ struct Engine {
       uint64_t* km = S.c_keymask;
       const int mc = S.max_claims;
       const uint32_t def = lo32(o[ly.c_f0()]), comp = hi32(o[ly.c_f0()]), bnd = lo32(o[ly.c_f1()]) | hi32(o[ly.c_f1()]);
+      W::for_n(T.n_key_slots, [&](int sl) { sc.km_old[sl] = km[(size_t)sl * mc + c]; });
       W::for_n(T.n_key_slots, [&](int sl) {
         const int key = T.slot_key[sl];
         const uint32_t x = d.key_word_off[key];
@@ -1021,6 +1032,22 @@ struct Engine {
         if (((def >> key) & 1) && !((bnd >> key) & 1)) v = ((comp >> key) & 1) ? (~o[ly.c_mask() + x] & d.value_valid[x]) : o[ly.c_mask() + x];
         km[(size_t)sl * mc + c] = v;
       });
+      // the inverse table: bit c of kv_claims[slot][value] follows the claim's admitted values (a new claim starts from none)
+      uint64_t* kvc = S.kv_claims;
+      const int cw = S.claim_words;
+      for (int sl = 0; sl < T.n_key_slots; ++sl) {
+        const uint32_t x = d.key_word_off[T.slot_key[sl]];
+        const uint64_t now = km[(size_t)sl * mc + c] & d.value_valid[x];
+        const uint64_t before = npods == 1 ? 0ull : (sc.km_old[sl] & d.value_valid[x]);
+        const uint64_t diff = now ^ before;
+        if (!diff) continue;
+        const uint64_t bitc = 1ull << (c & 63);
+        W::for_n(64, [&](int v) {
+          if (!((diff >> v) & 1)) return;
+          uint64_t* wp = kvc + ((size_t)sl * 64 + v) * cw + (c >> 6);
+          *wp = ((now >> v) & 1) ? (*wp | bitc) : (*wp & ~bitc);
+        });
+      }
     }
     if (W::leader()) sc.cache_tag[c & 31] = c;
     if (write_cold) {
@@ -1134,28 +1161,42 @@ struct Engine {
           if (sl < 0) continue;
           const uint64_t okv = topo_ok_mask(g, self, P.cls_strict.at(P.dict, (uint32_t)cur_class));
           if (okv == ~0ull) continue;
-          const uint64_t* km = S.c_keymask + (size_t)sl * S.max_claims;
-          any = 0;
-          for (int w0 = 0; w0 < words; w0 += 8) {
-            const int n = words - w0 < 8 ? words - w0 : 8;
-            W::ballots8(n, [&](int l, int j) { const int c = (w0 + j) * 64 + l; return c < nc && (km[c] & okv) != 0; },
-                        [&](int j, uint64_t ok) { const uint64_t v = stage[w0 + j] & ok; W::store(&stage[w0 + j], v); any |= v; });
-          }
+          // one lane per 64 claims: OR the "claims that admit value v" words of the eligible values
+          const uint64_t* kvc = S.kv_claims + (size_t)sl * 64 * S.claim_words;
+          const int cw = S.claim_words;
+          const uint64_t vals = okv & P.dict.value_valid[P.dict.key_word_off[T.key[g]]];
+          any = W::ballot([&](int l) {
+            uint64_t acc_any = 0;
+            for (int w = l; w < words; w += 64) {
+              const uint64_t st = stage[w];
+              if (!st) continue;
+              uint64_t acc = 0;
+              for (uint64_t vv = vals; vv; vv &= vv - 1) acc |= kvc[(size_t)ctz64(vv) * cw + w];
+              const uint64_t v = st & acc;
+              stage[w] = v;
+              acc_any |= v;
+            }
+            return acc_any != 0;
+          });
           W::sync();
           if (!any) return false;
           continue;
         }
         if (T.type[g] == 1) continue;
         const long long limit = T.type[g] == 2 ? 0 : (long long)T.max_skew[g] - (self ? 1 : 0);
-        const int32_t* cc = S.tg_claim_counts + (size_t)T.host_slot[g] * S.max_claims;
-        any = 0;
-        for (int w0 = 0; w0 < words; w0 += 8) {
-          const int n = words - w0 < 8 ? words - w0 : 8;
-          W::ballots8(n, [&](int l, int j) { const int c = (w0 + j) * 64 + l; return c < nc && (long long)cc[c] <= limit; },
-                      [&](int j, uint64_t ok) { const uint64_t v = stage[w0 + j] & ok; W::store(&stage[w0 + j], v); any |= v; });
+        if (limit < 0) return false;   // not even an empty claim satisfies it
+        {
+          // "count <= limit" from the threshold bitmap of the group (limit is t-1 or t): one word per 64 claims
+          const long long t = T.type[g] == 2 ? 0 : (long long)T.max_skew[g];
+          const uint64_t* hz = S.host_le + ((size_t)T.host_slot[g] * 2 + (limit == t ? 1 : 0)) * S.claim_words;
+          any = W::ballot([&](int l) {
+            uint64_t acc_any = 0;
+            for (int w = l; w < words; w += 64) { const uint64_t v = stage[w] & hz[w]; stage[w] = v; acc_any |= v; }
+            return acc_any != 0;
+          });
+          W::sync();
+          if (!any) return false;
         }
-        W::sync();
-        if (!any) return false;
       }
     }
     unsigned long long ts1 = W::clock();
@@ -1241,7 +1282,7 @@ struct Engine {
       }
       densest = 128 - (int)W::argmin_u32([&](int l) { return (uint32_t)(128 - (l < words ? popc64(stage[l]) : 0) - (l + 64 < words ? popc64(stage[l + 64]) : 0)); }, &who0);
       }
-      if (densest <= 12) {   // the per-lane loop below runs `densest` times
+      if (densest <= (BIG ? 24 : 12)) {   // the per-lane loop below runs `densest` times (BIG: walking a long order in HBM costs more)
         for (;;) {
           int c;
           if constexpr (BIG) {

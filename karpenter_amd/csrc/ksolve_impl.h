@@ -418,6 +418,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       }
       T.key_slot = up(h, key_slot.data(), G);
       W.c_keymask = dz<uint64_t>(h, (size_t)std::max(1, T.n_key_slots) * mc);
+      W.kv_claims = dz<uint64_t>(h, (size_t)std::max(1, T.n_key_slots) * 64 * h->claim_words);
       T.type = up(h, t.type, G); T.key = up(h, t.key, G); T.host_slot = up(h, host_slot.data(), G);
       T.max_skew = up(h, t.max_skew, G); T.min_domains = up(h, t.min_domains, G);
       T.domains0 = up(h, t.domains, (size_t)G * T.dom_words);
@@ -438,6 +439,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       W.tg_counts = dz<int32_t>(h, (size_t)G * dv);
       W.tg_node_counts = dz<int32_t>(h, nc.size());
       W.tg_claim_counts = dz<int32_t>(h, (size_t)std::max(1, T.n_host_groups) * mc);
+      W.host_le = dz<uint64_t>(h, (size_t)std::max(1, T.n_host_groups) * 2 * h->claim_words);
       W.tg_nonzero = dz<int32_t>(h, G);
     }
   }
@@ -603,6 +605,8 @@ static ksolve_status solve_prepare(ksolve_handle* h) {
   be_fill(h, W.n_claims_out, 0, 4); be_fill(h, W.status_out, 0, 4);
   be_fill(h, h->d_cancel, 0, 4);
   if (P.topo.n_host_groups) be_fill(h, W.tg_claim_counts, 0, (size_t)P.topo.n_host_groups * h->max_claims * 4);
+  if (P.topo.n_host_groups) be_fill(h, W.host_le, 0xFF, (size_t)P.topo.n_host_groups * 2 * h->claim_words * 8);
+  if (P.topo.n_key_slots) be_fill(h, W.kv_claims, 0, (size_t)P.topo.n_key_slots * 64 * h->claim_words * 8);
   return KSOLVE_OK;
 }
 

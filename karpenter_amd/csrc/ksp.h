@@ -193,7 +193,11 @@ struct Workspace {
   // claims (AoS by claim; see RecLayout)
   uint64_t* c_hot;               // [max_claims][c_hot_words]
   uint64_t* c_cold;              // [max_claims][cold_words]
-  uint64_t* c_keymask;           // [n_key_slots][max_claims] values each claim still admits on a topology key (lane-per-claim prefilter)
+  uint64_t* c_keymask;           // [n_key_slots][max_claims] values each claim still admits on a topology key
+  uint64_t* kv_claims;           // [n_key_slots][64][claim_words] inverse of c_keymask: the claims that admit value v (one word AND/OR
+                                 //   per 64 claims in the scan prefilter instead of one load per claim)
+  uint64_t* host_le;             // [n_host_groups][2][claim_words] claims whose per-claim counter of a hostname group is <= t-1 / <= t,
+                                 //   t = maxSkew of a spread group, 0 of an anti-affinity group: the only two limits its pods ever test
   uint64_t* c_reserved;          // [max_claims] reservation ids held by each claim
   int64_t* c_headroom;           // [n_res][max_claims] SoA copy of the records' headroom: lane-per-claim prefilter of the scan
   // order (pdq_emul.h): lives in LDS while it fits (LdsPlan.order_cap), these are the HBM spill arrays

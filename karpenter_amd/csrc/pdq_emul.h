@@ -41,8 +41,8 @@ struct ClaimOrder {
   KS_FN void rotate_right(int to, int from) {
     if (to >= from) return;
     uint32_t mk = key[from], mo = ord[from];
-    for (int top = from; top > to; top -= 64) {  // high to low so a round never reads what an earlier round wrote
-      int lo = top - 64 > to ? top - 64 : to;
+    for (int top = from; top > to; top -= kRound) {  // high to low so a round never reads what an earlier round wrote
+      int lo = top - kRound > to ? top - kRound : to;
       shift_round(lo, top, +1);
     }
     W::store(&key[to], mk); W::store(&ord[to], mo); W::store(&pos[mo], (uint32_t)to);
@@ -52,27 +52,42 @@ struct ClaimOrder {
   KS_FN void rotate_left(int from, int to) {
     if (to <= from) return;
     uint32_t mk = key[from], mo = ord[from];
-    for (int lo = from + 1; lo <= to; lo += 64) {
-      int hi = lo + 64 <= to + 1 ? lo + 64 : to + 1;
+    for (int lo = from + 1; lo <= to; lo += kRound) {
+      int hi = lo + kRound <= to + 1 ? lo + kRound : to + 1;
       shift_round(lo, hi, -1);
     }
     W::store(&key[to], mk); W::store(&ord[to], mo); W::store(&pos[mo], (uint32_t)to);
     W::sync();
   }
-  // elements [lo,hi) (at most 64) move by delta (+1 / -1): all reads of the round precede its writes
+  // elements [lo,hi) (at most kRound) move by delta (+1 / -1): all reads of the round precede its writes, and
+  // all of them are in flight together (a long move — tens of thousands of equally full claims — is bound by round trips)
+  static constexpr int kPerLane = sizeof(P32) == 8 ? 8 : 1;   // HBM-resident order (64-bit pointers): eight elements per lane per round
+  static constexpr int kRound = 64 * kPerLane;
   KS_FN void shift_round(int lo, int hi, int delta) {
 #if KS_DEVICE
-    int i = lo + W::lane();
-    uint32_t k = 0, o = 0;
-    bool act = i < hi;
-    if (act) { k = key[i]; o = ord[i]; }
+    uint32_t k[kPerLane], o[kPerLane];
+#pragma unroll
+    for (int j = 0; j < kPerLane; ++j) { const int i = lo + j * 64 + W::lane(); if (i < hi) { k[j] = key[i]; o[j] = ord[i]; } }
     W::sync();
-    if (act) { key[i + delta] = k; ord[i + delta] = o; pos[o] = (uint32_t)(i + delta); }
+#pragma unroll
+    for (int j = 0; j < kPerLane; ++j) { const int i = lo + j * 64 + W::lane(); if (i < hi) { key[i + delta] = k[j]; ord[i + delta] = o[j]; pos[o[j]] = (uint32_t)(i + delta); } }
     W::sync();
 #else
     if (delta > 0) for (int i = hi - 1; i >= lo; --i) { key[i + 1] = key[i]; ord[i + 1] = ord[i]; pos[ord[i + 1]] = i + 1; }
     else for (int i = lo; i < hi; ++i) { key[i - 1] = key[i]; ord[i - 1] = ord[i]; pos[ord[i - 1]] = i - 1; }
 #endif
+  }
+  // first x in [lo,hi) with key[x] >= v, hi if none — [lo,hi) is sorted ascending (binary search: a long run of equal keys
+  // costs log2 n round trips instead of n/64)
+  KS_FN int lower_bound_sorted(int lo, int hi, uint32_t v) const {
+    while (lo < hi) { const int mid = lo + (hi - lo) / 2; if (key[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+  }
+  // last x in [lo,hi) with key[x] <= v, lo-1 if none — [lo,hi) sorted ascending
+  KS_FN int upper_last_sorted(int lo, int hi, uint32_t v) const {
+    int a = lo, b = hi;
+    while (a < b) { const int mid = a + (b - a) / 2; if (!(v < key[mid])) a = mid + 1; else b = mid; }
+    return a - 1;
   }
 
   // ---- mutation by the scheduler ----
@@ -317,16 +332,18 @@ struct ClaimOrder {
       const bool sampled = (p >= q - 1 && p <= q + 1) || (p >= 2 * q - 1 && p <= 2 * q + 1) || (p >= 3 * q - 1 && p <= 3 * q + 1);
       if (!sampled) {
         const P32 kq = key;
+        // LDS-resident order: a vector search (usually one round); HBM-resident order: runs of equally full claims can be
+        // tens of thousands long, binary search instead
         if (defect_append) {
           const int i = n - 1;
           if (i >= 1 && key[i] < key[i - 1]) {
-            uint32_t mv = key[i];
-            int t = W::find_last(0, i, [kq, mv](int x) { return !(mv < kq[x]); });
+            const uint32_t mv = key[i];
+            const int t = kPerLane > 1 ? upper_last_sorted(0, i, mv) : W::find_last(0, i, [kq, mv](int x) { return !(mv < kq[x]); });   // [0, i) is sorted
             rotate_right(t + 1, i);
           }
         } else if (p + 1 < n && key[p + 1] < key[p]) {
-          uint32_t mv = key[p];
-          int e = W::find_first(p + 1, n, [kq, mv](int x) { return !(kq[x] < mv); });
+          const uint32_t mv = key[p];
+          const int e = kPerLane > 1 ? lower_bound_sorted(p + 1, n, mv) : W::find_first(p + 1, n, [kq, mv](int x) { return !(kq[x] < mv); });   // [p+1, n) is sorted
           rotate_left(p, e - 1);
         }
         defect = -1;
