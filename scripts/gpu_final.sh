@@ -15,3 +15,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   grep "ksolve_pack" $f | head -2
 done
 bash scripts/gpu_quick.sh
+bash scripts/gpu_c3big.sh
