@@ -3,7 +3,7 @@ timeout 1200 python - <<'PY'
 import time
 from karpenter_amd import fixtures as fx
 from karpenter_amd.scheduling import NewScheduler
-for pods in (200000,):
+for pods in (200000, 1000000):
     prob = fx.config3(pods=pods, n_types=500, seed=42)
     t = time.time(); s = NewScheduler(prob); tf = time.time() - t
     t = time.time(); r = s.Solve(want_results=False); ts = time.time() - t
