@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KSOLVE_ABI_VERSION 1
+#define KSOLVE_ABI_VERSION 2
 #define KSOLVE_MAX_KEYS 32        /* requirement keys per problem (one bit each in the u32 flag words) */
 #define KSOLVE_MAX_RES 8          /* resource dimensions */
 #define KSOLVE_MAX_TEMPLATES 32   /* NodeClaimTemplates (NodePools that survived prefiltering) */
@@ -227,7 +227,9 @@ typedef struct {
   /* counters: V = candidate-bin evaluations, plus timing of the device phases in microseconds */
   uint64_t bin_evaluations, it_evaluations, queue_pops, sorts, slow_sorts, relaxations;
   uint64_t ref_bin_evaluations;    /* V as the reference algorithm would count it: every claim up to the accepting one */
-  uint64_t phase_cycles[24];       /* shader clocks per pack-engine phase: queue, class fetch, sort, scan, record load, CanAdd, commit, new claim, dead mark, trySchedule, total */
+  uint64_t phase_cycles[24];       /* profiling builds only (-DKSOLVE_PHASE_TIMERS), zero otherwise: shader clocks per pack-engine phase
+                                    * (queue, class fetch, sort, scan, record load, CanAdd, commit, new claim, dead mark, trySchedule,
+                                    * total, CanAdd and scan sub-phases) and a few diagnostic counts */
   double us_upload, us_prepass, us_pack, us_finalize, us_download;
   double packing_cost;
   void* impl;

@@ -367,7 +367,6 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   W.c_headroom = dz<int64_t>(h, (size_t)mc * d->n_res);
   W.c_reserved = dz<uint64_t>(h, mc);
   W.o_key = dz<uint32_t>(h, mc); W.o_ord = dz<uint32_t>(h, mc); W.o_pos = dz<uint32_t>(h, mc);
-  W.closed = dz<uint64_t>(h, h->claim_words);
   W.queue = dz<uint32_t>(h, (size_t)d->n_pods + 1); W.last_len = dz<uint32_t>(h, d->n_pods);
   W.t_its = dz<uint64_t>(h, (size_t)d->n_templates * it_words);
   W.t_remaining = dz<int64_t>(h, (size_t)d->n_templates * (d->n_res + 1));
@@ -598,7 +597,6 @@ static ksolve_status solve_prepare(ksolve_handle* h) {
   be_toc(h, T_SORT);
 
   // ---- phase 4: pack ----
-  be_fill(h, W.closed, 0, (size_t)h->claim_words * 8);
   be_fill(h, W.last_len, 0, (size_t)n_pods * 4);
   be_fill(h, W.assign, 0xFF, (size_t)n_pods * 4);
   be_fill(h, W.err, 0, n_pods); be_fill(h, W.diag, 0, n_pods);

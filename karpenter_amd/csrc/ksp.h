@@ -182,7 +182,7 @@ struct ProblemView {
 };
 
 struct Counters {
-  unsigned long long bin_evaluations, full_evaluations, it_evaluations, queue_pops, sorts, slow_sorts, relaxations, column_resets, walk_scans;
+  unsigned long long bin_evaluations, full_evaluations, it_evaluations, queue_pops, sorts, slow_sorts, relaxations, column_resets;
   unsigned long long ref_bin_evaluations;  // V: candidate bins the reference would have evaluated
   unsigned long long cycles[24];           // shader clock spent per engine phase (profiling aid)
   unsigned long long full_filters;         // filterInstanceTypesByRequirements runs that had to re-evaluate compatibility + offerings
@@ -204,7 +204,6 @@ struct Workspace {
   uint32_t *o_key, *o_ord, *o_pos;
   // first-fit pruning
   uint64_t* dead;                // [n_classes][claim_words] bit set = claim known infeasible for the class
-  uint64_t* closed;              // [claim_words] claim cannot take any pod any more
   // existing nodes (mutable part): ExistingNode.requirements / remainingResources / Pods (existingnode.go:32-45)
   uint64_t* n_mask;              // [req_words][n_nodes]
   uint32_t *n_defined, *n_complement; // [n_nodes]
