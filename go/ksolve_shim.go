@@ -89,6 +89,30 @@ func (s *Scheduler) Solve(ctx context.Context, pods []*corev1.Pod) (pscheduling.
 
 func (s *Scheduler) Close() { C.ksolve_destroy(s.handle); s.flat.free() }
 
+// SolveBatch runs Solve() for several independent Schedulers with ONE launch of the pack kernel (ksolve_solve_batch:
+// block b = the wavefront of problem b). This is what disruption.SimulateScheduling's callers want: single-node
+// consolidation evaluates one simulation per candidate (singlenodeconsolidation.go:55-126), multi-node consolidation a
+// binary search over prefixes (multinodeconsolidation.go:117-207); the candidates' simulations are independent problems.
+func SolveBatch(ctx context.Context, scheds []*Scheduler) ([]pscheduling.Results, error) {
+	handles := make([]*C.ksolve_handle, len(scheds))
+	for i, s := range scheds {
+		handles[i] = s.handle
+	}
+	results := make([]C.ksolve_results, len(scheds))
+	st := C.ksolve_solve_batch((**C.ksolve_handle)(unsafe.Pointer(&handles[0])), C.uint32_t(len(scheds)), (*C.ksolve_results)(unsafe.Pointer(&results[0])))
+	out := make([]pscheduling.Results, len(scheds))
+	for i, s := range scheds {
+		if results[i].status == C.KSOLVE_OK || results[i].status == C.KSOLVE_ERR_CANCELLED {
+			out[i] = s.rehydrate(&results[i])
+		}
+		C.ksolve_results_free(&results[i])
+	}
+	if st != C.KSOLVE_OK {
+		return out, fmt.Errorf("ksolve_solve_batch: status %d", int(st))
+	}
+	return out, ctx.Err()
+}
+
 // rehydrate rebuilds scheduling.Results (scheduler.go:281-286) from the flat results.
 func (s *Scheduler) rehydrate(res *C.ksolve_results) pscheduling.Results {
 	n := int(res.n_pods)
@@ -109,7 +133,8 @@ func (s *Scheduler) rehydrate(res *C.ksolve_results) pscheduling.Results {
 		sort.Slice(m, func(i, j int) bool { return slot[m[i]] < slot[m[j]] })
 		claims = append(claims, s.flat.nodeClaim(res, c, m, s.pods)) // InstanceTypeOptions, Requirements (scheduling.Requirements), Spec.Resources.Requests
 	}
-	return pscheduling.Results{NewNodeClaims: claims, PodErrors: podErrors}
+	// ExistingNodes: assignment <= -2 is existing node (-2 - index) in sortExistingNodes order (scheduler.go:845-858)
+	return pscheduling.Results{NewNodeClaims: claims, ExistingNodes: s.flat.existingNodes(res, assign, slot, s.pods), PodErrors: podErrors}
 }
 
 var _ = scheduling.NewRequirements // the flattener builds PodData with the reference's own constructors (requirements.go:74-118)
