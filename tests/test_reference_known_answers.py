@@ -150,3 +150,25 @@ def test_existing_nodes(oracle, emu):
     # :1896-1913: a pod that does not fit the node gets a second one
     res = solve(oracle, emu, [fx.pod(requests={"cpu": "8"}), fx.pod(requests={"cpu": "8"})], state_nodes=[bare_node("node-c")])
     assert len(res["newNodeClaims"]) == 1 and sum(len(e["pods"]) for e in res["existingNodes"]) == 1
+
+
+def test_nodepool_limits(oracle, emu):
+    """pkg/controllers/provisioning/suite_test.go "Resource Limits" (:741-880)."""
+    its = fx.fake_default_instance_types()
+    # :742-764: an existing NodeClaim of the pool already uses 100 cpu against a limit of 20
+    node = fx.state_node("existing", its[0], "test-zone-1", "on-demand", "default", used={"cpu": "4", "pods": "5"})
+    node["capacity"]["cpu"] = "100"
+    node["available"] = {"cpu": "0", "memory": "0", "pods": "0"}
+    res = solve(oracle, emu, [fx.pod()], pools=[fx.node_pool(limits={"cpu": "20"})], state_nodes=[node])
+    assert len(res["podErrors"]) == 1 and not res["newNodeClaims"]
+    # :765-781: a 2-cpu node fits under a limit of 2
+    res = solve(oracle, emu, [fx.pod(requests={"cpu": "1.75"})], pools=[fx.node_pool(limits={"cpu": "2"})])
+    assert not res["podErrors"]
+    # :782-830: two pods that must not share a node, limit 3 cpu: exactly one schedules
+    foo = {"app": "foo"}
+    pods = [fx.pod(labels=foo, requests={"cpu": "1.5"}, pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, foo)]) for _ in range(2)]
+    res = solve(oracle, emu, pods, pools=[fx.node_pool(limits={"cpu": "3"})])
+    assert len(res["newNodeClaims"]) == 1 and len(res["podErrors"]) == 1
+    # :831-845: 2.1 cpu cannot fit under a limit of 2
+    res = solve(oracle, emu, [fx.pod(requests={"cpu": "2.1"})], pools=[fx.node_pool(limits={"cpu": "2"})])
+    assert len(res["podErrors"]) == 1
