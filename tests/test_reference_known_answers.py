@@ -172,3 +172,39 @@ def test_nodepool_limits(oracle, emu):
     # :831-845: 2.1 cpu cannot fit under a limit of 2
     res = solve(oracle, emu, [fx.pod(requests={"cpu": "2.1"})], pools=[fx.node_pool(limits={"cpu": "2"})])
     assert len(res["podErrors"]) == 1
+
+
+def launched_type(res, its):
+    """What the fake cloud provider would launch for the first NodeClaim: its cheapest instance type option."""
+    by = {t["name"]: t for t in its}
+    names = res["newNodeClaims"][0]["instanceTypes"]
+    return min(names, key=lambda n: min(o["price"] for o in by[n]["offerings"]))
+
+
+def test_daemonset_overhead_known_answers(oracle, emu):
+    """pkg/controllers/provisioning/suite_test.go "Daemonsets and Node Overhead" (:935-1330): with a 2 cpu / 2Gi daemonset a
+    1 cpu / 1Gi pod needs the 4 cpu / 4Gi type; without a (tolerating / compatible) daemonset the 2 cpu / 2Gi type suffices."""
+    its = fx.fake_default_instance_types()
+    pod = lambda **kw: fx.pod(requests={"cpu": "1", "memory": "1Gi"}, **kw)
+    ds = fx.pod(requests={"cpu": "2", "memory": "2Gi"})
+
+    def run(pods, daemons, pools=None):
+        prob = fx.problem(its, pools or [fx.node_pool()], pods, daemonset_pods=daemons)
+        want = oracle.solve(prob)
+        got = NewScheduler(prob, solver_lib=emu).Solve()
+        for r in (want, got):
+            for c in r["newNodeClaims"]:
+                c["instanceTypes"] = sorted(c["instanceTypes"])
+        parity.assert_same_results(got, want)
+        return want
+
+    assert launched_type(run([pod()], [ds]), its) == "default-instance-type"                               # :935-954
+    res = run([fx.pod()], [fx.pod(requests={"cpu": "10000", "memory": "10000Gi"})])                        # :1004-1012
+    assert len(res["podErrors"]) == 1
+    tainted = [fx.node_pool(taints=[{"key": "foo", "value": "bar", "effect": "NoSchedule"}])]
+    assert launched_type(run([pod(tolerations=[{"operator": "Exists"}])], [ds], pools=tainted), its) == "small-instance-type"   # :1143-1173
+    sized = [fx.pod(requests={"cpu": "1"}, node_requirements=[fx.req("size", "In", "small")]),
+             fx.pod(requests={"cpu": "10"}, node_requirements=[fx.req("size", "In", "large")])]
+    assert launched_type(run([pod()], sized), its) == "default-instance-type"                               # :1246-1274
+    notin = [fx.pod(requests={"cpu": "2", "memory": "2Gi"}, node_requirements=[fx.req("foo", "NotIn", "bar")])]
+    assert launched_type(run([pod(node_requirements=[fx.req(fx.ZONE, "In", "test-zone-2")])], notin), its) == "default-instance-type"   # :1276-1297
