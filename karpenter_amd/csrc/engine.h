@@ -899,6 +899,7 @@ struct Engine {
       if (bin_minv) {  // minValues of the bin carry over (pods cannot add any)
         const uint64_t* bc = bin_cold; uint64_t* oc = sc.out_cold;
         W::for_n(lay.cold_words(), [&](int i) { oc[i] = bc[i]; });
+        merged.minv = (const int32_t*)(sc.out_cold + 2 * lay.nk);   // a topology step that rewrites the set must keep them
       }
     } else {
       ReqRef br = claim_ref(bin, bin_cold);

@@ -1,0 +1,93 @@
+"""Cross-feature fuzz of the DEVICE ALGORITHM (host emulation of the product's engine, tests/emu) against the oracle: random
+problems that mix NodePool weights / taints / limits / minValues, reservations, daemonsets, existing nodes with running
+pods, every topology constraint kind, node selectors / affinities / preferences and the small LDS claim cap that forces
+the BIG engine. Features interact (this is how the minValues-lost-through-a-topology-step bug was found)."""
+import copy
+import random
+
+import pytest
+
+import parity
+from karpenter_amd import fixtures as fx
+from karpenter_amd.scheduling import NewScheduler, Unsupported
+from test_device_algorithm import emu  # noqa: F401  (fixture)
+
+ZONES = ["test-zone-1", "test-zone-2", "test-zone-3"]
+def run(oracle, emu, seed):
+    rng = random.Random(seed)
+    its = copy.deepcopy(fx.fake_default_instance_types() if rng.random() < 0.5 else fx.fake_instance_types(rng.choice([4, 8, 16])))
+    opts = {}
+    if rng.random() < 0.3:
+        opts["minValuesPolicy"] = rng.choice(["Strict", "BestEffort"])
+    if rng.random() < 0.3:
+        opts.update({"reservedCapacity": True, "reservedOfferingMode": rng.choice(["Strict", "Fallback"])})
+        for i in range(rng.randrange(1, 3)):
+            it = rng.choice(its)
+            for r in it["requirements"]:
+                if r["key"] == fx.CAPACITY_TYPE and "reserved" not in r["values"]: r["values"].append("reserved")
+            it["offerings"].append(fx.offering("reserved", rng.choice(ZONES[:2]), 0.001 * (i + 1), reservation_id=f"cr-{i}", reservation_capacity=rng.randrange(1, 4)))
+    if rng.random() < 0.2:
+        opts["ldsClaimCap"] = 64
+    pools = []
+    npools = rng.choice([1, 1, 2, 3])
+    for i in range(npools):
+        kw = {}
+        if rng.random() < 0.3: kw["taints"] = [{"key": "team", "value": f"t{i}", "effect": rng.choice(["NoSchedule", "PreferNoSchedule"])}]
+        if rng.random() < 0.3: kw["limits"] = {"cpu": str(rng.choice([8, 30, 100]))}
+        reqs = []
+        if rng.random() < 0.3: reqs.append(fx.req(fx.ZONE, "In", *rng.sample(ZONES, 2)))
+        if rng.random() < 0.15: reqs.append(fx.req(fx.INSTANCE_TYPE, "Exists", min_values=rng.choice([1, 2, 3])))
+        if rng.random() < 0.2: kw["labels"] = {"team": f"t{i}"}
+        pools.append(fx.node_pool(f"pool-{i}", weight=rng.randrange(0, 50), requirements=reqs, **kw))
+    labels = [{"app": c} for c in "abc"]
+    def rand_pod(**extra):
+        kw = dict(labels=rng.choice(labels), requests={"cpu": f"{rng.choice([100, 250, 500, 1000, 2000, 3500])}m", "memory": f"{rng.choice([64, 256, 1024, 3000])}Mi"})
+        r = rng.random()
+        sel = rng.choice(labels)
+        if r < 0.12: kw["topology_spread"] = [fx.spread(fx.ZONE, sel, max_skew=rng.choice([1, 2]), when=rng.choice(["DoNotSchedule", "ScheduleAnyway"]))]
+        elif r < 0.22: kw["topology_spread"] = [fx.spread(fx.HOSTNAME, sel, max_skew=rng.choice([1, 3]))]
+        elif r < 0.30: kw["pod_requirements"] = [fx.affinity_term(rng.choice([fx.ZONE, fx.HOSTNAME]), sel)]
+        elif r < 0.38: kw["pod_anti_requirements"] = [fx.affinity_term(rng.choice([fx.ZONE, fx.HOSTNAME]), sel)]
+        elif r < 0.44: kw["pod_anti_preferences"] = [fx.weighted(rng.randrange(1, 9), fx.affinity_term(fx.HOSTNAME, sel))]
+        r = rng.random()
+        if r < 0.15: kw["node_selector"] = {fx.ZONE: rng.choice(ZONES)}
+        elif r < 0.25: kw["node_requirements"] = [fx.req(fx.ARCH, rng.choice(["In", "NotIn"]), rng.choice(["amd64", "arm64"]))]
+        elif r < 0.32: kw["node_preferences"] = [fx.req(fx.ZONE, "In", rng.choice(ZONES))]
+        elif r < 0.36: kw["node_requirements"] = [[fx.req(fx.ZONE, "In", "nowhere")], [fx.req(fx.ZONE, "In", rng.choice(ZONES))]]
+        if rng.random() < 0.3: kw["tolerations"] = [{"key": "team", "operator": "Exists"}]
+        kw.update(extra)
+        return fx.pod(**kw)
+    pods = [rand_pod() for _ in range(rng.randrange(10, 120))]
+    daemons = []
+    if rng.random() < 0.4:
+        for _ in range(rng.randrange(1, 3)):
+            kw = dict(requests={"cpu": f"{rng.choice([50, 200])}m", "memory": "64Mi"})
+            if rng.random() < 0.4: kw["node_selector"] = {fx.ARCH: rng.choice(["amd64", "arm64"])}
+            if rng.random() < 0.5: kw["tolerations"] = [{"operator": "Exists"}]
+            daemons.append(fx.pod(**kw))
+    nodes, cluster = [], []
+    if rng.random() < 0.4:
+        for i in range(rng.randrange(1, 5)):
+            it = rng.choice(its)
+            n = fx.state_node(f"node-{i}", it, rng.choice(ZONES), "on-demand", pools[0]["name"], used={"cpu": "200m", "pods": "2"}, initialized=rng.random() < 0.8)
+            if rng.random() < 0.3: n["taints"] = [{"key": "team", "value": "t0", "effect": "NoSchedule"}]
+            nodes.append(n)
+            for _ in range(rng.randrange(0, 3)):
+                cluster.append(rand_pod(phase="Running", node_name=f"node-{i}"))
+    prob = fx.problem(its, pools, pods, state_nodes=nodes, cluster_pods=cluster, daemonset_pods=daemons, options=opts)
+    want = oracle.solve(prob)
+    try:
+        got = NewScheduler(prob, solver_lib=emu).Solve()
+    except Unsupported as e:
+        return ("unsupported", str(e)[:60])
+    for r in (want, got):
+        for c in r["newNodeClaims"]: c["instanceTypes"] = sorted(c["instanceTypes"])
+    parity.assert_same_results(got, want)
+    assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
+    return (len(pods), len(got["newNodeClaims"]), len(got["podErrors"]))
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_cross_feature_fuzz(oracle, emu, block):
+    for seed in range(block * 40, block * 40 + 40):
+        run(oracle, emu, seed)
