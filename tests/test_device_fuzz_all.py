@@ -91,3 +91,75 @@ def run(oracle, emu, seed):
 def test_cross_feature_fuzz(oracle, emu, block):
     for seed in range(block * 40, block * 40 + 40):
         run(oracle, emu, seed)
+
+
+def run_wide(oracle, emu, seed):
+    rng = random.Random(seed)
+    kwok = rng.random() < 0.5
+    if kwok:
+        its = fx.kwok_catalog(rng.choice([24, 72, 144])); wk = fx.KWOK_WELL_KNOWN; ZONES = list(fx.KWOK_ZONES)
+    else:
+        its = copy.deepcopy(fx.fake_instance_types(rng.choice([6, 20, 60]))); wk = fx.FAKE_WELL_KNOWN; ZONES = ["test-zone-1", "test-zone-2", "test-zone-3"]
+    opts = {}
+    if rng.random() < 0.15: opts["ldsClaimCap"] = 64
+    if rng.random() < 0.2: opts["preferencePolicy"] = "Ignore"
+    pools = []
+    for i in range(rng.choice([1, 1, 2])):
+        kw = {}
+        reqs = []
+        if rng.random() < 0.3: reqs.append(fx.req(fx.ZONE, rng.choice(["In", "NotIn"]), *rng.sample(ZONES, rng.choice([1, 2]))))
+        if kwok and rng.random() < 0.3: reqs.append(fx.req(fx.KWOK_CPU, rng.choice(["Gt", "Lt"]), str(rng.choice([2, 8, 32]))))
+        if rng.random() < 0.25: kw["taints"] = [{"key": "dedicated", "value": "x", "effect": "NoSchedule"}]
+        if rng.random() < 0.2: kw["limits"] = {"cpu": str(rng.choice([50, 400]))}
+        np_ = fx.node_pool(f"pool-{i}", weight=rng.randrange(0, 20), requirements=reqs, **kw)
+        if kwok: np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+        pools.append(np_)
+    labels = [{"app": c, "tier": rng.choice(["fe", "be"])} for c in "abcd"]
+    nss = ["default", "default", "other"]
+    pods = []
+    n = rng.choice([30, 80, 200, 500])
+    for _ in range(n):
+        lab = rng.choice(labels); sel = {"app": rng.choice("abcd")}
+        kw = dict(labels=lab, namespace=rng.choice(nss), requests={"cpu": f"{rng.choice([100, 250, 500, 1000, 1500, 4000])}m", "memory": f"{rng.choice([128, 512, 2048])}Mi"})
+        r = rng.random()
+        tsc = []
+        if r < 0.2:
+            c = fx.spread(rng.choice([fx.ZONE, fx.ZONE, fx.HOSTNAME, fx.CAPACITY_TYPE]), sel, max_skew=rng.choice([1, 1, 2, 5]), when=rng.choice(["DoNotSchedule", "DoNotSchedule", "ScheduleAnyway"]),
+                          min_domains=rng.choice([None, None, None, 2, 5]), taints_policy=rng.choice([None, None, "Honor"]), affinity_policy=rng.choice([None, None, "Ignore"]))
+            if rng.random() < 0.2: c["matchLabelKeys"] = ["tier"]
+            tsc.append(c)
+            if rng.random() < 0.3: tsc.append(fx.spread(fx.HOSTNAME, sel, max_skew=rng.choice([2, 4])))
+            kw["topology_spread"] = tsc
+        elif r < 0.3:
+            t = fx.affinity_term(rng.choice([fx.ZONE, fx.HOSTNAME]), sel, namespaces=rng.choice([None, None, ["default", "other"]]))
+            kw["pod_requirements"] = [t]
+        elif r < 0.4:
+            kw["pod_anti_requirements"] = [fx.affinity_term(rng.choice([fx.ZONE, fx.HOSTNAME, fx.HOSTNAME]), sel)]
+        elif r < 0.46:
+            kw["pod_preferences"] = [fx.weighted(rng.randrange(1, 50), fx.affinity_term(rng.choice([fx.ZONE, fx.HOSTNAME]), sel)) for _ in range(rng.randrange(1, 3))]
+        r = rng.random()
+        if r < 0.12: kw["node_selector"] = {fx.ZONE: rng.choice(ZONES)}
+        elif r < 0.2: kw["node_requirements"] = [fx.req(fx.ZONE, "NotIn", rng.choice(ZONES))]
+        elif r < 0.3: kw["node_preferences"] = [{"weight": rng.randrange(1, 9), "matchExpressions": [fx.req(fx.ZONE, "In", rng.choice(ZONES))]} for _ in range(rng.randrange(1, 3))]
+        elif r < 0.36 and kwok: kw["node_requirements"] = [fx.req(fx.KWOK_CPU, rng.choice(["Gt", "Lt"]), str(rng.choice([1, 4, 16, 64])))]
+        elif r < 0.42: kw["node_requirements"] = [[fx.req(fx.ZONE, "In", rng.choice(ZONES))], [fx.req(fx.CAPACITY_TYPE, "In", "spot")]]
+        if rng.random() < 0.3: kw["tolerations"] = [{"key": "dedicated", "operator": "Exists"}]
+        pods.append(fx.pod(**kw))
+    prob = fx.problem(its, pools, pods, well_known=wk, options=opts)
+    want = oracle.solve(prob)
+    try:
+        got = NewScheduler(prob, solver_lib=emu).Solve()
+    except Unsupported as e:
+        return ("unsupported", str(e)[:80])
+    parity.assert_same_results(got, want)
+    assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
+    return (len(pods), len(got["newNodeClaims"]), len(got["podErrors"]), got["counters"]["relaxations"])
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_wide_fuzz(oracle, emu, block):
+    """KWOK and fake catalogues, Gt/Lt bounds on NodePools and pods, namespaces, matchLabelKeys, minDomains, node taint /
+    affinity policies, preferred node affinities, PreferencePolicy=Ignore, up to 500 pods (claim order beyond the
+    insertion-sort regime of pdqsort)."""
+    for seed in range(block * 10, block * 10 + 10):
+        run_wide(oracle, emu, seed)
