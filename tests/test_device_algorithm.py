@@ -433,3 +433,39 @@ def test_batch_with_an_overflowing_problem(oracle, emu):
              for n in (50, 400, 90)]
     for got, prob in zip(SolveBatch([NewScheduler(p, solver_lib=emu) for p in probs]), probs):
         parity.assert_same_results(got, oracle.solve(prob))
+
+
+def test_size_limits_are_enforced_loudly(oracle, emu):
+    """The fixed capacities of the flat format: at the limit the problem solves (and matches the oracle), past it the
+    product reports Unsupported — it never degrades silently."""
+    # instance types: the format allows 2048 (32 mask words); what actually bounds a problem is that the per-type tables
+    # must fit one CU's LDS — 1000 KWOK types (BASELINE configs[3]) do, 2049 of anything do not
+    np_ = fx.node_pool()
+    np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    pods = [fx.pod(requests={"cpu": f"{c}"}) for c in (1, 3, 17, 100, 250)]
+    check(oracle, emu, fx.problem(fx.kwok_catalog(1000), [np_], pods, well_known=fx.KWOK_WELL_KNOWN))
+    check(oracle, emu, fx.problem(fx.fake_instance_types(800), [fx.node_pool()], pods))
+    with pytest.raises(Unsupported):
+        NewScheduler(fx.problem(fx.fake_instance_types(2049), [fx.node_pool()], [fx.pod()]), solver_lib=emu)
+    # requirement keys: the well-known / template keys plus custom pod keys, up to 32 in total
+    base = fx.fake_default_instance_types()
+    def with_keys(n):
+        return [fx.pod(node_requirements=[fx.req(f"custom-{i}", "NotIn", "x") for i in range(n)])]
+    check(oracle, emu, fx.problem(base, [fx.node_pool()], with_keys(8)))
+    with pytest.raises(Unsupported):
+        NewScheduler(fx.problem(base, [fx.node_pool()], with_keys(40)), solver_lib=emu)
+    # resource dimensions: cpu, memory, pods + five extended resources = 8
+    its8 = fx.fake_instance_types(4)
+    for i in range(5):
+        its8[0]["capacity"][f"vendor.com/res-{i}"] = "4"
+    check(oracle, emu, fx.problem(its8, [fx.node_pool()], [fx.pod(requests={f"vendor.com/res-{i}": "1" for i in range(5)})]))
+    its9 = fx.fake_instance_types(4)
+    for i in range(6):
+        its9[0]["capacity"][f"vendor.com/res-{i}"] = "4"
+    with pytest.raises(Unsupported):
+        NewScheduler(fx.problem(its9, [fx.node_pool()], [fx.pod()]), solver_lib=emu)
+    # NodePools: 32 templates
+    pools = [fx.node_pool(f"pool-{i:02d}", weight=i) for i in range(32)]
+    check(oracle, emu, fx.problem(base, pools, [fx.pod() for _ in range(5)]))
+    with pytest.raises(Unsupported):
+        NewScheduler(fx.problem(base, pools + [fx.node_pool("one-too-many")], [fx.pod()]), solver_lib=emu)
