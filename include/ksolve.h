@@ -193,6 +193,10 @@ typedef struct {
   uint32_t lds_claim_cap;          /* 0 = as many in-flight claims as the CU's LDS can order (<= 8192); smaller values shrink the
                                     * LDS footprint (more problems per CU in ksolve_solve_batch). A solve that needs more claims
                                     * is re-run on the engine variant that keeps the claim order in HBM. */
+  uint32_t truncate_instance_types; /* > 0: Results.TruncateInstanceTypes(n) (scheduler.go:419-437; the provisioner passes 600):
+                                    * every NodeClaim's instance types ordered by price (OrderByPrice, types.go:336-355, Go's unstable
+                                    * sort.Slice reproduced) and capped at n; a claim whose capped list breaks minValues is reported in
+                                    * ksolve_claims.truncation_failed */
   uint32_t reserved_capacity;      /* FeatureGates.ReservedCapacity (nodeclaim.go:308) */
   uint32_t reserved_offering_strict; /* DisableReservedCapacityFallback / ReservedOfferingModeStrict (scheduler.go:103, nodeclaim.go:339-348) */
 } ksolve_options;
@@ -213,6 +217,11 @@ typedef struct {
   const uint8_t* min_values_relaxed;    /* n_claims : annotation nodeclaim-min-values-relaxed (scheduler.go:763-772) */
   const double* cheapest_price;         /* n_claims : cheapest compatible available offering over InstanceTypeOptions */
   const uint32_t* hostname_seq;         /* n_claims : N of hostname-placeholder-%04d (nodeclaim.go:93) */
+  const int32_t* ordered_instance_types; /* NULL unless options.truncate_instance_types: n_claims * n_instance_types, the claim's types in
+                                          * OrderByPrice order; the first ordered_count[c] entries are the (truncated) options */
+  const uint32_t* ordered_count;        /* n_claims */
+  const uint8_t* truncation_failed;     /* n_claims : minValues no longer met after truncation (types.go:437-449) */
+  uint32_t n_instance_types;
   const uint64_t* reserved_mask;        /* n_claims : reservation ids held by the claim (NodeClaim.reservedOfferings, nodeclaim.go:60) */
 } ksolve_claims;
 

@@ -10,6 +10,7 @@
 //   finalize     : per claim cheapest compatible available offering (the packing-cost estimator)
 #pragma once
 #include "ksp.h"
+#include "go_sort.h"
 
 namespace ks {
 
@@ -281,6 +282,13 @@ struct FinalizeArgs {
   const uint32_t* it_resv_first;
   const uint8_t *resv_zone, *resv_id;
   const double* resv_price;
+  // Results.TruncateInstanceTypes (scheduler.go:419-437)
+  int truncate_n, best_effort;
+  ReqTable it_reqs;
+  int32_t* sort_idx;         // [n_claims][n_its] the claim's instance types, OrderByPrice order
+  double* sort_price;        // [n_claims][n_its]
+  uint32_t* ordered_count;   // [n_claims]
+  uint8_t* trunc_failed;     // [n_claims]
 };
 // one thread per claim: min over InstanceTypeOptions of the cheapest available offering compatible with the claim's
 // requirements (the comparator key of OrderByPrice, types.go:336-355)
@@ -328,6 +336,47 @@ KS_FN void finalize_body(int c, const FinalizeArgs& a) {
     }
   }
   a.cheapest[c] = best;
+  if (a.truncate_n > 0) {
+    // InstanceTypeOptions.Truncate (types.go:437-449): OrderByPrice — Go's sort.Slice on the cheapest compatible available
+    // offering of each type, an unstable sort whose tie order is part of the result — then the first truncate_n types,
+    // and minValues must still hold for them (unless the policy is BestEffort).
+    int32_t* idx = a.sort_idx + (size_t)c * a.n_its;
+    double* pr = a.sort_price + (size_t)c * a.n_its;
+    const uint64_t held = (a.c_reserved ? a.c_reserved[c] : 0ull);
+    int n = 0;
+    for (int w = 0; w < a.it_words; ++w) for (uint64_t m = its[w]; m; m &= m - 1) {
+      const int it = w * 64 + ctz64(m);
+      double p = 1.7976931348623157e308;
+      if (held) {
+        for (uint32_t o = a.it_resv_first[it]; o < a.it_resv_first[it + 1]; ++o)
+          if (((held >> a.resv_id[o]) & 1) && ((zones >> a.resv_zone[o]) & 1) && a.resv_price[o] < p) p = a.resv_price[o];
+      } else {
+        for (uint64_t av = a.it_off_avail[it] & cells; av; av &= av - 1) { const double q = a.it_off_price[(size_t)it * 64 + ctz64(av)]; if (q < p) p = q; }
+      }
+      idx[n] = it; pr[n] = p; n++;
+    }
+    go_sort_slice(n, [pr](int i, int j) { return pr[i] < pr[j]; },
+                  [pr, idx](int i, int j) { const double tp = pr[i]; pr[i] = pr[j]; pr[j] = tp; const int32_t ti = idx[i]; idx[i] = idx[j]; idx[j] = ti; });
+    const int keep = n < a.truncate_n ? n : a.truncate_n;
+    bool failed = false;
+    const uint32_t fl = (uint32_t)(hot[ly.c_meta2()] >> 32);
+    if ((fl & 2u) && !a.best_effort) {
+      const int32_t* mv = (const int32_t*)(cold + 2 * ly.nk);
+      for (int k = 0; k < ly.nk; ++k) {
+        if (mv[k] < 0) continue;
+        int have = 0;
+        if (k == d.key_it) have = keep;
+        else for (uint32_t x = d.key_word_off[k]; x < d.key_word_off[k + 1]; ++x) {
+          uint64_t u = 0;
+          for (int i = 0; i < keep; ++i) u |= a.it_reqs.mask[(size_t)idx[i] * d.req_words + x];
+          have += popc64(u);
+        }
+        if (have < mv[k]) failed = true;
+      }
+    }
+    a.trunc_failed[c] = failed ? 1 : 0;
+    a.ordered_count[c] = (uint32_t)(failed ? n : keep);
+  }
   // The smallest daemon overhead over the groups that still have an instance type on the claim. Groups are visited in
   // the order NewScheduler built them (first appearance over the template's prefiltered types, scheduler.go:985-1003;
   // the reference's own order is a Go map iteration). MinResources keeps the intersection of keys: a group without any

@@ -58,6 +58,9 @@ struct ksolve_handle {
   uint64_t *d_key_a = nullptr, *d_key_b = nullptr;
   double* d_cheapest = nullptr;
   int64_t* d_daemon_requests = nullptr;   // [max_claims][n_res] addDaemonRequests, by the finalize kernel
+  // Results.TruncateInstanceTypes (only when ksolve_options.truncate_instance_types > 0), sized by the claims of the last solve
+  int32_t* d_sort_idx = nullptr; double* d_sort_price = nullptr; uint32_t* d_ordered_count = nullptr; uint8_t* d_trunc_failed = nullptr;
+  size_t trunc_capacity = 0;
   int* d_cancel = nullptr;
   ks::MutReqTable d_cls_reqs{}, d_cls_strict{};
   std::vector<void*> allocations;
@@ -514,6 +517,7 @@ struct ResultsImpl {
   std::vector<uint8_t> err, diag, relaxed;
   std::vector<uint32_t> slot, npods, defined, complement, has_gte, has_lte, host_seq, ord;
   std::vector<uint64_t> its, mask, reserved;
+  std::vector<int32_t> t_idx; std::vector<uint32_t> t_cnt; std::vector<uint8_t> t_fail;
   std::vector<int64_t> requests, gte, lte;
   std::vector<int32_t> minv;
   std::vector<double> cheapest;
@@ -625,7 +629,17 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   be_tic(h, T_FINALIZE);
   ks::FinalizeArgs F{P.dict, (int)h->n_its, (int)h->it_words, P.n_zones, P.n_cts, P.it_off_avail, P.it_off_price, W.c_hot, W.c_cold, P.lay, h->d_cheapest,
                      P.dg_first, P.dg_ov, P.dg_its, P.dg_nonempty, W.t_its, h->d_daemon_requests,
-                     P.reserved_on ? W.c_reserved : nullptr, P.it_resv_first, P.resv_zone, P.resv_id, P.resv_price};
+                     P.reserved_on ? W.c_reserved : nullptr, P.it_resv_first, P.resv_zone, P.resv_id, P.resv_price,
+                     0, 0, P.it_reqs, nullptr, nullptr, nullptr, nullptr};
+  if (h->opts.truncate_instance_types && n_claims) {
+    if ((size_t)n_claims > h->trunc_capacity) {
+      h->trunc_capacity = (size_t)n_claims;
+      h->d_sort_idx = dz<int32_t>(h, (size_t)n_claims * h->n_its); h->d_sort_price = dz<double>(h, (size_t)n_claims * h->n_its);
+      h->d_ordered_count = dz<uint32_t>(h, n_claims); h->d_trunc_failed = dz<uint8_t>(h, n_claims);
+    }
+    F.truncate_n = (int)h->opts.truncate_instance_types; F.best_effort = h->opts.min_values_best_effort ? 1 : 0;
+    F.sort_idx = h->d_sort_idx; F.sort_price = h->d_sort_price; F.ordered_count = h->d_ordered_count; F.trunc_failed = h->d_trunc_failed;
+  }
   if (n_claims) be_launch_finalize(h, n_claims, F);
   be_toc(h, T_FINALIZE);
 
@@ -649,6 +663,7 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   std::vector<double> cheapest(C);
   std::vector<int64_t> daemon_req;
   std::vector<uint64_t> reserved;
+  std::vector<int32_t> t_idx; std::vector<uint32_t> t_cnt; std::vector<uint8_t> t_fail;
   std::vector<uint64_t> hot((size_t)C * ly.c_hot_words()), cold((size_t)C * ly.cold_words());
   if (C) {
     be_d2h(h, hot.data(), W.c_hot, hot.size() * 8);
@@ -656,6 +671,12 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
     be_d2h(h, cheapest.data(), h->d_cheapest, (size_t)C * 8);
     reserved.resize(C);
     be_d2h(h, reserved.data(), W.c_reserved, (size_t)C * 8);
+    if (h->opts.truncate_instance_types) {
+      t_idx.resize((size_t)C * h->n_its); t_cnt.resize(C); t_fail.resize(C);
+      be_d2h(h, t_idx.data(), h->d_sort_idx, t_idx.size() * 4);
+      be_d2h(h, t_cnt.data(), h->d_ordered_count, (size_t)C * 4);
+      be_d2h(h, t_fail.data(), h->d_trunc_failed, C);
+    }
     daemon_req.resize((size_t)C * n_res);
     be_d2h(h, daemon_req.data(), h->d_daemon_requests, (size_t)C * n_res * 8);
     be_d2h(h, ord.data(), W.o_ord, (size_t)C * 4);
@@ -713,6 +734,7 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   permute(im->gte, gte, h->n_keys); permute(im->lte, lte, h->n_keys); permute(im->minv, minv, h->n_keys);
   if (reserved.empty()) reserved.assign(C, 0);
   permute(im->reserved, reserved, 1);
+  if (!t_cnt.empty()) { permute(im->t_idx, t_idx, h->n_its); permute(im->t_cnt, t_cnt, 1); permute(im->t_fail, t_fail, 1); }
   permute(im->requests, requests, n_res); permute(im->host_seq, host_seq, 1); permute(im->relaxed, relaxed, 1); permute(im->cheapest, cheapest, 1);
   for (uint32_t p = 0; p < n_pods; ++p) if (im->assign[p] >= 0) im->assign[p] = (int32_t)newidx[im->assign[p]];
   double cost = 0;
@@ -728,6 +750,8 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   cl.req_has_gte = im->has_gte.data(); cl.req_has_lte = im->has_lte.data(); cl.req_gte = im->gte.data(); cl.req_lte = im->lte.data();
   cl.req_min_values = im->minv.data(); cl.min_values_relaxed = im->relaxed.data(); cl.cheapest_price = im->cheapest.data();
   cl.hostname_seq = im->host_seq.data(); cl.reserved_mask = im->reserved.data();
+  cl.n_instance_types = h->n_its;
+  if (!im->t_cnt.empty()) { cl.ordered_instance_types = im->t_idx.data(); cl.ordered_count = im->t_cnt.data(); cl.truncation_failed = im->t_fail.data(); }
   out->bin_evaluations = ctr.bin_evaluations; out->it_evaluations = ctr.it_evaluations; out->queue_pops = ctr.queue_pops;
   out->sorts = ctr.sorts; out->slow_sorts = ctr.slow_sorts; out->relaxations = ctr.relaxations;
   out->ref_bin_evaluations = ctr.ref_bin_evaluations;

@@ -1402,6 +1402,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     ko.max_steps = opts.at("maxSteps").i(-1);
     ko.device = (uint32_t)opts.at("device").i(0);
     ko.lds_claim_cap = (uint32_t)opts.at("ldsClaimCap").i(0);
+    ko.truncate_instance_types = (uint32_t)opts.at("truncateInstanceTypes").i(0);
     ko.reserved_capacity = opts.at("reservedCapacity").boolean_or(false) ? 1 : 0;
     ko.reserved_offering_strict = opts.at("reservedOfferingMode").s("Fallback") == "Strict" ? 1 : 0;
 
@@ -1523,8 +1524,17 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
         for (auto& m : members[c]) pj.push(Value::string(uid_of(m.second)));
         cj.set("pods", pj);
         Value itj = Value::array();
-        for (int i = 0; i < n_its; ++i) if ((cl.it_mask[(size_t)c * cl.it_words + i / 64] >> (i % 64)) & 1) itj.push(Value::string(S->it_names[i]));
+        if (cl.ordered_instance_types) {   // Results.TruncateInstanceTypes: price order, capped (scheduler.go:419-437)
+          for (uint32_t i = 0; i < cl.ordered_count[c]; ++i) itj.push(Value::string(S->it_names[cl.ordered_instance_types[(size_t)c * cl.n_instance_types + i]]));
+        } else {
+          for (int i = 0; i < n_its; ++i) if ((cl.it_mask[(size_t)c * cl.it_words + i / 64] >> (i % 64)) & 1) itj.push(Value::string(S->it_names[i]));
+        }
         cj.set("instanceTypes", itj);
+        if (cl.truncation_failed && cl.truncation_failed[c]) {
+          // the claim is dropped and its pods fail with the minValues error (scheduler.go:426-431)
+          for (auto& m : members[c]) { Value e = Value::object(); e.set("code", Value::integer(KSOLVE_POD_MIN_VALUES)); e.set("diag", Value::integer(128)); errs.set(uid_of(m.second), e); }
+          continue;
+        }
         Value rj = Value::array();
         // requirements in key-name order, like the oracle's std::map
         std::vector<std::pair<std::string, int>> keys;

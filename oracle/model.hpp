@@ -133,6 +133,7 @@ struct Options {
   bool reserved_offering_strict = false;     // DisableReservedCapacityFallback (scheduler.go:103)
   bool enforce_consolidate_after = false;    // IsConsolidationSimulation (scheduler.go:123)
   long long max_steps = -1;                  // stand-in for the ctx deadline (scheduler.go:477): stop after N pops
+  int truncate_instance_types = 0;           // > 0: Results.TruncateInstanceTypes(n) after Solve (scheduler.go:419-437)
 };
 
 struct Problem {
@@ -291,6 +292,7 @@ inline Problem parse_problem(const oj::Value& root) {
   pr.opts.reserved_offering_strict = o.at("reservedOfferingMode").s("Fallback") == "Strict";
   pr.opts.enforce_consolidate_after = o.at("consolidationSimulation").boolean_or(false);
   pr.opts.max_steps = o.at("maxSteps").i(-1);
+  pr.opts.truncate_instance_types = (int)o.at("truncateInstanceTypes").i(0);
 
   std::map<std::string, int> it_index;
   int ci = 0;

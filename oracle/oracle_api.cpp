@@ -91,6 +91,20 @@ char* oracle_solve_json(const char* problem_json) {
     oj::Value out = oj::Value::object();
     oj::Value claims = oj::Value::array();
     double total_cost = 0;
+    // Results.TruncateInstanceTypes — scheduler.go:419-437 ; InstanceTypes.Truncate — types.go:437-449
+    if (pr.opts.truncate_instance_types > 0) {
+      std::vector<NodeClaim*> valid;
+      for (auto* nc : res.new_node_claims) {
+        order_by_price(nc->its, nc->reqs);
+        std::vector<const InstanceType*> cut(nc->its.begin(), nc->its.begin() + std::min<size_t>(nc->its.size(), (size_t)pr.opts.truncate_instance_types));
+        bool ok = true;
+        if (nc->reqs.has_min_values() && !pr.opts.min_values_best_effort) satisfies_min_values(cut, nc->reqs, nullptr, &ok);
+        if (!ok) { for (auto* p : nc->pods) res.pod_errors[p->uid] = {ERR_MIN_VALUES, 128}; continue; }
+        nc->its = cut;
+        valid.push_back(nc);
+      }
+      res.new_node_claims = valid;
+    }
     for (auto* nc : res.new_node_claims) {
       oj::Value c = oj::Value::object();
       c.set("nodePool", oj::Value::string(nc->tmpl->nodepool_name));

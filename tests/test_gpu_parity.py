@@ -239,3 +239,19 @@ def test_big_engine_claim_order_in_hbm(oracle):
         assert len(c["pods"]) >= 1
     # every anti-affinity pod sits alone among its kind: count claims is at least the number of such pods
     assert r["counters"]["claims"] == len(r["newNodeClaims"])
+
+
+def test_truncate_instance_types_order_by_price(oracle):
+    """Results.TruncateInstanceTypes in the finalize kernel: OrderByPrice with Go's unstable sort, cap, minValues after the cap."""
+    np_ = fx.node_pool()
+    np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    pods = [fx.pod(requests={"cpu": f"{c}m", "memory": f"{m}Mi"}, node_selector=sel) for c in (100, 1500, 9000) for m in (100, 4096)
+            for sel in (None, {fx.ZONE: "test-zone-b"}, {fx.CAPACITY_TYPE: "on-demand"}, {fx.ARCH: "arm64"})]
+    for cap in (600, 5):
+        got, _ = check(oracle, fx.problem(fx.kwok_catalog(1000), [np_], pods, well_known=fx.KWOK_WELL_KNOWN, options={"truncateInstanceTypes": cap}))
+        assert all(len(c["instanceTypes"]) <= cap for c in got["newNodeClaims"])
+    from test_device_algorithm import _mv_types
+    two = [fx.pod(requests={"cpu": "0.9", "memory": "0.9Gi"}) for _ in range(2)]
+    pool = fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "In", "instance-type-1", "instance-type-2", min_values=2)])
+    got, _ = check(oracle, fx.problem(_mv_types(), [pool], two, options={"truncateInstanceTypes": 1}))
+    assert not got["newNodeClaims"] and len(got["podErrors"]) == 2

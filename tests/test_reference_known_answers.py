@@ -208,3 +208,26 @@ def test_daemonset_overhead_known_answers(oracle, emu):
     assert launched_type(run([pod()], sized), its) == "default-instance-type"                               # :1246-1274
     notin = [fx.pod(requests={"cpu": "2", "memory": "2Gi"}, node_requirements=[fx.req("foo", "NotIn", "bar")])]
     assert launched_type(run([pod(node_requirements=[fx.req(fx.ZONE, "In", "test-zone-2")])], notin), its) == "default-instance-type"   # :1276-1297
+
+
+def test_truncate_instance_types(oracle, emu):
+    """Results.TruncateInstanceTypes (scheduler.go:419-437): instance types in OrderByPrice order (types.go:336-355, Go's
+    unstable sort reproduced), capped; minValues must survive the cap (instance_selection_test.go:1261-1329)."""
+    from test_device_algorithm import _mv_types
+    two = [fx.pod(requests={"cpu": "0.9", "memory": "0.9Gi"}) for _ in range(2)]
+    pool = fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "In", "instance-type-1", "instance-type-2", min_values=2)])
+    res = solve(oracle, emu, two, its=_mv_types(), pools=[pool], options={"truncateInstanceTypes": 1})
+    assert not res["newNodeClaims"] and sorted(e["code"] for e in res["podErrors"].values()) == [10, 10]
+    res = solve(oracle, emu, two, its=_mv_types(), pools=[pool], options={"truncateInstanceTypes": 600})
+    assert len(res["newNodeClaims"]) == 2 and res["newNodeClaims"][0]["instanceTypes"] == ["instance-type-1", "instance-type-2"]   # cheapest first
+    # a large catalogue with many equal prices: the order Go's unstable sort leaves is part of the answer
+    np_ = fx.node_pool()
+    np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    pods = [fx.pod(requests={"cpu": f"{c}m", "memory": f"{m}Mi"}, node_selector=sel) for c in (100, 1500, 9000) for m in (100, 4096)
+            for sel in (None, {fx.ZONE: "test-zone-b"}, {fx.CAPACITY_TYPE: "on-demand"}, {fx.ARCH: "arm64"})]
+    for cap in (600, 60, 5):
+        res = solve(oracle, emu, pods, its=fx.kwok_catalog(1000), pools=[np_], well_known=fx.KWOK_WELL_KNOWN, options={"truncateInstanceTypes": cap})
+        assert all(len(c["instanceTypes"]) <= cap for c in res["newNodeClaims"]) and not res["podErrors"]
+    its = fx.fake_instance_types(300)
+    res = solve(oracle, emu, [fx.pod(requests={"cpu": str(c)}) for c in (1, 2, 7, 40)], its=its, options={"truncateInstanceTypes": 100})
+    assert all(len(c["instanceTypes"]) <= 100 for c in res["newNodeClaims"])
