@@ -231,3 +231,38 @@ def test_truncate_instance_types(oracle, emu):
     its = fx.fake_instance_types(300)
     res = solve(oracle, emu, [fx.pod(requests={"cpu": str(c)}) for c in (1, 2, 7, 40)], its=its, options={"truncateInstanceTypes": 100})
     assert all(len(c["instanceTypes"]) <= 100 for c in res["newNodeClaims"])
+
+
+def zone_of(claim):
+    return [q["values"] for q in claim["requirements"] if q["key"] == fx.ZONE][0]
+
+
+def test_preferential_fallback(oracle, emu):
+    """suite_test.go "Preferential Fallback" (:1126-1245): the relaxation ladder of Preferences.Relax (preferences.go:38-57)."""
+    term = lambda *reqs: list(reqs)
+    # :1128-1142 the last required term is never relaxed
+    pool = [fx.node_pool(requirements=[fx.req(fx.ZONE, "In", "test-zone-1"), fx.req(fx.INSTANCE_TYPE, "In", "default-instance-type")])]
+    res = solve(oracle, emu, [fx.pod(node_requirements=[term(fx.req(fx.ZONE, "In", "invalid"))])], pools=pool)
+    assert len(res["podErrors"]) == 1
+    # :1144-1165 required terms are OR'ed: dropped one by one until one works
+    terms = [term(fx.req(fx.ZONE, "In", "invalid")), term(fx.req(fx.ZONE, "In", "invalid")), term(fx.req(fx.ZONE, "In", "test-zone-1")), term(fx.req(fx.ZONE, "In", "test-zone-2"))]
+    res = solve(oracle, emu, [fx.pod(node_requirements=terms)])
+    assert zone_of(res["newNodeClaims"][0]) == ["test-zone-1"]
+    # :1168-1185 every preferred term can be dropped
+    prefs = [{"weight": 1, "matchExpressions": [fx.req(fx.ZONE, "In", "invalid")]}, {"weight": 1, "matchExpressions": [fx.req(fx.INSTANCE_TYPE, "In", "invalid")]}]
+    res = solve(oracle, emu, [fx.pod(node_preferences=prefs)])
+    assert not res["podErrors"]
+    # :1187-1212 heavier preferences are tried (and dropped) first
+    pool = [fx.node_pool(requirements=[fx.req(fx.ZONE, "In", "test-zone-1", "test-zone-2")])]
+    prefs = [{"weight": 100, "matchExpressions": [fx.req(fx.INSTANCE_TYPE, "In", "test-zone-3")]},
+             {"weight": 50, "matchExpressions": [fx.req(fx.ZONE, "In", "test-zone-2")]},
+             {"weight": 1, "matchExpressions": [fx.req(fx.ZONE, "In", "test-zone-1")]}]
+    res = solve(oracle, emu, [fx.pod(node_preferences=prefs)], pools=pool)
+    assert zone_of(res["newNodeClaims"][0]) == ["test-zone-2"]
+    # :1214-1233 a preference that conflicts with the requirement is dropped, the requirement stays
+    res = solve(oracle, emu, [fx.pod(node_requirements=[term(fx.req(fx.ZONE, "In", "test-zone-3"))],
+                                     node_preferences=[{"weight": 1, "matchExpressions": [fx.req(fx.ZONE, "NotIn", "test-zone-3")]}])])
+    assert zone_of(res["newNodeClaims"][0]) == ["test-zone-3"]
+    # :1235-1244 self-contradictory preferences
+    res = solve(oracle, emu, [fx.pod(node_preferences=[fx.req(fx.ZONE, "In", "invalid"), fx.req(fx.ZONE, "NotIn", "invalid")])])
+    assert not res["podErrors"]
