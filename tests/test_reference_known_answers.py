@@ -266,3 +266,18 @@ def test_preferential_fallback(oracle, emu):
     # :1235-1244 self-contradictory preferences
     res = solve(oracle, emu, [fx.pod(node_preferences=[fx.req(fx.ZONE, "In", "invalid"), fx.req(fx.ZONE, "NotIn", "invalid")])])
     assert not res["podErrors"]
+
+
+def test_self_affinity_first_empty_domain_only(oracle, emu):
+    # topology_test.go:2040-2071: ten pods with hostname self-affinity, the node holds five: one node, five pods, five errors
+    aff = {"security": "s2"}
+    pods = [fx.pod(labels=aff, pod_requirements=[fx.affinity_term(fx.HOSTNAME, aff)]) for _ in range(10)]
+    res = solve(oracle, emu, pods)
+    assert len(res["newNodeClaims"]) == 1 and len(res["newNodeClaims"][0]["pods"]) == 5 and len(res["podErrors"]) == 5
+    # :2082-2124 (second half): a matching pod already runs in test-zone-1; pods confined to zones 2/3 cannot join its host
+    its = fx.fake_default_instance_types()
+    node = fx.state_node("node-1", its[0], "test-zone-1", "on-demand", "default", used={"cpu": "100m", "pods": "5"})
+    running = fx.pod(labels=aff, phase="Running", node_name="node-1")
+    pods = [fx.pod(labels=aff, node_requirements=[fx.req(fx.ZONE, "In", "test-zone-2", "test-zone-3")], pod_requirements=[fx.affinity_term(fx.HOSTNAME, aff)]) for _ in range(10)]
+    res = solve(oracle, emu, pods, its=its, state_nodes=[node], cluster_pods=[running])
+    assert len(res["podErrors"]) == 10 and not res["newNodeClaims"]
