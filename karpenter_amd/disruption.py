@@ -90,8 +90,11 @@ def simulate_scheduling(cluster, candidates, solver):
         pods += c.get("pods", [])
     deleting_pods = [p for n in deleting for p in n.get("pods", [])]
     pods += deleting_pods
+    # the pods that stay where they are seed the topology counts and the inverse anti-affinity groups of the simulation
+    # (NewTopology / countDomains read the cluster's bound pods, topology.go:68-103, :361-459)
+    staying = [p for n in cluster["nodes"] if n["name"] not in names and not n.get("markedForDeletion") for p in n.get("pods", [])]
     prob = fx.problem(cluster["instanceTypes"], cluster["nodePools"], copy.deepcopy(pods), well_known=cluster.get("wellKnownLabels", fx.KWOK_WELL_KNOWN),
-                      state_nodes=state_nodes, options=dict(cluster.get("options", {}), consolidationSimulation=True),
+                      state_nodes=state_nodes, cluster_pods=copy.deepcopy(staying), options=dict(cluster.get("options", {}), consolidationSimulation=True),
                       deleting_node_names=[n["name"] for n in deleting])
     res = solver(prob)
     # pods that landed on an uninitialized node make the decision unsafe (helpers.go:133-153)
