@@ -90,6 +90,15 @@ double ksolve_last_kernel_ms(const ksolve_handle* h, const char* name) {
   return -1;
 }
 int ksolve_is_emulation(void) { return 1; }
+// The product's Go-sort (csrc/go_sort.h, used by the finalize kernel for OrderByPrice) on an array of integer keys:
+// out_perm receives the original indices in sorted order, ties as Go's sort.Slice leaves them.
+void ksolve_emu_go_sort(const long long* keys, int n, int* out_perm) {
+  std::vector<long long> k(keys, keys + n);
+  for (int i = 0; i < n; ++i) out_perm[i] = i;
+  long long* kp = k.data();
+  ks::go_sort_slice(n, [kp](int i, int j) { return kp[i] < kp[j]; },
+                    [kp, out_perm](int i, int j) { std::swap(kp[i], kp[j]); std::swap(out_perm[i], out_perm[j]); });
+}
 // Drives the device's claim-order emulation (pdq_emul.h) with a trace of commits; out_ids receives the final order.
 int ksolve_emu_order_trace(const int* ops, int n_ops, int* out_ids, unsigned long long* slow_sorts) {
   std::vector<uint32_t> key(n_ops + 1), ord(n_ops + 1), pos(n_ops + 1);

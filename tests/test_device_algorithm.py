@@ -469,3 +469,28 @@ def test_size_limits_are_enforced_loudly(oracle, emu):
     check(oracle, emu, fx.problem(base, pools, [fx.pod() for _ in range(5)]))
     with pytest.raises(Unsupported):
         NewScheduler(fx.problem(base, pools + [fx.node_pool("one-too-many")], [fx.pod()]), solver_lib=emu)
+
+
+def test_product_go_sort_matches_oracle_go_sort(oracle, emu):
+    """csrc/go_sort.h (the finalize kernel's OrderByPrice) and oracle/pdqsort.hpp are two independent restatements of
+    Go's sort.Slice; on inputs full of ties they must leave the same permutation (every pdqsort path: insertion sort,
+    ninther, partial insertion sort, partitionEqual, breakPatterns, heapsort)."""
+    lib = ctypes.CDLL(emu)
+    rng = random.Random(99)
+    shapes = []
+    for n in (0, 1, 2, 12, 13, 49, 50, 51, 100, 257, 1000, 3000):
+        shapes += [[rng.randrange(0, max(1, n // 8)) for _ in range(n)],             # many ties
+                   sorted(rng.randrange(0, 50) for _ in range(n)),                    # already sorted
+                   sorted((rng.randrange(0, 50) for _ in range(n)), reverse=True),    # reversed
+                   [rng.randrange(0, 3) for _ in range(n)],                           # three distinct keys
+                   [i % 7 for i in range(n)],                                         # periodic pattern
+                   list(range(n // 2)) + list(range(n - n // 2))]                     # two sorted runs
+    # the organ-pipe / killer patterns that push pdqsort into breakPatterns and heapsort
+    shapes.append([min(i, 2000 - i) for i in range(2000)])
+    shapes.append([(i * 7919) % 13 for i in range(4000)])
+    for keys in shapes:
+        n = len(keys)
+        arr = (ctypes.c_longlong * max(1, n))(*keys)
+        out = (ctypes.c_int * max(1, n))()
+        lib.ksolve_emu_go_sort(arr, n, out)
+        assert list(out[:n]) == oracle.evaluate({"fn": "sort_by_key", "keys": keys}), (n, keys[:20])
