@@ -11,6 +11,15 @@ Every probe is an independent Solve() on (cluster − candidates, pending + disp
 data-parallel: probes are independent scheduling problems, each one wavefront on its own CU (`sweep` runs them on
 several device sessions concurrently). `solver` is any callable problem -> Results document; the product passes
 `lambda p: NewScheduler(p).Solve()`, the parity tests pass the oracle.
+
+Around the simulator sits the float arithmetic that turns a simulation into a decision, also here:
+
+    EvictionCost / ReschedulingCost          utils/disruption/disruption.go:48-76
+    Candidate.Price / RescheduleDisruptionCost / SavingsRatio   disruption/types.go:94-146,209-210
+    computeNodePoolTotals / ScoreMove / EvaluateBalancedMove / balancedEvaluator   balanced.go:47-299
+    Command.EstimatedSavings / SourceCost / PoolDisruptionCost  types.go:272-284,355-386
+    validation.validateCommand (re-simulation + subset check)   validation.go:297-357
+
 Out of scope here (kube side effects): budgets, PDBs, validation delay, taint/launch orchestration.
 """
 from __future__ import annotations
@@ -61,18 +70,185 @@ def worst_launch_price(it, reqs_by_key):
 
 
 def candidate_price(cluster, node):
-    """Candidate price: the offering the node was launched with (disruption/types.go:161-211)."""
-    it = next(t for t in cluster["instanceTypes"] if t["name"] == node["labels"][fx.INSTANCE_TYPE])
+    """resolveNodePrice (disruption/types.go:113-127): the price of the offering matching the node's zone and
+    capacity-type labels; 0 when the instance type is unknown, no offering matches, or the price is NaN."""
+    it = next((t for t in cluster["instanceTypes"] if t["name"] == node["labels"].get(fx.INSTANCE_TYPE)), None)
+    if it is None:
+        return 0.0
     for o in it["offerings"]:
         zone = next(r["values"][0] for r in o["requirements"] if r["key"] == fx.ZONE)
-        if zone == node["labels"][fx.ZONE] and _capacity_type(o) == node["labels"][fx.CAPACITY_TYPE]:
-            return o["price"]
-    return math.inf
+        if zone == node["labels"].get(fx.ZONE) and _capacity_type(o) == node["labels"].get(fx.CAPACITY_TYPE):
+            return 0.0 if math.isnan(o["price"]) else o["price"]
+    return 0.0
+
+
+POD_DELETION_COST = "controller.kubernetes.io/pod-deletion-cost"
+PER_NODE_BASE_DISRUPTION_COST = 1.0   # types.go:132
+BALANCED_K = 2                        # apis/v1/nodepool.go:172
+BALANCED = "Balanced"
+
+
+def eviction_cost(pod):
+    """EvictionCost (utils/disruption/disruption.go:48-70): 1 + deletion-cost/2^27 + priority/2^25, clamped to [-10, 10].
+    An unparsable annotation is ignored (the reference logs and carries on)."""
+    cost = 1.0
+    raw = pod.get("annotations", {}).get(POD_DELETION_COST)
+    if raw is not None:
+        try:
+            cost += float(raw) / 2.0 ** 27
+        except ValueError:
+            pass
+    if pod.get("priority") is not None:
+        cost += float(pod["priority"]) / 2.0 ** 25
+    return min(10.0, max(-10.0, cost))
+
+
+def reschedule_disruption_cost(pods):
+    """computeRescheduleDisruptionCost (types.go:137-143): per-node base + the positive eviction costs."""
+    cost = PER_NODE_BASE_DISRUPTION_COST
+    for p in pods:
+        cost += max(0.0, eviction_cost(p))
+    return cost
 
 
 def savings_ratio(cluster, node):
-    """SavingsRatio = price / disruption cost (types.go:146); disruption cost here = number of reschedulable pods + 1."""
-    return candidate_price(cluster, node) / (len(node.get("pods", [])) + 1.0)
+    """Candidate.SavingsRatio = Price / RescheduleDisruptionCost (types.go:146)."""
+    return candidate_price(cluster, node) / reschedule_disruption_cost(node.get("pods", []))
+
+
+def _pool_name(node):
+    return node["labels"].get(fx.NODEPOOL)
+
+
+def _pool(cluster, name):
+    return next((np_ for np_ in cluster["nodePools"] if np_["name"] == name), None)
+
+
+def _is_balanced(cluster, pool_name):
+    np_ = _pool(cluster, pool_name)
+    return bool(np_) and np_.get("consolidationPolicy") == BALANCED
+
+
+class ScoreResult:
+    """ScoreResult (types.go:94-111): approved when (savings/total cost) / (disruption/total disruption) >= 1/k."""
+
+    def __init__(self, savings_fraction=0.0, disruption_fraction=0.0, k=BALANCED_K):
+        self.savings_fraction, self.disruption_fraction, self.k = savings_fraction, disruption_fraction, k
+
+    def score(self):
+        if self.savings_fraction <= 0:
+            return 0.0
+        if self.disruption_fraction == 0:
+            return math.inf
+        return self.savings_fraction / self.disruption_fraction
+
+    def threshold(self):
+        return 1.0 / float(self.k)
+
+    def approved(self):
+        return self.score() >= self.threshold()
+
+
+def score_move(savings, disruption_cost, totals, k=BALANCED_K):
+    """ScoreMove (balanced.go:105-121). `totals` = {"totalCost", "totalDisruptionCost"}."""
+    if totals.get("totalCost", 0.0) <= 0 or totals.get("totalDisruptionCost", 0.0) <= 0:
+        return ScoreResult(k=k)
+    return ScoreResult(savings / totals["totalCost"], disruption_cost / totals["totalDisruptionCost"], k)
+
+
+def compute_nodepool_totals(cluster, candidates, cluster_cost=None):
+    """computeNodePoolTotals (balanced.go:47-103). Cost: the pool's tracked cluster cost when positive, else the sum of
+    its candidates' prices. Disruption: every node of the pool (candidate or not) contributes its
+    RescheduleDisruptionCost — "non-candidate nodes still contribute to the denominators"."""
+    fallback = {}
+    for c in candidates:
+        fallback[_pool_name(c)] = fallback.get(_pool_name(c), 0.0) + candidate_price(cluster, c)
+    disruption = {}
+    for n in cluster["nodes"]:
+        name = _pool_name(n)
+        if name is None:
+            continue
+        disruption[name] = disruption.get(name, 0.0) + reschedule_disruption_cost(n.get("pods", []))
+    totals = {}
+    for name, cost in fallback.items():
+        cc = (cluster_cost or {}).get(name, 0.0)
+        totals[name] = {"totalCost": cc if cc > 0 else cost, "totalDisruptionCost": disruption.get(name, 0.0)}
+    return totals
+
+
+def estimated_savings(cluster, candidates, cmd):
+    """Command.EstimatedSavings (types.go:364-386): source price, minus — for a replace — the cheapest available
+    offering compatible with the claim's requirements of each new claim's FIRST instance type option."""
+    source = sum(candidate_price(cluster, c) for c in candidates)
+    if cmd["decision"] != REPLACE:
+        return source
+    by_name = {t["name"]: t for t in cluster["instanceTypes"]}
+    dest = 0.0
+    for i, claim in enumerate(cmd["results"]["newNodeClaims"]):
+        # the command's claim was put in OrderByPrice order before the price filter (consolidation.go:209), so option 0
+        # is the option with the lowest cheapest-compatible-available price; ties carry the same price
+        options = cmd["replacement"] if i == 0 else claim["instanceTypes"]
+        reqs = {r["key"]: r for r in claim["requirements"]}
+        best = math.inf
+        for n in options:
+            best = min([best] + [o["price"] for o in by_name[n]["offerings"] if o.get("available", True) and _offering_compatible(reqs, o)])
+        if best < math.inf:
+            dest += best
+    return source - dest
+
+
+def evaluate_balanced_move(cluster, candidates, cmd, totals):
+    """EvaluateBalancedMove (balanced.go:131-183) → (approved, {pool: ScoreResult}). Every Balanced pool among the
+    command's candidates must approve; other pools are skipped. Cross-pool moves split the net savings by each pool's
+    share of the source cost."""
+    if not candidates:
+        return False, None
+    by_pool = {}
+    for c in candidates:
+        by_pool.setdefault(_pool_name(c), []).append(c)
+    savings = estimated_savings(cluster, candidates, cmd)
+    total_cost = sum(candidate_price(cluster, c) for c in candidates)
+    approved, per_pool = True, {}
+    for name, members in by_pool.items():
+        if not _is_balanced(cluster, name):
+            continue
+        disruption = sum(reschedule_disruption_cost(c.get("pods", [])) for c in members)
+        pool_savings = savings
+        if total_cost > 0 and len(by_pool) > 1:
+            pool_savings = savings * (sum(candidate_price(cluster, c) for c in members) / total_cost)
+        r = score_move(pool_savings, disruption, totals.get(name, {}), BALANCED_K)
+        per_pool[name] = r
+        approved = approved and r.approved()
+    return approved, per_pool
+
+
+class BalancedEvaluator:
+    """balancedEvaluator (balanced.go:207-299) without the metrics/events. `NoopEvaluator` is what consolidation uses
+    until SetNodePoolTotals is called (consolidation.go:61-85)."""
+
+    def __init__(self, cluster, totals):
+        self.cluster, self.totals = cluster, totals
+
+    def approve_command(self, candidates, cmd):
+        return evaluate_balanced_move(self.cluster, candidates, cmd, self.totals)
+
+    def can_pass_threshold(self, candidate):
+        """A DELETE saves the whole node price: if even that cannot pass, no REPLACE will (balanced.go:284-299)."""
+        name = _pool_name(candidate)
+        if not _is_balanced(self.cluster, name):
+            return True
+        t = self.totals.get(name)
+        if not t or t["totalCost"] <= 0:
+            return True
+        return score_move(candidate_price(self.cluster, candidate), reschedule_disruption_cost(candidate.get("pods", [])), t, BALANCED_K).approved()
+
+
+class NoopEvaluator:
+    def approve_command(self, candidates, cmd):
+        return True, None
+
+    def can_pass_threshold(self, candidate):
+        return True
 
 
 def sort_candidates(cluster, nodes):
@@ -141,8 +317,10 @@ def compute_consolidation(cluster, candidates, solver):
     return cmd
 
 
-def first_n_consolidation_option(cluster, candidates, solver, max_n=100):
-    """multinodeconsolidation.go:117-207: binary search for the longest prefix that consolidates; same probe sequence."""
+def first_n_consolidation_option(cluster, candidates, solver, max_n=100, evaluator=None):
+    """multinodeconsolidation.go:117-207: binary search for the longest prefix that consolidates; same probe sequence.
+    A valid decision is then scored by the evaluator (:166-174): Balanced pools may reject it, which shrinks the window."""
+    evaluator = evaluator or NoopEvaluator()
     if len(candidates) < 2:
         return {"decision": NOOP, "candidates": []}, []
     lo, hi = 1, min(len(candidates) - 1, max_n - 1) if len(candidates) <= max_n else max_n
@@ -166,19 +344,53 @@ def first_n_consolidation_option(cluster, candidates, solver, max_n=100):
             cmd["replacement"] = [n for n in cmd["replacement"] if worst_launch_price(by_name[n], reqs) < max_price]
             valid = bool(cmd["replacement"])
         if valid:
+            approved, per_pool = evaluator.approve_command(candidates[: mid + 1], cmd)
+            cmd["scores"] = per_pool
+            valid = approved
+        if valid:
             last, lo = cmd, mid + 1
         else:
             hi = mid - 1
     return last, probes
 
 
-def single_node_consolidation(cluster, candidates, solver):
-    """singlenodeconsolidation.go:55-126: the first candidate (in sorted order) with a valid command."""
+def single_node_consolidation(cluster, candidates, solver, evaluator=None):
+    """singlenodeconsolidation.go:55-126: the first candidate (in sorted order) with a valid command. Candidates whose
+    best case (a DELETE) cannot pass the Balanced threshold are skipped without a simulation (:88), and a computed
+    command is scored before it is accepted (:101-104)."""
+    evaluator = evaluator or NoopEvaluator()
     for c in candidates:
+        if not evaluator.can_pass_threshold(c):
+            continue
         cmd = compute_consolidation(cluster, [c], solver)
-        if cmd["decision"] != NOOP:
-            return cmd
+        if cmd["decision"] == NOOP:
+            continue
+        approved, per_pool = evaluator.approve_command([c], cmd)
+        if not approved:
+            continue
+        cmd["scores"] = per_pool
+        return cmd
     return {"decision": NOOP, "candidates": []}
+
+
+def validate_command(cluster, candidates, cmd, solver):
+    """validation.validateCommand (validation.go:297-357): re-simulate on the current cluster and accept only when the
+    outcome still matches the command — no new claim for a delete; for a replace exactly one claim whose instance types
+    are a superset of the command's. Returns None when valid, else the reference's error text."""
+    if not candidates:
+        return "no candidates"
+    res = simulate_scheduling(cluster, candidates, solver)
+    if not res["allNonPendingPodsScheduled"]:
+        return "pods would not schedule"
+    claims = res["newNodeClaims"]
+    expecting = cmd["decision"] == REPLACE
+    if len(claims) == 0:
+        return None if not expecting else "scheduling simulation produced new results"
+    if len(claims) > 1 or not expecting:
+        return "scheduling simulation produced new results"
+    if not set(cmd["replacement"]) <= set(claims[0]["instanceTypes"]):   # instanceTypesAreSubset
+        return "scheduling simulation produced new results"
+    return None
 
 
 class _Recorder:
