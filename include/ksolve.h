@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KSOLVE_ABI_VERSION 2
+#define KSOLVE_ABI_VERSION 3
 #define KSOLVE_MAX_KEYS 32        /* requirement keys per problem (one bit each in the u32 flag words) */
 #define KSOLVE_MAX_RES 8          /* resource dimensions */
 #define KSOLVE_MAX_TEMPLATES 32   /* NodeClaimTemplates (NodePools that survived prefiltering) */
@@ -98,6 +98,13 @@ typedef struct {
                                 * order is undefined where the reference breaks ties, topologygroup.go:259,355,372; ties go
                                 * to the lexicographically smallest domain) */
   const int32_t* node_hostname_value;   /* n_nodes : value index of the node's hostname in key_hostname's dictionary, -1 = none */
+  const int32_t* alias_class;  /* n, may be NULL; -1 = none. Groups created by relaxation (initially_active == 0) that share one
+                                * TopologyGroup.Hash() but were built from different pods (the hash ignores the node filter's
+                                * values and the domains, topologygroup.go:188-222) carry the same class id in
+                                * [0, n_alias_classes): Topology.Update reuses the group found by hash (topology.go:162-194), so
+                                * only the member whose owner relaxes FIRST comes to exist, and every later owner of another
+                                * member owns that one instead. */
+  uint32_t n_alias_classes;
 } ksolve_topology;
 
 typedef struct {

@@ -1605,9 +1605,32 @@ struct Engine {
         if (w >= T.words) return false;
         const uint64_t ow = ct[w], se = ct[T.words + w], inv = T.inverse_mask[w];
         const uint64_t mt = (ow & ~inv) | (se & inv);
-        s_.t_owned[w] = ow; s_.t_sel[w] = se; s_.t_match[w] = mt; s_.t_active[w] |= ow & ~inv;
+        s_.t_owned[w] = ow; s_.t_sel[w] = se; s_.t_match[w] = mt; s_.t_active[w] |= ow & ~inv & ~T.alias_mask[w];
         return mt != 0;
       });
+      if (T.n_alias) {
+        // Topology.Update looks a relaxed pod's group up by TopologyGroup.Hash() (topology.go:162-194): of the same-hash
+        // groups different pods would build, the one created first exists and every later owner joins it
+        W::sync();
+        for (int w = 0; w < T.words; ++w) for (uint64_t m = ct[w] & T.alias_mask[w]; m; m &= m - 1) {
+          const int g = w * 64 + ctz64(m);
+          int32_t* slot = S.tg_alias_active + T.alias_class[g];
+          const int a = *slot;
+          const uint64_t gb = 1ull << (g & 63);
+          if (a < 0) {
+            W::store(slot, (int32_t)g);
+            W::store(&s_.t_active[w], (uint64_t)(s_.t_active[w] | gb));
+          } else if (a != g) {
+            W::store(&s_.t_owned[w], (uint64_t)(s_.t_owned[w] & ~gb));
+            W::store(&s_.t_match[w], (uint64_t)(s_.t_match[w] & ~gb));
+            W::sync();
+            const uint64_t ab = 1ull << (a & 63);
+            W::store(&s_.t_owned[a >> 6], (uint64_t)(s_.t_owned[a >> 6] | ab));
+            W::store(&s_.t_match[a >> 6], (uint64_t)(s_.t_match[a >> 6] | ab));
+          }
+          W::sync();
+        }
+      }
       const uint64_t anyR = W::ballot([&](int w) { return w < T.words && (ct[w] | ct[T.words + w]) != 0; });
       W::sync();
       cur_M = anyM != 0; cur_rec = anyR != 0;
@@ -1716,6 +1739,7 @@ struct Engine {
       W::for_n(T.n_host_groups * P.n_nodes, [&](int i) { Sw.tg_node_counts[i] = T.node_counts0[i]; });
       W::for_n(G, [&](int i) { Sw.tg_nonzero[i] = T.nonzero0[i]; });
       W::for_n(T.words, [&](int w) { sc.t_active[w] = T.initially_active[w]; });
+      W::for_n(T.n_alias, [&](int i) { Sw.tg_alias_active[i] = -1; });
     }
     load_tables();
     if (FULL && P.reserved_on) W::for_n(P.n_resv, [&](int i) { sc.resv_cap[i] = P.resv_cap0[i]; });

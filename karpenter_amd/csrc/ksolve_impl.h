@@ -389,8 +389,8 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     const uint32_t G = t.n;
     T.n_groups = (int)G; T.dom_words = (int)std::max(1u, t.domain_words);
     T.words = (int)((G + 63) / 64);
-    for (int w = 0; w < ks::kMaxTopoWords; ++w) { T.inverse_mask[w] = 0; T.initially_active[w] = 0; }
-    T.n_host_groups = 0;
+    for (int w = 0; w < ks::kMaxTopoWords; ++w) { T.inverse_mask[w] = 0; T.initially_active[w] = 0; T.alias_mask[w] = 0; }
+    T.n_host_groups = 0; T.n_alias = 0; T.alias_class = nullptr;
     if (G) {
       std::vector<int16_t> host_slot(G, -1);
       std::vector<int32_t> nonzero(G, 0);
@@ -443,6 +443,19 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       W.tg_claim_counts = dz<int32_t>(h, (size_t)std::max(1, T.n_host_groups) * mc);
       W.host_le = dz<uint64_t>(h, (size_t)std::max(1, T.n_host_groups) * 2 * h->claim_words);
       W.tg_nonzero = dz<int32_t>(h, G);
+      if (t.alias_class && t.n_alias_classes) {
+        std::vector<int16_t> ac(G, -1);
+        for (uint32_t g = 0; g < G; ++g) {
+          const int32_t c = t.alias_class[g];
+          if (c < 0) continue;
+          if ((uint32_t)c >= t.n_alias_classes || t.n_alias_classes > 32767) return fail(h, KSOLVE_ERR_INVALID, "topology alias class out of range");
+          if (t.inverse[g] || t.initially_active[g]) return fail(h, KSOLVE_ERR_INVALID, "only groups created by relaxation can share a hash with different contents");
+          ac[g] = (int16_t)c; T.alias_mask[g >> 6] |= 1ull << (g & 63);
+        }
+        T.n_alias = (int)t.n_alias_classes;
+        T.alias_class = up(h, ac.data(), G);
+        W.tg_alias_active = dz<int32_t>(h, t.n_alias_classes);
+      }
     }
   }
   {

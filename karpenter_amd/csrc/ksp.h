@@ -113,6 +113,9 @@ struct TopoView {
   const uint64_t* f_tolerates;   // [G]
   const uint16_t* value_rank;    // [req_words*64]
   const int32_t* node_host_value;  // [n_nodes]
+  int n_alias;                    // classes of same-hash groups of which only the first created member exists
+  const int16_t* alias_class;     // [G] class id or -1 (null when n_alias == 0)
+  uint64_t alias_mask[kMaxTopoWords];  // groups with alias_class >= 0
   const uint64_t* cls_topo;      // [n_classes][2*words] owned | selected (class_gather)
 };
 
@@ -218,6 +221,7 @@ struct Workspace {
   int32_t* tg_node_counts;       // [n_host_groups][n_nodes]      hostname groups: pods per existing node
   int32_t* tg_claim_counts;      // [n_host_groups][max_claims]   hostname groups: pods per in-flight claim
   int32_t* tg_nonzero;           // [G] number of domains with a positive count
+  int32_t* tg_alias_active;      // [n_alias] the member of each alias class that exists, -1 = none yet
   // queue (queue.go): circular buffer of pod ids + lastLen
   uint32_t* queue;               // [n_pods+1]
   uint32_t* last_len;            // [n_pods] 0 = never pushed

@@ -50,6 +50,8 @@ def quantity_float(q) -> float:
 
 
 def req(key, operator, *values, min_values=None):
+    if len(values) == 1 and isinstance(values[0], (list, tuple)):
+        values = tuple(values[0])
     r = {"key": key, "operator": operator, "values": [str(v) for v in values]}
     if min_values is not None:
         r["minValues"] = min_values

@@ -501,7 +501,7 @@ struct Session {
   std::vector<uint8_t> node_initialized;
   std::vector<std::pair<uint64_t, uint64_t>> group_of_pod;
   std::vector<i128> scale;
-  int n_pods = 0, n_rows = 0, n_its = 0, n_res = 0, it_words = 0, k_rid = -1;
+  int n_pods = 0, n_rows = 0, n_its = 0, n_res = 0, it_words = 0, k_rid = -1, n_topo_groups = 0, n_alias_classes = 0;
   std::string error_kind, error;
 };
 
@@ -1053,6 +1053,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     // KEYS and minValues, policies, tolerations); minDomains and requirement values are not part of it.
     struct HGroup {
       int type = 0; std::string key; bool inverse = false, initial = false;
+      int alias = -1;   // class of same-hash groups created by relaxation with different contents (first creator wins at solve time)
       std::set<std::string> namespaces; Selector sel; int max_skew = 0, min_domains = -1;
       std::string taint_policy, affinity_policy;
       std::vector<std::vector<Expr>> freqs; uint64_t ftol = 0;
@@ -1067,6 +1068,8 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       }
     };
     std::vector<HGroup> groups;
+    std::map<std::string, std::vector<int>> alias_members;
+    int n_alias_classes = 0;
     std::vector<std::vector<std::vector<int>>> variant_owned(specs.size());   // group ids per (spec, variant)
     std::vector<std::vector<int>> spec_inverse_owned(specs.size());
     bool any_topology = false;
@@ -1262,10 +1265,24 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
                 id = (int)groups.size() - 1;
                 group_by_identity[tg.identity] = id;
               } else if (!groups[id].initial) {
-                // a group that first appears when some pod relaxes is created by whichever pod relaxes first; that is only
-                // well-defined without running the solve when every candidate creator would build the same group
+                // a group that first appears when some pod relaxes is created by whichever pod relaxes first, and every
+                // later owner joins that one (Topology.Update looks the group up by hash, topology.go:162-194). Creators
+                // that would build different contents under one hash become members of an alias class; the solver keeps
+                // the member that is created first
                 count_domains(tg);
-                if (tg.content() != groups[id].content()) throw Unsupported("relaxation would create a topology group whose contents depend on scheduling order");
+                const std::string want = tg.content();
+                int match = -1;
+                for (int m : alias_members[tg.identity]) if (groups[m].content() == want) { match = m; break; }
+                if (match < 0 && groups[id].content() == want) match = id;
+                if (match < 0) {
+                  auto& members = alias_members[tg.identity];
+                  if (members.empty()) { members.push_back(id); groups[id].alias = n_alias_classes++; }
+                  tg.initial = false; tg.alias = groups[id].alias;
+                  groups.push_back(tg);
+                  match = (int)groups.size() - 1;
+                  members.push_back(match);
+                }
+                id = match;
               }
               variant_groups[si][vi].push_back(id);
             }
@@ -1285,7 +1302,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     }
     const int G = (int)groups.size();
     std::vector<uint8_t> tg_type(G), tg_inverse(G), tg_initial(G), tg_fa(G), tg_ft(G);
-    std::vector<int32_t> tg_key(G), tg_skew(G), tg_mind(G);
+    std::vector<int32_t> tg_key(G), tg_skew(G), tg_mind(G), tg_alias(G, -1);
     std::vector<uint32_t> tg_ffirst(G + 1, 0);
     std::vector<uint64_t> tg_ftol(G), tg_domains;
     std::vector<int32_t> tg_counts, tg_node_counts;
@@ -1304,7 +1321,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       for (int gi = 0; gi < G; ++gi) {
         const HGroup& g = groups[gi];
         tg_type[gi] = (uint8_t)g.type; tg_inverse[gi] = g.inverse; tg_initial[gi] = g.initial;
-        tg_skew[gi] = g.max_skew; tg_mind[gi] = g.min_domains;
+        tg_skew[gi] = g.max_skew; tg_mind[gi] = g.min_domains; tg_alias[gi] = g.alias;
         tg_fa[gi] = g.affinity_policy == "Honor"; tg_ft[gi] = g.taint_policy == "Honor"; tg_ftol[gi] = g.ftol;
         tg_ffirst[gi] = (uint32_t)fi;
         for (auto& r : g.freqs) {
@@ -1394,6 +1411,8 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       t.init_counts = tg_counts.data(); t.init_node_counts = tg_node_counts.data();
       t.filter_affinity_honor = tg_fa.data(); t.filter_taint_honor = tg_ft.data(); t.filter_first = tg_ffirst.data(); t.filter_reqs = tg_freqs.view();
       t.filter_tolerates = tg_ftol.data(); t.value_rank = value_rank.data(); t.node_hostname_value = node_host_value.data();
+      if (n_alias_classes) { t.alias_class = tg_alias.data(); t.n_alias_classes = (uint32_t)n_alias_classes; }
+      S->n_topo_groups = G; S->n_alias_classes = n_alias_classes;
       d.pod_topo_owned = pod_topo_owned.data(); d.pod_topo_selected = pod_topo_selected.data();
     }
     ksolve_options ko{};
@@ -1491,6 +1510,7 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
     counters.set("slowSorts", Value::integer((int64_t)res.slow_sorts)); counters.set("relaxations", Value::integer((int64_t)res.relaxations));
     counters.set("pods", Value::integer(n_pods)); counters.set("claims", Value::integer(cl.n_claims));
     counters.set("rows", Value::integer(n_rows)); counters.set("instanceTypes", Value::integer(n_its));
+    counters.set("topologyGroups", Value::integer(S->n_topo_groups)); counters.set("topologyAliasClasses", Value::integer(S->n_alias_classes));
     counters.set("reqWords", Value::integer(rw)); counters.set("itWords", Value::integer(it_words)); counters.set("keys", Value::integer(nk)); counters.set("resources", Value::integer(n_res));
     { Value pc = Value::array(); for (int i = 0; i < 24; ++i) pc.push(Value::integer((int64_t)res.phase_cycles[i])); counters.set("phaseCycles", pc); }
     out.set("counters", counters);

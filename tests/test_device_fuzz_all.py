@@ -84,7 +84,7 @@ def run(oracle, emu, seed):
         for c in r["newNodeClaims"]: c["instanceTypes"] = sorted(c["instanceTypes"])
     parity.assert_same_results(got, want)
     assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
-    return (len(pods), len(got["newNodeClaims"]), len(got["podErrors"]))
+    return (len(pods), len(got["newNodeClaims"]), len(got["podErrors"]), got["counters"]["topologyAliasClasses"])
 
 
 @pytest.mark.parametrize("block", range(6))
@@ -153,7 +153,7 @@ def run_wide(oracle, emu, seed):
         return ("unsupported", str(e)[:80])
     parity.assert_same_results(got, want)
     assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
-    return (len(pods), len(got["newNodeClaims"]), len(got["podErrors"]), got["counters"]["relaxations"])
+    return (len(pods), len(got["newNodeClaims"]), len(got["podErrors"]), got["counters"]["relaxations"], got["counters"]["topologyAliasClasses"])
 
 
 @pytest.mark.parametrize("block", range(4))

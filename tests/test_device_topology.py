@@ -140,3 +140,24 @@ def test_topology_fuzz(oracle, emu, seed):
         pools = [fx.node_pool("a", requirements=[fx.req(fx.ZONE, "In", ["test-zone-1", "test-zone-2"])], weight=10), fx.node_pool("b")]
     its = fx.fake_instance_types(12) if seed % 2 else fx.fake_default_instance_types()
     check(oracle, emu, fx.problem(its, pools, pods))
+
+
+def test_same_hash_groups_created_by_relaxation(oracle, emu):
+    """TopologyGroup.Hash() covers the node filter's KEYS, not its values (topologygroup.go:188-222), and Topology.Update
+    reuses whatever group it finds under the hash (topology.go:162-194). Two workloads whose first node-affinity term is
+    unsatisfiable relax to filters over the same key with different zones: whichever relaxes first creates the group and
+    the other joins it, so the outcome depends on the queue order. Both orders must match the oracle."""
+    def workload(cpu, zones, n):
+        terms = [[fx.req("example.com/unknown", "In", "x")], [fx.req(fx.ZONE, "In", *zones)]]
+        return [fx.pod(labels=LAB, requests={"cpu": cpu}, node_requirements=terms, topology_spread=[fx.spread(fx.ZONE, LAB)]) for _ in range(n)]
+    seen = []
+    for first, second in ((["test-zone-1", "test-zone-2"], ["test-zone-2", "test-zone-3"]), (["test-zone-2", "test-zone-3"], ["test-zone-1", "test-zone-2"])):
+        pods = workload("1", first, 5) + workload("500m", second, 5)     # the larger pods pop (and relax) first
+        got, _ = solve_both(oracle, emu, pods)
+        assert got["counters"]["topologyAliasClasses"] == 1 and got["counters"]["relaxations"] >= 2
+        seen.append(sorted((c["requirements"] and [r["values"] for r in c["requirements"] if r["key"] == fx.ZONE][0], len(c["pods"])) for c in got["newNodeClaims"]))
+    assert seen[0] != seen[1]
+    # three creators, one of them joining an identical existing member
+    pods = workload("2", ["test-zone-1"], 3) + workload("1", ["test-zone-3"], 3) + workload("500m", ["test-zone-1"], 3) + workload("250m", ["test-zone-2", "test-zone-3"], 3)
+    got, _ = solve_both(oracle, emu, pods)
+    assert got["counters"]["topologyAliasClasses"] == 1
