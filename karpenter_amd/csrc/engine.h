@@ -1595,7 +1595,7 @@ struct Engine {
     if (FULL && (sc.cls[lay.k_f1()] != 0 || (lo32(sc.cls[lay.k_meta()]) & 1u))) load_words(sc.cls_cold, P.cls_cold + (size_t)k * lay.cold_words(), lay.cold_words());
     cur_class = k;
 
-    if (P.topo.n_groups) {
+    if (FULL && P.topo.n_groups) {
       const TopoView& T = P.topo;
       const uint64_t* ct = T.cls_topo + (size_t)k * 2 * T.words;
       Scratch& s_ = sc;
@@ -1766,7 +1766,7 @@ struct Engine {
         W::for_n(64, [&](int l) {
           if (l < bn) { uint32_t p = queue[(h0 + (uint32_t)l) % cap]; bp[l] = p; bc[l] = rc_[p]; bl[l] = ll[p]; }
         });
-        if (S.cancel_flag && *S.cancel_flag) { status = 2; break; }   // ctx cancellation, polled once per 64 pods
+        if (S.cancel_flag && W::poll_flag(S.cancel_flag)) { status = 2; break; }   // ctx cancellation, polled once per 64 pods
       }
       int pod = (int)sc.blk_pod[blk_i];
       if (sc.blk_last[blk_i] == qlen) break;                                // queue.go:52-56

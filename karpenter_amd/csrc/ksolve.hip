@@ -53,7 +53,7 @@ static void be_fill(ksolve_handle* h, void* dst, int byte, size_t bytes) {
   if (!dst || !bytes) return;
   hip_check(h, hipMemsetAsync(dst, byte, bytes, HB(h)->stream), "hipMemsetAsync");
 }
-static void be_thread_init(ksolve_handle* h) { hipSetDevice(HB(h)->device); }
+static void be_thread_init(ksolve_handle* h) { (void)hipSetDevice(HB(h)->device); }
 static void be_sync(ksolve_handle* h) { hip_check(h, hipStreamSynchronize(HB(h)->stream), "hipStreamSynchronize"); }
 static bool be_ok(ksolve_handle* h) { return !HB(h)->failed; }
 static void be_tic(ksolve_handle* h, int slot) { hip_check(h, hipEventRecord(HB(h)->ev0[slot], HB(h)->stream), "hipEventRecord"); }
@@ -189,7 +189,7 @@ static void finish_batch_group(std::vector<ksolve_handle*>& g, ks::BatchItem* d_
   float ms = 0;
   if (hipEventElapsedTime(&ms, b->ev0[ksi::T_PACK], b->ev1[ksi::T_PACK]) == hipSuccess) h0->timers.ms[ksi::T_PACK] = ms;
   for (size_t i = 1; i < g.size(); ++i) { g[i]->timers.ms[ksi::T_PACK] = h0->timers.ms[ksi::T_PACK]; if (b->failed) { HB(g[i])->failed = true; g[i]->error = h0->error; } }
-  if (d_items) hipFree(d_items);
+  if (d_items) (void)hipFree(d_items);
 }
 static void be_launch_pack_batch(ksolve_handle** hs, int n) {
   std::vector<ksolve_handle*> lite, full;
@@ -218,7 +218,7 @@ static void be_sort_pods(ksolve_handle* h) {
     size_t need = 0;
     hip_check(h, rocprim::radix_sort_pairs(nullptr, need, h->d_key_a, h->d_key_b, in, out, (size_t)n, 0, 64, b->stream), "radix_sort_pairs(size)");
     if (need > b->sort_tmp_bytes) {
-      if (b->sort_tmp) hipFree(b->sort_tmp);
+      if (b->sort_tmp) (void)hipFree(b->sort_tmp);
       b->sort_tmp = nullptr;
       if (!hip_check(h, hipMalloc(&b->sort_tmp, need), "hipMalloc(sort)")) return;
       b->sort_tmp_bytes = need;
@@ -266,7 +266,7 @@ ksolve_status ksolve_cancel(ksolve_handle* h) {
   if (!h || !h->d_cancel) return KSOLVE_ERR_INVALID;
   int one = 1;
   // written from another thread while the pack kernel polls the flag between pods
-  hipMemcpy(h->d_cancel, &one, sizeof(int), hipMemcpyHostToDevice);
+  (void)hipMemcpy(h->d_cancel, &one, sizeof(int), hipMemcpyHostToDevice);
   return KSOLVE_OK;
 }
 void ksolve_results_free(ksolve_results* r) {
@@ -276,10 +276,10 @@ void ksolve_destroy(ksolve_handle* h) {
   if (!h) return;
   HipBackend* b = HB(h);
   if (b) {
-    if (b->stream) hipStreamSynchronize(b->stream);
-    for (void* p : h->allocations) hipFree(p);
-    if (b->sort_tmp) hipFree(b->sort_tmp);
-    if (b->stream) { for (int i = 0; i < 8; ++i) { hipEventDestroy(b->ev0[i]); hipEventDestroy(b->ev1[i]); } hipStreamDestroy(b->stream); }
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (void* p : h->allocations) (void)hipFree(p);
+    if (b->sort_tmp) (void)hipFree(b->sort_tmp);
+    if (b->stream) { for (int i = 0; i < 8; ++i) { (void)hipEventDestroy(b->ev0[i]); (void)hipEventDestroy(b->ev1[i]); } (void)hipStreamDestroy(b->stream); }
     delete b;
   }
   delete h;

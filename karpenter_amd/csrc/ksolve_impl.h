@@ -538,10 +538,14 @@ struct ResultsImpl {
 };
 
 // Phases 1-3 (instance-type index, pod classes, queue order) and the resets the pack kernel needs.
-static ksolve_status solve_prepare(ksolve_handle* h) {
+// fresh_context: this is the start of a Solve() call (not the re-run of one on the BIG engine): every Solve starts with
+// a context that is not cancelled. The flag is cleared synchronously, so a ksolve_cancel that arrives at any later
+// moment of the call — during classification, the queue sort or the pack kernel — is kept.
+static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) {
   ks::ProblemView& P = h->pv;
   ks::Workspace& W = h->ws;
   const uint32_t n_pods = h->n_pods, n_rows = h->n_rows, n_res = h->n_res;
+  if (fresh_context) { be_fill(h, h->d_cancel, 0, 4); be_sync(h); }
 
   // ---- phase 1: instance-type requirement index ----
   be_tic(h, T_INDEX);
@@ -618,7 +622,6 @@ static ksolve_status solve_prepare(ksolve_handle* h) {
   be_fill(h, W.assign, 0xFF, (size_t)n_pods * 4);
   be_fill(h, W.err, 0, n_pods); be_fill(h, W.diag, 0, n_pods);
   be_fill(h, W.n_claims_out, 0, 4); be_fill(h, W.status_out, 0, 4);
-  be_fill(h, h->d_cancel, 0, 4);
   if (P.topo.n_host_groups) be_fill(h, W.tg_claim_counts, 0, (size_t)P.topo.n_host_groups * h->max_claims * 4);
   if (P.topo.n_host_groups) be_fill(h, W.host_le, 0xFF, (size_t)P.topo.n_host_groups * 2 * h->claim_words * 8);
   if (P.topo.n_key_slots) be_fill(h, W.kv_claims, 0, (size_t)P.topo.n_key_slots * 64 * h->claim_words * 8);
@@ -779,10 +782,9 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
 }
 
 static void be_results_drop(ksolve_results* r) { if (r && r->impl) { delete (ResultsImpl*)r->impl; r->impl = nullptr; } }
-static ksolve_status solve(ksolve_handle* h, ksolve_results* out);
-static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
+static ksolve_status solve(ksolve_handle* h, ksolve_results* out, bool fresh_context = true) {
   memset(out, 0, sizeof(*out));
-  ksolve_status st = solve_prepare(h);
+  ksolve_status st = solve_prepare(h, fresh_context);
   if (st != KSOLVE_OK) return st;
   be_tic(h, T_PACK);
   if (h->n_pods) be_launch_pack(h);
@@ -794,7 +796,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out) {
     if (status == 1) {
       // more in-flight claims than the LDS-resident order holds: this problem runs on the BIG engine from now on
       h->pv.big = 1; h->pv.lite = 0; h->pv.lds = h->lds_big;
-      st = solve_prepare(h);
+      st = solve_prepare(h, false);
       if (st != KSOLVE_OK) return st;
       be_tic(h, T_PACK);
       be_launch_pack(h);
@@ -825,7 +827,7 @@ static ksolve_status solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results*
   parallel([&](uint32_t i) {
     if (st[i] != KSOLVE_OK) return;
     st[i] = solve_finish(hs[i], &outs[i]);
-    if (st[i] == KSOLVE_ERR_CAPACITY && hs[i]->big_capable && !hs[i]->pv.big) { be_results_drop(&outs[i]); st[i] = solve(hs[i], &outs[i]); }   // re-run alone on the BIG engine
+    if (st[i] == KSOLVE_ERR_CAPACITY && hs[i]->big_capable && !hs[i]->pv.big) { be_results_drop(&outs[i]); st[i] = solve(hs[i], &outs[i], false); }   // re-run alone on the BIG engine
   });
   ksolve_status worst = KSOLVE_OK;
   for (uint32_t i = 0; i < n; ++i) if (st[i] != KSOLVE_OK && st[i] != KSOLVE_ERR_CANCELLED) worst = st[i];

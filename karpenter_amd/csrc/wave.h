@@ -126,6 +126,9 @@ struct Wave {
     if (lane() == 0) *p = v;
   }
   KS_DEV static bool leader() { return lane() == 0; }
+  // A flag another agent (the host, over PCIe) may set while the kernel runs: a system-scope atomic load, so that it is
+  // not served from the scalar or vector caches forever.
+  KS_DEV static int poll_flag(const volatile int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
   // Shader clock for the per-phase counters of a profiling build (-DKSOLVE_PHASE_TIMERS, scripts/gpu_quick.sh). The
   // product build compiles the timers out: 24 live 64-bit accumulators and an s_memtime + s_waitcnt per phase boundary
   // cost a single wavefront ~10% and a lot of register pressure.
@@ -197,6 +200,7 @@ struct Wave {
   static void store(T* p, T v) { *p = v; }
   static bool leader() { return true; }
   static unsigned long long clock() { return 0; }
+  static int poll_flag(const volatile int* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
   template <class F>
   static uint32_t argmin_u32(F f, int* lane_out) {
     uint32_t m = 0xFFFFFFFFu; int who = -1;
@@ -215,8 +219,11 @@ struct LaneVec64 {
   KS_DEV void set(int lane, uint64_t x) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
-    // one SGPR operand per VOP3 (constant bus): the lane select goes through m0
-    asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(lo), "+v"(hi) : "s"(xl), "s"(lane), "s"(xh) : "m0");
+    // one SGPR operand per VOP3 (constant bus): the lane select goes through m0, which is put back afterwards (m0 is a
+    // reserved register: the compiler does not honour it in a clobber list)
+    uint32_t m0_saved;
+    asm volatile("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %4\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %5, m0\n\ts_mov_b32 m0, %2"
+                 : "+v"(lo), "+v"(hi), "=&s"(m0_saved) : "s"(xl), "s"(lane), "s"(xh));
     v = (uint64_t)lo | ((uint64_t)hi << 32);
   }
   KS_DEV uint64_t get(int) const { return v; }

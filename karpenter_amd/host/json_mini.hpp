@@ -51,6 +51,8 @@ struct Value {
     obj->push_back({k, v});
     return obj->back().second;
   }
+  // set() for a key the caller knows is new (set() scans the members: quadratic over a large object)
+  void add_new(const std::string& k, const Value& v) { obj->push_back({k, v}); }
   void push(const Value& v) { arr->push_back(v); }
   const Array& items() const { static Array e; return kind == Arr ? *arr : e; }
   const Object& members() const { static Object e; return kind == Obj ? *obj : e; }

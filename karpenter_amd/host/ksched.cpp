@@ -338,6 +338,7 @@ struct Api {
   decltype(&ksolve_destroy) destroy = nullptr;
   decltype(&ksolve_last_error) last_error = nullptr;
   decltype(&ksolve_last_kernel_ms) kernel_ms = nullptr;
+  decltype(&ksolve_cancel) cancel = nullptr;
   bool load(const char* path, std::string& err) {
     lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
     if (!lib) { err = std::string("cannot load solver library: ") + dlerror(); return false; }
@@ -347,6 +348,7 @@ struct Api {
     destroy = (decltype(destroy))dlsym(lib, "ksolve_destroy");
     last_error = (decltype(last_error))dlsym(lib, "ksolve_last_error");
     kernel_ms = (decltype(kernel_ms))dlsym(lib, "ksolve_last_kernel_ms");
+    cancel = (decltype(cancel))dlsym(lib, "ksolve_cancel");
     if (!create || !solve || !results_free || !destroy || !last_error) { err = "solver library lacks ksolve_* symbols"; return false; }
     return true;
   }
@@ -761,7 +763,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     std::vector<std::map<std::string, i128>> it_cap(n_its), it_over(n_its);
     for (int i = 0; i < n_its; ++i) {
       it_cap[i] = parse_resources(its_json[i].at("capacity")); it_over[i] = parse_resources(its_json[i].at("overhead"));
-      for (auto& kv : it_cap[i]) { if (kv.first.rfind("hugepages-", 0) == 0) throw Unsupported("hugepages"); add_res(kv.first); }
+      for (auto& kv : it_cap[i]) add_res(kv.first);
     }
     for (auto& s : specs) for (auto& kv : s.requests) add_res(kv.first);
     for (auto& dp : daemons) for (auto& kv : dp.requests) add_res(kv.first);
@@ -794,6 +796,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     };
     consider({{"pods", (i128)1000000000}});   // every pod requests pods: 1 (resources.go:30-38)
     for (int i = 0; i < n_its; ++i) { consider(it_cap[i]); consider(it_over[i]); }
+    for (int i = 0; i < n_its; ++i) for (auto& kv : it_cap[i]) if (kv.first.rfind("hugepages-", 0) == 0) consider({{"memory", kv.second}});  // subtracted from memory
     for (auto& s : specs) consider(s.requests);
     for (auto& dp : daemons) consider(dp.requests);
     for (int e = 0; e < n_nodes; ++e) consider(node_ds[e]);
@@ -832,6 +835,11 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       for (int r = 0; r < n_res; ++r) {
         i128 cap = res_get(it_cap[i], res_names[r]);
         i128 alloc = it_cap[i].count(res_names[r]) ? cap - res_get(it_over[i], res_names[r]) : 0;  // resources.Subtract keeps capacity's keys (resources.go:83-97)
+        if (r == 1) {
+          // hugepage reservations come out of the allocatable memory, one clamp at zero per hugepage size
+          // (computeAllocatable, types.go:281-291); capacity is a map, visited here in name order — the clamps commute
+          for (auto& kv : it_cap[i]) if (kv.first.rfind("hugepages-", 0) == 0) { alloc -= kv.second; if (alloc < 0) alloc = 0; }
+        }
         it_capv[(size_t)r * n_its + i] = to_dev(r, cap);
         it_alloc[(size_t)r * n_its + i] = to_dev(r, alloc);
       }
@@ -1458,6 +1466,13 @@ extern "C" const char* ksched_error_kind(void* session) {
   Session* S = (Session*)session;
   return (S && !S->error_kind.empty()) ? S->error_kind.c_str() : nullptr;
 }
+// The ctx deadline of Solve (scheduler.go:477-480): callable from another thread while ksched_solve runs; the solve
+// returns what it has placed so far with timedOut set.
+extern "C" int ksched_cancel(void* session) {
+  Session* S = (Session*)session;
+  if (!S || !S->handle || !S->api.cancel) return -1;
+  return (int)S->api.cancel(S->handle);
+}
 extern "C" void ksched_close(void* session) {
   Session* S = (Session*)session;
   if (!S) return;
@@ -1529,7 +1544,7 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
         int a = res.pod_assignment[p];
         if (a >= 0) members[a].push_back({res.pod_slot[p], p});
         else if (a <= -2) node_members[-2 - a].push_back({res.pod_slot[p], p});
-        else { Value e = Value::object(); e.set("code", Value::integer(res.pod_error[p])); e.set("diag", Value::integer(res.pod_error_diag[p])); errs.set(uid_of(p), e); }
+        else { Value e = Value::object(); e.set("code", Value::integer(res.pod_error[p])); e.set("diag", Value::integer(res.pod_error_diag[p])); errs.add_new(uid_of(p), e); }
       }
       Value claims = Value::array();
       for (uint32_t c = 0; c < cl.n_claims; ++c) {
@@ -1552,7 +1567,7 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
         cj.set("instanceTypes", itj);
         if (cl.truncation_failed && cl.truncation_failed[c]) {
           // the claim is dropped and its pods fail with the minValues error (scheduler.go:426-431)
-          for (auto& m : members[c]) { Value e = Value::object(); e.set("code", Value::integer(KSOLVE_POD_MIN_VALUES)); e.set("diag", Value::integer(128)); errs.set(uid_of(m.second), e); }
+          for (auto& m : members[c]) { Value e = Value::object(); e.set("code", Value::integer(KSOLVE_POD_MIN_VALUES)); e.set("diag", Value::integer(128)); errs.add_new(uid_of(m.second), e); }
           continue;
         }
         Value rj = Value::array();

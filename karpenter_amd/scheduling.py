@@ -54,6 +54,8 @@ def _load_ksched():
         lib.ksched_error_kind.restype = ctypes.c_char_p
         lib.ksched_error_kind.argtypes = [ctypes.c_void_p]
         lib.ksched_close.argtypes = [ctypes.c_void_p]
+        lib.ksched_cancel.restype = ctypes.c_int
+        lib.ksched_cancel.argtypes = [ctypes.c_void_p]
         lib.ksched_free.argtypes = [ctypes.c_void_p]
         lib.ksched_solve_batch.restype = ctypes.c_int
         lib.ksched_solve_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
@@ -129,6 +131,14 @@ class Scheduler:
             timings += out["timings"]
         out["timings"] = timings
         return Results(out)
+
+
+    def Cancel(self) -> None:
+        """The ctx deadline of Solve (scheduler.go:477-480, provisioner.go:427): call from another thread while Solve()
+        runs; Solve returns the pods placed so far with `timedOut` set. A cancel that arrives between solves is dropped
+        (every Solve starts with a fresh context)."""
+        if self._session:
+            self._lib.ksched_cancel(self._session)
 
 
 def NewScheduler(problem: dict, solver_lib: str | None = None) -> Scheduler:

@@ -69,7 +69,7 @@ ksolve_status ksolve_create(const ksolve_problem_desc* desc, const ksolve_option
 }
 ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out) { return ksi::solve(h, out); }
 ksolve_status ksolve_solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) { return ksi::solve_batch(hs, n, outs); }
-ksolve_status ksolve_cancel(ksolve_handle* h) { if (h->d_cancel) *h->d_cancel = 1; return KSOLVE_OK; }
+ksolve_status ksolve_cancel(ksolve_handle* h) { if (h->d_cancel) __atomic_store_n(h->d_cancel, 1, __ATOMIC_RELAXED); return KSOLVE_OK; }
 void ksolve_results_free(ksolve_results* r) { if (r && r->impl) { delete (ksi::ResultsImpl*)r->impl; r->impl = nullptr; } }
 void ksolve_destroy(ksolve_handle* h) {
   if (!h) return;

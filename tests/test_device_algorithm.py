@@ -175,10 +175,27 @@ def test_unsupported_is_loud_not_cpu(emu):
         term = fx.affinity_term(fx.ZONE, {"a": "b"})
         term["namespaceSelector"] = {"matchLabels": {"team": "x"}}
         NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], [fx.pod(pod_requirements=[term])]), solver_lib=emu)
-    with pytest.raises(Unsupported):   # hugepages change the allocatable memory per offering group (types.go:271-294)
+    with pytest.raises(Unsupported):   # an offering with its own capacity splits the type into allocatable groups (types.go:202-269)
         its = fx.fake_default_instance_types()
-        its[0]["capacity"]["hugepages-2Mi"] = "1Gi"
+        its[0]["offerings"][0]["capacityOverride"] = {"memory": "1Gi"}
         NewScheduler(fx.problem(its, [fx.node_pool()], [fx.pod()]), solver_lib=emu)
+
+
+def test_hugepages(oracle, emu):
+    """Hugepage capacity is carved out of the allocatable memory (computeAllocatable, types.go:281-291) and is a resource
+    dimension of its own for pods that request it."""
+    its = fx.fake_instance_types(6)
+    for i, it in enumerate(its):
+        it["capacity"]["hugepages-2Mi"] = f"{512 * (i + 1)}Mi"
+    its[0]["capacity"]["hugepages-1Gi"] = "4Gi"      # more than the type's memory: clamps at zero, nothing fits there
+    pods = [fx.pod(requests={"cpu": "500m", "memory": "1Gi"}) for _ in range(9)]
+    pods += [fx.pod(requests={"cpu": "250m", "memory": "256Mi", "hugepages-2Mi": "1Gi"}) for _ in range(5)]
+    pods += [fx.pod(requests={"memory": "3Gi", "hugepages-2Mi": "2560Mi"}) for _ in range(2)]
+    pods += [fx.pod(requests={"hugepages-1Gi": "8Gi"})]                                   # no type has that much
+    got, want = check(oracle, emu, fx.problem(its, [fx.node_pool()], pods))
+    assert len(got["podErrors"]) == 1 and got["newNodeClaims"]
+    # without the carve-out a 1Gi pod would fit the smallest type: it must not be among any claim's options
+    assert all("fake-it-0" not in c["instanceTypes"] for c in got["newNodeClaims"])
 
 
 def sorted_its(res):
@@ -494,3 +511,47 @@ def test_product_go_sort_matches_oracle_go_sort(oracle, emu):
         out = (ctypes.c_int * max(1, n))()
         lib.ksolve_emu_go_sort(arr, n, out)
         assert list(out[:n]) == oracle.evaluate({"fn": "sort_by_key", "keys": keys}), (n, keys[:20])
+
+
+def test_cancel_from_another_thread(oracle, emu):
+    """ksolve_cancel is the ctx deadline of Solve (scheduler.go:477-480): raised from another thread at any moment of the
+    call it stops the pack loop at the next queue block; what was placed so far is a prefix of the full solve, every
+    other pod is reported unscheduled, and the next Solve starts with a fresh context."""
+    import threading
+    import time
+    n = 300000
+    s = NewScheduler(fx.config2(pods=n), solver_lib=emu)
+    t0 = time.time()
+    full = s.Solve(want_results=False)
+    t_full = time.time() - t0
+    assert not full["timedOut"] and full["scheduledPods"] == n
+
+    def cancelled_after(delay):
+        out = {}
+        th = threading.Thread(target=lambda: out.update(r=s.Solve()))
+        th.start()
+        time.sleep(delay)
+        s.Cancel()
+        th.join()
+        return out["r"]
+
+    def check_prefix(r):
+        placed = sum(len(c["pods"]) for c in r["newNodeClaims"])
+        assert placed == r["scheduledPods"] < n and placed + len(r["podErrors"]) == n and r["counters"]["pops"] == placed
+        prob = fx.config2(pods=n)
+        prob.setdefault("options", {})["maxSteps"] = placed          # the cancelled run is the full run stopped after `placed` pops
+        parity.assert_same_results(r, NewScheduler(prob, solver_lib=emu).Solve())
+        return placed
+
+    # the moment the cancel lands is timing-dependent: try a few delays, early (classification / queue sort: the pack
+    # loop then stops before its first pod) and in the middle of the pack loop
+    landed = []
+    for frac in (0.03, 0.6, 0.75, 0.5, 0.85, 0.4, 0.9):
+        r = cancelled_after(frac * t_full)
+        if r["timedOut"]:
+            landed.append(check_prefix(r))
+        if len(landed) >= 2 and max(landed) > 0:
+            break
+    assert landed and max(landed) > 0, f"no cancel landed inside the pack loop: {landed}"
+    again = s.Solve(want_results=False)
+    assert not again["timedOut"] and again["scheduledPods"] == n

@@ -255,3 +255,45 @@ def test_truncate_instance_types_order_by_price(oracle):
     pool = fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "In", "instance-type-1", "instance-type-2", min_values=2)])
     got, _ = check(oracle, fx.problem(_mv_types(), [pool], two, options={"truncateInstanceTypes": 1}))
     assert not got["newNodeClaims"] and len(got["podErrors"]) == 2
+
+
+def test_same_hash_topology_groups_and_hugepages(oracle):
+    """Groups created by relaxation under one TopologyGroup.Hash() with different node filters (first creator wins,
+    topology.go:162-194), and hugepage capacity carved out of allocatable memory (types.go:281-291)."""
+    lab = {"test": "test"}
+
+    def workload(cpu, zones, n):
+        terms = [[fx.req("example.com/unknown", "In", "x")], [fx.req(fx.ZONE, "In", *zones)]]
+        return [fx.pod(labels=lab, requests={"cpu": cpu}, node_requirements=terms, topology_spread=[fx.spread(fx.ZONE, lab)]) for _ in range(n)]
+    for a, b in ((["test-zone-1", "test-zone-2"], ["test-zone-2", "test-zone-3"]), (["test-zone-2", "test-zone-3"], ["test-zone-1", "test-zone-2"])):
+        got, _ = check(oracle, fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], workload("1", a, 5) + workload("500m", b, 5)))
+        assert got["counters"]["topologyAliasClasses"] == 1
+    its = fx.fake_instance_types(6)
+    for i, it in enumerate(its):
+        it["capacity"]["hugepages-2Mi"] = f"{512 * (i + 1)}Mi"
+    pods = [fx.pod(requests={"cpu": "500m", "memory": "1Gi"}) for _ in range(9)] + [fx.pod(requests={"cpu": "250m", "hugepages-2Mi": "1Gi"}) for _ in range(5)]
+    check(oracle, fx.problem(its, [fx.node_pool()], pods))
+
+
+def test_cancel_stops_a_running_solve():
+    """ksolve_cancel from another thread (the ctx deadline, scheduler.go:477-480): the flag is written over PCIe while the
+    pack kernel runs and must be seen by its system-scope poll; the solve returns a prefix of the full result."""
+    import threading
+    import time
+    n = 1000000
+    s = NewScheduler(fx.config2(pods=n))
+    out = {}
+    th = threading.Thread(target=lambda: out.update(r=s.Solve(want_results=False)))
+    t0 = time.time()
+    th.start()
+    time.sleep(0.3)
+    while th.is_alive():
+        s.Cancel()
+        time.sleep(0.01)
+    th.join()
+    elapsed = time.time() - t0
+    r = out["r"]
+    assert r["timedOut"] and 0 < r["scheduledPods"] < n
+    assert elapsed < 4.0, f"a cancelled 1M-pod solve took {elapsed:.1f}s: the flag was not seen by the running kernel"
+    full = s.Solve(want_results=False)
+    assert not full["timedOut"] and full["scheduledPods"] == n
