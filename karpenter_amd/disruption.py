@@ -271,6 +271,7 @@ def simulate_scheduling(cluster, candidates, solver):
     staying = [p for n in cluster["nodes"] if n["name"] not in names and not n.get("markedForDeletion") for p in n.get("pods", [])]
     prob = fx.problem(cluster["instanceTypes"], cluster["nodePools"], copy.deepcopy(pods), well_known=cluster.get("wellKnownLabels", fx.KWOK_WELL_KNOWN),
                       state_nodes=state_nodes, cluster_pods=copy.deepcopy(staying), options=dict(cluster.get("options", {}), consolidationSimulation=True),
+                      namespaces=cluster.get("namespaces"),
                       deleting_node_names=[n["name"] for n in deleting])
     res = solver(prob)
     # pods that landed on an uninitialized node make the decision unsafe (helpers.go:133-153)

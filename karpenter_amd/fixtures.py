@@ -247,10 +247,13 @@ def spread(key, labels, max_skew=1, when="DoNotSchedule", min_domains=None, tain
     return c
 
 
-def affinity_term(key, labels, namespaces=None):
+def affinity_term(key, labels, namespaces=None, namespace_selector=None):
+    """corev1.PodAffinityTerm; namespace_selector is a metav1.LabelSelector dict ({} selects every namespace)."""
     t = {"labelSelector": {"matchLabels": dict(labels)}, "topologyKey": key}
     if namespaces:
         t["namespaces"] = list(namespaces)
+    if namespace_selector is not None:
+        t["namespaceSelector"] = dict(namespace_selector)
     return t
 
 
@@ -298,8 +301,10 @@ def state_node(name, instance_type, zone, capacity_type="on-demand", nodepool="d
 
 
 def problem(instance_types, node_pools, pods=None, pod_groups=None, well_known=FAKE_WELL_KNOWN, state_nodes=None, cluster_pods=None,
-            daemonset_pods=None, options=None, deleting_node_names=None):
-    return {"wellKnownLabels": list(well_known), "options": dict(options or {}), "instanceTypes": instance_types, "nodePools": node_pools,
+            daemonset_pods=None, options=None, deleting_node_names=None, namespaces=None):
+    """`namespaces`: [{"name", "labels"}] — what the namespace lister returns, for affinity terms with a namespaceSelector
+    (topology.go:536-557)."""
+    return {"namespaces": list(namespaces or []), "wellKnownLabels": list(well_known), "options": dict(options or {}), "instanceTypes": instance_types, "nodePools": node_pools,
             "stateNodes": list(state_nodes or []), "pods": list(pods or []), "podGroups": list(pod_groups or []),
             "daemonSetPods": list(daemonset_pods or []), "clusterPods": list(cluster_pods or []),
             "deletingNodeNames": list(deleting_node_names or [])}

@@ -300,7 +300,9 @@ struct Tsc {
   std::string key, when = "DoNotSchedule", taint_policy, affinity_policy;   // policies: "" = nil
   Selector sel;
 };
-struct AffTerm { Selector sel; std::string key; std::vector<std::string> namespaces; };
+// `namespaces` is already buildNamespaceList's answer when `resolved` (the term had a namespaceSelector): it may then be
+// empty, which selects nothing, unlike an absent list, which means the pod's own namespace (topology.go:536-557)
+struct AffTerm { Selector sel; std::string key; std::vector<std::string> namespaces; bool resolved = false; };
 
 // ---- pod model (only what the flattener needs) ----
 struct PodSpec {
@@ -417,12 +419,22 @@ static Selector parse_selector(const Value& v) {
   }
   return s;
 }
+// The namespace lister of the problem being flattened (root["namespaces"]: name + labels), standing in for the kube
+// client that buildNamespaceList queries (topology.go:548-550).
+static thread_local const std::vector<std::pair<std::string, std::map<std::string, std::string>>>* t_namespace_lister = nullptr;
 static AffTerm parse_aff_term(const Value& v) {
   AffTerm t;
   t.sel = parse_selector(v.at("labelSelector"));
   t.key = v.at("topologyKey").s();
   for (auto& n : v.at("namespaces").items()) t.namespaces.push_back(n.s());
-  if (v.has("namespaceSelector") && !v.at("namespaceSelector").is_null()) throw Unsupported("namespaceSelector needs a namespace lister");
+  if (v.has("namespaceSelector") && !v.at("namespaceSelector").is_null()) {
+    Selector ns = parse_selector(v.at("namespaceSelector"));
+    if (!ns.valid()) throw std::runtime_error("parsing selector: invalid namespaceSelector");   // topology.go:545-547
+    std::set<std::string> out(t.namespaces.begin(), t.namespaces.end());
+    if (t_namespace_lister) for (auto& n : *t_namespace_lister) if (ns.matches(n.second)) out.insert(n.first);
+    t.namespaces.assign(out.begin(), out.end());
+    t.resolved = true;
+  }
   return t;
 }
 static PodSpec parse_pod(const Value& v) {
@@ -627,6 +639,13 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     }
 
     // ---- pods (explicit list + deterministic groups) ----
+    std::vector<std::pair<std::string, std::map<std::string, std::string>>> namespace_lister;
+    for (auto& nv : root.at("namespaces").items()) {
+      std::map<std::string, std::string> labels;
+      for (auto& kv : nv.at("labels").members()) labels[kv.first] = kv.second.s();
+      namespace_lister.push_back({nv.at("name").s(), labels});
+    }
+    t_namespace_lister = &namespace_lister;   // read by parse_aff_term for every pod parsed below (this thread only)
     struct Row { int spec; };  // index into specs
     std::vector<PodSpec> specs;           // distinct pod templates (each explicit pod is its own spec)
     std::vector<int> pod_spec;            // per pod -> spec
@@ -1213,15 +1232,15 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
           g.counts[dom]++; g.domains.insert(dom);
         }
       };
-      auto namespace_list = [](const std::string& ns, const std::vector<std::string>& list) {
-        return list.empty() ? std::set<std::string>{ns} : std::set<std::string>(list.begin(), list.end());
+      auto namespace_list = [](const std::string& ns, const AffTerm& term) {
+        return (term.namespaces.empty() && !term.resolved) ? std::set<std::string>{ns} : std::set<std::string>(term.namespaces.begin(), term.namespaces.end());
       };
       // inverse anti-affinity groups — topology.go:310-355
       std::vector<HGroup> inverse;
       auto inverse_for = [&](const PodSpec& pod, int node) {
         std::vector<int> owned;
         for (auto& term : pod.anti_required) {
-          HGroup g = make_group(2, term.key, pod, namespace_list(pod.ns, term.namespaces), term.sel, INT32_MAX, -1, "", "");
+          HGroup g = make_group(2, term.key, pod, namespace_list(pod.ns, term), term.sel, INT32_MAX, -1, "", "");
           int id = -1;
           for (size_t i = 0; i < inverse.size(); ++i) if (inverse[i].identity == g.identity) { id = (int)i; break; }
           if (id < 0) { g.inverse = true; g.initial = true; inverse.push_back(g); id = (int)inverse.size() - 1; }
@@ -1256,12 +1275,12 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
               tgs.push_back(make_group(0, t.key, p, {p.ns}, t.sel, t.max_skew, t.min_domains, t.taint_policy, t.affinity_policy));
             }
             if (p.has_pod_affinity) {  // newForAffinities — topology.go:498-538
-              for (auto& t : p.aff_required) tgs.push_back(make_group(1, t.key, p, namespace_list(p.ns, t.namespaces), t.sel, INT32_MAX, -1, "", ""));
-              if (!ignore_prefs) for (auto& t : p.aff_preferred) tgs.push_back(make_group(1, t.second.key, p, namespace_list(p.ns, t.second.namespaces), t.second.sel, INT32_MAX, -1, "", ""));
+              for (auto& t : p.aff_required) tgs.push_back(make_group(1, t.key, p, namespace_list(p.ns, t), t.sel, INT32_MAX, -1, "", ""));
+              if (!ignore_prefs) for (auto& t : p.aff_preferred) tgs.push_back(make_group(1, t.second.key, p, namespace_list(p.ns, t.second), t.second.sel, INT32_MAX, -1, "", ""));
             }
             if (p.has_pod_anti) {
-              for (auto& t : p.anti_required) tgs.push_back(make_group(2, t.key, p, namespace_list(p.ns, t.namespaces), t.sel, INT32_MAX, -1, "", ""));
-              if (!ignore_prefs) for (auto& t : p.anti_preferred) tgs.push_back(make_group(2, t.second.key, p, namespace_list(p.ns, t.second.namespaces), t.second.sel, INT32_MAX, -1, "", ""));
+              for (auto& t : p.anti_required) tgs.push_back(make_group(2, t.key, p, namespace_list(p.ns, t), t.sel, INT32_MAX, -1, "", ""));
+              if (!ignore_prefs) for (auto& t : p.anti_preferred) tgs.push_back(make_group(2, t.second.key, p, namespace_list(p.ns, t.second), t.second.sel, INT32_MAX, -1, "", ""));
             }
             for (auto& tg : tgs) {
               auto found = group_by_identity.find(tg.identity);

@@ -24,6 +24,7 @@ struct PodAffinityTerm {
   LabelSelector selector;
   std::string topology_key;
   std::vector<std::string> namespaces;
+  LabelSelector namespace_selector;   // nil = absent
 };
 struct WeightedPodAffinityTerm { int weight = 0; PodAffinityTerm term; };
 struct TopologySpreadConstraint {
@@ -145,6 +146,7 @@ struct Problem {
   std::vector<Pod> daemonset_pods;
   std::vector<Pod> cluster_pods;        // bound pods, for topology counting
   std::set<std::string> deleting_node_names;
+  std::vector<std::pair<std::string, std::map<std::string, std::string>>> namespaces;   // the namespace lister: name, labels
 };
 
 // ------------------------------------------------------------------ JSON -> model
@@ -193,7 +195,8 @@ inline PodAffinityTerm parse_affinity_term(const oj::Value& v) {
   t.selector = parse_selector(v.at("labelSelector"));
   t.topology_key = v.at("topologyKey").s();
   for (auto& n : v.at("namespaces").items()) t.namespaces.push_back(n.s());
-  if (v.has("namespaceSelector") && !v.at("namespaceSelector").is_null()) throw std::runtime_error("namespaceSelector unsupported");
+  if (v.has("namespaceSelector")) t.namespace_selector = parse_selector(v.at("namespaceSelector"));
+  if (!t.namespace_selector.is_nil && !t.namespace_selector.valid()) throw std::runtime_error("parsing selector: invalid namespaceSelector");  // topology.go:545-547
   return t;
 }
 inline Requirements exprs_to_requirements(const std::vector<NodeSelectorExpr>& exprs) {  // requirements.go:49-65
@@ -378,6 +381,7 @@ inline Problem parse_problem(const oj::Value& root) {
   for (auto& v : root.at("daemonSetPods").items()) pr.daemonset_pods.push_back(parse_pod(v, di++));
   int cpi = 0;
   for (auto& v : root.at("clusterPods").items()) pr.cluster_pods.push_back(parse_pod(v, cpi++));
+  for (auto& v : root.at("namespaces").items()) pr.namespaces.push_back({v.at("name").s(), parse_strmap(v.at("labels"))});
   return pr;
 }
 

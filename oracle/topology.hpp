@@ -244,15 +244,18 @@ struct Topology {
   }
   const TopologyDomainGroup& dgroup(const std::string& key) { return domain_groups[key]; }
 
-  // buildNamespaceList — topology.go:526-550 (namespaceSelector rejected at parse time)
-  static std::set<std::string> namespace_list(const std::string& ns, const std::vector<std::string>& namespaces) {
-    if (namespaces.empty()) return {ns};
-    return std::set<std::string>(namespaces.begin(), namespaces.end());
+  // buildNamespaceList — topology.go:536-557: the pod's namespace when the term names none; otherwise the listed
+  // namespaces plus those whose labels the namespaceSelector matches (the problem's `namespaces` stand in for the lister)
+  std::set<std::string> namespace_list(const std::string& ns, const PodAffinityTerm& term) const {
+    if (term.namespaces.empty() && term.namespace_selector.is_nil) return {ns};
+    std::set<std::string> out(term.namespaces.begin(), term.namespaces.end());
+    if (!term.namespace_selector.is_nil && problem) for (auto& n : problem->namespaces) if (term.namespace_selector.matches(n.second)) out.insert(n.first);
+    return out;
   }
   // updateInverseAntiAffinity — topology.go:329-355
   void update_inverse_anti_affinity(const Pod& pod, const std::map<std::string, std::string>* node_labels) {
     for (auto& term : pod.anti_required) {
-      TopologyGroup tg = TopologyGroup::make(TopologyType::PodAntiAffinity, term.topology_key, pod, namespace_list(pod.ns, term.namespaces),
+      TopologyGroup tg = TopologyGroup::make(TopologyType::PodAntiAffinity, term.topology_key, pod, namespace_list(pod.ns, term),
                                              term.selector, INT32_MAX, std::nullopt, std::nullopt, std::nullopt, dgroup(term.topology_key));
       auto id = tg.identity();
       TopologyGroup* g = nullptr;
@@ -309,7 +312,7 @@ struct Topology {
   std::vector<TopologyGroup> new_for_affinities(const Pod& p) {
     std::vector<TopologyGroup> out;
     auto add = [&](TopologyType t, const PodAffinityTerm& term) {
-      out.push_back(TopologyGroup::make(t, term.topology_key, p, namespace_list(p.ns, term.namespaces), term.selector, INT32_MAX,
+      out.push_back(TopologyGroup::make(t, term.topology_key, p, namespace_list(p.ns, term), term.selector, INT32_MAX,
                                         std::nullopt, std::nullopt, std::nullopt, dgroup(term.topology_key)));
     };
     if (p.has_pod_affinity) {

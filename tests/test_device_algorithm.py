@@ -171,10 +171,9 @@ def test_empty_and_degenerate_inputs(oracle, emu):
 
 
 def test_unsupported_is_loud_not_cpu(emu):
-    with pytest.raises(Unsupported):   # namespaceSelector needs a namespace lister (topology.go:526-550)
-        term = fx.affinity_term(fx.ZONE, {"a": "b"})
-        term["namespaceSelector"] = {"matchLabels": {"team": "x"}}
-        NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], [fx.pod(pod_requirements=[term])]), solver_lib=emu)
+    with pytest.raises(Unsupported):   # more requirement keys than the device's key mask has bits
+        pods = [fx.pod(node_requirements=[fx.req(f"example.com/key-{i}", "Exists") for i in range(40)])]
+        NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], pods), solver_lib=emu)
     with pytest.raises(Unsupported):   # an offering with its own capacity splits the type into allocatable groups (types.go:202-269)
         its = fx.fake_default_instance_types()
         its[0]["offerings"][0]["capacityOverride"] = {"memory": "1Gi"}

@@ -281,3 +281,41 @@ def test_self_affinity_first_empty_domain_only(oracle, emu):
     pods = [fx.pod(labels=aff, node_requirements=[fx.req(fx.ZONE, "In", "test-zone-2", "test-zone-3")], pod_requirements=[fx.affinity_term(fx.HOSTNAME, aff)]) for _ in range(10)]
     res = solve(oracle, emu, pods, its=its, state_nodes=[node], cluster_pods=[running])
     assert len(res["podErrors"]) == 10 and not res["newNodeClaims"]
+
+
+def test_pod_affinity_namespaces_and_namespace_selector(oracle, emu):
+    """topology_test.go:2843-2962 — affinity terms only see pods of the namespaces they name: the pod's own by default,
+    an explicit list, or whatever a namespaceSelector matches among the cluster's namespaces (an empty selector matches
+    every namespace)."""
+    aff = {"security": "s2"}
+    spread = [fx.spread(fx.HOSTNAME, LABELS)]
+
+    def scenario(target_ns, term, namespaces):
+        target = fx.pod(labels=aff, namespace=target_ns)
+        follower = fx.pod(pod_requirements=[term])
+        pods = [fx.pod(labels=LABELS, topology_spread=spread) for _ in range(10)] + [target, follower]
+        res = solve(oracle, emu, pods, namespaces=namespaces)
+        where = {u: c["hostname"] for c in res["newNodeClaims"] for u in c["pods"]}
+        return where.get(target["uid"]), where.get(follower["uid"])
+
+    lister = [{"name": "default", "labels": {}}, {"name": "other", "labels": {"foo": "bar"}}]
+    # no matching pods: the target is in another namespace (:2843)
+    t, f = scenario("other", fx.affinity_term(fx.HOSTNAME, aff), lister)
+    assert t is not None and f is None
+    # namespace list (:2880)
+    t, f = scenario("other", fx.affinity_term(fx.HOSTNAME, aff, namespaces=["other"]), lister)
+    assert t is not None and t == f
+    # empty namespace selector = all namespaces (:2920)
+    t, f = scenario("other", fx.affinity_term(fx.HOSTNAME, aff, namespace_selector={"matchLabels": {}}), lister)
+    assert t is not None and t == f
+    # a selector on namespace labels
+    t, f = scenario("other", fx.affinity_term(fx.HOSTNAME, aff, namespace_selector={"matchLabels": {"foo": "bar"}}), lister)
+    assert t is not None and t == f
+    t, f = scenario("other", fx.affinity_term(fx.HOSTNAME, aff, namespace_selector={"matchLabels": {"foo": "nope"}}), lister)
+    assert t is not None and f is None
+    # a selector that matches nothing does not fall back to the pod's own namespace (topology.go:543-557)
+    t, f = scenario("default", fx.affinity_term(fx.HOSTNAME, aff, namespace_selector={"matchLabels": {"foo": "nope"}}), lister)
+    assert t is not None and f is None
+    # namespaces and namespaceSelector add up
+    t, f = scenario("default", fx.affinity_term(fx.HOSTNAME, aff, namespaces=["default"], namespace_selector={"matchLabels": {"foo": "bar"}}), lister)
+    assert t is not None and t == f
