@@ -63,3 +63,29 @@ def test_product_never_references_the_oracle():
                     if re.search(r"^\s*(import|from)\s+oracle\b", text, re.M) or re.search(r"#include\s+\"[^\"]*oracle/", text) or "liboracle" in text:
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_header_is_plain_c(tmp_path):
+    """cgo (and any other FFI generator) parses include/ksolve.h as C: it must compile as C99 without C++ features, and
+    every struct a binding fills must have the same size when compiled as C and as C++ (no hidden padding surprises)."""
+    import subprocess
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include <stdio.h>\n#include "ksolve.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(ksolve_problem_desc), '
+                     'sizeof(ksolve_topology), sizeof(ksolve_reqsets), sizeof(ksolve_options), sizeof(ksolve_claims), sizeof(ksolve_results)); return KSOLVE_ABI_VERSION == 3 ? 0 : 1; }\n')
+    inc = os.path.join(ROOT, "include")
+    sizes = []
+    for cc, std, exe in (("gcc", "-std=c99", "probe_c"), ("g++", "-std=c++17", "probe_cpp")):
+        src = probe if cc == "gcc" else tmp_path / "probe.cpp"
+        if cc == "g++":
+            src.write_text(probe.read_text())
+        subprocess.check_call([cc, std, "-Wall", "-Werror", "-pedantic", "-I", inc, "-o", str(tmp_path / exe), str(src)])
+        sizes.append(subprocess.check_output([str(tmp_path / exe)]).decode().split())
+    assert sizes[0] == sizes[1], sizes
+
+
+def test_go_shim_names_every_entry_point():
+    """go/ksolve_shim.go is the binding a Karpenter maintainer adds: it must call the boundary's entry
+    points by the names the header declares."""
+    shim = open(os.path.join(ROOT, "go", "ksolve_shim.go")).read()
+    for f in ("ksolve_create", "ksolve_solve", "ksolve_solve_batch", "ksolve_results_free", "ksolve_destroy", "ksolve_cancel"):
+        assert "C." + f in shim, f
