@@ -319,3 +319,132 @@ def test_pod_affinity_namespaces_and_namespace_selector(oracle, emu):
     # namespaces and namespaceSelector add up
     t, f = scenario("default", fx.affinity_term(fx.HOSTNAME, aff, namespaces=["default"], namespace_selector={"matchLabels": {"foo": "bar"}}), lister)
     assert t is not None and t == f
+
+
+def _launch_labels(res, its):
+    """What the fake cloud provider's Create would label the node with (fake/cloudprovider.go:108-170): the single-valued
+    requirements of the claim, the labels of its cheapest instance type option, and the zone / capacity type of that
+    type's cheapest offering the claim's requirements admit."""
+    from karpenter_amd.disruption import _offering_compatible
+    assert len(res["newNodeClaims"]) == 1
+    c = res["newNodeClaims"][0]
+    reqs = {q["key"]: q for q in c["requirements"]}
+    labels = {q["key"]: q["values"][0] for q in c["requirements"] if not q["complement"] and len(q["values"]) == 1}
+    by = {t["name"]: t for t in its}
+
+    def offers(n):
+        return [o for o in by[n]["offerings"] if o.get("available", True) and _offering_compatible(reqs, o)]
+    cheapest = min((n for n in c["instanceTypes"] if offers(n)), key=lambda n: (min(o["price"] for o in offers(n)), n))
+    for q in by[cheapest]["requirements"]:
+        if q["operator"] == "In" and len(q["values"]) == 1:
+            labels.setdefault(q["key"], q["values"][0])
+    best = min(offers(cheapest), key=lambda o: o["price"])
+    for q in best["requirements"]:
+        labels.setdefault(q["key"], q["values"][0])
+    return labels
+
+
+Z = fx.ZONE
+ZONES3 = ["test-zone-1", "test-zone-2", "test-zone-3"]
+WELL_KNOWN_CASES = [
+    # (suite_test.go line, NodePool requirements, pod kwargs, expected labels or None = not scheduled)
+    (205, [fx.req(Z, "In", "test-zone-2")], {}, {Z: "test-zone-2"}),
+    (214, [fx.req(Z, "In", "test-zone-1", "test-zone-2")], {"node_selector": {Z: "test-zone-2"}}, {Z: "test-zone-2"}),
+    (225, [], {"node_selector": {fx.HOSTNAME: "red-node"}}, None),
+    (233, [fx.req(Z, "In", "test-zone-1")], {"node_selector": {Z: "unknown"}}, None),
+    (243, [fx.req(Z, "In", "test-zone-1")], {"node_selector": {Z: "test-zone-2"}}, None),
+    (253, [], {"node_requirements": [fx.req(Z, "In", "test-zone-3")]}, {Z: "test-zone-3"}),
+    (264, [fx.req(fx.FAKE_INTEGER_LABEL, "Gt", "8")], {}, {fx.FAKE_INTEGER_LABEL: "16"}),
+    (273, [fx.req(fx.FAKE_INTEGER_LABEL, "Lt", "8")], {}, {fx.FAKE_INTEGER_LABEL: "2"}),
+    (282, [fx.req(fx.FAKE_INTEGER_LABEL, "Gte", "16")], {}, {fx.FAKE_INTEGER_LABEL: "16"}),
+    (291, [fx.req(fx.FAKE_INTEGER_LABEL, "Lte", "2")], {}, {fx.FAKE_INTEGER_LABEL: "2"}),
+    (300, [], {"node_requirements": [fx.req(Z, "In", "unknown")]}, None),
+    (310, [], {"node_requirements": [fx.req(Z, "NotIn", "test-zone-1", "test-zone-2", "unknown")]}, {Z: "test-zone-3"}),
+    (321, [], {"node_requirements": [fx.req(Z, "NotIn", *ZONES3, "unknown")]}, None),
+    (332, [], {"node_requirements": [fx.req(Z, "In", *ZONES3, "unknown")], "node_preferences": [fx.req(Z, "In", "test-zone-2", "unknown")]}, {Z: "test-zone-2"}),
+    (346, [], {"node_requirements": [fx.req(Z, "In", *ZONES3, "unknown")], "node_preferences": [fx.req(Z, "In", "unknown")]}, {}),
+    (359, [], {"node_requirements": [fx.req(Z, "In", *ZONES3, "unknown")], "node_preferences": [fx.req(Z, "NotIn", "test-zone-1", "test-zone-3")]}, {Z: "test-zone-2"}),
+    (373, [], {"node_requirements": [fx.req(Z, "In", *ZONES3, "unknown")], "node_preferences": [fx.req(Z, "NotIn", *ZONES3)]}, {}),
+    (386, [], {"node_selector": {Z: "test-zone-3"}, "node_requirements": [fx.req(Z, "In", *ZONES3)], "node_preferences": [fx.req(Z, "In", *ZONES3)]}, {Z: "test-zone-3"}),
+    (401, [], {"node_selector": {Z: "test-zone-3", fx.INSTANCE_TYPE: "arm-instance-type"},
+               "node_requirements": [fx.req(Z, "In", "test-zone-1", "test-zone-3"), fx.req(fx.INSTANCE_TYPE, "In", "default-instance-type", "arm-instance-type")],
+               "node_preferences": [fx.req(Z, "NotIn", "unknown"), fx.req(fx.INSTANCE_TYPE, "NotIn", "unknown")]},
+     {Z: "test-zone-3", fx.INSTANCE_TYPE: "arm-instance-type"}),
+]
+
+
+@pytest.mark.parametrize("line,pool_reqs,pod_kw,expect", WELL_KNOWN_CASES, ids=[f"suite_test.go:{c[0]}" for c in WELL_KNOWN_CASES])
+def test_well_known_label_constraints(oracle, emu, line, pool_reqs, pod_kw, expect):
+    """suite_test.go:204-423 "Custom Constraints / Well Known Labels": NodePool requirements, node selectors, required and
+    preferred node affinity on well-known labels, with the node labels the reference asserts after launch."""
+    its = fx.fake_default_instance_types()
+    res = solve(oracle, emu, [fx.pod(**pod_kw)], pools=[fx.node_pool(requirements=pool_reqs)], its=its)
+    if expect is None:
+        assert len(res["podErrors"]) == 1 and not res["newNodeClaims"]
+        return
+    assert not res["podErrors"]
+    labels = _launch_labels(res, its)
+    for k, v in expect.items():
+        assert labels.get(k) == v, (line, k, labels.get(k), v)
+
+
+TK = "test-key"
+POOL_TK = [fx.req(TK, "In", "test-value")]
+CUSTOM_LABEL_CASES = [
+    # (suite_test.go line, NodePool requirements, pod node requirements, scheduled?, test-key label on the node or None = absent / any)
+    (509, [], [fx.req(TK, "In", "test-value")], False, None),
+    (518, [], [fx.req(TK, "NotIn", "test-value")], True, None),
+    (528, [], [fx.req(TK, "Exists")], False, None),
+    (537, [], [fx.req(TK, "DoesNotExist")], True, None),
+    (547, POOL_TK, [], True, "test-value"),
+    (556, POOL_TK, [fx.req(TK, "In", "test-value")], True, "test-value"),
+    (568, POOL_TK, [fx.req(TK, "NotIn", "test-value")], False, None),
+    (579, POOL_TK, [fx.req(TK, "Exists")], True, "test-value"),
+    (591, POOL_TK, [fx.req(TK, "DoesNotExist")], False, None),
+    (603, POOL_TK, [fx.req(TK, "In", "another-value")], False, None),
+    (614, POOL_TK, [fx.req(TK, "NotIn", "another-value")], True, "test-value"),
+    (666, [], [fx.req(fx.ZONE, "In", "non-existent-zone"), fx.req(fx.ZONE, "Exists")], False, None),
+]
+
+
+@pytest.mark.parametrize("line,pool_reqs,pod_reqs,scheduled,label", CUSTOM_LABEL_CASES, ids=[f"suite_test.go:{c[0]}" for c in CUSTOM_LABEL_CASES])
+def test_custom_label_scheduling_logic(oracle, emu, line, pool_reqs, pod_reqs, scheduled, label):
+    """suite_test.go:501-677 "Custom Constraints / Scheduling Logic": a label key only the NodePool defines, against every
+    pod-side operator (undefined keys are not allowed for custom labels, requirements.go:193-235)."""
+    its = fx.fake_default_instance_types()
+    res = solve(oracle, emu, [fx.pod(node_requirements=pod_reqs or None)], pools=[fx.node_pool(requirements=pool_reqs)], its=its)
+    assert bool(res["newNodeClaims"]) == scheduled and bool(res["podErrors"]) != scheduled
+    if scheduled:
+        labels = _launch_labels(res, its)
+        assert labels.get(TK) == label
+        if line == 518:
+            assert labels.get(TK) != "test-value"
+
+
+def test_custom_label_pods_share_or_split_nodes(oracle, emu):
+    """suite_test.go:626-665: compatible requirements on a custom label collapse onto one node whose label is their
+    intersection; incompatible ones get a node each."""
+    its = fx.fake_default_instance_types()
+    pool = fx.node_pool(requirements=[fx.req(TK, "In", "test-value", "another-value")])
+    pods = [fx.pod(node_requirements=[fx.req(TK, "In", "test-value")]), fx.pod(node_requirements=[fx.req(TK, "NotIn", "another-value")])]
+    res = solve(oracle, emu, pods, pools=[pool], its=its)
+    assert len(res["newNodeClaims"]) == 1 and len(res["newNodeClaims"][0]["pods"]) == 2 and _launch_labels(res, its)[TK] == "test-value"
+    pods = [fx.pod(node_requirements=[fx.req(TK, "In", "test-value")]), fx.pod(node_requirements=[fx.req(TK, "In", "another-value")])]
+    res = solve(oracle, emu, pods, pools=[pool], its=its)
+    assert len(res["newNodeClaims"]) == 2
+    vals = sorted([q["values"] for q in c["requirements"] if q["key"] == TK][0][0] for c in res["newNodeClaims"])
+    assert vals == ["another-value", "test-value"]
+
+
+def test_well_known_selectors_and_kubernetes_domains(oracle, emu):
+    """suite_test.go:453-499: NodePool requirements under kubernetes.io / k8s.io (sub)domains end up as node labels; node
+    selectors on every well-known label schedule."""
+    its = fx.fake_default_instance_types()
+    for prefix in ("", "subdomain."):
+        reqs = [fx.req(f"{prefix}{d}/test", "In", "test-value") for d in ("kubernetes.io", "k8s.io")]
+        res = solve(oracle, emu, [fx.pod()], pools=[fx.node_pool(requirements=reqs)], its=its)
+        labels = _launch_labels(res, its)
+        assert all(labels.get(f"{prefix}{d}/test") == "test-value" for d in ("kubernetes.io", "k8s.io"))
+    pods = [fx.pod(node_selector=s) for s in ({fx.ZONE: "test-zone-1"}, {fx.INSTANCE_TYPE: "default-instance-type"}, {fx.ARCH: "arm64"}, {fx.OS: "linux"}, {fx.CAPACITY_TYPE: "spot"})]
+    res = solve(oracle, emu, pods, its=its)
+    assert not res["podErrors"]
