@@ -448,3 +448,100 @@ def test_well_known_selectors_and_kubernetes_domains(oracle, emu):
     pods = [fx.pod(node_selector=s) for s in ({fx.ZONE: "test-zone-1"}, {fx.INSTANCE_TYPE: "default-instance-type"}, {fx.ARCH: "arm64"}, {fx.OS: "linux"}, {fx.CAPACITY_TYPE: "spot"})]
     res = solve(oracle, emu, pods, its=its)
     assert not res["podErrors"]
+
+
+# ---- Reserved Instance Types: suite_test.go:4676-5195 ---------------------------------------------------------------
+
+def _reserved_catalog(small_capacity=1, medium_capacity=1, extra_small=None):
+    """BeforeEach :4677-4714 — large / medium / small; medium and small carry one reserved offering each in test-zone-1 at
+    1/100000 of the price. A capacity of 0 is an exhausted reservation (the provider marks the offering unavailable).
+    extra_small = (reservation id, capacity): a second reservation for the small type (:4894)."""
+    its = [fx.fake_instance_type(n, resources={"cpu": str(c), "memory": f"{c}Gi"}) for n, c in (("large-instance-type", 6), ("medium-instance-type", 3), ("small-instance-type", 2))]
+    for it, cap in ((its[1], medium_capacity), (its[2], small_capacity)):
+        for r in it["requirements"]:
+            if r["key"] == fx.CAPACITY_TYPE:
+                r["values"].append("reserved")
+        price = fx.fake_price(it["capacity"]) / 100000.0
+        it["offerings"].append(fx.offering("reserved", "test-zone-1", price, reservation_id="r-" + it["name"], reservation_capacity=max(cap, 0), available=cap > 0))
+        if it is its[2] and extra_small:
+            it["offerings"].append(fx.offering("reserved", "test-zone-1", price, reservation_id=extra_small[0], reservation_capacity=max(extra_small[1], 0), available=extra_small[1] > 0))
+    return its
+
+
+RESERVED = {"reservedCapacity": True, "reservedOfferingMode": "Strict"}     # what Provisioner.Schedule passes (provisioner.go:341-360)
+APP = {"app": "test"}
+
+
+def _spread_pod(**kw):
+    return fx.pod(labels=APP, pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, APP)], **kw)
+
+
+def _claim_summary(c):
+    ct = [q["values"] for q in c["requirements"] if q["key"] == fx.CAPACITY_TYPE and not q["complement"]]
+    return {"reserved": sorted(c["reservedOfferings"]), "capacityType": ct[0] if ct else None, "types": sorted(c["instanceTypes"]), "pool": c["nodePool"]}
+
+
+def test_reserved_shared_across_nodepools(oracle, emu):
+    # :4767-4822 — two NodePools draw on the same reservation: one pod gets the reserved instance, the other must wait
+    # (no fallback to on-demand / spot in the same pass); next pass the exhausted reservation is unavailable
+    pods = [_spread_pod(node_requirements=[fx.req(fx.INSTANCE_TYPE, "In", "small-instance-type"), fx.req(fx.NODEPOOL, "In", f"np-{i + 1}")]) for i in range(2)]
+    pools = [fx.node_pool("np-1"), fx.node_pool("np-2")]
+    res = solve(oracle, emu, pods, pools=pools, its=_reserved_catalog(), options=RESERVED)
+    assert len(res["newNodeClaims"]) == 1 and len(res["podErrors"]) == 1
+    s = _claim_summary(res["newNodeClaims"][0])
+    assert s["reserved"] == ["r-small-instance-type"] and s["capacityType"] == ["reserved"] and s["types"] == ["small-instance-type"]
+    left = [p for p in pods if p["uid"] in res["podErrors"]]
+    res = solve(oracle, emu, left, pools=pools, its=_reserved_catalog(small_capacity=0), options=RESERVED)
+    s = _claim_summary(res["newNodeClaims"][0])
+    assert not res["podErrors"] and s["reserved"] == [] and "reserved" not in (s["capacityType"] or []) and s["types"] == ["small-instance-type"]
+
+
+def test_reserved_multiple_reservations_one_instance_pool(oracle, emu):
+    # :4894-4975 — the small type has two reservations (1 and 2 instances): four mutually exclusive pods, two schedule in
+    # the first pass (the largest compatible reservation holds two), one in the second, the last falls back
+    pods = [_spread_pod(node_requirements=[fx.req(fx.INSTANCE_TYPE, "In", "small-instance-type")]) for _ in range(4)]
+    res = solve(oracle, emu, pods, its=_reserved_catalog(extra_small=("r-small-instance-type-2", 2)), options=RESERVED)
+    assert len(res["newNodeClaims"]) == 2 and len(res["podErrors"]) == 2
+    for c in res["newNodeClaims"]:
+        s = _claim_summary(c)
+        assert s["reserved"] and s["capacityType"] == ["reserved"] and s["types"] == ["small-instance-type"]
+    # the launch flow decides which reservations were consumed; take "one from each" (the first state the reference describes)
+    left = [p for p in pods if p["uid"] in res["podErrors"]]
+    res = solve(oracle, emu, left, its=_reserved_catalog(small_capacity=0, extra_small=("r-small-instance-type-2", 1)), options=RESERVED)
+    assert len(res["newNodeClaims"]) == 1 and len(res["podErrors"]) == 1 and _claim_summary(res["newNodeClaims"][0])["reserved"] == ["r-small-instance-type-2"]
+    left = [p for p in left if p["uid"] in res["podErrors"]]
+    res = solve(oracle, emu, left, its=_reserved_catalog(small_capacity=0, extra_small=("r-small-instance-type-2", 0)), options=RESERVED)
+    s = _claim_summary(res["newNodeClaims"][0])
+    assert not res["podErrors"] and s["reserved"] == [] and s["types"] == ["small-instance-type"]
+
+
+def test_reserved_error_does_not_relax_or_fall_through(oracle, emu):
+    # :5059-5140 — both pods prefer np-1 and exclude each other; the first takes the reservation through np-1, the second
+    # fails with a reserved-offering error and must NOT relax its preference to reach np-2 (scheduler.go:533-536)
+    pods = [_spread_pod(node_requirements=[fx.req(fx.INSTANCE_TYPE, "In", "small-instance-type")], node_preferences=[fx.req(fx.NODEPOOL, "In", "np-1")]) for _ in range(2)]
+    pools = [fx.node_pool("np-1"), fx.node_pool("np-2")]
+    res = solve(oracle, emu, pods, pools=pools, its=_reserved_catalog(), options=RESERVED)
+    assert len(res["newNodeClaims"]) == 1 and len(res["podErrors"]) == 1
+    s = _claim_summary(res["newNodeClaims"][0])
+    assert s["reserved"] == ["r-small-instance-type"] and s["pool"] == "np-1" and s["capacityType"] == ["reserved"]
+    assert [e["code"] for e in res["podErrors"].values()] == [8]          # reserved offering error
+    assert res["counters"]["relaxations"] == 0
+    left = [p for p in pods if p["uid"] in res["podErrors"]]
+    res = solve(oracle, emu, left, pools=pools, its=_reserved_catalog(small_capacity=0), options=RESERVED)
+    s = _claim_summary(res["newNodeClaims"][0])
+    assert not res["podErrors"] and s["reserved"] == [] and s["pool"] == "np-1"
+    # :4976-5057 in this problem format (one catalogue for every pool): a lower-weight pool is not used to dodge the error
+    pools = [fx.node_pool("np-primary", weight=100), fx.node_pool("np-fallback", weight=50)]
+    pods = [_spread_pod(node_requirements=[fx.req(fx.INSTANCE_TYPE, "In", "small-instance-type")]) for _ in range(2)]
+    res = solve(oracle, emu, pods, pools=pools, its=_reserved_catalog(), options=RESERVED)
+    assert len(res["newNodeClaims"]) == 1 and len(res["podErrors"]) == 1 and _claim_summary(res["newNodeClaims"][0])["pool"] == "np-primary"
+
+
+def test_reserved_node_takes_several_pods(oracle, emu):
+    # :5142-5194 — two pods with zonal self-affinity pinned to the reserved small type share one reserved node
+    reqs = [fx.req(fx.INSTANCE_TYPE, "In", "small-instance-type"), fx.req(fx.NODEPOOL, "In", "np-1"), fx.req(fx.CAPACITY_TYPE, "In", "reserved"), fx.req(fx.ZONE, "In", "test-zone-1")]
+    pods = [fx.pod(labels=APP, node_requirements=reqs, pod_requirements=[fx.affinity_term(fx.ZONE, APP)]) for _ in range(2)]
+    res = solve(oracle, emu, pods, pools=[fx.node_pool("np-1")], its=_reserved_catalog(), options=RESERVED)
+    assert not res["podErrors"] and len(res["newNodeClaims"]) == 1 and len(res["newNodeClaims"][0]["pods"]) == 2
+    s = _claim_summary(res["newNodeClaims"][0])
+    assert s["reserved"] == ["r-small-instance-type"] and s["capacityType"] == ["reserved"] and s["types"] == ["small-instance-type"]
