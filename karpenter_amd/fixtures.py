@@ -274,8 +274,27 @@ def node_pool(name="default", weight=0, requirements=None, labels=None, taints=N
     return np
 
 
+KNOWN_EPHEMERAL_TAINTS = [("node.kubernetes.io/not-ready", "NoSchedule"), ("node.kubernetes.io/not-ready", "NoExecute"),
+                          ("node.kubernetes.io/unreachable", "NoSchedule"), ("node.cloudprovider.kubernetes.io/uninitialized", "NoSchedule"),
+                          ("karpenter.sh/unregistered", "NoExecute")]          # scheduling/taints.go:38-44 (MatchTaint: key + effect)
+KNOWN_EPHEMERAL_TAINT_PREFIXES = ["readiness.k8s.io/"]                        # taints.go:49-52
+
+
+def state_node_taints(taints, startup_taints=None, initialized=True, managed=True):
+    """StateNode.Taints() — state/statenode.go:311-339: until a managed node is initialized its well-known ephemeral
+    taints and the NodeClaim's startup taints are not held against pods (they are expected to go away)."""
+    taints = [dict({"key": "", "value": "", "effect": ""}, **t) for t in (taints or [])]
+    if initialized or not managed:
+        return taints
+    startup = {(t["key"], t["effect"]) for t in (startup_taints or [])}
+
+    def ephemeral(t):
+        return (t["key"], t["effect"]) in KNOWN_EPHEMERAL_TAINTS or any(t["key"].startswith(p) for p in KNOWN_EPHEMERAL_TAINT_PREFIXES)
+    return [t for t in taints if not ephemeral(t) and (t["key"], t["effect"]) not in startup]
+
+
 def state_node(name, instance_type, zone, capacity_type="on-demand", nodepool="default", used=None, taints=None, initialized=True,
-               extra_labels=None, under_consolidate_after=False):
+               extra_labels=None, under_consolidate_after=False, startup_taints=None):
     """A state.StateNode as the scheduler reads it (existingnode.go:47-75): labels of a node launched from `instance_type`
     in `zone` (single-valued instance-type requirements become labels, like the fake/KWOK providers do on Create),
     Available() = allocatable - used, Capacity() incl. nodes: 1 (statenode.go:370-374)."""
@@ -283,8 +302,9 @@ def state_node(name, instance_type, zone, capacity_type="on-demand", nodepool="d
     for r in instance_type["requirements"]:
         if r["operator"] == "In" and len(r["values"]) == 1:
             labels[r["key"]] = r["values"][0]
-    labels.update({ZONE: zone, CAPACITY_TYPE: capacity_type, NODEPOOL: nodepool, HOSTNAME: name,
-                   "karpenter.sh/registered": "true", "karpenter.sh/initialized": "true"})
+    labels.update({ZONE: zone, CAPACITY_TYPE: capacity_type, NODEPOOL: nodepool, HOSTNAME: name, "karpenter.sh/registered": "true"})
+    if initialized:
+        labels["karpenter.sh/initialized"] = "true"
     labels.update(extra_labels or {})
     from decimal import Decimal
     def nano(q):
@@ -296,8 +316,60 @@ def state_node(name, instance_type, zone, capacity_type="on-demand", nodepool="d
         a = nano(v) - nano(instance_type["overhead"].get(k, "0")) - nano((used or {}).get(k, "0"))
         avail[k] = f"{a}n"
     cap = dict(instance_type["capacity"]); cap["nodes"] = "1"
-    return {"name": name, "labels": labels, "taints": [dict({"key": "", "value": "", "effect": ""}, **t) for t in (taints or [])],
+    return {"name": name, "labels": labels, "taints": state_node_taints(taints, startup_taints, initialized, managed=True),
             "available": avail, "capacity": cap, "initialized": initialized, "managed": True, "underConsolidateAfter": under_consolidate_after}
+
+
+def launch(results, instance_types, pods, name_prefix="node"):
+    """What happens between two provisioning passes in the reference's tests (ExpectProvisioned + node state reconcile):
+    every NodeClaim of `results` is created by the cloud provider — cheapest instance type option, cheapest available
+    offering its requirements admit (fake/cloudprovider.go:108-170) — and becomes an initialized state node with the
+    claim's pods bound to it. Returns (state_nodes, bound_pods): feed them to the next problem as state_nodes /
+    cluster_pods. Pods placed on existing nodes are returned as bound to those nodes."""
+    by_name = {t["name"]: t for t in instance_types}
+    by_uid = {p["uid"]: p for p in pods}
+
+    def has(r, value):
+        if r.get("gte") is not None or r.get("lte") is not None:
+            try:
+                v = int(value)
+            except ValueError:
+                return False
+            if (r.get("gte") is not None and v < r["gte"]) or (r.get("lte") is not None and v > r["lte"]):
+                return False
+        return (value not in r["values"]) if r["complement"] else (value in r["values"])
+
+    nodes, bound = [], []
+    for i, c in enumerate(results["newNodeClaims"]):
+        reqs = {r["key"]: r for r in c["requirements"]}
+        best = None
+        for n in c["instanceTypes"]:
+            for o in by_name[n]["offerings"]:
+                if not o.get("available", True):
+                    continue
+                if all(r["key"] not in reqs or has(reqs[r["key"]], r["values"][0]) for r in o["requirements"]):
+                    if best is None or (o["price"], n) < (best[0]["price"], best[1]):
+                        best = (o, n)
+        assert best is not None, "a NodeClaim without a launchable offering"
+        off, it_name = best
+        labels = {r["key"]: r["values"][0] for r in off["requirements"]}
+        name = f"{name_prefix}-{i:04d}"
+        members = [by_uid[u] for u in c["pods"]]
+        used = {}
+        for p in members:
+            for k, v in p["requests"].items():
+                used[k] = used.get(k, 0.0) + quantity_float(v)
+        used_q = {k: f"{int(round(v * 1000))}m" for k, v in used.items()}
+        used_q["pods"] = str(len(members))
+        extra = {r["key"]: r["values"][0] for r in c["requirements"] if not r["complement"] and len(r["values"]) == 1 and r["key"] != HOSTNAME}
+        node = state_node(name, by_name[it_name], labels[ZONE], labels[CAPACITY_TYPE], c["nodePool"], used=used_q, extra_labels=extra)
+        nodes.append(node)
+        for p in members:
+            bound.append(dict(p, phase="Running", nodeName=name))
+    for e in results.get("existingNodes", []):
+        for u in e["pods"]:
+            bound.append(dict(by_uid[u], phase="Running", nodeName=e["name"]))
+    return nodes, bound
 
 
 def problem(instance_types, node_pools, pods=None, pod_groups=None, well_known=FAKE_WELL_KNOWN, state_nodes=None, cluster_pods=None,

@@ -545,3 +545,103 @@ def test_reserved_node_takes_several_pods(oracle, emu):
     assert not res["podErrors"] and len(res["newNodeClaims"]) == 1 and len(res["newNodeClaims"][0]["pods"]) == 2
     s = _claim_summary(res["newNodeClaims"][0])
     assert s["reserved"] == ["r-small-instance-type"] and s["capacityType"] == ["reserved"] and s["types"] == ["small-instance-type"]
+
+
+FILTERED_OUT = 6   # "nodepool requirements filtered out all available instance types" (scheduler.go:606-611)
+
+
+@pytest.mark.parametrize("line,pool_reqs,n_pods,requests", [
+    (5197, [fx.req(fx.INSTANCE_TYPE, "In", "non-existent-instance-type")], 1, {"cpu": "32", "memory": "256Gi"}),
+    (5242, [fx.req(fx.ARCH, "In", "non-existent-arch")], 3, None),
+    (5273, [fx.req(fx.ARCH, "In", "amd64"), fx.req(fx.ARCH, "In", "arm64")], 1, None),
+    (5302, [fx.req(fx.ZONE, "In", "non-existent-zone-1", "non-existent-zone-2")], 1, None),
+], ids=lambda v: f"suite_test.go:{v}" if isinstance(v, int) and v > 1000 else None)
+def test_nodepool_requirements_filter_out_every_instance_type(oracle, emu, line, pool_reqs, n_pods, requests):
+    """suite_test.go:5196-5327: a NodePool whose requirements leave no instance type reports exactly that error for every
+    pod (the template is dropped before Solve, scheduler.go:141-160)."""
+    res = solve(oracle, emu, [fx.pod(requests=requests) for _ in range(n_pods)], pools=[fx.node_pool(requirements=pool_reqs)])
+    assert not res["newNodeClaims"] and len(res["podErrors"]) == n_pods
+    assert {e["code"] for e in res["podErrors"].values()} == {FILTERED_OUT}
+
+
+# ---- In-Flight Nodes: suite_test.go:1829-2016 (two provisioning passes with the first pass's nodes in the cluster) ----
+
+def _two_passes(oracle, emu, first, second, its=None, pools=None):
+    its = its if its is not None else fx.fake_default_instance_types()
+    pools = pools or [fx.node_pool()]
+    r1 = solve(oracle, emu, first, pools=pools, its=its)
+    assert not r1["podErrors"]
+    nodes, bound = fx.launch(r1, its, first)
+    r2 = solve(oracle, emu, second, pools=pools, its=its, state_nodes=nodes, cluster_pods=bound)
+    return r1, nodes, bound, r2
+
+
+def test_in_flight_node_is_reused(oracle, emu):
+    small = {"cpu": "10m"}
+    # :1830-1845 — the second pod fits the node launched for the first
+    _, nodes, _, r2 = _two_passes(oracle, emu, [fx.pod(requests=small)], [fx.pod(requests=small)])
+    assert not r2["newNodeClaims"] and [e["name"] for e in r2["existingNodes"] if e["pods"]] == [nodes[0]["name"]]
+    # :1847-1894 — node selectors: the in-flight node is in test-zone-2; zone-1|zone-2 reuses it, zone-1|zone-3 cannot
+    first = [fx.pod(requests=small, node_requirements=[fx.req(fx.ZONE, "In", "test-zone-2")])]
+    _, nodes, _, r2 = _two_passes(oracle, emu, first, [fx.pod(requests=small, node_requirements=[fx.req(fx.ZONE, "In", "test-zone-1", "test-zone-2")])])
+    assert nodes[0]["labels"][fx.ZONE] == "test-zone-2" and not r2["newNodeClaims"]
+    _, _, _, r2 = _two_passes(oracle, emu, first, [fx.pod(requests=small, node_requirements=[fx.req(fx.ZONE, "In", "test-zone-1", "test-zone-3")])])
+    assert len(r2["newNodeClaims"]) == 1 and not any(e["pods"] for e in r2["existingNodes"])
+    # :1896-1913 — 1001m went to the smallest type that holds it; another full CPU does not fit there
+    _, _, _, r2 = _two_passes(oracle, emu, [fx.pod(requests={"cpu": "1001m"})], [fx.pod(requests={"cpu": "1"})])
+    assert len(r2["newNodeClaims"]) == 1
+    # :1915-1930 — an arm64 pod is not compatible with the amd64 node in flight
+    _, nodes, _, r2 = _two_passes(oracle, emu, [fx.pod(requests=small)], [fx.pod(node_selector={fx.ARCH: "arm64"})])
+    assert nodes[0]["labels"][fx.ARCH] == "amd64" and len(r2["newNodeClaims"]) == 1
+
+
+def test_in_flight_nodes_and_topology(oracle, emu):
+    lab = {"foo": "bar"}
+    # :1959-1988 — zonal spread continues on the nodes of the first pass: 1,1,2 then 3,3,3 without a new node
+    tsc = [fx.spread(fx.ZONE, lab)]
+    first = [fx.pod(labels=lab, topology_spread=tsc) for _ in range(4)]
+    second = [fx.pod(labels=lab, topology_spread=tsc) for _ in range(5)]
+    r1, nodes, bound, r2 = _two_passes(oracle, emu, first, second)
+    assert skew(r1, fx.ZONE) == [1, 1, 2]
+    assert not r2["newNodeClaims"] and not r2["podErrors"]
+    zone_of = {n["name"]: n["labels"][fx.ZONE] for n in nodes}
+    per_zone = collections.Counter(zone_of[p["nodeName"]] for p in bound)
+    for e in r2["existingNodes"]:
+        per_zone[zone_of[e["name"]]] += len(e["pods"])
+    assert sorted(per_zone.values()) == [3, 3, 3]
+    # :1990-2015 — hostname spread: every pod of the second pass needs its own new node
+    tsc = [fx.spread(fx.HOSTNAME, lab)]
+    first = [fx.pod(labels=lab, topology_spread=tsc) for _ in range(4)]
+    second = [fx.pod(labels=lab, topology_spread=tsc) for _ in range(5)]
+    r1, nodes, bound, r2 = _two_passes(oracle, emu, first, second)
+    assert len(r1["newNodeClaims"]) == 4 and len(r2["newNodeClaims"]) == 5 and not any(e["pods"] for e in r2["existingNodes"])
+
+
+def test_in_flight_node_taints(oracle, emu):
+    """suite_test.go:2017-2172 with StateNode.Taints() (statenode.go:311-339): ephemeral and startup taints of a node that
+    is not initialized yet are not held against pods; once it is initialized every taint counts."""
+    its = fx.fake_default_instance_types()
+    by = {t["name"]: t for t in its}
+    not_ready = {"key": "node.kubernetes.io/not-ready", "effect": "NoExecute"}
+    custom = {"key": "foo.com/taint", "value": "tainted", "effect": "NoSchedule"}
+    startup = {"key": "ignore-me", "value": "nothing-to-see-here", "effect": "NoSchedule"}
+
+    def reused(node):
+        res = solve(oracle, emu, [fx.pod()], its=its, state_nodes=[node])
+        on_node = any(e["pods"] for e in res["existingNodes"])
+        assert on_node != bool(res["newNodeClaims"]) and not res["podErrors"]
+        return on_node
+
+    def node(**kw):
+        return fx.state_node("node-1", by["default-instance-type"], "test-zone-1", **kw)
+    assert reused(node())                                                                     # :2018 no taints
+    assert reused(node(taints=[not_ready], initialized=False))                                # :2040 ephemeral, uninitialized
+    assert not reused(node(taints=[not_ready], initialized=True))                             # :2040 ... then initialized
+    assert not reused(node(taints=[custom], initialized=True))                                # :2078
+    assert reused(node(taints=[custom], startup_taints=[custom], initialized=False))          # :2110 custom startup taint
+    assert not reused(node(taints=[startup], startup_taints=[startup], initialized=True))     # :2143 startup taint after initialization
+    assert not reused(node(taints=[custom], initialized=False))                               # an ordinary taint always counts
+    assert reused(node(taints=[{"key": "readiness.k8s.io/my-rule", "effect": "NoSchedule"}], initialized=False))   # taints.go:49-52
+    # a pod that tolerates the taint uses the initialized node
+    res = solve(oracle, emu, [fx.pod(tolerations=[{"key": "foo.com/taint", "operator": "Exists"}])], its=its, state_nodes=[node(taints=[custom])])
+    assert not res["newNodeClaims"]
