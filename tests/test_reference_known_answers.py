@@ -645,3 +645,150 @@ def test_in_flight_node_taints(oracle, emu):
     # a pod that tolerates the taint uses the initialized node
     res = solve(oracle, emu, [fx.pod(tolerations=[{"key": "foo.com/taint", "operator": "Exists"}])], its=its, state_nodes=[node(taints=[custom])])
     assert not res["newNodeClaims"]
+
+
+# ---- Combined topologies over several provisioning passes: topology_test.go:943-1133 --------------------------------
+
+class Cluster:
+    """The cluster as it grows over ExpectProvisioned calls: every pass solves with the nodes and bound pods of the passes
+    before it (fixtures.launch), on both the oracle and the device algorithm."""
+
+    def __init__(self, oracle, emu, its=None, pools=None):
+        self.oracle, self.emu = oracle, emu
+        self.its = its if its is not None else fx.fake_default_instance_types()
+        self.pools = pools or [fx.node_pool()]
+        self.nodes, self.bound = [], []
+
+    def provision(self, pods):
+        res = solve(self.oracle, self.emu, pods, pools=self.pools, its=self.its, state_nodes=self.nodes, cluster_pods=self.bound)
+        nodes, bound = fx.launch(res, self.its, pods, name_prefix=f"pass{len(self.nodes)}")
+        self.nodes += nodes
+        self.bound += bound
+        return res
+
+    def skew(self, key, selector=LABELS):
+        """ExpectSkew: bound pods matching the selector per domain of `key`."""
+        label = {n["name"]: n["labels"].get(key) for n in self.nodes}
+        cnt = collections.Counter(label[p["nodeName"]] for p in self.bound if all(p["labels"].get(k) == v for k, v in selector.items()))
+        return sorted(cnt.values())
+
+
+def _tsc_pods(n, constraints):
+    return [fx.pod(labels=LABELS, topology_spread=constraints) for _ in range(n)]
+
+
+def test_combined_hostname_and_zonal_spread_over_passes(oracle, emu):
+    # :944-982
+    tsc = [fx.spread(fx.ZONE, LABELS), fx.spread(fx.HOSTNAME, LABELS, max_skew=3)]
+    c = Cluster(oracle, emu)
+    for n, want in ((2, [1, 1]), (3, [1, 2, 2]), (5, [3, 3, 4]), (11, [7, 7, 7])):
+        assert not c.provision(_tsc_pods(n, tsc))["podErrors"]
+        assert c.skew(fx.ZONE) == want and max(c.skew(fx.HOSTNAME)) <= 3
+    # :1093-1132 capacity type + hostname
+    tsc = [fx.spread(fx.CAPACITY_TYPE, LABELS), fx.spread(fx.HOSTNAME, LABELS, max_skew=3)]
+    c = Cluster(oracle, emu)
+    for n, want in ((2, [1, 1]), (3, [2, 3]), (5, [5, 5]), (11, [10, 11])):
+        assert not c.provision(_tsc_pods(n, tsc))["podErrors"]
+        assert c.skew(fx.CAPACITY_TYPE) == want and max(c.skew(fx.HOSTNAME)) <= 3
+
+
+def test_spread_across_nodepool_requirement_values(oracle, emu):
+    # :984-1050 — a custom key whose domains come from two NodePools' requirements: 4 of 5 values are spot, 1 on-demand
+    key = "capacity.spread.4-1"
+    pools = [fx.node_pool("spot", requirements=[fx.req(fx.CAPACITY_TYPE, "In", "spot"), fx.req(key, "In", "2", "3", "4", "5")]),
+             fx.node_pool("on-demand", requirements=[fx.req(fx.CAPACITY_TYPE, "In", "on-demand"), fx.req(key, "In", "1")])]
+    c = Cluster(oracle, emu, pools=pools)
+    assert not c.provision(_tsc_pods(20, [fx.spread(key, LABELS)]))["podErrors"]
+    assert c.skew(key) == [4, 4, 4, 4, 4] and c.skew(fx.CAPACITY_TYPE) == [4, 16]
+
+
+def test_zonal_spread_stops_at_a_nodepool_without_capacity(oracle, emu):
+    # :1052-1091 — zone 3 exists only in a NodePool whose cpu limit is 0: after one pod per reachable zone the skew rule
+    # blocks the rest; the ScheduleAnyway hostname constraint is relaxed without helping
+    tsc = [fx.spread(fx.ZONE, LABELS), fx.spread(fx.HOSTNAME, LABELS, when="ScheduleAnyway")]
+    pools = [fx.node_pool("a", requirements=[fx.req(fx.ZONE, "In", "test-zone-1", "test-zone-2")]),
+             fx.node_pool("b", requirements=[fx.req(fx.ZONE, "In", "test-zone-3")], limits={"cpu": "0"})]
+    c = Cluster(oracle, emu, pools=pools)
+    res = c.provision(_tsc_pods(10, tsc))
+    assert len(res["podErrors"]) == 8 and c.skew(fx.ZONE) == [1, 1] and c.skew(fx.HOSTNAME) == [1, 1]
+
+
+# ---- matchLabelKeys, nodeTaintsPolicy, nodeAffinityPolicy: topology_test.go:1135-1662 -------------------------------
+
+def _claim_skew(res, pods, key, selector=LABELS):
+    """ExpectSkew over the NodeClaims of one pass: matching pods per value of `key` (from the claim's requirements)."""
+    by_uid = {p["uid"]: p for p in pods}
+    cnt = collections.Counter()
+    for c in res["newNodeClaims"]:
+        n = sum(1 for u in c["pods"] if all(by_uid[u]["labels"].get(k) == v for k, v in selector.items()))
+        if n:
+            dom = c["hostname"] if key == fx.HOSTNAME else [q["values"] for q in c["requirements"] if q["key"] == key][0][0]
+            cnt[dom] += n
+    return sorted(cnt.values())
+
+
+def test_match_label_keys(oracle, emu):
+    # :1142-1169 — matchLabelKeys splits the constraint per value of the pod's own label: 2 + 2 pods on two hosts
+    def tsc():
+        t = fx.spread(fx.HOSTNAME, LABELS)
+        t["matchLabelKeys"] = ["test-label"]
+        return [t]
+    pods = [fx.pod(labels=dict(LABELS, **{"test-label": v}), topology_spread=tsc()) for v in ("value-a", "value-a", "value-b", "value-b")]
+    res = solve(oracle, emu, pods)
+    assert _claim_skew(res, pods, fx.HOSTNAME) == [2, 2]
+    # :1171-1189 — a key the pods do not carry is ignored
+    pods = [fx.pod(labels=LABELS, topology_spread=tsc()) for _ in range(4)]
+    assert _claim_skew(solve(oracle, emu, pods), pods, fx.HOSTNAME) == [1, 1, 1, 1]
+
+
+SPREAD_LABEL = "fake-label"
+
+
+def _tiny_node(name, labels, taints=None):
+    n = bare_node(name, cpu="100m", labels=labels)
+    n["taints"] = [dict({"key": "", "value": "", "effect": ""}, **t) for t in (taints or [])]
+    return n
+
+
+@pytest.mark.parametrize("policy,want", [("Ignore", [1]), ("Honor", [5])])
+def test_node_taints_policy_with_tainted_nodes(oracle, emu, policy, want):
+    # :1199-1337 — two tainted nodes (too small for the pods) carry the domains foo / bar; the NodePool offers baz. With
+    # Ignore the tainted domains count and the skew rule stops after one pod; with Honor only baz is a domain
+    taint = [{"key": "taintname", "value": "taintvalue", "effect": "NoSchedule"}]
+    nodes = [_tiny_node("node-foo", {SPREAD_LABEL: "foo"}, taint), _tiny_node("node-bar", {SPREAD_LABEL: "bar"}, taint)]
+    pods = [fx.pod(labels=LABELS, requests={"cpu": "1"}, topology_spread=[fx.spread(SPREAD_LABEL, LABELS, taints_policy=policy)]) for _ in range(5)]
+    res = solve(oracle, emu, pods, pools=[fx.node_pool(labels={SPREAD_LABEL: "baz"})], state_nodes=nodes)
+    assert _claim_skew(res, pods, SPREAD_LABEL) == want
+
+
+@pytest.mark.parametrize("policy,want", [("Ignore", [1]), ("Honor", [2])])
+def test_node_taints_policy_with_domains_from_nodepools(oracle, emu, policy, want):
+    # :1339-1449 — the domain "bar" only exists in a tainted NodePool the pods do not tolerate
+    pools = [fx.node_pool("default", requirements=[fx.req(SPREAD_LABEL, "In", "foo")]),
+             fx.node_pool("tainted", requirements=[fx.req(fx.CAPACITY_TYPE, "Exists"), fx.req(SPREAD_LABEL, "In", "bar")],
+                          taints=[{"key": "taint-key", "value": "taint-value", "effect": "NoSchedule"}])]
+    pods = [fx.pod(labels=LABELS, topology_spread=[fx.spread(SPREAD_LABEL, LABELS, taints_policy=policy)]) for _ in range(2)]
+    res = solve(oracle, emu, pods, pools=pools)
+    assert _claim_skew(res, pods, SPREAD_LABEL) == want
+
+
+def test_node_taints_policy_mutually_exclusive_nodepools_share_a_domain(oracle, emu):
+    # :1451-1524 — pool 0 offers foo/bar, pool 1 foo/baz, each behind its own taint; 2 pods tolerate pool 0, 4 pool 1
+    pools = [fx.node_pool(f"np-{i}", requirements=[fx.req(fx.CAPACITY_TYPE, "Exists"), fx.req(SPREAD_LABEL, "In", *doms)],
+                          taints=[{"key": "taint-key", "value": f"nodepool-{i}", "effect": "NoSchedule"}]) for i, doms in enumerate((["foo", "bar"], ["foo", "baz"]))]
+    pods = []
+    for i in range(2):
+        pods += [fx.pod(labels=LABELS, topology_spread=[fx.spread(SPREAD_LABEL, LABELS, taints_policy="Honor")],
+                        tolerations=[{"key": "taint-key", "operator": "Equal", "effect": "NoSchedule", "value": f"nodepool-{i}"}]) for _ in range((i + 1) * 2)]
+    res = solve(oracle, emu, pods, pools=pools)
+    assert not res["podErrors"] and _claim_skew(res, pods, SPREAD_LABEL) == [1, 2, 3]
+
+
+@pytest.mark.parametrize("policy,want", [("Ignore", [1]), ("Honor", [5])])
+def test_node_affinity_policy(oracle, emu, policy, want):
+    # :1532-1662 — the two existing nodes do not match the pods' node selector: Honor leaves them out of the domains
+    nodes = [_tiny_node("node-foo", {SPREAD_LABEL: "foo", "selector": "mismatch"}), _tiny_node("node-bar", {SPREAD_LABEL: "bar", "selector": "mismatch"})]
+    pods = [fx.pod(labels=LABELS, requests={"cpu": "1"}, node_selector={"selector": "value"},
+                   topology_spread=[fx.spread(SPREAD_LABEL, LABELS, affinity_policy=policy)]) for _ in range(5)]
+    res = solve(oracle, emu, pods, pools=[fx.node_pool(labels={SPREAD_LABEL: "baz", "selector": "value"})], state_nodes=nodes)
+    assert _claim_skew(res, pods, SPREAD_LABEL) == want
