@@ -792,3 +792,71 @@ def test_node_affinity_policy(oracle, emu, policy, want):
                    topology_spread=[fx.spread(SPREAD_LABEL, LABELS, affinity_policy=policy)]) for _ in range(5)]
     res = solve(oracle, emu, pods, pools=[fx.node_pool(labels={SPREAD_LABEL: "baz", "selector": "value"})], state_nodes=nodes)
     assert _claim_skew(res, pods, SPREAD_LABEL) == want
+
+
+# ---- Combined topologies and node affinity: topology_test.go:1664-1926 ----------------------------------------------
+
+def test_combined_zonal_and_capacity_type_over_passes(oracle, emu):
+    # :1665-1702
+    tsc = [fx.spread(fx.CAPACITY_TYPE, LABELS), fx.spread(fx.ZONE, LABELS)]
+    c = Cluster(oracle, emu)
+    # the reference only bounds the counts here: zone 3 has no spot offering, so once (zone, capacity type) reach
+    # (2,2,1) / (3,2) the next pod needs spot in zone 3 and nothing more can schedule
+    for n, max_ct, max_zone in ((2, 1, 1), (3, 3, 2), (3, 5, 4), (11, 11, 7)):
+        c.provision(_tsc_pods(n, tsc))
+        assert max(c.skew(fx.CAPACITY_TYPE)) <= max_ct and max(c.skew(fx.ZONE)) <= max_zone
+    assert c.skew(fx.ZONE) == [1, 2, 2] and c.skew(fx.CAPACITY_TYPE) == [2, 3]
+
+
+def test_combined_hostname_zonal_capacity_type_over_many_passes(oracle, emu):
+    # :1705-1740 — the assorted catalogue, three constraints, 14 passes of growing size; every pod schedules and every
+    # max skew holds after every pass
+    tsc = [fx.spread(fx.CAPACITY_TYPE, LABELS), fx.spread(fx.ZONE, LABELS, max_skew=2), fx.spread(fx.HOSTNAME, LABELS, max_skew=3)]
+    c = Cluster(oracle, emu, its=fx.fake_instance_types_assorted())
+    for i in range(1, 15):
+        assert not c.provision(_tsc_pods(i, tsc))["podErrors"]
+        for key, allowed in ((fx.CAPACITY_TYPE, 1), (fx.ZONE, 2), (fx.HOSTNAME, 3)):
+            s = c.skew(key)
+            lo = 0 if key == fx.HOSTNAME else min(s)       # ExpectMaxSkew: hostname domains start at 0 (a new node is always possible)
+            assert max(s) - lo <= allowed, (i, key, s)
+
+
+def test_zonal_spread_limited_by_node_affinity(oracle, emu):
+    pod = lambda **kw: fx.pod(labels=LABELS, topology_spread=[fx.spread(fx.ZONE, LABELS)], **kw)
+    # :1743-1767 node selectors pin the pods: 5 and 10
+    c = Cluster(oracle, emu)
+    c.provision([pod(node_selector={fx.ZONE: "test-zone-1"}) for _ in range(5)] + [pod(node_selector={fx.ZONE: "test-zone-2"}) for _ in range(10)])
+    assert c.skew(fx.ZONE) == [5, 10]
+    # :1769-1789 required node affinity on two zones
+    c = Cluster(oracle, emu)
+    c.provision([pod(node_requirements=[fx.req(fx.ZONE, "In", "test-zone-1", "test-zone-2")]) for _ in range(10)])
+    assert c.skew(fx.ZONE) == [5, 5]
+    # :1791-1833 three passes with different affinities
+    c = Cluster(oracle, emu)
+    c.provision([pod(node_requirements=[fx.req(fx.ZONE, "In", "test-zone-1", "test-zone-2")]) for _ in range(6)])
+    assert c.skew(fx.ZONE) == [3, 3]
+    c.pools = [fx.node_pool(requirements=[fx.req(fx.ZONE, "In", "test-zone-1", "test-zone-2", "test-zone-3")])]
+    c.provision([pod(node_requirements=[fx.req(fx.ZONE, "In", "test-zone-2", "test-zone-3")])])
+    assert c.skew(fx.ZONE) == [1, 3, 3]
+    c.provision([pod() for _ in range(5)])
+    assert c.skew(fx.ZONE) == [4, 4, 4]
+    # :1835-1857 a preferred affinity does not limit the domains
+    c = Cluster(oracle, emu)
+    c.provision([pod(node_preferences=[fx.req(fx.ZONE, "In", "test-zone-1", "test-zone-2")]) for _ in range(6)])
+    assert c.skew(fx.ZONE) == [2, 2, 2]
+
+
+def test_capacity_type_spread_limited_by_node_affinity(oracle, emu):
+    # :1860-1882 ScheduleAnyway + node selectors
+    pod = lambda when="DoNotSchedule", **kw: fx.pod(labels=LABELS, topology_spread=[fx.spread(fx.CAPACITY_TYPE, LABELS, when=when)], **kw)
+    c = Cluster(oracle, emu)
+    c.provision([pod("ScheduleAnyway", node_selector={fx.CAPACITY_TYPE: "spot"}) for _ in range(5)] + [pod("ScheduleAnyway", node_selector={fx.CAPACITY_TYPE: "on-demand"}) for _ in range(5)])
+    assert c.skew(fx.CAPACITY_TYPE) == [5, 5]
+    # :1884-1925
+    c = Cluster(oracle, emu)
+    c.provision([pod(node_requirements=[fx.req(fx.CAPACITY_TYPE, "In", "spot")]) for _ in range(3)])
+    assert c.skew(fx.CAPACITY_TYPE) == [3]
+    c.provision([pod(node_requirements=[fx.req(fx.CAPACITY_TYPE, "In", "on-demand", "spot")])])
+    assert c.skew(fx.CAPACITY_TYPE) == [1, 3]
+    c.provision([pod() for _ in range(5)])
+    assert c.skew(fx.CAPACITY_TYPE) == [4, 5]
