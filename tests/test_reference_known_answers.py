@@ -860,3 +860,126 @@ def test_capacity_type_spread_limited_by_node_affinity(oracle, emu):
     assert c.skew(fx.CAPACITY_TYPE) == [1, 3]
     c.provision([pod() for _ in range(5)])
     assert c.skew(fx.CAPACITY_TYPE) == [4, 5]
+
+
+# ---- Pod affinity / anti-affinity: topology_test.go:1928-2842 -------------------------------------------------------
+
+AFF = {"security": "s2"}
+
+
+def _where(res):
+    """pod uid -> hostname of the NodeClaim (or existing node) it was placed on."""
+    out = {u: c["hostname"] for c in res["newNodeClaims"] for u in c["pods"]}
+    out.update({u: e["name"] for e in res.get("existingNodes", []) for u in e["pods"]})
+    return out
+
+
+def _claim_of(res, pod):
+    return next(c for c in res["newNodeClaims"] if pod["uid"] in c["pods"])
+
+
+def _single(c, key):
+    vals = [q["values"] for q in c["requirements"] if q["key"] == key and not q["complement"]]
+    return vals[0][0] if vals and len(vals[0]) == 1 else None
+
+
+def test_pod_affinity_hostname_and_arch(oracle, emu):
+    # :1939-1971 — the follower lands on the target's node even with ten spread-out nodes to choose from
+    target, follower = fx.pod(labels=AFF), fx.pod(pod_requirements=[fx.affinity_term(fx.HOSTNAME, AFF)])
+    pods = spread_pods(10, fx.HOSTNAME) + [target, follower]
+    w = _where(solve(oracle, emu, pods))
+    assert w[target["uid"]] == w[follower["uid"]]
+    # :1973-2014 — affinity on the architecture: same arch, different nodes (hostname spread among the two)
+    tsc = [fx.spread(fx.HOSTNAME, AFF)]
+    p1 = fx.pod(labels=AFF, topology_spread=tsc, requests={"cpu": "2"}, node_selector={fx.ARCH: "arm64"})
+    p2 = fx.pod(labels=AFF, topology_spread=tsc, requests={"cpu": "1"}, pod_requirements=[fx.affinity_term(fx.ARCH, AFF)])
+    res = solve(oracle, emu, [p1, p2])
+    w = _where(res)
+    assert w[p1["uid"]] != w[p2["uid"]] and _single(_claim_of(res, p1), fx.ARCH) == _single(_claim_of(res, p2), fx.ARCH) == "arm64"
+    # :2383-2424 — anti-affinity on the architecture: different arch
+    p2 = fx.pod(labels=AFF, topology_spread=tsc, requests={"cpu": "1"}, pod_anti_requirements=[fx.affinity_term(fx.ARCH, AFF)])
+    res = solve(oracle, emu, [p1, p2])
+    assert not res["podErrors"] and _single(_claim_of(res, p1), fx.ARCH) == "arm64" and _single(_claim_of(res, p2), fx.ARCH) == "amd64"
+
+
+def test_self_affinity_with_zone_constraints(oracle, emu):
+    # :2150-2179 — self affinity on zone with a zone requirement: one node in test-zone-3
+    pods = [fx.pod(labels=AFF, pod_requirements=[fx.affinity_term(fx.ZONE, AFF)], node_requirements=[fx.req(fx.ZONE, "In", "test-zone-3")]) for _ in range(3)]
+    res = solve(oracle, emu, pods)
+    assert len(res["newNodeClaims"]) == 1 and _single(res["newNodeClaims"][0], fx.ZONE) == "test-zone-3" and not res["podErrors"]
+    # :2181-2232 — matching affinities, incompatible zone selectors: two nodes are allowed
+    s1 = {"security": "s1"}
+    p1 = fx.pod(labels=s1, pod_requirements=[fx.affinity_term(fx.ZONE, s1)], node_requirements=[fx.req(fx.ZONE, "In", "test-zone-2")])
+    p2 = fx.pod(labels=s1, pod_requirements=[fx.affinity_term(fx.ZONE, s1)], node_requirements=[fx.req(fx.ZONE, "In", "test-zone-3")])
+    res = solve(oracle, emu, [p1, p2])
+    assert not res["podErrors"] and _single(_claim_of(res, p1), fx.ZONE) == "test-zone-2" and _single(_claim_of(res, p2), fx.ZONE) == "test-zone-3"
+
+
+def test_preferred_affinities_may_be_violated(oracle, emu):
+    # :2234-2265 — preferred affinity to pods that do not exist
+    lonely = fx.pod(pod_preferences=[fx.weighted(50, fx.affinity_term(fx.HOSTNAME, AFF))])
+    res = solve(oracle, emu, spread_pods(10, fx.HOSTNAME) + [lonely])
+    assert not res["podErrors"]
+    # :2267-2298 — ten pods prefer to avoid the zones of three spread pods: there are only three zones
+    avoiders = [fx.pod(pod_anti_preferences=[fx.weighted(50, fx.affinity_term(fx.ZONE, LABELS))]) for _ in range(10)]
+    res = solve(oracle, emu, spread_pods(3, fx.ZONE) + avoiders)
+    assert not res["podErrors"]
+    # :2426-2464 — inverse: three pods (one per zone) prefer not to share a zone with the labelled pod; it still schedules
+    anti = [fx.weighted(10, fx.affinity_term(fx.ZONE, AFF))]
+    zoned = [fx.pod(requests={"cpu": "2"}, pod_anti_preferences=anti, node_selector={fx.ZONE: f"test-zone-{i}"}) for i in (1, 2, 3)]
+    res = solve(oracle, emu, zoned + [fx.pod(labels=AFF)])
+    assert not res["podErrors"]
+    # :2633-2666 — a preference for the labelled pod's host conflicts with a required hostname spread: spread wins
+    target = fx.pod(labels=AFF)
+    tsc = [fx.spread(fx.HOSTNAME, LABELS)]
+    fans = [fx.pod(labels=LABELS, topology_spread=tsc, pod_preferences=[fx.weighted(50, fx.affinity_term(fx.HOSTNAME, AFF))]) for _ in range(3)]
+    res = solve(oracle, emu, fans + [target])
+    assert not res["podErrors"] and _claim_skew(res, fans + [target], fx.HOSTNAME) == [1, 1, 1]
+
+
+def test_anti_affinity_on_zone_other_schedules_first(oracle, emu):
+    # :2361-2381 — the labelled pod can be in any zone, so the pod that must avoid its zone cannot be placed
+    pod = fx.pod(labels=AFF, requests={"cpu": "2"})
+    avoider = fx.pod(pod_anti_requirements=[fx.affinity_term(fx.ZONE, AFF)])
+    res = solve(oracle, emu, [pod, avoider])
+    assert list(res["podErrors"]) == [avoider["uid"]] and len(res["newNodeClaims"]) == 1
+
+
+def test_zonal_anti_affinity_fills_one_zone_per_pass(oracle, emu):
+    # :2668-2711 — three mutually exclusive pods per pass: only one schedules per pass (the others could be anywhere),
+    # until every zone is taken
+    c = Cluster(oracle, emu)
+    for want in ([1], [1, 1], [1, 1, 1], [1, 1, 1]):
+        c.provision([fx.pod(labels=AFF, pod_anti_requirements=[fx.affinity_term(fx.ZONE, AFF)]) for _ in range(3)])
+        assert c.skew(fx.ZONE, selector=AFF) == want
+
+
+def test_zonal_affinity_to_a_target(oracle, emu):
+    # :2730-2761 — unconstrained target: the followers cannot know its zone in the same pass, they follow in the next
+    target = fx.pod(labels=AFF)
+    followers = [fx.pod(pod_requirements=[fx.affinity_term(fx.ZONE, AFF)]) for _ in range(10)]
+    c = Cluster(oracle, emu)
+    res = c.provision(followers + [target])
+    assert sorted(res["podErrors"]) == sorted(p["uid"] for p in followers) and c.skew(fx.ZONE, selector={}) == [1]
+    assert not c.provision(followers)["podErrors"]
+    assert c.skew(fx.ZONE, selector={}) == [11]
+    # :2763-2790 — a target pinned to a zone can be followed in the same pass
+    target = fx.pod(labels=AFF, node_requirements=[fx.req(fx.ZONE, "In", "test-zone-1")])
+    c = Cluster(oracle, emu)
+    assert not c.provision(followers + [target])["podErrors"]
+    assert c.skew(fx.ZONE, selector={}) == [11]
+
+
+def test_dependent_affinities(oracle, emu):
+    # :2792-2825 — db <- web <- cache <- ui on hostname: all four end up on one node
+    def lab(t):
+        return {"type": t, "spread": "spread"}
+    pods = [fx.pod(labels=lab("db")), fx.pod(labels=lab("web"), pod_requirements=[fx.affinity_term(fx.HOSTNAME, lab("db"))]),
+            fx.pod(labels=lab("cache"), pod_requirements=[fx.affinity_term(fx.HOSTNAME, lab("web"))]),
+            fx.pod(labels=lab("ui"), pod_requirements=[fx.affinity_term(fx.HOSTNAME, lab("cache"))])]
+    for order in (pods, pods[::-1], [pods[2], pods[0], pods[3], pods[1]]):
+        res = solve(oracle, emu, order)
+        assert not res["podErrors"] and len(set(_where(res).values())) == 1
+    # :2827-2841 — a dependency on pods that do not exist
+    res = solve(oracle, emu, [fx.pod(labels=lab("db"), pod_requirements=[fx.affinity_term(fx.HOSTNAME, lab("web"))])])
+    assert len(res["podErrors"]) == 1
