@@ -110,3 +110,122 @@ def test_wont_delete_node_if_it_would_violate_anti_affinity(oracle, emu):
         n["pods"][0].pop("podAntiAffinity")
     cmds = dz.sweep(cluster, nodes, oracle.solve)
     assert cmds[0]["decision"] in (dz.DELETE, dz.NOOP)
+
+
+# ---- known answers from consolidation_test.go -----------------------------------------------------------------------
+
+def _solvers(oracle, emu):
+    return (oracle.solve, lambda p: NewScheduler(p, solver_lib=emu).Solve())
+
+
+def _node_with_pods(name, it, zone, ct, cpus, pool="default", labels=None, **kw):
+    pods = [fx.pod(labels=labels or {"app": "test"}, requests={"cpu": c}, phase="Running", node_name=name) for c in cpus]
+    milli = sum(int(c[:-1]) if c.endswith("m") else int(float(c) * 1000) for c in cpus)
+    n = fx.state_node(name, it, zone, ct, pool, used={"cpu": f"{milli}m", "pods": str(len(pods))}, **kw)
+    n["pods"] = pods
+    return n
+
+
+def test_wont_replace_with_a_more_expensive_node(oracle, emu):
+    """consolidation_test.go:2222-2394: the replacement's worst launch price among the offerings the claim admits must be
+    below the current node's price (nodeclaim.go:411-420, types.go:587-598) — a cheap spot zone does not help if another
+    admitted spot zone costs more, and an on-demand-only NodePool compares on-demand prices."""
+    zones = ["test-zone-1a", "test-zone-1b", "test-zone-1c"]
+    current = fx.fake_instance_type("current-on-demand", {"cpu": "32", "memory": "64Gi", "pods": "100"}, offerings=[fx.offering("on-demand", zones[0], 0.5, available=False)])
+    spot_repl = fx.fake_instance_type("potential-spot-replacement", {"cpu": "32", "memory": "64Gi", "pods": "100"},
+                                      offerings=[fx.offering("spot", zones[0], 1.0), fx.offering("spot", zones[1], 0.2), fx.offering("spot", zones[2], 0.4)])
+    od_repl = fx.fake_instance_type("on-demand-replacement", {"cpu": "32", "memory": "64Gi", "pods": "100"},
+                                    offerings=[fx.offering("on-demand", zones[0], 0.6), fx.offering("on-demand", zones[1], 0.6), fx.offering("spot", zones[1], 0.2), fx.offering("spot", zones[2], 0.3)])
+    for its, pool in (([current, spot_repl], fx.node_pool()), ([current, od_repl], fx.node_pool(requirements=[fx.req(fx.CAPACITY_TYPE, "In", "on-demand")]))):
+        node = _node_with_pods("node-1", current, zones[0], "on-demand", ["1"])
+        cluster = {"instanceTypes": its, "nodePools": [pool], "nodes": [node], "pendingPods": []}
+        for solver in _solvers(oracle, emu):
+            cmd = dz.compute_consolidation(cluster, [node], solver)
+            assert len(cmd["results"]["newNodeClaims"]) == 1 and cmd["decision"] == dz.NOOP
+    # the same on-demand pool with a cheaper on-demand offering is replaced
+    od_cheap = fx.fake_instance_type("on-demand-replacement", {"cpu": "32", "memory": "64Gi", "pods": "100"}, offerings=[fx.offering("on-demand", zones[0], 0.4), fx.offering("spot", zones[1], 0.2)])
+    node = _node_with_pods("node-1", current, zones[0], "on-demand", ["1"])
+    cluster = {"instanceTypes": [current, od_cheap], "nodePools": [fx.node_pool(requirements=[fx.req(fx.CAPACITY_TYPE, "In", "on-demand")])], "nodes": [node], "pendingPods": []}
+    for solver in _solvers(oracle, emu):
+        cmd = dz.compute_consolidation(cluster, [node], solver)
+        assert cmd["decision"] == dz.REPLACE and cmd["replacement"] == ["on-demand-replacement"]
+
+
+def test_can_delete_nodes(oracle, emu):
+    """consolidation_test.go:2421-2460 (two pods on node 0, one on node 1: node 1 is deleted), :2539-2585 (capacity
+    Karpenter does not own can take the pods), :3442-3480 (no delete if a pod would go pending)."""
+    its = fx.fake_default_instance_types()
+    by = {t["name"]: t for t in its}
+    big = by["default-instance-type"]                                        # 4 cpu
+    n0 = _node_with_pods("node-0", big, "test-zone-1", "on-demand", ["1", "1"])
+    n1 = _node_with_pods("node-1", big, "test-zone-1", "on-demand", ["1"])
+    cluster = {"instanceTypes": its, "nodePools": [fx.node_pool()], "nodes": [n0, n1], "pendingPods": []}
+    for solver in _solvers(oracle, emu):
+        cands = dz.sort_candidates(cluster, cluster["nodes"])
+        assert [c["name"] for c in cands] == ["node-1", "node-0"]            # one pod is cheaper to disrupt than two
+        cmd = dz.single_node_consolidation(cluster, cands, solver)
+        assert cmd["decision"] == dz.DELETE and cmd["candidates"] == ["node-1"]
+        assert dz.validate_command(cluster, [n1], cmd, solver) is None
+    # an unmanaged node with room: the Karpenter node is deleted, its pods go there
+    from test_reference_known_answers import bare_node
+    foreign = bare_node("foreign", cpu="8")
+    foreign["pods"] = []
+    cluster = {"instanceTypes": its, "nodePools": [fx.node_pool()], "nodes": [n1, foreign], "pendingPods": []}
+    for solver in _solvers(oracle, emu):
+        cmd = dz.compute_consolidation(cluster, [n1], solver)
+        assert cmd["decision"] == dz.DELETE and [e["name"] for e in cmd["results"]["existingNodes"] if e["pods"]] == ["foreign"]
+    # a pod that fits nowhere else and no instance type is cheaper than the current one: nothing to do
+    small = by["small-instance-type"]
+    s0 = _node_with_pods("small-0", small, "test-zone-1", "spot", ["1500m"])
+    s1 = _node_with_pods("small-1", small, "test-zone-1", "spot", ["1500m"])
+    cluster = {"instanceTypes": its, "nodePools": [fx.node_pool()], "nodes": [s0, s1], "pendingPods": []}
+    for solver in _solvers(oracle, emu):
+        assert [c["decision"] for c in dz.sweep(cluster, [s0, s1], solver)] == [dz.NOOP, dz.NOOP]
+
+
+def test_wont_delete_onto_uninitialized_or_settling_nodes(oracle, emu):
+    """consolidation_test.go:3004-3048 (pods may not be counted on to land on an uninitialized node) and :3050-3119 (nor on
+    a node still inside its consolidateAfter window); :3121-3190 consolidateAfter=Never nodes do take them."""
+    its = fx.fake_default_instance_types()
+    big = {t["name"]: t for t in its}["default-instance-type"]
+    src = _node_with_pods("src", big, "test-zone-1", "on-demand", ["1"])
+    for kw, decision in (({"initialized": False}, dz.NOOP), ({"under_consolidate_after": True}, dz.NOOP), ({}, dz.DELETE)):
+        dst = _node_with_pods("dst", big, "test-zone-1", "on-demand", [], **kw)
+        cluster = {"instanceTypes": [big], "nodePools": [fx.node_pool()], "nodes": [src, dst], "pendingPods": []}
+        for solver in _solvers(oracle, emu):
+            assert dz.compute_consolidation(cluster, [src], solver)["decision"] == decision, kw
+
+
+def test_delete_with_a_permanently_pending_pod(oracle, emu):
+    """consolidation_test.go:3390-3440: a pending pod that can never schedule does not block the deletion of a node whose
+    own pods fit elsewhere (AllNonPendingPodsScheduled, scheduler.go:388-392)."""
+    its = fx.fake_default_instance_types()
+    big = {t["name"]: t for t in its}["default-instance-type"]
+    n0 = _node_with_pods("node-0", big, "test-zone-1", "on-demand", ["1", "1"])
+    n1 = _node_with_pods("node-1", big, "test-zone-1", "on-demand", ["1"])
+    stuck = fx.pod(requests={"cpu": "1"}, node_selector={"non-existent": "node-label"})
+    cluster = {"instanceTypes": its, "nodePools": [fx.node_pool()], "nodes": [n0, n1], "pendingPods": [stuck]}
+    for solver in _solvers(oracle, emu):
+        cmd = dz.compute_consolidation(cluster, [n1], solver)
+        assert cmd["decision"] == dz.DELETE and stuck["uid"] in cmd["results"]["podErrors"]
+
+
+def test_replace_keeps_zonal_spread(oracle, emu):
+    """consolidation_test.go:4525-4597: three oversized nodes, one per zone, one spread pod each. A node can be replaced
+    by a cheaper one, and the replacement is pinned to the zone the spread constraint leaves open — the candidate's own."""
+    its = fx.fake_default_instance_types()
+    by = {t["name"]: t for t in its}
+    lab = {"app": "test"}
+    tsc = [fx.spread(fx.ZONE, lab)]
+    nodes = []
+    for i, z in enumerate(("test-zone-1", "test-zone-2", "test-zone-3")):
+        pod = fx.pod(labels=lab, requests={"cpu": "1"}, topology_spread=tsc, phase="Running", node_name=f"node-{i}")
+        n = fx.state_node(f"node-{i}", by["arm-instance-type"], z, "on-demand", "default", used={"cpu": "15", "pods": "1"})   # no room for a second pod
+        n["pods"] = [pod]
+        nodes.append(n)
+    cluster = {"instanceTypes": its, "nodePools": [fx.node_pool()], "nodes": nodes, "pendingPods": []}
+    for solver in _solvers(oracle, emu):
+        cmd = dz.compute_consolidation(cluster, [nodes[1]], solver)
+        assert cmd["decision"] == dz.REPLACE and "arm-instance-type" not in cmd["replacement"]
+        zone = [q["values"] for q in cmd["results"]["newNodeClaims"][0]["requirements"] if q["key"] == fx.ZONE][0]
+        assert zone == ["test-zone-2"]
