@@ -229,3 +229,21 @@ def test_replace_keeps_zonal_spread(oracle, emu):
         assert cmd["decision"] == dz.REPLACE and "arm-instance-type" not in cmd["replacement"]
         zone = [q["values"] for q in cmd["results"]["newNodeClaims"][0]["requirements"] if q["key"] == fx.ZONE][0]
         assert zone == ["test-zone-2"]
+
+
+def test_merge_three_nodes_into_one(oracle, emu):
+    """consolidation_test.go:3982-4028: three nodes of the most expensive on-demand type with one small pod each are
+    replaced by a single cheaper node — the multi-node search ends on the whole prefix (multinodeconsolidation.go:117-207)."""
+    its = fx.fake_instance_types_assorted()
+    priciest, offering = max(((t, o) for t in its for o in t["offerings"] if dz._capacity_type(o) == "on-demand"), key=lambda x: x[1]["price"])
+    zone = [r["values"][0] for r in offering["requirements"] if r["key"] == fx.ZONE][0]
+    nodes = [_node_with_pods(f"node-{i}", priciest, zone, "on-demand", ["100m"]) for i in range(3)]
+    cluster = {"instanceTypes": its, "nodePools": [fx.node_pool()], "nodes": nodes, "pendingPods": []}
+    out = []
+    for solver in _solvers(oracle, emu):
+        cmd, probes = dz.first_n_consolidation_option(cluster, dz.sort_candidates(cluster, nodes), solver)
+        assert cmd["decision"] == dz.REPLACE and sorted(cmd["candidates"]) == ["node-0", "node-1", "node-2"]
+        assert [p[0] for p in probes] == [2, 3] and len(cmd["results"]["newNodeClaims"]) == 1
+        assert priciest["name"] not in cmd["replacement"] and cmd["replacement"]
+        out.append((cmd["replacement"], probes))
+    assert out[0] == out[1]
