@@ -163,3 +163,64 @@ def test_wide_fuzz(oracle, emu, block):
     insertion-sort regime of pdqsort)."""
     for seed in range(block * 10, block * 10 + 10):
         run_wide(oracle, emu, seed)
+
+
+def run_passes(oracle, emu, seed):
+    """Several provisioning passes on a growing cluster (fixtures.launch between them): every pass sees the nodes and the
+    bound pods of the passes before it, so countDomains, inverse anti-affinity groups of bound pods, node filters and
+    existing-node packing are exercised on states the solver itself produced. Also draws namespaces with labels,
+    namespaceSelector terms and hugepage capacity."""
+    rng = random.Random(10_000 + seed)
+    its = copy.deepcopy(fx.fake_default_instance_types() if rng.random() < 0.6 else fx.fake_instance_types(rng.choice([6, 12])))
+    if rng.random() < 0.3:
+        for it in rng.sample(its, max(1, len(its) // 3)):
+            it["capacity"]["hugepages-2Mi"] = rng.choice(["256Mi", "1Gi"])
+    namespaces = [{"name": "default", "labels": {"tier": "a"}}, {"name": "other", "labels": {"tier": "b"}}, {"name": "third", "labels": {}}]
+    pools = [fx.node_pool("pool-0")]
+    if rng.random() < 0.4:
+        pools.append(fx.node_pool("pool-1", weight=10, requirements=[fx.req(fx.ZONE, "In", *rng.sample(ZONES, 2))], taints=[{"key": "team", "value": "x", "effect": "NoSchedule"}]))
+    labels = [{"app": c} for c in "ab"]
+
+    def rand_pod():
+        kw = dict(labels=rng.choice(labels), namespace=rng.choice(["default", "default", "other"]),
+                  requests={"cpu": f"{rng.choice([100, 500, 1000, 2500])}m", "memory": f"{rng.choice([128, 1024, 2048])}Mi"})
+        sel = rng.choice(labels)
+        r = rng.random()
+        if r < 0.15: kw["topology_spread"] = [fx.spread(rng.choice([fx.ZONE, fx.HOSTNAME, fx.CAPACITY_TYPE]), sel, max_skew=rng.choice([1, 2]),
+                                                        taints_policy=rng.choice([None, "Honor"]), affinity_policy=rng.choice([None, "Ignore"]))]
+        elif r < 0.27:
+            nss = rng.choice([None, None, {"matchLabels": {}}, {"matchLabels": {"tier": "b"}}, {"matchLabels": {"tier": "zzz"}}])
+            kw["pod_requirements"] = [fx.affinity_term(rng.choice([fx.ZONE, fx.HOSTNAME]), sel, namespaces=rng.choice([None, ["other"]]), namespace_selector=nss)]
+        elif r < 0.37:
+            nss = rng.choice([None, None, {"matchLabels": {}}, {"matchLabels": {"tier": "a"}}])
+            kw["pod_anti_requirements"] = [fx.affinity_term(rng.choice([fx.ZONE, fx.HOSTNAME]), sel, namespace_selector=nss)]
+        elif r < 0.42: kw["pod_preferences"] = [fx.weighted(5, fx.affinity_term(fx.ZONE, sel))]
+        r = rng.random()
+        if r < 0.15: kw["node_selector"] = {fx.ZONE: rng.choice(ZONES)}
+        elif r < 0.22: kw["node_requirements"] = [fx.req(fx.CAPACITY_TYPE, "In", rng.choice(["spot", "on-demand"]))]
+        if rng.random() < 0.25: kw["tolerations"] = [{"key": "team", "operator": "Exists"}]
+        if rng.random() < 0.1: kw["requests"]["hugepages-2Mi"] = "128Mi"
+        return fx.pod(**kw)
+
+    nodes, bound, alias = [], [], 0
+    for pass_no in range(rng.choice([2, 3, 4])):
+        pods = [rand_pod() for _ in range(rng.randrange(3, 30))]
+        prob = fx.problem(its, pools, pods, state_nodes=nodes, cluster_pods=bound, namespaces=namespaces)
+        want = oracle.solve(prob)
+        try:
+            got = NewScheduler(prob, solver_lib=emu).Solve()
+        except Unsupported as e:
+            return ("unsupported", str(e)[:80])
+        parity.assert_same_results(got, want)
+        assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
+        alias += got["counters"]["topologyAliasClasses"]
+        nn, bb = fx.launch(want, its, pods, name_prefix=f"s{seed}p{pass_no}")
+        nodes += nn
+        bound += bb
+    return (len(nodes), len(bound), alias)
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_multi_pass_fuzz(oracle, emu, block):
+    for seed in range(block * 30, block * 30 + 30):
+        run_passes(oracle, emu, seed)
