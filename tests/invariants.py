@@ -1,0 +1,120 @@
+"""Invariants every Solve() result must satisfy whatever the algorithm — an independent sanity layer under the parity
+tests: parity says "device == oracle", the known answers say "oracle == reference on these scenarios", and these say "the
+answer is a valid packing" on every fuzzed problem. Only properties that hold in the reference by construction are
+checked (NodeClaim.CanAdd, nodeclaim.go:124-242; ExistingNode.CanAdd, existingnode.go:77-134):
+
+  * every pod is placed exactly once or carries an error, never both;
+  * every instance type option of a NodeClaim fits the claim's total requests (nodeclaim.go:541-600, before daemon overhead);
+  * NoSchedule / NoExecute taints of the claim's NodePool are tolerated by every pod on it (taints.go:83-95);
+  * a pod's nodeSelector is honoured: the claim's requirement on that key admits exactly that value;
+  * pods that repel each other on kubernetes.io/hostname (required anti-affinity, either direction) never share a bin.
+"""
+from decimal import Decimal
+import re
+
+from karpenter_amd import fixtures as fx
+
+_MULT = {"": 1, "n": Decimal("1e-9"), "u": Decimal("1e-6"), "m": Decimal("0.001"), "k": 10**3, "M": 10**6, "G": 10**9, "T": 10**12,
+         "Ki": 2**10, "Mi": 2**20, "Gi": 2**30, "Ti": 2**40}
+
+
+def _q(v):
+    m = re.fullmatch(r"(-?[0-9.]+)([a-zA-Z]*)", str(v))
+    return Decimal(m.group(1)) * _MULT[m.group(2)]
+
+
+def _tolerates(tol, taint):
+    """corev1.Toleration.ToleratesTaint."""
+    if tol.get("effect") and tol["effect"] != taint["effect"]:
+        return False
+    if tol.get("key") and tol["key"] != taint["key"]:
+        return False
+    op = tol.get("operator") or "Equal"
+    if op == "Exists":
+        return True
+    return tol.get("value", "") == taint.get("value", "")
+
+
+def _selector_matches(sel, labels):
+    if sel is None:
+        return False
+    for k, v in (sel.get("matchLabels") or {}).items():
+        if labels.get(k) != v:
+            return False
+    for e in sel.get("matchExpressions") or []:
+        has = e["key"] in labels
+        if e["operator"] == "In" and not (has and labels[e["key"]] in e["values"]):
+            return False
+        if e["operator"] == "NotIn" and has and labels[e["key"]] in e["values"]:
+            return False
+        if e["operator"] == "Exists" and not has:
+            return False
+        if e["operator"] == "DoesNotExist" and has:
+            return False
+    return True
+
+
+def _repels(p, q):
+    """p has a required hostname anti-affinity term that selects q (own namespace unless the term names others)."""
+    for t in (p.get("podAntiAffinity") or {}).get("required", []):
+        if t["topologyKey"] != fx.HOSTNAME or t.get("namespaceSelector") is not None:
+            continue
+        nss = t.get("namespaces") or [p.get("namespace", "default")]
+        if q.get("namespace", "default") in nss and _selector_matches(t.get("labelSelector"), q.get("labels", {})):
+            return True
+    return False
+
+
+def check(problem, res):
+    pods = {p["uid"]: p for p in problem["pods"]}
+    if problem.get("podGroups"):
+        return  # group pods have generated uids; the explicit-pod problems are what the fuzzers produce
+    pools = {np_["name"]: np_ for np_ in problem["nodePools"]}
+    its = {t["name"]: t for t in problem["instanceTypes"]}
+    placed = {}
+    for c in res["newNodeClaims"]:
+        for u in c["pods"]:
+            assert u not in placed, f"pod {u} placed twice"
+            placed[u] = c["hostname"]
+    for e in res.get("existingNodes", []):
+        for u in e["pods"]:
+            assert u not in placed, f"pod {u} placed twice"
+            placed[u] = e["name"]
+    assert not (set(placed) & set(res["podErrors"])), "a pod is both placed and in error"
+    assert set(placed) | set(res["podErrors"]) == set(pods) or res.get("timedOut"), "a pod is neither placed nor in error"
+
+    for c in res["newNodeClaims"]:
+        members = [pods[u] for u in c["pods"]]
+        total = {}
+        for p in members:
+            for k, v in p["requests"].items():
+                total[k] = total.get(k, Decimal(0)) + _q(v)
+        total["pods"] = total.get("pods", Decimal(0)) + len(members)
+        assert c["instanceTypes"], "a NodeClaim without instance type options"
+        for name in c["instanceTypes"]:
+            it = its[name]
+            for k, need in total.items():
+                alloc = _q(it["capacity"].get(k, "0")) - _q(it["overhead"].get(k, "0"))
+                if k == "memory":
+                    for hk, hv in it["capacity"].items():
+                        if hk.startswith("hugepages-"):
+                            alloc = max(Decimal(0), alloc - _q(hv))
+                assert need <= alloc, f"claim {c['hostname']}: {need} {k} does not fit {name} ({alloc})"
+        pool = pools[c["nodePool"]]
+        for t in pool.get("taints", []):
+            if t["effect"] in ("NoSchedule", "NoExecute"):
+                for p in members:
+                    assert any(_tolerates(tol, t) for tol in p.get("tolerations", [])), f"pod {p['uid']} does not tolerate {t} of {pool['name']}"
+        reqs = {q["key"]: q for q in c["requirements"]}
+        for p in members:
+            for k, v in (p.get("nodeSelector") or {}).items():
+                q = reqs.get(k)
+                assert q is not None and not q["complement"] and q["values"] == [v], f"nodeSelector {k}={v} of {p['uid']} not pinned on {c['hostname']}: {q}"
+
+    by_bin = {}
+    for u, b in placed.items():
+        by_bin.setdefault(b, []).append(pods[u])
+    for b, members in by_bin.items():
+        for i, p in enumerate(members):
+            for q in members[i + 1:]:
+                assert not _repels(p, q) and not _repels(q, p), f"{p['uid']} and {q['uid']} repel each other but share {b}"

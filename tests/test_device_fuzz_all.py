@@ -7,6 +7,7 @@ import random
 
 import pytest
 
+import invariants
 import parity
 from karpenter_amd import fixtures as fx
 from karpenter_amd.scheduling import NewScheduler, Unsupported
@@ -76,6 +77,7 @@ def run(oracle, emu, seed):
                 cluster.append(rand_pod(phase="Running", node_name=f"node-{i}"))
     prob = fx.problem(its, pools, pods, state_nodes=nodes, cluster_pods=cluster, daemonset_pods=daemons, options=opts)
     want = oracle.solve(prob)
+    invariants.check(prob, want)
     try:
         got = NewScheduler(prob, solver_lib=emu).Solve()
     except Unsupported as e:
@@ -147,6 +149,7 @@ def run_wide(oracle, emu, seed):
         pods.append(fx.pod(**kw))
     prob = fx.problem(its, pools, pods, well_known=wk, options=opts)
     want = oracle.solve(prob)
+    invariants.check(prob, want)
     try:
         got = NewScheduler(prob, solver_lib=emu).Solve()
     except Unsupported as e:
@@ -207,6 +210,7 @@ def run_passes(oracle, emu, seed):
         pods = [rand_pod() for _ in range(rng.randrange(3, 30))]
         prob = fx.problem(its, pools, pods, state_nodes=nodes, cluster_pods=bound, namespaces=namespaces)
         want = oracle.solve(prob)
+        invariants.check(prob, want)
         try:
             got = NewScheduler(prob, solver_lib=emu).Solve()
         except Unsupported as e:

@@ -1,0 +1,59 @@
+"""The invariant checker used by the fuzzers must itself notice broken packings."""
+import copy
+
+import pytest
+
+import invariants
+from karpenter_amd import fixtures as fx
+
+
+def _solved(oracle):
+    lab = {"app": "x"}
+    pods = [fx.pod(labels=lab, requests={"cpu": "100m"}, pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, lab)]) for _ in range(2)]
+    pods += [fx.pod(requests={"cpu": "500m"}, node_selector={fx.ZONE: "test-zone-2"}), fx.pod(requests={"cpu": "64"})]
+    pool = fx.node_pool(taints=[{"key": "team", "value": "a", "effect": "NoSchedule"}])
+    for p in pods:
+        p["tolerations"] = [{"key": "team", "operator": "Exists", "value": "", "effect": ""}]
+    prob = fx.problem(fx.fake_default_instance_types(), [pool], pods)
+    return prob, oracle.solve(prob)
+
+
+def test_valid_result_passes_and_corruptions_are_caught(oracle):
+    prob, res = _solved(oracle)
+    invariants.check(prob, res)
+    assert len(res["podErrors"]) == 1 and len(res["newNodeClaims"]) == 2
+
+    bad = copy.deepcopy(res)                       # both repelling pods on one claim
+    a, b = [c for c in bad["newNodeClaims"] if prob["pods"][0]["uid"] in c["pods"] or prob["pods"][1]["uid"] in c["pods"]]
+    a["pods"] += b["pods"]; b["pods"] = []
+    a["instanceTypes"] = ["default-instance-type"]; a["requirements"] = a["requirements"] + [q for q in b["requirements"] if q["key"] == fx.ZONE and not any(x["key"] == fx.ZONE for x in a["requirements"])]
+    with pytest.raises(AssertionError, match="repel"):
+        invariants.check(prob, bad)
+
+    bad = copy.deepcopy(res)                       # a pod reported twice
+    bad["newNodeClaims"][0]["pods"].append(bad["newNodeClaims"][1]["pods"][0])
+    with pytest.raises(AssertionError, match="placed twice"):
+        invariants.check(prob, bad)
+
+    bad = copy.deepcopy(res)                       # the pod that fits nowhere "placed" on a small claim
+    uid = next(iter(bad["podErrors"]))
+    del bad["podErrors"][uid]
+    bad["newNodeClaims"][0]["pods"].append(uid)
+    with pytest.raises(AssertionError, match="does not fit"):
+        invariants.check(prob, bad)
+
+    bad = copy.deepcopy(res)                       # zone selector dropped from the claim
+    c = next(c for c in bad["newNodeClaims"] if prob["pods"][2]["uid"] in c["pods"])
+    c["requirements"] = [q for q in c["requirements"] if q["key"] != fx.ZONE]
+    with pytest.raises(AssertionError, match="nodeSelector"):
+        invariants.check(prob, bad)
+
+    noprob = copy.deepcopy(prob)                   # a pod that does not tolerate the pool's taint
+    noprob["pods"][2]["tolerations"] = []
+    with pytest.raises(AssertionError, match="does not tolerate"):
+        invariants.check(noprob, res)
+
+    bad = copy.deepcopy(res)                       # a pod that vanished
+    bad["newNodeClaims"][0]["pods"].pop()
+    with pytest.raises(AssertionError):
+        invariants.check(prob, bad)
