@@ -1,0 +1,120 @@
+"""Pinning the oracle to the real Go Solve().
+
+go/golden_dump_test.go, run inside the reference's tree on a machine with Go, writes what the reference did for its own
+benchmark shapes; drop those files into tests/golden/go_dump/ and `test_oracle_matches_the_reference_dumps` compares the
+oracle with them NodeClaim by NodeClaim. There is no Go toolchain in this repository's image, so no dump is committed and
+that test skips; what runs here proves the converter and the comparison: the problem format survives a round trip through
+the Kubernetes wire shapes, and an oracle result written out in the dump's shape compares equal to itself and unequal
+when perturbed."""
+import copy
+import glob
+import json
+import os
+import random
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import from_go  # noqa: E402
+
+from karpenter_amd import fixtures as fx  # noqa: E402
+
+DUMP_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "go_dump")
+
+
+selector_form = from_go.selector_form
+
+
+def compare(got, expected):
+    """L1-strict: same NodeClaims in the same order, pods in commit order, instance type options in order, requirements,
+    requests; same set of unschedulable pods."""
+    assert len(got["newNodeClaims"]) == len(expected["newNodeClaims"])
+    for i, (g, e) in enumerate(zip(got["newNodeClaims"], expected["newNodeClaims"])):
+        assert g["nodePool"] == e["nodePool"], i
+        assert g["pods"] == e["pods"], (i, "pods")
+        assert g["instanceTypes"] == e["instanceTypes"], (i, "instance types")
+        greqs = sorted(x for q in g["requirements"] for x in selector_form(q))
+        ereqs = sorted((q["key"], q["operator"], tuple(sorted(q["values"]))) for q in e["requirements"])
+        assert greqs == ereqs, (i, "requirements", greqs, ereqs)
+        gq = {k: int(v) for k, v in g["requests"].items() if int(v)}
+        eq = {k: int(from_go._q(v) * 10**9) for k, v in e["requests"].items() if from_go._q(v)}
+        assert gq == eq, (i, "requests", gq, eq)
+    assert set(got["podErrors"]) == set(expected["podErrors"])
+
+
+def _random_problem(seed):
+    rng = random.Random(seed)
+    lab = [{"app": c} for c in "ab"]
+    zones = ["test-zone-1", "test-zone-2", "test-zone-3"]
+    pods = []
+    for i in range(rng.randrange(5, 40)):
+        kw = dict(labels=rng.choice(lab), requests={"cpu": f"{rng.choice([100, 500, 1500])}m", "memory": f"{rng.choice([128, 1024])}Mi"}, creation=1700000000 + i)
+        sel = rng.choice(lab)
+        r = rng.random()
+        if r < 0.2: kw["topology_spread"] = [fx.spread(rng.choice([fx.ZONE, fx.HOSTNAME]), sel, max_skew=rng.choice([1, 2]), min_domains=rng.choice([None, 2]))]
+        elif r < 0.35: kw["pod_requirements"] = [fx.affinity_term(fx.ZONE, sel, namespaces=rng.choice([None, ["default"]]))]
+        elif r < 0.5: kw["pod_anti_requirements"] = [fx.affinity_term(fx.HOSTNAME, sel)]
+        elif r < 0.6: kw["pod_anti_preferences"] = [fx.weighted(3, fx.affinity_term(fx.ZONE, sel))]
+        r = rng.random()
+        if r < 0.2: kw["node_selector"] = {fx.ZONE: rng.choice(zones)}
+        elif r < 0.35: kw["node_requirements"] = [[fx.req(fx.ZONE, "In", "nowhere")], [fx.req(fx.ARCH, "NotIn", "arm64")]]
+        elif r < 0.5: kw["node_preferences"] = [fx.req(fx.CAPACITY_TYPE, "In", "spot")]
+        if rng.random() < 0.3: kw["tolerations"] = [{"key": "team", "operator": "Exists"}]
+        pods.append(fx.pod(**kw))
+    pools = [fx.node_pool("pool-a", weight=rng.choice([0, 10]), limits={"cpu": "1000"}, labels={"team": "a"}, requirements=[fx.req(fx.FAKE_INTEGER_LABEL, "Gt", "1")])]
+    if rng.random() < 0.5:
+        pools.append(fx.node_pool("pool-b", taints=[{"key": "team", "value": "b", "effect": "NoSchedule"}], requirements=[fx.req(fx.INSTANCE_TYPE, "Exists", min_values=2)]))
+    return fx.problem(fx.fake_default_instance_types(), pools, pods, options={"preferencePolicy": rng.choice(["Respect", "Ignore"])})
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_round_trip_through_the_kubernetes_wire_shapes(oracle, seed):
+    prob = _random_problem(seed)
+    want = oracle.solve(prob)
+    back, expected = from_go.from_go(json.loads(json.dumps(from_go.to_go(prob, want))))
+    # the converted problem is the same scheduling problem: the oracle gives the same answer on it ...
+    got = oracle.solve(back)
+    compare(got, expected)
+    assert [c["pods"] for c in got["newNodeClaims"]] == [c["pods"] for c in want["newNodeClaims"]]
+    # ... and field by field the pods, pools and instance types survive (modulo defaults the format leaves implicit)
+    for a, b in zip(prob["pods"], back["pods"]):
+        for k in ("uid", "namespace", "labels", "nodeSelector", "nodeAffinity", "tolerations", "creationTimestamp"):
+            assert a.get(k) == b.get(k), (k, a.get(k), b.get(k))
+        assert {k: from_go._q(v) for k, v in a["requests"].items()} == {k: from_go._q(v) for k, v in b["requests"].items()}
+    assert [n["name"] for n in prob["nodePools"]] == [n["name"] for n in back["nodePools"]]
+    assert prob["instanceTypes"] == back["instanceTypes"]
+
+
+def test_comparison_notices_differences(oracle):
+    prob = _random_problem(3)
+    want = oracle.solve(prob)
+    _, expected = from_go.from_go(json.loads(json.dumps(from_go.to_go(prob, want))))
+    compare(want, expected)
+    assert want["newNodeClaims"], "the sample problem must produce NodeClaims"
+    for mutate in (lambda e: e["newNodeClaims"][0]["pods"].reverse() if len(e["newNodeClaims"][0]["pods"]) > 1 else e["newNodeClaims"][0]["pods"].append("x"),
+                   lambda e: e["newNodeClaims"][0]["instanceTypes"].pop(),
+                   lambda e: e["newNodeClaims"][0]["requirements"].pop(),
+                   lambda e: e["newNodeClaims"][0]["requests"].update(cpu="123"),
+                   lambda e: e["podErrors"].update(ghost="error")):
+        bad = copy.deepcopy(expected)
+        mutate(bad)
+        with pytest.raises(AssertionError):
+            compare(want, bad)
+
+
+def test_pod_requests_follow_the_resource_helper():
+    spec = {"containers": [{"resources": {"requests": {"cpu": "500m", "memory": "1Gi"}}}, {"resources": {"limits": {"cpu": "1"}, "requests": {"memory": "512Mi"}}}],
+            "initContainers": [{"resources": {"requests": {"cpu": "2", "memory": "256Mi"}}}], "overhead": {"cpu": "100m"}}
+    got = {k: from_go._q(v) for k, v in from_go.pod_requests(spec).items()}
+    assert got == {"cpu": from_go._q("2100m"), "memory": from_go._q("1536Mi")}
+
+
+DUMPS = sorted(glob.glob(os.path.join(DUMP_DIR, "*.json")))
+
+
+@pytest.mark.skipif(not DUMPS, reason="no dumps of the Go reference under tests/golden/go_dump (needs a Go toolchain: go/golden_dump_test.go)")
+@pytest.mark.parametrize("path", DUMPS or ["none"], ids=[os.path.basename(p) for p in DUMPS] or ["none"])
+def test_oracle_matches_the_reference_dumps(oracle, path):
+    problem, expected = from_go.from_go(json.load(open(path)))
+    compare(oracle.solve(problem), expected)
