@@ -18,7 +18,10 @@ import pytest
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 import from_go  # noqa: E402
 
+import parity  # noqa: E402
 from karpenter_amd import fixtures as fx  # noqa: E402
+from karpenter_amd.scheduling import NewScheduler  # noqa: E402
+from test_device_algorithm import emu  # noqa: E402,F401  (fixture)
 
 DUMP_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "go_dump")
 
@@ -69,13 +72,14 @@ def _random_problem(seed):
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_round_trip_through_the_kubernetes_wire_shapes(oracle, seed):
+def test_round_trip_through_the_kubernetes_wire_shapes(oracle, emu, seed):
     prob = _random_problem(seed)
     want = oracle.solve(prob)
     back, expected = from_go.from_go(json.loads(json.dumps(from_go.to_go(prob, want))))
     # the converted problem is the same scheduling problem: the oracle gives the same answer on it ...
     got = oracle.solve(back)
     compare(got, expected)
+    parity.assert_same_results(NewScheduler(back, solver_lib=emu).Solve(), got)     # the device algorithm takes converted problems too
     assert [c["pods"] for c in got["newNodeClaims"]] == [c["pods"] for c in want["newNodeClaims"]]
     # ... and field by field the pods, pools and instance types survive (modulo defaults the format leaves implicit)
     for a, b in zip(prob["pods"], back["pods"]):
@@ -115,6 +119,8 @@ DUMPS = sorted(glob.glob(os.path.join(DUMP_DIR, "*.json")))
 
 @pytest.mark.skipif(not DUMPS, reason="no dumps of the Go reference under tests/golden/go_dump (needs a Go toolchain: go/golden_dump_test.go)")
 @pytest.mark.parametrize("path", DUMPS or ["none"], ids=[os.path.basename(p) for p in DUMPS] or ["none"])
-def test_oracle_matches_the_reference_dumps(oracle, path):
+def test_oracle_matches_the_reference_dumps(oracle, emu, path):
     problem, expected = from_go.from_go(json.load(open(path)))
-    compare(oracle.solve(problem), expected)
+    got = oracle.solve(problem)
+    compare(got, expected)
+    parity.assert_same_results(NewScheduler(problem, solver_lib=emu).Solve(), got)
