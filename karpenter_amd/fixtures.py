@@ -165,7 +165,8 @@ def kwok_instance_types(cpus=(1, 2, 4, 8, 16, 32, 48, 64, 96, 128, 192, 256), me
                     name = f"{family}-{cpu}x-{arch}-{os_}" if mf in (2, 4, 8) else f"e{mf}-{cpu}x-{arch}-{os_}"
                     mem = cpu * mf
                     pods = max(0, min(cpu * 16, 1024))
-                    res = {"cpu": str(cpu), "memory": f"{mem}Gi", "pods": str(pods), "ephemeral-storage": "20Gi"}
+                    mem_q = f"{mem // 1024}Ti" if mem % 1024 == 0 else f"{mem}Gi"      # resource.Quantity's canonical form (1024Gi prints as 1Ti)
+                    res = {"cpu": str(cpu), "memory": mem_q, "pods": str(pods), "ephemeral-storage": "20Gi"}
                     price = 0.025 * cpu + 0.001 * (mem * 2.0**30) / 1e9
                     offs = []
                     for z in zones:
@@ -174,7 +175,7 @@ def kwok_instance_types(cpus=(1, 2, 4, 8, 16, 32, 48, 64, 96, 128, 192, 256), me
                     fam = re.split(r"[.-]", name, maxsplit=1)[0]
                     reqs = [req(INSTANCE_TYPE, "In", name), req(ARCH, "In", arch), req(OS, "In", os_), req(ZONE, "In", *zones),
                             req(CAPACITY_TYPE, "In", "spot", "on-demand"), req(KWOK_SIZE, "In", str(cpu)), req(KWOK_FAMILY, "In", fam),
-                            req(KWOK_CPU, "In", str(cpu)), req(KWOK_MEMORY, "In", f"{mem}Gi")]
+                            req(KWOK_CPU, "In", str(cpu)), req(KWOK_MEMORY, "In", mem_q)]
                     out.append({"name": name, "requirements": reqs, "capacity": res, "overhead": {"cpu": "100m", "memory": "10Mi"}, "offerings": offs})
                     if limit and len(out) >= limit:
                         return out

@@ -122,5 +122,27 @@ def main():
         len(out["intersection"]), len(out["has"]), len(out["operator"]), len(out["len"]), len(loose), len(strict)))
 
 
+def kwok_catalogue():
+    """The KWOK provider's stock catalogue (kwok/cloudprovider/instance_types.json, embedded by helpers.go:67-68 and turned
+    into cloudprovider.InstanceTypes by ConstructInstanceTypes, :70-95): a digest fixtures.kwok_instance_types() must
+    reproduce exactly — names, resources, architecture, operating systems and every offering's capacity type, zone and
+    price (bit-exact floats)."""
+    root = os.path.dirname(os.path.dirname(REF))
+    path = os.path.join(root, "kwok", "cloudprovider", "instance_types.json")
+    raw = json.load(open(path))
+    out = []
+    for t in raw:
+        offs = []
+        for o in t["offerings"]:
+            r = {q["key"]: q["values"][0] for q in o["Requirements"]}
+            offs.append([r["karpenter.sh/capacity-type"], r["topology.kubernetes.io/zone"], o["Price"]])
+        out.append({"name": t["name"], "architecture": t["architecture"], "operatingSystems": t["operatingSystems"], "resources": t["resources"], "offerings": offs})
+    json.dump({"source": "kwok/cloudprovider/instance_types.json", "instanceTypes": out}, open(os.path.join(OUT, "kwok_instance_types.json"), "w"), separators=(",", ":"))
+    print("kwok catalogue:", len(out), "instance types")
+
+
+
+
 if __name__ == "__main__":
     main()
+    kwok_catalogue()
