@@ -3,6 +3,7 @@ for the host (tests/emu/ksolve_emu.cpp, test infrastructure only) and driven thr
 flattener (karpenter_amd/libksched.so), compared with the oracle claim by claim (L1-strict: same claims in the same
 order with the same pod identities, instance types, requirements and requests). The GPU run of the same comparisons
 is tests/test_gpu_parity.py."""
+import copy
 import ctypes
 import random
 
@@ -554,3 +555,49 @@ def test_cancel_from_another_thread(oracle, emu):
     assert landed and max(landed) > 0, f"no cancel landed inside the pack loop: {landed}"
     again = s.Solve(want_results=False)
     assert not again["timedOut"] and again["scheduledPods"] == n
+
+
+def test_malformed_problems_are_rejected_not_crashed(emu):
+    """The flattener and ksolve_create validate what they are given: a problem document with fields removed, nulled or
+    replaced by garbage either still solves, or is refused as invalid / unsupported — it never takes the process down
+    (a segfault here would kill this test run)."""
+    lab = {"app": "a"}
+    its = fx.fake_default_instance_types()
+    pods = [fx.pod(labels=lab, requests={"cpu": "500m", "memory": "128Mi"}, topology_spread=[fx.spread(fx.ZONE, lab)], tolerations=[{"key": "k", "operator": "Exists"}],
+                   node_requirements=[[fx.req(fx.ZONE, "In", "test-zone-1")], [fx.req(fx.ARCH, "In", "amd64")]],
+                   pod_anti_preferences=[fx.weighted(2, fx.affinity_term(fx.HOSTNAME, lab))]) for _ in range(3)]
+    base = fx.problem(its, [fx.node_pool(limits={"cpu": "100"}, taints=[{"key": "k", "value": "v", "effect": "NoSchedule"}])], pods,
+                      state_nodes=[fx.state_node("n1", its[0], "test-zone-1")], cluster_pods=[fx.pod(labels=lab, phase="Running", node_name="n1")],
+                      daemonset_pods=[fx.pod(requests={"cpu": "100m"})], options={"reservedCapacity": True})
+
+    def paths(obj, prefix=()):
+        out = []
+        items = obj.items() if isinstance(obj, dict) else enumerate(obj[:6]) if isinstance(obj, list) else ()
+        for k, v in items:
+            out.append(prefix + (k,))
+            out += paths(v, prefix + (k,))
+        return out
+
+    outcomes = {"solved": 0, "refused": 0}
+    for seed in range(200):
+        rng = random.Random(seed)
+        bad = copy.deepcopy(base)
+        for _ in range(rng.randrange(1, 4)):
+            path = rng.choice(paths(bad))
+            cur = bad
+            try:
+                for k in path[:-1]:
+                    cur = cur[k]
+                r = rng.random()
+                if r < 0.3:
+                    cur.pop(path[-1])
+                else:
+                    cur[path[-1]] = rng.choice([None, "garbage", -1, [], {}, 1e308, "9" * 40])
+            except (KeyError, IndexError, TypeError):
+                pass
+        try:
+            NewScheduler(bad, solver_lib=emu).Solve()
+            outcomes["solved"] += 1
+        except (Unsupported, RuntimeError):
+            outcomes["refused"] += 1
+    assert outcomes["solved"] and outcomes["refused"]
