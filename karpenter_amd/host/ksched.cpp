@@ -506,6 +506,8 @@ static char* error_json(const char* kind, const std::string& msg) {
 extern "C" void ksched_free(char* p) { free(p); }
 
 // A problem flattened and resident on the device: what NewScheduler returns.
+constexpr long long kMaxPodsPerProblem = 1ll << 24;
+
 struct Session {
   Api api;
   ksolve_handle* handle = nullptr;
@@ -665,6 +667,9 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       int si = (int)specs.size() - 1;
       uint64_t seed = (uint64_t)g.at("uidSeed").i(0);
       long long cnt = g.at("count").i(0);
+      if (cnt < 0) throw std::runtime_error("podGroups[].count is negative");
+      // one Solve() of the reference handles a batch of pending pods; 16M pods is 16x the largest BASELINE configuration
+      if (cnt > kMaxPodsPerProblem || (long long)pod_spec.size() + cnt > kMaxPodsPerProblem) throw Unsupported("more than 16777216 pods in one problem");
       for (long long i = 0; i < cnt; ++i) {
         uint64_t hi, lo;
         group_uid(seed, (uint64_t)i, hi, lo, nullptr);
@@ -809,6 +814,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       for (auto& kv : m) {
         if (kv.first == "nodes") continue;
         int r = (int)(std::find(res_names.begin(), res_names.end(), kv.first) - res_names.begin());
+        if (r >= n_res) continue;   // a key only the overhead names: resources.Subtract keeps capacity's keys (resources.go:83-97)
         i128 v = kv.second < 0 ? -kv.second : kv.second;
         if (v) scale[r] = gcd128(scale[r], v);
       }

@@ -601,3 +601,22 @@ def test_malformed_problems_are_rejected_not_crashed(emu):
         except (Unsupported, RuntimeError):
             outcomes["refused"] += 1
     assert outcomes["solved"] and outcomes["refused"]
+
+
+def test_hostile_sizes_and_stray_resources(oracle, emu):
+    # an overhead entry for a resource the capacity does not have is ignored (resources.Subtract keeps capacity's keys)
+    its = fx.fake_default_instance_types()
+    its[3]["overhead"] = {"example.com/widget": 1}
+    check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod() for _ in range(3)]))
+    # pod group counts: negative is invalid, absurd is refused before anything is allocated
+    prob = fx.config2(pods=1000)
+    prob["podGroups"][0]["count"] = -5
+    with pytest.raises(RuntimeError, match="negative"):
+        NewScheduler(prob, solver_lib=emu)
+    prob["podGroups"][0]["count"] = 10**12
+    with pytest.raises(Unsupported, match="pods in one problem"):
+        NewScheduler(prob, solver_lib=emu)
+    # out-of-range options fall back to their defaults
+    prob = fx.config2(pods=1000)
+    prob["options"].update({"maxClaims": -3, "ldsClaimCap": 10**9, "truncateInstanceTypes": -2})
+    assert NewScheduler(prob, solver_lib=emu).Solve(want_results=False)["scheduledPods"] == 1000
