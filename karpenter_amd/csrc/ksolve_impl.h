@@ -367,7 +367,9 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   P.lay = lay;
   W.c_hot = dz<uint64_t>(h, (size_t)mc * lay.c_hot_words());
   W.c_cold = dz<uint64_t>(h, (size_t)mc * lay.cold_words());
-  W.c_headroom = dz<int64_t>(h, (size_t)mc * d->n_res);
+  // + 64: the headroom prefilter reads one lane per claim of a 64-claim word; when max_claims is not a multiple of 64
+  // the lanes past the last claim of the last dimension's row read (and discard) up to 63 entries beyond it
+  W.c_headroom = dz<int64_t>(h, (size_t)mc * d->n_res + 64);
   W.c_reserved = dz<uint64_t>(h, mc);
   W.o_key = dz<uint32_t>(h, mc); W.o_ord = dz<uint32_t>(h, mc); W.o_pos = dz<uint32_t>(h, mc);
   W.queue = dz<uint32_t>(h, (size_t)d->n_pods + 1); W.last_len = dz<uint32_t>(h, d->n_pods);
