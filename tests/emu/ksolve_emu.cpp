@@ -6,6 +6,7 @@
 // It is built only by tests/ (into tests/emu/), is never built by __graft_entry__.build() as part of the product, and
 // the product's Python host (karpenter_amd/scheduling.py) refuses to load it unless a test passes it explicitly.
 #define KSOLVE_HOST_EMULATION 1
+#include <algorithm>
 #include "../../karpenter_amd/csrc/ksolve_impl.h"
 
 struct EmuBackend { std::chrono::steady_clock::time_point t0[8]; };
@@ -46,13 +47,45 @@ static void be_sort_pods(ksolve_handle* h) {
   }
   h->pv.sorted_pods = idx;
 }
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/asan_interface.h>
+// AddressSanitizer build (scripts/asan_check.sh): the LDS segment is one allocation, so an overflow from one LDS table
+// into the next would go unnoticed — spread the tables apart and poison the gaps.
+static ks::LdsPlan guarded_plan(const ks::LdsPlan& in, std::vector<std::pair<int, int>>& gaps) {
+  ks::LdsPlan p = in;
+  int* offs[] = {&p.off_alloc, &p.off_avail, &p.off_kv, &p.off_keymask, &p.off_allocok, &p.off_kvslot, &p.off_tmpl, &p.off_tmplcold, &p.off_order,
+                 &p.off_closed, &p.off_stage, &p.off_cache, &p.off_scratch, &p.off_dgov, &p.off_dgits};
+  std::vector<int> starts;
+  for (int* o : offs) starts.push_back(*o);
+  std::sort(starts.begin(), starts.end());
+  starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
+  const int pad = 64;
+  for (int* o : offs) { int rank = (int)(std::lower_bound(starts.begin(), starts.end(), *o) - starts.begin()); *o += pad * rank; }
+  for (size_t i = 1; i < starts.size(); ++i) gaps.push_back({starts[i] + pad * (int)(i - 1), pad});   // the gap sits right before region i
+  p.total_bytes = in.total_bytes + pad * (int)starts.size();
+  gaps.push_back({p.total_bytes - pad, pad});
+  return p;
+}
+#endif
 static void be_launch_pack(ksolve_handle* h) {
-  std::vector<char> lds((size_t)h->pv.lds.total_bytes + 64);  // stands in for the CU's LDS segment
+#if defined(__SANITIZE_ADDRESS__)
+  std::vector<std::pair<int, int>> gaps;
+  ks::ProblemView pv = h->pv;
+  pv.lds = guarded_plan(h->pv.lds, gaps);
+  std::vector<char> lds((size_t)pv.lds.total_bytes + 64);
+  for (auto& g : gaps) __asan_poison_memory_region(lds.data() + g.first, (size_t)g.second);
+#else
+  const ks::ProblemView& pv = h->pv;
+  std::vector<char> lds((size_t)pv.lds.total_bytes + 64);  // stands in for the CU's LDS segment
+#endif
   ks::LdsTables tables;
-  tables.bind(lds.data(), h->pv.lds);
-  if (h->pv.big) { ks::Engine<ks::Wave, true, true> eng(h->pv, h->ws, tables); eng.solve(); }
-  else if (h->pv.lite) { ks::Engine<ks::Wave, false> eng(h->pv, h->ws, tables); eng.solve(); }
-  else { ks::Engine<ks::Wave, true> eng(h->pv, h->ws, tables); eng.solve(); }
+  tables.bind(lds.data(), pv.lds);
+  if (pv.big) { ks::Engine<ks::Wave, true, true> eng(pv, h->ws, tables); eng.solve(); }
+  else if (pv.lite) { ks::Engine<ks::Wave, false> eng(pv, h->ws, tables); eng.solve(); }
+  else { ks::Engine<ks::Wave, true> eng(pv, h->ws, tables); eng.solve(); }
+#if defined(__SANITIZE_ADDRESS__)
+  for (auto& g : gaps) __asan_unpoison_memory_region(lds.data() + g.first, (size_t)g.second);
+#endif
 }
 static void be_launch_pack_batch(ksolve_handle** hs, int n) {
   for (int i = 0; i < n; ++i) { be_tic(hs[i], ksi::T_PACK); be_launch_pack(hs[i]); be_toc(hs[i], ksi::T_PACK); }
