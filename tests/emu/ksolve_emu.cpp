@@ -72,11 +72,13 @@ static void be_launch_pack(ksolve_handle* h) {
   std::vector<std::pair<int, int>> gaps;
   ks::ProblemView pv = h->pv;
   pv.lds = guarded_plan(h->pv.lds, gaps);
-  std::vector<char> lds((size_t)pv.lds.total_bytes + 64);
+  std::vector<char> lds((size_t)pv.lds.total_bytes + 64, (char)0xA5);   // LDS is not zeroed at kernel start on the device either
   for (auto& g : gaps) __asan_poison_memory_region(lds.data() + g.first, (size_t)g.second);
 #else
   const ks::ProblemView& pv = h->pv;
-  std::vector<char> lds((size_t)pv.lds.total_bytes + 64);  // stands in for the CU's LDS segment
+  // stands in for the CU's LDS segment; filled with garbage because the device does not zero LDS at kernel start: an
+  // engine that relied on zeroed LDS would pass here and fail on the GPU
+  std::vector<char> lds((size_t)pv.lds.total_bytes + 64, (char)0xA5);
 #endif
   ks::LdsTables tables;
   tables.bind(lds.data(), pv.lds);
