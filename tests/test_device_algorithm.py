@@ -620,3 +620,29 @@ def test_hostile_sizes_and_stray_resources(oracle, emu):
     prob = fx.config2(pods=1000)
     prob["options"].update({"maxClaims": -3, "ldsClaimCap": 10**9, "truncateInstanceTypes": -2})
     assert NewScheduler(prob, solver_lib=emu).Solve(want_results=False)["scheduledPods"] == 1000
+
+
+def test_repeated_solves_on_one_handle_are_identical(oracle, emu):
+    """A handle is reused for every Solve() of a scheduler (bench.py re-solves the resident inputs): whatever one solve
+    leaves in the workspace — claims, dead rows, topology counters, reservation counters, the claim order, a cancelled
+    run's partial state — the next solve must start from scratch."""
+    its = reserved_types(2)
+    lab = {"app": "x"}
+    nodes = [fx.state_node(f"node-{i}", its[0], "test-zone-1", used={"cpu": "1", "pods": "1"}) for i in range(2)]
+    cluster = [fx.pod(labels=lab, phase="Running", node_name="node-0", pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, lab)])]
+    pods = [fx.pod(labels=lab, requests={"cpu": "700m"}, topology_spread=[fx.spread(fx.ZONE, lab)]) for _ in range(25)]
+    pods += [fx.pod(labels=lab, requests={"cpu": "300m"}, pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, lab)]) for _ in range(6)]
+    pods += [fx.pod(requests={"cpu": "1800m"}, node_preferences=[fx.req(fx.ZONE, "In", "test-zone-9")]) for _ in range(8)]
+    prob = fx.problem(its, [fx.node_pool(limits={"cpu": "60"})], pods, state_nodes=nodes, cluster_pods=cluster, daemonset_pods=[fx.pod(requests={"cpu": "100m"})],
+                      options={"reservedCapacity": True, "reservedOfferingMode": "Fallback", "ldsClaimCap": 16})
+    want = oracle.solve(prob)
+    s = NewScheduler(prob, solver_lib=emu)
+    first = s.Solve()
+    parity.assert_same_results(first, want)
+    for _ in range(3):
+        parity.assert_same_results(s.Solve(), first)
+    # a cancelled run in between leaves nothing behind either
+    import threading
+    th = threading.Thread(target=s.Solve)
+    th.start(); s.Cancel(); th.join()
+    parity.assert_same_results(s.Solve(), first)
