@@ -164,47 +164,59 @@ struct Wave {
 
 #else  // host emulation (tests only)
 
+// Lanes run one after the other here and in lockstep on the device, so a lambda that read what another lane of the same
+// call wrote would behave differently in the two. -DKS_EMU_REVERSE_LANES runs the lanes of every wave-wide call in the
+// opposite order: the fuzzers must give the same answers in both orders (tests/test_device_algorithm.py).
+#ifdef KS_EMU_REVERSE_LANES
+#define KS_LANES(l) for (int l = 63; l >= 0; --l)
+#else
+#define KS_LANES(l) for (int l = 0; l < 64; ++l)
+#endif
+
 struct Wave {
   static int lane() { return 0; }
   static void sync() {}
   template <class F>
   static uint64_t ballot(F f) {
     uint64_t m = 0;
-    for (int l = 0; l < 64; ++l) if (f(l)) m |= 1ull << l;
+    KS_LANES(l) if (f(l)) m |= 1ull << l;
     return m;
   }
   template <class F>
   static void ballot4(F f, uint64_t& m0, uint64_t& m1, uint64_t& m2, uint64_t& m3) {
     m0 = m1 = m2 = m3 = 0;
-    for (int l = 0; l < 64; ++l) { const int v = f(l); if (v & 1) m0 |= 1ull << l; if (v & 2) m1 |= 1ull << l; if (v & 4) m2 |= 1ull << l; if (v & 8) m3 |= 1ull << l; }
+    KS_LANES(l) { const int v = f(l); if (v & 1) m0 |= 1ull << l; if (v & 2) m1 |= 1ull << l; if (v & 4) m2 |= 1ull << l; if (v & 8) m3 |= 1ull << l; }
   }
   template <class F, class G>
   static void ballots8(int n, F f, G g) {
-    for (int j = 0; j < n; ++j) { uint64_t m = 0; for (int l = 0; l < 64; ++l) if (f(l, j)) m |= 1ull << l; g(j, m); }
+    for (int j = 0; j < n; ++j) { uint64_t m = 0; KS_LANES(l) if (f(l, j)) m |= 1ull << l; g(j, m); }
   }
+  // the device gives item i to lane i % 64: items of one round of 64 run together, rounds one after the other
   template <class F>
-  static void for_n(int n, F f) { for (int i = 0; i < n; ++i) f(i); }
+  static void for_n(int n, F f) {
+    for (int base = 0; base < n; base += 64) KS_LANES(l) if (base + l < n) f(base + l);
+  }
   template <class F>
   static int find_first(int lo, int hi, F pred) { for (int i = lo; i < hi; ++i) if (pred(i)) return i; return hi; }
   template <class F>
   static int find_last(int lo, int hi, F pred) { for (int i = hi - 1; i >= lo; --i) if (pred(i)) return i; return lo - 1; }
   template <class F>
-  static uint64_t reduce_min(int n, F f) { uint64_t v = ~0ull; for (int i = 0; i < n; ++i) { uint64_t x = f(i); if (x < v) v = x; } return v; }
+  static uint64_t reduce_min(int n, F f) { uint64_t v = ~0ull; for_n(n, [&](int i) { uint64_t x = f(i); if (x < v) v = x; }); return v; }
   template <class F>
-  static int64_t reduce_max_i64(int n, F f) { int64_t v = INT64_MIN; for (int i = 0; i < n; ++i) { int64_t x = f(i); if (x > v) v = x; } return v; }
+  static int64_t reduce_max_i64(int n, F f) { int64_t v = INT64_MIN; for_n(n, [&](int i) { int64_t x = f(i); if (x > v) v = x; }); return v; }
   template <class F>
-  static int64_t lanes_max_i64(F f) { int64_t v = INT64_MIN; for (int l = 0; l < 64; ++l) { int64_t x = f(l); if (x > v) v = x; } return v; }
+  static int64_t lanes_max_i64(F f) { int64_t v = INT64_MIN; KS_LANES(l) { int64_t x = f(l); if (x > v) v = x; } return v; }
   template <class F>
-  static uint64_t reduce_or(int n, F f) { uint64_t v = 0; for (int i = 0; i < n; ++i) v |= f(i); return v; }
+  static uint64_t reduce_or(int n, F f) { uint64_t v = 0; for_n(n, [&](int i) { v |= f(i); }); return v; }
   template <class T>
   static void store(T* p, T v) { *p = v; }
   static bool leader() { return true; }
   static unsigned long long clock() { return 0; }
   static int poll_flag(const volatile int* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
   template <class F>
-  static uint32_t argmin_u32(F f, int* lane_out) {
+  static uint32_t argmin_u32(F f, int* lane_out) {   // ties go to the lowest lane, whatever the evaluation order
     uint32_t m = 0xFFFFFFFFu; int who = -1;
-    for (int l = 0; l < 64; ++l) { uint32_t x = f(l); if (x < m) { m = x; who = l; } }
+    KS_LANES(l) { uint32_t x = f(l); if (x < m || (x == m && who >= 0 && l < who)) { m = x; who = l; } }
     *lane_out = who;
     return m;
   }

@@ -4,16 +4,18 @@ import os
 EMU_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libksolve_emu.so")
 
 
-def build_emu():
-    """Builds the TEST-ONLY host emulation of the device solver (tests/emu/ksolve_emu.cpp)."""
+def build_emu(reverse_lanes=False):
+    """Builds the TEST-ONLY host emulation of the device solver (tests/emu/ksolve_emu.cpp). reverse_lanes: the variant
+    whose wave-wide calls run their lanes in the opposite order (csrc/wave.h, KS_EMU_REVERSE_LANES) — same answers expected."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(root, "tests", "emu", "ksolve_emu.cpp")
     deps = [src] + [os.path.join(root, "karpenter_amd", "csrc", f) for f in os.listdir(os.path.join(root, "karpenter_amd", "csrc")) if f.endswith(".h")]
     deps.append(os.path.join(root, "include", "ksolve.h"))
-    if not os.path.exists(EMU_LIB) or any(os.path.getmtime(d) > os.path.getmtime(EMU_LIB) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", EMU_LIB, src])
-    return EMU_LIB
+    lib = EMU_LIB.replace(".so", "_reversed.so") if reverse_lanes else EMU_LIB
+    if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread"] + (["-DKS_EMU_REVERSE_LANES"] if reverse_lanes else []) + ["-o", lib, src])
+    return lib
 
 
 def canon_req(r):

@@ -228,3 +228,26 @@ def run_passes(oracle, emu, seed):
 def test_multi_pass_fuzz(oracle, emu, block):
     for seed in range(block * 30, block * 30 + 30):
         run_passes(oracle, emu, seed)
+
+
+@pytest.fixture(scope="module")
+def emu_reversed():
+    import __graft_entry__  # noqa: F401
+    return parity.build_emu(reverse_lanes=True)
+
+
+def test_lane_order_does_not_matter(oracle, emu_reversed):
+    """On the device the 64 lanes of a wave-wide step run in lockstep, in the emulation one after the other. If a lane's
+    work depended on what another lane of the same step wrote, the two would disagree — and so would the emulation with
+    itself when the lanes run in the opposite order. Same fuzzers, same oracle, reversed lanes."""
+    for seed in range(40):
+        run(oracle, emu_reversed, seed)
+        run_passes(oracle, emu_reversed, seed)
+    for seed in range(8):
+        run_wide(oracle, emu_reversed, seed)
+    # the BIG engine (claim order in HBM) and the lite engine (no topology)
+    prob = fx.config3(pods=1500, n_types=72, seed=5, anti_affinity_pods=200)
+    prob["options"]["ldsClaimCap"] = 64
+    parity.assert_same_results(NewScheduler(prob, solver_lib=emu_reversed).Solve(), oracle.solve(prob))
+    prob = fx.config2(pods=6000, n_types=144, seed=11)
+    parity.assert_same_results(NewScheduler(prob, solver_lib=emu_reversed).Solve(), oracle.solve(prob))
