@@ -321,6 +321,38 @@ def state_node(name, instance_type, zone, capacity_type="on-demand", nodepool="d
             "available": avail, "capacity": cap, "initialized": initialized, "managed": True, "underConsolidateAfter": under_consolidate_after}
 
 
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return x, z ^ (z >> 31)
+
+
+def group_pod_uid(seed, i):
+    """uid of pod i of a podGroup — the same 128 bits the host library and the oracle derive (ksched.cpp group_uid)."""
+    st = (seed * 0x9E3779B97F4A7C15 + i * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D) & _M64
+    st, a = _splitmix64(st)
+    st, b = _splitmix64(st)
+    return "%08x-%04x-%04x-%04x-%012x" % (a >> 32, (a >> 16) & 0xFFFF, a & 0xFFFF, b >> 48, b & 0xFFFFFFFFFFFF)
+
+
+def expand_pod_groups(problem):
+    """The same problem with every podGroup written out as explicit pods (for exporting a BASELINE configuration to the
+    reference's wire shapes, tests/golden/from_go.py:to_go)."""
+    out = dict(problem)
+    pods = list(problem.get("pods", []))
+    for g in problem.get("podGroups", []):
+        for i in range(g["count"]):
+            uid = group_pod_uid(g.get("uidSeed", 0), i)
+            pods.append(dict(g["template"], uid=uid, name=uid))
+    out["pods"], out["podGroups"] = pods, []
+    return out
+
+
 def launch(results, instance_types, pods, name_prefix="node"):
     """What happens between two provisioning passes in the reference's tests (ExpectProvisioned + node state reconcile):
     every NodeClaim of `results` is created by the cloud provider — cheapest instance type option, cheapest available

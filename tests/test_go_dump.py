@@ -124,3 +124,18 @@ def test_oracle_matches_the_reference_dumps(oracle, emu, path):
     got = oracle.solve(problem)
     compare(got, expected)
     parity.assert_same_results(NewScheduler(problem, solver_lib=emu).Solve(), got)
+
+
+def test_exported_baseline_configurations_round_trip(oracle, emu):
+    """tests/golden/export_for_go.py writes the BASELINE configurations for go/replay_test.go: pod groups written out as
+    explicit pods (fixtures.expand_pod_groups reproduces the uids the host library derives), then the wire shapes. What
+    comes back through from_go must be the same scheduling problem."""
+    for prob in (fx.config1(pods=600, n_types=50), fx.config2(pods=1500, n_types=100, seed=42), fx.config3(pods=900, n_types=72, seed=42, anti_affinity_pods=40)):
+        want = oracle.solve(prob)
+        expanded = fx.expand_pod_groups(prob)
+        assert len(expanded["pods"]) == sum(g["count"] for g in prob["podGroups"]) + len(prob["pods"]) and not expanded["podGroups"]
+        parity.assert_same_results(oracle.solve(expanded), want)
+        back, _ = from_go.from_go(json.loads(json.dumps(from_go.to_go(expanded, want))))
+        got = oracle.solve(back)
+        parity.assert_same_results(got, want)
+        parity.assert_same_results(NewScheduler(back, solver_lib=emu).Solve(), want)
