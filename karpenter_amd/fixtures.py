@@ -498,6 +498,28 @@ def config2(pods=1_000_000, n_types=500, seed=42, tolerating_fraction=0.25):
     return problem(kwok_catalog(n_types), [dedicated, default], pod_groups=groups, well_known=KWOK_WELL_KNOWN)
 
 
+def config4(pods=10_000_000, n_types=1000, n_pools=16, seed=42):
+    """C4: 16 NodePools with distinct weights; every pod pins its NodePool with a `karpenter.sh/nodepool` node selector, so
+    the pools are independent components of one provisioning pass. Pod shapes as in C2 (cpu x memory grid,
+    arch / zone / capacity-type selectors). karpenter_amd/components.py splits it, one sub-problem per pool."""
+    rng = random.Random(seed)
+    combos = [(c, m) for c in BENCH_CPU_M for m in BENCH_MEM_MI]
+    selectors = [{}, {ARCH: "amd64"}, {ARCH: "arm64"}, {CAPACITY_TYPE: "spot"}, {CAPACITY_TYPE: "on-demand"}] + [{ZONE: z} for z in KWOK_ZONES]
+    pools = []
+    for i in range(n_pools):
+        np_ = node_pool(f"pool-{i:02d}", weight=n_pools - i)
+        np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+        pools.append(np_)
+    classes = [(c, m, sel, i, 1 + rng.random()) for (c, m) in combos for sel in selectors for i in range(n_pools)]
+    counts = _split_counts(pods, [k[4] for k in classes], rng)
+    groups = []
+    for gi, ((c, m, sel, i, _), n) in enumerate(zip(classes, counts)):
+        if n:
+            t = pod(uid="t", requests={"cpu": f"{c}m", "memory": f"{m}Mi"}, node_selector=dict(sel, **{NODEPOOL: pools[i]["name"]}))
+            groups.append({"count": n, "uidSeed": seed * 100003 + gi, "template": t})
+    return problem(kwok_catalog(n_types), pools, pod_groups=groups, well_known=KWOK_WELL_KNOWN)
+
+
 def config3(pods=1_000_000, n_types=500, seed=42, anti_affinity_pods=None):
     """C3: podAntiAffinity + 3-zone topologySpreadConstraints, the reference benchmark's diverse mix
     (scheduling_benchmark_test.go:259-272): one fifth each of generic pods, zonal spread (maxSkew 1), hostname spread,
