@@ -247,3 +247,19 @@ def test_merge_three_nodes_into_one(oracle, emu):
         assert priciest["name"] not in cmd["replacement"] and cmd["replacement"]
         out.append((cmd["replacement"], probes))
     assert out[0] == out[1]
+
+
+def test_sweep_on_a_large_cluster(oracle, emu):
+    """BASELINE configs[4] shape at test size: thousands of existing nodes with their bound pods, a batched single-node
+    sweep over the best candidates (every probe re-solves against all the other nodes) — decisions and every probe's
+    placements equal the oracle's."""
+    from karpenter_amd.scheduling import SolveBatch
+    cluster = dz.make_cluster(n_nodes=2500, pods_per_node=6, seed=7)
+    cands = dz.sort_candidates(cluster, cluster["nodes"])[:5]
+    got = dz.sweep_batched(cluster, cands, lambda ps: SolveBatch([NewScheduler(p, solver_lib=emu) for p in ps]))
+    want = dz.sweep(cluster, cands, oracle.solve)
+    keys = ("decision", "candidates", "replacement", "replacementCapacityType")
+    assert [{k: c.get(k) for k in keys} for c in got] == [{k: c.get(k) for k in keys} for c in want]
+    for g, w in zip(got, want):
+        parity.assert_same_results(g["results"], w["results"])
+    assert any(c["decision"] != dz.NOOP for c in got)
