@@ -67,3 +67,54 @@ def test_two_rank_sharded_solve_and_allreduce():
     assert [int(x) for x in out["vec"][:-3]] == hist
     assert int(out["vec"][-3]) == want_sched and int(out["vec"][-1]) == want_claims
     assert abs(out["vec"][-2] - want_cost) < 1e-9 * max(1.0, want_cost)
+
+
+def _sweep_worker(rank, world, port, emu, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from karpenter_amd import disruption as dz
+    from karpenter_amd.scheduling import NewScheduler, SolveBatch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cluster = dz.make_cluster(n_nodes=60, pods_per_node=5, seed=9)          # every rank holds the cluster tables (replicated)
+    cands = dz.sort_candidates(cluster, cluster["nodes"])[:16]
+    mine = list(range(rank, len(cands), world))                              # candidates are sharded, no data-path collective
+    cmds = dz.sweep_batched(cluster, [cands[i] for i in mine], lambda ps: SolveBatch([NewScheduler(p, solver_lib=emu) for p in ps]))
+    code = {dz.NOOP: 0, dz.DELETE: 1, dz.REPLACE: 2}
+    verdicts = torch.full((len(cands),), -1, dtype=torch.int64)
+    for i, c in zip(mine, cmds):
+        verdicts[i] = code[c["decision"]]
+    dist.all_reduce(verdicts, op=dist.ReduceOp.MAX)                          # the (candidate, verdict) all-gather of SURVEY §8e(4)
+    if rank == 0:
+        q.put(verdicts.tolist())
+    dist.destroy_process_group()
+
+
+def test_two_rank_consolidation_sweep():
+    """BASELINE configs[4] shape: the single-node sweep shards its candidates over the ranks (each probe is an independent
+    Solve()), the verdicts are gathered, and the first valid candidate in the reference's order is the answer
+    (singlenodeconsolidation.go:55-126) — the same one the serial sweep on the oracle finds."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    import parity
+    from karpenter_amd import disruption as dz
+    emu = parity.build_emu()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sweep_worker, args=(r, 2, port, emu, q)) for r in range(2)]
+    for p in procs: p.start()
+    verdicts = q.get(timeout=240)
+    for p in procs: p.join(60)
+    assert all(p.exitcode == 0 for p in procs)
+    cluster = dz.make_cluster(n_nodes=60, pods_per_node=5, seed=9)
+    cands = dz.sort_candidates(cluster, cluster["nodes"])[:16]
+    code = {dz.NOOP: 0, dz.DELETE: 1, dz.REPLACE: 2}
+    want = [code[c["decision"]] for c in dz.sweep(cluster, cands, oracle.solve)]
+    assert verdicts == want and any(v > 0 for v in verdicts)
+    first = next(i for i, v in enumerate(verdicts) if v > 0)
+    serial = dz.single_node_consolidation(cluster, cands, oracle.solve)
+    assert serial["candidates"] == [cands[first]["name"]]
