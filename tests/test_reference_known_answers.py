@@ -983,3 +983,59 @@ def test_dependent_affinities(oracle, emu):
     # :2827-2841 — a dependency on pods that do not exist
     res = solve(oracle, emu, [fx.pod(labels=lab("db"), pod_requirements=[fx.affinity_term(fx.HOSTNAME, lab("web"))])])
     assert len(res["podErrors"]) == 1
+
+
+# ---- minValues: instance_selection_test.go:620-1500 -----------------------------------------------------------------
+
+GEN = "karpenter/numerical-value"
+
+
+def _mv_type(name, cpu, price, arch="arm64", gen=None):
+    extra = [fx.req(GEN, "In", gen)] if gen else None
+    return fx.fake_instance_type(name, {"cpu": str(cpu), "memory": f"{cpu}Gi"}, offerings=[fx.offering("spot", "test-zone-1-spot", price)],
+                                 architecture=arch, operating_systems=["linux"], requirements=extra)
+
+
+def _two_small_pods(**kw):
+    return [fx.pod(requests={"cpu": "900m", "memory": "900Mi"}, **kw) for _ in range(2)]
+
+
+def test_min_values_on_instance_type(oracle, emu):
+    # :621-691 — two pods would share instance-type-2, but minValues=2 on the instance type key keeps both types on
+    # every claim, so each pod gets its own node
+    its = [_mv_type("instance-type-1", 1, 0.52), _mv_type("instance-type-2", 4, 1.0)]
+    pool = fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "In", "instance-type-1", "instance-type-2", min_values=2)])
+    res = solve(oracle, emu, _two_small_pods(), pools=[pool], its=its)
+    assert not res["podErrors"] and len(res["newNodeClaims"]) == 2 and all(len(c["instanceTypes"]) >= 2 for c in res["newNodeClaims"])
+    # without minValues they share the big type
+    res = solve(oracle, emu, _two_small_pods(), pools=[fx.node_pool()], its=its)
+    assert len(res["newNodeClaims"]) == 1
+    # :1410-1490 — several keys with minValues: two architectures and one instance type
+    its = [_mv_type("instance-type-1", 1, 0.52, arch="arm64"), _mv_type("instance-type-2", 4, 1.0, arch="amd64")]
+    pool = fx.node_pool(requirements=[fx.req(fx.ARCH, "Exists", min_values=2), fx.req(fx.INSTANCE_TYPE, "In", "instance-type-1", "instance-type-2", min_values=1)])
+    res = solve(oracle, emu, _two_small_pods(), pools=[pool], its=its)
+    assert not res["podErrors"] and len(res["newNodeClaims"]) == 2 and all(len(c["instanceTypes"]) >= 2 for c in res["newNodeClaims"])
+
+
+def test_min_values_with_gt(oracle, emu):
+    # :693-782 — NodePool requires generation > 2 with two distinct values: types 2 and 3 (gen 3 and 4) must both stay
+    its = [_mv_type("instance-type-1", 1, 0.52, gen="2"), _mv_type("instance-type-2", 1, 1.0, gen="3"), _mv_type("instance-type-3", 4, 1.2, gen="4")]
+    pool = fx.node_pool(requirements=[fx.req(GEN, "Gt", "2", min_values=2)])
+    res = solve(oracle, emu, _two_small_pods(), pools=[pool], its=its)
+    assert not res["podErrors"] and len(res["newNodeClaims"]) == 2
+    assert all(sorted(c["instanceTypes"]) == ["instance-type-2", "instance-type-3"] for c in res["newNodeClaims"])
+    # :784-868 — Exists with minValues 2 on the NodePool, pods ask for generation > 2, only one such generation exists
+    its = [_mv_type("instance-type-1", 1, 0.52, gen="2"), _mv_type("instance-type-2", 4, 1.0, gen="3")]
+    pool = fx.node_pool(requirements=[fx.req(GEN, "Exists", min_values=2)])
+    res = solve(oracle, emu, _two_small_pods(node_requirements=[fx.req(GEN, "Gt", "2")]), pools=[pool], its=its)
+    assert len(res["podErrors"]) == 2 and not res["newNodeClaims"]
+
+
+def test_min_values_more_than_the_catalogue_has(oracle, emu):
+    # :1234-1259 — ten instance types, minValues 11 on the instance type key: nothing can be launched
+    its = fx.fake_instance_types(10)
+    pool = fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "Exists", min_values=11)])
+    res = solve(oracle, emu, [fx.pod()], pools=[pool], its=its)
+    assert len(res["podErrors"]) == 1 and not res["newNodeClaims"]
+    res = solve(oracle, emu, [fx.pod()], pools=[fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "Exists", min_values=10)])], its=its)
+    assert not res["podErrors"] and len(res["newNodeClaims"][0]["instanceTypes"]) == 10
