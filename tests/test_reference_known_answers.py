@@ -1039,3 +1039,74 @@ def test_min_values_more_than_the_catalogue_has(oracle, emu):
     assert len(res["podErrors"]) == 1 and not res["newNodeClaims"]
     res = solve(oracle, emu, [fx.pod()], pools=[fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "Exists", min_values=10)])], its=its)
     assert not res["podErrors"] and len(res["newNodeClaims"][0]["instanceTypes"]) == 10
+
+
+# ---- Instance Type Selection: instance_selection_test.go:40-618 ------------------------------------------------------
+
+DEFAULT_SELECTION_POOL = [fx.req(fx.CAPACITY_TYPE, "In", "spot", "on-demand"), fx.req(fx.ARCH, "In", "arm64", "amd64")]     # BeforeEach :48-70
+SELECTION_CASES = [
+    # (line, NodePool requirements or None = the BeforeEach pool, pod node requirements, {label: value every option must carry})
+    (82, None, [], {}),
+    (89, None, [fx.req(fx.ARCH, "In", "amd64")], {fx.ARCH: "amd64"}),
+    (103, None, [fx.req(fx.ARCH, "In", "arm64")], {fx.ARCH: "arm64"}),
+    (116, [fx.req(fx.ARCH, "In", "amd64")], [], {fx.ARCH: "amd64"}),
+    (131, [fx.req(fx.ARCH, "In", "arm64")], [], {fx.ARCH: "arm64"}),
+    (146, [fx.req(fx.OS, "In", "windows")], [], {fx.OS: "windows"}),
+    (161, None, [fx.req(fx.OS, "In", "windows")], {fx.OS: "windows"}),
+    (189, None, [fx.req(fx.OS, "In", "linux")], {fx.OS: "linux"}),
+    (215, [fx.req(fx.ZONE, "In", "test-zone-2")], [], {fx.ZONE: "test-zone-2"}),
+    (230, None, [fx.req(fx.ZONE, "In", "test-zone-2")], {fx.ZONE: "test-zone-2"}),
+    (243, [fx.req(fx.CAPACITY_TYPE, "In", "spot")], [], {fx.CAPACITY_TYPE: "spot"}),
+    (258, None, [fx.req(fx.CAPACITY_TYPE, "In", "spot")], {fx.CAPACITY_TYPE: "spot"}),
+    (271, [fx.req(fx.CAPACITY_TYPE, "In", "on-demand"), fx.req(fx.ZONE, "In", "test-zone-1")], [], {fx.CAPACITY_TYPE: "on-demand", fx.ZONE: "test-zone-1"}),
+    (291, None, [fx.req(fx.CAPACITY_TYPE, "In", "spot"), fx.req(fx.ZONE, "In", "test-zone-1")], {fx.CAPACITY_TYPE: "spot", fx.ZONE: "test-zone-1"}),
+    (310, [fx.req(fx.CAPACITY_TYPE, "In", "spot")], [fx.req(fx.ZONE, "In", "test-zone-2")], {fx.CAPACITY_TYPE: "spot", fx.ZONE: "test-zone-2"}),
+    (330, [fx.req(fx.CAPACITY_TYPE, "In", "on-demand"), fx.req(fx.ZONE, "In", "test-zone-1"), fx.req(fx.ARCH, "In", "arm64"), fx.req(fx.OS, "In", "windows")], [],
+     {fx.CAPACITY_TYPE: "on-demand", fx.ZONE: "test-zone-1", fx.ARCH: "arm64", fx.OS: "windows"}),
+    (362, [fx.req(fx.CAPACITY_TYPE, "In", "spot"), fx.req(fx.ZONE, "In", "test-zone-2")], [fx.req(fx.ARCH, "In", "amd64"), fx.req(fx.OS, "In", "linux")],
+     {fx.CAPACITY_TYPE: "spot", fx.ZONE: "test-zone-2", fx.ARCH: "amd64", fx.OS: "linux"}),
+    (396, None, [fx.req(fx.CAPACITY_TYPE, "In", "spot"), fx.req(fx.ZONE, "In", "test-zone-2"), fx.req(fx.ARCH, "In", "amd64"), fx.req(fx.OS, "In", "linux")],
+     {fx.CAPACITY_TYPE: "spot", fx.ZONE: "test-zone-2", fx.ARCH: "amd64", fx.OS: "linux"}),
+]
+
+
+@pytest.fixture(scope="module")
+def assorted():
+    import random
+    its = fx.fake_instance_types_assorted()
+    random.Random(7).shuffle(its)          # "add some randomness to instance type ordering to ensure we sort everywhere we need to" :72-75
+    return its
+
+
+@pytest.mark.parametrize("line,pool_reqs,pod_reqs,labels", SELECTION_CASES, ids=[f"instance_selection_test.go:{c[0]}" for c in SELECTION_CASES])
+def test_cheapest_instance_type_selection(oracle, emu, assorted, line, pool_reqs, pod_reqs, labels):
+    """The node is one of the globally cheapest (every slice of the assorted catalogue has a 1 cpu / 1 Gi member, so the
+    constrained minimum equals the global one) and every instance type handed to the cloud provider carries the labels."""
+    min_price = min(o["price"] for t in assorted for o in t["offerings"])
+    pool = fx.node_pool(requirements=DEFAULT_SELECTION_POOL if pool_reqs is None else pool_reqs)
+    res = solve(oracle, emu, [fx.pod(node_requirements=pod_reqs or None)], pools=[pool], its=assorted)
+    assert not res["podErrors"] and len(res["newNodeClaims"]) == 1
+    claim = res["newNodeClaims"][0]
+    assert claim["cheapestPrice"] == min_price
+    by = {t["name"]: t for t in assorted}
+    for name in claim["instanceTypes"]:
+        reqs = {r["key"]: r["values"] for r in by[name]["requirements"]}
+        for k, v in labels.items():
+            assert v in reqs[k], (name, k)
+
+
+def test_no_instance_type_matches_the_selector(oracle, emu, assorted):
+    # :428-446 — no arm64 types at all
+    amd_only = [t for t in assorted if any(r["key"] == fx.ARCH and r["values"] == ["amd64"] for r in t["requirements"])]
+    pool = fx.node_pool(requirements=DEFAULT_SELECTION_POOL)
+    res = solve(oracle, emu, [fx.pod(node_requirements=[fx.req(fx.ARCH, "In", "arm64")])], pools=[pool], its=amd_only)
+    assert len(res["podErrors"]) == 1 and not res["newNodeClaims"]
+    # :448-507 — no arm64 types in test-zone-2 (pod or NodePool asks for arm64, pod for the zone)
+    def keeps(t):
+        in_zone2 = any(r["values"] == ["test-zone-2"] for o in t["offerings"] for r in o["requirements"] if r["key"] == fx.ZONE)
+        return not in_zone2 or any(r["key"] == fx.ARCH and r["values"] == ["amd64"] for r in t["requirements"])
+    no_arm_in_zone2 = [t for t in assorted if keeps(t)]
+    res = solve(oracle, emu, [fx.pod(node_requirements=[fx.req(fx.ARCH, "In", "arm64"), fx.req(fx.ZONE, "In", "test-zone-2")])], pools=[pool], its=no_arm_in_zone2)
+    assert len(res["podErrors"]) == 1 and not res["newNodeClaims"]
+    res = solve(oracle, emu, [fx.pod(node_requirements=[fx.req(fx.ZONE, "In", "test-zone-2")])], pools=[fx.node_pool(requirements=[fx.req(fx.ARCH, "In", "arm64")])], its=no_arm_in_zone2)
+    assert len(res["podErrors"]) == 1 and not res["newNodeClaims"]
