@@ -1110,3 +1110,32 @@ def test_no_instance_type_matches_the_selector(oracle, emu, assorted):
     assert len(res["podErrors"]) == 1 and not res["newNodeClaims"]
     res = solve(oracle, emu, [fx.pod(node_requirements=[fx.req(fx.ZONE, "In", "test-zone-2")])], pools=[fx.node_pool(requirements=[fx.req(fx.ARCH, "In", "arm64")])], its=no_arm_in_zone2)
     assert len(res["podErrors"]) == 1 and not res["newNodeClaims"]
+
+
+def test_enough_resources_on_every_option(oracle, emu, assorted):
+    # :509-561 — three equal pods always share one node, and requests + overhead stay strictly below the capacity of every
+    # instance type handed to the provider
+    from decimal import Decimal
+    pool = fx.node_pool(requirements=DEFAULT_SELECTION_POOL)
+    by = {t["name"]: t for t in assorted}
+    for cpu in (0.1, 1.0, 2, 2.5, 4, 8, 16):
+        for mem in (0.1, 1.0, 2, 4, 8, 16, 32):
+            mem_bytes = int(Decimal(str(mem)) * 2**30)
+            pods = [fx.pod(requests={"cpu": f"{int(cpu * 1000)}m", "memory": str(mem_bytes)}) for _ in range(3)]
+            res = solve(oracle, emu, pods, pools=[pool], its=assorted)
+            assert not res["podErrors"] and len(res["newNodeClaims"]) == 1, (cpu, mem)
+            for name in res["newNodeClaims"][0]["instanceTypes"]:
+                it = by[name]
+                need_cpu = 3 * Decimal(str(cpu)) + Decimal("0.1")                       # overhead 100m / 10Mi
+                need_mem = 3 * mem_bytes + 10 * 2**20
+                assert need_cpu < Decimal(it["capacity"]["cpu"]) and need_mem < fx.quantity_float(it["capacity"]["memory"]), (cpu, mem, name)
+
+
+def test_on_demand_price_decides_under_an_on_demand_pool(oracle, emu):
+    # :563-618 — spot prices would order instance2 first, but the NodePool is on-demand only: instance1 is the cheaper one
+    def it(name, od, spot):
+        return fx.fake_instance_type(name, {"cpu": "1", "memory": "1Gi"}, architecture="amd64", operating_systems=["linux"],
+                                     offerings=[fx.offering("on-demand", "test-zone-1a", od), fx.offering("spot", "test-zone-1a", spot)])
+    its = [it("test-instance1", 1.0, 0.2), it("test-instance2", 1.3, 0.1)]
+    res = solve(oracle, emu, [fx.pod()], pools=[fx.node_pool(requirements=[fx.req(fx.CAPACITY_TYPE, "In", "on-demand")])], its=its)
+    assert _launch_labels(res, its)[fx.INSTANCE_TYPE] == "test-instance1" and res["newNodeClaims"][0]["cheapestPrice"] == 1.0
