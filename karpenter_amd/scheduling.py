@@ -148,8 +148,8 @@ def NewScheduler(problem: dict, solver_lib: str | None = None) -> Scheduler:
 def SolveBatch(schedulers, want_results: bool = True):
     """Solve() for many independent Schedulers with ONE launch of the pack kernel (ksolve_solve_batch): each problem is
     its own wavefront on its own CU. Same Results as calling Solve() on each; this is how a consolidation pass
-    (disruption/helpers.go:53-155: one simulation per candidate set) or the NodePool components of a provisioning pass
-    fill the GPU."""
+    (disruption/helpers.go:53-155: one simulation per candidate set) fills the GPU. NodePool components of ONE pass are
+    not the same thing: solved separately they give an equally good, not the identical, packing (components.py)."""
     schedulers = list(schedulers)
     if not schedulers:
         return []
