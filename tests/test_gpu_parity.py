@@ -297,3 +297,25 @@ def test_cancel_stops_a_running_solve():
     assert elapsed < 4.0, f"a cancelled 1M-pod solve took {elapsed:.1f}s: the flag was not seen by the running kernel"
     full = s.Solve(want_results=False)
     assert not full["timedOut"] and full["scheduledPods"] == n
+
+
+def test_config4_components_and_cluster_sweep(oracle):
+    """BASELINE configs[3] shape (16 NodePools, pods pinned to one each): the whole batch in one Solve() and every NodePool
+    component through one batched launch are exact against the oracle; configs[4] shape: a batched single-node
+    consolidation sweep over a 1000-node cluster gives the oracle's decisions and placements."""
+    from karpenter_amd import disruption as dz
+    from karpenter_amd.components import split_by_nodepool
+    from karpenter_amd.scheduling import SolveBatch
+    prob = fx.config4(pods=20000, n_types=144, n_pools=16, seed=2)
+    check(oracle, prob)
+    parts = split_by_nodepool(prob)
+    assert len(parts) == 16
+    for g, (_, sub) in zip(SolveBatch([NewScheduler(sub) for _, sub in parts]), parts):
+        parity.assert_same_results(g, oracle.solve(sub))
+    cluster = dz.make_cluster(n_nodes=1000, pods_per_node=6, seed=7)
+    cands = dz.sort_candidates(cluster, cluster["nodes"])[:4]
+    got = dz.sweep_batched(cluster, cands, lambda ps: SolveBatch([NewScheduler(p) for p in ps]))
+    want = dz.sweep(cluster, cands, oracle.solve)
+    for g, w in zip(got, want):
+        assert g["decision"] == w["decision"]
+        parity.assert_same_results(g["results"], w["results"])
