@@ -170,6 +170,67 @@ def SolveBatch(schedulers, want_results: bool = True):
     return results
 
 
+MAX_INSTANCE_TYPES = 600                      # scheduling.MaxInstanceTypes, nodeclaimtemplate.go:50
+_WELL_KNOWN_LABELS = {"karpenter.sh/nodepool", "topology.kubernetes.io/zone", "topology.kubernetes.io/region", "node.kubernetes.io/instance-type",
+                      "kubernetes.io/arch", "kubernetes.io/os", "karpenter.sh/capacity-type", "node.kubernetes.io/windows-build"}   # apis/v1/labels.go:75-84
+_SIMULATION_KEYS = ("karpenter.sh/registered", "karpenter.sh/initialized")   # schedulingSimulationKeys, nodeclaimtemplate.go:43-46
+
+
+def _req_admits(q, value):
+    if q.get("gte") is not None or q.get("lte") is not None:
+        try:
+            v = int(value)
+        except ValueError:
+            return False
+        if (q.get("gte") is not None and v < q["gte"]) or (q.get("lte") is not None and v > q["lte"]):
+            return False
+    return (value not in q["values"]) if q["complement"] else (value in q["values"])
+
+
+def ToNodeClaim(claim: dict, problem: dict, max_instance_types: int = MAX_INSTANCE_TYPES) -> dict:
+    """NodeClaimTemplate.ToNodeClaim (nodeclaimtemplate.go:109-175) for one NodeClaim of Results: the launch shaping that
+    follows Solve(). The instance-type requirement becomes `In` over the options ordered by price and capped at
+    MaxInstanceTypes (keeping the claim's minValues for that key), the capacity-type requirement is narrowed to the
+    capacity types those options can actually launch with, the scheduling-simulation-only keys are dropped, and custom
+    labels with a single possible value become node labels. Returns {"requirements", "labels", "instanceTypes"}.
+
+    Claims with more than `max_instance_types` options need the order the reference's unstable sort produces: solve with
+    options.truncateInstanceTypes set and the device returns it (Results.TruncateInstanceTypes, scheduler.go:419-437)."""
+    by_name = {t["name"]: t for t in problem["instanceTypes"]}
+    reqs = {q["key"]: dict(q) for q in claim["requirements"]}
+
+    def compatible_offerings(name):
+        return [o for o in by_name[name]["offerings"] if o.get("available", True)
+                and all(r["key"] not in reqs or _req_admits(reqs[r["key"]], r["values"][0]) for r in o["requirements"])]
+
+    names = list(claim["instanceTypes"])
+    if len(names) > max_instance_types:
+        raise ValueError("more instance type options than MaxInstanceTypes: solve with options.truncateInstanceTypes to get the reference's order")
+    names.sort(key=lambda n: min([o["price"] for o in compatible_offerings(n)], default=float("inf")))      # OrderByPrice; ties only matter beyond the cap
+    it_req = reqs.get("node.kubernetes.io/instance-type", {})
+    reqs["node.kubernetes.io/instance-type"] = {"key": "node.kubernetes.io/instance-type", "complement": False, "values": sorted(names), "gte": None, "lte": None,
+                                               "minValues": it_req.get("minValues"), "operator": "In"}
+    cts = []
+    for n in names:
+        for o in compatible_offerings(n):
+            ct = next(r["values"][0] for r in o["requirements"] if r["key"] == "karpenter.sh/capacity-type")
+            if ct not in cts:
+                cts.append(ct)
+    if cts:
+        old = reqs.get("karpenter.sh/capacity-type")
+        keep = [c for c in cts if old is None or _req_admits(old, c)]
+        reqs["karpenter.sh/capacity-type"] = {"key": "karpenter.sh/capacity-type", "complement": False, "values": sorted(keep), "gte": None, "lte": None,
+                                              "minValues": (old or {}).get("minValues"), "operator": "In"}
+    well_known = set(problem.get("wellKnownLabels", [])) | _WELL_KNOWN_LABELS
+    labels = {}
+    for k, q in reqs.items():
+        if k in well_known or k == "kubernetes.io/hostname" or k in _SIMULATION_KEYS or q["complement"] or not q["values"]:   # WellKnown / Restricted / simulation keys
+            continue
+        labels[k] = sorted(q["values"])[0]            # Requirement.Any(): a single concrete value is the interesting case
+    out = [q for k, q in sorted(reqs.items()) if k not in _SIMULATION_KEYS]
+    return {"requirements": out, "labels": labels, "instanceTypes": names}
+
+
 def device_available() -> bool:
     if not os.path.exists(KSOLVE_LIB):
         return False

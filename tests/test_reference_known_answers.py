@@ -9,7 +9,7 @@ import pytest
 
 import parity
 from karpenter_amd import fixtures as fx
-from karpenter_amd.scheduling import NewScheduler
+from karpenter_amd.scheduling import NewScheduler, ToNodeClaim
 from test_device_algorithm import emu  # noqa: F401  (fixture)
 
 LABELS = {"test": "test"}
@@ -1139,3 +1139,90 @@ def test_on_demand_price_decides_under_an_on_demand_pool(oracle, emu):
     its = [it("test-instance1", 1.0, 0.2), it("test-instance2", 1.3, 0.1)]
     res = solve(oracle, emu, [fx.pod()], pools=[fx.node_pool(requirements=[fx.req(fx.CAPACITY_TYPE, "In", "on-demand")])], its=its)
     assert _launch_labels(res, its)[fx.INSTANCE_TYPE] == "test-instance1" and res["newNodeClaims"][0]["cheapestPrice"] == 1.0
+
+
+# ---- MinValuesPolicy: pkg/controllers/provisioning/suite_test.go:2876-3400 ------------------------------------------
+
+def _policy_type(name, offerings):
+    return fx.fake_instance_type(name, {"cpu": "4", "memory": "4Gi"}, architecture="arm64", operating_systems=["linux"],
+                                 offerings=[fx.offering("spot", z, p) for z, p in offerings])
+
+
+def _claim_req(claim, key):
+    return next(q for q in claim["requirements"] if q["key"] == key)
+
+
+def test_min_values_policy_on_instance_types(oracle, emu):
+    its = [_policy_type("instance-type-1", [("test-zone-1-spot", 0.52)]), _policy_type("instance-type-2", [("test-zone-2-spot", 0.52)])]
+    names3 = ["instance-type-1", "instance-type-2", "instance-type-3"]
+    pool = fx.node_pool("default", weight=100, requirements=[fx.req(fx.INSTANCE_TYPE, "In", *names3, min_values=3)])
+    pod = lambda: fx.pod(requests={"cpu": "900m", "memory": "900Mi"})
+    # :2910-2955 Strict: two of the three named types exist, minValues 3 cannot be met
+    res = solve(oracle, emu, [pod()], pools=[pool], its=its, options={"minValuesPolicy": "Strict"})
+    assert len(res["podErrors"]) == 1 and not res["newNodeClaims"]
+    # :2961-3022 BestEffort: scheduled, annotated, and the claim carries minValues 2 over the two types that exist
+    res = solve(oracle, emu, [pod()], pools=[pool], its=its, options={"minValuesPolicy": "BestEffort"})
+    claim = res["newNodeClaims"][0]
+    assert not res["podErrors"] and claim["annotations"]["karpenter.sh/nodeclaim-min-values-relaxed"] == "true"
+    assert _claim_req(claim, fx.INSTANCE_TYPE)["minValues"] == 2        # Solve() keeps the pool's three names; the launched NodeClaim names the options
+    q = _claim_req(ToNodeClaim(claim, fx.problem(its, [pool], [])), fx.INSTANCE_TYPE)
+    assert sorted(q["values"]) == names3[:2] and q["minValues"] == 2 and _launch_labels(res, its)[fx.INSTANCE_TYPE] == "instance-type-1"
+    # :3024-3098 minValues are relaxed before a lower-weight NodePool without minValues is tried
+    plain = fx.node_pool("no-min-values", weight=10, requirements=[fx.req(fx.INSTANCE_TYPE, "In", *names3)])
+    res = solve(oracle, emu, [pod()], pools=[pool, plain], its=its, options={"minValuesPolicy": "BestEffort"})
+    claim = res["newNodeClaims"][0]
+    assert claim["nodePool"] == "default" and claim["annotations"]["karpenter.sh/nodeclaim-min-values-relaxed"] == "true" and _claim_req(claim, fx.INSTANCE_TYPE)["minValues"] == 2
+    # :3100-3185 two pools that both need relaxing: the heavier one wins
+    lower = fx.node_pool("lower", weight=10, requirements=[fx.req(fx.INSTANCE_TYPE, "In", *names3, min_values=3)])
+    res = solve(oracle, emu, [pod()], pools=[pool, lower], its=its, options={"minValuesPolicy": "BestEffort"})
+    assert res["newNodeClaims"][0]["nodePool"] == "default" and res["newNodeClaims"][0]["annotations"]["karpenter.sh/nodeclaim-min-values-relaxed"] == "true"
+    # Strict with the same two pools: the pool without minValues takes the pod, nothing is relaxed
+    res = solve(oracle, emu, [pod()], pools=[pool, plain], its=its, options={"minValuesPolicy": "Strict"})
+    assert res["newNodeClaims"][0]["nodePool"] == "no-min-values" and res["newNodeClaims"][0]["annotations"]["karpenter.sh/nodeclaim-min-values-relaxed"] == "false"
+
+
+def test_min_values_policy_on_zones(oracle, emu):
+    its = [_policy_type("instance-type-1", [("test-zone-1", 0.52), ("test-zone-2", 0.54)])]
+    zones3 = ["test-zone-1", "test-zone-2", "test-zone-3"]
+    pool = fx.node_pool(requirements=[fx.req(fx.ZONE, "In", *zones3, min_values=3)])
+    pod = lambda: fx.pod(requests={"cpu": "900m", "memory": "900Mi"})
+    # :3216-3252 Strict
+    res = solve(oracle, emu, [pod()], pools=[pool], its=its, options={"minValuesPolicy": "Strict"})
+    assert len(res["podErrors"]) == 1
+    # :3259-3313 BestEffort: the zone requirement keeps its three values, minValues drops to the two zones on offer
+    res = solve(oracle, emu, [pod()], pools=[pool], its=its, options={"minValuesPolicy": "BestEffort"})
+    claim = res["newNodeClaims"][0]
+    q = _claim_req(claim, fx.ZONE)
+    assert claim["annotations"]["karpenter.sh/nodeclaim-min-values-relaxed"] == "true" and sorted(q["values"]) == zones3 and q["minValues"] == 2
+    assert _launch_labels(res, its)[fx.ZONE] in ("test-zone-1", "test-zone-2")
+    # :3316-3400 both keys: instance type relaxes to 1, zone to 2
+    both = fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "In", "instance-type-1", "instance-type-2", "instance-type-3", min_values=3), fx.req(fx.ZONE, "In", *zones3, min_values=3)])
+    res = solve(oracle, emu, [pod()], pools=[both], its=its, options={"minValuesPolicy": "BestEffort"})
+    claim = res["newNodeClaims"][0]
+    wire = ToNodeClaim(claim, fx.problem(its, [both], []))
+    qi, qz = _claim_req(wire, fx.INSTANCE_TYPE), _claim_req(wire, fx.ZONE)
+    assert claim["annotations"]["karpenter.sh/nodeclaim-min-values-relaxed"] == "true"
+    assert qi["values"] == ["instance-type-1"] and qi["minValues"] == 1 and sorted(qz["values"]) == zones3 and qz["minValues"] == 2
+
+
+def test_to_node_claim_launch_shaping(oracle, emu):
+    """NodeClaimTemplate.ToNodeClaim (nodeclaimtemplate.go:109-175): what the provider's Create receives."""
+    its = fx.fake_default_instance_types()
+    pool = fx.node_pool(labels={"team": "a"}, requirements=[fx.req("example.com/tier", "In", "gold")])
+    prob_kw = dict(pools=[pool], its=its)
+    res = solve(oracle, emu, [fx.pod(requests={"cpu": "3"}, node_selector={fx.ZONE: "test-zone-3"})], **prob_kw)
+    claim = res["newNodeClaims"][0]
+    wire = ToNodeClaim(claim, fx.problem(its, [pool], []))
+    keys = {q["key"] for q in wire["requirements"]}
+    assert "karpenter.sh/registered" not in keys and "karpenter.sh/initialized" not in keys          # simulation-only keys
+    assert sorted(_claim_req(wire, fx.INSTANCE_TYPE)["values"]) == sorted(claim["instanceTypes"])
+    # only on-demand is offered in test-zone-3 (fake/instancetype.go default offerings): the capacity type is narrowed
+    assert _claim_req(wire, fx.CAPACITY_TYPE)["values"] == ["on-demand"]
+    # resolveCustomLabelsFromRequirements: every non-well-known key with a concrete value, the node class label included
+    assert wire["labels"] == {"team": "a", "example.com/tier": "gold", "karpenter.test.sh/testnodeclass": "default"}
+    # price order: the cheapest option first
+    by = {t["name"]: t for t in its}
+    prices = [min(o["price"] for o in by[n]["offerings"]) for n in wire["instanceTypes"]]
+    assert prices == sorted(prices)
+    with pytest.raises(ValueError):
+        ToNodeClaim(claim, fx.problem(its, [pool], []), max_instance_types=1)
