@@ -1226,3 +1226,52 @@ def test_to_node_claim_launch_shaping(oracle, emu):
     assert prices == sorted(prices)
     with pytest.raises(ValueError):
         ToNodeClaim(claim, fx.problem(its, [pool], []), max_instance_types=1)
+
+
+# ---- PreferencePolicy=Ignore: pkg/controllers/provisioning/suite_test.go:2562-2770 ----------------------------------
+
+IGNORE = {"preferencePolicy": "Ignore"}
+
+
+def _zone_scene(extra_pod):
+    zone1 = fx.pod(labels={"app": "foo"}, node_selector={fx.ZONE: "test-zone-1"}, requests={"cpu": "2"})
+    zone2 = [fx.pod(labels={"app": "bar"}, node_selector={fx.ZONE: "test-zone-2"}, requests={"cpu": "3"}) for _ in range(2)]
+    return zone1, zone2, [zone1] + zone2 + [extra_pod]
+
+
+def test_ignore_node_affinity_preference(oracle, emu):
+    # :2566-2625 — the preference for test-zone-2 is ignored: the pod joins the emptier zone-1 node
+    follower = fx.pod(labels={"app": "baz"}, requests={"cpu": "1"}, node_preferences=[fx.req(fx.ZONE, "In", "test-zone-2")])
+    zone1, zone2, pods = _zone_scene(follower)
+    w = _where(solve(oracle, emu, pods, its=fx.fake_default_instance_types(), options=IGNORE))
+    assert w[follower["uid"]] == w[zone1["uid"]] != w[zone2[0]["uid"]]
+    # with the default policy the preference is honoured
+    follower2 = fx.pod(labels={"app": "baz"}, requests={"cpu": "1"}, node_preferences=[fx.req(fx.ZONE, "In", "test-zone-2")])
+    zone1, zone2, pods = _zone_scene(follower2)
+    res = solve(oracle, emu, pods, its=fx.fake_default_instance_types())
+    assert _single(_claim_of(res, follower2), fx.ZONE) == "test-zone-2"
+
+
+@pytest.mark.parametrize("key", [fx.ZONE, fx.HOSTNAME])
+def test_ignore_soft_spread_and_anti_affinity_preferences(oracle, emu, key):
+    lab = {"app": "foo"}
+    # :2626-2660 ScheduleAnyway spread constraints are not even tried: five pods share one node
+    pods = [fx.pod(labels=lab, topology_spread=[fx.spread(key, lab, when="ScheduleAnyway")]) for _ in range(5)]
+    res = solve(oracle, emu, pods, options=IGNORE)
+    assert len(res["newNodeClaims"]) == 1 and res["counters"]["relaxations"] == 0
+    # :2661-2692 preferred anti-affinity likewise
+    pods = [fx.pod(labels=lab, pod_anti_preferences=[fx.weighted(1, fx.affinity_term(key, lab))]) for _ in range(5)]
+    res = solve(oracle, emu, pods, options=IGNORE)
+    assert len(res["newNodeClaims"]) == 1
+    # respected, they spread (one node per pod on hostname, three zones otherwise)
+    res = solve(oracle, emu, [fx.pod(labels=lab, topology_spread=[fx.spread(key, lab, when="ScheduleAnyway")]) for _ in range(5)])
+    assert len(res["newNodeClaims"]) == (5 if key == fx.HOSTNAME else 3)
+
+
+@pytest.mark.parametrize("key", [fx.ZONE, fx.HOSTNAME])
+def test_ignore_pod_affinity_preference(oracle, emu, key):
+    # :2693-2768 — a preferred affinity to the "bar" pods in zone 2 is ignored: the pod lands with the zone-1 pod
+    follower = fx.pod(labels={"app": "baz"}, requests={"cpu": "1"}, pod_preferences=[fx.weighted(1, fx.affinity_term(key, {"app": "bar"}))])
+    zone1, zone2, pods = _zone_scene(follower)
+    w = _where(solve(oracle, emu, pods, options=IGNORE))
+    assert w[follower["uid"]] == w[zone1["uid"]] != w[zone2[0]["uid"]]
