@@ -1275,3 +1275,41 @@ def test_ignore_pod_affinity_preference(oracle, emu, key):
     zone1, zone2, pods = _zone_scene(follower)
     w = _where(solve(oracle, emu, pods, options=IGNORE))
     assert w[follower["uid"]] == w[zone1["uid"]] != w[zone2[0]["uid"]]
+
+
+# ---- Multiple NodePools and PreferNoSchedule: pkg/controllers/provisioning/suite_test.go:2487-2846 -------------------
+
+def test_prefer_no_schedule_is_the_last_relaxation(oracle, emu):
+    # :2487-2512 — both unsatisfiable preferences are dropped first, then the PreferNoSchedule taint is tolerated
+    pod = fx.pod(node_preferences=[{"weight": 1, "matchExpressions": [fx.req(fx.ZONE, "In", "invalid")]}, {"weight": 1, "matchExpressions": [fx.req(fx.INSTANCE_TYPE, "In", "invalid")]}])
+    pool = fx.node_pool(taints=[{"key": "foo", "value": "bar", "effect": "PreferNoSchedule"}])
+    res = solve(oracle, emu, [pod], pools=[pool])
+    assert not res["podErrors"] and res["counters"]["relaxations"] == 3
+    # :2513-2559 — an unsatisfiable node preference does not keep the pod off the other pod's node
+    for key in (fx.ZONE, fx.HOSTNAME):
+        p1 = fx.pod(labels={"app": "foo"}, requests={"cpu": "2"})
+        p2 = fx.pod(labels={"app": "baz"}, requests={"cpu": "1"}, node_preferences=[fx.req(key, "In", "value-1")])
+        res = solve(oracle, emu, [p1, p2])
+        assert len(res["newNodeClaims"]) == 1 and not res["podErrors"]
+
+
+def test_multiple_nodepools(oracle, emu):
+    a, b = fx.node_pool("pool-a"), fx.node_pool("pool-b")
+    # :2773-2780 explicit selection by the nodepool label
+    res = solve(oracle, emu, [fx.pod(node_selector={fx.NODEPOOL: "pool-b"})], pools=[a, b])
+    assert res["newNodeClaims"][0]["nodePool"] == "pool-b"
+    # :2781-2796 selection by template labels
+    labelled = fx.node_pool("labelled", labels={"foo": "bar"})
+    res = solve(oracle, emu, [fx.pod(node_selector={"foo": "bar"})], pools=[fx.node_pool("plain"), labelled])
+    assert res["newNodeClaims"][0]["nodePool"] == "labelled"
+    # :2797-2813 a PreferNoSchedule pool is avoided while another pool matches
+    soft = fx.node_pool("aaa-soft-tainted", taints=[{"key": "foo", "value": "bar", "effect": "PreferNoSchedule"}])
+    res = solve(oracle, emu, [fx.pod()], pools=[soft, fx.node_pool("zzz-clean")])
+    assert res["newNodeClaims"][0]["nodePool"] == "zzz-clean"
+    # :2815-2830 the heaviest pool always wins
+    pools = [fx.node_pool("w0"), fx.node_pool("w20", weight=20), fx.node_pool("w100", weight=100)]
+    res = solve(oracle, emu, [fx.pod() for _ in range(3)], pools=pools)
+    assert {c["nodePool"] for c in res["newNodeClaims"]} == {"w100"}
+    # :2831-2845 ... unless the pod names another pool
+    res = solve(oracle, emu, [fx.pod(node_selector={fx.NODEPOOL: "w0"})], pools=pools)
+    assert res["newNodeClaims"][0]["nodePool"] == "w0"
