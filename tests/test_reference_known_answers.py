@@ -1313,3 +1313,30 @@ def test_multiple_nodepools(oracle, emu):
     # :2831-2845 ... unless the pod names another pool
     res = solve(oracle, emu, [fx.pod(node_selector={fx.NODEPOOL: "w0"})], pools=pools)
     assert res["newNodeClaims"][0]["nodePool"] == "w0"
+
+
+def test_daemonset_compatibility_known_answers(oracle, emu):
+    """pkg/controllers/provisioning/suite_test.go:1175-1494 — which daemonsets count towards a NodeClaim's overhead. With the
+    2 cpu / 2Gi daemonset counted, the 1 cpu / 1Gi pod needs the 4 cpu type; ignored, the 2 cpu type is enough."""
+    its = fx.fake_default_instance_types()
+    pod = lambda: fx.pod(requests={"cpu": "1", "memory": "1Gi"})
+    ds_req = {"cpu": "2", "memory": "2Gi"}
+
+    def launched(daemon, pool=None):
+        prob = fx.problem(its, [pool or fx.node_pool()], [pod()], daemonset_pods=[daemon])
+        want = oracle.solve(prob)
+        got = NewScheduler(prob, solver_lib=emu).Solve()
+        for r in (want, got):
+            for c in r["newNodeClaims"]:
+                c["instanceTypes"] = sorted(c["instanceTypes"])
+        parity.assert_same_results(got, want)
+        return launched_type(want, its)
+
+    COUNTED, IGNORED = "default-instance-type", "small-instance-type"
+    assert launched(fx.pod(requests=ds_req, node_selector={"node": "invalid"})) == IGNORED                                       # :1175
+    assert launched(fx.pod(requests=ds_req, node_requirements=[fx.req(fx.INSTANCE_TYPE, "In", "non-existent-instance-type")])) == IGNORED   # :1197
+    assert launched(fx.pod(requests=ds_req, node_selector={"purpose": "monitoring"}), fx.node_pool(labels={"purpose": "monitoring"})) == COUNTED   # :1219
+    two_terms = fx.pod(requests=ds_req, node_requirements=[[fx.req("foo", "In", "voo")], [fx.req("foo", "In", "bar")]])
+    assert launched(two_terms, fx.node_pool(labels={"foo": "bar"})) == COUNTED                                                   # :1371 second term matches
+    assert launched(fx.pod(requests=ds_req, node_preferences=[fx.req("node", "In", "invalid")])) == COUNTED                      # :1431 preferences do not exclude
+    assert launched(fx.pod(requests=ds_req), fx.node_pool(taints=[{"key": "test", "value": "", "effect": "PreferNoSchedule"}])) == COUNTED   # :1459
