@@ -139,3 +139,41 @@ def test_exported_baseline_configurations_round_trip(oracle, emu):
         got = oracle.solve(back)
         parity.assert_same_results(got, want)
         parity.assert_same_results(NewScheduler(back, solver_lib=emu).Solve(), want)
+
+
+def test_init_containers_and_limit_defaulting_known_answers(oracle, emu):
+    """pkg/controllers/provisioning/suite_test.go:1057-1133 — requests are max(sum of containers, largest init container),
+    with a missing request taking the limit; the converter computes them from the wire shape and the daemonset overhead
+    they produce decides the instance type."""
+    its = fx.fake_default_instance_types()
+
+    def daemon(spec):
+        return fx.pod(requests=from_go.pod_requests(spec))
+
+    def outcome(d):
+        prob = fx.problem(its, [fx.node_pool()], [fx.pod()], daemonset_pods=[d])
+        want = oracle.solve(prob)
+        got = NewScheduler(prob, solver_lib=emu).Solve()
+        for r in (want, got):
+            for c in r["newNodeClaims"]:
+                c["instanceTypes"] = sorted(c["instanceTypes"])
+        parity.assert_same_results(got, want)
+        if want["podErrors"]:
+            return None
+        by = {t["name"]: t for t in its}
+        return min(want["newNodeClaims"][0]["instanceTypes"], key=lambda n: min(o["price"] for o in by[n]["offerings"]))
+
+    # :1070-1096 container cpu 1 (+1Gi from the limit), init container cpu 3 (+3Gi from the limit) -> 3 cpu / 3Gi -> the 4 cpu type
+    spec = {"containers": [{"resources": {"limits": {"cpu": "10000", "memory": "1Gi"}, "requests": {"cpu": "1"}}}],
+            "initContainers": [{"resources": {"limits": {"cpu": "10000", "memory": "3Gi"}, "requests": {"cpu": "3"}}}]}
+    assert {k: from_go._q(v) for k, v in from_go.pod_requests(spec).items()} == {"cpu": 3, "memory": 3 * 2**30}
+    assert outcome(daemon(spec)) == "default-instance-type"
+    # :1098-1117 an init container whose memory (from its limit) fits nowhere
+    spec["initContainers"][0]["resources"] = {"limits": {"cpu": "10000", "memory": "10000Gi"}, "requests": {"cpu": "1"}}
+    assert outcome(daemon(spec)) is None
+    # :1119-1133 init container requests alone are too large
+    assert outcome(daemon({"containers": [{}], "initContainers": [{"resources": {"requests": {"cpu": "10000", "memory": "10000Gi"}}}]})) is None
+    # :1057-1068 no requests, limits too large
+    assert outcome(daemon({"containers": [{"resources": {"limits": {"cpu": "10000", "memory": "10000Gi"}}}]})) is None
+    # :1135-1141 nothing defined at all: schedules on the smallest type
+    assert outcome(daemon({"containers": [{}]})) == "small-instance-type"
