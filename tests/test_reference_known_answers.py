@@ -1340,3 +1340,20 @@ def test_daemonset_compatibility_known_answers(oracle, emu):
     assert launched(two_terms, fx.node_pool(labels={"foo": "bar"})) == COUNTED                                                   # :1371 second term matches
     assert launched(fx.pod(requests=ds_req, node_preferences=[fx.req("node", "In", "invalid")])) == COUNTED                      # :1431 preferences do not exclude
     assert launched(fx.pod(requests=ds_req), fx.node_pool(taints=[{"key": "test", "value": "", "effect": "PreferNoSchedule"}])) == COUNTED   # :1459
+
+
+def test_nodepool_taints_and_tolerations(oracle, emu):
+    # topology_test.go:3280-3326
+    pool = fx.node_pool(requirements=[fx.req(fx.CAPACITY_TYPE, "Exists")], taints=[{"key": "test-key", "value": "test-value", "effect": "NoSchedule"}])
+    tolerating = [fx.pod(tolerations=[{"key": "test-key", "operator": "Exists", "effect": "NoSchedule"}]),
+                  fx.pod(tolerations=[{"key": "test-key", "value": "test-value", "operator": "Equal", "effect": "NoSchedule"}]),
+                  fx.pod(tolerations=[{"effect": "NoSchedule", "operator": "Exists"}])]                     # :3280 tolerates every NoSchedule taint
+    res = solve(oracle, emu, tolerating, pools=[pool])
+    assert not res["podErrors"]
+    others = [fx.pod(), fx.pod(tolerations=[{"key": "invalid", "operator": "Exists"}]),
+              fx.pod(tolerations=[{"key": "test-key", "operator": "Equal", "effect": "NoSchedule"}])]         # value mismatch ("" != test-value)
+    res = solve(oracle, emu, others, pools=[pool])
+    assert len(res["podErrors"]) == 3 and {e["code"] for e in res["podErrors"].values()} == {1}             # "did not tolerate taint"
+    # startup taints are not scheduling taints (:3327-3333): the problem format simply does not carry them for new NodeClaims
+    res = solve(oracle, emu, [fx.pod()], pools=[fx.node_pool(requirements=[fx.req(fx.CAPACITY_TYPE, "Exists")])])
+    assert not res["podErrors"]
