@@ -1357,3 +1357,80 @@ def test_nodepool_taints_and_tolerations(oracle, emu):
     # startup taints are not scheduling taints (:3327-3333): the problem format simply does not carry them for new NodeClaims
     res = solve(oracle, emu, [fx.pod()], pools=[fx.node_pool(requirements=[fx.req(fx.CAPACITY_TYPE, "Exists")])])
     assert not res["podErrors"]
+
+
+# ---- Zonal spread with pods already in the cluster: topology_test.go:235-483 ----------------------------------------
+
+RR = {"cpu": "1100m"}
+
+
+def _zonal(n, **kw):
+    return [fx.pod(labels=LABELS, requests=RR, topology_spread=[fx.spread(fx.ZONE, LABELS, **kw)]) for _ in range(n)]
+
+
+def test_zonal_spread_with_existing_pods(oracle, emu):
+    # :235-267 one pod already in test-zone-3, the NodePool then only offers zones 1 and 2: 1,2,2 (zone 3 still counts)
+    c = Cluster(oracle, emu)
+    c.provision([fx.pod(labels=LABELS, requests=RR, node_selector={fx.ZONE: "test-zone-3"})])
+    c.pools = [fx.node_pool(requirements=[fx.req(fx.ZONE, "In", "test-zone-1", "test-zone-2")])]
+    c.provision(_zonal(6))
+    assert c.skew(fx.ZONE) == [1, 2, 2]
+    # :269-309 maxSkew 5 and a NodePool that only ever offers one zone at a time
+    c = Cluster(oracle, emu)
+    for zone, n, want in (("test-zone-1", 1, [1]), ("test-zone-2", 1, [1, 1]), ("test-zone-3", 10, [1, 1, 6])):
+        c.pools = [fx.node_pool(requirements=[fx.req(fx.ZONE, "In", zone)])]
+        c.provision(_zonal(n, max_skew=5))
+        assert c.skew(fx.ZONE) == want
+    # :311-348 nine pods 3/3/3, the ones outside zone 1 are deleted, three more only go to the now-empty zones
+    c = Cluster(oracle, emu)
+    c.provision(_zonal(9))
+    assert c.skew(fx.ZONE) == [3, 3, 3]
+    zone_of = {n["name"]: n["labels"][fx.ZONE] for n in c.nodes}
+    c.bound = [p for p in c.bound if zone_of[p["nodeName"]] == "test-zone-1"]
+    assert c.skew(fx.ZONE) == [3]
+    c.provision(_zonal(3))
+    assert c.skew(fx.ZONE) == [1, 2, 3]
+    # :350-381 / :383-413 zone 1 holds one pod (with or without its own constraint), the pool then offers zones 2 and 3 only
+    for first in (_zonal(1), [fx.pod(labels=LABELS, requests=RR)]):
+        c = Cluster(oracle, emu, pools=[fx.node_pool(requirements=[fx.req(fx.ZONE, "In", "test-zone-1")])])
+        c.provision(first)
+        c.pools = [fx.node_pool(requirements=[fx.req(fx.ZONE, "In", "test-zone-2", "test-zone-3")])]
+        res = c.provision(_zonal(10))
+        assert c.skew(fx.ZONE) == [1, 2, 2] and len(res["podErrors"]) == 6
+
+
+def test_zonal_spread_counts_only_the_right_pods(oracle, emu):
+    # :415-446 — of all the pods in the cluster only running ones with the labels, in the namespace, on a node that has the
+    # domain are counted: two in zone 1, one in zone 2; two new pods give 2,2,1
+    nodes = [bare_node("first", labels={fx.ZONE: "test-zone-1"}), bare_node("second", labels={fx.ZONE: "test-zone-2"}), bare_node("third")]
+    def bound(node, labels=LABELS, **kw):
+        p = fx.pod(labels=labels, phase=kw.pop("phase", "Running"), node_name=node, **kw)
+        return p
+    cluster = [bound("first", labels={}),                                  # ignored, missing labels
+               bound("third"),                                             # ignored, no domain on the node
+               bound("first", namespace="wrong-namespace"),                # ignored, wrong namespace
+               bound("first", phase="Failed"), bound("first", phase="Succeeded"),
+               bound("first"), bound("first"), bound("second")]
+    pods = [fx.pod(labels=LABELS, topology_spread=[fx.spread(fx.ZONE, LABELS)]) for _ in range(2)]
+    res = solve(oracle, emu, pods, state_nodes=nodes, cluster_pods=cluster)
+    assert not res["podErrors"]
+    counts = collections.Counter({"test-zone-1": 2, "test-zone-2": 1})
+    zone_of_node = {"first": "test-zone-1", "second": "test-zone-2"}
+    for e in res["existingNodes"]:
+        if e["pods"]:
+            counts[zone_of_node[e["name"]]] += len(e["pods"])
+    for cl in res["newNodeClaims"]:
+        counts[_single(cl, fx.ZONE)] += len(cl["pods"])
+    assert sorted(counts.values()) == [1, 2, 2]
+
+
+def test_spread_selector_corner_cases(oracle, emu):
+    # :448-458 a constraint without a label selector matches nothing (labels.Nothing): the pod simply schedules
+    t = fx.spread(fx.ZONE, LABELS)
+    t["labelSelector"] = None
+    res = solve(oracle, emu, [fx.pod(topology_spread=[t])])
+    assert not res["podErrors"] and len(res["newNodeClaims"]) == 1
+    # :460-483 pods that do not carry the labels their own hostname constraint selects: nothing to spread, one node
+    pods = [fx.pod(topology_spread=[fx.spread(fx.HOSTNAME, LABELS)]) for _ in range(5)]
+    res = solve(oracle, emu, pods)
+    assert len(res["newNodeClaims"]) == 1 and not res["podErrors"]
