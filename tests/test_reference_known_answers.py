@@ -1434,3 +1434,21 @@ def test_spread_selector_corner_cases(oracle, emu):
     pods = [fx.pod(topology_spread=[fx.spread(fx.HOSTNAME, LABELS)]) for _ in range(5)]
     res = solve(oracle, emu, pods)
     assert len(res["newNodeClaims"]) == 1 and not res["podErrors"]
+
+
+def test_hostname_spread_of_several_deployments(oracle, emu):
+    def spread_pod(app, arch=None):
+        lab = {"app": app}
+        return fx.pod(labels=lab, topology_spread=[fx.spread(fx.HOSTNAME, lab)], node_requirements=[fx.req(fx.ARCH, "In", arch)] if arch else None)
+    # topology_test.go:561-573 maxSkew 4: four pods share one host
+    lab = LABELS
+    res = solve(oracle, emu, [fx.pod(labels=lab, topology_spread=[fx.spread(fx.HOSTNAME, lab, max_skew=4)]) for _ in range(4)])
+    assert _claim_skew(res, [], fx.HOSTNAME, selector={}) == [4]
+    # :574-609 two deployments spread over hostnames share the same two nodes
+    pods = [spread_pod("app1"), spread_pod("app1"), spread_pod("app2"), spread_pod("app2")]
+    res = solve(oracle, emu, pods)
+    assert not res["podErrors"] and len(res["newNodeClaims"]) == 2
+    # :610-653 ... unless their architectures differ: four nodes
+    pods = [spread_pod("app1", "amd64"), spread_pod("app1", "amd64"), spread_pod("app2", "arm64"), spread_pod("app2", "arm64")]
+    res = solve(oracle, emu, pods)
+    assert not res["podErrors"] and len(res["newNodeClaims"]) == 4
