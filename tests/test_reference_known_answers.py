@@ -1452,3 +1452,45 @@ def test_hostname_spread_of_several_deployments(oracle, emu):
     pods = [spread_pod("app1", "amd64"), spread_pod("app1", "amd64"), spread_pod("app2", "arm64"), spread_pod("app2", "arm64")]
     res = solve(oracle, emu, pods)
     assert not res["podErrors"] and len(res["newNodeClaims"]) == 4
+
+
+# ---- Capacity-type (and arch) spread across passes: topology_test.go:684-941 ----------------------------------------
+
+def _ct_pods(n, when="DoNotSchedule", requests=RR, **kw):
+    return [fx.pod(labels=LABELS, requests=requests, topology_spread=[fx.spread(fx.CAPACITY_TYPE, LABELS, when=when)], **kw) for _ in range(n)]
+
+
+def test_capacity_type_spread_across_passes(oracle, emu):
+    spot_pool = [fx.node_pool(requirements=[fx.req(fx.CAPACITY_TYPE, "In", "spot")])]
+    od_pool = [fx.node_pool(requirements=[fx.req(fx.CAPACITY_TYPE, "In", "on-demand")])]
+    # :684-717 DoNotSchedule: one spot pod, then an on-demand-only pool: only two more fit under maxSkew 1
+    c = Cluster(oracle, emu, pools=spot_pool)
+    c.provision(_ct_pods(1))
+    c.pools = od_pool
+    res = c.provision(_ct_pods(5))
+    assert c.skew(fx.CAPACITY_TYPE) == [1, 2] and len(res["podErrors"]) == 3
+    # :719-748 ScheduleAnyway: the skew is violated rather than leaving pods pending
+    c = Cluster(oracle, emu, pools=spot_pool)
+    c.provision(_ct_pods(1, when="ScheduleAnyway"))
+    c.pools = od_pool
+    assert not c.provision(_ct_pods(5, when="ScheduleAnyway"))["podErrors"]
+    assert c.skew(fx.CAPACITY_TYPE) == [1, 5]
+    # :818-853 the pods' own required affinity pins them to spot: the constraint only sees the domains they can use
+    c = Cluster(oracle, emu)
+    c.provision([fx.pod(labels=LABELS, node_requirements=[fx.req(fx.ZONE, "In", "test-zone-1"), fx.req(fx.CAPACITY_TYPE, "In", "on-demand")])])
+    pinned = [fx.pod(labels=LABELS, topology_spread=[fx.spread(fx.CAPACITY_TYPE, LABELS)],
+                     node_requirements=[fx.req(fx.ZONE, "In", "test-zone-2"), fx.req(fx.CAPACITY_TYPE, "In", "spot")]) for _ in range(5)]
+    assert not c.provision(pinned)["podErrors"]
+    assert c.skew(fx.CAPACITY_TYPE) == [1, 5]
+    # :855-896 unconstrained pods against a spot-only pool with one on-demand pod in the cluster: 1 / 2
+    c = Cluster(oracle, emu)
+    c.provision([fx.pod(labels=LABELS, node_selector={fx.INSTANCE_TYPE: "single-pod-instance-type"}, node_requirements=[fx.req(fx.CAPACITY_TYPE, "In", "on-demand")])])
+    c.pools = spot_pool
+    res = c.provision(_ct_pods(5, requests={"cpu": "2"}))
+    assert c.skew(fx.CAPACITY_TYPE) == [1, 2] and len(res["podErrors"]) == 3
+    # :898-941 the same on the architecture label
+    c = Cluster(oracle, emu)
+    c.provision([fx.pod(labels=LABELS, node_selector={fx.INSTANCE_TYPE: "single-pod-instance-type"}, node_requirements=[fx.req(fx.ARCH, "In", "amd64")])])
+    c.pools = [fx.node_pool(requirements=[fx.req(fx.ARCH, "In", "arm64")])]
+    res = c.provision([fx.pod(labels=LABELS, requests={"cpu": "2"}, topology_spread=[fx.spread(fx.ARCH, LABELS)]) for _ in range(5)])
+    assert c.skew(fx.ARCH) == [1, 2] and len(res["podErrors"]) == 3
