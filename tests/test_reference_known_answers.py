@@ -1494,3 +1494,30 @@ def test_capacity_type_spread_across_passes(oracle, emu):
     c.pools = [fx.node_pool(requirements=[fx.req(fx.ARCH, "In", "arm64")])]
     res = c.provision([fx.pod(labels=LABELS, requests={"cpu": "2"}, topology_spread=[fx.spread(fx.ARCH, LABELS)]) for _ in range(5)])
     assert c.skew(fx.ARCH) == [1, 2] and len(res["podErrors"]) == 3
+
+
+def test_inverse_anti_affinity_of_bound_pods(oracle, emu):
+    """topology_test.go:2533-2631 — pods already running in every zone repel the label: a new pod carrying it has nowhere
+    to go (the inverse anti-affinity groups are built from the cluster's bound pods, topology.go:310-355); as a mere
+    preference of the running pods it does not bind the newcomer."""
+    def zoned(anti_kw):
+        return [fx.pod(requests={"cpu": "2"}, node_selector={fx.ZONE: f"test-zone-{i}"}, **anti_kw) for i in (1, 2, 3)]
+    c = Cluster(oracle, emu)
+    assert not c.provision(zoned({"pod_anti_requirements": [fx.affinity_term(fx.ZONE, AFF)]}))["podErrors"]
+    newcomer = fx.pod(labels=AFF)
+    res = c.provision([newcomer])
+    assert list(res["podErrors"]) == [newcomer["uid"]]
+    c = Cluster(oracle, emu)
+    assert not c.provision(zoned({"pod_anti_preferences": [fx.weighted(10, fx.affinity_term(fx.ZONE, AFF))]}))["podErrors"]
+    assert not c.provision([fx.pod(labels=AFF)])["podErrors"]
+
+
+def test_self_affinity_first_domain_with_constrained_zones(oracle, emu):
+    # topology_test.go:2082-2124 — the first pod of the set sits in test-zone-1; the others may only use zones 2 and 3, but
+    # hostname self-affinity only ever opens ONE empty domain, and that one exists already: none of them schedules
+    c = Cluster(oracle, emu)
+    term = [fx.affinity_term(fx.HOSTNAME, AFF)]
+    assert not c.provision([fx.pod(labels=AFF, node_selector={fx.ZONE: "test-zone-1"}, pod_requirements=term)])["podErrors"]
+    others = [fx.pod(labels=AFF, node_requirements=[fx.req(fx.ZONE, "In", "test-zone-2", "test-zone-3")], pod_requirements=term) for _ in range(10)]
+    res = c.provision(others)
+    assert len(res["podErrors"]) == 10 and not res["newNodeClaims"]
