@@ -89,3 +89,37 @@ def test_go_shim_names_every_entry_point():
     shim = open(os.path.join(ROOT, "go", "ksolve_shim.go")).read()
     for f in ("ksolve_create", "ksolve_solve", "ksolve_solve_batch", "ksolve_results_free", "ksolve_destroy", "ksolve_cancel"):
         assert "C." + f in shim, f
+
+
+EXAMPLE_OUTPUT = "claims=1 [pods=5 its=0x2 cpu=7500 price=0.40] assignment=00000"
+
+
+def build_example(tmp_path, lib_dir, lib_name):
+    """examples/ksolve_min.c: the C ABI used from plain C (what a cgo shim does), linked against `lib_name` in `lib_dir`."""
+    import subprocess
+    exe = str(tmp_path / ("ksolve_min_" + lib_name))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "ksolve_min.c"), "-o", exe,
+                           "-L", lib_dir, "-l" + lib_name, "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib"])
+    return exe
+
+
+def test_plain_c_example_against_the_emulation(built, tmp_path):
+    """The flat problem description filled in by hand in C — no flattener, no Python — gives the expected packing when the
+    same ABI is served by the test-only host emulation of the solver."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity
+    emu = parity.build_emu()
+    exe = build_example(tmp_path, os.path.dirname(emu), "ksolve_emu")
+    assert subprocess.check_output([exe]).decode().strip() == EXAMPLE_OUTPUT
+
+
+def test_plain_c_example_refuses_without_a_gpu(built, tmp_path):
+    import subprocess
+    from karpenter_amd.scheduling import device_available
+    if device_available():
+        pytest.skip("a GPU is present (tests/test_gpu_parity.py runs the example on it)")
+    exe = build_example(tmp_path, os.path.join(ROOT, "karpenter_amd"), "ksolve")
+    p = subprocess.run([exe], capture_output=True)
+    assert p.returncode == 1 and b"no usable gfx950 device" in p.stderr and not p.stdout

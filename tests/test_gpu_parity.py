@@ -319,3 +319,11 @@ def test_config4_components_and_cluster_sweep(oracle):
     for g, w in zip(got, want):
         assert g["decision"] == w["decision"]
         parity.assert_same_results(g["results"], w["results"])
+
+
+def test_plain_c_example_on_the_device(tmp_path):
+    """examples/ksolve_min.c linked against karpenter_amd/libksolve.so: the C ABI from plain C, no Python in the path."""
+    import subprocess
+    import test_abi
+    exe = test_abi.build_example(tmp_path, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "karpenter_amd"), "ksolve")
+    assert subprocess.check_output([exe]).decode().strip() == test_abi.EXAMPLE_OUTPUT
