@@ -270,7 +270,7 @@ def simulate_scheduling(cluster, candidates, solver):
     # (NewTopology / countDomains read the cluster's bound pods, topology.go:68-103, :361-459)
     staying = [p for n in cluster["nodes"] if n["name"] not in names and not n.get("markedForDeletion") for p in n.get("pods", [])]
     prob = fx.problem(cluster["instanceTypes"], cluster["nodePools"], copy.deepcopy(pods), well_known=cluster.get("wellKnownLabels", fx.KWOK_WELL_KNOWN),
-                      state_nodes=state_nodes, cluster_pods=copy.deepcopy(staying), options=dict(cluster.get("options", {}), consolidationSimulation=True),
+                      state_nodes=state_nodes, cluster_pods=copy.deepcopy(staying), options=dict(cluster.get("options", {}), consolidationSimulation=True, truncateInstanceTypes=max(1, len(cluster["instanceTypes"]))),   # OrderByPrice, nothing cut (consolidation.go:209)
                       namespaces=cluster.get("namespaces"),
                       deleting_node_names=[n["name"] for n in deleting])
     res = solver(prob)
@@ -287,6 +287,53 @@ def simulate_scheduling(cluster, candidates, solver):
     res["podErrors"] = errors
     res["allNonPendingPodsScheduled"] = not [u for u in errors if u not in pending_uids]  # AllNonPendingPodsScheduled, scheduler.go:388-392
     return res
+
+
+MIN_INSTANCE_TYPES_FOR_SPOT_TO_SPOT = 15      # consolidation.go:46
+
+
+def _min_types_for_min_values(names, reqs, by_name):
+    """InstanceTypes.SatisfiesMinValues (types.go:399-433): the length of the shortest prefix of `names` whose instance
+    types carry at least minValues distinct values for every key that asks for them, and whether the whole list does."""
+    wanted = {k: q["minValues"] for k, q in reqs.items() if q.get("minValues")}
+    if not wanted:
+        return 0, True
+    seen = {k: set() for k in wanted}
+    for i, n in enumerate(names):
+        for r in by_name[n]["requirements"]:
+            if r["key"] in wanted and r["operator"] == "In":
+                seen[r["key"]].update(v for v in r["values"] if _req_has(reqs[r["key"]], v))
+        if all(len(seen[k]) >= wanted[k] for k in wanted):
+            return i + 1, True
+    return len(names), False
+
+
+def _spot_to_spot(cluster, candidates, cmd, claim, reqs, price, by_name):
+    """computeSpotToSpotConsolidation (consolidation.go:261-342). The claim's instance types arrive in OrderByPrice order
+    (simulate_scheduling asks Solve() for it): pin the claim to spot, keep the types with a compatible available offering,
+    keep the cheaper ones; several candidates may then be replaced by whatever is left, a single candidate only if at
+    least 15 cheaper types remain, of which the 15 cheapest (more if minValues needs more) are launched — so that the
+    node that comes up is among them and is not consolidated again at once."""
+    if not cluster.get("options", {}).get("spotToSpotConsolidation"):
+        return cmd                                                       # feature gate off (the default)
+    reqs = dict(reqs)
+    old = reqs.get(fx.CAPACITY_TYPE) or {}
+    reqs[fx.CAPACITY_TYPE] = {"key": fx.CAPACITY_TYPE, "complement": False, "values": ["spot"], "gte": None, "lte": None, "minValues": old.get("minValues")}
+    compatible = [n for n in claim["instanceTypes"] if any(o.get("available", True) and _offering_compatible(reqs, o) for o in by_name[n]["offerings"])]
+    cheaper = [n for n in compatible if worst_launch_price(by_name[n], reqs) < price]
+    need, ok = _min_types_for_min_values(cheaper, reqs, by_name)
+    if not cheaper or not ok:
+        return cmd
+    if len(candidates) == 1:
+        if len(cheaper) < MIN_INSTANCE_TYPES_FOR_SPOT_TO_SPOT:
+            cmd["reason"] = f"SpotToSpotConsolidation requires {MIN_INSTANCE_TYPES_FOR_SPOT_TO_SPOT} cheaper instance type options than the current candidate to consolidate, got {len(cheaper)}"
+            return cmd
+        cheaper = cheaper[: max(MIN_INSTANCE_TYPES_FOR_SPOT_TO_SPOT, need)]
+    cmd["decision"] = REPLACE
+    cmd["replacement"] = sorted(cheaper)
+    cmd["replacementInPriceOrder"] = cheaper
+    cmd["replacementCapacityType"] = "spot"
+    return cmd
 
 
 def compute_consolidation(cluster, candidates, solver):
@@ -306,9 +353,9 @@ def compute_consolidation(cluster, candidates, solver):
     reqs = {r["key"]: r for r in claim["requirements"]}
     all_spot = all(c["labels"][fx.CAPACITY_TYPE] == "spot" for c in candidates)
     ct = reqs.get(fx.CAPACITY_TYPE)
-    if all_spot and (ct is None or _req_has(ct, "spot")):
-        return cmd  # SpotToSpotConsolidation feature gate is off by default (consolidation.go:261-270)
     by_name = {t["name"]: t for t in cluster["instanceTypes"]}
+    if all_spot and (ct is None or _req_has(ct, "spot")):
+        return _spot_to_spot(cluster, candidates, cmd, claim, reqs, price, by_name)
     cheaper = [n for n in claim["instanceTypes"] if worst_launch_price(by_name[n], reqs) < price]   # nodeclaim.go:411-420
     if not cheaper:
         return cmd

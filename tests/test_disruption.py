@@ -263,3 +263,65 @@ def test_sweep_on_a_large_cluster(oracle, emu):
     for g, w in zip(got, want):
         parity.assert_same_results(g["results"], w["results"])
     assert any(c["decision"] != dz.NOOP for c in got)
+
+
+# ---- spot-to-spot consolidation: consolidation_test.go:1005-1250, consolidation.go:261-342 --------------------------
+
+def _spot_cluster(its, node_type, n_nodes=1, gate=True):
+    off = next(o for o in node_type["offerings"] if dz._capacity_type(o) == "spot")
+    zone = [r["values"][0] for r in off["requirements"] if r["key"] == fx.ZONE][0]
+    nodes = [_node_with_pods(f"spot-{i}", node_type, zone, "spot", ["100m"]) for i in range(n_nodes)]
+    return {"instanceTypes": its, "nodePools": [fx.node_pool()], "nodes": nodes, "pendingPods": [], "options": {"spotToSpotConsolidation": gate}}, nodes
+
+
+def _spot_price(t):
+    return min([o["price"] for o in t["offerings"] if dz._capacity_type(o) == "spot"], default=None)
+
+
+def test_spot_to_spot_replacement(oracle, emu):
+    its = fx.fake_instance_types_assorted()
+    spot_types = [t for t in its if _spot_price(t) is not None]
+    priciest = max(spot_types, key=_spot_price)
+    # :1005-1058 (spot entry) — the most expensive spot node is replaced by the 15 cheapest spot types
+    cluster, nodes = _spot_cluster(its, priciest)
+    for solver in _solvers(oracle, emu):
+        cmd = dz.compute_consolidation(cluster, nodes, solver)
+        assert cmd["decision"] == dz.REPLACE and len(cmd["replacement"]) == dz.MIN_INSTANCE_TYPES_FOR_SPOT_TO_SPOT and cmd["replacementCapacityType"] == "spot"
+        assert priciest["name"] not in cmd["replacement"]
+        prices = [_spot_price(next(t for t in its if t["name"] == n)) for n in cmd["replacementInPriceOrder"]]
+        assert prices == sorted(prices) and max(prices) <= min(_spot_price(t) for t in spot_types if t["name"] not in cmd["replacement"])
+    # :1136-1175 — the feature gate is off: a spot node is never replaced by a spot node
+    cluster_off, nodes_off = _spot_cluster(its, priciest, gate=False)
+    for solver in _solvers(oracle, emu):
+        assert dz.compute_consolidation(cluster_off, nodes_off, solver)["decision"] == dz.NOOP
+    # :3982-4028 (spot entry) — several spot nodes merge without the 15-type rule
+    cluster3, nodes3 = _spot_cluster(its, priciest, n_nodes=3)
+    for solver in _solvers(oracle, emu):
+        cmd, _ = dz.first_n_consolidation_option(cluster3, nodes3, solver)
+        assert cmd["decision"] == dz.REPLACE and len(cmd["candidates"]) == 3 and len(cmd["replacement"]) > dz.MIN_INSTANCE_TYPES_FOR_SPOT_TO_SPOT
+
+
+def test_spot_to_spot_needs_fifteen_cheaper_types(oracle, emu):
+    import copy
+    # :1061-1134 — five instance types in all, one made very cheap: a single cheaper option is not enough flexibility
+    its = copy.deepcopy(fx.fake_instance_types_assorted()[:5])
+    its[0]["offerings"][0]["price"] = 0.001
+    for r in its[0]["offerings"][0]["requirements"]:
+        if r["key"] == fx.CAPACITY_TYPE:
+            r["values"] = ["spot"]
+    for r in its[0]["requirements"]:
+        if r["key"] == fx.CAPACITY_TYPE and "spot" not in r["values"]:
+            r["values"].append("spot")
+    spot_types = sorted([t for t in its if _spot_price(t) is not None], key=_spot_price)
+    cluster, nodes = _spot_cluster(its, spot_types[-1])
+    for solver in _solvers(oracle, emu):
+        cmd = dz.compute_consolidation(cluster, nodes, solver)
+        assert cmd["decision"] == dz.NOOP and "requires 15 cheaper instance type options" in cmd.get("reason", "")
+    # :1177-1245 — twenty types; the node's type is the second cheapest spot type, i.e. among the 15 cheapest: nothing to do
+    its = copy.deepcopy(fx.fake_instance_types_assorted()[:20])
+    its[0]["offerings"][0]["price"] = 0.001
+    spot_types = sorted([t for t in its if _spot_price(t) is not None], key=_spot_price)
+    if len(spot_types) >= 2:
+        cluster, nodes = _spot_cluster(its, spot_types[1])
+        for solver in _solvers(oracle, emu):
+            assert dz.compute_consolidation(cluster, nodes, solver)["decision"] == dz.NOOP
