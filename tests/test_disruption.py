@@ -325,3 +325,42 @@ def test_spot_to_spot_needs_fifteen_cheaper_types(oracle, emu):
         cluster, nodes = _spot_cluster(its, spot_types[1])
         for solver in _solvers(oracle, emu):
             assert dz.compute_consolidation(cluster, nodes, solver)["decision"] == dz.NOOP
+
+
+def test_consolidation_ignoring_preferences(oracle, emu):
+    """consolidation_test.go:4952-5062 — with PreferencePolicy=Ignore the simulation does not honour preferred
+    anti-affinity (the pod moves next to its peers: DELETE) or a preferred instance type (the node is REPLACED by a
+    cheaper one); with the default policy the same clusters stay as they are / replace onto the preferred type only."""
+    its = fx.fake_instance_types_assorted()
+    cheapest = min(its, key=lambda t: min(o["price"] for o in t["offerings"] if dz._capacity_type(o) == "on-demand") if any(dz._capacity_type(o) == "on-demand" for o in t["offerings"]) else 1e9)
+    five = next(t for t in its if t["capacity"]["cpu"] == "8" and any(dz._capacity_type(o) == "on-demand" for o in t["offerings"]))
+    zone = [r["values"][0] for o in five["offerings"] if dz._capacity_type(o) == "on-demand" for r in o["requirements"] if r["key"] == fx.ZONE][0]
+    lab = {"app": "foo"}
+    anti = [fx.weighted(1, fx.affinity_term(fx.HOSTNAME, lab))]
+
+    def node(name, n_pods):
+        pods = [fx.pod(labels=lab, requests={"cpu": "100m"}, pod_anti_preferences=anti, phase="Running", node_name=name) for _ in range(n_pods)]
+        n = fx.state_node(name, five, zone, "on-demand", "default", used={"cpu": f"{100 * n_pods}m", "pods": str(n_pods)})
+        n["pods"] = pods
+        return n
+    for policy, want in (("Ignore", dz.DELETE), ("Respect", dz.REPLACE)):
+        n0, n1 = node("node-0", 2), node("node-1", 1)
+        cluster = {"instanceTypes": its, "nodePools": [fx.node_pool()], "nodes": [n0, n1], "pendingPods": [], "options": {"preferencePolicy": policy}}
+        for solver in _solvers(oracle, emu):
+            cmd = dz.compute_consolidation(cluster, [n1], solver)
+            # Ignore: the preference is dropped before scheduling and the pod joins node-0. Respect: the preferred
+            # anti-affinity keeps it off node-0 first, so it gets a node of its own — a cheaper one
+            assert cmd["decision"] == want, (policy, cmd["decision"])
+    # :5017-5062 a pod that merely prefers the most expensive type does not pin the node to it
+    priciest, off = max(((t, o) for t in its for o in t["offerings"] if dz._capacity_type(o) == "on-demand"), key=lambda x: x[1]["price"])
+    pzone = [r["values"][0] for r in off["requirements"] if r["key"] == fx.ZONE][0]
+    pod = fx.pod(labels=lab, requests={"cpu": "100m"}, node_preferences=[fx.req(fx.INSTANCE_TYPE, "In", priciest["name"])], phase="Running", node_name="big")
+    big = fx.state_node("big", priciest, pzone, "on-demand", "default", used={"cpu": "100m", "pods": "1"})
+    big["pods"] = [pod]
+    cluster = {"instanceTypes": its, "nodePools": [fx.node_pool()], "nodes": [big], "pendingPods": [], "options": {"preferencePolicy": "Ignore"}}
+    for solver in _solvers(oracle, emu):
+        cmd = dz.compute_consolidation(cluster, [big], solver)
+        assert cmd["decision"] == dz.REPLACE and priciest["name"] not in cmd["replacement"]
+    cluster["options"] = {"preferencePolicy": "Respect"}
+    for solver in _solvers(oracle, emu):
+        assert dz.compute_consolidation(cluster, [big], solver)["decision"] == dz.NOOP      # the only acceptable type is the current one
