@@ -293,7 +293,7 @@ def test_cancel_stops_a_running_solve():
     th.join()
     elapsed = time.time() - t0
     r = out["r"]
-    assert r["timedOut"] and 0 < r["scheduledPods"] < n
+    assert r["timedOut"] and 0 <= r["scheduledPods"] < n      # 0 when the cancel lands before the pack loop placed its first block
     assert elapsed < 4.0, f"a cancelled 1M-pod solve took {elapsed:.1f}s: the flag was not seen by the running kernel"
     full = s.Solve(want_results=False)
     assert not full["timedOut"] and full["scheduledPods"] == n
