@@ -364,3 +364,50 @@ def test_consolidation_ignoring_preferences(oracle, emu):
     cluster["options"] = {"preferencePolicy": "Respect"}
     for solver in _solvers(oracle, emu):
         assert dz.compute_consolidation(cluster, [big], solver)["decision"] == dz.NOOP      # the only acceptable type is the current one
+
+
+def test_consolidation_into_reserved_capacity(oracle, emu):
+    """consolidation_test.go:4778-4949 — with the ReservedCapacity gate a node moves into a (much cheaper) reserved
+    offering: from on-demand / spot into the reservation of its own instance type, and from one reservation to the
+    reservation of the cheapest type."""
+    import copy
+    base = fx.fake_instance_types_assorted()
+
+    def with_reservation(its, t):
+        t = next(x for x in its if x["name"] == t["name"])
+        off = t["offerings"][0]
+        zone = [r["values"][0] for r in off["requirements"] if r["key"] == fx.ZONE][0]
+        for r in t["requirements"]:
+            if r["key"] == fx.CAPACITY_TYPE and "reserved" not in r["values"]:
+                r["values"].append("reserved")
+        t["offerings"].append(fx.offering("reserved", zone, off["price"] / 1_000_000.0, reservation_id="r-" + t["name"], reservation_capacity=10))
+        return zone
+
+    def od_price(t):
+        return min([o["price"] for o in t["offerings"] if dz._capacity_type(o) == "on-demand"], default=None)
+    od_types = [t for t in base if od_price(t) is not None]
+    priciest, cheapest = max(od_types, key=od_price), min(od_types, key=od_price)
+    # from on-demand into the reservation of the same (most expensive) instance type
+    its = copy.deepcopy(base)
+    zone = with_reservation(its, priciest)
+    p_it = next(t for t in its if t["name"] == priciest["name"])
+    node = _node_with_pods("od-node", p_it, zone, "on-demand", ["100m"])
+    cluster = {"instanceTypes": its, "nodePools": [fx.node_pool()], "nodes": [node], "pendingPods": [], "options": {"reservedCapacity": True},
+               "wellKnownLabels": fx.FAKE_WELL_KNOWN}       # the fake provider registers the reservation id label as well-known (fake/cloudprovider.go:44)
+    for solver in _solvers(oracle, emu):
+        cmd = dz.compute_consolidation(cluster, [node], solver)
+        claim = cmd["results"]["newNodeClaims"][0]
+        assert cmd["decision"] == dz.REPLACE and claim["reservedOfferings"] == ["r-" + priciest["name"]]
+        assert [q["values"] for q in claim["requirements"] if q["key"] == fx.CAPACITY_TYPE] == [["reserved"]]
+        assert cmd["replacement"] == [priciest["name"]]
+    # from that reservation into the reservation of the cheapest type
+    its = copy.deepcopy(base)
+    zone = with_reservation(its, priciest)
+    with_reservation(its, cheapest)
+    p_it = next(t for t in its if t["name"] == priciest["name"])
+    node = _node_with_pods("reserved-node", p_it, zone, "reserved", ["100m"], extra_labels={"karpenter.sh/reservation-id": "r-" + priciest["name"]})
+    cluster = {"instanceTypes": its, "nodePools": [fx.node_pool()], "nodes": [node], "pendingPods": [], "options": {"reservedCapacity": True},
+               "wellKnownLabels": fx.FAKE_WELL_KNOWN}
+    for solver in _solvers(oracle, emu):
+        cmd = dz.compute_consolidation(cluster, [node], solver)
+        assert cmd["decision"] == dz.REPLACE and cheapest["name"] in cmd["replacement"] and priciest["name"] not in cmd["replacement"]
