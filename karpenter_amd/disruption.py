@@ -357,6 +357,9 @@ def compute_consolidation(cluster, candidates, solver):
     if all_spot and (ct is None or _req_has(ct, "spot")):
         return _spot_to_spot(cluster, candidates, cmd, claim, reqs, price, by_name)
     cheaper = [n for n in claim["instanceTypes"] if worst_launch_price(by_name[n], reqs) < price]   # nodeclaim.go:411-420
+    if not _min_types_for_min_values(cheaper, reqs, by_name)[1]:
+        cmd["reason"] = "minValues requirement is not met after filtering by price"                # SatisfiesMinValues, nodeclaim.go:416-418
+        return cmd
     if not cheaper:
         return cmd
     cmd["decision"] = REPLACE

@@ -411,3 +411,30 @@ def test_consolidation_into_reserved_capacity(oracle, emu):
     for solver in _solvers(oracle, emu):
         cmd = dz.compute_consolidation(cluster, [node], solver)
         assert cmd["decision"] == dz.REPLACE and cheapest["name"] in cmd["replacement"] and priciest["name"] not in cmd["replacement"]
+
+
+def test_consolidation_respects_min_values_after_the_price_filter(oracle, emu):
+    """consolidation_test.go:5064-5145 — two instance types, the NodePool wants three (BestEffort relaxes that to two for the
+    simulation); dropping the current, more expensive type leaves one: the replacement would break minValues, so nothing
+    happens (RemoveInstanceTypeOptionsByPriceAndMinValues, nodeclaim.go:411-420)."""
+    its_all = fx.fake_instance_types_assorted()
+    def od(t):
+        return min([o["price"] for o in t["offerings"] if dz._capacity_type(o) == "on-demand"], default=None)
+    od_types = [t for t in its_all if od(t) is not None]
+    cheap, pricey = min(od_types, key=od), max(od_types, key=od)
+    its = [cheap, pricey]
+    pool = fx.node_pool(weight=100, requirements=[fx.req(fx.INSTANCE_TYPE, "In", cheap["name"], pricey["name"], "a-third-type", min_values=3)])
+    zone = [r["values"][0] for o in pricey["offerings"] if dz._capacity_type(o) == "on-demand" for r in o["requirements"] if r["key"] == fx.ZONE][0]
+    node = _node_with_pods("node-0", pricey, zone, "on-demand", ["100m"])
+    for policy in ("BestEffort", "Strict"):
+        cluster = {"instanceTypes": its, "nodePools": [pool], "nodes": [node], "pendingPods": [], "options": {"minValuesPolicy": policy}, "wellKnownLabels": fx.FAKE_WELL_KNOWN}
+        for solver in _solvers(oracle, emu):
+            cmd = dz.compute_consolidation(cluster, [node], solver)
+            assert cmd["decision"] == dz.NOOP
+            if policy == "BestEffort":
+                assert len(cmd["results"]["newNodeClaims"]) == 1 and "minValues" in cmd.get("reason", "")
+    # without minValues the same node is simply replaced by the cheap type
+    cluster = {"instanceTypes": its, "nodePools": [fx.node_pool()], "nodes": [node], "pendingPods": [], "wellKnownLabels": fx.FAKE_WELL_KNOWN}
+    for solver in _solvers(oracle, emu):
+        cmd = dz.compute_consolidation(cluster, [node], solver)
+        assert cmd["decision"] == dz.REPLACE and cmd["replacement"] == [cheap["name"]]
