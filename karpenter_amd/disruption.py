@@ -256,6 +256,26 @@ def sort_candidates(cluster, nodes):
     return sorted(nodes, key=lambda n: (-savings_ratio(cluster, n), n["name"]))
 
 
+def interweave_by_nodepool(candidates, previously_unseen=()):
+    """SingleNodeConsolidation.SortCandidates' second step (singlenodeconsolidation.go:141-172): the ratio-sorted list is
+    dealt out round-robin over the NodePools, so that one pool's long list cannot starve the others within the time
+    budget; pools that a timed-out earlier run never reached go first. (Among the remaining pools the reference follows
+    Go's map order, i.e. any; here: order of first appearance in the sorted list.)"""
+    by_pool, order = {}, [p for p in previously_unseen]
+    for c in candidates:
+        name = _pool_name(c)
+        by_pool.setdefault(name, []).append(c)
+        if name not in order:
+            order.append(name)
+    order = [p for p in order if p in by_pool]
+    out = []
+    for i in range(max((len(v) for v in by_pool.values()), default=0)):
+        for name in order:
+            if i < len(by_pool[name]):
+                out.append(by_pool[name][i])
+    return out
+
+
 def simulate_scheduling(cluster, candidates, solver):
     """helpers.go:53-155: Solve() with the candidates removed and their pods added to the pending set."""
     names = {c["name"] for c in candidates}

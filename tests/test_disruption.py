@@ -438,3 +438,26 @@ def test_consolidation_respects_min_values_after_the_price_filter(oracle, emu):
     for solver in _solvers(oracle, emu):
         cmd = dz.compute_consolidation(cluster, [node], solver)
         assert cmd["decision"] == dz.REPLACE and cmd["replacement"] == [cheap["name"]]
+
+
+def test_single_node_candidate_order(oracle):
+    """singlenodeconsolidation_test.go:104-170 — candidates sorted by savings ratio, then dealt out over the NodePools;
+    a pool that an earlier, timed-out run did not reach comes first."""
+    its = fx.fake_default_instance_types()
+    it = {t["name"]: t for t in its}["default-instance-type"]
+    pools = [fx.node_pool(f"nodepool-{i}") for i in (1, 2, 3)]
+    nodes = []
+    for pi, pool in enumerate(pools):
+        for k, n_pods in enumerate((0, 4, 19)):          # disruption cost 1, 5, 20 -> three distinct savings ratios per pool
+            nodes.append(_node_with_pods(f"{pool['name']}-n{k}", it, "test-zone-1", "on-demand", ["10m"] * n_pods, pool=pool["name"]))
+    cluster = {"instanceTypes": its, "nodePools": pools, "nodes": nodes, "pendingPods": []}
+    ranked = dz.sort_candidates(cluster, list(reversed(nodes)))
+    costs = [dz.reschedule_disruption_cost(n["pods"]) for n in ranked]
+    assert costs == [1.0] * 3 + [5.0] * 3 + [20.0] * 3                                        # :130-170
+    ratios = [dz.savings_ratio(cluster, n) for n in ranked]
+    assert ratios == sorted(ratios, reverse=True)                                             # :104-117
+    woven = dz.interweave_by_nodepool(ranked)
+    assert [dz._pool_name(n) for n in woven[:3]] == sorted({p["name"] for p in pools}) and len(woven) == 9
+    assert [dz._pool_name(n) for n in woven] == [dz._pool_name(n) for n in woven[:3]] * 3      # round robin
+    first = dz.interweave_by_nodepool(ranked, previously_unseen=["nodepool-2"])
+    assert dz._pool_name(first[0]) == "nodepool-2" and len(first) == 9                        # :119-128
