@@ -123,3 +123,18 @@ def test_plain_c_example_refuses_without_a_gpu(built, tmp_path):
     exe = build_example(tmp_path, os.path.join(ROOT, "karpenter_amd"), "ksolve")
     p = subprocess.run([exe], capture_output=True)
     assert p.returncode == 1 and b"no usable gfx950 device" in p.stderr and not p.stdout
+
+
+def test_only_tests_smoke_and_bench_touch_the_oracle():
+    """oracle/ is the checker: besides tests/, only __graft_entry__ (build + smoke) and bench.py (cpu_baseline) may import it."""
+    allowed = {os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")}
+    bad = []
+    for dp, dirs, files in os.walk(ROOT):
+        dirs[:] = [d for d in dirs if d not in (".git", "__pycache__", "gpurun_out", "oracle", "tests")]
+        for f in files:
+            path = os.path.join(dp, f)
+            if f.endswith((".py", ".sh")) and path not in allowed:
+                text = open(path, errors="ignore").read()
+                if re.search(r"^\s*(import|from)\s+oracle\b", text, re.M) or re.search(r"\bimport\s+[\w, ]*\boracle\b", text) or "liboracle" in text:
+                    bad.append(os.path.relpath(path, ROOT))
+    assert not bad, bad

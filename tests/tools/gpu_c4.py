@@ -1,6 +1,6 @@
 """BASELINE configs[3] / configs[4] shapes on the device against the oracle (small sizes, a few seconds)."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 t0 = time.time()
 import oracle, parity
 from karpenter_amd import fixtures as fx, disruption as dz

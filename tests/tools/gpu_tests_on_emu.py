@@ -2,7 +2,7 @@
 the TESTS (fixtures, expectations, sizes) on a machine without a GPU, so that a red GPU run at round end means the
 device and not the test. Not part of the product or of the pytest suites."""
 import sys, os, inspect, time, traceback
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); os.chdir(ROOT)
 import parity, oracle
 oracle.build()
