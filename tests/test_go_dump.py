@@ -177,3 +177,16 @@ def test_init_containers_and_limit_defaulting_known_answers(oracle, emu):
     assert outcome(daemon({"containers": [{"resources": {"limits": {"cpu": "10000", "memory": "10000Gi"}}}]})) is None
     # :1135-1141 nothing defined at all: schedules on the smallest type
     assert outcome(daemon({"containers": [{}]})) == "small-instance-type"
+
+
+def test_pod_overhead_from_the_runtime_class(oracle, emu):
+    """suite_test.go:1546-1573 — a RuntimeClass overhead of 2 cpu (admission copies it into pod.spec.overhead) on a 1-cpu pod
+    needs 3 cpu: the small type no longer fits."""
+    its = fx.fake_default_instance_types()
+    spec = {"containers": [{"resources": {"requests": {"cpu": "1"}}}], "overhead": {"cpu": "2"}}
+    for requests, want in ((from_go.pod_requests(spec), "default-instance-type"), (from_go.pod_requests({"containers": spec["containers"]}), "small-instance-type")):
+        prob = fx.problem(its, [fx.node_pool()], [fx.pod(requests=requests)])
+        res = oracle.solve(prob)
+        parity.assert_same_results(NewScheduler(prob, solver_lib=emu).Solve(), res)
+        by = {t["name"]: t for t in its}
+        assert min(res["newNodeClaims"][0]["instanceTypes"], key=lambda n: min(o["price"] for o in by[n]["offerings"])) == want
