@@ -1521,3 +1521,25 @@ def test_self_affinity_first_domain_with_constrained_zones(oracle, emu):
     others = [fx.pod(labels=AFF, node_requirements=[fx.req(fx.ZONE, "In", "test-zone-2", "test-zone-3")], pod_requirements=term) for _ in range(10)]
     res = c.provision(others)
     assert len(res["podErrors"]) == 10 and not res["newNodeClaims"]
+
+
+def test_daemonset_overhead_on_an_existing_node_without_the_domain(oracle, emu):
+    """suite_test.go:2729-2785 — a huge daemonset that requires test-zone-1 is not held against an existing node that has no
+    zone label (not strictly compatible): the pod fits the node. A second pod needs a new node, where the daemonset does
+    count and leaves no room on any instance type."""
+    node = bare_node("existing", cpu="1", memory="1Gi")
+    node["daemonSetRequests"] = {}
+    ds = fx.pod(requests={"cpu": "100", "memory": "100Gi"}, node_requirements=[fx.req(fx.ZONE, "In", "test-zone-1")])
+    pod = lambda: fx.pod(requests={"cpu": "1", "memory": "1Gi"})
+    its = fx.fake_default_instance_types()
+
+    def run(pods, nodes):
+        prob = fx.problem(its, [fx.node_pool()], pods, state_nodes=nodes, daemonset_pods=[ds])
+        want = oracle.solve(prob)
+        parity.assert_same_results(NewScheduler(prob, solver_lib=emu).Solve(), want)
+        return want
+    res = run([pod()], [node])
+    assert not res["newNodeClaims"] and not res["podErrors"] and [e["name"] for e in res["existingNodes"] if e["pods"]] == ["existing"]
+    full = bare_node("existing", cpu="0", memory="0")            # the node is now full
+    res = run([pod()], [full])
+    assert len(res["podErrors"]) == 1 and not res["newNodeClaims"]
