@@ -648,6 +648,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       namespace_lister.push_back({nv.at("name").s(), labels});
     }
     t_namespace_lister = &namespace_lister;   // read by parse_aff_term for every pod parsed below (this thread only)
+    struct ListerScope { ~ListerScope() { t_namespace_lister = nullptr; } } lister_scope;   // never leave it pointing at this frame
     struct Row { int spec; };  // index into specs
     std::vector<PodSpec> specs;           // distinct pod templates (each explicit pod is its own spec)
     std::vector<int> pod_spec;            // per pod -> spec
