@@ -224,9 +224,19 @@ def ToNodeClaim(claim: dict, problem: dict, max_instance_types: int = MAX_INSTAN
     well_known = set(problem.get("wellKnownLabels", [])) | _WELL_KNOWN_LABELS
     labels = {}
     for k, q in reqs.items():
-        if k in well_known or k == "kubernetes.io/hostname" or k in _SIMULATION_KEYS or q["complement"] or not q["values"]:   # WellKnown / Restricted / simulation keys
+        if k in well_known or k == "kubernetes.io/hostname" or k in _SIMULATION_KEYS:   # WellKnown / Restricted / simulation keys
             continue
-        labels[k] = sorted(q["values"])[0]            # Requirement.Any(): a single concrete value is the interesting case
+        if not q["complement"]:
+            if q["values"]:
+                labels[k] = sorted(q["values"])[0]    # Requirement.Any() of an In requirement: one of its values (requirement.go:256-259)
+            continue                                  # DoesNotExist: no label
+        # NotIn / Exists (possibly with Gt / Lt bounds): the reference draws a random integer inside the bounds
+        # (requirement.go:260-269); any admissible value is a faithful answer — take the smallest one
+        v = q["gte"] if q.get("gte") is not None else 0
+        while str(v) in q["values"]:
+            v += 1
+        if q.get("lte") is None or v <= q["lte"]:
+            labels[k] = str(v)
     out = [q for k, q in sorted(reqs.items()) if k not in _SIMULATION_KEYS]
     return {"requirements": out, "labels": labels, "instanceTypes": names}
 

@@ -1543,3 +1543,25 @@ def test_daemonset_overhead_on_an_existing_node_without_the_domain(oracle, emu):
     full = bare_node("existing", cpu="0", memory="0")            # the node is now full
     res = run([pod()], [full])
     assert len(res["podErrors"]) == 1 and not res["newNodeClaims"]
+
+
+def test_node_labels_from_nodepool_requirements(oracle, emu):
+    """pkg/controllers/provisioning/suite_test.go:1546-1642 — the labels a launched node gets from its NodePool's template
+    labels and custom requirements (ToNodeClaim / resolveCustomLabelsFromRequirements)."""
+    its = fx.fake_default_instance_types()
+    pool = fx.node_pool(labels={"test-key-1": "test-value-1"}, requirements=[
+        fx.req("test-key-2", "In", "test-value-2"), fx.req("test-key-3", "NotIn", "test-value-3"), fx.req("test-key-4", "Lt", "4"),
+        fx.req("test-key-5", "Gt", "5"), fx.req("test-key-6", "Exists"), fx.req("test-key-7", "DoesNotExist")])
+    res = solve(oracle, emu, [fx.pod()], pools=[pool], its=its)
+    wire = ToNodeClaim(res["newNodeClaims"][0], fx.problem(its, [pool], []))
+    lab = wire["labels"]
+    assert res["newNodeClaims"][0]["nodePool"] == "default"
+    assert lab["test-key-1"] == "test-value-1" and lab["test-key-2"] == "test-value-2"
+    assert "test-key-3" in lab and lab["test-key-3"] != "test-value-3"
+    assert int(lab["test-key-4"]) < 4 and int(lab["test-key-5"]) > 5
+    assert "test-key-6" in lab and "test-key-7" not in lab
+    # :1613-1641 well-known labels never come from requirements; custom ones do
+    pool = fx.node_pool(requirements=[fx.req("foo", "In", "bar"), fx.req("node.kubernetes.io/windows-build", "NotIn", "test-value")])
+    res = solve(oracle, emu, [fx.pod()], pools=[pool], its=its)
+    lab = ToNodeClaim(res["newNodeClaims"][0], fx.problem(its, [pool], []))["labels"]
+    assert lab.get("foo") == "bar" and "node.kubernetes.io/windows-build" not in lab
