@@ -65,6 +65,9 @@ struct Offering {
   double price = 0;
   bool available = true;
   int reservation_capacity = 0;
+  ResourceList capacity_override;            // Offering.CapacityOverride (types.go:484)
+  bool has_overhead_override = false;        // Offering.OverheadOverride != nil
+  ResourceList overhead_override;            // ... its Total()
   std::string capacity_type() const { return reqs.get(kCapacityTypeLabel).any(); }  // types.go:532
   std::string zone() const { return reqs.get(kLabelZone).any(); }                    // types.go:536
   std::string reservation_id() const { return reqs.get(kReservationIDLabel).any(); } // types.go:540
@@ -77,25 +80,53 @@ struct InstanceType {
   Requirements reqs;
   std::vector<Offering> offerings;
   ResourceList capacity, overhead;
-  std::vector<AllocatableOfferings> groups;  // AllocatableOfferingsList (types.go:325), base group only
+  std::vector<AllocatableOfferings> groups;  // AllocatableOfferingsList (types.go:325): base group first
   int catalog_index = 0;
 
-  // precompute / computeAllocatable — types.go:202-220, 271-294 (no CapacityOverride/OverheadOverride offerings:
-  // the problem format rejects them, so there is exactly the base group)
-  void precompute() {
-    AllocatableOfferings g;
-    g.allocatable = res_subtract(capacity, overhead);
-    for (auto& kv : capacity) {
+  // computeAllocatable — types.go:271-294: lo.Assign replaces whole keys, then capacity - overhead, then the hugepage
+  // reservation comes off memory (never below zero)
+  ResourceList compute_allocatable(const ResourceList* cap_ov, const ResourceList* oh_ov) const {
+    ResourceList cap = capacity, oh = overhead;
+    if (cap_ov && !cap_ov->empty()) for (auto& kv : *cap_ov) cap[kv.first] = kv.second;
+    if (oh_ov) for (auto& kv : *oh_ov) oh[kv.first] = kv.second;
+    ResourceList a = res_subtract(cap, oh);
+    for (auto& kv : cap) {
       if (kv.first.rfind("hugepages-", 0) == 0) {
-        i128 cur = g.allocatable.count("memory") ? g.allocatable["memory"] : 0;
+        i128 cur = a.count("memory") ? a["memory"] : 0;
         cur -= kv.second;
         if (cur < 0) cur = 0;
-        g.allocatable["memory"] = cur;
+        a["memory"] = cur;
       }
     }
-    for (auto& o : offerings) if (o.available) g.offerings.push_back(&o);
+    return a;
+  }
+
+  // precompute / groupOfferingsByOverride — types.go:202-269. Available offerings are grouped by their
+  // (CapacityOverride, OverheadOverride) pair in first-seen order behind the base group; every group gets its own
+  // allocatable. (Go keys the groups on the printed override; equal values printed differently would make two groups
+  // with the same allocatable, which fits() — the only reader, nodeclaim.go:624-638 — cannot tell from one.)
+  void precompute() {
     groups.clear();
-    groups.push_back(g);
+    AllocatableOfferings base;
+    base.allocatable = compute_allocatable(nullptr, nullptr);
+    groups.push_back(base);
+    std::vector<const Offering*> first;   // the offering whose overrides define group i (nullptr for the base)
+    first.push_back(nullptr);
+    for (auto& o : offerings) {
+      if (!o.available) continue;
+      if (o.capacity_override.empty() && !o.has_overhead_override) { groups[0].offerings.push_back(&o); continue; }
+      size_t g = 1;
+      for (; g < groups.size(); ++g)
+        if (first[g]->capacity_override == o.capacity_override && first[g]->has_overhead_override == o.has_overhead_override &&
+            first[g]->overhead_override == o.overhead_override) break;
+      if (g == groups.size()) {
+        AllocatableOfferings ng;
+        ng.allocatable = compute_allocatable(&o.capacity_override, o.has_overhead_override ? &o.overhead_override : nullptr);
+        groups.push_back(ng);
+        first.push_back(&o);
+      }
+      groups[g].offerings.push_back(&o);
+    }
   }
 };
 
@@ -316,7 +347,8 @@ inline Problem parse_problem(const oj::Value& root) {
       off.price = of.at("price").d();
       off.available = of.at("available").boolean_or(true);
       off.reservation_capacity = (int)of.at("reservationCapacity").i(0);
-      if (of.has("capacityOverride") || of.has("overheadOverride")) throw std::runtime_error("offering overrides unsupported");
+      if (of.has("capacityOverride") && !of.at("capacityOverride").is_null()) off.capacity_override = parse_resources(of.at("capacityOverride"));
+      if (of.has("overheadOverride") && !of.at("overheadOverride").is_null()) { off.has_overhead_override = true; off.overhead_override = parse_resources(of.at("overheadOverride")); }
       it.offerings.push_back(off);
     }
     it_index[it.name] = (int)pr.catalog.size();

@@ -218,3 +218,73 @@ def test_reserved_instance_types(oracle):
     # third loop: no reservation left, falls back to on-demand / spot
     r = oracle.solve(fx.problem(types(0, 0), [fx.node_pool()], pods[2:], options=opts))
     assert len(r["newNodeClaims"]) == 1 and not r["newNodeClaims"][0]["reservedOfferings"] and not r["podErrors"]
+
+
+# ---- offering capacity / overhead overrides (types.go:202-269; the device answers KSOLVE_ERR_UNSUPPORTED for these) ----
+
+def _with_override_offerings(it, available=True, capacity=None, overhead=None):
+    """suite_test.go:5532-5545: every base offering cloned with CapacityOverride / OverheadOverride."""
+    clones = []
+    for o in list(it["offerings"]):
+        c = dict(o, available=available)
+        if capacity is not None:
+            c["capacityOverride"] = dict(capacity)
+        if overhead is not None:
+            c["overheadOverride"] = dict(overhead)       # InstanceTypeOverhead.Total() of the override
+        clones.append(c)
+    it["offerings"] = it["offerings"] + clones
+    return it
+
+
+def test_offering_overrides_known_answers(oracle):
+    ext = "test.com/extended-slots"
+    res = {"cpu": "4", "memory": "8Gi"}
+    # suite_test.go:5524-5566: only the type whose override offerings carry the extended resource is selected
+    ov = _with_override_offerings(fx.fake_instance_type("override-capable", res), capacity={ext: "4"}, overhead={"memory": "1Gi"})
+    normal = fx.fake_instance_type("normal", res)
+    r, _ = solve(oracle, [fx.pod(requests={ext: "1"})], its=[ov, normal])
+    assert not r["podErrors"] and len(r["newNodeClaims"]) == 1
+    assert r["newNodeClaims"][0]["instanceTypes"] == ["override-capable"]
+    # suite_test.go:5568-5607: the override allocatable would fit, but its offerings are unavailable: no NodeClaim
+    ov = _with_override_offerings(fx.fake_instance_type("override-capable", res), available=False, capacity={ext: "4"}, overhead={"memory": "1Gi"})
+    r, _ = solve(oracle, [fx.pod(requests={ext: "1"})], its=[ov])
+    assert len(r["podErrors"]) == 1 and not r["newNodeClaims"]
+
+
+def test_offering_override_groups_semantics(oracle):
+    """groupOfferingsByOverride + fits (types.go:224-269, nodeclaim.go:624-638): a type fits when SOME group both fits the
+    requests and has an offering compatible with the requirements; the base group keeps the base allocatable."""
+    ext = "test.com/extended-slots"
+    res = {"cpu": "4", "memory": "8Gi"}
+    # the override group trades memory for slots (overhead 1Gi -> 7Gi allocatable): a 7.5Gi pod only fits the base group,
+    # a slot pod only the override group; both groups live on one type, so each pod gets a claim of that type, but they
+    # cannot share one (requests 7.5Gi + slots fit neither group)
+    ov = _with_override_offerings(fx.fake_instance_type("t", res), capacity={ext: "4"}, overhead={"memory": "1Gi"})
+    big, slot = fx.pod(requests={"memory": "7680Mi"}), fx.pod(requests={ext: "1"})
+    r, _ = solve(oracle, [big, slot], its=[ov])
+    assert not r["podErrors"] and sorted(len(c["pods"]) for c in r["newNodeClaims"]) == [1, 1]
+    r, _ = solve(oracle, [fx.pod(requests={ext: "1", "memory": "1Gi"}) for _ in range(4)] + [fx.pod(requests={ext: "1"})], its=[ov])
+    assert not r["podErrors"] and sorted(len(c["pods"]) for c in r["newNodeClaims"]) == [1, 4]          # four slots per node
+    # override offerings only in test-zone-3: a pod that needs slots AND zone 1 has a fitting group without a compatible
+    # offering and a compatible offering in a group that does not fit -> unschedulable; zone 3 works
+    t = fx.fake_instance_type("t", res)
+    z3 = [dict(o, capacityOverride={ext: "2"}) for o in t["offerings"] if any(q["key"] == fx.ZONE and q["values"] == ["test-zone-3"] for q in o["requirements"])]
+    t["offerings"] += z3
+    r, _ = solve(oracle, [fx.pod(requests={ext: "1"}, node_selector={fx.ZONE: "test-zone-1"})], its=[t])
+    assert len(r["podErrors"]) == 1
+    r, _ = solve(oracle, [fx.pod(requests={ext: "1"})], its=[t])
+    assert not r["podErrors"]
+    # fits() does not narrow the claim's zone requirement (the launch picks the offering): no zone requirement appears
+    assert not [q for q in r["newNodeClaims"][0]["requirements"] if q["key"] == fx.ZONE]
+    # a capacity override replaces the whole key (lo.Assign): memory 2Gi instead of 8Gi in that group; an empty override map
+    # with no overhead override is the base group
+    t = _with_override_offerings(fx.fake_instance_type("t", res), capacity={"memory": "2Gi"})
+    for o in t["offerings"][:5]:
+        o["available"] = False                                            # only the shrunken group can launch
+    r, _ = solve(oracle, [fx.pod(requests={"memory": "3Gi"})], its=[t])
+    assert len(r["podErrors"]) == 1
+    t = _with_override_offerings(fx.fake_instance_type("t", res), capacity={})
+    for o in t["offerings"][:5]:
+        o["available"] = False
+    r, _ = solve(oracle, [fx.pod(requests={"memory": "3Gi"})], its=[t])
+    assert not r["podErrors"]
