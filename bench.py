@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-problems", type=int, default=512, help="independent problems solved with ONE batched launch (reported beside the headline, 0 = skip)")
     ap.add_argument("--batch-pods", type=int, default=20_000, help="pods per problem of the batched measurement")
+    ap.add_argument("--solver-lib", default=None, help="TEST HOOK (tests/test_bench_contract.py): a host build of the engine behind the same C ABI, "
+                    "so that the launcher / collective / JSON contract can be exercised without a GPU; never a measurement, never a default")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -58,7 +60,12 @@ def main():
         import torch
         import torch.distributed as dist
         ngpu = torch.cuda.device_count()
-        if ngpu >= world:
+        if ngpu == 0:
+            if not args.solver_lib:
+                raise RuntimeError("bench.py: no GPU visible to torch (the product has no CPU path)")
+            dist.init_process_group(backend="gloo")     # contract test without a GPU: see --solver-lib
+            reduce_device = "cpu"
+        elif ngpu >= world:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
             reduce_device = "cuda"
@@ -79,10 +86,10 @@ def main():
 
     prob = fx.config2(pods=args.pods, n_types=args.types, seed=42 + rank)
     prob["options"]["device"] = device_index
-    sched = NewScheduler(prob)  # flatten + upload: inputs resident in HBM before the timed region
+    sched = NewScheduler(prob, solver_lib=args.solver_lib)  # flatten + upload: inputs resident in HBM before the timed region
 
     def sync():
-        if torch is not None:
+        if torch is not None and torch.cuda.is_available():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -155,7 +162,7 @@ def main():
         # Independent problems (NodePool components / consolidation probes) in ONE launch of the pack kernel:
         # block b = the wavefront of problem b. Reported beside the headline, never part of `value`.
         from karpenter_amd.scheduling import SolveBatch
-        scheds = [NewScheduler(dict(fx.config2(pods=args.batch_pods, n_types=args.types, seed=1000 + i), options={"device": device_index, "maxClaims": 1024})) for i in range(args.batch_problems)]   # 1024 in-flight claims per problem keep the LDS plan under 80 KB: two problems per CU
+        scheds = [NewScheduler(dict(fx.config2(pods=args.batch_pods, n_types=args.types, seed=1000 + i), options={"device": device_index, "maxClaims": 1024}), solver_lib=args.solver_lib) for i in range(args.batch_problems)]   # 1024 in-flight claims per problem keep the LDS plan under 80 KB: two problems per CU
         SolveBatch(scheds, want_results=False)   # warm-up
         tb = time.perf_counter()
         rs = SolveBatch(scheds, want_results=False)
@@ -174,6 +181,8 @@ def main():
         out["cpu_baseline"] = {"value": args.cpu_sample / secs, "unit": "pods/s", "cores": 1, "kind": "port",
                                "sample": f"{args.cpu_sample} pods of the same configs[1] mix x {args.types} instance types, fresh scheduler, oracle C++ restatement of the Go Solve() ({secs:.1f} s)",
                                "seconds": secs, "bin_evaluations": r["counters"]["binEvaluations"]}
+    if args.solver_lib:
+        out["data"] = "synthetic; TEST HOOK --solver-lib (host emulation of the engine): contract check only, not a measurement"
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

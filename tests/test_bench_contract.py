@@ -1,0 +1,78 @@
+"""bench.py's contract (one JSON line, whole-job value, max-over-ranks timing, summary all-reduce) exercised WITHOUT a
+GPU: the launcher command is the driver's (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...`), the
+collective runs on gloo, and the solver behind the C ABI is the test emulation passed through bench.py's --solver-lib
+test hook. Nothing here is a measurement; it pins that the N>1 path runs, that every rank solves its own problem and that
+the reduced packing summary is the sum of what the oracle finds for each rank's problem."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import parity
+from karpenter_amd import fixtures as fx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def _env():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    return env
+
+
+def test_single_rank_line(oracle):
+    emu = parity.build_emu()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--pods", "3000", "--types", "60", "--cpu-sample", "1500",
+           "--batch-problems", "3", "--batch-pods", "400", "--solver-lib", emu]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert REQUIRED <= set(line) and {"cpu_baseline", "batched", "packing", "counters"} <= set(line)
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["higher_is_better"] is True and line["dtype"] == "int64" and "workload" in line["config"] and "TEST HOOK" in line["data"]
+    want = oracle.solve(fx.config2(pods=3000, n_types=60, seed=42))
+    assert line["packing"]["pods_scheduled"] == 3000 - len(want["podErrors"]) and line["packing"]["node_claims"] == len(want["newNodeClaims"])
+    assert abs(line["packing"]["packing_cost_per_hour"] - want["packingCost"]) <= 1e-9 * want["packingCost"]
+    assert line["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
+    assert abs(line["value"] - line["packing"]["pods_scheduled"] / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["traffic"] is None            # the PMC figure belongs to the 1M-pod x 500-type launch only
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "pods/s" and cb["value"] > 0
+    assert line["batched"]["problems"] == 3 and line["batched"]["value"] > 0
+
+
+def test_two_ranks_under_the_drivers_launcher(oracle):
+    emu = parity.build_emu()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--pods", "2500", "--types", "60", "--solver-lib", emu]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = _json_line(r.stdout)
+    assert REQUIRED <= set(line) and line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert "cpu_baseline" not in line and "batched" not in line           # rank 0 at N=1 only
+    want = [oracle.solve(fx.config2(pods=2500, n_types=60, seed=42 + rank)) for rank in range(2)]   # every rank solves its own problem
+    assert line["packing"]["pods_scheduled"] == sum(2500 - len(w["podErrors"]) for w in want)
+    assert line["packing"]["node_claims"] == sum(len(w["newNodeClaims"]) for w in want)
+    cost = sum(w["packingCost"] for w in want)
+    assert abs(line["packing"]["packing_cost_per_hour"] - cost) <= 1e-9 * cost
+    # whole-job value: pods of ALL ranks over the max-over-ranks time of the timed region
+    assert abs(line["value"] - line["packing"]["pods_scheduled"] / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+
+
+def test_no_gpu_and_no_hook_is_loud():
+    """Without the test hook a multi-rank launch on a box without GPUs fails instead of computing anything on the CPU."""
+    env = dict(_env(), RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--pods", "100"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no GPU visible" in r.stderr
