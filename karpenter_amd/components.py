@@ -48,3 +48,70 @@ def split_by_nodepool(problem):
         if part["pods"] or part["podGroups"]:
             out.append((np_["name"], dict(problem, nodePools=[np_], pods=part["pods"], podGroups=part["podGroups"])))
     return out
+
+
+def _pinned_pools(p, pools):
+    """The NodePools a pod can ever land on, as far as its REQUIRED constraints on `karpenter.sh/nodepool` say (a node
+    selector, and/or every required node-affinity term carrying `In [...]` on that key — terms are OR-ed and relaxation only
+    drops terms, preferences.go:38-57, so the union over the terms bounds every relaxed variant). None = not provably pinned."""
+    if p.get("topologySpreadConstraints") or p.get("podAffinity") or p.get("podAntiAffinity"):
+        return None
+    allowed = None
+    sel = (p.get("nodeSelector") or {}).get(fx.NODEPOOL)
+    if sel is not None:
+        allowed = {sel}
+    terms = (p.get("nodeAffinity") or {}).get("required") or []
+    if terms:
+        union = set()
+        for term in terms:
+            ins = [set(q["values"]) for q in term if q["key"] == fx.NODEPOOL and q["operator"] == "In"]
+            if not ins:
+                union = None        # a term without the pin can reach any pool
+                break
+            union |= set.intersection(*ins)
+        if union is not None:
+            allowed = union if allowed is None else allowed & union
+    if allowed is None:
+        return None
+    allowed &= set(pools)
+    return allowed or None
+
+
+def split_components(problem):
+    """Connected components of the pods x NodePools graph: two NodePools are in one component when some
+    pod may land on either. Returns [(tuple of pool names, sub-problem)] in NodePool order, or None when some pod is not
+    provably pinned or the batch has anything `split_by_nodepool` refuses. Same contract as `split_by_nodepool`: each
+    component is a packing problem of its own, solved bit-exactly as such; the union is a packing of equal quality, not the
+    reference's pod-for-pod answer for the whole batch."""
+    if problem.get("stateNodes") or problem.get("clusterPods") or problem.get("options", {}).get("reservedCapacity"):
+        return None
+    names = [np_["name"] for np_ in problem["nodePools"]]
+    parent = {n: n for n in names}
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    owners = []
+    for kind, items in (("pods", problem.get("pods", [])), ("podGroups", problem.get("podGroups", []))):
+        for item in items:
+            allowed = _pinned_pools(item["template"] if kind == "podGroups" else item, names)
+            if allowed is None:
+                return None
+            first = min(allowed, key=names.index)
+            for other in allowed:
+                parent[find(other)] = find(first)
+            owners.append((kind, item, first))
+    comps = {}
+    for n in names:
+        comps.setdefault(find(n), {"pools": [], "pods": [], "podGroups": []})["pools"].append(n)
+    for kind, item, first in owners:
+        comps[find(first)][kind].append(item)
+    by_name = {np_["name"]: np_ for np_ in problem["nodePools"]}
+    out = []
+    for c in sorted(comps.values(), key=lambda c: names.index(c["pools"][0])):
+        if c["pods"] or c["podGroups"]:
+            out.append((tuple(c["pools"]), dict(problem, nodePools=[by_name[n] for n in c["pools"]], pods=c["pods"], podGroups=c["podGroups"])))
+    return out

@@ -6,7 +6,7 @@ import pytest
 
 import parity
 from karpenter_amd import fixtures as fx
-from karpenter_amd.components import split_by_nodepool
+from karpenter_amd.components import split_by_nodepool, split_components
 from karpenter_amd.scheduling import NewScheduler, SolveBatch
 from test_device_algorithm import emu  # noqa: F401  (fixture)
 
@@ -49,3 +49,32 @@ def test_split_refuses_what_it_cannot_prove(oracle):
     reserved = dict(base, options={"reservedCapacity": True})
     for prob in (unpinned, spread, unknown, with_nodes, reserved):
         assert split_by_nodepool(prob) is None
+
+
+def test_connected_components_of_pods_and_pools(oracle, emu):
+    """Pods that may land on either of two NodePools (a required node-affinity term per pool, or one `In [a, b]`) tie those
+    pools into one component; the other pools stay on their own. Every component is solved exactly as its own problem and
+    the union places every pod at about the whole-batch cost."""
+    prob = fx.config4(pods=6000, n_types=100, n_pools=6, seed=5)
+    pin = lambda *pools: [fx.req(fx.NODEPOOL, "In", *pools)]
+    extra = [fx.pod(requests={"cpu": "1", "memory": "1Gi"}, node_requirements=pin("pool-00", "pool-01")) for _ in range(40)]
+    extra += [fx.pod(requests={"cpu": "2", "memory": "1Gi"}, node_requirements=[pin("pool-03"), pin("pool-04")]) for _ in range(40)]   # OR-ed terms
+    extra += [fx.pod(requests={"cpu": "500m"}, node_selector={fx.NODEPOOL: "pool-04"}, node_requirements=pin("pool-04", "pool-05")) for _ in range(10)]   # selector AND affinity: pool-04 only
+    prob = dict(prob, pods=prob.get("pods", []) + extra)
+    parts = split_components(prob)
+    assert [pools for pools, _ in parts] == [("pool-00", "pool-01"), ("pool-02",), ("pool-03", "pool-04"), ("pool-05",)]
+    n_pods = lambda pr: len(pr.get("pods", [])) + sum(g["count"] for g in pr.get("podGroups", []))
+    assert sum(n_pods(sub) for _, sub in parts) == n_pods(prob)
+    got = SolveBatch([NewScheduler(sub, solver_lib=emu) for _, sub in parts])
+    want = [oracle.solve(sub) for _, sub in parts]
+    for g, w in zip(got, want):
+        parity.assert_same_results(g, w)
+    whole = oracle.solve(prob)
+    assert not whole["podErrors"] and not any(w["podErrors"] for w in want)
+    cost = sum(w["packingCost"] for w in want)
+    assert abs(cost - whole["packingCost"]) <= 0.03 * whole["packingCost"]      # small batch: ~1% either way (here the split is cheaper)
+    # a split by single NodePool must refuse this batch; the component split refuses what it cannot bound either
+    assert split_by_nodepool(prob) is None
+    loose = dict(prob, pods=prob["pods"] + [fx.pod(node_requirements=[pin("pool-00"), [fx.req(fx.ZONE, "In", "test-zone-1")]])])   # second term reaches any pool
+    assert split_components(loose) is None
+    assert split_components(dict(prob, pods=[fx.pod(node_requirements=pin("no-such-pool"))])) is None
