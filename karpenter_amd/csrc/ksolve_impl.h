@@ -830,6 +830,7 @@ static ksolve_status solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results*
     if (st[i] != KSOLVE_OK) return;
     st[i] = solve_finish(hs[i], &outs[i]);
     if (st[i] == KSOLVE_ERR_CAPACITY && hs[i]->big_capable && !hs[i]->pv.big) { be_results_drop(&outs[i]); st[i] = solve(hs[i], &outs[i], false); }   // re-run alone on the BIG engine
+    outs[i].status = st[i];   // solve_finish zeroes `out` before it can fail: the per-problem status must survive that
   });
   ksolve_status worst = KSOLVE_OK;
   for (uint32_t i = 0; i < n; ++i) if (st[i] != KSOLVE_OK && st[i] != KSOLVE_ERR_CANCELLED) worst = st[i];

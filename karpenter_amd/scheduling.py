@@ -158,16 +158,16 @@ def SolveBatch(schedulers, want_results: bool = True):
     sessions = (ctypes.c_void_p * n)(*[s._session for s in schedulers])
     outs = (ctypes.c_void_p * n)()
     lib.ksched_solve_batch(sessions, n, 1 if want_results else 0, outs)
-    results = []
-    for i in range(n):
+    docs = []
+    for i in range(n):   # every document is copied out and released before anything is raised: no leak on the first error
         try:
-            doc = json.loads(ctypes.string_at(outs[i]).decode())
+            docs.append(json.loads(ctypes.string_at(outs[i]).decode()))
         finally:
             lib.ksched_free(outs[i])
+    for doc in docs:
         if "error" in doc:
             _raise(doc.get("kind"), doc["error"])
-        results.append(Results(doc))
-    return results
+    return [Results(doc) for doc in docs]
 
 
 MAX_INSTANCE_TYPES = 600                      # scheduling.MaxInstanceTypes, nodeclaimtemplate.go:50

@@ -1,4 +1,6 @@
 """Shared helpers for parity tests: canonical comparison of a product Results document with the oracle's."""
+import hashlib
+import json
 import os
 
 EMU_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libksolve_emu.so")
@@ -45,3 +47,27 @@ def assert_same_results(got, want, check_price=True):
     gerr = {u: (e["code"], e["diag"]) for u, e in got["podErrors"].items()}
     werr = {u: (e["code"], e["diag"]) for u, e in want["podErrors"].items()}
     assert gerr == werr, (sorted(gerr.items())[:5], sorted(werr.items())[:5])
+
+
+def claim_fingerprint(c):
+    """sha256 of one NodeClaim in canonical form (pod identities in slot order, instance-type options, requirements,
+    requests, hostname, NodePool, the cheapest launch price bit-for-bit)."""
+    cc = canon_claim(c)
+    doc = [cc["nodePool"], cc["hostname"], cc["pods"], cc["instanceTypes"], cc["requirements"], cc["requests"], float(c["cheapestPrice"]).hex()]
+    return hashlib.sha256(json.dumps(doc, separators=(",", ":")).encode()).hexdigest()
+
+
+def results_digest(res):
+    """Digest of a whole Results document at L1-strict level: the claim stream in order, existing-node assignments and
+    pod errors. Two documents with the same digest pass assert_same_results. Used to pin the device at sizes where the
+    oracle takes hours: the oracle runs offline (tests/golden/make_fullsize_digests.py), the digest is committed."""
+    h = hashlib.sha256()
+    fps = [claim_fingerprint(c) for c in res["newNodeClaims"]]
+    for f in fps:
+        h.update(f.encode())
+    for e in sorted(res.get("existingNodes", []), key=lambda e: e["name"]):
+        if e["pods"]:
+            h.update(json.dumps([e["name"], e["pods"]], separators=(",", ":")).encode())
+    for u, e in sorted(res["podErrors"].items()):
+        h.update(json.dumps([u, e["code"], e["diag"]], separators=(",", ":")).encode())
+    return h.hexdigest(), fps
