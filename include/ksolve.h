@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KSOLVE_ABI_VERSION 3
+#define KSOLVE_ABI_VERSION 4
 #define KSOLVE_MAX_KEYS 32        /* requirement keys per problem (one bit each in the u32 flag words) */
 #define KSOLVE_MAX_RES 8          /* resource dimensions */
 #define KSOLVE_MAX_TEMPLATES 32   /* NodeClaimTemplates (NodePools that survived prefiltering) */
@@ -206,6 +206,11 @@ typedef struct {
                                     * ksolve_claims.truncation_failed */
   uint32_t reserved_capacity;      /* FeatureGates.ReservedCapacity (nodeclaim.go:308) */
   uint32_t reserved_offering_strict; /* DisableReservedCapacityFallback / ReservedOfferingModeStrict (scheduler.go:103, nodeclaim.go:339-348) */
+  uint32_t engine;                 /* which pack engine may run. 0 = automatic: the cursor engine (csrc/fast_engine.h) for problems whose
+                                    * requirement algebra is purely positive (In sets only, no topology / existing nodes / minValues /
+                                    * reservations / daemon overhead), the general engine otherwise or whenever the cursor engine stops;
+                                    * 1 = general engine only; 2 = cursor engine only (KSOLVE_ERR_UNSUPPORTED instead of the fallback:
+                                    * tests use it to prove which engine produced a result). Both give identical Results. */
 } ksolve_options;
 
 /* One NodeClaim of Results.NewNodeClaims (scheduler.go:282, nodeclaim.go:43-62), in the order the reference's
@@ -248,6 +253,8 @@ typedef struct {
                                     * total, CanAdd and scan sub-phases) and a few diagnostic counts */
   double us_upload, us_prepass, us_pack, us_finalize, us_download;
   double packing_cost;
+  uint32_t engine_used;            /* 1 = general engine, 2 = cursor engine */
+  uint32_t engine_fallback_reason; /* non-zero: why the cursor engine handed the problem to the general engine (csrc/fast_engine.h) */
   void* impl;
 } ksolve_results;
 

@@ -1,0 +1,734 @@
+// fast_engine.h — the cursor engine: Scheduler.Solve() (scheduler.go:440-519) for provisioning batches whose
+// requirement algebra is purely positive (every operator In — nodeSelector / node-affinity In terms, NodePool In
+// requirements, instance types that label themselves with In sets), no topology, no existing nodes, no daemon overhead,
+// no minValues, no reservations: BASELINE configs[0], [1] and [3]. One wavefront per scheduling problem, like engine.h,
+// but built on three facts that hold for this shape and make a step O(1) instead of a scan over the claims:
+//
+//  1. A claim's InstanceTypeOptions are a pure function of its requirement set and its requests:
+//         its = F(template, requirements) ∩ { it : allocatable(it) >= requests }          (nodeclaim.go:541-638)
+//     because both only ever narrow / grow (NodeClaim.Add, nodeclaim.go:247-263) and with positive sets
+//     Intersects (requirements.go:254-274) is monotone. So CanAdd (nodeclaim.go:124-242) needs no per-claim instance-type
+//     mask: "some type of F still fits" is a dominance test against the Pareto-maximal allocatable vectors of F, which are
+//     cached per distinct requirement set (a few hundred per problem) in LDS. The masks themselves are materialised once,
+//     after the loop, by ksolve_fast_records (one wavefront per claim).
+//  2. The requirement set of a claim is the template's plus a handful of keys pods select on; the values of those keys are
+//     packed into ONE 64-bit word per claim (`vmask`: bit = value still allowed), so Requirements.Compatible + Add
+//     (requirements.go:181-197, 133-140) is an AND and a few field tests in registers.
+//  3. CanAdd failures are permanent (fact 1), claims only move RIGHT in the reference's order when they gain a pod
+//     (sort.Slice by pod count, scheduler.go:598 — pdq_emul.h keeps Go's exact permutation), and a new claim enters at
+//     one known position. So each pod class keeps a cursor: "every claim left of it has rejected this class for good".
+//     addToInflightNode's "lowest index that accepts" (scheduler.go:667-686) is then the first acceptor at or after the
+//     cursor — in the steady state the claim AT the cursor — found by testing 64 positions per step, one lane each.
+//     Cursors live in vector registers (lane = class slot) and are kept valid under moves with three VALU ops.
+//
+// Everything this engine does not handle (an unschedulable pod, NodePool limits that actually exclude a type, more claims
+// than the LDS plan holds, non-positive operators, ...) makes it stop with status 3 before it has written a result;
+// the host then runs the general engine (engine.h) on the same problem. There is no CPU path.
+#pragma once
+#include "ksp.h"
+#include "pdq_emul.h"
+
+namespace ks {
+
+constexpr int kFastRows = 4;          // class slots = 64 lanes x kFastRows registers
+constexpr int kFastSlots = 64 * kFastRows;
+constexpr int kFastEnt = 512;         // requirement-set cache entries (open addressing)
+constexpr int kFastPool = 256;        // extra Pareto vectors
+constexpr int kFastMaxPareto = 16;    // per requirement set
+constexpr int kFastMaxVar = 12;       // keys pods select on
+constexpr int kFastVarBits = 56;      // their dictionary values must fit 56 bits; the top byte of vmask is the template
+
+struct FastClaim { uint64_t vmask; int32_t req[4]; };                                   // 24 B, LDS, by claim id
+struct FastSlot { uint64_t cvmask; int32_t size[4]; uint32_t tmplok; uint32_t kdef; };  // 32 B: a pod class as the scan needs it
+struct FastEnt { uint64_t vmask; int32_t cap[4]; uint32_t info; uint32_t idx; };        // 32 B: info bit0 valid, bits 8..15 extra vectors, bits 16..31 pool offset
+
+struct FastPlan {   // LDS plan of ksolve_pack_fast (bytes), computed by the host
+  int total_bytes, cap;
+  int off_state, off_key, off_ord, off_pos, off_ent, off_pool, off_slot, off_misc;
+};
+
+struct FastMisc {   // small LDS tables
+  uint64_t tvmask[32];                 // template: values it admits on the variable keys | template << 56
+  uint32_t tdef[32];
+  uint64_t fmask[kFastMaxVar];         // field of variable key j inside vmask
+  uint8_t vkey[kFastMaxVar], voff[kFastMaxVar], vwidth[kFastMaxVar];
+  uint16_t vword[kFastMaxVar];         // dictionary word of the key
+  uint64_t its[kMaxItWords], rem[kMaxItWords], cand[kMaxItWords];   // slow-path scratch
+  uint32_t blk_pod[64], blk_class[64];
+  uint16_t active[kFastSlots];         // class of each slot (for eviction)
+  uint64_t changed;                    // scratch flag
+};
+
+struct FastVar { int nv; uint8_t vkey[kFastMaxVar], voff[kFastMaxVar], vwidth[kFastMaxVar]; uint16_t vword[kFastMaxVar]; };   // the keys pods select on
+
+struct FastWork {   // HBM workspace of the cursor engine (host-allocated when the problem may qualify)
+  FastVar* var;           // written by the pack kernel, read by ksolve_fast_records
+  FastSlot* cls;          // [n_classes]
+  uint16_t* slot_of;      // [n_classes]
+  uint32_t* c_vdef;       // [max_claims] keys the claim's requirement set defines
+  uint32_t* c_hostseq;    // [max_claims]
+  uint16_t* c_ent;        // [max_claims] cache entry of the claim's requirement set
+  FastClaim* c_state;     // [max_claims] final state, written when the loop ends
+  uint32_t* c_npods;      // [max_claims]
+  uint64_t* ent_its;      // [kFastEnt][it_words] F(requirement set)
+  FastPlan plan;
+  int enabled;
+};
+
+// whole-record moves between LDS and registers (a struct behind an address-space-3 pointer has no implicit copy)
+template <class T>
+KS_FN T lds_get(const KS_LDS T* p) {
+  static_assert(sizeof(T) % 8 == 0, "lds_get: 8-byte multiples");
+  T out;
+  uint64_t* o = (uint64_t*)&out;
+  const KS_LDS uint64_t* s = (const KS_LDS uint64_t*)p;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 8); ++i) o[i] = s[i];
+  return out;
+}
+template <class T>
+KS_FN void lds_put(KS_LDS T* p, const T& v) {
+  static_assert(sizeof(T) % 8 == 0, "lds_put: 8-byte multiples");
+  const uint64_t* o = (const uint64_t*)&v;
+  KS_LDS uint64_t* s = (KS_LDS uint64_t*)p;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 8); ++i) s[i] = o[i];
+}
+
+#define KS_FAST_BAIL(why) do { bail(why); return; } while (0)
+
+template <class W>
+struct FastEngine {
+  const ProblemView& P;
+  Workspace& S;
+  FastWork& F;
+  typedef KS_LDS uint16_t* o16;
+  ClaimOrder<W, o16> order;
+  KS_LDS FastClaim* cst;
+  KS_LDS FastEnt* ent;
+  KS_LDS int32_t* pool;     // [kFastPool][4]
+  KS_LDS FastSlot* aslot;
+  FastMisc& M;
+  Counters ctr{};
+  int n_claims = 0, nv = 0, n_ent = 0, n_pool = 0, n_active = 0;
+  uint32_t host_seq = 0, active_templates = 0;
+  int bail_code = 0;
+  LaneVar<uint32_t> cur[kFastRows];   // cursor of class slot (row * 64 + lane)
+
+  KS_DEV FastEngine(const ProblemView& p, Workspace& s, FastWork& f, char* lds)
+      : P(p), S(s), F(f), M(*(FastMisc*)(lds + f.plan.off_misc)) {
+    const FastPlan& pl = f.plan;
+    cst = (KS_LDS FastClaim*)(lds + pl.off_state);
+    order.key = (o16)(lds + pl.off_key); order.ord = (o16)(lds + pl.off_ord); order.pos = (o16)(lds + pl.off_pos);
+    ent = (KS_LDS FastEnt*)(lds + pl.off_ent);
+    pool = (KS_LDS int32_t*)(lds + pl.off_pool);
+    aslot = (KS_LDS FastSlot*)(lds + pl.off_slot);
+  }
+
+  KS_DEV void bail(int why) {
+    bail_code = why;
+    W::store(S.status_out, 3);
+    ctr.cycles[20] = (unsigned long long)why;
+    if (W::leader()) *S.counters = ctr;
+    W::sync();
+  }
+
+  // ---- requirement-set cache --------------------------------------------------------------------------------------
+  KS_FN static uint32_t hash_vm(uint64_t vm) { return (uint32_t)((vm * 0x9E3779B97F4A7C15ull) >> 40) & (kFastEnt - 1); }
+  // entry of requirement set vm, or -1 (not cached yet). Per lane.
+  KS_FN int lookup(uint64_t vm) const {
+    uint32_t h = hash_vm(vm);
+    for (int probe = 0; probe < kFastEnt; ++probe) {
+      const uint32_t info = ent[h].info;
+      if (!(info & 1u)) return -1;
+      if (ent[h].vmask == vm) return (int)h;
+      h = (h + 1) & (kFastEnt - 1);
+    }
+    return -1;
+  }
+  // "some instance type of entry e holds `req` + `size`" — CanAdd's filterInstanceTypesByRequirements verdict
+  KS_FN bool fits(int e, const int32_t* req, const int32_t* size) const {
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ok = ok && size[r] <= ent[e].cap[r] - req[r];
+    if (ok) return true;
+    const uint32_t info = ent[e].info;
+    const int extra = (int)((info >> 8) & 0xFFu);
+    const int off = (int)(info >> 16);
+    for (int i = 0; i < extra; ++i) {
+      bool o2 = true;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o2 = o2 && size[r] <= pool[(off + i) * 4 + r] - req[r];
+      if (o2) return true;
+    }
+    return false;
+  }
+  // Requirements.Compatible + Add on the packed form: every key the class selects on keeps at least one value
+  KS_FN bool fields_ok(uint64_t m, uint32_t kdef) const {
+    for (int j = 0; j < nv; ++j) if (((kdef >> M.vkey[j]) & 1u) && !(m & M.fmask[j])) return false;
+    return true;
+  }
+
+  // F(requirement set vm) and its Pareto-maximal allocatable vectors -> a new cache entry. Wave-uniform slow path.
+  KS_DEV int create_entry(uint64_t vm) {
+    const int t = (int)(vm >> 56);
+    const int iw = P.it_words, n_its = P.n_its, nr = P.n_res;
+    const Dict& d = P.dict;
+    const ProblemView& Pv = P;
+    FastMisc& Mm = M;
+    const uint64_t* tits = S.t_its + (size_t)t * iw;
+    uint64_t* its = M.its;
+    const int nvv = nv;
+    // compatible(it, reqs) (nodeclaim.go:620-622) for the keys pods select on; the template's other keys are in t_its already
+    W::for_n(iw, [&](int w) {
+      uint64_t acc = tits[w];
+      for (int j = 0; j < nvv; ++j) {
+        const int k = Mm.vkey[j];
+        if (!((Pv.it_keys >> k) & 1u)) continue;
+        const uint64_t full = Mm.fmask[j] >> Mm.voff[j];
+        uint64_t field = (vm >> Mm.voff[j]) & full;
+        if (field == full) continue;
+        uint64_t r = Pv.key_undef[(size_t)k * iw + w];
+        const size_t base = (size_t)Mm.vword[j] * 64;
+        while (field) { const int b = ctz64(field); field &= field - 1; r |= Pv.kv_has[(base + b) * iw + w]; }
+        acc &= r;
+      }
+      its[w] = acc;
+    });
+    // a compatible available offering (nodeclaim.go:624-638, types.go:553-570)
+    uint32_t zones = (1u << P.n_zones) - 1, cts = (1u << P.n_cts) - 1;
+    {
+      const uint64_t* tm = P.tmpl_reqs.mask + (size_t)t * d.req_words;
+      const uint32_t tdef = M.tdef[t];
+      if (d.key_zone >= 0 && ((tdef >> d.key_zone) & 1u)) zones &= (uint32_t)tm[d.key_word_off[d.key_zone]];
+      if (d.key_ct >= 0 && ((tdef >> d.key_ct) & 1u)) cts &= (uint32_t)tm[d.key_word_off[d.key_ct]];
+      for (int j = 0; j < nv; ++j) {
+        const uint32_t field = (uint32_t)((vm >> M.voff[j]) & (M.fmask[j] >> M.voff[j]));
+        if (M.vkey[j] == d.key_zone) zones &= field;
+        if (M.vkey[j] == d.key_ct) cts &= field;
+      }
+    }
+    uint64_t cells = 0;
+    for (uint32_t z = zones; z; z &= z - 1) cells |= (uint64_t)cts << (__builtin_ctz(z) * 4);
+    for (int j = 0; j < iw; ++j) {
+      const uint64_t in = its[j];
+      const uint64_t okm = in ? W::ballot([&](int l) { const int it = j * 64 + l; return it < n_its && ((in >> l) & 1) && (Pv.it_off_avail[it] & cells) != 0; }) : 0ull;
+      W::store(&its[j], okm);
+    }
+    W::sync();
+    // slot
+    uint32_t h = hash_vm(vm);
+    while (ent[h].info & 1u) h = (h + 1) & (kFastEnt - 1);
+    if (n_ent * 2 >= kFastEnt) return -1;
+    uint64_t* eits = F.ent_its + (size_t)h * iw;
+    W::for_n(iw, [&](int w) { eits[w] = its[w]; });
+    // Pareto-maximal allocatable vectors of F: repeatedly take the lexicographic maximum, drop what it dominates
+    uint64_t* rem = M.rem; uint64_t* cand = M.cand;
+    W::for_n(iw, [&](int w) { rem[w] = its[w]; });
+    int count = 0, poff = n_pool;
+    int32_t first[4] = {-1, -1, -1, -1};
+    for (;;) {
+      const uint64_t any = W::reduce_or(iw, [&](int w) { return rem[w]; });
+      if (!any) break;
+      W::for_n(iw, [&](int w) { cand[w] = rem[w]; });
+      int64_t v[4] = {0x3FFFFFFF, 0x3FFFFFFF, 0x3FFFFFFF, 0x3FFFFFFF};
+      for (int r = 0; r < nr; ++r) {
+        const int64_t* al = P.it_alloc + (size_t)r * n_its;
+        const int64_t mx = W::reduce_max_i64(iw * 64, [&](int it) { return (it < n_its && ((cand[it >> 6] >> (it & 63)) & 1)) ? al[it] : INT64_MIN; });
+        v[r] = mx;
+        for (int j = 0; j < iw; ++j) {
+          const uint64_t in = cand[j];
+          const uint64_t eq = in ? W::ballot([&](int l) { const int it = j * 64 + l; return it < n_its && ((in >> l) & 1) && al[it] == mx; }) : 0ull;
+          W::store(&cand[j], eq);
+        }
+        W::sync();
+      }
+      if (count == 0) { for (int r = 0; r < 4; ++r) first[r] = (int32_t)v[r]; }
+      else {
+        if (count > kFastMaxPareto || n_pool >= kFastPool) return -1;
+        for (int r = 0; r < 4; ++r) W::store(&pool[n_pool * 4 + r], (int32_t)v[r]);
+        n_pool++;
+      }
+      count++;
+      for (int j = 0; j < iw; ++j) {
+        const uint64_t in = rem[j];
+        const uint64_t dom = in ? W::ballot([&](int l) {
+          const int it = j * 64 + l;
+          if (it >= n_its || !((in >> l) & 1)) return false;
+          bool le = true;
+          for (int r = 0; r < nr; ++r) le = le && Pv.it_alloc[(size_t)r * n_its + it] <= v[r];
+          return le;
+        }) : 0ull;
+        W::store(&rem[j], in & ~dom);
+      }
+      W::sync();
+    }
+    if (W::leader()) {
+      ent[h].vmask = vm;
+      for (int r = 0; r < 4; ++r) ent[h].cap[r] = first[r];
+      ent[h].info = 1u | ((uint32_t)(count > 1 ? count - 1 : 0) << 8) | ((uint32_t)poff << 16);
+      ent[h].idx = (uint32_t)n_ent;
+    }
+    n_ent++;
+    W::sync();
+    return (int)h;
+  }
+
+  // ---- setup ------------------------------------------------------------------------------------------------------
+  // Returns 0 when the problem is of the shape this engine solves, a reason code otherwise.
+  KS_DEV int setup() {
+    const Dict& d = P.dict;
+    const int nk = d.n_keys, iw = P.it_words, nr = P.n_res, n_its = P.n_its, nc = P.n_classes, T = P.n_templates;
+    const ProblemView& Pv = P;
+    if (!P.lite || P.n_rows != P.n_pods || nr > 4 || T > 32 || nc > 65535) return 1;
+    // instance types: only In sets (positive), so that compatible() is monotone
+    if (W::reduce_or(nk * iw, [&](int i) { return Pv.key_compl[i] | Pv.key_neg[i]; })) return 2;
+    // templates: only In sets
+    if (W::reduce_or(T, [&](int t) { return (uint64_t)(Pv.tmpl_reqs.complement[t] | (Pv.tmpl_reqs.has_gte ? Pv.tmpl_reqs.has_gte[t] : 0) | (Pv.tmpl_reqs.has_lte ? Pv.tmpl_reqs.has_lte[t] : 0)); })) return 3;
+    // classes: only In sets; the keys they define are the variable keys
+    if (W::reduce_or(nc, [&](int c) { return (uint64_t)Pv.cls_reqs.complement[c]; })) return 4;
+    const uint32_t vk = (uint32_t)W::reduce_or(nc, [&](int c) { return (uint64_t)Pv.cls_reqs.defined[c]; });
+    if (d.key_hostname >= 0 && ((vk >> d.key_hostname) & 1u)) return 5;
+    if (d.key_it >= 0 && ((vk >> d.key_it) & 1u)) return 5;
+    int bits = 0;
+    nv = 0;
+    for (int k = 0; k < nk; ++k) {
+      if (!((vk >> k) & 1u)) continue;
+      if (d.key_word_off[k + 1] - d.key_word_off[k] != 1 || nv >= kFastMaxVar) return 6;
+      const uint64_t valid = d.value_valid[d.key_word_off[k]];
+      const int width = valid ? 64 - __builtin_clzll(valid) : 1;
+      if (bits + width > kFastVarBits) return 6;
+      if (W::leader()) {
+        M.vkey[nv] = (uint8_t)k; M.voff[nv] = (uint8_t)bits; M.vwidth[nv] = (uint8_t)width; M.vword[nv] = (uint16_t)d.key_word_off[k];
+        M.fmask[nv] = ((width >= 64 ? ~0ull : ((1ull << width) - 1))) << bits;
+      }
+      bits += width; nv++;
+    }
+    if (W::leader()) {
+      FastVar fv;
+      fv.nv = nv;
+      for (int j = 0; j < kFastMaxVar; ++j) { fv.vkey[j] = M.vkey[j]; fv.voff[j] = M.voff[j]; fv.vwidth[j] = M.vwidth[j]; fv.vword[j] = M.vword[j]; }
+      *F.var = fv;
+    }
+    W::sync();
+    // every quantity in 31 bits
+    if (W::reduce_or(nr * n_its, [&](int i) { const int64_t a = Pv.it_alloc[i]; return (uint64_t)((a >= (1ll << 30) || a <= -(1ll << 30)) ? 1 : 0); })) return 7;
+    if (W::reduce_or(nr * nc, [&](int i) { const int64_t a = Pv.cls_requests[i]; return (uint64_t)((a >= (1ll << 30) || a < 0) ? 1 : 0); })) return 7;
+    // templates: packed form, and NewScheduler's prefilter (scheduler.go:156-171) with positive sets
+    FastMisc& Mm = M;
+    const int nvv = nv;
+    W::for_n(T, [&](int t) {
+      const uint64_t* tm = Pv.tmpl_reqs.mask + (size_t)t * d.req_words;
+      const uint32_t tdef = Pv.tmpl_reqs.defined[t];
+      uint64_t vm = ((uint64_t)t << 56) | ((1ull << kFastVarBits) - 1);
+      for (int j = 0; j < nvv; ++j) {
+        vm &= ~Mm.fmask[j];
+        if ((tdef >> Mm.vkey[j]) & 1u) vm |= (tm[Mm.vword[j]] << Mm.voff[j]) & Mm.fmask[j];
+        else vm |= Mm.fmask[j];
+      }
+      // bits of the 56 that belong to no field stay set (harmless: class masks keep them set too)
+      Mm.tvmask[t] = vm; Mm.tdef[t] = tdef;
+    });
+    active_templates = 0;
+    for (int t = 0; t < T; ++t) {
+      const uint64_t* tm = P.tmpl_reqs.mask + (size_t)t * d.req_words;
+      const uint32_t tdef = M.tdef[t];
+      uint64_t* tits = S.t_its + (size_t)t * iw;
+      const uint64_t* tin = P.tmpl_its + (size_t)t * iw;
+      W::for_n(iw, [&](int w) {
+        uint64_t acc = tin[w] & Pv.it_alloc_ok[w];
+        for (int k = 0; k < nk; ++k) {
+          if (!((tdef >> k) & 1u)) continue;
+          const uint32_t w0 = d.key_word_off[k], w1 = d.key_word_off[k + 1];
+          if (k == d.key_it) { acc &= tm[w0 + w]; continue; }
+          if (!((Pv.it_keys >> k) & 1u)) continue;
+          uint64_t r = Pv.key_undef[(size_t)k * iw + w];
+          for (uint32_t x = w0; x < w1; ++x) for (uint64_t b = tm[x]; b; b &= b - 1) r |= Pv.kv_has[((size_t)x * 64 + ctz64(b)) * iw + w];
+          acc &= r;
+        }
+        tits[w] = acc;
+      });
+      uint32_t zones = (1u << P.n_zones) - 1, cts = (1u << P.n_cts) - 1;
+      if (d.key_zone >= 0 && ((tdef >> d.key_zone) & 1u)) zones &= (uint32_t)tm[d.key_word_off[d.key_zone]];
+      if (d.key_ct >= 0 && ((tdef >> d.key_ct) & 1u)) cts &= (uint32_t)tm[d.key_word_off[d.key_ct]];
+      uint64_t cells = 0;
+      for (uint32_t z = zones; z; z &= z - 1) cells |= (uint64_t)cts << (__builtin_ctz(z) * 4);
+      uint64_t any = 0;
+      for (int j = 0; j < iw; ++j) {
+        const uint64_t in = tits[j];
+        const uint64_t okm = in ? W::ballot([&](int l) { const int it = j * 64 + l; return it < n_its && ((in >> l) & 1) && (Pv.it_off_avail[it] & cells) != 0; }) : 0ull;
+        W::store(&tits[j], okm);
+        any |= okm;
+      }
+      W::sync();
+      if (any) active_templates |= 1u << t;
+      int64_t* rem = S.t_remaining + (size_t)t * (nr + 1);
+      const int64_t* lim = P.tmpl_limits + (size_t)t * (nr + 1);
+      W::for_n(nr + 1, [&](int r) { rem[r] = lim[r]; });
+    }
+    // classes: packed form + the (class, template) verdicts that never change: taints (nodeclaim.go:126) and keys the
+    // template does not define (requirements.go:185-193; with positive operators such a key stays undefined for good)
+    FastSlot* fc = F.cls;
+    uint16_t* so = F.slot_of;
+    const uint32_t wk = d.well_known_mask;
+    const uint64_t bad = W::reduce_or(nc, [&](int c) {
+      const uint64_t* cm = Pv.cls_reqs.mask + (size_t)c * d.req_words;
+      const uint32_t kdef = Pv.cls_reqs.defined[c];
+      uint64_t vm = ~0ull, badc = 0;
+      for (int j = 0; j < nvv; ++j) if ((kdef >> Mm.vkey[j]) & 1u) {
+        const uint64_t f = (cm[Mm.vword[j]] << Mm.voff[j]) & Mm.fmask[j];
+        if (!f) badc = 1;   // In [] == DoesNotExist: not positive
+        vm = (vm & ~Mm.fmask[j]) | f;
+      }
+      FastSlot s;
+      s.cvmask = vm;
+      for (int r = 0; r < 4; ++r) s.size[r] = r < nr ? (int32_t)Pv.cls_requests[(size_t)c * nr + r] : 0;
+      uint32_t ok = 0;
+      const uint64_t tol = Pv.cls_tolerates[c];
+      for (int t = 0; t < T; ++t) if (!(Pv.tmpl_taints[t] & ~tol) && !(kdef & ~Mm.tdef[t] & ~wk)) ok |= 1u << t;
+      s.tmplok = ok; s.kdef = kdef;
+      fc[c] = s;
+      so[c] = 0xFFFF;
+      return badc;
+    });
+    if (bad) return 8;
+    W::for_n(kFastEnt, [&](int i) { ent[i].info = 0; });
+    W::each([&](int l) { for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = 0; });
+    return 0;
+  }
+
+  // ---- class slots ------------------------------------------------------------------------------------------------
+  KS_DEV int slot_for(int k) {
+    uint16_t s = F.slot_of[k];
+    if (s != 0xFFFF) return (int)s;
+    if (n_active == kFastSlots) {
+      // every slot taken: forget them all (their classes start again from position 0 if they ever come back)
+      const uint16_t* act = M.active; uint16_t* so = F.slot_of;
+      W::for_n(kFastSlots, [&](int i) { so[act[i]] = 0xFFFF; });
+      W::each([&](int l) { for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = 0; });
+      n_active = 0;
+      ctr.column_resets++;
+    }
+    const int slot = n_active++;
+    const FastSlot rec = F.cls[k];
+    if (W::leader()) { lds_put(&aslot[slot], rec); M.active[slot] = (uint16_t)k; F.slot_of[k] = (uint16_t)slot; }
+    W::each([&](int l) { for (int j = 0; j < kFastRows; ++j) if (j * 64 + l == slot) cur[j].at(l) = 0; });
+    W::sync();
+    return slot;
+  }
+  KS_DEV uint32_t get_cursor(int slot) const {
+    uint32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < kFastRows; ++j) if (j == (slot >> 6)) r = cur[j].bcast(slot & 63);
+    return r;
+  }
+  KS_DEV void set_cursor(int slot, uint32_t v) {
+    W::each([&](int l) {
+#pragma unroll
+      for (int j = 0; j < kFastRows; ++j) if (j * 64 + l == slot) cur[j].at(l) = v;
+    });
+  }
+
+  // ---- order maintenance + cursors ----------------------------------------------------------------------------------
+  // sort.Slice before the scan (scheduler.go:598): repairs the defect the previous commit left. Cursors follow the move.
+  KS_DEV void sort_and_fix() {
+    if (order.defect < 0) return;
+    const int n = order.n;
+    const int a = order.defect;
+    const bool app = order.defect_append;
+    const int moved = (int)order.ord[a];
+    // the single-defect cases whose effect is one stable move (pdq_emul.h sort()); everything else is diffed below
+    bool exact = n <= 12;
+    if (n >= 50) {
+      const int q = n / 4, p = a;
+      exact = !((p >= q - 1 && p <= q + 1) || (p >= 2 * q - 1 && p <= 2 * q + 1) || (p >= 3 * q - 1 && p <= 3 * q + 1));
+    }
+    if (!exact) {
+      // any other path of pdqsort: compare the order before and after; cursors inside the permuted range fall back to its start
+      uint32_t* old = S.o_ord;   // the output array is free until the loop ends
+      const o16 oo = order.ord;
+      W::for_n(n, [&](int i) { old[i] = oo[i]; });
+      order.sort();
+      const int lo = W::find_first(0, n, [&](int i) { return old[i] != (uint32_t)oo[i]; });
+      if (lo >= n) return;
+      const int hi = W::find_last(0, n, [&](int i) { return old[i] != (uint32_t)oo[i]; });
+      W::each([&](int l) {
+#pragma unroll
+        for (int j = 0; j < kFastRows; ++j) { const uint32_t r = cur[j].at(l); if (r > (uint32_t)lo && r <= (uint32_t)hi) cur[j].at(l) = (uint32_t)lo; }
+      });
+      return;
+    }
+    order.sort();
+    const int b = (int)order.pos[moved];
+    if (!app) {
+      // the claim moved from a to b >= a: positions (a, b] shifted left by one
+      if (b > a) W::each([&](int l) {
+#pragma unroll
+        for (int j = 0; j < kFastRows; ++j) { const uint32_t r = cur[j].at(l); cur[j].at(l) = r - (uint32_t)(((uint32_t)a < r && r <= (uint32_t)b) ? 1 : 0); }
+      });
+      return;
+    }
+    // the new claim moved from n-1 to b: positions [b, n-1) shifted right by one. A cursor past b has a claim in front of
+    // it that its class never tested: test it now, one lane per class slot — an acceptor pulls the cursor back to b.
+    const int nac = n_active;
+    const uint64_t cvm = cst[moved].vmask;
+    int32_t creq[4];
+    for (int r = 0; r < 4; ++r) creq[r] = cst[moved].req[r];
+    const int t = (int)(cvm >> 56);
+    for (int j = 0; j < kFastRows && j * 64 < nac; ++j) {
+      uint64_t todo = W::ballot([&](int l) { return j * 64 + l < nac && cur[j].at(l) > (uint32_t)b; });
+      while (todo) {
+        LaneVar<uint64_t> missv;
+        const uint64_t td = todo;
+        const uint64_t miss = W::ballot([&](int l) {
+          missv.at(l) = 0;
+          if (!((td >> l) & 1)) return false;
+          const FastSlot s = lds_get(&aslot[j * 64 + l]);
+          uint32_t nxt = cur[j].at(l) + 1;
+          if ((s.tmplok >> t) & 1u) {
+            const uint64_t m = cvm & s.cvmask;
+            if (fields_ok(m, s.kdef)) {
+              const int e = lookup(m);
+              if (e < 0) { missv.at(l) = m; return true; }
+              if (fits(e, creq, s.size)) nxt = (uint32_t)b;
+            }
+          }
+          cur[j].at(l) = nxt;
+          return false;
+        });
+        todo = miss;
+        if (miss && create_entry(missv.bcast(ctz64(miss))) < 0) { bail_code = 20; return; }
+      }
+    }
+  }
+
+  // ---- the loop -----------------------------------------------------------------------------------------------------
+  KS_DEV void solve() {
+    const int why = setup();
+    if (why) KS_FAST_BAIL(why);
+    const int np = P.n_pods, cap = F.plan.cap, T = P.n_templates, nr = P.n_res, iw = P.it_words;
+    const uint32_t* sorted = P.sorted_pods;
+    const uint32_t* rc_ = P.row_class;
+    int status = 0;
+    long long steps = 0;
+    for (int base = 0; base < np && !status; base += 64) {
+      const int bn = np - base < 64 ? np - base : 64;
+      uint32_t* bp = M.blk_pod; uint32_t* bc = M.blk_class;
+      W::for_n(64, [&](int l) { if (l < bn) { const uint32_t p = sorted[base + l]; bp[l] = p; bc[l] = rc_[p]; } });
+      if (S.cancel_flag && W::poll_flag(S.cancel_flag)) { status = 2; break; }
+      for (int bi = 0; bi < bn; ++bi) {
+        if (S.max_steps >= 0 && steps >= S.max_steps) { status = 2; break; }
+        steps++;
+        const int pod = (int)M.blk_pod[bi];
+        const int k = (int)M.blk_class[bi];
+        ctr.queue_pops++; ctr.sorts++;
+        sort_and_fix();
+        if (bail_code) KS_FAST_BAIL(bail_code);
+        const int slot = slot_for(k);
+        const FastSlot cs = lds_get(&aslot[slot]);
+        uint32_t r = get_cursor(slot);
+        const int n = order.n;
+        bool placed = false;
+        while ((int)r < n) {
+          // addToInflightNode: positions r .. r+63, one lane each
+          LaneVar<uint64_t> mv;
+          LaneVar<uint32_t> xv;
+          LaneVar<int32_t> ev;
+          uint64_t miss = 0;
+          const uint32_t r0 = r;
+          const o16 oo = order.ord;
+          const uint64_t okm = W::ballot([&](int l) {
+            const int p = (int)r0 + l;
+            mv.at(l) = 0; ev.at(l) = -2; xv.at(l) = 0;
+            if (p >= n) return false;
+            const uint32_t x = oo[p];
+            xv.at(l) = x;
+            const FastClaim st = lds_get(&cst[x]);
+            if (!((cs.tmplok >> (st.vmask >> 56)) & 1u)) return false;
+            const uint64_t m = st.vmask & cs.cvmask;
+            if (!fields_ok(m, cs.kdef)) return false;
+            mv.at(l) = m;
+            const int e = lookup(m);
+            ev.at(l) = e;
+            if (e < 0) return false;
+            return fits(e, st.req, cs.size);
+          });
+          miss = W::ballot([&](int l) { return ev.at(l) == -1; });
+          ctr.bin_evaluations += (unsigned long long)(n - (int)r0 < 64 ? n - (int)r0 : 64);
+          ctr.full_evaluations++;
+          const int first_ok = okm ? ctz64(okm) : 64;
+          const int first_miss = miss ? ctz64(miss) : 64;
+          if (first_miss < first_ok) {
+            // a requirement set that is not cached yet sits before the first acceptor: cache it, test these positions again
+            if (create_entry(mv.bcast(first_miss)) < 0) KS_FAST_BAIL(21);
+            continue;
+          }
+          if (!okm) { r = (uint32_t)((int)r0 + 64 < n ? (int)r0 + 64 : n); continue; }
+          // commit: NodeClaim.Add (nodeclaim.go:247-263)
+          const int a = (int)r0 + first_ok;
+          const int x = (int)xv.bcast(first_ok);
+          const uint64_t m = mv.bcast(first_ok);
+          const int e = ev.bcast(first_ok);
+          const FastClaim st = lds_get(&cst[x]);
+          const uint32_t cnt = order.key[a];
+          if (cnt >= 65534u) KS_FAST_BAIL(22);
+          if (W::leader()) {
+            FastClaim ns;
+            ns.vmask = m;
+            for (int q = 0; q < 4; ++q) ns.req[q] = st.req[q] + cs.size[q];
+            lds_put(&cst[x], ns);
+            if (m != st.vmask) F.c_ent[x] = (uint16_t)e;
+            const uint32_t vd = F.c_vdef[x];
+            if ((vd | cs.kdef) != vd) F.c_vdef[x] = vd | cs.kdef;
+            S.assign[pod] = (int32_t)x;
+            S.slot[pod] = cnt;
+          }
+          ctr.ref_bin_evaluations += (unsigned long long)a + 1;
+          order.increment(x);
+          r = (uint32_t)a;
+          placed = true;
+          break;
+        }
+        set_cursor(slot, r);
+        if (placed) continue;
+        // addToNewNodeClaim (scheduler.go:695-790)
+        ctr.ref_bin_evaluations += (unsigned long long)n;
+        bool made = false;
+        for (int t = 0; t < T && !made; ++t) {
+          if (!((active_templates >> t) & 1u)) continue;
+          const uint32_t lm = P.tmpl_limit_mask[t];
+          if (lm) {
+            // filterByRemainingResources (scheduler.go:1069-1085): this engine only continues while no type is excluded
+            int64_t* rem = S.t_remaining + (size_t)t * (nr + 1);
+            if (((lm >> nr) & 1) && rem[nr] <= 0) KS_FAST_BAIL(23);
+            const ProblemView& Pv = P;
+            const uint64_t* tits = S.t_its + (size_t)t * iw;
+            const int n_its = P.n_its;
+            uint64_t excluded = 0;
+            for (int w = 0; w < iw; ++w) {
+              const uint64_t in = tits[w];
+              if (!in) continue;
+              excluded |= W::ballot([&](int l) {
+                const int it = w * 64 + l;
+                if (it >= n_its || !((in >> l) & 1)) return false;
+                bool v = true;
+                for (int q = 0; q < nr; ++q) if ((lm >> q) & 1) v = v && Pv.it_cap[(size_t)q * n_its + it] <= rem[q];
+                return !v;
+              });
+            }
+            if (excluded) KS_FAST_BAIL(24);
+          }
+          host_seq++;
+          ctr.ref_bin_evaluations++;
+          if (!((cs.tmplok >> t) & 1u)) continue;
+          const uint64_t m = M.tvmask[t] & cs.cvmask;
+          if (!fields_ok(m, cs.kdef)) continue;
+          int e = lookup(m);
+          if (e < 0) { e = create_entry(m); if (e < 0) KS_FAST_BAIL(25); }
+          const int32_t zero[4] = {0, 0, 0, 0};
+          if (!fits(e, zero, cs.size)) continue;
+          if (n_claims >= cap || n_claims >= S.max_claims) {
+            if (n_claims >= S.max_claims) { W::store(S.status_out, 1); if (W::leader()) *S.counters = ctr; W::sync(); return; }
+            KS_FAST_BAIL(26);
+          }
+          const int c = n_claims++;
+          if (W::leader()) {
+            FastClaim ns;
+            ns.vmask = m;
+            for (int q = 0; q < 4; ++q) ns.req[q] = cs.size[q];
+            lds_put(&cst[c], ns);
+            F.c_ent[c] = (uint16_t)e;
+            F.c_vdef[c] = M.tdef[t] | cs.kdef;
+            F.c_hostseq[c] = host_seq;
+            S.assign[pod] = (int32_t)c;
+            S.slot[pod] = 0;
+          }
+          W::sync();
+          order.append(c);
+          if (lm) {
+            // subtractMax (scheduler.go:1049-1066) over the claim's instance types: F(m) ∩ fits(size)
+            int64_t* rem = S.t_remaining + (size_t)t * (nr + 1);
+            const uint64_t* eits = F.ent_its + (size_t)e * iw;
+            const ProblemView& Pv = P;
+            const int n_its = P.n_its;
+            for (int q = 0; q < nr; ++q) if ((lm >> q) & 1) {
+              const int64_t mx = W::reduce_max_i64(n_its, [&](int it) {
+                if (!((eits[it >> 6] >> (it & 63)) & 1)) return INT64_MIN;
+                for (int z = 0; z < nr; ++z) if (Pv.it_alloc[(size_t)z * n_its + it] < (int64_t)cs.size[z]) return INT64_MIN;
+                return Pv.it_cap[(size_t)q * n_its + it];
+              });
+              W::store(&rem[q], rem[q] - mx);
+            }
+            W::sync();
+          }
+          made = true;
+        }
+        if (!made) KS_FAST_BAIL(27);   // an unschedulable pod: error codes and diagnostics come from the general engine
+      }
+    }
+    // results: the final order (the defect of the last commit stays unsorted, as in the reference) and the claims' state
+    {
+      const int n = order.n;
+      uint32_t* go = S.o_ord;
+      const o16 oo = order.ord; const o16 ok_ = order.key; const o16 op = order.pos;
+      FastClaim* gs = F.c_state; uint32_t* gn = F.c_npods;
+      const KS_LDS FastClaim* ls = cst;
+      W::for_n(n, [&](int i) { go[i] = oo[i]; });
+      W::for_n(n, [&](int c) { gs[c] = lds_get(&ls[c]); gn[c] = ok_[op[c]]; });
+    }
+    ctr.slow_sorts = order.slow_sorts;
+    W::store(S.n_claims_out, n_claims);
+    if (status) W::store(S.status_out, status);
+    if (W::leader()) *S.counters = ctr;
+    W::sync();
+  }
+};
+
+// ksolve_fast_records — one wavefront per claim: materialises the hot claim record the finalize kernel and the result
+// download read (ksp.h RecLayout) from the cursor engine's compact state: requirement masks = the template's with the
+// variable keys' fields, InstanceTypeOptions = F(requirement set) ∩ { allocatable >= requests }.
+struct FastRecordArgs {
+  ProblemView pv;
+  Workspace ws;
+  FastWork fw;
+};
+template <class W>
+KS_DEV void fast_record_body(int c, const FastRecordArgs& a) {
+  const ProblemView& P = a.pv;
+  const RecLayout ly = P.lay;
+  const Dict& d = P.dict;
+  const FastClaim st = a.fw.c_state[c];
+  const int t = (int)(st.vmask >> 56);
+  const uint32_t vdef = a.fw.c_vdef[c];
+  const FastVar fv = *a.fw.var;
+  uint64_t* rec = a.ws.c_hot + (size_t)c * ly.c_hot_words();
+  const uint64_t* tm = P.tmpl_reqs.mask + (size_t)t * d.req_words;
+  W::for_n(ly.rw, [&](int w) {
+    uint64_t v = tm[w];
+    for (int j = 0; j < fv.nv; ++j) if (fv.vword[j] == w && ((vdef >> fv.vkey[j]) & 1u)) v = (st.vmask >> fv.voff[j]) & (fv.vwidth[j] >= 64 ? ~0ull : ((1ull << fv.vwidth[j]) - 1));
+    rec[ly.c_mask() + w] = v;
+  });
+  const int iw = ly.iw, nr = ly.nr, n_its = P.n_its;
+  const uint64_t* eits = a.fw.ent_its + (size_t)a.fw.c_ent[c] * iw;
+  for (int j = 0; j < iw; ++j) {
+    const uint64_t in = eits[j];
+    const uint64_t okm = in ? W::ballot([&](int l) {
+      const int it = j * 64 + l;
+      if (it >= n_its || !((in >> l) & 1)) return false;
+      bool f = true;
+      for (int r = 0; r < nr; ++r) f = f && (int64_t)st.req[r] <= P.it_alloc[(size_t)r * n_its + it];
+      return f;
+    }) : 0ull;
+    W::store(&rec[ly.c_its() + j], okm);
+  }
+  W::for_n(nr, [&](int r) { rec[ly.c_total() + r] = (uint64_t)(int64_t)st.req[r]; rec[ly.c_head() + r] = 0; });
+  if (W::leader()) {
+    rec[ly.c_f0()] = (uint64_t)vdef;
+    rec[ly.c_f1()] = 0;
+    rec[ly.c_meta()] = (uint64_t)(uint32_t)t | ((uint64_t)a.fw.c_npods[c] << 32);
+    rec[ly.c_meta2()] = (uint64_t)a.fw.c_hostseq[c];
+  }
+  W::sync();
+}
+
+}  // namespace ks

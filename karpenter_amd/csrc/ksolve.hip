@@ -141,6 +141,16 @@ __global__ void __launch_bounds__(64) ksolve_pack_batch_lite(ks::BatchItem* item
   ks::Engine<ks::Wave, false> eng(it.pv, it.ws, tables);
   eng.solve();
 }
+// The cursor engine (fast_engine.h) for purely positive provisioning batches: one wavefront, O(1) steps.
+__global__ void __launch_bounds__(64) ksolve_pack_fast(ks::ProblemView pv, ks::Workspace ws, ks::FastWork fw) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  ks::FastEngine<ks::Wave> eng(pv, ws, fw, lds);
+  eng.solve();
+}
+// One wavefront per claim: hot claim records (requirement masks, InstanceTypeOptions) from the cursor engine's compact state.
+__global__ void __launch_bounds__(64) ksolve_fast_records(ks::FastRecordArgs a) {
+  ks::fast_record_body<ks::Wave>((int)blockIdx.x, a);
+}
 static dim3 grid_for(int n) { return dim3((unsigned)((n + 255) / 256)); }
 static void be_launch_it_index(ksolve_handle* h, int n, const ks::ItIndexArgs& a) { hipLaunchKernelGGL(ksolve_it_index, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
 static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_row_hash, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
@@ -156,6 +166,18 @@ static void be_launch_pack(ksolve_handle* h) {
   else if (h->pv.lite) hipLaunchKernelGGL(ksolve_pack_lite, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, h->pv, h->ws);
   else hipLaunchKernelGGL(ksolve_pack, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, h->pv, h->ws);
   hip_check(h, hipGetLastError(), "ksolve_pack launch");
+}
+
+static void be_launch_pack_fast(ksolve_handle* h) {
+  const int lds_bytes = h->fw.plan.total_bytes;
+  if (!hip_check(h, hipFuncSetAttribute((const void*)ksolve_pack_fast, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
+  hipLaunchKernelGGL(ksolve_pack_fast, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, h->pv, h->ws, h->fw);
+  hip_check(h, hipGetLastError(), "ksolve_pack_fast launch");
+}
+static void be_launch_fast_records(ksolve_handle* h, int n_claims) {
+  ks::FastRecordArgs a{h->pv, h->ws, h->fw};
+  hipLaunchKernelGGL(ksolve_fast_records, dim3((unsigned)n_claims), dim3(64), 0, HB(h)->stream, a);
+  hip_check(h, hipGetLastError(), "ksolve_fast_records launch");
 }
 
 // One launch per engine flavour (lite / full problems of the batch), each on the stream of its first handle so that the

@@ -15,6 +15,7 @@
 
 #include "../../include/ksolve.h"
 #include "engine.h"
+#include "fast_engine.h"
 #include "kernels.h"
 
 // Backend contract (provided by the including TU):
@@ -70,6 +71,8 @@ struct ksolve_handle {
   ks::LdsPlan lds_big{};   // LDS plan of the BIG engine, used once a solve overflowed the LDS-resident claim order
   bool big_capable = false;
   int lite_saved = 0;
+  ks::FastWork fw{};            // cursor engine (fast_engine.h): workspace + LDS plan; fw.enabled while the problem may qualify
+  uint32_t engine_used = 0, fast_reason = 0;
 };
 
 // ---- backend hooks (defined by the including TU before this point is instantiated) ----
@@ -88,6 +91,8 @@ static void be_launch_row_class(ksolve_handle* h, int n, const ks::RowArgs& a);
 static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a);
 static void be_sort_pods(ksolve_handle* h);  // fills ws/pv.sorted_pods
 static void be_launch_pack(ksolve_handle* h);
+static void be_launch_pack_fast(ksolve_handle* h);                 // one wavefront: FastEngine::solve
+static void be_launch_fast_records(ksolve_handle* h, int n_claims); // one wavefront per claim: fast_record_body
 static void be_launch_pack_batch(ksolve_handle** hs, int n);
 static void be_thread_init(ksolve_handle* h);   // makes the handle's device current on a worker thread   // one block per handle; sets every handle's T_PACK timer
 static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a);
@@ -521,6 +526,36 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     P.lite = 0;   // A/B builds only
 #endif
   }
+  {
+    // cursor engine (fast_engine.h): candidate when the problem is lite and has no relaxation rows; the kernel itself checks the
+    // rest (positive operators only, packed variable keys, 31-bit quantities) and hands the problem back otherwise
+    ks::FastWork& fw = h->fw;
+    fw.enabled = (P.lite && h->opts.engine != 1 && d->n_pod_rows == d->n_pods && d->n_pods > 0) ? 1 : 0;
+    if (fw.enabled) {
+      auto align = [](int x) { return (x + 15) & ~15; };
+      ks::FastPlan& fp = fw.plan;
+      int off = 0;
+      fp.off_ent = off; off = align(off + ks::kFastEnt * (int)sizeof(ks::FastEnt));
+      fp.off_pool = off; off = align(off + ks::kFastPool * 16);
+      fp.off_slot = off; off = align(off + ks::kFastSlots * (int)sizeof(ks::FastSlot));
+      fp.off_misc = off; off = align(off + (int)sizeof(ks::FastMisc));
+      const int budget = 160 * 1024 - 512;
+      int cap = ((budget - off - 64) / (int)(sizeof(ks::FastClaim) + 6)) & ~63;
+      if (cap > 65472) cap = 65472;
+      if (h->opts.lds_claim_cap && (int)((h->opts.lds_claim_cap + 63) & ~63u) < cap) cap = (int)((h->opts.lds_claim_cap + 63) & ~63u);
+      if (cap > (int)((mc + 63) & ~63u)) cap = (int)((mc + 63) & ~63u);
+      fp.cap = cap;
+      fp.off_state = off; off = align(off + cap * (int)sizeof(ks::FastClaim));
+      fp.off_key = off; off = align(off + cap * 2);
+      fp.off_ord = off; off = align(off + cap * 2);
+      fp.off_pos = off; off = align(off + cap * 2);
+      fp.total_bytes = off;
+      fw.var = dz<ks::FastVar>(h, 1);
+      fw.c_vdef = dz<uint32_t>(h, mc); fw.c_hostseq = dz<uint32_t>(h, mc); fw.c_ent = dz<uint16_t>(h, mc);
+      fw.c_state = dz<ks::FastClaim>(h, mc); fw.c_npods = dz<uint32_t>(h, mc);
+      fw.ent_its = dz<uint64_t>(h, (size_t)ks::kFastEnt * it_words);
+    }
+  }
   be_sync(h);
   be_toc(h, T_UPLOAD);
   if (!be_ok(h)) return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "device allocation/upload failed" : h->error);
@@ -547,6 +582,7 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
   ks::ProblemView& P = h->pv;
   ks::Workspace& W = h->ws;
   const uint32_t n_pods = h->n_pods, n_rows = h->n_rows, n_res = h->n_res;
+  h->engine_used = 1;
   if (fresh_context) { be_fill(h, h->d_cancel, 0, 4); be_sync(h); }
 
   // ---- phase 1: instance-type requirement index ----
@@ -598,6 +634,7 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
     R.cls_topo = h->has_topology ? dz<uint64_t>(h, (size_t)n_classes * 2 * R.topo_words) : nullptr;
     R.lay = P.lay;
     h->ws.dead = dz<uint64_t>(h, (size_t)n_classes * h->claim_words);
+    if (h->fw.enabled) { h->fw.cls = dz<ks::FastSlot>(h, n_classes); h->fw.slot_of = dz<uint16_t>(h, n_classes); }
     if (h->n_nodes) h->ws.n_dead = dz<uint64_t>(h, (size_t)n_classes * P.node_words);
   }
   if (n_classes > 0) {
@@ -779,6 +816,7 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   out->us_prepass = (h->timers.ms[T_INDEX] + h->timers.ms[T_CLASSIFY] + h->timers.ms[T_SORT]) * 1e3;
   out->us_pack = h->timers.ms[T_PACK] * 1e3; out->us_finalize = h->timers.ms[T_FINALIZE] * 1e3; out->us_download = h->timers.ms[T_DOWNLOAD] * 1e3;
   out->packing_cost = cost;
+  out->engine_used = h->engine_used; out->engine_fallback_reason = h->fast_reason;
   out->impl = im;
   return out->status;
 }
@@ -788,6 +826,31 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out, bool fresh_con
   memset(out, 0, sizeof(*out));
   ksolve_status st = solve_prepare(h, fresh_context);
   if (st != KSOLVE_OK) return st;
+  if (h->fw.enabled && !h->pv.big && h->n_pods && h->n_classes) {
+    // the cursor engine first; status 3 = "not my shape / stopped before any result": the general engine takes over
+    be_tic(h, T_PACK);
+    be_launch_pack_fast(h);
+    be_toc(h, T_PACK);
+    int status = 0, n_claims = 0;
+    be_d2h(h, &status, h->ws.status_out, 4);
+    be_d2h(h, &n_claims, h->ws.n_claims_out, 4);
+    be_sync(h);
+    if (be_ok(h) && status != 3 && status != 1) {
+      h->engine_used = 2;
+      if (n_claims) be_launch_fast_records(h, n_claims);
+      return solve_finish(h, out);
+    }
+    if (be_ok(h) && status == 3) {
+      ks::Counters ctr{};
+      be_d2h(h, &ctr, h->ws.counters, sizeof(ctr));
+      be_sync(h);
+      h->fast_reason = (uint32_t)ctr.cycles[20];
+    } else if (be_ok(h)) h->fast_reason = 100;   // more claims than max_claims: the general engine reports it (or moves to BIG)
+    if (h->opts.engine == 2) return fail(h, KSOLVE_ERR_UNSUPPORTED, "cursor engine declined the problem (reason " + std::to_string(h->fast_reason) + ")");
+    h->fw.enabled = 0;   // later solves of this handle go straight to the general engine
+    st = solve_prepare(h, false);
+    if (st != KSOLVE_OK) return st;
+  }
   be_tic(h, T_PACK);
   if (h->n_pods) be_launch_pack(h);
   be_toc(h, T_PACK);

@@ -117,15 +117,18 @@ struct Wave {
     return v;
   }
   // scalar store: one lane writes, every lane may read it back afterwards (same wave, program order)
-  template <class T>
-  KS_DEV static void store(T* p, T v) {
-    if (lane() == 0) *p = v;
+  template <class T, class V>
+  KS_DEV static void store(T* p, V v) {
+    if (lane() == 0) *p = (T)v;
   }
-  template <class T>
-  KS_DEV static void store(KS_LDS T* p, T v) {
-    if (lane() == 0) *p = v;
+  template <class T, class V>
+  KS_DEV static void store(KS_LDS T* p, V v) {
+    if (lane() == 0) *p = (T)v;
   }
   KS_DEV static bool leader() { return lane() == 0; }
+  // f(lane) on every lane (per-lane register state; no result)
+  template <class F>
+  KS_DEV static void each(F f) { f(lane()); }
   // A flag another agent (the host, over PCIe) may set while the kernel runs: a system-scope atomic load, so that it is
   // not served from the scalar or vector caches forever.
   KS_DEV static int poll_flag(const volatile int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -208,9 +211,11 @@ struct Wave {
   static int64_t lanes_max_i64(F f) { int64_t v = INT64_MIN; KS_LANES(l) { int64_t x = f(l); if (x > v) v = x; } return v; }
   template <class F>
   static uint64_t reduce_or(int n, F f) { uint64_t v = 0; for_n(n, [&](int i) { v |= f(i); }); return v; }
-  template <class T>
-  static void store(T* p, T v) { *p = v; }
+  template <class T, class V>
+  static void store(T* p, V v) { *p = (T)v; }
   static bool leader() { return true; }
+  template <class F>
+  static void each(F f) { KS_LANES(l) f(l); }
   static unsigned long long clock() { return 0; }
   static int poll_flag(const volatile int* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
   template <class F>
@@ -243,6 +248,32 @@ struct LaneVec64 {
   uint64_t v[64] = {};
   void set(int lane, uint64_t x) { v[lane] = x; }
   uint64_t get(int l) const { return v[l]; }
+#endif
+};
+
+// One value per lane that lives in a vector register on the device (an array of 64 in the host emulation);
+// bcast(lane) makes one lane's value wave-uniform (v_readlane, no LDS round trip).
+template <class T>
+struct LaneVar {
+#if KS_DEVICE
+  T v;
+  KS_DEV T& at(int) { return v; }
+  KS_DEV T bcast(int lane) const {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "LaneVar: 32- or 64-bit values");
+    if constexpr (sizeof(T) == 4) {
+      const int x = __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane);
+      return __builtin_bit_cast(T, x);
+    } else {
+      const uint64_t u = __builtin_bit_cast(uint64_t, v);
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, lane);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane);
+      return __builtin_bit_cast(T, (uint64_t)lo | ((uint64_t)hi << 32));
+    }
+  }
+#else
+  T v[64];
+  T& at(int l) { return v[l]; }
+  T bcast(int lane) const { return v[lane]; }
 #endif
 };
 

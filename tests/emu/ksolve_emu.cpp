@@ -89,6 +89,15 @@ static void be_launch_pack(ksolve_handle* h) {
   for (auto& g : gaps) __asan_unpoison_memory_region(lds.data() + g.first, (size_t)g.second);
 #endif
 }
+static void be_launch_pack_fast(ksolve_handle* h) {
+  std::vector<char> lds((size_t)h->fw.plan.total_bytes + 64, (char)0xA5);   // garbage, like the device's LDS at kernel start
+  ks::FastEngine<ks::Wave> eng(h->pv, h->ws, h->fw, lds.data());
+  eng.solve();
+}
+static void be_launch_fast_records(ksolve_handle* h, int n_claims) {
+  ks::FastRecordArgs a{h->pv, h->ws, h->fw};
+  for (int c = 0; c < n_claims; ++c) ks::fast_record_body<ks::Wave>(c, a);
+}
 static void be_launch_pack_batch(ksolve_handle** hs, int n) {
   for (int i = 0; i < n; ++i) { be_tic(hs[i], ksi::T_PACK); be_launch_pack(hs[i]); be_toc(hs[i], ksi::T_PACK); }
 }

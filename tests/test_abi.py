@@ -71,7 +71,7 @@ def test_header_is_plain_c(tmp_path):
     import subprocess
     probe = tmp_path / "probe.c"
     probe.write_text('#include <stdio.h>\n#include "ksolve.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(ksolve_problem_desc), '
-                     'sizeof(ksolve_topology), sizeof(ksolve_reqsets), sizeof(ksolve_options), sizeof(ksolve_claims), sizeof(ksolve_results)); return KSOLVE_ABI_VERSION == 3 ? 0 : 1; }\n')
+                     'sizeof(ksolve_topology), sizeof(ksolve_reqsets), sizeof(ksolve_options), sizeof(ksolve_claims), sizeof(ksolve_results)); return KSOLVE_ABI_VERSION == 4 ? 0 : 1; }\n')
     inc = os.path.join(ROOT, "include")
     sizes = []
     for cc, std, exe in (("gcc", "-std=c99", "probe_c"), ("g++", "-std=c++17", "probe_cpp")):
