@@ -12,8 +12,8 @@
 //     cached per distinct requirement set (a few hundred per problem) in LDS. The masks themselves are materialised once,
 //     after the loop, by ksolve_fast_records (one wavefront per claim).
 //  2. The requirement set of a claim is the template's plus a handful of keys pods select on; the values of those keys are
-//     packed into ONE 64-bit word per claim (`vmask`: bit = value still allowed), so Requirements.Compatible + Add
-//     (requirements.go:181-197, 133-140) is an AND and a few field tests in registers.
+//     packed into ONE 64-bit word per claim (`vmask`: bit = value still allowed, one guard bit after every key's field),
+//     so Requirements.Compatible + Add (requirements.go:181-197, 133-140) is an AND, an ADD and a compare in registers.
 //  3. CanAdd failures are permanent (fact 1), claims only move RIGHT in the reference's order when they gain a pod
 //     (sort.Slice by pod count, scheduler.go:598 — pdq_emul.h keeps Go's exact permutation), and a new claim enters at
 //     one known position. So each pod class keeps a cursor: "every claim left of it has rejected this class for good".
@@ -21,26 +21,31 @@
 //     cursor — in the steady state the claim AT the cursor — found by testing 64 positions per step, one lane each.
 //     Cursors live in vector registers (lane = class slot) and are kept valid under moves with three VALU ops.
 //
+// The hot loop touches LDS and registers only (claim state, order, requirement-set cache, class slots); HBM sees the
+// queue (64 pods per fetch) and the two result stores per pod.
+//
 // Everything this engine does not handle (an unschedulable pod, NodePool limits that actually exclude a type, more claims
 // than the LDS plan holds, non-positive operators, ...) makes it stop with status 3 before it has written a result;
 // the host then runs the general engine (engine.h) on the same problem. There is no CPU path.
 #pragma once
-#include "ksp.h"
+#include "kernels.h"
 #include "pdq_emul.h"
 
 namespace ks {
 
 constexpr int kFastRows = 4;          // class slots = 64 lanes x kFastRows registers
 constexpr int kFastSlots = 64 * kFastRows;
-constexpr int kFastEnt = 512;         // requirement-set cache entries (open addressing)
+constexpr int kFastEnt = 1024;        // requirement-set cache slots (open addressing, filled to 80% at most)
 constexpr int kFastPool = 256;        // extra Pareto vectors
 constexpr int kFastMaxPareto = 16;    // per requirement set
 constexpr int kFastMaxVar = 12;       // keys pods select on
-constexpr int kFastVarBits = 56;      // their dictionary values must fit 56 bits; the top byte of vmask is the template
+constexpr int kFastVarBits = 56;      // their dictionary values + one guard bit each must fit 56 bits; the top byte of vmask is the template
 
 struct FastClaim { uint64_t vmask; int32_t req[4]; };                                   // 24 B, LDS, by claim id
-struct FastSlot { uint64_t cvmask; int32_t size[4]; uint32_t tmplok; uint32_t kdef; };  // 32 B: a pod class as the scan needs it
-struct FastEnt { uint64_t vmask; int32_t cap[4]; uint32_t info; uint32_t idx; };        // 32 B: info bit0 valid, bits 8..15 extra vectors, bits 16..31 pool offset
+// a pod class as the scan needs it: values it admits (all ones on keys it does not select on), the fields it selects on,
+// requests, templates whose taints it tolerates and whose keys cover its custom keys, keys it defines
+struct FastSlot { uint64_t cvmask; uint64_t dmask; int32_t size[4]; uint32_t tmplok; uint32_t kdef; };  // 40 B
+struct FastEnt { uint64_t vmask; int32_t cap[4]; uint32_t info; uint32_t pad; };        // 32 B: info bit0 valid, bits 8..15 extra vectors, bits 16..31 pool offset
 
 struct FastPlan {   // LDS plan of ksolve_pack_fast (bytes), computed by the host
   int total_bytes, cap;
@@ -54,9 +59,9 @@ struct FastMisc {   // small LDS tables
   uint8_t vkey[kFastMaxVar], voff[kFastMaxVar], vwidth[kFastMaxVar];
   uint16_t vword[kFastMaxVar];         // dictionary word of the key
   uint64_t its[kMaxItWords], rem[kMaxItWords], cand[kMaxItWords];   // slow-path scratch
-  uint32_t blk_pod[64], blk_class[64];
+  uint32_t blk_pod[64];
+  uint16_t blk_class[64], blk_slot[64];
   uint16_t active[kFastSlots];         // class of each slot (for eviction)
-  uint64_t changed;                    // scratch flag
 };
 
 struct FastVar { int nv; uint8_t vkey[kFastMaxVar], voff[kFastMaxVar], vwidth[kFastMaxVar]; uint16_t vword[kFastMaxVar]; };   // the keys pods select on
@@ -65,7 +70,7 @@ struct FastWork {   // HBM workspace of the cursor engine (host-allocated when t
   FastVar* var;           // written by the pack kernel, read by ksolve_fast_records
   FastSlot* cls;          // [n_classes]
   uint16_t* slot_of;      // [n_classes]
-  uint32_t* c_vdef;       // [max_claims] keys the claim's requirement set defines
+  uint32_t* c_tdef;       // [max_claims] keys the claim's template defines (ksolve_fast_vdef adds the keys of its pods)
   uint32_t* c_hostseq;    // [max_claims]
   uint16_t* c_ent;        // [max_claims] cache entry of the claim's requirement set
   FastClaim* c_state;     // [max_claims] final state, written when the loop ends
@@ -76,12 +81,13 @@ struct FastWork {   // HBM workspace of the cursor engine (host-allocated when t
 };
 
 // whole-record moves between LDS and registers (a struct behind an address-space-3 pointer has no implicit copy)
+typedef uint64_t __attribute__((may_alias)) u64_alias;   // the records are moved as 8-byte words whatever their field types
 template <class T>
 KS_FN T lds_get(const KS_LDS T* p) {
   static_assert(sizeof(T) % 8 == 0, "lds_get: 8-byte multiples");
   T out;
-  uint64_t* o = (uint64_t*)&out;
-  const KS_LDS uint64_t* s = (const KS_LDS uint64_t*)p;
+  u64_alias* o = (u64_alias*)&out;
+  const KS_LDS u64_alias* s = (const KS_LDS u64_alias*)p;
 #pragma unroll
   for (int i = 0; i < (int)(sizeof(T) / 8); ++i) o[i] = s[i];
   return out;
@@ -89,8 +95,8 @@ KS_FN T lds_get(const KS_LDS T* p) {
 template <class T>
 KS_FN void lds_put(KS_LDS T* p, const T& v) {
   static_assert(sizeof(T) % 8 == 0, "lds_put: 8-byte multiples");
-  const uint64_t* o = (const uint64_t*)&v;
-  KS_LDS uint64_t* s = (KS_LDS uint64_t*)p;
+  const u64_alias* o = (const u64_alias*)&v;
+  KS_LDS u64_alias* s = (KS_LDS u64_alias*)p;
 #pragma unroll
   for (int i = 0; i < (int)(sizeof(T) / 8); ++i) s[i] = o[i];
 }
@@ -100,23 +106,25 @@ KS_FN void lds_put(KS_LDS T* p, const T& v) {
 template <class W>
 struct FastEngine {
   const ProblemView& P;
-  Workspace& S;
-  FastWork& F;
+  const Workspace& S;
+  const FastWork& F;
   typedef KS_LDS uint16_t* o16;
   ClaimOrder<W, o16> order;
   KS_LDS FastClaim* cst;
   KS_LDS FastEnt* ent;
   KS_LDS int32_t* pool;     // [kFastPool][4]
   KS_LDS FastSlot* aslot;
-  FastMisc& M;
-  Counters ctr{};
+  KS_LDS FastMisc* Mp;
+  // what the hot loop reads of the kernel arguments, as values (registers)
+  int32_t* const g_assign; uint32_t* const g_slot; uint16_t* const g_slot_of; const FastSlot* const g_cls;
+  unsigned long long n_pops = 0, n_steps = 0, n_tests = 0, n_ref = 0, n_evict = 0;
   int n_claims = 0, nv = 0, n_ent = 0, n_pool = 0, n_active = 0;
   uint32_t host_seq = 0, active_templates = 0;
   int bail_code = 0;
   LaneVar<uint32_t> cur[kFastRows];   // cursor of class slot (row * 64 + lane)
 
-  KS_DEV FastEngine(const ProblemView& p, Workspace& s, FastWork& f, char* lds)
-      : P(p), S(s), F(f), M(*(FastMisc*)(lds + f.plan.off_misc)) {
+  KS_DEV FastEngine(const ProblemView& p, const Workspace& s, const FastWork& f, char* lds)
+      : P(p), S(s), F(f), Mp((KS_LDS FastMisc*)(lds + f.plan.off_misc)), g_assign(s.assign), g_slot(s.slot), g_slot_of(f.slot_of), g_cls(f.cls) {
     const FastPlan& pl = f.plan;
     cst = (KS_LDS FastClaim*)(lds + pl.off_state);
     order.key = (o16)(lds + pl.off_key); order.ord = (o16)(lds + pl.off_ord); order.pos = (o16)(lds + pl.off_pos);
@@ -125,36 +133,41 @@ struct FastEngine {
     aslot = (KS_LDS FastSlot*)(lds + pl.off_slot);
   }
 
+  KS_DEV void write_counters() {
+    Counters c{};
+    c.bin_evaluations = n_tests; c.full_evaluations = n_steps; c.queue_pops = n_pops; c.sorts = n_pops; c.slow_sorts = order.slow_sorts;
+    c.column_resets = n_evict; c.ref_bin_evaluations = n_ref;
+    c.cycles[20] = (unsigned long long)bail_code;
+    if (W::leader()) *S.counters = c;
+    W::sync();
+  }
   KS_DEV void bail(int why) {
     bail_code = why;
     W::store(S.status_out, 3);
-    ctr.cycles[20] = (unsigned long long)why;
-    if (W::leader()) *S.counters = ctr;
-    W::sync();
+    write_counters();
   }
 
   // ---- requirement-set cache --------------------------------------------------------------------------------------
   KS_FN static uint32_t hash_vm(uint64_t vm) { return (uint32_t)((vm * 0x9E3779B97F4A7C15ull) >> 40) & (kFastEnt - 1); }
-  // entry of requirement set vm, or -1 (not cached yet). Per lane.
-  KS_FN int lookup(uint64_t vm) const {
+  // entry of requirement set vm (copied to `out`), or -1 (not cached yet). Per lane; one 32-byte LDS read per probe.
+  KS_FN int lookup(uint64_t vm, FastEnt& out) const {
     uint32_t h = hash_vm(vm);
     for (int probe = 0; probe < kFastEnt; ++probe) {
-      const uint32_t info = ent[h].info;
-      if (!(info & 1u)) return -1;
-      if (ent[h].vmask == vm) return (int)h;
+      out = lds_get(&ent[h]);
+      if (!(out.info & 1u)) return -1;
+      if (out.vmask == vm) return (int)h;
       h = (h + 1) & (kFastEnt - 1);
     }
     return -1;
   }
-  // "some instance type of entry e holds `req` + `size`" — CanAdd's filterInstanceTypesByRequirements verdict
-  KS_FN bool fits(int e, const int32_t* req, const int32_t* size) const {
+  // "some instance type of the entry holds `req` + `size`" — CanAdd's filterInstanceTypesByRequirements verdict
+  KS_FN bool fits(const FastEnt& e, const int32_t* req, const int32_t* size) const {
     bool ok = true;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ok = ok && size[r] <= ent[e].cap[r] - req[r];
-    if (ok) return true;
-    const uint32_t info = ent[e].info;
-    const int extra = (int)((info >> 8) & 0xFFu);
-    const int off = (int)(info >> 16);
+    for (int r = 0; r < 4; ++r) ok = ok && size[r] <= e.cap[r] - req[r];
+    if (ok || !(e.info >> 8)) return ok;
+    const int extra = (int)((e.info >> 8) & 0xFFu);
+    const int off = (int)(e.info >> 16);
     for (int i = 0; i < extra; ++i) {
       bool o2 = true;
 #pragma unroll
@@ -163,10 +176,11 @@ struct FastEngine {
     }
     return false;
   }
-  // Requirements.Compatible + Add on the packed form: every key the class selects on keeps at least one value
-  KS_FN bool fields_ok(uint64_t m, uint32_t kdef) const {
-    for (int j = 0; j < nv; ++j) if (((kdef >> M.vkey[j]) & 1u) && !(m & M.fmask[j])) return false;
-    return true;
+  // Requirements.Compatible + Add on the packed form: every key the class selects on keeps at least one value. Adding the
+  // all-ones field to the field carries into the guard bit above it exactly when the field is not empty.
+  KS_FN static bool fields_ok(uint64_t m, uint64_t dmask) {
+    const uint64_t g = (dmask << 1) & ~dmask;
+    return (((m & dmask) + dmask) & g) == g;
   }
 
   // F(requirement set vm) and its Pareto-maximal allocatable vectors -> a new cache entry. Wave-uniform slow path.
@@ -175,9 +189,9 @@ struct FastEngine {
     const int iw = P.it_words, n_its = P.n_its, nr = P.n_res;
     const Dict& d = P.dict;
     const ProblemView& Pv = P;
-    FastMisc& Mm = M;
+    KS_LDS FastMisc& Mm = *Mp;
     const uint64_t* tits = S.t_its + (size_t)t * iw;
-    uint64_t* its = M.its;
+    KS_LDS uint64_t* its = Mp->its;
     const int nvv = nv;
     // compatible(it, reqs) (nodeclaim.go:620-622) for the keys pods select on; the template's other keys are in t_its already
     W::for_n(iw, [&](int w) {
@@ -199,13 +213,13 @@ struct FastEngine {
     uint32_t zones = (1u << P.n_zones) - 1, cts = (1u << P.n_cts) - 1;
     {
       const uint64_t* tm = P.tmpl_reqs.mask + (size_t)t * d.req_words;
-      const uint32_t tdef = M.tdef[t];
+      const uint32_t tdef = Mp->tdef[t];
       if (d.key_zone >= 0 && ((tdef >> d.key_zone) & 1u)) zones &= (uint32_t)tm[d.key_word_off[d.key_zone]];
       if (d.key_ct >= 0 && ((tdef >> d.key_ct) & 1u)) cts &= (uint32_t)tm[d.key_word_off[d.key_ct]];
       for (int j = 0; j < nv; ++j) {
-        const uint32_t field = (uint32_t)((vm >> M.voff[j]) & (M.fmask[j] >> M.voff[j]));
-        if (M.vkey[j] == d.key_zone) zones &= field;
-        if (M.vkey[j] == d.key_ct) cts &= field;
+        const uint32_t field = (uint32_t)((vm >> Mp->voff[j]) & (Mp->fmask[j] >> Mp->voff[j]));
+        if (Mp->vkey[j] == d.key_zone) zones &= field;
+        if (Mp->vkey[j] == d.key_ct) cts &= field;
       }
     }
     uint64_t cells = 0;
@@ -217,25 +231,26 @@ struct FastEngine {
     }
     W::sync();
     // slot
+    if (n_ent * 5 >= kFastEnt * 4) return -1;
     uint32_t h = hash_vm(vm);
     while (ent[h].info & 1u) h = (h + 1) & (kFastEnt - 1);
-    if (n_ent * 2 >= kFastEnt) return -1;
     uint64_t* eits = F.ent_its + (size_t)h * iw;
     W::for_n(iw, [&](int w) { eits[w] = its[w]; });
     // Pareto-maximal allocatable vectors of F: repeatedly take the lexicographic maximum, drop what it dominates
-    uint64_t* rem = M.rem; uint64_t* cand = M.cand;
+    KS_LDS uint64_t* rem = Mp->rem; KS_LDS uint64_t* cand = Mp->cand;
     W::for_n(iw, [&](int w) { rem[w] = its[w]; });
-    int count = 0, poff = n_pool;
-    int32_t first[4] = {-1, -1, -1, -1};
+    int count = 0;
+    const int poff = n_pool;
+    int32_t f0 = -1, f1 = -1, f2 = -1, f3 = -1;
     for (;;) {
-      const uint64_t any = W::reduce_or(iw, [&](int w) { return rem[w]; });
+      const uint64_t any = W::reduce_or(iw, [&](int w) { return (uint64_t)rem[w]; });
       if (!any) break;
       W::for_n(iw, [&](int w) { cand[w] = rem[w]; });
-      int64_t v[4] = {0x3FFFFFFF, 0x3FFFFFFF, 0x3FFFFFFF, 0x3FFFFFFF};
+      int64_t v0 = 0x3FFFFFFF, v1 = 0x3FFFFFFF, v2 = 0x3FFFFFFF, v3 = 0x3FFFFFFF;
       for (int r = 0; r < nr; ++r) {
         const int64_t* al = P.it_alloc + (size_t)r * n_its;
         const int64_t mx = W::reduce_max_i64(iw * 64, [&](int it) { return (it < n_its && ((cand[it >> 6] >> (it & 63)) & 1)) ? al[it] : INT64_MIN; });
-        v[r] = mx;
+        if (r == 0) v0 = mx; else if (r == 1) v1 = mx; else if (r == 2) v2 = mx; else v3 = mx;
         for (int j = 0; j < iw; ++j) {
           const uint64_t in = cand[j];
           const uint64_t eq = in ? W::ballot([&](int l) { const int it = j * 64 + l; return it < n_its && ((in >> l) & 1) && al[it] == mx; }) : 0ull;
@@ -243,10 +258,10 @@ struct FastEngine {
         }
         W::sync();
       }
-      if (count == 0) { for (int r = 0; r < 4; ++r) first[r] = (int32_t)v[r]; }
+      if (count == 0) { f0 = (int32_t)v0; f1 = (int32_t)v1; f2 = (int32_t)v2; f3 = (int32_t)v3; }
       else {
         if (count > kFastMaxPareto || n_pool >= kFastPool) return -1;
-        for (int r = 0; r < 4; ++r) W::store(&pool[n_pool * 4 + r], (int32_t)v[r]);
+        if (W::leader()) { pool[n_pool * 4 + 0] = (int32_t)v0; pool[n_pool * 4 + 1] = (int32_t)v1; pool[n_pool * 4 + 2] = (int32_t)v2; pool[n_pool * 4 + 3] = (int32_t)v3; }
         n_pool++;
       }
       count++;
@@ -255,8 +270,10 @@ struct FastEngine {
         const uint64_t dom = in ? W::ballot([&](int l) {
           const int it = j * 64 + l;
           if (it >= n_its || !((in >> l) & 1)) return false;
-          bool le = true;
-          for (int r = 0; r < nr; ++r) le = le && Pv.it_alloc[(size_t)r * n_its + it] <= v[r];
+          bool le = Pv.it_alloc[it] <= v0;
+          if (nr > 1) le = le && Pv.it_alloc[(size_t)n_its + it] <= v1;
+          if (nr > 2) le = le && Pv.it_alloc[(size_t)2 * n_its + it] <= v2;
+          if (nr > 3) le = le && Pv.it_alloc[(size_t)3 * n_its + it] <= v3;
           return le;
         }) : 0ull;
         W::store(&rem[j], in & ~dom);
@@ -264,10 +281,11 @@ struct FastEngine {
       W::sync();
     }
     if (W::leader()) {
-      ent[h].vmask = vm;
-      for (int r = 0; r < 4; ++r) ent[h].cap[r] = first[r];
-      ent[h].info = 1u | ((uint32_t)(count > 1 ? count - 1 : 0) << 8) | ((uint32_t)poff << 16);
-      ent[h].idx = (uint32_t)n_ent;
+      FastEnt e;
+      e.vmask = vm; e.cap[0] = f0; e.cap[1] = f1; e.cap[2] = f2; e.cap[3] = f3;
+      e.info = 1u | ((uint32_t)(count > 1 ? count - 1 : 0) << 8) | ((uint32_t)poff << 16);
+      e.pad = 0;
+      lds_put(&ent[h], e);
     }
     n_ent++;
     W::sync();
@@ -280,7 +298,7 @@ struct FastEngine {
     const Dict& d = P.dict;
     const int nk = d.n_keys, iw = P.it_words, nr = P.n_res, n_its = P.n_its, nc = P.n_classes, T = P.n_templates;
     const ProblemView& Pv = P;
-    if (!P.lite || P.n_rows != P.n_pods || nr > 4 || T > 32 || nc > 65535) return 1;
+    if (!P.plain || P.n_rows != P.n_pods || nr > 4 || T > 32 || nc > 65534 || iw > kMaxItWords) return 1;
     // instance types: only In sets (positive), so that compatible() is monotone
     if (W::reduce_or(nk * iw, [&](int i) { return Pv.key_compl[i] | Pv.key_neg[i]; })) return 2;
     // templates: only In sets
@@ -297,17 +315,19 @@ struct FastEngine {
       if (d.key_word_off[k + 1] - d.key_word_off[k] != 1 || nv >= kFastMaxVar) return 6;
       const uint64_t valid = d.value_valid[d.key_word_off[k]];
       const int width = valid ? 64 - __builtin_clzll(valid) : 1;
-      if (bits + width > kFastVarBits) return 6;
+      if (bits + width + 1 > kFastVarBits) return 6;
       if (W::leader()) {
-        M.vkey[nv] = (uint8_t)k; M.voff[nv] = (uint8_t)bits; M.vwidth[nv] = (uint8_t)width; M.vword[nv] = (uint16_t)d.key_word_off[k];
-        M.fmask[nv] = ((width >= 64 ? ~0ull : ((1ull << width) - 1))) << bits;
+        Mp->vkey[nv] = (uint8_t)k; Mp->voff[nv] = (uint8_t)bits; Mp->vwidth[nv] = (uint8_t)width; Mp->vword[nv] = (uint16_t)d.key_word_off[k];
+        Mp->fmask[nv] = ((1ull << width) - 1) << bits;
       }
-      bits += width; nv++;
+      bits += width + 1;   // + the guard bit
+      nv++;
     }
+    W::sync();
     if (W::leader()) {
       FastVar fv;
       fv.nv = nv;
-      for (int j = 0; j < kFastMaxVar; ++j) { fv.vkey[j] = M.vkey[j]; fv.voff[j] = M.voff[j]; fv.vwidth[j] = M.vwidth[j]; fv.vword[j] = M.vword[j]; }
+      for (int j = 0; j < kFastMaxVar; ++j) { fv.vkey[j] = Mp->vkey[j]; fv.voff[j] = Mp->voff[j]; fv.vwidth[j] = Mp->vwidth[j]; fv.vword[j] = Mp->vword[j]; }
       *F.var = fv;
     }
     W::sync();
@@ -315,24 +335,22 @@ struct FastEngine {
     if (W::reduce_or(nr * n_its, [&](int i) { const int64_t a = Pv.it_alloc[i]; return (uint64_t)((a >= (1ll << 30) || a <= -(1ll << 30)) ? 1 : 0); })) return 7;
     if (W::reduce_or(nr * nc, [&](int i) { const int64_t a = Pv.cls_requests[i]; return (uint64_t)((a >= (1ll << 30) || a < 0) ? 1 : 0); })) return 7;
     // templates: packed form, and NewScheduler's prefilter (scheduler.go:156-171) with positive sets
-    FastMisc& Mm = M;
+    KS_LDS FastMisc& Mm = *Mp;
     const int nvv = nv;
     W::for_n(T, [&](int t) {
       const uint64_t* tm = Pv.tmpl_reqs.mask + (size_t)t * d.req_words;
       const uint32_t tdef = Pv.tmpl_reqs.defined[t];
-      uint64_t vm = ((uint64_t)t << 56) | ((1ull << kFastVarBits) - 1);
+      uint64_t vm = (uint64_t)t << 56;
       for (int j = 0; j < nvv; ++j) {
-        vm &= ~Mm.fmask[j];
         if ((tdef >> Mm.vkey[j]) & 1u) vm |= (tm[Mm.vword[j]] << Mm.voff[j]) & Mm.fmask[j];
         else vm |= Mm.fmask[j];
       }
-      // bits of the 56 that belong to no field stay set (harmless: class masks keep them set too)
       Mm.tvmask[t] = vm; Mm.tdef[t] = tdef;
     });
     active_templates = 0;
     for (int t = 0; t < T; ++t) {
       const uint64_t* tm = P.tmpl_reqs.mask + (size_t)t * d.req_words;
-      const uint32_t tdef = M.tdef[t];
+      const uint32_t tdef = Mp->tdef[t];
       uint64_t* tits = S.t_its + (size_t)t * iw;
       const uint64_t* tin = P.tmpl_its + (size_t)t * iw;
       W::for_n(iw, [&](int w) {
@@ -374,14 +392,16 @@ struct FastEngine {
     const uint64_t bad = W::reduce_or(nc, [&](int c) {
       const uint64_t* cm = Pv.cls_reqs.mask + (size_t)c * d.req_words;
       const uint32_t kdef = Pv.cls_reqs.defined[c];
-      uint64_t vm = ~0ull, badc = 0;
-      for (int j = 0; j < nvv; ++j) if ((kdef >> Mm.vkey[j]) & 1u) {
-        const uint64_t f = (cm[Mm.vword[j]] << Mm.voff[j]) & Mm.fmask[j];
-        if (!f) badc = 1;   // In [] == DoesNotExist: not positive
-        vm = (vm & ~Mm.fmask[j]) | f;
+      uint64_t vm = 0xFFull << 56, dm = 0, badc = 0;
+      for (int j = 0; j < nvv; ++j) {
+        if ((kdef >> Mm.vkey[j]) & 1u) {
+          const uint64_t f = (cm[Mm.vword[j]] << Mm.voff[j]) & Mm.fmask[j];
+          if (!f) badc = 1;   // In [] == DoesNotExist: not positive
+          vm |= f; dm |= Mm.fmask[j];
+        } else vm |= Mm.fmask[j];
       }
       FastSlot s;
-      s.cvmask = vm;
+      s.cvmask = vm; s.dmask = dm;
       for (int r = 0; r < 4; ++r) s.size[r] = r < nr ? (int32_t)Pv.cls_requests[(size_t)c * nr + r] : 0;
       uint32_t ok = 0;
       const uint64_t tol = Pv.cls_tolerates[c];
@@ -393,26 +413,34 @@ struct FastEngine {
     });
     if (bad) return 8;
     W::for_n(kFastEnt, [&](int i) { ent[i].info = 0; });
-    W::each([&](int l) { for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = 0; });
+    W::each([&](int l) {
+#pragma unroll
+      for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = 0;
+    });
     return 0;
   }
 
   // ---- class slots ------------------------------------------------------------------------------------------------
-  KS_DEV int slot_for(int k) {
-    uint16_t s = F.slot_of[k];
-    if (s != 0xFFFF) return (int)s;
+  // a class seen for the first time (or after an eviction) gets a slot: its cursor starts at position 0
+  KS_DEV int new_slot(int k, int bn) {
+    KS_LDS uint16_t* bs = Mp->blk_slot; KS_LDS uint16_t* bc = Mp->blk_class;
     if (n_active == kFastSlots) {
       // every slot taken: forget them all (their classes start again from position 0 if they ever come back)
-      const uint16_t* act = M.active; uint16_t* so = F.slot_of;
+      KS_LDS uint16_t* act = Mp->active; uint16_t* so = g_slot_of;
       W::for_n(kFastSlots, [&](int i) { so[act[i]] = 0xFFFF; });
-      W::each([&](int l) { for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = 0; });
+      W::for_n(64, [&](int l) { bs[l] = 0xFFFF; });
+      W::each([&](int l) {
+#pragma unroll
+        for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = 0;
+      });
       n_active = 0;
-      ctr.column_resets++;
+      n_evict++;
     }
     const int slot = n_active++;
-    const FastSlot rec = F.cls[k];
-    if (W::leader()) { lds_put(&aslot[slot], rec); M.active[slot] = (uint16_t)k; F.slot_of[k] = (uint16_t)slot; }
-    W::each([&](int l) { for (int j = 0; j < kFastRows; ++j) if (j * 64 + l == slot) cur[j].at(l) = 0; });
+    const FastSlot rec = g_cls[k];
+    if (W::leader()) { lds_put(&aslot[slot], rec); Mp->active[slot] = (uint16_t)k; g_slot_of[k] = (uint16_t)slot; }
+    W::for_n(64, [&](int l) { if (l < bn && bc[l] == (uint16_t)k) bs[l] = (uint16_t)slot; });   // later pods of the class in this block
+    set_cursor(slot, 0);
     W::sync();
     return slot;
   }
@@ -436,7 +464,6 @@ struct FastEngine {
     const int n = order.n;
     const int a = order.defect;
     const bool app = order.defect_append;
-    const int moved = (int)order.ord[a];
     // the single-defect cases whose effect is one stable move (pdq_emul.h sort()); everything else is diffed below
     bool exact = n <= 12;
     if (n >= 50) {
@@ -458,24 +485,33 @@ struct FastEngine {
       });
       return;
     }
-    order.sort();
-    const int b = (int)order.pos[moved];
     if (!app) {
-      // the claim moved from a to b >= a: positions (a, b] shifted left by one
-      if (b > a) W::each([&](int l) {
+      // the claim at a gained a pod: it moves right past the claims with a smaller count (one stable move)
+      const uint32_t mv = order.key[a];
+      order.defect = -1;
+      if (a + 1 >= n || !(order.key[a + 1] < mv)) return;
+      const o16 kq = order.key;
+      const int e = W::find_first(a + 1, n, [kq, mv](int x) { return !(kq[x] < mv); });
+      const int b = e - 1;
+      order.rotate_left(a, b);
+      // positions (a, b] shifted left by one
+      W::each([&](int l) {
 #pragma unroll
         for (int j = 0; j < kFastRows; ++j) { const uint32_t r = cur[j].at(l); cur[j].at(l) = r - (uint32_t)(((uint32_t)a < r && r <= (uint32_t)b) ? 1 : 0); }
       });
       return;
     }
+    const int moved = (int)order.ord[a];
+    order.sort();
+    const int b = (int)order.pos[moved];
     // the new claim moved from n-1 to b: positions [b, n-1) shifted right by one. A cursor past b has a claim in front of
     // it that its class never tested: test it now, one lane per class slot — an acceptor pulls the cursor back to b.
     const int nac = n_active;
-    const uint64_t cvm = cst[moved].vmask;
-    int32_t creq[4];
-    for (int r = 0; r < 4; ++r) creq[r] = cst[moved].req[r];
-    const int t = (int)(cvm >> 56);
-    for (int j = 0; j < kFastRows && j * 64 < nac; ++j) {
+    const FastClaim nst = lds_get(&cst[moved]);
+    const int t = (int)(nst.vmask >> 56);
+#pragma unroll
+    for (int j = 0; j < kFastRows; ++j) {
+      if (j * 64 >= nac) continue;
       uint64_t todo = W::ballot([&](int l) { return j * 64 + l < nac && cur[j].at(l) > (uint32_t)b; });
       while (todo) {
         LaneVar<uint64_t> missv;
@@ -486,11 +522,11 @@ struct FastEngine {
           const FastSlot s = lds_get(&aslot[j * 64 + l]);
           uint32_t nxt = cur[j].at(l) + 1;
           if ((s.tmplok >> t) & 1u) {
-            const uint64_t m = cvm & s.cvmask;
-            if (fields_ok(m, s.kdef)) {
-              const int e = lookup(m);
-              if (e < 0) { missv.at(l) = m; return true; }
-              if (fits(e, creq, s.size)) nxt = (uint32_t)b;
+            const uint64_t m = nst.vmask & s.cvmask;
+            if (fields_ok(m, s.dmask)) {
+              FastEnt e;
+              if (lookup(m, e) < 0) { missv.at(l) = m; return true; }
+              if (fits(e, nst.req, s.size)) nxt = (uint32_t)b;
             }
           }
           cur[j].at(l) = nxt;
@@ -506,25 +542,30 @@ struct FastEngine {
   KS_DEV void solve() {
     const int why = setup();
     if (why) KS_FAST_BAIL(why);
-    const int np = P.n_pods, cap = F.plan.cap, T = P.n_templates, nr = P.n_res, iw = P.it_words;
-    const uint32_t* sorted = P.sorted_pods;
-    const uint32_t* rc_ = P.row_class;
+    const int np = P.n_pods, cap = F.plan.cap, T = P.n_templates, nr = P.n_res, iw = P.it_words, max_claims = S.max_claims;
+    const uint32_t* const sorted = P.sorted_pods;
+    const uint32_t* const rc_ = P.row_class;
+    const volatile int* const cancel = S.cancel_flag;
+    const long long max_steps = S.max_steps;
     int status = 0;
     long long steps = 0;
     for (int base = 0; base < np && !status; base += 64) {
       const int bn = np - base < 64 ? np - base : 64;
-      uint32_t* bp = M.blk_pod; uint32_t* bc = M.blk_class;
-      W::for_n(64, [&](int l) { if (l < bn) { const uint32_t p = sorted[base + l]; bp[l] = p; bc[l] = rc_[p]; } });
-      if (S.cancel_flag && W::poll_flag(S.cancel_flag)) { status = 2; break; }
+      {
+        KS_LDS uint32_t* bp = Mp->blk_pod; KS_LDS uint16_t* bc = Mp->blk_class; KS_LDS uint16_t* bs = Mp->blk_slot;
+        const uint16_t* so = g_slot_of;
+        W::for_n(64, [&](int l) { if (l < bn) { const uint32_t p = sorted[base + l]; const uint32_t k = rc_[p]; bp[l] = p; bc[l] = (uint16_t)k; bs[l] = so[k]; } });
+      }
+      if (cancel && W::poll_flag(cancel)) { status = 2; break; }
       for (int bi = 0; bi < bn; ++bi) {
-        if (S.max_steps >= 0 && steps >= S.max_steps) { status = 2; break; }
+        if (max_steps >= 0 && steps >= max_steps) { status = 2; break; }
         steps++;
-        const int pod = (int)M.blk_pod[bi];
-        const int k = (int)M.blk_class[bi];
-        ctr.queue_pops++; ctr.sorts++;
+        const int pod = (int)Mp->blk_pod[bi];
+        int slot = (int)Mp->blk_slot[bi];
+        n_pops++;
         sort_and_fix();
         if (bail_code) KS_FAST_BAIL(bail_code);
-        const int slot = slot_for(k);
+        if (slot == 0xFFFF) slot = new_slot((int)Mp->blk_class[bi], bn);
         const FastSlot cs = lds_get(&aslot[slot]);
         uint32_t r = get_cursor(slot);
         const int n = order.n;
@@ -532,30 +573,30 @@ struct FastEngine {
         while ((int)r < n) {
           // addToInflightNode: positions r .. r+63, one lane each
           LaneVar<uint64_t> mv;
-          LaneVar<uint32_t> xv;
-          LaneVar<int32_t> ev;
-          uint64_t miss = 0;
+          LaneVar<uint32_t> xv, fl;   // fl: 0 = rejected before the cache, 1 = requirement set not cached yet, 2 = tested
+          LaneVar<int32_t> q0, q1, q2, q3;
           const uint32_t r0 = r;
           const o16 oo = order.ord;
           const uint64_t okm = W::ballot([&](int l) {
             const int p = (int)r0 + l;
-            mv.at(l) = 0; ev.at(l) = -2; xv.at(l) = 0;
+            fl.at(l) = 0;
             if (p >= n) return false;
             const uint32_t x = oo[p];
             xv.at(l) = x;
             const FastClaim st = lds_get(&cst[x]);
+            q0.at(l) = st.req[0]; q1.at(l) = st.req[1]; q2.at(l) = st.req[2]; q3.at(l) = st.req[3];
             if (!((cs.tmplok >> (st.vmask >> 56)) & 1u)) return false;
             const uint64_t m = st.vmask & cs.cvmask;
-            if (!fields_ok(m, cs.kdef)) return false;
+            if (!fields_ok(m, cs.dmask)) return false;
             mv.at(l) = m;
-            const int e = lookup(m);
-            ev.at(l) = e;
-            if (e < 0) return false;
+            FastEnt e;
+            if (lookup(m, e) < 0) { fl.at(l) = 1; return false; }
+            fl.at(l) = 2;
             return fits(e, st.req, cs.size);
           });
-          miss = W::ballot([&](int l) { return ev.at(l) == -1; });
-          ctr.bin_evaluations += (unsigned long long)(n - (int)r0 < 64 ? n - (int)r0 : 64);
-          ctr.full_evaluations++;
+          const uint64_t miss = W::ballot([&](int l) { return fl.at(l) == 1; });
+          n_tests += (unsigned long long)(n - (int)r0 < 64 ? n - (int)r0 : 64);
+          n_steps++;
           const int first_ok = okm ? ctz64(okm) : 64;
           const int first_miss = miss ? ctz64(miss) : 64;
           if (first_miss < first_ok) {
@@ -567,24 +608,22 @@ struct FastEngine {
           // commit: NodeClaim.Add (nodeclaim.go:247-263)
           const int a = (int)r0 + first_ok;
           const int x = (int)xv.bcast(first_ok);
-          const uint64_t m = mv.bcast(first_ok);
-          const int e = ev.bcast(first_ok);
-          const FastClaim st = lds_get(&cst[x]);
           const uint32_t cnt = order.key[a];
           if (cnt >= 65534u) KS_FAST_BAIL(22);
+          FastClaim ns;
+          ns.vmask = mv.bcast(first_ok);
+          ns.req[0] = q0.bcast(first_ok) + cs.size[0]; ns.req[1] = q1.bcast(first_ok) + cs.size[1];
+          ns.req[2] = q2.bcast(first_ok) + cs.size[2]; ns.req[3] = q3.bcast(first_ok) + cs.size[3];
           if (W::leader()) {
-            FastClaim ns;
-            ns.vmask = m;
-            for (int q = 0; q < 4; ++q) ns.req[q] = st.req[q] + cs.size[q];
             lds_put(&cst[x], ns);
-            if (m != st.vmask) F.c_ent[x] = (uint16_t)e;
-            const uint32_t vd = F.c_vdef[x];
-            if ((vd | cs.kdef) != vd) F.c_vdef[x] = vd | cs.kdef;
-            S.assign[pod] = (int32_t)x;
-            S.slot[pod] = cnt;
+            g_assign[pod] = (int32_t)x;
+            g_slot[pod] = cnt;
           }
-          ctr.ref_bin_evaluations += (unsigned long long)a + 1;
-          order.increment(x);
+          n_ref += (unsigned long long)a + 1;
+          // order.increment(x) with the position already known
+          W::store(&order.key[a], cnt + 1);
+          W::sync();
+          order.defect = a; order.defect_append = false;
           r = (uint32_t)a;
           placed = true;
           break;
@@ -592,7 +631,7 @@ struct FastEngine {
         set_cursor(slot, r);
         if (placed) continue;
         // addToNewNodeClaim (scheduler.go:695-790)
-        ctr.ref_bin_evaluations += (unsigned long long)n;
+        n_ref += (unsigned long long)n;
         bool made = false;
         for (int t = 0; t < T && !made; ++t) {
           if (!((active_templates >> t) & 1u)) continue;
@@ -619,36 +658,34 @@ struct FastEngine {
             if (excluded) KS_FAST_BAIL(24);
           }
           host_seq++;
-          ctr.ref_bin_evaluations++;
+          n_ref++;
           if (!((cs.tmplok >> t) & 1u)) continue;
-          const uint64_t m = M.tvmask[t] & cs.cvmask;
-          if (!fields_ok(m, cs.kdef)) continue;
-          int e = lookup(m);
-          if (e < 0) { e = create_entry(m); if (e < 0) KS_FAST_BAIL(25); }
+          const uint64_t m = Mp->tvmask[t] & cs.cvmask;
+          if (!fields_ok(m, cs.dmask)) continue;
+          FastEnt e;
+          int eh = lookup(m, e);
+          if (eh < 0) { eh = create_entry(m); if (eh < 0) KS_FAST_BAIL(25); e = lds_get(&ent[eh]); }
           const int32_t zero[4] = {0, 0, 0, 0};
           if (!fits(e, zero, cs.size)) continue;
-          if (n_claims >= cap || n_claims >= S.max_claims) {
-            if (n_claims >= S.max_claims) { W::store(S.status_out, 1); if (W::leader()) *S.counters = ctr; W::sync(); return; }
-            KS_FAST_BAIL(26);
-          }
+          if (n_claims >= max_claims) { W::store(S.status_out, 1); write_counters(); return; }
+          if (n_claims >= cap) KS_FAST_BAIL(26);
           const int c = n_claims++;
           if (W::leader()) {
             FastClaim ns;
             ns.vmask = m;
             for (int q = 0; q < 4; ++q) ns.req[q] = cs.size[q];
             lds_put(&cst[c], ns);
-            F.c_ent[c] = (uint16_t)e;
-            F.c_vdef[c] = M.tdef[t] | cs.kdef;
+            F.c_tdef[c] = Mp->tdef[t];
             F.c_hostseq[c] = host_seq;
-            S.assign[pod] = (int32_t)c;
-            S.slot[pod] = 0;
+            g_assign[pod] = (int32_t)c;
+            g_slot[pod] = 0;
           }
           W::sync();
           order.append(c);
           if (lm) {
             // subtractMax (scheduler.go:1049-1066) over the claim's instance types: F(m) ∩ fits(size)
             int64_t* rem = S.t_remaining + (size_t)t * (nr + 1);
-            const uint64_t* eits = F.ent_its + (size_t)e * iw;
+            const uint64_t* eits = F.ent_its + (size_t)eh * iw;
             const ProblemView& Pv = P;
             const int n_its = P.n_its;
             for (int q = 0; q < nr; ++q) if ((lm >> q) & 1) {
@@ -663,26 +700,42 @@ struct FastEngine {
           }
           made = true;
         }
+#if !KS_DEVICE
+        if (!made && getenv("KS_FAST_DEBUG")) fprintf(stderr, "bail27 pod %d slot %d tmplok %x cv %llx dm %llx size %d %d %d %d act %x n %d\n", pod, slot, cs.tmplok, (unsigned long long)cs.cvmask, (unsigned long long)cs.dmask, cs.size[0], cs.size[1], cs.size[2], cs.size[3], active_templates, n);
+#endif
         if (!made) KS_FAST_BAIL(27);   // an unschedulable pod: error codes and diagnostics come from the general engine
       }
     }
-    // results: the final order (the defect of the last commit stays unsorted, as in the reference) and the claims' state
+    // results: the final order (the defect of the last commit stays unsorted, as in the reference), the claims' state and
+    // the cache entry of each claim's requirement set
     {
       const int n = order.n;
       uint32_t* go = S.o_ord;
       const o16 oo = order.ord; const o16 ok_ = order.key; const o16 op = order.pos;
-      FastClaim* gs = F.c_state; uint32_t* gn = F.c_npods;
+      FastClaim* gs = F.c_state; uint32_t* gn = F.c_npods; uint16_t* ge = F.c_ent;
       const KS_LDS FastClaim* ls = cst;
       W::for_n(n, [&](int i) { go[i] = oo[i]; });
-      W::for_n(n, [&](int c) { gs[c] = lds_get(&ls[c]); gn[c] = ok_[op[c]]; });
+      W::for_n(n, [&](int c) {
+        const FastClaim st = lds_get(&ls[c]);
+        FastEnt e;
+        gs[c] = st; gn[c] = ok_[op[c]]; ge[c] = (uint16_t)lookup(st.vmask, e);
+      });
     }
-    ctr.slow_sorts = order.slow_sorts;
     W::store(S.n_claims_out, n_claims);
     if (status) W::store(S.status_out, status);
-    if (W::leader()) *S.counters = ctr;
-    W::sync();
+    write_counters();
   }
 };
+
+// ksolve_fast_vdef — one thread per pod: the keys a claim's requirement set defines are its template's plus those of the
+// pods it holds (Requirements.Add, requirements.go:133-140).
+struct FastVdefArgs { int n_pods; const int32_t* assign; const uint32_t* row_class; const FastSlot* cls; uint32_t* c_vdef; };
+KS_FN void fast_vdef_body(int p, const FastVdefArgs& a) {
+  const int32_t c = a.assign[p];
+  if (c < 0) return;
+  const uint32_t kd = a.cls[a.row_class[p]].kdef;
+  if (kd & ~a.c_vdef[c]) atomic_or_u32(&a.c_vdef[c], kd);
+}
 
 // ksolve_fast_records — one wavefront per claim: materialises the hot claim record the finalize kernel and the result
 // download read (ksp.h RecLayout) from the cursor engine's compact state: requirement masks = the template's with the
@@ -699,13 +752,13 @@ KS_DEV void fast_record_body(int c, const FastRecordArgs& a) {
   const Dict& d = P.dict;
   const FastClaim st = a.fw.c_state[c];
   const int t = (int)(st.vmask >> 56);
-  const uint32_t vdef = a.fw.c_vdef[c];
+  const uint32_t vdef = a.fw.c_tdef[c];
   const FastVar fv = *a.fw.var;
   uint64_t* rec = a.ws.c_hot + (size_t)c * ly.c_hot_words();
   const uint64_t* tm = P.tmpl_reqs.mask + (size_t)t * d.req_words;
   W::for_n(ly.rw, [&](int w) {
     uint64_t v = tm[w];
-    for (int j = 0; j < fv.nv; ++j) if (fv.vword[j] == w && ((vdef >> fv.vkey[j]) & 1u)) v = (st.vmask >> fv.voff[j]) & (fv.vwidth[j] >= 64 ? ~0ull : ((1ull << fv.vwidth[j]) - 1));
+    for (int j = 0; j < fv.nv; ++j) if (fv.vword[j] == w && ((vdef >> fv.vkey[j]) & 1u)) v = (st.vmask >> fv.voff[j]) & ((1ull << fv.vwidth[j]) - 1);
     rec[ly.c_mask() + w] = v;
   });
   const int iw = ly.iw, nr = ly.nr, n_its = P.n_its;

@@ -15,8 +15,8 @@
 
 #include "../../include/ksolve.h"
 #include "engine.h"
-#include "fast_engine.h"
 #include "kernels.h"
+#include "fast_engine.h"
 
 // Backend contract (provided by the including TU):
 //   void* be_alloc(ksolve_handle*, size_t bytes)  — zero-initialised device memory owned by the handle
@@ -92,7 +92,7 @@ static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a
 static void be_sort_pods(ksolve_handle* h);  // fills ws/pv.sorted_pods
 static void be_launch_pack(ksolve_handle* h);
 static void be_launch_pack_fast(ksolve_handle* h);                 // one wavefront: FastEngine::solve
-static void be_launch_fast_records(ksolve_handle* h, int n_claims); // one wavefront per claim: fast_record_body
+static void be_launch_fast_records(ksolve_handle* h, int n_claims); // fast_vdef_body per pod, then one wavefront per claim: fast_record_body
 static void be_launch_pack_batch(ksolve_handle** hs, int n);
 static void be_thread_init(ksolve_handle* h);   // makes the handle's device current on a worker thread   // one block per handle; sets every handle's T_PACK timer
 static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a);
@@ -520,8 +520,8 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     if (d->tmpl_reqs.min_values) for (size_t i = 0; i < (size_t)d->n_templates * d->n_keys; ++i) if (d->tmpl_reqs.min_values[i] >= 0) any_minv = true;
     const bool bounds = any_nonzero(d->pod_reqs.has_gte, d->n_pod_rows) || any_nonzero(d->pod_reqs.has_lte, d->n_pod_rows) ||
                         any_nonzero(d->tmpl_reqs.has_gte, d->n_templates) || any_nonzero(d->tmpl_reqs.has_lte, d->n_templates);
-    P.lite = (d->topo.n == 0 && d->n_nodes == 0 && !d->tmpl_daemon_first && !any_minv && !P.reserved_on && !bounds && req_words <= 64 &&
-              it_words <= 8 && d->n_res <= 4) ? 1 : 0;
+    P.plain = (d->topo.n == 0 && d->n_nodes == 0 && !d->tmpl_daemon_first && !any_minv && !P.reserved_on && !bounds) ? 1 : 0;
+    P.lite = (P.plain && req_words <= 64 && it_words <= 8 && d->n_res <= 4) ? 1 : 0;
 #ifdef KSOLVE_NO_LITE
     P.lite = 0;   // A/B builds only
 #endif
@@ -530,7 +530,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     // cursor engine (fast_engine.h): candidate when the problem is lite and has no relaxation rows; the kernel itself checks the
     // rest (positive operators only, packed variable keys, 31-bit quantities) and hands the problem back otherwise
     ks::FastWork& fw = h->fw;
-    fw.enabled = (P.lite && h->opts.engine != 1 && d->n_pod_rows == d->n_pods && d->n_pods > 0) ? 1 : 0;
+    fw.enabled = (P.plain && d->n_res <= 4 && h->opts.engine != 1 && d->n_pod_rows == d->n_pods && d->n_pods > 0) ? 1 : 0;
     if (fw.enabled) {
       auto align = [](int x) { return (x + 15) & ~15; };
       ks::FastPlan& fp = fw.plan;
@@ -551,7 +551,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       fp.off_pos = off; off = align(off + cap * 2);
       fp.total_bytes = off;
       fw.var = dz<ks::FastVar>(h, 1);
-      fw.c_vdef = dz<uint32_t>(h, mc); fw.c_hostseq = dz<uint32_t>(h, mc); fw.c_ent = dz<uint16_t>(h, mc);
+      fw.c_tdef = dz<uint32_t>(h, mc); fw.c_hostseq = dz<uint32_t>(h, mc); fw.c_ent = dz<uint16_t>(h, mc);
       fw.c_state = dz<ks::FastClaim>(h, mc); fw.c_npods = dz<uint32_t>(h, mc);
       fw.ent_its = dz<uint64_t>(h, (size_t)ks::kFastEnt * it_words);
     }
@@ -826,6 +826,8 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out, bool fresh_con
   memset(out, 0, sizeof(*out));
   ksolve_status st = solve_prepare(h, fresh_context);
   if (st != KSOLVE_OK) return st;
+  if (h->opts.engine == 2 && !(h->fw.enabled && !h->pv.big && h->n_pods && h->n_classes))
+    return fail(h, KSOLVE_ERR_UNSUPPORTED, "cursor engine requested for a problem outside its shape (topology / existing nodes / minValues / reservations / relaxation rows)");
   if (h->fw.enabled && !h->pv.big && h->n_pods && h->n_classes) {
     // the cursor engine first; status 3 = "not my shape / stopped before any result": the general engine takes over
     be_tic(h, T_PACK);

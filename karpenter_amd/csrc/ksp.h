@@ -181,7 +181,8 @@ struct ProblemView {
   const uint8_t* pod_from_deleting; // [n_pods]
   TopoView topo;
   int big;                       // more in-flight claims than the LDS order holds: Engine<W, true, true> (order in HBM)
-  int lite;                      // no topology groups, existing nodes, daemon overhead, minValues or reservations: Engine<W, false>
+  int plain;                     // no topology groups, existing nodes, daemon overhead, minValues, reservations or bounds (any size)
+  int lite;                      // plain and small enough for the register tables:, existing nodes, daemon overhead, minValues or reservations: Engine<W, false>
 };
 
 struct Counters {
