@@ -39,6 +39,7 @@ constexpr int kFastEnt = 1024;        // requirement-set cache slots (open addre
 constexpr int kFastPool = 256;        // extra Pareto vectors
 constexpr int kFastMaxPareto = 16;    // per requirement set
 constexpr int kFastMaxVar = 12;       // keys pods select on
+constexpr int kFastClasses = 8192;    // pod classes per problem (class -> slot table in LDS)
 constexpr int kFastVarBits = 56;      // their dictionary values + one guard bit each must fit 56 bits; the top byte of vmask is the template
 
 struct FastClaim { uint64_t vmask; int32_t req[4]; };                                   // 24 B, LDS, by claim id
@@ -49,7 +50,7 @@ struct FastEnt { uint64_t vmask; int32_t cap[4]; uint32_t info; uint32_t pad; };
 
 struct FastPlan {   // LDS plan of ksolve_pack_fast (bytes), computed by the host
   int total_bytes, cap;
-  int off_state, off_key, off_ord, off_pos, off_ent, off_pool, off_slot, off_misc;
+  int off_state, off_key, off_ord, off_snap, off_ent, off_pool, off_slot, off_misc;
 };
 
 struct FastMisc {   // small LDS tables
@@ -59,9 +60,13 @@ struct FastMisc {   // small LDS tables
   uint8_t vkey[kFastMaxVar], voff[kFastMaxVar], vwidth[kFastMaxVar];
   uint16_t vword[kFastMaxVar];         // dictionary word of the key
   uint64_t its[kMaxItWords], rem[kMaxItWords], cand[kMaxItWords];   // slow-path scratch
-  uint32_t blk_pod[64];
-  uint16_t blk_class[64], blk_slot[64];
+  uint32_t blk_pod[64];                // the 64 queue entries being placed
+  uint16_t blk_class[64];
+  uint32_t out_claim[64];              // their results, written to HBM when the block is done
+  uint32_t out_cnt[64];
   uint16_t active[kFastSlots];         // class of each slot (for eviction)
+  uint16_t slot_of[kFastClasses];      // class -> slot, 0xFFFF = none
+  uint64_t acc[kFastRows];             // class slots that accept the claim just created (place_new_claim)
 };
 
 struct FastVar { int nv; uint8_t vkey[kFastMaxVar], voff[kFastMaxVar], vwidth[kFastMaxVar]; uint16_t vword[kFastMaxVar]; };   // the keys pods select on
@@ -69,7 +74,6 @@ struct FastVar { int nv; uint8_t vkey[kFastMaxVar], voff[kFastMaxVar], vwidth[kF
 struct FastWork {   // HBM workspace of the cursor engine (host-allocated when the problem may qualify)
   FastVar* var;           // written by the pack kernel, read by ksolve_fast_records
   FastSlot* cls;          // [n_classes]
-  uint16_t* slot_of;      // [n_classes]
   uint32_t* c_tdef;       // [max_claims] keys the claim's template defines (ksolve_fast_vdef adds the keys of its pods)
   uint32_t* c_hostseq;    // [max_claims]
   uint16_t* c_ent;        // [max_claims] cache entry of the claim's requirement set
@@ -103,88 +107,122 @@ KS_FN void lds_put(KS_LDS T* p, const T& v) {
 
 #define KS_FAST_BAIL(why) do { bail(why); return; } while (0)
 
+// What ksolve_pack_fast reads its problem from: ONE record in HBM (not kernel arguments: a by-value argument whose address
+// is taken is copied to private memory, and loads from private memory are divergent to the compiler — every branch of the
+// wave-uniform loop would be compiled as a divergent one).
+struct FastArgs { ProblemView pv; Workspace ws; FastWork fw; };
+
+// a wave-uniform value the compiler cannot prove uniform: pin it to scalar registers
+KS_FN int fast_uniform(int v) {
+#if KS_DEVICE
+  return __builtin_amdgcn_readfirstlane(v);
+#else
+  return v;
+#endif
+}
+#if KS_DEVICE
+template <class T>
+KS_FN KS_LDS T* fast_uniform(KS_LDS T* p) {
+  return (KS_LDS T*)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);
+}
+#endif
+template <class T>
+KS_FN T* fast_uniform(T* p) {
+#if KS_DEVICE
+  const uint64_t u = (uint64_t)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+  return (T*)((uint64_t)lo | ((uint64_t)hi << 32));
+#else
+  return p;
+#endif
+}
+
+#if KS_DEVICE
+#define KS_COLD __device__ __attribute__((noinline))
+#else
+#define KS_COLD inline
+#endif
+
+// requirement-set cache helpers (per lane)
+KS_FN uint32_t fast_hash(uint64_t vm) { return (uint32_t)((vm * 0x9E3779B97F4A7C15ull) >> 40) & (kFastEnt - 1); }
+// entry of requirement set vm (copied to `out`), or -1 (not cached yet); one 32-byte LDS read per probe
+KS_FN int fast_lookup(const KS_LDS FastEnt* ent, uint64_t vm, FastEnt& out) {
+  uint32_t h = fast_hash(vm);
+  for (int probe = 0; probe < kFastEnt; ++probe) {
+    out = lds_get(&ent[h]);
+    if (!(out.info & 1u)) return -1;
+    if (out.vmask == vm) return (int)h;
+    h = (h + 1) & (kFastEnt - 1);
+  }
+  return -1;
+}
+KS_FN bool fast_fits_first(const FastEnt& e, const int32_t* req, const int32_t* size) {
+  bool ok = true;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ok = ok && size[r] <= e.cap[r] - req[r];
+  return ok;
+}
+// "some instance type of the entry holds `req` + `size`" — CanAdd's filterInstanceTypesByRequirements verdict
+KS_FN bool fast_fits(const KS_LDS int32_t* pool, const FastEnt& e, const int32_t* req, const int32_t* size) {
+  if (fast_fits_first(e, req, size)) return true;
+  const int extra = (int)((e.info >> 8) & 0xFFu);
+  const int off = (int)(e.info >> 16);
+  for (int i = 0; i < extra; ++i) {
+    bool o2 = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o2 = o2 && size[r] <= pool[(off + i) * 4 + r] - req[r];
+    if (o2) return true;
+  }
+  return false;
+}
+// Requirements.Compatible + Add on the packed form: every key the class selects on keeps at least one value. Adding the
+// all-ones field to the field carries into the guard bit above it exactly when the field is not empty.
+KS_FN bool fast_fields_ok(uint64_t m, uint64_t dmask) {
+  const uint64_t g = (dmask << 1) & ~dmask;
+  return (((m & dmask) + dmask) & g) == g;
+}
+KS_FN bool fast_sampled(int n, int p) {   // choosePivot's nine positions (pdq_emul.h sort())
+  const int q = n / 4;
+  return (p >= q - 1 && p <= q + 1) || (p >= 2 * q - 1 && p <= 2 * q + 1) || (p >= 3 * q - 1 && p <= 3 * q + 1);
+}
+
+// Everything that happens rarely (a new requirement set, a new claim, a new class slot, pdqsort leaving its single-move
+// path): real function calls, so that their code and registers stay out of the loop that places a pod.
 template <class W>
-struct FastEngine {
-  const ProblemView& P;
-  const Workspace& S;
-  const FastWork& F;
+struct FastCold {
+  const ProblemView* Pk;
+  const Workspace* Sk;
+  const FastWork* Fk;
   typedef KS_LDS uint16_t* o16;
-  ClaimOrder<W, o16> order;
+  ClaimOrder<W, o16, false> order;
+  KS_LDS uint16_t* snap;    // [cap] order snapshot around a slow sort
   KS_LDS FastClaim* cst;
   KS_LDS FastEnt* ent;
   KS_LDS int32_t* pool;     // [kFastPool][4]
   KS_LDS FastSlot* aslot;
   KS_LDS FastMisc* Mp;
-  // what the hot loop reads of the kernel arguments, as values (registers)
-  int32_t* const g_assign; uint32_t* const g_slot; uint16_t* const g_slot_of; const FastSlot* const g_cls;
-  unsigned long long n_pops = 0, n_steps = 0, n_tests = 0, n_ref = 0, n_evict = 0;
-  int n_claims = 0, nv = 0, n_ent = 0, n_pool = 0, n_active = 0;
+  int n_claims = 0, nv = 0, n_ent = 0, n_pool = 0, n_active = 0, n_evict = 0;
   uint32_t host_seq = 0, active_templates = 0;
   int bail_code = 0;
-  LaneVar<uint32_t> cur[kFastRows];   // cursor of class slot (row * 64 + lane)
+  int lo_ = 0, hi_ = -1;    // positions a slow sort permuted
+  unsigned long long n_ref_extra = 0;
 
-  KS_DEV FastEngine(const ProblemView& p, const Workspace& s, const FastWork& f, char* lds)
-      : P(p), S(s), F(f), Mp((KS_LDS FastMisc*)(lds + f.plan.off_misc)), g_assign(s.assign), g_slot(s.slot), g_slot_of(f.slot_of), g_cls(f.cls) {
-    const FastPlan& pl = f.plan;
+  KS_DEV void init(const ProblemView* p, const Workspace* s, const FastWork* f, char* lds) {
+    Pk = p; Sk = s; Fk = f;
+    const FastPlan& pl = f->plan;
+    Mp = (KS_LDS FastMisc*)(lds + pl.off_misc);
     cst = (KS_LDS FastClaim*)(lds + pl.off_state);
-    order.key = (o16)(lds + pl.off_key); order.ord = (o16)(lds + pl.off_ord); order.pos = (o16)(lds + pl.off_pos);
+    order.key = (o16)(lds + pl.off_key); order.ord = (o16)(lds + pl.off_ord); order.pos = nullptr;
+    snap = (o16)(lds + pl.off_snap);
     ent = (KS_LDS FastEnt*)(lds + pl.off_ent);
     pool = (KS_LDS int32_t*)(lds + pl.off_pool);
     aslot = (KS_LDS FastSlot*)(lds + pl.off_slot);
   }
 
-  KS_DEV void write_counters() {
-    Counters c{};
-    c.bin_evaluations = n_tests; c.full_evaluations = n_steps; c.queue_pops = n_pops; c.sorts = n_pops; c.slow_sorts = order.slow_sorts;
-    c.column_resets = n_evict; c.ref_bin_evaluations = n_ref;
-    c.cycles[20] = (unsigned long long)bail_code;
-    if (W::leader()) *S.counters = c;
-    W::sync();
-  }
-  KS_DEV void bail(int why) {
-    bail_code = why;
-    W::store(S.status_out, 3);
-    write_counters();
-  }
-
-  // ---- requirement-set cache --------------------------------------------------------------------------------------
-  KS_FN static uint32_t hash_vm(uint64_t vm) { return (uint32_t)((vm * 0x9E3779B97F4A7C15ull) >> 40) & (kFastEnt - 1); }
-  // entry of requirement set vm (copied to `out`), or -1 (not cached yet). Per lane; one 32-byte LDS read per probe.
-  KS_FN int lookup(uint64_t vm, FastEnt& out) const {
-    uint32_t h = hash_vm(vm);
-    for (int probe = 0; probe < kFastEnt; ++probe) {
-      out = lds_get(&ent[h]);
-      if (!(out.info & 1u)) return -1;
-      if (out.vmask == vm) return (int)h;
-      h = (h + 1) & (kFastEnt - 1);
-    }
-    return -1;
-  }
-  // "some instance type of the entry holds `req` + `size`" — CanAdd's filterInstanceTypesByRequirements verdict
-  KS_FN bool fits(const FastEnt& e, const int32_t* req, const int32_t* size) const {
-    bool ok = true;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ok = ok && size[r] <= e.cap[r] - req[r];
-    if (ok || !(e.info >> 8)) return ok;
-    const int extra = (int)((e.info >> 8) & 0xFFu);
-    const int off = (int)(e.info >> 16);
-    for (int i = 0; i < extra; ++i) {
-      bool o2 = true;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o2 = o2 && size[r] <= pool[(off + i) * 4 + r] - req[r];
-      if (o2) return true;
-    }
-    return false;
-  }
-  // Requirements.Compatible + Add on the packed form: every key the class selects on keeps at least one value. Adding the
-  // all-ones field to the field carries into the guard bit above it exactly when the field is not empty.
-  KS_FN static bool fields_ok(uint64_t m, uint64_t dmask) {
-    const uint64_t g = (dmask << 1) & ~dmask;
-    return (((m & dmask) + dmask) & g) == g;
-  }
-
-  // F(requirement set vm) and its Pareto-maximal allocatable vectors -> a new cache entry. Wave-uniform slow path.
-  KS_DEV int create_entry(uint64_t vm) {
+  // F(requirement set vm) and its Pareto-maximal allocatable vectors -> a new cache entry
+  KS_COLD int create_entry(uint64_t vm) {
+    vm = W::uniform(vm);
+    const ProblemView& P = *Pk; const Workspace& S = *Sk; const FastWork& F = *Fk;
     const int t = (int)(vm >> 56);
     const int iw = P.it_words, n_its = P.n_its, nr = P.n_res;
     const Dict& d = P.dict;
@@ -232,7 +270,7 @@ struct FastEngine {
     W::sync();
     // slot
     if (n_ent * 5 >= kFastEnt * 4) return -1;
-    uint32_t h = hash_vm(vm);
+    uint32_t h = fast_hash(vm);
     while (ent[h].info & 1u) h = (h + 1) & (kFastEnt - 1);
     uint64_t* eits = F.ent_its + (size_t)h * iw;
     W::for_n(iw, [&](int w) { eits[w] = its[w]; });
@@ -292,13 +330,13 @@ struct FastEngine {
     return (int)h;
   }
 
-  // ---- setup ------------------------------------------------------------------------------------------------------
   // Returns 0 when the problem is of the shape this engine solves, a reason code otherwise.
-  KS_DEV int setup() {
+  KS_COLD int setup() {
+    const ProblemView& P = *Pk; const Workspace& S = *Sk; const FastWork& F = *Fk;
     const Dict& d = P.dict;
     const int nk = d.n_keys, iw = P.it_words, nr = P.n_res, n_its = P.n_its, nc = P.n_classes, T = P.n_templates;
     const ProblemView& Pv = P;
-    if (!P.plain || P.n_rows != P.n_pods || nr > 4 || T > 32 || nc > 65534 || iw > kMaxItWords) return 1;
+    if (!P.plain || P.n_rows != P.n_pods || nr > 4 || T > 32 || nc > kFastClasses || iw > kMaxItWords) return 1;
     // instance types: only In sets (positive), so that compatible() is monotone
     if (W::reduce_or(nk * iw, [&](int i) { return Pv.key_compl[i] | Pv.key_neg[i]; })) return 2;
     // templates: only In sets
@@ -387,7 +425,7 @@ struct FastEngine {
     // classes: packed form + the (class, template) verdicts that never change: taints (nodeclaim.go:126) and keys the
     // template does not define (requirements.go:185-193; with positive operators such a key stays undefined for good)
     FastSlot* fc = F.cls;
-    uint16_t* so = F.slot_of;
+    KS_LDS uint16_t* so = Mp->slot_of;
     const uint32_t wk = d.well_known_mask;
     const uint64_t bad = W::reduce_or(nc, [&](int c) {
       const uint64_t* cm = Pv.cls_reqs.mask + (size_t)c * d.req_words;
@@ -413,317 +451,450 @@ struct FastEngine {
     });
     if (bad) return 8;
     W::for_n(kFastEnt, [&](int i) { ent[i].info = 0; });
+    return 0;
+  }
+
+  // a class seen for the first time (or after an eviction) gets a slot; bit 16 of the result: every cursor must restart
+  KS_COLD int new_slot(int k) {
+    k = (int)W::uniform((uint64_t)(uint32_t)k);
+    KS_LDS uint16_t* so = Mp->slot_of;
+    int evicted = 0;
+    if (n_active == kFastSlots) {
+      // every slot taken: forget them all (their classes start again from position 0 if they ever come back)
+      KS_LDS uint16_t* act = Mp->active;
+      W::for_n(kFastSlots, [&](int i) { so[act[i]] = 0xFFFF; });
+      n_active = 0;
+      n_evict++;
+      evicted = 1 << 16;
+    }
+    const int slot = n_active++;
+    const FastSlot rec = Fk->cls[k];
+    if (W::leader()) { lds_put(&aslot[slot], rec); Mp->active[slot] = (uint16_t)k; so[k] = (uint16_t)slot; }
+    W::sync();
+    return slot | evicted;
+  }
+
+  // any path of pdqsort other than the single stable move: run the emulation, compare the order before and after
+  // (lo_..hi_ = the positions whose claim changed, hi_ < lo_: none)
+  KS_COLD void slow_sort(int n, int defect, int app) {
+    order.n = (int)W::uniform((uint64_t)(uint32_t)n); order.defect = (int)W::uniform((uint64_t)(uint32_t)defect); order.defect_append = W::uniform((uint64_t)app) != 0;
+    n = order.n;
+    const o16 oo = order.ord; const o16 sn = snap;
+    W::for_n(n, [&](int i) { sn[i] = oo[i]; });
+    order.sort();
+    lo_ = W::find_first(0, n, [&](int i) { return sn[i] != oo[i]; });
+    if (lo_ >= n) { lo_ = 0; hi_ = -1; return; }
+    hi_ = W::find_last(0, n, [&](int i) { return sn[i] != oo[i]; });
+  }
+  // The new claim (appended at n-1 with one pod) takes its place behind the last claim with at most one pod. Returns its
+  // position b >= 0 (Mp->acc = the class slots that accept it), -1 when pdqsort left the single-move path (lo_/hi_), -2: stop.
+  KS_COLD int place_new_claim(int n) {
+    n = (int)W::uniform((uint64_t)(uint32_t)n);
+    const int a = n - 1;
+    const int moved = (int)order.ord[a];
+    const bool exact = n <= 12 || (n >= 50 && !fast_sampled(n, a));
+    if (!exact) { slow_sort(n, a, 1); return -1; }
+    order.n = n; order.defect = a; order.defect_append = true;
+    order.sort();
+    const o16 kq = order.key;
+    const int b = W::find_first(0, n, [&](int i) { return kq[i] > 1u; }) - 1;   // the claims with one pod are the prefix it joined the end of
+    const int nac = n_active;
+    const FastClaim nst = lds_get(&cst[moved]);
+    const int t = (int)(nst.vmask >> 56);
+    for (int j = 0; j < kFastRows; ++j) {
+      uint64_t accm = 0;
+      uint64_t todo = j * 64 < nac ? W::ballot([&](int l) { return j * 64 + l < nac; }) : 0ull;
+      while (todo) {
+        LaneVar<uint64_t> missv;
+        const uint64_t td = todo;
+        uint64_t okb = 0, miss = 0, d0, d1;
+        W::ballot4([&](int l) {
+          missv.at(l) = 0;
+          if (!((td >> l) & 1)) return 0;
+          const FastSlot s = lds_get(&aslot[j * 64 + l]);
+          if (!((s.tmplok >> t) & 1u)) return 0;
+          const uint64_t m = nst.vmask & s.cvmask;
+          if (!fast_fields_ok(m, s.dmask)) return 0;
+          FastEnt e;
+          if (fast_lookup(ent, m, e) < 0) { missv.at(l) = m; return 2; }
+          return fast_fits(pool, e, nst.req, s.size) ? 1 : 0;
+        }, okb, miss, d0, d1);
+        accm |= okb;
+        todo = miss;
+        if (miss && create_entry(missv.bcast(ctz64(miss))) < 0) { bail_code = 20; return -2; }
+      }
+      W::store(&Mp->acc[j], accm);
+    }
+    W::sync();
+    return b;
+  }
+
+  // addToNewNodeClaim (scheduler.go:695-790) for a pod no in-flight claim accepted: 1 = claim n created (appended to the
+  // order with one pod), 0 = the engine must stop (bail_code; -1 = capacity).
+  KS_COLD int new_claim(int slot, int bi, int n) {
+    slot = (int)W::uniform((uint64_t)(uint32_t)slot); bi = (int)W::uniform((uint64_t)(uint32_t)bi); n = (int)W::uniform((uint64_t)(uint32_t)n);
+    const ProblemView& P = *Pk; const Workspace& S = *Sk; const FastWork& F = *Fk;
+    const FastSlot cs = lds_get(&aslot[slot]);
+    const int T = P.n_templates, nr = P.n_res, iw = P.it_words, cap = F.plan.cap;
+    n_ref_extra += (unsigned long long)n;
+    for (int t = 0; t < T; ++t) {
+      if (!((active_templates >> t) & 1u)) continue;
+      const uint32_t lm = P.tmpl_limit_mask[t];
+      if (lm) {
+        // filterByRemainingResources (scheduler.go:1069-1085): this engine only continues while no type is excluded
+        int64_t* rem = S.t_remaining + (size_t)t * (nr + 1);
+        if (((lm >> nr) & 1) && rem[nr] <= 0) { bail_code = 23; return 0; }
+        const ProblemView& Pv = P;
+        const uint64_t* tits = S.t_its + (size_t)t * iw;
+        const int n_its = P.n_its;
+        uint64_t excluded = 0;
+        for (int w = 0; w < iw; ++w) {
+          const uint64_t in = tits[w];
+          if (!in) continue;
+          excluded |= W::ballot([&](int l) {
+            const int it = w * 64 + l;
+            if (it >= n_its || !((in >> l) & 1)) return false;
+            bool v = true;
+            for (int q = 0; q < nr; ++q) if ((lm >> q) & 1) v = v && Pv.it_cap[(size_t)q * n_its + it] <= rem[q];
+            return !v;
+          });
+        }
+        if (excluded) { bail_code = 24; return 0; }
+      }
+      host_seq++;
+      n_ref_extra++;
+      if (!((cs.tmplok >> t) & 1u)) continue;
+      const uint64_t m = Mp->tvmask[t] & cs.cvmask;
+      if (!fast_fields_ok(m, cs.dmask)) continue;
+      FastEnt e;
+      int eh = fast_lookup(ent, m, e);
+      if (eh < 0) { eh = create_entry(m); if (eh < 0) { bail_code = 25; return 0; } e = lds_get(&ent[eh]); }
+      const int32_t zero[4] = {0, 0, 0, 0};
+      if (!fast_fits(pool, e, zero, cs.size)) continue;
+      if (n_claims >= S.max_claims) { bail_code = -1; return 0; }   // capacity: reported as such
+      if (n_claims >= cap) { bail_code = 26; return 0; }
+      const int c = n_claims++;
+      if (W::leader()) {
+        FastClaim ns;
+        ns.vmask = m;
+        for (int q = 0; q < 4; ++q) ns.req[q] = cs.size[q];
+        lds_put(&cst[c], ns);
+        F.c_tdef[c] = Mp->tdef[t];
+        F.c_hostseq[c] = host_seq;
+        Mp->out_claim[bi] = (uint32_t)c;
+        Mp->out_cnt[bi] = 0;
+        order.key[n] = 1; order.ord[n] = (uint16_t)c;   // order.append
+      }
+      W::sync();
+      if (lm) {
+        // subtractMax (scheduler.go:1049-1066) over the claim's instance types: F(m) ∩ fits(size)
+        int64_t* rem = S.t_remaining + (size_t)t * (nr + 1);
+        const uint64_t* eits = F.ent_its + (size_t)eh * iw;
+        const ProblemView& Pv = P;
+        const int n_its = P.n_its;
+        for (int q = 0; q < nr; ++q) if ((lm >> q) & 1) {
+          const int64_t mx = W::reduce_max_i64(n_its, [&](int it) {
+            if (!((eits[it >> 6] >> (it & 63)) & 1)) return INT64_MIN;
+            for (int z = 0; z < nr; ++z) if (Pv.it_alloc[(size_t)z * n_its + it] < (int64_t)cs.size[z]) return INT64_MIN;
+            return Pv.it_cap[(size_t)q * n_its + it];
+          });
+          W::store(&rem[q], rem[q] - mx);
+        }
+        W::sync();
+      }
+      return 1;
+    }
+    bail_code = 27;   // an unschedulable pod: error codes and diagnostics come from the general engine
+    return 0;
+  }
+
+  KS_COLD void finish(int status, int n, unsigned long long steps, unsigned long long n_steps, unsigned long long n_tests, unsigned long long n_ref, const unsigned long long* tc) {
+    // results: the final order (the defect of the last commit stays unsorted, as in the reference), the claims' state and
+    // the cache entry of each claim's requirement set
+    const Workspace& S = *Sk; const FastWork& F = *Fk;
+    if (status != 3 && status != 1) {
+      uint32_t* go = S.o_ord;
+      const o16 oo = order.ord; const o16 ok_ = order.key;
+      FastClaim* gs = F.c_state; uint32_t* gn = F.c_npods; uint16_t* ge = F.c_ent;
+      const KS_LDS FastClaim* ls = cst;
+      const KS_LDS FastEnt* en = ent;
+      W::for_n(n, [&](int i) { const uint32_t c = oo[i]; go[i] = c; gn[c] = ok_[i]; });
+      W::for_n(n, [&](int c) {
+        const FastClaim st = lds_get(&ls[c]);
+        FastEnt e;
+        gs[c] = st; ge[c] = (uint16_t)fast_lookup(en, st.vmask, e);
+      });
+      W::store(S.n_claims_out, n_claims);
+    }
+    if (status) W::store(S.status_out, status);
+    Counters c{};
+    c.bin_evaluations = n_tests; c.full_evaluations = n_steps; c.queue_pops = steps; c.sorts = steps; c.slow_sorts = order.slow_sorts;
+    c.column_resets = (unsigned long long)n_evict; c.ref_bin_evaluations = n_ref + n_ref_extra;
+    c.cycles[20] = (unsigned long long)(bail_code > 0 ? bail_code : 0);
+    if (tc) for (int i = 0; i < 8; ++i) c.cycles[i] = tc[i];
+    if (W::leader()) *S.counters = c;
+    W::sync();
+  }
+};
+
+// The loop that places a pod. Its state is local (registers); the cold object above lives in private memory and is only
+// touched through calls.
+template <class W>
+struct FastEngine {
+  FastCold<W> cold;
+  KS_DEV FastEngine(const ProblemView* p, const Workspace* s, const FastWork* f, char* lds) { cold.init(p, s, f, lds); }
+
+  KS_DEV void solve() {
+    typedef KS_LDS uint16_t* o16;
+#ifdef KSOLVE_PHASE_TIMERS
+    unsigned long long tc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // move+cursors, slot, scan, commit, slow sort, total, setup, new claim
+#define KS_TADD(i, v) (tc_[i] += (v))
+#else
+#define KS_TADD(i, v) ((void)0)
+#endif
+    const unsigned long long t_begin = W::clock();
+    {
+      const int why = (int)W::uniform((uint64_t)(uint32_t)cold.setup());
+      if (why) { cold.bail_code = why; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
+    }
+    KS_TADD(6, W::clock() - t_begin);
+    // everything the loop touches, as values
+    const o16 okey = fast_uniform(cold.order.key), oord = fast_uniform(cold.order.ord);
+    KS_LDS FastClaim* const cst = fast_uniform(cold.cst);
+    KS_LDS FastEnt* const ent = fast_uniform(cold.ent);
+    KS_LDS int32_t* const pool = fast_uniform(cold.pool);
+    KS_LDS FastSlot* const aslot = fast_uniform(cold.aslot);
+    KS_LDS FastMisc* const Mp = fast_uniform(cold.Mp);
+    const int np = fast_uniform(cold.Pk->n_pods);
+    const uint32_t* const sorted = fast_uniform(cold.Pk->sorted_pods);
+    const uint32_t* const rc_ = fast_uniform(cold.Pk->row_class);
+    const volatile int* const cancel = fast_uniform(cold.Sk->cancel_flag);
+    const long long ms_ = (long long)W::uniform((uint64_t)cold.Sk->max_steps);
+    const int max_steps = ms_ < 0 ? -1 : (int)(ms_ > 0x7FFFFFFF ? 0x7FFFFFFF : ms_);
+    int32_t* const g_assign = fast_uniform(cold.Sk->assign);
+    uint32_t* const g_slot = fast_uniform(cold.Sk->slot);
+    LaneVar<uint32_t> cur[kFastRows];   // cursor of class slot (row * 64 + lane)
     W::each([&](int l) {
 #pragma unroll
       for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = 0;
     });
-    return 0;
-  }
-
-  // ---- class slots ------------------------------------------------------------------------------------------------
-  // a class seen for the first time (or after an eviction) gets a slot: its cursor starts at position 0
-  KS_DEV int new_slot(int k, int bn) {
-    KS_LDS uint16_t* bs = Mp->blk_slot; KS_LDS uint16_t* bc = Mp->blk_class;
-    if (n_active == kFastSlots) {
-      // every slot taken: forget them all (their classes start again from position 0 if they ever come back)
-      KS_LDS uint16_t* act = Mp->active; uint16_t* so = g_slot_of;
-      W::for_n(kFastSlots, [&](int i) { so[act[i]] = 0xFFFF; });
-      W::for_n(64, [&](int l) { bs[l] = 0xFFFF; });
+    auto get_cursor = [&](int slot) -> uint32_t {
+      uint32_t r = 0;
+#pragma unroll
+      for (int j = 0; j < kFastRows; ++j) if (j == (slot >> 6)) r = cur[j].bcast(slot & 63);
+      return r;
+    };
+    auto set_cursor = [&](int slot, uint32_t v) {
       W::each([&](int l) {
 #pragma unroll
-        for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = 0;
+        for (int j = 0; j < kFastRows; ++j) if (j * 64 + l == slot) cur[j].at(l) = v;
       });
-      n_active = 0;
-      n_evict++;
-    }
-    const int slot = n_active++;
-    const FastSlot rec = g_cls[k];
-    if (W::leader()) { lds_put(&aslot[slot], rec); Mp->active[slot] = (uint16_t)k; g_slot_of[k] = (uint16_t)slot; }
-    W::for_n(64, [&](int l) { if (l < bn && bc[l] == (uint16_t)k) bs[l] = (uint16_t)slot; });   // later pods of the class in this block
-    set_cursor(slot, 0);
-    W::sync();
-    return slot;
-  }
-  KS_DEV uint32_t get_cursor(int slot) const {
-    uint32_t r = 0;
-#pragma unroll
-    for (int j = 0; j < kFastRows; ++j) if (j == (slot >> 6)) r = cur[j].bcast(slot & 63);
-    return r;
-  }
-  KS_DEV void set_cursor(int slot, uint32_t v) {
-    W::each([&](int l) {
-#pragma unroll
-      for (int j = 0; j < kFastRows; ++j) if (j * 64 + l == slot) cur[j].at(l) = v;
-    });
-  }
-
-  // ---- order maintenance + cursors ----------------------------------------------------------------------------------
-  // sort.Slice before the scan (scheduler.go:598): repairs the defect the previous commit left. Cursors follow the move.
-  KS_DEV void sort_and_fix() {
-    if (order.defect < 0) return;
-    const int n = order.n;
-    const int a = order.defect;
-    const bool app = order.defect_append;
-    // the single-defect cases whose effect is one stable move (pdq_emul.h sort()); everything else is diffed below
-    bool exact = n <= 12;
-    if (n >= 50) {
-      const int q = n / 4, p = a;
-      exact = !((p >= q - 1 && p <= q + 1) || (p >= 2 * q - 1 && p <= 2 * q + 1) || (p >= 3 * q - 1 && p <= 3 * q + 1));
-    }
-    if (!exact) {
-      // any other path of pdqsort: compare the order before and after; cursors inside the permuted range fall back to its start
-      uint32_t* old = S.o_ord;   // the output array is free until the loop ends
-      const o16 oo = order.ord;
-      W::for_n(n, [&](int i) { old[i] = oo[i]; });
-      order.sort();
-      const int lo = W::find_first(0, n, [&](int i) { return old[i] != (uint32_t)oo[i]; });
-      if (lo >= n) return;
-      const int hi = W::find_last(0, n, [&](int i) { return old[i] != (uint32_t)oo[i]; });
+    };
+    auto cursors_fallback = [&](int lo, int hi) {   // a slow sort permuted positions lo..hi
+      if (hi < lo) return;
       W::each([&](int l) {
 #pragma unroll
         for (int j = 0; j < kFastRows; ++j) { const uint32_t r = cur[j].at(l); if (r > (uint32_t)lo && r <= (uint32_t)hi) cur[j].at(l) = (uint32_t)lo; }
       });
-      return;
-    }
-    if (!app) {
-      // the claim at a gained a pod: it moves right past the claims with a smaller count (one stable move)
-      const uint32_t mv = order.key[a];
-      order.defect = -1;
-      if (a + 1 >= n || !(order.key[a + 1] < mv)) return;
-      const o16 kq = order.key;
-      const int e = W::find_first(a + 1, n, [kq, mv](int x) { return !(kq[x] < mv); });
-      const int b = e - 1;
-      order.rotate_left(a, b);
-      // positions (a, b] shifted left by one
-      W::each([&](int l) {
-#pragma unroll
-        for (int j = 0; j < kFastRows; ++j) { const uint32_t r = cur[j].at(l); cur[j].at(l) = r - (uint32_t)(((uint32_t)a < r && r <= (uint32_t)b) ? 1 : 0); }
-      });
-      return;
-    }
-    const int moved = (int)order.ord[a];
-    order.sort();
-    const int b = (int)order.pos[moved];
-    // the new claim moved from n-1 to b: positions [b, n-1) shifted right by one. A cursor past b has a claim in front of
-    // it that its class never tested: test it now, one lane per class slot — an acceptor pulls the cursor back to b.
-    const int nac = n_active;
-    const FastClaim nst = lds_get(&cst[moved]);
-    const int t = (int)(nst.vmask >> 56);
-#pragma unroll
-    for (int j = 0; j < kFastRows; ++j) {
-      if (j * 64 >= nac) continue;
-      uint64_t todo = W::ballot([&](int l) { return j * 64 + l < nac && cur[j].at(l) > (uint32_t)b; });
-      while (todo) {
-        LaneVar<uint64_t> missv;
-        const uint64_t td = todo;
-        const uint64_t miss = W::ballot([&](int l) {
-          missv.at(l) = 0;
-          if (!((td >> l) & 1)) return false;
-          const FastSlot s = lds_get(&aslot[j * 64 + l]);
-          uint32_t nxt = cur[j].at(l) + 1;
-          if ((s.tmplok >> t) & 1u) {
-            const uint64_t m = nst.vmask & s.cvmask;
-            if (fields_ok(m, s.dmask)) {
-              FastEnt e;
-              if (lookup(m, e) < 0) { missv.at(l) = m; return true; }
-              if (fits(e, nst.req, s.size)) nxt = (uint32_t)b;
-            }
-          }
-          cur[j].at(l) = nxt;
-          return false;
-        });
-        todo = miss;
-        if (miss && create_entry(missv.bcast(ctz64(miss))) < 0) { bail_code = 20; return; }
-      }
-    }
-  }
-
-  // ---- the loop -----------------------------------------------------------------------------------------------------
-  KS_DEV void solve() {
-    const int why = setup();
-    if (why) KS_FAST_BAIL(why);
-    const int np = P.n_pods, cap = F.plan.cap, T = P.n_templates, nr = P.n_res, iw = P.it_words, max_claims = S.max_claims;
-    const uint32_t* const sorted = P.sorted_pods;
-    const uint32_t* const rc_ = P.row_class;
-    const volatile int* const cancel = S.cancel_flag;
-    const long long max_steps = S.max_steps;
-    int status = 0;
-    long long steps = 0;
+    };
+    unsigned long long n_steps = 0, n_tests = 0, n_ref = 0;
+    int n = 0;                                       // claims in the order
+    int pend_a = -1, pend_x = 0; uint32_t pend_mv = 0;   // the move the last commit left for the next sort.Slice
+    bool pend_new = false;                           // ... or the claim the last pod created
+    int status = 0, steps = 0;
+    // the queue, 64 entries at a time; the next block's pod ids and classes are fetched while this one is placed
+    LaneVar<uint32_t> nxt_pod, nxt_cls;
+    W::each([&](int l) { if (l < np) { const uint32_t p = sorted[l]; nxt_pod.at(l) = p; nxt_cls.at(l) = rc_[p]; } });
     for (int base = 0; base < np && !status; base += 64) {
       const int bn = np - base < 64 ? np - base : 64;
       {
-        KS_LDS uint32_t* bp = Mp->blk_pod; KS_LDS uint16_t* bc = Mp->blk_class; KS_LDS uint16_t* bs = Mp->blk_slot;
-        const uint16_t* so = g_slot_of;
-        W::for_n(64, [&](int l) { if (l < bn) { const uint32_t p = sorted[base + l]; const uint32_t k = rc_[p]; bp[l] = p; bc[l] = (uint16_t)k; bs[l] = so[k]; } });
+        KS_LDS uint32_t* bp = Mp->blk_pod; KS_LDS uint16_t* bc = Mp->blk_class;
+        W::each([&](int l) { if (l < bn) { bp[l] = nxt_pod.at(l); bc[l] = (uint16_t)nxt_cls.at(l); } });
+        W::sync();
+        const int nb = base + 64;
+        W::each([&](int l) { if (nb + l < np) { const uint32_t p = sorted[nb + l]; nxt_pod.at(l) = p; nxt_cls.at(l) = rc_[p]; } });
       }
-      if (cancel && W::poll_flag(cancel)) { status = 2; break; }
+      if ((base & 1023) == 0 && cancel && fast_uniform(W::poll_flag(cancel))) { status = 2; break; }
+      int done = 0;
       for (int bi = 0; bi < bn; ++bi) {
         if (max_steps >= 0 && steps >= max_steps) { status = 2; break; }
         steps++;
-        const int pod = (int)Mp->blk_pod[bi];
-        int slot = (int)Mp->blk_slot[bi];
-        n_pops++;
-        sort_and_fix();
-        if (bail_code) KS_FAST_BAIL(bail_code);
-        if (slot == 0xFFFF) slot = new_slot((int)Mp->blk_class[bi], bn);
+        const unsigned long long ts0 = W::clock();
+        // ---- sort.Slice (scheduler.go:598): the move the last commit left ----
+        if (pend_a >= 0) {
+          const int a = pend_a;
+          pend_a = -1;
+          if (n <= 12 || (n >= 50 && !fast_sampled(n, a))) {
+            // one stable move: the claim at a (count pend_mv) goes right past the claims with a smaller count
+            int from = a;
+            const uint32_t mv = pend_mv;
+            for (;;) {
+              LaneVar<uint32_t> kv, ov;
+              const uint64_t less = W::ballot([&](int l) {
+                const int i = from + 1 + l;
+                if (i >= n) return false;
+                const uint32_t k = okey[i];
+                kv.at(l) = k; ov.at(l) = oord[i];
+                return k < mv;
+              });
+              const int s_ = less == ~0ull ? 64 : ctz64(~less);   // sorted beyond a: the smaller counts are a prefix
+              if (s_ == 0) break;
+              W::each([&](int l) { if (l < s_) { okey[from + l] = (uint16_t)kv.at(l); oord[from + l] = (uint16_t)ov.at(l); } });
+              from += s_;
+              if (s_ < 64) break;
+            }
+            if (from != a) {
+              if (W::leader()) { okey[from] = (uint16_t)mv; oord[from] = (uint16_t)pend_x; }
+              W::sync();
+              const int b = from;   // positions (a, b] moved left by one
+              W::each([&](int l) {
+#pragma unroll
+                for (int j = 0; j < kFastRows; ++j) { const uint32_t r = cur[j].at(l); cur[j].at(l) = r - (uint32_t)(((uint32_t)a < r && r <= (uint32_t)b) ? 1 : 0); }
+              });
+            }
+          } else {
+            const unsigned long long tq = W::clock();
+            cold.slow_sort(n, a, 0);
+            cursors_fallback(fast_uniform(cold.lo_), fast_uniform(cold.hi_));
+            KS_TADD(4, W::clock() - tq);
+          }
+        } else if (pend_new) {
+          pend_new = false;
+          const int b = fast_uniform(cold.place_new_claim(n));
+          if (b == -2) { cold.finish(3, n, 0, 0, 0, 0, nullptr); return; }
+          if (b == -1) cursors_fallback(fast_uniform(cold.lo_), fast_uniform(cold.hi_));
+          else {
+            // positions [b, n-1) moved right by one; a cursor past b either steps over the new claim or — if its class is
+            // accepted by it — comes back to it
+            const KS_LDS uint64_t* acc = Mp->acc;
+            W::each([&](int l) {
+#pragma unroll
+              for (int j = 0; j < kFastRows; ++j) {
+                const uint32_t r = cur[j].at(l);
+                if (r > (uint32_t)b) cur[j].at(l) = ((acc[j] >> l) & 1) ? (uint32_t)b : r + 1;
+              }
+            });
+          }
+        }
+        const unsigned long long ts1 = W::clock();
+        KS_TADD(0, ts1 - ts0);
+        // ---- the pod and its class slot ----
+        int slot = (int)Mp->slot_of[Mp->blk_class[bi]];
+        if (slot == 0xFFFF) {
+          const int sv = fast_uniform(cold.new_slot((int)Mp->blk_class[bi]));
+          slot = sv & 0xFFFF;
+          if (sv >> 16) W::each([&](int l) {
+#pragma unroll
+            for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = 0;
+          });
+          set_cursor(slot, 0);
+        }
         const FastSlot cs = lds_get(&aslot[slot]);
         uint32_t r = get_cursor(slot);
-        const int n = order.n;
         bool placed = false;
+        const unsigned long long ts2 = W::clock();
+        KS_TADD(1, ts2 - ts1);
         while ((int)r < n) {
-          // addToInflightNode: positions r .. r+63, one lane each
+          // ---- addToInflightNode (scheduler.go:658-692): positions r .. r+63, one lane each; straight-line: three
+          // dependent LDS reads (order -> claim state -> requirement-set cache), everything else in registers ----
           LaneVar<uint64_t> mv;
-          LaneVar<uint32_t> xv, fl;   // fl: 0 = rejected before the cache, 1 = requirement set not cached yet, 2 = tested
+          LaneVar<uint32_t> xv, kv;
           LaneVar<int32_t> q0, q1, q2, q3;
           const uint32_t r0 = r;
-          const o16 oo = order.ord;
-          const uint64_t okm = W::ballot([&](int l) {
+          uint64_t okm = 0, missm = 0, morem = 0, unused_ = 0;
+          W::ballot4([&](int l) {
             const int p = (int)r0 + l;
-            fl.at(l) = 0;
-            if (p >= n) return false;
-            const uint32_t x = oo[p];
-            xv.at(l) = x;
+            const bool valid = p < n;
+            const int pc = valid ? p : n - 1;
+            const uint32_t x = oord[pc];
+            xv.at(l) = x; kv.at(l) = okey[pc];
             const FastClaim st = lds_get(&cst[x]);
             q0.at(l) = st.req[0]; q1.at(l) = st.req[1]; q2.at(l) = st.req[2]; q3.at(l) = st.req[3];
-            if (!((cs.tmplok >> (st.vmask >> 56)) & 1u)) return false;
             const uint64_t m = st.vmask & cs.cvmask;
-            if (!fields_ok(m, cs.dmask)) return false;
             mv.at(l) = m;
-            FastEnt e;
-            if (lookup(m, e) < 0) { fl.at(l) = 1; return false; }
-            fl.at(l) = 2;
-            return fits(e, st.req, cs.size);
-          });
-          const uint64_t miss = W::ballot([&](int l) { return fl.at(l) == 1; });
+            const FastEnt e = lds_get(&ent[fast_hash(m)]);
+            const bool base_ok = valid && ((cs.tmplok >> (st.vmask >> 56)) & 1u) && fast_fields_ok(m, cs.dmask);
+            const bool ev = (e.info & 1u) != 0, hit = e.vmask == m;
+            const bool fit = fast_fits_first(e, st.req, cs.size);
+            const bool more = base_ok && ev && (!hit || (!fit && (e.info >> 8) != 0));   // a collision, or further Pareto vectors
+            return (base_ok && ev && hit && fit ? 1 : 0) | (base_ok && !ev ? 2 : 0) | (more ? 4 : 0);
+          }, okm, missm, morem, unused_);
+          if (morem) {
+            // rare: resolve those lanes with the full probe sequence / all Pareto vectors
+            const uint64_t mm = morem;
+            uint64_t ok2 = 0, miss2 = 0, d0, d1;
+            W::ballot4([&](int l) {
+              if (!((mm >> l) & 1)) return 0;
+              FastEnt e;
+              if (fast_lookup(ent, mv.at(l), e) < 0) return 2;
+              const int32_t rq[4] = {q0.at(l), q1.at(l), q2.at(l), q3.at(l)};
+              return fast_fits(pool, e, rq, cs.size) ? 1 : 0;
+            }, ok2, miss2, d0, d1);
+            okm |= ok2; missm |= miss2;
+          }
           n_tests += (unsigned long long)(n - (int)r0 < 64 ? n - (int)r0 : 64);
           n_steps++;
           const int first_ok = okm ? ctz64(okm) : 64;
-          const int first_miss = miss ? ctz64(miss) : 64;
+          const int first_miss = missm ? ctz64(missm) : 64;
           if (first_miss < first_ok) {
             // a requirement set that is not cached yet sits before the first acceptor: cache it, test these positions again
-            if (create_entry(mv.bcast(first_miss)) < 0) KS_FAST_BAIL(21);
+            if (fast_uniform(cold.create_entry(mv.bcast(first_miss))) < 0) { cold.bail_code = 21; cold.finish(3, n, 0, 0, 0, 0, nullptr); return; }
             continue;
           }
           if (!okm) { r = (uint32_t)((int)r0 + 64 < n ? (int)r0 + 64 : n); continue; }
-          // commit: NodeClaim.Add (nodeclaim.go:247-263)
+          // ---- commit: NodeClaim.Add (nodeclaim.go:247-263) ----
+          const unsigned long long ts3 = W::clock();
+          KS_TADD(2, ts3 - ts2);
           const int a = (int)r0 + first_ok;
           const int x = (int)xv.bcast(first_ok);
-          const uint32_t cnt = order.key[a];
-          if (cnt >= 65534u) KS_FAST_BAIL(22);
+          const uint32_t cnt = kv.bcast(first_ok);
+          if (cnt >= 65534u) { cold.bail_code = 22; cold.finish(3, n, 0, 0, 0, 0, nullptr); return; }
           FastClaim ns;
           ns.vmask = mv.bcast(first_ok);
           ns.req[0] = q0.bcast(first_ok) + cs.size[0]; ns.req[1] = q1.bcast(first_ok) + cs.size[1];
           ns.req[2] = q2.bcast(first_ok) + cs.size[2]; ns.req[3] = q3.bcast(first_ok) + cs.size[3];
           if (W::leader()) {
             lds_put(&cst[x], ns);
-            g_assign[pod] = (int32_t)x;
-            g_slot[pod] = cnt;
+            Mp->out_claim[bi] = (uint32_t)x;
+            Mp->out_cnt[bi] = cnt;
+            okey[a] = (uint16_t)(cnt + 1);
           }
-          n_ref += (unsigned long long)a + 1;
-          // order.increment(x) with the position already known
-          W::store(&order.key[a], cnt + 1);
           W::sync();
-          order.defect = a; order.defect_append = false;
+          n_ref += (unsigned long long)a + 1;
+          pend_a = a; pend_x = x; pend_mv = cnt + 1;
           r = (uint32_t)a;
           placed = true;
+          KS_TADD(3, W::clock() - ts3);
           break;
         }
         set_cursor(slot, r);
+        done = bi + 1;
         if (placed) continue;
-        // addToNewNodeClaim (scheduler.go:695-790)
-        n_ref += (unsigned long long)n;
-        bool made = false;
-        for (int t = 0; t < T && !made; ++t) {
-          if (!((active_templates >> t) & 1u)) continue;
-          const uint32_t lm = P.tmpl_limit_mask[t];
-          if (lm) {
-            // filterByRemainingResources (scheduler.go:1069-1085): this engine only continues while no type is excluded
-            int64_t* rem = S.t_remaining + (size_t)t * (nr + 1);
-            if (((lm >> nr) & 1) && rem[nr] <= 0) KS_FAST_BAIL(23);
-            const ProblemView& Pv = P;
-            const uint64_t* tits = S.t_its + (size_t)t * iw;
-            const int n_its = P.n_its;
-            uint64_t excluded = 0;
-            for (int w = 0; w < iw; ++w) {
-              const uint64_t in = tits[w];
-              if (!in) continue;
-              excluded |= W::ballot([&](int l) {
-                const int it = w * 64 + l;
-                if (it >= n_its || !((in >> l) & 1)) return false;
-                bool v = true;
-                for (int q = 0; q < nr; ++q) if ((lm >> q) & 1) v = v && Pv.it_cap[(size_t)q * n_its + it] <= rem[q];
-                return !v;
-              });
-            }
-            if (excluded) KS_FAST_BAIL(24);
-          }
-          host_seq++;
-          n_ref++;
-          if (!((cs.tmplok >> t) & 1u)) continue;
-          const uint64_t m = Mp->tvmask[t] & cs.cvmask;
-          if (!fields_ok(m, cs.dmask)) continue;
-          FastEnt e;
-          int eh = lookup(m, e);
-          if (eh < 0) { eh = create_entry(m); if (eh < 0) KS_FAST_BAIL(25); e = lds_get(&ent[eh]); }
-          const int32_t zero[4] = {0, 0, 0, 0};
-          if (!fits(e, zero, cs.size)) continue;
-          if (n_claims >= max_claims) { W::store(S.status_out, 1); write_counters(); return; }
-          if (n_claims >= cap) KS_FAST_BAIL(26);
-          const int c = n_claims++;
-          if (W::leader()) {
-            FastClaim ns;
-            ns.vmask = m;
-            for (int q = 0; q < 4; ++q) ns.req[q] = cs.size[q];
-            lds_put(&cst[c], ns);
-            F.c_tdef[c] = Mp->tdef[t];
-            F.c_hostseq[c] = host_seq;
-            g_assign[pod] = (int32_t)c;
-            g_slot[pod] = 0;
-          }
-          W::sync();
-          order.append(c);
-          if (lm) {
-            // subtractMax (scheduler.go:1049-1066) over the claim's instance types: F(m) ∩ fits(size)
-            int64_t* rem = S.t_remaining + (size_t)t * (nr + 1);
-            const uint64_t* eits = F.ent_its + (size_t)eh * iw;
-            const ProblemView& Pv = P;
-            const int n_its = P.n_its;
-            for (int q = 0; q < nr; ++q) if ((lm >> q) & 1) {
-              const int64_t mx = W::reduce_max_i64(n_its, [&](int it) {
-                if (!((eits[it >> 6] >> (it & 63)) & 1)) return INT64_MIN;
-                for (int z = 0; z < nr; ++z) if (Pv.it_alloc[(size_t)z * n_its + it] < (int64_t)cs.size[z]) return INT64_MIN;
-                return Pv.it_cap[(size_t)q * n_its + it];
-              });
-              W::store(&rem[q], rem[q] - mx);
-            }
-            W::sync();
-          }
-          made = true;
+        const unsigned long long tn = W::clock();
+        const int made = fast_uniform(cold.new_claim(slot, bi, n));
+        KS_TADD(7, W::clock() - tn);
+        if (!made) {
+          const int bc = fast_uniform(cold.bail_code);
+          cold.finish(bc < 0 ? 1 : 3, n, 0, 0, 0, 0, nullptr);
+          return;
         }
-#if !KS_DEVICE
-        if (!made && getenv("KS_FAST_DEBUG")) fprintf(stderr, "bail27 pod %d slot %d tmplok %x cv %llx dm %llx size %d %d %d %d act %x n %d\n", pod, slot, cs.tmplok, (unsigned long long)cs.cvmask, (unsigned long long)cs.dmask, cs.size[0], cs.size[1], cs.size[2], cs.size[3], active_templates, n);
-#endif
-        if (!made) KS_FAST_BAIL(27);   // an unschedulable pod: error codes and diagnostics come from the general engine
+        n++;
+        pend_new = true;
+      }
+      // the block's results
+      {
+        KS_LDS uint32_t* bp = Mp->blk_pod; KS_LDS uint32_t* oc = Mp->out_claim; KS_LDS uint32_t* on = Mp->out_cnt;
+        const int dn = done;
+        W::each([&](int l) { if (l < dn) { const uint32_t p = bp[l]; g_assign[p] = (int32_t)oc[l]; g_slot[p] = on[l]; } });
+        W::sync();
       }
     }
-    // results: the final order (the defect of the last commit stays unsorted, as in the reference), the claims' state and
-    // the cache entry of each claim's requirement set
-    {
-      const int n = order.n;
-      uint32_t* go = S.o_ord;
-      const o16 oo = order.ord; const o16 ok_ = order.key; const o16 op = order.pos;
-      FastClaim* gs = F.c_state; uint32_t* gn = F.c_npods; uint16_t* ge = F.c_ent;
-      const KS_LDS FastClaim* ls = cst;
-      W::for_n(n, [&](int i) { go[i] = oo[i]; });
-      W::for_n(n, [&](int c) {
-        const FastClaim st = lds_get(&ls[c]);
-        FastEnt e;
-        gs[c] = st; gn[c] = ok_[op[c]]; ge[c] = (uint16_t)lookup(st.vmask, e);
-      });
-    }
-    W::store(S.n_claims_out, n_claims);
-    if (status) W::store(S.status_out, status);
-    write_counters();
+    KS_TADD(5, W::clock() - t_begin);
+#ifdef KSOLVE_PHASE_TIMERS
+    cold.finish(status, n, (unsigned long long)steps, n_steps, n_tests, n_ref, tc_);
+#else
+    cold.finish(status, n, (unsigned long long)steps, n_steps, n_tests, n_ref, nullptr);
+#endif
   }
 };
 

@@ -142,9 +142,9 @@ __global__ void __launch_bounds__(64) ksolve_pack_batch_lite(ks::BatchItem* item
   eng.solve();
 }
 // The cursor engine (fast_engine.h) for purely positive provisioning batches: one wavefront, O(1) steps.
-__global__ void __launch_bounds__(64) ksolve_pack_fast(ks::ProblemView pv, ks::Workspace ws, ks::FastWork fw) {
+__global__ void __launch_bounds__(64) ksolve_pack_fast(const ks::FastArgs* a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  ks::FastEngine<ks::Wave> eng(pv, ws, fw, lds);
+  ks::FastEngine<ks::Wave> eng(&a->pv, &a->ws, &a->fw, lds);
   eng.solve();
 }
 // One wavefront per claim: hot claim records (requirement masks, InstanceTypeOptions) from the cursor engine's compact state.
@@ -175,7 +175,9 @@ static void be_launch_pack(ksolve_handle* h) {
 static void be_launch_pack_fast(ksolve_handle* h) {
   const int lds_bytes = h->fw.plan.total_bytes;
   if (!hip_check(h, hipFuncSetAttribute((const void*)ksolve_pack_fast, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
-  hipLaunchKernelGGL(ksolve_pack_fast, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, h->pv, h->ws, h->fw);
+  ks::FastArgs a{h->pv, h->ws, h->fw};
+  be_h2d(h, h->d_fast_args, &a, sizeof(a));
+  hipLaunchKernelGGL(ksolve_pack_fast, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
   hip_check(h, hipGetLastError(), "ksolve_pack_fast launch");
 }
 static void be_launch_fast_records(ksolve_handle* h, int n_claims) {

@@ -73,6 +73,7 @@ struct ksolve_handle {
   int lite_saved = 0;
   ks::FastWork fw{};            // cursor engine (fast_engine.h): workspace + LDS plan; fw.enabled while the problem may qualify
   uint32_t engine_used = 0, fast_reason = 0;
+  ks::FastArgs* d_fast_args = nullptr;   // the record ksolve_pack_fast reads its problem from
 };
 
 // ---- backend hooks (defined by the including TU before this point is instantiated) ----
@@ -548,12 +549,13 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       fp.off_state = off; off = align(off + cap * (int)sizeof(ks::FastClaim));
       fp.off_key = off; off = align(off + cap * 2);
       fp.off_ord = off; off = align(off + cap * 2);
-      fp.off_pos = off; off = align(off + cap * 2);
+      fp.off_snap = off; off = align(off + cap * 2);
       fp.total_bytes = off;
       fw.var = dz<ks::FastVar>(h, 1);
       fw.c_tdef = dz<uint32_t>(h, mc); fw.c_hostseq = dz<uint32_t>(h, mc); fw.c_ent = dz<uint16_t>(h, mc);
       fw.c_state = dz<ks::FastClaim>(h, mc); fw.c_npods = dz<uint32_t>(h, mc);
       fw.ent_its = dz<uint64_t>(h, (size_t)ks::kFastEnt * it_words);
+      h->d_fast_args = dz<ks::FastArgs>(h, 1);
     }
   }
   be_sync(h);
@@ -634,7 +636,7 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
     R.cls_topo = h->has_topology ? dz<uint64_t>(h, (size_t)n_classes * 2 * R.topo_words) : nullptr;
     R.lay = P.lay;
     h->ws.dead = dz<uint64_t>(h, (size_t)n_classes * h->claim_words);
-    if (h->fw.enabled) { h->fw.cls = dz<ks::FastSlot>(h, n_classes); h->fw.slot_of = dz<uint16_t>(h, n_classes); }
+    if (h->fw.enabled) h->fw.cls = dz<ks::FastSlot>(h, n_classes);
     if (h->n_nodes) h->ws.n_dead = dz<uint64_t>(h, (size_t)n_classes * P.node_words);
   }
   if (n_classes > 0) {

@@ -17,7 +17,8 @@
 namespace ks {
 
 // P32 = pointer type of the three arrays: LDS for problems whose claims fit the CU's LDS, HBM for larger ones.
-template <class W, class P32 = KS_LDS uint32_t*>
+// POS = false drops the inverse array (the cursor engine always knows the position of the claim it touches).
+template <class W, class P32 = KS_LDS uint32_t*, bool POS = true>
 struct ClaimOrder {
   P32 key;   // [cap] pod count of the claim at position i
   P32 ord;   // [cap] claim id at position i
@@ -34,7 +35,7 @@ struct ClaimOrder {
     uint32_t ki = key[i], kj = key[j], oi = ord[i], oj = ord[j];
     W::store(&key[i], kj); W::store(&key[j], ki);
     W::store(&ord[i], oj); W::store(&ord[j], oi);
-    W::store(&pos[oj], (uint32_t)i); W::store(&pos[oi], (uint32_t)j);
+    if constexpr (POS) { W::store(&pos[oj], (uint32_t)i); W::store(&pos[oi], (uint32_t)j); }
     W::sync();
   }
   // move element at `from` to `to` (to < from), shifting [to, from) right by one
@@ -45,7 +46,7 @@ struct ClaimOrder {
       int lo = top - kRound > to ? top - kRound : to;
       shift_round(lo, top, +1);
     }
-    W::store(&key[to], mk); W::store(&ord[to], mo); W::store(&pos[mo], (uint32_t)to);
+    W::store(&key[to], mk); W::store(&ord[to], mo); if constexpr (POS) W::store(&pos[mo], (uint32_t)to);
     W::sync();
   }
   // move element at `from` to `to` (to > from), shifting (from, to] left by one
@@ -56,7 +57,7 @@ struct ClaimOrder {
       int hi = lo + kRound <= to + 1 ? lo + kRound : to + 1;
       shift_round(lo, hi, -1);
     }
-    W::store(&key[to], mk); W::store(&ord[to], mo); W::store(&pos[mo], (uint32_t)to);
+    W::store(&key[to], mk); W::store(&ord[to], mo); if constexpr (POS) W::store(&pos[mo], (uint32_t)to);
     W::sync();
   }
   // elements [lo,hi) (at most kRound) move by delta (+1 / -1): all reads of the round precede its writes, and
@@ -70,11 +71,11 @@ struct ClaimOrder {
     for (int j = 0; j < kPerLane; ++j) { const int i = lo + j * 64 + W::lane(); if (i < hi) { k[j] = key[i]; o[j] = ord[i]; } }
     W::sync();
 #pragma unroll
-    for (int j = 0; j < kPerLane; ++j) { const int i = lo + j * 64 + W::lane(); if (i < hi) { key[i + delta] = k[j]; ord[i + delta] = o[j]; pos[o[j]] = (uint32_t)(i + delta); } }
+    for (int j = 0; j < kPerLane; ++j) { const int i = lo + j * 64 + W::lane(); if (i < hi) { key[i + delta] = k[j]; ord[i + delta] = o[j]; if constexpr (POS) pos[o[j]] = (uint32_t)(i + delta); } }
     W::sync();
 #else
-    if (delta > 0) for (int i = hi - 1; i >= lo; --i) { key[i + 1] = key[i]; ord[i + 1] = ord[i]; pos[ord[i + 1]] = i + 1; }
-    else for (int i = lo; i < hi; ++i) { key[i - 1] = key[i]; ord[i - 1] = ord[i]; pos[ord[i - 1]] = i - 1; }
+    if (delta > 0) for (int i = hi - 1; i >= lo; --i) { key[i + 1] = key[i]; ord[i + 1] = ord[i]; if constexpr (POS) pos[ord[i + 1]] = i + 1; }
+    else for (int i = lo; i < hi; ++i) { key[i - 1] = key[i]; ord[i - 1] = ord[i]; if constexpr (POS) pos[ord[i - 1]] = i - 1; }
 #endif
   }
   // first x in [lo,hi) with key[x] >= v, hi if none — [lo,hi) is sorted ascending (binary search: a long run of equal keys
@@ -98,7 +99,7 @@ struct ClaimOrder {
     defect = p; defect_append = false;
   }
   KS_FN void append(int claim) {     // a new claim with its first pod (scheduler.go:785)
-    W::store(&key[n], 1u); W::store(&ord[n], (uint32_t)claim); W::store(&pos[claim], (uint32_t)n);
+    W::store(&key[n], 1u); W::store(&ord[n], (uint32_t)claim); if constexpr (POS) W::store(&pos[claim], (uint32_t)n);
     W::sync();
     defect = n; defect_append = true;
     n++;

@@ -29,6 +29,12 @@ namespace ks {
 
 struct Wave {
   KS_DEV static int lane() { return (int)(threadIdx.x & 63); }
+  // A value every lane holds alike, moved to scalar registers: cross-lane shuffles leave the compiler believing the result
+  // is divergent, and a branch on it (and every value merged behind that branch) would be compiled as divergent code.
+  KS_DEV static uint64_t uniform(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+  }
   // Orders this wave's LDS/global accesses; the wave executes in lockstep so this is a compiler + counter fence only.
   KS_DEV static void sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -87,7 +93,7 @@ struct Wave {
       uint64_t o = __shfl_xor(v, off, 64);
       v = o < v ? o : v;
     }
-    return v;
+    return uniform(v);
   }
   template <class F>
   KS_DEV static int64_t reduce_max_i64(int n, F f) {
@@ -97,7 +103,7 @@ struct Wave {
       int64_t o = __shfl_xor(v, off, 64);
       v = o > v ? o : v;
     }
-    return v;
+    return (int64_t)uniform((uint64_t)v);
   }
   // max over the 64 lanes of f(lane)
   template <class F>
@@ -107,14 +113,14 @@ struct Wave {
       int64_t o = __shfl_xor(v, off, 64);
       v = o > v ? o : v;
     }
-    return v;
+    return (int64_t)uniform((uint64_t)v);
   }
   template <class F>
   KS_DEV static uint64_t reduce_or(int n, F f) {
     uint64_t v = 0;
     for (int i = lane(); i < n; i += 64) v |= f(i);
     for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
-    return v;
+    return uniform(v);
   }
   // scalar store: one lane writes, every lane may read it back afterwards (same wave, program order)
   template <class T, class V>
@@ -178,6 +184,7 @@ struct Wave {
 
 struct Wave {
   static int lane() { return 0; }
+  static uint64_t uniform(uint64_t v) { return v; }
   static void sync() {}
   template <class F>
   static uint64_t ballot(F f) {

@@ -91,7 +91,9 @@ static void be_launch_pack(ksolve_handle* h) {
 }
 static void be_launch_pack_fast(ksolve_handle* h) {
   std::vector<char> lds((size_t)h->fw.plan.total_bytes + 64, (char)0xA5);   // garbage, like the device's LDS at kernel start
-  ks::FastEngine<ks::Wave> eng(h->pv, h->ws, h->fw, lds.data());
+  ks::FastArgs a{h->pv, h->ws, h->fw};
+  be_h2d(h, h->d_fast_args, &a, sizeof(a));
+  ks::FastEngine<ks::Wave> eng(&h->d_fast_args->pv, &h->d_fast_args->ws, &h->d_fast_args->fw, lds.data());
   eng.solve();
 }
 static void be_launch_fast_records(ksolve_handle* h, int n_claims) {
