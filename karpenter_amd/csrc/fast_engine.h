@@ -123,7 +123,7 @@ KS_FN int fast_uniform(int v) {
 #if KS_DEVICE
 template <class T>
 KS_FN KS_LDS T* fast_uniform(KS_LDS T* p) {
-  return (KS_LDS T*)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);
+  return (KS_LDS T*)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);
 }
 #endif
 template <class T>
@@ -181,9 +181,9 @@ KS_FN bool fast_fields_ok(uint64_t m, uint64_t dmask) {
   const uint64_t g = (dmask << 1) & ~dmask;
   return (((m & dmask) + dmask) & g) == g;
 }
-KS_FN bool fast_sampled(int n, int p) {   // choosePivot's nine positions (pdq_emul.h sort())
-  const int q = n / 4;
-  return (p >= q - 1 && p <= q + 1) || (p >= 2 * q - 1 && p <= 2 * q + 1) || (p >= 3 * q - 1 && p <= 3 * q + 1);
+KS_FN bool fast_sampled(int n, int p) {   // choosePivot's nine positions (pdq_emul.h sort()); n >= 50
+  const unsigned q = (unsigned)n >> 2, u = (unsigned)p;
+  return u - (q - 1) <= 2u || u - (2 * q - 1) <= 2u || u - (3 * q - 1) <= 2u;
 }
 
 // Everything that happens rarely (a new requirement set, a new claim, a new class slot, pdqsort leaving its single-move
@@ -581,8 +581,6 @@ struct FastCold {
         lds_put(&cst[c], ns);
         F.c_tdef[c] = Mp->tdef[t];
         F.c_hostseq[c] = host_seq;
-        Mp->out_claim[bi] = (uint32_t)c;
-        Mp->out_cnt[bi] = 0;
         order.key[n] = 1; order.ord[n] = (uint16_t)c;   // order.append
       }
       W::sync();
@@ -699,20 +697,26 @@ struct FastEngine {
     };
     unsigned long long n_steps = 0, n_tests = 0, n_ref = 0;
     int n = 0;                                       // claims in the order
-    int pend_a = -1, pend_x = 0; uint32_t pend_mv = 0;   // the move the last commit left for the next sort.Slice
+    int rows = 1;                                    // cursor rows in use
+    int pend_a = -1, pend_x = 0; uint32_t pend_mv = 0;   // a move the last commit could not make itself (sort.Slice of the next add)
     bool pend_new = false;                           // ... or the claim the last pod created
     int status = 0, steps = 0;
-    // the queue, 64 entries at a time; the next block's pod ids and classes are fetched while this one is placed
-    LaneVar<uint32_t> nxt_pod, nxt_cls;
-    W::each([&](int l) { if (l < np) { const uint32_t p = sorted[l]; nxt_pod.at(l) = p; nxt_cls.at(l) = rc_[p]; } });
+    const KS_GLOBAL uint32_t* const gsorted = (const KS_GLOBAL uint32_t*)sorted;
+    const KS_GLOBAL uint32_t* const grc = (const KS_GLOBAL uint32_t*)rc_;
+    KS_GLOBAL int32_t* const gassign = (KS_GLOBAL int32_t*)g_assign;
+    KS_GLOBAL uint32_t* const gslot = (KS_GLOBAL uint32_t*)g_slot;
+    KS_LDS uint16_t* const slot_of = Mp->slot_of;
+    // the queue, 64 entries at a time, one per lane: pod, class, class slot, and the results (claim, position inside it);
+    // the next block's pod ids and classes are fetched while this one is placed
+    LaneVar<uint32_t> nxt_pod, nxt_cls, bpod, bcls, bslot, oclaim, ocnt;
+    W::each([&](int l) { nxt_pod.at(l) = 0; nxt_cls.at(l) = 0; bpod.at(l) = 0; bcls.at(l) = 0; bslot.at(l) = 0xFFFF; oclaim.at(l) = 0; ocnt.at(l) = 0; });
+    W::each([&](int l) { if (l < np) { const uint32_t p = gsorted[l]; nxt_pod.at(l) = p; nxt_cls.at(l) = grc[p]; } });
     for (int base = 0; base < np && !status; base += 64) {
       const int bn = np - base < 64 ? np - base : 64;
       {
-        KS_LDS uint32_t* bp = Mp->blk_pod; KS_LDS uint16_t* bc = Mp->blk_class;
-        W::each([&](int l) { if (l < bn) { bp[l] = nxt_pod.at(l); bc[l] = (uint16_t)nxt_cls.at(l); } });
-        W::sync();
+        W::each([&](int l) { bpod.at(l) = nxt_pod.at(l); bcls.at(l) = nxt_cls.at(l); bslot.at(l) = l < bn ? (uint32_t)slot_of[nxt_cls.at(l)] : 0xFFFFu; });
         const int nb = base + 64;
-        W::each([&](int l) { if (nb + l < np) { const uint32_t p = sorted[nb + l]; nxt_pod.at(l) = p; nxt_cls.at(l) = rc_[p]; } });
+        W::each([&](int l) { if (nb + l < np) { const uint32_t p = gsorted[nb + l]; nxt_pod.at(l) = p; nxt_cls.at(l) = grc[p]; } });
       }
       if ((base & 1023) == 0 && cancel && fast_uniform(W::poll_flag(cancel))) { status = 2; break; }
       int done = 0;
@@ -720,7 +724,7 @@ struct FastEngine {
         if (max_steps >= 0 && steps >= max_steps) { status = 2; break; }
         steps++;
         const unsigned long long ts0 = W::clock();
-        // ---- sort.Slice (scheduler.go:598): the move the last commit left ----
+        // ---- sort.Slice (scheduler.go:598) for a move the last commit left behind ----
         if (pend_a >= 0) {
           const int a = pend_a;
           pend_a = -1;
@@ -749,7 +753,7 @@ struct FastEngine {
               const int b = from;   // positions (a, b] moved left by one
               W::each([&](int l) {
 #pragma unroll
-                for (int j = 0; j < kFastRows; ++j) { const uint32_t r = cur[j].at(l); cur[j].at(l) = r - (uint32_t)(((uint32_t)a < r && r <= (uint32_t)b) ? 1 : 0); }
+                for (int j = 0; j < kFastRows; ++j) if (j < rows) { const uint32_t r = cur[j].at(l); cur[j].at(l) = r - (uint32_t)(((uint32_t)a < r && r <= (uint32_t)b) ? 1 : 0); }
               });
             }
           } else {
@@ -778,19 +782,27 @@ struct FastEngine {
         }
         const unsigned long long ts1 = W::clock();
         KS_TADD(0, ts1 - ts0);
-        // ---- the pod and its class slot ----
-        int slot = (int)Mp->slot_of[Mp->blk_class[bi]];
+        // ---- the pod's class slot ----
+        int slot = (int)bslot.bcast(bi);
         if (slot == 0xFFFF) {
-          const int sv = fast_uniform(cold.new_slot((int)Mp->blk_class[bi]));
+          const int k = (int)bcls.bcast(bi);
+          const int sv = fast_uniform(cold.new_slot(k));
           slot = sv & 0xFFFF;
-          if (sv >> 16) W::each([&](int l) {
+          if (sv >> 16) {   // every slot was taken: all classes start over
+            W::each([&](int l) {
+              bslot.at(l) = 0xFFFFu;
 #pragma unroll
-            for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = 0;
-          });
+              for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = 0;
+            });
+            rows = 1;
+          }
+          W::each([&](int l) { if (bcls.at(l) == (uint32_t)k) bslot.at(l) = (uint32_t)slot; });   // later pods of the class in this block
           set_cursor(slot, 0);
+          rows = (slot >> 6) + 1 > rows ? (slot >> 6) + 1 : rows;
         }
         const FastSlot cs = lds_get(&aslot[slot]);
-        uint32_t r = get_cursor(slot);
+        const uint32_t rc0 = get_cursor(slot);
+        uint32_t r = rc0;
         bool placed = false;
         const unsigned long long ts2 = W::clock();
         KS_TADD(1, ts2 - ts1);
@@ -807,7 +819,7 @@ struct FastEngine {
             const bool valid = p < n;
             const int pc = valid ? p : n - 1;
             const uint32_t x = oord[pc];
-            xv.at(l) = x; kv.at(l) = okey[pc];
+            xv.at(l) = x; kv.at(l) = valid ? (uint32_t)okey[pc] : 0xFFFFFFFFu;
             const FastClaim st = lds_get(&cst[x]);
             q0.at(l) = st.req[0]; q1.at(l) = st.req[1]; q2.at(l) = st.req[2]; q3.at(l) = st.req[3];
             const uint64_t m = st.vmask & cs.cvmask;
@@ -853,21 +865,43 @@ struct FastEngine {
           ns.vmask = mv.bcast(first_ok);
           ns.req[0] = q0.bcast(first_ok) + cs.size[0]; ns.req[1] = q1.bcast(first_ok) + cs.size[1];
           ns.req[2] = q2.bcast(first_ok) + cs.size[2]; ns.req[3] = q3.bcast(first_ok) + cs.size[3];
-          if (W::leader()) {
-            lds_put(&cst[x], ns);
-            Mp->out_claim[bi] = (uint32_t)x;
-            Mp->out_cnt[bi] = cnt;
-            okey[a] = (uint16_t)(cnt + 1);
-          }
-          W::sync();
+          if (W::leader()) lds_put(&cst[x], ns);
+          oclaim.set(bi, (uint32_t)x); ocnt.set(bi, cnt);
           n_ref += (unsigned long long)a + 1;
-          pend_a = a; pend_x = x; pend_mv = cnt + 1;
           r = (uint32_t)a;
           placed = true;
+          // The sort.Slice of the NEXT add (scheduler.go:598) repairs this claim's position: one stable move past the claims
+          // with a smaller count. When the next add follows inside this block and those claims are all among the positions
+          // just tested, their counts and ids are in registers already: move now, without reading the order again.
+          const uint32_t mvn = cnt + 1;
+          bool moved = false;
+          if (bi + 1 < bn && !(max_steps >= 0 && steps >= max_steps) && (n <= 12 || (n >= 50 && !fast_sampled(n, a)))) {
+            const uint64_t lessm = W::ballot([&](int l) { return l > first_ok && kv.at(l) < mvn; });   // lanes past n hold 0xFFFFFFFF
+            const uint64_t t = first_ok == 63 ? 0ull : (lessm >> (first_ok + 1));
+            const int s_ = t == ~0ull ? 64 : ctz64(~t);
+            if (first_ok + 1 + s_ < 64 || (int)r0 + 64 >= n) {
+              // lanes first_ok+1 .. first_ok+s_ step one position to the left, the claim lands behind them
+              W::each([&](int l) { if (l > first_ok && l <= first_ok + s_) { okey[(int)r0 + l - 1] = (uint16_t)kv.at(l); oord[(int)r0 + l - 1] = (uint16_t)xv.at(l); } });
+              if (W::leader()) { okey[a + s_] = (uint16_t)mvn; if (s_) oord[a + s_] = (uint16_t)x; }
+              if (s_) {
+                const int b = a + s_;
+                W::each([&](int l) {
+#pragma unroll
+                  for (int j = 0; j < kFastRows; ++j) if (j < rows) { const uint32_t rr = cur[j].at(l); cur[j].at(l) = rr - (uint32_t)(((uint32_t)a < rr && rr <= (uint32_t)b) ? 1 : 0); }
+                });
+              }
+              moved = true;
+            }
+          }
+          if (!moved) {
+            if (W::leader()) okey[a] = (uint16_t)mvn;
+            pend_a = a; pend_x = x; pend_mv = mvn;
+          }
+          W::sync();
           KS_TADD(3, W::clock() - ts3);
           break;
         }
-        set_cursor(slot, r);
+        if (r != rc0) set_cursor(slot, r);
         done = bi + 1;
         if (placed) continue;
         const unsigned long long tn = W::clock();
@@ -878,15 +912,14 @@ struct FastEngine {
           cold.finish(bc < 0 ? 1 : 3, n, 0, 0, 0, 0, nullptr);
           return;
         }
+        oclaim.set(bi, (uint32_t)n); ocnt.set(bi, 0u);   // claim ids are handed out in creation order: the new claim is claim n
         n++;
         pend_new = true;
       }
       // the block's results
       {
-        KS_LDS uint32_t* bp = Mp->blk_pod; KS_LDS uint32_t* oc = Mp->out_claim; KS_LDS uint32_t* on = Mp->out_cnt;
         const int dn = done;
-        W::each([&](int l) { if (l < dn) { const uint32_t p = bp[l]; g_assign[p] = (int32_t)oc[l]; g_slot[p] = on[l]; } });
-        W::sync();
+        W::each([&](int l) { if (l < dn) { const uint32_t p = bpod.at(l); gassign[p] = (int32_t)oclaim.at(l); gslot[p] = ocnt.at(l); } });
       }
     }
     KS_TADD(5, W::clock() - t_begin);

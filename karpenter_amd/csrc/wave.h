@@ -16,11 +16,13 @@
 #define KS_FN __host__ __device__ __forceinline__
 #define KS_DEV __device__ __forceinline__
 #define KS_LDS __attribute__((address_space(3)))   // pointers known to point into the CU's LDS: ds_* instead of flat_*
+#define KS_GLOBAL __attribute__((address_space(1)))   // pointers known to point into HBM: global_* instead of flat_* (a flat access also counts against lgkmcnt, so every LDS wait behind it waits for HBM)
 #else
 #define KS_DEVICE 0   // g++ (host flattener, test-only emulation): a wave is a loop over 64 lanes
 #define KS_FN inline
 #define KS_DEV inline
 #define KS_LDS
+#define KS_GLOBAL
 #endif
 
 namespace ks {
@@ -265,6 +267,15 @@ struct LaneVar {
 #if KS_DEVICE
   T v;
   KS_DEV T& at(int) { return v; }
+  KS_DEV void set(int lane, T x) {   // a wave-uniform value into one lane (v_writelane)
+    static_assert(sizeof(T) == 4, "LaneVar::set: 32-bit values");
+    uint32_t w = __builtin_bit_cast(uint32_t, v), m0_saved;
+    const uint32_t xs = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, x));   // in an SGPR, never a literal
+    lane = __builtin_amdgcn_readfirstlane(lane);
+    // one SGPR operand per VOP3 (constant bus): the lane select goes through m0, which is put back afterwards
+    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(w), "=&s"(m0_saved) : "s"(xs), "s"(lane));
+    v = __builtin_bit_cast(T, w);
+  }
   KS_DEV T bcast(int lane) const {
     static_assert(sizeof(T) == 4 || sizeof(T) == 8, "LaneVar: 32- or 64-bit values");
     if constexpr (sizeof(T) == 4) {
@@ -280,6 +291,7 @@ struct LaneVar {
 #else
   T v[64];
   T& at(int l) { return v[l]; }
+  void set(int lane, T x) { v[lane] = x; }
   T bcast(int lane) const { return v[lane]; }
 #endif
 };
