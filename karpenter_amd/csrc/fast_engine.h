@@ -50,7 +50,7 @@ struct FastEnt { uint64_t vmask; int32_t cap[4]; uint32_t info; uint32_t pad; };
 
 struct FastPlan {   // LDS plan of ksolve_pack_fast (bytes), computed by the host
   int total_bytes, cap;
-  int off_state, off_key, off_ord, off_snap, off_ent, off_pool, off_slot, off_misc;
+  int off_state, off_key, off_ord, off_snap, off_ent, off_pool, off_slot, off_misc, off_hot;
 };
 
 struct FastMisc {   // small LDS tables
@@ -105,7 +105,6 @@ KS_FN void lds_put(KS_LDS T* p, const T& v) {
   for (int i = 0; i < (int)(sizeof(T) / 8); ++i) s[i] = o[i];
 }
 
-#define KS_FAST_BAIL(why) do { bail(why); return; } while (0)
 
 // What ksolve_pack_fast reads its problem from: ONE record in HBM (not kernel arguments: a by-value argument whose address
 // is taken is copied to private memory, and loads from private memory are divergent to the compiler — every branch of the
@@ -137,6 +136,8 @@ KS_FN T* fast_uniform(T* p) {
 #endif
 }
 
+#define KS_LIKELY(x) __builtin_expect(!!(x), 1)
+#define KS_UNLIKELY(x) __builtin_expect(!!(x), 0)
 #if KS_DEVICE
 #define KS_COLD __device__ __attribute__((noinline))
 #else
@@ -157,10 +158,8 @@ KS_FN int fast_lookup(const KS_LDS FastEnt* ent, uint64_t vm, FastEnt& out) {
   return -1;
 }
 KS_FN bool fast_fits_first(const FastEnt& e, const int32_t* req, const int32_t* size) {
-  bool ok = true;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) ok = ok && size[r] <= e.cap[r] - req[r];
-  return ok;
+  // bitwise on purpose: four compares and three ANDs, no short-circuit branches
+  return (int)(size[0] <= e.cap[0] - req[0]) & (int)(size[1] <= e.cap[1] - req[1]) & (int)(size[2] <= e.cap[2] - req[2]) & (int)(size[3] <= e.cap[3] - req[3]);
 }
 // "some instance type of the entry holds `req` + `size`" — CanAdd's filterInstanceTypesByRequirements verdict
 KS_FN bool fast_fits(const KS_LDS int32_t* pool, const FastEnt& e, const int32_t* req, const int32_t* size) {
@@ -635,299 +634,323 @@ struct FastCold {
   }
 };
 
-// The loop that places a pod. Its state is local (registers); the cold object above lives in private memory and is only
-// touched through calls.
+// The loop's state between two events (LDS): scalars, the cursors and the 64-entry queue block, one value per lane
+struct FastHot {
+  int base, bi, bn, n, np, max_steps, steps, status;
+  int pend_a, pend_x, pend_new, ev_arg;
+  uint32_t pend_mv, pad0;
+  uint64_t ev_vm;
+  unsigned long long n_steps, n_tests, n_ref;
+  const uint32_t* sorted; const uint32_t* row_class; const volatile int* cancel; int32_t* g_assign; uint32_t* g_slot;
+  uint32_t cur[kFastRows][64];
+  uint32_t bpod[64], bcls[64], bslot[64], oclaim[64], ocnt[64], nxt_pod[64], nxt_cls[64];
+};
+struct FastHotCtx {   // LDS pointers of the loop, passed by value
+  KS_LDS uint16_t* okey; KS_LDS uint16_t* oord; KS_LDS FastClaim* cst; KS_LDS FastEnt* ent; KS_LDS int32_t* pool;
+  KS_LDS FastSlot* aslot; KS_LDS uint16_t* slot_of; KS_LDS FastHot* hs;
+};
+enum { FEV_DONE = 0, FEV_ENTRY = 1, FEV_SLOT = 2, FEV_SLOWSORT = 3, FEV_PLACE = 4, FEV_NEWCLAIM = 5, FEV_COUNT = 6 };
+
+// The loop that places pods: a function of its own, WITHOUT calls — whatever happens rarely (a requirement set seen for the
+// first time, a new class slot, a new claim, pdqsort leaving its single-move path) ends the run with an event code; the
+// driver handles it through FastCold and runs the loop again. So the compiler allocates registers for this loop alone.
+template <class W>
+KS_COLD int fast_hot_run(FastHotCtx cx) {
+  typedef KS_LDS uint16_t* o16;
+  const o16 okey = fast_uniform(cx.okey), oord = fast_uniform(cx.oord);
+  KS_LDS FastClaim* const cst = fast_uniform(cx.cst);
+  KS_LDS FastEnt* const ent = fast_uniform(cx.ent);
+  KS_LDS int32_t* const pool = fast_uniform(cx.pool);
+  KS_LDS FastSlot* const aslot = fast_uniform(cx.aslot);
+  KS_LDS uint16_t* const slot_of = fast_uniform(cx.slot_of);
+  KS_LDS FastHot* const hs = fast_uniform(cx.hs);
+  // ---- state in ----
+  const int np = fast_uniform(hs->np), max_steps = fast_uniform(hs->max_steps);
+  const KS_GLOBAL uint32_t* const gsorted = (const KS_GLOBAL uint32_t*)fast_uniform(hs->sorted);
+  const KS_GLOBAL uint32_t* const grc = (const KS_GLOBAL uint32_t*)fast_uniform(hs->row_class);
+  const volatile int* const cancel = fast_uniform(hs->cancel);
+  KS_GLOBAL int32_t* const gassign = (KS_GLOBAL int32_t*)fast_uniform(hs->g_assign);
+  KS_GLOBAL uint32_t* const gslot = (KS_GLOBAL uint32_t*)fast_uniform(hs->g_slot);
+  int base = fast_uniform(hs->base), bi = fast_uniform(hs->bi), bn = fast_uniform(hs->bn), n = fast_uniform(hs->n), steps = fast_uniform(hs->steps), status = fast_uniform(hs->status);
+  int pend_a = fast_uniform(hs->pend_a), pend_x = fast_uniform(hs->pend_x); uint32_t pend_mv = (uint32_t)fast_uniform((int)hs->pend_mv); bool pend_new = fast_uniform(hs->pend_new) != 0;
+  unsigned long long n_steps = W::uniform(hs->n_steps), n_tests = W::uniform(hs->n_tests), n_ref = W::uniform(hs->n_ref);
+  LaneVar<uint32_t> cur[kFastRows], nxt_pod, nxt_cls, bpod, bcls, bslot, oclaim, ocnt;
+  W::each([&](int l) {
+#pragma unroll
+    for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = hs->cur[j][l];
+    nxt_pod.at(l) = hs->nxt_pod[l]; nxt_cls.at(l) = hs->nxt_cls[l]; bpod.at(l) = hs->bpod[l]; bcls.at(l) = hs->bcls[l];
+    bslot.at(l) = hs->bslot[l]; oclaim.at(l) = hs->oclaim[l]; ocnt.at(l) = hs->ocnt[l];
+  });
+  int ev = FEV_DONE, ev_arg = 0; uint64_t ev_vm = 0;
+  for (;;) {
+    // ---- the next block of the queue ----
+    if (KS_UNLIKELY(bi >= bn)) {
+      if (bn > 0) {   // the finished block's results
+        const int dn = bn;
+        W::each([&](int l) { if (l < dn) { const uint32_t p = bpod.at(l); gassign[p] = (int32_t)oclaim.at(l); gslot[p] = ocnt.at(l); } });
+        base += 64;
+      }
+      if (base >= np || status) { bn = 0; bi = 0; break; }
+      bn = np - base < 64 ? np - base : 64;
+      bi = 0;
+      const int bnn = bn, nb = base + 64;
+      W::each([&](int l) { bpod.at(l) = nxt_pod.at(l); bcls.at(l) = nxt_cls.at(l); bslot.at(l) = l < bnn ? (uint32_t)slot_of[nxt_cls.at(l)] : 0xFFFFu; });
+      W::each([&](int l) { if (nb + l < np) { const uint32_t p = gsorted[nb + l]; nxt_pod.at(l) = p; nxt_cls.at(l) = grc[p]; } });
+      if ((base & 1023) == 0 && cancel && fast_uniform(W::poll_flag(cancel))) { status = 2; bn = 0; break; }
+    }
+    if (KS_UNLIKELY(max_steps >= 0 && steps >= max_steps)) { status = 2; break; }
+    // ---- sort.Slice (scheduler.go:598) for a move the last commit left behind ----
+    if (KS_UNLIKELY(pend_a >= 0 || pend_new)) {
+      if (pend_new) { ev = FEV_PLACE; break; }
+      const int a = pend_a;
+      if (!(n <= 12 || (n >= 50 && !fast_sampled(n, a)))) { ev = FEV_SLOWSORT; ev_arg = a; break; }
+      pend_a = -1;
+      // one stable move: the claim at a (count pend_mv) goes right past the claims with a smaller count
+      int from = a;
+      const uint32_t mv = pend_mv;
+      for (;;) {
+        LaneVar<uint32_t> kv, ov;
+        const uint64_t less = W::ballot([&](int l) {
+          const int i = from + 1 + l;
+          if (i >= n) return false;
+          const uint32_t k = okey[i];
+          kv.at(l) = k; ov.at(l) = oord[i];
+          return k < mv;
+        });
+        const int s_ = less == ~0ull ? 64 : ctz64(~less);   // sorted beyond a: the smaller counts are a prefix
+        if (s_ == 0) break;
+        W::each([&](int l) { if (l < s_) { okey[from + l] = (uint16_t)kv.at(l); oord[from + l] = (uint16_t)ov.at(l); } });
+        from += s_;
+        if (s_ < 64) break;
+      }
+      if (from != a) {
+        if (W::leader()) { okey[from] = (uint16_t)mv; oord[from] = (uint16_t)pend_x; }
+        W::sync();
+        const int b = from;   // positions (a, b] moved left by one
+        W::each([&](int l) {
+#pragma unroll
+          for (int j = 0; j < kFastRows; ++j) { const uint32_t r = cur[j].at(l); cur[j].at(l) = r - (uint32_t)(((uint32_t)a < r && r <= (uint32_t)b) ? 1 : 0); }
+        });
+      }
+    }
+    // ---- the pod's class slot ----
+    const int slot = (int)bslot.bcast(bi);
+    if (KS_UNLIKELY(slot == 0xFFFF)) { ev = FEV_SLOT; ev_arg = (int)bcls.bcast(bi); break; }
+    const FastSlot cs = lds_get(&aslot[slot]);
+    uint32_t rc0 = 0;
+    {
+      const uint32_t c0 = cur[0].bcast(slot & 63), c1 = cur[1].bcast(slot & 63), c2 = cur[2].bcast(slot & 63), c3 = cur[3].bcast(slot & 63);
+      const int row = slot >> 6;
+      rc0 = row == 0 ? c0 : row == 1 ? c1 : row == 2 ? c2 : c3;
+    }
+    static_assert(kFastRows == 4, "cursor rows are spelled out above");
+    uint32_t r = rc0;
+    int outcome = 0;   // 1 placed, 2 no acceptor, 3 event
+    while ((int)r < n) {
+      // ---- addToInflightNode (scheduler.go:658-692): positions r .. r+63, one lane each; straight-line: three
+      // dependent LDS reads (order -> claim state -> requirement-set cache), everything else in registers ----
+      LaneVar<uint64_t> mv;
+      LaneVar<uint32_t> xv, kv;
+      LaneVar<int32_t> q0, q1, q2, q3;
+      const uint32_t r0 = r;
+      uint64_t okm = 0, oddm = 0;
+      W::ballot2([&](int l) {
+        const int p = (int)r0 + l;
+        const bool valid = p < n;
+        const int pc = valid ? p : n - 1;
+        const uint32_t x = oord[pc];
+        xv.at(l) = x; kv.at(l) = valid ? (uint32_t)okey[pc] : 0xFFFFFFFFu;
+        const FastClaim st = lds_get(&cst[x]);
+        q0.at(l) = st.req[0]; q1.at(l) = st.req[1]; q2.at(l) = st.req[2]; q3.at(l) = st.req[3];
+        const uint64_t m = st.vmask & cs.cvmask;
+        mv.at(l) = m;
+        const FastEnt e = lds_get(&ent[fast_hash(m)]);
+        // predicates as 0/1 integers combined with & and |: straight-line code, no short-circuit branches
+        const int base_ok = (int)valid & (int)((cs.tmplok >> (st.vmask >> 56)) & 1u) & (int)fast_fields_ok(m, cs.dmask);
+        const int simple = (int)(e.info & 1u) & (int)(e.vmask == m);   // the cache's first probe is this requirement set
+        const int fit = (int)fast_fits_first(e, st.req, cs.size);
+        // bit 0: accepted; bit 1: needs the long way (requirement set not cached, a hash collision, or further Pareto vectors)
+        return (base_ok & simple & fit) | ((base_ok & ((simple ^ 1) | ((fit ^ 1) & (int)((e.info >> 8) != 0)))) << 1);
+      }, okm, oddm);
+      uint64_t missm = 0;
+      if (KS_UNLIKELY(oddm != 0)) {
+        // rare: resolve those lanes with the full probe sequence / all Pareto vectors
+        const uint64_t mm = oddm;
+        uint64_t ok2 = 0;
+        W::ballot2([&](int l) {
+          if (!((mm >> l) & 1)) return 0;
+          FastEnt e;
+          if (fast_lookup(ent, mv.at(l), e) < 0) return 2;
+          const int32_t rq[4] = {q0.at(l), q1.at(l), q2.at(l), q3.at(l)};
+          return fast_fits(pool, e, rq, cs.size) ? 1 : 0;
+        }, ok2, missm);
+        okm |= ok2;
+      }
+      n_tests += (unsigned long long)(n - (int)r0 < 64 ? n - (int)r0 : 64);
+      n_steps++;
+      const int first_ok = okm ? ctz64(okm) : 64;
+      if (KS_UNLIKELY(missm != 0 && ctz64(missm) < first_ok)) {
+        // a requirement set that is not cached yet sits before the first acceptor: cache it, test these positions again
+        ev = FEV_ENTRY; ev_vm = mv.bcast(ctz64(missm)); outcome = 3;
+        break;
+      }
+      if (!okm) { r = (uint32_t)((int)r0 + 64 < n ? (int)r0 + 64 : n); continue; }
+      // ---- commit: NodeClaim.Add (nodeclaim.go:247-263) ----
+      const int a = (int)r0 + first_ok;
+      const int x = (int)xv.bcast(first_ok);
+      const uint32_t cnt = kv.bcast(first_ok);
+      if (KS_UNLIKELY(cnt >= 65534u)) { ev = FEV_COUNT; outcome = 3; break; }
+      FastClaim ns;
+      ns.vmask = mv.bcast(first_ok);
+      ns.req[0] = q0.bcast(first_ok) + cs.size[0]; ns.req[1] = q1.bcast(first_ok) + cs.size[1];
+      ns.req[2] = q2.bcast(first_ok) + cs.size[2]; ns.req[3] = q3.bcast(first_ok) + cs.size[3];
+      if (W::leader()) lds_put(&cst[x], ns);
+      oclaim.set(bi, (uint32_t)x); ocnt.set(bi, cnt);
+      n_ref += (unsigned long long)a + 1;
+      r = (uint32_t)a;
+      outcome = 1;
+      // The sort.Slice of the NEXT add (scheduler.go:598) repairs this claim's position: one stable move past the claims
+      // with a smaller count. When the next add follows inside this block and those claims are all among the positions
+      // just tested, their counts and ids are in registers already: move now, without reading the order again.
+      const uint32_t mvn = cnt + 1;
+      bool moved = false;
+      if (KS_LIKELY(bi + 1 < bn && !(max_steps >= 0 && steps + 1 >= max_steps) && (n <= 12 || (n >= 50 && !fast_sampled(n, a))))) {
+        const uint64_t lessm = W::ballot([&](int l) { return l > first_ok && kv.at(l) < mvn; });   // lanes past n hold 0xFFFFFFFF
+        const uint64_t t = first_ok == 63 ? 0ull : (lessm >> (first_ok + 1));
+        const int s_ = t == ~0ull ? 64 : ctz64(~t);
+        if (KS_LIKELY(first_ok + 1 + s_ < 64 || (int)r0 + 64 >= n)) {
+          // lanes first_ok+1 .. first_ok+s_ step one position to the left, the claim lands behind them
+          W::each([&](int l) { if (l > first_ok && l <= first_ok + s_) { okey[(int)r0 + l - 1] = (uint16_t)kv.at(l); oord[(int)r0 + l - 1] = (uint16_t)xv.at(l); } });
+          if (W::leader()) { okey[a + s_] = (uint16_t)mvn; oord[a + s_] = (uint16_t)x; }
+          const int b = a + s_;
+          W::each([&](int l) {
+#pragma unroll
+            for (int j = 0; j < kFastRows; ++j) { const uint32_t rr = cur[j].at(l); cur[j].at(l) = rr - (uint32_t)(((uint32_t)a < rr && rr <= (uint32_t)b) ? 1 : 0); }
+          });
+          moved = true;
+        }
+      }
+      if (KS_UNLIKELY(!moved)) {
+        if (W::leader()) okey[a] = (uint16_t)mvn;
+        pend_a = a; pend_x = x; pend_mv = mvn;
+      }
+      W::sync();
+      break;
+    }
+    if (KS_UNLIKELY(outcome == 3)) {
+      // the event interrupts this pod: what the scan learned (claims that rejected it for good) is kept in its cursor
+      W::each([&](int l) {
+#pragma unroll
+        for (int j = 0; j < kFastRows; ++j) if (j * 64 + l == slot) cur[j].at(l) = r;
+      });
+      break;
+    }
+    if (r != rc0) W::each([&](int l) {
+#pragma unroll
+      for (int j = 0; j < kFastRows; ++j) if (j * 64 + l == slot) cur[j].at(l) = r;
+    });
+    steps++;
+    if (KS_LIKELY(outcome == 1)) { bi++; continue; }
+    ev = FEV_NEWCLAIM; ev_arg = slot;   // no in-flight claim accepted the pod: addToNewNodeClaim; the driver moves on to the next pod
+    break;
+  }
+  // ---- state out ----
+  if (W::leader()) {
+    hs->base = base; hs->bi = bi; hs->bn = bn; hs->n = n; hs->steps = steps; hs->status = status;
+    hs->pend_a = pend_a; hs->pend_x = pend_x; hs->pend_mv = pend_mv; hs->pend_new = pend_new ? 1 : 0;
+    hs->n_steps = n_steps; hs->n_tests = n_tests; hs->n_ref = n_ref; hs->ev_arg = ev_arg; hs->ev_vm = ev_vm;
+  }
+  W::each([&](int l) {
+#pragma unroll
+    for (int j = 0; j < kFastRows; ++j) hs->cur[j][l] = cur[j].at(l);
+    hs->nxt_pod[l] = nxt_pod.at(l); hs->nxt_cls[l] = nxt_cls.at(l); hs->bpod[l] = bpod.at(l); hs->bcls[l] = bcls.at(l);
+    hs->bslot[l] = bslot.at(l); hs->oclaim[l] = oclaim.at(l); hs->ocnt[l] = ocnt.at(l);
+  });
+  W::sync();
+  return ev;
+}
+
+// The driver: runs the loop, handles its events through FastCold.
 template <class W>
 struct FastEngine {
   FastCold<W> cold;
-  KS_DEV FastEngine(const ProblemView* p, const Workspace* s, const FastWork* f, char* lds) { cold.init(p, s, f, lds); }
+  KS_LDS FastHot* hs;
+  KS_DEV FastEngine(const ProblemView* p, const Workspace* s, const FastWork* f, char* lds) { cold.init(p, s, f, lds); hs = (KS_LDS FastHot*)(lds + f->plan.off_hot); }
 
   KS_DEV void solve() {
-    typedef KS_LDS uint16_t* o16;
-#ifdef KSOLVE_PHASE_TIMERS
-    unsigned long long tc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // move+cursors, slot, scan, commit, slow sort, total, setup, new claim
-#define KS_TADD(i, v) (tc_[i] += (v))
-#else
-#define KS_TADD(i, v) ((void)0)
-#endif
-    const unsigned long long t_begin = W::clock();
     {
       const int why = (int)W::uniform((uint64_t)(uint32_t)cold.setup());
       if (why) { cold.bail_code = why; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
     }
-    KS_TADD(6, W::clock() - t_begin);
-    // everything the loop touches, as values
-    const o16 okey = fast_uniform(cold.order.key), oord = fast_uniform(cold.order.ord);
-    KS_LDS FastClaim* const cst = fast_uniform(cold.cst);
-    KS_LDS FastEnt* const ent = fast_uniform(cold.ent);
-    KS_LDS int32_t* const pool = fast_uniform(cold.pool);
-    KS_LDS FastSlot* const aslot = fast_uniform(cold.aslot);
-    KS_LDS FastMisc* const Mp = fast_uniform(cold.Mp);
+    KS_LDS FastHot* const h = fast_uniform(hs);
     const int np = fast_uniform(cold.Pk->n_pods);
-    const uint32_t* const sorted = fast_uniform(cold.Pk->sorted_pods);
-    const uint32_t* const rc_ = fast_uniform(cold.Pk->row_class);
-    const volatile int* const cancel = fast_uniform(cold.Sk->cancel_flag);
-    const long long ms_ = (long long)W::uniform((uint64_t)cold.Sk->max_steps);
-    const int max_steps = ms_ < 0 ? -1 : (int)(ms_ > 0x7FFFFFFF ? 0x7FFFFFFF : ms_);
-    int32_t* const g_assign = fast_uniform(cold.Sk->assign);
-    uint32_t* const g_slot = fast_uniform(cold.Sk->slot);
-    LaneVar<uint32_t> cur[kFastRows];   // cursor of class slot (row * 64 + lane)
-    W::each([&](int l) {
-#pragma unroll
-      for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = 0;
-    });
-    auto get_cursor = [&](int slot) -> uint32_t {
-      uint32_t r = 0;
-#pragma unroll
-      for (int j = 0; j < kFastRows; ++j) if (j == (slot >> 6)) r = cur[j].bcast(slot & 63);
-      return r;
-    };
-    auto set_cursor = [&](int slot, uint32_t v) {
-      W::each([&](int l) {
-#pragma unroll
-        for (int j = 0; j < kFastRows; ++j) if (j * 64 + l == slot) cur[j].at(l) = v;
-      });
-    };
-    auto cursors_fallback = [&](int lo, int hi) {   // a slow sort permuted positions lo..hi
-      if (hi < lo) return;
-      W::each([&](int l) {
-#pragma unroll
-        for (int j = 0; j < kFastRows; ++j) { const uint32_t r = cur[j].at(l); if (r > (uint32_t)lo && r <= (uint32_t)hi) cur[j].at(l) = (uint32_t)lo; }
-      });
-    };
-    unsigned long long n_steps = 0, n_tests = 0, n_ref = 0;
-    int n = 0;                                       // claims in the order
-    int rows = 1;                                    // cursor rows in use
-    int pend_a = -1, pend_x = 0; uint32_t pend_mv = 0;   // a move the last commit could not make itself (sort.Slice of the next add)
-    bool pend_new = false;                           // ... or the claim the last pod created
-    int status = 0, steps = 0;
-    const KS_GLOBAL uint32_t* const gsorted = (const KS_GLOBAL uint32_t*)sorted;
-    const KS_GLOBAL uint32_t* const grc = (const KS_GLOBAL uint32_t*)rc_;
-    KS_GLOBAL int32_t* const gassign = (KS_GLOBAL int32_t*)g_assign;
-    KS_GLOBAL uint32_t* const gslot = (KS_GLOBAL uint32_t*)g_slot;
-    KS_LDS uint16_t* const slot_of = Mp->slot_of;
-    // the queue, 64 entries at a time, one per lane: pod, class, class slot, and the results (claim, position inside it);
-    // the next block's pod ids and classes are fetched while this one is placed
-    LaneVar<uint32_t> nxt_pod, nxt_cls, bpod, bcls, bslot, oclaim, ocnt;
-    W::each([&](int l) { nxt_pod.at(l) = 0; nxt_cls.at(l) = 0; bpod.at(l) = 0; bcls.at(l) = 0; bslot.at(l) = 0xFFFF; oclaim.at(l) = 0; ocnt.at(l) = 0; });
-    W::each([&](int l) { if (l < np) { const uint32_t p = gsorted[l]; nxt_pod.at(l) = p; nxt_cls.at(l) = grc[p]; } });
-    for (int base = 0; base < np && !status; base += 64) {
-      const int bn = np - base < 64 ? np - base : 64;
-      {
-        W::each([&](int l) { bpod.at(l) = nxt_pod.at(l); bcls.at(l) = nxt_cls.at(l); bslot.at(l) = l < bn ? (uint32_t)slot_of[nxt_cls.at(l)] : 0xFFFFu; });
-        const int nb = base + 64;
-        W::each([&](int l) { if (nb + l < np) { const uint32_t p = gsorted[nb + l]; nxt_pod.at(l) = p; nxt_cls.at(l) = grc[p]; } });
-      }
-      if ((base & 1023) == 0 && cancel && fast_uniform(W::poll_flag(cancel))) { status = 2; break; }
-      int done = 0;
-      for (int bi = 0; bi < bn; ++bi) {
-        if (max_steps >= 0 && steps >= max_steps) { status = 2; break; }
-        steps++;
-        const unsigned long long ts0 = W::clock();
-        // ---- sort.Slice (scheduler.go:598) for a move the last commit left behind ----
-        if (pend_a >= 0) {
-          const int a = pend_a;
-          pend_a = -1;
-          if (n <= 12 || (n >= 50 && !fast_sampled(n, a))) {
-            // one stable move: the claim at a (count pend_mv) goes right past the claims with a smaller count
-            int from = a;
-            const uint32_t mv = pend_mv;
-            for (;;) {
-              LaneVar<uint32_t> kv, ov;
-              const uint64_t less = W::ballot([&](int l) {
-                const int i = from + 1 + l;
-                if (i >= n) return false;
-                const uint32_t k = okey[i];
-                kv.at(l) = k; ov.at(l) = oord[i];
-                return k < mv;
-              });
-              const int s_ = less == ~0ull ? 64 : ctz64(~less);   // sorted beyond a: the smaller counts are a prefix
-              if (s_ == 0) break;
-              W::each([&](int l) { if (l < s_) { okey[from + l] = (uint16_t)kv.at(l); oord[from + l] = (uint16_t)ov.at(l); } });
-              from += s_;
-              if (s_ < 64) break;
-            }
-            if (from != a) {
-              if (W::leader()) { okey[from] = (uint16_t)mv; oord[from] = (uint16_t)pend_x; }
-              W::sync();
-              const int b = from;   // positions (a, b] moved left by one
-              W::each([&](int l) {
-#pragma unroll
-                for (int j = 0; j < kFastRows; ++j) if (j < rows) { const uint32_t r = cur[j].at(l); cur[j].at(l) = r - (uint32_t)(((uint32_t)a < r && r <= (uint32_t)b) ? 1 : 0); }
-              });
-            }
-          } else {
-            const unsigned long long tq = W::clock();
-            cold.slow_sort(n, a, 0);
-            cursors_fallback(fast_uniform(cold.lo_), fast_uniform(cold.hi_));
-            KS_TADD(4, W::clock() - tq);
-          }
-        } else if (pend_new) {
-          pend_new = false;
-          const int b = fast_uniform(cold.place_new_claim(n));
-          if (b == -2) { cold.finish(3, n, 0, 0, 0, 0, nullptr); return; }
-          if (b == -1) cursors_fallback(fast_uniform(cold.lo_), fast_uniform(cold.hi_));
-          else {
-            // positions [b, n-1) moved right by one; a cursor past b either steps over the new claim or — if its class is
-            // accepted by it — comes back to it
-            const KS_LDS uint64_t* acc = Mp->acc;
-            W::each([&](int l) {
-#pragma unroll
-              for (int j = 0; j < kFastRows; ++j) {
-                const uint32_t r = cur[j].at(l);
-                if (r > (uint32_t)b) cur[j].at(l) = ((acc[j] >> l) & 1) ? (uint32_t)b : r + 1;
-              }
-            });
-          }
-        }
-        const unsigned long long ts1 = W::clock();
-        KS_TADD(0, ts1 - ts0);
-        // ---- the pod's class slot ----
-        int slot = (int)bslot.bcast(bi);
-        if (slot == 0xFFFF) {
-          const int k = (int)bcls.bcast(bi);
-          const int sv = fast_uniform(cold.new_slot(k));
-          slot = sv & 0xFFFF;
-          if (sv >> 16) {   // every slot was taken: all classes start over
-            W::each([&](int l) {
-              bslot.at(l) = 0xFFFFu;
-#pragma unroll
-              for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = 0;
-            });
-            rows = 1;
-          }
-          W::each([&](int l) { if (bcls.at(l) == (uint32_t)k) bslot.at(l) = (uint32_t)slot; });   // later pods of the class in this block
-          set_cursor(slot, 0);
-          rows = (slot >> 6) + 1 > rows ? (slot >> 6) + 1 : rows;
-        }
-        const FastSlot cs = lds_get(&aslot[slot]);
-        const uint32_t rc0 = get_cursor(slot);
-        uint32_t r = rc0;
-        bool placed = false;
-        const unsigned long long ts2 = W::clock();
-        KS_TADD(1, ts2 - ts1);
-        while ((int)r < n) {
-          // ---- addToInflightNode (scheduler.go:658-692): positions r .. r+63, one lane each; straight-line: three
-          // dependent LDS reads (order -> claim state -> requirement-set cache), everything else in registers ----
-          LaneVar<uint64_t> mv;
-          LaneVar<uint32_t> xv, kv;
-          LaneVar<int32_t> q0, q1, q2, q3;
-          const uint32_t r0 = r;
-          uint64_t okm = 0, missm = 0, morem = 0, unused_ = 0;
-          W::ballot4([&](int l) {
-            const int p = (int)r0 + l;
-            const bool valid = p < n;
-            const int pc = valid ? p : n - 1;
-            const uint32_t x = oord[pc];
-            xv.at(l) = x; kv.at(l) = valid ? (uint32_t)okey[pc] : 0xFFFFFFFFu;
-            const FastClaim st = lds_get(&cst[x]);
-            q0.at(l) = st.req[0]; q1.at(l) = st.req[1]; q2.at(l) = st.req[2]; q3.at(l) = st.req[3];
-            const uint64_t m = st.vmask & cs.cvmask;
-            mv.at(l) = m;
-            const FastEnt e = lds_get(&ent[fast_hash(m)]);
-            const bool base_ok = valid && ((cs.tmplok >> (st.vmask >> 56)) & 1u) && fast_fields_ok(m, cs.dmask);
-            const bool ev = (e.info & 1u) != 0, hit = e.vmask == m;
-            const bool fit = fast_fits_first(e, st.req, cs.size);
-            const bool more = base_ok && ev && (!hit || (!fit && (e.info >> 8) != 0));   // a collision, or further Pareto vectors
-            return (base_ok && ev && hit && fit ? 1 : 0) | (base_ok && !ev ? 2 : 0) | (more ? 4 : 0);
-          }, okm, missm, morem, unused_);
-          if (morem) {
-            // rare: resolve those lanes with the full probe sequence / all Pareto vectors
-            const uint64_t mm = morem;
-            uint64_t ok2 = 0, miss2 = 0, d0, d1;
-            W::ballot4([&](int l) {
-              if (!((mm >> l) & 1)) return 0;
-              FastEnt e;
-              if (fast_lookup(ent, mv.at(l), e) < 0) return 2;
-              const int32_t rq[4] = {q0.at(l), q1.at(l), q2.at(l), q3.at(l)};
-              return fast_fits(pool, e, rq, cs.size) ? 1 : 0;
-            }, ok2, miss2, d0, d1);
-            okm |= ok2; missm |= miss2;
-          }
-          n_tests += (unsigned long long)(n - (int)r0 < 64 ? n - (int)r0 : 64);
-          n_steps++;
-          const int first_ok = okm ? ctz64(okm) : 64;
-          const int first_miss = missm ? ctz64(missm) : 64;
-          if (first_miss < first_ok) {
-            // a requirement set that is not cached yet sits before the first acceptor: cache it, test these positions again
-            if (fast_uniform(cold.create_entry(mv.bcast(first_miss))) < 0) { cold.bail_code = 21; cold.finish(3, n, 0, 0, 0, 0, nullptr); return; }
-            continue;
-          }
-          if (!okm) { r = (uint32_t)((int)r0 + 64 < n ? (int)r0 + 64 : n); continue; }
-          // ---- commit: NodeClaim.Add (nodeclaim.go:247-263) ----
-          const unsigned long long ts3 = W::clock();
-          KS_TADD(2, ts3 - ts2);
-          const int a = (int)r0 + first_ok;
-          const int x = (int)xv.bcast(first_ok);
-          const uint32_t cnt = kv.bcast(first_ok);
-          if (cnt >= 65534u) { cold.bail_code = 22; cold.finish(3, n, 0, 0, 0, 0, nullptr); return; }
-          FastClaim ns;
-          ns.vmask = mv.bcast(first_ok);
-          ns.req[0] = q0.bcast(first_ok) + cs.size[0]; ns.req[1] = q1.bcast(first_ok) + cs.size[1];
-          ns.req[2] = q2.bcast(first_ok) + cs.size[2]; ns.req[3] = q3.bcast(first_ok) + cs.size[3];
-          if (W::leader()) lds_put(&cst[x], ns);
-          oclaim.set(bi, (uint32_t)x); ocnt.set(bi, cnt);
-          n_ref += (unsigned long long)a + 1;
-          r = (uint32_t)a;
-          placed = true;
-          // The sort.Slice of the NEXT add (scheduler.go:598) repairs this claim's position: one stable move past the claims
-          // with a smaller count. When the next add follows inside this block and those claims are all among the positions
-          // just tested, their counts and ids are in registers already: move now, without reading the order again.
-          const uint32_t mvn = cnt + 1;
-          bool moved = false;
-          if (bi + 1 < bn && !(max_steps >= 0 && steps >= max_steps) && (n <= 12 || (n >= 50 && !fast_sampled(n, a)))) {
-            const uint64_t lessm = W::ballot([&](int l) { return l > first_ok && kv.at(l) < mvn; });   // lanes past n hold 0xFFFFFFFF
-            const uint64_t t = first_ok == 63 ? 0ull : (lessm >> (first_ok + 1));
-            const int s_ = t == ~0ull ? 64 : ctz64(~t);
-            if (first_ok + 1 + s_ < 64 || (int)r0 + 64 >= n) {
-              // lanes first_ok+1 .. first_ok+s_ step one position to the left, the claim lands behind them
-              W::each([&](int l) { if (l > first_ok && l <= first_ok + s_) { okey[(int)r0 + l - 1] = (uint16_t)kv.at(l); oord[(int)r0 + l - 1] = (uint16_t)xv.at(l); } });
-              if (W::leader()) { okey[a + s_] = (uint16_t)mvn; if (s_) oord[a + s_] = (uint16_t)x; }
-              if (s_) {
-                const int b = a + s_;
-                W::each([&](int l) {
-#pragma unroll
-                  for (int j = 0; j < kFastRows; ++j) if (j < rows) { const uint32_t rr = cur[j].at(l); cur[j].at(l) = rr - (uint32_t)(((uint32_t)a < rr && rr <= (uint32_t)b) ? 1 : 0); }
-                });
-              }
-              moved = true;
-            }
-          }
-          if (!moved) {
-            if (W::leader()) okey[a] = (uint16_t)mvn;
-            pend_a = a; pend_x = x; pend_mv = mvn;
-          }
-          W::sync();
-          KS_TADD(3, W::clock() - ts3);
-          break;
-        }
-        if (r != rc0) set_cursor(slot, r);
-        done = bi + 1;
-        if (placed) continue;
-        const unsigned long long tn = W::clock();
-        const int made = fast_uniform(cold.new_claim(slot, bi, n));
-        KS_TADD(7, W::clock() - tn);
-        if (!made) {
-          const int bc = fast_uniform(cold.bail_code);
-          cold.finish(bc < 0 ? 1 : 3, n, 0, 0, 0, 0, nullptr);
-          return;
-        }
-        oclaim.set(bi, (uint32_t)n); ocnt.set(bi, 0u);   // claim ids are handed out in creation order: the new claim is claim n
-        n++;
-        pend_new = true;
-      }
-      // the block's results
-      {
-        const int dn = done;
-        W::each([&](int l) { if (l < dn) { const uint32_t p = bpod.at(l); gassign[p] = (int32_t)oclaim.at(l); gslot[p] = ocnt.at(l); } });
-      }
+    if (W::leader()) {
+      h->base = 0; h->bi = 0; h->bn = 0; h->n = 0; h->np = np; h->steps = 0; h->status = 0;
+      const long long ms_ = cold.Sk->max_steps;
+      h->max_steps = ms_ < 0 ? -1 : (int)(ms_ > 0x7FFFFFFF ? 0x7FFFFFFF : ms_);
+      h->pend_a = -1; h->pend_x = 0; h->pend_mv = 0; h->pend_new = 0; h->ev_arg = 0; h->ev_vm = 0;
+      h->n_steps = 0; h->n_tests = 0; h->n_ref = 0;
+      h->sorted = cold.Pk->sorted_pods; h->row_class = cold.Pk->row_class; h->cancel = cold.Sk->cancel_flag;
+      h->g_assign = cold.Sk->assign; h->g_slot = cold.Sk->slot;
     }
-    KS_TADD(5, W::clock() - t_begin);
-#ifdef KSOLVE_PHASE_TIMERS
-    cold.finish(status, n, (unsigned long long)steps, n_steps, n_tests, n_ref, tc_);
-#else
-    cold.finish(status, n, (unsigned long long)steps, n_steps, n_tests, n_ref, nullptr);
-#endif
+    {
+      const uint32_t* sorted = cold.Pk->sorted_pods; const uint32_t* rc_ = cold.Pk->row_class;
+      W::each([&](int l) {
+        for (int j = 0; j < kFastRows; ++j) h->cur[j][l] = 0;
+        uint32_t p = 0, k = 0;
+        if (l < np) { p = sorted[l]; k = rc_[p]; }
+        h->nxt_pod[l] = p; h->nxt_cls[l] = k; h->bpod[l] = 0; h->bcls[l] = 0; h->bslot[l] = 0xFFFFu; h->oclaim[l] = 0; h->ocnt[l] = 0;
+      });
+    }
+    W::sync();
+    FastHotCtx cx;
+    cx.okey = cold.order.key; cx.oord = cold.order.ord; cx.cst = cold.cst; cx.ent = cold.ent; cx.pool = cold.pool;
+    cx.aslot = cold.aslot; cx.slot_of = cold.Mp->slot_of; cx.hs = hs;
+    for (;;) {
+      const int ev = fast_uniform(fast_hot_run<W>(cx));
+      if (ev == FEV_DONE) break;
+      if (ev == FEV_ENTRY) {
+        if (fast_uniform(cold.create_entry(h->ev_vm)) < 0) { cold.bail_code = 21; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
+      } else if (ev == FEV_SLOT) {
+        const int k = fast_uniform(h->ev_arg);
+        const int sv = fast_uniform(cold.new_slot(k));
+        const int slot = sv & 0xFFFF;
+        W::each([&](int l) {
+          if (sv >> 16) {   // every slot was taken: all classes start over
+            h->bslot[l] = 0xFFFFu;
+            for (int j = 0; j < kFastRows; ++j) h->cur[j][l] = 0;
+          }
+          if (h->bcls[l] == (uint32_t)k && l < h->bn) h->bslot[l] = (uint32_t)slot;   // this pod and later pods of the class in the block
+          if (l == (slot & 63)) h->cur[slot >> 6][l] = 0;
+        });
+        W::sync();
+      } else if (ev == FEV_SLOWSORT || ev == FEV_PLACE) {
+        const int n = fast_uniform(h->n);
+        int b = -1;
+        if (ev == FEV_SLOWSORT) cold.slow_sort(n, fast_uniform(h->ev_arg), 0);
+        else b = fast_uniform(cold.place_new_claim(n));
+        if (b == -2) { cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
+        if (b == -1) {
+          // pdqsort permuted positions lo..hi: cursors inside fall back to lo
+          const int lo = fast_uniform(cold.lo_), hi = fast_uniform(cold.hi_);
+          if (hi >= lo) W::each([&](int l) { for (int j = 0; j < kFastRows; ++j) { const uint32_t r = h->cur[j][l]; if (r > (uint32_t)lo && r <= (uint32_t)hi) h->cur[j][l] = (uint32_t)lo; } });
+        } else {
+          // positions [b, n-1) moved right by one; a cursor past b either steps over the new claim or — if its class is
+          // accepted by it — comes back to it
+          const KS_LDS uint64_t* acc = cold.Mp->acc;
+          W::each([&](int l) { for (int j = 0; j < kFastRows; ++j) { const uint32_t r = h->cur[j][l]; if (r > (uint32_t)b) h->cur[j][l] = ((acc[j] >> l) & 1) ? (uint32_t)b : r + 1; } });
+        }
+        if (W::leader()) { h->pend_a = -1; h->pend_new = 0; }
+        W::sync();
+      } else if (ev == FEV_NEWCLAIM) {
+        const int n = fast_uniform(h->n), bi = fast_uniform(h->bi);
+        const int made = fast_uniform(cold.new_claim(fast_uniform(h->ev_arg), bi, n));
+        if (!made) { cold.finish(fast_uniform(cold.bail_code) < 0 ? 1 : 3, 0, 0, 0, 0, 0, nullptr); return; }
+        if (W::leader()) { h->oclaim[bi] = (uint32_t)n; h->ocnt[bi] = 0; h->n = n + 1; h->pend_new = 1; h->bi = bi + 1; }   // claim ids are handed out in creation order
+        W::sync();
+      } else { cold.bail_code = 22; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
+    }
+    cold.finish(fast_uniform(h->status), fast_uniform(h->n), (unsigned long long)fast_uniform(h->steps), h->n_steps, h->n_tests, h->n_ref, nullptr);
   }
 };
 

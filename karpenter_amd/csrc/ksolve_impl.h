@@ -540,6 +540,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       fp.off_pool = off; off = align(off + ks::kFastPool * 16);
       fp.off_slot = off; off = align(off + ks::kFastSlots * (int)sizeof(ks::FastSlot));
       fp.off_misc = off; off = align(off + (int)sizeof(ks::FastMisc));
+      fp.off_hot = off; off = align(off + (int)sizeof(ks::FastHot));
       const int budget = 160 * 1024 - 512;
       int cap = ((budget - off - 64) / (int)(sizeof(ks::FastClaim) + 6)) & ~63;
       if (cap > 65472) cap = 65472;

@@ -50,6 +50,11 @@ struct Wave {
     const int v = f(lane());
     m0 = __ballot(v & 1); m1 = __ballot(v & 2); m2 = __ballot(v & 4); m3 = __ballot(v & 8);
   }
+  template <class F>
+  KS_DEV static void ballot2(F f, uint64_t& m0, uint64_t& m1) {
+    const int v = f(lane());
+    m0 = __ballot(v & 1); m1 = __ballot(v & 2);
+  }
   // g(j, ballot(f(lane, j))) for j < n <= 8: all predicates (and their loads) are evaluated before the first ballot, so
   // eight words cost one LDS latency instead of eight. No arrays: everything stays in registers.
   template <class F, class G>
@@ -198,6 +203,11 @@ struct Wave {
   static void ballot4(F f, uint64_t& m0, uint64_t& m1, uint64_t& m2, uint64_t& m3) {
     m0 = m1 = m2 = m3 = 0;
     KS_LANES(l) { const int v = f(l); if (v & 1) m0 |= 1ull << l; if (v & 2) m1 |= 1ull << l; if (v & 4) m2 |= 1ull << l; if (v & 8) m3 |= 1ull << l; }
+  }
+  template <class F>
+  static void ballot2(F f, uint64_t& m0, uint64_t& m1) {
+    m0 = m1 = 0;
+    KS_LANES(l) { const int v = f(l); if (v & 1) m0 |= 1ull << l; if (v & 2) m1 |= 1ull << l; }
   }
   template <class F, class G>
   static void ballots8(int n, F f, G g) {
