@@ -12,8 +12,9 @@
 //     cached per distinct requirement set (a few hundred per problem) in LDS. The masks themselves are materialised once,
 //     after the loop, by ksolve_fast_records (one wavefront per claim).
 //  2. The requirement set of a claim is the template's plus a handful of keys pods select on; the values of those keys are
-//     packed into ONE 64-bit word per claim (`vmask`: bit = value still allowed, one guard bit after every key's field),
-//     so Requirements.Compatible + Add (requirements.go:181-197, 133-140) is an AND, an ADD and a compare in registers.
+//     packed into ONE 64-bit word per claim (`vmask`: bit = value still allowed; after every key's field one guard bit,
+//     set while the requirement set does not define the key), so Requirements.Compatible + Add (requirements.go:181-197,
+//     133-140) is an AND, an ADD and a compare in registers.
 //  3. CanAdd failures are permanent (fact 1), claims only move RIGHT in the reference's order when they gain a pod
 //     (sort.Slice by pod count, scheduler.go:598 — pdq_emul.h keeps Go's exact permutation), and a new claim enters at
 //     one known position. So each pod class keeps a cursor: "every claim left of it has rejected this class for good".
@@ -74,7 +75,6 @@ struct FastVar { int nv; uint8_t vkey[kFastMaxVar], voff[kFastMaxVar], vwidth[kF
 struct FastWork {   // HBM workspace of the cursor engine (host-allocated when the problem may qualify)
   FastVar* var;           // written by the pack kernel, read by ksolve_fast_records
   FastSlot* cls;          // [n_classes]
-  uint32_t* c_tdef;       // [max_claims] keys the claim's template defines (ksolve_fast_vdef adds the keys of its pods)
   uint32_t* c_hostseq;    // [max_claims]
   uint16_t* c_ent;        // [max_claims] cache entry of the claim's requirement set
   FastClaim* c_state;     // [max_claims] final state, written when the loop ends
@@ -236,9 +236,8 @@ struct FastCold {
       for (int j = 0; j < nvv; ++j) {
         const int k = Mm.vkey[j];
         if (!((Pv.it_keys >> k) & 1u)) continue;
-        const uint64_t full = Mm.fmask[j] >> Mm.voff[j];
-        uint64_t field = (vm >> Mm.voff[j]) & full;
-        if (field == full) continue;
+        if ((vm >> (Mm.voff[j] + Mm.vwidth[j])) & 1) continue;   // guard bit set: the requirement set does not define the key
+        uint64_t field = (vm >> Mm.voff[j]) & (Mm.fmask[j] >> Mm.voff[j]);
         uint64_t r = Pv.key_undef[(size_t)k * iw + w];
         const size_t base = (size_t)Mm.vword[j] * 64;
         while (field) { const int b = ctz64(field); field &= field - 1; r |= Pv.kv_has[(base + b) * iw + w]; }
@@ -336,8 +335,8 @@ struct FastCold {
     const int nk = d.n_keys, iw = P.it_words, nr = P.n_res, n_its = P.n_its, nc = P.n_classes, T = P.n_templates;
     const ProblemView& Pv = P;
     if (!P.plain || P.n_rows != P.n_pods || nr > 4 || T > 32 || nc > kFastClasses || iw > kMaxItWords) return 1;
-    // instance types: only In sets (positive), so that compatible() is monotone
-    if (W::reduce_or(nk * iw, [&](int i) { return Pv.key_compl[i] | Pv.key_neg[i]; })) return 2;
+    // (instance types may use any operator: with positive sets on the claim side the NotIn / DoesNotExist escape of
+    // requirements.go:260-265 never applies, so compatible() stays monotone)
     // templates: only In sets
     if (W::reduce_or(T, [&](int t) { return (uint64_t)(Pv.tmpl_reqs.complement[t] | (Pv.tmpl_reqs.has_gte ? Pv.tmpl_reqs.has_gte[t] : 0) | (Pv.tmpl_reqs.has_lte ? Pv.tmpl_reqs.has_lte[t] : 0)); })) return 3;
     // classes: only In sets; the keys they define are the variable keys
@@ -380,7 +379,7 @@ struct FastCold {
       uint64_t vm = (uint64_t)t << 56;
       for (int j = 0; j < nvv; ++j) {
         if ((tdef >> Mm.vkey[j]) & 1u) vm |= (tm[Mm.vword[j]] << Mm.voff[j]) & Mm.fmask[j];
-        else vm |= Mm.fmask[j];
+        else vm |= Mm.fmask[j] | (1ull << (Mm.voff[j] + Mm.vwidth[j]));   // undefined: every value, and the guard bit says so
       }
       Mm.tvmask[t] = vm; Mm.tdef[t] = tdef;
     });
@@ -435,7 +434,7 @@ struct FastCold {
           const uint64_t f = (cm[Mm.vword[j]] << Mm.voff[j]) & Mm.fmask[j];
           if (!f) badc = 1;   // In [] == DoesNotExist: not positive
           vm |= f; dm |= Mm.fmask[j];
-        } else vm |= Mm.fmask[j];
+        } else vm |= Mm.fmask[j] | (1ull << (Mm.voff[j] + Mm.vwidth[j]));
       }
       FastSlot s;
       s.cvmask = vm; s.dmask = dm;
@@ -578,7 +577,6 @@ struct FastCold {
         ns.vmask = m;
         for (int q = 0; q < 4; ++q) ns.req[q] = cs.size[q];
         lds_put(&cst[c], ns);
-        F.c_tdef[c] = Mp->tdef[t];
         F.c_hostseq[c] = host_seq;
         order.key[n] = 1; order.ord[n] = (uint16_t)c;   // order.append
       }
@@ -854,6 +852,12 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
     ev = FEV_NEWCLAIM; ev_arg = slot;   // no in-flight claim accepted the pod: addToNewNodeClaim; the driver moves on to the next pod
     break;
   }
+  if (ev == FEV_DONE && bn > 0) {
+    // the deadline / a cancellation stopped the loop inside a block: the pods placed so far are results too
+    const int dn = bi < bn ? bi : bn;
+    W::each([&](int l) { if (l < dn) { const uint32_t p = bpod.at(l); gassign[p] = (int32_t)oclaim.at(l); gslot[p] = ocnt.at(l); } });
+    bn = 0; bi = 0;
+  }
   // ---- state out ----
   if (W::leader()) {
     hs->base = base; hs->bi = bi; hs->bn = bn; hs->n = n; hs->steps = steps; hs->status = status;
@@ -954,16 +958,6 @@ struct FastEngine {
   }
 };
 
-// ksolve_fast_vdef — one thread per pod: the keys a claim's requirement set defines are its template's plus those of the
-// pods it holds (Requirements.Add, requirements.go:133-140).
-struct FastVdefArgs { int n_pods; const int32_t* assign; const uint32_t* row_class; const FastSlot* cls; uint32_t* c_vdef; };
-KS_FN void fast_vdef_body(int p, const FastVdefArgs& a) {
-  const int32_t c = a.assign[p];
-  if (c < 0) return;
-  const uint32_t kd = a.cls[a.row_class[p]].kdef;
-  if (kd & ~a.c_vdef[c]) atomic_or_u32(&a.c_vdef[c], kd);
-}
-
 // ksolve_fast_records — one wavefront per claim: materialises the hot claim record the finalize kernel and the result
 // download read (ksp.h RecLayout) from the cursor engine's compact state: requirement masks = the template's with the
 // variable keys' fields, InstanceTypeOptions = F(requirement set) ∩ { allocatable >= requests }.
@@ -979,8 +973,13 @@ KS_DEV void fast_record_body(int c, const FastRecordArgs& a) {
   const Dict& d = P.dict;
   const FastClaim st = a.fw.c_state[c];
   const int t = (int)(st.vmask >> 56);
-  const uint32_t vdef = a.fw.c_tdef[c];
   const FastVar fv = *a.fw.var;
+  // keys the requirement set defines: the template's, and of the keys pods select on those whose guard bit is clear
+  uint32_t vdef = P.tmpl_reqs.defined[t];
+  for (int j = 0; j < fv.nv; ++j) {
+    const uint32_t kb = 1u << fv.vkey[j];
+    vdef = ((st.vmask >> (fv.voff[j] + fv.vwidth[j])) & 1) ? (vdef & ~kb) : (vdef | kb);
+  }
   uint64_t* rec = a.ws.c_hot + (size_t)c * ly.c_hot_words();
   const uint64_t* tm = P.tmpl_reqs.mask + (size_t)t * d.req_words;
   W::for_n(ly.rw, [&](int w) {

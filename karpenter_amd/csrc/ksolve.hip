@@ -148,10 +148,6 @@ __global__ void __launch_bounds__(64) ksolve_pack_fast(const ks::FastArgs* a) {
   eng.solve();
 }
 // One wavefront per claim: hot claim records (requirement masks, InstanceTypeOptions) from the cursor engine's compact state.
-__global__ void ksolve_fast_vdef(ks::FastVdefArgs a) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < a.n_pods) ks::fast_vdef_body(i, a);
-}
 __global__ void __launch_bounds__(64) ksolve_fast_records(ks::FastRecordArgs a) {
   ks::fast_record_body<ks::Wave>((int)blockIdx.x, a);
 }
@@ -181,8 +177,6 @@ static void be_launch_pack_fast(ksolve_handle* h) {
   hip_check(h, hipGetLastError(), "ksolve_pack_fast launch");
 }
 static void be_launch_fast_records(ksolve_handle* h, int n_claims) {
-  ks::FastVdefArgs v{(int)h->n_pods, h->ws.assign, h->pv.row_class, h->fw.cls, h->fw.c_tdef};
-  hipLaunchKernelGGL(ksolve_fast_vdef, grid_for((int)h->n_pods), dim3(256), 0, HB(h)->stream, v);
   ks::FastRecordArgs a{h->pv, h->ws, h->fw};
   hipLaunchKernelGGL(ksolve_fast_records, dim3((unsigned)n_claims), dim3(64), 0, HB(h)->stream, a);
   hip_check(h, hipGetLastError(), "ksolve_fast_records launch");

@@ -93,7 +93,7 @@ static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a
 static void be_sort_pods(ksolve_handle* h);  // fills ws/pv.sorted_pods
 static void be_launch_pack(ksolve_handle* h);
 static void be_launch_pack_fast(ksolve_handle* h);                 // one wavefront: FastEngine::solve
-static void be_launch_fast_records(ksolve_handle* h, int n_claims); // fast_vdef_body per pod, then one wavefront per claim: fast_record_body
+static void be_launch_fast_records(ksolve_handle* h, int n_claims); // one wavefront per claim: fast_record_body
 static void be_launch_pack_batch(ksolve_handle** hs, int n);
 static void be_thread_init(ksolve_handle* h);   // makes the handle's device current on a worker thread   // one block per handle; sets every handle's T_PACK timer
 static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a);
@@ -553,7 +553,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       fp.off_snap = off; off = align(off + cap * 2);
       fp.total_bytes = off;
       fw.var = dz<ks::FastVar>(h, 1);
-      fw.c_tdef = dz<uint32_t>(h, mc); fw.c_hostseq = dz<uint32_t>(h, mc); fw.c_ent = dz<uint16_t>(h, mc);
+      fw.c_hostseq = dz<uint32_t>(h, mc); fw.c_ent = dz<uint16_t>(h, mc);
       fw.c_state = dz<ks::FastClaim>(h, mc); fw.c_npods = dz<uint32_t>(h, mc);
       fw.ent_its = dz<uint64_t>(h, (size_t)ks::kFastEnt * it_words);
       h->d_fast_args = dz<ks::FastArgs>(h, 1);

@@ -97,8 +97,6 @@ static void be_launch_pack_fast(ksolve_handle* h) {
   eng.solve();
 }
 static void be_launch_fast_records(ksolve_handle* h, int n_claims) {
-  ks::FastVdefArgs v{(int)h->n_pods, h->ws.assign, h->pv.row_class, h->fw.cls, h->fw.c_tdef};
-  for (int p = 0; p < (int)h->n_pods; ++p) ks::fast_vdef_body(p, v);
   ks::FastRecordArgs a{h->pv, h->ws, h->fw};
   for (int c = 0; c < n_claims; ++c) ks::fast_record_body<ks::Wave>(c, a);
 }

@@ -32,7 +32,7 @@ def test_libksolve_exports_every_declared_symbol(built):
     for f in declared_functions():
         assert hasattr(lib, f), f
     lib.ksolve_abi_version.restype = ctypes.c_uint32
-    assert lib.ksolve_abi_version() == 3
+    assert lib.ksolve_abi_version() == 4
     assert not hasattr(lib, "ksolve_is_emulation")  # the product library is the HIP build, never the test emulation
 
 

@@ -1,0 +1,209 @@
+"""CPU tests of the CURSOR ENGINE (karpenter_amd/csrc/fast_engine.h) through the host emulation of the device code
+(tests/emu, test infrastructure only), the real C ABI and the real host flattener: every problem is solved with
+options.engine = "cursor" (the cursor engine or an error — never the fallback) and compared with the oracle claim by claim
+(L1-strict), and with the general engine. Shapes the cursor engine declines must be declined LOUDLY under engine="cursor"
+and solved — identically to the oracle — by the automatic fallback. The GPU run of the same comparisons is
+tests/test_gpu_parity.py."""
+import copy
+import random
+
+import pytest
+
+import parity
+from karpenter_amd import fixtures as fx
+from karpenter_amd.scheduling import NewScheduler, Unsupported
+from test_device_algorithm import emu  # noqa: F401  (fixture)
+
+
+def with_engine(prob, engine, **opts):
+    return dict(prob, options=dict(prob["options"], engine=engine, **opts))
+
+
+def check_cursor(oracle, emu, prob, want=None):
+    """engine=cursor result == oracle; returns the result."""
+    want = want or oracle.solve(prob)
+    got = NewScheduler(with_engine(prob, "cursor"), solver_lib=emu).Solve()
+    assert got["counters"]["engine"] == "cursor"
+    parity.assert_same_results(got, want)
+    assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
+    assert abs(got["packingCost"] - want["packingCost"]) < 1e-9 * max(1.0, want["packingCost"])
+    return got
+
+
+def check_declined(oracle, emu, prob, reason=None):
+    """engine=cursor refuses; automatic selection falls back to the general engine and matches the oracle."""
+    with pytest.raises(Unsupported, match="cursor engine"):
+        NewScheduler(with_engine(prob, "cursor"), solver_lib=emu).Solve()
+    got = NewScheduler(prob, solver_lib=emu).Solve()
+    assert got["counters"]["engine"] == "general"
+    if reason is not None:
+        assert got["counters"]["engineFallbackReason"] == reason, got["counters"]["engineFallbackReason"]
+    parity.assert_same_results(got, oracle.solve(prob))
+    return got
+
+
+def test_baseline_shapes_run_on_the_cursor_engine(oracle, emu):
+    for prob in (fx.config1(), fx.config2(pods=6000, n_types=144, seed=3), fx.config2(pods=20000, n_types=500, seed=9),
+                 fx.config4(pods=8000, n_types=1000, n_pools=16, seed=5)):
+        got = check_cursor(oracle, emu, prob)
+        auto = NewScheduler(prob, solver_lib=emu).Solve()
+        assert auto["counters"]["engine"] == "cursor"          # what bench.py measures
+        general = NewScheduler(with_engine(prob, "general"), solver_lib=emu).Solve()
+        assert general["counters"]["engine"] == "general"
+        parity.assert_same_results(got, general)
+        assert got["counters"]["slowSorts"] == general["counters"]["slowSorts"]   # pdqsort left its single-move path equally often
+
+
+def lite_problem(rng, n_pods):
+    """Random provisioning batches of the shape the cursor engine solves: In selectors on arch / os / zone / capacity type and
+    a custom NodePool label, taints + tolerations, weighted pools, instance types whose allocatable vectors do not dominate
+    each other (several Pareto-maximal types per requirement set), requests that straddle them."""
+    kwok = rng.random() < 0.4
+    if kwok:
+        its = fx.kwok_catalog(rng.choice([24, 72, 144, 300])); wk = fx.KWOK_WELL_KNOWN; zones = list(fx.KWOK_ZONES)
+    else:
+        its = copy.deepcopy(fx.fake_instance_types(rng.choice([6, 20, 60]))); wk = fx.FAKE_WELL_KNOWN; zones = ["test-zone-1", "test-zone-2", "test-zone-3"]
+        for it in its:   # cpu-heavy and memory-heavy shapes: no single type dominates
+            if rng.random() < 0.5:
+                it["capacity"]["memory"] = f"{rng.choice([1, 2, 4, 8, 64, 256])}Gi"
+            if rng.random() < 0.3:
+                it["capacity"]["pods"] = str(rng.choice([3, 8, 30, 110]))
+    archs = sorted({v for it in its for r in it["requirements"] if r["key"] == fx.ARCH for v in r["values"]})
+    pools, teams = [], []
+    for i in range(rng.choice([0, 0, 1, 2])):
+        kw = {}
+        reqs = []
+        if rng.random() < 0.4: reqs.append(fx.req(fx.ZONE, "In", *rng.sample(zones, rng.choice([1, 2, 3]))))
+        if rng.random() < 0.3: reqs.append(fx.req(fx.CAPACITY_TYPE, "In", rng.choice(["spot", "on-demand"])))
+        if rng.random() < 0.4: kw["taints"] = [{"key": "dedicated", "value": f"t{i}", "effect": "NoSchedule"}]
+        if rng.random() < 0.5: kw["labels"] = {"team": f"t{i}"}; teams.append(f"t{i}")
+        if rng.random() < 0.3: kw["limits"] = {"cpu": "100000"}     # present, never binding
+        pools.append(fx.node_pool(f"pool-{i}", weight=rng.randrange(1, 20), requirements=reqs, **kw))
+    pools.append(fx.node_pool("catch-all", weight=0))   # every pod without a team selector can land here
+    if kwok:
+        for np_ in pools: np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    sizes = [(c, m) for c in (100, 250, 700, 1500, 3000) for m in (64, 300, 1024, 5000)]
+    classes = []
+    for _ in range(rng.randrange(1, 40)):
+        sel = {}
+        if rng.random() < 0.3: sel[fx.ARCH] = rng.choice(archs)
+        if rng.random() < 0.3: sel[fx.ZONE] = rng.choice(zones[:2])
+        if rng.random() < 0.2: sel[fx.CAPACITY_TYPE] = rng.choice(["spot", "on-demand"])
+        if rng.random() < 0.15: sel[fx.OS] = "linux"
+        if teams and rng.random() < 0.15: sel["team"] = rng.choice(teams)
+        reqs = None
+        if fx.ZONE not in sel and rng.random() < 0.2: reqs = [fx.req(fx.ZONE, "In", *rng.sample(zones, 2))]
+        tol = [{"key": "dedicated", "operator": "Exists"}] if (rng.random() < 0.4 or "team" in sel) else None
+        c, m = rng.choice(sizes)
+        classes.append(dict(requests={"cpu": f"{c}m", "memory": f"{m}Mi"}, node_selector=sel or None, node_requirements=reqs, tolerations=tol))
+    pods = [fx.pod(**rng.choice(classes)) for _ in range(n_pods)]
+    return fx.problem(its, pools, pods, well_known=wk)
+
+
+@pytest.mark.parametrize("block", range(5))
+def test_fuzz_against_the_oracle(oracle, emu, block):
+    ran = declined = 0
+    for seed in range(block * 30, block * 30 + 30):
+        rng = random.Random(1000 + seed)
+        prob = lite_problem(rng, rng.choice([30, 200, 900]))
+        want = oracle.solve(prob)
+        try:
+            check_cursor(oracle, emu, prob, want)
+            ran += 1
+        except Unsupported:
+            # an unschedulable pod (a selector no pool / type satisfies): the general engine owns error codes
+            got = NewScheduler(prob, solver_lib=emu).Solve()
+            assert got["counters"]["engine"] == "general" and got["counters"]["engineFallbackReason"] in (8, 23, 24, 27), got["counters"]["engineFallbackReason"]
+            parity.assert_same_results(got, want)
+            declined += 1
+    assert ran >= 15, (ran, declined)
+
+
+def test_several_pareto_vectors_per_requirement_set(oracle, emu):
+    """A cpu-heavy and a memory-heavy instance type: neither dominates, so "some type still fits" needs both vectors."""
+    def it(name, cpu, mem):
+        return fx.fake_instance_type(name, resources={"cpu": str(cpu), "memory": f"{mem}Gi", "pods": "200"})
+    its = [it("cpu-heavy", 64, 8), it("mem-heavy", 8, 256), it("small", 2, 2), it("mid", 16, 32)]
+    pods = [fx.pod(requests={"cpu": "3", "memory": "100Mi"}) for _ in range(40)] + [fx.pod(requests={"cpu": "100m", "memory": "20Gi"}) for _ in range(40)] + \
+           [fx.pod(requests={"cpu": "500m", "memory": "1Gi"}) for _ in range(100)]
+    got = check_cursor(oracle, emu, fx.problem(its, [fx.node_pool()], pods))
+    assert len(got["newNodeClaims"]) >= 2
+
+
+def test_more_classes_than_slots_evicts_and_stays_exact(oracle, emu):
+    """More than 256 pod classes interleaved in one size run: class slots are recycled wholesale (cursors restart)."""
+    its = fx.kwok_catalog(72)
+    pods = []
+    for i in range(300):   # 300 classes of one (cpu, memory) size: they differ in ephemeral-storage and zone, and interleave by uid
+        pods.append(fx.pod(requests={"cpu": "500m", "memory": "128Mi", "ephemeral-storage": f"{i + 1}Mi"}, node_selector={fx.ZONE: fx.KWOK_ZONES[i % 4]}))
+    pods = pods * 3
+    np_ = fx.node_pool()
+    np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    got = check_cursor(oracle, emu, fx.problem(its, [np_], pods, well_known=fx.KWOK_WELL_KNOWN))
+    assert got["counters"]["phaseCycles"][22] > 0   # evictions happened
+    assert got["scheduledPods"] == 900
+
+
+def test_long_runs_of_equally_full_claims(oracle, emu):
+    """Every pod needs its own claim-sized share: hundreds of claims with the same pod count, so a commit moves a claim past
+    more than 64 others (the in-window move gives way to the general one)."""
+    its = fx.fake_instance_types(8)   # the largest type holds one 7-cpu pod
+    pods = [fx.pod(requests={"cpu": "7"}) for _ in range(400)] + [fx.pod(requests={"cpu": "300m"}) for _ in range(1500)]
+    got = check_cursor(oracle, emu, fx.problem(its, [fx.node_pool()], pods))
+    assert len(got["newNodeClaims"]) >= 400
+
+
+def test_declined_shapes_fall_back_loudly(oracle, emu):
+    its = fx.fake_instance_types(8)   # four resource dimensions (the default fake catalogue adds two GPU resources: general engine)
+    pool = fx.node_pool()
+    # an unschedulable pod: error codes and InstanceTypeFilterError diagnostics are the general engine's
+    check_declined(oracle, emu, fx.problem(its, [pool], [fx.pod(requests={"cpu": "1"}) for _ in range(20)] + [fx.pod(requests={"memory": "2Ti"})]), reason=27)
+    # NotIn on a pod, Exists on a pod, NotIn on the NodePool: not purely positive
+    check_declined(oracle, emu, fx.problem(its, [pool], [fx.pod(node_requirements=[fx.req(fx.ZONE, "NotIn", "test-zone-1")]) for _ in range(5)]), reason=4)
+    check_declined(oracle, emu, fx.problem(its, [pool], [fx.pod(node_requirements=[fx.req(fx.ZONE, "Exists")]) for _ in range(5)]), reason=4)
+    check_declined(oracle, emu, fx.problem(its, [fx.node_pool(requirements=[fx.req(fx.ZONE, "NotIn", "test-zone-2")])], [fx.pod() for _ in range(5)]), reason=3)
+    # a pod that selects on the instance type (a 500-value key does not pack into the claim word)
+    check_declined(oracle, emu, fx.problem(its, [pool], [fx.pod(node_selector={fx.INSTANCE_TYPE: "fake-it-3"}) for _ in range(5)]), reason=5)
+    # NodePool limits that exclude instance types
+    check_declined(oracle, emu, fx.problem(its, [fx.node_pool(limits={"cpu": "20"})], [fx.pod(requests={"cpu": "1"}) for _ in range(40)]))
+    # more than four resource dimensions (the fake provider's default catalogue carries two GPU resources)
+    got = NewScheduler(fx.problem(fx.fake_default_instance_types(), [pool], [fx.pod(requests={"cpu": "1"}) for _ in range(9)]), solver_lib=emu).Solve()
+    assert got["counters"]["engine"] == "general"
+    # more in-flight claims than the LDS plan holds
+    prob = fx.problem(its, [pool], [fx.pod(requests={"cpu": "7"}) for _ in range(200)], options={"ldsClaimCap": 64})
+    check_declined(oracle, emu, prob, reason=26)
+    # shapes outside `plain`: topology, relaxation rows
+    with pytest.raises(Unsupported, match="cursor engine"):
+        NewScheduler(with_engine(fx.problem(its, [pool], [fx.pod(labels={"a": "b"}, topology_spread=[fx.spread(fx.ZONE, {"a": "b"})]) for _ in range(4)]), "cursor"), solver_lib=emu).Solve()
+    with pytest.raises(Unsupported, match="cursor engine"):
+        NewScheduler(with_engine(fx.problem(its, [pool], [fx.pod(node_preferences=[fx.req(fx.ZONE, "In", "test-zone-1")]) for _ in range(4)]), "cursor"), solver_lib=emu).Solve()
+
+
+def test_a_handle_that_fell_back_stays_on_the_general_engine(oracle, emu):
+    its = fx.fake_instance_types(8)
+    prob = fx.problem(its, [fx.node_pool()], [fx.pod(requests={"cpu": "1"}) for _ in range(20)] + [fx.pod(requests={"memory": "2Ti"})])
+    s = NewScheduler(prob, solver_lib=emu)
+    a = s.Solve()
+    b = s.Solve()
+    assert a["counters"]["engine"] == b["counters"]["engine"] == "general"
+    parity.assert_same_results(a, b)
+    parity.assert_same_results(a, oracle.solve(prob))
+
+
+def test_deadline_mid_block_keeps_the_reference_state(oracle, emu):
+    """ctx deadline (maxSteps) in the middle of a 64-pod block: partial Results equal the general engine's at the same
+    step — including the claim order, whose last move must NOT have been made (the reference sorts at the next add)."""
+    prob = fx.config2(pods=3000, n_types=144, seed=21)
+    for steps in (1, 63, 64, 65, 777, 2999):
+        c = NewScheduler(with_engine(prob, "cursor", maxSteps=steps), solver_lib=emu).Solve()
+        g = NewScheduler(with_engine(prob, "general", maxSteps=steps), solver_lib=emu).Solve()
+        assert c["counters"]["engine"] == "cursor" and c["timedOut"] and g["timedOut"]
+        parity.assert_same_results(c, g)
+        assert c["counters"]["referenceBinEvaluations"] == g["counters"]["referenceBinEvaluations"]
+
+
+def test_repeated_solves_on_one_handle_are_identical(emu):
+    s = NewScheduler(with_engine(fx.config2(pods=5000, n_types=144, seed=8), "cursor"), solver_lib=emu)
+    a, b = s.Solve(), s.Solve()
+    parity.assert_same_results(a, b)
+    assert parity.results_digest(a)[0] == parity.results_digest(b)[0]
