@@ -2,19 +2,21 @@
 """bench.py — pods scheduled/sec through Solve() on MI355X (BASELINE.json metric).
 
 A "step" is one pass of the hot path — ksolve_solve(): pod classing, queue sort, the pack engine, finalize, results
-download — over one batch of synthetic pods whose flattened problem is already resident in HBM (ksolve_create is
-outside the timed region, like b.ResetTimer() after setupScheduler in scheduling_benchmark_test.go:166-169).
+download over the C ABI — over one batch of synthetic pods whose flattened problem is already resident in HBM
+(ksolve_create is outside the timed region, like b.ResetTimer() after setupScheduler in scheduling_benchmark_test.go:166-169;
+the JSON re-hydration of Results for Python is outside too: want_results=False, the flat C-ABI Results ARE downloaded).
 
   N = 1 : BASELINE.json configs[1] — 1M pods, 500 instance types, nodeSelector + taint/toleration constraints.
   N > 1 : weak scaling. Solve() is a serial chain inside one coupled problem, so the path shards across INDEPENDENT
           scheduling problems (NodePool components): rank r solves its own configs[1]-shaped problem
-          (different seed), no collective on the data path; after the timed solves one RCCL all-reduce over the
-          per-instance-type option-count / cost vector gives the global packing summary (north_star).
+          (seed 42 + r), no collective on the data path; after the timed solves ONE all-reduce (RCCL over xGMI) sums the
+          per-instance-type (NodeClaim count, $/h) vector of every rank's packing — the north_star's global packing summary.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -26,7 +28,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 
 def algorithmic_bytes(c):
     """bytes = P*B_pod + V*B_bin + P*B_bin(writeback) + N_it*T*B_it with the record sizes of the
-    layouts actually used (DESIGN.md §Data layout)."""
+    layouts actually used (DESIGN.md §Data layout). V = the bins the REFERENCE evaluates."""
     R, RW, IW, K = c["resources"], c["reqWords"], c["itWords"], c["keys"]
     b_pod = 8 * R + 2 * (8 * RW + 16) + 8 + 4 + 8 + 16 + 1
     b_bin = 8 * RW + 16 + 8 * IW + 16 * R + 20 * K + 16
@@ -35,20 +37,61 @@ def algorithmic_bytes(c):
     return total, {"B_pod": b_pod, "B_bin": b_bin, "B_it": b_it}
 
 
+def launch_type_vector(prob, res):
+    """Per-instance-type (NodeClaim count, $/h): every claim is booked on the instance type that gives its cheapest launch
+    price — the cheapest available offering its requirements admit (types.go:336-355; ties: catalogue order)."""
+    import numpy as np
+    its = prob["instanceTypes"]
+    names = {t["name"]: i for i, t in enumerate(its)}
+    zones = sorted({r["values"][0] for t in its for o in t["offerings"] for r in o["requirements"] if r["key"] == "topology.kubernetes.io/zone"})
+    cts = sorted({r["values"][0] for t in its for o in t["offerings"] for r in o["requirements"] if r["key"] == "karpenter.sh/capacity-type"})
+    price = np.full((len(its), len(zones), len(cts)), np.inf)
+    for i, t in enumerate(its):
+        for o in t["offerings"]:
+            if not o.get("available", True):
+                continue
+            rq = {r["key"]: r["values"][0] for r in o["requirements"]}
+            z, c = zones.index(rq["topology.kubernetes.io/zone"]), cts.index(rq["karpenter.sh/capacity-type"])
+            price[i, z, c] = min(price[i, z, c], o["price"])
+    vec = np.zeros((len(its), 2))
+    for cl in res["newNodeClaims"]:
+        rq = {r["key"]: r for r in cl["requirements"]}
+
+        def allowed(key, universe):
+            r = rq.get(key)
+            if r is None:
+                return np.ones(len(universe), bool)
+            return np.array([(v in r["values"]) != r["complement"] for v in universe])
+        zm, cm = allowed("topology.kubernetes.io/zone", zones), allowed("karpenter.sh/capacity-type", cts)
+        idx = np.array([names[n] for n in cl["instanceTypes"]])
+        best = price[idx][:, zm][:, :, cm].reshape(len(idx), -1).min(axis=1)
+        k = int(idx[int(np.argmin(best))])
+        vec[k, 0] += 1
+        vec[k, 1] += float(cl["cheapestPrice"])
+    return vec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pods", type=int, default=1_000_000, help="pods per GPU (configs[1] = 1M)")
     ap.add_argument("--types", type=int, default=500)
-    ap.add_argument("--cpu-sample", type=int, default=40_000, help="pods in the bounded cpu_baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=20_000, help="pods in the bounded cpu_baseline sample")
+    ap.add_argument("--cpu-runs", type=int, default=5, help="oracle runs of the sample (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-engine-baseline", action="store_true", help="skip timing the engine's own source compiled for one host core")
+    ap.add_argument("--topology-pods", type=int, default=200_000, help="BASELINE configs[2] shape (anti-affinity + 3-zone spread) reported beside the headline, 0 = skip")
     ap.add_argument("--batch-problems", type=int, default=512, help="independent problems solved with ONE batched launch (reported beside the headline, 0 = skip)")
     ap.add_argument("--batch-pods", type=int, default=20_000, help="pods per problem of the batched measurement")
-    ap.add_argument("--solver-lib", default=None, help="TEST HOOK (tests/test_bench_contract.py): a host build of the engine behind the same C ABI, "
-                    "so that the launcher / collective / JSON contract can be exercised without a GPU; never a measurement, never a default")
+    ap.add_argument("--no-parity-pin", action="store_true", help="skip the digest check of the timed problem against the committed oracle pin")
+    ap.add_argument("--engine", default="auto", choices=["auto", "general", "cursor"], help="pack engine (auto: the cursor engine for purely positive batches)")
+    ap.add_argument("--solver-lib", default=None, help="TEST HOOK (tests/test_bench_contract.py, needs KSOLVE_BENCH_TEST_HOOK=1): a host build of the engine behind the same "
+                    "C ABI, so that the launcher / collective / JSON contract can be exercised without a GPU; never a measurement, never a default")
     args = ap.parse_args()
+    if args.solver_lib and os.environ.get("KSOLVE_BENCH_TEST_HOOK") != "1":
+        raise SystemExit("bench.py: --solver-lib is a test hook (set KSOLVE_BENCH_TEST_HOOK=1); the product has no CPU path")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -56,6 +99,7 @@ def main():
     dist = None
     torch = None
     device_index = local_rank
+    reduce_device = "cpu"
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -64,7 +108,6 @@ def main():
             if not args.solver_lib:
                 raise RuntimeError("bench.py: no GPU visible to torch (the product has no CPU path)")
             dist.init_process_group(backend="gloo")     # contract test without a GPU: see --solver-lib
-            reduce_device = "cpu"
         elif ngpu >= world:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
@@ -74,7 +117,6 @@ def main():
             device_index = local_rank % max(1, ngpu)
             torch.cuda.set_device(device_index)
             dist.init_process_group(backend="gloo")
-            reduce_device = "cpu"
 
     import __graft_entry__
     if rank == 0:
@@ -84,8 +126,11 @@ def main():
     from karpenter_amd import fixtures as fx
     from karpenter_amd.scheduling import NewScheduler
 
-    prob = fx.config2(pods=args.pods, n_types=args.types, seed=42 + rank)
+    seed = 42 + rank
+    prob = fx.config2(pods=args.pods, n_types=args.types, seed=seed)
     prob["options"]["device"] = device_index
+    if args.engine != "auto":
+        prob["options"]["engine"] = args.engine
     sched = NewScheduler(prob, solver_lib=args.solver_lib)  # flatten + upload: inputs resident in HBM before the timed region
 
     def sync():
@@ -101,7 +146,7 @@ def main():
     last = None
     timings = []
     for _ in range(args.steps):
-        last = sched.Solve(want_results=False)  # synchronous: returns after the device finished and results are on the host
+        last = sched.Solve(want_results=False)  # synchronous: returns after the device finished and the flat Results are on the host
         timings += last["timings"]
     sync()
     if dist is not None:
@@ -111,14 +156,25 @@ def main():
     cost = last["packingCost"]
     claims = last["counters"]["claims"]
 
+    # ---- untimed: the packing itself (digest against the oracle's pin, per-instance-type summary) ----
+    full = sched.Solve(want_results=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity   # canonical Results digest (shared with the tests; does not touch oracle/)
+    digest, _ = parity.results_digest(full)
+    vec = launch_type_vector(prob, full)
+
     if dist is not None:
-        # max over ranks of the timed region; whole-job pods; global packing summary over xGMI (RCCL all-reduce)
+        # max over ranks of the timed region; the global packing summary = the per-instance-type (count, $/h) vectors of all
+        # ranks summed with one all-reduce (RCCL over xGMI when every rank has its GPU)
         t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        v = torch.tensor([float(scheduled), float(cost), float(claims)], dtype=torch.float64, device=reduce_device)
+        v = torch.tensor(vec.reshape(-1).tolist() + [float(scheduled)], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        scheduled, cost, claims = int(v[0].item()), float(v[1].item()), int(v[2].item())
+        scheduled = int(round(v[-1].item()))
+        import numpy as np
+        vec = np.array(v[:-1].tolist()).reshape(-1, 2)
+        claims, cost = int(round(vec[:, 0].sum())), float(vec[:, 1].sum())
 
     if rank != 0:
         if dist is not None:
@@ -133,31 +189,65 @@ def main():
     pack_ms = sum(t["pack_kernel_ms"] for t in timings) / len(timings)
     cls_ms = sum(t["classify_ms"] for t in timings) / len(timings)
     achieved = abytes / (pack_ms * 1e-3) / 1e9
+    kernel = "ksolve_pack_fast" if c.get("engine") == "cursor" else "ksolve_pack_lite"
     traffic = None
     try:
-        # HBM bytes of one ksolve_pack launch from the TCC counters (rocprofv3 --pmc, separate passes; scripts/gpu_pmc.sh).
+        # HBM bytes of one launch of the pack kernel from the TCC counters (rocprofv3 --pmc, separate passes; scripts/gpu_pmc.sh).
         # Collected on this workload in its own profiling run and committed under profiles/; not measurable from inside.
-        with open(os.path.join(ROOT, "profiles", "round1", "pmc_pack_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "round2", "pmc_pack_traffic.json")) as f:
             pmc = json.load(f)
-        if args.pods == 1_000_000 and args.types == 500:
+        if args.pods == 1_000_000 and args.types == 500 and pmc.get("kernel") == kernel:
             traffic = pmc["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         traffic = None
+    pin = None
+    if not args.no_parity_pin:
+        pin_path = os.path.join(ROOT, "tests", "golden", "fullsize", f"config2_p{args.pods}_t{args.types}_s{seed}.json")
+        if os.path.exists(pin_path):
+            with open(pin_path) as f:
+                g = json.load(f)
+            pin = {"pin": os.path.relpath(pin_path, ROOT), "digest_matches_oracle": digest == g["digest"], "claims_match": len(full["newNodeClaims"]) == g["claims"],
+                   "reference_bin_evaluations_match": full["counters"]["referenceBinEvaluations"] == g["binEvaluations"], "oracle_seconds_offline": g["oracleSeconds"]}
+            if not (pin["digest_matches_oracle"] and pin["reference_bin_evaluations_match"]):
+                raise SystemExit(f"bench.py: the timed problem's Results differ from the oracle's pin {pin}")   # the reference's in-bench gate (scheduling_benchmark_test.go:176-181), bit-exact
     stream_bytes = c["rows"] * rec["B_pod"]
+    nz = vec[:, 0] > 0
     out = {
         "metric": "pods scheduled/sec (Solve())", "value": value, "unit": "pods/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: {args.pods} pods/GPU x {args.types} kwok instance types, nodeSelector + taint/toleration, 2 NodePools",
-                   "pods_per_gpu": args.pods, "instance_types": args.types, "sharding": "one independent scheduling problem per GPU" if world > 1 else "single problem"},
-        "packing": {"node_claims": claims, "packing_cost_per_hour": cost, "pods_scheduled": scheduled},
-        "roofline": {"kernel": "ksolve_pack", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                   "pods_per_gpu": args.pods, "instance_types": args.types, "sharding": "one independent scheduling problem per GPU (weak scaling)" if world > 1 else "single coupled problem on one GPU",
+                   "timed_region": "ksolve_solve(): classing, queue sort, pack, finalize, download of the flat C-ABI Results; JSON re-hydration for Python excluded"},
+        "packing": {"node_claims": claims, "packing_cost_per_hour": cost, "pods_scheduled": scheduled,
+                    "per_instance_type": {"launch_types_used": int(nz.sum()), "max_claims_on_one_type": int(vec[:, 0].max()) if len(vec) else 0,
+                                          "vector": "count and $/h per instance type, all ranks summed" + (" with one all-reduce" if world > 1 else "")}},
+        "engine": c.get("engine"),
+        "parity": {"results_digest": digest, "oracle_pin": pin},
+        "roofline": {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes": abytes, "avg_kernel_ms": pack_ms, "records": rec,
-                     "note": "serial first-fit chain: latency-bound, one wavefront per problem; V = referenceBinEvaluations; traffic = 2*FETCH_SIZE + WRITE_SIZE of one launch (profiles/round1/pmc_pack_traffic.json): the working set stays in L2/Infinity Cache and exact pruning evaluates 1.1 of the reference's ~1009 bins per pod"},
-        "roofline_stream": {"kernel": "ksolve_row_hash+verify+class (pod classing)", "bound": "hbm", "bytes": stream_bytes, "avg_ms": cls_ms,
+                     "measured_traffic_GBps": (traffic / (pack_ms * 1e-3) / 1e9) if traffic else None,
+                     "note": "achieved = SURVEY §8(d) algorithmic bytes with V = the bins the REFERENCE evaluates (referenceBinEvaluations, equal to the oracle's count) / HIP-event time of the "
+                             "pack kernel. The kernel itself is a serial first-fit chain on ONE wavefront — instruction-issue bound (about 5.8 cycles per instruction for a lone wave, "
+                             "profiles/round2), not HBM bound: its working set lives in LDS, `traffic` (TCC counters of a separate rocprofv3 --pmc run) is what it really moves"},
+        "roofline_stream": {"kernel": "ksolve_row_hash+verify+class+gather (pod classing)", "bound": "hbm", "bytes": stream_bytes, "avg_ms": cls_ms,
                             "achieved": stream_bytes / (cls_ms * 1e-3) / 1e9 if cls_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s"},
         "phases_ms": {k: sum(t[k] for t in timings) / len(timings) for k in ("pack_kernel_ms", "classify_ms", "sort_ms", "it_index_ms")},
         "counters": c,
     }
+    sched.close()
+    if args.topology_pods > 0 and world == 1:
+        # BASELINE configs[2] shape (podAntiAffinity + 3-zone topologySpreadConstraints, the reference benchmark's diverse mix)
+        p3 = fx.config3(pods=args.topology_pods, n_types=args.types, seed=42)
+        p3["options"]["device"] = device_index
+        s3 = NewScheduler(p3, solver_lib=args.solver_lib)
+        s3.Solve(want_results=False)
+        tb = time.perf_counter()
+        r3 = s3.Solve(want_results=False)
+        dt = time.perf_counter() - tb
+        out["config2_topology"] = {"workload": f"BASELINE configs[2] shape: {args.topology_pods} pods, anti-affinity + zonal / hostname spread + zonal affinity, {args.types} types",
+                                   "pods": args.topology_pods, "seconds": dt, "value": r3["scheduledPods"] / dt, "unit": "pods/s", "node_claims": r3["counters"]["claims"],
+                                   "pack_kernel_ms": r3["timings"][0]["pack_kernel_ms"], "engine": r3["counters"].get("engine")}
+        s3.close()
     if args.batch_problems > 0 and world == 1:
         # Independent problems (NodePool components / consolidation probes) in ONE launch of the pack kernel:
         # block b = the wavefront of problem b. Reported beside the headline, never part of `value`.
@@ -176,11 +266,32 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         import oracle  # the checker, used here only as the reported CPU baseline
         sample = fx.config2(pods=args.cpu_sample, n_types=args.types, seed=42)
-        r = oracle.solve(sample)
-        secs = r["counters"]["solveSeconds"]
+        runs = []
+        for _ in range(max(1, args.cpu_runs)):
+            r = oracle.solve(sample)
+            runs.append(r["counters"]["solveSeconds"])
+        secs = statistics.median(runs)
         out["cpu_baseline"] = {"value": args.cpu_sample / secs, "unit": "pods/s", "cores": 1, "kind": "port",
-                               "sample": f"{args.cpu_sample} pods of the same configs[1] mix x {args.types} instance types, fresh scheduler, oracle C++ restatement of the Go Solve() ({secs:.1f} s)",
-                               "seconds": secs, "bin_evaluations": r["counters"]["binEvaluations"]}
+                               "sample": f"{args.cpu_sample} pods of the same configs[1] mix x {args.types} instance types, fresh scheduler, oracle C++ restatement of the Go Solve(): "
+                                         f"median of {len(runs)} runs ({secs:.2f} s); the oracle is O(pods x claims), so its rate falls with size "
+                                         f"(offline at the full 1M pods: see parity.oracle_pin.oracle_seconds_offline)",
+                               "seconds": secs, "runs_seconds": runs, "bin_evaluations": r["counters"]["binEvaluations"]}
+        if not args.no_host_engine_baseline and not args.solver_lib:
+            # the honest baseline for the ALGORITHM: this repository's own engine source compiled for ONE host core (the test
+            # emulation of the device code, tests/emu — a checker, never a product path), same problem, same Results
+            try:
+                emu = parity.build_emu()
+                eb = {}
+                for eng in ("general", "cursor"):
+                    pe = fx.config2(pods=args.pods, n_types=args.types, seed=42)
+                    pe["options"]["engine"] = eng
+                    se = NewScheduler(pe, solver_lib=emu)
+                    re_ = se.Solve(want_results=False)
+                    eb[eng] = {"pack_seconds": re_["timings"][0]["pack_kernel_ms"] * 1e-3, "pods_per_s": args.pods / (re_["timings"][0]["pack_kernel_ms"] * 1e-3)}
+                    se.close()
+                out["cpu_baseline_engine_host"] = {"cores": 1, "kind": "this repository's engine source on one host core (test emulation of the device code)", "pods": args.pods, "engines": eb}
+            except Exception as e:  # noqa: BLE001 - a missing host compiler must not lose the measurement
+                out["cpu_baseline_engine_host"] = {"error": str(e)[:200]}
     if args.solver_lib:
         out["data"] = "synthetic; TEST HOOK --solver-lib (host emulation of the engine): contract check only, not a measurement"
     print(json.dumps(out))

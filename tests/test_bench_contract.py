@@ -23,7 +23,7 @@ def _json_line(out):
 
 
 def _env():
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", KSOLVE_BENCH_TEST_HOOK="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     return env
@@ -31,12 +31,15 @@ def _env():
 
 def test_single_rank_line(oracle):
     emu = parity.build_emu()
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--pods", "3000", "--types", "60", "--cpu-sample", "1500",
-           "--batch-problems", "3", "--batch-pods", "400", "--solver-lib", emu]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--pods", "3000", "--types", "60", "--cpu-sample", "1500", "--cpu-runs", "3",
+           "--topology-pods", "400", "--batch-problems", "3", "--batch-pods", "400", "--solver-lib", emu]
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = _json_line(r.stdout)
-    assert REQUIRED <= set(line) and {"cpu_baseline", "batched", "packing", "counters"} <= set(line)
+    assert REQUIRED <= set(line) and {"cpu_baseline", "batched", "packing", "counters", "parity", "config2_topology", "engine"} <= set(line)
+    assert line["engine"] == "cursor" and line["parity"]["oracle_pin"] is None and len(line["parity"]["results_digest"]) == 64
+    assert line["config2_topology"]["pods"] == 400 and line["config2_topology"]["value"] > 0 and line["config2_topology"]["engine"] == "general"
+    assert line["packing"]["per_instance_type"]["launch_types_used"] >= 1
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak" and line["vs_baseline"] is None
     assert line["higher_is_better"] is True and line["dtype"] == "int64" and "workload" in line["config"] and "TEST HOOK" in line["data"]
     want = oracle.solve(fx.config2(pods=3000, n_types=60, seed=42))
@@ -48,7 +51,7 @@ def test_single_rank_line(oracle):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["traffic"] is None            # the PMC figure belongs to the 1M-pod x 500-type launch only
     cb = line["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "pods/s" and cb["value"] > 0
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "pods/s" and cb["value"] > 0 and len(cb["runs_seconds"]) == 3
     assert line["batched"]["problems"] == 3 and line["batched"]["value"] > 0
 
 
@@ -69,6 +72,13 @@ def test_two_ranks_under_the_drivers_launcher(oracle):
     assert abs(line["packing"]["packing_cost_per_hour"] - cost) <= 1e-9 * cost
     # whole-job value: pods of ALL ranks over the max-over-ranks time of the timed region
     assert abs(line["value"] - line["packing"]["pods_scheduled"] / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+
+
+def test_the_hook_needs_its_environment_switch():
+    env = _env()
+    env.pop("KSOLVE_BENCH_TEST_HOOK")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pods", "100", "--solver-lib", parity.build_emu()], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "test hook" in r.stderr
 
 
 def test_no_gpu_and_no_hook_is_loud():

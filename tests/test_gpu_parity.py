@@ -21,10 +21,17 @@ def built():
 
 
 def check(oracle, prob):
+    """The engine the library picks on its own (the cursor engine for purely positive provisioning batches, the general
+    engine otherwise) AND — when that was the cursor engine — the general engine too: both against the oracle."""
     want = oracle.solve(prob)
     got = NewScheduler(prob).Solve()
     parity.assert_same_results(got, want)
     assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
+    if got["counters"]["engine"] == "cursor":
+        gen = NewScheduler(dict(prob, options=dict(prob["options"], engine="general"))).Solve()
+        assert gen["counters"]["engine"] == "general"
+        parity.assert_same_results(gen, want)
+        assert gen["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
     return got, want
 
 
@@ -332,3 +339,37 @@ def test_plain_c_example_on_the_device(tmp_path):
     p = subprocess.run([exe], capture_output=True)
     assert p.returncode == 0, p.stderr.decode()
     assert p.stdout.decode().strip() == test_abi.EXAMPLE_OUTPUT
+
+
+# ---- parity at the benchmarked sizes ------------------------------------------------------------
+# The oracle needs hours at these sizes, so it ran OFFLINE in the CPU container (tests/golden/make_fullsize_digests.py)
+# and committed a digest of its canonical Results per configuration; here the device solves the same seeded problem and
+# must produce the same digest (L1-strict: claim order, pod identities and slots, instance types, requirements, requests,
+# launch price bits) and the same reference bin-evaluation count V.
+def _pins():
+    import glob
+    return sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize", "*.json")))
+
+
+@pytest.mark.parametrize("pin", _pins(), ids=lambda p: os.path.basename(p)[:-5])
+def test_full_size_digest(pin):
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_fullsize_digests import build_problem
+    g = json.load(open(pin))
+    prob = build_problem(g["config"], g["pods"], g["types"], g["seed"], g["extra"])
+    engines = ["auto"] + (["general"] if g["config"] != "config3" and g["pods"] <= 250000 else [])
+    for eng in engines:
+        s = NewScheduler(dict(prob, options=dict(prob["options"], engine=eng)))
+        r = s.Solve()
+        s.close()
+        digest, fps = parity.results_digest(r)
+        assert len(r["newNodeClaims"]) == g["claims"], (eng, len(r["newNodeClaims"]), g["claims"])
+        if digest != g["digest"]:
+            first = next(i for i, (a, b) in enumerate(zip(fps, g["claimFingerprints"])) if a[:12] != b)
+            raise AssertionError(f"{eng}: digest differs from the oracle's; first differing claim {first}")
+        assert r["counters"]["referenceBinEvaluations"] == g["binEvaluations"]
+        assert float(r["packingCost"]).hex() == g["packingCost"] or abs(r["packingCost"] - g["packingCostApprox"]) < 1e-9 * g["packingCostApprox"]
+        if eng == "auto":
+            assert r["counters"]["engine"] == ("general" if g["config"] == "config3" else "cursor"), r["counters"]
