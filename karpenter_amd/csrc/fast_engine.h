@@ -638,7 +638,7 @@ struct FastHot {
   int pend_a, pend_x, pend_new, ev_arg;
   uint32_t pend_mv, pad0;
   uint64_t ev_vm;
-  unsigned long long n_steps, n_tests, n_ref;
+  unsigned long long n_steps, n_tests, n_ref, hot_cycles;
   const uint32_t* sorted; const uint32_t* row_class; const volatile int* cancel; int32_t* g_assign; uint32_t* g_slot;
   uint32_t cur[kFastRows][64];
   uint32_t bpod[64], bcls[64], bslot[64], oclaim[64], ocnt[64], nxt_pod[64], nxt_cls[64];
@@ -655,6 +655,7 @@ enum { FEV_DONE = 0, FEV_ENTRY = 1, FEV_SLOT = 2, FEV_SLOWSORT = 3, FEV_PLACE = 
 template <class W>
 KS_COLD int fast_hot_run(FastHotCtx cx) {
   typedef KS_LDS uint16_t* o16;
+  const unsigned long long t_in = W::clock();
   const o16 okey = fast_uniform(cx.okey), oord = fast_uniform(cx.oord);
   KS_LDS FastClaim* const cst = fast_uniform(cx.cst);
   KS_LDS FastEnt* const ent = fast_uniform(cx.ent);
@@ -863,6 +864,7 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
     hs->base = base; hs->bi = bi; hs->bn = bn; hs->n = n; hs->steps = steps; hs->status = status;
     hs->pend_a = pend_a; hs->pend_x = pend_x; hs->pend_mv = pend_mv; hs->pend_new = pend_new ? 1 : 0;
     hs->n_steps = n_steps; hs->n_tests = n_tests; hs->n_ref = n_ref; hs->ev_arg = ev_arg; hs->ev_vm = ev_vm;
+    hs->hot_cycles += W::clock() - t_in;
   }
   W::each([&](int l) {
 #pragma unroll
@@ -893,7 +895,7 @@ struct FastEngine {
       const long long ms_ = cold.Sk->max_steps;
       h->max_steps = ms_ < 0 ? -1 : (int)(ms_ > 0x7FFFFFFF ? 0x7FFFFFFF : ms_);
       h->pend_a = -1; h->pend_x = 0; h->pend_mv = 0; h->pend_new = 0; h->ev_arg = 0; h->ev_vm = 0;
-      h->n_steps = 0; h->n_tests = 0; h->n_ref = 0;
+      h->n_steps = 0; h->n_tests = 0; h->n_ref = 0; h->hot_cycles = 0;
       h->sorted = cold.Pk->sorted_pods; h->row_class = cold.Pk->row_class; h->cancel = cold.Sk->cancel_flag;
       h->g_assign = cold.Sk->assign; h->g_slot = cold.Sk->slot;
     }
@@ -910,9 +912,12 @@ struct FastEngine {
     FastHotCtx cx;
     cx.okey = cold.order.key; cx.oord = cold.order.ord; cx.cst = cold.cst; cx.ent = cold.ent; cx.pool = cold.pool;
     cx.aslot = cold.aslot; cx.slot_of = cold.Mp->slot_of; cx.hs = hs;
+    unsigned long long tev[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = W::clock();
     for (;;) {
       const int ev = fast_uniform(fast_hot_run<W>(cx));
       if (ev == FEV_DONE) break;
+      const unsigned long long te0 = W::clock();
       if (ev == FEV_ENTRY) {
         if (fast_uniform(cold.create_entry(h->ev_vm)) < 0) { cold.bail_code = 21; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
       } else if (ev == FEV_SLOT) {
@@ -953,8 +958,11 @@ struct FastEngine {
         if (W::leader()) { h->oclaim[bi] = (uint32_t)n; h->ocnt[bi] = 0; h->n = n + 1; h->pend_new = 1; h->bi = bi + 1; }   // claim ids are handed out in creation order
         W::sync();
       } else { cold.bail_code = 22; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
+      if (ev >= 1 && ev <= 5) { tev[ev] += W::clock() - te0; nev[ev]++; }
     }
-    cold.finish(fast_uniform(h->status), fast_uniform(h->n), (unsigned long long)fast_uniform(h->steps), h->n_steps, h->n_tests, h->n_ref, nullptr);
+    // profiling builds (-DKSOLVE_PHASE_TIMERS): cycles inside the loop function, per event kind, in total; event counts
+    unsigned long long tc[8] = {h->hot_cycles, tev[1], tev[2], tev[3], tev[4], tev[5], W::clock() - t_begin, nev[3] + (nev[4] << 20) + (nev[1] << 40)};
+    cold.finish(fast_uniform(h->status), fast_uniform(h->n), (unsigned long long)fast_uniform(h->steps), h->n_steps, h->n_tests, h->n_ref, tc);
   }
 };
 

@@ -276,6 +276,9 @@ def interweave_by_nodepool(candidates, previously_unseen=()):
     return out
 
 
+MAX_INSTANCE_TYPES = 600   # scheduling.MaxInstanceTypes, nodeclaimtemplate.go:50
+
+
 def simulate_scheduling(cluster, candidates, solver):
     """helpers.go:53-155: Solve() with the candidates removed and their pods added to the pending set."""
     names = {c["name"] for c in candidates}
@@ -290,7 +293,7 @@ def simulate_scheduling(cluster, candidates, solver):
     # (NewTopology / countDomains read the cluster's bound pods, topology.go:68-103, :361-459)
     staying = [p for n in cluster["nodes"] if n["name"] not in names and not n.get("markedForDeletion") for p in n.get("pods", [])]
     prob = fx.problem(cluster["instanceTypes"], cluster["nodePools"], copy.deepcopy(pods), well_known=cluster.get("wellKnownLabels", fx.KWOK_WELL_KNOWN),
-                      state_nodes=state_nodes, cluster_pods=copy.deepcopy(staying), options=dict(cluster.get("options", {}), consolidationSimulation=True, truncateInstanceTypes=max(1, len(cluster["instanceTypes"]))),   # OrderByPrice, nothing cut (consolidation.go:209)
+                      state_nodes=state_nodes, cluster_pods=copy.deepcopy(staying), options=dict(cluster.get("options", {}), consolidationSimulation=True, truncateInstanceTypes=MAX_INSTANCE_TYPES),   # results.TruncateInstanceTypes(ctx, scheduling.MaxInstanceTypes): price order, capped at 600, minValues re-checked after the cut (helpers.go:131, scheduler.go:419-437)
                       namespaces=cluster.get("namespaces"),
                       deleting_node_names=[n["name"] for n in deleting])
     res = solver(prob)
@@ -413,7 +416,8 @@ def first_n_consolidation_option(cluster, candidates, solver, max_n=100, evaluat
             reqs = {r["key"]: r for r in cmd["results"]["newNodeClaims"][0]["requirements"]}
             by_name = {t["name"]: t for t in cluster["instanceTypes"]}
             cmd["replacement"] = [n for n in cmd["replacement"] if worst_launch_price(by_name[n], reqs) < max_price]
-            valid = bool(cmd["replacement"])
+            # RemoveInstanceTypeOptionsByPriceAndMinValues (nodeclaim.go:411-420): what survives the price filter must still meet minValues
+            valid = bool(cmd["replacement"]) and _min_types_for_min_values(cmd["replacement"], reqs, by_name)[1]
         if valid:
             approved, per_pool = evaluator.approve_command(candidates[: mid + 1], cmd)
             cmd["scores"] = per_pool

@@ -39,6 +39,11 @@ using kj::Value;
 struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
 
 // ---- resource.Quantity -> exact int128 nano-units ----
+// resource.Quantity saturates at +-(2^63 - 1) in its own scale; anything that would not fit 2^100 nano-units is far beyond
+// every real request and is refused loudly instead of wrapping to a small number (a pod asking for cpu "1e400000000" must
+// not be packed as if it asked for nothing).
+static const i128 kQuantityMax = (i128)1 << 100;
+bool go_atoi(const std::string& s, long long& out);
 i128 parse_quantity(const std::string& s) {
   if (s.empty()) throw std::runtime_error("quantity: empty");
   size_t i = 0;
@@ -49,7 +54,10 @@ i128 parse_quantity(const std::string& s) {
   bool dot = false, any = false;
   for (; i < s.size(); ++i) {
     char c = s[i];
-    if (c >= '0' && c <= '9') { mant = mant * 10 + (c - '0'); if (dot) ++frac; any = true; }
+    if (c >= '0' && c <= '9') {
+      if (mant > kQuantityMax / 10) throw Unsupported("quantity out of range (resource.Quantity would saturate): " + s);
+      mant = mant * 10 + (c - '0'); if (dot) ++frac; any = true;
+    }
     else if (c == '.' && !dot) dot = true;
     else break;
   }
@@ -61,11 +69,19 @@ i128 parse_quantity(const std::string& s) {
   i128 v = mant;
   auto d = dec.find(suf);
   if (d != dec.end()) e = d->second;
-  else if (bin.count(suf)) v *= (i128)1 << bin.at(suf);
-  else if (!suf.empty() && (suf[0] == 'e' || suf[0] == 'E')) e = atoi(suf.c_str() + 1);
-  else throw std::runtime_error("quantity suffix: '" + s + "'");
+  else if (bin.count(suf)) {
+    if (v > (kQuantityMax >> bin.at(suf))) throw Unsupported("quantity out of range (resource.Quantity would saturate): " + s);
+    v *= (i128)1 << bin.at(suf);
+  } else if (!suf.empty() && (suf[0] == 'e' || suf[0] == 'E')) {
+    long long ee = 0;
+    if (!go_atoi(suf.substr(1), ee) || ee > 40 || ee < -40) throw Unsupported("quantity exponent out of range: " + s);   // never a 2^31-step loop, never a silent wrap
+    e = (int)ee;
+  } else throw std::runtime_error("quantity suffix: '" + s + "'");
   e += 9 - frac;
-  for (; e > 0; --e) v *= 10;
+  for (; e > 0; --e) {
+    if (v > kQuantityMax / 10) throw Unsupported("quantity out of range (resource.Quantity would saturate): " + s);
+    v *= 10;
+  }
   for (; e < 0; ++e) { if (v % 10) throw Unsupported("quantity finer than nano: " + s); v /= 10; }
   return neg ? -v : v;
 }

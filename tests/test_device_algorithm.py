@@ -621,6 +621,22 @@ def test_malformed_problems_are_rejected_not_crashed(emu):
     assert outcomes["solved"] and outcomes["refused"]
 
 
+def test_quantities_out_of_range_are_refused_not_wrapped(emu):
+    """cpu "1e400000000" used to wrap to 0 in the flattener (the pod was then SCHEDULED as if it asked for nothing)
+    after a 2^31-step loop; resource.Quantity saturates such a value, so the reference leaves the pod unschedulable. The
+    flattener now refuses it loudly, quickly."""
+    import time
+    its = fx.fake_default_instance_types()
+    for q in ("1e400000000", "1e41", "9" * 60, "99999999999999999999999999999999Ei", "1e-41"):
+        t0 = time.time()
+        with pytest.raises((Unsupported, RuntimeError)):
+            NewScheduler(fx.problem(its, [fx.node_pool()], [fx.pod(requests={"cpu": q})]), solver_lib=emu).Solve()
+        assert time.time() - t0 < 5
+    # large but representable quantities still solve (and fail to fit, like in the reference)
+    got = NewScheduler(fx.problem(its, [fx.node_pool()], [fx.pod(requests={"cpu": "1e12"}), fx.pod(requests={"memory": "8Ei"})]), solver_lib=emu).Solve()
+    assert len(got["podErrors"]) == 2
+
+
 def test_hostile_sizes_and_stray_resources(oracle, emu):
     # an overhead entry for a resource the capacity does not have is ignored (resources.Subtract keeps capacity's keys)
     its = fx.fake_default_instance_types()

@@ -440,6 +440,34 @@ def test_consolidation_respects_min_values_after_the_price_filter(oracle, emu):
         assert cmd["decision"] == dz.REPLACE and cmd["replacement"] == [cheap["name"]]
 
 
+def test_simulation_truncates_to_600_instance_types_and_rechecks_min_values(oracle, emu):
+    """helpers.go:131 — SimulateScheduling ends with results.TruncateInstanceTypes(ctx, MaxInstanceTypes): the replacement's
+    options are the 600 cheapest, and a NodePool whose minValues needs more distinct instance types than the cut leaves
+    loses the claim (its pods fail, scheduler.go:419-437), so the candidate is not consolidated. 700 kwok types."""
+    its = fx.kwok_catalog(700)
+    assert len(its) == 700
+    pricey = max([t for t in its if "linux" in t["name"] and "amd64" in t["name"]], key=lambda t: t["offerings"][0]["price"])
+    def cluster_with(min_values):
+        pool = fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "Exists", min_values=min_values)] if min_values else None)
+        pool["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+        node = _node_with_pods("node-0", pricey, fx.KWOK_ZONES[0], "on-demand", ["100m"])
+        return {"instanceTypes": its, "nodePools": [pool], "nodes": [node], "pendingPods": [], "wellKnownLabels": fx.KWOK_WELL_KNOWN}, node
+    for solver in _solvers(oracle, emu):
+        cluster, node = cluster_with(None)
+        cmd = dz.compute_consolidation(cluster, [node], solver)
+        assert cmd["decision"] == dz.REPLACE
+        res = dz.simulate_scheduling(cluster, [node], solver)
+        assert len(res["newNodeClaims"]) == 1 and len(res["newNodeClaims"][0]["instanceTypes"]) == 600   # 700 compatible types, capped
+        # minValues = 650 distinct instance types: met by the 700 options Solve() leaves, broken by the cut to 600
+        cluster, node = cluster_with(650)
+        res = dz.simulate_scheduling(cluster, [node], solver)
+        assert not res["newNodeClaims"] and not res["allNonPendingPodsScheduled"]
+        assert dz.compute_consolidation(cluster, [node], solver)["decision"] == dz.NOOP
+        # minValues = 500 survives the cut
+        cluster, node = cluster_with(500)
+        assert dz.compute_consolidation(cluster, [node], solver)["decision"] == dz.REPLACE
+
+
 def test_single_node_candidate_order(oracle):
     """singlenodeconsolidation_test.go:104-170 — candidates sorted by savings ratio, then dealt out over the NodePools;
     a pool that an earlier, timed-out run did not reach comes first."""
