@@ -44,29 +44,42 @@ struct ClaimOrder {
     uint32_t mk = key[from], mo = ord[from];
     for (int top = from; top > to; top -= kRound) {  // high to low so a round never reads what an earlier round wrote
       int lo = top - kRound > to ? top - kRound : to;
-      shift_round(lo, top, +1);
+      shift_round(lo, top, +1, false);
     }
     W::store(&key[to], mk); W::store(&ord[to], mo); if constexpr (POS) W::store(&pos[mo], (uint32_t)to);
     W::sync();
   }
-  // move element at `from` to `to` (to > from), shifting (from, to] left by one
-  KS_FN void rotate_left(int from, int to) {
+  // move element at `from` to `to` (to > from), shifting (from, to] left by one. same_keys: the elements that shift all carry
+  // ONE count (the stable move of a claim that gained a pod passes claims of exactly its old count): their keys need not
+  // move at all — one key written at each end instead of one per element.
+  KS_FN void rotate_left(int from, int to, bool same_keys = false) {
     if (to <= from) return;
     uint32_t mk = key[from], mo = ord[from];
+    const uint32_t passed = key[from + 1];
     for (int lo = from + 1; lo <= to; lo += kRound) {
       int hi = lo + kRound <= to + 1 ? lo + kRound : to + 1;
-      shift_round(lo, hi, -1);
+      shift_round(lo, hi, -1, same_keys);
     }
+    if (same_keys) W::store(&key[from], passed);
     W::store(&key[to], mk); W::store(&ord[to], mo); if constexpr (POS) W::store(&pos[mo], (uint32_t)to);
     W::sync();
   }
   // elements [lo,hi) (at most kRound) move by delta (+1 / -1): all reads of the round precede its writes, and
   // all of them are in flight together (a long move — tens of thousands of equally full claims — is bound by round trips)
-  static constexpr int kPerLane = sizeof(P32) == 8 ? 8 : 1;   // HBM-resident order (64-bit pointers): eight elements per lane per round
+  static constexpr int kPerLane = sizeof(P32) == 8 ? 16 : 1;   // HBM-resident order (64-bit pointers): sixteen elements per lane per round
   static constexpr int kRound = 64 * kPerLane;
-  KS_FN void shift_round(int lo, int hi, int delta) {
+  KS_FN void shift_round(int lo, int hi, int delta, bool same_keys) {
 #if KS_DEVICE
     uint32_t k[kPerLane], o[kPerLane];
+    if (same_keys) {
+#pragma unroll
+      for (int j = 0; j < kPerLane; ++j) { const int i = lo + j * 64 + W::lane(); if (i < hi) o[j] = ord[i]; }
+      W::sync();
+#pragma unroll
+      for (int j = 0; j < kPerLane; ++j) { const int i = lo + j * 64 + W::lane(); if (i < hi) { ord[i + delta] = o[j]; if constexpr (POS) pos[o[j]] = (uint32_t)(i + delta); } }
+      W::sync();
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < kPerLane; ++j) { const int i = lo + j * 64 + W::lane(); if (i < hi) { k[j] = key[i]; o[j] = ord[i]; } }
     W::sync();
@@ -74,8 +87,8 @@ struct ClaimOrder {
     for (int j = 0; j < kPerLane; ++j) { const int i = lo + j * 64 + W::lane(); if (i < hi) { key[i + delta] = k[j]; ord[i + delta] = o[j]; if constexpr (POS) pos[o[j]] = (uint32_t)(i + delta); } }
     W::sync();
 #else
-    if (delta > 0) for (int i = hi - 1; i >= lo; --i) { key[i + 1] = key[i]; ord[i + 1] = ord[i]; if constexpr (POS) pos[ord[i + 1]] = i + 1; }
-    else for (int i = lo; i < hi; ++i) { key[i - 1] = key[i]; ord[i - 1] = ord[i]; if constexpr (POS) pos[ord[i - 1]] = i - 1; }
+    if (delta > 0) for (int i = hi - 1; i >= lo; --i) { if (!same_keys) key[i + 1] = key[i]; ord[i + 1] = ord[i]; if constexpr (POS) pos[ord[i + 1]] = i + 1; }
+    else for (int i = lo; i < hi; ++i) { if (!same_keys) key[i - 1] = key[i]; ord[i - 1] = ord[i]; if constexpr (POS) pos[ord[i - 1]] = i - 1; }
 #endif
   }
   // first x in [lo,hi) with key[x] >= v, hi if none — [lo,hi) is sorted ascending (binary search: a long run of equal keys
@@ -319,7 +332,7 @@ struct ClaimOrder {
         uint32_t mv = key[p];
         const P32 kp = key;
         int e = W::find_first(p + 1, n, [kp, mv](int x) { return !(kp[x] < mv); });
-        rotate_left(p, e - 1);
+        rotate_left(p, e - 1, true);   // everything between carries the claim's old count
       }
       defect = -1;
       return;
@@ -345,7 +358,7 @@ struct ClaimOrder {
         } else if (p + 1 < n && key[p + 1] < key[p]) {
           const uint32_t mv = key[p];
           const int e = kPerLane > 1 ? lower_bound_sorted(p + 1, n, mv) : W::find_first(p + 1, n, [kq, mv](int x) { return !(kq[x] < mv); });   // [p+1, n) is sorted
-          rotate_left(p, e - 1);
+          rotate_left(p, e - 1, true);   // everything between carries the claim's old count
         }
         defect = -1;
         return;
