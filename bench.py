@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--topology-pods", type=int, default=200_000, help="BASELINE configs[2] shape (anti-affinity + 3-zone spread) reported beside the headline, 0 = skip")
     ap.add_argument("--batch-problems", type=int, default=512, help="independent problems solved with ONE batched launch (reported beside the headline, 0 = skip)")
     ap.add_argument("--batch-pods", type=int, default=20_000, help="pods per problem of the batched measurement")
+    ap.add_argument("--components-pods", type=int, default=10_000_000, help="BASELINE configs[3]: pods of the 16-NodePool batch solved as NodePool components (one block each, one launch), 0 = skip")
+    ap.add_argument("--components-types", type=int, default=1000)
+    ap.add_argument("--components-calibration-pods", type=int, default=200_000, help="size at which the component split is compared with ONE Solve() of the whole batch (L2-canonical deltas)")
     ap.add_argument("--no-parity-pin", action="store_true", help="skip the digest check of the timed problem against the committed oracle pin")
     ap.add_argument("--engine", default="auto", choices=["auto", "general", "cursor"], help="pack engine (auto: the cursor engine for purely positive batches)")
     ap.add_argument("--solver-lib", default=None, help="TEST HOOK (tests/test_bench_contract.py, needs KSOLVE_BENCH_TEST_HOOK=1): a host build of the engine behind the same "
@@ -248,6 +251,45 @@ def main():
                                    "pods": args.topology_pods, "seconds": dt, "value": r3["scheduledPods"] / dt, "unit": "pods/s", "node_claims": r3["counters"]["claims"],
                                    "pack_kernel_ms": r3["timings"][0]["pack_kernel_ms"], "engine": r3["counters"].get("engine")}
         s3.close()
+    if args.components_pods > 0 and world == 1:
+        # BASELINE configs[3]: 10M pods x 1k instance types x 16 NodePools. Every pod pins its NodePool, so the batch falls into
+        # 16 components (karpenter_amd/components.py) that cannot share a claim; each is solved EXACTLY as its own problem, all
+        # in one launch (one wavefront per component). The union is a packing of equal quality, not the reference's pod-for-pod
+        # answer for the whole batch (the reference re-sorts ALL claims before every scan, scheduler.go:598): L2-canonical.
+        from karpenter_amd.components import split_by_nodepool
+        from karpenter_amd.scheduling import SolveBatch
+
+        def solve_components(pods, repeat):
+            parts = split_by_nodepool(fx.config4(pods=pods, n_types=args.components_types, n_pools=16, seed=42))
+            scheds = [NewScheduler(dict(sub, options=dict(sub["options"], device=device_index)), solver_lib=args.solver_lib) for _, sub in parts]
+            best, rs = None, None
+            for _ in range(repeat):
+                tb = time.perf_counter()
+                rs = SolveBatch(scheds, want_results=False)
+                dt = time.perf_counter() - tb
+                best = dt if best is None else min(best, dt)
+            for sc_ in scheds:
+                sc_.close()
+            return parts, rs, best
+        parts, rs, dt = solve_components(args.components_pods, 2)
+        comp = {"workload": f"BASELINE configs[3]: {args.components_pods} pods x {args.components_types} types x 16 NodePools, every pod pinned to its pool",
+                "components": len(parts), "pods": sum(r["scheduledPods"] for r in rs), "seconds": dt, "value": sum(r["scheduledPods"] for r in rs) / dt, "unit": "pods/s",
+                "node_claims": sum(r["counters"]["claims"] for r in rs), "packing_cost_per_hour": sum(r["packingCost"] for r in rs),
+                "pack_kernel_ms": max(r["timings"][0]["pack_kernel_ms"] for r in rs), "engines": sorted({r["counters"].get("engine") for r in rs}),
+                "parity": "each component bit-identical to the oracle on that component (tests); the union vs ONE Solve() of the whole batch: L2-canonical, see calibration"}
+        if args.components_calibration_pods > 0:
+            cp = args.components_calibration_pods
+            whole_p = fx.config4(pods=cp, n_types=args.components_types, n_pools=16, seed=42)
+            whole_p["options"]["device"] = device_index
+            sw = NewScheduler(whole_p, solver_lib=args.solver_lib)
+            rw = sw.Solve(want_results=False)
+            sw.close()
+            _, rc, _ = solve_components(cp, 1)
+            comp["calibration"] = {"pods": cp, "whole_batch": {"node_claims": rw["counters"]["claims"], "packing_cost_per_hour": rw["packingCost"], "engine": rw["counters"].get("engine")},
+                                   "components": {"node_claims": sum(r["counters"]["claims"] for r in rc), "packing_cost_per_hour": sum(r["packingCost"] for r in rc)},
+                                   "claims_delta": sum(r["counters"]["claims"] for r in rc) - rw["counters"]["claims"],
+                                   "cost_rel_delta": (sum(r["packingCost"] for r in rc) - rw["packingCost"]) / rw["packingCost"]}
+        out["config3_components"] = comp
     if args.batch_problems > 0 and world == 1:
         # Independent problems (NodePool components / consolidation probes) in ONE launch of the pack kernel:
         # block b = the wavefront of problem b. Reported beside the headline, never part of `value`.

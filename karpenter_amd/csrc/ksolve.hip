@@ -147,6 +147,13 @@ __global__ void __launch_bounds__(64) ksolve_pack_fast(const ks::FastArgs* a) {
   ks::FastEngine<ks::Wave> eng(&a->pv, &a->ws, &a->fw, lds);
   eng.solve();
 }
+// Batched form: block b runs the cursor engine on problem b.
+__global__ void __launch_bounds__(64) ksolve_pack_fast_batch(const ks::FastArgs* const* items) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const ks::FastArgs* a = items[blockIdx.x];
+  ks::FastEngine<ks::Wave> eng(&a->pv, &a->ws, &a->fw, lds);
+  eng.solve();
+}
 // One wavefront per claim: hot claim records (requirement masks, InstanceTypeOptions) from the cursor engine's compact state.
 __global__ void __launch_bounds__(64) ksolve_fast_records(ks::FastRecordArgs a) {
   ks::fast_record_body<ks::Wave>((int)blockIdx.x, a);
@@ -175,6 +182,34 @@ static void be_launch_pack_fast(ksolve_handle* h) {
   be_h2d(h, h->d_fast_args, &a, sizeof(a));
   hipLaunchKernelGGL(ksolve_pack_fast, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
   hip_check(h, hipGetLastError(), "ksolve_pack_fast launch");
+}
+static void be_launch_pack_fast_batch(ksolve_handle** hs, int n) {
+  if (n <= 0) return;
+  ksolve_handle* h0 = hs[0];
+  HipBackend* b = HB(h0);
+  std::vector<const ks::FastArgs*> ptrs((size_t)n);
+  int lds_bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    ks::FastArgs a{hs[i]->pv, hs[i]->ws, hs[i]->fw};
+    be_h2d(hs[i], hs[i]->d_fast_args, &a, sizeof(a));
+    ptrs[(size_t)i] = hs[i]->d_fast_args;
+    lds_bytes = std::max(lds_bytes, hs[i]->fw.plan.total_bytes);
+  }
+  const ks::FastArgs** d_ptrs = nullptr;
+  if (!hip_check(h0, hipMalloc((void**)&d_ptrs, (size_t)n * sizeof(void*)), "hipMalloc(batch)")) return;
+  hip_check(h0, hipMemcpyAsync(d_ptrs, ptrs.data(), (size_t)n * sizeof(void*), hipMemcpyHostToDevice, b->stream), "hipMemcpy(batch)");
+  hip_check(h0, hipStreamSynchronize(b->stream), "hipStreamSynchronize");
+  if (hip_check(h0, hipFuncSetAttribute((const void*)ksolve_pack_fast_batch, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) {
+    hip_check(h0, hipEventRecord(b->ev0[ksi::T_PACK], b->stream), "hipEventRecord");
+    hipLaunchKernelGGL(ksolve_pack_fast_batch, dim3((unsigned)n), dim3(64), (size_t)lds_bytes, b->stream, (const ks::FastArgs* const*)d_ptrs);
+    hip_check(h0, hipGetLastError(), "ksolve_pack_fast_batch launch");
+    hip_check(h0, hipEventRecord(b->ev1[ksi::T_PACK], b->stream), "hipEventRecord");
+    hip_check(h0, hipEventSynchronize(b->ev1[ksi::T_PACK]), "hipEventSynchronize");
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, b->ev0[ksi::T_PACK], b->ev1[ksi::T_PACK]) == hipSuccess) for (int i = 0; i < n; ++i) hs[i]->timers.ms[ksi::T_PACK] = ms;
+    if (b->failed) for (int i = 1; i < n; ++i) { HB(hs[i])->failed = true; hs[i]->error = h0->error; }
+  }
+  (void)hipFree(d_ptrs);
 }
 static void be_launch_fast_records(ksolve_handle* h, int n_claims) {
   ks::FastRecordArgs a{h->pv, h->ws, h->fw};

@@ -93,6 +93,7 @@ static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a
 static void be_sort_pods(ksolve_handle* h);  // fills ws/pv.sorted_pods
 static void be_launch_pack(ksolve_handle* h);
 static void be_launch_pack_fast(ksolve_handle* h);                 // one wavefront: FastEngine::solve
+static void be_launch_pack_fast_batch(ksolve_handle** hs, int n);   // block b = the cursor engine on problem b; sets every handle's T_PACK timer
 static void be_launch_fast_records(ksolve_handle* h, int n_claims); // one wavefront per claim: fast_record_body
 static void be_launch_pack_batch(ksolve_handle** hs, int n);
 static void be_thread_init(ksolve_handle* h);   // makes the handle's device current on a worker thread   // one block per handle; sets every handle's T_PACK timer
@@ -891,11 +892,44 @@ static ksolve_status solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results*
     for (auto& th : pool) th.join();
   };
   parallel([&](uint32_t i) { st[i] = solve_prepare(hs[i]); outs[i].status = st[i]; if (st[i] == KSOLVE_OK) be_sync(hs[i]); });
-  std::vector<ksolve_handle*> run;
-  for (uint32_t i = 0; i < n; ++i) if (st[i] == KSOLVE_OK && hs[i]->n_pods) run.push_back(hs[i]);
+  // problems of the cursor engine's shape go to it (one block each); the ones it hands back (status 3), and all others, run
+  // on the general engine's batched launch
+  std::vector<ksolve_handle*> fast, run;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (st[i] != KSOLVE_OK || !hs[i]->n_pods) continue;
+    ksolve_handle* h = hs[i];
+    if (h->fw.enabled && !h->pv.big && h->n_classes) fast.push_back(h);
+    else if (h->opts.engine == 2) st[i] = fail(h, KSOLVE_ERR_UNSUPPORTED, "cursor engine requested for a problem outside its shape");
+    else run.push_back(h);
+  }
+  if (!fast.empty()) {
+    be_launch_pack_fast_batch(fast.data(), (int)fast.size());
+    std::vector<int> handed_back(fast.size(), 0);
+    for (size_t k = 0; k < fast.size(); ++k) {
+      ksolve_handle* h = fast[k];
+      int status = 0, n_claims = 0;
+      be_d2h(h, &status, h->ws.status_out, 4);
+      be_d2h(h, &n_claims, h->ws.n_claims_out, 4);
+      be_sync(h);
+      if (be_ok(h) && status != 3 && status != 1) { h->engine_used = 2; if (n_claims) be_launch_fast_records(h, n_claims); continue; }
+      if (be_ok(h) && status == 3) { ks::Counters ctr{}; be_d2h(h, &ctr, h->ws.counters, sizeof(ctr)); be_sync(h); h->fast_reason = (uint32_t)ctr.cycles[20]; }
+      else if (be_ok(h)) h->fast_reason = 100;
+      handed_back[k] = 1;
+    }
+    for (size_t k = 0; k < fast.size(); ++k) {
+      if (!handed_back[k]) continue;
+      ksolve_handle* h = fast[k];
+      uint32_t idx = 0;
+      while (hs[idx] != h) ++idx;
+      if (h->opts.engine == 2) { st[idx] = fail(h, KSOLVE_ERR_UNSUPPORTED, "cursor engine declined the problem (reason " + std::to_string(h->fast_reason) + ")"); continue; }
+      h->fw.enabled = 0;
+      st[idx] = solve_prepare(h, false);
+      if (st[idx] == KSOLVE_OK) { be_sync(h); run.push_back(h); }
+    }
+  }
   if (!run.empty()) be_launch_pack_batch(run.data(), (int)run.size());
   parallel([&](uint32_t i) {
-    if (st[i] != KSOLVE_OK) return;
+    if (st[i] != KSOLVE_OK) { outs[i].status = st[i]; return; }
     st[i] = solve_finish(hs[i], &outs[i]);
     if (st[i] == KSOLVE_ERR_CAPACITY && hs[i]->big_capable && !hs[i]->pv.big) { be_results_drop(&outs[i]); st[i] = solve(hs[i], &outs[i], false); }   // re-run alone on the BIG engine
     outs[i].status = st[i];   // solve_finish zeroes `out` before it can fail: the per-problem status must survive that

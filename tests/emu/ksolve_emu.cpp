@@ -100,6 +100,9 @@ static void be_launch_fast_records(ksolve_handle* h, int n_claims) {
   ks::FastRecordArgs a{h->pv, h->ws, h->fw};
   for (int c = 0; c < n_claims; ++c) ks::fast_record_body<ks::Wave>(c, a);
 }
+static void be_launch_pack_fast_batch(ksolve_handle** hs, int n) {
+  for (int i = 0; i < n; ++i) { be_tic(hs[i], ksi::T_PACK); be_launch_pack_fast(hs[i]); be_toc(hs[i], ksi::T_PACK); }
+}
 static void be_launch_pack_batch(ksolve_handle** hs, int n) {
   for (int i = 0; i < n; ++i) { be_tic(hs[i], ksi::T_PACK); be_launch_pack(hs[i]); be_toc(hs[i], ksi::T_PACK); }
 }

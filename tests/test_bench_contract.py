@@ -32,7 +32,7 @@ def _env():
 def test_single_rank_line(oracle):
     emu = parity.build_emu()
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--pods", "3000", "--types", "60", "--cpu-sample", "1500", "--cpu-runs", "3",
-           "--topology-pods", "400", "--batch-problems", "3", "--batch-pods", "400", "--solver-lib", emu]
+           "--topology-pods", "400", "--components-pods", "4000", "--components-types", "60", "--components-calibration-pods", "4000", "--batch-problems", "3", "--batch-pods", "400", "--solver-lib", emu]
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = _json_line(r.stdout)
@@ -40,6 +40,8 @@ def test_single_rank_line(oracle):
     assert line["engine"] == "cursor" and line["parity"]["oracle_pin"] is None and len(line["parity"]["results_digest"]) == 64
     assert line["config2_topology"]["pods"] == 400 and line["config2_topology"]["value"] > 0 and line["config2_topology"]["engine"] == "general"
     assert line["packing"]["per_instance_type"]["launch_types_used"] >= 1
+    cc = line["config3_components"]
+    assert cc["components"] == 16 and cc["pods"] == 4000 and cc["engines"] == ["cursor"] and abs(cc["calibration"]["cost_rel_delta"]) < 0.05
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak" and line["vs_baseline"] is None
     assert line["higher_is_better"] is True and line["dtype"] == "int64" and "workload" in line["config"] and "TEST HOOK" in line["data"]
     want = oracle.solve(fx.config2(pods=3000, n_types=60, seed=42))
@@ -59,7 +61,7 @@ def test_two_ranks_under_the_drivers_launcher(oracle):
     emu = parity.build_emu()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--pods", "2500", "--types", "60", "--solver-lib", emu]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--pods", "2500", "--types", "60", "--components-pods", "0", "--solver-lib", emu]
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = _json_line(r.stdout)

@@ -207,3 +207,21 @@ def test_repeated_solves_on_one_handle_are_identical(emu):
     a, b = s.Solve(), s.Solve()
     parity.assert_same_results(a, b)
     assert parity.results_digest(a)[0] == parity.results_digest(b)[0]
+
+
+def test_batched_launch_mixes_engines(oracle, emu):
+    """ksolve_solve_batch: problems of the cursor engine's shape run on it (one block each), a problem it hands back (an
+    unschedulable pod) and a problem outside its shape (topology) run on the general engine's batched launch — one call,
+    every Results document equal to the oracle's."""
+    from karpenter_amd.scheduling import SolveBatch
+    its = fx.fake_instance_types(8)
+    probs = [fx.config2(pods=1500, n_types=60, seed=70 + i) for i in range(3)]
+    probs.append(fx.problem(its, [fx.node_pool()], [fx.pod(requests={"cpu": "1"}) for _ in range(20)] + [fx.pod(requests={"memory": "2Ti"})]))
+    probs.append(fx.problem(its, [fx.node_pool()], [fx.pod(labels={"a": "b"}, topology_spread=[fx.spread(fx.ZONE, {"a": "b"})]) for _ in range(6)]))
+    got = SolveBatch([NewScheduler(p, solver_lib=emu) for p in probs])
+    assert [g["counters"]["engine"] for g in got] == ["cursor", "cursor", "cursor", "general", "general"]
+    assert got[3]["counters"]["engineFallbackReason"] == 27
+    for g, p in zip(got, probs):
+        parity.assert_same_results(g, oracle.solve(p))
+    with pytest.raises(Unsupported, match="cursor engine"):
+        SolveBatch([NewScheduler(with_engine(probs[3], "cursor"), solver_lib=emu), NewScheduler(probs[0], solver_lib=emu)])

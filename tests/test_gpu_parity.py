@@ -341,6 +341,34 @@ def test_plain_c_example_on_the_device(tmp_path):
     assert p.stdout.decode().strip() == test_abi.EXAMPLE_OUTPUT
 
 
+def test_balanced_consolidation_scoring_and_validator_on_the_device(oracle):
+    """SURVEY §8 f-4 on the GPU: Balanced-consolidation scoring (balanced.go:47-183) gates commands whose simulations are
+    device solves; the single-node scan, the multi-node binary search (same probe sequence) and the validator replay
+    (validation.go:297-357) give what they give with the oracle's solves."""
+    from karpenter_amd import disruption as dz
+    cluster = dz.make_cluster(n_nodes=40, pods_per_node=5, seed=11)
+    cluster["nodePools"][0]["consolidationPolicy"] = dz.BALANCED
+    for n in cluster["nodes"][::3]:
+        for p in n["pods"]:
+            p["priority"] = 1000000000          # eviction cost 10 each: expensive to disrupt
+    cands = dz.sort_candidates(cluster, cluster["nodes"])
+    ev = dz.BalancedEvaluator(cluster, dz.compute_nodepool_totals(cluster, cands))
+    dev = lambda p: NewScheduler(p).Solve()
+    keys = ("decision", "candidates", "replacement", "replacementCapacityType")
+    a = dz.single_node_consolidation(cluster, cands, dev, ev)
+    b = dz.single_node_consolidation(cluster, cands, oracle.solve, ev)
+    assert {k: a.get(k) for k in keys} == {k: b.get(k) for k in keys}
+    assert a["decision"] != dz.NOOP and a["scores"]["default"].approved()
+    assert a["scores"]["default"].score() == b["scores"]["default"].score()      # float arithmetic on identical inputs
+    ma, pa = dz.first_n_consolidation_option(cluster, cands, dev, evaluator=ev)
+    mb, pb = dz.first_n_consolidation_option(cluster, cands, oracle.solve, evaluator=ev)
+    assert pa == pb and {k: ma.get(k) for k in keys} == {k: mb.get(k) for k in keys}
+    chosen = [c for c in cands if c["name"] in a["candidates"]]
+    assert dz.validate_command(cluster, chosen, a, dev) is None
+    shrunk = dict(cluster, nodes=[n for n in cluster["nodes"] if n["name"] in a["candidates"]])
+    assert dz.validate_command(shrunk, list(shrunk["nodes"]), a, dev) == dz.validate_command(shrunk, list(shrunk["nodes"]), a, oracle.solve)
+
+
 # ---- parity at the benchmarked sizes (VERDICT r1 item 2) ------------------------------------------------------------
 # The oracle needs hours at these sizes, so it ran OFFLINE in the CPU container (tests/golden/make_fullsize_digests.py)
 # and committed a digest of its canonical Results per configuration; here the device solves the same seeded problem and
