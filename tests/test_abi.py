@@ -94,11 +94,11 @@ def test_go_shim_names_every_entry_point():
 EXAMPLE_OUTPUT = "claims=1 [pods=5 its=0x2 cpu=7500 price=0.40] assignment=00000"
 
 
-def build_example(tmp_path, lib_dir, lib_name):
-    """examples/ksolve_min.c: the C ABI used from plain C (what a cgo shim does), linked against `lib_name` in `lib_dir`."""
+def build_example(tmp_path, lib_dir, lib_name, source="ksolve_min.c"):
+    """examples/*.c: the C ABI used from plain C (what a cgo shim does), linked against `lib_name` in `lib_dir`."""
     import subprocess
-    exe = str(tmp_path / ("ksolve_min_" + lib_name))
-    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "ksolve_min.c"), "-o", exe,
+    exe = str(tmp_path / (source[:-2] + "_" + lib_name))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", source), "-o", exe,
                            "-L", lib_dir, "-l" + lib_name, "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib"])
     return exe
 
@@ -113,6 +113,60 @@ def test_plain_c_example_against_the_emulation(built, tmp_path):
     emu = parity.build_emu()
     exe = build_example(tmp_path, os.path.dirname(emu), "ksolve_emu")
     assert subprocess.check_output([exe]).decode().strip() == EXAMPLE_OUTPUT
+
+
+EXAMPLE2_OUTPUT = "claims=1 [pods=2 its=0x1 zone=0x2 cpu=2000 price=0.20] assignment=-2,0,-2,0 errors=0000"
+
+
+def example2_problem():
+    """examples/ksolve_nodes_topology.c built with the Python fixtures instead (for the oracle)."""
+    from karpenter_amd import fixtures as fx
+    it = fx.fake_instance_type("m", {"cpu": "4", "memory": "8Gi", "pods": "10"},
+                               offerings=[fx.offering("on-demand", "zone-a", 0.20), fx.offering("on-demand", "zone-b", 0.20)])
+    it["overhead"] = {"cpu": "100m"}
+    lab = {"app": "web"}
+    pods = [fx.pod(uid=f"00000000-0000-0000-0000-{i + 1:012d}", labels=lab, requests={"cpu": "1", "memory": "512Mi"},
+                   topology_spread=[fx.spread(fx.ZONE, lab)]) for i in range(4)]
+    node = fx.state_node("node-1", it, "zone-a", used={"cpu": "1900m", "memory": "4Gi", "pods": "5"})
+    return fx.problem([it], [fx.node_pool()], pods, state_nodes=[node])
+
+
+def test_plain_c_example_with_an_existing_node_and_a_topology_group(built, oracle, tmp_path):
+    """examples/ksolve_nodes_topology.c: a desc with an existing node and a topology group filled in by hand (what
+    go/ksolve_flatten.go emits) against the emulation; the same problem from the fixtures through the oracle gives that packing."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity
+    emu = parity.build_emu()
+    exe = build_example(tmp_path, os.path.dirname(emu), "ksolve_emu", "ksolve_nodes_topology.c")
+    assert subprocess.check_output([exe]).decode().strip() == EXAMPLE2_OUTPUT
+    want = oracle.solve(example2_problem())
+    uid = lambda i: f"00000000-0000-0000-0000-{i + 1:012d}"
+    assert not want["podErrors"] and len(want["newNodeClaims"]) == 1
+    assert want["newNodeClaims"][0]["pods"] == [uid(1), uid(3)]
+    assert [e["pods"] for e in want["existingNodes"] if e["pods"]] == [[uid(0), uid(2)]]
+    zone = [r for r in want["newNodeClaims"][0]["requirements"] if r["key"] == "topology.kubernetes.io/zone"][0]
+    assert zone["operator"] == "In" and zone["values"] == ["zone-b"]
+
+
+def test_go_binding_uses_only_fields_the_header_declares():
+    """go/ksolve_*.go cannot be compiled here (no Go toolchain); what can be checked is that every field of the C structs
+    they touch exists in include/ksolve.h under that name (cgo spells the C field `type` as `_type`)."""
+    header = open(os.path.join(ROOT, "include", "ksolve.h")).read()
+    fields = set(re.findall(r"\b([a-z_0-9]+)\s*(?:\[[^\]]*\])?\s*[;,]", header)) | set(re.findall(r"\*\s*([a-z_0-9]+)\s*[;,]", header))
+    used = set()
+    for f in ("ksolve_flatten.go", "ksolve_rehydrate.go", "ksolve_shim.go"):
+        text = open(os.path.join(ROOT, "go", f)).read()
+        assert "//go:build cgo && ksolve" in text and "\npackage scheduling\n" in text, f
+        for var in ("desc", "t", "out", "f.opts", "cl", "res", "f.desc", "rs\\[j\\]"):
+            used |= set(re.findall(r"(?<![\w.])" + var + r"\.([a-z_][a-z_0-9]*)\b", text))
+    used = {u[1:] if u.startswith("_") else u for u in used}
+    go_only = {"add", "c", "free", "flat", "observe", "seal", "key", "value", "close", "handle", "s", "mask", "defined", "complement"} - fields
+    missing = sorted(u for u in used - fields - go_only if "_" in u or u in ("n", "type", "key", "status", "impl"))
+    assert not missing, missing
+    consts = set(re.findall(r"C\.(KSOLVE_[A-Z_]+)", "".join(open(os.path.join(ROOT, "go", f)).read() for f in os.listdir(os.path.join(ROOT, "go")))))
+    assert consts and all(c in header for c in consts), consts
 
 
 def test_plain_c_example_refuses_without_a_gpu(built, tmp_path):

@@ -328,17 +328,19 @@ def test_config4_components_and_cluster_sweep(oracle):
         parity.assert_same_results(g["results"], w["results"])
 
 
-def test_plain_c_example_on_the_device(tmp_path):
-    """examples/ksolve_min.c linked against karpenter_amd/libksolve.so: the C ABI from plain C, no Python in the path."""
+@pytest.mark.parametrize("source,expected", [("ksolve_min.c", "EXAMPLE_OUTPUT"), ("ksolve_nodes_topology.c", "EXAMPLE2_OUTPUT")])
+def test_plain_c_example_on_the_device(tmp_path, source, expected):
+    """examples/*.c linked against karpenter_amd/libksolve.so: the C ABI from plain C, no Python in the path (the second
+    one hands over an existing node and a topology group, the shapes go/ksolve_flatten.go emits)."""
     import subprocess
     import test_abi
     try:
-        exe = test_abi.build_example(tmp_path, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "karpenter_amd"), "ksolve")
+        exe = test_abi.build_example(tmp_path, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "karpenter_amd"), "ksolve", source)
     except (subprocess.CalledProcessError, FileNotFoundError) as e:      # no C toolchain on this box: nothing to say about the solver
         pytest.skip(f"cannot build the C example here: {e}")
     p = subprocess.run([exe], capture_output=True)
     assert p.returncode == 0, p.stderr.decode()
-    assert p.stdout.decode().strip() == test_abi.EXAMPLE_OUTPUT
+    assert p.stdout.decode().strip() == getattr(test_abi, expected)
 
 
 def test_balanced_consolidation_scoring_and_validator_on_the_device(oracle):
