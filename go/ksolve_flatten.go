@@ -374,12 +374,14 @@ func flatten(ctx context.Context, s *Scheduler, pods []*corev1.Pod, maxSteps int
 		d.observe(it.Requirements)
 		for _, o := range it.Offerings {
 			d.observe(o.Requirements)
-			if len(o.CapacityOverride) > 0 || o.OverheadOverride != nil {
-				return nil, fmt.Errorf("%w: offering capacity / overhead overrides", ErrKSolveUnsupported)
+			if (len(o.CapacityOverride) > 0 || o.OverheadOverride != nil) && o.CapacityType() == v1.CapacityTypeReserved {
+				return nil, fmt.Errorf("%w: capacity / overhead overrides on a reserved offering", ErrKSolveUnsupported)
 			}
 		}
 		q.observe(it.Capacity)
-		q.observe(it.Allocatable())
+		for _, g := range it.AllocatableOfferingsList() { // base group first, then one group per distinct override pair (types.go:222-269)
+			q.observe(g.Allocatable)
+		}
 	}
 	for _, t := range s.nodeClaimTemplates {
 		d.observe(t.Requirements)
@@ -458,6 +460,11 @@ func flatten(ctx context.Context, s *Scheduler, pods []*corev1.Pod, maxSteps int
 	}
 	alloc, capacity := make([]int64, nr*nIT), make([]int64, nr*nIT)
 	avail, price := make([]uint64, nIT), make([]float64, nIT*64)
+	baseAvail := make([]uint64, nIT)
+	var xgIT []uint32
+	var xgAvail []uint64
+	var xgAlloc [][]int64 // per extra group: nr values
+	cellOf := func(o *cloudprovider.Offering) int { return d.valIndex[keyZone][o.Zone()]*4 + d.valIndex[keyCT][o.CapacityType()] }
 	itReqs := &reqTable{d: d}
 	for i, it := range f.its {
 		if err := q.vector(it.Allocatable(), alloc, nIT, i); err != nil {
@@ -467,15 +474,32 @@ func flatten(ctx context.Context, s *Scheduler, pods []*corev1.Pod, maxSteps int
 			return nil, err
 		}
 		itReqs.add(it.Requirements)
-		for _, o := range it.Offerings {
-			if !o.Available || o.CapacityType() == v1.CapacityTypeReserved { // reserved offerings travel in their own CSR (below)
+		for _, o := range it.Offerings { // reserved offerings sit in their cell too and, in detail, in their own CSR (below)
+			if !o.Available {
 				continue
 			}
-			cell := d.valIndex[keyZone][o.Zone()]*4 + d.valIndex[keyCT][o.CapacityType()]
+			cell := cellOf(o)
 			if avail[i]&(1<<uint(cell)) == 0 || o.Price < price[i*64+cell] {
 				price[i*64+cell] = o.Price
 			}
 			avail[i] |= 1 << uint(cell)
+		}
+		// the reference has already grouped the available offerings by override (AllocatableOfferingsList): group 0 is the
+		// base group (it_allocatable above), every other group becomes one override row
+		for g, group := range it.AllocatableOfferingsList() {
+			var cells uint64
+			for _, o := range group.Offerings {
+				cells |= 1 << uint(cellOf(o))
+			}
+			if g == 0 {
+				baseAvail[i] = cells
+				continue
+			}
+			row := make([]int64, nr)
+			if err := q.vector(group.Allocatable, row, 1, 0); err != nil {
+				return nil, err
+			}
+			xgIT, xgAvail, xgAlloc = append(xgIT, uint32(i)), append(xgAvail, cells), append(xgAlloc, row)
 		}
 	}
 	// reserved offerings: a CSR per instance type; the reservation index is the id's value index in ReservationIDLabel's
@@ -521,6 +545,20 @@ func flatten(ctx context.Context, s *Scheduler, pods []*corev1.Pod, maxSteps int
 	desc.it_allocatable, desc.it_capacity = cI64(a, alloc), cI64(a, capacity)
 	desc.it_reqs = itReqs.c(a)
 	desc.it_offering_avail, desc.it_offering_price = cU64(a, avail), cF64(a, price)
+	if nx := len(xgIT); nx > 0 {
+		if nx > int(C.KSOLVE_MAX_OVERRIDE_GROUPS) {
+			return nil, fmt.Errorf("%w: %d offering override groups", ErrKSolveUnsupported, nx)
+		}
+		soa := make([]int64, nr*nx)
+		for e, row := range xgAlloc {
+			for r, v := range row {
+				soa[r*nx+e] = v
+			}
+		}
+		desc.n_override_groups = C.uint32_t(nx)
+		desc.override_it, desc.override_allocatable, desc.override_avail = cU32(a, xgIT), cI64(a, soa), cU64(a, xgAvail)
+		desc.it_base_avail = cU64(a, baseAvail)
+	}
 	desc.n_zones, desc.n_captypes = C.uint32_t(nz), C.uint32_t(nct)
 
 	// ---- distinct taints: a pod's toleration mask and a template's / node's taint mask are bits over this list ----

@@ -24,13 +24,14 @@
 extern "C" {
 #endif
 
-#define KSOLVE_ABI_VERSION 4
+#define KSOLVE_ABI_VERSION 5
 #define KSOLVE_MAX_KEYS 32        /* requirement keys per problem (one bit each in the u32 flag words) */
 #define KSOLVE_MAX_RES 8          /* resource dimensions */
 #define KSOLVE_MAX_TEMPLATES 32   /* NodeClaimTemplates (NodePools that survived prefiltering) */
 #define KSOLVE_MAX_ITWORDS 32     /* ceil(n_instance_types / 64) */
 #define KSOLVE_MAX_ZONES 16       /* distinct offering zones  */
 #define KSOLVE_MAX_CAPTYPES 4     /* distinct offering capacity types */
+#define KSOLVE_MAX_OVERRIDE_GROUPS 4096 /* extra allocatable groups (offering overrides) per problem */
 #define KSOLVE_MAX_TOPO_GROUPS 1024 /* topology groups per problem; pod group masks take ceil(n/64) words */
 
 typedef enum {
@@ -132,6 +133,17 @@ typedef struct {
   const double* it_offering_price;   /* n_its * 64 */
   uint32_t n_zones, n_captypes;    /* zone_idx / ct_idx are value indices in key_zone / key_capacity_type dictionaries */
 
+  /* ---- offering capacity / overhead overrides (types.go:202-269): an instance type whose AVAILABLE offerings carry a
+   *      CapacityOverride / OverheadOverride has one more AllocatableOfferings group per distinct override pair, behind the
+   *      base group (it_allocatable + the offerings without overrides). fits() accepts the type when SOME group both holds
+   *      the requests and has an offering compatible with the requirements (nodeclaim.go:624-638). it_offering_avail /
+   *      it_offering_price stay the union over all groups (hasOffering, prices). n_override_groups == 0: nothing below is read. ---- */
+  uint32_t n_override_groups;            /* extra groups over all instance types, <= KSOLVE_MAX_OVERRIDE_GROUPS */
+  const uint32_t* override_it;           /* n_override_groups : the instance type the group belongs to */
+  const int64_t* override_allocatable;   /* n_res * n_override_groups (SoA) : computeAllocatable(override) (types.go:271-294) */
+  const uint64_t* override_avail;        /* n_override_groups : cells (zone_idx*4 + ct_idx) of the group's available offerings */
+  const uint64_t* it_base_avail;         /* n_its : cells of the available offerings WITHOUT overrides (the base group) */
+
   /* ---- templates: NodeClaimTemplate per NodePool, in OrderByWeight order (nodepool.go:161-171) ---- */
   uint32_t n_templates;
   ksolve_reqsets tmpl_reqs;        /* nodeclaimtemplate.go:66-94 */
@@ -177,6 +189,16 @@ typedef struct {
   const uint64_t* pod_uid_lo;
   const uint8_t* pod_is_pending;   /* n_pods : Status.Phase == Pending (scheduler.go:628) */
   const uint8_t* pod_from_deleting_node; /* n_pods */
+
+  /* ---- host ports (hostportusage.go:39-117): bit masks over the problem's distinct <hostIP, hostPort, protocol> triples
+   *      (<= 64). A pod joins a bin only when none of its triples matches (same protocol and port, equal IPs or one of them
+   *      unspecified) a triple in use there: an existing node's (existingnode.go:87-93), or — per daemon-overhead group —
+   *      the group's daemon pods' plus the pods already on the NodeClaim (nodeclaim.go:256-259, :562-565).
+   *      pod_host_ports == NULL: no pod of the problem binds a host port and nothing below is read. ---- */
+  const uint64_t* pod_host_ports;          /* n_pod_rows : triples the pod binds */
+  const uint64_t* pod_host_port_conflicts; /* n_pod_rows : every triple of the problem that matches one of the pod's */
+  const uint64_t* node_host_ports;         /* n_nodes : triples in use on the node (StateNode.HostPortUsage); may be NULL */
+  const uint64_t* daemon_group_host_ports; /* n_groups : triples of the group's daemon pods (scheduler.go:990-993); may be NULL */
 
   /* ---- existing nodes, already in sortExistingNodes order (scheduler.go:845-858) ---- */
   uint32_t n_nodes;

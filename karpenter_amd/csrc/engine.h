@@ -57,6 +57,8 @@ struct Scratch {
   uint64_t cm[kMaxItWords];         // instance types compatible with the merged requirements
   uint64_t its[kMaxItWords];        // surviving InstanceTypeOptions
   uint64_t lim[kMaxItWords];        // instance types within NodePool limits
+  uint64_t xfit[kMaxItWords];       // instance types that an offering-override group makes fit (requests <= its allocatable, compatible offering)
+  uint64_t xoff[kMaxItWords];       // instance types with a compatible offering in an override group
   uint64_t cand[64];                // candidate list: (position << 32 | claim)
   uint64_t stage[128];              // live words of the class's dead row (two per lane: up to 8192 claims)
   int64_t total[kMaxRes];
@@ -142,6 +144,8 @@ struct Engine {
   bool cur_M = false;               // the class being placed has matching topology groups
   bool cur_rec = false;             // ... or is counted by some group when it is committed
   int cur_class = 0;
+  uint64_t cur_hp_use = 0, cur_hp_conf = 0;   // host-port triples the pod being placed binds / that match one of them
+  uint64_t bin_hp = 0;                        // host-port triples already bound by the pods of the candidate bin
   bool topo_reached = false;        // the last can_add got as far as the topology stage (its verdict is not cacheable)
 
   KS_DEV Engine(const ProblemView& p, Workspace& s, const LdsTables& l) : P(p), S(s), L(l), sc(*l.scratch), lay(p.lay) {
@@ -183,7 +187,7 @@ struct Engine {
     LdsTables& Lt = L;
     for (int r = 0; r < nr; ++r)
       W::for_n(np, [&](int it) { Lt.alloc[(size_t)r * np + it] = it < n_its ? Pv.it_alloc[(size_t)r * n_its + it] : INT64_MIN; });
-    W::for_n(np, [&](int it) { Lt.avail[it] = it < n_its ? Pv.it_off_avail[it] : 0; });
+    W::for_n(np, [&](int it) { Lt.avail[it] = it < n_its ? Pv.it_base_avail[it] : 0; });   // base group == every offering unless overrides exist
     W::for_n(iw, [&](int w) { Lt.allocok[w] = Pv.it_alloc_ok[w]; });
     const int nki = d.n_keys * iw;
     W::for_n(3 * nki, [&](int i) {
@@ -208,13 +212,13 @@ struct Engine {
     W::for_n(Pv.n_templates + 1, [&](int t) { sc.dg_first[t] = Pv.dg_first[t]; });
     W::for_n(Pv.n_dg * nr, [&](int i) { Lt.dg_ov[i] = Pv.dg_ov[i]; });
     W::for_n(Pv.n_dg * iw, [&](int i) { Lt.dg_its[i] = Pv.dg_its[i]; });
-    regs_ok = !FULL || (iw <= kRegIw && nr <= kRegNr);   // lite problems fit the register tables by definition
+    regs_ok = !FULL || (iw <= kRegIw && nr <= kRegNr && Pv.n_xg == 0);   // lite problems fit the register tables by definition
     if (regs_ok) {
       W::ballot([&](int l) {
 #pragma unroll
         for (int j = 0; j < kRegIw; ++j) {
           const int it = j * 64 + l;
-          RAV(l, j) = (j < iw && it < n_its) ? Pv.it_off_avail[it] : 0ull;
+          RAV(l, j) = (j < iw && it < n_its) ? Pv.it_base_avail[it] : 0ull;
 #pragma unroll
           for (int r = 0; r < kRegNr; ++r) RA(l, j, r) = (j < iw && r < nr && it < n_its) ? Pv.it_alloc[(size_t)r * n_its + it] : INT64_MIN;
         }
@@ -304,12 +308,22 @@ struct Engine {
       KS_DIAG(ctr.full_filters++);
       compat_mask(reqs);
       cells = offering_cells(reqs);
+    } else if (FULL && P.n_xg) {
+      cells = offering_cells(reqs);   // which GROUP of a type has the compatible offering decides which allocatable counts
     }
     FilterDiagAcc acc;
     const int nr = P.n_res, iw = P.it_words;
     const int g0 = (!FULL || tmpl < 0) ? 0 : sc.dg_first[tmpl], g1 = (!FULL || tmpl < 0) ? 1 : sc.dg_first[tmpl + 1];
+    // a daemon-overhead group whose host ports — its daemon pods' and the bin's own pods' (nodeclaim.go:256-259) — match
+    // one of the pod's is skipped as a whole (nodeclaim.go:562-565); the NewScheduler prefilter (tmpl < 0) has no pod
+    const bool hp = FULL && tmpl >= 0 && P.hp_on && cur_hp_conf != 0;
     bool any;
-    if (!FULL || g1 - g0 == 1) {
+    if (hp && g1 - g0 == 1 && ((bin_hp | P.dg_hp[g0]) & cur_hp_conf)) {
+      uint64_t* its_out = sc.its;
+      W::for_n(iw, [&](int w) { its_out[w] = 0; });
+      W::sync();
+      any = false;
+    } else if (!FULL || g1 - g0 == 1) {
       const int64_t* tot = total;
       if (FULL && tmpl >= 0 && ((P.dg_nonzero >> g0) & 1)) {
         const int64_t* ov = L.dg_ov + (size_t)g0 * nr;
@@ -323,6 +337,7 @@ struct Engine {
       W::for_n(iw, [&](int w) { its_out[w] = 0; });
       any = false;
       for (int g = g0; g < g1; ++g) {
+        if (hp && ((bin_hp | P.dg_hp[g]) & cur_hp_conf)) continue;
         const uint64_t* gm = L.dg_its + (size_t)g * iw;
         const int64_t* ov = L.dg_ov + (size_t)g * nr;
         uint64_t* gin = sc.gin;
@@ -372,6 +387,30 @@ struct Engine {
       return nonempty != 0;
     }
     bool& d_req = acc.d_req; bool& d_fit = acc.d_fit; bool& d_off = acc.d_off; bool& d_ro = acc.d_ro; bool& d_fo = acc.d_fo;
+    // offering-override groups (types.go:202-269): one lane per mask word collects the types that an EXTRA group lets
+    // through — requests within the group's allocatable (no negative dimension, resources.go:190) and an offering of
+    // that group compatible with the requirements (nodeclaim.go:624-638) — and the types with a compatible offering in one
+    const int nx = FULL ? P.n_xg : 0;
+    const uint64_t* xf = sc.xfit;
+    const uint64_t* xo = sc.xoff;
+    if (nx) {
+      uint64_t* wf = sc.xfit; uint64_t* wo = sc.xoff;
+      const ProblemView& Pv = P;
+      W::for_n(iw, [&](int w) {
+        uint64_t f = 0, o = 0;
+        for (int e = 0; e < nx; ++e) {
+          const uint32_t it = Pv.xg_it[e];
+          if ((int)(it >> 6) != w || !(Pv.xg_avail[e] & cells)) continue;
+          bool fit = true;
+          for (int r = 0; r < nr; ++r) { const int64_t a = Pv.xg_alloc[(size_t)r * nx + e]; fit = fit && a >= 0 && total[r] <= a; }
+          o |= 1ull << (it & 63);
+          if (fit) f |= 1ull << (it & 63);
+        }
+        wf[w] = f; wo[w] = o;
+      });
+      W::sync();
+    }
+    const bool offer = full || nx != 0;
     for (int w0 = 0; w0 < iw; w0 += 8) {
       const int n = iw - w0 < 8 ? iw - w0 : 8;
       // one lane per instance type, eight mask words per step; every allocatable / availability load of the step is in
@@ -380,14 +419,14 @@ struct Engine {
       const uint64_t* cmw = sc.cm;
       W::ballots8(n, [&](int l, int j) {
         int it = (w0 + j) * 64 + l;
-        int f = full ? (int)((Lt.avail[it] & cells) != 0) : 1;
+        int f = offer ? (int)((Lt.avail[it] & cells) != 0) : 1;
         for (int r = 0; r < nr; ++r) f &= (int)(total[r] <= Lt.alloc[(size_t)r * np + it]);
         return f != 0;
       }, [&](int j, uint64_t fit_and_off) {
         const int w = w0 + j;
         const uint64_t in = bin_its[w];
         const uint64_t cm = full ? cmw[w] : ~0ull;
-        const uint64_t itfits = in & Lt.allocok[w] & fit_and_off;
+        const uint64_t itfits = in & ((Lt.allocok[w] & fit_and_off) | (nx ? xf[w] : 0ull));
         const uint64_t keep = cm & itfits;
         KS_DIAG(ctr.it_evaluations += popc64(in));
         if (want_diag) { d_req |= (in & cm) != 0; d_fit |= itfits != 0; d_fo |= (itfits & ~cm) != 0; }
@@ -397,19 +436,19 @@ struct Engine {
       if (want_diag) {
         // InstanceTypeFilterError flags (nodeclaim.go:585-592) need resource fit and offering separately (failure path only)
         W::ballots8(n, [&](int l, int j) { return (Lt.avail[(w0 + j) * 64 + l] & cells) != 0; },
-                    [&](int j, uint64_t offb) { W::store(&sc.lim[w0 + j], offb); });
+                    [&](int j, uint64_t offb) { W::store(&sc.lim[w0 + j], (uint64_t)(offb | (nx ? xo[w0 + j] : 0ull))); });
         W::sync();
         W::ballots8(n, [&](int l, int j) {
           int it = (w0 + j) * 64 + l;
-          int f = 1;
+          int f = nx ? (int)((Lt.avail[it] & cells) != 0) : 1;    // with override groups the base allocatable only counts with a base offering
           for (int r = 0; r < nr; ++r) f &= (int)(total[r] <= Lt.alloc[(size_t)r * np + it]);
           return f != 0;
         }, [&](int j, uint64_t fitb) {
           const int w = w0 + j;
           const uint64_t in = bin_its[w];
           const uint64_t cm = full ? cmw[w] : ~0ull;
-          const uint64_t off = full ? (in & sc.lim[w]) : in;
-          const uint64_t itfits = in & Lt.allocok[w] & fitb & off;
+          const uint64_t off = offer ? (in & sc.lim[w]) : in;
+          const uint64_t itfits = (in & Lt.allocok[w] & fitb & off) | (nx ? (in & xf[w]) : 0ull);
           d_off |= off != 0;
           d_ro |= (in & cm & off & ~itfits) != 0;
         });
@@ -869,6 +908,7 @@ struct Engine {
     const int nr = lay.nr;
     ctr.bin_evaluations++;
     topo_reached = false;
+    if (FULL && P.hp_on) bin_hp = claim_id >= 0 ? S.c_hp[claim_id] : 0ull;
     unsigned long long ta = W::clock();
     const uint64_t bin_taints = sc.tmpl_taints[lo32(bin[lay.c_meta()]) & 31u];
     if (bin_taints & ~sc.cls[lay.k_tol()]) return E_TAINTS;                              // Taints.ToleratesPod — nodeclaim.go:126
@@ -973,7 +1013,7 @@ struct Engine {
           int64_t mx = W::reduce_max_i64(np, [&](int it) { return ((sits[it >> 6] & gm[it >> 6]) >> (it & 63)) & 1 ? Lt.alloc[(size_t)r * np + it] : INT64_MIN; });
           if (mx != INT64_MIN && mx - Lt.dg_ov[(size_t)g * nr + r] > best) best = mx - Lt.dg_ov[(size_t)g * nr + r];
         }
-        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(best - ntot[r]);
+        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(best - ntot[r] + P.xg_bonus[r]);
       }
     } else if (recompute_head && regs_ok) {
       // headroom = max allocatable over the surviving instance types - total, from the register tables
@@ -995,7 +1035,7 @@ struct Engine {
       // headroom = max allocatable over the surviving instance types - total
       for (int r = 0; r < nr; ++r) {
         int64_t mx = W::reduce_max_i64(np, [&](int it) { return ((sits[it >> 6] >> (it & 63)) & 1) ? Lt.alloc[(size_t)r * np + it] : INT64_MIN; });
-        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(mx - (FULL ? Lt.dg_ov[(size_t)hg0 * nr + r] : 0) - ntot[r]);
+        if (W::leader()) o[ly.c_head() + r] = (uint64_t)(mx - (FULL ? Lt.dg_ov[(size_t)hg0 * nr + r] : 0) - ntot[r] + (FULL ? P.xg_bonus[r] : 0));   // an override group may hold more than the base allocatable
       }
     } else {
       const int64_t* bh = (const int64_t*)(bin + ly.c_head());
@@ -1102,6 +1142,7 @@ struct Engine {
     const bool out_cold = FULL && changed && (sc.out[ly.c_f1()] != 0 || (m2 & 2u));
     if (FULL && cur_rec) topo_record(sc.tmpl_taints[tmpl & 31u], out_ref(changed ? sc.out_cold : sc.claim_cold), 0, c);   // nodeclaim.go:252-253
     if (FULL && P.reserved_on) commit_reservations(c, false);
+    if (FULL && P.hp_on && cur_hp_use) W::store(&S.c_hp[c], (uint64_t)(S.c_hp[c] | cur_hp_use));   // HostPortUsage.Add — nodeclaim.go:256-259
     finish_record(c, sc.claim, its_changed, tmpl, np + 1, lo32(sc.claim[ly.c_meta2()]), m2, out_cold);
     order.increment(c);
     if (changed) reset_column(c);
@@ -1430,6 +1471,7 @@ struct Engine {
       const bool cold = sc.out[ly.c_f1()] != 0 || (tm2 & 2u);
       if (FULL && cur_rec) topo_record(sc.tmpl_taints[t & 31], out_ref(sc.out_cold), 0, c);
       if (FULL && P.reserved_on) commit_reservations(c, true);
+      if (FULL && P.hp_on) W::store(&S.c_hp[c], cur_hp_use);
       uint32_t relaxed = 0;
       if (minv_lowered) {
         // karpenter.sh/nodeclaim-min-values-relaxed — scheduler.go:763-772
@@ -1474,6 +1516,7 @@ struct Engine {
     const uint32_t kdef = lo32(cls[ly.k_f0()]), kcomp = hi32(cls[ly.k_f0()]);
     const uint32_t khg = lo32(cls[ly.k_f1()]), khl = hi32(cls[ly.k_f1()]);
     const uint64_t ktol = cls[ly.k_tol()];
+    const uint64_t khpc = Pv.hp_on ? cur_hp_conf : 0ull;
     const int64_t* req = (const int64_t*)(cls + ly.k_req());
     // keys on which the pod's operator is NotIn / DoesNotExist (may be undefined on the node, requirements.go:188)
     uint32_t kneg = 0;
@@ -1497,6 +1540,7 @@ struct Engine {
         if (!((todo >> l) & 1)) return false;
         const int e_ = base + l;
         if (Pv.node_taints[e_] & ~ktol) return false;                                    // taints — existingnode.go:83
+        if (khpc && (Sw.n_hp[e_] & khpc)) return false;                                  // host ports — existingnode.go:87-93
         bool fit = true;                                                                   // resources.Fits — :96
         for (int r = 0; r < nr; ++r) { int64_t rem = Sw.n_remaining[(size_t)r * ne + e_]; fit = fit && rem >= 0 && req[r] <= rem; }
         if (!fit) return false;
@@ -1563,6 +1607,7 @@ struct Engine {
       if (cur_rec) topo_record(Pv.node_taints[en], m.ref(), 1, en);              // existingnode.go:184
       int64_t* nrem = S.n_remaining;
       W::for_n(nr, [&](int r) { nrem[(size_t)r * ne + en] -= req[r]; });                  // resources.SubtractFrom — existingnode.go:175
+      if (Pv.hp_on && cur_hp_use) W::store(&S.n_hp[en], (uint64_t)(S.n_hp[en] | cur_hp_use));   // existingnode.go:178
       const uint32_t np_ = S.n_npods[en];
       W::store(&S.n_npods[en], np_ + 1);
       W::store(&S.assign[pod], (int32_t)(-2 - en));
@@ -1594,6 +1639,7 @@ struct Engine {
     load_words(sc.cls, P.cls_hot + (size_t)k * hw, hw);
     if (FULL && (sc.cls[lay.k_f1()] != 0 || (lo32(sc.cls[lay.k_meta()]) & 1u))) load_words(sc.cls_cold, P.cls_cold + (size_t)k * lay.cold_words(), lay.cold_words());
     cur_class = k;
+    if (FULL && P.hp_on) { cur_hp_use = P.cls_hp[(size_t)k * 2]; cur_hp_conf = P.cls_hp[(size_t)k * 2 + 1]; }
 
     if (FULL && P.topo.n_groups) {
       const TopoView& T = P.topo;
@@ -1729,6 +1775,7 @@ struct Engine {
       W::for_n(lay.rw * ne, [&](int i) { Sw.n_mask[i] = Sw.n_mask0[i]; });
       W::for_n(lay.nr * ne, [&](int i) { Sw.n_remaining[i] = Sw.n_remaining0[i]; });
       W::for_n(ne, [&](int i) { Sw.n_defined[i] = Sw.n_defined0[i]; Sw.n_complement[i] = Sw.n_complement0[i]; Sw.n_npods[i] = 0; });
+      if (P.hp_on) { const uint64_t* h0 = P.node_hp0; W::for_n(ne, [&](int i) { Sw.n_hp[i] = h0 ? h0[i] : 0ull; }); }
     }
     if (FULL && P.topo.n_groups) {
       const TopoView& T = P.topo;

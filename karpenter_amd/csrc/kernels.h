@@ -85,6 +85,8 @@ struct RowArgs {
   const int64_t* requests;  // [n_res][n_rows]
   ReqTable reqs, strict;
   const uint64_t* tolerates;
+  const uint64_t* host_ports;     // [n_rows][2] host-port triples bound | matched (nullptr: no pod binds one)
+  uint64_t* cls_host_ports;       // [n_classes][2]
   const uint64_t* topo_owned;     // [n_rows][topo_words] or nullptr
   const uint64_t* topo_selected;
   int topo_words;
@@ -150,6 +152,7 @@ KS_FN void row_hash_body(int row, const RowArgs& a) {
   h = hash_reqset(a.dict, h, a.reqs.at(a.dict, row));
   h = hash_reqset(a.dict, h, a.strict.at(a.dict, row));
   h = mix64(h, a.tolerates[row]);
+  if (a.host_ports) { h = mix64(h, a.host_ports[(size_t)row * 2]); h = mix64(h, a.host_ports[(size_t)row * 2 + 1]); }
   if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) { h = mix64(h, a.topo_owned[(size_t)row * a.topo_words + w]); h = mix64(h, a.topo_selected[(size_t)row * a.topo_words + w]); }
   if (h == 0) h = 1;
   a.row_hash[row] = h;
@@ -167,6 +170,7 @@ KS_FN bool rows_equal(const RowArgs& a, int x, int y) {
   if (!equal_reqset(a.dict, a.reqs.at(a.dict, x), a.reqs.at(a.dict, y))) return false;
   if (!equal_reqset(a.dict, a.strict.at(a.dict, x), a.strict.at(a.dict, y))) return false;
   if (a.tolerates[x] != a.tolerates[y]) return false;
+  if (a.host_ports && (a.host_ports[(size_t)x * 2] != a.host_ports[(size_t)y * 2] || a.host_ports[(size_t)x * 2 + 1] != a.host_ports[(size_t)y * 2 + 1])) return false;
   if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) {
     if (a.topo_owned[(size_t)x * a.topo_words + w] != a.topo_owned[(size_t)y * a.topo_words + w]) return false;
     if (a.topo_selected[(size_t)x * a.topo_words + w] != a.topo_selected[(size_t)y * a.topo_words + w]) return false;
@@ -211,6 +215,7 @@ KS_FN void class_gather_body(int cls, const RowArgs& a) {
   copy_reqset(a.dict, a.cls_reqs, cls, a.reqs.at(a.dict, row));
   copy_reqset(a.dict, a.cls_strict, cls, a.strict.at(a.dict, row));
   a.cls_tolerates[cls] = a.tolerates[row];
+  if (a.host_ports) { a.cls_host_ports[(size_t)cls * 2] = a.host_ports[(size_t)row * 2]; a.cls_host_ports[(size_t)cls * 2 + 1] = a.host_ports[(size_t)row * 2 + 1]; }
   // packed records for the pack engine (RecLayout)
   const RecLayout& ly = a.lay;
   ReqRef q = a.reqs.at(a.dict, row);

@@ -220,6 +220,27 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   P.it_off_avail = up(h, d->it_offering_avail, d->n_its);
   P.it_off_price = up(h, d->it_offering_price, (size_t)d->n_its * 64);
   P.n_zones = d->n_zones; P.n_cts = d->n_captypes;
+  P.n_xg = (int)d->n_override_groups; P.xg_it = nullptr; P.xg_alloc = nullptr; P.xg_avail = nullptr; P.it_base_avail = P.it_off_avail;
+  for (int r = 0; r < 8; ++r) P.xg_bonus[r] = 0;
+  if (d->n_override_groups) {
+    // offering override groups (types.go:202-269)
+    const uint32_t nx = d->n_override_groups;
+    if (nx > KSOLVE_MAX_OVERRIDE_GROUPS) return fail(h, KSOLVE_ERR_UNSUPPORTED, "more than KSOLVE_MAX_OVERRIDE_GROUPS offering override groups");
+    if (!d->override_it || !d->override_allocatable || !d->override_avail || !d->it_base_avail) return fail(h, KSOLVE_ERR_INVALID, "override groups without their arrays");
+    for (uint32_t e = 0; e < nx; ++e) {
+      if (d->override_it[e] >= d->n_its) return fail(h, KSOLVE_ERR_INVALID, "override group of an unknown instance type");
+      if (d->override_avail[e] & ~d->it_offering_avail[d->override_it[e]]) return fail(h, KSOLVE_ERR_INVALID, "override group offering outside it_offering_avail");
+      for (uint32_t r = 0; r < d->n_res; ++r) {
+        const int64_t a = d->override_allocatable[(size_t)r * nx + e], b = d->it_allocatable[(size_t)r * d->n_its + d->override_it[e]];
+        if (a > b && a - b > P.xg_bonus[r]) P.xg_bonus[r] = a - b;
+      }
+    }
+    for (uint32_t i = 0; i < d->n_its; ++i) if (d->it_base_avail[i] & ~d->it_offering_avail[i]) return fail(h, KSOLVE_ERR_INVALID, "it_base_avail outside it_offering_avail");
+    P.xg_it = up(h, d->override_it, nx);
+    P.xg_alloc = up(h, d->override_allocatable, (size_t)d->n_res * nx);
+    P.xg_avail = up(h, d->override_avail, nx);
+    P.it_base_avail = up(h, d->it_base_avail, d->n_its);
+  }
   P.it_reqs = upload_reqs(h, d->it_reqs, d->n_its, req_words, d->n_keys);
   uint64_t* kv_has = dz<uint64_t>(h, (size_t)req_words * 64 * it_words);
   uint64_t* key_undef = dz<uint64_t>(h, (size_t)d->n_keys * it_words);
@@ -290,6 +311,15 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     P.dg_ov = up(h, ov.data(), ov.size());
     P.dg_its = up(h, gits.data(), gits.size());
     P.dg_nonzero = nonzero; P.dg_nonempty = nonempty;
+    // host ports: only matter when some pod binds one
+    P.hp_on = d->pod_host_ports ? 1 : 0; P.cls_hp = nullptr; P.dg_hp = nullptr; P.node_hp0 = nullptr;
+    if (P.hp_on) {
+      if (!d->pod_host_port_conflicts) return fail(h, KSOLVE_ERR_INVALID, "pod_host_ports without pod_host_port_conflicts");
+      std::vector<uint64_t> ghp((size_t)std::max(1, P.n_dg), 0);
+      if (d->tmpl_daemon_first && d->daemon_group_host_ports) for (int g = 0; g < P.n_dg; ++g) ghp[g] = d->daemon_group_host_ports[g];
+      P.dg_hp = up(h, ghp.data(), ghp.size());
+      if (d->n_nodes && d->node_host_ports) P.node_hp0 = up(h, d->node_host_ports, d->n_nodes);
+    }
   }
 
   {
@@ -317,6 +347,12 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   if (d->pod_strict_reqs.mask == d->pod_reqs.mask || d->pod_strict_reqs.mask == nullptr) R.strict = R.reqs;
   else R.strict = upload_reqs(h, d->pod_strict_reqs, d->n_pod_rows, req_words, d->n_keys);
   R.tolerates = up(h, d->pod_tolerates, d->n_pod_rows);
+  R.host_ports = nullptr; R.cls_host_ports = nullptr;
+  if (P.hp_on) {
+    std::vector<uint64_t> hp((size_t)d->n_pod_rows * 2);
+    for (uint32_t r = 0; r < d->n_pod_rows; ++r) { hp[(size_t)r * 2] = d->pod_host_ports[r]; hp[(size_t)r * 2 + 1] = d->pod_host_port_conflicts[r]; }
+    R.host_ports = up(h, hp.data(), hp.size());
+  }
   R.topo_words = (int)((d->topo.n + 63) / 64);
   R.topo_owned = d->topo.n ? up(h, d->pod_topo_owned, (size_t)d->n_pod_rows * R.topo_words) : nullptr;
   R.topo_selected = d->topo.n ? up(h, d->pod_topo_selected, (size_t)d->n_pod_rows * R.topo_words) : nullptr;
@@ -348,6 +384,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       h->ws.n_defined = dz<uint32_t>(h, ne); h->ws.n_complement = dz<uint32_t>(h, ne);
       h->ws.n_remaining = dz<int64_t>(h, (size_t)d->n_res * ne);
       h->ws.n_npods = dz<uint32_t>(h, ne);
+      h->ws.n_hp = P.hp_on ? dz<uint64_t>(h, ne) : nullptr;
       P.node_taints = up(h, d->node_taints, ne);
       std::vector<uint8_t> fl(ne);
       for (uint32_t e = 0; e < ne; ++e) fl[e] = (uint8_t)((d->node_initialized && d->node_initialized[e] ? 1 : 0) | (d->node_under_consolidate_after && d->node_under_consolidate_after[e] ? 2 : 0));
@@ -378,6 +415,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   // the lanes past the last claim of the last dimension's row read (and discard) up to 63 entries beyond it
   W.c_headroom = dz<int64_t>(h, (size_t)mc * d->n_res + 64);
   W.c_reserved = dz<uint64_t>(h, mc);
+  W.c_hp = P.hp_on ? dz<uint64_t>(h, mc) : nullptr;
   W.o_key = dz<uint32_t>(h, mc); W.o_ord = dz<uint32_t>(h, mc); W.o_pos = dz<uint32_t>(h, mc);
   W.queue = dz<uint32_t>(h, (size_t)d->n_pods + 1); W.last_len = dz<uint32_t>(h, d->n_pods);
   W.t_its = dz<uint64_t>(h, (size_t)d->n_templates * it_words);
@@ -522,7 +560,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     if (d->tmpl_reqs.min_values) for (size_t i = 0; i < (size_t)d->n_templates * d->n_keys; ++i) if (d->tmpl_reqs.min_values[i] >= 0) any_minv = true;
     const bool bounds = any_nonzero(d->pod_reqs.has_gte, d->n_pod_rows) || any_nonzero(d->pod_reqs.has_lte, d->n_pod_rows) ||
                         any_nonzero(d->tmpl_reqs.has_gte, d->n_templates) || any_nonzero(d->tmpl_reqs.has_lte, d->n_templates);
-    P.plain = (d->topo.n == 0 && d->n_nodes == 0 && !d->tmpl_daemon_first && !any_minv && !P.reserved_on && !bounds) ? 1 : 0;
+    P.plain = (d->topo.n == 0 && d->n_nodes == 0 && !d->tmpl_daemon_first && !any_minv && !P.reserved_on && !bounds && !d->n_override_groups && !P.hp_on) ? 1 : 0;
     P.lite = (P.plain && req_words <= 64 && it_words <= 8 && d->n_res <= 4) ? 1 : 0;
 #ifdef KSOLVE_NO_LITE
     P.lite = 0;   // A/B builds only
@@ -633,6 +671,7 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
     h->d_cls_strict = alloc_reqs(h, n_classes, h->req_words, h->n_keys);
     R.cls_reqs = h->d_cls_reqs; R.cls_strict = h->d_cls_strict;
     R.cls_tolerates = dz<uint64_t>(h, n_classes);
+    R.cls_host_ports = P.hp_on ? dz<uint64_t>(h, (size_t)n_classes * 2) : nullptr;
     R.cls_hot = dz<uint64_t>(h, (size_t)n_classes * P.lay.k_hot_words());
     R.cls_cold = dz<uint64_t>(h, (size_t)n_classes * P.lay.cold_words());
     R.cls_topo = h->has_topology ? dz<uint64_t>(h, (size_t)n_classes * 2 * R.topo_words) : nullptr;
@@ -649,6 +688,7 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
   P.n_classes = (int)n_classes;
   P.cls_requests = R.cls_requests; P.cls_reqs = as_const(h->d_cls_reqs); P.cls_strict = as_const(h->d_cls_strict);
   P.cls_tolerates = R.cls_tolerates;
+  P.cls_hp = R.cls_host_ports;
   P.cls_hot = R.cls_hot; P.cls_cold = R.cls_cold;
   P.topo.cls_topo = R.cls_topo;
   if (n_classes) be_fill(h, W.dead, 0, (size_t)n_classes * h->claim_words * 8);

@@ -128,6 +128,14 @@ struct ProblemView {
   const uint64_t* it_off_avail;  // [n_its] bit zone*4+ct
   const double* it_off_price;    // [n_its][64]
   int n_zones, n_cts;
+  // offering override groups (types.go:202-269): extra allocatable groups behind each type's base group. fits() passes a
+  // type when some group holds the requests and has a compatible offering (nodeclaim.go:624-638).
+  int n_xg;
+  const uint32_t* xg_it;         // [n_xg] owning instance type
+  const int64_t* xg_alloc;       // [n_res][n_xg]
+  const uint64_t* xg_avail;      // [n_xg] offering cells of the group
+  const uint64_t* it_base_avail; // [n_its] offering cells of the base group (== it_off_avail when n_xg == 0)
+  int64_t xg_bonus[8];           // per dimension: the most an override group adds over its type's base allocatable (headroom bound)
   // instance-type requirement index, built by the prepass kernel (k_build_it_index):
   const uint64_t* kv_has;        // [req_words*64][it_words] ITs whose requirement on the value's key Has(value) (incl. complements)
   const uint64_t* key_undef;     // [n_keys][it_words] ITs that do not define the key
@@ -154,6 +162,12 @@ struct ProblemView {
   const uint32_t* it_resv_first; // [n_its+1]
   const uint8_t *resv_zone, *resv_id;
   const double* resv_price;
+
+  // host ports (hostportusage.go): masks over the problem's distinct <ip, port, protocol> triples
+  int hp_on;                     // some pod binds a host port
+  const uint64_t* cls_hp;        // [n_classes][2] triples the class binds | triples that match one of them
+  const uint64_t* dg_hp;         // [n_dg] triples of each daemon-overhead group's daemon pods
+  const uint64_t* node_hp0;      // [n_nodes] triples in use on each existing node before the solve (null = none)
 
   int n_pods, n_rows;
   const int32_t* row_next;       // [n_rows] relaxation chain
@@ -203,6 +217,8 @@ struct Workspace {
   uint64_t* host_le;             // [n_host_groups][2][claim_words] claims whose per-claim counter of a hostname group is <= t-1 / <= t,
                                  //   t = maxSkew of a spread group, 0 of an anti-affinity group: the only two limits its pods ever test
   uint64_t* c_reserved;          // [max_claims] reservation ids held by each claim
+  uint64_t* c_hp;                // [max_claims] host-port triples bound by the claim's pods (null unless hp_on)
+  uint64_t* n_hp;                // [n_nodes] host-port triples in use on each existing node
   int64_t* c_headroom;           // [n_res][max_claims] SoA copy of the records' headroom: lane-per-claim prefilter of the scan
   // order (pdq_emul.h): lives in LDS while it fits (LdsPlan.order_cap), these are the HBM spill arrays
   uint32_t *o_key, *o_ord, *o_pos;

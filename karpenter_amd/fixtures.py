@@ -206,8 +206,9 @@ _uid_counter = [0]
 
 def pod(uid=None, name=None, namespace="default", labels=None, requests=None, node_selector=None, node_requirements=None,
         node_preferences=None, tolerations=None, topology_spread=None, pod_requirements=None, pod_preferences=None,
-        pod_anti_requirements=None, pod_anti_preferences=None, creation=0, phase="Pending", node_name=""):
-    """test.Pod — pkg/test/pods.go:88. node_requirements: list of NodeSelectorRequirement (one term) or list of terms."""
+        pod_anti_requirements=None, pod_anti_preferences=None, creation=0, phase="Pending", node_name="", host_ports=None):
+    """test.Pod — pkg/test/pods.go:88. node_requirements: list of NodeSelectorRequirement (one term) or list of terms.
+    host_ports: port numbers (PodOptions.HostPorts: TCP, no hostIP) or {"port", "ip", "protocol"} dicts."""
     if uid is None:
         _uid_counter[0] += 1
         uid = f"00000000-0000-0000-0000-{_uid_counter[0]:012d}"
@@ -215,6 +216,8 @@ def pod(uid=None, name=None, namespace="default", labels=None, requests=None, no
          "creationTimestamp": creation, "phase": phase, "nodeName": node_name}
     if node_selector:
         p["nodeSelector"] = dict(node_selector)
+    if host_ports:
+        p["hostPorts"] = [host_port(h) if not isinstance(h, dict) else host_port(**h) for h in host_ports]
     if node_requirements or node_preferences:
         na = {}
         if node_requirements:
@@ -235,6 +238,11 @@ def pod(uid=None, name=None, namespace="default", labels=None, requests=None, no
     if pod_anti_requirements or pod_anti_preferences:
         p["podAntiAffinity"] = {"required": pod_anti_requirements or [], "preferred": pod_anti_preferences or []}
     return p
+
+
+def host_port(port, ip="", protocol="TCP"):
+    """corev1.ContainerPort with a HostPort (scheduling.GetHostPorts, hostportusage.go:93-117: hostIP "" reads 0.0.0.0)."""
+    return {"port": int(port), "ip": ip, "protocol": protocol}
 
 
 def spread(key, labels, max_skew=1, when="DoNotSchedule", min_domains=None, taints_policy=None, affinity_policy=None):
@@ -295,7 +303,7 @@ def state_node_taints(taints, startup_taints=None, initialized=True, managed=Tru
 
 
 def state_node(name, instance_type, zone, capacity_type="on-demand", nodepool="default", used=None, taints=None, initialized=True,
-               extra_labels=None, under_consolidate_after=False, startup_taints=None):
+               extra_labels=None, under_consolidate_after=False, startup_taints=None, host_ports=None):
     """A state.StateNode as the scheduler reads it (existingnode.go:47-75): labels of a node launched from `instance_type`
     in `zone` (single-valued instance-type requirements become labels, like the fake/KWOK providers do on Create),
     Available() = allocatable - used, Capacity() incl. nodes: 1 (statenode.go:370-374)."""
@@ -317,8 +325,11 @@ def state_node(name, instance_type, zone, capacity_type="on-demand", nodepool="d
         a = nano(v) - nano(instance_type["overhead"].get(k, "0")) - nano((used or {}).get(k, "0"))
         avail[k] = f"{a}n"
     cap = dict(instance_type["capacity"]); cap["nodes"] = "1"
-    return {"name": name, "labels": labels, "taints": state_node_taints(taints, startup_taints, initialized, managed=True),
+    node = {"name": name, "labels": labels, "taints": state_node_taints(taints, startup_taints, initialized, managed=True),
             "available": avail, "capacity": cap, "initialized": initialized, "managed": True, "underConsolidateAfter": under_consolidate_after}
+    if host_ports:   # StateNode.HostPortUsage(): host ports of the pods bound to the node (statenode.go:489)
+        node["hostPorts"] = [host_port(h) if not isinstance(h, dict) else host_port(**h) for h in host_ports]
+    return node
 
 
 _M64 = (1 << 64) - 1
@@ -395,7 +406,8 @@ def launch(results, instance_types, pods, name_prefix="node"):
         used_q = {k: f"{int(round(v * 1000))}m" for k, v in used.items()}
         used_q["pods"] = str(len(members))
         extra = {r["key"]: r["values"][0] for r in c["requirements"] if not r["complement"] and len(r["values"]) == 1 and r["key"] != HOSTNAME}
-        node = state_node(name, by_name[it_name], labels[ZONE], labels[CAPACITY_TYPE], c["nodePool"], used=used_q, extra_labels=extra)
+        ports = [h for p in members for h in p.get("hostPorts", [])]
+        node = state_node(name, by_name[it_name], labels[ZONE], labels[CAPACITY_TYPE], c["nodePool"], used=used_q, extra_labels=extra, host_ports=ports)
         nodes.append(node)
         for p in members:
             bound.append(dict(p, phase="Running", nodeName=name))

@@ -321,7 +321,46 @@ struct Tsc {
 struct AffTerm { Selector sel; std::string key; std::vector<std::string> namespaces; bool resolved = false; };
 
 // ---- pod model (only what the flattener needs) ----
+// scheduling.HostPort (hostportusage.go:39-62); the IP in the canonical text net.ParseIP would print ("<nil>" when it
+// does not parse), hostIP "" read as 0.0.0.0 (hostportusage.go:103-106)
+struct HostPort {
+  std::string ip; int port; std::string protocol;
+  bool unspecified() const { return ip == "0.0.0.0" || ip == "::"; }
+  bool matches(const HostPort& o) const { return protocol == o.protocol && port == o.port && (ip == o.ip || unspecified() || o.unspecified()); }
+  bool operator==(const HostPort& o) const { return ip == o.ip && port == o.port && protocol == o.protocol; }
+};
+static std::string canonical_ip(std::string s) {
+  for (auto& c : s) c = (char)tolower((unsigned char)c);
+  if (s.rfind("::ffff:", 0) == 0 && s.find('.') != std::string::npos) s = s.substr(7);
+  if (s.find(':') != std::string::npos) {
+    bool zero = true;
+    for (char c : s) if (c != ':' && c != '0') zero = false;
+    return zero ? "::" : s;
+  }
+  int parts = 0, val = -1;
+  bool ok = !s.empty();
+  std::string out;
+  for (size_t i = 0; i <= s.size() && ok; ++i) {
+    if (i == s.size() || s[i] == '.') { if (val < 0 || val > 255) ok = false; else { out += (parts ? "." : "") + std::to_string(val); parts++; val = -1; } }
+    else if (s[i] >= '0' && s[i] <= '9') val = (val < 0 ? 0 : val * 10) + (s[i] - '0');
+    else ok = false;
+  }
+  return ok && parts == 4 ? out : "<nil>";
+}
+static std::vector<HostPort> parse_host_ports(const Value& v) {
+  std::vector<HostPort> out;
+  if (v.is_null()) return out;
+  for (auto& e : v.items()) {
+    const int port = (int)e.at("port").i(0);
+    if (port == 0) continue;
+    const std::string ip = e.at("ip").s("");
+    out.push_back({canonical_ip(ip.empty() ? "0.0.0.0" : ip), port, e.at("protocol").s("TCP")});
+  }
+  return out;
+}
+
 struct PodSpec {
+  std::vector<HostPort> host_ports;   // GetHostPorts (hostportusage.go:93-117)
   std::string ns = "default", phase = "Pending";
   std::map<std::string, std::string> labels;
   std::vector<Tsc> tscs;
@@ -455,6 +494,7 @@ static AffTerm parse_aff_term(const Value& v) {
 }
 static PodSpec parse_pod(const Value& v) {
   PodSpec p;
+  p.host_ports = parse_host_ports(v.at("hostPorts"));
   p.uid = v.at("uid").s();
   p.creation = v.at("creationTimestamp").i(0);
   p.pending = v.at("phase").s("Pending") == "Pending";
@@ -570,7 +610,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     }
     // offering zones / capacity types first so their value indices are the offering cell coordinates
     std::vector<std::vector<Expr>> it_exprs(n_its);
-    struct Off { int zone, ct; double price; bool available; int rid; };
+    struct Off { int zone, ct; double price; bool available; int rid; std::map<std::string, i128> cap_ov; bool has_oh; std::map<std::string, i128> oh_ov; };
     std::vector<std::vector<Off>> it_offs(n_its);
     const char* kReservationID = "karpenter.sh/reservation-id";   // cloudprovider.ReservationIDLabel
     int k_rid = -1;
@@ -587,7 +627,12 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
           else throw Unsupported("offering requirement on " + x.key);
         }
         if (zone.empty() || ct.empty()) throw std::runtime_error("offering without zone/capacity-type");
-        if (of.has("capacityOverride") || of.has("overheadOverride")) throw Unsupported("offering overrides");
+        // Offering.CapacityOverride / OverheadOverride (types.go:476-483): the offering belongs to an allocatable group of its own
+        std::map<std::string, i128> cap_ov, oh_ov;
+        bool has_oh = false;
+        if (of.has("capacityOverride") && !of.at("capacityOverride").is_null()) cap_ov = parse_resources(of.at("capacityOverride"));
+        if (of.has("overheadOverride") && !of.at("overheadOverride").is_null()) { has_oh = true; oh_ov = parse_resources(of.at("overheadOverride")); }
+        if ((!cap_ov.empty() || has_oh) && ct == "reserved") throw Unsupported("capacity / overhead overrides on a reserved offering");
         int ridx = -1;
         if (ct == "reserved") {
           if (rid.empty()) throw std::runtime_error("reserved offering without a reservation id");
@@ -597,7 +642,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
           if (ridx >= (int)resv_capacity.size()) resv_capacity.resize(ridx + 1, INT32_MAX);
           if (cap < resv_capacity[ridx]) resv_capacity[ridx] = cap;
         } else if (!rid.empty()) throw Unsupported("reservation id on a non-reserved offering");
-        it_offs[i].push_back({D.value(k_zone, zone), D.value(k_ct, ct), of.at("price").d(), of.at("available").boolean_or(true), ridx});
+        it_offs[i].push_back({D.value(k_zone, zone), D.value(k_ct, ct), of.at("price").d(), of.at("available").boolean_or(true), ridx, cap_ov, has_oh, oh_ov});
       }
     const int n_resv = (int)resv_capacity.size();
     if (n_resv > 64) throw Unsupported("more than 64 capacity reservations");
@@ -805,6 +850,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     for (int i = 0; i < n_its; ++i) {
       it_cap[i] = parse_resources(its_json[i].at("capacity")); it_over[i] = parse_resources(its_json[i].at("overhead"));
       for (auto& kv : it_cap[i]) add_res(kv.first);
+      for (auto& o : it_offs[i]) for (auto& kv : o.cap_ov) add_res(kv.first);   // lo.Assign(capacity, override) may add keys (types.go:274-277)
     }
     for (auto& s : specs) for (auto& kv : s.requests) add_res(kv.first);
     for (auto& dp : daemons) for (auto& kv : dp.requests) add_res(kv.first);
@@ -839,6 +885,10 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     consider({{"pods", (i128)1000000000}});   // every pod requests pods: 1 (resources.go:30-38)
     for (int i = 0; i < n_its; ++i) { consider(it_cap[i]); consider(it_over[i]); }
     for (int i = 0; i < n_its; ++i) for (auto& kv : it_cap[i]) if (kv.first.rfind("hugepages-", 0) == 0) consider({{"memory", kv.second}});  // subtracted from memory
+    for (int i = 0; i < n_its; ++i) for (auto& o : it_offs[i]) {
+      consider(o.cap_ov); consider(o.oh_ov);
+      for (auto& kv : o.cap_ov) if (kv.first.rfind("hugepages-", 0) == 0) consider({{"memory", kv.second}});
+    }
     for (auto& s : specs) consider(s.requests);
     for (auto& dp : daemons) consider(dp.requests);
     for (int e = 0; e < n_nodes; ++e) consider(node_ds[e]);
@@ -873,23 +923,44 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     std::vector<double> it_price((size_t)n_its * 64, 0.0);
     ReqTableBuilder it_reqs;
     it_reqs.init(n_its, rw, nk);
-    for (int i = 0; i < n_its; ++i) {
+    // computeAllocatable (types.go:271-294): capacity - overhead over capacity's keys (resources.Subtract, resources.go:83-97),
+    // then hugepage reservations come out of the allocatable memory, one clamp at zero per hugepage size (capacity is a
+    // map, visited here in name order — the clamps commute)
+    auto compute_alloc = [&](const std::map<std::string, i128>& cap, const std::map<std::string, i128>& over, int64_t* out, size_t stride) {
       for (int r = 0; r < n_res; ++r) {
-        i128 cap = res_get(it_cap[i], res_names[r]);
-        i128 alloc = it_cap[i].count(res_names[r]) ? cap - res_get(it_over[i], res_names[r]) : 0;  // resources.Subtract keeps capacity's keys (resources.go:83-97)
-        if (r == 1) {
-          // hugepage reservations come out of the allocatable memory, one clamp at zero per hugepage size
-          // (computeAllocatable, types.go:281-291); capacity is a map, visited here in name order — the clamps commute
-          for (auto& kv : it_cap[i]) if (kv.first.rfind("hugepages-", 0) == 0) { alloc -= kv.second; if (alloc < 0) alloc = 0; }
-        }
-        it_capv[(size_t)r * n_its + i] = to_dev(r, cap);
-        it_alloc[(size_t)r * n_its + i] = to_dev(r, alloc);
+        i128 alloc = cap.count(res_names[r]) ? res_get(cap, res_names[r]) - res_get(over, res_names[r]) : 0;
+        if (r == 1) for (auto& kv : cap) if (kv.first.rfind("hugepages-", 0) == 0) { alloc -= kv.second; if (alloc < 0) alloc = 0; }
+        out[(size_t)r * stride] = to_dev(r, alloc);
       }
+    };
+    // offering override groups (groupOfferingsByOverride, types.go:224-269): available offerings with a non-empty
+    // CapacityOverride or an OverheadOverride, grouped by the override pair in first-seen order behind the base group
+    std::vector<uint64_t> it_base_avail(n_its, 0), xg_avail;
+    std::vector<uint32_t> xg_it;
+    std::vector<std::vector<int64_t>> xg_alloc_rows;   // per group: n_res values
+    for (int i = 0; i < n_its; ++i) {
+      for (int r = 0; r < n_res; ++r) it_capv[(size_t)r * n_its + i] = to_dev(r, res_get(it_cap[i], res_names[r]));
+      compute_alloc(it_cap[i], it_over[i], &it_alloc[i], n_its);
+      std::vector<const Off*> first;   // the offering that defines extra group g of this type
+      const size_t g0 = xg_it.size();
       for (auto& o : it_offs[i]) {
         int cell = o.zone * 4 + o.ct;
         if (o.available) {
           if ((it_avail[i] >> cell) & 1) { if (o.price < it_price[(size_t)i * 64 + cell]) it_price[(size_t)i * 64 + cell] = o.price; }
           else { it_avail[i] |= 1ull << cell; it_price[(size_t)i * 64 + cell] = o.price; }
+          if (o.cap_ov.empty() && !o.has_oh) { it_base_avail[i] |= 1ull << cell; continue; }
+          size_t g = 0;
+          for (; g < first.size(); ++g) if (first[g]->cap_ov == o.cap_ov && first[g]->has_oh == o.has_oh && first[g]->oh_ov == o.oh_ov) break;
+          if (g == first.size()) {
+            first.push_back(&o);
+            std::map<std::string, i128> cap = it_cap[i], over = it_over[i];
+            for (auto& kv : o.cap_ov) cap[kv.first] = kv.second;          // lo.Assign replaces whole keys
+            if (o.has_oh) for (auto& kv : o.oh_ov) over[kv.first] = kv.second;
+            std::vector<int64_t> row(n_res);
+            compute_alloc(cap, over, row.data(), 1);
+            xg_it.push_back((uint32_t)i); xg_avail.push_back(0); xg_alloc_rows.push_back(row);
+          }
+          xg_avail[g0 + g] |= 1ull << cell;
         }
       }
       ks::ReqBuf b;
@@ -944,6 +1015,32 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     }
     // daemon-overhead groups per template (scheduler.go:972-1043): instance types keyed by the set of daemonset pods that
     // could run on a node of that type from that NodePool
+    // host ports: the distinct <ip, port, protocol> triples of the problem, one bit each. They only matter when a pod to
+    // be scheduled binds one; then the triples of daemon pods and of the existing nodes' bound pods join the dictionary.
+    std::vector<HostPort> hp_dict;
+    bool hp_on = false;
+    for (auto& sp : specs) hp_on = hp_on || !sp.host_ports.empty();
+    auto hp_mask = [&](const std::vector<HostPort>& ports) {
+      uint64_t m = 0;
+      for (auto& h : ports) {
+        size_t i = 0;
+        for (; i < hp_dict.size(); ++i) if (hp_dict[i] == h) break;
+        if (i == hp_dict.size()) { if (hp_dict.size() == 64) throw Unsupported("more than 64 distinct host ports"); hp_dict.push_back(h); }
+        m |= 1ull << i;
+      }
+      return m;
+    };
+    std::vector<uint64_t> spec_hp(specs.size(), 0), daemon_hp(daemons.size(), 0), node_hp(n_nodes, 0), dg_hp;
+    if (hp_on) {
+      for (size_t si = 0; si < specs.size(); ++si) spec_hp[si] = hp_mask(specs[si].host_ports);
+      for (size_t di = 0; di < daemons.size(); ++di) daemon_hp[di] = hp_mask(daemons[di].host_ports);
+      for (int e = 0; e < n_nodes; ++e) node_hp[e] = hp_mask(parse_host_ports(nodes[e].v->at("hostPorts")));
+    }
+    auto hp_conflicts = [&](uint64_t use) {   // every triple of the dictionary that Matches one of `use`
+      uint64_t m = 0;
+      for (size_t i = 0; i < hp_dict.size(); ++i) if ((use >> i) & 1) for (size_t j = 0; j < hp_dict.size(); ++j) if (hp_dict[i].matches(hp_dict[j])) m |= 1ull << j;
+      return m;
+    };
     std::vector<uint32_t> dg_first;
     std::vector<uint64_t> dg_its;
     std::vector<int64_t> dg_ov;
@@ -996,6 +1093,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
             keys.push_back(key);
             dg_its.resize(dg_its.size() + it_words, 0);
             dg_nonempty.push_back(key != 0);
+            { uint64_t m = 0; for (size_t di = 0; di < daemons.size(); ++di) if ((key >> di) & 1) m |= daemon_hp[di]; dg_hp.push_back(m); }   // scheduler.go:990-993
             for (int r = 0; r < n_res; ++r) {
               i128 sum = 0;
               for (size_t di = 0; di < daemons.size(); ++di) if ((key >> di) & 1) sum += res_names[r] == "pods" ? (i128)1000000000 : res_get(daemons[di].requests, res_names[r]);
@@ -1004,7 +1102,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
           }
           dg_its[(base + gi) * it_words + i / 64] |= 1ull << (i % 64);
         }
-        if (keys.empty()) { dg_its.resize(dg_its.size() + it_words, 0); dg_nonempty.push_back(0); for (int r = 0; r < n_res; ++r) dg_ov.push_back(0); }
+        if (keys.empty()) { dg_its.resize(dg_its.size() + it_words, 0); dg_nonempty.push_back(0); dg_hp.push_back(0); for (int r = 0; r < n_res; ++r) dg_ov.push_back(0); }
         dg_first.push_back((uint32_t)dg_nonempty.size());
       }
       if (dg_nonempty.size() > 64) throw Unsupported("more than 64 daemon-overhead groups");
@@ -1057,7 +1155,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     std::vector<int64_t> pod_requests((size_t)n_res * n_rows);
     ReqTableBuilder pod_reqs, pod_strict;
     pod_reqs.init(n_rows, rw, nk); pod_strict.init(n_rows, rw, nk);
-    std::vector<uint64_t> pod_tol(n_rows, 0);
+    std::vector<uint64_t> pod_tol(n_rows, 0), pod_hp(n_rows, 0), pod_hpc(n_rows, 0);
     std::vector<int32_t> pod_next(n_rows, -1);
     std::vector<int64_t> pod_creation(n_pods);
     std::vector<uint8_t> pod_pending(n_pods);
@@ -1082,9 +1180,12 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       for (int r = 0; r < n_res; ++r) pod_requests[(size_t)r * n_rows + row] = e.req[r];
       pod_reqs.put(row, e.reqs); pod_strict.put(row, e.strict); pod_tol[row] = e.tol;
     };
+    std::vector<uint64_t> spec_hpc(specs.size(), 0);
+    for (size_t si = 0; si < specs.size(); ++si) spec_hpc[si] = hp_conflicts(spec_hp[si]);
     for (int p = 0; p < n_pods; ++p) {
       int si = pod_spec[p];
       put_row(p, enc[si][0]);
+      pod_hp[p] = spec_hp[si]; pod_hpc[p] = spec_hpc[si];
       pod_next[p] = spec_first_extra[si];
       pod_creation[p] = specs[si].creation;
       pod_pending[p] = specs[si].pending ? 1 : 0;
@@ -1093,6 +1194,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       for (size_t vi = 1; vi < ladders[si].size(); ++vi) {
         int row = spec_first_extra[si] + (int)vi - 1;
         put_row(row, enc[si][vi]);
+        pod_hp[row] = spec_hp[si]; pod_hpc[row] = spec_hpc[si];
         pod_next[row] = vi + 1 < ladders[si].size() ? row + 1 : -1;
       }
 
@@ -1434,6 +1536,13 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     d.n_res = (uint32_t)n_res;
     d.n_its = (uint32_t)n_its; d.it_allocatable = it_alloc.data(); d.it_capacity = it_capv.data(); d.it_reqs = it_reqs.view();
     d.it_offering_avail = it_avail.data(); d.it_offering_price = it_price.data(); d.n_zones = (uint32_t)n_zones; d.n_captypes = (uint32_t)n_cts;
+    std::vector<int64_t> xg_alloc((size_t)n_res * xg_it.size());
+    for (size_t e = 0; e < xg_it.size(); ++e) for (int r = 0; r < n_res; ++r) xg_alloc[(size_t)r * xg_it.size() + e] = xg_alloc_rows[e][r];
+    if (!xg_it.empty()) {
+      if (xg_it.size() > KSOLVE_MAX_OVERRIDE_GROUPS) throw Unsupported("more than 4096 offering override groups");
+      d.n_override_groups = (uint32_t)xg_it.size(); d.override_it = xg_it.data(); d.override_allocatable = xg_alloc.data();
+      d.override_avail = xg_avail.data(); d.it_base_avail = it_base_avail.data();
+    }
     d.n_templates = (uint32_t)n_templates; d.tmpl_reqs = tmpl_reqs.view(); d.tmpl_taints = tmpl_taints.data(); d.tmpl_its = tmpl_its.data();
     d.tmpl_limit_mask = tmpl_limit_mask.data(); d.tmpl_limits = tmpl_lim.data();
     d.n_reservations = (uint32_t)n_resv; d.reservation_capacity = resv_capacity.data(); d.key_reservation_id = k_rid;
@@ -1442,6 +1551,11 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     if (!dg_first.empty()) { d.tmpl_daemon_first = dg_first.data(); d.daemon_group_its = dg_its.data(); d.daemon_group_overhead = dg_ov.data(); d.daemon_group_nonempty = dg_nonempty.data(); }
     d.n_pods = (uint32_t)n_pods; d.n_pod_rows = (uint32_t)n_rows; d.pod_requests = pod_requests.data();
     d.pod_reqs = pod_reqs.view(); d.pod_strict_reqs = pod_strict.view(); d.pod_tolerates = pod_tol.data(); d.pod_next_variant = pod_next.data();
+    if (hp_on) {
+      d.pod_host_ports = pod_hp.data(); d.pod_host_port_conflicts = pod_hpc.data();
+      if (n_nodes) d.node_host_ports = node_hp.data();
+      if (!dg_first.empty()) d.daemon_group_host_ports = dg_hp.data();
+    }
     d.pod_creation = pod_creation.data(); d.pod_uid_hi = uid_hi.data(); d.pod_uid_lo = uid_lo.data(); d.pod_is_pending = pod_pending.data();
     d.n_taints = (uint32_t)distinct_taints.size();
     d.key_hostname = fl.kd.key_hostname;

@@ -39,8 +39,46 @@ struct TopologySpreadConstraint {
 
 // corev1.Pod subset read by the path. `requests` is the output of resourcehelper.PodRequests (flattened upstream
 // of the boundary); RequestsForPods adds pods=1 (resources.go:36).
+// scheduling.HostPort — hostportusage.go:39-62. The IP is kept as the canonical text net.ParseIP would print ("" and
+// unparsable text become one nil value, IPv4-mapped IPv6 folds to IPv4); Matches: same protocol and port, and equal IPs or
+// one of them unspecified (0.0.0.0 or ::).
+struct HostPort {
+  std::string ip;
+  int port = 0;
+  std::string protocol;
+  bool unspecified() const { return ip == "0.0.0.0" || ip == "::"; }
+  bool matches(const HostPort& o) const {
+    if (protocol != o.protocol || port != o.port) return false;
+    return ip == o.ip || unspecified() || o.unspecified();
+  }
+};
+inline std::string canonical_ip(std::string s) {
+  for (auto& c : s) c = (char)tolower((unsigned char)c);
+  if (s.rfind("::ffff:", 0) == 0 && s.find('.') != std::string::npos) s = s.substr(7);
+  if (s.find(':') != std::string::npos) {   // IPv6: only the forms that need no expansion are told apart; "::" variants of zero fold
+    bool zero = true;
+    for (char c : s) if (c != ':' && c != '0') zero = false;
+    return zero ? "::" : s;
+  }
+  int parts = 0, val = -1;
+  bool ok = !s.empty();
+  std::string out;
+  for (size_t i = 0; i <= s.size() && ok; ++i) {
+    if (i == s.size() || s[i] == '.') { if (val < 0 || val > 255) ok = false; else { out += (parts ? "." : "") + std::to_string(val); parts++; val = -1; } }
+    else if (s[i] >= '0' && s[i] <= '9') val = (val < 0 ? 0 : val * 10) + (s[i] - '0');
+    else ok = false;
+  }
+  return ok && parts == 4 ? out : "<nil>";
+}
+// HostPortUsage.Conflicts — hostportusage.go:76-87 (the pod being placed is never among the users here)
+inline bool host_ports_conflict(const std::vector<HostPort>& wanted, const std::vector<HostPort>& used) {
+  for (auto& w : wanted) for (auto& u : used) if (w.matches(u)) return true;
+  return false;
+}
+
 struct Pod {
   std::string uid, ns = "default", name;
+  std::vector<HostPort> host_ports;   // GetHostPorts — hostportusage.go:93-117 (hostIP "" reads 0.0.0.0)
   std::map<std::string, std::string> labels;
   long long creation = 0;
   std::string phase = "Pending";
@@ -149,6 +187,7 @@ struct StateNode {
   std::map<std::string, std::string> labels;
   std::vector<Taint> taints;
   ResourceList available, capacity, daemonset_requests;
+  std::vector<HostPort> host_ports;   // StateNode.HostPortUsage(): ports of the pods bound to the node (statenode.go:407,489)
   bool initialized = true, managed = true, has_node = true, marked_for_deletion = false;
   bool under_consolidate_after = false;  // disruption.IsUnderConsolidateAfter, evaluated upstream
 };
@@ -235,8 +274,23 @@ inline Requirements exprs_to_requirements(const std::vector<NodeSelectorExpr>& e
   for (auto& e : exprs) r.add(Requirement::make(e.key, e.op, e.min_values, e.values));
   return r;
 }
+inline std::vector<HostPort> parse_host_ports(const oj::Value& v) {
+  std::vector<HostPort> out;
+  if (v.is_null()) return out;
+  for (auto& e : v.items()) {
+    HostPort h;
+    h.port = (int)e.at("port").i(0);
+    if (h.port == 0) continue;                                  // hostportusage.go:97
+    std::string ip = e.at("ip").s("");
+    h.ip = canonical_ip(ip.empty() ? "0.0.0.0" : ip);           // hostportusage.go:103-106
+    h.protocol = e.at("protocol").s("TCP");
+    out.push_back(h);
+  }
+  return out;
+}
 inline Pod parse_pod(const oj::Value& v, int idx) {
   Pod p;
+  p.host_ports = parse_host_ports(v.at("hostPorts"));
   p.input_index = idx;
   p.uid = v.at("uid").s();
   p.ns = v.at("namespace").s("default");
@@ -387,6 +441,7 @@ inline Problem parse_problem(const oj::Value& root) {
     n.available = parse_resources(v.at("available"));
     n.capacity = parse_resources(v.at("capacity"));
     n.daemonset_requests = parse_resources(v.at("daemonSetRequests"));
+    n.host_ports = parse_host_ports(v.at("hostPorts"));
     n.initialized = v.at("initialized").boolean_or(true);
     n.managed = v.at("managed").boolean_or(true);
     n.has_node = v.at("hasNode").boolean_or(true);

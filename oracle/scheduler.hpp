@@ -104,10 +104,11 @@ struct ReservationManager {
 };
 
 // ---- scheduling types ------------------------------------------------------------------------------------------
-struct DaemonOverheadGroup {  // scheduler.go:963-967 (host ports are out of the problem format)
+struct DaemonOverheadGroup {  // scheduler.go:963-967
   std::set<const InstanceType*> its;
   std::vector<const InstanceType*> its_ordered;
   ResourceList overhead;
+  std::vector<HostPort> host_ports;   // HostPortUsage of the group's daemon pods (scheduler.go:990-993)
 };
 
 // NodeClaimTemplate — nodeclaimtemplate.go:55-94
@@ -176,10 +177,14 @@ inline void it_fits(const InstanceType& it, const ResourceList& requests, const 
 // filterInstanceTypesByRequirements — nodeclaim.go:541-618
 inline bool filter_instance_types(const std::vector<const InstanceType*>& its, Requirements& reqs, const std::vector<DaemonOverheadGroup>& groups,
                                   const ResourceList& total_requests, bool relax_min_values, std::vector<const InstanceType*>& remaining,
-                                  std::map<std::string, int>& unsat, FilterDiag& d, Counters* ctr) {
+                                  std::map<std::string, int>& unsat, FilterDiag& d, Counters* ctr,
+                                  const std::vector<HostPort>* pod_ports = nullptr, const std::vector<HostPort>* bin_ports = nullptr) {
   remaining.clear();
   std::set<const InstanceType*> eligible(its.begin(), its.end());
   for (auto& g : groups) {
+    // a group whose host ports (its daemon pods' + the pods already on the NodeClaim, nodeclaim.go:256-259) collide with
+    // the pod's is skipped as a whole (nodeclaim.go:562-565)
+    if (pod_ports && !pod_ports->empty() && (host_ports_conflict(*pod_ports, g.host_ports) || (bin_ports && host_ports_conflict(*pod_ports, *bin_ports)))) continue;
     ResourceList total = g.overhead.empty() ? total_requests : res_merge(total_requests, g.overhead);
     for (auto* it : g.its_ordered) {
       if (!eligible.count(it)) continue;
@@ -218,6 +223,7 @@ struct NodeClaim {
   std::string hostname;
   std::map<std::string, std::string> annotations;
   std::vector<const Offering*> reserved_offerings;
+  std::vector<HostPort> host_ports;   // what Add put into every daemon group's HostPortUsage (nodeclaim.go:256-259)
   int id = 0;  // creation order
 };
 
@@ -227,6 +233,7 @@ struct ExistingNode {
   std::vector<Pod*> pods;
   ResourceList remaining;
   Requirements reqs;
+  std::vector<HostPort> host_ports;   // StateNode.HostPortUsage() + the pods added in this Solve (existingnode.go:178)
   bool under_consolidate_after = false;
 };
 
@@ -361,6 +368,7 @@ struct Scheduler {
         if (!compat.empty()) {
           for (auto* p : compat) ng.overhead = res_merge(ng.overhead, p->requests);
           ng.overhead["pods"] = (i128)compat.size() * 1000000000;
+          for (auto* p : compat) ng.host_ports.insert(ng.host_ports.end(), p->host_ports.begin(), p->host_ports.end());
         }
         groups.push_back({key, ng});
         g = &groups.back().second;
@@ -421,6 +429,7 @@ struct Scheduler {
     for (auto& n : problem.state_nodes) {
       auto en = std::make_unique<ExistingNode>();
       en->node = &n;
+      en->host_ports = n.host_ports;
       // daemons compatible with the node (scheduler.go:805-832) minus what already runs there (existingnode.go:50-60)
       ResourceList daemon;
       int ndaemons = 0;
@@ -459,6 +468,7 @@ struct Scheduler {
   bool existing_can_add(ExistingNode& n, const Pod& pod, const PodData& pd, Requirements& out) {
     ctr.bin_evaluations++;
     if (!taints_tolerated(n.node->taints, pod.tolerations)) { last_err = ERR_TAINTS; return false; }
+    if (host_ports_conflict(pod.host_ports, n.host_ports)) { last_err = ERR_EXISTING; return false; }   // existingnode.go:87-93
     if (!res_fits(pd.requests, n.remaining)) { last_err = ERR_RESOURCES; return false; }
     if (!n.reqs.compatible(pd.reqs, false)) { last_err = ERR_INCOMPATIBLE; return false; }
     Requirements base = n.reqs;
@@ -474,6 +484,7 @@ struct Scheduler {
     n.pods.push_back(pod);
     res_subtract_from(n.remaining, pd.requests);
     n.reqs = reqs;
+    n.host_ports.insert(n.host_ports.end(), pod->host_ports.begin(), pod->host_ports.end());   // existingnode.go:178
     topology.record(*pod, n.node->taints, reqs);
   }
 
@@ -523,7 +534,7 @@ struct Scheduler {
     ResourceList requests = res_merge(n.requests, pd.requests);
     std::map<std::string, int> unsat;
     FilterDiag d;
-    bool ok = filter_instance_types(n.its, base, n.tmpl->daemon_groups, requests, relax_min_values, out_its, unsat, d, &ctr);
+    bool ok = filter_instance_types(n.its, base, n.tmpl->daemon_groups, requests, relax_min_values, out_its, unsat, d, &ctr, &pod.host_ports, &n.host_ports);
     if (relax_min_values) for (auto& kv : unsat) base.m[kv.first].min_values = kv.second;
     if (!ok) { last_err = d.min_values_incompatible ? ERR_MIN_VALUES : ERR_INSTANCE_TYPES; last_diag = d.bits(); return false; }
     if (!offerings_to_reserve(n, out_its, base, out_ofs)) { last_err = ERR_RESERVED; return false; }
@@ -536,6 +547,7 @@ struct Scheduler {
     n.its = its;
     n.requests = res_merge(n.requests, pd.requests);
     n.reqs = reqs;
+    n.host_ports.insert(n.host_ports.end(), pod->host_ports.begin(), pod->host_ports.end());
     topology.reg(kLabelHostname, n.hostname);
     topology.record(*pod, n.tmpl->taints, reqs);
     reservations.reserve(n.hostname, ofs);

@@ -175,10 +175,95 @@ def test_unsupported_is_loud_not_cpu(emu):
     with pytest.raises(Unsupported):   # more requirement keys than the device's key mask has bits
         pods = [fx.pod(node_requirements=[fx.req(f"example.com/key-{i}", "Exists") for i in range(40)])]
         NewScheduler(fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], pods), solver_lib=emu)
-    with pytest.raises(Unsupported):   # an offering with its own capacity splits the type into allocatable groups (types.go:202-269)
+    with pytest.raises(Unsupported):   # override groups are solved on the device, except on reserved offerings
         its = fx.fake_default_instance_types()
-        its[0]["offerings"][0]["capacityOverride"] = {"memory": "1Gi"}
-        NewScheduler(fx.problem(its, [fx.node_pool()], [fx.pod()]), solver_lib=emu)
+        its[0]["offerings"].append(dict(fx.offering("reserved", "test-zone-1", 0.01, reservation_id="r-1", reservation_capacity=1), capacityOverride={"memory": "1Gi"}))
+        NewScheduler(fx.problem(its, [fx.node_pool()], [fx.pod()], options={"reservedCapacity": True}), solver_lib=emu)
+
+
+def _with_override_offerings(it, available=True, capacity=None, overhead=None, zones=None):
+    """suite_test.go:5532-5545: base offerings cloned with CapacityOverride / OverheadOverride."""
+    clones = []
+    for o in list(it["offerings"]):
+        if zones is not None and not any(q["key"] == fx.ZONE and q["values"][0] in zones for q in o["requirements"]):
+            continue
+        c = dict(o, available=available)
+        if capacity is not None:
+            c["capacityOverride"] = dict(capacity)
+        if overhead is not None:
+            c["overheadOverride"] = dict(overhead)
+        clones.append(c)
+    it["offerings"] = it["offerings"] + clones
+    return it
+
+
+def test_offering_override_groups(oracle, emu):
+    """Offering CapacityOverride / OverheadOverride (types.go:202-269): every distinct override pair is one more allocatable
+    group of the type; fits() passes the type when SOME group holds the requests and has a compatible offering
+    (nodeclaim.go:624-638). The reference's two scenarios (suite_test.go:5524-5607) and the group semantics, on the device."""
+    ext = "test.com/extended-slots"
+    res = {"cpu": "4", "memory": "8Gi"}
+    mk = lambda name="t", **kw: _with_override_offerings(fx.fake_instance_type(name, dict(res)), **kw)
+    # suite_test.go:5524-5566: only the type whose override offerings carry the extended resource is selected
+    got, _ = check(oracle, emu, fx.problem([mk("override-capable", capacity={ext: "4"}, overhead={"memory": "1Gi"}), fx.fake_instance_type("normal", dict(res))],
+                                           [fx.node_pool()], [fx.pod(requests={ext: "1"})]))
+    assert not got["podErrors"] and got["newNodeClaims"][0]["instanceTypes"] == ["override-capable"]
+    # suite_test.go:5568-5607: the override allocatable would fit, but its offerings are unavailable
+    got, _ = check(oracle, emu, fx.problem([mk("override-capable", available=False, capacity={ext: "4"}, overhead={"memory": "1Gi"})], [fx.node_pool()], [fx.pod(requests={ext: "1"})]))
+    assert len(got["podErrors"]) == 1 and not got["newNodeClaims"]
+    # one group trades memory for slots: the two pods fit different groups of the same type and cannot share a claim
+    ov = mk(capacity={ext: "4"}, overhead={"memory": "1Gi"})
+    got, _ = check(oracle, emu, fx.problem([ov], [fx.node_pool()], [fx.pod(requests={"memory": "7680Mi"}), fx.pod(requests={ext: "1"})]))
+    assert sorted(len(c["pods"]) for c in got["newNodeClaims"]) == [1, 1]
+    got, _ = check(oracle, emu, fx.problem([ov], [fx.node_pool()], [fx.pod(requests={ext: "1", "memory": "1Gi"}) for _ in range(4)] + [fx.pod(requests={ext: "1"})]))
+    assert sorted(len(c["pods"]) for c in got["newNodeClaims"]) == [1, 4]
+    # the fitting group has no compatible offering (overrides only in zone 3, pod pinned to zone 1): error flags included
+    z3 = mk(capacity={ext: "2"}, zones=["test-zone-3"])
+    got, _ = check(oracle, emu, fx.problem([z3], [fx.node_pool()], [fx.pod(requests={ext: "1"}, node_selector={fx.ZONE: "test-zone-1"})]))
+    assert len(got["podErrors"]) == 1
+    got, _ = check(oracle, emu, fx.problem([z3], [fx.node_pool()], [fx.pod(requests={ext: "1"}), fx.pod(requests={ext: "1"}, node_selector={fx.ZONE: "test-zone-3"})]))
+    assert not got["podErrors"]
+    # a capacity override replaces the whole key; with the base offerings unavailable only the shrunken group can launch
+    t = mk(capacity={"memory": "2Gi"})
+    for o in t["offerings"][:5]:
+        o["available"] = False
+    got, _ = check(oracle, emu, fx.problem([t], [fx.node_pool()], [fx.pod(requests={"memory": "3Gi"}), fx.pod(requests={"memory": "1Gi"})]))
+    assert len(got["podErrors"]) == 1 and len(got["newNodeClaims"]) == 1
+    t = mk(capacity={})                                  # an empty override map without an overhead override is the base group
+    for o in t["offerings"][:5]:
+        o["available"] = False
+    got, _ = check(oracle, emu, fx.problem([t], [fx.node_pool()], [fx.pod(requests={"memory": "3Gi"})]))
+    assert not got["podErrors"]
+    # an overhead override that drives a dimension negative: resources.Fits refuses that group (resources.go:190)
+    t = mk(overhead={"memory": "9Gi"}, zones=["test-zone-1"])
+    check(oracle, emu, fx.problem([t], [fx.node_pool()], [fx.pod(node_selector={fx.ZONE: "test-zone-1"}), fx.pod()]))
+
+
+def test_offering_override_groups_fuzz(oracle, emu):
+    """Random catalogues where some types carry one or two override groups in some zones, pods with zone selectors and
+    extended-resource requests, daemonset overhead, existing claims that keep growing: claim by claim against the oracle."""
+    ext = "test.com/extended-slots"
+    for seed in range(8):
+        rng = random.Random(900 + seed)
+        its = fx.fake_instance_types(rng.choice([6, 12, 70]))
+        for it in its:
+            if rng.random() < 0.5:
+                _with_override_offerings(it, capacity={ext: str(rng.choice([2, 4, 8]))}, overhead=rng.choice([None, {"memory": "1Gi"}, {"cpu": "1"}]),
+                                         zones=rng.choice([None, ["test-zone-1"], ["test-zone-2", "test-zone-3"]]))
+            if rng.random() < 0.25:
+                _with_override_offerings(it, capacity={"memory": rng.choice(["2Gi", "64Gi"])}, zones=[rng.choice(["test-zone-1", "test-zone-2", "test-zone-3"])],
+                                         available=rng.random() < 0.8)
+        pods = []
+        for _ in range(rng.choice([20, 60])):
+            req = {"cpu": rng.choice(["100m", "500m", "1", "2"]), "memory": rng.choice(["128Mi", "1Gi", "3Gi"])}
+            if rng.random() < 0.5:
+                req[ext] = str(rng.choice([1, 2, 3]))
+            sel = {fx.ZONE: rng.choice(["test-zone-1", "test-zone-2", "test-zone-3"])} if rng.random() < 0.4 else None
+            pods.append(fx.pod(requests=req, node_selector=sel))
+        kw = {}
+        if seed % 3 == 0:
+            kw["daemonset_pods"] = [fx.pod(requests={"cpu": "100m", "memory": "64Mi"})]
+        check(oracle, emu, fx.problem(its, [fx.node_pool()], pods, **kw))
 
 
 def test_hugepages(oracle, emu):

@@ -403,3 +403,12 @@ def test_full_size_digest(pin):
         assert float(r["packingCost"]).hex() == g["packingCost"] or abs(r["packingCost"] - g["packingCostApprox"]) < 1e-9 * g["packingCostApprox"]
         if eng == "auto":
             assert r["counters"]["engine"] == ("general" if g["config"] == "config3" else "cursor"), r["counters"]
+
+
+def test_offering_override_groups_on_the_device(oracle):
+    """Offering capacity / overhead override groups (types.go:202-269, nodeclaim.go:624-638) on the GPU: the reference's
+    two known answers (suite_test.go:5524-5607), the group semantics and the seeded fuzz of tests/test_device_algorithm.py,
+    with libksolve.so instead of the emulation (solver_lib=None = the product library)."""
+    import test_device_algorithm as tda
+    tda.test_offering_override_groups(oracle, None)
+    tda.test_offering_override_groups_fuzz(oracle, None)
