@@ -394,9 +394,6 @@ func flatten(ctx context.Context, s *Scheduler, pods []*corev1.Pod, maxSteps int
 		if r.data.HasResourceClaimRequests || len(r.data.VolumeRequirements) > 0 {
 			return nil, fmt.Errorf("%w: pod %s/%s has resource claims / volume topology alternatives", ErrKSolveUnsupported, r.pod.Namespace, r.pod.Name)
 		}
-		if len(scheduling.GetHostPorts(r.pod)) > 0 {
-			return nil, fmt.Errorf("%w: pod %s/%s uses host ports", ErrKSolveUnsupported, r.pod.Namespace, r.pod.Name)
-		}
 		d.observe(r.data.Requirements)
 		d.observe(r.data.StrictRequirements)
 		q.observe(r.data.Requests)
@@ -689,6 +686,77 @@ func flatten(ctx context.Context, s *Scheduler, pods []*corev1.Pod, maxSteps int
 			if scheduling.Taints([]corev1.Taint{taints[i]}).ToleratesPod(row.pod) == nil {
 				tolerates[r] |= 1 << uint(i)
 			}
+		}
+	}
+	// ---- host ports (hostportusage.go:39-117): bits over the distinct <hostIP, hostPort, protocol> triples; only when a
+	// pod of this Solve binds one. A row's conflict mask is every triple of the dictionary that Matches one of its own.
+	var hpDict []scheduling.HostPort
+	hpMask := func(ports []scheduling.HostPort) (uint64, error) {
+		var m uint64
+		for _, p := range ports {
+			i := 0
+			for ; i < len(hpDict); i++ {
+				if hpDict[i].IP.Equal(p.IP) && hpDict[i].Port == p.Port && hpDict[i].Protocol == p.Protocol {
+					break
+				}
+			}
+			if i == len(hpDict) {
+				if i == 64 {
+					return 0, fmt.Errorf("%w: more than 64 distinct host ports", ErrKSolveUnsupported)
+				}
+				hpDict = append(hpDict, p)
+			}
+			m |= 1 << uint(i)
+		}
+		return m, nil
+	}
+	hpOn := false
+	for _, row := range rows {
+		hpOn = hpOn || len(scheduling.GetHostPorts(row.pod)) > 0
+	}
+	if hpOn {
+		use := make([]uint64, R)
+		var err error
+		for r, row := range rows {
+			if use[r], err = hpMask(scheduling.GetHostPorts(row.pod)); err != nil {
+				return nil, err
+			}
+		}
+		nodeHP := make([]uint64, max(E, 1))
+		for e, n := range s.existingNodes {
+			if nodeHP[e], err = hpMask(n.HostPortUsage().Reserved()); err != nil { // accessor added by go/hostportusage_ksolve.go
+				return nil, err
+			}
+		}
+		var groupHP []uint64
+		for _, t := range s.nodeClaimTemplates {
+			for _, g := range s.daemonOverheadGroups[t] {
+				m, err := hpMask(g.HostPortUsage.Reserved())
+				if err != nil {
+					return nil, err
+				}
+				groupHP = append(groupHP, m)
+			}
+		}
+		conf := make([]uint64, R)
+		for r := range rows {
+			for i := range hpDict {
+				if use[r]&(1<<uint(i)) == 0 {
+					continue
+				}
+				for j := range hpDict {
+					if hpDict[i].Matches(hpDict[j]) {
+						conf[r] |= 1 << uint(j)
+					}
+				}
+			}
+		}
+		desc.pod_host_ports, desc.pod_host_port_conflicts = cU64(a, use), cU64(a, conf)
+		if E > 0 {
+			desc.node_host_ports = cU64(a, nodeHP)
+		}
+		if anyDaemons {
+			desc.daemon_group_host_ports = cU64(a, groupHP)
 		}
 	}
 	desc.tmpl_taints = cU64(a, tmplTaints)

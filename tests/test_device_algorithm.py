@@ -239,6 +239,68 @@ def test_offering_override_groups(oracle, emu):
     check(oracle, emu, fx.problem([t], [fx.node_pool()], [fx.pod(node_selector={fx.ZONE: "test-zone-1"}), fx.pod()]))
 
 
+def test_host_ports(oracle, emu):
+    """HostPortUsage (hostportusage.go:39-117) in NodeClaim.CanAdd (per daemon-overhead group, nodeclaim.go:256-259 and
+    :562-565) and ExistingNode.CanAdd (existingnode.go:87-93, :178). The reference's three known answers and the matching
+    rule (protocol, port, equal or unspecified IP)."""
+    its = fx.fake_default_instance_types()
+    # scheduling/suite_test.go:2593-2603: the same host port twice -> two nodes
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(host_ports=[8080]), fx.pod(host_ports=[8080])]))
+    assert len(got["newNodeClaims"]) == 2 and not got["podErrors"]
+    # provisioning/suite_test.go:956-973: a compatible daemonset holds the port on every node that could be launched
+    ds = fx.pod(requests={"cpu": "2", "memory": "2Gi"}, host_ports=[8080])
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(requests={"cpu": "1", "memory": "1Gi"}, host_ports=[8080])], daemonset_pods=[ds]))
+    assert len(got["podErrors"]) == 1 and not got["newNodeClaims"]
+    # provisioning/suite_test.go:1496-1530: the daemonset with the port only runs on large types, the pod asks for small ones
+    size = lambda v: [fx.req(fx.FAKE_LABEL_INSTANCE_SIZE, "In", v)]
+    dss = [fx.pod(requests={"cpu": "4", "memory": "4Gi"}, node_requirements=size("large"), host_ports=[8080]),
+           fx.pod(requests={"cpu": "2", "memory": "2Gi"}, node_requirements=size("small"), host_ports=[8081])]
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(requests={"cpu": "1", "memory": "1Gi"}, node_requirements=size("small"), host_ports=[8080])], daemonset_pods=dss))
+    assert not got["podErrors"] and len(got["newNodeClaims"]) == 1
+    # without the size requirement the pod's claim keeps only the group whose daemons leave the port free
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(requests={"cpu": "1", "memory": "1Gi"}, host_ports=[8080]),
+                                                                   fx.pod(requests={"cpu": "1"}, host_ports=[8081])], daemonset_pods=dss))
+    # HostPort.Matches: protocol and port must agree; IPs must be equal unless one side is unspecified (0.0.0.0, "" or ::)
+    hp = lambda port, ip="", proto="TCP": {"port": port, "ip": ip, "protocol": proto}
+    pods = [fx.pod(host_ports=[hp(80, "10.0.0.1")]), fx.pod(host_ports=[hp(80, "10.0.0.2")]), fx.pod(host_ports=[hp(80, "10.0.0.1", "UDP")]),
+            fx.pod(host_ports=[hp(80)]), fx.pod(host_ports=[hp(80, "::")]), fx.pod(host_ports=[hp(81, "10.0.0.1"), hp(82)]), fx.pod(host_ports=[hp(82, "10.0.0.9")]),
+            fx.pod(host_ports=[hp(0)]), fx.pod()]
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], pods))
+    assert not got["podErrors"]
+    # existing nodes: ports of bound pods (StateNode.HostPortUsage) and of pods added during this Solve
+    node = fx.state_node("node-a", its[2], "test-zone-1", host_ports=[8080])
+    free = fx.state_node("node-b", its[2], "test-zone-2")
+    pods = [fx.pod(host_ports=[8080]), fx.pod(host_ports=[8080]), fx.pod(host_ports=[8080]), fx.pod(host_ports=[9090]), fx.pod(host_ports=[9090])]
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], pods, state_nodes=[node, free]))
+    on_nodes = {e["name"]: len(e["pods"]) for e in got["existingNodes"]}
+    assert on_nodes == {"node-a": 1, "node-b": 2} and len(got["newNodeClaims"]) == 2
+    # two passes: what the first pass launched keeps its ports in the second
+    first = fx.problem(its, [fx.node_pool()], [fx.pod(host_ports=[8080]), fx.pod(host_ports=[8443])])
+    got, _ = check(oracle, emu, first)
+    nodes, bound = fx.launch(got, its, first["pods"])
+    assert sum(len(n.get("hostPorts", [])) for n in nodes) == 2
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(host_ports=[8080, 8443]), fx.pod(host_ports=[8081])], state_nodes=nodes, cluster_pods=bound))
+    assert len(got["newNodeClaims"]) == 1
+
+
+def test_host_ports_fuzz(oracle, emu):
+    for seed in range(8):
+        rng = random.Random(700 + seed)
+        its = fx.fake_instance_types(rng.choice([6, 20]))
+        ports = [8080, 8081, 9000, 9001, 53]
+        pick = lambda: [{"port": rng.choice(ports), "ip": rng.choice(["", "", "10.0.0.1", "10.0.0.2"]), "protocol": rng.choice(["TCP", "TCP", "UDP"])}
+                        for _ in range(rng.choice([0, 0, 1, 1, 2]))]
+        pods = [fx.pod(requests={"cpu": rng.choice(["100m", "500m", "1"])}, host_ports=pick(),
+                       node_selector=({fx.ZONE: rng.choice(["test-zone-1", "test-zone-2"])} if rng.random() < 0.3 else None)) for _ in range(rng.choice([15, 40]))]
+        kw = {}
+        if seed % 2 == 0:
+            kw["daemonset_pods"] = [fx.pod(requests={"cpu": "100m"}, host_ports=[{"port": 9000, "ip": "", "protocol": "TCP"}],
+                                           node_requirements=[fx.req(fx.ZONE, "In", "test-zone-1")]), fx.pod(requests={"memory": "64Mi"}, host_ports=pick())]
+        if seed % 3 == 0:
+            kw["state_nodes"] = [fx.state_node(f"n-{i}", its[-1], rng.choice(["test-zone-1", "test-zone-2"]), host_ports=pick()) for i in range(3)]
+        check(oracle, emu, fx.problem(its, [fx.node_pool()], pods, **kw))
+
+
 def test_offering_override_groups_fuzz(oracle, emu):
     """Random catalogues where some types carry one or two override groups in some zones, pods with zone selectors and
     extended-resource requests, daemonset overhead, existing claims that keep growing: claim by claim against the oracle."""

@@ -412,3 +412,11 @@ def test_offering_override_groups_on_the_device(oracle):
     import test_device_algorithm as tda
     tda.test_offering_override_groups(oracle, None)
     tda.test_offering_override_groups_fuzz(oracle, None)
+
+
+def test_host_ports_on_the_device(oracle):
+    """HostPortUsage in NodeClaim.CanAdd / ExistingNode.CanAdd (hostportusage.go:39-117) on the GPU: the reference's three
+    known answers, the matching rule, existing nodes over two passes and the seeded fuzz of tests/test_device_algorithm.py."""
+    import test_device_algorithm as tda
+    tda.test_host_ports(oracle, None)
+    tda.test_host_ports_fuzz(oracle, None)
