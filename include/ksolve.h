@@ -282,6 +282,21 @@ typedef struct {
 
 typedef struct ksolve_handle ksolve_handle;
 
+/* One probe of a RESIDENT cluster — disruption.SimulateScheduling (disruption/helpers.go:53-155) runs Solve() on "the
+ * cluster without these candidate nodes, with their pods pending", once per candidate set of a consolidation sweep
+ * (singlenodeconsolidation.go:55-126, multinodeconsolidation.go:117-207). The base handle is created ONCE for the whole
+ * cluster: every node as an existing node, every pod that some probe may have to place as a pod row. A probe names the
+ * nodes that are not there and the pods to place; ksolve_probe_create makes a handle that SHARES the base handle's device
+ * tables (dictionaries, instance types, templates, pod classes, queue order, pristine node state) and owns only its
+ * workspace, so a sweep costs one upload + one classing pass, and its probes go to ksolve_solve_batch in ONE launch. */
+typedef struct {
+  const uint64_t* removed_nodes;   /* ceil(n_nodes / 64) words over the base problem's existing nodes: bit set = not in this simulation */
+  uint32_t n_pods;
+  const uint32_t* pods;            /* n_pods distinct pod indices (< base n_pods): the pods this simulation schedules */
+  const int64_t* tmpl_limits;      /* n_templates * (n_res+1), or NULL = the base problem's: NodePool limits left once the capacity
+                                    * of the removed nodes is handed back (scheduler.go:835-842) */
+} ksolve_probe;
+
 /* Validates and uploads a problem: device buffers + a HIP stream owned by the handle (NewScheduler). */
 ksolve_status ksolve_create(const ksolve_problem_desc* desc, const ksolve_options* opts, ksolve_handle** out);
 /* Runs Solve() on the device. One in-flight solve per handle; distinct handles are independent and thread-safe. */
@@ -291,6 +306,11 @@ ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out);
  * This is the entry point for consolidation sweeps (disruption/helpers.go:53-155 runs one Solve() per candidate set)
  * and for NodePool components of one provisioning pass. */
 ksolve_status ksolve_solve_batch(ksolve_handle** handles, uint32_t n, ksolve_results* outs);
+/* A handle for one probe of `base` (see ksolve_probe). `base` must outlive it and must not be solved concurrently with it;
+ * results use the base problem's pod and node numbering (pods outside the probe: assignment -1, error 0; removed nodes take
+ * no pods). Works with ksolve_solve, ksolve_solve_batch, ksolve_cancel, ksolve_destroy. KSOLVE_ERR_UNSUPPORTED when the base
+ * problem has topology groups (their per-probe counts are not derived yet: such sweeps create one handle per probe). */
+ksolve_status ksolve_probe_create(ksolve_handle* base, const ksolve_probe* probe, ksolve_handle** out);
 /* Asks a running ksolve_solve on another thread to stop at the next pod boundary (ctx cancellation). */
 ksolve_status ksolve_cancel(ksolve_handle* h);
 void ksolve_results_free(ksolve_results* r);

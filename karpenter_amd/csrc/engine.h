@@ -1531,7 +1531,8 @@ struct Engine {
     for (int base = 0; base < ne; base += 64) {
       const uint64_t deadw = ndead[base >> 6];
       const int cnt = ne - base < 64 ? ne - base : 64;
-      const uint64_t validm = cnt == 64 ? ~0ull : ((1ull << cnt) - 1);
+      // a probe of a resident cluster leaves its candidate nodes out (helpers.go:76-80): they are not in s.existingNodes at all
+      const uint64_t validm = (cnt == 64 ? ~0ull : ((1ull << cnt) - 1)) & (Pv.node_removed ? ~Pv.node_removed[base >> 6] : ~0ull);
       // nodes under consolidateAfter are skipped for non-pending pods that do not come from a deleting node (:628)
       const uint64_t skipped = exempt_pod ? 0ull : W::ballot([&](int l) { return l < cnt && (Pv.node_flags[base + l] & 2) != 0; });
       uint64_t todo = validm & ~deadw & ~skipped;

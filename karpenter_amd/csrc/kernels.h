@@ -16,14 +16,14 @@ namespace ks {
 
 #if KS_DEVICE
 KS_DEV uint64_t atomic_cas_u64(uint64_t* p, uint64_t expect, uint64_t v) { return (uint64_t)atomicCAS((unsigned long long*)p, (unsigned long long)expect, (unsigned long long)v); }
-KS_DEV void atomic_min_u32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+KS_DEV uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
 KS_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 KS_DEV void atomic_min_i64(int64_t* p, int64_t v) { atomicMin((long long*)p, (long long)v); }
 KS_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
 KS_DEV void atomic_or_u32(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 #else
 inline uint64_t atomic_cas_u64(uint64_t* p, uint64_t expect, uint64_t v) { uint64_t o = *p; if (o == expect) *p = v; return o; }
-inline void atomic_min_u32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
+inline uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
 inline uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p += v; return o; }
 inline void atomic_min_i64(int64_t* p, int64_t v) { if (v < *p) *p = v; }
 inline void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }
@@ -146,25 +146,6 @@ KS_FN bool equal_reqset(const Dict& d, const ReqRef& a, const ReqRef& b) {
   }
   return true;
 }
-KS_FN void row_hash_body(int row, const RowArgs& a) {
-  uint64_t h = a.seed;
-  for (int r = 0; r < a.n_res; ++r) h = mix64(h, (uint64_t)a.requests[(size_t)r * a.n_rows + row]);
-  h = hash_reqset(a.dict, h, a.reqs.at(a.dict, row));
-  h = hash_reqset(a.dict, h, a.strict.at(a.dict, row));
-  h = mix64(h, a.tolerates[row]);
-  if (a.host_ports) { h = mix64(h, a.host_ports[(size_t)row * 2]); h = mix64(h, a.host_ports[(size_t)row * 2 + 1]); }
-  if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) { h = mix64(h, a.topo_owned[(size_t)row * a.topo_words + w]); h = mix64(h, a.topo_selected[(size_t)row * a.topo_words + w]); }
-  if (h == 0) h = 1;
-  a.row_hash[row] = h;
-  uint32_t slot = (uint32_t)(h >> 17) & (a.table_size - 1);
-  for (;;) {
-    uint64_t prev = atomic_cas_u64(&a.table_hash[slot], 0ull, h);
-    if (prev == 0ull || prev == h) break;
-    slot = (slot + 1) & (a.table_size - 1);
-  }
-  atomic_min_u32(&a.table_rep[slot], (uint32_t)row);
-  a.row_slot[row] = slot;
-}
 KS_FN bool rows_equal(const RowArgs& a, int x, int y) {
   for (int r = 0; r < a.n_res; ++r) if (a.requests[(size_t)r * a.n_rows + x] != a.requests[(size_t)r * a.n_rows + y]) return false;
   if (!equal_reqset(a.dict, a.reqs.at(a.dict, x), a.reqs.at(a.dict, y))) return false;
@@ -177,17 +158,41 @@ KS_FN bool rows_equal(const RowArgs& a, int x, int y) {
   }
   return true;
 }
-// verify against the representative (a 64-bit hash collision between different rows is reported, the host re-seeds) and
-// let each representative draw a class id
+// One pass over the pod rows (the 421 B/row stream of the classing prepass): hash the row, find its slot, keep the smallest
+// row of the slot as the class representative, and check the row against a row that reached the slot earlier — equality
+// is transitive, so every row of a slot equals its first row unless a 64-bit hash collision is reported (the host
+// re-seeds). The table is read before it is written: with a few thousand classes for a million rows nearly every row
+// finds its hash and a smaller representative already there and issues no atomic at all (a stale read only shows an
+// older state — empty slot, larger representative — and falls through to the atomic).
+KS_FN void row_hash_body(int row, const RowArgs& a) {
+  uint64_t h = a.seed;
+  for (int r = 0; r < a.n_res; ++r) h = mix64(h, (uint64_t)a.requests[(size_t)r * a.n_rows + row]);
+  h = hash_reqset(a.dict, h, a.reqs.at(a.dict, row));
+  h = hash_reqset(a.dict, h, a.strict.at(a.dict, row));
+  h = mix64(h, a.tolerates[row]);
+  if (a.host_ports) { h = mix64(h, a.host_ports[(size_t)row * 2]); h = mix64(h, a.host_ports[(size_t)row * 2 + 1]); }
+  if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) { h = mix64(h, a.topo_owned[(size_t)row * a.topo_words + w]); h = mix64(h, a.topo_selected[(size_t)row * a.topo_words + w]); }
+  if (h == 0) h = 1;
+  a.row_hash[row] = h;
+  uint32_t slot = (uint32_t)(h >> 17) & (a.table_size - 1);
+  for (;;) {
+    uint64_t cur = ((volatile uint64_t*)a.table_hash)[slot];
+    if (cur == h) break;
+    if (cur == 0ull) {
+      cur = atomic_cas_u64(&a.table_hash[slot], 0ull, h);
+      if (cur == 0ull || cur == h) break;
+    }
+    slot = (slot + 1) & (a.table_size - 1);
+  }
+  a.row_slot[row] = slot;
+  uint32_t other = ((volatile uint32_t*)a.table_rep)[slot];
+  if (other > (uint32_t)row) other = atomic_min_u32(&a.table_rep[slot], (uint32_t)row);
+  if (other != 0xFFFFFFFFu && other != (uint32_t)row && !rows_equal(a, row, (int)other)) *a.collision = 1;
+}
+// each slot's final representative draws the class id
 KS_FN void row_verify_body(int row, const RowArgs& a) {
   uint32_t slot = a.row_slot[row];
-  uint32_t rep = a.table_rep[slot];
-  if (rep == (uint32_t)row) {
-    uint32_t id = atomic_add_u32(a.n_classes, 1u);
-    a.table_class[slot] = id;
-  } else if (!rows_equal(a, row, (int)rep)) {
-    *a.collision = 1;
-  }
+  if (a.table_rep[slot] == (uint32_t)row) a.table_class[slot] = atomic_add_u32(a.n_classes, 1u);
 }
 KS_FN void row_class_body(int row, const RowArgs& a) {
   uint32_t slot = a.row_slot[row];
@@ -195,48 +200,55 @@ KS_FN void row_class_body(int row, const RowArgs& a) {
   a.row_class[row] = id;
   if (a.table_rep[slot] == (uint32_t)row) a.class_rep[id] = (uint32_t)row;
 }
-KS_FN void copy_reqset(const Dict& d, const MutReqTable& dst, uint32_t di, const ReqRef& s) {
+KS_FN void copy_reqset(const Dict& d, const MutReqTable& dst, uint32_t di, const ReqRef& s, int lane = 0, int nl = 1) {
   uint64_t* m = dst.mask + (size_t)di * d.req_words;
-  for (int w = 0; w < d.req_words; ++w) m[w] = s.mask[w];
-  dst.defined[di] = s.defined; dst.complement[di] = s.complement; dst.has_gte[di] = s.has_gte; dst.has_lte[di] = s.has_lte;
-  for (int k = 0; k < d.n_keys; ++k) {
+  for (int w = lane; w < d.req_words; w += nl) m[w] = s.mask[w];
+  if (lane == 0) { dst.defined[di] = s.defined; dst.complement[di] = s.complement; dst.has_gte[di] = s.has_gte; dst.has_lte[di] = s.has_lte; }
+  for (int k = lane; k < d.n_keys; k += nl) {
     dst.gte[(size_t)di * d.n_keys + k] = (s.gte && bit(s.has_gte, k)) ? s.gte[k] : 0;
     dst.lte[(size_t)di * d.n_keys + k] = (s.lte && bit(s.has_lte, k)) ? s.lte[k] : 0;
     dst.minv[(size_t)di * d.n_keys + k] = s.minv ? s.minv[k] : -1;
   }
 }
-KS_FN void class_gather_body(int cls, const RowArgs& a) {
+// class tables from the representative row; `lane` of `nl` cooperating lanes (the device runs one wavefront per class, the
+// host emulation one call per class)
+KS_FN void class_gather_body(int cls, const RowArgs& a, int lane = 0, int nl = 1) {
   int row = (int)a.class_rep[cls];
-  for (int r = 0; r < a.n_res; ++r) {
+  for (int r = lane; r < a.n_res; r += nl) {
     int64_t v = a.requests[(size_t)r * a.n_rows + row];
     a.cls_requests[(size_t)cls * a.n_res + r] = v;
     atomic_min_i64(&a.min_request[r], v);
   }
-  copy_reqset(a.dict, a.cls_reqs, cls, a.reqs.at(a.dict, row));
-  copy_reqset(a.dict, a.cls_strict, cls, a.strict.at(a.dict, row));
-  a.cls_tolerates[cls] = a.tolerates[row];
-  if (a.host_ports) { a.cls_host_ports[(size_t)cls * 2] = a.host_ports[(size_t)row * 2]; a.cls_host_ports[(size_t)cls * 2 + 1] = a.host_ports[(size_t)row * 2 + 1]; }
+  copy_reqset(a.dict, a.cls_reqs, cls, a.reqs.at(a.dict, row), lane, nl);
+  copy_reqset(a.dict, a.cls_strict, cls, a.strict.at(a.dict, row), lane, nl);
+  if (lane == 0) {
+    a.cls_tolerates[cls] = a.tolerates[row];
+    if (a.host_ports) { a.cls_host_ports[(size_t)cls * 2] = a.host_ports[(size_t)row * 2]; a.cls_host_ports[(size_t)cls * 2 + 1] = a.host_ports[(size_t)row * 2 + 1]; }
+  }
   // packed records for the pack engine (RecLayout)
   const RecLayout& ly = a.lay;
   ReqRef q = a.reqs.at(a.dict, row);
   uint64_t* hot = a.cls_hot + (size_t)cls * ly.k_hot_words();
   uint64_t* cold = a.cls_cold + (size_t)cls * ly.cold_words();
-  for (int w = 0; w < ly.rw; ++w) hot[ly.k_mask() + w] = q.mask[w];
-  for (int r = 0; r < a.n_res; ++r) hot[ly.k_req() + r] = (uint64_t)a.requests[(size_t)r * a.n_rows + row];
-  hot[ly.k_f0()] = (uint64_t)q.defined | ((uint64_t)q.complement << 32);
-  hot[ly.k_f1()] = (uint64_t)q.has_gte | ((uint64_t)q.has_lte << 32);
-  hot[ly.k_tol()] = a.tolerates[row];
+  for (int w = lane; w < ly.rw; w += nl) hot[ly.k_mask() + w] = q.mask[w];
+  for (int r = lane; r < a.n_res; r += nl) hot[ly.k_req() + r] = (uint64_t)a.requests[(size_t)r * a.n_rows + row];
   bool has_minv = false;
   int64_t* cg = (int64_t*)cold; int64_t* cl = cg + ly.nk; int32_t* cv = (int32_t*)(cold + 2 * ly.nk);
   for (int k = 0; k < ly.nk; ++k) {
+    int32_t mv = q.minv ? q.minv[k] : -1;
+    if (mv >= 0 && bit(q.defined, k)) has_minv = true;
+    if (k % nl != lane) continue;
     cg[k] = (q.gte && bit(q.has_gte, k)) ? q.gte[k] : 0;
     cl[k] = (q.lte && bit(q.has_lte, k)) ? q.lte[k] : 0;
-    int32_t mv = q.minv ? q.minv[k] : -1;
     cv[k] = mv;
-    if (mv >= 0 && bit(q.defined, k)) has_minv = true;
   }
-  hot[ly.k_meta()] = has_minv ? 1u : 0u;
-  if (a.cls_topo) for (int w = 0; w < a.topo_words; ++w) {
+  if (lane == 0) {
+    hot[ly.k_f0()] = (uint64_t)q.defined | ((uint64_t)q.complement << 32);
+    hot[ly.k_f1()] = (uint64_t)q.has_gte | ((uint64_t)q.has_lte << 32);
+    hot[ly.k_tol()] = a.tolerates[row];
+    hot[ly.k_meta()] = has_minv ? 1u : 0u;
+  }
+  if (a.cls_topo) for (int w = lane; w < a.topo_words; w += nl) {
     a.cls_topo[(size_t)cls * 2 * a.topo_words + w] = a.topo_owned[(size_t)row * a.topo_words + w];
     a.cls_topo[(size_t)cls * 2 * a.topo_words + a.topo_words + w] = a.topo_selected[(size_t)row * a.topo_words + w];
   }

@@ -2,8 +2,9 @@
 //
 // Kernels (names as they appear in rocprofv3 traces):
 //   ksolve_it_index      one thread per instance type: inverts InstanceType.Requirements into per-(key,value) bitmasks
-//   ksolve_row_hash      one thread per pod row: streams the pod SoA from HBM, hashes, inserts into the class table
-//   ksolve_row_verify    exact compare against the class representative, class numbering
+//   ksolve_row_hash      one thread per pod row, ONE pass over the pod SoA: hash, class-table slot (read before any atomic),
+//                        smallest row of the slot as representative, exact compare against an earlier row of the slot
+//   ksolve_row_verify    class numbering (every slot's final representative draws an id)
 //   ksolve_row_class / ksolve_class_gather   class ids per row, class tables
 //   ksolve_sort_key      queue-order key extraction (5 stable LSD passes with rocprim::radix_sort_pairs)
 //   ksolve_pack          the pack engine: ONE wavefront per scheduling problem (engine.h)
@@ -81,9 +82,9 @@ __global__ void ksolve_row_class(int n, ks::RowArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ks::row_class_body(i, a);
 }
-__global__ void ksolve_class_gather(int n, ks::RowArgs a) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) ks::class_gather_body(i, a);
+__global__ void ksolve_class_gather(int n, ks::RowArgs a) {   // one wavefront per class
+  int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i < n) ks::class_gather_body(i, a, (int)(threadIdx.x & 63), 64);
 }
 __global__ void ksolve_sort_key(int n, ks::SortKeyArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,7 +164,7 @@ static void be_launch_it_index(ksolve_handle* h, int n, const ks::ItIndexArgs& a
 static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_row_hash, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
 static void be_launch_row_verify(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_row_verify, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
 static void be_launch_row_class(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_row_class, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
-static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_class_gather, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
+static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_class_gather, grid_for(n * 64), dim3(256), 0, HB(h)->stream, n, a); }
 static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a) { hipLaunchKernelGGL(ksolve_finalize, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
 static void be_launch_pack(ksolve_handle* h) {
   const int lds_bytes = h->pv.lds.total_bytes;
@@ -309,6 +310,19 @@ ksolve_status ksolve_create(const ksolve_problem_desc* desc, const ksolve_option
   if (!hip_check(h, hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate")) return KSOLVE_ERR_DEVICE;
   for (int i = 0; i < 8; ++i) { hip_check(h, hipEventCreate(&b->ev0[i]), "hipEventCreate"); hip_check(h, hipEventCreate(&b->ev1[i]), "hipEventCreate"); }
   return ksi::create(desc, opts, h);
+}
+ksolve_status ksolve_probe_create(ksolve_handle* base, const ksolve_probe* probe, ksolve_handle** out) {
+  if (!out) return KSOLVE_ERR_INVALID;
+  ksolve_handle* h = new ksolve_handle();
+  HipBackend* b = new HipBackend();
+  h->backend = b;
+  *out = h;
+  if (!base || !base->backend) { h->error = "null base handle"; return KSOLVE_ERR_INVALID; }
+  b->device = HB(base)->device;
+  if (!hip_check(h, hipSetDevice(b->device), "hipSetDevice")) return KSOLVE_ERR_DEVICE;
+  if (!hip_check(h, hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate")) return KSOLVE_ERR_DEVICE;
+  for (int i = 0; i < 8; ++i) { hip_check(h, hipEventCreate(&b->ev0[i]), "hipEventCreate"); hip_check(h, hipEventCreate(&b->ev1[i]), "hipEventCreate"); }
+  return ksi::probe_create(base, probe, h);
 }
 ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out) {
   if (!h || !h->backend) return KSOLVE_ERR_INVALID;

@@ -74,6 +74,10 @@ struct ksolve_handle {
   ks::FastWork fw{};            // cursor engine (fast_engine.h): workspace + LDS plan; fw.enabled while the problem may qualify
   uint32_t engine_used = 0, fast_reason = 0;
   ks::FastArgs* d_fast_args = nullptr;   // the record ksolve_pack_fast reads its problem from
+  // probes of a resident cluster (ksolve_probe_create): a probe handle shares the base's device tables
+  ksolve_handle* base = nullptr;         // non-null: this handle is a probe of `base`
+  bool prepared = false;                 // base: phases 1-3 have run and h_rank is valid
+  std::vector<uint32_t> h_rank;          // base: queue position of every pod (queue.go:72-108 order)
 };
 
 // ---- backend hooks (defined by the including TU before this point is instantiated) ----
@@ -312,7 +316,8 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     P.dg_its = up(h, gits.data(), gits.size());
     P.dg_nonzero = nonzero; P.dg_nonempty = nonempty;
     // host ports: only matter when some pod binds one
-    P.hp_on = d->pod_host_ports ? 1 : 0; P.cls_hp = nullptr; P.dg_hp = nullptr; P.node_hp0 = nullptr;
+    P.node_removed = nullptr;
+  P.hp_on = d->pod_host_ports ? 1 : 0; P.cls_hp = nullptr; P.dg_hp = nullptr; P.node_hp0 = nullptr;
     if (P.hp_on) {
       if (!d->pod_host_port_conflicts) return fail(h, KSOLVE_ERR_INVALID, "pod_host_ports without pod_host_port_conflicts");
       std::vector<uint64_t> ghp((size_t)std::max(1, P.n_dg), 0);
@@ -604,6 +609,120 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   return KSOLVE_OK;
 }
 
+static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context);
+
+// ksolve_probe_create: a handle that shares `base`'s device tables and owns one arena with its workspace.
+static ksolve_status probe_create(ksolve_handle* base, const ksolve_probe* pr, ksolve_handle* h) {
+  if (!base || base->base || !pr) return fail(h, KSOLVE_ERR_INVALID, "probe of a null handle / of a probe");
+  if (base->has_topology) return fail(h, KSOLVE_ERR_UNSUPPORTED, "probes of a cluster with topology groups: create one handle per probe");
+  if (pr->n_pods && !pr->pods) return fail(h, KSOLVE_ERR_INVALID, "probe pods missing");
+  if (base->n_nodes && !pr->removed_nodes) return fail(h, KSOLVE_ERR_INVALID, "probe removed_nodes missing");
+  if (!base->prepared) {
+    ksolve_status st = solve_prepare(base, true);
+    if (st != KSOLVE_OK) return fail(h, st, base->error);
+    std::vector<uint32_t> order(base->n_pods);
+    if (base->n_pods) be_d2h(base, order.data(), base->pv.sorted_pods, (size_t)base->n_pods * 4);
+    be_sync(base);
+    if (!be_ok(base)) return fail(h, KSOLVE_ERR_DEVICE, base->error);
+    base->h_rank.assign(base->n_pods, 0);
+    for (uint32_t i = 0; i < base->n_pods; ++i) base->h_rank[order[i]] = i;
+    base->prepared = true;
+  }
+  const uint32_t m = pr->n_pods;
+  std::vector<uint32_t> pods(pr->pods, pr->pods + m);
+  for (uint32_t p : pods) if (p >= base->n_pods) return fail(h, KSOLVE_ERR_INVALID, "probe pod index out of range");
+  std::sort(pods.begin(), pods.end(), [&](uint32_t a, uint32_t b) { return base->h_rank[a] < base->h_rank[b]; });   // the base queue order, restricted
+  for (uint32_t i = 1; i < m; ++i) if (pods[i] == pods[i - 1]) return fail(h, KSOLVE_ERR_INVALID, "probe pod listed twice");
+
+  h->base = base;
+  h->opts = base->opts;
+  h->n_keys = base->n_keys; h->req_words = base->req_words; h->n_res = base->n_res; h->n_its = base->n_its; h->it_words = base->it_words;
+  h->n_templates = base->n_templates; h->n_pods = base->n_pods; h->n_rows = base->n_rows; h->n_classes = base->n_classes;
+  h->class_capacity = base->n_classes; h->n_nodes = base->n_nodes; h->n_kv = base->n_kv; h->has_topology = false;
+  h->pv = base->pv;
+  ks::ProblemView& P = h->pv;
+  ks::Workspace& W = h->ws;
+  W = ks::Workspace{};
+  uint32_t mc = std::max(1u, m);
+  if (h->opts.max_claims && h->opts.max_claims < mc) mc = h->opts.max_claims;
+  h->max_claims = mc; h->claim_words = (mc + 63) / 64;
+  W.max_claims = (int)mc; W.claim_words = (int)h->claim_words;
+  const ks::RecLayout lay = P.lay;
+  const uint32_t ne = base->n_nodes, nr = base->n_res, T = base->n_templates, nc = base->n_classes, np_all = base->n_pods;
+  const size_t nw = (size_t)P.node_words;
+
+  // one arena: laid out twice (measure, then carve)
+  char* arena = nullptr;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { void* p = arena ? (void*)(arena + off) : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
+  uint32_t* d_sorted = nullptr; uint64_t* d_removed = nullptr; int64_t* d_limits = nullptr;
+  auto layout = [&]() {
+    off = 0;
+    W.c_hot = (uint64_t*)take((size_t)mc * lay.c_hot_words() * 8);
+    W.c_cold = (uint64_t*)take((size_t)mc * lay.cold_words() * 8);
+    W.c_headroom = (int64_t*)take(((size_t)mc * nr + 64) * 8);
+    W.c_reserved = (uint64_t*)take((size_t)mc * 8);
+    W.c_hp = P.hp_on ? (uint64_t*)take((size_t)mc * 8) : nullptr;
+    W.o_key = (uint32_t*)take((size_t)mc * 4); W.o_ord = (uint32_t*)take((size_t)mc * 4); W.o_pos = (uint32_t*)take((size_t)mc * 4);
+    W.queue = (uint32_t*)take(((size_t)m + 1) * 4);
+    W.last_len = (uint32_t*)take((size_t)np_all * 4);
+    W.t_its = (uint64_t*)take((size_t)T * h->it_words * 8);
+    W.t_remaining = (int64_t*)take((size_t)T * (nr + 1) * 8);
+    W.assign = (int32_t*)take((size_t)np_all * 4); W.err = (uint8_t*)take(np_all); W.diag = (uint8_t*)take(np_all); W.slot = (uint32_t*)take((size_t)np_all * 4);
+    W.n_claims_out = (int*)take(4); W.status_out = (int*)take(4);
+    h->d_cancel = (int*)take(4);
+    W.counters = (ks::Counters*)take(sizeof(ks::Counters));
+    h->d_cheapest = (double*)take((size_t)mc * 8);
+    h->d_daemon_requests = (int64_t*)take((size_t)mc * nr * 8);
+    W.dead = (uint64_t*)take((size_t)std::max(1u, nc) * h->claim_words * 8);
+    if (ne) {
+      W.n_dead = (uint64_t*)take((size_t)std::max(1u, nc) * nw * 8);
+      W.n_mask = (uint64_t*)take((size_t)h->req_words * ne * 8);
+      W.n_defined = (uint32_t*)take((size_t)ne * 4); W.n_complement = (uint32_t*)take((size_t)ne * 4);
+      W.n_remaining = (int64_t*)take((size_t)nr * ne * 8);
+      W.n_npods = (uint32_t*)take((size_t)ne * 4);
+      W.n_hp = P.hp_on ? (uint64_t*)take((size_t)ne * 8) : nullptr;
+      d_removed = (uint64_t*)take(nw * 8);
+    }
+    d_sorted = (uint32_t*)take(((size_t)m + 1) * 4);
+    d_limits = pr->tmpl_limits ? (int64_t*)take((size_t)T * (nr + 1) * 8) : nullptr;
+  };
+  layout();
+  const size_t total = off;
+  arena = (char*)be_alloc(h, total);    // zero-filled
+  if (!arena) return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "device allocation failed" : h->error);
+  layout();
+  W.n_mask0 = base->ws.n_mask0; W.n_defined0 = base->ws.n_defined0; W.n_complement0 = base->ws.n_complement0; W.n_remaining0 = base->ws.n_remaining0;
+  W.cancel_flag = h->d_cancel;
+  W.max_steps = h->opts.max_steps;
+  W.min_values_best_effort = h->opts.min_values_best_effort ? 1 : 0;
+  if (m) be_h2d(h, d_sorted, pods.data(), (size_t)m * 4);
+  if (ne) be_h2d(h, d_removed, pr->removed_nodes, nw * 8);
+  if (d_limits) be_h2d(h, d_limits, pr->tmpl_limits, (size_t)T * (nr + 1) * 8);
+  P.n_pods = (int)m;
+  P.sorted_pods = d_sorted;
+  P.node_removed = ne ? d_removed : nullptr;
+  if (d_limits) P.tmpl_limits = d_limits;
+  // LDS plan: the base plan with the claim order cut down to this probe's pods
+  {
+    ks::LdsPlan& lp = P.lds;
+    auto align = [](int x) { return (x + 15) & ~15; };
+    int cap = lp.order_cap;
+    if (cap > (int)((mc + 63) & ~63u)) cap = (int)((mc + 63) & ~63u);
+    int o = lp.off_order;
+    lp.order_cap = cap;
+    o = align(o + cap * 12);
+    lp.off_closed = o; o = align(o + cap / 8 + 8);
+    lp.total_bytes = o;
+    P.big = 0;
+    h->lds_big = lp; h->big_capable = false;
+  }
+  h->fw = ks::FastWork{};   // existing nodes: never the cursor engine's shape
+  be_sync(h);
+  if (!be_ok(h)) return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "device allocation/upload failed" : h->error);
+  return KSOLVE_OK;
+}
+
 struct ResultsImpl {
   std::vector<int32_t> assign, tmpl;
   std::vector<uint8_t> err, diag, relaxed;
@@ -626,6 +745,16 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
   const uint32_t n_pods = h->n_pods, n_rows = h->n_rows, n_res = h->n_res;
   h->engine_used = 1;
   if (fresh_context) { be_fill(h, h->d_cancel, 0, 4); be_sync(h); }
+  if (h->base) {
+    // a probe of a resident cluster: index, classes and queue order are the base handle's; only the workspace is reset
+    if (h->n_classes) be_fill(h, W.dead, 0, (size_t)h->n_classes * h->claim_words * 8);
+    if (h->n_classes && h->n_nodes) be_fill(h, W.n_dead, 0, (size_t)h->n_classes * P.node_words * 8);
+    be_fill(h, W.last_len, 0, (size_t)n_pods * 4);
+    be_fill(h, W.assign, 0xFF, (size_t)n_pods * 4);
+    be_fill(h, W.err, 0, n_pods); be_fill(h, W.diag, 0, n_pods);
+    be_fill(h, W.n_claims_out, 0, 4); be_fill(h, W.status_out, 0, 4);
+    return KSOLVE_OK;
+  }
 
   // ---- phase 1: instance-type requirement index ----
   be_tic(h, T_INDEX);

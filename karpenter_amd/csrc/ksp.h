@@ -164,6 +164,7 @@ struct ProblemView {
   const double* resv_price;
 
   // host ports (hostportusage.go): masks over the problem's distinct <ip, port, protocol> triples
+  const uint64_t* node_removed;  // [node_words] existing nodes that are absent in this probe of a resident cluster (null: none)
   int hp_on;                     // some pod binds a host port
   const uint64_t* cls_hp;        // [n_classes][2] triples the class binds | triples that match one of them
   const uint64_t* dg_hp;         // [n_dg] triples of each daemon-overhead group's daemon pods

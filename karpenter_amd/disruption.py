@@ -279,8 +279,84 @@ def interweave_by_nodepool(candidates, previously_unseen=()):
 MAX_INSTANCE_TYPES = 600   # scheduling.MaxInstanceTypes, nodeclaimtemplate.go:50
 
 
+def _finish_simulation(cluster, res, deleting_uids):
+    """helpers.go:133-153 on the Results of one simulation: pods that landed on an uninitialized node make the decision
+    unsafe; AllNonPendingPodsScheduled (scheduler.go:388-392)."""
+    errors = dict(res["podErrors"])
+    for en in res["existingNodes"]:
+        if not en.get("initialized", True):
+            for uid in en["pods"]:
+                if uid not in deleting_uids:
+                    errors[uid] = {"code": 100, "diag": 0}  # UninitializedNodeError
+    pending_uids = {p["uid"] for p in cluster.get("pendingPods", [])}
+    res = dict(res)
+    res["podErrors"] = errors
+    res["allNonPendingPodsScheduled"] = not [u for u in errors if u not in pending_uids]
+    return res
+
+
+def _has_topology(pod):
+    return bool(pod.get("topologySpreadConstraints") or pod.get("podAffinity") or pod.get("podAntiAffinity"))
+
+
+class ResidentCluster:
+    """The cluster uploaded ONCE (ksolve_create), every simulation a probe of it (ksolve_probe_create: removed-node bitmap
+    + displaced-pod rows) — SimulateScheduling (helpers.go:53-155) without assembling, flattening or uploading a problem
+    per candidate set. Passed wherever this module takes a `solver`: simulate_scheduling() asks it for the Results.
+
+    `prefetch(candidate_sets)` sends all those simulations to the device as ONE batched launch (one wavefront per probe)
+    and keeps their Results; single-node consolidation prefetches every candidate, the multi-node binary search every
+    prefix it can reach. Clusters whose pods carry topology constraints are not probed (the per-probe domain counts are
+    not derived on the device yet): Unsupported is raised at construction and the caller keeps the per-probe path."""
+
+    def __init__(self, cluster, candidates, solver_lib=None):
+        from .scheduling import NewScheduler, Unsupported
+        self.cluster = cluster
+        deleting = [n for n in cluster["nodes"] if n.get("markedForDeletion")]
+        self._deleting_pods = [p for n in deleting for p in n.get("pods", [])]
+        self._deleting_uids = {p["uid"] for p in self._deleting_pods}
+        self._always = list(cluster.get("pendingPods", [])) + self._deleting_pods          # part of every simulation
+        displaced = [p for c in candidates if not c.get("markedForDeletion") for p in c.get("pods", [])]
+        if any(_has_topology(p) for n in cluster["nodes"] for p in n.get("pods", [])) or any(_has_topology(p) for p in self._always):
+            raise Unsupported("probes of a cluster whose pods carry topology constraints")
+        state_nodes = [{k: v for k, v in n.items() if k != "pods"} for n in cluster["nodes"] if not n.get("markedForDeletion")]
+        prob = fx.problem(cluster["instanceTypes"], cluster["nodePools"], copy.deepcopy(self._always + displaced),
+                          well_known=cluster.get("wellKnownLabels", fx.KWOK_WELL_KNOWN), state_nodes=state_nodes,
+                          options=dict(cluster.get("options", {}), consolidationSimulation=True, truncateInstanceTypes=MAX_INSTANCE_TYPES),
+                          namespaces=cluster.get("namespaces"), deleting_node_names=[n["name"] for n in deleting])
+        self.scheduler = NewScheduler(prob, solver_lib)
+        self._cache = {}
+
+    def _key(self, candidates):
+        return tuple(sorted(c["name"] for c in candidates))
+
+    def _probe(self, candidates):
+        live = [c for c in candidates if not c.get("markedForDeletion")]
+        pods = [p["uid"] for p in self._always] + [p["uid"] for c in live for p in c.get("pods", [])]
+        return self.scheduler.Probe([c["name"] for c in live], pods)
+
+    def prefetch(self, candidate_sets):
+        from .scheduling import SolveBatch
+        todo = [cs for cs in candidate_sets if self._key(cs) not in self._cache]
+        if not todo:
+            return
+        probes = [self._probe(cs) for cs in todo]
+        for cs, res, pr in zip(todo, SolveBatch(probes), probes):
+            self._cache[self._key(cs)] = _finish_simulation(self.cluster, res, self._deleting_uids)
+            pr.close()
+
+    def simulate(self, candidates):
+        self.prefetch([candidates])
+        return self._cache[self._key(candidates)]
+
+    def close(self):
+        self.scheduler.close()
+
+
 def simulate_scheduling(cluster, candidates, solver):
     """helpers.go:53-155: Solve() with the candidates removed and their pods added to the pending set."""
+    if isinstance(solver, ResidentCluster):
+        return solver.simulate(candidates)
     names = {c["name"] for c in candidates}
     state_nodes = [{k: v for k, v in n.items() if k != "pods"} for n in cluster["nodes"] if n["name"] not in names and not n.get("markedForDeletion")]
     deleting = [n for n in cluster["nodes"] if n.get("markedForDeletion") and n["name"] not in names]
@@ -297,19 +373,7 @@ def simulate_scheduling(cluster, candidates, solver):
                       namespaces=cluster.get("namespaces"),
                       deleting_node_names=[n["name"] for n in deleting])
     res = solver(prob)
-    # pods that landed on an uninitialized node make the decision unsafe (helpers.go:133-153)
-    deleting_uids = {p["uid"] for p in deleting_pods}
-    errors = dict(res["podErrors"])
-    for en in res["existingNodes"]:
-        if not en.get("initialized", True):
-            for uid in en["pods"]:
-                if uid not in deleting_uids:
-                    errors[uid] = {"code": 100, "diag": 0}  # UninitializedNodeError
-    pending_uids = {p["uid"] for p in cluster.get("pendingPods", [])}
-    res = dict(res)
-    res["podErrors"] = errors
-    res["allNonPendingPodsScheduled"] = not [u for u in errors if u not in pending_uids]  # AllNonPendingPodsScheduled, scheduler.go:388-392
-    return res
+    return _finish_simulation(cluster, res, {p["uid"] for p in deleting_pods})
 
 
 MIN_INSTANCE_TYPES_FOR_SPOT_TO_SPOT = 15      # consolidation.go:46
@@ -499,6 +563,14 @@ def sweep_batched(cluster, candidates, batch_solver):
             pass
     rec.results = batch_solver(rec.problems)
     return [compute_consolidation(cluster, [c], rec) for c in candidates]
+
+
+def sweep_resident(cluster, candidates, solver_lib=None):
+    """Single-node consolidation sweep over a RESIDENT cluster: one upload, one probe descriptor per candidate, one
+    batched launch. Same decisions as sweep(); returns (decisions, ResidentCluster) — close() it when done."""
+    rc = ResidentCluster(cluster, candidates, solver_lib)
+    rc.prefetch([[c] for c in candidates])
+    return [compute_consolidation(cluster, [c], rc) for c in candidates], rc
 
 
 def sweep(cluster, candidates, solver, workers=1):

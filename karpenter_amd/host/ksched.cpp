@@ -575,6 +575,16 @@ struct Session {
   std::vector<i128> scale;
   int n_pods = 0, n_rows = 0, n_its = 0, n_res = 0, it_words = 0, k_rid = -1, n_topo_groups = 0, n_alias_classes = 0;
   std::string error_kind, error;
+  // probes of a resident cluster (ksched_probe): what a probe needs from the base session besides the device handle
+  int n_templates = 0;
+  std::vector<int> node_tmpl;              // template (NodePool) of each existing node, -1 = none / pool without limits
+  std::vector<int64_t> node_limit_cap;     // [n_nodes][n_res+1] node capacity on the dimensions its pool limits (device units)
+  std::vector<int64_t> tmpl_lim;           // [n_templates][n_res+1] remaining limits of the base problem
+  std::map<std::string, int> node_index, pod_index;   // built on the first probe
+  // a probe session: shares the base session's metadata, owns its handle
+  Session* base = nullptr;
+  std::vector<uint8_t> probe_member, probe_removed;
+  int probe_pods = 0;
 };
 
 static char* session_error(Session* s) { char* r = error_json(s->error_kind.c_str(), s->error); return r; }
@@ -832,12 +842,17 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     const int n_nodes = (int)nodes.size();
     std::vector<std::vector<Expr>> node_exprs(n_nodes);
     std::vector<uint64_t> node_taints(n_nodes, 0);
+    // Every requirement source other than the nodes has been noted by now. When none of them mentions kubernetes.io/hostname
+    // — no pod, NodePool, instance type or daemonset selects on it — a node's own hostname requirement (existingnode.go:72)
+    // can never meet another requirement on that key (hostname topology groups count per node index, not per dictionary
+    // value), so it is left out instead of spending one dictionary value per node (a 10k-node cluster would need 157 words).
+    const bool hostname_selected = D.key_index.count(kHostname) != 0;
     for (int e = 0; e < n_nodes; ++e) {
       node_exprs[e] = label_exprs(nodes[e].v->at("labels"));
       // NewExistingNode adds hostname In [HostName()] (existingnode.go:72); drop a hostname label so it is not intersected twice
       node_exprs[e].erase(std::remove_if(node_exprs[e].begin(), node_exprs[e].end(), [](const Expr& x) { return x.key == kHostname; }), node_exprs[e].end());
-      if (nodes[e].v->at("labels").has(kHostname)) node_exprs[e].push_back(Expr{kHostname, "In", {nodes[e].v->at("labels").at(kHostname).s()}, -1});
-      node_exprs[e].push_back(Expr{kHostname, "In", {nodes[e].hostname}, -1});
+      if (hostname_selected && nodes[e].v->at("labels").has(kHostname)) node_exprs[e].push_back(Expr{kHostname, "In", {nodes[e].v->at("labels").at(kHostname).s()}, -1});
+      if (hostname_selected) node_exprs[e].push_back(Expr{kHostname, "In", {nodes[e].hostname}, -1});
       for (auto& x : node_exprs[e]) D.note(x);
       for (auto& tv : nodes[e].v->at("taints").items()) node_taints[e] |= 1ull << taint_id(Taint{tv.at("key").s(), tv.at("value").s(), tv.at("effect").s()});
     }
@@ -982,6 +997,8 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     std::vector<uint64_t> tmpl_its((size_t)n_templates * it_words, 0);
     std::vector<uint32_t> tmpl_limit_mask(n_templates, 0);
     std::vector<int64_t> tmpl_lim((size_t)n_templates * (n_res + 1), 0);
+    S->node_tmpl.assign(n_nodes, -1);
+    S->node_limit_cap.assign((size_t)n_nodes * (n_res + 1), 0);
     for (int t = 0; t < n_templates; ++t) {
       ks::ReqBuf b;
       Flattener::clear(b);
@@ -1004,6 +1021,18 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
           const Value& nl = nodes[e].v->at("labels");
           if (!nl.has(kNodePool) || nl.at(kNodePool).s() != pools[t].name) continue;
           for (auto& kv : tmpl_limits[t]) { auto f = node_cap[e].find(kv.first); if (f != node_cap[e].end()) kv.second -= f->second; }
+        }
+        for (int e = 0; e < n_nodes; ++e) {
+          const Value& nl = nodes[e].v->at("labels");
+          if (!nl.has(kNodePool) || nl.at(kNodePool).s() != pools[t].name) continue;
+          S->node_tmpl[e] = t;
+          for (auto& kv : tmpl_limits[t]) {
+            auto f = node_cap[e].find(kv.first);
+            if (f == node_cap[e].end()) continue;
+            if (kv.first == "nodes") { S->node_limit_cap[(size_t)e * (n_res + 1) + n_res] = (int64_t)(f->second / 1000000000); continue; }
+            int r = (int)(std::find(res_names.begin(), res_names.end(), kv.first) - res_names.begin());
+            S->node_limit_cap[(size_t)e * (n_res + 1) + r] = to_dev(r, f->second);
+          }
         }
         for (auto& kv : tmpl_limits[t]) {
           if (kv.first == "nodes") { tmpl_limit_mask[t] |= 1u << n_res; tmpl_lim[(size_t)t * (n_res + 1) + n_res] = (int64_t)(kv.second / 1000000000); continue; }
@@ -1123,7 +1152,10 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       if (!daemons.empty()) {
         ks::ReqBuf lb;
         Flattener::clear(lb);
-        for (auto& x : label_exprs(nodes[e].v->at("labels"))) { ks::ReqBuf one; fl.encode(x, one); ks::reqbuf_add(fl.kd, lb, ks::reqbuf_ref_with_minv(one)); }
+        for (auto& x : label_exprs(nodes[e].v->at("labels"))) {
+          if (x.key == kHostname && !hostname_selected) continue;   // not in the dictionary: no daemonset selects on it
+          ks::ReqBuf one; fl.encode(x, one); ks::reqbuf_add(fl.kd, lb, ks::reqbuf_ref_with_minv(one));
+        }
         for (auto& dp : daemons) {
           bool tolerated = true;
           for (size_t ti = 0; ti < distinct_taints.size(); ++ti) if ((node_taints[e] >> ti) & 1) {
@@ -1278,7 +1310,11 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       std::vector<std::map<std::string, std::string>> node_labels(n_nodes);
       for (int e = 0; e < n_nodes; ++e) {
         Flattener::clear(node_label_reqs[e]);
-        for (auto& x : label_exprs(nodes[e].v->at("labels"))) { ks::ReqBuf one; fl.encode(x, one); ks::reqbuf_add(fl.kd, node_label_reqs[e], ks::reqbuf_ref_with_minv(one)); node_labels[e][x.key] = x.values[0]; }
+        for (auto& x : label_exprs(nodes[e].v->at("labels"))) {
+          node_labels[e][x.key] = x.values[0];
+          if (x.key == kHostname && !hostname_selected) continue;   // not in the dictionary: nothing selects on it (see above)
+          ks::ReqBuf one; fl.encode(x, one); ks::reqbuf_add(fl.kd, node_label_reqs[e], ks::reqbuf_ref_with_minv(one));
+        }
       }
       std::map<std::string, int> node_by_name;
       for (int e = 0; e < n_nodes; ++e) node_by_name[nodes[e].name] = e;
@@ -1603,6 +1639,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     for (int i = 0; i < n_its; ++i) S->it_names.push_back(its_json[i].at("name").s());
     S->k_rid = k_rid;
     S->n_pods = n_pods; S->n_rows = n_rows; S->n_its = n_its; S->n_res = n_res; S->it_words = it_words;
+    S->n_templates = n_templates; S->tmpl_lim = tmpl_lim;
     return S;
   } catch (const Unsupported& e) {
     if (S->handle) { api.destroy(S->handle); S->handle = nullptr; }
@@ -1630,6 +1667,60 @@ extern "C" int ksched_cancel(void* session) {
   if (!S || !S->handle || !S->api.cancel) return -1;
   return (int)S->api.cancel(S->handle);
 }
+// One probe of a resident cluster (ksolve_probe_create): `probe_json` = {"removeNodes": [node names], "pods": [uids]}.
+// The new session shares the base session's tables on the host and on the device; close it before the base session.
+extern "C" void* ksched_probe(void* base_session, const char* probe_json) {
+  Session* B = (Session*)base_session;
+  Session* S = new Session();
+  if (!B || !B->handle || B->base) { S->error_kind = "invalid"; S->error = "probe needs an open base session"; return S; }
+  S->api = B->api;
+  S->base = B;
+  try {
+    auto create = (decltype(&ksolve_probe_create))dlsym(B->api.lib, "ksolve_probe_create");
+    if (!create) { S->error_kind = "load"; S->error = "solver library lacks ksolve_probe_create"; return S; }
+    if (B->node_index.empty()) for (size_t e = 0; e < B->node_names.size(); ++e) B->node_index[B->node_names[e]] = (int)e;
+    if (B->pod_index.empty()) for (int p = 0; p < B->n_pods; ++p) if (!B->uid_text[p].empty()) B->pod_index[B->uid_text[p]] = p;
+    Value doc = kj::Parser(probe_json).parse();
+    const size_t ne = B->node_names.size();
+    const int nr1 = B->n_res + 1;
+    std::vector<uint64_t> removed((ne + 63) / 64 + 1, 0);
+    S->probe_removed.assign(ne, 0);
+    std::vector<int64_t> lim = B->tmpl_lim;
+    for (auto& n : doc.at("removeNodes").items()) {
+      auto f = B->node_index.find(n.s());
+      if (f == B->node_index.end()) throw std::runtime_error("probe removes an unknown node " + n.s());
+      const int e = f->second;
+      if (S->probe_removed[e]) continue;
+      S->probe_removed[e] = 1;
+      removed[e / 64] |= 1ull << (e % 64);
+      const int t = B->node_tmpl[e];   // the pool gets the node's capacity back (scheduler.go:835-842)
+      if (t >= 0) for (int r = 0; r < nr1; ++r) lim[(size_t)t * nr1 + r] += B->node_limit_cap[(size_t)e * nr1 + r];
+    }
+    std::vector<uint32_t> pods;
+    S->probe_member.assign(B->n_pods, 0);
+    for (auto& u : doc.at("pods").items()) {
+      auto f = B->pod_index.find(u.s());
+      if (f == B->pod_index.end()) throw std::runtime_error("probe schedules an unknown pod " + u.s());
+      if (S->probe_member[f->second]) throw std::runtime_error("probe lists pod " + u.s() + " twice");
+      S->probe_member[f->second] = 1;
+      pods.push_back((uint32_t)f->second);
+    }
+    S->probe_pods = (int)pods.size();
+    ksolve_probe pr{};
+    pr.removed_nodes = removed.data(); pr.n_pods = (uint32_t)pods.size(); pr.pods = pods.data();
+    pr.tmpl_limits = lim.empty() ? nullptr : lim.data();
+    ksolve_status st = create(B->handle, &pr, &S->handle);
+    if (st != KSOLVE_OK) {
+      S->error = S->handle ? S->api.last_error(S->handle) : "ksolve_probe_create failed";
+      S->error_kind = st == KSOLVE_ERR_UNSUPPORTED ? "unsupported" : "create";
+      if (S->handle) { S->api.destroy(S->handle); S->handle = nullptr; }
+    }
+  } catch (const std::exception& e) {
+    if (S->handle) { S->api.destroy(S->handle); S->handle = nullptr; }
+    S->error_kind = "invalid"; S->error = e.what();
+  }
+  return S;
+}
 extern "C" void ksched_close(void* session) {
   Session* S = (Session*)session;
   if (!S) return;
@@ -1643,6 +1734,10 @@ extern "C" void ksched_close(void* session) {
 static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int want_results) {
   Api& api = S->api;
   ksolve_handle* handle = S->handle;
+  Session* own = S;                       // the session whose handle ran (a probe owns only that and its membership tables)
+  if (S->base) S = S->base;               // names, dictionaries and scales are the base session's
+  auto in_probe = [&](int p) { return !own->base || own->probe_member[p]; };
+  auto node_there = [&](size_t e) { return !own->base || !own->probe_removed[e]; };
   Flattener& fl = S->fl;
   Dictionary& D = fl.dict;
   const int n_pods = S->n_pods, n_rows = S->n_rows, n_its = S->n_its, n_res = S->n_res, it_words = S->it_words;
@@ -1680,7 +1775,7 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
     counters.set("referenceBinEvaluations", Value::integer((int64_t)res.ref_bin_evaluations));
     counters.set("pops", Value::integer((int64_t)res.queue_pops)); counters.set("sorts", Value::integer((int64_t)res.sorts));
     counters.set("slowSorts", Value::integer((int64_t)res.slow_sorts)); counters.set("relaxations", Value::integer((int64_t)res.relaxations));
-    counters.set("pods", Value::integer(n_pods)); counters.set("claims", Value::integer(cl.n_claims));
+    counters.set("pods", Value::integer(own->base ? own->probe_pods : n_pods)); counters.set("claims", Value::integer(cl.n_claims));
     counters.set("engine", Value::string(res.engine_used == 2 ? "cursor" : "general")); counters.set("engineFallbackReason", Value::integer((int64_t)res.engine_fallback_reason));
     counters.set("rows", Value::integer(n_rows)); counters.set("instanceTypes", Value::integer(n_its));
     counters.set("topologyGroups", Value::integer(S->n_topo_groups)); counters.set("topologyAliasClasses", Value::integer(S->n_alias_classes));
@@ -1691,14 +1786,15 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
     out.set("timedOut", Value::boolean(st == KSOLVE_ERR_CANCELLED));
     out.set("packingCost", Value::number(res.packing_cost));
     int unscheduled = 0;
-    for (int p = 0; p < n_pods; ++p) if (res.pod_assignment[p] == -1) unscheduled++;
-    counters.set("existingNodes", Value::integer((int64_t)S->node_names.size()));
-    out.set("scheduledPods", Value::integer(n_pods - unscheduled));
+    for (int p = 0; p < n_pods; ++p) if (in_probe(p) && res.pod_assignment[p] == -1) unscheduled++;
+    { int64_t there = 0; for (size_t e = 0; e < S->node_names.size(); ++e) if (node_there(e)) there++; counters.set("existingNodes", Value::integer(there)); }
+    out.set("scheduledPods", Value::integer((own->base ? own->probe_pods : n_pods) - unscheduled));
     if (want_results) {
       std::vector<std::vector<std::pair<uint32_t, int>>> members(cl.n_claims);
       std::vector<std::vector<std::pair<uint32_t, int>>> node_members(S->node_names.size());
       Value errs = Value::object();
       for (int p = 0; p < n_pods; ++p) {
+        if (!in_probe(p)) continue;
         int a = res.pod_assignment[p];
         if (a >= 0) members[a].push_back({res.pod_slot[p], p});
         else if (a <= -2) node_members[-2 - a].push_back({res.pod_slot[p], p});
@@ -1773,6 +1869,8 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
       out.set("newNodeClaims", claims);
       Value ens = Value::array();
       for (size_t e = 0; e < S->node_names.size(); ++e) {
+        if (!node_there(e)) continue;
+        if (own->base && node_members[e].empty()) continue;   // a probe of a 10k-node cluster reports the nodes that took pods
         Value ej = Value::object();
         ej.set("name", Value::string(S->node_names[e]));
         std::sort(node_members[e].begin(), node_members[e].end());

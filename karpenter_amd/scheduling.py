@@ -59,6 +59,8 @@ def _load_ksched():
         lib.ksched_free.argtypes = [ctypes.c_void_p]
         lib.ksched_solve_batch.restype = ctypes.c_int
         lib.ksched_solve_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        lib.ksched_probe.restype = ctypes.c_void_p
+        lib.ksched_probe.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
         _ksched = lib
     return _ksched
 
@@ -104,9 +106,35 @@ class Scheduler:
             _raise(kind, msg)
 
     def close(self):
+        for p in getattr(self, "_probes", []):   # probes share this session's tables: they go first
+            p.close()
+        self._probes = []
         if getattr(self, "_session", None):
             self._lib.ksched_close(self._session)
             self._session = None
+
+    def Probe(self, remove_nodes=(), pods=()) -> "Scheduler":
+        """One probe of a RESIDENT cluster (ksolve_probe_create; disruption/helpers.go:53-155): this scheduler holds the
+        whole cluster — every node as a state node, every pod some probe may place as a pod — and the probe is that
+        cluster without `remove_nodes` (names), scheduling `pods` (uids). The returned Scheduler shares the tables already
+        on the device (nothing is flattened or uploaded again), solves alone or through SolveBatch, and is closed with
+        this one. Raises Unsupported for clusters whose pods carry topology constraints (one NewScheduler per probe then)."""
+        if not self._session:
+            raise RuntimeError("scheduler is closed")
+        doc = json.dumps({"removeNodes": list(remove_nodes), "pods": list(pods)}).encode()
+        probe = object.__new__(Scheduler)
+        probe.problem, probe._solver_lib, probe._lib, probe._probes = None, self._solver_lib, self._lib, []
+        probe._session = self._lib.ksched_probe(self._session, doc)
+        err = self._lib.ksched_error(probe._session)
+        if err is not None:
+            kind = self._lib.ksched_error_kind(probe._session).decode()
+            msg = err.decode()
+            probe.close()
+            _raise(kind, msg)
+        if not hasattr(self, "_probes"):
+            self._probes = []
+        self._probes.append(probe)
+        return probe
 
     def __del__(self):
         try:

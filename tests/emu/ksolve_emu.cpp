@@ -116,6 +116,12 @@ ksolve_status ksolve_create(const ksolve_problem_desc* desc, const ksolve_option
   *out = h;  // returned even on failure so the caller can read ksolve_last_error
   return s;
 }
+ksolve_status ksolve_probe_create(ksolve_handle* base, const ksolve_probe* probe, ksolve_handle** out) {
+  ksolve_handle* h = new ksolve_handle();
+  h->backend = new EmuBackend();
+  *out = h;
+  return ksi::probe_create(base, probe, h);
+}
 ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out) { return ksi::solve(h, out); }
 ksolve_status ksolve_solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) { return ksi::solve_batch(hs, n, outs); }
 ksolve_status ksolve_cancel(ksolve_handle* h) { if (h->d_cancel) __atomic_store_n(h->d_cancel, 1, __ATOMIC_RELAXED); return KSOLVE_OK; }

@@ -489,3 +489,82 @@ def test_single_node_candidate_order(oracle):
     assert [dz._pool_name(n) for n in woven] == [dz._pool_name(n) for n in woven[:3]] * 3      # round robin
     first = dz.interweave_by_nodepool(ranked, previously_unseen=["nodepool-2"])
     assert dz._pool_name(first[0]) == "nodepool-2" and len(first) == 9                        # :119-128
+
+
+def _tight_cluster(seed, n_nodes=30, limits=None):
+    """make_cluster with most nodes squeezed (what is still available on them shrunk to a sliver), so that displaced pods
+    often need a replacement NodeClaim instead of fitting elsewhere; a few nodes uninitialized / inside consolidateAfter,
+    one marked for deletion, one pending pod."""
+    import random
+    rng = random.Random(seed)
+    cluster = dz.make_cluster(n_nodes=n_nodes, pods_per_node=5, n_types=60, seed=seed, utilisation=0.8)
+    for i, n in enumerate(cluster["nodes"]):
+        if rng.random() < 0.95:
+            n["available"] = dict(n["available"], cpu=f"{rng.choice([0, 100, 300])}m")
+        if i % 11 == 3:
+            n["initialized"] = False
+            n["labels"].pop("karpenter.sh/initialized", None)
+        if i % 13 == 5:
+            n["underConsolidateAfter"] = True
+    cluster["nodes"][-1]["markedForDeletion"] = True
+    cluster["pendingPods"] = [fx.pod(requests={"cpu": "250m", "memory": "128Mi"})]
+    if limits:
+        cluster["nodePools"][0]["limits"] = limits
+    return cluster
+
+
+@pytest.mark.parametrize("seed,limits", [(1, None), (2, {"cpu": "2000"}), (3, {"cpu": "150", "nodes": "31"})])
+def test_resident_cluster_probes_match_per_probe_rebuild(oracle, emu, seed, limits):
+    """ksolve_probe_create (one ksolve_create for the cluster, a removed-node bitmap + displaced-pod rows per simulation, one
+    batched launch) gives, probe by probe, the Results of SimulateScheduling assembled from scratch and solved by the
+    oracle (helpers.go:53-155): single-node sweep, multi-node sets, NodePool limits handed back by the removed nodes
+    (scheduler.go:835-842), uninitialized / consolidateAfter / deleting nodes, a pending pod."""
+    import random
+    cluster = _tight_cluster(seed, limits=limits)
+    cands = [n for n in dz.sort_candidates(cluster, cluster["nodes"]) if not n.get("markedForDeletion")][:14]
+    got, rc = dz.sweep_resident(cluster, cands, solver_lib=emu)
+    want = dz.sweep(cluster, cands, oracle.solve)
+    assert [strip(c) for c in got] == [strip(c) for c in want]
+    for g, w in zip(got, want):
+        parity.assert_same_results(g["results"], w["results"])
+        assert g["results"]["counters"]["referenceBinEvaluations"] == w["results"]["counters"]["binEvaluations"]
+        assert g["results"]["allNonPendingPodsScheduled"] == w["results"]["allNonPendingPodsScheduled"]
+    assert seed != 1 or {c["decision"] for c in got} == {dz.DELETE, dz.REPLACE, dz.NOOP}
+    # multi-node sets through the same resident cluster: the binary search's probe sequence and command
+    rng = random.Random(seed)
+    sets = [rng.sample(cands, k) for k in (2, 3, 5)]
+    rc.prefetch(sets)
+    for cs in sets:
+        g, w = dz.compute_consolidation(cluster, cs, rc), dz.compute_consolidation(cluster, cs, oracle.solve)
+        assert strip(g) == strip(w)
+        parity.assert_same_results(g["results"], w["results"])
+    a, pa = dz.first_n_consolidation_option(cluster, cands, rc)
+    b, pb = dz.first_n_consolidation_option(cluster, cands, oracle.solve)
+    assert pa == pb and strip(a) == strip(b)
+    assert strip(dz.single_node_consolidation(cluster, cands, rc)) == strip(dz.single_node_consolidation(cluster, cands, oracle.solve))
+    rc.close()
+
+
+def test_resident_cluster_declines_topology(emu):
+    from karpenter_amd.scheduling import Unsupported
+    cluster = dz.make_cluster(n_nodes=6, pods_per_node=2, seed=1)
+    lab = {"app": "x"}
+    cluster["nodes"][0]["pods"][0]["labels"] = lab
+    cluster["nodes"][0]["pods"][0]["topologySpreadConstraints"] = [fx.spread(fx.ZONE, lab)]
+    with pytest.raises(Unsupported):
+        dz.ResidentCluster(cluster, cluster["nodes"][:2], solver_lib=emu)
+
+
+def test_probe_api_rejects_bad_descriptors(emu):
+    cluster = dz.make_cluster(n_nodes=6, pods_per_node=2, seed=2)
+    rc = dz.ResidentCluster(cluster, cluster["nodes"][:3], solver_lib=emu)
+    uid = cluster["nodes"][0]["pods"][0]["uid"]
+    with pytest.raises(RuntimeError):
+        rc.scheduler.Probe(["no-such-node"], [uid])
+    with pytest.raises(RuntimeError):
+        rc.scheduler.Probe([cluster["nodes"][0]["name"]], [uid, uid])
+    with pytest.raises(RuntimeError):
+        rc.scheduler.Probe([], ["no-such-pod"])
+    ok = rc.scheduler.Probe([cluster["nodes"][0]["name"]], [uid]).Solve()
+    assert ok["counters"]["pods"] == 1 and ok["counters"]["existingNodes"] == 5
+    rc.close()

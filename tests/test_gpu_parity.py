@@ -420,3 +420,12 @@ def test_host_ports_on_the_device(oracle):
     import test_device_algorithm as tda
     tda.test_host_ports(oracle, None)
     tda.test_host_ports_fuzz(oracle, None)
+
+
+@pytest.mark.parametrize("seed,limits", [(1, None), (3, {"cpu": "150", "nodes": "31"})])
+def test_resident_cluster_probes_on_the_device(oracle, seed, limits):
+    """ksolve_probe_create on the GPU: one ksolve_create for the cluster, a removed-node bitmap + displaced-pod rows per
+    simulation, all probes in one ksolve_solve_batch launch — against SimulateScheduling assembled from scratch and solved
+    by the oracle (tests/test_disruption.py::test_resident_cluster_probes_match_per_probe_rebuild with libksolve.so)."""
+    import test_disruption as td
+    td.test_resident_cluster_probes_match_per_probe_rebuild(oracle, None, seed, limits)
