@@ -179,6 +179,76 @@ def main():
         vec = np.array(v[:-1].tolist()).reshape(-1, 2)
         claims, cost = int(round(vec[:, 0].sum())), float(vec[:, 1].sum())
 
+    # ---- BASELINE configs[3] (all ranks take part): 10M pods x 1k instance types x 16 NodePools. Every pod pins its NodePool, so the
+    # batch falls into 16 components (karpenter_amd/components.py) that cannot share a claim; each is solved EXACTLY as its own
+    # problem. One GPU: all components in one launch (one wavefront each). N GPUs: component c goes to rank c % N, every rank runs
+    # its components in one launch, and the per-instance-type (NodeClaim count, $/h) vectors are summed with ONE all-reduce — the
+    # north_star's global packing summary. The union is a packing of equal quality, not the reference's pod-for-pod answer for the
+    # whole batch (the reference re-sorts ALL claims before every scan, scheduler.go:598): L2-canonical, see `calibration`.
+    comp = None
+    if args.components_pods > 0:
+        from karpenter_amd.components import split_by_nodepool
+        from karpenter_amd.scheduling import SolveBatch
+        import numpy as np
+
+        def solve_components(pods, repeat, want_results=False, shard=True):
+            whole = fx.config4(pods=pods, n_types=args.components_types, n_pools=16, seed=42)
+            parts = split_by_nodepool(whole)
+            mine = [pt for i, pt in enumerate(parts) if not shard or i % world == rank]
+            scheds = [NewScheduler(dict(sub, options=dict(sub["options"], device=device_index)), solver_lib=args.solver_lib) for _, sub in mine]
+            best, rs = None, []
+            for _ in range(repeat):
+                if dist is not None and shard:
+                    dist.barrier()
+                sync()
+                tb = time.perf_counter()
+                rs = SolveBatch(scheds, want_results=want_results) if scheds else []
+                sync()
+                if dist is not None and shard:
+                    dist.barrier()
+                dt = time.perf_counter() - tb
+                best = dt if best is None else min(best, dt)
+            for sc_ in scheds:
+                sc_.close()
+            return whole, parts, mine, rs, best
+
+        whole, parts, mine, rs, dt = solve_components(args.components_pods, 2, want_results="claims")
+        cvec = np.zeros((len(whole["instanceTypes"]), 2))
+        for (_, sub), r in zip(mine, rs):
+            cvec += launch_type_vector(sub, r)
+        totals = [float(sum(r["scheduledPods"] for r in rs)), float(sum(r["counters"]["claims"] for r in rs)), float(sum(r["packingCost"] for r in rs)),
+                  max([r["timings"][0]["pack_kernel_ms"] for r in rs], default=0.0)]
+        engines = sorted({r["counters"].get("engine") for r in rs})
+        if dist is not None:
+            t = torch.tensor([dt, totals[3]], dtype=torch.float64, device=reduce_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, totals[3] = float(t[0].item()), float(t[1].item())
+            v = torch.tensor(cvec.reshape(-1).tolist() + totals[:3], dtype=torch.float64, device=reduce_device)
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)       # the per-instance-type (count, $/h) vector of the whole batch: one collective
+            cvec = np.array(v[:-3].tolist()).reshape(-1, 2)
+            totals[:3] = [float(x) for x in v[-3:].tolist()]
+        if rank == 0:
+            nzc = cvec[:, 0] > 0
+            comp = {"workload": f"BASELINE configs[3]: {args.components_pods} pods x {args.components_types} types x 16 NodePools, every pod pinned to its pool",
+                    "components": len(parts), "ranks": world, "sharding": "component c -> rank c % N, one batched launch per rank" if world > 1 else "all components in one launch on one GPU",
+                    "pods": int(round(totals[0])), "seconds": dt, "value": totals[0] / dt, "unit": "pods/s",
+                    "node_claims": int(round(totals[1])), "packing_cost_per_hour": totals[2], "pack_kernel_ms": totals[3], "engines": engines,
+                    "per_instance_type": {"launch_types_used": int(nzc.sum()), "claims_from_vector": int(round(cvec[:, 0].sum())), "cost_from_vector": float(cvec[:, 1].sum()),
+                                          "vector": "count and $/h per instance type over all components" + (", summed over ranks with one all-reduce" if world > 1 else "")},
+                    "parity": "each component bit-identical to the oracle on that component (tests); the union vs ONE Solve() of the whole batch: L2-canonical, see calibration"}
+            if args.components_calibration_pods > 0:
+                cp = args.components_calibration_pods
+                whole_p = fx.config4(pods=cp, n_types=args.components_types, n_pools=16, seed=42)
+                whole_p["options"]["device"] = device_index
+                sw = NewScheduler(whole_p, solver_lib=args.solver_lib)
+                rw = sw.Solve(want_results=False)
+                sw.close()
+                _, _, _, rc, _ = solve_components(cp, 1, shard=False)
+                comp["calibration"] = {"pods": cp, "whole_batch": {"node_claims": rw["counters"]["claims"], "packing_cost_per_hour": rw["packingCost"], "engine": rw["counters"].get("engine")},
+                                       "components": {"node_claims": sum(r["counters"]["claims"] for r in rc), "packing_cost_per_hour": sum(r["packingCost"] for r in rc)},
+                                       "claims_delta": sum(r["counters"]["claims"] for r in rc) - rw["counters"]["claims"],
+                                       "cost_rel_delta": (sum(r["packingCost"] for r in rc) - rw["packingCost"]) / rw["packingCost"]}
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -251,44 +321,7 @@ def main():
                                    "pods": args.topology_pods, "seconds": dt, "value": r3["scheduledPods"] / dt, "unit": "pods/s", "node_claims": r3["counters"]["claims"],
                                    "pack_kernel_ms": r3["timings"][0]["pack_kernel_ms"], "engine": r3["counters"].get("engine")}
         s3.close()
-    if args.components_pods > 0 and world == 1:
-        # BASELINE configs[3]: 10M pods x 1k instance types x 16 NodePools. Every pod pins its NodePool, so the batch falls into
-        # 16 components (karpenter_amd/components.py) that cannot share a claim; each is solved EXACTLY as its own problem, all
-        # in one launch (one wavefront per component). The union is a packing of equal quality, not the reference's pod-for-pod
-        # answer for the whole batch (the reference re-sorts ALL claims before every scan, scheduler.go:598): L2-canonical.
-        from karpenter_amd.components import split_by_nodepool
-        from karpenter_amd.scheduling import SolveBatch
-
-        def solve_components(pods, repeat):
-            parts = split_by_nodepool(fx.config4(pods=pods, n_types=args.components_types, n_pools=16, seed=42))
-            scheds = [NewScheduler(dict(sub, options=dict(sub["options"], device=device_index)), solver_lib=args.solver_lib) for _, sub in parts]
-            best, rs = None, None
-            for _ in range(repeat):
-                tb = time.perf_counter()
-                rs = SolveBatch(scheds, want_results=False)
-                dt = time.perf_counter() - tb
-                best = dt if best is None else min(best, dt)
-            for sc_ in scheds:
-                sc_.close()
-            return parts, rs, best
-        parts, rs, dt = solve_components(args.components_pods, 2)
-        comp = {"workload": f"BASELINE configs[3]: {args.components_pods} pods x {args.components_types} types x 16 NodePools, every pod pinned to its pool",
-                "components": len(parts), "pods": sum(r["scheduledPods"] for r in rs), "seconds": dt, "value": sum(r["scheduledPods"] for r in rs) / dt, "unit": "pods/s",
-                "node_claims": sum(r["counters"]["claims"] for r in rs), "packing_cost_per_hour": sum(r["packingCost"] for r in rs),
-                "pack_kernel_ms": max(r["timings"][0]["pack_kernel_ms"] for r in rs), "engines": sorted({r["counters"].get("engine") for r in rs}),
-                "parity": "each component bit-identical to the oracle on that component (tests); the union vs ONE Solve() of the whole batch: L2-canonical, see calibration"}
-        if args.components_calibration_pods > 0:
-            cp = args.components_calibration_pods
-            whole_p = fx.config4(pods=cp, n_types=args.components_types, n_pools=16, seed=42)
-            whole_p["options"]["device"] = device_index
-            sw = NewScheduler(whole_p, solver_lib=args.solver_lib)
-            rw = sw.Solve(want_results=False)
-            sw.close()
-            _, rc, _ = solve_components(cp, 1)
-            comp["calibration"] = {"pods": cp, "whole_batch": {"node_claims": rw["counters"]["claims"], "packing_cost_per_hour": rw["packingCost"], "engine": rw["counters"].get("engine")},
-                                   "components": {"node_claims": sum(r["counters"]["claims"] for r in rc), "packing_cost_per_hour": sum(r["packingCost"] for r in rc)},
-                                   "claims_delta": sum(r["counters"]["claims"] for r in rc) - rw["counters"]["claims"],
-                                   "cost_rel_delta": (sum(r["packingCost"] for r in rc) - rw["packingCost"]) / rw["packingCost"]}
+    if comp is not None:
         out["config3_components"] = comp
     if args.batch_problems > 0 and world == 1:
         # Independent problems (NodePool components / consolidation probes) in ONE launch of the pack kernel:

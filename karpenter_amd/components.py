@@ -50,12 +50,33 @@ def split_by_nodepool(problem):
     return out
 
 
+def _topology_selectors(p):
+    """[(namespaces, matchLabels)] of every topology group the pod can own — spread constraints, required and preferred pod
+    (anti-)affinity terms (topology.go:461-533) — or None when a term cannot be evaluated here (matchExpressions,
+    namespaceSelector). A group counts exactly the pods its namespaces + selector match (topologygroup.go:442), whatever
+    NodePool they land on: those pods and the owner must be solved together."""
+    out = []
+    ns = p.get("namespace", "default")
+    for c in p.get("topologySpreadConstraints") or []:
+        sel = c.get("labelSelector") or {}
+        if sel.get("matchExpressions"):
+            return None
+        out.append(({ns}, dict(sel.get("matchLabels") or {})))
+    for field in ("podAffinity", "podAntiAffinity"):
+        aff = p.get(field) or {}
+        terms = list(aff.get("required") or []) + [w["term"] for w in (aff.get("preferred") or [])]
+        for t in terms:
+            sel = t.get("labelSelector") or {}
+            if sel.get("matchExpressions") or t.get("namespaceSelector") is not None:
+                return None
+            out.append((set(t.get("namespaces") or [ns]), dict(sel.get("matchLabels") or {})))
+    return out
+
+
 def _pinned_pools(p, pools):
     """The NodePools a pod can ever land on, as far as its REQUIRED constraints on `karpenter.sh/nodepool` say (a node
     selector, and/or every required node-affinity term carrying `In [...]` on that key — terms are OR-ed and relaxation only
     drops terms, preferences.go:38-57, so the union over the terms bounds every relaxed variant). None = not provably pinned."""
-    if p.get("topologySpreadConstraints") or p.get("podAffinity") or p.get("podAntiAffinity"):
-        return None
     allowed = None
     sel = (p.get("nodeSelector") or {}).get(fx.NODEPOOL)
     if sel is not None:
@@ -79,7 +100,9 @@ def _pinned_pools(p, pools):
 
 def split_components(problem):
     """Connected components of the pods x NodePools graph: two NodePools are in one component when some
-    pod may land on either. Returns [(tuple of pool names, sub-problem)] in NodePool order, or None when some pod is not
+    pod may land on either, or when a topology group owned by a pod of one (spread constraint, pod affinity / anti-affinity
+    term) selects a pod of the other — the group's domain counts move with every selected pod that is placed
+    (topology.go:197-224), so owner and selected pods stay in one Solve(). Returns [(tuple of pool names, sub-problem)] in NodePool order, or None when some pod is not
     provably pinned or the batch has anything `split_by_nodepool` refuses. Same contract as `split_by_nodepool`: each
     component is a packing problem of its own, solved bit-exactly as such; the union is a packing of equal quality, not the
     reference's pod-for-pod answer for the whole batch."""
@@ -104,6 +127,20 @@ def split_components(problem):
             for other in allowed:
                 parent[find(other)] = find(first)
             owners.append((kind, item, first))
+    # topology groups tie their owner to every pod they select
+    by_sig = {}
+    for kind, item, first in owners:
+        t = item["template"] if kind == "podGroups" else item
+        by_sig.setdefault((t.get("namespace", "default"), tuple(sorted((t.get("labels") or {}).items()))), []).append(first)
+    for kind, item, first in owners:
+        sels = _topology_selectors(item["template"] if kind == "podGroups" else item)
+        if sels is None:
+            return None
+        for namespaces, match in sels:
+            for (ns, labels), firsts in by_sig.items():
+                if ns in namespaces and all(dict(labels).get(k) == v for k, v in match.items()):
+                    for f in firsts:
+                        parent[find(f)] = find(first)
     comps = {}
     for n in names:
         comps.setdefault(find(n), {"pools": [], "pods": [], "podGroups": []})["pools"].append(n)

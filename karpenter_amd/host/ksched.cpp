@@ -1810,8 +1810,9 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
         cj.set("hostname", Value::string(hb));
         std::sort(members[c].begin(), members[c].end());
         Value pj = Value::array();
-        for (auto& m : members[c]) pj.push(Value::string(uid_of(m.second)));
+        if (want_results == 1) for (auto& m : members[c]) pj.push(Value::string(uid_of(m.second)));   // want_results 2: the claims without their pod lists
         cj.set("pods", pj);
+        cj.set("podCount", Value::integer((int64_t)members[c].size()));
         Value itj = Value::array();
         if (cl.ordered_instance_types) {   // Results.TruncateInstanceTypes: price order, capped (scheduler.go:419-437)
           for (uint32_t i = 0; i < cl.ordered_count[c]; ++i) itj.push(Value::string(S->it_names[cl.ordered_instance_types[(size_t)c * cl.n_instance_types + i]]));

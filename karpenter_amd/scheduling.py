@@ -80,6 +80,10 @@ class Results(dict):
         return not self["podErrors"]
 
 
+def _want(want_results):
+    return 2 if want_results == "claims" else (1 if want_results else 0)
+
+
 def _raise(kind, msg):
     if kind == "unsupported":
         raise Unsupported(msg)
@@ -142,14 +146,16 @@ class Scheduler:
         except Exception:
             pass
 
-    def Solve(self, repeat: int = 1, want_results: bool = True) -> Results:
-        """Runs Solve() on the device; `repeat` re-solves on the same resident inputs and collects every run's timings."""
+    def Solve(self, repeat: int = 1, want_results=True) -> Results:
+        """Runs Solve() on the device; `repeat` re-solves on the same resident inputs and collects every run's timings.
+        want_results: False = counters and timings only; True = the full Results; "claims" = the NodeClaims without their
+        pod lists (a 10M-pod packing summary does not need 10M uids)."""
         if not self._session:
             raise RuntimeError("scheduler is closed")
         timings = []
         out = None
         for _ in range(max(1, int(repeat))):
-            ptr = self._lib.ksched_solve(self._session, 1 if want_results else 0)
+            ptr = self._lib.ksched_solve(self._session, _want(want_results))
             try:
                 out = json.loads(ctypes.string_at(ptr).decode())
             finally:
@@ -185,7 +191,7 @@ def SolveBatch(schedulers, want_results: bool = True):
     n = len(schedulers)
     sessions = (ctypes.c_void_p * n)(*[s._session for s in schedulers])
     outs = (ctypes.c_void_p * n)()
-    lib.ksched_solve_batch(sessions, n, 1 if want_results else 0, outs)
+    lib.ksched_solve_batch(sessions, n, _want(want_results), outs)
     docs = []
     for i in range(n):   # every document is copied out and released before anything is raised: no leak on the first error
         try:

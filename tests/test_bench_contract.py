@@ -42,6 +42,8 @@ def test_single_rank_line(oracle):
     assert line["packing"]["per_instance_type"]["launch_types_used"] >= 1
     cc = line["config3_components"]
     assert cc["components"] == 16 and cc["pods"] == 4000 and cc["engines"] == ["cursor"] and abs(cc["calibration"]["cost_rel_delta"]) < 0.05
+    assert cc["ranks"] == 1 and cc["per_instance_type"]["claims_from_vector"] == cc["node_claims"]
+    assert abs(cc["per_instance_type"]["cost_from_vector"] - cc["packing_cost_per_hour"]) <= 1e-9 * cc["packing_cost_per_hour"]
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak" and line["vs_baseline"] is None
     assert line["higher_is_better"] is True and line["dtype"] == "int64" and "workload" in line["config"] and "TEST HOOK" in line["data"]
     want = oracle.solve(fx.config2(pods=3000, n_types=60, seed=42))
@@ -61,7 +63,7 @@ def test_two_ranks_under_the_drivers_launcher(oracle):
     emu = parity.build_emu()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--pods", "2500", "--types", "60", "--components-pods", "0", "--solver-lib", emu]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--pods", "2500", "--types", "60", "--components-pods", "4000", "--components-types", "60", "--components-calibration-pods", "4000", "--solver-lib", emu]
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = _json_line(r.stdout)
@@ -74,6 +76,16 @@ def test_two_ranks_under_the_drivers_launcher(oracle):
     assert abs(line["packing"]["packing_cost_per_hour"] - cost) <= 1e-9 * cost
     # whole-job value: pods of ALL ranks over the max-over-ranks time of the timed region
     assert abs(line["value"] - line["packing"]["pods_scheduled"] / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    # BASELINE configs[3] across the ranks: component c on rank c % 2, per-instance-type (count, $/h) vectors all-reduced — the
+    # totals equal the oracle's over the 16 components solved one by one
+    from karpenter_amd.components import split_by_nodepool
+    cc = line["config3_components"]
+    parts = [oracle.solve(sub) for _, sub in split_by_nodepool(fx.config4(pods=4000, n_types=60, n_pools=16, seed=42))]
+    assert cc["ranks"] == 2 and cc["components"] == 16 and cc["pods"] == 4000
+    assert cc["node_claims"] == sum(len(w["newNodeClaims"]) for w in parts) == cc["per_instance_type"]["claims_from_vector"]
+    ccost = sum(w["packingCost"] for w in parts)
+    assert abs(cc["packing_cost_per_hour"] - ccost) <= 1e-9 * ccost and abs(cc["per_instance_type"]["cost_from_vector"] - ccost) <= 1e-9 * ccost
+    assert abs(cc["calibration"]["cost_rel_delta"]) < 0.05 and abs(cc["calibration"]["claims_delta"]) <= 0.05 * cc["calibration"]["whole_batch"]["node_claims"]
 
 
 def test_the_hook_needs_its_environment_switch():

@@ -78,3 +78,35 @@ def test_connected_components_of_pods_and_pools(oracle, emu):
     loose = dict(prob, pods=prob["pods"] + [fx.pod(node_requirements=[pin("pool-00"), [fx.req(fx.ZONE, "In", "test-zone-1")]])])   # second term reaches any pool
     assert split_components(loose) is None
     assert split_components(dict(prob, pods=[fx.pod(node_requirements=pin("no-such-pool"))])) is None
+
+
+def test_components_through_topology_groups(oracle, emu):
+    """Pods with spread constraints / pod (anti-)affinity stay splittable as long as every topology group lives inside one
+    component: a group ties its owner to every pod its namespaces + selector match (topologygroup.go:442), so pools whose
+    pods are selected by one group merge, the others stay apart. Each component is solved exactly as its own problem."""
+    prob = fx.config4(pods=3000, n_types=100, n_pools=5, seed=7)
+    on = lambda pool: {fx.NODEPOOL: pool}
+    web, db, cache = {"app": "web"}, {"app": "db"}, {"app": "cache"}
+    extra = [fx.pod(labels=web, node_selector=on("pool-00"), requests={"cpu": "500m"}, topology_spread=[fx.spread(fx.ZONE, web)]) for _ in range(12)]       # spread inside pool-00
+    extra += [fx.pod(labels=db, node_selector=on("pool-01"), requests={"cpu": "1"}, pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, db)]) for _ in range(6)]   # anti-affinity inside pool-01
+    extra += [fx.pod(labels=cache, node_selector=on("pool-02"), requests={"cpu": "250m"}) for _ in range(8)]
+    extra += [fx.pod(labels={"app": "api"}, node_selector=on("pool-03"), requests={"cpu": "250m"}, pod_requirements=[fx.affinity_term(fx.ZONE, cache)]) for _ in range(5)]   # pool-03 follows pool-02's pods
+    extra += [fx.pod(labels={"app": "batch"}, node_selector=on("pool-04"), pod_preferences=[fx.weighted(5, fx.affinity_term(fx.ZONE, {"app": "nothing"}))]) for _ in range(4)]  # selects nobody
+    prob = dict(prob, pods=prob.get("pods", []) + extra)
+    parts = split_components(prob)
+    assert [pools for pools, _ in parts] == [("pool-00",), ("pool-01",), ("pool-02", "pool-03"), ("pool-04",)]
+    got = SolveBatch([NewScheduler(sub, solver_lib=emu) for _, sub in parts])
+    want = [oracle.solve(sub) for _, sub in parts]
+    for g, w in zip(got, want):
+        parity.assert_same_results(g, w)
+    whole = oracle.solve(prob)
+    assert not whole["podErrors"] and not any(w["podErrors"] for w in want)
+    assert abs(sum(len(w["newNodeClaims"]) for w in want) - len(whole["newNodeClaims"])) <= 0.03 * len(whole["newNodeClaims"])
+    assert abs(sum(w["packingCost"] for w in want) - whole["packingCost"]) <= 0.01 * whole["packingCost"]
+    # a selector that reaches pods of another pool merges the two; what cannot be evaluated here is refused
+    reach = dict(prob, pods=prob["pods"] + [fx.pod(labels=web, node_selector=on("pool-04"))])
+    assert [pools for pools, _ in split_components(reach)][0] == ("pool-00", "pool-04")
+    expr = fx.pod(node_selector=on("pool-00"), topology_spread=[dict(fx.spread(fx.ZONE, web), labelSelector={"matchExpressions": [{"key": "app", "operator": "Exists"}]})])
+    assert split_components(dict(prob, pods=prob["pods"] + [expr])) is None
+    nssel = fx.pod(node_selector=on("pool-00"), pod_requirements=[fx.affinity_term(fx.ZONE, web, namespace_selector={})])
+    assert split_components(dict(prob, pods=prob["pods"] + [nssel])) is None
