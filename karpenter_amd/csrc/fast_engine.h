@@ -80,6 +80,12 @@ struct FastWork {   // HBM workspace of the cursor engine (host-allocated when t
   FastClaim* c_state;     // [max_claims] final state, written when the loop ends
   uint32_t* c_npods;      // [max_claims]
   uint64_t* ent_its;      // [kFastEnt][it_words] F(requirement set)
+  // The loop reads the queue and writes its results in QUEUE order, 64 consecutive entries per access: one wave touching
+  // 64 random pods per block pays for 64 address translations in a row. ksolve_fast_queue (before) and
+  // ksolve_fast_scatter (after) do the random accesses with every CU busy.
+  uint32_t* q_class;      // [n_pods] class of queue entry i = row_class[sorted_pods[i]]
+  uint32_t* q_claim;      // [n_pods] claim of queue entry i (0xFFFFFFFF: not placed)
+  uint32_t* q_cnt;        // [n_pods] pods the claim held before it
   FastPlan plan;
   int enabled;
 };
@@ -626,7 +632,7 @@ struct FastCold {
     c.bin_evaluations = n_tests; c.full_evaluations = n_steps; c.queue_pops = steps; c.sorts = steps; c.slow_sorts = order.slow_sorts;
     c.column_resets = (unsigned long long)n_evict; c.ref_bin_evaluations = n_ref + n_ref_extra;
     c.cycles[20] = (unsigned long long)(bail_code > 0 ? bail_code : 0);
-    if (tc) for (int i = 0; i < 8; ++i) c.cycles[i] = tc[i];
+    if (tc) for (int i = 0; i < 16; ++i) c.cycles[i] = tc[i];
     if (W::leader()) *S.counters = c;
     W::sync();
   }
@@ -639,9 +645,10 @@ struct FastHot {
   uint32_t pend_mv, pad0;
   uint64_t ev_vm;
   unsigned long long n_steps, n_tests, n_ref, hot_cycles;
-  const uint32_t* sorted; const uint32_t* row_class; const volatile int* cancel; int32_t* g_assign; uint32_t* g_slot;
+  unsigned long long tsec[8];   // profiling builds: shader clock per path of the loop
+  const uint32_t* q_class; const volatile int* cancel; uint32_t* q_claim; uint32_t* q_cnt;
   uint32_t cur[kFastRows][64];
-  uint32_t bpod[64], bcls[64], bslot[64], oclaim[64], ocnt[64], nxt_pod[64], nxt_cls[64];
+  uint32_t bcls[64], bslot[64], oclaim[64], ocnt[64], nxt_cls[64];
 };
 struct FastHotCtx {   // LDS pointers of the loop, passed by value
   KS_LDS uint16_t* okey; KS_LDS uint16_t* oord; KS_LDS FastClaim* cst; KS_LDS FastEnt* ent; KS_LDS int32_t* pool;
@@ -665,42 +672,70 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
   KS_LDS FastHot* const hs = fast_uniform(cx.hs);
   // ---- state in ----
   const int np = fast_uniform(hs->np), max_steps = fast_uniform(hs->max_steps);
-  const KS_GLOBAL uint32_t* const gsorted = (const KS_GLOBAL uint32_t*)fast_uniform(hs->sorted);
-  const KS_GLOBAL uint32_t* const grc = (const KS_GLOBAL uint32_t*)fast_uniform(hs->row_class);
+  const KS_GLOBAL uint32_t* const gqcls = (const KS_GLOBAL uint32_t*)fast_uniform(hs->q_class);
   const volatile int* const cancel = fast_uniform(hs->cancel);
-  KS_GLOBAL int32_t* const gassign = (KS_GLOBAL int32_t*)fast_uniform(hs->g_assign);
-  KS_GLOBAL uint32_t* const gslot = (KS_GLOBAL uint32_t*)fast_uniform(hs->g_slot);
+  KS_GLOBAL uint32_t* const gqclaim = (KS_GLOBAL uint32_t*)fast_uniform(hs->q_claim);
+  KS_GLOBAL uint32_t* const gqcnt = (KS_GLOBAL uint32_t*)fast_uniform(hs->q_cnt);
   int base = fast_uniform(hs->base), bi = fast_uniform(hs->bi), bn = fast_uniform(hs->bn), n = fast_uniform(hs->n), steps = fast_uniform(hs->steps), status = fast_uniform(hs->status);
   int pend_a = fast_uniform(hs->pend_a), pend_x = fast_uniform(hs->pend_x); uint32_t pend_mv = (uint32_t)fast_uniform((int)hs->pend_mv); bool pend_new = fast_uniform(hs->pend_new) != 0;
   unsigned long long n_steps = W::uniform(hs->n_steps), n_tests = W::uniform(hs->n_tests), n_ref = W::uniform(hs->n_ref);
-  LaneVar<uint32_t> cur[kFastRows], nxt_pod, nxt_cls, bpod, bcls, bslot, oclaim, ocnt;
+  LaneVar<uint32_t> cur[kFastRows], nxt_cls, bcls, bslot, oclaim, ocnt;
   W::each([&](int l) {
 #pragma unroll
     for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = hs->cur[j][l];
-    nxt_pod.at(l) = hs->nxt_pod[l]; nxt_cls.at(l) = hs->nxt_cls[l]; bpod.at(l) = hs->bpod[l]; bcls.at(l) = hs->bcls[l];
+    nxt_cls.at(l) = hs->nxt_cls[l]; bcls.at(l) = hs->bcls[l];
     bslot.at(l) = hs->bslot[l]; oclaim.at(l) = hs->oclaim[l]; ocnt.at(l) = hs->ocnt[l];
   });
   int ev = FEV_DONE, ev_arg = 0; uint64_t ev_vm = 0;
+  // ---- group speculation ----
+  // One CanAdd test serves up to eight queue entries: lane 8j+q tests queue entry bi+j (its class) against the claim at
+  // position cursor(class)+q — the same three dependent LDS reads as a window test of one pod. The verdicts are taken
+  // against the state at that moment; they are used for the entries one after the other, in queue order:
+  //   * a rejection is final (fact 3 above), whatever happened to the claim since;
+  //   * an acceptance holds while the claim has not gained a pod since the test (g_touched: lanes whose claim has);
+  //   * claims only move right, past claims with fewer pods, so between an entry's cursor and its first accepting lane
+  //     there are only claims that rejected it (those of its window, those that came from the left of its cursor); a
+  //     claim from the right never gets in front of it. So entry bi+j goes to the claim of its first accepting lane iff
+  //     that claim is untouched — addToInflightNode's "lowest index that accepts" (scheduler.go:667-686) without a new
+  //     test. gp follows every lane's claim through the moves (the same update as the cursors).
+  // Every other entry (first acceptor touched, an unresolved lane before it, nothing in eight positions) takes the window
+  // test below; the rest of the group stays valid behind it. A move that is not one short shift (the pending path,
+  // pdqsort's other paths, a new claim) drops the group.
+  LaneVar<uint32_t> gx, gk, gp, gB, gq0, gq1, gq2, gq3;   // gB: a lower bound of the position of the first claim behind the entry's eight
+  LaneVar<uint64_t> gm;
+  uint64_t g_acc = 0, g_odd = 0, g_touched = 0, g_jumped = 0;   // g_jumped: lanes whose claim a commit moved past another claim
+  int gj = 0, gn = 0;   // entries gj .. gn-1 of the group are still to be placed; entry gj is queue entry bi
+  // choosePivot's sampled positions (fast_sampled) as three starts; n is fixed inside one run of this function. With
+  // 12 < n < 50 every re-sort is pdqsort's other path: no groups then.
+  const bool use_groups = max_steps < 0 && (n <= 12 || n >= 50);
+  const uint32_t e1 = n >= 50 ? (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u, e2 = n >= 50 ? 2u * (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u, e3 = n >= 50 ? 3u * (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u;
+#ifdef KSOLVE_PHASE_TIMERS
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0, ts7 = 0, tlast = W::clock();
+#define KS_SEC(v) { const unsigned long long t_ = W::clock(); v += t_ - tlast; tlast = t_; }
+#else
+#define KS_SEC(v)
+#endif
   for (;;) {
     // ---- the next block of the queue ----
     if (KS_UNLIKELY(bi >= bn)) {
       if (bn > 0) {   // the finished block's results
-        const int dn = bn;
-        W::each([&](int l) { if (l < dn) { const uint32_t p = bpod.at(l); gassign[p] = (int32_t)oclaim.at(l); gslot[p] = ocnt.at(l); } });
+        const int dn = bn, b0 = base;
+        W::each([&](int l) { if (l < dn) { gqclaim[b0 + l] = oclaim.at(l); gqcnt[b0 + l] = ocnt.at(l); } });
         base += 64;
       }
       if (base >= np || status) { bn = 0; bi = 0; break; }
       bn = np - base < 64 ? np - base : 64;
-      bi = 0;
+      bi = 0; gj = 0; gn = 0;
       const int bnn = bn, nb = base + 64;
-      W::each([&](int l) { bpod.at(l) = nxt_pod.at(l); bcls.at(l) = nxt_cls.at(l); bslot.at(l) = l < bnn ? (uint32_t)slot_of[nxt_cls.at(l)] : 0xFFFFu; });
-      W::each([&](int l) { if (nb + l < np) { const uint32_t p = gsorted[nb + l]; nxt_pod.at(l) = p; nxt_cls.at(l) = grc[p]; } });
+      W::each([&](int l) { bcls.at(l) = nxt_cls.at(l); bslot.at(l) = l < bnn ? (uint32_t)slot_of[nxt_cls.at(l)] : 0xFFFFu; });
+      W::each([&](int l) { if (nb + l < np) nxt_cls.at(l) = gqcls[nb + l]; });
       if ((base & 1023) == 0 && cancel && fast_uniform(W::poll_flag(cancel))) { status = 2; bn = 0; break; }
     }
     if (KS_UNLIKELY(max_steps >= 0 && steps >= max_steps)) { status = 2; break; }
     // ---- sort.Slice (scheduler.go:598) for a move the last commit left behind ----
     if (KS_UNLIKELY(pend_a >= 0 || pend_new)) {
       if (pend_new) { ev = FEV_PLACE; break; }
+      gj = 0; gn = 0;
       const int a = pend_a;
       if (!(n <= 12 || (n >= 50 && !fast_sampled(n, a)))) { ev = FEV_SLOWSORT; ev_arg = a; break; }
       pend_a = -1;
@@ -732,14 +767,167 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
         });
       }
     }
+    KS_SEC(ts0)   // block fetch, pending move
     // ---- the pod's class slot ----
     const int slot = (int)bslot.bcast(bi);
     if (KS_UNLIKELY(slot == 0xFFFF)) { ev = FEV_SLOT; ev_arg = (int)bcls.bcast(bi); break; }
-    const FastSlot cs = lds_get(&aslot[slot]);
+    if (use_groups && gj >= gn && bi + 1 < bn) {
+      // ---- a new group: the next entries of the block that have a class slot, eight at most ----
+      const int g0 = bn - bi - 1 < 8 ? bn - bi - 1 : 8, bi0 = bi, nn = n;   // not the block's last entry (its move is left pending)
+      LaneVar<uint32_t> gs, gr;
+      W::each([&](int l) { const int j = l >> 3; gs.at(l) = bslot.shuffle(l, (bi0 + (j < g0 ? j : 0)) & 63); });
+      W::each([&](int l) {
+        const uint32_t sv = gs.at(l);
+        const int sl = (int)(sv & 63u);
+        const uint32_t a0 = cur[0].shuffle(l, sl), a1 = cur[1].shuffle(l, sl), a2 = cur[2].shuffle(l, sl), a3 = cur[3].shuffle(l, sl);
+        const uint32_t row = (sv >> 6) & 3u;
+        gr.at(l) = row == 0 ? a0 : row == 1 ? a1 : row == 2 ? a2 : a3;
+      });
+      const uint64_t nos = W::ballot([&](int l) { return (l >> 3) >= g0 || gs.at(l) == 0xFFFFu; });
+      gn = nos ? ctz64(nos) >> 3 : 8;   // >= 1: this entry has its slot
+      gj = 0; g_touched = 0; g_jumped = 0;
+      const int gnn = gn;
+      W::ballot2([&](int l) {
+        const int j = l >> 3, q = l & 7;
+        const int p = (int)gr.at(l) + q;
+        gx.at(l) = 0xFFFFFFFFu; gk.at(l) = 0; gp.at(l) = 0xFFFFFFFFu; gm.at(l) = 0; gq0.at(l) = 0; gq1.at(l) = 0; gq2.at(l) = 0; gq3.at(l) = 0;
+        gB.at(l) = gr.at(l) + 8u;
+        if (j >= gnn || p >= nn) return 0;
+        const uint32_t x = oord[p];
+        const FastClaim st = lds_get(&cst[x]);
+        const FastSlot s = lds_get(&aslot[gs.at(l)]);
+        const uint64_t m = st.vmask & s.cvmask;
+        FastEnt e = lds_get(&ent[fast_hash(m)]);
+        gx.at(l) = x; gk.at(l) = okey[p]; gp.at(l) = (uint32_t)p; gm.at(l) = m;
+        gq0.at(l) = st.req[0] + s.size[0]; gq1.at(l) = st.req[1] + s.size[1]; gq2.at(l) = st.req[2] + s.size[2]; gq3.at(l) = st.req[3] + s.size[3];
+        const int base_ok = (int)((s.tmplok >> (st.vmask >> 56)) & 1u) & (int)fast_fields_ok(m, s.dmask);
+        int simple = (int)(e.info & 1u) & (int)(e.vmask == m);
+        if (base_ok & (simple ^ 1) & (int)(e.info & 1u)) simple = (int)(fast_lookup(ent, m, e) >= 0);   // not the cache's first probe: the probe sequence
+        int fit = (int)fast_fits_first(e, st.req, s.size);
+        if (base_ok & simple & (fit ^ 1) & (int)(((e.info >> 8) & 0xFFu) != 0)) fit = (int)fast_fits(pool, e, st.req, s.size);   // the other Pareto vectors
+        // bit 0: accepted; bit 1: the requirement set is not cached yet (the window test raises the event)
+        return (base_ok & simple & fit) | ((base_ok & (simple ^ 1)) << 1);
+      }, g_acc, g_odd);
+      n_tests += (unsigned long long)(8 * gnn);
+      n_steps++;
+      KS_SEC(ts1)   // group test
+#ifdef KSOLVE_PHASE_TIMERS
+      ts5++;
+#endif
+    }
+    // ---- entries of the group that take no window test ----
+    bool placed_any = false;
+    while (gj < gn) {
+      const int j = gj;
+      const uint32_t gb = (uint32_t)(g_acc >> (8 * j)) & 0xFFu, ob = (uint32_t)(g_odd >> (8 * j)) & 0xFFu;
+      const int qf = __builtin_ctz(gb | 0x100u);
+      if (qf == 8 || (ob & ((1u << qf) - 1u))) break;   // nothing in eight positions, or an unresolved lane first: the window test
+      int L = 8 * j + qf;
+      if (KS_UNLIKELY(((g_touched & g_jumped) >> L) & 1)) {
+        // The first accepting lane's claim moved past other claims since the test: the entry's first candidate is now the
+        // accepting lane whose claim stands leftmost. It may be used when everything between the class's cursor and it is
+        // known to reject the entry: no unresolved lane before it, and it has not passed the first claim behind the eight.
+        const uint64_t accj = g_acc & (0xFFull << (8 * j)), oddj = g_odd & (0xFFull << (8 * j));
+        int c = -1;
+        const uint32_t pmin = W::argmin_u32([&](int l) { return ((accj >> l) & 1) ? gp.at(l) : 0xFFFFFFFFu; }, &c);
+        const uint64_t blockers = W::ballot([&](int l) { return ((oddj >> l) & 1) != 0 && gp.at(l) < pmin; });
+        if (blockers != 0 || pmin >= gB.bcast(8 * j) || c < 0) break;
+        L = fast_uniform(c);
+      }
+      const uint32_t x = gx.bcast(L);
+      const int a = (int)gp.bcast(L);
+      // only the move that is one short shift (otherwise: pdqsort's other paths, behind the window test)
+      if (KS_UNLIKELY((int)((uint32_t)a - e1 <= 2u) | (int)((uint32_t)a - e2 <= 2u) | (int)((uint32_t)a - e3 <= 2u))) break;
+      const int sj = (int)bslot.bcast(bi);
+      if ((g_touched >> L) & 1) {
+        // The claim gained pods since the group's test; it is still this entry's first candidate (its place among the others
+        // is what it was, or it was chosen by position above): test this one claim again.
+        const FastSlot cs = lds_get(&aslot[sj]);
+        const FastClaim st = lds_get(&cst[x]);
+        const uint32_t know = okey[a];
+        const uint64_t m = st.vmask & cs.cvmask;
+        const FastEnt e = lds_get(&ent[fast_hash(m)]);
+        const int base_ok = (int)((cs.tmplok >> (st.vmask >> 56)) & 1u) & (int)fast_fields_ok(m, cs.dmask);
+        const int simple = (int)(e.info & 1u) & (int)(e.vmask == m);
+        int fit = (int)fast_fits_first(e, st.req, cs.size);
+        if (base_ok & simple & (fit ^ 1) & (int)(((e.info >> 8) & 0xFFu) != 0)) fit = (int)fast_fits(pool, e, st.req, cs.size);
+        n_tests++;
+        if (base_ok & (simple ^ 1)) break;   // the requirement set is not the cache's first probe: the window test
+        if (!(base_ok & simple & fit)) { g_acc &= ~(1ull << L); continue; }   // rejected for good: the entry's next accepting lane
+        W::each([&](int l) {
+          if (l == L) {
+            gk.at(l) = know; gm.at(l) = m;
+            gq0.at(l) = (uint32_t)(st.req[0] + cs.size[0]); gq1.at(l) = (uint32_t)(st.req[1] + cs.size[1]);
+            gq2.at(l) = (uint32_t)(st.req[2] + cs.size[2]); gq3.at(l) = (uint32_t)(st.req[3] + cs.size[3]);
+          }
+        });
+        g_touched &= ~(1ull << L);
+      }
+      const uint32_t cnt = gk.bcast(L);
+      if (KS_UNLIKELY(cnt >= 65534u)) break;   // the window test raises the event
+      const uint32_t mvn = cnt + 1, ua = (uint32_t)a;
+      // the claims behind it, for the move of the next add's sort.Slice (scheduler.go:598)
+      LaneVar<uint32_t> kv2, ov2;
+      const int nm1 = n - 1;
+      const uint64_t lessm = W::ballot([&](int l) {
+        const int i0 = a + 1 + l, i = i0 < nm1 ? i0 : nm1;   // clamped: no lane is switched off for the two reads
+        const uint32_t k = okey[i];
+        kv2.at(l) = k; ov2.at(l) = oord[i];
+        return (int)(i0 <= nm1) & (int)(k < mvn);
+      });
+      const int s_ = lessm == ~0ull ? 64 : ctz64(~lessm);   // sorted beyond a: the smaller counts are a prefix
+      if (KS_UNLIKELY(s_ >= 64)) break;                      // a long run: the pending path
+      // ---- NodeClaim.Add (nodeclaim.go:247-263) on the claim of lane L; the claim lands behind the s_ claims it passes ----
+      W::each([&](int l) {
+        if (l == L) {
+          FastClaim ns;
+          ns.vmask = gm.at(l); ns.req[0] = (int32_t)gq0.at(l); ns.req[1] = (int32_t)gq1.at(l); ns.req[2] = (int32_t)gq2.at(l); ns.req[3] = (int32_t)gq3.at(l);
+          lds_put(&cst[gx.at(l)], ns);
+        }
+        if (l <= s_) { okey[a + l] = (uint16_t)(l == s_ ? mvn : kv2.at(l)); oord[a + l] = (uint16_t)(l == s_ ? x : ov2.at(l)); }
+        const bool me = l == bi;
+        oclaim.at(l) = me ? x : oclaim.at(l); ocnt.at(l) = me ? cnt : ocnt.at(l);
+      });
+      n_ref += (unsigned long long)a + 1;
+      const uint64_t same = W::ballot([&](int l) { return gx.at(l) == x; });
+      g_touched |= same;
+      {
+        // cursors and the group's positions in (a, a+s_] step left; the class's own cursor comes to a (the claims between it
+        // and this one rejected the class for good). Plain arithmetic: (r - a - 1) < s_ as unsigned is a < r <= a + s_.
+        const uint32_t ua1 = ua + 1u, su = (uint32_t)s_, usj = (uint32_t)sj;
+        W::each([&](int l) {
+#pragma unroll
+          for (int jj = 0; jj < kFastRows; ++jj) {
+            const uint32_t rr = cur[jj].at(l);
+            const uint32_t sh = rr - (uint32_t)((rr - ua1) < su);
+            cur[jj].at(l) = (uint32_t)(jj * 64 + l) == usj ? ua : sh;
+          }
+        });
+        if (s_) {
+          g_jumped |= same;
+          const uint32_t b = ua + su;
+          W::each([&](int l) {
+            const uint32_t pp = gp.at(l), bb = gB.at(l);
+            gp.at(l) = ((same >> l) & 1) ? b : pp - (uint32_t)((pp - ua1) < su);
+            gB.at(l) = bb - (uint32_t)((bb - ua1) < su);
+          });
+        }
+      }
+      W::sync();
+      gj++; bi++; steps++;
+      placed_any = true;
+    }
+    KS_SEC(ts2)   // entries placed from the group
+    if (gn > 0) {
+      if (gj >= gn) { gj = 0; gn = 0; continue; }   // the group is used up (its last entry was placed above)
+      gj++;                                           // the window test places this entry; the rest of the group stays valid behind it
+    }
+    const int slot_w = placed_any ? (int)bslot.bcast(bi) : slot;
+    const FastSlot cs = lds_get(&aslot[slot_w]);
     uint32_t rc0 = 0;
     {
-      const uint32_t c0 = cur[0].bcast(slot & 63), c1 = cur[1].bcast(slot & 63), c2 = cur[2].bcast(slot & 63), c3 = cur[3].bcast(slot & 63);
-      const int row = slot >> 6;
+      const uint32_t c0 = cur[0].bcast(slot_w & 63), c1 = cur[1].bcast(slot_w & 63), c2 = cur[2].bcast(slot_w & 63), c3 = cur[3].bcast(slot_w & 63);
+      const int row = slot_w >> 6;
       rc0 = row == 0 ? c0 : row == 1 ? c1 : row == 2 ? c2 : c3;
     }
     static_assert(kFastRows == 4, "cursor rows are spelled out above");
@@ -769,7 +957,7 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
         const int simple = (int)(e.info & 1u) & (int)(e.vmask == m);   // the cache's first probe is this requirement set
         const int fit = (int)fast_fits_first(e, st.req, cs.size);
         // bit 0: accepted; bit 1: needs the long way (requirement set not cached, a hash collision, or further Pareto vectors)
-        return (base_ok & simple & fit) | ((base_ok & ((simple ^ 1) | ((fit ^ 1) & (int)((e.info >> 8) != 0)))) << 1);
+        return (base_ok & simple & fit) | ((base_ok & ((simple ^ 1) | ((fit ^ 1) & (int)(((e.info >> 8) & 0xFFu) != 0)))) << 1);
       }, okm, oddm);
       uint64_t missm = 0;
       if (KS_UNLIKELY(oddm != 0)) {
@@ -826,12 +1014,23 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
 #pragma unroll
             for (int j = 0; j < kFastRows; ++j) { const uint32_t rr = cur[j].at(l); cur[j].at(l) = rr - (uint32_t)(((uint32_t)a < rr && rr <= (uint32_t)b) ? 1 : 0); }
           });
+          if (gj < gn) {   // the group's lanes follow the move; the claim's acceptances there are void
+            const uint64_t same = W::ballot([&](int l) { return gx.at(l) == (uint32_t)x; });
+            g_touched |= same;
+            if (s_) g_jumped |= same;
+            W::each([&](int l) {
+              const uint32_t pp = gp.at(l), bb = gB.at(l);
+              gp.at(l) = ((same >> l) & 1) ? (uint32_t)b : pp - (uint32_t)(((uint32_t)a < pp && pp <= (uint32_t)b) ? 1 : 0);
+              gB.at(l) = bb - (uint32_t)(((uint32_t)a < bb && bb <= (uint32_t)b) ? 1 : 0);
+            });
+          }
           moved = true;
         }
       }
       if (KS_UNLIKELY(!moved)) {
         if (W::leader()) okey[a] = (uint16_t)mvn;
         pend_a = a; pend_x = x; pend_mv = mvn;
+        gj = 0; gn = 0;
       }
       W::sync();
       break;
@@ -840,23 +1039,27 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
       // the event interrupts this pod: what the scan learned (claims that rejected it for good) is kept in its cursor
       W::each([&](int l) {
 #pragma unroll
-        for (int j = 0; j < kFastRows; ++j) if (j * 64 + l == slot) cur[j].at(l) = r;
+        for (int j = 0; j < kFastRows; ++j) if (j * 64 + l == slot_w) cur[j].at(l) = r;
       });
       break;
     }
     if (r != rc0) W::each([&](int l) {
 #pragma unroll
-      for (int j = 0; j < kFastRows; ++j) if (j * 64 + l == slot) cur[j].at(l) = r;
+      for (int j = 0; j < kFastRows; ++j) if (j * 64 + l == slot_w) cur[j].at(l) = r;
     });
     steps++;
+    KS_SEC(ts3)   // entry placed by the window test
+#ifdef KSOLVE_PHASE_TIMERS
+    ts7++;
+#endif
     if (KS_LIKELY(outcome == 1)) { bi++; continue; }
-    ev = FEV_NEWCLAIM; ev_arg = slot;   // no in-flight claim accepted the pod: addToNewNodeClaim; the driver moves on to the next pod
+    ev = FEV_NEWCLAIM; ev_arg = slot_w;   // no in-flight claim accepted the pod: addToNewNodeClaim; the driver moves on to the next pod
     break;
   }
   if (ev == FEV_DONE && bn > 0) {
     // the deadline / a cancellation stopped the loop inside a block: the pods placed so far are results too
-    const int dn = bi < bn ? bi : bn;
-    W::each([&](int l) { if (l < dn) { const uint32_t p = bpod.at(l); gassign[p] = (int32_t)oclaim.at(l); gslot[p] = ocnt.at(l); } });
+    const int dn = bi < bn ? bi : bn, b0 = base;
+    W::each([&](int l) { if (l < dn) { gqclaim[b0 + l] = oclaim.at(l); gqcnt[b0 + l] = ocnt.at(l); } });
     bn = 0; bi = 0;
   }
   // ---- state out ----
@@ -865,11 +1068,15 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
     hs->pend_a = pend_a; hs->pend_x = pend_x; hs->pend_mv = pend_mv; hs->pend_new = pend_new ? 1 : 0;
     hs->n_steps = n_steps; hs->n_tests = n_tests; hs->n_ref = n_ref; hs->ev_arg = ev_arg; hs->ev_vm = ev_vm;
     hs->hot_cycles += W::clock() - t_in;
+#ifdef KSOLVE_PHASE_TIMERS
+    hs->tsec[0] += ts0; hs->tsec[1] += ts1; hs->tsec[2] += ts2; hs->tsec[3] += ts3; hs->tsec[4] += ts4; hs->tsec[5] += ts5; hs->tsec[6] += ts6; hs->tsec[7] += ts7;
+#endif
   }
+#undef KS_SEC
   W::each([&](int l) {
 #pragma unroll
     for (int j = 0; j < kFastRows; ++j) hs->cur[j][l] = cur[j].at(l);
-    hs->nxt_pod[l] = nxt_pod.at(l); hs->nxt_cls[l] = nxt_cls.at(l); hs->bpod[l] = bpod.at(l); hs->bcls[l] = bcls.at(l);
+    hs->nxt_cls[l] = nxt_cls.at(l); hs->bcls[l] = bcls.at(l);
     hs->bslot[l] = bslot.at(l); hs->oclaim[l] = oclaim.at(l); hs->ocnt[l] = ocnt.at(l);
   });
   W::sync();
@@ -896,16 +1103,15 @@ struct FastEngine {
       h->max_steps = ms_ < 0 ? -1 : (int)(ms_ > 0x7FFFFFFF ? 0x7FFFFFFF : ms_);
       h->pend_a = -1; h->pend_x = 0; h->pend_mv = 0; h->pend_new = 0; h->ev_arg = 0; h->ev_vm = 0;
       h->n_steps = 0; h->n_tests = 0; h->n_ref = 0; h->hot_cycles = 0;
-      h->sorted = cold.Pk->sorted_pods; h->row_class = cold.Pk->row_class; h->cancel = cold.Sk->cancel_flag;
-      h->g_assign = cold.Sk->assign; h->g_slot = cold.Sk->slot;
+      for (int i = 0; i < 8; ++i) h->tsec[i] = 0;
+      h->q_class = cold.Fk->q_class; h->cancel = cold.Sk->cancel_flag;
+      h->q_claim = cold.Fk->q_claim; h->q_cnt = cold.Fk->q_cnt;
     }
     {
-      const uint32_t* sorted = cold.Pk->sorted_pods; const uint32_t* rc_ = cold.Pk->row_class;
+      const uint32_t* qc = cold.Fk->q_class;
       W::each([&](int l) {
         for (int j = 0; j < kFastRows; ++j) h->cur[j][l] = 0;
-        uint32_t p = 0, k = 0;
-        if (l < np) { p = sorted[l]; k = rc_[p]; }
-        h->nxt_pod[l] = p; h->nxt_cls[l] = k; h->bpod[l] = 0; h->bcls[l] = 0; h->bslot[l] = 0xFFFFu; h->oclaim[l] = 0; h->ocnt[l] = 0;
+        h->nxt_cls[l] = l < np ? qc[l] : 0; h->bcls[l] = 0; h->bslot[l] = 0xFFFFu; h->oclaim[l] = 0; h->ocnt[l] = 0;
       });
     }
     W::sync();
@@ -961,10 +1167,26 @@ struct FastEngine {
       if (ev >= 1 && ev <= 5) { tev[ev] += W::clock() - te0; nev[ev]++; }
     }
     // profiling builds (-DKSOLVE_PHASE_TIMERS): cycles inside the loop function, per event kind, in total; event counts
-    unsigned long long tc[8] = {h->hot_cycles, tev[1], tev[2], tev[3], tev[4], tev[5], W::clock() - t_begin, nev[3] + (nev[4] << 20) + (nev[1] << 40)};
+    unsigned long long tc[16] = {h->hot_cycles, tev[1], tev[2], tev[3], tev[4], tev[5], W::clock() - t_begin, nev[3] + (nev[4] << 20) + (nev[1] << 40),
+                                 h->tsec[0], h->tsec[1], h->tsec[2], h->tsec[3], h->tsec[4], h->tsec[5], h->tsec[6], h->tsec[7]};
     cold.finish(fast_uniform(h->status), fast_uniform(h->n), (unsigned long long)fast_uniform(h->steps), h->n_steps, h->n_tests, h->n_ref, tc);
   }
 };
+
+// ksolve_fast_queue — one thread per queue entry, before the loop: its class, and "not placed"
+// ksolve_fast_scatter — one thread per queue entry, after the loop: the entry's result under its pod index (Results.pod_assignment / pod_slot)
+struct FastQueueArgs {
+  const uint32_t* sorted; const uint32_t* row_class;
+  uint32_t* q_class; uint32_t* q_claim; uint32_t* q_cnt;
+  int32_t* assign; uint32_t* slot;
+};
+KS_FN void fast_queue_body(int i, const FastQueueArgs& a) { a.q_class[i] = a.row_class[a.sorted[i]]; a.q_claim[i] = 0xFFFFFFFFu; }
+KS_FN void fast_scatter_body(int i, const FastQueueArgs& a) {
+  const uint32_t c = a.q_claim[i];
+  if (c == 0xFFFFFFFFu) return;
+  const uint32_t p = a.sorted[i];
+  a.assign[p] = (int32_t)c; a.slot[p] = a.q_cnt[i];
+}
 
 // ksolve_fast_records — one wavefront per claim: materialises the hot claim record the finalize kernel and the result
 // download read (ksp.h RecLayout) from the cursor engine's compact state: requirement masks = the template's with the

@@ -155,6 +155,14 @@ __global__ void __launch_bounds__(64) ksolve_pack_fast_batch(const ks::FastArgs*
   ks::FastEngine<ks::Wave> eng(&a->pv, &a->ws, &a->fw, lds);
   eng.solve();
 }
+__global__ void ksolve_fast_queue(int n, ks::FastQueueArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ks::fast_queue_body(i, a);
+}
+__global__ void ksolve_fast_scatter(int n, ks::FastQueueArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ks::fast_scatter_body(i, a);
+}
 // One wavefront per claim: hot claim records (requirement masks, InstanceTypeOptions) from the cursor engine's compact state.
 __global__ void __launch_bounds__(64) ksolve_fast_records(ks::FastRecordArgs a) {
   ks::fast_record_body<ks::Wave>((int)blockIdx.x, a);
@@ -212,10 +220,21 @@ static void be_launch_pack_fast_batch(ksolve_handle** hs, int n) {
   }
   (void)hipFree(d_ptrs);
 }
+static ks::FastQueueArgs fast_queue_args(ksolve_handle* h) {
+  return ks::FastQueueArgs{h->pv.sorted_pods, h->pv.row_class, h->fw.q_class, h->fw.q_claim, h->fw.q_cnt, h->ws.assign, h->ws.slot};
+}
 static void be_launch_fast_records(ksolve_handle* h, int n_claims) {
   ks::FastRecordArgs a{h->pv, h->ws, h->fw};
   hipLaunchKernelGGL(ksolve_fast_records, dim3((unsigned)n_claims), dim3(64), 0, HB(h)->stream, a);
   hip_check(h, hipGetLastError(), "ksolve_fast_records launch");
+  const int n = (int)h->n_pods;
+  hipLaunchKernelGGL(ksolve_fast_scatter, grid_for(n), dim3(256), 0, HB(h)->stream, n, fast_queue_args(h));
+  hip_check(h, hipGetLastError(), "ksolve_fast_scatter launch");
+}
+static void be_launch_fast_queue(ksolve_handle* h) {
+  const int n = (int)h->n_pods;
+  hipLaunchKernelGGL(ksolve_fast_queue, grid_for(n), dim3(256), 0, HB(h)->stream, n, fast_queue_args(h));
+  hip_check(h, hipGetLastError(), "ksolve_fast_queue launch");
 }
 
 // One launch per engine flavour (lite / full problems of the batch), each on the stream of its first handle so that the

@@ -98,7 +98,8 @@ static void be_sort_pods(ksolve_handle* h);  // fills ws/pv.sorted_pods
 static void be_launch_pack(ksolve_handle* h);
 static void be_launch_pack_fast(ksolve_handle* h);                 // one wavefront: FastEngine::solve
 static void be_launch_pack_fast_batch(ksolve_handle** hs, int n);   // block b = the cursor engine on problem b; sets every handle's T_PACK timer
-static void be_launch_fast_records(ksolve_handle* h, int n_claims); // one wavefront per claim: fast_record_body
+static void be_launch_fast_records(ksolve_handle* h, int n_claims); // one wavefront per claim: fast_record_body; then fast_scatter_body per queue entry
+static void be_launch_fast_queue(ksolve_handle* h);                // one thread per queue entry: fast_queue_body
 static void be_launch_pack_batch(ksolve_handle** hs, int n);
 static void be_thread_init(ksolve_handle* h);   // makes the handle's device current on a worker thread   // one block per handle; sets every handle's T_PACK timer
 static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a);
@@ -600,6 +601,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       fw.c_hostseq = dz<uint32_t>(h, mc); fw.c_ent = dz<uint16_t>(h, mc);
       fw.c_state = dz<ks::FastClaim>(h, mc); fw.c_npods = dz<uint32_t>(h, mc);
       fw.ent_its = dz<uint64_t>(h, (size_t)ks::kFastEnt * it_words);
+      fw.q_class = dz<uint32_t>(h, d->n_pods); fw.q_claim = dz<uint32_t>(h, d->n_pods); fw.q_cnt = dz<uint32_t>(h, d->n_pods);
       h->d_fast_args = dz<ks::FastArgs>(h, 1);
     }
   }
@@ -827,6 +829,7 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
   // ---- phase 3: queue order ----
   be_tic(h, T_SORT);
   be_sort_pods(h);
+  if (h->fw.enabled && !P.big && n_pods) be_launch_fast_queue(h);   // the cursor engine reads the queue's classes in queue order
   be_toc(h, T_SORT);
 
   // ---- phase 4: pack ----

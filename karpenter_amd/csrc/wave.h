@@ -286,6 +286,12 @@ struct LaneVar {
     asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(w), "=&s"(m0_saved) : "s"(xs), "s"(lane));
     v = __builtin_bit_cast(T, w);
   }
+  // this lane reads lane `src`'s value (ds_bpermute_b32: the LDS crossbar, no LDS memory); `src` may differ per lane
+  KS_DEV T shuffle(int, int src) const {
+    static_assert(sizeof(T) == 4, "LaneVar::shuffle: 32-bit values");
+    const int x = __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, v));
+    return __builtin_bit_cast(T, x);
+  }
   KS_DEV T bcast(int lane) const {
     static_assert(sizeof(T) == 4 || sizeof(T) == 8, "LaneVar: 32- or 64-bit values");
     if constexpr (sizeof(T) == 4) {
@@ -302,6 +308,7 @@ struct LaneVar {
   T v[64];
   T& at(int l) { return v[l]; }
   void set(int lane, T x) { v[lane] = x; }
+  T shuffle(int, int src) const { return v[src & 63]; }   // callers never read a lane the same wave-wide call writes
   T bcast(int lane) const { return v[lane]; }
 #endif
 };

@@ -5,8 +5,8 @@ timeout 900 python - <<'PY' 2>&1 | tee gpurun_out/r2/fast_phases.log
 import sys, time, json, os
 from karpenter_amd import fixtures as fx
 from karpenter_amd.scheduling import NewScheduler
-names = ["hot loop","ev:entry","ev:slot","ev:slowsort","ev:place","ev:newclaim","total","counts"]
-for label, prob in (("config2 200k", fx.config2(pods=200000)), ("config2 1M", fx.config2(pods=1000000))):
+names = ["hot loop","ev:entry","ev:slot","ev:slowsort","ev:place","ev:newclaim","total","counts","top: block+pend","group tests","group placements","window placements","-","n group tests","n group placements","n window placements"]
+for label, prob in (("config2 1M", fx.config2(pods=1000000)),):
     s = NewScheduler(prob, solver_lib=os.path.abspath("karpenter_amd/variants/libksolve_timers.so"))
     r = s.Solve(repeat=2, want_results=False)
     c = r["counters"]; pc = c["phaseCycles"]

@@ -96,9 +96,18 @@ static void be_launch_pack_fast(ksolve_handle* h) {
   ks::FastEngine<ks::Wave> eng(&h->d_fast_args->pv, &h->d_fast_args->ws, &h->d_fast_args->fw, lds.data());
   eng.solve();
 }
+static ks::FastQueueArgs fast_queue_args(ksolve_handle* h) {
+  return ks::FastQueueArgs{h->pv.sorted_pods, h->pv.row_class, h->fw.q_class, h->fw.q_claim, h->fw.q_cnt, h->ws.assign, h->ws.slot};
+}
 static void be_launch_fast_records(ksolve_handle* h, int n_claims) {
   ks::FastRecordArgs a{h->pv, h->ws, h->fw};
   for (int c = 0; c < n_claims; ++c) ks::fast_record_body<ks::Wave>(c, a);
+  const ks::FastQueueArgs q = fast_queue_args(h);
+  for (int i = 0; i < (int)h->n_pods; ++i) ks::fast_scatter_body(i, q);
+}
+static void be_launch_fast_queue(ksolve_handle* h) {
+  const ks::FastQueueArgs q = fast_queue_args(h);
+  for (int i = 0; i < (int)h->n_pods; ++i) ks::fast_queue_body(i, q);
 }
 static void be_launch_pack_fast_batch(ksolve_handle** hs, int n) {
   for (int i = 0; i < n; ++i) { be_tic(hs[i], ksi::T_PACK); be_launch_pack_fast(hs[i]); be_toc(hs[i], ksi::T_PACK); }
