@@ -96,7 +96,6 @@ struct RowArgs {
   uint64_t* table_hash;     // 0 = empty
   uint32_t* table_rep;      // smallest row with that hash
   uint32_t* table_class;
-  uint64_t* row_hash;
   uint32_t* row_slot;
   uint32_t* row_class;
   uint32_t* n_classes;
@@ -164,35 +163,103 @@ KS_FN bool rows_equal(const RowArgs& a, int x, int y) {
 // re-seeds). The table is read before it is written: with a few thousand classes for a million rows nearly every row
 // finds its hash and a smaller representative already there and issues no atomic at all (a stale read only shows an
 // older state — empty slot, larger representative — and falls through to the atomic).
-KS_FN void row_hash_body(int row, const RowArgs& a) {
+// rows_equal with the row's own requirement sets at hand (q, qs) and no early exit on the mask words: every word of the
+// other row is loaded whatever the words before it held, so the loads are independent and in flight together (an early
+// exit per word makes 2 x req_words DEPENDENT round trips to L2 out of one comparison). Words of keys the set does not
+// define are ignored, as in equal_reqset.
+KS_FN uint64_t reqset_diff(const Dict& d, const ReqRef& a, const ReqRef& b) {
+  uint64_t diff = (uint64_t)((a.defined ^ b.defined) | (a.complement ^ b.complement) | (a.has_gte ^ b.has_gte) | (a.has_lte ^ b.has_lte));
+  // bit w of wdef: word w belongs to a key the set defines
+  uint64_t wdef0 = 0, wdef1 = 0;
+  for (int k = 0; k < d.n_keys; ++k) {
+    if (!bit(a.defined, k)) continue;
+    for (uint32_t w = d.key_word_off[k]; w < d.key_word_off[k + 1]; ++w) { if (w < 64) wdef0 |= 1ull << w; else wdef1 |= 1ull << (w - 64); }
+  }
+  const int rw = d.req_words;
+  int w = 0;
+  for (; w + 4 <= rw; w += 4) {
+    const uint64_t b0 = b.mask[w], b1 = b.mask[w + 1], b2 = b.mask[w + 2], b3 = b.mask[w + 3];
+    const uint64_t a0 = a.mask[w], a1 = a.mask[w + 1], a2 = a.mask[w + 2], a3 = a.mask[w + 3];
+    const uint64_t sel = w < 64 ? wdef0 >> w : wdef1 >> (w - 64);   // four-word groups never straddle bit 64
+    diff |= (a0 ^ b0) & (0ull - (sel & 1)); diff |= (a1 ^ b1) & (0ull - ((sel >> 1) & 1));
+    diff |= (a2 ^ b2) & (0ull - ((sel >> 2) & 1)); diff |= (a3 ^ b3) & (0ull - ((sel >> 3) & 1));
+  }
+  for (; w < rw; ++w) { const uint64_t sel = w < 64 ? wdef0 >> w : wdef1 >> (w - 64); diff |= (a.mask[w] ^ b.mask[w]) & (0ull - (sel & 1)); }
+  if (a.minv != nullptr || b.minv != nullptr) {
+    // minValues of the defined keys: every key's pair is loaded, the comparison is masked (independent loads again)
+    const int nk = d.n_keys;
+    for (int k = 0; k < nk; ++k) {
+      const int32_t am = a.minv ? a.minv[k] : -1, bm = b.minv ? b.minv[k] : -1;
+      diff |= (uint64_t)(uint32_t)(am ^ bm) & (0ull - (uint64_t)((a.defined >> k) & 1u));
+    }
+  }
+  if (a.has_gte | a.has_lte) {
+    uint32_t keys = a.defined;
+    while (keys) {
+      int k = __builtin_ctz(keys);
+      keys &= keys - 1;
+      if (bit(a.has_gte, k) && a.gte[k] != b.gte[k]) diff |= 1;
+      if (bit(a.has_lte, k) && a.lte[k] != b.lte[k]) diff |= 1;
+    }
+  }
+  return diff;
+}
+KS_FN bool rows_equal_q(const RowArgs& a, int x, int y, const ReqRef& q, const ReqRef& qs) {
+  uint64_t diff = 0;
+  for (int r = 0; r < a.n_res; ++r) diff |= (uint64_t)(a.requests[(size_t)r * a.n_rows + x] ^ a.requests[(size_t)r * a.n_rows + y]);
+  diff |= reqset_diff(a.dict, q, a.reqs.at(a.dict, y));
+  diff |= reqset_diff(a.dict, qs, a.strict.at(a.dict, y));
+  diff |= a.tolerates[x] ^ a.tolerates[y];
+  if (a.host_ports) diff |= (a.host_ports[(size_t)x * 2] ^ a.host_ports[(size_t)y * 2]) | (a.host_ports[(size_t)x * 2 + 1] ^ a.host_ports[(size_t)y * 2 + 1]);
+  if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) {
+    diff |= a.topo_owned[(size_t)x * a.topo_words + w] ^ a.topo_owned[(size_t)y * a.topo_words + w];
+    diff |= a.topo_selected[(size_t)x * a.topo_words + w] ^ a.topo_selected[(size_t)y * a.topo_words + w];
+  }
+  return diff == 0;
+}
+// q / qs: the row's two requirement sets — read from the tables (row_hash_body), or with their mask words staged in LDS by
+// the wave-cooperative loader of the device kernel (ksolve.hip: ksolve_row_hash_coop), where 64 rows' masks arrive as
+// fully coalesced 512-byte accesses instead of 64 lanes striding through 160-byte records.
+KS_FN uint64_t row_hash_value(int row, const RowArgs& a, const ReqRef& q, const ReqRef& qs) {
   uint64_t h = a.seed;
   for (int r = 0; r < a.n_res; ++r) h = mix64(h, (uint64_t)a.requests[(size_t)r * a.n_rows + row]);
-  h = hash_reqset(a.dict, h, a.reqs.at(a.dict, row));
-  h = hash_reqset(a.dict, h, a.strict.at(a.dict, row));
+  h = hash_reqset(a.dict, h, q);
+  h = hash_reqset(a.dict, h, qs);
   h = mix64(h, a.tolerates[row]);
   if (a.host_ports) { h = mix64(h, a.host_ports[(size_t)row * 2]); h = mix64(h, a.host_ports[(size_t)row * 2 + 1]); }
   if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) { h = mix64(h, a.topo_owned[(size_t)row * a.topo_words + w]); h = mix64(h, a.topo_selected[(size_t)row * a.topo_words + w]); }
-  if (h == 0) h = 1;
-  a.row_hash[row] = h;
+  return h ? h : 1;
+}
+// The row's slot in the class table (*slot_out), and the row this one has to equal (a row that reached the slot earlier) or
+// 0xFFFFFFFF when there is nothing to check. Every access here is device-wide (one address per class for all rows of the
+// class): the device kernel calls it once per DISTINCT hash of a wavefront, not once per row.
+KS_FN uint32_t row_table_insert(int row, const RowArgs& a, uint64_t h, uint32_t* slot_out) {
   uint32_t slot = (uint32_t)(h >> 17) & (a.table_size - 1);
   for (;;) {
     uint64_t cur = ((volatile uint64_t*)a.table_hash)[slot];
     if (cur == h) break;
     if (cur == 0ull) {
       cur = atomic_cas_u64(&a.table_hash[slot], 0ull, h);
-      if (cur == 0ull || cur == h) break;
+      if (cur == 0ull) { a.table_class[slot] = atomic_add_u32(a.n_classes, 1u); break; }   // the row that opens a slot draws its class id
+      if (cur == h) break;
     }
     slot = (slot + 1) & (a.table_size - 1);
   }
-  a.row_slot[row] = slot;
+  *slot_out = slot;
   uint32_t other = ((volatile uint32_t*)a.table_rep)[slot];
   if (other > (uint32_t)row) other = atomic_min_u32(&a.table_rep[slot], (uint32_t)row);
-  if (other != 0xFFFFFFFFu && other != (uint32_t)row && !rows_equal(a, row, (int)other)) *a.collision = 1;
+  return other == (uint32_t)row ? 0xFFFFFFFFu : other;
 }
-// each slot's final representative draws the class id
-KS_FN void row_verify_body(int row, const RowArgs& a) {
-  uint32_t slot = a.row_slot[row];
-  if (a.table_rep[slot] == (uint32_t)row) a.table_class[slot] = atomic_add_u32(a.n_classes, 1u);
+KS_FN uint32_t row_hash_insert(int row, const RowArgs& a, const ReqRef& q, const ReqRef& qs) {
+  uint32_t slot = 0;
+  const uint32_t other = row_table_insert(row, a, row_hash_value(row, a, q, qs), &slot);
+  a.row_slot[row] = slot;
+  return other;
+}
+KS_FN void row_hash_body(int row, const RowArgs& a) {
+  const ReqRef q = a.reqs.at(a.dict, row), qs = a.strict.at(a.dict, row);
+  const uint32_t other = row_hash_insert(row, a, q, qs);
+  if (other != 0xFFFFFFFFu && !rows_equal_q(a, row, (int)other, q, qs)) *a.collision = 1;
 }
 KS_FN void row_class_body(int row, const RowArgs& a) {
   uint32_t slot = a.row_slot[row];
@@ -217,7 +284,7 @@ KS_FN void class_gather_body(int cls, const RowArgs& a, int lane = 0, int nl = 1
   for (int r = lane; r < a.n_res; r += nl) {
     int64_t v = a.requests[(size_t)r * a.n_rows + row];
     a.cls_requests[(size_t)cls * a.n_res + r] = v;
-    atomic_min_i64(&a.min_request[r], v);
+    if (v < ((volatile int64_t*)a.min_request)[r]) atomic_min_i64(&a.min_request[r], v);   // a few thousand classes, n_res addresses: read first
   }
   copy_reqset(a.dict, a.cls_reqs, cls, a.reqs.at(a.dict, row), lane, nl);
   copy_reqset(a.dict, a.cls_strict, cls, a.strict.at(a.dict, row), lane, nl);

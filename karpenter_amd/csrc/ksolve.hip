@@ -4,7 +4,6 @@
 //   ksolve_it_index      one thread per instance type: inverts InstanceType.Requirements into per-(key,value) bitmasks
 //   ksolve_row_hash      one thread per pod row, ONE pass over the pod SoA: hash, class-table slot (read before any atomic),
 //                        smallest row of the slot as representative, exact compare against an earlier row of the slot
-//   ksolve_row_verify    class numbering (every slot's final representative draws an id)
 //   ksolve_row_class / ksolve_class_gather   class ids per row, class tables
 //   ksolve_sort_key      queue-order key extraction (5 stable LSD passes with rocprim::radix_sort_pairs)
 //   ksolve_pack          the pack engine: ONE wavefront per scheduling problem (engine.h)
@@ -74,9 +73,125 @@ __global__ void ksolve_row_hash(int n, ks::RowArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ks::row_hash_body(i, a);
 }
-__global__ void ksolve_row_verify(int n, ks::RowArgs a) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) ks::row_verify_body(i, a);
+// The same pass with the rows' mask words staged through LDS: one wavefront per 64 consecutive rows; the 64 x req_words
+// words of each table are contiguous in HBM, so lane l loads words l, l+64, ... (512 bytes per access, fully coalesced) and
+// drops them at [row][word] in LDS (odd row stride: the per-row reads that follow spread over the banks); every lane then
+// hashes its own row exactly as row_hash_body does.
+__global__ void __launch_bounds__(64) ksolve_row_hash_coop(int n, ks::RowArgs a, int rw, uint32_t magic, uint32_t kmagic) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t coop_lds[];
+  const int l = (int)threadIdx.x;
+  const int row0 = (int)blockIdx.x * 64;
+  const int rows = n - row0 < 64 ? n - row0 : 64;
+  const int stride = rw | 1;
+  const int total = rows * rw;
+  uint64_t* t0 = coop_lds;
+  uint64_t* t1 = coop_lds + 64 * stride;
+  const uint64_t* g0 = a.reqs.mask + (size_t)row0 * rw;
+  const uint64_t* g1 = a.strict.mask + (size_t)row0 * rw;
+  for (int e = l; e < total; e += 256) {
+    // four accesses of each table in flight per lane and round
+    const int e1 = e + 64, e2 = e + 128, e3 = e + 192;
+    const uint64_t a0 = g0[e], b0 = g1[e];
+    const uint64_t a1 = e1 < total ? g0[e1] : 0, b1 = e1 < total ? g1[e1] : 0;
+    const uint64_t a2 = e2 < total ? g0[e2] : 0, b2 = e2 < total ? g1[e2] : 0;
+    const uint64_t a3 = e3 < total ? g0[e3] : 0, b3 = e3 < total ? g1[e3] : 0;
+    { const int r = (int)__umulhi((uint32_t)e, magic); const int x = r * stride + (e - r * rw); t0[x] = a0; t1[x] = b0; }
+    if (e1 < total) { const int r = (int)__umulhi((uint32_t)e1, magic); const int x = r * stride + (e1 - r * rw); t0[x] = a1; t1[x] = b1; }
+    if (e2 < total) { const int r = (int)__umulhi((uint32_t)e2, magic); const int x = r * stride + (e2 - r * rw); t0[x] = a2; t1[x] = b2; }
+    if (e3 < total) { const int r = (int)__umulhi((uint32_t)e3, magic); const int x = r * stride + (e3 - r * rw); t0[x] = a3; t1[x] = b3; }
+  }
+  // minValues tables ([rows][n_keys] int32, read once per defined key by the hash): staged the same way
+  const int nk = a.dict.n_keys, kstride = nk | 1;
+  int32_t* m0 = (int32_t*)(coop_lds + 2 * 64 * stride);
+  int32_t* m1 = m0 + 64 * kstride;
+  const int ktotal = rows * nk;
+  if (a.reqs.minv) { const int32_t* g = a.reqs.minv + (size_t)row0 * nk; for (int e = l; e < ktotal; e += 64) { const int r = (int)__umulhi((uint32_t)e, kmagic); m0[r * kstride + (e - r * nk)] = g[e]; } }
+  if (a.strict.minv) { const int32_t* g = a.strict.minv + (size_t)row0 * nk; for (int e = l; e < ktotal; e += 64) { const int r = (int)__umulhi((uint32_t)e, kmagic); m1[r * kstride + (e - r * nk)] = g[e]; } }
+  // requests and the toleration mask of the 64 rows: [row][n_res + 1]
+  const int nr = a.n_res, rstride = nr + 1;
+  uint64_t* rqs = (uint64_t*)(m1 + 64 * kstride + ((64 * kstride) & 1));
+  const int row = row0 + l;
+  const bool live = row < n;
+  const int rowc = live ? row : n - 1;
+  for (int r = 0; r < nr; ++r) rqs[l * rstride + r] = (uint64_t)a.requests[(size_t)r * a.n_rows + rowc];
+  rqs[l * rstride + nr] = a.tolerates[rowc];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  ks::ReqRef q = a.reqs.at(a.dict, (uint32_t)rowc), qs = a.strict.at(a.dict, (uint32_t)rowc);
+  q.mask = t0 + (size_t)l * stride;
+  qs.mask = t1 + (size_t)l * stride;
+  if (q.minv) q.minv = m0 + (size_t)l * kstride;
+  if (qs.minv) qs.minv = m1 + (size_t)l * kstride;
+  const uint64_t h = live ? ks::row_hash_value(row, a, q, qs) : 0ull;
+  // The class table is one address per class for a million rows: every device-wide access to it is made ONCE per distinct
+  // hash of the wavefront (neighbouring pods mostly share their class), by the first lane that carries it. The other lanes
+  // take its slot and have to equal ITS row — both rows are in LDS. It has to equal the row that reached the slot before it
+  // (equality is transitive): that row's words are fetched by the whole wavefront, one lane per word (coalesced), and
+  // compared with the LDS copy — no lane walks a row of HBM word by word.
+  uint64_t todo = __ballot(live ? 1 : 0);
+  bool bad = false;
+  while (todo) {
+    const int j = __builtin_ctzll(todo);
+    const uint32_t hlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, j), hhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h >> 32), j);
+    const uint64_t hj = (uint64_t)hlo | ((uint64_t)hhi << 32);
+    const bool mine = live && h == hj;
+    todo &= ~__ballot(mine ? 1 : 0);
+    uint32_t slot = 0, other = 0xFFFFFFFFu;
+    if (l == j) other = ks::row_table_insert(row, a, h, &slot);
+    slot = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
+    const uint32_t rep = (uint32_t)__builtin_amdgcn_readlane((int)other, j);
+    // the first lane's requirement sets, wave-uniform flags and LDS words
+    ks::ReqRef qj, qsj;
+    qj.defined = (uint32_t)__builtin_amdgcn_readlane((int)q.defined, j); qj.complement = (uint32_t)__builtin_amdgcn_readlane((int)q.complement, j);
+    qj.has_gte = (uint32_t)__builtin_amdgcn_readlane((int)q.has_gte, j); qj.has_lte = (uint32_t)__builtin_amdgcn_readlane((int)q.has_lte, j);
+    qsj.defined = (uint32_t)__builtin_amdgcn_readlane((int)qs.defined, j); qsj.complement = (uint32_t)__builtin_amdgcn_readlane((int)qs.complement, j);
+    qsj.has_gte = (uint32_t)__builtin_amdgcn_readlane((int)qs.has_gte, j); qsj.has_lte = (uint32_t)__builtin_amdgcn_readlane((int)qs.has_lte, j);
+    const size_t rowj = (size_t)(row0 + j);
+    qj.mask = t0 + (size_t)j * stride; qsj.mask = t1 + (size_t)j * stride;
+    qj.minv = a.reqs.minv ? m0 + (size_t)j * kstride : nullptr; qsj.minv = a.strict.minv ? m1 + (size_t)j * kstride : nullptr;
+    qj.gte = a.reqs.gte ? a.reqs.gte + rowj * nk : nullptr; qj.lte = a.reqs.lte ? a.reqs.lte + rowj * nk : nullptr;
+    qsj.gte = a.strict.gte ? a.strict.gte + rowj * nk : nullptr; qsj.lte = a.strict.lte ? a.strict.lte + rowj * nk : nullptr;
+    if (mine) {
+      a.row_slot[row] = slot;
+      if (l != j) {
+        uint64_t d = ks::reqset_diff(a.dict, q, qj) | ks::reqset_diff(a.dict, qs, qsj);
+        for (int r = 0; r <= nr; ++r) d |= rqs[l * rstride + r] ^ rqs[j * rstride + r];
+        if (a.host_ports) d |= (a.host_ports[(size_t)row * 2] ^ a.host_ports[rowj * 2]) | (a.host_ports[(size_t)row * 2 + 1] ^ a.host_ports[rowj * 2 + 1]);
+        if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) {
+          d |= a.topo_owned[(size_t)row * a.topo_words + w] ^ a.topo_owned[rowj * a.topo_words + w];
+          d |= a.topo_selected[(size_t)row * a.topo_words + w] ^ a.topo_selected[rowj * a.topo_words + w];
+        }
+        if (d) bad = true;
+      }
+    }
+    if (rep != 0xFFFFFFFFu) {
+      uint64_t d = 0;
+      d |= (uint64_t)((a.reqs.defined[rep] ^ qj.defined) | (a.reqs.complement[rep] ^ qj.complement) | ((a.reqs.has_gte ? a.reqs.has_gte[rep] : 0u) ^ qj.has_gte) | ((a.reqs.has_lte ? a.reqs.has_lte[rep] : 0u) ^ qj.has_lte));
+      d |= (uint64_t)((a.strict.defined[rep] ^ qsj.defined) | (a.strict.complement[rep] ^ qsj.complement) | ((a.strict.has_gte ? a.strict.has_gte[rep] : 0u) ^ qsj.has_gte) | ((a.strict.has_lte ? a.strict.has_lte[rep] : 0u) ^ qsj.has_lte));
+      if (l <= nr) d |= (l < nr ? (uint64_t)a.requests[(size_t)l * a.n_rows + rep] : a.tolerates[rep]) ^ rqs[j * rstride + l];
+      for (int w = l; w < rw; w += 64) {   // one lane per mask word; words of keys the set does not define are ignored (equal_reqset)
+        int kw = 0;
+        for (int k = 0; k < nk; ++k) kw += (int)((uint32_t)w >= a.dict.key_word_off[k + 1]);
+        const uint64_t x0 = a.reqs.mask[(size_t)rep * rw + w] ^ t0[j * stride + w], x1 = a.strict.mask[(size_t)rep * rw + w] ^ t1[j * stride + w];
+        d |= (((qj.defined >> kw) & 1u) ? x0 : 0ull) | (((qsj.defined >> kw) & 1u) ? x1 : 0ull);
+      }
+      if (l < nk) {   // one lane per key: minValues and bounds of the keys the set defines
+        if (a.reqs.minv && ((qj.defined >> l) & 1u)) d |= (uint64_t)(uint32_t)(a.reqs.minv[(size_t)rep * nk + l] ^ m0[j * kstride + l]);
+        if (a.strict.minv && ((qsj.defined >> l) & 1u)) d |= (uint64_t)(uint32_t)(a.strict.minv[(size_t)rep * nk + l] ^ m1[j * kstride + l]);
+        if ((qj.has_gte >> l) & 1u) d |= (uint64_t)(a.reqs.gte[(size_t)rep * nk + l] ^ qj.gte[l]);
+        if ((qj.has_lte >> l) & 1u) d |= (uint64_t)(a.reqs.lte[(size_t)rep * nk + l] ^ qj.lte[l]);
+        if ((qsj.has_gte >> l) & 1u) d |= (uint64_t)(a.strict.gte[(size_t)rep * nk + l] ^ qsj.gte[l]);
+        if ((qsj.has_lte >> l) & 1u) d |= (uint64_t)(a.strict.lte[(size_t)rep * nk + l] ^ qsj.lte[l]);
+      }
+      if (a.host_ports && l < 2) d |= a.host_ports[(size_t)rep * 2 + l] ^ a.host_ports[rowj * 2 + l];
+      if (a.topo_owned) for (int w = l; w < a.topo_words; w += 64) {
+        d |= a.topo_owned[(size_t)rep * a.topo_words + w] ^ a.topo_owned[rowj * a.topo_words + w];
+        d |= a.topo_selected[(size_t)rep * a.topo_words + w] ^ a.topo_selected[rowj * a.topo_words + w];
+      }
+      if (__ballot(d != 0 ? 1 : 0)) bad = true;
+    }
+  }
+  if (bad) *a.collision = 1;
 }
 __global__ void ksolve_row_class(int n, ks::RowArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -169,8 +284,19 @@ __global__ void __launch_bounds__(64) ksolve_fast_records(ks::FastRecordArgs a) 
 }
 static dim3 grid_for(int n) { return dim3((unsigned)((n + 255) / 256)); }
 static void be_launch_it_index(ksolve_handle* h, int n, const ks::ItIndexArgs& a) { hipLaunchKernelGGL(ksolve_it_index, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
-static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_row_hash, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
-static void be_launch_row_verify(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_row_verify, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
+static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) {
+  const int rw = a.dict.req_words;
+  const int nk = a.dict.n_keys;
+  const size_t lds = (size_t)2 * 64 * (size_t)(rw | 1) * 8 + (size_t)2 * 64 * (size_t)(nk | 1) * 4 + 8 + (size_t)64 * (size_t)(a.n_res + 1) * 8;
+  if (rw >= 1 && nk >= 1 && lds <= 64 * 1024) {
+    // floor(e / rw) = umulhi(e, magic) for every e < 64 * rw (e * rw < 2^32)
+    const uint32_t magic = (uint32_t)((0x100000000ull + (uint64_t)rw - 1) / (uint64_t)rw);
+    const uint32_t kmagic = (uint32_t)((0x100000000ull + (uint64_t)nk - 1) / (uint64_t)nk);
+    hipLaunchKernelGGL(ksolve_row_hash_coop, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, HB(h)->stream, n, a, rw, magic, kmagic);
+  } else {
+    hipLaunchKernelGGL(ksolve_row_hash, grid_for(n), dim3(256), 0, HB(h)->stream, n, a);
+  }
+}
 static void be_launch_row_class(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_row_class, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
 static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a) { hipLaunchKernelGGL(ksolve_class_gather, grid_for(n * 64), dim3(256), 0, HB(h)->stream, n, a); }
 static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a) { hipLaunchKernelGGL(ksolve_finalize, grid_for(n), dim3(256), 0, HB(h)->stream, n, a); }
@@ -384,6 +510,7 @@ double ksolve_last_kernel_ms(const ksolve_handle* h, const char* name) {
   std::string n(name ? name : "");
   if (n == "ksolve_pack") return h->timers.ms[ksi::T_PACK];
   if (n == "classify") return h->timers.ms[ksi::T_CLASSIFY];
+  if (n == "row_hash") return h->timers.ms[ksi::T_ROWHASH];
   if (n == "sort") return h->timers.ms[ksi::T_SORT];
   if (n == "it_index") return h->timers.ms[ksi::T_INDEX];
   return -1;

@@ -37,7 +37,7 @@ struct HostReqTable {  // device pointers of an uploaded ksolve_reqsets
 struct Timers {
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
-enum { T_UPLOAD = 0, T_INDEX = 1, T_CLASSIFY = 2, T_SORT = 3, T_PACK = 4, T_FINALIZE = 5, T_DOWNLOAD = 6 };
+enum { T_UPLOAD = 0, T_INDEX = 1, T_CLASSIFY = 2, T_SORT = 3, T_PACK = 4, T_FINALIZE = 5, T_DOWNLOAD = 6, T_ROWHASH = 7 };   // T_ROWHASH: the streaming kernel of the classing phase alone (inside T_CLASSIFY)
 
 }  // namespace ksi
 
@@ -91,7 +91,6 @@ static void be_tic(ksolve_handle* h, int slot);
 static void be_toc(ksolve_handle* h, int slot);
 static void be_launch_it_index(ksolve_handle* h, int n, const ks::ItIndexArgs& a);
 static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a);
-static void be_launch_row_verify(ksolve_handle* h, int n, const ks::RowArgs& a);
 static void be_launch_row_class(ksolve_handle* h, int n, const ks::RowArgs& a);
 static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a);
 static void be_sort_pods(ksolve_handle* h);  // fills ws/pv.sorted_pods
@@ -367,7 +366,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   while (ts < 2 * d->n_pod_rows) ts <<= 1;
   R.table_size = ts; R.seed = 0x6b73703176310a01ull;
   R.table_hash = dz<uint64_t>(h, ts); R.table_rep = dz<uint32_t>(h, ts); R.table_class = dz<uint32_t>(h, ts);
-  R.row_hash = dz<uint64_t>(h, d->n_pod_rows); R.row_slot = dz<uint32_t>(h, d->n_pod_rows);
+  R.row_slot = dz<uint32_t>(h, d->n_pod_rows);
   uint32_t* row_class = dz<uint32_t>(h, d->n_pod_rows);
   R.row_class = row_class; P.row_class = row_class;
   R.n_classes = dz<uint32_t>(h, 1); R.collision = dz<uint32_t>(h, 1);
@@ -778,7 +777,7 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
     be_fill(h, R.table_rep, 0xFF, (size_t)R.table_size * 4);
     be_fill(h, R.n_classes, 0, 4);
     be_fill(h, R.collision, 0, 4);
-    if (n_rows) { be_launch_row_hash(h, (int)n_rows, R); be_launch_row_verify(h, (int)n_rows, R); }
+    if (n_rows) { be_tic(h, T_ROWHASH); be_launch_row_hash(h, (int)n_rows, R); be_toc(h, T_ROWHASH); }
     uint32_t coll = 0;
     be_d2h(h, &n_classes, R.n_classes, 4);
     be_d2h(h, &coll, R.collision, 4);

@@ -1759,6 +1759,7 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
       if (api.kernel_ms) {
         t.set("pack_kernel_ms", Value::number(api.kernel_ms(handle, "ksolve_pack")));
         t.set("classify_ms", Value::number(api.kernel_ms(handle, "classify")));
+        t.set("row_hash_ms", Value::number(api.kernel_ms(handle, "row_hash")));
         t.set("sort_ms", Value::number(api.kernel_ms(handle, "sort")));
         t.set("it_index_ms", Value::number(api.kernel_ms(handle, "it_index")));
       }

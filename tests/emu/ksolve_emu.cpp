@@ -24,7 +24,6 @@ static void be_toc(ksolve_handle* h, int slot) {
 }
 static void be_launch_it_index(ksolve_handle*, int n, const ks::ItIndexArgs& a) { for (int i = 0; i < n; ++i) ks::it_index_body(i, a); }
 static void be_launch_row_hash(ksolve_handle*, int n, const ks::RowArgs& a) { for (int i = 0; i < n; ++i) ks::row_hash_body(i, a); }
-static void be_launch_row_verify(ksolve_handle*, int n, const ks::RowArgs& a) { for (int i = 0; i < n; ++i) ks::row_verify_body(i, a); }
 static void be_launch_row_class(ksolve_handle*, int n, const ks::RowArgs& a) { for (int i = 0; i < n; ++i) ks::row_class_body(i, a); }
 static void be_launch_class_gather(ksolve_handle*, int n, const ks::RowArgs& a) { for (int i = 0; i < n; ++i) ks::class_gather_body(i, a); }
 static void be_launch_finalize(ksolve_handle*, int n, const ks::FinalizeArgs& a) { for (int i = 0; i < n; ++i) ks::finalize_body(i, a); }
@@ -149,6 +148,7 @@ double ksolve_last_kernel_ms(const ksolve_handle* h, const char* name) {
   std::string n(name ? name : "");
   if (n == "ksolve_pack") return h->timers.ms[ksi::T_PACK];
   if (n == "classify") return h->timers.ms[ksi::T_CLASSIFY];
+  if (n == "row_hash") return h->timers.ms[ksi::T_ROWHASH];
   if (n == "sort") return h->timers.ms[ksi::T_SORT];
   if (n == "it_index") return h->timers.ms[ksi::T_INDEX];
   return -1;
