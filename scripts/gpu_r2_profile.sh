@@ -27,3 +27,22 @@ for tag in ("sq", "fetch", "write"):
             out.setdefault(k, {})[c] = {"sum": v, "launches": n, "per_launch": v / n}
 json.dump(out, open(f"{O}/pmc_raw.json", "w"), indent=1)
 PY
+python - $O <<'PY'
+import json, sys
+O = sys.argv[1]
+raw = json.load(open(O + "/pmc_raw.json"))
+k = raw["ksolve_pack_fast"]
+fetch_kb, write_kb = k["FETCH_SIZE"]["per_launch"], k["WRITE_SIZE"]["per_launch"]
+out = {"kernel": "ksolve_pack_fast",
+       "workload": "bench.py --steps 3 --warmup 1 (configs[1]: 1M pods x 500 types), rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace only (scripts/gpu_r2_profile.sh)",
+       "fetch_kb_per_launch": fetch_kb, "write_kb_per_launch": write_kb,
+       "traffic_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
+       "note": "FETCH_SIZE doubled (gfx950: the counter tallies 128-byte requests at 64 bytes, MI355X_MICROARCH.md); WRITE_SIZE as reported"}
+json.dump(out, open(O + "/pmc_pack_traffic.json", "w"), indent=1)
+print(out)
+PY
+# lone-wave cost model, cursor-engine per-path counters, the resident-cluster consolidation sweep
+(cd tests/tools/ubench && ./branch_cost && ./lds_latency) > $O/ubench.log 2>&1; cat $O/ubench.log
+bash scripts/gpu_fast_phases.sh | grep -v upload_us > $O/fast_phases.log 2>&1; tail -12 $O/fast_phases.log
+timeout 900 python tests/tools/consolidation_sweep.py 10000 256 6 --types 500 --out $O/consolidation_sweep_10k_256.json > $O/sweep.log 2>&1
+tail -c 1500 $O/sweep.log
