@@ -771,9 +771,10 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
     // ---- the pod's class slot ----
     const int slot = (int)bslot.bcast(bi);
     if (KS_UNLIKELY(slot == 0xFFFF)) { ev = FEV_SLOT; ev_arg = (int)bcls.bcast(bi); break; }
-    if (use_groups && gj >= gn && bi + 1 < bn) {
+    const int lastq = base + bn >= np ? 1 : 0;   // the queue's last entry is not placed from a group: no add follows it, its move stays undone (as in the reference)
+    if (use_groups && gj >= gn && bi + lastq < bn) {
       // ---- a new group: the next entries of the block that have a class slot, eight at most ----
-      const int g0 = bn - bi - 1 < 8 ? bn - bi - 1 : 8, bi0 = bi, nn = n;   // not the block's last entry (its move is left pending)
+      const int g0 = bn - bi - lastq < 8 ? bn - bi - lastq : 8, bi0 = bi, nn = n;
       LaneVar<uint32_t> gs, gr;
       W::each([&](int l) { const int j = l >> 3; gs.at(l) = bslot.shuffle(l, (bi0 + (j < g0 ? j : 0)) & 63); });
       W::each([&](int l) {
@@ -846,13 +847,14 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
         const FastClaim st = lds_get(&cst[x]);
         const uint32_t know = okey[a];
         const uint64_t m = st.vmask & cs.cvmask;
-        const FastEnt e = lds_get(&ent[fast_hash(m)]);
+        FastEnt e = lds_get(&ent[fast_hash(m)]);
         const int base_ok = (int)((cs.tmplok >> (st.vmask >> 56)) & 1u) & (int)fast_fields_ok(m, cs.dmask);
-        const int simple = (int)(e.info & 1u) & (int)(e.vmask == m);
+        int simple = (int)(e.info & 1u) & (int)(e.vmask == m);
+        if (base_ok & (simple ^ 1) & (int)(e.info & 1u)) simple = (int)(fast_lookup(ent, m, e) >= 0);   // not the cache's first probe: the probe sequence
         int fit = (int)fast_fits_first(e, st.req, cs.size);
         if (base_ok & simple & (fit ^ 1) & (int)(((e.info >> 8) & 0xFFu) != 0)) fit = (int)fast_fits(pool, e, st.req, cs.size);
         n_tests++;
-        if (base_ok & (simple ^ 1)) break;   // the requirement set is not the cache's first probe: the window test
+        if (base_ok & (simple ^ 1)) break;   // the requirement set is not cached yet: the window test raises the event
         if (!(base_ok & simple & fit)) { g_acc &= ~(1ull << L); continue; }   // rejected for good: the entry's next accepting lane
         W::each([&](int l) {
           if (l == L) {

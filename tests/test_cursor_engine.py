@@ -119,6 +119,28 @@ def test_fuzz_against_the_oracle(oracle, emu, block):
     assert ran >= 15, (ran, declined)
 
 
+@pytest.mark.parametrize("block", range(4))
+def test_group_speculation_against_the_general_engine(emu, block):
+    """Group speculation (one CanAdd test for eight queue entries, fast_engine.h) only runs with at most 12 or at least 50
+    in-flight claims: mid-size batches with hundreds of claims, many classes that share them, and runs of equal pod counts —
+    touched claims, claims that moved past others, rejected re-tests, the block's last entry. Compared with the general
+    engine (itself fuzzed against the oracle) claim by claim, including the reference-equivalent evaluation count."""
+    ran = 0
+    for seed in range(block * 6, block * 6 + 6):
+        rng = random.Random(7000 + seed)
+        prob = lite_problem(rng, rng.choice([2500, 4000, 6000]))
+        try:
+            c = NewScheduler(with_engine(prob, "cursor"), solver_lib=emu).Solve()
+        except Unsupported:
+            continue
+        g = NewScheduler(with_engine(prob, "general"), solver_lib=emu).Solve()
+        assert c["counters"]["engine"] == "cursor" and g["counters"]["engine"] == "general"
+        parity.assert_same_results(c, g)
+        assert c["counters"]["referenceBinEvaluations"] == g["counters"]["referenceBinEvaluations"]
+        ran += 1
+    assert ran >= 2, ran
+
+
 def test_several_pareto_vectors_per_requirement_set(oracle, emu):
     """A cpu-heavy and a memory-heavy instance type: neither dominates, so "some type still fits" needs both vectors."""
     def it(name, cpu, mem):
