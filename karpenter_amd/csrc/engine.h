@@ -24,6 +24,7 @@
 #include "ksp.h"
 #include <type_traits>
 #include "pdq_emul.h"
+#include "run_order.h"
 
 // diagnostic counters that only the profiling build keeps (every live 64-bit counter costs the lone wave registers)
 #ifdef KSOLVE_PHASE_TIMERS
@@ -87,6 +88,7 @@ struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host b
   KS_LDS uint32_t *okey, *oord, *opos;   // claim order (pdq_emul.h)
   uint64_t* closed;     // [claim words] claims that cannot take any pod any more
   uint64_t* stage_big;  // [claim words] live-set staging of the BIG engine (the others use Scratch::stage)
+  KS_LDS RunTables* runs;   // BIG engine: per-count ring tables of the claim order (run_order.h), in place of okey / oord / opos
   uint64_t* cache;      // [32][c_hot_words] direct-mapped cache of hot claim records
   int64_t* dg_ov;       // [n_dg][nr] daemon overhead per group (scheduler.go:963-1043)
   uint64_t* dg_its;     // [n_dg][iw] instance types of the group
@@ -96,6 +98,7 @@ struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host b
     keymask = (uint64_t*)(base + p.off_keymask); allocok = (uint64_t*)(base + p.off_allocok); kvslot = (uint16_t*)(base + p.off_kvslot);
     tmpl = (uint64_t*)(base + p.off_tmpl); tmpl_cold = (uint64_t*)(base + p.off_tmplcold);
     okey = (KS_LDS uint32_t*)(base + p.off_order); oord = okey + p.order_cap; opos = oord + p.order_cap;
+    runs = (KS_LDS RunTables*)(base + p.off_order);
     closed = (uint64_t*)(base + p.off_closed); cache = (uint64_t*)(base + p.off_cache);
     stage_big = (uint64_t*)(base + p.off_stage);
     dg_ov = (int64_t*)(base + p.off_dgov); dg_its = (uint64_t*)(base + p.off_dgits);
@@ -115,7 +118,7 @@ struct Engine {
   Scratch& sc;
   const RecLayout lay;
   typedef typename std::conditional<BIG, uint32_t*, KS_LDS uint32_t*>::type order_ptr;
-  ClaimOrder<W, order_ptr> order;
+  typename std::conditional<BIG, RunOrder<W>, ClaimOrder<W, order_ptr>>::type order;   // BIG: one ring per pod count in HBM (run_order.h)
   int n_claims = 0;
   uint32_t host_seq = 0;
   uint32_t active_templates = 0;
@@ -149,7 +152,7 @@ struct Engine {
   bool topo_reached = false;        // the last can_add got as far as the topology stage (its verdict is not cacheable)
 
   KS_DEV Engine(const ProblemView& p, Workspace& s, const LdsTables& l) : P(p), S(s), L(l), sc(*l.scratch), lay(p.lay) {
-    if constexpr (BIG) { order.key = s.o_key; order.ord = s.o_ord; order.pos = s.o_pos; }
+    if constexpr (BIG) order.init(L.runs, s.o_ring, s.o_cnt, s.o_pos, s.o_key, s.o_ord, s.run_tabs, s.run_off, s.run_log, s.run_kmax);
     else { order.key = L.okey; order.ord = L.oord; order.pos = L.opos; }
     min_values_best_effort = s.min_values_best_effort != 0;
   }
@@ -1132,7 +1135,7 @@ struct Engine {
     ctr.cycles[5] += t2 - t1;
     if (rc != E_OK) return rc;
     const uint32_t tmpl = lo32(sc.claim[ly.c_meta()]), np = hi32(sc.claim[ly.c_meta()]);
-    ctr.ref_bin_evaluations += (unsigned long long)order.pos[c] + 1;   // the reference walked every claim up to this position
+    ctr.ref_bin_evaluations += (unsigned long long)order.position(c) + 1;   // the reference walked every claim up to this position
     if (!changed) {
       // requirements untouched: carry masks and flags over from the bin record
       uint64_t* o = sc.out;
@@ -1255,13 +1258,11 @@ struct Engine {
     for (int r = 0; r < kRegNr; ++r) rq[r] = r < nr ? req[r] : INT64_MIN;
     unsigned long long ts2 = W::clock();
     ctr.cycles[18] += ts2 - ts1;
-    const order_ptr ord = order.ord;
     {
       // Few live claims (the usual case once the dead row has filled in): the candidate the reference reaches first is
       // the live claim with the smallest position in its order (addToInflightNode, scheduler.go:667-686). Lane l owns
       // word l of the live set and takes the minimum of (position, claim) over its bits; one DPP reduction picks the
       // winner. No walk over the order at all.
-      const order_ptr pos = order.pos;
       int who0;
       int densest;
       if constexpr (BIG) {
@@ -1332,7 +1333,7 @@ struct Engine {
               uint64_t mine = ~0ull;
               for (int w = l; w < words; w += 64) for (uint64_t b = stage[w]; b; b &= b - 1) {
                 const uint32_t cc = (uint32_t)(w * 64 + ctz64(b));
-                const uint64_t key = ((uint64_t)pos[cc] << 32) | cc;
+                const uint64_t key = ((uint64_t)order.position((int)cc) << 32) | cc;
                 mine = key < mine ? key : mine;
               }
               return mine;
@@ -1345,7 +1346,7 @@ struct Engine {
               uint32_t mine = 0xFFFFFFFFu;
               for (int w = l; w < words; w += 64) for (uint64_t b = stage[w]; b; b &= b - 1) {
                 const uint32_t cc = (uint32_t)(w * 64 + ctz64(b));
-                const uint32_t key = (pos[cc] << 13) | cc;
+                const uint32_t key = (order.position((int)cc) << 13) | cc;
                 mine = key < mine ? key : mine;
               }
               return mine;
@@ -1368,48 +1369,64 @@ struct Engine {
       }
     }
     // Many live claims: walk the claims in the reference's order, 64 positions per ballot, testing the staged live bits:
-    // the first live position is the first candidate; a failed probe clears its bit.
-    for (int base0 = 0; base0 < nc; base0 += 512) {
-      // 512 positions per step: eight independent (ord -> live bit) gathers in flight, then eight ballots
-      const int nchunks = (nc - base0 + 63) / 64 < 8 ? (nc - base0 + 63) / 64 : 8;
-      uint64_t found = 0;   // first chunk with a live position
-      int found_j = -1;
-      W::ballots8(nchunks, [&](int l, int j) {
-        int i = base0 + j * 64 + l;
-        if (i >= nc) return false;
-        uint32_t c = ord[i];
-        return ((stage[c >> 6] >> (c & 63)) & 1) != 0;
-      }, [&](int j, uint64_t m) { if (m && found_j < 0) { found_j = j; found = m; } });
-      if (found_j < 0) continue;
-      // probe from the first live position on, chunk by chunk (re-ballot after a failed probe: stage changed)
-      for (int base = base0 + found_j * 64; base < nc && base < base0 + 512; base += 64) {
-        uint64_t m = base == base0 + found_j * 64 ? found : W::ballot([&](int l) {
-          int i = base + l;
-          if (i >= nc) return false;
-          uint32_t c = ord[i];
+    // the first live position is the first candidate; a failed probe clears its bit. The order is walked one SEGMENT at a
+    // time — the whole array (LDS-resident order), or one ring per pod count, smallest count first (BIG: run_order.h; the
+    // sort that precedes the scan leaves no pending move).
+    auto walk = [&](int seg_n, auto claim_of) -> bool {
+      for (int base0 = 0; base0 < seg_n; base0 += 512) {
+        // 512 positions per step: eight independent (order -> live bit) gathers in flight, then eight ballots
+        const int nchunks = (seg_n - base0 + 63) / 64 < 8 ? (seg_n - base0 + 63) / 64 : 8;
+        uint64_t found = 0;   // first chunk with a live position
+        int found_j = -1;
+        W::ballots8(nchunks, [&](int l, int j) {
+          int i = base0 + j * 64 + l;
+          if (i >= seg_n) return false;
+          uint32_t c = claim_of(i);
           return ((stage[c >> 6] >> (c & 63)) & 1) != 0;
-        });
-        while (m) {
-          int i = base + ctz64(m);
-          m &= m - 1;
-          const int c = (int)ord[i];
-          const int l = c >> 6;
-          const uint64_t valid = (l == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
-          const uint64_t live = stage[l] & ~(1ull << (c & 63));
-          if (try_claim(k, c, pod) == E_OK) return true;
-          unsigned long long tf = W::clock();
-          // the class's dead word becomes: everything not live any more (closed claims may be recorded as dead too —
-          // both are permanent until the column is reset), never touching bits of claims that do not exist yet. Classes
-          // under topology constraints only record the failures that did not depend on domain counters.
-          if (!FULL || !cur_M) W::store(&drow[l], (uint64_t)(~live & valid));
-          else if (!topo_reached) W::store(&drow[l], (uint64_t)(drow[l] | (1ull << (c & 63))));
-          W::store(&stage[l], live);
-          W::sync();
-          ctr.cycles[8] += W::clock() - tf;
+        }, [&](int j, uint64_t m) { if (m && found_j < 0) { found_j = j; found = m; } });
+        if (found_j < 0) continue;
+        // probe from the first live position on, chunk by chunk (re-ballot after a failed probe: stage changed)
+        for (int base = base0 + found_j * 64; base < seg_n && base < base0 + 512; base += 64) {
+          uint64_t m = base == base0 + found_j * 64 ? found : W::ballot([&](int l) {
+            int i = base + l;
+            if (i >= seg_n) return false;
+            uint32_t c = claim_of(i);
+            return ((stage[c >> 6] >> (c & 63)) & 1) != 0;
+          });
+          while (m) {
+            int i = base + ctz64(m);
+            m &= m - 1;
+            const int c = (int)W::uniform((uint64_t)claim_of(i));
+            const int l = c >> 6;
+            const uint64_t valid = (l == words - 1 && (nc & 63)) ? ((1ull << (nc & 63)) - 1) : ~0ull;
+            const uint64_t live = stage[l] & ~(1ull << (c & 63));
+            if (try_claim(k, c, pod) == E_OK) return true;
+            unsigned long long tf = W::clock();
+            // the class's dead word becomes: everything not live any more (closed claims may be recorded as dead too —
+            // both are permanent until the column is reset), never touching bits of claims that do not exist yet. Classes
+            // under topology constraints only record the failures that did not depend on domain counters.
+            if (!FULL || !cur_M) W::store(&drow[l], (uint64_t)(~live & valid));
+            else if (!topo_reached) W::store(&drow[l], (uint64_t)(drow[l] | (1ull << (c & 63))));
+            W::store(&stage[l], live);
+            W::sync();
+            ctr.cycles[8] += W::clock() - tf;
+          }
         }
       }
+      return false;
+    };
+    if constexpr (BIG) {
+      for (int kc = 1; kc <= order.max_cnt; ++kc) {
+        const int sz = (int)W::uniform((uint64_t)order.size_(kc));
+        if (!sz) continue;
+        const uint32_t h = (uint32_t)W::uniform((uint64_t)order.head_(kc)), m = (uint32_t)W::uniform((uint64_t)order.mask_of(kc));
+        const uint32_t* rg = order.ring + (uint32_t)W::uniform((uint64_t)order.off_(kc));
+        if (walk(sz, [&](int i) { return rg[(h + (uint32_t)i) & m]; })) return true;
+      }
+      return false;
+    } else {
+      return walk(nc, [&](int i) { return order.claim_at(i); });
     }
-    return false;
   }
   // ---- new claim: addToNewNodeClaim (scheduler.go:695-790) --------------------------------------------------
   KS_DEV int add_to_new_claim(int k, int pod) {
@@ -1690,6 +1707,7 @@ struct Engine {
     ctr.sorts++;
     unsigned long long t0 = W::clock();
     order.sort();                                      // scheduler.go:598
+    if constexpr (BIG) { if (order.overflow) { W::store(S.status_out, 1); return -1; } }   // a claim with more pods than the ring tables provide for: capacity
     unsigned long long t1 = W::clock();
     ctr.cycles[2] += t1 - t0;
     bool ok = scan_inflight(k, pod);                   // scheduler.go:601
@@ -1849,7 +1867,7 @@ struct Engine {
         uint32_t* go = S.o_ord;
         const KS_LDS uint32_t* lo_ = L.oord;
         W::for_n(n_claims, [&](int i) { go[i] = lo_[i]; });
-      }
+      } else order.write_final();
     }
     W::store(S.n_claims_out, n_claims);
     if (status) W::store(S.status_out, status);

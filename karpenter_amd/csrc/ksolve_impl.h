@@ -543,11 +543,11 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     h->lds_big = lp;
     h->big_capable = false;
     if ((int)mc > cap) {
-      const long long fit = ((long long)(budget - off - 64) * 8 / 2) & ~63ll;
+      const long long fit = ((long long)(budget - off - 64 - (int)sizeof(ks::RunTables)) * 8 / 2) & ~63ll;
       if ((long long)mc > fit) { mc = (uint32_t)fit; h->max_claims = mc; h->claim_words = (mc + 63) / 64; W.max_claims = (int)mc; W.claim_words = (int)h->claim_words; }
       ks::LdsPlan& lb = h->lds_big;
       int ob = off;
-      lb.order_cap = 0; lb.off_order = ob;
+      lb.order_cap = 0; lb.off_order = ob; ob = align(ob + (int)sizeof(ks::RunTables));   // the claim order's ring tables (run_order.h)
       lb.stage_words = (int)((mc + 63) / 64);
       lb.off_closed = ob; ob = align(ob + lb.stage_words * 8);
       lb.off_stage = ob; ob = align(ob + lb.stage_words * 8);
@@ -996,6 +996,28 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   return out->status;
 }
 
+// BIG engine: one ring per pod count for the claim order (run_order.h). A run of claims with k pods each holds at most
+// n_pods / k claims (and never more than max_claims): ring k gets the next power of two.
+static void alloc_run_order(ksolve_handle* h) {
+  if (h->ws.o_ring) return;
+  const size_t kmax = (size_t)h->n_pods + 2;
+  std::vector<uint32_t> off(kmax, 0);
+  std::vector<uint8_t> lg(kmax, 0);
+  uint64_t total = 0;
+  for (size_t k = 1; k < kmax; ++k) {
+    uint64_t need = std::min<uint64_t>(h->max_claims, (uint64_t)h->n_pods / (uint64_t)k + 2) + 2;
+    int l2 = 1;
+    while ((1ull << l2) < need) ++l2;
+    off[k] = (uint32_t)total; lg[k] = (uint8_t)l2;
+    total += 1ull << l2;
+  }
+  h->ws.o_ring = dz<uint32_t>(h, (size_t)total);
+  h->ws.o_cnt = dz<uint32_t>(h, h->max_claims);
+  h->ws.run_tabs = dz<uint32_t>(h, 3 * kmax);
+  h->ws.run_off = up(h, off.data(), off.size());
+  h->ws.run_log = up(h, lg.data(), lg.size());
+  h->ws.run_kmax = (int)kmax;
+}
 static void be_results_drop(ksolve_results* r) { if (r && r->impl) { delete (ResultsImpl*)r->impl; r->impl = nullptr; } }
 static ksolve_status solve(ksolve_handle* h, ksolve_results* out, bool fresh_context = true) {
   memset(out, 0, sizeof(*out));
@@ -1038,6 +1060,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out, bool fresh_con
     if (status == 1) {
       // more in-flight claims than the LDS-resident order holds: this problem runs on the BIG engine from now on
       h->pv.big = 1; h->pv.lite = 0; h->pv.lds = h->lds_big;
+      alloc_run_order(h);
       st = solve_prepare(h, false);
       if (st != KSOLVE_OK) return st;
       be_tic(h, T_PACK);

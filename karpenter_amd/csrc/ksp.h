@@ -223,6 +223,13 @@ struct Workspace {
   int64_t* c_headroom;           // [n_res][max_claims] SoA copy of the records' headroom: lane-per-claim prefilter of the scan
   // order (pdq_emul.h): lives in LDS while it fits (LdsPlan.order_cap), these are the HBM spill arrays
   uint32_t *o_key, *o_ord, *o_pos;
+  // BIG engine (run_order.h): one ring per pod count; o_pos holds the claims' ring slots there, o_key / o_ord the array form
+  uint32_t* o_ring;              // all rings
+  uint32_t* o_cnt;               // [max_claims] pod count of the claim
+  uint32_t* run_tabs;            // [3][run_kmax] head | size | prefix of every count's ring (the first kRunMaxCount entries live in LDS)
+  const uint32_t* run_off;       // [run_kmax] first word of each count's ring
+  const uint8_t* run_log;        // [run_kmax] log2 of its capacity
+  int run_kmax;                  // pods of the problem + 2
   // first-fit pruning
   uint64_t* dead;                // [n_classes][claim_words] bit set = claim known infeasible for the class
   // existing nodes (mutable part): ExistingNode.requirements / remainingResources / Pods (existingnode.go:32-45)

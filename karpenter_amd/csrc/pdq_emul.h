@@ -28,6 +28,9 @@ struct ClaimOrder {
   bool defect_append = false;
   uint64_t slow_sorts = 0;
 
+  // ---- lookups (the BIG engine's RunOrder answers the same two questions from its rings) ----
+  KS_FN uint32_t position(int c) const { return pos[c]; }
+  KS_FN uint32_t claim_at(int i) const { return ord[i]; }
   // ---- element access (uniform) ----
   KS_FN bool less(int i, int j) const { return key[i] < key[j]; }
   KS_FN void swap(int i, int j) {
