@@ -706,8 +706,11 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
   uint64_t g_acc = 0, g_odd = 0, g_touched = 0, g_jumped = 0;   // g_jumped: lanes whose claim a commit moved past another claim
   int gj = 0, gn = 0;   // entries gj .. gn-1 of the group are still to be placed; entry gj is queue entry bi
   // choosePivot's sampled positions (fast_sampled) as three starts; n is fixed inside one run of this function. With
-  // 12 < n < 50 every re-sort is pdqsort's other path: no groups then.
-  const bool use_groups = max_steps < 0 && (n <= 12 || n >= 50);
+  // 12 < n < 50 every re-sort that has something to move is pdqsort's other path (mid_n). A commit that leaves the order
+  // sorted as it stands — the next claim has at least the new count — needs no sort at all, whatever n and the position:
+  // pdqsort finds no descent and does nothing.
+  const bool use_groups = max_steps < 0;
+  const bool mid_n = n > 12 && n < 50;
   const uint32_t e1 = n >= 50 ? (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u, e2 = n >= 50 ? 2u * (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u, e3 = n >= 50 ? 3u * (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u;
 #ifdef KSOLVE_PHASE_TIMERS
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0, ts7 = 0, tlast = W::clock();
@@ -737,7 +740,8 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
       if (pend_new) { ev = FEV_PLACE; break; }
       gj = 0; gn = 0;
       const int a = pend_a;
-      if (!(n <= 12 || (n >= 50 && !fast_sampled(n, a)))) { ev = FEV_SLOWSORT; ev_arg = a; break; }
+      if (!(a + 1 >= n || (uint32_t)okey[a + 1 < n ? a + 1 : a] >= pend_mv) &&   // something to move ...
+          !(n <= 12 || (n >= 50 && !fast_sampled(n, a)))) { ev = FEV_SLOWSORT; ev_arg = a; break; }   // ... and not by the single stable move
       pend_a = -1;
       // one stable move: the claim at a (count pend_mv) goes right past the claims with a smaller count
       int from = a;
@@ -837,8 +841,6 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
       }
       const uint32_t x = gx.bcast(L);
       const int a = (int)gp.bcast(L);
-      // only the move that is one short shift (otherwise: pdqsort's other paths, behind the window test)
-      if (KS_UNLIKELY((int)((uint32_t)a - e1 <= 2u) | (int)((uint32_t)a - e2 <= 2u) | (int)((uint32_t)a - e3 <= 2u))) break;
       const int sj = (int)bslot.bcast(bi);
       if ((g_touched >> L) & 1) {
         // The claim gained pods since the group's test; it is still this entry's first candidate (its place among the others
@@ -879,6 +881,8 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
       });
       const int s_ = lessm == ~0ull ? 64 : ctz64(~lessm);   // sorted beyond a: the smaller counts are a prefix
       if (KS_UNLIKELY(s_ >= 64)) break;                      // a long run: the pending path
+      // only the move that is one short shift, or none (otherwise: pdqsort's other paths, behind the window test)
+      if (KS_UNLIKELY(s_ != 0 && ((int)mid_n | (int)((uint32_t)a - e1 <= 2u) | (int)((uint32_t)a - e2 <= 2u) | (int)((uint32_t)a - e3 <= 2u)))) break;
       // ---- NodeClaim.Add (nodeclaim.go:247-263) on the claim of lane L; the claim lands behind the s_ claims it passes ----
       W::each([&](int l) {
         if (l == L) {
@@ -1003,11 +1007,12 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
       // just tested, their counts and ids are in registers already: move now, without reading the order again.
       const uint32_t mvn = cnt + 1;
       bool moved = false;
-      if (KS_LIKELY(bi + 1 < bn && !(max_steps >= 0 && steps + 1 >= max_steps) && (n <= 12 || (n >= 50 && !fast_sampled(n, a))))) {
+      if (KS_LIKELY(bi + 1 < bn && !(max_steps >= 0 && steps + 1 >= max_steps))) {
         const uint64_t lessm = W::ballot([&](int l) { return l > first_ok && kv.at(l) < mvn; });   // lanes past n hold 0xFFFFFFFF
         const uint64_t t = first_ok == 63 ? 0ull : (lessm >> (first_ok + 1));
         const int s_ = t == ~0ull ? 64 : ctz64(~t);
-        if (KS_LIKELY(first_ok + 1 + s_ < 64 || (int)r0 + 64 >= n)) {
+        // the single stable move — or no move at all (the next claim has at least the new count: sorted as it stands)
+        if (KS_LIKELY((first_ok + 1 + s_ < 64 || (int)r0 + 64 >= n) && (s_ == 0 || n <= 12 || (n >= 50 && !fast_sampled(n, a))))) {
           // lanes first_ok+1 .. first_ok+s_ step one position to the left, the claim lands behind them
           W::each([&](int l) { if (l > first_ok && l <= first_ok + s_) { okey[(int)r0 + l - 1] = (uint16_t)kv.at(l); oord[(int)r0 + l - 1] = (uint16_t)xv.at(l); } });
           if (W::leader()) { okey[a + s_] = (uint16_t)mvn; oord[a + s_] = (uint16_t)x; }
