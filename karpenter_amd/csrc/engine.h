@@ -820,7 +820,7 @@ struct Engine {
   KS_DEV int distinct_values(int key, const uint64_t* its) {
     const Dict& d = P.dict;
     const LdsTables& Lt = L;
-    const int iw = lay.iw;
+    const int iw = lay.iw, nk = d.n_keys;
     int total = 0;
     if (key == d.key_it) {   // every type requires In [own name]
       for (int w = 0; w < iw; ++w) total += popc64(its[w]);
@@ -831,9 +831,13 @@ struct Engine {
       total += popc64(W::ballot([&](int b) {
         if (!((vb >> b) & 1)) return false;
         const uint16_t sl = Lt.kvslot[x * 64 + b];
-        if (sl == 0xFFFF) return false;
+        // kv = the types whose requirement HAS the value. A type lists it when it is an In requirement that has it, or a
+        // complement (NotIn) that does not: Values() of a NotIn requirement are the excluded ones, of Exists none.
         uint64_t any = 0;
-        for (int w = 0; w < iw; ++w) any |= Lt.kv[(size_t)sl * iw + w] & its[w];
+        for (int w = 0; w < iw; ++w) {
+          const uint64_t has = sl == 0xFFFF ? 0ull : Lt.kv[(size_t)sl * iw + w], cm = Lt.keymask[(size_t)(nk + key) * iw + w];
+          any |= ((has & ~cm) | (~has & cm)) & its[w];
+        }
         return any != 0;
       }));
     }

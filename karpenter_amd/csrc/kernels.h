@@ -92,6 +92,7 @@ struct RowArgs {
   int topo_words;
   // table
   uint64_t seed;
+  uint64_t hash_keep;       // bits of the row hash that are used (all ones; narrowed only by the collision-detection test)
   uint32_t table_size;      // power of two
   uint64_t* table_hash;     // 0 = empty
   uint32_t* table_rep;      // smallest row with that hash
@@ -220,23 +221,36 @@ KS_FN bool rows_equal_q(const RowArgs& a, int x, int y, const ReqRef& q, const R
 // q / qs: the row's two requirement sets — read from the tables (row_hash_body), or with their mask words staged in LDS by
 // the wave-cooperative loader of the device kernel (ksolve.hip: ksolve_row_hash_coop), where 64 rows' masks arrive as
 // fully coalesced 512-byte accesses instead of 64 lanes striding through 160-byte records.
-KS_FN uint64_t row_hash_value(int row, const RowArgs& a, const ReqRef& q, const ReqRef& qs) {
+// req_at(r) = the row's request in dimension r, tol = its toleration mask: read from the tables (row_hash_value), or already
+// in registers (the wave-cooperative kernel loads them with everything else of the block in one go).
+template <class ReqAt>
+KS_FN uint64_t row_hash_value_with(int row, const RowArgs& a, const ReqRef& q, const ReqRef& qs, ReqAt req_at, uint64_t tol) {
   uint64_t h = a.seed;
-  for (int r = 0; r < a.n_res; ++r) h = mix64(h, (uint64_t)a.requests[(size_t)r * a.n_rows + row]);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) if (r < a.n_res) h = mix64(h, (uint64_t)req_at(r));   // n_res <= 8 (ksolve.h); unrolled: req_at may index registers
   h = hash_reqset(a.dict, h, q);
   h = hash_reqset(a.dict, h, qs);
-  h = mix64(h, a.tolerates[row]);
+  h = mix64(h, tol);
   if (a.host_ports) { h = mix64(h, a.host_ports[(size_t)row * 2]); h = mix64(h, a.host_ports[(size_t)row * 2 + 1]); }
   if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) { h = mix64(h, a.topo_owned[(size_t)row * a.topo_words + w]); h = mix64(h, a.topo_selected[(size_t)row * a.topo_words + w]); }
   return h ? h : 1;
 }
+// hash_keep is all ones; a test narrows it to force distinct rows onto one hash and watch the verification report them
+KS_FN uint64_t row_hash_kept(const RowArgs& a, uint64_t h) { h &= a.hash_keep; return h ? h : 1ull; }
+KS_FN uint64_t row_hash_value(int row, const RowArgs& a, const ReqRef& q, const ReqRef& qs) {
+  return row_hash_value_with(row, a, q, qs, [&](int r) { return a.requests[(size_t)r * a.n_rows + row]; }, a.tolerates[row]);
+}
 // The row's slot in the class table (*slot_out), and the row this one has to equal (a row that reached the slot earlier) or
 // 0xFFFFFFFF when there is nothing to check. Every access here is device-wide (one address per class for all rows of the
-// class): the device kernel calls it once per DISTINCT hash of a wavefront, not once per row.
+// class): the device kernel calls it once per DISTINCT hash of a wavefront, not once per row. The representative of the
+// first slot is read together with its hash — one round trip when the slot is the row's own, which it nearly always is;
+// a stale value is an earlier representative of the same slot (or none yet), and the atomic below sorts that out.
 KS_FN uint32_t row_table_insert(int row, const RowArgs& a, uint64_t h, uint32_t* slot_out) {
   uint32_t slot = (uint32_t)(h >> 17) & (a.table_size - 1);
+  const uint32_t slot0 = slot;
+  uint64_t cur = ((volatile uint64_t*)a.table_hash)[slot];
+  uint32_t other = ((volatile uint32_t*)a.table_rep)[slot];
   for (;;) {
-    uint64_t cur = ((volatile uint64_t*)a.table_hash)[slot];
     if (cur == h) break;
     if (cur == 0ull) {
       cur = atomic_cas_u64(&a.table_hash[slot], 0ull, h);
@@ -244,22 +258,107 @@ KS_FN uint32_t row_table_insert(int row, const RowArgs& a, uint64_t h, uint32_t*
       if (cur == h) break;
     }
     slot = (slot + 1) & (a.table_size - 1);
+    cur = ((volatile uint64_t*)a.table_hash)[slot];
   }
   *slot_out = slot;
-  uint32_t other = ((volatile uint32_t*)a.table_rep)[slot];
+  if (slot != slot0) other = ((volatile uint32_t*)a.table_rep)[slot];
   if (other > (uint32_t)row) other = atomic_min_u32(&a.table_rep[slot], (uint32_t)row);
   return other == (uint32_t)row ? 0xFFFFFFFFu : other;
 }
-KS_FN uint32_t row_hash_insert(int row, const RowArgs& a, const ReqRef& q, const ReqRef& qs) {
-  uint32_t slot = 0;
-  const uint32_t other = row_table_insert(row, a, row_hash_value(row, a, q, qs), &slot);
-  a.row_slot[row] = slot;
-  return other;
+// bit w of (m0, m1): mask word w belongs to a key the set defines
+KS_FN void word_defined_mask(const Dict& d, uint32_t defined, uint64_t& m0, uint64_t& m1) {
+  m0 = 0; m1 = 0;
+  for (int k = 0; k < d.n_keys; ++k) {
+    if (!bit(defined, k)) continue;
+    for (uint32_t w = d.key_word_off[k]; w < d.key_word_off[k + 1]; ++w) { if (w < 64) m0 |= 1ull << w; else m1 |= 1ull << (w - 64); }
+  }
+}
+// rows_equal(row, rep) for a row whose requirement sets (q, qs), requests (req_at) and toleration mask (tol) are at hand and
+// a representative `rep` that is far away (HBM / L2): every access to rep's row is issued before the first one is used —
+// flags, requests, minValues and the first kRowFarBatch mask words of both sets are ONE round trip, not one per field.
+// Returns 0 when the rows are equal. Words of keys the set does not define are ignored, as in equal_reqset.
+constexpr int kRowFarBatch = 20;   // mask words per set and batch: a 1280-value dictionary in one batch
+constexpr int kRowFarKeys = 16;
+template <class ReqAt>
+KS_FN uint64_t row_diff_far(int row, const RowArgs& a, uint32_t rep, const ReqRef& q, const ReqRef& qs, ReqAt req_at, uint64_t tol) {
+  const Dict& d = a.dict;
+  const int rw = d.req_words, nk = d.n_keys, nr = a.n_res;
+  const uint64_t* b0 = a.reqs.mask + (size_t)rep * rw;
+  const uint64_t* b1 = a.strict.mask + (size_t)rep * rw;
+  // ---- the loads ----
+  uint64_t w0[kRowFarBatch], w1[kRowFarBatch];
+#pragma unroll
+  for (int i = 0; i < kRowFarBatch; ++i) { w0[i] = i < rw ? b0[i] : 0ull; w1[i] = i < rw ? b1[i] : 0ull; }
+  const uint32_t f0 = a.reqs.defined[rep], f1 = a.reqs.complement[rep], f2 = a.reqs.has_gte ? a.reqs.has_gte[rep] : 0u, f3 = a.reqs.has_lte ? a.reqs.has_lte[rep] : 0u;
+  const uint32_t s0 = a.strict.defined[rep], s1 = a.strict.complement[rep], s2 = a.strict.has_gte ? a.strict.has_gte[rep] : 0u, s3 = a.strict.has_lte ? a.strict.has_lte[rep] : 0u;
+  int64_t bq[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) bq[r] = r < nr ? a.requests[(size_t)r * a.n_rows + rep] : 0;
+  const uint64_t btol = a.tolerates[rep];
+  const int32_t* bm0 = a.reqs.minv ? a.reqs.minv + (size_t)rep * nk : nullptr;
+  const int32_t* bm1 = a.strict.minv ? a.strict.minv + (size_t)rep * nk : nullptr;
+  int32_t v0[kRowFarKeys], v1[kRowFarKeys];
+#pragma unroll
+  for (int k = 0; k < kRowFarKeys; ++k) { v0[k] = (bm0 && k < nk) ? bm0[k] : -1; v1[k] = (bm1 && k < nk) ? bm1[k] : -1; }
+  // ---- the comparison ----
+  uint64_t diff = (uint64_t)((f0 ^ q.defined) | (f1 ^ q.complement) | (f2 ^ q.has_gte) | (f3 ^ q.has_lte) |
+                             (s0 ^ qs.defined) | (s1 ^ qs.complement) | (s2 ^ qs.has_gte) | (s3 ^ qs.has_lte));
+  diff |= btol ^ tol;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) if (r < nr) diff |= (uint64_t)(bq[r] ^ req_at(r));
+  uint64_t d00, d01, d10, d11;
+  word_defined_mask(d, q.defined, d00, d01);
+  word_defined_mask(d, qs.defined, d10, d11);
+#pragma unroll
+  for (int i = 0; i < kRowFarBatch; ++i) if (i < rw) {
+    diff |= (q.mask[i] ^ w0[i]) & (0ull - ((d00 >> i) & 1ull));
+    diff |= (qs.mask[i] ^ w1[i]) & (0ull - ((d10 >> i) & 1ull));
+  }
+  for (int w = kRowFarBatch; w < rw; w += kRowFarBatch) {   // dictionaries beyond one batch
+#pragma unroll
+    for (int i = 0; i < kRowFarBatch; ++i) { w0[i] = w + i < rw ? b0[w + i] : 0ull; w1[i] = w + i < rw ? b1[w + i] : 0ull; }
+#pragma unroll
+    for (int i = 0; i < kRowFarBatch; ++i) if (w + i < rw) {
+      const int x = w + i;
+      diff |= (q.mask[x] ^ w0[i]) & (0ull - (((x < 64 ? d00 >> x : d01 >> (x - 64))) & 1ull));
+      diff |= (qs.mask[x] ^ w1[i]) & (0ull - (((x < 64 ? d10 >> x : d11 >> (x - 64))) & 1ull));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kRowFarKeys; ++k) if (k < nk) {
+    const int32_t am = q.minv ? q.minv[k] : -1, as = qs.minv ? qs.minv[k] : -1;
+    diff |= (uint64_t)(uint32_t)(am ^ v0[k]) & (0ull - (uint64_t)((q.defined >> k) & 1u));
+    diff |= (uint64_t)(uint32_t)(as ^ v1[k]) & (0ull - (uint64_t)((qs.defined >> k) & 1u));
+  }
+  for (int k = kRowFarKeys; k < nk; ++k) {
+    const int32_t am = q.minv ? q.minv[k] : -1, as = qs.minv ? qs.minv[k] : -1;
+    diff |= (uint64_t)(uint32_t)(am ^ (bm0 ? bm0[k] : -1)) & (0ull - (uint64_t)((q.defined >> k) & 1u));
+    diff |= (uint64_t)(uint32_t)(as ^ (bm1 ? bm1[k] : -1)) & (0ull - (uint64_t)((qs.defined >> k) & 1u));
+  }
+  if (q.has_gte | q.has_lte | qs.has_gte | qs.has_lte) {   // bounds: rare, key by key
+    const ReqRef b = a.reqs.at(d, rep), bs = a.strict.at(d, rep);
+    for (int k = 0; k < nk; ++k) {
+      if (bit(q.has_gte, k) && q.gte[k] != b.gte[k]) diff |= 1;
+      if (bit(q.has_lte, k) && q.lte[k] != b.lte[k]) diff |= 1;
+      if (bit(qs.has_gte, k) && qs.gte[k] != bs.gte[k]) diff |= 1;
+      if (bit(qs.has_lte, k) && qs.lte[k] != bs.lte[k]) diff |= 1;
+    }
+  }
+  if (a.host_ports) diff |= (a.host_ports[(size_t)row * 2] ^ a.host_ports[(size_t)rep * 2]) | (a.host_ports[(size_t)row * 2 + 1] ^ a.host_ports[(size_t)rep * 2 + 1]);
+  if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) {
+    diff |= a.topo_owned[(size_t)row * a.topo_words + w] ^ a.topo_owned[(size_t)rep * a.topo_words + w];
+    diff |= a.topo_selected[(size_t)row * a.topo_words + w] ^ a.topo_selected[(size_t)rep * a.topo_words + w];
+  }
+  return diff;
 }
 KS_FN void row_hash_body(int row, const RowArgs& a) {
   const ReqRef q = a.reqs.at(a.dict, row), qs = a.strict.at(a.dict, row);
-  const uint32_t other = row_hash_insert(row, a, q, qs);
-  if (other != 0xFFFFFFFFu && !rows_equal_q(a, row, (int)other, q, qs)) *a.collision = 1;
+  auto req_at = [&](int r) { return a.requests[(size_t)r * a.n_rows + row]; };
+  const uint64_t tol = a.tolerates[row];
+  uint32_t slot = 0;
+  const uint32_t other = row_table_insert(row, a, row_hash_kept(a, row_hash_value_with(row, a, q, qs, req_at, tol)), &slot);
+  a.row_slot[row] = slot;
+  if (other != 0xFFFFFFFFu && row_diff_far(row, a, other, q, qs, req_at, tol) != 0) *a.collision = 1;
 }
 KS_FN void row_class_body(int row, const RowArgs& a) {
   uint32_t slot = a.row_slot[row];

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop(int n, ks::RowArgs a,
   qs.mask = t1 + (size_t)l * stride;
   if (q.minv) q.minv = m0 + (size_t)l * kstride;
   if (qs.minv) qs.minv = m1 + (size_t)l * kstride;
-  const uint64_t h = live ? ks::row_hash_value(row, a, q, qs) : 0ull;
+  const uint64_t h = live ? ks::row_hash_kept(a, ks::row_hash_value(row, a, q, qs)) : 0ull;
   // The class table is one address per class for a million rows: every device-wide access to it is made ONCE per distinct
   // hash of the wavefront (neighbouring pods mostly share their class), by the first lane that carries it. The other lanes
   // take its slot and have to equal ITS row — both rows are in LDS. It has to equal the row that reached the slot before it
@@ -192,6 +192,178 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop(int n, ks::RowArgs a,
     }
   }
   if (bad) *a.collision = 1;
+}
+// ---- the classing kernel (pod equivalence classes: the HBM-streaming kernel of the path) ----
+// One wavefront per 64 consecutive rows, and ONE round trip to HBM for everything the block reads: the 64 x req_words mask
+// words of both requirement tables and the 64 x n_keys minValues of both are contiguous, so lane l takes 16-byte pieces
+// l, l+64, ... (1 KiB per access, fully coalesced) — every access of the block is issued before the first value is used,
+// 20 + 8 + 14 loads per lane in flight for a 1280-value dictionary — and drops them at [row][word] in LDS (odd row stride:
+// the per-row reads that follow spread over the banks). Every lane then hashes its own row out of LDS and registers.
+// The class table is one address per class for a million rows: it is touched once per DISTINCT hash of the wavefront
+// (neighbouring pods mostly share their class), by the first lane that carries the hash, all those lanes at once: slot and
+// representative in one round trip, the representative's row in another (row_diff_far). The other lanes take their leader's
+// slot and have to equal ITS row (equality is transitive) — both rows are in LDS.
+constexpr int kCoopMaskCh = 10;   // 16-byte mask accesses per lane, table and round: 64 rows x 20 words
+constexpr int kCoopMinvCh = 4;    // 16-byte minValues accesses per lane, table and round: 64 rows x 16 keys
+__device__ __forceinline__ uint4 coop_load_u64x2(const uint64_t* g, int e, int total) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (e + 2 <= total) v = *(const uint4*)(g + e);
+  else if (e < total) { const uint64_t x = g[e]; v.x = (uint32_t)x; v.y = (uint32_t)(x >> 32); }
+  return v;
+}
+__device__ __forceinline__ uint4 coop_load_i32x4(const int32_t* g, int e, int total) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (e + 4 <= total) v = *(const uint4*)(g + e);
+  else {
+    if (e < total) v.x = (uint32_t)g[e];
+    if (e + 1 < total) v.y = (uint32_t)g[e + 1];
+    if (e + 2 < total) v.z = (uint32_t)g[e + 2];
+  }
+  return v;
+}
+template <bool WHOLE = false>   // WHOLE: a piece is inside the table or past its end, never across it
+__device__ __forceinline__ void coop_drop_u64x2(uint64_t* t, uint4 v, int e, int total, int rw, int stride, uint32_t magic) {
+  if (WHOLE) {
+    if (e < total) {
+      const int r = (int)__umulhi((uint32_t)e, magic), r1 = (int)__umulhi((uint32_t)(e + 1), magic);
+      t[r * stride + (e - r * rw)] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+      t[r1 * stride + (e + 1 - r1 * rw)] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
+    return;
+  }
+  if (e < total) { const int r = (int)__umulhi((uint32_t)e, magic); t[r * stride + (e - r * rw)] = (uint64_t)v.x | ((uint64_t)v.y << 32); }
+  if (e + 1 < total) { const int r = (int)__umulhi((uint32_t)(e + 1), magic); t[r * stride + (e + 1 - r * rw)] = (uint64_t)v.z | ((uint64_t)v.w << 32); }
+}
+template <bool WHOLE = false>
+__device__ __forceinline__ void coop_drop_i32x4(int32_t* t, uint4 v, int e, int total, int nk, int kstride, uint32_t kmagic) {
+  const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+  if (WHOLE && e >= total) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (WHOLE || e + i < total) { const int r = (int)__umulhi((uint32_t)(e + i), kmagic); t[r * kstride + (e + i - r * nk)] = (int32_t)x[i]; }
+}
+namespace ks {
+struct CoopStage {
+  const uint64_t *g0, *g1; const int32_t *k0, *k1;
+  uint64_t *t0, *t1; int32_t *m0, *m1;
+  int total, ktotal, rw, stride, nk, kstride; uint32_t magic, kmagic; int l;
+};
+}
+// FULL: 64 rows, so both totals are multiples of the access width and an access is either whole or past the end; an access
+// past the end reads piece 0 instead (no branch around a load: a branch makes the compiler wait for every load before it).
+template <bool FULL>
+__device__ __forceinline__ void coop_stage(const ks::CoopStage& s, const ks::RowArgs& a, int rowc, ks::ReqRef& q, ks::ReqRef& qs, int64_t (&rq)[8], uint64_t& tol) {
+  uint4 A[kCoopMaskCh], B[kCoopMaskCh], KA[kCoopMinvCh], KB[kCoopMinvCh];
+  const int l = s.l, nr = a.n_res;
+#pragma unroll
+  for (int i = 0; i < kCoopMaskCh; ++i) {
+    const int e = 2 * (l + 64 * i);
+    if (FULL) { const int x = e < s.total ? e : 0; A[i] = *(const uint4*)(s.g0 + x); B[i] = *(const uint4*)(s.g1 + x); }
+    else { A[i] = coop_load_u64x2(s.g0, e, s.total); B[i] = coop_load_u64x2(s.g1, e, s.total); }
+  }
+#pragma unroll
+  for (int i = 0; i < kCoopMinvCh; ++i) {
+    const int e = 4 * (l + 64 * i);
+    if (FULL) { const int x = e < s.ktotal ? e : 0; KA[i] = *(const uint4*)(s.k0 + x); KB[i] = *(const uint4*)(s.k1 + x); }
+    else { KA[i] = coop_load_i32x4(s.k0, e, s.ktotal); KB[i] = coop_load_i32x4(s.k1, e, s.ktotal); }
+  }
+  q.defined = a.reqs.defined[rowc]; q.complement = a.reqs.complement[rowc]; q.has_gte = a.reqs.has_gte[rowc]; q.has_lte = a.reqs.has_lte[rowc];
+  qs.defined = a.strict.defined[rowc]; qs.complement = a.strict.complement[rowc]; qs.has_gte = a.strict.has_gte[rowc]; qs.has_lte = a.strict.has_lte[rowc];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) rq[r] = a.requests[(size_t)(r < nr ? r : 0) * a.n_rows + rowc];
+  tol = a.tolerates[rowc];
+#pragma unroll
+  for (int i = 0; i < kCoopMaskCh; ++i) { const int e = 2 * (l + 64 * i); coop_drop_u64x2<FULL>(s.t0, A[i], e, s.total, s.rw, s.stride, s.magic); coop_drop_u64x2<FULL>(s.t1, B[i], e, s.total, s.rw, s.stride, s.magic); }
+#pragma unroll
+  for (int i = 0; i < kCoopMinvCh; ++i) { const int e = 4 * (l + 64 * i); coop_drop_i32x4<FULL>(s.m0, KA[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); coop_drop_i32x4<FULL>(s.m1, KB[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); }
+  for (int base = 2 * 64 * kCoopMaskCh; base < s.total; base += 2 * 64 * kCoopMaskCh) {   // dictionaries beyond one round
+#pragma unroll
+    for (int i = 0; i < kCoopMaskCh; ++i) { const int e = base + 2 * (l + 64 * i); A[i] = coop_load_u64x2(s.g0, e, s.total); B[i] = coop_load_u64x2(s.g1, e, s.total); }
+#pragma unroll
+    for (int i = 0; i < kCoopMaskCh; ++i) { const int e = base + 2 * (l + 64 * i); coop_drop_u64x2(s.t0, A[i], e, s.total, s.rw, s.stride, s.magic); coop_drop_u64x2(s.t1, B[i], e, s.total, s.rw, s.stride, s.magic); }
+  }
+  for (int base = 4 * 64 * kCoopMinvCh; base < s.ktotal; base += 4 * 64 * kCoopMinvCh) {
+#pragma unroll
+    for (int i = 0; i < kCoopMinvCh; ++i) { const int e = base + 4 * (l + 64 * i); KA[i] = coop_load_i32x4(s.k0, e, s.ktotal); KB[i] = coop_load_i32x4(s.k1, e, s.ktotal); }
+#pragma unroll
+    for (int i = 0; i < kCoopMinvCh; ++i) { const int e = base + 4 * (l + 64 * i); coop_drop_i32x4(s.m0, KA[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); coop_drop_i32x4(s.m1, KB[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); }
+  }
+}
+__global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a, int rw, uint32_t magic, uint32_t kmagic) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t coop_lds[];
+  const int l = (int)threadIdx.x;
+  const int row0 = (int)blockIdx.x * 64;
+  const int rows = n - row0 < 64 ? n - row0 : 64;
+  const int stride = rw | 1;
+  const int total = rows * rw;
+  const int nk = a.dict.n_keys, kstride = nk | 1, ktotal = rows * nk;
+  const int nr = a.n_res;
+  uint64_t* t0 = coop_lds;
+  uint64_t* t1 = coop_lds + 64 * stride;
+  int32_t* m0 = (int32_t*)(coop_lds + 2 * 64 * stride);
+  int32_t* m1 = m0 + 64 * kstride;
+  const uint64_t* g0 = a.reqs.mask + (size_t)row0 * rw;
+  const uint64_t* g1 = a.strict.mask + (size_t)row0 * rw;
+  const int32_t* k0 = a.reqs.minv + (size_t)row0 * nk;   // the launcher takes this kernel only when every optional table of the rows exists
+  const int32_t* k1 = a.strict.minv + (size_t)row0 * nk;
+  const int row = row0 + l;
+  const bool live = row < n;
+  const int rowc = live ? row : n - 1;
+  // ---- every HBM access of the block, then [row][word] in LDS ----
+  ks::ReqRef q, qs;
+  int64_t rq[8];
+  uint64_t tol;
+  const ks::CoopStage st{g0, g1, k0, k1, t0, t1, m0, m1, total, ktotal, rw, stride, nk, kstride, magic, kmagic, l};
+  if (rows == 64) coop_stage<true>(st, a, rowc, q, qs, rq, tol);     // branch-free: no wait is placed before the last load is out
+  else coop_stage<false>(st, a, rowc, q, qs, rq, tol);               // the last block of the table
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // ---- the row's hash, out of LDS and registers ----
+  q.mask = t0 + (size_t)l * stride; qs.mask = t1 + (size_t)l * stride;
+  q.minv = m0 + (size_t)l * kstride; qs.minv = m1 + (size_t)l * kstride;
+  q.gte = a.reqs.gte ? a.reqs.gte + (size_t)rowc * nk : nullptr; q.lte = a.reqs.lte ? a.reqs.lte + (size_t)rowc * nk : nullptr;
+  qs.gte = a.strict.gte ? a.strict.gte + (size_t)rowc * nk : nullptr; qs.lte = a.strict.lte ? a.strict.lte + (size_t)rowc * nk : nullptr;
+  auto req_at = [&](int r) -> int64_t { return rq[r]; };   // every caller unrolls over r: register indices
+  const uint64_t h = live ? ks::row_hash_kept(a, ks::row_hash_value_with(row, a, q, qs, req_at, tol)) : 0ull;
+  // ---- the first lane of every distinct hash ----
+  int lead = l;
+  uint64_t todo = __ballot(live ? 1 : 0);
+  while (todo) {
+    const int j = __builtin_ctzll(todo);
+    const uint32_t hlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, j), hhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h >> 32), j);
+    const bool mine = live && h == ((uint64_t)hlo | ((uint64_t)hhi << 32));
+    todo &= ~__ballot(mine ? 1 : 0);
+    if (mine) lead = j;
+  }
+  const bool leader = live && lead == l;
+  uint32_t slot = 0, rep = 0xFFFFFFFFu;
+  if (leader) rep = ks::row_table_insert(row, a, h, &slot);
+  slot = (uint32_t)__shfl((int)slot, lead, 64);
+  if (live) a.row_slot[row] = slot;
+  uint64_t d = 0;
+  if (leader && rep != 0xFFFFFFFFu) d = ks::row_diff_far(row, a, rep, q, qs, req_at, tol);
+  // ---- a follower equals its leader: flags and requests by shuffle, mask words and minValues LDS to LDS ----
+  ks::ReqRef qj, qsj;
+  qj.defined = (uint32_t)__shfl((int)q.defined, lead, 64); qj.complement = (uint32_t)__shfl((int)q.complement, lead, 64);
+  qj.has_gte = (uint32_t)__shfl((int)q.has_gte, lead, 64); qj.has_lte = (uint32_t)__shfl((int)q.has_lte, lead, 64);
+  qsj.defined = (uint32_t)__shfl((int)qs.defined, lead, 64); qsj.complement = (uint32_t)__shfl((int)qs.complement, lead, 64);
+  qsj.has_gte = (uint32_t)__shfl((int)qs.has_gte, lead, 64); qsj.has_lte = (uint32_t)__shfl((int)qs.has_lte, lead, 64);
+  uint64_t dq = (uint64_t)__shfl((unsigned long long)tol, lead, 64) ^ tol;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) if (r < nr) dq |= (uint64_t)__shfl((unsigned long long)rq[r], lead, 64) ^ (uint64_t)rq[r];
+  if (live && !leader) {
+    const size_t rowj = (size_t)(row0 + lead);
+    qj.mask = t0 + (size_t)lead * stride; qsj.mask = t1 + (size_t)lead * stride;
+    qj.minv = m0 + (size_t)lead * kstride; qsj.minv = m1 + (size_t)lead * kstride;
+    qj.gte = a.reqs.gte ? a.reqs.gte + rowj * nk : nullptr; qj.lte = a.reqs.lte ? a.reqs.lte + rowj * nk : nullptr;
+    qsj.gte = a.strict.gte ? a.strict.gte + rowj * nk : nullptr; qsj.lte = a.strict.lte ? a.strict.lte + rowj * nk : nullptr;
+    d = dq | ks::reqset_diff(a.dict, q, qj) | ks::reqset_diff(a.dict, qs, qsj);
+    if (a.host_ports) d |= (a.host_ports[(size_t)row * 2] ^ a.host_ports[rowj * 2]) | (a.host_ports[(size_t)row * 2 + 1] ^ a.host_ports[rowj * 2 + 1]);
+    if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) {
+      d |= a.topo_owned[(size_t)row * a.topo_words + w] ^ a.topo_owned[rowj * a.topo_words + w];
+      d |= a.topo_selected[(size_t)row * a.topo_words + w] ^ a.topo_selected[rowj * a.topo_words + w];
+    }
+  }
+  if (d) *a.collision = 1;
 }
 __global__ void ksolve_row_class(int n, ks::RowArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -287,12 +459,21 @@ static void be_launch_it_index(ksolve_handle* h, int n, const ks::ItIndexArgs& a
 static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) {
   const int rw = a.dict.req_words;
   const int nk = a.dict.n_keys;
-  const size_t lds = (size_t)2 * 64 * (size_t)(rw | 1) * 8 + (size_t)2 * 64 * (size_t)(nk | 1) * 4 + 8 + (size_t)64 * (size_t)(a.n_res + 1) * 8;
-  if (rw >= 1 && nk >= 1 && lds <= 64 * 1024) {
-    // floor(e / rw) = umulhi(e, magic) for every e < 64 * rw (e * rw < 2^32)
-    const uint32_t magic = (uint32_t)((0x100000000ull + (uint64_t)rw - 1) / (uint64_t)rw);
-    const uint32_t kmagic = (uint32_t)((0x100000000ull + (uint64_t)nk - 1) / (uint64_t)nk);
-    hipLaunchKernelGGL(ksolve_row_hash_coop, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, HB(h)->stream, n, a, rw, magic, kmagic);
+  // A/B switch for measurements (scripts/gpu_r3_classing.sh): "coop1" = the previous wave-cooperative kernel, "plain" = one thread per row
+  const char* variant = getenv("KSOLVE_ROWHASH_KERNEL");
+  const bool aligned = (((uintptr_t)a.reqs.mask | (uintptr_t)a.strict.mask | (uintptr_t)a.reqs.minv | (uintptr_t)a.strict.minv) & 15) == 0;
+  // floor(e / rw) = umulhi(e, magic) for every e < 64 * rw (e * rw < 2^32)
+  const uint32_t magic = rw >= 1 ? (uint32_t)((0x100000000ull + (uint64_t)rw - 1) / (uint64_t)rw) : 0;
+  const uint32_t kmagic = nk >= 1 ? (uint32_t)((0x100000000ull + (uint64_t)nk - 1) / (uint64_t)nk) : 0;
+  const size_t lds2 = (size_t)2 * 64 * (size_t)(rw | 1) * 8 + (size_t)2 * 64 * (size_t)(nk | 1) * 4;
+  const size_t lds1 = lds2 + 8 + (size_t)64 * (size_t)(a.n_res + 1) * 8;
+  const bool plain = variant && !strcmp(variant, "plain");
+  const bool coop1 = variant && !strcmp(variant, "coop1");
+  const bool tables = a.reqs.minv && a.strict.minv && a.reqs.has_gte && a.reqs.has_lte && a.strict.has_gte && a.strict.has_lte;
+  if (!plain && !coop1 && rw >= 1 && nk >= 1 && a.n_res >= 1 && a.n_res <= 8 && aligned && tables && lds2 <= 64 * 1024) {
+    hipLaunchKernelGGL(ksolve_row_hash_coop2, dim3((unsigned)((n + 63) / 64)), dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic);
+  } else if (!plain && rw >= 1 && nk >= 1 && lds1 <= 64 * 1024) {
+    hipLaunchKernelGGL(ksolve_row_hash_coop, dim3((unsigned)((n + 63) / 64)), dim3(64), lds1, HB(h)->stream, n, a, rw, magic, kmagic);
   } else {
     hipLaunchKernelGGL(ksolve_row_hash, grid_for(n), dim3(256), 0, HB(h)->stream, n, a);
   }

@@ -173,14 +173,6 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   }
   if (d->topo.n > KSOLVE_MAX_TOPO_GROUPS) return fail(h, KSOLVE_ERR_UNSUPPORTED, "more than 1024 topology groups");
   if (d->topo.n && (!d->pod_topo_owned || !d->pod_topo_selected)) return fail(h, KSOLVE_ERR_INVALID, "topology groups without pod_topo_owned / pod_topo_selected");
-  if (d->tmpl_reqs.min_values) {
-    // distinct-value counting uses the instance types' value lists: a NotIn/Exists instance-type requirement on a
-    // minValues key has no such list (its Values() are the excluded ones)
-    for (uint32_t t = 0; t < d->n_templates; ++t) for (uint32_t k = 0; k < d->n_keys; ++k) {
-      if (d->tmpl_reqs.min_values[(size_t)t * d->n_keys + k] < 0 || (int32_t)k == d->key_instance_type) continue;
-      for (uint32_t i = 0; i < d->n_its; ++i) if ((d->it_reqs.complement[i] >> k) & 1) return fail(h, KSOLVE_ERR_UNSUPPORTED, "minValues on a key that an instance type constrains with NotIn/Exists");
-    }
-  }
   for (uint32_t i = 0; i < d->n_its; ++i) {
     // reserved offerings would need the ReservationManager; capacity type index >= n_captypes never occurs by construction
     (void)i;
@@ -365,6 +357,8 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   uint32_t ts = 64;
   while (ts < 2 * d->n_pod_rows) ts <<= 1;
   R.table_size = ts; R.seed = 0x6b73703176310a01ull;
+  R.hash_keep = ~0ull;
+  if (const char* keep = getenv("KSOLVE_TEST_HASH_KEEP")) R.hash_keep = strtoull(keep, nullptr, 0);   // collision-detection test: distinct rows forced onto one hash must be reported, never merged
   R.table_hash = dz<uint64_t>(h, ts); R.table_rep = dz<uint32_t>(h, ts); R.table_class = dz<uint32_t>(h, ts);
   R.row_slot = dz<uint32_t>(h, d->n_pod_rows);
   uint32_t* row_class = dz<uint32_t>(h, d->n_pod_rows);

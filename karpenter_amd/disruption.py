@@ -388,8 +388,8 @@ def _min_types_for_min_values(names, reqs, by_name):
     seen = {k: set() for k in wanted}
     for i, n in enumerate(names):
         for r in by_name[n]["requirements"]:
-            if r["key"] in wanted and r["operator"] == "In":
-                seen[r["key"]].update(v for v in r["values"] if _req_has(reqs[r["key"]], v))
+            if r["key"] in wanted:       # Requirement.Values(): the stored list whatever the operator (NotIn: the excluded values), unfiltered
+                seen[r["key"]].update(r.get("values") or [])
         if all(len(seen[k]) >= wanted[k] for k in wanted):
             return i + 1, True
     return len(names), False

@@ -827,3 +827,57 @@ def test_repeated_solves_on_one_handle_are_identical(oracle, emu):
     th = threading.Thread(target=s.Solve)
     th.start(); s.Cancel(); th.join()
     parity.assert_same_results(s.Solve(), first)
+
+
+def test_row_hash_collisions_are_reported_never_merged(oracle, emu, monkeypatch):
+    """Pod classing (csrc/kernels.h: row_hash_body → row_table_insert + row_diff_far). With the row hash narrowed to a few
+    bits, distinct rows share a hash; the verification against the slot's representative has to report every one of them
+    (the host re-seeds, and gives up after four attempts) — a merged class would be a wrong packing with no error."""
+    prob = fx.config2(pods=600, n_types=50, seed=11)
+    monkeypatch.setenv("KSOLVE_TEST_HASH_KEEP", "0x7")
+    with pytest.raises(RuntimeError, match="row hash collisions persist"):
+        NewScheduler(prob, solver_lib=emu).Solve()
+    # all bits but one: a single class table slot chain per half, still exact
+    monkeypatch.setenv("KSOLVE_TEST_HASH_KEEP", "0xFFFFFFFFFFFFFFFF")
+    check(oracle, emu, prob)
+    # identical rows only (one class): a narrowed hash cannot collide, and must not report
+    monkeypatch.setenv("KSOLVE_TEST_HASH_KEEP", "0x1")
+    same = fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], [fx.pod(requests={"cpu": "1"}, node_selector=AMD) for _ in range(200)])
+    check(oracle, emu, same)
+
+
+def _complement_family_types():
+    """Eight instance types whose requirement on a custom `family` key uses every operator: In, NotIn (Values() = the
+    excluded ones), Exists (Values() = none), DoesNotExist, and no requirement at all."""
+    fam = "example.com/family"
+    shapes = [("a", fx.req(fam, "In", "m5")), ("b", fx.req(fam, "In", "c5", "c6")), ("c", fx.req(fam, "NotIn", "r5")), ("d", fx.req(fam, "NotIn", "m5", "x1")),
+              ("e", fx.req(fam, "Exists")), ("f", None), ("g", fx.req(fam, "In", "m5")), ("h", fx.req(fam, "NotIn", "z9"))]
+    its = []
+    for i, (n, r) in enumerate(shapes):
+        its.append(fx.fake_instance_type(f"fam-{n}", {"cpu": str(2 + 2 * (i % 4)), "memory": f"{4 + 4 * (i % 4)}Gi", "pods": "20"}, requirements=[r] if r else None))
+    return fam, its
+
+
+def test_min_values_on_a_key_instance_types_constrain_with_notin_exists(oracle, emu):
+    """InstanceTypes.SatisfiesMinValues (types.go:399-433) unions `it.Requirements.Get(key).Values()`: for a NotIn requirement
+    these are the EXCLUDED values, for Exists / DoesNotExist / an absent requirement none. The device counts a value when an In
+    type has it or a complement type does not (engine.h distinct_values)."""
+    fam, its = _complement_family_types()
+    pods = [fx.pod(requests={"cpu": f"{c}m", "memory": f"{m}Mi"}) for c in (300, 1500, 2500, 5000) for m in (256, 3000, 9000) for _ in range(3)]
+    seen_err, seen_ok = False, False
+    for mv in (1, 2, 3, 4, 5, 6, 7, 9):
+        for policy in ("Strict", "BestEffort"):
+            for op, vals in (("Exists", ()), ("NotIn", ("q1",)), ("In", ("m5", "c5", "c6", "r5", "x1", "z9"))):
+                pool = fx.node_pool(requirements=[fx.req(fam, op, *vals, min_values=mv)])
+                got, _ = check(oracle, emu, fx.problem(its, [pool], pods, options={"minValuesPolicy": policy}))
+                seen_err |= bool(got["podErrors"])
+                seen_ok |= bool(got["newNodeClaims"])
+    assert seen_err and seen_ok
+    # pods that narrow the key themselves
+    sel = [fx.pod(requests={"cpu": "500m"}, node_selector={fam: v}) for v in ("m5", "c5", "r5", "m5", "q1")] + pods[:6]
+    for mv in (1, 2, 4):
+        pool = fx.node_pool(requirements=[fx.req(fam, "Exists", min_values=mv)])
+        check(oracle, emu, fx.problem(its, [pool], sel))
+    # launch shaping: Truncate's re-check (scheduler.go:419-437) on the same catalogue
+    pool = fx.node_pool(requirements=[fx.req(fam, "Exists", min_values=3)])
+    check(oracle, emu, fx.problem(its, [pool], pods, options={"truncateInstanceTypes": 3}))

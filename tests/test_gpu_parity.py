@@ -429,3 +429,20 @@ def test_resident_cluster_probes_on_the_device(oracle, seed, limits):
     by the oracle (tests/test_disruption.py::test_resident_cluster_probes_match_per_probe_rebuild with libksolve.so)."""
     import test_disruption as td
     td.test_resident_cluster_probes_match_per_probe_rebuild(oracle, None, seed, limits)
+
+
+def test_row_hash_collisions_are_reported_on_the_device(oracle, monkeypatch):
+    """The classing kernel (ksolve_row_hash_coop2) with the row hash narrowed to three bits: distinct rows share a hash, inside
+    one wavefront (follower against its leader, LDS to LDS) and across wavefronts (leader against the slot's representative,
+    row_diff_far); every such pair has to be reported — the host re-seeds and gives up — never merged into one class."""
+    prob = fx.config2(pods=6000, n_types=144, seed=3)
+    monkeypatch.setenv("KSOLVE_TEST_HASH_KEEP", "0x7")
+    with pytest.raises(RuntimeError, match="row hash collisions persist"):
+        NewScheduler(prob).Solve()
+    monkeypatch.setenv("KSOLVE_TEST_HASH_KEEP", "0x1")
+    same = fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], [fx.pod(requests={"cpu": "1"}, node_selector=AMD) for _ in range(300)])
+    check(oracle, same)
+    monkeypatch.delenv("KSOLVE_TEST_HASH_KEEP")
+    for kernel in ("coop1", "plain"):    # the previous kernels (A/B switch of the launcher) class the rows alike
+        monkeypatch.setenv("KSOLVE_ROWHASH_KERNEL", kernel)
+        check(oracle, prob)
