@@ -310,7 +310,8 @@ def main():
                              "profiles/round2), not HBM bound: its working set lives in LDS, `traffic` (TCC counters of a separate rocprofv3 --pmc run) is what it really moves"},
         # the one kernel of the path that streams the pod rows from HBM (rows x B_pod): HIP events around it alone;
         # `phase_ms` is the whole classing phase (table memsets, this kernel, a host round trip for the class count, row_class, class_gather)
-        "roofline_stream": {"kernel": "ksolve_row_hash_coop (pod classing: stage 64 rows' words through LDS, hash, class-table slot, verify)", "bound": "hbm", "bytes": stream_bytes,
+        "roofline_stream": {"kernel": "ksolve_row_hash_coop2 (pod classing: one round trip for a 64-row block, words staged through LDS, hash, class-table slot, verify)", "bound": "hbm", "bytes": stream_bytes,
+                            "bytes_read_by_the_kernel": c["rows"] * (2 * (8 * c["reqWords"] + 16) + 8 * c["resources"] + 8 + 4),   # both mask tables + flag words, requests, toleration mask, slot written; all-nil minValues tables are not streamed
                             "avg_ms": rh_ms, "achieved": stream_bytes / (rh_ms * 1e-3) / 1e9 if rh_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": stream_bytes / (rh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rh_ms > 0 else None, "phase_ms": cls_ms},
         "phases_ms": {k: sum(t.get(k, 0.0) for t in timings) / len(timings) for k in ("pack_kernel_ms", "classify_ms", "row_hash_ms", "sort_ms", "it_index_ms")},

@@ -250,7 +250,7 @@ struct CoopStage {
 }
 // FULL: 64 rows, so both totals are multiples of the access width and an access is either whole or past the end; an access
 // past the end reads piece 0 instead (no branch around a load: a branch makes the compiler wait for every load before it).
-template <bool FULL>
+template <bool FULL, bool MINV>
 __device__ __forceinline__ void coop_stage(const ks::CoopStage& s, const ks::RowArgs& a, int rowc, ks::ReqRef& q, ks::ReqRef& qs, int64_t (&rq)[8], uint64_t& tol) {
   uint4 A[kCoopMaskCh], B[kCoopMaskCh], KA[kCoopMinvCh], KB[kCoopMinvCh];
   const int l = s.l, nr = a.n_res;
@@ -260,11 +260,13 @@ __device__ __forceinline__ void coop_stage(const ks::CoopStage& s, const ks::Row
     if (FULL) { const int x = e < s.total ? e : 0; A[i] = *(const uint4*)(s.g0 + x); B[i] = *(const uint4*)(s.g1 + x); }
     else { A[i] = coop_load_u64x2(s.g0, e, s.total); B[i] = coop_load_u64x2(s.g1, e, s.total); }
   }
+  if (MINV) {
 #pragma unroll
-  for (int i = 0; i < kCoopMinvCh; ++i) {
-    const int e = 4 * (l + 64 * i);
-    if (FULL) { const int x = e < s.ktotal ? e : 0; KA[i] = *(const uint4*)(s.k0 + x); KB[i] = *(const uint4*)(s.k1 + x); }
-    else { KA[i] = coop_load_i32x4(s.k0, e, s.ktotal); KB[i] = coop_load_i32x4(s.k1, e, s.ktotal); }
+    for (int i = 0; i < kCoopMinvCh; ++i) {
+      const int e = 4 * (l + 64 * i);
+      if (FULL) { const int x = e < s.ktotal ? e : 0; KA[i] = *(const uint4*)(s.k0 + x); KB[i] = *(const uint4*)(s.k1 + x); }
+      else { KA[i] = coop_load_i32x4(s.k0, e, s.ktotal); KB[i] = coop_load_i32x4(s.k1, e, s.ktotal); }
+    }
   }
   q.defined = a.reqs.defined[rowc]; q.complement = a.reqs.complement[rowc]; q.has_gte = a.reqs.has_gte[rowc]; q.has_lte = a.reqs.has_lte[rowc];
   qs.defined = a.strict.defined[rowc]; qs.complement = a.strict.complement[rowc]; qs.has_gte = a.strict.has_gte[rowc]; qs.has_lte = a.strict.has_lte[rowc];
@@ -273,21 +275,26 @@ __device__ __forceinline__ void coop_stage(const ks::CoopStage& s, const ks::Row
   tol = a.tolerates[rowc];
 #pragma unroll
   for (int i = 0; i < kCoopMaskCh; ++i) { const int e = 2 * (l + 64 * i); coop_drop_u64x2<FULL>(s.t0, A[i], e, s.total, s.rw, s.stride, s.magic); coop_drop_u64x2<FULL>(s.t1, B[i], e, s.total, s.rw, s.stride, s.magic); }
+  if (MINV) {
 #pragma unroll
-  for (int i = 0; i < kCoopMinvCh; ++i) { const int e = 4 * (l + 64 * i); coop_drop_i32x4<FULL>(s.m0, KA[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); coop_drop_i32x4<FULL>(s.m1, KB[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); }
+    for (int i = 0; i < kCoopMinvCh; ++i) { const int e = 4 * (l + 64 * i); coop_drop_i32x4<FULL>(s.m0, KA[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); coop_drop_i32x4<FULL>(s.m1, KB[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); }
+  }
   for (int base = 2 * 64 * kCoopMaskCh; base < s.total; base += 2 * 64 * kCoopMaskCh) {   // dictionaries beyond one round
 #pragma unroll
     for (int i = 0; i < kCoopMaskCh; ++i) { const int e = base + 2 * (l + 64 * i); A[i] = coop_load_u64x2(s.g0, e, s.total); B[i] = coop_load_u64x2(s.g1, e, s.total); }
 #pragma unroll
     for (int i = 0; i < kCoopMaskCh; ++i) { const int e = base + 2 * (l + 64 * i); coop_drop_u64x2(s.t0, A[i], e, s.total, s.rw, s.stride, s.magic); coop_drop_u64x2(s.t1, B[i], e, s.total, s.rw, s.stride, s.magic); }
   }
-  for (int base = 4 * 64 * kCoopMinvCh; base < s.ktotal; base += 4 * 64 * kCoopMinvCh) {
+  if (MINV) for (int base = 4 * 64 * kCoopMinvCh; base < s.ktotal; base += 4 * 64 * kCoopMinvCh) {
 #pragma unroll
     for (int i = 0; i < kCoopMinvCh; ++i) { const int e = base + 4 * (l + 64 * i); KA[i] = coop_load_i32x4(s.k0, e, s.ktotal); KB[i] = coop_load_i32x4(s.k1, e, s.ktotal); }
 #pragma unroll
     for (int i = 0; i < kCoopMinvCh; ++i) { const int e = base + 4 * (l + 64 * i); coop_drop_i32x4(s.m0, KA[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); coop_drop_i32x4(s.m1, KB[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); }
   }
 }
+// MINV: the rows carry minValues (pod rows never do when they come from the reference's PodData — minValues belong to NodePool
+// requirements — so the tables are absent and neither streamed nor staged)
+template <bool MINV>
 __global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a, int rw, uint32_t magic, uint32_t kmagic) {
   extern __shared__ __attribute__((aligned(16))) uint64_t coop_lds[];
   const int l = (int)threadIdx.x;
@@ -303,8 +310,8 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a
   int32_t* m1 = m0 + 64 * kstride;
   const uint64_t* g0 = a.reqs.mask + (size_t)row0 * rw;
   const uint64_t* g1 = a.strict.mask + (size_t)row0 * rw;
-  const int32_t* k0 = a.reqs.minv + (size_t)row0 * nk;   // the launcher takes this kernel only when every optional table of the rows exists
-  const int32_t* k1 = a.strict.minv + (size_t)row0 * nk;
+  const int32_t* k0 = MINV ? a.reqs.minv + (size_t)row0 * nk : nullptr;   // the launcher: both minValues tables or neither, every other optional table exists
+  const int32_t* k1 = MINV ? a.strict.minv + (size_t)row0 * nk : nullptr;
   const int row = row0 + l;
   const bool live = row < n;
   const int rowc = live ? row : n - 1;
@@ -313,13 +320,13 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a
   int64_t rq[8];
   uint64_t tol;
   const ks::CoopStage st{g0, g1, k0, k1, t0, t1, m0, m1, total, ktotal, rw, stride, nk, kstride, magic, kmagic, l};
-  if (rows == 64) coop_stage<true>(st, a, rowc, q, qs, rq, tol);     // branch-free: no wait is placed before the last load is out
-  else coop_stage<false>(st, a, rowc, q, qs, rq, tol);               // the last block of the table
+  if (rows == 64) coop_stage<true, MINV>(st, a, rowc, q, qs, rq, tol);     // branch-free: no wait is placed before the last load is out
+  else coop_stage<false, MINV>(st, a, rowc, q, qs, rq, tol);               // the last block of the table
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
   // ---- the row's hash, out of LDS and registers ----
   q.mask = t0 + (size_t)l * stride; qs.mask = t1 + (size_t)l * stride;
-  q.minv = m0 + (size_t)l * kstride; qs.minv = m1 + (size_t)l * kstride;
+  q.minv = MINV ? m0 + (size_t)l * kstride : nullptr; qs.minv = MINV ? m1 + (size_t)l * kstride : nullptr;
   q.gte = a.reqs.gte ? a.reqs.gte + (size_t)rowc * nk : nullptr; q.lte = a.reqs.lte ? a.reqs.lte + (size_t)rowc * nk : nullptr;
   qs.gte = a.strict.gte ? a.strict.gte + (size_t)rowc * nk : nullptr; qs.lte = a.strict.lte ? a.strict.lte + (size_t)rowc * nk : nullptr;
   auto req_at = [&](int r) -> int64_t { return rq[r]; };   // every caller unrolls over r: register indices
@@ -353,7 +360,7 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a
   if (live && !leader) {
     const size_t rowj = (size_t)(row0 + lead);
     qj.mask = t0 + (size_t)lead * stride; qsj.mask = t1 + (size_t)lead * stride;
-    qj.minv = m0 + (size_t)lead * kstride; qsj.minv = m1 + (size_t)lead * kstride;
+    qj.minv = MINV ? m0 + (size_t)lead * kstride : nullptr; qsj.minv = MINV ? m1 + (size_t)lead * kstride : nullptr;
     qj.gte = a.reqs.gte ? a.reqs.gte + rowj * nk : nullptr; qj.lte = a.reqs.lte ? a.reqs.lte + rowj * nk : nullptr;
     qsj.gte = a.strict.gte ? a.strict.gte + rowj * nk : nullptr; qsj.lte = a.strict.lte ? a.strict.lte + rowj * nk : nullptr;
     d = dq | ks::reqset_diff(a.dict, q, qj) | ks::reqset_diff(a.dict, qs, qsj);
@@ -465,13 +472,16 @@ static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) {
   // floor(e / rw) = umulhi(e, magic) for every e < 64 * rw (e * rw < 2^32)
   const uint32_t magic = rw >= 1 ? (uint32_t)((0x100000000ull + (uint64_t)rw - 1) / (uint64_t)rw) : 0;
   const uint32_t kmagic = nk >= 1 ? (uint32_t)((0x100000000ull + (uint64_t)nk - 1) / (uint64_t)nk) : 0;
-  const size_t lds2 = (size_t)2 * 64 * (size_t)(rw | 1) * 8 + (size_t)2 * 64 * (size_t)(nk | 1) * 4;
-  const size_t lds1 = lds2 + 8 + (size_t)64 * (size_t)(a.n_res + 1) * 8;
+  const bool minv = a.reqs.minv && a.strict.minv, no_minv = !a.reqs.minv && !a.strict.minv;
+  size_t lds2 = (size_t)2 * 64 * (size_t)(rw | 1) * 8 + (minv ? (size_t)2 * 64 * (size_t)(nk | 1) * 4 : 0);
+  if (const char* pad = getenv("KSOLVE_TEST_LDS_PAD")) lds2 += (size_t)atoi(pad);   // occupancy probe of tests/tools/gpu_classing_ab.py: fewer wavefronts per CU
+  const size_t lds1 = (size_t)2 * 64 * (size_t)(rw | 1) * 8 + (size_t)2 * 64 * (size_t)(nk | 1) * 4 + 8 + (size_t)64 * (size_t)(a.n_res + 1) * 8;
   const bool plain = variant && !strcmp(variant, "plain");
   const bool coop1 = variant && !strcmp(variant, "coop1");
-  const bool tables = a.reqs.minv && a.strict.minv && a.reqs.has_gte && a.reqs.has_lte && a.strict.has_gte && a.strict.has_lte;
+  const bool tables = (minv || no_minv) && a.reqs.has_gte && a.reqs.has_lte && a.strict.has_gte && a.strict.has_lte;
   if (!plain && !coop1 && rw >= 1 && nk >= 1 && a.n_res >= 1 && a.n_res <= 8 && aligned && tables && lds2 <= 64 * 1024) {
-    hipLaunchKernelGGL(ksolve_row_hash_coop2, dim3((unsigned)((n + 63) / 64)), dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic);
+    if (minv) hipLaunchKernelGGL(ksolve_row_hash_coop2<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic);
+    else hipLaunchKernelGGL(ksolve_row_hash_coop2<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic);
   } else if (!plain && rw >= 1 && nk >= 1 && lds1 <= 64 * 1024) {
     hipLaunchKernelGGL(ksolve_row_hash_coop, dim3((unsigned)((n + 63) / 64)), dim3(64), lds1, HB(h)->stream, n, a, rw, magic, kmagic);
   } else {

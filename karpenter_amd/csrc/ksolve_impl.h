@@ -116,7 +116,7 @@ static T* up(ksolve_handle* h, const T* src, size_t n) {
 template <class T>
 static T* dz(ksolve_handle* h, size_t n) { return (T*)be_alloc(h, (n ? n : 1) * sizeof(T)); }
 
-static ReqTable upload_reqs(ksolve_handle* h, const ksolve_reqsets& r, uint32_t n, uint32_t req_words, uint32_t n_keys) {
+static ReqTable upload_reqs(ksolve_handle* h, const ksolve_reqsets& r, uint32_t n, uint32_t req_words, uint32_t n_keys, bool with_minv = true) {
   ReqTable t{};
   t.mask = up(h, r.mask, (size_t)n * req_words);
   t.defined = up(h, r.defined, n);
@@ -125,7 +125,8 @@ static ReqTable upload_reqs(ksolve_handle* h, const ksolve_reqsets& r, uint32_t 
   t.has_lte = r.has_lte ? up(h, r.has_lte, n) : dz<uint32_t>(h, n);
   t.gte = r.gte ? up(h, r.gte, (size_t)n * n_keys) : dz<int64_t>(h, (size_t)n * n_keys);
   t.lte = r.lte ? up(h, r.lte, (size_t)n * n_keys) : dz<int64_t>(h, (size_t)n * n_keys);
-  if (r.min_values) t.minv = up(h, r.min_values, (size_t)n * n_keys);
+  if (!with_minv) t.minv = nullptr;
+  else if (r.min_values) t.minv = up(h, r.min_values, (size_t)n * n_keys);
   else { int32_t* m = dz<int32_t>(h, (size_t)n * n_keys); be_fill(h, m, 0xFF, (size_t)n * n_keys * sizeof(int32_t)); t.minv = m; }
   return t;
 }
@@ -340,9 +341,19 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   ks::RowArgs& R = h->row_args;
   R.dict = dict; R.n_rows = d->n_pod_rows; R.n_res = d->n_res;
   R.requests = up(h, d->pod_requests, (size_t)d->n_res * d->n_pod_rows);
-  R.reqs = upload_reqs(h, d->pod_reqs, d->n_pod_rows, req_words, d->n_keys);
-  if (d->pod_strict_reqs.mask == d->pod_reqs.mask || d->pod_strict_reqs.mask == nullptr) R.strict = R.reqs;
-  else R.strict = upload_reqs(h, d->pod_strict_reqs, d->n_pod_rows, req_words, d->n_keys);
+  // Pod rows carry no minValues when they come from the reference's PodData (minValues belong to NodePool requirements): a
+  // table of nils is neither uploaded nor streamed by the classing kernel (absent == nil everywhere it is read).
+  auto all_nil = [&](const ksolve_reqsets& r) {
+    if (!r.min_values) return true;
+    const size_t n = (size_t)d->n_pod_rows * d->n_keys;
+    for (size_t i = 0; i < n; ++i) if (r.min_values[i] >= 0) return false;
+    return true;
+  };
+  const bool strict_same = d->pod_strict_reqs.mask == d->pod_reqs.mask || d->pod_strict_reqs.mask == nullptr;
+  const bool rows_nil = all_nil(d->pod_reqs) && (strict_same || all_nil(d->pod_strict_reqs));
+  R.reqs = upload_reqs(h, d->pod_reqs, d->n_pod_rows, req_words, d->n_keys, !rows_nil);
+  if (strict_same) R.strict = R.reqs;
+  else R.strict = upload_reqs(h, d->pod_strict_reqs, d->n_pod_rows, req_words, d->n_keys, !rows_nil);
   R.tolerates = up(h, d->pod_tolerates, d->n_pod_rows);
   R.host_ports = nullptr; R.cls_host_ports = nullptr;
   if (P.hp_on) {

@@ -96,6 +96,9 @@ struct Pod {
   std::vector<WeightedPodAffinityTerm> affinity_preferred, anti_preferred;
   bool owned_by_daemonset = false, owned_by_node = false;
   int input_index = 0;
+  // volumeReqsByPod[pod.UID] (scheduler.go:138, :572): the alternatives VolumeTopology.GetRequirements derived from the pod's
+  // volumes, one requirement set per valid combination of volume topologies; empty = no volume constraint
+  std::vector<std::vector<NodeSelectorExpr>> volume_requirements;
 };
 
 struct Offering {
@@ -303,6 +306,11 @@ inline Pod parse_pod(const oj::Value& v, int idx) {
   p.node_selector = parse_strmap(v.at("nodeSelector"));
   p.owned_by_daemonset = v.at("ownedByDaemonSet").boolean_or(false);
   p.owned_by_node = v.at("ownedByNode").boolean_or(false);
+  for (auto& alt : v.at("volumeRequirements").items()) {
+    std::vector<NodeSelectorExpr> exprs;
+    for (auto& e : alt.items()) exprs.push_back(parse_expr(e));
+    p.volume_requirements.push_back(exprs);
+  }
   const oj::Value& na = v.at("nodeAffinity");
   if (!na.is_null()) {
     p.has_node_affinity = true;

@@ -156,6 +156,7 @@ struct Counters {
 struct PodData {  // scheduler.go:217-229
   ResourceList requests;
   Requirements reqs, strict_reqs;
+  std::vector<Requirements> volume_reqs;   // VolumeRequirements (scheduler.go:222, :572): alternatives, tried in order
 };
 
 // compatible / fits — nodeclaim.go:620-638
@@ -283,6 +284,7 @@ struct Scheduler {
     if (p.has_node_affinity && !p.preferred_terms.empty()) d.strict_reqs = pod_requirements(p, true);
     d.requests = p.requests;                       // RequestsForPods — resources.go:30-38
     d.requests["pods"] = (i128)1 * 1000000000;
+    for (auto& alt : p.volume_requirements) d.volume_reqs.push_back(exprs_to_requirements(alt));   // scheduler.go:572
     cached[p.uid] = d;
   }
 
@@ -471,14 +473,25 @@ struct Scheduler {
     if (host_ports_conflict(pod.host_ports, n.host_ports)) { last_err = ERR_EXISTING; return false; }   // existingnode.go:87-93
     if (!res_fits(pd.requests, n.remaining)) { last_err = ERR_RESOURCES; return false; }
     if (!n.reqs.compatible(pd.reqs, false)) { last_err = ERR_INCOMPATIBLE; return false; }
-    Requirements base = n.reqs;
-    base.add_all(pd.reqs);
-    Requirements topo;
-    if (!topology.add_requirements(pod, n.node->taints, pd.strict_reqs, base, topo)) { last_err = ERR_TOPOLOGY; return false; }
-    if (!base.compatible(topo, false)) { last_err = ERR_TOPOLOGY; return false; }
-    base.add_all(topo);
-    out = base;
-    return true;
+    Requirements base0 = n.reqs;
+    base0.add_all(pd.reqs);
+    // volume requirement alternatives — existingnode.go:108-139; tryVolumeAlternative :143-168. They narrow the node's
+    // requirements only: topology counts with the pod's own (strict) requirements.
+    const size_t n_alt = pd.volume_reqs.empty() ? 1 : pd.volume_reqs.size();
+    for (size_t a = 0; a < n_alt; ++a) {
+      Requirements base = base0;
+      if (!pd.volume_reqs.empty()) {
+        if (!base.compatible(pd.volume_reqs[a], false)) { last_err = ERR_INCOMPATIBLE; continue; }
+        base.add_all(pd.volume_reqs[a]);
+      }
+      Requirements topo;
+      if (!topology.add_requirements(pod, n.node->taints, pd.strict_reqs, base, topo)) { last_err = ERR_TOPOLOGY; continue; }
+      if (!base.compatible(topo, false)) { last_err = ERR_TOPOLOGY; continue; }
+      base.add_all(topo);
+      out = base;
+      return true;
+    }
+    return false;
   }
   void existing_add(ExistingNode& n, Pod* pod, const PodData& pd, const Requirements& reqs) {
     n.pods.push_back(pod);
@@ -518,28 +531,42 @@ struct Scheduler {
     }
     return true;
   }
-  // CanAdd — nodeclaim.go:124-242 (single volume alternative: nil)
+  // CanAdd — nodeclaim.go:124-242
   bool claim_can_add(NodeClaim& n, const Pod& pod, const PodData& pd, bool relax_min_values, Requirements& out_reqs,
                      std::vector<const InstanceType*>& out_its, std::vector<const Offering*>& out_ofs) {
     ctr.bin_evaluations++;
     last_diag = 0;
     if (!taints_tolerated(n.tmpl->taints, pod.tolerations)) { last_err = ERR_TAINTS; return false; }
-    Requirements base = n.reqs;
-    if (!base.compatible(pd.reqs, true)) { last_err = ERR_INCOMPATIBLE; return false; }
-    base.add_all(pd.reqs);
-    Requirements topo;
-    if (!topology.add_requirements(pod, n.tmpl->taints, pd.strict_reqs, base, topo)) { last_err = ERR_TOPOLOGY; return false; }
-    if (!base.compatible(topo, true)) { last_err = ERR_TOPOLOGY; return false; }
-    base.add_all(topo);
-    ResourceList requests = res_merge(n.requests, pd.requests);
-    std::map<std::string, int> unsat;
-    FilterDiag d;
-    bool ok = filter_instance_types(n.its, base, n.tmpl->daemon_groups, requests, relax_min_values, out_its, unsat, d, &ctr, &pod.host_ports, &n.host_ports);
-    if (relax_min_values) for (auto& kv : unsat) base.m[kv.first].min_values = kv.second;
-    if (!ok) { last_err = d.min_values_incompatible ? ERR_MIN_VALUES : ERR_INSTANCE_TYPES; last_diag = d.bits(); return false; }
-    if (!offerings_to_reserve(n, out_its, base, out_ofs)) { last_err = ERR_RESERVED; return false; }
-    out_reqs = base;
-    return true;
+    Requirements base0 = n.reqs;
+    if (!base0.compatible(pd.reqs, true)) { last_err = ERR_INCOMPATIBLE; return false; }
+    base0.add_all(pd.reqs);
+    // volume requirement alternatives — nodeclaim.go:138-157; tryVolumeAlternative :164-242: the first alternative that passes
+    // topology, the instance-type filter and the reservation check wins; the error reported is the last alternative's
+    const size_t n_alt = pd.volume_reqs.empty() ? 1 : pd.volume_reqs.size();
+    for (size_t a = 0; a < n_alt; ++a) {
+      Requirements base = base0;
+      last_diag = 0;
+      if (!pd.volume_reqs.empty()) {
+        if (!base.compatible(pd.volume_reqs[a], true)) { last_err = ERR_INCOMPATIBLE; continue; }
+        base.add_all(pd.volume_reqs[a]);
+      }
+      Requirements topo;
+      if (!topology.add_requirements(pod, n.tmpl->taints, pd.strict_reqs, base, topo)) { last_err = ERR_TOPOLOGY; continue; }
+      if (!base.compatible(topo, true)) { last_err = ERR_TOPOLOGY; continue; }
+      base.add_all(topo);
+      ResourceList requests = res_merge(n.requests, pd.requests);
+      std::map<std::string, int> unsat;
+      FilterDiag d;
+      std::vector<const InstanceType*> its;
+      bool ok = filter_instance_types(n.its, base, n.tmpl->daemon_groups, requests, relax_min_values, its, unsat, d, &ctr, &pod.host_ports, &n.host_ports);
+      if (relax_min_values) for (auto& kv : unsat) base.m[kv.first].min_values = kv.second;
+      if (!ok) { last_err = d.min_values_incompatible ? ERR_MIN_VALUES : ERR_INSTANCE_TYPES; last_diag = d.bits(); continue; }
+      std::vector<const Offering*> ofs;
+      if (!offerings_to_reserve(n, its, base, ofs)) { last_err = ERR_RESERVED; continue; }
+      out_reqs = base; out_its = its; out_ofs = ofs;
+      return true;
+    }
+    return false;
   }
   // Add — nodeclaim.go:247-263
   void claim_add(NodeClaim& n, Pod* pod, const PodData& pd, const Requirements& reqs, const std::vector<const InstanceType*>& its, const std::vector<const Offering*>& ofs) {
