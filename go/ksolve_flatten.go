@@ -227,6 +227,24 @@ func (t *reqTable) c(a *cArena) C.ksolve_reqsets {
 	return out
 }
 
+// requirementsIdentity prints a requirement set so that equal sets print alike and different sets differently (every key,
+// operator, value and minValues; Requirements.String() hides restricted labels and shortens long value lists).
+func requirementsIdentity(r scheduling.Requirements) string {
+	reqs := r.NodeSelectorRequirements()
+	sort.Slice(reqs, func(i, j int) bool { return reqs[i].Key < reqs[j].Key })
+	var b strings.Builder
+	for _, q := range reqs {
+		vals := append([]string(nil), q.Values...)
+		sort.Strings(vals)
+		fmt.Fprintf(&b, "%s\x01%s\x01%s\x01", q.Key, q.Operator, strings.Join(vals, "\x02"))
+		if q.MinValues != nil {
+			fmt.Fprintf(&b, "%d", *q.MinValues)
+		}
+		b.WriteByte(3)
+	}
+	return b.String()
+}
+
 // quantities: every resource dimension is scaled by the greatest common divisor (in nano units) of all its quantities in
 // the problem, so that the device's int64 arithmetic is exact (resource.Quantity is an exact decimal, SURVEY Appendix B3).
 type quantities struct {
@@ -325,8 +343,8 @@ func (f *flatProblem) free() { f.arena.free() }
 // flatten encodes scheduler s (already assembled by NewScheduler) and the pods of this Solve().
 // nolint:gocyclo
 func flatten(ctx context.Context, s *Scheduler, pods []*corev1.Pod, maxSteps int64) (*flatProblem, error) {
-	if s.allocator != nil || len(s.volumeReqsByPod) > 0 {
-		return nil, fmt.Errorf("%w: dynamic resource allocation / volume topology alternatives", ErrKSolveUnsupported)
+	if s.allocator != nil {
+		return nil, fmt.Errorf("%w: dynamic resource allocation", ErrKSolveUnsupported)
 	}
 	f := &flatProblem{dict: &dictionary{keyIndex: map[string]int{}}, qty: &quantities{index: map[corev1.ResourceName]int{}}, pods: pods,
 		templates: s.nodeClaimTemplates, nodes: s.existingNodes}
@@ -391,8 +409,11 @@ func flatten(ctx context.Context, s *Scheduler, pods []*corev1.Pod, maxSteps int
 		}
 	}
 	for _, r := range rows {
-		if r.data.HasResourceClaimRequests || len(r.data.VolumeRequirements) > 0 {
-			return nil, fmt.Errorf("%w: pod %s/%s has resource claims / volume topology alternatives", ErrKSolveUnsupported, r.pod.Namespace, r.pod.Name)
+		if r.data.HasResourceClaimRequests {
+			return nil, fmt.Errorf("%w: pod %s/%s has resource claims", ErrKSolveUnsupported, r.pod.Namespace, r.pod.Name)
+		}
+		for _, alt := range r.data.VolumeRequirements { // volumeReqsByPod[uid] (scheduler.go:572): the alternatives, in order
+			d.observe(alt)
 		}
 		d.observe(r.data.Requirements)
 		d.observe(r.data.StrictRequirements)
@@ -758,6 +779,44 @@ func flatten(ctx context.Context, s *Scheduler, pods []*corev1.Pod, maxSteps int
 		if anyDaemons {
 			desc.daemon_group_host_ports = cU64(a, groupHP)
 		}
+	}
+	// ---- volume requirement alternatives (PodData.VolumeRequirements; nodeclaim.go:138-157, existingnode.go:108-139): one
+	// requirement set per alternative, list after list; pods with equal lists share (first, count) — it is part of a pod's
+	// class identity on the device. A relaxed row carries its pod's list (updateCachedPodData copies it by UID).
+	anyVolumes := false
+	for _, row := range rows {
+		anyVolumes = anyVolumes || len(row.data.VolumeRequirements) > 0
+	}
+	if anyVolumes {
+		volReqs := &reqTable{d: d}
+		lists := map[string][2]uint32{}
+		first, count := make([]uint32, R), make([]uint32, R)
+		for r, row := range rows {
+			alts := row.data.VolumeRequirements
+			if len(alts) == 0 {
+				continue
+			}
+			var key strings.Builder
+			for _, alt := range alts {
+				key.WriteString(requirementsIdentity(alt))
+				key.WriteByte(0)
+			}
+			fc, ok := lists[key.String()]
+			if !ok {
+				fc = [2]uint32{uint32(len(volReqs.defined)), uint32(len(alts))}
+				for _, alt := range alts {
+					volReqs.add(alt)
+				}
+				lists[key.String()] = fc
+			}
+			first[r], count[r] = fc[0], fc[1]
+		}
+		if volReqs.anyMinValues {
+			return nil, fmt.Errorf("%w: volume requirements with minValues", ErrKSolveUnsupported)
+		}
+		desc.n_volume_reqs = C.uint32_t(len(volReqs.defined))
+		desc.volume_reqs = volReqs.c(a)
+		desc.pod_volume_first, desc.pod_volume_count = cU32(a, first), cU32(a, count)
 	}
 	desc.tmpl_taints = cU64(a, tmplTaints)
 	desc.n_taints = C.uint32_t(len(taints))

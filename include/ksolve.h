@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KSOLVE_ABI_VERSION 5
+#define KSOLVE_ABI_VERSION 6
 #define KSOLVE_MAX_KEYS 32        /* requirement keys per problem (one bit each in the u32 flag words) */
 #define KSOLVE_MAX_RES 8          /* resource dimensions */
 #define KSOLVE_MAX_TEMPLATES 32   /* NodeClaimTemplates (NodePools that survived prefiltering) */
@@ -199,6 +199,17 @@ typedef struct {
   const uint64_t* pod_host_port_conflicts; /* n_pod_rows : every triple of the problem that matches one of the pod's */
   const uint64_t* node_host_ports;         /* n_nodes : triples in use on the node (StateNode.HostPortUsage); may be NULL */
   const uint64_t* daemon_group_host_ports; /* n_groups : triples of the group's daemon pods (scheduler.go:990-993); may be NULL */
+
+  /* ---- volume requirement alternatives (PodData.VolumeRequirements = volumeReqsByPod[pod.UID], scheduler.go:138, :222,
+   *      :572): NodeClaim.CanAdd (nodeclaim.go:138-157, tryVolumeAlternative :164-242) and ExistingNode.CanAdd
+   *      (existingnode.go:108-139, :143-168) intersect the bin's requirements — not the pod's — with the first alternative
+   *      that passes every later check, trying them in order; the error kept is the last alternative's. Pods with equal lists
+   *      carry equal (first, count) (it is part of the pod's class identity); every variant row of a pod carries the pod's.
+   *      pod_volume_first == NULL: no pod of the problem has volume requirements and nothing below is read. ---- */
+  uint32_t n_volume_reqs;                  /* requirement sets in volume_reqs */
+  ksolve_reqsets volume_reqs;              /* the alternatives of every distinct list, list after list; no minValues */
+  const uint32_t* pod_volume_first;        /* n_pod_rows : first alternative of the pod's list */
+  const uint32_t* pod_volume_count;        /* n_pod_rows : alternatives of the pod (0 = none: one pass with no extra requirement) */
 
   /* ---- existing nodes, already in sortExistingNodes order (scheduler.go:845-858) ---- */
   uint32_t n_nodes;

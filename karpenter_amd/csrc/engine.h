@@ -46,6 +46,7 @@ constexpr int kMaxCold = 2 * kMaxKeys + (kMaxKeys + 1) / 2;
 struct Scratch {
   ReqBuf merged;                    // slow-path working set (bounds / minValues / very wide dictionaries)
   ReqBuf topo;                      // nodeRequirements ∧ topology domains (Topology.AddRequirements, topology.go:226-250)
+  ReqBuf vbase;                     // bin ∧ pod before a volume requirement alternative is added (nodeclaim.go:130-136, existingnode.go:105-106)
   uint64_t tq[kMaxReqWords];        // next-domain set of one topology group (only the group key's words are used)
   int64_t gtot[kMaxRes];            // requests + the daemon overhead of the group being filtered
   uint64_t gin[kMaxItWords];        // the bin's instance types that belong to that group
@@ -148,6 +149,7 @@ struct Engine {
   bool cur_rec = false;             // ... or is counted by some group when it is committed
   int cur_class = 0;
   uint64_t cur_hp_use = 0, cur_hp_conf = 0;   // host-port triples the pod being placed binds / that match one of them
+  uint32_t cur_vol_first = 0, cur_vol_n = 0;  // volume requirement alternatives of the pod being placed (PodData.VolumeRequirements)
   uint64_t bin_hp = 0;                        // host-port triples already bound by the pods of the candidate bin
   bool topo_reached = false;        // the last can_add got as far as the topology stage (its verdict is not cacheable)
 
@@ -895,6 +897,26 @@ struct Engine {
     W::store(&S.c_reserved[c], now);
     W::sync();
   }
+  // dst <- src (wave-cooperative)
+  KS_DEV void reqbuf_copy(ReqBuf& dst, const ReqBuf& src) {
+    W::for_n(lay.rw, [&](int w) { dst.mask[w] = src.mask[w]; });
+    W::for_n(lay.nk, [&](int k) { dst.gte[k] = src.gte[k]; dst.lte[k] = src.lte[k]; dst.minv[k] = src.minv[k]; });
+    if (W::leader()) { dst.defined = src.defined; dst.complement = src.complement; dst.has_gte = src.has_gte; dst.has_lte = src.has_lte; dst.has_minv = src.has_minv; }
+    W::sync();
+  }
+  // dst <- the requirement set r (reqbuf_load, wave-cooperative)
+  KS_DEV void reqbuf_copy_in(ReqBuf& dst, const ReqRef& r) {
+    W::for_n(lay.rw, [&](int w) { dst.mask[w] = r.mask[w]; });
+    uint32_t hm = 0;
+    if (r.minv) for (int k = 0; k < lay.nk; ++k) if (r.minv[k] >= 0) hm |= 1u << k;
+    W::for_n(lay.nk, [&](int k) {
+      dst.gte[k] = (r.gte && bit(r.has_gte, k)) ? r.gte[k] : 0;
+      dst.lte[k] = (r.lte && bit(r.has_lte, k)) ? r.lte[k] : 0;
+      dst.minv[k] = r.minv ? r.minv[k] : -1;
+    });
+    if (W::leader()) { dst.defined = r.defined; dst.complement = r.complement; dst.has_gte = r.has_gte; dst.has_lte = r.has_lte; dst.has_minv = hm; }
+    W::sync();
+  }
   // the merged requirement set `m` becomes the record being built (sc.out / sc.out_cold)
   KS_DEV ReqRef reqbuf_to_out(const ReqBuf& m) {
     uint64_t* o = sc.out;
@@ -957,6 +979,36 @@ struct Engine {
       changed = reqbuf_add(d, sc.merged, q);
       merged = reqbuf_to_out(sc.merged);
     }
+    if (FULL && cur_vol_n) {
+      // volume requirement alternatives — nodeclaim.go:138-157: each starts from bin ∧ pod, the first one that passes the rest
+      // of CanAdd wins, the error kept is the last one's
+      reqbuf_copy_in(sc.vbase, merged);
+      int err = E_INCOMPATIBLE;
+      for (uint32_t va = 0; va < cur_vol_n; ++va) {
+        ReqRef vr = P.vol_reqs.at(d, cur_vol_first + va);
+        if (hn >= 0 && bit(vr.defined, hn)) {
+          // against the claim's own hostname In [hostname-placeholder-N]: only an unbounded complement intersects it
+          if (!bit(vr.complement, hn) || bit(vr.has_gte | vr.has_lte, hn)) { err = E_INCOMPATIBLE; continue; }
+          vr.defined &= ~(1u << hn);
+        }
+        if (reqs_compatible(d, sc.vbase.ref(), vr, true) != COMPAT_OK) { err = E_INCOMPATIBLE; continue; }   // nodeclaim.go:170-173
+        reqbuf_copy(sc.merged, sc.vbase);
+        const bool vch = reqbuf_add(d, sc.merged, vr);
+        W::sync();
+        err = can_add_rest(bin, fresh, want_diag, reqs_changed, its_changed, claim_id, reqbuf_to_out(sc.merged), changed || vch, bin_minv);
+        if (err == E_OK) return E_OK;
+      }
+      return err;
+    }
+    return can_add_rest(bin, fresh, want_diag, reqs_changed, its_changed, claim_id, merged, changed, bin_minv);
+  }
+  // tryVolumeAlternative past the volume requirements (nodeclaim.go:195-242): topology, requests, the instance-type filter,
+  // minValues, the reservations. `merged` = the requirement set so far, already in the record being built (sc.out / sc.out_cold).
+  KS_DEV int can_add_rest(const uint64_t* bin, bool fresh, bool want_diag, bool* reqs_changed, bool* its_changed, int claim_id, ReqRef merged, bool changed, bool bin_minv) {
+    const int nr = lay.nr;
+    const int64_t* req = (const int64_t*)(sc.cls + lay.k_req());
+    const int64_t* tot = (const int64_t*)(bin + lay.c_total());
+    unsigned long long tb = W::clock();
     if (FULL && cur_M) {
       // topology: nodeclaim.go:195-208
       topo_reached = true;
@@ -1591,18 +1643,32 @@ struct Engine {
       int l = -1;
       bool changed = false;
       ReqBuf* fin = &sc.merged;
-      if (!cur_M) {
+      if (!cur_M && !cur_vol_n) {
         if (ok) l = ctz64(ok);
         if (l >= 0) changed = node_merge(base + l);
       } else {
-        // topology decides among the nodes that passed everything else (existingnode.go:111-122), lowest index first
+        // volume requirement alternatives and topology decide among the nodes that passed everything else
+        // (existingnode.go:108-139, tryVolumeAlternative :143-168), lowest index first
         for (uint64_t cand = ok; cand; cand &= cand - 1) {
           const int cl_ = ctz64(cand);
           const bool ch = node_merge(base + cl_);
-          bool tch = false;
+          bool tch = false, vch = false, got = false;
           ctr.bin_evaluations++;
-          if (!topo_apply(sc.merged.ref(), 1, base + cl_, false, &tch)) continue;
-          l = cl_; changed = ch || tch;
+          if (cur_vol_n) {
+            reqbuf_copy(sc.vbase, sc.merged);
+            for (uint32_t va = 0; va < cur_vol_n && !got; ++va) {
+              if (va) reqbuf_copy(sc.merged, sc.vbase);
+              const ReqRef vr = P.vol_reqs.at(d, cur_vol_first + va);
+              if (reqs_compatible(d, sc.merged.ref(), vr, false) != COMPAT_OK) continue;           // existingnode.go:149-153
+              vch = reqbuf_add(d, sc.merged, vr);
+              W::sync();
+              tch = false;
+              if (cur_M && !topo_apply(sc.merged.ref(), 1, base + cl_, false, &tch)) continue;
+              got = true;
+            }
+          } else got = topo_apply(sc.merged.ref(), 1, base + cl_, false, &tch);
+          if (!got) continue;
+          l = cl_; changed = ch || vch || tch;
           if (tch) fin = &sc.topo;
           break;
         }
@@ -1662,6 +1728,7 @@ struct Engine {
     if (FULL && (sc.cls[lay.k_f1()] != 0 || (lo32(sc.cls[lay.k_meta()]) & 1u))) load_words(sc.cls_cold, P.cls_cold + (size_t)k * lay.cold_words(), lay.cold_words());
     cur_class = k;
     if (FULL && P.hp_on) { cur_hp_use = P.cls_hp[(size_t)k * 2]; cur_hp_conf = P.cls_hp[(size_t)k * 2 + 1]; }
+    if (FULL && P.vol_on) { const uint64_t v = P.cls_vol[k]; cur_vol_first = lo32(v); cur_vol_n = hi32(v); }
 
     if (FULL && P.topo.n_groups) {
       const TopoView& T = P.topo;

@@ -775,7 +775,11 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
     // ---- the pod's class slot ----
     const int slot = (int)bslot.bcast(bi);
     if (KS_UNLIKELY(slot == 0xFFFF)) { ev = FEV_SLOT; ev_arg = (int)bcls.bcast(bi); break; }
-    const int lastq = base + bn >= np ? 1 : 0;   // the queue's last entry is not placed from a group: no add follows it, its move stays undone (as in the reference)
+    // The queue's last entry is not placed from a group: no add follows it, its move stays undone (as in the reference). The
+    // same holds for the last entry before a block boundary at which the cancel flag is polled: a cancelled Solve() ends there,
+    // and the claim order it reports is the one of the last sort the reference would have run (scheduler.go:598 sorts at the
+    // start of an add, never after the last one).
+    const int lastq = (base + bn >= np || (cancel && ((base + 64) & 1023) == 0)) ? 1 : 0;
     if (use_groups && gj >= gn && bi + lastq < bn) {
       // ---- a new group: the next entries of the block that have a class slot, eight at most ----
       const int g0 = bn - bi - lastq < 8 ? bn - bi - lastq : 8, bi0 = bi, nn = n;

@@ -87,6 +87,8 @@ struct RowArgs {
   const uint64_t* tolerates;
   const uint64_t* host_ports;     // [n_rows][2] host-port triples bound | matched (nullptr: no pod binds one)
   uint64_t* cls_host_ports;       // [n_classes][2]
+  const uint64_t* vol;            // [n_rows] volume requirement alternatives: first | count << 32 (nullptr: no pod has any)
+  uint64_t* cls_vol;              // [n_classes]
   const uint64_t* topo_owned;     // [n_rows][topo_words] or nullptr
   const uint64_t* topo_selected;
   int topo_words;
@@ -152,6 +154,7 @@ KS_FN bool rows_equal(const RowArgs& a, int x, int y) {
   if (!equal_reqset(a.dict, a.strict.at(a.dict, x), a.strict.at(a.dict, y))) return false;
   if (a.tolerates[x] != a.tolerates[y]) return false;
   if (a.host_ports && (a.host_ports[(size_t)x * 2] != a.host_ports[(size_t)y * 2] || a.host_ports[(size_t)x * 2 + 1] != a.host_ports[(size_t)y * 2 + 1])) return false;
+  if (a.vol && a.vol[x] != a.vol[y]) return false;
   if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) {
     if (a.topo_owned[(size_t)x * a.topo_words + w] != a.topo_owned[(size_t)y * a.topo_words + w]) return false;
     if (a.topo_selected[(size_t)x * a.topo_words + w] != a.topo_selected[(size_t)y * a.topo_words + w]) return false;
@@ -212,6 +215,7 @@ KS_FN bool rows_equal_q(const RowArgs& a, int x, int y, const ReqRef& q, const R
   diff |= reqset_diff(a.dict, qs, a.strict.at(a.dict, y));
   diff |= a.tolerates[x] ^ a.tolerates[y];
   if (a.host_ports) diff |= (a.host_ports[(size_t)x * 2] ^ a.host_ports[(size_t)y * 2]) | (a.host_ports[(size_t)x * 2 + 1] ^ a.host_ports[(size_t)y * 2 + 1]);
+  if (a.vol) diff |= a.vol[x] ^ a.vol[y];
   if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) {
     diff |= a.topo_owned[(size_t)x * a.topo_words + w] ^ a.topo_owned[(size_t)y * a.topo_words + w];
     diff |= a.topo_selected[(size_t)x * a.topo_words + w] ^ a.topo_selected[(size_t)y * a.topo_words + w];
@@ -232,6 +236,7 @@ KS_FN uint64_t row_hash_value_with(int row, const RowArgs& a, const ReqRef& q, c
   h = hash_reqset(a.dict, h, qs);
   h = mix64(h, tol);
   if (a.host_ports) { h = mix64(h, a.host_ports[(size_t)row * 2]); h = mix64(h, a.host_ports[(size_t)row * 2 + 1]); }
+  if (a.vol) h = mix64(h, a.vol[row]);
   if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) { h = mix64(h, a.topo_owned[(size_t)row * a.topo_words + w]); h = mix64(h, a.topo_selected[(size_t)row * a.topo_words + w]); }
   return h ? h : 1;
 }
@@ -345,6 +350,7 @@ KS_FN uint64_t row_diff_far(int row, const RowArgs& a, uint32_t rep, const ReqRe
     }
   }
   if (a.host_ports) diff |= (a.host_ports[(size_t)row * 2] ^ a.host_ports[(size_t)rep * 2]) | (a.host_ports[(size_t)row * 2 + 1] ^ a.host_ports[(size_t)rep * 2 + 1]);
+  if (a.vol) diff |= a.vol[row] ^ a.vol[rep];
   if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) {
     diff |= a.topo_owned[(size_t)row * a.topo_words + w] ^ a.topo_owned[(size_t)rep * a.topo_words + w];
     diff |= a.topo_selected[(size_t)row * a.topo_words + w] ^ a.topo_selected[(size_t)rep * a.topo_words + w];
@@ -390,6 +396,7 @@ KS_FN void class_gather_body(int cls, const RowArgs& a, int lane = 0, int nl = 1
   if (lane == 0) {
     a.cls_tolerates[cls] = a.tolerates[row];
     if (a.host_ports) { a.cls_host_ports[(size_t)cls * 2] = a.host_ports[(size_t)row * 2]; a.cls_host_ports[(size_t)cls * 2 + 1] = a.host_ports[(size_t)row * 2 + 1]; }
+    if (a.vol) a.cls_vol[cls] = a.vol[row];
   }
   // packed records for the pack engine (RecLayout)
   const RecLayout& ly = a.lay;

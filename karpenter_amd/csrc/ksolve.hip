@@ -157,6 +157,7 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop(int n, ks::RowArgs a,
         uint64_t d = ks::reqset_diff(a.dict, q, qj) | ks::reqset_diff(a.dict, qs, qsj);
         for (int r = 0; r <= nr; ++r) d |= rqs[l * rstride + r] ^ rqs[j * rstride + r];
         if (a.host_ports) d |= (a.host_ports[(size_t)row * 2] ^ a.host_ports[rowj * 2]) | (a.host_ports[(size_t)row * 2 + 1] ^ a.host_ports[rowj * 2 + 1]);
+        if (a.vol) d |= a.vol[row] ^ a.vol[rowj];
         if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) {
           d |= a.topo_owned[(size_t)row * a.topo_words + w] ^ a.topo_owned[rowj * a.topo_words + w];
           d |= a.topo_selected[(size_t)row * a.topo_words + w] ^ a.topo_selected[rowj * a.topo_words + w];
@@ -184,6 +185,7 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop(int n, ks::RowArgs a,
         if ((qsj.has_lte >> l) & 1u) d |= (uint64_t)(a.strict.lte[(size_t)rep * nk + l] ^ qsj.lte[l]);
       }
       if (a.host_ports && l < 2) d |= a.host_ports[(size_t)rep * 2 + l] ^ a.host_ports[rowj * 2 + l];
+      if (a.vol && l == 0) d |= a.vol[rep] ^ a.vol[rowj];
       if (a.topo_owned) for (int w = l; w < a.topo_words; w += 64) {
         d |= a.topo_owned[(size_t)rep * a.topo_words + w] ^ a.topo_owned[rowj * a.topo_words + w];
         d |= a.topo_selected[(size_t)rep * a.topo_words + w] ^ a.topo_selected[rowj * a.topo_words + w];
@@ -365,6 +367,7 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a
     qsj.gte = a.strict.gte ? a.strict.gte + rowj * nk : nullptr; qsj.lte = a.strict.lte ? a.strict.lte + rowj * nk : nullptr;
     d = dq | ks::reqset_diff(a.dict, q, qj) | ks::reqset_diff(a.dict, qs, qsj);
     if (a.host_ports) d |= (a.host_ports[(size_t)row * 2] ^ a.host_ports[rowj * 2]) | (a.host_ports[(size_t)row * 2 + 1] ^ a.host_ports[rowj * 2 + 1]);
+        if (a.vol) d |= a.vol[row] ^ a.vol[rowj];
     if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) {
       d |= a.topo_owned[(size_t)row * a.topo_words + w] ^ a.topo_owned[rowj * a.topo_words + w];
       d |= a.topo_selected[(size_t)row * a.topo_words + w] ^ a.topo_selected[rowj * a.topo_words + w];

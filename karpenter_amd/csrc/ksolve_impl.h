@@ -200,6 +200,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     auto acc = [&](const ksolve_reqsets& r, uint32_t n) { if (r.mask) for (size_t i = 0; i < (size_t)n * req_words; ++i) valid[i % req_words] |= r.mask[i]; };
     acc(d->it_reqs, d->n_its); acc(d->tmpl_reqs, d->n_templates); acc(d->pod_reqs, d->n_pod_rows); acc(d->pod_strict_reqs, d->n_pod_rows);
     acc(d->node_reqs, d->n_nodes);
+    if (d->pod_volume_first) acc(d->volume_reqs, d->n_volume_reqs);
     if (d->topo.n) {
       acc(d->topo.filter_reqs, d->topo.filter_first[d->topo.n]);
       for (uint32_t g = 0; g < d->topo.n; ++g) if (d->topo.key[g] >= 0) {
@@ -355,6 +356,21 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   if (strict_same) R.strict = R.reqs;
   else R.strict = upload_reqs(h, d->pod_strict_reqs, d->n_pod_rows, req_words, d->n_keys, !rows_nil);
   R.tolerates = up(h, d->pod_tolerates, d->n_pod_rows);
+  // volume requirement alternatives (nodeclaim.go:138-157, existingnode.go:108-139)
+  P.vol_on = d->pod_volume_first ? 1 : 0; P.cls_vol = nullptr; P.vol_reqs = ReqTable{};
+  R.vol = nullptr; R.cls_vol = nullptr;
+  if (P.vol_on) {
+    if (!d->pod_volume_count || (d->n_volume_reqs && !d->volume_reqs.mask)) return fail(h, KSOLVE_ERR_INVALID, "pod_volume_first without pod_volume_count / volume_reqs");
+    std::vector<uint64_t> vol(d->n_pod_rows);
+    for (uint32_t r = 0; r < d->n_pod_rows; ++r) {
+      const uint32_t f = d->pod_volume_first[r], c = d->pod_volume_count[r];
+      if ((uint64_t)f + c > d->n_volume_reqs) return fail(h, KSOLVE_ERR_INVALID, "pod volume alternatives outside volume_reqs");
+      vol[r] = c ? ((uint64_t)f | ((uint64_t)c << 32)) : 0ull;
+    }
+    if (d->volume_reqs.min_values) for (size_t i = 0; i < (size_t)d->n_volume_reqs * d->n_keys; ++i) if (d->volume_reqs.min_values[i] >= 0) return fail(h, KSOLVE_ERR_INVALID, "volume requirements carry no minValues");
+    R.vol = up(h, vol.data(), vol.size());
+    P.vol_reqs = upload_reqs(h, d->volume_reqs, d->n_volume_reqs ? d->n_volume_reqs : 1, req_words, d->n_keys);
+  }
   R.host_ports = nullptr; R.cls_host_ports = nullptr;
   if (P.hp_on) {
     std::vector<uint64_t> hp((size_t)d->n_pod_rows * 2);
@@ -570,7 +586,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     if (d->tmpl_reqs.min_values) for (size_t i = 0; i < (size_t)d->n_templates * d->n_keys; ++i) if (d->tmpl_reqs.min_values[i] >= 0) any_minv = true;
     const bool bounds = any_nonzero(d->pod_reqs.has_gte, d->n_pod_rows) || any_nonzero(d->pod_reqs.has_lte, d->n_pod_rows) ||
                         any_nonzero(d->tmpl_reqs.has_gte, d->n_templates) || any_nonzero(d->tmpl_reqs.has_lte, d->n_templates);
-    P.plain = (d->topo.n == 0 && d->n_nodes == 0 && !d->tmpl_daemon_first && !any_minv && !P.reserved_on && !bounds && !d->n_override_groups && !P.hp_on) ? 1 : 0;
+    P.plain = (d->topo.n == 0 && d->n_nodes == 0 && !d->tmpl_daemon_first && !any_minv && !P.reserved_on && !bounds && !d->n_override_groups && !P.hp_on && !P.vol_on) ? 1 : 0;
     P.lite = (P.plain && req_words <= 64 && it_words <= 8 && d->n_res <= 4) ? 1 : 0;
 #ifdef KSOLVE_NO_LITE
     P.lite = 0;   // A/B builds only
@@ -807,6 +823,7 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
     R.cls_reqs = h->d_cls_reqs; R.cls_strict = h->d_cls_strict;
     R.cls_tolerates = dz<uint64_t>(h, n_classes);
     R.cls_host_ports = P.hp_on ? dz<uint64_t>(h, (size_t)n_classes * 2) : nullptr;
+    R.cls_vol = P.vol_on ? dz<uint64_t>(h, n_classes) : nullptr;
     R.cls_hot = dz<uint64_t>(h, (size_t)n_classes * P.lay.k_hot_words());
     R.cls_cold = dz<uint64_t>(h, (size_t)n_classes * P.lay.cold_words());
     R.cls_topo = h->has_topology ? dz<uint64_t>(h, (size_t)n_classes * 2 * R.topo_words) : nullptr;
@@ -824,6 +841,7 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
   P.cls_requests = R.cls_requests; P.cls_reqs = as_const(h->d_cls_reqs); P.cls_strict = as_const(h->d_cls_strict);
   P.cls_tolerates = R.cls_tolerates;
   P.cls_hp = R.cls_host_ports;
+  P.cls_vol = R.cls_vol;
   P.cls_hot = R.cls_hot; P.cls_cold = R.cls_cold;
   P.topo.cls_topo = R.cls_topo;
   if (n_classes) be_fill(h, W.dead, 0, (size_t)n_classes * h->claim_words * 8);

@@ -167,6 +167,9 @@ struct ProblemView {
   const uint64_t* node_removed;  // [node_words] existing nodes that are absent in this probe of a resident cluster (null: none)
   int hp_on;                     // some pod binds a host port
   const uint64_t* cls_hp;        // [n_classes][2] triples the class binds | triples that match one of them
+  int vol_on;                    // some pod has volume requirement alternatives
+  const uint64_t* cls_vol;       // [n_classes] first | count << 32 into vol_reqs
+  ReqTable vol_reqs;             // the alternatives (ksolve_problem_desc.volume_reqs)
   const uint64_t* dg_hp;         // [n_dg] triples of each daemon-overhead group's daemon pods
   const uint64_t* node_hp0;      // [n_nodes] triples in use on each existing node before the solve (null = none)
 

@@ -206,9 +206,11 @@ _uid_counter = [0]
 
 def pod(uid=None, name=None, namespace="default", labels=None, requests=None, node_selector=None, node_requirements=None,
         node_preferences=None, tolerations=None, topology_spread=None, pod_requirements=None, pod_preferences=None,
-        pod_anti_requirements=None, pod_anti_preferences=None, creation=0, phase="Pending", node_name="", host_ports=None):
+        pod_anti_requirements=None, pod_anti_preferences=None, creation=0, phase="Pending", node_name="", host_ports=None,
+        volume_requirements=None):
     """test.Pod — pkg/test/pods.go:88. node_requirements: list of NodeSelectorRequirement (one term) or list of terms.
-    host_ports: port numbers (PodOptions.HostPorts: TCP, no hostIP) or {"port", "ip", "protocol"} dicts."""
+    host_ports: port numbers (PodOptions.HostPorts: TCP, no hostIP) or {"port", "ip", "protocol"} dicts.
+    volume_requirements: volumeReqsByPod[uid] (scheduler.go:138) — a list of alternatives, each a list of requirements."""
     if uid is None:
         _uid_counter[0] += 1
         uid = f"00000000-0000-0000-0000-{_uid_counter[0]:012d}"
@@ -216,6 +218,8 @@ def pod(uid=None, name=None, namespace="default", labels=None, requests=None, no
          "creationTimestamp": creation, "phase": phase, "nodeName": node_name}
     if node_selector:
         p["nodeSelector"] = dict(node_selector)
+    if volume_requirements:
+        p["volumeRequirements"] = [list(alt) for alt in volume_requirements]
     if host_ports:
         p["hostPorts"] = [host_port(h) if not isinstance(h, dict) else host_port(**h) for h in host_ports]
     if node_requirements or node_preferences:

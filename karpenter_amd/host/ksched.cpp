@@ -377,6 +377,7 @@ struct PodSpec {
   std::vector<std::vector<Expr>> required_terms;
   std::vector<std::pair<int, std::vector<Expr>>> preferred;  // (weight, exprs)
   std::vector<Toleration> tolerations;
+  std::vector<std::vector<Expr>> volume_requirements;        // volumeReqsByPod[uid] (scheduler.go:138, :572): alternatives, in order
 };
 
 // Go's insertion sort (sort.Slice on <= 12 elements is a stable insertion sort; pods with more than 12 preferred
@@ -501,6 +502,7 @@ static PodSpec parse_pod(const Value& v) {
   p.node_name = v.at("nodeName").s("");
   p.requests = parse_resources(v.at("requests"));
   p.node_selector = v.at("nodeSelector");
+  for (auto& alt : v.at("volumeRequirements").items()) p.volume_requirements.push_back(parse_exprs(alt));
   const Value& na = v.at("nodeAffinity");
   if (!na.is_null()) {
     p.has_node_affinity = true;
@@ -784,6 +786,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         for (auto& e : v.reqs) D.note(e);
         for (auto& e : v.strict) D.note(e);
         for (auto& term : p.required_terms) for (auto& e : term) D.note(e);   // every term feeds the TopologyNodeFilter (topologynodefilter.go:50-62)
+        for (auto& alt : p.volume_requirements) for (auto& e : alt) D.note(e);
         for (auto& t : p.tscs) if (t.key != kHostname) D.key(t.key);
         for (auto* list : {&p.aff_required, &p.anti_required}) for (auto& t : *list) if (t.key != kHostname) D.key(t.key);
         for (auto* list : {&p.aff_preferred, &p.anti_preferred}) for (auto& t : *list) if (t.second.key != kHostname) D.key(t.second.key);
@@ -1214,10 +1217,44 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     };
     std::vector<uint64_t> spec_hpc(specs.size(), 0);
     for (size_t si = 0; si < specs.size(); ++si) spec_hpc[si] = hp_conflicts(spec_hp[si]);
+    // volume requirement alternatives (PodData.VolumeRequirements): one requirement set per alternative, equal lists shared
+    bool any_volume = false;
+    for (auto& sp : specs) any_volume = any_volume || !sp.volume_requirements.empty();
+    std::vector<uint32_t> spec_vol_first(specs.size(), 0), spec_vol_count(specs.size(), 0), pod_vol_first, pod_vol_count;
+    std::vector<ks::ReqBuf> vol_sets;
+    if (any_volume) {
+      std::map<std::string, std::pair<uint32_t, uint32_t>> lists;
+      for (size_t si = 0; si < specs.size(); ++si) {
+        auto& alts = specs[si].volume_requirements;
+        if (alts.empty()) continue;
+        std::string key;
+        for (auto& alt : alts) {
+          for (auto& e : alt) { key += e.key; key += '\x01'; key += e.op; for (auto& v : e.values) { key += '\x02'; key += v; } key += '\x03'; }
+          key += '\x04';
+        }
+        auto it = lists.find(key);
+        if (it == lists.end()) {
+          const uint32_t first = (uint32_t)vol_sets.size();
+          for (auto& alt : alts) {
+            ks::ReqBuf b;
+            Flattener::clear(b);
+            for (auto& x : alt) { if (x.min_values >= 0) throw Unsupported("volume requirements with minValues"); ks::ReqBuf one; fl.encode(x, one); ks::reqbuf_add(fl.kd, b, ks::reqbuf_ref_with_minv(one)); }
+            vol_sets.push_back(b);
+          }
+          it = lists.emplace(key, std::make_pair(first, (uint32_t)alts.size())).first;
+        }
+        spec_vol_first[si] = it->second.first; spec_vol_count[si] = it->second.second;
+      }
+      pod_vol_first.assign(n_rows, 0); pod_vol_count.assign(n_rows, 0);
+    }
+    ReqTableBuilder vol_reqs;
+    vol_reqs.init((int)vol_sets.size(), rw, nk);
+    for (size_t i = 0; i < vol_sets.size(); ++i) vol_reqs.put((int)i, vol_sets[i]);
     for (int p = 0; p < n_pods; ++p) {
       int si = pod_spec[p];
       put_row(p, enc[si][0]);
       pod_hp[p] = spec_hp[si]; pod_hpc[p] = spec_hpc[si];
+      if (any_volume) { pod_vol_first[p] = spec_vol_first[si]; pod_vol_count[p] = spec_vol_count[si]; }
       pod_next[p] = spec_first_extra[si];
       pod_creation[p] = specs[si].creation;
       pod_pending[p] = specs[si].pending ? 1 : 0;
@@ -1227,6 +1264,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         int row = spec_first_extra[si] + (int)vi - 1;
         put_row(row, enc[si][vi]);
         pod_hp[row] = spec_hp[si]; pod_hpc[row] = spec_hpc[si];
+        if (any_volume) { pod_vol_first[row] = spec_vol_first[si]; pod_vol_count[row] = spec_vol_count[si]; }
         pod_next[row] = vi + 1 < ladders[si].size() ? row + 1 : -1;
       }
 
@@ -1591,6 +1629,10 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       d.pod_host_ports = pod_hp.data(); d.pod_host_port_conflicts = pod_hpc.data();
       if (n_nodes) d.node_host_ports = node_hp.data();
       if (!dg_first.empty()) d.daemon_group_host_ports = dg_hp.data();
+    }
+    if (any_volume) {
+      d.n_volume_reqs = (uint32_t)vol_sets.size(); d.volume_reqs = vol_reqs.view();
+      d.pod_volume_first = pod_vol_first.data(); d.pod_volume_count = pod_vol_count.data();
     }
     d.pod_creation = pod_creation.data(); d.pod_uid_hi = uid_hi.data(); d.pod_uid_lo = uid_lo.data(); d.pod_is_pending = pod_pending.data();
     d.n_taints = (uint32_t)distinct_taints.size();

@@ -881,3 +881,99 @@ def test_min_values_on_a_key_instance_types_constrain_with_notin_exists(oracle, 
     # launch shaping: Truncate's re-check (scheduler.go:419-437) on the same catalogue
     pool = fx.node_pool(requirements=[fx.req(fam, "Exists", min_values=3)])
     check(oracle, emu, fx.problem(its, [pool], pods, options={"truncateInstanceTypes": 3}))
+
+
+def _zone_of(claim):
+    return next(tuple(sorted(r["values"])) for r in claim["requirements"] if r["key"] == fx.ZONE)
+
+
+def test_volume_requirement_alternatives(oracle, emu):
+    """PodData.VolumeRequirements (volumeReqsByPod, scheduler.go:138, :222, :572) in NodeClaim.CanAdd (nodeclaim.go:138-157,
+    tryVolumeAlternative :164-242) and ExistingNode.CanAdd (existingnode.go:108-139, :143-168): the alternatives narrow the
+    bin's requirements, not the pod's; they are tried in order. Known answers of provisioning/suite_test.go "Volume Topology
+    Requirements" (:1987-2400) with the requirement sets VolumeTopology.GetRequirements derives from the fixtures there
+    (storage class zones test-zone-2/3 = one alternative; a bound PersistentVolume in test-zone-3 = one alternative)."""
+    its = fx.fake_default_instance_types()
+    zone = lambda *z: fx.req(fx.ZONE, "In", *z)
+    sc = [[zone("test-zone-2", "test-zone-3")]]
+    pv3 = [[zone("test-zone-3")]]
+    # :2103-2115 storage class zones ∩ the pod's own zones
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(node_requirements=[zone("test-zone-1", "test-zone-3")], volume_requirements=sc)]))
+    assert [_zone_of(c) for c in got["newNodeClaims"]] == [("test-zone-3",)] and not got["podErrors"]
+    # :2171-2181 the zone of a bound volume
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(volume_requirements=pv3)]))
+    assert [_zone_of(c) for c in got["newNodeClaims"]] == [("test-zone-3",)]
+    # :2317-2329 the pod wants another zone than its volume
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(node_requirements=[zone("test-zone-1")], volume_requirements=pv3)]))
+    assert len(got["podErrors"]) == 1 and not got["newNodeClaims"]
+    # :2290-2316 a volume pinned to a hostname: no NodeClaim carries that name
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(volume_requirements=[[fx.req(fx.HOSTNAME, "In", "some-node")]])]))
+    assert len(got["podErrors"]) == 1 and not got["newNodeClaims"]
+    # ... but an existing node with that name takes it, and Exists / NotIn on the hostname pass on a new claim
+    by = {t["name"]: t for t in its}
+    nodes = [fx.state_node("some-node", by["default-instance-type"], "test-zone-1"), fx.state_node("other-node", by["default-instance-type"], "test-zone-2")]
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(volume_requirements=[[fx.req(fx.HOSTNAME, "In", "some-node")]]),
+                                                                   fx.pod(volume_requirements=[[fx.req(fx.HOSTNAME, "NotIn", "some-node", "other-node")]]),
+                                                                   fx.pod(volume_requirements=[[fx.req(fx.HOSTNAME, "In", "gone")], [fx.req(fx.HOSTNAME, "In", "other-node")]])], state_nodes=nodes))
+    assert {e["name"]: len(e["pods"]) for e in got["existingNodes"]} == {"some-node": 1, "other-node": 1} and len(got["newNodeClaims"]) == 1
+    # :2353-2400 the volume's zone survives relaxation: the first required term cannot be met, the second can
+    p = fx.pod(node_requirements=[[fx.req("example.com/label", "In", "unsupported")], [fx.req(fx.CAPACITY_TYPE, "In", "on-demand")]], volume_requirements=pv3)
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [p]))
+    assert [_zone_of(c) for c in got["newNodeClaims"]] == [("test-zone-3",)] and not got["podErrors"]
+    # alternatives in order: the first one the NodePool admits wins; pods with different lists do not share a class
+    pool = fx.node_pool(requirements=[zone("test-zone-2", "test-zone-3")])
+    alts = [[zone("test-zone-1")], [zone("test-zone-3")], [zone("test-zone-2")]]
+    got, _ = check(oracle, emu, fx.problem(its, [pool], [fx.pod(requests={"cpu": "1"}, volume_requirements=alts) for _ in range(3)]
+                                                        + [fx.pod(requests={"cpu": "1"}, volume_requirements=alts[::-1]) for _ in range(3)] + [fx.pod(requests={"cpu": "1"})]))
+    assert sorted(_zone_of(c) for c in got["newNodeClaims"]) == [("test-zone-2",), ("test-zone-3",)]
+    # an alternative can fail late: no instance type in its zone holds the pod (the filter, nodeclaim.go:213), the next one does
+    big3 = [fx.fake_instance_type("big-z3", {"cpu": "32", "memory": "64Gi"}, offerings=[fx.offering("on-demand", "test-zone-3", 3.0)]),
+            fx.fake_instance_type("small-all", {"cpu": "2", "memory": "4Gi"})]
+    got, _ = check(oracle, emu, fx.problem(big3, [fx.node_pool()], [fx.pod(requests={"cpu": "10"}, volume_requirements=[[zone("test-zone-1")], [zone("test-zone-3")]]),
+                                                                    fx.pod(requests={"cpu": "10"}, volume_requirements=[[zone("test-zone-1")], [zone("test-zone-2")]])]))
+    assert [_zone_of(c) for c in got["newNodeClaims"]] == [("test-zone-3",)] and len(got["podErrors"]) == 1
+    # topology counts with the pod's own requirements while the claim takes the volume's zone (nodeclaim.go:197-201)
+    lab = {"app": "db"}
+    pods = [fx.pod(labels=lab, requests={"cpu": "1"}, topology_spread=[fx.spread(fx.ZONE, lab)], volume_requirements=[[zone(z)], [zone("test-zone-2")]]) for z in ("test-zone-1", "test-zone-1", "test-zone-3", "test-zone-3", "test-zone-1")]
+    check(oracle, emu, fx.problem(its, [fx.node_pool()], pods))
+    # a custom label that only the volume mentions (undefined on the claim: allowed for well-known labels only, nodeclaim.go:171)
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [fx.pod(volume_requirements=[[fx.req("example.com/rack", "In", "r1")]]),
+                                                                   fx.pod(volume_requirements=[[fx.req("example.com/rack", "NotIn", "r1")]]),
+                                                                   fx.pod(volume_requirements=[[fx.req("example.com/rack", "In", "r1")], [zone("test-zone-2")]])]))
+    assert len(got["podErrors"]) == 1
+    check(oracle, emu, fx.problem(its, [fx.node_pool(labels={"example.com/rack": "r1"})], [fx.pod(volume_requirements=[[fx.req("example.com/rack", "In", "r1")]]),
+                                                                                          fx.pod(volume_requirements=[[fx.req("example.com/rack", "In", "r2")]])]))
+
+
+def test_volume_requirement_alternatives_fuzz(oracle, emu):
+    zones = ["test-zone-1", "test-zone-2", "test-zone-3"]
+    for seed in range(14):
+        rng = random.Random(9100 + seed)
+        its = fx.fake_instance_types(rng.choice([5, 12])) if seed % 2 else fx.fake_default_instance_types()
+        by = {t["name"]: t for t in its}
+        names = sorted(by)
+
+        def alt():
+            reqs = []
+            if rng.random() < 0.8: reqs.append(fx.req(fx.ZONE, rng.choice(["In", "In", "NotIn"]), *rng.sample(zones, rng.choice([1, 1, 2]))))
+            if rng.random() < 0.25: reqs.append(fx.req(fx.CAPACITY_TYPE, "In", rng.choice(["spot", "on-demand"])))
+            if rng.random() < 0.2: reqs.append(fx.req("example.com/rack", rng.choice(["In", "NotIn", "Exists", "DoesNotExist"]), *([] if rng.random() < 0.3 else [rng.choice(["r1", "r2"])])))
+            if rng.random() < 0.15: reqs.append(fx.req(fx.HOSTNAME, rng.choice(["In", "NotIn"]), rng.choice(["node-0", "node-1", "nowhere"])))
+            for r in reqs:
+                if r["operator"] in ("Exists", "DoesNotExist"): r["values"] = []
+                elif not r["values"]: r["values"] = ["r1"]
+            return reqs or [fx.req(fx.ZONE, "In", rng.choice(zones))]
+        lists = [[alt() for _ in range(rng.choice([1, 1, 2, 3]))] for _ in range(4)]
+        lab = {"app": "a"}
+        pods = []
+        for j in range(rng.choice([12, 40])):
+            kw = {}
+            if rng.random() < 0.3: kw["node_selector"] = {fx.ZONE: rng.choice(zones)}
+            if rng.random() < 0.2: kw["node_preferences"] = [fx.req(fx.ZONE, "In", rng.choice(zones))]
+            if rng.random() < 0.25: kw.update(labels=lab, topology_spread=[fx.spread(rng.choice([fx.ZONE, fx.HOSTNAME]), lab, when=rng.choice(["DoNotSchedule", "ScheduleAnyway"]))])
+            pods.append(fx.pod(requests={"cpu": rng.choice(["100m", "500m", "1", "3"])}, volume_requirements=rng.choice(lists) if rng.random() < 0.7 else None, **kw))
+        nodes = [fx.state_node(f"node-{i}", by[rng.choice(names)], rng.choice(zones), used={"cpu": rng.choice(["0", "1"])}, extra_labels=({"example.com/rack": rng.choice(["r1", "r2"])} if rng.random() < 0.5 else None))
+                 for i in range(rng.choice([0, 0, 2, 5]))]
+        pool = fx.node_pool(requirements=[fx.req(fx.ZONE, "In", *rng.sample(zones, rng.choice([2, 3])))] if rng.random() < 0.5 else None,
+                            labels={"example.com/rack": "r1"} if rng.random() < 0.3 else None)
+        got, _ = check(oracle, emu, fx.problem(its, [pool], pods, state_nodes=nodes))

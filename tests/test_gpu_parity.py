@@ -422,6 +422,17 @@ def test_host_ports_on_the_device(oracle):
     tda.test_host_ports_fuzz(oracle, None)
 
 
+def test_volume_requirement_alternatives_and_complement_min_values_on_the_device(oracle):
+    """PodData.VolumeRequirements in NodeClaim.CanAdd / ExistingNode.CanAdd (nodeclaim.go:138-242, existingnode.go:108-168):
+    the known answers of provisioning/suite_test.go "Volume Topology Requirements", the order of the alternatives, late
+    failures, topology and the seeded fuzz of tests/test_device_algorithm.py on the GPU; and minValues over instance types
+    that constrain the key with NotIn / Exists (types.go:399-433)."""
+    import test_device_algorithm as tda
+    tda.test_volume_requirement_alternatives(oracle, None)
+    tda.test_volume_requirement_alternatives_fuzz(oracle, None)
+    tda.test_min_values_on_a_key_instance_types_constrain_with_notin_exists(oracle, None)
+
+
 @pytest.mark.parametrize("seed,limits", [(1, None), (3, {"cpu": "150", "nodes": "31"})])
 def test_resident_cluster_probes_on_the_device(oracle, seed, limits):
     """ksolve_probe_create on the GPU: one ksolve_create for the cluster, a removed-node bitmap + displaced-pod rows per
