@@ -711,11 +711,13 @@ def test_cancel_from_another_thread(oracle, emu):
     # the moment the cancel lands is timing-dependent: try a few delays, early (classification / queue sort: the pack
     # loop then stops before its first pod) and in the middle of the pack loop
     landed = []
-    for frac in (0.03, 0.6, 0.75, 0.5, 0.85, 0.4, 0.9):
+    # (every cancel that lands checks that the claim order reported is the one of the last sort the reference would have run:
+    # the cursor engine places the entries before a poll boundary without the eager re-sort of the group path)
+    for frac in (0.03, 0.6, 0.75, 0.5, 0.85, 0.4, 0.9, 0.55, 0.65, 0.7, 0.8, 0.45):
         r = cancelled_after(frac * t_full)
         if r["timedOut"]:
             landed.append(check_prefix(r))
-        if len(landed) >= 2 and max(landed) > 0:
+        if len([x for x in landed if x > 0]) >= 4:
             break
     assert landed and max(landed) > 0, f"no cancel landed inside the pack loop: {landed}"
     again = s.Solve(want_results=False)

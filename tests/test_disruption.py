@@ -513,14 +513,24 @@ def _tight_cluster(seed, n_nodes=30, limits=None):
     return cluster
 
 
-@pytest.mark.parametrize("seed,limits", [(1, None), (2, {"cpu": "2000"}), (3, {"cpu": "150", "nodes": "31"})])
+@pytest.mark.parametrize("seed,limits", [(1, None), (2, {"cpu": "2000"}), (3, {"cpu": "150", "nodes": "31"}), (4, "volumes")])
 def test_resident_cluster_probes_match_per_probe_rebuild(oracle, emu, seed, limits):
     """ksolve_probe_create (one ksolve_create for the cluster, a removed-node bitmap + displaced-pod rows per simulation, one
     batched launch) gives, probe by probe, the Results of SimulateScheduling assembled from scratch and solved by the
     oracle (helpers.go:53-155): single-node sweep, multi-node sets, NodePool limits handed back by the removed nodes
     (scheduler.go:835-842), uninitialized / consolidateAfter / deleting nodes, a pending pod."""
     import random
-    cluster = _tight_cluster(seed, limits=limits)
+    volumes = limits == "volumes"
+    cluster = _tight_cluster(seed, limits=None if volumes else limits)
+    if volumes:
+        # bound pods with volume requirement alternatives (volumeReqsByPod): the zone of the volume they mount — their node's
+        # zone, or that one and a second one
+        vr = random.Random(40 + seed)
+        for n in cluster["nodes"]:
+            for p in n["pods"]:
+                if vr.random() < 0.4:
+                    zs = [n["labels"][fx.ZONE]] + ([vr.choice(fx.KWOK_ZONES)] if vr.random() < 0.4 else [])
+                    p["volumeRequirements"] = [[fx.req(fx.ZONE, "In", z)] for z in zs]
     cands = [n for n in dz.sort_candidates(cluster, cluster["nodes"]) if not n.get("markedForDeletion")][:14]
     got, rc = dz.sweep_resident(cluster, cands, solver_lib=emu)
     want = dz.sweep(cluster, cands, oracle.solve)
@@ -530,6 +540,8 @@ def test_resident_cluster_probes_match_per_probe_rebuild(oracle, emu, seed, limi
         assert g["results"]["counters"]["referenceBinEvaluations"] == w["results"]["counters"]["binEvaluations"]
         assert g["results"]["allNonPendingPodsScheduled"] == w["results"]["allNonPendingPodsScheduled"]
     assert seed != 1 or {c["decision"] for c in got} == {dz.DELETE, dz.REPLACE, dz.NOOP}
+    if volumes:   # the volume's zone ends up in the replacement's requirements
+        assert any(tuple(r["values"]) in [(z,) for z in fx.KWOK_ZONES] for c in got for cl in c["results"]["newNodeClaims"] for r in cl["requirements"] if r["key"] == fx.ZONE)
     # multi-node sets through the same resident cluster: the binary search's probe sequence and command
     rng = random.Random(seed)
     sets = [rng.sample(cands, k) for k in (2, 3, 5)]

@@ -433,7 +433,7 @@ def test_volume_requirement_alternatives_and_complement_min_values_on_the_device
     tda.test_min_values_on_a_key_instance_types_constrain_with_notin_exists(oracle, None)
 
 
-@pytest.mark.parametrize("seed,limits", [(1, None), (3, {"cpu": "150", "nodes": "31"})])
+@pytest.mark.parametrize("seed,limits", [(1, None), (3, {"cpu": "150", "nodes": "31"}), (4, "volumes")])
 def test_resident_cluster_probes_on_the_device(oracle, seed, limits):
     """ksolve_probe_create on the GPU: one ksolve_create for the cluster, a removed-node bitmap + displaced-pod rows per
     simulation, all probes in one ksolve_solve_batch launch — against SimulateScheduling assembled from scratch and solved
