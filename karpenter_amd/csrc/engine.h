@@ -1903,7 +1903,10 @@ struct Engine {
         W::for_n(64, [&](int l) {
           if (l < bn) { uint32_t p = queue[(h0 + (uint32_t)l) % cap]; bp[l] = p; bc[l] = rc_[p]; bl[l] = ll[p]; }
         });
-        if (S.cancel_flag && W::poll_flag(S.cancel_flag)) { status = 2; break; }   // ctx cancellation, polled once per 64 pods
+        if (S.cancel_flag) {   // ctx cancellation, polled once per 64 pods (< 0: tests only, see fast_engine.h)
+          const int cv = W::poll_flag(S.cancel_flag);
+          if (cv > 0 || (cv < 0 && (long long)steps >= -(long long)cv)) { status = 2; break; }
+        }
       }
       int pod = (int)sc.blk_pod[blk_i];
       if (sc.blk_last[blk_i] == qlen) break;                                // queue.go:52-56

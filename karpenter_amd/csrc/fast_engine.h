@@ -732,7 +732,11 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
       const int bnn = bn, nb = base + 64;
       W::each([&](int l) { bcls.at(l) = nxt_cls.at(l); bslot.at(l) = l < bnn ? (uint32_t)slot_of[nxt_cls.at(l)] : 0xFFFFu; });
       W::each([&](int l) { if (nb + l < np) nxt_cls.at(l) = gqcls[nb + l]; });
-      if ((base & 1023) == 0 && cancel && fast_uniform(W::poll_flag(cancel))) { status = 2; bn = 0; break; }
+      if ((base & 1023) == 0 && cancel) {
+        // > 0: ksolve_cancel / the deadline. < 0 (tests only, KSOLVE_TEST_CANCEL_AT): as if the cancel landed once -flag pods were placed
+        const int cv = fast_uniform((int)W::poll_flag(cancel));
+        if (cv > 0 || (cv < 0 && base >= -cv)) { status = 2; bn = 0; break; }
+      }
     }
     if (KS_UNLIKELY(max_steps >= 0 && steps >= max_steps)) { status = 2; break; }
     // ---- sort.Slice (scheduler.go:598) for a move the last commit left behind ----

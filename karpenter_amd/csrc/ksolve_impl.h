@@ -766,7 +766,11 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
   ks::Workspace& W = h->ws;
   const uint32_t n_pods = h->n_pods, n_rows = h->n_rows, n_res = h->n_res;
   h->engine_used = 1;
-  if (fresh_context) { be_fill(h, h->d_cancel, 0, 4); be_sync(h); }
+  if (fresh_context) {
+    be_fill(h, h->d_cancel, 0, 4);
+    if (const char* at = getenv("KSOLVE_TEST_CANCEL_AT")) { const int v = -atoi(at); if (v < 0) be_h2d(h, h->d_cancel, &v, 4); }   // deterministic cancellation for the tests
+    be_sync(h);
+  }
   if (h->base) {
     // a probe of a resident cluster: index, classes and queue order are the base handle's; only the workspace is reset
     if (h->n_classes) be_fill(h, W.dead, 0, (size_t)h->n_classes * h->claim_words * 8);

@@ -979,3 +979,21 @@ def test_volume_requirement_alternatives_fuzz(oracle, emu):
         pool = fx.node_pool(requirements=[fx.req(fx.ZONE, "In", *rng.sample(zones, rng.choice([2, 3])))] if rng.random() < 0.5 else None,
                             labels={"example.com/rack": "r1"} if rng.random() < 0.3 else None)
         got, _ = check(oracle, emu, fx.problem(its, [pool], pods, state_nodes=nodes))
+
+
+@pytest.mark.parametrize("at", [1024, 5 * 1024, 37 * 1024, 100 * 1024, 150 * 1024])
+def test_cancel_at_a_poll_boundary_is_the_full_run_stopped_there(emu, monkeypatch, at):
+    """The cancel flag is polled at queue-block boundaries (every 1024 pods on the cursor engine, every 64 on the general one).
+    KSOLVE_TEST_CANCEL_AT makes it land deterministically once `at` pods are placed: the Results must be the full run stopped
+    after exactly that many pops — in particular the claim order is the one of the last sort the reference would have run
+    (scheduler.go:598 sorts at the start of an add), not one re-sort further (the cursor engine's group path re-sorts eagerly)."""
+    n = 200000
+    for engine in ("auto", "general"):
+        prob = fx.config2(pods=n, n_types=500, seed=42)
+        prob["options"] = dict(prob.get("options") or {}, engine=engine)
+        monkeypatch.setenv("KSOLVE_TEST_CANCEL_AT", str(at))
+        got = NewScheduler(prob, solver_lib=emu).Solve()
+        monkeypatch.delenv("KSOLVE_TEST_CANCEL_AT")
+        assert got["timedOut"] and got["scheduledPods"] == at and got["counters"]["engine"] == ("cursor" if engine == "auto" else "general")
+        prob["options"]["maxSteps"] = at
+        parity.assert_same_results(got, NewScheduler(prob, solver_lib=emu).Solve())

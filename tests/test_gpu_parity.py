@@ -422,6 +422,14 @@ def test_host_ports_on_the_device(oracle):
     tda.test_host_ports_fuzz(oracle, None)
 
 
+@pytest.mark.parametrize("at", [5 * 1024, 150 * 1024])
+def test_cancel_at_a_poll_boundary_on_the_device(monkeypatch, at):
+    """A cancellation that lands at a poll boundary leaves exactly the full run stopped there (claim order included), on both
+    engines: tests/test_device_algorithm.py::test_cancel_at_a_poll_boundary_is_the_full_run_stopped_there with libksolve.so."""
+    import test_device_algorithm as tda
+    tda.test_cancel_at_a_poll_boundary_is_the_full_run_stopped_there(None, monkeypatch, at)
+
+
 def test_volume_requirement_alternatives_and_complement_min_values_on_the_device(oracle):
     """PodData.VolumeRequirements in NodeClaim.CanAdd / ExistingNode.CanAdd (nodeclaim.go:138-242, existingnode.go:108-168):
     the known answers of provisioning/suite_test.go "Volume Topology Requirements", the order of the alternatives, late
