@@ -297,32 +297,32 @@ __device__ __forceinline__ void coop_stage(const ks::CoopStage& s, const ks::Row
 // MINV: the rows carry minValues (pod rows never do when they come from the reference's PodData — minValues belong to NodePool
 // requirements — so the tables are absent and neither streamed nor staged)
 template <bool MINV>
-__global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a, int rw, uint32_t magic, uint32_t kmagic) {
+__global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a, int rw, uint32_t magic, uint32_t kmagic, int rpb) {
   extern __shared__ __attribute__((aligned(16))) uint64_t coop_lds[];
   const int l = (int)threadIdx.x;
-  const int row0 = (int)blockIdx.x * 64;
-  const int rows = n - row0 < 64 ? n - row0 : 64;
+  const int row0 = (int)blockIdx.x * rpb;   // rpb rows per block: 64 (60, a multiple of 4, only through the A/B switch of the launcher)
+  const int rows = n - row0 < rpb ? n - row0 : rpb;
   const int stride = rw | 1;
   const int total = rows * rw;
   const int nk = a.dict.n_keys, kstride = nk | 1, ktotal = rows * nk;
   const int nr = a.n_res;
   uint64_t* t0 = coop_lds;
-  uint64_t* t1 = coop_lds + 64 * stride;
-  int32_t* m0 = (int32_t*)(coop_lds + 2 * 64 * stride);
-  int32_t* m1 = m0 + 64 * kstride;
+  uint64_t* t1 = coop_lds + rpb * stride;
+  int32_t* m0 = (int32_t*)(coop_lds + 2 * rpb * stride);
+  int32_t* m1 = m0 + rpb * kstride;
   const uint64_t* g0 = a.reqs.mask + (size_t)row0 * rw;
   const uint64_t* g1 = a.strict.mask + (size_t)row0 * rw;
   const int32_t* k0 = MINV ? a.reqs.minv + (size_t)row0 * nk : nullptr;   // the launcher: both minValues tables or neither, every other optional table exists
   const int32_t* k1 = MINV ? a.strict.minv + (size_t)row0 * nk : nullptr;
   const int row = row0 + l;
-  const bool live = row < n;
+  const bool live = l < rows;
   const int rowc = live ? row : n - 1;
   // ---- every HBM access of the block, then [row][word] in LDS ----
   ks::ReqRef q, qs;
   int64_t rq[8];
   uint64_t tol;
   const ks::CoopStage st{g0, g1, k0, k1, t0, t1, m0, m1, total, ktotal, rw, stride, nk, kstride, magic, kmagic, l};
-  if (rows == 64) coop_stage<true, MINV>(st, a, rowc, q, qs, rq, tol);     // branch-free: no wait is placed before the last load is out
+  if (rows == rpb) coop_stage<true, MINV>(st, a, rowc, q, qs, rq, tol);     // branch-free: no wait is placed before the last load is out
   else coop_stage<false, MINV>(st, a, rowc, q, qs, rq, tol);               // the last block of the table
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -476,15 +476,20 @@ static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) {
   const uint32_t magic = rw >= 1 ? (uint32_t)((0x100000000ull + (uint64_t)rw - 1) / (uint64_t)rw) : 0;
   const uint32_t kmagic = nk >= 1 ? (uint32_t)((0x100000000ull + (uint64_t)nk - 1) / (uint64_t)nk) : 0;
   const bool minv = a.reqs.minv && a.strict.minv, no_minv = !a.reqs.minv && !a.strict.minv;
-  size_t lds2 = (size_t)2 * 64 * (size_t)(rw | 1) * 8 + (minv ? (size_t)2 * 64 * (size_t)(nk | 1) * 4 : 0);
+  // 64 rows per block. 60 rows (4 idle lanes) would let an eighth block fit the CU's 160 KiB of LDS at configs[1]'s dictionary;
+  // measured (profiles/round2/classing_ab3.log): 153 us against 150.5 us — the idle lanes cost what the wavefront buys.
+  auto lds_for = [&](int rpb) { return (size_t)2 * rpb * (size_t)(rw | 1) * 8 + (minv ? (size_t)2 * rpb * (size_t)(nk | 1) * 4 : 0); };
+  int rpb = 64;
+  if (const char* r = getenv("KSOLVE_TEST_ROWS_PER_BLOCK")) { const int v = atoi(r); if (v == 60 || v == 64) rpb = v; }   // A/B switch of tests/tools/gpu_classing_ab.py
+  size_t lds2 = lds_for(rpb);
   if (const char* pad = getenv("KSOLVE_TEST_LDS_PAD")) lds2 += (size_t)atoi(pad);   // occupancy probe of tests/tools/gpu_classing_ab.py: fewer wavefronts per CU
   const size_t lds1 = (size_t)2 * 64 * (size_t)(rw | 1) * 8 + (size_t)2 * 64 * (size_t)(nk | 1) * 4 + 8 + (size_t)64 * (size_t)(a.n_res + 1) * 8;
   const bool plain = variant && !strcmp(variant, "plain");
   const bool coop1 = variant && !strcmp(variant, "coop1");
   const bool tables = (minv || no_minv) && a.reqs.has_gte && a.reqs.has_lte && a.strict.has_gte && a.strict.has_lte;
   if (!plain && !coop1 && rw >= 1 && nk >= 1 && a.n_res >= 1 && a.n_res <= 8 && aligned && tables && lds2 <= 64 * 1024) {
-    if (minv) hipLaunchKernelGGL(ksolve_row_hash_coop2<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic);
-    else hipLaunchKernelGGL(ksolve_row_hash_coop2<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic);
+    if (minv) hipLaunchKernelGGL(ksolve_row_hash_coop2<true>, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
+    else hipLaunchKernelGGL(ksolve_row_hash_coop2<false>, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
   } else if (!plain && rw >= 1 && nk >= 1 && lds1 <= 64 * 1024) {
     hipLaunchKernelGGL(ksolve_row_hash_coop, dim3((unsigned)((n + 63) / 64)), dim3(64), lds1, HB(h)->stream, n, a, rw, magic, kmagic);
   } else {

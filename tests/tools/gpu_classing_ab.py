@@ -25,9 +25,11 @@ s.Solve(want_results=False)
 digests = set()
 for v in variants:
     os.environ.pop("KSOLVE_TEST_LDS_PAD", None)
-    if v.startswith("coop2"):                      # "coop2+6000": 6000 bytes of unused LDS per block (occupancy probe)
+    os.environ.pop("KSOLVE_TEST_ROWS_PER_BLOCK", None)
+    if v.startswith("coop2"):                      # "coop2+6000": 6000 bytes of unused LDS per block (occupancy probe); "coop2@64": rows per block
         os.environ.pop("KSOLVE_ROWHASH_KERNEL", None)
-        if "+" in v: os.environ["KSOLVE_TEST_LDS_PAD"] = v.split("+")[1]
+        if "+" in v: os.environ["KSOLVE_TEST_LDS_PAD"] = v.split("+")[1].split("@")[0]
+        if "@" in v: os.environ["KSOLVE_TEST_ROWS_PER_BLOCK"] = v.split("@")[1]
     else: os.environ["KSOLVE_ROWHASH_KERNEL"] = v
     r = s.Solve(want_results=False, repeat=3)
     rh = sorted(t["row_hash_ms"] for t in r["timings"])
@@ -40,6 +42,7 @@ for v in variants:
         print("   digest", d[:16], "matches the oracle's pin" if d == want else ("(no pin)" if want is None else "DIFFERS from the pin"), "classes", full["counters"].get("classes"), flush=True)
 os.environ.pop("KSOLVE_ROWHASH_KERNEL", None)
 os.environ.pop("KSOLVE_TEST_LDS_PAD", None)
+os.environ.pop("KSOLVE_TEST_ROWS_PER_BLOCK", None)
 s.close()
 assert len(digests) == 1, digests
 assert want is None or digests == {want}
