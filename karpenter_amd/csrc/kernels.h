@@ -167,10 +167,10 @@ KS_FN bool rows_equal(const RowArgs& a, int x, int y) {
 // re-seeds). The table is read before it is written: with a few thousand classes for a million rows nearly every row
 // finds its hash and a smaller representative already there and issues no atomic at all (a stale read only shows an
 // older state — empty slot, larger representative — and falls through to the atomic).
-// rows_equal with the row's own requirement sets at hand (q, qs) and no early exit on the mask words: every word of the
-// other row is loaded whatever the words before it held, so the loads are independent and in flight together (an early
-// exit per word makes 2 x req_words DEPENDENT round trips to L2 out of one comparison). Words of keys the set does not
-// define are ignored, as in equal_reqset.
+// The difference of two requirement sets whose words are near (LDS): no early exit on the mask words, every word is loaded
+// whatever the words before it held, so the loads are independent and in flight together (an early exit per word makes
+// 2 x req_words DEPENDENT round trips out of one comparison). Words of keys the set does not define are ignored, as in
+// equal_reqset.
 KS_FN uint64_t reqset_diff(const Dict& d, const ReqRef& a, const ReqRef& b) {
   uint64_t diff = (uint64_t)((a.defined ^ b.defined) | (a.complement ^ b.complement) | (a.has_gte ^ b.has_gte) | (a.has_lte ^ b.has_lte));
   // bit w of wdef: word w belongs to a key the set defines
@@ -207,20 +207,6 @@ KS_FN uint64_t reqset_diff(const Dict& d, const ReqRef& a, const ReqRef& b) {
     }
   }
   return diff;
-}
-KS_FN bool rows_equal_q(const RowArgs& a, int x, int y, const ReqRef& q, const ReqRef& qs) {
-  uint64_t diff = 0;
-  for (int r = 0; r < a.n_res; ++r) diff |= (uint64_t)(a.requests[(size_t)r * a.n_rows + x] ^ a.requests[(size_t)r * a.n_rows + y]);
-  diff |= reqset_diff(a.dict, q, a.reqs.at(a.dict, y));
-  diff |= reqset_diff(a.dict, qs, a.strict.at(a.dict, y));
-  diff |= a.tolerates[x] ^ a.tolerates[y];
-  if (a.host_ports) diff |= (a.host_ports[(size_t)x * 2] ^ a.host_ports[(size_t)y * 2]) | (a.host_ports[(size_t)x * 2 + 1] ^ a.host_ports[(size_t)y * 2 + 1]);
-  if (a.vol) diff |= a.vol[x] ^ a.vol[y];
-  if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) {
-    diff |= a.topo_owned[(size_t)x * a.topo_words + w] ^ a.topo_owned[(size_t)y * a.topo_words + w];
-    diff |= a.topo_selected[(size_t)x * a.topo_words + w] ^ a.topo_selected[(size_t)y * a.topo_words + w];
-  }
-  return diff == 0;
 }
 // q / qs: the row's two requirement sets — read from the tables (row_hash_body), or with their mask words staged in LDS by
 // the wave-cooperative loader of the device kernel (ksolve.hip: ksolve_row_hash_coop), where 64 rows' masks arrive as
@@ -364,7 +350,12 @@ KS_FN void row_hash_body(int row, const RowArgs& a) {
   uint32_t slot = 0;
   const uint32_t other = row_table_insert(row, a, row_hash_kept(a, row_hash_value_with(row, a, q, qs, req_at, tol)), &slot);
   a.row_slot[row] = slot;
-  if (other != 0xFFFFFFFFu && row_diff_far(row, a, other, q, qs, req_at, tol) != 0) *a.collision = 1;
+  if (other == 0xFFFFFFFFu) return;
+  const bool differ = row_diff_far(row, a, other, q, qs, req_at, tol) != 0;
+  if (differ) *a.collision = 1;
+#if !KS_DEVICE
+  if (differ == rows_equal(a, row, (int)other)) *a.collision = 2;   // test emulation: the batched comparison against the plain definition, on every comparison of every test
+#endif
 }
 KS_FN void row_class_body(int row, const RowArgs& a) {
   uint32_t slot = a.row_slot[row];

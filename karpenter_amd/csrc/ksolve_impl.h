@@ -808,6 +808,7 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
     be_d2h(h, &coll, R.collision, 4);
     be_sync(h);
     if (!coll) break;
+    if (coll == 2) return fail(h, KSOLVE_ERR_DEVICE, "row_diff_far disagrees with rows_equal");   // raised by the test emulation only
     R.seed = R.seed * 6364136223846793005ull + 1442695040888963407ull;  // a 64-bit collision between different rows: re-seed
     if (attempt == 3) return fail(h, KSOLVE_ERR_DEVICE, "row hash collisions persist");
   }

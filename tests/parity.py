@@ -15,8 +15,15 @@ def build_emu(reverse_lanes=False):
     deps = [src] + [os.path.join(root, "karpenter_amd", "csrc", f) for f in os.listdir(os.path.join(root, "karpenter_amd", "csrc")) if f.endswith(".h")]
     deps.append(os.path.join(root, "include", "ksolve.h"))
     lib = EMU_LIB.replace(".so", "_reversed.so") if reverse_lanes else EMU_LIB
-    if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread"] + (["-DKS_EMU_REVERSE_LANES"] if reverse_lanes else []) + ["-o", lib, src])
+    stale = lambda: not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps)
+    if stale():
+        import fcntl
+        with open(lib + ".lock", "w") as lock:      # pytest-xdist workers: one of them builds, the others wait and find it fresh
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if stale():
+                tmp = lib + f".{os.getpid()}.tmp"
+                subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread"] + (["-DKS_EMU_REVERSE_LANES"] if reverse_lanes else []) + ["-o", tmp, src])
+                os.replace(tmp, lib)
     return lib
 
 
