@@ -235,7 +235,11 @@ struct Wave {
   static bool leader() { return true; }
   template <class F>
   static void each(F f) { KS_LANES(l) f(l); }
+#if defined(KSOLVE_PHASE_TIMERS) && defined(__x86_64__)
+  static unsigned long long clock() { return __builtin_ia32_rdtsc(); }   // host profile of the emulation (tests/tools): where the work is, not the latency
+#else
   static unsigned long long clock() { return 0; }
+#endif
   static int poll_flag(const volatile int* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
   template <class F>
   static uint32_t argmin_u32(F f, int* lane_out) {   // ties go to the lowest lane, whatever the evaluation order
