@@ -279,6 +279,16 @@ def main():
             traffic = pmc["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         traffic = None
+    stream_traffic = None
+    try:
+        # the same for the classing kernel (profiles/round2/pmc_raw.json: FETCH_SIZE and WRITE_SIZE in KB per launch, separate passes;
+        # FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes)
+        with open(os.path.join(ROOT, "profiles", "round2", "pmc_raw.json")) as f:
+            k = json.load(f)["void ksolve_row_hash_coop2<false>"]
+        if args.pods == 1_000_000 and args.types == 500:
+            stream_traffic = int(2 * k["FETCH_SIZE"]["per_launch"] * 1024 + k["WRITE_SIZE"]["per_launch"] * 1024)
+    except (OSError, KeyError, ValueError):
+        stream_traffic = None
     pin = None
     if not args.no_parity_pin:
         pin_path = os.path.join(ROOT, "tests", "golden", "fullsize", f"config2_p{args.pods}_t{args.types}_s{seed}.json")
@@ -313,7 +323,7 @@ def main():
         "roofline_stream": {"kernel": "ksolve_row_hash_coop2 (pod classing: one round trip for a 64-row block, words staged through LDS, hash, class-table slot, verify)", "bound": "hbm", "bytes": stream_bytes,
                             "bytes_read_by_the_kernel": c["rows"] * (2 * (8 * c["reqWords"] + 16) + 8 * c["resources"] + 8 + 4),   # both mask tables + flag words, requests, toleration mask, slot written; all-nil minValues tables are not streamed
                             "avg_ms": rh_ms, "achieved": stream_bytes / (rh_ms * 1e-3) / 1e9 if rh_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": stream_bytes / (rh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rh_ms > 0 else None, "phase_ms": cls_ms},
+                            "frac": stream_bytes / (rh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rh_ms > 0 else None, "traffic": stream_traffic, "phase_ms": cls_ms},
         "phases_ms": {k: sum(t.get(k, 0.0) for t in timings) / len(timings) for k in ("pack_kernel_ms", "classify_ms", "row_hash_ms", "sort_ms", "it_index_ms")},
         "counters": c,
     }
