@@ -997,3 +997,28 @@ def test_cancel_at_a_poll_boundary_is_the_full_run_stopped_there(emu, monkeypatc
         assert got["timedOut"] and got["scheduledPods"] == at and got["counters"]["engine"] == ("cursor" if engine == "auto" else "general")
         prob["options"]["maxSteps"] = at
         parity.assert_same_results(got, NewScheduler(prob, solver_lib=emu).Solve())
+
+
+def test_volume_requirement_alternatives_at_scale(oracle, emu):
+    """A few thousand pods on the KWOK catalogue: a third of them with volume requirement alternatives over zones, some with a
+    zonal spread constraint, a cluster of existing nodes in front — long enough for claims to fill up, be re-sorted and be
+    skipped through the dead bits while alternatives are being tried (the pruning must stay exact with them)."""
+    rng = random.Random(4242)
+    its = fx.kwok_catalog(144)
+    nodes = _cluster(its, rng, 40)
+    lab = {"app": "store"}
+    pods = []
+    for j in range(5000):
+        kw = {}
+        if rng.random() < 0.33:
+            zs = rng.sample(fx.KWOK_ZONES, rng.choice([1, 1, 2, 3]))
+            kw["volume_requirements"] = [[fx.req(fx.ZONE, "In", z)] for z in zs] if rng.random() < 0.7 else [[fx.req(fx.ZONE, "In", *zs)]]
+        if rng.random() < 0.1:
+            kw.update(labels=lab, topology_spread=[fx.spread(fx.ZONE, lab, max_skew=rng.choice([1, 3]))])
+        if rng.random() < 0.15:
+            kw["node_selector"] = {fx.ZONE: rng.choice(fx.KWOK_ZONES)}
+        pods.append(fx.pod(requests={"cpu": f"{rng.choice([500, 2000, 7000, 15000, 30000])}m", "memory": f"{rng.choice([256, 1024, 8192])}Mi"}, **kw))
+    np_ = fx.node_pool("default")
+    np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    got, _ = check(oracle, emu, fx.problem(its, [np_], pods, well_known=fx.KWOK_WELL_KNOWN, state_nodes=nodes))
+    assert len(got["newNodeClaims"]) > 100 and sum(len(e["pods"]) for e in got["existingNodes"]) > 0
