@@ -7,7 +7,9 @@ checked (NodeClaim.CanAdd, nodeclaim.go:124-242; ExistingNode.CanAdd, existingno
   * every instance type option of a NodeClaim fits the claim's total requests (nodeclaim.go:541-600, before daemon overhead);
   * NoSchedule / NoExecute taints of the claim's NodePool are tolerated by every pod on it (taints.go:83-95);
   * a pod's nodeSelector is honoured: the claim's requirement on that key admits exactly that value;
-  * pods that repel each other on kubernetes.io/hostname (required anti-affinity, either direction) never share a bin.
+  * pods that repel each other on kubernetes.io/hostname (required anti-affinity, either direction) never share a bin;
+  * a pod with volume requirement alternatives sits on a NodeClaim whose final requirements are inside at least one of them
+    (the chosen alternative was intersected into the claim, nodeclaim.go:170-175; later pods only narrow it further).
 """
 from decimal import Decimal
 import re
@@ -52,6 +54,23 @@ def _selector_matches(sel, labels):
         if e["operator"] == "DoesNotExist" and has:
             return False
     return True
+
+
+def _inside(q, r):
+    """The claim's requirement q (None = no requirement on the key) admits only values the In / NotIn / Exists / DoesNotExist
+    requirement r admits."""
+    op, vals = r["operator"], set(r.get("values") or [])
+    if op == "Exists":
+        return q is not None and (q["complement"] or bool(q["values"]))      # anything but DoesNotExist
+    if op == "DoesNotExist":
+        return q is None or (not q["complement"] and not q["values"])
+    if op == "In":
+        return q is not None and not q["complement"] and set(q["values"]) <= vals and bool(q["values"])
+    if op == "NotIn":
+        if q is None:
+            return False          # the intersection would have left a NotIn requirement on the claim
+        return vals <= set(q["values"]) if q["complement"] else not (set(q["values"]) & vals)
+    return True                   # Gt / Lt / Gte / Lte: not checked here
 
 
 def _repels(p, q):
@@ -110,6 +129,11 @@ def check(problem, res):
             for k, v in (p.get("nodeSelector") or {}).items():
                 q = reqs.get(k)
                 assert q is not None and not q["complement"] and q["values"] == [v], f"nodeSelector {k}={v} of {p['uid']} not pinned on {c['hostname']}: {q}"
+
+        for p in members:
+            alts = p.get("volumeRequirements") or []
+            assert not alts or any(all(_inside(reqs.get(r["key"]), r) for r in alt if r["key"] != fx.HOSTNAME) for alt in alts), \
+                f"claim {c['hostname']} satisfies no volume requirement alternative of {p['uid']}: {alts} vs {c['requirements']}"
 
     by_bin = {}
     for u, b in placed.items():

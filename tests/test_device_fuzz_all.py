@@ -14,7 +14,7 @@ from karpenter_amd.scheduling import NewScheduler, Unsupported
 from test_device_algorithm import emu  # noqa: F401  (fixture)
 
 ZONES = ["test-zone-1", "test-zone-2", "test-zone-3"]
-def run(oracle, emu, seed):
+def run(oracle, emu, seed, volumes=False):
     rng = random.Random(seed)
     its = copy.deepcopy(fx.fake_default_instance_types() if rng.random() < 0.5 else fx.fake_instance_types(rng.choice([4, 8, 16])))
     opts = {}
@@ -75,6 +75,18 @@ def run(oracle, emu, seed):
             nodes.append(n)
             for _ in range(rng.randrange(0, 3)):
                 cluster.append(rand_pod(phase="Running", node_name=f"node-{i}"))
+    if volumes:
+        # volume requirement alternatives (volumeReqsByPod) on a quarter of the pods, from a generator of their own so that the
+        # problems of the seeds above stay what they were
+        vr = random.Random(seed * 7919 + 13)
+        def alt():
+            reqs = [fx.req(fx.ZONE, vr.choice(["In", "In", "NotIn"]), *vr.sample(ZONES, vr.choice([1, 1, 2])))] if vr.random() < 0.8 else []
+            if vr.random() < 0.3: reqs.append(fx.req(fx.CAPACITY_TYPE, "In", vr.choice(["spot", "on-demand", "reserved"])))
+            if vr.random() < 0.15: reqs.append(fx.req(fx.HOSTNAME, vr.choice(["In", "NotIn"]), vr.choice(["node-0", "node-1", "elsewhere"])))
+            return reqs or [fx.req(fx.ARCH, "In", vr.choice(["amd64", "arm64"]))]
+        for p in pods:
+            if vr.random() < 0.25:
+                p["volumeRequirements"] = [alt() for _ in range(vr.choice([1, 1, 2, 3]))]
     prob = fx.problem(its, pools, pods, state_nodes=nodes, cluster_pods=cluster, daemonset_pods=daemons, options=opts)
     want = oracle.solve(prob)
     invariants.check(prob, want)
@@ -93,6 +105,17 @@ def run(oracle, emu, seed):
 def test_cross_feature_fuzz(oracle, emu, block):
     for seed in range(block * 40, block * 40 + 40):
         run(oracle, emu, seed)
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_cross_feature_fuzz_with_volume_alternatives(oracle, emu, block):
+    """The same problems with volume requirement alternatives on a quarter of the pods: every later stage of CanAdd —
+    topology, daemon overhead groups, minValues (Strict and BestEffort), reservations (Strict and Fallback), NodePool limits,
+    relaxation — now runs once per alternative (nodeclaim.go:149-157, existingnode.go:116-139)."""
+    solved = 0
+    for seed in range(block * 40, block * 40 + 40):
+        solved += run(oracle, emu, seed, volumes=True)[0] != "unsupported"
+    assert solved >= 35
 
 
 def run_wide(oracle, emu, seed):

@@ -57,3 +57,20 @@ def test_valid_result_passes_and_corruptions_are_caught(oracle):
     bad["newNodeClaims"][0]["pods"].pop()
     with pytest.raises(AssertionError):
         invariants.check(prob, bad)
+
+
+def test_volume_requirement_alternatives_invariant(oracle):
+    zone = lambda *z: fx.req(fx.ZONE, "In", *z)
+    pods = [fx.pod(requests={"cpu": "500m"}, volume_requirements=[[zone("test-zone-1")], [zone("test-zone-3")]]),
+            fx.pod(requests={"cpu": "500m"}, volume_requirements=[[fx.req(fx.ZONE, "NotIn", "test-zone-1", "test-zone-2")]])]
+    prob = fx.problem(fx.fake_default_instance_types(), [fx.node_pool(requirements=[zone("test-zone-2", "test-zone-3")])], pods)
+    res = oracle.solve(prob)
+    invariants.check(prob, res)
+    assert not res["podErrors"]
+    bad = copy.deepcopy(res)                       # the claim drifts to a zone no alternative admits
+    for c in bad["newNodeClaims"]:
+        for q in c["requirements"]:
+            if q["key"] == fx.ZONE:
+                q["values"] = ["test-zone-2"]
+    with pytest.raises(AssertionError, match="no volume requirement alternative"):
+        invariants.check(prob, bad)
