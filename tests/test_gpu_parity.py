@@ -422,6 +422,17 @@ def test_host_ports_on_the_device(oracle):
     tda.test_host_ports_fuzz(oracle, None)
 
 
+def test_cross_feature_fuzz_on_the_device(oracle):
+    """tests/test_device_fuzz_all.py's cross-feature problems (topology, daemon groups, minValues, reservations, limits,
+    relaxation, existing nodes) through libksolve.so: thirty as they are, thirty with volume requirement alternatives."""
+    import test_device_fuzz_all as tdf
+    solved = 0
+    for seed in range(30):
+        solved += tdf.run(oracle, None, seed)[0] != "unsupported"
+        solved += tdf.run(oracle, None, seed, volumes=True)[0] != "unsupported"
+    assert solved >= 50
+
+
 @pytest.mark.parametrize("at", [5 * 1024, 150 * 1024])
 def test_cancel_at_a_poll_boundary_on_the_device(monkeypatch, at):
     """A cancellation that lands at a poll boundary leaves exactly the full run stopped there (claim order included), on both
