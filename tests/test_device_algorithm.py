@@ -1022,3 +1022,20 @@ def test_volume_requirement_alternatives_at_scale(oracle, emu):
     np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
     got, _ = check(oracle, emu, fx.problem(its, [np_], pods, well_known=fx.KWOK_WELL_KNOWN, state_nodes=nodes))
     assert len(got["newNodeClaims"]) > 100 and sum(len(e["pods"]) for e in got["existingNodes"]) > 0
+
+
+def test_volume_requirement_alternatives_edge_cases(oracle, emu):
+    """An alternative without requirements (admits everything), Exists / DoesNotExist and Gt / Lt inside an alternative (the
+    bounds go through the working-set path of CanAdd), an alternative list that ends in the empty one."""
+    its = fx.fake_default_instance_types()
+    zone = lambda *z: fx.req(fx.ZONE, "In", *z)
+    pods = [fx.pod(volume_requirements=[[]]), fx.pod(volume_requirements=[[], [zone("test-zone-1")]]),
+            fx.pod(node_selector={fx.ZONE: "test-zone-2"}, volume_requirements=[[zone("test-zone-1")], []]),
+            fx.pod(volume_requirements=[[fx.req(fx.ZONE, "Exists")]]), fx.pod(volume_requirements=[[fx.req(fx.ZONE, "DoesNotExist")]]),
+            fx.pod(volume_requirements=[[fx.req(fx.FAKE_INTEGER_LABEL, "Gt", "2")]]),
+            fx.pod(volume_requirements=[[fx.req(fx.FAKE_INTEGER_LABEL, "Lt", "1")], [fx.req(fx.FAKE_INTEGER_LABEL, "Gt", "3")]])]
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], pods))
+    assert len(got["podErrors"]) == 1 and pods[4]["uid"] in got["podErrors"]      # a zone that must not exist: every offering has one
+    by = {t["name"]: t for t in its}
+    nodes = [fx.state_node("n1", by["default-instance-type"], "test-zone-1"), fx.state_node("n2", by["arm-instance-type"], "test-zone-2")]
+    check(oracle, emu, fx.problem(its, [fx.node_pool()], pods, state_nodes=nodes))
