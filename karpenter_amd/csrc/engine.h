@@ -1204,7 +1204,11 @@ struct Engine {
     if (FULL && P.hp_on && cur_hp_use) W::store(&S.c_hp[c], (uint64_t)(S.c_hp[c] | cur_hp_use));   // HostPortUsage.Add — nodeclaim.go:256-259
     finish_record(c, sc.claim, its_changed, tmpl, np + 1, lo32(sc.claim[ly.c_meta2()]), m2, out_cold);
     order.increment(c);
-    if (changed) reset_column(c);
+    // A class the claim rejected before topology stays rejected while the claim only narrows (value sets, instance types and
+    // headroom shrink; bound host ports grow). The one way back is a key that becomes DEFINED on the claim: a pod's In / Exists
+    // on a custom label the claim did not carry is "undefined key" (requirements.go:185-193) until another pod's NotIn /
+    // DoesNotExist has put the key there. Only then are the column's verdicts void.
+    if (changed && lo32(sc.out[ly.c_f0()]) != lo32(sc.claim[ly.c_f0()])) reset_column(c);
     commit_pod(pod, c, np);
     ctr.cycles[6] += W::clock() - t2;
     return E_OK;
@@ -1684,13 +1688,16 @@ struct Engine {
       const ReqBuf& m = *fin;
       uint64_t* nm = S.n_mask;
       if (changed) {
+        const bool key_defined = m.defined != Sw.n_defined[en];   // see try_claim: only a newly defined key voids the node's verdicts
         W::for_n(ly.rw, [&](int w) { nm[(size_t)w * ne + en] = m.mask[w]; });
         W::store(&S.n_defined[en], m.defined);
         W::store(&S.n_complement[en], m.complement);
-        uint64_t* nd = S.n_dead;
-        const int nwd = P.node_words;
-        const uint64_t clr = ~(1ull << (en & 63));
-        W::for_n(P.n_classes, [&](int kk) { nd[(size_t)kk * nwd + (en >> 6)] &= clr; });
+        if (key_defined) {
+          uint64_t* nd = S.n_dead;
+          const int nwd = P.node_words;
+          const uint64_t clr = ~(1ull << (en & 63));
+          W::for_n(P.n_classes, [&](int kk) { nd[(size_t)kk * nwd + (en >> 6)] &= clr; });
+        }
       }
       if (cur_rec) topo_record(Pv.node_taints[en], m.ref(), 1, en);              // existingnode.go:184
       int64_t* nrem = S.n_remaining;

@@ -1039,3 +1039,37 @@ def test_volume_requirement_alternatives_edge_cases(oracle, emu):
     by = {t["name"]: t for t in its}
     nodes = [fx.state_node("n1", by["default-instance-type"], "test-zone-1"), fx.state_node("n2", by["arm-instance-type"], "test-zone-2")]
     check(oracle, emu, fx.problem(its, [fx.node_pool()], pods, state_nodes=nodes))
+
+
+def test_a_rejected_class_comes_back_when_its_key_becomes_defined(oracle, emu):
+    """The per-(class, bin) rejections the scan keeps are final while a bin only narrows — except for the undefined-key rule of
+    Requirements.Compatible (requirements.go:185-193): `rack In [r1]` on a custom label the NodeClaim does not carry is
+    rejected, a later pod's `rack NotIn [r2]` is not (negative operators may meet an undefined key) and DEFINES the key on the
+    claim (Add, requirements.go:133-140), after which `In [r1]` intersects it. The pod that failed is retried by the queue
+    (queue.go:52-66) and must find the bin open again; the same on an existing node (existingnode.go:100-106)."""
+    its = fx.fake_default_instance_types()
+    rack = "example.com/rack"
+    first = fx.pod(requests={"cpu": "2"})
+    wants = [fx.pod(requests={"cpu": "1500m"}, node_requirements=[fx.req(rack, "In", "r1")]) for _ in range(2)]
+    opens = fx.pod(requests={"cpu": "1"}, node_requirements=[fx.req(rack, "NotIn", "r2")])
+    exists = fx.pod(requests={"cpu": "900m"}, node_requirements=[fx.req(rack, "Exists")])
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [first] + wants + [opens, exists]))
+    on = {u: c["hostname"] for c in got["newNodeClaims"] for u in c["pods"]}
+    assert not got["podErrors"] and on[wants[0]["uid"]] == on[opens["uid"]]
+    # without the NotIn pod the key never appears: the In / Exists pods cannot be scheduled at all
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [first] + wants + [exists]))
+    assert len(got["podErrors"]) == 3
+    # an existing node: the key is not among its labels
+    by = {t["name"]: t for t in its}
+    node = fx.state_node("node-a", by["arm-instance-type"], "test-zone-1")
+    got, _ = check(oracle, emu, fx.problem(its, [fx.node_pool()], [first] + wants + [opens, exists], state_nodes=[node]))
+    assert not got["podErrors"] and sum(len(e["pods"]) for e in got["existingNodes"]) >= 3
+    # many of them, with zonal spread narrowing the claims in between (a change that defines no key)
+    lab = {"app": "z"}
+    pods = []
+    for i in range(60):
+        pods.append(fx.pod(requests={"cpu": f"{2000 - 10 * i}m"}, node_requirements=[fx.req(rack, "In", f"r{i % 3}")]))
+        pods.append(fx.pod(requests={"cpu": f"{900 - 5 * i}m"}, node_requirements=[fx.req(rack, "NotIn", f"r{(i + 1) % 3}")]))
+        pods.append(fx.pod(labels=lab, requests={"cpu": f"{700 - 5 * i}m"}, topology_spread=[fx.spread(fx.ZONE, lab)]))
+    check(oracle, emu, fx.problem(its, [fx.node_pool()], pods))
+    check(oracle, emu, fx.problem(its, [fx.node_pool()], pods, state_nodes=[node, fx.state_node("node-b", by["arm-instance-type"], "test-zone-2")]))
