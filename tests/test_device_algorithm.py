@@ -1073,3 +1073,36 @@ def test_a_rejected_class_comes_back_when_its_key_becomes_defined(oracle, emu):
         pods.append(fx.pod(labels=lab, requests={"cpu": f"{700 - 5 * i}m"}, topology_spread=[fx.spread(fx.ZONE, lab)]))
     check(oracle, emu, fx.problem(its, [fx.node_pool()], pods))
     check(oracle, emu, fx.problem(its, [fx.node_pool()], pods, state_nodes=[node, fx.state_node("node-b", by["arm-instance-type"], "test-zone-2")]))
+
+
+def test_undefined_key_revival_fuzz(oracle, emu):
+    """Custom labels that no NodePool or instance type defines, under every operator: In / Exists / Gt fail on a bin until a
+    NotIn / DoesNotExist pod has defined the key there, the queue retries the failed pods (queue.go:52-66) — the rejections
+    the scan remembers must be dropped exactly when a key becomes defined. Claims and existing nodes, with zonal spread
+    narrowing the bins in between."""
+    keys = ["example.com/rack", "example.com/tier"]
+    revived = 0
+    for seed in range(24):
+        rng = random.Random(5200 + seed)
+        its = fx.fake_default_instance_types() if seed % 2 else fx.fake_instance_types(rng.choice([6, 12]))
+        by = {t["name"]: t for t in its}
+        lab = {"app": "s"}
+        pods = []
+        for i in range(rng.choice([30, 70])):
+            kw = {}
+            r = rng.random()
+            if r < 0.55:
+                k = rng.choice(keys)
+                op = rng.choice(["In", "In", "NotIn", "NotIn", "Exists", "DoesNotExist", "Gt"])
+                vals = [] if op in ("Exists", "DoesNotExist") else (["2"] if op == "Gt" else rng.sample(["1", "3", "5", "x"], rng.choice([1, 2])))
+                kw["node_requirements"] = [fx.req(k, op, *vals)]
+            elif r < 0.7:
+                kw.update(labels=lab, topology_spread=[fx.spread(fx.ZONE, lab)])
+            pods.append(fx.pod(requests={"cpu": f"{rng.choice([100, 300, 700, 1500])}m"}, **kw))
+        nodes = [fx.state_node(f"node-{i}", by[rng.choice(sorted(by))], rng.choice(["test-zone-1", "test-zone-2"]),
+                               extra_labels=({keys[0]: "3"} if rng.random() < 0.3 else None)) for i in range(rng.choice([0, 2]))]
+        pool = fx.node_pool(labels={keys[1]: "1"} if rng.random() < 0.25 else None)
+        got, _ = check(oracle, emu, fx.problem(its, [pool], pods, state_nodes=nodes))
+        placed = {u for c in got["newNodeClaims"] for u in c["pods"]} | {u for e in got["existingNodes"] for u in e["pods"]}
+        revived += sum(1 for p in pods if p["uid"] in placed and any(r["operator"] in ("In", "Exists", "Gt") and r["key"] in keys for term in (p.get("nodeAffinity") or {}).get("required", []) for r in term))
+    assert revived > 20     # positive operators on an undefined custom key got a bin: only possible through a key that became defined
