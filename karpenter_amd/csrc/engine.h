@@ -1158,6 +1158,27 @@ struct Engine {
     if (is_closed && W::leader()) L.closed[c >> 6] |= 1ull << (c & 63);
     W::sync();
   }
+  // Keys whose Operator() is Exists (requirement.go:290-301): a complement set that excludes nothing (bare Exists, Gt, Lt).
+  // `mask` = the record's requirement words at stride `stride`.
+  template <class M>
+  KS_DEV uint32_t exists_keys(uint32_t complement, M mask_word) {
+    if (!complement) return 0;
+    const uint8_t* wk = sc.word_key;
+    const uint32_t nonempty = (uint32_t)W::reduce_or(lay.rw, [&](int l) { return mask_word(l) ? (uint64_t)1 << wk[l] : (uint64_t)0; });
+    return complement & ~nonempty;
+  }
+  // Does a commit that turned requirement set `before` into `after` void the rejections cached for this bin? A class
+  // rejected before topology stays rejected while the bin only narrows (value sets, instance types and headroom shrink; bound
+  // host ports grow). Two ways back, both through Requirements.Compatible:
+  //   * a key becomes DEFINED on the bin: a pod's In / Exists on a custom label the bin did not carry is "undefined key"
+  //     (requirements.go:185-193) until another pod's NotIn / DoesNotExist has put the key there;
+  //   * a key's operator goes from Exists to NotIn (another pod's NotIn narrowed a bare Exists / Gt / Lt): Intersects lets a
+  //     NotIn / DoesNotExist pair through whatever their values (requirements.go:258-265), so a `k DoesNotExist` pod the
+  //     `k Exists` bin rejected is compatible with the `k NotIn [x]` bin.
+  // Every other operator change leaves the NotIn / DoesNotExist class or stays inside it.
+  KS_DEV bool revives_rejections(uint32_t def_before, uint32_t def_after, uint32_t exists_before, uint32_t exists_after) {
+    return def_before != def_after || (exists_before & ~exists_after) != 0;
+  }
   KS_DEV void reset_column(int c) {
     KS_DIAG(ctr.column_resets++);
     uint64_t* dead = S.dead;
@@ -1204,11 +1225,13 @@ struct Engine {
     if (FULL && P.hp_on && cur_hp_use) W::store(&S.c_hp[c], (uint64_t)(S.c_hp[c] | cur_hp_use));   // HostPortUsage.Add — nodeclaim.go:256-259
     finish_record(c, sc.claim, its_changed, tmpl, np + 1, lo32(sc.claim[ly.c_meta2()]), m2, out_cold);
     order.increment(c);
-    // A class the claim rejected before topology stays rejected while the claim only narrows (value sets, instance types and
-    // headroom shrink; bound host ports grow). The one way back is a key that becomes DEFINED on the claim: a pod's In / Exists
-    // on a custom label the claim did not carry is "undefined key" (requirements.go:185-193) until another pod's NotIn /
-    // DoesNotExist has put the key there. Only then are the column's verdicts void.
-    if (changed && lo32(sc.out[ly.c_f0()]) != lo32(sc.claim[ly.c_f0()])) reset_column(c);
+    // the column of cached rejections is cleared only when the new requirement set can bring a class back (revives_rejections)
+    if (changed) {
+      const uint64_t* cb = sc.claim + ly.c_mask(); const uint64_t* co = sc.out + ly.c_mask();
+      const uint32_t ex_b = exists_keys(hi32(sc.claim[ly.c_f0()]), [&](int l) { return cb[l]; });
+      const uint32_t ex_a = ex_b ? exists_keys(hi32(sc.out[ly.c_f0()]), [&](int l) { return co[l]; }) : 0;
+      if (revives_rejections(lo32(sc.claim[ly.c_f0()]), lo32(sc.out[ly.c_f0()]), ex_b, ex_a)) reset_column(c);
+    }
     commit_pod(pod, c, np);
     ctr.cycles[6] += W::clock() - t2;
     return E_OK;
@@ -1623,21 +1646,26 @@ struct Engine {
         for (int r = 0; r < nr; ++r) { int64_t rem = Sw.n_remaining[(size_t)r * ne + e_]; fit = fit && rem >= 0 && req[r] <= rem; }
         if (!fit) return false;
         const uint32_t ndef = Sw.n_defined[e_], ncomp = Sw.n_complement[e_];
+        const uint32_t nhg = Sw.n_hg ? Sw.n_hg[e_] : 0u, nhl = Sw.n_hg ? Sw.n_hl[e_] : 0u;   // bounds a Gt / Lt pod left on the node
         if (kdef & ~ndef & ~kneg) return false;                                           // undefined key — requirements.go:185-193
         for (uint32_t both = kdef & ndef; both; both &= both - 1) {                       // Intersects — requirements.go:254-274
           const int key = __builtin_ctz(both);
           const bool ca = (ncomp >> key) & 1, cb = (kcomp >> key) & 1;
-          if (ca && cb) continue;
-          const bool hg = (khg >> key) & 1, hl = (khl >> key) & 1;
+          bool hg = (khg >> key) & 1, hl = (khl >> key) & 1;
+          int64_t g = hg ? ((const int64_t*)cls_cold)[key] : 0, lq = hl ? ((const int64_t*)cls_cold)[ly.nk + key] : 0;
+          if ((nhg >> key) & 1) { const int64_t v = Sw.n_gte[(size_t)key * ne + e_]; g = hg && g > v ? g : v; hg = true; }   // maxIntPtr / minIntPtr — requirement.go:352-376
+          if ((nhl >> key) & 1) { const int64_t v = Sw.n_lte[(size_t)key * ne + e_]; lq = hl && lq < v ? lq : v; hl = true; }
+          const bool empty_bounds = hg && hl && g > lq;                                     // HasIntersection — requirement.go:220-224
+          if (ca && cb && !empty_bounds) continue;
           bool hit = false, nonempty_n = false;
           for (uint32_t w = d.key_word_off[key]; w < d.key_word_off[key + 1]; ++w) {
             const uint64_t a = Sw.n_mask[(size_t)w * ne + e_], b = cls[ly.k_mask() + w];
             nonempty_n = nonempty_n || a != 0;
             uint64_t c = ca ? (b & ~a) : cb ? (a & ~b) : (a & b);
-            if (c && (hg || hl)) c = inbounds_word(d, w, c, hg, hg ? ((const int64_t*)cls_cold)[key] : 0, hl, hl ? ((const int64_t*)cls_cold)[ly.nk + key] : 0);
+            if (c && (hg || hl)) c = inbounds_word(d, w, c, hg, g, hl, lq);
             hit = hit || c != 0;
           }
-          if (hit) continue;
+          if (hit && !empty_bounds) continue;
           const bool neg_n = ca ? nonempty_n : !nonempty_n;
           if (neg_n && ((kneg >> key) & 1)) continue;
           return false;
@@ -1688,10 +1716,19 @@ struct Engine {
       const ReqBuf& m = *fin;
       uint64_t* nm = S.n_mask;
       if (changed) {
-        const bool key_defined = m.defined != Sw.n_defined[en];   // see try_claim: only a newly defined key voids the node's verdicts
+        // the same predicate as try_claim (node labels are single-valued In sets today, so only the defined-key half can fire)
+        const uint32_t ex_b = exists_keys(Sw.n_complement[en], [&](int l) { return nm[(size_t)l * ne + en]; });
+        const uint32_t ex_a = ex_b ? exists_keys(m.complement, [&](int l) { return m.mask[l]; }) : 0;
+        const bool key_defined = revives_rejections(Sw.n_defined[en], m.defined, ex_b, ex_a);
         W::for_n(ly.rw, [&](int w) { nm[(size_t)w * ne + en] = m.mask[w]; });
         W::store(&S.n_defined[en], m.defined);
         W::store(&S.n_complement[en], m.complement);
+        if (S.n_hg) {
+          int64_t* ng = S.n_gte; int64_t* nl = S.n_lte;
+          W::for_n(ly.nk, [&](int kk) { ng[(size_t)kk * ne + en] = m.gte[kk]; nl[(size_t)kk * ne + en] = m.lte[kk]; });
+          W::store(&S.n_hg[en], m.has_gte);
+          W::store(&S.n_hl[en], m.has_lte);
+        }
         if (key_defined) {
           uint64_t* nd = S.n_dead;
           const int nwd = P.node_words;
@@ -1720,8 +1757,13 @@ struct Engine {
     const uint64_t* nm = S.n_mask;
     W::for_n(lay.rw, [&](int w) { m.mask[w] = nm[(size_t)w * ne + en]; });
     if (W::leader()) {
-      m.defined = S.n_defined[en]; m.complement = S.n_complement[en]; m.has_gte = m.has_lte = m.has_minv = 0;
-      for (int kk = 0; kk < lay.nk; ++kk) { m.gte[kk] = 0; m.lte[kk] = 0; m.minv[kk] = -1; }
+      m.defined = S.n_defined[en]; m.complement = S.n_complement[en]; m.has_minv = 0;
+      m.has_gte = S.n_hg ? S.n_hg[en] : 0u; m.has_lte = S.n_hg ? S.n_hl[en] : 0u;
+      for (int kk = 0; kk < lay.nk; ++kk) {
+        m.gte[kk] = ((m.has_gte >> kk) & 1u) ? S.n_gte[(size_t)kk * ne + en] : 0;
+        m.lte[kk] = ((m.has_lte >> kk) & 1u) ? S.n_lte[(size_t)kk * ne + en] : 0;
+        m.minv[kk] = -1;
+      }
     }
     W::sync();
     ReqRef q = class_ref(sc.cls, sc.cls_cold);
@@ -1873,6 +1915,7 @@ struct Engine {
       W::for_n(lay.nr * ne, [&](int i) { Sw.n_remaining[i] = Sw.n_remaining0[i]; });
       W::for_n(ne, [&](int i) { Sw.n_defined[i] = Sw.n_defined0[i]; Sw.n_complement[i] = Sw.n_complement0[i]; Sw.n_npods[i] = 0; });
       if (P.hp_on) { const uint64_t* h0 = P.node_hp0; W::for_n(ne, [&](int i) { Sw.n_hp[i] = h0 ? h0[i] : 0ull; }); }
+      if (Sw.n_hg) W::for_n(ne, [&](int i) { Sw.n_hg[i] = 0; Sw.n_hl[i] = 0; });
     }
     if (FULL && P.topo.n_groups) {
       const TopoView& T = P.topo;

@@ -408,6 +408,10 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       h->ws.n_remaining0 = up(h, d->node_remaining, (size_t)d->n_res * ne);
       h->ws.n_mask = dz<uint64_t>(h, tm.size());
       h->ws.n_defined = dz<uint32_t>(h, ne); h->ws.n_complement = dz<uint32_t>(h, ne);
+      if (any_nonzero(d->pod_reqs.has_gte, d->n_pod_rows) || any_nonzero(d->pod_reqs.has_lte, d->n_pod_rows)) {
+        h->ws.n_hg = dz<uint32_t>(h, ne); h->ws.n_hl = dz<uint32_t>(h, ne);
+        h->ws.n_gte = dz<int64_t>(h, (size_t)d->n_keys * ne); h->ws.n_lte = dz<int64_t>(h, (size_t)d->n_keys * ne);
+      }
       h->ws.n_remaining = dz<int64_t>(h, (size_t)d->n_res * ne);
       h->ws.n_npods = dz<uint32_t>(h, ne);
       h->ws.n_hp = P.hp_on ? dz<uint64_t>(h, ne) : nullptr;
@@ -701,6 +705,10 @@ static ksolve_status probe_create(ksolve_handle* base, const ksolve_probe* pr, k
       W.n_dead = (uint64_t*)take((size_t)std::max(1u, nc) * nw * 8);
       W.n_mask = (uint64_t*)take((size_t)h->req_words * ne * 8);
       W.n_defined = (uint32_t*)take((size_t)ne * 4); W.n_complement = (uint32_t*)take((size_t)ne * 4);
+      if (base->ws.n_hg) {
+        W.n_hg = (uint32_t*)take((size_t)ne * 4); W.n_hl = (uint32_t*)take((size_t)ne * 4);
+        W.n_gte = (int64_t*)take((size_t)base->pv.dict.n_keys * ne * 8); W.n_lte = (int64_t*)take((size_t)base->pv.dict.n_keys * ne * 8);
+      }
       W.n_remaining = (int64_t*)take((size_t)nr * ne * 8);
       W.n_npods = (uint32_t*)take((size_t)ne * 4);
       W.n_hp = P.hp_on ? (uint64_t*)take((size_t)ne * 8) : nullptr;

@@ -238,6 +238,8 @@ struct Workspace {
   // existing nodes (mutable part): ExistingNode.requirements / remainingResources / Pods (existingnode.go:32-45)
   uint64_t* n_mask;              // [req_words][n_nodes]
   uint32_t *n_defined, *n_complement; // [n_nodes]
+  uint32_t *n_hg, *n_hl;         // [n_nodes] keys with an integer bound on the node (nullptr: no pod of the problem carries Gt / Lt). Labels have none;
+  int64_t *n_gte, *n_lte;        // [n_keys][n_nodes]   a Gt / Lt pod leaves one on a key a NotIn pod defined there (requirement.go:181-214)
   int64_t* n_remaining;          // [n_res][n_nodes]
   uint32_t* n_npods;             // [n_nodes]
   uint64_t* n_dead;              // [n_classes][node_words] node known infeasible for the class

@@ -42,7 +42,7 @@ json.dump(out, open(O + "/pmc_pack_traffic.json", "w"), indent=1)
 print(out)
 PY
 # lone-wave cost model, cursor-engine per-path counters, the resident-cluster consolidation sweep
-(cd tests/tools/ubench && ./branch_cost && ./lds_latency) > $O/ubench.log 2>&1; cat $O/ubench.log
+(cd tests/tools/ubench && for b in branch_cost lds_latency; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $b $b.hip; done && ./branch_cost && ./lds_latency) > $O/ubench.log 2>&1; cat $O/ubench.log
 bash scripts/gpu_fast_phases.sh | grep -v upload_us > $O/fast_phases.log 2>&1; tail -12 $O/fast_phases.log
 timeout 900 python tests/tools/consolidation_sweep.py 10000 256 6 --types 500 --out $O/consolidation_sweep_10k_256.json > $O/sweep.log 2>&1
 tail -c 1500 $O/sweep.log

@@ -1075,6 +1075,33 @@ def test_a_rejected_class_comes_back_when_its_key_becomes_defined(oracle, emu):
     check(oracle, emu, fx.problem(its, [fx.node_pool()], pods, state_nodes=[node, fx.state_node("node-b", by["arm-instance-type"], "test-zone-2")]))
 
 
+def test_a_rejected_class_comes_back_when_exists_becomes_notin(oracle, emu):
+    """The second way a rejected class comes back (round-2 advisor finding): Intersects lets a NotIn / DoesNotExist pair through
+    whatever the values (requirements.go:258-265), and the claim's Operator() depends on its current value set
+    (requirement.go:290-301). A claim holding `rack Exists` (from the NodePool) rejects a `rack DoesNotExist` pod; a
+    `rack NotIn [x]` pod narrows the claim to NotIn [x]; the DoesNotExist pod, retried by the queue (queue.go:52-66), is now
+    compatible with that claim — the defined-key mask never changed, so only the operator-class rule drops the stale verdict."""
+    its = fx.fake_default_instance_types()
+    rack = "example.com/rack"
+    for op, vals in (("Exists", []), ("Gt", ["1"]), ("Lt", ["9"])):
+        pool = fx.node_pool(requirements=[fx.req(rack, op, *vals)])
+        first = fx.pod(requests={"cpu": "900m"})
+        absent = fx.pod(requests={"cpu": "700m"}, node_requirements=[fx.req(rack, "DoesNotExist")])
+        notin = fx.pod(requests={"cpu": "300m"}, node_requirements=[fx.req(rack, "NotIn", "5")])
+        got, _ = check(oracle, emu, fx.problem(its, [pool], [first, absent, notin]))
+        on = {u: c["hostname"] for c in got["newNodeClaims"] for u in c["pods"]}
+        assert not got["podErrors"] and on[absent["uid"]] == on[first["uid"]] == on[notin["uid"]], op
+    # many claims, with In pods and zonal spread narrowing them in between
+    lab = {"app": "z"}
+    pods = []
+    for i in range(50):
+        pods.append(fx.pod(requests={"cpu": f"{2000 - 10 * i}m"}, node_requirements=[fx.req(rack, "DoesNotExist")]))
+        pods.append(fx.pod(requests={"cpu": f"{900 - 5 * i}m"}, node_requirements=[fx.req(rack, "NotIn", f"r{i % 3}")]))
+        pods.append(fx.pod(requests={"cpu": f"{800 - 5 * i}m"}, node_requirements=[fx.req(rack, "In", f"r{(i + 1) % 3}")]))
+        pods.append(fx.pod(labels=lab, requests={"cpu": f"{700 - 5 * i}m"}, topology_spread=[fx.spread(fx.ZONE, lab)]))
+    check(oracle, emu, fx.problem(its, [fx.node_pool(requirements=[fx.req(rack, "Exists")])], pods))
+
+
 def test_undefined_key_revival_fuzz(oracle, emu):
     """Custom labels that no NodePool or instance type defines, under every operator: In / Exists / Gt fail on a bin until a
     NotIn / DoesNotExist pod has defined the key there, the queue retries the failed pods (queue.go:52-66) — the rejections
@@ -1102,6 +1129,8 @@ def test_undefined_key_revival_fuzz(oracle, emu):
         nodes = [fx.state_node(f"node-{i}", by[rng.choice(sorted(by))], rng.choice(["test-zone-1", "test-zone-2"]),
                                extra_labels=({keys[0]: "3"} if rng.random() < 0.3 else None)) for i in range(rng.choice([0, 2]))]
         pool = fx.node_pool(labels={keys[1]: "1"} if rng.random() < 0.25 else None)
+        if seed % 3 == 2:   # the key is on the claim from the start under an Exists-class operator: revival through Exists -> NotIn
+            pool = fx.node_pool(requirements=[fx.req(keys[0], *rng.choice([("Exists",), ("Gt", "0"), ("Lt", "7")]))])
         got, _ = check(oracle, emu, fx.problem(its, [pool], pods, state_nodes=nodes))
         placed = {u for c in got["newNodeClaims"] for u in c["pods"]} | {u for e in got["existingNodes"] for u in e["pods"]}
         revived += sum(1 for p in pods if p["uid"] in placed and any(r["operator"] in ("In", "Exists", "Gt") and r["key"] in keys for term in (p.get("nodeAffinity") or {}).get("required", []) for r in term))
