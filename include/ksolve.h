@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KSOLVE_ABI_VERSION 6
+#define KSOLVE_ABI_VERSION 7
 #define KSOLVE_MAX_KEYS 32        /* requirement keys per problem (one bit each in the u32 flag words) */
 #define KSOLVE_MAX_RES 8          /* resource dimensions */
 #define KSOLVE_MAX_TEMPLATES 32   /* NodeClaimTemplates (NodePools that survived prefiltering) */
@@ -322,6 +322,44 @@ ksolve_status ksolve_solve_batch(ksolve_handle** handles, uint32_t n, ksolve_res
  * no pods). Works with ksolve_solve, ksolve_solve_batch, ksolve_cancel, ksolve_destroy. KSOLVE_ERR_UNSUPPORTED when the base
  * problem has topology groups (their per-probe counts are not derived yet: such sweeps create one handle per probe). */
 ksolve_status ksolve_probe_create(ksolve_handle* base, const ksolve_probe* probe, ksolve_handle** out);
+/* A whole consolidation sweep in ONE call: n_probes simulations of the resident cluster `base` — single-node consolidation
+ * tries every candidate (singlenodeconsolidation.go:55-126), multi-node consolidation every prefix its binary search can reach
+ * (multinodeconsolidation.go:117-207), the validator replays commands (validation.go:297-357); each of them is
+ * SimulateScheduling (disruption/helpers.go:53-155): Solve() on the cluster without the probe's nodes, with the probe's pods
+ * pending. The descriptors are CSR arrays (one upload), every probe is one wavefront of one launch, its workspace is a slice
+ * of one arena that the base handle keeps between calls (a probe owns only the claims it creates and an overlay of the few
+ * nodes it commits pods to; the cluster's tables stay shared and pristine), and the results come back in one download. */
+typedef struct {
+  uint32_t n_probes;
+  const uint32_t* node_off;        /* n_probes + 1 : CSR into nodes */
+  const uint32_t* nodes;           /* existing-node indices of the base problem that are not part of the simulation (the candidates) */
+  const uint32_t* pod_off;         /* n_probes + 1 : CSR into pods */
+  const uint32_t* pods;            /* pod indices of the base problem the simulation schedules, distinct within a probe, any order */
+  const int64_t* tmpl_limits;      /* NULL = the base problem's, else n_probes * n_templates * (n_res+1): NodePool limits with the removed
+                                    * nodes' capacity handed back (scheduler.go:835-842) */
+} ksolve_sweep_desc;
+
+typedef struct {
+  uint32_t n_probes;
+  const int32_t* status;           /* n_probes : ksolve_status of each simulation (KSOLVE_ERR_CAPACITY: more NodeClaims than a probe may hold) */
+  /* per pod, aligned with ksolve_sweep_desc.pods (same CSR offsets, same order as given) */
+  const int32_t* pod_assignment;   /* >= 0: index into THIS PROBE's claims (claim_off[p] + value is the row in `claims`); <= -2 existing node
+                                    * (-2 - node index); -1 unscheduled */
+  const uint8_t* pod_error;        /* ksolve_pod_error */
+  const uint8_t* pod_error_diag;
+  const uint32_t* pod_slot;        /* position of the pod inside its claim's / node's Pods slice (node slots count only this probe's pods) */
+  const uint32_t* claim_off;       /* n_probes + 1 : the probe's rows in `claims`, in the order the reference's s.newNodeClaims ends in */
+  ksolve_claims claims;            /* every probe's NodeClaims, concatenated */
+  const uint64_t* ref_bin_evaluations;   /* n_probes : V of each simulation */
+  double us_upload, us_pack, us_finalize, us_download;
+  void* impl;
+} ksolve_sweep_results;
+
+/* Runs the sweep. One sweep (or solve) per base handle at a time. KSOLVE_ERR_UNSUPPORTED when the base problem has topology
+ * groups (see ksolve_probe_create). The function's status is that of the call (arguments, device); each simulation's own
+ * status is in results.status. */
+ksolve_status ksolve_sweep(ksolve_handle* base, const ksolve_sweep_desc* desc, ksolve_sweep_results* out);
+void ksolve_sweep_results_free(ksolve_sweep_results* r);
 /* Asks a running ksolve_solve on another thread to stop at the next pod boundary (ctx cancellation). */
 ksolve_status ksolve_cancel(ksolve_handle* h);
 void ksolve_results_free(ksolve_results* r);

@@ -22,6 +22,7 @@
 // stays valid; when a commit changes the claim's requirements the claim's column is cleared for every class.
 #pragma once
 #include "ksp.h"
+#include "nodecheck.h"
 #include <type_traits>
 #include "pdq_emul.h"
 #include "run_order.h"
@@ -70,7 +71,7 @@ struct Scratch {
   uint64_t cls_cold[kMaxCold];
   uint64_t out[kMaxHot];            // record being committed
   uint64_t out_cold[kMaxCold];
-  uint32_t blk_pod[64], blk_class[64], blk_last[64];
+  uint32_t blk_pod[64], blk_class[64], blk_last[64], blk_out[64];   // the queue block being placed: pod, class, lastLen, output index
   uint64_t tmpl_taints[32];         // template taint masks
   int64_t min_request[kMaxRes];     // min over classes per dimension (closed-claim test)
   int32_t cache_tag[32];            // claim id held by each record-cache line, -1 = empty
@@ -152,6 +153,8 @@ struct Engine {
   uint32_t cur_vol_first = 0, cur_vol_n = 0;  // volume requirement alternatives of the pod being placed (PodData.VolumeRequirements)
   uint64_t bin_hp = 0;                        // host-port triples already bound by the pods of the candidate bin
   bool topo_reached = false;        // the last can_add got as far as the topology stage (its verdict is not cacheable)
+  int cur_out = 0;                  // where the pod being placed reports its result: its pod index, or its position in Workspace::pr_sorted (probes)
+  int n_revived = 0;                // probes: entries of Workspace::pr_revived
 
   KS_DEV Engine(const ProblemView& p, Workspace& s, const LdsTables& l) : P(p), S(s), L(l), sc(*l.scratch), lay(p.lay) {
     if constexpr (BIG) order.init(L.runs, s.o_ring, s.o_cnt, s.o_pos, s.o_key, s.o_ord, s.run_tabs, s.run_off, s.run_log, s.run_kmax);
@@ -212,7 +215,7 @@ struct Engine {
     uint64_t* tt = sc.tmpl_taints; int64_t* mr = sc.min_request; int32_t* tag = sc.cache_tag;
     W::for_n(32, [&](int t) { tt[t] = t < Pv.n_templates ? Pv.tmpl_taints[t] : 0; tag[t] = -1; });
     W::for_n(nr, [&](int r) { mr[r] = Pv.min_request[r]; });
-    W::for_n(BIG ? Pv.lds.stage_words : Pv.lds.order_cap / 64, [&](int w) { Lt.closed[w] = 0; });
+    W::for_n(BIG ? Pv.lds.stage_words : (S.probe ? S.pr_order_cap : Pv.lds.order_cap) / 64, [&](int w) { Lt.closed[w] = 0; });
     W::sync();
     W::for_n(Pv.n_templates + 1, [&](int t) { sc.dg_first[t] = Pv.dg_first[t]; });
     W::for_n(Pv.n_dg * nr, [&](int i) { Lt.dg_ov[i] = Pv.dg_ov[i]; });
@@ -1188,8 +1191,9 @@ struct Engine {
     W::for_n(P.n_classes, [&](int k) { dead[(size_t)k * cw + word] &= clr; });
   }
   KS_DEV void commit_pod(int pod, int claim, uint32_t slot) {
-    W::store(&S.assign[pod], (int32_t)claim);
-    W::store(&S.slot[pod], slot);
+    (void)pod;
+    W::store(&S.assign[cur_out], (int32_t)claim);
+    W::store(&S.slot[cur_out], slot);
   }
 
   // ---- in-flight scan: addToInflightNode (scheduler.go:658-692) ---------------------------------------------
@@ -1557,7 +1561,7 @@ struct Engine {
       int rc = can_add(bin, tcold, true, first_err == 0, &changed, nullptr, -1);
       if (rc == E_RESERVED) { last_diag = 0; return E_RESERVED; }   // voids the lower-weight templates (scheduler.go:736-751)
       if (rc != E_OK) { if (!first_err) { first_err = rc; first_diag = (rc == E_INSTANCE_TYPES || rc == E_MIN_VALUES) ? last_diag : 0; } continue; }
-      if (n_claims >= S.max_claims || (!BIG && n_claims >= P.lds.order_cap)) { W::store(S.status_out, 1); return -1; }
+      if (n_claims >= S.max_claims || (!BIG && n_claims >= (S.probe ? S.pr_order_cap : P.lds.order_cap))) { W::store(S.status_out, 1); return -1; }
       int c = n_claims++;
       const uint32_t tm2 = hi32(trec[ly.c_meta2()]);
       uint64_t* o = sc.out;
@@ -1603,6 +1607,90 @@ struct Engine {
   // ---- existing nodes: addToExistingNode (scheduler.go:614-656), ExistingNode.CanAdd/Add (existingnode.go:81-185) ----
   // 64 nodes per step, one lane per node, SoA loads coalesced across lanes; the lowest passing index wins
   // (scheduler.go:639). Strict Compatible (no AllowUndefinedWellKnownLabels, existingnode.go:100).
+  //
+  // A probe of a resident cluster (Workspace::probe) reads the cluster's pristine, shared node tables and keeps the nodes it
+  // has committed pods to in its overlay (ov_*): the mutable n_* arrays are then indexed by overlay slot.
+  KS_DEV int nst() const { return S.probe ? S.ov_cap : P.n_nodes; }   // stride of the mutable node arrays
+  KS_DEV static uint32_t ov_hash(int e) { return (uint32_t)e * 2654435761u; }
+  // slot of node e's mutable state: e itself outside probes, its overlay slot or -1 (pristine) in a probe. Per lane.
+  KS_DEV int ov_find(int e) const {
+    if (!S.probe) return e;
+    const uint32_t m = (uint32_t)S.ov_cap - 1;
+    for (uint32_t h = (ov_hash(e) >> 8) & m;; h = (h + 1) & m) {
+      const uint32_t kx = S.ov_key[h];
+      if (kx == (uint32_t)e + 1u) return (int)h;
+      if (!kx) return -1;
+    }
+  }
+  KS_DEV NodeTabs node_tabs(bool overlay) const {
+    NodeTabs t;
+    if (overlay) { t.mask = S.n_mask; t.defined = S.n_defined; t.complement = S.n_complement; t.hg = S.n_hg; t.hl = S.n_hl; t.gte = S.n_gte; t.lte = S.n_lte; t.remaining = S.n_remaining; t.hp = P.hp_on ? S.n_hp : nullptr; t.stride = (size_t)nst(); }
+    else { t.mask = S.n_mask0; t.defined = S.n_defined0; t.complement = S.n_complement0; t.hg = nullptr; t.hl = nullptr; t.gte = nullptr; t.lte = nullptr; t.remaining = S.n_remaining0; t.hp = P.node_hp0; t.stride = (size_t)P.n_nodes; }
+    return t;
+  }
+  // the overlay slot of node en, created from the pristine tables when the probe touches the node for the first time
+  KS_DEV int ov_touch(int en) {
+    int os = ov_find(en);
+    if (os >= 0) return os;
+    const uint32_t m = (uint32_t)S.ov_cap - 1;
+    uint32_t h = (ov_hash(en) >> 8) & m;
+    while (S.ov_key[h]) h = (h + 1) & m;
+    os = (int)h;
+    const int ne = P.n_nodes, oc = S.ov_cap;
+    const Workspace& Sw = S;
+    const ProblemView& Pv = P;
+    uint64_t* nm = S.n_mask; int64_t* nrem = S.n_remaining;
+    W::for_n(lay.rw, [&](int w) { nm[(size_t)w * oc + os] = Sw.n_mask0[(size_t)w * ne + en]; });
+    W::for_n(lay.nr, [&](int r) { nrem[(size_t)r * oc + os] = Sw.n_remaining0[(size_t)r * ne + en]; });
+    if (W::leader()) {
+      S.n_defined[os] = S.n_defined0[en]; S.n_complement[os] = S.n_complement0[en]; S.n_npods[os] = 0;
+      if (S.n_hg) { S.n_hg[os] = 0; S.n_hl[os] = 0; }
+      if (Pv.hp_on) S.n_hp[os] = Pv.node_hp0 ? Pv.node_hp0[en] : 0ull;
+      S.ov_key[os] = (uint32_t)en + 1u;
+    }
+    W::sync();
+    return os;
+  }
+  // How many existing nodes before index `upto` the reference would have evaluated for this pod (probe mode): every node
+  // that is part of the simulation and not skipped by the consolidateAfter rule (scheduler.go:628).
+  KS_DEV unsigned long long probe_nodes_before(int upto, bool exempt_pod) const {
+    long long n = upto;
+    const int w = upto >> 6, bq = upto & 63;
+    if (!exempt_pod && P.node_skip) n -= (long long)P.node_skip_prefix[w] + (bq ? popc64(P.node_skip[w] & ((1ull << bq) - 1)) : 0);
+    for (int i = 0; i < S.pr_n_removed; ++i) {
+      const int r = (int)S.pr_removed[i];
+      if (r >= upto) break;
+      if (exempt_pod || !P.node_skip || !((P.node_skip[r >> 6] >> (r & 63)) & 1)) n--;
+    }
+    return (unsigned long long)n;
+  }
+  // probe mode: the next 64-node block after `base` that holds a node worth testing — not rejected in the pristine cluster
+  // (n_dead0; an overlaid node only narrows, so the verdict stands unless a commit revived it), part of the simulation, not
+  // skipped. The class's row is read 64 words (4096 nodes) per step. Returns the block's first node or -1; `todo` = its nodes.
+  KS_DEV int probe_next_block(int k, int base, bool exempt_pod, int n_revived, uint64_t* todo) {
+    const int ne = P.n_nodes, nw = P.node_words;
+    const uint64_t* drow = P.n_dead0 + (size_t)k * nw;
+    const uint64_t* skip = exempt_pod ? nullptr : P.node_skip;
+    const Workspace& Sw = S;
+    for (int w0 = (base >> 6) + 1; w0 < nw; w0 += 64) {
+      LaneVar<uint64_t> lv;
+      const uint64_t any = W::ballot([&](int l) {
+        const int w = w0 + l;
+        uint64_t live = 0;
+        if (w < nw) {
+          live = ~drow[w];
+          for (int i = 0; i < n_revived; ++i) { const uint32_t r = Sw.pr_revived[i]; if ((int)(r >> 6) == w) live |= 1ull << (r & 63); }
+          if (w == nw - 1 && (ne & 63)) live &= (1ull << (ne & 63)) - 1;
+          if (skip) live &= ~skip[w];
+          for (int i = 0; i < Sw.pr_n_removed; ++i) { const uint32_t r = Sw.pr_removed[i]; if ((int)(r >> 6) == w) live &= ~(1ull << (r & 63)); }
+        }
+        lv.at(l) = live;
+        return live != 0;
+      });
+      if (any) { const int l = ctz64(any); *todo = lv.bcast(l); return (w0 + l) * 64; }
+    }
+    return -1;
+  }
   KS_DEV bool add_to_existing(int k, int pod) {
     const int ne = P.n_nodes;
     if (ne == 0) return false;
@@ -1611,66 +1699,36 @@ struct Engine {
     const int nr = ly.nr;
     const Workspace& Sw = S;
     const ProblemView& Pv = P;
-    const uint64_t* cls = sc.cls;
-    const uint64_t* cls_cold = sc.cls_cold;
-    const uint32_t kdef = lo32(cls[ly.k_f0()]), kcomp = hi32(cls[ly.k_f0()]);
-    const uint32_t khg = lo32(cls[ly.k_f1()]), khl = hi32(cls[ly.k_f1()]);
-    const uint64_t ktol = cls[ly.k_tol()];
-    const uint64_t khpc = Pv.hp_on ? cur_hp_conf : 0ull;
-    const int64_t* req = (const int64_t*)(cls + ly.k_req());
-    // keys on which the pod's operator is NotIn / DoesNotExist (may be undefined on the node, requirements.go:188)
-    uint32_t kneg = 0;
-    for (uint32_t ks_ = kdef; ks_; ks_ &= ks_ - 1) {
-      int key = __builtin_ctz(ks_);
-      bool ne_ = false;
-      for (uint32_t w = d.key_word_off[key]; w < d.key_word_off[key + 1]; ++w) ne_ = ne_ || cls[ly.k_mask() + w] != 0;
-      if (((kcomp >> key) & 1) ? ne_ : !ne_) kneg |= 1u << key;
-    }
+    const bool probe = S.probe != 0;
+    const NodeClassCtx cx = node_class_ctx(d, ly, sc.cls, sc.cls_cold, Pv.hp_on ? cur_hp_conf : 0ull);
+    const int64_t* req = cx.req;
+    const NodeTabs mut = node_tabs(true), pris = node_tabs(false);
     const bool exempt_pod = Pv.pod_is_pending[pod] != 0 || (Pv.pod_from_deleting && Pv.pod_from_deleting[pod] != 0);
-    uint64_t* ndead = S.n_dead + (size_t)k * P.node_words;
-    for (int base = 0; base < ne; base += 64) {
-      const uint64_t deadw = ndead[base >> 6];
-      const int cnt = ne - base < 64 ? ne - base : 64;
-      // a probe of a resident cluster leaves its candidate nodes out (helpers.go:76-80): they are not in s.existingNodes at all
-      const uint64_t validm = (cnt == 64 ? ~0ull : ((1ull << cnt) - 1)) & (Pv.node_removed ? ~Pv.node_removed[base >> 6] : ~0ull);
-      // nodes under consolidateAfter are skipped for non-pending pods that do not come from a deleting node (:628)
-      const uint64_t skipped = exempt_pod ? 0ull : W::ballot([&](int l) { return l < cnt && (Pv.node_flags[base + l] & 2) != 0; });
-      uint64_t todo = validm & ~deadw & ~skipped;
-      if (!todo) { ctr.ref_bin_evaluations += popc64(validm & ~skipped); continue; }
+    uint64_t* ndead = probe ? nullptr : S.n_dead + (size_t)k * P.node_words;
+    int base = -64;
+    for (;;) {
+      uint64_t todo, deadw = 0, validm = 0, skipped = 0;
+      if (!probe) {
+        base += 64;
+        if (base >= ne) break;
+        deadw = ndead[base >> 6];
+        const int cnt = ne - base < 64 ? ne - base : 64;
+        validm = cnt == 64 ? ~0ull : ((1ull << cnt) - 1);
+        // nodes under consolidateAfter are skipped for non-pending pods that do not come from a deleting node (:628)
+        const int b0 = base;
+        skipped = exempt_pod ? 0ull : W::ballot([&](int l) { return l < cnt && (Pv.node_flags[b0 + l] & 2) != 0; });
+        todo = validm & ~deadw & ~skipped;
+        if (!todo) { ctr.ref_bin_evaluations += popc64(validm & ~skipped); continue; }
+      } else {
+        base = probe_next_block(k, base, exempt_pod, n_revived, &todo);
+        if (base < 0) break;
+      }
+      const int b0 = base;
       const uint64_t ok = W::ballot([&](int l) {
         if (!((todo >> l) & 1)) return false;
-        const int e_ = base + l;
-        if (Pv.node_taints[e_] & ~ktol) return false;                                    // taints — existingnode.go:83
-        if (khpc && (Sw.n_hp[e_] & khpc)) return false;                                  // host ports — existingnode.go:87-93
-        bool fit = true;                                                                   // resources.Fits — :96
-        for (int r = 0; r < nr; ++r) { int64_t rem = Sw.n_remaining[(size_t)r * ne + e_]; fit = fit && rem >= 0 && req[r] <= rem; }
-        if (!fit) return false;
-        const uint32_t ndef = Sw.n_defined[e_], ncomp = Sw.n_complement[e_];
-        const uint32_t nhg = Sw.n_hg ? Sw.n_hg[e_] : 0u, nhl = Sw.n_hg ? Sw.n_hl[e_] : 0u;   // bounds a Gt / Lt pod left on the node
-        if (kdef & ~ndef & ~kneg) return false;                                           // undefined key — requirements.go:185-193
-        for (uint32_t both = kdef & ndef; both; both &= both - 1) {                       // Intersects — requirements.go:254-274
-          const int key = __builtin_ctz(both);
-          const bool ca = (ncomp >> key) & 1, cb = (kcomp >> key) & 1;
-          bool hg = (khg >> key) & 1, hl = (khl >> key) & 1;
-          int64_t g = hg ? ((const int64_t*)cls_cold)[key] : 0, lq = hl ? ((const int64_t*)cls_cold)[ly.nk + key] : 0;
-          if ((nhg >> key) & 1) { const int64_t v = Sw.n_gte[(size_t)key * ne + e_]; g = hg && g > v ? g : v; hg = true; }   // maxIntPtr / minIntPtr — requirement.go:352-376
-          if ((nhl >> key) & 1) { const int64_t v = Sw.n_lte[(size_t)key * ne + e_]; lq = hl && lq < v ? lq : v; hl = true; }
-          const bool empty_bounds = hg && hl && g > lq;                                     // HasIntersection — requirement.go:220-224
-          if (ca && cb && !empty_bounds) continue;
-          bool hit = false, nonempty_n = false;
-          for (uint32_t w = d.key_word_off[key]; w < d.key_word_off[key + 1]; ++w) {
-            const uint64_t a = Sw.n_mask[(size_t)w * ne + e_], b = cls[ly.k_mask() + w];
-            nonempty_n = nonempty_n || a != 0;
-            uint64_t c = ca ? (b & ~a) : cb ? (a & ~b) : (a & b);
-            if (c && (hg || hl)) c = inbounds_word(d, w, c, hg, g, hl, lq);
-            hit = hit || c != 0;
-          }
-          if (hit && !empty_bounds) continue;
-          const bool neg_n = ca ? nonempty_n : !nonempty_n;
-          if (neg_n && ((kneg >> key) & 1)) continue;
-          return false;
-        }
-        return true;
+        const int e_ = b0 + l;
+        const int os = ov_find(e_);
+        return os >= 0 ? node_static_ok(d, ly, cx, Pv.node_taints[e_], mut, (size_t)os) : node_static_ok(d, ly, cx, Pv.node_taints[e_], pris, (size_t)e_);
       });
       int l = -1;
       bool changed = false;
@@ -1705,63 +1763,72 @@ struct Engine {
           break;
         }
       }
-      // nodes that failed a check that does not involve topology stay failed until their requirements change
       const uint64_t below = l < 0 ? ~0ull : (l == 0 ? 0ull : ((1ull << l) - 1));
-      W::store(&ndead[base >> 6], (uint64_t)(deadw | (todo & ~ok & below)));
-      if (l < 0) { ctr.ref_bin_evaluations += popc64(validm & ~skipped); continue; }
+      // nodes that failed a check that does not involve topology stay failed until their requirements change
+      if (!probe) W::store(&ndead[base >> 6], (uint64_t)(deadw | (todo & ~ok & below)));
+      if (l < 0) { if (!probe) ctr.ref_bin_evaluations += popc64(validm & ~skipped); continue; }
       const int en = base + l;
-      ctr.ref_bin_evaluations += popc64(validm & ~skipped & (below | (1ull << l)));
+      if (!probe) ctr.ref_bin_evaluations += popc64(validm & ~skipped & (below | (1ull << l)));
+      else ctr.ref_bin_evaluations += probe_nodes_before(en, exempt_pod) + 1;
       ctr.bin_evaluations += popc64(todo & (below | (1ull << l)));
       // ---- ExistingNode.Add (existingnode.go:172-185): requirements <- node ∧ pod ∧ topology, remaining -= requests
       const ReqBuf& m = *fin;
+      const int os = probe ? ov_touch(en) : en;     // the node's mutable state (a probe's overlay slot)
+      const size_t st = (size_t)nst();
       uint64_t* nm = S.n_mask;
       if (changed) {
         // the same predicate as try_claim (node labels are single-valued In sets today, so only the defined-key half can fire)
-        const uint32_t ex_b = exists_keys(Sw.n_complement[en], [&](int l) { return nm[(size_t)l * ne + en]; });
+        const uint32_t ex_b = exists_keys(Sw.n_complement[os], [&](int l) { return nm[(size_t)l * st + os]; });
         const uint32_t ex_a = ex_b ? exists_keys(m.complement, [&](int l) { return m.mask[l]; }) : 0;
-        const bool key_defined = revives_rejections(Sw.n_defined[en], m.defined, ex_b, ex_a);
-        W::for_n(ly.rw, [&](int w) { nm[(size_t)w * ne + en] = m.mask[w]; });
-        W::store(&S.n_defined[en], m.defined);
-        W::store(&S.n_complement[en], m.complement);
+        const bool revive = revives_rejections(Sw.n_defined[os], m.defined, ex_b, ex_a);
+        W::for_n(ly.rw, [&](int w) { nm[(size_t)w * st + os] = m.mask[w]; });
+        W::store(&S.n_defined[os], m.defined);
+        W::store(&S.n_complement[os], m.complement);
         if (S.n_hg) {
           int64_t* ng = S.n_gte; int64_t* nl = S.n_lte;
-          W::for_n(ly.nk, [&](int kk) { ng[(size_t)kk * ne + en] = m.gte[kk]; nl[(size_t)kk * ne + en] = m.lte[kk]; });
-          W::store(&S.n_hg[en], m.has_gte);
-          W::store(&S.n_hl[en], m.has_lte);
+          W::for_n(ly.nk, [&](int kk) { ng[(size_t)kk * st + os] = m.gte[kk]; nl[(size_t)kk * st + os] = m.lte[kk]; });
+          W::store(&S.n_hg[os], m.has_gte);
+          W::store(&S.n_hl[os], m.has_lte);
         }
-        if (key_defined) {
+        if (revive && !probe) {
           uint64_t* nd = S.n_dead;
           const int nwd = P.node_words;
           const uint64_t clr = ~(1ull << (en & 63));
           W::for_n(P.n_classes, [&](int kk) { nd[(size_t)kk * nwd + (en >> 6)] &= clr; });
+        } else if (revive) {
+          bool listed = false;
+          for (int i = 0; i < n_revived; ++i) listed = listed || S.pr_revived[i] == (uint32_t)en;
+          if (!listed) { W::store(&S.pr_revived[n_revived], (uint32_t)en); n_revived++; }
         }
       }
       if (cur_rec) topo_record(Pv.node_taints[en], m.ref(), 1, en);              // existingnode.go:184
       int64_t* nrem = S.n_remaining;
-      W::for_n(nr, [&](int r) { nrem[(size_t)r * ne + en] -= req[r]; });                  // resources.SubtractFrom — existingnode.go:175
-      if (Pv.hp_on && cur_hp_use) W::store(&S.n_hp[en], (uint64_t)(S.n_hp[en] | cur_hp_use));   // existingnode.go:178
-      const uint32_t np_ = S.n_npods[en];
-      W::store(&S.n_npods[en], np_ + 1);
-      W::store(&S.assign[pod], (int32_t)(-2 - en));
-      W::store(&S.slot[pod], np_);
+      W::for_n(nr, [&](int r) { nrem[(size_t)r * st + os] -= req[r]; });                  // resources.SubtractFrom — existingnode.go:175
+      if (Pv.hp_on && cur_hp_use) W::store(&S.n_hp[os], (uint64_t)(S.n_hp[os] | cur_hp_use));   // existingnode.go:178
+      const uint32_t np_ = S.n_npods[os];
+      W::store(&S.n_npods[os], np_ + 1);
+      W::store(&S.assign[cur_out], (int32_t)(-2 - en));
+      W::store(&S.slot[cur_out], np_);
       W::sync();
       return true;
     }
+    if (probe) ctr.ref_bin_evaluations += probe_nodes_before(ne, exempt_pod);   // the reference evaluated every node of the simulation
     return false;
   }
   // sc.merged <- ExistingNode.requirements ∧ the pod's (existingnode.go:105-108); true when that differs from the node's
   KS_DEV bool node_merge(int en) {
     const Dict& d = P.dict;
-    const int ne = P.n_nodes;
     ReqBuf& m = sc.merged;
-    const uint64_t* nm = S.n_mask;
-    W::for_n(lay.rw, [&](int w) { m.mask[w] = nm[(size_t)w * ne + en]; });
+    const int os = ov_find(en);
+    const NodeTabs t = node_tabs(os >= 0);
+    const size_t i = os >= 0 ? (size_t)os : (size_t)en;
+    W::for_n(lay.rw, [&](int w) { m.mask[w] = t.mask[(size_t)w * t.stride + i]; });
     if (W::leader()) {
-      m.defined = S.n_defined[en]; m.complement = S.n_complement[en]; m.has_minv = 0;
-      m.has_gte = S.n_hg ? S.n_hg[en] : 0u; m.has_lte = S.n_hg ? S.n_hl[en] : 0u;
+      m.defined = t.defined[i]; m.complement = t.complement[i]; m.has_minv = 0;
+      m.has_gte = t.hg ? t.hg[i] : 0u; m.has_lte = t.hg ? t.hl[i] : 0u;
       for (int kk = 0; kk < lay.nk; ++kk) {
-        m.gte[kk] = ((m.has_gte >> kk) & 1u) ? S.n_gte[(size_t)kk * ne + en] : 0;
-        m.lte[kk] = ((m.has_lte >> kk) & 1u) ? S.n_lte[(size_t)kk * ne + en] : 0;
+        m.gte[kk] = ((m.has_gte >> kk) & 1u) ? t.gte[(size_t)kk * t.stride + i] : 0;
+        m.lte[kk] = ((m.has_lte >> kk) & 1u) ? t.lte[(size_t)kk * t.stride + i] : 0;
         m.minv[kk] = -1;
       }
     }
@@ -1899,7 +1966,7 @@ struct Engine {
       W::for_n(iw, [&](int w) { rec[ly.c_its() + w] = sits[w]; tits[w] = sits[w]; });
       if (any) active_templates |= 1u << t;
       int64_t* rem = S.t_remaining + (size_t)t * (nr + 1);
-      const int64_t* lim = P.tmpl_limits + (size_t)t * (nr + 1);
+      const int64_t* lim = ((S.probe && S.pr_limits) ? S.pr_limits : P.tmpl_limits) + (size_t)t * (nr + 1);
       W::for_n(nr + 1, [&](int r) { rem[r] = lim[r]; });
     }
   }
@@ -1907,7 +1974,12 @@ struct Engine {
   // Solve — scheduler.go:440-519 with Queue (queue.go:31-108)
   KS_DEV void solve() {
     const unsigned long long t_begin = W::clock();
-    if (FULL && P.n_nodes) {
+    if (FULL && P.n_nodes && S.probe) {
+      // a probe of a resident cluster: nothing is copied, the overlay starts empty
+      Workspace& Sw = S;
+      W::for_n(S.ov_cap, [&](int i) { Sw.ov_key[i] = 0; });
+      n_revived = 0;
+    } else if (FULL && P.n_nodes) {
       // ExistingNodes are mutated by Solve: start from the pristine copies
       const int ne = P.n_nodes;
       Workspace& Sw = S;
@@ -1931,11 +2003,14 @@ struct Engine {
     load_tables();
     if (FULL && P.reserved_on) W::for_n(P.n_resv, [&](int i) { sc.resv_cap[i] = P.resv_cap0[i]; });
     prefilter_templates();
-    const int np = P.n_pods;
+    // The queue holds pod indices; a probe's queue holds positions in its own pod list (Workspace::pr_sorted), which is also
+    // how its per-pod outputs are indexed.
+    const bool probe = S.probe != 0;
+    const int np = probe ? S.pr_n_pods : P.n_pods;
     const uint32_t cap = (uint32_t)np + 1;
-    const uint32_t* sorted = P.sorted_pods;
+    const uint32_t* sorted = probe ? S.pr_sorted : P.sorted_pods;
     uint32_t* queue = S.queue;
-    W::for_n(np, [&](int i) { queue[i] = sorted[i]; });
+    W::for_n(np, [&](int i) { queue[i] = probe ? (uint32_t)i : sorted[i]; });
     uint32_t head = 0, tail = (uint32_t)np % cap, qlen = (uint32_t)np;
     long long steps = 0;
     int status = 0;
@@ -1946,12 +2021,12 @@ struct Engine {
         // fetch the next (up to) 64 queue entries with their class ids and lastLen in two coalesced round trips
         blk_n = qlen < 64 ? (int)qlen : 64;
         blk_i = 0;
-        uint32_t* bp = sc.blk_pod; uint32_t* bc = sc.blk_class; uint32_t* bl = sc.blk_last;
+        uint32_t* bp = sc.blk_pod; uint32_t* bc = sc.blk_class; uint32_t* bl = sc.blk_last; uint32_t* bo = sc.blk_out;
         const uint32_t* rc_ = P.row_class; const uint32_t* ll = S.last_len;
         const int bn = blk_n;
         const uint32_t h0 = head;
         W::for_n(64, [&](int l) {
-          if (l < bn) { uint32_t p = queue[(h0 + (uint32_t)l) % cap]; bp[l] = p; bc[l] = rc_[p]; bl[l] = ll[p]; }
+          if (l < bn) { const uint32_t q = queue[(h0 + (uint32_t)l) % cap]; const uint32_t p = probe ? sorted[q] : q; bp[l] = p; bo[l] = q; bc[l] = rc_[p]; bl[l] = ll[q]; }
         });
         if (S.cancel_flag) {   // ctx cancellation, polled once per 64 pods (< 0: tests only, see fast_engine.h)
           const int cv = W::poll_flag(S.cancel_flag);
@@ -1959,6 +2034,8 @@ struct Engine {
         }
       }
       int pod = (int)sc.blk_pod[blk_i];
+      const int out = (int)sc.blk_out[blk_i];
+      cur_out = out;
       if (sc.blk_last[blk_i] == qlen) break;                                // queue.go:52-56
       if (S.max_steps >= 0 && steps >= S.max_steps) { status = 2; break; }
       int k0 = (int)sc.blk_class[blk_i];
@@ -1972,15 +2049,15 @@ struct Engine {
       ctr.cycles[9] += W::clock() - ts;
       if (rc < 0) { status = 1; break; }
       if (rc != E_OK) {
-        W::store(&S.err[pod], (uint8_t)rc);
-        W::store(&S.diag[pod], (uint8_t)last_diag);
-        W::store(&S.queue[tail], (uint32_t)pod);
+        W::store(&S.err[out], (uint8_t)rc);
+        W::store(&S.diag[out], (uint8_t)last_diag);
+        W::store(&S.queue[tail], (uint32_t)out);
         tail = (tail + 1) % cap; qlen++;
-        W::store(&S.last_len[pod], qlen);                                   // queue.go:63-66
+        W::store(&S.last_len[out], qlen);                                   // queue.go:63-66
         W::sync();
       } else {
-        W::store(&S.err[pod], (uint8_t)0);
-        W::store(&S.diag[pod], (uint8_t)0);
+        W::store(&S.err[out], (uint8_t)0);
+        W::store(&S.diag[out], (uint8_t)0);
       }
     }
     ctr.slow_sorts = order.slow_sorts;

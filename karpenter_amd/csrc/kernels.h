@@ -10,6 +10,7 @@
 //   finalize     : per claim cheapest compatible available offering (the packing-cost estimator)
 #pragma once
 #include "ksp.h"
+#include "nodecheck.h"
 #include "go_sort.h"
 
 namespace ks {
@@ -470,14 +471,18 @@ struct FinalizeArgs {
   double* sort_price;        // [n_claims][n_its]
   uint32_t* ordered_count;   // [n_claims]
   uint8_t* trunc_failed;     // [n_claims]
+  // a sweep finalizes the claims of all its probes in one launch: claim c is the record at slot_of[c] of the claim arrays
+  // (c_hot, c_cold, c_reserved), its template's prefiltered types are the same for every probe; outputs are indexed by c
+  const uint32_t* slot_of;   // null: c
 };
 // one thread per claim: min over InstanceTypeOptions of the cheapest available offering compatible with the claim's
 // requirements (the comparator key of OrderByPrice, types.go:336-355)
 KS_FN void finalize_body(int c, const FinalizeArgs& a) {
   const Dict& d = a.dict;
   const RecLayout& ly = a.lay;
-  const uint64_t* hot = a.c_hot + (size_t)c * ly.c_hot_words();
-  const uint64_t* cold = a.c_cold + (size_t)c * ly.cold_words();
+  const size_t src = a.slot_of ? (size_t)a.slot_of[c] : (size_t)c;
+  const uint64_t* hot = a.c_hot + src * ly.c_hot_words();
+  const uint64_t* cold = a.c_cold + src * ly.cold_words();
   ReqRef r;
   r.mask = hot + ly.c_mask();
   r.defined = (uint32_t)hot[ly.c_f0()]; r.complement = (uint32_t)(hot[ly.c_f0()] >> 32);
@@ -507,8 +512,8 @@ KS_FN void finalize_body(int c, const FinalizeArgs& a) {
       }
     }
   }
-  if (a.c_reserved && a.c_reserved[c]) {
-    const uint64_t held = a.c_reserved[c];
+  if (a.c_reserved && a.c_reserved[src]) {
+    const uint64_t held = a.c_reserved[src];
     best = 1.7976931348623157e308;
     for (int w = 0; w < a.it_words; ++w) for (uint64_t m = its[w]; m; m &= m - 1) {
       const int it = w * 64 + ctz64(m);
@@ -523,7 +528,7 @@ KS_FN void finalize_body(int c, const FinalizeArgs& a) {
     // and minValues must still hold for them (unless the policy is BestEffort).
     int32_t* idx = a.sort_idx + (size_t)c * a.n_its;
     double* pr = a.sort_price + (size_t)c * a.n_its;
-    const uint64_t held = (a.c_reserved ? a.c_reserved[c] : 0ull);
+    const uint64_t held = (a.c_reserved ? a.c_reserved[src] : 0ull);
     int n = 0;
     for (int w = 0; w < a.it_words; ++w) for (uint64_t m = its[w]; m; m &= m - 1) {
       const int it = w * 64 + ctz64(m);
@@ -588,6 +593,52 @@ KS_FN void finalize_body(int c, const FinalizeArgs& a) {
     }
     for (int r = 0; r < nr; ++r) a.daemon_requests[(size_t)c * nr + r] = cur_empty ? 0 : cur[r];
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------ resident-cluster sweeps
+// ksolve_node_dead0: every pod class against every PRISTINE existing node of a resident cluster, once per base handle, for
+// all the probes of every sweep (disruption/helpers.go:53-155 runs Solve() once per candidate set against the same cluster).
+// dead0[k][w] bit b = node 64w+b fails ExistingNode.CanAdd for class k before volume alternatives / topology
+// (existingnode.go:81-106; nodecheck.h). One wavefront per 64 consecutive nodes, the classes one after the other: the node
+// side is read coalesced (SoA tables, lane = node), the class record is the same address for every lane.
+struct NodeDeadArgs {
+  Dict dict;
+  RecLayout lay;
+  int n_nodes, node_words, n_classes, hp_on;
+  const uint64_t* cls_hot;      // [n_classes][k_hot_words]
+  const uint64_t* cls_cold;     // [n_classes][cold_words]
+  const uint64_t* cls_hp;       // [n_classes][2] or null
+  const uint64_t* node_taints;  // [n_nodes]
+  NodeTabs pristine;
+  uint64_t* dead0;              // [n_classes][node_words]
+};
+template <class W>
+KS_DEV void node_dead0_body(int block, const NodeDeadArgs& a) {
+  const int base = block * 64;
+  const int cnt = a.n_nodes - base < 64 ? a.n_nodes - base : 64;
+  const RecLayout ly = a.lay;
+  for (int k = 0; k < a.n_classes; ++k) {
+    const uint64_t* cls = a.cls_hot + (size_t)k * ly.k_hot_words();
+    const NodeClassCtx cx = node_class_ctx(a.dict, ly, cls, a.cls_cold + (size_t)k * ly.cold_words(), (a.hp_on && a.cls_hp) ? a.cls_hp[(size_t)k * 2 + 1] : 0ull);
+    const uint64_t ok = W::ballot([&](int l) { return l < cnt && node_static_ok(a.dict, ly, cx, a.node_taints[base + l], a.pristine, (size_t)(base + l)); });
+    W::store(&a.dead0[(size_t)k * a.node_words + block], (uint64_t)~ok);
+  }
+}
+
+// the claims a sweep's probes created, gathered into compact arrays for the download (one thread per claim)
+struct ClaimGatherArgs {
+  RecLayout lay;
+  const uint32_t* slot_of;     // [n] slot in the sweep's claim arrays
+  const uint64_t *c_hot, *c_cold, *c_reserved;
+  uint64_t *out_hot, *out_cold, *out_reserved;
+};
+KS_FN void claim_gather_body(int i, const ClaimGatherArgs& a) {
+  const size_t src = a.slot_of[i];
+  const int hw = a.lay.c_hot_words(), cw = a.lay.cold_words();
+  for (int w = 0; w < hw; ++w) a.out_hot[(size_t)i * hw + w] = a.c_hot[src * hw + w];
+  for (int w = 0; w < cw; ++w) a.out_cold[(size_t)i * cw + w] = a.c_cold[src * cw + w];
+  a.out_reserved[i] = a.c_reserved[src];
 }
 
 }  // namespace ks

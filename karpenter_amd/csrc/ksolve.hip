@@ -439,6 +439,23 @@ __global__ void __launch_bounds__(64) ksolve_pack_batch_lite(ks::BatchItem* item
   ks::Engine<ks::Wave, false> eng(it.pv, it.ws, tables);
   eng.solve();
 }
+// A consolidation sweep over a resident cluster: block b runs the general engine on probes b, b + gridDim.x, ... — one view of
+// the cluster for all of them (HBM), one workspace per probe (its claims and its node overlay), one LDS plan for the launch.
+__global__ void __launch_bounds__(64) ksolve_pack_sweep(const ks::ProblemView* pv, ks::Workspace* items, int n, ks::LdsPlan plan) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  ks::LdsTables tables;
+  tables.bind(lds, plan);
+  for (int p = (int)blockIdx.x; p < n; p += (int)gridDim.x) {
+    ks::Engine<ks::Wave, true> eng(*pv, items[p], tables);
+    eng.solve();
+  }
+}
+// every pod class against every pristine node of a resident cluster (kernels.h node_dead0_body): one wavefront per 64 nodes
+__global__ void __launch_bounds__(64) ksolve_node_dead0(ks::NodeDeadArgs a) { ks::node_dead0_body<ks::Wave>((int)blockIdx.x, a); }
+__global__ void ksolve_claim_gather(int n, ks::ClaimGatherArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ks::claim_gather_body(i, a);
+}
 // The cursor engine (fast_engine.h) for purely positive provisioning batches: one wavefront, O(1) steps.
 __global__ void __launch_bounds__(64) ksolve_pack_fast(const ks::FastArgs* a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -509,6 +526,34 @@ static void be_launch_pack(ksolve_handle* h) {
   hip_check(h, hipGetLastError(), "ksolve_pack launch");
 }
 
+static void be_free(ksolve_handle* h, void* p) {
+  if (!p) return;
+  hip_check(h, hipStreamSynchronize(HB(h)->stream), "hipStreamSynchronize");
+  auto it = std::find(h->allocations.begin(), h->allocations.end(), p);
+  if (it != h->allocations.end()) h->allocations.erase(it);
+  (void)hipFree(p);
+}
+static void be_launch_node_dead0(ksolve_handle* h, int n_blocks, const ks::NodeDeadArgs& a) {
+  hipLaunchKernelGGL(ksolve_node_dead0, dim3((unsigned)n_blocks), dim3(64), 0, HB(h)->stream, a);
+  hip_check(h, hipGetLastError(), "ksolve_node_dead0 launch");
+}
+static void be_launch_claim_gather(ksolve_handle* h, int n, const ks::ClaimGatherArgs& a) {
+  hipLaunchKernelGGL(ksolve_claim_gather, grid_for(n), dim3(256), 0, HB(h)->stream, n, a);
+  hip_check(h, hipGetLastError(), "ksolve_claim_gather launch");
+}
+static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, ks::Workspace* d_items, int n, const ks::LdsPlan& plan) {
+  if (n <= 0) return;
+  HipBackend* b = HB(h);
+  if (!hip_check(h, hipFuncSetAttribute((const void*)ksolve_pack_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, plan.total_bytes), "hipFuncSetAttribute(LDS)")) return;
+  const int grid = n < 8192 ? n : 8192;
+  hip_check(h, hipEventRecord(b->ev0[ksi::T_PACK], b->stream), "hipEventRecord");
+  hipLaunchKernelGGL(ksolve_pack_sweep, dim3((unsigned)grid), dim3(64), (size_t)plan.total_bytes, b->stream, d_pv, d_items, n, plan);
+  hip_check(h, hipGetLastError(), "ksolve_pack_sweep launch");
+  hip_check(h, hipEventRecord(b->ev1[ksi::T_PACK], b->stream), "hipEventRecord");
+  hip_check(h, hipEventSynchronize(b->ev1[ksi::T_PACK]), "hipEventSynchronize");
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, b->ev0[ksi::T_PACK], b->ev1[ksi::T_PACK]) == hipSuccess) h->timers.ms[ksi::T_PACK] = ms;
+}
 static void be_launch_pack_fast(ksolve_handle* h) {
   const int lds_bytes = h->fw.plan.total_bytes;
   if (!hip_check(h, hipFuncSetAttribute((const void*)ksolve_pack_fast, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
@@ -673,6 +718,12 @@ ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out) {
   if (hipSetDevice(HB(h)->device) != hipSuccess) return KSOLVE_ERR_DEVICE;
   return ksi::solve(h, out);
 }
+ksolve_status ksolve_sweep(ksolve_handle* base, const ksolve_sweep_desc* desc, ksolve_sweep_results* out) {
+  if (!base || !base->backend || !out) return KSOLVE_ERR_INVALID;
+  if (hipSetDevice(HB(base)->device) != hipSuccess) return KSOLVE_ERR_DEVICE;
+  return ksi::sweep(base, desc, out);
+}
+void ksolve_sweep_results_free(ksolve_sweep_results* r) { if (r && r->impl) { delete (ksi::SweepImpl*)r->impl; r->impl = nullptr; } }
 ksolve_status ksolve_solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) {
   if (!hs || !outs || n == 0) return KSOLVE_ERR_INVALID;
   for (uint32_t i = 0; i < n; ++i) if (!hs[i] || !hs[i]->backend || HB(hs[i])->device != HB(hs[0])->device) return KSOLVE_ERR_INVALID;

@@ -78,6 +78,15 @@ struct ksolve_handle {
   ksolve_handle* base = nullptr;         // non-null: this handle is a probe of `base`
   bool prepared = false;                 // base: phases 1-3 have run and h_rank is valid
   std::vector<uint32_t> h_rank;          // base: queue position of every pod (queue.go:72-108 order)
+  // a probe handle is its descriptor; ksolve_solve / ksolve_solve_batch run it through the sweep machinery (sweep_run)
+  std::vector<uint32_t> pr_nodes, pr_pods;
+  std::vector<int64_t> pr_limits;
+  // base: what every sweep shares — rejections of the pristine nodes per class, the consolidateAfter bitmap, the view in HBM,
+  // and the arena the probes' workspaces are carved from (kept between sweeps, grown when a sweep needs more)
+  bool sweep_ready = false;
+  ks::ProblemView* d_pv = nullptr;
+  char* sweep_arena = nullptr; size_t sweep_arena_bytes = 0;
+  char* sweep_fin = nullptr; size_t sweep_fin_bytes = 0;     // finalize outputs + gathered claim records of a sweep
 };
 
 // ---- backend hooks (defined by the including TU before this point is instantiated) ----
@@ -103,6 +112,10 @@ static void be_launch_pack_batch(ksolve_handle** hs, int n);
 static void be_thread_init(ksolve_handle* h);   // makes the handle's device current on a worker thread   // one block per handle; sets every handle's T_PACK timer
 static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a);
 static int be_device_available();
+static void be_free(ksolve_handle* h, void* p);   // releases one be_alloc'ed block before the handle goes
+static void be_launch_node_dead0(ksolve_handle* h, int n_blocks, const ks::NodeDeadArgs& a);   // one wavefront per 64 nodes
+static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, ks::Workspace* d_items, int n, const ks::LdsPlan& plan);   // block b = the general engine on probe b; sets T_PACK
+static void be_launch_claim_gather(ksolve_handle* h, int n, const ks::ClaimGatherArgs& a);
 
 namespace ksi {
 
@@ -637,119 +650,30 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
 
 static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context);
 
-// ksolve_probe_create: a handle that shares `base`'s device tables and owns one arena with its workspace.
+// ksolve_probe_create: a probe handle is its descriptor (nodes that are not there, pods to place, NodePool limits); solving it
+// — alone or in a batch — goes through sweep_run below, which shares `base`'s device tables.
 static ksolve_status probe_create(ksolve_handle* base, const ksolve_probe* pr, ksolve_handle* h) {
   if (!base || base->base || !pr) return fail(h, KSOLVE_ERR_INVALID, "probe of a null handle / of a probe");
   if (base->has_topology) return fail(h, KSOLVE_ERR_UNSUPPORTED, "probes of a cluster with topology groups: create one handle per probe");
   if (pr->n_pods && !pr->pods) return fail(h, KSOLVE_ERR_INVALID, "probe pods missing");
   if (base->n_nodes && !pr->removed_nodes) return fail(h, KSOLVE_ERR_INVALID, "probe removed_nodes missing");
-  if (!base->prepared) {
-    ksolve_status st = solve_prepare(base, true);
-    if (st != KSOLVE_OK) return fail(h, st, base->error);
-    std::vector<uint32_t> order(base->n_pods);
-    if (base->n_pods) be_d2h(base, order.data(), base->pv.sorted_pods, (size_t)base->n_pods * 4);
-    be_sync(base);
-    if (!be_ok(base)) return fail(h, KSOLVE_ERR_DEVICE, base->error);
-    base->h_rank.assign(base->n_pods, 0);
-    for (uint32_t i = 0; i < base->n_pods; ++i) base->h_rank[order[i]] = i;
-    base->prepared = true;
+  h->pr_pods.assign(pr->pods, pr->pods + pr->n_pods);
+  for (uint32_t p : h->pr_pods) if (p >= base->n_pods) return fail(h, KSOLVE_ERR_INVALID, "probe pod index out of range");
+  {
+    std::vector<uint32_t> sorted = h->pr_pods;
+    std::sort(sorted.begin(), sorted.end());
+    for (size_t i = 1; i < sorted.size(); ++i) if (sorted[i] == sorted[i - 1]) return fail(h, KSOLVE_ERR_INVALID, "probe pod listed twice");
   }
-  const uint32_t m = pr->n_pods;
-  std::vector<uint32_t> pods(pr->pods, pr->pods + m);
-  for (uint32_t p : pods) if (p >= base->n_pods) return fail(h, KSOLVE_ERR_INVALID, "probe pod index out of range");
-  std::sort(pods.begin(), pods.end(), [&](uint32_t a, uint32_t b) { return base->h_rank[a] < base->h_rank[b]; });   // the base queue order, restricted
-  for (uint32_t i = 1; i < m; ++i) if (pods[i] == pods[i - 1]) return fail(h, KSOLVE_ERR_INVALID, "probe pod listed twice");
-
+  for (uint32_t e = 0; e < base->n_nodes; ++e) if ((pr->removed_nodes[e >> 6] >> (e & 63)) & 1) h->pr_nodes.push_back(e);
+  if (pr->tmpl_limits) h->pr_limits.assign(pr->tmpl_limits, pr->tmpl_limits + (size_t)base->n_templates * (base->n_res + 1));
   h->base = base;
   h->opts = base->opts;
   h->n_keys = base->n_keys; h->req_words = base->req_words; h->n_res = base->n_res; h->n_its = base->n_its; h->it_words = base->it_words;
   h->n_templates = base->n_templates; h->n_pods = base->n_pods; h->n_rows = base->n_rows; h->n_classes = base->n_classes;
-  h->class_capacity = base->n_classes; h->n_nodes = base->n_nodes; h->n_kv = base->n_kv; h->has_topology = false;
-  h->pv = base->pv;
-  ks::ProblemView& P = h->pv;
-  ks::Workspace& W = h->ws;
-  W = ks::Workspace{};
-  uint32_t mc = std::max(1u, m);
-  if (h->opts.max_claims && h->opts.max_claims < mc) mc = h->opts.max_claims;
-  h->max_claims = mc; h->claim_words = (mc + 63) / 64;
-  W.max_claims = (int)mc; W.claim_words = (int)h->claim_words;
-  const ks::RecLayout lay = P.lay;
-  const uint32_t ne = base->n_nodes, nr = base->n_res, T = base->n_templates, nc = base->n_classes, np_all = base->n_pods;
-  const size_t nw = (size_t)P.node_words;
-
-  // one arena: laid out twice (measure, then carve)
-  char* arena = nullptr;
-  size_t off = 0;
-  auto take = [&](size_t bytes) { void* p = arena ? (void*)(arena + off) : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
-  uint32_t* d_sorted = nullptr; uint64_t* d_removed = nullptr; int64_t* d_limits = nullptr;
-  auto layout = [&]() {
-    off = 0;
-    W.c_hot = (uint64_t*)take((size_t)mc * lay.c_hot_words() * 8);
-    W.c_cold = (uint64_t*)take((size_t)mc * lay.cold_words() * 8);
-    W.c_headroom = (int64_t*)take(((size_t)mc * nr + 64) * 8);
-    W.c_reserved = (uint64_t*)take((size_t)mc * 8);
-    W.c_hp = P.hp_on ? (uint64_t*)take((size_t)mc * 8) : nullptr;
-    W.o_key = (uint32_t*)take((size_t)mc * 4); W.o_ord = (uint32_t*)take((size_t)mc * 4); W.o_pos = (uint32_t*)take((size_t)mc * 4);
-    W.queue = (uint32_t*)take(((size_t)m + 1) * 4);
-    W.last_len = (uint32_t*)take((size_t)np_all * 4);
-    W.t_its = (uint64_t*)take((size_t)T * h->it_words * 8);
-    W.t_remaining = (int64_t*)take((size_t)T * (nr + 1) * 8);
-    W.assign = (int32_t*)take((size_t)np_all * 4); W.err = (uint8_t*)take(np_all); W.diag = (uint8_t*)take(np_all); W.slot = (uint32_t*)take((size_t)np_all * 4);
-    W.n_claims_out = (int*)take(4); W.status_out = (int*)take(4);
-    h->d_cancel = (int*)take(4);
-    W.counters = (ks::Counters*)take(sizeof(ks::Counters));
-    h->d_cheapest = (double*)take((size_t)mc * 8);
-    h->d_daemon_requests = (int64_t*)take((size_t)mc * nr * 8);
-    W.dead = (uint64_t*)take((size_t)std::max(1u, nc) * h->claim_words * 8);
-    if (ne) {
-      W.n_dead = (uint64_t*)take((size_t)std::max(1u, nc) * nw * 8);
-      W.n_mask = (uint64_t*)take((size_t)h->req_words * ne * 8);
-      W.n_defined = (uint32_t*)take((size_t)ne * 4); W.n_complement = (uint32_t*)take((size_t)ne * 4);
-      if (base->ws.n_hg) {
-        W.n_hg = (uint32_t*)take((size_t)ne * 4); W.n_hl = (uint32_t*)take((size_t)ne * 4);
-        W.n_gte = (int64_t*)take((size_t)base->pv.dict.n_keys * ne * 8); W.n_lte = (int64_t*)take((size_t)base->pv.dict.n_keys * ne * 8);
-      }
-      W.n_remaining = (int64_t*)take((size_t)nr * ne * 8);
-      W.n_npods = (uint32_t*)take((size_t)ne * 4);
-      W.n_hp = P.hp_on ? (uint64_t*)take((size_t)ne * 8) : nullptr;
-      d_removed = (uint64_t*)take(nw * 8);
-    }
-    d_sorted = (uint32_t*)take(((size_t)m + 1) * 4);
-    d_limits = pr->tmpl_limits ? (int64_t*)take((size_t)T * (nr + 1) * 8) : nullptr;
-  };
-  layout();
-  const size_t total = off;
-  arena = (char*)be_alloc(h, total);    // zero-filled
-  if (!arena) return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "device allocation failed" : h->error);
-  layout();
-  W.n_mask0 = base->ws.n_mask0; W.n_defined0 = base->ws.n_defined0; W.n_complement0 = base->ws.n_complement0; W.n_remaining0 = base->ws.n_remaining0;
-  W.cancel_flag = h->d_cancel;
-  W.max_steps = h->opts.max_steps;
-  W.min_values_best_effort = h->opts.min_values_best_effort ? 1 : 0;
-  if (m) be_h2d(h, d_sorted, pods.data(), (size_t)m * 4);
-  if (ne) be_h2d(h, d_removed, pr->removed_nodes, nw * 8);
-  if (d_limits) be_h2d(h, d_limits, pr->tmpl_limits, (size_t)T * (nr + 1) * 8);
-  P.n_pods = (int)m;
-  P.sorted_pods = d_sorted;
-  P.node_removed = ne ? d_removed : nullptr;
-  if (d_limits) P.tmpl_limits = d_limits;
-  // LDS plan: the base plan with the claim order cut down to this probe's pods
-  {
-    ks::LdsPlan& lp = P.lds;
-    auto align = [](int x) { return (x + 15) & ~15; };
-    int cap = lp.order_cap;
-    if (cap > (int)((mc + 63) & ~63u)) cap = (int)((mc + 63) & ~63u);
-    int o = lp.off_order;
-    lp.order_cap = cap;
-    o = align(o + cap * 12);
-    lp.off_closed = o; o = align(o + cap / 8 + 8);
-    lp.total_bytes = o;
-    P.big = 0;
-    h->lds_big = lp; h->big_capable = false;
-  }
-  h->fw = ks::FastWork{};   // existing nodes: never the cursor engine's shape
+  h->n_nodes = base->n_nodes; h->has_topology = false;
+  h->d_cancel = (int*)be_alloc(h, 4);
   be_sync(h);
-  if (!be_ok(h)) return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "device allocation/upload failed" : h->error);
+  if (!be_ok(h)) return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "device allocation failed" : h->error);
   return KSOLVE_OK;
 }
 
@@ -779,17 +703,6 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
     if (const char* at = getenv("KSOLVE_TEST_CANCEL_AT")) { const int v = -atoi(at); if (v < 0) be_h2d(h, h->d_cancel, &v, 4); }   // deterministic cancellation for the tests
     be_sync(h);
   }
-  if (h->base) {
-    // a probe of a resident cluster: index, classes and queue order are the base handle's; only the workspace is reset
-    if (h->n_classes) be_fill(h, W.dead, 0, (size_t)h->n_classes * h->claim_words * 8);
-    if (h->n_classes && h->n_nodes) be_fill(h, W.n_dead, 0, (size_t)h->n_classes * P.node_words * 8);
-    be_fill(h, W.last_len, 0, (size_t)n_pods * 4);
-    be_fill(h, W.assign, 0xFF, (size_t)n_pods * 4);
-    be_fill(h, W.err, 0, n_pods); be_fill(h, W.diag, 0, n_pods);
-    be_fill(h, W.n_claims_out, 0, 4); be_fill(h, W.status_out, 0, 4);
-    return KSOLVE_OK;
-  }
-
   // ---- phase 1: instance-type requirement index ----
   be_tic(h, T_INDEX);
   be_fill(h, (void*)P.kv_has, 0, (size_t)h->req_words * 64 * h->it_words * 8);
@@ -878,6 +791,53 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
   return KSOLVE_OK;
 }
 
+struct ClaimCols {   // the columns of ksolve_claims while they are being decoded from claim records
+  std::vector<int32_t> tmpl, minv;
+  std::vector<uint32_t> npods, defined, complement, has_gte, has_lte, host_seq;
+  std::vector<uint8_t> relaxed;
+  std::vector<uint64_t> its, mask;
+  std::vector<int64_t> requests, gte, lte;
+  void resize(size_t C, const ksolve_handle* h) {
+    tmpl.resize(C); npods.resize(C); defined.resize(C); complement.resize(C); has_gte.resize(C); has_lte.resize(C); host_seq.resize(C); relaxed.resize(C);
+    its.resize(C * h->it_words); mask.resize(C * h->req_words); requests.resize(C * h->n_res); gte.resize(C * h->n_keys); lte.resize(C * h->n_keys); minv.resize(C * h->n_keys);
+  }
+};
+// one hot / cold claim record (RecLayout) -> row c of the columns; `reserved` = reservation ids the claim holds, `dreq` = addDaemonRequests
+static void decode_claim(const ksolve_handle* h, const ks::ProblemView& P, uint32_t c, const uint64_t* hr, const uint64_t* cr, uint64_t reserved, const int64_t* dreq, ClaimCols& o) {
+  const ks::RecLayout ly = P.lay;
+  const uint32_t n_res = h->n_res;
+  auto &tmpl = o.tmpl; auto &npods = o.npods, &defined = o.defined, &complement = o.complement, &has_gte = o.has_gte, &has_lte = o.has_lte, &host_seq = o.host_seq;
+  auto &relaxed = o.relaxed; auto &its = o.its, &mask = o.mask; auto &requests = o.requests, &gte = o.gte, &lte = o.lte; auto &minv = o.minv;
+    for (uint32_t x = 0; x < h->req_words; ++x) mask[(size_t)c * h->req_words + x] = hr[ly.c_mask() + x];
+    for (uint32_t x = 0; x < h->it_words; ++x) its[(size_t)c * h->it_words + x] = hr[ly.c_its() + x];
+    for (uint32_t r = 0; r < n_res; ++r) requests[(size_t)c * n_res + r] = (int64_t)hr[ly.c_total() + r] + dreq[r];   // FinalizeScheduling, nodeclaim.go:405-408
+    defined[c] = (uint32_t)hr[ly.c_f0()]; complement[c] = (uint32_t)(hr[ly.c_f0()] >> 32);
+    has_gte[c] = (uint32_t)hr[ly.c_f1()]; has_lte[c] = (uint32_t)(hr[ly.c_f1()] >> 32);
+    if (P.reserved_on && reserved) {
+      // FinalizeScheduling pins the claim to its reservations (nodeclaim.go:391-403): capacity-type = reserved,
+      // reservation-id In [held ids]
+      const uint32_t kc = (uint32_t)P.dict.key_ct, kr = (uint32_t)P.key_rid;
+      uint64_t* mk = mask.data() + (size_t)c * h->req_words;
+      for (uint32_t x = P.dict.key_word_off[kc]; x < P.dict.key_word_off[kc + 1]; ++x) mk[x] = 0;
+      mk[P.dict.key_word_off[kc] + (uint32_t)P.ct_reserved / 64] = 1ull << (P.ct_reserved % 64);
+      defined[c] |= 1u << kc; complement[c] &= ~(1u << kc); has_gte[c] &= ~(1u << kc); has_lte[c] &= ~(1u << kc);
+      const uint32_t rx = P.dict.key_word_off[kr];
+      if ((defined[c] >> kr) & 1) mk[rx] = ((complement[c] >> kr) & 1) ? (reserved & ~mk[rx]) : (reserved & mk[rx]);
+      else mk[rx] = reserved;
+      defined[c] |= 1u << kr; complement[c] &= ~(1u << kr);
+    }
+    tmpl[c] = (int32_t)(uint32_t)hr[ly.c_meta()]; npods[c] = (uint32_t)(hr[ly.c_meta()] >> 32);
+    host_seq[c] = (uint32_t)hr[ly.c_meta2()];
+    const uint32_t fl = (uint32_t)(hr[ly.c_meta2()] >> 32);
+    relaxed[c] = fl & 1u;
+    const bool cold_valid = hr[ly.c_f1()] != 0 || (fl & 2u);
+    for (uint32_t k = 0; k < h->n_keys; ++k) {
+      gte[(size_t)c * h->n_keys + k] = cold_valid ? ((const int64_t*)cr)[k] : 0;
+      lte[(size_t)c * h->n_keys + k] = cold_valid ? ((const int64_t*)cr)[h->n_keys + k] : 0;
+      minv[(size_t)c * h->n_keys + k] = (fl & 2u) ? ((const int32_t*)(cr + 2 * h->n_keys))[k] : -1;
+    }
+}
+
 // Phases 5-6 (finalize, download) after the pack kernel has run.
 static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   memset(out, 0, sizeof(*out));
@@ -920,12 +880,10 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   }
   const uint32_t C = (uint32_t)n_claims;
   const ks::RecLayout ly = P.lay;
-  std::vector<int32_t> tmpl(C);
-  std::vector<uint32_t> npods(C), defined(C), complement(C), has_gte(C), has_lte(C), host_seq(C), ord(C);
-  std::vector<uint8_t> relaxed(C);
-  std::vector<uint64_t> its((size_t)C * h->it_words), mask((size_t)C * h->req_words);
-  std::vector<int64_t> requests((size_t)C * n_res), gte((size_t)C * h->n_keys), lte((size_t)C * h->n_keys);
-  std::vector<int32_t> minv((size_t)C * h->n_keys);
+  ClaimCols cc; cc.resize(C, h);
+  auto &tmpl = cc.tmpl; auto &npods = cc.npods, &defined = cc.defined, &complement = cc.complement, &has_gte = cc.has_gte, &has_lte = cc.has_lte, &host_seq = cc.host_seq;
+  auto &relaxed = cc.relaxed; auto &its = cc.its, &mask = cc.mask; auto &requests = cc.requests, &gte = cc.gte, &lte = cc.lte; auto &minv = cc.minv;
+  std::vector<uint32_t> ord(C);
   std::vector<double> cheapest(C);
   std::vector<int64_t> daemon_req;
   std::vector<uint64_t> reserved;
@@ -954,38 +912,8 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   be_sync(h);
   be_toc(h, T_DOWNLOAD);
   if (!be_ok(h)) { delete im; return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "download failed" : h->error); }
-  for (uint32_t c = 0; c < C; ++c) {
-    const uint64_t* hr = hot.data() + (size_t)c * ly.c_hot_words();
-    const uint64_t* cr = cold.data() + (size_t)c * ly.cold_words();
-    for (uint32_t x = 0; x < h->req_words; ++x) mask[(size_t)c * h->req_words + x] = hr[ly.c_mask() + x];
-    for (uint32_t x = 0; x < h->it_words; ++x) its[(size_t)c * h->it_words + x] = hr[ly.c_its() + x];
-    for (uint32_t r = 0; r < n_res; ++r) requests[(size_t)c * n_res + r] = (int64_t)hr[ly.c_total() + r] + daemon_req[(size_t)c * n_res + r];   // FinalizeScheduling, nodeclaim.go:405-408
-    defined[c] = (uint32_t)hr[ly.c_f0()]; complement[c] = (uint32_t)(hr[ly.c_f0()] >> 32);
-    has_gte[c] = (uint32_t)hr[ly.c_f1()]; has_lte[c] = (uint32_t)(hr[ly.c_f1()] >> 32);
-    if (P.reserved_on && reserved[c]) {
-      // FinalizeScheduling pins the claim to its reservations (nodeclaim.go:391-403): capacity-type = reserved,
-      // reservation-id In [held ids]
-      const uint32_t kc = (uint32_t)P.dict.key_ct, kr = (uint32_t)P.key_rid;
-      uint64_t* mk = mask.data() + (size_t)c * h->req_words;
-      for (uint32_t x = P.dict.key_word_off[kc]; x < P.dict.key_word_off[kc + 1]; ++x) mk[x] = 0;
-      mk[P.dict.key_word_off[kc] + (uint32_t)P.ct_reserved / 64] = 1ull << (P.ct_reserved % 64);
-      defined[c] |= 1u << kc; complement[c] &= ~(1u << kc); has_gte[c] &= ~(1u << kc); has_lte[c] &= ~(1u << kc);
-      const uint32_t rx = P.dict.key_word_off[kr];
-      if ((defined[c] >> kr) & 1) mk[rx] = ((complement[c] >> kr) & 1) ? (reserved[c] & ~mk[rx]) : (reserved[c] & mk[rx]);
-      else mk[rx] = reserved[c];
-      defined[c] |= 1u << kr; complement[c] &= ~(1u << kr);
-    }
-    tmpl[c] = (int32_t)(uint32_t)hr[ly.c_meta()]; npods[c] = (uint32_t)(hr[ly.c_meta()] >> 32);
-    host_seq[c] = (uint32_t)hr[ly.c_meta2()];
-    const uint32_t fl = (uint32_t)(hr[ly.c_meta2()] >> 32);
-    relaxed[c] = fl & 1u;
-    const bool cold_valid = hr[ly.c_f1()] != 0 || (fl & 2u);
-    for (uint32_t k = 0; k < h->n_keys; ++k) {
-      gte[(size_t)c * h->n_keys + k] = cold_valid ? ((const int64_t*)cr)[k] : 0;
-      lte[(size_t)c * h->n_keys + k] = cold_valid ? ((const int64_t*)cr)[h->n_keys + k] : 0;
-      minv[(size_t)c * h->n_keys + k] = (fl & 2u) ? ((const int32_t*)(cr + 2 * h->n_keys))[k] : -1;
-    }
-  }
+  for (uint32_t c = 0; c < C; ++c)
+    decode_claim(h, P, c, hot.data() + (size_t)c * ly.c_hot_words(), cold.data() + (size_t)c * ly.cold_words(), reserved[c], daemon_req.data() + (size_t)c * n_res, cc);
 
   // Report claims in the order the reference's s.newNodeClaims slice ends in (position order), so claim index i in the
   // results is position i; pod assignments are remapped accordingly.
@@ -1054,9 +982,441 @@ static void alloc_run_order(ksolve_handle* h) {
   h->ws.run_log = up(h, lg.data(), lg.size());
   h->ws.run_kmax = (int)kmax;
 }
+// ---------------------------------------------------------------------------------------------------------------------------
+// Sweeps over a resident cluster (ksolve_sweep; probe handles go through the same code). SimulateScheduling
+// (disruption/helpers.go:53-155) runs Solve() once per candidate set against the same cluster: the base handle holds the
+// cluster (every node an existing node, every displaceable pod a pod row, classes and queue order computed once), a probe is
+// (nodes that are not there, pods to place, NodePool limits) and owns only what it creates: its NodeClaims and an overlay of
+// the nodes it commits pods to.
+struct SweepImpl {   // host side of ksolve_sweep_results
+  std::vector<int32_t> status, assign;
+  std::vector<uint8_t> err, diag;
+  std::vector<uint32_t> slot, claim_off;
+  std::vector<uint64_t> ref;
+  ResultsImpl claims;
+  std::vector<ks::Counters> counters;
+};
+
+// base-level tables every probe shares; computed once, after the classes and the queue order exist
+static ksolve_status sweep_prepare_base(ksolve_handle* base) {
+  if (base->sweep_ready) return KSOLVE_OK;
+  if (!base->prepared) {
+    ksolve_status st = solve_prepare(base, true);
+    if (st != KSOLVE_OK) return st;
+    std::vector<uint32_t> order(base->n_pods);
+    if (base->n_pods) be_d2h(base, order.data(), base->pv.sorted_pods, (size_t)base->n_pods * 4);
+    be_sync(base);
+    if (!be_ok(base)) return fail(base, KSOLVE_ERR_DEVICE, base->error);
+    base->h_rank.assign(base->n_pods, 0);
+    for (uint32_t i = 0; i < base->n_pods; ++i) base->h_rank[order[i]] = i;
+    base->prepared = true;
+  }
+  ks::ProblemView& P = base->pv;
+  const uint32_t ne = base->n_nodes, nw = (uint32_t)P.node_words, nc = base->n_classes;
+  if (ne) {
+    // consolidateAfter bitmap + prefix counts (scheduler.go:628)
+    std::vector<uint8_t> fl(ne);
+    be_d2h(base, fl.data(), P.node_flags, ne);
+    be_sync(base);
+    std::vector<uint64_t> skip(nw, 0);
+    std::vector<uint32_t> prefix(nw + 1, 0);
+    bool any = false;
+    for (uint32_t e = 0; e < ne; ++e) if (fl[e] & 2) { skip[e >> 6] |= 1ull << (e & 63); any = true; }
+    for (uint32_t w = 0; w < nw; ++w) prefix[w + 1] = prefix[w] + (uint32_t)__builtin_popcountll(skip[w]);
+    if (any) { P.node_skip = up(base, skip.data(), skip.size()); P.node_skip_prefix = up(base, prefix.data(), prefix.size()); }
+    else { P.node_skip = nullptr; P.node_skip_prefix = nullptr; }
+    // every class against every pristine node
+    uint64_t* dead0 = dz<uint64_t>(base, (size_t)std::max(1u, nc) * nw);
+    ks::NodeDeadArgs a{};
+    a.dict = P.dict; a.lay = P.lay; a.n_nodes = (int)ne; a.node_words = (int)nw; a.n_classes = (int)nc; a.hp_on = P.hp_on;
+    a.cls_hot = P.cls_hot; a.cls_cold = P.cls_cold; a.cls_hp = P.cls_hp; a.node_taints = P.node_taints;
+    a.pristine.mask = base->ws.n_mask0; a.pristine.defined = base->ws.n_defined0; a.pristine.complement = base->ws.n_complement0;
+    a.pristine.hg = nullptr; a.pristine.hl = nullptr; a.pristine.gte = nullptr; a.pristine.lte = nullptr;
+    a.pristine.remaining = base->ws.n_remaining0; a.pristine.hp = P.node_hp0; a.pristine.stride = ne;
+    a.dead0 = dead0;
+    if (nc) be_launch_node_dead0(base, (int)nw, a);
+    P.n_dead0 = dead0;
+  }
+  base->d_pv = dz<ks::ProblemView>(base, 1);
+  be_sync(base);
+  if (!be_ok(base)) return fail(base, KSOLVE_ERR_DEVICE, base->error.empty() ? "sweep tables failed" : base->error);
+  base->sweep_ready = true;
+  return KSOLVE_OK;
+}
+
+static char* sweep_buffer(ksolve_handle* base, char*& buf, size_t& have, size_t need) {
+  if (need > have) {
+    if (buf) be_free(base, buf);
+    const size_t want = need + need / 4 + 4096;
+    buf = (char*)be_alloc(base, want);
+    have = buf ? want : 0;
+  }
+  return buf;
+}
+
+// Runs n probes of `base` in one launch. node_off/nodes, pod_off/pods: CSR descriptors (pods in the caller's order);
+// limits: null or n * T*(nr+1); cancel[i]: the flag probe i polls (null entries: the base's own).
+static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* node_off, const uint32_t* nodes, const uint32_t* pod_off, const uint32_t* pods,
+                               const int64_t* const* limits, int* const* cancel, SweepImpl* im, double* us) {
+  ksolve_status st = sweep_prepare_base(base);
+  if (st != KSOLVE_OK) return st;
+  ks::ProblemView& P = base->pv;
+  const ks::RecLayout lay = P.lay;
+  const uint32_t ne = base->n_nodes, nr = base->n_res, T = base->n_templates, nc = std::max(1u, base->n_classes), nk = base->n_keys;
+  const uint32_t total_pods = pod_off[n], total_nodes = node_off[n];
+  const bool bounds = base->ws.n_hg != nullptr;
+  be_tic(base, T_UPLOAD);
+  // ---- validate + queue order per probe (the base queue order, restricted) ----
+  std::vector<uint32_t> sorted(total_pods), perm(total_pods);   // perm: position in the probe's sorted list -> position in the caller's list
+  for (uint32_t p = 0; p < n; ++p) {
+    const uint32_t b = pod_off[p], m = pod_off[p + 1] - b;
+    for (uint32_t i = 0; i < m; ++i) { if (pods[b + i] >= base->n_pods) return fail(base, KSOLVE_ERR_INVALID, "probe pod index out of range"); perm[b + i] = i; }
+    std::sort(perm.begin() + b, perm.begin() + b + m, [&](uint32_t x, uint32_t y) { return base->h_rank[pods[b + x]] < base->h_rank[pods[b + y]]; });
+    for (uint32_t i = 0; i < m; ++i) sorted[b + i] = pods[b + perm[b + i]];
+    for (uint32_t i = 1; i < m; ++i) if (sorted[b + i] == sorted[b + i - 1]) return fail(base, KSOLVE_ERR_INVALID, "probe pod listed twice");
+  }
+  std::vector<uint32_t> removed(nodes, nodes + total_nodes);
+  for (uint32_t p = 0; p < n; ++p) {
+    std::sort(removed.begin() + node_off[p], removed.begin() + node_off[p + 1]);
+    for (uint32_t i = node_off[p]; i < node_off[p + 1]; ++i) if (removed[i] >= ne) return fail(base, KSOLVE_ERR_INVALID, "probe node index out of range");
+  }
+  // ---- LDS plan of the launch: the base plan with the claim order cut down to the largest probe ----
+  uint32_t max_m = 1;
+  for (uint32_t p = 0; p < n; ++p) max_m = std::max(max_m, pod_off[p + 1] - pod_off[p]);
+  ks::LdsPlan lp = P.lds;
+  {
+    auto align = [](int x) { return (x + 15) & ~15; };
+    uint32_t want = max_m;
+    if (base->opts.max_claims && base->opts.max_claims < want) want = base->opts.max_claims;
+    int cap = lp.order_cap;
+    if (cap > (int)((want + 63) & ~63u)) cap = (int)((want + 63) & ~63u);
+    int o = lp.off_order;
+    lp.order_cap = cap;
+    o = align(o + cap * 12);
+    lp.off_closed = o; o = align(o + cap / 8 + 8);
+    lp.total_bytes = o;
+  }
+  // ---- arena: every probe's workspace, carved in two passes (measure, then assign) ----
+  std::vector<ks::Workspace> items(n);
+  std::vector<uint32_t> claim_base(n + 1, 0);
+  for (uint32_t p = 0; p < n; ++p) {
+    uint32_t mc = std::max(1u, pod_off[p + 1] - pod_off[p]);
+    if (base->opts.max_claims && base->opts.max_claims < mc) mc = base->opts.max_claims;
+    claim_base[p + 1] = claim_base[p] + mc;
+  }
+  const uint32_t total_mc = claim_base[n];
+  char* arena = nullptr;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { void* q = arena ? (void*)(arena + off) : nullptr; off += (bytes + 63) & ~(size_t)63; return q; };
+  // regions shared by all probes (indexed by pod offset / claim slot / probe)
+  uint32_t* d_sorted = nullptr; uint32_t* d_removed = nullptr; int64_t* d_limits = nullptr;
+  int32_t* d_assign = nullptr; uint32_t* d_slot = nullptr; uint8_t* d_err = nullptr; uint8_t* d_diag = nullptr; uint32_t* d_last = nullptr; uint32_t* d_queue = nullptr;
+  uint64_t* d_hot = nullptr; uint64_t* d_cold = nullptr; uint64_t* d_resv = nullptr; uint64_t* d_chp = nullptr; uint32_t* d_okey = nullptr; uint32_t* d_oord = nullptr; uint32_t* d_opos = nullptr;
+  int* d_nclaims = nullptr; int* d_status = nullptr; ks::Counters* d_ctr = nullptr; ks::Workspace* d_items = nullptr;
+  size_t zero_from = 0, zero_to = 0;
+  bool any_limits = false;
+  for (uint32_t p = 0; p < n; ++p) any_limits = any_limits || (limits && limits[p]);
+  auto layout = [&]() {
+    off = 0;
+    d_items = (ks::Workspace*)take((size_t)n * sizeof(ks::Workspace));
+    d_sorted = (uint32_t*)take((size_t)total_pods * 4 + 4);
+    d_removed = (uint32_t*)take((size_t)total_nodes * 4 + 4);
+    d_limits = any_limits ? (int64_t*)take((size_t)n * T * (nr + 1) * 8) : nullptr;
+    zero_from = off;                                       // everything from here on starts as zeroes
+    d_slot = (uint32_t*)take((size_t)total_pods * 4 + 4); d_err = (uint8_t*)take(total_pods + 4); d_diag = (uint8_t*)take(total_pods + 4);
+    d_last = (uint32_t*)take((size_t)total_pods * 4 + 4); d_queue = (uint32_t*)take(((size_t)total_pods + n) * 4 + 4);
+    d_hot = (uint64_t*)take((size_t)total_mc * lay.c_hot_words() * 8); d_cold = (uint64_t*)take((size_t)total_mc * lay.cold_words() * 8);
+    d_resv = (uint64_t*)take((size_t)total_mc * 8); d_chp = P.hp_on ? (uint64_t*)take((size_t)total_mc * 8) : nullptr;
+    d_okey = (uint32_t*)take((size_t)total_mc * 4); d_oord = (uint32_t*)take((size_t)total_mc * 4); d_opos = (uint32_t*)take((size_t)total_mc * 4);
+    d_nclaims = (int*)take((size_t)n * 4); d_status = (int*)take((size_t)n * 4); d_ctr = (ks::Counters*)take((size_t)n * sizeof(ks::Counters));
+    for (uint32_t p = 0; p < n; ++p) {
+      ks::Workspace& W = items[p];
+      const uint32_t m = pod_off[p + 1] - pod_off[p], mc = claim_base[p + 1] - claim_base[p], cw = (mc + 63) / 64;
+      uint32_t oc = 64;
+      while (oc < 2 * std::min(std::max(1u, m), std::max(1u, ne))) oc <<= 1;
+      W.c_headroom = (int64_t*)take(((size_t)mc * nr + 64) * 8);
+      W.t_its = (uint64_t*)take((size_t)T * base->it_words * 8);
+      W.t_remaining = (int64_t*)take((size_t)T * (nr + 1) * 8);
+      W.dead = (uint64_t*)take((size_t)nc * cw * 8);
+      if (ne) {
+        W.ov_key = (uint32_t*)take((size_t)oc * 4); W.pr_revived = (uint32_t*)take((size_t)oc * 4);
+        W.n_mask = (uint64_t*)take((size_t)base->req_words * oc * 8);
+        W.n_defined = (uint32_t*)take((size_t)oc * 4); W.n_complement = (uint32_t*)take((size_t)oc * 4);
+        if (bounds) { W.n_hg = (uint32_t*)take((size_t)oc * 4); W.n_hl = (uint32_t*)take((size_t)oc * 4); W.n_gte = (int64_t*)take((size_t)nk * oc * 8); W.n_lte = (int64_t*)take((size_t)nk * oc * 8); }
+        W.n_remaining = (int64_t*)take((size_t)nr * oc * 8);
+        W.n_npods = (uint32_t*)take((size_t)oc * 4);
+        W.n_hp = P.hp_on ? (uint64_t*)take((size_t)oc * 8) : nullptr;
+      }
+      W.ov_cap = (int)oc;
+    }
+    zero_to = off;
+    d_assign = (int32_t*)take((size_t)total_pods * 4 + 4);   // starts as -1
+  };
+  layout();
+  const size_t total = off;
+  arena = sweep_buffer(base, base->sweep_arena, base->sweep_arena_bytes, total);
+  if (!arena) return fail(base, KSOLVE_ERR_DEVICE, base->error.empty() ? "device allocation failed (sweep arena)" : base->error);
+  for (uint32_t p = 0; p < n; ++p) items[p] = ks::Workspace{};
+  layout();
+  std::vector<int64_t> lim;
+  if (any_limits) {
+    lim.resize((size_t)n * T * (nr + 1));
+    std::vector<int64_t> base_lim((size_t)T * (nr + 1));
+    be_d2h(base, base_lim.data(), P.tmpl_limits, base_lim.size() * 8);
+    be_sync(base);
+    for (uint32_t p = 0; p < n; ++p) memcpy(lim.data() + (size_t)p * T * (nr + 1), (limits[p] ? limits[p] : base_lim.data()), (size_t)T * (nr + 1) * 8);
+  }
+  for (uint32_t p = 0; p < n; ++p) {
+    ks::Workspace& W = items[p];
+    const uint32_t b = pod_off[p], m = pod_off[p + 1] - b, cb = claim_base[p], mc = claim_base[p + 1] - cb;
+    W.max_claims = (int)mc; W.claim_words = (int)((mc + 63) / 64);
+    W.c_hot = d_hot + (size_t)cb * lay.c_hot_words(); W.c_cold = d_cold + (size_t)cb * lay.cold_words();
+    W.c_reserved = d_resv + cb; W.c_hp = d_chp ? d_chp + cb : nullptr;
+    W.o_key = d_okey + cb; W.o_ord = d_oord + cb; W.o_pos = d_opos + cb;
+    W.queue = d_queue + b + p; W.last_len = d_last + b;
+    W.assign = d_assign + b; W.slot = d_slot + b; W.err = d_err + b; W.diag = d_diag + b;
+    W.n_claims_out = d_nclaims + p; W.status_out = d_status + p; W.counters = d_ctr + p;
+    W.cancel_flag = (cancel && cancel[p]) ? cancel[p] : base->d_cancel;   // ksolve_cancel(base) stops every probe of a ksolve_sweep
+    W.max_steps = base->opts.max_steps;
+    W.min_values_best_effort = base->opts.min_values_best_effort ? 1 : 0;
+    W.n_mask0 = base->ws.n_mask0; W.n_defined0 = base->ws.n_defined0; W.n_complement0 = base->ws.n_complement0; W.n_remaining0 = base->ws.n_remaining0;
+    W.probe = 1; W.pr_n_pods = (int)m; W.pr_sorted = d_sorted + b;
+    W.pr_removed = d_removed + node_off[p]; W.pr_n_removed = (int)(node_off[p + 1] - node_off[p]);
+    W.pr_limits = d_limits ? d_limits + (size_t)p * T * (nr + 1) : nullptr;
+    W.pr_order_cap = lp.order_cap;
+  }
+  be_h2d(base, d_items, items.data(), (size_t)n * sizeof(ks::Workspace));
+  if (total_pods) be_h2d(base, d_sorted, sorted.data(), (size_t)total_pods * 4);
+  if (total_nodes) be_h2d(base, d_removed, removed.data(), (size_t)total_nodes * 4);
+  if (d_limits) be_h2d(base, d_limits, lim.data(), lim.size() * 8);
+  be_fill(base, arena + zero_from, 0, zero_to - zero_from);
+  be_fill(base, d_assign, 0xFF, (size_t)total_pods * 4 + 4);
+  be_h2d(base, base->d_pv, &P, sizeof(P));
+  be_sync(base);
+  be_toc(base, T_UPLOAD);
+  if (!be_ok(base)) return fail(base, KSOLVE_ERR_DEVICE, base->error.empty() ? "sweep upload failed" : base->error);
+
+  // ---- the launch: block b = the general engine on probe b ----
+  be_launch_pack_sweep(base, base->d_pv, d_items, (int)n, lp);
+  std::vector<int> n_claims(n, 0), status(n, 0);
+  be_d2h(base, n_claims.data(), d_nclaims, (size_t)n * 4);
+  be_d2h(base, status.data(), d_status, (size_t)n * 4);
+  std::vector<uint32_t> oord(total_mc);
+  if (total_mc) be_d2h(base, oord.data(), d_oord, (size_t)total_mc * 4);
+  be_sync(base);
+  if (!be_ok(base)) return fail(base, KSOLVE_ERR_DEVICE, base->error.empty() ? "sweep launch failed" : base->error);
+
+  // ---- finalize over the claims of every probe, in the order the reference's slices end in ----
+  be_tic(base, T_FINALIZE);
+  im->claim_off.assign(n + 1, 0);
+  im->status.assign(n, KSOLVE_OK);
+  std::vector<uint32_t> slot_of;
+  for (uint32_t p = 0; p < n; ++p) {
+    if (status[p] == 1) { im->status[p] = KSOLVE_ERR_CAPACITY; n_claims[p] = 0; }
+    else if (status[p] == 2) im->status[p] = KSOLVE_ERR_CANCELLED;
+    for (int i = 0; i < n_claims[p]; ++i) slot_of.push_back(claim_base[p] + oord[claim_base[p] + i]);
+    im->claim_off[p + 1] = (uint32_t)slot_of.size();
+  }
+  const uint32_t C = (uint32_t)slot_of.size();
+  const uint32_t n_its = base->n_its;
+  const bool trunc = base->opts.truncate_instance_types != 0;
+  std::vector<uint64_t> hot((size_t)C * lay.c_hot_words()), cold((size_t)C * lay.cold_words()), reserved(C);
+  std::vector<double> cheapest(C);
+  std::vector<int64_t> daemon_req((size_t)C * nr);
+  std::vector<int32_t> t_idx; std::vector<uint32_t> t_cnt; std::vector<uint8_t> t_fail;
+  if (C) {
+    size_t fo = 0;
+    char* fb = nullptr;
+    auto ftake = [&](size_t bytes) { void* q = fb ? (void*)(fb + fo) : nullptr; fo += (bytes + 63) & ~(size_t)63; return q; };
+    uint32_t* f_slot; double* f_cheap; int64_t* f_dreq; int32_t* f_idx = nullptr; double* f_price = nullptr; uint32_t* f_cnt = nullptr; uint8_t* f_fail = nullptr;
+    uint64_t *g_hot, *g_cold, *g_resv;
+    auto flay = [&]() {
+      fo = 0;
+      f_slot = (uint32_t*)ftake((size_t)C * 4); f_cheap = (double*)ftake((size_t)C * 8); f_dreq = (int64_t*)ftake((size_t)C * nr * 8);
+      if (trunc) { f_idx = (int32_t*)ftake((size_t)C * n_its * 4); f_price = (double*)ftake((size_t)C * n_its * 8); f_cnt = (uint32_t*)ftake((size_t)C * 4); f_fail = (uint8_t*)ftake(C); }
+      g_hot = (uint64_t*)ftake(hot.size() * 8); g_cold = (uint64_t*)ftake(cold.size() * 8); g_resv = (uint64_t*)ftake((size_t)C * 8);
+    };
+    flay();
+    fb = sweep_buffer(base, base->sweep_fin, base->sweep_fin_bytes, fo);
+    if (!fb) return fail(base, KSOLVE_ERR_DEVICE, base->error.empty() ? "device allocation failed (sweep finalize)" : base->error);
+    flay();
+    be_h2d(base, f_slot, slot_of.data(), (size_t)C * 4);
+    ks::FinalizeArgs F{P.dict, (int)n_its, (int)base->it_words, P.n_zones, P.n_cts, P.it_off_avail, P.it_off_price, d_hot, d_cold, lay, f_cheap,
+                       P.dg_first, P.dg_ov, P.dg_its, P.dg_nonempty, items[0].t_its, f_dreq,
+                       P.reserved_on ? d_resv : nullptr, P.it_resv_first, P.resv_zone, P.resv_id, P.resv_price,
+                       0, 0, P.it_reqs, nullptr, nullptr, nullptr, nullptr, f_slot};
+    if (trunc) {
+      F.truncate_n = (int)base->opts.truncate_instance_types; F.best_effort = base->opts.min_values_best_effort ? 1 : 0;
+      F.sort_idx = f_idx; F.sort_price = f_price; F.ordered_count = f_cnt; F.trunc_failed = f_fail;
+    }
+    be_launch_finalize(base, (int)C, F);
+    ks::ClaimGatherArgs G{lay, f_slot, d_hot, d_cold, d_resv, g_hot, g_cold, g_resv};
+    be_launch_claim_gather(base, (int)C, G);
+    be_toc(base, T_FINALIZE);
+    be_tic(base, T_DOWNLOAD);
+    be_d2h(base, hot.data(), g_hot, hot.size() * 8); be_d2h(base, cold.data(), g_cold, cold.size() * 8); be_d2h(base, reserved.data(), g_resv, (size_t)C * 8);
+    be_d2h(base, cheapest.data(), f_cheap, (size_t)C * 8); be_d2h(base, daemon_req.data(), f_dreq, daemon_req.size() * 8);
+    if (trunc) {
+      t_idx.resize((size_t)C * n_its); t_cnt.resize(C); t_fail.resize(C);
+      be_d2h(base, t_idx.data(), f_idx, t_idx.size() * 4); be_d2h(base, t_cnt.data(), f_cnt, (size_t)C * 4); be_d2h(base, t_fail.data(), f_fail, C);
+    }
+  } else { be_toc(base, T_FINALIZE); be_tic(base, T_DOWNLOAD); }
+  std::vector<int32_t> assign(total_pods); std::vector<uint32_t> slot(total_pods); std::vector<uint8_t> err(total_pods), diag(total_pods);
+  if (total_pods) {
+    be_d2h(base, assign.data(), d_assign, (size_t)total_pods * 4); be_d2h(base, slot.data(), d_slot, (size_t)total_pods * 4);
+    be_d2h(base, err.data(), d_err, total_pods); be_d2h(base, diag.data(), d_diag, total_pods);
+  }
+  im->counters.resize(n);
+  be_d2h(base, im->counters.data(), d_ctr, (size_t)n * sizeof(ks::Counters));
+  be_sync(base);
+  be_toc(base, T_DOWNLOAD);
+  if (!be_ok(base)) return fail(base, KSOLVE_ERR_DEVICE, base->error.empty() ? "sweep download failed" : base->error);
+
+  // ---- rows of ksolve_claims + per-pod results in the caller's pod order ----
+  ClaimCols cc; cc.resize(C, base);
+  for (uint32_t c = 0; c < C; ++c)
+    decode_claim(base, P, c, hot.data() + (size_t)c * lay.c_hot_words(), cold.data() + (size_t)c * lay.cold_words(), reserved[c], daemon_req.data() + (size_t)c * nr, cc);
+  ResultsImpl& R = im->claims;
+  R.tmpl = std::move(cc.tmpl); R.npods = std::move(cc.npods); R.its = std::move(cc.its); R.mask = std::move(cc.mask);
+  R.defined = std::move(cc.defined); R.complement = std::move(cc.complement); R.has_gte = std::move(cc.has_gte); R.has_lte = std::move(cc.has_lte);
+  R.gte = std::move(cc.gte); R.lte = std::move(cc.lte); R.minv = std::move(cc.minv); R.requests = std::move(cc.requests);
+  R.host_seq = std::move(cc.host_seq); R.relaxed = std::move(cc.relaxed); R.cheapest = std::move(cheapest); R.reserved = std::move(reserved);
+  R.t_idx = std::move(t_idx); R.t_cnt = std::move(t_cnt); R.t_fail = std::move(t_fail);
+  im->assign.assign(total_pods, -1); im->slot.assign(total_pods, 0); im->err.assign(total_pods, 0); im->diag.assign(total_pods, 0);
+  im->ref.assign(n, 0);
+  std::vector<uint32_t> newidx;
+  for (uint32_t p = 0; p < n; ++p) {
+    const uint32_t b = pod_off[p], m = pod_off[p + 1] - b, cb = claim_base[p];
+    const uint32_t Cp = im->claim_off[p + 1] - im->claim_off[p];
+    newidx.assign(claim_base[p + 1] - cb, 0);
+    for (uint32_t i = 0; i < Cp; ++i) newidx[oord[cb + i]] = i;
+    for (uint32_t i = 0; i < m; ++i) {
+      const uint32_t dst = b + perm[b + i];   // sorted position i is the caller's pod perm[i]
+      int32_t a = assign[b + i];
+      if (im->status[p] == KSOLVE_ERR_CAPACITY) a = -1;
+      else if (a >= 0) a = (int32_t)newidx[a];
+      im->assign[dst] = a; im->slot[dst] = slot[b + i]; im->err[dst] = err[b + i]; im->diag[dst] = diag[b + i];
+    }
+    im->ref[p] = im->counters[p].ref_bin_evaluations;
+  }
+  if (us) { us[0] = base->timers.ms[T_UPLOAD] * 1e3; us[1] = base->timers.ms[T_PACK] * 1e3; us[2] = base->timers.ms[T_FINALIZE] * 1e3; us[3] = base->timers.ms[T_DOWNLOAD] * 1e3; }
+  return KSOLVE_OK;
+}
+
+static void fill_claims_view(const ksolve_handle* h, const ResultsImpl& R, size_t first, uint32_t count, ksolve_claims& cl) {
+  cl.n_claims = count; cl.it_words = h->it_words; cl.req_words = h->req_words; cl.n_keys = h->n_keys; cl.n_res = h->n_res;
+  cl.template_idx = R.tmpl.data() + first; cl.pod_count = R.npods.data() + first; cl.it_mask = R.its.data() + first * h->it_words; cl.requests = R.requests.data() + first * h->n_res;
+  cl.req_mask = R.mask.data() + first * h->req_words; cl.req_defined = R.defined.data() + first; cl.req_complement = R.complement.data() + first;
+  cl.req_has_gte = R.has_gte.data() + first; cl.req_has_lte = R.has_lte.data() + first; cl.req_gte = R.gte.data() + first * h->n_keys; cl.req_lte = R.lte.data() + first * h->n_keys;
+  cl.req_min_values = R.minv.data() + first * h->n_keys; cl.min_values_relaxed = R.relaxed.data() + first; cl.cheapest_price = R.cheapest.data() + first;
+  cl.hostname_seq = R.host_seq.data() + first; cl.reserved_mask = R.reserved.data() + first;
+  cl.n_instance_types = h->n_its;
+  if (!R.t_cnt.empty()) { cl.ordered_instance_types = R.t_idx.data() + first * h->n_its; cl.ordered_count = R.t_cnt.data() + first; cl.truncation_failed = R.t_fail.data() + first; }
+}
+
+// ksolve_sweep
+static ksolve_status sweep(ksolve_handle* base, const ksolve_sweep_desc* d, ksolve_sweep_results* out) {
+  memset(out, 0, sizeof(*out));
+  if (!base || base->base || !d) return base ? fail(base, KSOLVE_ERR_INVALID, "sweep of a null handle / of a probe") : KSOLVE_ERR_INVALID;
+  if (base->has_topology) return fail(base, KSOLVE_ERR_UNSUPPORTED, "sweeps of a cluster with topology groups: create one handle per probe");
+  if (d->n_probes && (!d->node_off || !d->pod_off || (d->pod_off[d->n_probes] && !d->pods) || (d->node_off[d->n_probes] && !d->nodes)))
+    return fail(base, KSOLVE_ERR_INVALID, "sweep descriptor arrays missing");
+  const uint32_t n = d->n_probes;
+  const size_t lsz = (size_t)base->n_templates * (base->n_res + 1);
+  std::vector<const int64_t*> lims(n, nullptr);
+  if (d->tmpl_limits) for (uint32_t p = 0; p < n; ++p) lims[p] = d->tmpl_limits + (size_t)p * lsz;
+  SweepImpl* im = new SweepImpl();
+  double us[4] = {0, 0, 0, 0};
+  const uint32_t zero_off[1] = {0};
+  be_fill(base, base->d_cancel, 0, 4);   // a fresh context, as in solve_prepare
+  be_sync(base);
+  ksolve_status st = n ? sweep_run(base, n, d->node_off, d->nodes, d->pod_off, d->pods, d->tmpl_limits ? lims.data() : nullptr, nullptr, im, us) : KSOLVE_OK;
+  if (!n) { im->claim_off.assign(1, 0); (void)zero_off; }
+  if (st != KSOLVE_OK) { delete im; return st; }
+  out->n_probes = n;
+  out->status = im->status.data();
+  out->pod_assignment = im->assign.data(); out->pod_error = im->err.data(); out->pod_error_diag = im->diag.data(); out->pod_slot = im->slot.data();
+  out->claim_off = im->claim_off.data();
+  fill_claims_view(base, im->claims, 0, im->claim_off[n], out->claims);
+  out->ref_bin_evaluations = im->ref.data();
+  out->us_upload = us[0]; out->us_pack = us[1]; out->us_finalize = us[2]; out->us_download = us[3];
+  out->impl = im;
+  return KSOLVE_OK;
+}
+
+// ksolve_results of ONE probe handle from its slice of a sweep: the contract of ksolve_probe_create — the base problem's pod
+// numbering, pods outside the probe unassigned
+static ksolve_status probe_results(ksolve_handle* h, const SweepImpl& S, uint32_t p, uint32_t pod_base, ksolve_results* out) {
+  memset(out, 0, sizeof(*out));
+  ksolve_handle* base = h->base;
+  if (S.status[p] == KSOLVE_ERR_CAPACITY) return fail(h, KSOLVE_ERR_CAPACITY, "more in-flight NodeClaims than a probe keeps resident (ksolve_options.max_claims / the LDS claim order)");
+  ResultsImpl* im = new ResultsImpl();
+  const uint32_t n_pods = base->n_pods;
+  im->assign.assign(n_pods, -1); im->err.assign(n_pods, 0); im->diag.assign(n_pods, 0); im->slot.assign(n_pods, 0);
+  for (size_t i = 0; i < h->pr_pods.size(); ++i) {
+    const uint32_t g = h->pr_pods[i];
+    im->assign[g] = S.assign[pod_base + i]; im->err[g] = S.err[pod_base + i]; im->diag[g] = S.diag[pod_base + i]; im->slot[g] = S.slot[pod_base + i];
+  }
+  const uint32_t c0 = S.claim_off[p], C = S.claim_off[p + 1] - c0;
+  const ResultsImpl& R = S.claims;
+  auto cut = [&](auto& dst, const auto& src, size_t width) { if (!src.empty()) dst.assign(src.begin() + (size_t)c0 * width, src.begin() + (size_t)(c0 + C) * width); };
+  cut(im->tmpl, R.tmpl, 1); cut(im->npods, R.npods, 1); cut(im->its, R.its, h->it_words); cut(im->mask, R.mask, h->req_words);
+  cut(im->defined, R.defined, 1); cut(im->complement, R.complement, 1); cut(im->has_gte, R.has_gte, 1); cut(im->has_lte, R.has_lte, 1);
+  cut(im->gte, R.gte, h->n_keys); cut(im->lte, R.lte, h->n_keys); cut(im->minv, R.minv, h->n_keys); cut(im->requests, R.requests, h->n_res);
+  cut(im->host_seq, R.host_seq, 1); cut(im->relaxed, R.relaxed, 1); cut(im->cheapest, R.cheapest, 1); cut(im->reserved, R.reserved, 1);
+  cut(im->t_idx, R.t_idx, h->n_its); cut(im->t_cnt, R.t_cnt, 1); cut(im->t_fail, R.t_fail, 1);
+  double cost = 0;
+  for (uint32_t i = 0; i < C; ++i) if (im->cheapest[i] < 1e300) cost += im->cheapest[i];
+  out->status = (ksolve_status)S.status[p];
+  out->n_pods = n_pods;
+  out->pod_assignment = im->assign.data(); out->pod_error = im->err.data(); out->pod_error_diag = im->diag.data(); out->pod_slot = im->slot.data();
+  fill_claims_view(h, *im, 0, C, out->claims);
+  const ks::Counters& ctr = S.counters[p];
+  out->bin_evaluations = ctr.bin_evaluations; out->it_evaluations = ctr.it_evaluations; out->queue_pops = ctr.queue_pops;
+  out->sorts = ctr.sorts; out->slow_sorts = ctr.slow_sorts; out->relaxations = ctr.relaxations;
+  out->ref_bin_evaluations = ctr.ref_bin_evaluations;
+  for (int i = 0; i < 24; ++i) out->phase_cycles[i] = ctr.cycles[i];
+  out->us_upload = base->timers.ms[T_UPLOAD] * 1e3; out->us_pack = base->timers.ms[T_PACK] * 1e3;
+  out->us_finalize = base->timers.ms[T_FINALIZE] * 1e3; out->us_download = base->timers.ms[T_DOWNLOAD] * 1e3;
+  h->timers = base->timers;
+  out->packing_cost = cost;
+  out->engine_used = 1; out->engine_fallback_reason = 0;
+  out->impl = im;
+  return out->status;
+}
+
+// probe handles of one base, one launch
+static void solve_probes(ksolve_handle** hs, uint32_t n, ksolve_results* outs, ksolve_status* st, bool fresh_context) {
+  ksolve_handle* base = hs[0]->base;
+  std::vector<uint32_t> node_off(n + 1, 0), pod_off(n + 1, 0), nodes, pods;
+  std::vector<const int64_t*> lims(n, nullptr);
+  std::vector<int*> cancel(n, nullptr);
+  bool any_lim = false;
+  for (uint32_t i = 0; i < n; ++i) {
+    ksolve_handle* h = hs[i];
+    nodes.insert(nodes.end(), h->pr_nodes.begin(), h->pr_nodes.end()); pods.insert(pods.end(), h->pr_pods.begin(), h->pr_pods.end());
+    node_off[i + 1] = (uint32_t)nodes.size(); pod_off[i + 1] = (uint32_t)pods.size();
+    if (!h->pr_limits.empty()) { lims[i] = h->pr_limits.data(); any_lim = true; }
+    cancel[i] = h->d_cancel;
+    if (fresh_context) {
+      be_fill(h, h->d_cancel, 0, 4);
+      if (const char* at = getenv("KSOLVE_TEST_CANCEL_AT")) { const int v = -atoi(at); if (v < 0) be_h2d(h, h->d_cancel, &v, 4); }
+      be_sync(h);
+    }
+  }
+  SweepImpl S;
+  ksolve_status rc = sweep_run(base, n, node_off.data(), nodes.data(), pod_off.data(), pods.data(), any_lim ? lims.data() : nullptr, cancel.data(), &S, nullptr);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (rc != KSOLVE_OK) { memset(&outs[i], 0, sizeof(outs[i])); st[i] = fail(hs[i], rc, base->error); outs[i].status = st[i]; continue; }
+    st[i] = probe_results(hs[i], S, i, pod_off[i], &outs[i]);
+    outs[i].status = st[i];
+  }
+}
+
 static void be_results_drop(ksolve_results* r) { if (r && r->impl) { delete (ResultsImpl*)r->impl; r->impl = nullptr; } }
 static ksolve_status solve(ksolve_handle* h, ksolve_results* out, bool fresh_context = true) {
   memset(out, 0, sizeof(*out));
+  if (h->base) { ksolve_status st = KSOLVE_OK; solve_probes(&h, 1, out, &st, fresh_context); return st; }
   ksolve_status st = solve_prepare(h, fresh_context);
   if (st != KSOLVE_OK) return st;
   if (h->opts.engine == 2 && !(h->fw.enabled && !h->pv.big && h->n_pods && h->n_classes))
@@ -1109,7 +1469,7 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out, bool fresh_con
 
 // Many independent problems, one launch: block b of the pack kernel is the wavefront of problem b. This is how
 // consolidation sweeps (helpers.go:53-155: one Solve() per candidate set) and NodePool components fill the chip.
-static ksolve_status solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) {
+static ksolve_status solve_batch_plain(ksolve_handle** hs, uint32_t n, ksolve_results* outs) {
   for (uint32_t i = 0; i < n; ++i) memset(&outs[i], 0, sizeof(outs[i]));
   std::vector<ksolve_status> st(n, KSOLVE_OK);
   // The prepass (classes, queue order) and the result download of different problems are independent: a few host
@@ -1166,6 +1526,36 @@ static ksolve_status solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results*
   });
   ksolve_status worst = KSOLVE_OK;
   for (uint32_t i = 0; i < n; ++i) if (st[i] != KSOLVE_OK && st[i] != KSOLVE_ERR_CANCELLED) worst = st[i];
+  return worst;
+}
+
+// ksolve_solve_batch: probes of a resident cluster run as one sweep per base handle, everything else as above
+static ksolve_status solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) {
+  std::vector<uint32_t> plain_idx;
+  std::vector<ksolve_handle*> bases;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!hs[i]->base) { plain_idx.push_back(i); continue; }
+    if (std::find(bases.begin(), bases.end(), hs[i]->base) == bases.end()) bases.push_back(hs[i]->base);
+  }
+  if (bases.empty()) return solve_batch_plain(hs, n, outs);
+  ksolve_status worst = KSOLVE_OK;
+  for (ksolve_handle* b : bases) {
+    std::vector<uint32_t> idx;
+    std::vector<ksolve_handle*> g;
+    for (uint32_t i = 0; i < n; ++i) if (hs[i]->base == b) { idx.push_back(i); g.push_back(hs[i]); }
+    std::vector<ksolve_results> ro(g.size());
+    std::vector<ksolve_status> st(g.size(), KSOLVE_OK);
+    solve_probes(g.data(), (uint32_t)g.size(), ro.data(), st.data(), true);
+    for (size_t k = 0; k < g.size(); ++k) { outs[idx[k]] = ro[k]; if (st[k] != KSOLVE_OK && st[k] != KSOLVE_ERR_CANCELLED) worst = st[k]; }
+  }
+  if (!plain_idx.empty()) {
+    std::vector<ksolve_handle*> g;
+    for (uint32_t i : plain_idx) g.push_back(hs[i]);
+    std::vector<ksolve_results> ro(g.size());
+    const ksolve_status rc = solve_batch_plain(g.data(), (uint32_t)g.size(), ro.data());
+    for (size_t k = 0; k < g.size(); ++k) outs[plain_idx[k]] = ro[k];
+    if (rc != KSOLVE_OK) worst = rc;
+  }
   return worst;
 }
 

@@ -197,6 +197,10 @@ struct ProblemView {
   const uint64_t* node_taints;   // [n_nodes]
   const uint8_t* node_flags;     // [n_nodes] bit0 initialized, bit1 under consolidateAfter
   const uint8_t* pod_from_deleting; // [n_pods]
+  // resident-cluster probes (ksolve_sweep, ksolve_probe_create): computed once per base handle, shared by every probe
+  const uint64_t* n_dead0;       // [n_classes][node_words] class k cannot go on the PRISTINE node e for a reason that precedes topology (ksolve_node_dead0)
+  const uint64_t* node_skip;     // [node_words] the nodes under consolidateAfter (node_flags bit1) as a bitmap
+  const uint32_t* node_skip_prefix;   // [node_words + 1] how many of them precede each word
   TopoView topo;
   int big;                       // more in-flight claims than the LDS order holds: Engine<W, true, true> (order in HBM)
   int plain;                     // no topology groups, existing nodes, daemon overhead, minValues, reservations or bounds (any size)
@@ -262,6 +266,21 @@ struct Workspace {
   int32_t* assign;               // [n_pods]
   uint8_t *err, *diag;           // [n_pods]
   uint32_t* slot;                // [n_pods]
+  // ---- a probe of a resident cluster (disruption/helpers.go:53-155: Solve() on "the cluster without these nodes, with these
+  // pods pending") ----  The cluster's node tables stay pristine and shared (n_*0, ProblemView::node_hp0); the probe keeps the
+  // few nodes it commits pods to in an open-addressing overlay: the mutable n_* arrays above then have ov_cap slots (their
+  // stride) instead of n_nodes, n_dead is not used (ProblemView::n_dead0 + the nodes in pr_revived), and the per-pod outputs
+  // (assign, slot, err, diag, last_len) are indexed by the pod's position in pr_sorted.
+  int probe;
+  int pr_n_pods;                 // pods this probe schedules
+  const uint32_t* pr_sorted;     // [pr_n_pods] their pod indices in the base problem, in queue order
+  const uint32_t* pr_removed;    // [pr_n_removed] existing nodes that are not part of the simulation (helpers.go:76-80), ascending
+  int pr_n_removed;
+  const int64_t* pr_limits;      // [n_templates][n_res+1] NodePool limits with the removed nodes' capacity handed back, or null = the base problem's
+  int pr_order_cap;              // claims the launch's LDS plan can order
+  uint32_t* ov_key;              // [ov_cap] node + 1, 0 = free
+  int ov_cap;                    // a power of two >= 2 * min(pr_n_pods, n_nodes)
+  uint32_t* pr_revived;          // [ov_cap] overlaid nodes whose pristine rejections a commit has voided (revives_rejections)
   // scalars
   int* n_claims_out;
   int* status_out;               // 0 ok, 1 capacity exceeded, 2 cancelled/timed out

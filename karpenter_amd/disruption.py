@@ -277,6 +277,7 @@ def interweave_by_nodepool(candidates, previously_unseen=()):
 
 
 MAX_INSTANCE_TYPES = 600   # scheduling.MaxInstanceTypes, nodeclaimtemplate.go:50
+PARTITION = "example.com/partition"   # make_resident_cluster: the custom label that splits its dedicated NodePool
 
 
 def _finish_simulation(cluster, res, deleting_uids):
@@ -327,6 +328,17 @@ class ResidentCluster:
         self.scheduler = NewScheduler(prob, solver_lib)
         self._cache = {}
 
+    @classmethod
+    def from_compact(cls, cc, solver_lib=None):
+        """The resident cluster of a compact cluster (make_resident_cluster): every bound pod is a pod row of the base problem,
+        so any node can be a candidate. Only decisions() is available (no per-probe pod lists on the Python side)."""
+        from .scheduling import NewScheduler
+        self = object.__new__(cls)
+        self.cluster = cc
+        self._deleting_pods, self._deleting_uids, self._always, self._cache = [], set(), list(cc.get("pendingPods", [])), {}
+        self.scheduler = NewScheduler(compact_problem(cc, pods=copy.deepcopy(self._always)), solver_lib)
+        return self
+
     def _key(self, candidates):
         return tuple(sorted(c["name"] for c in candidates))
 
@@ -349,8 +361,195 @@ class ResidentCluster:
         self.prefetch([candidates])
         return self._cache[self._key(candidates)]
 
+    def decisions(self, candidate_sets, detail=False):
+        """computeConsolidation (consolidation.go:159-256) for every candidate set in ONE device launch, verdicts included
+        (Scheduler.Sweep / ksolve_sweep): [{"decision", "candidates", "replacement", "replacementCapacityType"}], the commands
+        compute_consolidation() returns without their Results. Descriptors and verdicts are computed by the host library."""
+        cluster = self.cluster
+        live = [[c for c in cs if not c.get("markedForDeletion")] for cs in candidate_sets]
+        prices = [sum(self._price(c) for c in cs) for cs in candidate_sets]
+        all_spot = [all(c["labels"][fx.CAPACITY_TYPE] == "spot" for c in cs) for cs in candidate_sets]
+        out = self.scheduler.Sweep([[c["name"] for c in cs] for cs in live], prices, all_spot, detail=detail)
+        repl = {r["probe"]: r for r in out["replacements"]}
+        cmds = []
+        for i, cs in enumerate(candidate_sets):
+            d = out["decisions"][i]
+            if d == 3:   # spot-to-spot behind its feature gate: the per-probe path has the whole ordered list
+                cmd = dict(compute_consolidation(cluster, cs, self))
+                cmd.pop("results", None)
+                cmds.append(cmd)
+                continue
+            cmd = {"decision": (NOOP, DELETE, REPLACE)[d], "candidates": [c["name"] for c in cs], "replacement": None}
+            if d == 2:
+                cmd["replacement"] = repl[i]["instanceTypes"]
+                cmd["replacementCapacityType"] = repl[i]["capacityType"]
+            if str(i) in out["reasons"]:
+                cmd["reason"] = out["reasons"][str(i)]
+            cmds.append(cmd)
+        self.last_sweep = out
+        return cmds
+
+    def _price(self, node):
+        key = (node["labels"].get(fx.INSTANCE_TYPE), node["labels"].get(fx.ZONE), node["labels"].get(fx.CAPACITY_TYPE))
+        cache = self.__dict__.setdefault("_price_cache", {})
+        if key not in cache:
+            cache[key] = candidate_price(self.cluster, node)
+        return cache[key]
+
     def close(self):
         self.scheduler.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: a cluster of 100k nodes / 2M bound pods does not fit a list of pod dicts. The COMPACT form keeps the
+# state nodes as dicts (without their pods) and the bound pods as pod groups — {count, uidSeed, template, nodeIndex}: pod i of
+# the group runs on nodes[nodeIndex[i]] — which is also how the host library takes them (podGroups[].nodeIndexB64).
+# ---------------------------------------------------------------------------------------------------------------
+def make_resident_cluster(n_nodes=100_000, seed=42, n_types=144, dedicated_fraction=0.3, scale_down=0.3):
+    """A synthetic under-utilised cluster in compact form, shaped like test/suites/performance/basic_test.go:61-68 (scale the
+    workload out, let the provisioner pack nodes, scale it down by 30%): every node is packed with pods of the benchmark's
+    cpu x memory grid (scheduling_benchmark_test.go:447-455) until its instance type is full, then pods are removed.
+    Two NodePools so that a single-node sweep meets every verdict of computeConsolidation (consolidation.go:159-256):
+      default    ~70% of the nodes, every node loses ~scale_down of its pods: a candidate's pods fit the free room of the
+                 others (delete);
+      dedicated  tainted dedicated=batch:NoSchedule and split into partitions (a custom label the pool admits; pods are pinned
+                 to their partition by node selector + toleration). In 80% of the partitions the nodes stayed full but for a
+                 few that kept a quarter of their pods: a full candidate's pods find room for some of them at most and need
+                 a NodeClaim — a smaller instance type than the one they sit on (replace), the same type again (nothing to
+                 do), or they all fit (delete).
+    A few nodes are not initialized or are under consolidateAfter (helpers.go:133-153, scheduler.go:628).
+    Returns {"instanceTypes", "nodePools", "wellKnownLabels", "nodes", "podGroups", "pendingPods", "nodePodCount"}."""
+    import base64
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    its = fx.kwok_catalog(n_types)
+    sizes = [t for t in its if "linux" in t["name"] and "amd64" in t["name"] and int(t["capacity"]["cpu"]) in (8, 16, 32, 48) and t["name"].startswith(("c-", "s-", "m-"))]
+    n_part = max(4, min(192, n_nodes // 400))
+    parts = [f"p{i:03d}" for i in range(n_part)]
+    pools = [fx.node_pool("dedicated", weight=10, taints=[{"key": "dedicated", "value": "batch", "effect": "NoSchedule"}],
+                          requirements=[fx.req(PARTITION, "In", *parts)]),
+             fx.node_pool("default", weight=0)]
+    for np_ in pools:
+        np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    # the default pool runs the benchmark's small pods; the dedicated pool's batch pods are large — the crumbs a packed node has
+    # left (less than the pod that did not fit) are no home for them
+    small = [(c, m) for c in fx.BENCH_CPU_M for m in fx.BENCH_MEM_MI]
+    combos = small + [(c, m) for c in (4000, 6000) for m in (4096, 8192, 16384)]
+    ccpu = np.array([c for c, _ in combos], dtype=np.int64)                    # milli
+    cmem = np.array([m for _, m in combos], dtype=np.int64)                    # Mi
+    n_ded = int(n_nodes * dedicated_fraction)
+    pool_of = np.zeros(n_nodes, dtype=np.int8)                                 # 1 = dedicated
+    pool_of[rng.choice(n_nodes, n_ded, replace=False)] = 1
+    type_of = rng.integers(0, len(sizes), n_nodes)
+    zone_of = rng.integers(0, len(fx.KWOK_ZONES), n_nodes)
+    spot = rng.random(n_nodes) < 0.35
+    alloc_cpu = np.array([int(t["capacity"]["cpu"]) * 1000 - 100 for t in sizes], dtype=np.int64)[type_of]
+    alloc_mem = np.array([int(t["capacity"]["memory"][:-2]) * 1024 - 10 for t in sizes], dtype=np.int64)[type_of]   # Mi
+    alloc_pods = np.array([int(t["capacity"]["pods"]) for t in sizes], dtype=np.int64)[type_of]
+    # pack: 96 random pods per node, keep the prefix that fits (what first-fit packing leaves on a node: full)
+    part_of = rng.integers(0, n_part, n_nodes)
+    tight = rng.random(n_part) < 0.8                                           # partitions whose nodes stayed full but for a few
+    p_small = min(0.5, 0.7 * n_part / max(1, n_ded))                          # about one scaled-down node per tight partition
+    keep_ded = np.where(tight[part_of], np.where(rng.random(n_nodes) < 1.0 - p_small, 1.0, 0.25), 1.0 - scale_down)
+    keep_p = np.where(pool_of == 0, 1.0 - scale_down, keep_ded)
+    draw = np.empty((n_nodes, 96), dtype=np.int8)
+    kept = np.empty((n_nodes, 96), dtype=bool)
+    used_cpu = np.empty(n_nodes, dtype=np.int64); used_mem = np.empty(n_nodes, dtype=np.int64)
+    for lo in range(0, n_nodes, 8192):                                         # in slices: the temporaries stay small
+        hi = min(n_nodes, lo + 8192)
+        d = np.where(pool_of[lo:hi, None] == 1, rng.integers(len(small), len(combos), (hi - lo, 96)), rng.integers(0, len(small), (hi - lo, 96)))
+        fits = (np.cumsum(ccpu[d], axis=1) <= alloc_cpu[lo:hi, None]) & (np.cumsum(cmem[d], axis=1) <= alloc_mem[lo:hi, None]) & (np.arange(1, 97)[None, :] <= alloc_pods[lo:hi, None])
+        k = fits.cumprod(axis=1).astype(bool) & (rng.random((hi - lo, 96)) < keep_p[lo:hi, None])   # packed, then scaled down
+        draw[lo:hi] = d; kept[lo:hi] = k
+        used_cpu[lo:hi] = (ccpu[d] * k).sum(axis=1); used_mem[lo:hi] = (cmem[d] * k).sum(axis=1)
+    n_kept = kept.sum(axis=1)
+    uninit = rng.random(n_nodes) < 0.002
+    uca = rng.random(n_nodes) < 0.01
+    label_cache = {}
+    nodes = []
+    import gc
+    gc_was = gc.isenabled()
+    gc.disable()                                                               # 100k dicts of dicts: no cycles to find, a lot of generations to scan
+    type_of, zone_of, spot_l, pool_l, uninit_l, part_l = type_of.tolist(), zone_of.tolist(), spot.tolist(), pool_of.tolist(), uninit.tolist(), part_of.tolist()
+    free_cpu, free_mem, free_pods, uca_l = (alloc_cpu - used_cpu).tolist(), (alloc_mem - used_mem).tolist(), (alloc_pods - n_kept).tolist(), uca.tolist()
+    for i in range(n_nodes):
+        key = (type_of[i], zone_of[i], spot_l[i], pool_l[i], uninit_l[i])
+        base = label_cache.get(key)
+        if base is None:
+            nd = fx.state_node("x", sizes[type_of[i]], fx.KWOK_ZONES[zone_of[i]], "spot" if spot_l[i] else "on-demand", "dedicated" if pool_l[i] else "default",
+                               taints=pools[0]["taints"] if pool_l[i] else None, initialized=not uninit_l[i])
+            base = label_cache[key] = nd
+        name = f"node-{i:06d}"
+        labels = dict(base["labels"]); labels[fx.HOSTNAME] = name
+        if pool_l[i]:
+            labels[PARTITION] = parts[part_l[i]]
+        avail = dict(base["available"])
+        avail["cpu"] = f"{free_cpu[i] * 1_000_000}n"
+        avail["memory"] = f"{free_mem[i] * 1048576 * 10**9}n"
+        avail["pods"] = f"{free_pods[i] * 10**9}n"
+        nodes.append({"name": name, "labels": labels, "taints": base["taints"], "available": avail, "capacity": base["capacity"], "initialized": base["initialized"],
+                      "managed": True, "underConsolidateAfter": uca_l[i]})
+    if gc_was:
+        gc.enable()
+    # bound pods: one group per (pool, cpu, memory)
+    groups = []
+    node_idx, slot_idx = np.nonzero(kept)
+    combo_idx = draw[node_idx, slot_idx]
+    pod_part = np.where(pool_of[node_idx] == 1, part_of[node_idx], -1)         # -1: the default pool
+    gkey = (pod_part + 1) * len(combos) + combo_idx                            # one group per (partition, cpu, memory)
+    by_group = np.argsort(gkey, kind="stable")
+    bounds = np.searchsorted(gkey[by_group], np.arange((n_part + 1) * len(combos) + 1))
+    gi = 0
+    for part in range(-1, n_part):
+        for ci, (c, m) in enumerate(combos):
+            g_ = (part + 1) * len(combos) + ci
+            sel = node_idx[by_group[bounds[g_]:bounds[g_ + 1]]]
+            gi += 1
+            if not len(sel):
+                continue
+            kw = dict(requests={"cpu": f"{c}m", "memory": f"{m}Mi"}, phase="Running")
+            if part >= 0:
+                kw.update(node_selector={PARTITION: parts[part]}, tolerations=[{"key": "dedicated", "operator": "Exists", "effect": "NoSchedule"}])
+            groups.append({"count": int(len(sel)), "uidSeed": seed * 100003 + gi, "template": fx.pod(uid="t", **kw),
+                           "nodeIndexB64": base64.b64encode(sel.astype("<i4").tobytes()).decode(), "_nodeIndex": sel.astype(np.int32)})
+    return {"instanceTypes": its, "nodePools": pools, "wellKnownLabels": fx.KWOK_WELL_KNOWN, "nodes": nodes, "podGroups": groups, "pendingPods": [],
+            "nodePodCount": n_kept.astype(int).tolist()}
+
+
+def compact_node_pods(cc, node_index):
+    """The pods bound to node `node_index` of a compact cluster as pod dicts (uids as the host library derives them)."""
+    import numpy as np
+    out = []
+    for g in cc["podGroups"]:
+        for pos in np.nonzero(g["_nodeIndex"] == node_index)[0]:
+            out.append(dict(g["template"], uid=fx.group_pod_uid(g["uidSeed"], int(pos)), nodeName=cc["nodes"][node_index]["name"]))
+    return out
+
+
+def compact_candidates(cc):
+    """sortCandidates (consolidation.go:149-154) over a compact cluster: descending price / disruption cost, names break ties;
+    returns node indices. Every bound pod costs 1 (no deletion-cost annotations or priorities in the synthetic cluster)."""
+    price_cache = {}
+    keyed = []
+    for i, n in enumerate(cc["nodes"]):
+        k = (n["labels"].get(fx.INSTANCE_TYPE), n["labels"].get(fx.ZONE), n["labels"].get(fx.CAPACITY_TYPE))
+        if k not in price_cache:
+            price_cache[k] = candidate_price(cc, n)
+        keyed.append((-(price_cache[k] / (PER_NODE_BASE_DISRUPTION_COST + cc["nodePodCount"][i])), n["name"], i))
+    keyed.sort()
+    return [i for _, _, i in keyed]
+
+
+def compact_problem(cc, pods=None, pod_groups=None, strip=True):
+    groups = [{k: v for k, v in g.items() if not k.startswith("_")} for g in (cc["podGroups"] if pod_groups is None else pod_groups)]
+    # maxClaims: the base handle of a resident cluster is never solved itself; a probe may create this many NodeClaims
+    return fx.problem(cc["instanceTypes"], cc["nodePools"], pods or [], pod_groups=groups, well_known=cc["wellKnownLabels"], state_nodes=cc["nodes"],
+                      options=dict(cc.get("options", {}), consolidationSimulation=True, truncateInstanceTypes=MAX_INSTANCE_TYPES, maxClaims=cc.get("maxClaimsPerProbe", 2048)))
+
+
+def decide(cluster, candidates, res):
+    """computeConsolidation (consolidation.go:159-256) from the Results of the simulation."""
+    return compute_consolidation(cluster, candidates, lambda _prob: None, results=res)
 
 
 def simulate_scheduling(cluster, candidates, solver):
@@ -423,9 +622,10 @@ def _spot_to_spot(cluster, candidates, cmd, claim, reqs, price, by_name):
     return cmd
 
 
-def compute_consolidation(cluster, candidates, solver):
-    """consolidation.go:159-256 → {"decision", "candidates", "replacement": instance type names}."""
-    res = simulate_scheduling(cluster, candidates, solver)
+def compute_consolidation(cluster, candidates, solver, results=None):
+    """consolidation.go:159-256 → {"decision", "candidates", "replacement": instance type names}. `results`: the Results of the
+    simulation when the caller already has them (finished by _finish_simulation)."""
+    res = simulate_scheduling(cluster, candidates, solver) if results is None else results
     cmd = {"decision": NOOP, "candidates": [c["name"] for c in candidates], "replacement": None, "results": res}
     if not res["allNonPendingPodsScheduled"]:
         return cmd

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <set>
@@ -192,20 +193,27 @@ struct ReqTableBuilder {
   std::vector<uint32_t> defined, complement, has_gte, has_lte;
   std::vector<int64_t> gte, lte;
   std::vector<int32_t> minv;
-  void init(int n_, int rw, int nk) {
+  // the bounds and minValues columns (n * n_keys each) exist once a set carries one: a table of a million pod rows without
+  // Gt / Lt / minValues hands the ABI null columns (absent == none) instead of 40 bytes per row and key of zeroes
+  void init(int n_, int rw, int nk, bool lazy_columns = false) {   // lazy_columns: the pod-row tables
     n = n_; req_words = rw; n_keys = nk;
     mask.assign((size_t)n * rw, 0); defined.assign(n, 0); complement.assign(n, 0); has_gte.assign(n, 0); has_lte.assign(n, 0);
-    gte.assign((size_t)n * nk, 0); lte.assign((size_t)n * nk, 0); minv.assign((size_t)n * nk, -1);
+    gte.clear(); lte.clear(); minv.clear();
+    if (!lazy_columns) { gte.assign((size_t)n * nk, 0); lte.assign((size_t)n * nk, 0); minv.assign((size_t)n * nk, -1); }
   }
   void put(int e, const ks::ReqBuf& b) {
     for (int w = 0; w < req_words; ++w) mask[(size_t)e * req_words + w] = b.mask[w];
     defined[e] = b.defined; complement[e] = b.complement; has_gte[e] = b.has_gte; has_lte[e] = b.has_lte;
-    for (int k = 0; k < n_keys; ++k) { gte[(size_t)e * n_keys + k] = b.gte[k]; lte[(size_t)e * n_keys + k] = b.lte[k]; minv[(size_t)e * n_keys + k] = b.minv[k]; }
+    if ((b.has_gte | b.has_lte) && gte.empty()) { gte.assign((size_t)n * n_keys, 0); lte.assign((size_t)n * n_keys, 0); }
+    if (b.has_minv && minv.empty()) minv.assign((size_t)n * n_keys, -1);
+    if (!gte.empty()) for (int k = 0; k < n_keys; ++k) { gte[(size_t)e * n_keys + k] = b.gte[k]; lte[(size_t)e * n_keys + k] = b.lte[k]; }
+    if (!minv.empty()) for (int k = 0; k < n_keys; ++k) minv[(size_t)e * n_keys + k] = b.minv[k];
   }
   ksolve_reqsets view() const {
     ksolve_reqsets r{};
     r.n = (uint32_t)n; r.mask = mask.data(); r.defined = defined.data(); r.complement = complement.data();
-    r.has_gte = has_gte.data(); r.has_lte = has_lte.data(); r.gte = gte.data(); r.lte = lte.data(); r.min_values = minv.data();
+    r.has_gte = has_gte.data(); r.has_lte = has_lte.data();
+    r.gte = gte.empty() ? nullptr : gte.data(); r.lte = lte.empty() ? nullptr : lte.data(); r.min_values = minv.empty() ? nullptr : minv.data();
     return r;
   }
 };
@@ -462,6 +470,19 @@ bool parse_uuid(const std::string& s, uint64_t& hi, uint64_t& lo) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
+static std::vector<int32_t> b64_int32(const std::string& t) {
+  std::vector<uint8_t> bytes;
+  uint32_t acc = 0; int bits = 0;
+  for (char c : t) {
+    int v = (c >= 'A' && c <= 'Z') ? c - 'A' : (c >= 'a' && c <= 'z') ? c - 'a' + 26 : (c >= '0' && c <= '9') ? c - '0' + 52 : c == '+' ? 62 : c == '/' ? 63 : -1;
+    if (v < 0) continue;   // padding / whitespace
+    acc = (acc << 6) | (uint32_t)v; bits += 6;
+    if (bits >= 8) { bits -= 8; bytes.push_back((uint8_t)(acc >> bits)); }
+  }
+  std::vector<int32_t> out(bytes.size() / 4);
+  if (!out.empty()) memcpy(out.data(), bytes.data(), out.size() * 4);
+  return out;
+}
 static Selector parse_selector(const Value& v) {
   Selector s;
   if (v.is_null()) return s;
@@ -583,6 +604,15 @@ struct Session {
   std::vector<int64_t> node_limit_cap;     // [n_nodes][n_res+1] node capacity on the dimensions its pool limits (device units)
   std::vector<int64_t> tmpl_lim;           // [n_templates][n_res+1] remaining limits of the base problem
   std::map<std::string, int> node_index, pod_index;   // built on the first probe
+  // sweeps of a resident cluster (ksched_sweep): which node every pod sits on, the verdict inputs computeConsolidation needs
+  std::vector<int32_t> pod_node;           // existing node (sorted order) a pod is bound to, -1 = pending / on a deleting node: part of every simulation
+  std::vector<uint8_t> pod_pending_flag, pod_deleting_flag;
+  std::vector<uint32_t> node_pod_off, node_pod_list, always_pods;   // CSR of the pods on each node; built on the first sweep
+  std::vector<int32_t> node_input_index;   // position in the problem's stateNodes list -> sorted node index
+  struct OffLite { int zone, ct, rid; double price; bool available; };
+  std::vector<std::vector<OffLite>> it_offerings;
+  std::vector<std::vector<Expr>> it_exprs;
+  bool sweep_tables = false;
   // a probe session: shares the base session's metadata, owns its handle
   Session* base = nullptr;
   std::vector<uint8_t> probe_member, probe_removed;
@@ -599,6 +629,15 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
   std::string err;
   if (!api.load(solver_lib, err)) { S->error_kind = "load"; S->error = err; return S; }
   ksolve_handle*& handle = S->handle;
+  // KSCHED_TRACE=1: wall time of every phase of NewScheduler on stderr
+  const bool tracing = getenv("KSCHED_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto trace = [&](const char* next) {
+    if (!tracing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "ksched_open: %8.1f ms until '%s'\n", std::chrono::duration<double, std::milli>(now - t_last).count(), next);
+    t_last = now;
+  };
   try {
     S->root = kj::Parser(problem_json).parse();
     Value& root = S->root;
@@ -608,6 +647,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     const Value& opts = root.at("options");
     bool ignore_prefs = opts.at("preferencePolicy").s("Respect") == "Ignore";
 
+    trace("instance types");
     // ---- instance types ----
     const auto& its_json = root.at("instanceTypes").items();
     const int n_its = (int)its_json.size();
@@ -662,6 +702,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     if (n_zones > KSOLVE_MAX_ZONES || n_cts > KSOLVE_MAX_CAPTYPES) throw Unsupported("more than 16 offering zones or 4 capacity types");
     for (int i = 0; i < n_its; ++i) { it_exprs[i] = parse_exprs(its_json[i].at("requirements")); for (auto& e : it_exprs[i]) D.note(e); }
 
+    trace("node pools");
     // ---- node pools -> templates (OrderByWeight; static pools and pools without instance types are skipped) ----
     struct Pool { const Value* v; std::string name; int weight; };
     std::vector<Pool> pools;
@@ -713,6 +754,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       }
     }
 
+    trace("pods");
     // ---- pods (explicit list + deterministic groups) ----
     std::vector<std::pair<std::string, std::map<std::string, std::string>>> namespace_lister;
     for (auto& nv : root.at("namespaces").items()) {
@@ -729,12 +771,14 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     std::vector<std::string> uid_text;    // explicit pods only ("" for group pods: regenerated on demand)
     std::vector<std::pair<uint64_t, uint64_t>> group_of_pod;  // (seed, index) for group pods
     bool all_uuid = true;
+    std::vector<int> pod_node_input;      // group pods bound to a node: index into the problem's stateNodes list, else -1
     for (auto& pv : root.at("pods").items()) {
       specs.push_back(parse_pod(pv));
       pod_spec.push_back((int)specs.size() - 1);
       uint64_t hi = 0, lo = 0;
       if (!parse_uuid(specs.back().uid, hi, lo)) all_uuid = false;
       uid_hi.push_back(hi); uid_lo.push_back(lo); uid_text.push_back(specs.back().uid); group_of_pod.push_back({0, 0});
+      pod_node_input.push_back(-1);
     }
     for (auto& g : root.at("podGroups").items()) {
       specs.push_back(parse_pod(g.at("template")));
@@ -742,12 +786,20 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       uint64_t seed = (uint64_t)g.at("uidSeed").i(0);
       long long cnt = g.at("count").i(0);
       if (cnt < 0) throw std::runtime_error("podGroups[].count is negative");
+      // bound pods of a resident cluster: pod i of the group runs on stateNodes[nodeIndex[i]] (a 2M-pod cluster is a few
+      // hundred templates and one integer per pod); nodeIndexB64 = the same list as base64 of little-endian int32
+      std::vector<int32_t> gnode;
+      if (g.has("nodeIndexB64") && !g.at("nodeIndexB64").is_null()) gnode = b64_int32(g.at("nodeIndexB64").s());
+      else if (g.has("nodeIndex") && !g.at("nodeIndex").is_null()) for (auto& x : g.at("nodeIndex").items()) gnode.push_back((int32_t)x.i(-1));
+      const bool bound = !gnode.empty();
+      if (bound && (long long)gnode.size() != cnt) throw std::runtime_error("podGroups[].nodeIndex must have one entry per pod");
       // one Solve() of the reference handles a batch of pending pods; 16M pods is 16x the largest BASELINE configuration
       if (cnt > kMaxPodsPerProblem || (long long)pod_spec.size() + cnt > kMaxPodsPerProblem) throw Unsupported("more than 16777216 pods in one problem");
       for (long long i = 0; i < cnt; ++i) {
         uint64_t hi, lo;
         group_uid(seed, (uint64_t)i, hi, lo, nullptr);
         pod_spec.push_back(si); uid_hi.push_back(hi); uid_lo.push_back(lo); uid_text.push_back(std::string()); group_of_pod.push_back({seed, (uint64_t)i});
+        pod_node_input.push_back(bound ? (int)gnode[(size_t)i] : -1);
       }
     }
     const int n_pods = (int)pod_spec.size();
@@ -824,6 +876,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         break;
       }
     }
+    trace("daemonset pods");
     // ---- daemonset pods: only their scheduling constraints and requests matter (scheduler.go:972-1043) ----
     std::vector<PodSpec> daemons;
     for (auto& dv : root.at("daemonSetPods").items()) {
@@ -833,6 +886,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       for (auto& term : dp.required_terms) for (auto& e : term) D.note(e);
     }
     if (daemons.size() > 64) throw Unsupported("more than 64 daemonset pods");
+    trace("existing nodes");
     // ---- existing nodes (state.StateNode read accessors): sortExistingNodes order (scheduler.go:845-858) ----
     struct NodeIn { const Value* v; std::string name, hostname; bool initialized; };
     std::vector<NodeIn> nodes;
@@ -860,6 +914,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       for (auto& tv : nodes[e].v->at("taints").items()) node_taints[e] |= 1ull << taint_id(Taint{tv.at("key").s(), tv.at("value").s(), tv.at("effect").s()});
     }
 
+    trace("resources");
     // ---- resources: dimensions and exact scales ----
     std::vector<std::string> res_names = {"cpu", "memory"};
     auto add_res = [&](const std::string& r) { if (r == "nodes") return; if (std::find(res_names.begin(), res_names.end(), r) == res_names.end()) res_names.push_back(r); };
@@ -921,6 +976,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     };
     auto res_get = [&](const std::map<std::string, i128>& m, const std::string& k) { auto it = m.find(k); return it == m.end() ? (i128)0 : it->second; };
 
+    trace("dictionary complete");
     // ---- dictionary is complete ----
     const int it_words = std::max(1, (n_its + 63) / 64);
     fl.finalize_dictionary(it_words);
@@ -1189,7 +1245,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     for (size_t si = 0; si < specs.size(); ++si) if (ladders[si].size() > 1) { spec_first_extra[si] = n_rows; n_rows += (int)ladders[si].size() - 1; }
     std::vector<int64_t> pod_requests((size_t)n_res * n_rows);
     ReqTableBuilder pod_reqs, pod_strict;
-    pod_reqs.init(n_rows, rw, nk); pod_strict.init(n_rows, rw, nk);
+    pod_reqs.init(n_rows, rw, nk, true);
     std::vector<uint64_t> pod_tol(n_rows, 0), pod_hp(n_rows, 0), pod_hpc(n_rows, 0);
     std::vector<int32_t> pod_next(n_rows, -1);
     std::vector<int64_t> pod_creation(n_pods);
@@ -1211,9 +1267,14 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         enc[si].push_back(e);
       }
     }
+    // StrictRequirements (without the preferred terms, scheduler.go:217-229) differ from Requirements only for pods with
+    // preferences: when no variant of any pod has one, the strict table IS the requirement table (one upload, one stream)
+    bool strict_differs = false;
+    for (auto& ev : enc) for (auto& e : ev) strict_differs = strict_differs || memcmp(&e.reqs, &e.strict, sizeof(ks::ReqBuf)) != 0;
+    if (strict_differs) pod_strict.init(n_rows, rw, nk, true);
     auto put_row = [&](int row, const Enc& e) {
       for (int r = 0; r < n_res; ++r) pod_requests[(size_t)r * n_rows + row] = e.req[r];
-      pod_reqs.put(row, e.reqs); pod_strict.put(row, e.strict); pod_tol[row] = e.tol;
+      pod_reqs.put(row, e.reqs); if (strict_differs) pod_strict.put(row, e.strict); pod_tol[row] = e.tol;
     };
     std::vector<uint64_t> spec_hpc(specs.size(), 0);
     for (size_t si = 0; si < specs.size(); ++si) spec_hpc[si] = hp_conflicts(spec_hp[si]);
@@ -1268,6 +1329,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         pod_next[row] = vi + 1 < ladders[si].size() ? row + 1 : -1;
       }
 
+    trace("topology groups");
     // ---- topology groups (NewTopology, topology.go:68-103; Update, :162-194) --------------------------------
     // The device keeps one counter per (group, domain); which groups exist, what they select and what each pod variant
     // owns is object wrangling done here. Group identity follows TopologyGroup.Hash() (topologygroup.go:188-222):
@@ -1601,6 +1663,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         for (size_t vi = 1; vi < ladders[si].size(); ++vi) put_masks(spec_first_extra[si] + (int)vi - 1, si, vi);
     }
 
+    trace("describe");
     // ---- describe & solve ----
     ksolve_problem_desc d{};
     d.abi_version = KSOLVE_ABI_VERSION;
@@ -1624,7 +1687,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     d.it_reserved_first = it_resv_first.data(); d.reserved_zone = resv_zone.data(); d.reserved_id = resv_id.data(); d.reserved_price = resv_price.data();
     if (!dg_first.empty()) { d.tmpl_daemon_first = dg_first.data(); d.daemon_group_its = dg_its.data(); d.daemon_group_overhead = dg_ov.data(); d.daemon_group_nonempty = dg_nonempty.data(); }
     d.n_pods = (uint32_t)n_pods; d.n_pod_rows = (uint32_t)n_rows; d.pod_requests = pod_requests.data();
-    d.pod_reqs = pod_reqs.view(); d.pod_strict_reqs = pod_strict.view(); d.pod_tolerates = pod_tol.data(); d.pod_next_variant = pod_next.data();
+    d.pod_reqs = pod_reqs.view(); d.pod_strict_reqs = strict_differs ? pod_strict.view() : pod_reqs.view(); d.pod_tolerates = pod_tol.data(); d.pod_next_variant = pod_next.data();
     if (hp_on) {
       d.pod_host_ports = pod_hp.data(); d.pod_host_port_conflicts = pod_hpc.data();
       if (n_nodes) d.node_host_ports = node_hp.data();
@@ -1668,7 +1731,9 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     ko.reserved_offering_strict = opts.at("reservedOfferingMode").s("Fallback") == "Strict" ? 1 : 0;
     { const std::string eng = opts.at("engine").s("auto"); ko.engine = eng == "general" ? 1u : eng == "cursor" ? 2u : 0u; }
 
+    trace("ksolve_create");
     ksolve_status st = api.create(&d, &ko, &handle);
+    trace("session tables");
     if (st != KSOLVE_OK) {
       S->error = handle ? api.last_error(handle) : "ksolve_create failed";
       S->error_kind = st == KSOLVE_ERR_UNSUPPORTED ? "unsupported" : st == KSOLVE_ERR_NO_DEVICE ? "no_device" : "create";
@@ -1682,6 +1747,28 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     S->k_rid = k_rid;
     S->n_pods = n_pods; S->n_rows = n_rows; S->n_its = n_its; S->n_res = n_res; S->it_words = it_words;
     S->n_templates = n_templates; S->tmpl_lim = tmpl_lim;
+    // what ksched_sweep needs: the node of every pod, its pending / deleting flags, offerings and requirement values per type
+    {
+      std::map<std::string, int> sorted_index;
+      for (size_t e = 0; e < S->node_names.size(); ++e) sorted_index[S->node_names[e]] = (int)e;
+      const auto& sn = root.at("stateNodes").items();
+      S->node_input_index.assign(sn.size(), -1);
+      for (size_t i = 0; i < sn.size(); ++i) { auto f = sorted_index.find(sn[i].at("name").s()); if (f != sorted_index.end()) S->node_input_index[i] = f->second; }
+      S->pod_node.assign(n_pods, -1);
+      std::vector<int> spec_node(specs.size(), -2);
+      for (int p = 0; p < n_pods; ++p) {
+        if (pod_node_input[p] >= 0) { S->pod_node[p] = pod_node_input[p] < (int)S->node_input_index.size() ? S->node_input_index[pod_node_input[p]] : -1; continue; }
+        int& sn_ = spec_node[pod_spec[p]];
+        if (sn_ == -2) { auto f = sorted_index.find(specs[pod_spec[p]].node_name); sn_ = f == sorted_index.end() ? -1 : f->second; }
+        S->pod_node[p] = sn_;
+      }
+      S->pod_pending_flag.assign(pod_pending.begin(), pod_pending.end());
+      S->pod_deleting_flag.assign(pod_from_deleting.begin(), pod_from_deleting.begin() + n_pods);
+      S->it_offerings.resize(n_its);
+      for (int i = 0; i < n_its; ++i) for (auto& o : it_offs[i]) S->it_offerings[i].push_back({o.zone, o.ct, o.rid, o.price, o.available});
+      S->it_exprs = it_exprs;
+    }
+    trace("done");
     return S;
   } catch (const Unsupported& e) {
     if (S->handle) { api.destroy(S->handle); S->handle = nullptr; }
@@ -1762,6 +1849,190 @@ extern "C" void* ksched_probe(void* base_session, const char* probe_json) {
     S->error_kind = "invalid"; S->error = e.what();
   }
   return S;
+}
+// A whole consolidation sweep (ksolve_sweep): `sweep_json` = {"candidates": [[node, ...], ...], "prices": [sum of the candidates'
+// prices per probe], "allSpot": [every candidate of the probe is a spot node], "detail": false}; a node is its name or its
+// position in the problem's stateNodes list. Every probe is SimulateScheduling (disruption/helpers.go:53-155) of the resident
+// cluster without its candidates — their pods, the pending pods and the pods of deleting nodes are scheduled — followed by
+// computeConsolidation's verdict (consolidation.go:159-256): delete when no NodeClaim is needed, replace when exactly one is
+// and a cheaper instance type remains after the price filter (nodeclaim.go:411-420), otherwise nothing. The probe descriptors
+// are built here (CSR arrays over the session's node -> pods tables), not in the caller's language. Returns one document.
+extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
+  Session* B = (Session*)base_session;
+  if (!B || !B->handle || B->base) return error_json("invalid", "sweep needs an open base session");
+  try {
+    auto run = (decltype(&ksolve_sweep))dlsym(B->api.lib, "ksolve_sweep");
+    auto release = (decltype(&ksolve_sweep_results_free))dlsym(B->api.lib, "ksolve_sweep_results_free");
+    if (!run || !release) return error_json("load", "solver library lacks ksolve_sweep");
+    const auto t_begin = std::chrono::steady_clock::now();
+    const int ne = (int)B->node_names.size(), n_res = B->n_res, nr1 = n_res + 1, T = B->n_templates, n_its = B->n_its;
+    if (!B->sweep_tables) {
+      B->node_pod_off.assign((size_t)ne + 1, 0);
+      for (int p = 0; p < B->n_pods; ++p) { if (B->pod_node[p] >= 0) B->node_pod_off[(size_t)B->pod_node[p] + 1]++; else B->always_pods.push_back((uint32_t)p); }
+      for (int e = 0; e < ne; ++e) B->node_pod_off[(size_t)e + 1] += B->node_pod_off[e];
+      B->node_pod_list.assign(B->node_pod_off[ne], 0);
+      std::vector<uint32_t> fill(B->node_pod_off.begin(), B->node_pod_off.end() - 1);
+      for (int p = 0; p < B->n_pods; ++p) if (B->pod_node[p] >= 0) B->node_pod_list[fill[B->pod_node[p]]++] = (uint32_t)p;
+      if (B->node_index.empty()) for (size_t e = 0; e < B->node_names.size(); ++e) B->node_index[B->node_names[e]] = (int)e;
+      B->sweep_tables = true;
+    }
+    Value doc = kj::Parser(sweep_json).parse();
+    const auto& cands = doc.at("candidates").items();
+    const uint32_t n = (uint32_t)cands.size();
+    const auto& prices = doc.at("prices").items();
+    const auto& all_spot = doc.at("allSpot").items();
+    const bool detail = doc.at("detail").boolean_or(false);
+    const bool spot_to_spot = B->root.at("options").at("spotToSpotConsolidation").boolean_or(false);
+    std::vector<uint32_t> node_off(n + 1, 0), pod_off(n + 1, 0), nodes, pods;
+    std::vector<int64_t> lims;
+    const bool limits = !B->tmpl_lim.empty();
+    if (limits) lims.resize((size_t)n * T * nr1);
+    for (uint32_t p = 0; p < n; ++p) {
+      const size_t n0 = nodes.size();
+      for (auto& nv : cands[p].items()) {
+        int e = -1;
+        if (nv.kind == Value::Str) { auto f = B->node_index.find(nv.s()); if (f == B->node_index.end()) throw std::runtime_error("sweep removes an unknown node " + nv.s()); e = f->second; }
+        else { const int64_t i = nv.i(-1); if (i < 0 || i >= (int64_t)B->node_input_index.size() || B->node_input_index[(size_t)i] < 0) throw std::runtime_error("sweep removes an unknown node index"); e = B->node_input_index[(size_t)i]; }
+        bool dup = false;
+        for (size_t j = n0; j < nodes.size(); ++j) dup = dup || nodes[j] == (uint32_t)e;
+        if (!dup) nodes.push_back((uint32_t)e);
+      }
+      node_off[p + 1] = (uint32_t)nodes.size();
+      pods.insert(pods.end(), B->always_pods.begin(), B->always_pods.end());
+      for (size_t j = n0; j < nodes.size(); ++j) pods.insert(pods.end(), B->node_pod_list.begin() + B->node_pod_off[nodes[j]], B->node_pod_list.begin() + B->node_pod_off[nodes[j] + 1]);
+      pod_off[p + 1] = (uint32_t)pods.size();
+      if (limits) {
+        int64_t* l = lims.data() + (size_t)p * T * nr1;
+        memcpy(l, B->tmpl_lim.data(), (size_t)T * nr1 * 8);
+        for (size_t j = n0; j < nodes.size(); ++j) {   // the pool gets the node's capacity back (scheduler.go:835-842)
+          const int e = (int)nodes[j], t = B->node_tmpl[e];
+          if (t >= 0) for (int r = 0; r < nr1; ++r) l[(size_t)t * nr1 + r] += B->node_limit_cap[(size_t)e * nr1 + r];
+        }
+      }
+    }
+    ksolve_sweep_desc sd{};
+    sd.n_probes = n; sd.node_off = node_off.data(); sd.nodes = nodes.data(); sd.pod_off = pod_off.data(); sd.pods = pods.data();
+    sd.tmpl_limits = limits ? lims.data() : nullptr;
+    const auto t_desc = std::chrono::steady_clock::now();
+    ksolve_sweep_results res{};
+    ksolve_status st = run(B->handle, &sd, &res);
+    const auto t_solved = std::chrono::steady_clock::now();
+    if (st != KSOLVE_OK) return error_json(st == KSOLVE_ERR_UNSUPPORTED ? "unsupported" : st == KSOLVE_ERR_CAPACITY ? "capacity" : "solve", B->api.last_error(B->handle));
+
+    // ---- verdicts ----
+    Flattener& fl = B->fl;
+    Dictionary& D = fl.dict;
+    const ks::Dict& kd = fl.kd;
+    const int nk = kd.n_keys;
+    const ksolve_claims& cl = res.claims;
+    auto ct_index = [&](const char* name) { if (kd.key_ct < 0) return -1; auto f = D.value_index[kd.key_ct].find(name); return f == D.value_index[kd.key_ct].end() ? -1 : f->second; };
+    const int ct_order[3] = {ct_index("reserved"), ct_index("spot"), ct_index("on-demand")};
+    Value decisions = Value::array(), scheduled = Value::array(), n_claims_j = Value::array(), status_j = Value::array(), refs = Value::array(), repl = Value::array(), reasons = Value::object();
+    Value details = Value::array();
+    auto uid_of = [&](int p) { if (!B->uid_text[p].empty()) return B->uid_text[p]; std::string u; uint64_t a, b; group_uid(B->group_of_pod[p].first, B->group_of_pod[p].second, a, b, &u); return u; };
+    for (uint32_t p = 0; p < n; ++p) {
+      int decision = 0;   // 0 no-op, 1 delete, 2 replace
+      bool all_ok = true;
+      const uint32_t c0 = res.claim_off[p], C = res.claim_off[p + 1] - c0;
+      if (res.status[p] != KSOLVE_OK) all_ok = false;
+      for (uint32_t i = pod_off[p]; i < pod_off[p + 1] && all_ok; ++i) {
+        const int g = (int)pods[i];
+        if (B->pod_pending_flag[g]) continue;                         // AllNonPendingPodsScheduled (scheduler.go:388-392)
+        const int a = res.pod_assignment[i];
+        if (a == -1) all_ok = false;
+        else if (a >= 0 && cl.truncation_failed && cl.truncation_failed[c0 + (uint32_t)a]) all_ok = false;   // the claim is dropped, its pods fail (scheduler.go:426-431)
+        else if (a <= -2 && !B->node_initialized[(size_t)(-2 - a)] && !B->pod_deleting_flag[g]) all_ok = false;   // UninitializedNodeError (helpers.go:133-153)
+      }
+      uint32_t live = 0, only = 0;
+      for (uint32_t c = 0; c < C; ++c) if (!(cl.truncation_failed && cl.truncation_failed[c0 + c])) { live++; only = c0 + c; }
+      if (all_ok && live == 0) decision = 1;
+      else if (all_ok && live == 1) {
+        const uint32_t c = only;
+        const double price = p < prices.size() ? prices[p].d(0) : 0.0;
+        ks::ReqRef r;
+        r.mask = cl.req_mask + (size_t)c * cl.req_words; r.defined = cl.req_defined[c]; r.complement = cl.req_complement[c];
+        r.has_gte = cl.req_has_gte[c]; r.has_lte = cl.req_has_lte[c]; r.gte = cl.req_gte + (size_t)c * nk; r.lte = cl.req_lte + (size_t)c * nk; r.minv = nullptr;
+        auto has = [&](int key, int v) { return key < 0 || !ks::bit(r.defined, key) || ks::req_has(kd, r, key, kd.key_word_off[key] + (uint32_t)(v >> 6), v & 63); };
+        const bool ct_defined = kd.key_ct >= 0 && ks::bit(r.defined, kd.key_ct);
+        const bool spot_ok = !ct_defined || (ct_order[1] >= 0 && has(kd.key_ct, ct_order[1]));
+        const bool od_ok = !ct_defined || (ct_order[2] >= 0 && has(kd.key_ct, ct_order[2]));
+        if (p < all_spot.size() && all_spot[p].boolean_or(false) && spot_ok) {
+          // computeSpotToSpotConsolidation (consolidation.go:261-342): behind its feature gate; with the gate on the caller takes
+          // the per-probe path (the 15-cheapest rule needs the whole ordered list)
+          if (spot_to_spot) { decision = 3; }
+        } else {
+          // Offerings.Available().WorstLaunchPrice(reqs) (types.go:587-598): reserved, then spot, then on-demand
+          auto worst = [&](int it) {
+            for (int q = 0; q < 3; ++q) {
+              if (ct_order[q] < 0) continue;
+              double mx = -1; bool any = false;
+              for (auto& o : B->it_offerings[it]) {
+                if (!o.available || o.ct != ct_order[q] || !has(kd.key_zone, o.zone) || !has(kd.key_ct, o.ct)) continue;
+                if (o.rid >= 0 && !has(B->k_rid, o.rid)) continue;
+                if (!any || o.price > mx) mx = o.price;
+                any = true;
+              }
+              if (any) return mx;
+            }
+            return 1.0 / 0.0;
+          };
+          std::vector<int> cheaper;
+          if (cl.ordered_instance_types) { for (uint32_t i = 0; i < cl.ordered_count[c]; ++i) { const int it = cl.ordered_instance_types[(size_t)c * cl.n_instance_types + i]; if (worst(it) < price) cheaper.push_back(it); } }
+          else for (int it = 0; it < n_its; ++it) if (((cl.it_mask[(size_t)c * cl.it_words + it / 64] >> (it % 64)) & 1) && worst(it) < price) cheaper.push_back(it);
+          // InstanceTypes.SatisfiesMinValues after the price filter (nodeclaim.go:416-418, types.go:399-433)
+          bool mv_ok = true;
+          for (int k = 0; k < nk && mv_ok; ++k) {
+            const int want = cl.req_min_values[(size_t)c * nk + k];
+            if (want < 0 || !ks::bit(r.defined, k)) continue;
+            std::set<std::string> seen;
+            for (int it : cheaper) for (auto& e : B->it_exprs[it]) if (e.key == D.keys[k]) seen.insert(e.values.begin(), e.values.end());
+            if ((int)seen.size() < want) mv_ok = false;
+          }
+          if (!mv_ok) reasons.add_new(std::to_string(p), Value::string("minValues requirement is not met after filtering by price"));
+          else if (!cheaper.empty()) {
+            decision = 2;
+            Value rj = Value::object();
+            rj.set("probe", Value::integer(p));
+            std::vector<std::string> names;
+            for (int it : cheaper) names.push_back(B->it_names[it]);
+            std::sort(names.begin(), names.end());
+            Value nj = Value::array();
+            for (auto& nm : names) nj.push(Value::string(nm));
+            rj.set("instanceTypes", nj);
+            rj.set("capacityType", (!ct_defined || (spot_ok && od_ok)) ? Value::string("spot") : Value());   // consolidation.go:238-243
+            repl.push(rj);
+          }
+        }
+      }
+      decisions.push(Value::integer(decision)); scheduled.push(Value::boolean(all_ok)); n_claims_j.push(Value::integer(live));
+      status_j.push(Value::integer(res.status[p])); refs.push(Value::integer((int64_t)res.ref_bin_evaluations[p]));
+      if (detail) {
+        // where every pod of the probe went: uid -> claim index (>= 0), node name, or null
+        Value dj = Value::object(), where = Value::object();
+        for (uint32_t i = pod_off[p]; i < pod_off[p + 1]; ++i) {
+          const int a = res.pod_assignment[i];
+          where.add_new(uid_of((int)pods[i]), a >= 0 ? Value::integer(a) : a <= -2 ? Value::string(B->node_names[(size_t)(-2 - a)]) : Value());
+        }
+        dj.set("pods", where);
+        details.push(dj);
+      }
+    }
+    const auto t_end = std::chrono::steady_clock::now();
+    Value out = Value::object();
+    out.set("decisions", decisions); out.set("allNonPendingPodsScheduled", scheduled); out.set("claims", n_claims_j); out.set("status", status_j);
+    out.set("referenceBinEvaluations", refs); out.set("replacements", repl); out.set("reasons", reasons);
+    if (detail) out.set("details", details);
+    Value tj = Value::object();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    tj.set("descriptors_ms", Value::number(ms(t_begin, t_desc))); tj.set("sweep_ms", Value::number(ms(t_desc, t_solved))); tj.set("verdicts_ms", Value::number(ms(t_solved, t_end)));
+    tj.set("upload_us", Value::number(res.us_upload)); tj.set("pack_us", Value::number(res.us_pack)); tj.set("finalize_us", Value::number(res.us_finalize)); tj.set("download_us", Value::number(res.us_download));
+    tj.set("probes", Value::integer(n)); tj.set("pods", Value::integer((int64_t)pods.size()));
+    out.set("timings", tj);
+    release(&res);
+    return dup_json(out);
+  } catch (const std::exception& e) {
+    return error_json("invalid", e.what());
+  }
 }
 extern "C" void ksched_close(void* session) {
   Session* S = (Session*)session;

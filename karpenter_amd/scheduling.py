@@ -61,6 +61,8 @@ def _load_ksched():
         lib.ksched_solve_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         lib.ksched_probe.restype = ctypes.c_void_p
         lib.ksched_probe.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        lib.ksched_sweep.restype = ctypes.c_void_p
+        lib.ksched_sweep.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
         _ksched = lib
     return _ksched
 
@@ -139,6 +141,25 @@ class Scheduler:
             self._probes = []
         self._probes.append(probe)
         return probe
+
+    def Sweep(self, candidates, prices, all_spot, detail=False) -> dict:
+        """A whole consolidation sweep of a RESIDENT cluster in one call (ksolve_sweep; disruption/helpers.go:53-155 +
+        consolidation.go:159-256 per candidate set): `candidates` = one list of nodes (names, or positions in the problem's
+        stateNodes list) per simulation, `prices` the summed candidate prices, `all_spot` whether every candidate is a spot
+        node. The probe descriptors (displaced pods, NodePool limits handed back) are built by the host library, every
+        simulation is one wavefront of one launch, the verdicts (0 no-op, 1 delete, 2 replace) come back with the replacement
+        instance types of the replace commands. detail=True adds where every pod went (tests)."""
+        if not self._session:
+            raise RuntimeError("scheduler is closed")
+        doc = json.dumps({"candidates": candidates, "prices": prices, "allSpot": all_spot, "detail": bool(detail)}).encode()
+        ptr = self._lib.ksched_sweep(self._session, doc)
+        try:
+            out = json.loads(ctypes.string_at(ptr).decode())
+        finally:
+            self._lib.ksched_free(ptr)
+        if "error" in out:
+            _raise(out.get("kind"), out["error"])
+        return out
 
     def __del__(self):
         try:

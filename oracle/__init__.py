@@ -24,7 +24,7 @@ def _lib():
     global _LIB
     if _LIB is None:
         lib = ctypes.CDLL(build())
-        for fn in (lib.oracle_solve_json, lib.oracle_eval_json):
+        for fn in (lib.oracle_solve_json, lib.oracle_eval_json, lib.oracle_sweep_json):
             fn.restype = ctypes.c_void_p
             fn.argtypes = [ctypes.c_char_p]
         lib.oracle_free.argtypes = [ctypes.c_void_p]
@@ -47,6 +47,13 @@ def _call(fn, doc):
 def solve(problem: dict) -> dict:
     """Reference-semantics Solve() on the CPU. Returns the results document."""
     return _call(_lib().oracle_solve_json, problem)
+
+
+def sweep(problem: dict, probes: list, threads: int = 1) -> list:
+    """SimulateScheduling for many candidate sets of one cluster (oracle_api.cpp: oracle_sweep_json): `problem` = the cluster as
+    a problem document, `probes` = [{"removeNodes": [names], "pods": [pod documents]}]; one Results document per probe.
+    The simulations are independent: `threads` of them run at a time."""
+    return _call(_lib().oracle_sweep_json, {"problem": problem, "probes": probes, "threads": int(threads)})["results"]
 
 
 def evaluate(query: dict):

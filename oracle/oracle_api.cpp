@@ -7,6 +7,7 @@
 // toolchain in this image); topology tie-breaks are canonicalised because the reference itself leaves them to Go
 // map iteration order.
 #include <chrono>
+#include <thread>
 #include <cstring>
 
 #include "scheduler.hpp"
@@ -77,13 +78,67 @@ extern "C" {
 void oracle_free(char* p) { free(p); }
 
 // Full Solve(): problem JSON -> results JSON.
+static oj::Value solve_doc(const Problem& pr, const std::vector<Pod>* probe_pods = nullptr, const std::vector<char>* removed = nullptr);
 char* oracle_solve_json(const char* problem_json) {
   try {
     oj::Value root = oj::Parser(problem_json).parse();
     Problem pr = parse_problem(root);
+    return dup_out(solve_doc(pr));
+  } catch (const std::exception& e) {
+    return err_out(e.what());
+  }
+}
+
+// SimulateScheduling (disruption/helpers.go:53-155) for many candidate sets of ONE cluster: {"problem": the cluster as a problem
+// document (every node a state node, no pods), "probes": [{"removeNodes": [names], "pods": [pod documents]}], "threads": n} ->
+// {"results": [one Results document per probe]}. Every probe is a fresh Scheduler over the cluster without its candidates —
+// what the reference does per simulation; only the parse of the cluster document is shared. The simulations are independent,
+// so `threads` of them run at a time (the reference's own candidate fan-out is parallelizeUntil, scheduler.go:939-961).
+char* oracle_sweep_json(const char* doc_json) {
+  try {
+    oj::Value root = oj::Parser(doc_json).parse();
+    const Problem pr = parse_problem(root.at("problem"));
+    std::map<std::string, size_t> by_name;
+    for (size_t i = 0; i < pr.state_nodes.size(); ++i) by_name[pr.state_nodes[i].name] = i;
+    const auto& probes = root.at("probes").items();
+    const size_t n = probes.size();
+    std::vector<std::vector<Pod>> pods(n);
+    std::vector<std::vector<char>> removed(n);
+    for (size_t i = 0; i < n; ++i) {
+      removed[i].assign(pr.state_nodes.size(), 0);
+      for (auto& nn : probes[i].at("removeNodes").items()) {
+        auto f = by_name.find(nn.s());
+        if (f == by_name.end()) throw std::runtime_error("probe removes an unknown node " + nn.s());
+        removed[i][f->second] = 1;
+      }
+      int idx = 0;
+      for (auto& v : probes[i].at("pods").items()) pods[i].push_back(parse_pod(v, idx++));
+    }
+    std::vector<oj::Value> docs(n);
+    std::vector<std::string> errors(n);
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>(n, (size_t)root.at("threads").i(1)));
+    auto work = [&](size_t t) {
+      for (size_t i = t; i < n; i += n_threads) {
+        try { docs[i] = solve_doc(pr, &pods[i], &removed[i]); } catch (const std::exception& e) { errors[i] = e.what(); }
+      }
+    };
+    if (n_threads == 1) work(0);
+    else { std::vector<std::thread> pool; for (size_t t = 0; t < n_threads; ++t) pool.emplace_back(work, t); for (auto& th : pool) th.join(); }
+    oj::Value results = oj::Value::array();
+    for (size_t i = 0; i < n; ++i) { if (!errors[i].empty()) throw std::runtime_error(errors[i]); results.push(docs[i]); }
+    oj::Value out = oj::Value::object();
+    out.set("results", results);
+    return dup_out(out);
+  } catch (const std::exception& e) {
+    return err_out(e.what());
+  }
+}
+
+static oj::Value solve_doc(const Problem& pr, const std::vector<Pod>* probe_pods, const std::vector<char>* removed) {
+  {
     Scheduler s;
     auto t0 = std::chrono::steady_clock::now();
-    s.init(pr);
+    s.init(pr, probe_pods, removed);
     auto t1 = std::chrono::steady_clock::now();
     Results res = s.solve();
     auto t2 = std::chrono::steady_clock::now();
@@ -160,13 +215,11 @@ char* oracle_solve_json(const char* problem_json) {
     c.set("sorts", oj::Value::integer(s.ctr.sorts));
     c.set("pops", oj::Value::integer(s.ctr.pops));
     c.set("relaxations", oj::Value::integer(s.ctr.relaxations));
-    c.set("pods", oj::Value::integer((long long)pr.pods.size()));
+    c.set("pods", oj::Value::integer((long long)s.pods.size()));
     c.set("initSeconds", oj::Value::number(std::chrono::duration<double>(t1 - t0).count()));
     c.set("solveSeconds", oj::Value::number(std::chrono::duration<double>(t2 - t1).count()));
     out.set("counters", c);
-    return dup_out(out);
-  } catch (const std::exception& e) {
-    return err_out(e.what());
+    return out;
   }
 }
 

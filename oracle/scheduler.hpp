@@ -382,17 +382,22 @@ struct Scheduler {
   }
 
   // ---- NewScheduler — scheduler.go:127-215 (+ Provisioner.NewScheduler ordering, provisioner.go:293) --------
-  void init(const Problem& problem) {
+  // `probe_pods` / `removed`: oracle_sweep_json simulates many candidate sets of one cluster document (possibly on several
+  // threads): the pods of this simulation and the state nodes (by index) that are not part of it (helpers.go:76-80)
+  const std::vector<char>* removed = nullptr;
+  bool is_removed(const StateNode& n) const { return removed && (*removed)[(size_t)(&n - pr->state_nodes.data())]; }
+  void init(const Problem& problem, const std::vector<Pod>* probe_pods = nullptr, const std::vector<char>* removed_nodes = nullptr) {
     pr = &problem;
     opts = problem.opts;
-    pods = problem.pods;
+    removed = removed_nodes;
+    pods = probe_pods ? *probe_pods : problem.pods;
     for (auto& np : problem.node_pools) if (!np.is_static) pools.push_back(&np);
     // OrderByWeight — pkg/utils/nodepool/nodepool.go:161-171 (total order: weight desc, name desc)
     std::sort(pools.begin(), pools.end(), [](const NodePool* a, const NodePool* b) { return a->weight != b->weight ? a->weight > b->weight : a->name > b->name; });
     for (auto* np : pools) for (auto& t : np->taints) if (t.effect == "PreferNoSchedule") tolerate_prefer_no_schedule = true;
 
     std::vector<const StateNode*> snodes;
-    for (auto& n : problem.state_nodes) snodes.push_back(&n);
+    for (auto& n : problem.state_nodes) if (!is_removed(n)) snodes.push_back(&n);
     topology.init(problem, pools, snodes, pods, opts.ignore_preferences);
 
     for (auto* np : pools) {
@@ -429,6 +434,7 @@ struct Scheduler {
     reservations.init(problem, pools);
     // calculateExistingNodeClaims — scheduler.go:792-802
     for (auto& n : problem.state_nodes) {
+      if (is_removed(n)) continue;
       auto en = std::make_unique<ExistingNode>();
       en->node = &n;
       en->host_ports = n.host_ports;

@@ -266,7 +266,7 @@ struct Topology {
     }
   }
   const StateNode* find_node(const std::string& name) const {
-    for (auto& n : problem->state_nodes) if (n.name == name) return &n;
+    for (auto* n : state_nodes) if (n->name == name) return n;   // the nodes of this simulation
     return nullptr;
   }
   // countDomains — topology.go:361-459 (kube reads replaced by the problem's clusterPods / stateNodes)

@@ -115,6 +115,24 @@ static void be_launch_pack_batch(ksolve_handle** hs, int n) {
   for (int i = 0; i < n; ++i) { be_tic(hs[i], ksi::T_PACK); be_launch_pack(hs[i]); be_toc(hs[i], ksi::T_PACK); }
 }
 static int be_device_available() { return 1; }
+static void be_free(ksolve_handle* h, void* p) {
+  auto it = std::find(h->allocations.begin(), h->allocations.end(), p);
+  if (it != h->allocations.end()) h->allocations.erase(it);
+  free(p);
+}
+static void be_launch_node_dead0(ksolve_handle*, int n_blocks, const ks::NodeDeadArgs& a) { for (int b = 0; b < n_blocks; ++b) ks::node_dead0_body<ks::Wave>(b, a); }
+static void be_launch_claim_gather(ksolve_handle*, int n, const ks::ClaimGatherArgs& a) { for (int i = 0; i < n; ++i) ks::claim_gather_body(i, a); }
+static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, ks::Workspace* d_items, int n, const ks::LdsPlan& plan) {
+  be_tic(h, ksi::T_PACK);
+  for (int p = 0; p < n; ++p) {
+    std::vector<char> lds((size_t)plan.total_bytes + 64, (char)0xA5);   // garbage, like the device's LDS at kernel start
+    ks::LdsTables tables;
+    tables.bind(lds.data(), plan);
+    ks::Engine<ks::Wave, true> eng(*d_pv, d_items[p], tables);
+    eng.solve();
+  }
+  be_toc(h, ksi::T_PACK);
+}
 
 extern "C" {
 ksolve_status ksolve_create(const ksolve_problem_desc* desc, const ksolve_options* opts, ksolve_handle** out) {
@@ -131,6 +149,8 @@ ksolve_status ksolve_probe_create(ksolve_handle* base, const ksolve_probe* probe
   return ksi::probe_create(base, probe, h);
 }
 ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out) { return ksi::solve(h, out); }
+ksolve_status ksolve_sweep(ksolve_handle* base, const ksolve_sweep_desc* desc, ksolve_sweep_results* out) { return ksi::sweep(base, desc, out); }
+void ksolve_sweep_results_free(ksolve_sweep_results* r) { if (r && r->impl) { delete (ksi::SweepImpl*)r->impl; r->impl = nullptr; } }
 ksolve_status ksolve_solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) { return ksi::solve_batch(hs, n, outs); }
 ksolve_status ksolve_cancel(ksolve_handle* h) { if (h->d_cancel) __atomic_store_n(h->d_cancel, 1, __ATOMIC_RELAXED); return KSOLVE_OK; }
 void ksolve_results_free(ksolve_results* r) { if (r && r->impl) { delete (ksi::ResultsImpl*)r->impl; r->impl = nullptr; } }
