@@ -26,6 +26,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def source_sha():
+    """sha256 over the kernel sources (csrc/, include/): identifies the build a profile was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "karpenter_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/ksolve.h"]:
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes(c):
     """bytes = P*B_pod + V*B_bin + P*B_bin(writeback) + N_it*T*B_it with the record sizes of the
     layouts actually used (DESIGN.md §Data layout). V = the bins the REFERENCE evaluates."""
@@ -71,6 +82,66 @@ def launch_type_vector(prob, res):
     return vec
 
 
+def config4_sweep(args, device_index, rank, world):
+    """BASELINE configs[4]: the consolidation replay. A resident cluster (disruption.make_resident_cluster: nodes packed with the
+    benchmark's pods, then scaled down — test/suites/performance/basic_test.go:61-68) is uploaded once; single-node consolidation
+    (singlenodeconsolidation.go:55-126) then simulates every candidate — SimulateScheduling (disruption/helpers.go:53-155) +
+    computeConsolidation (consolidation.go:159-256) — as ONE ksolve_sweep launch, one wavefront per candidate. With N ranks the
+    candidates are dealt out round-robin (the cluster tables are replicated, no collective on the data path); the verdict counts
+    are summed afterwards. A sample of the probes is re-simulated by the oracle: the check, and this leg's CPU baseline."""
+    from collections import Counter
+    from karpenter_amd import disruption as dz
+    out = {"workload": f"BASELINE configs[4]: single-node consolidation sweep over a resident cluster of {args.sweep_nodes} existing nodes"}
+    t = time.perf_counter(); cc = dz.make_resident_cluster(n_nodes=args.sweep_nodes, seed=42); out["generate_s"] = time.perf_counter() - t
+    cc["options"] = {"device": device_index}
+    out["nodes"], out["bound_pods"] = args.sweep_nodes, sum(g["count"] for g in cc["podGroups"])
+    t = time.perf_counter(); rc = dz.ResidentCluster.from_compact(cc, solver_lib=args.solver_lib); out["new_scheduler_s"] = time.perf_counter() - t
+    order = dz.compact_candidates(cc)
+    order = order[::max(1, len(order) // max(1, args.sweep_candidates))][:args.sweep_candidates]   # every k-th of sortCandidates' order: the whole list's mix
+    mine = order[rank::world]
+    cands = [[cc["nodes"][i]] for i in mine]
+    rc.decisions(cands[:64])                       # warm-up: the arena, the per-cluster tables (ksolve_node_dead0)
+    t = time.perf_counter(); cmds = rc.decisions(cands); dt = time.perf_counter() - t
+    tm = rc.last_sweep["timings"]
+    lib_s = (tm["descriptors_ms"] + tm["sweep_ms"] + tm["verdicts_ms"]) * 1e-3
+    out.update(candidates=len(cands), decisions=dict(Counter(c["decision"] for c in cmds)), displaced_pods=tm["pods"],
+               seconds={"descriptors": tm["descriptors_ms"] * 1e-3, "upload": tm["upload_us"] * 1e-6, "pack_kernel": tm["pack_us"] * 1e-6, "finalize": tm["finalize_us"] * 1e-6,
+                        "download": tm["download_us"] * 1e-6, "verdicts": tm["verdicts_ms"] * 1e-3, "library_call": lib_s, "python_call": dt},
+               value=len(cands) / lib_s, unit="probes/s",
+               probes_per_s={"pack_kernel_only": len(cands) / (tm["pack_us"] * 1e-6), "ksolve_sweep_call": len(cands) / (tm["sweep_ms"] * 1e-3),
+                             "with_descriptors_and_verdicts": len(cands) / lib_s, "through_python": len(cands) / dt},
+               timed_region="ksched_sweep(): probe descriptors (host library), ksolve_sweep (upload, one launch, finalize, download), verdicts; candidate prices and the JSON of the call are Python's")
+    if args.sweep_sample > 0 and rank == 0:
+        import random
+        import oracle   # the checker: re-simulates sampled probes; its rate is this leg's CPU baseline
+        rng = random.Random(1)
+        by_dec = {}
+        for j, c in enumerate(cmds):
+            by_dec.setdefault(c["decision"], []).append(j)
+        sample = []
+        for _, js in sorted(by_dec.items()):       # every verdict is represented
+            sample += rng.sample(js, min(len(js), max(1, args.sweep_sample // len(by_dec))))
+        base = dz.compact_problem(cc, pod_groups=[])
+        probes = [{"removeNodes": [cc["nodes"][mine[j]]["name"]], "pods": dz.compact_node_pods(cc, mine[j])} for j in sample]
+        threads = min(len(probes), os.cpu_count() or 1)
+        t = time.perf_counter(); res = oracle.sweep(base, probes, threads=threads); osec = time.perf_counter() - t
+        bad = []
+        for j, r, pr in zip(sample, res, probes):
+            want = dz.decide(cc, [dict(cc["nodes"][mine[j]], pods=pr["pods"])], dz._finish_simulation(cc, r, set()))
+            got = cmds[j]
+            if (got["decision"], got["replacement"], got.get("replacementCapacityType")) != (want["decision"], want["replacement"], want.get("replacementCapacityType")) \
+                    or rc.last_sweep["referenceBinEvaluations"][j] != r["counters"]["binEvaluations"]:
+                bad.append(cc["nodes"][mine[j]]["name"])
+        if bad:
+            raise SystemExit(f"bench.py: configs[4] probes differ from the oracle's simulation: {bad[:5]}")
+        out["oracle_check"] = {"probes": len(sample), "by_decision": dict(Counter(cmds[j]["decision"] for j in sample)), "all_identical": True,
+                               "compared": "decision, replacement instance types, capacity type, reference-equivalent evaluation count"}
+        out["cpu_baseline"] = {"value": len(sample) / osec, "unit": "probes/s", "cores": threads, "kind": "port",
+                               "sample": f"{len(sample)} of the swept probes, each a fresh oracle Scheduler over the {args.sweep_nodes}-node cluster (what the reference does per simulation), {threads} at a time", "seconds": osec}
+    rc.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +159,9 @@ def main():
     ap.add_argument("--components-pods", type=int, default=10_000_000, help="BASELINE configs[3]: pods of the 16-NodePool batch solved as NodePool components (one block each, one launch), 0 = skip")
     ap.add_argument("--components-types", type=int, default=1000)
     ap.add_argument("--components-calibration-pods", type=int, default=200_000, help="size at which the component split is compared with ONE Solve() of the whole batch (L2-canonical deltas)")
+    ap.add_argument("--sweep-nodes", type=int, default=100_000, help="BASELINE configs[4]: existing nodes of the resident cluster swept by single-node consolidation (about 20 bound pods each), 0 = skip")
+    ap.add_argument("--sweep-candidates", type=int, default=10_000, help="candidates (probes) per launch of the sweep")
+    ap.add_argument("--sweep-sample", type=int, default=32, help="probes of the sweep re-simulated by the oracle (checker + CPU baseline of this leg)")
     ap.add_argument("--no-parity-pin", action="store_true", help="skip the digest check of the timed problem against the committed oracle pin")
     ap.add_argument("--engine", default="auto", choices=["auto", "general", "cursor"], help="pack engine (auto: the cursor engine for purely positive batches)")
     ap.add_argument("--solver-lib", default=None, help="TEST HOOK (tests/test_bench_contract.py, needs KSOLVE_BENCH_TEST_HOOK=1): a host build of the engine behind the same "
@@ -254,6 +328,22 @@ def main():
                                        "claims_delta": sum(r["counters"]["claims"] for r in rc) - rw["counters"]["claims"],
                                        "cost_rel_delta": (sum(r["packingCost"] for r in rc) - rw["packingCost"]) / rw["packingCost"]}
 
+    # ---- BASELINE configs[4] (all ranks take part): the consolidation replay over a resident cluster ----
+    sweep = None
+    if args.sweep_nodes > 0:
+        sweep = config4_sweep(args, device_index, rank, world)
+        if dist is not None:
+            names = ("delete", "replace", "no-op")
+            v = torch.tensor([float(sweep["candidates"])] + [float(sweep["decisions"].get(k, 0)) for k in names], dtype=torch.float64, device=reduce_device)
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            t = torch.tensor([sweep["seconds"]["library_call"]], dtype=torch.float64, device=reduce_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sweep["ranks"] = world
+            sweep["candidates_all_ranks"] = int(v[0].item())
+            sweep["decisions_all_ranks"] = {k: int(v[1 + i].item()) for i, k in enumerate(names)}
+            sweep["value"] = v[0].item() / t.item()   # probes of all ranks / slowest rank's call
+            sweep["sharding"] = "candidates dealt out round-robin over the ranks, cluster tables replicated, no data-path collective; verdict counts summed with one all-reduce"
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -269,26 +359,20 @@ def main():
     rh_ms = sum(t.get("row_hash_ms", 0.0) for t in timings) / len(timings)
     achieved = abytes / (pack_ms * 1e-3) / 1e9
     kernel = "ksolve_pack_fast" if c.get("engine") == "cursor" else "ksolve_pack_lite"
-    traffic = None
+    # HBM bytes per launch from the TCC counters: collected by scripts/gpu_pmc_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate passes, --kernel-trace only; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes) on this workload and
+    # written to profiles/round3/pmc_traffic.json together with a hash of the kernel sources. A figure is used only for the build
+    # it was measured on: after any change of the sources it reads null until the script has run again.
+    traffic, stream_traffic, traffic_note = None, None, "not measured for this build (scripts/gpu_pmc_traffic.sh)"
     try:
-        # HBM bytes of one launch of the pack kernel from the TCC counters (rocprofv3 --pmc, separate passes; scripts/gpu_pmc.sh).
-        # Collected on this workload in its own profiling run and committed under profiles/; not measurable from inside.
-        with open(os.path.join(ROOT, "profiles", "round2", "pmc_pack_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "round3", "pmc_traffic.json")) as f:
             pmc = json.load(f)
-        if args.pods == 1_000_000 and args.types == 500 and pmc.get("kernel") == kernel:
-            traffic = pmc["traffic_bytes_per_launch"]
+        if pmc.get("source_sha") == source_sha() and pmc.get("pods") == args.pods and pmc.get("types") == args.types:
+            traffic = pmc["kernels"].get(kernel, {}).get("traffic_bytes_per_launch")
+            stream_traffic = pmc["kernels"].get("ksolve_row_hash_coop2", {}).get("traffic_bytes_per_launch")
+            traffic_note = "TCC FETCH_SIZE x2 + WRITE_SIZE per launch, rocprofv3 --pmc on this build (profiles/round3/pmc_traffic.json)"
     except (OSError, KeyError, ValueError):
-        traffic = None
-    stream_traffic = None
-    try:
-        # the same for the classing kernel (profiles/round2/pmc_raw.json: FETCH_SIZE and WRITE_SIZE in KB per launch, separate passes;
-        # FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes)
-        with open(os.path.join(ROOT, "profiles", "round2", "pmc_raw.json")) as f:
-            k = json.load(f)["void ksolve_row_hash_coop2<false>"]
-        if args.pods == 1_000_000 and args.types == 500:
-            stream_traffic = int(2 * k["FETCH_SIZE"]["per_launch"] * 1024 + k["WRITE_SIZE"]["per_launch"] * 1024)
-    except (OSError, KeyError, ValueError):
-        stream_traffic = None
+        pass
     pin = None
     if not args.no_parity_pin:
         pin_path = os.path.join(ROOT, "tests", "golden", "fullsize", f"config2_p{args.pods}_t{args.types}_s{seed}.json")
@@ -312,18 +396,22 @@ def main():
                                           "vector": "count and $/h per instance type, all ranks summed" + (" with one all-reduce" if world > 1 else "")}},
         "engine": c.get("engine"),
         "parity": {"results_digest": digest, "oracle_pin": pin},
-        "roofline": {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes": abytes, "avg_kernel_ms": pack_ms, "records": rec,
-                     "measured_traffic_GBps": (traffic / (pack_ms * 1e-3) / 1e9) if traffic else None,
-                     "note": "achieved = SURVEY §8(d) algorithmic bytes with V = the bins the REFERENCE evaluates (referenceBinEvaluations, equal to the oracle's count) / HIP-event time of the "
-                             "pack kernel. The kernel itself is a serial first-fit chain on ONE wavefront — instruction-issue bound (about 5.8 cycles per instruction for a lone wave, "
-                             "profiles/round2), not HBM bound: its working set lives in LDS, `traffic` (TCC counters of a separate rocprofv3 --pmc run) is what it really moves"},
-        # the one kernel of the path that streams the pod rows from HBM (rows x B_pod): HIP events around it alone;
-        # `phase_ms` is the whole classing phase (table memsets, this kernel, a host round trip for the class count, row_class, class_gather)
-        "roofline_stream": {"kernel": "ksolve_row_hash_coop2 (pod classing: one round trip for a 64-row block, words staged through LDS, hash, class-table slot, verify)", "bound": "hbm", "bytes": stream_bytes,
-                            "bytes_read_by_the_kernel": c["rows"] * (2 * (8 * c["reqWords"] + 16) + 8 * c["resources"] + 8 + 4),   # both mask tables + flag words, requests, toleration mask, slot written; all-nil minValues tables are not streamed
-                            "avg_ms": rh_ms, "achieved": stream_bytes / (rh_ms * 1e-3) / 1e9 if rh_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": stream_bytes / (rh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rh_ms > 0 else None, "traffic": stream_traffic, "phase_ms": cls_ms},
+        # The kernel of the path that streams from HBM: pod classing — every pod row (requirement masks of both tables, flag words,
+        # requests, toleration mask) is read once, hashed and matched against the class table. rows x B_pod algorithmic bytes
+        # ("the feasibility pre-pass ... is the one to hold to the >= 40% HBM target"); HIP events around the kernel alone.
+        "roofline": {"kernel": "ksolve_row_hash_coop2", "bound": "hbm", "achieved": stream_bytes / (rh_ms * 1e-3) / 1e9 if rh_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": stream_bytes / (rh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rh_ms > 0 else None, "traffic": stream_traffic, "traffic_source": traffic_note,
+                     "algorithmic_bytes": stream_bytes, "bytes_per_row": rec["B_pod"], "rows": c["rows"], "avg_kernel_ms": rh_ms, "classing_phase_ms": cls_ms,
+                     "bytes_read_by_the_kernel": c["rows"] * (2 * (8 * c["reqWords"] + 16) + 8 * c["resources"] + 8 + 4),   # both mask tables + flag words, requests, toleration mask, slot written; all-nil minValues tables are not streamed
+                     "note": "B_pod is the row of the layout actually used (DESIGN.md §3); SURVEY §8(d)'s sketch of a row (K = 16 keys, one mask word each) is 188 B"},
+        # The pack kernel is a serial first-fit chain on ONE wavefront: bound by the instruction issue and the dependent LDS round
+        # trips of a lone wave, not by HBM — no roofline is claimed for it. `achieved` is what it really moves.
+        "pack_kernel": {"kernel": kernel, "bound": "latency / instruction issue of one wavefront", "avg_kernel_ms": pack_ms, "traffic": traffic, "traffic_source": traffic_note,
+                        "achieved": (traffic / (pack_ms * 1e-3) / 1e9) if traffic else None, "unit": "GB/s",
+                        "reference_equivalent": {"bytes": abytes, "GBps": achieved, "frac_of_hbm_peak": achieved / HBM_PEAK_GBS, "records": rec,
+                                                 "note": "SURVEY §8(d) formula P*B_pod + V*B_bin + P*B_bin + N_it*T*B_it with V = the bins the REFERENCE evaluates (referenceBinEvaluations, equal to the "
+                                                         "oracle's count) and the record sizes of the layout in use (SURVEY's sketch: 188 / 248 / 185 B): the bytes the reference's scan would "
+                                                         "touch, not what this kernel moves — cursors and permanent rejections make almost all of those evaluations unnecessary"}},
         "phases_ms": {k: sum(t.get(k, 0.0) for t in timings) / len(timings) for k in ("pack_kernel_ms", "classify_ms", "row_hash_ms", "sort_ms", "it_index_ms")},
         "counters": c,
     }
@@ -343,6 +431,8 @@ def main():
         s3.close()
     if comp is not None:
         out["config3_components"] = comp
+    if sweep is not None:
+        out["config4_sweep"] = sweep
     if args.batch_problems > 0 and world == 1:
         # Independent problems (NodePool components / consolidation probes) in ONE launch of the pack kernel:
         # block b = the wavefront of problem b. Reported beside the headline, never part of `value`.
