@@ -142,6 +142,15 @@ def config4_sweep(args, device_index, rank, world):
     return out
 
 
+def packing_vector(res, n_its):
+    """The same vector from the solver library (ksolve_packing_vector through the Results document): [type, count, $/h] triples."""
+    import numpy as np
+    vec = np.zeros((n_its, 2))
+    for i, c, d in res["packingVector"]:
+        vec[i] = (c, d)
+    return vec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,7 +162,7 @@ def main():
     ap.add_argument("--cpu-runs", type=int, default=5, help="oracle runs of the sample (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-engine-baseline", action="store_true", help="skip timing the engine's own source compiled for one host core")
-    ap.add_argument("--topology-pods", type=int, default=200_000, help="BASELINE configs[2] shape (anti-affinity + 3-zone spread) reported beside the headline, 0 = skip")
+    ap.add_argument("--topology-pods", type=int, default=1_000_000, help="BASELINE configs[2] shape (anti-affinity + 3-zone spread) reported beside the headline, 0 = skip")
     ap.add_argument("--batch-problems", type=int, default=512, help="independent problems solved with ONE batched launch (reported beside the headline, 0 = skip)")
     ap.add_argument("--batch-pods", type=int, default=20_000, help="pods per problem of the batched measurement")
     ap.add_argument("--components-pods", type=int, default=10_000_000, help="BASELINE configs[3]: pods of the 16-NodePool batch solved as NodePool components (one block each, one launch), 0 = skip")
@@ -238,7 +247,7 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity   # canonical Results digest (shared with the tests; does not touch oracle/)
     digest, _ = parity.results_digest(full)
-    vec = launch_type_vector(prob, full)
+    vec = packing_vector(full, len(prob["instanceTypes"]))   # ksolve_packing_vector; tests/test_distributed_gloo.py checks it against launch_type_vector on the oracle's claims
 
     if dist is not None:
         # max over ranks of the timed region; the global packing summary = the per-instance-type (count, $/h) vectors of all
@@ -290,10 +299,10 @@ def main():
                 sc_.close()
             return whole, parts, mine, rs, best
 
-        whole, parts, mine, rs, dt = solve_components(args.components_pods, 2, want_results="claims")
+        whole, parts, mine, rs, dt = solve_components(args.components_pods, 2)
         cvec = np.zeros((len(whole["instanceTypes"]), 2))
-        for (_, sub), r in zip(mine, rs):
-            cvec += launch_type_vector(sub, r)
+        for r in rs:
+            cvec += packing_vector(r, len(whole["instanceTypes"]))   # per component by the library (ksolve_packing_vector); summed here, all-reduced below
         totals = [float(sum(r["scheduledPods"] for r in rs)), float(sum(r["counters"]["claims"] for r in rs)), float(sum(r["packingCost"] for r in rs)),
                   max([r["timings"][0]["pack_kernel_ms"] for r in rs], default=0.0)]
         engines = sorted({r["counters"].get("engine") for r in rs})
@@ -310,7 +319,7 @@ def main():
             comp = {"workload": f"BASELINE configs[3]: {args.components_pods} pods x {args.components_types} types x 16 NodePools, every pod pinned to its pool",
                     "components": len(parts), "ranks": world, "sharding": "component c -> rank c % N, one batched launch per rank" if world > 1 else "all components in one launch on one GPU",
                     "pods": int(round(totals[0])), "seconds": dt, "value": totals[0] / dt, "unit": "pods/s",
-                    "timed_region": "ksolve_solve_batch(): classing, queue sort, pack, finalize, download of the flat C-ABI Results of every component; the NodeClaims are re-hydrated for the per-instance-type vector by a second, untimed call",
+                    "timed_region": "ksolve_solve_batch(): classing, queue sort, pack, finalize, download of the flat C-ABI Results of every component (+ ksolve_packing_vector per component)",
                     "node_claims": int(round(totals[1])), "packing_cost_per_hour": totals[2], "pack_kernel_ms": totals[3], "engines": engines,
                     "per_instance_type": {"launch_types_used": int(nzc.sum()), "claims_from_vector": int(round(cvec[:, 0].sum())), "cost_from_vector": float(cvec[:, 1].sum()),
                                           "vector": "count and $/h per instance type over all components" + (", summed over ranks with one all-reduce" if world > 1 else "")},
@@ -322,7 +331,15 @@ def main():
                 sw = NewScheduler(whole_p, solver_lib=args.solver_lib)
                 rw = sw.Solve(want_results=False)
                 sw.close()
-                _, _, _, rc, _ = solve_components(cp, 1, shard=False)
+                _, cparts, cmine, rc, _ = solve_components(cp, 1, want_results=True, shard=False)
+                if not args.no_cpu_baseline and not args.no_parity_pin:
+                    # every component of the calibration batch against the oracle's Solve() of that component, in the run
+                    # (the 10M-pod components are beyond the oracle: O(pods x claims))
+                    import oracle
+                    bad = [name for (name, sub), r in zip(cmine, rc) if parity.results_digest(r)[0] != parity.results_digest(oracle.solve(sub))[0]]
+                    if bad:
+                        raise SystemExit(f"bench.py: configs[3] components differ from the oracle: {bad}")
+                    comp["components_check"] = {"pods": cp, "components": len(cmine), "all_digests_match_oracle": True}
                 comp["calibration"] = {"pods": cp, "whole_batch": {"node_claims": rw["counters"]["claims"], "packing_cost_per_hour": rw["packingCost"], "engine": rw["counters"].get("engine")},
                                        "components": {"node_claims": sum(r["counters"]["claims"] for r in rc), "packing_cost_per_hour": sum(r["packingCost"] for r in rc)},
                                        "claims_delta": sum(r["counters"]["claims"] for r in rc) - rw["counters"]["claims"],
@@ -417,18 +434,45 @@ def main():
     }
     sched.close()
     if args.topology_pods > 0 and world == 1:
-        # BASELINE configs[2] shape (podAntiAffinity + 3-zone topologySpreadConstraints, the reference benchmark's diverse mix)
-        p3 = fx.config3(pods=args.topology_pods, n_types=args.types, seed=42)
-        p3["options"]["device"] = device_index
-        s3 = NewScheduler(p3, solver_lib=args.solver_lib)
-        s3.Solve(want_results=False)
-        tb = time.perf_counter()
-        r3 = s3.Solve(want_results=False)
-        dt = time.perf_counter() - tb
-        out["config2_topology"] = {"workload": f"BASELINE configs[2] shape: {args.topology_pods} pods, anti-affinity + zonal / hostname spread + zonal affinity, {args.types} types",
-                                   "pods": args.topology_pods, "seconds": dt, "value": r3["scheduledPods"] / dt, "unit": "pods/s", "node_claims": r3["counters"]["claims"],
-                                   "pack_kernel_ms": r3["timings"][0]["pack_kernel_ms"], "engine": r3["counters"].get("engine")}
-        s3.close()
+        # BASELINE configs[2] shape (podAntiAffinity + 3-zone topologySpreadConstraints, the reference benchmark's diverse mix): ONE
+        # Solve() of the whole batch on the general engine (BIG variant: every anti-affinity pod is its own NodeClaim). The size asked
+        # for is timed; its Results are checked against the oracle's pin when one exists for that size (the oracle is O(pods x
+        # claims): tests/golden/make_fullsize_digests.py), and the largest pinned size below it is solved and checked as well.
+        import glob
+        import re
+
+        def topology_run(pods, timed_solves):
+            p3 = fx.config3(pods=pods, n_types=args.types, seed=42)
+            p3["options"]["device"] = device_index
+            s3 = NewScheduler(p3, solver_lib=args.solver_lib)
+            best, r3 = None, None
+            for _ in range(timed_solves):
+                tb = time.perf_counter()
+                r3 = s3.Solve(want_results=False)
+                dt = time.perf_counter() - tb
+                best = dt if best is None else min(best, dt)
+            e = {"pods": pods, "seconds": best, "value": r3["scheduledPods"] / best, "unit": "pods/s", "node_claims": r3["counters"]["claims"],
+                 "pack_kernel_ms": r3["timings"][0]["pack_kernel_ms"], "engine": r3["counters"].get("engine"), "oracle_pin": None}
+            pin_path = os.path.join(ROOT, "tests", "golden", "fullsize", f"config3_p{pods}_t{args.types}_s42.json")
+            if os.path.exists(pin_path) and not args.no_parity_pin:
+                with open(pin_path) as f:
+                    g = json.load(f)
+                full3 = s3.Solve(want_results=True)
+                d3, _ = parity.results_digest(full3)
+                e["oracle_pin"] = {"pin": os.path.relpath(pin_path, ROOT), "digest_matches_oracle": d3 == g["digest"], "reference_bin_evaluations_match": full3["counters"]["referenceBinEvaluations"] == g["binEvaluations"],
+                                   "oracle_seconds_offline": g["oracleSeconds"], "oracle_threads": g.get("oracleThreads", 1)}
+                if not (e["oracle_pin"]["digest_matches_oracle"] and e["oracle_pin"]["reference_bin_evaluations_match"]):
+                    raise SystemExit(f"bench.py: the configs[2] problem's Results differ from the oracle's pin {e['oracle_pin']}")
+            s3.close()
+            return e
+        e = topology_run(args.topology_pods, 1 if args.topology_pods > 300_000 else 2)
+        e["workload"] = f"BASELINE configs[2] shape: {args.topology_pods} pods, anti-affinity + zonal / hostname spread + zonal affinity, {args.types} types"
+        if e["oracle_pin"] is None:
+            pinned = sorted(int(re.search(r"_p(\d+)_", os.path.basename(f)).group(1)) for f in glob.glob(os.path.join(ROOT, "tests", "golden", "fullsize", f"config3_p*_t{args.types}_s42.json")))
+            pinned = [n for n in pinned if n < args.topology_pods]
+            if pinned and not args.no_parity_pin:
+                e["largest_pinned_size"] = topology_run(pinned[-1], 1)
+        out["config2_topology"] = e
     if comp is not None:
         out["config3_components"] = comp
     if sweep is not None:

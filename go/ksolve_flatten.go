@@ -780,6 +780,114 @@ func flatten(ctx context.Context, s *Scheduler, pods []*corev1.Pod, maxSteps int
 			desc.daemon_group_host_ports = cU64(a, groupHP)
 		}
 	}
+	// ---- CSI volume limits of existing nodes (VolumeUsage.ExceedsLimits / Add, pkg/scheduling/volumeusage.go:193-209; checked by
+	// ExistingNode.CanAdd at existingnode.go:88, updated by Add at :179). A volume is a distinct <driver, PVC> pair; only drivers
+	// with a limit on some node are tracked. Same tables as the C++ twin (karpenter_amd/host/ksched.cpp).
+	if E > 0 {
+		driverIdx := map[string]int{}
+		for _, n := range s.existingNodes {
+			_, limits := n.VolumeUsage().Tracked() // accessor added by go/volumeusage_ksolve.go
+			for drv := range limits {
+				if _, ok := driverIdx[drv]; !ok {
+					driverIdx[drv] = len(driverIdx)
+				}
+			}
+		}
+		if len(driverIdx) > C.KSOLVE_MAX_VOLUME_DRIVERS {
+			return nil, fmt.Errorf("%w: %d CSI drivers with volume limits", ErrKSolveUnsupported, len(driverIdx))
+		}
+		if nd := len(driverIdx); nd > 0 {
+			type volKey struct {
+				drv int
+				pvc string
+			}
+			volID := map[volKey]uint32{}
+			var volDriver []uint8
+			vid := func(drv, pvc string) (uint32, bool) {
+				di, ok := driverIdx[drv]
+				if !ok {
+					return 0, false
+				}
+				k := volKey{di, pvc}
+				if id, ok := volID[k]; ok {
+					return id, true
+				}
+				id := uint32(len(volID))
+				volID[k] = id
+				volDriver = append(volDriver, uint8(di))
+				return id, true
+			}
+			podFirst := make([]uint32, len(pods)+1)
+			var podPVs []uint32
+			for i, p := range pods { // rows [0, len(pods)) are the pods as submitted; variant rows share their pod's volumes
+				podFirst[i] = uint32(len(podPVs))
+				vols, err := scheduling.GetVolumes(ctx, s.kubeClient, p) // scheduler.go:622-626
+				if err != nil {
+					return nil, err
+				}
+				seen := map[uint32]bool{}
+				for drv, pvcs := range vols {
+					for pvc := range pvcs {
+						if id, ok := vid(drv, pvc); ok && !seen[id] {
+							seen[id] = true
+							podPVs = append(podPVs, id)
+						}
+					}
+				}
+				if len(seen) > 64 {
+					return nil, fmt.Errorf("%w: pod %s/%s mounts more than 64 volumes under CSI limits", ErrKSolveUnsupported, p.Namespace, p.Name)
+				}
+			}
+			podFirst[len(pods)] = uint32(len(podPVs))
+			nodeFirst := make([]uint32, E+1)
+			overLimit := false
+			var nodePVs []uint32
+			nodeLimit := make([]int32, E*nd)
+			for i := range nodeLimit {
+				nodeLimit[i] = -1
+			}
+			for e, n := range s.existingNodes {
+				nodeFirst[e] = uint32(len(nodePVs))
+				volumes, limits := n.VolumeUsage().Tracked()
+				var ids []uint32
+				used := make([]int, nd)
+				for drv, pvcs := range volumes {
+					for pvc := range pvcs {
+						if id, ok := vid(drv, pvc); ok {
+							ids = append(ids, id)
+							used[driverIdx[drv]]++
+						}
+					}
+				}
+				sort.Slice(ids, func(i, j int) bool { return ids[i] < ids[j] })
+				nodePVs = append(nodePVs, ids...)
+				for drv, lim := range limits {
+					nodeLimit[e*nd+driverIdx[drv]] = int32(lim)
+					if used[driverIdx[drv]] > lim {
+						// over a limit already: ExceedsLimits rejects every pod (it walks the drivers of the union) — the
+						// device sees a node without room
+						nodeRemaining[0*E+e] = -1
+						overLimit = true
+					}
+				}
+			}
+			if overLimit {
+				desc.node_remaining = cI64(a, nodeRemaining) // the table was copied before this block
+			}
+			nodeFirst[E] = uint32(len(nodePVs))
+			if len(podPVs) == 0 {
+				podPVs = []uint32{0}
+			}
+			if len(nodePVs) == 0 {
+				nodePVs = []uint32{0}
+			}
+			desc.n_volume_drivers, desc.n_volumes = C.uint32_t(nd), C.uint32_t(len(volDriver))
+			desc.volume_driver = cU8(a, volDriver)
+			desc.pod_pv_first, desc.pod_pvs = cU32(a, podFirst), cU32(a, podPVs)
+			desc.node_pv_first, desc.node_pvs = cU32(a, nodeFirst), cU32(a, nodePVs)
+			desc.node_pv_limit = cI32(a, nodeLimit)
+		}
+	}
 	// ---- volume requirement alternatives (PodData.VolumeRequirements; nodeclaim.go:138-157, existingnode.go:108-139): one
 	// requirement set per alternative, list after list; pods with equal lists share (first, count) — it is part of a pod's
 	// class identity on the device. A relaxed row carries its pod's list (updateCachedPodData copies it by UID).

@@ -31,6 +31,7 @@ extern "C" {
 #define KSOLVE_MAX_ITWORDS 32     /* ceil(n_instance_types / 64) */
 #define KSOLVE_MAX_ZONES 16       /* distinct offering zones  */
 #define KSOLVE_MAX_CAPTYPES 4     /* distinct offering capacity types */
+#define KSOLVE_MAX_VOLUME_DRIVERS 8
 #define KSOLVE_MAX_OVERRIDE_GROUPS 4096 /* extra allocatable groups (offering overrides) per problem */
 #define KSOLVE_MAX_TOPO_GROUPS 1024 /* topology groups per problem; pod group masks take ceil(n/64) words */
 
@@ -223,6 +224,23 @@ typedef struct {
 
   /* ---- distinct taints of the problem (for filter_taint_honor only the masks matter) ---- */
   uint32_t n_taints;
+
+  /* ---- CSI volume limits of existing nodes: StateNode.VolumeUsage() (statenode.go:411, :466-490), VolumeUsage.ExceedsLimits /
+   *      Add (pkg/scheduling/volumeusage.go:193-209), checked by ExistingNode.CanAdd right after the taints (existingnode.go:88)
+   *      and updated by ExistingNode.Add (:179). A volume is a distinct <CSI driver, PVC> pair of the problem (what
+   *      scheduling.GetVolumes resolves per pod, volumeusage.go:83-114 — upstream of Solve()); volume ids are numbered so that
+   *      volume_driver[id] is its driver. A pod joins a node only if, for every driver with a limit on that node, the union of
+   *      the node's and the pod's volumes of the driver stays within the limit. A node that is over a limit before the solve
+   *      rejects every pod (ExceedsLimits walks the union's drivers): the flattener gives such a node negative remaining
+   *      resources. New NodeClaims have no limits (no CSINode yet). n_volume_drivers == 0: nothing below is read. ---- */
+  uint32_t n_volume_drivers;               /* drivers that have a limit on some node, <= KSOLVE_MAX_VOLUME_DRIVERS */
+  uint32_t n_volumes;                      /* distinct volumes of those drivers */
+  const uint8_t* volume_driver;            /* n_volumes */
+  const uint32_t* pod_pv_first;            /* n_pods + 1 : CSR into pod_pvs (variant rows share their pod's) */
+  const uint32_t* pod_pvs;                 /* volume ids, distinct within a pod */
+  const uint32_t* node_pv_first;           /* n_nodes + 1 : CSR into node_pvs */
+  const uint32_t* node_pvs;                /* volume ids in use on the node, ascending */
+  const int32_t* node_pv_limit;            /* n_nodes * n_volume_drivers : attach limit, -1 = none */
 } ksolve_problem_desc;
 
 typedef struct {
@@ -312,8 +330,11 @@ typedef struct {
 ksolve_status ksolve_create(const ksolve_problem_desc* desc, const ksolve_options* opts, ksolve_handle** out);
 /* Runs Solve() on the device. One in-flight solve per handle; distinct handles are independent and thread-safe. */
 ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out);
-/* Solves n independent problems (handles on the same device) with ONE launch of the pack kernel: block b is the
- * wavefront of problem b. Results are identical to n ksolve_solve calls; outs[i].status carries each problem's status.
+/* Solves n independent problems with ONE launch of the pack kernel per device: block b is the wavefront of problem b. The
+ * handles may live on several devices (ksolve_options.device): every device's problems run as one batch on that device, the
+ * devices side by side (one host thread and one stream set each), and the call returns when all are done — the one-process
+ * form of "partition the batch across the GPUs". Results are identical to n ksolve_solve calls; outs[i].status carries each
+ * problem's status.
  * This is the entry point for consolidation sweeps (disruption/helpers.go:53-155 runs one Solve() per candidate set)
  * and for NodePool components of one provisioning pass. */
 ksolve_status ksolve_solve_batch(ksolve_handle** handles, uint32_t n, ksolve_results* outs);
@@ -360,6 +381,17 @@ typedef struct {
  * status is in results.status. */
 ksolve_status ksolve_sweep(ksolve_handle* base, const ksolve_sweep_desc* desc, ksolve_sweep_results* out);
 void ksolve_sweep_results_free(ksolve_sweep_results* r);
+/* The north_star's global packing summary: per instance type, how many of the NodeClaims of `results` launch on it and their
+ * $/h (a claim launches on the instance type with its cheapest compatible available offering — OrderByPrice's key,
+ * types.go:336-355; ties: the lower index). count / cost: n_instance_types doubles each, overwritten.
+ * Sharded solves (ksolve_solve_batch over handles on several devices, one process per GPU, ...) SUM these vectors: that sum is
+ * the reduction the design calls for — 16 KB at 1000 instance types. Inside one process it is a host loop
+ * (ksolve_packing_vector_sum); across processes it is one all-reduce of the same vector (bench.py: torch.distributed, RCCL over
+ * xGMI) — latency-bound either way. */
+ksolve_status ksolve_packing_vector(const ksolve_handle* h, const ksolve_results* results, double* count, double* cost);
+/* The same over n solved problems (handles[i] solved into results[i]; any devices): element-wise sum of their vectors. All
+ * handles must share the instance-type catalogue size. */
+ksolve_status ksolve_packing_vector_sum(ksolve_handle* const* handles, const ksolve_results* results, uint32_t n, double* count, double* cost);
 /* Asks a running ksolve_solve on another thread to stop at the next pod boundary (ctx cancellation). */
 ksolve_status ksolve_cancel(ksolve_handle* h);
 void ksolve_results_free(ksolve_results* r);

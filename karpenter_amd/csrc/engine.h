@@ -153,6 +153,8 @@ struct Engine {
   uint32_t cur_vol_first = 0, cur_vol_n = 0;  // volume requirement alternatives of the pod being placed (PodData.VolumeRequirements)
   uint64_t bin_hp = 0;                        // host-port triples already bound by the pods of the candidate bin
   bool topo_reached = false;        // the last can_add got as far as the topology stage (its verdict is not cacheable)
+  uint32_t cur_pv_first = 0, cur_pv_n = 0;    // the pod's volumes of drivers with a limit somewhere (ProblemView::pod_pvs)
+  int n_pv_log = 0;                 // entries of Workspace::pv_log
   int cur_out = 0;                  // where the pod being placed reports its result: its pod index, or its position in Workspace::pr_sorted (probes)
   int n_revived = 0;                // probes: entries of Workspace::pr_revived
 
@@ -1691,6 +1693,38 @@ struct Engine {
     }
     return -1;
   }
+  // VolumeUsage.ExceedsLimits (volumeusage.go:193-200) for the pod being placed on existing node en: per driver with a limit
+  // there, |volumes in use (before the solve + added by this solve's commits) ∪ the pod's| <= limit. One lane per volume of
+  // the pod; `fresh` (out) = the pod's volumes that are not on the node yet, as a mask over its first 64 (more: never fresh
+  // past the first block — pods mount a handful of volumes; a pod with more than 64 tracked volumes is refused upstream).
+  KS_DEV bool node_exceeds_volume_limits(int en, uint64_t* fresh) {
+    const ProblemView& Pv = P;
+    const Workspace& Sw = S;
+    const int nd = Pv.n_pv_drivers, nlog = n_pv_log;
+    const uint32_t n0 = Pv.node_pv_first[en], n1 = Pv.node_pv_first[en + 1], pf = cur_pv_first, pn = cur_pv_n;
+    const uint64_t want = W::ballot([&](int l) {
+      if ((uint32_t)l >= pn) return false;
+      const uint32_t v = Pv.pod_pvs[pf + l];
+      uint32_t lo = n0, hi = n1;                      // binary search in the node's ascending list
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (Pv.node_pvs[mid] < v) lo = mid + 1; else hi = mid; }
+      if (lo < n1 && Pv.node_pvs[lo] == v) return false;
+      const uint64_t key = ((uint64_t)(uint32_t)en << 32) | v;
+      for (int i = 0; i < nlog; ++i) if (Sw.pv_log[i] == key) return false;
+      return true;
+    });
+    *fresh = want;
+    bool exceeds = false;
+    for (int dq = 0; dq < nd; ++dq) {
+      const int32_t lim = Pv.node_pv_limit[(size_t)en * nd + dq];
+      if (lim < 0) continue;
+      int used = 0;
+      for (uint32_t b = n0; b < n1; b += 64) used += popc64(W::ballot([&](int l) { return b + l < n1 && Pv.pv_driver[Pv.node_pvs[b + l]] == dq; }));
+      for (int b = 0; b < nlog; b += 64) used += popc64(W::ballot([&](int l) { return b + l < nlog && (int)(Sw.pv_log[b + l] >> 32) == en && Pv.pv_driver[(uint32_t)Sw.pv_log[b + l]] == dq; }));
+      used += popc64(W::ballot([&](int l) { return ((want >> l) & 1) && Pv.pv_driver[Pv.pod_pvs[pf + l]] == dq; }));
+      exceeds = exceeds || used > lim;
+    }
+    return exceeds;
+  }
   KS_DEV bool add_to_existing(int k, int pod) {
     const int ne = P.n_nodes;
     if (ne == 0) return false;
@@ -1733,7 +1767,8 @@ struct Engine {
       int l = -1;
       bool changed = false;
       ReqBuf* fin = &sc.merged;
-      if (!cur_M && !cur_vol_n) {
+      uint64_t pv_fresh = 0;
+      if (!cur_M && !cur_vol_n && !cur_pv_n) {
         if (ok) l = ctz64(ok);
         if (l >= 0) changed = node_merge(base + l);
       } else {
@@ -1741,6 +1776,7 @@ struct Engine {
         // (existingnode.go:108-139, tryVolumeAlternative :143-168), lowest index first
         for (uint64_t cand = ok; cand; cand &= cand - 1) {
           const int cl_ = ctz64(cand);
+          if (cur_pv_n && node_exceeds_volume_limits(base + cl_, &pv_fresh)) continue;   // VolumeUsage.ExceedsLimits — existingnode.go:88
           const bool ch = node_merge(base + cl_);
           bool tch = false, vch = false, got = false;
           ctr.bin_evaluations++;
@@ -1756,7 +1792,7 @@ struct Engine {
               if (cur_M && !topo_apply(sc.merged.ref(), 1, base + cl_, false, &tch)) continue;
               got = true;
             }
-          } else got = topo_apply(sc.merged.ref(), 1, base + cl_, false, &tch);
+          } else got = !cur_M || topo_apply(sc.merged.ref(), 1, base + cl_, false, &tch);
           if (!got) continue;
           l = cl_; changed = ch || vch || tch;
           if (tch) fin = &sc.topo;
@@ -1805,6 +1841,15 @@ struct Engine {
       int64_t* nrem = S.n_remaining;
       W::for_n(nr, [&](int r) { nrem[(size_t)r * st + os] -= req[r]; });                  // resources.SubtractFrom — existingnode.go:175
       if (Pv.hp_on && cur_hp_use) W::store(&S.n_hp[os], (uint64_t)(S.n_hp[os] | cur_hp_use));   // existingnode.go:178
+      if (cur_pv_n && pv_fresh) {   // VolumeUsage.Add — existingnode.go:179: the pod's volumes that the node did not hold yet
+        const uint64_t fr = pv_fresh;
+        const int at = n_pv_log;
+        const uint32_t pf = cur_pv_first;
+        uint64_t* lg = S.pv_log;
+        W::each([&](int l) { if ((fr >> l) & 1) lg[at + popc64(fr & ((1ull << l) - 1))] = ((uint64_t)(uint32_t)en << 32) | Pv.pod_pvs[pf + l]; });
+        n_pv_log += popc64(fr);
+        W::sync();
+      }
       const uint32_t np_ = S.n_npods[os];
       W::store(&S.n_npods[os], np_ + 1);
       W::store(&S.assign[cur_out], (int32_t)(-2 - en));
@@ -2000,6 +2045,7 @@ struct Engine {
       W::for_n(T.words, [&](int w) { sc.t_active[w] = T.initially_active[w]; });
       W::for_n(T.n_alias, [&](int i) { Sw.tg_alias_active[i] = -1; });
     }
+    n_pv_log = 0;
     load_tables();
     if (FULL && P.reserved_on) W::for_n(P.n_resv, [&](int i) { sc.resv_cap[i] = P.resv_cap0[i]; });
     prefilter_templates();
@@ -2036,6 +2082,7 @@ struct Engine {
       int pod = (int)sc.blk_pod[blk_i];
       const int out = (int)sc.blk_out[blk_i];
       cur_out = out;
+      if (FULL && P.pv_on) { cur_pv_first = P.pod_pv_first[pod]; cur_pv_n = P.pod_pv_first[pod + 1] - cur_pv_first; }
       if (sc.blk_last[blk_i] == qlen) break;                                // queue.go:52-56
       if (S.max_steps >= 0 && steps >= S.max_steps) { status = 2; break; }
       int k0 = (int)sc.blk_class[blk_i];

@@ -526,6 +526,7 @@ static void be_launch_pack(ksolve_handle* h) {
   hip_check(h, hipGetLastError(), "ksolve_pack launch");
 }
 
+static int be_device_of(const ksolve_handle* h) { return HB(h)->device; }
 static void be_free(ksolve_handle* h, void* p) {
   if (!p) return;
   hip_check(h, hipStreamSynchronize(HB(h)->stream), "hipStreamSynchronize");
@@ -726,9 +727,17 @@ ksolve_status ksolve_sweep(ksolve_handle* base, const ksolve_sweep_desc* desc, k
 void ksolve_sweep_results_free(ksolve_sweep_results* r) { if (r && r->impl) { delete (ksi::SweepImpl*)r->impl; r->impl = nullptr; } }
 ksolve_status ksolve_solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) {
   if (!hs || !outs || n == 0) return KSOLVE_ERR_INVALID;
-  for (uint32_t i = 0; i < n; ++i) if (!hs[i] || !hs[i]->backend || HB(hs[i])->device != HB(hs[0])->device) return KSOLVE_ERR_INVALID;
+  for (uint32_t i = 0; i < n; ++i) if (!hs[i] || !hs[i]->backend) return KSOLVE_ERR_INVALID;
   if (hipSetDevice(HB(hs[0])->device) != hipSuccess) return KSOLVE_ERR_DEVICE;
   return ksi::solve_batch(hs, n, outs);
+}
+ksolve_status ksolve_packing_vector(const ksolve_handle* h, const ksolve_results* r, double* count, double* cost) {
+  if (!h || !r || !count || !cost) return KSOLVE_ERR_INVALID;
+  return ksi::packing_vector(h, r->claims, count, cost);
+}
+ksolve_status ksolve_packing_vector_sum(ksolve_handle* const* hs, const ksolve_results* rs, uint32_t n, double* count, double* cost) {
+  if (!hs || !rs || !count || !cost || n == 0) return KSOLVE_ERR_INVALID;
+  return ksi::packing_vector_sum(hs, rs, n, count, cost);
 }
 ksolve_status ksolve_cancel(ksolve_handle* h) {
   if (!h || !h->d_cancel) return KSOLVE_ERR_INVALID;

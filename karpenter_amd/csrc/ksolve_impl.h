@@ -79,6 +79,12 @@ struct ksolve_handle {
   bool prepared = false;                 // base: phases 1-3 have run and h_rank is valid
   std::vector<uint32_t> h_rank;          // base: queue position of every pod (queue.go:72-108 order)
   // a probe handle is its descriptor; ksolve_solve / ksolve_solve_batch run it through the sweep machinery (sweep_run)
+  std::vector<uint64_t> h_it_off_avail, h_value_is_int;
+  std::vector<double> h_it_off_price;
+  std::vector<int64_t> h_value_int;
+  int h_n_zones = 0, h_n_cts = 0;
+  uint32_t pv_entries = 0;               // volume entries of all pods (capacity of Workspace::pv_log)
+  std::vector<uint32_t> h_pod_pv_first;  // base: ProblemView::pod_pv_first on the host (a probe's log is sized by its own pods)
   std::vector<uint32_t> pr_nodes, pr_pods;
   std::vector<int64_t> pr_limits;
   // base: what every sweep shares — rejections of the pristine nodes per class, the consolidateAfter bitmap, the view in HBM,
@@ -112,6 +118,7 @@ static void be_launch_pack_batch(ksolve_handle** hs, int n);
 static void be_thread_init(ksolve_handle* h);   // makes the handle's device current on a worker thread   // one block per handle; sets every handle's T_PACK timer
 static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a);
 static int be_device_available();
+static int be_device_of(const ksolve_handle* h);     // the device ordinal the handle lives on
 static void be_free(ksolve_handle* h, void* p);   // releases one be_alloc'ed block before the handle goes
 static void be_launch_node_dead0(ksolve_handle* h, int n_blocks, const ks::NodeDeadArgs& a);   // one wavefront per 64 nodes
 static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, ks::Workspace* d_items, int n, const ks::LdsPlan& plan);   // block b = the general engine on probe b; sets T_PACK
@@ -230,6 +237,12 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   P.it_cap = up(h, d->it_capacity, (size_t)d->n_res * d->n_its);
   P.it_off_avail = up(h, d->it_offering_avail, d->n_its);
   P.it_off_price = up(h, d->it_offering_price, (size_t)d->n_its * 64);
+  // host copies for ksolve_packing_vector (the per-instance-type summary of a Results is computed where the Results are)
+  h->h_it_off_avail.assign(d->it_offering_avail, d->it_offering_avail + d->n_its);
+  h->h_it_off_price.assign(d->it_offering_price, d->it_offering_price + (size_t)d->n_its * 64);
+  h->h_value_int.assign(d->value_int, d->value_int + (size_t)req_words * 64);
+  h->h_value_is_int.assign(d->value_is_int, d->value_is_int + req_words);
+  h->h_n_zones = (int)d->n_zones; h->h_n_cts = (int)d->n_captypes;
   P.n_zones = d->n_zones; P.n_cts = d->n_captypes;
   P.n_xg = (int)d->n_override_groups; P.xg_it = nullptr; P.xg_alloc = nullptr; P.xg_avail = nullptr; P.it_base_avail = P.it_off_avail;
   for (int r = 0; r < 8; ++r) P.xg_bonus[r] = 0;
@@ -434,6 +447,31 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       P.node_flags = up(h, fl.data(), ne);
     }
     P.pod_from_deleting = d->pod_from_deleting_node ? up(h, d->pod_from_deleting_node, d->n_pods) : nullptr;
+    // CSI volume limits of existing nodes (VolumeUsage)
+    P.pv_on = 0; P.n_pv_drivers = 0;
+    if (d->n_volume_drivers && ne) {
+      if (d->n_volume_drivers > KSOLVE_MAX_VOLUME_DRIVERS) return fail(h, KSOLVE_ERR_UNSUPPORTED, "more than 8 CSI drivers with volume limits");
+      if (!d->volume_driver || !d->pod_pv_first || !d->pod_pvs || !d->node_pv_first || !d->node_pvs || !d->node_pv_limit) return fail(h, KSOLVE_ERR_INVALID, "volume limit tables missing");
+      for (uint32_t p = 0; p < d->n_pods; ++p) {
+        if (d->pod_pv_first[p + 1] < d->pod_pv_first[p] || d->pod_pv_first[p + 1] - d->pod_pv_first[p] > 64) return fail(h, KSOLVE_ERR_UNSUPPORTED, "a pod with more than 64 volumes under CSI limits");
+        for (uint32_t i = d->pod_pv_first[p]; i < d->pod_pv_first[p + 1]; ++i) if (d->pod_pvs[i] >= d->n_volumes) return fail(h, KSOLVE_ERR_INVALID, "pod volume id out of range");
+      }
+      for (uint32_t e = 0; e < ne; ++e) for (uint32_t i = d->node_pv_first[e]; i < d->node_pv_first[e + 1]; ++i) {
+        if (d->node_pvs[i] >= d->n_volumes) return fail(h, KSOLVE_ERR_INVALID, "node volume id out of range");
+        if (i > d->node_pv_first[e] && d->node_pvs[i] <= d->node_pvs[i - 1]) return fail(h, KSOLVE_ERR_INVALID, "node volume ids must ascend");
+      }
+      for (uint32_t v = 0; v < d->n_volumes; ++v) if (d->volume_driver[v] >= d->n_volume_drivers) return fail(h, KSOLVE_ERR_INVALID, "volume driver out of range");
+      P.pv_on = 1; P.n_pv_drivers = (int)d->n_volume_drivers;
+      P.pv_driver = up(h, d->volume_driver, d->n_volumes);
+      P.pod_pv_first = up(h, d->pod_pv_first, (size_t)d->n_pods + 1);
+      P.pod_pvs = up(h, d->pod_pvs, std::max<size_t>(1, d->pod_pv_first[d->n_pods]));
+      P.node_pv_first = up(h, d->node_pv_first, (size_t)ne + 1);
+      P.node_pvs = up(h, d->node_pvs, std::max<size_t>(1, d->node_pv_first[ne]));
+      P.node_pv_limit = up(h, d->node_pv_limit, (size_t)ne * d->n_volume_drivers);
+      h->ws.pv_log = dz<uint64_t>(h, std::max<size_t>(1, d->pod_pv_first[d->n_pods]));
+      h->pv_entries = d->pod_pv_first[d->n_pods];
+      h->h_pod_pv_first.assign(d->pod_pv_first, d->pod_pv_first + d->n_pods + 1);
+    }
   }
 
   ks::SortKeyArgs& S = h->sort_args;
@@ -1146,6 +1184,11 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
         W.n_remaining = (int64_t*)take((size_t)nr * oc * 8);
         W.n_npods = (uint32_t*)take((size_t)oc * 4);
         W.n_hp = P.hp_on ? (uint64_t*)take((size_t)oc * 8) : nullptr;
+        if (P.pv_on) {
+          size_t entries = 0;
+          for (uint32_t i = pod_off[p]; i < pod_off[p + 1]; ++i) entries += base->h_pod_pv_first[pods[i] + 1] - base->h_pod_pv_first[pods[i]];
+          W.pv_log = (uint64_t*)take(std::max<size_t>(1, entries) * 8);
+        }
       }
       W.ov_cap = (int)oc;
     }
@@ -1344,6 +1387,55 @@ static ksolve_status sweep(ksolve_handle* base, const ksolve_sweep_desc* d, ksol
   return KSOLVE_OK;
 }
 
+// ksolve_packing_vector: per instance type, the NodeClaims that launch on it and their $/h. A claim launches on the type that
+// gives its cheapest launch price — the cheapest available offering its requirements admit (OrderByPrice's key, types.go:336-355;
+// ties: the lower instance-type index) — and is booked there with that price (cheapest_price of the Results).
+static ksolve_status packing_vector(const ksolve_handle* h, const ksolve_claims& cl, double* count, double* cost) {
+  const ksolve_handle* b = h->base ? h->base : h;
+  const uint32_t n_its = b->n_its;
+  for (uint32_t i = 0; i < n_its; ++i) { count[i] = 0; cost[i] = 0; }
+  ks::Dict d = b->pv.dict;
+  d.value_int = b->h_value_int.data(); d.value_is_int = b->h_value_is_int.data(); d.value_valid = nullptr;
+  const int nk = (int)b->n_keys;
+  for (uint32_t c = 0; c < cl.n_claims; ++c) {
+    ks::ReqRef r;
+    r.mask = cl.req_mask + (size_t)c * cl.req_words; r.defined = cl.req_defined[c]; r.complement = cl.req_complement[c];
+    r.has_gte = cl.req_has_gte[c]; r.has_lte = cl.req_has_lte[c]; r.gte = cl.req_gte + (size_t)c * nk; r.lte = cl.req_lte + (size_t)c * nk; r.minv = nullptr;
+    uint32_t zones = 0, cts = 0;
+    if (d.key_zone >= 0 && ks::bit(r.defined, d.key_zone)) { for (int z = 0; z < b->h_n_zones; ++z) if (ks::req_has(d, r, d.key_zone, d.key_word_off[d.key_zone], z)) zones |= 1u << z; }
+    else zones = (1u << b->h_n_zones) - 1;
+    if (d.key_ct >= 0 && ks::bit(r.defined, d.key_ct)) { for (int t = 0; t < b->h_n_cts; ++t) if (ks::req_has(d, r, d.key_ct, d.key_word_off[d.key_ct], t)) cts |= 1u << t; }
+    else cts = (1u << b->h_n_cts) - 1;
+    uint64_t cells = 0;
+    for (uint32_t zz = zones; zz; zz &= zz - 1) cells |= (uint64_t)cts << (__builtin_ctz(zz) * 4);
+    double best = 1.7976931348623157e308;
+    int best_it = -1;
+    for (uint32_t it = 0; it < n_its; ++it) {
+      if (!((cl.it_mask[(size_t)c * cl.it_words + it / 64] >> (it % 64)) & 1)) continue;
+      for (uint64_t av = b->h_it_off_avail[it] & cells; av; av &= av - 1) {
+        const double p = b->h_it_off_price[(size_t)it * 64 + __builtin_ctzll(av)];
+        if (p < best) { best = p; best_it = (int)it; }
+      }
+    }
+    if (best_it < 0) continue;   // nothing launchable (reserved-only claims keep their price in cheapest_price; not booked per type)
+    count[best_it] += 1;
+    cost[best_it] += cl.cheapest_price[c] < 1e300 ? cl.cheapest_price[c] : best;
+  }
+  return KSOLVE_OK;
+}
+
+static ksolve_status packing_vector_sum(ksolve_handle* const* hs, const ksolve_results* rs, uint32_t n, double* count, double* cost) {
+  const uint32_t n_its = (hs[0]->base ? hs[0]->base : hs[0])->n_its;
+  std::vector<double> c(n_its), d(n_its);
+  for (uint32_t i = 0; i < n_its; ++i) { count[i] = 0; cost[i] = 0; }
+  for (uint32_t p = 0; p < n; ++p) {
+    if ((hs[p]->base ? hs[p]->base : hs[p])->n_its != n_its) return fail(hs[0], KSOLVE_ERR_INVALID, "packing vectors of different catalogue sizes");
+    packing_vector(hs[p], rs[p].claims, c.data(), d.data());
+    for (uint32_t i = 0; i < n_its; ++i) { count[i] += c[i]; cost[i] += d[i]; }
+  }
+  return KSOLVE_OK;
+}
+
 // ksolve_results of ONE probe handle from its slice of a sweep: the contract of ksolve_probe_create — the base problem's pod
 // numbering, pods outside the probe unassigned
 static ksolve_status probe_results(ksolve_handle* h, const SweepImpl& S, uint32_t p, uint32_t pod_base, ksolve_results* out) {
@@ -1529,8 +1621,31 @@ static ksolve_status solve_batch_plain(ksolve_handle** hs, uint32_t n, ksolve_re
   return worst;
 }
 
-// ksolve_solve_batch: probes of a resident cluster run as one sweep per base handle, everything else as above
+static ksolve_status solve_batch_one_device(ksolve_handle** hs, uint32_t n, ksolve_results* outs);
+// ksolve_solve_batch: the handles' devices side by side (one host thread each), one batch per device
 static ksolve_status solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) {
+  std::vector<int> devices;
+  for (uint32_t i = 0; i < n; ++i) { const int dv = be_device_of(hs[i]); if (std::find(devices.begin(), devices.end(), dv) == devices.end()) devices.push_back(dv); }
+  if (devices.size() <= 1) return solve_batch_one_device(hs, n, outs);
+  std::vector<ksolve_status> rc(devices.size(), KSOLVE_OK);
+  std::vector<std::thread> pool;
+  for (size_t g = 0; g < devices.size(); ++g) pool.emplace_back([&, g]() {
+    std::vector<uint32_t> idx;
+    std::vector<ksolve_handle*> grp;
+    for (uint32_t i = 0; i < n; ++i) if (be_device_of(hs[i]) == devices[g]) { idx.push_back(i); grp.push_back(hs[i]); }
+    be_thread_init(grp[0]);
+    std::vector<ksolve_results> ro(grp.size());
+    rc[g] = solve_batch_one_device(grp.data(), (uint32_t)grp.size(), ro.data());
+    for (size_t k = 0; k < grp.size(); ++k) outs[idx[k]] = ro[k];
+  });
+  for (auto& th : pool) th.join();
+  ksolve_status worst = KSOLVE_OK;
+  for (auto r : rc) if (r != KSOLVE_OK) worst = r;
+  return worst;
+}
+
+// one device: probes of a resident cluster run as one sweep per base handle, everything else as above
+static ksolve_status solve_batch_one_device(ksolve_handle** hs, uint32_t n, ksolve_results* outs) {
   std::vector<uint32_t> plain_idx;
   std::vector<ksolve_handle*> bases;
   for (uint32_t i = 0; i < n; ++i) {

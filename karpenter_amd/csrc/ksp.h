@@ -197,6 +197,14 @@ struct ProblemView {
   const uint64_t* node_taints;   // [n_nodes]
   const uint8_t* node_flags;     // [n_nodes] bit0 initialized, bit1 under consolidateAfter
   const uint8_t* pod_from_deleting; // [n_pods]
+  // CSI volume limits of existing nodes (VolumeUsage, volumeusage.go:178-209): volume = a distinct <driver, PVC> pair
+  int pv_on, n_pv_drivers;       // pv_on: some node has a limit
+  const uint8_t* pv_driver;      // [n_volumes]
+  const uint32_t* pod_pv_first;  // [n_pods+1] CSR into pod_pvs
+  const uint32_t* pod_pvs;
+  const uint32_t* node_pv_first; // [n_nodes+1] CSR into node_pvs (ascending ids): the volumes in use before the solve
+  const uint32_t* node_pvs;
+  const int32_t* node_pv_limit;  // [n_nodes][n_pv_drivers], -1 = none
   // resident-cluster probes (ksolve_sweep, ksolve_probe_create): computed once per base handle, shared by every probe
   const uint64_t* n_dead0;       // [n_classes][node_words] class k cannot go on the PRISTINE node e for a reason that precedes topology (ksolve_node_dead0)
   const uint64_t* node_skip;     // [node_words] the nodes under consolidateAfter (node_flags bit1) as a bitmap
@@ -247,6 +255,7 @@ struct Workspace {
   int64_t* n_remaining;          // [n_res][n_nodes]
   uint32_t* n_npods;             // [n_nodes]
   uint64_t* n_dead;              // [n_classes][node_words] node known infeasible for the class
+  uint64_t* pv_log;              // [pods' volume entries] node << 32 | volume: what the pods placed on existing nodes in this solve added (VolumeUsage.Add)
   // pristine copies restored at the start of every solve
   const uint64_t* n_mask0; const uint32_t *n_defined0, *n_complement0; const int64_t* n_remaining0;
   // topology group state (TopologyGroup.domains / emptyDomains, topologygroup.go:74-76)

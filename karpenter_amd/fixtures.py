@@ -207,7 +207,7 @@ _uid_counter = [0]
 def pod(uid=None, name=None, namespace="default", labels=None, requests=None, node_selector=None, node_requirements=None,
         node_preferences=None, tolerations=None, topology_spread=None, pod_requirements=None, pod_preferences=None,
         pod_anti_requirements=None, pod_anti_preferences=None, creation=0, phase="Pending", node_name="", host_ports=None,
-        volume_requirements=None):
+        volume_requirements=None, volumes=None):
     """test.Pod — pkg/test/pods.go:88. node_requirements: list of NodeSelectorRequirement (one term) or list of terms.
     host_ports: port numbers (PodOptions.HostPorts: TCP, no hostIP) or {"port", "ip", "protocol"} dicts.
     volume_requirements: volumeReqsByPod[uid] (scheduler.go:138) — a list of alternatives, each a list of requirements."""
@@ -220,6 +220,8 @@ def pod(uid=None, name=None, namespace="default", labels=None, requests=None, no
         p["nodeSelector"] = dict(node_selector)
     if volume_requirements:
         p["volumeRequirements"] = [list(alt) for alt in volume_requirements]
+    if volumes:   # scheduling.GetVolumes(pod) (volumeusage.go:83-114): (CSI driver, namespace/name of the PVC) per tracked volume
+        p["volumes"] = [{"driver": d, "pvc": c} for d, c in volumes]
     if host_ports:
         p["hostPorts"] = [host_port(h) if not isinstance(h, dict) else host_port(**h) for h in host_ports]
     if node_requirements or node_preferences:
@@ -307,7 +309,7 @@ def state_node_taints(taints, startup_taints=None, initialized=True, managed=Tru
 
 
 def state_node(name, instance_type, zone, capacity_type="on-demand", nodepool="default", used=None, taints=None, initialized=True,
-               extra_labels=None, under_consolidate_after=False, startup_taints=None, host_ports=None):
+               extra_labels=None, under_consolidate_after=False, startup_taints=None, host_ports=None, volumes=None, volume_limits=None):
     """A state.StateNode as the scheduler reads it (existingnode.go:47-75): labels of a node launched from `instance_type`
     in `zone` (single-valued instance-type requirements become labels, like the fake/KWOK providers do on Create),
     Available() = allocatable - used, Capacity() incl. nodes: 1 (statenode.go:370-374)."""
@@ -331,6 +333,8 @@ def state_node(name, instance_type, zone, capacity_type="on-demand", nodepool="d
     cap = dict(instance_type["capacity"]); cap["nodes"] = "1"
     node = {"name": name, "labels": labels, "taints": state_node_taints(taints, startup_taints, initialized, managed=True),
             "available": avail, "capacity": cap, "initialized": initialized, "managed": True, "underConsolidateAfter": under_consolidate_after}
+    if volumes or volume_limits:   # StateNode.VolumeUsage() (statenode.go:411,466-490): volumes of the bound pods, the CSINode's attach limits
+        node["volumeUsage"] = {"volumes": [{"driver": d, "pvc": c} for d, c in (volumes or [])], "limits": dict(volume_limits or {})}
     if host_ports:   # StateNode.HostPortUsage(): host ports of the pods bound to the node (statenode.go:489)
         node["hostPorts"] = [host_port(h) if not isinstance(h, dict) else host_port(**h) for h in host_ports]
     return node

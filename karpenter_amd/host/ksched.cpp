@@ -386,6 +386,7 @@ struct PodSpec {
   std::vector<std::pair<int, std::vector<Expr>>> preferred;  // (weight, exprs)
   std::vector<Toleration> tolerations;
   std::vector<std::vector<Expr>> volume_requirements;        // volumeReqsByPod[uid] (scheduler.go:138, :572): alternatives, in order
+  std::vector<std::pair<std::string, std::string>> volumes;   // scheduling.GetVolumes(pod) (volumeusage.go:83-114): <CSI driver, PVC>
 };
 
 // Go's insertion sort (sort.Slice on <= 12 elements is a stable insertion sort; pods with more than 12 preferred
@@ -524,6 +525,7 @@ static PodSpec parse_pod(const Value& v) {
   p.requests = parse_resources(v.at("requests"));
   p.node_selector = v.at("nodeSelector");
   for (auto& alt : v.at("volumeRequirements").items()) p.volume_requirements.push_back(parse_exprs(alt));
+  for (auto& vv : v.at("volumes").items()) p.volumes.push_back({vv.at("driver").s(), vv.at("pvc").s()});
   const Value& na = v.at("nodeAffinity");
   if (!na.is_null()) {
     p.has_node_affinity = true;
@@ -1309,6 +1311,64 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       pod_vol_first.assign(n_rows, 0); pod_vol_count.assign(n_rows, 0);
     }
     ReqTableBuilder vol_reqs;
+    // ---- CSI volume limits of existing nodes (VolumeUsage, volumeusage.go:178-209; existingnode.go:88, :179) ----
+    // Only drivers that have a limit on some node can ever reject a pod; volumes of other drivers are dropped here.
+    std::vector<std::string> pv_drivers;
+    std::vector<uint8_t> volume_driver;
+    std::vector<uint32_t> pod_pv_first, pod_pvs, node_pv_first, node_pvs;
+    std::vector<int32_t> node_pv_limit;
+    {
+      std::map<std::string, int> drv;
+      for (int e = 0; e < n_nodes; ++e)
+        for (auto& kv : nodes[e].v->at("volumeUsage").at("limits").members()) if (!drv.count(kv.first)) { const int id = (int)drv.size(); drv[kv.first] = id; pv_drivers.push_back(kv.first); }
+      if (pv_drivers.size() > KSOLVE_MAX_VOLUME_DRIVERS) throw Unsupported("more than 8 CSI drivers with volume limits");
+      if (!pv_drivers.empty()) {
+        const int nd = (int)pv_drivers.size();
+        std::map<std::pair<int, std::string>, uint32_t> vol_id;
+        auto vid = [&](const std::string& d, const std::string& c) -> int64_t {
+          auto f = drv.find(d);
+          if (f == drv.end()) return -1;
+          auto key = std::make_pair(f->second, c);
+          auto g = vol_id.find(key);
+          if (g != vol_id.end()) return g->second;
+          const uint32_t id = (uint32_t)vol_id.size();
+          vol_id[key] = id; volume_driver.push_back((uint8_t)f->second);
+          return id;
+        };
+        std::vector<std::vector<uint32_t>> spec_pvs(specs.size());
+        for (size_t si = 0; si < specs.size(); ++si) {
+          for (auto& dv : specs[si].volumes) { const int64_t id = vid(dv.first, dv.second); if (id >= 0) spec_pvs[si].push_back((uint32_t)id); }
+          std::sort(spec_pvs[si].begin(), spec_pvs[si].end());
+          spec_pvs[si].erase(std::unique(spec_pvs[si].begin(), spec_pvs[si].end()), spec_pvs[si].end());
+        }
+        pod_pv_first.assign((size_t)n_pods + 1, 0);
+        for (int p = 0; p < n_pods; ++p) { pod_pv_first[p] = (uint32_t)pod_pvs.size(); pod_pvs.insert(pod_pvs.end(), spec_pvs[pod_spec[p]].begin(), spec_pvs[pod_spec[p]].end()); }
+        pod_pv_first[n_pods] = (uint32_t)pod_pvs.size();
+        node_pv_first.assign((size_t)n_nodes + 1, 0);
+        node_pv_limit.assign((size_t)n_nodes * nd, -1);
+        for (int e = 0; e < n_nodes; ++e) {
+          node_pv_first[e] = (uint32_t)node_pvs.size();
+          std::vector<uint32_t> ids;
+          for (auto& vv : nodes[e].v->at("volumeUsage").at("volumes").items()) { const int64_t id = vid(vv.at("driver").s(), vv.at("pvc").s()); if (id >= 0) ids.push_back((uint32_t)id); }
+          std::sort(ids.begin(), ids.end());
+          ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+          node_pvs.insert(node_pvs.end(), ids.begin(), ids.end());
+          std::vector<int> used(nd, 0);
+          for (uint32_t id : ids) used[volume_driver[id]]++;
+          bool over = false;
+          for (auto& kv : nodes[e].v->at("volumeUsage").at("limits").members()) {
+            const int dq = drv.at(kv.first);
+            node_pv_limit[(size_t)e * nd + dq] = (int32_t)kv.second.i();
+            if (used[dq] > kv.second.i()) over = true;
+          }
+          // already over a limit: ExceedsLimits fails for every pod, with or without volumes (it walks the union's drivers)
+          if (over) node_remaining[(size_t)0 * n_nodes + e] = -1;
+        }
+        node_pv_first[n_nodes] = (uint32_t)node_pvs.size();
+        if (pod_pvs.empty()) pod_pvs.push_back(0);
+        if (node_pvs.empty()) node_pvs.push_back(0);
+      }
+    }
     vol_reqs.init((int)vol_sets.size(), rw, nk);
     for (size_t i = 0; i < vol_sets.size(); ++i) vol_reqs.put((int)i, vol_sets[i]);
     for (int p = 0; p < n_pods; ++p) {
@@ -1709,6 +1769,11 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       if (!deleting.empty()) for (int p = 0; p < n_pods; ++p) if (deleting.count(specs[pod_spec[p]].node_name)) pod_from_deleting[p] = 1;
     }
     d.pod_from_deleting_node = pod_from_deleting.data();
+    if (!pv_drivers.empty()) {
+      d.n_volume_drivers = (uint32_t)pv_drivers.size(); d.n_volumes = (uint32_t)volume_driver.size(); d.volume_driver = volume_driver.data();
+      d.pod_pv_first = pod_pv_first.data(); d.pod_pvs = pod_pvs.data(); d.node_pv_first = node_pv_first.data(); d.node_pvs = node_pvs.data();
+      d.node_pv_limit = node_pv_limit.data();
+    }
     if (G) {
       ksolve_topology& t = d.topo;
       t.n = (uint32_t)G; t.type = tg_type.data(); t.inverse = tg_inverse.data(); t.initially_active = tg_initial.data(); t.key = tg_key.data();
@@ -2099,6 +2164,18 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
     out.set("timings", timings);
     out.set("timedOut", Value::boolean(st == KSOLVE_ERR_CANCELLED));
     out.set("packingCost", Value::number(res.packing_cost));
+    {
+      // the per-instance-type (NodeClaim count, $/h) vector of this packing (ksolve_packing_vector): sparse, [type, count, cost]
+      auto pvec = (decltype(&ksolve_packing_vector))dlsym(api.lib, "ksolve_packing_vector");
+      if (pvec && st == KSOLVE_OK) {
+        std::vector<double> cnt(n_its), cst(n_its);
+        if (pvec(handle, &res, cnt.data(), cst.data()) == KSOLVE_OK) {
+          Value pv = Value::array();
+          for (int i = 0; i < n_its; ++i) if (cnt[i] > 0) { Value e = Value::array(); e.push(Value::integer(i)); e.push(Value::number(cnt[i])); e.push(Value::number(cst[i])); pv.push(e); }
+          out.set("packingVector", pv);
+        }
+      }
+    }
     int unscheduled = 0;
     for (int p = 0; p < n_pods; ++p) if (in_probe(p) && res.pod_assignment[p] == -1) unscheduled++;
     { int64_t there = 0; for (size_t e = 0; e < S->node_names.size(); ++e) if (node_there(e)) there++; counters.set("existingNodes", Value::integer(there)); }

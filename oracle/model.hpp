@@ -99,6 +99,9 @@ struct Pod {
   // volumeReqsByPod[pod.UID] (scheduler.go:138, :572): the alternatives VolumeTopology.GetRequirements derived from the pod's
   // volumes, one requirement set per valid combination of volume topologies; empty = no volume constraint
   std::vector<std::vector<NodeSelectorExpr>> volume_requirements;
+  // scheduling.GetVolumes(pod) (volumeusage.go:83-114, scheduler.go:622-626): CSI driver -> the PVCs the pod mounts through it;
+  // resolved from PVC / PV / StorageClass objects upstream of Solve()
+  std::map<std::string, std::set<std::string>> volumes;
 };
 
 struct Offering {
@@ -193,6 +196,10 @@ struct StateNode {
   std::vector<HostPort> host_ports;   // StateNode.HostPortUsage(): ports of the pods bound to the node (statenode.go:407,489)
   bool initialized = true, managed = true, has_node = true, marked_for_deletion = false;
   bool under_consolidate_after = false;  // disruption.IsUnderConsolidateAfter, evaluated upstream
+  // StateNode.VolumeUsage() (statenode.go:411; volumeusage.go:178-189): the volumes of the pods bound to the node per CSI driver,
+  // and the CSINode's per-driver attach limits
+  std::map<std::string, std::set<std::string>> volumes;
+  std::map<std::string, int> volume_limits;
 };
 
 // pods already bound in the cluster (topology.go:361-459 countDomains, :310-324 inverse anti-affinities)
@@ -311,6 +318,7 @@ inline Pod parse_pod(const oj::Value& v, int idx) {
     for (auto& e : alt.items()) exprs.push_back(parse_expr(e));
     p.volume_requirements.push_back(exprs);
   }
+  for (auto& vv : v.at("volumes").items()) p.volumes[vv.at("driver").s()].insert(vv.at("pvc").s());
   const oj::Value& na = v.at("nodeAffinity");
   if (!na.is_null()) {
     p.has_node_affinity = true;
@@ -455,6 +463,8 @@ inline Problem parse_problem(const oj::Value& root) {
     n.has_node = v.at("hasNode").boolean_or(true);
     n.marked_for_deletion = v.at("markedForDeletion").boolean_or(false);
     n.under_consolidate_after = v.at("underConsolidateAfter").boolean_or(false);
+    for (auto& vv : v.at("volumeUsage").at("volumes").items()) n.volumes[vv.at("driver").s()].insert(vv.at("pvc").s());
+    for (auto& kv : v.at("volumeUsage").at("limits").members()) n.volume_limits[kv.first] = (int)kv.second.i();
     pr.state_nodes.push_back(n);
   }
   for (auto& n : root.at("deletingNodeNames").items()) pr.deleting_node_names.insert(n.s());

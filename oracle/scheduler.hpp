@@ -5,6 +5,11 @@
 // Single-threaded: parallelizeUntil (scheduler.go:939-961) only fans out candidate checks and always keeps the
 // lowest index (:639,:674,:759), so a sequential first-success scan is equivalent.
 #pragma once
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include "topology.hpp"
 
 namespace oracle {
@@ -235,6 +240,7 @@ struct ExistingNode {
   ResourceList remaining;
   Requirements reqs;
   std::vector<HostPort> host_ports;   // StateNode.HostPortUsage() + the pods added in this Solve (existingnode.go:178)
+  std::map<std::string, std::set<std::string>> volumes;   // StateNode.VolumeUsage().volumes + the pods added in this Solve (existingnode.go:179)
   bool under_consolidate_after = false;
 };
 
@@ -263,6 +269,14 @@ struct Scheduler {
   long long node_id = 0;  // hostname-placeholder counter (nodeclaim.go:83,93); per-solve in the oracle
   Counters ctr;
   int last_err = 0, last_diag = 0;
+  struct EvalCtx { Counters ctr; int err = 0, diag = 0; };
+  // parallelizeUntil (scheduler.go:939-961): the reference evaluates the candidates of addToInflightNode on a worker pool and
+  // keeps the lowest index that succeeds (:667-686). `threads` > 1 does the same here — same winner, same counters as the
+  // sequential scan (every claim up to the winner is counted once); used for the offline pins of the largest configurations.
+  int threads = 1;
+  size_t parallel_min = 512;          // scans shorter than this stay sequential
+  struct Pool;
+  std::shared_ptr<Pool> pool;
 
   // ---- pod requirement derivation: requirements.go:74-118 --------------------------------------------------
   static Requirements pod_requirements(Pod& p, bool required_only) {
@@ -438,6 +452,7 @@ struct Scheduler {
       auto en = std::make_unique<ExistingNode>();
       en->node = &n;
       en->host_ports = n.host_ports;
+      en->volumes = n.volumes;
       // daemons compatible with the node (scheduler.go:805-832) minus what already runs there (existingnode.go:50-60)
       ResourceList daemon;
       int ndaemons = 0;
@@ -476,6 +491,21 @@ struct Scheduler {
   bool existing_can_add(ExistingNode& n, const Pod& pod, const PodData& pd, Requirements& out) {
     ctr.bin_evaluations++;
     if (!taints_tolerated(n.node->taints, pod.tolerations)) { last_err = ERR_TAINTS; return false; }
+    // VolumeUsage.ExceedsLimits (volumeusage.go:193-200; existingnode.go:88): over the UNION of the node's and the pod's volumes,
+    // every driver with a limit — also one the pod adds nothing to
+    for (auto& kv : n.volumes) {
+      auto lim = n.node->volume_limits.find(kv.first);
+      if (lim == n.node->volume_limits.end()) continue;
+      std::set<std::string> u = kv.second;
+      auto pv = pod.volumes.find(kv.first);
+      if (pv != pod.volumes.end()) u.insert(pv->second.begin(), pv->second.end());
+      if ((int)u.size() > lim->second) { last_err = ERR_EXISTING; return false; }
+    }
+    for (auto& kv : pod.volumes) {
+      if (n.volumes.count(kv.first)) continue;
+      auto lim = n.node->volume_limits.find(kv.first);
+      if (lim != n.node->volume_limits.end() && (int)kv.second.size() > lim->second) { last_err = ERR_EXISTING; return false; }
+    }
     if (host_ports_conflict(pod.host_ports, n.host_ports)) { last_err = ERR_EXISTING; return false; }   // existingnode.go:87-93
     if (!res_fits(pd.requests, n.remaining)) { last_err = ERR_RESOURCES; return false; }
     if (!n.reqs.compatible(pd.reqs, false)) { last_err = ERR_INCOMPATIBLE; return false; }
@@ -504,6 +534,7 @@ struct Scheduler {
     res_subtract_from(n.remaining, pd.requests);
     n.reqs = reqs;
     n.host_ports.insert(n.host_ports.end(), pod->host_ports.begin(), pod->host_ports.end());   // existingnode.go:178
+    for (auto& kv : pod->volumes) n.volumes[kv.first].insert(kv.second.begin(), kv.second.end());  // VolumeUsage.Add — existingnode.go:179, volumeusage.go:206-209
     topology.record(*pod, n.node->taints, reqs);
   }
 
@@ -539,7 +570,11 @@ struct Scheduler {
   }
   // CanAdd — nodeclaim.go:124-242
   bool claim_can_add(NodeClaim& n, const Pod& pod, const PodData& pd, bool relax_min_values, Requirements& out_reqs,
-                     std::vector<const InstanceType*>& out_its, std::vector<const Offering*>& out_ofs) {
+                     std::vector<const InstanceType*>& out_its, std::vector<const Offering*>& out_ofs, EvalCtx* cx = nullptr) {
+    // cx: the counters and error slots of a worker of the parallel in-flight scan (add_to_inflight); none: the scheduler's own
+    Counters& ctr = cx ? cx->ctr : this->ctr;
+    int& last_err = cx ? cx->err : this->last_err;
+    int& last_diag = cx ? cx->diag : this->last_diag;
     ctr.bin_evaluations++;
     last_diag = 0;
     if (!taints_tolerated(n.tmpl->taints, pod.tolerations)) { last_err = ERR_TAINTS; return false; }
@@ -669,12 +704,15 @@ struct Scheduler {
   }
   bool add_to_inflight(Pod& pod, Pod* queue_pod) {
     const PodData& pd = cached[pod.uid];
+    if (threads > 1 && new_node_claims.size() >= parallel_min) return add_to_inflight_parallel(pod, queue_pod, pd);
     for (auto* nc : new_node_claims) {
       Requirements r; std::vector<const InstanceType*> its; std::vector<const Offering*> ofs;
       if (claim_can_add(*nc, pod, pd, false, r, its, ofs)) { claim_add(*nc, queue_pod, pd, r, its, ofs); return true; }
     }
     return false;
   }
+
+  bool add_to_inflight_parallel(Pod& pod, Pod* queue_pod, const PodData& pd);
 
   // trySchedule — scheduler.go:521-552 (p is the DeepCopy)
   bool try_schedule(Pod& copy, Pod* queue_pod) {
@@ -759,5 +797,72 @@ struct Scheduler {
     return res;
   }
 };
+
+
+// A persistent worker pool for the parallel in-flight scan: one job at a time, the caller takes part. The workers spin on the
+// generation counter between jobs (a job arrives with every pod; a condition variable's wake-up costs more than a scan).
+struct Scheduler::Pool {
+  std::vector<std::thread> workers;
+  const std::function<void(int)>* job = nullptr;
+  std::atomic<long long> generation{0};
+  std::atomic<int> pending{0};
+  std::atomic<bool> stop{false};
+  explicit Pool(int n) {
+    for (int t = 1; t < n; ++t) workers.emplace_back([this, t]() {
+      long long seen = 0;
+      for (;;) {
+        int spins = 0;
+        while (generation.load(std::memory_order_acquire) == seen) {
+          if (stop.load(std::memory_order_relaxed)) return;
+          if (++spins > 20000) { std::this_thread::yield(); spins = 0; }
+        }
+        seen = generation.load(std::memory_order_acquire);
+        (*job)(t);
+        pending.fetch_sub(1, std::memory_order_acq_rel);
+      }
+    });
+  }
+  ~Pool() { stop = true; for (auto& w : workers) w.join(); }
+  void run(const std::function<void(int)>& f) {
+    job = &f;
+    pending.store((int)workers.size(), std::memory_order_release);
+    generation.fetch_add(1, std::memory_order_acq_rel);
+    f(0);
+    while (pending.load(std::memory_order_acquire) != 0) {}
+  }
+};
+
+inline bool Scheduler::add_to_inflight_parallel(Pod& pod, Pod* queue_pod, const PodData& pd) {
+  if (!pool) pool = std::make_shared<Pool>(threads);
+  const size_t n = new_node_claims.size();
+  std::atomic<size_t> best(n), next(0);
+  std::vector<unsigned long long> it_evals(n, 0);
+  const size_t chunk = 8;
+  pool->run([&](int) {
+    for (;;) {
+      const size_t i0 = next.fetch_add(chunk);
+      if (i0 >= n || i0 > best.load()) return;
+      for (size_t j = i0; j < std::min(n, i0 + chunk); ++j) {
+        if (j > best.load()) return;
+        EvalCtx cx;
+        Requirements r; std::vector<const InstanceType*> its; std::vector<const Offering*> ofs;
+        const bool ok = claim_can_add(*new_node_claims[j], pod, pd, false, r, its, ofs, &cx);
+        it_evals[j] = (unsigned long long)cx.ctr.it_evaluations;
+        if (ok) { size_t cur = best.load(); while (j < cur && !best.compare_exchange_weak(cur, j)) {} }
+      }
+    }
+  });
+  const size_t w = best.load();
+  // the sequential scan's counters: every claim up to the winner once
+  const size_t counted = w < n ? w : n;
+  ctr.bin_evaluations += (long long)counted;
+  for (size_t j = 0; j < counted; ++j) ctr.it_evaluations += (long long)it_evals[j];
+  if (w == n) return false;
+  Requirements r; std::vector<const InstanceType*> its; std::vector<const Offering*> ofs;
+  const bool ok = claim_can_add(*new_node_claims[w], pod, pd, false, r, its, ofs);   // the winner again, for its outputs (counts itself)
+  if (!ok) throw std::runtime_error("parallel in-flight scan: the winner does not reproduce");
+  claim_add(*new_node_claims[w], queue_pod, pd, r, its, ofs);
+  return true;
+}
 
 }  // namespace oracle

@@ -115,6 +115,7 @@ static void be_launch_pack_batch(ksolve_handle** hs, int n) {
   for (int i = 0; i < n; ++i) { be_tic(hs[i], ksi::T_PACK); be_launch_pack(hs[i]); be_toc(hs[i], ksi::T_PACK); }
 }
 static int be_device_available() { return 1; }
+static int be_device_of(const ksolve_handle* h) { return (int)h->opts.device; }   // the emulation has as many "devices" as the options name
 static void be_free(ksolve_handle* h, void* p) {
   auto it = std::find(h->allocations.begin(), h->allocations.end(), p);
   if (it != h->allocations.end()) h->allocations.erase(it);
@@ -152,6 +153,8 @@ ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out) { return ksi::
 ksolve_status ksolve_sweep(ksolve_handle* base, const ksolve_sweep_desc* desc, ksolve_sweep_results* out) { return ksi::sweep(base, desc, out); }
 void ksolve_sweep_results_free(ksolve_sweep_results* r) { if (r && r->impl) { delete (ksi::SweepImpl*)r->impl; r->impl = nullptr; } }
 ksolve_status ksolve_solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) { return ksi::solve_batch(hs, n, outs); }
+ksolve_status ksolve_packing_vector(const ksolve_handle* h, const ksolve_results* r, double* count, double* cost) { return ksi::packing_vector(h, r->claims, count, cost); }
+ksolve_status ksolve_packing_vector_sum(ksolve_handle* const* hs, const ksolve_results* rs, uint32_t n, double* count, double* cost) { return ksi::packing_vector_sum(hs, rs, n, count, cost); }
 ksolve_status ksolve_cancel(ksolve_handle* h) { if (h->d_cancel) __atomic_store_n(h->d_cancel, 1, __ATOMIC_RELAXED); return KSOLVE_OK; }
 void ksolve_results_free(ksolve_results* r) { if (r && r->impl) { delete (ksi::ResultsImpl*)r->impl; r->impl = nullptr; } }
 void ksolve_destroy(ksolve_handle* h) {

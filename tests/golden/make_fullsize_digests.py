@@ -5,6 +5,7 @@ The `-m gpu` tests and bench.py then solve the same seeded problem on the device
 in-benchmark gate (scheduling_benchmark_test.go:176-181) made bit-exact.
 
   python tests/golden/make_fullsize_digests.py config2 1000000 500 42      # ~2 h on one core (O(pods x claims))
+  ORACLE_THREADS=128 python tests/golden/make_fullsize_digests.py config3 500000 500 42   # candidate fan-out like parallelizeUntil
 
 The oracle is O(pods x claims); the device is checked against it, never the other way round.
 """
@@ -49,10 +50,12 @@ def main():
     out = {"config": name, "pods": pods, "types": types, "seed": seed, "extra": extra,
            "digest": digest, "claims": len(res["newNodeClaims"]), "podErrors": len(res["podErrors"]),
            "binEvaluations": res["counters"]["binEvaluations"], "packingCost": float(res["packingCost"]).hex(),
-           "packingCostApprox": res["packingCost"], "oracleSeconds": round(dt, 1),
+           "packingCostApprox": res["packingCost"], "oracleSeconds": round(dt, 1), "oracleThreads": int(os.environ.get("ORACLE_THREADS", "1")),
            "claimPods": [len(c["pods"]) for c in res["newNodeClaims"]],
            "claimFingerprints": [f[:12] for f in fps]}
-    path = os.path.join(HERE, "fullsize", pin_name(name, pods, types, seed, extra) + ".json")
+    # PIN_OUT_DIR: where the pin goes when it is made on another machine (the 256-core GPU box: ORACLE_THREADS=128 and the
+    # candidate fan-out of the in-flight scan, oracle/scheduler.hpp add_to_inflight_parallel); copied to fullsize/ afterwards
+    path = os.path.join(os.environ.get("PIN_OUT_DIR") or os.path.join(HERE, "fullsize"), pin_name(name, pods, types, seed, extra) + ".json")
     with open(path, "w") as f:
         json.dump(out, f)
     print(path, digest, out["claims"], dt)

@@ -32,8 +32,8 @@ def _env():
 def test_single_rank_line(oracle):
     emu = parity.build_emu()
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--pods", "3000", "--types", "60", "--cpu-sample", "1500", "--cpu-runs", "3",
-           "--topology-pods", "400", "--components-pods", "4000", "--components-types", "60", "--components-calibration-pods", "4000", "--batch-problems", "3", "--batch-pods", "400", "--solver-lib", emu]
-    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+           "--topology-pods", "400", "--components-pods", "4000", "--components-types", "60", "--components-calibration-pods", "4000", "--batch-problems", "3", "--batch-pods", "400", "--sweep-nodes", "300", "--sweep-candidates", "40", "--sweep-sample", "6", "--solver-lib", emu]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = _json_line(r.stdout)
     assert REQUIRED <= set(line) and {"cpu_baseline", "batched", "packing", "counters", "parity", "config2_topology", "engine"} <= set(line)
@@ -51,9 +51,18 @@ def test_single_rank_line(oracle):
     assert abs(line["packing"]["packing_cost_per_hour"] - want["packingCost"]) <= 1e-9 * want["packingCost"]
     assert line["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
     assert abs(line["value"] - line["packing"]["pods_scheduled"] / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
-    rf = line["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert rf["traffic"] is None            # the PMC figure belongs to the 1M-pod x 500-type launch only
+    rf = line["roofline"]            # the streaming kernel of the path (pod classing), not the latency-bound pack kernel
+    assert rf["kernel"] == "ksolve_row_hash_coop2" and rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["traffic"] is None            # a PMC figure is only quoted for the build and the workload it was measured on
+    assert abs(rf["achieved"] - rf["algorithmic_bytes"] / (rf["avg_kernel_ms"] * 1e-3) / 1e9) < 1e-9 * rf["achieved"] and rf["algorithmic_bytes"] == rf["rows"] * rf["bytes_per_row"]
+    pk = line["pack_kernel"]
+    assert pk["kernel"] == "ksolve_pack_fast" and "latency" in pk["bound"] and pk["traffic"] is None and pk["achieved"] is None and pk["reference_equivalent"]["bytes"] > 0
+    assert cc["components_check"]["all_digests_match_oracle"] is True and cc["components_check"]["components"] == 16
+    sw = line["config4_sweep"]
+    assert sw["nodes"] == 300 and sw["candidates"] == 40 and sum(sw["decisions"].values()) == 40 and sw["unit"] == "probes/s" and sw["value"] > 0
+    assert sw["oracle_check"]["all_identical"] is True and sw["oracle_check"]["probes"] >= 3 and sw["cpu_baseline"]["kind"] == "port" and sw["cpu_baseline"]["unit"] == "probes/s"
+    assert abs(sw["value"] - sw["candidates"] / sw["seconds"]["library_call"]) <= 1e-9 * sw["value"]
+    assert line["config2_topology"]["oracle_pin"] is None
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "pods/s" and cb["value"] > 0 and len(cb["runs_seconds"]) == 3
     assert line["batched"]["problems"] == 3 and line["batched"]["value"] > 0
@@ -63,7 +72,7 @@ def test_two_ranks_under_the_drivers_launcher(oracle):
     emu = parity.build_emu()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--pods", "2500", "--types", "60", "--components-pods", "4000", "--components-types", "60", "--components-calibration-pods", "4000", "--solver-lib", emu]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--pods", "2500", "--types", "60", "--components-pods", "4000", "--components-types", "60", "--components-calibration-pods", "4000", "--sweep-nodes", "300", "--sweep-candidates", "41", "--sweep-sample", "3", "--solver-lib", emu]
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = _json_line(r.stdout)
@@ -86,6 +95,9 @@ def test_two_ranks_under_the_drivers_launcher(oracle):
     ccost = sum(w["packingCost"] for w in parts)
     assert abs(cc["packing_cost_per_hour"] - ccost) <= 1e-9 * ccost and abs(cc["per_instance_type"]["cost_from_vector"] - ccost) <= 1e-9 * ccost
     assert abs(cc["calibration"]["cost_rel_delta"]) < 0.05 and abs(cc["calibration"]["claims_delta"]) <= 0.05 * cc["calibration"]["whole_batch"]["node_claims"]
+    # BASELINE configs[4] across the ranks: the candidates dealt out round-robin, verdict counts summed with one all-reduce
+    sw = line["config4_sweep"]
+    assert sw["ranks"] == 2 and sw["candidates_all_ranks"] == 41 and sum(sw["decisions_all_ranks"].values()) == 41 and sw["candidates"] == 21 and sw["value"] > 0
 
 
 def test_the_hook_needs_its_environment_switch():

@@ -580,3 +580,35 @@ def test_probe_api_rejects_bad_descriptors(emu):
     ok = rc.scheduler.Probe([cluster["nodes"][0]["name"]], [uid]).Solve()
     assert ok["counters"]["pods"] == 1 and ok["counters"]["existingNodes"] == 5
     rc.close()
+
+
+def test_resident_cluster_probes_with_volume_limits(oracle, emu):
+    """CSI attach limits of the cluster's nodes (VolumeUsage, existingnode.go:88, :179) inside probes of a resident cluster:
+    the displaced pods' claims count against the limits of the nodes they move to, each probe with its own log of what it
+    added (the nodes' tables are shared and pristine)."""
+    import random
+    rng = random.Random(77)
+    cluster = _tight_cluster(5)
+    csi = "ebs.csi"
+    for n in cluster["nodes"]:
+        vols = []
+        for p in n["pods"]:
+            if rng.random() < 0.7:
+                p["volumes"] = [{"driver": csi, "pvc": f"default/pvc-{rng.randrange(40)}"} for _ in range(rng.choice([1, 2]))]
+                vols += p["volumes"]
+        n["volumeUsage"] = {"volumes": vols, "limits": {csi: len({v["pvc"] for v in vols}) + rng.choice([0, 0, 1])}}
+    cands = [n for n in dz.sort_candidates(cluster, cluster["nodes"]) if not n.get("markedForDeletion")][:12]
+    got, rc = dz.sweep_resident(cluster, cands, solver_lib=emu)
+    want = dz.sweep(cluster, cands, oracle.solve)
+    assert [strip(c) for c in got] == [strip(c) for c in want]
+    for g, w in zip(got, want):
+        parity.assert_same_results(g["results"], w["results"])
+    fast = rc.decisions([[c] for c in cands])
+    assert [(c["decision"], c["replacement"]) for c in fast] == [(c["decision"], c["replacement"]) for c in want]
+    rc.close()
+    # the limits decide something: without them some displaced pods land on other nodes
+    for n in cluster["nodes"]:
+        n["volumeUsage"]["limits"] = {}
+    free = dz.sweep(cluster, cands, oracle.solve)
+    placed = lambda cmds: [sorted((e["name"], tuple(e["pods"])) for e in c["results"]["existingNodes"] if e["pods"]) for c in cmds]
+    assert placed(free) != placed(want)

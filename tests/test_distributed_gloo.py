@@ -118,3 +118,33 @@ def test_two_rank_consolidation_sweep():
     first = next(i for i, v in enumerate(verdicts) if v > 0)
     serial = dz.single_node_consolidation(cluster, cands, oracle.solve)
     assert serial["candidates"] == [cands[first]["name"]]
+
+
+def test_batch_over_two_devices_through_the_c_abi(oracle):
+    """ksolve_solve_batch over handles on different devices (ksolve_options.device): one batch per device, side by side; and the
+    per-instance-type (NodeClaim count, $/h) vectors of the solves (ksolve_packing_vector) sum to the whole job's — the
+    north_star's reduction as the C ABI offers it to a one-process caller. The emulation has as many "devices" as the options
+    name; every problem's Results equal the oracle's, the summed vector equals the one derived from the oracle's claims."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    import parity
+    from karpenter_amd import fixtures as fx
+    from karpenter_amd.scheduling import NewScheduler, SolveBatch
+    emu = parity.build_emu()
+    probs = [dict(fx.config2(pods=1500 + 200 * i, n_types=60, seed=50 + i), options={"device": i % 2}) for i in range(5)]
+    scheds = [NewScheduler(p, solver_lib=emu) for p in probs]
+    got = SolveBatch(scheds)
+    n_its = len(probs[0]["instanceTypes"])
+    total = np.zeros((n_its, 2))
+    want_total = np.zeros((n_its, 2))
+    for p, g in zip(probs, got):
+        w = oracle.solve(p)
+        parity.assert_same_results(g, w)
+        for i, c, d in g["packingVector"]:
+            total[i] += (c, d)
+        want_total += bench.launch_type_vector(p, w)
+    assert np.array_equal(total[:, 0], want_total[:, 0]) and np.allclose(total[:, 1], want_total[:, 1], rtol=1e-12, atol=0)
+    for s_ in scheds:
+        s_.close()

@@ -10,7 +10,7 @@ import pytest
 import parity
 from karpenter_amd import fixtures as fx
 from karpenter_amd.scheduling import NewScheduler, ToNodeClaim
-from test_device_algorithm import emu  # noqa: F401  (fixture)
+from test_device_algorithm import emu, check  # noqa: F401  (fixture; check = oracle vs device algorithm on one problem)
 
 LABELS = {"test": "test"}
 
@@ -1565,3 +1565,64 @@ def test_node_labels_from_nodepool_requirements(oracle, emu):
     res = solve(oracle, emu, [fx.pod()], pools=[pool], its=its)
     lab = ToNodeClaim(res["newNodeClaims"][0], fx.problem(its, [pool], []))["labels"]
     assert lab.get("foo") == "bar" and "node.kubernetes.io/windows-build" not in lab
+
+
+def test_volume_usage_limits_on_existing_nodes(oracle, emu):
+    """VolumeUsage.ExceedsLimits / Add (pkg/scheduling/volumeusage.go:193-209) in ExistingNode.CanAdd / Add (existingnode.go:88,
+    :179): the CSINode attach limit of an existing node counts DISTINCT PVCs per CSI driver. Known answers of
+    scheduling/suite_test.go "VolumeUsage": six pods with two claims each against a limit of ten -> five on the node, a second
+    node for the sixth (:2903-2958); a hundred pods sharing one claim -> one node (:2959-3008)."""
+    csi = "fake.csi.provider"
+    it = fx.fake_instance_type("instance-type", resources={"cpu": "1024", "pods": "1024"})
+    zone1 = [[fx.req(fx.ZONE, "In", "test-zone-1")]]
+    node = fx.state_node("node-a", it, "test-zone-1", volume_limits={csi: 10})
+    pods = [fx.pod(volume_requirements=zone1, volumes=[(csi, f"default/my-claim-a-{i}"), (csi, f"default/my-claim-b-{i}")]) for i in range(6)]
+    got, _ = check(oracle, emu, fx.problem([it], [fx.node_pool()], pods, state_nodes=[node]))
+    assert sum(len(e["pods"]) for e in got["existingNodes"]) == 5 and len(got["newNodeClaims"]) == 1 and not got["podErrors"]
+    same = [fx.pod(volume_requirements=zone1, volumes=[(csi, "default/my-claim")]) for _ in range(100)]
+    got, _ = check(oracle, emu, fx.problem([it], [fx.node_pool()], same, state_nodes=[fx.state_node("node-a", it, "test-zone-1", volume_limits={csi: 10})]))
+    assert sum(len(e["pods"]) for e in got["existingNodes"]) == 100 and not got["newNodeClaims"]
+    # volumes already on the node count, shared ones once; a driver without a limit on the node is not tracked
+    node = fx.state_node("node-a", it, "test-zone-1", volumes=[(csi, "default/x"), (csi, "default/y"), ("other.csi", "default/z")], volume_limits={csi: 3})
+    pods = [fx.pod(requests={"cpu": "2"}, volumes=[(csi, "default/x"), (csi, "default/y")]),                 # nothing new
+            fx.pod(requests={"cpu": "1500m"}, volumes=[(csi, "default/x"), (csi, "default/n1")]),            # one new: 3 of 3
+            fx.pod(requests={"cpu": "1"}, volumes=[(csi, "default/n2")]),                                    # a fourth: no
+            fx.pod(requests={"cpu": "500m"}, volumes=[(csi, "default/n1"), ("other.csi", "default/q"), ("unlimited.csi", "default/r")])]   # n1 is there by now
+    got, _ = check(oracle, emu, fx.problem([it], [fx.node_pool()], pods, state_nodes=[node]))
+    on_node = {u for e in got["existingNodes"] for u in e["pods"]}
+    assert on_node == {pods[0]["uid"], pods[1]["uid"], pods[3]["uid"]} and len(got["newNodeClaims"]) == 1
+    # a node that is over its limit before the solve takes no pod at all, not even one without volumes (ExceedsLimits walks the
+    # drivers of the union, volumeusage.go:194-199)
+    over = fx.state_node("node-a", it, "test-zone-1", volumes=[(csi, "default/x"), (csi, "default/y")], volume_limits={csi: 1})
+    got, _ = check(oracle, emu, fx.problem([it], [fx.node_pool()], [fx.pod(requests={"cpu": "1"}), fx.pod(volumes=[(csi, "default/x")])], state_nodes=[over]))
+    assert not any(e["pods"] for e in got["existingNodes"]) and len(got["newNodeClaims"]) == 1
+
+
+def test_volume_usage_limits_fuzz(oracle, emu):
+    """Seeded clusters: nodes with limits on one or two drivers and volumes in use, pods with shared and private claims, zonal
+    spread and volume requirement alternatives in between; also as probes of a resident cluster (per-probe volume log)."""
+    import random
+    drivers = ["ebs.csi", "efs.csi", "nolimit.csi"]
+    for seed in range(16):
+        rng = random.Random(7700 + seed)
+        its = fx.fake_default_instance_types() if seed % 2 else fx.fake_instance_types(rng.choice([6, 12]))
+        by = {t["name"]: t for t in its}
+        claims = [f"default/pvc-{i}" for i in range(rng.choice([4, 9]))]
+        vol = lambda: (rng.choice(drivers), rng.choice(claims))
+        nodes = []
+        for i in range(rng.choice([2, 5])):
+            lim = {d: rng.choice([0, 1, 2, 3, 5]) for d in drivers[:2] if rng.random() < 0.7}
+            nodes.append(fx.state_node(f"node-{i}", by[rng.choice(sorted(by))], rng.choice(["test-zone-1", "test-zone-2"]),
+                                       volumes=[vol() for _ in range(rng.choice([0, 1, 3]))], volume_limits=lim))
+        lab = {"app": "v"}
+        pods = []
+        for i in range(rng.choice([20, 60])):
+            kw = {}
+            if rng.random() < 0.6:
+                kw["volumes"] = [vol() for _ in range(rng.choice([1, 1, 2, 3]))]
+            if rng.random() < 0.2:
+                kw.update(labels=lab, topology_spread=[fx.spread(fx.ZONE, lab)])
+            if rng.random() < 0.2:
+                kw["volume_requirements"] = [[fx.req(fx.ZONE, "In", rng.choice(["test-zone-1", "test-zone-2"]))]]
+            pods.append(fx.pod(requests={"cpu": f"{rng.choice([100, 300, 700])}m"}, **kw))
+        check(oracle, emu, fx.problem(its, [fx.node_pool()], pods, state_nodes=nodes))
