@@ -41,7 +41,8 @@ def algorithmic_bytes(c):
     """bytes = P*B_pod + V*B_bin + P*B_bin(writeback) + N_it*T*B_it with the record sizes of the
     layouts actually used (DESIGN.md §Data layout). V = the bins the REFERENCE evaluates."""
     R, RW, IW, K = c["resources"], c["reqWords"], c["itWords"], c["keys"]
-    b_pod = 8 * R + 2 * (8 * RW + 16) + 8 + 4 + 8 + 16 + 1
+    tables = 1 if c.get("strictTableShared") else 2   # PodData.StrictRequirements: its own table only when some pod has a preference
+    b_pod = 8 * R + tables * (8 * RW + 16) + 8 + 4 + 8 + 16 + 1
     b_bin = 8 * RW + 16 + 8 * IW + 16 * R + 20 * K + 16
     b_it = 16 * R + 8 * RW + 16 + 8 + 512
     total = c["pods"] * b_pod + c["referenceBinEvaluations"] * b_bin + c["pods"] * b_bin + c["instanceTypes"] * c.get("templates", 1) * b_it
@@ -217,7 +218,9 @@ def main():
     prob["options"]["device"] = device_index
     if args.engine != "auto":
         prob["options"]["engine"] = args.engine
+    t_open = time.perf_counter()
     sched = NewScheduler(prob, solver_lib=args.solver_lib)  # flatten + upload: inputs resident in HBM before the timed region
+    t_open = time.perf_counter() - t_open
 
     def sync():
         if torch is not None and torch.cuda.is_available():
@@ -243,7 +246,9 @@ def main():
     claims = last["counters"]["claims"]
 
     # ---- untimed: the packing itself (digest against the oracle's pin, per-instance-type summary) ----
+    t_full = time.perf_counter()
     full = sched.Solve(want_results=True)
+    t_full = time.perf_counter() - t_full
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity   # canonical Results digest (shared with the tests; does not touch oracle/)
     digest, _ = parity.results_digest(full)
@@ -419,7 +424,8 @@ def main():
         "roofline": {"kernel": "ksolve_row_hash_coop2", "bound": "hbm", "achieved": stream_bytes / (rh_ms * 1e-3) / 1e9 if rh_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": stream_bytes / (rh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rh_ms > 0 else None, "traffic": stream_traffic, "traffic_source": traffic_note,
                      "algorithmic_bytes": stream_bytes, "bytes_per_row": rec["B_pod"], "rows": c["rows"], "avg_kernel_ms": rh_ms, "classing_phase_ms": cls_ms,
-                     "bytes_read_by_the_kernel": c["rows"] * (2 * (8 * c["reqWords"] + 16) + 8 * c["resources"] + 8 + 4),   # both mask tables + flag words, requests, toleration mask, slot written; all-nil minValues tables are not streamed
+                     "bytes_read_by_the_kernel": c["rows"] * ((1 if c.get("strictTableShared") else 2) * (8 * c["reqWords"] + 16) + 8 * c["resources"] + 8 + 4),   # the mask table(s) + flag words, requests, toleration mask, slot written; all-nil minValues tables are not streamed
+                     "mask_tables": 1 if c.get("strictTableShared") else 2,
                      "note": "B_pod is the row of the layout actually used (DESIGN.md §3); SURVEY §8(d)'s sketch of a row (K = 16 keys, one mask word each) is 188 B"},
         # The pack kernel is a serial first-fit chain on ONE wavefront: bound by the instruction issue and the dependent LDS round
         # trips of a lone wave, not by HBM — no roofline is claimed for it. `achieved` is what it really moves.
@@ -429,6 +435,14 @@ def main():
                                                  "note": "SURVEY §8(d) formula P*B_pod + V*B_bin + P*B_bin + N_it*T*B_it with V = the bins the REFERENCE evaluates (referenceBinEvaluations, equal to the "
                                                          "oracle's count) and the record sizes of the layout in use (SURVEY's sketch: 188 / 248 / 185 B): the bytes the reference's scan would "
                                                          "touch, not what this kernel moves — cursors and permanent rejections make almost all of those evaluations unnecessary"}},
+        # What Solve() costs through the real boundary: the cgo shim flattens and uploads INSIDE Solve() (go/ksolve_shim.go:124-150)
+        # and rehydrates Results after it, and the reference's own Solve() includes updateCachedPodData for every pod
+        # (scheduler.go:453-455). Here: NewScheduler (the host library parses the problem document — pods arrive as a few hundred
+        # groups, which spares JSON, not flattening: every pod becomes a row —, flattens, ksolve_create uploads), one timed solve, and
+        # a solve that also rehydrates every NodeClaim and pod assignment into the Results document.
+        "end_to_end": {"new_scheduler_s": t_open, "upload_ms": timings[0].get("upload_us", 0.0) * 1e-3, "solve_s": elapsed / args.steps, "solve_and_rehydrate_s": t_full,
+                       "pods_per_s_through_the_boundary": scheduled / world / (t_open + t_full),
+                       "note": "rank 0's problem; flatten + upload + solve + download + rehydration, nothing overlapped"},
         "phases_ms": {k: sum(t.get(k, 0.0) for t in timings) / len(timings) for k in ("pack_kernel_ms", "classify_ms", "row_hash_ms", "sort_ms", "it_index_ms")},
         "counters": c,
     }
@@ -505,6 +519,19 @@ def main():
                                          f"median of {len(runs)} runs ({secs:.2f} s); the oracle is O(pods x claims), so its rate falls with size "
                                          f"(offline at the full 1M pods: see parity.oracle_pin.oracle_seconds_offline)",
                                "seconds": secs, "runs_seconds": runs, "bin_evaluations": r["counters"]["binEvaluations"]}
+        # N threads: the reference fans the candidates of addToInflightNode out over a worker pool (parallelizeUntil,
+        # scheduler.go:939-961); the oracle does the same when ORACLE_THREADS is set (same Results, same counters)
+        n_thr = min(64, os.cpu_count() or 1)
+        if n_thr > 1:
+            os.environ["ORACLE_THREADS"], os.environ["ORACLE_PAR_MIN"] = str(n_thr), "64"
+            try:
+                rt = oracle.solve(sample)
+            finally:
+                os.environ.pop("ORACLE_THREADS", None); os.environ.pop("ORACLE_PAR_MIN", None)
+            out["cpu_baseline_threads"] = {"value": args.cpu_sample / rt["counters"]["solveSeconds"], "unit": "pods/s", "cores": n_thr, "kind": "port",
+                                           "sample": out["cpu_baseline"]["sample"], "seconds": rt["counters"]["solveSeconds"],
+                                           "note": "candidate fan-out of the in-flight scan; scans shorter than 64 claims stay sequential (most of this sample's are: "
+                                                   f"{r['counters']['binEvaluations'] / args.cpu_sample:.0f} evaluations per pod on average)"}
         if not args.no_host_engine_baseline and not args.solver_lib:
             # the honest baseline for the ALGORITHM: this repository's own engine source compiled for ONE host core (the test
             # emulation of the device code, tests/emu — a checker, never a product path), same problem, same Results

@@ -107,6 +107,12 @@ typedef struct {
                                 * only the member whose owner relaxes FIRST comes to exist, and every later owner of another
                                 * member owns that one instead. */
   uint32_t n_alias_classes;
+  /* Resident clusters (ksolve_problem_desc.pod_node != NULL; ksolve_sweep / ksolve_probe_create): init_counts then count EVERY
+   * bound pod of the cluster, also those that are pod rows, and a probe takes the share of its displaced pods and removed nodes
+   * out again (what countDomains does by excluding the pods being scheduled, topology.go:92-94, :361-459). For that it needs to
+   * know which registered domains only exist through nodes: */
+  const uint64_t* domain_universe;   /* n * domain_words : domains the NodePools / instance types offer (ForEachDomain, topologydomaingroup.go:61-72); NULL = `domains` */
+  const int32_t* domain_node_regs;   /* n * domain_words * 64 : existing nodes that pass the group's node filter and carry the domain (topology.go:376-384); may be NULL */
 } ksolve_topology;
 
 typedef struct {
@@ -190,6 +196,9 @@ typedef struct {
   const uint64_t* pod_uid_lo;
   const uint8_t* pod_is_pending;   /* n_pods : Status.Phase == Pending (scheduler.go:628) */
   const uint8_t* pod_from_deleting_node; /* n_pods */
+  const int32_t* pod_node;         /* n_pods or NULL. Non-NULL marks a RESIDENT CLUSTER: the pod rows include the pods bound to the existing
+                                    * nodes (pod_node = the node's index, -1 = pending), so that any set of nodes can be a probe's candidates
+                                    * (ksolve_sweep); such a problem is only solved through probes */
 
   /* ---- host ports (hostportusage.go:39-117): bit masks over the problem's distinct <hostIP, hostPort, protocol> triples
    *      (<= 64). A pod joins a bin only when none of its triples matches (same protocol and port, equal IPs or one of them

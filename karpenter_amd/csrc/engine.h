@@ -1882,6 +1882,108 @@ struct Engine {
     return reqbuf_add(d, sc.merged, q);
   }
 
+  // ---- topology state of a probe of a resident cluster ------------------------------------------------------
+  // The base problem's counts (TopoView::counts0 / node_counts0 / domains0) cover the whole cluster: every bound pod, every node.
+  // A simulation counts the cluster WITHOUT its candidates and without the pods it is about to schedule (NewTopology puts them in
+  // excludedPods, topology.go:92-94; countDomains :361-459 and updateInverseAffinities :310-355 skip them). So, after the copy:
+  //   * a removed node: its per-node counters of hostname groups go, and it no longer registers its label values as domains;
+  //   * a displaced pod (a row of this probe bound to a removed node): one less in every regular group that selects it on a
+  //     node that passed the group's filter, and in every inverse anti-affinity group it owns;
+  //   * the registered domains and the non-empty-domain counts of the dictionary-keyed groups are derived again.
+  KS_DEV bool probe_node_removed(int e) const {
+    for (int i = 0; i < S.pr_n_removed; ++i) if ((int)S.pr_removed[i] == e) return true;
+    return false;
+  }
+  // sc.merged <- the pristine requirement set of existing node e (its labels); removed nodes are never overlaid
+  KS_DEV void probe_load_node(int e) {
+    ReqBuf& m = sc.merged;
+    const int ne = P.n_nodes;
+    const uint64_t* nm = S.n_mask0;
+    W::for_n(lay.rw, [&](int w) { m.mask[w] = nm[(size_t)w * ne + e]; });
+    if (W::leader()) {
+      m.defined = S.n_defined0[e]; m.complement = S.n_complement0[e]; m.has_gte = m.has_lte = m.has_minv = 0;
+      for (int kk = 0; kk < lay.nk; ++kk) { m.gte[kk] = 0; m.lte[kk] = 0; m.minv[kk] = -1; }
+    }
+    W::sync();
+  }
+  // the dictionary value a node's label gives key `key` (labels are single-valued In sets), -1 = the node has no such label
+  KS_DEV int probe_node_value(int key) const {
+    const Dict& d = P.dict;
+    if (!bit(sc.merged.defined, key) || bit(sc.merged.complement, key)) return -1;
+    for (uint32_t w = d.key_word_off[key]; w < d.key_word_off[key + 1]; ++w) if (sc.merged.mask[w]) return (int)(w - d.key_word_off[key]) * 64 + ctz64(sc.merged.mask[w]);
+    return -1;
+  }
+  KS_DEV void probe_topology_adjust() {
+    const TopoView& T = P.topo;
+    const int G = T.n_groups, dv = T.dom_words * 64, ne = P.n_nodes;
+    Workspace& Sw = S;
+    if (T.dom_regs0) W::for_n(G * dv, [&](int i) { Sw.tg_regs[i] = T.dom_regs0[i]; });
+    for (int ri = 0; ri < S.pr_n_removed; ++ri) {
+      const int e = (int)S.pr_removed[ri];
+      probe_load_node(e);
+      const uint64_t taints = P.node_taints[e];
+      for (int g = 0; g < G; ++g) {
+        const int key = T.key[g];
+        if (key < 0) {
+          int32_t* pc = S.tg_node_counts + (size_t)T.host_slot[g] * ne + e;
+          if (*pc > 0) { W::store(&S.tg_nonzero[g], S.tg_nonzero[g] - 1); W::store(pc, 0); W::sync(); }
+          continue;
+        }
+        if (!T.dom_regs0 || ((T.inverse_mask[g >> 6] >> (g & 63)) & 1)) continue;
+        const int v = probe_node_value(key);
+        if (v < 0 || !topo_filter_matches(g, taints, sc.merged.ref(), 1)) continue;
+        int32_t* pr = S.tg_regs + (size_t)g * dv + v;
+        W::store(pr, *pr - 1);
+        W::sync();
+      }
+    }
+    int loaded = -1;
+    for (int i = 0; i < S.pr_n_pods; ++i) {
+      const int pod = (int)S.pr_sorted[i];
+      const int e = P.pod_node ? P.pod_node[pod] : -1;
+      if (e < 0 || !probe_node_removed(e)) continue;
+      if (loaded != e) { probe_load_node(e); loaded = e; }
+      const uint64_t taints = P.node_taints[e];
+      const uint64_t* ct = T.cls_topo + (size_t)P.row_class[pod] * 2 * T.words;
+      for (int tw = 0; tw < T.words; ++tw)
+      for (uint64_t todo = (ct[T.words + tw] & ~T.inverse_mask[tw]) | (ct[tw] & T.inverse_mask[tw]); todo; todo &= todo - 1) {
+        const int g = tw * 64 + ctz64(todo);
+        const int key = T.key[g];
+        if (key < 0) continue;                                  // per-node counters of the removed node are gone already
+        const bool inv = (T.inverse_mask[tw] >> (g & 63)) & 1;
+        const int v = probe_node_value(key);
+        if (v < 0) continue;
+        if (!inv && !topo_filter_matches(g, taints, sc.merged.ref(), 1)) continue;
+        int32_t* pc = S.tg_counts + (size_t)g * dv + v;
+        W::store(pc, *pc - 1);
+        W::sync();
+      }
+    }
+    // NewTopology creates the groups of the pods it is given (topology.go:96-99): of the base problem's initially existing regular
+    // groups only those a pod of THIS probe owns as submitted exist from the start; the others come into being if a pod relaxes
+    // into them (fetch_class), and see no Record before that. Inverse groups come from the cluster's pods: all there.
+    for (int tw = 0; tw < T.words; ++tw) {
+      uint64_t own = 0;
+      for (int i = 0; i < S.pr_n_pods; ++i) own |= T.cls_topo[(size_t)P.row_class[S.pr_sorted[i]] * 2 * T.words + tw];
+      W::store(&sc.t_active[tw], (uint64_t)(T.initially_active[tw] & (T.inverse_mask[tw] | own)));
+    }
+    // registered domains (universe ∪ nodes that are still there ∪ counted) and the number of non-empty domains, per group
+    for (int g = 0; g < G; ++g) {
+      if (T.key[g] < 0) continue;
+      const int32_t* cnt = S.tg_counts + (size_t)g * dv;
+      const int32_t* rg = T.dom_regs0 ? S.tg_regs + (size_t)g * dv : nullptr;
+      int nz = 0;
+      for (int x = 0; x < T.dom_words; ++x) {
+        const uint64_t counted = W::ballot([&](int b) { return cnt[x * 64 + b] > 0; });
+        const uint64_t regd = rg ? W::ballot([&](int b) { return rg[x * 64 + b] > 0; }) : 0ull;
+        nz += popc64(counted);
+        if (T.dom_universe) W::store(&S.tg_domains[(size_t)g * T.dom_words + x], (uint64_t)(T.dom_universe[(size_t)g * T.dom_words + x] | regd | counted));
+      }
+      W::store(&S.tg_nonzero[g], nz);
+    }
+    W::sync();
+  }
+
   // ---- class record of the pod being placed ----------------------------------------------------------------
   KS_DEV void fetch_class(int k) {
     const int hw = lay.k_hot_words();
@@ -2044,6 +2146,7 @@ struct Engine {
       W::for_n(G, [&](int i) { Sw.tg_nonzero[i] = T.nonzero0[i]; });
       W::for_n(T.words, [&](int w) { sc.t_active[w] = T.initially_active[w]; });
       W::for_n(T.n_alias, [&](int i) { Sw.tg_alias_active[i] = -1; });
+      if (S.probe) probe_topology_adjust();
     }
     n_pv_log = 0;
     load_tables();

@@ -252,51 +252,54 @@ struct CoopStage {
 }
 // FULL: 64 rows, so both totals are multiples of the access width and an access is either whole or past the end; an access
 // past the end reads piece 0 instead (no branch around a load: a branch makes the compiler wait for every load before it).
-template <bool FULL, bool MINV>
+// SAME: the strict table IS the requirement table (no pod of the batch has a preference: PodData.StrictRequirements ==
+// Requirements, scheduler.go:217-229, and the flattener hands both under one pointer) — it is read and staged once.
+template <bool FULL, bool MINV, bool SAME>
 __device__ __forceinline__ void coop_stage(const ks::CoopStage& s, const ks::RowArgs& a, int rowc, ks::ReqRef& q, ks::ReqRef& qs, int64_t (&rq)[8], uint64_t& tol) {
-  uint4 A[kCoopMaskCh], B[kCoopMaskCh], KA[kCoopMinvCh], KB[kCoopMinvCh];
+  uint4 A[kCoopMaskCh], B[SAME ? 1 : kCoopMaskCh], KA[kCoopMinvCh], KB[SAME ? 1 : kCoopMinvCh];
   const int l = s.l, nr = a.n_res;
 #pragma unroll
   for (int i = 0; i < kCoopMaskCh; ++i) {
     const int e = 2 * (l + 64 * i);
-    if (FULL) { const int x = e < s.total ? e : 0; A[i] = *(const uint4*)(s.g0 + x); B[i] = *(const uint4*)(s.g1 + x); }
-    else { A[i] = coop_load_u64x2(s.g0, e, s.total); B[i] = coop_load_u64x2(s.g1, e, s.total); }
+    if (FULL) { const int x = e < s.total ? e : 0; A[i] = *(const uint4*)(s.g0 + x); if (!SAME) B[i] = *(const uint4*)(s.g1 + x); }
+    else { A[i] = coop_load_u64x2(s.g0, e, s.total); if (!SAME) B[i] = coop_load_u64x2(s.g1, e, s.total); }
   }
   if (MINV) {
 #pragma unroll
     for (int i = 0; i < kCoopMinvCh; ++i) {
       const int e = 4 * (l + 64 * i);
-      if (FULL) { const int x = e < s.ktotal ? e : 0; KA[i] = *(const uint4*)(s.k0 + x); KB[i] = *(const uint4*)(s.k1 + x); }
-      else { KA[i] = coop_load_i32x4(s.k0, e, s.ktotal); KB[i] = coop_load_i32x4(s.k1, e, s.ktotal); }
+      if (FULL) { const int x = e < s.ktotal ? e : 0; KA[i] = *(const uint4*)(s.k0 + x); if (!SAME) KB[i] = *(const uint4*)(s.k1 + x); }
+      else { KA[i] = coop_load_i32x4(s.k0, e, s.ktotal); if (!SAME) KB[i] = coop_load_i32x4(s.k1, e, s.ktotal); }
     }
   }
   q.defined = a.reqs.defined[rowc]; q.complement = a.reqs.complement[rowc]; q.has_gte = a.reqs.has_gte[rowc]; q.has_lte = a.reqs.has_lte[rowc];
-  qs.defined = a.strict.defined[rowc]; qs.complement = a.strict.complement[rowc]; qs.has_gte = a.strict.has_gte[rowc]; qs.has_lte = a.strict.has_lte[rowc];
+  if (SAME) { qs.defined = q.defined; qs.complement = q.complement; qs.has_gte = q.has_gte; qs.has_lte = q.has_lte; }
+  else { qs.defined = a.strict.defined[rowc]; qs.complement = a.strict.complement[rowc]; qs.has_gte = a.strict.has_gte[rowc]; qs.has_lte = a.strict.has_lte[rowc]; }
 #pragma unroll
   for (int r = 0; r < 8; ++r) rq[r] = a.requests[(size_t)(r < nr ? r : 0) * a.n_rows + rowc];
   tol = a.tolerates[rowc];
 #pragma unroll
-  for (int i = 0; i < kCoopMaskCh; ++i) { const int e = 2 * (l + 64 * i); coop_drop_u64x2<FULL>(s.t0, A[i], e, s.total, s.rw, s.stride, s.magic); coop_drop_u64x2<FULL>(s.t1, B[i], e, s.total, s.rw, s.stride, s.magic); }
+  for (int i = 0; i < kCoopMaskCh; ++i) { const int e = 2 * (l + 64 * i); coop_drop_u64x2<FULL>(s.t0, A[i], e, s.total, s.rw, s.stride, s.magic); if (!SAME) coop_drop_u64x2<FULL>(s.t1, B[i], e, s.total, s.rw, s.stride, s.magic); }
   if (MINV) {
 #pragma unroll
-    for (int i = 0; i < kCoopMinvCh; ++i) { const int e = 4 * (l + 64 * i); coop_drop_i32x4<FULL>(s.m0, KA[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); coop_drop_i32x4<FULL>(s.m1, KB[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); }
+    for (int i = 0; i < kCoopMinvCh; ++i) { const int e = 4 * (l + 64 * i); coop_drop_i32x4<FULL>(s.m0, KA[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); if (!SAME) coop_drop_i32x4<FULL>(s.m1, KB[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); }
   }
   for (int base = 2 * 64 * kCoopMaskCh; base < s.total; base += 2 * 64 * kCoopMaskCh) {   // dictionaries beyond one round
 #pragma unroll
-    for (int i = 0; i < kCoopMaskCh; ++i) { const int e = base + 2 * (l + 64 * i); A[i] = coop_load_u64x2(s.g0, e, s.total); B[i] = coop_load_u64x2(s.g1, e, s.total); }
+    for (int i = 0; i < kCoopMaskCh; ++i) { const int e = base + 2 * (l + 64 * i); A[i] = coop_load_u64x2(s.g0, e, s.total); if (!SAME) B[i] = coop_load_u64x2(s.g1, e, s.total); }
 #pragma unroll
-    for (int i = 0; i < kCoopMaskCh; ++i) { const int e = base + 2 * (l + 64 * i); coop_drop_u64x2(s.t0, A[i], e, s.total, s.rw, s.stride, s.magic); coop_drop_u64x2(s.t1, B[i], e, s.total, s.rw, s.stride, s.magic); }
+    for (int i = 0; i < kCoopMaskCh; ++i) { const int e = base + 2 * (l + 64 * i); coop_drop_u64x2(s.t0, A[i], e, s.total, s.rw, s.stride, s.magic); if (!SAME) coop_drop_u64x2(s.t1, B[i], e, s.total, s.rw, s.stride, s.magic); }
   }
   if (MINV) for (int base = 4 * 64 * kCoopMinvCh; base < s.ktotal; base += 4 * 64 * kCoopMinvCh) {
 #pragma unroll
-    for (int i = 0; i < kCoopMinvCh; ++i) { const int e = base + 4 * (l + 64 * i); KA[i] = coop_load_i32x4(s.k0, e, s.ktotal); KB[i] = coop_load_i32x4(s.k1, e, s.ktotal); }
+    for (int i = 0; i < kCoopMinvCh; ++i) { const int e = base + 4 * (l + 64 * i); KA[i] = coop_load_i32x4(s.k0, e, s.ktotal); if (!SAME) KB[i] = coop_load_i32x4(s.k1, e, s.ktotal); }
 #pragma unroll
-    for (int i = 0; i < kCoopMinvCh; ++i) { const int e = base + 4 * (l + 64 * i); coop_drop_i32x4(s.m0, KA[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); coop_drop_i32x4(s.m1, KB[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); }
+    for (int i = 0; i < kCoopMinvCh; ++i) { const int e = base + 4 * (l + 64 * i); coop_drop_i32x4(s.m0, KA[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); if (!SAME) coop_drop_i32x4(s.m1, KB[i], e, s.ktotal, s.nk, s.kstride, s.kmagic); }
   }
 }
 // MINV: the rows carry minValues (pod rows never do when they come from the reference's PodData — minValues belong to NodePool
 // requirements — so the tables are absent and neither streamed nor staged)
-template <bool MINV>
+template <bool MINV, bool SAME = false>
 __global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a, int rw, uint32_t magic, uint32_t kmagic, int rpb) {
   extern __shared__ __attribute__((aligned(16))) uint64_t coop_lds[];
   const int l = (int)threadIdx.x;
@@ -307,9 +310,9 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a
   const int nk = a.dict.n_keys, kstride = nk | 1, ktotal = rows * nk;
   const int nr = a.n_res;
   uint64_t* t0 = coop_lds;
-  uint64_t* t1 = coop_lds + rpb * stride;
-  int32_t* m0 = (int32_t*)(coop_lds + 2 * rpb * stride);
-  int32_t* m1 = m0 + rpb * kstride;
+  uint64_t* t1 = SAME ? t0 : coop_lds + rpb * stride;
+  int32_t* m0 = (int32_t*)(coop_lds + (SAME ? 1 : 2) * rpb * stride);
+  int32_t* m1 = SAME ? m0 : m0 + rpb * kstride;
   const uint64_t* g0 = a.reqs.mask + (size_t)row0 * rw;
   const uint64_t* g1 = a.strict.mask + (size_t)row0 * rw;
   const int32_t* k0 = MINV ? a.reqs.minv + (size_t)row0 * nk : nullptr;   // the launcher: both minValues tables or neither, every other optional table exists
@@ -322,8 +325,8 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a
   int64_t rq[8];
   uint64_t tol;
   const ks::CoopStage st{g0, g1, k0, k1, t0, t1, m0, m1, total, ktotal, rw, stride, nk, kstride, magic, kmagic, l};
-  if (rows == rpb) coop_stage<true, MINV>(st, a, rowc, q, qs, rq, tol);     // branch-free: no wait is placed before the last load is out
-  else coop_stage<false, MINV>(st, a, rowc, q, qs, rq, tol);               // the last block of the table
+  if (rows == rpb) coop_stage<true, MINV, SAME>(st, a, rowc, q, qs, rq, tol);     // branch-free: no wait is placed before the last load is out
+  else coop_stage<false, MINV, SAME>(st, a, rowc, q, qs, rq, tol);               // the last block of the table
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
   // ---- the row's hash, out of LDS and registers ----
@@ -495,7 +498,9 @@ static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) {
   const bool minv = a.reqs.minv && a.strict.minv, no_minv = !a.reqs.minv && !a.strict.minv;
   // 64 rows per block. 60 rows (4 idle lanes) would let an eighth block fit the CU's 160 KiB of LDS at configs[1]'s dictionary;
   // measured (profiles/round2/classing_ab3.log): 153 us against 150.5 us — the idle lanes cost what the wavefront buys.
-  auto lds_for = [&](int rpb) { return (size_t)2 * rpb * (size_t)(rw | 1) * 8 + (minv ? (size_t)2 * rpb * (size_t)(nk | 1) * 4 : 0); };
+  // one table to stage when the strict requirements ARE the requirements (same device table): half the LDS, half the loads
+  const bool same = a.strict.mask == a.reqs.mask && a.strict.minv == a.reqs.minv && a.strict.defined == a.reqs.defined && !getenv("KSOLVE_TEST_NO_SHARED_STRICT");
+  auto lds_for = [&](int rpb) { return (size_t)(same ? 1 : 2) * rpb * (size_t)(rw | 1) * 8 + (minv ? (size_t)(same ? 1 : 2) * rpb * (size_t)(nk | 1) * 4 : 0); };
   int rpb = 64;
   if (const char* r = getenv("KSOLVE_TEST_ROWS_PER_BLOCK")) { const int v = atoi(r); if (v == 60 || v == 64) rpb = v; }   // A/B switch of tests/tools/gpu_classing_ab.py
   size_t lds2 = lds_for(rpb);
@@ -505,8 +510,11 @@ static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) {
   const bool coop1 = variant && !strcmp(variant, "coop1");
   const bool tables = (minv || no_minv) && a.reqs.has_gte && a.reqs.has_lte && a.strict.has_gte && a.strict.has_lte;
   if (!plain && !coop1 && rw >= 1 && nk >= 1 && a.n_res >= 1 && a.n_res <= 8 && aligned && tables && lds2 <= 64 * 1024) {
-    if (minv) hipLaunchKernelGGL(ksolve_row_hash_coop2<true>, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
-    else hipLaunchKernelGGL(ksolve_row_hash_coop2<false>, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
+    const dim3 grid((unsigned)((n + rpb - 1) / rpb));
+    if (minv && same) hipLaunchKernelGGL((ksolve_row_hash_coop2<true, true>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
+    else if (minv) hipLaunchKernelGGL((ksolve_row_hash_coop2<true, false>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
+    else if (same) hipLaunchKernelGGL((ksolve_row_hash_coop2<false, true>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
+    else hipLaunchKernelGGL((ksolve_row_hash_coop2<false, false>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
   } else if (!plain && rw >= 1 && nk >= 1 && lds1 <= 64 * 1024) {
     hipLaunchKernelGGL(ksolve_row_hash_coop, dim3((unsigned)((n + 63) / 64)), dim3(64), lds1, HB(h)->stream, n, a, rw, magic, kmagic);
   } else {

@@ -89,6 +89,7 @@ struct ksolve_handle {
   std::vector<int64_t> pr_limits;
   // base: what every sweep shares — rejections of the pristine nodes per class, the consolidateAfter bitmap, the view in HBM,
   // and the arena the probes' workspaces are carved from (kept between sweeps, grown when a sweep needs more)
+  bool resident = false;                 // ksolve_problem_desc.pod_node given: the problem is a whole cluster, solved through probes only
   bool sweep_ready = false;
   ks::ProblemView* d_pv = nullptr;
   char* sweep_arena = nullptr; size_t sweep_arena_bytes = 0;
@@ -447,6 +448,9 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       P.node_flags = up(h, fl.data(), ne);
     }
     P.pod_from_deleting = d->pod_from_deleting_node ? up(h, d->pod_from_deleting_node, d->n_pods) : nullptr;
+    P.pod_node = d->pod_node ? up(h, d->pod_node, d->n_pods) : nullptr;
+    h->resident = d->pod_node != nullptr;
+    if (d->pod_node) for (uint32_t p = 0; p < d->n_pods; ++p) if (d->pod_node[p] >= (int32_t)ne) return fail(h, KSOLVE_ERR_INVALID, "pod_node out of range");
     // CSI volume limits of existing nodes (VolumeUsage)
     P.pv_on = 0; P.n_pv_drivers = 0;
     if (d->n_volume_drivers && ne) {
@@ -565,6 +569,8 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       T.value_rank = up(h, t.value_rank, (size_t)req_words * 64);
       T.node_host_value = d->n_nodes ? (t.node_hostname_value ? up(h, t.node_hostname_value, d->n_nodes) : nullptr) : nullptr;
       if (d->n_nodes && !t.node_hostname_value) return fail(h, KSOLVE_ERR_INVALID, "topology with existing nodes needs node_hostname_value");
+      T.dom_universe = t.domain_universe ? up(h, t.domain_universe, (size_t)G * T.dom_words) : nullptr;
+      T.dom_regs0 = t.domain_node_regs ? up(h, t.domain_node_regs, (size_t)G * dv) : nullptr;
       W.tg_domains = dz<uint64_t>(h, (size_t)G * T.dom_words);
       W.tg_counts = dz<int32_t>(h, (size_t)G * dv);
       W.tg_node_counts = dz<int32_t>(h, nc.size());
@@ -672,6 +678,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       fp.off_ord = off; off = align(off + cap * 2);
       fp.off_snap = off; off = align(off + cap * 2);
       fp.total_bytes = off;
+      { const char* w = getenv("KSOLVE_FAST_WINDOW"); fw.window = (w && !strcmp(w, "0")) ? 0 : (w && !strcmp(w, "2")) ? 2 : 1; }
       fw.var = dz<ks::FastVar>(h, 1);
       fw.c_hostseq = dz<uint32_t>(h, mc); fw.c_ent = dz<uint16_t>(h, mc);
       fw.c_state = dz<ks::FastClaim>(h, mc); fw.c_npods = dz<uint32_t>(h, mc);
@@ -692,7 +699,7 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context);
 // — alone or in a batch — goes through sweep_run below, which shares `base`'s device tables.
 static ksolve_status probe_create(ksolve_handle* base, const ksolve_probe* pr, ksolve_handle* h) {
   if (!base || base->base || !pr) return fail(h, KSOLVE_ERR_INVALID, "probe of a null handle / of a probe");
-  if (base->has_topology) return fail(h, KSOLVE_ERR_UNSUPPORTED, "probes of a cluster with topology groups: create one handle per probe");
+  if (base->has_topology && !base->resident) return fail(h, KSOLVE_ERR_UNSUPPORTED, "probes of a problem with topology groups need a resident-cluster base (ksolve_problem_desc.pod_node): its counts include the candidates' pods");
   if (pr->n_pods && !pr->pods) return fail(h, KSOLVE_ERR_INVALID, "probe pods missing");
   if (base->n_nodes && !pr->removed_nodes) return fail(h, KSOLVE_ERR_INVALID, "probe removed_nodes missing");
   h->pr_pods.assign(pr->pods, pr->pods + pr->n_pods);
@@ -708,7 +715,7 @@ static ksolve_status probe_create(ksolve_handle* base, const ksolve_probe* pr, k
   h->opts = base->opts;
   h->n_keys = base->n_keys; h->req_words = base->req_words; h->n_res = base->n_res; h->n_its = base->n_its; h->it_words = base->it_words;
   h->n_templates = base->n_templates; h->n_pods = base->n_pods; h->n_rows = base->n_rows; h->n_classes = base->n_classes;
-  h->n_nodes = base->n_nodes; h->has_topology = false;
+  h->n_nodes = base->n_nodes; h->has_topology = base->has_topology;
   h->d_cancel = (int*)be_alloc(h, 4);
   be_sync(h);
   if (!be_ok(h)) return fail(h, KSOLVE_ERR_DEVICE, h->error.empty() ? "device allocation failed" : h->error);
@@ -1151,7 +1158,7 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
   int32_t* d_assign = nullptr; uint32_t* d_slot = nullptr; uint8_t* d_err = nullptr; uint8_t* d_diag = nullptr; uint32_t* d_last = nullptr; uint32_t* d_queue = nullptr;
   uint64_t* d_hot = nullptr; uint64_t* d_cold = nullptr; uint64_t* d_resv = nullptr; uint64_t* d_chp = nullptr; uint32_t* d_okey = nullptr; uint32_t* d_oord = nullptr; uint32_t* d_opos = nullptr;
   int* d_nclaims = nullptr; int* d_status = nullptr; ks::Counters* d_ctr = nullptr; ks::Workspace* d_items = nullptr;
-  size_t zero_from = 0, zero_to = 0;
+  size_t zero_from = 0, zero_to = 0, ones_to = 0;
   bool any_limits = false;
   for (uint32_t p = 0; p < n; ++p) any_limits = any_limits || (limits && limits[p]);
   auto layout = [&]() {
@@ -1184,6 +1191,15 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
         W.n_remaining = (int64_t*)take((size_t)nr * oc * 8);
         W.n_npods = (uint32_t*)take((size_t)oc * 4);
         W.n_hp = P.hp_on ? (uint64_t*)take((size_t)oc * 8) : nullptr;
+        if (base->has_topology) {
+          const ks::TopoView& T = P.topo;
+          const size_t G = (size_t)T.n_groups, dv = (size_t)T.dom_words * 64, hg = (size_t)std::max(1, T.n_host_groups);
+          W.tg_domains = (uint64_t*)take(G * T.dom_words * 8); W.tg_counts = (int32_t*)take(G * dv * 4); W.tg_regs = (int32_t*)take(G * dv * 4);
+          W.tg_node_counts = (int32_t*)take(hg * std::max(1u, ne) * 4); W.tg_claim_counts = (int32_t*)take(hg * mc * 4);
+          W.tg_nonzero = (int32_t*)take(G * 4); W.tg_alias_active = T.n_alias ? (int32_t*)take((size_t)T.n_alias * 4) : nullptr;
+          W.c_keymask = (uint64_t*)take((size_t)std::max(1, T.n_key_slots) * mc * 8);
+          W.kv_claims = (uint64_t*)take((size_t)std::max(1, T.n_key_slots) * 64 * cw * 8);
+        }
         if (P.pv_on) {
           size_t entries = 0;
           for (uint32_t i = pod_off[p]; i < pod_off[p + 1]; ++i) entries += base->h_pod_pv_first[pods[i] + 1] - base->h_pod_pv_first[pods[i]];
@@ -1193,7 +1209,12 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
       W.ov_cap = (int)oc;
     }
     zero_to = off;
-    d_assign = (int32_t*)take((size_t)total_pods * 4 + 4);   // starts as -1
+    d_assign = (int32_t*)take((size_t)total_pods * 4 + 4);   // starts as -1; so do the hostname-group threshold bitmaps (all claims below every threshold)
+    if (base->has_topology) for (uint32_t p = 0; p < n; ++p) {
+      const uint32_t mc = claim_base[p + 1] - claim_base[p], cw = (mc + 63) / 64;
+      items[p].host_le = (uint64_t*)take((size_t)std::max(1, P.topo.n_host_groups) * 2 * cw * 8);
+    }
+    ones_to = off;
   };
   layout();
   const size_t total = off;
@@ -1233,7 +1254,7 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
   if (total_nodes) be_h2d(base, d_removed, removed.data(), (size_t)total_nodes * 4);
   if (d_limits) be_h2d(base, d_limits, lim.data(), lim.size() * 8);
   be_fill(base, arena + zero_from, 0, zero_to - zero_from);
-  be_fill(base, d_assign, 0xFF, (size_t)total_pods * 4 + 4);
+  be_fill(base, arena + zero_to, 0xFF, ones_to - zero_to);
   be_h2d(base, base->d_pv, &P, sizeof(P));
   be_sync(base);
   be_toc(base, T_UPLOAD);
@@ -1346,6 +1367,45 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
   return KSOLVE_OK;
 }
 
+// Sweeps whose workspaces would not fit a sensible arena (a cluster with hostname topology groups needs a per-node counter table
+// per probe) run as several launches; the results are those of one.
+static ksolve_status sweep_run_chunked(ksolve_handle* base, uint32_t n, const uint32_t* node_off, const uint32_t* nodes, const uint32_t* pod_off, const uint32_t* pods,
+                                       const int64_t* const* limits, int* const* cancel, SweepImpl* im, double* us) {
+  size_t per_probe = 64 * 1024;
+  if (base->has_topology) {
+    const ks::TopoView& T = base->pv.topo;
+    per_probe += (size_t)std::max(1, T.n_host_groups) * std::max(1u, base->n_nodes) * 4 + (size_t)T.n_groups * T.dom_words * 64 * 8 + (size_t)T.n_groups * T.dom_words * 8;
+  }
+  size_t budget = (size_t)4 << 30;
+  if (const char* b = getenv("KSOLVE_SWEEP_ARENA_MB")) budget = (size_t)std::max(1, atoi(b)) << 20;   // tests: force several launches
+  const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n, budget / per_probe));
+  if (chunk >= n) return sweep_run(base, n, node_off, nodes, pod_off, pods, limits, cancel, im, us);
+  double total_us[4] = {0, 0, 0, 0};
+  im->claim_off.assign(1, 0);
+  for (uint32_t lo = 0; lo < n; lo += chunk) {
+    const uint32_t m = std::min(chunk, n - lo);
+    std::vector<uint32_t> no(m + 1), po(m + 1);
+    for (uint32_t i = 0; i <= m; ++i) { no[i] = node_off[lo + i] - node_off[lo]; po[i] = pod_off[lo + i] - pod_off[lo]; }
+    SweepImpl part;
+    double u[4] = {0, 0, 0, 0};
+    ksolve_status st = sweep_run(base, m, no.data(), nodes + node_off[lo], po.data(), pods + pod_off[lo], limits ? limits + lo : nullptr, cancel ? cancel + lo : nullptr, &part, u);
+    if (st != KSOLVE_OK) return st;
+    for (int k = 0; k < 4; ++k) total_us[k] += u[k];
+    auto app = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
+    app(im->status, part.status); app(im->assign, part.assign); app(im->err, part.err); app(im->diag, part.diag); app(im->slot, part.slot);
+    app(im->ref, part.ref); app(im->counters, part.counters);
+    const uint32_t c0 = im->claim_off.back();
+    for (uint32_t i = 1; i <= m; ++i) im->claim_off.push_back(c0 + part.claim_off[i]);
+    ResultsImpl& R = im->claims; const ResultsImpl& Q = part.claims;
+    app(R.tmpl, Q.tmpl); app(R.npods, Q.npods); app(R.its, Q.its); app(R.mask, Q.mask); app(R.defined, Q.defined); app(R.complement, Q.complement);
+    app(R.has_gte, Q.has_gte); app(R.has_lte, Q.has_lte); app(R.gte, Q.gte); app(R.lte, Q.lte); app(R.minv, Q.minv); app(R.requests, Q.requests);
+    app(R.host_seq, Q.host_seq); app(R.relaxed, Q.relaxed); app(R.cheapest, Q.cheapest); app(R.reserved, Q.reserved);
+    app(R.t_idx, Q.t_idx); app(R.t_cnt, Q.t_cnt); app(R.t_fail, Q.t_fail);
+  }
+  if (us) for (int k = 0; k < 4; ++k) us[k] = total_us[k];
+  return KSOLVE_OK;
+}
+
 static void fill_claims_view(const ksolve_handle* h, const ResultsImpl& R, size_t first, uint32_t count, ksolve_claims& cl) {
   cl.n_claims = count; cl.it_words = h->it_words; cl.req_words = h->req_words; cl.n_keys = h->n_keys; cl.n_res = h->n_res;
   cl.template_idx = R.tmpl.data() + first; cl.pod_count = R.npods.data() + first; cl.it_mask = R.its.data() + first * h->it_words; cl.requests = R.requests.data() + first * h->n_res;
@@ -1361,7 +1421,7 @@ static void fill_claims_view(const ksolve_handle* h, const ResultsImpl& R, size_
 static ksolve_status sweep(ksolve_handle* base, const ksolve_sweep_desc* d, ksolve_sweep_results* out) {
   memset(out, 0, sizeof(*out));
   if (!base || base->base || !d) return base ? fail(base, KSOLVE_ERR_INVALID, "sweep of a null handle / of a probe") : KSOLVE_ERR_INVALID;
-  if (base->has_topology) return fail(base, KSOLVE_ERR_UNSUPPORTED, "sweeps of a cluster with topology groups: create one handle per probe");
+  if (base->has_topology && !base->resident) return fail(base, KSOLVE_ERR_UNSUPPORTED, "sweeps of a problem with topology groups need a resident-cluster base (ksolve_problem_desc.pod_node): its counts include the candidates' pods");
   if (d->n_probes && (!d->node_off || !d->pod_off || (d->pod_off[d->n_probes] && !d->pods) || (d->node_off[d->n_probes] && !d->nodes)))
     return fail(base, KSOLVE_ERR_INVALID, "sweep descriptor arrays missing");
   const uint32_t n = d->n_probes;
@@ -1373,7 +1433,7 @@ static ksolve_status sweep(ksolve_handle* base, const ksolve_sweep_desc* d, ksol
   const uint32_t zero_off[1] = {0};
   be_fill(base, base->d_cancel, 0, 4);   // a fresh context, as in solve_prepare
   be_sync(base);
-  ksolve_status st = n ? sweep_run(base, n, d->node_off, d->nodes, d->pod_off, d->pods, d->tmpl_limits ? lims.data() : nullptr, nullptr, im, us) : KSOLVE_OK;
+  ksolve_status st = n ? sweep_run_chunked(base, n, d->node_off, d->nodes, d->pod_off, d->pods, d->tmpl_limits ? lims.data() : nullptr, nullptr, im, us) : KSOLVE_OK;
   if (!n) { im->claim_off.assign(1, 0); (void)zero_off; }
   if (st != KSOLVE_OK) { delete im; return st; }
   out->n_probes = n;
@@ -1497,7 +1557,7 @@ static void solve_probes(ksolve_handle** hs, uint32_t n, ksolve_results* outs, k
     }
   }
   SweepImpl S;
-  ksolve_status rc = sweep_run(base, n, node_off.data(), nodes.data(), pod_off.data(), pods.data(), any_lim ? lims.data() : nullptr, cancel.data(), &S, nullptr);
+  ksolve_status rc = sweep_run_chunked(base, n, node_off.data(), nodes.data(), pod_off.data(), pods.data(), any_lim ? lims.data() : nullptr, cancel.data(), &S, nullptr);
   for (uint32_t i = 0; i < n; ++i) {
     if (rc != KSOLVE_OK) { memset(&outs[i], 0, sizeof(outs[i])); st[i] = fail(hs[i], rc, base->error); outs[i].status = st[i]; continue; }
     st[i] = probe_results(hs[i], S, i, pod_off[i], &outs[i]);
@@ -1508,6 +1568,7 @@ static void solve_probes(ksolve_handle** hs, uint32_t n, ksolve_results* outs, k
 static void be_results_drop(ksolve_results* r) { if (r && r->impl) { delete (ResultsImpl*)r->impl; r->impl = nullptr; } }
 static ksolve_status solve(ksolve_handle* h, ksolve_results* out, bool fresh_context = true) {
   memset(out, 0, sizeof(*out));
+  if (h->resident && h->has_topology) return fail(h, KSOLVE_ERR_INVALID, "a resident cluster with topology groups is solved through probes (ksolve_sweep / ksolve_probe_create): its counts include the bound pod rows");
   if (h->base) { ksolve_status st = KSOLVE_OK; solve_probes(&h, 1, out, &st, fresh_context); return st; }
   ksolve_status st = solve_prepare(h, fresh_context);
   if (st != KSOLVE_OK) return st;

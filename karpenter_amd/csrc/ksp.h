@@ -117,6 +117,9 @@ struct TopoView {
   const int16_t* alias_class;     // [G] class id or -1 (null when n_alias == 0)
   uint64_t alias_mask[kMaxTopoWords];  // groups with alias_class >= 0
   const uint64_t* cls_topo;      // [n_classes][2*words] owned | selected (class_gather)
+  // resident clusters: where registered domains come from (a probe re-derives them without its removed nodes)
+  const uint64_t* dom_universe;  // [G][dom_words] offered by NodePools / instance types; null = not a resident cluster
+  const int32_t* dom_regs0;      // [G][dom_words*64] existing nodes that register the domain
 };
 
 struct ProblemView {
@@ -197,6 +200,7 @@ struct ProblemView {
   const uint64_t* node_taints;   // [n_nodes]
   const uint8_t* node_flags;     // [n_nodes] bit0 initialized, bit1 under consolidateAfter
   const uint8_t* pod_from_deleting; // [n_pods]
+  const int32_t* pod_node;       // [n_pods] resident clusters: the existing node a pod row is bound to, -1 = pending; null otherwise
   // CSI volume limits of existing nodes (VolumeUsage, volumeusage.go:178-209): volume = a distinct <driver, PVC> pair
   int pv_on, n_pv_drivers;       // pv_on: some node has a limit
   const uint8_t* pv_driver;      // [n_volumes]
@@ -265,6 +269,7 @@ struct Workspace {
   int32_t* tg_claim_counts;      // [n_host_groups][max_claims]   hostname groups: pods per in-flight claim
   int32_t* tg_nonzero;           // [G] number of domains with a positive count
   int32_t* tg_alias_active;      // [n_alias] the member of each alias class that exists, -1 = none yet
+  int32_t* tg_regs;              // [G][dom_words*64] probes of a resident cluster: nodes registering each domain without the removed ones (scratch of the probe's set-up)
   // queue (queue.go): circular buffer of pod ids + lastLen
   uint32_t* queue;               // [n_pods+1]
   uint32_t* last_len;            // [n_pods] 0 = never pushed

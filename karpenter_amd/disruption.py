@@ -318,12 +318,16 @@ class ResidentCluster:
         self._deleting_uids = {p["uid"] for p in self._deleting_pods}
         self._always = list(cluster.get("pendingPods", [])) + self._deleting_pods          # part of every simulation
         displaced = [p for c in candidates if not c.get("markedForDeletion") for p in c.get("pods", [])]
-        if any(_has_topology(p) for n in cluster["nodes"] for p in n.get("pods", [])) or any(_has_topology(p) for p in self._always):
-            raise Unsupported("probes of a cluster whose pods carry topology constraints")
+        # With topology constraints anywhere in the cluster, EVERY bound pod is a row of the base problem: the device counts the
+        # whole cluster once (options.residentCluster) and a probe takes its displaced pods' share out again (countDomains
+        # without the pods being scheduled, topology.go:92-94, :361-459)
+        topo = any(_has_topology(p) for n in cluster["nodes"] for p in n.get("pods", [])) or any(_has_topology(p) for p in self._always)
+        if topo:
+            displaced = [p for n in cluster["nodes"] if not n.get("markedForDeletion") for p in n.get("pods", [])]
         state_nodes = [{k: v for k, v in n.items() if k != "pods"} for n in cluster["nodes"] if not n.get("markedForDeletion")]
         prob = fx.problem(cluster["instanceTypes"], cluster["nodePools"], copy.deepcopy(self._always + displaced),
                           well_known=cluster.get("wellKnownLabels", fx.KWOK_WELL_KNOWN), state_nodes=state_nodes,
-                          options=dict(cluster.get("options", {}), consolidationSimulation=True, truncateInstanceTypes=MAX_INSTANCE_TYPES),
+                          options=dict(cluster.get("options", {}), consolidationSimulation=True, truncateInstanceTypes=MAX_INSTANCE_TYPES, residentCluster=True),
                           namespaces=cluster.get("namespaces"), deleting_node_names=[n["name"] for n in deleting])
         self.scheduler = NewScheduler(prob, solver_lib)
         self._cache = {}
@@ -405,7 +409,7 @@ class ResidentCluster:
 # state nodes as dicts (without their pods) and the bound pods as pod groups — {count, uidSeed, template, nodeIndex}: pod i of
 # the group runs on nodes[nodeIndex[i]] — which is also how the host library takes them (podGroups[].nodeIndexB64).
 # ---------------------------------------------------------------------------------------------------------------
-def make_resident_cluster(n_nodes=100_000, seed=42, n_types=144, dedicated_fraction=0.3, scale_down=0.3):
+def make_resident_cluster(n_nodes=100_000, seed=42, n_types=144, dedicated_fraction=0.3, scale_down=0.3, topology=False):
     """A synthetic under-utilised cluster in compact form, shaped like test/suites/performance/basic_test.go:61-68 (scale the
     workload out, let the provisioner pack nodes, scale it down by 30%): every node is packed with pods of the benchmark's
     cpu x memory grid (scheduling_benchmark_test.go:447-455) until its instance type is full, then pods are removed.
@@ -418,6 +422,8 @@ def make_resident_cluster(n_nodes=100_000, seed=42, n_types=144, dedicated_fract
                  a NodeClaim — a smaller instance type than the one they sit on (replace), the same type again (nothing to
                  do), or they all fit (delete).
     A few nodes are not initialized or are under consolidateAfter (helpers.go:133-153, scheduler.go:628).
+    topology=True: two fifths of the default pool's pod templates carry a spread constraint — zonal (maxSkew 2) over one of three
+    app labels, or per hostname (maxSkew 8) — so that every probe re-derives domain counts without its candidates.
     Returns {"instanceTypes", "nodePools", "wellKnownLabels", "nodes", "podGroups", "pendingPods", "nodePodCount"}."""
     import base64
     import numpy as np
@@ -508,6 +514,12 @@ def make_resident_cluster(n_nodes=100_000, seed=42, n_types=144, dedicated_fract
             if not len(sel):
                 continue
             kw = dict(requests={"cpu": f"{c}m", "memory": f"{m}Mi"}, phase="Running")
+            if topology and part < 0 and ci % 5 == 0:
+                lab = {"app": f"zonal-{ci % 3}"}
+                kw.update(labels=lab, topology_spread=[fx.spread(fx.ZONE, lab, max_skew=2)])
+            elif topology and part < 0 and ci % 5 == 1:
+                lab = {"app": f"host-{ci % 2}"}
+                kw.update(labels=lab, topology_spread=[fx.spread(fx.HOSTNAME, lab, max_skew=8)])
             if part >= 0:
                 kw.update(node_selector={PARTITION: parts[part]}, tolerations=[{"key": "dedicated", "operator": "Exists", "effect": "NoSchedule"}])
             groups.append({"count": int(len(sel)), "uidSeed": seed * 100003 + gi, "template": fx.pod(uid="t", **kw),
@@ -540,11 +552,22 @@ def compact_candidates(cc):
     return [i for _, _, i in keyed]
 
 
+def compact_cluster_pods(cc):
+    """Every bound pod of a compact cluster as a pod dict (uid, nodeName): the clusterPods of a problem assembled for one
+    simulation — what seeds the topology counts there (topology.go:361-459)."""
+    out = []
+    for g in cc["podGroups"]:
+        names = [cc["nodes"][i]["name"] for i in g["_nodeIndex"].tolist()]
+        for pos, nm in enumerate(names):
+            out.append(dict(g["template"], uid=fx.group_pod_uid(g["uidSeed"], pos), nodeName=nm))
+    return out
+
+
 def compact_problem(cc, pods=None, pod_groups=None, strip=True):
     groups = [{k: v for k, v in g.items() if not k.startswith("_")} for g in (cc["podGroups"] if pod_groups is None else pod_groups)]
     # maxClaims: the base handle of a resident cluster is never solved itself; a probe may create this many NodeClaims
     return fx.problem(cc["instanceTypes"], cc["nodePools"], pods or [], pod_groups=groups, well_known=cc["wellKnownLabels"], state_nodes=cc["nodes"],
-                      options=dict(cc.get("options", {}), consolidationSimulation=True, truncateInstanceTypes=MAX_INSTANCE_TYPES, maxClaims=cc.get("maxClaimsPerProbe", 2048)))
+                      options=dict(cc.get("options", {}), consolidationSimulation=True, truncateInstanceTypes=MAX_INSTANCE_TYPES, maxClaims=cc.get("maxClaimsPerProbe", 2048), residentCluster=True))
 
 
 def decide(cluster, candidates, res):

@@ -615,6 +615,7 @@ struct Session {
   std::vector<std::vector<OffLite>> it_offerings;
   std::vector<std::vector<Expr>> it_exprs;
   bool sweep_tables = false;
+  bool strict_shared = false;              // no pod has a preference: PodData.StrictRequirements IS Requirements, one table on the device
   // a probe session: shares the base session's metadata, owns its handle
   Session* base = nullptr;
   std::vector<uint8_t> probe_member, probe_removed;
@@ -899,6 +900,25 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     }
     std::stable_sort(nodes.begin(), nodes.end(), [](const NodeIn& a, const NodeIn& b) { if (a.initialized != b.initialized) return a.initialized; return a.name < b.name; });
     const int n_nodes = (int)nodes.size();
+    // the existing node every pod is bound to (sorted index), -1 = none: explicit pods by nodeName, group pods by nodeIndex
+    std::vector<int32_t> pod_node_sorted(n_pods, -1);
+    std::vector<int32_t> node_input_index;
+    {
+      std::map<std::string, int> sorted_index;
+      for (int e = 0; e < n_nodes; ++e) sorted_index[nodes[e].name] = e;
+      const auto& sn = root.at("stateNodes").items();
+      node_input_index.assign(sn.size(), -1);
+      for (size_t i = 0; i < sn.size(); ++i) { auto f = sorted_index.find(sn[i].at("name").s()); if (f != sorted_index.end()) node_input_index[i] = f->second; }
+      std::vector<int> spec_node(specs.size(), -2);
+      for (int p = 0; p < n_pods; ++p) {
+        if (pod_node_input[p] >= 0) { pod_node_sorted[p] = pod_node_input[p] < (int)node_input_index.size() ? node_input_index[pod_node_input[p]] : -1; continue; }
+        int& sn_ = spec_node[pod_spec[p]];
+        if (sn_ == -2) { auto f = sorted_index.find(specs[pod_spec[p]].node_name); sn_ = f == sorted_index.end() ? -1 : f->second; }
+        pod_node_sorted[p] = sn_;
+      }
+    }
+    // options.residentCluster: the problem is a whole cluster — bound pods are pod rows, every simulation is a probe (ksolve_sweep)
+    const bool resident = opts.at("residentCluster").boolean_or(false);
     std::vector<std::vector<Expr>> node_exprs(n_nodes);
     std::vector<uint64_t> node_taints(n_nodes, 0);
     // Every requirement source other than the nodes has been noted by now. When none of them mentions kubernetes.io/hostname
@@ -1403,6 +1423,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       std::vector<std::vector<Expr>> freqs; uint64_t ftol = 0;
       std::string identity;
       std::set<std::string> domains; std::map<std::string, int> counts;
+      std::set<std::string> universe; std::map<std::string, int> node_regs;   // resident clusters: where a registered domain comes from
       std::string content() const {
         std::string c = identity + "|md" + std::to_string(min_domains) + "|tol" + std::to_string(ftol) + "|";
         for (auto& d : domains) c += d + ",";
@@ -1478,8 +1499,11 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       }
       std::map<std::string, int> node_by_name;
       for (int e = 0; e < n_nodes; ++e) node_by_name[nodes[e].name] = e;
+      // a resident cluster counts its bound pods although they are pod rows: a probe takes its displaced pods' share out again
+      std::vector<std::vector<int32_t>> spec_bound_nodes(specs.size());
+      if (resident) for (int p = 0; p < n_pods; ++p) if (pod_node_sorted[p] >= 0) spec_bound_nodes[pod_spec[p]].push_back(pod_node_sorted[p]);
       std::set<std::string> excluded;   // pods being scheduled are not counted from the cluster (topology.go:92-94)
-      if (!cluster_pods.empty()) for (int p = 0; p < n_pods; ++p) {
+      if (!cluster_pods.empty() && !resident) for (int p = 0; p < n_pods; ++p) {
         if (!uid_text[p].empty()) excluded.insert(uid_text[p]);
         else { std::string t; uint64_t a, b; group_uid(group_of_pod[p].first, group_of_pod[p].second, a, b, &t); excluded.insert(t); }
       }
@@ -1526,6 +1550,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
           if (!ok) for (uint64_t taints : kv.second) if (!(taints & ~ptol)) { ok = true; break; }
           if (ok) g.domains.insert(kv.first);
         }
+        g.universe = g.domains;
         return g;
       };
       // countDomains — topology.go:361-459
@@ -1534,7 +1559,25 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
           if (!nodes[e].v->at("hasNode").boolean_or(true)) continue;
           if (!filter_matches(g, node_taints[e], node_label_reqs[e])) continue;
           auto it = node_labels[e].find(g.key);
-          if (it != node_labels[e].end()) g.domains.insert(it->second);
+          if (it != node_labels[e].end()) { g.domains.insert(it->second); g.node_regs[it->second]++; }
+        }
+        if (resident) {
+          // the bound pod rows, spec by spec (a 2M-pod cluster is a few hundred specs)
+          std::vector<int8_t> node_ok(n_nodes, -1);
+          for (size_t si = 0; si < specs.size(); ++si) {
+            if (spec_bound_nodes[si].empty() || !g.namespaces.count(specs[si].ns) || (!g.sel.nil && !g.sel.matches(specs[si].labels))) continue;
+            if (specs[si].phase == "Failed" || specs[si].phase == "Succeeded") continue;
+            for (int32_t e : spec_bound_nodes[si]) {
+              std::string dom;
+              auto it = node_labels[e].find(g.key);
+              if (it != node_labels[e].end()) dom = it->second;
+              else if (g.key == kHostname) dom = nodes[e].name;
+              else continue;
+              if (node_ok[e] < 0) node_ok[e] = filter_matches(g, node_taints[e], node_label_reqs[e]) ? 1 : 0;
+              if (!node_ok[e]) continue;
+              g.counts[dom]++; g.domains.insert(dom);
+            }
+          }
         }
         for (auto& cp : cluster_pods) {
           if (!g.namespaces.count(cp.ns)) continue;
@@ -1576,6 +1619,11 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         auto nf = node_by_name.find(cp.node_name);
         if (nf == node_by_name.end()) continue;
         inverse_for(cp, nf->second);
+      }
+      if (resident) for (size_t si = 0; si < specs.size(); ++si) {
+        if (spec_bound_nodes[si].empty() || !(specs[si].has_pod_anti && !specs[si].anti_required.empty())) continue;
+        const std::vector<int> ids = inverse_for(specs[si], -1);
+        for (int id : ids) for (int32_t e : spec_bound_nodes[si]) { auto it = node_labels[e].find(inverse[id].key); if (it != node_labels[e].end()) { inverse[id].counts[it->second]++; inverse[id].domains.insert(it->second); } }
       }
       std::vector<std::vector<std::vector<int>>> variant_groups(specs.size());
       std::map<std::string, int> group_by_identity;
@@ -1653,7 +1701,8 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     std::vector<int32_t> tg_key(G), tg_skew(G), tg_mind(G), tg_alias(G, -1);
     std::vector<uint32_t> tg_ffirst(G + 1, 0);
     std::vector<uint64_t> tg_ftol(G), tg_domains;
-    std::vector<int32_t> tg_counts, tg_node_counts;
+    std::vector<int32_t> tg_counts, tg_node_counts, tg_regs;
+    std::vector<uint64_t> tg_universe;
     std::vector<uint16_t> value_rank((size_t)rw * 64, 0);
     std::vector<int32_t> node_host_value(std::max(1, n_nodes), -1);
     std::vector<uint64_t> pod_topo_owned, pod_topo_selected;
@@ -1662,6 +1711,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     if (G) {
       for (auto& g : groups) if (g.key != kHostname) { int k = D.key_index.at(g.key); dom_words = std::max(dom_words, fl.key_word_off[k + 1] - fl.key_word_off[k]); }
       tg_domains.assign((size_t)G * dom_words, 0); tg_counts.assign((size_t)G * dom_words * 64, 0); tg_node_counts.assign((size_t)G * std::max(1, n_nodes), 0);
+      if (resident) { tg_universe.assign((size_t)G * dom_words, 0); tg_regs.assign((size_t)G * dom_words * 64, 0); }
       int n_f = 0;
       for (auto& g : groups) n_f += (int)g.freqs.size();
       tg_freqs.init(std::max(1, n_f), rw, nk);
@@ -1696,6 +1746,10 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
           tg_domains[(size_t)gi * dom_words + vi->second / 64] |= 1ull << (vi->second % 64);
         }
         for (auto& kv : g.counts) tg_counts[(size_t)gi * dom_words * 64 + D.value_index[k].at(kv.first)] = kv.second;
+        if (resident) {
+          for (auto& dom : g.universe) { const int v = D.value_index[k].at(dom); tg_universe[(size_t)gi * dom_words + v / 64] |= 1ull << (v % 64); }
+          for (auto& kv : g.node_regs) tg_regs[(size_t)gi * dom_words * 64 + D.value_index[k].at(kv.first)] = kv.second;
+        }
       }
       tg_ffirst[G] = (uint32_t)fi;
       for (int k = 0; k < nk; ++k) {
@@ -1769,6 +1823,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       if (!deleting.empty()) for (int p = 0; p < n_pods; ++p) if (deleting.count(specs[pod_spec[p]].node_name)) pod_from_deleting[p] = 1;
     }
     d.pod_from_deleting_node = pod_from_deleting.data();
+    if (resident) d.pod_node = pod_node_sorted.data();
     if (!pv_drivers.empty()) {
       d.n_volume_drivers = (uint32_t)pv_drivers.size(); d.n_volumes = (uint32_t)volume_driver.size(); d.volume_driver = volume_driver.data();
       d.pod_pv_first = pod_pv_first.data(); d.pod_pvs = pod_pvs.data(); d.node_pv_first = node_pv_first.data(); d.node_pvs = node_pvs.data();
@@ -1782,6 +1837,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       t.filter_affinity_honor = tg_fa.data(); t.filter_taint_honor = tg_ft.data(); t.filter_first = tg_ffirst.data(); t.filter_reqs = tg_freqs.view();
       t.filter_tolerates = tg_ftol.data(); t.value_rank = value_rank.data(); t.node_hostname_value = node_host_value.data();
       if (n_alias_classes) { t.alias_class = tg_alias.data(); t.n_alias_classes = (uint32_t)n_alias_classes; }
+      if (resident) { t.domain_universe = tg_universe.data(); t.domain_node_regs = tg_regs.data(); }
       S->n_topo_groups = G; S->n_alias_classes = n_alias_classes;
       d.pod_topo_owned = pod_topo_owned.data(); d.pod_topo_selected = pod_topo_selected.data();
     }
@@ -1811,22 +1867,11 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     for (int i = 0; i < n_its; ++i) S->it_names.push_back(its_json[i].at("name").s());
     S->k_rid = k_rid;
     S->n_pods = n_pods; S->n_rows = n_rows; S->n_its = n_its; S->n_res = n_res; S->it_words = it_words;
-    S->n_templates = n_templates; S->tmpl_lim = tmpl_lim;
+    S->n_templates = n_templates; S->tmpl_lim = tmpl_lim; S->strict_shared = !strict_differs;
     // what ksched_sweep needs: the node of every pod, its pending / deleting flags, offerings and requirement values per type
     {
-      std::map<std::string, int> sorted_index;
-      for (size_t e = 0; e < S->node_names.size(); ++e) sorted_index[S->node_names[e]] = (int)e;
-      const auto& sn = root.at("stateNodes").items();
-      S->node_input_index.assign(sn.size(), -1);
-      for (size_t i = 0; i < sn.size(); ++i) { auto f = sorted_index.find(sn[i].at("name").s()); if (f != sorted_index.end()) S->node_input_index[i] = f->second; }
-      S->pod_node.assign(n_pods, -1);
-      std::vector<int> spec_node(specs.size(), -2);
-      for (int p = 0; p < n_pods; ++p) {
-        if (pod_node_input[p] >= 0) { S->pod_node[p] = pod_node_input[p] < (int)S->node_input_index.size() ? S->node_input_index[pod_node_input[p]] : -1; continue; }
-        int& sn_ = spec_node[pod_spec[p]];
-        if (sn_ == -2) { auto f = sorted_index.find(specs[pod_spec[p]].node_name); sn_ = f == sorted_index.end() ? -1 : f->second; }
-        S->pod_node[p] = sn_;
-      }
+      S->node_input_index = node_input_index;
+      S->pod_node = pod_node_sorted;
       S->pod_pending_flag.assign(pod_pending.begin(), pod_pending.end());
       S->pod_deleting_flag.assign(pod_from_deleting.begin(), pod_from_deleting.begin() + n_pods);
       S->it_offerings.resize(n_its);
@@ -2156,7 +2201,7 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
     counters.set("slowSorts", Value::integer((int64_t)res.slow_sorts)); counters.set("relaxations", Value::integer((int64_t)res.relaxations));
     counters.set("pods", Value::integer(own->base ? own->probe_pods : n_pods)); counters.set("claims", Value::integer(cl.n_claims));
     counters.set("engine", Value::string(res.engine_used == 2 ? "cursor" : "general")); counters.set("engineFallbackReason", Value::integer((int64_t)res.engine_fallback_reason));
-    counters.set("rows", Value::integer(n_rows)); counters.set("instanceTypes", Value::integer(n_its));
+    counters.set("rows", Value::integer(n_rows)); counters.set("instanceTypes", Value::integer(n_its)); counters.set("strictTableShared", Value::boolean(S->strict_shared));
     counters.set("topologyGroups", Value::integer(S->n_topo_groups)); counters.set("topologyAliasClasses", Value::integer(S->n_alias_classes));
     counters.set("reqWords", Value::integer(rw)); counters.set("itWords", Value::integer(it_words)); counters.set("keys", Value::integer(nk)); counters.set("resources", Value::integer(n_res));
     { Value pc = Value::array(); for (int i = 0; i < 24; ++i) pc.push(Value::integer((int64_t)res.phase_cycles[i])); counters.set("phaseCycles", pc); }

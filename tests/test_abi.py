@@ -192,3 +192,51 @@ def test_only_tests_smoke_and_bench_touch_the_oracle():
                 if re.search(r"^\s*(import|from)\s+oracle\b", text, re.M) or re.search(r"\bimport\s+[\w, ]*\boracle\b", text) or "liboracle" in text:
                     bad.append(os.path.relpath(path, ROOT))
     assert not bad, bad
+
+
+def test_go_binding_uses_only_members_the_reference_declares():
+    """The Go side of the boundary: go/ksolve_*.go live in the reference's package scheduling and read its unexported state
+    (Scheduler.nodeClaimTemplates, Topology.topologyGroups, ExistingNode.remainingResources, ...). They cannot be compiled here
+    (no Go toolchain), so — like the header check above — every member they select on those types must exist under that name
+    in the reference checkout (struct field, embedded type or method). Skipped where the checkout is absent (the GPU box)."""
+    import glob
+    ref = "/root/reference/pkg/controllers/provisioning/scheduling"
+    if not os.path.isdir(ref):
+        pytest.skip("no reference checkout on this machine")
+    sources = [open(f).read() for f in glob.glob(ref + "/*.go") if not f.endswith("_test.go")]
+
+    def members(type_name):
+        out = set()
+        for t in sources:
+            m = re.search(r"type %s struct \{(.*?)\n\}" % type_name, t, re.S)
+            if m:
+                for line in m.group(1).split("\n"):
+                    mm = re.match(r"\t(\*?[\w.]+)(\s|$)", line)
+                    if mm and not line.strip().startswith("//"):
+                        out.add(mm.group(1).lstrip("*").split(".")[-1])      # a field, or the name of an embedded type
+            out |= set(re.findall(r"func \(\w+ \*?%s\) (\w+)\(" % type_name, t))
+        return out
+    text = "".join(open(os.path.join(ROOT, "go", f)).read() for f in ("ksolve_flatten.go", "ksolve_rehydrate.go", "ksolve_shim.go"))
+    text = re.sub(r"//[^\n]*", "", text)                                     # comments name things too
+    checks = {"Scheduler": r"(?<![\w.])s\.([A-Za-z_]\w*)", "Topology": r"\bs\.topology\.([A-Za-z_]\w*)", "PodData": r"\brow\.data\.([A-Za-z_]\w*)"}
+    used_any = 0
+    for type_name, pattern in checks.items():
+        have = members(type_name)
+        assert have, type_name
+        used = set(re.findall(pattern, text))
+        used_any += len(used)
+        missing = sorted(u for u in used if u not in have)
+        assert not missing, (type_name, missing)
+    # members of ExistingNode / NodeClaim / TopologyGroup the binding reads through loop variables
+    for type_name, names in {"ExistingNode": ["remainingResources", "requirements", "cachedTaints", "Pods"], "NodeClaim": ["Pods", "NodeClaimTemplate", "reservedOfferings", "hostname"],
+                             "TopologyGroup": ["domains", "emptyDomains", "maxSkew", "minDomains", "nodeFilter", "owners", "Key", "Type"], "Topology": ["topologyGroups", "inverseTopologyGroups"]}.items():
+        have = members(type_name)
+        for nm in names:
+            if re.search(r"\.%s\b" % nm, text):
+                assert nm in have, (type_name, nm)
+                used_any += 1
+    assert used_any > 20
+    # accessors the binding adds to pkg/scheduling must not collide with something the reference already has
+    sched = "".join(open(f).read() for f in glob.glob("/root/reference/pkg/scheduling/*.go") if not f.endswith("_test.go"))
+    assert "func (u *HostPortUsage) Reserved(" not in sched and "func (v *VolumeUsage) Tracked(" not in sched
+    assert "reserved " in re.search(r"type HostPortUsage struct \{(.*?)\n\}", sched, re.S).group(1) and "limits " in re.search(r"type VolumeUsage struct \{(.*?)\n\}", sched, re.S).group(1)

@@ -557,16 +557,6 @@ def test_resident_cluster_probes_match_per_probe_rebuild(oracle, emu, seed, limi
     rc.close()
 
 
-def test_resident_cluster_declines_topology(emu):
-    from karpenter_amd.scheduling import Unsupported
-    cluster = dz.make_cluster(n_nodes=6, pods_per_node=2, seed=1)
-    lab = {"app": "x"}
-    cluster["nodes"][0]["pods"][0]["labels"] = lab
-    cluster["nodes"][0]["pods"][0]["topologySpreadConstraints"] = [fx.spread(fx.ZONE, lab)]
-    with pytest.raises(Unsupported):
-        dz.ResidentCluster(cluster, cluster["nodes"][:2], solver_lib=emu)
-
-
 def test_probe_api_rejects_bad_descriptors(emu):
     cluster = dz.make_cluster(n_nodes=6, pods_per_node=2, seed=2)
     rc = dz.ResidentCluster(cluster, cluster["nodes"][:3], solver_lib=emu)
@@ -612,3 +602,54 @@ def test_resident_cluster_probes_with_volume_limits(oracle, emu):
     free = dz.sweep(cluster, cands, oracle.solve)
     placed = lambda cmds: [sorted((e["name"], tuple(e["pods"])) for e in c["results"]["existingNodes"] if e["pods"]) for c in cmds]
     assert placed(free) != placed(want)
+
+
+def _topology_cluster(seed, n_nodes=40):
+    """A cluster whose bound pods carry topology constraints: zonal and hostname spread, zonal self-affinity, hostname
+    anti-affinity (a cluster pod's anti-affinity is an inverse group for everything that moves), one pod per node without any."""
+    import random
+    rng = random.Random(seed)
+    cluster = dz.make_cluster(n_nodes=n_nodes, pods_per_node=4, seed=seed, utilisation=0.6)
+    web, db, batch = {"app": "web"}, {"app": "db"}, {"app": "batch"}
+    for n in cluster["nodes"]:
+        for j, p in enumerate(n["pods"]):
+            r = rng.random()
+            if r < 0.25:
+                p["labels"] = web; p["topologySpreadConstraints"] = [fx.spread(fx.ZONE, web, max_skew=rng.choice([1, 2]))]
+            elif r < 0.45:
+                p["labels"] = batch; p["topologySpreadConstraints"] = [fx.spread(fx.HOSTNAME, batch, max_skew=rng.choice([2, 3]))]
+            elif r < 0.55:
+                p["labels"] = db; p["podAntiAffinity"] = {"required": [fx.affinity_term(fx.HOSTNAME, db)]}
+            elif r < 0.65:
+                p["labels"] = {"app": "cache"}; p["podAffinity"] = {"required": [fx.affinity_term(fx.ZONE, {"app": "cache"})]}
+            elif r < 0.7:
+                p["labels"] = web      # counted by the web spread, constrains nothing itself
+    return cluster
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_resident_cluster_probes_with_topology(oracle, emu, seed):
+    """Probes of a resident cluster whose pods carry topology constraints: the cluster is counted ONCE on the device (every bound
+    pod, every node's domains) and each probe takes its candidates' share out — the removed nodes' per-node counters and domain
+    registrations, the displaced pods' counts in the groups that select them and in the inverse anti-affinity groups they own —
+    which is what NewTopology / countDomains give for the simulation (topology.go:68-103, :310-355, :361-459). Compared, probe by
+    probe, with the oracle solving SimulateScheduling assembled from scratch (staying pods as cluster pods)."""
+    import random
+    cluster = _topology_cluster(seed)
+    cands = [n for n in dz.sort_candidates(cluster, cluster["nodes"]) if not n.get("markedForDeletion")][:12]
+    got, rc = dz.sweep_resident(cluster, cands, solver_lib=emu)
+    want = dz.sweep(cluster, cands, oracle.solve)
+    for g, w in zip(got, want):
+        parity.assert_same_results(g["results"], w["results"])
+        assert g["results"]["counters"]["referenceBinEvaluations"] == w["results"]["counters"]["binEvaluations"]
+    assert [strip(c) for c in got] == [strip(c) for c in want]
+    fast = rc.decisions([[c] for c in cands])
+    assert [(c["decision"], c["replacement"]) for c in fast] == [(c["decision"], c["replacement"]) for c in want]
+    rng = random.Random(seed)
+    sets = [rng.sample(cands, k) for k in (2, 4)]
+    rc.prefetch(sets)
+    for cs in sets:
+        g, w = dz.compute_consolidation(cluster, cs, rc), dz.compute_consolidation(cluster, cs, oracle.solve)
+        parity.assert_same_results(g["results"], w["results"])
+        assert strip(g) == strip(w)
+    rc.close()

@@ -476,3 +476,53 @@ def test_row_hash_collisions_are_reported_on_the_device(oracle, monkeypatch):
     for kernel in ("coop1", "plain"):    # the previous kernels (A/B switch of the launcher) class the rows alike
         monkeypatch.setenv("KSOLVE_ROWHASH_KERNEL", kernel)
         check(oracle, prob)
+
+
+def test_volume_usage_limits_on_the_device(oracle):
+    """VolumeUsage.ExceedsLimits / Add on existing nodes (volumeusage.go:193-209, existingnode.go:88, :179) on the GPU: the
+    reference's known answers, the seeded fuzz, and probes of a resident cluster with CSI attach limits."""
+    import test_reference_known_answers as tk
+    import test_disruption as td
+    tk.test_volume_usage_limits_on_existing_nodes(oracle, None)
+    tk.test_volume_usage_limits_fuzz(oracle, None)
+    td.test_resident_cluster_probes_with_volume_limits(oracle, None)
+
+
+@pytest.mark.parametrize("seed", [11, 13])
+def test_resident_cluster_probes_with_topology_on_the_device(oracle, seed):
+    """Probes of a resident cluster whose pods carry spread / affinity / anti-affinity constraints (the device counts the
+    cluster once, every probe takes its candidates' share out): tests/test_disruption.py's comparison with libksolve.so."""
+    import test_disruption as td
+    td.test_resident_cluster_probes_with_topology(oracle, None, seed)
+
+
+def test_consolidation_sweep_over_a_10k_node_cluster_with_topology_pods(oracle, monkeypatch):
+    """BASELINE configs[4] shape at a tenth of its size: a resident cluster of 10k nodes / ~195k bound pods, two fifths of the
+    default pool's pod templates with zonal or hostname spread constraints, 1000 single-node candidates through ksolve_sweep —
+    in several launches (the arena budget is lowered so that the chunked path runs too). Sampled probes of every verdict are
+    re-simulated by the oracle (a fresh Scheduler over the cluster without the candidate, the other bound pods as cluster
+    pods): decision, replacement and the reference-equivalent evaluation count must be identical."""
+    import random
+    from collections import Counter
+    from karpenter_amd import disruption as dz
+    monkeypatch.setenv("KSOLVE_SWEEP_ARENA_MB", "256")
+    cc = dz.make_resident_cluster(n_nodes=10_000, seed=7, topology=True)
+    rc = dz.ResidentCluster.from_compact(cc)
+    order = dz.compact_candidates(cc)
+    order = order[::len(order) // 1000][:1000]
+    cmds = rc.decisions([[cc["nodes"][i]] for i in order])
+    verdicts = Counter(c["decision"] for c in cmds)
+    assert set(verdicts) == {dz.DELETE, dz.REPLACE, dz.NOOP}, verdicts
+    rng = random.Random(3)
+    sample = []
+    for d in sorted(verdicts):
+        sample += rng.sample([j for j, c in enumerate(cmds) if c["decision"] == d], 3)
+    base = dz.compact_problem(cc, pod_groups=[])
+    base["clusterPods"] = dz.compact_cluster_pods(cc)
+    probes = [{"removeNodes": [cc["nodes"][order[j]]["name"]], "pods": dz.compact_node_pods(cc, order[j])} for j in sample]
+    res = oracle.sweep(base, probes, threads=min(len(probes), os.cpu_count() or 1))
+    for j, r, pr in zip(sample, res, probes):
+        want = dz.decide(cc, [dict(cc["nodes"][order[j]], pods=pr["pods"])], dz._finish_simulation(cc, r, set()))
+        assert (cmds[j]["decision"], cmds[j]["replacement"]) == (want["decision"], want["replacement"]), (j, cmds[j], want["decision"])
+        assert rc.last_sweep["referenceBinEvaluations"][j] == r["counters"]["binEvaluations"]
+    rc.close()

@@ -12,9 +12,10 @@ from karpenter_amd import disruption as dz  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("nodes", type=int); ap.add_argument("candidates", type=int); ap.add_argument("sample", type=int, nargs="?", default=32)
 ap.add_argument("--solver-lib", default=None); ap.add_argument("--seed", type=int, default=42); ap.add_argument("--repeat", type=int, default=2)
+ap.add_argument("--topology", action="store_true", help="two fifths of the default pool's pod templates carry spread constraints")
 args = ap.parse_args()
 out = {"nodes": args.nodes}
-t = time.time(); cc = dz.make_resident_cluster(n_nodes=args.nodes, seed=args.seed); out["generate_s"] = time.time() - t
+t = time.time(); cc = dz.make_resident_cluster(n_nodes=args.nodes, seed=args.seed, topology=args.topology); out["generate_s"] = time.time() - t
 out["bound_pods"] = sum(g["count"] for g in cc["podGroups"])
 t = time.time(); rc = dz.ResidentCluster.from_compact(cc, solver_lib=args.solver_lib); out["new_scheduler_s"] = time.time() - t
 order = dz.compact_candidates(cc)
@@ -35,6 +36,8 @@ if args.sample:
     for d, js in sorted(by_dec.items()):   # every verdict is represented
         sample += rng.sample(js, min(len(js), max(1, args.sample // len(by_dec))))
     base = dz.compact_problem(cc, pod_groups=[])
+    if args.topology:
+        base["clusterPods"] = dz.compact_cluster_pods(cc)   # the oracle counts domains from them, minus the pods of the probe (excludedPods)
     probes = [{"removeNodes": [cc["nodes"][order[j]]["name"]], "pods": dz.compact_node_pods(cc, order[j])} for j in sample]
     threads = min(len(probes), os.cpu_count() or 1)
     t = time.time(); res = oracle.sweep(base, probes, threads=threads); out["oracle_s"] = time.time() - t; out["oracle_threads"] = threads
