@@ -152,7 +152,7 @@ KS_FN T* fast_uniform(T* p) {
 #endif
 
 // requirement-set cache helpers (per lane)
-KS_FN uint32_t fast_hash(uint64_t vm) { return (uint32_t)((vm * 0x9E3779B97F4A7C15ull) >> 40) & (kFastEnt - 1); }
+KS_FN uint32_t fast_hash(uint64_t vm) { return (uint32_t)((vm * 0x9E3779B97F4A7C15ull) >> 54) & (kFastEnt - 1); }   // the TOP bits of the product: the only ones every input bit reaches (the template id sits in bits 56..63)
 // entry of requirement set vm (copied to `out`), or -1 (not cached yet); one 32-byte LDS read per probe
 KS_FN int fast_lookup(const KS_LDS FastEnt* ent, uint64_t vm, FastEnt& out) {
   uint32_t h = fast_hash(vm);
@@ -736,7 +736,7 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
         lds_put(&cst[wx.at(l)], fs_); okey[p0_ + l] = (uint16_t)wk.at(l); oord[p0_ + l] = (uint16_t)wx.at(l); \
       } \
     }); \
-    W::sync(); win_live = false; }
+    W::sync(); win_live = false; KS_SEC(ts6) }
   const bool mid_n = n > 12 && n < 50;
   const uint32_t e1 = n >= 50 ? (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u, e2 = n >= 50 ? 2u * (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u, e3 = n >= 50 ? 3u * (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u;
 #ifdef KSOLVE_PHASE_TIMERS
@@ -850,6 +850,10 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
           });
           win_live = true;
         }
+        KS_SEC(ts1)   // window load
+#ifdef KSOLVE_PHASE_TIMERS
+        ts5++;
+#endif
       }
       if (win_live) {
         bool placed = false;
@@ -872,6 +876,7 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
             return (base_ok & simple & fit) | ((base_ok & ((simple ^ 1) | ((fit ^ 1) & (int)(((e.info >> 8) & 0xFFu) != 0)))) << 1);
           }, okm, oddm);
           uint64_t missm = 0;
+          oddm &= okm ? (okm & (0ull - okm)) - 1ull : ~0ull;   // only the lanes before the first plain acceptor can change the answer
           if (KS_UNLIKELY(oddm != 0)) {
             // rare: a second probe of the cache, or the other Pareto vectors of the requirement set
             const uint64_t mm = oddm;
@@ -887,6 +892,7 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
           }
           const int first_ok = okm ? ctz64(okm) : 64;
           const bool uncached = missm != 0 && ctz64(missm) < first_ok;   // the scan below raises the event (after the flush)
+          KS_SEC(ts2)   // window test
           if (!okm && !uncached) {
             // every claim of the window from the cursor on rejects the class for good: the scan goes on behind the window
             const uint32_t pe = (uint32_t)(p0 + wn);
@@ -945,6 +951,7 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
             }
           }
         }
+        KS_SEC(ts4)   // window commit
         if (placed) { bi++; steps++; continue; }
         if (!win_beyond) KS_WIN_FLUSH()   // this entry takes the paths below; the next one loads the window again
       }
@@ -1139,6 +1146,7 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
         return (base_ok & simple & fit) | ((base_ok & ((simple ^ 1) | ((fit ^ 1) & (int)(((e.info >> 8) & 0xFFu) != 0)))) << 1);
       }, okm, oddm);
       uint64_t missm = 0;
+      oddm &= okm ? (okm & (0ull - okm)) - 1ull : ~0ull;   // only the lanes before the first plain acceptor can change the answer
       if (KS_UNLIKELY(oddm != 0)) {
         // rare: resolve those lanes with the full probe sequence / all Pareto vectors
         const uint64_t mm = oddm;
