@@ -349,8 +349,10 @@ ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out);
 ksolve_status ksolve_solve_batch(ksolve_handle** handles, uint32_t n, ksolve_results* outs);
 /* A handle for one probe of `base` (see ksolve_probe). `base` must outlive it and must not be solved concurrently with it;
  * results use the base problem's pod and node numbering (pods outside the probe: assignment -1, error 0; removed nodes take
- * no pods). Works with ksolve_solve, ksolve_solve_batch, ksolve_cancel, ksolve_destroy. KSOLVE_ERR_UNSUPPORTED when the base
- * problem has topology groups (their per-probe counts are not derived yet: such sweeps create one handle per probe). */
+ * no pods). Works with ksolve_solve, ksolve_solve_batch, ksolve_cancel, ksolve_destroy. A base problem with topology groups
+ * must be a RESIDENT CLUSTER (ksolve_problem_desc.pod_node: the domain counts include every bound pod row, the domain universe
+ * and the per-domain node registrations are given apart): a probe then takes its candidates' share out of its own copy of the
+ * counters (topology.go:68-103, :310-355, :361-459). KSOLVE_ERR_UNSUPPORTED for topology groups on any other base. */
 ksolve_status ksolve_probe_create(ksolve_handle* base, const ksolve_probe* probe, ksolve_handle** out);
 /* A whole consolidation sweep in ONE call: n_probes simulations of the resident cluster `base` — single-node consolidation
  * tries every candidate (singlenodeconsolidation.go:55-126), multi-node consolidation every prefix its binary search can reach
@@ -385,8 +387,9 @@ typedef struct {
   void* impl;
 } ksolve_sweep_results;
 
-/* Runs the sweep. One sweep (or solve) per base handle at a time. KSOLVE_ERR_UNSUPPORTED when the base problem has topology
- * groups (see ksolve_probe_create). The function's status is that of the call (arguments, device); each simulation's own
+/* Runs the sweep. One sweep (or solve) per base handle at a time. Topology groups: see ksolve_probe_create (resident-cluster
+ * bases only). Sweeps whose probes need more workspace than the arena budget (KSOLVE_SWEEP_ARENA_MB, default 4096) run as
+ * several launches inside the call. The function's status is that of the call (arguments, device); each simulation's own
  * status is in results.status. */
 ksolve_status ksolve_sweep(ksolve_handle* base, const ksolve_sweep_desc* desc, ksolve_sweep_results* out);
 void ksolve_sweep_results_free(ksolve_sweep_results* r);

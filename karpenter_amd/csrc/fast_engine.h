@@ -88,7 +88,6 @@ struct FastWork {   // HBM workspace of the cursor engine (host-allocated when t
   uint32_t* q_cnt;        // [n_pods] pods the claim held before it
   FastPlan plan;
   int enabled;
-  int window;             // the frontier window (fast_hot_run) is on: 1 unless KSOLVE_FAST_WINDOW=0 (A/B switch of the measurements)
 };
 
 // whole-record moves between LDS and registers (a struct behind an address-space-3 pointer has no implicit copy)
@@ -643,7 +642,6 @@ struct FastCold {
 struct FastHot {
   int base, bi, bn, n, np, max_steps, steps, status;
   int pend_a, pend_x, pend_new, ev_arg;
-  int window;
   uint32_t pend_mv, pad0;
   uint64_t ev_vm;
   unsigned long long n_steps, n_tests, n_ref, hot_cycles;
@@ -711,32 +709,7 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
   // 12 < n < 50 every re-sort that has something to move is pdqsort's other path (mid_n). A commit that leaves the order
   // sorted as it stands — the next claim has at least the new count — needs no sort at all, whatever n and the position:
   // pdqsort finds no descent and does nothing.
-  const bool use_groups = max_steps < 0 && fast_uniform(hs->window) == 0;   // the group speculation below is the path without the frontier window
-  // ---- the frontier window ----
-  // Measured on configs[1] (tests/tools, round 3): the claims that 64 consecutive queue entries go to stand within seven
-  // positions of each other (median; within 64 positions for 78% of the blocks) — every class's cursor sits at the same short
-  // stretch of the order, the frontier of the claims that still have room. So the claims at positions p0 .. p0+63 are kept IN
-  // REGISTERS, one lane each (id, pod count, requirement word, requests): a pod is tested against all of them with one LDS round
-  // trip (the requirement-set cache) instead of three dependent ones (order -> claim state -> cache), its commit and the claim's
-  // move are register work (a rotation of the lanes it passes), and nothing is written to LDS until the window is given up.
-  // Anything the window cannot decide by itself — a class whose cursor lies left of it, no acceptor inside, a move that would
-  // leave it or that pdqsort would not do as one stable move, an uncached requirement set, the entries after which no add
-  // follows — flushes it and takes the paths below; the result is the same packing either way.
-  const bool use_window = max_steps < 0 && fast_uniform(hs->window) != 0;
-  const bool win_hop = fast_uniform(hs->window) == 2;   // KSOLVE_FAST_WINDOW=2: a class whose frontier lies right of the window moves the window there instead of scanning LDS
-  bool win_live = false;
-  int p0 = 0, wn = 0;
-  LaneVar<uint32_t> wx, wk, wvlo, wvhi;
-  LaneVar<int32_t> wq0, wq1, wq2, wq3;
-#define KS_WIN_FLUSH() { \
-    const int p0_ = p0, wn_ = wn; \
-    W::each([&](int l) { \
-      if (l < wn_) { \
-        FastClaim fs_; fs_.vmask = (uint64_t)wvlo.at(l) | ((uint64_t)wvhi.at(l) << 32); fs_.req[0] = wq0.at(l); fs_.req[1] = wq1.at(l); fs_.req[2] = wq2.at(l); fs_.req[3] = wq3.at(l); \
-        lds_put(&cst[wx.at(l)], fs_); okey[p0_ + l] = (uint16_t)wk.at(l); oord[p0_ + l] = (uint16_t)wx.at(l); \
-      } \
-    }); \
-    W::sync(); win_live = false; KS_SEC(ts6) }
+  const bool use_groups = max_steps < 0;
   const bool mid_n = n > 12 && n < 50;
   const uint32_t e1 = n >= 50 ? (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u, e2 = n >= 50 ? 2u * (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u, e3 = n >= 50 ? 3u * (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u;
 #ifdef KSOLVE_PHASE_TIMERS
@@ -811,151 +784,6 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
     // and the claim order it reports is the one of the last sort the reference would have run (scheduler.go:598 sorts at the
     // start of an add, never after the last one).
     const int lastq = (base + bn >= np || (cancel && ((base + 64) & 1023) == 0)) ? 1 : 0;
-    bool win_beyond = false;   // the entry is placed by the scan below, right of the (live) window: LDS is current there
-    if (use_window && bi + lastq < bn) {
-      uint32_t curk = 0;
-      {
-        const uint32_t c0 = cur[0].bcast(slot & 63), c1 = cur[1].bcast(slot & 63), c2 = cur[2].bcast(slot & 63), c3 = cur[3].bcast(slot & 63);
-        const int row = slot >> 6;
-        curk = row == 0 ? c0 : row == 1 ? c1 : row == 2 ? c2 : c3;
-      }
-      bool anchor_here = false;
-      if (win_live && (int)curk < p0) KS_WIN_FLUSH()   // a class whose cursor lies left of the window: a new window, from the smallest cursor
-      else if (win_live && win_hop && (int)curk >= p0 + wn && (int)curk < n) { KS_WIN_FLUSH() anchor_here = true; }   // ... right of it: the window hops to that class's frontier
-      if (!win_live) {
-        // the window starts at the smallest cursor of the classes of the block's remaining entries (or, hopping, at this class's)
-        LaneVar<uint32_t> ecur;
-        const int bi0 = bi, bnn = bn;
-        W::each([&](int l) {
-          const uint32_t sv = bslot.at(l);
-          const int sl = (int)(sv & 63u);
-          const uint32_t a0 = cur[0].shuffle(l, sl), a1 = cur[1].shuffle(l, sl), a2 = cur[2].shuffle(l, sl), a3 = cur[3].shuffle(l, sl);
-          const uint32_t row = (sv >> 6) & 3u;
-          const uint32_t c = row == 0 ? a0 : row == 1 ? a1 : row == 2 ? a2 : a3;
-          ecur.at(l) = (l >= bi0 && l < bnn && sv != 0xFFFFu) ? c : 0xFFFFFFFFu;
-        });
-        int wl_ = 0;
-        uint32_t pm = W::argmin_u32([&](int l) { return ecur.at(l); }, &wl_);
-        if (anchor_here) pm = curk;
-        if (pm < (uint32_t)n) {
-          p0 = fast_uniform((int)pm); wn = n - p0 < 64 ? n - p0 : 64;
-          const int p0_ = p0, nn_ = n;
-          W::each([&](int l) {
-            const int p = p0_ + l, pc = p < nn_ ? p : nn_ - 1;
-            const uint32_t x = oord[pc];
-            const FastClaim st = lds_get(&cst[x]);
-            wx.at(l) = x; wk.at(l) = p < nn_ ? (uint32_t)okey[pc] : 0xFFFFFFFFu;
-            wvlo.at(l) = (uint32_t)st.vmask; wvhi.at(l) = (uint32_t)(st.vmask >> 32);
-            wq0.at(l) = st.req[0]; wq1.at(l) = st.req[1]; wq2.at(l) = st.req[2]; wq3.at(l) = st.req[3];
-          });
-          win_live = true;
-        }
-        KS_SEC(ts1)   // window load
-#ifdef KSOLVE_PHASE_TIMERS
-        ts5++;
-#endif
-      }
-      if (win_live) {
-        bool placed = false;
-        const int off = (int)curk - p0;
-        if (off >= wn) win_beyond = true;            // every claim of the window rejected this class long ago
-        else {
-          const FastSlot cs = lds_get(&aslot[slot]);
-          const int wn_ = wn;
-          LaneVar<uint32_t> mlo, mhi;
-          uint64_t okm = 0, oddm = 0;
-          W::ballot2([&](int l) {
-            const uint64_t vm = (uint64_t)wvlo.at(l) | ((uint64_t)wvhi.at(l) << 32);
-            const uint64_t m = vm & cs.cvmask;
-            mlo.at(l) = (uint32_t)m; mhi.at(l) = (uint32_t)(m >> 32);
-            const FastEnt e = lds_get(&ent[fast_hash(m)]);
-            const int32_t rq[4] = {wq0.at(l), wq1.at(l), wq2.at(l), wq3.at(l)};
-            const int base_ok = (int)(l >= off) & (int)(l < wn_) & (int)((cs.tmplok >> (vm >> 56)) & 1u) & (int)fast_fields_ok(m, cs.dmask);
-            const int simple = (int)(e.info & 1u) & (int)(e.vmask == m);
-            const int fit = (int)fast_fits_first(e, rq, cs.size);
-            return (base_ok & simple & fit) | ((base_ok & ((simple ^ 1) | ((fit ^ 1) & (int)(((e.info >> 8) & 0xFFu) != 0)))) << 1);
-          }, okm, oddm);
-          uint64_t missm = 0;
-          oddm &= okm ? (okm & (0ull - okm)) - 1ull : ~0ull;   // only the lanes before the first plain acceptor can change the answer
-          if (KS_UNLIKELY(oddm != 0)) {
-            // rare: a second probe of the cache, or the other Pareto vectors of the requirement set
-            const uint64_t mm = oddm;
-            uint64_t ok2 = 0;
-            W::ballot2([&](int l) {
-              if (!((mm >> l) & 1)) return 0;
-              FastEnt e;
-              if (fast_lookup(ent, (uint64_t)mlo.at(l) | ((uint64_t)mhi.at(l) << 32), e) < 0) return 2;
-              const int32_t rq[4] = {wq0.at(l), wq1.at(l), wq2.at(l), wq3.at(l)};
-              return fast_fits(pool, e, rq, cs.size) ? 1 : 0;
-            }, ok2, missm);
-            okm |= ok2;
-          }
-          const int first_ok = okm ? ctz64(okm) : 64;
-          const bool uncached = missm != 0 && ctz64(missm) < first_ok;   // the scan below raises the event (after the flush)
-          KS_SEC(ts2)   // window test
-          if (!okm && !uncached) {
-            // every claim of the window from the cursor on rejects the class for good: the scan goes on behind the window
-            const uint32_t pe = (uint32_t)(p0 + wn);
-            W::each([&](int l) {
-#pragma unroll
-              for (int jj = 0; jj < kFastRows; ++jj) if (jj * 64 + l == slot) cur[jj].at(l) = pe;
-            });
-            win_beyond = true;
-          } else if (!uncached) {
-            const int a = p0 + first_ok;
-            const uint32_t cnt = wk.bcast(first_ok);
-            const uint32_t mvn = cnt + 1;
-            const uint64_t lessm = W::ballot([&](int l) { return l > first_ok && l < wn_ && wk.at(l) < mvn; });
-            const uint64_t t = first_ok == 63 ? 0ull : (lessm >> (first_ok + 1));
-            const int s_ = t == ~0ull ? 64 : ctz64(~t);
-            const bool known = first_ok + 1 + s_ < wn || p0 + wn >= n;          // the claim behind the run is in sight (or there is none)
-            const bool one_move = s_ == 0 || n <= 12 || (n >= 50 && !fast_sampled(n, a));
-            if (cnt < 65534u && known && one_move) {
-              // ---- NodeClaim.Add (nodeclaim.go:247-263) on the claim of lane first_ok; it lands behind the s_ claims it passes ----
-              const uint32_t x = wx.bcast(first_ok);
-              W::each([&](int l) {
-                if (l == first_ok) {
-                  wvlo.at(l) = mlo.at(l); wvhi.at(l) = mhi.at(l); wk.at(l) = mvn;
-                  wq0.at(l) += cs.size[0]; wq1.at(l) += cs.size[1]; wq2.at(l) += cs.size[2]; wq3.at(l) += cs.size[3];
-                }
-              });
-              if (s_) {
-                const int lo_ = first_ok, hi_ = first_ok + s_;
-                LaneVar<uint32_t> t0, t1, t2, t3, t4, t5, t6, t7;
-                W::each([&](int l) {
-                  const int src = (l >= lo_ && l < hi_) ? l + 1 : (l == hi_ ? lo_ : l);
-                  t0.at(l) = wx.shuffle(l, src); t1.at(l) = wk.shuffle(l, src); t2.at(l) = wvlo.shuffle(l, src); t3.at(l) = wvhi.shuffle(l, src);
-                  t4.at(l) = (uint32_t)wq0.shuffle(l, src); t5.at(l) = (uint32_t)wq1.shuffle(l, src); t6.at(l) = (uint32_t)wq2.shuffle(l, src); t7.at(l) = (uint32_t)wq3.shuffle(l, src);
-                });
-                W::each([&](int l) {
-                  wx.at(l) = t0.at(l); wk.at(l) = t1.at(l); wvlo.at(l) = t2.at(l); wvhi.at(l) = t3.at(l);
-                  wq0.at(l) = (int32_t)t4.at(l); wq1.at(l) = (int32_t)t5.at(l); wq2.at(l) = (int32_t)t6.at(l); wq3.at(l) = (int32_t)t7.at(l);
-                });
-              }
-              oclaim.set(bi, x); ocnt.set(bi, cnt);
-              n_ref += (unsigned long long)a + 1;
-              n_tests += (unsigned long long)(wn - off);
-              n_steps++;
-              {
-                const uint32_t ua = (uint32_t)a, ua1 = ua + 1u, su = (uint32_t)s_, usj = (uint32_t)slot;
-                W::each([&](int l) {
-#pragma unroll
-                  for (int jj = 0; jj < kFastRows; ++jj) {
-                    const uint32_t rr = cur[jj].at(l);
-                    const uint32_t sh = rr - (uint32_t)((rr - ua1) < su);
-                    cur[jj].at(l) = (uint32_t)(jj * 64 + l) == usj ? ua : sh;
-                  }
-                });
-              }
-              placed = true;
-            }
-          }
-        }
-        KS_SEC(ts4)   // window commit
-        if (placed) { bi++; steps++; continue; }
-        if (!win_beyond) KS_WIN_FLUSH()   // this entry takes the paths below; the next one loads the window again
-      }
-    } else if (win_live) KS_WIN_FLUSH()   // an entry the window does not place (no add follows it): the paths below read LDS
     if (use_groups && gj >= gn && bi + lastq < bn) {
       // ---- a new group: the next entries of the block that have a class slot, eight at most ----
       const int g0 = bn - bi - lastq < 8 ? bn - bi - lastq : 8, bi0 = bi, nn = n;
@@ -1244,8 +1072,6 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
     ev = FEV_NEWCLAIM; ev_arg = slot_w;   // no in-flight claim accepted the pod: addToNewNodeClaim; the driver moves on to the next pod
     break;
   }
-  if (win_live) KS_WIN_FLUSH()
-#undef KS_WIN_FLUSH
   if (ev == FEV_DONE && bn > 0) {
     // the deadline / a cancellation stopped the loop inside a block: the pods placed so far are results too
     const int dn = bi < bn ? bi : bn, b0 = base;
@@ -1294,7 +1120,6 @@ struct FastEngine {
       h->pend_a = -1; h->pend_x = 0; h->pend_mv = 0; h->pend_new = 0; h->ev_arg = 0; h->ev_vm = 0;
       h->n_steps = 0; h->n_tests = 0; h->n_ref = 0; h->hot_cycles = 0;
       for (int i = 0; i < 8; ++i) h->tsec[i] = 0;
-      h->window = cold.Fk->window;
       h->q_class = cold.Fk->q_class; h->cancel = cold.Sk->cancel_flag;
       h->q_claim = cold.Fk->q_claim; h->q_cnt = cold.Fk->q_cnt;
     }

@@ -214,13 +214,15 @@ KS_FN uint64_t reqset_diff(const Dict& d, const ReqRef& a, const ReqRef& b) {
 // fully coalesced 512-byte accesses instead of 64 lanes striding through 160-byte records.
 // req_at(r) = the row's request in dimension r, tol = its toleration mask: read from the tables (row_hash_value), or already
 // in registers (the wave-cooperative kernel loads them with everything else of the block in one go).
-template <class ReqAt>
+// SAME: the strict table of this launch IS the requirement table (every row's qs equals its q): the second set adds nothing to
+// the hash of a row among the rows of the same launch, so it is left out — all rows of a launch are hashed by the same kernel.
+template <bool SAME = false, class ReqAt>
 KS_FN uint64_t row_hash_value_with(int row, const RowArgs& a, const ReqRef& q, const ReqRef& qs, ReqAt req_at, uint64_t tol) {
   uint64_t h = a.seed;
 #pragma unroll
   for (int r = 0; r < 8; ++r) if (r < a.n_res) h = mix64(h, (uint64_t)req_at(r));   // n_res <= 8 (ksolve.h); unrolled: req_at may index registers
   h = hash_reqset(a.dict, h, q);
-  h = hash_reqset(a.dict, h, qs);
+  if (!SAME) h = hash_reqset(a.dict, h, qs);
   h = mix64(h, tol);
   if (a.host_ports) { h = mix64(h, a.host_ports[(size_t)row * 2]); h = mix64(h, a.host_ports[(size_t)row * 2 + 1]); }
   if (a.vol) h = mix64(h, a.vol[row]);
@@ -271,7 +273,7 @@ KS_FN void word_defined_mask(const Dict& d, uint32_t defined, uint64_t& m0, uint
 // Returns 0 when the rows are equal. Words of keys the set does not define are ignored, as in equal_reqset.
 constexpr int kRowFarBatch = 20;   // mask words per set and batch: a 1280-value dictionary in one batch
 constexpr int kRowFarKeys = 16;
-template <class ReqAt>
+template <bool SAME = false, class ReqAt>   // SAME: see row_hash_value_with — the strict side is the same memory, compared once
 KS_FN uint64_t row_diff_far(int row, const RowArgs& a, uint32_t rep, const ReqRef& q, const ReqRef& qs, ReqAt req_at, uint64_t tol) {
   const Dict& d = a.dict;
   const int rw = d.req_words, nk = d.n_keys, nr = a.n_res;
@@ -280,18 +282,18 @@ KS_FN uint64_t row_diff_far(int row, const RowArgs& a, uint32_t rep, const ReqRe
   // ---- the loads ----
   uint64_t w0[kRowFarBatch], w1[kRowFarBatch];
 #pragma unroll
-  for (int i = 0; i < kRowFarBatch; ++i) { w0[i] = i < rw ? b0[i] : 0ull; w1[i] = i < rw ? b1[i] : 0ull; }
+  for (int i = 0; i < kRowFarBatch; ++i) { w0[i] = i < rw ? b0[i] : 0ull; w1[i] = (!SAME && i < rw) ? b1[i] : 0ull; }
   const uint32_t f0 = a.reqs.defined[rep], f1 = a.reqs.complement[rep], f2 = a.reqs.has_gte ? a.reqs.has_gte[rep] : 0u, f3 = a.reqs.has_lte ? a.reqs.has_lte[rep] : 0u;
-  const uint32_t s0 = a.strict.defined[rep], s1 = a.strict.complement[rep], s2 = a.strict.has_gte ? a.strict.has_gte[rep] : 0u, s3 = a.strict.has_lte ? a.strict.has_lte[rep] : 0u;
+  const uint32_t s0 = SAME ? f0 : a.strict.defined[rep], s1 = SAME ? f1 : a.strict.complement[rep], s2 = SAME ? f2 : a.strict.has_gte ? a.strict.has_gte[rep] : 0u, s3 = SAME ? f3 : a.strict.has_lte ? a.strict.has_lte[rep] : 0u;
   int64_t bq[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) bq[r] = r < nr ? a.requests[(size_t)r * a.n_rows + rep] : 0;
   const uint64_t btol = a.tolerates[rep];
   const int32_t* bm0 = a.reqs.minv ? a.reqs.minv + (size_t)rep * nk : nullptr;
-  const int32_t* bm1 = a.strict.minv ? a.strict.minv + (size_t)rep * nk : nullptr;
+  const int32_t* bm1 = (!SAME && a.strict.minv) ? a.strict.minv + (size_t)rep * nk : nullptr;
   int32_t v0[kRowFarKeys], v1[kRowFarKeys];
 #pragma unroll
-  for (int k = 0; k < kRowFarKeys; ++k) { v0[k] = (bm0 && k < nk) ? bm0[k] : -1; v1[k] = (bm1 && k < nk) ? bm1[k] : -1; }
+  for (int k = 0; k < kRowFarKeys; ++k) { v0[k] = (bm0 && k < nk) ? bm0[k] : -1; v1[k] = (!SAME && bm1 && k < nk) ? bm1[k] : -1; }
   // ---- the comparison ----
   uint64_t diff = (uint64_t)((f0 ^ q.defined) | (f1 ^ q.complement) | (f2 ^ q.has_gte) | (f3 ^ q.has_lte) |
                              (s0 ^ qs.defined) | (s1 ^ qs.complement) | (s2 ^ qs.has_gte) | (s3 ^ qs.has_lte));
@@ -300,40 +302,40 @@ KS_FN uint64_t row_diff_far(int row, const RowArgs& a, uint32_t rep, const ReqRe
   for (int r = 0; r < 8; ++r) if (r < nr) diff |= (uint64_t)(bq[r] ^ req_at(r));
   uint64_t d00, d01, d10, d11;
   word_defined_mask(d, q.defined, d00, d01);
-  word_defined_mask(d, qs.defined, d10, d11);
+  if (SAME) { d10 = 0; d11 = 0; } else word_defined_mask(d, qs.defined, d10, d11);
 #pragma unroll
   for (int i = 0; i < kRowFarBatch; ++i) if (i < rw) {
     diff |= (q.mask[i] ^ w0[i]) & (0ull - ((d00 >> i) & 1ull));
-    diff |= (qs.mask[i] ^ w1[i]) & (0ull - ((d10 >> i) & 1ull));
+    if (!SAME) diff |= (qs.mask[i] ^ w1[i]) & (0ull - ((d10 >> i) & 1ull));
   }
   for (int w = kRowFarBatch; w < rw; w += kRowFarBatch) {   // dictionaries beyond one batch
 #pragma unroll
-    for (int i = 0; i < kRowFarBatch; ++i) { w0[i] = w + i < rw ? b0[w + i] : 0ull; w1[i] = w + i < rw ? b1[w + i] : 0ull; }
+    for (int i = 0; i < kRowFarBatch; ++i) { w0[i] = w + i < rw ? b0[w + i] : 0ull; w1[i] = (!SAME && w + i < rw) ? b1[w + i] : 0ull; }
 #pragma unroll
     for (int i = 0; i < kRowFarBatch; ++i) if (w + i < rw) {
       const int x = w + i;
       diff |= (q.mask[x] ^ w0[i]) & (0ull - (((x < 64 ? d00 >> x : d01 >> (x - 64))) & 1ull));
-      diff |= (qs.mask[x] ^ w1[i]) & (0ull - (((x < 64 ? d10 >> x : d11 >> (x - 64))) & 1ull));
+      if (!SAME) diff |= (qs.mask[x] ^ w1[i]) & (0ull - (((x < 64 ? d10 >> x : d11 >> (x - 64))) & 1ull));
     }
   }
 #pragma unroll
   for (int k = 0; k < kRowFarKeys; ++k) if (k < nk) {
     const int32_t am = q.minv ? q.minv[k] : -1, as = qs.minv ? qs.minv[k] : -1;
     diff |= (uint64_t)(uint32_t)(am ^ v0[k]) & (0ull - (uint64_t)((q.defined >> k) & 1u));
-    diff |= (uint64_t)(uint32_t)(as ^ v1[k]) & (0ull - (uint64_t)((qs.defined >> k) & 1u));
+    if (!SAME) diff |= (uint64_t)(uint32_t)(as ^ v1[k]) & (0ull - (uint64_t)((qs.defined >> k) & 1u));
   }
   for (int k = kRowFarKeys; k < nk; ++k) {
     const int32_t am = q.minv ? q.minv[k] : -1, as = qs.minv ? qs.minv[k] : -1;
     diff |= (uint64_t)(uint32_t)(am ^ (bm0 ? bm0[k] : -1)) & (0ull - (uint64_t)((q.defined >> k) & 1u));
-    diff |= (uint64_t)(uint32_t)(as ^ (bm1 ? bm1[k] : -1)) & (0ull - (uint64_t)((qs.defined >> k) & 1u));
+    if (!SAME) diff |= (uint64_t)(uint32_t)(as ^ (bm1 ? bm1[k] : -1)) & (0ull - (uint64_t)((qs.defined >> k) & 1u));
   }
   if (q.has_gte | q.has_lte | qs.has_gte | qs.has_lte) {   // bounds: rare, key by key
     const ReqRef b = a.reqs.at(d, rep), bs = a.strict.at(d, rep);
     for (int k = 0; k < nk; ++k) {
       if (bit(q.has_gte, k) && q.gte[k] != b.gte[k]) diff |= 1;
       if (bit(q.has_lte, k) && q.lte[k] != b.lte[k]) diff |= 1;
-      if (bit(qs.has_gte, k) && qs.gte[k] != bs.gte[k]) diff |= 1;
-      if (bit(qs.has_lte, k) && qs.lte[k] != bs.lte[k]) diff |= 1;
+      if (!SAME && bit(qs.has_gte, k) && qs.gte[k] != bs.gte[k]) diff |= 1;
+      if (!SAME && bit(qs.has_lte, k) && qs.lte[k] != bs.lte[k]) diff |= 1;
     }
   }
   if (a.host_ports) diff |= (a.host_ports[(size_t)row * 2] ^ a.host_ports[(size_t)rep * 2]) | (a.host_ports[(size_t)row * 2 + 1] ^ a.host_ports[(size_t)rep * 2 + 1]);

@@ -299,9 +299,8 @@ __device__ __forceinline__ void coop_stage(const ks::CoopStage& s, const ks::Row
 }
 // MINV: the rows carry minValues (pod rows never do when they come from the reference's PodData — minValues belong to NodePool
 // requirements — so the tables are absent and neither streamed nor staged)
-template <bool MINV, bool SAME = false>
-__global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a, int rw, uint32_t magic, uint32_t kmagic, int rpb) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t coop_lds[];
+template <bool MINV, bool SAME>
+__device__ __forceinline__ void row_hash_coop2_body(uint64_t* coop_lds, int n, const ks::RowArgs& a, int rw, uint32_t magic, uint32_t kmagic, int rpb) {
   const int l = (int)threadIdx.x;
   const int row0 = (int)blockIdx.x * rpb;   // rpb rows per block: 64 (60, a multiple of 4, only through the A/B switch of the launcher)
   const int rows = n - row0 < rpb ? n - row0 : rpb;
@@ -335,7 +334,7 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a
   q.gte = a.reqs.gte ? a.reqs.gte + (size_t)rowc * nk : nullptr; q.lte = a.reqs.lte ? a.reqs.lte + (size_t)rowc * nk : nullptr;
   qs.gte = a.strict.gte ? a.strict.gte + (size_t)rowc * nk : nullptr; qs.lte = a.strict.lte ? a.strict.lte + (size_t)rowc * nk : nullptr;
   auto req_at = [&](int r) -> int64_t { return rq[r]; };   // every caller unrolls over r: register indices
-  const uint64_t h = live ? ks::row_hash_kept(a, ks::row_hash_value_with(row, a, q, qs, req_at, tol)) : 0ull;
+  const uint64_t h = live ? ks::row_hash_kept(a, ks::row_hash_value_with<SAME>(row, a, q, qs, req_at, tol)) : 0ull;
   // ---- the first lane of every distinct hash ----
   int lead = l;
   uint64_t todo = __ballot(live ? 1 : 0);
@@ -352,7 +351,7 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a
   slot = (uint32_t)__shfl((int)slot, lead, 64);
   if (live) a.row_slot[row] = slot;
   uint64_t d = 0;
-  if (leader && rep != 0xFFFFFFFFu) d = ks::row_diff_far(row, a, rep, q, qs, req_at, tol);
+  if (leader && rep != 0xFFFFFFFFu) d = ks::row_diff_far<SAME>(row, a, rep, q, qs, req_at, tol);
   // ---- a follower equals its leader: flags and requests by shuffle, mask words and minValues LDS to LDS ----
   ks::ReqRef qj, qsj;
   qj.defined = (uint32_t)__shfl((int)q.defined, lead, 64); qj.complement = (uint32_t)__shfl((int)q.complement, lead, 64);
@@ -368,7 +367,8 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a
     qj.minv = MINV ? m0 + (size_t)lead * kstride : nullptr; qsj.minv = MINV ? m1 + (size_t)lead * kstride : nullptr;
     qj.gte = a.reqs.gte ? a.reqs.gte + rowj * nk : nullptr; qj.lte = a.reqs.lte ? a.reqs.lte + rowj * nk : nullptr;
     qsj.gte = a.strict.gte ? a.strict.gte + rowj * nk : nullptr; qsj.lte = a.strict.lte ? a.strict.lte + rowj * nk : nullptr;
-    d = dq | ks::reqset_diff(a.dict, q, qj) | ks::reqset_diff(a.dict, qs, qsj);
+    d = dq | ks::reqset_diff(a.dict, q, qj);
+    if (!SAME) d |= ks::reqset_diff(a.dict, qs, qsj);
     if (a.host_ports) d |= (a.host_ports[(size_t)row * 2] ^ a.host_ports[rowj * 2]) | (a.host_ports[(size_t)row * 2 + 1] ^ a.host_ports[rowj * 2 + 1]);
         if (a.vol) d |= a.vol[row] ^ a.vol[rowj];
     if (a.topo_owned) for (int w = 0; w < a.topo_words; ++w) {
@@ -377,6 +377,19 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a
     }
   }
   if (d) *a.collision = 1;
+}
+template <bool MINV, bool SAME = false>
+__global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a, int rw, uint32_t magic, uint32_t kmagic, int rpb) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t coop_lds[];
+  row_hash_coop2_body<MINV, SAME>(coop_lds, n, a, rw, magic, kmagic, rpb);
+}
+// The one-table form at four wavefronts per SIMD (128 VGPRs; it needs 149 left to itself): the kernel is latency-bound per
+// wavefront (three dependent round trips), so wavefronts in flight are what it is short of; with one staged table a block holds
+// 10.5 KB of LDS at configs[1]'s dictionary and 14 blocks fit a CU.
+template <bool MINV>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) ksolve_row_hash_coop2_w4(int n, ks::RowArgs a, int rw, uint32_t magic, uint32_t kmagic, int rpb) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t coop_lds[];
+  row_hash_coop2_body<MINV, true>(coop_lds, n, a, rw, magic, kmagic, rpb);
 }
 __global__ void ksolve_row_class(int n, ks::RowArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -511,7 +524,10 @@ static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) {
   const bool tables = (minv || no_minv) && a.reqs.has_gte && a.reqs.has_lte && a.strict.has_gte && a.strict.has_lte;
   if (!plain && !coop1 && rw >= 1 && nk >= 1 && a.n_res >= 1 && a.n_res <= 8 && aligned && tables && lds2 <= 64 * 1024) {
     const dim3 grid((unsigned)((n + rpb - 1) / rpb));
-    if (minv && same) hipLaunchKernelGGL((ksolve_row_hash_coop2<true, true>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
+    const bool w4 = same && getenv("KSOLVE_ROWHASH_W4");   // A/B switch of the measurements (profiles/README.md)
+    if (w4 && minv) hipLaunchKernelGGL((ksolve_row_hash_coop2_w4<true>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
+    else if (w4) hipLaunchKernelGGL((ksolve_row_hash_coop2_w4<false>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
+    else if (minv && same) hipLaunchKernelGGL((ksolve_row_hash_coop2<true, true>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
     else if (minv) hipLaunchKernelGGL((ksolve_row_hash_coop2<true, false>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
     else if (same) hipLaunchKernelGGL((ksolve_row_hash_coop2<false, true>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
     else hipLaunchKernelGGL((ksolve_row_hash_coop2<false, false>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);

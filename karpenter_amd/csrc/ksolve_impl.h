@@ -678,7 +678,6 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       fp.off_ord = off; off = align(off + cap * 2);
       fp.off_snap = off; off = align(off + cap * 2);
       fp.total_bytes = off;
-      { const char* w = getenv("KSOLVE_FAST_WINDOW"); fw.window = (w && !strcmp(w, "0")) ? 0 : (w && !strcmp(w, "2")) ? 2 : 1; }
       fw.var = dz<ks::FastVar>(h, 1);
       fw.c_hostseq = dz<uint32_t>(h, mc); fw.c_ent = dz<uint16_t>(h, mc);
       fw.c_state = dz<ks::FastClaim>(h, mc); fw.c_npods = dz<uint32_t>(h, mc);

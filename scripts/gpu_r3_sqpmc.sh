@@ -1,3 +1,4 @@
+# NOTE: as run at commit 361dd55, when the cursor engine still had its frontier window (KSOLVE_FAST_WINDOW; removed after these measurements, profiles/README.md)
 # round 3: SQ instruction / cycle counters of the pack kernel with the frontier window off and on (configs[1], 1M pods)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp

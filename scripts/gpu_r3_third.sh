@@ -1,3 +1,4 @@
+# NOTE: as run at commit 361dd55, when the cursor engine still had its frontier window (KSOLVE_FAST_WINDOW; removed after these measurements, profiles/README.md)
 # round 3, third GPU run: the frontier window of the cursor engine (A/B against the group path), the shared strict table of the
 # classing kernel, the new parity tests (volume limits, topology probes, the 10k-node sweep with topology pods)
 cd $GRAFT_REPO_ROOT
