@@ -139,7 +139,73 @@ def config4_sweep(args, device_index, rank, world):
                                "compared": "decision, replacement instance types, capacity type, reference-equivalent evaluation count"}
         out["cpu_baseline"] = {"value": len(sample) / osec, "unit": "probes/s", "cores": threads, "kind": "port",
                                "sample": f"{len(sample)} of the swept probes, each a fresh oracle Scheduler over the {args.sweep_nodes}-node cluster (what the reference does per simulation), {threads} at a time", "seconds": osec}
+    if args.sweep_windows > 0:
+        out["multi_node"] = config4_multi_node(args, cc, rc, rank, world)
     rc.close()
+    return out
+
+
+def config4_multi_node(args, cc, rc, rank, world):
+    """The multi-node half of the replay: MultiNodeConsolidation.ComputeCommands (multinodeconsolidation.go:51-111) takes the first
+    100 candidates of sortCandidates' order and binary-searches the longest prefix that consolidates (firstNConsolidationOption,
+    :117-207: about seven dependent simulations). Here every prefix the search can reach — sizes 2..101 of a window of 101
+    candidates — is a probe, the windows are consecutive slices of the sorted candidate list (one per pass of a replay that has
+    consolidated the earlier ones away), all windows' prefixes are ONE ksolve_sweep (several launches when their workspaces pass
+    the arena budget), verdicts incl. filterOutSameInstanceType (:209-246) from the host library, and the binary search is a walk
+    over the verdicts. With N ranks the windows are dealt out round-robin. A few prefixes are re-simulated by the oracle."""
+    from collections import Counter
+    from karpenter_amd import disruption as dz
+    K = args.sweep_window_size + 1
+    full = dz.compact_candidates(cc)                   # sortCandidates (consolidation.go:149-154)
+    n_windows = min(args.sweep_windows, len(full) // K)
+    mine = list(range(n_windows))[rank::world]
+    sets, key = [], []
+    for w in mine:
+        win = [cc["nodes"][i] for i in full[w * K:(w + 1) * K]]
+        for k in range(2, K + 1):
+            sets.append(win[:k]); key.append((w, k))
+    out = {"workload": f"multi-node consolidation: {n_windows} windows of {K} candidates (sortCandidates' order), every prefix of 2..{K} nodes simulated: {(K - 1) * n_windows} probes",
+           "windows": n_windows, "window_candidates": K, "probes": len(sets)}
+    if not sets:
+        return out
+    rc.decisions(sets[:K - 1], multi_node=True, library_prices=True)      # warm-up: grows the arena to the largest prefix
+    t = time.perf_counter(); cmds = rc.decisions(sets, multi_node=True, library_prices=True); dt = time.perf_counter() - t
+    tm = rc.last_sweep["timings"]
+    lib_s = (tm["descriptors_ms"] + tm["sweep_ms"] + tm["verdicts_ms"]) * 1e-3
+    by = dict(zip(key, cmds))
+    chosen = []
+    for w in mine:
+        cmd, probes = dz.first_n_from_commands(K, lambda k: by[(w, k)], args.sweep_window_size)
+        chosen.append((len(cmd.get("candidates") or []), cmd["decision"], len(probes)))
+    out.update(displaced_pods=tm["pods"], decisions_of_all_prefixes=dict(Counter(c["decision"] for c in cmds)),
+               commands={"decisions": dict(Counter(d for _, d, _ in chosen)), "nodes_consolidated": sum(n for n, _, _ in chosen),
+                         "largest_prefix": max(n for n, _, _ in chosen), "binary_search_steps_replaced_per_window": max(p for _, _, p in chosen)},
+               seconds={"descriptors": tm["descriptors_ms"] * 1e-3, "upload": tm["upload_us"] * 1e-6, "pack_kernel": tm["pack_us"] * 1e-6, "finalize": tm["finalize_us"] * 1e-6,
+                        "download": tm["download_us"] * 1e-6, "verdicts": tm["verdicts_ms"] * 1e-3, "library_call": lib_s, "python_call": dt},
+               value=len(sets) / lib_s, unit="probes/s", pods_placed_per_s=tm["pods"] / lib_s, windows_per_s=len(mine) / lib_s)
+    if args.sweep_sample > 0 and rank == 0:
+        import oracle
+        picks = sorted({(mine[0], 2), (mine[0], 7), (mine[len(mine) // 2], 23), (mine[-1], min(K, 60)), (mine[-1], K)} & set(key))
+        base = dz.compact_problem(cc, pod_groups=[])
+        probes, cand_sets = [], []
+        for w, k in picks:
+            idx = full[w * K:w * K + k]
+            pods = [dz.compact_node_pods(cc, i) for i in idx]
+            probes.append({"removeNodes": [cc["nodes"][i]["name"] for i in idx], "pods": [p for ps in pods for p in ps]})
+            cand_sets.append([dict(cc["nodes"][i], pods=ps) for i, ps in zip(idx, pods)])
+        threads = min(len(probes), os.cpu_count() or 1)
+        t = time.perf_counter(); res = oracle.sweep(base, probes, threads=threads); osec = time.perf_counter() - t
+        pos = {kk: j for j, kk in enumerate(key)}
+        for kk, r, cs in zip(picks, res, cand_sets):
+            want = dz.decide(cc, cs, dz._finish_simulation(cc, r, set()))
+            if want["decision"] == dz.REPLACE and not dz.filter_out_same_instance_type(cc, cs, want):
+                want = {"decision": dz.NOOP, "replacement": None}
+            got = by[kk]
+            if (got["decision"], got["replacement"]) != (want["decision"], want.get("replacement")) or rc.last_sweep["referenceBinEvaluations"][pos[kk]] != r["counters"]["binEvaluations"]:
+                raise SystemExit(f"bench.py: configs[4] multi-node probe (window {kk[0]}, {kk[1]} nodes) differs from the oracle's simulation")
+        out["oracle_check"] = {"probes": len(picks), "prefix_sizes": [k for _, k in picks], "all_identical": True, "compared": "decision, replacement instance types after filterOutSameInstanceType, reference-equivalent evaluation count"}
+        out["cpu_baseline"] = {"value": len(picks) / osec, "unit": "probes/s", "cores": threads, "kind": "port", "seconds": osec,
+                               "sample": f"{len(picks)} of the swept prefixes ({sum(len(p['pods']) for p in probes)} displaced pods), each a fresh oracle Scheduler over the cluster, {threads} at a time"}
     return out
 
 
@@ -171,6 +237,8 @@ def main():
     ap.add_argument("--components-calibration-pods", type=int, default=200_000, help="size at which the component split is compared with ONE Solve() of the whole batch (L2-canonical deltas)")
     ap.add_argument("--sweep-nodes", type=int, default=100_000, help="BASELINE configs[4]: existing nodes of the resident cluster swept by single-node consolidation (about 20 bound pods each), 0 = skip")
     ap.add_argument("--sweep-candidates", type=int, default=10_000, help="candidates (probes) per launch of the sweep")
+    ap.add_argument("--sweep-windows", type=int, default=32, help="multi-node consolidation: windows of the sorted candidate list whose prefixes are all simulated in one sweep, 0 = skip")
+    ap.add_argument("--sweep-window-size", type=int, default=100, help="MultiNodeConsolidation's batch (multinodeconsolidation.go:80): the search covers prefixes of up to this many + 1 candidates")
     ap.add_argument("--sweep-sample", type=int, default=32, help="probes of the sweep re-simulated by the oracle (checker + CPU baseline of this leg)")
     ap.add_argument("--no-parity-pin", action="store_true", help="skip the digest check of the timed problem against the committed oracle pin")
     ap.add_argument("--engine", default="auto", choices=["auto", "general", "cursor"], help="pack engine (auto: the cursor engine for purely positive batches)")
@@ -365,6 +433,15 @@ def main():
             sweep["decisions_all_ranks"] = {k: int(v[1 + i].item()) for i, k in enumerate(names)}
             sweep["value"] = v[0].item() / t.item()   # probes of all ranks / slowest rank's call
             sweep["sharding"] = "candidates dealt out round-robin over the ranks, cluster tables replicated, no data-path collective; verdict counts summed with one all-reduce"
+            mn = sweep.get("multi_node")
+            if mn is not None:     # windows dealt out round-robin: probes and displaced pods of all ranks / the slowest rank's call
+                v = torch.tensor([float(mn.get("probes", 0)), float(mn.get("displaced_pods", 0)), float(mn.get("commands", {}).get("nodes_consolidated", 0))], dtype=torch.float64, device=reduce_device)
+                dist.all_reduce(v, op=dist.ReduceOp.SUM)
+                t = torch.tensor([mn.get("seconds", {}).get("library_call", 0.0)], dtype=torch.float64, device=reduce_device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                mn.update(ranks=world, probes_all_ranks=int(v[0].item()), displaced_pods_all_ranks=int(v[1].item()), nodes_consolidated_all_ranks=int(v[2].item()))
+                if t.item() > 0:
+                    mn["value"] = v[0].item() / t.item(); mn["pods_placed_per_s"] = v[1].item() / t.item()
 
     if rank != 0:
         if dist is not None:

@@ -383,14 +383,8 @@ __global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a
   extern __shared__ __attribute__((aligned(16))) uint64_t coop_lds[];
   row_hash_coop2_body<MINV, SAME>(coop_lds, n, a, rw, magic, kmagic, rpb);
 }
-// The one-table form at four wavefronts per SIMD (128 VGPRs; it needs 149 left to itself): the kernel is latency-bound per
-// wavefront (three dependent round trips), so wavefronts in flight are what it is short of; with one staged table a block holds
-// 10.5 KB of LDS at configs[1]'s dictionary and 14 blocks fit a CU.
-template <bool MINV>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) ksolve_row_hash_coop2_w4(int n, ks::RowArgs a, int rw, uint32_t magic, uint32_t kmagic, int rpb) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t coop_lds[];
-  row_hash_coop2_body<MINV, true>(coop_lds, n, a, rw, magic, kmagic, rpb);
-}
+// (A build of the one-table form at four wavefronts per SIMD — amdgpu_waves_per_eu(4,4), 128 VGPRs instead of the 149 it takes —
+// measured 157 us against 79.6 us: the spills cost more than the fourth wavefront hides; profiles/README.md.)
 __global__ void ksolve_row_class(int n, ks::RowArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ks::row_class_body(i, a);
@@ -524,10 +518,7 @@ static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) {
   const bool tables = (minv || no_minv) && a.reqs.has_gte && a.reqs.has_lte && a.strict.has_gte && a.strict.has_lte;
   if (!plain && !coop1 && rw >= 1 && nk >= 1 && a.n_res >= 1 && a.n_res <= 8 && aligned && tables && lds2 <= 64 * 1024) {
     const dim3 grid((unsigned)((n + rpb - 1) / rpb));
-    const bool w4 = same && getenv("KSOLVE_ROWHASH_W4");   // A/B switch of the measurements (profiles/README.md)
-    if (w4 && minv) hipLaunchKernelGGL((ksolve_row_hash_coop2_w4<true>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
-    else if (w4) hipLaunchKernelGGL((ksolve_row_hash_coop2_w4<false>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
-    else if (minv && same) hipLaunchKernelGGL((ksolve_row_hash_coop2<true, true>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
+    if (minv && same) hipLaunchKernelGGL((ksolve_row_hash_coop2<true, true>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
     else if (minv) hipLaunchKernelGGL((ksolve_row_hash_coop2<true, false>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
     else if (same) hipLaunchKernelGGL((ksolve_row_hash_coop2<false, true>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
     else hipLaunchKernelGGL((ksolve_row_hash_coop2<false, false>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);

@@ -307,8 +307,8 @@ class ResidentCluster:
 
     `prefetch(candidate_sets)` sends all those simulations to the device as ONE batched launch (one wavefront per probe)
     and keeps their Results; single-node consolidation prefetches every candidate, the multi-node binary search every
-    prefix it can reach. Clusters whose pods carry topology constraints are not probed (the per-probe domain counts are
-    not derived on the device yet): Unsupported is raised at construction and the caller keeps the per-probe path."""
+    prefix it can reach. Clusters whose pods carry topology constraints are probed too: every bound pod becomes a pod row,
+    the device counts the whole cluster once and a probe takes its candidates' share out of its own counters."""
 
     def __init__(self, cluster, candidates, solver_lib=None):
         from .scheduling import NewScheduler, Unsupported
@@ -365,21 +365,27 @@ class ResidentCluster:
         self.prefetch([candidates])
         return self._cache[self._key(candidates)]
 
-    def decisions(self, candidate_sets, detail=False):
+    def decisions(self, candidate_sets, detail=False, multi_node=False, library_prices=False):
         """computeConsolidation (consolidation.go:159-256) for every candidate set in ONE device launch, verdicts included
         (Scheduler.Sweep / ksolve_sweep): [{"decision", "candidates", "replacement", "replacementCapacityType"}], the commands
-        compute_consolidation() returns without their Results. Descriptors and verdicts are computed by the host library."""
+        compute_consolidation() returns without their Results. Descriptors and verdicts are computed by the host library.
+        multi_node: the sets are prefixes of MultiNodeConsolidation's search — a REPLACE over several candidates goes through
+        filterOutSameInstanceType (multinodeconsolidation.go:209-246) and comes back as NOOP when it does not stand.
+        library_prices: the candidates' prices and capacity types are taken from the host library's node table instead of
+        being summed here."""
         cluster = self.cluster
         live = [[c for c in cs if not c.get("markedForDeletion")] for cs in candidate_sets]
-        prices = [sum(self._price(c) for c in cs) for cs in candidate_sets]
-        all_spot = [all(c["labels"][fx.CAPACITY_TYPE] == "spot" for c in cs) for cs in candidate_sets]
-        out = self.scheduler.Sweep([[c["name"] for c in cs] for cs in live], prices, all_spot, detail=detail)
+        prices = None if library_prices else [sum(self._price(c) for c in cs) for cs in candidate_sets]
+        all_spot = None if library_prices else [all(c["labels"][fx.CAPACITY_TYPE] == "spot" for c in cs) for cs in candidate_sets]
+        out = self.scheduler.Sweep([[c["name"] for c in cs] for cs in live], prices, all_spot, detail=detail, multi_node=multi_node)
         repl = {r["probe"]: r for r in out["replacements"]}
         cmds = []
         for i, cs in enumerate(candidate_sets):
             d = out["decisions"][i]
             if d == 3:   # spot-to-spot behind its feature gate: the per-probe path has the whole ordered list
                 cmd = dict(compute_consolidation(cluster, cs, self))
+                if multi_node and cmd["decision"] == REPLACE and len(cs) > 1 and not filter_out_same_instance_type(cluster, cs, cmd):
+                    cmd = {"decision": NOOP, "candidates": [], "replacement": None}
                 cmd.pop("results", None)
                 cmds.append(cmd)
                 continue
@@ -392,6 +398,19 @@ class ResidentCluster:
             cmds.append(cmd)
         self.last_sweep = out
         return cmds
+
+    def first_n(self, candidates, max_n=100, evaluator=None):
+        """MultiNodeConsolidation.firstNConsolidationOption (multinodeconsolidation.go:117-207) with every prefix the binary
+        search can reach simulated in ONE launch (the search itself is a chain of dependent simulations — about seven for
+        100 candidates; all 99 prefixes at once cost one sweep and the walk over their verdicts is a lookup).
+        Returns (command, probe sequence) like first_n_consolidation_option."""
+        if len(candidates) < 2:
+            return {"decision": NOOP, "candidates": []}, []
+        lo, hi = first_n_bounds(len(candidates), max_n)
+        sizes = list(range(lo + 1, hi + 2))
+        cmds = self.decisions([candidates[:k] for k in sizes], multi_node=True)
+        by_size = dict(zip(sizes, cmds))
+        return first_n_from_commands(len(candidates), lambda k: by_size[k], max_n, evaluator, candidates)
 
     def _price(self, node):
         key = (node["labels"].get(fx.INSTANCE_TYPE), node["labels"].get(fx.ZONE), node["labels"].get(fx.CAPACITY_TYPE))
@@ -678,6 +697,52 @@ def compute_consolidation(cluster, candidates, solver, results=None):
     return cmd
 
 
+def filter_out_same_instance_type(cluster, candidates, cmd):
+    """filterOutSameInstanceType (multinodeconsolidation.go:209-246) on a REPLACE command of several candidates: when a replacement
+    option is one of the instance types being removed, every option must be cheaper than the cheapest candidate of that type
+    (else deleting the others is the better command). Narrows cmd["replacement"] in place; returns whether the command stands."""
+    existing = {}
+    for c in candidates:
+        n = c["labels"][fx.INSTANCE_TYPE]
+        existing[n] = min(existing.get(n, math.inf), candidate_price(cluster, c))
+    max_price = min([existing[n] for n in cmd["replacement"] if n in existing], default=math.inf)
+    reqs = {r["key"]: r for r in cmd["results"]["newNodeClaims"][0]["requirements"]}
+    by_name = {t["name"]: t for t in cluster["instanceTypes"]}
+    cmd["replacement"] = [n for n in cmd["replacement"] if worst_launch_price(by_name[n], reqs) < max_price]
+    # RemoveInstanceTypeOptionsByPriceAndMinValues (nodeclaim.go:411-420): what survives the price filter must still meet minValues
+    return bool(cmd["replacement"]) and _min_types_for_min_values(cmd["replacement"], reqs, by_name)[1]
+
+
+def first_n_bounds(n_candidates, max_n=100):
+    """The binary search's first window (multinodeconsolidation.go:117-126): prefix sizes lo+1 .. hi+1."""
+    return 1, (n_candidates - 1 if n_candidates <= max_n else max_n)
+
+
+def first_n_from_commands(n_candidates, command_of_prefix, max_n=100, evaluator=None, candidates=None):
+    """firstNConsolidationOption's walk (multinodeconsolidation.go:117-207) over commands that are already computed:
+    command_of_prefix(k) = the command for candidates[:k] with filterOutSameInstanceType applied (decision NOOP when it does not
+    stand). Same probe sequence and result as first_n_consolidation_option."""
+    evaluator = evaluator or NoopEvaluator()
+    if n_candidates < 2:
+        return {"decision": NOOP, "candidates": []}, []
+    lo, hi = first_n_bounds(n_candidates, max_n)
+    last, probes = {"decision": NOOP, "candidates": []}, []
+    while lo <= hi:
+        mid = (lo + hi) // 2
+        cmd = command_of_prefix(mid + 1)
+        probes.append((mid + 1, cmd["decision"]))
+        valid = cmd["decision"] in (DELETE, REPLACE)
+        if valid and candidates is not None:
+            approved, per_pool = evaluator.approve_command(candidates[: mid + 1], cmd)
+            cmd["scores"] = per_pool
+            valid = approved
+        if valid:
+            last, lo = cmd, mid + 1
+        else:
+            hi = mid - 1
+    return last, probes
+
+
 def first_n_consolidation_option(cluster, candidates, solver, max_n=100, evaluator=None):
     """multinodeconsolidation.go:117-207: binary search for the longest prefix that consolidates; same probe sequence.
     A valid decision is then scored by the evaluator (:166-174): Balanced pools may reject it, which shrinks the window."""
@@ -694,17 +759,7 @@ def first_n_consolidation_option(cluster, candidates, solver, max_n=100, evaluat
         probes.append((mid + 1, cmd["decision"]))
         valid = cmd["decision"] == DELETE
         if cmd["decision"] == REPLACE:
-            # filterOutSameInstanceType (multinodeconsolidation.go:209-246)
-            existing = {}
-            for c in candidates[: mid + 1]:
-                n = c["labels"][fx.INSTANCE_TYPE]
-                existing[n] = min(existing.get(n, math.inf), candidate_price(cluster, c))
-            max_price = min([existing[n] for n in cmd["replacement"] if n in existing], default=math.inf)
-            reqs = {r["key"]: r for r in cmd["results"]["newNodeClaims"][0]["requirements"]}
-            by_name = {t["name"]: t for t in cluster["instanceTypes"]}
-            cmd["replacement"] = [n for n in cmd["replacement"] if worst_launch_price(by_name[n], reqs) < max_price]
-            # RemoveInstanceTypeOptionsByPriceAndMinValues (nodeclaim.go:411-420): what survives the price filter must still meet minValues
-            valid = bool(cmd["replacement"]) and _min_types_for_min_values(cmd["replacement"], reqs, by_name)[1]
+            valid = filter_out_same_instance_type(cluster, candidates[: mid + 1], cmd)
         if valid:
             approved, per_pool = evaluator.approve_command(candidates[: mid + 1], cmd)
             cmd["scores"] = per_pool

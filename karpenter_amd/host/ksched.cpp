@@ -611,6 +611,9 @@ struct Session {
   std::vector<uint8_t> pod_pending_flag, pod_deleting_flag;
   std::vector<uint32_t> node_pod_off, node_pod_list, always_pods;   // CSR of the pods on each node; built on the first sweep
   std::vector<int32_t> node_input_index;   // position in the problem's stateNodes list -> sorted node index
+  std::vector<int32_t> node_it;            // instance type of each existing node (its node.kubernetes.io/instance-type label), -1 = unknown
+  std::vector<double> node_price;          // resolveNodePrice (disruption/types.go:113-127): the offering of its zone and capacity type, 0 = none
+  std::vector<uint8_t> node_spot;          // capacity-type label == spot
   struct OffLite { int zone, ct, rid; double price; bool available; };
   std::vector<std::vector<OffLite>> it_offerings;
   std::vector<std::vector<Expr>> it_exprs;
@@ -1877,6 +1880,21 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       S->it_offerings.resize(n_its);
       for (int i = 0; i < n_its; ++i) for (auto& o : it_offs[i]) S->it_offerings[i].push_back({o.zone, o.ct, o.rid, o.price, o.available});
       S->it_exprs = it_exprs;
+      std::map<std::string, int> it_by_name;
+      for (int i = 0; i < n_its; ++i) it_by_name.emplace(S->it_names[i], i);
+      S->node_it.assign(nodes.size(), -1); S->node_price.assign(nodes.size(), 0.0); S->node_spot.assign(nodes.size(), 0);
+      for (size_t e = 0; e < nodes.size(); ++e) {
+        const Value& nl = nodes[e].v->at("labels");
+        auto label = [&](const char* k) { return nl.has(k) ? nl.at(k).s() : std::string(); };
+        const std::string ctl = label(kCapacityType), zl = label(kZone);
+        S->node_spot[e] = ctl == "spot" ? 1 : 0;
+        auto f = it_by_name.find(label(kInstanceType));
+        if (f == it_by_name.end()) continue;
+        S->node_it[e] = f->second;
+        auto zi = D.value_index[k_zone].find(zl); auto ci = D.value_index[k_ct].find(ctl);
+        if (zi == D.value_index[k_zone].end() || ci == D.value_index[k_ct].end()) continue;
+        for (auto& o : it_offs[f->second]) if (o.zone == zi->second && o.ct == ci->second) { S->node_price[e] = o.price != o.price ? 0.0 : o.price; break; }
+      }
     }
     trace("done");
     return S;
@@ -1989,8 +2007,14 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
     Value doc = kj::Parser(sweep_json).parse();
     const auto& cands = doc.at("candidates").items();
     const uint32_t n = (uint32_t)cands.size();
-    const auto& prices = doc.at("prices").items();
-    const auto& all_spot = doc.at("allSpot").items();
+    // "prices" / "allSpot" may be left out: the session then takes every candidate's price from its own offering (node_price) and
+    // its capacity type from its label. "multiNode": the simulations are prefixes of MultiNodeConsolidation's binary search —
+    // a replace verdict over several candidates goes through filterOutSameInstanceType (multinodeconsolidation.go:209-246)
+    const bool own_prices = !doc.has("prices");
+    static const std::vector<Value> no_items;
+    const auto& prices = own_prices ? no_items : doc.at("prices").items();
+    const auto& all_spot = own_prices ? no_items : doc.at("allSpot").items();
+    const bool multi_node = doc.at("multiNode").boolean_or(false);
     const bool detail = doc.at("detail").boolean_or(false);
     const bool spot_to_spot = B->root.at("options").at("spotToSpotConsolidation").boolean_or(false);
     std::vector<uint32_t> node_off(n + 1, 0), pod_off(n + 1, 0), nodes, pods;
@@ -2058,7 +2082,12 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
       if (all_ok && live == 0) decision = 1;
       else if (all_ok && live == 1) {
         const uint32_t c = only;
-        const double price = p < prices.size() ? prices[p].d(0) : 0.0;
+        double price = p < prices.size() ? prices[p].d(0) : 0.0;
+        bool every_spot = p < all_spot.size() && all_spot[p].boolean_or(false);
+        if (own_prices) {   // getCandidatePrices (consolidation.go:345-356) and the allSpot test of :215-222, from the session's node table
+          price = 0.0; every_spot = node_off[p + 1] > node_off[p];
+          for (uint32_t j = node_off[p]; j < node_off[p + 1]; ++j) { price += B->node_price[nodes[j]]; every_spot = every_spot && B->node_spot[nodes[j]]; }
+        }
         ks::ReqRef r;
         r.mask = cl.req_mask + (size_t)c * cl.req_words; r.defined = cl.req_defined[c]; r.complement = cl.req_complement[c];
         r.has_gte = cl.req_has_gte[c]; r.has_lte = cl.req_has_lte[c]; r.gte = cl.req_gte + (size_t)c * nk; r.lte = cl.req_lte + (size_t)c * nk; r.minv = nullptr;
@@ -2066,7 +2095,7 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
         const bool ct_defined = kd.key_ct >= 0 && ks::bit(r.defined, kd.key_ct);
         const bool spot_ok = !ct_defined || (ct_order[1] >= 0 && has(kd.key_ct, ct_order[1]));
         const bool od_ok = !ct_defined || (ct_order[2] >= 0 && has(kd.key_ct, ct_order[2]));
-        if (p < all_spot.size() && all_spot[p].boolean_or(false) && spot_ok) {
+        if (every_spot && spot_ok) {
           // computeSpotToSpotConsolidation (consolidation.go:261-342): behind its feature gate; with the gate on the caller takes
           // the per-probe path (the 15-cheapest rule needs the whole ordered list)
           if (spot_to_spot) { decision = 3; }
@@ -2097,6 +2126,35 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
             std::set<std::string> seen;
             for (int it : cheaper) for (auto& e : B->it_exprs[it]) if (e.key == D.keys[k]) seen.insert(e.values.begin(), e.values.end());
             if ((int)seen.size() < want) mv_ok = false;
+          }
+          auto min_values_ok = [&](const std::vector<int>& its_) {
+            for (int k = 0; k < nk; ++k) {
+              const int want = cl.req_min_values[(size_t)c * nk + k];
+              if (want < 0 || !ks::bit(r.defined, k)) continue;
+              std::set<std::string> seen;
+              for (int it : its_) for (auto& e : B->it_exprs[it]) if (e.key == D.keys[k]) seen.insert(e.values.begin(), e.values.end());
+              if ((int)seen.size() < want) return false;
+            }
+            return true;
+          };
+          if (mv_ok && multi_node && !cheaper.empty() && node_off[p + 1] - node_off[p] > 1) {
+            // filterOutSameInstanceType (multinodeconsolidation.go:209-246): when a replacement option is one of the types being
+            // removed, the replacement must be cheaper than the cheapest candidate of that type — else deleting the others is the
+            // better command; RemoveInstanceTypeOptionsByPriceAndMinValues again with that price
+            std::map<int, double> existing;
+            for (uint32_t j = node_off[p]; j < node_off[p + 1]; ++j) {
+              const int it = B->node_it[nodes[j]];
+              if (it < 0) continue;
+              auto f = existing.find(it);
+              if (f == existing.end()) existing[it] = B->node_price[nodes[j]]; else if (B->node_price[nodes[j]] < f->second) f->second = B->node_price[nodes[j]];
+            }
+            double max_price = 1.0 / 0.0;
+            for (int it : cheaper) { auto f = existing.find(it); if (f != existing.end() && f->second < max_price) max_price = f->second; }
+            std::vector<int> kept;
+            for (int it : cheaper) if (worst(it) < max_price) kept.push_back(it);
+            cheaper.swap(kept);
+            if (cheaper.empty()) reasons.add_new(std::to_string(p), Value::string("every replacement option is one of the types being removed, or more expensive"));
+            else mv_ok = min_values_ok(cheaper);
           }
           if (!mv_ok) reasons.add_new(std::to_string(p), Value::string("minValues requirement is not met after filtering by price"));
           else if (!cheaper.empty()) {

@@ -142,16 +142,21 @@ class Scheduler:
         self._probes.append(probe)
         return probe
 
-    def Sweep(self, candidates, prices, all_spot, detail=False) -> dict:
+    def Sweep(self, candidates, prices=None, all_spot=None, detail=False, multi_node=False) -> dict:
         """A whole consolidation sweep of a RESIDENT cluster in one call (ksolve_sweep; disruption/helpers.go:53-155 +
         consolidation.go:159-256 per candidate set): `candidates` = one list of nodes (names, or positions in the problem's
         stateNodes list) per simulation, `prices` the summed candidate prices, `all_spot` whether every candidate is a spot
         node. The probe descriptors (displaced pods, NodePool limits handed back) are built by the host library, every
         simulation is one wavefront of one launch, the verdicts (0 no-op, 1 delete, 2 replace) come back with the replacement
-        instance types of the replace commands. detail=True adds where every pod went (tests)."""
+        instance types of the replace commands. detail=True adds where every pod went (tests). multi_node=True: the sets are
+        prefixes of MultiNodeConsolidation's binary search, a replace verdict over several candidates is filtered by
+        filterOutSameInstanceType (multinodeconsolidation.go:209-246)."""
         if not self._session:
             raise RuntimeError("scheduler is closed")
-        doc = json.dumps({"candidates": candidates, "prices": prices, "allSpot": all_spot, "detail": bool(detail)}).encode()
+        doc = {"candidates": candidates, "detail": bool(detail), "multiNode": bool(multi_node)}
+        if prices is not None:      # None: the library takes every candidate's price and capacity type from its own node table
+            doc.update(prices=prices, allSpot=all_spot)
+        doc = json.dumps(doc).encode()
         ptr = self._lib.ksched_sweep(self._session, doc)
         try:
             out = json.loads(ctypes.string_at(ptr).decode())

@@ -32,7 +32,7 @@ def _env():
 def test_single_rank_line(oracle):
     emu = parity.build_emu()
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--pods", "3000", "--types", "60", "--cpu-sample", "1500", "--cpu-runs", "3",
-           "--topology-pods", "400", "--components-pods", "4000", "--components-types", "60", "--components-calibration-pods", "4000", "--batch-problems", "3", "--batch-pods", "400", "--sweep-nodes", "300", "--sweep-candidates", "40", "--sweep-sample", "6", "--solver-lib", emu]
+           "--topology-pods", "400", "--components-pods", "4000", "--components-types", "60", "--components-calibration-pods", "4000", "--batch-problems", "3", "--batch-pods", "400", "--sweep-nodes", "300", "--sweep-candidates", "40", "--sweep-sample", "6", "--sweep-windows", "3", "--sweep-window-size", "12", "--solver-lib", emu]
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = _json_line(r.stdout)
@@ -62,6 +62,9 @@ def test_single_rank_line(oracle):
     assert sw["nodes"] == 300 and sw["candidates"] == 40 and sum(sw["decisions"].values()) == 40 and sw["unit"] == "probes/s" and sw["value"] > 0
     assert sw["oracle_check"]["all_identical"] is True and sw["oracle_check"]["probes"] >= 3 and sw["cpu_baseline"]["kind"] == "port" and sw["cpu_baseline"]["unit"] == "probes/s"
     assert abs(sw["value"] - sw["candidates"] / sw["seconds"]["library_call"]) <= 1e-9 * sw["value"]
+    mn = sw["multi_node"]      # the multi-node half of the replay: every prefix of every window in one sweep, the binary search as a walk
+    assert mn["windows"] == 3 and mn["window_candidates"] == 13 and mn["probes"] == 36 == sum(mn["decisions_of_all_prefixes"].values()) and sum(mn["commands"]["decisions"].values()) == 3
+    assert mn["oracle_check"]["all_identical"] is True and mn["oracle_check"]["probes"] >= 3 and mn["unit"] == "probes/s" and abs(mn["value"] - mn["probes"] / mn["seconds"]["library_call"]) <= 1e-9 * mn["value"]
     assert line["config2_topology"]["oracle_pin"] is None
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "pods/s" and cb["value"] > 0 and len(cb["runs_seconds"]) == 3
@@ -72,7 +75,7 @@ def test_two_ranks_under_the_drivers_launcher(oracle):
     emu = parity.build_emu()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--pods", "2500", "--types", "60", "--components-pods", "4000", "--components-types", "60", "--components-calibration-pods", "4000", "--sweep-nodes", "300", "--sweep-candidates", "41", "--sweep-sample", "3", "--solver-lib", emu]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--pods", "2500", "--types", "60", "--components-pods", "4000", "--components-types", "60", "--components-calibration-pods", "4000", "--sweep-nodes", "300", "--sweep-candidates", "41", "--sweep-sample", "3", "--sweep-windows", "3", "--sweep-window-size", "12", "--solver-lib", emu]
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = _json_line(r.stdout)
@@ -98,6 +101,8 @@ def test_two_ranks_under_the_drivers_launcher(oracle):
     # BASELINE configs[4] across the ranks: the candidates dealt out round-robin, verdict counts summed with one all-reduce
     sw = line["config4_sweep"]
     assert sw["ranks"] == 2 and sw["candidates_all_ranks"] == 41 and sum(sw["decisions_all_ranks"].values()) == 41 and sw["candidates"] == 21 and sw["value"] > 0
+    mn = sw["multi_node"]      # three windows over two ranks: rank 0 holds two of them
+    assert mn["ranks"] == 2 and mn["windows"] == 3 and mn["probes"] == 24 and mn["probes_all_ranks"] == 36 and mn["value"] > 0
 
 
 def test_the_hook_needs_its_environment_switch():

@@ -557,6 +557,58 @@ def test_resident_cluster_probes_match_per_probe_rebuild(oracle, emu, seed, limi
     rc.close()
 
 
+@pytest.mark.parametrize("seed", [1, 3, 5, 8])
+def test_multi_node_search_as_one_sweep(oracle, emu, seed):
+    """MultiNodeConsolidation.firstNConsolidationOption (multinodeconsolidation.go:117-207) with EVERY prefix simulated in one
+    launch (ResidentCluster.first_n: ksolve_sweep over all the prefixes, verdicts incl. filterOutSameInstanceType from the host
+    library, then the binary search as a walk over them): the same probe sequence and command as the search that calls the
+    oracle once per step, and every prefix's verdict equals computeConsolidation + the same-type filter on the oracle's Results."""
+    cluster = _tight_cluster(seed)
+    cands = [n for n in dz.sort_candidates(cluster, cluster["nodes"]) if not n.get("markedForDeletion")][:14]
+    rc = dz.ResidentCluster(cluster, cands, solver_lib=emu)
+    a, pa = rc.first_n(cands)
+    b, pb = dz.first_n_consolidation_option(cluster, cands, oracle.solve)
+    assert pa == pb and strip(a) == strip(b)
+    sets = [cands[:k] for k in range(2, len(cands) + 1)]
+    got = rc.decisions(sets, multi_node=True)
+    assert [strip(c) for c in rc.decisions(sets, multi_node=True, library_prices=True)] == [strip(c) for c in got]   # prices / capacity types from the library's node table
+    for cs, g in zip(sets, got):
+        w = dz.compute_consolidation(cluster, cs, oracle.solve)
+        if w["decision"] == dz.REPLACE and not dz.filter_out_same_instance_type(cluster, cs, w):
+            w = {"decision": dz.NOOP, "replacement": None}
+        assert (g["decision"], g["replacement"]) == (w["decision"], w.get("replacement")), (len(cs), g, strip(w))
+    rc.close()
+
+
+def test_same_instance_type_filter_in_the_sweep(oracle, emu):
+    """filterOutSameInstanceType (multinodeconsolidation.go:209-246) inside the sweep's verdicts. [2 x the priciest type, 1 x a
+    small type] -> one node: the small type is among the replacement options, so only options cheaper than the small node
+    survive; when nothing is cheaper the prefix is no command at all, while plain computeConsolidation (single-node, validation)
+    keeps its unfiltered list."""
+    its = fx.fake_instance_types_assorted()
+    od = lambda t: [o for o in t["offerings"] if dz._capacity_type(o) == "on-demand"]
+    priciest, offering = max(((t, o) for t in its for o in od(t)), key=lambda x: x[1]["price"])
+    zone = [r["values"][0] for r in offering["requirements"] if r["key"] == fx.ZONE][0]
+    in_zone = lambda t: [o for o in od(t) if [r["values"][0] for r in o["requirements"] if r["key"] == fx.ZONE][0] == zone and o.get("available", True)]
+    fits = sorted((t for t in its if in_zone(t) and int(t["capacity"]["cpu"]) >= 2), key=lambda t: in_zone(t)[0]["price"])
+    changed = 0
+    for small in (fits[0], fits[len(fits) // 3]):
+        nodes = [_node_with_pods("node-0", priciest, zone, "on-demand", ["100m"]), _node_with_pods("node-1", priciest, zone, "on-demand", ["100m"]),
+                 _node_with_pods("node-2", small, zone, "on-demand", ["100m"])]
+        cluster = {"instanceTypes": its, "nodePools": [fx.node_pool()], "nodes": nodes, "pendingPods": []}
+        cands = dz.sort_candidates(cluster, nodes)
+        rc = dz.ResidentCluster(cluster, cands, solver_lib=emu)
+        a, pa = rc.first_n(cands)
+        b, pb = dz.first_n_consolidation_option(cluster, cands, oracle.solve)
+        assert pa == pb and strip(a) == strip(b)
+        plain, filtered = rc.decisions([cands], multi_node=False)[0], rc.decisions([cands], multi_node=True)[0]
+        assert plain["decision"] == dz.REPLACE and small["name"] in plain["replacement"]
+        assert filtered["decision"] == dz.NOOP or (small["name"] not in filtered["replacement"] and set(filtered["replacement"]) < set(plain["replacement"]))
+        changed += filtered != plain
+        rc.close()
+    assert changed == 2
+
+
 def test_probe_api_rejects_bad_descriptors(emu):
     cluster = dz.make_cluster(n_nodes=6, pods_per_node=2, seed=2)
     rc = dz.ResidentCluster(cluster, cluster["nodes"][:3], solver_lib=emu)

@@ -526,3 +526,47 @@ def test_consolidation_sweep_over_a_10k_node_cluster_with_topology_pods(oracle, 
         assert (cmds[j]["decision"], cmds[j]["replacement"]) == (want["decision"], want["replacement"]), (j, cmds[j], want["decision"])
         assert rc.last_sweep["referenceBinEvaluations"][j] == r["counters"]["binEvaluations"]
     rc.close()
+
+
+@pytest.mark.parametrize("topology", [False, True], ids=["plain", "topology"])
+def test_multi_node_consolidation_windows_on_a_10k_node_cluster(oracle, monkeypatch, topology):
+    """The multi-node half of BASELINE configs[4] at a tenth of its size: a resident cluster of 10k nodes, four windows of 41
+    candidates in sortCandidates' order, every prefix of 2..41 nodes a probe of ONE ksolve_sweep (chunked: the arena budget is
+    lowered), verdicts incl. filterOutSameInstanceType from the host library, firstNConsolidationOption's binary search
+    (multinodeconsolidation.go:117-207) as a walk over them. Prefixes of several sizes are re-simulated by the oracle — with
+    topology, over a cluster whose bound pods carry spread constraints (the probe takes up to 41 nodes' pods out of the counts)."""
+    from karpenter_amd import disruption as dz
+    monkeypatch.setenv("KSOLVE_SWEEP_ARENA_MB", "512")
+    cc = dz.make_resident_cluster(n_nodes=10_000, seed=11, topology=topology)
+    rc = dz.ResidentCluster.from_compact(cc)
+    full, K = dz.compact_candidates(cc), 41
+    sets, key = [], []
+    for w in range(4):
+        win = [cc["nodes"][i] for i in full[w * K * 50:w * K * 50 + K]]          # windows from different stretches of the order
+        for k in range(2, K + 1):
+            sets.append(win[:k]); key.append((w, k))
+    cmds = rc.decisions(sets, multi_node=True, library_prices=True)
+    refs = rc.last_sweep["referenceBinEvaluations"]
+    assert [(c["decision"], c["replacement"]) for c in rc.decisions(sets[:40], multi_node=True)] == [(c["decision"], c["replacement"]) for c in cmds[:40]]   # prices summed by the caller
+    by = dict(zip(key, cmds))
+    for w in range(4):
+        cmd, probes = dz.first_n_from_commands(K, lambda k: by[(w, k)], K - 1)
+        assert 4 <= len(probes) <= 6 and (cmd["decision"] == dz.NOOP or len(cmd["candidates"]) >= 2)
+    picks = [(0, 2), (1, 9), (2, 20), (3, 41), (0, 41)]
+    base = dz.compact_problem(cc, pod_groups=[])
+    if topology:
+        base["clusterPods"] = dz.compact_cluster_pods(cc)
+    probes, cand_sets = [], []
+    for w, k in picks:
+        idx = full[w * K * 50:w * K * 50 + k]
+        pods = [dz.compact_node_pods(cc, i) for i in idx]
+        probes.append({"removeNodes": [cc["nodes"][i]["name"] for i in idx], "pods": [p for ps in pods for p in ps]})
+        cand_sets.append([dict(cc["nodes"][i], pods=ps) for i, ps in zip(idx, pods)])
+    res = oracle.sweep(base, probes, threads=min(len(probes), os.cpu_count() or 1))
+    for kk, r, cs in zip(picks, res, cand_sets):
+        want = dz.decide(cc, cs, dz._finish_simulation(cc, r, set()))
+        if want["decision"] == dz.REPLACE and not dz.filter_out_same_instance_type(cc, cs, want):
+            want = {"decision": dz.NOOP, "replacement": None}
+        assert (by[kk]["decision"], by[kk]["replacement"]) == (want["decision"], want.get("replacement")), (kk, by[kk], want["decision"])
+        assert refs[key.index(kk)] == r["counters"]["binEvaluations"]
+    rc.close()

@@ -15,8 +15,11 @@ ks.Scheduler.__init__ = _init
 import test_gpu_parity as t
 import pathlib, tempfile
 failed = 0
+only = sys.argv[1:]      # optional: substrings of the test names to run
+class _Env:              # the one thing the tests ask of pytest's monkeypatch
+    def setenv(self, k, v): os.environ[k] = v
 for name, fn in sorted(inspect.getmembers(t, inspect.isfunction)):
-    if not name.startswith("test_") or name == "test_plain_c_example_on_the_device":
+    if not name.startswith("test_") or name == "test_plain_c_example_on_the_device" or (only and not any(o in name for o in only)):
         continue
     params = inspect.signature(fn).parameters
     marks = [m for m in getattr(fn, "pytestmark", []) if m.name == "parametrize"]
@@ -28,6 +31,7 @@ for name, fn in sorted(inspect.getmembers(t, inspect.isfunction)):
         kw = dict(case) if case else {}
         if "oracle" in params: kw["oracle"] = oracle
         if "tmp_path" in params: kw["tmp_path"] = pathlib.Path(tempfile.mkdtemp())
+        if "monkeypatch" in params: kw["monkeypatch"] = _Env()
         t0 = time.time()
         try:
             fn(**kw); print("ok  ", name, case if case else "", round(time.time()-t0, 1), "s", flush=True)
