@@ -168,6 +168,16 @@ KS_FN bool rows_equal(const RowArgs& a, int x, int y) {
 // re-seeds). The table is read before it is written: with a few thousand classes for a million rows nearly every row
 // finds its hash and a smaller representative already there and issues no atomic at all (a stale read only shows an
 // older state — empty slot, larger representative — and falls through to the atomic).
+// bit w of (m0, m1): mask word w belongs to a key the set defines
+// (A branch-free form — every key's word range as uniform masks, selected by the lane's `defined` bit — measured slower on the
+// MI355X, 87-89 us against 77 us for the classing kernel: rows define a few of the 13 keys, skipping the others is cheaper.)
+KS_FN void word_defined_mask(const Dict& d, uint32_t defined, uint64_t& m0, uint64_t& m1) {
+  m0 = 0; m1 = 0;
+  for (int k = 0; k < d.n_keys; ++k) {
+    if (!bit(defined, k)) continue;
+    for (uint32_t w = d.key_word_off[k]; w < d.key_word_off[k + 1]; ++w) { if (w < 64) m0 |= 1ull << w; else m1 |= 1ull << (w - 64); }
+  }
+}
 // The difference of two requirement sets whose words are near (LDS): no early exit on the mask words, every word is loaded
 // whatever the words before it held, so the loads are independent and in flight together (an early exit per word makes
 // 2 x req_words DEPENDENT round trips out of one comparison). Words of keys the set does not define are ignored, as in
@@ -175,11 +185,8 @@ KS_FN bool rows_equal(const RowArgs& a, int x, int y) {
 KS_FN uint64_t reqset_diff(const Dict& d, const ReqRef& a, const ReqRef& b) {
   uint64_t diff = (uint64_t)((a.defined ^ b.defined) | (a.complement ^ b.complement) | (a.has_gte ^ b.has_gte) | (a.has_lte ^ b.has_lte));
   // bit w of wdef: word w belongs to a key the set defines
-  uint64_t wdef0 = 0, wdef1 = 0;
-  for (int k = 0; k < d.n_keys; ++k) {
-    if (!bit(a.defined, k)) continue;
-    for (uint32_t w = d.key_word_off[k]; w < d.key_word_off[k + 1]; ++w) { if (w < 64) wdef0 |= 1ull << w; else wdef1 |= 1ull << (w - 64); }
-  }
+  uint64_t wdef0, wdef1;
+  word_defined_mask(d, a.defined, wdef0, wdef1);
   const int rw = d.req_words;
   int w = 0;
   for (; w + 4 <= rw; w += 4) {
@@ -216,11 +223,13 @@ KS_FN uint64_t reqset_diff(const Dict& d, const ReqRef& a, const ReqRef& b) {
 // in registers (the wave-cooperative kernel loads them with everything else of the block in one go).
 // SAME: the strict table of this launch IS the requirement table (every row's qs equals its q): the second set adds nothing to
 // the hash of a row among the rows of the same launch, so it is left out — all rows of a launch are hashed by the same kernel.
-template <bool SAME = false, class ReqAt>
+// NRM: the caller's bound on n_res (8 = ksolve.h's; a launch of a problem with at most four resource dimensions says 4 and
+// carries four request registers instead of eight).
+template <bool SAME = false, int NRM = 8, class ReqAt>
 KS_FN uint64_t row_hash_value_with(int row, const RowArgs& a, const ReqRef& q, const ReqRef& qs, ReqAt req_at, uint64_t tol) {
   uint64_t h = a.seed;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) if (r < a.n_res) h = mix64(h, (uint64_t)req_at(r));   // n_res <= 8 (ksolve.h); unrolled: req_at may index registers
+  for (int r = 0; r < NRM; ++r) if (r < a.n_res) h = mix64(h, (uint64_t)req_at(r));   // unrolled: req_at may index registers
   h = hash_reqset(a.dict, h, q);
   if (!SAME) h = hash_reqset(a.dict, h, qs);
   h = mix64(h, tol);
@@ -259,21 +268,17 @@ KS_FN uint32_t row_table_insert(int row, const RowArgs& a, uint64_t h, uint32_t*
   if (other > (uint32_t)row) other = atomic_min_u32(&a.table_rep[slot], (uint32_t)row);
   return other == (uint32_t)row ? 0xFFFFFFFFu : other;
 }
-// bit w of (m0, m1): mask word w belongs to a key the set defines
-KS_FN void word_defined_mask(const Dict& d, uint32_t defined, uint64_t& m0, uint64_t& m1) {
-  m0 = 0; m1 = 0;
-  for (int k = 0; k < d.n_keys; ++k) {
-    if (!bit(defined, k)) continue;
-    for (uint32_t w = d.key_word_off[k]; w < d.key_word_off[k + 1]; ++w) { if (w < 64) m0 |= 1ull << w; else m1 |= 1ull << (w - 64); }
-  }
-}
 // rows_equal(row, rep) for a row whose requirement sets (q, qs), requests (req_at) and toleration mask (tol) are at hand and
 // a representative `rep` that is far away (HBM / L2): every access to rep's row is issued before the first one is used —
 // flags, requests, minValues and the first kRowFarBatch mask words of both sets are ONE round trip, not one per field.
 // Returns 0 when the rows are equal. Words of keys the set does not define are ignored, as in equal_reqset.
 constexpr int kRowFarBatch = 20;   // mask words per set and batch: a 1280-value dictionary in one batch
 constexpr int kRowFarKeys = 16;
-template <bool SAME = false, class ReqAt>   // SAME: see row_hash_value_with — the strict side is the same memory, compared once
+// SAME: see row_hash_value_with — the strict side is the same memory, compared once. MINV = false: the launch has no minValues
+// tables (the caller knows). Loads of mask words and requests past the row's end are CLAMPED, not branched around: a uniform
+// branch per element costs a lone SIMD more than the load, and a word past req_words belongs to no defined key (its compare is
+// masked), a request past n_res repeats request 0 on both sides.
+template <bool SAME = false, bool MINV = true, int NRM = 8, class ReqAt>
 KS_FN uint64_t row_diff_far(int row, const RowArgs& a, uint32_t rep, const ReqRef& q, const ReqRef& qs, ReqAt req_at, uint64_t tol) {
   const Dict& d = a.dict;
   const int rw = d.req_words, nk = d.n_keys, nr = a.n_res;
@@ -282,31 +287,32 @@ KS_FN uint64_t row_diff_far(int row, const RowArgs& a, uint32_t rep, const ReqRe
   // ---- the loads ----
   uint64_t w0[kRowFarBatch], w1[kRowFarBatch];
 #pragma unroll
-  for (int i = 0; i < kRowFarBatch; ++i) { w0[i] = i < rw ? b0[i] : 0ull; w1[i] = (!SAME && i < rw) ? b1[i] : 0ull; }
+  for (int i = 0; i < kRowFarBatch; ++i) { const int x = i < rw ? i : rw - 1; w0[i] = b0[x]; w1[i] = SAME ? 0ull : b1[x]; }
   const uint32_t f0 = a.reqs.defined[rep], f1 = a.reqs.complement[rep], f2 = a.reqs.has_gte ? a.reqs.has_gte[rep] : 0u, f3 = a.reqs.has_lte ? a.reqs.has_lte[rep] : 0u;
   const uint32_t s0 = SAME ? f0 : a.strict.defined[rep], s1 = SAME ? f1 : a.strict.complement[rep], s2 = SAME ? f2 : a.strict.has_gte ? a.strict.has_gte[rep] : 0u, s3 = SAME ? f3 : a.strict.has_lte ? a.strict.has_lte[rep] : 0u;
-  int64_t bq[8];
+  int64_t bq[NRM];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) bq[r] = r < nr ? a.requests[(size_t)r * a.n_rows + rep] : 0;
+  for (int r = 0; r < NRM; ++r) bq[r] = a.requests[(size_t)(r < nr ? r : 0) * a.n_rows + rep];
   const uint64_t btol = a.tolerates[rep];
-  const int32_t* bm0 = a.reqs.minv ? a.reqs.minv + (size_t)rep * nk : nullptr;
-  const int32_t* bm1 = (!SAME && a.strict.minv) ? a.strict.minv + (size_t)rep * nk : nullptr;
+  const int32_t* bm0 = (MINV && a.reqs.minv) ? a.reqs.minv + (size_t)rep * nk : nullptr;
+  const int32_t* bm1 = (MINV && !SAME && a.strict.minv) ? a.strict.minv + (size_t)rep * nk : nullptr;
   int32_t v0[kRowFarKeys], v1[kRowFarKeys];
 #pragma unroll
-  for (int k = 0; k < kRowFarKeys; ++k) { v0[k] = (bm0 && k < nk) ? bm0[k] : -1; v1[k] = (!SAME && bm1 && k < nk) ? bm1[k] : -1; }
+  for (int k = 0; k < kRowFarKeys; ++k) { v0[k] = (MINV && bm0 && k < nk) ? bm0[k] : -1; v1[k] = (MINV && !SAME && bm1 && k < nk) ? bm1[k] : -1; }
   // ---- the comparison ----
   uint64_t diff = (uint64_t)((f0 ^ q.defined) | (f1 ^ q.complement) | (f2 ^ q.has_gte) | (f3 ^ q.has_lte) |
                              (s0 ^ qs.defined) | (s1 ^ qs.complement) | (s2 ^ qs.has_gte) | (s3 ^ qs.has_lte));
   diff |= btol ^ tol;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) if (r < nr) diff |= (uint64_t)(bq[r] ^ req_at(r));
+  for (int r = 0; r < NRM; ++r) if (r < nr) diff |= (uint64_t)(bq[r] ^ req_at(r));
   uint64_t d00, d01, d10, d11;
   word_defined_mask(d, q.defined, d00, d01);
   if (SAME) { d10 = 0; d11 = 0; } else word_defined_mask(d, qs.defined, d10, d11);
 #pragma unroll
-  for (int i = 0; i < kRowFarBatch; ++i) if (i < rw) {
-    diff |= (q.mask[i] ^ w0[i]) & (0ull - ((d00 >> i) & 1ull));
-    if (!SAME) diff |= (qs.mask[i] ^ w1[i]) & (0ull - ((d10 >> i) & 1ull));
+  for (int i = 0; i < kRowFarBatch; ++i) {   // i >= rw: no defined key owns the word, the mask is zero (q.mask is read clamped too)
+    const int x = i < rw ? i : rw - 1;
+    diff |= (q.mask[x] ^ w0[i]) & (0ull - ((d00 >> i) & 1ull));
+    if (!SAME) diff |= (qs.mask[x] ^ w1[i]) & (0ull - ((d10 >> i) & 1ull));
   }
   for (int w = kRowFarBatch; w < rw; w += kRowFarBatch) {   // dictionaries beyond one batch
 #pragma unroll
@@ -318,13 +324,15 @@ KS_FN uint64_t row_diff_far(int row, const RowArgs& a, uint32_t rep, const ReqRe
       if (!SAME) diff |= (qs.mask[x] ^ w1[i]) & (0ull - (((x < 64 ? d10 >> x : d11 >> (x - 64))) & 1ull));
     }
   }
+  if (MINV) {
 #pragma unroll
-  for (int k = 0; k < kRowFarKeys; ++k) if (k < nk) {
-    const int32_t am = q.minv ? q.minv[k] : -1, as = qs.minv ? qs.minv[k] : -1;
-    diff |= (uint64_t)(uint32_t)(am ^ v0[k]) & (0ull - (uint64_t)((q.defined >> k) & 1u));
-    if (!SAME) diff |= (uint64_t)(uint32_t)(as ^ v1[k]) & (0ull - (uint64_t)((qs.defined >> k) & 1u));
+    for (int k = 0; k < kRowFarKeys; ++k) if (k < nk) {
+      const int32_t am = q.minv ? q.minv[k] : -1, as = qs.minv ? qs.minv[k] : -1;
+      diff |= (uint64_t)(uint32_t)(am ^ v0[k]) & (0ull - (uint64_t)((q.defined >> k) & 1u));
+      if (!SAME) diff |= (uint64_t)(uint32_t)(as ^ v1[k]) & (0ull - (uint64_t)((qs.defined >> k) & 1u));
+    }
   }
-  for (int k = kRowFarKeys; k < nk; ++k) {
+  if (MINV) for (int k = kRowFarKeys; k < nk; ++k) {
     const int32_t am = q.minv ? q.minv[k] : -1, as = qs.minv ? qs.minv[k] : -1;
     diff |= (uint64_t)(uint32_t)(am ^ (bm0 ? bm0[k] : -1)) & (0ull - (uint64_t)((q.defined >> k) & 1u));
     if (!SAME) diff |= (uint64_t)(uint32_t)(as ^ (bm1 ? bm1[k] : -1)) & (0ull - (uint64_t)((qs.defined >> k) & 1u));

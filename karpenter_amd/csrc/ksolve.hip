@@ -254,8 +254,8 @@ struct CoopStage {
 // past the end reads piece 0 instead (no branch around a load: a branch makes the compiler wait for every load before it).
 // SAME: the strict table IS the requirement table (no pod of the batch has a preference: PodData.StrictRequirements ==
 // Requirements, scheduler.go:217-229, and the flattener hands both under one pointer) — it is read and staged once.
-template <bool FULL, bool MINV, bool SAME>
-__device__ __forceinline__ void coop_stage(const ks::CoopStage& s, const ks::RowArgs& a, int rowc, ks::ReqRef& q, ks::ReqRef& qs, int64_t (&rq)[8], uint64_t& tol) {
+template <bool FULL, bool MINV, bool SAME, int NRM>
+__device__ __forceinline__ void coop_stage(const ks::CoopStage& s, const ks::RowArgs& a, int rowc, ks::ReqRef& q, ks::ReqRef& qs, int64_t (&rq)[NRM], uint64_t& tol) {
   uint4 A[kCoopMaskCh], B[SAME ? 1 : kCoopMaskCh], KA[kCoopMinvCh], KB[SAME ? 1 : kCoopMinvCh];
   const int l = s.l, nr = a.n_res;
 #pragma unroll
@@ -276,7 +276,7 @@ __device__ __forceinline__ void coop_stage(const ks::CoopStage& s, const ks::Row
   if (SAME) { qs.defined = q.defined; qs.complement = q.complement; qs.has_gte = q.has_gte; qs.has_lte = q.has_lte; }
   else { qs.defined = a.strict.defined[rowc]; qs.complement = a.strict.complement[rowc]; qs.has_gte = a.strict.has_gte[rowc]; qs.has_lte = a.strict.has_lte[rowc]; }
 #pragma unroll
-  for (int r = 0; r < 8; ++r) rq[r] = a.requests[(size_t)(r < nr ? r : 0) * a.n_rows + rowc];
+  for (int r = 0; r < NRM; ++r) rq[r] = a.requests[(size_t)(r < nr ? r : 0) * a.n_rows + rowc];
   tol = a.tolerates[rowc];
 #pragma unroll
   for (int i = 0; i < kCoopMaskCh; ++i) { const int e = 2 * (l + 64 * i); coop_drop_u64x2<FULL>(s.t0, A[i], e, s.total, s.rw, s.stride, s.magic); if (!SAME) coop_drop_u64x2<FULL>(s.t1, B[i], e, s.total, s.rw, s.stride, s.magic); }
@@ -299,7 +299,7 @@ __device__ __forceinline__ void coop_stage(const ks::CoopStage& s, const ks::Row
 }
 // MINV: the rows carry minValues (pod rows never do when they come from the reference's PodData — minValues belong to NodePool
 // requirements — so the tables are absent and neither streamed nor staged)
-template <bool MINV, bool SAME>
+template <bool MINV, bool SAME, int NRM>
 __device__ __forceinline__ void row_hash_coop2_body(uint64_t* coop_lds, int n, const ks::RowArgs& a, int rw, uint32_t magic, uint32_t kmagic, int rpb) {
   const int l = (int)threadIdx.x;
   const int row0 = (int)blockIdx.x * rpb;   // rpb rows per block: 64 (60, a multiple of 4, only through the A/B switch of the launcher)
@@ -321,11 +321,11 @@ __device__ __forceinline__ void row_hash_coop2_body(uint64_t* coop_lds, int n, c
   const int rowc = live ? row : n - 1;
   // ---- every HBM access of the block, then [row][word] in LDS ----
   ks::ReqRef q, qs;
-  int64_t rq[8];
+  int64_t rq[NRM];   // NRM = 4 when the problem has at most four resource dimensions (the launcher knows)
   uint64_t tol;
   const ks::CoopStage st{g0, g1, k0, k1, t0, t1, m0, m1, total, ktotal, rw, stride, nk, kstride, magic, kmagic, l};
-  if (rows == rpb) coop_stage<true, MINV, SAME>(st, a, rowc, q, qs, rq, tol);     // branch-free: no wait is placed before the last load is out
-  else coop_stage<false, MINV, SAME>(st, a, rowc, q, qs, rq, tol);               // the last block of the table
+  if (rows == rpb) coop_stage<true, MINV, SAME, NRM>(st, a, rowc, q, qs, rq, tol);     // branch-free: no wait is placed before the last load is out
+  else coop_stage<false, MINV, SAME, NRM>(st, a, rowc, q, qs, rq, tol);               // the last block of the table
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
   // ---- the row's hash, out of LDS and registers ----
@@ -334,7 +334,7 @@ __device__ __forceinline__ void row_hash_coop2_body(uint64_t* coop_lds, int n, c
   q.gte = a.reqs.gte ? a.reqs.gte + (size_t)rowc * nk : nullptr; q.lte = a.reqs.lte ? a.reqs.lte + (size_t)rowc * nk : nullptr;
   qs.gte = a.strict.gte ? a.strict.gte + (size_t)rowc * nk : nullptr; qs.lte = a.strict.lte ? a.strict.lte + (size_t)rowc * nk : nullptr;
   auto req_at = [&](int r) -> int64_t { return rq[r]; };   // every caller unrolls over r: register indices
-  const uint64_t h = live ? ks::row_hash_kept(a, ks::row_hash_value_with<SAME>(row, a, q, qs, req_at, tol)) : 0ull;
+  const uint64_t h = live ? ks::row_hash_kept(a, ks::row_hash_value_with<SAME, NRM>(row, a, q, qs, req_at, tol)) : 0ull;
   // ---- the first lane of every distinct hash ----
   int lead = l;
   uint64_t todo = __ballot(live ? 1 : 0);
@@ -351,7 +351,7 @@ __device__ __forceinline__ void row_hash_coop2_body(uint64_t* coop_lds, int n, c
   slot = (uint32_t)__shfl((int)slot, lead, 64);
   if (live) a.row_slot[row] = slot;
   uint64_t d = 0;
-  if (leader && rep != 0xFFFFFFFFu) d = ks::row_diff_far<SAME>(row, a, rep, q, qs, req_at, tol);
+  if (leader && rep != 0xFFFFFFFFu) d = ks::row_diff_far<SAME, MINV, NRM>(row, a, rep, q, qs, req_at, tol);
   // ---- a follower equals its leader: flags and requests by shuffle, mask words and minValues LDS to LDS ----
   ks::ReqRef qj, qsj;
   qj.defined = (uint32_t)__shfl((int)q.defined, lead, 64); qj.complement = (uint32_t)__shfl((int)q.complement, lead, 64);
@@ -360,7 +360,7 @@ __device__ __forceinline__ void row_hash_coop2_body(uint64_t* coop_lds, int n, c
   qsj.has_gte = (uint32_t)__shfl((int)qs.has_gte, lead, 64); qsj.has_lte = (uint32_t)__shfl((int)qs.has_lte, lead, 64);
   uint64_t dq = (uint64_t)__shfl((unsigned long long)tol, lead, 64) ^ tol;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) if (r < nr) dq |= (uint64_t)__shfl((unsigned long long)rq[r], lead, 64) ^ (uint64_t)rq[r];
+  for (int r = 0; r < NRM; ++r) if (r < nr) dq |= (uint64_t)__shfl((unsigned long long)rq[r], lead, 64) ^ (uint64_t)rq[r];
   if (live && !leader) {
     const size_t rowj = (size_t)(row0 + lead);
     qj.mask = t0 + (size_t)lead * stride; qsj.mask = t1 + (size_t)lead * stride;
@@ -378,10 +378,10 @@ __device__ __forceinline__ void row_hash_coop2_body(uint64_t* coop_lds, int n, c
   }
   if (d) *a.collision = 1;
 }
-template <bool MINV, bool SAME = false>
+template <bool MINV, bool SAME = false, int NRM = 8>
 __global__ void __launch_bounds__(64) ksolve_row_hash_coop2(int n, ks::RowArgs a, int rw, uint32_t magic, uint32_t kmagic, int rpb) {
   extern __shared__ __attribute__((aligned(16))) uint64_t coop_lds[];
-  row_hash_coop2_body<MINV, SAME>(coop_lds, n, a, rw, magic, kmagic, rpb);
+  row_hash_coop2_body<MINV, SAME, NRM>(coop_lds, n, a, rw, magic, kmagic, rpb);
 }
 // (A build of the one-table form at four wavefronts per SIMD — amdgpu_waves_per_eu(4,4), 128 VGPRs instead of the 149 it takes —
 // measured 157 us against 79.6 us: the spills cost more than the fourth wavefront hides; profiles/README.md.)
@@ -518,9 +518,12 @@ static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) {
   const bool tables = (minv || no_minv) && a.reqs.has_gte && a.reqs.has_lte && a.strict.has_gte && a.strict.has_lte;
   if (!plain && !coop1 && rw >= 1 && nk >= 1 && a.n_res >= 1 && a.n_res <= 8 && aligned && tables && lds2 <= 64 * 1024) {
     const dim3 grid((unsigned)((n + rpb - 1) / rpb));
+    const bool nr4 = a.n_res <= 4;   // four request registers instead of eight (cpu, memory, pods, ephemeral-storage: the usual problem)
     if (minv && same) hipLaunchKernelGGL((ksolve_row_hash_coop2<true, true>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
     else if (minv) hipLaunchKernelGGL((ksolve_row_hash_coop2<true, false>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
+    else if (same && nr4) hipLaunchKernelGGL((ksolve_row_hash_coop2<false, true, 4>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
     else if (same) hipLaunchKernelGGL((ksolve_row_hash_coop2<false, true>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
+    else if (nr4) hipLaunchKernelGGL((ksolve_row_hash_coop2<false, false, 4>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
     else hipLaunchKernelGGL((ksolve_row_hash_coop2<false, false>), grid, dim3(64), lds2, HB(h)->stream, n, a, rw, magic, kmagic, rpb);
   } else if (!plain && rw >= 1 && nk >= 1 && lds1 <= 64 * 1024) {
     hipLaunchKernelGGL(ksolve_row_hash_coop, dim3((unsigned)((n + 63) / 64)), dim3(64), lds1, HB(h)->stream, n, a, rw, magic, kmagic);

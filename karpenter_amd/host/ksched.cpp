@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstring>
 #include <map>
+#include <unordered_map>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -605,7 +606,7 @@ struct Session {
   std::vector<int> node_tmpl;              // template (NodePool) of each existing node, -1 = none / pool without limits
   std::vector<int64_t> node_limit_cap;     // [n_nodes][n_res+1] node capacity on the dimensions its pool limits (device units)
   std::vector<int64_t> tmpl_lim;           // [n_templates][n_res+1] remaining limits of the base problem
-  std::map<std::string, int> node_index, pod_index;   // built on the first probe
+  std::unordered_map<std::string, int> node_index, pod_index;   // built on the first probe
   // sweeps of a resident cluster (ksched_sweep): which node every pod sits on, the verdict inputs computeConsolidation needs
   std::vector<int32_t> pod_node;           // existing node (sorted order) a pod is bound to, -1 = pending / on a deleting node: part of every simulation
   std::vector<uint8_t> pod_pending_flag, pod_deleting_flag;
@@ -1935,7 +1936,7 @@ extern "C" void* ksched_probe(void* base_session, const char* probe_json) {
   try {
     auto create = (decltype(&ksolve_probe_create))dlsym(B->api.lib, "ksolve_probe_create");
     if (!create) { S->error_kind = "load"; S->error = "solver library lacks ksolve_probe_create"; return S; }
-    if (B->node_index.empty()) for (size_t e = 0; e < B->node_names.size(); ++e) B->node_index[B->node_names[e]] = (int)e;
+    if (B->node_index.empty()) { B->node_index.reserve(B->node_names.size() * 2); for (size_t e = 0; e < B->node_names.size(); ++e) B->node_index[B->node_names[e]] = (int)e; }
     if (B->pod_index.empty()) for (int p = 0; p < B->n_pods; ++p) if (!B->uid_text[p].empty()) B->pod_index[B->uid_text[p]] = p;
     Value doc = kj::Parser(probe_json).parse();
     const size_t ne = B->node_names.size();
@@ -2001,7 +2002,7 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
       B->node_pod_list.assign(B->node_pod_off[ne], 0);
       std::vector<uint32_t> fill(B->node_pod_off.begin(), B->node_pod_off.end() - 1);
       for (int p = 0; p < B->n_pods; ++p) if (B->pod_node[p] >= 0) B->node_pod_list[fill[B->pod_node[p]]++] = (uint32_t)p;
-      if (B->node_index.empty()) for (size_t e = 0; e < B->node_names.size(); ++e) B->node_index[B->node_names[e]] = (int)e;
+      if (B->node_index.empty()) { B->node_index.reserve(B->node_names.size() * 2); for (size_t e = 0; e < B->node_names.size(); ++e) B->node_index[B->node_names[e]] = (int)e; }
       B->sweep_tables = true;
     }
     Value doc = kj::Parser(sweep_json).parse();
