@@ -580,6 +580,42 @@ def test_multi_node_search_as_one_sweep(oracle, emu, seed):
     rc.close()
 
 
+@pytest.mark.parametrize("seed,topology", [(2, False), (13, True), (21, True)])
+def test_multi_node_sets_on_a_compact_cluster_fuzz(oracle, emu, seed, topology):
+    """Prefixes of three windows of sortCandidates' order and arbitrary node sets of 1..24 nodes on a 500-node compact cluster
+    (make_resident_cluster, with and without spread constraints on the bound pods): every verdict of the sweep — multiNode filter
+    and the library's own candidate prices included — and every reference-equivalent evaluation count equals the oracle's
+    simulation of the same set (an offline run of this loop over 24 seeds x 2 = 4608 sets was clean)."""
+    import random
+    cc = dz.make_resident_cluster(n_nodes=500, seed=seed, topology=topology)
+    rc = dz.ResidentCluster.from_compact(cc, solver_lib=emu)
+    full, rng, K = dz.compact_candidates(cc), random.Random(seed), 24
+    sets, idxs = [], []
+    for w in range(4):
+        off = rng.randrange(0, len(full) - K)
+        for k in range(1, K + 1):
+            idx = full[off:off + k] if w < 3 else rng.sample(full, k)
+            sets.append([cc["nodes"][i] for i in idx]); idxs.append(idx)
+    cmds = rc.decisions(sets, multi_node=True, library_prices=True)
+    refs = rc.last_sweep["referenceBinEvaluations"]
+    base = dz.compact_problem(cc, pod_groups=[])
+    if topology:
+        base["clusterPods"] = dz.compact_cluster_pods(cc)
+    probes, cand_sets = [], []
+    for idx in idxs:
+        pods = [dz.compact_node_pods(cc, i) for i in idx]
+        probes.append({"removeNodes": [cc["nodes"][i]["name"] for i in idx], "pods": [p for ps in pods for p in ps]})
+        cand_sets.append([dict(cc["nodes"][i], pods=ps) for i, ps in zip(idx, pods)])
+    for j, (r, cs) in enumerate(zip(oracle.sweep(base, probes, threads=2), cand_sets)):
+        want = dz.decide(cc, cs, dz._finish_simulation(cc, r, set()))
+        if len(cs) > 1 and want["decision"] == dz.REPLACE and not dz.filter_out_same_instance_type(cc, cs, want):
+            want = {"decision": dz.NOOP, "replacement": None}
+        assert (cmds[j]["decision"], cmds[j]["replacement"]) == (want["decision"], want.get("replacement")), (j, len(cs), cmds[j], want["decision"])
+        assert refs[j] == r["counters"]["binEvaluations"], (j, len(cs))
+    assert len({c["decision"] for c in cmds}) == 3
+    rc.close()
+
+
 def test_same_instance_type_filter_in_the_sweep(oracle, emu):
     """filterOutSameInstanceType (multinodeconsolidation.go:209-246) inside the sweep's verdicts. [2 x the priciest type, 1 x a
     small type] -> one node: the small type is among the replacement options, so only options cheaper than the small node
