@@ -341,6 +341,7 @@ class ResidentCluster:
         self.cluster = cc
         self._deleting_pods, self._deleting_uids, self._always, self._cache = [], set(), list(cc.get("pendingPods", [])), {}
         self.scheduler = NewScheduler(compact_problem(cc, pods=copy.deepcopy(self._always)), solver_lib)
+        self._position = {n["name"]: i for i, n in enumerate(cc["nodes"])}      # candidates travel as positions in the stateNodes list
         return self
 
     def _key(self, candidates):
@@ -377,7 +378,9 @@ class ResidentCluster:
         live = [[c for c in cs if not c.get("markedForDeletion")] for cs in candidate_sets]
         prices = None if library_prices else [sum(self._price(c) for c in cs) for cs in candidate_sets]
         all_spot = None if library_prices else [all(c["labels"][fx.CAPACITY_TYPE] == "spot" for c in cs) for cs in candidate_sets]
-        out = self.scheduler.Sweep([[c["name"] for c in cs] for cs in live], prices, all_spot, detail=detail, multi_node=multi_node)
+        pos = getattr(self, "_position", None)
+        names = [[pos[c["name"]] for c in cs] for cs in live] if pos is not None else [[c["name"] for c in cs] for cs in live]
+        out = self.scheduler.Sweep(names, prices, all_spot, detail=detail, multi_node=multi_node)
         repl = {r["probe"]: r for r in out["replacements"]}
         cmds = []
         for i, cs in enumerate(candidate_sets):
