@@ -139,8 +139,9 @@ func podError(code, diag uint8) error {
 
 // rehydrate fills s.newNodeClaims / s.existingNodes exactly where the stock Solve() would have left them and returns
 // the Results value that points at them.
-func (f *flatProblem) rehydrate(s *Scheduler, res *C.ksolve_results) Results {
-	cl := &res.claims
+// claimsOf builds the NodeClaims of rows [c0, c1) of a claim table — all of a Solve()'s, or one probe's slice of a sweep's —
+// without their pods.
+func (f *flatProblem) claimsOf(s *Scheduler, cl *C.ksolve_claims, c0, c1 int) []*NodeClaim {
 	nc, nr, iw := int(cl.n_claims), int(cl.n_res), int(cl.it_words)
 	tmpl := cSlice[int32](cl.template_idx, nc)
 	itMask := cSlice[uint64](cl.it_mask, nc*iw)
@@ -151,8 +152,8 @@ func (f *flatProblem) rehydrate(s *Scheduler, res *C.ksolve_results) Results {
 	ordered := cSlice[int32](cl.ordered_instance_types, nc*int(cl.n_instance_types))
 	orderedCount := cSlice[uint32](cl.ordered_count, nc)
 
-	claims := make([]*NodeClaim, nc)
-	for c := 0; c < nc; c++ {
+	claims := make([]*NodeClaim, 0, c1-c0)
+	for c := c0; c < c1; c++ {
 		t := f.templates[tmpl[c]]
 		var its []*cloudprovider.InstanceType
 		if ordered != nil { // Results.TruncateInstanceTypes already applied on the device (scheduler.go:419-437)
@@ -191,8 +192,16 @@ func (f *flatProblem) rehydrate(s *Scheduler, res *C.ksolve_results) Results {
 				}
 			}
 		}
-		claims[c] = n
+		claims = append(claims, n)
 	}
+
+	return claims
+}
+
+func (f *flatProblem) rehydrate(s *Scheduler, res *C.ksolve_results) Results {
+	cl := &res.claims
+	nc := int(cl.n_claims)
+	claims := f.claimsOf(s, cl, 0, nc)
 
 	// pods into their bins, in the order the reference appended them (pod_slot)
 	P := int(res.n_pods)

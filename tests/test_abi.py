@@ -89,6 +89,11 @@ def test_go_shim_names_every_entry_point():
     shim = open(os.path.join(ROOT, "go", "ksolve_shim.go")).read()
     for f in ("ksolve_create", "ksolve_solve", "ksolve_solve_batch", "ksolve_results_free", "ksolve_destroy", "ksolve_cancel"):
         assert "C." + f in shim, f
+    sweep = open(os.path.join(ROOT, "go", "ksolve_sweep.go")).read()        # the consolidation sweep's binding
+    for f in ("ksolve_create", "ksolve_sweep", "ksolve_sweep_results_free", "ksolve_last_error"):
+        assert "C." + f + "(" in sweep, f
+    for t in ("ksolve_sweep_desc", "ksolve_sweep_results"):
+        assert "C." + t in sweep, t
 
 
 EXAMPLE_OUTPUT = "claims=1 [pods=5 its=0x2 cpu=7500 price=0.40] assignment=00000"
@@ -156,13 +161,13 @@ def test_go_binding_uses_only_fields_the_header_declares():
     header = open(os.path.join(ROOT, "include", "ksolve.h")).read()
     fields = set(re.findall(r"\b([a-z_0-9]+)\s*(?:\[[^\]]*\])?\s*[;,]", header)) | set(re.findall(r"\*\s*([a-z_0-9]+)\s*[;,]", header))
     used = set()
-    for f in ("ksolve_flatten.go", "ksolve_rehydrate.go", "ksolve_shim.go"):
+    for f in ("ksolve_flatten.go", "ksolve_rehydrate.go", "ksolve_shim.go", "ksolve_sweep.go"):
         text = open(os.path.join(ROOT, "go", f)).read()
         assert "//go:build cgo && ksolve" in text and "\npackage scheduling\n" in text, f
-        for var in ("desc", "t", "out", "f.opts", "cl", "res", "f.desc", "rs\\[j\\]"):
+        for var in ("desc", "t", "out", "f.opts", "cl", "res", "f.desc", "flat.desc", "rs\\[j\\]"):
             used |= set(re.findall(r"(?<![\w.])" + var + r"\.([a-z_][a-z_0-9]*)\b", text))
     used = {u[1:] if u.startswith("_") else u for u in used}
-    go_only = {"add", "c", "free", "flat", "observe", "seal", "key", "value", "close", "handle", "s", "mask", "defined", "complement"} - fields
+    go_only = {"add", "c", "free", "flat", "observe", "seal", "key", "value", "close", "handle", "s", "mask", "defined", "complement", "PodErrors", "NewNodeClaims", "ExistingNodes"} - fields
     missing = sorted(u for u in used - fields - go_only if "_" in u or u in ("n", "type", "key", "status", "impl"))
     assert not missing, missing
     consts = set(re.findall(r"C\.(KSOLVE_[A-Z_]+)", "".join(open(os.path.join(ROOT, "go", f)).read() for f in os.listdir(os.path.join(ROOT, "go")))))
@@ -216,7 +221,7 @@ def test_go_binding_uses_only_members_the_reference_declares():
                         out.add(mm.group(1).lstrip("*").split(".")[-1])      # a field, or the name of an embedded type
             out |= set(re.findall(r"func \(\w+ \*?%s\) (\w+)\(" % type_name, t))
         return out
-    text = "".join(open(os.path.join(ROOT, "go", f)).read() for f in ("ksolve_flatten.go", "ksolve_rehydrate.go", "ksolve_shim.go"))
+    text = "".join(open(os.path.join(ROOT, "go", f)).read() for f in ("ksolve_flatten.go", "ksolve_rehydrate.go", "ksolve_shim.go", "ksolve_sweep.go"))
     text = re.sub(r"//[^\n]*", "", text)                                     # comments name things too
     checks = {"Scheduler": r"(?<![\w.])s\.([A-Za-z_]\w*)", "Topology": r"\bs\.topology\.([A-Za-z_]\w*)", "PodData": r"\brow\.data\.([A-Za-z_]\w*)"}
     used_any = 0
