@@ -137,8 +137,6 @@ func podError(code, diag uint8) error {
 	return fmt.Errorf("pod could not be scheduled")
 }
 
-// rehydrate fills s.newNodeClaims / s.existingNodes exactly where the stock Solve() would have left them and returns
-// the Results value that points at them.
 // claimsOf builds the NodeClaims of rows [c0, c1) of a claim table — all of a Solve()'s, or one probe's slice of a sweep's —
 // without their pods.
 func (f *flatProblem) claimsOf(s *Scheduler, cl *C.ksolve_claims, c0, c1 int) []*NodeClaim {
@@ -198,6 +196,8 @@ func (f *flatProblem) claimsOf(s *Scheduler, cl *C.ksolve_claims, c0, c1 int) []
 	return claims
 }
 
+// rehydrate fills s.newNodeClaims / s.existingNodes exactly where the stock Solve() would have left them and returns
+// the Results value that points at them.
 func (f *flatProblem) rehydrate(s *Scheduler, res *C.ksolve_results) Results {
 	cl := &res.claims
 	nc := int(cl.n_claims)
