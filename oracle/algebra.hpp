@@ -7,8 +7,9 @@
 //   k8s.io/apimachinery v0.36.1 resource.Quantity (exact decimal)    -> Quantity below (int128 nano-units, exact)
 //   k8s.io/api v0.36.1 core/v1 Toleration.ToleratesTaint(.., true)   -> tolerates_taint below   [parity unpinned at unit level]
 //   k8s.io/apimachinery labels.Selector                                -> LabelSelector::matches
-// Every function cites the reference file:line it follows. String sets are kept as real string sets on purpose:
-// this file must stay an independent restatement of the reference, not a copy of the product's bitmask encoding.
+// Every function cites the reference file:line it follows. Value sets are real sets of (interned) strings on purpose:
+// this file must stay an independent restatement of the reference, not a copy of the product's bitmask encoding
+// (intern.hpp says what interning changes — the containers — and what it does not — the algorithm).
 #pragma once
 #include <algorithm>
 #include <climits>
@@ -20,9 +21,21 @@
 #include <string>
 #include <vector>
 
+#include "intern.hpp"
+
 namespace oracle {
 
 typedef __int128 i128;
+
+// The strings the path names literally, interned once.
+struct WellKnownSyms {
+  Sym hostname, zone, region, instance_type, arch, os, windows_build, nodepool, capacity_type, initialized, registered, reservation_id;
+  Sym pods, cpu, memory, nodes;
+  Sym empty, Equal, Exists, Lt, Gt;
+  Sym PreferNoSchedule, Honor, Ignore, DoNotSchedule, ScheduleAnyway, Pending, Failed, Succeeded, reserved, spot, on_demand, true_;
+  Sym ip_any4, ip_any6;
+};
+inline const WellKnownSyms& W();
 
 // ---------------------------------------------------------------------------------------------------------------
 // resource.Quantity (k8s.io/apimachinery/pkg/api/resource) — exact decimal. Stored as int128 nano-units, which is
@@ -66,8 +79,36 @@ inline i128 parse_quantity(const std::string& s) {
   return neg ? -v : v;
 }
 
-// v1.ResourceList
-typedef std::map<std::string, i128> ResourceList;
+// v1.ResourceList: resource name -> quantity, a small array sorted by the name's symbol
+struct ResEntry { Sym first; i128 second; };
+class ResourceList {
+  SmallVec<ResEntry, 5> v_;
+  size_t lower(Sym k) const { size_t i = 0; while (i < v_.size() && v_[i].first < k) ++i; return i; }
+
+ public:
+  typedef ResEntry* iterator;
+  typedef const ResEntry* const_iterator;
+  iterator begin() { return v_.begin(); }
+  iterator end() { return v_.end(); }
+  const_iterator begin() const { return v_.begin(); }
+  const_iterator end() const { return v_.end(); }
+  size_t size() const { return v_.size(); }
+  bool empty() const { return v_.empty(); }
+  const_iterator find(Sym k) const { size_t i = lower(k); return i < v_.size() && v_[i].first == k ? v_.begin() + i : v_.end(); }
+  iterator find(Sym k) { size_t i = lower(k); return i < v_.size() && v_[i].first == k ? v_.begin() + i : v_.end(); }
+  bool count(Sym k) const { return find(k) != end(); }
+  i128& operator[](Sym k) {
+    size_t i = lower(k);
+    if (i == v_.size() || v_[i].first != k) v_.insert_at(i, ResEntry{k, 0});
+    return v_[i].second;
+  }
+  iterator erase(iterator it) { size_t i = it - v_.begin(); v_.erase_at(i); return v_.begin() + i; }
+  bool operator==(const ResourceList& o) const {
+    if (v_.size() != o.v_.size()) return false;
+    for (size_t i = 0; i < v_.size(); ++i) if (v_[i].first != o.v_[i].first || v_[i].second != o.v_[i].second) return false;
+    return true;
+  }
+};
 
 // resources.Merge — pkg/utils/resources/resources.go:52-66
 inline ResourceList res_merge(const ResourceList& a, const ResourceList& b) {
@@ -143,15 +184,36 @@ static const char* kNodeRegisteredLabel = "karpenter.sh/registered";
 static const char* kReservationIDLabel = "karpenter.sh/reservation-id";  // cloudprovider.ReservationIDLabel
 static const char* kMinValuesRelaxedAnnotation = "karpenter.sh/nodeclaim-min-values-relaxed";
 
+inline const WellKnownSyms& W() {
+  static const WellKnownSyms w = [] {
+    WellKnownSyms x;
+    x.hostname = sym(kLabelHostname); x.zone = sym(kLabelZone); x.region = sym(kLabelRegion); x.instance_type = sym(kLabelInstanceType);
+    x.arch = sym(kLabelArch); x.os = sym(kLabelOS); x.windows_build = sym(kLabelWindowsBuild); x.nodepool = sym(kNodePoolLabel);
+    x.capacity_type = sym(kCapacityTypeLabel); x.initialized = sym(kNodeInitializedLabel); x.registered = sym(kNodeRegisteredLabel);
+    x.reservation_id = sym(kReservationIDLabel);
+    x.pods = sym("pods"); x.cpu = sym("cpu"); x.memory = sym("memory"); x.nodes = sym("nodes");
+    x.empty = sym(""); x.Equal = sym("Equal"); x.Exists = sym("Exists"); x.Lt = sym("Lt"); x.Gt = sym("Gt");
+    x.PreferNoSchedule = sym("PreferNoSchedule"); x.Honor = sym("Honor"); x.Ignore = sym("Ignore");
+    x.DoNotSchedule = sym("DoNotSchedule"); x.ScheduleAnyway = sym("ScheduleAnyway");
+    x.Pending = sym("Pending"); x.Failed = sym("Failed"); x.Succeeded = sym("Succeeded");
+    x.reserved = sym("reserved"); x.spot = sym("spot"); x.on_demand = sym("on-demand"); x.true_ = sym("true");
+    x.ip_any4 = sym("0.0.0.0"); x.ip_any6 = sym("::");
+    return x;
+  }();
+  return w;
+}
+
 struct Labels {
-  std::set<std::string> well_known{kNodePoolLabel, kLabelZone, kLabelRegion, kLabelInstanceType,
-                                   kLabelArch,     kLabelOS,   kCapacityTypeLabel, kLabelWindowsBuild};
+  SymSet well_known{W().nodepool, W().zone, W().region, W().instance_type, W().arch, W().os, W().capacity_type, W().windows_build};
   // NormalizedLabels — labels.go:121-127
-  std::map<std::string, std::string> normalized{{"failure-domain.beta.kubernetes.io/zone", kLabelZone},
-                                                {"beta.kubernetes.io/arch", kLabelArch},
-                                                {"beta.kubernetes.io/os", kLabelOS},
-                                                {"beta.kubernetes.io/instance-type", kLabelInstanceType},
-                                                {"failure-domain.beta.kubernetes.io/region", kLabelRegion}};
+  SymMap normalized;
+  Labels() {
+    normalized.set(sym("failure-domain.beta.kubernetes.io/zone"), W().zone);
+    normalized.set(sym("beta.kubernetes.io/arch"), W().arch);
+    normalized.set(sym("beta.kubernetes.io/os"), W().os);
+    normalized.set(sym("beta.kubernetes.io/instance-type"), W().instance_type);
+    normalized.set(sym("failure-domain.beta.kubernetes.io/region"), W().region);
+  }
 };
 inline Labels& labels_registry() { static Labels l; return l; }
 
@@ -201,10 +263,10 @@ inline const char* op_name(Op o) {
 typedef std::optional<long long> OptInt;
 
 // withinBounds — requirement.go:334-350
-inline bool within_bounds(const std::string& v, const OptInt& gte, const OptInt& lte) {
+inline bool within_bounds(Sym v, const OptInt& gte, const OptInt& lte) {
   if (!gte && !lte) return true;
   long long val;
-  if (!go_atoi(v, val)) return false;
+  if (!go_atoi(str(v), val)) return false;
   if (gte && val < *gte) return false;
   if (lte && val > *lte) return false;
   return true;
@@ -214,36 +276,42 @@ inline OptInt max_opt(const OptInt& a, const OptInt& b) { if (!a) return b; if (
 
 // Requirement — requirement.go:36-43
 struct Requirement {
-  std::string key;
+  Sym key = kNoSym;
   bool complement = false;
-  std::set<std::string> values;
+  SymSet values;
   OptInt gte, lte;
   std::optional<int> min_values;
 
   // NewRequirementWithFlexibility — requirement.go:48-110
-  static Requirement make(std::string key, Op op, std::optional<int> min_values, std::vector<std::string> vals) {
-    auto& reg = labels_registry();
-    auto nit = reg.normalized.find(key);
-    if (nit != reg.normalized.end()) key = nit->second;
+  static Requirement make(Sym key, Op op, std::optional<int> min_values, const Sym* vals, size_t n_vals) {
+    if (auto* nz = labels_registry().normalized.find(key)) key = nz->second;
     Requirement r;
     r.key = key;
     r.min_values = min_values;
-    if (op == Op::In) { r.values.insert(vals.begin(), vals.end()); r.complement = false; return r; }
+    if (op == Op::In) { r.values.insert(vals, vals + n_vals); r.complement = false; return r; }
     r.complement = true;
     if (op == Op::DoesNotExist) r.complement = false;
-    if (op == Op::NotIn) r.values.insert(vals.begin(), vals.end());
-    auto atoi0 = [&](const std::string& s) { long long v = 0; go_atoi(s, v); return v; };
+    if (op == Op::NotIn) r.values.insert(vals, vals + n_vals);
+    auto atoi0 = [&](Sym s) { long long v = 0; go_atoi(str(s), v); return v; };
     if (op == Op::Gt) {
-      long long v = vals.empty() ? 0 : atoi0(vals[0]);
-      if (v == LLONG_MAX) return make(key, Op::DoesNotExist, std::nullopt, {});  // requirement.go:85-88 (minValues dropped)
+      long long v = n_vals == 0 ? 0 : atoi0(vals[0]);
+      if (v == LLONG_MAX) return make(key, Op::DoesNotExist, std::nullopt, nullptr, 0);  // requirement.go:85-88 (minValues dropped)
       r.gte = v + 1;
     }
-    if (op == Op::Lt) { long long v = vals.empty() ? 0 : atoi0(vals[0]); r.lte = v - 1; }
-    if (op == Op::Gte) r.gte = vals.empty() ? 0 : atoi0(vals[0]);
-    if (op == Op::Lte) r.lte = vals.empty() ? 0 : atoi0(vals[0]);
+    if (op == Op::Lt) { long long v = n_vals == 0 ? 0 : atoi0(vals[0]); r.lte = v - 1; }
+    if (op == Op::Gte) r.gte = n_vals == 0 ? 0 : atoi0(vals[0]);
+    if (op == Op::Lte) r.lte = n_vals == 0 ? 0 : atoi0(vals[0]);
     return r;
   }
-  static Requirement make(const std::string& key, Op op, std::vector<std::string> vals = {}) { return make(key, op, std::nullopt, vals); }
+  static Requirement make(Sym key, Op op) { return make(key, op, std::nullopt, nullptr, 0); }
+  static Requirement make(Sym key, Op op, Sym one) { return make(key, op, std::nullopt, &one, 1); }
+  static Requirement make(Sym key, Op op, std::optional<int> min_values, const std::vector<Sym>& vals) { return make(key, op, min_values, vals.data(), vals.size()); }
+  // from strings (parsing, tests)
+  static Requirement make_s(const std::string& key, Op op, std::optional<int> min_values, const std::vector<std::string>& vals) {
+    std::vector<Sym> v;
+    for (auto& x : vals) v.push_back(sym(x));
+    return make(sym(key), op, min_values, v);
+  }
 
   // Len — requirement.go:303-308 (MaxInt64 - |values| for complements)
   long long len() const { return complement ? LLONG_MAX - (long long)values.size() : (long long)values.size(); }
@@ -253,7 +321,7 @@ struct Requirement {
     return len() > 0 ? Op::In : Op::DoesNotExist;
   }
   // Has — requirement.go:275-280
-  bool has(const std::string& v) const {
+  bool has(Sym v) const {
     if (complement) return !values.count(v) && within_bounds(v, gte, lte);
     return values.count(v) && within_bounds(v, gte, lte);
   }
@@ -264,16 +332,21 @@ struct Requirement {
     std::optional<int> mv;
     if (min_values && q.min_values) mv = std::max(*min_values, *q.min_values);
     else mv = min_values ? min_values : q.min_values;
-    if (g && l && *g > *l) return make(key, Op::DoesNotExist, mv, {});
-    std::set<std::string> vals;
-    if (complement && q.complement) { vals = values; vals.insert(q.values.begin(), q.values.end()); }
-    else if (complement && !q.complement) { for (auto& v : q.values) if (!values.count(v)) vals.insert(v); }
-    else if (!complement && q.complement) { for (auto& v : values) if (!q.values.count(v)) vals.insert(v); }
-    else { for (auto& v : values) if (q.values.count(v)) vals.insert(v); }
-    for (auto it = vals.begin(); it != vals.end();) { if (!within_bounds(*it, g, l)) it = vals.erase(it); else ++it; }
-    if (!comp) { g.reset(); l.reset(); }
+    if (g && l && *g > *l) return make(key, Op::DoesNotExist, mv, nullptr, 0);
     Requirement out;
-    out.key = key; out.values = vals; out.complement = comp; out.gte = g; out.lte = l; out.min_values = mv;
+    SymSet& vals = out.values;
+    const bool bounded = g || l;
+    if (complement && q.complement) { vals = values; vals.insert(q.values.begin(), q.values.end()); }
+    else if (complement && !q.complement) { for (Sym v : q.values) if (!values.count(v)) vals.append_sorted(v); }
+    else if (!complement && q.complement) { for (Sym v : values) if (!q.values.count(v)) vals.append_sorted(v); }
+    else { for (Sym v : values) if (q.values.count(v)) vals.append_sorted(v); }
+    if (bounded) {
+      SymSet kept;
+      for (Sym v : vals) if (within_bounds(v, g, l)) kept.append_sorted(v);
+      vals = kept;
+    }
+    if (!comp) { g.reset(); l.reset(); }
+    out.key = key; out.complement = comp; out.gte = g; out.lte = l; out.min_values = mv;
     return out;
   }
   // HasIntersection — requirement.go:220-254
@@ -281,56 +354,66 @@ struct Requirement {
     OptInt g = max_opt(gte, q.gte), l = min_opt(lte, q.lte);
     if (g && l && *g > *l) return false;
     if (complement && q.complement) return true;
-    if (complement && !q.complement) { for (auto& v : q.values) if (!values.count(v) && within_bounds(v, g, l)) return true; return false; }
-    if (!complement && q.complement) { for (auto& v : values) if (!q.values.count(v) && within_bounds(v, g, l)) return true; return false; }
-    for (auto& v : values) if (q.values.count(v) && within_bounds(v, g, l)) return true;
+    if (complement && !q.complement) { for (Sym v : q.values) if (!values.count(v) && within_bounds(v, g, l)) return true; return false; }
+    if (!complement && q.complement) { for (Sym v : values) if (!q.values.count(v) && within_bounds(v, g, l)) return true; return false; }
+    for (Sym v : values) if (q.values.count(v) && within_bounds(v, g, l)) return true;
     return false;
   }
   // Any — requirement.go:256-271. The reference draws a random element; callers in scope only use it on
   // single-valued requirements (Offering.Zone()/CapacityType()). Canonicalised: lexicographically smallest value.
-  std::string any() const {
-    if (op() == Op::In) return *values.begin();
-    return "";
+  Sym any() const {
+    if (op() == Op::In) return values.lex_min();
+    return W().empty;
   }
   bool operator==(const Requirement& o) const {
     return key == o.key && complement == o.complement && values == o.values && gte == o.gte && lte == o.lte && min_values == o.min_values;
   }
 };
 
-// Requirements — requirements.go:34-47
+// Requirements — requirements.go:34-47: key -> Requirement, kept as an array sorted by the key's symbol. No result depends on
+// the order the reference's map is walked in (error texts aside, which are Go-map-order dependent there too).
 struct Requirements {
-  std::map<std::string, Requirement> m;
+  std::vector<Requirement> m;
 
+  size_t lower(Sym k) const { size_t i = 0; while (i < m.size() && m[i].key < k) ++i; return i; }
+  const Requirement* find(Sym k) const { size_t i = lower(k); return i < m.size() && m[i].key == k ? &m[i] : nullptr; }
+  Requirement* find(Sym k) { size_t i = lower(k); return i < m.size() && m[i].key == k ? &m[i] : nullptr; }
+  void put(const Requirement& r) {   // map assignment
+    size_t i = lower(r.key);
+    if (i < m.size() && m[i].key == r.key) m[i] = r; else m.insert(m.begin() + i, r);
+  }
+  void erase(Sym k) { size_t i = lower(k); if (i < m.size() && m[i].key == k) m.erase(m.begin() + i); }
   // Add — requirements.go:133-140 : incoming.Intersection(existing)
   void add(const Requirement& in) {
-    auto it = m.find(in.key);
-    if (it != m.end()) it->second = in.intersection(it->second);
-    else m.emplace(in.key, in);
+    size_t i = lower(in.key);
+    if (i < m.size() && m[i].key == in.key) m[i] = in.intersection(m[i]);
+    else m.insert(m.begin() + i, in);
   }
-  void add_all(const Requirements& o) { for (auto& kv : o.m) add(kv.second); }
-  bool has(const std::string& k) const { return m.count(k) != 0; }
+  void add_all(const Requirements& o) { for (auto& r : o.m) add(r); }
+  bool has(Sym k) const { return find(k) != nullptr; }
   // Get — requirements.go:160-166 (undefined => Exists)
-  Requirement get(const std::string& k) const {
-    auto it = m.find(k);
-    if (it == m.end()) return Requirement::make(k, Op::Exists);
-    return it->second;
+  Requirement get(Sym k) const {
+    const Requirement* r = find(k);
+    if (!r) return Requirement::make(k, Op::Exists);
+    return *r;
   }
-  bool has_min_values() const { for (auto& kv : m) if (kv.second.min_values) return true; return false; }  // requirements.go:276-283
+  bool has_min_values() const { for (auto& r : m) if (r.min_values) return true; return false; }  // requirements.go:276-283
 
-  // Intersects — requirements.go:254-274 ; returns "" on success else first offending key
-  bool intersects(const Requirements& in, std::string* bad_key = nullptr) const {
-    for (auto& kv : m) {
-      auto jt = in.m.find(kv.first);
-      if (jt == in.m.end()) continue;
-      const Requirement& existing = kv.second;
-      const Requirement& incoming = jt->second;
+  // Intersects — requirements.go:254-274 ; on failure *bad_key = an offending key
+  bool intersects(const Requirements& in, Sym* bad_key = nullptr) const {
+    size_t j = 0;
+    for (auto& existing : m) {
+      while (j < in.m.size() && in.m[j].key < existing.key) ++j;
+      if (j == in.m.size()) break;
+      if (in.m[j].key != existing.key) continue;
+      const Requirement& incoming = in.m[j];
       if (!existing.has_intersection(incoming)) {
         Op oi = incoming.op();
         if (oi == Op::NotIn || oi == Op::DoesNotExist) {
           Op oe = existing.op();
           if (oe == Op::NotIn || oe == Op::DoesNotExist) continue;
         }
-        if (bad_key) *bad_key = kv.first;
+        if (bad_key) *bad_key = existing.key;
         return false;
       }
     }
@@ -339,41 +422,43 @@ struct Requirements {
   // Compatible — requirements.go:181-197 ; allow_undefined = AllowUndefinedWellKnownLabels when true
   bool compatible(const Requirements& in, bool allow_undefined_well_known, std::string* why = nullptr) const {
     auto& wk = labels_registry().well_known;
-    for (auto& kv : in.m) {
-      if (allow_undefined_well_known && wk.count(kv.first)) continue;
-      Op o = kv.second.op();
-      if (has(kv.first) || o == Op::NotIn || o == Op::DoesNotExist) continue;
-      if (why) *why = "label \"" + kv.first + "\" does not have known values";
+    for (auto& r : in.m) {
+      if (allow_undefined_well_known && wk.count(r.key)) continue;
+      if (has(r.key)) continue;
+      Op o = r.op();
+      if (o == Op::NotIn || o == Op::DoesNotExist) continue;
+      if (why) *why = "label \"" + str(r.key) + "\" does not have known values";
       return false;
     }
-    std::string bad;
-    if (!intersects(in, &bad)) { if (why) *why = "key " + bad + " incompatible"; return false; }
+    Sym bad = kNoSym;
+    if (!intersects(in, &bad)) { if (why) *why = "key " + str(bad) + " incompatible"; return false; }
     return true;
   }
 };
 
 // NewLabelRequirements — requirements.go:67-73
-inline Requirements label_requirements(const std::map<std::string, std::string>& labels) {
+inline Requirements label_requirements(const SymMap& labels) {
   Requirements r;
-  for (auto& kv : labels) r.add(Requirement::make(kv.first, Op::In, {kv.second}));
+  for (auto& kv : labels) r.add(Requirement::make(kv.first, Op::In, kv.second));
   return r;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Taints — pkg/scheduling/taints.go:78-95 and k8s.io/api core/v1 Toleration.ToleratesTaint
 // ---------------------------------------------------------------------------------------------------------------
-struct Taint { std::string key, value, effect; };
-struct Toleration { std::string key, op, value, effect; };
+struct Taint { Sym key, value, effect; };
+struct Toleration { Sym key, op, value, effect; };
 
 inline bool tolerates_taint(const Toleration& t, const Taint& taint) {
-  if (!t.effect.empty() && t.effect != taint.effect) return false;
-  if (!t.key.empty() && t.key != taint.key) return false;
-  if (t.op.empty() || t.op == "Equal") return t.value == taint.value;
-  if (t.op == "Exists") return true;
-  if (t.op == "Lt" || t.op == "Gt") {  // enableComparisonOperators == true at taints.go:89
+  const WellKnownSyms& w = W();
+  if (t.effect != w.empty && t.effect != taint.effect) return false;
+  if (t.key != w.empty && t.key != taint.key) return false;
+  if (t.op == w.empty || t.op == w.Equal) return t.value == taint.value;
+  if (t.op == w.Exists) return true;
+  if (t.op == w.Lt || t.op == w.Gt) {  // enableComparisonOperators == true at taints.go:89
     long long tv, xv;
-    if (!go_atoi(t.value, tv) || !go_atoi(taint.value, xv)) return false;
-    return t.op == "Lt" ? xv < tv : xv > tv;
+    if (!go_atoi(str(t.value), tv) || !go_atoi(str(taint.value), xv)) return false;
+    return t.op == w.Lt ? xv < tv : xv > tv;
   }
   return false;
 }
@@ -391,39 +476,48 @@ inline bool taints_tolerated(const std::vector<Taint>& taints, const std::vector
 // metav1.LabelSelector -> labels.Selector (LabelSelectorAsSelector): nil selector matches nothing,
 // empty selector matches everything (topologygroup.go:101-104, :443).
 // ---------------------------------------------------------------------------------------------------------------
+enum class SelOp { In, NotIn, Exists, DoesNotExist, Invalid };
 struct SelectorExpr {
-  std::string key, op;
-  std::set<std::string> values;
-  bool operator<(const SelectorExpr& o) const { return std::tie(key, op, values) < std::tie(o.key, o.op, o.values); }
-  bool operator==(const SelectorExpr& o) const { return key == o.key && op == o.op && values == o.values; }
+  Sym key = kNoSym;
+  SelOp op = SelOp::Invalid;
+  Sym op_text = kNoSym;   // the operator as written (an unknown one makes the selector invalid, but still tells groups apart)
+  SymSet values;
+  bool operator==(const SelectorExpr& o) const { return key == o.key && op_text == o.op_text && values == o.values; }
 };
 struct LabelSelector {
   bool is_nil = true;
-  std::map<std::string, std::string> match_labels;
+  SymMap match_labels;
   std::vector<SelectorExpr> match_expressions;
 
   bool valid() const {
     for (auto& e : match_expressions) {
-      if (e.op == "In" || e.op == "NotIn") { if (e.values.empty()) return false; }
-      else if (e.op == "Exists" || e.op == "DoesNotExist") { if (!e.values.empty()) return false; }
+      if (e.op == SelOp::In || e.op == SelOp::NotIn) { if (e.values.empty()) return false; }
+      else if (e.op == SelOp::Exists || e.op == SelOp::DoesNotExist) { if (!e.values.empty()) return false; }
       else return false;
     }
     return true;
   }
-  bool matches(const std::map<std::string, std::string>& labels) const {
+  bool matches(const SymMap& labels) const {
     if (is_nil) return false;   // labels.Nothing()
     if (!valid()) return false; // parse error => labels.Nothing()  (topologygroup.go:102-104)
     for (auto& kv : match_labels) {
-      auto it = labels.find(kv.first);
-      if (it == labels.end() || it->second != kv.second) return false;
+      auto* it = labels.find(kv.first);
+      if (!it || it->second != kv.second) return false;
     }
     for (auto& e : match_expressions) {
-      auto it = labels.find(e.key);
-      if (e.op == "In") { if (it == labels.end() || !e.values.count(it->second)) return false; }
-      else if (e.op == "NotIn") { if (it != labels.end() && e.values.count(it->second)) return false; }
-      else if (e.op == "Exists") { if (it == labels.end()) return false; }
-      else if (e.op == "DoesNotExist") { if (it != labels.end()) return false; }
+      auto* it = labels.find(e.key);
+      if (e.op == SelOp::In) { if (!it || !e.values.count(it->second)) return false; }
+      else if (e.op == SelOp::NotIn) { if (it && e.values.count(it->second)) return false; }
+      else if (e.op == SelOp::Exists) { if (!it) return false; }
+      else if (e.op == SelOp::DoesNotExist) { if (it) return false; }
     }
+    return true;
+  }
+  // the selector as a set of expressions (hashstructure hashes slices as sets, topologygroup.go:188-205)
+  bool same_as(const LabelSelector& o) const {
+    if (is_nil != o.is_nil || !(match_labels == o.match_labels)) return false;
+    for (auto& e : match_expressions) { bool f = false; for (auto& x : o.match_expressions) f = f || e == x; if (!f) return false; }
+    for (auto& e : o.match_expressions) { bool f = false; for (auto& x : match_expressions) f = f || e == x; if (!f) return false; }
     return true;
   }
 };

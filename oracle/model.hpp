@@ -13,28 +13,28 @@
 namespace oracle {
 
 struct NodeSelectorExpr {
-  std::string key;
+  Sym key;
   Op op;
-  std::vector<std::string> values;
+  std::vector<Sym> values;
   std::optional<int> min_values;
 };
 typedef std::vector<NodeSelectorExpr> NodeSelectorTerm;
 struct PreferredSchedulingTerm { int weight = 0; NodeSelectorTerm preference; };
 struct PodAffinityTerm {
   LabelSelector selector;
-  std::string topology_key;
-  std::vector<std::string> namespaces;
+  Sym topology_key = kNoSym;
+  std::vector<Sym> namespaces;
   LabelSelector namespace_selector;   // nil = absent
 };
 struct WeightedPodAffinityTerm { int weight = 0; PodAffinityTerm term; };
 struct TopologySpreadConstraint {
   int max_skew = 1;
-  std::string topology_key;
-  std::string when_unsatisfiable = "DoNotSchedule";
+  Sym topology_key = kNoSym;
+  Sym when_unsatisfiable = W().DoNotSchedule;
   LabelSelector selector;
   std::optional<int> min_domains;
-  std::optional<std::string> node_taints_policy, node_affinity_policy;
-  std::vector<std::string> match_label_keys;
+  std::optional<Sym> node_taints_policy, node_affinity_policy;
+  std::vector<Sym> match_label_keys;
 };
 
 // corev1.Pod subset read by the path. `requests` is the output of resourcehelper.PodRequests (flattened upstream
@@ -43,10 +43,10 @@ struct TopologySpreadConstraint {
 // unparsable text become one nil value, IPv4-mapped IPv6 folds to IPv4); Matches: same protocol and port, and equal IPs or
 // one of them unspecified (0.0.0.0 or ::).
 struct HostPort {
-  std::string ip;
+  Sym ip = kNoSym;
   int port = 0;
-  std::string protocol;
-  bool unspecified() const { return ip == "0.0.0.0" || ip == "::"; }
+  Sym protocol = kNoSym;
+  bool unspecified() const { return ip == W().ip_any4 || ip == W().ip_any6; }
   bool matches(const HostPort& o) const {
     if (protocol != o.protocol || port != o.port) return false;
     return ip == o.ip || unspecified() || o.unspecified();
@@ -77,14 +77,16 @@ inline bool host_ports_conflict(const std::vector<HostPort>& wanted, const std::
 }
 
 struct Pod {
-  std::string uid, ns = "default", name;
+  std::string uid, name;
+  Sym uid_s = kNoSym;                 // the UID as a symbol: what owner sets, caches and the queue's lastLen are keyed by
+  Sym ns = kNoSym;
   std::vector<HostPort> host_ports;   // GetHostPorts — hostportusage.go:93-117 (hostIP "" reads 0.0.0.0)
-  std::map<std::string, std::string> labels;
+  SymMap labels;
   long long creation = 0;
-  std::string phase = "Pending";
-  std::string node_name;
+  Sym phase = W().Pending;
+  Sym node_name = W().empty;
   ResourceList requests;
-  std::map<std::string, std::string> node_selector;
+  SymMap node_selector;
   bool has_node_affinity = false;
   bool has_required = false;  // RequiredDuringSchedulingIgnoredDuringExecution != nil
   std::vector<NodeSelectorTerm> required_terms;
@@ -101,7 +103,7 @@ struct Pod {
   std::vector<std::vector<NodeSelectorExpr>> volume_requirements;
   // scheduling.GetVolumes(pod) (volumeusage.go:83-114, scheduler.go:622-626): CSI driver -> the PVCs the pod mounts through it;
   // resolved from PVC / PV / StorageClass objects upstream of Solve()
-  std::map<std::string, std::set<std::string>> volumes;
+  std::map<Sym, SymSet> volumes;
 };
 
 struct Offering {
@@ -112,9 +114,9 @@ struct Offering {
   ResourceList capacity_override;            // Offering.CapacityOverride (types.go:484)
   bool has_overhead_override = false;        // Offering.OverheadOverride != nil
   ResourceList overhead_override;            // ... its Total()
-  std::string capacity_type() const { return reqs.get(kCapacityTypeLabel).any(); }  // types.go:532
-  std::string zone() const { return reqs.get(kLabelZone).any(); }                    // types.go:536
-  std::string reservation_id() const { return reqs.get(kReservationIDLabel).any(); } // types.go:540
+  Sym capacity_type() const { return reqs.get(W().capacity_type).any(); }   // types.go:532
+  Sym zone() const { return reqs.get(W().zone).any(); }                      // types.go:536
+  Sym reservation_id() const { return reqs.get(W().reservation_id).any(); }  // types.go:540
 };
 
 struct AllocatableOfferings { ResourceList allocatable; std::vector<const Offering*> offerings; };
@@ -135,11 +137,11 @@ struct InstanceType {
     if (oh_ov) for (auto& kv : *oh_ov) oh[kv.first] = kv.second;
     ResourceList a = res_subtract(cap, oh);
     for (auto& kv : cap) {
-      if (kv.first.rfind("hugepages-", 0) == 0) {
-        i128 cur = a.count("memory") ? a["memory"] : 0;
+      if (str(kv.first).rfind("hugepages-", 0) == 0) {
+        i128 cur = a.count(W().memory) ? a[W().memory] : 0;
         cur -= kv.second;
         if (cur < 0) cur = 0;
-        a["memory"] = cur;
+        a[W().memory] = cur;
       }
     }
     return a;
@@ -178,19 +180,20 @@ struct NodePool {
   std::string name;
   int weight = 0;
   std::vector<NodeSelectorExpr> requirements;
-  std::map<std::string, std::string> labels;
+  SymMap labels;
   std::vector<Taint> taints;
   bool has_limits = false;
   ResourceList limits;
   bool is_static = false;
-  std::string node_class_label_key = "karpenter.test.sh/testnodeclass", node_class_name = "default";
+  Sym node_class_label_key = sym("karpenter.test.sh/testnodeclass"), node_class_name = sym("default");
   std::vector<int> instance_types;  // indices into the catalogue, in GetInstanceTypes order
 };
 
 // state.StateNode accessors the scheduler reads (existingnode.go:47-75, scheduler.go:792-858)
 struct StateNode {
-  std::string name, hostname;
-  std::map<std::string, std::string> labels;
+  std::string name;
+  Sym name_s = kNoSym, hostname = kNoSym;
+  SymMap labels;
   std::vector<Taint> taints;
   ResourceList available, capacity, daemonset_requests;
   std::vector<HostPort> host_ports;   // StateNode.HostPortUsage(): ports of the pods bound to the node (statenode.go:407,489)
@@ -198,8 +201,8 @@ struct StateNode {
   bool under_consolidate_after = false;  // disruption.IsUnderConsolidateAfter, evaluated upstream
   // StateNode.VolumeUsage() (statenode.go:411; volumeusage.go:178-189): the volumes of the pods bound to the node per CSI driver,
   // and the CSINode's per-driver attach limits
-  std::map<std::string, std::set<std::string>> volumes;
-  std::map<std::string, int> volume_limits;
+  std::map<Sym, SymSet> volumes;
+  std::map<Sym, int> volume_limits;
 };
 
 // pods already bound in the cluster (topology.go:361-459 countDomains, :310-324 inverse anti-affinities)
@@ -225,36 +228,36 @@ struct Problem {
   std::vector<Pod> pods;
   std::vector<Pod> daemonset_pods;
   std::vector<Pod> cluster_pods;        // bound pods, for topology counting
-  std::set<std::string> deleting_node_names;
-  std::vector<std::pair<std::string, std::map<std::string, std::string>>> namespaces;   // the namespace lister: name, labels
+  SymSet deleting_node_names;
+  std::vector<std::pair<Sym, SymMap>> namespaces;   // the namespace lister: name, labels
 };
 
 // ------------------------------------------------------------------ JSON -> model
-inline std::map<std::string, std::string> parse_strmap(const oj::Value& v) {
-  std::map<std::string, std::string> m;
-  for (auto& kv : v.members()) m[kv.first] = kv.second.s();
+inline SymMap parse_strmap(const oj::Value& v) {
+  SymMap m;
+  for (auto& kv : v.members()) m.set(sym(kv.first), sym(kv.second.s()));
   return m;
 }
 inline ResourceList parse_resources(const oj::Value& v) {
   ResourceList r;
   for (auto& kv : v.members()) {
-    if (kv.second.kind == oj::Value::Str) r[kv.first] = parse_quantity(kv.second.str);
-    else if (kv.second.kind == oj::Value::Num && kv.second.is_int) r[kv.first] = (i128)kv.second.inum * 1000000000;
+    if (kv.second.kind == oj::Value::Str) r[sym(kv.first)] = parse_quantity(kv.second.str);
+    else if (kv.second.kind == oj::Value::Num && kv.second.is_int) r[sym(kv.first)] = (i128)kv.second.inum * 1000000000;
     else throw std::runtime_error("resource quantity must be a string or integer");
   }
   return r;
 }
 inline NodeSelectorExpr parse_expr(const oj::Value& v) {
   NodeSelectorExpr e;
-  e.key = v.at("key").s();
+  e.key = sym(v.at("key").s());
   e.op = parse_op(v.at("operator").s());
-  for (auto& x : v.at("values").items()) e.values.push_back(x.s());
+  for (auto& x : v.at("values").items()) e.values.push_back(sym(x.s()));
   if (v.has("minValues") && !v.at("minValues").is_null()) e.min_values = (int)v.at("minValues").i();
   return e;
 }
 inline std::vector<Taint> parse_taints(const oj::Value& v) {
   std::vector<Taint> out;
-  for (auto& t : v.items()) out.push_back({t.at("key").s(), t.at("value").s(), t.at("effect").s()});
+  for (auto& t : v.items()) out.push_back({sym(t.at("key").s()), sym(t.at("value").s()), sym(t.at("effect").s())});
   return out;
 }
 inline LabelSelector parse_selector(const oj::Value& v) {
@@ -264,8 +267,11 @@ inline LabelSelector parse_selector(const oj::Value& v) {
   s.match_labels = parse_strmap(v.at("matchLabels"));
   for (auto& e : v.at("matchExpressions").items()) {
     SelectorExpr x;
-    x.key = e.at("key").s(); x.op = e.at("operator").s();
-    for (auto& val : e.at("values").items()) x.values.insert(val.s());
+    x.key = sym(e.at("key").s());
+    const std::string op = e.at("operator").s();
+    x.op_text = sym(op);
+    x.op = op == "In" ? SelOp::In : op == "NotIn" ? SelOp::NotIn : op == "Exists" ? SelOp::Exists : op == "DoesNotExist" ? SelOp::DoesNotExist : SelOp::Invalid;
+    for (auto& val : e.at("values").items()) x.values.insert(sym(val.s()));
     s.match_expressions.push_back(x);
   }
   return s;
@@ -273,8 +279,8 @@ inline LabelSelector parse_selector(const oj::Value& v) {
 inline PodAffinityTerm parse_affinity_term(const oj::Value& v) {
   PodAffinityTerm t;
   t.selector = parse_selector(v.at("labelSelector"));
-  t.topology_key = v.at("topologyKey").s();
-  for (auto& n : v.at("namespaces").items()) t.namespaces.push_back(n.s());
+  t.topology_key = sym(v.at("topologyKey").s());
+  for (auto& n : v.at("namespaces").items()) t.namespaces.push_back(sym(n.s()));
   if (v.has("namespaceSelector")) t.namespace_selector = parse_selector(v.at("namespaceSelector"));
   if (!t.namespace_selector.is_nil && !t.namespace_selector.valid()) throw std::runtime_error("parsing selector: invalid namespaceSelector");  // topology.go:545-547
   return t;
@@ -292,8 +298,8 @@ inline std::vector<HostPort> parse_host_ports(const oj::Value& v) {
     h.port = (int)e.at("port").i(0);
     if (h.port == 0) continue;                                  // hostportusage.go:97
     std::string ip = e.at("ip").s("");
-    h.ip = canonical_ip(ip.empty() ? "0.0.0.0" : ip);           // hostportusage.go:103-106
-    h.protocol = e.at("protocol").s("TCP");
+    h.ip = sym(canonical_ip(ip.empty() ? "0.0.0.0" : ip));      // hostportusage.go:103-106
+    h.protocol = sym(e.at("protocol").s("TCP"));
     out.push_back(h);
   }
   return out;
@@ -303,12 +309,13 @@ inline Pod parse_pod(const oj::Value& v, int idx) {
   p.host_ports = parse_host_ports(v.at("hostPorts"));
   p.input_index = idx;
   p.uid = v.at("uid").s();
-  p.ns = v.at("namespace").s("default");
+  p.uid_s = sym(p.uid);
+  p.ns = sym(v.at("namespace").s("default"));
   p.name = v.at("name").s(p.uid);
   p.labels = parse_strmap(v.at("labels"));
   p.creation = v.at("creationTimestamp").i(0);
-  p.phase = v.at("phase").s("Pending");
-  p.node_name = v.at("nodeName").s("");
+  p.phase = sym(v.at("phase").s("Pending"));
+  p.node_name = sym(v.at("nodeName").s(""));
   p.requests = parse_resources(v.at("requests"));
   p.node_selector = parse_strmap(v.at("nodeSelector"));
   p.owned_by_daemonset = v.at("ownedByDaemonSet").boolean_or(false);
@@ -318,7 +325,7 @@ inline Pod parse_pod(const oj::Value& v, int idx) {
     for (auto& e : alt.items()) exprs.push_back(parse_expr(e));
     p.volume_requirements.push_back(exprs);
   }
-  for (auto& vv : v.at("volumes").items()) p.volumes[vv.at("driver").s()].insert(vv.at("pvc").s());
+  for (auto& vv : v.at("volumes").items()) p.volumes[sym(vv.at("driver").s())].insert(sym(vv.at("pvc").s()));
   const oj::Value& na = v.at("nodeAffinity");
   if (!na.is_null()) {
     p.has_node_affinity = true;
@@ -338,17 +345,17 @@ inline Pod parse_pod(const oj::Value& v, int idx) {
     }
   }
   for (auto& t : v.at("tolerations").items())
-    p.tolerations.push_back({t.at("key").s(), t.at("operator").s(), t.at("value").s(), t.at("effect").s()});
+    p.tolerations.push_back({sym(t.at("key").s()), sym(t.at("operator").s()), sym(t.at("value").s()), sym(t.at("effect").s())});
   for (auto& c : v.at("topologySpreadConstraints").items()) {
     TopologySpreadConstraint t;
     t.max_skew = (int)c.at("maxSkew").i(1);
-    t.topology_key = c.at("topologyKey").s();
-    t.when_unsatisfiable = c.at("whenUnsatisfiable").s("DoNotSchedule");
+    t.topology_key = sym(c.at("topologyKey").s());
+    t.when_unsatisfiable = sym(c.at("whenUnsatisfiable").s("DoNotSchedule"));
     t.selector = parse_selector(c.at("labelSelector"));
     if (c.has("minDomains") && !c.at("minDomains").is_null()) t.min_domains = (int)c.at("minDomains").i();
-    if (c.has("nodeTaintsPolicy") && !c.at("nodeTaintsPolicy").is_null()) t.node_taints_policy = c.at("nodeTaintsPolicy").s();
-    if (c.has("nodeAffinityPolicy") && !c.at("nodeAffinityPolicy").is_null()) t.node_affinity_policy = c.at("nodeAffinityPolicy").s();
-    for (auto& k : c.at("matchLabelKeys").items()) t.match_label_keys.push_back(k.s());
+    if (c.has("nodeTaintsPolicy") && !c.at("nodeTaintsPolicy").is_null()) t.node_taints_policy = sym(c.at("nodeTaintsPolicy").s());
+    if (c.has("nodeAffinityPolicy") && !c.at("nodeAffinityPolicy").is_null()) t.node_affinity_policy = sym(c.at("nodeAffinityPolicy").s());
+    for (auto& k : c.at("matchLabelKeys").items()) t.match_label_keys.push_back(sym(k.s()));
     p.tscs.push_back(t);
   }
   const oj::Value& pa = v.at("podAffinity");
@@ -388,7 +395,7 @@ inline Problem parse_problem(const oj::Value& root) {
   Problem pr;
   auto& reg = labels_registry();
   reg = Labels();
-  for (auto& k : root.at("wellKnownLabels").items()) reg.well_known.insert(k.s());
+  for (auto& k : root.at("wellKnownLabels").items()) reg.well_known.insert(sym(k.s()));
   const oj::Value& o = root.at("options");
   pr.opts.ignore_preferences = o.at("preferencePolicy").s("Respect") == "Ignore";
   pr.opts.min_values_best_effort = o.at("minValuesPolicy").s("Strict") == "BestEffort";
@@ -435,8 +442,8 @@ inline Problem parse_problem(const oj::Value& root) {
     np.taints = parse_taints(v.at("taints"));
     if (v.has("limits") && !v.at("limits").is_null()) { np.has_limits = true; np.limits = parse_resources(v.at("limits")); }
     np.is_static = v.at("static").boolean_or(false);
-    if (v.has("nodeClassLabelKey")) np.node_class_label_key = v.at("nodeClassLabelKey").s();
-    if (v.has("nodeClassName")) np.node_class_name = v.at("nodeClassName").s();
+    if (v.has("nodeClassLabelKey")) np.node_class_label_key = sym(v.at("nodeClassLabelKey").s());
+    if (v.has("nodeClassName")) np.node_class_name = sym(v.at("nodeClassName").s());
     if (v.has("instanceTypes") && !v.at("instanceTypes").is_null()) {
       for (auto& n : v.at("instanceTypes").items()) {
         auto f = it_index.find(n.s());
@@ -451,8 +458,9 @@ inline Problem parse_problem(const oj::Value& root) {
   for (auto& v : root.at("stateNodes").items()) {
     StateNode n;
     n.name = v.at("name").s();
+    n.name_s = sym(n.name);
     n.labels = parse_strmap(v.at("labels"));
-    n.hostname = v.has("hostname") ? v.at("hostname").s() : (n.labels.count(kLabelHostname) ? n.labels[kLabelHostname] : n.name);
+    n.hostname = v.has("hostname") ? sym(v.at("hostname").s()) : (n.labels.count(W().hostname) ? n.labels.find(W().hostname)->second : n.name_s);
     n.taints = parse_taints(v.at("taints"));
     n.available = parse_resources(v.at("available"));
     n.capacity = parse_resources(v.at("capacity"));
@@ -463,11 +471,11 @@ inline Problem parse_problem(const oj::Value& root) {
     n.has_node = v.at("hasNode").boolean_or(true);
     n.marked_for_deletion = v.at("markedForDeletion").boolean_or(false);
     n.under_consolidate_after = v.at("underConsolidateAfter").boolean_or(false);
-    for (auto& vv : v.at("volumeUsage").at("volumes").items()) n.volumes[vv.at("driver").s()].insert(vv.at("pvc").s());
-    for (auto& kv : v.at("volumeUsage").at("limits").members()) n.volume_limits[kv.first] = (int)kv.second.i();
+    for (auto& vv : v.at("volumeUsage").at("volumes").items()) n.volumes[sym(vv.at("driver").s())].insert(sym(vv.at("pvc").s()));
+    for (auto& kv : v.at("volumeUsage").at("limits").members()) n.volume_limits[sym(kv.first)] = (int)kv.second.i();
     pr.state_nodes.push_back(n);
   }
-  for (auto& n : root.at("deletingNodeNames").items()) pr.deleting_node_names.insert(n.s());
+  for (auto& n : root.at("deletingNodeNames").items()) pr.deleting_node_names.insert(sym(n.s()));
   int idx = 0;
   for (auto& v : root.at("pods").items()) pr.pods.push_back(parse_pod(v, idx++));
   for (auto& g : root.at("podGroups").items()) {
@@ -477,6 +485,7 @@ inline Problem parse_problem(const oj::Value& root) {
     for (long long i = 0; i < n; ++i) {
       Pod p = tmpl;
       p.uid = group_uid(seed, (uint64_t)i);
+      p.uid_s = sym(p.uid);
       p.name = p.uid;
       p.input_index = idx++;
       pr.pods.push_back(std::move(p));
@@ -486,7 +495,7 @@ inline Problem parse_problem(const oj::Value& root) {
   for (auto& v : root.at("daemonSetPods").items()) pr.daemonset_pods.push_back(parse_pod(v, di++));
   int cpi = 0;
   for (auto& v : root.at("clusterPods").items()) pr.cluster_pods.push_back(parse_pod(v, cpi++));
-  for (auto& v : root.at("namespaces").items()) pr.namespaces.push_back({v.at("name").s(), parse_strmap(v.at("labels"))});
+  for (auto& v : root.at("namespaces").items()) pr.namespaces.push_back({sym(v.at("name").s()), parse_strmap(v.at("labels"))});
   return pr;
 }
 

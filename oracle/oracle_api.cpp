@@ -27,10 +27,10 @@ static std::string i128_to_string(i128 v) {
 
 static oj::Value req_to_json(const Requirement& r) {
   oj::Value o = oj::Value::object();
-  o.set("key", oj::Value::string(r.key));
+  o.set("key", oj::Value::string(str(r.key)));
   o.set("complement", oj::Value::boolean(r.complement));
   oj::Value vals = oj::Value::array();
-  for (auto& v : r.values) vals.push(oj::Value::string(v));
+  for (auto& v : r.values.strings()) vals.push(oj::Value::string(v));   // in string order
   o.set("values", vals);
   o.set("gte", r.gte ? oj::Value::integer(*r.gte) : oj::Value());
   o.set("lte", r.lte ? oj::Value::integer(*r.lte) : oj::Value());
@@ -43,7 +43,7 @@ static Requirement req_from_json(const oj::Value& v) {
   for (auto& x : v.at("values").items()) vals.push_back(x.s());
   std::optional<int> mv;
   if (v.has("minValues") && !v.at("minValues").is_null()) mv = (int)v.at("minValues").i();
-  return Requirement::make(v.at("key").s(), parse_op(v.at("operator").s()), mv, vals);
+  return Requirement::make_s(v.at("key").s(), parse_op(v.at("operator").s()), mv, vals);
 }
 static Requirements reqs_from_json(const oj::Value& v) {
   Requirements r;
@@ -52,12 +52,18 @@ static Requirements reqs_from_json(const oj::Value& v) {
 }
 static oj::Value reqs_to_json(const Requirements& r) {
   oj::Value a = oj::Value::array();
-  for (auto& kv : r.m) a.push(req_to_json(kv.second));
+  std::vector<const Requirement*> by_key;
+  for (auto& q : r.m) by_key.push_back(&q);
+  std::sort(by_key.begin(), by_key.end(), [](const Requirement* x, const Requirement* y) { return str(x->key) < str(y->key); });
+  for (auto* q : by_key) a.push(req_to_json(*q));
   return a;
 }
 static oj::Value res_to_json(const ResourceList& r) {
   oj::Value o = oj::Value::object();
-  for (auto& kv : r) o.set(kv.first, oj::Value::string(i128_to_string(kv.second)));  // nano-units, decimal string
+  std::vector<const ResEntry*> by_name;
+  for (auto& kv : r) by_name.push_back(&kv);
+  std::sort(by_name.begin(), by_name.end(), [](const ResEntry* x, const ResEntry* y) { return str(x->first) < str(y->first); });
+  for (auto* kv : by_name) o.set(str(kv->first), oj::Value::string(i128_to_string(kv->second)));  // nano-units, decimal string
   return o;
 }
 static char* dup_out(const oj::Value& v) {
@@ -167,7 +173,7 @@ static oj::Value solve_doc(const Problem& pr, const std::vector<Pod>* probe_pods
     for (auto* nc : res.new_node_claims) {
       oj::Value c = oj::Value::object();
       c.set("nodePool", oj::Value::string(nc->tmpl->nodepool_name));
-      c.set("hostname", oj::Value::string(nc->hostname));
+      c.set("hostname", oj::Value::string(str(nc->hostname)));
       oj::Value pods = oj::Value::array();
       for (auto* p : nc->pods) pods.push(oj::Value::string(p->uid));
       c.set("pods", pods);
@@ -185,7 +191,7 @@ static oj::Value solve_doc(const Problem& pr, const std::vector<Pod>* probe_pods
       for (auto& kv : nc->annotations) ann.set(kv.first, oj::Value::string(kv.second));
       c.set("annotations", ann);
       oj::Value ro = oj::Value::array();
-      for (auto* o : nc->reserved_offerings) ro.push(oj::Value::string(o->reservation_id()));
+      for (auto* o : nc->reserved_offerings) ro.push(oj::Value::string(str(o->reservation_id())));
       c.set("reservedOfferings", ro);
       c.set("cheapestPrice", oj::Value::number(cheapest == DBL_MAX ? -1.0 : cheapest));
       if (cheapest != DBL_MAX) total_cost += cheapest;
@@ -243,7 +249,7 @@ char* oracle_eval_json(const char* query_json) {
     oj::Value q = oj::Parser(query_json).parse();
     auto& reg = labels_registry();
     reg = Labels();
-    for (auto& k : q.at("wellKnownLabels").items()) reg.well_known.insert(k.s());
+    for (auto& k : q.at("wellKnownLabels").items()) reg.well_known.insert(sym(k.s()));
     std::string fn = q.at("fn").s();
     oj::Value out = oj::Value::object();
     if (fn == "intersection") {
@@ -251,7 +257,7 @@ char* oracle_eval_json(const char* query_json) {
     } else if (fn == "has_intersection") {
       out.set("result", oj::Value::boolean(req_from_json(q.at("a")).has_intersection(req_from_json(q.at("b")))));
     } else if (fn == "has") {
-      out.set("result", oj::Value::boolean(req_from_json(q.at("a")).has(q.at("value").s())));
+      out.set("result", oj::Value::boolean(req_from_json(q.at("a")).has(sym(q.at("value").s()))));
     } else if (fn == "describe") {
       Requirement r = req_from_json(q.at("a"));
       oj::Value d = req_to_json(r);
@@ -282,7 +288,7 @@ char* oracle_eval_json(const char* query_json) {
       else throw std::runtime_error("bad resources op");
     } else if (fn == "tolerates") {
       std::vector<Toleration> tols;
-      for (auto& t : q.at("tolerations").items()) tols.push_back({t.at("key").s(), t.at("operator").s(), t.at("value").s(), t.at("effect").s()});
+      for (auto& t : q.at("tolerations").items()) tols.push_back({sym(t.at("key").s()), sym(t.at("operator").s()), sym(t.at("value").s()), sym(t.at("effect").s())});
       out.set("result", oj::Value::boolean(taints_tolerated(parse_taints(q.at("taints")), tols)));
     } else if (fn == "sort_by_key") {
       std::vector<std::pair<long long, int>> v;

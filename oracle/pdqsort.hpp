@@ -13,9 +13,12 @@
 
 namespace oracle {
 
+// LessFn / SwapFn: the two closures Go's sort.Slice builds (less(i, j) on positions, the reflect swapper)
+template <class LessFn, class SwapFn>
 struct GoSort {
-  std::function<bool(int, int)> less;
-  std::function<void(int, int)> swap;
+  LessFn less;
+  SwapFn swap;
+  GoSort(LessFn l, SwapFn s) : less(l), swap(s) {}
 
   enum Hint { unknownHint = 0, increasingHint, decreasingHint };
 
@@ -158,9 +161,9 @@ struct GoSort {
 // sort.Slice over a std::vector with a value comparator.
 template <class T, class Less>
 void go_sort_slice(std::vector<T>& v, Less lt) {
-  GoSort s;
-  s.less = [&](int i, int j) { return lt(v[i], v[j]); };
-  s.swap = [&](int i, int j) { std::swap(v[i], v[j]); };
+  auto less = [&](int i, int j) { return lt(v[i], v[j]); };
+  auto swap = [&](int i, int j) { std::swap(v[i], v[j]); };
+  GoSort<decltype(less), decltype(swap)> s(less, swap);
   s.sort_slice((int)v.size());
 }
 

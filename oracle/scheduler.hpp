@@ -10,6 +10,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include "topology.hpp"
 
 namespace oracle {
@@ -19,15 +20,15 @@ namespace oracle {
 inline bool offering_compatible(const Requirements& reqs, const Offering& o) { return reqs.compatible(o.reqs, true); }
 
 // InstanceTypes.SatisfiesMinValues — types.go:399-433
-inline int satisfies_min_values(const std::vector<const InstanceType*>& its, const Requirements& reqs, std::map<std::string, int>* unsat, bool* ok) {
+inline int satisfies_min_values(const std::vector<const InstanceType*>& its, const Requirements& reqs, std::map<Sym, int>* unsat, bool* ok) {
   *ok = true;
   if (!reqs.has_min_values()) return 0;
-  std::map<std::string, int> incompatible;
-  std::map<std::string, std::set<std::string>> values_for_key;
+  std::map<Sym, int> incompatible;
+  std::map<Sym, SymSet> values_for_key;
   for (size_t i = 0; i < its.size(); ++i) {
-    for (auto& kv : reqs.m) if (kv.second.min_values) {
-      Requirement r = its[i]->reqs.get(kv.first);
-      values_for_key[kv.first].insert(r.values.begin(), r.values.end());
+    for (auto& q : reqs.m) if (q.min_values) {
+      Requirement r = its[i]->reqs.get(q.key);
+      values_for_key[q.key].insert(r.values.begin(), r.values.end());
     }
     for (auto& kv : values_for_key) {
       int mv = *reqs.get(kv.first).min_values;
@@ -51,9 +52,9 @@ inline void order_by_price(std::vector<const InstanceType*>& its, const Requirem
 }
 // Offerings.WorstLaunchPrice — types.go:587-598
 inline double worst_launch_price(const InstanceType& it, const Requirements& reqs) {
-  for (const char* ct : {"reserved", "spot", "on-demand"}) {
+  for (Sym ct : {W().reserved, W().spot, W().on_demand}) {
     Requirements ctr;
-    ctr.add(Requirement::make(kCapacityTypeLabel, Op::In, {ct}));
+    ctr.add(Requirement::make(W().capacity_type, Op::In, ct));
     double worst = -1;
     bool any = false;
     for (auto& o : it.offerings) {
@@ -70,39 +71,39 @@ inline double worst_launch_price(const InstanceType& it, const Requirements& req
 
 // ---- ReservationManager — reservationmanager.go:28-110 ---------------------------------------------------------
 struct ReservationManager {
-  std::map<std::string, std::set<std::string>> reservations;  // hostname -> reservation ids
-  std::map<std::string, int> capacity;                        // reservation id -> remaining
+  std::map<Sym, SymSet> reservations;  // hostname -> reservation ids
+  std::map<Sym, int> capacity;         // reservation id -> remaining
   void init(const Problem& pr, const std::vector<const NodePool*>& pools) {
     for (auto* np : pools)
       for (int idx : np->instance_types)
         for (auto& o : pr.catalog[idx].offerings) {
-          if (o.capacity_type() != "reserved") continue;
-          std::string id = o.reservation_id();
+          if (o.capacity_type() != W().reserved) continue;
+          Sym id = o.reservation_id();
           auto it = capacity.find(id);
           if (it == capacity.end()) capacity[id] = o.reservation_capacity;
           else if (o.reservation_capacity < it->second) it->second = o.reservation_capacity;  // keep the most pessimistic
         }
   }
-  bool has_reservation(const std::string& host, const std::string& id) const {
+  bool has_reservation(Sym host, Sym id) const {
     auto it = reservations.find(host);
     return it != reservations.end() && it->second.count(id);
   }
-  bool can_reserve(const std::string& host, const Offering& o) const {
-    std::string id = o.reservation_id();
+  bool can_reserve(Sym host, const Offering& o) const {
+    Sym id = o.reservation_id();
     if (has_reservation(host, id)) return true;
     auto it = capacity.find(id);
     return it != capacity.end() && it->second > 0;
   }
-  void reserve(const std::string& host, const std::vector<const Offering*>& ofs) {
+  void reserve(Sym host, const std::vector<const Offering*>& ofs) {
     for (auto* o : ofs) {
-      std::string id = o->reservation_id();
+      Sym id = o->reservation_id();
       if (has_reservation(host, id)) continue;
       capacity[id] -= 1;
       reservations[host].insert(id);
     }
   }
-  void release(const std::string& host, const Offering& o) {
-    std::string id = o.reservation_id();
+  void release(Sym host, const Offering& o) {
+    Sym id = o.reservation_id();
     auto it = reservations.find(host);
     if (it != reservations.end() && it->second.count(id)) { it->second.erase(id); capacity[id] += 1; }
   }
@@ -183,17 +184,21 @@ inline void it_fits(const InstanceType& it, const ResourceList& requests, const 
 // filterInstanceTypesByRequirements — nodeclaim.go:541-618
 inline bool filter_instance_types(const std::vector<const InstanceType*>& its, Requirements& reqs, const std::vector<DaemonOverheadGroup>& groups,
                                   const ResourceList& total_requests, bool relax_min_values, std::vector<const InstanceType*>& remaining,
-                                  std::map<std::string, int>& unsat, FilterDiag& d, Counters* ctr,
+                                  std::map<Sym, int>& unsat, FilterDiag& d, Counters* ctr,
                                   const std::vector<HostPort>* pod_ports = nullptr, const std::vector<HostPort>* bin_ports = nullptr) {
   remaining.clear();
-  std::set<const InstanceType*> eligible(its.begin(), its.end());
+  // membership in `its` (the NodeClaim's InstanceTypeOptions) by catalogue position
+  int max_index = -1;
+  for (auto* it : its) max_index = std::max(max_index, it->catalog_index);
+  std::vector<char> eligible((size_t)(max_index + 1), 0);
+  for (auto* it : its) eligible[(size_t)it->catalog_index] = 1;
   for (auto& g : groups) {
     // a group whose host ports (its daemon pods' + the pods already on the NodeClaim, nodeclaim.go:256-259) collide with
     // the pod's is skipped as a whole (nodeclaim.go:562-565)
     if (pod_ports && !pod_ports->empty() && (host_ports_conflict(*pod_ports, g.host_ports) || (bin_ports && host_ports_conflict(*pod_ports, *bin_ports)))) continue;
     ResourceList total = g.overhead.empty() ? total_requests : res_merge(total_requests, g.overhead);
     for (auto* it : g.its_ordered) {
-      if (!eligible.count(it)) continue;
+      if (it->catalog_index > max_index || !eligible[(size_t)it->catalog_index]) continue;
       if (ctr) ctr->it_evaluations++;
       bool compat = it_compatible(*it, reqs);
       bool fits, has_off;
@@ -207,7 +212,7 @@ inline bool filter_instance_types(const std::vector<const InstanceType*>& its, R
   }
   if (reqs.has_min_values()) {
     bool ok;
-    std::map<std::string, int> u;
+    std::map<Sym, int> u;
     satisfies_min_values(remaining, reqs, &u, &ok);
     if (!ok) {
       unsat = u;
@@ -226,7 +231,7 @@ struct NodeClaim {
   std::vector<const InstanceType*> its;
   ResourceList requests;
   std::vector<Pod*> pods;
-  std::string hostname;
+  Sym hostname = kNoSym;
   std::map<std::string, std::string> annotations;
   std::vector<const Offering*> reserved_offerings;
   std::vector<HostPort> host_ports;   // what Add put into every daemon group's HostPortUsage (nodeclaim.go:256-259)
@@ -240,7 +245,7 @@ struct ExistingNode {
   ResourceList remaining;
   Requirements reqs;
   std::vector<HostPort> host_ports;   // StateNode.HostPortUsage() + the pods added in this Solve (existingnode.go:178)
-  std::map<std::string, std::set<std::string>> volumes;   // StateNode.VolumeUsage().volumes + the pods added in this Solve (existingnode.go:179)
+  std::map<Sym, SymSet> volumes;   // StateNode.VolumeUsage().volumes + the pods added in this Solve (existingnode.go:179)
   bool under_consolidate_after = false;
 };
 
@@ -262,7 +267,7 @@ struct Scheduler {
   std::vector<std::unique_ptr<ExistingNode>> existing_store;
   std::vector<ExistingNode*> existing_nodes;
   std::map<std::string, ResourceList> remaining_resources;  // nodepool -> remaining (only pools present in the map count)
-  std::map<std::string, PodData> cached;                    // by uid
+  std::unordered_map<Sym, PodData> cached;                  // by uid
   Topology topology;
   ReservationManager reservations;
   bool tolerate_prefer_no_schedule = false;
@@ -297,9 +302,9 @@ struct Scheduler {
     d.strict_reqs = d.reqs;
     if (p.has_node_affinity && !p.preferred_terms.empty()) d.strict_reqs = pod_requirements(p, true);
     d.requests = p.requests;                       // RequestsForPods — resources.go:30-38
-    d.requests["pods"] = (i128)1 * 1000000000;
+    d.requests[W().pods] = (i128)1 * 1000000000;
     for (auto& alt : p.volume_requirements) d.volume_reqs.push_back(exprs_to_requirements(alt));   // scheduler.go:572
-    cached[p.uid] = d;
+    cached[p.uid_s] = d;
   }
 
   // ---- Preferences — preferences.go:38-146 -----------------------------------------------------------------
@@ -331,7 +336,7 @@ struct Scheduler {
   }
   static bool remove_topology_spread_schedule_anyway(Pod& p) {
     for (size_t i = 0; i < p.tscs.size(); ++i)
-      if (p.tscs[i].when_unsatisfiable == "ScheduleAnyway") {
+      if (p.tscs[i].when_unsatisfiable == W().ScheduleAnyway) {
         p.tscs[i] = p.tscs.back();
         p.tscs.pop_back();
         return true;
@@ -340,8 +345,9 @@ struct Scheduler {
   }
   static bool tolerate_prefer_no_schedule_taints(Pod& p) {
     // MatchToleration: key, operator, value, effect all equal
-    for (auto& t : p.tolerations) if (t.key.empty() && t.op == "Exists" && t.value.empty() && t.effect == "PreferNoSchedule") return false;
-    p.tolerations.push_back({"", "Exists", "", "PreferNoSchedule"});
+    const WellKnownSyms& w = W();
+    for (auto& t : p.tolerations) if (t.key == w.empty && t.op == w.Exists && t.value == w.empty && t.effect == w.PreferNoSchedule) return false;
+    p.tolerations.push_back({w.empty, w.Exists, w.empty, w.PreferNoSchedule});
     return true;
   }
   bool relax(Pod& p) {
@@ -373,7 +379,7 @@ struct Scheduler {
       std::vector<const Pod*> compat;
       for (auto& dp : pr->daemonset_pods) if (daemon_pod_compatible(nct, *it, dp)) compat.push_back(&dp);
       std::vector<std::string> keys;
-      for (auto* p : compat) keys.push_back(p->ns + "/" + p->name);
+      for (auto* p : compat) keys.push_back(str(p->ns) + "/" + p->name);
       std::sort(keys.begin(), keys.end());
       std::string key;
       for (auto& k : keys) { if (!key.empty()) key += ","; key += k; }
@@ -383,7 +389,7 @@ struct Scheduler {
         DaemonOverheadGroup ng;
         if (!compat.empty()) {
           for (auto* p : compat) ng.overhead = res_merge(ng.overhead, p->requests);
-          ng.overhead["pods"] = (i128)compat.size() * 1000000000;
+          ng.overhead[W().pods] = (i128)compat.size() * 1000000000;
           for (auto* p : compat) ng.host_ports.insert(ng.host_ports.end(), p->host_ports.begin(), p->host_ports.end());
         }
         groups.push_back({key, ng});
@@ -408,7 +414,7 @@ struct Scheduler {
     for (auto& np : problem.node_pools) if (!np.is_static) pools.push_back(&np);
     // OrderByWeight — pkg/utils/nodepool/nodepool.go:161-171 (total order: weight desc, name desc)
     std::sort(pools.begin(), pools.end(), [](const NodePool* a, const NodePool* b) { return a->weight != b->weight ? a->weight > b->weight : a->name > b->name; });
-    for (auto* np : pools) for (auto& t : np->taints) if (t.effect == "PreferNoSchedule") tolerate_prefer_no_schedule = true;
+    for (auto* np : pools) for (auto& t : np->taints) if (t.effect == W().PreferNoSchedule) tolerate_prefer_no_schedule = true;
 
     std::vector<const StateNode*> snodes;
     for (auto& n : problem.state_nodes) if (!is_removed(n)) snodes.push_back(&n);
@@ -420,19 +426,19 @@ struct Scheduler {
       NodeClaimTemplate nct;
       nct.np = np; nct.nodepool_name = np->name; nct.weight = np->weight; nct.taints = np->taints;
       nct.reqs.add_all(exprs_to_requirements(np->requirements));
-      std::map<std::string, std::string> labels = np->labels;
-      labels[kNodePoolLabel] = np->name;
-      labels[np->node_class_label_key] = np->node_class_name;
+      SymMap labels = np->labels;
+      labels.set(W().nodepool, sym(np->name));
+      labels.set(np->node_class_label_key, np->node_class_name);
       nct.reqs.add_all(label_requirements(labels));
-      nct.reqs.add(Requirement::make(kNodeRegisteredLabel, Op::In, {"true"}));
-      nct.reqs.add(Requirement::make(kNodeInitializedLabel, Op::In, {"true"}));
+      nct.reqs.add(Requirement::make(W().registered, Op::In, W().true_));
+      nct.reqs.add(Requirement::make(W().initialized, Op::In, W().true_));
       // prefilter — scheduler.go:159
       std::vector<const InstanceType*> all;
       for (int idx : np->instance_types) all.push_back(&problem.catalog[idx]);
       DaemonOverheadGroup g0;
       g0.its.insert(all.begin(), all.end());
       g0.its_ordered = all;
-      std::map<std::string, int> unsat;
+      std::map<Sym, int> unsat;
       FilterDiag d;
       ResourceList none;
       std::vector<const InstanceType*> remaining;
@@ -463,18 +469,18 @@ struct Scheduler {
         daemon = res_merge(daemon, p.requests);
         ndaemons++;
       }
-      daemon["pods"] = (i128)ndaemons * 1000000000;
+      daemon[W().pods] = (i128)ndaemons * 1000000000;
       res_subtract_from(daemon, n.daemonset_requests);
       for (auto& kv : daemon) if (kv.second < 0) kv.second = 0;
       en->remaining = res_subtract(n.available, daemon);
       en->reqs = label_requirements(n.labels);
-      en->reqs.add(Requirement::make(kLabelHostname, Op::In, {n.hostname}));
+      en->reqs.add(Requirement::make(W().hostname, Op::In, n.hostname));
       en->under_consolidate_after = opts.enforce_consolidate_after && n.under_consolidate_after;
-      topology.reg(kLabelHostname, n.hostname);
+      topology.reg(W().hostname, n.hostname);
       // updateRemainingResources — scheduler.go:835-842
-      auto npit = n.labels.find(kNodePoolLabel);
-      if (npit != n.labels.end()) {
-        auto rr = remaining_resources.find(npit->second);
+      auto* npit = n.labels.find(W().nodepool);
+      if (npit) {
+        auto rr = remaining_resources.find(str(npit->second));
         if (rr != remaining_resources.end()) rr->second = res_subtract(rr->second, n.capacity);
       }
       existing_nodes.push_back(en.get());
@@ -496,7 +502,7 @@ struct Scheduler {
     for (auto& kv : n.volumes) {
       auto lim = n.node->volume_limits.find(kv.first);
       if (lim == n.node->volume_limits.end()) continue;
-      std::set<std::string> u = kv.second;
+      SymSet u = kv.second;
       auto pv = pod.volumes.find(kv.first);
       if (pv != pod.volumes.end()) u.insert(pv->second.begin(), pv->second.end());
       if ((int)u.size() > lim->second) { last_err = ERR_EXISTING; return false; }
@@ -514,8 +520,9 @@ struct Scheduler {
     // volume requirement alternatives — existingnode.go:108-139; tryVolumeAlternative :143-168. They narrow the node's
     // requirements only: topology counts with the pod's own (strict) requirements.
     const size_t n_alt = pd.volume_reqs.empty() ? 1 : pd.volume_reqs.size();
+    Requirements alt_base;
     for (size_t a = 0; a < n_alt; ++a) {
-      Requirements base = base0;
+      Requirements& base = pd.volume_reqs.empty() ? base0 : (alt_base = base0);
       if (!pd.volume_reqs.empty()) {
         if (!base.compatible(pd.volume_reqs[a], false)) { last_err = ERR_INCOMPATIBLE; continue; }
         base.add_all(pd.volume_reqs[a]);
@@ -543,10 +550,10 @@ struct Scheduler {
     auto nc = std::make_unique<NodeClaim>();
     char buf[64];
     snprintf(buf, sizeof buf, "hostname-placeholder-%04lld", ++node_id);
-    nc->hostname = buf;
+    nc->hostname = sym(buf);
     nc->tmpl = &t;
     nc->reqs = t.reqs;
-    nc->reqs.add(Requirement::make(kLabelHostname, Op::In, {nc->hostname}));
+    nc->reqs.add(Requirement::make(W().hostname, Op::In, nc->hostname));
     nc->its = its;
     return nc;
   }
@@ -557,7 +564,7 @@ struct Scheduler {
     bool has_compatible = false;
     for (auto* it : its)
       for (auto& o : it->offerings) {
-        if (o.capacity_type() != "reserved" || !o.available) continue;
+        if (o.capacity_type() != W().reserved || !o.available) continue;
         if (!reqs.compatible(o.reqs, true)) continue;
         has_compatible = true;
         if (reservations.can_reserve(n.hostname, o)) out.push_back(&o);
@@ -578,14 +585,18 @@ struct Scheduler {
     ctr.bin_evaluations++;
     last_diag = 0;
     if (!taints_tolerated(n.tmpl->taints, pod.tolerations)) { last_err = ERR_TAINTS; return false; }
+    // nodeclaim.go:130-136: the reference copies the claim's requirements, then tests Compatible on the copy, then Adds;
+    // Compatible does not write, so the copy is made once the test has passed
+    if (!n.reqs.compatible(pd.reqs, true)) { last_err = ERR_INCOMPATIBLE; return false; }
     Requirements base0 = n.reqs;
-    if (!base0.compatible(pd.reqs, true)) { last_err = ERR_INCOMPATIBLE; return false; }
     base0.add_all(pd.reqs);
     // volume requirement alternatives — nodeclaim.go:138-157; tryVolumeAlternative :164-242: the first alternative that passes
     // topology, the instance-type filter and the reservation check wins; the error reported is the last alternative's
     const size_t n_alt = pd.volume_reqs.empty() ? 1 : pd.volume_reqs.size();
+    Requirements alt_base;
     for (size_t a = 0; a < n_alt; ++a) {
-      Requirements base = base0;
+      // every alternative starts from the claim's requirements + the pod's; without alternatives that set is used in place
+      Requirements& base = pd.volume_reqs.empty() ? base0 : (alt_base = base0);
       last_diag = 0;
       if (!pd.volume_reqs.empty()) {
         if (!base.compatible(pd.volume_reqs[a], true)) { last_err = ERR_INCOMPATIBLE; continue; }
@@ -596,11 +607,15 @@ struct Scheduler {
       if (!base.compatible(topo, true)) { last_err = ERR_TOPOLOGY; continue; }
       base.add_all(topo);
       ResourceList requests = res_merge(n.requests, pd.requests);
-      std::map<std::string, int> unsat;
+      std::map<Sym, int> unsat;
       FilterDiag d;
       std::vector<const InstanceType*> its;
       bool ok = filter_instance_types(n.its, base, n.tmpl->daemon_groups, requests, relax_min_values, its, unsat, d, &ctr, &pod.host_ports, &n.host_ports);
-      if (relax_min_values) for (auto& kv : unsat) base.m[kv.first].min_values = kv.second;
+      if (relax_min_values) for (auto& kv : unsat) {
+        Requirement* r = base.find(kv.first);   // a key of `base` by construction (SatisfiesMinValues walks its keys)
+        if (!r) throw std::runtime_error("minValues relaxation names a key the requirements do not have");
+        r->min_values = kv.second;
+      }
       if (!ok) { last_err = d.min_values_incompatible ? ERR_MIN_VALUES : ERR_INSTANCE_TYPES; last_diag = d.bits(); continue; }
       std::vector<const Offering*> ofs;
       if (!offerings_to_reserve(n, its, base, ofs)) { last_err = ERR_RESERVED; continue; }
@@ -616,10 +631,10 @@ struct Scheduler {
     n.requests = res_merge(n.requests, pd.requests);
     n.reqs = reqs;
     n.host_ports.insert(n.host_ports.end(), pod->host_ports.begin(), pod->host_ports.end());
-    topology.reg(kLabelHostname, n.hostname);
+    topology.reg(W().hostname, n.hostname);
     topology.record(*pod, n.tmpl->taints, reqs);
     reservations.reserve(n.hostname, ofs);
-    std::set<std::string> updated;
+    SymSet updated;
     for (auto* o : ofs) updated.insert(o->reservation_id());
     for (auto* o : n.reserved_offerings) if (!updated.count(o->reservation_id())) reservations.release(n.hostname, *o);
     n.reserved_offerings = ofs;
@@ -645,13 +660,13 @@ struct Scheduler {
     return out;
   }
   bool add_to_new_claim(Pod& pod, Pod* queue_pod) {
-    const PodData& pd = cached[pod.uid];
+    const PodData& pd = cached[pod.uid_s];
     int first_err = 0, first_diag = 0;
     for (auto& t : templates) {
       std::vector<const InstanceType*> its = t.its;
       auto rr = remaining_resources.find(t.nodepool_name);
       if (rr != remaining_resources.end()) {
-        auto nodes = rr->second.find("nodes");
+        auto nodes = rr->second.find(W().nodes);
         if (nodes != rr->second.end() && nodes->second == 0) { if (!first_err) first_err = ERR_LIMITS; continue; }
         its = filter_by_remaining(its, rr->second);
         if (its.empty()) { if (!first_err) first_err = ERR_LIMITS; continue; }
@@ -665,9 +680,9 @@ struct Scheduler {
       }
       // minValuesRelaxed annotation — scheduler.go:763-772
       bool relaxed = false;
-      for (auto& kv : nc->reqs.m) {
-        auto upd = r.get(kv.first).min_values;
-        auto orig = kv.second.min_values;
+      for (auto& q : nc->reqs.m) {
+        auto upd = r.get(q.key).min_values;
+        auto orig = q.min_values;
         if (orig && upd && *upd < *orig) relaxed = true;
       }
       nc->annotations[kMinValuesRelaxedAnnotation] = relaxed ? "true" : "false";
@@ -694,16 +709,16 @@ struct Scheduler {
   // The reference appends the *relaxed copy* it was handed to Pods; results are reported by uid so the distinction is
   // invisible. queue_pod keeps the pointer stable.
   bool add_to_existing(Pod& pod, Pod* queue_pod) {
-    const PodData& pd = cached[pod.uid];
+    const PodData& pd = cached[pod.uid_s];
     for (auto* en : existing_nodes) {
-      if (en->under_consolidate_after && (pod.phase != "Pending" && !pr->deleting_node_names.count(pod.node_name))) continue;
+      if (en->under_consolidate_after && (pod.phase != W().Pending && !pr->deleting_node_names.count(pod.node_name))) continue;
       Requirements r;
       if (existing_can_add(*en, pod, pd, r)) { existing_add(*en, queue_pod, pd, r); return true; }
     }
     return false;
   }
   bool add_to_inflight(Pod& pod, Pod* queue_pod) {
-    const PodData& pd = cached[pod.uid];
+    const PodData& pd = cached[pod.uid_s];
     if (threads > 1 && new_node_claims.size() >= parallel_min) return add_to_inflight_parallel(pod, queue_pod, pd);
     for (auto* nc : new_node_claims) {
       Requirements r; std::vector<const InstanceType*> its; std::vector<const Offering*> ofs;
@@ -735,23 +750,23 @@ struct Scheduler {
     for (auto& p : pods) q.push_back(&p);
     // NewQueue: sort.Slice(byCPUAndMemoryDescending) — total order, any sort gives the same result (queue.go:37-41,72-108)
     std::sort(q.begin(), q.end(), [&](Pod* a, Pod* b) {
-      const ResourceList& l = cached[a->uid].requests; const ResourceList& r = cached[b->uid].requests;
-      auto get = [](const ResourceList& m, const char* k) { auto it = m.find(k); return it == m.end() ? (i128)0 : it->second; };
-      i128 lc = get(l, "cpu"), rc = get(r, "cpu");
+      const ResourceList& l = cached[a->uid_s].requests; const ResourceList& r = cached[b->uid_s].requests;
+      auto get = [](const ResourceList& m, Sym k) { auto it = m.find(k); return it == m.end() ? (i128)0 : it->second; };
+      i128 lc = get(l, W().cpu), rc = get(r, W().cpu);
       if (lc != rc) return lc > rc;
-      i128 lm = get(l, "memory"), rm = get(r, "memory");
+      i128 lm = get(l, W().memory), rm = get(r, W().memory);
       if (lm != rm) return lm > rm;
       if (a->creation != b->creation) return a->creation < b->creation;
       return a->uid < b->uid;
     });
-    std::map<std::string, size_t> last_len;
+    std::unordered_map<Sym, size_t> last_len;
     size_t head = 0;
     long long steps = 0;
     for (;;) {
       size_t qlen = q.size() - head;
       if (qlen == 0) break;
       Pod* p = q[head];
-      auto ll = last_len.find(p->uid);
+      auto ll = last_len.find(p->uid_s);
       if (ll != last_len.end() && ll->second == qlen) break;   // queue.go:52-56 (checked before popping)
       if (opts.max_steps >= 0 && steps >= opts.max_steps) { res.timed_out = true; break; }  // ctx deadline stand-in
       head++;
@@ -765,17 +780,17 @@ struct Scheduler {
         topology.update(*p);
         update_cached_pod_data(*p);
         q.push_back(p);
-        last_len[p->uid] = q.size() - head;   // queue.go:63-66
+        last_len[p->uid_s] = q.size() - head;   // queue.go:63-66
       }
     }
     // FinalizeScheduling — nodeclaim.go:383-409
     for (auto* nc : new_node_claims) {
-      nc->reqs.m.erase(kLabelHostname);
+      nc->reqs.erase(W().hostname);
       if (!nc->reserved_offerings.empty()) {
-        nc->reqs.m[kCapacityTypeLabel] = Requirement::make(kCapacityTypeLabel, Op::In, {"reserved"});
-        std::vector<std::string> ids;
+        nc->reqs.put(Requirement::make(W().capacity_type, Op::In, W().reserved));
+        std::vector<Sym> ids;
         for (auto* o : nc->reserved_offerings) ids.push_back(o->reservation_id());
-        nc->reqs.add(Requirement::make(kReservationIDLabel, Op::In, ids));
+        nc->reqs.add(Requirement::make(W().reservation_id, Op::In, std::nullopt, ids));
       }
       // addDaemonRequests — nodeclaim.go:353-377
       std::set<const InstanceType*> remaining(nc->its.begin(), nc->its.end());

@@ -3,8 +3,12 @@
 // Restatement of pkg/controllers/provisioning/scheduling/{topology.go, topologygroup.go, topologynodefilter.go,
 // topologydomaingroup.go}. Where the reference iterates a Go map (topologygroup.go:259,274,355,372,380,432) the
 // result of a tie is undefined in the reference itself; the oracle canonicalises every such choice to the
-// lexicographically smallest domain (documented in DESIGN.md) — domains are kept in std::map for that reason.
+// lexicographically smallest domain (documented in DESIGN.md) — domains are kept in a std::map ordered by the domain's
+// STRING for that reason (DomainTable below; a hash index beside it answers the per-candidate lookups of the hostname
+// fast paths, where a group holds one domain per NodeClaim).
 #pragma once
+#include <unordered_set>
+
 #include "model.hpp"
 
 namespace oracle {
@@ -14,11 +18,11 @@ enum class TopologyType { Spread = 0, PodAffinity = 1, PodAntiAffinity = 2 };
 // TopologyNodeFilter — topologynodefilter.go:31-96
 struct TopologyNodeFilter {
   std::vector<Requirements> requirements;
-  std::string taint_policy, affinity_policy;  // "" for the zero value used by (anti-)affinity groups
+  Sym taint_policy = W().empty, affinity_policy = W().empty;  // "" for the zero value used by (anti-)affinity groups
   std::vector<Toleration> tolerations;
 
   // MakeTopologyNodeFilter — topologynodefilter.go:38-65
-  static TopologyNodeFilter make(const Pod& p, const std::string& taint_policy, const std::string& affinity_policy) {
+  static TopologyNodeFilter make(const Pod& p, Sym taint_policy, Sym affinity_policy) {
     TopologyNodeFilter f;
     f.taint_policy = taint_policy;
     f.affinity_policy = affinity_policy;
@@ -35,27 +39,27 @@ struct TopologyNodeFilter {
   }
   // matchesRequirements — topologynodefilter.go:84-96 (note: Matches does NOT forward compatibility options, :71)
   bool matches_requirements(const Requirements& reqs) const {
-    if (requirements.empty() || affinity_policy == "Ignore") return true;
+    if (requirements.empty() || affinity_policy == W().Ignore) return true;
     for (auto& r : requirements) if (reqs.compatible(r, false)) return true;
     return false;
   }
   // Matches — topologynodefilter.go:68-79
   bool matches(const std::vector<Taint>& taints, const Requirements& reqs) const {
     bool a = true, t = true;
-    if (affinity_policy == "Honor") a = matches_requirements(reqs);
-    if (taint_policy == "Honor") t = taints_tolerated(taints, tolerations);
+    if (affinity_policy == W().Honor) a = matches_requirements(reqs);
+    if (taint_policy == W().Honor) t = taints_tolerated(taints, tolerations);
     return a && t;
   }
   // What hashstructure sees of this struct (topologygroup.go:188-205): unexported Requirement fields
   // (complement/values/gte/lte) are skipped by the hasher, so only (key, minValues) per requirement contribute;
   // slices are hashed as sets. Two filters that differ only in selector VALUES therefore share one group.
-  typedef std::set<std::set<std::pair<std::string, int>>> ReqView;
-  typedef std::set<std::tuple<std::string, std::string, std::string, std::string>> TolView;
-  std::tuple<ReqView, std::string, std::string, TolView> hash_view() const {
+  typedef std::set<std::set<std::pair<Sym, int>>> ReqView;
+  typedef std::set<std::tuple<Sym, Sym, Sym, Sym>> TolView;
+  std::tuple<ReqView, Sym, Sym, TolView> hash_view() const {
     ReqView rv;
     for (auto& r : requirements) {
-      std::set<std::pair<std::string, int>> one;
-      for (auto& kv : r.m) one.insert({kv.first, kv.second.min_values ? *kv.second.min_values : -1});
+      std::set<std::pair<Sym, int>> one;
+      for (auto& q : r.m) one.insert({q.key, q.min_values ? *q.min_values : -1});
       rv.insert(one);
     }
     TolView tv;
@@ -66,143 +70,165 @@ struct TopologyNodeFilter {
 
 // TopologyDomainGroup — topologydomaingroup.go:28-72
 struct TopologyDomainGroup {
-  std::map<std::string, std::vector<std::vector<Taint>>> d;
-  void insert(const std::string& domain, const std::vector<Taint>& taints) {
+  std::map<Sym, std::vector<std::vector<Taint>>> d;
+  void insert(Sym domain, const std::vector<Taint>& taints) {
     auto it = d.find(domain);
     if (it == d.end() || taints.empty()) { d[domain] = {taints}; return; }
     if (it->second[0].empty()) return;
     it->second.push_back(taints);
   }
   template <class F>
-  void for_each_domain(const Pod& p, const std::string& taint_policy, F f) const {
+  void for_each_domain(const Pod& p, Sym taint_policy, F f) const {
     for (auto& kv : d) {
-      if (taint_policy == "Ignore") { f(kv.first); continue; }
+      if (taint_policy == W().Ignore) { f(kv.first); continue; }
       for (auto& taints : kv.second) if (taints_tolerated(taints, p.tolerations)) { f(kv.first); break; }
     }
   }
 };
 
+// domains map[string]int32 + emptyDomains sets.Set[string] (topologygroup.go:68-70). `count` is the map; `names` holds its
+// keys ordered by the domain's string (the canonical tie order — walked wherever the reference ranges over the map).
+struct DomainTable {
+  std::unordered_map<Sym, int> count;
+  std::set<Sym, SymLexLess> names;
+  std::set<Sym, SymLexLess> empty;   // emptyDomains
+  size_t size() const { return count.size(); }
+  bool has(Sym d) const { return count.count(d) != 0; }
+  const int* find(Sym d) const { auto it = count.find(d); return it == count.end() ? nullptr : &it->second; }
+  int of(Sym d) const { auto it = count.find(d); return it == count.end() ? 0 : it->second; }
+  void put_zero(Sym d) { if (count.emplace(d, 0).second) names.insert(d); else count[d] = 0; empty.insert(d); }
+  bool is_empty_domain(Sym d) const { const int* c = find(d); return c && *c == 0 && empty.count(d); }
+};
+
 // TopologyGroup — topologygroup.go:55-126
 struct TopologyGroup {
-  std::string key;
+  Sym key = kNoSym;
   TopologyType type = TopologyType::Spread;
   int max_skew = 0;
   std::optional<int> min_domains;
-  std::set<std::string> namespaces;
+  SymSet namespaces;
   LabelSelector selector;
   TopologyNodeFilter node_filter;
-  std::set<std::string> owners;
-  std::map<std::string, int> domains;
-  std::set<std::string> empty_domains;
+  std::unordered_set<Sym> owners;
+  DomainTable domains;
 
-  static TopologyGroup make(TopologyType type, const std::string& key, const Pod& pod, const std::set<std::string>& namespaces,
+  static TopologyGroup make(TopologyType type, Sym key, const Pod& pod, const SymSet& namespaces,
                             const LabelSelector& sel, int max_skew, std::optional<int> min_domains,
-                            const std::optional<std::string>& taint_policy, const std::optional<std::string>& affinity_policy,
+                            const std::optional<Sym>& taint_policy, const std::optional<Sym>& affinity_policy,
                             const TopologyDomainGroup& dg) {
     TopologyGroup g;
     g.type = type; g.key = key; g.namespaces = namespaces; g.selector = sel; g.max_skew = max_skew; g.min_domains = min_domains;
     if (type == TopologyType::Spread) {
-      std::string tp = taint_policy ? *taint_policy : "Ignore";
-      std::string ap = affinity_policy ? *affinity_policy : "Honor";
+      Sym tp = taint_policy ? *taint_policy : W().Ignore;
+      Sym ap = affinity_policy ? *affinity_policy : W().Honor;
       g.node_filter = TopologyNodeFilter::make(pod, tp, ap);
     }
-    dg.for_each_domain(pod, g.node_filter.taint_policy, [&](const std::string& dom) { g.domains[dom] = 0; g.empty_domains.insert(dom); });
+    dg.for_each_domain(pod, g.node_filter.taint_policy, [&](Sym dom) { g.domains.put_zero(dom); });
     return g;
   }
   // Hash() equivalence (topologygroup.go:188-222): same fields the hasher sees; minDomains is NOT hashed.
-  typedef std::tuple<bool, std::map<std::string, std::string>, std::set<SelectorExpr>> SelView;
-  auto identity() const {
-    SelView sv{selector.is_nil, selector.match_labels, std::set<SelectorExpr>(selector.match_expressions.begin(), selector.match_expressions.end())};
-    return std::make_tuple(key, (int)type, namespaces, max_skew, node_filter.hash_view(), sv);
+  bool same_identity(const TopologyGroup& o) const {
+    return key == o.key && type == o.type && namespaces == o.namespaces && max_skew == o.max_skew &&
+           selector.same_as(o.selector) && node_filter.hash_view() == o.node_filter.hash_view();
   }
   bool selects(const Pod& p) const { return namespaces.count(p.ns) && selector.matches(p.labels); }  // :442
   bool counts(const Pod& p, const std::vector<Taint>& taints, const Requirements& reqs) const {      // :152
     return selects(p) && node_filter.matches(taints, reqs);
   }
-  void record(const std::string& dom) { domains[dom]++; empty_domains.erase(dom); }                 // :143
-  void reg(const std::string& dom) { if (!domains.count(dom)) { domains[dom] = 0; empty_domains.insert(dom); } }  // :157
-  void unreg(const std::string& dom) { domains.erase(dom); empty_domains.erase(dom); }              // :166
+  void record(Sym dom) {                                                                            // :143
+    auto r = domains.count.emplace(dom, 0);
+    if (r.second) domains.names.insert(dom);
+    if (r.first->second++ == 0) domains.empty.erase(dom);   // emptyDomains.Delete: only a domain at zero can be in it
+  }
+  void reg(Sym dom) { if (!domains.has(dom)) domains.put_zero(dom); }                               // :157
+  void unreg(Sym dom) { domains.count.erase(dom); domains.names.erase(dom); domains.empty.erase(dom); }   // :166
 
-  static Requirement dne(const std::string& key) { return Requirement::make(key, Op::DoesNotExist); }
-  int domain_count(const std::string& d) const { auto it = domains.find(d); return it == domains.end() ? 0 : it->second; }
+  static Requirement dne(Sym key) { return Requirement::make(key, Op::DoesNotExist); }
+  int domain_count(Sym d) const { const int* c = domains.find(d); return c ? *c : 0; }
 
   // domainMinCount — topologygroup.go:300-322
   int domain_min_count(const Requirement& pod_domains) const {
-    if (key == kLabelHostname) return 0;
+    if (key == W().hostname) return 0;
     int mn = INT32_MAX, supported = 0;
-    for (auto& kv : domains) if (pod_domains.has(kv.first)) { supported++; if (kv.second < mn) mn = kv.second; }
+    for (Sym d : domains.names) if (pod_domains.has(d)) { supported++; int c = domains.of(d); if (c < mn) mn = c; }
     if (min_domains && supported < *min_domains) mn = 0;
     return mn;
   }
   // nextDomainTopologySpread — topologygroup.go:229-298
-  Requirement next_spread(const Pod& pod, const Requirement& pod_domains, const Requirement& node_domains, std::set<std::string>* valid = nullptr) const {
+  Requirement next_spread(const Pod& pod, const Requirement& pod_domains, const Requirement& node_domains) const {
     int mn = domain_min_count(pod_domains);
     bool self = selects(pod);
-    std::string min_domain;
+    Sym min_domain = kNoSym;
     bool have = false;
     int min_count = INT32_MAX;
-    if (key == kLabelHostname && node_domains.values.size() == 1) {
-      const std::string& host = *node_domains.values.begin();
+    if (key == W().hostname && node_domains.values.size() == 1) {
+      Sym host = *node_domains.values.begin();
       int count = domain_count(host);
       if (self) count++;
-      if (count <= max_skew) { if (valid) valid->insert(host); return Requirement::make(key, Op::In, {host}); }
+      if (count <= max_skew) return Requirement::make(key, Op::In, host);
       return dne(key);
     }
-    auto consider = [&](const std::string& dom, int count) {
+    auto consider = [&](Sym dom, int count) {
       if (self) count++;
       // int32 arithmetic as in the reference: count-min with min==MaxInt32 (no supported domain) stays negative
       if ((long long)count - (long long)mn <= (long long)max_skew) {
-        if (valid) valid->insert(dom);
         if (count < min_count) { min_domain = dom; min_count = count; have = true; }  // first strict minimum in sorted order
       }
     };
     if (node_domains.op() == Op::In) {
-      for (auto& dom : node_domains.values) { auto it = domains.find(dom); if (it != domains.end()) consider(dom, it->second); }
+      // the values in string order, first strict minimum == the minimum by (count, string): no need to sort them first
+      for (Sym dom : node_domains.values) {
+        const int* c = domains.find(dom);
+        if (!c) continue;
+        int count = *c + (self ? 1 : 0);
+        if ((long long)count - (long long)mn > (long long)max_skew) continue;
+        if (!have || count < min_count || (count == min_count && sym_lex_less(dom, min_domain))) { min_domain = dom; min_count = count; have = true; }
+      }
     } else {
-      for (auto& kv : domains) if (node_domains.has(kv.first)) consider(kv.first, kv.second);
+      for (Sym d : domains.names) if (node_domains.has(d)) consider(d, domains.of(d));
     }
-    if (!have || min_domain.empty()) return dne(key);
-    return Requirement::make(key, Op::In, {min_domain});
+    if (!have || min_domain == W().empty) return dne(key);
+    return Requirement::make(key, Op::In, min_domain);
   }
   bool any_compatible_pod_domain(const Requirement& pod_domains) const {  // :393-400
-    for (auto& kv : domains) if (pod_domains.has(kv.first) && kv.second > 0) return true;
+    for (Sym d : domains.names) if (pod_domains.has(d) && domains.of(d) > 0) return true;
     return false;
   }
   // nextDomainAffinity — topologygroup.go:324-388
   Requirement next_affinity(const Pod& pod, const Requirement& pod_domains, const Requirement& node_domains) const {
     Requirement options = dne(key);
-    if (key == kLabelHostname && node_domains.values.size() == 1) {
-      const std::string& host = *node_domains.values.begin();
+    if (key == W().hostname && node_domains.values.size() == 1) {
+      Sym host = *node_domains.values.begin();
       if (!pod_domains.has(host)) return options;
       if (domain_count(host) > 0) { options.values.insert(host); return options; }
-      if (selects(pod) && (domains.size() == empty_domains.size() || !any_compatible_pod_domain(pod_domains))) { options.values.insert(host); return options; }
+      if (selects(pod) && (domains.size() == domains.empty.size() || !any_compatible_pod_domain(pod_domains))) { options.values.insert(host); return options; }
       return options;
     }
     if (node_domains.op() == Op::In) {
-      for (auto& dom : node_domains.values) { auto it = domains.find(dom); if (pod_domains.has(dom) && it != domains.end() && it->second > 0) options.values.insert(dom); }
+      for (Sym dom : node_domains.values) { const int* c = domains.find(dom); if (pod_domains.has(dom) && c && *c > 0) options.values.insert(dom); }
     } else {
-      for (auto& kv : domains) if (pod_domains.has(kv.first) && kv.second > 0 && node_domains.has(kv.first)) options.values.insert(kv.first);
+      for (Sym d : domains.names) if (pod_domains.has(d) && domains.of(d) > 0 && node_domains.has(d)) options.values.insert(d);
     }
     if (options.len() != 0) return options;
-    if (selects(pod) && (domains.size() == empty_domains.size() || !any_compatible_pod_domain(pod_domains))) {
+    if (selects(pod) && (domains.size() == domains.empty.size() || !any_compatible_pod_domain(pod_domains))) {
       Requirement inter = pod_domains.intersection(node_domains);
-      for (auto& kv : domains) if (inter.has(kv.first)) { options.values.insert(kv.first); break; }  // canonical: smallest
-      for (auto& kv : domains) if (pod_domains.has(kv.first)) { options.values.insert(kv.first); break; }
+      for (Sym d : domains.names) if (inter.has(d)) { options.values.insert(d); break; }  // canonical: smallest
+      for (Sym d : domains.names) if (pod_domains.has(d)) { options.values.insert(d); break; }
     }
     return options;
   }
   // nextDomainAntiAffinity — topologygroup.go:404-439
   Requirement next_anti_affinity(const Requirement& pod_domains, const Requirement& node_domains) const {
     Requirement options = dne(key);
-    if (key == kLabelHostname && node_domains.values.size() == 1) {
-      const std::string& host = *node_domains.values.begin();
+    if (key == W().hostname && node_domains.values.size() == 1) {
+      Sym host = *node_domains.values.begin();
       if (domain_count(host) == 0) options.values.insert(host);
       return options;
     }
-    if (node_domains.op() == Op::In && node_domains.len() < (long long)empty_domains.size()) {
-      for (auto& dom : node_domains.values) if (empty_domains.count(dom) && pod_domains.has(dom)) options.values.insert(dom);
+    if (node_domains.op() == Op::In && node_domains.len() < (long long)domains.empty.size()) {
+      for (Sym dom : node_domains.values) if (domains.is_empty_domain(dom) && pod_domains.has(dom)) options.values.insert(dom);
     } else {
-      for (auto& dom : empty_domains) if (node_domains.has(dom) && pod_domains.has(dom)) options.values.insert(dom);
+      for (Sym dom : domains.empty) if (node_domains.has(dom) && pod_domains.has(dom)) options.values.insert(dom);
     }
     return options;
   }
@@ -218,77 +244,81 @@ struct TopologyGroup {
 
 struct Topology {
   bool ignore_preferences = false;
-  // insertion-ordered; identity() stands in for Hash() (topology.go:181-191)
+  // insertion-ordered; same_identity() stands in for Hash() (topology.go:181-191)
   std::vector<TopologyGroup> groups, inverse_groups;
-  std::map<std::string, TopologyDomainGroup> domain_groups;
-  std::set<std::string> excluded_pods;
+  // which of `groups` hold a pod as an owner (ascending positions): getMatchingTopologies (topology.go:561-574) walks every
+  // group and asks owners.Has(uid); this index answers the same question for all groups at once. Kept in step with `owners`.
+  std::unordered_map<Sym, std::vector<int>> owned;
+  std::map<Sym, TopologyDomainGroup> domain_groups;
+  std::unordered_set<Sym> excluded_pods;
   const Problem* problem = nullptr;
   std::vector<const StateNode*> state_nodes;
+  std::unordered_map<Sym, const StateNode*> node_by_name;
 
   // buildDomainGroups — topology.go:105-146
-  static std::map<std::string, TopologyDomainGroup> build_domain_groups(const Problem& pr, const std::vector<const NodePool*>& pools) {
-    std::map<std::string, TopologyDomainGroup> dg;
+  static std::map<Sym, TopologyDomainGroup> build_domain_groups(const Problem& pr, const std::vector<const NodePool*>& pools) {
+    std::map<Sym, TopologyDomainGroup> dg;
     for (auto* np : pools) {
       for (int idx : np->instance_types) {
         const InstanceType& it = pr.catalog[idx];
         Requirements r = exprs_to_requirements(np->requirements);
         r.add_all(label_requirements(np->labels));
         r.add_all(it.reqs);
-        for (auto& kv : r.m) for (auto& dom : kv.second.values) dg[kv.first].insert(dom, np->taints);
+        for (auto& q : r.m) for (Sym dom : q.values) dg[q.key].insert(dom, np->taints);
       }
       Requirements r = exprs_to_requirements(np->requirements);
       r.add_all(label_requirements(np->labels));
-      for (auto& kv : r.m) if (kv.second.op() == Op::In) for (auto& v : kv.second.values) dg[kv.first].insert(v, np->taints);
+      for (auto& q : r.m) if (q.op() == Op::In) for (Sym v : q.values) dg[q.key].insert(v, np->taints);
     }
     return dg;
   }
-  const TopologyDomainGroup& dgroup(const std::string& key) { return domain_groups[key]; }
+  const TopologyDomainGroup& dgroup(Sym key) { return domain_groups[key]; }
 
   // buildNamespaceList — topology.go:536-557: the pod's namespace when the term names none; otherwise the listed
   // namespaces plus those whose labels the namespaceSelector matches (the problem's `namespaces` stand in for the lister)
-  std::set<std::string> namespace_list(const std::string& ns, const PodAffinityTerm& term) const {
-    if (term.namespaces.empty() && term.namespace_selector.is_nil) return {ns};
-    std::set<std::string> out(term.namespaces.begin(), term.namespaces.end());
+  SymSet namespace_list(Sym ns, const PodAffinityTerm& term) const {
+    if (term.namespaces.empty() && term.namespace_selector.is_nil) return SymSet{ns};
+    SymSet out;
+    out.insert(term.namespaces.begin(), term.namespaces.end());
     if (!term.namespace_selector.is_nil && problem) for (auto& n : problem->namespaces) if (term.namespace_selector.matches(n.second)) out.insert(n.first);
     return out;
   }
   // updateInverseAntiAffinity — topology.go:329-355
-  void update_inverse_anti_affinity(const Pod& pod, const std::map<std::string, std::string>* node_labels) {
+  void update_inverse_anti_affinity(const Pod& pod, const SymMap* node_labels) {
     for (auto& term : pod.anti_required) {
       TopologyGroup tg = TopologyGroup::make(TopologyType::PodAntiAffinity, term.topology_key, pod, namespace_list(pod.ns, term),
                                              term.selector, INT32_MAX, std::nullopt, std::nullopt, std::nullopt, dgroup(term.topology_key));
-      auto id = tg.identity();
       TopologyGroup* g = nullptr;
-      for (auto& e : inverse_groups) if (e.identity() == id) { g = &e; break; }
+      for (auto& e : inverse_groups) if (e.same_identity(tg)) { g = &e; break; }
       if (!g) { inverse_groups.push_back(tg); g = &inverse_groups.back(); }
-      if (node_labels) { auto it = node_labels->find(g->key); if (it != node_labels->end()) g->record(it->second); }
-      g->owners.insert(pod.uid);
+      if (node_labels) { auto* it = node_labels->find(g->key); if (it) g->record(it->second); }
+      g->owners.insert(pod.uid_s);
     }
   }
-  const StateNode* find_node(const std::string& name) const {
-    for (auto* n : state_nodes) if (n->name == name) return n;   // the nodes of this simulation
-    return nullptr;
+  const StateNode* find_node(Sym name) const {
+    auto it = node_by_name.find(name);   // the nodes of this simulation
+    return it == node_by_name.end() ? nullptr : it->second;
   }
   // countDomains — topology.go:361-459 (kube reads replaced by the problem's clusterPods / stateNodes)
   void count_domains(TopologyGroup& tg) {
     for (auto* n : state_nodes) {
       if (!n->has_node) continue;
       if (!tg.node_filter.matches(n->taints, label_requirements(n->labels))) continue;
-      auto it = n->labels.find(tg.key);
-      if (it == n->labels.end()) continue;
+      auto* it = n->labels.find(tg.key);
+      if (!it) continue;
       tg.reg(it->second);
     }
     for (auto& p : problem->cluster_pods) {
       if (!tg.namespaces.count(p.ns)) continue;
       if (!tg.selector.is_nil && !tg.selector.matches(p.labels)) continue;  // TopologyListOptions: nil selector lists everything
-      if (p.node_name.empty() || p.phase == "Failed" || p.phase == "Succeeded") continue;  // IgnoredForTopology :614
-      if (excluded_pods.count(p.uid)) continue;
+      if (p.node_name == W().empty || p.phase == W().Failed || p.phase == W().Succeeded) continue;  // IgnoredForTopology :614
+      if (excluded_pods.count(p.uid_s)) continue;
       const StateNode* node = find_node(p.node_name);
       if (!node) continue;
-      std::string dom;
-      auto it = node->labels.find(tg.key);
-      if (it != node->labels.end()) dom = it->second;
-      else if (tg.key == kLabelHostname) dom = node->name;
+      Sym dom;
+      auto* it = node->labels.find(tg.key);
+      if (it) dom = it->second;
+      else if (tg.key == W().hostname) dom = node->name_s;
       else continue;
       if (!tg.node_filter.matches(node->taints, label_requirements(node->labels))) continue;
       tg.record(dom);
@@ -298,12 +328,17 @@ struct Topology {
   std::vector<TopologyGroup> new_for_topologies(Pod& p) {
     std::vector<TopologyGroup> out;
     for (auto& tsc : p.tscs) {
-      if (ignore_preferences && tsc.when_unsatisfiable != "DoNotSchedule") continue;
-      for (auto& k : tsc.match_label_keys) {
-        auto it = p.labels.find(k);
-        if (it != p.labels.end()) { tsc.selector.is_nil = false; tsc.selector.match_expressions.push_back({k, "In", {it->second}}); }
+      if (ignore_preferences && tsc.when_unsatisfiable != W().DoNotSchedule) continue;
+      for (Sym k : tsc.match_label_keys) {
+        auto* it = p.labels.find(k);
+        if (it) {
+          tsc.selector.is_nil = false;
+          SelectorExpr x;
+          x.key = k; x.op = SelOp::In; x.op_text = sym("In"); x.values.insert(it->second);
+          tsc.selector.match_expressions.push_back(x);
+        }
       }
-      out.push_back(TopologyGroup::make(TopologyType::Spread, tsc.topology_key, p, {p.ns}, tsc.selector, tsc.max_skew, tsc.min_domains,
+      out.push_back(TopologyGroup::make(TopologyType::Spread, tsc.topology_key, p, SymSet{p.ns}, tsc.selector, tsc.max_skew, tsc.min_domains,
                                         tsc.node_taints_policy, tsc.node_affinity_policy, dgroup(tsc.topology_key)));
     }
     return out;
@@ -327,18 +362,21 @@ struct Topology {
   }
   // Update — topology.go:162-194
   void update(Pod& p) {
-    for (auto& g : groups) g.owners.erase(p.uid);
+    auto ow = owned.find(p.uid_s);   // for _, tg := range t.topologyGroups { tg.RemoveOwner(p.UID) }: only these hold it
+    if (ow != owned.end()) { for (int gi : ow->second) groups[gi].owners.erase(p.uid_s); owned.erase(ow); }
     bool any_anti = p.has_pod_anti_affinity && (!p.anti_required.empty() || !p.anti_preferred.empty());
     bool req_anti = any_anti && !p.anti_required.empty();
     if ((ignore_preferences && req_anti) || (!ignore_preferences && any_anti)) update_inverse_anti_affinity(p, nullptr);
     std::vector<TopologyGroup> tgs = new_for_topologies(p);
     for (auto& g : new_for_affinities(p)) tgs.push_back(g);
     for (auto& tg : tgs) {
-      auto id = tg.identity();
-      TopologyGroup* g = nullptr;
-      for (auto& e : groups) if (e.identity() == id) { g = &e; break; }
-      if (!g) { count_domains(tg); groups.push_back(tg); g = &groups.back(); }
-      g->owners.insert(p.uid);
+      int gi = -1;
+      for (size_t i = 0; i < groups.size(); ++i) if (groups[i].same_identity(tg)) { gi = (int)i; break; }
+      if (gi < 0) { count_domains(tg); groups.push_back(tg); gi = (int)groups.size() - 1; }
+      if (groups[gi].owners.insert(p.uid_s).second) {
+        std::vector<int>& l = owned[p.uid_s];
+        l.insert(std::upper_bound(l.begin(), l.end(), gi), gi);
+      }
     }
   }
   // NewTopology — topology.go:68-103
@@ -346,12 +384,13 @@ struct Topology {
     problem = &pr;
     ignore_preferences = ignore_prefs;
     state_nodes = snodes;
+    for (auto* n : snodes) node_by_name.emplace(n->name_s, n);   // first of equal names, as the linear search found
     domain_groups = build_domain_groups(pr, pools);
-    for (auto& p : pods) excluded_pods.insert(p.uid);
+    for (auto& p : pods) excluded_pods.insert(p.uid_s);
     // updateInverseAffinities — topology.go:310-324 : bound pods with required anti-affinity
     for (auto& cp : pr.cluster_pods) {
       if (!(cp.has_pod_anti_affinity && !cp.anti_required.empty())) continue;
-      if (excluded_pods.count(cp.uid)) continue;
+      if (excluded_pods.count(cp.uid_s)) continue;
       const StateNode* node = find_node(cp.node_name);
       if (!node) continue;
       update_inverse_anti_affinity(cp, &node->labels);
@@ -359,24 +398,32 @@ struct Topology {
     for (auto& p : pods) update(p);
   }
   // Register / Unregister — topology.go:284-308
-  void reg(const std::string& key, const std::string& dom) {
+  void reg(Sym key, Sym dom) {
     for (auto& g : groups) if (g.key == key) g.reg(dom);
     for (auto& g : inverse_groups) if (g.key == key) g.reg(dom);
   }
-  // AddRequirements — topology.go:226-250 ; returns false when some matching topology has no valid domain
+  // AddRequirements — topology.go:226-250 ; returns false when some matching topology has no valid domain. `out` is built
+  // only once every matching topology has produced a domain (the reference copies nodeRequirements first, :227, and returns
+  // an error before anyone reads the copy; node_domains is read from nodeRequirements, never from the copy).
   bool add_requirements(const Pod& p, const std::vector<Taint>& taints, const Requirements& pod_reqs, const Requirements& node_reqs, Requirements& out) const {
-    out = node_reqs;
+    Requirement adds_inl[4];
+    std::vector<Requirement> adds_more;
+    size_t n_adds = 0;
     auto apply = [&](const TopologyGroup& tg) {
-      Requirement pod_domains = pod_reqs.has(tg.key) ? pod_reqs.get(tg.key) : Requirement::make(tg.key, Op::Exists);
-      Requirement node_domains = node_reqs.has(tg.key) ? node_reqs.get(tg.key) : Requirement::make(tg.key, Op::Exists);
-      Requirement d = tg.get(p, pod_domains, node_domains);
+      const Requirement* pr_ = pod_reqs.find(tg.key);
+      const Requirement* nr_ = node_reqs.find(tg.key);
+      Requirement d = tg.get(p, pr_ ? *pr_ : Requirement::make(tg.key, Op::Exists), nr_ ? *nr_ : Requirement::make(tg.key, Op::Exists));
       if (d.len() == 0) return false;
-      out.add(d);
+      if (n_adds < 4) adds_inl[n_adds] = std::move(d); else adds_more.push_back(std::move(d));
+      n_adds++;
       return true;
     };
     // getMatchingTopologies — topology.go:561-574
-    for (auto& tg : groups) if (tg.owners.count(p.uid)) if (!apply(tg)) return false;
+    auto ow = owned.find(p.uid_s);
+    if (ow != owned.end()) for (int gi : ow->second) if (!apply(groups[gi])) return false;
     for (auto& tg : inverse_groups) if (tg.counts(p, taints, node_reqs)) if (!apply(tg)) return false;
+    out = node_reqs;
+    for (size_t i = 0; i < n_adds; ++i) out.add(i < 4 ? adds_inl[i] : adds_more[i - 4]);
     return true;
   }
   // Record — topology.go:197-220
@@ -384,11 +431,11 @@ struct Topology {
     for (auto& tg : groups) {
       if (tg.counts(p, taints, reqs)) {
         Requirement domains = reqs.get(tg.key);
-        if (tg.type == TopologyType::PodAntiAffinity) { for (auto& v : domains.values) tg.record(v); }
+        if (tg.type == TopologyType::PodAntiAffinity) { for (Sym v : domains.values) tg.record(v); }
         else if (domains.len() == 1) tg.record(*domains.values.begin());
       }
     }
-    for (auto& tg : inverse_groups) if (tg.owners.count(p.uid)) { Requirement d = reqs.get(tg.key); for (auto& v : d.values) tg.record(v); }
+    for (auto& tg : inverse_groups) if (tg.owners.count(p.uid_s)) { Requirement d = reqs.get(tg.key); for (Sym v : d.values) tg.record(v); }
   }
 };
 
