@@ -125,18 +125,17 @@ def config4_sweep(args, device_index, rank, world):
         base = dz.compact_problem(cc, pod_groups=[])
         probes = [{"removeNodes": [cc["nodes"][mine[j]]["name"]], "pods": dz.compact_node_pods(cc, mine[j])} for j in sample]
         threads = min(len(probes), os.cpu_count() or 1)
-        t = time.perf_counter(); res = oracle.sweep(base, probes, threads=threads); osec = time.perf_counter() - t
+        t = time.perf_counter(); res = oracle.sweep(base, probes, threads=threads, verdicts=True); osec = time.perf_counter() - t
         bad = []
         for j, r, pr in zip(sample, res, probes):
-            want = dz.decide(cc, [dict(cc["nodes"][mine[j]], pods=pr["pods"])], dz._finish_simulation(cc, r, set()))
-            got = cmds[j]
-            if (got["decision"], got["replacement"], got.get("replacementCapacityType")) != (want["decision"], want["replacement"], want.get("replacementCapacityType")) \
+            got = cmds[j]      # judged by the oracle's own computeConsolidation (oracle/consolidation.hpp), not by karpenter_amd.disruption
+            if (got["decision"], got["replacement"], got.get("replacementCapacityType")) != oracle.verdict_key(r["verdict"]) \
                     or rc.last_sweep["referenceBinEvaluations"][j] != r["counters"]["binEvaluations"]:
                 bad.append(cc["nodes"][mine[j]]["name"])
         if bad:
             raise SystemExit(f"bench.py: configs[4] probes differ from the oracle's simulation: {bad[:5]}")
         out["oracle_check"] = {"probes": len(sample), "by_decision": dict(Counter(cmds[j]["decision"] for j in sample)), "all_identical": True,
-                               "compared": "decision, replacement instance types, capacity type, reference-equivalent evaluation count"}
+                               "compared": "decision, replacement instance types, capacity type (all three from oracle/consolidation.hpp's restatement of computeConsolidation on the oracle's own Results), reference-equivalent evaluation count"}
         out["cpu_baseline"] = {"value": len(sample) / osec, "unit": "probes/s", "cores": threads, "kind": "port",
                                "sample": f"{len(sample)} of the swept probes, each a fresh oracle Scheduler over the {args.sweep_nodes}-node cluster (what the reference does per simulation), {threads} at a time", "seconds": osec}
     if args.sweep_windows > 0:
@@ -194,16 +193,13 @@ def config4_multi_node(args, cc, rc, rank, world):
             probes.append({"removeNodes": [cc["nodes"][i]["name"] for i in idx], "pods": [p for ps in pods for p in ps]})
             cand_sets.append([dict(cc["nodes"][i], pods=ps) for i, ps in zip(idx, pods)])
         threads = min(len(probes), os.cpu_count() or 1)
-        t = time.perf_counter(); res = oracle.sweep(base, probes, threads=threads); osec = time.perf_counter() - t
+        t = time.perf_counter(); res = oracle.sweep(base, probes, threads=threads, verdicts=True, multi_node=True); osec = time.perf_counter() - t
         pos = {kk: j for j, kk in enumerate(key)}
         for kk, r, cs in zip(picks, res, cand_sets):
-            want = dz.decide(cc, cs, dz._finish_simulation(cc, r, set()))
-            if want["decision"] == dz.REPLACE and not dz.filter_out_same_instance_type(cc, cs, want):
-                want = {"decision": dz.NOOP, "replacement": None}
             got = by[kk]
-            if (got["decision"], got["replacement"]) != (want["decision"], want.get("replacement")) or rc.last_sweep["referenceBinEvaluations"][pos[kk]] != r["counters"]["binEvaluations"]:
+            if (got["decision"], got["replacement"], got.get("replacementCapacityType")) != oracle.verdict_key(r["verdict"]) or rc.last_sweep["referenceBinEvaluations"][pos[kk]] != r["counters"]["binEvaluations"]:
                 raise SystemExit(f"bench.py: configs[4] multi-node probe (window {kk[0]}, {kk[1]} nodes) differs from the oracle's simulation")
-        out["oracle_check"] = {"probes": len(picks), "prefix_sizes": [k for _, k in picks], "all_identical": True, "compared": "decision, replacement instance types after filterOutSameInstanceType, reference-equivalent evaluation count"}
+        out["oracle_check"] = {"probes": len(picks), "prefix_sizes": [k for _, k in picks], "all_identical": True, "compared": "decision, replacement instance types after filterOutSameInstanceType, capacity type (the oracle's own restatement of the multi-node step), reference-equivalent evaluation count"}
         out["cpu_baseline"] = {"value": len(picks) / osec, "unit": "probes/s", "cores": threads, "kind": "port", "seconds": osec,
                                "sample": f"{len(picks)} of the swept prefixes ({sum(len(p['pods']) for p in probes)} displaced pods), each a fresh oracle Scheduler over the cluster, {threads} at a time"}
     return out

@@ -710,6 +710,12 @@ def filter_out_same_instance_type(cluster, candidates, cmd):
         existing[n] = min(existing.get(n, math.inf), candidate_price(cluster, c))
     max_price = min([existing[n] for n in cmd["replacement"] if n in existing], default=math.inf)
     reqs = {r["key"]: r for r in cmd["results"]["newNodeClaims"][0]["requirements"]}
+    if cmd.get("replacementCapacityType") == "spot":
+        # the Replacement IS the NodeClaim computeConsolidation narrowed (types.go:224-226 wraps the pointer): when it pinned the
+        # claim to spot (consolidation.go:238-243, :272) this filter prices every option by its spot offerings — a type without
+        # one has WorstLaunchPrice MaxFloat64 and never passes the strict '<', even when max_price is MaxFloat64 itself
+        old = reqs.get(fx.CAPACITY_TYPE) or {}
+        reqs[fx.CAPACITY_TYPE] = {"key": fx.CAPACITY_TYPE, "complement": False, "values": ["spot"], "gte": None, "lte": None, "minValues": old.get("minValues")}
     by_name = {t["name"]: t for t in cluster["instanceTypes"]}
     cmd["replacement"] = [n for n in cmd["replacement"] if worst_launch_price(by_name[n], reqs) < max_price]
     # RemoveInstanceTypeOptionsByPriceAndMinValues (nodeclaim.go:411-420): what survives the price filter must still meet minValues

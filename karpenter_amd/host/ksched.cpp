@@ -2102,12 +2102,15 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
           if (spot_to_spot) { decision = 3; }
         } else {
           // Offerings.Available().WorstLaunchPrice(reqs) (types.go:587-598): reserved, then spot, then on-demand
+          // pin_spot: the claim's requirements after consolidation.go:238-243 narrowed capacity-type to In [spot]
+          bool pin_spot = false;
           auto worst = [&](int it) {
             for (int q = 0; q < 3; ++q) {
               if (ct_order[q] < 0) continue;
               double mx = -1; bool any = false;
               for (auto& o : B->it_offerings[it]) {
                 if (!o.available || o.ct != ct_order[q] || !has(kd.key_zone, o.zone) || !has(kd.key_ct, o.ct)) continue;
+                if (pin_spot && o.ct != ct_order[1]) continue;
                 if (o.rid >= 0 && !has(B->k_rid, o.rid)) continue;
                 if (!any || o.price > mx) mx = o.price;
                 any = true;
@@ -2151,6 +2154,10 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
             }
             double max_price = 1.0 / 0.0;
             for (int it : cheaper) { auto f = existing.find(it); if (f != existing.end() && f->second < max_price) max_price = f->second; }
+            // the Replacement wraps the NodeClaim computeConsolidation just narrowed (disruption/types.go:224-226): when it was
+            // pinned to spot, the options are priced by their spot offerings here — one without any has WorstLaunchPrice
+            // MaxFloat64 and fails the strict '<' even against a MaxFloat64 ceiling (found by oracle/consolidation.hpp, round 4)
+            pin_spot = !ct_defined || (spot_ok && od_ok);
             std::vector<int> kept;
             for (int it : cheaper) if (worst(it) < max_price) kept.push_back(it);
             cheaper.swap(kept);

@@ -218,6 +218,7 @@ struct Options {
   bool enforce_consolidate_after = false;    // IsConsolidationSimulation (scheduler.go:123)
   long long max_steps = -1;                  // stand-in for the ctx deadline (scheduler.go:477): stop after N pops
   int truncate_instance_types = 0;           // > 0: Results.TruncateInstanceTypes(n) after Solve (scheduler.go:419-437)
+  bool spot_to_spot_consolidation = false;   // FeatureGates.SpotToSpotConsolidation (consolidation.go:264), read by consolidation.hpp only
 };
 
 struct Problem {
@@ -404,6 +405,7 @@ inline Problem parse_problem(const oj::Value& root) {
   pr.opts.enforce_consolidate_after = o.at("consolidationSimulation").boolean_or(false);
   pr.opts.max_steps = o.at("maxSteps").i(-1);
   pr.opts.truncate_instance_types = (int)o.at("truncateInstanceTypes").i(0);
+  pr.opts.spot_to_spot_consolidation = o.at("spotToSpotConsolidation").boolean_or(false);
 
   std::map<std::string, int> it_index;
   int ci = 0;

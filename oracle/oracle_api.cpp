@@ -10,7 +10,7 @@
 #include <thread>
 #include <cstring>
 
-#include "scheduler.hpp"
+#include "consolidation.hpp"
 
 using namespace oracle;
 
@@ -84,7 +84,8 @@ extern "C" {
 void oracle_free(char* p) { free(p); }
 
 // Full Solve(): problem JSON -> results JSON.
-static oj::Value solve_doc(const Problem& pr, const std::vector<Pod>* probe_pods = nullptr, const std::vector<char>* removed = nullptr);
+struct ProbeVerdict { bool want = false, multi_node = false; const std::vector<size_t>* candidates = nullptr; };   // candidates: state-node positions, in the caller's order
+static oj::Value solve_doc(const Problem& pr, const std::vector<Pod>* probe_pods = nullptr, const std::vector<char>* removed = nullptr, const ProbeVerdict* verdict = nullptr);
 char* oracle_solve_json(const char* problem_json) {
   try {
     oj::Value root = oj::Parser(problem_json).parse();
@@ -100,6 +101,9 @@ char* oracle_solve_json(const char* problem_json) {
 // {"results": [one Results document per probe]}. Every probe is a fresh Scheduler over the cluster without its candidates —
 // what the reference does per simulation; only the parse of the cluster document is shared. The simulations are independent,
 // so `threads` of them run at a time (the reference's own candidate fan-out is parallelizeUntil, scheduler.go:939-961).
+// "verdicts": true adds to every Results document "verdict": the command computeConsolidation derives from that simulation
+// (consolidation.hpp; candidates = removeNodes in the order given) — with "multiNode": true the command of one step of
+// firstNConsolidationOption's search, i.e. a replacement also has to survive filterOutSameInstanceType.
 char* oracle_sweep_json(const char* doc_json) {
   try {
     oj::Value root = oj::Parser(doc_json).parse();
@@ -110,11 +114,14 @@ char* oracle_sweep_json(const char* doc_json) {
     const size_t n = probes.size();
     std::vector<std::vector<Pod>> pods(n);
     std::vector<std::vector<char>> removed(n);
+    std::vector<std::vector<size_t>> cand(n);
+    const bool want_verdicts = root.at("verdicts").boolean_or(false), multi_node = root.at("multiNode").boolean_or(false);
     for (size_t i = 0; i < n; ++i) {
       removed[i].assign(pr.state_nodes.size(), 0);
       for (auto& nn : probes[i].at("removeNodes").items()) {
         auto f = by_name.find(nn.s());
         if (f == by_name.end()) throw std::runtime_error("probe removes an unknown node " + nn.s());
+        if (!removed[i][f->second]) cand[i].push_back(f->second);
         removed[i][f->second] = 1;
       }
       int idx = 0;
@@ -125,7 +132,9 @@ char* oracle_sweep_json(const char* doc_json) {
     const size_t n_threads = std::max<size_t>(1, std::min<size_t>(n, (size_t)root.at("threads").i(1)));
     auto work = [&](size_t t) {
       for (size_t i = t; i < n; i += n_threads) {
-        try { docs[i] = solve_doc(pr, &pods[i], &removed[i]); } catch (const std::exception& e) { errors[i] = e.what(); }
+        ProbeVerdict pv;
+        pv.want = want_verdicts; pv.multi_node = multi_node; pv.candidates = &cand[i];
+        try { docs[i] = solve_doc(pr, &pods[i], &removed[i], &pv); } catch (const std::exception& e) { errors[i] = e.what(); }
       }
     };
     if (n_threads == 1) work(0);
@@ -140,7 +149,7 @@ char* oracle_sweep_json(const char* doc_json) {
   }
 }
 
-static oj::Value solve_doc(const Problem& pr, const std::vector<Pod>* probe_pods, const std::vector<char>* removed) {
+static oj::Value solve_doc(const Problem& pr, const std::vector<Pod>* probe_pods, const std::vector<char>* removed, const ProbeVerdict* verdict) {
   {
     Scheduler s;
     auto t0 = std::chrono::steady_clock::now();
@@ -157,19 +166,7 @@ static oj::Value solve_doc(const Problem& pr, const std::vector<Pod>* probe_pods
     oj::Value claims = oj::Value::array();
     double total_cost = 0;
     // Results.TruncateInstanceTypes — scheduler.go:419-437 ; InstanceTypes.Truncate — types.go:437-449
-    if (pr.opts.truncate_instance_types > 0) {
-      std::vector<NodeClaim*> valid;
-      for (auto* nc : res.new_node_claims) {
-        order_by_price(nc->its, nc->reqs);
-        std::vector<const InstanceType*> cut(nc->its.begin(), nc->its.begin() + std::min<size_t>(nc->its.size(), (size_t)pr.opts.truncate_instance_types));
-        bool ok = true;
-        if (nc->reqs.has_min_values() && !pr.opts.min_values_best_effort) satisfies_min_values(cut, nc->reqs, nullptr, &ok);
-        if (!ok) { for (auto* p : nc->pods) res.pod_errors[p->uid] = {ERR_MIN_VALUES, 128}; continue; }
-        nc->its = cut;
-        valid.push_back(nc);
-      }
-      res.new_node_claims = valid;
-    }
+    if (pr.opts.truncate_instance_types > 0) truncate_instance_types(pr, res, pr.opts.truncate_instance_types);
     for (auto* nc : res.new_node_claims) {
       oj::Value c = oj::Value::object();
       c.set("nodePool", oj::Value::string(nc->tmpl->nodepool_name));
@@ -229,6 +226,27 @@ static oj::Value solve_doc(const Problem& pr, const std::vector<Pod>* probe_pods
     c.set("initSeconds", oj::Value::number(std::chrono::duration<double>(t1 - t0).count()));
     c.set("solveSeconds", oj::Value::number(std::chrono::duration<double>(t2 - t1).count()));
     out.set("counters", c);
+    if (verdict && verdict->want) {
+      // the decision on top of this simulation (consolidation.hpp); computed last: it narrows the NodeClaim it judges
+      mark_uninitialized_nodes(pr, res);
+      std::vector<Candidate> cands;
+      for (size_t e : *verdict->candidates) cands.push_back(make_candidate(pr, pr.state_nodes[e]));
+      Command cmd = verdict->multi_node && cands.size() > 1 ? multi_node_step(pr, cands, s.pods, res) : compute_consolidation(pr, cands, s.pods, res);
+      oj::Value v = oj::Value::object();
+      v.set("decision", oj::Value::string(cmd.decision == Decision::Delete ? "delete" : cmd.decision == Decision::Replace ? "replace" : "no-op"));
+      oj::Value names = oj::Value::array();
+      for (auto* it : cmd.replacement) names.push(oj::Value::string(it->name));
+      v.set("replacement", cmd.decision == Decision::Replace ? names : oj::Value());
+      Requirement ct = cmd.replacement_reqs.get(W().capacity_type);
+      v.set("replacementCapacityTypes", cmd.decision == Decision::Replace && ct.op() == Op::In ? [&] { oj::Value a = oj::Value::array(); for (auto& x : ct.values.strings()) a.push(oj::Value::string(x)); return a; }() : oj::Value());
+      v.set("pinnedToSpot", oj::Value::boolean(cmd.pinned_to_spot));
+      v.set("reason", oj::Value::string(cmd.reason));
+      v.set("allNonPendingPodsScheduled", oj::Value::boolean(all_non_pending_pods_scheduled(s.pods, res)));
+      double price = 0;
+      for (auto& cnd : cands) price += cnd.price;
+      v.set("candidatePrice", oj::Value::number(price));
+      out.set("verdict", v);
+    }
     return out;
   }
 }

@@ -18,6 +18,42 @@ def strip(cmd):
     return {k: cmd.get(k) for k in ("decision", "candidates", "replacement", "replacementCapacityType")}
 
 
+@pytest.fixture(autouse=True)
+def oracle_judges_every_command(monkeypatch, oracle):
+    """Round 4: the consolidation DECISION has its own restatement in the oracle (oracle/consolidation.hpp: computeConsolidation,
+    the price filter, the minValues re-check, the spot-to-spot branch, filterOutSameInstanceType). Every command this module
+    derives with the oracle as the solver — the reference's known answers below included — is computed a second time by
+    that restatement, from the cluster document alone, and must be the same command; so the product's Python (disruption.py)
+    and C++ (ksched_sweep) verdict layers are both held against code that shares no line with them."""
+    real, real_filter = dz.compute_consolidation, dz.filter_out_same_instance_type
+    seen = {"commands": 0}
+
+    def key(cmd):
+        return (cmd["decision"], cmd["replacement"], cmd.get("replacementCapacityType"))
+
+    def checked(cluster, candidates, solver, results=None):
+        cmd = real(cluster, candidates, solver, results=results)
+        if solver is oracle.solve and results is None:
+            v = oracle.cluster_verdicts(cluster, [candidates], well_known=fx.KWOK_WELL_KNOWN)[0]
+            assert key(cmd) == oracle.verdict_key(v), (key(cmd), v)
+            seen["commands"] += 1
+            cmd["_oracle_cluster"] = cluster
+        return cmd
+
+    def checked_filter(cluster, candidates, cmd):
+        before = list(cmd["replacement"])
+        ok = real_filter(cluster, candidates, cmd)
+        if cmd.get("_oracle_cluster") is cluster:      # one step of the multi-node search, judged as a whole by the oracle
+            v = oracle.cluster_verdicts(cluster, [candidates], multi_node=True, well_known=fx.KWOK_WELL_KNOWN)[0]
+            want = (dz.REPLACE, sorted(cmd["replacement"])) if ok else (dz.NOOP, None)
+            assert want == oracle.verdict_key(v)[:2], (want, v, before)
+        return ok
+
+    monkeypatch.setattr(dz, "compute_consolidation", checked)
+    monkeypatch.setattr(dz, "filter_out_same_instance_type", checked_filter)
+    yield seen
+
+
 def test_simulate_scheduling_delete_replace_noop(oracle, emu):
     # consolidation_test.go Delete :2396-, Replace :1005-, "can't remove without creating N candidates"
     its = fx.kwok_catalog(144)
@@ -572,11 +608,12 @@ def test_multi_node_search_as_one_sweep(oracle, emu, seed):
     sets = [cands[:k] for k in range(2, len(cands) + 1)]
     got = rc.decisions(sets, multi_node=True)
     assert [strip(c) for c in rc.decisions(sets, multi_node=True, library_prices=True)] == [strip(c) for c in got]   # prices / capacity types from the library's node table
-    for cs, g in zip(sets, got):
+    for cs, g, v in zip(sets, got, oracle.cluster_verdicts(cluster, sets, multi_node=True, well_known=fx.KWOK_WELL_KNOWN)):
         w = dz.compute_consolidation(cluster, cs, oracle.solve)
         if w["decision"] == dz.REPLACE and not dz.filter_out_same_instance_type(cluster, cs, w):
             w = {"decision": dz.NOOP, "replacement": None}
         assert (g["decision"], g["replacement"]) == (w["decision"], w.get("replacement")), (len(cs), g, strip(w))
+        assert (g["decision"], g["replacement"]) == oracle.verdict_key(v)[:2], (len(cs), g, v)      # the oracle's own decision layer
     rc.close()
 
 
@@ -606,11 +643,10 @@ def test_multi_node_sets_on_a_compact_cluster_fuzz(oracle, emu, seed, topology):
         pods = [dz.compact_node_pods(cc, i) for i in idx]
         probes.append({"removeNodes": [cc["nodes"][i]["name"] for i in idx], "pods": [p for ps in pods for p in ps]})
         cand_sets.append([dict(cc["nodes"][i], pods=ps) for i, ps in zip(idx, pods)])
-    for j, (r, cs) in enumerate(zip(oracle.sweep(base, probes, threads=2), cand_sets)):
-        want = dz.decide(cc, cs, dz._finish_simulation(cc, r, set()))
-        if len(cs) > 1 and want["decision"] == dz.REPLACE and not dz.filter_out_same_instance_type(cc, cs, want):
-            want = {"decision": dz.NOOP, "replacement": None}
-        assert (cmds[j]["decision"], cmds[j]["replacement"]) == (want["decision"], want.get("replacement")), (j, len(cs), cmds[j], want["decision"])
+    # the expectation is the oracle's from end to end: its simulation AND its restatement of computeConsolidation /
+    # filterOutSameInstanceType (oracle/consolidation.hpp) — nothing of karpenter_amd.disruption judges the sweep here
+    for j, (r, cs) in enumerate(zip(oracle.sweep(base, probes, threads=2, verdicts=True, multi_node=True), cand_sets)):
+        assert (cmds[j]["decision"], cmds[j]["replacement"], cmds[j].get("replacementCapacityType")) == oracle.verdict_key(r["verdict"]), (j, len(cs), cmds[j], r["verdict"])
         assert refs[j] == r["counters"]["binEvaluations"], (j, len(cs))
     assert len({c["decision"] for c in cmds}) == 3
     rc.close()
