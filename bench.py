@@ -243,6 +243,8 @@ def main():
     args = ap.parse_args()
     if args.solver_lib and os.environ.get("KSOLVE_BENCH_TEST_HOOK") != "1":
         raise SystemExit("bench.py: --solver-lib is a test hook (set KSOLVE_BENCH_TEST_HOOK=1); the product has no CPU path")
+    if args.solver_lib:
+        os.environ["KSOLVE_TEST_SOLVER_LIB"] = "1"      # the same gate on NewScheduler(solver_lib=) (karpenter_amd/scheduling.py)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -610,6 +612,7 @@ def main():
             # emulation of the device code, tests/emu — a checker, never a product path), same problem, same Results
             try:
                 emu = parity.build_emu()
+                os.environ["KSOLVE_TEST_SOLVER_LIB"] = "1"   # baseline leg only, after every measured solve: the emulation is handed in through the test hook
                 eb = {}
                 for eng in ("general", "cursor"):
                     pe = fx.config2(pods=args.pods, n_types=args.types, seed=42)

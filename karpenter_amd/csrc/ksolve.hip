@@ -497,7 +497,13 @@ static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) {
   const int rw = a.dict.req_words;
   const int nk = a.dict.n_keys;
   // A/B switch for measurements (scripts/gpu_r3_classing.sh): "coop1" = the previous wave-cooperative kernel, "plain" = one thread per row
+#ifdef KSOLVE_TEST_HOOKS
   const char* variant = getenv("KSOLVE_ROWHASH_KERNEL");
+  const bool no_shared_strict = getenv("KSOLVE_TEST_NO_SHARED_STRICT") != nullptr;
+#else
+  const char* variant = nullptr;   // the product binary reads no test / measurement switch (tests/emu/libksolve_hooks.so is the build that does)
+  const bool no_shared_strict = false;
+#endif
   const bool aligned = (((uintptr_t)a.reqs.mask | (uintptr_t)a.strict.mask | (uintptr_t)a.reqs.minv | (uintptr_t)a.strict.minv) & 15) == 0;
   // floor(e / rw) = umulhi(e, magic) for every e < 64 * rw (e * rw < 2^32)
   const uint32_t magic = rw >= 1 ? (uint32_t)((0x100000000ull + (uint64_t)rw - 1) / (uint64_t)rw) : 0;
@@ -506,12 +512,16 @@ static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a) {
   // 64 rows per block. 60 rows (4 idle lanes) would let an eighth block fit the CU's 160 KiB of LDS at configs[1]'s dictionary;
   // measured (profiles/round2/classing_ab3.log): 153 us against 150.5 us — the idle lanes cost what the wavefront buys.
   // one table to stage when the strict requirements ARE the requirements (same device table): half the LDS, half the loads
-  const bool same = a.strict.mask == a.reqs.mask && a.strict.minv == a.reqs.minv && a.strict.defined == a.reqs.defined && !getenv("KSOLVE_TEST_NO_SHARED_STRICT");
+  const bool same = a.strict.mask == a.reqs.mask && a.strict.minv == a.reqs.minv && a.strict.defined == a.reqs.defined && !no_shared_strict;
   auto lds_for = [&](int rpb) { return (size_t)(same ? 1 : 2) * rpb * (size_t)(rw | 1) * 8 + (minv ? (size_t)(same ? 1 : 2) * rpb * (size_t)(nk | 1) * 4 : 0); };
   int rpb = 64;
+#ifdef KSOLVE_TEST_HOOKS
   if (const char* r = getenv("KSOLVE_TEST_ROWS_PER_BLOCK")) { const int v = atoi(r); if (v == 60 || v == 64) rpb = v; }   // A/B switch of tests/tools/gpu_classing_ab.py
+#endif
   size_t lds2 = lds_for(rpb);
+#ifdef KSOLVE_TEST_HOOKS
   if (const char* pad = getenv("KSOLVE_TEST_LDS_PAD")) lds2 += (size_t)atoi(pad);   // occupancy probe of tests/tools/gpu_classing_ab.py: fewer wavefronts per CU
+#endif
   const size_t lds1 = (size_t)2 * 64 * (size_t)(rw | 1) * 8 + (size_t)2 * 64 * (size_t)(nk | 1) * 4 + 8 + (size_t)64 * (size_t)(a.n_res + 1) * 8;
   const bool plain = variant && !strcmp(variant, "plain");
   const bool coop1 = variant && !strcmp(variant, "coop1");

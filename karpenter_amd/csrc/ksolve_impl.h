@@ -412,7 +412,9 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   while (ts < 2 * d->n_pod_rows) ts <<= 1;
   R.table_size = ts; R.seed = 0x6b73703176310a01ull;
   R.hash_keep = ~0ull;
+#ifdef KSOLVE_TEST_HOOKS   // only the test builds of the library (tests/emu/) read test switches; the product binary has none
   if (const char* keep = getenv("KSOLVE_TEST_HASH_KEEP")) R.hash_keep = strtoull(keep, nullptr, 0);   // collision-detection test: distinct rows forced onto one hash must be reported, never merged
+#endif
   R.table_hash = dz<uint64_t>(h, ts); R.table_rep = dz<uint32_t>(h, ts); R.table_class = dz<uint32_t>(h, ts);
   R.row_slot = dz<uint32_t>(h, d->n_pod_rows);
   uint32_t* row_class = dz<uint32_t>(h, d->n_pod_rows);
@@ -744,7 +746,9 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
   h->engine_used = 1;
   if (fresh_context) {
     be_fill(h, h->d_cancel, 0, 4);
+#ifdef KSOLVE_TEST_HOOKS
     if (const char* at = getenv("KSOLVE_TEST_CANCEL_AT")) { const int v = -atoi(at); if (v < 0) be_h2d(h, h->d_cancel, &v, 4); }   // deterministic cancellation for the tests
+#endif
     be_sync(h);
   }
   // ---- phase 1: instance-type requirement index ----
@@ -1551,7 +1555,9 @@ static void solve_probes(ksolve_handle** hs, uint32_t n, ksolve_results* outs, k
     cancel[i] = h->d_cancel;
     if (fresh_context) {
       be_fill(h, h->d_cancel, 0, 4);
+#ifdef KSOLVE_TEST_HOOKS
       if (const char* at = getenv("KSOLVE_TEST_CANCEL_AT")) { const int v = -atoi(at); if (v < 0) be_h2d(h, h->d_cancel, &v, 4); }
+#endif
       be_sync(h);
     }
   }

@@ -99,6 +99,10 @@ class Scheduler:
 
     def __init__(self, problem: dict, solver_lib: str | None = None):
         self.problem = problem
+        # solver_lib is a TEST HOOK (the host emulation of the engine, the gfx950 build with test switches): the product loads its own
+        # libksolve.so and nothing else; the tests' conftest.py opens the gate
+        if solver_lib and os.environ.get("KSOLVE_TEST_SOLVER_LIB") != "1":
+            raise SolverUnavailable("solver_lib is a test hook (set KSOLVE_TEST_SOLVER_LIB=1); the product has no CPU path and one device library")
         self._solver_lib = solver_lib or KSOLVE_LIB
         if not os.path.exists(self._solver_lib):
             raise SolverUnavailable(f"{self._solver_lib} is not built (hipcc --offload-arch=gfx950; see __graft_entry__.build)")

@@ -8,6 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+os.environ["KSOLVE_TEST_SOLVER_LIB"] = "1"   # tests may hand a test build of the solver library to NewScheduler(solver_lib=) (karpenter_amd/scheduling.py gates it)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -6,6 +6,7 @@
 // It is built only by tests/ (into tests/emu/), is never built by __graft_entry__.build() as part of the product, and
 // the product's Python host (karpenter_amd/scheduling.py) refuses to load it unless a test passes it explicitly.
 #define KSOLVE_HOST_EMULATION 1
+#define KSOLVE_TEST_HOOKS 1   // the test switches (KSOLVE_TEST_*) exist in the test builds only
 #include <algorithm>
 #include "../../karpenter_amd/csrc/ksolve_impl.h"
 

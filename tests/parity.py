@@ -27,6 +27,26 @@ def build_emu(reverse_lanes=False):
     return lib
 
 
+HOOKS_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libksolve_hooks.so")
+
+
+def build_hooks():
+    """The DEVICE library compiled once more with -DKSOLVE_TEST_HOOKS (tests/emu/libksolve_hooks.so): the only gfx950 build that
+    reads the KSOLVE_TEST_* / KSOLVE_ROWHASH_KERNEL switches (narrowed row hash, deterministic cancellation, the previous classing
+    kernels). karpenter_amd/libksolve.so — the product — is compiled without them. Built here when missing or stale (several
+    minutes of hipcc), so keep it built in-tree before a gpurun call: it travels with the snapshot."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "karpenter_amd", "csrc")
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(root, "include", "ksolve.h")]
+    if not os.path.exists(HOOKS_LIB) or any(os.path.getmtime(d) > os.path.getmtime(HOOKS_LIB) for d in deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        tmp = HOOKS_LIB + f".{os.getpid()}.tmp"
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DKSOLVE_TEST_HOOKS", "-o", tmp, os.path.join(csrc, "ksolve.hip")])
+        os.replace(tmp, HOOKS_LIB)
+    return HOOKS_LIB
+
+
 def canon_req(r):
     return (r["key"], r["complement"], tuple(sorted(r["values"])), r["gte"], r["lte"], r["minValues"])
 

@@ -20,15 +20,15 @@ def built():
     assert device_available(), "GPU tests need a usable gfx950 device and karpenter_amd/libksolve.so (no CPU fallback)"
 
 
-def check(oracle, prob):
+def check(oracle, prob, solver_lib=None):
     """The engine the library picks on its own (the cursor engine for purely positive provisioning batches, the general
     engine otherwise) AND — when that was the cursor engine — the general engine too: both against the oracle."""
     want = oracle.solve(prob)
-    got = NewScheduler(prob).Solve()
+    got = NewScheduler(prob, solver_lib=solver_lib).Solve()
     parity.assert_same_results(got, want)
     assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
     if got["counters"]["engine"] == "cursor":
-        gen = NewScheduler(dict(prob, options=dict(prob["options"], engine="general"))).Solve()
+        gen = NewScheduler(dict(prob, options=dict(prob["options"], engine="general")), solver_lib=solver_lib).Solve()
         assert gen["counters"]["engine"] == "general"
         parity.assert_same_results(gen, want)
         assert gen["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
@@ -465,17 +465,19 @@ def test_row_hash_collisions_are_reported_on_the_device(oracle, monkeypatch):
     """The classing kernel (ksolve_row_hash_coop2) with the row hash narrowed to three bits: distinct rows share a hash, inside
     one wavefront (follower against its leader, LDS to LDS) and across wavefronts (leader against the slot's representative,
     row_diff_far); every such pair has to be reported — the host re-seeds and gives up — never merged into one class."""
+    hooks = parity.build_hooks()       # the product binary has no test switches: this is the gfx950 build with -DKSOLVE_TEST_HOOKS
     prob = fx.config2(pods=6000, n_types=144, seed=3)
     monkeypatch.setenv("KSOLVE_TEST_HASH_KEEP", "0x7")
+    NewScheduler(prob).Solve()          # ... and the product ignores the switch
     with pytest.raises(RuntimeError, match="row hash collisions persist"):
-        NewScheduler(prob).Solve()
+        NewScheduler(prob, solver_lib=hooks).Solve()
     monkeypatch.setenv("KSOLVE_TEST_HASH_KEEP", "0x1")
     same = fx.problem(fx.fake_default_instance_types(), [fx.node_pool()], [fx.pod(requests={"cpu": "1"}, node_selector=AMD) for _ in range(300)])
-    check(oracle, same)
+    check(oracle, same, solver_lib=hooks)
     monkeypatch.delenv("KSOLVE_TEST_HASH_KEEP")
     for kernel in ("coop1", "plain"):    # the previous kernels (A/B switch of the launcher) class the rows alike
         monkeypatch.setenv("KSOLVE_ROWHASH_KERNEL", kernel)
-        check(oracle, prob)
+        check(oracle, prob, solver_lib=hooks)
 
 
 def test_volume_usage_limits_on_the_device(oracle):

@@ -1,4 +1,6 @@
 """BASELINE configs[3] / configs[4] shapes on the device against the oracle (small sizes, a few seconds)."""
+import os as _os
+_os.environ.setdefault("KSOLVE_TEST_SOLVER_LIB", "1")   # a test tool: may hand a test build of the solver library to NewScheduler(solver_lib=)
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 t0 = time.time()

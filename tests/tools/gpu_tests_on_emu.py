@@ -1,6 +1,8 @@
 """Runs the functions of tests/test_gpu_parity.py against the host emulation of the solver instead of the device: a check of
 the TESTS (fixtures, expectations, sizes) on a machine without a GPU, so that a red GPU run at round end means the
 device and not the test. Not part of the product or of the pytest suites."""
+import os as _os
+_os.environ.setdefault("KSOLVE_TEST_SOLVER_LIB", "1")   # a test tool: may hand a test build of the solver library to NewScheduler(solver_lib=)
 import sys, os, inspect, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); os.chdir(ROOT)

@@ -1,6 +1,8 @@
 """Host profile of the engine (TEST TOOL): the test emulation built with -DKSOLVE_PHASE_TIMERS counts host TSC cycles per
 phase of the pack loop — where the WORK is (instructions), as opposed to the device's shader-clock counters, which are
 dominated by the latency of a lone wavefront. usage: python tests/tools/host_phase_profile.py [pods] [config2|config3]"""
+import os as _os
+_os.environ.setdefault("KSOLVE_TEST_SOLVER_LIB", "1")   # a test tool: may hand a test build of the solver library to NewScheduler(solver_lib=)
 import os
 import subprocess
 import sys

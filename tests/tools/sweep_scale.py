@@ -2,6 +2,8 @@
 ksolve_sweep, a sample of the probes checked against the oracle's SimulateScheduling of the same candidate (decision, replacement
 and the reference-equivalent evaluation count). Lives with the tests because it uses the oracle.
 usage: sweep_scale.py NODES CANDIDATES [SAMPLE] [--solver-lib LIB]"""
+import os as _os
+_os.environ.setdefault("KSOLVE_TEST_SOLVER_LIB", "1")   # a test tool: may hand a test build of the solver library to NewScheduler(solver_lib=)
 import argparse, json, os, random, sys, time
 from collections import Counter
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

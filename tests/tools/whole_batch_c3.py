@@ -3,6 +3,8 @@ the reference — beside the component split bench.py reports (VERDICT r2 item 8
 against the oracle's offline pin (tests/golden/fullsize/config4_p1000000_t1000_s42_x16.json); at 10M pods no oracle run
 exists (it would take days): the run reports time, engine, NodeClaims and cost next to the sum over the 16 components.
 Usage: python tests/tools/whole_batch_c3.py [--pods 1000000 10000000] [--out file.json]"""
+import os as _os
+_os.environ.setdefault("KSOLVE_TEST_SOLVER_LIB", "1")   # a test tool: may hand a test build of the solver library to NewScheduler(solver_lib=)
 import argparse
 import json
 import os
