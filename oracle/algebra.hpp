@@ -374,20 +374,21 @@ struct Requirement {
 // the order the reference's map is walked in (error texts aside, which are Go-map-order dependent there too).
 struct Requirements {
   std::vector<Requirement> m;
+  SmallVec<Sym, 12> keys;   // m[i].key, side by side: looking a key up does not walk the 88-byte records
 
-  size_t lower(Sym k) const { size_t i = 0; while (i < m.size() && m[i].key < k) ++i; return i; }
-  const Requirement* find(Sym k) const { size_t i = lower(k); return i < m.size() && m[i].key == k ? &m[i] : nullptr; }
-  Requirement* find(Sym k) { size_t i = lower(k); return i < m.size() && m[i].key == k ? &m[i] : nullptr; }
+  size_t lower(Sym k) const { size_t i = 0; const size_t n = keys.size(); while (i < n && keys[i] < k) ++i; return i; }
+  const Requirement* find(Sym k) const { size_t i = lower(k); return i < keys.size() && keys[i] == k ? &m[i] : nullptr; }
+  Requirement* find(Sym k) { size_t i = lower(k); return i < keys.size() && keys[i] == k ? &m[i] : nullptr; }
   void put(const Requirement& r) {   // map assignment
     size_t i = lower(r.key);
-    if (i < m.size() && m[i].key == r.key) m[i] = r; else m.insert(m.begin() + i, r);
+    if (i < keys.size() && keys[i] == r.key) m[i] = r; else { m.insert(m.begin() + i, r); keys.insert_at(i, r.key); }
   }
-  void erase(Sym k) { size_t i = lower(k); if (i < m.size() && m[i].key == k) m.erase(m.begin() + i); }
+  void erase(Sym k) { size_t i = lower(k); if (i < keys.size() && keys[i] == k) { m.erase(m.begin() + i); keys.erase_at(i); } }
   // Add — requirements.go:133-140 : incoming.Intersection(existing)
   void add(const Requirement& in) {
     size_t i = lower(in.key);
-    if (i < m.size() && m[i].key == in.key) m[i] = in.intersection(m[i]);
-    else m.insert(m.begin() + i, in);
+    if (i < keys.size() && keys[i] == in.key) m[i] = in.intersection(m[i]);
+    else { m.insert(m.begin() + i, in); keys.insert_at(i, in.key); }
   }
   void add_all(const Requirements& o) { for (auto& r : o.m) add(r); }
   bool has(Sym k) const { return find(k) != nullptr; }
@@ -402,10 +403,13 @@ struct Requirements {
   // Intersects — requirements.go:254-274 ; on failure *bad_key = an offending key
   bool intersects(const Requirements& in, Sym* bad_key = nullptr) const {
     size_t j = 0;
-    for (auto& existing : m) {
-      while (j < in.m.size() && in.m[j].key < existing.key) ++j;
-      if (j == in.m.size()) break;
-      if (in.m[j].key != existing.key) continue;
+    const size_t ni = in.keys.size();
+    for (size_t i = 0; i < keys.size(); ++i) {
+      const Sym key = keys[i];
+      while (j < ni && in.keys[j] < key) ++j;
+      if (j == ni) break;
+      if (in.keys[j] != key) continue;
+      const Requirement& existing = m[i];
       const Requirement& incoming = in.m[j];
       if (!existing.has_intersection(incoming)) {
         Op oi = incoming.op();
@@ -413,7 +417,7 @@ struct Requirements {
           Op oe = existing.op();
           if (oe == Op::NotIn || oe == Op::DoesNotExist) continue;
         }
-        if (bad_key) *bad_key = existing.key;
+        if (bad_key) *bad_key = key;
         return false;
       }
     }

@@ -264,6 +264,8 @@ struct Scheduler {
   std::vector<NodeClaimTemplate> templates;
   std::vector<std::unique_ptr<NodeClaim>> claim_store;
   std::vector<NodeClaim*> new_node_claims;   // s.newNodeClaims: physically re-sorted in place (scheduler.go:598)
+  std::vector<uint32_t> claim_pods;          // len(new_node_claims[i].Pods), moved with it: the sort's less() reads it here instead of
+                                             // chasing 200k NodeClaim pointers per sort (same values, same comparisons, same swaps)
   std::vector<std::unique_ptr<ExistingNode>> existing_store;
   std::vector<ExistingNode*> existing_nodes;
   std::map<std::string, ResourceList> remaining_resources;  // nodepool -> remaining (only pools present in the map count)
@@ -515,23 +517,28 @@ struct Scheduler {
     if (host_ports_conflict(pod.host_ports, n.host_ports)) { last_err = ERR_EXISTING; return false; }   // existingnode.go:87-93
     if (!res_fits(pd.requests, n.remaining)) { last_err = ERR_RESOURCES; return false; }
     if (!n.reqs.compatible(pd.reqs, false)) { last_err = ERR_INCOMPATIBLE; return false; }
-    Requirements base0 = n.reqs;
-    base0.add_all(pd.reqs);
+    // the node's requirements + the pod's. Copies are made when something is written: adding an empty set leaves the set as it
+    // is, and a candidate that fails before its requirements are returned needs none (the reference's copies are Go values)
+    Requirements merged;
+    const Requirements* base0 = &n.reqs;
+    if (!pd.reqs.m.empty()) { merged = n.reqs; merged.add_all(pd.reqs); base0 = &merged; }
     // volume requirement alternatives — existingnode.go:108-139; tryVolumeAlternative :143-168. They narrow the node's
     // requirements only: topology counts with the pod's own (strict) requirements.
     const size_t n_alt = pd.volume_reqs.empty() ? 1 : pd.volume_reqs.size();
     Requirements alt_base;
     for (size_t a = 0; a < n_alt; ++a) {
-      Requirements& base = pd.volume_reqs.empty() ? base0 : (alt_base = base0);
+      const Requirements* base = base0;
       if (!pd.volume_reqs.empty()) {
-        if (!base.compatible(pd.volume_reqs[a], false)) { last_err = ERR_INCOMPATIBLE; continue; }
-        base.add_all(pd.volume_reqs[a]);
+        if (!base0->compatible(pd.volume_reqs[a], false)) { last_err = ERR_INCOMPATIBLE; continue; }
+        alt_base = *base0;
+        alt_base.add_all(pd.volume_reqs[a]);
+        base = &alt_base;
       }
       Requirements topo;
-      if (!topology.add_requirements(pod, n.node->taints, pd.strict_reqs, base, topo)) { last_err = ERR_TOPOLOGY; continue; }
-      if (!base.compatible(topo, false)) { last_err = ERR_TOPOLOGY; continue; }
-      base.add_all(topo);
-      out = base;
+      if (!topology.add_requirements(pod, n.node->taints, pd.strict_reqs, *base, topo)) { last_err = ERR_TOPOLOGY; continue; }
+      if (!base->compatible(topo, false)) { last_err = ERR_TOPOLOGY; continue; }
+      out = *base;
+      out.add_all(topo);
       return true;
     }
     return false;
@@ -588,23 +595,29 @@ struct Scheduler {
     // nodeclaim.go:130-136: the reference copies the claim's requirements, then tests Compatible on the copy, then Adds;
     // Compatible does not write, so the copy is made once the test has passed
     if (!n.reqs.compatible(pd.reqs, true)) { last_err = ERR_INCOMPATIBLE; return false; }
-    Requirements base0 = n.reqs;
-    base0.add_all(pd.reqs);
+    // (the same goes for the Add: a pod without requirements of its own adds nothing, and a candidate that fails topology
+    // never hands its set on — the working copy is made on the way to the instance-type filter)
+    Requirements merged;
+    const Requirements* base0 = &n.reqs;
+    if (!pd.reqs.m.empty()) { merged = n.reqs; merged.add_all(pd.reqs); base0 = &merged; }
     // volume requirement alternatives — nodeclaim.go:138-157; tryVolumeAlternative :164-242: the first alternative that passes
     // topology, the instance-type filter and the reservation check wins; the error reported is the last alternative's
     const size_t n_alt = pd.volume_reqs.empty() ? 1 : pd.volume_reqs.size();
     Requirements alt_base;
     for (size_t a = 0; a < n_alt; ++a) {
-      // every alternative starts from the claim's requirements + the pod's; without alternatives that set is used in place
-      Requirements& base = pd.volume_reqs.empty() ? base0 : (alt_base = base0);
+      // every alternative starts from the claim's requirements + the pod's
+      const Requirements* base_in = base0;
       last_diag = 0;
       if (!pd.volume_reqs.empty()) {
-        if (!base.compatible(pd.volume_reqs[a], true)) { last_err = ERR_INCOMPATIBLE; continue; }
-        base.add_all(pd.volume_reqs[a]);
+        if (!base0->compatible(pd.volume_reqs[a], true)) { last_err = ERR_INCOMPATIBLE; continue; }
+        alt_base = *base0;
+        alt_base.add_all(pd.volume_reqs[a]);
+        base_in = &alt_base;
       }
       Requirements topo;
-      if (!topology.add_requirements(pod, n.tmpl->taints, pd.strict_reqs, base, topo)) { last_err = ERR_TOPOLOGY; continue; }
-      if (!base.compatible(topo, true)) { last_err = ERR_TOPOLOGY; continue; }
+      if (!topology.add_requirements(pod, n.tmpl->taints, pd.strict_reqs, *base_in, topo)) { last_err = ERR_TOPOLOGY; continue; }
+      if (!base_in->compatible(topo, true)) { last_err = ERR_TOPOLOGY; continue; }
+      Requirements base = *base_in;
       base.add_all(topo);
       ResourceList requests = res_merge(n.requests, pd.requests);
       std::map<Sym, int> unsat;
@@ -689,6 +702,7 @@ struct Scheduler {
       claim_add(*nc, queue_pod, pd, r, rem, ofs);
       nc->id = (int)claim_store.size();
       new_node_claims.push_back(nc.get());
+      claim_pods.push_back((uint32_t)nc->pods.size());
       if (rr != remaining_resources.end()) rr->second = subtract_max(rr->second, nc->its);
       claim_store.push_back(std::move(nc));
       return true;
@@ -701,7 +715,12 @@ struct Scheduler {
     if (add_to_existing(pod, queue_pod)) return true;
     // sort.Slice(s.newNodeClaims, len(Pods) asc) — scheduler.go:598, Go pdqsort (unstable)
     ctr.sorts++;
-    go_sort_slice(new_node_claims, [](const NodeClaim* a, const NodeClaim* b) { return a->pods.size() < b->pods.size(); });
+    {
+      auto less = [&](int i, int j) { return claim_pods[(size_t)i] < claim_pods[(size_t)j]; };
+      auto swap = [&](int i, int j) { std::swap(new_node_claims[(size_t)i], new_node_claims[(size_t)j]); std::swap(claim_pods[(size_t)i], claim_pods[(size_t)j]); };
+      GoSort<decltype(less), decltype(swap)> srt(less, swap);
+      srt.sort_slice((int)new_node_claims.size());
+    }
     if (add_to_inflight(pod, queue_pod)) return true;
     if (templates.empty()) { last_err = ERR_NO_TEMPLATES; last_diag = 0; return false; }
     return add_to_new_claim(pod, queue_pod);
@@ -720,9 +739,12 @@ struct Scheduler {
   bool add_to_inflight(Pod& pod, Pod* queue_pod) {
     const PodData& pd = cached[pod.uid_s];
     if (threads > 1 && new_node_claims.size() >= parallel_min) return add_to_inflight_parallel(pod, queue_pod, pd);
-    for (auto* nc : new_node_claims) {
+    const size_t n_claims = new_node_claims.size();
+    for (size_t i = 0; i < n_claims; ++i) {
+      NodeClaim* nc = new_node_claims[i];
+      if (i + 4 < n_claims) { const NodeClaim* ahead = new_node_claims[i + 4]; __builtin_prefetch(ahead); __builtin_prefetch(ahead->reqs.m.data()); }   // memory latency only
       Requirements r; std::vector<const InstanceType*> its; std::vector<const Offering*> ofs;
-      if (claim_can_add(*nc, pod, pd, false, r, its, ofs)) { claim_add(*nc, queue_pod, pd, r, its, ofs); return true; }
+      if (claim_can_add(*nc, pod, pd, false, r, its, ofs)) { claim_add(*nc, queue_pod, pd, r, its, ofs); claim_pods[i] = (uint32_t)nc->pods.size(); return true; }
     }
     return false;
   }
@@ -877,6 +899,7 @@ inline bool Scheduler::add_to_inflight_parallel(Pod& pod, Pod* queue_pod, const 
   const bool ok = claim_can_add(*new_node_claims[w], pod, pd, false, r, its, ofs);   // the winner again, for its outputs (counts itself)
   if (!ok) throw std::runtime_error("parallel in-flight scan: the winner does not reproduce");
   claim_add(*new_node_claims[w], queue_pod, pd, r, its, ofs);
+  claim_pods[w] = (uint32_t)new_node_claims[w]->pods.size();
   return true;
 }
 

@@ -88,15 +88,57 @@ struct TopologyDomainGroup {
 
 // domains map[string]int32 + emptyDomains sets.Set[string] (topologygroup.go:68-70). `count` is the map; `names` holds its
 // keys ordered by the domain's string (the canonical tie order — walked wherever the reference ranges over the map).
+// Sym -> int32 with open addressing (one cache line per lookup; a hostname group holds one domain per NodeClaim and is asked
+// about one of them by every candidate of every scan)
+class CountMap {
+  struct E { Sym k; int v; };
+  std::vector<E> t_;
+  size_t n_ = 0;
+  static size_t h(Sym k) { return (size_t)((uint32_t)k * 2654435761u); }
+  void grow() {
+    std::vector<E> old;
+    old.swap(t_);
+    t_.assign(old.empty() ? 16 : old.size() * 2, E{kNoSym, 0});
+    n_ = 0;
+    for (auto& e : old) if (e.k != kNoSym) *slot(e.k, true) = e.v;
+  }
+  int* slot(Sym k, bool create) {
+    if (t_.empty()) { if (!create) return nullptr; grow(); }
+    const size_t mask = t_.size() - 1;
+    for (size_t i = h(k) & mask;; i = (i + 1) & mask) {
+      if (t_[i].k == k) return &t_[i].v;
+      if (t_[i].k == kNoSym) {
+        if (!create) return nullptr;
+        if ((n_ + 1) * 10 > t_.size() * 7) { grow(); return slot(k, true); }
+        t_[i].k = k; t_[i].v = 0; n_++;
+        return &t_[i].v;
+      }
+    }
+  }
+
+ public:
+  size_t size() const { return n_; }
+  const int* find(Sym k) const { return const_cast<CountMap*>(this)->slot(k, false); }
+  // (value, inserted)
+  std::pair<int*, bool> emplace(Sym k) { const size_t before = n_; int* v = slot(k, true); return {v, n_ != before}; }
+  void erase(Sym k) {   // rebuild without k (Unregister is not on the scheduling path)
+    if (!find(k)) return;
+    std::vector<E> old;
+    old.swap(t_);
+    t_.assign(old.size(), E{kNoSym, 0});
+    n_ = 0;
+    for (auto& e : old) if (e.k != kNoSym && e.k != k) *slot(e.k, true) = e.v;
+  }
+};
 struct DomainTable {
-  std::unordered_map<Sym, int> count;
+  CountMap count;
   std::set<Sym, SymLexLess> names;
   std::set<Sym, SymLexLess> empty;   // emptyDomains
   size_t size() const { return count.size(); }
-  bool has(Sym d) const { return count.count(d) != 0; }
-  const int* find(Sym d) const { auto it = count.find(d); return it == count.end() ? nullptr : &it->second; }
-  int of(Sym d) const { auto it = count.find(d); return it == count.end() ? 0 : it->second; }
-  void put_zero(Sym d) { if (count.emplace(d, 0).second) names.insert(d); else count[d] = 0; empty.insert(d); }
+  bool has(Sym d) const { return count.find(d) != nullptr; }
+  const int* find(Sym d) const { return count.find(d); }
+  int of(Sym d) const { const int* c = count.find(d); return c ? *c : 0; }
+  void put_zero(Sym d) { auto r = count.emplace(d); if (r.second) names.insert(d); *r.first = 0; empty.insert(d); }
   bool is_empty_domain(Sym d) const { const int* c = find(d); return c && *c == 0 && empty.count(d); }
 };
 
@@ -136,9 +178,9 @@ struct TopologyGroup {
     return selects(p) && node_filter.matches(taints, reqs);
   }
   void record(Sym dom) {                                                                            // :143
-    auto r = domains.count.emplace(dom, 0);
+    auto r = domains.count.emplace(dom);
     if (r.second) domains.names.insert(dom);
-    if (r.first->second++ == 0) domains.empty.erase(dom);   // emptyDomains.Delete: only a domain at zero can be in it
+    if ((*r.first)++ == 0) domains.empty.erase(dom);   // emptyDomains.Delete: only a domain at zero can be in it
   }
   void reg(Sym dom) { if (!domains.has(dom)) domains.put_zero(dom); }                               // :157
   void unreg(Sym dom) { domains.count.erase(dom); domains.names.erase(dom); domains.empty.erase(dom); }   // :166
@@ -412,7 +454,10 @@ struct Topology {
     auto apply = [&](const TopologyGroup& tg) {
       const Requirement* pr_ = pod_reqs.find(tg.key);
       const Requirement* nr_ = node_reqs.find(tg.key);
-      Requirement d = tg.get(p, pr_ ? *pr_ : Requirement::make(tg.key, Op::Exists), nr_ ? *nr_ : Requirement::make(tg.key, Op::Exists));
+      Requirement pod_exists, node_exists;   // NewRequirement(topology.Key, Exists) when the set does not have the key
+      if (!pr_) { pod_exists = Requirement::make(tg.key, Op::Exists); pr_ = &pod_exists; }
+      if (!nr_) { node_exists = Requirement::make(tg.key, Op::Exists); nr_ = &node_exists; }
+      Requirement d = tg.get(p, *pr_, *nr_);
       if (d.len() == 0) return false;
       if (n_adds < 4) adds_inl[n_adds] = std::move(d); else adds_more.push_back(std::move(d));
       n_adds++;
