@@ -83,8 +83,10 @@ def launch_type_vector(prob, res):
     return vec
 
 
-def config4_sweep(args, device_index, rank, world):
-    """BASELINE configs[4]: the consolidation replay. A resident cluster (disruption.make_resident_cluster: nodes packed with the
+def config4_sweep(args, device_index, rank, world, topology=False):
+    """BASELINE configs[4]: the consolidation replay (topology=True: the same cluster with spread constraints on two fifths of the
+    default pool's pod templates — every probe then takes its candidates' share out of the cluster-wide domain counts, and the
+    oracle re-simulates the sampled probes over all 2M bound pods). A resident cluster (disruption.make_resident_cluster: nodes packed with the
     benchmark's pods, then scaled down — test/suites/performance/basic_test.go:61-68) is uploaded once; single-node consolidation
     (singlenodeconsolidation.go:55-126) then simulates every candidate — SimulateScheduling (disruption/helpers.go:53-155) +
     computeConsolidation (consolidation.go:159-256) — as ONE ksolve_sweep launch, one wavefront per candidate. With N ranks the
@@ -92,8 +94,9 @@ def config4_sweep(args, device_index, rank, world):
     are summed afterwards. A sample of the probes is re-simulated by the oracle: the check, and this leg's CPU baseline."""
     from collections import Counter
     from karpenter_amd import disruption as dz
-    out = {"workload": f"BASELINE configs[4]: single-node consolidation sweep over a resident cluster of {args.sweep_nodes} existing nodes"}
-    t = time.perf_counter(); cc = dz.make_resident_cluster(n_nodes=args.sweep_nodes, seed=42); out["generate_s"] = time.perf_counter() - t
+    out = {"workload": f"BASELINE configs[4]: single-node consolidation sweep over a resident cluster of {args.sweep_nodes} existing nodes" + (", bound pods with zonal / hostname spread constraints" if topology else "")}
+    t = time.perf_counter(); cc = dz.make_resident_cluster(n_nodes=args.sweep_nodes, seed=42, topology=topology); out["generate_s"] = time.perf_counter() - t
+    n_sample = args.sweep_topology_sample if topology else args.sweep_sample
     cc["options"] = {"device": device_index}
     out["nodes"], out["bound_pods"] = args.sweep_nodes, sum(g["count"] for g in cc["podGroups"])
     t = time.perf_counter(); rc = dz.ResidentCluster.from_compact(cc, solver_lib=args.solver_lib); out["new_scheduler_s"] = time.perf_counter() - t
@@ -112,7 +115,7 @@ def config4_sweep(args, device_index, rank, world):
                probes_per_s={"pack_kernel_only": len(cands) / (tm["pack_us"] * 1e-6), "ksolve_sweep_call": len(cands) / (tm["sweep_ms"] * 1e-3),
                              "with_descriptors_and_verdicts": len(cands) / lib_s, "through_python": len(cands) / dt},
                timed_region="ksched_sweep(): probe descriptors (host library), ksolve_sweep (upload, one launch, finalize, download), verdicts; candidate prices and the JSON of the call are Python's")
-    if args.sweep_sample > 0 and rank == 0:
+    if n_sample > 0 and rank == 0:
         import random
         import oracle   # the checker: re-simulates sampled probes; its rate is this leg's CPU baseline
         rng = random.Random(1)
@@ -121,8 +124,10 @@ def config4_sweep(args, device_index, rank, world):
             by_dec.setdefault(c["decision"], []).append(j)
         sample = []
         for _, js in sorted(by_dec.items()):       # every verdict is represented
-            sample += rng.sample(js, min(len(js), max(1, args.sweep_sample // len(by_dec))))
+            sample += rng.sample(js, min(len(js), max(1, n_sample // len(by_dec))))
         base = dz.compact_problem(cc, pod_groups=[])
+        if topology:
+            base["clusterPods"] = dz.compact_cluster_pods(cc)   # countDomains reads every bound pod (topology.go:361-459), minus the probe's own
         probes = [{"removeNodes": [cc["nodes"][mine[j]]["name"]], "pods": dz.compact_node_pods(cc, mine[j])} for j in sample]
         threads = min(len(probes), os.cpu_count() or 1)
         t = time.perf_counter(); res = oracle.sweep(base, probes, threads=threads, verdicts=True); osec = time.perf_counter() - t
@@ -138,7 +143,7 @@ def config4_sweep(args, device_index, rank, world):
                                "compared": "decision, replacement instance types, capacity type (all three from oracle/consolidation.hpp's restatement of computeConsolidation on the oracle's own Results), reference-equivalent evaluation count"}
         out["cpu_baseline"] = {"value": len(sample) / osec, "unit": "probes/s", "cores": threads, "kind": "port",
                                "sample": f"{len(sample)} of the swept probes, each a fresh oracle Scheduler over the {args.sweep_nodes}-node cluster (what the reference does per simulation), {threads} at a time", "seconds": osec}
-    if args.sweep_windows > 0:
+    if args.sweep_windows > 0 and not topology:
         out["multi_node"] = config4_multi_node(args, cc, rc, rank, world)
     rc.close()
     return out
@@ -221,8 +226,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pods", type=int, default=1_000_000, help="pods per GPU (configs[1] = 1M)")
     ap.add_argument("--types", type=int, default=500)
-    ap.add_argument("--cpu-sample", type=int, default=20_000, help="pods in the bounded cpu_baseline sample")
-    ap.add_argument("--cpu-runs", type=int, default=5, help="oracle runs of the sample (median reported)")
+    ap.add_argument("--cpu-sample", type=int, default=120_000, help="pods in the bounded cpu_baseline sample (about 10-30 s of one core with the round-4 oracle)")
+    ap.add_argument("--cpu-runs", type=int, default=1, help="oracle runs of the sample (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-engine-baseline", action="store_true", help="skip timing the engine's own source compiled for one host core")
     ap.add_argument("--topology-pods", type=int, default=1_000_000, help="BASELINE configs[2] shape (anti-affinity + 3-zone spread) reported beside the headline, 0 = skip")
@@ -236,6 +241,7 @@ def main():
     ap.add_argument("--sweep-windows", type=int, default=32, help="multi-node consolidation: windows of the sorted candidate list whose prefixes are all simulated in one sweep, 0 = skip")
     ap.add_argument("--sweep-window-size", type=int, default=100, help="MultiNodeConsolidation's batch (multinodeconsolidation.go:80): the search covers prefixes of up to this many + 1 candidates")
     ap.add_argument("--sweep-sample", type=int, default=32, help="probes of the sweep re-simulated by the oracle (checker + CPU baseline of this leg)")
+    ap.add_argument("--sweep-topology-sample", type=int, default=12, help="the second configs[4] leg — the same cluster with spread constraints on its bound pods — re-simulates this many probes by the oracle; 0 = skip the leg")
     ap.add_argument("--no-parity-pin", action="store_true", help="skip the digest check of the timed problem against the committed oracle pin")
     ap.add_argument("--engine", default="auto", choices=["auto", "general", "cursor"], help="pack engine (auto: the cursor engine for purely positive batches)")
     ap.add_argument("--solver-lib", default=None, help="TEST HOOK (tests/test_bench_contract.py, needs KSOLVE_BENCH_TEST_HOOK=1): a host build of the engine behind the same "
@@ -370,7 +376,16 @@ def main():
                 sc_.close()
             return whole, parts, mine, rs, best
 
-        whole, parts, mine, rs, dt = solve_components(args.components_pods, 2)
+        whole, parts, mine, rs, dt = solve_components(args.components_pods, 2, want_results="claims" if not args.no_parity_pin else False)
+        comp_inv = None
+        if not args.no_parity_pin:
+            # no oracle pin exists at this size (27k NodeClaims, 1e11 reference evaluations): every NodeClaim of every component is
+            # checked against the reference's rules instead (tests/invariants.py check_claims), outside the timed region
+            import invariants
+            t_inv = time.perf_counter()
+            n_checked = sum(invariants.check_claims(sub, r, expect_pods=sum(g["count"] for g in sub["podGroups"]))["node_claims"] for (_, sub), r in zip(mine, rs))
+            comp_inv = {"node_claims_checked": n_checked, "violations": 0, "seconds": time.perf_counter() - t_inv,
+                        "checked": "every instance type option of every NodeClaim holds its requests, pod counts add up to the component's pods, requirements inside the NodePool's (tests/invariants.py check_claims)"}
         cvec = np.zeros((len(whole["instanceTypes"]), 2))
         for r in rs:
             cvec += packing_vector(r, len(whole["instanceTypes"]))   # per component by the library (ksolve_packing_vector); summed here, all-reduced below
@@ -394,7 +409,8 @@ def main():
                     "node_claims": int(round(totals[1])), "packing_cost_per_hour": totals[2], "pack_kernel_ms": totals[3], "engines": engines,
                     "per_instance_type": {"launch_types_used": int(nzc.sum()), "claims_from_vector": int(round(cvec[:, 0].sum())), "cost_from_vector": float(cvec[:, 1].sum()),
                                           "vector": "count and $/h per instance type over all components" + (", summed over ranks with one all-reduce" if world > 1 else "")},
-                    "parity": "each component bit-identical to the oracle on that component (tests); the union vs ONE Solve() of the whole batch: L2-canonical, see calibration"}
+                    "parity": "each component bit-identical to the oracle on that component (tests); the union vs ONE Solve() of the whole batch: L2-canonical, see calibration",
+                    "invariants": comp_inv}
             if args.components_calibration_pods > 0:
                 cp = args.components_calibration_pods
                 whole_p = fx.config4(pods=cp, n_types=args.components_types, n_pools=16, seed=42)
@@ -420,6 +436,8 @@ def main():
     sweep = None
     if args.sweep_nodes > 0:
         sweep = config4_sweep(args, device_index, rank, world)
+        if args.sweep_topology_sample > 0 and world == 1:
+            sweep["with_topology_pods"] = config4_sweep(args, device_index, rank, world, topology=True)
         if dist is not None:
             names = ("delete", "replace", "no-op")
             v = torch.tensor([float(sweep["candidates"])] + [float(sweep["decisions"].get(k, 0)) for k in names], dtype=torch.float64, device=reduce_device)
@@ -541,12 +559,23 @@ def main():
                 dt = time.perf_counter() - tb
                 best = dt if best is None else min(best, dt)
             e = {"pods": pods, "seconds": best, "value": r3["scheduledPods"] / best, "unit": "pods/s", "node_claims": r3["counters"]["claims"],
-                 "pack_kernel_ms": r3["timings"][0]["pack_kernel_ms"], "engine": r3["counters"].get("engine"), "oracle_pin": None}
+                 "pack_kernel_ms": r3["timings"][0]["pack_kernel_ms"], "engine": r3["counters"].get("engine"), "oracle_pin": None, "invariants": None}
             pin_path = os.path.join(ROOT, "tests", "golden", "fullsize", f"config3_p{pods}_t{args.types}_s42.json")
+            full3 = None
+            if not args.no_parity_pin:
+                # with or without a pin: the placements replayed in queue order against the reference's topology rules
+                # (tests/invariants.py check_topology_mix: anti-affinity, hostname spread, the zonal skew rule with its minimum-count
+                # choice, zonal self-affinity) and the claim-level packing rules; a violation stops the run
+                import invariants
+                full3 = s3.Solve(want_results=True)
+                t_inv = time.perf_counter()
+                rep = invariants.check_topology_mix(p3, full3)
+                invariants.check_claims(p3, full3, expect_pods=pods)
+                e["invariants"] = {"violations": 0, "seconds": time.perf_counter() - t_inv, "decisions_replayed": rep,
+                                   "checked": "every pod placed once, in queue order; every zonal-spread / hostname-spread / zonal-affinity / hostname-anti-affinity decision re-derived from the domain counts at that moment; every instance type option holds its NodeClaim's requests"}
             if os.path.exists(pin_path) and not args.no_parity_pin:
                 with open(pin_path) as f:
                     g = json.load(f)
-                full3 = s3.Solve(want_results=True)
                 d3, _ = parity.results_digest(full3)
                 e["oracle_pin"] = {"pin": os.path.relpath(pin_path, ROOT), "digest_matches_oracle": d3 == g["digest"], "reference_bin_evaluations_match": full3["counters"]["referenceBinEvaluations"] == g["binEvaluations"],
                                    "oracle_seconds_offline": g["oracleSeconds"], "oracle_threads": g.get("oracleThreads", 1)}
@@ -594,19 +623,9 @@ def main():
                                          f"median of {len(runs)} runs ({secs:.2f} s); the oracle is O(pods x claims), so its rate falls with size "
                                          f"(offline at the full 1M pods: see parity.oracle_pin.oracle_seconds_offline)",
                                "seconds": secs, "runs_seconds": runs, "bin_evaluations": r["counters"]["binEvaluations"]}
-        # N threads: the reference fans the candidates of addToInflightNode out over a worker pool (parallelizeUntil,
-        # scheduler.go:939-961); the oracle does the same when ORACLE_THREADS is set (same Results, same counters)
-        n_thr = min(64, os.cpu_count() or 1)
-        if n_thr > 1:
-            os.environ["ORACLE_THREADS"], os.environ["ORACLE_PAR_MIN"] = str(n_thr), "64"
-            try:
-                rt = oracle.solve(sample)
-            finally:
-                os.environ.pop("ORACLE_THREADS", None); os.environ.pop("ORACLE_PAR_MIN", None)
-            out["cpu_baseline_threads"] = {"value": args.cpu_sample / rt["counters"]["solveSeconds"], "unit": "pods/s", "cores": n_thr, "kind": "port",
-                                           "sample": out["cpu_baseline"]["sample"], "seconds": rt["counters"]["solveSeconds"],
-                                           "note": "candidate fan-out of the in-flight scan; scans shorter than 64 claims stay sequential (most of this sample's are: "
-                                                   f"{r['counters']['binEvaluations'] / args.cpu_sample:.0f} evaluations per pod on average)"}
+        # (An N-thread form of the oracle exists — ORACLE_THREADS: the candidates of one addToInflightNode call over a worker pool, as
+        # parallelizeUntil does, scheduler.go:939-961 — and is not reported: at this mix a scan is a few dozen candidates and the
+        # fan-out costs more than it saves; rounds 3 and 4 measured 1.00x on 64 cores and 0.75x on 6.)
         if not args.no_host_engine_baseline and not args.solver_lib:
             # the honest baseline for the ALGORITHM: this repository's own engine source compiled for ONE host core (the test
             # emulation of the device code, tests/emu — a checker, never a product path), same problem, same Results

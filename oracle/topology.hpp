@@ -296,6 +296,7 @@ struct Topology {
   const Problem* problem = nullptr;
   std::vector<const StateNode*> state_nodes;
   std::unordered_map<Sym, const StateNode*> node_by_name;
+  std::unordered_map<Sym, size_t> node_index;   // name -> position in state_nodes
 
   // buildDomainGroups — topology.go:105-146
   static std::map<Sym, TopologyDomainGroup> build_domain_groups(const Problem& pr, const std::vector<const NodePool*>& pools) {
@@ -341,11 +342,16 @@ struct Topology {
     auto it = node_by_name.find(name);   // the nodes of this simulation
     return it == node_by_name.end() ? nullptr : it->second;
   }
-  // countDomains — topology.go:361-459 (kube reads replaced by the problem's clusterPods / stateNodes)
+  // countDomains — topology.go:361-459 (kube reads replaced by the problem's clusterPods / stateNodes). The reference asks
+  // TopologyNodeFilter.Matches(node) once for the node and once more for every pod bound to it; the answer is the node's, so it
+  // is computed once per node here (a 100k-node cluster carries 2M bound pods, and every probe of a sweep counts every group).
   void count_domains(TopologyGroup& tg) {
-    for (auto* n : state_nodes) {
+    std::vector<char> node_matches(state_nodes.size(), 0);
+    for (size_t i = 0; i < state_nodes.size(); ++i) {
+      const StateNode* n = state_nodes[i];
+      node_matches[i] = tg.node_filter.matches(n->taints, label_requirements(n->labels)) ? 1 : 0;
       if (!n->has_node) continue;
-      if (!tg.node_filter.matches(n->taints, label_requirements(n->labels))) continue;
+      if (!node_matches[i]) continue;
       auto* it = n->labels.find(tg.key);
       if (!it) continue;
       tg.reg(it->second);
@@ -355,14 +361,15 @@ struct Topology {
       if (!tg.selector.is_nil && !tg.selector.matches(p.labels)) continue;  // TopologyListOptions: nil selector lists everything
       if (p.node_name == W().empty || p.phase == W().Failed || p.phase == W().Succeeded) continue;  // IgnoredForTopology :614
       if (excluded_pods.count(p.uid_s)) continue;
-      const StateNode* node = find_node(p.node_name);
-      if (!node) continue;
+      auto ni = node_index.find(p.node_name);
+      if (ni == node_index.end()) continue;
+      const StateNode* node = state_nodes[ni->second];
       Sym dom;
       auto* it = node->labels.find(tg.key);
       if (it) dom = it->second;
       else if (tg.key == W().hostname) dom = node->name_s;
       else continue;
-      if (!tg.node_filter.matches(node->taints, label_requirements(node->labels))) continue;
+      if (!node_matches[ni->second]) continue;
       tg.record(dom);
     }
   }
@@ -426,7 +433,7 @@ struct Topology {
     problem = &pr;
     ignore_preferences = ignore_prefs;
     state_nodes = snodes;
-    for (auto* n : snodes) node_by_name.emplace(n->name_s, n);   // first of equal names, as the linear search found
+    for (size_t i = 0; i < snodes.size(); ++i) { node_by_name.emplace(snodes[i]->name_s, snodes[i]); node_index.emplace(snodes[i]->name_s, i); }   // first of equal names, as the linear search found
     domain_groups = build_domain_groups(pr, pools);
     for (auto& p : pods) excluded_pods.insert(p.uid_s);
     // updateInverseAffinities — topology.go:310-324 : bound pods with required anti-affinity

@@ -142,3 +142,185 @@ def check(problem, res):
         for i, p in enumerate(members):
             for q in members[i + 1:]:
                 assert not _repels(p, q) and not _repels(q, p), f"{p['uid']} and {q['uid']} repel each other but share {b}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Checkers for the BASELINE-sized results (pod groups, a million pods and more), where the oracle has no pin (round 4).
+# They are written against the reference's rules, not against either implementation:
+#   check_claims        — claim level: every instance type option holds the claim's total requests (nodeclaim.go:541-600), the pod
+#                         counts add up to the pods scheduled, the claim's requirements stay inside its NodePool's
+#   check_topology_mix  — pod level, for the configs[2] shape (fixtures.config3): a REPLAY of the placements in queue order
+#                         (queue.go:72-108) that re-derives every topology decision from the counts at that moment:
+#                         hostname anti-affinity (topologygroup.go:404-439), hostname spread (:229-252), zonal spread with its
+#                         skew rule and minimum-count choice (:253-298, ties to the smallest zone name: the oracle's
+#                         canonicalisation), zonal self-affinity with its bootstrap (:324-388), and Record's "only when the node
+#                         is down to one domain" (topology.go:197-220).
+# ---------------------------------------------------------------------------------------------------------------------------
+def _alloc(it):
+    out = {}
+    for k, v in it["capacity"].items():
+        out[k] = _q(v) - _q(it.get("overhead", {}).get(k, "0"))
+    for hk, hv in it["capacity"].items():
+        if hk.startswith("hugepages-"):
+            out["memory"] = max(Decimal(0), out.get("memory", Decimal(0)) - _q(hv))
+    return out
+
+
+def check_claims(problem, res, expect_pods=None):
+    """Claim-level invariants of a Results document (works on want_results="claims" documents too). Returns a summary dict;
+    raises AssertionError on a violation. Quantities are compared exactly, as integers of 1/1000 of the resource's unit."""
+    import numpy as np
+    names = [t["name"] for t in problem["instanceTypes"]]
+    index = {n: i for i, n in enumerate(names)}
+    res_names = sorted({k for t in problem["instanceTypes"] for k in t["capacity"]} | {"pods"})
+    col = {k: j for j, k in enumerate(res_names)}
+    alloc = np.zeros((len(names), len(res_names)), dtype=np.int64)
+    for i, t in enumerate(problem["instanceTypes"]):
+        for k, v in _alloc(t).items():
+            m = v * 1000
+            assert m == int(m), f"{t['name']}: {k} finer than 1/1000"
+            alloc[i, col[k]] = int(m)
+    pools = {np_["name"]: np_ for np_ in problem["nodePools"]}
+    total_pods = 0
+    for c in res["newNodeClaims"]:
+        n = c.get("podCount", len(c["pods"]))
+        assert n >= 1, f"empty NodeClaim {c['hostname']}"
+        total_pods += n
+        need = np.zeros(len(res_names), dtype=np.int64)
+        for k, v in c["requests"].items():
+            nano = int(v)
+            assert nano % 1_000_000 == 0, f"claim {c['hostname']}: {k} finer than 1/1000"
+            assert k in col or nano == 0, f"claim {c['hostname']} requests {k}, which no instance type has"
+            if k in col:
+                need[col[k]] = nano // 1_000_000
+        assert need[col["pods"]] == n * 1000, f"claim {c['hostname']}: pods request {need[col['pods']]} != {n} pods"
+        assert c["instanceTypes"], f"claim {c['hostname']} has no instance type option"
+        idx = np.fromiter((index[name] for name in c["instanceTypes"]), dtype=np.int64, count=len(c["instanceTypes"]))
+        ok = (alloc[idx] >= need).all(axis=1)
+        assert ok.all(), f"claim {c['hostname']}: requests {c['requests']} do not fit {names[int(idx[int(np.argmin(ok))])]}"
+        reqs = {q["key"]: q for q in c["requirements"]}
+        for r in pools[c["nodePool"]].get("requirements", []):
+            if r["operator"] == "In":
+                q = reqs.get(r["key"])
+                assert q is not None and not q["complement"] and set(q["values"]) <= set(r["values"]) and q["values"], f"claim {c['hostname']} left its NodePool's {r['key']}: {q}"
+        q = reqs.get(fx.NODEPOOL)
+        assert q is not None and q["values"] == [c["nodePool"]], f"claim {c['hostname']}: nodepool requirement {q}"
+    placed_existing = sum(len(e["pods"]) for e in res.get("existingNodes", []))
+    if expect_pods is not None:
+        assert total_pods + placed_existing + len(res["podErrors"]) == expect_pods, (total_pods, placed_existing, len(res["podErrors"]), expect_pods)
+    return {"node_claims": len(res["newNodeClaims"]), "pods_on_claims": total_pods, "checked": "every instance type option holds the claim's requests; pod counts add up; requirements inside the NodePool's"}
+
+
+def check_topology_mix(problem, res):
+    """Replay checker for fixtures.config3-shaped problems (pod groups; one NodePool; labels my-label / my-affininity / app). `res`
+    must carry the pod lists (want_results=True). Raises AssertionError on the first violated rule; returns counts of what it
+    checked."""
+    assert not res["podErrors"] and not res.get("existingNodes"), "the replay expects every pod on a new NodeClaim"
+    pool = problem["nodePools"][0]
+    zones = sorted(next(r["values"] for r in pool["requirements"] if r["key"] == fx.ZONE))
+    # pods: (cpu desc, memory desc, creation asc, uid asc) — queue.go:72-108
+    order = []
+    kind_of = []
+    for gi, g in enumerate(problem["podGroups"]):
+        t = g["template"]
+        cpu, mem = _q(t["requests"].get("cpu", "0")), _q(t["requests"].get("memory", "0"))
+        tsc = t.get("topologySpreadConstraints") or []
+        aff = (t.get("podAffinity") or {}).get("required") or []
+        anti = (t.get("podAntiAffinity") or {}).get("required") or []
+        kind_of.append((t.get("labels", {}), tsc, aff, anti))
+        for i in range(g["count"]):
+            order.append((-cpu, -mem, t.get("creationTimestamp", 0), fx.group_pod_uid(g["uidSeed"], i), gi))
+    order.sort()
+    where = {}       # uid -> (claim index, slot)
+    claim_zone = []  # the claim's final zone requirement
+    for ci, c in enumerate(res["newNodeClaims"]):
+        for s, u in enumerate(c["pods"]):
+            assert u not in where, f"pod {u} placed twice"
+            where[u] = (ci, s)
+        zq = next((q for q in c["requirements"] if q["key"] == fx.ZONE), None)
+        claim_zone.append(sorted(zq["values"]) if zq is not None and not zq["complement"] else list(zones))
+    assert len(where) == len(order), (len(where), len(order))
+    # a claim is down to ONE zone from the first pod that owns a zonal constraint (its requirement is intersected into the claim)
+    narrow_slot = [None] * len(claim_zone)
+    for ci, c in enumerate(res["newNodeClaims"]):
+        pass
+    slot_kinds = {}
+    for (_, _, _, uid, gi) in order:
+        ci, s = where[uid]
+        labels, tsc, aff, anti = kind_of[gi]
+        zonal = any(t["topologyKey"] == fx.ZONE for t in tsc) or any(t["topologyKey"] == fx.ZONE for t in aff)
+        if zonal and (narrow_slot[ci] is None or s < narrow_slot[ci]):
+            narrow_slot[ci] = s
+    for ci, ns in enumerate(narrow_slot):
+        if ns is not None:
+            assert len(claim_zone[ci]) == 1, f"claim {ci} hosts a pod with a zonal constraint but admits zones {claim_zone[ci]}"
+    sel_key = lambda sel: tuple(sorted((sel.get("matchLabels") or {}).items()))
+    zone_counts = {}    # (type, selector) -> {zone: count}
+    host_counts = {}    # (type, selector) -> {claim: count}
+    groups_seen = {"zonal_spread": set(), "hostname_spread": set(), "zonal_affinity": set(), "hostname_anti_affinity": set()}
+    # the groups exist from the start (Topology.Update runs for every pod before the first one is placed)
+    all_groups = []
+    for labels, tsc, aff, anti in kind_of:
+        for t in tsc:
+            all_groups.append(("spread", t["topologyKey"], sel_key(t["labelSelector"]), t.get("maxSkew", 1)))
+        for t in aff:
+            all_groups.append(("affinity", t["topologyKey"], sel_key(t["labelSelector"]), 0))
+        for t in anti:
+            all_groups.append(("anti", t["topologyKey"], sel_key(t["labelSelector"]), 0))
+    all_groups = sorted(set(all_groups))
+    for g in all_groups:
+        (zone_counts if g[1] == fx.ZONE else host_counts)[g] = {z: 0 for z in zones} if g[1] == fx.ZONE else {}
+    selects = lambda g, labels: all(labels.get(k) == v for k, v in g[2])
+    checked = {"zonal_spread": 0, "hostname_spread": 0, "zonal_affinity": 0, "hostname_anti_affinity": 0, "pods": 0}
+    placed_slots = [0] * len(claim_zone)
+    for (_, _, _, uid, gi) in order:
+        ci, s = where[uid]
+        assert s == placed_slots[ci], f"pod {uid} sits in slot {s} of claim {ci} but {placed_slots[ci]} pods were placed there before it (queue order)"
+        placed_slots[ci] += 1
+        labels, tsc, aff, anti = kind_of[gi]
+        # the zones the claim admits when this pod arrives
+        narrowed = narrow_slot[ci] is not None and s > narrow_slot[ci]
+        node_zones = claim_zone[ci] if narrowed else list(zones)
+        z_final = claim_zone[ci][0] if narrow_slot[ci] is not None else None
+        for t in tsc:
+            g = ("spread", t["topologyKey"], sel_key(t["labelSelector"]), t.get("maxSkew", 1))
+            self_sel = 1 if selects(g, labels) else 0
+            if t["topologyKey"] == fx.ZONE:
+                cnt = zone_counts[g]
+                mn = min(cnt.values())
+                valid = [z for z in node_zones if cnt[z] + self_sel - mn <= g[3]]
+                assert valid, f"pod {uid}: no zone of {node_zones} keeps the skew of {g} (counts {cnt})"
+                best = min(valid, key=lambda z: (cnt[z] + self_sel, z))
+                assert z_final == best, f"pod {uid}: zonal spread {g} picks {best} (counts {cnt}), the claim sits in {z_final}"
+                checked["zonal_spread"] += 1
+            else:
+                c_here = host_counts[g].get(ci, 0)
+                assert c_here + self_sel <= g[3], f"pod {uid}: hostname spread {g} violated on claim {ci} ({c_here} + {self_sel})"
+                checked["hostname_spread"] += 1
+        for t in aff:
+            g = ("affinity", t["topologyKey"], sel_key(t["labelSelector"]), 0)
+            cnt = zone_counts[g]
+            options = [z for z in node_zones if cnt[z] > 0]
+            if options:
+                assert z_final in options, f"pod {uid}: affinity {g} allows {options}, the claim sits in {z_final}"
+            else:
+                assert selects(g, labels) and all(v == 0 for v in cnt.values()), f"pod {uid}: affinity {g} has no populated zone in {node_zones} and no bootstrap (counts {cnt})"
+            checked["zonal_affinity"] += 1
+        for t in anti:
+            g = ("anti", t["topologyKey"], sel_key(t["labelSelector"]), 0)
+            assert host_counts[g].get(ci, 0) == 0, f"pod {uid}: anti-affinity {g} but claim {ci} already hosts a selected pod"
+            checked["hostname_anti_affinity"] += 1
+        # inverse anti-affinity: a pod SELECTED by somebody's required anti-affinity may not join a claim that hosts an owner
+        # (here owners and selected pods are the same app=nginx pods, covered above)
+        # Record — topology.go:197-220
+        now_single = narrow_slot[ci] is not None and s >= narrow_slot[ci]
+        for g in all_groups:
+            if not selects(g, labels):
+                continue
+            if g[1] == fx.ZONE:
+                if g[0] == "anti" or now_single:
+                    zone_counts[g][claim_zone[ci][0]] += 1
+            else:
+                host_counts[g][ci] = host_counts[g].get(ci, 0) + 1
+        checked["pods"] += 1
+    return checked

@@ -74,3 +74,39 @@ def test_volume_requirement_alternatives_invariant(oracle):
                 q["values"] = ["test-zone-2"]
     with pytest.raises(AssertionError, match="no volume requirement alternative"):
         invariants.check(prob, bad)
+
+
+def test_fullsize_checkers_accept_the_oracle_and_reject_tampering(oracle):
+    """check_claims / check_topology_mix (the checkers bench.py runs on the results no oracle pin exists for): the oracle's own
+    Results of the configs[2] shape pass — including the replay of every zonal-spread choice with its tie rule — and every
+    tampered copy is caught: a pod moved onto a claim that already hosts an anti-affinity peer, a claim moved to another zone, a
+    claim whose requests are raised above an option's allocatable, a pod listed twice."""
+    import copy
+    p = fx.config3(pods=4000, n_types=144, seed=9)
+    r = oracle.solve(p)
+    got = invariants.check_topology_mix(p, r)
+    assert got["pods"] == 4000 and all(got[k] > 0 for k in ("zonal_spread", "hostname_spread", "zonal_affinity", "hostname_anti_affinity"))
+    assert invariants.check_claims(p, r, expect_pods=4000)["node_claims"] == len(r["newNodeClaims"])
+    nginx = {fx.group_pod_uid(g["uidSeed"], i) for g in p["podGroups"] if g["template"]["labels"].get("app") == "nginx" for i in range(g["count"])}
+    hosts = [i for i, c in enumerate(r["newNodeClaims"]) if nginx & set(c["pods"])]
+    bad = copy.deepcopy(r)                        # two app=nginx pods on one NodeClaim
+    u = next(x for x in bad["newNodeClaims"][hosts[0]]["pods"] if x in nginx)
+    bad["newNodeClaims"][hosts[0]]["pods"].remove(u)
+    bad["newNodeClaims"][hosts[1]]["pods"].append(u)
+    with pytest.raises(AssertionError):
+        invariants.check_topology_mix(p, bad)
+    bad = copy.deepcopy(r)                        # a zonal claim in another zone
+    ci = next(i for i, c in enumerate(bad["newNodeClaims"]) if any(q["key"] == fx.ZONE and len(q["values"]) == 1 for q in c["requirements"]))
+    for q in bad["newNodeClaims"][ci]["requirements"]:
+        if q["key"] == fx.ZONE:
+            q["values"] = [z for z in fx.KWOK_ZONES[:3] if z != q["values"][0]][:1]
+    with pytest.raises(AssertionError):
+        invariants.check_topology_mix(p, bad)
+    bad = copy.deepcopy(r)                        # requests above an option's allocatable
+    bad["newNodeClaims"][0]["requests"]["cpu"] = str(10 ** 15)
+    with pytest.raises(AssertionError):
+        invariants.check_claims(p, bad)
+    bad = copy.deepcopy(r)                        # a pod listed twice
+    bad["newNodeClaims"][1]["pods"].append(bad["newNodeClaims"][0]["pods"][0])
+    with pytest.raises(AssertionError):
+        invariants.check_topology_mix(p, bad)
