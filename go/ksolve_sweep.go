@@ -154,11 +154,16 @@ func (rc *ResidentCluster) Sweep(ctx context.Context, candidateSets [][]string) 
 	for i, set := range candidateSets {
 		lim := append([]int64(nil), base...)
 		pods = append(pods, rc.always...)
+		seen := map[uint32]bool{}
 		for _, name := range set {
 			e, ok := rc.nodeOf[name]
 			if !ok {
 				return nil, fmt.Errorf("candidate %s is not a state node of the resident cluster", name)
 			}
+			if seen[e] { // a candidate named twice is one candidate (the C ABI rejects a node listed twice)
+				continue
+			}
+			seen[e] = true
 			nodes = append(nodes, e)
 			pods = append(pods, rc.nodePods[e]...)
 			if t := rc.nodeTmpl[e]; t >= 0 {
@@ -197,7 +202,13 @@ func (rc *ResidentCluster) Sweep(ctx context.Context, candidateSets [][]string) 
 		// the probe's slice of the results, re-hydrated exactly like a Solve() of its own (ksolve_rehydrate.go): its claims
 		// are rows claimOff[i]..claimOff[i+1] of out.claims, its pods' assignments the slice podOff[i]..podOff[i+1]
 		sims[i].Results = flat.rehydrateProbe(rc.p.s, &out, int(claimOff[i]), int(claimOff[i+1]), pods[podOff[i]:podOff[i+1]], int(podOff[i]))
-		sims[i].Err = ctx.Err()
+		if status[i] == int32(C.KSOLVE_ERR_CANCELLED) {
+			// only a simulation the cancellation actually cut short carries the context's error (Solve returns its partial
+			// Results with ctx.Err(), scheduler.go:477-480); the ones that had finished are complete and stay error-free
+			if sims[i].Err = ctx.Err(); sims[i].Err == nil {
+				sims[i].Err = context.Canceled
+			}
+		}
 	}
 	return sims, nil
 }

@@ -364,9 +364,14 @@ ksolve_status ksolve_probe_create(ksolve_handle* base, const ksolve_probe* probe
 typedef struct {
   uint32_t n_probes;
   const uint32_t* node_off;        /* n_probes + 1 : CSR into nodes */
-  const uint32_t* nodes;           /* existing-node indices of the base problem that are not part of the simulation (the candidates) */
+  const uint32_t* nodes;           /* existing-node indices of the base problem that are not part of the simulation (the candidates);
+                                    * distinct within a probe (KSOLVE_ERR_INVALID otherwise), offsets non-decreasing */
   const uint32_t* pod_off;         /* n_probes + 1 : CSR into pods */
-  const uint32_t* pods;            /* pod indices of the base problem the simulation schedules, distinct within a probe, any order */
+  const uint32_t* pods;            /* pod indices of the base problem the simulation schedules, distinct within a probe, any order.
+                                    * Topology bases: EVERY bound pod row of a removed node must be listed — a hostname group's
+                                    * per-node counter leaves the simulation with the node (the reference's countDomains would
+                                    * still count a bound pod the caller chose not to reschedule, e.g. one a PodDisruptionBudget
+                                    * holds back, topology.go:361-459 / helpers.go:86-95: keep such a node out of the sweep) */
   const int64_t* tmpl_limits;      /* NULL = the base problem's, else n_probes * n_templates * (n_res+1): NodePool limits with the removed
                                     * nodes' capacity handed back (scheduler.go:835-842) */
 } ksolve_sweep_desc;
@@ -389,7 +394,8 @@ typedef struct {
 
 /* Runs the sweep. One sweep (or solve) per base handle at a time. Topology groups: see ksolve_probe_create (resident-cluster
  * bases only). Sweeps whose probes need more workspace than the arena budget (KSOLVE_SWEEP_ARENA_MB, default 4096) run as
- * several launches inside the call. The function's status is that of the call (arguments, device); each simulation's own
+ * several launches inside the call, cut by the probes' measured workspace sizes; a launch whose arena the device refuses is
+ * retried at half its size. The function's status is that of the call (arguments, device); each simulation's own
  * status is in results.status. */
 ksolve_status ksolve_sweep(ksolve_handle* base, const ksolve_sweep_desc* desc, ksolve_sweep_results* out);
 void ksolve_sweep_results_free(ksolve_sweep_results* r);

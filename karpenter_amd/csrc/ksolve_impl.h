@@ -93,6 +93,7 @@ struct ksolve_handle {
   bool sweep_ready = false;
   ks::ProblemView* d_pv = nullptr;
   char* sweep_arena = nullptr; size_t sweep_arena_bytes = 0;
+  size_t sweep_last_total = 0;   // arena bytes the last sweep_run laid out (held against sweep_probe_bytes by the test builds)
   char* sweep_fin = nullptr; size_t sweep_fin_bytes = 0;     // finalize outputs + gathered claim records of a sweep
 };
 
@@ -1126,7 +1127,11 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
   std::vector<uint32_t> removed(nodes, nodes + total_nodes);
   for (uint32_t p = 0; p < n; ++p) {
     std::sort(removed.begin() + node_off[p], removed.begin() + node_off[p + 1]);
-    for (uint32_t i = node_off[p]; i < node_off[p + 1]; ++i) if (removed[i] >= ne) return fail(base, KSOLVE_ERR_INVALID, "probe node index out of range");
+    for (uint32_t i = node_off[p]; i < node_off[p + 1]; ++i) {
+      if (removed[i] >= ne) return fail(base, KSOLVE_ERR_INVALID, "probe node index out of range");
+      // a node listed twice would be taken out of the evaluation counts and the topology registrations twice
+      if (i > node_off[p] && removed[i] == removed[i - 1]) return fail(base, KSOLVE_ERR_INVALID, "probe node listed twice");
+    }
   }
   // ---- LDS plan of the launch: the base plan with the claim order cut down to the largest probe ----
   uint32_t max_m = 1;
@@ -1221,6 +1226,7 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
   };
   layout();
   const size_t total = off;
+  base->sweep_last_total = total;
   arena = sweep_buffer(base, base->sweep_arena, base->sweep_arena_bytes, total);
   if (!arena) return fail(base, KSOLVE_ERR_DEVICE, base->error.empty() ? "device allocation failed (sweep arena)" : base->error);
   for (uint32_t p = 0; p < n; ++p) items[p] = ks::Workspace{};
@@ -1372,27 +1378,84 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
 
 // Sweeps whose workspaces would not fit a sensible arena (a cluster with hostname topology groups needs a per-node counter table
 // per probe) run as several launches; the results are those of one.
+// Bytes of arena probe p of a sweep needs: sweep_run's layout() written out per probe (its share of the per-pod and per-claim
+// regions + its own workspace), every region rounded up as take() rounds it.
+static size_t sweep_probe_bytes(const ksolve_handle* base, uint32_t m, size_t pv_entries, bool with_limits) {
+  const ks::ProblemView& P = base->pv;
+  const ks::RecLayout lay = P.lay;
+  const size_t ne = base->n_nodes, nr = base->n_res, T = base->n_templates, nc = std::max(1u, base->n_classes), nk = base->n_keys;
+  size_t mc = std::max(1u, m);
+  if (base->opts.max_claims && base->opts.max_claims < mc) mc = base->opts.max_claims;
+  const size_t cw = (mc + 63) / 64;
+  size_t oc = 64;
+  while (oc < 2 * std::min<size_t>(std::max<size_t>(1, m), std::max<size_t>(1, ne))) oc <<= 1;
+  auto r = [](size_t b) { return (b + 63) & ~(size_t)63; };
+  size_t b = sizeof(ks::Workspace) + 8 + sizeof(ks::Counters);
+  b += (size_t)m * (4 + 4 + 1 + 1 + 4 + 4 + 4) + 4;                                     // sorted, slot, err, diag, lastLen, queue, assign
+  b += mc * ((size_t)lay.c_hot_words() * 8 + (size_t)lay.cold_words() * 8 + 8 + (P.hp_on ? 8 : 0) + 12);
+  if (with_limits) b += T * (nr + 1) * 8;
+  b += r((mc * nr + 64) * 8) + r(T * base->it_words * 8) + r(T * (nr + 1) * 8) + r(nc * cw * 8);
+  if (ne) {
+    const bool bounds = base->ws.n_hg != nullptr;
+    b += 2 * r(oc * 4) + r((size_t)base->req_words * oc * 8) + 2 * r(oc * 4) + r(nr * oc * 8) + r(oc * 4) + (P.hp_on ? r(oc * 8) : 0);
+    if (bounds) b += 2 * r(oc * 4) + 2 * r(nk * oc * 8);
+    if (base->has_topology) {
+      const ks::TopoView& Tv = P.topo;
+      const size_t G = (size_t)Tv.n_groups, dv = (size_t)Tv.dom_words * 64, hg = (size_t)std::max(1, Tv.n_host_groups), ks_ = (size_t)std::max(1, Tv.n_key_slots);
+      b += r(G * Tv.dom_words * 8) + 2 * r(G * dv * 4) + r(hg * std::max<size_t>(1, ne) * 4) + r(hg * mc * 4) + r(G * 4) + (Tv.n_alias ? r((size_t)Tv.n_alias * 4) : 0);
+      b += r(ks_ * mc * 8) + r(ks_ * 64 * cw * 8) + r(hg * 2 * cw * 8);
+    }
+    if (P.pv_on) b += r(std::max<size_t>(1, pv_entries) * 8);
+  }
+  return b + b / 64 + 2048;   // + the rounding of the ~20 shared regions (each up to 63 bytes, paid in full by a launch of one probe) and 1.5% of slack; the test builds fail a sweep whose arena outgrows this figure
+}
+
+// Sweeps whose workspaces would not fit the arena budget run as several launches; the results are those of one. The chunks are
+// cut by the probes' MEASURED sizes (a multi-node prefix of 2000 pods needs ~1 MB, a single-node probe ~60 KB, a cluster with
+// hostname topology groups a per-node counter table per probe); a chunk whose arena the device still refuses is halved and retried.
 static ksolve_status sweep_run_chunked(ksolve_handle* base, uint32_t n, const uint32_t* node_off, const uint32_t* nodes, const uint32_t* pod_off, const uint32_t* pods,
                                        const int64_t* const* limits, int* const* cancel, SweepImpl* im, double* us) {
-  size_t per_probe = 64 * 1024;
-  if (base->has_topology) {
-    const ks::TopoView& T = base->pv.topo;
-    per_probe += (size_t)std::max(1, T.n_host_groups) * std::max(1u, base->n_nodes) * 4 + (size_t)T.n_groups * T.dom_words * 64 * 8 + (size_t)T.n_groups * T.dom_words * 8;
-  }
+  for (uint32_t p = 0; p < n; ++p)
+    if (node_off[p + 1] < node_off[p] || pod_off[p + 1] < pod_off[p]) return fail(base, KSOLVE_ERR_INVALID, "sweep descriptor offsets must not decrease");
   size_t budget = (size_t)4 << 30;
-  if (const char* b = getenv("KSOLVE_SWEEP_ARENA_MB")) budget = (size_t)std::max(1, atoi(b)) << 20;   // tests: force several launches
-  const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n, budget / per_probe));
-  if (chunk >= n) return sweep_run(base, n, node_off, nodes, pod_off, pods, limits, cancel, im, us);
+  if (const char* b = getenv("KSOLVE_SWEEP_ARENA_MB")) budget = (size_t)std::max(1, atoi(b)) << 20;   // the arena budget of a launch (tests lower it to force several)
+  bool any_limits = false;
+  for (uint32_t p = 0; p < n; ++p) any_limits = any_limits || (limits && limits[p]);
+  std::vector<size_t> need(n);
+  size_t total_need = 0;
+  for (uint32_t p = 0; p < n; ++p) {
+    size_t entries = 0;
+    if (base->pv.pv_on) for (uint32_t i = pod_off[p]; i < pod_off[p + 1]; ++i) if (pods[i] < base->n_pods) entries += base->h_pod_pv_first[pods[i] + 1] - base->h_pod_pv_first[pods[i]];
+    need[p] = sweep_probe_bytes(base, pod_off[p + 1] - pod_off[p], entries, any_limits);
+    total_need += need[p];
+  }
+  if (total_need <= budget) {
+    ksolve_status st = sweep_run(base, n, node_off, nodes, pod_off, pods, limits, cancel, im, us);
+#ifdef KSOLVE_TEST_HOOKS
+    if (st == KSOLVE_OK && base->sweep_last_total > total_need) return fail(base, KSOLVE_ERR_INVALID, "sweep_probe_bytes underestimates the arena: " + std::to_string(base->sweep_last_total) + " > " + std::to_string(total_need) + " for " + std::to_string(n) + " probes");
+#endif
+    if (st != KSOLVE_ERR_DEVICE || n < 2) return st;
+    budget = total_need / 2;            // the device refused the arena: go on with half of it per launch
+    base->error.clear();
+    *im = SweepImpl();
+  }
   double total_us[4] = {0, 0, 0, 0};
   im->claim_off.assign(1, 0);
-  for (uint32_t lo = 0; lo < n; lo += chunk) {
-    const uint32_t m = std::min(chunk, n - lo);
+  for (uint32_t lo = 0; lo < n;) {
+    uint32_t m = 0;
+    size_t acc = 0;
+    while (lo + m < n && (m == 0 || acc + need[lo + m] <= budget)) { acc += need[lo + m]; ++m; }
     std::vector<uint32_t> no(m + 1), po(m + 1);
     for (uint32_t i = 0; i <= m; ++i) { no[i] = node_off[lo + i] - node_off[lo]; po[i] = pod_off[lo + i] - pod_off[lo]; }
     SweepImpl part;
     double u[4] = {0, 0, 0, 0};
     ksolve_status st = sweep_run(base, m, no.data(), nodes + node_off[lo], po.data(), pods + pod_off[lo], limits ? limits + lo : nullptr, cancel ? cancel + lo : nullptr, &part, u);
+    if (st == KSOLVE_ERR_DEVICE && m > 1) { budget = std::max<size_t>(acc / 2, 1); base->error.clear(); continue; }   // smaller launches from here on
     if (st != KSOLVE_OK) return st;
+#ifdef KSOLVE_TEST_HOOKS   // the test builds hold the estimate to the layout it restates
+    if (base->sweep_last_total > acc) return fail(base, KSOLVE_ERR_INVALID, "sweep_probe_bytes underestimates the arena");
+#endif
+    lo += m;
     for (int k = 0; k < 4; ++k) total_us[k] += u[k];
     auto app = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
     app(im->status, part.status); app(im->assign, part.assign); app(im->err, part.err); app(im->diag, part.diag); app(im->slot, part.slot);

@@ -2122,15 +2122,6 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
           std::vector<int> cheaper;
           if (cl.ordered_instance_types) { for (uint32_t i = 0; i < cl.ordered_count[c]; ++i) { const int it = cl.ordered_instance_types[(size_t)c * cl.n_instance_types + i]; if (worst(it) < price) cheaper.push_back(it); } }
           else for (int it = 0; it < n_its; ++it) if (((cl.it_mask[(size_t)c * cl.it_words + it / 64] >> (it % 64)) & 1) && worst(it) < price) cheaper.push_back(it);
-          // InstanceTypes.SatisfiesMinValues after the price filter (nodeclaim.go:416-418, types.go:399-433)
-          bool mv_ok = true;
-          for (int k = 0; k < nk && mv_ok; ++k) {
-            const int want = cl.req_min_values[(size_t)c * nk + k];
-            if (want < 0 || !ks::bit(r.defined, k)) continue;
-            std::set<std::string> seen;
-            for (int it : cheaper) for (auto& e : B->it_exprs[it]) if (e.key == D.keys[k]) seen.insert(e.values.begin(), e.values.end());
-            if ((int)seen.size() < want) mv_ok = false;
-          }
           auto min_values_ok = [&](const std::vector<int>& its_) {
             for (int k = 0; k < nk; ++k) {
               const int want = cl.req_min_values[(size_t)c * nk + k];
@@ -2141,6 +2132,9 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
             }
             return true;
           };
+          // InstanceTypes.SatisfiesMinValues after the price filter (nodeclaim.go:416-418, types.go:399-433); an empty list
+          // satisfies it (no error), so "no cheaper type" is reported as that, not as a minValues failure (consolidation.go:228-233)
+          bool mv_ok = cheaper.empty() || min_values_ok(cheaper);
           if (mv_ok && multi_node && !cheaper.empty() && node_off[p + 1] - node_off[p] > 1) {
             // filterOutSameInstanceType (multinodeconsolidation.go:209-246): when a replacement option is one of the types being
             // removed, the replacement must be cheaper than the cheapest candidate of that type — else deleting the others is the
@@ -2165,6 +2159,7 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
             else mv_ok = min_values_ok(cheaper);
           }
           if (!mv_ok) reasons.add_new(std::to_string(p), Value::string("minValues requirement is not met after filtering by price"));
+          else if (cheaper.empty() && !reasons.has(std::to_string(p))) reasons.add_new(std::to_string(p), Value::string("Can't replace with a cheaper node"));
           else if (!cheaper.empty()) {
             decision = 2;
             Value rj = Value::object();
