@@ -115,6 +115,7 @@ def config4_sweep(args, device_index, rank, world, topology=False):
                probes_per_s={"pack_kernel_only": len(cands) / (tm["pack_us"] * 1e-6), "ksolve_sweep_call": len(cands) / (tm["sweep_ms"] * 1e-3),
                              "with_descriptors_and_verdicts": len(cands) / lib_s, "through_python": len(cands) / dt},
                timed_region="ksched_sweep(): probe descriptors (host library), ksolve_sweep (upload, one launch, finalize, download), verdicts; candidate prices and the JSON of the call are Python's")
+    out["kernels"] = sweep_rooflines(tm, len(cands))
     if n_sample > 0 and rank == 0:
         import random
         import oracle   # the checker: re-simulates sampled probes; its rate is this leg's CPU baseline
@@ -146,6 +147,46 @@ def config4_sweep(args, device_index, rank, world, topology=False):
     if args.sweep_windows > 0 and not topology:
         out["multi_node"] = config4_multi_node(args, cc, rc, rank, world)
     rc.close()
+    return out
+
+
+def sweep_rooflines(tm, n_probes):
+    """The two kernels of the consolidation path that fill the chip, with the bytes their algorithm has to move:
+    ksolve_pack_sweep — per displaced pod its class record and outputs, per 4096-node step of an existing-node scan 512 B of
+    the class's rejection row, per node / NodeClaim actually evaluated its record; ksolve_node_dead0 — the node tables once,
+    one bit per (class, node) out. `traffic` = measured HBM bytes of the same kernels (profiles/round4/pmc_traffic.json, when
+    it was taken on this build)."""
+    rw, nr, iw = tm.get("req_words", 0), tm.get("resources", 0), tm.get("it_words", 0)
+    if not rw:
+        return None
+    b_cls = 8 * rw + 16 + 8 * nr + 8              # class record: requirement masks, flag words, requests, toleration mask
+    b_node = 8 * rw + 8 + 8 * nr + 8 + 4          # pristine node: masks, defined / complement, remaining, taints, pod count
+    b_claim = 8 * rw + 16 + 8 * iw + 16 * nr + 16   # NodeClaim hot record: masks, flags, instance types, total + headroom, meta
+    b_out = 4 + 4 + 1 + 1 + 4                     # per pod: queue entry, assignment, error, diag, slot
+    claim_evals = max(0, tm["bin_evaluations"] - tm["node_evaluations"])
+    alg = tm["pods"] * (b_cls + b_out) + tm["node_block_steps"] * 512 + tm["node_evaluations"] * b_node + claim_evals * 2 * b_claim
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "round4", "pmc_traffic.json")) as f:
+            doc = json.load(f)
+        if doc.get("source_sha") == source_sha():
+            pmc = doc.get("sweep_kernels", {})
+    except (OSError, ValueError):
+        pass
+    ps = tm["pack_us"] * 1e-6
+    out = {"ksolve_pack_sweep": {"bound": "latency per probe (one wavefront each), occupancy per sweep", "grid": f"{min(n_probes, 8192)} blocks of one wavefront", "probes": n_probes,
+                                 "algorithmic_bytes": alg, "avg_kernel_ms": ps * 1e3, "achieved": alg / ps / 1e9 if ps > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": alg / ps / 1e9 / HBM_PEAK_GBS if ps > 0 else None, "traffic": pmc.get("ksolve_pack_sweep", {}).get("traffic_bytes_per_launch"),
+                                 "waves": pmc.get("ksolve_pack_sweep", {}).get("SQ_WAVES", {}).get("per_launch"),
+                                 "terms": {"displaced_pods": tm["pods"], "class_record_bytes": b_cls, "node_block_steps": tm["node_block_steps"], "nodes_evaluated": tm["node_evaluations"], "node_record_bytes": b_node,
+                                           "claims_evaluated": claim_evals, "claim_record_bytes": b_claim}}}
+    ds = tm.get("node_dead0_us", 0.0) * 1e-6
+    if ds > 0:
+        alg0 = tm["nodes"] * b_node + tm["classes"] * b_cls + tm["classes"] * ((tm["nodes"] + 63) // 64) * 8
+        out["ksolve_node_dead0"] = {"bound": "compare throughput (classes x nodes tests; the node tables are streamed once per class from L2)", "grid": f"{(tm['nodes'] + 63) // 64} blocks of one wavefront",
+                                    "class_node_tests": tm["classes"] * tm["nodes"], "tests_per_s": tm["classes"] * tm["nodes"] / ds,
+                                    "algorithmic_bytes": alg0, "avg_kernel_ms": ds * 1e3, "achieved": alg0 / ds / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg0 / ds / 1e9 / HBM_PEAK_GBS,
+                                    "traffic": pmc.get("ksolve_node_dead0", {}).get("traffic_bytes_per_launch")}
     return out
 
 
@@ -480,12 +521,12 @@ def main():
     # it was measured on: after any change of the sources it reads null until the script has run again.
     traffic, stream_traffic, traffic_note = None, None, "not measured for this build (scripts/gpu_pmc_traffic.sh)"
     try:
-        with open(os.path.join(ROOT, "profiles", "round3", "pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "round4", "pmc_traffic.json")) as f:
             pmc = json.load(f)
         if pmc.get("source_sha") == source_sha() and pmc.get("pods") == args.pods and pmc.get("types") == args.types:
             traffic = pmc["kernels"].get(kernel, {}).get("traffic_bytes_per_launch")
             stream_traffic = pmc["kernels"].get("ksolve_row_hash_coop2", {}).get("traffic_bytes_per_launch")
-            traffic_note = "TCC FETCH_SIZE x2 + WRITE_SIZE per launch, rocprofv3 --pmc on this build (profiles/round3/pmc_traffic.json)"
+            traffic_note = "TCC FETCH_SIZE x2 + WRITE_SIZE per launch, rocprofv3 --pmc on this build (profiles/round4/pmc_traffic.json)"
     except (OSError, KeyError, ValueError):
         pass
     pin = None
@@ -498,7 +539,11 @@ def main():
                    "reference_bin_evaluations_match": full["counters"]["referenceBinEvaluations"] == g["binEvaluations"], "oracle_seconds_offline": g["oracleSeconds"]}
             if not (pin["digest_matches_oracle"] and pin["reference_bin_evaluations_match"]):
                 raise SystemExit(f"bench.py: the timed problem's Results differ from the oracle's pin {pin}")   # the reference's in-bench gate (scheduling_benchmark_test.go:176-181), bit-exact
-    stream_bytes = c["rows"] * rec["B_pod"]
+    # what the classing kernel reads and writes per row: the mask table(s) + flag words, requests, toleration mask, the slot it
+    # writes; all-nil minValues tables are not streamed, and the row's bookkeeping words (next_variant, creation, uid, pending:
+    # 29 B of B_pod) belong to other kernels — they are NOT in this numerator (round-3 review)
+    row_bytes = (1 if c.get("strictTableShared") else 2) * (8 * c["reqWords"] + 16) + 8 * c["resources"] + 8 + 4
+    stream_bytes = c["rows"] * row_bytes
     nz = vec[:, 0] > 0
     out = {
         "metric": "pods scheduled/sec (Solve())", "value": value, "unit": "pods/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -516,10 +561,12 @@ def main():
         # ("the feasibility pre-pass ... is the one to hold to the >= 40% HBM target"); HIP events around the kernel alone.
         "roofline": {"kernel": "ksolve_row_hash_coop2", "bound": "hbm", "achieved": stream_bytes / (rh_ms * 1e-3) / 1e9 if rh_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": stream_bytes / (rh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rh_ms > 0 else None, "traffic": stream_traffic, "traffic_source": traffic_note,
-                     "algorithmic_bytes": stream_bytes, "bytes_per_row": rec["B_pod"], "rows": c["rows"], "avg_kernel_ms": rh_ms, "classing_phase_ms": cls_ms,
-                     "bytes_read_by_the_kernel": c["rows"] * ((1 if c.get("strictTableShared") else 2) * (8 * c["reqWords"] + 16) + 8 * c["resources"] + 8 + 4),   # the mask table(s) + flag words, requests, toleration mask, slot written; all-nil minValues tables are not streamed
+                     "algorithmic_bytes": stream_bytes, "bytes_per_row": row_bytes, "rows": c["rows"], "avg_kernel_ms": rh_ms, "classing_phase_ms": cls_ms,
+                     "achieved_from_traffic": (stream_traffic / (rh_ms * 1e-3) / 1e9) if (stream_traffic and rh_ms > 0) else None,
+                     "frac_from_traffic": (stream_traffic / (rh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (stream_traffic and rh_ms > 0) else None,
                      "mask_tables": 1 if c.get("strictTableShared") else 2,
-                     "note": "B_pod is the row of the layout actually used (DESIGN.md §3); SURVEY §8(d)'s sketch of a row (K = 16 keys, one mask word each) is 188 B"},
+                     "note": "numerator = the bytes this kernel reads and writes per row (not the whole B_pod row of DESIGN.md §3: 245 B with its bookkeeping words); "
+                             "the table of the headline problem (220 MB) is smaller than the 256 MiB Infinity Cache — profiles/round4/classing_rows.json has the same kernel at 2M and 4M rows"},
         # The pack kernel is a serial first-fit chain on ONE wavefront: bound by the instruction issue and the dependent LDS round
         # trips of a lone wave, not by HBM — no roofline is claimed for it. `achieved` is what it really moves.
         "pack_kernel": {"kernel": kernel, "bound": "latency / instruction issue of one wavefront", "avg_kernel_ms": pack_ms, "traffic": traffic, "traffic_source": traffic_note,

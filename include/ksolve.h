@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KSOLVE_ABI_VERSION 7
+#define KSOLVE_ABI_VERSION 8
 #define KSOLVE_MAX_KEYS 32        /* requirement keys per problem (one bit each in the u32 flag words) */
 #define KSOLVE_MAX_RES 8          /* resource dimensions */
 #define KSOLVE_MAX_TEMPLATES 32   /* NodeClaimTemplates (NodePools that survived prefiltering) */
@@ -389,6 +389,13 @@ typedef struct {
   ksolve_claims claims;            /* every probe's NodeClaims, concatenated */
   const uint64_t* ref_bin_evaluations;   /* n_probes : V of each simulation */
   double us_upload, us_pack, us_finalize, us_download;
+  /* what the launch(es) read, summed over the probes — the terms of the sweep kernel's algorithmic bytes */
+  uint64_t total_bin_evaluations;        /* CanAdd calls: existing nodes, in-flight claims, new claims */
+  uint64_t total_node_evaluations;       /* existing nodes whose tables a scan read */
+  uint64_t total_node_block_steps;       /* 512-byte steps over the per-class rejection rows of the pristine nodes */
+  uint32_t n_classes;                    /* pod classes of the base problem (rows of the per-class rejection table) */
+  uint32_t it_words, n_nodes;
+  double us_node_dead0;                  /* the once-per-cluster kernel that fills that table (every class x every pristine node) */
   void* impl;
 } ksolve_sweep_results;
 

@@ -1675,6 +1675,7 @@ struct Engine {
     const uint64_t* skip = exempt_pod ? nullptr : P.node_skip;
     const Workspace& Sw = S;
     for (int w0 = (base >> 6) + 1; w0 < nw; w0 += 64) {
+      ctr.node_block_steps++;
       LaneVar<uint64_t> lv;
       const uint64_t any = W::ballot([&](int l) {
         const int w = w0 + l;
@@ -1758,6 +1759,7 @@ struct Engine {
         if (base < 0) break;
       }
       const int b0 = base;
+      ctr.node_evaluations += (unsigned long long)popc64(todo);
       const uint64_t ok = W::ballot([&](int l) {
         if (!((todo >> l) & 1)) return false;
         const int e_ = b0 + l;

@@ -93,6 +93,7 @@ struct ksolve_handle {
   bool sweep_ready = false;
   ks::ProblemView* d_pv = nullptr;
   char* sweep_arena = nullptr; size_t sweep_arena_bytes = 0;
+  double dead0_us = 0;            // ksolve_node_dead0 (every class x every pristine node), once per resident cluster
   size_t sweep_last_total = 0;   // arena bytes the last sweep_run laid out (held against sweep_probe_bytes by the test builds)
   char* sweep_fin = nullptr; size_t sweep_fin_bytes = 0;     // finalize outputs + gathered claim records of a sweep
 };
@@ -1083,7 +1084,7 @@ static ksolve_status sweep_prepare_base(ksolve_handle* base) {
     a.pristine.hg = nullptr; a.pristine.hl = nullptr; a.pristine.gte = nullptr; a.pristine.lte = nullptr;
     a.pristine.remaining = base->ws.n_remaining0; a.pristine.hp = P.node_hp0; a.pristine.stride = ne;
     a.dead0 = dead0;
-    if (nc) be_launch_node_dead0(base, (int)nw, a);
+    if (nc) { be_tic(base, T_INDEX); be_launch_node_dead0(base, (int)nw, a); be_toc(base, T_INDEX); base->dead0_us = base->timers.ms[T_INDEX] * 1e3; }
     P.n_dead0 = dead0;
   }
   base->d_pv = dz<ks::ProblemView>(base, 1);
@@ -1115,23 +1116,43 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
   const uint32_t total_pods = pod_off[n], total_nodes = node_off[n];
   const bool bounds = base->ws.n_hg != nullptr;
   be_tic(base, T_UPLOAD);
+#ifdef KSOLVE_TEST_HOOKS
+  const bool trace = getenv("KSOLVE_TEST_SWEEP_TRACE") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto t_a = tnow();
+#endif
   // ---- validate + queue order per probe (the base queue order, restricted) ----
   std::vector<uint32_t> sorted(total_pods), perm(total_pods);   // perm: position in the probe's sorted list -> position in the caller's list
-  for (uint32_t p = 0; p < n; ++p) {
-    const uint32_t b = pod_off[p], m = pod_off[p + 1] - b;
-    for (uint32_t i = 0; i < m; ++i) { if (pods[b + i] >= base->n_pods) return fail(base, KSOLVE_ERR_INVALID, "probe pod index out of range"); perm[b + i] = i; }
-    std::sort(perm.begin() + b, perm.begin() + b + m, [&](uint32_t x, uint32_t y) { return base->h_rank[pods[b + x]] < base->h_rank[pods[b + y]]; });
-    for (uint32_t i = 0; i < m; ++i) sorted[b + i] = pods[b + perm[b + i]];
-    for (uint32_t i = 1; i < m; ++i) if (sorted[b + i] == sorted[b + i - 1]) return fail(base, KSOLVE_ERR_INVALID, "probe pod listed twice");
-  }
   std::vector<uint32_t> removed(nodes, nodes + total_nodes);
-  for (uint32_t p = 0; p < n; ++p) {
-    std::sort(removed.begin() + node_off[p], removed.begin() + node_off[p + 1]);
-    for (uint32_t i = node_off[p]; i < node_off[p + 1]; ++i) {
-      if (removed[i] >= ne) return fail(base, KSOLVE_ERR_INVALID, "probe node index out of range");
-      // a node listed twice would be taken out of the evaluation counts and the topology registrations twice
-      if (i > node_off[p] && removed[i] == removed[i - 1]) return fail(base, KSOLVE_ERR_INVALID, "probe node listed twice");
-    }
+  {
+    // every probe on its own (a few host threads): its pods in queue order — (rank << 32 | position) keys, one plain sort — and
+    // its removed nodes ascending
+    const uint32_t nt = n < 1024 ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<const char*> bad(nt, nullptr);
+    auto work = [&](uint32_t t) {
+      std::vector<uint64_t> key;
+      for (uint32_t p = (uint32_t)((uint64_t)n * t / nt), pe = (uint32_t)((uint64_t)n * (t + 1) / nt); p < pe && !bad[t]; ++p) {
+        const uint32_t b = pod_off[p], m = pod_off[p + 1] - b;
+        key.resize(m);
+        for (uint32_t i = 0; i < m; ++i) {
+          if (pods[b + i] >= base->n_pods) { bad[t] = "probe pod index out of range"; break; }
+          key[i] = ((uint64_t)base->h_rank[pods[b + i]] << 32) | i;
+        }
+        if (bad[t]) break;
+        std::sort(key.begin(), key.end());
+        for (uint32_t i = 0; i < m; ++i) { perm[b + i] = (uint32_t)key[i]; sorted[b + i] = pods[b + (uint32_t)key[i]]; }
+        for (uint32_t i = 1; i < m; ++i) if (sorted[b + i] == sorted[b + i - 1]) { bad[t] = "probe pod listed twice"; break; }
+        std::sort(removed.begin() + node_off[p], removed.begin() + node_off[p + 1]);
+        for (uint32_t i = node_off[p]; i < node_off[p + 1]; ++i) {
+          if (removed[i] >= ne) { bad[t] = "probe node index out of range"; break; }
+          // a node listed twice would be taken out of the evaluation counts and the topology registrations twice
+          if (i > node_off[p] && removed[i] == removed[i - 1]) { bad[t] = "probe node listed twice"; break; }
+        }
+      }
+    };
+    if (nt == 1) work(0);
+    else { std::vector<std::thread> pool; for (uint32_t t = 0; t < nt; ++t) pool.emplace_back(work, t); for (auto& th : pool) th.join(); }
+    for (uint32_t t = 0; t < nt; ++t) if (bad[t]) return fail(base, KSOLVE_ERR_INVALID, bad[t]);
   }
   // ---- LDS plan of the launch: the base plan with the claim order cut down to the largest probe ----
   uint32_t max_m = 1;
@@ -1224,6 +1245,9 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
     }
     ones_to = off;
   };
+#ifdef KSOLVE_TEST_HOOKS
+  auto t_b = tnow();
+#endif
   layout();
   const size_t total = off;
   base->sweep_last_total = total;
@@ -1258,6 +1282,9 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
     W.pr_limits = d_limits ? d_limits + (size_t)p * T * (nr + 1) : nullptr;
     W.pr_order_cap = lp.order_cap;
   }
+#ifdef KSOLVE_TEST_HOOKS
+  auto t_c = tnow();
+#endif
   be_h2d(base, d_items, items.data(), (size_t)n * sizeof(ks::Workspace));
   if (total_pods) be_h2d(base, d_sorted, sorted.data(), (size_t)total_pods * 4);
   if (total_nodes) be_h2d(base, d_removed, removed.data(), (size_t)total_nodes * 4);
@@ -1266,6 +1293,12 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
   be_fill(base, arena + zero_to, 0xFF, ones_to - zero_to);
   be_h2d(base, base->d_pv, &P, sizeof(P));
   be_sync(base);
+#ifdef KSOLVE_TEST_HOOKS
+  if (trace) {
+    auto us_ = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "sweep_run host: validate+sort %.0f us, layout+items %.0f us, h2d+fill %.0f us, arena %zu bytes, sizeof(Workspace) %zu\n", us_(t_a, t_b), us_(t_b, t_c), us_(t_c, tnow()), total, sizeof(ks::Workspace));
+  }
+#endif
   be_toc(base, T_UPLOAD);
   if (!be_ok(base)) return fail(base, KSOLVE_ERR_DEVICE, base->error.empty() ? "sweep upload failed" : base->error);
 
@@ -1417,6 +1450,7 @@ static ksolve_status sweep_run_chunked(ksolve_handle* base, uint32_t n, const ui
                                        const int64_t* const* limits, int* const* cancel, SweepImpl* im, double* us) {
   for (uint32_t p = 0; p < n; ++p)
     if (node_off[p + 1] < node_off[p] || pod_off[p + 1] < pod_off[p]) return fail(base, KSOLVE_ERR_INVALID, "sweep descriptor offsets must not decrease");
+  { ksolve_status st = sweep_prepare_base(base); if (st != KSOLVE_OK) return st; }   // the class count enters the sizes below
   size_t budget = (size_t)4 << 30;
   if (const char* b = getenv("KSOLVE_SWEEP_ARENA_MB")) budget = (size_t)std::max(1, atoi(b)) << 20;   // the arena budget of a launch (tests lower it to force several)
   bool any_limits = false;
@@ -1509,6 +1543,8 @@ static ksolve_status sweep(ksolve_handle* base, const ksolve_sweep_desc* d, ksol
   fill_claims_view(base, im->claims, 0, im->claim_off[n], out->claims);
   out->ref_bin_evaluations = im->ref.data();
   out->us_upload = us[0]; out->us_pack = us[1]; out->us_finalize = us[2]; out->us_download = us[3];
+  out->n_classes = base->n_classes; out->us_node_dead0 = base->dead0_us; out->it_words = base->it_words; out->n_nodes = base->n_nodes;
+  for (auto& c : im->counters) { out->total_bin_evaluations += c.bin_evaluations; out->total_node_evaluations += c.node_evaluations; out->total_node_block_steps += c.node_block_steps; }
   out->impl = im;
   return KSOLVE_OK;
 }

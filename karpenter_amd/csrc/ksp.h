@@ -224,6 +224,8 @@ struct Counters {
   unsigned long long ref_bin_evaluations;  // V: candidate bins the reference would have evaluated
   unsigned long long cycles[24];           // shader clock spent per engine phase (profiling aid)
   unsigned long long full_filters;         // filterInstanceTypesByRequirements runs that had to re-evaluate compatibility + offerings
+  unsigned long long node_block_steps;     // probes: 64-word steps over a class's n_dead0 row (512 B each) in the existing-node scan
+  unsigned long long node_evaluations;     // existing nodes whose tables a scan actually read (the live bits of the blocks it stopped at)
 };
 
 struct Workspace {

@@ -22,6 +22,7 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ksolve.h"
@@ -1986,6 +1987,20 @@ extern "C" void* ksched_probe(void* base_session, const char* probe_json) {
 // computeConsolidation's verdict (consolidation.go:159-256): delete when no NodeClaim is needed, replace when exactly one is
 // and a cheaper instance type remains after the price filter (nodeclaim.go:411-420), otherwise nothing. The probe descriptors
 // are built here (CSR arrays over the session's node -> pods tables), not in the caller's language. Returns one document.
+// fn(i) for i in [0, n) on a few threads (the probes of a sweep are independent: their descriptors and verdicts are too)
+template <class F>
+static void parallel_for(size_t n, F fn) {
+  const size_t nt = n < 1024 ? 1 : std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency()));
+  if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+  std::vector<std::thread> pool;
+  std::vector<std::string> errors(nt);
+  for (size_t t = 0; t < nt; ++t) pool.emplace_back([&, t]() {
+    try { for (size_t i = n * t / nt, e = n * (t + 1) / nt; i < e; ++i) fn(i); } catch (const std::exception& e) { errors[t] = e.what(); }
+  });
+  for (auto& th : pool) th.join();
+  for (auto& e : errors) if (!e.empty()) throw std::runtime_error(e);
+}
+
 extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
   Session* B = (Session*)base_session;
   if (!B || !B->handle || B->base) return error_json("invalid", "sweep needs an open base session");
@@ -2006,8 +2021,46 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
       B->sweep_tables = true;
     }
     Value doc = kj::Parser(sweep_json).parse();
-    const auto& cands = doc.at("candidates").items();
-    const uint32_t n = (uint32_t)cands.size();
+    // candidates: one list of nodes per simulation ("candidates": [[name | position, ...], ...]) or the same as CSR arrays of
+    // positions in the stateNodes list ("candidateOff": n + 1 offsets, "candidateNodes")
+    std::vector<uint32_t> node_off(1, 0), nodes;
+    auto by_position = [&](int64_t i) {
+      if (i < 0 || i >= (int64_t)B->node_input_index.size() || B->node_input_index[(size_t)i] < 0) throw std::runtime_error("sweep removes an unknown node index");
+      return (uint32_t)B->node_input_index[(size_t)i];
+    };
+    auto end_probe = [&](size_t n0) {   // a candidate named twice is one candidate; the order given stays (the prices are summed in it)
+      size_t w = n0;
+      for (size_t r = n0; r < nodes.size(); ++r) {
+        bool dup = false;
+        for (size_t j = n0; j < w && !dup; ++j) dup = nodes[j] == nodes[r];
+        if (!dup) nodes[w++] = nodes[r];
+      }
+      nodes.resize(w);
+      node_off.push_back((uint32_t)nodes.size());
+    };
+    if (doc.has("candidateOff")) {
+      const auto& off = doc.at("candidateOff").items();
+      const auto& flat = doc.at("candidateNodes").items();
+      if (off.empty() || off.back().i(-1) != (int64_t)flat.size()) throw std::runtime_error("sweep: candidateOff does not cover candidateNodes");
+      nodes.reserve(flat.size());
+      for (size_t p = 0; p + 1 < off.size(); ++p) {
+        const int64_t a = off[p].i(-1), e = off[p + 1].i(-1);
+        if (a < 0 || e < a || e > (int64_t)flat.size()) throw std::runtime_error("sweep: candidateOff must not decrease");
+        const size_t n0 = nodes.size();
+        for (int64_t j = a; j < e; ++j) nodes.push_back(by_position(flat[(size_t)j].i(-1)));
+        end_probe(n0);
+      }
+    } else {
+      for (auto& cv : doc.at("candidates").items()) {
+        const size_t n0 = nodes.size();
+        for (auto& nv : cv.items()) {
+          if (nv.kind == Value::Str) { auto f = B->node_index.find(nv.s()); if (f == B->node_index.end()) throw std::runtime_error("sweep removes an unknown node " + nv.s()); nodes.push_back((uint32_t)f->second); }
+          else nodes.push_back(by_position(nv.i(-1)));
+        }
+        end_probe(n0);
+      }
+    }
+    const uint32_t n = (uint32_t)node_off.size() - 1;
     // "prices" / "allSpot" may be left out: the session then takes every candidate's price from its own offering (node_price) and
     // its capacity type from its label. "multiNode": the simulations are prefixes of MultiNodeConsolidation's binary search —
     // a replace verdict over several candidates goes through filterOutSameInstanceType (multinodeconsolidation.go:209-246)
@@ -2018,33 +2071,34 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
     const bool multi_node = doc.at("multiNode").boolean_or(false);
     const bool detail = doc.at("detail").boolean_or(false);
     const bool spot_to_spot = B->root.at("options").at("spotToSpotConsolidation").boolean_or(false);
-    std::vector<uint32_t> node_off(n + 1, 0), pod_off(n + 1, 0), nodes, pods;
+    // the displaced pods of every probe: sizes first, then every probe fills its own slice (independent: on a few threads)
+    std::vector<uint32_t> pod_off(n + 1, 0), pods;
+    const size_t n_always = B->always_pods.size();
+    for (uint32_t p = 0; p < n; ++p) {
+      size_t m = n_always;
+      for (uint32_t j = node_off[p]; j < node_off[p + 1]; ++j) m += B->node_pod_off[nodes[j] + 1] - B->node_pod_off[nodes[j]];
+      pod_off[p + 1] = pod_off[p] + (uint32_t)m;
+    }
+    pods.resize(pod_off[n]);
     std::vector<int64_t> lims;
     const bool limits = !B->tmpl_lim.empty();
     if (limits) lims.resize((size_t)n * T * nr1);
-    for (uint32_t p = 0; p < n; ++p) {
-      const size_t n0 = nodes.size();
-      for (auto& nv : cands[p].items()) {
-        int e = -1;
-        if (nv.kind == Value::Str) { auto f = B->node_index.find(nv.s()); if (f == B->node_index.end()) throw std::runtime_error("sweep removes an unknown node " + nv.s()); e = f->second; }
-        else { const int64_t i = nv.i(-1); if (i < 0 || i >= (int64_t)B->node_input_index.size() || B->node_input_index[(size_t)i] < 0) throw std::runtime_error("sweep removes an unknown node index"); e = B->node_input_index[(size_t)i]; }
-        bool dup = false;
-        for (size_t j = n0; j < nodes.size(); ++j) dup = dup || nodes[j] == (uint32_t)e;
-        if (!dup) nodes.push_back((uint32_t)e);
+    parallel_for(n, [&](size_t p) {
+      uint32_t* dst = pods.data() + pod_off[p];
+      if (n_always) { memcpy(dst, B->always_pods.data(), n_always * 4); dst += n_always; }
+      for (uint32_t j = node_off[p]; j < node_off[p + 1]; ++j) {
+        const uint32_t a = B->node_pod_off[nodes[j]], e = B->node_pod_off[nodes[j] + 1];
+        if (e > a) { memcpy(dst, B->node_pod_list.data() + a, (size_t)(e - a) * 4); dst += e - a; }
       }
-      node_off[p + 1] = (uint32_t)nodes.size();
-      pods.insert(pods.end(), B->always_pods.begin(), B->always_pods.end());
-      for (size_t j = n0; j < nodes.size(); ++j) pods.insert(pods.end(), B->node_pod_list.begin() + B->node_pod_off[nodes[j]], B->node_pod_list.begin() + B->node_pod_off[nodes[j] + 1]);
-      pod_off[p + 1] = (uint32_t)pods.size();
       if (limits) {
-        int64_t* l = lims.data() + (size_t)p * T * nr1;
+        int64_t* l = lims.data() + p * T * nr1;
         memcpy(l, B->tmpl_lim.data(), (size_t)T * nr1 * 8);
-        for (size_t j = n0; j < nodes.size(); ++j) {   // the pool gets the node's capacity back (scheduler.go:835-842)
+        for (uint32_t j = node_off[p]; j < node_off[p + 1]; ++j) {   // the pool gets the node's capacity back (scheduler.go:835-842)
           const int e = (int)nodes[j], t = B->node_tmpl[e];
           if (t >= 0) for (int r = 0; r < nr1; ++r) l[(size_t)t * nr1 + r] += B->node_limit_cap[(size_t)e * nr1 + r];
         }
       }
-    }
+    });
     ksolve_sweep_desc sd{};
     sd.n_probes = n; sd.node_off = node_off.data(); sd.nodes = nodes.data(); sd.pod_off = pod_off.data(); sd.pods = pods.data();
     sd.tmpl_limits = limits ? lims.data() : nullptr;
@@ -2065,7 +2119,12 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
     Value decisions = Value::array(), scheduled = Value::array(), n_claims_j = Value::array(), status_j = Value::array(), refs = Value::array(), repl = Value::array(), reasons = Value::object();
     Value details = Value::array();
     auto uid_of = [&](int p) { if (!B->uid_text[p].empty()) return B->uid_text[p]; std::string u; uint64_t a, b; group_uid(B->group_of_pod[p].first, B->group_of_pod[p].second, a, b, &u); return u; };
-    for (uint32_t p = 0; p < n; ++p) {
+    // every probe's verdict is computed on its own (a few threads), the document is put together afterwards in probe order
+    struct Verdict { int decision = 0; bool all_ok = true; uint32_t live = 0; std::vector<int> cheaper; bool pin_spot = false; const char* reason = nullptr; };
+    std::vector<Verdict> verdicts(n);
+    parallel_for(n, [&](size_t pp) {
+      const uint32_t p = (uint32_t)pp;
+      Verdict& V = verdicts[p];
       int decision = 0;   // 0 no-op, 1 delete, 2 replace
       bool all_ok = true;
       const uint32_t c0 = res.claim_off[p], C = res.claim_off[p + 1] - c0;
@@ -2155,27 +2214,36 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
             std::vector<int> kept;
             for (int it : cheaper) if (worst(it) < max_price) kept.push_back(it);
             cheaper.swap(kept);
-            if (cheaper.empty()) reasons.add_new(std::to_string(p), Value::string("every replacement option is one of the types being removed, or more expensive"));
+            if (cheaper.empty()) V.reason = "every replacement option is one of the types being removed, or more expensive";
             else mv_ok = min_values_ok(cheaper);
           }
-          if (!mv_ok) reasons.add_new(std::to_string(p), Value::string("minValues requirement is not met after filtering by price"));
-          else if (cheaper.empty() && !reasons.has(std::to_string(p))) reasons.add_new(std::to_string(p), Value::string("Can't replace with a cheaper node"));
+          if (!mv_ok) V.reason = "minValues requirement is not met after filtering by price";
+          else if (cheaper.empty() && !V.reason) V.reason = "Can't replace with a cheaper node";
           else if (!cheaper.empty()) {
             decision = 2;
-            Value rj = Value::object();
-            rj.set("probe", Value::integer(p));
-            std::vector<std::string> names;
-            for (int it : cheaper) names.push_back(B->it_names[it]);
-            std::sort(names.begin(), names.end());
-            Value nj = Value::array();
-            for (auto& nm : names) nj.push(Value::string(nm));
-            rj.set("instanceTypes", nj);
-            rj.set("capacityType", (!ct_defined || (spot_ok && od_ok)) ? Value::string("spot") : Value());   // consolidation.go:238-243
-            repl.push(rj);
+            V.cheaper.swap(cheaper);
+            V.pin_spot = !ct_defined || (spot_ok && od_ok);   // consolidation.go:238-243
           }
         }
       }
-      decisions.push(Value::integer(decision)); scheduled.push(Value::boolean(all_ok)); n_claims_j.push(Value::integer(live));
+      V.decision = decision; V.all_ok = all_ok; V.live = live;
+    });
+    for (uint32_t p = 0; p < n; ++p) {
+      const Verdict& V = verdicts[p];
+      if (V.reason) reasons.add_new(std::to_string(p), Value::string(V.reason));
+      if (V.decision == 2) {
+        Value rj = Value::object();
+        rj.set("probe", Value::integer(p));
+        std::vector<std::string> names;
+        for (int it : V.cheaper) names.push_back(B->it_names[it]);
+        std::sort(names.begin(), names.end());
+        Value nj = Value::array();
+        for (auto& nm : names) nj.push(Value::string(nm));
+        rj.set("instanceTypes", nj);
+        rj.set("capacityType", V.pin_spot ? Value::string("spot") : Value());
+        repl.push(rj);
+      }
+      decisions.push(Value::integer(V.decision)); scheduled.push(Value::boolean(V.all_ok)); n_claims_j.push(Value::integer(V.live));
       status_j.push(Value::integer(res.status[p])); refs.push(Value::integer((int64_t)res.ref_bin_evaluations[p]));
       if (detail) {
         // where every pod of the probe went: uid -> claim index (>= 0), node name, or null
@@ -2198,6 +2266,10 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
     tj.set("descriptors_ms", Value::number(ms(t_begin, t_desc))); tj.set("sweep_ms", Value::number(ms(t_desc, t_solved))); tj.set("verdicts_ms", Value::number(ms(t_solved, t_end)));
     tj.set("upload_us", Value::number(res.us_upload)); tj.set("pack_us", Value::number(res.us_pack)); tj.set("finalize_us", Value::number(res.us_finalize)); tj.set("download_us", Value::number(res.us_download));
     tj.set("probes", Value::integer(n)); tj.set("pods", Value::integer((int64_t)pods.size()));
+    tj.set("bin_evaluations", Value::integer((int64_t)res.total_bin_evaluations)); tj.set("node_evaluations", Value::integer((int64_t)res.total_node_evaluations));
+    tj.set("node_block_steps", Value::integer((int64_t)res.total_node_block_steps));
+    tj.set("req_words", Value::integer(kd.req_words)); tj.set("resources", Value::integer(n_res)); tj.set("classes", Value::integer((int64_t)res.n_classes));
+    tj.set("it_words", Value::integer((int64_t)res.it_words)); tj.set("nodes", Value::integer((int64_t)res.n_nodes)); tj.set("node_dead0_us", Value::number(res.us_node_dead0));
     out.set("timings", tj);
     release(&res);
     return dup_json(out);

@@ -157,7 +157,15 @@ class Scheduler:
         filterOutSameInstanceType (multinodeconsolidation.go:209-246)."""
         if not self._session:
             raise RuntimeError("scheduler is closed")
-        doc = {"candidates": candidates, "detail": bool(detail), "multiNode": bool(multi_node)}
+        if candidates and all(isinstance(x, int) for cs in candidates for x in cs):
+            # positions in the stateNodes list: handed over as two flat arrays (CSR), not as ten thousand little lists
+            off, flat = [0], []
+            for cs in candidates:
+                flat += cs
+                off.append(len(flat))
+            doc = {"candidateOff": off, "candidateNodes": flat, "detail": bool(detail), "multiNode": bool(multi_node)}
+        else:
+            doc = {"candidates": candidates, "detail": bool(detail), "multiNode": bool(multi_node)}
         if prices is not None:      # None: the library takes every candidate's price and capacity type from its own node table
             doc.update(prices=prices, allSpot=all_spot)
         doc = json.dumps(doc).encode()

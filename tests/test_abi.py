@@ -32,7 +32,7 @@ def test_libksolve_exports_every_declared_symbol(built):
     for f in declared_functions():
         assert hasattr(lib, f), f
     lib.ksolve_abi_version.restype = ctypes.c_uint32
-    assert lib.ksolve_abi_version() == 7
+    assert lib.ksolve_abi_version() == 8
     assert not hasattr(lib, "ksolve_is_emulation")  # the product library is the HIP build, never the test emulation
 
 
@@ -71,7 +71,7 @@ def test_header_is_plain_c(tmp_path):
     import subprocess
     probe = tmp_path / "probe.c"
     probe.write_text('#include <stdio.h>\n#include "ksolve.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(ksolve_problem_desc), '
-                     'sizeof(ksolve_topology), sizeof(ksolve_reqsets), sizeof(ksolve_options), sizeof(ksolve_claims), sizeof(ksolve_results)); return KSOLVE_ABI_VERSION == 7 ? 0 : 1; }\n')
+                     'sizeof(ksolve_topology), sizeof(ksolve_reqsets), sizeof(ksolve_options), sizeof(ksolve_claims), sizeof(ksolve_results)); return KSOLVE_ABI_VERSION == 8 ? 0 : 1; }\n')
     inc = os.path.join(ROOT, "include")
     sizes = []
     for cc, std, exe in (("gcc", "-std=c99", "probe_c"), ("g++", "-std=c++17", "probe_cpp")):
