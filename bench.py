@@ -362,6 +362,14 @@ def main():
     t_full = time.perf_counter()
     full = sched.Solve(want_results=True)
     t_full = time.perf_counter() - t_full
+    # ... and re-hydrated the way a caller that keeps its pods by position does it (the cgo shim: go/ksolve_rehydrate.go walks
+    # pod_assignment / pod_slot; here Scheduler.PodsByClaim): the NodeClaims as objects + two flat arrays, no uid text
+    t_pos = time.perf_counter()
+    by_pos = sched.Solve(want_results="claims")
+    pods_of = sched.PodsByClaim(len(by_pos["newNodeClaims"]))
+    t_pos = time.perf_counter() - t_pos
+    if [len(x) for x in pods_of] != [len(c["pods"]) for c in full["newNodeClaims"]]:
+        raise SystemExit("bench.py: re-hydration by position disagrees with the Results document")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity   # canonical Results digest (shared with the tests; does not touch oracle/)
     digest, _ = parity.results_digest(full)
@@ -580,9 +588,12 @@ def main():
         # (scheduler.go:453-455). Here: NewScheduler (the host library parses the problem document — pods arrive as a few hundred
         # groups, which spares JSON, not flattening: every pod becomes a row —, flattens, ksolve_create uploads), one timed solve, and
         # a solve that also rehydrates every NodeClaim and pod assignment into the Results document.
-        "end_to_end": {"new_scheduler_s": t_open, "upload_ms": timings[0].get("upload_us", 0.0) * 1e-3, "solve_s": elapsed / args.steps, "solve_and_rehydrate_s": t_full,
-                       "pods_per_s_through_the_boundary": scheduled / world / (t_open + t_full),
-                       "note": "rank 0's problem; flatten + upload + solve + download + rehydration, nothing overlapped"},
+        "end_to_end": {"new_scheduler_s": t_open, "upload_ms": timings[0].get("upload_us", 0.0) * 1e-3, "solve_s": elapsed / args.steps,
+                       "solve_and_rehydrate_by_position_s": t_pos, "pods_per_s_through_the_boundary": scheduled / world / (t_open + t_pos),
+                       "solve_and_rehydrate_uid_text_s": t_full, "pods_per_s_with_uid_text": scheduled / world / (t_open + t_full),
+                       "note": "rank 0's problem; flatten (a few host threads) + upload + solve + download + re-hydration, nothing overlapped. by_position: NodeClaims as objects, "
+                               "every pod put on its NodeClaim from the flat pod_assignment / pod_slot arrays (what the cgo shim does); uid_text: the Results document with "
+                               "a million uid strings formatted by the host library and parsed by Python"},
         "phases_ms": {k: sum(t.get(k, 0.0) for t in timings) / len(timings) for k in ("pack_kernel_ms", "classify_ms", "row_hash_ms", "sort_ms", "it_index_ms")},
         "counters": c,
     }

@@ -189,6 +189,21 @@ struct Dictionary {
 };
 
 // A table of requirement sets under construction (host memory, ABI layout).
+// fn(i) for i in [0, n) on a few threads, contiguous ranges (the probes of a sweep are independent — descriptors, verdicts — and so
+// are the rows of a million pods)
+template <class F>
+static void parallel_for(size_t n, F fn) {
+  const size_t nt = n < 1024 ? 1 : std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency()));
+  if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+  std::vector<std::thread> pool;
+  std::vector<std::string> errors(nt);
+  for (size_t t = 0; t < nt; ++t) pool.emplace_back([&, t]() {
+    try { for (size_t i = n * t / nt, e = n * (t + 1) / nt; i < e; ++i) fn(i); } catch (const std::exception& e) { errors[t] = e.what(); }
+  });
+  for (auto& th : pool) th.join();
+  for (auto& e : errors) if (!e.empty()) throw std::runtime_error(e);
+}
+
 struct ReqTableBuilder {
   int n = 0, req_words = 0, n_keys = 0;
   std::vector<uint64_t> mask;
@@ -202,6 +217,11 @@ struct ReqTableBuilder {
     mask.assign((size_t)n * rw, 0); defined.assign(n, 0); complement.assign(n, 0); has_gte.assign(n, 0); has_lte.assign(n, 0);
     gte.clear(); lte.clear(); minv.clear();
     if (!lazy_columns) { gte.assign((size_t)n * nk, 0); lte.assign((size_t)n * nk, 0); minv.assign((size_t)n * nk, -1); }
+  }
+  // the lazily created columns up front (put() from several threads must not be the one that creates them)
+  void ensure_columns(bool bounds, bool min_values) {
+    if (bounds && gte.empty()) { gte.assign((size_t)n * n_keys, 0); lte.assign((size_t)n * n_keys, 0); }
+    if (min_values && minv.empty()) minv.assign((size_t)n * n_keys, -1);
   }
   void put(int e, const ks::ReqBuf& b) {
     for (int w = 0; w < req_words; ++w) mask[(size_t)e * req_words + w] = b.mask[w];
@@ -587,6 +607,8 @@ static char* error_json(const char* kind, const std::string& msg) {
 }
 
 extern "C" void ksched_free(char* p) { free(p); }
+struct Session;
+extern "C" uint32_t ksched_assignment(void* session, int32_t* assign, uint32_t* slot, uint32_t capacity);
 
 // A problem flattened and resident on the device: what NewScheduler returns.
 constexpr long long kMaxPodsPerProblem = 1ll << 24;
@@ -611,6 +633,8 @@ struct Session {
   // sweeps of a resident cluster (ksched_sweep): which node every pod sits on, the verdict inputs computeConsolidation needs
   std::vector<int32_t> pod_node;           // existing node (sorted order) a pod is bound to, -1 = pending / on a deleting node: part of every simulation
   std::vector<uint8_t> pod_pending_flag, pod_deleting_flag;
+  std::vector<int32_t> last_assign;      // want_results 2: the flat per-pod outputs of the last solve, for ksched_assignment
+  std::vector<uint32_t> last_slot;
   std::vector<uint32_t> node_pod_off, node_pod_list, always_pods;   // CSR of the pods on each node; built on the first sweep
   std::vector<int32_t> node_input_index;   // position in the problem's stateNodes list -> sorted node index
   std::vector<int32_t> node_it;            // instance type of each existing node (its node.kubernetes.io/instance-type label), -1 = unknown
@@ -803,12 +827,15 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       if (bound && (long long)gnode.size() != cnt) throw std::runtime_error("podGroups[].nodeIndex must have one entry per pod");
       // one Solve() of the reference handles a batch of pending pods; 16M pods is 16x the largest BASELINE configuration
       if (cnt > kMaxPodsPerProblem || (long long)pod_spec.size() + cnt > kMaxPodsPerProblem) throw Unsupported("more than 16777216 pods in one problem");
-      for (long long i = 0; i < cnt; ++i) {
+      const size_t at = pod_spec.size();
+      pod_spec.resize(at + (size_t)cnt, si); uid_hi.resize(at + (size_t)cnt); uid_lo.resize(at + (size_t)cnt); uid_text.resize(at + (size_t)cnt);
+      group_of_pod.resize(at + (size_t)cnt); pod_node_input.resize(at + (size_t)cnt, -1);
+      parallel_for((size_t)cnt, [&](size_t i) {
         uint64_t hi, lo;
         group_uid(seed, (uint64_t)i, hi, lo, nullptr);
-        pod_spec.push_back(si); uid_hi.push_back(hi); uid_lo.push_back(lo); uid_text.push_back(std::string()); group_of_pod.push_back({seed, (uint64_t)i});
-        pod_node_input.push_back(bound ? (int)gnode[(size_t)i] : -1);
-      }
+        uid_hi[at + i] = hi; uid_lo[at + i] = lo; group_of_pod[at + i] = {seed, (uint64_t)i};
+        if (bound) pod_node_input[at + i] = (int)gnode[i];
+      });
     }
     const int n_pods = (int)pod_spec.size();
     if (!all_uuid) {
@@ -1396,15 +1423,21 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     }
     vol_reqs.init((int)vol_sets.size(), rw, nk);
     for (size_t i = 0; i < vol_sets.size(); ++i) vol_reqs.put((int)i, vol_sets[i]);
-    for (int p = 0; p < n_pods; ++p) {
-      int si = pod_spec[p];
+    {
+      bool bounds = false, minv = false;
+      for (auto& ev : enc) for (auto& e : ev) { bounds = bounds || ((e.reqs.has_gte | e.reqs.has_lte | e.strict.has_gte | e.strict.has_lte) != 0); minv = minv || e.reqs.has_minv || e.strict.has_minv; }
+      pod_reqs.ensure_columns(bounds, minv);
+      if (strict_differs) pod_strict.ensure_columns(bounds, minv);
+    }
+    parallel_for((size_t)n_pods, [&](size_t pp) {     // every pod's row is its spec's encoding: independent writes
+      const int p = (int)pp, si = pod_spec[p];
       put_row(p, enc[si][0]);
       pod_hp[p] = spec_hp[si]; pod_hpc[p] = spec_hpc[si];
       if (any_volume) { pod_vol_first[p] = spec_vol_first[si]; pod_vol_count[p] = spec_vol_count[si]; }
       pod_next[p] = spec_first_extra[si];
       pod_creation[p] = specs[si].creation;
       pod_pending[p] = specs[si].pending ? 1 : 0;
-    }
+    });
     for (size_t si = 0; si < specs.size(); ++si) if (spec_first_extra[si] >= 0)
       for (size_t vi = 1; vi < ladders[si].size(); ++vi) {
         int row = spec_first_extra[si] + (int)vi - 1;
@@ -1987,20 +2020,6 @@ extern "C" void* ksched_probe(void* base_session, const char* probe_json) {
 // computeConsolidation's verdict (consolidation.go:159-256): delete when no NodeClaim is needed, replace when exactly one is
 // and a cheaper instance type remains after the price filter (nodeclaim.go:411-420), otherwise nothing. The probe descriptors
 // are built here (CSR arrays over the session's node -> pods tables), not in the caller's language. Returns one document.
-// fn(i) for i in [0, n) on a few threads (the probes of a sweep are independent: their descriptors and verdicts are too)
-template <class F>
-static void parallel_for(size_t n, F fn) {
-  const size_t nt = n < 1024 ? 1 : std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency()));
-  if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
-  std::vector<std::thread> pool;
-  std::vector<std::string> errors(nt);
-  for (size_t t = 0; t < nt; ++t) pool.emplace_back([&, t]() {
-    try { for (size_t i = n * t / nt, e = n * (t + 1) / nt; i < e; ++i) fn(i); } catch (const std::exception& e) { errors[t] = e.what(); }
-  });
-  for (auto& th : pool) th.join();
-  for (auto& e : errors) if (!e.empty()) throw std::runtime_error(e);
-}
-
 extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
   Session* B = (Session*)base_session;
   if (!B || !B->handle || B->base) return error_json("invalid", "sweep needs an open base session");
@@ -2277,6 +2296,17 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
     return error_json("invalid", e.what());
   }
 }
+// The flat per-pod outputs of the session's last Solve(want_results = 2): pod i (position in the problem: the explicit pods, then
+// the groups' pods in order) sits in slot[i] of NodeClaim assign[i] (>= 0: index into newNodeClaims), of existing node -2 - assign[i],
+// or nowhere (-1). Returns the number of pods (copies min(capacity, pods) entries).
+extern "C" uint32_t ksched_assignment(void* session, int32_t* assign, uint32_t* slot, uint32_t capacity) {
+  Session* S = (Session*)session;
+  if (!S) return 0;
+  const uint32_t n = (uint32_t)S->last_assign.size(), m = std::min(n, capacity);
+  if (assign && m) memcpy(assign, S->last_assign.data(), (size_t)m * 4);
+  if (slot && m) memcpy(slot, S->last_slot.data(), (size_t)m * 4);
+  return n;
+}
 extern "C" void ksched_close(void* session) {
   Session* S = (Session*)session;
   if (!S) return;
@@ -2359,13 +2389,20 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
     { int64_t there = 0; for (size_t e = 0; e < S->node_names.size(); ++e) if (node_there(e)) there++; counters.set("existingNodes", Value::integer(there)); }
     out.set("scheduledPods", Value::integer((own->base ? own->probe_pods : n_pods) - unscheduled));
     if (want_results) {
-      std::vector<std::vector<std::pair<uint32_t, int>>> members(cl.n_claims);
+      std::vector<std::vector<std::pair<uint32_t, int>>> members(want_results == 1 ? cl.n_claims : 0);
+      std::vector<uint32_t> member_count(cl.n_claims, 0);
       std::vector<std::vector<std::pair<uint32_t, int>>> node_members(S->node_names.size());
       Value errs = Value::object();
+      if (want_results == 2) {
+        // the claims without their pod lists: the per-pod outputs stay flat (ksched_assignment hands them over as two arrays —
+        // a caller that holds its pods by position needs no uid text to put them on their NodeClaims)
+        own->last_assign.assign(res.pod_assignment, res.pod_assignment + n_pods);
+        own->last_slot.assign(res.pod_slot, res.pod_slot + n_pods);
+      }
       for (int p = 0; p < n_pods; ++p) {
         if (!in_probe(p)) continue;
         int a = res.pod_assignment[p];
-        if (a >= 0) members[a].push_back({res.pod_slot[p], p});
+        if (a >= 0) { member_count[a]++; if (want_results == 1) members[a].push_back({res.pod_slot[p], p}); }
         else if (a <= -2) node_members[-2 - a].push_back({res.pod_slot[p], p});
         else { Value e = Value::object(); e.set("code", Value::integer(res.pod_error[p])); e.set("diag", Value::integer(res.pod_error_diag[p])); errs.add_new(uid_of(p), e); }
       }
@@ -2377,11 +2414,10 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
         char hb[64];
         snprintf(hb, sizeof hb, "hostname-placeholder-%04u", cl.hostname_seq[c]);
         cj.set("hostname", Value::string(hb));
-        std::sort(members[c].begin(), members[c].end());
         Value pj = Value::array();
-        if (want_results == 1) for (auto& m : members[c]) pj.push(Value::string(uid_of(m.second)));   // want_results 2: the claims without their pod lists
+        if (want_results == 1) { std::sort(members[c].begin(), members[c].end()); for (auto& m : members[c]) pj.push(Value::string(uid_of(m.second))); }   // want_results 2: the claims without their pod lists
         cj.set("pods", pj);
-        cj.set("podCount", Value::integer((int64_t)members[c].size()));
+        cj.set("podCount", Value::integer((int64_t)member_count[c]));
         Value itj = Value::array();
         if (cl.ordered_instance_types) {   // Results.TruncateInstanceTypes: price order, capped (scheduler.go:419-437)
           for (uint32_t i = 0; i < cl.ordered_count[c]; ++i) itj.push(Value::string(S->it_names[cl.ordered_instance_types[(size_t)c * cl.n_instance_types + i]]));

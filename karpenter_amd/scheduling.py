@@ -63,6 +63,8 @@ def _load_ksched():
         lib.ksched_probe.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
         lib.ksched_sweep.restype = ctypes.c_void_p
         lib.ksched_sweep.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        lib.ksched_assignment.restype = ctypes.c_uint32
+        lib.ksched_assignment.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         _ksched = lib
     return _ksched
 
@@ -204,6 +206,28 @@ class Scheduler:
         out["timings"] = timings
         return Results(out)
 
+
+    def Assignment(self):
+        """The per-pod outputs of the last Solve(want_results="claims") as two numpy arrays over the problem's pods in input order
+        (explicit pods, then the groups' pods): assign[i] >= 0 is an index into newNodeClaims, <= -2 the existing node -2 - assign[i],
+        -1 unscheduled; slot[i] is the pod's position in that NodeClaim's / node's Pods slice. This is what a caller that keeps
+        its pods by position re-hydrates from — no uid text is formatted or parsed for it."""
+        import numpy as np
+        n = self._lib.ksched_assignment(self._session, None, None, 0)
+        assign, slot = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.uint32)
+        if n:
+            self._lib.ksched_assignment(self._session, assign.ctypes.data, slot.ctypes.data, n)
+        return assign, slot
+
+    def PodsByClaim(self, n_claims: int):
+        """NodeClaim.Pods for every new NodeClaim of the last Solve(want_results="claims"), as arrays of pod positions in slot order
+        (the order the reference appended them in, nodeclaim.go:248)."""
+        import numpy as np
+        assign, slot = self.Assignment()
+        on_claims = np.nonzero(assign >= 0)[0]
+        order = on_claims[np.lexsort((slot[on_claims], assign[on_claims]))]
+        bounds = np.searchsorted(assign[order], np.arange(n_claims + 1))
+        return [order[bounds[c]:bounds[c + 1]] for c in range(n_claims)]
 
     def Cancel(self) -> None:
         """The ctx deadline of Solve (scheduler.go:477-480, provisioner.go:427): call from another thread while Solve()

@@ -1135,3 +1135,23 @@ def test_undefined_key_revival_fuzz(oracle, emu):
         placed = {u for c in got["newNodeClaims"] for u in c["pods"]} | {u for e in got["existingNodes"] for u in e["pods"]}
         revived += sum(1 for p in pods if p["uid"] in placed and any(r["operator"] in ("In", "Exists", "Gt") and r["key"] in keys for term in (p.get("nodeAffinity") or {}).get("required", []) for r in term))
     assert revived > 20     # positive operators on an undefined custom key got a bin: only possible through a key that became defined
+
+
+def test_rehydration_by_position_equals_the_results_document(oracle, emu):
+    """Scheduler.Assignment / PodsByClaim (ksched_assignment): the flat pod_assignment / pod_slot arrays of a Solve(want_results=
+    "claims") put every pod on the same NodeClaim, in the same slot, as the Results document with its uid lists — with existing
+    nodes and an unschedulable pod in the problem."""
+    import numpy as np
+    prob = fx.config2(pods=6000, n_types=144, seed=11)
+    prob["pods"] = [fx.pod(uid="00000000-0000-0000-0000-00000000dead", requests={"cpu": "4000"})]      # fits nothing
+    s = NewScheduler(prob, solver_lib=emu)
+    full = s.Solve()
+    lean = s.Solve(want_results="claims")
+    assert [c["podCount"] for c in lean["newNodeClaims"]] == [len(c["pods"]) for c in full["newNodeClaims"]] and not any(c["pods"] for c in lean["newNodeClaims"])
+    uids = [p["uid"] for p in prob["pods"]] + [fx.group_pod_uid(g["uidSeed"], i) for g in prob["podGroups"] for i in range(g["count"])]
+    by = s.PodsByClaim(len(lean["newNodeClaims"]))
+    assert [[uids[i] for i in pods] for pods in by] == [c["pods"] for c in full["newNodeClaims"]]
+    assign, _ = s.Assignment()
+    assert assign[0] == -1 and list(full["podErrors"]) == [uids[0]] and int((assign == -1).sum()) == 1
+    s.close()
+    parity.assert_same_results(full, oracle.solve(prob))
