@@ -28,6 +28,7 @@ import (
 	"context"
 	"errors"
 	"fmt"
+	"math"
 	"math/big"
 	"sort"
 	"strconv"
@@ -336,18 +337,23 @@ type flatProblem struct {
 	its       []*cloudprovider.InstanceType // catalogue order = instance-type key dictionary
 	templates []*NodeClaimTemplate
 	nodes     []*ExistingNode
+	// resident clusters (ksolve_sweep.go): the StateNode name every pod row is bound to ("" = pending); nil otherwise
+	boundTo []string
 }
 
 func (f *flatProblem) free() { f.arena.free() }
 
 // flatten encodes scheduler s (already assembled by NewScheduler) and the pods of this Solve().
 // nolint:gocyclo
-func flatten(ctx context.Context, s *Scheduler, pods []*corev1.Pod, maxSteps int64) (*flatProblem, error) {
+func flatten(ctx context.Context, s *Scheduler, pods []*corev1.Pod, maxSteps int64, boundTo ...[]string) (*flatProblem, error) {
 	if s.allocator != nil {
 		return nil, fmt.Errorf("%w: dynamic resource allocation", ErrKSolveUnsupported)
 	}
 	f := &flatProblem{dict: &dictionary{keyIndex: map[string]int{}}, qty: &quantities{index: map[corev1.ResourceName]int{}}, pods: pods,
 		templates: s.nodeClaimTemplates, nodes: s.existingNodes}
+	if len(boundTo) == 1 {
+		f.boundTo = boundTo[0] // a resident cluster: the topology tables then count the bound pod rows too (flattenTopology)
+	}
 	d, q := f.dict, f.qty
 	a := &f.arena
 	q.dim(corev1.ResourceCPU)    // dimension 0 and 1 are what the queue sorts on (queue.go:72-90)
@@ -1107,6 +1113,119 @@ func flattenTopology(ctx context.Context, f *flatProblem, s *Scheduler, rows []p
 		}
 	}
 	filterFirst[G] = uint32(len(filterReqs.defined))
+	// ---- resident clusters: what NewTopology would have counted had the bound pod rows not been "pods being scheduled" ----
+	// s.topology was assembled with every pod of f.pods in excludedPods (topology.go:92-94), so g.domains misses the bound
+	// rows. A probe of the sweep takes ITS displaced pods out again; for that the base must count them all (countDomains,
+	// topology.go:361-459, restated over the rows), know which domains the NodePools / instance types offer by themselves
+	// (domain_universe: ForEachDomain, topologydomaingroup.go:61-72) and how many nodes register each domain
+	// (domain_node_regs: the loop over t.stateNodes, topology.go:376-392). The C++ twin: karpenter_amd/host/ksched.cpp.
+	var universe []uint64
+	var nodeRegs []int32
+	if f.boundTo != nil {
+		universe, nodeRegs = make([]uint64, G*domainWords), make([]int32, G*domainWords*64)
+		nodeByName := map[string]int{}
+		for e, n := range f.nodes {
+			nodeByName[n.Name()] = e
+		}
+		nodeReqs := make([]scheduling.Requirements, E)
+		for e, n := range f.nodes {
+			nodeReqs[e] = scheduling.NewLabelRequirements(n.Labels())
+		}
+		for i, e := range all {
+			g := e.g
+			matches := make([]int8, E) // TopologyNodeFilter.Matches per node, evaluated once: 0 unknown, 1 yes, -1 no
+			nodeMatches := func(en int) bool {
+				if matches[en] == 0 {
+					matches[en] = -1
+					if g.nodeFilter.Matches(f.nodes[en].Taints(), nodeReqs[en]) {
+						matches[en] = 1
+					}
+				}
+				return matches[en] == 1
+			}
+			if g.Key != corev1.LabelHostname {
+				k := d.keyIndex[g.Key]
+				probe := &corev1.Pod{Spec: corev1.PodSpec{Tolerations: g.nodeFilter.Tolerations}}
+				s.topology.domainGroups[g.Key].ForEachDomain(probe, g.nodeFilter.TaintPolicy, func(dom string) {
+					if v, ok := d.valIndex[k][dom]; ok {
+						universe[i*domainWords+v/64] |= 1 << uint(v%64)
+					}
+				})
+				for en, n := range f.nodes { // the nodes that register a domain (topology.go:376-392)
+					if n.Node == nil || !nodeMatches(en) {
+						continue
+					}
+					if dom, ok := n.Labels()[g.Key]; ok {
+						if v, ok := d.valIndex[k][dom]; ok {
+							nodeRegs[(i*domainWords)*64+v]++
+						}
+					}
+				}
+			}
+			if e.inverse {
+				continue // inverse groups count their OWNERS' domains: below
+			}
+			for r, p := range f.pods { // the bound rows this group selects (TopologyListOptions + countDomains' loop)
+				if f.boundTo[r] == "" || IgnoredForTopology(p) || !g.selects(p) {
+					continue
+				}
+				en, ok := nodeByName[f.boundTo[r]]
+				if !ok {
+					continue
+				}
+				dom, ok := f.nodes[en].Labels()[g.Key]
+				if !ok && g.Key == corev1.LabelHostname {
+					dom, ok = f.nodes[en].Name(), true
+				}
+				if !ok || !nodeMatches(en) {
+					continue
+				}
+				if g.Key == corev1.LabelHostname {
+					nodeCounts[i*max(E, 1)+en]++
+				} else {
+					k := d.keyIndex[g.Key]
+					v := d.valIndex[k][dom]
+					domains[i*domainWords+v/64] |= 1 << uint(v%64)
+					counts[(i*domainWords)*64+v]++
+				}
+			}
+		}
+		// inverse anti-affinity groups: every bound row that OWNS a required anti-affinity term blocks its node's domain
+		// (updateInverseAffinities / updateInverseAntiAffinity with the node's labels, topology.go:310-355)
+		for r, p := range f.pods {
+			if f.boundTo[r] == "" || IgnoredForTopology(p) || p.Spec.Affinity == nil || p.Spec.Affinity.PodAntiAffinity == nil {
+				continue
+			}
+			en, ok := nodeByName[f.boundTo[r]]
+			if !ok {
+				continue
+			}
+			for _, term := range p.Spec.Affinity.PodAntiAffinity.RequiredDuringSchedulingIgnoredDuringExecution {
+				namespaces, err := s.topology.buildNamespaceList(ctx, p.Namespace, term.Namespaces, term.NamespaceSelector)
+				if err != nil {
+					return fmt.Errorf("%w: %v", ErrKSolveUnsupported, err)
+				}
+				tg := NewTopologyGroup(TopologyTypePodAntiAffinity, term.TopologyKey, p, namespaces, term.LabelSelector, math.MaxInt32, nil, nil, nil, s.topology.domainGroups[term.TopologyKey])
+				g, ok := s.topology.inverseTopologyGroups[tg.Hash()]
+				if !ok {
+					continue
+				}
+				i := index[g]
+				dom, ok := f.nodes[en].Labels()[g.Key]
+				if !ok {
+					continue
+				}
+				if g.Key == corev1.LabelHostname {
+					nodeCounts[i*max(E, 1)+en]++
+				} else {
+					k := d.keyIndex[g.Key]
+					v := d.valIndex[k][dom]
+					domains[i*domainWords+v/64] |= 1 << uint(v%64)
+					counts[(i*domainWords)*64+v]++
+				}
+			}
+		}
+	}
 	// value ranks: ties between domains go to the lexicographically smallest name (the reference's tie is a Go map order)
 	rank := make([]uint16, d.reqWords()*64)
 	for k := range d.keys {
@@ -1154,6 +1273,9 @@ func flattenTopology(ctx context.Context, f *flatProblem, s *Scheduler, rows []p
 	t.key, t.max_skew, t.min_domains = cI32(a, key), cI32(a, skew), cI32(a, minDom)
 	t.domain_words = C.uint32_t(domainWords)
 	t.domains, t.init_counts = cU64(a, domains), cI32(a, counts)
+	if universe != nil {
+		t.domain_universe, t.domain_node_regs = cU64(a, universe), cI32(a, nodeRegs)
+	}
 	if E > 0 {
 		t.init_node_counts = cI32(a, nodeCounts)
 		t.node_hostname_value = cI32(a, hostValue)

@@ -16,11 +16,12 @@
 // Added to pkg/controllers/provisioning/scheduling next to ksolve_shim.go. The C++ twin of this file is
 // karpenter_amd/host/ksched.cpp (ksched_sweep), which is what this repository's tests and bench.py drive.
 //
-// Scope of THIS file: clusters whose Scheduler carries no topology groups. With topology groups the resident base needs the
-// counts of NewTopology over every bound pod plus the domain universe / node registrations apart (ksolve_topology.
-// domain_universe / domain_node_regs; karpenter_amd/host/ksched.cpp builds them under options.residentCluster); until the Go
-// flattener does the same NewResidentCluster returns ErrKSolveUnsupported for such clusters and the caller keeps calling
-// SimulateScheduling per candidate set.
+// Clusters whose pods carry topology constraints sweep the same way (round 4): the resident base counts every bound pod row into
+// its groups and hands the domain universe / node registrations apart (ksolve_topology.domain_universe / domain_node_regs, built
+// by flattenTopology when flatten() is told which node every row is bound to); a probe then takes its candidates' share out of
+// its own copy of the counters on the device (include/ksolve.h, ksolve_probe_create). Every bound pod of a candidate must be
+// among `pods`: a pod that a PodDisruptionBudget holds back stays counted under its node in the reference (helpers.go:86-95) —
+// keep such a candidate out of the sweep and simulate it with SimulateScheduling.
 //
 // NOT COMPILED IN THIS REPOSITORY'S IMAGE (no Go toolchain, SURVEY.md §8c).
 package scheduling
@@ -57,10 +58,10 @@ type ResidentCluster struct {
 // being deleted: part of every simulation). The caller builds that list once from the candidates' reschedulable pods
 // (helpers.go:63-101 does it per call).
 func NewResidentCluster(ctx context.Context, s *Scheduler, pods []*corev1.Pod, boundTo []string) (*ResidentCluster, error) {
-	if len(s.topology.topologyGroups) != 0 || len(s.topology.inverseTopologyGroups) != 0 {
-		return nil, fmt.Errorf("%w: a resident cluster with topology groups (see the header of ksolve_sweep.go)", ErrKSolveUnsupported)
+	if len(boundTo) != len(pods) {
+		return nil, fmt.Errorf("NewResidentCluster: %d pods, %d bindings", len(pods), len(boundTo))
 	}
-	flat, err := flatten(ctx, s, pods, -1)
+	flat, err := flatten(ctx, s, pods, -1, boundTo)
 	if err != nil {
 		return nil, err
 	}
