@@ -405,6 +405,12 @@ typedef struct {
  * retried at half its size. The function's status is that of the call (arguments, device); each simulation's own
  * status is in results.status. */
 ksolve_status ksolve_sweep(ksolve_handle* base, const ksolve_sweep_desc* desc, ksolve_sweep_results* out);
+/* The same sweep over several devices of the node in one call: `bases` are handles created from ONE resident-cluster problem with
+ * different ksolve_options.device (replicas; nothing is exchanged between devices). The probes are cut into contiguous shares of
+ * about equal displaced-pod counts, every device runs its share (one host thread, one or several launches each), the results
+ * come back in probe order exactly as ksolve_sweep(bases[0], ...) would have produced them; the timings are those of the slowest
+ * device. For a one-process caller that owns all GPUs of the node (BASELINE configs[4] on 8 x MI355X without a collective). */
+ksolve_status ksolve_sweep_replicas(ksolve_handle** bases, uint32_t n_bases, const ksolve_sweep_desc* desc, ksolve_sweep_results* out);
 void ksolve_sweep_results_free(ksolve_sweep_results* r);
 /* The north_star's global packing summary: per instance type, how many of the NodeClaims of `results` launch on it and their
  * $/h (a claim launches on the instance type with its cheapest compatible available offering — OrderByPrice's key,

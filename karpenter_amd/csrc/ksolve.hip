@@ -752,6 +752,12 @@ ksolve_status ksolve_sweep(ksolve_handle* base, const ksolve_sweep_desc* desc, k
   if (hipSetDevice(HB(base)->device) != hipSuccess) return KSOLVE_ERR_DEVICE;
   return ksi::sweep(base, desc, out);
 }
+ksolve_status ksolve_sweep_replicas(ksolve_handle** bases, uint32_t n_bases, const ksolve_sweep_desc* desc, ksolve_sweep_results* out) {
+  if (!bases || !n_bases || !out) return KSOLVE_ERR_INVALID;
+  for (uint32_t i = 0; i < n_bases; ++i) if (!bases[i] || !bases[i]->backend) return KSOLVE_ERR_INVALID;
+  if (hipSetDevice(HB(bases[0])->device) != hipSuccess) return KSOLVE_ERR_DEVICE;
+  return ksi::sweep_replicas(bases, n_bases, desc, out);
+}
 void ksolve_sweep_results_free(ksolve_sweep_results* r) { if (r && r->impl) { delete (ksi::SweepImpl*)r->impl; r->impl = nullptr; } }
 ksolve_status ksolve_solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) {
   if (!hs || !outs || n == 0) return KSOLVE_ERR_INVALID;

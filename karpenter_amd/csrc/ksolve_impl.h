@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <array>
 #include <thread>
 #include <vector>
 
@@ -1411,6 +1412,7 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
 
 // Sweeps whose workspaces would not fit a sensible arena (a cluster with hostname topology groups needs a per-node counter table
 // per probe) run as several launches; the results are those of one.
+static void sweep_append(SweepImpl* im, const SweepImpl& part, uint32_t m);
 // Bytes of arena probe p of a sweep needs: sweep_run's layout() written out per probe (its share of the per-pod and per-claim
 // regions + its own workspace), every region rounded up as take() rounds it.
 static size_t sweep_probe_bytes(const ksolve_handle* base, uint32_t m, size_t pv_entries, bool with_limits) {
@@ -1491,16 +1493,7 @@ static ksolve_status sweep_run_chunked(ksolve_handle* base, uint32_t n, const ui
 #endif
     lo += m;
     for (int k = 0; k < 4; ++k) total_us[k] += u[k];
-    auto app = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
-    app(im->status, part.status); app(im->assign, part.assign); app(im->err, part.err); app(im->diag, part.diag); app(im->slot, part.slot);
-    app(im->ref, part.ref); app(im->counters, part.counters);
-    const uint32_t c0 = im->claim_off.back();
-    for (uint32_t i = 1; i <= m; ++i) im->claim_off.push_back(c0 + part.claim_off[i]);
-    ResultsImpl& R = im->claims; const ResultsImpl& Q = part.claims;
-    app(R.tmpl, Q.tmpl); app(R.npods, Q.npods); app(R.its, Q.its); app(R.mask, Q.mask); app(R.defined, Q.defined); app(R.complement, Q.complement);
-    app(R.has_gte, Q.has_gte); app(R.has_lte, Q.has_lte); app(R.gte, Q.gte); app(R.lte, Q.lte); app(R.minv, Q.minv); app(R.requests, Q.requests);
-    app(R.host_seq, Q.host_seq); app(R.relaxed, Q.relaxed); app(R.cheapest, Q.cheapest); app(R.reserved, Q.reserved);
-    app(R.t_idx, Q.t_idx); app(R.t_cnt, Q.t_cnt); app(R.t_fail, Q.t_fail);
+    sweep_append(im, part, m);
   }
   if (us) for (int k = 0; k < 4; ++k) us[k] = total_us[k];
   return KSOLVE_OK;
@@ -1544,6 +1537,94 @@ static ksolve_status sweep(ksolve_handle* base, const ksolve_sweep_desc* d, ksol
   out->ref_bin_evaluations = im->ref.data();
   out->us_upload = us[0]; out->us_pack = us[1]; out->us_finalize = us[2]; out->us_download = us[3];
   out->n_classes = base->n_classes; out->us_node_dead0 = base->dead0_us; out->it_words = base->it_words; out->n_nodes = base->n_nodes;
+  for (auto& c : im->counters) { out->total_bin_evaluations += c.bin_evaluations; out->total_node_evaluations += c.node_evaluations; out->total_node_block_steps += c.node_block_steps; }
+  out->impl = im;
+  return KSOLVE_OK;
+}
+
+// Appends the results of the probes of `part` behind those already in `im` (chunks of one sweep, shares of several devices).
+static void sweep_append(SweepImpl* im, const SweepImpl& part, uint32_t m) {
+  auto app = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
+  app(im->status, part.status); app(im->assign, part.assign); app(im->err, part.err); app(im->diag, part.diag); app(im->slot, part.slot);
+  app(im->ref, part.ref); app(im->counters, part.counters);
+  const uint32_t c0 = im->claim_off.back();
+  for (uint32_t i = 1; i <= m; ++i) im->claim_off.push_back(c0 + part.claim_off[i]);
+  ResultsImpl& R = im->claims; const ResultsImpl& Q = part.claims;
+  app(R.tmpl, Q.tmpl); app(R.npods, Q.npods); app(R.its, Q.its); app(R.mask, Q.mask); app(R.defined, Q.defined); app(R.complement, Q.complement);
+  app(R.has_gte, Q.has_gte); app(R.has_lte, Q.has_lte); app(R.gte, Q.gte); app(R.lte, Q.lte); app(R.minv, Q.minv); app(R.requests, Q.requests);
+  app(R.host_seq, Q.host_seq); app(R.relaxed, Q.relaxed); app(R.cheapest, Q.cheapest); app(R.reserved, Q.reserved);
+  app(R.t_idx, Q.t_idx); app(R.t_cnt, Q.t_cnt); app(R.t_fail, Q.t_fail);
+}
+
+// ksolve_sweep_replicas: ONE sweep over several devices. `bases` are resident-cluster handles created from the SAME problem on
+// different devices (ksolve_options.device; the cluster tables are replicated — 0.6 GB at 100k nodes / 2M pods against 288 GB of
+// HBM per device — so that no probe needs anything from another device). The probes are cut into contiguous shares of about equal
+// displaced-pod counts, every device runs its share on its own host thread (one or several launches), and the results come back
+// in probe order as if one device had run them all: a one-process caller (the Go controller that owns the node's eight GPUs)
+// needs no collective for configs[4]. SimulateScheduling per probe: disruption/helpers.go:53-155.
+static ksolve_status sweep_replicas(ksolve_handle** bases, uint32_t nb, const ksolve_sweep_desc* d, ksolve_sweep_results* out) {
+  if (nb == 1) return sweep(bases[0], d, out);
+  memset(out, 0, sizeof(*out));
+  ksolve_handle* b0 = bases[0];
+  for (uint32_t g = 0; g < nb; ++g) {
+    ksolve_handle* b = bases[g];
+    if (!b || b->base) return fail(b0, KSOLVE_ERR_INVALID, "sweep over a null handle / a probe");
+    if (b->n_pods != b0->n_pods || b->n_nodes != b0->n_nodes || b->n_templates != b0->n_templates || b->n_res != b0->n_res || b->n_its != b0->n_its || b->req_words != b0->req_words)
+      return fail(b0, KSOLVE_ERR_INVALID, "the handles of a replicated sweep must be replicas of one problem");
+    if (b->has_topology && !b->resident) return fail(b0, KSOLVE_ERR_UNSUPPORTED, "sweeps of a problem with topology groups need a resident-cluster base");
+  }
+  if (!d || (d->n_probes && (!d->node_off || !d->pod_off || (d->pod_off[d->n_probes] && !d->pods) || (d->node_off[d->n_probes] && !d->nodes))))
+    return fail(b0, KSOLVE_ERR_INVALID, "sweep descriptor arrays missing");
+  const uint32_t n = d->n_probes;
+  for (uint32_t p = 0; p < n; ++p)
+    if (d->node_off[p + 1] < d->node_off[p] || d->pod_off[p + 1] < d->pod_off[p]) return fail(b0, KSOLVE_ERR_INVALID, "sweep descriptor offsets must not decrease");
+  // contiguous shares of about equal work (displaced pods + one per probe)
+  std::vector<uint32_t> cut(nb + 1, n);
+  cut[0] = 0;
+  {
+    const uint64_t total = (uint64_t)d->pod_off[n] + n;
+    uint32_t p = 0;
+    for (uint32_t g = 1; g < nb; ++g) {
+      const uint64_t want = total * g / nb;
+      while (p < n && (uint64_t)d->pod_off[p] + p < want) ++p;
+      cut[g] = p;
+    }
+  }
+  const size_t lsz = (size_t)b0->n_templates * (b0->n_res + 1);
+  std::vector<SweepImpl> parts(nb);
+  std::vector<ksolve_status> rc(nb, KSOLVE_OK);
+  std::vector<std::array<double, 4>> uss(nb);
+  std::vector<std::thread> pool;
+  for (uint32_t g = 0; g < nb; ++g) pool.emplace_back([&, g]() {
+    const uint32_t lo = cut[g], m = cut[g + 1] - lo;
+    uss[g] = {0, 0, 0, 0};
+    if (!m) { parts[g].claim_off.assign(1, 0); return; }
+    ksolve_handle* b = bases[g];
+    be_thread_init(b);
+    std::vector<uint32_t> no(m + 1), po(m + 1);
+    for (uint32_t i = 0; i <= m; ++i) { no[i] = d->node_off[lo + i] - d->node_off[lo]; po[i] = d->pod_off[lo + i] - d->pod_off[lo]; }
+    std::vector<const int64_t*> lims(m, nullptr);
+    if (d->tmpl_limits) for (uint32_t i = 0; i < m; ++i) lims[i] = d->tmpl_limits + (size_t)(lo + i) * lsz;
+    be_fill(b, b->d_cancel, 0, 4);
+    be_sync(b);
+    rc[g] = sweep_run_chunked(b, m, no.data(), d->nodes + d->node_off[lo], po.data(), d->pods + d->pod_off[lo], d->tmpl_limits ? lims.data() : nullptr, nullptr, &parts[g], uss[g].data());
+  });
+  for (auto& th : pool) th.join();
+  for (uint32_t g = 0; g < nb; ++g) if (rc[g] != KSOLVE_OK) return fail(b0, rc[g], "device " + std::to_string(g) + " of the sweep: " + bases[g]->error);
+  SweepImpl* im = new SweepImpl();
+  im->claim_off.assign(1, 0);
+  for (uint32_t g = 0; g < nb; ++g) if (cut[g + 1] > cut[g]) sweep_append(im, parts[g], cut[g + 1] - cut[g]);
+  out->n_probes = n;
+  out->status = im->status.data();
+  out->pod_assignment = im->assign.data(); out->pod_error = im->err.data(); out->pod_error_diag = im->diag.data(); out->pod_slot = im->slot.data();
+  out->claim_off = im->claim_off.data();
+  fill_claims_view(b0, im->claims, 0, im->claim_off[n], out->claims);
+  out->ref_bin_evaluations = im->ref.data();
+  for (uint32_t g = 0; g < nb; ++g) {   // the devices run side by side: the call takes as long as the slowest
+    out->us_upload = std::max(out->us_upload, uss[g][0]); out->us_pack = std::max(out->us_pack, uss[g][1]);
+    out->us_finalize = std::max(out->us_finalize, uss[g][2]); out->us_download = std::max(out->us_download, uss[g][3]);
+  }
+  out->n_classes = b0->n_classes; out->us_node_dead0 = b0->dead0_us; out->it_words = b0->it_words; out->n_nodes = b0->n_nodes;
   for (auto& c : im->counters) { out->total_bin_evaluations += c.bin_evaluations; out->total_node_evaluations += c.node_evaluations; out->total_node_block_steps += c.node_block_steps; }
   out->impl = im;
   return KSOLVE_OK;

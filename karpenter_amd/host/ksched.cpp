@@ -2020,11 +2020,29 @@ extern "C" void* ksched_probe(void* base_session, const char* probe_json) {
 // computeConsolidation's verdict (consolidation.go:159-256): delete when no NodeClaim is needed, replace when exactly one is
 // and a cheaper instance type remains after the price filter (nodeclaim.go:411-420), otherwise nothing. The probe descriptors
 // are built here (CSR arrays over the session's node -> pods tables), not in the caller's language. Returns one document.
+static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas, const char* sweep_json);
 extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
   Session* B = (Session*)base_session;
   if (!B || !B->handle || B->base) return error_json("invalid", "sweep needs an open base session");
+  return sweep_impl(B, {}, sweep_json);
+}
+// The same sweep spread over several devices: `sessions` were opened from ONE cluster document with different options.device
+// (replicas); the first one supplies the descriptor / verdict tables, ksolve_sweep_replicas deals the probes out.
+extern "C" char* ksched_sweep_replicas(void** sessions, int n, const char* sweep_json) {
+  if (!sessions || n < 1) return error_json("invalid", "sweep needs at least one open base session");
+  std::vector<ksolve_handle*> hs;
+  for (int i = 0; i < n; ++i) {
+    Session* S = (Session*)sessions[i];
+    if (!S || !S->handle || S->base) return error_json("invalid", "sweep needs open base sessions");
+    hs.push_back(S->handle);
+  }
+  return sweep_impl((Session*)sessions[0], hs, sweep_json);
+}
+static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas, const char* sweep_json) {
   try {
     auto run = (decltype(&ksolve_sweep))dlsym(B->api.lib, "ksolve_sweep");
+    auto run_replicas = (decltype(&ksolve_sweep_replicas))dlsym(B->api.lib, "ksolve_sweep_replicas");
+    if (replicas.size() > 1 && !run_replicas) return error_json("load", "solver library lacks ksolve_sweep_replicas");
     auto release = (decltype(&ksolve_sweep_results_free))dlsym(B->api.lib, "ksolve_sweep_results_free");
     if (!run || !release) return error_json("load", "solver library lacks ksolve_sweep");
     const auto t_begin = std::chrono::steady_clock::now();
@@ -2123,7 +2141,7 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
     sd.tmpl_limits = limits ? lims.data() : nullptr;
     const auto t_desc = std::chrono::steady_clock::now();
     ksolve_sweep_results res{};
-    ksolve_status st = run(B->handle, &sd, &res);
+    ksolve_status st = replicas.size() > 1 ? run_replicas(const_cast<ksolve_handle**>(replicas.data()), (uint32_t)replicas.size(), &sd, &res) : run(B->handle, &sd, &res);
     const auto t_solved = std::chrono::steady_clock::now();
     if (st != KSOLVE_OK) return error_json(st == KSOLVE_ERR_UNSUPPORTED ? "unsupported" : st == KSOLVE_ERR_CAPACITY ? "capacity" : "solve", B->api.last_error(B->handle));
 
@@ -2284,7 +2302,7 @@ extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     tj.set("descriptors_ms", Value::number(ms(t_begin, t_desc))); tj.set("sweep_ms", Value::number(ms(t_desc, t_solved))); tj.set("verdicts_ms", Value::number(ms(t_solved, t_end)));
     tj.set("upload_us", Value::number(res.us_upload)); tj.set("pack_us", Value::number(res.us_pack)); tj.set("finalize_us", Value::number(res.us_finalize)); tj.set("download_us", Value::number(res.us_download));
-    tj.set("probes", Value::integer(n)); tj.set("pods", Value::integer((int64_t)pods.size()));
+    tj.set("probes", Value::integer(n)); tj.set("pods", Value::integer((int64_t)pods.size())); tj.set("devices", Value::integer((int64_t)std::max<size_t>(1, replicas.size())));
     tj.set("bin_evaluations", Value::integer((int64_t)res.total_bin_evaluations)); tj.set("node_evaluations", Value::integer((int64_t)res.total_node_evaluations));
     tj.set("node_block_steps", Value::integer((int64_t)res.total_node_block_steps));
     tj.set("req_words", Value::integer(kd.req_words)); tj.set("resources", Value::integer(n_res)); tj.set("classes", Value::integer((int64_t)res.n_classes));

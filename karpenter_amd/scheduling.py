@@ -63,6 +63,8 @@ def _load_ksched():
         lib.ksched_probe.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
         lib.ksched_sweep.restype = ctypes.c_void_p
         lib.ksched_sweep.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        lib.ksched_sweep_replicas.restype = ctypes.c_void_p
+        lib.ksched_sweep_replicas.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_char_p]
         lib.ksched_assignment.restype = ctypes.c_uint32
         lib.ksched_assignment.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         _ksched = lib
@@ -148,7 +150,7 @@ class Scheduler:
         self._probes.append(probe)
         return probe
 
-    def Sweep(self, candidates, prices=None, all_spot=None, detail=False, multi_node=False) -> dict:
+    def Sweep(self, candidates, prices=None, all_spot=None, detail=False, multi_node=False, replicas=()) -> dict:
         """A whole consolidation sweep of a RESIDENT cluster in one call (ksolve_sweep; disruption/helpers.go:53-155 +
         consolidation.go:159-256 per candidate set): `candidates` = one list of nodes (names, or positions in the problem's
         stateNodes list) per simulation, `prices` the summed candidate prices, `all_spot` whether every candidate is a spot
@@ -156,7 +158,9 @@ class Scheduler:
         simulation is one wavefront of one launch, the verdicts (0 no-op, 1 delete, 2 replace) come back with the replacement
         instance types of the replace commands. detail=True adds where every pod went (tests). multi_node=True: the sets are
         prefixes of MultiNodeConsolidation's binary search, a replace verdict over several candidates is filtered by
-        filterOutSameInstanceType (multinodeconsolidation.go:209-246)."""
+        filterOutSameInstanceType (multinodeconsolidation.go:209-246). replicas: Schedulers opened from the same cluster document on
+        OTHER devices (options.device): the probes are dealt out over all of them inside the call (ksolve_sweep_replicas), the
+        results are those of one device."""
         if not self._session:
             raise RuntimeError("scheduler is closed")
         if candidates and all(isinstance(x, int) for cs in candidates for x in cs):
@@ -171,7 +175,11 @@ class Scheduler:
         if prices is not None:      # None: the library takes every candidate's price and capacity type from its own node table
             doc.update(prices=prices, allSpot=all_spot)
         doc = json.dumps(doc).encode()
-        ptr = self._lib.ksched_sweep(self._session, doc)
+        if replicas:
+            sessions = (ctypes.c_void_p * (1 + len(replicas)))(self._session, *[r._session for r in replicas])
+            ptr = self._lib.ksched_sweep_replicas(sessions, 1 + len(replicas), doc)
+        else:
+            ptr = self._lib.ksched_sweep(self._session, doc)
         try:
             out = json.loads(ctypes.string_at(ptr).decode())
         finally:

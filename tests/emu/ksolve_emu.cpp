@@ -152,6 +152,7 @@ ksolve_status ksolve_probe_create(ksolve_handle* base, const ksolve_probe* probe
 }
 ksolve_status ksolve_solve(ksolve_handle* h, ksolve_results* out) { return ksi::solve(h, out); }
 ksolve_status ksolve_sweep(ksolve_handle* base, const ksolve_sweep_desc* desc, ksolve_sweep_results* out) { return ksi::sweep(base, desc, out); }
+ksolve_status ksolve_sweep_replicas(ksolve_handle** bases, uint32_t n_bases, const ksolve_sweep_desc* desc, ksolve_sweep_results* out) { return (bases && n_bases && out) ? ksi::sweep_replicas(bases, n_bases, desc, out) : KSOLVE_ERR_INVALID; }
 void ksolve_sweep_results_free(ksolve_sweep_results* r) { if (r && r->impl) { delete (ksi::SweepImpl*)r->impl; r->impl = nullptr; } }
 ksolve_status ksolve_solve_batch(ksolve_handle** hs, uint32_t n, ksolve_results* outs) { return ksi::solve_batch(hs, n, outs); }
 ksolve_status ksolve_packing_vector(const ksolve_handle* h, const ksolve_results* r, double* count, double* cost) { return ksi::packing_vector(h, r->claims, count, cost); }

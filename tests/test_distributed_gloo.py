@@ -148,3 +148,28 @@ def test_batch_over_two_devices_through_the_c_abi(oracle):
     assert np.array_equal(total[:, 0], want_total[:, 0]) and np.allclose(total[:, 1], want_total[:, 1], rtol=1e-12, atol=0)
     for s_ in scheds:
         s_.close()
+
+
+def test_sweep_over_replicas_on_several_devices():
+    """ksolve_sweep_replicas (BASELINE configs[4] for a one-process caller that owns several GPUs): three replicas of one resident
+    cluster on three "devices" of the emulation, single-node probes and multi-node prefixes dealt out in contiguous shares inside
+    the call — decisions, replacements, statuses and reference-equivalent evaluation counts come back in probe order exactly as
+    one device produces them, with and without topology constraints on the bound pods."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity
+    from karpenter_amd import disruption as dz
+    from karpenter_amd.scheduling import NewScheduler
+    emu = parity.build_emu()
+    for topology in (False, True):
+        cc = dz.make_resident_cluster(n_nodes=1500, seed=9, topology=topology)
+        scheds = [NewScheduler(dz.compact_problem(dict(cc, options={"device": dev}), pods=[]), solver_lib=emu) for dev in range(3)]
+        order = dz.compact_candidates(cc)[:200]
+        cands = [[i] for i in order] + [order[:k] for k in range(2, 30)]
+        one = scheds[0].Sweep(cands, multi_node=True)
+        many = scheds[0].Sweep(cands, multi_node=True, replicas=scheds[1:])
+        for k in ("decisions", "allNonPendingPodsScheduled", "claims", "status", "referenceBinEvaluations", "replacements", "reasons"):
+            assert one[k] == many[k], (topology, k)
+        assert many["timings"]["devices"] == 3 and len(set(one["decisions"])) == 3
+        for s in scheds:
+            s.close()
