@@ -176,8 +176,8 @@ def sweep_rooflines(tm, n_probes):
     ps = tm["pack_us"] * 1e-6
     out = {"ksolve_pack_sweep": {"bound": "latency per probe (one wavefront each), occupancy per sweep", "grid": f"{min(n_probes, 8192)} blocks of one wavefront", "probes": n_probes,
                                  "algorithmic_bytes": alg, "avg_kernel_ms": ps * 1e3, "achieved": alg / ps / 1e9 if ps > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": alg / ps / 1e9 / HBM_PEAK_GBS if ps > 0 else None, "traffic": pmc.get("ksolve_pack_sweep", {}).get("traffic_bytes_per_launch"),
-                                 "waves": pmc.get("ksolve_pack_sweep", {}).get("SQ_WAVES", {}).get("per_launch"),
+                                 "frac": alg / ps / 1e9 / HBM_PEAK_GBS if ps > 0 else None, "traffic": pmc.get("ksolve_pack_sweep", {}).get("traffic_bytes_largest_launch"),
+                                 "waves": pmc.get("ksolve_pack_sweep", {}).get("SQ_WAVES", {}).get("largest_launch"),
                                  "terms": {"displaced_pods": tm["pods"], "class_record_bytes": b_cls, "node_block_steps": tm["node_block_steps"], "nodes_evaluated": tm["node_evaluations"], "node_record_bytes": b_node,
                                            "claims_evaluated": claim_evals, "claim_record_bytes": b_claim}}}
     ds = tm.get("node_dead0_us", 0.0) * 1e-6
@@ -186,7 +186,7 @@ def sweep_rooflines(tm, n_probes):
         out["ksolve_node_dead0"] = {"bound": "compare throughput (classes x nodes tests; the node tables are streamed once per class from L2)", "grid": f"{(tm['nodes'] + 63) // 64} blocks of one wavefront",
                                     "class_node_tests": tm["classes"] * tm["nodes"], "tests_per_s": tm["classes"] * tm["nodes"] / ds,
                                     "algorithmic_bytes": alg0, "avg_kernel_ms": ds * 1e3, "achieved": alg0 / ds / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg0 / ds / 1e9 / HBM_PEAK_GBS,
-                                    "traffic": pmc.get("ksolve_node_dead0", {}).get("traffic_bytes_per_launch")}
+                                    "traffic": pmc.get("ksolve_node_dead0", {}).get("traffic_bytes_largest_launch")}
     return out
 
 

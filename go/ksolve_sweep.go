@@ -51,7 +51,13 @@ type ResidentCluster struct {
 	always   []uint32             // pod rows of every simulation: pending pods, pods of nodes that are being deleted (helpers.go:69-101)
 	limitCap map[uint32][]int64   // per existing node: what its NodePool gets back when the node goes (scheduler.go:835-842), [n_res+1]
 	nodeTmpl map[uint32]int       // per existing node: template (NodePool) index, -1 = a pool without limits
+	replicas []*ResidentCluster   // the same cluster on other devices (AddReplica): Sweep deals its probes out over all of them
 }
+
+// AddReplica registers `other` — NewResidentCluster of the same Scheduler and pods with another ksolve_options.device — as a
+// replica: Sweep then runs through ksolve_sweep_replicas, every device simulating a contiguous share of the candidate sets
+// (include/ksolve.h). The cluster tables are replicated (0.6 GB at 100k nodes / 2M pods), nothing crosses between devices.
+func (rc *ResidentCluster) AddReplica(other *ResidentCluster) { rc.replicas = append(rc.replicas, other) }
 
 // NewResidentCluster flattens `s` — the stock Scheduler assembled over ALL state nodes, no candidate taken out — together with
 // every pod some simulation may have to place: pods[i] runs on the node named boundTo[i] ("" = pending, or from a node that is
@@ -186,7 +192,17 @@ func (rc *ResidentCluster) Sweep(ctx context.Context, candidateSets [][]string) 
 	desc.tmpl_limits = cI64(&arena, limits)
 	var out C.ksolve_sweep_results
 	stop := watch(ctx, rc.p.handle)
-	st := C.ksolve_sweep(rc.p.handle, &desc, &out)
+	var st C.ksolve_status
+	if len(rc.replicas) == 0 {
+		st = C.ksolve_sweep(rc.p.handle, &desc, &out)
+	} else {
+		handles := (*[1 << 16]*C.ksolve_handle)(arena.bytes((1 + len(rc.replicas)) * int(unsafe.Sizeof(rc.p.handle))))
+		handles[0] = rc.p.handle
+		for i, r := range rc.replicas {
+			handles[1+i] = r.p.handle
+		}
+		st = C.ksolve_sweep_replicas(&handles[0], C.uint32_t(1+len(rc.replicas)), &desc, &out)
+	}
 	stop()
 	if st != C.KSOLVE_OK && st != C.KSOLVE_ERR_CANCELLED {
 		return nil, fmt.Errorf("ksolve_sweep: %s", C.GoString(C.ksolve_last_error(rc.p.handle)))

@@ -10,6 +10,7 @@
 //   ksolve_finalize      one thread per claim: cheapest compatible available offering
 // Each handle owns a stream; every phase is bracketed by HIP events recorded on that stream.
 #include <cstring>
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <rocprim/rocprim.hpp>
@@ -56,12 +57,31 @@ static void be_fill(ksolve_handle* h, void* dst, int byte, size_t bytes) {
 static void be_thread_init(ksolve_handle* h) { (void)hipSetDevice(HB(h)->device); }
 static void be_sync(ksolve_handle* h) { hip_check(h, hipStreamSynchronize(HB(h)->stream), "hipStreamSynchronize"); }
 static bool be_ok(ksolve_handle* h) { return !HB(h)->failed; }
-static void be_tic(ksolve_handle* h, int slot) { hip_check(h, hipEventRecord(HB(h)->ev0[slot], HB(h)->stream), "hipEventRecord"); }
+// Phase ranges for `rocprofv3 --marker-trace` (ROCTx; the reference's analogue is the pprof endpoint around its controllers,
+// pkg/operator/operator.go:209-224): every timed phase of a solve / sweep is a named range on the calling thread. The library is
+// looked up at run time — a box without libroctx64 runs without ranges.
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  RoctxApi() {
+    void* l = dlopen("libroctx64.so", RTLD_LAZY | RTLD_GLOBAL);
+    if (!l) l = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_GLOBAL);
+    if (l) { push = (int (*)(const char*))dlsym(l, "roctxRangePushA"); pop = (int (*)())dlsym(l, "roctxRangePop"); }
+    if (!push || !pop) { push = nullptr; pop = nullptr; }
+  }
+};
+static RoctxApi& roctx() { static RoctxApi r; return r; }
+static const char* const kPhaseRange[8] = {"ksolve:upload", "ksolve:instance_type_index / node_dead0", "ksolve:classing", "ksolve:queue_sort", "ksolve:pack", "ksolve:finalize", "ksolve:download", "ksolve:row_hash"};
+static void be_tic(ksolve_handle* h, int slot) {
+  if (roctx().push) roctx().push(kPhaseRange[slot & 7]);
+  hip_check(h, hipEventRecord(HB(h)->ev0[slot], HB(h)->stream), "hipEventRecord");
+}
 static void be_toc(ksolve_handle* h, int slot) {
   hip_check(h, hipEventRecord(HB(h)->ev1[slot], HB(h)->stream), "hipEventRecord");
   hip_check(h, hipEventSynchronize(HB(h)->ev1[slot]), "hipEventSynchronize");
   float ms = 0;
   if (hipEventElapsedTime(&ms, HB(h)->ev0[slot], HB(h)->ev1[slot]) == hipSuccess) h->timers.ms[slot] = ms;
+  if (roctx().pop) roctx().pop();
 }
 
 // ---- kernels ----

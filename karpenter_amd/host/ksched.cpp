@@ -1591,31 +1591,65 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         g.universe = g.domains;
         return g;
       };
-      // countDomains — topology.go:361-459
-      auto count_domains = [&](HGroup& g) {
+      // countDomains — topology.go:361-459. A resident cluster asks this of 100k nodes and 2M bound pods for every group (and once
+      // per disruption pass), so the per-node facts are worked out once and the counting itself runs on integers: the node's domain
+      // under a key as an id (per KEY), whether the node passes a group's node filter (per distinct FILTER), whether it has a Node.
+      struct KeyDomains { std::vector<int32_t> label_val, pod_val; std::vector<std::string> names; };   // pod_val: hostname falls back to the node's name (:438-442)
+      std::map<std::string, KeyDomains> key_domains;
+      auto domains_of_key = [&](const std::string& key) -> KeyDomains& {
+        auto f = key_domains.find(key);
+        if (f != key_domains.end()) return f->second;
+        KeyDomains& kd2 = key_domains[key];
+        kd2.label_val.assign(n_nodes, -1); kd2.pod_val.assign(n_nodes, -1);
+        std::unordered_map<std::string, int32_t> ids;
+        auto id_of = [&](const std::string& v) { auto r = ids.emplace(v, (int32_t)kd2.names.size()); if (r.second) kd2.names.push_back(v); return r.first->second; };
         for (int e = 0; e < n_nodes; ++e) {
-          if (!nodes[e].v->at("hasNode").boolean_or(true)) continue;
-          if (!filter_matches(g, node_taints[e], node_label_reqs[e])) continue;
-          auto it = node_labels[e].find(g.key);
-          if (it != node_labels[e].end()) { g.domains.insert(it->second); g.node_regs[it->second]++; }
+          auto it = node_labels[e].find(key);
+          if (it != node_labels[e].end()) kd2.label_val[e] = kd2.pod_val[e] = id_of(it->second);
+          else if (key == kHostname) kd2.pod_val[e] = id_of(nodes[e].name);
         }
+        return kd2;
+      };
+      std::vector<char> node_has_node(n_nodes, 1);
+      for (int e = 0; e < n_nodes; ++e) node_has_node[e] = nodes[e].v->at("hasNode").boolean_or(true) ? 1 : 0;
+      std::map<std::string, std::vector<char>> filter_verdicts;   // by what a node filter consists of
+      auto nodes_passing = [&](const HGroup& g) -> const std::vector<char>& {
+        std::string sig = g.taint_policy + "|" + g.affinity_policy + "|" + std::to_string(g.ftol) + "|";
+        for (auto& r : g.freqs) { for (auto& e : r) { sig += e.key + " " + e.op + " ["; for (auto& v : e.values) sig += v + ","; sig += "];"; } sig += "/"; }
+        auto f = filter_verdicts.find(sig);
+        if (f != filter_verdicts.end()) return f->second;
+        std::vector<char>& ok = filter_verdicts[sig];
+        ok.assign(n_nodes, 1);
+        if (g.taint_policy == "Honor" || (g.affinity_policy == "Honor" && !g.freqs.empty())) {
+          std::vector<ks::ReqBuf> enc_f;   // the filter's requirement sets, encoded once
+          for (auto& r : g.freqs) { ks::ReqBuf b; Flattener::clear(b); for (auto& e : r) { ks::ReqBuf one; fl.encode(e, one); ks::reqbuf_add(fl.kd, b, ks::reqbuf_ref_with_minv(one)); } enc_f.push_back(b); }
+          for (int e = 0; e < n_nodes; ++e) {
+            bool pass = !(g.taint_policy == "Honor" && (node_taints[e] & ~g.ftol));
+            if (pass && g.affinity_policy == "Honor" && !enc_f.empty()) {
+              pass = false;
+              for (auto& b : enc_f) if (ks::reqs_compatible(fl.kd, ks::reqbuf_ref_with_minv(node_label_reqs[e]), ks::reqbuf_ref_with_minv(b), false) == ks::COMPAT_OK) { pass = true; break; }
+            }
+            ok[e] = pass ? 1 : 0;
+          }
+        }
+        return ok;
+      };
+      auto count_domains = [&](HGroup& g) {
+        KeyDomains& kd2 = domains_of_key(g.key);
+        const std::vector<char>& node_ok = nodes_passing(g);
+        std::vector<int32_t> regs(kd2.names.size(), 0), cnt(kd2.names.size(), 0);
+        for (int e = 0; e < n_nodes; ++e) if (node_has_node[e] && node_ok[e] && kd2.label_val[e] >= 0) regs[kd2.label_val[e]]++;
         if (resident) {
           // the bound pod rows, spec by spec (a 2M-pod cluster is a few hundred specs)
-          std::vector<int8_t> node_ok(n_nodes, -1);
           for (size_t si = 0; si < specs.size(); ++si) {
             if (spec_bound_nodes[si].empty() || !g.namespaces.count(specs[si].ns) || (!g.sel.nil && !g.sel.matches(specs[si].labels))) continue;
             if (specs[si].phase == "Failed" || specs[si].phase == "Succeeded") continue;
-            for (int32_t e : spec_bound_nodes[si]) {
-              std::string dom;
-              auto it = node_labels[e].find(g.key);
-              if (it != node_labels[e].end()) dom = it->second;
-              else if (g.key == kHostname) dom = nodes[e].name;
-              else continue;
-              if (node_ok[e] < 0) node_ok[e] = filter_matches(g, node_taints[e], node_label_reqs[e]) ? 1 : 0;
-              if (!node_ok[e]) continue;
-              g.counts[dom]++; g.domains.insert(dom);
-            }
+            for (int32_t e : spec_bound_nodes[si]) { const int32_t v = kd2.pod_val[e]; if (v >= 0 && node_ok[e]) cnt[v]++; }
           }
+        }
+        for (size_t v = 0; v < regs.size(); ++v) {
+          if (regs[v]) { g.domains.insert(kd2.names[v]); g.node_regs[kd2.names[v]] += regs[v]; }
+          if (cnt[v]) { g.counts[kd2.names[v]] += cnt[v]; g.domains.insert(kd2.names[v]); }
         }
         for (auto& cp : cluster_pods) {
           if (!g.namespaces.count(cp.ns)) continue;
@@ -1753,6 +1787,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       int n_f = 0;
       for (auto& g : groups) n_f += (int)g.freqs.size();
       tg_freqs.init(std::max(1, n_f), rw, nk);
+      std::unordered_map<std::string, int> node_of_hostname;   // a hostname group of a 100k-node cluster counts pods on most of them
       int fi = 0;
       for (int gi = 0; gi < G; ++gi) {
         const HGroup& g = groups[gi];
@@ -1768,11 +1803,11 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
         }
         if (g.key == kHostname) {
           tg_key[gi] = -1;
+          if (node_of_hostname.empty()) for (int e = n_nodes - 1; e >= 0; --e) node_of_hostname[nodes[e].hostname] = e;   // the first node of a hostname wins, as the linear search it replaces did
           for (auto& kv : g.counts) {
-            int found = -1;
-            for (int e = 0; e < n_nodes; ++e) if (nodes[e].hostname == kv.first) { found = e; break; }
-            if (found < 0) throw Unsupported("pods counted on a hostname that is not a state node");
-            tg_node_counts[(size_t)gi * n_nodes + found] += kv.second;
+            auto f = node_of_hostname.find(kv.first);
+            if (f == node_of_hostname.end()) throw Unsupported("pods counted on a hostname that is not a state node");
+            tg_node_counts[(size_t)gi * n_nodes + f->second] += kv.second;
           }
           continue;
         }

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r4pmc
 mkdir -p $O
 HEAD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --topology-pods 0 --batch-problems 0 --components-pods 0 --sweep-nodes 0 --no-host-engine-baseline --no-cpu-baseline"
-SWEEP="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --pods 20000 --no-parity-pin --topology-pods 0 --batch-problems 0 --components-pods 0 --sweep-sample 0 --sweep-topology-sample 0 --sweep-windows 8 --no-host-engine-baseline --no-cpu-baseline"
+SWEEP="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --pods 20000 --no-parity-pin --topology-pods 0 --batch-problems 0 --components-pods 0 --sweep-sample 0 --sweep-topology-sample 0 --sweep-windows 0 --no-host-engine-baseline --no-cpu-baseline"
 (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_head -o bench -- $HEAD > $O/stats_head.log 2>&1)
 find $O/stats_head -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} cp {} $O/rocprofv3_kernel_stats_bench_1m.csv
 (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sweep -o bench -- $SWEEP > $O/stats_sweep.log 2>&1)
@@ -27,21 +27,26 @@ import bench
 O = sys.argv[1]
 def collect(leg):
     acc = collections.defaultdict(lambda: [0.0, 0])
+    big = collections.defaultdict(float)
     for tag in ("fetch", "write", "sq"):
         for f in glob.glob(f"{O}/pmc_{leg}_{tag}/**/*counter_collection*.csv", recursive=True):
             for r in csv.DictReader(open(f)):
                 k = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0].split("<")[0]
                 a = acc[(k, r["Counter_Name"])]
                 a[0] += float(r["Counter_Value"]); a[1] += 1
+                big[(k, r["Counter_Name"])] = max(big[(k, r["Counter_Name"])], float(r["Counter_Value"]))
     kernels = {}
     for (k, c), (v, n) in sorted(acc.items()):
         if "ksolve" in k:
-            kernels.setdefault(k, {})[c] = {"per_launch": v / n, "launches": n}
+            kernels.setdefault(k, {})[c] = {"per_launch": v / n, "launches": n, "largest_launch": big[(k, c)]}
     for k, d in kernels.items():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             d["traffic_bytes_per_launch"] = int(2 * d["FETCH_SIZE"]["per_launch"] * 1024 + d["WRITE_SIZE"]["per_launch"] * 1024)
+            # the command's launches of one kernel differ in size (a warm-up sweep of 64 probes before the 10k-probe one): the
+            # largest launch is the one the bench line times
+            d["traffic_bytes_largest_launch"] = int(2 * d["FETCH_SIZE"]["largest_launch"] * 1024 + d["WRITE_SIZE"]["largest_launch"] * 1024)
     return kernels
-out = {"source_sha": bench.source_sha(), "pods": 1000000, "types": 500, "command": "bench.py --steps 3 --warmup 1 (headline leg only); sweep_kernels: the configs[4] leg (100k nodes, 10k single-node probes + 8 windows of 100 prefixes)",
+out = {"source_sha": bench.source_sha(), "pods": 1000000, "types": 500, "command": "bench.py --steps 3 --warmup 1 (headline leg only); sweep_kernels: the configs[4] leg (100k nodes; a warm-up sweep of 64 probes, then the 10k single-node probes the bench line times = largest_launch)",
        "units": "FETCH_SIZE / WRITE_SIZE in KB per launch (rocprofv3 --pmc, separate passes); traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950); per_launch = mean over the launches of that kernel in the command",
        "kernels": collect("head"), "sweep_kernels": collect("sweep")}
 json.dump(out, open(f"{O}/pmc_traffic.json", "w"), indent=1)

@@ -440,7 +440,8 @@ def test_cancel_at_a_poll_boundary_on_the_device(monkeypatch, at):
     """A cancellation that lands at a poll boundary leaves exactly the full run stopped there (claim order included), on both
     engines: tests/test_device_algorithm.py::test_cancel_at_a_poll_boundary_is_the_full_run_stopped_there with libksolve.so."""
     import test_device_algorithm as tda
-    tda.test_cancel_at_a_poll_boundary_is_the_full_run_stopped_there(None, monkeypatch, at)
+    # KSOLVE_TEST_CANCEL_AT exists only in the gfx950 build with -DKSOLVE_TEST_HOOKS (the product binary reads no test switch)
+    tda.test_cancel_at_a_poll_boundary_is_the_full_run_stopped_there(parity.build_hooks(), monkeypatch, at)
 
 
 def test_volume_requirement_alternatives_and_complement_min_values_on_the_device(oracle):
