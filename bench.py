@@ -365,7 +365,7 @@ def main():
     # ... and re-hydrated the way a caller that keeps its pods by position does it (the cgo shim: go/ksolve_rehydrate.go walks
     # pod_assignment / pod_slot; here Scheduler.PodsByClaim): the NodeClaims as objects + two flat arrays, no uid text
     t_pos = time.perf_counter()
-    by_pos = sched.Solve(want_results="claims")
+    by_pos = sched.Solve(want_results="claims-compact")
     pods_of = sched.PodsByClaim(len(by_pos["newNodeClaims"]))
     t_pos = time.perf_counter() - t_pos
     if [len(x) for x in pods_of] != [len(c["pods"]) for c in full["newNodeClaims"]]:

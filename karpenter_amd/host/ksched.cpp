@@ -204,6 +204,14 @@ static void parallel_for(size_t n, F fn) {
   for (auto& e : errors) if (!e.empty()) throw std::runtime_error(e);
 }
 
+// UID texts of the explicit pods of a problem (they come first); the pods of a group have none — theirs are derived from
+// (seed, position) on demand — so a million group pods do not cost a million empty strings here and again in the session.
+struct UidTexts {
+  std::vector<std::string> explicit_;
+  const std::string& operator[](size_t p) const { static const std::string none; return p < explicit_.size() ? explicit_[p] : none; }
+  void push_back(const std::string& u) { explicit_.push_back(u); }
+};
+
 struct ReqTableBuilder {
   int n = 0, req_words = 0, n_keys = 0;
   std::vector<uint64_t> mask;
@@ -609,6 +617,7 @@ static char* error_json(const char* kind, const std::string& msg) {
 extern "C" void ksched_free(char* p) { free(p); }
 struct Session;
 extern "C" uint32_t ksched_assignment(void* session, int32_t* assign, uint32_t* slot, uint32_t capacity);
+extern "C" uint32_t ksched_pods_by_claim(void* session, uint32_t n_claims, uint32_t* claim_off, uint32_t* pods, uint32_t capacity);
 
 // A problem flattened and resident on the device: what NewScheduler returns.
 constexpr long long kMaxPodsPerProblem = 1ll << 24;
@@ -618,7 +627,8 @@ struct Session {
   ksolve_handle* handle = nullptr;
   Value root;
   Flattener fl;
-  std::vector<std::string> pool_names, uid_text, res_names, it_names, node_names;
+  std::vector<std::string> pool_names, res_names, it_names, node_names;
+  UidTexts uid_text;
   std::vector<uint8_t> node_initialized;
   std::vector<std::pair<uint64_t, uint64_t>> group_of_pod;
   std::vector<i128> scale;
@@ -800,7 +810,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     std::vector<PodSpec> specs;           // distinct pod templates (each explicit pod is its own spec)
     std::vector<int> pod_spec;            // per pod -> spec
     std::vector<uint64_t> uid_hi, uid_lo;
-    std::vector<std::string> uid_text;    // explicit pods only ("" for group pods: regenerated on demand)
+    UidTexts uid_text;    // explicit pods only (group pods: regenerated on demand)
     std::vector<std::pair<uint64_t, uint64_t>> group_of_pod;  // (seed, index) for group pods
     bool all_uuid = true;
     std::vector<int> pod_node_input;      // group pods bound to a node: index into the problem's stateNodes list, else -1
@@ -828,7 +838,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       // one Solve() of the reference handles a batch of pending pods; 16M pods is 16x the largest BASELINE configuration
       if (cnt > kMaxPodsPerProblem || (long long)pod_spec.size() + cnt > kMaxPodsPerProblem) throw Unsupported("more than 16777216 pods in one problem");
       const size_t at = pod_spec.size();
-      pod_spec.resize(at + (size_t)cnt, si); uid_hi.resize(at + (size_t)cnt); uid_lo.resize(at + (size_t)cnt); uid_text.resize(at + (size_t)cnt);
+      pod_spec.resize(at + (size_t)cnt, si); uid_hi.resize(at + (size_t)cnt); uid_lo.resize(at + (size_t)cnt);
       group_of_pod.resize(at + (size_t)cnt); pod_node_input.resize(at + (size_t)cnt, -1);
       parallel_for((size_t)cnt, [&](size_t i) {
         uint64_t hi, lo;
@@ -2360,6 +2370,27 @@ extern "C" uint32_t ksched_assignment(void* session, int32_t* assign, uint32_t* 
   if (slot && m) memcpy(slot, S->last_slot.data(), (size_t)m * 4);
   return n;
 }
+// NodeClaim.Pods of every new NodeClaim of the last Solve(want_results >= 2) as one CSR: pods[claim_off[c] .. claim_off[c + 1]) are
+// the positions of claim c's pods in slot order (the order the reference appended them in, nodeclaim.go:248). A pod's slot IS its
+// place inside its claim, so this is one counting pass and one scatter — no sort, no uid text. Returns the number of pods on
+// NodeClaims (fills at most `capacity` of them; claim_off has n_claims + 1 entries).
+extern "C" uint32_t ksched_pods_by_claim(void* session, uint32_t n_claims, uint32_t* claim_off, uint32_t* pods, uint32_t capacity) {
+  Session* S = (Session*)session;
+  if (!S || !claim_off) return 0;
+  const size_t n = S->last_assign.size();
+  for (uint32_t c = 0; c <= n_claims; ++c) claim_off[c] = 0;
+  for (size_t p = 0; p < n; ++p) { const int32_t a = S->last_assign[p]; if (a >= 0 && (uint32_t)a < n_claims) claim_off[(size_t)a + 1]++; }
+  for (uint32_t c = 0; c < n_claims; ++c) claim_off[c + 1] += claim_off[c];
+  const uint32_t total = claim_off[n_claims];
+  if (pods && total <= capacity)
+    for (size_t p = 0; p < n; ++p) {
+      const int32_t a = S->last_assign[p];
+      if (a < 0 || (uint32_t)a >= n_claims) continue;
+      const uint32_t at = claim_off[a] + S->last_slot[p];
+      if (at < claim_off[(size_t)a + 1]) pods[at] = (uint32_t)p;
+    }
+  return total;
+}
 extern "C" void ksched_close(void* session) {
   Session* S = (Session*)session;
   if (!S) return;
@@ -2381,7 +2412,7 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
   Dictionary& D = fl.dict;
   const int n_pods = S->n_pods, n_rows = S->n_rows, n_its = S->n_its, n_res = S->n_res, it_words = S->it_words;
   const int nk = fl.kd.n_keys, rw = fl.kd.req_words;
-  const std::vector<std::string>& uid_text = S->uid_text;
+  const UidTexts& uid_text = S->uid_text;
   const std::vector<std::pair<uint64_t, uint64_t>>& group_of_pod = S->group_of_pod;
   const std::vector<std::string>& res_names = S->res_names;
   const std::vector<i128>& scale = S->scale;
@@ -2446,7 +2477,7 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
       std::vector<uint32_t> member_count(cl.n_claims, 0);
       std::vector<std::vector<std::pair<uint32_t, int>>> node_members(S->node_names.size());
       Value errs = Value::object();
-      if (want_results == 2) {
+      if (want_results >= 2) {
         // the claims without their pod lists: the per-pod outputs stay flat (ksched_assignment hands them over as two arrays —
         // a caller that holds its pods by position needs no uid text to put them on their NodeClaims)
         own->last_assign.assign(res.pod_assignment, res.pod_assignment + n_pods);
@@ -2472,15 +2503,20 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
         cj.set("pods", pj);
         cj.set("podCount", Value::integer((int64_t)member_count[c]));
         Value itj = Value::array();
+        // want_results 3: the options as positions in the problem's instanceTypes list (a caller that holds the catalogue needs no
+        // names: 2,763 NodeClaims x a few hundred options are megabytes of repeated strings)
+        auto option = [&](int i) { return want_results == 3 ? Value::integer(i) : Value::string(S->it_names[i]); };
         if (cl.ordered_instance_types) {   // Results.TruncateInstanceTypes: price order, capped (scheduler.go:419-437)
-          for (uint32_t i = 0; i < cl.ordered_count[c]; ++i) itj.push(Value::string(S->it_names[cl.ordered_instance_types[(size_t)c * cl.n_instance_types + i]]));
+          for (uint32_t i = 0; i < cl.ordered_count[c]; ++i) itj.push(option((int)cl.ordered_instance_types[(size_t)c * cl.n_instance_types + i]));
         } else {
-          for (int i = 0; i < n_its; ++i) if ((cl.it_mask[(size_t)c * cl.it_words + i / 64] >> (i % 64)) & 1) itj.push(Value::string(S->it_names[i]));
+          for (int i = 0; i < n_its; ++i) if ((cl.it_mask[(size_t)c * cl.it_words + i / 64] >> (i % 64)) & 1) itj.push(option(i));
         }
-        cj.set("instanceTypes", itj);
+        cj.set(want_results == 3 ? "instanceTypeIndices" : "instanceTypes", itj);
         if (cl.truncation_failed && cl.truncation_failed[c]) {
           // the claim is dropped and its pods fail with the minValues error (scheduler.go:426-431)
-          for (auto& m : members[c]) { Value e = Value::object(); e.set("code", Value::integer(KSOLVE_POD_MIN_VALUES)); e.set("diag", Value::integer(128)); errs.add_new(uid_of(m.second), e); }
+          auto failed = [&](int p) { Value e = Value::object(); e.set("code", Value::integer(KSOLVE_POD_MIN_VALUES)); e.set("diag", Value::integer(128)); errs.add_new(uid_of(p), e); };
+          if (want_results == 1) for (auto& m : members[c]) failed(m.second);
+          else for (int p = 0; p < n_pods; ++p) if (in_probe(p) && res.pod_assignment[p] == (int)c) failed(p);
           continue;
         }
         Value rj = Value::array();

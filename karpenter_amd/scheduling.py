@@ -65,6 +65,8 @@ def _load_ksched():
         lib.ksched_sweep.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
         lib.ksched_sweep_replicas.restype = ctypes.c_void_p
         lib.ksched_sweep_replicas.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_char_p]
+        lib.ksched_pods_by_claim.restype = ctypes.c_uint32
+        lib.ksched_pods_by_claim.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         lib.ksched_assignment.restype = ctypes.c_uint32
         lib.ksched_assignment.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         _ksched = lib
@@ -87,7 +89,9 @@ class Results(dict):
 
 
 def _want(want_results):
-    return 2 if want_results == "claims" else (1 if want_results else 0)
+    # "claims": the NodeClaims without their pod lists; "claims-compact": ... and with instance type options as positions in the
+    # problem's instanceTypes list ("instanceTypeIndices") — both leave the pods to Scheduler.Assignment / PodsByClaim
+    return 3 if want_results == "claims-compact" else 2 if want_results == "claims" else (1 if want_results else 0)
 
 
 def _raise(kind, msg):
@@ -231,11 +235,12 @@ class Scheduler:
         """NodeClaim.Pods for every new NodeClaim of the last Solve(want_results="claims"), as arrays of pod positions in slot order
         (the order the reference appended them in, nodeclaim.go:248)."""
         import numpy as np
-        assign, slot = self.Assignment()
-        on_claims = np.nonzero(assign >= 0)[0]
-        order = on_claims[np.lexsort((slot[on_claims], assign[on_claims]))]
-        bounds = np.searchsorted(assign[order], np.arange(n_claims + 1))
-        return [order[bounds[c]:bounds[c + 1]] for c in range(n_claims)]
+        off = np.zeros(n_claims + 1, dtype=np.uint32)
+        total = self._lib.ksched_pods_by_claim(self._session, n_claims, off.ctypes.data, None, 0)
+        pods = np.empty(total, dtype=np.uint32)
+        if total:
+            self._lib.ksched_pods_by_claim(self._session, n_claims, off.ctypes.data, pods.ctypes.data, total)
+        return [pods[off[c]:off[c + 1]] for c in range(n_claims)]
 
     def Cancel(self) -> None:
         """The ctx deadline of Solve (scheduler.go:477-480, provisioner.go:427): call from another thread while Solve()
