@@ -107,7 +107,17 @@ def config4_sweep(args, device_index, rank, world, topology=False):
     rc.decisions(cands[:64])                       # warm-up: the arena, the per-cluster tables (ksolve_node_dead0)
     t = time.perf_counter(); cmds = rc.decisions(cands); dt = time.perf_counter() - t
     tm = rc.last_sweep["timings"]
+    first_call_s = (tm["descriptors_ms"] + tm["sweep_ms"] + tm["verdicts_ms"]) * 1e-3
+    # the sweep once more: the first call of this size also grows the arena the base handle keeps between sweeps (a device
+    # allocation of up to 4 GB); a disruption controller sweeps every pass and pays that once
+    t = time.perf_counter(); cmds2 = rc.decisions(cands); dt = min(dt, time.perf_counter() - t)
+    if [(c["decision"], c["replacement"]) for c in cmds2] != [(c["decision"], c["replacement"]) for c in cmds]:
+        raise SystemExit("bench.py: two sweeps of the same candidates disagree")
+    tm2 = rc.last_sweep["timings"]
+    if (tm2["descriptors_ms"] + tm2["sweep_ms"] + tm2["verdicts_ms"]) * 1e-3 <= first_call_s:
+        tm = tm2
     lib_s = (tm["descriptors_ms"] + tm["sweep_ms"] + tm["verdicts_ms"]) * 1e-3
+    out["first_call_s"] = first_call_s
     out.update(candidates=len(cands), decisions=dict(Counter(c["decision"] for c in cmds)), displaced_pods=tm["pods"],
                seconds={"descriptors": tm["descriptors_ms"] * 1e-3, "upload": tm["upload_us"] * 1e-6, "pack_kernel": tm["pack_us"] * 1e-6, "finalize": tm["finalize_us"] * 1e-6,
                         "download": tm["download_us"] * 1e-6, "verdicts": tm["verdicts_ms"] * 1e-3, "library_call": lib_s, "python_call": dt},
