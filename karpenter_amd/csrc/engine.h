@@ -547,24 +547,47 @@ struct Engine {
     if (v < 0) return open;
     return req_has(P.dict, pod, hn, P.dict.key_word_off[hn] + (uint32_t)(v >> 6), v & 63);
   }
-  KS_DEV int32_t* host_counter(int g, int bin_kind, int bin) const {
+  // Pods a hostname group counts on existing node e. Outside probes: the solve's own table. In a probe the cluster's counts stay
+  // SHARED and pristine (TopoView::node_counts0) like the node tables; the probe keeps what its commits add in the overlay slot of
+  // the node (tg_node_counts is [n_host_groups][ov_cap] there, zero at the start) — a single-node probe touches a handful of 100k
+  // nodes, and copying a counter per node and group into every probe made a 10k-probe sweep of a cluster with hostname groups
+  // 12 GB of arena. A removed node counts nothing: its pods are the displaced ones. Per lane.
+  KS_DEV int32_t node_host_count(int hs, int e) const {
+    if (!S.probe) return S.tg_node_counts[(size_t)hs * P.n_nodes + e];
+    if (probe_node_removed(e)) return 0;
+    int32_t c = P.topo.node_counts0[(size_t)hs * P.n_nodes + e];
+    const int os = ov_find(e);
+    if (os >= 0) c += S.tg_node_counts[(size_t)hs * S.ov_cap + os];
+    return c;
+  }
+  KS_DEV int32_t host_count(int g, int bin_kind, int bin) const {
     const int hs = P.topo.host_slot[g];
-    return bin_kind == 0 ? S.tg_claim_counts + (size_t)hs * S.max_claims + bin : S.tg_node_counts + (size_t)hs * P.n_nodes + bin;
+    return bin_kind == 0 ? S.tg_claim_counts[(size_t)hs * S.max_claims + bin] : node_host_count(hs, bin);
+  }
+  // Record: one more pod on the bin; returns the count before it (uniform)
+  KS_DEV int32_t host_count_add(int g, int bin_kind, int bin) {
+    const int hs = P.topo.host_slot[g];
+    if (bin_kind == 0) { int32_t* p = S.tg_claim_counts + (size_t)hs * S.max_claims + bin; const int32_t c = *p; W::store(p, c + 1); return c; }
+    if (!S.probe) { int32_t* p = S.tg_node_counts + (size_t)hs * P.n_nodes + bin; const int32_t c = *p; W::store(p, c + 1); return c; }
+    const int32_t before = node_host_count(hs, bin);
+    const int os = ov_touch(bin);    // the commit that records has touched the node already
+    int32_t* p = S.tg_node_counts + (size_t)hs * S.ov_cap + os;
+    W::store(p, *p + 1);
+    return before;
   }
   // anyCompatiblePodDomain for a hostname group — topologygroup.go:393-400
   KS_DEV bool topo_any_compatible_host(int g, const ReqRef& pod) {
     const int hs = P.topo.host_slot[g];
-    const int32_t* nc = S.tg_node_counts + (size_t)hs * P.n_nodes;
     const int32_t* cc = S.tg_claim_counts + (size_t)hs * S.max_claims;
     const int ne = P.n_nodes, ncl = n_claims;
-    if (W::find_first(0, ne, [&](int e) { return nc[e] > 0 && pod_has_host(pod, 1, e); }) < ne) return true;
+    if (W::find_first(0, ne, [&](int e) { return node_host_count(hs, e) > 0 && pod_has_host(pod, 1, e); }) < ne) return true;
     if (!pod_has_host(pod, 0, 0)) return false;
     return W::find_first(0, ncl, [&](int c) { return cc[c] > 0; }) < ncl;
   }
   // the hostname groups of the class on bin `bin` (-1 = a claim that does not exist yet: count 0)
   KS_DEV bool topo_hostname_ok(int g, bool self, const ReqRef& pod, int bin_kind, int bin) {
     const TopoView& T = P.topo;
-    const int cnt = bin >= 0 ? *host_counter(g, bin_kind, bin) : 0;
+    const int cnt = bin >= 0 ? host_count(g, bin_kind, bin) : 0;
     switch (T.type[g]) {
       case 0: return (long long)cnt + (self ? 1 : 0) <= (long long)T.max_skew[g];       // topologygroup.go:240-247
       case 2: return cnt == 0;                                                            // :409-414
@@ -767,9 +790,7 @@ struct Engine {
       if (!inv && !topo_filter_matches(g, taints, fin, bin_kind)) continue;
       const int key = T.key[g];
       if (key < 0) {
-        int32_t* p = host_counter(g, bin_kind, bin);
-        const int32_t c = *p;
-        W::store(p, c + 1);
+        const int32_t c = host_count_add(g, bin_kind, bin);
         if (c == 0) W::store(&S.tg_nonzero[g], S.tg_nonzero[g] + 1);
         if (bin_kind == 0 && T.type[g] != 1) {
           // threshold bitmaps of the scan prefilter: "count <= t-1" ends when the count reaches t, "count <= t" at t+1
@@ -1927,8 +1948,8 @@ struct Engine {
       for (int g = 0; g < G; ++g) {
         const int key = T.key[g];
         if (key < 0) {
-          int32_t* pc = S.tg_node_counts + (size_t)T.host_slot[g] * ne + e;
-          if (*pc > 0) { W::store(&S.tg_nonzero[g], S.tg_nonzero[g] - 1); W::store(pc, 0); W::sync(); }
+          // the removed node's counter leaves with it (node_host_count reads 0 for it from here on)
+          if (T.node_counts0[(size_t)T.host_slot[g] * ne + e] > 0) { W::store(&S.tg_nonzero[g], S.tg_nonzero[g] - 1); W::sync(); }
           continue;
         }
         if (!T.dom_regs0 || ((T.inverse_mask[g >> 6] >> (g & 63)) & 1)) continue;
@@ -2144,7 +2165,7 @@ struct Engine {
       const int G = T.n_groups, dv = T.dom_words * 64;
       W::for_n(G * T.dom_words, [&](int i) { Sw.tg_domains[i] = T.domains0[i]; });
       W::for_n(G * dv, [&](int i) { Sw.tg_counts[i] = T.counts0[i]; });
-      W::for_n(T.n_host_groups * P.n_nodes, [&](int i) { Sw.tg_node_counts[i] = T.node_counts0[i]; });
+      if (!S.probe) W::for_n(T.n_host_groups * P.n_nodes, [&](int i) { Sw.tg_node_counts[i] = T.node_counts0[i]; });   // probes: shared + overlay (node_host_count)
       W::for_n(G, [&](int i) { Sw.tg_nonzero[i] = T.nonzero0[i]; });
       W::for_n(T.words, [&](int w) { sc.t_active[w] = T.initially_active[w]; });
       W::for_n(T.n_alias, [&](int i) { Sw.tg_alias_active[i] = -1; });

@@ -1225,7 +1225,7 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
           const ks::TopoView& T = P.topo;
           const size_t G = (size_t)T.n_groups, dv = (size_t)T.dom_words * 64, hg = (size_t)std::max(1, T.n_host_groups);
           W.tg_domains = (uint64_t*)take(G * T.dom_words * 8); W.tg_counts = (int32_t*)take(G * dv * 4); W.tg_regs = (int32_t*)take(G * dv * 4);
-          W.tg_node_counts = (int32_t*)take(hg * std::max(1u, ne) * 4); W.tg_claim_counts = (int32_t*)take(hg * mc * 4);
+          W.tg_node_counts = (int32_t*)take(hg * oc * 4); W.tg_claim_counts = (int32_t*)take(hg * mc * 4);   // per overlay slot: what this probe's commits add to the cluster's shared per-node counts
           W.tg_nonzero = (int32_t*)take(G * 4); W.tg_alias_active = T.n_alias ? (int32_t*)take((size_t)T.n_alias * 4) : nullptr;
           W.c_keymask = (uint64_t*)take((size_t)std::max(1, T.n_key_slots) * mc * 8);
           W.kv_claims = (uint64_t*)take((size_t)std::max(1, T.n_key_slots) * 64 * cw * 8);
@@ -1437,7 +1437,7 @@ static size_t sweep_probe_bytes(const ksolve_handle* base, uint32_t m, size_t pv
     if (base->has_topology) {
       const ks::TopoView& Tv = P.topo;
       const size_t G = (size_t)Tv.n_groups, dv = (size_t)Tv.dom_words * 64, hg = (size_t)std::max(1, Tv.n_host_groups), ks_ = (size_t)std::max(1, Tv.n_key_slots);
-      b += r(G * Tv.dom_words * 8) + 2 * r(G * dv * 4) + r(hg * std::max<size_t>(1, ne) * 4) + r(hg * mc * 4) + r(G * 4) + (Tv.n_alias ? r((size_t)Tv.n_alias * 4) : 0);
+      b += r(G * Tv.dom_words * 8) + 2 * r(G * dv * 4) + r(hg * oc * 4) + r(hg * mc * 4) + r(G * 4) + (Tv.n_alias ? r((size_t)Tv.n_alias * 4) : 0);
       b += r(ks_ * mc * 8) + r(ks_ * 64 * cw * 8) + r(hg * 2 * cw * 8);
     }
     if (P.pv_on) b += r(std::max<size_t>(1, pv_entries) * 8);

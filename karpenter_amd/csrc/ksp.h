@@ -267,7 +267,7 @@ struct Workspace {
   // topology group state (TopologyGroup.domains / emptyDomains, topologygroup.go:74-76)
   uint64_t* tg_domains;          // [G][dom_words] registered domains (Record can add one, topologygroup.go:143-150)
   int32_t* tg_counts;            // [G][dom_words*64]
-  int32_t* tg_node_counts;       // [n_host_groups][n_nodes]      hostname groups: pods per existing node
+  int32_t* tg_node_counts;       // [n_host_groups][n_nodes]      hostname groups: pods per existing node (probes: [n_host_groups][ov_cap], what the probe adds to TopoView::node_counts0)
   int32_t* tg_claim_counts;      // [n_host_groups][max_claims]   hostname groups: pods per in-flight claim
   int32_t* tg_nonzero;           // [G] number of domains with a positive count
   int32_t* tg_alias_active;      // [n_alias] the member of each alias class that exists, -1 = none yet

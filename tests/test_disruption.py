@@ -777,3 +777,32 @@ def test_resident_cluster_probes_with_topology(oracle, emu, seed):
         parity.assert_same_results(g["results"], w["results"])
         assert strip(g) == strip(w)
     rc.close()
+
+
+@pytest.mark.parametrize("seed", [100, 103, 107])
+def test_probes_with_hostname_affinity_groups_and_shared_node_counters(oracle, emu, seed):
+    """Probes of a resident cluster keep the cluster's per-node counters of hostname groups SHARED (round 4: what a probe's commits
+    add lives in the overlay slot of the node, a removed node counts nothing) instead of copying a counter per node and group.
+    Every kind of hostname group is in the cluster — spread, anti-affinity, self-affinity (with its bootstrap and
+    anyCompatiblePodDomain, topologygroup.go:324-400) and affinity to another workload — and the verdict of every single-node probe
+    and of a few multi-node prefixes equals the oracle's own (simulation and decision)."""
+    import random
+    rng = random.Random(seed)
+    cluster = _topology_cluster(seed, n_nodes=30)
+    for n in cluster["nodes"]:
+        for p in n["pods"]:
+            if "topologySpreadConstraints" in p or "podAntiAffinity" in p or "podAffinity" in p:
+                continue
+            r = rng.random()
+            if r < 0.3:
+                p["labels"] = {"app": "pair"}; p["podAffinity"] = {"required": [fx.affinity_term(fx.HOSTNAME, {"app": "pair"})]}
+            elif r < 0.45:
+                p["labels"] = {"app": "follower"}; p["podAffinity"] = {"required": [fx.affinity_term(fx.HOSTNAME, {"app": "batch"})]}
+    cands = dz.sort_candidates(cluster, cluster["nodes"])[:12]
+    rc = dz.ResidentCluster(cluster, cands, solver_lib=emu)
+    sets = [[c] for c in cands] + [cands[:k] for k in (2, 3, 5)]
+    cmds = rc.decisions(sets, multi_node=True)
+    want = oracle.cluster_verdicts(cluster, sets, multi_node=True, well_known=fx.KWOK_WELL_KNOWN)
+    for i, (c, v) in enumerate(zip(cmds, want)):
+        assert (c["decision"], c["replacement"], c.get("replacementCapacityType")) == oracle.verdict_key(v), (seed, i, c, v)
+    rc.close()
