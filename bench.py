@@ -286,6 +286,8 @@ def main():
     ap.add_argument("--batch-pods", type=int, default=20_000, help="pods per problem of the batched measurement")
     ap.add_argument("--components-pods", type=int, default=10_000_000, help="BASELINE configs[3]: pods of the 16-NodePool batch solved as NodePool components (one block each, one launch), 0 = skip")
     ap.add_argument("--components-types", type=int, default=1000)
+    ap.add_argument("--whole-batch-pods", type=int, default=1_000_000, help="BASELINE configs[3] as ONE exact Solve() of the whole batch (all 16 NodePools in one claim order), "
+                    "digest-checked against the oracle's pin of that size when one is committed; 0 = skip. 10M pods take the general engine ~700 s (tests/tools/whole_batch_c3.py)")
     ap.add_argument("--components-calibration-pods", type=int, default=200_000, help="size at which the component split is compared with ONE Solve() of the whole batch (L2-canonical deltas)")
     ap.add_argument("--sweep-nodes", type=int, default=100_000, help="BASELINE configs[4]: existing nodes of the resident cluster swept by single-node consolidation (about 20 bound pods each), 0 = skip")
     ap.add_argument("--sweep-candidates", type=int, default=10_000, help="candidates (probes) per launch of the sweep")
@@ -470,6 +472,27 @@ def main():
                                           "vector": "count and $/h per instance type over all components" + (", summed over ranks with one all-reduce" if world > 1 else "")},
                     "parity": "each component bit-identical to the oracle on that component (tests); the union vs ONE Solve() of the whole batch: L2-canonical, see calibration",
                     "invariants": comp_inv}
+            if args.whole_batch_pods > 0 and world == 1:
+                # the same shape as ONE coupled problem: what the reference's Solve() computes for the whole batch, bit for bit
+                wp = fx.config4(pods=args.whole_batch_pods, n_types=args.components_types, n_pools=16, seed=42)
+                wp["options"]["device"] = device_index
+                sw = NewScheduler(wp, solver_lib=args.solver_lib)
+                tb = time.perf_counter(); rw_ = sw.Solve(want_results=False); wdt = time.perf_counter() - tb
+                wb = {"pods": args.whole_batch_pods, "seconds": wdt, "value": rw_["scheduledPods"] / wdt, "unit": "pods/s", "node_claims": rw_["counters"]["claims"],
+                      "engine": rw_["counters"].get("engine"), "pack_kernel_ms": rw_["timings"][0]["pack_kernel_ms"], "oracle_pin": None,
+                      "note": "ONE Solve() over all 16 NodePools: exact (bit-identical to the reference's answer for the batch), not shardable; the 10M-pod batch needs 27,345 in-flight "
+                              "NodeClaims — more than the cursor engine's LDS order holds — and takes the general engine ~700 s (profiles/round3/whole_batch_c3.json)"}
+                wpin = os.path.join(ROOT, "tests", "golden", "fullsize", f"config4_p{args.whole_batch_pods}_t{args.components_types}_s42_x16.json")
+                if os.path.exists(wpin) and not args.no_parity_pin:
+                    with open(wpin) as f:
+                        g = json.load(f)
+                    fullw = sw.Solve(want_results=True)
+                    dw, _ = parity.results_digest(fullw)
+                    wb["oracle_pin"] = {"pin": os.path.relpath(wpin, ROOT), "digest_matches_oracle": dw == g["digest"], "reference_bin_evaluations_match": fullw["counters"]["referenceBinEvaluations"] == g["binEvaluations"]}
+                    if not (wb["oracle_pin"]["digest_matches_oracle"] and wb["oracle_pin"]["reference_bin_evaluations_match"]):
+                        raise SystemExit(f"bench.py: the whole-batch configs[3] Results differ from the oracle's pin {wb['oracle_pin']}")
+                sw.close()
+                comp["whole_batch"] = wb
             if args.components_calibration_pods > 0:
                 cp = args.components_calibration_pods
                 whole_p = fx.config4(pods=cp, n_types=args.components_types, n_pools=16, seed=42)
