@@ -64,7 +64,10 @@ struct RoctxApi {
   int (*push)(const char*) = nullptr;
   int (*pop)() = nullptr;
   RoctxApi() {
-    void* l = dlopen("libroctx64.so", RTLD_LAZY | RTLD_GLOBAL);
+    // rocprofv3 --marker-trace listens to the rocprofiler-sdk build of ROCTx; roctracer's libroctx64 is the fallback for older tools
+    void* l = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_GLOBAL);
+    if (!l) l = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_GLOBAL);
+    if (!l) l = dlopen("libroctx64.so", RTLD_LAZY | RTLD_GLOBAL);
     if (!l) l = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_GLOBAL);
     if (l) { push = (int (*)(const char*))dlsym(l, "roctxRangePushA"); pop = (int (*)())dlsym(l, "roctxRangePop"); }
     if (!push || !pop) { push = nullptr; pop = nullptr; }

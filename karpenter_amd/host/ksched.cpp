@@ -822,6 +822,8 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       uid_hi.push_back(hi); uid_lo.push_back(lo); uid_text.push_back(specs.back().uid); group_of_pod.push_back({0, 0});
       pod_node_input.push_back(-1);
     }
+    struct GroupSpan { size_t at; long long cnt; uint64_t seed; std::vector<int32_t> node; };
+    std::vector<GroupSpan> spans;
     for (auto& g : root.at("podGroups").items()) {
       specs.push_back(parse_pod(g.at("template")));
       int si = (int)specs.size() - 1;
@@ -838,13 +840,24 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
       // one Solve() of the reference handles a batch of pending pods; 16M pods is 16x the largest BASELINE configuration
       if (cnt > kMaxPodsPerProblem || (long long)pod_spec.size() + cnt > kMaxPodsPerProblem) throw Unsupported("more than 16777216 pods in one problem");
       const size_t at = pod_spec.size();
-      pod_spec.resize(at + (size_t)cnt, si); uid_hi.resize(at + (size_t)cnt); uid_lo.resize(at + (size_t)cnt);
-      group_of_pod.resize(at + (size_t)cnt); pod_node_input.resize(at + (size_t)cnt, -1);
-      parallel_for((size_t)cnt, [&](size_t i) {
+      pod_spec.resize(at + (size_t)cnt, si);
+      spans.push_back(GroupSpan{at, cnt, seed, std::move(gnode)});
+    }
+    // every group pod's uid and binding: one pass over all groups on a few threads (a 1M-pod batch is ~600 groups)
+    uid_hi.resize(pod_spec.size()); uid_lo.resize(pod_spec.size()); group_of_pod.resize(pod_spec.size()); pod_node_input.resize(pod_spec.size(), -1);
+    {
+      std::vector<size_t> starts;
+      for (auto& sp : spans) starts.push_back(sp.at);
+      const size_t first = spans.empty() ? pod_spec.size() : spans[0].at;
+      parallel_for(pod_spec.size() - first, [&](size_t k) {
+        const size_t p = first + k;
+        const size_t gi = (size_t)(std::upper_bound(starts.begin(), starts.end(), p) - starts.begin()) - 1;
+        const GroupSpan& sp = spans[gi];
+        const uint64_t i = (uint64_t)(p - sp.at);
         uint64_t hi, lo;
-        group_uid(seed, (uint64_t)i, hi, lo, nullptr);
-        uid_hi[at + i] = hi; uid_lo[at + i] = lo; group_of_pod[at + i] = {seed, (uint64_t)i};
-        if (bound) pod_node_input[at + i] = (int)gnode[i];
+        group_uid(sp.seed, i, hi, lo, nullptr);
+        uid_hi[p] = hi; uid_lo[p] = lo; group_of_pod[p] = {sp.seed, i};
+        if (!sp.node.empty()) pod_node_input[p] = (int)sp.node[(size_t)i];
       });
     }
     const int n_pods = (int)pod_spec.size();
