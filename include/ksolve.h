@@ -270,7 +270,9 @@ typedef struct {
                                     * requirement algebra is purely positive (In sets only, no topology / existing nodes / minValues /
                                     * reservations / daemon overhead), the general engine otherwise or whenever the cursor engine stops;
                                     * 1 = general engine only; 2 = cursor engine only (KSOLVE_ERR_UNSUPPORTED instead of the fallback:
-                                    * tests use it to prove which engine produced a result). Both give identical Results. */
+                                    * tests use it to prove which engine produced a result); 3 = cursor engine only, with the claims' state
+                                    * in HBM from the start (the plan the library moves to by itself when the LDS plan runs out of
+                                    * claims). All give identical Results. */
 } ksolve_options;
 
 /* One NodeClaim of Results.NewNodeClaims (scheduler.go:282, nodeclaim.go:43-62), in the order the reference's
@@ -315,6 +317,8 @@ typedef struct {
   double packing_cost;
   uint32_t engine_used;            /* 1 = general engine, 2 = cursor engine */
   uint32_t engine_fallback_reason; /* non-zero: why the cursor engine handed the problem to the general engine (csrc/fast_engine.h) */
+  uint32_t cursor_wide;            /* engine_used == 2: 1 when the claims' state was kept in HBM (more in-flight NodeClaims than the LDS plan
+                                    * holds: ~3,000; the wide plan holds ~15,000) */
   void* impl;
 } ksolve_results;
 

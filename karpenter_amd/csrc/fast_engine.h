@@ -52,6 +52,8 @@ struct FastEnt { uint64_t vmask; int32_t cap[4]; uint32_t info; uint32_t pad; };
 struct FastPlan {   // LDS plan of ksolve_pack_fast (bytes), computed by the host
   int total_bytes, cap;
   int off_state, off_key, off_ord, off_snap, off_ent, off_pool, off_slot, off_misc, off_hot;
+  int global_state;   // 1: the claims' state (FastClaim, 24 B each) lives in HBM (FastWork::c_state), only the order arrays in LDS:
+                      //    ~15,000 in-flight claims instead of ~3,000 (round 4). off_state is unused then.
 };
 
 struct FastMisc {   // small LDS tables
@@ -111,6 +113,45 @@ KS_FN void lds_put(KS_LDS T* p, const T& v) {
   for (int i = 0; i < (int)(sizeof(T) / 8); ++i) s[i] = o[i];
 }
 
+
+// The in-flight claims' state by claim id. LDS while the problem's claims fit beside the order arrays and the caches (the
+// benchmarked configuration: 2,763 claims); HBM otherwise (GS = true): the lane that tests a claim then gathers its 24 bytes from
+// L2 instead of LDS — three 8-byte loads at agent scope, so that a store another lane of this wavefront made earlier is what it
+// sees (the vector L1 is not kept coherent with the wavefront's own stores from other lanes).
+template <bool GS> struct ClaimStates;
+template <> struct ClaimStates<false> {
+  KS_LDS FastClaim* p;
+  KS_FN FastClaim get(uint32_t c) const { return lds_get(&p[c]); }
+  KS_FN void put(uint32_t c, const FastClaim& v) const { lds_put(&p[c], v); }
+};
+template <> struct ClaimStates<true> {
+  FastClaim* p;
+  KS_FN FastClaim get(uint32_t c) const {
+    FastClaim out;
+    u64_alias* o = (u64_alias*)&out;
+#if KS_DEVICE
+    const uint64_t* s = (const uint64_t*)&p[c];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(FastClaim) / 8); ++i) o[i] = __hip_atomic_load(&s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    const u64_alias* s = (const u64_alias*)&p[c];
+    for (int i = 0; i < (int)(sizeof(FastClaim) / 8); ++i) o[i] = s[i];
+#endif
+    return out;
+  }
+  KS_FN void put(uint32_t c, const FastClaim& v) const {
+    const u64_alias* o = (const u64_alias*)&v;
+#if KS_DEVICE
+    uint64_t* s = (uint64_t*)&p[c];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(FastClaim) / 8); ++i) __hip_atomic_store(&s[i], o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    u64_alias* s = (u64_alias*)&p[c];
+    for (int i = 0; i < (int)(sizeof(FastClaim) / 8); ++i) s[i] = o[i];
+#endif
+  }
+};
+template <bool GS> KS_FN ClaimStates<GS> fast_uniform(ClaimStates<GS> c) { c.p = fast_uniform(c.p); return c; }
 
 // What ksolve_pack_fast reads its problem from: ONE record in HBM (not kernel arguments: a by-value argument whose address
 // is taken is copied to private memory, and loads from private memory are divergent to the compiler — every branch of the
@@ -193,7 +234,7 @@ KS_FN bool fast_sampled(int n, int p) {   // choosePivot's nine positions (pdq_e
 
 // Everything that happens rarely (a new requirement set, a new claim, a new class slot, pdqsort leaving its single-move
 // path): real function calls, so that their code and registers stay out of the loop that places a pod.
-template <class W>
+template <class W, bool GS = false>
 struct FastCold {
   const ProblemView* Pk;
   const Workspace* Sk;
@@ -201,7 +242,7 @@ struct FastCold {
   typedef KS_LDS uint16_t* o16;
   ClaimOrder<W, o16, false> order;
   KS_LDS uint16_t* snap;    // [cap] order snapshot around a slow sort
-  KS_LDS FastClaim* cst;
+  ClaimStates<GS> cst;
   KS_LDS FastEnt* ent;
   KS_LDS int32_t* pool;     // [kFastPool][4]
   KS_LDS FastSlot* aslot;
@@ -216,7 +257,7 @@ struct FastCold {
     Pk = p; Sk = s; Fk = f;
     const FastPlan& pl = f->plan;
     Mp = (KS_LDS FastMisc*)(lds + pl.off_misc);
-    cst = (KS_LDS FastClaim*)(lds + pl.off_state);
+    if constexpr (GS) cst.p = f->c_state; else cst.p = (KS_LDS FastClaim*)(lds + pl.off_state);
     order.key = (o16)(lds + pl.off_key); order.ord = (o16)(lds + pl.off_ord); order.pos = nullptr;
     snap = (o16)(lds + pl.off_snap);
     ent = (KS_LDS FastEnt*)(lds + pl.off_ent);
@@ -503,7 +544,7 @@ struct FastCold {
     const o16 kq = order.key;
     const int b = W::find_first(0, n, [&](int i) { return kq[i] > 1u; }) - 1;   // the claims with one pod are the prefix it joined the end of
     const int nac = n_active;
-    const FastClaim nst = lds_get(&cst[moved]);
+    const FastClaim nst = cst.get((uint32_t)moved);
     const int t = (int)(nst.vmask >> 56);
     for (int j = 0; j < kFastRows; ++j) {
       uint64_t accm = 0;
@@ -582,7 +623,7 @@ struct FastCold {
         FastClaim ns;
         ns.vmask = m;
         for (int q = 0; q < 4; ++q) ns.req[q] = cs.size[q];
-        lds_put(&cst[c], ns);
+        cst.put((uint32_t)c, ns);
         F.c_hostseq[c] = host_seq;
         order.key[n] = 1; order.ord[n] = (uint16_t)c;   // order.append
       }
@@ -617,13 +658,14 @@ struct FastCold {
       uint32_t* go = S.o_ord;
       const o16 oo = order.ord; const o16 ok_ = order.key;
       FastClaim* gs = F.c_state; uint32_t* gn = F.c_npods; uint16_t* ge = F.c_ent;
-      const KS_LDS FastClaim* ls = cst;
+      const ClaimStates<GS> ls = cst;
       const KS_LDS FastEnt* en = ent;
       W::for_n(n, [&](int i) { const uint32_t c = oo[i]; go[i] = c; gn[c] = ok_[i]; });
       W::for_n(n, [&](int c) {
-        const FastClaim st = lds_get(&ls[c]);
+        const FastClaim st = ls.get((uint32_t)c);
         FastEnt e;
-        gs[c] = st; ge[c] = (uint16_t)fast_lookup(en, st.vmask, e);
+        if constexpr (!GS) gs[c] = st;      // GS: the state has lived in F.c_state all along
+        ge[c] = (uint16_t)fast_lookup(en, st.vmask, e);
       });
       W::store(S.n_claims_out, n_claims);
     }
@@ -650,8 +692,9 @@ struct FastHot {
   uint32_t cur[kFastRows][64];
   uint32_t bcls[64], bslot[64], oclaim[64], ocnt[64], nxt_cls[64];
 };
+template <bool GS>
 struct FastHotCtx {   // LDS pointers of the loop, passed by value
-  KS_LDS uint16_t* okey; KS_LDS uint16_t* oord; KS_LDS FastClaim* cst; KS_LDS FastEnt* ent; KS_LDS int32_t* pool;
+  KS_LDS uint16_t* okey; KS_LDS uint16_t* oord; ClaimStates<GS> cst; KS_LDS FastEnt* ent; KS_LDS int32_t* pool;
   KS_LDS FastSlot* aslot; KS_LDS uint16_t* slot_of; KS_LDS FastHot* hs;
 };
 enum { FEV_DONE = 0, FEV_ENTRY = 1, FEV_SLOT = 2, FEV_SLOWSORT = 3, FEV_PLACE = 4, FEV_NEWCLAIM = 5, FEV_COUNT = 6 };
@@ -659,12 +702,12 @@ enum { FEV_DONE = 0, FEV_ENTRY = 1, FEV_SLOT = 2, FEV_SLOWSORT = 3, FEV_PLACE = 
 // The loop that places pods: a function of its own, WITHOUT calls — whatever happens rarely (a requirement set seen for the
 // first time, a new class slot, a new claim, pdqsort leaving its single-move path) ends the run with an event code; the
 // driver handles it through FastCold and runs the loop again. So the compiler allocates registers for this loop alone.
-template <class W>
-KS_COLD int fast_hot_run(FastHotCtx cx) {
+template <class W, bool GS>
+KS_COLD int fast_hot_run(FastHotCtx<GS> cx) {
   typedef KS_LDS uint16_t* o16;
   const unsigned long long t_in = W::clock();
   const o16 okey = fast_uniform(cx.okey), oord = fast_uniform(cx.oord);
-  KS_LDS FastClaim* const cst = fast_uniform(cx.cst);
+  const ClaimStates<GS> cst = fast_uniform(cx.cst);
   KS_LDS FastEnt* const ent = fast_uniform(cx.ent);
   KS_LDS int32_t* const pool = fast_uniform(cx.pool);
   KS_LDS FastSlot* const aslot = fast_uniform(cx.aslot);
@@ -807,7 +850,7 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
         gB.at(l) = gr.at(l) + 8u;
         if (j >= gnn || p >= nn) return 0;
         const uint32_t x = oord[p];
-        const FastClaim st = lds_get(&cst[x]);
+        const FastClaim st = cst.get(x);
         const FastSlot s = lds_get(&aslot[gs.at(l)]);
         const uint64_t m = st.vmask & s.cvmask;
         FastEnt e = lds_get(&ent[fast_hash(m)]);
@@ -854,7 +897,7 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
         // The claim gained pods since the group's test; it is still this entry's first candidate (its place among the others
         // is what it was, or it was chosen by position above): test this one claim again.
         const FastSlot cs = lds_get(&aslot[sj]);
-        const FastClaim st = lds_get(&cst[x]);
+        const FastClaim st = cst.get(x);
         const uint32_t know = okey[a];
         const uint64_t m = st.vmask & cs.cvmask;
         FastEnt e = lds_get(&ent[fast_hash(m)]);
@@ -896,7 +939,7 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
         if (l == L) {
           FastClaim ns;
           ns.vmask = gm.at(l); ns.req[0] = (int32_t)gq0.at(l); ns.req[1] = (int32_t)gq1.at(l); ns.req[2] = (int32_t)gq2.at(l); ns.req[3] = (int32_t)gq3.at(l);
-          lds_put(&cst[gx.at(l)], ns);
+          cst.put(gx.at(l), ns);
         }
         if (l <= s_) { okey[a + l] = (uint16_t)(l == s_ ? mvn : kv2.at(l)); oord[a + l] = (uint16_t)(l == s_ ? x : ov2.at(l)); }
         const bool me = l == bi;
@@ -961,7 +1004,7 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
         const int pc = valid ? p : n - 1;
         const uint32_t x = oord[pc];
         xv.at(l) = x; kv.at(l) = valid ? (uint32_t)okey[pc] : 0xFFFFFFFFu;
-        const FastClaim st = lds_get(&cst[x]);
+        const FastClaim st = cst.get(x);
         q0.at(l) = st.req[0]; q1.at(l) = st.req[1]; q2.at(l) = st.req[2]; q3.at(l) = st.req[3];
         const uint64_t m = st.vmask & cs.cvmask;
         mv.at(l) = m;
@@ -1006,7 +1049,7 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
       ns.vmask = mv.bcast(first_ok);
       ns.req[0] = q0.bcast(first_ok) + cs.size[0]; ns.req[1] = q1.bcast(first_ok) + cs.size[1];
       ns.req[2] = q2.bcast(first_ok) + cs.size[2]; ns.req[3] = q3.bcast(first_ok) + cs.size[3];
-      if (W::leader()) lds_put(&cst[x], ns);
+      if (W::leader()) cst.put(x, ns);
       oclaim.set(bi, (uint32_t)x); ocnt.set(bi, cnt);
       n_ref += (unsigned long long)a + 1;
       r = (uint32_t)a;
@@ -1100,9 +1143,9 @@ KS_COLD int fast_hot_run(FastHotCtx cx) {
 }
 
 // The driver: runs the loop, handles its events through FastCold.
-template <class W>
+template <class W, bool GS = false>
 struct FastEngine {
-  FastCold<W> cold;
+  FastCold<W, GS> cold;
   KS_LDS FastHot* hs;
   KS_DEV FastEngine(const ProblemView* p, const Workspace* s, const FastWork* f, char* lds) { cold.init(p, s, f, lds); hs = (KS_LDS FastHot*)(lds + f->plan.off_hot); }
 
@@ -1131,13 +1174,13 @@ struct FastEngine {
       });
     }
     W::sync();
-    FastHotCtx cx;
+    FastHotCtx<GS> cx;
     cx.okey = cold.order.key; cx.oord = cold.order.ord; cx.cst = cold.cst; cx.ent = cold.ent; cx.pool = cold.pool;
     cx.aslot = cold.aslot; cx.slot_of = cold.Mp->slot_of; cx.hs = hs;
     unsigned long long tev[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = W::clock();
     for (;;) {
-      const int ev = fast_uniform(fast_hot_run<W>(cx));
+      const int ev = fast_uniform(fast_hot_run<W, GS>(cx));
       if (ev == FEV_DONE) break;
       const unsigned long long te0 = W::clock();
       if (ev == FEV_ENTRY) {

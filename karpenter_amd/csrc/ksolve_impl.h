@@ -94,6 +94,7 @@ struct ksolve_handle {
   bool sweep_ready = false;
   ks::ProblemView* d_pv = nullptr;
   char* sweep_arena = nullptr; size_t sweep_arena_bytes = 0;
+  uint32_t fast_mc = 0;           // max_claims the cursor engine's plans are cut to
   double dead0_us = 0;            // ksolve_node_dead0 (every class x every pristine node), once per resident cluster
   size_t sweep_last_total = 0;   // arena bytes the last sweep_run laid out (held against sweep_probe_bytes by the test builds)
   char* sweep_fin = nullptr; size_t sweep_fin_bytes = 0;     // finalize outputs + gathered claim records of a sweep
@@ -179,6 +180,7 @@ static bool any_nonzero(const uint32_t* p, uint32_t n) {
   return false;
 }
 
+static void fast_plan_set(ksolve_handle* h, bool wide);   // the cursor engine's LDS plan (claim state in LDS / in HBM)
 static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* o, ksolve_handle* h) {
   if (!d || d->abi_version != KSOLVE_ABI_VERSION) return fail(h, KSOLVE_ERR_INVALID, "abi version mismatch");
   if (d->n_keys == 0 || d->n_keys > KSOLVE_MAX_KEYS) return fail(h, KSOLVE_ERR_INVALID, "n_keys out of range");
@@ -664,25 +666,8 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     ks::FastWork& fw = h->fw;
     fw.enabled = (P.plain && d->n_res <= 4 && h->opts.engine != 1 && d->n_pod_rows == d->n_pods && d->n_pods > 0) ? 1 : 0;
     if (fw.enabled) {
-      auto align = [](int x) { return (x + 15) & ~15; };
-      ks::FastPlan& fp = fw.plan;
-      int off = 0;
-      fp.off_ent = off; off = align(off + ks::kFastEnt * (int)sizeof(ks::FastEnt));
-      fp.off_pool = off; off = align(off + ks::kFastPool * 16);
-      fp.off_slot = off; off = align(off + ks::kFastSlots * (int)sizeof(ks::FastSlot));
-      fp.off_misc = off; off = align(off + (int)sizeof(ks::FastMisc));
-      fp.off_hot = off; off = align(off + (int)sizeof(ks::FastHot));
-      const int budget = 160 * 1024 - 512;
-      int cap = ((budget - off - 64) / (int)(sizeof(ks::FastClaim) + 6)) & ~63;
-      if (cap > 65472) cap = 65472;
-      if (h->opts.lds_claim_cap && (int)((h->opts.lds_claim_cap + 63) & ~63u) < cap) cap = (int)((h->opts.lds_claim_cap + 63) & ~63u);
-      if (cap > (int)((mc + 63) & ~63u)) cap = (int)((mc + 63) & ~63u);
-      fp.cap = cap;
-      fp.off_state = off; off = align(off + cap * (int)sizeof(ks::FastClaim));
-      fp.off_key = off; off = align(off + cap * 2);
-      fp.off_ord = off; off = align(off + cap * 2);
-      fp.off_snap = off; off = align(off + cap * 2);
-      fp.total_bytes = off;
+      h->fast_mc = mc;
+      fast_plan_set(h, h->opts.engine == 3);
       fw.var = dz<ks::FastVar>(h, 1);
       fw.c_hostseq = dz<uint32_t>(h, mc); fw.c_ent = dz<uint16_t>(h, mc);
       fw.c_state = dz<ks::FastClaim>(h, mc); fw.c_npods = dz<uint32_t>(h, mc);
@@ -698,6 +683,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
 }
 
 static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context);
+
 
 // ksolve_probe_create: a probe handle is its descriptor (nodes that are not there, pods to place, NodePool limits); solving it
 // — alone or in a batch — goes through sweep_run below, which shares `base`'s device tables.
@@ -1006,7 +992,7 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   out->us_prepass = (h->timers.ms[T_INDEX] + h->timers.ms[T_CLASSIFY] + h->timers.ms[T_SORT]) * 1e3;
   out->us_pack = h->timers.ms[T_PACK] * 1e3; out->us_finalize = h->timers.ms[T_FINALIZE] * 1e3; out->us_download = h->timers.ms[T_DOWNLOAD] * 1e3;
   out->packing_cost = cost;
-  out->engine_used = h->engine_used; out->engine_fallback_reason = h->fast_reason;
+  out->engine_used = h->engine_used; out->engine_fallback_reason = h->fast_reason; out->cursor_wide = (h->engine_used == 2 && h->fw.plan.global_state) ? 1u : 0u;
   out->impl = im;
   return out->status;
 }
@@ -1750,6 +1736,32 @@ static void solve_probes(ksolve_handle** hs, uint32_t n, ksolve_results* outs, k
   }
 }
 
+// LDS plan of the cursor engine. wide = false: claim state (24 B) + order arrays (6 B) per claim in LDS, ~3,000 claims beside the
+// caches; wide = true: the claim state in HBM (FastWork::c_state), only the order arrays in LDS: ~15,000 claims.
+static void fast_plan_set(ksolve_handle* h, bool wide) {
+  auto align = [](int x) { return (x + 15) & ~15; };
+  ks::FastPlan& fp = h->fw.plan;
+  int off = 0;
+  fp.off_ent = off; off = align(off + ks::kFastEnt * (int)sizeof(ks::FastEnt));
+  fp.off_pool = off; off = align(off + ks::kFastPool * 16);
+  fp.off_slot = off; off = align(off + ks::kFastSlots * (int)sizeof(ks::FastSlot));
+  fp.off_misc = off; off = align(off + (int)sizeof(ks::FastMisc));
+  fp.off_hot = off; off = align(off + (int)sizeof(ks::FastHot));
+  const int budget = 160 * 1024 - 512;
+  const int per_claim = (wide ? 0 : (int)sizeof(ks::FastClaim)) + 6;
+  int cap = ((budget - off - 64) / per_claim) & ~63;
+  if (cap > 65472) cap = 65472;
+  if (!wide && h->opts.lds_claim_cap && (int)((h->opts.lds_claim_cap + 63) & ~63u) < cap) cap = (int)((h->opts.lds_claim_cap + 63) & ~63u);
+  if (cap > (int)((h->fast_mc + 63) & ~63u)) cap = (int)((h->fast_mc + 63) & ~63u);
+  fp.cap = cap;
+  fp.global_state = wide ? 1 : 0;
+  fp.off_state = off; if (!wide) off = align(off + cap * (int)sizeof(ks::FastClaim));
+  fp.off_key = off; off = align(off + cap * 2);
+  fp.off_ord = off; off = align(off + cap * 2);
+  fp.off_snap = off; off = align(off + cap * 2);
+  fp.total_bytes = off;
+}
+
 static void be_results_drop(ksolve_results* r) { if (r && r->impl) { delete (ResultsImpl*)r->impl; r->impl = nullptr; } }
 static ksolve_status solve(ksolve_handle* h, ksolve_results* out, bool fresh_context = true) {
   memset(out, 0, sizeof(*out));
@@ -1757,29 +1769,43 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out, bool fresh_con
   if (h->base) { ksolve_status st = KSOLVE_OK; solve_probes(&h, 1, out, &st, fresh_context); return st; }
   ksolve_status st = solve_prepare(h, fresh_context);
   if (st != KSOLVE_OK) return st;
-  if (h->opts.engine == 2 && !(h->fw.enabled && !h->pv.big && h->n_pods && h->n_classes))
+  if (h->opts.engine >= 2 && !(h->fw.enabled && !h->pv.big && h->n_pods && h->n_classes))
     return fail(h, KSOLVE_ERR_UNSUPPORTED, "cursor engine requested for a problem outside its shape (topology / existing nodes / minValues / reservations / relaxation rows)");
   if (h->fw.enabled && !h->pv.big && h->n_pods && h->n_classes) {
-    // the cursor engine first; status 3 = "not my shape / stopped before any result": the general engine takes over
-    be_tic(h, T_PACK);
-    be_launch_pack_fast(h);
-    be_toc(h, T_PACK);
-    int status = 0, n_claims = 0;
-    be_d2h(h, &status, h->ws.status_out, 4);
-    be_d2h(h, &n_claims, h->ws.n_claims_out, 4);
-    be_sync(h);
-    if (be_ok(h) && status != 3 && status != 1) {
-      h->engine_used = 2;
-      if (n_claims) be_launch_fast_records(h, n_claims);
-      return solve_finish(h, out);
-    }
-    if (be_ok(h) && status == 3) {
-      ks::Counters ctr{};
-      be_d2h(h, &ctr, h->ws.counters, sizeof(ctr));
+    // the cursor engine first; status 3 = "not my shape / stopped before any result": the general engine takes over — unless all
+    // that stopped it was the number of claims its LDS plan holds (reason 26): then once more with the claims' state in HBM
+    for (;;) {
+      be_tic(h, T_PACK);
+      be_launch_pack_fast(h);
+      be_toc(h, T_PACK);
+      int status = 0, n_claims = 0;
+      be_d2h(h, &status, h->ws.status_out, 4);
+      be_d2h(h, &n_claims, h->ws.n_claims_out, 4);
       be_sync(h);
-      h->fast_reason = (uint32_t)ctr.cycles[20];
-    } else if (be_ok(h)) h->fast_reason = 100;   // more claims than max_claims: the general engine reports it (or moves to BIG)
-    if (h->opts.engine == 2) return fail(h, KSOLVE_ERR_UNSUPPORTED, "cursor engine declined the problem (reason " + std::to_string(h->fast_reason) + ")");
+      if (be_ok(h) && status != 3 && status != 1) {
+        h->engine_used = 2;
+        h->fast_reason = 0;   // (a first attempt that ran out of LDS claim slots is not a fallback to the general engine)
+        if (n_claims) be_launch_fast_records(h, n_claims);
+        return solve_finish(h, out);
+      }
+      if (be_ok(h) && status == 3) {
+        ks::Counters ctr{};
+        be_d2h(h, &ctr, h->ws.counters, sizeof(ctr));
+        be_sync(h);
+        h->fast_reason = (uint32_t)ctr.cycles[20];
+      } else if (be_ok(h)) h->fast_reason = 100;   // more claims than max_claims: the general engine reports it (or moves to BIG)
+      if (be_ok(h) && h->fast_reason == 26 && !h->fw.plan.global_state && !h->opts.lds_claim_cap) {
+        const int had = h->fw.plan.cap;
+        fast_plan_set(h, true);                      // later solves of this handle start there
+        if (h->fw.plan.cap > had) {
+          st = solve_prepare(h, false);
+          if (st != KSOLVE_OK) return st;
+          continue;
+        }
+      }
+      break;
+    }
+    if (h->opts.engine >= 2) return fail(h, KSOLVE_ERR_UNSUPPORTED, "cursor engine declined the problem (reason " + std::to_string(h->fast_reason) + ")");
     h->fw.enabled = 0;   // later solves of this handle go straight to the general engine
     st = solve_prepare(h, false);
     if (st != KSOLVE_OK) return st;
@@ -1827,7 +1853,7 @@ static ksolve_status solve_batch_plain(ksolve_handle** hs, uint32_t n, ksolve_re
     if (st[i] != KSOLVE_OK || !hs[i]->n_pods) continue;
     ksolve_handle* h = hs[i];
     if (h->fw.enabled && !h->pv.big && h->n_classes) fast.push_back(h);
-    else if (h->opts.engine == 2) st[i] = fail(h, KSOLVE_ERR_UNSUPPORTED, "cursor engine requested for a problem outside its shape");
+    else if (h->opts.engine >= 2) st[i] = fail(h, KSOLVE_ERR_UNSUPPORTED, "cursor engine requested for a problem outside its shape");
     else run.push_back(h);
   }
   if (!fast.empty()) {
@@ -1849,7 +1875,7 @@ static ksolve_status solve_batch_plain(ksolve_handle** hs, uint32_t n, ksolve_re
       ksolve_handle* h = fast[k];
       uint32_t idx = 0;
       while (hs[idx] != h) ++idx;
-      if (h->opts.engine == 2) { st[idx] = fail(h, KSOLVE_ERR_UNSUPPORTED, "cursor engine declined the problem (reason " + std::to_string(h->fast_reason) + ")"); continue; }
+      if (h->opts.engine >= 2) { st[idx] = fail(h, KSOLVE_ERR_UNSUPPORTED, "cursor engine declined the problem (reason " + std::to_string(h->fast_reason) + ")"); continue; }
       h->fw.enabled = 0;
       st[idx] = solve_prepare(h, false);
       if (st[idx] == KSOLVE_OK) { be_sync(h); run.push_back(h); }

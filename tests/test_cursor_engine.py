@@ -247,3 +247,29 @@ def test_batched_launch_mixes_engines(oracle, emu):
         parity.assert_same_results(g, oracle.solve(p))
     with pytest.raises(Unsupported, match="cursor engine"):
         SolveBatch([NewScheduler(with_engine(probs[3], "cursor"), solver_lib=emu), NewScheduler(probs[0], solver_lib=emu)])
+
+
+def test_claim_state_in_hbm_when_the_lds_plan_runs_out_of_claims(oracle, emu):
+    """The cursor engine's LDS plan holds ~3,000 in-flight NodeClaims. A batch that needs more stops it with reason 26, and the
+    library runs it once more with the claims' state in HBM (ClaimStates<true>: ~15,000 claims, only the order arrays in LDS)
+    instead of handing the problem to the general engine. 3,600 pods that each need a node of their own, plus small pods that fill
+    the gaps: both plans, the automatic switch and the general engine agree with the oracle claim by claim."""
+    big = fx.pod(uid="t", requests={"cpu": "130", "memory": "1Gi"})
+    small = fx.pod(uid="t", requests={"cpu": "500m", "memory": "256Mi"}, node_selector={fx.ARCH: "amd64"})
+    np_ = fx.node_pool("default")
+    np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    prob = fx.problem(fx.kwok_catalog(144), [np_], pod_groups=[{"count": 3600, "uidSeed": 7, "template": big}, {"count": 5000, "uidSeed": 8, "template": small}], well_known=fx.KWOK_WELL_KNOWN)
+    want = oracle.solve(prob)
+    assert len(want["newNodeClaims"]) > 3100
+    seen = {}
+    for engine in ("auto", "cursor-wide", "general"):
+        s = NewScheduler(dict(prob, options=dict(prob["options"], engine=engine)), solver_lib=emu)
+        got = s.Solve()
+        parity.assert_same_results(got, want)
+        assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
+        seen[engine] = (got["counters"]["engine"], got["counters"]["cursorClaimStateInHBM"], got["counters"]["engineFallbackReason"])
+        if engine == "auto":      # the handle remembers: the second Solve() starts with the wide plan
+            again = s.Solve()
+            parity.assert_same_results(again, want)
+        s.close()
+    assert seen == {"auto": ("cursor", True, 0), "cursor-wide": ("cursor", True, 0), "general": ("general", False, 0)}, seen

@@ -391,7 +391,9 @@ def test_full_size_digest(pin):
     if g["pods"] > 2_000_000 and os.environ.get("KSOLVE_TEST_HUGE_PINS") != "1":
         pytest.skip("a whole-batch pin of this size takes the general engine minutes of GPU time: KSOLVE_TEST_HUGE_PINS=1, or tests/tools/whole_batch_c3.py")
     prob = build_problem(g["config"], g["pods"], g["types"], g["seed"], g["extra"])
-    engines = ["auto"] + (["general"] if g["config"] != "config3" and g["pods"] <= 250000 else [])
+    # cursor-wide: the cursor engine with the claims' state in HBM (the plan the library moves to when the LDS plan runs out of claims) —
+    # every load of a claim another lane stored has to come from L2, not a stale L1 line: the digest of a million placements says so
+    engines = ["auto"] + (["general"] if g["config"] != "config3" and g["pods"] <= 250000 else []) + (["cursor-wide"] if g["config"] in ("config1", "config2", "config4") and g["pods"] <= 2_000_000 else [])
     for eng in engines:
         s = NewScheduler(dict(prob, options=dict(prob["options"], engine=eng)))
         r = s.Solve()
@@ -405,6 +407,8 @@ def test_full_size_digest(pin):
         assert float(r["packingCost"]).hex() == g["packingCost"] or abs(r["packingCost"] - g["packingCostApprox"]) < 1e-9 * g["packingCostApprox"]
         if eng == "auto":
             assert r["counters"]["engine"] == ("general" if g["config"] == "config3" else "cursor"), r["counters"]
+        if eng == "cursor-wide":
+            assert r["counters"]["engine"] == "cursor" and r["counters"]["cursorClaimStateInHBM"] is True
 
 
 def test_offering_override_groups_on_the_device(oracle):
@@ -573,3 +577,10 @@ def test_multi_node_consolidation_windows_on_a_10k_node_cluster(oracle, monkeypa
         assert (by[kk]["decision"], by[kk]["replacement"], by[kk].get("replacementCapacityType")) == oracle.verdict_key(r["verdict"]), (kk, by[kk], r["verdict"])
         assert refs[key.index(kk)] == r["counters"]["binEvaluations"]
     rc.close()
+
+
+def test_cursor_engine_moves_its_claim_state_to_hbm_on_the_device(oracle):
+    """tests/test_cursor_engine.py::test_claim_state_in_hbm_when_the_lds_plan_runs_out_of_claims with libksolve.so: more in-flight
+    NodeClaims than the cursor engine's LDS plan holds -> the same engine with the claims' state in HBM, not the general engine."""
+    import test_cursor_engine as tce
+    tce.test_claim_state_in_hbm_when_the_lds_plan_runs_out_of_claims(oracle, None)
