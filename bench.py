@@ -286,6 +286,8 @@ def main():
     ap.add_argument("--batch-pods", type=int, default=20_000, help="pods per problem of the batched measurement")
     ap.add_argument("--components-pods", type=int, default=10_000_000, help="BASELINE configs[3]: pods of the 16-NodePool batch solved as NodePool components (one block each, one launch), 0 = skip")
     ap.add_argument("--components-types", type=int, default=1000)
+    ap.add_argument("--beyond-lds-pods", type=int, default=2_000_000, help="the configs[1] mix at a size whose NodeClaims no longer fit the cursor engine's LDS plan (~3,000): "
+                    "the engine moves its claim state to HBM (round 4) instead of handing the batch to the general engine; digest-checked against the oracle's pin of that size when committed; 0 = skip")
     ap.add_argument("--whole-batch-pods", type=int, default=1_000_000, help="BASELINE configs[3] as ONE exact Solve() of the whole batch (all 16 NodePools in one claim order), "
                     "digest-checked against the oracle's pin of that size when one is committed; 0 = skip. 10M pods take the general engine ~700 s (tests/tools/whole_batch_c3.py)")
     ap.add_argument("--components-calibration-pods", type=int, default=200_000, help="size at which the component split is compared with ONE Solve() of the whole batch (L2-canonical deltas)")
@@ -687,6 +689,33 @@ def main():
             if pinned and not args.no_parity_pin:
                 e["largest_pinned_size"] = topology_run(pinned[-1], 1)
         out["config2_topology"] = e
+    if args.beyond_lds_pods > 0 and world == 1:
+        # right above the benchmarked size: the same mix with more NodeClaims than the cursor engine's LDS plan holds
+        pb = fx.config2(pods=args.beyond_lds_pods, n_types=args.types, seed=42)
+        pb["options"]["device"] = device_index
+        sb = NewScheduler(pb, solver_lib=args.solver_lib)
+        tb = time.perf_counter(); rb1 = sb.Solve(want_results=False); first_s = time.perf_counter() - tb     # LDS plan until it runs out of claims, then the HBM plan
+        tb = time.perf_counter(); rb = sb.Solve(want_results=False); steady_s = time.perf_counter() - tb     # the handle remembers: the HBM plan from the start
+        bl = {"workload": f"BASELINE configs[1] mix at {args.beyond_lds_pods} pods x {args.types} types: more in-flight NodeClaims than the cursor engine's LDS plan holds",
+              "pods": args.beyond_lds_pods, "node_claims": rb["counters"]["claims"], "engine": rb["counters"].get("engine"), "claim_state_in_hbm": rb["counters"].get("cursorClaimStateInHBM"),
+              "first_solve_s": first_s, "seconds": steady_s, "value": rb["scheduledPods"] / steady_s, "unit": "pods/s", "pack_kernel_ms": rb["timings"][0]["pack_kernel_ms"],
+              "us_per_pod": steady_s * 1e6 / max(1, rb["scheduledPods"]), "oracle_pin": None,
+              "note": "first_solve_s includes the attempt with the LDS plan (it stops when it needs claim 3,009) and the run with the claims' state in HBM; later solves of the handle start there"}
+        bpin = os.path.join(ROOT, "tests", "golden", "fullsize", f"config2_p{args.beyond_lds_pods}_t{args.types}_s42.json")
+        if os.path.exists(bpin) and not args.no_parity_pin:
+            with open(bpin) as f:
+                g = json.load(f)
+            fb = sb.Solve(want_results=True)
+            db, _ = parity.results_digest(fb)
+            bl["oracle_pin"] = {"pin": os.path.relpath(bpin, ROOT), "digest_matches_oracle": db == g["digest"], "reference_bin_evaluations_match": fb["counters"]["referenceBinEvaluations"] == g["binEvaluations"], "oracle_seconds_offline": g["oracleSeconds"]}
+            if not (bl["oracle_pin"]["digest_matches_oracle"] and bl["oracle_pin"]["reference_bin_evaluations_match"]):
+                raise SystemExit(f"bench.py: the configs[1] mix at {args.beyond_lds_pods} pods differs from the oracle's pin {bl['oracle_pin']}")
+        elif not args.no_parity_pin:
+            import invariants
+            fb = sb.Solve(want_results="claims")
+            bl["invariants"] = invariants.check_claims(pb, fb, expect_pods=args.beyond_lds_pods)
+        sb.close()
+        out["config1_beyond_lds"] = bl
     if comp is not None:
         out["config3_components"] = comp
     if sweep is not None:

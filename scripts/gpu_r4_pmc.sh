@@ -7,8 +7,8 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r4pmc
 mkdir -p $O
-HEAD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --topology-pods 0 --batch-problems 0 --components-pods 0 --sweep-nodes 0 --no-host-engine-baseline --no-cpu-baseline"
-SWEEP="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --pods 20000 --no-parity-pin --topology-pods 0 --batch-problems 0 --components-pods 0 --sweep-sample 0 --sweep-topology-sample 0 --sweep-windows 0 --no-host-engine-baseline --no-cpu-baseline"
+HEAD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --topology-pods 0 --batch-problems 0 --components-pods 0 --beyond-lds-pods 0 --sweep-nodes 0 --no-host-engine-baseline --no-cpu-baseline"
+SWEEP="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --pods 20000 --no-parity-pin --topology-pods 0 --batch-problems 0 --components-pods 0 --beyond-lds-pods 0 --sweep-sample 0 --sweep-topology-sample 0 --sweep-windows 0 --no-host-engine-baseline --no-cpu-baseline"
 (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_head -o bench -- $HEAD > $O/stats_head.log 2>&1)
 find $O/stats_head -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} cp {} $O/rocprofv3_kernel_stats_bench_1m.csv
 (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sweep -o bench -- $SWEEP > $O/stats_sweep.log 2>&1)

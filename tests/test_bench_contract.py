@@ -32,7 +32,7 @@ def _env():
 def test_single_rank_line(oracle):
     emu = parity.build_emu()
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--pods", "3000", "--types", "60", "--cpu-sample", "1500", "--cpu-runs", "3",
-           "--topology-pods", "400", "--components-pods", "4000", "--components-types", "60", "--components-calibration-pods", "4000", "--whole-batch-pods", "3000", "--batch-problems", "3", "--batch-pods", "400", "--sweep-nodes", "300", "--sweep-candidates", "40", "--sweep-sample", "6", "--sweep-topology-sample", "6", "--sweep-windows", "3", "--sweep-window-size", "12", "--solver-lib", emu]
+           "--topology-pods", "400", "--components-pods", "4000", "--components-types", "60", "--components-calibration-pods", "4000", "--whole-batch-pods", "3000", "--beyond-lds-pods", "0", "--batch-problems", "3", "--batch-pods", "400", "--sweep-nodes", "300", "--sweep-candidates", "40", "--sweep-sample", "6", "--sweep-topology-sample", "6", "--sweep-windows", "3", "--sweep-window-size", "12", "--solver-lib", emu]
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = _json_line(r.stdout)
