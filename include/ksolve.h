@@ -272,7 +272,8 @@ typedef struct {
                                     * 1 = general engine only; 2 = cursor engine only (KSOLVE_ERR_UNSUPPORTED instead of the fallback:
                                     * tests use it to prove which engine produced a result); 3 = cursor engine only, with the claims' state
                                     * in HBM from the start (the plan the library moves to by itself when the LDS plan runs out of
-                                    * claims). All give identical Results. */
+                                    * claims); 4 = cursor engine only, claim state AND claim order in HBM from the start (the plan above
+                                    * ~15,000 in-flight NodeClaims, up to 65,472). All give identical Results. */
 } ksolve_options;
 
 /* One NodeClaim of Results.NewNodeClaims (scheduler.go:282, nodeclaim.go:43-62), in the order the reference's
@@ -317,8 +318,10 @@ typedef struct {
   double packing_cost;
   uint32_t engine_used;            /* 1 = general engine, 2 = cursor engine */
   uint32_t engine_fallback_reason; /* non-zero: why the cursor engine handed the problem to the general engine (csrc/fast_engine.h) */
-  uint32_t cursor_wide;            /* engine_used == 2: 1 when the claims' state was kept in HBM (more in-flight NodeClaims than the LDS plan
-                                    * holds: ~3,000; the wide plan holds ~15,000) */
+  uint32_t cursor_wide;            /* engine_used == 2: the memory plan it ran with. 0 = claim state and order in LDS (~3,000 in-flight
+                                    * NodeClaims); 1 = the claims' state in HBM (~15,000); 2 = their order too (65,472) */
+  uint32_t cursor_attempts;        /* runs of the cursor engine this solve took: 1, or one more per plan it outgrew (a later solve of the
+                                    * handle starts with the plan that held) */
   void* impl;
 } ksolve_results;
 

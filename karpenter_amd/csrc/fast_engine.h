@@ -29,6 +29,7 @@
 // than the LDS plan holds, non-positive operators, ...) makes it stop with status 3 before it has written a result;
 // the host then runs the general engine (engine.h) on the same problem. There is no CPU path.
 #pragma once
+#include <type_traits>
 #include "kernels.h"
 #include "pdq_emul.h"
 
@@ -54,6 +55,8 @@ struct FastPlan {   // LDS plan of ksolve_pack_fast (bytes), computed by the hos
   int off_state, off_key, off_ord, off_snap, off_ent, off_pool, off_slot, off_misc, off_hot;
   int global_state;   // 1: the claims' state (FastClaim, 24 B each) lives in HBM (FastWork::c_state), only the order arrays in LDS:
                       //    ~15,000 in-flight claims instead of ~3,000 (round 4). off_state is unused then.
+                      // 2: the order arrays too (FastWork::o_key / o_ord / o_snap): 65,472 claims — what 16-bit claim ids address;
+                      //    LDS holds the caches, the class slots and the loop's own state only.
 };
 
 struct FastMisc {   // small LDS tables
@@ -88,6 +91,9 @@ struct FastWork {   // HBM workspace of the cursor engine (host-allocated when t
   uint32_t* q_class;      // [n_pods] class of queue entry i = row_class[sorted_pods[i]]
   uint32_t* q_claim;      // [n_pods] claim of queue entry i (0xFFFFFFFF: not placed)
   uint32_t* q_cnt;        // [n_pods] pods the claim held before it
+  uint16_t* o_key;        // [max_claims] plan 2: the claim order (pod count / claim id by position) and its snapshot, in HBM
+  uint16_t* o_ord;
+  uint16_t* o_snap;
   FastPlan plan;
   int enabled;
 };
@@ -152,6 +158,18 @@ template <> struct ClaimStates<true> {
   }
 };
 template <bool GS> KS_FN ClaimStates<GS> fast_uniform(ClaimStates<GS> c) { c.p = fast_uniform(c.p); return c; }
+// The plan the engine is compiled for (FastPlan::global_state): 0 everything in LDS, 1 claim state in HBM, 2 claim state and
+// order arrays in HBM. The order's accesses are plain loads and stores: the wavefront is the only reader and writer, its vector
+// memory operations execute in order, and W::sync() (a wavefront-scope fence) stands between a store and another lane's load.
+template <int GS> struct FastMem {
+  static constexpr bool kStateHbm = GS >= 1, kOrderHbm = GS >= 2;
+#if KS_DEVICE
+  typedef typename std::conditional<kOrderHbm, uint16_t*, KS_LDS uint16_t*>::type o16;
+#else
+  typedef uint16_t* o16;
+#endif
+  typedef ClaimStates<kStateHbm> States;
+};
 
 // What ksolve_pack_fast reads its problem from: ONE record in HBM (not kernel arguments: a by-value argument whose address
 // is taken is copied to private memory, and loads from private memory are divergent to the compiler — every branch of the
@@ -234,15 +252,15 @@ KS_FN bool fast_sampled(int n, int p) {   // choosePivot's nine positions (pdq_e
 
 // Everything that happens rarely (a new requirement set, a new claim, a new class slot, pdqsort leaving its single-move
 // path): real function calls, so that their code and registers stay out of the loop that places a pod.
-template <class W, bool GS = false>
+template <class W, int GS = 0>
 struct FastCold {
   const ProblemView* Pk;
   const Workspace* Sk;
   const FastWork* Fk;
-  typedef KS_LDS uint16_t* o16;
+  typedef typename FastMem<GS>::o16 o16;
   ClaimOrder<W, o16, false> order;
-  KS_LDS uint16_t* snap;    // [cap] order snapshot around a slow sort
-  ClaimStates<GS> cst;
+  o16 snap;                 // [cap] order snapshot around a slow sort
+  typename FastMem<GS>::States cst;
   KS_LDS FastEnt* ent;
   KS_LDS int32_t* pool;     // [kFastPool][4]
   KS_LDS FastSlot* aslot;
@@ -257,9 +275,10 @@ struct FastCold {
     Pk = p; Sk = s; Fk = f;
     const FastPlan& pl = f->plan;
     Mp = (KS_LDS FastMisc*)(lds + pl.off_misc);
-    if constexpr (GS) cst.p = f->c_state; else cst.p = (KS_LDS FastClaim*)(lds + pl.off_state);
-    order.key = (o16)(lds + pl.off_key); order.ord = (o16)(lds + pl.off_ord); order.pos = nullptr;
-    snap = (o16)(lds + pl.off_snap);
+    if constexpr (GS >= 1) cst.p = f->c_state; else cst.p = (KS_LDS FastClaim*)(lds + pl.off_state);
+    if constexpr (GS >= 2) { order.key = (o16)f->o_key; order.ord = (o16)f->o_ord; snap = (o16)f->o_snap; }
+    else { order.key = (o16)(lds + pl.off_key); order.ord = (o16)(lds + pl.off_ord); snap = (o16)(lds + pl.off_snap); }
+    order.pos = nullptr;
     ent = (KS_LDS FastEnt*)(lds + pl.off_ent);
     pool = (KS_LDS int32_t*)(lds + pl.off_pool);
     aslot = (KS_LDS FastSlot*)(lds + pl.off_slot);
@@ -658,13 +677,13 @@ struct FastCold {
       uint32_t* go = S.o_ord;
       const o16 oo = order.ord; const o16 ok_ = order.key;
       FastClaim* gs = F.c_state; uint32_t* gn = F.c_npods; uint16_t* ge = F.c_ent;
-      const ClaimStates<GS> ls = cst;
+      const typename FastMem<GS>::States ls = cst;
       const KS_LDS FastEnt* en = ent;
       W::for_n(n, [&](int i) { const uint32_t c = oo[i]; go[i] = c; gn[c] = ok_[i]; });
       W::for_n(n, [&](int c) {
         const FastClaim st = ls.get((uint32_t)c);
         FastEnt e;
-        if constexpr (!GS) gs[c] = st;      // GS: the state has lived in F.c_state all along
+        if constexpr (GS == 0) gs[c] = st;   // otherwise the state has lived in F.c_state all along
         ge[c] = (uint16_t)fast_lookup(en, st.vmask, e);
       });
       W::store(S.n_claims_out, n_claims);
@@ -692,9 +711,9 @@ struct FastHot {
   uint32_t cur[kFastRows][64];
   uint32_t bcls[64], bslot[64], oclaim[64], ocnt[64], nxt_cls[64];
 };
-template <bool GS>
+template <int GS>
 struct FastHotCtx {   // LDS pointers of the loop, passed by value
-  KS_LDS uint16_t* okey; KS_LDS uint16_t* oord; ClaimStates<GS> cst; KS_LDS FastEnt* ent; KS_LDS int32_t* pool;
+  typename FastMem<GS>::o16 okey, oord; typename FastMem<GS>::States cst; KS_LDS FastEnt* ent; KS_LDS int32_t* pool;
   KS_LDS FastSlot* aslot; KS_LDS uint16_t* slot_of; KS_LDS FastHot* hs;
 };
 enum { FEV_DONE = 0, FEV_ENTRY = 1, FEV_SLOT = 2, FEV_SLOWSORT = 3, FEV_PLACE = 4, FEV_NEWCLAIM = 5, FEV_COUNT = 6 };
@@ -702,12 +721,12 @@ enum { FEV_DONE = 0, FEV_ENTRY = 1, FEV_SLOT = 2, FEV_SLOWSORT = 3, FEV_PLACE = 
 // The loop that places pods: a function of its own, WITHOUT calls — whatever happens rarely (a requirement set seen for the
 // first time, a new class slot, a new claim, pdqsort leaving its single-move path) ends the run with an event code; the
 // driver handles it through FastCold and runs the loop again. So the compiler allocates registers for this loop alone.
-template <class W, bool GS>
+template <class W, int GS>
 KS_COLD int fast_hot_run(FastHotCtx<GS> cx) {
-  typedef KS_LDS uint16_t* o16;
+  typedef typename FastMem<GS>::o16 o16;
   const unsigned long long t_in = W::clock();
   const o16 okey = fast_uniform(cx.okey), oord = fast_uniform(cx.oord);
-  const ClaimStates<GS> cst = fast_uniform(cx.cst);
+  const typename FastMem<GS>::States cst = fast_uniform(cx.cst);
   KS_LDS FastEnt* const ent = fast_uniform(cx.ent);
   KS_LDS int32_t* const pool = fast_uniform(cx.pool);
   KS_LDS FastSlot* const aslot = fast_uniform(cx.aslot);
@@ -1143,7 +1162,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS> cx) {
 }
 
 // The driver: runs the loop, handles its events through FastCold.
-template <class W, bool GS = false>
+template <class W, int GS = 0>
 struct FastEngine {
   FastCold<W, GS> cold;
   KS_LDS FastHot* hs;
@@ -1219,7 +1238,7 @@ struct FastEngine {
       } else if (ev == FEV_NEWCLAIM) {
         const int n = fast_uniform(h->n), bi = fast_uniform(h->bi);
         const int made = fast_uniform(cold.new_claim(fast_uniform(h->ev_arg), bi, n));
-        if (!made) { cold.finish(fast_uniform(cold.bail_code) < 0 ? 1 : 3, 0, 0, 0, 0, 0, nullptr); return; }
+        if (!made) { cold.finish(fast_uniform(cold.bail_code) < 0 ? 1 : 3, 0, (unsigned long long)fast_uniform(h->steps), 0, 0, 0, nullptr); return; }
         if (W::leader()) { h->oclaim[bi] = (uint32_t)n; h->ocnt[bi] = 0; h->n = n + 1; h->pend_new = 1; h->bi = bi + 1; }   // claim ids are handed out in creation order
         W::sync();
       } else { cold.bail_code = 22; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }

@@ -492,14 +492,20 @@ __global__ void ksolve_claim_gather(int n, ks::ClaimGatherArgs a) {
 // The cursor engine (fast_engine.h) for purely positive provisioning batches: one wavefront, O(1) steps.
 __global__ void __launch_bounds__(64) ksolve_pack_fast(const ks::FastArgs* a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  ks::FastEngine<ks::Wave, false> eng(&a->pv, &a->ws, &a->fw, lds);
+  ks::FastEngine<ks::Wave, 0> eng(&a->pv, &a->ws, &a->fw, lds);
   eng.solve();
 }
 // ... with the claims' state in HBM and only the order arrays in LDS: problems that need more in-flight claims than a CU's LDS
 // holds beside the caches (fast_engine.h ClaimStates<true>; the host retries here when the LDS plan ran out of claims)
 __global__ void __launch_bounds__(64) ksolve_pack_fast_wide(const ks::FastArgs* a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  ks::FastEngine<ks::Wave, true> eng(&a->pv, &a->ws, &a->fw, lds);
+  ks::FastEngine<ks::Wave, 1> eng(&a->pv, &a->ws, &a->fw, lds);
+  eng.solve();
+}
+// ... and with the order arrays in HBM too (plan 2): up to 65,472 in-flight claims — the exact configs[3] batch (10M pods, 27,345)
+__global__ void __launch_bounds__(64) ksolve_pack_fast_hbm(const ks::FastArgs* a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  ks::FastEngine<ks::Wave, 2> eng(&a->pv, &a->ws, &a->fw, lds);
   eng.solve();
 }
 // Batched form: block b runs the cursor engine on problem b.
@@ -615,11 +621,13 @@ static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, 
 }
 static void be_launch_pack_fast(ksolve_handle* h) {
   const int lds_bytes = h->fw.plan.total_bytes;
-  const bool wide = h->fw.plan.global_state != 0;
-  if (!hip_check(h, hipFuncSetAttribute(wide ? (const void*)ksolve_pack_fast_wide : (const void*)ksolve_pack_fast, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
+  const int plan = h->fw.plan.global_state;
+  const void* fn = plan == 2 ? (const void*)ksolve_pack_fast_hbm : plan == 1 ? (const void*)ksolve_pack_fast_wide : (const void*)ksolve_pack_fast;
+  if (!hip_check(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
   ks::FastArgs a{h->pv, h->ws, h->fw};
   be_h2d(h, h->d_fast_args, &a, sizeof(a));
-  if (wide) hipLaunchKernelGGL(ksolve_pack_fast_wide, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
+  if (plan == 2) hipLaunchKernelGGL(ksolve_pack_fast_hbm, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
+  else if (plan == 1) hipLaunchKernelGGL(ksolve_pack_fast_wide, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
   else hipLaunchKernelGGL(ksolve_pack_fast, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
   hip_check(h, hipGetLastError(), "ksolve_pack_fast launch");
 }

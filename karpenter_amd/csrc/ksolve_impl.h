@@ -73,7 +73,7 @@ struct ksolve_handle {
   bool big_capable = false;
   int lite_saved = 0;
   ks::FastWork fw{};            // cursor engine (fast_engine.h): workspace + LDS plan; fw.enabled while the problem may qualify
-  uint32_t engine_used = 0, fast_reason = 0;
+  uint32_t engine_used = 0, fast_reason = 0, fast_attempts = 0;
   ks::FastArgs* d_fast_args = nullptr;   // the record ksolve_pack_fast reads its problem from
   // probes of a resident cluster (ksolve_probe_create): a probe handle shares the base's device tables
   ksolve_handle* base = nullptr;         // non-null: this handle is a probe of `base`
@@ -180,7 +180,7 @@ static bool any_nonzero(const uint32_t* p, uint32_t n) {
   return false;
 }
 
-static void fast_plan_set(ksolve_handle* h, bool wide);   // the cursor engine's LDS plan (claim state in LDS / in HBM)
+static void fast_plan_set(ksolve_handle* h, int plan);   // the cursor engine's memory plan (0 LDS / 1 claim state in HBM / 2 order arrays too)
 static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* o, ksolve_handle* h) {
   if (!d || d->abi_version != KSOLVE_ABI_VERSION) return fail(h, KSOLVE_ERR_INVALID, "abi version mismatch");
   if (d->n_keys == 0 || d->n_keys > KSOLVE_MAX_KEYS) return fail(h, KSOLVE_ERR_INVALID, "n_keys out of range");
@@ -667,12 +667,13 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     fw.enabled = (P.plain && d->n_res <= 4 && h->opts.engine != 1 && d->n_pod_rows == d->n_pods && d->n_pods > 0) ? 1 : 0;
     if (fw.enabled) {
       h->fast_mc = mc;
-      fast_plan_set(h, h->opts.engine == 3);
+      fast_plan_set(h, h->opts.engine == 4 ? 2 : h->opts.engine == 3 ? 1 : 0);
       fw.var = dz<ks::FastVar>(h, 1);
       fw.c_hostseq = dz<uint32_t>(h, mc); fw.c_ent = dz<uint16_t>(h, mc);
       fw.c_state = dz<ks::FastClaim>(h, mc); fw.c_npods = dz<uint32_t>(h, mc);
       fw.ent_its = dz<uint64_t>(h, (size_t)ks::kFastEnt * it_words);
       fw.q_class = dz<uint32_t>(h, d->n_pods); fw.q_claim = dz<uint32_t>(h, d->n_pods); fw.q_cnt = dz<uint32_t>(h, d->n_pods);
+      { const size_t oc = std::min<size_t>(65472, ((size_t)mc + 63) & ~(size_t)63) + 64; fw.o_key = dz<uint16_t>(h, oc); fw.o_ord = dz<uint16_t>(h, oc); fw.o_snap = dz<uint16_t>(h, oc); }
       h->d_fast_args = dz<ks::FastArgs>(h, 1);
     }
   }
@@ -992,7 +993,7 @@ static ksolve_status solve_finish(ksolve_handle* h, ksolve_results* out) {
   out->us_prepass = (h->timers.ms[T_INDEX] + h->timers.ms[T_CLASSIFY] + h->timers.ms[T_SORT]) * 1e3;
   out->us_pack = h->timers.ms[T_PACK] * 1e3; out->us_finalize = h->timers.ms[T_FINALIZE] * 1e3; out->us_download = h->timers.ms[T_DOWNLOAD] * 1e3;
   out->packing_cost = cost;
-  out->engine_used = h->engine_used; out->engine_fallback_reason = h->fast_reason; out->cursor_wide = (h->engine_used == 2 && h->fw.plan.global_state) ? 1u : 0u;
+  out->engine_used = h->engine_used; out->engine_fallback_reason = h->fast_reason; out->cursor_wide = h->engine_used == 2 ? (uint32_t)h->fw.plan.global_state : 0u; out->cursor_attempts = h->fast_attempts;
   out->impl = im;
   return out->status;
 }
@@ -1736,9 +1737,11 @@ static void solve_probes(ksolve_handle** hs, uint32_t n, ksolve_results* outs, k
   }
 }
 
-// LDS plan of the cursor engine. wide = false: claim state (24 B) + order arrays (6 B) per claim in LDS, ~3,000 claims beside the
-// caches; wide = true: the claim state in HBM (FastWork::c_state), only the order arrays in LDS: ~15,000 claims.
-static void fast_plan_set(ksolve_handle* h, bool wide) {
+// Memory plan of the cursor engine. 0: claim state (24 B) + order arrays (6 B) per claim in LDS, ~3,000 claims beside the caches;
+// 1: the claim state in HBM (FastWork::c_state), only the order arrays in LDS: ~15,000 claims; 2: the order arrays in HBM too
+// (FastWork::o_key / o_ord / o_snap): 65,472 claims, the range of the 16-bit claim ids.
+static void fast_plan_set(ksolve_handle* h, int plan) {
+  const bool wide = plan >= 1;
   auto align = [](int x) { return (x + 15) & ~15; };
   ks::FastPlan& fp = h->fw.plan;
   int off = 0;
@@ -1749,16 +1752,20 @@ static void fast_plan_set(ksolve_handle* h, bool wide) {
   fp.off_hot = off; off = align(off + (int)sizeof(ks::FastHot));
   const int budget = 160 * 1024 - 512;
   const int per_claim = (wide ? 0 : (int)sizeof(ks::FastClaim)) + 6;
-  int cap = ((budget - off - 64) / per_claim) & ~63;
+  int cap = plan >= 2 ? 65472 : ((budget - off - 64) / per_claim) & ~63;
   if (cap > 65472) cap = 65472;
   if (!wide && h->opts.lds_claim_cap && (int)((h->opts.lds_claim_cap + 63) & ~63u) < cap) cap = (int)((h->opts.lds_claim_cap + 63) & ~63u);
+#ifdef KSOLVE_TEST_HOOKS
+  if (plan == 1) if (const char* e = getenv("KSOLVE_TEST_WIDE_CAP")) { const int c = (atoi(e) + 63) & ~63; if (c > 0 && c < cap) cap = c; }   // tests: a small plan 1, so that small problems reach plan 2
+#endif
   if (cap > (int)((h->fast_mc + 63) & ~63u)) cap = (int)((h->fast_mc + 63) & ~63u);
   fp.cap = cap;
-  fp.global_state = wide ? 1 : 0;
+  fp.global_state = plan >= 2 ? 2 : wide ? 1 : 0;
   fp.off_state = off; if (!wide) off = align(off + cap * (int)sizeof(ks::FastClaim));
-  fp.off_key = off; off = align(off + cap * 2);
-  fp.off_ord = off; off = align(off + cap * 2);
-  fp.off_snap = off; off = align(off + cap * 2);
+  const int lds_order = plan >= 2 ? 0 : cap;
+  fp.off_key = off; off = align(off + lds_order * 2);
+  fp.off_ord = off; off = align(off + lds_order * 2);
+  fp.off_snap = off; off = align(off + lds_order * 2);
   fp.total_bytes = off;
 }
 
@@ -1774,7 +1781,9 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out, bool fresh_con
   if (h->fw.enabled && !h->pv.big && h->n_pods && h->n_classes) {
     // the cursor engine first; status 3 = "not my shape / stopped before any result": the general engine takes over — unless all
     // that stopped it was the number of claims its LDS plan holds (reason 26): then once more with the claims' state in HBM
+    h->fast_attempts = 0;
     for (;;) {
+      h->fast_attempts++;
       be_tic(h, T_PACK);
       be_launch_pack_fast(h);
       be_toc(h, T_PACK);
@@ -1788,15 +1797,26 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out, bool fresh_con
         if (n_claims) be_launch_fast_records(h, n_claims);
         return solve_finish(h, out);
       }
+      unsigned long long ctr_pops = 0;
       if (be_ok(h) && status == 3) {
         ks::Counters ctr{};
         be_d2h(h, &ctr, h->ws.counters, sizeof(ctr));
         be_sync(h);
         h->fast_reason = (uint32_t)ctr.cycles[20];
+        ctr_pops = ctr.queue_pops;
       } else if (be_ok(h)) h->fast_reason = 100;   // more claims than max_claims: the general engine reports it (or moves to BIG)
-      if (be_ok(h) && h->fast_reason == 26 && !h->fw.plan.global_state && !h->opts.lds_claim_cap) {
+      if (be_ok(h) && h->fast_reason == 26 && h->fw.plan.global_state < 2 && !h->opts.lds_claim_cap) {
+        // out of claim slots: the next plan (later solves of this handle start there). The attempt says how many pods its
+        // claims took: when the whole queue, at that rate and a quarter more, would not fit plan 1 either, go to plan 2 at once.
         const int had = h->fw.plan.cap;
-        fast_plan_set(h, true);                      // later solves of this handle start there
+        int next = h->fw.plan.global_state + 1;
+        if (next == 1) {
+          fast_plan_set(h, 1);
+          const double placed = (double)(ctr_pops > 0 ? ctr_pops : 1);
+          const bool holds_all = h->fw.plan.cap >= (int)((h->fast_mc + 63) & ~63u);   // plan 1 has a slot for every claim the problem may open
+          if (!holds_all && (double)had * (double)h->n_pods / placed * 1.25 > (double)h->fw.plan.cap) next = 2;
+        }
+        fast_plan_set(h, next);
         if (h->fw.plan.cap > had) {
           st = solve_prepare(h, false);
           if (st != KSOLVE_OK) return st;

@@ -93,8 +93,9 @@ static void be_launch_pack_fast(ksolve_handle* h) {
   std::vector<char> lds((size_t)h->fw.plan.total_bytes + 64, (char)0xA5);   // garbage, like the device's LDS at kernel start
   ks::FastArgs a{h->pv, h->ws, h->fw};
   be_h2d(h, h->d_fast_args, &a, sizeof(a));
-  if (h->fw.plan.global_state) { ks::FastEngine<ks::Wave, true> eng(&h->d_fast_args->pv, &h->d_fast_args->ws, &h->d_fast_args->fw, lds.data()); eng.solve(); }
-  else { ks::FastEngine<ks::Wave, false> eng(&h->d_fast_args->pv, &h->d_fast_args->ws, &h->d_fast_args->fw, lds.data()); eng.solve(); }
+  if (h->fw.plan.global_state == 2) { ks::FastEngine<ks::Wave, 2> eng(&h->d_fast_args->pv, &h->d_fast_args->ws, &h->d_fast_args->fw, lds.data()); eng.solve(); }
+  else if (h->fw.plan.global_state) { ks::FastEngine<ks::Wave, 1> eng(&h->d_fast_args->pv, &h->d_fast_args->ws, &h->d_fast_args->fw, lds.data()); eng.solve(); }
+  else { ks::FastEngine<ks::Wave, 0> eng(&h->d_fast_args->pv, &h->d_fast_args->ws, &h->d_fast_args->fw, lds.data()); eng.solve(); }
 }
 static ks::FastQueueArgs fast_queue_args(ksolve_handle* h) {
   return ks::FastQueueArgs{h->pv.sorted_pods, h->pv.row_class, h->fw.q_class, h->fw.q_claim, h->fw.q_cnt, h->ws.assign, h->ws.slot};

@@ -27,6 +27,11 @@ def check_cursor(oracle, emu, prob, want=None):
     parity.assert_same_results(got, want)
     assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
     assert abs(got["packingCost"] - want["packingCost"]) < 1e-9 * max(1.0, want["packingCost"])
+    for plan, engine in ((1, "cursor-wide"), (2, "cursor-hbm")):   # the same engine with its claim state / claim order in HBM (fast_engine.h FastMem)
+        other = NewScheduler(with_engine(prob, engine), solver_lib=emu).Solve()
+        assert other["counters"]["cursorMemoryPlan"] == plan
+        parity.assert_same_results(other, want)
+        assert other["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"] and other["counters"]["slowSorts"] == got["counters"]["slowSorts"]
     return got
 
 
@@ -262,14 +267,42 @@ def test_claim_state_in_hbm_when_the_lds_plan_runs_out_of_claims(oracle, emu):
     want = oracle.solve(prob)
     assert len(want["newNodeClaims"]) > 3100
     seen = {}
-    for engine in ("auto", "cursor-wide", "general"):
+    for engine in ("auto", "cursor-wide", "cursor-hbm", "general"):
         s = NewScheduler(dict(prob, options=dict(prob["options"], engine=engine)), solver_lib=emu)
         got = s.Solve()
         parity.assert_same_results(got, want)
         assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
-        seen[engine] = (got["counters"]["engine"], got["counters"]["cursorClaimStateInHBM"], got["counters"]["engineFallbackReason"])
+        seen[engine] = (got["counters"]["engine"], got["counters"]["cursorMemoryPlan"], got["counters"]["engineFallbackReason"])
         if engine == "auto":      # the handle remembers: the second Solve() starts with the wide plan
             again = s.Solve()
             parity.assert_same_results(again, want)
         s.close()
-    assert seen == {"auto": ("cursor", True, 0), "cursor-wide": ("cursor", True, 0), "general": ("general", False, 0)}, seen
+    assert seen == {"auto": ("cursor", 1, 0), "cursor-wide": ("cursor", 1, 0), "cursor-hbm": ("cursor", 2, 0), "general": ("general", -1, 0)}, seen
+
+
+def test_claim_order_in_hbm_above_the_wide_plan(oracle, emu, monkeypatch):
+    """Above ~15,000 in-flight NodeClaims the order arrays leave LDS too (plan 2, FastMem<2>: 65,472 claims — the exact configs[3]
+    batch of 10M pods ends with 27,345). With plan 1 shrunk by the test switch KSOLVE_TEST_WIDE_CAP the automatic path reaches plan 2
+    both ways: straight from the LDS plan when the first attempt's claims-per-pod rate says plan 1 cannot hold the queue either
+    (the big pods come first: one claim per pod placed), and step by step (0 -> 1 -> 2) when the rate said it would
+    (claims that open late: pods with little cpu — the end of the queue — and 1.5 TiB of memory each; 3,000 of them join the
+    big pods' claims, the other 1,500 need their own)."""
+    big = fx.pod(uid="t", requests={"cpu": "130", "memory": "1Gi"})
+    small = fx.pod(uid="t", requests={"cpu": "500m", "memory": "256Mi"}, node_selector={fx.ARCH: "amd64"})
+    late = fx.pod(uid="t", requests={"cpu": "100m", "memory": "1500Gi"})
+    np_ = fx.node_pool("default")
+    np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    cases = (("straight", 3200, [{"count": 3600, "uidSeed": 7, "template": big}, {"count": 5000, "uidSeed": 8, "template": small}]),
+             ("stepwise", 4160, [{"count": 3000, "uidSeed": 7, "template": big}, {"count": 20000, "uidSeed": 8, "template": small}, {"count": 4500, "uidSeed": 9, "template": late}]))
+    for how, wide_cap, groups in cases:
+        monkeypatch.setenv("KSOLVE_TEST_WIDE_CAP", str(wide_cap))
+        prob = fx.problem(fx.kwok_catalog(144), [np_], pod_groups=groups, well_known=fx.KWOK_WELL_KNOWN)
+        want = oracle.solve(prob)
+        assert len(want["newNodeClaims"]) > wide_cap, (how, len(want["newNodeClaims"]))
+        s = NewScheduler(prob, solver_lib=emu)
+        got = s.Solve()
+        parity.assert_same_results(got, want)
+        assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
+        assert (got["counters"]["engine"], got["counters"]["cursorMemoryPlan"], got["counters"]["engineFallbackReason"]) == ("cursor", 2, 0), (how, got["counters"])
+        assert got["counters"]["cursorAttempts"] == (2 if how == "straight" else 3), (how, got["counters"]["cursorAttempts"])
+        s.close()

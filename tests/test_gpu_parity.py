@@ -388,12 +388,14 @@ def test_full_size_digest(pin):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     from make_fullsize_digests import build_problem
     g = json.load(open(pin))
-    if g["pods"] > 2_000_000 and os.environ.get("KSOLVE_TEST_HUGE_PINS") != "1":
-        pytest.skip("a whole-batch pin of this size takes the general engine minutes of GPU time: KSOLVE_TEST_HUGE_PINS=1, or tests/tools/whole_batch_c3.py")
+    if g["pods"] > 2_000_000 and g["config"] == "config3" and os.environ.get("KSOLVE_TEST_HUGE_PINS") != "1":
+        pytest.skip("a pin of this size on the general engine takes minutes of GPU time: KSOLVE_TEST_HUGE_PINS=1, or tests/tools/whole_batch_c3.py")
     prob = build_problem(g["config"], g["pods"], g["types"], g["seed"], g["extra"])
     # cursor-wide: the cursor engine with the claims' state in HBM (the plan the library moves to when the LDS plan runs out of claims) —
     # every load of a claim another lane stored has to come from L2, not a stale L1 line: the digest of a million placements says so
-    engines = ["auto"] + (["general"] if g["config"] != "config3" and g["pods"] <= 250000 else []) + (["cursor-wide"] if g["config"] in ("config1", "config2", "config4") and g["pods"] <= 2_000_000 else [])
+    # cursor-hbm: the claim order in HBM too (plan 2, above ~15,000 claims: the 10M-pod configs[3] batch as ONE problem runs there)
+    cursor_shape = g["config"] in ("config1", "config2", "config4")
+    engines = ["auto"] + (["general"] if g["config"] != "config3" and g["pods"] <= 250000 else []) + (["cursor-wide", "cursor-hbm"] if cursor_shape and g["pods"] <= 2_000_000 else [])
     for eng in engines:
         s = NewScheduler(dict(prob, options=dict(prob["options"], engine=eng)))
         r = s.Solve()
@@ -407,8 +409,8 @@ def test_full_size_digest(pin):
         assert float(r["packingCost"]).hex() == g["packingCost"] or abs(r["packingCost"] - g["packingCostApprox"]) < 1e-9 * g["packingCostApprox"]
         if eng == "auto":
             assert r["counters"]["engine"] == ("general" if g["config"] == "config3" else "cursor"), r["counters"]
-        if eng == "cursor-wide":
-            assert r["counters"]["engine"] == "cursor" and r["counters"]["cursorClaimStateInHBM"] is True
+        if eng in ("cursor-wide", "cursor-hbm"):
+            assert r["counters"]["engine"] == "cursor" and r["counters"]["cursorMemoryPlan"] == (1 if eng == "cursor-wide" else 2), r["counters"]
 
 
 def test_offering_override_groups_on_the_device(oracle):
@@ -584,3 +586,10 @@ def test_cursor_engine_moves_its_claim_state_to_hbm_on_the_device(oracle):
     NodeClaims than the cursor engine's LDS plan holds -> the same engine with the claims' state in HBM, not the general engine."""
     import test_cursor_engine as tce
     tce.test_claim_state_in_hbm_when_the_lds_plan_runs_out_of_claims(oracle, None)
+
+
+def test_cursor_engine_moves_its_claim_order_to_hbm_on_the_device(oracle, monkeypatch):
+    """tests/test_cursor_engine.py::test_claim_order_in_hbm_above_the_wide_plan on the GPU (the -DKSOLVE_TEST_HOOKS build of the device
+    library: it reads KSOLVE_TEST_WIDE_CAP, the product does not): plan 2 reached straight from the LDS plan and step by step."""
+    import test_cursor_engine as tce
+    tce.test_claim_order_in_hbm_above_the_wide_plan(oracle, parity.build_hooks(), monkeypatch)
