@@ -121,9 +121,11 @@ KS_FN void lds_put(KS_LDS T* p, const T& v) {
 
 
 // The in-flight claims' state by claim id. LDS while the problem's claims fit beside the order arrays and the caches (the
-// benchmarked configuration: 2,763 claims); HBM otherwise (GS = true): the lane that tests a claim then gathers its 24 bytes from
-// L2 instead of LDS — three 8-byte loads at agent scope, so that a store another lane of this wavefront made earlier is what it
-// sees (the vector L1 is not kept coherent with the wavefront's own stores from other lanes).
+// benchmarked configuration: 2,763 claims); HBM otherwise (GS = true): the lane that tests a claim then gathers its 24 bytes
+// through the vector L1 / L2 instead of LDS. Plain loads and stores: this wavefront is the only reader and writer, its vector
+// memory operations execute in order, W::sync() (a wavefront-scope fence) follows every store — what the general engine's
+// HBM-resident claim records have relied on since round 1. (-DKS_CLAIM_STATE_AGENT_SCOPE: relaxed atomics at agent scope
+// instead, every access served by L2 — the first build of the plan, 1.48 µs per pod at 2M pods of configs[1].)
 template <bool GS> struct ClaimStates;
 template <> struct ClaimStates<false> {
   KS_LDS FastClaim* p;
@@ -135,24 +137,26 @@ template <> struct ClaimStates<true> {
   KS_FN FastClaim get(uint32_t c) const {
     FastClaim out;
     u64_alias* o = (u64_alias*)&out;
-#if KS_DEVICE
+#if KS_DEVICE && defined(KS_CLAIM_STATE_AGENT_SCOPE)
     const uint64_t* s = (const uint64_t*)&p[c];
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(FastClaim) / 8); ++i) o[i] = __hip_atomic_load(&s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
     const u64_alias* s = (const u64_alias*)&p[c];
+#pragma unroll
     for (int i = 0; i < (int)(sizeof(FastClaim) / 8); ++i) o[i] = s[i];
 #endif
     return out;
   }
   KS_FN void put(uint32_t c, const FastClaim& v) const {
     const u64_alias* o = (const u64_alias*)&v;
-#if KS_DEVICE
+#if KS_DEVICE && defined(KS_CLAIM_STATE_AGENT_SCOPE)
     uint64_t* s = (uint64_t*)&p[c];
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(FastClaim) / 8); ++i) __hip_atomic_store(&s[i], o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
     u64_alias* s = (u64_alias*)&p[c];
+#pragma unroll
     for (int i = 0; i < (int)(sizeof(FastClaim) / 8); ++i) s[i] = o[i];
 #endif
   }
@@ -544,11 +548,11 @@ struct FastCold {
     order.n = (int)W::uniform((uint64_t)(uint32_t)n); order.defect = (int)W::uniform((uint64_t)(uint32_t)defect); order.defect_append = W::uniform((uint64_t)app) != 0;
     n = order.n;
     const o16 oo = order.ord; const o16 sn = snap;
-    W::for_n(n, [&](int i) { sn[i] = oo[i]; });
+    if constexpr (FastMem<GS>::kOrderHbm) W::copy8(sn, oo, n); else W::for_n(n, [&](int i) { sn[i] = oo[i]; });
     order.sort();
-    lo_ = W::find_first(0, n, [&](int i) { return sn[i] != oo[i]; });
+    lo_ = order.ff(0, n, [&](int i) { return sn[i] != oo[i]; });
     if (lo_ >= n) { lo_ = 0; hi_ = -1; return; }
-    hi_ = W::find_last(0, n, [&](int i) { return sn[i] != oo[i]; });
+    hi_ = order.fl(0, n, [&](int i) { return sn[i] != oo[i]; });
   }
   // The new claim (appended at n-1 with one pod) takes its place behind the last claim with at most one pod. Returns its
   // position b >= 0 (Mp->acc = the class slots that accept it), -1 when pdqsort left the single-move path (lo_/hi_), -2: stop.

@@ -71,6 +71,9 @@ struct ClaimOrder {
   // all of them are in flight together (a long move — tens of thousands of equally full claims — is bound by round trips)
   static constexpr int kPerLane = sizeof(P32) == 8 ? 16 : 1;   // HBM-resident order (64-bit pointers): sixteen elements per lane per round
   static constexpr int kRound = 64 * kPerLane;
+  // searches over the order: one round trip per 64 elements in LDS; eight rounds in flight over an HBM-resident order
+  template <class F> KS_FN int ff(int lo, int hi, F pred) const { if constexpr (kPerLane > 1) return W::find_first8(lo, hi, pred); else return W::find_first(lo, hi, pred); }
+  template <class F> KS_FN int fl(int lo, int hi, F pred) const { if constexpr (kPerLane > 1) return W::find_last8(lo, hi, pred); else return W::find_last(lo, hi, pred); }
   KS_FN void shift_round(int lo, int hi, int delta, bool same_keys) {
 #if KS_DEVICE
     uint32_t k[kPerLane], o[kPerLane];
@@ -182,7 +185,7 @@ struct ClaimOrder {
       return b;
     }
     const P32 kp = key;
-    return W::find_first(i, b, [kp](int x) { return kp[x] < kp[x - 1]; });
+    return ff(i, b, [kp](int x) { return kp[x] < kp[x - 1]; });
   }
   KS_FN bool partial_insertion_sort(int a, int b, bool top) {
     int i = a + 1;
@@ -196,11 +199,11 @@ struct ClaimOrder {
         const P32 kq = key;
         if (defect_append) {           // i == n-1: the new claim moves left behind the last claim with <= its count
           uint32_t mv = key[i];
-          int t = W::find_last(0, i, [kq, mv](int x) { return !(mv < kq[x]); });
+          int t = fl(0, i, [kq, mv](int x) { return !(mv < kq[x]); });
           rotate_right(t + 1, i);
         } else {                       // i == p+1: the incremented claim at p moves right past the claims with a smaller count
           uint32_t mv = key[i - 1];
-          int e = W::find_first(i, b, [kq, mv](int x) { return !(kq[x] < mv); });
+          int e = ff(i, b, [kq, mv](int x) { return !(kq[x] < mv); });
           rotate_left(i - 1, e - 1);
         }
         defect = -1;
@@ -210,13 +213,13 @@ struct ClaimOrder {
       if (i - a >= 2) {  // shift the smaller one to the left (Go uses the absolute bound j >= 1)
         uint32_t mv = key[i - 1];
         const P32 kp = key;
-        int t = W::find_last(0, i - 1, [kp, mv](int x) { return !(mv < kp[x]); });
+        int t = fl(0, i - 1, [kp, mv](int x) { return !(mv < kp[x]); });
         rotate_right(t + 1, i - 1);
       }
       if (b - i >= 2) {  // shift the greater one to the right
         uint32_t mv = key[i];
         const P32 kp = key;
-        int e = W::find_first(i + 1, b, [kp, mv](int x) { return !(kp[x] < mv); });
+        int e = ff(i + 1, b, [kp, mv](int x) { return !(kp[x] < mv); });
         rotate_left(i, e - 1);
       }
       if (top) defect = -1;  // the single defect is repaired: the rest of the array is known sorted
@@ -243,8 +246,8 @@ struct ClaimOrder {
     const P32 kp = key;
     int i = a + 1, j = b - 1;
     for (;;) {
-      i = W::find_first(i, j + 1, [kp, pv](int x) { return pv < kp[x]; });
-      j = W::find_last(i, j + 1, [kp, pv](int x) { return !(pv < kp[x]); });
+      i = ff(i, j + 1, [kp, pv](int x) { return pv < kp[x]; });
+      j = fl(i, j + 1, [kp, pv](int x) { return !(pv < kp[x]); });
       if (i > j) break;
       swap(i, j); i++; j--;
     }
@@ -255,13 +258,13 @@ struct ClaimOrder {
     uint32_t pv = key[a];
     const P32 kp = key;
     int i = a + 1, j = b - 1;
-    i = W::find_first(i, j + 1, [kp, pv](int x) { return !(kp[x] < pv); });
-    j = W::find_last(i, j + 1, [kp, pv](int x) { return kp[x] < pv; });
+    i = ff(i, j + 1, [kp, pv](int x) { return !(kp[x] < pv); });
+    j = fl(i, j + 1, [kp, pv](int x) { return kp[x] < pv; });
     if (i > j) { swap(j, a); already = true; return j; }
     swap(i, j); i++; j--;
     for (;;) {
-      i = W::find_first(i, j + 1, [kp, pv](int x) { return !(kp[x] < pv); });
-      j = W::find_last(i, j + 1, [kp, pv](int x) { return kp[x] < pv; });
+      i = ff(i, j + 1, [kp, pv](int x) { return !(kp[x] < pv); });
+      j = fl(i, j + 1, [kp, pv](int x) { return kp[x] < pv; });
       if (i > j) break;
       swap(i, j); i++; j--;
     }
@@ -328,13 +331,13 @@ struct ClaimOrder {
       if (defect_append) {
         uint32_t mv = key[n - 1];
         const P32 kp = key;
-        int t = W::find_last(0, n - 1, [kp, mv](int x) { return !(mv < kp[x]); });
+        int t = fl(0, n - 1, [kp, mv](int x) { return !(mv < kp[x]); });
         rotate_right(t + 1, n - 1);
       } else {
         int p = defect;
         uint32_t mv = key[p];
         const P32 kp = key;
-        int e = W::find_first(p + 1, n, [kp, mv](int x) { return !(kp[x] < mv); });
+        int e = ff(p + 1, n, [kp, mv](int x) { return !(kp[x] < mv); });
         rotate_left(p, e - 1, true);   // everything between carries the claim's old count
       }
       defect = -1;
@@ -355,12 +358,12 @@ struct ClaimOrder {
           const int i = n - 1;
           if (i >= 1 && key[i] < key[i - 1]) {
             const uint32_t mv = key[i];
-            const int t = kPerLane > 1 ? upper_last_sorted(0, i, mv) : W::find_last(0, i, [kq, mv](int x) { return !(mv < kq[x]); });   // [0, i) is sorted
+            const int t = kPerLane > 1 ? upper_last_sorted(0, i, mv) : fl(0, i, [kq, mv](int x) { return !(mv < kq[x]); });   // [0, i) is sorted
             rotate_right(t + 1, i);
           }
         } else if (p + 1 < n && key[p + 1] < key[p]) {
           const uint32_t mv = key[p];
-          const int e = kPerLane > 1 ? lower_bound_sorted(p + 1, n, mv) : W::find_first(p + 1, n, [kq, mv](int x) { return !(kq[x] < mv); });   // [p+1, n) is sorted
+          const int e = kPerLane > 1 ? lower_bound_sorted(p + 1, n, mv) : ff(p + 1, n, [kq, mv](int x) { return !(kq[x] < mv); });   // [p+1, n) is sorted
           rotate_left(p, e - 1, true);   // everything between carries the claim's old count
         }
         defect = -1;
