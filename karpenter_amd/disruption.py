@@ -366,21 +366,29 @@ class ResidentCluster:
         self.prefetch([candidates])
         return self._cache[self._key(candidates)]
 
-    def decisions(self, candidate_sets, detail=False, multi_node=False, library_prices=False):
+    def decisions(self, candidate_sets, detail=False, multi_node=False, library_prices=False, arrays=False):
         """computeConsolidation (consolidation.go:159-256) for every candidate set in ONE device launch, verdicts included
         (Scheduler.Sweep / ksolve_sweep): [{"decision", "candidates", "replacement", "replacementCapacityType"}], the commands
         compute_consolidation() returns without their Results. Descriptors and verdicts are computed by the host library.
         multi_node: the sets are prefixes of MultiNodeConsolidation's search — a REPLACE over several candidates goes through
         filterOutSameInstanceType (multinodeconsolidation.go:209-246) and comes back as NOOP when it does not stand.
         library_prices: the candidates' prices and capacity types are taken from the host library's node table instead of
-        being summed here."""
+        being summed here. arrays: the binary form of the call (Scheduler.SweepArrays / ksched_sweep_arrays: no JSON on either side
+        of the host library, what a cgo caller does; the library's prices; no `reason` texts)."""
         cluster = self.cluster
         live = [[c for c in cs if not c.get("markedForDeletion")] for cs in candidate_sets]
         prices = None if library_prices else [sum(self._price(c) for c in cs) for cs in candidate_sets]
         all_spot = None if library_prices else [all(c["labels"][fx.CAPACITY_TYPE] == "spot" for c in cs) for cs in candidate_sets]
         pos = getattr(self, "_position", None)
         names = [[pos[c["name"]] for c in cs] for cs in live] if pos is not None else [[c["name"] for c in cs] for cs in live]
-        out = self.scheduler.Sweep(names, prices, all_spot, detail=detail, multi_node=multi_node)
+        if arrays:
+            if pos is None or detail:
+                raise ValueError("the binary sweep takes node positions (ResidentCluster.from_compact) and has no detail form")
+            if not hasattr(self, "_it_names"):
+                self._it_names = [t["name"] for t in cluster["instanceTypes"]]
+            out = self.scheduler.SweepArrays(names, multi_node=multi_node, instance_type_names=self._it_names)
+        else:
+            out = self.scheduler.Sweep(names, prices, all_spot, detail=detail, multi_node=multi_node)
         repl = {r["probe"]: r for r in out["replacements"]}
         cmds = []
         for i, cs in enumerate(candidate_sets):

@@ -2078,7 +2078,15 @@ extern "C" void* ksched_probe(void* base_session, const char* probe_json) {
 // computeConsolidation's verdict (consolidation.go:159-256): delete when no NodeClaim is needed, replace when exactly one is
 // and a cheaper instance type remains after the price filter (nodeclaim.go:411-420), otherwise nothing. The probe descriptors
 // are built here (CSR arrays over the session's node -> pods tables), not in the caller's language. Returns one document.
-static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas, const char* sweep_json);
+// the binary form of a sweep: candidates in as one CSR of positions in the stateNodes list, verdicts out as arrays (what a cgo caller
+// hands over and reads back; no JSON on either side)
+struct SweepArrays {
+  uint32_t n; const uint32_t* cand_off; const uint32_t* cand_nodes; int multi_node;
+  int32_t* decisions; uint8_t* all_scheduled; uint32_t* live_claims; int32_t* status; uint64_t* ref_evals;   // [n] each
+  uint32_t* repl_off; uint32_t* repl_its; uint32_t repl_cap; uint8_t* repl_spot;                            // replace verdicts: instance type indices (CSR over probes), pinned-to-spot flag
+  double* timings; uint32_t n_timings;
+};
+static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas, const char* sweep_json, SweepArrays* A = nullptr);
 extern "C" char* ksched_sweep(void* base_session, const char* sweep_json) {
   Session* B = (Session*)base_session;
   if (!B || !B->handle || B->base) return error_json("invalid", "sweep needs an open base session");
@@ -2096,7 +2104,29 @@ extern "C" char* ksched_sweep_replicas(void** sessions, int n, const char* sweep
   }
   return sweep_impl((Session*)sessions[0], hs, sweep_json);
 }
-static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas, const char* sweep_json) {
+// The sweep without JSON on either side — the form a cgo caller uses: probe p removes the stateNodes at positions
+// cand_nodes[cand_off[p] .. cand_off[p + 1]) (their prices and capacity types come from the session's node table); out come
+// computeConsolidation's verdict per probe (0 nothing, 1 delete, 2 replace, 3 spot-to-spot: the caller's per-probe path), whether all
+// non-pending pods were scheduled, the live NodeClaims, the solver status, the reference-equivalent bin evaluations, and for replace
+// verdicts the instance types that passed the price filter (indices into the problem's instanceTypes, CSR repl_off / repl_its) with the
+// pinned-to-spot flag. timings[]: descriptors_ms, sweep_ms, verdicts_ms, upload_us, pack_us, finalize_us, download_us, pods, bin
+// evaluations, node evaluations, node block steps, classes, it_words, nodes, node_dead0_us, req_words, resources, devices.
+// Returns NULL, or an error document (ksched_free).
+extern "C" char* ksched_sweep_arrays(void** sessions, int n_sessions, uint32_t n, const uint32_t* cand_off, const uint32_t* cand_nodes, int multi_node,
+                                     int32_t* decisions, uint8_t* all_scheduled, uint32_t* live_claims, int32_t* status, uint64_t* ref_evals,
+                                     uint32_t* repl_off, uint32_t* repl_its, uint32_t repl_cap, uint8_t* repl_spot, double* timings, uint32_t n_timings) {
+  if (!sessions || n_sessions < 1 || !cand_off || (cand_off[n] && !cand_nodes)) return error_json("invalid", "sweep needs an open base session and candidate arrays");
+  std::vector<ksolve_handle*> hs;
+  for (int i = 0; i < n_sessions; ++i) {
+    Session* S = (Session*)sessions[i];
+    if (!S || !S->handle || S->base) return error_json("invalid", "sweep needs open base sessions");
+    hs.push_back(S->handle);
+  }
+  if (hs.size() == 1) hs.clear();
+  SweepArrays A{n, cand_off, cand_nodes, multi_node, decisions, all_scheduled, live_claims, status, ref_evals, repl_off, repl_its, repl_cap, repl_spot, timings, n_timings};
+  return sweep_impl((Session*)sessions[0], hs, nullptr, &A);
+}
+static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas, const char* sweep_json, SweepArrays* A) {
   try {
     auto run = (decltype(&ksolve_sweep))dlsym(B->api.lib, "ksolve_sweep");
     auto run_replicas = (decltype(&ksolve_sweep_replicas))dlsym(B->api.lib, "ksolve_sweep_replicas");
@@ -2115,7 +2145,7 @@ static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas,
       if (B->node_index.empty()) { B->node_index.reserve(B->node_names.size() * 2); for (size_t e = 0; e < B->node_names.size(); ++e) B->node_index[B->node_names[e]] = (int)e; }
       B->sweep_tables = true;
     }
-    Value doc = kj::Parser(sweep_json).parse();
+    Value doc = A ? Value::object() : kj::Parser(sweep_json).parse();
     // candidates: one list of nodes per simulation ("candidates": [[name | position, ...], ...]) or the same as CSR arrays of
     // positions in the stateNodes list ("candidateOff": n + 1 offsets, "candidateNodes")
     std::vector<uint32_t> node_off(1, 0), nodes;
@@ -2133,7 +2163,15 @@ static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas,
       nodes.resize(w);
       node_off.push_back((uint32_t)nodes.size());
     };
-    if (doc.has("candidateOff")) {
+    if (A) {
+      nodes.reserve(A->cand_off[A->n]);
+      for (uint32_t p = 0; p < A->n; ++p) {
+        if (A->cand_off[p + 1] < A->cand_off[p]) throw std::runtime_error("sweep: candidate offsets must not decrease");
+        const size_t n0 = nodes.size();
+        for (uint32_t j = A->cand_off[p]; j < A->cand_off[p + 1]; ++j) nodes.push_back(by_position((int64_t)A->cand_nodes[j]));
+        end_probe(n0);
+      }
+    } else if (doc.has("candidateOff")) {
       const auto& off = doc.at("candidateOff").items();
       const auto& flat = doc.at("candidateNodes").items();
       if (off.empty() || off.back().i(-1) != (int64_t)flat.size()) throw std::runtime_error("sweep: candidateOff does not cover candidateNodes");
@@ -2163,7 +2201,7 @@ static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas,
     static const std::vector<Value> no_items;
     const auto& prices = own_prices ? no_items : doc.at("prices").items();
     const auto& all_spot = own_prices ? no_items : doc.at("allSpot").items();
-    const bool multi_node = doc.at("multiNode").boolean_or(false);
+    const bool multi_node = A ? A->multi_node != 0 : doc.at("multiNode").boolean_or(false);
     const bool detail = doc.at("detail").boolean_or(false);
     const bool spot_to_spot = B->root.at("options").at("spotToSpotConsolidation").boolean_or(false);
     // the displaced pods of every probe: sizes first, then every probe fills its own slice (independent: on a few threads)
@@ -2323,6 +2361,35 @@ static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas,
       }
       V.decision = decision; V.all_ok = all_ok; V.live = live;
     });
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    if (A) {
+      uint32_t at = 0;
+      bool overflow = false;
+      for (uint32_t p = 0; p < n; ++p) {
+        const Verdict& V = verdicts[p];
+        if (A->decisions) A->decisions[p] = V.decision;
+        if (A->all_scheduled) A->all_scheduled[p] = V.all_ok ? 1 : 0;
+        if (A->live_claims) A->live_claims[p] = V.live;
+        if (A->status) A->status[p] = (int32_t)res.status[p];
+        if (A->ref_evals) A->ref_evals[p] = res.ref_bin_evaluations[p];
+        if (A->repl_spot) A->repl_spot[p] = V.pin_spot ? 1 : 0;
+        if (A->repl_off) A->repl_off[p] = at;
+        if (V.decision == 2) {
+          if (A->repl_its && at + V.cheaper.size() <= A->repl_cap) memcpy(A->repl_its + at, V.cheaper.data(), V.cheaper.size() * 4);
+          else if (A->repl_its) overflow = true;
+          at += (uint32_t)V.cheaper.size();
+        }
+      }
+      if (A->repl_off) A->repl_off[n] = at;
+      const auto t_end = std::chrono::steady_clock::now();
+      const double tv[] = {ms(t_begin, t_desc), ms(t_desc, t_solved), ms(t_solved, t_end), res.us_upload, res.us_pack, res.us_finalize, res.us_download, (double)pods.size(),
+                           (double)res.total_bin_evaluations, (double)res.total_node_evaluations, (double)res.total_node_block_steps, (double)res.n_classes, (double)res.it_words, (double)res.n_nodes,
+                           res.us_node_dead0, (double)kd.req_words, (double)n_res, (double)std::max<size_t>(1, replicas.size())};
+      for (uint32_t i = 0; i < A->n_timings && i < sizeof(tv) / sizeof(tv[0]); ++i) A->timings[i] = tv[i];
+      release(&res);
+      if (overflow) return error_json("capacity", "replacement instance types exceed repl_cap (repl_off[n] says how many there are)");
+      return nullptr;
+    }
     for (uint32_t p = 0; p < n; ++p) {
       const Verdict& V = verdicts[p];
       if (V.reason) reasons.add_new(std::to_string(p), Value::string(V.reason));
@@ -2357,7 +2424,6 @@ static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas,
     out.set("referenceBinEvaluations", refs); out.set("replacements", repl); out.set("reasons", reasons);
     if (detail) out.set("details", details);
     Value tj = Value::object();
-    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     tj.set("descriptors_ms", Value::number(ms(t_begin, t_desc))); tj.set("sweep_ms", Value::number(ms(t_desc, t_solved))); tj.set("verdicts_ms", Value::number(ms(t_solved, t_end)));
     tj.set("upload_us", Value::number(res.us_upload)); tj.set("pack_us", Value::number(res.us_pack)); tj.set("finalize_us", Value::number(res.us_finalize)); tj.set("download_us", Value::number(res.us_download));
     tj.set("probes", Value::integer(n)); tj.set("pods", Value::integer((int64_t)pods.size())); tj.set("devices", Value::integer((int64_t)std::max<size_t>(1, replicas.size())));

@@ -65,6 +65,8 @@ def _load_ksched():
         lib.ksched_sweep.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
         lib.ksched_sweep_replicas.restype = ctypes.c_void_p
         lib.ksched_sweep_replicas.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_char_p]
+        lib.ksched_sweep_arrays.restype = ctypes.c_void_p
+        lib.ksched_sweep_arrays.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         lib.ksched_pods_by_claim.restype = ctypes.c_uint32
         lib.ksched_pods_by_claim.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         lib.ksched_assignment.restype = ctypes.c_uint32
@@ -191,6 +193,49 @@ class Scheduler:
         if "error" in out:
             _raise(out.get("kind"), out["error"])
         return out
+
+    _SWEEP_TIMINGS = ("descriptors_ms", "sweep_ms", "verdicts_ms", "upload_us", "pack_us", "finalize_us", "download_us", "pods", "bin_evaluations", "node_evaluations",
+                      "node_block_steps", "classes", "it_words", "nodes", "node_dead0_us", "req_words", "resources", "devices")
+
+    def SweepArrays(self, candidates, multi_node=False, replicas=(), instance_type_names=None) -> dict:
+        """Sweep() without JSON on either side of the host library (ksched_sweep_arrays) — what a cgo caller does: the candidate sets go
+        in as one CSR of positions in the problem's stateNodes list, the verdicts come back as arrays (prices and capacity types are the
+        session's own). Returns the same document as Sweep() (built here, outside the library's timed region); replacement instance
+        types are names when `instance_type_names` (the problem's instanceTypes names, in order) is given, indices otherwise."""
+        import numpy as np
+        if not self._session:
+            raise RuntimeError("scheduler is closed")
+        n = len(candidates)
+        off = np.zeros(n + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(c) for c in candidates], dtype=np.int64)
+        flat = np.fromiter((x for cs in candidates for x in cs), dtype=np.uint32, count=int(off[n]))
+        dec = np.zeros(n, np.int32); ok = np.zeros(n, np.uint8); live = np.zeros(n, np.uint32); status = np.zeros(n, np.int32); refs = np.zeros(n, np.uint64)
+        roff = np.zeros(n + 1, np.uint32); spot = np.zeros(n, np.uint8); tv = np.zeros(len(self._SWEEP_TIMINGS), np.float64)
+        sessions = (ctypes.c_void_p * (1 + len(replicas)))(self._session, *[r._session for r in replicas])
+        cap = max(1 << 16, 64 * n)
+        for _ in range(2):
+            rits = np.zeros(cap, np.uint32)
+            ptr = self._lib.ksched_sweep_arrays(sessions, 1 + len(replicas), n, off.ctypes.data, flat.ctypes.data if len(flat) else None, 1 if multi_node else 0,
+                                                dec.ctypes.data, ok.ctypes.data, live.ctypes.data, status.ctypes.data, refs.ctypes.data, roff.ctypes.data, rits.ctypes.data, cap, spot.ctypes.data,
+                                                tv.ctypes.data, len(tv))
+            if not ptr:
+                break
+            try:
+                err = json.loads(ctypes.string_at(ptr).decode())
+            finally:
+                self._lib.ksched_free(ptr)
+            if err.get("kind") == "capacity" and int(roff[n]) > cap:
+                cap = int(roff[n])
+                continue
+            _raise(err.get("kind"), err["error"])
+        repl = []
+        for p in np.nonzero(dec == 2)[0].tolist():
+            its = rits[roff[p]:roff[p + 1]].tolist()
+            repl.append({"probe": p, "instanceTypes": sorted(instance_type_names[i] for i in its) if instance_type_names else its, "capacityType": "spot" if spot[p] else None})
+        timings = {k: (float(v) if k.endswith(("_ms", "_us")) else int(v)) for k, v in zip(self._SWEEP_TIMINGS, tv.tolist())}
+        timings["probes"] = n
+        return {"decisions": dec.tolist(), "allNonPendingPodsScheduled": [bool(x) for x in ok.tolist()], "claims": live.tolist(), "status": status.tolist(),
+                "referenceBinEvaluations": [int(x) for x in refs.tolist()], "replacements": repl, "reasons": {}, "timings": timings}
 
     def __del__(self):
         try:

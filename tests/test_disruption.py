@@ -635,6 +635,13 @@ def test_multi_node_sets_on_a_compact_cluster_fuzz(oracle, emu, seed, topology):
             sets.append([cc["nodes"][i] for i in idx]); idxs.append(idx)
     cmds = rc.decisions(sets, multi_node=True, library_prices=True)
     refs = rc.last_sweep["referenceBinEvaluations"]
+    json_form = rc.last_sweep
+    # the binary form of the same call (ksched_sweep_arrays: a CSR of node positions in, arrays out — what a cgo caller uses)
+    binary = rc.decisions(sets, multi_node=True, library_prices=True, arrays=True)
+    strip = lambda c: {k: v for k, v in c.items() if k != "reason"}
+    assert [strip(c) for c in binary] == [strip(c) for c in cmds]
+    for k in ("decisions", "allNonPendingPodsScheduled", "claims", "status", "referenceBinEvaluations"):
+        assert rc.last_sweep[k] == json_form[k], k
     base = dz.compact_problem(cc, pod_groups=[])
     if topology:
         base["clusterPods"] = dz.compact_cluster_pods(cc)
