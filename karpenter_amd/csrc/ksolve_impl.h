@@ -106,6 +106,7 @@ static void be_h2d(ksolve_handle* h, void* dst, const void* src, size_t bytes);
 static void be_d2h(ksolve_handle* h, void* dst, const void* src, size_t bytes);
 static void be_fill(ksolve_handle* h, void* dst, int byte, size_t bytes);
 static void be_sync(ksolve_handle* h);
+static void* be_stage(ksolve_handle* h, size_t bytes);   // page-locked host memory kept by the handle (valid until the next be_stage of the handle)
 static bool be_ok(ksolve_handle* h);
 static void be_tic(ksolve_handle* h, int slot);
 static void be_toc(ksolve_handle* h, int slot);
@@ -1110,8 +1111,16 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
   auto t_a = tnow();
 #endif
   // ---- validate + queue order per probe (the base queue order, restricted) ----
-  std::vector<uint32_t> sorted(total_pods), perm(total_pods);   // perm: position in the probe's sorted list -> position in the caller's list
-  std::vector<uint32_t> removed(nodes, nodes + total_nodes);
+  // what the launch reads — every probe's workspace record, its pods in queue order, its removed nodes — is written straight into
+  // the handle's page-locked staging memory: one DMA each instead of a staged copy out of pageable vectors
+  const size_t st_items = ((size_t)n * sizeof(ks::Workspace) + 63) & ~(size_t)63, st_sorted = ((size_t)total_pods * 4 + 67) & ~(size_t)63, st_removed = ((size_t)total_nodes * 4 + 67) & ~(size_t)63;
+  char* stage = (char*)be_stage(base, st_items + st_sorted + st_removed);
+  if (!stage) return fail(base, KSOLVE_ERR_DEVICE, base->error.empty() ? "host staging allocation failed" : base->error);
+  ks::Workspace* const items = (ks::Workspace*)stage;
+  uint32_t* const sorted = (uint32_t*)(stage + st_items);
+  uint32_t* const removed = (uint32_t*)(stage + st_items + st_sorted);
+  std::vector<uint32_t> perm(total_pods);   // perm: position in the probe's sorted list -> position in the caller's list
+  if (total_nodes) memcpy(removed, nodes, (size_t)total_nodes * 4);
   {
     // every probe on its own (a few host threads): its pods in queue order — (rank << 32 | position) keys, one plain sort — and
     // its removed nodes ascending
@@ -1130,7 +1139,7 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
         std::sort(key.begin(), key.end());
         for (uint32_t i = 0; i < m; ++i) { perm[b + i] = (uint32_t)key[i]; sorted[b + i] = pods[b + (uint32_t)key[i]]; }
         for (uint32_t i = 1; i < m; ++i) if (sorted[b + i] == sorted[b + i - 1]) { bad[t] = "probe pod listed twice"; break; }
-        std::sort(removed.begin() + node_off[p], removed.begin() + node_off[p + 1]);
+        std::sort(removed + node_off[p], removed + node_off[p + 1]);
         for (uint32_t i = node_off[p]; i < node_off[p + 1]; ++i) {
           if (removed[i] >= ne) { bad[t] = "probe node index out of range"; break; }
           // a node listed twice would be taken out of the evaluation counts and the topology registrations twice
@@ -1159,7 +1168,6 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
     lp.total_bytes = o;
   }
   // ---- arena: every probe's workspace, carved in two passes (measure, then assign) ----
-  std::vector<ks::Workspace> items(n);
   std::vector<uint32_t> claim_base(n + 1, 0);
   for (uint32_t p = 0; p < n; ++p) {
     uint32_t mc = std::max(1u, pod_off[p + 1] - pod_off[p]);
@@ -1273,9 +1281,9 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
 #ifdef KSOLVE_TEST_HOOKS
   auto t_c = tnow();
 #endif
-  be_h2d(base, d_items, items.data(), (size_t)n * sizeof(ks::Workspace));
-  if (total_pods) be_h2d(base, d_sorted, sorted.data(), (size_t)total_pods * 4);
-  if (total_nodes) be_h2d(base, d_removed, removed.data(), (size_t)total_nodes * 4);
+  be_h2d(base, d_items, items, (size_t)n * sizeof(ks::Workspace));
+  if (total_pods) be_h2d(base, d_sorted, sorted, (size_t)total_pods * 4);
+  if (total_nodes) be_h2d(base, d_removed, removed, (size_t)total_nodes * 4);
   if (d_limits) be_h2d(base, d_limits, lim.data(), lim.size() * 8);
   be_fill(base, arena + zero_from, 0, zero_to - zero_from);
   be_fill(base, arena + zero_to, 0xFF, ones_to - zero_to);

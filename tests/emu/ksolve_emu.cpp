@@ -17,6 +17,12 @@ static void be_h2d(ksolve_handle*, void* dst, const void* src, size_t bytes) { m
 static void be_d2h(ksolve_handle*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
 static void be_fill(ksolve_handle*, void* dst, int byte, size_t bytes) { memset(dst, byte, bytes); }
 static void be_sync(ksolve_handle*) {}
+static void* be_stage(ksolve_handle* h, size_t bytes) {   // the device build: page-locked memory kept by the handle
+  static thread_local std::vector<char> stage;
+  (void)h;
+  if (stage.size() < bytes) stage.resize(bytes + bytes / 4 + 4096);
+  return stage.data();
+}
 static void be_thread_init(ksolve_handle*) {}
 static bool be_ok(ksolve_handle*) { return true; }
 static void be_tic(ksolve_handle* h, int slot) { ((EmuBackend*)h->backend)->t0[slot] = std::chrono::steady_clock::now(); }
