@@ -299,6 +299,7 @@ def main():
     ap.add_argument("--components-types", type=int, default=1000)
     ap.add_argument("--beyond-lds-pods", type=int, default=2_000_000, help="the configs[1] mix at a size whose NodeClaims no longer fit the cursor engine's LDS plan (~3,000): "
                     "the engine moves its claim state to HBM (round 4) instead of handing the batch to the general engine; digest-checked against the oracle's pin of that size when committed; 0 = skip")
+    ap.add_argument("--whole-batch-exact-pods", type=int, default=10_000_000, help="BASELINE configs[3] at its own size as ONE exact Solve() (27,345 in-flight NodeClaims: the cursor engine's HBM plan), ~40 s; 0 = skip")
     ap.add_argument("--whole-batch-pods", type=int, default=1_000_000, help="BASELINE configs[3] as ONE exact Solve() of the whole batch (all 16 NodePools in one claim order), "
                     "digest-checked against the oracle's pin of that size when one is committed; 0 = skip. 10M pods take the general engine ~700 s (tests/tools/whole_batch_c3.py)")
     ap.add_argument("--components-calibration-pods", type=int, default=200_000, help="size at which the component split is compared with ONE Solve() of the whole batch (L2-canonical deltas)")
@@ -498,8 +499,7 @@ def main():
                 tb = time.perf_counter(); rw_ = sw.Solve(want_results=False); wdt = time.perf_counter() - tb
                 wb = {"pods": args.whole_batch_pods, "seconds": wdt, "value": rw_["scheduledPods"] / wdt, "unit": "pods/s", "node_claims": rw_["counters"]["claims"],
                       "engine": rw_["counters"].get("engine"), "pack_kernel_ms": rw_["timings"][0]["pack_kernel_ms"], "oracle_pin": None,
-                      "note": "ONE Solve() over all 16 NodePools: exact (bit-identical to the reference's answer for the batch), not shardable; the 10M-pod batch needs 27,345 in-flight "
-                              "NodeClaims — more than the cursor engine's LDS order holds — and takes the general engine ~700 s (profiles/round3/whole_batch_c3.json)"}
+                      "note": "ONE Solve() over all 16 NodePools: exact (bit-identical to the reference's answer for the batch), not shardable"}
                 wpin = os.path.join(ROOT, "tests", "golden", "fullsize", f"config4_p{args.whole_batch_pods}_t{args.components_types}_s42_x16.json")
                 if os.path.exists(wpin) and not args.no_parity_pin:
                     with open(wpin) as f:
@@ -511,6 +511,36 @@ def main():
                         raise SystemExit(f"bench.py: the whole-batch configs[3] Results differ from the oracle's pin {wb['oracle_pin']}")
                 sw.close()
                 comp["whole_batch"] = wb
+            if args.whole_batch_exact_pods > 0 and world == 1:
+                # ... and at the configuration's own size: 10M pods as ONE Solve(). 27,345 in-flight NodeClaims: the cursor engine with
+                # claim state and claim order in HBM (plan 2, round 4; round 3: the general engine, 702 s). One Solve() is timed — the
+                # first of the handle, including the attempt on the LDS plan that tells the library which plan to take.
+                ep = fx.config4(pods=args.whole_batch_exact_pods, n_types=args.components_types, n_pools=16, seed=42)
+                ep["options"] = dict(ep["options"], device=device_index, maxClaims=max(65536, args.whole_batch_exact_pods // 100))
+                tb = time.perf_counter(); se = NewScheduler(ep, solver_lib=args.solver_lib); e_new = time.perf_counter() - tb
+                tb = time.perf_counter(); re_ = se.Solve(want_results="claims"); edt = time.perf_counter() - tb
+                ce = re_["counters"]
+                ex = {"pods": args.whole_batch_exact_pods, "new_scheduler_s": e_new, "seconds": edt, "value": re_["scheduledPods"] / edt, "unit": "pods/s", "node_claims": ce["claims"],
+                      "engine": ce.get("engine"), "cursor_memory_plan": ce.get("cursorMemoryPlan"), "cursor_attempts": ce.get("cursorAttempts"), "pack_kernel_ms": re_["timings"][0]["pack_kernel_ms"],
+                      "reference_bin_evaluations": ce["referenceBinEvaluations"], "packing_cost_per_hour": sum(d for _, _, d in re_.get("packingVector", [])) or None,
+                      "components_ratio": {"cost": None, "claims": None}, "oracle_pin": None,
+                      "note": "the exact answer of the reference for the whole batch; the component split above is what the north_star shards and what `value` of this leg reports"}
+                if comp.get("packing_cost_per_hour") and ex["packing_cost_per_hour"] and comp.get("pods") == args.whole_batch_exact_pods:
+                    ex["components_ratio"] = {"cost": comp["packing_cost_per_hour"] / ex["packing_cost_per_hour"], "claims": comp["node_claims"] / max(1, ce["claims"])}
+                if not args.no_parity_pin:
+                    import invariants
+                    ex["invariants"] = invariants.check_claims(ep, re_, expect_pods=args.whole_batch_exact_pods)
+                    epin = os.path.join(ROOT, "tests", "golden", "fullsize", f"config4_p{args.whole_batch_exact_pods}_t{args.components_types}_s42_x16.json")
+                    if os.path.exists(epin):
+                        with open(epin) as f:
+                            g = json.load(f)
+                        fulle = se.Solve(want_results=True)
+                        de, _ = parity.results_digest(fulle)
+                        ex["oracle_pin"] = {"pin": os.path.relpath(epin, ROOT), "digest_matches_oracle": de == g["digest"], "reference_bin_evaluations_match": fulle["counters"]["referenceBinEvaluations"] == g["binEvaluations"], "oracle_seconds_offline": g.get("oracleSeconds")}
+                        if not (ex["oracle_pin"]["digest_matches_oracle"] and ex["oracle_pin"]["reference_bin_evaluations_match"]):
+                            raise SystemExit(f"bench.py: the exact configs[3] batch differs from the oracle's pin {ex['oracle_pin']}")
+                se.close()
+                comp["whole_batch_exact"] = ex
             if args.components_calibration_pods > 0:
                 cp = args.components_calibration_pods
                 whole_p = fx.config4(pods=cp, n_types=args.components_types, n_pools=16, seed=42)

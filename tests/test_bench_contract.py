@@ -32,7 +32,7 @@ def _env():
 def test_single_rank_line(oracle):
     emu = parity.build_emu()
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--pods", "3000", "--types", "60", "--cpu-sample", "1500", "--cpu-runs", "3",
-           "--topology-pods", "400", "--components-pods", "4000", "--components-types", "60", "--components-calibration-pods", "4000", "--whole-batch-pods", "3000", "--beyond-lds-pods", "0", "--batch-problems", "3", "--batch-pods", "400", "--sweep-nodes", "300", "--sweep-candidates", "40", "--sweep-sample", "6", "--sweep-topology-sample", "6", "--sweep-windows", "3", "--sweep-window-size", "12", "--solver-lib", emu]
+           "--topology-pods", "400", "--components-pods", "4000", "--components-types", "60", "--components-calibration-pods", "4000", "--whole-batch-pods", "3000", "--whole-batch-exact-pods", "4000", "--beyond-lds-pods", "0", "--batch-problems", "3", "--batch-pods", "400", "--sweep-nodes", "300", "--sweep-candidates", "40", "--sweep-sample", "6", "--sweep-topology-sample", "6", "--sweep-windows", "3", "--sweep-window-size", "12", "--solver-lib", emu]
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = _json_line(r.stdout)
@@ -69,6 +69,9 @@ def test_single_rank_line(oracle):
     inv = line["config2_topology"]["invariants"]      # no pin at this size: the placements replayed against the reference's topology rules
     assert inv["violations"] == 0 and inv["decisions_replayed"]["pods"] == 400
     assert cc["whole_batch"]["pods"] == 3000 and cc["whole_batch"]["engine"] == "cursor" and cc["whole_batch"]["oracle_pin"] is None
+    ex = cc["whole_batch_exact"]
+    assert ex["pods"] == 4000 and ex["engine"] == "cursor" and ex["invariants"]["pods_on_claims"] == 4000 and ex["node_claims"] == ex["invariants"]["node_claims"]
+    assert ex["packing_cost_per_hour"] > 0 and 0.9 < ex["components_ratio"]["cost"] < 1.1
     assert cc["invariants"]["violations"] == 0 and cc["invariants"]["node_claims_checked"] == cc["node_claims"]
     tw = sw["with_topology_pods"]       # the same sweep over a cluster whose bound pods carry spread constraints, judged by the oracle
     assert tw["nodes"] == 300 and sum(tw["decisions"].values()) == 40 and tw["oracle_check"]["all_identical"] is True and tw["oracle_check"]["probes"] >= 3 and "multi_node" not in tw
