@@ -195,7 +195,16 @@ def sweep_rooflines(tm, n_probes):
     except (OSError, ValueError):
         pass
     ps = tm["pack_us"] * 1e-6
-    out = {"ksolve_pack_sweep": {"bound": "latency per probe (one wavefront each), occupancy per sweep", "grid": f"{min(n_probes, 8192)} blocks of one wavefront", "probes": n_probes,
+    # the compact form of the launch (ksolve_pack_sweep4: four wavefronts per workgroup sharing the read-only tables, eight probes per CU)
+    # runs whenever the cluster's dictionaries fit its working set (<= 32 requirement words, <= 512 instance types): every KWOK cluster
+    compact = rw <= 32 and iw <= 8
+    kname = "ksolve_pack_sweep4" if compact and "ksolve_pack_sweep4" in pmc else "ksolve_pack_sweep"
+    if compact and kname != "ksolve_pack_sweep4" and "ksolve_pack_sweep" in pmc:
+        pmc = dict(pmc, ksolve_pack_sweep={})   # counters of the one-wavefront kernel do not describe this launch
+    pmc = dict(pmc, ksolve_pack_sweep=pmc.get(kname, {}))
+    out = {"ksolve_pack_sweep": {"kernel": "ksolve_pack_sweep4" if compact else "ksolve_pack_sweep",
+                                 "bound": "latency per probe (one wavefront each), probes in flight per CU (8 compact / 4 general: registers and LDS)",
+                                 "grid": "workgroups of four wavefronts, as many as the chip holds at once (2 per CU), each wavefront striding over the probes" if compact else f"{min(n_probes, 8192)} blocks of one wavefront", "probes": n_probes,
                                  "algorithmic_bytes": alg, "avg_kernel_ms": ps * 1e3, "achieved": alg / ps / 1e9 if ps > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": alg / ps / 1e9 / HBM_PEAK_GBS if ps > 0 else None, "traffic": pmc.get("ksolve_pack_sweep", {}).get("traffic_bytes_largest_launch"),
                                  "waves": pmc.get("ksolve_pack_sweep", {}).get("SQ_WAVES", {}).get("largest_launch"),

@@ -41,42 +41,54 @@ enum {
   E_LIMITS = 7, E_RESERVED = 8, E_EXISTING = 9, E_MIN_VALUES = 10
 };
 
-constexpr int kMaxHot = kMaxReqWords + kMaxItWords + 2 * kMaxRes + 4;
 constexpr int kMaxCold = 2 * kMaxKeys + (kMaxKeys + 1) / 2;
 
-struct Scratch {
-  ReqBuf merged;                    // slow-path working set (bounds / minValues / very wide dictionaries)
-  ReqBuf topo;                      // nodeRequirements ∧ topology domains (Topology.AddRequirements, topology.go:226-250)
-  ReqBuf vbase;                     // bin ∧ pod before a volume requirement alternative is added (nodeclaim.go:130-136, existingnode.go:105-106)
-  uint64_t tq[kMaxReqWords];        // next-domain set of one topology group (only the group key's words are used)
+// The engine's working set in LDS, one per wavefront. RW / IW = requirement mask words / instance-type mask words it is built for,
+// CL = lines of the hot-record cache (a power of two). `Scratch` (the bounds of the library) serves every kernel but the compact
+// consolidation sweep, whose wavefronts use ScratchT<32, 8, 4> when the cluster's dictionaries fit (every KWOK catalogue does):
+// a third of the bytes, so that eight probes instead of four share a CU (ksolve_pack_sweep4 in ksolve.hip).
+template <int RW, int IW, int CL, bool REGS = true>
+struct ScratchT {
+  static constexpr int kReqWords = RW, kItWords = IW, kCacheLines = CL;
+  static constexpr bool kRegTables = REGS;   // the engine keeps the instance-type tables in registers too (80 VGPRs; the resource-fit test of the instance-type filter without LDS traffic)
+  static constexpr int kHot = RW + IW + 2 * kMaxRes + 4;
+  typedef ReqBufT<RW> Buf;
+  Buf merged;                       // slow-path working set (bounds / minValues / very wide dictionaries)
+  Buf topo;                         // nodeRequirements ∧ topology domains (Topology.AddRequirements, topology.go:226-250)
+  Buf vbase;                        // bin ∧ pod before a volume requirement alternative is added (nodeclaim.go:130-136, existingnode.go:105-106)
+  uint64_t tq[RW];                  // next-domain set of one topology group (only the group key's words are used)
   int64_t gtot[kMaxRes];            // requests + the daemon overhead of the group being filtered
-  uint64_t gin[kMaxItWords];        // the bin's instance types that belong to that group
+  uint64_t gin[IW];                 // the bin's instance types that belong to that group
   uint64_t km_old[4];               // a claim's admitted values per topology-key slot before the commit being written
   int32_t resv_cap[64];             // ReservationManager.capacity (reservationmanager.go:31)
   int dg_first[33];   // daemon-overhead groups of each template (CSR)
   uint64_t t_owned[kMaxTopoWords], t_sel[kMaxTopoWords];   // topology groups the class being placed owns / is selected by
   uint64_t t_match[kMaxTopoWords];  // getMatchingTopologies (topology.go:561-574)
   uint64_t t_active[kMaxTopoWords]; // groups created so far
-  uint64_t cm[kMaxItWords];         // instance types compatible with the merged requirements
-  uint64_t its[kMaxItWords];        // surviving InstanceTypeOptions
-  uint64_t lim[kMaxItWords];        // instance types within NodePool limits
-  uint64_t xfit[kMaxItWords];       // instance types that an offering-override group makes fit (requests <= its allocatable, compatible offering)
-  uint64_t xoff[kMaxItWords];       // instance types with a compatible offering in an override group
+  uint64_t cm[IW];                  // instance types compatible with the merged requirements
+  uint64_t its[IW];                 // surviving InstanceTypeOptions
+  uint64_t lim[IW];                 // instance types within NodePool limits
+  uint64_t xfit[IW];                // instance types that an offering-override group makes fit (requests <= its allocatable, compatible offering)
+  uint64_t xoff[IW];                // instance types with a compatible offering in an override group
   uint64_t cand[64];                // candidate list: (position << 32 | claim)
   uint64_t stage[128];              // live words of the class's dead row (two per lane: up to 8192 claims)
   int64_t total[kMaxRes];
-  uint64_t claim[kMaxHot];          // candidate bin, hot record
+  uint64_t claim[kHot];             // candidate bin, hot record
   uint64_t claim_cold[kMaxCold];
-  uint64_t cls[kMaxReqWords + kMaxRes + 4];
+  uint64_t cls[RW + kMaxRes + 4];
   uint64_t cls_cold[kMaxCold];
-  uint64_t out[kMaxHot];            // record being committed
+  uint64_t out[kHot];               // record being committed
   uint64_t out_cold[kMaxCold];
   uint32_t blk_pod[64], blk_class[64], blk_last[64], blk_out[64];   // the queue block being placed: pod, class, lastLen, output index
   uint64_t tmpl_taints[32];         // template taint masks
   int64_t min_request[kMaxRes];     // min over classes per dimension (closed-claim test)
-  int32_t cache_tag[32];            // claim id held by each record-cache line, -1 = empty
-  uint8_t word_key[kMaxReqWords];   // dictionary word -> key
+  int32_t cache_tag[CL];            // claim id held by each record-cache line, -1 = empty
+  uint8_t word_key[RW];             // dictionary word -> key
 };
+typedef ScratchT<kMaxReqWords, kMaxItWords, 32> Scratch;
+// the compact sweep's: dictionaries of <= 32 mask words, <= 512 instance types; no register tables — a probe's pods go to existing
+// nodes, the instance-type filter runs for the odd new NodeClaim only, and the 80 registers are what lets two wavefronts share a SIMD
+typedef ScratchT<32, 8, 4, false> ScratchSmall;
 
 struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host buffer (test emulation)
   int64_t* alloc;       // [nr][iw*64]
@@ -91,11 +103,13 @@ struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host b
   uint64_t* closed;     // [claim words] claims that cannot take any pod any more
   uint64_t* stage_big;  // [claim words] live-set staging of the BIG engine (the others use Scratch::stage)
   KS_LDS RunTables* runs;   // BIG engine: per-count ring tables of the claim order (run_order.h), in place of okey / oord / opos
-  uint64_t* cache;      // [32][c_hot_words] direct-mapped cache of hot claim records
+  uint64_t* cache;      // [Scratch::kCacheLines][c_hot_words] direct-mapped cache of hot claim records
   int64_t* dg_ov;       // [n_dg][nr] daemon overhead per group (scheduler.go:963-1043)
   uint64_t* dg_its;     // [n_dg][iw] instance types of the group
-  Scratch* scratch;
-  KS_FN void bind(char* base, const LdsPlan& p) {
+  char* scratch;        // the wavefront's ScratchT (the engine knows which)
+  KS_FN void bind(char* base, const LdsPlan& p, int wave = 0) {
+    char* const shared = base;
+    base += (size_t)wave * (size_t)p.wave_stride;   // the wavefront's own tables (compact sweep); the shared ones are re-bound below
     alloc = (int64_t*)(base + p.off_alloc); avail = (uint64_t*)(base + p.off_avail); kv = (uint64_t*)(base + p.off_kv);
     keymask = (uint64_t*)(base + p.off_keymask); allocok = (uint64_t*)(base + p.off_allocok); kvslot = (uint16_t*)(base + p.off_kvslot);
     tmpl = (uint64_t*)(base + p.off_tmpl); tmpl_cold = (uint64_t*)(base + p.off_tmplcold);
@@ -104,7 +118,13 @@ struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host b
     closed = (uint64_t*)(base + p.off_closed); cache = (uint64_t*)(base + p.off_cache);
     stage_big = (uint64_t*)(base + p.off_stage);
     dg_ov = (int64_t*)(base + p.off_dgov); dg_its = (uint64_t*)(base + p.off_dgits);
-    scratch = (Scratch*)(base + p.off_scratch);
+    scratch = base + p.off_scratch;
+    if (wave) {
+      alloc = (int64_t*)(shared + p.off_alloc); avail = (uint64_t*)(shared + p.off_avail); kv = (uint64_t*)(shared + p.off_kv);
+      keymask = (uint64_t*)(shared + p.off_keymask); allocok = (uint64_t*)(shared + p.off_allocok); kvslot = (uint16_t*)(shared + p.off_kvslot);
+      tmpl = (uint64_t*)(shared + p.off_tmpl); tmpl_cold = (uint64_t*)(shared + p.off_tmplcold);
+      dg_ov = (int64_t*)(shared + p.off_dgov); dg_its = (uint64_t*)(shared + p.off_dgits);
+    }
   }
 };
 
@@ -112,13 +132,15 @@ struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host b
 // and reservations (C1/C2-shaped provisioning batches): those code paths and their live state drop out of the kernel.
 // BIG = true keeps the claim order in HBM and sizes the live-set staging area and the closed bitmap by the problem
 // (hundreds of thousands of in-flight claims: anti-affinity / hostname-spread workloads where every pod is its own node).
-template <class W, bool FULL = true, bool BIG = false>
+template <class W, bool FULL = true, bool BIG = false, class SC = Scratch>
 struct Engine {
   const ProblemView& P;
   Workspace& S;
   LdsTables L;
-  Scratch& sc;
+  SC& sc;
   const RecLayout lay;
+  typedef typename SC::Buf ReqBuf;   // the requirement buffers of this engine's scratch
+  static constexpr int kLineMask = SC::kCacheLines - 1;
   typedef typename std::conditional<BIG, uint32_t*, KS_LDS uint32_t*>::type order_ptr;
   typename std::conditional<BIG, RunOrder<W>, ClaimOrder<W, order_ptr>>::type order;   // BIG: one ring per pod count in HBM (run_order.h)
   int n_claims = 0;
@@ -158,7 +180,7 @@ struct Engine {
   int cur_out = 0;                  // where the pod being placed reports its result: its pod index, or its position in Workspace::pr_sorted (probes)
   int n_revived = 0;                // probes: entries of Workspace::pr_revived
 
-  KS_DEV Engine(const ProblemView& p, Workspace& s, const LdsTables& l) : P(p), S(s), L(l), sc(*l.scratch), lay(p.lay) {
+  KS_DEV Engine(const ProblemView& p, Workspace& s, const LdsTables& l) : P(p), S(s), L(l), sc(*(SC*)l.scratch), lay(p.lay) {
     if constexpr (BIG) order.init(L.runs, s.o_ring, s.o_cnt, s.o_pos, s.o_key, s.o_ord, s.run_tabs, s.run_off, s.run_log, s.run_kmax);
     else { order.key = L.okey; order.ord = L.oord; order.pos = L.opos; }
     min_values_best_effort = s.min_values_best_effort != 0;
@@ -189,41 +211,45 @@ struct Engine {
   }
 
   // ------------------------------------------------------------------------------------------------------------
-  // one-time: instance-type tables, dictionary helpers and templates into LDS
-  KS_DEV void load_tables() {
+  // one-time: instance-type tables, dictionary helpers and templates into LDS. Two halves: the tables every solve of the same
+  // problem reads alike (`shared`: the compact sweep fills them once per workgroup and its wavefronts share them) and the
+  // wavefront's own working set (Scratch, cache tags, the closed bitmap, the register tables).
+  KS_DEV void load_tables(bool shared = true) {
     const Dict& d = P.dict;
     const int nr = P.n_res, iw = P.it_words, n_its = P.n_its, np = iw * 64;
     const ProblemView& Pv = P;
     LdsTables& Lt = L;
-    for (int r = 0; r < nr; ++r)
-      W::for_n(np, [&](int it) { Lt.alloc[(size_t)r * np + it] = it < n_its ? Pv.it_alloc[(size_t)r * n_its + it] : INT64_MIN; });
-    W::for_n(np, [&](int it) { Lt.avail[it] = it < n_its ? Pv.it_base_avail[it] : 0; });   // base group == every offering unless overrides exist
-    W::for_n(iw, [&](int w) { Lt.allocok[w] = Pv.it_alloc_ok[w]; });
-    const int nki = d.n_keys * iw;
-    W::for_n(3 * nki, [&](int i) {
-      int which = i / nki, rest = i % nki;
-      const uint64_t* src = which == 0 ? Pv.key_undef : which == 1 ? Pv.key_compl : Pv.key_neg;
-      Lt.keymask[i] = src[rest];
-    });
-    W::for_n(d.req_words * 64, [&](int v) {
-      uint16_t slot = Pv.kv_slot[v];
-      Lt.kvslot[v] = slot;
-      if (slot != 0xFFFF) for (int w = 0; w < iw; ++w) Lt.kv[(size_t)slot * iw + w] = Pv.kv_has[(size_t)v * iw + w];
-    });
+    if (shared) {
+      for (int r = 0; r < nr; ++r)
+        W::for_n(np, [&](int it) { Lt.alloc[(size_t)r * np + it] = it < n_its ? Pv.it_alloc[(size_t)r * n_its + it] : INT64_MIN; });
+      W::for_n(np, [&](int it) { Lt.avail[it] = it < n_its ? Pv.it_base_avail[it] : 0; });   // base group == every offering unless overrides exist
+      W::for_n(iw, [&](int w) { Lt.allocok[w] = Pv.it_alloc_ok[w]; });
+      const int nki = d.n_keys * iw;
+      W::for_n(3 * nki, [&](int i) {
+        int which = i / nki, rest = i % nki;
+        const uint64_t* src = which == 0 ? Pv.key_undef : which == 1 ? Pv.key_compl : Pv.key_neg;
+        Lt.keymask[i] = src[rest];
+      });
+      W::for_n(d.req_words * 64, [&](int v) {
+        uint16_t slot = Pv.kv_slot[v];
+        Lt.kvslot[v] = slot;
+        if (slot != 0xFFFF) for (int w = 0; w < iw; ++w) Lt.kv[(size_t)slot * iw + w] = Pv.kv_has[(size_t)v * iw + w];
+      });
+      W::for_n(Pv.n_dg * nr, [&](int i) { Lt.dg_ov[i] = Pv.dg_ov[i]; });
+      W::for_n(Pv.n_dg * iw, [&](int i) { Lt.dg_its[i] = Pv.dg_its[i]; });
+    }
     uint8_t* wk = sc.word_key;
     if (W::leader())
       for (int k = 0; k < d.n_keys; ++k)
         for (uint32_t w = d.key_word_off[k]; w < d.key_word_off[k + 1]; ++w) wk[w] = (uint8_t)k;
     uint64_t* tt = sc.tmpl_taints; int64_t* mr = sc.min_request; int32_t* tag = sc.cache_tag;
-    W::for_n(32, [&](int t) { tt[t] = t < Pv.n_templates ? Pv.tmpl_taints[t] : 0; tag[t] = -1; });
+    W::for_n(32, [&](int t) { tt[t] = t < Pv.n_templates ? Pv.tmpl_taints[t] : 0; if (t < SC::kCacheLines) tag[t] = -1; });
     W::for_n(nr, [&](int r) { mr[r] = Pv.min_request[r]; });
     W::for_n(BIG ? Pv.lds.stage_words : (S.probe ? S.pr_order_cap : Pv.lds.order_cap) / 64, [&](int w) { Lt.closed[w] = 0; });
     W::sync();
     W::for_n(Pv.n_templates + 1, [&](int t) { sc.dg_first[t] = Pv.dg_first[t]; });
-    W::for_n(Pv.n_dg * nr, [&](int i) { Lt.dg_ov[i] = Pv.dg_ov[i]; });
-    W::for_n(Pv.n_dg * iw, [&](int i) { Lt.dg_its[i] = Pv.dg_its[i]; });
-    regs_ok = !FULL || (iw <= kRegIw && nr <= kRegNr && Pv.n_xg == 0);   // lite problems fit the register tables by definition
-    if (regs_ok) {
+    regs_ok = SC::kRegTables && (!FULL || (iw <= kRegIw && nr <= kRegNr && Pv.n_xg == 0));   // lite problems fit the register tables by definition
+    if (SC::kRegTables && regs_ok) {
       W::ballot([&](int l) {
 #pragma unroll
         for (int j = 0; j < kRegIw; ++j) {
@@ -366,7 +392,7 @@ struct Engine {
     const LdsTables& Lt = L;
     const int nr = P.n_res, iw = P.it_words, np = iw * 64;
     uint64_t any = 0;
-    if (regs_ok && !want_diag) {
+    if (SC::kRegTables && regs_ok && !want_diag) {
       // register tables: every compare of the step is VALU work on this lane's own instance types
       unsigned long long q0 = W::clock();
       int64_t tt[kRegNr];
@@ -1100,7 +1126,7 @@ struct Engine {
         }
         if (W::leader()) o[ly.c_head() + r] = (uint64_t)(best - ntot[r] + P.xg_bonus[r]);
       }
-    } else if (recompute_head && regs_ok) {
+    } else if (SC::kRegTables && recompute_head && regs_ok) {
       // headroom = max allocatable over the surviving instance types - total, from the register tables
       uint64_t sw[kRegIw];
 #pragma unroll
@@ -1140,7 +1166,7 @@ struct Engine {
     const int64_t* oh = (const int64_t*)(o + ly.c_head());
     const bool is_closed = W::ballot([&](int l) { return l < nr && mr[l] > 0 && oh[l] < mr[l]; }) != 0;
     uint64_t* dst = S.c_hot + (size_t)c * ly.c_hot_words();
-    uint64_t* line = L.cache + (size_t)(c & 31) * ly.c_hot_words();
+    uint64_t* line = L.cache + (size_t)(c & kLineMask) * ly.c_hot_words();
     W::for_n(ly.c_hot_words(), [&](int i) { uint64_t v = o[i]; dst[i] = v; line[i] = v; });
     { int64_t* hd = S.c_headroom; const int mc = S.max_claims; W::for_n(nr, [&](int r) { hd[(size_t)r * mc + c] = oh[r]; }); }
     if (FULL && P.topo.n_key_slots) {
@@ -1175,7 +1201,7 @@ struct Engine {
         });
       }
     }
-    if (W::leader()) sc.cache_tag[c & 31] = c;
+    if (W::leader()) sc.cache_tag[c & kLineMask] = c;
     if (write_cold) {
       uint64_t* dc = S.c_cold + (size_t)c * ly.cold_words();
       const uint64_t* oc = sc.out_cold;
@@ -1226,7 +1252,7 @@ struct Engine {
     unsigned long long t0 = W::clock();
     const RecLayout ly = lay;
     // hot record: from the LDS record cache when this claim was the last one committed to its line, else one coalesced load
-    if (sc.cache_tag[c & 31] == c) load_words(sc.claim, L.cache + (size_t)(c & 31) * ly.c_hot_words(), ly.c_hot_words());
+    if (sc.cache_tag[c & kLineMask] == c) load_words(sc.claim, L.cache + (size_t)(c & kLineMask) * ly.c_hot_words(), ly.c_hot_words());
     else load_words(sc.claim, S.c_hot + (size_t)c * ly.c_hot_words(), ly.c_hot_words());
     const uint64_t f1 = sc.claim[ly.c_f1()];
     const uint32_t m2 = hi32(sc.claim[ly.c_meta2()]);
@@ -2019,7 +2045,7 @@ struct Engine {
     if (FULL && P.topo.n_groups) {
       const TopoView& T = P.topo;
       const uint64_t* ct = T.cls_topo + (size_t)k * 2 * T.words;
-      Scratch& s_ = sc;
+      SC& s_ = sc;
       // getMatchingTopologies — topology.go:561-574: groups the pod owns + inverse anti-affinity groups that select it;
       // Topology.Update creates the groups of a relaxed pod (topology.go:162-194)
       const uint64_t anyM = W::ballot([&](int w) {
@@ -2098,11 +2124,25 @@ struct Engine {
   // NewScheduler's per-template prefilter (scheduler.go:156-171): instance types compatible with the template's own
   // requirements, with non-negative allocatable and a compatible available offering. Templates become claim-shaped
   // records in LDS (total 0, unlimited headroom).
-  KS_DEV void prefilter_templates() {
+  // warm: the template records in LDS (L.tmpl / L.tmpl_cold) and `warm_active` come from another solve of the same problem (the
+  // compact sweep: the prefilter does not depend on the probe); only this solve's own copies are written
+  KS_DEV void prefilter_templates(bool warm = false, uint32_t warm_active = 0) {
     const Dict& d = P.dict;
     active_templates = 0;
     const int nr = lay.nr, iw = lay.iw;
     const RecLayout ly = lay;
+    if (warm) {
+      active_templates = warm_active;
+      for (int t = 0; t < P.n_templates; ++t) {
+        const uint64_t* rec = L.tmpl + (size_t)t * ly.c_hot_words();
+        uint64_t* tits = S.t_its + (size_t)t * iw;
+        W::for_n(iw, [&](int w) { tits[w] = rec[ly.c_its() + w]; });
+        int64_t* rem = S.t_remaining + (size_t)t * (nr + 1);
+        const int64_t* lim = ((S.probe && S.pr_limits) ? S.pr_limits : P.tmpl_limits) + (size_t)t * (nr + 1);
+        W::for_n(nr + 1, [&](int r) { rem[r] = lim[r]; });
+      }
+      return;
+    }
     for (int r = 0; r < nr; ++r) W::store(&sc.total[r], (int64_t)0);
     W::sync();
     for (int t = 0; t < P.n_templates; ++t) {
@@ -2141,8 +2181,19 @@ struct Engine {
     }
   }
 
+  // The compact sweep's once-per-workgroup half of solve(): the shared LDS tables and the template records (the prefilter does not
+  // depend on the probe; the Workspace passed to this engine only lends its per-template arrays). Returns the surviving templates.
+  KS_DEV uint32_t prepare() {
+    load_tables(true);
+    prefilter_templates();
+    W::sync();
+    return active_templates;
+  }
+
   // Solve — scheduler.go:440-519 with Queue (queue.go:31-108)
-  KS_DEV void solve() {
+  // warm != nullptr: the compact sweep — the LDS tables shared by the workgroup's wavefronts and the template records are in
+  // place (*warm = the templates that survived the prefilter); this solve sets up its own working set only.
+  KS_DEV void solve(const uint32_t* warm = nullptr) {
     const unsigned long long t_begin = W::clock();
     if (FULL && P.n_nodes && S.probe) {
       // a probe of a resident cluster: nothing is copied, the overlay starts empty
@@ -2172,9 +2223,9 @@ struct Engine {
       if (S.probe) probe_topology_adjust();
     }
     n_pv_log = 0;
-    load_tables();
+    load_tables(warm == nullptr);
     if (FULL && P.reserved_on) W::for_n(P.n_resv, [&](int i) { sc.resv_cap[i] = P.resv_cap0[i]; });
-    prefilter_templates();
+    prefilter_templates(warm != nullptr, warm ? *warm : 0u);
     // The queue holds pod indices; a probe's queue holds positions in its own pod list (Workspace::pr_sorted), which is also
     // how its per-pod outputs are indexed.
     const bool probe = S.probe != 0;

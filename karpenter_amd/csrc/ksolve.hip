@@ -26,6 +26,7 @@ struct HipBackend {
   void* stage = nullptr;        // pinned host staging of a sweep's descriptors (be_stage)
   size_t stage_bytes = 0;
   int device = 0;
+  int n_cus = 256;              // compute units of the device (the compact sweep launches what the chip holds at once)
 };
 #define HB(h) ((HipBackend*)(h)->backend)
 static bool hip_check(ksolve_handle* h, hipError_t e, const char* what) {
@@ -512,6 +513,30 @@ __global__ void __launch_bounds__(64) ksolve_pack_sweep(const ks::ProblemView* p
     eng.solve();
   }
 }
+// The compact form of the sweep (LdsPlan::waves = 4): four wavefronts per workgroup, each on its own probes, sharing the read-only
+// instance-type tables and the template records in LDS (wave 0 fills them and runs the template prefilter once, then the
+// workgroup's only barrier); every wavefront keeps a ScratchSmall working set. 256 VGPRs per wavefront (two wavefronts per
+// SIMD): eight probes per CU in flight instead of four — the probes are chains of dependent steps, so a launch goes as fast as
+// the number of them the chip holds at once. Wave w of block b runs probes 4b + w, 4b + w + 4 * gridDim.x, ...
+__global__ void __launch_bounds__(256, 2) ksolve_pack_sweep4(const ks::ProblemView* pv, ks::Workspace* items, int n, ks::LdsPlan plan) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef ks::Engine<ks::Wave, true, false, ks::ScratchSmall> Eng;
+  const int wave = (int)(threadIdx.x >> 6);
+  ks::LdsTables tables;
+  tables.bind(lds, plan, wave);
+  uint32_t* misc = (uint32_t*)(lds + plan.off_shared_misc);
+  if (wave == 0) {
+    Eng eng(*pv, items[(int)blockIdx.x * 4], tables);
+    const uint32_t active = eng.prepare();
+    if ((threadIdx.x & 63) == 0) misc[0] = active;
+  }
+  __syncthreads();
+  const uint32_t active = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
+  for (int p = (int)blockIdx.x * 4 + wave; p < n; p += (int)gridDim.x * 4) {
+    Eng eng(*pv, items[p], tables);
+    eng.solve(&active);
+  }
+}
 // every pod class against every pristine node of a resident cluster (kernels.h node_dead0_body): one wavefront per 64 nodes
 __global__ void __launch_bounds__(64) ksolve_node_dead0(ks::NodeDeadArgs a) { ks::node_dead0_body<ks::Wave>((int)blockIdx.x, a); }
 __global__ void ksolve_claim_gather(int n, ks::ClaimGatherArgs a) {
@@ -639,6 +664,23 @@ static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, 
   if (n <= 0) return;
   HipBackend* b = HB(h);
   if (!hip_check(h, hipFuncSetAttribute((const void*)ksolve_pack_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, plan.total_bytes), "hipFuncSetAttribute(LDS)")) return;
+  if (plan.waves == 4) {
+    // the compact form: as many workgroups as the chip holds at once (two per CU by registers, fewer when their LDS is large), each
+    // wavefront striding over the probes — the shared tables and the template prefilter are paid once per workgroup
+    if (!hip_check(h, hipFuncSetAttribute((const void*)ksolve_pack_sweep4, hipFuncAttributeMaxDynamicSharedMemorySize, plan.total_bytes), "hipFuncSetAttribute(LDS)")) return;
+    int per_cu = (160 * 1024) / (plan.total_bytes + 256);
+    per_cu = per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu;
+    const int resident = b->n_cus * per_cu, want = (n + 3) / 4;
+    const int grid4 = want < resident ? want : resident;
+    hip_check(h, hipEventRecord(b->ev0[ksi::T_PACK], b->stream), "hipEventRecord");
+    hipLaunchKernelGGL(ksolve_pack_sweep4, dim3((unsigned)grid4), dim3(256), (size_t)plan.total_bytes, b->stream, d_pv, d_items, n, plan);
+    hip_check(h, hipGetLastError(), "ksolve_pack_sweep4 launch");
+    hip_check(h, hipEventRecord(b->ev1[ksi::T_PACK], b->stream), "hipEventRecord");
+    hip_check(h, hipEventSynchronize(b->ev1[ksi::T_PACK]), "hipEventSynchronize");
+    float ms4 = 0;
+    if (hipEventElapsedTime(&ms4, b->ev0[ksi::T_PACK], b->ev1[ksi::T_PACK]) == hipSuccess) h->timers.ms[ksi::T_PACK] = ms4;
+    return;
+  }
   const int grid = n < 8192 ? n : 8192;
   hip_check(h, hipEventRecord(b->ev0[ksi::T_PACK], b->stream), "hipEventRecord");
   hipLaunchKernelGGL(ksolve_pack_sweep, dim3((unsigned)grid), dim3(64), (size_t)plan.total_bytes, b->stream, d_pv, d_items, n, plan);
@@ -794,6 +836,7 @@ ksolve_status ksolve_create(const ksolve_problem_desc* desc, const ksolve_option
   if (!be_device_available()) { h->error = "no usable gfx950 device (hipGetDeviceCount/hipGetDeviceProperties)"; return KSOLVE_ERR_NO_DEVICE; }
   b->device = opts ? (int)opts->device : 0;
   if (!hip_check(h, hipSetDevice(b->device), "hipSetDevice")) return KSOLVE_ERR_DEVICE;
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) == hipSuccess && cus > 0) b->n_cus = cus; }
   if (!hip_check(h, hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate")) return KSOLVE_ERR_DEVICE;
   for (int i = 0; i < 8; ++i) { hip_check(h, hipEventCreate(&b->ev0[i]), "hipEventCreate"); hip_check(h, hipEventCreate(&b->ev1[i]), "hipEventCreate"); }
   return ksi::create(desc, opts, h);
@@ -805,7 +848,7 @@ ksolve_status ksolve_probe_create(ksolve_handle* base, const ksolve_probe* probe
   h->backend = b;
   *out = h;
   if (!base || !base->backend) { h->error = "null base handle"; return KSOLVE_ERR_INVALID; }
-  b->device = HB(base)->device;
+  b->device = HB(base)->device; b->n_cus = HB(base)->n_cus;
   if (!hip_check(h, hipSetDevice(b->device), "hipSetDevice")) return KSOLVE_ERR_DEVICE;
   if (!hip_check(h, hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate")) return KSOLVE_ERR_DEVICE;
   for (int i = 0; i < 8; ++i) { hip_check(h, hipEventCreate(&b->ev0[i]), "hipEventCreate"); hip_check(h, hipEventCreate(&b->ev1[i]), "hipEventCreate"); }

@@ -606,6 +606,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     auto align = [](int x) { return (x + 15) & ~15; };
     const int np = (int)it_words * 64;
     int off = 0;
+    lp.waves = 0; lp.wave_stride = 0; lp.off_shared_misc = 0;   // a one-wavefront plan (the compact sweep lays out its own, sweep_run)
     lp.off_alloc = off; off = align(off + (int)d->n_res * np * 8);
     lp.off_avail = off; off = align(off + np * 8);
     lp.n_kv = h->n_kv;
@@ -1166,6 +1167,42 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
     o = align(o + cap * 12);
     lp.off_closed = o; o = align(o + cap / 8 + 8);
     lp.total_bytes = o;
+    lp.waves = 0; lp.wave_stride = 0; lp.off_shared_misc = 0;
+    // The compact form of the launch (ksolve_pack_sweep4, engine.h ScratchSmall): four wavefronts per workgroup share the read-only
+    // tables and the template records; each keeps its own working set, a third of the general Scratch. With 256 VGPRs per wavefront
+    // (two per SIMD) a CU then runs eight probes at a time instead of four — the launch is bound by the latency of each probe's
+    // dependent steps, so the probes in flight are its throughput. Needs dictionaries of <= 32 mask words and <= 512 instance types
+    // (ScratchSmall) and a claim order short enough for four working sets beside the shared tables.
+    const ks::RecLayout& ly = P.lay;
+    bool compact = ly.rw <= ks::ScratchSmall::kReqWords && ly.iw <= ks::ScratchSmall::kItWords;
+#ifdef KSOLVE_TEST_HOOKS
+    if (getenv("KSOLVE_TEST_SWEEP_GENERAL")) compact = false;   // tests / A-B runs: the one-wavefront kernel with the general Scratch
+#endif
+    if (compact) {
+      ks::LdsPlan c = lp;
+      const int np = ly.iw * 64, T = std::max(1, P.n_templates);
+      int so = 0;
+      c.off_alloc = so; so = align(so + ly.nr * np * 8);
+      c.off_avail = so; so = align(so + np * 8);
+      c.off_kv = so; so = align(so + std::max(1, lp.n_kv) * ly.iw * 8);
+      c.off_keymask = so; so = align(so + 3 * ly.nk * ly.iw * 8);
+      c.off_allocok = so; so = align(so + ly.iw * 8);
+      c.off_kvslot = so; so = align(so + ly.rw * 64 * 2);
+      c.off_tmpl = so; so = align(so + T * ly.c_hot_words() * 8);
+      c.off_tmplcold = so; so = align(so + T * ly.cold_words() * 8);
+      c.off_dgov = so; so = align(so + std::max(1, P.n_dg) * ly.nr * 8);
+      c.off_dgits = so; so = align(so + std::max(1, P.n_dg) * ly.iw * 8);
+      c.off_shared_misc = so; so = align(so + 16);
+      const int w0 = so;   // wave 0's working set starts here
+      c.off_scratch = so; so = align(so + (int)sizeof(ks::ScratchSmall));
+      c.off_cache = so; so = align(so + ks::ScratchSmall::kCacheLines * ly.c_hot_words() * 8);
+      c.off_order = so; so = align(so + cap * 12);
+      c.off_closed = so; so = align(so + cap / 8 + 8);
+      c.off_stage = so; c.stage_words = 0;
+      c.waves = 4; c.wave_stride = so - w0;
+      c.total_bytes = w0 + c.waves * c.wave_stride;
+      if (c.total_bytes <= 160 * 1024 - 512) lp = c;
+    }
   }
   // ---- arena: every probe's workspace, carved in two passes (measure, then assign) ----
   std::vector<uint32_t> claim_base(n + 1, 0);
@@ -1292,7 +1329,7 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
 #ifdef KSOLVE_TEST_HOOKS
   if (trace) {
     auto us_ = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    fprintf(stderr, "sweep_run host: validate+sort %.0f us, layout+items %.0f us, h2d+fill %.0f us, arena %zu bytes, sizeof(Workspace) %zu\n", us_(t_a, t_b), us_(t_b, t_c), us_(t_c, tnow()), total, sizeof(ks::Workspace));
+    fprintf(stderr, "sweep_run host: validate+sort %.0f us, layout+items %.0f us, h2d+fill %.0f us, arena %zu bytes, sizeof(Workspace) %zu, LDS %d bytes per workgroup of %d wavefront(s)\n", us_(t_a, t_b), us_(t_b, t_c), us_(t_c, tnow()), total, sizeof(ks::Workspace), lp.total_bytes, lp.waves ? lp.waves : 1);
   }
 #endif
   be_toc(base, T_UPLOAD);

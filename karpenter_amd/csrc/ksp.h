@@ -87,6 +87,11 @@ struct LdsPlan {
   int off_dgov;       // i64 [n_dg][nr]       daemon overhead per group
   int off_dgits;      // u64 [n_dg][iw]       group membership
   int n_kv;
+  // The compact consolidation sweep (ksolve_pack_sweep4): `waves` wavefronts of one workgroup share the read-only tables above and
+  // the template records; each owns its Scratch, record cache, claim order and closed bitmap — those offsets are wave 0's, wave w's
+  // lie w * wave_stride bytes further. 0 waves: the plan of a one-wavefront kernel.
+  int waves, wave_stride;
+  int off_shared_misc;   // u32 [4]: templates that survived the prefilter, written by wave 0 before the workgroup's barrier
 };
 
 // Topology groups (topologygroup.go:55-77), regular groups then inverse anti-affinity groups; group sets are bit masks of

@@ -36,8 +36,12 @@ struct ReqRef {
 };
 
 // Working copy (the "nodeClaimRequirements" being built in NodeClaim.CanAdd, nodeclaim.go:130-208).
-struct ReqBuf {
-  uint64_t mask[kMaxReqWords];
+// A requirement set being built (mask words + bounds + minValues). RW = mask words it holds: kMaxReqWords for any problem the
+// library accepts; the consolidation sweep's compact scratch (engine.h ScratchT) uses a smaller bound when the problem's
+// dictionaries allow it — the code only ever touches the first Dict::req_words words.
+template <int RW>
+struct ReqBufT {
+  uint64_t mask[RW];
   uint32_t defined, complement, has_gte, has_lte, has_minv;
   int64_t gte[kMaxKeys], lte[kMaxKeys];
   int32_t minv[kMaxKeys];
@@ -49,6 +53,7 @@ struct ReqBuf {
     return r;
   }
 };
+typedef ReqBufT<kMaxReqWords> ReqBuf;
 
 KS_FN bool bit(uint32_t m, int k) { return (m >> k) & 1u; }
 
@@ -143,7 +148,8 @@ KS_FN int reqs_compatible(const Dict& d, const ReqRef& r, const ReqRef& q, bool 
   return reqs_intersect(d, r, q) ? COMPAT_OK : COMPAT_NO_INTERSECTION;
 }
 
-KS_FN void reqbuf_load(const Dict& d, ReqBuf& out, const ReqRef& r) {
+template <class RB>
+KS_FN void reqbuf_load(const Dict& d, RB& out, const ReqRef& r) {
   for (int w = 0; w < d.req_words; ++w) out.mask[w] = r.mask[w];
   out.defined = r.defined; out.complement = r.complement; out.has_gte = r.has_gte; out.has_lte = r.has_lte;
   out.has_minv = 0;
@@ -158,7 +164,8 @@ KS_FN void reqbuf_load(const Dict& d, ReqBuf& out, const ReqRef& r) {
 
 // Requirements.Add(q...) — requirements.go:133-140 with Requirement.Intersection — requirement.go:181-214.
 // Returns true when any key of `acc` changed (used to know when a claim's requirement state moved).
-KS_FN bool reqbuf_add(const Dict& d, ReqBuf& acc, const ReqRef& q) {
+template <class RB>
+KS_FN bool reqbuf_add(const Dict& d, RB& acc, const ReqRef& q) {
   bool changed = false;
   uint32_t keys = q.defined;
   while (keys) {

@@ -2019,6 +2019,20 @@ extern "C" int ksched_cancel(void* session) {
 }
 // One probe of a resident cluster (ksolve_probe_create): `probe_json` = {"removeNodes": [node names], "pods": [uids]}.
 // The new session shares the base session's tables on the host and on the device; close it before the base session.
+// the session's node -> bound pods table (CSR) and the pods every simulation schedules (pending pods, pods of deleting nodes): built
+// on the first sweep / the first probe that asks for a node's pods
+static void ensure_sweep_tables(Session* B) {
+  if (B->sweep_tables) return;
+  const int ne = (int)B->node_names.size();
+  B->node_pod_off.assign((size_t)ne + 1, 0);
+  for (int p = 0; p < B->n_pods; ++p) { if (B->pod_node[p] >= 0) B->node_pod_off[(size_t)B->pod_node[p] + 1]++; else B->always_pods.push_back((uint32_t)p); }
+  for (int e = 0; e < ne; ++e) B->node_pod_off[(size_t)e + 1] += B->node_pod_off[e];
+  B->node_pod_list.assign(B->node_pod_off[ne], 0);
+  std::vector<uint32_t> fill(B->node_pod_off.begin(), B->node_pod_off.end() - 1);
+  for (int p = 0; p < B->n_pods; ++p) if (B->pod_node[p] >= 0) B->node_pod_list[fill[B->pod_node[p]]++] = (uint32_t)p;
+  if (B->node_index.empty()) { B->node_index.reserve(B->node_names.size() * 2); for (size_t e = 0; e < B->node_names.size(); ++e) B->node_index[B->node_names[e]] = (int)e; }
+  B->sweep_tables = true;
+}
 extern "C" void* ksched_probe(void* base_session, const char* probe_json) {
   Session* B = (Session*)base_session;
   Session* S = new Session();
@@ -2048,6 +2062,18 @@ extern "C" void* ksched_probe(void* base_session, const char* probe_json) {
     }
     std::vector<uint32_t> pods;
     S->probe_member.assign(B->n_pods, 0);
+    if (doc.at("podsOfRemovedNodes").boolean_or(false)) {
+      // the simulation a sweep runs for these candidates (helpers.go:53-155): the pods every simulation schedules, then the pods bound
+      // to each removed node — a resident cluster whose pods travel as groups has no uid text to list them by
+      if (B->pod_node.empty()) throw std::runtime_error("podsOfRemovedNodes needs a resident cluster (options.residentCluster)");
+      ensure_sweep_tables(B);
+      auto take = [&](uint32_t p) { if (!S->probe_member[p]) { S->probe_member[p] = 1; pods.push_back(p); } };
+      for (uint32_t p : B->always_pods) take(p);
+      for (auto& n : doc.at("removeNodes").items()) {
+        const int e = B->node_index.find(n.s())->second;
+        for (uint32_t i = B->node_pod_off[e]; i < B->node_pod_off[e + 1]; ++i) take(B->node_pod_list[i]);
+      }
+    }
     for (auto& u : doc.at("pods").items()) {
       auto f = B->pod_index.find(u.s());
       if (f == B->pod_index.end()) throw std::runtime_error("probe schedules an unknown pod " + u.s());
@@ -2135,16 +2161,7 @@ static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas,
     if (!run || !release) return error_json("load", "solver library lacks ksolve_sweep");
     const auto t_begin = std::chrono::steady_clock::now();
     const int ne = (int)B->node_names.size(), n_res = B->n_res, nr1 = n_res + 1, T = B->n_templates, n_its = B->n_its;
-    if (!B->sweep_tables) {
-      B->node_pod_off.assign((size_t)ne + 1, 0);
-      for (int p = 0; p < B->n_pods; ++p) { if (B->pod_node[p] >= 0) B->node_pod_off[(size_t)B->pod_node[p] + 1]++; else B->always_pods.push_back((uint32_t)p); }
-      for (int e = 0; e < ne; ++e) B->node_pod_off[(size_t)e + 1] += B->node_pod_off[e];
-      B->node_pod_list.assign(B->node_pod_off[ne], 0);
-      std::vector<uint32_t> fill(B->node_pod_off.begin(), B->node_pod_off.end() - 1);
-      for (int p = 0; p < B->n_pods; ++p) if (B->pod_node[p] >= 0) B->node_pod_list[fill[B->pod_node[p]]++] = (uint32_t)p;
-      if (B->node_index.empty()) { B->node_index.reserve(B->node_names.size() * 2); for (size_t e = 0; e < B->node_names.size(); ++e) B->node_index[B->node_names[e]] = (int)e; }
-      B->sweep_tables = true;
-    }
+    ensure_sweep_tables(B);
     Value doc = A ? Value::object() : kj::Parser(sweep_json).parse();
     // candidates: one list of nodes per simulation ("candidates": [[name | position, ...], ...]) or the same as CSR arrays of
     // positions in the stateNodes list ("candidateOff": n + 1 offsets, "candidateNodes")

@@ -133,15 +133,17 @@ class Scheduler:
             self._lib.ksched_close(self._session)
             self._session = None
 
-    def Probe(self, remove_nodes=(), pods=()) -> "Scheduler":
+    def Probe(self, remove_nodes=(), pods=(), pods_of_removed_nodes=False) -> "Scheduler":
         """One probe of a RESIDENT cluster (ksolve_probe_create; disruption/helpers.go:53-155): this scheduler holds the
         whole cluster — every node as a state node, every pod some probe may place as a pod — and the probe is that
         cluster without `remove_nodes` (names), scheduling `pods` (uids). The returned Scheduler shares the tables already
         on the device (nothing is flattened or uploaded again), solves alone or through SolveBatch, and is closed with
-        this one. Raises Unsupported for clusters whose pods carry topology constraints (one NewScheduler per probe then)."""
+        this one. Raises Unsupported for clusters whose pods carry topology constraints (one NewScheduler per probe then).
+        pods_of_removed_nodes=True: the probe schedules what a sweep schedules for these candidates — the pods of every simulation and
+        the pods bound to the removed nodes (a resident cluster whose pods travel as groups has no uids to list them by)."""
         if not self._session:
             raise RuntimeError("scheduler is closed")
-        doc = json.dumps({"removeNodes": list(remove_nodes), "pods": list(pods)}).encode()
+        doc = json.dumps({"removeNodes": list(remove_nodes), "pods": list(pods), "podsOfRemovedNodes": bool(pods_of_removed_nodes)}).encode()
         probe = object.__new__(Scheduler)
         probe.problem, probe._solver_lib, probe._lib, probe._probes = None, self._solver_lib, self._lib, []
         probe._session = self._lib.ksched_probe(self._session, doc)

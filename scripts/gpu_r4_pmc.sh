@@ -54,5 +54,5 @@ for grp, names in (("kernels", ("ksolve_pack_fast", "ksolve_row_hash_coop2")), (
     for k in names:
         print(k, {c: (round(v["per_launch"], 1) if isinstance(v, dict) else v) for c, v in out[grp].get(k, {}).items()})
 PY
-timeout 600 python tests/tools/gpu_classing_rows.py > $O/classing_rows.json 2> $O/classing_rows.err; cat $O/classing_rows.json
+[ -n "$KSOLVE_PMC_SKIP_CLASSING_ROWS" ] || { timeout 600 python tests/tools/gpu_classing_rows.py > $O/classing_rows.json 2> $O/classing_rows.err; cat $O/classing_rows.json; }
 rm -rf $O/pmc_*_fetch $O/pmc_*_write $O/pmc_*_sq $O/stats_head $O/stats_sweep

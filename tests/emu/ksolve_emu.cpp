@@ -133,6 +133,29 @@ static void be_launch_node_dead0(ksolve_handle*, int n_blocks, const ks::NodeDea
 static void be_launch_claim_gather(ksolve_handle*, int n, const ks::ClaimGatherArgs& a) { for (int i = 0; i < n; ++i) ks::claim_gather_body(i, a); }
 static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, ks::Workspace* d_items, int n, const ks::LdsPlan& plan) {
   be_tic(h, ksi::T_PACK);
+  if (plan.waves == 4) {
+    // the compact form (ksolve_pack_sweep4): workgroups of four wavefronts over one LDS segment — wave 0 prepares the shared tables,
+    // then every wavefront strides over its probes with its own ScratchSmall working set. A small grid, so that wavefronts run
+    // several probes on the same working set as they do on the device.
+    typedef ks::Engine<ks::Wave, true, false, ks::ScratchSmall> Eng;
+    const int grid = std::max(1, std::min((n + 3) / 4, 3));
+    for (int b = 0; b < grid; ++b) {
+      std::vector<char> lds((size_t)plan.total_bytes + 64, (char)0xA5);   // garbage, like the device's LDS at kernel start
+      uint32_t* misc = (uint32_t*)(lds.data() + plan.off_shared_misc);
+      {
+        ks::LdsTables t0; t0.bind(lds.data(), plan, 0);
+        Eng eng(*d_pv, d_items[b * 4], t0);
+        misc[0] = eng.prepare();
+      }
+      const uint32_t active = misc[0];
+      for (int wave = 0; wave < 4; ++wave) {
+        ks::LdsTables tables; tables.bind(lds.data(), plan, wave);
+        for (int p = b * 4 + wave; p < n; p += grid * 4) { Eng eng(*d_pv, d_items[p], tables); eng.solve(&active); }
+      }
+    }
+    be_toc(h, ksi::T_PACK);
+    return;
+  }
   for (int p = 0; p < n; ++p) {
     std::vector<char> lds((size_t)plan.total_bytes + 64, (char)0xA5);   // garbage, like the device's LDS at kernel start
     ks::LdsTables tables;

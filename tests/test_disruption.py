@@ -659,6 +659,44 @@ def test_multi_node_sets_on_a_compact_cluster_fuzz(oracle, emu, seed, topology):
     rc.close()
 
 
+@pytest.mark.parametrize("topology", [False, True])
+def test_compact_sweep_equals_the_one_wavefront_kernel(emu, monkeypatch, topology):
+    """ksolve_sweep runs a cluster whose dictionaries fit it through the COMPACT form of the launch (ksolve_pack_sweep4: four
+    wavefronts per workgroup share the read-only instance-type tables and the template records that wave 0 prepared once, every
+    wavefront runs several probes one after the other on a ScratchSmall working set). It must give what the one-wavefront kernel
+    with the general Scratch gives (KSOLVE_TEST_SWEEP_GENERAL, test builds only) for every probe: decisions, replacements, where
+    every pod went, NodeClaims, evaluation counts — 240 single-node probes and 40 multi-node sets, so that each emulated wavefront
+    goes through ~20 probes on the same working set. A probe handle (one simulation through ksolve_solve) gives the sweep's result too."""
+    import random
+    cc = dz.make_resident_cluster(n_nodes=600, seed=7, topology=topology)
+    order = dz.compact_candidates(cc)
+    rng = random.Random(3)
+    singles = [[cc["nodes"][i]] for i in order[:240]]
+    multis = [[cc["nodes"][i] for i in rng.sample(order, k)] for k in range(2, 42)]
+    outs = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("KSOLVE_TEST_SWEEP_GENERAL", "1")
+        else:
+            monkeypatch.delenv("KSOLVE_TEST_SWEEP_GENERAL", raising=False)
+        rc = dz.ResidentCluster.from_compact(cc, solver_lib=emu)
+        a = rc.decisions(singles, detail=True); la = rc.last_sweep
+        b = rc.decisions(multis, detail=True, multi_node=True, library_prices=True); lb = rc.last_sweep
+        keys = ("decisions", "allNonPendingPodsScheduled", "claims", "status", "referenceBinEvaluations")
+        outs.append((a, b, [la[k] for k in keys], [lb[k] for k in keys]))
+        if not general:
+            # one simulation as a probe handle of the resident cluster: the pods a sweep schedules for this candidate
+            j = next(i for i, c in enumerate(a) if c["decision"] == "replace")
+            pr = rc.scheduler.Probe([singles[j][0]["name"]], pods_of_removed_nodes=True)
+            res = pr.Solve()
+            assert res["counters"]["referenceBinEvaluations"] == la["referenceBinEvaluations"][j]
+            assert len(res["newNodeClaims"]) == la["claims"][j] == 1
+            pr.close()
+        rc.close()
+    assert outs[0] == outs[1]
+    assert len({c["decision"] for c in outs[0][0]}) == 3
+
+
 def test_same_instance_type_filter_in_the_sweep(oracle, emu):
     """filterOutSameInstanceType (multinodeconsolidation.go:209-246) inside the sweep's verdicts. [2 x the priciest type, 1 x a
     small type] -> one node: the small type is among the replacement options, so only options cheaper than the small node

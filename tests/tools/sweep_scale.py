@@ -26,6 +26,9 @@ cands = [[cc["nodes"][i]] for i in order]
 for _ in range(args.repeat):
     t = time.time(); cmds = rc.decisions(cands); dt = time.time() - t
 tm = rc.last_sweep["timings"]
+import hashlib  # noqa: E402
+out["verdict_digest"] = hashlib.sha256(json.dumps([[c["decision"], c["replacement"], c.get("replacementCapacityType")] for c in cmds] + [list(rc.last_sweep["referenceBinEvaluations"])],
+                                                  sort_keys=True).encode()).hexdigest()[:16]   # every probe's verdict and reference-equivalent evaluation count: equal across builds / kernels
 out.update(candidates=len(cands), decisions=dict(Counter(c["decision"] for c in cmds)), python_call_s=dt, timings=tm,
            probes_per_s_kernel=len(cands) / (tm["pack_us"] * 1e-6), probes_per_s_library=len(cands) / ((tm["descriptors_ms"] + tm["sweep_ms"] + tm["verdicts_ms"]) * 1e-3),
            probes_per_s_python=len(cands) / dt)
