@@ -22,6 +22,21 @@ for m in ("compact", "general"):
         except Exception as e:
             print(m + t, "failed", e)
 PY
+# per-probe shader cycles by verdict and phase (profiling build with the test switches: the same binary runs both forms)
+for mode in compact general; do
+  if [ $mode = general ]; then export KSOLVE_TEST_SWEEP_GENERAL=1; else unset KSOLVE_TEST_SWEEP_GENERAL; fi
+  timeout 300 python tests/tools/sweep_probe_costs.py 100000 10000 48 --solver-lib karpenter_amd/variants/libksolve_timers.so 2>$O/probe_costs_${mode}.err | tail -1 > $O/probe_costs_${mode}.json
+done
+unset KSOLVE_TEST_SWEEP_GENERAL
+python - <<'PY'
+import json
+for m in ("compact", "general"):
+    try:
+        d = json.load(open(f"gpurun_out/r4h/probe_costs_{m}.json"))
+        print(m, d["sweep_timings"]["pack_us"], {k: (v["cycles_mean"], v["cycles_median"], v["cycles_p90"], v["cycles_max"]) for k, v in d["by_decision"].items()})
+    except Exception as e:
+        print(m, "failed", e)
+PY
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -8 | tee $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 | tee $O/smoke.log
 timeout 900 python bench.py --topology-pods 0 --components-pods 0 --beyond-lds-pods 0 --whole-batch-exact-pods 0 --batch-problems 0 --sweep-sample 12 --sweep-topology-sample 4 2>$O/bench_reduced.err | tail -1 > $O/bench_reduced.json
