@@ -131,26 +131,35 @@ static void be_free(ksolve_handle* h, void* p) {
 }
 static void be_launch_node_dead0(ksolve_handle*, int n_blocks, const ks::NodeDeadArgs& a) { for (int b = 0; b < n_blocks; ++b) ks::node_dead0_body<ks::Wave>(b, a); }
 static void be_launch_claim_gather(ksolve_handle*, int n, const ks::ClaimGatherArgs& a) { for (int i = 0; i < n; ++i) ks::claim_gather_body(i, a); }
-static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, ks::Workspace* d_items, int n, const ks::LdsPlan& plan) {
+static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, ks::Workspace* d_items, int n, const ks::LdsPlan& plan, const uint32_t* d_order, uint32_t* d_next) {
   be_tic(h, ksi::T_PACK);
   if (plan.waves == 4) {
-    // the compact form (ksolve_pack_sweep4): workgroups of four wavefronts over one LDS segment — wave 0 prepares the shared tables,
-    // then every wavefront strides over its probes with its own ScratchSmall working set. A small grid, so that wavefronts run
-    // several probes on the same working set as they do on the device.
+    // the compact form (ksolve_pack_sweep4): workgroups of four wavefronts over one LDS segment each — wave 0 prepares the shared
+    // tables with the first probe it takes — and the probes handed out through the launch's counter in `d_order`. The emulated
+    // wavefronts take one probe at a time in turn, so that each runs several probes on its own working set beside its neighbours'.
     typedef ks::Engine<ks::Wave, true, false, ks::ScratchSmall> Eng;
     const int grid = std::max(1, std::min((n + 3) / 4, 3));
+    auto fetch = [&]() -> int { const uint32_t i = (*d_next)++; return i < (uint32_t)n ? (int)d_order[i] : -1; };
+    std::vector<std::vector<char>> lds((size_t)grid);
+    std::vector<uint32_t> active((size_t)grid, 0);
     for (int b = 0; b < grid; ++b) {
-      std::vector<char> lds((size_t)plan.total_bytes + 64, (char)0xA5);   // garbage, like the device's LDS at kernel start
-      uint32_t* misc = (uint32_t*)(lds.data() + plan.off_shared_misc);
-      {
-        ks::LdsTables t0; t0.bind(lds.data(), plan, 0);
-        Eng eng(*d_pv, d_items[b * 4], t0);
-        misc[0] = eng.prepare();
-      }
-      const uint32_t active = misc[0];
-      for (int wave = 0; wave < 4; ++wave) {
-        ks::LdsTables tables; tables.bind(lds.data(), plan, wave);
-        for (int p = b * 4 + wave; p < n; p += grid * 4) { Eng eng(*d_pv, d_items[p], tables); eng.solve(&active); }
+      lds[b].assign((size_t)plan.total_bytes + 64, (char)0xA5);   // garbage, like the device's LDS at kernel start
+      const int p = fetch();
+      if (p < 0) continue;
+      ks::LdsTables t0; t0.bind(lds[b].data(), plan, 0);
+      { Eng eng(*d_pv, d_items[p], t0); active[b] = eng.prepare(); }
+      Eng eng(*d_pv, d_items[p], t0);
+      eng.solve(&active[b]);
+    }
+    for (bool more = true; more;) {
+      more = false;
+      for (int b = 0; b < grid; ++b) for (int wave = 0; wave < 4; ++wave) {
+        const int p = fetch();
+        if (p < 0) continue;
+        more = true;
+        ks::LdsTables tables; tables.bind(lds[b].data(), plan, (wave + 1) & 3);   // wave 0 had the first turn
+        Eng eng(*d_pv, d_items[p], tables);
+        eng.solve(&active[b]);
       }
     }
     be_toc(h, ksi::T_PACK);
