@@ -243,10 +243,13 @@ def config4_multi_node(args, cc, rc, rank, world):
            "windows": n_windows, "window_candidates": K, "probes": len(sets)}
     if not sets:
         return out
-    rc.decisions(sets[:K - 1], multi_node=True, library_prices=True)      # warm-up: grows the arena to the largest prefix
+    # timed in steady state like the single-node sweep: the first call also grows the handle's device arena (GBs for 3,200 prefixes of
+    # up to 2,000 pods: an allocation of 3-30 ms by box) and its page-locked staging memory; a controller sweeps every few seconds
+    t = time.perf_counter(); rc.decisions(sets, multi_node=True, library_prices=True); first_s = time.perf_counter() - t
     t = time.perf_counter(); cmds = rc.decisions(sets, multi_node=True, library_prices=True); dt = time.perf_counter() - t
     tm = rc.last_sweep["timings"]
     lib_s = (tm["descriptors_ms"] + tm["sweep_ms"] + tm["verdicts_ms"]) * 1e-3
+    out["first_call_python_s"] = first_s
     by = dict(zip(key, cmds))
     chosen = []
     for w in mine:
