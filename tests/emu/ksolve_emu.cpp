@@ -131,19 +131,30 @@ static void be_free(ksolve_handle* h, void* p) {
 }
 static void be_launch_node_dead0(ksolve_handle*, int n_blocks, const ks::NodeDeadArgs& a) { for (int b = 0; b < n_blocks; ++b) ks::node_dead0_body<ks::Wave>(b, a); }
 static void be_launch_claim_gather(ksolve_handle*, int n, const ks::ClaimGatherArgs& a) { for (int i = 0; i < n; ++i) ks::claim_gather_body(i, a); }
-static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, ks::Workspace* d_items, int n, const ks::LdsPlan& plan, const uint32_t* d_order, uint32_t* d_next) {
+static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, ks::Workspace* d_items, int n, const ks::LdsPlan& plan_in, const uint32_t* d_order, uint32_t* d_next) {
   be_tic(h, ksi::T_PACK);
-  if (plan.waves == 4) {
+  if (plan_in.waves == 4) {
     // the compact form (ksolve_pack_sweep4): workgroups of four wavefronts over one LDS segment each — wave 0 prepares the shared
     // tables with the first probe it takes — and the probes handed out through the launch's counter in `d_order`. The emulated
     // wavefronts take one probe at a time in turn, so that each runs several probes on its own working set beside its neighbours'.
     typedef ks::Engine<ks::Wave, true, false, ks::ScratchSmall> Eng;
+#if defined(__SANITIZE_ADDRESS__)
+    // AddressSanitizer build: every wavefront's working set gets a poisoned tail, so that a working set outgrowing its slice of the
+    // workgroup's LDS (into its neighbour's Scratch) is reported
+    ks::LdsPlan plan = plan_in;
+    plan.wave_stride += 64; plan.total_bytes += 4 * 64;
+#else
+    const ks::LdsPlan& plan = plan_in;
+#endif
     const int grid = std::max(1, std::min((n + 3) / 4, 3));
     auto fetch = [&]() -> int { const uint32_t i = (*d_next)++; return i < (uint32_t)n ? (int)d_order[i] : -1; };
     std::vector<std::vector<char>> lds((size_t)grid);
     std::vector<uint32_t> active((size_t)grid, 0);
     for (int b = 0; b < grid; ++b) {
       lds[b].assign((size_t)plan.total_bytes + 64, (char)0xA5);   // garbage, like the device's LDS at kernel start
+#if defined(__SANITIZE_ADDRESS__)
+      for (int w = 0; w < 4; ++w) __asan_poison_memory_region(lds[b].data() + (plan.total_bytes - (4 - w) * plan.wave_stride) + plan.wave_stride - 64, 64);
+#endif
       const int p = fetch();
       if (p < 0) continue;
       ks::LdsTables t0; t0.bind(lds[b].data(), plan, 0);
@@ -165,6 +176,7 @@ static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, 
     be_toc(h, ksi::T_PACK);
     return;
   }
+  const ks::LdsPlan& plan = plan_in;
   for (int p = 0; p < n; ++p) {
     std::vector<char> lds((size_t)plan.total_bytes + 64, (char)0xA5);   // garbage, like the device's LDS at kernel start
     ks::LdsTables tables;
