@@ -10,6 +10,7 @@
 //   ksolve_finalize      one thread per claim: cheapest compatible available offering
 // Each handle owns a stream; every phase is bracketed by HIP events recorded on that stream.
 #include <cstring>
+#include <mutex>
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -57,24 +58,63 @@ static void* be_stage(ksolve_handle* h, size_t bytes) {
   }
   return b->stage;
 }
+// Large uploads out of the caller's pageable tables (a million pod rows: 220-245 MB) go through two page-locked buffers the PROCESS
+// keeps: the host copies chunk i + 1 into one while the DMA engine reads chunk i out of the other. The runtime's own pageable path
+// moved the 245 MB of the headline problem at 2.4 GB/s (100 ms of a 210 ms NewScheduler); page-locking the caller's memory for the
+// copy (hipHostRegister, the round-4 attempt) costs as much as it saves. Portable memory: handles on any device of the process use it,
+// one at a time.
+struct H2dPipe {
+  std::mutex mu;
+  void* buf[2] = {nullptr, nullptr};
+  static constexpr size_t kChunk = (size_t)16 << 20;
+  bool tried = false, ok = false;
+};
+static H2dPipe& h2d_pipe() { static H2dPipe p; return p; }
+static bool h2d_staged(ksolve_handle* h, void* dst, const void* src, size_t bytes) {
+  H2dPipe& P = h2d_pipe();
+  std::lock_guard<std::mutex> guard(P.mu);
+  if (!P.tried) {
+    P.tried = true;
+    P.ok = hipHostMalloc(&P.buf[0], H2dPipe::kChunk, hipHostMallocPortable) == hipSuccess && hipHostMalloc(&P.buf[1], H2dPipe::kChunk, hipHostMallocPortable) == hipSuccess;
+    if (!P.ok) { (void)hipGetLastError(); for (auto& b : P.buf) { if (b) (void)hipHostFree(b); b = nullptr; } }
+  }
+  if (!P.ok) return false;
+  hipStream_t st = HB(h)->stream;
+  hipEvent_t ev[2];
+  if (hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(ev[0]); return false; }
+  bool used[2] = {false, false}, good = true;
+  size_t off = 0;
+  for (int i = 0; off < bytes && good; i ^= 1) {
+    const size_t n = std::min(H2dPipe::kChunk, bytes - off);
+    if (used[i]) good = hip_check(h, hipEventSynchronize(ev[i]), "hipEventSynchronize (upload staging)");   // the DMA that read this buffer is done
+    if (!good) break;
+    memcpy(P.buf[i], (const char*)src + off, n);
+    good = hip_check(h, hipMemcpyAsync((char*)dst + off, P.buf[i], n, hipMemcpyHostToDevice, st), "hipMemcpy H2D (staged)") &&
+           hip_check(h, hipEventRecord(ev[i], st), "hipEventRecord (upload staging)");
+    used[i] = true;
+    off += n;
+  }
+  hip_check(h, hipStreamSynchronize(st), "hipStreamSynchronize");   // the buffers are free again, the caller's source is no longer read
+  (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+  return true;   // errors are on the handle (hip_check)
+}
 static void be_h2d(ksolve_handle* h, void* dst, const void* src, size_t bytes) {
   if (!dst || !bytes) return;
-  // a large table out of the caller's pageable memory (a million pod rows: 220 MB): page-lock it for the copy — the runtime's own
-  // path stages it through bounce buffers at a few GB/s
-  bool locked = false;
 #ifdef KSOLVE_TEST_HOOKS
-  static const bool no_lock = getenv("KSOLVE_TEST_NO_HOST_REGISTER") != nullptr;
+  static const bool no_stage = getenv("KSOLVE_TEST_NO_HOST_REGISTER") != nullptr;   // tests / A-B runs: the runtime's own pageable path
 #else
-  const bool no_lock = false;
+  const bool no_stage = false;
 #endif
-  if (bytes >= (size_t)8 << 20 && !no_lock) {
-    locked = hipHostRegister(const_cast<void*>(src), bytes, hipHostRegisterDefault) == hipSuccess;
-    if (!locked) (void)hipGetLastError();   // (already registered, or not lockable: the plain copy)
+  if (bytes >= (size_t)8 << 20 && !no_stage) {
+    // page-locked already (the handle's own staging memory of a large sweep): one DMA at link speed as it is
+    hipPointerAttribute_t at{};
+    const bool pinned = hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost;
+    if (!pinned) { (void)hipGetLastError(); if (h2d_staged(h, dst, src, bytes)) return; }
   }
   hip_check(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, HB(h)->stream), "hipMemcpy H2D");
   // source buffers are caller-owned and only guaranteed for the duration of the call
   hip_check(h, hipStreamSynchronize(HB(h)->stream), "hipStreamSynchronize");
-  if (locked) (void)hipHostUnregister(const_cast<void*>(src));
 }
 static void be_d2h(ksolve_handle* h, void* dst, const void* src, size_t bytes) {
   if (!src || !bytes) return;

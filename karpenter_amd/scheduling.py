@@ -283,11 +283,10 @@ class Scheduler:
         (the order the reference appended them in, nodeclaim.go:248)."""
         import numpy as np
         off = np.zeros(n_claims + 1, dtype=np.uint32)
-        total = self._lib.ksched_pods_by_claim(self._session, n_claims, off.ctypes.data, None, 0)
-        pods = np.empty(total, dtype=np.uint32)
-        if total:
-            self._lib.ksched_pods_by_claim(self._session, n_claims, off.ctypes.data, pods.ctypes.data, total)
-        return [pods[off[c]:off[c + 1]] for c in range(n_claims)]
+        n = self._lib.ksched_assignment(self._session, None, None, 0)    # the problem's pods: room enough for every claim's list, so one call counts and scatters
+        pods = np.empty(max(1, n), dtype=np.uint32)
+        total = self._lib.ksched_pods_by_claim(self._session, n_claims, off.ctypes.data, pods.ctypes.data, n)
+        return [pods[off[c]:off[c + 1]] for c in range(n_claims)] if total <= n else []
 
     def Cancel(self) -> None:
         """The ctx deadline of Solve (scheduler.go:477-480, provisioner.go:427): call from another thread while Solve()
