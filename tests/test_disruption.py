@@ -695,6 +695,13 @@ def test_compact_sweep_equals_the_one_wavefront_kernel(emu, monkeypatch, topolog
         rc.close()
     assert outs[0] == outs[1]
     assert len({c["decision"] for c in outs[0][0]}) == 3
+    # ... and as several launches (an arena budget of 8 MB per launch: every chunk has its own hand-out order and counter)
+    monkeypatch.delenv("KSOLVE_TEST_SWEEP_GENERAL", raising=False)
+    monkeypatch.setenv("KSOLVE_SWEEP_ARENA_MB", "8")
+    rc = dz.ResidentCluster.from_compact(cc, solver_lib=emu)
+    a = rc.decisions(singles, detail=True)
+    assert a == outs[0][0]
+    rc.close()
 
 
 def test_same_instance_type_filter_in_the_sweep(oracle, emu):
