@@ -395,7 +395,9 @@ def test_full_size_digest(pin):
     # every load of a claim another lane stored has to come from L2, not a stale L1 line: the digest of a million placements says so
     # cursor-hbm: the claim order in HBM too (plan 2, above ~15,000 claims: the 10M-pod configs[3] batch as ONE problem runs there)
     cursor_shape = g["config"] in ("config1", "config2", "config4")
-    engines = ["auto"] + (["general"] if g["config"] != "config3" and g["pods"] <= 250000 else []) + (["cursor-wide", "cursor-hbm"] if cursor_shape and g["pods"] <= 2_000_000 else [])
+    engines = ["auto"] + (["general"] if g["config"] != "config3" and g["pods"] <= 250000 else []) + (["cursor-wide", "cursor-hbm"] if cursor_shape and g["pods"] <= 1_000_000 else [])
+    if cursor_shape and 1_000_000 < g["pods"] <= 2_000_000:
+        engines.append("cursor-hbm")   # beyond the LDS plan "auto" IS the plan with the claims' state in HBM (cursor-wide); the order in HBM too is the other one
     for eng in engines:
         s = NewScheduler(dict(prob, options=dict(prob["options"], engine=eng)))
         r = s.Solve()
