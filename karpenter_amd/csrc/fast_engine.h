@@ -35,16 +35,21 @@
 
 namespace ks {
 
-constexpr int kFastRows = 4;          // class slots = 64 lanes x kFastRows registers
-constexpr int kFastSlots = 64 * kFastRows;
+constexpr int kFastRows = 4;          // class slots = 64 lanes x R rows, R = 1 or kFastRows (FastPlan::rows; the engine is compiled for both)
+constexpr uint32_t kFastFree = 0xFFFFFFFFu;   // class id of a free slot
+constexpr uint32_t kFastLastBit = 0x80000000u;   // q_class: the class's last entry in the queue (its slot is free afterwards)
 constexpr int kFastEnt = 1024;        // requirement-set cache slots (open addressing, filled to 80% at most)
 constexpr int kFastPool = 256;        // extra Pareto vectors
 constexpr int kFastMaxPareto = 16;    // per requirement set
 constexpr int kFastMaxVar = 12;       // keys pods select on
-constexpr int kFastClasses = 8192;    // pod classes per problem (class -> slot table in LDS)
 constexpr int kFastVarBits = 56;      // their dictionary values + one guard bit each must fit 56 bits; the top byte of vmask is the template
 
-struct FastClaim { uint64_t vmask; int32_t req[4]; };                                   // 24 B, LDS, by claim id
+struct FastClaim { uint64_t vmask; int32_t req[4]; };                                   // 24 B: a claim's state (requirement set, requests)
+// The in-flight claim as the loop keeps it, by claim id: its state and its ACCEPTANCE WORDS — bit s of acc[j] says that the
+// class in slot 64 j + s passes CanAdd on this claim as it stands (nodeclaim.go:124-242). The words are exact at all times:
+// they are recomputed for the one claim a commit changes (64 classes per instruction, one lane each), for a new claim when it
+// is created, and for one class over all claims when the class takes a slot.
+template <int R> struct FastRec { uint64_t vmask; int32_t req[4]; uint64_t acc[R]; };  // 32 B (R = 1) / 56 B (R = 4)
 // a pod class as the scan needs it: values it admits (all ones on keys it does not select on), the fields it selects on,
 // requests, templates whose taints it tolerates and whose keys cover its custom keys, keys it defines
 struct FastSlot { uint64_t cvmask; uint64_t dmask; int32_t size[4]; uint32_t tmplok; uint32_t kdef; };  // 40 B
@@ -53,10 +58,12 @@ struct FastEnt { uint64_t vmask; int32_t cap[4]; uint32_t info; uint32_t pad; };
 struct FastPlan {   // LDS plan of ksolve_pack_fast (bytes), computed by the host
   int total_bytes, cap;
   int off_state, off_key, off_ord, off_snap, off_ent, off_pool, off_slot, off_misc, off_hot;
-  int global_state;   // 1: the claims' state (FastClaim, 24 B each) lives in HBM (FastWork::c_state), only the order arrays in LDS:
+  int global_state;   // 1: the claims' records (FastRec) live in HBM (FastWork::c_rec), only the order arrays in LDS:
                       //    ~15,000 in-flight claims instead of ~3,000 (round 4). off_state is unused then.
                       // 2: the order arrays too (FastWork::o_key / o_ord / o_snap): 65,472 claims — what 16-bit claim ids address;
                       //    LDS holds the caches, the class slots and the loop's own state only.
+  int rows;           // class slots / 64: 1 when at most 64 pod classes are ever live at once in the queue (FastWork::max_active,
+                      //    counted before the loop by ksolve_fast_overlap), kFastRows otherwise
 };
 
 struct FastMisc {   // small LDS tables
@@ -66,13 +73,7 @@ struct FastMisc {   // small LDS tables
   uint8_t vkey[kFastMaxVar], voff[kFastMaxVar], vwidth[kFastMaxVar];
   uint16_t vword[kFastMaxVar];         // dictionary word of the key
   uint64_t its[kMaxItWords], rem[kMaxItWords], cand[kMaxItWords];   // slow-path scratch
-  uint32_t blk_pod[64];                // the 64 queue entries being placed
-  uint16_t blk_class[64];
-  uint32_t out_claim[64];              // their results, written to HBM when the block is done
-  uint32_t out_cnt[64];
-  uint16_t active[kFastSlots];         // class of each slot (for eviction)
-  uint16_t slot_of[kFastClasses];      // class -> slot, 0xFFFF = none
-  uint64_t acc[kFastRows];             // class slots that accept the claim just created (place_new_claim)
+  uint64_t acc[kFastRows];             // acceptance words of the claim just created (new_claim -> place_new_claim)
 };
 
 struct FastVar { int nv; uint8_t vkey[kFastMaxVar], voff[kFastMaxVar], vwidth[kFastMaxVar]; uint16_t vword[kFastMaxVar]; };   // the keys pods select on
@@ -88,12 +89,16 @@ struct FastWork {   // HBM workspace of the cursor engine (host-allocated when t
   // The loop reads the queue and writes its results in QUEUE order, 64 consecutive entries per access: one wave touching
   // 64 random pods per block pays for 64 address translations in a row. ksolve_fast_queue (before) and
   // ksolve_fast_scatter (after) do the random accesses with every CU busy.
-  uint32_t* q_class;      // [n_pods] class of queue entry i = row_class[sorted_pods[i]]
+  uint32_t* q_class;      // [n_pods] class of queue entry i = row_class[sorted_pods[i]] | kFastLastBit on the class's last entry
   uint32_t* q_claim;      // [n_pods] claim of queue entry i (0xFFFFFFFF: not placed)
   uint32_t* q_cnt;        // [n_pods] pods the claim held before it
   uint16_t* o_key;        // [max_claims] plan 2: the claim order (pod count / claim id by position) and its snapshot, in HBM
   uint16_t* o_ord;
   uint16_t* o_snap;
+  uint64_t* c_rec;        // plans 1, 2: [max_claims] FastRec<rows>, the claims' records in HBM
+  uint32_t* cls_first;    // [n_classes] first / last queue entry of the class (ksolve_fast_queue)
+  uint32_t* cls_last;
+  uint32_t* max_active;   // [1] the most classes live at once: max over classes c of #{c' : first(c') <= first(c) <= last(c')} (ksolve_fast_overlap)
   FastPlan plan;
   int enabled;
 };
@@ -120,59 +125,49 @@ KS_FN void lds_put(KS_LDS T* p, const T& v) {
 }
 
 
-// The in-flight claims' state by claim id. LDS while the problem's claims fit beside the order arrays and the caches (the
-// benchmarked configuration: 2,763 claims); HBM otherwise (GS = true): the lane that tests a claim then gathers its 24 bytes
+// The in-flight claims' records by claim id. LDS while the problem's claims fit beside the order arrays and the caches (the
+// benchmarked configuration: 2,763 claims); HBM otherwise (HBM = true): the lane that reads a claim then gathers its record
 // through the vector L1 / L2 instead of LDS. Plain loads and stores: this wavefront is the only reader and writer, its vector
 // memory operations execute in order, W::sync() (a wavefront-scope fence) follows every store — what the general engine's
-// HBM-resident claim records have relied on since round 1. (-DKS_CLAIM_STATE_AGENT_SCOPE: relaxed atomics at agent scope
-// instead, every access served by L2 — the first build of the plan, 1.48 µs per pod at 2M pods of configs[1].)
-template <bool GS> struct ClaimStates;
-template <> struct ClaimStates<false> {
-  KS_LDS FastClaim* p;
-  KS_FN FastClaim get(uint32_t c) const { return lds_get(&p[c]); }
-  KS_FN void put(uint32_t c, const FastClaim& v) const { lds_put(&p[c], v); }
+// HBM-resident claim records have relied on since round 1.
+template <bool HBM, int R> struct ClaimRecs;
+template <int R> struct ClaimRecs<false, R> {
+  KS_LDS FastRec<R>* p;
+  KS_FN FastClaim state(uint32_t c) const { return lds_get((const KS_LDS FastClaim*)&p[c]); }
+  KS_FN void put_state(uint32_t c, const FastClaim& v) const { lds_put((KS_LDS FastClaim*)&p[c], v); }
+  KS_FN uint64_t acc(uint32_t c, int row) const { return p[c].acc[row]; }
+  KS_FN void put_acc(uint32_t c, int row, uint64_t v) const { p[c].acc[row] = v; }
 };
-template <> struct ClaimStates<true> {
-  FastClaim* p;
-  KS_FN FastClaim get(uint32_t c) const {
+template <int R> struct ClaimRecs<true, R> {
+  FastRec<R>* p;
+  KS_FN FastClaim state(uint32_t c) const {
     FastClaim out;
     u64_alias* o = (u64_alias*)&out;
-#if KS_DEVICE && defined(KS_CLAIM_STATE_AGENT_SCOPE)
-    const uint64_t* s = (const uint64_t*)&p[c];
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(FastClaim) / 8); ++i) o[i] = __hip_atomic_load(&s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
     const u64_alias* s = (const u64_alias*)&p[c];
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(FastClaim) / 8); ++i) o[i] = s[i];
-#endif
     return out;
   }
-  KS_FN void put(uint32_t c, const FastClaim& v) const {
+  KS_FN void put_state(uint32_t c, const FastClaim& v) const {
     const u64_alias* o = (const u64_alias*)&v;
-#if KS_DEVICE && defined(KS_CLAIM_STATE_AGENT_SCOPE)
-    uint64_t* s = (uint64_t*)&p[c];
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(FastClaim) / 8); ++i) __hip_atomic_store(&s[i], o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
     u64_alias* s = (u64_alias*)&p[c];
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(FastClaim) / 8); ++i) s[i] = o[i];
-#endif
   }
+  KS_FN uint64_t acc(uint32_t c, int row) const { return p[c].acc[row]; }
+  KS_FN void put_acc(uint32_t c, int row, uint64_t v) const { p[c].acc[row] = v; }
 };
-template <bool GS> KS_FN ClaimStates<GS> fast_uniform(ClaimStates<GS> c) { c.p = fast_uniform(c.p); return c; }
-// The plan the engine is compiled for (FastPlan::global_state): 0 everything in LDS, 1 claim state in HBM, 2 claim state and
+// The plan the engine is compiled for (FastPlan::global_state): 0 everything in LDS, 1 claim records in HBM, 2 claim records and
 // order arrays in HBM. The order's accesses are plain loads and stores: the wavefront is the only reader and writer, its vector
 // memory operations execute in order, and W::sync() (a wavefront-scope fence) stands between a store and another lane's load.
-template <int GS> struct FastMem {
+template <int GS, int R> struct FastMem {
   static constexpr bool kStateHbm = GS >= 1, kOrderHbm = GS >= 2;
 #if KS_DEVICE
   typedef typename std::conditional<kOrderHbm, uint16_t*, KS_LDS uint16_t*>::type o16;
 #else
   typedef uint16_t* o16;
 #endif
-  typedef ClaimStates<kStateHbm> States;
+  typedef ClaimRecs<kStateHbm, R> States;
 };
 
 // What ksolve_pack_fast reads its problem from: ONE record in HBM (not kernel arguments: a by-value argument whose address
@@ -205,6 +200,8 @@ KS_FN T* fast_uniform(T* p) {
 #endif
 }
 
+template <bool H, int R> KS_FN ClaimRecs<H, R> fast_uniform(ClaimRecs<H, R> c) { c.p = fast_uniform(c.p); return c; }
+
 #define KS_LIKELY(x) __builtin_expect(!!(x), 1)
 #define KS_UNLIKELY(x) __builtin_expect(!!(x), 0)
 #if KS_DEVICE
@@ -214,7 +211,13 @@ KS_FN T* fast_uniform(T* p) {
 #endif
 
 // requirement-set cache helpers (per lane)
-KS_FN uint32_t fast_hash(uint64_t vm) { return (uint32_t)((vm * 0x9E3779B97F4A7C15ull) >> 54) & (kFastEnt - 1); }   // the TOP bits of the product: the only ones every input bit reaches (the template id sits in bits 56..63)
+// One 32-bit multiply (a quarter-rate instruction: 16 cycles of a lone wavefront; the 64-bit product of the first version was three of
+// them): the two halves folded with a rotation — the template id sits in the top byte, the fields of the keys pods select on
+// fill the word from bit 0 — and the TOP ten bits of the product, the only ones every input bit reaches.
+KS_FN uint32_t fast_hash(uint64_t vm) {
+  const uint32_t lo = (uint32_t)vm, hi = (uint32_t)(vm >> 32);
+  return (((lo ^ ((hi << 15) | (hi >> 17))) * 0x9E3779B1u) >> 22) & (kFastEnt - 1);
+}
 // entry of requirement set vm (copied to `out`), or -1 (not cached yet); one 32-byte LDS read per probe
 KS_FN int fast_lookup(const KS_LDS FastEnt* ent, uint64_t vm, FastEnt& out) {
   uint32_t h = fast_hash(vm);
@@ -256,30 +259,45 @@ KS_FN bool fast_sampled(int n, int p) {   // choosePivot's nine positions (pdq_e
 
 // Everything that happens rarely (a new requirement set, a new claim, a new class slot, pdqsort leaving its single-move
 // path): real function calls, so that their code and registers stay out of the loop that places a pod.
-template <class W, int GS = 0>
+// The loop's state between two events (LDS): scalars, the class slots (lane = slot: class id, cursor) and the 64-entry queue block
+struct FastHot {
+  int base, bi, bn, n, np, max_steps, steps, status;
+  int pend_a, pend_x, pend_new, ev_arg;
+  uint32_t pend_mv, pad0;
+  unsigned long long n_steps, n_tests, n_ref, hot_cycles;
+  unsigned long long tsec[8];   // profiling builds: shader clock per path of the loop
+  const uint32_t* q_class; const volatile int* cancel; uint32_t* q_claim; uint32_t* q_cnt;
+  uint32_t cur[kFastRows][64];    // cursor of the class in the slot: every claim left of it has rejected the class for good
+  uint32_t scls[kFastRows][64];   // class in the slot, kFastFree = none
+  uint32_t bcls[64], oclaim[64], ocnt[64], nxt_cls[64];
+};
+
+template <class W, int GS, int R>
 struct FastCold {
   const ProblemView* Pk;
   const Workspace* Sk;
   const FastWork* Fk;
-  typedef typename FastMem<GS>::o16 o16;
+  typedef typename FastMem<GS, R>::o16 o16;
   ClaimOrder<W, o16, false> order;
   o16 snap;                 // [cap] order snapshot around a slow sort
-  typename FastMem<GS>::States cst;
+  typename FastMem<GS, R>::States cst;
   KS_LDS FastEnt* ent;
   KS_LDS int32_t* pool;     // [kFastPool][4]
-  KS_LDS FastSlot* aslot;
+  KS_LDS FastSlot* aslot;   // [64 R] the class of each slot
   KS_LDS FastMisc* Mp;
-  int n_claims = 0, nv = 0, n_ent = 0, n_pool = 0, n_active = 0, n_evict = 0;
+  KS_LDS FastHot* hs;
+  int n_claims = 0, nv = 0, n_ent = 0, n_pool = 0, n_evict = 0;
   uint32_t host_seq = 0, active_templates = 0;
   int bail_code = 0;
   int lo_ = 0, hi_ = -1;    // positions a slow sort permuted
-  unsigned long long n_ref_extra = 0;
+  unsigned long long n_ref_extra = 0, n_cold_tests = 0;
 
   KS_DEV void init(const ProblemView* p, const Workspace* s, const FastWork* f, char* lds) {
     Pk = p; Sk = s; Fk = f;
     const FastPlan& pl = f->plan;
     Mp = (KS_LDS FastMisc*)(lds + pl.off_misc);
-    if constexpr (GS >= 1) cst.p = f->c_state; else cst.p = (KS_LDS FastClaim*)(lds + pl.off_state);
+    hs = (KS_LDS FastHot*)(lds + pl.off_hot);
+    if constexpr (GS >= 1) cst.p = (FastRec<R>*)f->c_rec; else cst.p = (KS_LDS FastRec<R>*)(lds + pl.off_state);
     if constexpr (GS >= 2) { order.key = (o16)f->o_key; order.ord = (o16)f->o_ord; snap = (o16)f->o_snap; }
     else { order.key = (o16)(lds + pl.off_key); order.ord = (o16)(lds + pl.off_ord); snap = (o16)(lds + pl.off_snap); }
     order.pos = nullptr;
@@ -404,7 +422,7 @@ struct FastCold {
     const Dict& d = P.dict;
     const int nk = d.n_keys, iw = P.it_words, nr = P.n_res, n_its = P.n_its, nc = P.n_classes, T = P.n_templates;
     const ProblemView& Pv = P;
-    if (!P.plain || P.n_rows != P.n_pods || nr > 4 || T > 32 || nc > kFastClasses || iw > kMaxItWords) return 1;
+    if (!P.plain || P.n_rows != P.n_pods || nr > 4 || T > 32 || iw > kMaxItWords) return 1;
     // (instance types may use any operator: with positive sets on the claim side the NotIn / DoesNotExist escape of
     // requirements.go:260-265 never applies, so compatible() stays monotone)
     // templates: only In sets
@@ -493,7 +511,6 @@ struct FastCold {
     // classes: packed form + the (class, template) verdicts that never change: taints (nodeclaim.go:126) and keys the
     // template does not define (requirements.go:185-193; with positive operators such a key stays undefined for good)
     FastSlot* fc = F.cls;
-    KS_LDS uint16_t* so = Mp->slot_of;
     const uint32_t wk = d.well_known_mask;
     const uint64_t bad = W::reduce_or(nc, [&](int c) {
       const uint64_t* cm = Pv.cls_reqs.mask + (size_t)c * d.req_words;
@@ -514,30 +531,113 @@ struct FastCold {
       for (int t = 0; t < T; ++t) if (!(Pv.tmpl_taints[t] & ~tol) && !(kdef & ~Mm.tdef[t] & ~wk)) ok |= 1u << t;
       s.tmplok = ok; s.kdef = kdef;
       fc[c] = s;
-      so[c] = 0xFFFF;
       return badc;
     });
     if (bad) return 8;
-    W::for_n(kFastEnt, [&](int i) { ent[i].info = 0; });
+    W::for_n(kFastEnt, [&](int i) { ent[i].info = 0; ent[i].vmask = ~0ull; });   // (no requirement set is all ones: the top byte is a template id < 32)
     return 0;
   }
 
-  // a class seen for the first time (or after an eviction) gets a slot; bit 16 of the result: every cursor must restart
+  // CanAdd (nodeclaim.go:124-242) of a claim in state `st` for the classes in the 64 slots of row j, one lane each -> the claim's
+  // acceptance word of the row. A requirement set met for the first time gets its cache entry here. bail_code != 0: stop.
+  KS_DEV uint64_t row_accepts(const FastClaim& st, int j) {
+    const int t = (int)(st.vmask >> 56);
+    const KS_LDS uint32_t* sc = hs->scls[j];
+    uint64_t accm = 0;
+    uint64_t todo = W::ballot([&](int l) { return sc[l] != kFastFree; });
+    n_cold_tests += (unsigned long long)popc64(todo);
+    while (todo) {
+      LaneVar<uint64_t> missv;
+      const uint64_t td = todo;
+      uint64_t okb = 0, miss = 0, d0, d1;
+      W::ballot4([&](int l) {
+        missv.at(l) = 0;
+        if (!((td >> l) & 1)) return 0;
+        const FastSlot s = lds_get(&aslot[j * 64 + l]);
+        if (!((s.tmplok >> t) & 1u)) return 0;
+        const uint64_t m = st.vmask & s.cvmask;
+        if (!fast_fields_ok(m, s.dmask)) return 0;
+        FastEnt e;
+        if (fast_lookup(ent, m, e) < 0) { missv.at(l) = m; return 2; }
+        return fast_fits(pool, e, st.req, s.size) ? 1 : 0;
+      }, okb, miss, d0, d1);
+      accm |= okb;
+      todo = miss;
+      if (miss && create_entry(missv.bcast(ctz64(miss))) < 0) { bail_code = 20; return 0; }
+    }
+    return accm;
+  }
+  // every acceptance word of claim x, from its state (the loop met a requirement set that is not cached yet, a cache slot
+  // that is not the set's first probe, or further Pareto vectors, while it refreshed the claim after a commit)
+  KS_COLD int refresh_claim(int x) {
+    x = (int)W::uniform((uint64_t)(uint32_t)x);
+    const FastClaim st = cst.state((uint32_t)x);
+    for (int j = 0; j < R; ++j) {
+      const uint64_t a = row_accepts(st, j);
+      if (bail_code) return -1;
+      if (W::leader()) cst.put_acc((uint32_t)x, j, a);
+    }
+    W::sync();
+    return 0;
+  }
+
+  // A class seen for the first time (or again after its slot was taken) gets a slot, and bit `slot` of every claim's
+  // acceptance word: the class against all in-flight claims, one lane each. Returns the slot, bit 16: every slot was taken
+  // and all of them were dropped (their classes take new slots when they come back), -1: stop (bail_code).
   KS_COLD int new_slot(int k) {
     k = (int)W::uniform((uint64_t)(uint32_t)k);
-    KS_LDS uint16_t* so = Mp->slot_of;
-    int evicted = 0;
-    if (n_active == kFastSlots) {
-      // every slot taken: forget them all (their classes start again from position 0 if they ever come back)
-      KS_LDS uint16_t* act = Mp->active;
-      W::for_n(kFastSlots, [&](int i) { so[act[i]] = 0xFFFF; });
-      n_active = 0;
+    int evicted = 0, slot = -1;
+    for (int j = 0; j < R && slot < 0; ++j) {
+      const KS_LDS uint32_t* sc = hs->scls[j];
+      const uint64_t fr = W::ballot([&](int l) { return sc[l] == kFastFree; });
+      if (fr) slot = j * 64 + ctz64(fr);
+    }
+    if (slot < 0) {
+      // every slot taken by a class that has entries left: forget them all
+      KS_LDS FastHot* h = hs;
+      W::each([&](int l) { for (int j = 0; j < R; ++j) { h->scls[j][l] = kFastFree; h->cur[j][l] = 0; } });
+      W::sync();
       n_evict++;
       evicted = 1 << 16;
+      slot = 0;
     }
-    const int slot = n_active++;
+    const int row = slot >> 6, sl = slot & 63;
     const FastSlot rec = Fk->cls[k];
-    if (W::leader()) { lds_put(&aslot[slot], rec); Mp->active[slot] = (uint16_t)k; so[k] = (uint16_t)slot; }
+    if (W::leader()) { lds_put(&aslot[slot], rec); hs->scls[row][sl] = (uint32_t)k; hs->cur[row][sl] = 0; }
+    W::sync();
+    const uint64_t bit = 1ull << sl;
+    const int nc = n_claims;
+    const typename FastMem<GS, R>::States cs_ = cst;
+    for (int x0 = 0; x0 < nc; x0 += 64) {
+      uint64_t todo = W::ballot([&](int l) { return x0 + l < nc; });
+      uint64_t accm = 0;
+      n_cold_tests += (unsigned long long)popc64(todo);
+      while (todo) {
+        LaneVar<uint64_t> missv;
+        const uint64_t td = todo;
+        uint64_t okb = 0, miss = 0, d0, d1;
+        W::ballot4([&](int l) {
+          missv.at(l) = 0;
+          if (!((td >> l) & 1)) return 0;
+          const FastClaim st = cs_.state((uint32_t)(x0 + l));
+          if (!((rec.tmplok >> (st.vmask >> 56)) & 1u)) return 0;
+          const uint64_t m = st.vmask & rec.cvmask;
+          if (!fast_fields_ok(m, rec.dmask)) return 0;
+          FastEnt e;
+          if (fast_lookup(ent, m, e) < 0) { missv.at(l) = m; return 2; }
+          return fast_fits(pool, e, st.req, rec.size) ? 1 : 0;
+        }, okb, miss, d0, d1);
+        accm |= okb;
+        todo = miss;
+        if (miss && create_entry(missv.bcast(ctz64(miss))) < 0) { bail_code = 20; return -1; }
+      }
+      W::each([&](int l) {
+        if (x0 + l < nc) {
+          const uint64_t w = cs_.acc((uint32_t)(x0 + l), row);
+          cs_.put_acc((uint32_t)(x0 + l), row, (w & ~bit) | (((accm >> l) & 1) ? bit : 0ull));
+        }
+      });
+    }
     W::sync();
     return slot | evicted;
   }
@@ -548,57 +648,27 @@ struct FastCold {
     order.n = (int)W::uniform((uint64_t)(uint32_t)n); order.defect = (int)W::uniform((uint64_t)(uint32_t)defect); order.defect_append = W::uniform((uint64_t)app) != 0;
     n = order.n;
     const o16 oo = order.ord; const o16 sn = snap;
-    if constexpr (FastMem<GS>::kOrderHbm) W::copy8(sn, oo, n); else W::for_n(n, [&](int i) { sn[i] = oo[i]; });
+    if constexpr (FastMem<GS, R>::kOrderHbm) W::copy8(sn, oo, n); else W::for_n(n, [&](int i) { sn[i] = oo[i]; });
     order.sort();
     lo_ = order.ff(0, n, [&](int i) { return sn[i] != oo[i]; });
     if (lo_ >= n) { lo_ = 0; hi_ = -1; return; }
     hi_ = order.fl(0, n, [&](int i) { return sn[i] != oo[i]; });
   }
   // The new claim (appended at n-1 with one pod) takes its place behind the last claim with at most one pod. Returns its
-  // position b >= 0 (Mp->acc = the class slots that accept it), -1 when pdqsort left the single-move path (lo_/hi_), -2: stop.
+  // position b >= 0 (Mp->acc = the class slots that accept it, from new_claim), -1 when pdqsort left the single-move path (lo_/hi_).
   KS_COLD int place_new_claim(int n) {
     n = (int)W::uniform((uint64_t)(uint32_t)n);
     const int a = n - 1;
-    const int moved = (int)order.ord[a];
     const bool exact = n <= 12 || (n >= 50 && !fast_sampled(n, a));
     if (!exact) { slow_sort(n, a, 1); return -1; }
     order.n = n; order.defect = a; order.defect_append = true;
     order.sort();
     const o16 kq = order.key;
-    const int b = W::find_first(0, n, [&](int i) { return kq[i] > 1u; }) - 1;   // the claims with one pod are the prefix it joined the end of
-    const int nac = n_active;
-    const FastClaim nst = cst.get((uint32_t)moved);
-    const int t = (int)(nst.vmask >> 56);
-    for (int j = 0; j < kFastRows; ++j) {
-      uint64_t accm = 0;
-      uint64_t todo = j * 64 < nac ? W::ballot([&](int l) { return j * 64 + l < nac; }) : 0ull;
-      while (todo) {
-        LaneVar<uint64_t> missv;
-        const uint64_t td = todo;
-        uint64_t okb = 0, miss = 0, d0, d1;
-        W::ballot4([&](int l) {
-          missv.at(l) = 0;
-          if (!((td >> l) & 1)) return 0;
-          const FastSlot s = lds_get(&aslot[j * 64 + l]);
-          if (!((s.tmplok >> t) & 1u)) return 0;
-          const uint64_t m = nst.vmask & s.cvmask;
-          if (!fast_fields_ok(m, s.dmask)) return 0;
-          FastEnt e;
-          if (fast_lookup(ent, m, e) < 0) { missv.at(l) = m; return 2; }
-          return fast_fits(pool, e, nst.req, s.size) ? 1 : 0;
-        }, okb, miss, d0, d1);
-        accm |= okb;
-        todo = miss;
-        if (miss && create_entry(missv.bcast(ctz64(miss))) < 0) { bail_code = 20; return -2; }
-      }
-      W::store(&Mp->acc[j], accm);
-    }
-    W::sync();
-    return b;
+    return W::find_first(0, n, [&](int i) { return kq[i] > 1u; }) - 1;   // the claims with one pod are the prefix it joined the end of
   }
 
   // addToNewNodeClaim (scheduler.go:695-790) for a pod no in-flight claim accepted: 1 = claim n created (appended to the
-  // order with one pod), 0 = the engine must stop (bail_code; -1 = capacity).
+  // order with one pod; its acceptance words computed), 0 = the engine must stop (bail_code; -1 = capacity).
   KS_COLD int new_claim(int slot, int bi, int n) {
     slot = (int)W::uniform((uint64_t)(uint32_t)slot); bi = (int)W::uniform((uint64_t)(uint32_t)bi); n = (int)W::uniform((uint64_t)(uint32_t)n);
     const ProblemView& P = *Pk; const Workspace& S = *Sk; const FastWork& F = *Fk;
@@ -642,13 +712,19 @@ struct FastCold {
       if (n_claims >= S.max_claims) { bail_code = -1; return 0; }   // capacity: reported as such
       if (n_claims >= cap) { bail_code = 26; return 0; }
       const int c = n_claims++;
+      FastClaim ns;
+      ns.vmask = m;
+      for (int q = 0; q < 4; ++q) ns.req[q] = cs.size[q];
       if (W::leader()) {
-        FastClaim ns;
-        ns.vmask = m;
-        for (int q = 0; q < 4; ++q) ns.req[q] = cs.size[q];
-        cst.put((uint32_t)c, ns);
+        cst.put_state((uint32_t)c, ns);
         F.c_hostseq[c] = host_seq;
         order.key[n] = 1; order.ord[n] = (uint16_t)c;   // order.append
+      }
+      W::sync();
+      for (int j = 0; j < R; ++j) {
+        const uint64_t aw = row_accepts(ns, j);
+        if (bail_code) return 0;
+        if (W::leader()) { cst.put_acc((uint32_t)c, j, aw); Mp->acc[j] = aw; }
       }
       W::sync();
       if (lm) {
@@ -681,20 +757,20 @@ struct FastCold {
       uint32_t* go = S.o_ord;
       const o16 oo = order.ord; const o16 ok_ = order.key;
       FastClaim* gs = F.c_state; uint32_t* gn = F.c_npods; uint16_t* ge = F.c_ent;
-      const typename FastMem<GS>::States ls = cst;
+      const typename FastMem<GS, R>::States ls = cst;
       const KS_LDS FastEnt* en = ent;
       W::for_n(n, [&](int i) { const uint32_t c = oo[i]; go[i] = c; gn[c] = ok_[i]; });
       W::for_n(n, [&](int c) {
-        const FastClaim st = ls.get((uint32_t)c);
+        const FastClaim st = ls.state((uint32_t)c);
         FastEnt e;
-        if constexpr (GS == 0) gs[c] = st;   // otherwise the state has lived in F.c_state all along
+        gs[c] = st;
         ge[c] = (uint16_t)fast_lookup(en, st.vmask, e);
       });
       W::store(S.n_claims_out, n_claims);
     }
     if (status) W::store(S.status_out, status);
     Counters c{};
-    c.bin_evaluations = n_tests; c.full_evaluations = n_steps; c.queue_pops = steps; c.sorts = steps; c.slow_sorts = order.slow_sorts;
+    c.bin_evaluations = n_tests + n_cold_tests; c.full_evaluations = n_steps; c.queue_pops = steps; c.sorts = steps; c.slow_sorts = order.slow_sorts;
     c.column_resets = (unsigned long long)n_evict; c.ref_bin_evaluations = n_ref + n_ref_extra;
     c.cycles[20] = (unsigned long long)(bail_code > 0 ? bail_code : 0);
     if (tc) for (int i = 0; i < 16; ++i) c.cycles[i] = tc[i];
@@ -703,80 +779,64 @@ struct FastCold {
   }
 };
 
-// The loop's state between two events (LDS): scalars, the cursors and the 64-entry queue block, one value per lane
-struct FastHot {
-  int base, bi, bn, n, np, max_steps, steps, status;
-  int pend_a, pend_x, pend_new, ev_arg;
-  uint32_t pend_mv, pad0;
-  uint64_t ev_vm;
-  unsigned long long n_steps, n_tests, n_ref, hot_cycles;
-  unsigned long long tsec[8];   // profiling builds: shader clock per path of the loop
-  const uint32_t* q_class; const volatile int* cancel; uint32_t* q_claim; uint32_t* q_cnt;
-  uint32_t cur[kFastRows][64];
-  uint32_t bcls[64], bslot[64], oclaim[64], ocnt[64], nxt_cls[64];
-};
-template <int GS>
+template <int GS, int R>
 struct FastHotCtx {   // LDS pointers of the loop, passed by value
-  typename FastMem<GS>::o16 okey, oord; typename FastMem<GS>::States cst; KS_LDS FastEnt* ent; KS_LDS int32_t* pool;
-  KS_LDS FastSlot* aslot; KS_LDS uint16_t* slot_of; KS_LDS FastHot* hs;
+  typename FastMem<GS, R>::o16 okey, oord; typename FastMem<GS, R>::States cst; KS_LDS FastEnt* ent; KS_LDS int32_t* pool;
+  KS_LDS FastSlot* aslot; KS_LDS FastHot* hs;
 };
-enum { FEV_DONE = 0, FEV_ENTRY = 1, FEV_SLOT = 2, FEV_SLOWSORT = 3, FEV_PLACE = 4, FEV_NEWCLAIM = 5, FEV_COUNT = 6 };
+enum { FEV_DONE = 0, FEV_REFRESH = 1, FEV_SLOT = 2, FEV_SLOWSORT = 3, FEV_PLACE = 4, FEV_NEWCLAIM = 5, FEV_COUNT = 6 };
 
 // The loop that places pods: a function of its own, WITHOUT calls — whatever happens rarely (a requirement set seen for the
-// first time, a new class slot, a new claim, pdqsort leaving its single-move path) ends the run with an event code; the
+// first time, a class without a slot, a new claim, pdqsort leaving its single-move path) ends the run with an event code; the
 // driver handles it through FastCold and runs the loop again. So the compiler allocates registers for this loop alone.
-template <class W, int GS>
-KS_COLD int fast_hot_run(FastHotCtx<GS> cx) {
-  typedef typename FastMem<GS>::o16 o16;
+//
+// One step of Solve() (scheduler.go:440-519) for the pod at the head of the queue, class k in slot s:
+//   select   addToInflightNode's "lowest index that accepts" (scheduler.go:667-686) is the first position at or after the
+//            class's cursor whose claim has bit s of its acceptance word set: 64 positions per step, one lane each, two
+//            dependent reads (order -> claim record), no test — the words are exact;
+//   commit   NodeClaim.Add (nodeclaim.go:247-263) on that claim, and the stable move that the sort.Slice of the next add
+//            (scheduler.go:598) makes of it, from the counts the select step already holds in registers;
+//   refresh  the claim's acceptance words from its new state: CanAdd for the classes of all slots at once, lane = slot, the
+//            classes' records in registers, one requirement-set cache read per lane.
+// Nothing is speculated, so nothing is validated: ~110 instructions per pod, three dependent LDS round trips.
+template <class W, int GS, int R>
+KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
+  typedef typename FastMem<GS, R>::o16 o16;
   const unsigned long long t_in = W::clock();
   const o16 okey = fast_uniform(cx.okey), oord = fast_uniform(cx.oord);
-  const typename FastMem<GS>::States cst = fast_uniform(cx.cst);
+  const typename FastMem<GS, R>::States cst = fast_uniform(cx.cst);
   KS_LDS FastEnt* const ent = fast_uniform(cx.ent);
   KS_LDS int32_t* const pool = fast_uniform(cx.pool);
   KS_LDS FastSlot* const aslot = fast_uniform(cx.aslot);
-  KS_LDS uint16_t* const slot_of = fast_uniform(cx.slot_of);
   KS_LDS FastHot* const hs = fast_uniform(cx.hs);
   // ---- state in ----
-  const int np = fast_uniform(hs->np), max_steps = fast_uniform(hs->max_steps);
+  const int np = fast_uniform(hs->np), max_steps_in = fast_uniform(hs->max_steps);
+  const int max_steps = max_steps_in < 0 ? 0x7FFFFFFF : max_steps_in;   // (no limit: one compare per pod)
   const KS_GLOBAL uint32_t* const gqcls = (const KS_GLOBAL uint32_t*)fast_uniform(hs->q_class);
   const volatile int* const cancel = fast_uniform(hs->cancel);
   KS_GLOBAL uint32_t* const gqclaim = (KS_GLOBAL uint32_t*)fast_uniform(hs->q_claim);
   KS_GLOBAL uint32_t* const gqcnt = (KS_GLOBAL uint32_t*)fast_uniform(hs->q_cnt);
   int base = fast_uniform(hs->base), bi = fast_uniform(hs->bi), bn = fast_uniform(hs->bn), n = fast_uniform(hs->n), steps = fast_uniform(hs->steps), status = fast_uniform(hs->status);
   int pend_a = fast_uniform(hs->pend_a), pend_x = fast_uniform(hs->pend_x); uint32_t pend_mv = (uint32_t)fast_uniform((int)hs->pend_mv); bool pend_new = fast_uniform(hs->pend_new) != 0;
-  unsigned long long n_steps = W::uniform(hs->n_steps), n_tests = W::uniform(hs->n_tests), n_ref = W::uniform(hs->n_ref);
-  LaneVar<uint32_t> cur[kFastRows], nxt_cls, bcls, bslot, oclaim, ocnt;
+  unsigned long long n_steps = W::uniform(hs->n_steps), n_ref = W::uniform(hs->n_ref);   // n_steps: select steps beyond a pod's first
+  LaneVar<uint32_t> cur[R], scls[R], tok[R], nxt_cls, bcls, oclaim, ocnt;
+  LaneVar<uint64_t> cvm[R], dm[R], gd[R];                  // the class of lane's slot: values it admits, fields it selects on, their guard bits
+  LaneVar<int32_t> z0[R], z1[R], z2[R], z3[R];             // its requests
   W::each([&](int l) {
 #pragma unroll
-    for (int j = 0; j < kFastRows; ++j) cur[j].at(l) = hs->cur[j][l];
-    nxt_cls.at(l) = hs->nxt_cls[l]; bcls.at(l) = hs->bcls[l];
-    bslot.at(l) = hs->bslot[l]; oclaim.at(l) = hs->oclaim[l]; ocnt.at(l) = hs->ocnt[l];
+    for (int j = 0; j < R; ++j) {
+      cur[j].at(l) = hs->cur[j][l]; scls[j].at(l) = hs->scls[j][l];
+      const FastSlot s = lds_get(&aslot[j * 64 + l]);
+      cvm[j].at(l) = s.cvmask; dm[j].at(l) = s.dmask; gd[j].at(l) = (s.dmask << 1) & ~s.dmask;
+      z0[j].at(l) = s.size[0]; z1[j].at(l) = s.size[1]; z2[j].at(l) = s.size[2]; z3[j].at(l) = s.size[3];
+      tok[j].at(l) = scls[j].at(l) == kFastFree ? 0u : s.tmplok;   // a free slot accepts nothing
+    }
+    nxt_cls.at(l) = hs->nxt_cls[l]; bcls.at(l) = hs->bcls[l]; oclaim.at(l) = hs->oclaim[l]; ocnt.at(l) = hs->ocnt[l];
   });
-  int ev = FEV_DONE, ev_arg = 0; uint64_t ev_vm = 0;
-  // ---- group speculation ----
-  // One CanAdd test serves up to eight queue entries: lane 8j+q tests queue entry bi+j (its class) against the claim at
-  // position cursor(class)+q — the same three dependent LDS reads as a window test of one pod. The verdicts are taken
-  // against the state at that moment; they are used for the entries one after the other, in queue order:
-  //   * a rejection is final (fact 3 above), whatever happened to the claim since;
-  //   * an acceptance holds while the claim has not gained a pod since the test (g_touched: lanes whose claim has);
-  //   * claims only move right, past claims with fewer pods, so between an entry's cursor and its first accepting lane
-  //     there are only claims that rejected it (those of its window, those that came from the left of its cursor); a
-  //     claim from the right never gets in front of it. So entry bi+j goes to the claim of its first accepting lane iff
-  //     that claim is untouched — addToInflightNode's "lowest index that accepts" (scheduler.go:667-686) without a new
-  //     test. gp follows every lane's claim through the moves (the same update as the cursors).
-  // Every other entry (first acceptor touched, an unresolved lane before it, nothing in eight positions) takes the window
-  // test below; the rest of the group stays valid behind it. A move that is not one short shift (the pending path,
-  // pdqsort's other paths, a new claim) drops the group.
-  LaneVar<uint32_t> gx, gk, gp, gB, gq0, gq1, gq2, gq3;   // gB: a lower bound of the position of the first claim behind the entry's eight
-  LaneVar<uint64_t> gm;
-  uint64_t g_acc = 0, g_odd = 0, g_touched = 0, g_jumped = 0;   // g_jumped: lanes whose claim a commit moved past another claim
-  int gj = 0, gn = 0;   // entries gj .. gn-1 of the group are still to be placed; entry gj is queue entry bi
-  // choosePivot's sampled positions (fast_sampled) as three starts; n is fixed inside one run of this function. With
-  // 12 < n < 50 every re-sort that has something to move is pdqsort's other path (mid_n). A commit that leaves the order
-  // sorted as it stands — the next claim has at least the new count — needs no sort at all, whatever n and the position:
-  // pdqsort finds no descent and does nothing.
-  const bool use_groups = max_steps < 0;
-  const bool mid_n = n > 12 && n < 50;
+  int ev = FEV_DONE, ev_arg = 0;
+  // choosePivot's sampled positions (fast_sampled) as three starts; n is fixed inside one run of this function. With n <= 12 every
+  // re-sort is the stable insertion sort; with 12 < n < 50 every re-sort that has something to move is pdqsort's other path.
+  const bool always_exact = n <= 12, never_exact = n > 12 && n < 50;
   const uint32_t e1 = n >= 50 ? (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u, e2 = n >= 50 ? 2u * (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u, e3 = n >= 50 ? 3u * (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u;
 #ifdef KSOLVE_PHASE_TIMERS
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0, ts7 = 0, tlast = W::clock();
@@ -794,9 +854,9 @@ KS_COLD int fast_hot_run(FastHotCtx<GS> cx) {
       }
       if (base >= np || status) { bn = 0; bi = 0; break; }
       bn = np - base < 64 ? np - base : 64;
-      bi = 0; gj = 0; gn = 0;
-      const int bnn = bn, nb = base + 64;
-      W::each([&](int l) { bcls.at(l) = nxt_cls.at(l); bslot.at(l) = l < bnn ? (uint32_t)slot_of[nxt_cls.at(l)] : 0xFFFFu; });
+      bi = 0;
+      const int nb = base + 64;
+      W::each([&](int l) { bcls.at(l) = nxt_cls.at(l); });
       W::each([&](int l) { if (nb + l < np) nxt_cls.at(l) = gqcls[nb + l]; });
       if ((base & 1023) == 0 && cancel) {
         // > 0: ksolve_cancel / the deadline. < 0 (tests only, KSOLVE_TEST_CANCEL_AT): as if the cancel landed once -flag pods were placed
@@ -804,11 +864,10 @@ KS_COLD int fast_hot_run(FastHotCtx<GS> cx) {
         if (cv > 0 || (cv < 0 && base >= -cv)) { status = 2; bn = 0; break; }
       }
     }
-    if (KS_UNLIKELY(max_steps >= 0 && steps >= max_steps)) { status = 2; break; }
+    if (KS_UNLIKELY(steps >= max_steps)) { status = 2; break; }
     // ---- sort.Slice (scheduler.go:598) for a move the last commit left behind ----
-    if (KS_UNLIKELY(pend_a >= 0 || pend_new)) {
+    if (KS_UNLIKELY(pend_a >= 0)) {
       if (pend_new) { ev = FEV_PLACE; break; }
-      gj = 0; gn = 0;
       const int a = pend_a;
       if (!(a + 1 >= n || (uint32_t)okey[a + 1 < n ? a + 1 : a] >= pend_mv) &&   // something to move ...
           !(n <= 12 || (n >= 50 && !fast_sampled(n, a)))) { ev = FEV_SLOWSORT; ev_arg = a; break; }   // ... and not by the single stable move
@@ -837,306 +896,193 @@ KS_COLD int fast_hot_run(FastHotCtx<GS> cx) {
         const int b = from;   // positions (a, b] moved left by one
         W::each([&](int l) {
 #pragma unroll
-          for (int j = 0; j < kFastRows; ++j) { const uint32_t r = cur[j].at(l); cur[j].at(l) = r - (uint32_t)(((uint32_t)a < r && r <= (uint32_t)b) ? 1 : 0); }
+          for (int j = 0; j < R; ++j) { const uint32_t r = cur[j].at(l); cur[j].at(l) = r - (uint32_t)(((uint32_t)a < r && r <= (uint32_t)b) ? 1 : 0); }
         });
       }
     }
     KS_SEC(ts0)   // block fetch, pending move
-    // ---- the pod's class slot ----
-    const int slot = (int)bslot.bcast(bi);
-    if (KS_UNLIKELY(slot == 0xFFFF)) { ev = FEV_SLOT; ev_arg = (int)bcls.bcast(bi); break; }
-    // The queue's last entry is not placed from a group: no add follows it, its move stays undone (as in the reference). The
-    // same holds for the last entry before a block boundary at which the cancel flag is polled: a cancelled Solve() ends there,
-    // and the claim order it reports is the one of the last sort the reference would have run (scheduler.go:598 sorts at the
-    // start of an add, never after the last one).
-    const int lastq = (base + bn >= np || (cancel && ((base + 64) & 1023) == 0)) ? 1 : 0;
-    if (use_groups && gj >= gn && bi + lastq < bn) {
-      // ---- a new group: the next entries of the block that have a class slot, eight at most ----
-      const int g0 = bn - bi - lastq < 8 ? bn - bi - lastq : 8, bi0 = bi, nn = n;
-      LaneVar<uint32_t> gs, gr;
-      W::each([&](int l) { const int j = l >> 3; gs.at(l) = bslot.shuffle(l, (bi0 + (j < g0 ? j : 0)) & 63); });
-      W::each([&](int l) {
-        const uint32_t sv = gs.at(l);
-        const int sl = (int)(sv & 63u);
-        const uint32_t a0 = cur[0].shuffle(l, sl), a1 = cur[1].shuffle(l, sl), a2 = cur[2].shuffle(l, sl), a3 = cur[3].shuffle(l, sl);
-        const uint32_t row = (sv >> 6) & 3u;
-        gr.at(l) = row == 0 ? a0 : row == 1 ? a1 : row == 2 ? a2 : a3;
-      });
-      const uint64_t nos = W::ballot([&](int l) { return (l >> 3) >= g0 || gs.at(l) == 0xFFFFu; });
-      gn = nos ? ctz64(nos) >> 3 : 8;   // >= 1: this entry has its slot
-      gj = 0; g_touched = 0; g_jumped = 0;
-      const int gnn = gn;
-      W::ballot2([&](int l) {
-        const int j = l >> 3, q = l & 7;
-        const int p = (int)gr.at(l) + q;
-        gx.at(l) = 0xFFFFFFFFu; gk.at(l) = 0; gp.at(l) = 0xFFFFFFFFu; gm.at(l) = 0; gq0.at(l) = 0; gq1.at(l) = 0; gq2.at(l) = 0; gq3.at(l) = 0;
-        gB.at(l) = gr.at(l) + 8u;
-        if (j >= gnn || p >= nn) return 0;
-        const uint32_t x = oord[p];
-        const FastClaim st = cst.get(x);
-        const FastSlot s = lds_get(&aslot[gs.at(l)]);
-        const uint64_t m = st.vmask & s.cvmask;
-        FastEnt e = lds_get(&ent[fast_hash(m)]);
-        gx.at(l) = x; gk.at(l) = okey[p]; gp.at(l) = (uint32_t)p; gm.at(l) = m;
-        gq0.at(l) = st.req[0] + s.size[0]; gq1.at(l) = st.req[1] + s.size[1]; gq2.at(l) = st.req[2] + s.size[2]; gq3.at(l) = st.req[3] + s.size[3];
-        const int base_ok = (int)((s.tmplok >> (st.vmask >> 56)) & 1u) & (int)fast_fields_ok(m, s.dmask);
-        int simple = (int)(e.info & 1u) & (int)(e.vmask == m);
-        if (base_ok & (simple ^ 1) & (int)(e.info & 1u)) simple = (int)(fast_lookup(ent, m, e) >= 0);   // not the cache's first probe: the probe sequence
-        int fit = (int)fast_fits_first(e, st.req, s.size);
-        if (base_ok & simple & (fit ^ 1) & (int)(((e.info >> 8) & 0xFFu) != 0)) fit = (int)fast_fits(pool, e, st.req, s.size);   // the other Pareto vectors
-        // bit 0: accepted; bit 1: the requirement set is not cached yet (the window test raises the event)
-        return (base_ok & simple & fit) | ((base_ok & (simple ^ 1)) << 1);
-      }, g_acc, g_odd);
-      n_tests += (unsigned long long)(8 * gnn);
-      n_steps++;
-      KS_SEC(ts1)   // group test
-#ifdef KSOLVE_PHASE_TIMERS
-      ts5++;
-#endif
+    // ---- the pod's class and its slot ----
+    const uint32_t clsw = bcls.bcast(bi), kcls = clsw & ~kFastLastBit;
+    int row = -1, sl = 0;
+    if constexpr (R == 1) {
+      const uint64_t m0 = W::ballot([&](int l) { return scls[0].at(l) == kcls; });
+      if (KS_LIKELY(m0 != 0)) { row = 0; sl = ctz64(m0); }
+    } else {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const uint64_t mj = W::ballot([&](int l) { return scls[j].at(l) == kcls; });
+        if (mj != 0 && row < 0) { row = j; sl = ctz64(mj); }
+      }
     }
-    // ---- entries of the group that take no window test ----
-    bool placed_any = false;
-    while (gj < gn) {
-      const int j = gj;
-      const uint32_t gb = (uint32_t)(g_acc >> (8 * j)) & 0xFFu, ob = (uint32_t)(g_odd >> (8 * j)) & 0xFFu;
-      const int qf = __builtin_ctz(gb | 0x100u);
-      if (qf == 8 || (ob & ((1u << qf) - 1u))) break;   // nothing in eight positions, or an unresolved lane first: the window test
-      int L = 8 * j + qf;
-      if (KS_UNLIKELY(((g_touched & g_jumped) >> L) & 1)) {
-        // The first accepting lane's claim moved past other claims since the test: the entry's first candidate is now the
-        // accepting lane whose claim stands leftmost. It may be used when everything between the class's cursor and it is
-        // known to reject the entry: no unresolved lane before it, and it has not passed the first claim behind the eight.
-        const uint64_t accj = g_acc & (0xFFull << (8 * j)), oddj = g_odd & (0xFFull << (8 * j));
-        int c = -1;
-        const uint32_t pmin = W::argmin_u32([&](int l) { return ((accj >> l) & 1) ? gp.at(l) : 0xFFFFFFFFu; }, &c);
-        const uint64_t blockers = W::ballot([&](int l) { return ((oddj >> l) & 1) != 0 && gp.at(l) < pmin; });
-        if (blockers != 0 || pmin >= gB.bcast(8 * j) || c < 0) break;
-        L = fast_uniform(c);
-      }
-      const uint32_t x = gx.bcast(L);
-      const int a = (int)gp.bcast(L);
-      const int sj = (int)bslot.bcast(bi);
-      if ((g_touched >> L) & 1) {
-        // The claim gained pods since the group's test; it is still this entry's first candidate (its place among the others
-        // is what it was, or it was chosen by position above): test this one claim again.
-        const FastSlot cs = lds_get(&aslot[sj]);
-        const FastClaim st = cst.get(x);
-        const uint32_t know = okey[a];
-        const uint64_t m = st.vmask & cs.cvmask;
-        FastEnt e = lds_get(&ent[fast_hash(m)]);
-        const int base_ok = (int)((cs.tmplok >> (st.vmask >> 56)) & 1u) & (int)fast_fields_ok(m, cs.dmask);
-        int simple = (int)(e.info & 1u) & (int)(e.vmask == m);
-        if (base_ok & (simple ^ 1) & (int)(e.info & 1u)) simple = (int)(fast_lookup(ent, m, e) >= 0);   // not the cache's first probe: the probe sequence
-        int fit = (int)fast_fits_first(e, st.req, cs.size);
-        if (base_ok & simple & (fit ^ 1) & (int)(((e.info >> 8) & 0xFFu) != 0)) fit = (int)fast_fits(pool, e, st.req, cs.size);
-        n_tests++;
-        if (base_ok & (simple ^ 1)) break;   // the requirement set is not cached yet: the window test raises the event
-        if (!(base_ok & simple & fit)) { g_acc &= ~(1ull << L); continue; }   // rejected for good: the entry's next accepting lane
-        W::each([&](int l) {
-          if (l == L) {
-            gk.at(l) = know; gm.at(l) = m;
-            gq0.at(l) = (uint32_t)(st.req[0] + cs.size[0]); gq1.at(l) = (uint32_t)(st.req[1] + cs.size[1]);
-            gq2.at(l) = (uint32_t)(st.req[2] + cs.size[2]); gq3.at(l) = (uint32_t)(st.req[3] + cs.size[3]);
-          }
-        });
-        g_touched &= ~(1ull << L);
-      }
-      const uint32_t cnt = gk.bcast(L);
-      if (KS_UNLIKELY(cnt >= 65534u)) break;   // the window test raises the event
-      const uint32_t mvn = cnt + 1, ua = (uint32_t)a;
-      // the claims behind it, for the move of the next add's sort.Slice (scheduler.go:598)
-      LaneVar<uint32_t> kv2, ov2;
-      const int nm1 = n - 1;
-      const uint64_t lessm = W::ballot([&](int l) {
-        const int i0 = a + 1 + l, i = i0 < nm1 ? i0 : nm1;   // clamped: no lane is switched off for the two reads
-        const uint32_t k = okey[i];
-        kv2.at(l) = k; ov2.at(l) = oord[i];
-        return (int)(i0 <= nm1) & (int)(k < mvn);
+    if (KS_UNLIKELY(row < 0)) { ev = FEV_SLOT; ev_arg = (int)kcls; break; }
+    if constexpr (R == 1) row = 0;
+    const int slot = row * 64 + sl;
+    const FastSlot cs = lds_get(&aslot[slot]);
+    uint32_t rc0 = cur[0].bcast(sl);
+#pragma unroll
+    for (int j = 1; j < R; ++j) { const uint32_t cj = cur[j].bcast(sl); rc0 = row == j ? cj : rc0; }
+    // ---- select: addToInflightNode (scheduler.go:658-692), positions r .. r+63, one lane each: the order's entry, then the
+    // claim's whole record (state and acceptance word in one round trip: the commit needs the state of the claim it finds) ----
+    LaneVar<uint64_t> mvv;
+    LaneVar<uint32_t> xv, kv;
+    LaneVar<int32_t> q0, q1, q2, q3;
+    uint32_t r = rc0, r0 = rc0;
+    uint64_t okm = 0;
+    const int nm1 = n - 1;
+    const uint64_t slbit = 1ull << sl;
+    auto scan = [&](uint32_t rr0) {
+      return W::ballot([&](int l) {
+        const int p = (int)rr0 + l;
+        const int pc = p < nm1 ? p : nm1;                 // clamped: no lane is switched off for the reads
+        const uint64_t want = p < n ? slbit : 0ull;       // (ready before the reads come back: the ballot is one AND and one compare behind them)
+        const uint32_t x = oord[pc], k = okey[pc];
+        const FastClaim st = cst.state(x);
+        const uint64_t aw = cst.acc(x, row);
+        xv.at(l) = x; kv.at(l) = p < n ? k : 0xFFFFFFFFu;
+        q0.at(l) = st.req[0]; q1.at(l) = st.req[1]; q2.at(l) = st.req[2]; q3.at(l) = st.req[3];
+        mvv.at(l) = st.vmask;
+        return (aw & want) != 0;
       });
-      const int s_ = lessm == ~0ull ? 64 : ctz64(~lessm);   // sorted beyond a: the smaller counts are a prefix
-      if (KS_UNLIKELY(s_ >= 64)) break;                      // a long run: the pending path
-      // only the move that is one short shift, or none (otherwise: pdqsort's other paths, behind the window test)
-      if (KS_UNLIKELY(s_ != 0 && ((int)mid_n | (int)((uint32_t)a - e1 <= 2u) | (int)((uint32_t)a - e2 <= 2u) | (int)((uint32_t)a - e3 <= 2u)))) break;
-      // ---- NodeClaim.Add (nodeclaim.go:247-263) on the claim of lane L; the claim lands behind the s_ claims it passes ----
-      W::each([&](int l) {
-        if (l == L) {
-          FastClaim ns;
-          ns.vmask = gm.at(l); ns.req[0] = (int32_t)gq0.at(l); ns.req[1] = (int32_t)gq1.at(l); ns.req[2] = (int32_t)gq2.at(l); ns.req[3] = (int32_t)gq3.at(l);
-          cst.put(gx.at(l), ns);
+    };
+    if (KS_LIKELY((int)r < n)) {
+      okm = scan(r0);
+      if (KS_UNLIKELY(okm == 0)) {
+        // not among the 64 claims at the cursor: the rest of the order, 64 positions per step
+        r = (uint32_t)((int)r0 + 64 < n ? (int)r0 + 64 : n);
+        while ((int)r < n) {
+          r0 = r;
+          okm = scan(r0);
+          n_steps++;
+          if (okm != 0) break;
+          r = (uint32_t)((int)r0 + 64 < n ? (int)r0 + 64 : n);
         }
-        if (l <= s_) { okey[a + l] = (uint16_t)(l == s_ ? mvn : kv2.at(l)); oord[a + l] = (uint16_t)(l == s_ ? x : ov2.at(l)); }
-        const bool me = l == bi;
-        oclaim.at(l) = me ? x : oclaim.at(l); ocnt.at(l) = me ? cnt : ocnt.at(l);
+      }
+    }
+    KS_SEC(ts1)   // select
+    if (KS_UNLIKELY(okm == 0)) {
+      // no in-flight claim accepts the pod: addToNewNodeClaim; the driver moves on to the next pod
+      W::each([&](int l) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const bool me = j * 64 + l == slot;
+          cur[j].at(l) = me ? r : cur[j].at(l);
+          if (clsw & kFastLastBit) { scls[j].at(l) = me ? kFastFree : scls[j].at(l); tok[j].at(l) = me ? 0u : tok[j].at(l); }
+        }
       });
-      n_ref += (unsigned long long)a + 1;
-      const uint64_t same = W::ballot([&](int l) { return gx.at(l) == x; });
-      g_touched |= same;
-      {
-        // cursors and the group's positions in (a, a+s_] step left; the class's own cursor comes to a (the claims between it
-        // and this one rejected the class for good). Plain arithmetic: (r - a - 1) < s_ as unsigned is a < r <= a + s_.
-        const uint32_t ua1 = ua + 1u, su = (uint32_t)s_, usj = (uint32_t)sj;
+      steps++;
+      ev = FEV_NEWCLAIM; ev_arg = slot;
+      break;
+    }
+    // ---- commit: NodeClaim.Add (nodeclaim.go:247-263) ----
+    const int first_ok = ctz64(okm);
+    const int a = (int)r0 + first_ok;
+    const int x = (int)xv.bcast(first_ok);
+    const uint32_t cnt = kv.bcast(first_ok);
+    if (KS_UNLIKELY(cnt >= 65534u)) { ev = FEV_COUNT; break; }
+    FastClaim ns;
+    ns.vmask = mvv.bcast(first_ok) & cs.cvmask;
+    ns.req[0] = q0.bcast(first_ok) + cs.size[0]; ns.req[1] = q1.bcast(first_ok) + cs.size[1];
+    ns.req[2] = q2.bcast(first_ok) + cs.size[2]; ns.req[3] = q3.bcast(first_ok) + cs.size[3];
+    n_ref += (unsigned long long)a + 1;
+    // The sort.Slice of the NEXT add (scheduler.go:598) repairs this claim's position: one stable move past the claims
+    // with a smaller count. When the next add follows inside this block and those claims are all among the positions
+    // just read, their counts and ids are in registers already: move now, without reading the order again.
+    const uint32_t mvn = cnt + 1;
+    int s_ = -1;   // claims the move passes; -1: not decided here (the pending path of the next add)
+    if (KS_LIKELY(bi + 1 < bn && steps + 1 < max_steps)) {
+      const uint64_t lessm = W::ballot([&](int l) { return kv.at(l) < mvn; });   // lanes past n hold 0xFFFFFFFF; the lanes up to first_ok are shifted out
+      const uint64_t t = first_ok == 63 ? 0ull : (lessm >> (first_ok + 1));
+      const int sm = t == ~0ull ? 64 : ctz64(~t);
+      const bool in_window = first_ok + 1 + sm < 64 || (int)r0 + 64 >= n;
+      if (KS_LIKELY(sm == 0)) {
+        // no move at all (the next claim has at least the new count: sorted as it stands, pdqsort finds no descent)
+        if (KS_LIKELY(in_window)) s_ = 0;
+      } else if (in_window && (always_exact || (!never_exact && !(((uint32_t)a - e1 <= 2u) | ((uint32_t)a - e2 <= 2u) | ((uint32_t)a - e3 <= 2u))))) {
+        // the single stable move: lanes first_ok+1 .. first_ok+sm step one position to the left, the claim lands behind them
+        s_ = sm;
+        const int rb = (int)r0;
+        W::each([&](int l) { if (l > first_ok && l <= first_ok + sm) { okey[rb + l - 1] = (uint16_t)kv.at(l); oord[rb + l - 1] = (uint16_t)xv.at(l); } });
+        const uint32_t ua1 = (uint32_t)a + 1u, su = (uint32_t)sm;
         W::each([&](int l) {
 #pragma unroll
-          for (int jj = 0; jj < kFastRows; ++jj) {
-            const uint32_t rr = cur[jj].at(l);
-            const uint32_t sh = rr - (uint32_t)((rr - ua1) < su);
-            cur[jj].at(l) = (uint32_t)(jj * 64 + l) == usj ? ua : sh;
-          }
+          for (int j = 0; j < R; ++j) { const uint32_t rr = cur[j].at(l); cur[j].at(l) = rr - (uint32_t)((rr - ua1) < su); }   // a < rr <= a + sm
         });
-        if (s_) {
-          g_jumped |= same;
-          const uint32_t b = ua + su;
-          W::each([&](int l) {
-            const uint32_t pp = gp.at(l), bb = gB.at(l);
-            gp.at(l) = ((same >> l) & 1) ? b : pp - (uint32_t)((pp - ua1) < su);
-            gB.at(l) = bb - (uint32_t)((bb - ua1) < su);
-          });
-        }
       }
-      W::sync();
-      gj++; bi++; steps++;
-      placed_any = true;
     }
-    KS_SEC(ts2)   // entries placed from the group
-    if (gn > 0) {
-      if (gj >= gn) { gj = 0; gn = 0; continue; }   // the group is used up (its last entry was placed above)
-      gj++;                                           // the window test places this entry; the rest of the group stays valid behind it
-    }
-    const int slot_w = placed_any ? (int)bslot.bcast(bi) : slot;
-    const FastSlot cs = lds_get(&aslot[slot_w]);
-    uint32_t rc0 = 0;
+    if (KS_UNLIKELY(s_ < 0)) { pend_a = a; pend_x = x; pend_mv = mvn; }
+    // the pod's result; the class's cursor comes to a (the claims between its old place and this one rejected the class for
+    // good); its slot is free after the class's last entry (branch-free: kFastFree is all ones)
     {
-      const uint32_t c0 = cur[0].bcast(slot_w & 63), c1 = cur[1].bcast(slot_w & 63), c2 = cur[2].bcast(slot_w & 63), c3 = cur[3].bcast(slot_w & 63);
-      const int row = slot_w >> 6;
-      rc0 = row == 0 ? c0 : row == 1 ? c1 : row == 2 ? c2 : c3;
+      const uint32_t lastm = (clsw & kFastLastBit) ? 0xFFFFFFFFu : 0u;
+      const int bb = bi;
+      W::each([&](int l) {
+        const bool mine = l == bb;
+        oclaim.at(l) = mine ? (uint32_t)x : oclaim.at(l); ocnt.at(l) = mine ? cnt : ocnt.at(l);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const bool me = j * 64 + l == slot;
+          const uint32_t fm = me ? lastm : 0u;
+          cur[j].at(l) = me ? (uint32_t)a : cur[j].at(l);
+          scls[j].at(l) |= fm; tok[j].at(l) &= ~fm;
+        }
+      });
     }
-    static_assert(kFastRows == 4, "cursor rows are spelled out above");
-    uint32_t r = rc0;
-    int outcome = 0;   // 1 placed, 2 no acceptor, 3 event
-    while ((int)r < n) {
-      // ---- addToInflightNode (scheduler.go:658-692): positions r .. r+63, one lane each; straight-line: three
-      // dependent LDS reads (order -> claim state -> requirement-set cache), everything else in registers ----
-      LaneVar<uint64_t> mv;
-      LaneVar<uint32_t> xv, kv;
-      LaneVar<int32_t> q0, q1, q2, q3;
-      const uint32_t r0 = r;
-      uint64_t okm = 0, oddm = 0;
-      W::ballot2([&](int l) {
-        const int p = (int)r0 + l;
-        const bool valid = p < n;
-        const int pc = valid ? p : n - 1;
-        const uint32_t x = oord[pc];
-        xv.at(l) = x; kv.at(l) = valid ? (uint32_t)okey[pc] : 0xFFFFFFFFu;
-        const FastClaim st = cst.get(x);
-        q0.at(l) = st.req[0]; q1.at(l) = st.req[1]; q2.at(l) = st.req[2]; q3.at(l) = st.req[3];
-        const uint64_t m = st.vmask & cs.cvmask;
-        mv.at(l) = m;
+    KS_SEC(ts2)   // commit
+    // ---- refresh: CanAdd (nodeclaim.go:124-242) of the claim as it stands now, for the classes of all slots (lane = slot) ----
+    const uint32_t tbit = 1u << (uint32_t)(ns.vmask >> 56);
+    bool cold_refresh = false;
+    uint64_t accw[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      LaneVar<uint64_t> mlv, evm;
+      LaneVar<int32_t> c0, c1, c2, c3;
+      LaneVar<uint32_t> einfo;
+      W::each([&](int l) {
+        const uint64_t m = ns.vmask & cvm[j].at(l);
         const FastEnt e = lds_get(&ent[fast_hash(m)]);
-        // predicates as 0/1 integers combined with & and |: straight-line code, no short-circuit branches
-        const int base_ok = (int)valid & (int)((cs.tmplok >> (st.vmask >> 56)) & 1u) & (int)fast_fields_ok(m, cs.dmask);
-        const int simple = (int)(e.info & 1u) & (int)(e.vmask == m);   // the cache's first probe is this requirement set
-        const int fit = (int)fast_fits_first(e, st.req, cs.size);
-        // bit 0: accepted; bit 1: needs the long way (requirement set not cached, a hash collision, or further Pareto vectors)
-        return (base_ok & simple & fit) | ((base_ok & ((simple ^ 1) | ((fit ^ 1) & (int)(((e.info >> 8) & 0xFFu) != 0)))) << 1);
-      }, okm, oddm);
-      uint64_t missm = 0;
-      oddm &= okm ? (okm & (0ull - okm)) - 1ull : ~0ull;   // only the lanes before the first plain acceptor can change the answer
+        mlv.at(l) = m; evm.at(l) = e.vmask; einfo.at(l) = e.info;
+        c0.at(l) = e.cap[0]; c1.at(l) = e.cap[1]; c2.at(l) = e.cap[2]; c3.at(l) = e.cap[3];
+      });
+      // every predicate is one compare whose result is the 64-lane mask; the masks are combined in scalar registers
+      const uint64_t tokm = W::ballot([&](int l) { return (tok[j].at(l) & tbit) != 0; });                       // taints, custom keys (nodeclaim.go:126; requirements.go:185-193)
+      const uint64_t fldm = W::ballot([&](int l) { return (((mlv.at(l) & dm[j].at(l)) + dm[j].at(l)) & gd[j].at(l)) == gd[j].at(l); });   // Compatible on the keys the class selects on
+      const uint64_t simm = W::ballot([&](int l) { return evm.at(l) == mlv.at(l); });                          // the cache's first probe is this requirement set
+      const uint64_t f0 = W::ballot([&](int l) { return z0[j].at(l) <= c0.at(l) - ns.req[0]; });
+      const uint64_t f1 = W::ballot([&](int l) { return z1[j].at(l) <= c1.at(l) - ns.req[1]; });
+      const uint64_t f2 = W::ballot([&](int l) { return z2[j].at(l) <= c2.at(l) - ns.req[2]; });
+      const uint64_t f3 = W::ballot([&](int l) { return z3[j].at(l) <= c3.at(l) - ns.req[3]; });
+      const uint64_t extm = W::ballot([&](int l) { return (einfo.at(l) & 0xFF00u) != 0; });                   // further Pareto vectors
+      const uint64_t basem = tokm & fldm, fitm = f0 & f1 & f2 & f3;
+      uint64_t accm = basem & simm & fitm;
+      const uint64_t oddm = basem & (~simm | (~fitm & extm));   // needs the long way: set not cached / a hash collision / further Pareto vectors
       if (KS_UNLIKELY(oddm != 0)) {
-        // rare: resolve those lanes with the full probe sequence / all Pareto vectors
+        // resolve those lanes with the full probe sequence / all Pareto vectors; a set that is not cached: the driver
         const uint64_t mm = oddm;
-        uint64_t ok2 = 0;
+        uint64_t ok2 = 0, missm = 0;
         W::ballot2([&](int l) {
           if (!((mm >> l) & 1)) return 0;
           FastEnt e;
-          if (fast_lookup(ent, mv.at(l), e) < 0) return 2;
-          const int32_t rq[4] = {q0.at(l), q1.at(l), q2.at(l), q3.at(l)};
-          return fast_fits(pool, e, rq, cs.size) ? 1 : 0;
+          if (fast_lookup(ent, mlv.at(l), e) < 0) return 2;
+          const int32_t sz[4] = {z0[j].at(l), z1[j].at(l), z2[j].at(l), z3[j].at(l)};
+          return fast_fits(pool, e, ns.req, sz) ? 1 : 0;
         }, ok2, missm);
-        okm |= ok2;
+        accm |= ok2;
+        if (missm) cold_refresh = true;
       }
-      n_tests += (unsigned long long)(n - (int)r0 < 64 ? n - (int)r0 : 64);
-      n_steps++;
-      const int first_ok = okm ? ctz64(okm) : 64;
-      if (KS_UNLIKELY(missm != 0 && ctz64(missm) < first_ok)) {
-        // a requirement set that is not cached yet sits before the first acceptor: cache it, test these positions again
-        ev = FEV_ENTRY; ev_vm = mv.bcast(ctz64(missm)); outcome = 3;
-        break;
-      }
-      if (!okm) { r = (uint32_t)((int)r0 + 64 < n ? (int)r0 + 64 : n); continue; }
-      // ---- commit: NodeClaim.Add (nodeclaim.go:247-263) ----
-      const int a = (int)r0 + first_ok;
-      const int x = (int)xv.bcast(first_ok);
-      const uint32_t cnt = kv.bcast(first_ok);
-      if (KS_UNLIKELY(cnt >= 65534u)) { ev = FEV_COUNT; outcome = 3; break; }
-      FastClaim ns;
-      ns.vmask = mv.bcast(first_ok);
-      ns.req[0] = q0.bcast(first_ok) + cs.size[0]; ns.req[1] = q1.bcast(first_ok) + cs.size[1];
-      ns.req[2] = q2.bcast(first_ok) + cs.size[2]; ns.req[3] = q3.bcast(first_ok) + cs.size[3];
-      if (W::leader()) cst.put(x, ns);
-      oclaim.set(bi, (uint32_t)x); ocnt.set(bi, cnt);
-      n_ref += (unsigned long long)a + 1;
-      r = (uint32_t)a;
-      outcome = 1;
-      // The sort.Slice of the NEXT add (scheduler.go:598) repairs this claim's position: one stable move past the claims
-      // with a smaller count. When the next add follows inside this block and those claims are all among the positions
-      // just tested, their counts and ids are in registers already: move now, without reading the order again.
-      const uint32_t mvn = cnt + 1;
-      bool moved = false;
-      if (KS_LIKELY(bi + 1 < bn && !(max_steps >= 0 && steps + 1 >= max_steps))) {
-        const uint64_t lessm = W::ballot([&](int l) { return l > first_ok && kv.at(l) < mvn; });   // lanes past n hold 0xFFFFFFFF
-        const uint64_t t = first_ok == 63 ? 0ull : (lessm >> (first_ok + 1));
-        const int s_ = t == ~0ull ? 64 : ctz64(~t);
-        // the single stable move — or no move at all (the next claim has at least the new count: sorted as it stands)
-        if (KS_LIKELY((first_ok + 1 + s_ < 64 || (int)r0 + 64 >= n) && (s_ == 0 || n <= 12 || (n >= 50 && !fast_sampled(n, a))))) {
-          // lanes first_ok+1 .. first_ok+s_ step one position to the left, the claim lands behind them
-          W::each([&](int l) { if (l > first_ok && l <= first_ok + s_) { okey[(int)r0 + l - 1] = (uint16_t)kv.at(l); oord[(int)r0 + l - 1] = (uint16_t)xv.at(l); } });
-          if (W::leader()) { okey[a + s_] = (uint16_t)mvn; oord[a + s_] = (uint16_t)x; }
-          const int b = a + s_;
-          W::each([&](int l) {
-#pragma unroll
-            for (int j = 0; j < kFastRows; ++j) { const uint32_t rr = cur[j].at(l); cur[j].at(l) = rr - (uint32_t)(((uint32_t)a < rr && rr <= (uint32_t)b) ? 1 : 0); }
-          });
-          if (gj < gn) {   // the group's lanes follow the move; the claim's acceptances there are void
-            const uint64_t same = W::ballot([&](int l) { return gx.at(l) == (uint32_t)x; });
-            g_touched |= same;
-            if (s_) g_jumped |= same;
-            W::each([&](int l) {
-              const uint32_t pp = gp.at(l), bb = gB.at(l);
-              gp.at(l) = ((same >> l) & 1) ? (uint32_t)b : pp - (uint32_t)(((uint32_t)a < pp && pp <= (uint32_t)b) ? 1 : 0);
-              gB.at(l) = bb - (uint32_t)(((uint32_t)a < bb && bb <= (uint32_t)b) ? 1 : 0);
-            });
-          }
-          moved = true;
-        }
-      }
-      if (KS_UNLIKELY(!moved)) {
-        if (W::leader()) okey[a] = (uint16_t)mvn;
-        pend_a = a; pend_x = x; pend_mv = mvn;
-        gj = 0; gn = 0;
-      }
-      W::sync();
-      break;
+      accw[j] = accm;
     }
-    if (KS_UNLIKELY(outcome == 3)) {
-      // the event interrupts this pod: what the scan learned (claims that rejected it for good) is kept in its cursor
-      W::each([&](int l) {
+    // the claim's record and its place in the order: one lane writes
+    if (W::leader()) {
+      cst.put_state((uint32_t)x, ns);
 #pragma unroll
-        for (int j = 0; j < kFastRows; ++j) if (j * 64 + l == slot_w) cur[j].at(l) = r;
-      });
-      break;
+      for (int j = 0; j < R; ++j) cst.put_acc((uint32_t)x, j, accw[j]);
+      if (s_ <= 0) okey[a] = (uint16_t)mvn;
+      else { okey[a + s_] = (uint16_t)mvn; oord[a + s_] = (uint16_t)x; }
     }
-    if (r != rc0) W::each([&](int l) {
-#pragma unroll
-      for (int j = 0; j < kFastRows; ++j) if (j * 64 + l == slot_w) cur[j].at(l) = r;
-    });
-    steps++;
-    KS_SEC(ts3)   // entry placed by the window test
-#ifdef KSOLVE_PHASE_TIMERS
-    ts7++;
-#endif
-    if (KS_LIKELY(outcome == 1)) { bi++; continue; }
-    ev = FEV_NEWCLAIM; ev_arg = slot_w;   // no in-flight claim accepted the pod: addToNewNodeClaim; the driver moves on to the next pod
-    break;
+    W::sync();
+    KS_SEC(ts3)   // refresh
+    bi++; steps++;
+    if (KS_UNLIKELY(cold_refresh)) { ev = FEV_REFRESH; ev_arg = x; break; }
   }
   if (ev == FEV_DONE && bn > 0) {
     // the deadline / a cancellation stopped the loop inside a block: the pods placed so far are results too
@@ -1148,7 +1094,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS> cx) {
   if (W::leader()) {
     hs->base = base; hs->bi = bi; hs->bn = bn; hs->n = n; hs->steps = steps; hs->status = status;
     hs->pend_a = pend_a; hs->pend_x = pend_x; hs->pend_mv = pend_mv; hs->pend_new = pend_new ? 1 : 0;
-    hs->n_steps = n_steps; hs->n_tests = n_tests; hs->n_ref = n_ref; hs->ev_arg = ev_arg; hs->ev_vm = ev_vm;
+    hs->n_steps = n_steps; hs->n_ref = n_ref; hs->ev_arg = ev_arg;
     hs->hot_cycles += W::clock() - t_in;
 #ifdef KSOLVE_PHASE_TIMERS
     hs->tsec[0] += ts0; hs->tsec[1] += ts1; hs->tsec[2] += ts2; hs->tsec[3] += ts3; hs->tsec[4] += ts4; hs->tsec[5] += ts5; hs->tsec[6] += ts6; hs->tsec[7] += ts7;
@@ -1157,33 +1103,34 @@ KS_COLD int fast_hot_run(FastHotCtx<GS> cx) {
 #undef KS_SEC
   W::each([&](int l) {
 #pragma unroll
-    for (int j = 0; j < kFastRows; ++j) hs->cur[j][l] = cur[j].at(l);
-    hs->nxt_cls[l] = nxt_cls.at(l); hs->bcls[l] = bcls.at(l);
-    hs->bslot[l] = bslot.at(l); hs->oclaim[l] = oclaim.at(l); hs->ocnt[l] = ocnt.at(l);
+    for (int j = 0; j < R; ++j) { hs->cur[j][l] = cur[j].at(l); hs->scls[j][l] = scls[j].at(l); }
+    hs->nxt_cls[l] = nxt_cls.at(l); hs->bcls[l] = bcls.at(l); hs->oclaim[l] = oclaim.at(l); hs->ocnt[l] = ocnt.at(l);
   });
   W::sync();
   return ev;
 }
 
 // The driver: runs the loop, handles its events through FastCold.
-template <class W, int GS = 0>
+template <class W, int GS = 0, int R = 1>
 struct FastEngine {
-  FastCold<W, GS> cold;
+  FastCold<W, GS, R> cold;
   KS_LDS FastHot* hs;
-  KS_DEV FastEngine(const ProblemView* p, const Workspace* s, const FastWork* f, char* lds) { cold.init(p, s, f, lds); hs = (KS_LDS FastHot*)(lds + f->plan.off_hot); }
+  KS_DEV FastEngine(const ProblemView* p, const Workspace* s, const FastWork* f, char* lds) { cold.init(p, s, f, lds); hs = cold.hs; }
 
   KS_DEV void solve() {
+    KS_LDS FastHot* const h = fast_uniform(hs);
+    W::each([&](int l) { for (int j = 0; j < kFastRows; ++j) { h->cur[j][l] = 0; h->scls[j][l] = kFastFree; } });
+    W::sync();
     {
       const int why = (int)W::uniform((uint64_t)(uint32_t)cold.setup());
       if (why) { cold.bail_code = why; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
     }
-    KS_LDS FastHot* const h = fast_uniform(hs);
     const int np = fast_uniform(cold.Pk->n_pods);
     if (W::leader()) {
       h->base = 0; h->bi = 0; h->bn = 0; h->n = 0; h->np = np; h->steps = 0; h->status = 0;
       const long long ms_ = cold.Sk->max_steps;
       h->max_steps = ms_ < 0 ? -1 : (int)(ms_ > 0x7FFFFFFF ? 0x7FFFFFFF : ms_);
-      h->pend_a = -1; h->pend_x = 0; h->pend_mv = 0; h->pend_new = 0; h->ev_arg = 0; h->ev_vm = 0;
+      h->pend_a = -1; h->pend_x = 0; h->pend_mv = 0; h->pend_new = 0; h->ev_arg = 0;
       h->n_steps = 0; h->n_tests = 0; h->n_ref = 0; h->hot_cycles = 0;
       for (int i = 0; i < 8; ++i) h->tsec[i] = 0;
       h->q_class = cold.Fk->q_class; h->cancel = cold.Sk->cancel_flag;
@@ -1191,51 +1138,36 @@ struct FastEngine {
     }
     {
       const uint32_t* qc = cold.Fk->q_class;
-      W::each([&](int l) {
-        for (int j = 0; j < kFastRows; ++j) h->cur[j][l] = 0;
-        h->nxt_cls[l] = l < np ? qc[l] : 0; h->bcls[l] = 0; h->bslot[l] = 0xFFFFu; h->oclaim[l] = 0; h->ocnt[l] = 0;
-      });
+      W::each([&](int l) { h->nxt_cls[l] = l < np ? qc[l] : 0; h->bcls[l] = 0; h->oclaim[l] = 0; h->ocnt[l] = 0; });
     }
     W::sync();
-    FastHotCtx<GS> cx;
+    FastHotCtx<GS, R> cx;
     cx.okey = cold.order.key; cx.oord = cold.order.ord; cx.cst = cold.cst; cx.ent = cold.ent; cx.pool = cold.pool;
-    cx.aslot = cold.aslot; cx.slot_of = cold.Mp->slot_of; cx.hs = hs;
+    cx.aslot = cold.aslot; cx.hs = hs;
     unsigned long long tev[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = W::clock();
     for (;;) {
-      const int ev = fast_uniform(fast_hot_run<W, GS>(cx));
+      const int ev = fast_uniform(fast_hot_run<W, GS, R>(cx));
       if (ev == FEV_DONE) break;
       const unsigned long long te0 = W::clock();
-      if (ev == FEV_ENTRY) {
-        if (fast_uniform(cold.create_entry(h->ev_vm)) < 0) { cold.bail_code = 21; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
+      if (ev == FEV_REFRESH) {
+        if (fast_uniform(cold.refresh_claim(fast_uniform(h->ev_arg))) < 0) { cold.bail_code = 21; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
       } else if (ev == FEV_SLOT) {
-        const int k = fast_uniform(h->ev_arg);
-        const int sv = fast_uniform(cold.new_slot(k));
-        const int slot = sv & 0xFFFF;
-        W::each([&](int l) {
-          if (sv >> 16) {   // every slot was taken: all classes start over
-            h->bslot[l] = 0xFFFFu;
-            for (int j = 0; j < kFastRows; ++j) h->cur[j][l] = 0;
-          }
-          if (h->bcls[l] == (uint32_t)k && l < h->bn) h->bslot[l] = (uint32_t)slot;   // this pod and later pods of the class in the block
-          if (l == (slot & 63)) h->cur[slot >> 6][l] = 0;
-        });
-        W::sync();
+        if (fast_uniform(cold.new_slot(fast_uniform(h->ev_arg))) < 0) { cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
       } else if (ev == FEV_SLOWSORT || ev == FEV_PLACE) {
         const int n = fast_uniform(h->n);
         int b = -1;
         if (ev == FEV_SLOWSORT) cold.slow_sort(n, fast_uniform(h->ev_arg), 0);
         else b = fast_uniform(cold.place_new_claim(n));
-        if (b == -2) { cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
         if (b == -1) {
           // pdqsort permuted positions lo..hi: cursors inside fall back to lo
           const int lo = fast_uniform(cold.lo_), hi = fast_uniform(cold.hi_);
-          if (hi >= lo) W::each([&](int l) { for (int j = 0; j < kFastRows; ++j) { const uint32_t r = h->cur[j][l]; if (r > (uint32_t)lo && r <= (uint32_t)hi) h->cur[j][l] = (uint32_t)lo; } });
+          if (hi >= lo) W::each([&](int l) { for (int j = 0; j < R; ++j) { const uint32_t r = h->cur[j][l]; if (r > (uint32_t)lo && r <= (uint32_t)hi) h->cur[j][l] = (uint32_t)lo; } });
         } else {
           // positions [b, n-1) moved right by one; a cursor past b either steps over the new claim or — if its class is
           // accepted by it — comes back to it
           const KS_LDS uint64_t* acc = cold.Mp->acc;
-          W::each([&](int l) { for (int j = 0; j < kFastRows; ++j) { const uint32_t r = h->cur[j][l]; if (r > (uint32_t)b) h->cur[j][l] = ((acc[j] >> l) & 1) ? (uint32_t)b : r + 1; } });
+          W::each([&](int l) { for (int j = 0; j < R; ++j) { const uint32_t r = h->cur[j][l]; if (r > (uint32_t)b) h->cur[j][l] = ((acc[j] >> l) & 1) ? (uint32_t)b : r + 1; } });
         }
         if (W::leader()) { h->pend_a = -1; h->pend_new = 0; }
         W::sync();
@@ -1243,7 +1175,7 @@ struct FastEngine {
         const int n = fast_uniform(h->n), bi = fast_uniform(h->bi);
         const int made = fast_uniform(cold.new_claim(fast_uniform(h->ev_arg), bi, n));
         if (!made) { cold.finish(fast_uniform(cold.bail_code) < 0 ? 1 : 3, 0, (unsigned long long)fast_uniform(h->steps), 0, 0, 0, nullptr); return; }
-        if (W::leader()) { h->oclaim[bi] = (uint32_t)n; h->ocnt[bi] = 0; h->n = n + 1; h->pend_new = 1; h->bi = bi + 1; }   // claim ids are handed out in creation order
+        if (W::leader()) { h->oclaim[bi] = (uint32_t)n; h->ocnt[bi] = 0; h->n = n + 1; h->pend_new = 1; h->pend_a = 0x7FFFFFFF; h->bi = bi + 1; }   // (pend_a: the loop tests one flag)   // claim ids are handed out in creation order
         W::sync();
       } else { cold.bail_code = 22; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
       if (ev >= 1 && ev <= 5) { tev[ev] += W::clock() - te0; nev[ev]++; }
@@ -1251,18 +1183,41 @@ struct FastEngine {
     // profiling builds (-DKSOLVE_PHASE_TIMERS): cycles inside the loop function, per event kind, in total; event counts
     unsigned long long tc[16] = {h->hot_cycles, tev[1], tev[2], tev[3], tev[4], tev[5], W::clock() - t_begin, nev[3] + (nev[4] << 20) + (nev[1] << 40),
                                  h->tsec[0], h->tsec[1], h->tsec[2], h->tsec[3], h->tsec[4], h->tsec[5], h->tsec[6], h->tsec[7]};
-    cold.finish(fast_uniform(h->status), fast_uniform(h->n), (unsigned long long)fast_uniform(h->steps), h->n_steps, h->n_tests, h->n_ref, tc);
+    const unsigned long long steps = (unsigned long long)fast_uniform(h->steps);
+    // CanAdd evaluations of the loop: after every placement the claim against the classes of all slots; select steps: one per pod and the extra ones
+    cold.finish(fast_uniform(h->status), fast_uniform(h->n), steps, h->n_steps + steps, steps * (unsigned long long)(64 * R), h->n_ref, tc);
   }
 };
 
-// ksolve_fast_queue — one thread per queue entry, before the loop: its class, and "not placed"
+// ksolve_fast_queue   — one thread per queue entry, before the loop: its class, "not placed", and the class's first / last entry
+// ksolve_fast_overlap — one thread per class: how many classes are live at the class's first entry (the most over all classes =
+//                       the slots the loop needs so that no class ever loses its slot); marks nothing
+// ksolve_fast_mark    — one thread per queue entry: kFastLastBit on the last entry of its class
 // ksolve_fast_scatter — one thread per queue entry, after the loop: the entry's result under its pod index (Results.pod_assignment / pod_slot)
 struct FastQueueArgs {
   const uint32_t* sorted; const uint32_t* row_class;
   uint32_t* q_class; uint32_t* q_claim; uint32_t* q_cnt;
   int32_t* assign; uint32_t* slot;
+  uint32_t* cls_first; uint32_t* cls_last; uint32_t* max_active;
 };
-KS_FN void fast_queue_body(int i, const FastQueueArgs& a) { a.q_class[i] = a.row_class[a.sorted[i]]; a.q_claim[i] = 0xFFFFFFFFu; }
+KS_DEV void fast_queue_body(int i, const FastQueueArgs& a) {
+  const uint32_t c = a.row_class[a.sorted[i]];
+  a.q_class[i] = c; a.q_claim[i] = 0xFFFFFFFFu;
+  // (a plain read first: most entries lie inside what other threads have published already)
+  if (a.cls_first[c] > (uint32_t)i) atomic_min_u32(&a.cls_first[c], (uint32_t)i);
+  if (a.cls_last[c] < (uint32_t)i) atomic_max_u32(&a.cls_last[c], (uint32_t)i);
+}
+KS_DEV void fast_overlap_body(int c, int nc, const FastQueueArgs& a) {
+  const uint32_t f = a.cls_first[c];
+  if (f == 0xFFFFFFFFu) return;
+  uint32_t live = 0;
+  for (int o = 0; o < nc; ++o) live += (uint32_t)((a.cls_first[o] <= f) & (a.cls_last[o] >= f));
+  if (*a.max_active < live) atomic_max_u32(a.max_active, live);
+}
+KS_FN void fast_mark_body(int i, const FastQueueArgs& a) {
+  const uint32_t c = a.q_class[i];
+  if (a.cls_last[c] == (uint32_t)i) a.q_class[i] = c | kFastLastBit;
+}
 KS_FN void fast_scatter_body(int i, const FastQueueArgs& a) {
   const uint32_t c = a.q_claim[i];
   if (c == 0xFFFFFFFFu) return;

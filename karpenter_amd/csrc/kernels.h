@@ -18,6 +18,7 @@ namespace ks {
 #if KS_DEVICE
 KS_DEV uint64_t atomic_cas_u64(uint64_t* p, uint64_t expect, uint64_t v) { return (uint64_t)atomicCAS((unsigned long long*)p, (unsigned long long)expect, (unsigned long long)v); }
 KS_DEV uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
+KS_DEV uint32_t atomic_max_u32(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
 KS_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 KS_DEV void atomic_min_i64(int64_t* p, int64_t v) { atomicMin((long long*)p, (long long)v); }
 KS_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
@@ -25,6 +26,7 @@ KS_DEV void atomic_or_u32(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 #else
 inline uint64_t atomic_cas_u64(uint64_t* p, uint64_t expect, uint64_t v) { uint64_t o = *p; if (o == expect) *p = v; return o; }
 inline uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
+inline uint32_t atomic_max_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 inline uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p += v; return o; }
 inline void atomic_min_i64(int64_t* p, int64_t v) { if (v < *p) *p = v; }
 inline void atomic_or_u64(uint64_t* p, uint64_t v) { *p |= v; }

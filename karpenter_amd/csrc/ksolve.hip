@@ -609,35 +609,34 @@ __global__ void ksolve_claim_gather(int n, ks::ClaimGatherArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ks::claim_gather_body(i, a);
 }
-// The cursor engine (fast_engine.h) for purely positive provisioning batches: one wavefront, O(1) steps.
+// The cursor engine (fast_engine.h) for purely positive provisioning batches: one wavefront, O(1) steps. Compiled per memory plan
+// (GS = 0: claim records and order in LDS; 1: records in HBM — problems that need more in-flight claims than a CU's LDS holds
+// beside the caches, the host retries here when the LDS plan ran out of claims; 2: the order arrays in HBM too, up to 65,472
+// in-flight claims — the exact configs[3] batch of 10M pods, 27,345) and per number of class-slot rows (FastPlan::rows).
+template <int GS, int R>
 __global__ void __launch_bounds__(64) ksolve_pack_fast(const ks::FastArgs* a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  ks::FastEngine<ks::Wave, 0> eng(&a->pv, &a->ws, &a->fw, lds);
+  ks::FastEngine<ks::Wave, GS, R> eng(&a->pv, &a->ws, &a->fw, lds);
   eng.solve();
 }
-// ... with the claims' state in HBM and only the order arrays in LDS: problems that need more in-flight claims than a CU's LDS
-// holds beside the caches (fast_engine.h ClaimStates<true>; the host retries here when the LDS plan ran out of claims)
-__global__ void __launch_bounds__(64) ksolve_pack_fast_wide(const ks::FastArgs* a) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  ks::FastEngine<ks::Wave, 1> eng(&a->pv, &a->ws, &a->fw, lds);
-  eng.solve();
-}
-// ... and with the order arrays in HBM too (plan 2): up to 65,472 in-flight claims — the exact configs[3] batch (10M pods, 27,345)
-__global__ void __launch_bounds__(64) ksolve_pack_fast_hbm(const ks::FastArgs* a) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  ks::FastEngine<ks::Wave, 2> eng(&a->pv, &a->ws, &a->fw, lds);
-  eng.solve();
-}
-// Batched form: block b runs the cursor engine on problem b.
+// Batched form: block b runs the cursor engine (LDS plan) on problem b.
 __global__ void __launch_bounds__(64) ksolve_pack_fast_batch(const ks::FastArgs* const* items) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const ks::FastArgs* a = items[blockIdx.x];
-  ks::FastEngine<ks::Wave> eng(&a->pv, &a->ws, &a->fw, lds);
-  eng.solve();
+  if (a->fw.plan.rows == 1) { ks::FastEngine<ks::Wave, 0, 1> eng(&a->pv, &a->ws, &a->fw, lds); eng.solve(); }
+  else { ks::FastEngine<ks::Wave, 0, ks::kFastRows> eng(&a->pv, &a->ws, &a->fw, lds); eng.solve(); }
 }
 __global__ void ksolve_fast_queue(int n, ks::FastQueueArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ks::fast_queue_body(i, a);
+}
+__global__ void ksolve_fast_overlap(int nc, ks::FastQueueArgs a) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nc) ks::fast_overlap_body(c, nc, a);
+}
+__global__ void ksolve_fast_mark(int n, ks::FastQueueArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ks::fast_mark_body(i, a);
 }
 __global__ void ksolve_fast_scatter(int n, ks::FastQueueArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -756,16 +755,18 @@ static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, 
   float ms = 0;
   if (hipEventElapsedTime(&ms, b->ev0[ksi::T_PACK], b->ev1[ksi::T_PACK]) == hipSuccess) h->timers.ms[ksi::T_PACK] = ms;
 }
+typedef void (*ksolve_pack_fast_fn)(const ks::FastArgs*);
+static ksolve_pack_fast_fn pack_fast_kernel(int plan, int rows) {
+  if (rows == 1) return plan == 2 ? ksolve_pack_fast<2, 1> : plan == 1 ? ksolve_pack_fast<1, 1> : ksolve_pack_fast<0, 1>;
+  return plan == 2 ? ksolve_pack_fast<2, ks::kFastRows> : plan == 1 ? ksolve_pack_fast<1, ks::kFastRows> : ksolve_pack_fast<0, ks::kFastRows>;
+}
 static void be_launch_pack_fast(ksolve_handle* h) {
   const int lds_bytes = h->fw.plan.total_bytes;
-  const int plan = h->fw.plan.global_state;
-  const void* fn = plan == 2 ? (const void*)ksolve_pack_fast_hbm : plan == 1 ? (const void*)ksolve_pack_fast_wide : (const void*)ksolve_pack_fast;
-  if (!hip_check(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
+  const ksolve_pack_fast_fn fn = pack_fast_kernel(h->fw.plan.global_state, h->fw.plan.rows);
+  if (!hip_check(h, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
   ks::FastArgs a{h->pv, h->ws, h->fw};
   be_h2d(h, h->d_fast_args, &a, sizeof(a));
-  if (plan == 2) hipLaunchKernelGGL(ksolve_pack_fast_hbm, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
-  else if (plan == 1) hipLaunchKernelGGL(ksolve_pack_fast_wide, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
-  else hipLaunchKernelGGL(ksolve_pack_fast, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
+  hipLaunchKernelGGL(fn, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
   hip_check(h, hipGetLastError(), "ksolve_pack_fast launch");
 }
 static void be_launch_pack_fast_batch(ksolve_handle** hs, int n) {
@@ -797,7 +798,7 @@ static void be_launch_pack_fast_batch(ksolve_handle** hs, int n) {
   (void)hipFree(d_ptrs);
 }
 static ks::FastQueueArgs fast_queue_args(ksolve_handle* h) {
-  return ks::FastQueueArgs{h->pv.sorted_pods, h->pv.row_class, h->fw.q_class, h->fw.q_claim, h->fw.q_cnt, h->ws.assign, h->ws.slot};
+  return ks::FastQueueArgs{h->pv.sorted_pods, h->pv.row_class, h->fw.q_class, h->fw.q_claim, h->fw.q_cnt, h->ws.assign, h->ws.slot, h->fw.cls_first, h->fw.cls_last, h->fw.max_active};
 }
 static void be_launch_fast_records(ksolve_handle* h, int n_claims) {
   ks::FastRecordArgs a{h->pv, h->ws, h->fw};
@@ -811,6 +812,13 @@ static void be_launch_fast_queue(ksolve_handle* h) {
   const int n = (int)h->n_pods;
   hipLaunchKernelGGL(ksolve_fast_queue, grid_for(n), dim3(256), 0, HB(h)->stream, n, fast_queue_args(h));
   hip_check(h, hipGetLastError(), "ksolve_fast_queue launch");
+  const int nc = (int)h->n_classes;
+  if (nc > 64 && nc <= 32768) {
+    hipLaunchKernelGGL(ksolve_fast_overlap, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, HB(h)->stream, nc, fast_queue_args(h));
+    hip_check(h, hipGetLastError(), "ksolve_fast_overlap launch");
+  }
+  hipLaunchKernelGGL(ksolve_fast_mark, grid_for(n), dim3(256), 0, HB(h)->stream, n, fast_queue_args(h));
+  hip_check(h, hipGetLastError(), "ksolve_fast_mark launch");
 }
 
 // One launch per engine flavour (lite / full problems of the batch), each on the stream of its first handle so that the

@@ -72,6 +72,7 @@ struct ksolve_handle {
   ks::LdsPlan lds_big{};   // LDS plan of the BIG engine, used once a solve overflowed the LDS-resident claim order
   bool big_capable = false;
   int lite_saved = 0;
+  uint32_t fast_live = 0;       // cursor engine: the most pod classes live at once in the queue (ksolve_fast_overlap)
   ks::FastWork fw{};            // cursor engine (fast_engine.h): workspace + LDS plan; fw.enabled while the problem may qualify
   uint32_t engine_used = 0, fast_reason = 0, fast_attempts = 0;
   ks::FastArgs* d_fast_args = nullptr;   // the record ksolve_pack_fast reads its problem from
@@ -181,7 +182,7 @@ static bool any_nonzero(const uint32_t* p, uint32_t n) {
   return false;
 }
 
-static void fast_plan_set(ksolve_handle* h, int plan);   // the cursor engine's memory plan (0 LDS / 1 claim state in HBM / 2 order arrays too)
+static void fast_plan_set(ksolve_handle* h, int plan, int rows);   // the cursor engine's memory plan (0 LDS / 1 claim state in HBM / 2 order arrays too)
 static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* o, ksolve_handle* h) {
   if (!d || d->abi_version != KSOLVE_ABI_VERSION) return fail(h, KSOLVE_ERR_INVALID, "abi version mismatch");
   if (d->n_keys == 0 || d->n_keys > KSOLVE_MAX_KEYS) return fail(h, KSOLVE_ERR_INVALID, "n_keys out of range");
@@ -669,10 +670,12 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     fw.enabled = (P.plain && d->n_res <= 4 && h->opts.engine != 1 && d->n_pod_rows == d->n_pods && d->n_pods > 0) ? 1 : 0;
     if (fw.enabled) {
       h->fast_mc = mc;
-      fast_plan_set(h, h->opts.engine == 4 ? 2 : h->opts.engine == 3 ? 1 : 0);
+      fast_plan_set(h, h->opts.engine == 4 ? 2 : h->opts.engine == 3 ? 1 : 0, 1);
       fw.var = dz<ks::FastVar>(h, 1);
       fw.c_hostseq = dz<uint32_t>(h, mc); fw.c_ent = dz<uint16_t>(h, mc);
       fw.c_state = dz<ks::FastClaim>(h, mc); fw.c_npods = dz<uint32_t>(h, mc);
+      fw.c_rec = dz<uint64_t>(h, (size_t)mc * (sizeof(ks::FastRec<ks::kFastRows>) / 8));
+      fw.max_active = dz<uint32_t>(h, 1);
       fw.ent_its = dz<uint64_t>(h, (size_t)ks::kFastEnt * it_words);
       fw.q_class = dz<uint32_t>(h, d->n_pods); fw.q_claim = dz<uint32_t>(h, d->n_pods); fw.q_cnt = dz<uint32_t>(h, d->n_pods);
       { const size_t oc = std::min<size_t>(65472, ((size_t)mc + 63) & ~(size_t)63) + 64; fw.o_key = dz<uint16_t>(h, oc); fw.o_ord = dz<uint16_t>(h, oc); fw.o_snap = dz<uint16_t>(h, oc); }
@@ -795,7 +798,7 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
     R.cls_topo = h->has_topology ? dz<uint64_t>(h, (size_t)n_classes * 2 * R.topo_words) : nullptr;
     R.lay = P.lay;
     h->ws.dead = dz<uint64_t>(h, (size_t)n_classes * h->claim_words);
-    if (h->fw.enabled) h->fw.cls = dz<ks::FastSlot>(h, n_classes);
+    if (h->fw.enabled) { h->fw.cls = dz<ks::FastSlot>(h, n_classes); h->fw.cls_first = dz<uint32_t>(h, n_classes); h->fw.cls_last = dz<uint32_t>(h, n_classes); }
     if (h->n_nodes) h->ws.n_dead = dz<uint64_t>(h, (size_t)n_classes * P.node_words);
   }
   if (n_classes > 0) {
@@ -817,7 +820,17 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
   // ---- phase 3: queue order ----
   be_tic(h, T_SORT);
   be_sort_pods(h);
-  if (h->fw.enabled && !P.big && n_pods) be_launch_fast_queue(h);   // the cursor engine reads the queue's classes in queue order
+  if (h->fw.enabled && !P.big && n_pods && n_classes) {
+    // the cursor engine reads the queue's classes in queue order; how many classes are live at once decides its rows of class slots
+    be_fill(h, h->fw.cls_first, 0xFF, (size_t)n_classes * 4); be_fill(h, h->fw.cls_last, 0, (size_t)n_classes * 4); be_fill(h, h->fw.max_active, 0, 4);
+    be_launch_fast_queue(h);
+    uint32_t live = 0xFFFFFFFFu;
+    if (n_classes <= 64) live = n_classes;
+    else if (n_classes <= 32768) { be_d2h(h, &live, h->fw.max_active, 4); be_sync(h); }   // (beyond: the count is quadratic in the classes — four rows)
+    h->fast_live = live;
+    const int rows = live <= 64 ? 1 : ks::kFastRows;
+    if (rows != h->fw.plan.rows) fast_plan_set(h, h->fw.plan.global_state, rows);
+  }
   be_toc(h, T_SORT);
 
   // ---- phase 4: pack ----
@@ -1798,21 +1811,25 @@ static void solve_probes(ksolve_handle** hs, uint32_t n, ksolve_results* outs, k
   }
 }
 
-// Memory plan of the cursor engine. 0: claim state (24 B) + order arrays (6 B) per claim in LDS, ~3,000 claims beside the caches;
-// 1: the claim state in HBM (FastWork::c_state), only the order arrays in LDS: ~15,000 claims; 2: the order arrays in HBM too
-// (FastWork::o_key / o_ord / o_snap): 65,472 claims, the range of the 16-bit claim ids.
-static void fast_plan_set(ksolve_handle* h, int plan) {
+// Memory plan of the cursor engine. 0: claim records (32 B with one row of class slots, 56 B with four) + order arrays (6 B) per
+// claim in LDS, ~3,000 claims beside the caches; 1: the claim records in HBM (FastWork::c_rec), only the order arrays in LDS: ~15,000
+// claims; 2: the order arrays in HBM too (FastWork::o_key / o_ord / o_snap): 65,472 claims, the range of the 16-bit claim ids.
+// rows: 1 while at most 64 pod classes are ever live at once in the queue (counted before the loop), ks::kFastRows otherwise.
+static void fast_plan_set(ksolve_handle* h, int plan, int rows) {
   const bool wide = plan >= 1;
   auto align = [](int x) { return (x + 15) & ~15; };
   ks::FastPlan& fp = h->fw.plan;
+  rows = rows <= 1 ? 1 : ks::kFastRows;
+  fp.rows = rows;
+  const int rec_bytes = rows == 1 ? (int)sizeof(ks::FastRec<1>) : (int)sizeof(ks::FastRec<ks::kFastRows>);
   int off = 0;
   fp.off_ent = off; off = align(off + ks::kFastEnt * (int)sizeof(ks::FastEnt));
   fp.off_pool = off; off = align(off + ks::kFastPool * 16);
-  fp.off_slot = off; off = align(off + ks::kFastSlots * (int)sizeof(ks::FastSlot));
+  fp.off_slot = off; off = align(off + rows * 64 * (int)sizeof(ks::FastSlot));
   fp.off_misc = off; off = align(off + (int)sizeof(ks::FastMisc));
   fp.off_hot = off; off = align(off + (int)sizeof(ks::FastHot));
   const int budget = 160 * 1024 - 512;
-  const int per_claim = (wide ? 0 : (int)sizeof(ks::FastClaim)) + 6;
+  const int per_claim = (wide ? 0 : rec_bytes) + 6;
   int cap = plan >= 2 ? 65472 : ((budget - off - 64) / per_claim) & ~63;
   if (cap > 65472) cap = 65472;
   if (!wide && h->opts.lds_claim_cap && (int)((h->opts.lds_claim_cap + 63) & ~63u) < cap) cap = (int)((h->opts.lds_claim_cap + 63) & ~63u);
@@ -1822,7 +1839,7 @@ static void fast_plan_set(ksolve_handle* h, int plan) {
   if (cap > (int)((h->fast_mc + 63) & ~63u)) cap = (int)((h->fast_mc + 63) & ~63u);
   fp.cap = cap;
   fp.global_state = plan >= 2 ? 2 : wide ? 1 : 0;
-  fp.off_state = off; if (!wide) off = align(off + cap * (int)sizeof(ks::FastClaim));
+  fp.off_state = off; if (!wide) off = align(off + cap * rec_bytes);
   const int lds_order = plan >= 2 ? 0 : cap;
   fp.off_key = off; off = align(off + lds_order * 2);
   fp.off_ord = off; off = align(off + lds_order * 2);
@@ -1872,12 +1889,12 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out, bool fresh_con
         const int had = h->fw.plan.cap;
         int next = h->fw.plan.global_state + 1;
         if (next == 1) {
-          fast_plan_set(h, 1);
+          fast_plan_set(h, 1, h->fw.plan.rows);
           const double placed = (double)(ctr_pops > 0 ? ctr_pops : 1);
           const bool holds_all = h->fw.plan.cap >= (int)((h->fast_mc + 63) & ~63u);   // plan 1 has a slot for every claim the problem may open
           if (!holds_all && (double)had * (double)h->n_pods / placed * 1.25 > (double)h->fw.plan.cap) next = 2;
         }
-        fast_plan_set(h, next);
+        fast_plan_set(h, next, h->fw.plan.rows);
         if (h->fw.plan.cap > had) {
           st = solve_prepare(h, false);
           if (st != KSOLVE_OK) return st;
@@ -1930,10 +1947,16 @@ static ksolve_status solve_batch_plain(ksolve_handle** hs, uint32_t n, ksolve_re
   // problems of the cursor engine's shape go to it (one block each); the ones it hands back (status 3), and all others, run
   // on the general engine's batched launch
   std::vector<ksolve_handle*> fast, run;
+  std::vector<char> alone(n, 0);   // solved on their own (results complete)
   for (uint32_t i = 0; i < n; ++i) {
     if (st[i] != KSOLVE_OK || !hs[i]->n_pods) continue;
     ksolve_handle* h = hs[i];
-    if (h->fw.enabled && !h->pv.big && h->n_classes) fast.push_back(h);
+    if (h->fw.enabled && !h->pv.big && h->n_classes) {
+      // the batched kernel is the LDS plan; a handle whose claims live in HBM (an earlier Solve() moved it there, or engine =
+      // cursor-wide / cursor-hbm) runs alone on the kernel of its plan
+      if (h->fw.plan.global_state == 0) fast.push_back(h);
+      else { be_results_drop(&outs[i]); st[i] = solve(h, &outs[i], false); outs[i].status = st[i]; alone[i] = 1; }
+    }
     else if (h->opts.engine >= 2) st[i] = fail(h, KSOLVE_ERR_UNSUPPORTED, "cursor engine requested for a problem outside its shape");
     else run.push_back(h);
   }
@@ -1956,6 +1979,12 @@ static ksolve_status solve_batch_plain(ksolve_handle** hs, uint32_t n, ksolve_re
       ksolve_handle* h = fast[k];
       uint32_t idx = 0;
       while (hs[idx] != h) ++idx;
+      if (h->fast_reason == 26 && !h->opts.lds_claim_cap) {
+        // more in-flight claims than the LDS plan holds: alone, on the plans that keep them in HBM (solve() escalates further)
+        fast_plan_set(h, 1, h->fw.plan.rows);
+        be_results_drop(&outs[idx]); st[idx] = solve(h, &outs[idx], false); outs[idx].status = st[idx]; alone[idx] = 1;
+        continue;
+      }
       if (h->opts.engine >= 2) { st[idx] = fail(h, KSOLVE_ERR_UNSUPPORTED, "cursor engine declined the problem (reason " + std::to_string(h->fast_reason) + ")"); continue; }
       h->fw.enabled = 0;
       st[idx] = solve_prepare(h, false);
@@ -1964,6 +1993,7 @@ static ksolve_status solve_batch_plain(ksolve_handle** hs, uint32_t n, ksolve_re
   }
   if (!run.empty()) be_launch_pack_batch(run.data(), (int)run.size());
   parallel([&](uint32_t i) {
+    if (alone[i]) return;
     if (st[i] != KSOLVE_OK) { outs[i].status = st[i]; return; }
     st[i] = solve_finish(hs[i], &outs[i]);
     if (st[i] == KSOLVE_ERR_CAPACITY && hs[i]->big_capable && !hs[i]->pv.big) { be_results_drop(&outs[i]); st[i] = solve(hs[i], &outs[i], false); }   // re-run alone on the BIG engine

@@ -43,17 +43,17 @@ struct Wave {
     __builtin_amdgcn_wave_barrier();
   }
   template <class F>
-  KS_DEV static uint64_t ballot(F f) { return __ballot(f(lane()) ? 1 : 0); }
+  KS_DEV static uint64_t ballot(F f) { return __builtin_amdgcn_ballot_w64((bool)f(lane())); }   // (the builtin on a bool: the compare itself writes the mask; __ballot(int) materialises 0 / 1 in a VGPR and compares again)
   // four ballots from ONE evaluation of f(lane) (bits 0..3 of its result): the loads behind the predicates happen once
   template <class F>
   KS_DEV static void ballot4(F f, uint64_t& m0, uint64_t& m1, uint64_t& m2, uint64_t& m3) {
     const int v = f(lane());
-    m0 = __ballot(v & 1); m1 = __ballot(v & 2); m2 = __ballot(v & 4); m3 = __ballot(v & 8);
+    m0 = __builtin_amdgcn_ballot_w64((v & 1) != 0); m1 = __builtin_amdgcn_ballot_w64((v & 2) != 0); m2 = __builtin_amdgcn_ballot_w64((v & 4) != 0); m3 = __builtin_amdgcn_ballot_w64((v & 8) != 0);
   }
   template <class F>
   KS_DEV static void ballot2(F f, uint64_t& m0, uint64_t& m1) {
     const int v = f(lane());
-    m0 = __ballot(v & 1); m1 = __ballot(v & 2);
+    m0 = __builtin_amdgcn_ballot_w64((v & 1) != 0); m1 = __builtin_amdgcn_ballot_w64((v & 2) != 0);
   }
   // g(j, ballot(f(lane, j))) for j < n <= 8: all predicates (and their loads) are evaluated before the first ballot, so
   // eight words cost one LDS latency instead of eight. No arrays: everything stays in registers.
@@ -76,7 +76,7 @@ struct Wave {
   KS_DEV static int find_first(int lo, int hi, F pred) {
     for (int base = lo; base < hi; base += 64) {
       int i = base + lane();
-      uint64_t m = __ballot((i < hi && pred(i)) ? 1 : 0);
+      uint64_t m = __builtin_amdgcn_ballot_w64(i < hi && pred(i));
       if (m) return base + __builtin_ctzll(m);
     }
     return hi;
@@ -86,7 +86,7 @@ struct Wave {
   KS_DEV static int find_last(int lo, int hi, F pred) {
     for (int top = hi; top > lo; top -= 64) {
       int i = top - 64 + lane();
-      uint64_t m = __ballot((i >= lo && pred(i)) ? 1 : 0);
+      uint64_t m = __builtin_amdgcn_ballot_w64(i >= lo && pred(i));
       if (m) return top - 64 + (63 - __builtin_clzll(m));
     }
     return lo - 1;
@@ -208,7 +208,7 @@ struct Wave {
   KS_DEV static uint32_t argmin_u32(F f, int* lane_out) {
     uint32_t mine = f(lane());
     uint32_t m = min_u32(mine);
-    uint64_t who = __ballot(mine == m ? 1 : 0);
+    uint64_t who = __builtin_amdgcn_ballot_w64(mine == m);
     *lane_out = m == 0xFFFFFFFFu ? -1 : (int)__builtin_ctzll(who);
     return m;
   }

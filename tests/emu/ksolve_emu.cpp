@@ -99,12 +99,20 @@ static void be_launch_pack_fast(ksolve_handle* h) {
   std::vector<char> lds((size_t)h->fw.plan.total_bytes + 64, (char)0xA5);   // garbage, like the device's LDS at kernel start
   ks::FastArgs a{h->pv, h->ws, h->fw};
   be_h2d(h, h->d_fast_args, &a, sizeof(a));
-  if (h->fw.plan.global_state == 2) { ks::FastEngine<ks::Wave, 2> eng(&h->d_fast_args->pv, &h->d_fast_args->ws, &h->d_fast_args->fw, lds.data()); eng.solve(); }
-  else if (h->fw.plan.global_state) { ks::FastEngine<ks::Wave, 1> eng(&h->d_fast_args->pv, &h->d_fast_args->ws, &h->d_fast_args->fw, lds.data()); eng.solve(); }
-  else { ks::FastEngine<ks::Wave, 0> eng(&h->d_fast_args->pv, &h->d_fast_args->ws, &h->d_fast_args->fw, lds.data()); eng.solve(); }
+  const ks::FastArgs* a_ = h->d_fast_args;
+  const int gs = h->fw.plan.global_state;
+  if (h->fw.plan.rows == 1) {
+    if (gs == 2) { ks::FastEngine<ks::Wave, 2, 1> eng(&a_->pv, &a_->ws, &a_->fw, lds.data()); eng.solve(); }
+    else if (gs) { ks::FastEngine<ks::Wave, 1, 1> eng(&a_->pv, &a_->ws, &a_->fw, lds.data()); eng.solve(); }
+    else { ks::FastEngine<ks::Wave, 0, 1> eng(&a_->pv, &a_->ws, &a_->fw, lds.data()); eng.solve(); }
+  } else {
+    if (gs == 2) { ks::FastEngine<ks::Wave, 2, ks::kFastRows> eng(&a_->pv, &a_->ws, &a_->fw, lds.data()); eng.solve(); }
+    else if (gs) { ks::FastEngine<ks::Wave, 1, ks::kFastRows> eng(&a_->pv, &a_->ws, &a_->fw, lds.data()); eng.solve(); }
+    else { ks::FastEngine<ks::Wave, 0, ks::kFastRows> eng(&a_->pv, &a_->ws, &a_->fw, lds.data()); eng.solve(); }
+  }
 }
 static ks::FastQueueArgs fast_queue_args(ksolve_handle* h) {
-  return ks::FastQueueArgs{h->pv.sorted_pods, h->pv.row_class, h->fw.q_class, h->fw.q_claim, h->fw.q_cnt, h->ws.assign, h->ws.slot};
+  return ks::FastQueueArgs{h->pv.sorted_pods, h->pv.row_class, h->fw.q_class, h->fw.q_claim, h->fw.q_cnt, h->ws.assign, h->ws.slot, h->fw.cls_first, h->fw.cls_last, h->fw.max_active};
 }
 static void be_launch_fast_records(ksolve_handle* h, int n_claims) {
   ks::FastRecordArgs a{h->pv, h->ws, h->fw};
@@ -115,6 +123,9 @@ static void be_launch_fast_records(ksolve_handle* h, int n_claims) {
 static void be_launch_fast_queue(ksolve_handle* h) {
   const ks::FastQueueArgs q = fast_queue_args(h);
   for (int i = 0; i < (int)h->n_pods; ++i) ks::fast_queue_body(i, q);
+  const int nc = (int)h->n_classes;
+  if (nc > 64 && nc <= 32768) for (int c = 0; c < nc; ++c) ks::fast_overlap_body(c, nc, q);
+  for (int i = 0; i < (int)h->n_pods; ++i) ks::fast_mark_body(i, q);
 }
 static void be_launch_pack_fast_batch(ksolve_handle** hs, int n) {
   for (int i = 0; i < n; ++i) { be_tic(hs[i], ksi::T_PACK); be_launch_pack_fast(hs[i]); be_toc(hs[i], ksi::T_PACK); }

@@ -158,17 +158,18 @@ def test_several_pareto_vectors_per_requirement_set(oracle, emu):
 
 
 def test_more_classes_than_slots_evicts_and_stays_exact(oracle, emu):
-    """More than 256 pod classes interleaved in one size run: class slots are recycled wholesale (cursors restart)."""
+    """More than 256 pod classes LIVE AT ONCE in one size run (a class's slot is free again after its last pod, so the classes must
+    overlap: 700 of them, two pods each): class slots are recycled wholesale (cursors restart, acceptance bits recomputed)."""
     its = fx.kwok_catalog(72)
     pods = []
-    for i in range(300):   # 300 classes of one (cpu, memory) size: they differ in ephemeral-storage and zone, and interleave by uid
-        pods.append(fx.pod(requests={"cpu": "500m", "memory": "128Mi", "ephemeral-storage": f"{i + 1}Mi"}, node_selector={fx.ZONE: fx.KWOK_ZONES[i % 4]}))
-    pods = pods * 3
+    for rep in range(2):
+        for i in range(700):   # 700 classes of one (cpu, memory) size: they differ in ephemeral-storage and zone; a class's two pods lie 700 queue entries apart
+            pods.append(fx.pod(requests={"cpu": "500m", "memory": "128Mi", "ephemeral-storage": f"{i + 1}Mi"}, node_selector={fx.ZONE: fx.KWOK_ZONES[i % 4]}))
     np_ = fx.node_pool()
     np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
     got = check_cursor(oracle, emu, fx.problem(its, [np_], pods, well_known=fx.KWOK_WELL_KNOWN))
     assert got["counters"]["phaseCycles"][22] > 0   # evictions happened
-    assert got["scheduledPods"] == 900
+    assert got["scheduledPods"] == 1400
 
 
 def test_long_runs_of_equally_full_claims(oracle, emu):
@@ -252,6 +253,38 @@ def test_batched_launch_mixes_engines(oracle, emu):
         parity.assert_same_results(g, oracle.solve(p))
     with pytest.raises(Unsupported, match="cursor engine"):
         SolveBatch([NewScheduler(with_engine(probs[3], "cursor"), solver_lib=emu), NewScheduler(probs[0], solver_lib=emu)])
+
+
+def test_batched_launch_with_handles_on_the_hbm_plans(oracle, emu):
+    """ksolve_solve_batch with handles whose claims do not live in LDS (the batched kernel is compiled for the LDS plan
+    only): engine = cursor-wide / cursor-hbm handles, and a handle an earlier Solve() moved to plan 1 — each runs alone on the
+    kernel of its plan inside the same call; a problem that runs out of LDS claim slots in the batched launch moves to plan 1
+    instead of the general engine."""
+    from karpenter_amd.scheduling import SolveBatch
+    probs = [fx.config2(pods=1200, n_types=60, seed=80 + i) for i in range(4)]
+    want = [oracle.solve(p) for p in probs]
+    scheds = [NewScheduler(probs[0], solver_lib=emu), NewScheduler(with_engine(probs[1], "cursor-wide"), solver_lib=emu),
+              NewScheduler(with_engine(probs[2], "cursor-hbm"), solver_lib=emu), NewScheduler(with_engine(probs[3], "cursor"), solver_lib=emu)]
+    got = SolveBatch(scheds)
+    assert [g["counters"]["cursorMemoryPlan"] for g in got] == [0, 1, 2, 0]
+    for g, w in zip(got, want):
+        assert g["counters"]["engine"] == "cursor"
+        parity.assert_same_results(g, w)
+    # more claims than the LDS plan holds: 3,400 pods that each need a node of their own
+    its = fx.fake_instance_types(8)
+    big = fx.problem(its, [fx.node_pool()], [fx.pod(requests={"cpu": "7"}) for _ in range(3400)] + [fx.pod(requests={"cpu": "300m"}) for _ in range(600)])
+    pair = SolveBatch([NewScheduler(big, solver_lib=emu), NewScheduler(probs[0], solver_lib=emu)])
+    assert pair[0]["counters"]["engine"] == "cursor" and pair[0]["counters"]["cursorMemoryPlan"] == 1
+    parity.assert_same_results(pair[0], oracle.solve(big))
+    parity.assert_same_results(pair[1], want[0])
+    # ... and the handle stays there: batched again, it runs alone on plan 1
+    s = NewScheduler(big, solver_lib=emu)
+    first = s.Solve()
+    assert first["counters"]["cursorMemoryPlan"] == 1
+    again = SolveBatch([s, NewScheduler(probs[1], solver_lib=emu)])
+    assert again[0]["counters"]["cursorMemoryPlan"] == 1
+    parity.assert_same_results(again[0], first)
+    parity.assert_same_results(again[1], want[1])
 
 
 def test_claim_state_in_hbm_when_the_lds_plan_runs_out_of_claims(oracle, emu):
