@@ -784,7 +784,7 @@ struct FastHotCtx {   // LDS pointers of the loop, passed by value
   typename FastMem<GS, R>::o16 okey, oord; typename FastMem<GS, R>::States cst; KS_LDS FastEnt* ent; KS_LDS int32_t* pool;
   KS_LDS FastSlot* aslot; KS_LDS FastHot* hs;
 };
-enum { FEV_DONE = 0, FEV_REFRESH = 1, FEV_SLOT = 2, FEV_SLOWSORT = 3, FEV_PLACE = 4, FEV_NEWCLAIM = 5, FEV_COUNT = 6 };
+enum { FEV_DONE = 0, FEV_REFRESH = 1, FEV_SLOT = 2, FEV_SLOWSORT = 3, FEV_PLACE = 4, FEV_NEWCLAIM = 5, FEV_COUNT = 6, FEV_SLOW = 7, FEV_CONT = 8 };
 
 // The loop that places pods: a function of its own, WITHOUT calls — whatever happens rarely (a requirement set seen for the
 // first time, a class without a slot, a new claim, pdqsort leaving its single-move path) ends the run with an event code; the
@@ -800,7 +800,8 @@ enum { FEV_DONE = 0, FEV_REFRESH = 1, FEV_SLOT = 2, FEV_SLOWSORT = 3, FEV_PLACE 
 //            classes' records in registers, one requirement-set cache read per lane.
 // Nothing is speculated, so nothing is validated: ~110 instructions per pod, three dependent LDS round trips.
 template <class W, int GS, int R>
-KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
+KS_COLD int fast_slow_run(FastHotCtx<GS, R> cx, int budget) {
+  budget = fast_uniform(budget);
   typedef typename FastMem<GS, R>::o16 o16;
   const unsigned long long t_in = W::clock();
   const o16 okey = fast_uniform(cx.okey), oord = fast_uniform(cx.oord);
@@ -1083,6 +1084,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
     KS_SEC(ts3)   // refresh
     bi++; steps++;
     if (KS_UNLIKELY(cold_refresh)) { ev = FEV_REFRESH; ev_arg = x; break; }
+    if (--budget <= 0 && pend_a < 0) { ev = FEV_CONT; break; }   // back to the fast loop (a move left pending: the next add sorts first)
   }
   if (ev == FEV_DONE && bn > 0) {
     // the deadline / a cancellation stopped the loop inside a block: the pods placed so far are results too
@@ -1108,6 +1110,240 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
   });
   W::sync();
   return ev;
+}
+
+// ---- the fast loop -------------------------------------------------------------------------------------------------------
+// The same step as fast_slow_run below, for the pod whose step is the plain one — its class has a slot, a claim among the 64 at
+// the class's cursor accepts it, the move of that claim is decided inside those 64 positions, every requirement set met while the
+// claim is refreshed is cached — and nothing else. A step is a TRANSACTION: every test comes before the first write, and the first
+// thing that is not plain (the last entry before a block where the cancel flag is polled, a pending move, a class without a slot,
+// no acceptor in the window, pdqsort's other paths, a requirement set that is not cached) leaves the loop with the state as it
+// was: the driver runs fast_slow_run for that one pod and comes back. Why two functions: with every rare path inside one loop the
+// compiler merged ~30 loop-carried values behind each of them — 274 instructions per pod of which 140 scalar moves, selects and
+// branches (SQ counters, profiles/round5); this loop has ONE path and one exit.
+template <class W, int GS, int R>
+KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
+  typedef typename FastMem<GS, R>::o16 o16;
+  KS_LDS FastHot* const hs = fast_uniform(cx.hs);
+  // (nothing to do here: a pending move / a new claim to place, a step limit — tests —, a stopped solve)
+  // (... or no claim yet: the select step reads the order's entries unconditionally, clamped to the last one)
+  if (fast_uniform(hs->pend_a) >= 0 || fast_uniform(hs->max_steps) >= 0 || fast_uniform(hs->status) != 0 || fast_uniform(hs->n) <= 0) return FEV_SLOW;
+  const o16 okey = fast_uniform(cx.okey), oord = fast_uniform(cx.oord);
+  const typename FastMem<GS, R>::States cst = fast_uniform(cx.cst);
+  KS_LDS FastEnt* const ent = fast_uniform(cx.ent);
+  KS_LDS int32_t* const pool = fast_uniform(cx.pool);
+  KS_LDS FastSlot* const aslot = fast_uniform(cx.aslot);
+  const int np = fast_uniform(hs->np), n = fast_uniform(hs->n);
+  const KS_GLOBAL uint32_t* const gqcls = (const KS_GLOBAL uint32_t*)fast_uniform(hs->q_class);
+  const bool polled = fast_uniform(hs->cancel) != nullptr;
+  KS_GLOBAL uint32_t* const gqclaim = (KS_GLOBAL uint32_t*)fast_uniform(hs->q_claim);
+  KS_GLOBAL uint32_t* const gqcnt = (KS_GLOBAL uint32_t*)fast_uniform(hs->q_cnt);
+  int base = fast_uniform(hs->base), bi = fast_uniform(hs->bi), bn = fast_uniform(hs->bn), steps = fast_uniform(hs->steps);
+  unsigned long long n_ref = W::uniform(hs->n_ref);
+  const int bi_in = bi, base_in = base;
+  LaneVar<uint32_t> cur[R], scls[R], tok[R], nxt_cls, bcls, oclaim, ocnt;
+  LaneVar<uint64_t> cvm[R], dm[R], gd[R];
+  LaneVar<int32_t> z0[R], z1[R], z2[R], z3[R];
+  W::each([&](int l) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      cur[j].at(l) = hs->cur[j][l]; scls[j].at(l) = hs->scls[j][l];
+      const FastSlot s = lds_get(&aslot[j * 64 + l]);
+      cvm[j].at(l) = s.cvmask; dm[j].at(l) = s.dmask; gd[j].at(l) = (s.dmask << 1) & ~s.dmask;
+      z0[j].at(l) = s.size[0]; z1[j].at(l) = s.size[1]; z2[j].at(l) = s.size[2]; z3[j].at(l) = s.size[3];
+      tok[j].at(l) = scls[j].at(l) == kFastFree ? 0u : s.tmplok;
+    }
+    nxt_cls.at(l) = hs->nxt_cls[l]; bcls.at(l) = hs->bcls[l]; oclaim.at(l) = hs->oclaim[l]; ocnt.at(l) = hs->ocnt[l];
+  });
+  // pdqsort's other paths: with 12 < n < 50 every re-sort that has something to move; with n >= 50 a move from one of choosePivot's
+  // nine sampled positions (fast_sampled, as three starts); with n <= 12 none (the stable insertion sort)
+  const uint32_t inexact = (n > 12 && n < 50) ? 1u : 0u;
+  const uint32_t e1 = n >= 50 ? (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u, e2 = n >= 50 ? 2u * (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u, e3 = n >= 50 ? 3u * (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u;
+  const int nm1 = n - 1;
+  for (;;) {   // blocks of the queue
+    // entries of this block the loop may place: not the queue's last one, nor the last one before a block at which the cancel flag
+    // is polled (a Solve() that ends there reports the order of the last sort the reference would have run: their move stays undone)
+    const int bf = bn - ((base + bn >= np || (polled && ((base + 64) & 1023) == 0)) ? 1 : 0);
+    while (bi < bf) {
+      // Everything up to the first write is ONE basic block: whatever is not plain sets a bit of `bad` and the step goes on with
+      // harmless values (lane 0, position 0), so that no branch stands between the loads and the compiler issues them together —
+      // with a `break` behind the acceptor test it had sunk the count, state and class reads below it: five dependent LDS round
+      // trips per pod instead of three (order -> claim record -> requirement-set cache).
+      // ---- the pod's class and its slot ----
+      const uint32_t clsw = bcls.bcast(bi), kcls = clsw & ~kFastLastBit;
+      int row = 0, sl = 0;
+      uint32_t bad = 0;
+      if constexpr (R == 1) {
+        const uint64_t m0 = W::ballot([&](int l) { return scls[0].at(l) == kcls; });
+        bad |= (uint32_t)(m0 == 0);
+        sl = ctz64(m0 | (1ull << 63));
+      } else {
+        uint64_t mf = 0;
+#pragma unroll
+        for (int j = R - 1; j >= 0; --j) {
+          const uint64_t mj = W::ballot([&](int l) { return scls[j].at(l) == kcls; });
+          row = mj != 0 ? j : row; mf = mj != 0 ? mj : mf;     // (a class sits in one slot)
+        }
+        bad |= (uint32_t)(mf == 0);
+        sl = ctz64(mf | (1ull << 63));
+      }
+      const int slot = row * 64 + sl;
+      const FastSlot cs = lds_get(&aslot[slot]);
+      uint32_t rc0 = cur[0].bcast(sl);
+#pragma unroll
+      for (int j = 1; j < R; ++j) { const uint32_t cj = cur[j].bcast(sl); rc0 = row == j ? cj : rc0; }
+      // ---- select: the 64 positions at the cursor, one lane each: the order's entry, then the claim's whole record (a cursor at the
+      // end of the order: no lane is valid, nothing accepts) ----
+      LaneVar<uint64_t> mvv;
+      LaneVar<uint32_t> xv, kv;
+      LaneVar<int32_t> q0, q1, q2, q3;
+      const uint64_t slbit = 1ull << sl;
+      const uint64_t okm = W::ballot([&](int l) {
+        const int p = (int)rc0 + l;
+        int pc = p < nm1 ? p : nm1; pc = pc < 0 ? 0 : pc;   // clamped: no lane is switched off for the reads
+        const uint64_t want = p < n ? slbit : 0ull;       // (ready before the reads come back)
+        const uint32_t x = oord[pc], k = okey[pc];
+        const FastClaim st = cst.state(x);
+        const uint64_t aw = cst.acc(x, row);
+        xv.at(l) = x; kv.at(l) = p < n ? k : 0xFFFFFFFFu;
+        q0.at(l) = st.req[0]; q1.at(l) = st.req[1]; q2.at(l) = st.req[2]; q3.at(l) = st.req[3];
+        mvv.at(l) = st.vmask;
+        return (aw & want) != 0;
+      });
+      bad |= (uint32_t)(okm == 0);
+      const int first_ok = ctz64(okm | (1ull << 63));
+      const int a = (int)rc0 + first_ok;
+      const int x = (int)xv.bcast(first_ok);
+      const uint32_t cnt = kv.bcast(first_ok);
+      bad |= (uint32_t)(cnt >= 65534u);
+      // ---- NodeClaim.Add (nodeclaim.go:247-263): the claim's new state (every lane for the claim it read; lane first_ok's is the one) ----
+      FastClaim ns;
+      LaneVar<uint64_t> nmv; LaneVar<int32_t> n0v, n1v, n2v, n3v;
+      W::each([&](int l) {
+        nmv.at(l) = mvv.at(l) & cs.cvmask;
+        n0v.at(l) = q0.at(l) + cs.size[0]; n1v.at(l) = q1.at(l) + cs.size[1]; n2v.at(l) = q2.at(l) + cs.size[2]; n3v.at(l) = q3.at(l) + cs.size[3];
+      });
+      ns.vmask = nmv.bcast(first_ok);
+      ns.req[0] = n0v.bcast(first_ok); ns.req[1] = n1v.bcast(first_ok); ns.req[2] = n2v.bcast(first_ok); ns.req[3] = n3v.bcast(first_ok);
+      // ---- the move of the next add's sort.Slice (scheduler.go:598), decided from the counts the select step read ----
+      const uint32_t mvn = cnt + 1;
+      const uint64_t lessm = W::ballot([&](int l) { return kv.at(l) < mvn; });   // lanes past n hold 0xFFFFFFFF; the lanes up to first_ok are shifted out
+      const uint64_t tsh = (lessm >> 1) >> first_ok;                             // (two shifts: first_ok may be 63)
+      const int sm = ctz64(~tsh);                                                // < 64: the top bit of tsh is clear
+      bad |= (uint32_t)(first_ok + 1 + sm >= 64) & (uint32_t)((int)rc0 + 64 < n);                   // beyond the window: the pending path
+      bad |= (uint32_t)(sm != 0) & (inexact | (uint32_t)((uint32_t)a - e1 <= 2u) | (uint32_t)((uint32_t)a - e2 <= 2u) | (uint32_t)((uint32_t)a - e3 <= 2u));   // pdqsort's other paths
+      // ---- refresh: CanAdd (nodeclaim.go:124-242) of the claim as it will stand, for the classes of all slots (lane = slot) ----
+      const uint32_t tbit = 1u << (uint32_t)(ns.vmask >> 56);
+      uint64_t accw[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        LaneVar<uint64_t> mlv, evm;
+        LaneVar<int32_t> c0, c1, c2, c3;
+        LaneVar<uint32_t> einfo;
+        W::each([&](int l) {
+          const uint64_t m = ns.vmask & cvm[j].at(l);
+          const FastEnt e = lds_get(&ent[fast_hash(m)]);
+          mlv.at(l) = m; evm.at(l) = e.vmask; einfo.at(l) = e.info;
+          c0.at(l) = e.cap[0]; c1.at(l) = e.cap[1]; c2.at(l) = e.cap[2]; c3.at(l) = e.cap[3];
+        });
+        // every predicate is one compare whose result is the 64-lane mask; the masks are combined in scalar registers
+        const uint64_t tokm = W::ballot([&](int l) { return (tok[j].at(l) & tbit) != 0; });
+        const uint64_t fldm = W::ballot([&](int l) { return (((mlv.at(l) & dm[j].at(l)) + dm[j].at(l)) & gd[j].at(l)) == gd[j].at(l); });
+        const uint64_t simm = W::ballot([&](int l) { return evm.at(l) == mlv.at(l); });
+        const uint64_t f0 = W::ballot([&](int l) { return z0[j].at(l) <= c0.at(l) - ns.req[0]; });
+        const uint64_t f1 = W::ballot([&](int l) { return z1[j].at(l) <= c1.at(l) - ns.req[1]; });
+        const uint64_t f2 = W::ballot([&](int l) { return z2[j].at(l) <= c2.at(l) - ns.req[2]; });
+        const uint64_t f3 = W::ballot([&](int l) { return z3[j].at(l) <= c3.at(l) - ns.req[3]; });
+        const uint64_t extm = W::ballot([&](int l) { return (einfo.at(l) & 0xFF00u) != 0; });
+        const uint64_t basem = tokm & fldm, fitm = f0 & f1 & f2 & f3;
+        uint64_t accm = basem & simm & fitm;
+        const uint64_t oddm = basem & (~simm | (~fitm & extm));   // set not at its first probe / not cached / further Pareto vectors
+        if (KS_UNLIKELY(oddm != 0)) {
+          uint64_t ok2 = 0, missm = 0;
+          W::ballot2([&](int l) {
+            if (!((oddm >> l) & 1)) return 0;
+            FastEnt e;
+            if (fast_lookup(ent, mlv.at(l), e) < 0) return 2;
+            const int32_t sz[4] = {z0[j].at(l), z1[j].at(l), z2[j].at(l), z3[j].at(l)};
+            return fast_fits(pool, e, ns.req, sz) ? 1 : 0;
+          }, ok2, missm);
+          accm |= ok2;
+          bad |= (uint32_t)(missm != 0);
+        }
+        accw[j] = accm;
+      }
+      if (KS_UNLIKELY(bad != 0)) break;
+      // ---- nothing has been written so far; from here on the step is the plain one ----
+      {
+        // The order: lanes first_ok+1 .. first_ok+sm (the claims with a smaller count) step one position to the left, the claim
+        // lands behind them with its new count — lane first_ok writes that entry, and the claim's record: its state (the lane
+        // computed it for the claim it read) and the acceptance words.
+        const int rb = (int)rc0, fo = first_ok, smv = sm;
+        W::each([&](int l) {
+          if (l >= fo && l <= fo + smv) {
+            const bool me = l == fo;
+            const int dst = me ? rb + l + smv : rb + l - 1;
+            okey[dst] = (uint16_t)(me ? kv.at(l) + 1u : kv.at(l)); oord[dst] = (uint16_t)xv.at(l);
+          }
+        });
+        W::each([&](int l) {
+          if (l == fo) {
+            FastClaim mine;
+            mine.vmask = nmv.at(l); mine.req[0] = n0v.at(l); mine.req[1] = n1v.at(l); mine.req[2] = n2v.at(l); mine.req[3] = n3v.at(l);
+            cst.put_state(xv.at(l), mine);
+#pragma unroll
+            for (int j = 0; j < R; ++j) cst.put_acc(xv.at(l), j, accw[j]);
+          }
+        });
+      }
+      {
+        // cursors in (a, a+sm] step left; the pod's result; the class's cursor comes to a; its slot is free after its last entry
+        const uint32_t ua1 = (uint32_t)a + 1u, su = (uint32_t)sm;
+        const uint32_t lastm = (uint32_t)((int32_t)clsw >> 31);   // all ones on the class's last entry (kFastLastBit is the sign bit)
+        const int bb = bi;
+        W::each([&](int l) {
+          const bool mine = l == bb;
+          oclaim.at(l) = mine ? (uint32_t)x : oclaim.at(l); ocnt.at(l) = mine ? cnt : ocnt.at(l);
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            const bool me = j * 64 + l == slot;
+            const uint32_t fm = me ? lastm : 0u;
+            const uint32_t rr = cur[j].at(l);
+            cur[j].at(l) = me ? (uint32_t)a : rr - (uint32_t)((rr - ua1) < su);
+            scls[j].at(l) |= fm; tok[j].at(l) &= ~fm;
+          }
+        });
+      }
+      n_ref += (unsigned long long)((uint32_t)a + 1u);
+      W::sync();
+      bi++; steps++;
+    }
+    if (bi < bf || bf < bn) break;          // a pod the loop does not place / the block's last entry is not the loop's
+    // ---- the block is done: its results, the next block ----
+    if (bn > 0) {
+      const int dn = bn, b0 = base;
+      W::each([&](int l) { if (l < dn) { gqclaim[b0 + l] = oclaim.at(l); gqcnt[b0 + l] = ocnt.at(l); } });
+    }
+    const int nbase = bn > 0 ? base + 64 : base;
+    if (nbase >= np || (polled && (nbase & 1023) == 0)) break;   // the end of the queue, a block at which the cancel flag is polled: fast_slow_run
+    base = nbase;
+    bn = np - base < 64 ? np - base : 64;
+    bi = 0;
+    const int nb = base + 64;
+    W::each([&](int l) { bcls.at(l) = nxt_cls.at(l); });
+    W::each([&](int l) { if (nb + l < np) nxt_cls.at(l) = gqcls[nb + l]; });
+  }
+  // ---- state out (only what this function changes) ----
+  if (bi != bi_in || base != base_in) {
+    if (W::leader()) { hs->base = base; hs->bi = bi; hs->bn = bn; hs->steps = steps; hs->n_ref = n_ref; }
+    W::each([&](int l) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) { hs->cur[j][l] = cur[j].at(l); hs->scls[j][l] = scls[j].at(l); }
+      hs->nxt_cls[l] = nxt_cls.at(l); hs->bcls[l] = bcls.at(l); hs->oclaim[l] = oclaim.at(l); hs->ocnt[l] = ocnt.at(l);
+    });
+    W::sync();
+  }
+  return FEV_SLOW;
 }
 
 // The driver: runs the loop, handles its events through FastCold.
@@ -1146,8 +1382,11 @@ struct FastEngine {
     cx.aslot = cold.aslot; cx.hs = hs;
     unsigned long long tev[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = W::clock();
+    const bool use_fast = fast_uniform(h->max_steps) < 0;   // (a step limit — tests — is counted by the general loop)
     for (;;) {
-      const int ev = fast_uniform(fast_hot_run<W, GS, R>(cx));
+      int ev = use_fast ? fast_uniform(fast_hot_run<W, GS, R>(cx)) : (int)FEV_SLOW;
+      if (ev == FEV_SLOW) ev = fast_uniform(fast_slow_run<W, GS, R>(cx, use_fast ? 1 : 0x7FFFFFFF));
+      if (ev == FEV_CONT) continue;
       if (ev == FEV_DONE) break;
       const unsigned long long te0 = W::clock();
       if (ev == FEV_REFRESH) {

@@ -1,0 +1,36 @@
+# round 5, GPU pass B: the cursor engine's new loop (exact acceptance words per claim, refreshed lane = class slot after every commit):
+# pins on the three memory plans, a reduced bench line, kernel stats
+set -x
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r5b; mkdir -p $O
+export TMPDIR=/tmp
+for pin in config1_p5000_t50_s42 config2_p200000_t500_s42 config2_p1000000_t500_s42 config4_p1000000_t1000_s42_x16; do
+  for eng in auto cursor-wide cursor-hbm; do timeout 300 python tests/tools/gpu_check_pin.py tests/golden/fullsize/$pin.json $eng 2>&1 | tail -1 | tee -a $O/pins.log; done
+done
+timeout 300 python tests/tools/gpu_check_pin.py tests/golden/fullsize/config2_p2000000_t500_s42.json auto 2>&1 | tail -1 | tee -a $O/pins.log
+timeout 900 python bench.py --steps 5 --topology-pods 0 --components-pods 0 --beyond-lds-pods 0 --whole-batch-exact-pods 0 --whole-batch-pods 0 --batch-problems 0 --sweep-nodes 0 --no-cpu-baseline 2>$O/bench_reduced.err | tail -1 > $O/bench_reduced.json
+tail -3 $O/bench_reduced.err
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r5b/bench_reduced.json"))
+print("value", d["value"], "ms_per_step", d["ms_per_step"], "host engine", d.get("cpu_baseline_engine_host"))
+print("pack", d.get("pack_kernel"))
+PY
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "edge or cursor or batch or full_size" 2>&1 | tail -5 | tee $O/pytest_subset.log
+# SQ counters of the pack kernel (instructions per pod, wait share)
+HEAD="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --topology-pods 0 --batch-problems 0 --components-pods 0 --beyond-lds-pods 0 --whole-batch-exact-pods 0 --whole-batch-pods 0 --sweep-nodes 0 --no-host-engine-baseline --no-cpu-baseline"
+(cd /tmp && timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_sq -o sq -- $HEAD > $GRAFT_REPO_ROOT/$O/pmc_sq.log 2>&1)
+(cd /tmp && timeout 400 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_ANY --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_sq2 -o sq -- $HEAD > $GRAFT_REPO_ROOT/$O/pmc_sq2.log 2>&1)
+python - <<'PY'
+import csv, glob, collections
+acc = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob("gpurun_out/r5b/pmc_sq*/**/*counter_collection*.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "pack_fast" in r["Kernel_Name"]:
+            a = acc[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+print({k: round(v[0] / v[1]) for k, v in acc.items()})
+PY
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_head -o bench -- $HEAD > $GRAFT_REPO_ROOT/$O/stats_head.log 2>&1)
+find $O/stats_head -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} cp {} $O/rocprofv3_kernel_stats_bench_1m.csv
+cut -c1-160 $O/rocprofv3_kernel_stats_bench_1m.csv | head -6
+rm -rf $O/pmc_sq $O/pmc_sq2 $O/stats_head
