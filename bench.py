@@ -137,6 +137,10 @@ def config4_sweep(args, device_index, rank, world, topology=False):
                              "with_descriptors_and_verdicts": len(cands) / lib_s, "through_python": len(cands) / dt},
                timed_region="ksched_sweep_arrays() (the faster of it and ksched_sweep(), the JSON form: library_call_json_form_s): probe descriptors (host library), ksolve_sweep (upload, one launch, finalize, download), verdicts")
     out["kernels"] = sweep_rooflines(tm, len(cands))
+    if world == 1 and not args.no_parity_pin:
+        # population-scale pin: the oracle's verdicts of a stratified 1,000 of these probes, made offline (tests/golden/make_sweep_pins.py)
+        out["oracle_pin"] = sweep_pin_check("single-topology" if topology else "single", args.sweep_nodes, len(cands),
+                                            lambda j: (cmds[j]["decision"], cmds[j]["replacement"], cmds[j].get("replacementCapacityType"), rc.last_sweep["referenceBinEvaluations"][j]))
     if n_sample > 0 and rank == 0:
         import random
         import oracle   # the checker: re-simulates sampled probes; its rate is this leg's CPU baseline
@@ -171,11 +175,38 @@ def config4_sweep(args, device_index, rank, world, topology=False):
     return out
 
 
+def sweep_pin_check(leg, nodes, n_swept, verdict_at):
+    """The device's verdicts of the probes a committed sweep pin samples (tests/golden/sweeps/<leg>_n<nodes>_s42.json: the oracle's
+    simulation AND decision of ~1,000 stratified probes, one sha256) against that pin. verdict_at(position) -> (decision,
+    replacement instance types, capacity type, reference bin evaluations) of the probe at `position` of this sweep. None when no pin
+    matches this sweep's shape; a mismatch stops the run."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_sweep_pins as msp
+    path = msp.pin_path(leg, nodes)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        g = json.load(f)
+    if leg != "multi" and g.get("swept_candidates") != n_swept:
+        return None
+    keys = []
+    for pos in g["positions"]:
+        d, rep, ct, ev = verdict_at(tuple(pos) if isinstance(pos, list) else pos)
+        keys.append(msp.probe_key(d, rep, ct, ev))
+    ok = msp.digest_of(keys) == g["digest"]
+    if not ok:
+        bad = [pos for pos, a, b in zip(g["positions"], keys, g["keys"]) if a != b]
+        raise SystemExit(f"bench.py: the configs[4] {leg} sweep differs from the oracle's pin at {len(bad)} of {len(keys)} probes (first: {bad[:3]})")
+    return {"pin": os.path.relpath(path, ROOT), "probes": len(keys), "by_decision": g["decisions"], "digest_matches_oracle": True,
+            "oracle_seconds_offline": g["oracleSeconds"], "oracle_threads": g["oracleThreads"],
+            "compared": "per probe: decision, replacement instance types, capacity type, reference bin evaluations (the oracle's own simulation and computeConsolidation); one sha256 over the sample"}
+
+
 def sweep_rooflines(tm, n_probes):
     """The two kernels of the consolidation path that fill the chip, with the bytes their algorithm has to move:
     ksolve_pack_sweep — per displaced pod its class record and outputs, per 4096-node step of an existing-node scan 512 B of
     the class's rejection row, per node / NodeClaim actually evaluated its record; ksolve_node_dead0 — the node tables once,
-    one bit per (class, node) out. `traffic` = measured HBM bytes of the same kernels (profiles/round4/pmc_traffic.json, when
+    one bit per (class, node) out. `traffic` = measured HBM bytes of the same kernels (profiles/round5/pmc_traffic.json, when
     it was taken on this build)."""
     rw, nr, iw = tm.get("req_words", 0), tm.get("resources", 0), tm.get("it_words", 0)
     if not rw:
@@ -188,7 +219,7 @@ def sweep_rooflines(tm, n_probes):
     alg = tm["pods"] * (b_cls + b_out) + tm["node_block_steps"] * 512 + tm["node_evaluations"] * b_node + claim_evals * 2 * b_claim
     pmc = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "round4", "pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "round5", "pmc_traffic.json")) as f:
             doc = json.load(f)
         if doc.get("source_sha") == source_sha():
             pmc = doc.get("sweep_kernels", {})
@@ -261,6 +292,10 @@ def config4_multi_node(args, cc, rc, rank, world):
                seconds={"descriptors": tm["descriptors_ms"] * 1e-3, "upload": tm["upload_us"] * 1e-6, "pack_kernel": tm["pack_us"] * 1e-6, "finalize": tm["finalize_us"] * 1e-6,
                         "download": tm["download_us"] * 1e-6, "verdicts": tm["verdicts_ms"] * 1e-3, "library_call": lib_s, "python_call": dt},
                value=len(sets) / lib_s, unit="probes/s", pods_placed_per_s=tm["pods"] / lib_s, windows_per_s=len(mine) / lib_s)
+    if world == 1 and not args.no_parity_pin and n_windows == 32 and K == 101:
+        pos_of = {kk: j for j, kk in enumerate(key)}
+        out["oracle_pin"] = sweep_pin_check("multi", args.sweep_nodes, None,
+                                            lambda wk: (by[wk]["decision"], by[wk]["replacement"], by[wk].get("replacementCapacityType"), rc.last_sweep["referenceBinEvaluations"][pos_of[wk]]))
     if args.sweep_sample > 0 and rank == 0:
         import oracle
         picks = sorted({(mine[0], 2), (mine[0], 7), (mine[len(mine) // 2], 23), (mine[-1], min(K, 60)), (mine[-1], K)} & set(key))
@@ -301,7 +336,7 @@ def main():
     ap.add_argument("--pods", type=int, default=1_000_000, help="pods per GPU (configs[1] = 1M)")
     ap.add_argument("--types", type=int, default=500)
     ap.add_argument("--cpu-sample", type=int, default=120_000, help="pods in the bounded cpu_baseline sample (about 10-30 s of one core with the round-4 oracle)")
-    ap.add_argument("--cpu-runs", type=int, default=1, help="oracle runs of the sample (median reported)")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="oracle runs of the sample (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-engine-baseline", action="store_true", help="skip timing the engine's own source compiled for one host core")
     ap.add_argument("--topology-pods", type=int, default=1_000_000, help="BASELINE configs[2] shape (anti-affinity + 3-zone spread) reported beside the headline, 0 = skip")
@@ -620,14 +655,20 @@ def main():
     # separate passes, --kernel-trace only; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes) on this workload and
     # written to profiles/round3/pmc_traffic.json together with a hash of the kernel sources. A figure is used only for the build
     # it was measured on: after any change of the sources it reads null until the script has run again.
-    traffic, stream_traffic, traffic_note = None, None, "not measured for this build (scripts/gpu_pmc_traffic.sh)"
+    traffic, stream_traffic, traffic_note, sq = None, None, "not measured for this build (scripts/gpu_r5_pmc.sh)", None
     try:
-        with open(os.path.join(ROOT, "profiles", "round4", "pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "round5", "pmc_traffic.json")) as f:
             pmc = json.load(f)
         if pmc.get("source_sha") == source_sha() and pmc.get("pods") == args.pods and pmc.get("types") == args.types:
             traffic = pmc["kernels"].get(kernel, {}).get("traffic_bytes_per_launch")
             stream_traffic = pmc["kernels"].get("ksolve_row_hash_coop2", {}).get("traffic_bytes_per_launch")
-            traffic_note = "TCC FETCH_SIZE x2 + WRITE_SIZE per launch, rocprofv3 --pmc on this build (profiles/round4/pmc_traffic.json)"
+            traffic_note = "TCC FETCH_SIZE x2 + WRITE_SIZE per launch, rocprofv3 --pmc on this build (profiles/round5/pmc_traffic.json)"
+            k = pmc["kernels"].get(kernel, {})
+            if "SQ_INSTS_VALU" in k:
+                per = lambda name: k[name]["per_launch"] / args.pods if name in k else None
+                sq = {"waves": k.get("SQ_WAVES", {}).get("per_launch"), "valu_per_pod": per("SQ_INSTS_VALU"), "salu_per_pod": per("SQ_INSTS_SALU"), "lds_per_pod": per("SQ_INSTS_LDS"),
+                      "wave_cycles_per_pod": 4 * per("SQ_WAVE_CYCLES") if per("SQ_WAVE_CYCLES") else None, "wait_cycles_per_pod": 4 * per("SQ_WAIT_ANY") if per("SQ_WAIT_ANY") else None,
+                      "note": "SQ_WAVE_CYCLES / SQ_WAIT_ANY count in units of four shader cycles"}
     except (OSError, KeyError, ValueError):
         pass
     pin = None
@@ -670,7 +711,9 @@ def main():
                              "the table of the headline problem (220 MB) is smaller than the 256 MiB Infinity Cache — profiles/round4/classing_rows.json has the same kernel at 2M and 4M rows"},
         # The pack kernel is a serial first-fit chain on ONE wavefront: bound by the instruction issue and the dependent LDS round
         # trips of a lone wave, not by HBM — no roofline is claimed for it. `achieved` is what it really moves.
-        "pack_kernel": {"kernel": kernel, "bound": "latency / instruction issue of one wavefront", "avg_kernel_ms": pack_ms, "traffic": traffic, "traffic_source": traffic_note,
+        # sq_counters: instructions and wave cycles per pod of THIS build's pack kernel (rocprofv3 --pmc SQ_*, profiles/round5/pmc_traffic.json),
+        # null when the sources changed since they were measured.
+        "pack_kernel": {"kernel": kernel, "bound": "latency / instruction issue of one wavefront", "avg_kernel_ms": pack_ms, "us_per_pod": pack_ms * 1e3 / max(1, args.pods), "sq_counters": sq, "traffic": traffic, "traffic_source": traffic_note,
                         "achieved": (traffic / (pack_ms * 1e-3) / 1e9) if traffic else None, "unit": "GB/s",
                         "reference_equivalent": {"bytes": abytes, "GBps": achieved, "frac_of_hbm_peak": achieved / HBM_PEAK_GBS, "records": rec,
                                                  "note": "SURVEY §8(d) formula P*B_pod + V*B_bin + P*B_bin + N_it*T*B_it with V = the bins the REFERENCE evaluates (referenceBinEvaluations, equal to the "
@@ -801,6 +844,12 @@ def main():
                                          f"median of {len(runs)} runs ({secs:.2f} s); the oracle is O(pods x claims), so its rate falls with size "
                                          f"(offline at the full 1M pods: see parity.oracle_pin.oracle_seconds_offline)",
                                "seconds": secs, "runs_seconds": runs, "bin_evaluations": r["counters"]["binEvaluations"]}
+        # like for like: the same oracle on the HEADLINE problem itself (all args.pods pods), timed offline when its pin was made —
+        # the oracle walks every in-flight claim for every pod, O(pods x claims), so its rate at the full size is far below the sample's
+        if pin is not None and pin.get("oracle_seconds_offline"):
+            out["cpu_baseline_full_size"] = {"value": args.pods / pin["oracle_seconds_offline"], "unit": "pods/s", "cores": 1, "kind": "port", "seconds": pin["oracle_seconds_offline"],
+                                             "sample": f"the whole timed problem ({args.pods} pods), one run, offline (tests/golden/make_fullsize_digests.py; the pin's oracleSeconds): "
+                                                       "O(pods x claims) — 1.0e9 bin evaluations at 1M pods"}
         # (An N-thread form of the oracle exists — ORACLE_THREADS: the candidates of one addToInflightNode call over a worker pool, as
         # parallelizeUntil does, scheduler.go:939-961 — and is not reported: at this mix a scan is a few dozen candidates and the
         # fan-out costs more than it saves; rounds 3 and 4 measured 1.00x on 64 cores and 0.75x on 6.)
@@ -818,7 +867,8 @@ def main():
                     re_ = se.Solve(want_results=False)
                     eb[eng] = {"pack_seconds": re_["timings"][0]["pack_kernel_ms"] * 1e-3, "pods_per_s": args.pods / (re_["timings"][0]["pack_kernel_ms"] * 1e-3)}
                     se.close()
-                out["cpu_baseline_engine_host"] = {"cores": 1, "kind": "this repository's engine source on one host core (test emulation of the device code)", "pods": args.pods, "engines": eb}
+                out["cpu_baseline_engine_host"] = {"cores": 1, "kind": "this repository's engine source on one host core (test emulation of the device code: a wave-wide operation is a loop over 64 lanes there)", "pods": args.pods, "engines": eb,
+                                                   "device_over_host_pack": (args.pods / (pack_ms * 1e-3)) / eb["cursor"]["pods_per_s"] if c.get("engine") == "cursor" else None}
             except Exception as e:  # noqa: BLE001 - a missing host compiler must not lose the measurement
                 out["cpu_baseline_engine_host"] = {"error": str(e)[:200]}
     if args.solver_lib:

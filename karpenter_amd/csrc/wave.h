@@ -42,6 +42,10 @@ struct Wave {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+  // Compiler-only ordering of this wavefront's memory accesses: nothing is emitted and nothing is waited for. Enough between a
+  // store and a later load of the SAME memory (LDS, or one wavefront's plain global accesses): the hardware keeps a wavefront's
+  // accesses to one memory in order.
+  KS_DEV static void order() { asm volatile("" ::: "memory"); }
   template <class F>
   KS_DEV static uint64_t ballot(F f) { return __builtin_amdgcn_ballot_w64((bool)f(lane())); }   // (the builtin on a bool: the compare itself writes the mask; __ballot(int) materialises 0 / 1 in a VGPR and compares again)
   // four ballots from ONE evaluation of f(lane) (bits 0..3 of its result): the loads behind the predicates happen once
@@ -229,6 +233,7 @@ struct Wave {
   static int lane() { return 0; }
   static uint64_t uniform(uint64_t v) { return v; }
   static void sync() {}
+  static void order() {}
   template <class F>
   static uint64_t ballot(F f) {
     uint64_t m = 0;

@@ -415,6 +415,35 @@ def test_full_size_digest(pin):
             assert r["counters"]["engine"] == "cursor" and r["counters"]["cursorMemoryPlan"] == (1 if eng == "cursor-wide" else 2), r["counters"]
 
 
+def test_the_headline_problem_one_hundred_times():
+    """The timed problem of bench.py (BASELINE configs[1], 1M pods x 500 types) solved 100 times on one handle: every run must place
+    every pod on the same NodeClaim in the same slot and report the same NodeClaims, and the first run's Results must carry the
+    digest of the oracle's 1M pin. (Round-4 review: a kernel whose steps overlap — this round's fast loop issues the next pod's
+    reads before the current pod's last write — has to show that nothing depends on timing.)"""
+    import hashlib
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_fullsize_digests import build_problem
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize", "config2_p1000000_t500_s42.json")))
+    prob = build_problem(g["config"], g["pods"], g["types"], g["seed"], g["extra"])
+    s = NewScheduler(prob)
+    full = s.Solve()
+    digest, _ = parity.results_digest(full)
+    assert digest == g["digest"] and full["counters"]["referenceBinEvaluations"] == g["binEvaluations"]
+    seen = set()
+    for _ in range(100):
+        r = s.Solve(want_results="claims")
+        assign, slot = s.Assignment()
+        h = hashlib.sha256()
+        h.update(assign.tobytes()); h.update(slot.tobytes())
+        h.update(json.dumps([[c["nodePool"], c["instanceTypes"], c["requirements"], c["requests"], c["cheapestPrice"]] for c in r["newNodeClaims"]], sort_keys=True).encode())
+        h.update(str(r["counters"]["referenceBinEvaluations"]).encode())
+        seen.add(h.hexdigest())
+    s.close()
+    assert len(seen) == 1, f"{len(seen)} different answers in 100 solves of one problem"
+
+
 def test_offering_override_groups_on_the_device(oracle):
     """Offering capacity / overhead override groups (types.go:202-269, nodeclaim.go:624-638) on the GPU: the reference's
     two known answers (suite_test.go:5524-5607), the group semantics and the seeded fuzz of tests/test_device_algorithm.py,
