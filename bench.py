@@ -468,20 +468,22 @@ def main():
 
     # ---- BASELINE configs[3] (all ranks take part): 10M pods x 1k instance types x 16 NodePools. Every pod pins its NodePool, so the
     # batch falls into 16 components (karpenter_amd/components.py) that cannot share a claim; each is solved EXACTLY as its own
-    # problem. One GPU: all components in one launch (one wavefront each). N GPUs: component c goes to rank c % N, every rank runs
+    # problem. One GPU: all components in one launch (one wavefront each). N GPUs: the components are dealt over the ranks by pod count (LPT, in the host library), every rank runs
     # its components in one launch, and the per-instance-type (NodeClaim count, $/h) vectors are summed with ONE all-reduce — the
     # north_star's global packing summary. The union is a packing of equal quality, not the reference's pod-for-pod answer for the
     # whole batch (the reference re-sorts ALL claims before every scan, scheduler.go:598): L2-canonical, see `calibration`.
     comp = None
     if args.components_pods > 0:
-        from karpenter_amd.components import split_by_nodepool
+        from karpenter_amd.components import split_components
         from karpenter_amd.scheduling import SolveBatch
         import numpy as np
 
         def solve_components(pods, repeat, want_results=False, shard=True):
             whole = fx.config4(pods=pods, n_types=args.components_types, n_pools=16, seed=42)
-            parts = split_by_nodepool(whole)
-            mine = [pt for i, pt in enumerate(parts) if not shard or i % world == rank]
+            # the host library's split (ksched_split_components: union-find over NodePool pins and topology selectors) and its deal of
+            # the components over the ranks by pod count, largest first (LPT) — the same call a Go controller makes
+            parts, bins = split_components(whole, bins=world if shard else 1)
+            mine = [parts[i] for i in (bins[rank] if shard else range(len(parts)))]
             scheds = [NewScheduler(dict(sub, options=dict(sub["options"], device=device_index)), solver_lib=args.solver_lib) for _, sub in mine]
             best, rs = None, []
             for _ in range(repeat):
@@ -530,7 +532,7 @@ def main():
         if rank == 0:
             nzc = cvec[:, 0] > 0
             comp = {"workload": f"BASELINE configs[3]: {args.components_pods} pods x {args.components_types} types x 16 NodePools, every pod pinned to its pool",
-                    "components": len(parts), "ranks": world, "sharding": "component c -> rank c % N, one batched launch per rank" if world > 1 else "all components in one launch on one GPU",
+                    "components": len(parts), "ranks": world, "sharding": "components dealt over the ranks by pod count, largest first (ksched_split_components), one batched launch per rank" if world > 1 else "all components in one launch on one GPU",
                     "pods": int(round(totals[0])), "seconds": dt, "value": totals[0] / dt, "unit": "pods/s",
                     "timed_region": "ksolve_solve_batch(): classing, queue sort, pack, finalize, download of the flat C-ABI Results of every component (+ ksolve_packing_vector per component)",
                     "node_claims": int(round(totals[1])), "packing_cost_per_hour": totals[2], "pack_kernel_ms": totals[3], "engines": engines,

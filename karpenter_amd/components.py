@@ -98,7 +98,21 @@ def _pinned_pools(p, pools):
     return allowed or None
 
 
-def split_components(problem):
+def split_components(problem, bins=None):
+    """The host library's split (ksched_split_components in karpenter_amd/host/ksched.cpp — what a Go controller calls through
+    go/ksolve_components.go): [(tuple of pool names, sub-problem)] in NodePool order, or None when independence cannot be shown.
+    With `bins` = N also the deal of the components over N devices: ([(pools, sub-problem)], [[component index] per device]),
+    components by pod count, largest first, each to the device with the fewest pods so far (LPT). `split_components_reference`
+    below is the same rule in Python, kept as the cross-check of tests/test_components.py."""
+    from .scheduling import SplitComponents
+    out = SplitComponents(problem, bins or 1)
+    if out["components"] is None:
+        return None
+    parts = [(tuple(c["pools"]), c["problem"]) for c in out["components"]]
+    return parts if bins is None else (parts, out["bins"])
+
+
+def split_components_reference(problem):
     """Connected components of the pods x NodePools graph: two NodePools are in one component when some
     pod may land on either, or when a topology group owned by a pod of one (spread constraint, pod affinity / anti-affinity
     term) selects a pod of the other — the group's domain counts move with every selected pod that is placed

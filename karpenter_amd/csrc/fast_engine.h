@@ -42,6 +42,8 @@ constexpr int kFastEnt = 1024;        // requirement-set cache slots (open addre
 constexpr int kFastPool = 256;        // extra Pareto vectors
 constexpr int kFastMaxPareto = 16;    // per requirement set
 constexpr int kFastMaxVar = 12;       // keys pods select on
+constexpr uint64_t kFastExtBit = 1ull << 63;   // FastEnt::vmask of an entry with further Pareto vectors (template ids are < 32: the bit is free): "the slot's key equals the set"
+                                                // is then false in the loops' one-compare test, and the entry is read the long way (fast_lookup + fast_fits)
 constexpr int kFastVarBits = 56;      // their dictionary values + one guard bit each must fit 56 bits; the top byte of vmask is the template
 
 struct FastClaim { uint64_t vmask; int32_t req[4]; };                                   // 24 B: a claim's state (requirement set, requests)
@@ -252,7 +254,7 @@ KS_FN int fast_lookup(const KS_LDS FastEnt* ent, uint64_t vm, FastEnt& out) {
   for (int probe = 0; probe < kFastEnt; ++probe) {
     out = lds_get(&ent[h]);
     if (!(out.info & 1u)) return -1;
-    if (out.vmask == vm) return (int)h;
+    if ((out.vmask & ~kFastExtBit) == vm) return (int)h;
     h = (h + 1) & (kFastEnt - 1);
   }
   return -1;
@@ -435,7 +437,7 @@ struct FastCold {
     }
     if (W::leader()) {
       FastEnt e;
-      e.vmask = vm; e.cap[0] = f0; e.cap[1] = f1; e.cap[2] = f2; e.cap[3] = f3;
+      e.vmask = count > 1 ? (vm | kFastExtBit) : vm; e.cap[0] = f0; e.cap[1] = f1; e.cap[2] = f2; e.cap[3] = f3;
       e.info = 1u | ((uint32_t)(count > 1 ? count - 1 : 0) << 8) | ((uint32_t)poff << 16);
       e.pad = 0;
       lds_put(&ent[h], e);
@@ -1194,10 +1196,20 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
   // on this pod's writes to the order and on the cursors, both done before the cache read is waited for. So a step issues, in
   // this order: its record reads | its order writes | its cache reads | the NEXT pod's order reads | its record write. The
   // LDS executes a wavefront's accesses in order, so the next pod's record reads (first thing of the next step) see that write.
+  unsigned long long n_ext = 0;   // four-window steps of scans beyond a cursor's window
   int rf = -1;              // a claim whose refresh met a requirement set that is not cached: the driver computes its words
   LaneVar<uint32_t> xv, kv; // the order's entries of the pod about to be placed: claim id and pod count at positions rc0 + lane
   uint32_t clsw = 0, rc0 = 0, badA = 0;
   int row = 0, sl = 0;
+  // the order's 64 entries at positions rr .. rr+63 (n >= 1 here)
+  auto order_reads = [&](uint32_t rr) {
+    W::each([&](int l) {
+      const int p = (int)rr + l;
+      int pc = p < nm1 ? p : nm1; pc = pc < 0 ? 0 : pc;   // clamped: no lane is switched off for the reads (a cursor at the end of the order: no lane is valid)
+      const uint32_t kk = okey[pc];
+      xv.at(l) = oord[pc]; kv.at(l) = p < n ? kk : 0xFFFFFFFFu;
+    });
+  };
   // stage A of entry i: its class slot, the class's cursor, the order's 64 entries there
   auto stage_a = [&](int i) {
     clsw = bcls.bcast(i & 63);
@@ -1220,13 +1232,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
     rc0 = cur[0].bcast(sl);
 #pragma unroll
     for (int j = 1; j < R; ++j) { const uint32_t cj = cur[j].bcast(sl); rc0 = row == j ? cj : rc0; }
-    const uint32_t rr = rc0;
-    W::each([&](int l) {
-      const int p = (int)rr + l;
-      int pc = p < nm1 ? p : nm1; pc = pc < 0 ? 0 : pc;   // clamped: no lane is switched off for the reads (a cursor at the end of the order: no lane is valid)
-      const uint32_t kk = okey[pc];
-      xv.at(l) = oord[pc]; kv.at(l) = p < n ? kk : 0xFFFFFFFFu;
-    });
+    order_reads(rc0);
   };
   for (;;) {   // blocks of the queue
     // entries of this block the loop may place: not the queue's last one, nor the last one before a block at which the cancel flag
@@ -1245,18 +1251,49 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       LaneVar<uint64_t> mvv;
       LaneVar<int32_t> q0, q1, q2, q3;
       const uint64_t slbit = 1ull << sl;
-      const uint32_t rcs = rc0;
       const int rws = row;
-      const uint64_t okm = W::ballot([&](int l) {
-        const uint64_t want = (int)rcs + l < n ? slbit : 0ull;
-        const FastRec<R> st = cst.rec(xv.at(l));
-        uint64_t aw = st.acc[0];
+      auto select = [&]() {
+        const uint32_t rcs = rc0;
+        return W::ballot([&](int l) {
+          const uint64_t want = (int)rcs + l < n ? slbit : 0ull;
+          const FastRec<R> st = cst.rec(xv.at(l));
+          uint64_t aw = st.acc[0];
 #pragma unroll
-        for (int j = 1; j < R; ++j) aw = rws == j ? st.acc[j] : aw;
-        q0.at(l) = st.req[0]; q1.at(l) = st.req[1]; q2.at(l) = st.req[2]; q3.at(l) = st.req[3];
-        mvv.at(l) = st.vmask;
-        return (aw & want) != 0;
-      });
+          for (int j = 1; j < R; ++j) aw = rws == j ? st.acc[j] : aw;
+          q0.at(l) = st.req[0]; q1.at(l) = st.req[1]; q2.at(l) = st.req[2]; q3.at(l) = st.req[3];
+          mvv.at(l) = st.vmask;
+          return (aw & want) != 0;
+        });
+      };
+      uint64_t okm = select();
+      if (KS_UNLIKELY((okm == 0) & (badA == 0) & ((int)rc0 + 64 < n))) {
+        // The class's next acceptor is not among the 64 claims at its cursor (the claim it was filling is full): the rest of the
+        // order, four windows per step, acceptance words only, all eight reads of a step in flight before the first is used;
+        // then the select step once more, at the window that holds it.
+        int r = (int)rc0 + 64, found = -1;
+        while (r < n && found < 0) {
+          uint64_t m4[4];
+          LaneVar<uint32_t> x4[4];
+          W::each([&](int l) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int p = r + 64 * j + l; x4[j].at(l) = oord[p < nm1 ? p : nm1]; }
+          });
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int rj = r + 64 * j;
+            m4[j] = W::ballot([&](int l) { return ((cst.acc(x4[j].at(l), rws) & slbit) != 0) & (rj + l < n); });
+          }
+          n_ext++;
+#pragma unroll
+          for (int j = 3; j >= 0; --j) found = m4[j] != 0 ? r + 64 * j : found;
+          r += 256;
+        }
+        if (found >= 0) {     // (none: no in-flight claim accepts the pod — addToNewNodeClaim, through fast_slow_run)
+          rc0 = (uint32_t)found;
+          order_reads(rc0);
+          okm = select();
+        }
+      }
       bad |= (uint32_t)(okm == 0);
       const int first_ok = ctz64(okm | (1ull << 63));
       const int a = (int)rc0 + first_ok;
@@ -1326,13 +1363,12 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       const uint32_t tbit = 1u << (uint32_t)(ns.vmask >> 56);
       LaneVar<uint64_t> mlv[R], evm[R];
       LaneVar<int32_t> c0[R], c1[R], c2[R], c3[R];
-      LaneVar<uint32_t> einfo[R];
       W::each([&](int l) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
           const uint64_t m = ns.vmask & cvm[j].at(l);
           const FastEnt e = lds_get16(&ent[fast_hash(m)]);
-          mlv[j].at(l) = m; evm[j].at(l) = e.vmask; einfo[j].at(l) = e.info;
+          mlv[j].at(l) = m; evm[j].at(l) = e.vmask;
           c0[j].at(l) = e.cap[0]; c1[j].at(l) = e.cap[1]; c2[j].at(l) = e.cap[2]; c3[j].at(l) = e.cap[3];
         }
       });
@@ -1347,10 +1383,9 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
         const uint64_t f1 = W::ballot([&](int l) { return z1[j].at(l) <= c1[j].at(l) - ns.req[1]; });
         const uint64_t f2 = W::ballot([&](int l) { return z2[j].at(l) <= c2[j].at(l) - ns.req[2]; });
         const uint64_t f3 = W::ballot([&](int l) { return z3[j].at(l) <= c3[j].at(l) - ns.req[3]; });
-        const uint64_t extm = W::ballot([&](int l) { return (einfo[j].at(l) & 0xFF00u) != 0; });
         const uint64_t basem = tokm & fldm, fitm = f0 & f1 & f2 & f3;
         uint64_t accm = basem & simm & fitm;
-        const uint64_t oddm = basem & (~simm | (~fitm & extm));   // set not at its first probe / not cached / further Pareto vectors
+        const uint64_t oddm = basem & ~simm;   // set not at its first probe / not cached / an entry with further Pareto vectors (kFastExtBit)
         if (KS_UNLIKELY(oddm != 0)) {
           uint64_t ok2 = 0, missm = 0;
           W::ballot2([&](int l) {
@@ -1396,7 +1431,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
   }
   // ---- state out (only what this function changes) ----
   if (bi != bi_in || base != base_in) {
-    if (W::leader()) { hs->base = base; hs->bi = bi; hs->bn = bn; hs->steps = steps; hs->n_ref = n_ref; hs->rf_x = rf; }
+    if (W::leader()) { hs->base = base; hs->bi = bi; hs->bn = bn; hs->steps = steps; hs->n_ref = n_ref; hs->rf_x = rf; hs->n_steps += 4 * n_ext; }
     W::each([&](int l) {
 #pragma unroll
       for (int j = 0; j < R; ++j) { hs->cur[j][l] = cur[j].at(l); hs->scls[j][l] = scls[j].at(l); }

@@ -17,6 +17,7 @@
 #include <climits>
 #include <chrono>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <unordered_map>
 #include <set>
@@ -2710,6 +2711,168 @@ extern "C" int ksched_solve_batch(void** sessions, int n, int want_results, char
 }
 
 // Convenience: open + solve (repeat times, last result returned with every run's timings) + close.
+// ---- NodePool components: the host-side split of one provisioning batch for several devices -----------------------
+// Two NodePools are in one component when some pod may land on either (its REQUIRED constraints on karpenter.sh/nodepool: a node
+// selector and/or every required node-affinity term carrying In [...] on that key — pkg/utils/nodepool/nodepool.go:161-171 orders the
+// pools, provisioner.go:293-297 hands all of them to one Scheduler), or when a topology group a pod of one owns (spread constraint,
+// pod affinity / anti-affinity term, topology.go:461-533) selects a pod of the other: its domain counts move with every selected pod
+// that is placed (topology.go:197-224). Returns {"components": [{"pools", "pods", "bin", "problem"}], "bins": [[component index]],
+// "binPods": [pods per bin]} — components in NodePool order, dealt over `n_bins` devices by pod count, largest first (LPT) — or
+// {"components": null, "reason"} when independence cannot be shown (existing nodes, cluster pods, reserved capacity, a pod that is not
+// provably pinned, a selector this code cannot evaluate). Each component is a packing problem of its own, solved bit-exactly as such;
+// the union is a packing of equal quality, NOT the reference's pod-for-pod answer for the whole batch.
+static const char* kNodePoolKey = "karpenter.sh/nodepool";
+struct SplitRefusal { std::string why; };
+static std::vector<int> split_pinned_pools(const Value& p, const std::vector<std::string>& names) {
+  auto idx = [&](const std::string& n) { for (size_t i = 0; i < names.size(); ++i) if (names[i] == n) return (int)i; return -1; };
+  bool have = false;
+  std::vector<char> allowed(names.size(), 0);
+  const Value& sel = p.at("nodeSelector").at(kNodePoolKey);
+  if (!sel.is_null()) { have = true; const int i = idx(sel.s()); if (i >= 0) allowed[(size_t)i] = 1; }
+  const auto& terms = p.at("nodeAffinity").at("required").items();
+  if (!terms.empty()) {
+    std::vector<char> uni(names.size(), 0);
+    bool pinned = true;
+    for (auto& term : terms) {
+      std::vector<char> in_all(names.size(), 1);
+      bool any = false;
+      for (auto& q : term.items()) if (q.at("key").s() == kNodePoolKey && q.at("operator").s() == "In") {
+        any = true;
+        std::vector<char> in(names.size(), 0);
+        for (auto& v : q.at("values").items()) { const int i = idx(v.s()); if (i >= 0) in[(size_t)i] = 1; }
+        for (size_t i = 0; i < names.size(); ++i) in_all[i] = in_all[i] && in[i];
+      }
+      if (!any) { pinned = false; break; }     // a term without the pin can reach any pool
+      for (size_t i = 0; i < names.size(); ++i) uni[i] = uni[i] || in_all[i];
+    }
+    if (pinned) {
+      if (!have) { allowed = uni; have = true; }
+      else for (size_t i = 0; i < names.size(); ++i) allowed[i] = allowed[i] && uni[i];
+    }
+  }
+  std::vector<int> out;
+  if (have) for (size_t i = 0; i < names.size(); ++i) if (allowed[i]) out.push_back((int)i);
+  return out;
+}
+struct SplitSelector { std::vector<std::string> namespaces; std::vector<std::pair<std::string, std::string>> match; };
+static bool split_selectors(const Value& p, std::vector<SplitSelector>& out) {   // false: a term this code cannot evaluate
+  const std::string ns = p.at("namespace").s("default");
+  for (auto& c : p.at("topologySpreadConstraints").items()) {
+    const Value& sel = c.at("labelSelector");
+    if (!sel.at("matchExpressions").items().empty()) return false;
+    SplitSelector s; s.namespaces = {ns};
+    for (auto& kv : sel.at("matchLabels").members()) s.match.push_back({kv.first, kv.second.s()});
+    out.push_back(s);
+  }
+  for (const char* field : {"podAffinity", "podAntiAffinity"}) {
+    const Value& aff = p.at(field);
+    std::vector<const Value*> terms;
+    for (auto& t : aff.at("required").items()) terms.push_back(&t);
+    for (auto& w : aff.at("preferred").items()) terms.push_back(&w.at("term"));
+    for (const Value* t : terms) {
+      const Value& sel = t->at("labelSelector");
+      if (!sel.at("matchExpressions").items().empty() || !t->at("namespaceSelector").is_null()) return false;
+      SplitSelector s;
+      for (auto& n : t->at("namespaces").items()) s.namespaces.push_back(n.s());
+      if (s.namespaces.empty()) s.namespaces = {ns};
+      for (auto& kv : sel.at("matchLabels").members()) s.match.push_back({kv.first, kv.second.s()});
+      out.push_back(s);
+    }
+  }
+  return true;
+}
+extern "C" char* ksched_split_components(const char* problem_json, int n_bins) {
+  try {
+    const Value prob = kj::Parser(problem_json).parse();
+    auto refuse = [](const std::string& why) { Value o = Value::object(); o.set("components", Value()); o.set("reason", Value::string(why)); return dup_json(o); };
+    if (!prob.at("stateNodes").items().empty()) return refuse("existing nodes are bins every NodePool's pods share");
+    if (!prob.at("clusterPods").items().empty()) return refuse("cluster pods: shared topology counts");
+    if (prob.at("options").at("reservedCapacity").boolean_or(false)) return refuse("reservations are shared between NodePools");
+    std::vector<std::string> names;
+    for (auto& np : prob.at("nodePools").items()) names.push_back(np.at("name").s());
+    const int P = (int)names.size();
+    std::vector<int> parent((size_t)P);
+    for (int i = 0; i < P; ++i) parent[(size_t)i] = i;
+    std::function<int(int)> find = [&](int x) { while (parent[(size_t)x] != x) { parent[(size_t)x] = parent[(size_t)parent[(size_t)x]]; x = parent[(size_t)x]; } return x; };
+    struct Item { bool group; const Value* v; const Value* tmpl; int first; int64_t pods; };
+    std::vector<Item> items;
+    for (int kind = 0; kind < 2; ++kind) for (auto& it : prob.at(kind ? "podGroups" : "pods").items()) {
+      const Value& t = kind ? it.at("template") : it;
+      const std::vector<int> allowed = split_pinned_pools(t, names);
+      if (allowed.empty()) return refuse("a pod is not provably pinned to NodePools by its required constraints on karpenter.sh/nodepool");
+      for (int o : allowed) parent[(size_t)find(o)] = find(allowed[0]);
+      items.push_back({kind != 0, &it, &t, allowed[0], kind ? it.at("count").i(0) : 1});
+    }
+    // topology groups tie their owner to every pod they select: pods by (namespace, labels) signature
+    struct Sig { std::string ns; const Value* labels; std::vector<int> firsts; };
+    std::vector<Sig> sigs;
+    {
+      std::map<std::string, size_t> seen;
+      for (auto& it : items) {
+        std::string key = it.tmpl->at("namespace").s("default") + "\x01";
+        std::vector<std::pair<std::string, std::string>> ls;
+        for (auto& kv : it.tmpl->at("labels").members()) ls.push_back({kv.first, kv.second.s()});
+        std::sort(ls.begin(), ls.end());
+        for (auto& kv : ls) key += kv.first + "\x02" + kv.second + "\x03";
+        auto f = seen.find(key);
+        if (f == seen.end()) { seen[key] = sigs.size(); sigs.push_back({it.tmpl->at("namespace").s("default"), &it.tmpl->at("labels"), {it.first}}); }
+        else sigs[f->second].firsts.push_back(it.first);
+      }
+    }
+    for (auto& it : items) {
+      std::vector<SplitSelector> sels;
+      if (!split_selectors(*it.tmpl, sels)) return refuse("a topology selector with matchExpressions / a namespaceSelector");
+      for (auto& sl : sels) for (auto& sg : sigs) {
+        if (std::find(sl.namespaces.begin(), sl.namespaces.end(), sg.ns) == sl.namespaces.end()) continue;
+        bool all = true;
+        for (auto& kv : sl.match) { const Value& v = sg.labels->at(kv.first); if (v.is_null() || v.s() != kv.second) { all = false; break; } }
+        if (all) for (int f : sg.firsts) parent[(size_t)find(f)] = find(it.first);
+      }
+    }
+    // components in NodePool order
+    std::vector<int> comp_of((size_t)P, -1);
+    std::vector<std::vector<int>> comp_pools;
+    for (int i = 0; i < P; ++i) { const int r = find(i); if (comp_of[(size_t)r] < 0) { comp_of[(size_t)r] = (int)comp_pools.size(); comp_pools.push_back({}); } comp_pools[(size_t)comp_of[(size_t)r]].push_back(i); }
+    const size_t C = comp_pools.size();
+    std::vector<Value> pods, groups;   // (one array each: a copied Value shares its array)
+    for (size_t c = 0; c < C; ++c) { pods.push_back(Value::array()); groups.push_back(Value::array()); }
+    std::vector<int64_t> count(C, 0);
+    for (auto& it : items) { const size_t c = (size_t)comp_of[(size_t)find(it.first)]; (it.group ? groups[c] : pods[c]).push(*it.v); count[c] += it.pods; }
+    std::vector<size_t> keep;
+    for (size_t c = 0; c < C; ++c) if (count[c] > 0) keep.push_back(c);
+    // LPT: the component with the most pods first, each to the bin with the fewest pods so far (lowest index on ties)
+    const int B = n_bins < 1 ? 1 : n_bins;
+    std::vector<int64_t> load((size_t)B, 0);
+    std::vector<int> bin_of(C, 0);
+    std::vector<size_t> by_size = keep;
+    std::stable_sort(by_size.begin(), by_size.end(), [&](size_t a, size_t b) { return count[a] > count[b]; });
+    for (size_t c : by_size) { int best = 0; for (int b = 1; b < B; ++b) if (load[(size_t)b] < load[(size_t)best]) best = b; bin_of[c] = best; load[(size_t)best] += count[c]; }
+    Value out = Value::object(), comps = Value::array(), bins = Value::array(), bin_pods = Value::array();
+    std::vector<Value> bin_lists;
+    for (int b = 0; b < B; ++b) bin_lists.push_back(Value::array());
+    for (size_t k = 0; k < keep.size(); ++k) {
+      const size_t c = keep[k];
+      Value sub = Value::object();
+      for (auto& kv : prob.members()) {
+        if (kv.first == "nodePools") { Value nps = Value::array(); for (int i : comp_pools[c]) nps.push(prob.at("nodePools").items()[(size_t)i]); sub.add_new("nodePools", nps); }
+        else if (kv.first == "pods") sub.add_new("pods", pods[c]);
+        else if (kv.first == "podGroups") sub.add_new("podGroups", groups[c]);
+        else sub.add_new(kv.first, kv.second);
+      }
+      Value e = Value::object(), pn = Value::array();
+      for (int i : comp_pools[c]) pn.push(Value::string(names[(size_t)i]));
+      e.set("pools", pn); e.set("pods", Value::integer(count[c])); e.set("bin", Value::integer(bin_of[c])); e.set("problem", sub);
+      comps.push(e);
+      bin_lists[(size_t)bin_of[c]].push(Value::integer((int64_t)k));
+    }
+    for (int b = 0; b < B; ++b) { bins.push(bin_lists[(size_t)b]); bin_pods.push(Value::integer(load[(size_t)b])); }
+    out.set("components", comps); out.set("bins", bins); out.set("binPods", bin_pods);
+    return dup_json(out);
+  } catch (const std::exception& e) {
+    return error_json("invalid", e.what());
+  }
+}
+
 extern "C" char* ksched_solve_json(const char* problem_json, const char* solver_lib, int repeat, int want_results) {
   void* s = ksched_open(problem_json, solver_lib);
   if (ksched_error(s)) { char* e = session_error((Session*)s); ksched_close(s); return e; }

@@ -69,6 +69,8 @@ def _load_ksched():
         lib.ksched_sweep_arrays.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         lib.ksched_pods_by_claim.restype = ctypes.c_uint32
         lib.ksched_pods_by_claim.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+        lib.ksched_split_components.restype = ctypes.c_void_p
+        lib.ksched_split_components.argtypes = [ctypes.c_char_p, ctypes.c_int]
         lib.ksched_assignment.restype = ctypes.c_uint32
         lib.ksched_assignment.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         _ksched = lib
@@ -394,6 +396,22 @@ def ToNodeClaim(claim: dict, problem: dict, max_instance_types: int = MAX_INSTAN
             labels[k] = str(v)
     out = [q for k, q in sorted(reqs.items()) if k not in _SIMULATION_KEYS]
     return {"requirements": out, "labels": labels, "instanceTypes": names}
+
+
+def SplitComponents(problem: dict, bins: int = 1):
+    """The NodePool components of one provisioning batch, from the host library (ksched_split_components): connected
+    components of the pods x NodePools graph (pins on karpenter.sh/nodepool, topology selectors), dealt over `bins` devices by pod
+    count, largest first. Returns {"components": [{"pools", "pods", "bin", "problem"}], "bins", "binPods"} or {"components": None,
+    "reason"} when independence cannot be shown. The Go twin is go/ksolve_components.go."""
+    lib = _load_ksched()
+    ptr = lib.ksched_split_components(json.dumps(problem).encode(), int(bins))
+    try:
+        out = json.loads(ctypes.string_at(ptr).decode())
+    finally:
+        lib.ksched_free(ptr)
+    if "error" in out:
+        _raise(out.get("kind"), out["error"])
+    return out
 
 
 def device_available() -> bool:
