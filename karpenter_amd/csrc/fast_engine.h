@@ -1194,8 +1194,8 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
   // Software pipeline over the pods of a block: a step has three dependent LDS round trips (the order's entries -> the claims'
   // records -> the requirement-set cache), and the FIRST one of the next pod does not depend on the LAST one of this pod — only
   // on this pod's writes to the order and on the cursors, both done before the cache read is waited for. So a step issues, in
-  // this order: its record reads | its order writes | its cache reads | the NEXT pod's order reads | its record write. The
-  // LDS executes a wavefront's accesses in order, so the next pod's record reads (first thing of the next step) see that write.
+  // this order: its order writes | the NEXT pod's order reads | its cache reads | its record write | the NEXT pod's record reads.
+  // The LDS executes a wavefront's accesses in order, so those record reads see the write in front of them.
   unsigned long long n_ext = 0;   // four-window steps of scans beyond a cursor's window
   int rf = -1;              // a claim whose refresh met a requirement set that is not cached: the driver computes its words
   LaneVar<uint32_t> xv, kv; // the order's entries of the pod about to be placed: claim id and pod count at positions rc0 + lane
@@ -1208,6 +1208,20 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       int pc = p < nm1 ? p : nm1; pc = pc < 0 ? 0 : pc;   // clamped: no lane is switched off for the reads (a cursor at the end of the order: no lane is valid)
       const uint32_t kk = okey[pc];
       xv.at(l) = oord[pc]; kv.at(l) = p < n ? kk : 0xFFFFFFFFu;
+    });
+  };
+  // the records of the claims the order read brought (state and acceptance word of the class's row), one lane each
+  LaneVar<uint64_t> mvv, awv;
+  LaneVar<int32_t> q0, q1, q2, q3;
+  auto gather = [&]() {
+    const int rws = row;
+    W::each([&](int l) {
+      const FastRec<R> st = cst.rec(xv.at(l));
+      uint64_t aw = st.acc[0];
+#pragma unroll
+      for (int j = 1; j < R; ++j) aw = rws == j ? st.acc[j] : aw;
+      awv.at(l) = aw; mvv.at(l) = st.vmask;
+      q0.at(l) = st.req[0]; q1.at(l) = st.req[1]; q2.at(l) = st.req[2]; q3.at(l) = st.req[3];
     });
   };
   // stage A of entry i: its class slot, the class's cursor, the order's 64 entries there
@@ -1238,7 +1252,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
     // entries of this block the loop may place: not the queue's last one, nor the last one before a block at which the cancel flag
     // is polled (a Solve() that ends there reports the order of the last sort the reference would have run: their move stays undone)
     const int bf = bn - ((base + bn >= np || (polled && ((base + 64) & 1023) == 0)) ? 1 : 0);
-    if (bi < bf) stage_a(bi);
+    if (bi < bf) { stage_a(bi); gather(); }
     while (bi < bf) {
       // Everything up to the first write is ONE basic block: whatever is not plain sets a bit of `bad` and the step goes on with
       // harmless values (lane 0, position 0), so that no branch stands between the loads and the compiler issues them together —
@@ -1248,22 +1262,11 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       const int slot = row * 64 + sl;
       const FastSlot cs = lds_get(&aslot[slot]);
       // ---- select: the claims at the 64 positions, one lane each: the whole record (state and acceptance words) ----
-      LaneVar<uint64_t> mvv;
-      LaneVar<int32_t> q0, q1, q2, q3;
       const uint64_t slbit = 1ull << sl;
       const int rws = row;
       auto select = [&]() {
         const uint32_t rcs = rc0;
-        return W::ballot([&](int l) {
-          const uint64_t want = (int)rcs + l < n ? slbit : 0ull;
-          const FastRec<R> st = cst.rec(xv.at(l));
-          uint64_t aw = st.acc[0];
-#pragma unroll
-          for (int j = 1; j < R; ++j) aw = rws == j ? st.acc[j] : aw;
-          q0.at(l) = st.req[0]; q1.at(l) = st.req[1]; q2.at(l) = st.req[2]; q3.at(l) = st.req[3];
-          mvv.at(l) = st.vmask;
-          return (aw & want) != 0;
-        });
+        return W::ballot([&](int l) { return (awv.at(l) & ((int)rcs + l < n ? slbit : 0ull)) != 0; });
       };
       uint64_t okm = select();
       if (KS_UNLIKELY((okm == 0) & (badA == 0) & ((int)rc0 + 64 < n))) {
@@ -1291,6 +1294,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
         if (found >= 0) {     // (none: no in-flight claim accepts the pod — addToNewNodeClaim, through fast_slow_run)
           rc0 = (uint32_t)found;
           order_reads(rc0);
+          gather();
           okm = select();
         }
       }
@@ -1410,7 +1414,8 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
           cst.put_rec(xw.at(l), mine);
         }
       });
-      if constexpr (FastMem<GS, R>::kStateHbm) W::sync(); else W::order();   // (LDS: no wait — it executes a wavefront's accesses in order, the next step's reads see these writes)
+      if constexpr (FastMem<GS, R>::kStateHbm) W::sync(); else W::order();   // (LDS: no wait — it executes a wavefront's accesses in order, the reads below see these writes)
+      gather();     // the next pod's claims (behind this pod's record write): in flight while the loop comes around
       bi++; steps++;
       if (KS_UNLIKELY(rf >= 0)) break;
     }

@@ -444,6 +444,41 @@ def test_the_headline_problem_one_hundred_times():
     assert len(seen) == 1, f"{len(seen)} different answers in 100 solves of one problem"
 
 
+@pytest.mark.parametrize("leg", ["single", "single-topology", "multi"])
+def test_consolidation_sweeps_against_the_population_pins(leg):
+    """The probes the oracle simulated AND judged offline for the committed sweep pins (tests/golden/sweeps/: 1,000 stratified
+    single-node probes of the 100k-node bench cluster, plain and with spread constraints on its bound pods, and 320 multi-node
+    prefixes — tests/golden/make_sweep_pins.py) swept on the device: decision, replacement instance types, capacity type and
+    reference bin evaluations of every one of them in one sha256 (round-4 review: 0.2 % of the swept probes were oracle-judged)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_sweep_pins as msp
+    from karpenter_amd import disruption as dz
+    path = msp.pin_path(leg, 100000)
+    if not os.path.exists(path):
+        pytest.skip("no pin for this leg (tests/golden/make_sweep_pins.py)")
+    g = json.load(open(path))
+    cc = dz.make_resident_cluster(n_nodes=g["nodes"], seed=g["seed"], topology=(leg == "single-topology"))
+    rc = dz.ResidentCluster.from_compact(cc)
+    full = dz.compact_candidates(cc)
+    if leg == "multi":
+        K = g["windows"][1]
+        sets = [[cc["nodes"][i] for i in full[w * K:w * K + k]] for w, k in g["positions"]]
+        cmds = rc.decisions(sets, multi_node=True, library_prices=True)
+    else:
+        n_cand = g["swept_candidates"]
+        swept = full[::max(1, len(full) // max(1, n_cand))][:n_cand]
+        sets = [[cc["nodes"][swept[j]]] for j in g["positions"]]
+        cmds = rc.decisions(sets, library_prices=True, arrays=True)
+    ev = rc.last_sweep["referenceBinEvaluations"]
+    keys = [msp.probe_key(c["decision"], c["replacement"], c.get("replacementCapacityType"), ev[j]) for j, c in enumerate(cmds)]
+    rc.close()
+    bad = [pos for pos, a, b in zip(g["positions"], keys, g["keys"]) if a != b]
+    assert not bad, f"{len(bad)} of {len(keys)} probes differ from the oracle's pin, first at {bad[:3]}"
+    assert msp.digest_of(keys) == g["digest"]
+
+
 def test_offering_override_groups_on_the_device(oracle):
     """Offering capacity / overhead override groups (types.go:202-269, nodeclaim.go:624-638) on the GPU: the reference's
     two known answers (suite_test.go:5524-5607), the group semantics and the seeded fuzz of tests/test_device_algorithm.py,
