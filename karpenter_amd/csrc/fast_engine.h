@@ -141,6 +141,15 @@ KS_FN T lds_get16(const KS_LDS T* p) {
   for (int i = 0; i < (int)(sizeof(T) / 16); ++i) o[i] = s[i];
   return out;
 }
+// the live 24 bytes of a cache entry (key, capacities): one 16-byte and one 8-byte read — no destination register is dead, so the
+// register allocator cannot hand one to the next instruction while the read is in flight (a write-after-write wait)
+KS_FN FastEnt ent_live(const KS_LDS FastEnt* p) {
+  FastEnt out;
+  *(u32x4_alias*)&out = *(const KS_LDS u32x4_alias*)p;
+  *(u64_alias*)&out.cap[2] = *(const KS_LDS u64_alias*)&p->cap[2];
+  out.info = 1; out.pad = 0;
+  return out;
+}
 template <class T>
 KS_FN void lds_put16(KS_LDS T* p, const T& v) {
   static_assert(sizeof(T) % 16 == 0, "lds_put16: 16-byte multiples");
@@ -1359,11 +1368,6 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       n_ref += (unsigned long long)((uint32_t)a + 1u);
       // ---- refresh: CanAdd (nodeclaim.go:124-242) of the claim as it stands now, for the classes of all slots (lane = slot):
       // the next pod's order reads go out first, the cache reads behind them (both in flight together), then the predicates ----
-      const int fo_ = first_ok;
-      LaneVar<uint32_t> xw;   // (the claim ids of this step: the record write below still needs lane first_ok's)
-      W::each([&](int l) { xw.at(l) = xv.at(l); });
-      if constexpr (FastMem<GS, R>::kOrderHbm) W::sync(); else W::order();   // (an order in HBM: the stores are waited for, as everywhere in this engine; in LDS nothing is)
-      stage_a(bi + 1);      // entry bi+1 of the block (entry 64 of a full block does not exist: its values are never used)
       const uint32_t tbit = 1u << (uint32_t)(ns.vmask >> 56);
       LaneVar<uint64_t> mlv[R], evm[R];
       LaneVar<int32_t> c0[R], c1[R], c2[R], c3[R];
@@ -1371,11 +1375,18 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
           const uint64_t m = ns.vmask & cvm[j].at(l);
-          const FastEnt e = lds_get16(&ent[fast_hash(m)]);
+          const FastEnt e = ent_live(&ent[fast_hash(m)]);
           mlv[j].at(l) = m; evm[j].at(l) = e.vmask;
           c0[j].at(l) = e.cap[0]; c1[j].at(l) = e.cap[1]; c2[j].at(l) = e.cap[2]; c3[j].at(l) = e.cap[3];
         }
       });
+      const int fo_ = first_ok;
+      LaneVar<uint32_t> xw;   // (the claim ids of this step: the record write below still needs lane first_ok's)
+      W::each([&](int l) { xw.at(l) = xv.at(l); });
+      if constexpr (FastMem<GS, R>::kOrderHbm) W::sync(); else W::order();   // (an order in HBM: the stores are waited for, as everywhere in this engine; in LDS nothing is)
+      W::sched_fence();
+      stage_a(bi + 1);      // entry bi+1 of the block (entry 64 of a full block does not exist: its values are never used)
+      W::sched_fence();
       uint64_t accw[R];
 #pragma unroll
       for (int j = 0; j < R; ++j) {
@@ -1482,10 +1493,13 @@ struct FastEngine {
     cx.okey = cold.order.key; cx.oord = cold.order.ord; cx.cst = cold.cst; cx.ent = cold.ent; cx.pool = cold.pool;
     cx.aslot = cold.aslot; cx.hs = hs;
     unsigned long long tev[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_fast = 0, n_fast = 0, t_slow = 0, n_slow = 0;   // profiling builds: shader clock inside the two loops, calls of each
     const unsigned long long t_begin = W::clock();
     const bool use_fast = fast_uniform(h->max_steps) < 0;   // (a step limit — tests — is counted by the general loop)
     for (;;) {
+      const unsigned long long tf0 = W::clock();
       int ev = use_fast ? fast_uniform(fast_hot_run<W, GS, R>(cx)) : (int)FEV_SLOW;
+      t_fast += W::clock() - tf0; n_fast++;
       if (use_fast && fast_uniform(h->rf_x) >= 0) {
         const int rx = fast_uniform(h->rf_x);
         if (W::leader()) h->rf_x = -1;
@@ -1493,7 +1507,7 @@ struct FastEngine {
         if (fast_uniform(cold.refresh_claim(rx)) < 0) { cold.bail_code = 21; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
         continue;
       }
-      if (ev == FEV_SLOW) ev = fast_uniform(fast_slow_run<W, GS, R>(cx, use_fast ? 1 : 0x7FFFFFFF));
+      if (ev == FEV_SLOW) { const unsigned long long ts0 = W::clock(); ev = fast_uniform(fast_slow_run<W, GS, R>(cx, use_fast ? 1 : 0x7FFFFFFF)); t_slow += W::clock() - ts0; n_slow++; }
       if (ev == FEV_CONT) continue;
       if (ev == FEV_DONE) break;
       const unsigned long long te0 = W::clock();
@@ -1529,7 +1543,7 @@ struct FastEngine {
     }
     // profiling builds (-DKSOLVE_PHASE_TIMERS): cycles inside the loop function, per event kind, in total; event counts
     unsigned long long tc[16] = {h->hot_cycles, tev[1], tev[2], tev[3], tev[4], tev[5], W::clock() - t_begin, nev[3] + (nev[4] << 20) + (nev[1] << 40),
-                                 h->tsec[0], h->tsec[1], h->tsec[2], h->tsec[3], h->tsec[4], h->tsec[5], h->tsec[6], h->tsec[7]};
+                                 t_fast, n_fast, t_slow, n_slow, nev[1], nev[2], nev[3] + (nev[4] << 32), nev[5]};
     const unsigned long long steps = (unsigned long long)fast_uniform(h->steps);
     // CanAdd evaluations of the loop: after every placement the claim against the classes of all slots; select steps: one per pod and the extra ones
     cold.finish(fast_uniform(h->status), fast_uniform(h->n), steps, h->n_steps + steps, steps * (unsigned long long)(64 * R), h->n_ref, tc);

@@ -45,6 +45,13 @@ static void* be_alloc(ksolve_handle* h, size_t bytes) {
   hip_check(h, hipMemsetAsync(p, 0, bytes ? bytes : 8, HB(h)->stream), "hipMemsetAsync");
   return p;
 }
+static void* be_try_alloc(ksolve_handle* h, size_t bytes) {
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // refused: the error is taken off the runtime's slate, the handle stays usable
+  h->allocations.push_back(p);
+  hip_check(h, hipMemsetAsync(p, 0, bytes ? bytes : 8, HB(h)->stream), "hipMemsetAsync");
+  return p;
+}
 // Page-locked host memory the handle keeps between calls (grown on demand): what a sweep writes its per-probe workspace records and
 // probe lists into, so that their upload is one DMA at link speed instead of a staged copy out of pageable memory (10,000 probes:
 // 6 MB of records, 1.5 of the call's 1.9 ms of upload).

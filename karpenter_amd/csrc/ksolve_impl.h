@@ -97,12 +97,14 @@ struct ksolve_handle {
   char* sweep_arena = nullptr; size_t sweep_arena_bytes = 0;
   uint32_t fast_mc = 0;           // max_claims the cursor engine's plans are cut to
   double dead0_us = 0;            // ksolve_node_dead0 (every class x every pristine node), once per resident cluster
+  bool sweep_arena_refused = false;   // the last sweep_run stopped because the device refused its arena (sweep() then halves the launch)
   size_t sweep_last_total = 0;   // arena bytes the last sweep_run laid out (held against sweep_probe_bytes by the test builds)
   char* sweep_fin = nullptr; size_t sweep_fin_bytes = 0;     // finalize outputs + gathered claim records of a sweep
 };
 
 // ---- backend hooks (defined by the including TU before this point is instantiated) ----
 static void* be_alloc(ksolve_handle* h, size_t bytes);
+static void* be_try_alloc(ksolve_handle* h, size_t bytes);   // the same, but a refusal is not an error of the handle: null, nothing recorded (the sweep arena: the caller retries smaller)
 static void be_h2d(ksolve_handle* h, void* dst, const void* src, size_t bytes);
 static void be_d2h(ksolve_handle* h, void* dst, const void* src, size_t bytes);
 static void be_fill(ksolve_handle* h, void* dst, int byte, size_t bytes);
@@ -1097,11 +1099,14 @@ static ksolve_status sweep_prepare_base(ksolve_handle* base) {
   return KSOLVE_OK;
 }
 
-static char* sweep_buffer(ksolve_handle* base, char*& buf, size_t& have, size_t need) {
+static char* sweep_buffer(ksolve_handle* base, char*& buf, size_t& have, size_t need, bool may_refuse = false) {
   if (need > have) {
     if (buf) be_free(base, buf);
     const size_t want = need + need / 4 + 4096;
-    buf = (char*)be_alloc(base, want);
+    // the arena of a launch may be more than the device has left: that is not an error of the handle (hip_check made the
+    // refusal sticky and the retry with smaller launches could never run) — null, and sweep() goes on with half the probes per launch
+    buf = (char*)(may_refuse ? be_try_alloc(base, want) : be_alloc(base, want));
+    if (!buf && may_refuse) { buf = (char*)be_try_alloc(base, need + 4096); have = buf ? need + 4096 : 0; base->sweep_arena_refused = buf == nullptr; return buf; }   // (once more without the growth margin)
     have = buf ? want : 0;
   }
   return buf;
@@ -1302,7 +1307,8 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
   layout();
   const size_t total = off;
   base->sweep_last_total = total;
-  arena = sweep_buffer(base, base->sweep_arena, base->sweep_arena_bytes, total);
+  base->sweep_arena_refused = false;
+  arena = sweep_buffer(base, base->sweep_arena, base->sweep_arena_bytes, total, true);
   if (!arena) return fail(base, KSOLVE_ERR_DEVICE, base->error.empty() ? "device allocation failed (sweep arena)" : base->error);
   for (uint32_t p = 0; p < n; ++p) items[p] = ks::Workspace{};
   layout();
@@ -1531,7 +1537,7 @@ static ksolve_status sweep_run_chunked(ksolve_handle* base, uint32_t n, const ui
 #ifdef KSOLVE_TEST_HOOKS
     if (st == KSOLVE_OK && base->sweep_last_total > total_need) return fail(base, KSOLVE_ERR_INVALID, "sweep_probe_bytes underestimates the arena: " + std::to_string(base->sweep_last_total) + " > " + std::to_string(total_need) + " for " + std::to_string(n) + " probes");
 #endif
-    if (st != KSOLVE_ERR_DEVICE || n < 2) return st;
+    if (st != KSOLVE_ERR_DEVICE || n < 2 || !base->sweep_arena_refused) return st;   // (only a refused arena is retried, not any device error)
     budget = total_need / 2;            // the device refused the arena: go on with half of it per launch
     base->error.clear();
     *im = SweepImpl();
@@ -1547,7 +1553,7 @@ static ksolve_status sweep_run_chunked(ksolve_handle* base, uint32_t n, const ui
     SweepImpl part;
     double u[4] = {0, 0, 0, 0};
     ksolve_status st = sweep_run(base, m, no.data(), nodes + node_off[lo], po.data(), pods + pod_off[lo], limits ? limits + lo : nullptr, cancel ? cancel + lo : nullptr, &part, u);
-    if (st == KSOLVE_ERR_DEVICE && m > 1) { budget = std::max<size_t>(acc / 2, 1); base->error.clear(); continue; }   // smaller launches from here on
+    if (st == KSOLVE_ERR_DEVICE && m > 1 && base->sweep_arena_refused) { budget = std::max<size_t>(acc / 2, 1); base->error.clear(); continue; }   // smaller launches from here on
     if (st != KSOLVE_OK) return st;
 #ifdef KSOLVE_TEST_HOOKS   // the test builds hold the estimate to the layout it restates
     if (base->sweep_last_total > acc) return fail(base, KSOLVE_ERR_INVALID, "sweep_probe_bytes underestimates the arena");

@@ -46,6 +46,7 @@ struct Wave {
   // store and a later load of the SAME memory (LDS, or one wavefront's plain global accesses): the hardware keeps a wavefront's
   // accesses to one memory in order.
   KS_DEV static void order() { asm volatile("" ::: "memory"); }
+  KS_DEV static void sched_fence() { __builtin_amdgcn_sched_barrier(0); }   // the instruction scheduler moves nothing across this point
   template <class F>
   KS_DEV static uint64_t ballot(F f) { return __builtin_amdgcn_ballot_w64((bool)f(lane())); }   // (the builtin on a bool: the compare itself writes the mask; __ballot(int) materialises 0 / 1 in a VGPR and compares again)
   // four ballots from ONE evaluation of f(lane) (bits 0..3 of its result): the loads behind the predicates happen once
@@ -234,6 +235,7 @@ struct Wave {
   static uint64_t uniform(uint64_t v) { return v; }
   static void sync() {}
   static void order() {}
+  static void sched_fence() {}
   template <class F>
   static uint64_t ballot(F f) {
     uint64_t m = 0;

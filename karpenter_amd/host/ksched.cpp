@@ -2579,6 +2579,15 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
         // a caller that holds its pods by position needs no uid text to put them on their NodeClaims)
         own->last_assign.assign(res.pod_assignment, res.pod_assignment + n_pods);
         own->last_slot.assign(res.pod_slot, res.pod_slot + n_pods);
+        if (cl.truncation_failed) {
+          // a NodeClaim that TruncateInstanceTypes drops (scheduler.go:426-431) is not in newNodeClaims: the indices ksched_assignment /
+          // ksched_pods_by_claim hand out are positions in the EMITTED list, the dropped claims' pods are unscheduled
+          std::vector<int32_t> emitted(cl.n_claims, -1);
+          int32_t next = 0;
+          bool any = false;
+          for (uint32_t c = 0; c < cl.n_claims; ++c) { if (cl.truncation_failed[c]) any = true; else emitted[c] = next++; }
+          if (any) for (auto& a : own->last_assign) if (a >= 0 && (uint32_t)a < cl.n_claims) a = emitted[(size_t)a];
+        }
       }
       for (int p = 0; p < n_pods; ++p) {
         if (!in_probe(p)) continue;

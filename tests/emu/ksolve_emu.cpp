@@ -13,6 +13,11 @@
 struct EmuBackend { std::chrono::steady_clock::time_point t0[8]; };
 
 static void* be_alloc(ksolve_handle* h, size_t bytes) { void* p = calloc(1, bytes ? bytes : 1); h->allocations.push_back(p); return p; }
+// KSOLVE_TEST_ARENA_LIMIT_MB: an emulated device that refuses a sweep arena above that size (tests of the halving retry)
+static void* be_try_alloc(ksolve_handle* h, size_t bytes) {
+  if (const char* e = getenv("KSOLVE_TEST_ARENA_LIMIT_MB")) if (bytes > ((size_t)atoi(e) << 20)) return nullptr;
+  return be_alloc(h, bytes);
+}
 static void be_h2d(ksolve_handle*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
 static void be_d2h(ksolve_handle*, void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
 static void be_fill(ksolve_handle*, void* dst, int byte, size_t bytes) { memset(dst, byte, bytes); }

@@ -702,6 +702,16 @@ def test_compact_sweep_equals_the_one_wavefront_kernel(emu, monkeypatch, topolog
     a = rc.decisions(singles, detail=True)
     assert a == outs[0][0]
     rc.close()
+    # ... and on a device that REFUSES the arena of the whole sweep (the refusal was sticky on the HIP backend and the
+    # retry could never run; the emulation refuses above KSOLVE_TEST_ARENA_LIMIT_MB): the sweep goes on with half the probes per
+    # launch until the arena fits, the handle stays usable, the verdicts are those of one launch
+    monkeypatch.delenv("KSOLVE_SWEEP_ARENA_MB")
+    monkeypatch.setenv("KSOLVE_TEST_ARENA_LIMIT_MB", "6")
+    rc = dz.ResidentCluster.from_compact(cc, solver_lib=emu)
+    a = rc.decisions(singles, detail=True)
+    assert a == outs[0][0]
+    assert rc.decisions(singles[:5], detail=True) == outs[0][0][:5]     # a later, smaller sweep of the same handle
+    rc.close()
 
 
 def test_same_instance_type_filter_in_the_sweep(oracle, emu):

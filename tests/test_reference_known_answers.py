@@ -218,6 +218,19 @@ def test_truncate_instance_types(oracle, emu):
     pool = fx.node_pool(requirements=[fx.req(fx.INSTANCE_TYPE, "In", "instance-type-1", "instance-type-2", min_values=2)])
     res = solve(oracle, emu, two, its=_mv_types(), pools=[pool], options={"truncateInstanceTypes": 1})
     assert not res["newNodeClaims"] and sorted(e["code"] for e in res["podErrors"].values()) == [10, 10]
+    # the flat per-pod outputs follow the EMITTED NodeClaims: with both claims dropped nobody is assigned; with a third
+    # pod on a claim that survives (no minValues on its NodePool) that claim is newNodeClaims[0] although the device numbered it 2
+    from karpenter_amd.scheduling import NewScheduler
+    free_pool = dict(fx.node_pool(name="free", weight=0), requirements=[])
+    third = fx.pod(requests={"cpu": "0.9", "memory": "0.9Gi"}, node_selector={fx.NODEPOOL: "free"})
+    pinned = [dict(p, nodeSelector={fx.NODEPOOL: pool["name"]}) for p in two]
+    prob = fx.problem(_mv_types(), [pool, free_pool], pinned + [third], options={"truncateInstanceTypes": 1})
+    s = NewScheduler(prob, solver_lib=emu)
+    r = s.Solve(want_results="claims")
+    assign, _ = s.Assignment()
+    assert len(r["newNodeClaims"]) == 1 and list(assign) == [-1, -1, 0]
+    assert [list(x) for x in s.PodsByClaim(1)] == [[2]]
+    s.close()
     res = solve(oracle, emu, two, its=_mv_types(), pools=[pool], options={"truncateInstanceTypes": 600})
     assert len(res["newNodeClaims"]) == 2 and res["newNodeClaims"][0]["instanceTypes"] == ["instance-type-1", "instance-type-2"]   # cheapest first
     # a large catalogue with many equal prices: the order Go's unstable sort leaves is part of the answer
