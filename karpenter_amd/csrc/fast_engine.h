@@ -60,8 +60,9 @@ struct FastEnt { uint64_t vmask; int32_t cap[4]; uint32_t info; uint32_t pad; };
 struct FastPlan {   // LDS plan of ksolve_pack_fast (bytes), computed by the host
   int total_bytes, cap;
   int off_state, off_key, off_ord, off_snap, off_ent, off_pool, off_slot, off_misc, off_hot;
-  int global_state;   // 1: the claims' records (FastRec) live in HBM (FastWork::c_rec), only the order arrays in LDS:
-                      //    ~15,000 in-flight claims instead of ~3,000 (round 4). off_state is unused then.
+  int global_state;   // 1: the claims' records (FastRec) live in HBM (FastWork::c_rec) and so does the snapshot a slow sort compares
+                      //    with (FastWork::o_snap); only the order's keys and ids (4 B per claim) in LDS: ~27,000 in-flight claims
+                      //    instead of ~3,000 (round 4: ~15,000 with the snapshot in LDS too). off_state / off_snap are unused then.
                       // 2: the order arrays too (FastWork::o_key / o_ord / o_snap): 65,472 claims — what 16-bit claim ids address;
                       //    LDS holds the caches, the class slots and the loop's own state only.
   int rows;           // class slots / 64: 1 when at most 64 pod classes are ever live at once in the queue (FastWork::max_active,
@@ -200,11 +201,16 @@ template <int R> struct ClaimRecs<true, R> {
 // order arrays in HBM. The order's accesses are plain loads and stores: the wavefront is the only reader and writer, its vector
 // memory operations execute in order, and W::sync() (a wavefront-scope fence) stands between a store and another lane's load.
 template <int GS, int R> struct FastMem {
-  static constexpr bool kStateHbm = GS >= 1, kOrderHbm = GS >= 2;
+  static constexpr bool kStateHbm = GS >= 1, kOrderHbm = GS >= 2, kSnapHbm = GS >= 1;   // (the snapshot around a slow sort is cold: in HBM as soon as LDS is short)
 #if KS_DEVICE
   typedef typename std::conditional<kOrderHbm, uint16_t*, KS_LDS uint16_t*>::type o16;
 #else
   typedef uint16_t* o16;
+#endif
+#if KS_DEVICE
+  typedef typename std::conditional<kSnapHbm, uint16_t*, KS_LDS uint16_t*>::type s16;
+#else
+  typedef uint16_t* s16;
 #endif
   typedef ClaimRecs<kStateHbm, R> States;
 };
@@ -319,7 +325,7 @@ struct FastCold {
   const FastWork* Fk;
   typedef typename FastMem<GS, R>::o16 o16;
   ClaimOrder<W, o16, false> order;
-  o16 snap;                 // [cap] order snapshot around a slow sort
+  typename FastMem<GS, R>::s16 snap;   // [cap] order snapshot around a slow sort (HBM on plans 1 and 2)
   typename FastMem<GS, R>::States cst;
   KS_LDS FastEnt* ent;
   KS_LDS int32_t* pool;     // [kFastPool][4]
@@ -338,8 +344,10 @@ struct FastCold {
     Mp = (KS_LDS FastMisc*)(lds + pl.off_misc);
     hs = (KS_LDS FastHot*)(lds + pl.off_hot);
     if constexpr (GS >= 1) cst.p = (FastRec<R>*)f->c_rec; else cst.p = (KS_LDS FastRec<R>*)(lds + pl.off_state);
-    if constexpr (GS >= 2) { order.key = (o16)f->o_key; order.ord = (o16)f->o_ord; snap = (o16)f->o_snap; }
-    else { order.key = (o16)(lds + pl.off_key); order.ord = (o16)(lds + pl.off_ord); snap = (o16)(lds + pl.off_snap); }
+    typedef typename FastMem<GS, R>::s16 s16;
+    if constexpr (GS >= 2) { order.key = (o16)f->o_key; order.ord = (o16)f->o_ord; }
+    else { order.key = (o16)(lds + pl.off_key); order.ord = (o16)(lds + pl.off_ord); }
+    if constexpr (GS >= 1) snap = (s16)f->o_snap; else snap = (s16)(lds + pl.off_snap);
     order.pos = nullptr;
     ent = (KS_LDS FastEnt*)(lds + pl.off_ent);
     pool = (KS_LDS int32_t*)(lds + pl.off_pool);
@@ -687,12 +695,30 @@ struct FastCold {
   KS_COLD void slow_sort(int n, int defect, int app) {
     order.n = (int)W::uniform((uint64_t)(uint32_t)n); order.defect = (int)W::uniform((uint64_t)(uint32_t)defect); order.defect_append = W::uniform((uint64_t)app) != 0;
     n = order.n;
-    const o16 oo = order.ord; const o16 sn = snap;
-    if constexpr (FastMem<GS, R>::kOrderHbm) W::copy8(sn, oo, n); else W::for_n(n, [&](int i) { sn[i] = oo[i]; });
-    order.sort();
-    lo_ = order.ff(0, n, [&](int i) { return sn[i] != oo[i]; });
-    if (lo_ >= n) { lo_ = 0; hi_ = -1; return; }
-    hi_ = order.fl(0, n, [&](int i) { return sn[i] != oo[i]; });
+    const o16 oo = order.ord; const typename FastMem<GS, R>::s16 sn = snap;
+    if constexpr (FastMem<GS, R>::kSnapHbm) {
+      W::copy8(sn, oo, n);
+      order.sort();
+      // (a snapshot in HBM: eight rounds of loads in flight per search step)
+      lo_ = W::find_first8(0, n, [&](int i) { return sn[i] != oo[i]; });
+      if (lo_ >= n) { lo_ = 0; hi_ = -1; return; }
+      hi_ = W::find_last8(0, n, [&](int i) { return sn[i] != oo[i]; });
+    } else {
+      // Both arrays in LDS, 16-byte aligned: the snapshot and the two searches in pieces of eight claim ids (one ds_read_b128 per
+      // lane: 512 positions per step instead of 64 — the copy and the compares were half of a slow sort's 27k cycles). The
+      // ids past n in the last piece are copied along and stay equal: the sort does not touch them.
+      const int n8 = (n + 7) >> 3;
+      const KS_LDS u32x4_alias* const o8 = (const KS_LDS u32x4_alias*)oo;
+      KS_LDS u32x4_alias* const s8 = (KS_LDS u32x4_alias*)sn;
+      W::for_n(n8, [&](int i) { s8[i] = o8[i]; });
+      order.sort();
+      auto differs = [&](int i) { const u32x4_alias a = s8[i], b = o8[i]; return ((a[0] ^ b[0]) | (a[1] ^ b[1]) | (a[2] ^ b[2]) | (a[3] ^ b[3])) != 0; };
+      const int c0 = W::find_first(0, n8, differs);
+      if (c0 >= n8) { lo_ = 0; hi_ = -1; return; }
+      const int c1 = W::find_last(0, n8, differs);
+      lo_ = W::find_first(c0 * 8, c0 * 8 + 8 < n ? c0 * 8 + 8 : n, [&](int i) { return sn[i] != oo[i]; });
+      hi_ = W::find_last(c1 * 8, c1 * 8 + 8 < n ? c1 * 8 + 8 : n, [&](int i) { return sn[i] != oo[i]; });
+    }
   }
   // The new claim (appended at n-1 with one pod) takes its place behind the last claim with at most one pod. Returns its
   // position b >= 0 (Mp->acc = the class slots that accept it, from new_claim), -1 when pdqsort left the single-move path (lo_/hi_).
@@ -1240,7 +1266,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
     row = 0;
     if constexpr (R == 1) {
       const uint64_t m0 = W::ballot([&](int l) { return scls[0].at(l) == kcls; });
-      badA = (uint32_t)(m0 == 0);
+      badA = (uint32_t)fast_uniform((int)(m0 == 0));
       sl = ctz64(m0 | (1ull << 63));
     } else {
       uint64_t mf = 0;
@@ -1249,7 +1275,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
         const uint64_t mj = W::ballot([&](int l) { return scls[j].at(l) == kcls; });
         row = mj != 0 ? j : row; mf = mj != 0 ? mj : mf;     // (a class sits in one slot)
       }
-      badA = (uint32_t)(mf == 0);
+      badA = (uint32_t)fast_uniform((int)(mf == 0));
       sl = ctz64(mf | (1ull << 63));
     }
     rc0 = cur[0].bcast(sl);
@@ -1383,7 +1409,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       const int fo_ = first_ok;
       LaneVar<uint32_t> xw;   // (the claim ids of this step: the record write below still needs lane first_ok's)
       W::each([&](int l) { xw.at(l) = xv.at(l); });
-      if constexpr (FastMem<GS, R>::kOrderHbm) W::sync(); else W::order();   // (an order in HBM: the stores are waited for, as everywhere in this engine; in LDS nothing is)
+      if constexpr (FastMem<GS, R>::kOrderHbm) W::hbm_sync(); else W::order();   // (an order in HBM: the stores are waited for, as everywhere in this engine; in LDS nothing is)
       W::sched_fence();
       stage_a(bi + 1);      // entry bi+1 of the block (entry 64 of a full block does not exist: its values are never used)
       W::sched_fence();
@@ -1425,7 +1451,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
           cst.put_rec(xw.at(l), mine);
         }
       });
-      if constexpr (FastMem<GS, R>::kStateHbm) W::sync(); else W::order();   // (LDS: no wait — it executes a wavefront's accesses in order, the reads below see these writes)
+      if constexpr (FastMem<GS, R>::kStateHbm) W::hbm_sync(); else W::order();   // (LDS: no wait — it executes a wavefront's accesses in order, the reads below see these writes)
       gather();     // the next pod's claims (behind this pod's record write): in flight while the loop comes around
       bi++; steps++;
       if (KS_UNLIKELY(rf >= 0)) break;

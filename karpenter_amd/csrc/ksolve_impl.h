@@ -1818,8 +1818,8 @@ static void solve_probes(ksolve_handle** hs, uint32_t n, ksolve_results* outs, k
 }
 
 // Memory plan of the cursor engine. 0: claim records (32 B with one row of class slots, 56 B with four) + order arrays (6 B) per
-// claim in LDS, ~3,000 claims beside the caches; 1: the claim records in HBM (FastWork::c_rec), only the order arrays in LDS: ~15,000
-// claims; 2: the order arrays in HBM too (FastWork::o_key / o_ord / o_snap): 65,472 claims, the range of the 16-bit claim ids.
+// claim in LDS, ~3,000 claims beside the caches; 1: the claim records and the slow sorts' snapshot in HBM (FastWork::c_rec / o_snap), only the
+// order's keys and ids in LDS: ~27,000 claims; 2: the order arrays in HBM too (FastWork::o_key / o_ord / o_snap): 65,472 claims, the range of the 16-bit claim ids.
 // rows: 1 while at most 64 pod classes are ever live at once in the queue (counted before the loop), ks::kFastRows otherwise.
 static void fast_plan_set(ksolve_handle* h, int plan, int rows) {
   const bool wide = plan >= 1;
@@ -1835,7 +1835,7 @@ static void fast_plan_set(ksolve_handle* h, int plan, int rows) {
   fp.off_misc = off; off = align(off + (int)sizeof(ks::FastMisc));
   fp.off_hot = off; off = align(off + (int)sizeof(ks::FastHot));
   const int budget = 160 * 1024 - 512;
-  const int per_claim = (wide ? 0 : rec_bytes) + 6;
+  const int per_claim = wide ? 4 : rec_bytes + 6;   // plan 1: the order's keys and ids; plan 0: the record, the order and the order's snapshot
   int cap = plan >= 2 ? 65472 : ((budget - off - 64) / per_claim) & ~63;
   if (cap > 65472) cap = 65472;
   if (!wide && h->opts.lds_claim_cap && (int)((h->opts.lds_claim_cap + 63) & ~63u) < cap) cap = (int)((h->opts.lds_claim_cap + 63) & ~63u);
@@ -1849,7 +1849,7 @@ static void fast_plan_set(ksolve_handle* h, int plan, int rows) {
   const int lds_order = plan >= 2 ? 0 : cap;
   fp.off_key = off; off = align(off + lds_order * 2);
   fp.off_ord = off; off = align(off + lds_order * 2);
-  fp.off_snap = off; off = align(off + lds_order * 2);
+  fp.off_snap = off; if (!wide) off = align(off + lds_order * 2);   // (plans 1, 2: the snapshot is FastWork::o_snap)
   fp.total_bytes = off;
 }
 

@@ -47,6 +47,14 @@ struct Wave {
   // accesses to one memory in order.
   KS_DEV static void order() { asm volatile("" ::: "memory"); }
   KS_DEV static void sched_fence() { __builtin_amdgcn_sched_barrier(0); }   // the instruction scheduler moves nothing across this point
+  // Between a store to HBM and another lane's load of the same address in the cursor engine's fast loop: the fence (the stores are
+  // waited for). -DKS_FAST_NO_HBM_FENCE (measurement builds only, scripts/gpu_r5_f.sh) makes it a compiler-only barrier, relying on
+  // the memory pipeline keeping one wavefront's accesses to an address in order.
+#ifdef KS_FAST_NO_HBM_FENCE
+  KS_DEV static void hbm_sync() { order(); }
+#else
+  KS_DEV static void hbm_sync() { sync(); }
+#endif
   template <class F>
   KS_DEV static uint64_t ballot(F f) { return __builtin_amdgcn_ballot_w64((bool)f(lane())); }   // (the builtin on a bool: the compare itself writes the mask; __ballot(int) materialises 0 / 1 in a VGPR and compares again)
   // four ballots from ONE evaluation of f(lane) (bits 0..3 of its result): the loads behind the predicates happen once
@@ -236,6 +244,7 @@ struct Wave {
   static void sync() {}
   static void order() {}
   static void sched_fence() {}
+  static void hbm_sync() {}
   template <class F>
   static uint64_t ballot(F f) {
     uint64_t m = 0;
