@@ -191,7 +191,17 @@ func (rc *ResidentCluster) Sweep(ctx context.Context, candidateSets [][]string) 
 	desc.pod_off, desc.pods = cU32(&arena, podOff), cU32(&arena, pods)
 	desc.tmpl_limits = cI64(&arena, limits)
 	var out C.ksolve_sweep_results
-	stop := watch(ctx, rc.p.handle)
+	// every device's share polls its own handle's flag: a cancelled context reaches all of them (ADVICE r4: only the first
+	// device's probes stopped, the call still waited for the slowest replica)
+	stops := []func(){watch(ctx, rc.p.handle)}
+	for _, r := range rc.replicas {
+		stops = append(stops, watch(ctx, r.p.handle))
+	}
+	stop := func() {
+		for _, f := range stops {
+			f()
+		}
+	}
 	var st C.ksolve_status
 	if len(rc.replicas) == 0 {
 		st = C.ksolve_sweep(rc.p.handle, &desc, &out)

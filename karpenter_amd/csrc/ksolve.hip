@@ -166,6 +166,7 @@ static void be_tic(ksolve_handle* h, int slot) {
   if (roctx().push) roctx().push(kPhaseRange[slot & 7]);
   hip_check(h, hipEventRecord(HB(h)->ev0[slot], HB(h)->stream), "hipEventRecord");
 }
+static void be_range_drop(ksolve_handle*) { if (roctx().pop) roctx().pop(); }
 static void be_toc(ksolve_handle* h, int slot) {
   hip_check(h, hipEventRecord(HB(h)->ev1[slot], HB(h)->stream), "hipEventRecord");
   hip_check(h, hipEventSynchronize(HB(h)->ev1[slot]), "hipEventSynchronize");

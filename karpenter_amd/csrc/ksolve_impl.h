@@ -113,6 +113,10 @@ static void* be_stage(ksolve_handle* h, size_t bytes);   // page-locked host mem
 static bool be_ok(ksolve_handle* h);
 static void be_tic(ksolve_handle* h, int slot);
 static void be_toc(ksolve_handle* h, int slot);
+static void be_range_drop(ksolve_handle* h);   // closes the trace range of a be_tic whose phase ends in an error (no timing)
+// a phase that has several error exits: the range be_tic opened is closed on whichever way out (the marker trace nested wrongly
+// for the rest of the process after a failed sweep)
+struct PhaseRange { ksolve_handle* h; bool open; ~PhaseRange() { if (open) be_range_drop(h); } };
 static void be_launch_it_index(ksolve_handle* h, int n, const ks::ItIndexArgs& a);
 static void be_launch_row_hash(ksolve_handle* h, int n, const ks::RowArgs& a);
 static void be_launch_row_class(ksolve_handle* h, int n, const ks::RowArgs& a);
@@ -1124,6 +1128,7 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
   const uint32_t total_pods = pod_off[n], total_nodes = node_off[n];
   const bool bounds = base->ws.n_hg != nullptr;
   be_tic(base, T_UPLOAD);
+  PhaseRange upload_range{base, true};
 #ifdef KSOLVE_TEST_HOOKS
   const bool trace = getenv("KSOLVE_TEST_SWEEP_TRACE") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
@@ -1368,6 +1373,7 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
   }
 #endif
   be_toc(base, T_UPLOAD);
+  upload_range.open = false;
   if (!be_ok(base)) return fail(base, KSOLVE_ERR_DEVICE, base->error.empty() ? "sweep upload failed" : base->error);
 
   // ---- the launch: block b = the general engine on probe b ----

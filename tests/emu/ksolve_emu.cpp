@@ -31,6 +31,7 @@ static void* be_stage(ksolve_handle* h, size_t bytes) {   // the device build: p
 static void be_thread_init(ksolve_handle*) {}
 static bool be_ok(ksolve_handle*) { return true; }
 static void be_tic(ksolve_handle* h, int slot) { ((EmuBackend*)h->backend)->t0[slot] = std::chrono::steady_clock::now(); }
+static void be_range_drop(ksolve_handle*) {}
 static void be_toc(ksolve_handle* h, int slot) {
   h->timers.ms[slot] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ((EmuBackend*)h->backend)->t0[slot]).count();
 }
