@@ -273,7 +273,10 @@ typedef struct {
                                     * tests use it to prove which engine produced a result); 3 = cursor engine only, with the claims' state
                                     * in HBM from the start (the plan the library moves to by itself when the LDS plan runs out of
                                     * claims); 4 = cursor engine only, claim state AND claim order in HBM from the start (the plan above
-                                    * ~15,000 in-flight NodeClaims, up to 65,472). All give identical Results. */
+                                    * ~15,000 in-flight NodeClaims, up to 65,472); 5 = cursor engine only, LDS plan, on ONE wavefront (by
+                                    * default the LDS plan with one row of class slots runs the two-wavefront kernel ksolve_pack_fast2:
+                                    * a second wavefront recomputes a NodeClaim's acceptance words while the first places the next pod).
+                                    * All give identical Results. */
 } ksolve_options;
 
 /* One NodeClaim of Results.NewNodeClaims (scheduler.go:282, nodeclaim.go:43-62), in the order the reference's

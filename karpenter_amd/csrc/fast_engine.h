@@ -67,6 +67,8 @@ struct FastPlan {   // LDS plan of ksolve_pack_fast (bytes), computed by the hos
                       //    LDS holds the caches, the class slots and the loop's own state only.
   int rows;           // class slots / 64: 1 when at most 64 pod classes are ever live at once in the queue (FastWork::max_active,
                       //    counted before the loop by ksolve_fast_overlap), kFastRows otherwise
+  int helper;         // 1: the two-wavefront kernel (ksolve_pack_fast2: plan 0, one row of class slots) — a second wavefront of the
+                      //    workgroup recomputes a claim's acceptance words while the first one goes on to the next pod (FastMail)
 };
 
 struct FastMisc {   // small LDS tables
@@ -305,11 +307,40 @@ KS_FN bool fast_sampled(int n, int p) {   // choosePivot's nine positions (pdq_e
 // Everything that happens rarely (a new requirement set, a new claim, a new class slot, pdqsort leaving its single-move
 // path): real function calls, so that their code and registers stay out of the loop that places a pod.
 // The loop's state between two events (LDS): scalars, the class slots (lane = slot: class id, cursor) and the 64-entry queue block
+// The mailbox between the wavefront that places pods ("placer") and the one that recomputes acceptance words ("refresher") in the
+// two-wavefront kernel (ksolve_pack_fast2). A ring of two requests: request s (1, 2, ...) is ONE word, (s << 16) | claim, in
+// word[s & 1], written after the claim's new state (NodeClaim.Add) went to its record; the refresher serves the requests in order:
+// the claim's state from its record, CanAdd of that claim for the classes of all slots, the claim's acceptance word (or, when a
+// requirement set is not cached, `miss_x` of the ring slot and the sticky low bit of `done`: the word stays as it was, the placer
+// leaves its loop and the driver computes it), then `done` = s << 1 | miss.
+// Between a request and its `done` the claim's word is STALE, and a stale word is a superset of the true one (a claim that gained a
+// pod accepts no class it rejected before: requests only grow, the instance-type set only shrinks — the monotonicity the cursors
+// rest on): the placer's select may run on it, and waits only when the first acceptor it finds IS a claim with a request in flight.
+// The LDS executes every wavefront's accesses in the order they were issued, so whoever sees the second of two words written in
+// order sees the first.
+struct FastMail {
+  uint32_t word[2];   // request s: (s << 16) | claim, in word[s & 1]
+  uint32_t done;      // (s << 1) | miss: every request up to s is served
+  uint32_t gen;       // bumped by the placer at every entry into its loop (the class slots may have changed; a reported miss is taken)
+  uint32_t quit;      // the kernel is over
+  int32_t miss_x[2];
+  uint32_t pad;
+};
+#if KS_DEVICE
+KS_FN uint32_t mail_load(const KS_LDS uint32_t* p) { return *(const volatile KS_LDS uint32_t*)p; }
+KS_FN void mail_store(KS_LDS uint32_t* p, uint32_t v) { *(volatile KS_LDS uint32_t*)p = v; }
+#else
+KS_FN uint32_t mail_load(const uint32_t* p) { return *p; }
+KS_FN void mail_store(uint32_t* p, uint32_t v) { *p = v; }
+#endif
+
 struct FastHot {
+  alignas(16) FastMail mail;
   int base, bi, bn, n, np, max_steps, steps, status;
   int pend_a, pend_x, pend_new, ev_arg;
   uint32_t pend_mv;
   int rf_x;   // a claim whose acceptance words the driver must compute (the fast loop met a requirement set that is not cached), -1 = none
+  int rf_x2;  // two-wavefront kernel: a second one (the claim placed while the refresher reported the first)
   unsigned long long n_steps, n_tests, n_ref, hot_cycles;
   unsigned long long tsec[8];   // profiling builds: shader clock per path of the loop
   const uint32_t* q_class; const volatile int* cancel; uint32_t* q_claim; uint32_t* q_cnt;
@@ -850,7 +881,129 @@ struct FastHotCtx {   // LDS pointers of the loop, passed by value
   typename FastMem<GS, R>::o16 okey, oord; typename FastMem<GS, R>::States cst; KS_LDS FastEnt* ent; KS_LDS int32_t* pool;
   KS_LDS FastSlot* aslot; KS_LDS FastHot* hs;
 };
-enum { FEV_DONE = 0, FEV_REFRESH = 1, FEV_SLOT = 2, FEV_SLOWSORT = 3, FEV_PLACE = 4, FEV_NEWCLAIM = 5, FEV_COUNT = 6, FEV_SLOW = 7, FEV_CONT = 8 };
+enum { FEV_DONE = 0, FEV_REFRESH = 1, FEV_SLOT = 2, FEV_SLOWSORT = 3, FEV_PLACE = 4, FEV_NEWCLAIM = 5, FEV_COUNT = 6, FEV_SLOW = 7, FEV_CONT = 8, FEV_DEAD = 9 };
+
+// ---- the refresher (second wavefront of ksolve_pack_fast2) ---------------------------------------------------------------
+// The classes of the slots, one lane each, as the refresh needs them (registers of the refresher between two changes of the slots)
+template <int R>
+struct FastHelperK {
+  LaneVar<uint32_t> tok[R];
+  LaneVar<uint64_t> cvm[R], dm[R], gd[R];
+  LaneVar<int32_t> z0[R], z1[R], z2[R], z3[R];
+  uint32_t gen = 0xFFFFFFFFu, miss = 0;
+};
+template <class W, int R>
+KS_FN void fast_helper_consts(FastHelperK<R>& k, const KS_LDS FastSlot* aslot, const KS_LDS FastHot* hs) {
+  W::each([&](int l) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const FastSlot s = lds_get(&aslot[j * 64 + l]);
+      k.cvm[j].at(l) = s.cvmask; k.dm[j].at(l) = s.dmask; k.gd[j].at(l) = (s.dmask << 1) & ~s.dmask;
+      k.z0[j].at(l) = s.size[0]; k.z1[j].at(l) = s.size[1]; k.z2[j].at(l) = s.size[2]; k.z3[j].at(l) = s.size[3];
+      k.tok[j].at(l) = hs->scls[j][l] == kFastFree ? 0u : s.tmplok;   // (a slot whose class left inside the placer's run keeps its bits: nobody reads them before the next activation)
+    }
+  });
+}
+// Request s: CanAdd (nodeclaim.go:124-242) of the claim as it stands after the add, for the classes of all slots (lane = slot) — the
+// same predicates as the one-wavefront loop's refresh (fast_hot_run<.., false>)
+template <class W, int GS, int R>
+KS_FN void fast_helper_serve(FastHelperK<R>& k, FastHotCtx<GS, R> cx, uint32_t s_, uint32_t w_) {
+  KS_LDS FastHot* const hs = cx.hs;
+  KS_LDS FastMail* const mail = &hs->mail;
+  W::order();
+  const uint32_t gen = (uint32_t)fast_uniform((int)mail->gen);
+  if (gen != k.gen) { fast_helper_consts<W, R>(k, cx.aslot, hs); k.gen = gen; k.miss = 0; }
+  const uint32_t x = (uint32_t)fast_uniform((int)(w_ & 0xFFFFu));
+  const FastClaim st = cx.cst.state(x);      // (the placer does not touch a claim with a request in flight)
+  const uint64_t vmask = W::uniform(st.vmask);
+  const int32_t req[4] = {fast_uniform(st.req[0]), fast_uniform(st.req[1]), fast_uniform(st.req[2]), fast_uniform(st.req[3])};
+  const uint32_t tbit = 1u << (uint32_t)(vmask >> 56);
+  LaneVar<uint64_t> mlv[R], evm[R];
+  LaneVar<int32_t> c0[R], c1[R], c2[R], c3[R];
+  W::each([&](int l) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const uint64_t m = vmask & k.cvm[j].at(l);
+      const FastEnt e = ent_live(&cx.ent[fast_hash(m)]);
+      mlv[j].at(l) = m; evm[j].at(l) = e.vmask;
+      c0[j].at(l) = e.cap[0]; c1[j].at(l) = e.cap[1]; c2[j].at(l) = e.cap[2]; c3[j].at(l) = e.cap[3];
+    }
+  });
+  uint64_t accw[R];
+  bool miss = false;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const uint64_t tokm = W::ballot([&](int l) { return (k.tok[j].at(l) & tbit) != 0; });
+    const uint64_t fldm = W::ballot([&](int l) { return (((mlv[j].at(l) & k.dm[j].at(l)) + k.dm[j].at(l)) & k.gd[j].at(l)) == k.gd[j].at(l); });
+    const uint64_t simm = W::ballot([&](int l) { return evm[j].at(l) == mlv[j].at(l); });
+    const uint64_t f0 = W::ballot([&](int l) { return k.z0[j].at(l) <= c0[j].at(l) - req[0]; });
+    const uint64_t f1 = W::ballot([&](int l) { return k.z1[j].at(l) <= c1[j].at(l) - req[1]; });
+    const uint64_t f2 = W::ballot([&](int l) { return k.z2[j].at(l) <= c2[j].at(l) - req[2]; });
+    const uint64_t f3 = W::ballot([&](int l) { return k.z3[j].at(l) <= c3[j].at(l) - req[3]; });
+    const uint64_t basem = tokm & fldm, fitm = f0 & f1 & f2 & f3;
+    uint64_t accm = basem & simm & fitm;
+    const uint64_t oddm = basem & ~simm;   // set not at its first probe / not cached / an entry with further Pareto vectors (kFastExtBit)
+    if (KS_UNLIKELY(oddm != 0)) {
+      uint64_t ok2 = 0, missm = 0;
+      W::ballot2([&](int l) {
+        if (!((oddm >> l) & 1)) return 0;
+        FastEnt e;
+        if (fast_lookup(cx.ent, mlv[j].at(l), e) < 0) return 2;
+        const int32_t sz[4] = {k.z0[j].at(l), k.z1[j].at(l), k.z2[j].at(l), k.z3[j].at(l)};
+        return fast_fits(cx.pool, e, req, sz) ? 1 : 0;
+      }, ok2, missm);
+      accm |= ok2;
+      if (missm) miss = true;
+    }
+    accw[j] = accm;
+  }
+  if (W::leader()) {
+    if (KS_UNLIKELY(miss)) mail->miss_x[s_ & 1u] = (int32_t)x;
+    else {
+#pragma unroll
+      for (int j = 0; j < R; ++j) cx.cst.put_acc(x, j, accw[j]);
+    }
+  }
+  if (miss) k.miss = 1u;
+  W::order();
+  if (W::leader()) mail_store(&mail->done, (s_ << 1) | k.miss);
+}
+// before the two wavefronts part (the kernel's first statement, in front of its only barrier)
+KS_FN void fast_mail_init(KS_LDS FastMail* mail) {
+  mail->word[0] = 0; mail->word[1] = 0; mail->done = 0; mail->gen = 0; mail->quit = 0; mail->miss_x[0] = -1; mail->miss_x[1] = -1;
+}
+#if !KS_DEVICE
+// the emulation's refresher: a function the placer calls when it waits for a request (or, KSOLVE_EMU_REFRESHER_EAGER=1, right after
+// posting one) — the slowest and the fastest refresher there can be; the device's is anywhere in between
+template <int R> inline FastHelperK<R>& fast_emu_helper_k() { static thread_local FastHelperK<R> k; return k; }
+inline bool& fast_emu_helper_eager() { static thread_local bool e = false; return e; }   // (set per solve by the emulation's launcher)
+#endif
+#if KS_DEVICE
+// the refresher's life: poll, serve in order, leave when the placer says so
+template <class W, int GS, int R>
+KS_DEV void fast_helper_run(const FastWork* f, char* lds) {
+  const FastPlan& pl = f->plan;
+  FastHotCtx<GS, R> cx;
+  cx.hs = fast_uniform((KS_LDS FastHot*)(lds + pl.off_hot));
+  cx.cst.p = fast_uniform((KS_LDS FastRec<R>*)(lds + pl.off_state));
+  cx.okey = nullptr; cx.oord = nullptr;
+  cx.ent = fast_uniform((KS_LDS FastEnt*)(lds + pl.off_ent));
+  cx.pool = fast_uniform((KS_LDS int32_t*)(lds + pl.off_pool));
+  cx.aslot = fast_uniform((KS_LDS FastSlot*)(lds + pl.off_slot));
+  KS_LDS FastMail* const mail = &cx.hs->mail;
+  FastHelperK<R> k;
+  uint32_t seen = 0;
+  for (;;) {
+    const uint32_t w0 = mail_load(&mail->word[0]), w1 = mail_load(&mail->word[1]), quit = mail_load(&mail->quit);   // (the reads in flight together)
+    if (fast_uniform((int)quit) != 0) break;
+    const uint32_t nxt = seen + 1u;
+    const uint32_t w = (uint32_t)fast_uniform((int)((nxt & 1u) ? w1 : w0));
+    if ((w >> 16) != (nxt & 0xFFFFu)) continue;
+    fast_helper_serve<W, GS, R>(k, cx, nxt, w);
+    seen = nxt;
+  }
+}
+#endif
 
 // The loop that places pods: a function of its own, WITHOUT calls — whatever happens rarely (a requirement set seen for the
 // first time, a class without a slot, a new claim, pdqsort leaving its single-move path) ends the run with an event code; the
@@ -1187,7 +1340,7 @@ KS_COLD int fast_slow_run(FastHotCtx<GS, R> cx, int budget) {
 // was: the driver runs fast_slow_run for that one pod and comes back. Why two functions: with every rare path inside one loop the
 // compiler merged ~30 loop-carried values behind each of them — 274 instructions per pod of which 140 scalar moves, selects and
 // branches (SQ counters, profiles/round5); this loop has ONE path and one exit.
-template <class W, int GS, int R>
+template <class W, int GS, int R, bool HP = false>
 KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
   typedef typename FastMem<GS, R>::o16 o16;
   KS_LDS FastHot* const hs = fast_uniform(cx.hs);
@@ -1214,13 +1367,45 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       cur[j].at(l) = hs->cur[j][l]; scls[j].at(l) = hs->scls[j][l];
-      const FastSlot s = lds_get(&aslot[j * 64 + l]);
-      cvm[j].at(l) = s.cvmask; dm[j].at(l) = s.dmask; gd[j].at(l) = (s.dmask << 1) & ~s.dmask;
-      z0[j].at(l) = s.size[0]; z1[j].at(l) = s.size[1]; z2[j].at(l) = s.size[2]; z3[j].at(l) = s.size[3];
-      tok[j].at(l) = scls[j].at(l) == kFastFree ? 0u : s.tmplok;
+      if constexpr (!HP) {   // (two wavefronts: the classes' records are the refresher's registers)
+        const FastSlot s = lds_get(&aslot[j * 64 + l]);
+        cvm[j].at(l) = s.cvmask; dm[j].at(l) = s.dmask; gd[j].at(l) = (s.dmask << 1) & ~s.dmask;
+        z0[j].at(l) = s.size[0]; z1[j].at(l) = s.size[1]; z2[j].at(l) = s.size[2]; z3[j].at(l) = s.size[3];
+        tok[j].at(l) = scls[j].at(l) == kFastFree ? 0u : s.tmplok;
+      }
     }
     nxt_cls.at(l) = hs->nxt_cls[l]; bcls.at(l) = hs->bcls[l]; oclaim.at(l) = hs->oclaim[l]; ocnt.at(l) = hs->ocnt[l];
   });
+  // ---- two wavefronts: the requests in flight at the refresher (FastMail) ----
+  KS_LDS FastMail* const mail = &hs->mail;
+  uint32_t seq = 0;            // the last request posted
+  int pend1 = -1, pend2 = -1;  // the claims of requests seq and seq - 1 (until this wavefront waited for them)
+  bool dead = false;           // the refresher does not answer (never expected: the solve is handed to the general engine)
+  if constexpr (HP) {
+    seq = (uint32_t)fast_uniform((int)mail->done) >> 1;   // (nothing is in flight between two runs of this loop)
+    const uint32_t g = (uint32_t)fast_uniform((int)mail->gen) + 1u;
+    if (W::leader()) mail->gen = g;                     // the class slots may have changed; a reported miss has been taken
+    W::order();
+  }
+  // done counter >= s, as the refresher last reported (low bit: a miss)
+  auto done_word = [&]() -> uint32_t { return (uint32_t)fast_uniform((int)mail_load(&mail->done)); };
+  // wait until request s is served (emulation: serve it here — the laziest refresher there can be)
+  auto wait_for = [&](uint32_t s_) -> uint32_t {
+    uint32_t dw = done_word();
+#if KS_DEVICE
+    uint32_t spins = 0;
+    while ((int32_t)((dw >> 1) - s_) < 0) { if (++spins > (1u << 22)) { dead = true; break; } dw = done_word(); }
+#else
+    if ((int32_t)((dw >> 1) - s_) < 0) {
+      FastHelperK<R>& k = fast_emu_helper_k<R>();
+      uint32_t d = dw >> 1;
+      while (d != s_) { ++d; fast_helper_serve<W, GS, R>(k, cx, d, mail->word[d & 1u]); }
+      dw = done_word();
+    }
+#endif
+    W::order();
+    return dw;
+  };
   // pdqsort's other paths: with 12 < n < 50 every re-sort that has something to move; with n >= 50 a move from one of choosePivot's
   // nine sampled positions (fast_sampled, as three starts); with n <= 12 none (the stable insertion sort)
   const uint32_t inexact = (n > 12 && n < 50) ? 1u : 0u;
@@ -1296,6 +1481,8 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       uint32_t bad = badA;
       const int slot = row * 64 + sl;
       const FastSlot cs = lds_get(&aslot[slot]);
+      LaneVar<uint32_t> dwl;   // two wavefronts: the refresher's done word, read with the class record (made uniform behind the select)
+      if constexpr (HP) { W::order(); W::each([&](int l) { dwl.at(l) = mail->done; }); }
       // ---- select: the claims at the 64 positions, one lane each: the whole record (state and acceptance words) ----
       const uint64_t slbit = 1ull << sl;
       const int rws = row;
@@ -1304,10 +1491,24 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
         return W::ballot([&](int l) { return (awv.at(l) & ((int)rcs + l < n ? slbit : 0ull)) != 0; });
       };
       uint64_t okm = select();
+      if constexpr (HP) {
+        // The select ran on the words as they stand: the claims of the last two requests may still show classes they no longer
+        // accept. If the first acceptor is one of them: their words once more, behind the refresher's `done`.
+        const int x0 = (int)xv.bcast(ctz64(okm | (1ull << 63)));
+        if (KS_UNLIKELY((okm != 0) & ((x0 == pend1) | (x0 == pend2)))) {
+          const uint32_t dw2 = wait_for(seq);
+          bad |= (dw2 & 1u) << 5;                               // a requirement set that is not cached: out, nothing written
+          const int p1 = pend1, p2 = pend2;
+          W::each([&](int l) { const int xl = (int)xv.at(l); if (xl == p1 || xl == p2) awv.at(l) = cst.acc((uint32_t)xl, rws); });
+          pend1 = -1; pend2 = -1;
+          okm = select();
+        }
+      }
       if (KS_UNLIKELY((okm == 0) & (badA == 0) & ((int)rc0 + 64 < n))) {
         // The class's next acceptor is not among the 64 claims at its cursor (the claim it was filling is full): the rest of the
         // order, four windows per step, acceptance words only, all eight reads of a step in flight before the first is used;
         // then the select step once more, at the window that holds it.
+        if constexpr (HP) { if (pend1 >= 0 || pend2 >= 0) { const uint32_t dw2 = wait_for(seq); bad |= (dw2 & 1u) << 5; pend1 = -1; pend2 = -1; } }   // (exact words for the scan)
         int r = (int)rc0 + 64, found = -1;
         while (r < n && found < 0) {
           uint64_t m4[4];
@@ -1361,6 +1562,33 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       }
       if (KS_UNLIKELY(bad != 0)) break;
       // ---- nothing has been written so far; from here on the step is the plain one ----
+      if constexpr (HP) {
+        // The claim's new state goes to its record and the claim, as request seq + 1, to the refresher — FIRST, so that the refresher
+        // works while this wavefront moves the claim in the order, steps the cursors and reads the next pod's claims. The request
+        // takes the ring slot of request seq - 1, which must be done (it is, unless the refresher is the slower of the two).
+        {
+          const uint32_t dw = (uint32_t)fast_uniform((int)dwl.bcast(0));
+          if (KS_UNLIKELY(((int32_t)((dw >> 1) - (seq - 1u)) < 0) | ((dw & 1u) != 0))) {
+            const uint32_t dw2 = wait_for(seq - 1u);
+            if (dw2 & 1u) break;                                // a requirement set that is not cached: out, nothing written
+          }
+        }
+        ++seq;
+        const int fo = first_ok; const uint32_t sq = seq;
+        W::each([&](int l) {
+          if (l == fo) {
+            FastClaim mine;
+            mine.vmask = nmv.at(l); mine.req[0] = n0v.at(l); mine.req[1] = n1v.at(l); mine.req[2] = n2v.at(l); mine.req[3] = n3v.at(l);
+            cst.put_state(xv.at(l), mine);
+            W::order();
+            mail_store(&mail->word[sq & 1u], (sq << 16) | xv.at(l));
+          }
+        });
+        pend2 = pend1; pend1 = x;
+#if !KS_DEVICE
+        if (fast_emu_helper_eager()) wait_for(seq);   // (emulation: the refresher at its fastest; by default at its laziest)
+#endif
+      }
       {
         // The order: lanes first_ok+1 .. first_ok+sm (the claims with a smaller count) step one position to the left, the claim
         // lands behind them with its new count (lane first_ok writes that entry)
@@ -1387,11 +1615,21 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
             const uint32_t fm = me ? lastm : 0u;
             const uint32_t rr = cur[j].at(l);
             cur[j].at(l) = me ? (uint32_t)a : rr - (uint32_t)((rr - ua1) < su);
-            scls[j].at(l) |= fm; tok[j].at(l) &= ~fm;
+            scls[j].at(l) |= fm;
+            if constexpr (!HP) tok[j].at(l) &= ~fm;
           }
         });
       }
       n_ref += (unsigned long long)((uint32_t)a + 1u);
+      if constexpr (HP) {
+        // the next pod: its class slot and cursor, the order's entries there (behind this pod's order writes), the claims' records
+        if constexpr (FastMem<GS, R>::kOrderHbm) W::hbm_sync(); else W::order();
+        W::sched_fence();
+        stage_a(bi + 1);
+        gather();
+        bi++; steps++;
+        continue;
+      }
       // ---- refresh: CanAdd (nodeclaim.go:124-242) of the claim as it stands now, for the classes of all slots (lane = slot):
       // the next pod's order reads go out first, the cache reads behind them (both in flight together), then the predicates ----
       const uint32_t tbit = 1u << (uint32_t)(ns.vmask >> 56);
@@ -1471,9 +1709,22 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
     W::each([&](int l) { bcls.at(l) = nxt_cls.at(l); });
     W::each([&](int l) { if (nb + l < np) nxt_cls.at(l) = gqcls[nb + l]; });
   }
+  // ---- two wavefronts: nothing stays in flight between two runs of this loop; a miss the refresher reported is the driver's ----
+  int rf2 = -1;
+  if constexpr (HP) {
+    const uint32_t dw = wait_for(seq);
+    if (KS_UNLIKELY((dw & 1u) != 0)) {
+      rf = fast_uniform((int)mail->miss_x[0]); rf2 = fast_uniform((int)mail->miss_x[1]);
+      if (rf < 0) { rf = rf2; rf2 = -1; }
+      W::order();
+      if (W::leader()) { mail->miss_x[0] = -1; mail->miss_x[1] = -1; mail_store(&mail->done, seq << 1); }
+      W::order();
+    }
+    if (KS_UNLIKELY(dead)) return FEV_DEAD;
+  }
   // ---- state out (only what this function changes) ----
   if (bi != bi_in || base != base_in) {
-    if (W::leader()) { hs->base = base; hs->bi = bi; hs->bn = bn; hs->steps = steps; hs->n_ref = n_ref; hs->rf_x = rf; hs->n_steps += 4 * n_ext; }
+    if (W::leader()) { hs->base = base; hs->bi = bi; hs->bn = bn; hs->steps = steps; hs->n_ref = n_ref; hs->rf_x = rf; hs->rf_x2 = rf2; hs->n_steps += 4 * n_ext; }
     W::each([&](int l) {
 #pragma unroll
       for (int j = 0; j < R; ++j) { hs->cur[j][l] = cur[j].at(l); hs->scls[j][l] = scls[j].at(l); }
@@ -1485,7 +1736,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
 }
 
 // The driver: runs the loop, handles its events through FastCold.
-template <class W, int GS = 0, int R = 1>
+template <class W, int GS = 0, int R = 1, bool HP = false>
 struct FastEngine {
   FastCold<W, GS, R> cold;
   KS_LDS FastHot* hs;
@@ -1504,7 +1755,7 @@ struct FastEngine {
       h->base = 0; h->bi = 0; h->bn = 0; h->n = 0; h->np = np; h->steps = 0; h->status = 0;
       const long long ms_ = cold.Sk->max_steps;
       h->max_steps = ms_ < 0 ? -1 : (int)(ms_ > 0x7FFFFFFF ? 0x7FFFFFFF : ms_);
-      h->pend_a = -1; h->pend_x = 0; h->pend_mv = 0; h->pend_new = 0; h->ev_arg = 0; h->rf_x = -1;
+      h->pend_a = -1; h->pend_x = 0; h->pend_mv = 0; h->pend_new = 0; h->ev_arg = 0; h->rf_x = -1; h->rf_x2 = -1;
       h->n_steps = 0; h->n_tests = 0; h->n_ref = 0; h->hot_cycles = 0;
       for (int i = 0; i < 8; ++i) h->tsec[i] = 0;
       h->q_class = cold.Fk->q_class; h->cancel = cold.Sk->cancel_flag;
@@ -1524,13 +1775,15 @@ struct FastEngine {
     const bool use_fast = fast_uniform(h->max_steps) < 0;   // (a step limit — tests — is counted by the general loop)
     for (;;) {
       const unsigned long long tf0 = W::clock();
-      int ev = use_fast ? fast_uniform(fast_hot_run<W, GS, R>(cx)) : (int)FEV_SLOW;
+      int ev = use_fast ? fast_uniform(fast_hot_run<W, GS, R, HP>(cx)) : (int)FEV_SLOW;
       t_fast += W::clock() - tf0; n_fast++;
+      if (HP && ev == FEV_DEAD) { cold.bail_code = 28; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }   // (the refresher wavefront does not answer)
       if (use_fast && fast_uniform(h->rf_x) >= 0) {
-        const int rx = fast_uniform(h->rf_x);
-        if (W::leader()) h->rf_x = -1;
+        const int rx = fast_uniform(h->rf_x), rx2 = HP ? fast_uniform(h->rf_x2) : -1;
+        if (W::leader()) { h->rf_x = -1; h->rf_x2 = -1; }
         W::sync();
         if (fast_uniform(cold.refresh_claim(rx)) < 0) { cold.bail_code = 21; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
+        if (rx2 >= 0 && fast_uniform(cold.refresh_claim(rx2)) < 0) { cold.bail_code = 21; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }
         continue;
       }
       if (ev == FEV_SLOW) { const unsigned long long ts0 = W::clock(); ev = fast_uniform(fast_slow_run<W, GS, R>(cx, use_fast ? 1 : 0x7FFFFFFF)); t_slow += W::clock() - ts0; n_slow++; }

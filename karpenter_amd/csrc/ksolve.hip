@@ -627,6 +627,19 @@ __global__ void __launch_bounds__(64) ksolve_pack_fast(const ks::FastArgs* a) {
   ks::FastEngine<ks::Wave, GS, R> eng(&a->pv, &a->ws, &a->fw, lds);
   eng.solve();
 }
+// The LDS plan with one row of class slots on TWO wavefronts (FastPlan::helper; fast_engine.h FastMail): wavefront 0 places the
+// pods, wavefront 1 — on another SIMD of the same CU, so the two issue side by side — recomputes the acceptance words of the claim a
+// pod was added to while wavefront 0 is at the next pod. One barrier, in front of everything: the mailbox is zero when they part.
+__global__ void __launch_bounds__(128) ksolve_pack_fast2(const ks::FastArgs* a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  KS_LDS ks::FastHot* const hs = (KS_LDS ks::FastHot*)(lds + a->fw.plan.off_hot);
+  if (threadIdx.x == 0) ks::fast_mail_init(&hs->mail);
+  __syncthreads();
+  if (threadIdx.x >= 64) { ks::fast_helper_run<ks::Wave, 0, 1>(&a->fw, lds); return; }
+  ks::FastEngine<ks::Wave, 0, 1, true> eng(&a->pv, &a->ws, &a->fw, lds);
+  eng.solve();
+  if (threadIdx.x == 0) ks::mail_store(&hs->mail.quit, 1u);
+}
 // Batched form: block b runs the cursor engine (LDS plan) on problem b.
 __global__ void __launch_bounds__(64) ksolve_pack_fast_batch(const ks::FastArgs* const* items) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -770,11 +783,12 @@ static ksolve_pack_fast_fn pack_fast_kernel(int plan, int rows) {
 }
 static void be_launch_pack_fast(ksolve_handle* h) {
   const int lds_bytes = h->fw.plan.total_bytes;
-  const ksolve_pack_fast_fn fn = pack_fast_kernel(h->fw.plan.global_state, h->fw.plan.rows);
+  const bool two = h->fw.plan.helper != 0;   // (plan 0, one row of class slots: placer + refresher)
+  const ksolve_pack_fast_fn fn = two ? ksolve_pack_fast2 : pack_fast_kernel(h->fw.plan.global_state, h->fw.plan.rows);
   if (!hip_check(h, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
   ks::FastArgs a{h->pv, h->ws, h->fw};
   be_h2d(h, h->d_fast_args, &a, sizeof(a));
-  hipLaunchKernelGGL(fn, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
+  hipLaunchKernelGGL(fn, dim3(1), dim3(two ? 128 : 64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
   hip_check(h, hipGetLastError(), "ksolve_pack_fast launch");
 }
 static void be_launch_pack_fast_batch(ksolve_handle** hs, int n) {

@@ -1833,6 +1833,7 @@ static void fast_plan_set(ksolve_handle* h, int plan, int rows) {
   ks::FastPlan& fp = h->fw.plan;
   rows = rows <= 1 ? 1 : ks::kFastRows;
   fp.rows = rows;
+  fp.helper = (plan == 0 && rows == 1 && h->opts.engine != 5) ? 1 : 0;   // the two-wavefront kernel (engine 5: tests and measurements of the one-wavefront form)
   const int rec_bytes = rows == 1 ? (int)sizeof(ks::FastRec<1>) : (int)sizeof(ks::FastRec<ks::kFastRows>);
   int off = 0;
   fp.off_ent = off; off = align(off + ks::kFastEnt * (int)sizeof(ks::FastEnt));

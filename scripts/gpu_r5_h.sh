@@ -1,0 +1,33 @@
+# round 5, GPU pass H: where the pack kernel's time goes — shader clock inside the fast loop, the one-pod loop and every event kind
+# (profiling build, -DKSOLVE_PHASE_TIMERS), and the product's bench line
+set -x
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r5h; mkdir -p $O
+export TMPDIR=/tmp
+timeout 600 python - <<'PY' 2>&1 | tee $O/fast_phases.log
+import os
+os.environ["KSOLVE_TEST_SOLVER_LIB"] = "1"
+from karpenter_amd import fixtures as fx
+from karpenter_amd.scheduling import NewScheduler
+names = ["slow loop (inside)", "ev:refresh", "ev:slot", "ev:slowsort", "ev:place", "ev:newclaim", "total", "counts(packed)", "fast loop", "n fast calls", "slow loop (calls)", "n slow calls", "n refresh", "n slot", "n slowsort | n place<<32", "n newclaim"]
+for label, prob in (("config2 1M", fx.config2(pods=1000000)), ("config4 1M (four rows)", fx.config4(pods=1000000, n_types=1000, n_pools=16, seed=42))):
+    s = NewScheduler(prob, solver_lib=os.path.abspath("karpenter_amd/variants/libksolve_timers.so"))
+    r = s.Solve(repeat=2, want_results=False)
+    c = r["counters"]; pc = c["phaseCycles"]
+    print(label, c["engine"], "plan", c.get("cursorMemoryPlan"), "pack ms", [round(t["pack_kernel_ms"], 1) for t in r["timings"]], "pods", c["pods"], "claims", c["claims"])
+    for n, v in zip(names, pc):
+        print("%-28s %14d  %9.1f /pod" % (n, v, v / c["pods"]))
+    s.close()
+PY
+timeout 900 python bench.py --steps 5 --topology-pods 0 --components-pods 0 --beyond-lds-pods 0 --whole-batch-exact-pods 0 --whole-batch-pods 0 --batch-problems 0 --sweep-nodes 0 --no-cpu-baseline --no-host-engine-baseline 2>$O/bench_reduced.err | tail -1 > $O/bench_reduced.json
+tail -3 $O/bench_reduced.err
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r5h/bench_reduced.json"))
+print("value", d["value"], "ms_per_step", d["ms_per_step"], "pack ms", d["pack_kernel"]["avg_kernel_ms"])
+PY
+for eng in auto cursor-wide cursor-hbm; do timeout 300 python tests/tools/gpu_check_pin.py tests/golden/fullsize/config2_p1000000_t500_s42.json $eng 2>&1 | tail -1 | tee -a $O/pins.log; done
+for eng in auto cursor-hbm; do timeout 300 python tests/tools/gpu_check_pin.py tests/golden/fullsize/config4_p1000000_t1000_s42_x16.json $eng 2>&1 | tail -1 | tee -a $O/pins.log; done
+timeout 300 python tests/tools/gpu_check_pin.py tests/golden/fullsize/config2_p2000000_t500_s42.json auto 2>&1 | tail -1 | tee -a $O/pins.log
+timeout 300 python tests/tools/gpu_check_pin.py tests/golden/fullsize/config1_p5000_t50_s42.json auto 2>&1 | tail -1 | tee -a $O/pins.log
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "edge or cursor or batch or hundred or ragged or empty" 2>&1 | tail -5 | tee $O/pytest_subset.log

@@ -107,7 +107,14 @@ static void be_launch_pack_fast(ksolve_handle* h) {
   be_h2d(h, h->d_fast_args, &a, sizeof(a));
   const ks::FastArgs* a_ = h->d_fast_args;
   const int gs = h->fw.plan.global_state;
-  if (h->fw.plan.rows == 1) {
+  if (h->fw.plan.helper) {
+    // ksolve_pack_fast2: the placer's code; the refresher wavefront is a function the placer calls when it waits for it
+    ks::FastHot* hs = (ks::FastHot*)(lds.data() + h->fw.plan.off_hot);
+    ks::fast_mail_init(&hs->mail);
+    ks::fast_emu_helper_k<1>() = ks::FastHelperK<1>();
+    { const char* v = getenv("KSOLVE_EMU_REFRESHER_EAGER"); ks::fast_emu_helper_eager() = v && v[0] == '1'; }
+    ks::FastEngine<ks::Wave, 0, 1, true> eng(&a_->pv, &a_->ws, &a_->fw, lds.data()); eng.solve();
+  } else if (h->fw.plan.rows == 1) {
     if (gs == 2) { ks::FastEngine<ks::Wave, 2, 1> eng(&a_->pv, &a_->ws, &a_->fw, lds.data()); eng.solve(); }
     else if (gs) { ks::FastEngine<ks::Wave, 1, 1> eng(&a_->pv, &a_->ws, &a_->fw, lds.data()); eng.solve(); }
     else { ks::FastEngine<ks::Wave, 0, 1> eng(&a_->pv, &a_->ws, &a_->fw, lds.data()); eng.solve(); }

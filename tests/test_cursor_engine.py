@@ -27,7 +27,10 @@ def check_cursor(oracle, emu, prob, want=None):
     parity.assert_same_results(got, want)
     assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
     assert abs(got["packingCost"] - want["packingCost"]) < 1e-9 * max(1.0, want["packingCost"])
-    for plan, engine in ((1, "cursor-wide"), (2, "cursor-hbm")):   # the same engine with its claim state / claim order in HBM (fast_engine.h FastMem)
+    # the same engine on ONE wavefront (engine="cursor" on the LDS plan with one row of class slots is the placer + refresher pair of
+    # ksolve_pack_fast2, whose refresher the emulation runs as late as the protocol allows), and with its claim state / claim order in
+    # HBM (fast_engine.h FastMem)
+    for plan, engine in ((0, "cursor-solo"), (1, "cursor-wide"), (2, "cursor-hbm")):
         other = NewScheduler(with_engine(prob, engine), solver_lib=emu).Solve()
         assert other["counters"]["cursorMemoryPlan"] == plan
         parity.assert_same_results(other, want)
@@ -122,6 +125,28 @@ def test_fuzz_against_the_oracle(oracle, emu, block):
             parity.assert_same_results(got, want)
             declined += 1
     assert ran >= 15, (ran, declined)
+
+
+def test_refresher_wavefront_early_or_late_same_results(oracle, emu, monkeypatch):
+    """The two-wavefront kernel's answer must not depend on WHEN the refresher serves a request: the emulation runs it as late as
+    the protocol allows by default (a request is served when the placer waits for it: every stale acceptance word the placer can
+    ever see, it sees) and right behind the request with KSOLVE_EMU_REFRESHER_EAGER=1; the device is anywhere in between."""
+    for seed in range(12):
+        rng = random.Random(7000 + seed)
+        prob = lite_problem(rng, rng.choice([200, 900, 2500]))
+        try:
+            monkeypatch.delenv("KSOLVE_EMU_REFRESHER_EAGER", raising=False)
+            late = NewScheduler(with_engine(prob, "cursor"), solver_lib=emu).Solve()
+        except Unsupported:
+            continue
+        monkeypatch.setenv("KSOLVE_EMU_REFRESHER_EAGER", "1")
+        early = NewScheduler(with_engine(prob, "cursor"), solver_lib=emu).Solve()
+        monkeypatch.delenv("KSOLVE_EMU_REFRESHER_EAGER")
+        solo = NewScheduler(with_engine(prob, "cursor-solo"), solver_lib=emu).Solve()
+        want = oracle.solve(prob)
+        for got in (late, early, solo):
+            parity.assert_same_results(got, want)
+            assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
 
 
 @pytest.mark.parametrize("block", range(4))
