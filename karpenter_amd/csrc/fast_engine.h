@@ -324,7 +324,8 @@ struct FastMail {
   uint32_t gen;       // bumped by the placer at every entry into its loop (the class slots may have changed; a reported miss is taken)
   uint32_t quit;      // the kernel is over
   int32_t miss_x[2];
-  uint32_t pad;
+  uint32_t helper;    // which wavefront of the workgroup is the refresher (the kernel picks one on another SIMD than the placer's)
+  uint32_t simd[4];   // SIMD of each wavefront of the workgroup (HW_ID), written before the barrier
 };
 #if KS_DEVICE
 KS_FN uint32_t mail_load(const KS_LDS uint32_t* p) { return *(const volatile KS_LDS uint32_t*)p; }
@@ -343,6 +344,7 @@ struct FastHot {
   int rf_x2;  // two-wavefront kernel: a second one (the claim placed while the refresher reported the first)
   unsigned long long n_steps, n_tests, n_ref, hot_cycles;
   unsigned long long tsec[8];   // profiling builds: shader clock per path of the loop
+  unsigned long long hw[4];     // profiling builds, two wavefronts: waits for the claim of a request in flight (count, cycles), for a ring slot (count), cycles from a request to its `done` as seen at those waits
   const uint32_t* q_class; const volatile int* cancel; uint32_t* q_claim; uint32_t* q_cnt;
   uint32_t cur[kFastRows][64];    // cursor of the class in the slot: every claim left of it has rejected the class for good
   uint32_t scls[kFastRows][64];   // class in the slot, kFastFree = none
@@ -688,9 +690,27 @@ struct FastCold {
     const int nc = n_claims;
     const typename FastMem<GS, R>::States cs_ = cst;
     for (int x0 = 0; x0 < nc; x0 += 64) {
-      uint64_t todo = W::ballot([&](int l) { return x0 + l < nc; });
-      uint64_t accm = 0;
-      n_cold_tests += (unsigned long long)popc64(todo);
+      // the plain verdicts first, straight-line (the claim's record, the first probe of the requirement-set cache, one compare per
+      // predicate); the lanes that need the long way — a set that is not at its first probe or not cached yet, an entry with further
+      // Pareto vectors — go through the probe loop below
+      LaneVar<uint64_t> mlv, evm, vmv;
+      LaneVar<int32_t> c0, c1, c2, c3, r0, r1, r2, r3;
+      W::each([&](int l) {
+        const int x = x0 + l < nc ? x0 + l : nc - 1;
+        const FastClaim st = cs_.state((uint32_t)x);
+        const uint64_t m = st.vmask & rec.cvmask;
+        const FastEnt e = lds_get16(&ent[fast_hash(m)]);
+        mlv.at(l) = m; evm.at(l) = e.vmask; vmv.at(l) = st.vmask;
+        c0.at(l) = e.cap[0]; c1.at(l) = e.cap[1]; c2.at(l) = e.cap[2]; c3.at(l) = e.cap[3];
+        r0.at(l) = st.req[0]; r1.at(l) = st.req[1]; r2.at(l) = st.req[2]; r3.at(l) = st.req[3];
+      });
+      const uint64_t validm = W::ballot([&](int l) { return x0 + l < nc; });
+      const uint64_t basem = validm & W::ballot([&](int l) { return ((rec.tmplok >> (vmv.at(l) >> 56)) & 1u) != 0 && fast_fields_ok(mlv.at(l), rec.dmask); });
+      const uint64_t simm = W::ballot([&](int l) { return evm.at(l) == mlv.at(l); });
+      const uint64_t fitm = W::ballot([&](int l) { return (rec.size[0] <= c0.at(l) - r0.at(l)) & (rec.size[1] <= c1.at(l) - r1.at(l)) & (rec.size[2] <= c2.at(l) - r2.at(l)) & (rec.size[3] <= c3.at(l) - r3.at(l)); });
+      uint64_t accm = basem & simm & fitm;
+      uint64_t todo = basem & ~simm;
+      n_cold_tests += (unsigned long long)popc64(validm);
       while (todo) {
         LaneVar<uint64_t> missv;
         const uint64_t td = todo;
@@ -753,15 +773,66 @@ struct FastCold {
   }
   // The new claim (appended at n-1 with one pod) takes its place behind the last claim with at most one pod. Returns its
   // position b >= 0 (Mp->acc = the class slots that accept it, from new_claim), -1 when pdqsort left the single-move path (lo_/hi_).
+  // arr[b+1 .. a] = arr[b .. a-1] for an LDS-resident array of 16-bit entries, 512 entries per step: every lane takes a 16-byte
+  // piece (eight entries), shifts it by one entry through its registers (the entry that crosses into the piece comes from the lane
+  // below it) and writes it back in place — from the top piece down, so that a step reads nothing an earlier step wrote. The
+  // one-entry-per-lane move this replaces cost a new claim's sort.Slice 43 dependent read-write rounds at 2,763 claims.
+  KS_DEV void shift_right16(KS_LDS uint16_t* arr, int b, int a) {
+    KS_LDS u32x4_alias* const v = (KS_LDS u32x4_alias*)arr;
+    const KS_LDS uint32_t* const dw = (const KS_LDS uint32_t*)arr;
+    for (int e0 = a & ~511; e0 >= 0 && e0 + 511 >= b; e0 -= 512) {
+      LaneVar<uint32_t> d0, d1, d2, d3, pv;
+      const uint32_t below = e0 > 0 ? dw[(e0 >> 1) - 1] : 0u;      // the two entries under the step's first piece
+      W::each([&](int l) {
+        const int e = e0 + 8 * l;
+        d0.at(l) = 0; d1.at(l) = 0; d2.at(l) = 0; d3.at(l) = 0;
+        if (e <= a && e + 7 >= b) { const u32x4_alias x = v[(e0 >> 3) + l]; d0.at(l) = x[0]; d1.at(l) = x[1]; d2.at(l) = x[2]; d3.at(l) = x[3]; }
+      });
+      // (the exchange runs on EVERY lane, then lane 0 takes the word below the step: a lane that is switched off during ds_bpermute
+      // reads as zero for its neighbour — the first build had the exchange inside the select and lane 1 got a zero from lane 0)
+      LaneVar<uint32_t> up;
+      W::each([&](int l) { up.at(l) = d3.shuffle(l, (l + 63) & 63); });
+      W::each([&](int l) { pv.at(l) = l ? up.at(l) : below; });
+      W::each([&](int l) {
+        const int e = e0 + 8 * l;
+        if (!(e <= a && e + 7 > b)) return;
+        auto mix = [&](uint32_t cur, uint32_t prev, int elo) {   // entries elo (low half) and elo + 1 (high half) of one word
+          const uint32_t sh = (cur << 16) | (prev >> 16);
+          const uint32_t m = ((elo > b && elo <= a) ? 0xFFFFu : 0u) | ((elo + 1 > b && elo + 1 <= a) ? 0xFFFF0000u : 0u);
+          return (sh & m) | (cur & ~m);
+        };
+        u32x4_alias y;
+        y[0] = mix(d0.at(l), pv.at(l), e); y[1] = mix(d1.at(l), d0.at(l), e + 2); y[2] = mix(d2.at(l), d1.at(l), e + 4); y[3] = mix(d3.at(l), d2.at(l), e + 6);
+        v[(e0 >> 3) + l] = y;
+      });
+      W::sync();
+    }
+  }
   KS_COLD int place_new_claim(int n) {
     n = (int)W::uniform((uint64_t)(uint32_t)n);
     const int a = n - 1;
     const bool exact = n <= 12 || (n >= 50 && !fast_sampled(n, a));
     if (!exact) { slow_sort(n, a, 1); return -1; }
-    order.n = n; order.defect = a; order.defect_append = true;
-    order.sort();
-    const o16 kq = order.key;
-    return W::find_first(0, n, [&](int i) { return kq[i] > 1u; }) - 1;   // the claims with one pod are the prefix it joined the end of
+    if constexpr (!FastMem<GS, R>::kOrderHbm) {
+      // insertion sort (n <= 12) and partialInsertionSort (pdq_emul.h) both make ONE stable move of the appended claim: left,
+      // behind the last claim whose count is not larger than its own — one pod, the smallest count there is: behind the claims
+      // with one pod, which the sorted array keeps in front
+      const o16 kq = order.key, oq = order.ord;
+      const int b = W::find_first(0, a, [&](int i) { return kq[i] > 1u; });
+      if (b < a) {
+        const uint32_t mo = oq[a];
+        shift_right16(kq, b, a);
+        shift_right16(oq, b, a);
+        if (W::leader()) { kq[b] = (uint16_t)1; oq[b] = (uint16_t)mo; }
+        W::sync();
+      }
+      return b;
+    } else {
+      order.n = n; order.defect = a; order.defect_append = true;
+      order.sort();
+      const o16 kq = order.key;
+      return W::find_first(0, n, [&](int i) { return kq[i] > 1u; }) - 1;   // the claims with one pod are the prefix it joined the end of
+    }
   }
 
   // addToNewNodeClaim (scheduler.go:695-790) for a pod no in-flight claim accepted: 1 = claim n created (appended to the
@@ -871,6 +942,10 @@ struct FastCold {
     c.column_resets = (unsigned long long)n_evict; c.ref_bin_evaluations = n_ref + n_ref_extra;
     c.cycles[20] = (unsigned long long)(bail_code > 0 ? bail_code : 0);
     if (tc) for (int i = 0; i < 16; ++i) c.cycles[i] = tc[i];
+#ifdef KSOLVE_PHASE_TIMERS
+    for (int i = 0; i < 4; ++i) c.cycles[16 + i] = hs->hw[i];
+    c.cycles[18] = (hs->hw[2] << 32) | (unsigned long long)(hs->mail.simd[0] | (hs->mail.simd[1] << 8) | (hs->mail.simd[2] << 16) | (hs->mail.simd[3] << 24));
+#endif
     if (W::leader()) *S.counters = c;
     W::sync();
   }
@@ -1381,6 +1456,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
   uint32_t seq = 0;            // the last request posted
   int pend1 = -1, pend2 = -1;  // the claims of requests seq and seq - 1 (until this wavefront waited for them)
   bool dead = false;           // the refresher does not answer (never expected: the solve is handed to the general engine)
+  unsigned long long hw0 = 0, hw1 = 0, hw2 = 0, hw3 = 0, t_post = 0;   // profiling builds: waits on a claim in flight (count, cycles), on a ring slot (count), request -> seen done (cycles, at those waits)
   if constexpr (HP) {
     seq = (uint32_t)fast_uniform((int)mail->done) >> 1;   // (nothing is in flight between two runs of this loop)
     const uint32_t g = (uint32_t)fast_uniform((int)mail->gen) + 1u;
@@ -1496,7 +1572,13 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
         // accept. If the first acceptor is one of them: their words once more, behind the refresher's `done`.
         const int x0 = (int)xv.bcast(ctz64(okm | (1ull << 63)));
         if (KS_UNLIKELY((okm != 0) & ((x0 == pend1) | (x0 == pend2)))) {
+#ifdef KSOLVE_PHASE_TIMERS
+          const unsigned long long tw0 = W::clock();
+#endif
           const uint32_t dw2 = wait_for(seq);
+#ifdef KSOLVE_PHASE_TIMERS
+          { const unsigned long long tw1 = W::clock(); hw0++; hw1 += tw1 - tw0; hw3 += tw1 - t_post; }
+#endif
           bad |= (dw2 & 1u) << 5;                               // a requirement set that is not cached: out, nothing written
           const int p1 = pend1, p2 = pend2;
           W::each([&](int l) { const int xl = (int)xv.at(l); if (xl == p1 || xl == p2) awv.at(l) = cst.acc((uint32_t)xl, rws); });
@@ -1569,7 +1651,13 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
         {
           const uint32_t dw = (uint32_t)fast_uniform((int)dwl.bcast(0));
           if (KS_UNLIKELY(((int32_t)((dw >> 1) - (seq - 1u)) < 0) | ((dw & 1u) != 0))) {
+#ifdef KSOLVE_PHASE_TIMERS
+            const unsigned long long tw0 = W::clock();
+#endif
             const uint32_t dw2 = wait_for(seq - 1u);
+#ifdef KSOLVE_PHASE_TIMERS
+            hw2++; (void)tw0;
+#endif
             if (dw2 & 1u) break;                                // a requirement set that is not cached: out, nothing written
           }
         }
@@ -1585,6 +1673,9 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
           }
         });
         pend2 = pend1; pend1 = x;
+#ifdef KSOLVE_PHASE_TIMERS
+        t_post = W::clock();
+#endif
 #if !KS_DEVICE
         if (fast_emu_helper_eager()) wait_for(seq);   // (emulation: the refresher at its fastest; by default at its laziest)
 #endif
@@ -1721,6 +1812,9 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       W::order();
     }
     if (KS_UNLIKELY(dead)) return FEV_DEAD;
+#ifdef KSOLVE_PHASE_TIMERS
+    if (W::leader()) { hs->hw[0] += hw0; hs->hw[1] += hw1; hs->hw[2] += hw2; hs->hw[3] += hw3; }
+#endif
   }
   // ---- state out (only what this function changes) ----
   if (bi != bi_in || base != base_in) {
@@ -1758,6 +1852,7 @@ struct FastEngine {
       h->pend_a = -1; h->pend_x = 0; h->pend_mv = 0; h->pend_new = 0; h->ev_arg = 0; h->rf_x = -1; h->rf_x2 = -1;
       h->n_steps = 0; h->n_tests = 0; h->n_ref = 0; h->hot_cycles = 0;
       for (int i = 0; i < 8; ++i) h->tsec[i] = 0;
+      for (int i = 0; i < 4; ++i) h->hw[i] = 0;
       h->q_class = cold.Fk->q_class; h->cancel = cold.Sk->cancel_flag;
       h->q_claim = cold.Fk->q_claim; h->q_cnt = cold.Fk->q_cnt;
     }
@@ -1775,7 +1870,10 @@ struct FastEngine {
     const bool use_fast = fast_uniform(h->max_steps) < 0;   // (a step limit — tests — is counted by the general loop)
     for (;;) {
       const unsigned long long tf0 = W::clock();
-      int ev = use_fast ? fast_uniform(fast_hot_run<W, GS, R, HP>(cx)) : (int)FEV_SLOW;
+      // (a new claim waits for its place in the order and the next pod is inside the current block — no block switch, no cancel poll
+      // stands before the sort: the driver's event at once, without a turn through fast_slow_run)
+      const bool place_now = use_fast && fast_uniform(h->pend_new) != 0 && fast_uniform(h->bi) < fast_uniform(h->bn) && fast_uniform(h->status) == 0;
+      int ev = place_now ? (int)FEV_PLACE : use_fast ? fast_uniform(fast_hot_run<W, GS, R, HP>(cx)) : (int)FEV_SLOW;
       t_fast += W::clock() - tf0; n_fast++;
       if (HP && ev == FEV_DEAD) { cold.bail_code = 28; cold.finish(3, 0, 0, 0, 0, 0, nullptr); return; }   // (the refresher wavefront does not answer)
       if (use_fast && fast_uniform(h->rf_x) >= 0) {

@@ -628,14 +628,24 @@ __global__ void __launch_bounds__(64) ksolve_pack_fast(const ks::FastArgs* a) {
   eng.solve();
 }
 // The LDS plan with one row of class slots on TWO wavefronts (FastPlan::helper; fast_engine.h FastMail): wavefront 0 places the
-// pods, wavefront 1 — on another SIMD of the same CU, so the two issue side by side — recomputes the acceptance words of the claim a
-// pod was added to while wavefront 0 is at the next pod. One barrier, in front of everything: the mailbox is zero when they part.
-__global__ void __launch_bounds__(128) ksolve_pack_fast2(const ks::FastArgs* a) {
+// pods, another one recomputes the acceptance words of the claim a pod was added to while wavefront 0 is at the next pod. The two must
+// sit on DIFFERENT SIMDs to issue side by side, and where the dispatcher puts a workgroup's wavefronts is its business: the
+// workgroup comes with four, each notes its SIMD (HW_ID bits 5:4), and the first one on another SIMD than wavefront 0's stays as
+// the refresher; the others leave. One barrier, in front of everything: the mailbox is zero when they part.
+__global__ void __launch_bounds__(256) ksolve_pack_fast2(const ks::FastArgs* a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   KS_LDS ks::FastHot* const hs = (KS_LDS ks::FastHot*)(lds + a->fw.plan.off_hot);
+  const int wave = (int)(threadIdx.x >> 6);
   if (threadIdx.x == 0) ks::fast_mail_init(&hs->mail);
+  if ((threadIdx.x & 63) == 0) hs->mail.simd[wave] = (uint32_t)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);   // HW_REG_HW_ID, SIMD_ID
   __syncthreads();
-  if (threadIdx.x >= 64) { ks::fast_helper_run<ks::Wave, 0, 1>(&a->fw, lds); return; }
+  if (wave > 0) {
+    int pick = 1;
+    for (int w = 3; w >= 1; --w) if (hs->mail.simd[w] != hs->mail.simd[0]) pick = w;
+    if (wave != __builtin_amdgcn_readfirstlane(pick)) return;
+    ks::fast_helper_run<ks::Wave, 0, 1>(&a->fw, lds);
+    return;
+  }
   ks::FastEngine<ks::Wave, 0, 1, true> eng(&a->pv, &a->ws, &a->fw, lds);
   eng.solve();
   if (threadIdx.x == 0) ks::mail_store(&hs->mail.quit, 1u);
@@ -788,7 +798,7 @@ static void be_launch_pack_fast(ksolve_handle* h) {
   if (!hip_check(h, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
   ks::FastArgs a{h->pv, h->ws, h->fw};
   be_h2d(h, h->d_fast_args, &a, sizeof(a));
-  hipLaunchKernelGGL(fn, dim3(1), dim3(two ? 128 : 64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
+  hipLaunchKernelGGL(fn, dim3(1), dim3(two ? 256 : 64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
   hip_check(h, hipGetLastError(), "ksolve_pack_fast launch");
 }
 static void be_launch_pack_fast_batch(ksolve_handle** hs, int n) {
