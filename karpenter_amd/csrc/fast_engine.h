@@ -1482,6 +1482,10 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
     W::order();
     return dw;
   };
+  // the refresher's done word as it stood BEFORE the records of the pod's claims were read (the LDS serves a wavefront's reads in
+  // order): a request it shows done had its acceptance word written when the gather read it
+  LaneVar<uint32_t> dwl;
+  auto read_done = [&]() { if constexpr (HP) { W::order(); W::each([&](int l) { dwl.at(l) = mail->done; }); } };
   // pdqsort's other paths: with 12 < n < 50 every re-sort that has something to move; with n >= 50 a move from one of choosePivot's
   // nine sampled positions (fast_sampled, as three starts); with n <= 12 none (the stable insertion sort)
   const uint32_t inexact = (n > 12 && n < 50) ? 1u : 0u;
@@ -1548,7 +1552,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
     // entries of this block the loop may place: not the queue's last one, nor the last one before a block at which the cancel flag
     // is polled (a Solve() that ends there reports the order of the last sort the reference would have run: their move stays undone)
     const int bf = bn - ((base + bn >= np || (polled && ((base + 64) & 1023) == 0)) ? 1 : 0);
-    if (bi < bf) { stage_a(bi); gather(); }
+    if (bi < bf) { stage_a(bi); read_done(); gather(); }
     while (bi < bf) {
       // Everything up to the first write is ONE basic block: whatever is not plain sets a bit of `bad` and the step goes on with
       // harmless values (lane 0, position 0), so that no branch stands between the loads and the compiler issues them together —
@@ -1557,8 +1561,6 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       uint32_t bad = badA;
       const int slot = row * 64 + sl;
       const FastSlot cs = lds_get(&aslot[slot]);
-      LaneVar<uint32_t> dwl;   // two wavefronts: the refresher's done word, read with the class record (made uniform behind the select)
-      if constexpr (HP) { W::order(); W::each([&](int l) { dwl.at(l) = mail->done; }); }
       // ---- select: the claims at the 64 positions, one lane each: the whole record (state and acceptance words) ----
       const uint64_t slbit = 1ull << sl;
       const int rws = row;
@@ -1568,22 +1570,44 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       };
       uint64_t okm = select();
       if constexpr (HP) {
-        // The select ran on the words as they stand: the claims of the last two requests may still show classes they no longer
-        // accept. If the first acceptor is one of them: their words once more, behind the refresher's `done`.
+        // The select ran on the words as the gather found them: the claims of the last two requests may still show classes they no
+        // longer accept — unless the done word read in front of the gather says their request was served. If the first acceptor is
+        // such a claim: wait for the refresher, the two claims' words in the same round trip as its done word, the select again.
         const int x0 = (int)xv.bcast(ctz64(okm | (1ull << 63)));
         if (KS_UNLIKELY((okm != 0) & ((x0 == pend1) | (x0 == pend2)))) {
+          const uint32_t dn = (uint32_t)fast_uniform((int)dwl.bcast(0)) >> 1;
+          const bool stale1 = pend1 >= 0 && (int32_t)(dn - seq) < 0, stale2 = pend2 >= 0 && (int32_t)(dn - (seq - 1u)) < 0;
+          if ((x0 == pend1 && stale1) || (x0 == pend2 && stale2)) {
 #ifdef KSOLVE_PHASE_TIMERS
-          const unsigned long long tw0 = W::clock();
+            const unsigned long long tw0 = W::clock();
 #endif
-          const uint32_t dw2 = wait_for(seq);
+            const uint32_t c1 = (uint32_t)(pend1 < 0 ? 0 : pend1), c2 = (uint32_t)(pend2 < 0 ? 0 : pend2);
+            uint64_t a1 = 0, a2 = 0;
+            uint32_t dw2 = 0;
+#if KS_DEVICE
+            for (uint32_t spins = 0;; ++spins) {
+              const uint32_t dv = mail_load(&mail->done);
+              W::order();
+              const uint64_t v1 = cst.acc(c1, 0), v2 = cst.acc(c2, 0);     // (behind the done word: served means written)
+              dw2 = (uint32_t)fast_uniform((int)dv); a1 = W::uniform(v1); a2 = W::uniform(v2);
+              if ((int32_t)((dw2 >> 1) - seq) >= 0) break;
+              if (spins > (1u << 22)) { dead = true; break; }
+              W::order();
+            }
+#else
+            dw2 = wait_for(seq); a1 = cst.acc(c1, 0); a2 = cst.acc(c2, 0);
+#endif
 #ifdef KSOLVE_PHASE_TIMERS
-          { const unsigned long long tw1 = W::clock(); hw0++; hw1 += tw1 - tw0; hw3 += tw1 - t_post; }
+            { const unsigned long long tw1 = W::clock(); hw0++; hw1 += tw1 - tw0; hw3 += tw1 - t_post; }
 #endif
-          bad |= (dw2 & 1u) << 5;                               // a requirement set that is not cached: out, nothing written
-          const int p1 = pend1, p2 = pend2;
-          W::each([&](int l) { const int xl = (int)xv.at(l); if (xl == p1 || xl == p2) awv.at(l) = cst.acc((uint32_t)xl, rws); });
-          pend1 = -1; pend2 = -1;
-          okm = select();
+            bad |= ((dw2 & 1u) | (uint32_t)dead) << 5;              // a requirement set that is not cached: out, nothing written
+            const int p1 = pend1, p2 = pend2;
+            W::each([&](int l) { const int xl = (int)xv.at(l); awv.at(l) = xl == p1 ? a1 : xl == p2 ? a2 : awv.at(l); });
+            okm = select();
+            pend1 = -1; pend2 = -1;                                 // (every request is served)
+          } else {
+            pend1 = stale1 ? pend1 : -1; pend2 = stale2 ? pend2 : -1;   // (served before the gather read their words)
+          }
         }
       }
       if (KS_UNLIKELY((okm == 0) & (badA == 0) & ((int)rc0 + 64 < n))) {
@@ -1645,20 +1669,18 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       if (KS_UNLIKELY(bad != 0)) break;
       // ---- nothing has been written so far; from here on the step is the plain one ----
       if constexpr (HP) {
+        static_assert(!HP || R == 1, "the two-wavefront loop: one row of class slots");
         // The claim's new state goes to its record and the claim, as request seq + 1, to the refresher — FIRST, so that the refresher
         // works while this wavefront moves the claim in the order, steps the cursors and reads the next pod's claims. The request
         // takes the ring slot of request seq - 1, which must be done (it is, unless the refresher is the slower of the two).
         {
           const uint32_t dw = (uint32_t)fast_uniform((int)dwl.bcast(0));
           if (KS_UNLIKELY(((int32_t)((dw >> 1) - (seq - 1u)) < 0) | ((dw & 1u) != 0))) {
-#ifdef KSOLVE_PHASE_TIMERS
-            const unsigned long long tw0 = W::clock();
-#endif
             const uint32_t dw2 = wait_for(seq - 1u);
 #ifdef KSOLVE_PHASE_TIMERS
-            hw2++; (void)tw0;
+            hw2++;
 #endif
-            if (dw2 & 1u) break;                                // a requirement set that is not cached: out, nothing written
+            if ((dw2 & 1u) | (uint32_t)dead) break;             // a requirement set that is not cached: out, nothing written
           }
         }
         ++seq;
@@ -1679,6 +1701,52 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
 #if !KS_DEVICE
         if (fast_emu_helper_eager()) wait_for(seq);   // (emulation: the refresher at its fastest; by default at its laziest)
 #endif
+        // the order: lanes first_ok+1 .. first_ok+sm step one position to the left, the claim lands behind them with its new count
+        {
+          const int rb = (int)rc0, smv = sm;
+          W::each([&](int l) {
+            if (l >= fo && l <= fo + smv) {
+              const bool me = l == fo;
+              const int dst = me ? rb + l + smv : rb + l - 1;
+              okey[dst] = (uint16_t)(me ? kv.at(l) + 1u : kv.at(l)); oord[dst] = (uint16_t)xv.at(l);
+            }
+          });
+        }
+        W::order();
+        // The next pod's stage A on the cursors AS THEY WILL BE — its class's cursor, read before the update below and corrected in
+        // scalar registers (this class's cursor comes to a; a cursor in (a, a+sm] steps left) — so that the order's entries are on
+        // their way while the vector registers are brought up to date. (The slot match runs on the slots as they were: a class that
+        // leaves with this pod is not the next pod's.)
+        const uint32_t ua1 = (uint32_t)a + 1u, su = (uint32_t)sm;
+        const uint32_t lastm = (uint32_t)((int32_t)clsw >> 31);   // all ones on the class's last entry (kFastLastBit is the sign bit)
+        const int slot_now = slot;
+        {
+          clsw = bcls.bcast((bi + 1) & 63);
+          const uint32_t kcls = clsw & ~kFastLastBit;
+          const uint64_t m0 = W::ballot([&](int l) { return scls[0].at(l) == kcls; });
+          badA = (uint32_t)fast_uniform((int)(m0 == 0));
+          sl = ctz64(m0 | (1ull << 63));
+          const uint32_t rr = cur[0].bcast(sl);
+          rc0 = sl == slot_now ? (uint32_t)a : rr - (uint32_t)((rr - ua1) < su);
+          order_reads(rc0);
+        }
+        // cursors in (a, a+sm] step left; the pod's result; the class's cursor comes to a; its slot is free after its last entry
+        {
+          const int bb = bi;
+          W::each([&](int l) {
+            const bool mine = l == bb;
+            oclaim.at(l) = mine ? (uint32_t)x : oclaim.at(l); ocnt.at(l) = mine ? cnt : ocnt.at(l);
+            const bool me = l == slot_now;
+            const uint32_t rr = cur[0].at(l);
+            cur[0].at(l) = me ? (uint32_t)a : rr - (uint32_t)((rr - ua1) < su);
+            scls[0].at(l) |= me ? lastm : 0u;
+          });
+        }
+        n_ref += (unsigned long long)ua1;
+        read_done();
+        gather();
+        bi++; steps++;
+        continue;
       }
       {
         // The order: lanes first_ok+1 .. first_ok+sm (the claims with a smaller count) step one position to the left, the claim
@@ -1706,21 +1774,11 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
             const uint32_t fm = me ? lastm : 0u;
             const uint32_t rr = cur[j].at(l);
             cur[j].at(l) = me ? (uint32_t)a : rr - (uint32_t)((rr - ua1) < su);
-            scls[j].at(l) |= fm;
-            if constexpr (!HP) tok[j].at(l) &= ~fm;
+            scls[j].at(l) |= fm; tok[j].at(l) &= ~fm;
           }
         });
       }
       n_ref += (unsigned long long)((uint32_t)a + 1u);
-      if constexpr (HP) {
-        // the next pod: its class slot and cursor, the order's entries there (behind this pod's order writes), the claims' records
-        if constexpr (FastMem<GS, R>::kOrderHbm) W::hbm_sync(); else W::order();
-        W::sched_fence();
-        stage_a(bi + 1);
-        gather();
-        bi++; steps++;
-        continue;
-      }
       // ---- refresh: CanAdd (nodeclaim.go:124-242) of the claim as it stands now, for the classes of all slots (lane = slot):
       // the next pod's order reads go out first, the cache reads behind them (both in flight together), then the predicates ----
       const uint32_t tbit = 1u << (uint32_t)(ns.vmask >> 56);
