@@ -137,6 +137,32 @@ def config4_sweep(args, device_index, rank, world, topology=False):
                              "with_descriptors_and_verdicts": len(cands) / lib_s, "through_python": len(cands) / dt},
                timed_region="ksched_sweep_arrays() (the faster of it and ksched_sweep(), the JSON form: library_call_json_form_s): probe descriptors (host library), ksolve_sweep (upload, one launch, finalize, download), verdicts")
     out["kernels"] = sweep_rooflines(tm, len(cands))
+    if args.sweep_contexts > 1 and not topology:
+        # Several contexts of the same cluster on THIS device (ksolve_sweep_replicas over handles that share a device): each handle
+        # has its own stream, page-locked staging and arena, its share of the probes runs on a host thread of its own — one share's
+        # descriptors / upload / finalize / download go beside another share's kernel. What a controller that keeps K handles per
+        # GPU gets from the same library call; the cluster tables are replicated K times (0.6 GB each at 100k nodes).
+        ctx = {}
+        extra = []
+        try:
+            for k in sorted({2, args.sweep_contexts}):
+                while len(extra) < k - 1:
+                    extra.append(dz.ResidentCluster.from_compact(cc, solver_lib=args.solver_lib))
+                best = None
+                for _ in range(4):
+                    cm = rc.decisions(cands, library_prices=True, arrays=True, replicas=extra[:k - 1])
+                    if [(c["decision"], c["replacement"], c.get("replacementCapacityType")) for c in cm] != [(c["decision"], c["replacement"], c.get("replacementCapacityType")) for c in cmds]:
+                        raise SystemExit("bench.py: the sweep over several contexts of one device disagrees with the sweep over one")
+                    t_ = rc.last_sweep["timings"]
+                    sec = (t_["descriptors_ms"] + t_["sweep_ms"] + t_["verdicts_ms"]) * 1e-3
+                    if best is None or sec < best[0]:
+                        best = (sec, t_)
+                ctx[str(k)] = {"library_call": best[0], "probes_per_s": len(cands) / best[0], "descriptors": best[1]["descriptors_ms"] * 1e-3, "ksolve_sweep_replicas": best[1]["sweep_ms"] * 1e-3,
+                               "verdicts": best[1]["verdicts_ms"] * 1e-3, "slowest_share": {"upload": best[1]["upload_us"] * 1e-6, "pack_kernel": best[1]["pack_us"] * 1e-6, "finalize": best[1]["finalize_us"] * 1e-6, "download": best[1]["download_us"] * 1e-6}}
+        finally:
+            for e in extra:
+                e.close()
+        out["contexts_on_one_device"] = dict(ctx, note="ksched_sweep_arrays over K handles of the same cluster on one GPU (ksolve_sweep_replicas: contiguous shares of about equal displaced pods, one host thread and one stream per handle); verdicts equal to the one-handle sweep's; `value` of this leg stays the one-handle call")
     if world == 1 and not args.no_parity_pin:
         # population-scale pin: the oracle's verdicts of a stratified 1,000 of these probes, made offline (tests/golden/make_sweep_pins.py)
         out["oracle_pin"] = sweep_pin_check("single-topology" if topology else "single", args.sweep_nodes, len(cands),
@@ -352,6 +378,7 @@ def main():
     ap.add_argument("--components-calibration-pods", type=int, default=200_000, help="size at which the component split is compared with ONE Solve() of the whole batch (L2-canonical deltas)")
     ap.add_argument("--sweep-nodes", type=int, default=100_000, help="BASELINE configs[4]: existing nodes of the resident cluster swept by single-node consolidation (about 20 bound pods each), 0 = skip")
     ap.add_argument("--sweep-candidates", type=int, default=10_000, help="candidates (probes) per launch of the sweep")
+    ap.add_argument("--sweep-contexts", type=int, default=4, help="configs[4]: also sweep through K handles of the same cluster on one device (2 and K are measured), <= 1 = skip")
     ap.add_argument("--sweep-windows", type=int, default=32, help="multi-node consolidation: windows of the sorted candidate list whose prefixes are all simulated in one sweep, 0 = skip")
     ap.add_argument("--sweep-window-size", type=int, default=100, help="MultiNodeConsolidation's batch (multinodeconsolidation.go:80): the search covers prefixes of up to this many + 1 candidates")
     ap.add_argument("--sweep-sample", type=int, default=32, help="probes of the sweep re-simulated by the oracle (checker + CPU baseline of this leg)")

@@ -273,9 +273,10 @@ typedef struct {
                                     * tests use it to prove which engine produced a result); 3 = cursor engine only, with the claims' state
                                     * in HBM from the start (the plan the library moves to by itself when the LDS plan runs out of
                                     * claims); 4 = cursor engine only, claim state AND claim order in HBM from the start (the plan above
-                                    * ~15,000 in-flight NodeClaims, up to 65,472); 5 = cursor engine only, LDS plan, on ONE wavefront (by
-                                    * default the LDS plan with one row of class slots runs the two-wavefront kernel ksolve_pack_fast2:
-                                    * a second wavefront recomputes a NodeClaim's acceptance words while the first places the next pod).
+                                    * ~15,000 in-flight NodeClaims, up to 65,472); 5 = cursor engine only, LDS plan with one row of class slots on
+                                    * TWO wavefronts (ksolve_pack_fast2: a second wavefront recomputes a NodeClaim's acceptance words
+                                    * while the first places the next pod; kept for measurements — on the MI355X it is 5.7% slower than
+                                    * the one-wavefront kernel every other setting runs, profiles/round5/pass_i).
                                     * All give identical Results. */
 } ksolve_options;
 

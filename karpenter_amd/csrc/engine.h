@@ -107,6 +107,7 @@ struct LdsTables {  // pointers into the dynamic LDS segment (device) / a host b
   int64_t* dg_ov;       // [n_dg][nr] daemon overhead per group (scheduler.go:963-1043)
   uint64_t* dg_its;     // [n_dg][iw] instance types of the group
   char* scratch;        // the wavefront's ScratchT (the engine knows which)
+  char* topo = nullptr; // room for the topology groups' descriptors and small state (LdsPlan::off_topo), or null; set by the one-problem kernels after bind
   KS_FN void bind(char* base, const LdsPlan& p, int wave = 0) {
     char* const shared = base;
     base += (size_t)wave * (size_t)p.wave_stride;   // the wavefront's own tables (compact sweep); the shared ones are re-bound below
@@ -165,6 +166,13 @@ struct Engine {
   uint64_t& RAV(int l, int j) { return rav_[l][j]; }
 #endif
   bool regs_ok = false;
+  // The topology groups' descriptors and their small mutable state (registered domains, per-domain counts, non-empty-domain
+  // counts) are read through these pointers — the problem's HBM tables, or copies in LDS when the launch planned room for them
+  // (LdsPlan::off_topo) and the kernel allows it (one problem per kernel; probes and batches keep them in HBM). Measured in round 4
+  // as an experiment (1.08-1.09x on the configs[2] shape: a tenth of the 136 dependent vector reads per pod), shipped in round 5.
+  struct TopoPtrs { const uint8_t* type; const int32_t* key; const int8_t* key_slot; const int16_t* host_slot; const int32_t *max_skew, *min_domains;
+                    const uint8_t *f_affinity, *f_taint; const uint32_t* f_first; const uint64_t* f_tolerates; } TT;
+  uint64_t* tgD = nullptr; int32_t* tgC = nullptr; int32_t* tgN = nullptr;
   uint64_t pending_reserved = 0;    // offerings the last successful can_add wants reserved (offeringsToReserve, nodeclaim.go:303-350)
   bool min_values_best_effort = false;   // MinValuesPolicyBestEffort (scheduler.go:117)
   bool minv_lowered = false;        // the last can_add lowered a minValues requirement (BestEffort)
@@ -184,6 +192,32 @@ struct Engine {
     if constexpr (BIG) order.init(L.runs, s.o_ring, s.o_cnt, s.o_pos, s.o_key, s.o_ord, s.run_tabs, s.run_off, s.run_log, s.run_kmax);
     else { order.key = L.okey; order.ord = L.oord; order.pos = L.opos; }
     min_values_best_effort = s.min_values_best_effort != 0;
+    const TopoView& T0 = p.topo;
+    TT.type = T0.type; TT.key = T0.key; TT.key_slot = T0.key_slot; TT.host_slot = T0.host_slot; TT.max_skew = T0.max_skew; TT.min_domains = T0.min_domains;
+    TT.f_affinity = T0.f_affinity; TT.f_taint = T0.f_taint; TT.f_first = T0.f_first; TT.f_tolerates = T0.f_tolerates;
+    tgD = s.tg_domains; tgC = s.tg_counts; tgN = s.tg_nonzero;
+  }
+  // copies the descriptors into LDS and points the mutable group state there (before solve() fills it from the pristine tables)
+  KS_DEV void topo_to_lds() {
+    if (!FULL || !L.topo || !P.topo.n_groups || S.probe) return;
+    const TopoView& T0 = P.topo;
+    const int G = T0.n_groups, dw = T0.dom_words;
+    char* q = L.topo;
+    auto al = [](size_t b) { return (b + 7) & ~(size_t)7; };
+    { uint8_t* d = (uint8_t*)q; const uint8_t* a = T0.type; W::for_n(G, [&](int i) { d[i] = a[i]; }); TT.type = d; q += al(G); }
+    { int32_t* d = (int32_t*)q; const int32_t* a = T0.key; W::for_n(G, [&](int i) { d[i] = a[i]; }); TT.key = d; q += al((size_t)G * 4); }
+    { int8_t* d = (int8_t*)q; const int8_t* a = T0.key_slot; W::for_n(G, [&](int i) { d[i] = a[i]; }); TT.key_slot = d; q += al(G); }
+    { int16_t* d = (int16_t*)q; const int16_t* a = T0.host_slot; W::for_n(G, [&](int i) { d[i] = a[i]; }); TT.host_slot = d; q += al((size_t)G * 2); }
+    { int32_t* d = (int32_t*)q; const int32_t* a = T0.max_skew; W::for_n(G, [&](int i) { d[i] = a[i]; }); TT.max_skew = d; q += al((size_t)G * 4); }
+    { int32_t* d = (int32_t*)q; const int32_t* a = T0.min_domains; W::for_n(G, [&](int i) { d[i] = a[i]; }); TT.min_domains = d; q += al((size_t)G * 4); }
+    { uint8_t* d = (uint8_t*)q; const uint8_t* a = T0.f_affinity; W::for_n(G, [&](int i) { d[i] = a[i]; }); TT.f_affinity = d; q += al(G); }
+    { uint8_t* d = (uint8_t*)q; const uint8_t* a = T0.f_taint; W::for_n(G, [&](int i) { d[i] = a[i]; }); TT.f_taint = d; q += al(G); }
+    { uint32_t* d = (uint32_t*)q; const uint32_t* a = T0.f_first; W::for_n(G + 1, [&](int i) { d[i] = a[i]; }); TT.f_first = d; q += al((size_t)(G + 1) * 4); }
+    { uint64_t* d = (uint64_t*)q; const uint64_t* a = T0.f_tolerates; W::for_n(G, [&](int i) { d[i] = a[i]; }); TT.f_tolerates = d; q += al((size_t)G * 8); }
+    tgD = (uint64_t*)q; q += al((size_t)G * dw * 8);
+    tgC = (int32_t*)q; q += al((size_t)G * dw * 64 * 4);
+    tgN = (int32_t*)q; q += al((size_t)G * 4);
+    W::sync();
   }
 
   // ------------------------------------------------------------------------------------------------------------
@@ -587,12 +621,12 @@ struct Engine {
     return c;
   }
   KS_DEV int32_t host_count(int g, int bin_kind, int bin) const {
-    const int hs = P.topo.host_slot[g];
+    const int hs = TT.host_slot[g];
     return bin_kind == 0 ? S.tg_claim_counts[(size_t)hs * S.max_claims + bin] : node_host_count(hs, bin);
   }
   // Record: one more pod on the bin; returns the count before it (uniform)
   KS_DEV int32_t host_count_add(int g, int bin_kind, int bin) {
-    const int hs = P.topo.host_slot[g];
+    const int hs = TT.host_slot[g];
     if (bin_kind == 0) { int32_t* p = S.tg_claim_counts + (size_t)hs * S.max_claims + bin; const int32_t c = *p; W::store(p, c + 1); return c; }
     if (!S.probe) { int32_t* p = S.tg_node_counts + (size_t)hs * P.n_nodes + bin; const int32_t c = *p; W::store(p, c + 1); return c; }
     const int32_t before = node_host_count(hs, bin);
@@ -603,7 +637,7 @@ struct Engine {
   }
   // anyCompatiblePodDomain for a hostname group — topologygroup.go:393-400
   KS_DEV bool topo_any_compatible_host(int g, const ReqRef& pod) {
-    const int hs = P.topo.host_slot[g];
+    const int hs = TT.host_slot[g];
     const int32_t* cc = S.tg_claim_counts + (size_t)hs * S.max_claims;
     const int ne = P.n_nodes, ncl = n_claims;
     if (W::find_first(0, ne, [&](int e) { return node_host_count(hs, e) > 0 && pod_has_host(pod, 1, e); }) < ne) return true;
@@ -614,14 +648,14 @@ struct Engine {
   KS_DEV bool topo_hostname_ok(int g, bool self, const ReqRef& pod, int bin_kind, int bin) {
     const TopoView& T = P.topo;
     const int cnt = bin >= 0 ? host_count(g, bin_kind, bin) : 0;
-    switch (T.type[g]) {
-      case 0: return (long long)cnt + (self ? 1 : 0) <= (long long)T.max_skew[g];       // topologygroup.go:240-247
+    switch (TT.type[g]) {
+      case 0: return (long long)cnt + (self ? 1 : 0) <= (long long)TT.max_skew[g];       // topologygroup.go:240-247
       case 2: return cnt == 0;                                                            // :409-414
       default:                                                                            // :331-343
         if (!pod_has_host(pod, bin_kind, bin)) return false;
         if (cnt > 0) return true;
         if (!self) return false;
-        if (S.tg_nonzero[g] == 0) return true;
+        if (tgN[g] == 0) return true;
         return !topo_any_compatible_host(g, pod);
     }
   }
@@ -630,10 +664,10 @@ struct Engine {
   KS_DEV bool topo_next_domain(int g, bool self, const ReqRef& pod, const ReqRef& node) {
     const TopoView& T = P.topo;
     const Dict& d = P.dict;
-    const int key = T.key[g], type = T.type[g];
+    const int key = TT.key[g], type = TT.type[g];
     const uint32_t w0 = d.key_word_off[key], nw = d.key_word_off[key + 1] - w0;
-    const uint64_t* D = S.tg_domains + (size_t)g * T.dom_words;
-    const int32_t* cnt = S.tg_counts + (size_t)g * T.dom_words * 64;
+    const uint64_t* D = tgD + (size_t)g * T.dom_words;
+    const int32_t* cnt = tgC + (size_t)g * T.dom_words * 64;
     const uint16_t* rank = T.value_rank + (size_t)w0 * 64;
     uint64_t* tq = sc.tq;
     uint64_t any = 0;
@@ -648,9 +682,9 @@ struct Engine {
         const uint64_t m = W::reduce_min(64, [&](int b) -> uint64_t { return ((sup >> b) & 1) ? (uint64_t)(uint32_t)cnt[x * 64 + b] : NONE; });
         if (m != NONE && (long long)m < mn) mn = (long long)m;
       }
-      if (T.min_domains[g] >= 0 && supported < T.min_domains[g]) mn = 0;
+      if (TT.min_domains[g] >= 0 && supported < TT.min_domains[g]) mn = 0;
       // the valid domain with the fewest pods, the smallest name among equals — topologygroup.go:251-297
-      const long long skew = T.max_skew[g];
+      const long long skew = TT.max_skew[g];
       uint64_t best = NONE;
       for (uint32_t x = 0; x < nw; ++x) {
         const uint64_t dw = D[x];
@@ -690,7 +724,7 @@ struct Engine {
     }
     W::sync();
     if (any) return true;
-    if (!self || !(S.tg_nonzero[g] == 0 || any_pod_nonzero == 0)) return false;
+    if (!self || !(tgN[g] == 0 || any_pod_nonzero == 0)) return false;
     // nothing to be affine to yet and the pod matches its own selector: bootstrap a domain (:372-386)
     uint64_t b1 = NONE, b2 = NONE;
     for (uint32_t x = 0; x < nw; ++x) {
@@ -717,10 +751,10 @@ struct Engine {
   KS_DEV uint64_t topo_ok_mask(int g, bool self, const ReqRef& pod) {
     const TopoView& T = P.topo;
     const Dict& d = P.dict;
-    const int key = T.key[g], type = T.type[g];
+    const int key = TT.key[g], type = TT.type[g];
     const uint32_t w0 = d.key_word_off[key];
-    const uint64_t dw = S.tg_domains[(size_t)g * T.dom_words];
-    const int32_t* cnt = S.tg_counts + (size_t)g * T.dom_words * 64;
+    const uint64_t dw = tgD[(size_t)g * T.dom_words];
+    const int32_t* cnt = tgC + (size_t)g * T.dom_words * 64;
     // the pod's own requirement on the key narrows the bin's domains (nodeRequirements = bin ∧ pod, nodeclaim.go:137-140)
     uint64_t podreq = ~0ull;
     {
@@ -734,8 +768,8 @@ struct Engine {
       long long mn = INT32_MAX;
       const uint64_t m = W::reduce_min(64, [&](int b) -> uint64_t { return ((sup >> b) & 1) ? (uint64_t)(uint32_t)cnt[b] : NONE; });
       if (m != NONE) mn = (long long)m;
-      if (T.min_domains[g] >= 0 && popc64(sup) < T.min_domains[g]) mn = 0;
-      const long long skew = T.max_skew[g];
+      if (TT.min_domains[g] >= 0 && popc64(sup) < TT.min_domains[g]) mn = 0;
+      const long long skew = TT.max_skew[g];
       const uint64_t valid = W::ballot([&](int b) { return ((dw >> b) & 1) != 0 && (long long)cnt[b] + (self ? 1 : 0) - mn <= skew; });
       return valid & podreq;
     }
@@ -767,7 +801,7 @@ struct Engine {
     for (int tw = 0; tw < T.words; ++tw) for (uint64_t m = sc.t_match[tw]; m; m &= m - 1) {
       const int g = tw * 64 + ctz64(m);
       const bool self = (sc.t_sel[tw] >> (g & 63)) & 1;
-      const int key = T.key[g];
+      const int key = TT.key[g];
       if (key < 0) {
         if (!topo_hostname_ok(g, self, pod, bin_kind, bin)) return false;
         continue;   // In [bin's hostname] ∧ the bin's own hostname requirement: nothing changes
@@ -789,9 +823,9 @@ struct Engine {
   KS_DEV bool topo_filter_matches(int g, uint64_t taints, const ReqRef& fin, int bin_kind) {
     const TopoView& T = P.topo;
     const Dict& d = P.dict;
-    if (T.f_taint[g] && (taints & ~T.f_tolerates[g])) return false;
-    if (!T.f_affinity[g]) return true;
-    const uint32_t a = T.f_first[g], b = T.f_first[g + 1];
+    if (TT.f_taint[g] && (taints & ~TT.f_tolerates[g])) return false;
+    if (!TT.f_affinity[g]) return true;
+    const uint32_t a = TT.f_first[g], b = TT.f_first[g + 1];
     if (a == b) return true;
     const int hn = d.key_hostname;
     for (uint32_t i = a; i < b; ++i) {
@@ -814,16 +848,16 @@ struct Engine {
       const int g = tw * 64 + ctz64(todo);
       const bool inv = (T.inverse_mask[tw] >> (g & 63)) & 1;
       if (!inv && !topo_filter_matches(g, taints, fin, bin_kind)) continue;
-      const int key = T.key[g];
+      const int key = TT.key[g];
       if (key < 0) {
         const int32_t c = host_count_add(g, bin_kind, bin);
-        if (c == 0) W::store(&S.tg_nonzero[g], S.tg_nonzero[g] + 1);
-        if (bin_kind == 0 && T.type[g] != 1) {
+        if (c == 0) W::store(&tgN[g], tgN[g] + 1);
+        if (bin_kind == 0 && TT.type[g] != 1) {
           // threshold bitmaps of the scan prefilter: "count <= t-1" ends when the count reaches t, "count <= t" at t+1
-          const long long t = T.type[g] == 2 ? 0 : (long long)T.max_skew[g];
+          const long long t = TT.type[g] == 2 ? 0 : (long long)TT.max_skew[g];
           const long long n = (long long)c + 1;
           if (n == t || n == t + 1) {
-            uint64_t* hz = S.host_le + ((size_t)T.host_slot[g] * 2 + (n == t ? 0 : 1)) * S.claim_words + (bin >> 6);
+            uint64_t* hz = S.host_le + ((size_t)TT.host_slot[g] * 2 + (n == t ? 0 : 1)) * S.claim_words + (bin >> 6);
             W::store(hz, (uint64_t)(*hz & ~(1ull << (bin & 63))));
           }
         }
@@ -832,14 +866,14 @@ struct Engine {
       }
       if (!bit(fin.defined, key)) continue;   // Exists: no values
       const uint32_t w0 = d.key_word_off[key], nw = d.key_word_off[key + 1] - w0;
-      const bool anti = inv || T.type[g] == 2;
+      const bool anti = inv || TT.type[g] == 2;
       int nvals = 0;
       for (uint32_t x = 0; x < nw; ++x) nvals += popc64(fin.mask[w0 + x]);
       // anti-affinity blocks every stored value (domains.Values(), also for a NotIn set); the others count a pod only
       // once its domain is decided (topology.go:203-211)
       if (!anti && (bit(fin.complement, key) || nvals != 1)) continue;
-      uint64_t* D = S.tg_domains + (size_t)g * T.dom_words;
-      int32_t* cnt = S.tg_counts + (size_t)g * T.dom_words * 64;
+      uint64_t* D = tgD + (size_t)g * T.dom_words;
+      int32_t* cnt = tgC + (size_t)g * T.dom_words * 64;
       int fresh = 0;
       for (uint32_t x = 0; x < nw; ++x) {
         const uint64_t mk = fin.mask[w0 + x];
@@ -853,7 +887,7 @@ struct Engine {
         fresh += popc64(was_zero);
         W::store(&D[x], (uint64_t)(D[x] | mk));
       }
-      if (fresh) W::store(&S.tg_nonzero[g], S.tg_nonzero[g] + fresh);
+      if (fresh) W::store(&tgN[g], tgN[g] + fresh);
       W::sync();
     }
   }
@@ -1336,16 +1370,16 @@ struct Engine {
       for (int tw = 0; tw < T.words; ++tw) for (uint64_t m = sc.t_match[tw]; m; m &= m - 1) {
         const int g = tw * 64 + ctz64(m);
         const bool self = (sc.t_sel[tw] >> (g & 63)) & 1;
-        if (T.key[g] >= 0) {
+        if (TT.key[g] >= 0) {
           // dictionary key: skip the claims whose admitted values miss every domain the group could pick
-          const int sl = T.key_slot[g];
+          const int sl = TT.key_slot[g];
           if (sl < 0) continue;
           const uint64_t okv = topo_ok_mask(g, self, P.cls_strict.at(P.dict, (uint32_t)cur_class));
           if (okv == ~0ull) continue;
           // one lane per 64 claims: OR the "claims that admit value v" words of the eligible values
           const uint64_t* kvc = S.kv_claims + (size_t)sl * 64 * S.claim_words;
           const int cw = S.claim_words;
-          const uint64_t vals = okv & P.dict.value_valid[P.dict.key_word_off[T.key[g]]];
+          const uint64_t vals = okv & P.dict.value_valid[P.dict.key_word_off[TT.key[g]]];
           any = W::ballot([&](int l) {
             uint64_t acc_any = 0;
             for (int w = l; w < words; w += 64) {
@@ -1363,13 +1397,13 @@ struct Engine {
           if (!any) return false;
           continue;
         }
-        if (T.type[g] == 1) continue;
-        const long long limit = T.type[g] == 2 ? 0 : (long long)T.max_skew[g] - (self ? 1 : 0);
+        if (TT.type[g] == 1) continue;
+        const long long limit = TT.type[g] == 2 ? 0 : (long long)TT.max_skew[g] - (self ? 1 : 0);
         if (limit < 0) return false;   // not even an empty claim satisfies it
         {
           // "count <= limit" from the threshold bitmap of the group (limit is t-1 or t): one word per 64 claims
-          const long long t = T.type[g] == 2 ? 0 : (long long)T.max_skew[g];
-          const uint64_t* hz = S.host_le + ((size_t)T.host_slot[g] * 2 + (limit == t ? 1 : 0)) * S.claim_words;
+          const long long t = TT.type[g] == 2 ? 0 : (long long)TT.max_skew[g];
+          const uint64_t* hz = S.host_le + ((size_t)TT.host_slot[g] * 2 + (limit == t ? 1 : 0)) * S.claim_words;
           any = W::ballot([&](int l) {
             uint64_t acc_any = 0;
             for (int w = l; w < words; w += 64) { const uint64_t v = stage[w] & hz[w]; stage[w] = v; acc_any |= v; }
@@ -1972,10 +2006,10 @@ struct Engine {
       probe_load_node(e);
       const uint64_t taints = P.node_taints[e];
       for (int g = 0; g < G; ++g) {
-        const int key = T.key[g];
+        const int key = TT.key[g];
         if (key < 0) {
           // the removed node's counter leaves with it (node_host_count reads 0 for it from here on)
-          if (T.node_counts0[(size_t)T.host_slot[g] * ne + e] > 0) { W::store(&S.tg_nonzero[g], S.tg_nonzero[g] - 1); W::sync(); }
+          if (T.node_counts0[(size_t)TT.host_slot[g] * ne + e] > 0) { W::store(&tgN[g], tgN[g] - 1); W::sync(); }
           continue;
         }
         if (!T.dom_regs0 || ((T.inverse_mask[g >> 6] >> (g & 63)) & 1)) continue;
@@ -1997,13 +2031,13 @@ struct Engine {
       for (int tw = 0; tw < T.words; ++tw)
       for (uint64_t todo = (ct[T.words + tw] & ~T.inverse_mask[tw]) | (ct[tw] & T.inverse_mask[tw]); todo; todo &= todo - 1) {
         const int g = tw * 64 + ctz64(todo);
-        const int key = T.key[g];
+        const int key = TT.key[g];
         if (key < 0) continue;                                  // per-node counters of the removed node are gone already
         const bool inv = (T.inverse_mask[tw] >> (g & 63)) & 1;
         const int v = probe_node_value(key);
         if (v < 0) continue;
         if (!inv && !topo_filter_matches(g, taints, sc.merged.ref(), 1)) continue;
-        int32_t* pc = S.tg_counts + (size_t)g * dv + v;
+        int32_t* pc = tgC + (size_t)g * dv + v;
         W::store(pc, *pc - 1);
         W::sync();
       }
@@ -2018,17 +2052,17 @@ struct Engine {
     }
     // registered domains (universe ∪ nodes that are still there ∪ counted) and the number of non-empty domains, per group
     for (int g = 0; g < G; ++g) {
-      if (T.key[g] < 0) continue;
-      const int32_t* cnt = S.tg_counts + (size_t)g * dv;
+      if (TT.key[g] < 0) continue;
+      const int32_t* cnt = tgC + (size_t)g * dv;
       const int32_t* rg = T.dom_regs0 ? S.tg_regs + (size_t)g * dv : nullptr;
       int nz = 0;
       for (int x = 0; x < T.dom_words; ++x) {
         const uint64_t counted = W::ballot([&](int b) { return cnt[x * 64 + b] > 0; });
         const uint64_t regd = rg ? W::ballot([&](int b) { return rg[x * 64 + b] > 0; }) : 0ull;
         nz += popc64(counted);
-        if (T.dom_universe) W::store(&S.tg_domains[(size_t)g * T.dom_words + x], (uint64_t)(T.dom_universe[(size_t)g * T.dom_words + x] | regd | counted));
+        if (T.dom_universe) W::store(&tgD[(size_t)g * T.dom_words + x], (uint64_t)(T.dom_universe[(size_t)g * T.dom_words + x] | regd | counted));
       }
-      W::store(&S.tg_nonzero[g], nz);
+      W::store(&tgN[g], nz);
     }
     W::sync();
   }
@@ -2210,14 +2244,15 @@ struct Engine {
       if (P.hp_on) { const uint64_t* h0 = P.node_hp0; W::for_n(ne, [&](int i) { Sw.n_hp[i] = h0 ? h0[i] : 0ull; }); }
       if (Sw.n_hg) W::for_n(ne, [&](int i) { Sw.n_hg[i] = 0; Sw.n_hl[i] = 0; });
     }
+    topo_to_lds();
     if (FULL && P.topo.n_groups) {
       const TopoView& T = P.topo;
       Workspace& Sw = S;
       const int G = T.n_groups, dv = T.dom_words * 64;
-      W::for_n(G * T.dom_words, [&](int i) { Sw.tg_domains[i] = T.domains0[i]; });
-      W::for_n(G * dv, [&](int i) { Sw.tg_counts[i] = T.counts0[i]; });
+      W::for_n(G * T.dom_words, [&](int i) { tgD[i] = T.domains0[i]; });
+      W::for_n(G * dv, [&](int i) { tgC[i] = T.counts0[i]; });
       if (!S.probe) W::for_n(T.n_host_groups * P.n_nodes, [&](int i) { Sw.tg_node_counts[i] = T.node_counts0[i]; });   // probes: shared + overlay (node_host_count)
-      W::for_n(G, [&](int i) { Sw.tg_nonzero[i] = T.nonzero0[i]; });
+      W::for_n(G, [&](int i) { tgN[i] = T.nonzero0[i]; });
       W::for_n(T.words, [&](int w) { sc.t_active[w] = T.initially_active[w]; });
       W::for_n(T.n_alias, [&](int i) { Sw.tg_alias_active[i] = -1; });
       if (S.probe) probe_topology_adjust();

@@ -1505,7 +1505,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
   auto order_reads = [&](uint32_t rr) {
     W::each([&](int l) {
       const int p = (int)rr + l;
-      int pc = p < nm1 ? p : nm1; pc = pc < 0 ? 0 : pc;   // clamped: no lane is switched off for the reads (a cursor at the end of the order: no lane is valid)
+      const uint32_t pc = (uint32_t)p < (uint32_t)nm1 ? (uint32_t)p : (uint32_t)nm1;   // clamped (cursors are positions: p >= 0, and n >= 1 here): no lane is switched off for the reads (a cursor at the end of the order: no lane is valid)
       const uint32_t kk = okey[pc];
       xv.at(l) = oord[pc]; kv.at(l) = p < n ? kk : 0xFFFFFFFFu;
     });
@@ -1553,7 +1553,8 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
     // is polled (a Solve() that ends there reports the order of the last sort the reference would have run: their move stays undone)
     const int bf = bn - ((base + bn >= np || (polled && ((base + 64) & 1023) == 0)) ? 1 : 0);
     if (bi < bf) { stage_a(bi); read_done(); gather(); }
-    while (bi < bf) {
+    int bfx = bf;   // the loop's end: bf, or right behind the step whose refresh met a requirement set that is not cached (rf) — one compare per step for both
+    while (bi < bfx) {
       // Everything up to the first write is ONE basic block: whatever is not plain sets a bit of `bad` and the step goes on with
       // harmless values (lane 0, position 0), so that no branch stands between the loads and the compiler issues them together —
       // with a `break` behind the acceptor test it had sunk the count, state and class reads below it: five dependent LDS round
@@ -1666,7 +1667,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
         const uint32_t dmin = d1 < d2 ? (d1 < d3 ? d1 : d3) : (d2 < d3 ? d2 : d3);
         bad |= (uint32_t)(sm != 0) & (inexact | (uint32_t)(dmin <= 2u));   // pdqsort's other paths
       }
-      if (KS_UNLIKELY(bad != 0)) break;
+      if (KS_UNLIKELY(bad != 0)) { bfx = bi; continue; }   // (out through the loop's own test: one exit)
       // ---- nothing has been written so far; from here on the step is the plain one ----
       if constexpr (HP) {
         static_assert(!HP || R == 1, "the two-wavefront loop: one row of class slots");
@@ -1824,7 +1825,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
             return fast_fits(pool, e, ns.req, sz) ? 1 : 0;
           }, ok2, missm);
           accm |= ok2;
-          if (missm) rf = x;
+          if (missm) { rf = x; bfx = bi + 1; }
         }
         accw[j] = accm;
       }
@@ -1841,7 +1842,6 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       if constexpr (FastMem<GS, R>::kStateHbm) W::hbm_sync(); else W::order();   // (LDS: no wait — it executes a wavefront's accesses in order, the reads below see these writes)
       gather();     // the next pod's claims (behind this pod's record write): in flight while the loop comes around
       bi++; steps++;
-      if (KS_UNLIKELY(rf >= 0)) break;
     }
     if (bi < bf || bf < bn || rf >= 0) break;          // a pod the loop does not place / the block's last entry is not the loop's
     // ---- the block is done: its results, the next block ----

@@ -521,6 +521,7 @@ __global__ void __launch_bounds__(64) ksolve_pack(ks::ProblemView pv, ks::Worksp
   extern __shared__ __attribute__((aligned(16))) char lds[];
   ks::LdsTables tables;
   tables.bind(lds, pv.lds);
+  if (pv.lds.topo_bytes) tables.topo = lds + pv.lds.off_topo;   // (one problem per launch: the topology groups' descriptors and small state in LDS, engine.h topo_to_lds)
   ks::Engine<ks::Wave, true> eng(pv, ws, tables);
   eng.solve();
 }
@@ -540,6 +541,7 @@ __global__ void __launch_bounds__(64) ksolve_pack_big(ks::ProblemView pv, ks::Wo
   extern __shared__ __attribute__((aligned(16))) char lds[];
   ks::LdsTables tables;
   tables.bind(lds, pv.lds);
+  if (pv.lds.topo_bytes) tables.topo = lds + pv.lds.off_topo;   // (one problem per launch: the topology groups' descriptors and small state in LDS, engine.h topo_to_lds)
   ks::Engine<ks::Wave, true, true> eng(pv, ws, tables);
   eng.solve();
 }

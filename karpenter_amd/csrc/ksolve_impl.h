@@ -627,6 +627,17 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     lp.off_dgov = off; off = align(off + std::max(1, P.n_dg) * (int)d->n_res * 8);
     lp.off_dgits = off; off = align(off + std::max(1, P.n_dg) * (int)it_words * 8);
     lp.off_cache = off; off = align(off + 32 * lay.c_hot_words() * 8);
+    // The topology groups' descriptors and small mutable state in LDS, when they are few and small enough (round 4 measured 136
+    // dependent vector reads per pod on the configs[2] shape, a tenth of them these: 1.08-1.09x, profiles/round4/experiments). Only
+    // the one-problem kernels (ksolve_pack / ksolve_pack_big) use the room; a sweep's plan leaves it out (sweep_run).
+    lp.off_topo = 0; lp.topo_bytes = 0;
+    if (h->has_topology) {
+      const ks::TopoView& Tv = P.topo;
+      auto al8 = [](size_t b) { return (b + 7) & ~(size_t)7; };
+      const size_t G = (size_t)Tv.n_groups, dw = (size_t)Tv.dom_words;
+      const size_t tb = al8(G) * 4 + al8(G * 4) * 3 + al8(G * 2) + al8((G + 1) * 4) + al8(G * 8) + al8(G * dw * 8) + al8(G * dw * 64 * 4) + al8(G * 4) + 64;
+      if (tb <= 24 * 1024) { lp.off_topo = off; lp.topo_bytes = (int)tb; off = align(off + (int)tb); }
+    }
     const int budget = 160 * 1024 - 512;
     if (off + 13 * 64 > budget) return fail(h, KSOLVE_ERR_UNSUPPORTED, "instance-type tables do not fit the 160 KiB LDS of one CU");
     // the claim order (12 B per claim) and the closed bitmap (1 bit per claim) get what is left
@@ -1187,7 +1198,8 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
     if (base->opts.max_claims && base->opts.max_claims < want) want = base->opts.max_claims;
     int cap = lp.order_cap;
     if (cap > (int)((want + 63) & ~63u)) cap = (int)((want + 63) & ~63u);
-    int o = lp.off_order;
+    int o = lp.topo_bytes ? lp.off_topo : lp.off_order;   // (probes read the topology tables from HBM: no room for them in every workgroup's LDS)
+    lp.off_order = o; lp.off_stage = o; lp.off_topo = 0; lp.topo_bytes = 0;
     lp.order_cap = cap;
     o = align(o + cap * 12);
     lp.off_closed = o; o = align(o + cap / 8 + 8);
@@ -1833,7 +1845,7 @@ static void fast_plan_set(ksolve_handle* h, int plan, int rows) {
   ks::FastPlan& fp = h->fw.plan;
   rows = rows <= 1 ? 1 : ks::kFastRows;
   fp.rows = rows;
-  fp.helper = (plan == 0 && rows == 1 && h->opts.engine != 5) ? 1 : 0;   // the two-wavefront kernel (engine 5: tests and measurements of the one-wavefront form)
+  fp.helper = (plan == 0 && rows == 1 && h->opts.engine == 5) ? 1 : 0;   // the two-wavefront kernel: on request only (engine 5) — measured 5.7% SLOWER than one wavefront on the headline problem (profiles/round5/pass_i)
   const int rec_bytes = rows == 1 ? (int)sizeof(ks::FastRec<1>) : (int)sizeof(ks::FastRec<ks::kFastRows>);
   int off = 0;
   fp.off_ent = off; off = align(off + ks::kFastEnt * (int)sizeof(ks::FastEnt));

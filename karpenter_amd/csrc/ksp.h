@@ -92,6 +92,8 @@ struct LdsPlan {
   // lie w * wave_stride bytes further. 0 waves: the plan of a one-wavefront kernel.
   int waves, wave_stride;
   int off_shared_misc;   // u32 [4]: templates that survived the prefilter, written by wave 0 before the workgroup's barrier
+  int off_topo, topo_bytes;   // the topology groups' descriptors and small mutable state (registered domains, per-domain counts, non-empty-domain
+                              // counts) in LDS — Engine::topo_to_lds, the one-problem kernels only; 0 bytes: not planned (they stay in HBM)
 };
 
 // Topology groups (topologygroup.go:55-77), regular groups then inverse anti-affinity groups; group sets are bit masks of

@@ -366,7 +366,7 @@ class ResidentCluster:
         self.prefetch([candidates])
         return self._cache[self._key(candidates)]
 
-    def decisions(self, candidate_sets, detail=False, multi_node=False, library_prices=False, arrays=False):
+    def decisions(self, candidate_sets, detail=False, multi_node=False, library_prices=False, arrays=False, replicas=()):
         """computeConsolidation (consolidation.go:159-256) for every candidate set in ONE device launch, verdicts included
         (Scheduler.Sweep / ksolve_sweep): [{"decision", "candidates", "replacement", "replacementCapacityType"}], the commands
         compute_consolidation() returns without their Results. Descriptors and verdicts are computed by the host library.
@@ -374,7 +374,10 @@ class ResidentCluster:
         filterOutSameInstanceType (multinodeconsolidation.go:209-246) and comes back as NOOP when it does not stand.
         library_prices: the candidates' prices and capacity types are taken from the host library's node table instead of
         being summed here. arrays: the binary form of the call (Scheduler.SweepArrays / ksched_sweep_arrays: no JSON on either side
-        of the host library, what a cgo caller does; the library's prices; no `reason` texts)."""
+        of the host library, what a cgo caller does; the library's prices; no `reason` texts). replicas: further ResidentClusters
+        of the same cluster document — on other devices, or further contexts on this one (each handle has its own stream, staging
+        memory and arena, so one share's upload / finalize / download runs beside another share's kernel): the probes are dealt
+        out over all of them inside the call (ksolve_sweep_replicas)."""
         cluster = self.cluster
         live = [[c for c in cs if not c.get("markedForDeletion")] for cs in candidate_sets]
         prices = None if library_prices else [sum(self._price(c) for c in cs) for cs in candidate_sets]
@@ -386,9 +389,9 @@ class ResidentCluster:
                 raise ValueError("the binary sweep takes node positions (ResidentCluster.from_compact) and has no detail form")
             if not hasattr(self, "_it_names"):
                 self._it_names = [t["name"] for t in cluster["instanceTypes"]]
-            out = self.scheduler.SweepArrays(names, multi_node=multi_node, instance_type_names=self._it_names)
+            out = self.scheduler.SweepArrays(names, multi_node=multi_node, replicas=tuple(r.scheduler for r in replicas), instance_type_names=self._it_names)
         else:
-            out = self.scheduler.Sweep(names, prices, all_spot, detail=detail, multi_node=multi_node)
+            out = self.scheduler.Sweep(names, prices, all_spot, detail=detail, multi_node=multi_node, replicas=tuple(r.scheduler for r in replicas))
         repl = {r["probe"]: r for r in out["replacements"]}
         cmds = []
         for i, cs in enumerate(candidate_sets):

@@ -1947,7 +1947,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     ko.truncate_instance_types = (uint32_t)opts.at("truncateInstanceTypes").i(0);
     ko.reserved_capacity = opts.at("reservedCapacity").boolean_or(false) ? 1 : 0;
     ko.reserved_offering_strict = opts.at("reservedOfferingMode").s("Fallback") == "Strict" ? 1 : 0;
-    { const std::string eng = opts.at("engine").s("auto"); ko.engine = eng == "general" ? 1u : eng == "cursor" ? 2u : eng == "cursor-wide" ? 3u : eng == "cursor-hbm" ? 4u : eng == "cursor-solo" ? 5u : 0u; }
+    { const std::string eng = opts.at("engine").s("auto"); ko.engine = eng == "general" ? 1u : eng == "cursor" ? 2u : eng == "cursor-wide" ? 3u : eng == "cursor-hbm" ? 4u : eng == "cursor-pair" ? 5u : 0u; }
 
     trace("ksolve_create");
     ksolve_status st = api.create(&d, &ko, &handle);

@@ -66,7 +66,8 @@ static void be_sort_pods(ksolve_handle* h) {
 static ks::LdsPlan guarded_plan(const ks::LdsPlan& in, std::vector<std::pair<int, int>>& gaps) {
   ks::LdsPlan p = in;
   int* offs[] = {&p.off_alloc, &p.off_avail, &p.off_kv, &p.off_keymask, &p.off_allocok, &p.off_kvslot, &p.off_tmpl, &p.off_tmplcold, &p.off_order,
-                 &p.off_closed, &p.off_stage, &p.off_cache, &p.off_scratch, &p.off_dgov, &p.off_dgits};
+                 &p.off_closed, &p.off_stage, &p.off_cache, &p.off_scratch, &p.off_dgov, &p.off_dgits, &p.off_topo};
+  if (!in.topo_bytes) p.off_topo = p.off_cache;   // (not planned: rides with a region that is)
   std::vector<int> starts;
   for (int* o : offs) starts.push_back(*o);
   std::sort(starts.begin(), starts.end());
@@ -94,6 +95,7 @@ static void be_launch_pack(ksolve_handle* h) {
 #endif
   ks::LdsTables tables;
   tables.bind(lds.data(), pv.lds);
+  if (pv.lds.topo_bytes) tables.topo = lds.data() + pv.lds.off_topo;   // (one problem per launch: the topology groups' descriptors and small state in LDS)
   if (pv.big) { ks::Engine<ks::Wave, true, true> eng(pv, h->ws, tables); eng.solve(); }
   else if (pv.lite) { ks::Engine<ks::Wave, false> eng(pv, h->ws, tables); eng.solve(); }
   else { ks::Engine<ks::Wave, true> eng(pv, h->ws, tables); eng.solve(); }

@@ -27,10 +27,10 @@ def check_cursor(oracle, emu, prob, want=None):
     parity.assert_same_results(got, want)
     assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
     assert abs(got["packingCost"] - want["packingCost"]) < 1e-9 * max(1.0, want["packingCost"])
-    # the same engine on ONE wavefront (engine="cursor" on the LDS plan with one row of class slots is the placer + refresher pair of
-    # ksolve_pack_fast2, whose refresher the emulation runs as late as the protocol allows), and with its claim state / claim order in
-    # HBM (fast_engine.h FastMem)
-    for plan, engine in ((0, "cursor-solo"), (1, "cursor-wide"), (2, "cursor-hbm")):
+    # the same engine as the placer + refresher pair of ksolve_pack_fast2 (engine="cursor-pair": the LDS plan with one row of class
+    # slots on two wavefronts; the emulation runs the refresher as late as the protocol allows), and with its claim state / claim
+    # order in HBM (fast_engine.h FastMem)
+    for plan, engine in ((0, "cursor-pair"), (1, "cursor-wide"), (2, "cursor-hbm")):
         other = NewScheduler(with_engine(prob, engine), solver_lib=emu).Solve()
         assert other["counters"]["cursorMemoryPlan"] == plan
         parity.assert_same_results(other, want)
@@ -136,13 +136,13 @@ def test_refresher_wavefront_early_or_late_same_results(oracle, emu, monkeypatch
         prob = lite_problem(rng, rng.choice([200, 900, 2500]))
         try:
             monkeypatch.delenv("KSOLVE_EMU_REFRESHER_EAGER", raising=False)
-            late = NewScheduler(with_engine(prob, "cursor"), solver_lib=emu).Solve()
+            late = NewScheduler(with_engine(prob, "cursor-pair"), solver_lib=emu).Solve()
         except Unsupported:
             continue
         monkeypatch.setenv("KSOLVE_EMU_REFRESHER_EAGER", "1")
-        early = NewScheduler(with_engine(prob, "cursor"), solver_lib=emu).Solve()
+        early = NewScheduler(with_engine(prob, "cursor-pair"), solver_lib=emu).Solve()
         monkeypatch.delenv("KSOLVE_EMU_REFRESHER_EAGER")
-        solo = NewScheduler(with_engine(prob, "cursor-solo"), solver_lib=emu).Solve()
+        solo = NewScheduler(with_engine(prob, "cursor"), solver_lib=emu).Solve()
         want = oracle.solve(prob)
         for got in (late, early, solo):
             parity.assert_same_results(got, want)
