@@ -668,7 +668,13 @@ struct FastCold {
   KS_COLD int new_slot(int k) {
     k = (int)W::uniform((uint64_t)(uint32_t)k);
     int evicted = 0, slot = -1;
-    for (int j = 0; j < R && slot < 0; ++j) {
+    // With several rows of class slots a class goes to the row of its (lowest tolerated) template while that row has room: the
+    // classes that can ever be accepted by a claim of one template then sit in few rows, and the refresh after a commit skips the
+    // rows none of whose classes tolerates the claim's template (fast_hot_run) — with every pod pinned to one of 16 NodePools
+    // (BASELINE configs[3]) that is three rows of four.
+    const int pref = R > 1 ? (int)(ctz64((uint64_t)W::uniform((uint64_t)Fk->cls[k].tmplok) | (1ull << 32)) % R) : 0;
+    for (int jj = 0; jj < R && slot < 0; ++jj) {
+      const int j = (jj + pref) % R;
       const KS_LDS uint32_t* sc = hs->scls[j];
       const uint64_t fr = W::ballot([&](int l) { return sc[l] == kFastFree; });
       if (fr) slot = j * 64 + ctz64(fr);
@@ -1785,9 +1791,15 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       const uint32_t tbit = 1u << (uint32_t)(ns.vmask >> 56);
       LaneVar<uint64_t> mlv[R], evm[R];
       LaneVar<int32_t> c0[R], c1[R], c2[R], c3[R];
+      // several rows of class slots: a row none of whose classes tolerates the claim's template has no bit to compute — no cache
+      // read, no predicates (new_slot puts a class into the row of its template while there is room)
+      uint64_t rowm[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) rowm[j] = R > 1 ? W::ballot([&](int l) { return (tok[j].at(l) & tbit) != 0; }) : ~0ull;
       W::each([&](int l) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
+          if (R > 1 && rowm[j] == 0) continue;
           const uint64_t m = ns.vmask & cvm[j].at(l);
           const FastEnt e = ent_live(&ent[fast_hash(m)]);
           mlv[j].at(l) = m; evm[j].at(l) = e.vmask;
@@ -1804,8 +1816,9 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       uint64_t accw[R];
 #pragma unroll
       for (int j = 0; j < R; ++j) {
+        if (R > 1 && rowm[j] == 0) { accw[j] = 0; continue; }
         // every predicate is one compare whose result is the 64-lane mask; the masks are combined in scalar registers
-        const uint64_t tokm = W::ballot([&](int l) { return (tok[j].at(l) & tbit) != 0; });
+        const uint64_t tokm = R > 1 ? rowm[j] : W::ballot([&](int l) { return (tok[j].at(l) & tbit) != 0; });
         const uint64_t fldm = W::ballot([&](int l) { return (((mlv[j].at(l) & dm[j].at(l)) + dm[j].at(l)) & gd[j].at(l)) == gd[j].at(l); });
         const uint64_t simm = W::ballot([&](int l) { return evm[j].at(l) == mlv[j].at(l); });
         const uint64_t f0 = W::ballot([&](int l) { return z0[j].at(l) <= c0[j].at(l) - ns.req[0]; });
