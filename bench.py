@@ -378,7 +378,7 @@ def main():
     ap.add_argument("--components-calibration-pods", type=int, default=200_000, help="size at which the component split is compared with ONE Solve() of the whole batch (L2-canonical deltas)")
     ap.add_argument("--sweep-nodes", type=int, default=100_000, help="BASELINE configs[4]: existing nodes of the resident cluster swept by single-node consolidation (about 20 bound pods each), 0 = skip")
     ap.add_argument("--sweep-candidates", type=int, default=10_000, help="candidates (probes) per launch of the sweep")
-    ap.add_argument("--sweep-contexts", type=int, default=4, help="configs[4]: also sweep through K handles of the same cluster on one device (2 and K are measured), <= 1 = skip")
+    ap.add_argument("--sweep-contexts", type=int, default=0, help="configs[4]: also sweep through K handles of the same cluster on one device (2 and K are measured), <= 1 = skip")
     ap.add_argument("--sweep-windows", type=int, default=32, help="multi-node consolidation: windows of the sorted candidate list whose prefixes are all simulated in one sweep, 0 = skip")
     ap.add_argument("--sweep-window-size", type=int, default=100, help="MultiNodeConsolidation's batch (multinodeconsolidation.go:80): the search covers prefixes of up to this many + 1 candidates")
     ap.add_argument("--sweep-sample", type=int, default=32, help="probes of the sweep re-simulated by the oracle (checker + CPU baseline of this leg)")

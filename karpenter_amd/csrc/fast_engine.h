@@ -668,11 +668,28 @@ struct FastCold {
   KS_COLD int new_slot(int k) {
     k = (int)W::uniform((uint64_t)(uint32_t)k);
     int evicted = 0, slot = -1;
-    // With several rows of class slots a class goes to the row of its (lowest tolerated) template while that row has room: the
-    // classes that can ever be accepted by a claim of one template then sit in few rows, and the refresh after a commit skips the
-    // rows none of whose classes tolerates the claim's template (fast_hot_run) — with every pod pinned to one of 16 NodePools
-    // (BASELINE configs[3]) that is three rows of four.
-    const int pref = R > 1 ? (int)(ctz64((uint64_t)W::uniform((uint64_t)Fk->cls[k].tmplok) | (1ull << 32)) % R) : 0;
+    // With several rows of class slots a class goes to the row that holds the most classes it could share a NodeClaim with
+    // (templates both tolerate, a common value on every key both select on), the emptiest row among equals: classes that exclude
+    // each other — pods pinned to different NodePools, BASELINE configs[3] — end up in different rows, and the refresh after a
+    // commit skips every row none of whose classes the claim can still accept (fast_hot_run).
+    int pref = 0;
+    if constexpr (R > 1) {
+      const FastSlot mine = Fk->cls[k];
+      int best = -1;
+      for (int j = 0; j < R; ++j) {
+        const KS_LDS uint32_t* sc = hs->scls[j];
+        const KS_LDS FastSlot* as = aslot + j * 64;
+        const uint64_t used = W::ballot([&](int l) { return sc[l] != kFastFree; });
+        if (used == ~0ull) continue;
+        const uint64_t friends = W::ballot([&](int l) {
+          if (sc[l] == kFastFree) return false;
+          const FastSlot o = lds_get(&as[l]);
+          return (o.tmplok & mine.tmplok) != 0 && fast_fields_ok(o.cvmask & mine.cvmask, o.dmask & mine.dmask);
+        });
+        const int score = popc64(friends) * 128 + (64 - popc64(used));
+        if (score > best) { best = score; pref = j; }
+      }
+    }
     for (int jj = 0; jj < R && slot < 0; ++jj) {
       const int j = (jj + pref) % R;
       const KS_LDS uint32_t* sc = hs->scls[j];
@@ -1791,11 +1808,20 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       const uint32_t tbit = 1u << (uint32_t)(ns.vmask >> 56);
       LaneVar<uint64_t> mlv[R], evm[R];
       LaneVar<int32_t> c0[R], c1[R], c2[R], c3[R];
-      // several rows of class slots: a row none of whose classes tolerates the claim's template has no bit to compute — no cache
-      // read, no predicates (new_slot puts a class into the row of its template while there is room)
+      // several rows of class slots: the two predicates that need no cache entry first (the class tolerates the claim's template; on
+      // every key the class selects on the claim keeps a value) — a row in which no class passes them has no bit to compute: no cache
+      // read, no fit tests (new_slot keeps classes that exclude each other in different rows)
       uint64_t rowm[R];
+      if constexpr (R > 1) {
+        W::each([&](int l) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) rowm[j] = R > 1 ? W::ballot([&](int l) { return (tok[j].at(l) & tbit) != 0; }) : ~0ull;
+          for (int j = 0; j < R; ++j) mlv[j].at(l) = ns.vmask & cvm[j].at(l);
+        });
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+          rowm[j] = W::ballot([&](int l) { return (tok[j].at(l) & tbit) != 0; }) &
+                    W::ballot([&](int l) { return (((mlv[j].at(l) & dm[j].at(l)) + dm[j].at(l)) & gd[j].at(l)) == gd[j].at(l); });
+      } else rowm[0] = ~0ull;
       W::each([&](int l) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
@@ -1819,7 +1845,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
         if (R > 1 && rowm[j] == 0) { accw[j] = 0; continue; }
         // every predicate is one compare whose result is the 64-lane mask; the masks are combined in scalar registers
         const uint64_t tokm = R > 1 ? rowm[j] : W::ballot([&](int l) { return (tok[j].at(l) & tbit) != 0; });
-        const uint64_t fldm = W::ballot([&](int l) { return (((mlv[j].at(l) & dm[j].at(l)) + dm[j].at(l)) & gd[j].at(l)) == gd[j].at(l); });
+        const uint64_t fldm = R > 1 ? ~0ull : W::ballot([&](int l) { return (((mlv[j].at(l) & dm[j].at(l)) + dm[j].at(l)) & gd[j].at(l)) == gd[j].at(l); });   // (several rows: inside rowm already)
         const uint64_t simm = W::ballot([&](int l) { return evm[j].at(l) == mlv[j].at(l); });
         const uint64_t f0 = W::ballot([&](int l) { return z0[j].at(l) <= c0[j].at(l) - ns.req[0]; });
         const uint64_t f1 = W::ballot([&](int l) { return z1[j].at(l) <= c1[j].at(l) - ns.req[1]; });
