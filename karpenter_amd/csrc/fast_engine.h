@@ -1438,9 +1438,6 @@ KS_COLD int fast_slow_run(FastHotCtx<GS, R> cx, int budget) {
 // was: the driver runs fast_slow_run for that one pod and comes back. Why two functions: with every rare path inside one loop the
 // compiler merged ~30 loop-carried values behind each of them — 274 instructions per pod of which 140 scalar moves, selects and
 // branches (SQ counters, profiles/round5); this loop has ONE path and one exit.
-#ifndef KS_FAST_EARLY_GATHER_MASK
-#define KS_FAST_EARLY_GATHER_MASK 2   // bit GS: the plans whose fast loop gathers the next pod's claims before this pod's predicates (plan 1: claim records in HBM)
-#endif
 template <class W, int GS, int R, bool HP = false>
 KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
   typedef typename FastMem<GS, R>::o16 o16;
@@ -1578,10 +1575,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
     // entries of this block the loop may place: not the queue's last one, nor the last one before a block at which the cancel flag
     // is polled (a Solve() that ends there reports the order of the last sort the reference would have run: their move stays undone)
     const int bf = bn - ((base + bn >= np || (polled && ((base + 64) & 1023) == 0)) ? 1 : 0);
-    if (bi < bf) {
-      if constexpr (((KS_FAST_EARLY_GATHER_MASK >> GS) & 1) != 0 && FastMem<GS, R>::kStateHbm) W::hbm_sync();   // (the last step's words are on their way to the records)
-      stage_a(bi); read_done(); gather();
-    }
+    if (bi < bf) { stage_a(bi); read_done(); gather(); }
     int bfx = bf;   // the loop's end: bf, or right behind the step whose refresh met a requirement set that is not cached (rf) — one compare per step for both
     while (bi < bfx) {
       // Everything up to the first write is ONE basic block: whatever is not plain sets a bit of `bad` and the step goes on with
@@ -1645,7 +1639,6 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
         // order, four windows per step, acceptance words only, all eight reads of a step in flight before the first is used;
         // then the select step once more, at the window that holds it.
         if constexpr (HP) { if (pend1 >= 0 || pend2 >= 0) { const uint32_t dw2 = wait_for(seq); bad |= (dw2 & 1u) << 5; pend1 = -1; pend2 = -1; } }   // (exact words for the scan)
-        if constexpr (((KS_FAST_EARLY_GATHER_MASK >> GS) & 1) != 0 && FastMem<GS, R>::kStateHbm) W::hbm_sync();   // (the scan reads acceptance words from the records: the last step's are on their way)
         int r = (int)rc0 + 64, found = -1;
         while (r < n && found < 0) {
           uint64_t m4[4];
@@ -1841,35 +1834,11 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       });
       const int fo_ = first_ok;
       LaneVar<uint32_t> xw;   // (the claim ids of this step: the record write below still needs lane first_ok's)
-      // Claim records in HBM (plan 1; KS_FAST_EARLY_GATHER_MASK, one bit per plan): the claim's new STATE goes to its record now, its
-      // acceptance words after the predicates — and the next pod's claims are gathered in between, as soon as its order entries are
-      // back, so that the round trip to L2 / HBM runs behind the predicates instead of standing in front of the next select. The
-      // gather may find this claim's record in any state between old and new: the lanes that read this claim take its record from
-      // registers below, so no store of this step is waited for (the one fence of a step stands in front of its stores and waits for
-      // the step before's). (With the records in LDS the trade is even — the gather's latency for the order read's: not used.)
-      constexpr bool kEarly = ((KS_FAST_EARLY_GATHER_MASK >> GS) & 1) != 0;
-      if constexpr (kEarly) {
-        // the fence FIRST: it waits for the stores of the step before (long done), nothing of this step stands behind it
-        if constexpr (FastMem<GS, R>::kStateHbm) W::hbm_sync();
-        W::each([&](int l) {
-          if (l == fo_) {
-            FastClaim mine;
-            mine.vmask = nmv.at(l); mine.req[0] = n0v.at(l); mine.req[1] = n1v.at(l); mine.req[2] = n2v.at(l); mine.req[3] = n3v.at(l);
-            cst.put_state(xv.at(l), mine);
-          }
-        });
-        if constexpr (FastMem<GS, R>::kOrderHbm) W::hbm_sync(); else W::order();   // (an order in HBM: its stores are waited for before the next pod's entries are read)
-        W::sched_fence();
-        stage_a(bi + 1);      // entry bi+1 of the block (entry 64 of a full block does not exist: its values are never used)
-        gather();             // the next pod's claims: this claim's record as it was, or as it is now, or in between — the lanes that read it take it from registers below
-        W::sched_fence();
-      } else {
-        W::each([&](int l) { xw.at(l) = xv.at(l); });
-        if constexpr (FastMem<GS, R>::kOrderHbm) W::hbm_sync(); else W::order();   // (an order in HBM: the stores are waited for, as everywhere in this engine; in LDS nothing is)
-        W::sched_fence();
-        stage_a(bi + 1);      // entry bi+1 of the block (entry 64 of a full block does not exist: its values are never used)
-        W::sched_fence();
-      }
+      W::each([&](int l) { xw.at(l) = xv.at(l); });
+      if constexpr (FastMem<GS, R>::kOrderHbm) W::hbm_sync(); else W::order();   // (an order in HBM: the stores are waited for, as everywhere in this engine; in LDS nothing is)
+      W::sched_fence();
+      stage_a(bi + 1);      // entry bi+1 of the block (entry 64 of a full block does not exist: its values are never used)
+      W::sched_fence();
       uint64_t accw[R];
 #pragma unroll
       for (int j = 0; j < R; ++j) {
@@ -1899,37 +1868,18 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
         }
         accw[j] = accm;
       }
-      if constexpr (kEarly) {
-        // the claim's acceptance words: to its record (no fence: the next step's stands in front of its own gather); the lanes of the
-        // next pod's gather that read this claim take its whole record — new state, new words — from registers
-        const uint32_t xc = (uint32_t)x;
-        if (W::leader()) {
+      // the claim's record: its state (lane first_ok computed it for the claim it read) and the acceptance words
+      W::each([&](int l) {
+        if (l == fo_) {
+          FastRec<R> mine;
+          mine.vmask = nmv.at(l); mine.req[0] = n0v.at(l); mine.req[1] = n1v.at(l); mine.req[2] = n2v.at(l); mine.req[3] = n3v.at(l);
 #pragma unroll
-          for (int j = 0; j < R; ++j) cst.put_acc(xc, j, accw[j]);
+          for (int j = 0; j < R; ++j) mine.acc[j] = accw[j];
+          cst.put_rec(xw.at(l), mine);
         }
-        uint64_t pa = accw[0];
-#pragma unroll
-        for (int j = 1; j < R; ++j) pa = row == j ? accw[j] : pa;     // (row: the next pod's, stage_a above)
-        const FastClaim nsx = ns;
-        W::each([&](int l) {
-          const bool me = xv.at(l) == xc;
-          awv.at(l) = me ? pa : awv.at(l); mvv.at(l) = me ? nsx.vmask : mvv.at(l);
-          q0.at(l) = me ? nsx.req[0] : q0.at(l); q1.at(l) = me ? nsx.req[1] : q1.at(l); q2.at(l) = me ? nsx.req[2] : q2.at(l); q3.at(l) = me ? nsx.req[3] : q3.at(l);
-        });
-      } else {
-        // the claim's record: its state (lane first_ok computed it for the claim it read) and the acceptance words
-        W::each([&](int l) {
-          if (l == fo_) {
-            FastRec<R> mine;
-            mine.vmask = nmv.at(l); mine.req[0] = n0v.at(l); mine.req[1] = n1v.at(l); mine.req[2] = n2v.at(l); mine.req[3] = n3v.at(l);
-  #pragma unroll
-            for (int j = 0; j < R; ++j) mine.acc[j] = accw[j];
-            cst.put_rec(xw.at(l), mine);
-          }
-        });
-        if constexpr (FastMem<GS, R>::kStateHbm) W::hbm_sync(); else W::order();   // (LDS: no wait — it executes a wavefront's accesses in order, the reads below see these writes)
-        gather();     // the next pod's claims (behind this pod's record write): in flight while the loop comes around
-      }
+      });
+      if constexpr (FastMem<GS, R>::kStateHbm) W::hbm_sync(); else W::order();   // (LDS: no wait — it executes a wavefront's accesses in order, the reads below see these writes)
+      gather();     // the next pod's claims (behind this pod's record write): in flight while the loop comes around
       bi++; steps++;
     }
     if (bi < bf || bf < bn || rf >= 0) break;          // a pod the loop does not place / the block's last entry is not the loop's

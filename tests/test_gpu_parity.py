@@ -659,3 +659,29 @@ def test_cursor_engine_moves_its_claim_order_to_hbm_on_the_device(oracle, monkey
     library: it reads KSOLVE_TEST_WIDE_CAP, the product does not): plan 2 reached straight from the LDS plan and step by step."""
     import test_cursor_engine as tce
     tce.test_claim_order_in_hbm_above_the_wide_plan(oracle, parity.build_hooks(), monkeypatch)
+
+
+def test_two_wavefront_cursor_kernel_on_the_device(oracle):
+    """ksolve_pack_fast2 (engine "cursor-pair": a placer wavefront and a refresher wavefront behind an LDS mailbox, fast_engine.h
+    FastMail) against the oracle and against the one-wavefront kernel `auto` runs: on the device the refresher serves a request at
+    whatever moment the hardware gives it — anywhere between the two extremes the emulation runs (tests/test_cursor_engine.py) — and
+    the Results must not depend on it: several problem sizes, each solved five times on one handle."""
+    import random
+    import test_cursor_engine as tce
+    for seed, pods in ((1, 900), (2, 6000), (3, 40000)):
+        prob = tce.lite_problem(random.Random(8100 + seed), pods)
+        try:
+            s = NewScheduler(tce.with_engine(prob, "cursor-pair"))
+            pair = s.Solve()
+        except tce.Unsupported:
+            continue
+        want = oracle.solve(prob)
+        parity.assert_same_results(pair, want)
+        assert pair["counters"]["engine"] == "cursor" and pair["counters"]["cursorMemoryPlan"] == 0
+        assert pair["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]
+        first = parity.results_digest(pair)[0]
+        for _ in range(4):
+            assert parity.results_digest(s.Solve())[0] == first
+        s.close()
+        solo = NewScheduler(tce.with_engine(prob, "cursor")).Solve()
+        assert parity.results_digest(solo)[0] == first
