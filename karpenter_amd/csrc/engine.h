@@ -50,6 +50,7 @@ constexpr int kMaxCold = 2 * kMaxKeys + (kMaxKeys + 1) / 2;
 template <int RW, int IW, int CL, bool REGS = true>
 struct ScratchT {
   static constexpr int kReqWords = RW, kItWords = IW, kCacheLines = CL;
+  static constexpr bool kTopoLds = REGS;     // an engine on this working set may keep the topology groups' descriptors / small state in LDS (Engine::topo_to_lds); the compact sweep's never does: its engine reads them where the problem has them, with no pointers of its own to keep in registers
   static constexpr bool kRegTables = REGS;   // the engine keeps the instance-type tables in registers too (80 VGPRs; the resource-fit test of the instance-type filter without LDS traffic)
   static constexpr int kHot = RW + IW + 2 * kMaxRes + 4;
   typedef ReqBufT<RW> Buf;
@@ -173,6 +174,19 @@ struct Engine {
   struct TopoPtrs { const uint8_t* type; const int32_t* key; const int8_t* key_slot; const int16_t* host_slot; const int32_t *max_skew, *min_domains;
                     const uint8_t *f_affinity, *f_taint; const uint32_t* f_first; const uint64_t* f_tolerates; } TT;
   uint64_t* tgD = nullptr; int32_t* tgC = nullptr; int32_t* tgN = nullptr;
+  KS_DEV const uint8_t* tt_type() const { if constexpr (SC::kTopoLds) return TT.type; else return P.topo.type; }
+  KS_DEV const int32_t* tt_key() const { if constexpr (SC::kTopoLds) return TT.key; else return P.topo.key; }
+  KS_DEV const int8_t* tt_key_slot() const { if constexpr (SC::kTopoLds) return TT.key_slot; else return P.topo.key_slot; }
+  KS_DEV const int16_t* tt_host_slot() const { if constexpr (SC::kTopoLds) return TT.host_slot; else return P.topo.host_slot; }
+  KS_DEV const int32_t* tt_max_skew() const { if constexpr (SC::kTopoLds) return TT.max_skew; else return P.topo.max_skew; }
+  KS_DEV const int32_t* tt_min_domains() const { if constexpr (SC::kTopoLds) return TT.min_domains; else return P.topo.min_domains; }
+  KS_DEV const uint8_t* tt_f_affinity() const { if constexpr (SC::kTopoLds) return TT.f_affinity; else return P.topo.f_affinity; }
+  KS_DEV const uint8_t* tt_f_taint() const { if constexpr (SC::kTopoLds) return TT.f_taint; else return P.topo.f_taint; }
+  KS_DEV const uint32_t* tt_f_first() const { if constexpr (SC::kTopoLds) return TT.f_first; else return P.topo.f_first; }
+  KS_DEV const uint64_t* tt_f_tolerates() const { if constexpr (SC::kTopoLds) return TT.f_tolerates; else return P.topo.f_tolerates; }
+  KS_DEV uint64_t* tg_D() const { if constexpr (SC::kTopoLds) return tgD; else return S.tg_domains; }
+  KS_DEV int32_t* tg_C() const { if constexpr (SC::kTopoLds) return tgC; else return S.tg_counts; }
+  KS_DEV int32_t* tg_N() const { if constexpr (SC::kTopoLds) return tgN; else return S.tg_nonzero; }
   uint64_t pending_reserved = 0;    // offerings the last successful can_add wants reserved (offeringsToReserve, nodeclaim.go:303-350)
   bool min_values_best_effort = false;   // MinValuesPolicyBestEffort (scheduler.go:117)
   bool minv_lowered = false;        // the last can_add lowered a minValues requirement (BestEffort)
@@ -199,7 +213,7 @@ struct Engine {
   }
   // copies the descriptors into LDS and points the mutable group state there (before solve() fills it from the pristine tables)
   KS_DEV void topo_to_lds() {
-    if (!FULL || !L.topo || !P.topo.n_groups || S.probe) return;
+    if (!SC::kTopoLds || !FULL || !L.topo || !P.topo.n_groups || S.probe) return;
     const TopoView& T0 = P.topo;
     const int G = T0.n_groups, dw = T0.dom_words;
     char* q = L.topo;
@@ -621,12 +635,12 @@ struct Engine {
     return c;
   }
   KS_DEV int32_t host_count(int g, int bin_kind, int bin) const {
-    const int hs = TT.host_slot[g];
+    const int hs = tt_host_slot()[g];
     return bin_kind == 0 ? S.tg_claim_counts[(size_t)hs * S.max_claims + bin] : node_host_count(hs, bin);
   }
   // Record: one more pod on the bin; returns the count before it (uniform)
   KS_DEV int32_t host_count_add(int g, int bin_kind, int bin) {
-    const int hs = TT.host_slot[g];
+    const int hs = tt_host_slot()[g];
     if (bin_kind == 0) { int32_t* p = S.tg_claim_counts + (size_t)hs * S.max_claims + bin; const int32_t c = *p; W::store(p, c + 1); return c; }
     if (!S.probe) { int32_t* p = S.tg_node_counts + (size_t)hs * P.n_nodes + bin; const int32_t c = *p; W::store(p, c + 1); return c; }
     const int32_t before = node_host_count(hs, bin);
@@ -637,7 +651,7 @@ struct Engine {
   }
   // anyCompatiblePodDomain for a hostname group — topologygroup.go:393-400
   KS_DEV bool topo_any_compatible_host(int g, const ReqRef& pod) {
-    const int hs = TT.host_slot[g];
+    const int hs = tt_host_slot()[g];
     const int32_t* cc = S.tg_claim_counts + (size_t)hs * S.max_claims;
     const int ne = P.n_nodes, ncl = n_claims;
     if (W::find_first(0, ne, [&](int e) { return node_host_count(hs, e) > 0 && pod_has_host(pod, 1, e); }) < ne) return true;
@@ -648,14 +662,14 @@ struct Engine {
   KS_DEV bool topo_hostname_ok(int g, bool self, const ReqRef& pod, int bin_kind, int bin) {
     const TopoView& T = P.topo;
     const int cnt = bin >= 0 ? host_count(g, bin_kind, bin) : 0;
-    switch (TT.type[g]) {
-      case 0: return (long long)cnt + (self ? 1 : 0) <= (long long)TT.max_skew[g];       // topologygroup.go:240-247
+    switch (tt_type()[g]) {
+      case 0: return (long long)cnt + (self ? 1 : 0) <= (long long)tt_max_skew()[g];       // topologygroup.go:240-247
       case 2: return cnt == 0;                                                            // :409-414
       default:                                                                            // :331-343
         if (!pod_has_host(pod, bin_kind, bin)) return false;
         if (cnt > 0) return true;
         if (!self) return false;
-        if (tgN[g] == 0) return true;
+        if (tg_N()[g] == 0) return true;
         return !topo_any_compatible_host(g, pod);
     }
   }
@@ -664,10 +678,10 @@ struct Engine {
   KS_DEV bool topo_next_domain(int g, bool self, const ReqRef& pod, const ReqRef& node) {
     const TopoView& T = P.topo;
     const Dict& d = P.dict;
-    const int key = TT.key[g], type = TT.type[g];
+    const int key = tt_key()[g], type = tt_type()[g];
     const uint32_t w0 = d.key_word_off[key], nw = d.key_word_off[key + 1] - w0;
-    const uint64_t* D = tgD + (size_t)g * T.dom_words;
-    const int32_t* cnt = tgC + (size_t)g * T.dom_words * 64;
+    const uint64_t* D = tg_D() + (size_t)g * T.dom_words;
+    const int32_t* cnt = tg_C() + (size_t)g * T.dom_words * 64;
     const uint16_t* rank = T.value_rank + (size_t)w0 * 64;
     uint64_t* tq = sc.tq;
     uint64_t any = 0;
@@ -682,9 +696,9 @@ struct Engine {
         const uint64_t m = W::reduce_min(64, [&](int b) -> uint64_t { return ((sup >> b) & 1) ? (uint64_t)(uint32_t)cnt[x * 64 + b] : NONE; });
         if (m != NONE && (long long)m < mn) mn = (long long)m;
       }
-      if (TT.min_domains[g] >= 0 && supported < TT.min_domains[g]) mn = 0;
+      if (tt_min_domains()[g] >= 0 && supported < tt_min_domains()[g]) mn = 0;
       // the valid domain with the fewest pods, the smallest name among equals — topologygroup.go:251-297
-      const long long skew = TT.max_skew[g];
+      const long long skew = tt_max_skew()[g];
       uint64_t best = NONE;
       for (uint32_t x = 0; x < nw; ++x) {
         const uint64_t dw = D[x];
@@ -724,7 +738,7 @@ struct Engine {
     }
     W::sync();
     if (any) return true;
-    if (!self || !(tgN[g] == 0 || any_pod_nonzero == 0)) return false;
+    if (!self || !(tg_N()[g] == 0 || any_pod_nonzero == 0)) return false;
     // nothing to be affine to yet and the pod matches its own selector: bootstrap a domain (:372-386)
     uint64_t b1 = NONE, b2 = NONE;
     for (uint32_t x = 0; x < nw; ++x) {
@@ -751,10 +765,10 @@ struct Engine {
   KS_DEV uint64_t topo_ok_mask(int g, bool self, const ReqRef& pod) {
     const TopoView& T = P.topo;
     const Dict& d = P.dict;
-    const int key = TT.key[g], type = TT.type[g];
+    const int key = tt_key()[g], type = tt_type()[g];
     const uint32_t w0 = d.key_word_off[key];
-    const uint64_t dw = tgD[(size_t)g * T.dom_words];
-    const int32_t* cnt = tgC + (size_t)g * T.dom_words * 64;
+    const uint64_t dw = tg_D()[(size_t)g * T.dom_words];
+    const int32_t* cnt = tg_C() + (size_t)g * T.dom_words * 64;
     // the pod's own requirement on the key narrows the bin's domains (nodeRequirements = bin ∧ pod, nodeclaim.go:137-140)
     uint64_t podreq = ~0ull;
     {
@@ -768,8 +782,8 @@ struct Engine {
       long long mn = INT32_MAX;
       const uint64_t m = W::reduce_min(64, [&](int b) -> uint64_t { return ((sup >> b) & 1) ? (uint64_t)(uint32_t)cnt[b] : NONE; });
       if (m != NONE) mn = (long long)m;
-      if (TT.min_domains[g] >= 0 && popc64(sup) < TT.min_domains[g]) mn = 0;
-      const long long skew = TT.max_skew[g];
+      if (tt_min_domains()[g] >= 0 && popc64(sup) < tt_min_domains()[g]) mn = 0;
+      const long long skew = tt_max_skew()[g];
       const uint64_t valid = W::ballot([&](int b) { return ((dw >> b) & 1) != 0 && (long long)cnt[b] + (self ? 1 : 0) - mn <= skew; });
       return valid & podreq;
     }
@@ -801,7 +815,7 @@ struct Engine {
     for (int tw = 0; tw < T.words; ++tw) for (uint64_t m = sc.t_match[tw]; m; m &= m - 1) {
       const int g = tw * 64 + ctz64(m);
       const bool self = (sc.t_sel[tw] >> (g & 63)) & 1;
-      const int key = TT.key[g];
+      const int key = tt_key()[g];
       if (key < 0) {
         if (!topo_hostname_ok(g, self, pod, bin_kind, bin)) return false;
         continue;   // In [bin's hostname] ∧ the bin's own hostname requirement: nothing changes
@@ -823,9 +837,9 @@ struct Engine {
   KS_DEV bool topo_filter_matches(int g, uint64_t taints, const ReqRef& fin, int bin_kind) {
     const TopoView& T = P.topo;
     const Dict& d = P.dict;
-    if (TT.f_taint[g] && (taints & ~TT.f_tolerates[g])) return false;
-    if (!TT.f_affinity[g]) return true;
-    const uint32_t a = TT.f_first[g], b = TT.f_first[g + 1];
+    if (tt_f_taint()[g] && (taints & ~tt_f_tolerates()[g])) return false;
+    if (!tt_f_affinity()[g]) return true;
+    const uint32_t a = tt_f_first()[g], b = tt_f_first()[g + 1];
     if (a == b) return true;
     const int hn = d.key_hostname;
     for (uint32_t i = a; i < b; ++i) {
@@ -848,16 +862,16 @@ struct Engine {
       const int g = tw * 64 + ctz64(todo);
       const bool inv = (T.inverse_mask[tw] >> (g & 63)) & 1;
       if (!inv && !topo_filter_matches(g, taints, fin, bin_kind)) continue;
-      const int key = TT.key[g];
+      const int key = tt_key()[g];
       if (key < 0) {
         const int32_t c = host_count_add(g, bin_kind, bin);
-        if (c == 0) W::store(&tgN[g], tgN[g] + 1);
-        if (bin_kind == 0 && TT.type[g] != 1) {
+        if (c == 0) W::store(&tg_N()[g], tg_N()[g] + 1);
+        if (bin_kind == 0 && tt_type()[g] != 1) {
           // threshold bitmaps of the scan prefilter: "count <= t-1" ends when the count reaches t, "count <= t" at t+1
-          const long long t = TT.type[g] == 2 ? 0 : (long long)TT.max_skew[g];
+          const long long t = tt_type()[g] == 2 ? 0 : (long long)tt_max_skew()[g];
           const long long n = (long long)c + 1;
           if (n == t || n == t + 1) {
-            uint64_t* hz = S.host_le + ((size_t)TT.host_slot[g] * 2 + (n == t ? 0 : 1)) * S.claim_words + (bin >> 6);
+            uint64_t* hz = S.host_le + ((size_t)tt_host_slot()[g] * 2 + (n == t ? 0 : 1)) * S.claim_words + (bin >> 6);
             W::store(hz, (uint64_t)(*hz & ~(1ull << (bin & 63))));
           }
         }
@@ -866,14 +880,14 @@ struct Engine {
       }
       if (!bit(fin.defined, key)) continue;   // Exists: no values
       const uint32_t w0 = d.key_word_off[key], nw = d.key_word_off[key + 1] - w0;
-      const bool anti = inv || TT.type[g] == 2;
+      const bool anti = inv || tt_type()[g] == 2;
       int nvals = 0;
       for (uint32_t x = 0; x < nw; ++x) nvals += popc64(fin.mask[w0 + x]);
       // anti-affinity blocks every stored value (domains.Values(), also for a NotIn set); the others count a pod only
       // once its domain is decided (topology.go:203-211)
       if (!anti && (bit(fin.complement, key) || nvals != 1)) continue;
-      uint64_t* D = tgD + (size_t)g * T.dom_words;
-      int32_t* cnt = tgC + (size_t)g * T.dom_words * 64;
+      uint64_t* D = tg_D() + (size_t)g * T.dom_words;
+      int32_t* cnt = tg_C() + (size_t)g * T.dom_words * 64;
       int fresh = 0;
       for (uint32_t x = 0; x < nw; ++x) {
         const uint64_t mk = fin.mask[w0 + x];
@@ -887,7 +901,7 @@ struct Engine {
         fresh += popc64(was_zero);
         W::store(&D[x], (uint64_t)(D[x] | mk));
       }
-      if (fresh) W::store(&tgN[g], tgN[g] + fresh);
+      if (fresh) W::store(&tg_N()[g], tg_N()[g] + fresh);
       W::sync();
     }
   }
@@ -1370,16 +1384,16 @@ struct Engine {
       for (int tw = 0; tw < T.words; ++tw) for (uint64_t m = sc.t_match[tw]; m; m &= m - 1) {
         const int g = tw * 64 + ctz64(m);
         const bool self = (sc.t_sel[tw] >> (g & 63)) & 1;
-        if (TT.key[g] >= 0) {
+        if (tt_key()[g] >= 0) {
           // dictionary key: skip the claims whose admitted values miss every domain the group could pick
-          const int sl = TT.key_slot[g];
+          const int sl = tt_key_slot()[g];
           if (sl < 0) continue;
           const uint64_t okv = topo_ok_mask(g, self, P.cls_strict.at(P.dict, (uint32_t)cur_class));
           if (okv == ~0ull) continue;
           // one lane per 64 claims: OR the "claims that admit value v" words of the eligible values
           const uint64_t* kvc = S.kv_claims + (size_t)sl * 64 * S.claim_words;
           const int cw = S.claim_words;
-          const uint64_t vals = okv & P.dict.value_valid[P.dict.key_word_off[TT.key[g]]];
+          const uint64_t vals = okv & P.dict.value_valid[P.dict.key_word_off[tt_key()[g]]];
           any = W::ballot([&](int l) {
             uint64_t acc_any = 0;
             for (int w = l; w < words; w += 64) {
@@ -1397,13 +1411,13 @@ struct Engine {
           if (!any) return false;
           continue;
         }
-        if (TT.type[g] == 1) continue;
-        const long long limit = TT.type[g] == 2 ? 0 : (long long)TT.max_skew[g] - (self ? 1 : 0);
+        if (tt_type()[g] == 1) continue;
+        const long long limit = tt_type()[g] == 2 ? 0 : (long long)tt_max_skew()[g] - (self ? 1 : 0);
         if (limit < 0) return false;   // not even an empty claim satisfies it
         {
           // "count <= limit" from the threshold bitmap of the group (limit is t-1 or t): one word per 64 claims
-          const long long t = TT.type[g] == 2 ? 0 : (long long)TT.max_skew[g];
-          const uint64_t* hz = S.host_le + ((size_t)TT.host_slot[g] * 2 + (limit == t ? 1 : 0)) * S.claim_words;
+          const long long t = tt_type()[g] == 2 ? 0 : (long long)tt_max_skew()[g];
+          const uint64_t* hz = S.host_le + ((size_t)tt_host_slot()[g] * 2 + (limit == t ? 1 : 0)) * S.claim_words;
           any = W::ballot([&](int l) {
             uint64_t acc_any = 0;
             for (int w = l; w < words; w += 64) { const uint64_t v = stage[w] & hz[w]; stage[w] = v; acc_any |= v; }
@@ -2006,10 +2020,10 @@ struct Engine {
       probe_load_node(e);
       const uint64_t taints = P.node_taints[e];
       for (int g = 0; g < G; ++g) {
-        const int key = TT.key[g];
+        const int key = tt_key()[g];
         if (key < 0) {
           // the removed node's counter leaves with it (node_host_count reads 0 for it from here on)
-          if (T.node_counts0[(size_t)TT.host_slot[g] * ne + e] > 0) { W::store(&tgN[g], tgN[g] - 1); W::sync(); }
+          if (T.node_counts0[(size_t)tt_host_slot()[g] * ne + e] > 0) { W::store(&tg_N()[g], tg_N()[g] - 1); W::sync(); }
           continue;
         }
         if (!T.dom_regs0 || ((T.inverse_mask[g >> 6] >> (g & 63)) & 1)) continue;
@@ -2031,13 +2045,13 @@ struct Engine {
       for (int tw = 0; tw < T.words; ++tw)
       for (uint64_t todo = (ct[T.words + tw] & ~T.inverse_mask[tw]) | (ct[tw] & T.inverse_mask[tw]); todo; todo &= todo - 1) {
         const int g = tw * 64 + ctz64(todo);
-        const int key = TT.key[g];
+        const int key = tt_key()[g];
         if (key < 0) continue;                                  // per-node counters of the removed node are gone already
         const bool inv = (T.inverse_mask[tw] >> (g & 63)) & 1;
         const int v = probe_node_value(key);
         if (v < 0) continue;
         if (!inv && !topo_filter_matches(g, taints, sc.merged.ref(), 1)) continue;
-        int32_t* pc = tgC + (size_t)g * dv + v;
+        int32_t* pc = tg_C() + (size_t)g * dv + v;
         W::store(pc, *pc - 1);
         W::sync();
       }
@@ -2052,17 +2066,17 @@ struct Engine {
     }
     // registered domains (universe ∪ nodes that are still there ∪ counted) and the number of non-empty domains, per group
     for (int g = 0; g < G; ++g) {
-      if (TT.key[g] < 0) continue;
-      const int32_t* cnt = tgC + (size_t)g * dv;
+      if (tt_key()[g] < 0) continue;
+      const int32_t* cnt = tg_C() + (size_t)g * dv;
       const int32_t* rg = T.dom_regs0 ? S.tg_regs + (size_t)g * dv : nullptr;
       int nz = 0;
       for (int x = 0; x < T.dom_words; ++x) {
         const uint64_t counted = W::ballot([&](int b) { return cnt[x * 64 + b] > 0; });
         const uint64_t regd = rg ? W::ballot([&](int b) { return rg[x * 64 + b] > 0; }) : 0ull;
         nz += popc64(counted);
-        if (T.dom_universe) W::store(&tgD[(size_t)g * T.dom_words + x], (uint64_t)(T.dom_universe[(size_t)g * T.dom_words + x] | regd | counted));
+        if (T.dom_universe) W::store(&tg_D()[(size_t)g * T.dom_words + x], (uint64_t)(T.dom_universe[(size_t)g * T.dom_words + x] | regd | counted));
       }
-      W::store(&tgN[g], nz);
+      W::store(&tg_N()[g], nz);
     }
     W::sync();
   }
@@ -2249,10 +2263,10 @@ struct Engine {
       const TopoView& T = P.topo;
       Workspace& Sw = S;
       const int G = T.n_groups, dv = T.dom_words * 64;
-      W::for_n(G * T.dom_words, [&](int i) { tgD[i] = T.domains0[i]; });
-      W::for_n(G * dv, [&](int i) { tgC[i] = T.counts0[i]; });
+      W::for_n(G * T.dom_words, [&](int i) { tg_D()[i] = T.domains0[i]; });
+      W::for_n(G * dv, [&](int i) { tg_C()[i] = T.counts0[i]; });
       if (!S.probe) W::for_n(T.n_host_groups * P.n_nodes, [&](int i) { Sw.tg_node_counts[i] = T.node_counts0[i]; });   // probes: shared + overlay (node_host_count)
-      W::for_n(G, [&](int i) { tgN[i] = T.nonzero0[i]; });
+      W::for_n(G, [&](int i) { tg_N()[i] = T.nonzero0[i]; });
       W::for_n(T.words, [&](int w) { sc.t_active[w] = T.initially_active[w]; });
       W::for_n(T.n_alias, [&](int i) { Sw.tg_alias_active[i] = -1; });
       if (S.probe) probe_topology_adjust();

@@ -197,6 +197,47 @@ def test_more_classes_than_slots_evicts_and_stays_exact(oracle, emu):
     assert got["scheduledPods"] == 1400
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_several_rows_of_class_slots_with_classes_that_overlap(oracle, emu, seed):
+    """More than 64 pod classes live at once (several rows of class slots) whose selectors and tolerations OVERLAP: classes pinned to a
+    team's pool, classes any pool takes, zone / capacity-type / arch selectors in every combination, three pools with and without taints
+    — so the rows new_slot builds (a class goes where the classes it could share a NodeClaim with sit) are not separable, and the
+    refresh's row skip (no class of the row tolerates the claim's template and keeps a value on every selected key) must fire exactly
+    when the row has no bit to compute. One size per run of the queue keeps every class live for the whole run. Against the oracle on
+    the three memory plans (check_cursor)."""
+    rng = random.Random(9100 + seed)
+    its = fx.kwok_catalog(rng.choice([72, 144])); zones = list(fx.KWOK_ZONES)
+    archs = sorted({v for it in its for r in it["requirements"] if r["key"] == fx.ARCH for v in r["values"]})
+    pools = []
+    for i in range(3):
+        kw = {"labels": {"team": f"t{i}"}}
+        if i < 2: kw["taints"] = [{"key": "dedicated", "value": f"t{i}", "effect": "NoSchedule"}]
+        pools.append(fx.node_pool(f"pool-{i}", weight=rng.randrange(1, 20), **kw))
+    pools.append(fx.node_pool("catch-all", weight=0))
+    for np_ in pools: np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+    classes, seen = [], set()
+    while len(classes) < rng.choice([90, 150, 230]):
+        sel = {}
+        if rng.random() < 0.5: sel["team"] = f"t{rng.randrange(3)}"
+        if rng.random() < 0.5: sel[fx.ZONE] = rng.choice(zones)
+        if rng.random() < 0.4: sel[fx.CAPACITY_TYPE] = rng.choice(["spot", "on-demand"])
+        if rng.random() < 0.4: sel[fx.ARCH] = rng.choice(archs)
+        tol = rng.choice([None, [{"key": "dedicated", "operator": "Exists"}], [{"key": "dedicated", "operator": "Equal", "value": "t0", "effect": "NoSchedule"}]])
+        if sel.get("team") == "t1" or (sel.get("team") == "t0" and tol is None): tol = [{"key": "dedicated", "operator": "Exists"}]   # (every pod can be scheduled)
+        mem = 64 if len(classes) % 10 else 96    # one size for nine classes in ten: they are all live at once for the whole run of that size
+        key = (tuple(sorted(sel.items())), str(tol), mem)
+        if key in seen: continue
+        seen.add(key)
+        classes.append(dict(requests={"cpu": "250m", "memory": f"{mem}Mi"}, node_selector=sel or None, tolerations=tol))
+    pods = [fx.pod(**rng.choice(classes)) for _ in range(rng.choice([3000, 6000]))]
+    prob = fx.problem(its, pools, pods, well_known=fx.KWOK_WELL_KNOWN)
+    want = oracle.solve(prob)
+    try:
+        check_cursor(oracle, emu, prob, want)
+    except Unsupported:
+        pytest.skip("declined by the cursor engine (an unschedulable pod in this draw)")
+
+
 def test_long_runs_of_equally_full_claims(oracle, emu):
     """Every pod needs its own claim-sized share: hundreds of claims with the same pod count, so a commit moves a claim past
     more than 64 others (the in-window move gives way to the general one)."""
