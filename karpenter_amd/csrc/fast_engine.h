@@ -1511,7 +1511,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
   auto read_done = [&]() { if constexpr (HP) { W::order(); W::each([&](int l) { dwl.at(l) = mail->done; }); } };
   // pdqsort's other paths: with 12 < n < 50 every re-sort that has something to move; with n >= 50 a move from one of choosePivot's
   // nine sampled positions (fast_sampled, as three starts); with n <= 12 none (the stable insertion sort)
-  const uint32_t inexact = (n > 12 && n < 50) ? 1u : 0u;
+  const bool inexact_b = n > 12 && n < 50;
   const uint32_t e1 = n >= 50 ? (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u, e2 = n >= 50 ? 2u * (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u, e3 = n >= 50 ? 3u * (uint32_t)(n >> 2) - 1u : 0x7FFFFFF0u;
   const int nm1 = n - 1;
   // Software pipeline over the pods of a block: a step has three dependent LDS round trips (the order's entries -> the claims'
@@ -1522,7 +1522,8 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
   unsigned long long n_ext = 0;   // four-window steps of scans beyond a cursor's window
   int rf = -1;              // a claim whose refresh met a requirement set that is not cached: the driver computes its words
   LaneVar<uint32_t> xv, kv; // the order's entries of the pod about to be placed: claim id and pod count at positions rc0 + lane
-  uint32_t clsw = 0, rc0 = 0, badA = 0;
+  uint32_t clsw = 0, rc0 = 0;
+  uint64_t badA = 0;   // all ones: the pod's class has no slot (booleans of the step are 64-bit masks in scalar registers: what the compiler makes of a uniform condition anyway, without a trip through a vector register at the end)
   int row = 0, sl = 0;
   // the order's 64 entries at positions rr .. rr+63 (n >= 1 here)
   auto order_reads = [&](uint32_t rr) {
@@ -1554,7 +1555,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
     row = 0;
     if constexpr (R == 1) {
       const uint64_t m0 = W::ballot([&](int l) { return scls[0].at(l) == kcls; });
-      badA = (uint32_t)fast_uniform((int)(m0 == 0));
+      badA = m0 == 0 ? ~0ull : 0ull;
       sl = ctz64(m0 | (1ull << 63));
     } else {
       uint64_t mf = 0;
@@ -1563,7 +1564,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
         const uint64_t mj = W::ballot([&](int l) { return scls[j].at(l) == kcls; });
         row = mj != 0 ? j : row; mf = mj != 0 ? mj : mf;     // (a class sits in one slot)
       }
-      badA = (uint32_t)fast_uniform((int)(mf == 0));
+      badA = mf == 0 ? ~0ull : 0ull;
       sl = ctz64(mf | (1ull << 63));
     }
     rc0 = cur[0].bcast(sl);
@@ -1582,15 +1583,16 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       // harmless values (lane 0, position 0), so that no branch stands between the loads and the compiler issues them together —
       // with a `break` behind the acceptor test it had sunk the count, state and class reads below it: five dependent LDS round
       // trips per pod instead of three.
-      uint32_t bad = badA;
+      uint64_t bad = badA;
       const int slot = row * 64 + sl;
       const FastSlot cs = lds_get(&aslot[slot]);
       // ---- select: the claims at the 64 positions, one lane each: the whole record (state and acceptance words) ----
       const uint64_t slbit = 1ull << sl;
       const int rws = row;
       auto select = [&]() {
-        const uint32_t rcs = rc0;
-        return W::ballot([&](int l) { return (awv.at(l) & ((int)rcs + l < n ? slbit : 0ull)) != 0; });
+        const int rem = n - (int)rc0;                       // positions of the window that exist (a cursor at the end of the order: none)
+        const uint64_t vm = rem >= 64 ? ~0ull : ((1ull << (rem < 0 ? 0 : rem)) - 1ull);
+        return W::ballot([&](int l) { return (awv.at(l) & slbit) != 0; }) & vm;
       };
       uint64_t okm = select();
       if constexpr (HP) {
@@ -1624,7 +1626,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
 #ifdef KSOLVE_PHASE_TIMERS
             { const unsigned long long tw1 = W::clock(); hw0++; hw1 += tw1 - tw0; hw3 += tw1 - t_post; }
 #endif
-            bad |= ((dw2 & 1u) | (uint32_t)dead) << 5;              // a requirement set that is not cached: out, nothing written
+            bad |= (((dw2 & 1u) != 0) | dead) ? ~0ull : 0ull;              // a requirement set that is not cached: out, nothing written
             const int p1 = pend1, p2 = pend2;
             W::each([&](int l) { const int xl = (int)xv.at(l); awv.at(l) = xl == p1 ? a1 : xl == p2 ? a2 : awv.at(l); });
             okm = select();
@@ -1634,11 +1636,11 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
           }
         }
       }
-      if (KS_UNLIKELY((okm == 0) & (badA == 0) & ((int)rc0 + 64 < n))) {
+      if (KS_UNLIKELY(okm == 0)) if (badA == 0 && (int)rc0 + 64 < n) {   // (the common case pays one compare: the other two only when no claim of the window accepts)
         // The class's next acceptor is not among the 64 claims at its cursor (the claim it was filling is full): the rest of the
         // order, four windows per step, acceptance words only, all eight reads of a step in flight before the first is used;
         // then the select step once more, at the window that holds it.
-        if constexpr (HP) { if (pend1 >= 0 || pend2 >= 0) { const uint32_t dw2 = wait_for(seq); bad |= (dw2 & 1u) << 5; pend1 = -1; pend2 = -1; } }   // (exact words for the scan)
+        if constexpr (HP) { if (pend1 >= 0 || pend2 >= 0) { const uint32_t dw2 = wait_for(seq); bad |= (dw2 & 1u) != 0 ? ~0ull : 0ull; pend1 = -1; pend2 = -1; } }   // (exact words for the scan)
         int r = (int)rc0 + 64, found = -1;
         while (r < n && found < 0) {
           uint64_t m4[4];
@@ -1664,12 +1666,11 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
           okm = select();
         }
       }
-      bad |= (uint32_t)(okm == 0);
-      const int first_ok = ctz64(okm | (1ull << 63));
+      const int first_ok = ctz64(okm | (1ull << 63));   // (no acceptor: lane 63, and the reach test below says "not plain")
       const int a = (int)rc0 + first_ok;
       const int x = (int)xv.bcast(first_ok);
       const uint32_t cnt = kv.bcast(first_ok);
-      bad |= (uint32_t)(cnt >= 65534u);
+      bad |= cnt >= 65534u ? ~0ull : 0ull;
       // ---- NodeClaim.Add (nodeclaim.go:247-263): the claim's new state (every lane for the claim it read; lane first_ok's is the one) ----
       FastClaim ns;
       LaneVar<uint64_t> nmv; LaneVar<int32_t> n0v, n1v, n2v, n3v;
@@ -1684,11 +1685,11 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       const uint64_t lessm = W::ballot([&](int l) { return kv.at(l) < mvn; });   // lanes past n hold 0xFFFFFFFF; the lanes up to first_ok are shifted out
       const uint64_t tsh = (lessm >> 1) >> first_ok;                             // (two shifts: first_ok may be 63)
       const int sm = ctz64(~tsh);                                                // < 64: the top bit of tsh is clear
-      bad |= (uint32_t)(first_ok + 1 + sm >= 64) & (uint32_t)((int)rc0 + 64 < n);                   // beyond the window: the pending path
+      bad |= first_ok + 1 + sm >= 64 ? ~0ull : 0ull;   // the move reaches the window's last lane or beyond (the pending path), or no claim of the window accepts (first_ok = 63) — a window over the order's tail whose claim lands on lane 63 goes the long way too: rare, exact
       {
         const uint32_t d1 = (uint32_t)a - e1, d2 = (uint32_t)a - e2, d3 = (uint32_t)a - e3;
         const uint32_t dmin = d1 < d2 ? (d1 < d3 ? d1 : d3) : (d2 < d3 ? d2 : d3);
-        bad |= (uint32_t)(sm != 0) & (inexact | (uint32_t)(dmin <= 2u));   // pdqsort's other paths
+        bad |= ((sm != 0) & (inexact_b | (dmin <= 2u))) ? ~0ull : 0ull;   // pdqsort's other paths
       }
       if (KS_UNLIKELY(bad != 0)) { bfx = bi; continue; }   // (out through the loop's own test: one exit)
       // ---- nothing has been written so far; from here on the step is the plain one ----
@@ -1748,7 +1749,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
           clsw = bcls.bcast((bi + 1) & 63);
           const uint32_t kcls = clsw & ~kFastLastBit;
           const uint64_t m0 = W::ballot([&](int l) { return scls[0].at(l) == kcls; });
-          badA = (uint32_t)fast_uniform((int)(m0 == 0));
+          badA = m0 == 0 ? ~0ull : 0ull;
           sl = ctz64(m0 | (1ull << 63));
           const uint32_t rr = cur[0].bcast(sl);
           rc0 = sl == slot_now ? (uint32_t)a : rr - (uint32_t)((rr - ua1) < su);
