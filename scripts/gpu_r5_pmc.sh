@@ -11,10 +11,10 @@ HEAD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --topology-pods 0 --
 SWEEP="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --pods 20000 --no-parity-pin --topology-pods 0 --batch-problems 0 --components-pods 0 --beyond-lds-pods 0 --sweep-sample 0 --sweep-topology-sample 0 --sweep-windows 0 --no-host-engine-baseline --no-cpu-baseline"
 (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_head -o bench -- $HEAD > $O/stats_head.log 2>&1)
 find $O/stats_head -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} cp {} $O/rocprofv3_kernel_stats_bench_1m.csv
-(cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sweep -o bench -- $SWEEP > $O/stats_sweep.log 2>&1)
+[ "${KSOLVE_PMC_LEGS:-head sweep}" = head ] || (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sweep -o bench -- $SWEEP > $O/stats_sweep.log 2>&1)
 find $O/stats_sweep -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} cp {} $O/rocprofv3_kernel_stats_sweep.csv
 cut -c1-150 $O/rocprofv3_kernel_stats_bench_1m.csv | head -8; cut -c1-150 $O/rocprofv3_kernel_stats_sweep.csv | head -10
-for leg in head sweep; do
+for leg in ${KSOLVE_PMC_LEGS:-head sweep}; do
   CMD="$HEAD"; [ $leg = sweep ] && CMD="$SWEEP"
   (cd /tmp && timeout 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_${leg}_fetch -o f -- $CMD > $O/pmc_${leg}_fetch.log 2>&1)
   (cd /tmp && timeout 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_${leg}_write -o w -- $CMD > $O/pmc_${leg}_write.log 2>&1)
@@ -50,6 +50,13 @@ def collect(leg):
 out = {"source_sha": bench.source_sha(), "pods": 1000000, "types": 500, "command": "bench.py --steps 3 --warmup 1 (headline leg only); sweep_kernels: the configs[4] leg (100k nodes; a warm-up sweep of 64 probes, then the 10k single-node probes the bench line times = largest_launch)",
        "units": "FETCH_SIZE / WRITE_SIZE in KB per launch (rocprofv3 --pmc, separate passes); traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950); per_launch = mean over the launches of that kernel in the command",
        "kernels": collect("head"), "sweep_kernels": collect("sweep")}
+if os.environ.get("KSOLVE_PMC_LEGS", "head sweep") == "head":
+    # the headline leg alone was re-measured: the sweep kernels' counters are carried over from the committed file, which says on which
+    # build they were taken (a build that differs from this one in files no sweep kernel instantiates — stated by whoever ran this)
+    prev = json.load(open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "profiles", "round5", "pmc_traffic.json")))
+    out["sweep_kernels"] = prev.get("sweep_kernels", {})
+    out["sweep_kernels_measured_on_source_sha"] = prev.get("sweep_kernels_measured_on_source_sha", prev.get("source_sha"))
+    out["sweep_kernels_note"] = os.environ.get("KSOLVE_PMC_SWEEP_NOTE", "")
 json.dump(out, open(f"{O}/pmc_traffic.json", "w"), indent=1)
 for grp, names in (("kernels", ("ksolve_pack_fast", "ksolve_row_hash_coop2")), ("sweep_kernels", ("ksolve_pack_sweep", "ksolve_node_dead0"))):
     for k in names:
