@@ -1523,7 +1523,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
   int rf = -1;              // a claim whose refresh met a requirement set that is not cached: the driver computes its words
   LaneVar<uint32_t> xv, kv; // the order's entries of the pod about to be placed: claim id and pod count at positions rc0 + lane
   uint32_t clsw = 0, rc0 = 0;
-  uint64_t badA = 0;   // all ones: the pod's class has no slot (booleans of the step are 64-bit masks in scalar registers: what the compiler makes of a uniform condition anyway, without a trip through a vector register at the end)
+  uint64_t slbitA = 0;   // the bit of the class's slot in an acceptance word — none when the class has no slot: then no claim "accepts", the select comes back empty and the step is not plain (no flag of its own to carry around the loop)
   int row = 0, sl = 0;
   // the order's 64 entries at positions rr .. rr+63 (n >= 1 here)
   auto order_reads = [&](uint32_t rr) {
@@ -1555,7 +1555,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
     row = 0;
     if constexpr (R == 1) {
       const uint64_t m0 = W::ballot([&](int l) { return scls[0].at(l) == kcls; });
-      badA = m0 == 0 ? ~0ull : 0ull;
+      slbitA = m0 & (0ull - m0);
       sl = ctz64(m0 | (1ull << 63));
     } else {
       uint64_t mf = 0;
@@ -1564,7 +1564,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
         const uint64_t mj = W::ballot([&](int l) { return scls[j].at(l) == kcls; });
         row = mj != 0 ? j : row; mf = mj != 0 ? mj : mf;     // (a class sits in one slot)
       }
-      badA = mf == 0 ? ~0ull : 0ull;
+      slbitA = mf & (0ull - mf);
       sl = ctz64(mf | (1ull << 63));
     }
     rc0 = cur[0].bcast(sl);
@@ -1583,11 +1583,11 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       // harmless values (lane 0, position 0), so that no branch stands between the loads and the compiler issues them together —
       // with a `break` behind the acceptor test it had sunk the count, state and class reads below it: five dependent LDS round
       // trips per pod instead of three.
-      uint64_t bad = badA;
+      uint64_t bad = 0;   // (booleans of the step are 64-bit masks in scalar registers: what the compiler makes of a uniform condition anyway)
       const int slot = row * 64 + sl;
       const FastSlot cs = lds_get(&aslot[slot]);
       // ---- select: the claims at the 64 positions, one lane each: the whole record (state and acceptance words) ----
-      const uint64_t slbit = 1ull << sl;
+      const uint64_t slbit = slbitA;
       const int rws = row;
       auto select = [&]() {
         const int rem = n - (int)rc0;                       // positions of the window that exist (a cursor at the end of the order: none)
@@ -1636,7 +1636,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
           }
         }
       }
-      if (KS_UNLIKELY(okm == 0)) if (badA == 0 && (int)rc0 + 64 < n) {   // (the common case pays one compare: the other two only when no claim of the window accepts)
+      if (KS_UNLIKELY(okm == 0)) if (slbit != 0 && (int)rc0 + 64 < n) {   // (the common case pays one compare: the other two only when no claim of the window accepts)
         // The class's next acceptor is not among the 64 claims at its cursor (the claim it was filling is full): the rest of the
         // order, four windows per step, acceptance words only, all eight reads of a step in flight before the first is used;
         // then the select step once more, at the window that holds it.
@@ -1749,7 +1749,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
           clsw = bcls.bcast((bi + 1) & 63);
           const uint32_t kcls = clsw & ~kFastLastBit;
           const uint64_t m0 = W::ballot([&](int l) { return scls[0].at(l) == kcls; });
-          badA = m0 == 0 ? ~0ull : 0ull;
+          slbitA = m0 & (0ull - m0);
           sl = ctz64(m0 | (1ull << 63));
           const uint32_t rr = cur[0].bcast(sl);
           rc0 = sl == slot_now ? (uint32_t)a : rr - (uint32_t)((rr - ua1) < su);
@@ -1796,12 +1796,19 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
 #pragma unroll
           for (int j = 0; j < R; ++j) {
             const bool me = j * 64 + l == slot;
-            const uint32_t fm = me ? lastm : 0u;
             const uint32_t rr = cur[j].at(l);
             cur[j].at(l) = me ? (uint32_t)a : rr - (uint32_t)((rr - ua1) < su);
-            scls[j].at(l) |= fm; tok[j].at(l) &= ~fm;
           }
         });
+        if (KS_UNLIKELY(lastm != 0)) {     // the class's last entry (once per class): its slot is free
+          W::each([&](int l) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+              const bool me = j * 64 + l == slot;
+              scls[j].at(l) = me ? kFastFree : scls[j].at(l); tok[j].at(l) = me ? 0u : tok[j].at(l);
+            }
+          });
+        }
       }
       n_ref += (unsigned long long)((uint32_t)a + 1u);
       // ---- refresh: CanAdd (nodeclaim.go:124-242) of the claim as it stands now, for the classes of all slots (lane = slot):
