@@ -1796,19 +1796,12 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
 #pragma unroll
           for (int j = 0; j < R; ++j) {
             const bool me = j * 64 + l == slot;
+            const uint32_t fm = me ? lastm : 0u;     // (branch-free: a branch taken once per class measured slower than these three instructions per pod, pass N)
             const uint32_t rr = cur[j].at(l);
             cur[j].at(l) = me ? (uint32_t)a : rr - (uint32_t)((rr - ua1) < su);
+            scls[j].at(l) |= fm; tok[j].at(l) &= ~fm;
           }
         });
-        if (KS_UNLIKELY(lastm != 0)) {     // the class's last entry (once per class): its slot is free
-          W::each([&](int l) {
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-              const bool me = j * 64 + l == slot;
-              scls[j].at(l) = me ? kFastFree : scls[j].at(l); tok[j].at(l) = me ? 0u : tok[j].at(l);
-            }
-          });
-        }
       }
       n_ref += (unsigned long long)((uint32_t)a + 1u);
       // ---- refresh: CanAdd (nodeclaim.go:124-242) of the claim as it stands now, for the classes of all slots (lane = slot):
