@@ -299,6 +299,17 @@ KS_FN bool fast_fields_ok(uint64_t m, uint64_t dmask) {
   const uint64_t g = (dmask << 1) & ~dmask;
   return (((m & dmask) + dmask) & g) == g;
 }
+// the smaller of two wave-uniform values, in scalar registers (left to itself the compiler builds v_min3_u32 out of three of these:
+// two moves into vector registers, the minimum, a readfirstlane back)
+KS_FN uint32_t fast_umin_s(uint32_t a, uint32_t b) {
+#if KS_DEVICE
+  uint32_t r;
+  asm("s_min_u32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
+  return r;
+#else
+  return a < b ? a : b;
+#endif
+}
 KS_FN bool fast_sampled(int n, int p) {   // choosePivot's nine positions (pdq_emul.h sort()); n >= 50
   const unsigned q = (unsigned)n >> 2, u = (unsigned)p;
   return u - (q - 1) <= 2u || u - (2 * q - 1) <= 2u || u - (3 * q - 1) <= 2u;
@@ -1531,7 +1542,7 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       const int p = (int)rr + l;
       const uint32_t pc = (uint32_t)p < (uint32_t)nm1 ? (uint32_t)p : (uint32_t)nm1;   // clamped (cursors are positions: p >= 0, and n >= 1 here): no lane is switched off for the reads (a cursor at the end of the order: no lane is valid)
       const uint32_t kk = okey[pc];
-      xv.at(l) = oord[pc]; kv.at(l) = p < n ? kk : 0xFFFFFFFFu;
+      xv.at(l) = oord[pc]; kv.at(l) = kk;   // (lanes past the order's end repeat its last entry: the window's validity mask, one scalar value per step, takes them out of the select and of the move)
     });
   };
   // the records of the claims the order read brought (state and acceptance word of the class's row), one lane each
@@ -1589,9 +1600,10 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       // ---- select: the claims at the 64 positions, one lane each: the whole record (state and acceptance words) ----
       const uint64_t slbit = slbitA;
       const int rws = row;
+      uint64_t vm = 0;                                      // the positions of the window that exist
       auto select = [&]() {
-        const int rem = n - (int)rc0;                       // positions of the window that exist (a cursor at the end of the order: none)
-        const uint64_t vm = rem >= 64 ? ~0ull : ((1ull << (rem < 0 ? 0 : rem)) - 1ull);
+        const int rem = n - (int)rc0;                       // (a cursor at the end of the order: none)
+        vm = rem >= 64 ? ~0ull : ((1ull << (rem < 0 ? 0 : rem)) - 1ull);
         return W::ballot([&](int l) { return (awv.at(l) & slbit) != 0; }) & vm;
       };
       uint64_t okm = select();
@@ -1682,13 +1694,13 @@ KS_COLD int fast_hot_run(FastHotCtx<GS, R> cx) {
       ns.req[0] = n0v.bcast(first_ok); ns.req[1] = n1v.bcast(first_ok); ns.req[2] = n2v.bcast(first_ok); ns.req[3] = n3v.bcast(first_ok);
       // ---- the move of the next add's sort.Slice (scheduler.go:598), decided from the counts the order read brought ----
       const uint32_t mvn = cnt + 1;
-      const uint64_t lessm = W::ballot([&](int l) { return kv.at(l) < mvn; });   // lanes past n hold 0xFFFFFFFF; the lanes up to first_ok are shifted out
+      const uint64_t lessm = W::ballot([&](int l) { return kv.at(l) < mvn; }) & vm;   // (the lanes up to first_ok are shifted out)
       const uint64_t tsh = (lessm >> 1) >> first_ok;                             // (two shifts: first_ok may be 63)
       const int sm = ctz64(~tsh);                                                // < 64: the top bit of tsh is clear
       bad |= first_ok + 1 + sm >= 64 ? ~0ull : 0ull;   // the move reaches the window's last lane or beyond (the pending path), or no claim of the window accepts (first_ok = 63) — a window over the order's tail whose claim lands on lane 63 goes the long way too: rare, exact
       {
         const uint32_t d1 = (uint32_t)a - e1, d2 = (uint32_t)a - e2, d3 = (uint32_t)a - e3;
-        const uint32_t dmin = d1 < d2 ? (d1 < d3 ? d1 : d3) : (d2 < d3 ? d2 : d3);
+        const uint32_t dmin = fast_umin_s(fast_umin_s(d1, d2), d3);
         bad |= ((sm != 0) & (inexact_b | (dmin <= 2u))) ? ~0ull : 0ull;   // pdqsort's other paths
       }
       if (KS_UNLIKELY(bad != 0)) { bfx = bi; continue; }   // (out through the loop's own test: one exit)
