@@ -388,15 +388,15 @@ def test_full_size_digest(pin):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     from make_fullsize_digests import build_problem
     g = json.load(open(pin))
-    if g["pods"] > 2_000_000 and g["config"] == "config3" and os.environ.get("KSOLVE_TEST_HUGE_PINS") != "1":
-        pytest.skip("a pin of this size on the general engine takes minutes of GPU time: KSOLVE_TEST_HUGE_PINS=1, or tests/tools/whole_batch_c3.py")
+    if g["pods"] > 2_000_000 and os.environ.get("KSOLVE_TEST_HUGE_PINS") != "1":
+        pytest.skip("a pin of this size takes minutes of GPU time (the general engine) or of host time for the digest of its Results: KSOLVE_TEST_HUGE_PINS=1, or tests/tools/gpu_check_pin.py")
     prob = build_problem(g["config"], g["pods"], g["types"], g["seed"], g["extra"])
     # cursor-wide: the cursor engine with the claims' state in HBM (the plan the library moves to when the LDS plan runs out of claims) —
     # every load of a claim another lane stored has to come from L2, not a stale L1 line: the digest of a million placements says so
     # cursor-hbm: the claim order in HBM too (plan 2, above ~15,000 claims: the 10M-pod configs[3] batch as ONE problem runs there)
     cursor_shape = g["config"] in ("config1", "config2", "config4")
     engines = ["auto"] + (["general"] if g["config"] != "config3" and g["pods"] <= 250000 else []) + (["cursor-wide", "cursor-hbm"] if cursor_shape and g["pods"] <= 1_000_000 else [])
-    if cursor_shape and 1_000_000 < g["pods"] <= 2_000_000:
+    if cursor_shape and g["pods"] > 1_000_000:
         engines.append("cursor-hbm")   # beyond the LDS plan "auto" IS the plan with the claims' state in HBM (cursor-wide); the order in HBM too is the other one
     for eng in engines:
         s = NewScheduler(dict(prob, options=dict(prob["options"], engine=eng)))
