@@ -62,6 +62,23 @@ def test_baseline_shapes_run_on_the_cursor_engine(oracle, emu):
         assert got["counters"]["slowSorts"] == general["counters"]["slowSorts"]   # pdqsort left its single-move path equally often
 
 
+def test_the_x16_pin_at_one_million_pods_on_the_emulation(emu):
+    """The oracle's offline pin of the exact configs[3] shape (1M pods x 1000 types x 16 NodePools as ONE Solve(): 2,767 NodeClaims, 160
+    pod classes live at once — four rows of class slots, clustered by compatibility, rows a claim cannot meet skipped) reproduced by the
+    device algorithm without a GPU: digest, NodeClaim count and reference evaluation count, on the plan `auto` picks (claim records
+    outside LDS). The GPU tests and bench.py hold the device against the same file."""
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_fullsize_digests import build_problem
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize", "config4_p1000000_t1000_s42_x16.json")))
+    r = NewScheduler(build_problem(g["config"], g["pods"], g["types"], g["seed"], g["extra"]), solver_lib=emu).Solve()
+    assert r["counters"]["engine"] == "cursor" and r["counters"]["cursorMemoryPlan"] == 1
+    assert len(r["newNodeClaims"]) == g["claims"] and r["counters"]["referenceBinEvaluations"] == g["binEvaluations"]
+    assert parity.results_digest(r)[0] == g["digest"]
+
+
 def lite_problem(rng, n_pods):
     """Random provisioning batches of the shape the cursor engine solves: In selectors on arch / os / zone / capacity type and
     a custom NodePool label, taints + tolerations, weighted pools, instance types whose allocatable vectors do not dominate
