@@ -616,6 +616,14 @@ static char* error_json(const char* kind, const std::string& msg) {
 }
 
 extern "C" void ksched_free(char* p) { free(p); }
+// parse + write of one document (tests hold the library's JSON reader / writer against an independent implementation with it)
+extern "C" char* ksched_json_roundtrip(const char* doc) {
+  try {
+    return dup_json(kj::Parser(doc).parse());
+  } catch (const std::exception& e) {
+    return error_json("parse", e.what());
+  }
+}
 struct Session;
 extern "C" uint32_t ksched_assignment(void* session, int32_t* assign, uint32_t* slot, uint32_t capacity);
 extern "C" uint32_t ksched_pods_by_claim(void* session, uint32_t n_claims, uint32_t* claim_off, uint32_t* pods, uint32_t capacity);

@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY. Never linked into or called by the product path.
 // Minimal JSON value + parser + writer used by the CPU oracle to read problem files and emit results.
 #pragma once
+#include <cerrno>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -82,18 +83,31 @@ class Parser {
     }
   }
   void expect(const char* lit) { for (; *lit; ++lit, ++p_) if (*p_ != *lit) fail("literal"); }
+  static bool digit(char c) { return c >= '0' && c <= '9'; }
+  // RFC 8259 number: -? (0 | [1-9][0-9]*) (\.[0-9]+)? ([eE][+-]?[0-9]+)? — an integer that does not fit 64 bits becomes a double
   Value number() {
     const char* s = p_;
     bool isint = true;
     if (*p_ == '-') ++p_;
-    while ((*p_ >= '0' && *p_ <= '9') || *p_ == '.' || *p_ == 'e' || *p_ == 'E' || *p_ == '+' || *p_ == '-') {
-      if (*p_ == '.' || *p_ == 'e' || *p_ == 'E') isint = false;
-      ++p_;
-    }
-    if (p_ == s) fail("number");
+    if (*p_ == '0') ++p_;
+    else if (*p_ >= '1' && *p_ <= '9') { while (digit(*p_)) ++p_; }
+    else fail("number");
+    if (*p_ == '.') { isint = false; ++p_; if (!digit(*p_)) fail("number"); while (digit(*p_)) ++p_; }
+    if (*p_ == 'e' || *p_ == 'E') { isint = false; ++p_; if (*p_ == '+' || *p_ == '-') ++p_; if (!digit(*p_)) fail("number"); while (digit(*p_)) ++p_; }
     std::string t(s, p_);
-    if (isint) { Value v = Value::integer(strtoll(t.c_str(), nullptr, 10)); v.num = strtod(t.c_str(), nullptr); return v; }
+    if (isint) {
+      errno = 0;
+      const long long iv = strtoll(t.c_str(), nullptr, 10);
+      if (errno != ERANGE) { Value v = Value::integer(iv); v.num = strtod(t.c_str(), nullptr); return v; }
+    }
     return Value::number(strtod(t.c_str(), nullptr));
+  }
+  static int hexv(char c) { return c >= '0' && c <= '9' ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : -1; }
+  unsigned hex4() {   // p_ at the 'u' of an escape; leaves it at the last of the four digits
+    unsigned cp = 0;
+    for (int k = 1; k <= 4; ++k) { const int h = hexv(p_[k]); if (h < 0) fail("\\u escape"); cp = cp * 16 + (unsigned)h; }
+    p_ += 4;
+    return cp;
   }
   std::string str() {
     ++p_;
@@ -104,16 +118,23 @@ class Parser {
         switch (*p_) {
           case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break;
           case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+          case '"': case '\\': case '/': out += *p_; break;
           case 'u': {
-            unsigned cp = 0;
-            for (int k = 1; k <= 4; ++k) { char c = p_[k]; cp = cp * 16 + (c <= '9' ? c - '0' : (c | 32) - 'a' + 10); }
-            p_ += 4;
+            unsigned cp = hex4();
+            if (cp >= 0xD800 && cp <= 0xDBFF && p_[1] == '\\' && p_[2] == 'u') {   // a surrogate pair: ONE code point beyond the BMP (found by tests/test_json_parsers.py: the pair used to come out as two three-byte sequences, which is not UTF-8)
+              const char* save = p_;
+              p_ += 2;
+              const unsigned lo = hex4();
+              if (lo >= 0xDC00 && lo <= 0xDFFF) cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+              else p_ = save;
+            }
             if (cp < 0x80) out += (char)cp;
             else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
-            else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+            else if (cp < 0x10000) { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+            else { out += (char)(0xF0 | (cp >> 18)); out += (char)(0x80 | ((cp >> 12) & 0x3F)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
             break;
           }
-          default: out += *p_;
+          default: fail("escape");
         }
         ++p_;
       } else out += *p_++;

@@ -83,6 +83,16 @@ extern "C" {
 
 void oracle_free(char* p) { free(p); }
 
+// parse + write of one document: lets a test hold this parser against an independent one (Python's json) — the product's host
+// library carries a copy of the same parser, so a parse bug would otherwise be common to checker and product
+char* oracle_json_roundtrip(const char* doc) {
+  try {
+    return dup_out(oj::Parser(doc).parse());
+  } catch (const std::exception& e) {
+    return err_out(e.what());
+  }
+}
+
 // Full Solve(): problem JSON -> results JSON.
 struct ProbeVerdict { bool want = false, multi_node = false; const std::vector<size_t>* candidates = nullptr; };   // candidates: state-node positions, in the caller's order
 static oj::Value solve_doc(const Problem& pr, const std::vector<Pod>* probe_pods = nullptr, const std::vector<char>* removed = nullptr, const ProbeVerdict* verdict = nullptr);
