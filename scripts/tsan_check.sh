@@ -1,6 +1,6 @@
 #!/bin/bash
 # ThreadSanitizer over the paths that use more than one host thread: ksolve_solve_batch (prepass / finish of the handles on a
-# thread pool) and ksolve_cancel raised while a solve runs. Host flattener + host emulation of the engine, built into /tmp.
+# thread pool), ksolve_cancel raised while a solve runs, a sweep (host threads for descriptors / verdicts) and ksolve_sweep_replicas. Host flattener + host emulation of the engine, built into /tmp.
 set -e
 cd "$(dirname "$0")/.."
 TSAN=$(ls /usr/lib/gcc/x86_64-linux-gnu/*/libtsan.so | head -1)
@@ -10,6 +10,7 @@ g++ -O1 -g -fsanitize=thread -fno-omit-frame-pointer -std=c++17 -fPIC -shared -p
 g++ -O1 -g -fsanitize=thread -fno-omit-frame-pointer -std=c++17 -fPIC -shared -o /tmp/tsan/libksched.so karpenter_amd/host/ksched.cpp -ldl
 cat > /tmp/tsan/run.py <<'PY'
 import os, sys, threading, time
+os.environ["KSOLVE_TEST_SOLVER_LIB"] = "1"   # solver_lib is a test switch (karpenter_amd/scheduling.py)
 sys.path.insert(0, os.getcwd())
 import karpenter_amd.scheduling as ks
 ks.KSCHED_LIB = "/tmp/tsan/libksched.so"
@@ -25,6 +26,16 @@ out = {}
 th = threading.Thread(target=lambda: out.update(r=scheds[0].Solve()))
 th.start(); time.sleep(0.01); scheds[0].Cancel(); th.join()
 print("cancel: timedOut =", out["r"]["timedOut"])
+# a sweep: probe descriptors / validation / verdicts on a few host threads, then the same sweep dealt out over three handles
+# ("devices" of the emulation; also what several handles of ONE device do), each share on a host thread of its own
+from karpenter_amd import disruption as dz
+cc = dz.make_resident_cluster(n_nodes=1500, seed=9)
+reps = [NewScheduler(dz.compact_problem(dict(cc, options={"device": d}), pods=[]), solver_lib=emu) for d in range(3)]
+order = dz.compact_candidates(cc)[:1200]
+cands = [[i] for i in order] + [order[:k] for k in range(2, 20)]
+one = reps[0].Sweep(cands, multi_node=True)
+many = reps[0].Sweep(cands, multi_node=True, replicas=reps[1:])
+print("sweep: equal =", one["decisions"] == many["decisions"], "probes", len(cands), "devices", many["timings"]["devices"])
 PY
 LD_PRELOAD="$TSAN $STD" TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" python /tmp/tsan/run.py > /tmp/tsan/log 2>&1 || true
 tail -2 /tmp/tsan/log
