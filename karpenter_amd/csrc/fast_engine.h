@@ -508,20 +508,22 @@ struct FastCold {
     return (int)h;
   }
 
-  // Returns 0 when the problem is of the shape this engine solves, a reason code otherwise.
-  KS_COLD int setup() {
+  // Returns 0 when the problem is of the shape this engine solves, a reason code otherwise. topo: on behalf of the spread engine
+  // (topo_engine.h) — topology groups are its business, and the dictionary keys they spread over are variable keys too.
+  KS_COLD int setup(bool topo = false) {
     const ProblemView& P = *Pk; const Workspace& S = *Sk; const FastWork& F = *Fk;
     const Dict& d = P.dict;
     const int nk = d.n_keys, iw = P.it_words, nr = P.n_res, n_its = P.n_its, nc = P.n_classes, T = P.n_templates;
     const ProblemView& Pv = P;
-    if (!P.plain || P.n_rows != P.n_pods || nr > 4 || T > 32 || iw > kMaxItWords) return 1;
+    if (!(topo ? P.plain_topo : P.plain) || P.n_rows != P.n_pods || nr > 4 || T > 32 || iw > kMaxItWords) return 1;
     // (instance types may use any operator: with positive sets on the claim side the NotIn / DoesNotExist escape of
     // requirements.go:260-265 never applies, so compatible() stays monotone)
     // templates: only In sets
     if (W::reduce_or(T, [&](int t) { return (uint64_t)(Pv.tmpl_reqs.complement[t] | (Pv.tmpl_reqs.has_gte ? Pv.tmpl_reqs.has_gte[t] : 0) | (Pv.tmpl_reqs.has_lte ? Pv.tmpl_reqs.has_lte[t] : 0)); })) return 3;
     // classes: only In sets; the keys they define are the variable keys
     if (W::reduce_or(nc, [&](int c) { return (uint64_t)Pv.cls_reqs.complement[c]; })) return 4;
-    const uint32_t vk = (uint32_t)W::reduce_or(nc, [&](int c) { return (uint64_t)Pv.cls_reqs.defined[c]; });
+    uint32_t vk = (uint32_t)W::reduce_or(nc, [&](int c) { return (uint64_t)Pv.cls_reqs.defined[c]; });
+    if (topo) vk |= (uint32_t)W::reduce_or(P.topo.n_groups, [&](int g) { return Pv.topo.key[g] >= 0 ? (uint64_t)1 << Pv.topo.key[g] : (uint64_t)0; });
     if (d.key_hostname >= 0 && ((vk >> d.key_hostname) & 1u)) return 5;
     if (d.key_it >= 0 && ((vk >> d.key_it) & 1u)) return 5;
     int bits = 0;

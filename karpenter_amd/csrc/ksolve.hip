@@ -652,6 +652,14 @@ __global__ void __launch_bounds__(256) ksolve_pack_fast2(const ks::FastArgs* a) 
   eng.solve();
   if (threadIdx.x == 0) ks::mail_store(&hs->mail.quit, 1u);
 }
+// The spread engine (topo_engine.h): the cursor engine's shape plus topology spread / pod affinity on dictionary keys and spread /
+// anti-affinity on the hostname — BASELINE configs[2]. One wavefront; claims in HBM (32 B each), the order's rings in HBM, the
+// caches, the ring tables and the topology counters in LDS.
+__global__ void __launch_bounds__(64) ksolve_pack_topo(const ks::TopoArgs* a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  ks::TopoEngine<ks::Wave> eng(&a->pv, &a->ws, &a->fw, &a->tw, lds);
+  eng.solve();
+}
 // Batched form: block b runs the cursor engine (LDS plan) on problem b.
 __global__ void __launch_bounds__(64) ksolve_pack_fast_batch(const ks::FastArgs* const* items) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -803,6 +811,14 @@ static void be_launch_pack_fast(ksolve_handle* h) {
   hipLaunchKernelGGL(fn, dim3(1), dim3(two ? 256 : 64), (size_t)lds_bytes, HB(h)->stream, (const ks::FastArgs*)h->d_fast_args);
   hip_check(h, hipGetLastError(), "ksolve_pack_fast launch");
 }
+static void be_launch_pack_topo(ksolve_handle* h) {
+  const int lds_bytes = h->tw.plan.total_bytes;
+  if (!hip_check(h, hipFuncSetAttribute((const void*)ksolve_pack_topo, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)")) return;
+  ks::TopoArgs a{h->pv, h->ws, h->fw, h->tw};
+  be_h2d(h, h->d_topo_args, &a, sizeof(a));
+  hipLaunchKernelGGL(ksolve_pack_topo, dim3(1), dim3(64), (size_t)lds_bytes, HB(h)->stream, (const ks::TopoArgs*)h->d_topo_args);
+  hip_check(h, hipGetLastError(), "ksolve_pack_topo launch");
+}
 static void be_launch_pack_fast_batch(ksolve_handle** hs, int n) {
   if (n <= 0) return;
   ksolve_handle* h0 = hs[0];
@@ -847,7 +863,7 @@ static void be_launch_fast_queue(ksolve_handle* h) {
   hipLaunchKernelGGL(ksolve_fast_queue, grid_for(n), dim3(256), 0, HB(h)->stream, n, fast_queue_args(h));
   hip_check(h, hipGetLastError(), "ksolve_fast_queue launch");
   const int nc = (int)h->n_classes;
-  if (nc > 64 && nc <= 32768) {
+  if (h->fw.enabled && nc > 64 && nc <= 32768) {   // (the spread engine has no class slots to count)
     hipLaunchKernelGGL(ksolve_fast_overlap, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, HB(h)->stream, nc, fast_queue_args(h));
     hip_check(h, hipGetLastError(), "ksolve_fast_overlap launch");
   }

@@ -18,6 +18,7 @@
 #include "engine.h"
 #include "kernels.h"
 #include "fast_engine.h"
+#include "topo_engine.h"
 
 // Backend contract (provided by the including TU):
 //   void* be_alloc(ksolve_handle*, size_t bytes)  — zero-initialised device memory owned by the handle
@@ -76,6 +77,8 @@ struct ksolve_handle {
   ks::FastWork fw{};            // cursor engine (fast_engine.h): workspace + LDS plan; fw.enabled while the problem may qualify
   uint32_t engine_used = 0, fast_reason = 0, fast_attempts = 0;
   ks::FastArgs* d_fast_args = nullptr;   // the record ksolve_pack_fast reads its problem from
+  ks::TopoWork tw{};            // spread engine (topo_engine.h): workspace + LDS plan; tw.enabled while the problem may qualify (it borrows fw's buffers)
+  ks::TopoArgs* d_topo_args = nullptr;
   // probes of a resident cluster (ksolve_probe_create): a probe handle shares the base's device tables
   ksolve_handle* base = nullptr;         // non-null: this handle is a probe of `base`
   bool prepared = false;                 // base: phases 1-3 have run and h_rank is valid
@@ -124,6 +127,7 @@ static void be_launch_class_gather(ksolve_handle* h, int n, const ks::RowArgs& a
 static void be_sort_pods(ksolve_handle* h);  // fills ws/pv.sorted_pods
 static void be_launch_pack(ksolve_handle* h);
 static void be_launch_pack_fast(ksolve_handle* h);                 // one wavefront: FastEngine::solve
+static void be_launch_pack_topo(ksolve_handle* h);                 // one wavefront: TopoEngine::solve
 static void be_launch_pack_fast_batch(ksolve_handle** hs, int n);   // block b = the cursor engine on problem b; sets every handle's T_PACK timer
 static void be_launch_fast_records(ksolve_handle* h, int n_claims); // one wavefront per claim: fast_record_body; then fast_scatter_body per queue entry
 static void be_launch_fast_queue(ksolve_handle* h);                // one thread per queue entry: fast_queue_body
@@ -393,6 +397,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
   const bool strict_same = d->pod_strict_reqs.mask == d->pod_reqs.mask || d->pod_strict_reqs.mask == nullptr;
   const bool rows_nil = all_nil(d->pod_reqs) && (strict_same || all_nil(d->pod_strict_reqs));
   R.reqs = upload_reqs(h, d->pod_reqs, d->n_pod_rows, req_words, d->n_keys, !rows_nil);
+  P.strict_same = strict_same ? 1 : 0;
   if (strict_same) R.strict = R.reqs;
   else R.strict = upload_reqs(h, d->pod_strict_reqs, d->n_pod_rows, req_words, d->n_keys, !rows_nil);
   R.tolerates = up(h, d->pod_tolerates, d->n_pod_rows);
@@ -675,6 +680,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     const bool bounds = any_nonzero(d->pod_reqs.has_gte, d->n_pod_rows) || any_nonzero(d->pod_reqs.has_lte, d->n_pod_rows) ||
                         any_nonzero(d->tmpl_reqs.has_gte, d->n_templates) || any_nonzero(d->tmpl_reqs.has_lte, d->n_templates);
     P.plain = (d->topo.n == 0 && d->n_nodes == 0 && !d->tmpl_daemon_first && !any_minv && !P.reserved_on && !bounds && !d->n_override_groups && !P.hp_on && !P.vol_on) ? 1 : 0;
+    P.plain_topo = (d->n_nodes == 0 && !d->tmpl_daemon_first && !any_minv && !P.reserved_on && !bounds && !d->n_override_groups && !P.hp_on && !P.vol_on) ? 1 : 0;
     P.lite = (P.plain && req_words <= 64 && it_words <= 8 && d->n_res <= 4) ? 1 : 0;
 #ifdef KSOLVE_NO_LITE
     P.lite = 0;   // A/B builds only
@@ -697,6 +703,36 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       fw.q_class = dz<uint32_t>(h, d->n_pods); fw.q_claim = dz<uint32_t>(h, d->n_pods); fw.q_cnt = dz<uint32_t>(h, d->n_pods);
       { const size_t oc = std::min<size_t>(65472, ((size_t)mc + 63) & ~(size_t)63) + 64; fw.o_key = dz<uint16_t>(h, oc); fw.o_ord = dz<uint16_t>(h, oc); fw.o_snap = dz<uint16_t>(h, oc); }
       h->d_fast_args = dz<ks::FastArgs>(h, 1);
+    }
+    // spread engine (topo_engine.h): candidate when the problem is plain but for its topology groups and has no relaxation rows; the
+    // kernel checks the rest (which kinds of groups, positive operators, ...) and hands the problem back otherwise. It runs on the
+    // cursor engine's tables (requirement-set cache, class records, queue-order arrays) and on the BIG engine's claim order (run_order.h).
+    ks::TopoWork& tw = h->tw;
+    tw.enabled = (!fw.enabled && P.plain_topo && d->topo.n > 0 && d->topo.n <= (uint32_t)ks::kTopoMaxGroups && d->n_res <= 4 && (h->opts.engine == 0 || h->opts.engine == 6) &&
+                  d->n_pod_rows == d->n_pods && d->n_pods > 0 && !d->pod_node) ? 1 : 0;
+    if (tw.enabled) {
+      fw.var = dz<ks::FastVar>(h, 1);
+      fw.c_hostseq = dz<uint32_t>(h, mc); fw.c_ent = dz<uint16_t>(h, mc);
+      fw.c_state = dz<ks::FastClaim>(h, mc); fw.c_npods = dz<uint32_t>(h, mc);
+      fw.c_rec = nullptr; fw.max_active = dz<uint32_t>(h, 1);
+      fw.ent_its = dz<uint64_t>(h, (size_t)ks::kFastEnt * it_words);
+      fw.q_class = dz<uint32_t>(h, d->n_pods); fw.q_claim = dz<uint32_t>(h, d->n_pods); fw.q_cnt = dz<uint32_t>(h, d->n_pods);
+      fw.o_key = nullptr; fw.o_ord = nullptr; fw.o_snap = nullptr;
+      tw.rec = dz<ks::TopoRec>(h, mc);
+      auto align = [](int x) { return (x + 15) & ~15; };
+      ks::FastPlan& fp = fw.plan;
+      int off = 0;
+      fp.rows = 1; fp.helper = 0; fp.global_state = 2; fp.cap = 0;
+      fp.off_ent = off; off = align(off + ks::kFastEnt * (int)sizeof(ks::FastEnt));
+      fp.off_pool = off; off = align(off + ks::kFastPool * 16);
+      fp.off_slot = off; off = align(off + 64 * (int)sizeof(ks::FastSlot));
+      fp.off_misc = off; off = align(off + (int)sizeof(ks::FastMisc));
+      fp.off_hot = off; off = align(off + (int)sizeof(ks::FastHot));
+      fp.off_state = fp.off_key = fp.off_ord = fp.off_snap = off;
+      tw.plan.off_run = off; off = align(off + (int)sizeof(ks::RunTables));
+      tw.plan.off_state = off; off = align(off + (int)sizeof(ks::TopoState));
+      tw.plan.total_bytes = off; fp.total_bytes = off;
+      h->d_topo_args = dz<ks::TopoArgs>(h, 1);
     }
   }
   be_sync(h);
@@ -815,7 +851,8 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
     R.cls_topo = h->has_topology ? dz<uint64_t>(h, (size_t)n_classes * 2 * R.topo_words) : nullptr;
     R.lay = P.lay;
     h->ws.dead = dz<uint64_t>(h, (size_t)n_classes * h->claim_words);
-    if (h->fw.enabled) { h->fw.cls = dz<ks::FastSlot>(h, n_classes); h->fw.cls_first = dz<uint32_t>(h, n_classes); h->fw.cls_last = dz<uint32_t>(h, n_classes); }
+    if (h->fw.enabled || h->tw.enabled) { h->fw.cls = dz<ks::FastSlot>(h, n_classes); h->fw.cls_first = dz<uint32_t>(h, n_classes); h->fw.cls_last = dz<uint32_t>(h, n_classes); }
+    if (h->tw.enabled) h->tw.cls = dz<ks::TopoClass>(h, n_classes);
     if (h->n_nodes) h->ws.n_dead = dz<uint64_t>(h, (size_t)n_classes * P.node_words);
   }
   if (n_classes > 0) {
@@ -847,6 +884,11 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
     h->fast_live = live;
     const int rows = live <= 64 ? 1 : ks::kFastRows;
     if (rows != h->fw.plan.rows) fast_plan_set(h, h->fw.plan.global_state, rows);
+  }
+  if (h->tw.enabled && n_pods && n_classes) {
+    // the spread engine reads the queue's classes in queue order too (no class slots: the overlap count is not needed)
+    be_fill(h, h->fw.cls_first, 0xFF, (size_t)n_classes * 4); be_fill(h, h->fw.cls_last, 0, (size_t)n_classes * 4); be_fill(h, h->fw.max_active, 0, 4);
+    be_launch_fast_queue(h);
   }
   be_toc(h, T_SORT);
 
@@ -1879,8 +1921,37 @@ static ksolve_status solve(ksolve_handle* h, ksolve_results* out, bool fresh_con
   if (h->base) { ksolve_status st = KSOLVE_OK; solve_probes(&h, 1, out, &st, fresh_context); return st; }
   ksolve_status st = solve_prepare(h, fresh_context);
   if (st != KSOLVE_OK) return st;
-  if (h->opts.engine >= 2 && !(h->fw.enabled && !h->pv.big && h->n_pods && h->n_classes))
+  if (h->opts.engine == 6 && !(h->tw.enabled && h->n_pods && h->n_classes))
+    return fail(h, KSOLVE_ERR_UNSUPPORTED, "spread engine requested for a problem outside its shape (no topology groups / existing nodes / minValues / reservations / relaxation rows)");
+  if (h->opts.engine >= 2 && h->opts.engine != 6 && !(h->fw.enabled && !h->pv.big && h->n_pods && h->n_classes))
     return fail(h, KSOLVE_ERR_UNSUPPORTED, "cursor engine requested for a problem outside its shape (topology / existing nodes / minValues / reservations / relaxation rows)");
+  if (h->tw.enabled && h->n_pods && h->n_classes) {
+    // the spread engine first; status 3 = "not my shape / stopped before any result": the general engine takes over
+    alloc_run_order(h);
+    be_tic(h, T_PACK);
+    be_launch_pack_topo(h);
+    be_toc(h, T_PACK);
+    int status = 0, n_claims = 0;
+    be_d2h(h, &status, h->ws.status_out, 4);
+    be_d2h(h, &n_claims, h->ws.n_claims_out, 4);
+    be_sync(h);
+    if (be_ok(h) && status != 3 && status != 1) {
+      h->engine_used = 3;
+      h->fast_reason = 0; h->fast_attempts = 1;
+      if (n_claims) be_launch_fast_records(h, n_claims);
+      return solve_finish(h, out);
+    }
+    if (be_ok(h) && status == 3) {
+      ks::Counters ctr{};
+      be_d2h(h, &ctr, h->ws.counters, sizeof(ctr));
+      be_sync(h);
+      h->fast_reason = (uint32_t)ctr.cycles[20];
+    } else if (be_ok(h)) h->fast_reason = 100;
+    if (h->opts.engine == 6) return fail(h, KSOLVE_ERR_UNSUPPORTED, "spread engine declined the problem (reason " + std::to_string(h->fast_reason) + ")");
+    if (h->fast_reason != 27 && h->fast_reason != 100) h->tw.enabled = 0;   // not its shape: later solves of this handle go straight to the general engine
+    st = solve_prepare(h, false);
+    if (st != KSOLVE_OK) return st;
+  }
   if (h->fw.enabled && !h->pv.big && h->n_pods && h->n_classes) {
     // the cursor engine first; status 3 = "not my shape / stopped before any result": the general engine takes over — unless all
     // that stopped it was the number of claims its LDS plan holds (reason 26): then once more with the claims' state in HBM

@@ -223,6 +223,8 @@ struct ProblemView {
   TopoView topo;
   int big;                       // more in-flight claims than the LDS order holds: Engine<W, true, true> (order in HBM)
   int plain;                     // no topology groups, existing nodes, daemon overhead, minValues, reservations or bounds (any size)
+  int strict_same;               // PodData.StrictRequirements == Requirements for every pod row (no preferred terms): one table uploaded, two gathered
+  int plain_topo;                // the same, but for topology groups: what the spread engine (topo_engine.h) looks at
   int lite;                      // plain and small enough for the register tables:, existing nodes, daemon overhead, minValues or reservations: Engine<W, false>
 };
 

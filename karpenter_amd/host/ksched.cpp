@@ -1955,7 +1955,7 @@ extern "C" void* ksched_open(const char* problem_json, const char* solver_lib) {
     ko.truncate_instance_types = (uint32_t)opts.at("truncateInstanceTypes").i(0);
     ko.reserved_capacity = opts.at("reservedCapacity").boolean_or(false) ? 1 : 0;
     ko.reserved_offering_strict = opts.at("reservedOfferingMode").s("Fallback") == "Strict" ? 1 : 0;
-    { const std::string eng = opts.at("engine").s("auto"); ko.engine = eng == "general" ? 1u : eng == "cursor" ? 2u : eng == "cursor-wide" ? 3u : eng == "cursor-hbm" ? 4u : eng == "cursor-pair" ? 5u : 0u; }
+    { const std::string eng = opts.at("engine").s("auto"); ko.engine = eng == "general" ? 1u : eng == "cursor" ? 2u : eng == "cursor-wide" ? 3u : eng == "cursor-hbm" ? 4u : eng == "cursor-pair" ? 5u : eng == "spread" ? 6u : 0u; }
 
     trace("ksolve_create");
     ksolve_status st = api.create(&d, &ko, &handle);
@@ -2552,7 +2552,7 @@ static char* results_json(Session* S, ksolve_results& res, ksolve_status st, int
     counters.set("pops", Value::integer((int64_t)res.queue_pops)); counters.set("sorts", Value::integer((int64_t)res.sorts));
     counters.set("slowSorts", Value::integer((int64_t)res.slow_sorts)); counters.set("relaxations", Value::integer((int64_t)res.relaxations));
     counters.set("pods", Value::integer(own->base ? own->probe_pods : n_pods)); counters.set("claims", Value::integer(cl.n_claims));
-    counters.set("engine", Value::string(res.engine_used == 2 ? "cursor" : "general")); counters.set("cursorClaimStateInHBM", Value::boolean(res.engine_used == 2 && res.cursor_wide != 0)); counters.set("cursorMemoryPlan", Value::integer(res.engine_used == 2 ? (int64_t)res.cursor_wide : -1)); counters.set("cursorAttempts", Value::integer((int64_t)res.cursor_attempts)); counters.set("engineFallbackReason", Value::integer((int64_t)res.engine_fallback_reason));
+    counters.set("engine", Value::string(res.engine_used == 2 ? "cursor" : res.engine_used == 3 ? "spread" : "general")); counters.set("cursorClaimStateInHBM", Value::boolean(res.engine_used == 2 && res.cursor_wide != 0)); counters.set("cursorMemoryPlan", Value::integer(res.engine_used == 2 ? (int64_t)res.cursor_wide : -1)); counters.set("cursorAttempts", Value::integer((int64_t)res.cursor_attempts)); counters.set("engineFallbackReason", Value::integer((int64_t)res.engine_fallback_reason));
     counters.set("rows", Value::integer(n_rows)); counters.set("instanceTypes", Value::integer(n_its)); counters.set("strictTableShared", Value::boolean(S->strict_shared));
     counters.set("topologyGroups", Value::integer(S->n_topo_groups)); counters.set("topologyAliasClasses", Value::integer(S->n_alias_classes));
     counters.set("reqWords", Value::integer(rw)); counters.set("itWords", Value::integer(it_words)); counters.set("keys", Value::integer(nk)); counters.set("resources", Value::integer(n_res));

@@ -126,6 +126,14 @@ static void be_launch_pack_fast(ksolve_handle* h) {
     else { ks::FastEngine<ks::Wave, 0, ks::kFastRows> eng(&a_->pv, &a_->ws, &a_->fw, lds.data()); eng.solve(); }
   }
 }
+static void be_launch_pack_topo(ksolve_handle* h) {
+  std::vector<char> lds((size_t)h->tw.plan.total_bytes + 64, (char)0xA5);   // garbage, like the device's LDS at kernel start
+  ks::TopoArgs a{h->pv, h->ws, h->fw, h->tw};
+  be_h2d(h, h->d_topo_args, &a, sizeof(a));
+  const ks::TopoArgs* a_ = h->d_topo_args;
+  ks::TopoEngine<ks::Wave> eng(&a_->pv, &a_->ws, &a_->fw, &a_->tw, lds.data());
+  eng.solve();
+}
 static ks::FastQueueArgs fast_queue_args(ksolve_handle* h) {
   return ks::FastQueueArgs{h->pv.sorted_pods, h->pv.row_class, h->fw.q_class, h->fw.q_claim, h->fw.q_cnt, h->ws.assign, h->ws.slot, h->fw.cls_first, h->fw.cls_last, h->fw.max_active};
 }
@@ -139,7 +147,7 @@ static void be_launch_fast_queue(ksolve_handle* h) {
   const ks::FastQueueArgs q = fast_queue_args(h);
   for (int i = 0; i < (int)h->n_pods; ++i) ks::fast_queue_body(i, q);
   const int nc = (int)h->n_classes;
-  if (nc > 64 && nc <= 32768) for (int c = 0; c < nc; ++c) ks::fast_overlap_body(c, nc, q);
+  if (h->fw.enabled && nc > 64 && nc <= 32768) for (int c = 0; c < nc; ++c) ks::fast_overlap_body(c, nc, q);
   for (int i = 0; i < (int)h->n_pods; ++i) ks::fast_mark_body(i, q);
 }
 static void be_launch_pack_fast_batch(ksolve_handle** hs, int n) {

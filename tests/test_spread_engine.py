@@ -1,0 +1,222 @@
+"""The spread engine (csrc/topo_engine.h; BASELINE configs[2]: the reference benchmark's own mix of zonal / hostname topology spread,
+zonal pod affinity and hostname anti-affinity, scheduling_benchmark_test.go:259-455) against the oracle, claim by claim and in the
+reference-equivalent evaluation count. CPU tests run the engine's source compiled for the host (tests/emu, test infrastructure)
+behind the real C ABI and the host flattener; the `-m gpu` tests at the bottom run the same cases on the device library."""
+import random
+
+import pytest
+
+import parity
+from karpenter_amd import fixtures as fx
+from karpenter_amd.scheduling import NewScheduler, Unsupported, device_available
+from test_device_algorithm import emu  # noqa: F401  (fixture)
+
+
+def solve(prob, engine, lib):
+    s = NewScheduler(dict(prob, options=dict(prob.get("options", {}), engine=engine)), solver_lib=lib)
+    try:
+        return s.Solve()
+    finally:
+        s.close()
+
+
+def same(got, want):
+    parity.assert_same_results(got, want)
+    assert got["counters"]["referenceBinEvaluations"] == want["counters"]["binEvaluations"]   # V
+    assert abs(got["packingCost"] - want["packingCost"]) < 1e-9 * max(1.0, want["packingCost"])
+
+
+def check_spread(oracle, lib, prob):
+    """engine=spread must solve it (no fallback) and equal the oracle; so must auto (which has to pick it) and the general engine."""
+    want = oracle.solve(prob)
+    got = solve(prob, "spread", lib)
+    assert got["counters"]["engine"] == "spread", got["counters"]
+    same(got, want)
+    auto = solve(prob, "auto", lib)
+    assert auto["counters"]["engine"] == "spread", auto["counters"]
+    same(auto, want)
+    same(solve(prob, "general", lib), want)
+    return got, want
+
+
+@pytest.mark.parametrize("pods,types,seed", [(300, 144, 1), (1500, 144, 5), (4000, 500, 42), (2500, 60, 9)])
+def test_the_benchmark_mix(oracle, emu, pods, types, seed):
+    got, want = check_spread(oracle, emu, fx.config3(pods=pods, n_types=types, seed=seed))
+    assert not got["podErrors"] and len(got["newNodeClaims"]) == pods // 5   # every anti-affinity pod a NodeClaim of its own
+
+
+def test_few_anti_affinity_pods_many_claims_without_one(oracle, emu):
+    # the list of claims that hold no member of the anti-affinity group is the normal case here, not the exception; with a small
+    # catalogue the claims fill up and the scan goes past the first window
+    prob = fx.config3(pods=3000, n_types=20, seed=11, anti_affinity_pods=40)
+    got, _ = check_spread(oracle, emu, prob)
+    assert len(got["newNodeClaims"]) > 40
+
+
+def mix(rng, n, zones=("test-zone-1", "test-zone-2", "test-zone-3"), letters="abc", kinds=range(8), big=False, filters=False):
+    labels = [{"my-label": c} for c in letters]
+    cpus = [100, 250, 500, 1000, 1500] if not big else [1000, 2000, 4000]
+    res = lambda: {"cpu": f"{rng.choice(cpus)}m", "memory": f"{rng.choice([100, 256, 512, 1024])}Mi"}
+    pods = []
+    for _ in range(n):
+        kind = rng.choice(list(kinds))
+        lab, sel = rng.choice(labels), rng.choice(labels)
+        kw = dict(labels=lab, requests=res())
+        if kind == 0:
+            kw["topology_spread"] = [fx.spread(fx.ZONE, sel, max_skew=rng.choice([1, 1, 2, 3]))]
+        elif kind == 1:
+            kw["topology_spread"] = [fx.spread(fx.HOSTNAME, sel, max_skew=rng.choice([1, 1, 2]))]
+        elif kind == 2:
+            kw["pod_requirements"] = [fx.affinity_term(fx.ZONE, lab if rng.random() < 0.8 else sel)]
+        elif kind == 3:
+            kw["pod_anti_requirements"] = [fx.affinity_term(fx.HOSTNAME, lab if rng.random() < 0.7 else sel)]
+        elif kind == 4:
+            kw["topology_spread"] = [fx.spread(fx.ZONE, sel), fx.spread(fx.HOSTNAME, sel, max_skew=2)]
+        elif kind == 5:
+            kw["node_selector"] = {fx.ZONE: rng.choice(zones)}
+            if filters and rng.random() < 0.5:
+                kw["topology_spread"] = [fx.spread(fx.CAPACITY_TYPE, sel)]
+        elif kind == 6:
+            kw["node_selector"] = {fx.CAPACITY_TYPE: rng.choice(["spot", "on-demand"])}
+            if filters:
+                kw["topology_spread"] = [fx.spread(fx.ZONE, sel, max_skew=rng.choice([1, 2]))]
+        elif kind == 7 and not filters:
+            kw["topology_spread"] = [fx.spread(fx.CAPACITY_TYPE, sel)]
+        pods.append(fx.pod(**kw))
+    return pods
+
+
+def fuzz_problem(seed):
+    rng = random.Random(7000 + seed)
+    kwok = seed % 2 == 0
+    zones = tuple(fx.KWOK_ZONES[:3]) if kwok else ("test-zone-1", "test-zone-2", "test-zone-3")
+    pods = mix(rng, rng.randrange(30, 160), zones=zones, big=seed % 4 == 3, filters=seed % 8 == 7)
+    pools = [fx.node_pool()]
+    if seed % 3 == 1:
+        pools = [fx.node_pool("a", requirements=[fx.req(fx.ZONE, "In", *zones[:2])], weight=10), fx.node_pool("b")]
+    if seed % 5 == 2:
+        pools = [fx.node_pool("few", limits={"cpu": "20"}, weight=5), fx.node_pool("rest")]
+    if kwok:
+        for np_ in pools:
+            np_["nodeClassLabelKey"] = "karpenter.kwok.sh/kwoknodeclass"
+        return fx.problem(fx.kwok_catalog(24), pools, pods, well_known=fx.KWOK_WELL_KNOWN)
+    return fx.problem(fx.fake_instance_types(12), pools, pods)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_spread_fuzz(oracle, emu, seed):
+    """Random mixes inside the engine's shape, on small catalogues so that constraints interact: shared selectors across kinds,
+    pods pinned to zones / capacity types, several NodePools with different zones, claims that fill up. Whatever `auto` runs must
+    equal the oracle; where the spread engine ran to the end (no unschedulable pod) it is held to the oracle by itself."""
+    prob = fuzz_problem(seed)
+    want = oracle.solve(prob)
+    auto = solve(prob, "auto", emu)
+    same(auto, want)
+    if auto["counters"]["engine"] == "spread":
+        got = solve(prob, "spread", emu)
+        assert got["counters"]["engine"] == "spread"
+        same(got, want)
+    else:
+        # outside the shape (a pod with a nodeSelector AND a spread constraint: its groups carry a node filter), an unschedulable pod,
+        # a NodePool limit that excludes a type: the general engine, and asking for the spread engine alone is refused
+        assert auto["counters"]["engine"] == "general" and auto["counters"]["engineFallbackReason"] != 0, auto["counters"]
+        with pytest.raises(Unsupported):
+            solve(prob, "spread", emu)
+
+
+def test_fuzz_really_runs_the_spread_engine(oracle, emu):
+    ran = 0
+    for seed in range(12):
+        rng = random.Random(9100 + seed)
+        prob = fx.problem(fx.fake_instance_types(12), [fx.node_pool()], mix(rng, 80, kinds=[0, 1, 2, 3, 7, 7]))
+        r = solve(prob, "auto", emu)
+        same(r, oracle.solve(prob))
+        ran += r["counters"]["engine"] == "spread"
+    assert ran >= 8, ran
+
+
+def test_kwok_catalogue_with_selectors_and_taints(oracle, emu):
+    # BASELINE configs[1]'s selectors and the tainted NodePool, plus configs[2]'s constraints on a third of the pods
+    rng = random.Random(5)
+    base = fx.config2(pods=1200, n_types=144, seed=3)
+    pods = fx.expand_pod_groups(base)["pods"]
+    for i, p in enumerate(pods):
+        lab = {"my-label": "abc"[i % 3]}
+        p["labels"] = lab
+        r = rng.random()
+        if r < 0.15:
+            p["topologySpreadConstraints"] = [fx.spread(fx.ZONE, lab)]
+        elif r < 0.3:
+            p["topologySpreadConstraints"] = [fx.spread(fx.HOSTNAME, lab, max_skew=2)]
+        elif r < 0.35:
+            p["podAntiAffinity"] = {"required": [fx.affinity_term(fx.HOSTNAME, {"my-label": "a"})], "preferred": []}
+    prob = dict(base, pods=pods, podGroups=[])
+    want = oracle.solve(prob)
+    auto = solve(prob, "auto", emu)
+    same(auto, want)
+
+
+@pytest.mark.parametrize("case", ["min_domains", "hostname_affinity", "zonal_anti_affinity", "preference", "two_zonal_groups", "node_affinity_filter", "skew_7"])
+def test_outside_its_shape_it_declines_loudly(oracle, emu, case):
+    lab = {"app": "x"}
+    kw = {"min_domains": dict(topology_spread=[fx.spread(fx.ZONE, lab, min_domains=2)]),
+          "hostname_affinity": dict(pod_requirements=[fx.affinity_term(fx.HOSTNAME, lab)]),
+          "zonal_anti_affinity": dict(pod_anti_requirements=[fx.affinity_term(fx.ZONE, lab)]),
+          "preference": dict(pod_preferences=[fx.weighted(10, fx.affinity_term(fx.ZONE, lab))]),
+          "two_zonal_groups": dict(topology_spread=[fx.spread(fx.ZONE, lab), fx.spread(fx.CAPACITY_TYPE, lab)]),
+          "node_affinity_filter": dict(topology_spread=[fx.spread(fx.ZONE, lab)], node_selector={fx.ZONE: "test-zone-1"}),
+          "skew_7": dict(topology_spread=[fx.spread(fx.HOSTNAME, lab, max_skew=7)])}[case]
+    pods = [fx.pod(labels=lab, requests={"cpu": "500m"}, **kw) for _ in range(6)]
+    prob = fx.problem(fx.fake_instance_types(12), [fx.node_pool()], pods)
+    with pytest.raises(Unsupported):
+        solve(prob, "spread", emu)
+    auto = solve(prob, "auto", emu)
+    assert auto["counters"]["engine"] == "general"
+    same(auto, oracle.solve(prob))
+
+
+def test_an_unschedulable_pod_hands_the_problem_to_the_general_engine(oracle, emu):
+    lab = {"app": "x"}
+    pods = [fx.pod(labels=lab, requests={"cpu": "500m"}, topology_spread=[fx.spread(fx.ZONE, lab)]) for _ in range(5)]
+    pods.append(fx.pod(labels=lab, requests={"cpu": "100000"}, topology_spread=[fx.spread(fx.HOSTNAME, lab)]))
+    prob = fx.problem(fx.fake_instance_types(12), [fx.node_pool()], pods)
+    auto = solve(prob, "auto", emu)
+    assert auto["counters"]["engine"] == "general" and auto["counters"]["engineFallbackReason"] == 27 and len(auto["podErrors"]) == 1
+    same(auto, oracle.solve(prob))
+
+
+def test_repeated_solves_and_a_step_limit(oracle, emu):
+    prob = fx.config3(pods=2000, n_types=144, seed=8)
+    s = NewScheduler(dict(prob, options=dict(prob["options"], engine="spread")), solver_lib=emu)
+    a, b = s.Solve(), s.Solve()
+    s.close()
+    assert parity.results_digest(a)[0] == parity.results_digest(b)[0]
+    same(a, oracle.solve(prob))
+    # the ctx deadline stand-in (scheduler.go:477-480): the pods placed so far are the results, the rest is not an error of theirs
+    lim = solve(dict(prob, options=dict(prob["options"], maxSteps=700)), "spread", emu)
+    assert lim["counters"]["engine"] == "spread" and lim["scheduledPods"] == 700
+
+
+# ---- the same on the device ------------------------------------------------------------------------------------------------
+gpu = pytest.mark.gpu
+
+
+@gpu
+@pytest.mark.parametrize("pods,types,seed", [(1500, 144, 5), (20000, 500, 42)])
+def test_the_benchmark_mix_on_the_device(oracle, pods, types, seed):
+    assert device_available()
+    check_spread(oracle, None, fx.config3(pods=pods, n_types=types, seed=seed))
+
+
+@gpu
+def test_spread_fuzz_on_the_device(oracle):
+    assert device_available()
+    ran = 0
+    for seed in range(24):
+        prob = fuzz_problem(seed)
+        r = solve(prob, "auto", None)
+        same(r, oracle.solve(prob))
+        ran += r["counters"]["engine"] == "spread"
+    assert ran >= 8, ran
+    prob = fx.config3(pods=3000, n_types=20, seed=11, anti_affinity_pods=40)
+    check_spread(oracle, None, prob)

@@ -12,6 +12,6 @@ eng = sys.argv[2] if len(sys.argv) > 2 else "auto"
 prob = build_problem(g["config"], g["pods"], g["types"], g["seed"], g["extra"])
 t = time.time(); s = NewScheduler(dict(prob, options=dict(prob["options"], engine=eng))); r = s.Solve(); s.close(); dt = time.time() - t
 digest, _ = parity.results_digest(r)
-print(json.dumps({"pin": os.path.basename(sys.argv[1]), "engine": eng, "engine_used": r["counters"]["engine"], "plan": r["counters"].get("cursorMemoryPlan"), "seconds": round(dt, 2),
+print(json.dumps({"pin": os.path.basename(sys.argv[1]), "engine": eng, "engine_used": r["counters"]["engine"], "plan": r["counters"].get("cursorMemoryPlan"), "seconds": round(dt, 2), "pack_kernel_ms": r["timings"][0].get("pack_kernel_ms"), "fallback_reason": r["counters"].get("engineFallbackReason"),
                   "claims": [len(r["newNodeClaims"]), g["claims"]], "digest_matches": digest == g["digest"],
                   "reference_bin_evaluations_match": r["counters"]["referenceBinEvaluations"] == g["binEvaluations"]}))
