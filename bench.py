@@ -31,7 +31,7 @@ def source_sha():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "karpenter_amd", "csrc")
-    for f in sorted(os.listdir(d)) + ["../../include/ksolve.h"]:
+    for f in sorted(f for f in os.listdir(d) if os.path.isfile(os.path.join(d, f))) + ["../../include/ksolve.h"]:
         with open(os.path.join(d, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
@@ -232,7 +232,7 @@ def sweep_rooflines(tm, n_probes):
     """The two kernels of the consolidation path that fill the chip, with the bytes their algorithm has to move:
     ksolve_pack_sweep — per displaced pod its class record and outputs, per 4096-node step of an existing-node scan 512 B of
     the class's rejection row, per node / NodeClaim actually evaluated its record; ksolve_node_dead0 — the node tables once,
-    one bit per (class, node) out. `traffic` = measured HBM bytes of the same kernels (profiles/round5/pmc_traffic.json, when
+    one bit per (class, node) out. `traffic` = measured HBM bytes of the same kernels (profiles/round6/pmc_traffic.json, when
     it was taken on this build)."""
     rw, nr, iw = tm.get("req_words", 0), tm.get("resources", 0), tm.get("it_words", 0)
     if not rw:
@@ -245,7 +245,7 @@ def sweep_rooflines(tm, n_probes):
     alg = tm["pods"] * (b_cls + b_out) + tm["node_block_steps"] * 512 + tm["node_evaluations"] * b_node + claim_evals * 2 * b_claim
     pmc = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "round5", "pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "round6", "pmc_traffic.json")) as f:
             doc = json.load(f)
         if doc.get("source_sha") == source_sha():
             pmc = doc.get("sweep_kernels", {})
@@ -684,15 +684,17 @@ def main():
     # separate passes, --kernel-trace only; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes) on this workload and
     # written to profiles/round3/pmc_traffic.json together with a hash of the kernel sources. A figure is used only for the build
     # it was measured on: after any change of the sources it reads null until the script has run again.
-    traffic, stream_traffic, traffic_note, sq = None, None, "not measured for this build (scripts/gpu_r5_pmc.sh)", None
+    traffic, stream_traffic, traffic_note, sq, pmc_doc = None, None, "not measured for this build (scripts/gpu_r6_pmc.sh)", None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "round5", "pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "round6", "pmc_traffic.json")) as f:
             pmc = json.load(f)
         if pmc.get("source_sha") == source_sha() and pmc.get("pods") == args.pods and pmc.get("types") == args.types:
-            traffic = pmc["kernels"].get(kernel, {}).get("traffic_bytes_per_launch")
+            pk = next((n for n in sorted(pmc["kernels"]) if n.startswith(kernel)), kernel)   # ksolve_pack_fast_g<plan>r<rows>: one kernel per memory plan and row count
+            traffic = pmc["kernels"].get(pk, {}).get("traffic_bytes_per_launch")
             stream_traffic = pmc["kernels"].get("ksolve_row_hash_coop2", {}).get("traffic_bytes_per_launch")
-            traffic_note = "TCC FETCH_SIZE x2 + WRITE_SIZE per launch, rocprofv3 --pmc on this build (profiles/round5/pmc_traffic.json)"
-            k = pmc["kernels"].get(kernel, {})
+            traffic_note = "TCC FETCH_SIZE x2 + WRITE_SIZE per launch, rocprofv3 --pmc on this build (profiles/round6/pmc_traffic.json)"
+            k = pmc["kernels"].get(pk, {})
+            pmc_doc = pmc
             if "SQ_INSTS_VALU" in k:
                 per = lambda name: k[name]["per_launch"] / args.pods if name in k else None
                 sq = {"waves": k.get("SQ_WAVES", {}).get("per_launch"), "valu_per_pod": per("SQ_INSTS_VALU"), "salu_per_pod": per("SQ_INSTS_SALU"), "lds_per_pod": per("SQ_INSTS_LDS"),
@@ -736,11 +738,19 @@ def main():
                      "achieved_from_traffic": (stream_traffic / (rh_ms * 1e-3) / 1e9) if (stream_traffic and rh_ms > 0) else None,
                      "frac_from_traffic": (stream_traffic / (rh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (stream_traffic and rh_ms > 0) else None,
                      "mask_tables": 1 if c.get("strictTableShared") else 2,
+                     # ... and beside the streaming kernel, the kernel the step's time goes to (round-5 review: the record the driver
+                     # keeps must show both): its share of the step, what it moves, and SURVEY §8(d)'s notional bytes over its time
+                     "dominant": {"kernel": kernel, "share_of_step_time": pack_ms / ms_per_step if ms_per_step else None, "avg_kernel_ms": pack_ms, "bound": "latency / instruction issue of ONE wavefront (1 of the chip's 1,024 SIMDs)",
+                                  "waves": (sq or {}).get("waves", 1), "traffic": traffic,
+                                  "frac_notional_survey_sizes": (c["pods"] * 188 + c["referenceBinEvaluations"] * 248 + c["pods"] * 248 + c["instanceTypes"] * c.get("templates", 1) * 185) / (pack_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pack_ms else None,
+                                  "frac_notional_layout_sizes": achieved / HBM_PEAK_GBS,
+                                  "note": "notional = the bytes SURVEY §8(d) charges the REFERENCE's scan for the same answer (V = its bin evaluations) over this kernel's time; "
+                                          "the kernel itself moves `traffic` bytes per launch: it is not an HBM-bound kernel and claims no HBM roofline"},
                      "note": "numerator = the bytes this kernel reads and writes per row (not the whole B_pod row of DESIGN.md §3: 245 B with its bookkeeping words); "
                              "the table of the headline problem (220 MB) is smaller than the 256 MiB Infinity Cache — profiles/round4/classing_rows.json has the same kernel at 2M and 4M rows"},
         # The pack kernel is a serial first-fit chain on ONE wavefront: bound by the instruction issue and the dependent LDS round
         # trips of a lone wave, not by HBM — no roofline is claimed for it. `achieved` is what it really moves.
-        # sq_counters: instructions and wave cycles per pod of THIS build's pack kernel (rocprofv3 --pmc SQ_*, profiles/round5/pmc_traffic.json),
+        # sq_counters: instructions and wave cycles per pod of THIS build's pack kernel (rocprofv3 --pmc SQ_*, profiles/round6/pmc_traffic.json),
         # null when the sources changed since they were measured.
         "pack_kernel": {"kernel": kernel, "bound": "latency / instruction issue of one wavefront", "avg_kernel_ms": pack_ms, "us_per_pod": pack_ms * 1e3 / max(1, args.pods), "sq_counters": sq, "traffic": traffic, "traffic_source": traffic_note,
                         "achieved": (traffic / (pack_ms * 1e-3) / 1e9) if traffic else None, "unit": "GB/s",
@@ -783,6 +793,24 @@ def main():
                 best = dt if best is None else min(best, dt)
             e = {"pods": pods, "seconds": best, "value": r3["scheduledPods"] / best, "unit": "pods/s", "node_claims": r3["counters"]["claims"],
                  "pack_kernel_ms": r3["timings"][0]["pack_kernel_ms"], "engine": r3["counters"].get("engine"), "oracle_pin": None, "invariants": None}
+            # the leg's dominant kernel: the spread engine (csrc/topo_engine.h, one wavefront) — bound by the instruction issue and the
+            # dependent round trips of a lone wavefront like every pack kernel here; `reference_equivalent` = SURVEY §8(d)'s bytes for
+            # the bins the REFERENCE evaluates (2.0e10 at 1M pods: every anti-affinity pod walks every claim) over the kernel's time
+            c3 = dict(r3["counters"]); c3["templates"] = len(p3["nodePools"])
+            ab3, rec3 = algorithmic_bytes(c3)
+            pk_ms = e["pack_kernel_ms"]
+            kname = {"spread": "ksolve_pack_topo", "general": "ksolve_pack_big" if c3["claims"] > 8192 else "ksolve_pack"}.get(e["engine"], "?")
+            sq3 = None
+            if pmc_doc is not None and pods == args.topology_pods and kname in pmc_doc.get("topology_kernels", {}):
+                k3 = pmc_doc["topology_kernels"][kname]
+                per3 = lambda name: k3[name]["per_launch"] / pods if name in k3 else None
+                sq3 = {"waves": k3.get("SQ_WAVES", {}).get("per_launch"), "valu_per_pod": per3("SQ_INSTS_VALU"), "salu_per_pod": per3("SQ_INSTS_SALU"), "lds_per_pod": per3("SQ_INSTS_LDS"),
+                       "vmem_per_pod": (per3("SQ_INSTS_VMEM_RD") or 0) + (per3("SQ_INSTS_VMEM_WR") or 0) if per3("SQ_INSTS_VMEM_RD") is not None else None,
+                       "wave_cycles_per_pod": 4 * per3("SQ_WAVE_CYCLES") if per3("SQ_WAVE_CYCLES") else None, "wait_cycles_per_pod": 4 * per3("SQ_WAIT_ANY") if per3("SQ_WAIT_ANY") else None,
+                       "traffic_bytes_per_launch": k3.get("traffic_bytes_per_launch"), "note": "SQ_WAVE_CYCLES / SQ_WAIT_ANY count in units of four shader cycles; rocprofv3 --pmc on this build (profiles/round6/pmc_traffic.json)"}
+            e["pack_kernel"] = {"kernel": kname, "bound": "latency / instruction issue of one wavefront", "avg_kernel_ms": pk_ms, "us_per_pod": pk_ms * 1e3 / max(1, pods), "sq_counters": sq3,
+                                "reference_equivalent": {"bytes": ab3, "GBps": ab3 / (pk_ms * 1e-3) / 1e9 if pk_ms else None, "frac_of_hbm_peak": ab3 / (pk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pk_ms else None,
+                                                         "records": rec3, "reference_bin_evaluations": c3["referenceBinEvaluations"]}}
             pin_path = os.path.join(ROOT, "tests", "golden", "fullsize", f"config3_p{pods}_t{args.types}_s42.json")
             full3 = None
             if not args.no_parity_pin:

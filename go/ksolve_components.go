@@ -208,7 +208,12 @@ type componentSelector struct {
 // every topology group the pod can own, as (namespaces, matchLabels); false when a term cannot be evaluated here
 func topologySelectors(p *corev1.Pod) ([]componentSelector, bool) {
 	var out []componentSelector
+	// A group on any key but the hostname draws its domain universe from EVERY NodePool (buildDomainGroups, topology.go:104-142) and
+	// domainMinCount takes the minimum over all of it (topologygroup.go:300-322): its owner cannot be cut off from the other pools.
 	for _, c := range p.Spec.TopologySpreadConstraints {
+		if c.TopologyKey != corev1.LabelHostname {
+			return nil, false
+		}
 		if c.LabelSelector == nil {
 			out = append(out, componentSelector{map[string]bool{p.Namespace: true}, nil})
 			continue
@@ -233,6 +238,9 @@ func topologySelectors(p *corev1.Pod) ([]componentSelector, bool) {
 			}
 		}
 		for _, t := range terms {
+			if t.TopologyKey != corev1.LabelHostname {
+				return nil, false
+			}
 			if t.NamespaceSelector != nil || (t.LabelSelector != nil && len(t.LabelSelector.MatchExpressions) > 0) {
 				return nil, false
 			}

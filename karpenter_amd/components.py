@@ -57,9 +57,11 @@ def _topology_selectors(p):
     NodePool they land on: those pods and the owner must be solved together."""
     out = []
     ns = p.get("namespace", "default")
+    # (a group on any key but the hostname draws its domain universe from EVERY NodePool — buildDomainGroups, topology.go:104-142 —
+    # and domainMinCount takes the minimum over all of it, topologygroup.go:300-322: its owner cannot be cut off from the other pools)
     for c in p.get("topologySpreadConstraints") or []:
         sel = c.get("labelSelector") or {}
-        if sel.get("matchExpressions"):
+        if c.get("topologyKey") != fx.HOSTNAME or sel.get("matchExpressions"):
             return None
         out.append(({ns}, dict(sel.get("matchLabels") or {})))
     for field in ("podAffinity", "podAntiAffinity"):
@@ -67,7 +69,7 @@ def _topology_selectors(p):
         terms = list(aff.get("required") or []) + [w["term"] for w in (aff.get("preferred") or [])]
         for t in terms:
             sel = t.get("labelSelector") or {}
-            if sel.get("matchExpressions") or t.get("namespaceSelector") is not None:
+            if t.get("topologyKey") != fx.HOSTNAME or sel.get("matchExpressions") or t.get("namespaceSelector") is not None:
                 return None
             out.append((set(t.get("namespaces") or [ns]), dict(sel.get("matchLabels") or {})))
     return out

@@ -18,6 +18,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "ksolve_impl.h"
+#include "pack_kernels.h"
 
 struct HipBackend {
   hipStream_t stream = nullptr;
@@ -516,156 +517,11 @@ __global__ void ksolve_finalize(int n, ks::FinalizeArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ks::finalize_body(i, a);
 }
-// One wavefront (64 threads) per problem; the working requirement set and candidate lists live in LDS.
-__global__ void __launch_bounds__(64) ksolve_pack(ks::ProblemView pv, ks::Workspace ws) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  ks::LdsTables tables;
-  tables.bind(lds, pv.lds);
-  if (pv.lds.topo_bytes) tables.topo = lds + pv.lds.off_topo;   // (one problem per launch: the topology groups' descriptors and small state in LDS, engine.h topo_to_lds)
-  ks::Engine<ks::Wave, true> eng(pv, ws, tables);
-  eng.solve();
-}
-// The same engine compiled without topology / existing nodes / daemon overhead / minValues / reservations, for problems
-// that use none of them (ProblemView::lite): less code and far less live state around the hot loop.
-__global__ void __launch_bounds__(64) ksolve_pack_lite(ks::ProblemView pv, ks::Workspace ws) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  ks::LdsTables tables;
-  tables.bind(lds, pv.lds);
-  ks::Engine<ks::Wave, false> eng(pv, ws, tables);
-  eng.solve();
-}
-
-// The full engine with the claim order in HBM, for problems with more in-flight claims than a CU's LDS can order
-// (every anti-affinity / hostname-spread pod is its own NodeClaim): ProblemView::big.
-__global__ void __launch_bounds__(64) ksolve_pack_big(ks::ProblemView pv, ks::Workspace ws) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  ks::LdsTables tables;
-  tables.bind(lds, pv.lds);
-  if (pv.lds.topo_bytes) tables.topo = lds + pv.lds.off_topo;   // (one problem per launch: the topology groups' descriptors and small state in LDS, engine.h topo_to_lds)
-  ks::Engine<ks::Wave, true, true> eng(pv, ws, tables);
-  eng.solve();
-}
-// Batched form: block b solves problem b (its view and workspace are read from HBM instead of the kernel arguments).
-__global__ void __launch_bounds__(64) ksolve_pack_batch(ks::BatchItem* items) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  ks::BatchItem& it = items[blockIdx.x];
-  ks::LdsTables tables;
-  tables.bind(lds, it.pv.lds);
-  ks::Engine<ks::Wave, true> eng(it.pv, it.ws, tables);
-  eng.solve();
-}
-__global__ void __launch_bounds__(64) ksolve_pack_batch_lite(ks::BatchItem* items) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  ks::BatchItem& it = items[blockIdx.x];
-  ks::LdsTables tables;
-  tables.bind(lds, it.pv.lds);
-  ks::Engine<ks::Wave, false> eng(it.pv, it.ws, tables);
-  eng.solve();
-}
-// A consolidation sweep over a resident cluster: block b runs the general engine on probes b, b + gridDim.x, ... — one view of
-// the cluster for all of them (HBM), one workspace per probe (its claims and its node overlay), one LDS plan for the launch.
-__global__ void __launch_bounds__(64) ksolve_pack_sweep(const ks::ProblemView* pv, ks::Workspace* items, int n, ks::LdsPlan plan) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  ks::LdsTables tables;
-  tables.bind(lds, plan);
-  for (int p = (int)blockIdx.x; p < n; p += (int)gridDim.x) {
-    ks::Engine<ks::Wave, true> eng(*pv, items[p], tables);
-    eng.solve();
-  }
-}
-// The compact form of the sweep (LdsPlan::waves = 4): four wavefronts per workgroup, each on its own probes, sharing the read-only
-// instance-type tables and the template records in LDS (wave 0 fills them and runs the template prefilter once, then the
-// workgroup's only barrier); every wavefront keeps a ScratchSmall working set. 256 VGPRs per wavefront (two wavefronts per
-// SIMD): eight probes per CU in flight instead of four — the probes are chains of dependent steps, so a launch goes as fast as
-// the number of them the chip holds at once. Wave w of block b runs probes 4b + w, 4b + w + 4 * gridDim.x, ...
-__global__ void __launch_bounds__(256, 2) ksolve_pack_sweep4(const ks::ProblemView* pv, ks::Workspace* items, int n, ks::LdsPlan plan, const uint32_t* order, uint32_t* next) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  typedef ks::Engine<ks::Wave, true, false, ks::ScratchSmall> Eng;
-  const int wave = (int)(threadIdx.x >> 6);
-  ks::LdsTables tables;
-  tables.bind(lds, plan, wave);
-  uint32_t* misc = (uint32_t*)(lds + plan.off_shared_misc);
-  // The probes are handed out through one counter, in `order` (most displaced pods first): a wavefront that is free takes the next
-  // one. With a fixed share per wavefront the launch lasted as long as its unluckiest wavefront — 2.9 ms where the mean work of
-  // 2048 wavefronts over 10,000 probes is 1.9 ms. Which wavefront runs a probe does not touch its result: probes share nothing
-  // but the read-only cluster.
-  auto fetch = [&]() -> int {
-    unsigned i = 0;
-    if ((threadIdx.x & 63) == 0) i = atomicAdd(next, 1u);
-    i = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
-    return i < (unsigned)n ? (int)order[i] : -1;
-  };
-  int p = -1;
-  if (wave == 0) {
-    p = fetch();
-    if (p >= 0) {
-      Eng eng(*pv, items[p], tables);   // this probe's workspace lends its per-template arrays; the wavefront solves it next
-      const uint32_t active = eng.prepare();
-      if ((threadIdx.x & 63) == 0) misc[0] = active;
-    }
-  }
-  __syncthreads();
-  const uint32_t active = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
-  if (wave != 0) p = fetch();
-  while (p >= 0) {
-    Eng eng(*pv, items[p], tables);
-    eng.solve(&active);
-    p = fetch();
-  }
-}
 // every pod class against every pristine node of a resident cluster (kernels.h node_dead0_body): one wavefront per 64 nodes
 __global__ void __launch_bounds__(64) ksolve_node_dead0(ks::NodeDeadArgs a) { ks::node_dead0_body<ks::Wave>((int)blockIdx.x, a); }
 __global__ void ksolve_claim_gather(int n, ks::ClaimGatherArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ks::claim_gather_body(i, a);
-}
-// The cursor engine (fast_engine.h) for purely positive provisioning batches: one wavefront, O(1) steps. Compiled per memory plan
-// (GS = 0: claim records and order in LDS; 1: records in HBM — problems that need more in-flight claims than a CU's LDS holds
-// beside the caches, the host retries here when the LDS plan ran out of claims; 2: the order arrays in HBM too, up to 65,472
-// in-flight claims — the exact configs[3] batch of 10M pods, 27,345) and per number of class-slot rows (FastPlan::rows).
-template <int GS, int R>
-__global__ void __launch_bounds__(64) ksolve_pack_fast(const ks::FastArgs* a) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  ks::FastEngine<ks::Wave, GS, R> eng(&a->pv, &a->ws, &a->fw, lds);
-  eng.solve();
-}
-// The LDS plan with one row of class slots on TWO wavefronts (FastPlan::helper; fast_engine.h FastMail): wavefront 0 places the
-// pods, another one recomputes the acceptance words of the claim a pod was added to while wavefront 0 is at the next pod. The two must
-// sit on DIFFERENT SIMDs to issue side by side, and where the dispatcher puts a workgroup's wavefronts is its business: the
-// workgroup comes with four, each notes its SIMD (HW_ID bits 5:4), and the first one on another SIMD than wavefront 0's stays as
-// the refresher; the others leave. One barrier, in front of everything: the mailbox is zero when they part.
-__global__ void __launch_bounds__(256) ksolve_pack_fast2(const ks::FastArgs* a) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  KS_LDS ks::FastHot* const hs = (KS_LDS ks::FastHot*)(lds + a->fw.plan.off_hot);
-  const int wave = (int)(threadIdx.x >> 6);
-  if (threadIdx.x == 0) ks::fast_mail_init(&hs->mail);
-  if ((threadIdx.x & 63) == 0) hs->mail.simd[wave] = (uint32_t)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);   // HW_REG_HW_ID, SIMD_ID
-  __syncthreads();
-  if (wave > 0) {
-    int pick = 1;
-    for (int w = 3; w >= 1; --w) if (hs->mail.simd[w] != hs->mail.simd[0]) pick = w;
-    if (wave != __builtin_amdgcn_readfirstlane(pick)) return;
-    ks::fast_helper_run<ks::Wave, 0, 1>(&a->fw, lds);
-    return;
-  }
-  ks::FastEngine<ks::Wave, 0, 1, true> eng(&a->pv, &a->ws, &a->fw, lds);
-  eng.solve();
-  if (threadIdx.x == 0) ks::mail_store(&hs->mail.quit, 1u);
-}
-// The spread engine (topo_engine.h): the cursor engine's shape plus topology spread / pod affinity on dictionary keys and spread /
-// anti-affinity on the hostname — BASELINE configs[2]. One wavefront; claims in HBM (32 B each), the order's rings in HBM, the
-// caches, the ring tables and the topology counters in LDS.
-__global__ void __launch_bounds__(64) ksolve_pack_topo(const ks::TopoArgs* a) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  ks::TopoEngine<ks::Wave> eng(&a->pv, &a->ws, &a->fw, &a->tw, lds);
-  eng.solve();
-}
-// Batched form: block b runs the cursor engine (LDS plan) on problem b.
-__global__ void __launch_bounds__(64) ksolve_pack_fast_batch(const ks::FastArgs* const* items) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const ks::FastArgs* a = items[blockIdx.x];
-  if (a->fw.plan.rows == 1) { ks::FastEngine<ks::Wave, 0, 1> eng(&a->pv, &a->ws, &a->fw, lds); eng.solve(); }
-  else { ks::FastEngine<ks::Wave, 0, ks::kFastRows> eng(&a->pv, &a->ws, &a->fw, lds); eng.solve(); }
 }
 __global__ void ksolve_fast_queue(int n, ks::FastQueueArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -798,8 +654,8 @@ static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, 
 }
 typedef void (*ksolve_pack_fast_fn)(const ks::FastArgs*);
 static ksolve_pack_fast_fn pack_fast_kernel(int plan, int rows) {
-  if (rows == 1) return plan == 2 ? ksolve_pack_fast<2, 1> : plan == 1 ? ksolve_pack_fast<1, 1> : ksolve_pack_fast<0, 1>;
-  return plan == 2 ? ksolve_pack_fast<2, ks::kFastRows> : plan == 1 ? ksolve_pack_fast<1, ks::kFastRows> : ksolve_pack_fast<0, ks::kFastRows>;
+  if (rows == 1) return plan == 2 ? ksolve_pack_fast_g2r1 : plan == 1 ? ksolve_pack_fast_g1r1 : ksolve_pack_fast_g0r1;
+  return plan == 2 ? ksolve_pack_fast_g2r4 : plan == 1 ? ksolve_pack_fast_g1r4 : ksolve_pack_fast_g0r4;
 }
 static void be_launch_pack_fast(ksolve_handle* h) {
   const int lds_bytes = h->fw.plan.total_bytes;

@@ -18,7 +18,7 @@
 #include "engine.h"
 #include "kernels.h"
 #include "fast_engine.h"
-#include "topo_engine.h"
+#include "topo_types.h"
 
 // Backend contract (provided by the including TU):
 //   void* be_alloc(ksolve_handle*, size_t bytes)  — zero-initialised device memory owned by the handle

@@ -1,0 +1,43 @@
+// ksolve_pack_sweep4.hip — the compact consolidation sweep: four wavefronts per workgroup on ScratchSmall.
+#include "pack_kernels.h"
+
+// The compact form of the sweep (LdsPlan::waves = 4): four wavefronts per workgroup, each on its own probes, sharing the read-only
+// instance-type tables and the template records in LDS (wave 0 fills them and runs the template prefilter once, then the
+// workgroup's only barrier); every wavefront keeps a ScratchSmall working set. 256 VGPRs per wavefront (two wavefronts per
+// SIMD): eight probes per CU in flight instead of four — the probes are chains of dependent steps, so a launch goes as fast as
+// the number of them the chip holds at once. Wave w of block b runs probes 4b + w, 4b + w + 4 * gridDim.x, ...
+__global__ void __launch_bounds__(256, 2) ksolve_pack_sweep4(const ks::ProblemView* pv, ks::Workspace* items, int n, ks::LdsPlan plan, const uint32_t* order, uint32_t* next) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef ks::Engine<ks::Wave, true, false, ks::ScratchSmall> Eng;
+  const int wave = (int)(threadIdx.x >> 6);
+  ks::LdsTables tables;
+  tables.bind(lds, plan, wave);
+  uint32_t* misc = (uint32_t*)(lds + plan.off_shared_misc);
+  // The probes are handed out through one counter, in `order` (most displaced pods first): a wavefront that is free takes the next
+  // one. With a fixed share per wavefront the launch lasted as long as its unluckiest wavefront — 2.9 ms where the mean work of
+  // 2048 wavefronts over 10,000 probes is 1.9 ms. Which wavefront runs a probe does not touch its result: probes share nothing
+  // but the read-only cluster.
+  auto fetch = [&]() -> int {
+    unsigned i = 0;
+    if ((threadIdx.x & 63) == 0) i = atomicAdd(next, 1u);
+    i = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
+    return i < (unsigned)n ? (int)order[i] : -1;
+  };
+  int p = -1;
+  if (wave == 0) {
+    p = fetch();
+    if (p >= 0) {
+      Eng eng(*pv, items[p], tables);   // this probe's workspace lends its per-template arrays; the wavefront solves it next
+      const uint32_t active = eng.prepare();
+      if ((threadIdx.x & 63) == 0) misc[0] = active;
+    }
+  }
+  __syncthreads();
+  const uint32_t active = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
+  if (wave != 0) p = fetch();
+  while (p >= 0) {
+    Eng eng(*pv, items[p], tables);
+    eng.solve(&active);
+    p = fetch();
+  }
+}

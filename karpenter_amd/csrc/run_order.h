@@ -22,11 +22,16 @@ namespace ks {
 
 constexpr int kRunMaxCount = 1024;   // counts whose table entries are mirrored in LDS; fuller claims use the HBM tables alone
 
-struct RunTables {   // LDS mirror of the tables' first kRunMaxCount entries
-  uint32_t head[kRunMaxCount];     // ring index of the run's first claim
-  uint32_t size[kRunMaxCount];     // claims in the run
-  uint32_t prefix[kRunMaxCount];   // claims with a smaller count = position of the run's first claim
-  uint32_t off[kRunMaxCount];      // the ring's first word in `ring`
+// LDS mirror of the tables' first kRunMaxCount entries, one 16-byte record per count (the spread engine reads the records of the
+// sixteen lowest runs with ONE ds_read_b128, one lane each: topo_engine.h window())
+struct RunEnt {
+  uint32_t head;     // ring index of the run's first claim
+  uint32_t size;     // claims in the run
+  uint32_t prefix;   // claims with a smaller count = position of the run's first claim
+  uint32_t off;      // the ring's first word in `ring`
+};
+struct RunTables {
+  alignas(16) RunEnt e[kRunMaxCount];
   uint8_t log2cap[kRunMaxCount];   // ring capacity = 1 << log2cap
 };
 
@@ -57,19 +62,19 @@ struct RunOrder {
     ghead = tabs; gsize = tabs + kmax_; gprefix = tabs + 2 * (size_t)kmax_; goff = off_tab; glog = log_tab;
     KS_LDS RunTables* tt = t;
     const int km = kmax_;
-    W::for_n(kRunMaxCount, [&](int k) { tt->head[k] = 0; tt->size[k] = 0; tt->prefix[k] = 0; tt->off[k] = k < km ? off_tab[k] : 0; tt->log2cap[k] = k < km ? log_tab[k] : 0; });
+    W::for_n(kRunMaxCount, [&](int k) { tt->e[k].head = 0; tt->e[k].size = 0; tt->e[k].prefix = 0; tt->e[k].off = k < km ? off_tab[k] : 0; tt->log2cap[k] = k < km ? log_tab[k] : 0; });
     // the HBM tables above the mirror are cleared as the largest count grows (grow_to)
     n = 0; max_cnt = 1; defect = -1; defect_claim = -1; defect_append = false; overflow = false; slow_sorts = 0;
   }
   // table entries: LDS below kRunMaxCount, HBM above
-  KS_FN uint32_t head_(int k) const { return k < kRunMaxCount ? T->head[k] : ghead[k]; }
-  KS_FN uint32_t size_(int k) const { return k < kRunMaxCount ? T->size[k] : gsize[k]; }
-  KS_FN uint32_t prefix_(int k) const { return k < kRunMaxCount ? T->prefix[k] : gprefix[k]; }
-  KS_FN uint32_t off_(int k) const { return k < kRunMaxCount ? T->off[k] : goff[k]; }
+  KS_FN uint32_t head_(int k) const { return k < kRunMaxCount ? T->e[k].head : ghead[k]; }
+  KS_FN uint32_t size_(int k) const { return k < kRunMaxCount ? T->e[k].size : gsize[k]; }
+  KS_FN uint32_t prefix_(int k) const { return k < kRunMaxCount ? T->e[k].prefix : gprefix[k]; }
+  KS_FN uint32_t off_(int k) const { return k < kRunMaxCount ? T->e[k].off : goff[k]; }
   KS_FN uint32_t mask_of(int k) const { return (1u << (k < kRunMaxCount ? T->log2cap[k] : glog[k])) - 1u; }
-  KS_DEV void set_head(int k, uint32_t v) { if (k < kRunMaxCount) W::store(&T->head[k], v); else W::store(&ghead[k], v); }
-  KS_DEV void set_size(int k, uint32_t v) { if (k < kRunMaxCount) W::store(&T->size[k], v); else W::store(&gsize[k], v); }
-  KS_DEV void set_prefix(int k, uint32_t v) { if (k < kRunMaxCount) W::store(&T->prefix[k], v); else W::store(&gprefix[k], v); }
+  KS_DEV void set_head(int k, uint32_t v) { if (k < kRunMaxCount) W::store(&T->e[k].head, v); else W::store(&ghead[k], v); }
+  KS_DEV void set_size(int k, uint32_t v) { if (k < kRunMaxCount) W::store(&T->e[k].size, v); else W::store(&gsize[k], v); }
+  KS_DEV void set_prefix(int k, uint32_t v) { if (k < kRunMaxCount) W::store(&T->e[k].prefix, v); else W::store(&gprefix[k], v); }
   // a claim reaches count k for the first time: run k and the prefix behind it start out empty / "every claim"
   KS_DEV void grow_to(int k, uint32_t claims_before_next) {
     if (k <= max_cnt) return;
@@ -133,23 +138,30 @@ struct RunOrder {
   // the single stable move of pdqsort's partialInsertionSort / insertionSort on "sorted except one element"
   KS_DEV void apply_move() {
     const int x = defect_claim;
-    if (defect_append) {
-      // behind the last claim with at most one pod: the end of run 1; every later run starts one position further right
-      const uint32_t m = mask_of(1), s = (head_(1) + size_(1)) & m;
-      W::store(&ring[off_(1) + s], (uint32_t)x);
-      W::store(&slot[x], s);
-      set_size(1, size_(1) + 1);
-      KS_LDS RunTables* tt = T;
-      uint32_t* gp = gprefix;
-      const int top = max_cnt + 1;   // prefix is kept for counts 1 .. max_cnt + 1
-      W::for_n(top - 1, [&](int i) { const int k = i + 2; if (k < kRunMaxCount) tt->prefix[k] += 1; else gp[k] += 1; });
-      return;
-    }
+    if (defect_append) { move_appended(x); return; }
     const int k = (int)W::uniform((uint64_t)cnt[x]);
+    if (k + 2 >= kmax) { overflow = true; return; }
+    const uint32_t i = (uint32_t)W::uniform((uint64_t)((slot[x] - head_(k)) & mask_of(k)));   // index inside the run
+    move_known(x, k, i);
+  }
+  // a new claim (count 1, at the end of the array): behind the last claim with at most one pod — the end of run 1; every later run
+  // starts one position further right
+  KS_DEV void move_appended(int x) {
+    const uint32_t m = mask_of(1), s = (head_(1) + size_(1)) & m;
+    W::store(&ring[off_(1) + s], (uint32_t)x);
+    W::store(&slot[x], s);
+    set_size(1, size_(1) + 1);
+    KS_LDS RunTables* tt = T;
+    uint32_t* gp = gprefix;
+    const int top = max_cnt + 1;   // prefix is kept for counts 1 .. max_cnt + 1
+    W::for_n(top - 1, [&](int i) { const int k = i + 2; if (k < kRunMaxCount) tt->e[k].prefix += 1; else gp[k] += 1; });
+  }
+  // claim x, the i-th of run k, has gained a pod: it leaves its run and becomes the first claim of run k + 1 (callers that know k and
+  // i — the spread engine has both from its scan — skip the two dependent loads of apply_move)
+  KS_DEV void move_known(int x, int k, uint32_t i) {
     if (k + 2 >= kmax) { overflow = true; return; }
     grow_to(k + 1, (uint32_t)n);
     const uint32_t m = mask_of(k), h = head_(k), sz = size_(k);
-    const uint32_t i = (uint32_t)W::uniform((uint64_t)((slot[x] - h) & m));   // index inside the run
     uint32_t new_head = h;
     if (i == 0) new_head = (h + 1) & m;
     else if (i + 1 < sz) {
@@ -164,6 +176,13 @@ struct RunOrder {
     const uint32_t s1 = size_(k + 1), p1 = prefix_(k + 1);
     set_head(k, new_head); set_size(k, sz - 1); set_head(k + 1, h1); set_size(k + 1, s1 + 1); set_prefix(k + 1, p1 - 1);
     W::sync();
+  }
+  // would sort() repair a defect at position p with ONE stable move (pdqsort's insertion sort / partialInsertionSort path)?
+  KS_FN bool single_move(int p) const {
+    if (n <= 12) return true;
+    if (n < 50) return false;
+    const int q = n / 4;
+    return !((p >= q - 1 && p <= q + 1) || (p >= 2 * q - 1 && p <= 2 * q + 1) || (p >= 3 * q - 1 && p <= 3 * q + 1));
   }
   // array form: key[p] / ord[p] for every position, the touched claim still where it was (with its new count)
   KS_DEV void materialize() {
@@ -193,19 +212,19 @@ struct RunOrder {
       const int k = k1 + 1;
       int lo = 0, hi = nn;
       while (lo < hi) { const int mid = lo + (hi - lo) / 2; if (kk[mid] < (uint32_t)k) lo = mid + 1; else hi = mid; }
-      if (k < kRunMaxCount) { tt->prefix[k] = (uint32_t)lo; tt->head[k] = 0; } else { gp[k] = (uint32_t)lo; gh[k] = 0; }
+      if (k < kRunMaxCount) { tt->e[k].prefix = (uint32_t)lo; tt->e[k].head = 0; } else { gp[k] = (uint32_t)lo; gh[k] = 0; }
     });
     W::for_n(mx, [&](int k1) {
       const int k = k1 + 1;
-      const uint32_t a = k < kRunMaxCount ? tt->prefix[k] : gp[k], b = k + 1 < kRunMaxCount ? tt->prefix[k + 1] : gp[k + 1];
-      if (k < kRunMaxCount) tt->size[k] = b - a; else gs[k] = b - a;
+      const uint32_t a = k < kRunMaxCount ? tt->e[k].prefix : gp[k], b = k + 1 < kRunMaxCount ? tt->e[k + 1].prefix : gp[k + 1];
+      if (k < kRunMaxCount) tt->e[k].size = b - a; else gs[k] = b - a;
     });
     max_cnt = mx;
     uint32_t* rr = ring; uint32_t* cc = cnt; uint32_t* ss = slot;
     const uint32_t* go = goff;
     W::for_n(nn, [&](int p) {
       const uint32_t k = kk[p], x = oo[p];
-      const uint32_t p0 = k < (uint32_t)kRunMaxCount ? tt->prefix[k] : gp[k], o = k < (uint32_t)kRunMaxCount ? tt->off[k] : go[k];
+      const uint32_t p0 = k < (uint32_t)kRunMaxCount ? tt->e[k].prefix : gp[k], o = k < (uint32_t)kRunMaxCount ? tt->e[k].off : go[k];
       const uint32_t s = (uint32_t)p - p0;
       rr[o + s] = x; cc[x] = k; ss[x] = s;
     });

@@ -29,43 +29,9 @@
 #pragma once
 #include "fast_engine.h"
 #include "run_order.h"
+#include "topo_types.h"
 
 namespace ks {
-
-constexpr int kTopoMaxGroups = 128;   // topology groups of a problem this engine takes
-constexpr int kTopoMaxHost = 16;      // of them on kubernetes.io/hostname (regular + inverse): one 4-bit field each
-constexpr int kTopoMaxZg = 64;        // ... and on dictionary keys
-constexpr int kTopoMaxDom = 16;       // domains of such a key
-constexpr int kTopoTrack = 4;         // anti-affinity counters with a list of the claims that hold no member
-constexpr int kTopoFreeCap = 1024;    // entries of such a list (more: the list is dropped, its classes scan the order)
-constexpr uint64_t kTopoGuard = 0x8888888888888888ull, kTopoOnes = 0x1111111111111111ull;
-
-struct TopoRec { uint64_t vmask; int32_t req[4]; uint64_t hcnt; };   // 32 B: an in-flight claim (requirement set, requests, hostname-group counters)
-// a pod class's topology: limits on the hostname counters it is tested against (field = 8 | limit; 8 | 7 where it has none),
-// the counters and dictionary-key groups a pod of the class is counted by, the dictionary-key group it owns
-struct TopoClass { uint64_t hlim, hinc, zsel; int32_t zg; uint32_t zself; uint32_t excl; uint32_t pad; };   // 48 B
-struct TopoZg {   // a group on a dictionary key (LDS)
-  int32_t cnt[kTopoMaxDom];
-  uint16_t rank[kTopoMaxDom];
-  uint32_t dom;        // registered domains (TopologyGroup.domains)
-  int32_t nonzero;     // domains with a positive count
-  int32_t skew;
-  uint8_t type, var, p0, p1;   // 0 spread / 1 affinity; index of its key among the variable keys (FastMisc::vkey)
-};
-struct TopoState {   // LDS
-  TopoZg zg[kTopoMaxZg];
-  uint32_t freel[kTopoTrack][kTopoFreeCap];
-  int32_t n_free[kTopoTrack];
-  uint32_t track_field[kTopoTrack];   // hostname counter of list t; 0xFF: none / dropped
-  int16_t gmap[kTopoMaxGroups];       // group -> hostname counter (0..15) | 0x100 + dictionary-key group | -1
-  uint64_t zkey[kTopoMaxDom];         // the pod's priority key per domain (~0: not a candidate)
-  uint32_t blk_cls[64], blk_claim[64], blk_cnt[64];
-  TopoClass blk_tc[64];
-  FastSlot blk_cs[64];
-};
-struct TopoPlan { int total_bytes, off_run, off_state; };   // (the cursor engine's tables sit where FastWork::plan says)
-struct TopoWork { TopoClass* cls; TopoRec* rec; TopoPlan plan; int enabled; };
-struct TopoArgs { ProblemView pv; Workspace ws; FastWork fw; TopoWork tw; };
 
 template <class W>
 struct TopoEngine {
@@ -78,6 +44,8 @@ struct TopoEngine {
   uint64_t track_fields = 0;   // bit 4 f: counter f has a list
   unsigned long long n_ref = 0, n_tests = 0, n_windows = 0, n_listed = 0;
   int bail = 0;
+  unsigned long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0, tc5 = 0, tc6 = 0, tc7 = 0, tc8 = 0, tc9 = 0;   // profiling builds (-DKSOLVE_PHASE_TIMERS): shader clock per phase of a step
+  int last_kind = 0, last_x = 0, last_p = 0;   // the move of the last step (1: a claim gained a pod, from position last_p; 2: a new claim), 0: pending in `order` / none
 
   KS_DEV TopoEngine(const ProblemView* p, const Workspace* s, const FastWork* f, const TopoWork* t, char* lds) {
     Pk = p; Sk = s; Fk = f; Tk = t;
@@ -135,7 +103,7 @@ struct TopoEngine {
         W::for_n(kTopoMaxDom, [&](int z) { Z.cnt[z] = c0[z]; Z.rank[z] = rk[z]; });
         if (W::leader()) {
           Z.dom = (uint32_t)T.domains0[(size_t)g * T.dom_words]; Z.nonzero = T.nonzero0[g]; Z.skew = T.max_skew[g];
-          Z.type = (uint8_t)type; Z.var = (uint8_t)var;
+          Z.type = (uint8_t)type; Z.var = (uint8_t)var; Z.off = Mp->voff[var]; Z.width = Mp->vwidth[var];
         }
         // (domains beyond the sixteen the field holds cannot exist: the field's width is the key's highest valid value)
         if (T.domains0[(size_t)g * T.dom_words] >> kTopoMaxDom) return 50;
@@ -188,64 +156,65 @@ struct TopoEngine {
   }
 
   // ---- the pod's domain choice on the dictionary-key group it owns, before any claim is looked at ----
-  // vm: candidate domains; st->zkey[z]: priority of domain z (smaller wins; spread: count, then name rank — topologygroup.go:251-297
+  // vm: candidate domains; zkv: priority of domain z in lane z (smaller wins; spread: count, then name rank — topologygroup.go:251-297
   // with the canonical tie-break of DESIGN.md §2); multi: every candidate the claim admits stays (affinity with pods to be affine to,
-  // topologygroup.go:345-364). false: no domain can satisfy the pod wherever it goes.
+  // topologygroup.go:345-364). possible = false: no domain can satisfy the pod wherever it goes. Registers and LDS only.
   struct ZChoice { uint32_t vm; int off, width; bool multi, on; uint64_t clear; };
-  KS_DEV ZChoice choose_domains(const TopoClass& tc, const FastSlot& cs, bool* possible) {
+  KS_DEV ZChoice choose_domains(int zg, bool self, uint64_t cvmask, LaneVar<uint64_t>& zkv, bool& possible) const {
     ZChoice zc; zc.vm = 0; zc.off = 0; zc.width = 0; zc.multi = false; zc.on = false; zc.clear = 0;
-    *possible = true;
-    if (tc.zg < 0) return zc;
-    KS_LDS TopoZg& Z = st->zg[tc.zg];
-    const int j = Z.var;
-    const int off = Mp->voff[j], width = Mp->vwidth[j];
+    possible = true;
+    if (zg < 0) return zc;
+    KS_LDS TopoZg* const Z = &st->zg[zg];
+    TopoZgHead hd = lds_get16((const KS_LDS TopoZgHead*)&Z->dom);
+    const uint32_t D = (uint32_t)fast_uniform((int)hd.dom);
+    const int skew = fast_uniform(hd.skew);
+    const uint32_t tv = (uint32_t)fast_uniform((int)((uint32_t)hd.type | ((uint32_t)hd.off << 8) | ((uint32_t)hd.width << 16)));
+    const int type = (int)(tv & 0xFF), off = (int)((tv >> 8) & 0xFF), width = (int)((tv >> 16) & 0xFF);
     const uint32_t fmn = (1u << width) - 1;
-    const uint32_t podf = (uint32_t)(cs.cvmask >> off) & fmn;   // the values the pod itself admits (every one when it does not select on the key)
-    const uint32_t D = Z.dom;
-    const bool self = tc.zself != 0;
+    const uint32_t podf = (uint32_t)(cvmask >> off) & fmn;   // the values the pod itself admits (every one when it does not select on the key)
     zc.on = true; zc.off = off; zc.width = width;
-    zc.clear = Mp->fmask[j] | (1ull << (off + width));
-    KS_LDS uint64_t* zk = st->zkey;
-    KS_LDS TopoZg* Zp = &Z;
-    if (Z.type == 0) {
+    zc.clear = ((uint64_t)fmn << off) | (1ull << (off + width));
+    LaneVar<int32_t> cz; LaneVar<uint32_t> rz;
+    W::each([&](int z) { cz.at(z) = Z->cnt[z & (kTopoMaxDom - 1)]; rz.at(z) = Z->rank[z & (kTopoMaxDom - 1)]; });
+    if (type == 0) {
       // domainMinCount over the domains the pod supports (topologygroup.go:300-322), then count + self - min <= maxSkew
       const uint32_t sup = D & podf;
-      const uint64_t mn64 = W::reduce_min(kTopoMaxDom, [&](int z) -> uint64_t { return ((sup >> z) & 1) ? (uint64_t)(uint32_t)Zp->cnt[z] : ~0ull; });
-      const long long mn = mn64 == ~0ull ? (long long)INT32_MAX : (long long)mn64;
-      const long long skew = Z.skew;
+      int who = 0;
+      const uint32_t mn32 = W::argmin_u32([&](int z) { return (z < kTopoMaxDom && ((sup >> z) & 1)) ? (uint32_t)cz.at(z) : 0xFFFFFFFFu; }, &who);
+      const long long mn = mn32 == 0xFFFFFFFFu ? (long long)INT32_MAX : (long long)mn32;
       const uint64_t vb = W::ballot([&](int z) {
-        if (z >= kTopoMaxDom) return false;
-        const bool v = ((D >> z) & 1) && (long long)Zp->cnt[z] + (self ? 1 : 0) - mn <= skew;
-        zk[z] = v ? (((uint64_t)(uint32_t)(Zp->cnt[z] + (self ? 1 : 0)) << 32) | ((uint64_t)Zp->rank[z] << 8) | (uint64_t)z) : ~0ull;
+        const bool v = z < kTopoMaxDom && ((D >> z) & 1) && (long long)cz.at(z) + (self ? 1 : 0) - mn <= (long long)skew;
+        zkv.at(z) = v ? (((uint64_t)(uint32_t)(cz.at(z) + (self ? 1 : 0)) << 32) | ((uint64_t)rz.at(z) << 8) | (uint64_t)z) : ~0ull;
         return v;
       });
       zc.vm = (uint32_t)vb;
-      W::sync();
-      if (!zc.vm) *possible = false;
+      if (!zc.vm) possible = false;
       return zc;
     }
     // affinity (topologygroup.go:324-388)
-    const uint32_t pn = (uint32_t)W::ballot([&](int z) { return z < kTopoMaxDom && ((D >> z) & 1) && Zp->cnt[z] > 0 && ((podf >> z) & 1); });
+    const uint32_t pn = (uint32_t)W::ballot([&](int z) { return z < kTopoMaxDom && ((D >> z) & 1) && cz.at(z) > 0 && ((podf >> z) & 1); });
     if (pn) { zc.vm = pn; zc.multi = true; return zc; }
-    if (!self) { *possible = false; return zc; }
+    if (!self) { possible = false; return zc; }
     // nothing to be affine to yet and the pod matches its own selector: the first domain the claim and the pod admit (:372-386; the
     // second loop's pick is the same domain whenever it lies inside the claim's set, and drops out of the intersection otherwise)
     const uint32_t ph = D & podf;
-    W::each([&](int z) { if (z < kTopoMaxDom) zk[z] = ((ph >> z) & 1) ? (((uint64_t)Zp->rank[z] << 8) | (uint64_t)z) : ~0ull; });
-    W::sync();
+    W::each([&](int z) { zkv.at(z) = (z < kTopoMaxDom && ((ph >> z) & 1)) ? (((uint64_t)rz.at(z) << 8) | (uint64_t)z) : ~0ull; });
     zc.vm = ph;
-    if (!ph) *possible = false;
+    if (!ph) possible = false;
     return zc;
   }
 
-  // CanAdd (nodeclaim.go:124-242) of the class on the claim whose record this lane holds -> bit 0: accepts by the first probe of the
-  // requirement-set cache, bit 1: the set is not at its first probe (or has further Pareto vectors): undecided. m2 = the narrowed set.
-  KS_DEV int lane_test(const TopoRec& r, const TopoClass& tc, const FastSlot& cs, const ZChoice& zc, uint64_t& m2) const {
-    const int t = (int)(r.vmask >> 56);
-    const uint64_t m = r.vmask & cs.cvmask;
+  // CanAdd (nodeclaim.go:124-242) of a class on the claim whose state this lane holds -> 1: accepts, by the first probe of the
+  // requirement-set cache; 2: the set is not at its first probe (or has further Pareto vectors): undecided; 0: rejects. m2 = the set
+  // narrowed by the pod's selectors and its domain choice.
+  struct KClass { uint64_t hlim, cvmask, dmask; int32_t s0, s1, s2, s3; uint32_t tmplok; };
+  KS_DEV int lane_test(uint64_t vmask, int32_t r0, int32_t r1, int32_t r2, int32_t r3, uint64_t hcnt, const KClass& k, const ZChoice& zc, const LaneVar<uint64_t>& zkv,
+                       const KS_LDS FastEnt* ent, uint64_t& m2) const {
+    const int t = (int)(vmask >> 56);
+    const uint64_t m = vmask & k.cvmask;
     m2 = m;
-    bool ok = ((cs.tmplok >> t) & 1u) != 0 && fast_fields_ok(m, cs.dmask);
-    ok = ok && (((tc.hlim - r.hcnt) & kTopoGuard) == kTopoGuard);
+    bool ok = ((k.tmplok >> t) & 1u) != 0 && fast_fields_ok(m, k.dmask);
+    ok = ok && (((k.hlim - hcnt) & kTopoGuard) == kTopoGuard);
     if (zc.on) {
       const uint32_t zf = (uint32_t)(m >> zc.off) & ((1u << zc.width) - 1);
       const uint32_t cand = zf & zc.vm;
@@ -253,20 +222,21 @@ struct TopoEngine {
       uint32_t nf = cand;
       if (!zc.multi) {
         uint64_t best = ~0ull;
-        for (int z = 0; z < zc.width; ++z) { const uint64_t kz = st->zkey[z]; if (((cand >> z) & 1) && kz < best) best = kz; }
-        nf = 1u << (best & 0xFF & (kTopoMaxDom - 1));
+        for (int z = 0; z < zc.width; ++z) { const uint64_t kz = zkv.bcast(z); if (((cand >> z) & 1) && kz < best) best = kz; }
+        nf = 1u << (best & (kTopoMaxDom - 1));
       }
       m2 = (m & ~zc.clear) | ((uint64_t)nf << zc.off);
     }
+    const FastEnt e = lds_get16(&ent[fast_hash(m2)]);   // (read whatever `ok` says: no branch in front of the LDS access)
     if (!ok) return 0;
-    const FastEnt e = lds_get16(&cold.ent[fast_hash(m2)]);
     if (e.vmask != m2) return 2;
-    return fast_fits_first(e, r.req, cs.size) ? 1 : 0;
+    return (int)((k.s0 <= e.cap[0] - r0) & (k.s1 <= e.cap[1] - r1) & (k.s2 <= e.cap[2] - r2) & (k.s3 <= e.cap[3] - r3));
   }
   // the lanes of `todo` the long way: every probe of the cache, every Pareto vector; a set that is not cached gets its entry.
-  // Returns the lanes that accept; bail != 0: stop.
-  KS_COLD uint64_t resolve(uint64_t todo, LaneVar<uint64_t>& m2v, LaneVar<int32_t>& q0, LaneVar<int32_t>& q1, LaneVar<int32_t>& q2, LaneVar<int32_t>& q3, const FastSlot& cs) {
+  // Returns the lanes that accept; bail != 0: stop. (Everything by value: a reference into the caller's registers would pin them to scratch.)
+  KS_COLD uint64_t resolve(uint64_t todo, LaneVar<uint64_t> m2v, LaneVar<int32_t> q0, LaneVar<int32_t> q1, LaneVar<int32_t> q2, LaneVar<int32_t> q3, int32_t s0, int32_t s1, int32_t s2, int32_t s3) {
     uint64_t acc = 0;
+    const int32_t sz[4] = {s0, s1, s2, s3};
     while (todo) {
       const uint64_t td = todo;
       uint64_t okb = 0, miss = 0;
@@ -275,7 +245,7 @@ struct TopoEngine {
         FastEnt e;
         if (fast_lookup(cold.ent, m2v.at(l), e) < 0) return 2;
         const int32_t rq[4] = {q0.at(l), q1.at(l), q2.at(l), q3.at(l)};
-        return fast_fits(cold.pool, e, rq, cs.size) ? 1 : 0;
+        return fast_fits(cold.pool, e, rq, sz) ? 1 : 0;
       }, okb, miss);
       acc |= okb;
       todo = miss;
@@ -285,17 +255,17 @@ struct TopoEngine {
   }
 
   // Record (topology.go:197-220) on the dictionary-key groups that count the pod: only once the claim is down to ONE domain
-  KS_DEV void record_zonal(const TopoClass& tc, uint64_t m2) {
-    for (uint64_t zs = tc.zsel; zs; zs &= zs - 1) {
-      KS_LDS TopoZg& Z = st->zg[ctz64(zs)];
-      const int j = Z.var, off = Mp->voff[j], width = Mp->vwidth[j];
+  KS_DEV void record_zonal(uint64_t zsel, uint64_t m2) const {
+    for (uint64_t zs = zsel; zs; zs &= zs - 1) {
+      KS_LDS TopoZg* const Z = &st->zg[ctz64(zs)];
+      const uint32_t ow = (uint32_t)fast_uniform((int)(*(const KS_LDS uint32_t*)&Z->type));   // type | var << 8 | off << 16 | width << 24
+      const int off = (int)((ow >> 16) & 0xFF), width = (int)(ow >> 24);
       if ((m2 >> (off + width)) & 1) continue;   // the claim does not define the key: Exists, no values
       const uint32_t f = (uint32_t)(m2 >> off) & ((1u << width) - 1);
       if (popc64(f) != 1) continue;
       const int z = ctz64(f);
-      if (W::leader()) { const int32_t c = Z.cnt[z]; Z.cnt[z] = c + 1; if (c == 0) Z.nonzero = Z.nonzero + 1; Z.dom = Z.dom | f; }
+      if (W::leader()) { const int32_t c = Z->cnt[z]; Z->cnt[z] = c + 1; if (c == 0) Z->nonzero = Z->nonzero + 1; Z->dom = Z->dom | f; }
     }
-    W::sync();
   }
   KS_FN static uint64_t host_add(uint64_t hcnt, uint64_t hinc) {   // per-field +1, saturating at 7
     const uint64_t full = hcnt & (hcnt >> 1) & (hcnt >> 2) & kTopoOnes;
@@ -329,19 +299,26 @@ struct TopoEngine {
     }
   }
 
-  // addToNewNodeClaim (scheduler.go:695-790) for a pod no in-flight claim accepted: 1 = claim created, 0 = stop (bail; -1 = capacity)
-  KS_COLD int new_claim(const TopoClass& tc, const FastSlot& cs, const ZChoice& zc, int bi) {
+  // addToNewNodeClaim (scheduler.go:695-790) for a pod no in-flight claim accepted, every case: several templates, NodePool limits,
+  // requirement sets that are not cached yet, pdqsort's other paths. The claim's id, or -1: stop (bail; -1 = capacity).
+  // (solve() places the common case itself: one template without limits, the set cached, the single stable move.)
+  KS_COLD int new_claim(TopoClass tc, FastSlot cs) {
     const ProblemView& P = *Pk; const Workspace& S = *Sk; const FastWork& F = *Fk;
     const int T = P.n_templates, nr = P.n_res, iw = P.it_words;
     const int n = order.n;
     n_ref += (unsigned long long)n;
+    LaneVar<uint64_t> zkv;
+    bool possible = true;
+    const ZChoice zc = choose_domains(tc.zg, tc.zself != 0, cs.cvmask, zkv, possible);
+    if (!possible) { bail = 27; return -1; }
+    KClass kc; kc.hlim = tc.hlim; kc.cvmask = cs.cvmask; kc.dmask = cs.dmask; kc.s0 = cs.size[0]; kc.s1 = cs.size[1]; kc.s2 = cs.size[2]; kc.s3 = cs.size[3]; kc.tmplok = cs.tmplok;
     for (int t = 0; t < T; ++t) {
       if (!((cold.active_templates >> t) & 1u)) continue;
       const uint32_t lm = P.tmpl_limit_mask[t];
       if (lm) {
         // filterByRemainingResources (scheduler.go:1069-1085): this engine only continues while no type is excluded
         int64_t* rem = S.t_remaining + (size_t)t * (nr + 1);
-        if (((lm >> nr) & 1) && rem[nr] <= 0) { bail = 23; return 0; }
+        if (((lm >> nr) & 1) && rem[nr] <= 0) { bail = 23; return -1; }
         const ProblemView& Pv = P;
         const uint64_t* tits = S.t_its + (size_t)t * iw;
         const int n_its = P.n_its;
@@ -357,23 +334,22 @@ struct TopoEngine {
             return !v;
           });
         }
-        if (excluded) { bail = 24; return 0; }
+        if (excluded) { bail = 24; return -1; }
       }
       cold.host_seq++;
       n_ref++;
       // CanAdd on the fresh claim: the template's set, no requests, every hostname counter zero (the limits are >= 0)
-      TopoRec fresh; fresh.vmask = Mp->tvmask[t]; fresh.req[0] = fresh.req[1] = fresh.req[2] = fresh.req[3] = 0; fresh.hcnt = 0;
       uint64_t m2 = 0;
-      // (every lane computes the same verdict: the record is wave-uniform)
-      int v = lane_test(fresh, tc, cs, zc, m2);
+      int v = lane_test(Mp->tvmask[t], 0, 0, 0, 0, 0ull, kc, zc, zkv, cold.ent, m2);   // (every lane computes the same verdict: the state is wave-uniform)
       v = fast_uniform(v);
       m2 = W::uniform(m2);
       if (v == 0) continue;
       FastEnt e;
       int eh = fast_lookup(cold.ent, m2, e);
-      if (eh < 0) { eh = cold.create_entry(m2); if (eh < 0) { bail = 25; return 0; } e = lds_get(&cold.ent[eh]); }
-      if (!fast_fits(cold.pool, e, fresh.req, cs.size)) continue;
-      if (cold.n_claims >= S.max_claims) { bail = -1; return 0; }
+      if (eh < 0) { eh = cold.create_entry(m2); if (eh < 0) { bail = 25; return -1; } e = lds_get(&cold.ent[eh]); }
+      const int32_t zero[4] = {0, 0, 0, 0};
+      if (!fast_fits(cold.pool, e, zero, cs.size)) continue;
+      if (cold.n_claims >= S.max_claims) { bail = -1; return -1; }
       const int c = cold.n_claims++;
       TopoRec nrq;
       nrq.vmask = m2;
@@ -381,9 +357,13 @@ struct TopoEngine {
       nrq.hcnt = host_add(0, tc.hinc);
       if (W::leader()) { Tk->rec[c] = nrq; F.c_hostseq[c] = cold.host_seq; }
       order.append(c);
-      record_zonal(tc, m2);
+      if (order.single_move(order.defect)) {   // (its place behind the claims with one pod: now, like every single stable move)
+        order.move_appended(c);
+        order.defect = -1; order.defect_claim = -1; order.defect_append = false;
+        last_kind = 2; last_x = c; last_p = 0;
+      } else last_kind = 0;
+      record_zonal(tc.zsel, m2);
       if (track_fields) lists_add(nrq.hcnt, (uint32_t)c);
-      if (W::leader()) { st->blk_claim[bi] = (uint32_t)c; st->blk_cnt[bi] = 0; }
       W::sync();
       if (lm) {
         // subtractMax (scheduler.go:1049-1066) over the claim's instance types: F(m2) ∩ fits(size)
@@ -401,33 +381,24 @@ struct TopoEngine {
         }
         W::sync();
       }
-      return 1;
+      return c;
     }
     bail = 27;   // an unschedulable pod: error codes, diagnostics and the relaxation ladder are the general engine's
-    return 0;
+    return -1;
   }
-
-  // the claims at positions p0 .. p0+63 of the order, one per lane (0xFFFFFFFF past the end); (k, i) = run and index inside it of
-  // position p0, moved on to position p0 + 64
-  KS_DEV void window(int& k, uint32_t& i, LaneVar<uint32_t>& xv) {
-    int filled = 0;
-    W::each([&](int l) { xv.at(l) = 0xFFFFFFFFu; });
-    const uint32_t* ring = order.ring;
-    while (filled < 64 && k <= order.max_cnt) {
-      const uint32_t sz = (uint32_t)fast_uniform((int)order.size_(k));
-      if (i < sz) {
-        const uint32_t left = sz - i;
-        const int take = left < (uint32_t)(64 - filled) ? (int)left : 64 - filled;
-        const uint32_t h = (uint32_t)fast_uniform((int)order.head_(k)), m = (uint32_t)fast_uniform((int)order.mask_of(k)), o = (uint32_t)fast_uniform((int)order.off_(k)), i0 = i;
-        const int f0 = filled;
-        W::each([&](int l) { if (l >= f0 && l < f0 + take) xv.at(l) = ring[o + ((h + i0 + (uint32_t)(l - f0)) & m)]; });
-        filled += take;
-        i += (uint32_t)take;
-        if (i < sz) break;
-      }
-      k++; i = 0;
+  // a claim gained a pod and pdqsort's repair is not the single stable move (or its run lies beyond the LDS tables): through RunOrder
+  KS_COLD void move_cold(int x, int k, uint32_t a_pos) {
+    if (order.single_move((int)a_pos)) {
+      const uint32_t idx = a_pos - order.prefix_(k);
+      order.move_known(x, k, idx);
+      last_kind = 1; last_x = x; last_p = (int)a_pos;
+    } else {
+      order.defect = (int)a_pos; order.defect_claim = x; order.defect_append = false;   // RunOrder::increment: at the next sort
+      last_kind = 0;
+      W::sync();
     }
   }
+  KS_COLD void sort_cold() { order.sort(); }
 
   KS_COLD void finish(int status, unsigned long long steps) {
     const Workspace& S = *Sk; const FastWork& F = *Fk;
@@ -436,6 +407,14 @@ struct TopoEngine {
       const int dc = order.defect_claim;
       const bool dapp = order.defect_append;
       order.write_final();   // the array form: o_key (pod counts), o_ord (claims) by position; the last move stays undone, as in the reference
+      if (last_kind && dc < 0) {
+        // ... and this engine makes a step's move at once (it knows the claim's run and index from its scan): the last one is taken
+        // back in the array form — the claim returns to where it stood, with its new count (scheduler.go:598 sorts at the NEXT add)
+        ClaimOrder<W, uint32_t*, false> t;
+        t.key = order.key; t.ord = order.ord; t.pos = nullptr; t.n = n;
+        const int q = (int)W::uniform((uint64_t)order.position(last_x));
+        if (last_kind == 1) t.rotate_right(last_p, q); else t.rotate_left(q, n - 1);
+      }
       FastClaim* gs = F.c_state; uint32_t* gn = F.c_npods; uint16_t* ge = F.c_ent;
       const TopoRec* rec = Tk->rec;
       const uint32_t* cnt = order.cnt;
@@ -455,25 +434,27 @@ struct TopoEngine {
     c.bin_evaluations = n_tests; c.full_evaluations = n_windows; c.queue_pops = steps; c.sorts = steps; c.slow_sorts = order.slow_sorts;
     c.ref_bin_evaluations = n_ref; c.it_evaluations = n_listed;
     c.cycles[20] = (unsigned long long)(bail > 0 ? bail : 0);
+    c.cycles[0] = tc0; c.cycles[1] = tc1; c.cycles[2] = tc2; c.cycles[3] = tc3; c.cycles[4] = tc4; c.cycles[5] = tc5; c.cycles[6] = tc6; c.cycles[7] = tc7; c.cycles[8] = tc8; c.cycles[9] = tc9;
     if (W::leader()) *S.counters = c;
     W::sync();
   }
 
-  // the block's class records, wave-uniform (LDS reads leave the compiler believing they are per-lane values)
-  KS_DEV TopoClass class_of(int bi) const {
-    TopoClass t = lds_get(&st->blk_tc[bi]);
-    t.hlim = W::uniform(t.hlim); t.hinc = W::uniform(t.hinc); t.zsel = W::uniform(t.zsel);
-    t.zg = fast_uniform(t.zg); t.zself = (uint32_t)fast_uniform((int)t.zself); t.excl = (uint32_t)fast_uniform((int)t.excl); t.pad = 0;
-    return t;
+  KS_DEV static TopoRec load_rec(const KS_GLOBAL TopoRec* p) {   // two 16-byte loads
+    TopoRec r;
+    const KS_GLOBAL u32x4_alias* s = (const KS_GLOBAL u32x4_alias*)p;
+    u32x4_alias* o = (u32x4_alias*)&r;
+    o[0] = s[0]; o[1] = s[1];
+    return r;
   }
-  KS_DEV FastSlot slot_of(int bi) const {
-    FastSlot c = lds_get(&st->blk_cs[bi]);
-    c.cvmask = W::uniform(c.cvmask); c.dmask = W::uniform(c.dmask);
-    for (int q = 0; q < 4; ++q) c.size[q] = fast_uniform(c.size[q]);
-    c.tmplok = (uint32_t)fast_uniform((int)c.tmplok); c.kdef = (uint32_t)fast_uniform((int)c.kdef);
-    return c;
+  KS_DEV static void store_rec(KS_GLOBAL TopoRec* p, const TopoRec& r) {
+    KS_GLOBAL u32x4_alias* d = (KS_GLOBAL u32x4_alias*)p;
+    const u32x4_alias* o = (const u32x4_alias*)&r;
+    d[0] = o[0]; d[1] = o[1];
   }
 
+  // Solve — scheduler.go:440-519. The loop below keeps its own state in registers (claims, pods placed, counters; the classes of the
+  // block's 64 pods one per lane) and reads LDS and HBM through pointers of its own: the engine object (`cold`, `order`, the
+  // counters) is what the out-of-line paths work on, and the loop hands its registers over around every such call.
   KS_DEV void solve() {
     {
       const int why = (int)W::uniform((uint64_t)(uint32_t)cold.setup(true));
@@ -481,28 +462,69 @@ struct TopoEngine {
       const int why2 = (int)W::uniform((uint64_t)(uint32_t)setup_topo());
       if (why2) { bail = why2; finish(3, 0); return; }
     }
-    const ProblemView& P = *Pk; const Workspace& S = *Sk; const FastWork& F = *Fk;
-    const int np = P.n_pods;
-    const uint32_t* gqcls = F.q_class; uint32_t* gqclaim = F.q_claim; uint32_t* gqcnt = F.q_cnt;
-    const TopoClass* gtc = Tk->cls; const FastSlot* gcs = F.cls;
-    TopoRec* rec = Tk->rec;
-    const uint32_t* ocnt = order.cnt;
-    KS_LDS TopoState& S_ = *st;
-    const volatile int* cancel = S.cancel_flag;
-    const long long max_steps = S.max_steps;
-    unsigned long long steps = 0;
+    const int np = fast_uniform(Pk->n_pods);
+    const int max_claims = fast_uniform(Sk->max_claims);
+    KS_GLOBAL TopoRec* const rec = (KS_GLOBAL TopoRec*)fast_uniform(Tk->rec);
+    KS_GLOBAL uint32_t* const ring = (KS_GLOBAL uint32_t*)fast_uniform(order.ring);
+    KS_GLOBAL uint32_t* const ocnt = (KS_GLOBAL uint32_t*)fast_uniform(order.cnt);
+    KS_GLOBAL uint32_t* const oslot = (KS_GLOBAL uint32_t*)fast_uniform(order.slot);
+    KS_LDS RunTables* const RT = fast_uniform(order.T);
+    KS_LDS TopoState* const S_ = fast_uniform(st);
+    if (W::leader()) {
+      S_->q_class = Fk->q_class; S_->q_claim = Fk->q_claim; S_->q_cnt = Fk->q_cnt; S_->tcls = Tk->cls; S_->fcls = Fk->cls; S_->hostseq = Fk->c_hostseq;
+      S_->last[0] = 0; S_->last[1] = 0; S_->last[2] = 0; S_->last[3] = 0;
+    }
+    W::sync();
+    const KS_LDS FastEnt* const ent = fast_uniform(cold.ent);
+    const volatile int* const cancel = fast_uniform(Sk->cancel_flag);
+    const long long max_steps = (long long)W::uniform((uint64_t)Sk->max_steps);
+    const int kmax = fast_uniform(order.kmax);
+    // the template a new claim comes from, when there is exactly one and it has no limits (the loop opens such claims itself)
+    int fast_t = -1;
+    {
+      const uint32_t at = (uint32_t)fast_uniform((int)cold.active_templates);
+      if (at && !(at & (at - 1)) && !Pk->tmpl_limit_mask[ctz64(at)]) fast_t = ctz64(at);
+    }
+    const uint64_t fast_tv = fast_t >= 0 ? W::uniform(Mp->tvmask[fast_t]) : 0ull;
+    // ---- the loop's registers (the object's copies are written before / read after every out-of-line call) ----
+    int n = 0, max_cnt = 1, n_claims = 0;            // order.n, order.max_cnt, cold.n_claims
+    uint32_t host_seq = 0;                           // cold.host_seq
+    uint64_t trk = W::uniform(track_fields);
+    bool pending = false;                            // `order` holds a move for its next sort()
+    unsigned long long ref = 0;
+    uint32_t windows = 0, steps = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, t8 = 0;
     int status = 0;
+    auto push = [&]() { order.n = n; order.max_cnt = max_cnt; cold.n_claims = n_claims; cold.host_seq = host_seq; track_fields = trk; last_kind = S_->last[0]; last_x = S_->last[1]; last_p = S_->last[2]; n_ref = ref; };
+    auto set_last = [&](int kind, int x, int pos) { if (W::leader()) { S_->last[0] = kind; S_->last[1] = x; S_->last[2] = pos; } };
+    auto pull = [&]() {
+      n = fast_uniform(order.n); max_cnt = fast_uniform(order.max_cnt); n_claims = fast_uniform(cold.n_claims); host_seq = (uint32_t)fast_uniform((int)cold.host_seq);
+      trk = W::uniform(track_fields); set_last(last_kind, last_x, last_p); ref = W::uniform(n_ref);
+      pending = fast_uniform(order.defect_claim) >= 0;
+    };
     for (int base = 0; base < np && !status; base += 64) {
       const int bn = np - base < 64 ? np - base : 64;
-      // the block's classes with their records: one gather per 64 pods
+      // the classes of the block's pods, one per lane: one gather per 64 pods, a handful of v_readlane per pod
+      LaneVar<uint64_t> c_hlim, c_hinc, c_zsel, c_cvm, c_dm;
+      LaneVar<int32_t> c_zg, c_s0, c_s1, c_s2, c_s3;
+      LaneVar<uint32_t> c_zself, c_excl, c_tok, oclaim, ocntv;
+      const KS_GLOBAL uint32_t* const gqcls = (const KS_GLOBAL uint32_t*)fast_uniform(S_->q_class);
+      const KS_GLOBAL TopoClass* const gtc = (const KS_GLOBAL TopoClass*)fast_uniform(S_->tcls);
+      const KS_GLOBAL FastSlot* const gcs = (const KS_GLOBAL FastSlot*)fast_uniform(S_->fcls);
       W::each([&](int l) {
-        if (l < bn) {
-          const uint32_t k = gqcls[base + l] & ~kFastLastBit;
-          S_.blk_cls[l] = k; lds_put(&S_.blk_tc[l], gtc[k]); lds_put(&S_.blk_cs[l], gcs[k]);
-          S_.blk_claim[l] = 0xFFFFFFFFu; S_.blk_cnt[l] = 0;
-        }
+        const int q = base + (l < bn ? l : bn - 1);
+        const uint32_t k = gqcls[q] & ~kFastLastBit;
+        const KS_GLOBAL u64_alias* tp = (const KS_GLOBAL u64_alias*)(gtc + k);
+        const uint64_t w3 = tp[3], w4 = tp[4];
+        c_hlim.at(l) = tp[0]; c_hinc.at(l) = tp[1]; c_zsel.at(l) = tp[2];
+        c_zg.at(l) = (int32_t)(uint32_t)w3; c_zself.at(l) = (uint32_t)(w3 >> 32); c_excl.at(l) = (uint32_t)w4;
+        const KS_GLOBAL u64_alias* sp = (const KS_GLOBAL u64_alias*)(gcs + k);
+        const uint64_t v2 = sp[2], v3 = sp[3], v4 = sp[4];
+        c_cvm.at(l) = sp[0]; c_dm.at(l) = sp[1];
+        c_s0.at(l) = (int32_t)(uint32_t)v2; c_s1.at(l) = (int32_t)(uint32_t)(v2 >> 32); c_s2.at(l) = (int32_t)(uint32_t)v3; c_s3.at(l) = (int32_t)(uint32_t)(v3 >> 32);
+        c_tok.at(l) = (uint32_t)v4;
+        oclaim.at(l) = 0xFFFFFFFFu; ocntv.at(l) = 0;
       });
-      W::sync();
       if (cancel) {
         // > 0: ksolve_cancel / the deadline; < 0 (tests only, KSOLVE_TEST_CANCEL_AT): as if the cancel landed once -flag pods were placed
         const int cv = fast_uniform((int)W::poll_flag(cancel));
@@ -512,52 +534,66 @@ struct TopoEngine {
       for (; bi < bn; ++bi) {
         if (max_steps >= 0 && (long long)steps >= max_steps) { status = 2; break; }
         steps++;
-        order.sort();                                      // scheduler.go:598: the move the last commit left behind
-        if (order.overflow) { status = 1; break; }
-        const TopoClass tc = class_of(bi);
-        const FastSlot cs = slot_of(bi);
+        unsigned long long tq = W::clock();
+#define KS_TSEC(acc) { const unsigned long long tn_ = W::clock(); acc += tn_ - tq; tq = tn_; }
+        if (pending) {   // scheduler.go:598: a move pdqsort makes the long way
+          push(); sort_cold(); pull();
+          if (fast_uniform((int)order.overflow)) { status = 1; break; }
+        }
+        KS_TSEC(t0)
+        // ---- the pod's class ----
+        KClass kc;
+        kc.hlim = c_hlim.bcast(bi); kc.cvmask = c_cvm.bcast(bi); kc.dmask = c_dm.bcast(bi);
+        kc.s0 = c_s0.bcast(bi); kc.s1 = c_s1.bcast(bi); kc.s2 = c_s2.bcast(bi); kc.s3 = c_s3.bcast(bi); kc.tmplok = c_tok.bcast(bi);
+        const uint64_t hinc = c_hinc.bcast(bi), zsel = c_zsel.bcast(bi);
+        const int zg = c_zg.bcast(bi);
+        const bool zself = c_zself.bcast(bi) != 0;
+        const uint32_t excl = c_excl.bcast(bi);
+        KS_TSEC(t1)
+        LaneVar<uint64_t> zkv;
         bool possible = true;
-        const ZChoice zc = choose_domains(tc, cs, &possible);
+        const ZChoice zc = choose_domains(zg, zself, kc.cvmask, zkv, possible);
         if (!possible) { bail = 27; status = 3; break; }
-        const int n = order.n;
+        KS_TSEC(t2)
         // ---- addToInflightNode (scheduler.go:658-692): the first claim of the order that accepts ----
-        LaneVar<uint64_t> m2v, hcv;
-        LaneVar<uint32_t> xv, pv, cv;
-        LaneVar<int32_t> q0, q1, q2, q3;
-        uint64_t okm = 0;
         bool found = false;
         // the acceptor (wave-uniform): claim, position, its narrowed requirement set, hostname counters, requests, pod count
-        uint32_t kx = 0, a_pos = 0, kc = 0; uint64_t km = 0, kh = 0; int32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
-        const bool listed = tc.excl != 0xFFu && fast_uniform((int)S_.track_field[tc.excl & (kTopoTrack - 1)]) != 0xFF;
+        uint32_t kx = 0, a_pos = 0, kcn = 0; uint64_t km = 0, kh = 0; int32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+        const bool listed = excl != 0xFFu && fast_uniform((int)S_->track_field[excl & (kTopoTrack - 1)]) != 0xFF;
         if (listed) {
           // every member of an anti-affinity group it owns needs a claim without one: the claims that hold none yet, wherever they
           // stand in the order — the lowest position among those that accept
-          const int t = (int)tc.excl;
-          const int nf = fast_uniform((int)S_.n_free[t]);
-          n_listed++;
+          const int t = (int)excl;
+          const int nf = fast_uniform((int)S_->n_free[t]);
           uint32_t best_pos = 0xFFFFFFFFu;
           for (int f0 = 0; f0 < nf; f0 += 64) {
-            uint64_t und = 0;
+            LaneVar<uint64_t> m2v, hcv;
+            LaneVar<uint32_t> xv, pv, cv;
+            LaneVar<int32_t> q0, q1, q2, q3;
+            uint64_t okm = 0, und = 0;
             W::ballot2([&](int l) {
-              xv.at(l) = 0xFFFFFFFFu; pv.at(l) = 0xFFFFFFFFu;
-              if (f0 + l >= nf) return 0;
-              const uint32_t x = S_.freel[t][f0 + l];
-              const TopoRec r = rec[x];
+              const uint32_t x = S_->freel[t][f0 + l < nf ? f0 + l : nf - 1];
+              const TopoRec r = load_rec(rec + x);
+              const uint32_t c = ocnt[x], sl = oslot[x];
               uint64_t m2;
-              const int v = lane_test(r, tc, cs, zc, m2);
-              xv.at(l) = x; m2v.at(l) = m2; hcv.at(l) = r.hcnt; pv.at(l) = order.position((int)x); cv.at(l) = ocnt[x];
+              const int v = lane_test(r.vmask, r.req[0], r.req[1], r.req[2], r.req[3], r.hcnt, kc, zc, zkv, ent, m2);
+              // position = the run's first position + the claim's index inside the run (run_order.h)
+              const RunEnt e = lds_get16(&RT->e[c < (uint32_t)kRunMaxCount ? c : 0]);
+              const uint32_t mk = (1u << RT->log2cap[c < (uint32_t)kRunMaxCount ? c : 0]) - 1u;
+              xv.at(l) = x; m2v.at(l) = m2; hcv.at(l) = r.hcnt; cv.at(l) = c;
+              pv.at(l) = (f0 + l < nf && c < (uint32_t)kRunMaxCount) ? e.prefix + ((sl - e.head) & mk) : 0xFFFFFFFFu;
               q0.at(l) = r.req[0]; q1.at(l) = r.req[1]; q2.at(l) = r.req[2]; q3.at(l) = r.req[3];
-              return v;
+              return f0 + l < nf ? v : 0;
             }, okm, und);
-            n_tests += (unsigned long long)(nf - f0 < 64 ? nf - f0 : 64);
-            if (und) { okm |= resolve(und, m2v, q0, q1, q2, q3, cs); if (bail) break; }
+            if (W::ballot([&](int l) { return f0 + l < nf && cv.at(l) >= (uint32_t)kRunMaxCount; })) { bail = 61; break; }   // (a claim beyond the LDS ring tables in a list: not this engine's shape)
+            if (und) { push(); okm |= resolve(und, m2v, q0, q1, q2, q3, kc.s0, kc.s1, kc.s2, kc.s3); pull(); if (bail) break; }
             if (okm) {
               int who = -1;
               const uint64_t om = okm;
               const uint32_t p = W::argmin_u32([&](int l) { return ((om >> l) & 1) ? pv.at(l) : 0xFFFFFFFFu; }, &who);
               if (p < best_pos) {
                 best_pos = p; found = true; a_pos = p;
-                kx = xv.bcast(who); km = m2v.bcast(who); kh = hcv.bcast(who); kc = cv.bcast(who);
+                kx = xv.bcast(who); km = m2v.bcast(who); kh = hcv.bcast(who); kcn = cv.bcast(who);
                 k0 = q0.bcast(who); k1 = q1.bcast(who); k2 = q2.bcast(who); k3 = q3.bcast(who);
               }
             }
@@ -566,62 +602,208 @@ struct TopoEngine {
         } else {
           int k = 1; uint32_t i = 0;
           for (int p0 = 0; p0 < n; p0 += 64) {
-            window(k, i, xv);
-            n_windows++;
-            uint64_t und = 0;
+            // ---- the claims at positions p0 .. p0+63, one per lane: the table records of sixteen runs in one LDS round trip ----
+            LaneVar<uint32_t> xv;
+            W::each([&](int l) { xv.at(l) = 0xFFFFFFFFu; });
+            {
+              int filled = 0;
+              bool done = false;
+              while (!done && filled < 64 && k <= max_cnt) {
+                if (k + 16 >= kRunMaxCount) { bail = 62; break; }   // (a run beyond the LDS ring tables at the front of the order: not this engine's shape)
+                LaneVar<uint32_t> eh, es, eo, em;
+                const int kb = k;
+                W::each([&](int l) {
+                  const int kk = kb + (l & 15);
+                  const RunEnt e = lds_get16(&RT->e[kk]);
+                  eh.at(l) = e.head; es.at(l) = e.size; eo.at(l) = e.off; em.at(l) = (1u << RT->log2cap[kk]) - 1u;
+                });
+                for (int j = 0; j < 16 && k <= max_cnt; ++j) {
+                  const uint32_t sz = es.bcast(j);
+                  if (i < sz) {
+                    const uint32_t left = sz - i;
+                    const int take = left < (uint32_t)(64 - filled) ? (int)left : 64 - filled;
+                    const uint32_t h = eh.bcast(j), m = em.bcast(j), o = eo.bcast(j), i0 = i;
+                    const int f0 = filled;
+                    W::each([&](int l) { if (l >= f0 && l < f0 + take) xv.at(l) = ring[o + ((h + i0 + (uint32_t)(l - f0)) & m)]; });
+                    filled += take;
+                    i += (uint32_t)take;
+                    if (i < sz || filled >= 64) { done = true; break; }
+                  }
+                  k++; i = 0;
+                }
+              }
+            }
+            if (bail) break;
+            windows++;
+            KS_TSEC(t3)
+            LaneVar<uint64_t> m2v, hcv;
+            LaneVar<uint32_t> cv;
+            LaneVar<int32_t> q0, q1, q2, q3;
+            uint64_t okm = 0, und = 0;
+            const int lastl = n - p0 - 1;   // (lanes past the order's end read the last claim again: no lane is switched off for the loads)
             W::ballot2([&](int l) {
-              const uint32_t x = xv.at(l);
-              if (x == 0xFFFFFFFFu) return 0;
-              const TopoRec r = rec[x];
+              const uint32_t x = xv.shuffle(l, l <= lastl ? l : (lastl < 63 ? lastl : 63));
+              const TopoRec r = load_rec(rec + x);
+              const uint32_t c = ocnt[x];
               uint64_t m2;
-              const int v = lane_test(r, tc, cs, zc, m2);
-              m2v.at(l) = m2; hcv.at(l) = r.hcnt; cv.at(l) = ocnt[x];
+              const int v = lane_test(r.vmask, r.req[0], r.req[1], r.req[2], r.req[3], r.hcnt, kc, zc, zkv, ent, m2);
+              m2v.at(l) = m2; hcv.at(l) = r.hcnt; cv.at(l) = c;
               q0.at(l) = r.req[0]; q1.at(l) = r.req[1]; q2.at(l) = r.req[2]; q3.at(l) = r.req[3];
-              return v;
+              return l <= lastl ? v : 0;
             }, okm, und);
-            n_tests += (unsigned long long)(n - p0 < 64 ? n - p0 : 64);
+            KS_TSEC(t4)
             // the lanes in front of the first plain acceptor whose requirement set is not at its first probe: the long way
             const uint64_t before = okm ? (und & ((1ull << ctz64(okm)) - 1)) : und;
-            if (before) { okm |= resolve(before, m2v, q0, q1, q2, q3, cs); if (bail) break; }
+            if (before) { push(); okm |= resolve(before, m2v, q0, q1, q2, q3, kc.s0, kc.s1, kc.s2, kc.s3); pull(); if (bail) break; }
             if (okm) {
               const int a = ctz64(okm);
               found = true; a_pos = (uint32_t)(p0 + a);
-              kx = xv.bcast(a); km = m2v.bcast(a); kh = hcv.bcast(a); kc = cv.bcast(a);
+              kx = xv.bcast(a); km = m2v.bcast(a); kh = hcv.bcast(a); kcn = cv.bcast(a);
               k0 = q0.bcast(a); k1 = q1.bcast(a); k2 = q2.bcast(a); k3 = q3.bcast(a);
               break;
             }
           }
           if (bail) { status = 3; break; }
         }
+        KS_TSEC(t5)
         if (!found) {
-          const int made = fast_uniform(new_claim(tc, cs, zc, bi));
-          if (!made) { status = bail < 0 ? 1 : 3; break; }
+          // ---- addToNewNodeClaim (scheduler.go:695-790) ----
+          bool made = false;
+          if (fast_t >= 0 && n >= 50 && n_claims < max_claims && max_cnt + 2 < kRunMaxCount) {
+            // one template without limits, the order past pdqsort's small-array paths: the claim is opened here. NewNodeClaim draws a
+            // hostname number, CanAdd runs on the template's requirement set with nothing requested and every hostname counter zero
+            uint64_t m2 = 0;
+            const int v = fast_uniform(lane_test(fast_tv, 0, 0, 0, 0, 0ull, kc, zc, zkv, ent, m2));
+            m2 = W::uniform(m2);
+            if (v == 1) {
+              ref += (unsigned long long)n + 1;
+              host_seq++;
+              const int c = n_claims++;
+              TopoRec nrq;
+              nrq.vmask = m2; nrq.req[0] = kc.s0; nrq.req[1] = kc.s1; nrq.req[2] = kc.s2; nrq.req[3] = kc.s3; nrq.hcnt = host_add(0, hinc);
+              // the new claim: behind the last claim with one pod — the end of run 1; every later run starts one position further right
+              const RunEnt e1 = lds_get16(&RT->e[1]);
+              const uint32_t m1 = (1u << RT->log2cap[1]) - 1u;
+              const uint32_t s1 = ((uint32_t)fast_uniform((int)e1.head) + (uint32_t)fast_uniform((int)e1.size)) & (uint32_t)fast_uniform((int)m1);
+              const uint32_t o1 = (uint32_t)fast_uniform((int)e1.off);
+              if (W::leader()) {
+                store_rec(rec + c, nrq); ((KS_GLOBAL uint32_t*)S_->hostseq)[c] = host_seq;
+                ring[o1 + s1] = (uint32_t)c; oslot[c] = s1; ocnt[c] = 1u;
+                RT->e[1].size = e1.size + 1;
+              }
+              const int top = max_cnt + 1;
+              W::each([&](int l) { for (int kk = 2 + l; kk <= top; kk += 64) RT->e[kk].prefix += 1; });
+              n++;
+              record_zonal(zsel, m2);
+              if (trk) {
+                // the lists of claims without a member of an anti-affinity group: the new claim joins those whose counter it leaves at zero
+                const uint64_t zero_now = ~(nrq.hcnt | (nrq.hcnt >> 1) | (nrq.hcnt >> 2)) & kTopoOnes & trk;
+                if (zero_now) { push(); lists_add(nrq.hcnt, (uint32_t)c); pull(); }
+              }
+              oclaim.set(bi, (uint32_t)c); ocntv.set(bi, 0u);
+              set_last(2, c, 0);
+              W::sync();
+              made = true;
+            }
+          }
+          if (!made) {
+            push();
+            TopoClass tcc; tcc.hlim = kc.hlim; tcc.hinc = hinc; tcc.zsel = zsel; tcc.zg = zg; tcc.zself = zself ? 1u : 0u; tcc.excl = excl; tcc.pad = 0;
+            FastSlot csc; csc.cvmask = kc.cvmask; csc.dmask = kc.dmask; csc.size[0] = kc.s0; csc.size[1] = kc.s1; csc.size[2] = kc.s2; csc.size[3] = kc.s3; csc.tmplok = kc.tmplok; csc.kdef = 0;
+            const int c = fast_uniform(new_claim(tcc, csc));
+            pull();
+            if (c < 0) { status = fast_uniform(bail) < 0 ? 1 : 3; break; }
+            oclaim.set(bi, (uint32_t)c); ocntv.set(bi, 0u);
+          }
+          KS_TSEC(t6)
           continue;
         }
         // ---- NodeClaim.Add (nodeclaim.go:247-263) ----
-        n_ref += (unsigned long long)a_pos + 1;
+        ref += (unsigned long long)a_pos + 1;
         TopoRec nrq;
         nrq.vmask = km;
-        nrq.req[0] = k0 + cs.size[0]; nrq.req[1] = k1 + cs.size[1]; nrq.req[2] = k2 + cs.size[2]; nrq.req[3] = k3 + cs.size[3];
-        nrq.hcnt = host_add(kh, tc.hinc);
-        if (W::leader()) { rec[kx] = nrq; S_.blk_claim[bi] = kx; S_.blk_cnt[bi] = kc; }
-        record_zonal(tc, km);
+        nrq.req[0] = k0 + kc.s0; nrq.req[1] = k1 + kc.s1; nrq.req[2] = k2 + kc.s2; nrq.req[3] = k3 + kc.s3;
+        nrq.hcnt = host_add(kh, hinc);
+        if (W::leader()) store_rec(rec + kx, nrq);
+        oclaim.set(bi, kx); ocntv.set(bi, kcn);
+        record_zonal(zsel, km);
         // the anti-affinity lists: the claim leaves those whose counter this pod takes from zero
         {
           const uint64_t zero_before = ~(kh | (kh >> 1) | (kh >> 2)) & kTopoOnes;
-          const uint64_t leaving = tc.hinc & zero_before & track_fields;
-          if (leaving) lists_remove(leaving, kx);
+          const uint64_t leaving = hinc & zero_before & trk;
+          if (leaving) { push(); lists_remove(leaving, kx); pull(); }
         }
-        order.defect = (int)a_pos; order.defect_claim = (int)kx; order.defect_append = false;   // RunOrder::increment: it moves at the next sort
-        W::sync();
+        KS_TSEC(t7)
+        // The sort.Slice of the NEXT add (scheduler.go:598) moves this claim behind the claims with fewer pods. When that is pdqsort's
+        // single stable move — the claim leaves its run and becomes the first of the next one (run_order.h) — it is made now: run and
+        // index are known from the scan, no load stands in front of it.
+        {
+          const int k = (int)kcn;
+          const unsigned q4 = (unsigned)n >> 2;
+          const bool single = n <= 12 || (n >= 50 && !(a_pos - (q4 - 1) <= 2u || a_pos - (2 * q4 - 1) <= 2u || a_pos - (3 * q4 - 1) <= 2u));
+          bool moved = false;
+          if (single && k + 3 < kRunMaxCount && k + 2 < kmax) {
+            const RunEnt ea = lds_get16(&RT->e[k]), eb = lds_get16(&RT->e[k + 1]);
+            const uint32_t ma = (1u << RT->log2cap[k]) - 1u, mb = (1u << RT->log2cap[k + 1]) - 1u;
+            const uint32_t h = (uint32_t)fast_uniform((int)ea.head), sz = (uint32_t)fast_uniform((int)ea.size), oa = (uint32_t)fast_uniform((int)ea.off), m = (uint32_t)fast_uniform((int)ma);
+            const uint32_t idx = a_pos - (uint32_t)fast_uniform((int)ea.prefix);
+            uint32_t hb = (uint32_t)fast_uniform((int)eb.head), sb = (uint32_t)fast_uniform((int)eb.size), pb = (uint32_t)fast_uniform((int)eb.prefix);
+            const uint32_t ob = (uint32_t)fast_uniform((int)eb.off), mbu = (uint32_t)fast_uniform((int)mb);
+            if (k + 1 > max_cnt) {
+              // the first claim with k + 1 pods: run k + 1 starts out empty, and every claim lies in front of run k + 2 (RunOrder::grow_to)
+              hb = 0; sb = 0;
+              if (W::leader()) RT->e[k + 2].prefix = (uint32_t)n;
+              max_cnt = k + 1;
+            }
+            uint32_t new_head = h;
+            bool ok_shift = true;
+            if (idx == 0) new_head = (h + 1) & m;
+            else if (idx + 1 < sz) {
+              if (idx <= sz - 1 - idx && idx <= 64) {
+                // the claims in front of it step one ring slot towards the hole (at most 64 of them: one round, read before written)
+                LaneVar<uint32_t> mv;
+                W::each([&](int l) { mv.at(l) = (uint32_t)l < idx ? ring[oa + ((h + (uint32_t)l) & m)] : 0u; });
+                W::each([&](int l) { if ((uint32_t)l < idx) { const uint32_t s = (h + (uint32_t)l + 1u) & m; ring[oa + s] = mv.at(l); oslot[mv.at(l)] = s; } });
+                new_head = (h + 1) & m;
+              } else if (sz - 1 - idx <= 64 && idx > sz - 1 - idx) {
+                const uint32_t cntb = sz - 1 - idx;   // ... or the claims behind it do
+                LaneVar<uint32_t> mv;
+                W::each([&](int l) { mv.at(l) = (uint32_t)l < cntb ? ring[oa + ((h + idx + 1u + (uint32_t)l) & m)] : 0u; });
+                W::each([&](int l) { if ((uint32_t)l < cntb) { const uint32_t s = (h + idx + (uint32_t)l) & m; ring[oa + s] = mv.at(l); oslot[mv.at(l)] = s; } });
+              } else ok_shift = false;
+            }
+            if (ok_shift) {
+              const uint32_t h1 = (hb - 1u) & mbu;
+              if (W::leader()) {
+                ring[ob + h1] = kx; oslot[kx] = h1; ocnt[kx] = (uint32_t)(k + 1);
+                RT->e[k].head = new_head; RT->e[k].size = sz - 1;
+                RT->e[k + 1].head = h1; RT->e[k + 1].size = sb + 1; RT->e[k + 1].prefix = pb - 1;
+              }
+              set_last(1, (int)kx, (int)a_pos);
+              moved = true;
+              W::sync();
+            }
+          }
+          if (!moved) {
+            push(); move_cold((int)kx, k, a_pos); pull();
+            if (fast_uniform((int)order.overflow)) { status = 1; break; }
+          }
+        }
+        KS_TSEC(t8)
       }
+#undef KS_TSEC
       // the block's results, in queue order (ksolve_fast_scatter puts them under the pod indices)
       {
         const int dn = bi < bn ? bi : bn;
-        W::each([&](int l) { if (l < dn) { gqclaim[base + l] = S_.blk_claim[l]; gqcnt[base + l] = S_.blk_cnt[l]; } });
-        W::sync();
+        KS_GLOBAL uint32_t* const gqclaim = (KS_GLOBAL uint32_t*)fast_uniform(S_->q_claim);
+        KS_GLOBAL uint32_t* const gqcnt = (KS_GLOBAL uint32_t*)fast_uniform(S_->q_cnt);
+        W::each([&](int l) { if (l < dn) { gqclaim[base + l] = oclaim.at(l); gqcnt[base + l] = ocntv.at(l); } });
       }
     }
+    push();
+    n_tests = (unsigned long long)windows * 64; n_windows = windows; n_listed = 0;
+    tc0 = t0; tc1 = t1; tc2 = t2; tc3 = t3; tc4 = t4; tc5 = t5; tc6 = t6; tc7 = t7; tc8 = t8;
+    W::sync();
     finish(status, steps);
   }
 };

@@ -2774,8 +2774,12 @@ static std::vector<int> split_pinned_pools(const Value& p, const std::vector<std
 struct SplitSelector { std::vector<std::string> namespaces; std::vector<std::pair<std::string, std::string>> match; };
 static bool split_selectors(const Value& p, std::vector<SplitSelector>& out) {   // false: a term this code cannot evaluate
   const std::string ns = p.at("namespace").s("default");
+  // (a group on any key but the hostname draws its domain universe from EVERY NodePool — buildDomainGroups, topology.go:104-142;
+  // domainMinCount takes the minimum over all of them, topologygroup.go:300-322 — so its owner cannot be cut off from the other pools:
+  // the whole batch may reject a pod a component would schedule. Such a term refuses the split. ADVICE r5.)
   for (auto& c : p.at("topologySpreadConstraints").items()) {
     const Value& sel = c.at("labelSelector");
+    if (c.at("topologyKey").s() != "kubernetes.io/hostname") return false;
     if (!sel.at("matchExpressions").items().empty()) return false;
     SplitSelector s; s.namespaces = {ns};
     for (auto& kv : sel.at("matchLabels").members()) s.match.push_back({kv.first, kv.second.s()});
@@ -2788,6 +2792,7 @@ static bool split_selectors(const Value& p, std::vector<SplitSelector>& out) {  
     for (auto& w : aff.at("preferred").items()) terms.push_back(&w.at("term"));
     for (const Value* t : terms) {
       const Value& sel = t->at("labelSelector");
+      if (t->at("topologyKey").s() != "kubernetes.io/hostname") return false;
       if (!sel.at("matchExpressions").items().empty() || !t->at("namespaceSelector").is_null()) return false;
       SplitSelector s;
       for (auto& n : t->at("namespaces").items()) s.namespaces.push_back(n.s());
@@ -2838,7 +2843,7 @@ extern "C" char* ksched_split_components(const char* problem_json, int n_bins) {
     }
     for (auto& it : items) {
       std::vector<SplitSelector> sels;
-      if (!split_selectors(*it.tmpl, sels)) return refuse("a topology selector with matchExpressions / a namespaceSelector");
+      if (!split_selectors(*it.tmpl, sels)) return refuse("a topology group on a key other than kubernetes.io/hostname (its domains come from every NodePool), or a topology selector with matchExpressions / a namespaceSelector");
       for (auto& sl : sels) for (auto& sg : sigs) {
         if (std::find(sl.namespaces.begin(), sl.namespaces.end(), sg.ns) == sl.namespaces.end()) continue;
         bool all = true;

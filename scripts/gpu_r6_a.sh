@@ -2,7 +2,7 @@
 # on it and on the general engine, kernel stats + SQ counters of the 1M-pod pin.   usage (GPU box): bash scripts/gpu_r6_a.sh
 set -x
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r6a; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r6a; mkdir -p $O
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_spread_engine.py -m gpu -x -q 2>&1 | tail -5 | tee $O/pytest_spread.log
 for pin in config3_p200000_t500_s42 config3_p1000000_t500_s42; do

@@ -9,6 +9,7 @@
 #define KSOLVE_TEST_HOOKS 1   // the test switches (KSOLVE_TEST_*) exist in the test builds only
 #include <algorithm>
 #include "../../karpenter_amd/csrc/ksolve_impl.h"
+#include "../../karpenter_amd/csrc/topo_engine.h"
 
 struct EmuBackend { std::chrono::steady_clock::time_point t0[8]; };
 

@@ -35,15 +35,12 @@ def build_hooks():
     reads the KSOLVE_TEST_* / KSOLVE_ROWHASH_KERNEL switches (narrowed row hash, deterministic cancellation, the previous classing
     kernels). karpenter_amd/libksolve.so — the product — is compiled without them. Built here when missing or stale (several
     minutes of hipcc), so keep it built in-tree before a gpurun call: it travels with the snapshot."""
-    import subprocess
+    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    csrc = os.path.join(root, "karpenter_amd", "csrc")
-    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(root, "include", "ksolve.h")]
-    if not os.path.exists(HOOKS_LIB) or any(os.path.getmtime(d) > os.path.getmtime(HOOKS_LIB) for d in deps):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        tmp = HOOKS_LIB + f".{os.getpid()}.tmp"
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DKSOLVE_TEST_HOOKS", "-o", tmp, os.path.join(csrc, "ksolve.hip")])
-        os.replace(tmp, HOOKS_LIB)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    ge.build_ksolve(HOOKS_LIB, defines=("-DKSOLVE_TEST_HOOKS",))
     return HOOKS_LIB
 
 

@@ -38,7 +38,7 @@ def test_single_rank_line(oracle):
     line = _json_line(r.stdout)
     assert REQUIRED <= set(line) and {"cpu_baseline", "batched", "packing", "counters", "parity", "config2_topology", "engine"} <= set(line)
     assert line["engine"] == "cursor" and line["parity"]["oracle_pin"] is None and len(line["parity"]["results_digest"]) == 64
-    assert line["config2_topology"]["pods"] == 400 and line["config2_topology"]["value"] > 0 and line["config2_topology"]["engine"] == "general"
+    assert line["config2_topology"]["pods"] == 400 and line["config2_topology"]["value"] > 0 and line["config2_topology"]["engine"] == "spread" and line["config2_topology"]["pack_kernel"]["kernel"] == "ksolve_pack_topo" and "dominant" in line["roofline"]
     assert line["packing"]["per_instance_type"]["launch_types_used"] >= 1
     cc = line["config3_components"]
     assert cc["components"] == 16 and cc["pods"] == 4000 and cc["engines"] == ["cursor"] and abs(cc["calibration"]["cost_rel_delta"]) < 0.05

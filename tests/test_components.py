@@ -87,11 +87,11 @@ def test_components_through_topology_groups(oracle, emu):
     prob = fx.config4(pods=3000, n_types=100, n_pools=5, seed=7)
     on = lambda pool: {fx.NODEPOOL: pool}
     web, db, cache = {"app": "web"}, {"app": "db"}, {"app": "cache"}
-    extra = [fx.pod(labels=web, node_selector=on("pool-00"), requests={"cpu": "500m"}, topology_spread=[fx.spread(fx.ZONE, web)]) for _ in range(12)]       # spread inside pool-00
+    extra = [fx.pod(labels=web, node_selector=on("pool-00"), requests={"cpu": "500m"}, topology_spread=[fx.spread(fx.HOSTNAME, web, max_skew=2)]) for _ in range(12)]       # spread inside pool-00
     extra += [fx.pod(labels=db, node_selector=on("pool-01"), requests={"cpu": "1"}, pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, db)]) for _ in range(6)]   # anti-affinity inside pool-01
     extra += [fx.pod(labels=cache, node_selector=on("pool-02"), requests={"cpu": "250m"}) for _ in range(8)]
-    extra += [fx.pod(labels={"app": "api"}, node_selector=on("pool-03"), requests={"cpu": "250m"}, pod_requirements=[fx.affinity_term(fx.ZONE, cache)]) for _ in range(5)]   # pool-03 follows pool-02's pods
-    extra += [fx.pod(labels={"app": "batch"}, node_selector=on("pool-04"), pod_preferences=[fx.weighted(5, fx.affinity_term(fx.ZONE, {"app": "nothing"}))]) for _ in range(4)]  # selects nobody
+    extra += [fx.pod(labels={"app": "api"}, node_selector=on("pool-03"), requests={"cpu": "250m"}, pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, cache)]) for _ in range(5)]   # pool-03's pods avoid pool-02's
+    extra += [fx.pod(labels={"app": "batch"}, node_selector=on("pool-04"), pod_anti_preferences=[fx.weighted(5, fx.affinity_term(fx.HOSTNAME, {"app": "nothing"}))]) for _ in range(4)]  # selects nobody
     prob = dict(prob, pods=prob.get("pods", []) + extra)
     parts = split_components(prob)
     assert [pools for pools, _ in parts] == [("pool-00",), ("pool-01",), ("pool-02", "pool-03"), ("pool-04",)]
@@ -101,15 +101,40 @@ def test_components_through_topology_groups(oracle, emu):
         parity.assert_same_results(g, w)
     whole = oracle.solve(prob)
     assert not whole["podErrors"] and not any(w["podErrors"] for w in want)
-    assert abs(sum(len(w["newNodeClaims"]) for w in want) - len(whole["newNodeClaims"])) <= 0.03 * len(whole["newNodeClaims"])
-    assert abs(sum(w["packingCost"] for w in want) - whole["packingCost"]) <= 0.01 * whole["packingCost"]
+    assert abs(sum(len(w["newNodeClaims"]) for w in want) - len(whole["newNodeClaims"])) <= max(2, 0.03 * len(whole["newNodeClaims"]))
+    assert abs(sum(w["packingCost"] for w in want) - whole["packingCost"]) <= 0.02 * whole["packingCost"]
     # a selector that reaches pods of another pool merges the two; what cannot be evaluated here is refused
     reach = dict(prob, pods=prob["pods"] + [fx.pod(labels=web, node_selector=on("pool-04"))])
     assert [pools for pools, _ in split_components(reach)][0] == ("pool-00", "pool-04")
-    expr = fx.pod(node_selector=on("pool-00"), topology_spread=[dict(fx.spread(fx.ZONE, web), labelSelector={"matchExpressions": [{"key": "app", "operator": "Exists"}]})])
+    expr = fx.pod(node_selector=on("pool-00"), topology_spread=[dict(fx.spread(fx.HOSTNAME, web), labelSelector={"matchExpressions": [{"key": "app", "operator": "Exists"}]})])
     assert split_components(dict(prob, pods=prob["pods"] + [expr])) is None
-    nssel = fx.pod(node_selector=on("pool-00"), pod_requirements=[fx.affinity_term(fx.ZONE, web, namespace_selector={})])
+    nssel = fx.pod(node_selector=on("pool-00"), pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, web, namespace_selector={})])
     assert split_components(dict(prob, pods=prob["pods"] + [nssel])) is None
+    # a group on any key but the hostname sees the domains of EVERY NodePool (below): refused
+    zonal = fx.pod(labels=web, node_selector=on("pool-00"), topology_spread=[fx.spread(fx.ZONE, web)])
+    assert split_components(dict(prob, pods=prob["pods"] + [zonal])) is None
+    zaff = fx.pod(labels=web, node_selector=on("pool-00"), pod_requirements=[fx.affinity_term(fx.ZONE, web)])
+    assert split_components(dict(prob, pods=prob["pods"] + [zaff])) is None
+
+
+def test_a_zonal_group_sees_the_domains_of_every_nodepool(oracle):
+    """the reference builds a group's domain universe over ALL NodePools (topology.go:104-142 buildDomainGroups) and
+    domainMinCount takes the minimum over every domain of the key (topologygroup.go:300-322). Ten pods pinned to pool-a (zones 1-2)
+    with a zonal spread of maxSkew 1, pool-b offering zone 3: the whole batch leaves eight of them unschedulable (zone 3 stays at
+    zero and nothing may get more than one ahead of it) — a component that only knows pool-a's zones would schedule all ten. The
+    split must refuse such a batch, in the host library and in the Python rule."""
+    from karpenter_amd.components import split_components_reference
+    lab = {"app": "web"}
+    pools = [fx.node_pool("pool-a", requirements=[fx.req(fx.ZONE, "In", "test-zone-1", "test-zone-2")]),
+             fx.node_pool("pool-b", requirements=[fx.req(fx.ZONE, "In", "test-zone-3")])]
+    pods = [fx.pod(labels=lab, requests={"cpu": "500m"}, node_selector={fx.NODEPOOL: "pool-a"}, topology_spread=[fx.spread(fx.ZONE, lab)]) for _ in range(10)]
+    pods += [fx.pod(requests={"cpu": "500m"}, node_selector={fx.NODEPOOL: "pool-b"}) for _ in range(3)]
+    prob = fx.problem(fx.fake_instance_types(12), pools, pods)
+    whole = oracle.solve(prob)
+    assert len(whole["podErrors"]) == 8
+    alone = oracle.solve(dict(prob, nodePools=pools[:1], pods=pods[:10]))
+    assert not alone["podErrors"]          # what a component cut off from pool-b would answer
+    assert split_components(prob) is None and split_components_reference(prob) is None
 
 
 def test_the_host_library_split_equals_the_python_rule_and_deals_by_pod_count():
@@ -123,8 +148,8 @@ def test_the_host_library_split_equals_the_python_rule_and_deals_by_pod_count():
     on = lambda pool: {fx.NODEPOOL: pool}
     web = {"app": "web"}
     extra = [fx.pod(requests={"cpu": "1"}, node_requirements=pin("pool-00", "pool-01")) for _ in range(10)]
-    extra += [fx.pod(labels=web, node_selector=on("pool-02"), topology_spread=[fx.spread(fx.ZONE, web)]) for _ in range(6)]
-    extra += [fx.pod(labels={"app": "api"}, node_selector=on("pool-03"), pod_requirements=[fx.affinity_term(fx.ZONE, web)]) for _ in range(3)]
+    extra += [fx.pod(labels=web, node_selector=on("pool-02"), topology_spread=[fx.spread(fx.HOSTNAME, web)]) for _ in range(6)]
+    extra += [fx.pod(labels={"app": "api"}, node_selector=on("pool-03"), pod_anti_requirements=[fx.affinity_term(fx.HOSTNAME, web)]) for _ in range(3)]
     for batch in (prob, dict(prob, pods=extra), fx.config4(pods=20000, n_types=60, n_pools=16, seed=42)):
         lib, ref = split_components(batch), split_components_reference(batch)
         assert [pools for pools, _ in lib] == [pools for pools, _ in ref]

@@ -10,8 +10,8 @@ from karpenter_amd.scheduling import NewScheduler
 g = json.load(open(sys.argv[1]))
 eng = sys.argv[2] if len(sys.argv) > 2 else "auto"
 prob = build_problem(g["config"], g["pods"], g["types"], g["seed"], g["extra"])
-t = time.time(); s = NewScheduler(dict(prob, options=dict(prob["options"], engine=eng))); r = s.Solve(); s.close(); dt = time.time() - t
+t = time.time(); s = NewScheduler(dict(prob, options=dict(prob["options"], engine=eng)), **({"solver_lib": os.environ["KSOLVE_LIB"]} if os.environ.get("KSOLVE_LIB") else {})); r = s.Solve(); s.close(); dt = time.time() - t
 digest, _ = parity.results_digest(r)
-print(json.dumps({"pin": os.path.basename(sys.argv[1]), "engine": eng, "engine_used": r["counters"]["engine"], "plan": r["counters"].get("cursorMemoryPlan"), "seconds": round(dt, 2), "pack_kernel_ms": r["timings"][0].get("pack_kernel_ms"), "fallback_reason": r["counters"].get("engineFallbackReason"),
+print(json.dumps({"pin": os.path.basename(sys.argv[1]), "engine": eng, "engine_used": r["counters"]["engine"], "plan": r["counters"].get("cursorMemoryPlan"), "seconds": round(dt, 2), "pack_kernel_ms": r["timings"][0].get("pack_kernel_ms"), "fallback_reason": r["counters"].get("engineFallbackReason"), **({"phase_cycles": r["counters"].get("phaseCycles")} if os.environ.get("KSOLVE_LIB") else {}),
                   "claims": [len(r["newNodeClaims"]), g["claims"]], "digest_matches": digest == g["digest"],
                   "reference_bin_evaluations_match": r["counters"]["referenceBinEvaluations"] == g["binEvaluations"]}))
