@@ -270,7 +270,8 @@ def sweep_rooflines(tm, n_probes):
     ds = tm.get("node_dead0_us", 0.0) * 1e-6
     if ds > 0:
         alg0 = tm["nodes"] * b_node + tm["classes"] * b_cls + tm["classes"] * ((tm["nodes"] + 63) // 64) * 8
-        out["ksolve_node_dead0"] = {"bound": "compare throughput (classes x nodes tests; the node tables are streamed once per class from L2)", "grid": f"{(tm['nodes'] + 63) // 64} blocks of one wavefront",
+        out["ksolve_node_dead0"] = {"bound": "compare throughput (classes x nodes tests): a lane holds its node's scalars in registers across the 32 classes of its wavefront's chunk; the node tables are read once per chunk, from L2 after the first",
+                                    "grid": f"{(tm['nodes'] + 63) // 64} x {(tm['classes'] + 31) // 32} blocks of one wavefront (64 nodes x 32 classes each)",
                                     "class_node_tests": tm["classes"] * tm["nodes"], "tests_per_s": tm["classes"] * tm["nodes"] / ds,
                                     "algorithmic_bytes": alg0, "avg_kernel_ms": ds * 1e3, "achieved": alg0 / ds / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg0 / ds / 1e9 / HBM_PEAK_GBS,
                                     "traffic": pmc.get("ksolve_node_dead0", {}).get("traffic_bytes_largest_launch")}

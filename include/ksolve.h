@@ -276,8 +276,12 @@ typedef struct {
                                     * ~15,000 in-flight NodeClaims, up to 65,472); 5 = cursor engine only, LDS plan with one row of class slots on
                                     * TWO wavefronts (ksolve_pack_fast2: a second wavefront recomputes a NodeClaim's acceptance words
                                     * while the first places the next pod; kept for measurements — on the MI355X it is 5.7% slower than
-                                    * the one-wavefront kernel every other setting runs, profiles/round5/pass_i).
-                                    * All give identical Results. */
+                                    * the one-wavefront kernel every other setting runs, profiles/round5/pass_i);
+                                    * 6 = spread engine only (csrc/topo_engine.h, round 6): the cursor engine's shape plus topology spread /
+                                    * pod affinity on dictionary keys and spread / anti-affinity on the hostname (BASELINE configs[2]);
+                                    * KSOLVE_ERR_UNSUPPORTED when the problem is outside that shape. Automatic (0) tries it first on every
+                                    * problem that is plain but for its topology groups and falls back to the general engine when it
+                                    * declines. All give identical Results. */
 } ksolve_options;
 
 /* One NodeClaim of Results.NewNodeClaims (scheduler.go:282, nodeclaim.go:43-62), in the order the reference's
@@ -320,8 +324,9 @@ typedef struct {
                                     * total, CanAdd and scan sub-phases) and a few diagnostic counts */
   double us_upload, us_prepass, us_pack, us_finalize, us_download;
   double packing_cost;
-  uint32_t engine_used;            /* 1 = general engine, 2 = cursor engine */
-  uint32_t engine_fallback_reason; /* non-zero: why the cursor engine handed the problem to the general engine (csrc/fast_engine.h) */
+  uint32_t engine_used;            /* 1 = general engine, 2 = cursor engine, 3 = spread engine */
+  uint32_t engine_fallback_reason; /* non-zero: why the cursor / spread engine handed the problem to the general engine (csrc/fast_engine.h
+                                    * setup(): 1-8; run time: 20-28; csrc/topo_engine.h setup_topo(): 40-51, run time: 60-62) */
   uint32_t cursor_wide;            /* engine_used == 2: the memory plan it ran with. 0 = claim state and order in LDS (~3,000 in-flight
                                     * NodeClaims); 1 = the claims' state in HBM (~15,000); 2 = their order too (65,472) */
   uint32_t cursor_attempts;        /* runs of the cursor engine this solve took: 1, or one more per plan it outgrew (a later solve of the

@@ -517,8 +517,8 @@ __global__ void ksolve_finalize(int n, ks::FinalizeArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ks::finalize_body(i, a);
 }
-// every pod class against every pristine node of a resident cluster (kernels.h node_dead0_body): one wavefront per 64 nodes
-__global__ void __launch_bounds__(64) ksolve_node_dead0(ks::NodeDeadArgs a) { ks::node_dead0_body<ks::Wave>((int)blockIdx.x, a); }
+// every pod class against every pristine node of a resident cluster (kernels.h node_dead0_body): one wavefront per 64 nodes x 32 classes
+__global__ void __launch_bounds__(64) ksolve_node_dead0(ks::NodeDeadArgs a) { ks::node_dead0_body<ks::Wave>((int)blockIdx.x, (int)blockIdx.y, a); }
 __global__ void ksolve_claim_gather(int n, ks::ClaimGatherArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ks::claim_gather_body(i, a);
@@ -615,7 +615,7 @@ static void be_free(ksolve_handle* h, void* p) {
   (void)hipFree(p);
 }
 static void be_launch_node_dead0(ksolve_handle* h, int n_blocks, const ks::NodeDeadArgs& a) {
-  hipLaunchKernelGGL(ksolve_node_dead0, dim3((unsigned)n_blocks), dim3(64), 0, HB(h)->stream, a);
+  hipLaunchKernelGGL(ksolve_node_dead0, dim3((unsigned)n_blocks, (unsigned)((a.n_classes + ks::kDead0Classes - 1) / ks::kDead0Classes)), dim3(64), 0, HB(h)->stream, a);
   hip_check(h, hipGetLastError(), "ksolve_node_dead0 launch");
 }
 static void be_launch_claim_gather(ksolve_handle* h, int n, const ks::ClaimGatherArgs& a) {

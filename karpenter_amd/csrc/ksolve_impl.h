@@ -99,6 +99,7 @@ struct ksolve_handle {
   ks::ProblemView* d_pv = nullptr;
   char* sweep_arena = nullptr; size_t sweep_arena_bytes = 0;
   uint32_t fast_mc = 0;           // max_claims the cursor engine's plans are cut to
+  double fast_need = 0;           // lower bound of the NodeClaims the batch needs (total requests / largest allocatable): picks the cursor engine's first plan
   double dead0_us = 0;            // ksolve_node_dead0 (every class x every pristine node), once per resident cluster
   bool sweep_arena_refused = false;   // the last sweep_run stopped because the device refused its arena (sweep() then halves the launch)
   size_t sweep_last_total = 0;   // arena bytes the last sweep_run laid out (held against sweep_probe_bytes by the test builds)
@@ -694,6 +695,25 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
     if (fw.enabled) {
       h->fast_mc = mc;
       fast_plan_set(h, h->opts.engine == 4 ? 2 : h->opts.engine == 3 ? 1 : 0, 1);
+      if ((h->opts.engine == 0 || h->opts.engine == 2) && !h->opts.lds_claim_cap) {
+        // Which plan will hold the problem's NodeClaims is predictable from the rows themselves: no packing needs fewer claims than
+        // the batch's total requests over the largest allocatable of any type, per resource (round-5 review: the exact configs[3]
+        // batch — 27,345 claims — spent a whole attempt on the LDS plan before it moved to plan 2). A problem whose bound already
+        // exceeds a plan's capacity starts on the next one; anything the bound misses still moves on by itself (reason 26).
+        double need = 0;
+        for (uint32_t r = 0; r < d->n_res; ++r) {
+          int64_t best = 0;
+          for (uint32_t t = 0; t < d->n_its; ++t) best = std::max(best, d->it_allocatable[(size_t)r * d->n_its + t]);
+          if (best <= 0) continue;
+          long double sum = 0;
+          const int64_t* col = d->pod_requests + (size_t)r * d->n_pod_rows;
+          for (uint32_t p = 0; p < d->n_pods; ++p) sum += (long double)col[p];
+          need = std::max(need, (double)(sum / (long double)best));
+        }
+        h->fast_need = need;
+        int plan = 0;
+        while (plan < 2 && need > (double)h->fw.plan.cap) { ++plan; fast_plan_set(h, plan, h->fw.plan.rows); }
+      }
       fw.var = dz<ks::FastVar>(h, 1);
       fw.c_hostseq = dz<uint32_t>(h, mc); fw.c_ent = dz<uint16_t>(h, mc);
       fw.c_state = dz<ks::FastClaim>(h, mc); fw.c_npods = dz<uint32_t>(h, mc);
@@ -883,7 +903,11 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
     else if (n_classes <= 32768) { be_d2h(h, &live, h->fw.max_active, 4); be_sync(h); }   // (beyond: the count is quadratic in the classes — four rows)
     h->fast_live = live;
     const int rows = live <= 64 ? 1 : ks::kFastRows;
-    if (rows != h->fw.plan.rows) fast_plan_set(h, h->fw.plan.global_state, rows);
+    if (rows != h->fw.plan.rows) {
+      fast_plan_set(h, h->fw.plan.global_state, rows);
+      if ((h->opts.engine == 0 || h->opts.engine == 2) && !h->opts.lds_claim_cap)   // (a plan's capacity depends on the rows of class slots: the bound of create() once more)
+        while (h->fw.plan.global_state < 2 && h->fast_need > (double)h->fw.plan.cap) fast_plan_set(h, h->fw.plan.global_state + 1, rows);
+    }
   }
   if (h->tw.enabled && n_pods && n_classes) {
     // the spread engine reads the queue's classes in queue order too (no class slots: the overlap count is not needed)

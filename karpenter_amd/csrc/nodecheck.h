@@ -45,14 +45,41 @@ struct NodeTabs {
   size_t stride;
 };
 
+// A node's scalars as one lane reads them ONCE (ksolve_node_dead0 holds them in registers across its classes)
+struct NodePre {
+  uint64_t taints, hp;
+  int64_t rem[kMaxRes];
+  uint32_t ndef, ncomp, nhg, nhl;
+};
+KS_FN NodePre node_preload(const RecLayout& ly, uint64_t taints, const NodeTabs& t, size_t i) {
+  NodePre n;
+  n.taints = taints; n.hp = t.hp ? t.hp[i] : 0ull;
+#pragma unroll
+  for (int r = 0; r < kMaxRes; ++r) n.rem[r] = r < ly.nr ? t.remaining[(size_t)r * t.stride + i] : 0;
+  n.ndef = t.defined[i]; n.ncomp = t.complement[i];
+  n.nhg = t.hg ? t.hg[i] : 0u; n.nhl = t.hg ? t.hl[i] : 0u;             // bounds a Gt / Lt pod left on the node
+  return n;
+}
+// the checks behind taints, host ports and resources.Fits: strict Requirements.Compatible of the pod's set with the node's
+KS_FN bool node_reqs_ok(const Dict& d, const RecLayout& ly, const NodeClassCtx& x, uint32_t ndef, uint32_t ncomp, uint32_t nhg, uint32_t nhl, const NodeTabs& t, size_t i);
 KS_FN bool node_static_ok(const Dict& d, const RecLayout& ly, const NodeClassCtx& x, uint64_t taints, const NodeTabs& t, size_t i) {
   if (taints & ~x.ktol) return false;                                              // taints — existingnode.go:83
   if (x.khpc && t.hp && (t.hp[i] & x.khpc)) return false;                          // host ports — existingnode.go:87-93
   bool fit = true;                                                                 // resources.Fits — :96
   for (int r = 0; r < ly.nr; ++r) { const int64_t rem = t.remaining[(size_t)r * t.stride + i]; fit = fit && rem >= 0 && x.req[r] <= rem; }
   if (!fit) return false;
-  const uint32_t ndef = t.defined[i], ncomp = t.complement[i];
-  const uint32_t nhg = t.hg ? t.hg[i] : 0u, nhl = t.hg ? t.hl[i] : 0u;             // bounds a Gt / Lt pod left on the node
+  return node_reqs_ok(d, ly, x, t.defined[i], t.complement[i], t.hg ? t.hg[i] : 0u, t.hg ? t.hl[i] : 0u, t, i);   // (bounds a Gt / Lt pod left on the node)
+}
+KS_FN bool node_static_ok_pre(const Dict& d, const RecLayout& ly, const NodeClassCtx& x, const NodePre& n, const NodeTabs& t, size_t i) {
+  if (n.taints & ~x.ktol) return false;
+  if (x.khpc && (n.hp & x.khpc)) return false;
+  bool fit = true;
+#pragma unroll
+  for (int r = 0; r < kMaxRes; ++r) if (r < ly.nr) { const int64_t rem = n.rem[r]; fit = fit && rem >= 0 && x.req[r] <= rem; }
+  if (!fit) return false;
+  return node_reqs_ok(d, ly, x, n.ndef, n.ncomp, n.nhg, n.nhl, t, i);
+}
+KS_FN bool node_reqs_ok(const Dict& d, const RecLayout& ly, const NodeClassCtx& x, uint32_t ndef, uint32_t ncomp, uint32_t nhg, uint32_t nhl, const NodeTabs& t, size_t i) {
   if (x.kdef & ~ndef & ~x.kneg) return false;                                      // undefined key — requirements.go:185-193
   for (uint32_t both = x.kdef & ndef; both; both &= both - 1) {                    // Intersects — requirements.go:254-274
     const int key = __builtin_ctz(both);
