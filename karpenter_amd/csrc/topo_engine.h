@@ -210,7 +210,7 @@ struct TopoEngine {
   struct KClass { uint64_t hlim, cvmask, dmask; int32_t s0, s1, s2, s3; uint32_t tmplok; };
   KS_DEV int lane_test(uint64_t vmask, int32_t r0, int32_t r1, int32_t r2, int32_t r3, uint64_t hcnt, const KClass& k, const ZChoice& zc, const LaneVar<uint64_t>& zkv,
                        const KS_LDS FastEnt* ent, uint64_t& m2) const {
-    const int t = (int)(vmask >> 56);
+    const int t = (int)(vmask >> 56) & 31;   // (template ids are < 32; a lane past the window's end holds anything)
     const uint64_t m = vmask & k.cvmask;
     m2 = m;
     bool ok = ((k.tmplok >> t) & 1u) != 0 && fast_fields_ok(m, k.dmask);
@@ -502,6 +502,36 @@ struct TopoEngine {
       trk = W::uniform(track_fields); set_last(last_kind, last_x, last_p); ref = W::uniform(n_ref);
       pending = fast_uniform(order.defect_claim) >= 0;
     };
+    // ---- the front of the order, in registers: the claims at positions 0 .. wn-1 with their records (lane = position) ----
+    // Pods go to the emptiest claims (scheduler.go:598 sorts by pod count), so the first acceptor is almost always among the first
+    // positions, and a step changes that front by ONE claim: the acceptor leaves its place (the claims behind it, up to its new place,
+    // step one position to the left; it re-enters at the first position of the next run when that lies inside the window), a new claim
+    // enters behind the claims with one pod. The loop keeps the window up to date with lane shuffles instead of reading the rings and
+    // the records again: the common step issues NO load from HBM — only the stores of what it changed — and needs no fence; a fence
+    // stands in front of the first load after stores (`dirty`). A claim that leaves beyond the window shrinks it (wn); it is read
+    // again from the rings when it gets short, when the acceptor lies beyond it, and after every out-of-line path.
+    LaneVar<uint32_t> wx, wc;          // claim, pod count
+    LaneVar<uint64_t> wv, wh;          // requirement set, hostname counters
+    LaneVar<int32_t> wq0, wq1, wq2, wq3;   // requests
+    int wn = 0;
+    bool wvalid = false, dirty = false;
+    constexpr int kRefill = 24;
+    W::each([&](int l) { wx.at(l) = 0; wc.at(l) = 0; wv.at(l) = 0; wh.at(l) = 0; wq0.at(l) = 0; wq1.at(l) = 0; wq2.at(l) = 0; wq3.at(l) = 0; });
+    auto fence = [&]() { if (dirty) { W::sync(); dirty = false; } };
+    // the window's lanes take the values of lanes srcf(lane); lane `ins` (if >= 0) takes the given claim instead
+    auto wmove = [&](auto srcf, int ins, uint32_t ix, uint32_t ic, uint64_t iv, uint64_t ih, int32_t i0, int32_t i1, int32_t i2, int32_t i3) {
+      LaneVar<uint32_t> nx, nc_; LaneVar<uint64_t> nv, nh; LaneVar<int32_t> n0, n1, n2, n3;
+      W::each([&](int l) {
+        const int src = srcf(l) & 63;
+        nx.at(l) = wx.shuffle(l, src); nc_.at(l) = wc.shuffle(l, src); nv.at(l) = wv.shuffle(l, src); nh.at(l) = wh.shuffle(l, src);
+        n0.at(l) = wq0.shuffle(l, src); n1.at(l) = wq1.shuffle(l, src); n2.at(l) = wq2.shuffle(l, src); n3.at(l) = wq3.shuffle(l, src);
+      });
+      W::each([&](int l) {
+        const bool me = l == ins;
+        wx.at(l) = me ? ix : nx.at(l); wc.at(l) = me ? ic : nc_.at(l); wv.at(l) = me ? iv : nv.at(l); wh.at(l) = me ? ih : nh.at(l);
+        wq0.at(l) = me ? i0 : n0.at(l); wq1.at(l) = me ? i1 : n1.at(l); wq2.at(l) = me ? i2 : n2.at(l); wq3.at(l) = me ? i3 : n3.at(l);
+      });
+    };
     for (int base = 0; base < np && !status; base += 64) {
       const int bn = np - base < 64 ? np - base : 64;
       // the classes of the block's pods, one per lane: one gather per 64 pods, a handful of v_readlane per pod
@@ -537,7 +567,7 @@ struct TopoEngine {
         unsigned long long tq = W::clock();
 #define KS_TSEC(acc) { const unsigned long long tn_ = W::clock(); acc += tn_ - tq; tq = tn_; }
         if (pending) {   // scheduler.go:598: a move pdqsort makes the long way
-          push(); sort_cold(); pull();
+          fence(); push(); sort_cold(); pull(); wvalid = false;
           if (fast_uniform((int)order.overflow)) { status = 1; break; }
         }
         KS_TSEC(t0)
@@ -559,12 +589,14 @@ struct TopoEngine {
         bool found = false;
         // the acceptor (wave-uniform): claim, position, its narrowed requirement set, hostname counters, requests, pod count
         uint32_t kx = 0, a_pos = 0, kcn = 0; uint64_t km = 0, kh = 0; int32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+        bool from_window = false;   // the acceptor is lane a_pos of the window registers
         const bool listed = excl != 0xFFu && fast_uniform((int)S_->track_field[excl & (kTopoTrack - 1)]) != 0xFF;
         if (listed) {
           // every member of an anti-affinity group it owns needs a claim without one: the claims that hold none yet, wherever they
           // stand in the order — the lowest position among those that accept
           const int t = (int)excl;
           const int nf = fast_uniform((int)S_->n_free[t]);
+          if (nf) fence();
           uint32_t best_pos = 0xFFFFFFFFu;
           for (int f0 = 0; f0 < nf; f0 += 64) {
             LaneVar<uint64_t> m2v, hcv;
@@ -600,8 +632,76 @@ struct TopoEngine {
           }
           if (bail) { status = 3; break; }
         } else {
+          const int wfull = n < 64 ? n : 64;
+          if (!wvalid || (wn < kRefill && wn < wfull)) {
+            // ---- (re)read the window: the claims at positions 0 .. 63 from the rings, then their records ----
+            fence();
+            int k = 1; uint32_t i = 0;
+            int filled = 0;
+            bool done = false;
+            LaneVar<uint32_t> xv;
+            W::each([&](int l) { xv.at(l) = 0; });
+            while (!done && filled < 64 && k <= max_cnt) {
+              if (k + 16 >= kRunMaxCount) { bail = 62; break; }   // (a run beyond the LDS ring tables at the front of the order: not this engine's shape)
+              LaneVar<uint32_t> eh, es, eo, em;
+              const int kb = k;
+              W::each([&](int l) {
+                const int kk = kb + (l & 15);
+                const RunEnt e = lds_get16(&RT->e[kk]);
+                eh.at(l) = e.head; es.at(l) = e.size; eo.at(l) = e.off; em.at(l) = (1u << RT->log2cap[kk]) - 1u;
+              });
+              for (int j = 0; j < 16 && k <= max_cnt; ++j) {
+                const uint32_t sz = es.bcast(j);
+                if (i < sz) {
+                  const uint32_t left = sz - i;
+                  const int take = left < (uint32_t)(64 - filled) ? (int)left : 64 - filled;
+                  const uint32_t h = eh.bcast(j), m = em.bcast(j), o = eo.bcast(j), i0 = i;
+                  const int f0 = filled;
+                  W::each([&](int l) { if (l >= f0 && l < f0 + take) xv.at(l) = ring[o + ((h + i0 + (uint32_t)(l - f0)) & m)]; });
+                  filled += take;
+                  i += (uint32_t)take;
+                  if (i < sz || filled >= 64) { done = true; break; }
+                }
+                k++; i = 0;
+              }
+            }
+            if (bail) { status = 3; break; }
+            const int fl = filled;
+            W::each([&](int l) {
+              const uint32_t x = xv.shuffle(l, l < fl ? l : (fl > 0 ? fl - 1 : 0));   // (lanes past the order's end read the last claim again: no lane is switched off for the loads)
+              const TopoRec r = load_rec(rec + x);
+              wx.at(l) = x; wc.at(l) = ocnt[x]; wv.at(l) = r.vmask; wh.at(l) = r.hcnt;
+              wq0.at(l) = r.req[0]; wq1.at(l) = r.req[1]; wq2.at(l) = r.req[2]; wq3.at(l) = r.req[3];
+            });
+            wn = filled; wvalid = true;
+            windows++;
+          }
+          KS_TSEC(t3)
+          {
+            // ---- CanAdd on the window's claims, from registers ----
+            LaneVar<uint64_t> m2v;
+            uint64_t okm = 0, und = 0;
+            const int lim = wn;
+            W::ballot2([&](int l) {
+              uint64_t m2;
+              const int v = lane_test(wv.at(l), wq0.at(l), wq1.at(l), wq2.at(l), wq3.at(l), wh.at(l), kc, zc, zkv, ent, m2);
+              m2v.at(l) = m2;
+              return l < lim ? v : 0;
+            }, okm, und);
+            KS_TSEC(t4)
+            const uint64_t before = okm ? (und & ((1ull << ctz64(okm)) - 1)) : und;
+            if (before) { fence(); push(); okm |= resolve(before, m2v, wq0, wq1, wq2, wq3, kc.s0, kc.s1, kc.s2, kc.s3); pull(); if (bail) { status = 3; break; } }
+            if (okm) {
+              const int a = ctz64(okm);
+              found = true; from_window = true; a_pos = (uint32_t)a;
+              kx = wx.bcast(a); km = m2v.bcast(a); kh = wh.bcast(a); kcn = wc.bcast(a);
+              k0 = wq0.bcast(a); k1 = wq1.bcast(a); k2 = wq2.bcast(a); k3 = wq3.bcast(a);
+            }
+          }
+          // ---- no acceptor inside the window and the order goes on beyond it: the rings and the records, 64 positions per step ----
           int k = 1; uint32_t i = 0;
-          for (int p0 = 0; p0 < n; p0 += 64) {
+          if (!found && wn < n) fence();
+          for (int p0 = 0; !found && wn < n && p0 < n; p0 += 64) {
             // ---- the claims at positions p0 .. p0+63, one per lane: the table records of sixteen runs in one LDS round trip ----
             LaneVar<uint32_t> xv;
             W::each([&](int l) { xv.at(l) = 0xFFFFFFFFu; });
@@ -702,7 +802,15 @@ struct TopoEngine {
               }
               oclaim.set(bi, (uint32_t)c); ocntv.set(bi, 0u);
               set_last(2, c, 0);
-              W::sync();
+              dirty = true;
+              if (wvalid) {
+                // the window: the new claim stands at position b = the claims with one pod in front of it; the claims from b on step right
+                const int b = fast_uniform((int)e1.size);
+                if (b <= wn) {
+                  wmove([&](int l) { return l > b ? l - 1 : l; }, b, (uint32_t)c, 1u, m2, nrq.hcnt, kc.s0, kc.s1, kc.s2, kc.s3);
+                  if (wn < 64) wn++;
+                }
+              }
               made = true;
             }
           }
@@ -710,8 +818,9 @@ struct TopoEngine {
             push();
             TopoClass tcc; tcc.hlim = kc.hlim; tcc.hinc = hinc; tcc.zsel = zsel; tcc.zg = zg; tcc.zself = zself ? 1u : 0u; tcc.excl = excl; tcc.pad = 0;
             FastSlot csc; csc.cvmask = kc.cvmask; csc.dmask = kc.dmask; csc.size[0] = kc.s0; csc.size[1] = kc.s1; csc.size[2] = kc.s2; csc.size[3] = kc.s3; csc.tmplok = kc.tmplok; csc.kdef = 0;
+            fence();
             const int c = fast_uniform(new_claim(tcc, csc));
-            pull();
+            pull(); wvalid = false;
             if (c < 0) { status = fast_uniform(bail) < 0 ? 1 : 3; break; }
             oclaim.set(bi, (uint32_t)c); ocntv.set(bi, 0u);
           }
@@ -725,13 +834,14 @@ struct TopoEngine {
         nrq.req[0] = k0 + kc.s0; nrq.req[1] = k1 + kc.s1; nrq.req[2] = k2 + kc.s2; nrq.req[3] = k3 + kc.s3;
         nrq.hcnt = host_add(kh, hinc);
         if (W::leader()) store_rec(rec + kx, nrq);
+        dirty = true;
         oclaim.set(bi, kx); ocntv.set(bi, kcn);
         record_zonal(zsel, km);
         // the anti-affinity lists: the claim leaves those whose counter this pod takes from zero
         {
           const uint64_t zero_before = ~(kh | (kh >> 1) | (kh >> 2)) & kTopoOnes;
           const uint64_t leaving = hinc & zero_before & trk;
-          if (leaving) { push(); lists_remove(leaving, kx); pull(); }
+          if (leaving) { push(); lists_remove(leaving, kx); pull(); }   // (LDS only)
         }
         KS_TSEC(t7)
         // The sort.Slice of the NEXT add (scheduler.go:598) moves this claim behind the claims with fewer pods. When that is pdqsort's
@@ -759,8 +869,13 @@ struct TopoEngine {
             bool ok_shift = true;
             if (idx == 0) new_head = (h + 1) & m;
             else if (idx + 1 < sz) {
-              if (idx <= sz - 1 - idx && idx <= 64) {
-                // the claims in front of it step one ring slot towards the hole (at most 64 of them: one round, read before written)
+              if (from_window) {
+                // the claims in front of it inside its run are window lanes: they step one ring slot towards the hole, from registers
+                const uint32_t pk = a_pos - idx;
+                W::each([&](int l) { if ((uint32_t)l >= pk && (uint32_t)l < a_pos) { const uint32_t s = (h + ((uint32_t)l - pk) + 1u) & m; ring[oa + s] = wx.at(l); oslot[wx.at(l)] = s; } });
+                new_head = (h + 1) & m;
+              } else if (idx <= sz - 1 - idx && idx <= 64) {
+                // (found beyond the window: at most 64 claims in front of it, one round, read before written)
                 LaneVar<uint32_t> mv;
                 W::each([&](int l) { mv.at(l) = (uint32_t)l < idx ? ring[oa + ((h + (uint32_t)l) & m)] : 0u; });
                 W::each([&](int l) { if ((uint32_t)l < idx) { const uint32_t s = (h + (uint32_t)l + 1u) & m; ring[oa + s] = mv.at(l); oslot[mv.at(l)] = s; } });
@@ -781,11 +896,19 @@ struct TopoEngine {
               }
               set_last(1, (int)kx, (int)a_pos);
               moved = true;
-              W::sync();
+              dirty = true;
+              if (from_window) {
+                // the window: the claims behind the acceptor, up to its new place q, step one position to the left; it re-enters at q
+                // when q lies inside the window, otherwise the window is one claim shorter
+                const int a = (int)a_pos, q = (int)pb - 1;
+                const bool inside = q < wn;
+                wmove([&](int l) { return (l >= a && l < q) ? l + 1 : l; }, inside ? q : -1, kx, (uint32_t)(k + 1), nrq.vmask, nrq.hcnt, nrq.req[0], nrq.req[1], nrq.req[2], nrq.req[3]);
+                if (!inside) wn--;
+              } else wvalid = false;
             }
           }
           if (!moved) {
-            push(); move_cold((int)kx, k, a_pos); pull();
+            fence(); push(); move_cold((int)kx, k, a_pos); pull(); wvalid = false;
             if (fast_uniform((int)order.overflow)) { status = 1; break; }
           }
         }

@@ -350,9 +350,16 @@ struct LaneVar {
   }
   // this lane reads lane `src`'s value (ds_bpermute_b32: the LDS crossbar, no LDS memory); `src` may differ per lane
   KS_DEV T shuffle(int, int src) const {
-    static_assert(sizeof(T) == 4, "LaneVar::shuffle: 32-bit values");
-    const int x = __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, v));
-    return __builtin_bit_cast(T, x);
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "LaneVar::shuffle: 32- or 64-bit values");
+    if constexpr (sizeof(T) == 4) {
+      const int x = __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, v));
+      return __builtin_bit_cast(T, x);
+    } else {
+      const uint64_t u = __builtin_bit_cast(uint64_t, v);
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)u);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)(u >> 32));
+      return __builtin_bit_cast(T, (uint64_t)lo | ((uint64_t)hi << 32));
+    }
   }
   KS_DEV T bcast(int lane) const {
     static_assert(sizeof(T) == 4 || sizeof(T) == 8, "LaneVar: 32- or 64-bit values");
