@@ -625,17 +625,19 @@ static void be_launch_claim_gather(ksolve_handle* h, int n, const ks::ClaimGathe
 static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, ks::Workspace* d_items, int n, const ks::LdsPlan& plan, const uint32_t* d_order, uint32_t* d_next) {
   if (n <= 0) return;
   HipBackend* b = HB(h);
-  if (!hip_check(h, hipFuncSetAttribute((const void*)ksolve_pack_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, plan.total_bytes), "hipFuncSetAttribute(LDS)")) return;
+  const int lds1 = ((plan.total_bytes + 15) & ~15) + ks::kSweepLdsExtra;   // + the view and one workspace record (ksolve_pack_sweep)
+  if (!hip_check(h, hipFuncSetAttribute((const void*)ksolve_pack_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, lds1), "hipFuncSetAttribute(LDS)")) return;
   if (plan.waves == 4) {
     // the compact form: as many workgroups as the chip holds at once (two per CU by registers, fewer when their LDS is large), each
     // wavefront striding over the probes — the shared tables and the template prefilter are paid once per workgroup
-    if (!hip_check(h, hipFuncSetAttribute((const void*)ksolve_pack_sweep4, hipFuncAttributeMaxDynamicSharedMemorySize, plan.total_bytes), "hipFuncSetAttribute(LDS)")) return;
-    int per_cu = (160 * 1024) / (plan.total_bytes + 256);
+    const int lds4 = ((plan.total_bytes + 15) & ~15) + ks::kSweepLdsExtra;   // + the view and the workspace records (ksolve_pack_sweep4)
+    if (!hip_check(h, hipFuncSetAttribute((const void*)ksolve_pack_sweep4, hipFuncAttributeMaxDynamicSharedMemorySize, lds4), "hipFuncSetAttribute(LDS)")) return;
+    int per_cu = (160 * 1024) / (lds4 + 256);
     per_cu = per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu;
     const int resident = b->n_cus * per_cu, want = (n + 3) / 4;
     const int grid4 = want < resident ? want : resident;
     hip_check(h, hipEventRecord(b->ev0[ksi::T_PACK], b->stream), "hipEventRecord");
-    hipLaunchKernelGGL(ksolve_pack_sweep4, dim3((unsigned)grid4), dim3(256), (size_t)plan.total_bytes, b->stream, d_pv, d_items, n, plan, d_order, d_next);
+    hipLaunchKernelGGL(ksolve_pack_sweep4, dim3((unsigned)grid4), dim3(256), (size_t)lds4, b->stream, d_pv, d_items, n, plan, d_order, d_next);
     hip_check(h, hipGetLastError(), "ksolve_pack_sweep4 launch");
     hip_check(h, hipEventRecord(b->ev1[ksi::T_PACK], b->stream), "hipEventRecord");
     hip_check(h, hipEventSynchronize(b->ev1[ksi::T_PACK]), "hipEventSynchronize");
@@ -645,7 +647,7 @@ static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, 
   }
   const int grid = n < 8192 ? n : 8192;
   hip_check(h, hipEventRecord(b->ev0[ksi::T_PACK], b->stream), "hipEventRecord");
-  hipLaunchKernelGGL(ksolve_pack_sweep, dim3((unsigned)grid), dim3(64), (size_t)plan.total_bytes, b->stream, d_pv, d_items, n, plan);
+  hipLaunchKernelGGL(ksolve_pack_sweep, dim3((unsigned)grid), dim3(64), (size_t)lds1, b->stream, d_pv, d_items, n, plan);
   hip_check(h, hipGetLastError(), "ksolve_pack_sweep launch");
   hip_check(h, hipEventRecord(b->ev1[ksi::T_PACK], b->stream), "hipEventRecord");
   hip_check(h, hipEventSynchronize(b->ev1[ksi::T_PACK]), "hipEventSynchronize");
@@ -736,7 +738,7 @@ static void launch_batch_group(std::vector<ksolve_handle*>& g, bool lite, ks::Ba
   HipBackend* b = HB(h0);
   std::vector<ks::BatchItem> items(g.size());
   int lds_bytes = 0;
-  for (size_t i = 0; i < g.size(); ++i) { items[i].pv = g[i]->pv; items[i].ws = g[i]->ws; lds_bytes = std::max(lds_bytes, g[i]->pv.lds.total_bytes); }
+  for (size_t i = 0; i < g.size(); ++i) { items[i].pv = g[i]->pv; items[i].ws = g[i]->ws; lds_bytes = std::max(lds_bytes, ((g[i]->pv.lds.total_bytes + 15) & ~15) + ks::kSweepLdsExtra); }   // + the block's copy of its view and workspace record
   ks::BatchItem* d_items = nullptr;
   if (!hip_check(h0, hipMalloc((void**)&d_items, items.size() * sizeof(ks::BatchItem)), "hipMalloc(batch)")) return;
   *d_items_out = d_items;

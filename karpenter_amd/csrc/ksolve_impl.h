@@ -644,7 +644,7 @@ static ksolve_status create(const ksolve_problem_desc* d, const ksolve_options* 
       const size_t tb = al8(G) * 4 + al8(G * 4) * 3 + al8(G * 2) + al8((G + 1) * 4) + al8(G * 8) + al8(G * dw * 8) + al8(G * dw * 64 * 4) + al8(G * 4) + 64;
       if (tb <= 24 * 1024) { lp.off_topo = off; lp.topo_bytes = (int)tb; off = align(off + (int)tb); }
     }
-    const int budget = 160 * 1024 - 512;
+    const int budget = 160 * 1024 - 512 - ks::kSweepLdsExtra;   // (the batched and sweep kernels keep the view and a workspace record behind the plan: ksolve_pack_batch.hip)
     if (off + 13 * 64 > budget) return fail(h, KSOLVE_ERR_UNSUPPORTED, "instance-type tables do not fit the 160 KiB LDS of one CU");
     // the claim order (12 B per claim) and the closed bitmap (1 bit per claim) get what is left
     int cap = (int)(((long long)(budget - off) * 8) / (12 * 8 + 1));
@@ -1304,7 +1304,7 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
       c.off_stage = so; c.stage_words = 0;
       c.waves = 4; c.wave_stride = so - w0;
       c.total_bytes = w0 + c.waves * c.wave_stride;
-      if (c.total_bytes <= 160 * 1024 - 512) lp = c;
+      if (c.total_bytes + ks::kSweepLdsExtra + 16 <= 160 * 1024 - 512) lp = c;
     }
   }
   // ---- arena: every probe's workspace, carved in two passes (measure, then assign) ----

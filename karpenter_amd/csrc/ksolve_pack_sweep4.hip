@@ -6,6 +6,10 @@
 // workgroup's only barrier); every wavefront keeps a ScratchSmall working set. 256 VGPRs per wavefront (two wavefronts per
 // SIMD): eight probes per CU in flight instead of four — the probes are chains of dependent steps, so a launch goes as fast as
 // the number of them the chip holds at once. Wave w of block b runs probes 4b + w, 4b + w + 4 * gridDim.x, ...
+// (round 6) The cluster's view and each probe's workspace record are copied into LDS before an engine is built on them: the engine
+// reads their fields (table pointers, sizes, option flags) all through a probe, and from HBM every such read was a vector load with
+// an L2 round trip in front of its use — the records are wave-uniform, but the compiler cannot scalarise loads through a pointer it
+// cannot prove read-only. ks::kSweepLdsExtra bytes behind the plan's own: the view once per workgroup, a workspace per wavefront.
 __global__ void __launch_bounds__(256, 2) ksolve_pack_sweep4(const ks::ProblemView* pv, ks::Workspace* items, int n, ks::LdsPlan plan, const uint32_t* order, uint32_t* next) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef ks::Engine<ks::Wave, true, false, ks::ScratchSmall> Eng;
@@ -13,6 +17,23 @@ __global__ void __launch_bounds__(256, 2) ksolve_pack_sweep4(const ks::ProblemVi
   ks::LdsTables tables;
   tables.bind(lds, plan, wave);
   uint32_t* misc = (uint32_t*)(lds + plan.off_shared_misc);
+  char* const extra = lds + ((plan.total_bytes + 15) & ~15);
+  ks::ProblemView* const lpv = (ks::ProblemView*)extra;
+  ks::Workspace* const lws = (ks::Workspace*)(extra + ((sizeof(ks::ProblemView) + 15) & ~(size_t)15) + (size_t)wave * ((sizeof(ks::Workspace) + 15) & ~(size_t)15));
+  static_assert(((sizeof(ks::ProblemView) + 15) & ~(size_t)15) + 4 * ((sizeof(ks::Workspace) + 15) & ~(size_t)15) <= (size_t)ks::kSweepLdsExtra, "kSweepLdsExtra");
+  {
+    const uint64_t* src = (const uint64_t*)pv;
+    uint64_t* dst = (uint64_t*)lpv;
+    for (int i = (int)threadIdx.x; i < (int)(sizeof(ks::ProblemView) / 8); i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  auto take = [&](int p) {   // probe p's workspace record into this wavefront's LDS copy
+    const uint64_t* src = (const uint64_t*)(items + p);
+    uint64_t* dst = (uint64_t*)lws;
+    for (int i = (int)(threadIdx.x & 63); i < (int)(sizeof(ks::Workspace) / 8); i += 64) dst[i] = src[i];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
   // The probes are handed out through one counter, in `order` (most displaced pods first): a wavefront that is free takes the next
   // one. With a fixed share per wavefront the launch lasted as long as its unluckiest wavefront — 2.9 ms where the mean work of
   // 2048 wavefronts over 10,000 probes is 1.9 ms. Which wavefront runs a probe does not touch its result: probes share nothing
@@ -27,7 +48,8 @@ __global__ void __launch_bounds__(256, 2) ksolve_pack_sweep4(const ks::ProblemVi
   if (wave == 0) {
     p = fetch();
     if (p >= 0) {
-      Eng eng(*pv, items[p], tables);   // this probe's workspace lends its per-template arrays; the wavefront solves it next
+      take(p);
+      Eng eng(*lpv, *lws, tables);   // this probe's workspace lends its per-template arrays; the wavefront solves it next
       const uint32_t active = eng.prepare();
       if ((threadIdx.x & 63) == 0) misc[0] = active;
     }
@@ -36,7 +58,8 @@ __global__ void __launch_bounds__(256, 2) ksolve_pack_sweep4(const ks::ProblemVi
   const uint32_t active = (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[0]);
   if (wave != 0) p = fetch();
   while (p >= 0) {
-    Eng eng(*pv, items[p], tables);
+    take(p);
+    Eng eng(*lpv, *lws, tables);
     eng.solve(&active);
     p = fetch();
   }

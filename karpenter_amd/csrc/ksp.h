@@ -315,6 +315,8 @@ struct Workspace {
   Counters* counters;
 };
 
+constexpr int kSweepLdsExtra = 4096;   // LDS behind the compact sweep's plan: the cluster's view once per workgroup + a workspace record per wavefront (ksolve_pack_sweep4)
+
 struct BatchItem {  // one scheduling problem of a batched pack launch
   ProblemView pv;
   Workspace ws;
