@@ -398,6 +398,147 @@ struct TopoEngine {
       W::sync();
     }
   }
+  // ---- the select step's rare forms, out of line (by value in, by value out: nothing of the loop's registers is pinned) ----
+  struct Accept { int found; uint32_t x, pos, cnt; uint64_t m2, hcnt; int32_t q0, q1, q2, q3; };
+  struct Win { LaneVar<uint32_t> x, c; LaneVar<uint64_t> v, h; LaneVar<int32_t> q0, q1, q2, q3; int n; };
+  // every member of an anti-affinity group the class owns needs a claim without one: the claims of list t — those that hold none yet,
+  // wherever they stand in the order — and among those that accept the one at the lowest position
+  KS_COLD Accept scan_list(int t, KClass kc, ZChoice zc, LaneVar<uint64_t> zkv) {
+    Accept A; A.found = 0; A.x = 0; A.pos = 0; A.cnt = 0; A.m2 = 0; A.hcnt = 0; A.q0 = A.q1 = A.q2 = A.q3 = 0;
+    KS_LDS TopoState* const S_ = st;
+    KS_LDS RunTables* const RT = order.T;
+    const KS_GLOBAL TopoRec* const rec = (const KS_GLOBAL TopoRec*)Tk->rec;
+    const KS_GLOBAL uint32_t* const ocnt = (const KS_GLOBAL uint32_t*)order.cnt;
+    const KS_GLOBAL uint32_t* const oslot = (const KS_GLOBAL uint32_t*)order.slot;
+    const KS_LDS FastEnt* const ent = cold.ent;
+    const int nf = (int)W::uniform((uint64_t)(uint32_t)S_->n_free[t]);
+    uint32_t best_pos = 0xFFFFFFFFu;
+    for (int f0 = 0; f0 < nf; f0 += 64) {
+      LaneVar<uint64_t> m2v, hcv;
+      LaneVar<uint32_t> xv, pv, cv;
+      LaneVar<int32_t> q0, q1, q2, q3;
+      uint64_t okm = 0, und = 0;
+      W::ballot2([&](int l) {
+        const uint32_t x = S_->freel[t][f0 + l < nf ? f0 + l : nf - 1];
+        const TopoRec r = load_rec(rec + x);
+        const uint32_t c = ocnt[x], sl = oslot[x];
+        uint64_t m2;
+        const int v = lane_test(r.vmask, r.req[0], r.req[1], r.req[2], r.req[3], r.hcnt, kc, zc, zkv, ent, m2);
+        // position = the run's first position + the claim's index inside the run (run_order.h)
+        const RunEnt e = lds_get16(&RT->e[c < (uint32_t)kRunMaxCount ? c : 0]);
+        const uint32_t mk = (1u << RT->log2cap[c < (uint32_t)kRunMaxCount ? c : 0]) - 1u;
+        xv.at(l) = x; m2v.at(l) = m2; hcv.at(l) = r.hcnt; cv.at(l) = c;
+        pv.at(l) = (f0 + l < nf && c < (uint32_t)kRunMaxCount) ? e.prefix + ((sl - e.head) & mk) : 0xFFFFFFFFu;
+        q0.at(l) = r.req[0]; q1.at(l) = r.req[1]; q2.at(l) = r.req[2]; q3.at(l) = r.req[3];
+        return f0 + l < nf ? v : 0;
+      }, okm, und);
+      if (W::ballot([&](int l) { return f0 + l < nf && cv.at(l) >= (uint32_t)kRunMaxCount; })) { bail = 61; return A; }   // (a claim beyond the LDS ring tables in a list: not this engine's shape)
+      if (und) { okm |= resolve(und, m2v, q0, q1, q2, q3, kc.s0, kc.s1, kc.s2, kc.s3); if (bail) return A; }
+      if (okm) {
+        int who = -1;
+        const uint64_t om = okm;
+        const uint32_t p = W::argmin_u32([&](int l) { return ((om >> l) & 1) ? pv.at(l) : 0xFFFFFFFFu; }, &who);
+        if (p < best_pos) {
+          best_pos = p; A.found = 1; A.pos = p;
+          A.x = xv.bcast(who); A.m2 = m2v.bcast(who); A.hcnt = hcv.bcast(who); A.cnt = cv.bcast(who);
+          A.q0 = q0.bcast(who); A.q1 = q1.bcast(who); A.q2 = q2.bcast(who); A.q3 = q3.bcast(who);
+        }
+      }
+    }
+    return A;
+  }
+  // the claims at positions p0 .. p0+63 of the order, one per lane (0 past the end), `filled` of them; (k, i) = run and index inside
+  // it of position p0, moved on to p0 + 64. The table records of sixteen runs come in one LDS round trip (one lane each).
+  KS_DEV int order_window(int& k, uint32_t& i, LaneVar<uint32_t>& xv) {
+    KS_LDS RunTables* const RT = order.T;
+    const KS_GLOBAL uint32_t* const ring = (const KS_GLOBAL uint32_t*)order.ring;
+    const int max_cnt = order.max_cnt;
+    int filled = 0;
+    bool done = false;
+    W::each([&](int l) { xv.at(l) = 0; });
+    while (!done && filled < 64 && k <= max_cnt) {
+      if (k + 16 >= kRunMaxCount) { bail = 62; return filled; }   // (a run beyond the LDS ring tables at the front of the order: not this engine's shape)
+      LaneVar<uint32_t> eh, es, eo, em;
+      const int kb = k;
+      W::each([&](int l) {
+        const int kk = kb + (l & 15);
+        const RunEnt e = lds_get16(&RT->e[kk]);
+        eh.at(l) = e.head; es.at(l) = e.size; eo.at(l) = e.off; em.at(l) = (1u << RT->log2cap[kk]) - 1u;
+      });
+      for (int j = 0; j < 16 && k <= max_cnt; ++j) {
+        const uint32_t sz = es.bcast(j);
+        if (i < sz) {
+          const uint32_t left = sz - i;
+          const int take = left < (uint32_t)(64 - filled) ? (int)left : 64 - filled;
+          const uint32_t h = eh.bcast(j), m = em.bcast(j), o = eo.bcast(j), i0 = i;
+          const int f0 = filled;
+          W::each([&](int l) { if (l >= f0 && l < f0 + take) xv.at(l) = ring[o + ((h + i0 + (uint32_t)(l - f0)) & m)]; });
+          filled += take;
+          i += (uint32_t)take;
+          if (i < sz || filled >= 64) { done = true; break; }
+        }
+        k++; i = 0;
+      }
+    }
+    return filled;
+  }
+  // the front of the order with its records, for the loop's window registers
+  KS_COLD Win read_window() {
+    Win w;
+    const KS_GLOBAL TopoRec* const rec = (const KS_GLOBAL TopoRec*)Tk->rec;
+    const KS_GLOBAL uint32_t* const ocnt = (const KS_GLOBAL uint32_t*)order.cnt;
+    int k = 1; uint32_t i = 0;
+    LaneVar<uint32_t> xv;
+    const int fl = order_window(k, i, xv);
+    W::each([&](int l) {
+      const uint32_t x = xv.shuffle(l, l < fl ? l : (fl > 0 ? fl - 1 : 0));   // (lanes past the order's end read the last claim again: no lane is switched off for the loads)
+      const TopoRec r = load_rec(rec + x);
+      w.x.at(l) = x; w.c.at(l) = ocnt[x]; w.v.at(l) = r.vmask; w.h.at(l) = r.hcnt;
+      w.q0.at(l) = r.req[0]; w.q1.at(l) = r.req[1]; w.q2.at(l) = r.req[2]; w.q3.at(l) = r.req[3];
+    });
+    w.n = fl;
+    return w;
+  }
+  // no acceptor inside the window and the order goes on beyond it: the rings and the records, 64 positions per step, from the front
+  KS_COLD Accept scan_order(KClass kc, ZChoice zc, LaneVar<uint64_t> zkv) {
+    Accept A; A.found = 0; A.x = 0; A.pos = 0; A.cnt = 0; A.m2 = 0; A.hcnt = 0; A.q0 = A.q1 = A.q2 = A.q3 = 0;
+    const KS_GLOBAL TopoRec* const rec = (const KS_GLOBAL TopoRec*)Tk->rec;
+    const KS_GLOBAL uint32_t* const ocnt = (const KS_GLOBAL uint32_t*)order.cnt;
+    const KS_LDS FastEnt* const ent = cold.ent;
+    const int n = order.n;
+    int k = 1; uint32_t i = 0;
+    for (int p0 = 0; p0 < n; p0 += 64) {
+      LaneVar<uint32_t> xv;
+      const int fl = order_window(k, i, xv);
+      if (bail) return A;
+      n_windows++;
+      LaneVar<uint64_t> m2v, hcv;
+      LaneVar<uint32_t> cv;
+      LaneVar<int32_t> q0, q1, q2, q3;
+      uint64_t okm = 0, und = 0;
+      W::ballot2([&](int l) {
+        const uint32_t x = xv.shuffle(l, l < fl ? l : (fl > 0 ? fl - 1 : 0));
+        const TopoRec r = load_rec(rec + x);
+        const uint32_t c = ocnt[x];
+        uint64_t m2;
+        const int v = lane_test(r.vmask, r.req[0], r.req[1], r.req[2], r.req[3], r.hcnt, kc, zc, zkv, ent, m2);
+        m2v.at(l) = m2; hcv.at(l) = r.hcnt; cv.at(l) = c;
+        q0.at(l) = r.req[0]; q1.at(l) = r.req[1]; q2.at(l) = r.req[2]; q3.at(l) = r.req[3];
+        return l < fl ? v : 0;
+      }, okm, und);
+      // the lanes in front of the first plain acceptor whose requirement set is not at its first probe: the long way
+      const uint64_t before = okm ? (und & ((1ull << ctz64(okm)) - 1)) : und;
+      if (before) { okm |= resolve(before, m2v, q0, q1, q2, q3, kc.s0, kc.s1, kc.s2, kc.s3); if (bail) return A; }
+      if (okm) {
+        const int a = ctz64(okm);
+        A.found = 1; A.pos = (uint32_t)(p0 + a);
+        A.x = xv.bcast(a); A.m2 = m2v.bcast(a); A.hcnt = hcv.bcast(a); A.cnt = cv.bcast(a);
+        A.q0 = q0.bcast(a); A.q1 = q1.bcast(a); A.q2 = q2.bcast(a); A.q3 = q3.bcast(a);
+        return A;
+      }
+    }
+    return A;
+  }
   KS_COLD void sort_cold() { order.sort(); }
 
   KS_COLD void finish(int status, unsigned long long steps) {
@@ -592,88 +733,27 @@ struct TopoEngine {
         bool from_window = false;   // the acceptor is lane a_pos of the window registers
         const bool listed = excl != 0xFFu && fast_uniform((int)S_->track_field[excl & (kTopoTrack - 1)]) != 0xFF;
         if (listed) {
-          // every member of an anti-affinity group it owns needs a claim without one: the claims that hold none yet, wherever they
-          // stand in the order — the lowest position among those that accept
-          const int t = (int)excl;
-          const int nf = fast_uniform((int)S_->n_free[t]);
-          if (nf) fence();
-          uint32_t best_pos = 0xFFFFFFFFu;
-          for (int f0 = 0; f0 < nf; f0 += 64) {
-            LaneVar<uint64_t> m2v, hcv;
-            LaneVar<uint32_t> xv, pv, cv;
-            LaneVar<int32_t> q0, q1, q2, q3;
-            uint64_t okm = 0, und = 0;
-            W::ballot2([&](int l) {
-              const uint32_t x = S_->freel[t][f0 + l < nf ? f0 + l : nf - 1];
-              const TopoRec r = load_rec(rec + x);
-              const uint32_t c = ocnt[x], sl = oslot[x];
-              uint64_t m2;
-              const int v = lane_test(r.vmask, r.req[0], r.req[1], r.req[2], r.req[3], r.hcnt, kc, zc, zkv, ent, m2);
-              // position = the run's first position + the claim's index inside the run (run_order.h)
-              const RunEnt e = lds_get16(&RT->e[c < (uint32_t)kRunMaxCount ? c : 0]);
-              const uint32_t mk = (1u << RT->log2cap[c < (uint32_t)kRunMaxCount ? c : 0]) - 1u;
-              xv.at(l) = x; m2v.at(l) = m2; hcv.at(l) = r.hcnt; cv.at(l) = c;
-              pv.at(l) = (f0 + l < nf && c < (uint32_t)kRunMaxCount) ? e.prefix + ((sl - e.head) & mk) : 0xFFFFFFFFu;
-              q0.at(l) = r.req[0]; q1.at(l) = r.req[1]; q2.at(l) = r.req[2]; q3.at(l) = r.req[3];
-              return f0 + l < nf ? v : 0;
-            }, okm, und);
-            if (W::ballot([&](int l) { return f0 + l < nf && cv.at(l) >= (uint32_t)kRunMaxCount; })) { bail = 61; break; }   // (a claim beyond the LDS ring tables in a list: not this engine's shape)
-            if (und) { push(); okm |= resolve(und, m2v, q0, q1, q2, q3, kc.s0, kc.s1, kc.s2, kc.s3); pull(); if (bail) break; }
-            if (okm) {
-              int who = -1;
-              const uint64_t om = okm;
-              const uint32_t p = W::argmin_u32([&](int l) { return ((om >> l) & 1) ? pv.at(l) : 0xFFFFFFFFu; }, &who);
-              if (p < best_pos) {
-                best_pos = p; found = true; a_pos = p;
-                kx = xv.bcast(who); km = m2v.bcast(who); kh = hcv.bcast(who); kcn = cv.bcast(who);
-                k0 = q0.bcast(who); k1 = q1.bcast(who); k2 = q2.bcast(who); k3 = q3.bcast(who);
-              }
+          // (usually nobody is on the list: every claim holds a member already — straight to addToNewNodeClaim)
+          if (fast_uniform((int)S_->n_free[excl & (kTopoTrack - 1)]) > 0) {
+            fence(); push();
+            const Accept A = scan_list((int)excl, kc, zc, zkv);
+            pull();
+            if (fast_uniform(bail)) { status = 3; break; }
+            if (fast_uniform(A.found)) {
+              found = true; a_pos = (uint32_t)fast_uniform((int)A.pos); kx = (uint32_t)fast_uniform((int)A.x); kcn = (uint32_t)fast_uniform((int)A.cnt);
+              km = W::uniform(A.m2); kh = W::uniform(A.hcnt); k0 = fast_uniform(A.q0); k1 = fast_uniform(A.q1); k2 = fast_uniform(A.q2); k3 = fast_uniform(A.q3);
             }
           }
-          if (bail) { status = 3; break; }
         } else {
           const int wfull = n < 64 ? n : 64;
           if (!wvalid || (wn < kRefill && wn < wfull)) {
             // ---- (re)read the window: the claims at positions 0 .. 63 from the rings, then their records ----
-            fence();
-            int k = 1; uint32_t i = 0;
-            int filled = 0;
-            bool done = false;
-            LaneVar<uint32_t> xv;
-            W::each([&](int l) { xv.at(l) = 0; });
-            while (!done && filled < 64 && k <= max_cnt) {
-              if (k + 16 >= kRunMaxCount) { bail = 62; break; }   // (a run beyond the LDS ring tables at the front of the order: not this engine's shape)
-              LaneVar<uint32_t> eh, es, eo, em;
-              const int kb = k;
-              W::each([&](int l) {
-                const int kk = kb + (l & 15);
-                const RunEnt e = lds_get16(&RT->e[kk]);
-                eh.at(l) = e.head; es.at(l) = e.size; eo.at(l) = e.off; em.at(l) = (1u << RT->log2cap[kk]) - 1u;
-              });
-              for (int j = 0; j < 16 && k <= max_cnt; ++j) {
-                const uint32_t sz = es.bcast(j);
-                if (i < sz) {
-                  const uint32_t left = sz - i;
-                  const int take = left < (uint32_t)(64 - filled) ? (int)left : 64 - filled;
-                  const uint32_t h = eh.bcast(j), m = em.bcast(j), o = eo.bcast(j), i0 = i;
-                  const int f0 = filled;
-                  W::each([&](int l) { if (l >= f0 && l < f0 + take) xv.at(l) = ring[o + ((h + i0 + (uint32_t)(l - f0)) & m)]; });
-                  filled += take;
-                  i += (uint32_t)take;
-                  if (i < sz || filled >= 64) { done = true; break; }
-                }
-                k++; i = 0;
-              }
-            }
-            if (bail) { status = 3; break; }
-            const int fl = filled;
-            W::each([&](int l) {
-              const uint32_t x = xv.shuffle(l, l < fl ? l : (fl > 0 ? fl - 1 : 0));   // (lanes past the order's end read the last claim again: no lane is switched off for the loads)
-              const TopoRec r = load_rec(rec + x);
-              wx.at(l) = x; wc.at(l) = ocnt[x]; wv.at(l) = r.vmask; wh.at(l) = r.hcnt;
-              wq0.at(l) = r.req[0]; wq1.at(l) = r.req[1]; wq2.at(l) = r.req[2]; wq3.at(l) = r.req[3];
-            });
-            wn = filled; wvalid = true;
+            fence(); push();
+            Win w = read_window();
+            pull();
+            if (fast_uniform(bail)) { status = 3; break; }
+            W::each([&](int l) { wx.at(l) = w.x.at(l); wc.at(l) = w.c.at(l); wv.at(l) = w.v.at(l); wh.at(l) = w.h.at(l); wq0.at(l) = w.q0.at(l); wq1.at(l) = w.q1.at(l); wq2.at(l) = w.q2.at(l); wq3.at(l) = w.q3.at(l); });
+            wn = fast_uniform(w.n); wvalid = true;
             windows++;
           }
           KS_TSEC(t3)
@@ -690,7 +770,7 @@ struct TopoEngine {
             }, okm, und);
             KS_TSEC(t4)
             const uint64_t before = okm ? (und & ((1ull << ctz64(okm)) - 1)) : und;
-            if (before) { fence(); push(); okm |= resolve(before, m2v, wq0, wq1, wq2, wq3, kc.s0, kc.s1, kc.s2, kc.s3); pull(); if (bail) { status = 3; break; } }
+            if (before) { fence(); push(); okm |= resolve(before, m2v, wq0, wq1, wq2, wq3, kc.s0, kc.s1, kc.s2, kc.s3); pull(); if (fast_uniform(bail)) { status = 3; break; } }
             if (okm) {
               const int a = ctz64(okm);
               found = true; from_window = true; a_pos = (uint32_t)a;
@@ -698,72 +778,16 @@ struct TopoEngine {
               k0 = wq0.bcast(a); k1 = wq1.bcast(a); k2 = wq2.bcast(a); k3 = wq3.bcast(a);
             }
           }
-          // ---- no acceptor inside the window and the order goes on beyond it: the rings and the records, 64 positions per step ----
-          int k = 1; uint32_t i = 0;
-          if (!found && wn < n) fence();
-          for (int p0 = 0; !found && wn < n && p0 < n; p0 += 64) {
-            // ---- the claims at positions p0 .. p0+63, one per lane: the table records of sixteen runs in one LDS round trip ----
-            LaneVar<uint32_t> xv;
-            W::each([&](int l) { xv.at(l) = 0xFFFFFFFFu; });
-            {
-              int filled = 0;
-              bool done = false;
-              while (!done && filled < 64 && k <= max_cnt) {
-                if (k + 16 >= kRunMaxCount) { bail = 62; break; }   // (a run beyond the LDS ring tables at the front of the order: not this engine's shape)
-                LaneVar<uint32_t> eh, es, eo, em;
-                const int kb = k;
-                W::each([&](int l) {
-                  const int kk = kb + (l & 15);
-                  const RunEnt e = lds_get16(&RT->e[kk]);
-                  eh.at(l) = e.head; es.at(l) = e.size; eo.at(l) = e.off; em.at(l) = (1u << RT->log2cap[kk]) - 1u;
-                });
-                for (int j = 0; j < 16 && k <= max_cnt; ++j) {
-                  const uint32_t sz = es.bcast(j);
-                  if (i < sz) {
-                    const uint32_t left = sz - i;
-                    const int take = left < (uint32_t)(64 - filled) ? (int)left : 64 - filled;
-                    const uint32_t h = eh.bcast(j), m = em.bcast(j), o = eo.bcast(j), i0 = i;
-                    const int f0 = filled;
-                    W::each([&](int l) { if (l >= f0 && l < f0 + take) xv.at(l) = ring[o + ((h + i0 + (uint32_t)(l - f0)) & m)]; });
-                    filled += take;
-                    i += (uint32_t)take;
-                    if (i < sz || filled >= 64) { done = true; break; }
-                  }
-                  k++; i = 0;
-                }
-              }
-            }
-            if (bail) break;
-            windows++;
-            KS_TSEC(t3)
-            LaneVar<uint64_t> m2v, hcv;
-            LaneVar<uint32_t> cv;
-            LaneVar<int32_t> q0, q1, q2, q3;
-            uint64_t okm = 0, und = 0;
-            const int lastl = n - p0 - 1;   // (lanes past the order's end read the last claim again: no lane is switched off for the loads)
-            W::ballot2([&](int l) {
-              const uint32_t x = xv.shuffle(l, l <= lastl ? l : (lastl < 63 ? lastl : 63));
-              const TopoRec r = load_rec(rec + x);
-              const uint32_t c = ocnt[x];
-              uint64_t m2;
-              const int v = lane_test(r.vmask, r.req[0], r.req[1], r.req[2], r.req[3], r.hcnt, kc, zc, zkv, ent, m2);
-              m2v.at(l) = m2; hcv.at(l) = r.hcnt; cv.at(l) = c;
-              q0.at(l) = r.req[0]; q1.at(l) = r.req[1]; q2.at(l) = r.req[2]; q3.at(l) = r.req[3];
-              return l <= lastl ? v : 0;
-            }, okm, und);
-            KS_TSEC(t4)
-            // the lanes in front of the first plain acceptor whose requirement set is not at its first probe: the long way
-            const uint64_t before = okm ? (und & ((1ull << ctz64(okm)) - 1)) : und;
-            if (before) { push(); okm |= resolve(before, m2v, q0, q1, q2, q3, kc.s0, kc.s1, kc.s2, kc.s3); pull(); if (bail) break; }
-            if (okm) {
-              const int a = ctz64(okm);
-              found = true; a_pos = (uint32_t)(p0 + a);
-              kx = xv.bcast(a); km = m2v.bcast(a); kh = hcv.bcast(a); kcn = cv.bcast(a);
-              k0 = q0.bcast(a); k1 = q1.bcast(a); k2 = q2.bcast(a); k3 = q3.bcast(a);
-              break;
+          if (!found && wn < n) {
+            fence(); push();
+            const Accept A = scan_order(kc, zc, zkv);
+            pull();
+            if (fast_uniform(bail)) { status = 3; break; }
+            if (fast_uniform(A.found)) {
+              found = true; a_pos = (uint32_t)fast_uniform((int)A.pos); kx = (uint32_t)fast_uniform((int)A.x); kcn = (uint32_t)fast_uniform((int)A.cnt);
+              km = W::uniform(A.m2); kh = W::uniform(A.hcnt); k0 = fast_uniform(A.q0); k1 = fast_uniform(A.q1); k2 = fast_uniform(A.q2); k3 = fast_uniform(A.q3);
             }
           }
-          if (bail) { status = 3; break; }
         }
         KS_TSEC(t5)
         if (!found) {
@@ -852,13 +876,13 @@ struct TopoEngine {
           const unsigned q4 = (unsigned)n >> 2;
           const bool single = n <= 12 || (n >= 50 && !(a_pos - (q4 - 1) <= 2u || a_pos - (2 * q4 - 1) <= 2u || a_pos - (3 * q4 - 1) <= 2u));
           bool moved = false;
-          if (single && k + 3 < kRunMaxCount && k + 2 < kmax) {
+          if (from_window && single && k + 3 < kRunMaxCount && k + 2 < kmax) {
             const RunEnt ea = lds_get16(&RT->e[k]), eb = lds_get16(&RT->e[k + 1]);
             const uint32_t ma = (1u << RT->log2cap[k]) - 1u, mb = (1u << RT->log2cap[k + 1]) - 1u;
             const uint32_t h = (uint32_t)fast_uniform((int)ea.head), sz = (uint32_t)fast_uniform((int)ea.size), oa = (uint32_t)fast_uniform((int)ea.off), m = (uint32_t)fast_uniform((int)ma);
             const uint32_t idx = a_pos - (uint32_t)fast_uniform((int)ea.prefix);
-            uint32_t hb = (uint32_t)fast_uniform((int)eb.head), sb = (uint32_t)fast_uniform((int)eb.size), pb = (uint32_t)fast_uniform((int)eb.prefix);
-            const uint32_t ob = (uint32_t)fast_uniform((int)eb.off), mbu = (uint32_t)fast_uniform((int)mb);
+            uint32_t hb = (uint32_t)fast_uniform((int)eb.head), sb = (uint32_t)fast_uniform((int)eb.size);
+            const uint32_t pb = (uint32_t)fast_uniform((int)eb.prefix), ob = (uint32_t)fast_uniform((int)eb.off), mbu = (uint32_t)fast_uniform((int)mb);
             if (k + 1 > max_cnt) {
               // the first claim with k + 1 pods: run k + 1 starts out empty, and every claim lies in front of run k + 2 (RunOrder::grow_to)
               hb = 0; sb = 0;
@@ -866,46 +890,28 @@ struct TopoEngine {
               max_cnt = k + 1;
             }
             uint32_t new_head = h;
-            bool ok_shift = true;
             if (idx == 0) new_head = (h + 1) & m;
             else if (idx + 1 < sz) {
-              if (from_window) {
-                // the claims in front of it inside its run are window lanes: they step one ring slot towards the hole, from registers
-                const uint32_t pk = a_pos - idx;
-                W::each([&](int l) { if ((uint32_t)l >= pk && (uint32_t)l < a_pos) { const uint32_t s = (h + ((uint32_t)l - pk) + 1u) & m; ring[oa + s] = wx.at(l); oslot[wx.at(l)] = s; } });
-                new_head = (h + 1) & m;
-              } else if (idx <= sz - 1 - idx && idx <= 64) {
-                // (found beyond the window: at most 64 claims in front of it, one round, read before written)
-                LaneVar<uint32_t> mv;
-                W::each([&](int l) { mv.at(l) = (uint32_t)l < idx ? ring[oa + ((h + (uint32_t)l) & m)] : 0u; });
-                W::each([&](int l) { if ((uint32_t)l < idx) { const uint32_t s = (h + (uint32_t)l + 1u) & m; ring[oa + s] = mv.at(l); oslot[mv.at(l)] = s; } });
-                new_head = (h + 1) & m;
-              } else if (sz - 1 - idx <= 64 && idx > sz - 1 - idx) {
-                const uint32_t cntb = sz - 1 - idx;   // ... or the claims behind it do
-                LaneVar<uint32_t> mv;
-                W::each([&](int l) { mv.at(l) = (uint32_t)l < cntb ? ring[oa + ((h + idx + 1u + (uint32_t)l) & m)] : 0u; });
-                W::each([&](int l) { if ((uint32_t)l < cntb) { const uint32_t s = (h + idx + (uint32_t)l) & m; ring[oa + s] = mv.at(l); oslot[mv.at(l)] = s; } });
-              } else ok_shift = false;
+              // the claims in front of it inside its run are window lanes: they step one ring slot towards the hole, from registers
+              const uint32_t pk = a_pos - idx;
+              W::each([&](int l) { if ((uint32_t)l >= pk && (uint32_t)l < a_pos) { const uint32_t s2 = (h + ((uint32_t)l - pk) + 1u) & m; ring[oa + s2] = wx.at(l); oslot[wx.at(l)] = s2; } });
+              new_head = (h + 1) & m;
             }
-            if (ok_shift) {
-              const uint32_t h1 = (hb - 1u) & mbu;
-              if (W::leader()) {
-                ring[ob + h1] = kx; oslot[kx] = h1; ocnt[kx] = (uint32_t)(k + 1);
-                RT->e[k].head = new_head; RT->e[k].size = sz - 1;
-                RT->e[k + 1].head = h1; RT->e[k + 1].size = sb + 1; RT->e[k + 1].prefix = pb - 1;
-              }
-              set_last(1, (int)kx, (int)a_pos);
-              moved = true;
-              dirty = true;
-              if (from_window) {
-                // the window: the claims behind the acceptor, up to its new place q, step one position to the left; it re-enters at q
-                // when q lies inside the window, otherwise the window is one claim shorter
-                const int a = (int)a_pos, q = (int)pb - 1;
-                const bool inside = q < wn;
-                wmove([&](int l) { return (l >= a && l < q) ? l + 1 : l; }, inside ? q : -1, kx, (uint32_t)(k + 1), nrq.vmask, nrq.hcnt, nrq.req[0], nrq.req[1], nrq.req[2], nrq.req[3]);
-                if (!inside) wn--;
-              } else wvalid = false;
+            const uint32_t h1 = (hb - 1u) & mbu;
+            if (W::leader()) {
+              ring[ob + h1] = kx; oslot[kx] = h1; ocnt[kx] = (uint32_t)(k + 1);
+              RT->e[k].head = new_head; RT->e[k].size = sz - 1;
+              RT->e[k + 1].head = h1; RT->e[k + 1].size = sb + 1; RT->e[k + 1].prefix = pb - 1;
             }
+            set_last(1, (int)kx, (int)a_pos);
+            moved = true;
+            dirty = true;
+            // the window: the claims behind the acceptor, up to its new place q, step one position to the left; it re-enters at q
+            // when q lies inside the window, otherwise the window is one claim shorter
+            const int a = (int)a_pos, q = (int)pb - 1;
+            const bool inside = q < wn;
+            wmove([&](int l) { return (l >= a && l < q) ? l + 1 : l; }, inside ? q : -1, kx, (uint32_t)(k + 1), nrq.vmask, nrq.hcnt, nrq.req[0], nrq.req[1], nrq.req[2], nrq.req[3]);
+            if (!inside) wn--;
           }
           if (!moved) {
             fence(); push(); move_cold((int)kx, k, a_pos); pull(); wvalid = false;
