@@ -42,10 +42,15 @@ type Component struct {
 
 // SplitComponents returns the components of (nodePools, pods) in NodePool order, dealt over nDevices by pod count — the
 // component with the most pods first, each to the device with the fewest pods so far (LPT: never worse than 4/3 of the best
-// possible load) — or an error naming why independence cannot be shown.
-func SplitComponents(nodePools []*v1.NodePool, pods []*corev1.Pod, stateNodes []*state.StateNode, reservedCapacity bool, nDevices int) ([]Component, error) {
+// possible load) — or an error naming why independence cannot be shown. clusterPods: the pods already bound in the cluster that
+// NewTopology counts (topology.go:361-459) — any of them is shared topology state, as in ksched_split_components. A nil LabelSelector
+// is treated as selecting every pod of its namespaces here (k8s selects nothing): conservative, it can only merge components.
+func SplitComponents(nodePools []*v1.NodePool, pods []*corev1.Pod, stateNodes []*state.StateNode, clusterPods []*corev1.Pod, reservedCapacity bool, nDevices int) ([]Component, error) {
 	if len(stateNodes) > 0 {
 		return nil, fmt.Errorf("existing nodes are bins every NodePool's pods share")
+	}
+	if len(clusterPods) > 0 {
+		return nil, fmt.Errorf("cluster pods: shared topology counts")
 	}
 	if reservedCapacity {
 		return nil, fmt.Errorf("reservations are shared between NodePools")

@@ -716,12 +716,12 @@ static void be_launch_fast_records(ksolve_handle* h, int n_claims) {
   hipLaunchKernelGGL(ksolve_fast_scatter, grid_for(n), dim3(256), 0, HB(h)->stream, n, fast_queue_args(h));
   hip_check(h, hipGetLastError(), "ksolve_fast_scatter launch");
 }
-static void be_launch_fast_queue(ksolve_handle* h) {
+static void be_launch_fast_queue(ksolve_handle* h, bool count_live) {
   const int n = (int)h->n_pods;
   hipLaunchKernelGGL(ksolve_fast_queue, grid_for(n), dim3(256), 0, HB(h)->stream, n, fast_queue_args(h));
   hip_check(h, hipGetLastError(), "ksolve_fast_queue launch");
   const int nc = (int)h->n_classes;
-  if (h->fw.enabled && nc > 64 && nc <= 32768) {   // (the spread engine has no class slots to count)
+  if (count_live && h->fw.enabled && nc > 64 && nc <= 32768) {   // (the spread engine has no class slots to count)
     hipLaunchKernelGGL(ksolve_fast_overlap, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, HB(h)->stream, nc, fast_queue_args(h));
     hip_check(h, hipGetLastError(), "ksolve_fast_overlap launch");
   }

@@ -74,6 +74,7 @@ struct ksolve_handle {
   bool big_capable = false;
   int lite_saved = 0;
   uint32_t fast_live = 0;       // cursor engine: the most pod classes live at once in the queue (ksolve_fast_overlap)
+  bool fast_live_known = false; uint32_t fast_live_classes = 0;   // ... counted by the handle's first solve (for that many classes)
   ks::FastWork fw{};            // cursor engine (fast_engine.h): workspace + LDS plan; fw.enabled while the problem may qualify
   uint32_t engine_used = 0, fast_reason = 0, fast_attempts = 0;
   ks::FastArgs* d_fast_args = nullptr;   // the record ksolve_pack_fast reads its problem from
@@ -131,7 +132,7 @@ static void be_launch_pack_fast(ksolve_handle* h);                 // one wavefr
 static void be_launch_pack_topo(ksolve_handle* h);                 // one wavefront: TopoEngine::solve
 static void be_launch_pack_fast_batch(ksolve_handle** hs, int n);   // block b = the cursor engine on problem b; sets every handle's T_PACK timer
 static void be_launch_fast_records(ksolve_handle* h, int n_claims); // one wavefront per claim: fast_record_body; then fast_scatter_body per queue entry
-static void be_launch_fast_queue(ksolve_handle* h);                // one thread per queue entry: fast_queue_body
+static void be_launch_fast_queue(ksolve_handle* h, bool count_live);   // one thread per queue entry: fast_queue_body (+ ksolve_fast_overlap when asked)
 static void be_launch_pack_batch(ksolve_handle** hs, int n);
 static void be_thread_init(ksolve_handle* h);   // makes the handle's device current on a worker thread   // one block per handle; sets every handle's T_PACK timer
 static void be_launch_finalize(ksolve_handle* h, int n, const ks::FinalizeArgs& a);
@@ -897,11 +898,17 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
   if (h->fw.enabled && !P.big && n_pods && n_classes) {
     // the cursor engine reads the queue's classes in queue order; how many classes are live at once decides its rows of class slots
     be_fill(h, h->fw.cls_first, 0xFF, (size_t)n_classes * 4); be_fill(h, h->fw.cls_last, 0, (size_t)n_classes * 4); be_fill(h, h->fw.max_active, 0, 4);
-    be_launch_fast_queue(h);
-    uint32_t live = 0xFFFFFFFFu;
-    if (n_classes <= 64) live = n_classes;
-    else if (n_classes <= 32768) { be_d2h(h, &live, h->fw.max_active, 4); be_sync(h); }   // (beyond: the count is quadratic in the classes — four rows)
-    h->fast_live = live;
+    // (the count of classes live at once — quadratic in the classes, and a blocking 4-byte download — belongs to the problem, not to
+    // the solve: a handle's rows do not change, so later solves of the handle reuse the first one's. ADVICE r5.)
+    const bool count_live = !h->fast_live_known || h->fast_live_classes != n_classes;
+    be_launch_fast_queue(h, count_live);
+    uint32_t live = h->fast_live;
+    if (count_live) {
+      live = 0xFFFFFFFFu;
+      if (n_classes <= 64) live = n_classes;
+      else if (n_classes <= 32768) { be_d2h(h, &live, h->fw.max_active, 4); be_sync(h); }   // (beyond: four rows)
+      h->fast_live = live; h->fast_live_known = true; h->fast_live_classes = n_classes;
+    }
     const int rows = live <= 64 ? 1 : ks::kFastRows;
     if (rows != h->fw.plan.rows) {
       fast_plan_set(h, h->fw.plan.global_state, rows);
@@ -912,7 +919,7 @@ static ksolve_status solve_prepare(ksolve_handle* h, bool fresh_context = true) 
   if (h->tw.enabled && n_pods && n_classes) {
     // the spread engine reads the queue's classes in queue order too (no class slots: the overlap count is not needed)
     be_fill(h, h->fw.cls_first, 0xFF, (size_t)n_classes * 4); be_fill(h, h->fw.cls_last, 0, (size_t)n_classes * 4); be_fill(h, h->fw.max_active, 0, 4);
-    be_launch_fast_queue(h);
+    be_launch_fast_queue(h, false);
   }
   be_toc(h, T_SORT);
 

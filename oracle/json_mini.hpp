@@ -128,6 +128,7 @@ class Parser {
               if (lo >= 0xDC00 && lo <= 0xDFFF) cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
               else p_ = save;
             }
+            if (cp >= 0xD800 && cp <= 0xDFFF) fail("lone surrogate");   // (an unpaired \uD800-\uDFFF has no UTF-8 form: refused, like Python's json in strict UTF-8 output — ADVICE r5)
             if (cp < 0x80) out += (char)cp;
             else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
             else if (cp < 0x10000) { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }

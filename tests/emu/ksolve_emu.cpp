@@ -144,11 +144,11 @@ static void be_launch_fast_records(ksolve_handle* h, int n_claims) {
   const ks::FastQueueArgs q = fast_queue_args(h);
   for (int i = 0; i < (int)h->n_pods; ++i) ks::fast_scatter_body(i, q);
 }
-static void be_launch_fast_queue(ksolve_handle* h) {
+static void be_launch_fast_queue(ksolve_handle* h, bool count_live) {
   const ks::FastQueueArgs q = fast_queue_args(h);
   for (int i = 0; i < (int)h->n_pods; ++i) ks::fast_queue_body(i, q);
   const int nc = (int)h->n_classes;
-  if (h->fw.enabled && nc > 64 && nc <= 32768) for (int c = 0; c < nc; ++c) ks::fast_overlap_body(c, nc, q);
+  if (count_live && h->fw.enabled && nc > 64 && nc <= 32768) for (int c = 0; c < nc; ++c) ks::fast_overlap_body(c, nc, q);
   for (int i = 0; i < (int)h->n_pods; ++i) ks::fast_mark_body(i, q);
 }
 static void be_launch_pack_fast_batch(ksolve_handle** hs, int n) {

@@ -90,3 +90,16 @@ def test_broken_documents_are_refused(name):
             json.loads(doc)
         out = json.loads(rt(doc))
         assert isinstance(out, dict) and "error" in out, (name, doc, out)
+
+
+@pytest.mark.parametrize("name", ["oracle", "host library"])
+def test_lone_surrogates_are_refused(name):
+    """an unpaired \\uD800-\\uDFFF (alone, a high one followed by a non-low escape, a low one first) has no UTF-8 form; both
+    parsers used to emit a three-byte sequence for it. Refused now — Python accepts such escapes into a str that cannot be encoded."""
+    rt = _roundtrippers()[name]
+    for doc in ['"\\ud800"', '"\\udc00"', '"a\\ud83dz"', '"\\ud83d\\u0041"', '"\\ude00\\ud83d"', '["ok", "\\udfff"]']:
+        with pytest.raises(UnicodeEncodeError):
+            json.loads(doc).__str__().encode("utf-8") if not isinstance(json.loads(doc), list) else json.loads(doc)[1].encode("utf-8")
+        out = json.loads(rt(doc))
+        assert isinstance(out, dict) and "error" in out, (name, doc, out)
+    assert json.loads(rt('"\\ud83d\\ude00"')) == "\U0001F600"      # the pair itself stays one code point
