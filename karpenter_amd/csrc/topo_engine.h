@@ -77,7 +77,6 @@ struct TopoEngine {
         for (uint32_t i = T.f_first[g]; i < T.f_first[g + 1]; ++i) if (T.f_reqs.defined[i] == 0) open = true;
         if (!open) return 43;
       }
-      if (T.min_domains[g] >= 0) return 44;
       const int key = T.key[g], type = T.type[g];
       if (key < 0) {
         if (type == 1 || (inv && type != 2)) return 45;                           // affinity on the hostname
@@ -91,7 +90,8 @@ struct TopoEngine {
         W::store(&S_.gmap[g], (int16_t)n_host);
         n_host++;
       } else {
-        if (inv || type == 2) return 48;                                          // anti-affinity on a dictionary key blocks every value (topology.go:203-206)
+        if (inv && type != 2) return 48;
+        if (type == 0 && (T.max_skew[g] < 1 || T.max_skew[g] > 30000 || T.min_domains[g] > 30000)) return 44;
         if (n_zg >= kTopoMaxZg) return 49;
         int var = -1;
         for (int j = 0; j < nvv; ++j) if (Mp->vkey[j] == key) var = j;
@@ -102,7 +102,7 @@ struct TopoEngine {
         const uint16_t* rk = T.value_rank + (size_t)w0 * 64;
         W::for_n(kTopoMaxDom, [&](int z) { Z.cnt[z] = c0[z]; Z.rank[z] = rk[z]; });
         if (W::leader()) {
-          Z.dom = (uint32_t)T.domains0[(size_t)g * T.dom_words]; Z.nonzero = T.nonzero0[g]; Z.skew = T.max_skew[g];
+          Z.dom = (uint32_t)T.domains0[(size_t)g * T.dom_words]; Z.nonzero = T.nonzero0[g]; Z.skew = (int16_t)(type == 0 ? T.max_skew[g] : 0); Z.min_domains = (int16_t)(type == 0 ? T.min_domains[g] : -1);
           Z.type = (uint8_t)type; Z.var = (uint8_t)var; Z.off = Mp->voff[var]; Z.width = Mp->vwidth[var];
         }
         // (domains beyond the sixteen the field holds cannot exist: the field's width is the key's highest valid value)
@@ -118,7 +118,7 @@ struct TopoEngine {
     const uint64_t bad = W::reduce_or(nc, [&](int c) -> uint64_t {
       const uint64_t* ct = T.cls_topo + (size_t)c * 2 * words;
       TopoClass k;
-      k.hlim = kTopoGuard | (kTopoOnes * 7); k.hinc = 0; k.zsel = 0; k.zg = -1; k.zself = 0; k.excl = 0xFFu; k.pad = 0;
+      k.hlim = kTopoGuard | (kTopoOnes * 7); k.hinc = 0; k.zsel = 0; k.zg[0] = -1; k.zg[1] = -1; k.zself = 0; k.excl = 0xFFu; k.pad = 0;
       uint64_t b = 0;
       for (int w = 0; w < words; ++w) {
         const uint64_t ow = ct[w], se = ct[words + w], inv = T.inverse_mask[w];
@@ -136,8 +136,10 @@ struct TopoEngine {
             if (lim == 0 && T.type[g] == 2 && k.excl == 0xFFu)
               for (int t = 0; t < kTopoTrack; ++t) if (S_.track_field[t] == (uint32_t)gm) k.excl = (uint32_t)t;
           } else {
-            if (k.zg >= 0) { b = 1; continue; }   // two groups on dictionary keys: each narrows from the claim's own set (topology.go:226-250)
-            k.zg = gm - 0x100; k.zself = self ? 1u : 0u;
+            // (up to two groups on dictionary keys: each narrows from the claim's own set, the intersection stands — topology.go:226-250)
+            const int slot = k.zg[0] < 0 ? 0 : k.zg[1] < 0 ? 1 : -1;
+            if (slot < 0) { b = 1; continue; }
+            k.zg[slot] = (int16_t)(gm - 0x100); if (self) k.zself |= 1u << slot;
           }
         }
         // Record (topology.go:197-220): the regular groups that select the pod, the inverse groups it owns
@@ -167,7 +169,7 @@ struct TopoEngine {
     KS_LDS TopoZg* const Z = &st->zg[zg];
     TopoZgHead hd = lds_get16((const KS_LDS TopoZgHead*)&Z->dom);
     const uint32_t D = (uint32_t)fast_uniform((int)hd.dom);
-    const int skew = fast_uniform(hd.skew);
+    const int skew = fast_uniform((int)hd.skew), mind = fast_uniform((int)hd.min_domains);
     const uint32_t tv = (uint32_t)fast_uniform((int)((uint32_t)hd.type | ((uint32_t)hd.off << 8) | ((uint32_t)hd.width << 16)));
     const int type = (int)(tv & 0xFF), off = (int)((tv >> 8) & 0xFF), width = (int)((tv >> 16) & 0xFF);
     const uint32_t fmn = (1u << width) - 1;
@@ -181,13 +183,21 @@ struct TopoEngine {
       const uint32_t sup = D & podf;
       int who = 0;
       const uint32_t mn32 = W::argmin_u32([&](int z) { return (z < kTopoMaxDom && ((sup >> z) & 1)) ? (uint32_t)cz.at(z) : 0xFFFFFFFFu; }, &who);
-      const long long mn = mn32 == 0xFFFFFFFFu ? (long long)INT32_MAX : (long long)mn32;
+      long long mn = mn32 == 0xFFFFFFFFu ? (long long)INT32_MAX : (long long)mn32;
+      if (mind >= 0 && popc64(sup) < mind) mn = 0;                               // minDomains — topologygroup.go:318-320
       const uint64_t vb = W::ballot([&](int z) {
         const bool v = z < kTopoMaxDom && ((D >> z) & 1) && (long long)cz.at(z) + (self ? 1 : 0) - mn <= (long long)skew;
         zkv.at(z) = v ? (((uint64_t)(uint32_t)(cz.at(z) + (self ? 1 : 0)) << 32) | ((uint64_t)rz.at(z) << 8) | (uint64_t)z) : ~0ull;
         return v;
       });
       zc.vm = (uint32_t)vb;
+      if (!zc.vm) possible = false;
+      return zc;
+    }
+    if (type == 2) {
+      // anti-affinity: the empty domains the pod admits (topologygroup.go:404-439); every one the claim admits stays
+      zc.vm = (uint32_t)W::ballot([&](int z) { return z < kTopoMaxDom && ((D >> z) & 1) && cz.at(z) == 0 && ((podf >> z) & 1); });
+      zc.multi = true;
       if (!zc.vm) possible = false;
       return zc;
     }
@@ -208,25 +218,33 @@ struct TopoEngine {
   // requirement-set cache; 2: the set is not at its first probe (or has further Pareto vectors): undecided; 0: rejects. m2 = the set
   // narrowed by the pod's selectors and its domain choice.
   struct KClass { uint64_t hlim, cvmask, dmask; int32_t s0, s1, s2, s3; uint32_t tmplok; };
+  // one group's choice on the claim's set: the claim's field of the key ∧ the candidates (∧ what an earlier group of the same key left)
+  KS_DEV bool apply_choice(uint64_t m, uint64_t& m2, const ZChoice& zc, const LaneVar<uint64_t>& zkv) const {
+    const uint32_t fm = (1u << zc.width) - 1;
+    const uint32_t zf = (uint32_t)(m >> zc.off) & fm;
+    const uint32_t cand = zf & zc.vm;
+    uint32_t nf = cand;
+    if (!zc.multi) {
+      uint64_t best = ~0ull;
+      for (int z = 0; z < zc.width; ++z) { const uint64_t kz = zkv.bcast(z); if (((cand >> z) & 1) && kz < best) best = kz; }
+      nf = cand ? 1u << (best & (kTopoMaxDom - 1)) : 0u;
+    }
+    nf &= (uint32_t)(m2 >> zc.off) & fm;
+    m2 = (m2 & ~zc.clear) | ((uint64_t)nf << zc.off);
+    return nf != 0;
+  }
+  // TWO = false: the loop's own form — a class with a second group on a dictionary key goes through the out-of-line paths, so that the
+  // step of every other class carries neither its code nor its registers
+  template <bool TWO = true>
   KS_DEV int lane_test(uint64_t vmask, int32_t r0, int32_t r1, int32_t r2, int32_t r3, uint64_t hcnt, const KClass& k, const ZChoice& zc, const LaneVar<uint64_t>& zkv,
-                       const KS_LDS FastEnt* ent, uint64_t& m2) const {
+                       const ZChoice& zd, const LaneVar<uint64_t>& zkw, const KS_LDS FastEnt* ent, uint64_t& m2) const {
     const int t = (int)(vmask >> 56) & 31;   // (template ids are < 32; a lane past the window's end holds anything)
     const uint64_t m = vmask & k.cvmask;
     m2 = m;
     bool ok = ((k.tmplok >> t) & 1u) != 0 && fast_fields_ok(m, k.dmask);
     ok = ok && (((k.hlim - hcnt) & kTopoGuard) == kTopoGuard);
-    if (zc.on) {
-      const uint32_t zf = (uint32_t)(m >> zc.off) & ((1u << zc.width) - 1);
-      const uint32_t cand = zf & zc.vm;
-      ok = ok && cand != 0;
-      uint32_t nf = cand;
-      if (!zc.multi) {
-        uint64_t best = ~0ull;
-        for (int z = 0; z < zc.width; ++z) { const uint64_t kz = zkv.bcast(z); if (((cand >> z) & 1) && kz < best) best = kz; }
-        nf = 1u << (best & (kTopoMaxDom - 1));
-      }
-      m2 = (m & ~zc.clear) | ((uint64_t)nf << zc.off);
-    }
+    if (zc.on) ok = apply_choice(m, m2, zc, zkv) && ok;
+    if constexpr (TWO) { if (zd.on) ok = apply_choice(m, m2, zd, zkw) && ok; }
     const FastEnt e = lds_get16(&ent[fast_hash(m2)]);   // (read whatever `ok` says: no branch in front of the LDS access)
     if (!ok) return 0;
     if (e.vmask != m2) return 2;
@@ -262,6 +280,11 @@ struct TopoEngine {
       const int off = (int)((ow >> 16) & 0xFF), width = (int)(ow >> 24);
       if ((m2 >> (off + width)) & 1) continue;   // the claim does not define the key: Exists, no values
       const uint32_t f = (uint32_t)(m2 >> off) & ((1u << width) - 1);
+      if ((ow & 0xFF) == 2) {
+        // anti-affinity (and its inverse groups) blocks every domain the pod could land in (topology.go:203-206, :213-219)
+        if (W::leader()) { int fresh = 0; for (uint32_t b = f; b; b &= b - 1) { const int z = ctz64(b); const int32_t c = Z->cnt[z]; Z->cnt[z] = c + 1; fresh += c == 0; } Z->nonzero = Z->nonzero + fresh; Z->dom = Z->dom | f; }
+        continue;
+      }
       if (popc64(f) != 1) continue;
       const int z = ctz64(f);
       if (W::leader()) { const int32_t c = Z->cnt[z]; Z->cnt[z] = c + 1; if (c == 0) Z->nonzero = Z->nonzero + 1; Z->dom = Z->dom | f; }
@@ -307,10 +330,11 @@ struct TopoEngine {
     const int T = P.n_templates, nr = P.n_res, iw = P.it_words;
     const int n = order.n;
     n_ref += (unsigned long long)n;
-    LaneVar<uint64_t> zkv;
-    bool possible = true;
-    const ZChoice zc = choose_domains(tc.zg, tc.zself != 0, cs.cvmask, zkv, possible);
-    if (!possible) { bail = 27; return -1; }
+    LaneVar<uint64_t> zkv, zkw;
+    bool possible = true, possible2 = true;
+    const ZChoice zc = choose_domains(tc.zg[0], (tc.zself & 1u) != 0, cs.cvmask, zkv, possible);
+    const ZChoice zd = choose_domains(tc.zg[1], (tc.zself & 2u) != 0, cs.cvmask, zkw, possible2);
+    if (!possible || !possible2) { bail = 27; return -1; }
     KClass kc; kc.hlim = tc.hlim; kc.cvmask = cs.cvmask; kc.dmask = cs.dmask; kc.s0 = cs.size[0]; kc.s1 = cs.size[1]; kc.s2 = cs.size[2]; kc.s3 = cs.size[3]; kc.tmplok = cs.tmplok;
     for (int t = 0; t < T; ++t) {
       if (!((cold.active_templates >> t) & 1u)) continue;
@@ -340,7 +364,7 @@ struct TopoEngine {
       n_ref++;
       // CanAdd on the fresh claim: the template's set, no requests, every hostname counter zero (the limits are >= 0)
       uint64_t m2 = 0;
-      int v = lane_test(Mp->tvmask[t], 0, 0, 0, 0, 0ull, kc, zc, zkv, cold.ent, m2);   // (every lane computes the same verdict: the state is wave-uniform)
+      int v = lane_test(Mp->tvmask[t], 0, 0, 0, 0, 0ull, kc, zc, zkv, zd, zkw, cold.ent, m2);   // (every lane computes the same verdict: the state is wave-uniform)
       v = fast_uniform(v);
       m2 = W::uniform(m2);
       if (v == 0) continue;
@@ -403,7 +427,7 @@ struct TopoEngine {
   struct Win { LaneVar<uint32_t> x, c; LaneVar<uint64_t> v, h; LaneVar<int32_t> q0, q1, q2, q3; int n; };
   // every member of an anti-affinity group the class owns needs a claim without one: the claims of list t — those that hold none yet,
   // wherever they stand in the order — and among those that accept the one at the lowest position
-  KS_COLD Accept scan_list(int t, KClass kc, ZChoice zc, LaneVar<uint64_t> zkv) {
+  KS_COLD Accept scan_list(int t, KClass kc, ZChoice zc, LaneVar<uint64_t> zkv, ZChoice zd, LaneVar<uint64_t> zkw) {
     Accept A; A.found = 0; A.x = 0; A.pos = 0; A.cnt = 0; A.m2 = 0; A.hcnt = 0; A.q0 = A.q1 = A.q2 = A.q3 = 0;
     KS_LDS TopoState* const S_ = st;
     KS_LDS RunTables* const RT = order.T;
@@ -423,7 +447,7 @@ struct TopoEngine {
         const TopoRec r = load_rec(rec + x);
         const uint32_t c = ocnt[x], sl = oslot[x];
         uint64_t m2;
-        const int v = lane_test(r.vmask, r.req[0], r.req[1], r.req[2], r.req[3], r.hcnt, kc, zc, zkv, ent, m2);
+        const int v = lane_test(r.vmask, r.req[0], r.req[1], r.req[2], r.req[3], r.hcnt, kc, zc, zkv, zd, zkw, ent, m2);
         // position = the run's first position + the claim's index inside the run (run_order.h)
         const RunEnt e = lds_get16(&RT->e[c < (uint32_t)kRunMaxCount ? c : 0]);
         const uint32_t mk = (1u << RT->log2cap[c < (uint32_t)kRunMaxCount ? c : 0]) - 1u;
@@ -500,7 +524,7 @@ struct TopoEngine {
     return w;
   }
   // no acceptor inside the window and the order goes on beyond it: the rings and the records, 64 positions per step, from the front
-  KS_COLD Accept scan_order(KClass kc, ZChoice zc, LaneVar<uint64_t> zkv) {
+  KS_COLD Accept scan_order(KClass kc, ZChoice zc, LaneVar<uint64_t> zkv, ZChoice zd, LaneVar<uint64_t> zkw) {
     Accept A; A.found = 0; A.x = 0; A.pos = 0; A.cnt = 0; A.m2 = 0; A.hcnt = 0; A.q0 = A.q1 = A.q2 = A.q3 = 0;
     const KS_GLOBAL TopoRec* const rec = (const KS_GLOBAL TopoRec*)Tk->rec;
     const KS_GLOBAL uint32_t* const ocnt = (const KS_GLOBAL uint32_t*)order.cnt;
@@ -521,7 +545,7 @@ struct TopoEngine {
         const TopoRec r = load_rec(rec + x);
         const uint32_t c = ocnt[x];
         uint64_t m2;
-        const int v = lane_test(r.vmask, r.req[0], r.req[1], r.req[2], r.req[3], r.hcnt, kc, zc, zkv, ent, m2);
+        const int v = lane_test(r.vmask, r.req[0], r.req[1], r.req[2], r.req[3], r.hcnt, kc, zc, zkv, zd, zkw, ent, m2);
         m2v.at(l) = m2; hcv.at(l) = r.hcnt; cv.at(l) = c;
         q0.at(l) = r.req[0]; q1.at(l) = r.req[1]; q2.at(l) = r.req[2]; q3.at(l) = r.req[3];
         return l < fl ? v : 0;
@@ -538,6 +562,14 @@ struct TopoEngine {
       }
     }
     return A;
+  }
+  // the select step of a class with a second group on a dictionary key: its choice, then the list (list_t >= 0) or the whole order
+  KS_COLD Accept scan_two(int list_t, KClass kc, ZChoice zc, LaneVar<uint64_t> zkv, int zg1, bool self1) {
+    LaneVar<uint64_t> zkw;
+    bool p2 = true;
+    const ZChoice zd = choose_domains(zg1, self1, kc.cvmask, zkw, p2);
+    if (!p2) { bail = 27; Accept A; A.found = 0; A.x = 0; A.pos = 0; A.cnt = 0; A.m2 = 0; A.hcnt = 0; A.q0 = A.q1 = A.q2 = A.q3 = 0; return A; }
+    return list_t >= 0 ? scan_list(list_t, kc, zc, zkv, zd, zkw) : scan_order(kc, zc, zkv, zd, zkw);
   }
   KS_COLD void sort_cold() { order.sort(); }
 
@@ -688,7 +720,7 @@ struct TopoEngine {
         const KS_GLOBAL u64_alias* tp = (const KS_GLOBAL u64_alias*)(gtc + k);
         const uint64_t w3 = tp[3], w4 = tp[4];
         c_hlim.at(l) = tp[0]; c_hinc.at(l) = tp[1]; c_zsel.at(l) = tp[2];
-        c_zg.at(l) = (int32_t)(uint32_t)w3; c_zself.at(l) = (uint32_t)(w3 >> 32); c_excl.at(l) = (uint32_t)w4;
+        c_zg.at(l) = (int32_t)(uint32_t)w3; c_zself.at(l) = (uint32_t)(w3 >> 32); c_excl.at(l) = (uint32_t)w4;   // (zg: two int16 in one word)
         const KS_GLOBAL u64_alias* sp = (const KS_GLOBAL u64_alias*)(gcs + k);
         const uint64_t v2 = sp[2], v3 = sp[3], v4 = sp[4];
         c_cvm.at(l) = sp[0]; c_dm.at(l) = sp[1];
@@ -717,14 +749,16 @@ struct TopoEngine {
         kc.hlim = c_hlim.bcast(bi); kc.cvmask = c_cvm.bcast(bi); kc.dmask = c_dm.bcast(bi);
         kc.s0 = c_s0.bcast(bi); kc.s1 = c_s1.bcast(bi); kc.s2 = c_s2.bcast(bi); kc.s3 = c_s3.bcast(bi); kc.tmplok = c_tok.bcast(bi);
         const uint64_t hinc = c_hinc.bcast(bi), zsel = c_zsel.bcast(bi);
-        const int zg = c_zg.bcast(bi);
-        const bool zself = c_zself.bcast(bi) != 0;
+        const int zgw = c_zg.bcast(bi);
+        const int zg0 = (int)(int16_t)(uint16_t)(uint32_t)zgw, zg1 = (int)(int16_t)(uint16_t)((uint32_t)zgw >> 16);
+        const uint32_t zselfw = c_zself.bcast(bi);
         const uint32_t excl = c_excl.bcast(bi);
         KS_TSEC(t1)
         LaneVar<uint64_t> zkv;
         bool possible = true;
-        const ZChoice zc = choose_domains(zg, zself, kc.cvmask, zkv, possible);
+        const ZChoice zc = choose_domains(zg0, (zselfw & 1u) != 0, kc.cvmask, zkv, possible);
         if (!possible) { bail = 27; status = 3; break; }
+        const bool two = zg1 >= 0;   // a second group on a dictionary key (rare): its pods take the out-of-line paths all the way
         KS_TSEC(t2)
         // ---- addToInflightNode (scheduler.go:658-692): the first claim of the order that accepts ----
         bool found = false;
@@ -736,13 +770,23 @@ struct TopoEngine {
           // (usually nobody is on the list: every claim holds a member already — straight to addToNewNodeClaim)
           if (fast_uniform((int)S_->n_free[excl & (kTopoTrack - 1)]) > 0) {
             fence(); push();
-            const Accept A = scan_list((int)excl, kc, zc, zkv);
+            ZChoice zn; zn.vm = 0; zn.off = 0; zn.width = 0; zn.multi = false; zn.on = false; zn.clear = 0;
+            const Accept A = two ? scan_two((int)excl, kc, zc, zkv, zg1, (zselfw & 2u) != 0) : scan_list((int)excl, kc, zc, zkv, zn, zkv);
             pull();
             if (fast_uniform(bail)) { status = 3; break; }
             if (fast_uniform(A.found)) {
               found = true; a_pos = (uint32_t)fast_uniform((int)A.pos); kx = (uint32_t)fast_uniform((int)A.x); kcn = (uint32_t)fast_uniform((int)A.cnt);
               km = W::uniform(A.m2); kh = W::uniform(A.hcnt); k0 = fast_uniform(A.q0); k1 = fast_uniform(A.q1); k2 = fast_uniform(A.q2); k3 = fast_uniform(A.q3);
             }
+          }
+        } else if (two) {
+          fence(); push();
+          const Accept A = scan_two(-1, kc, zc, zkv, zg1, (zselfw & 2u) != 0);
+          pull();
+          if (fast_uniform(bail)) { status = 3; break; }
+          if (fast_uniform(A.found)) {
+            found = true; a_pos = (uint32_t)fast_uniform((int)A.pos); kx = (uint32_t)fast_uniform((int)A.x); kcn = (uint32_t)fast_uniform((int)A.cnt);
+            km = W::uniform(A.m2); kh = W::uniform(A.hcnt); k0 = fast_uniform(A.q0); k1 = fast_uniform(A.q1); k2 = fast_uniform(A.q2); k3 = fast_uniform(A.q3);
           }
         } else {
           const int wfull = n < 64 ? n : 64;
@@ -764,7 +808,7 @@ struct TopoEngine {
             const int lim = wn;
             W::ballot2([&](int l) {
               uint64_t m2;
-              const int v = lane_test(wv.at(l), wq0.at(l), wq1.at(l), wq2.at(l), wq3.at(l), wh.at(l), kc, zc, zkv, ent, m2);
+              const int v = lane_test<false>(wv.at(l), wq0.at(l), wq1.at(l), wq2.at(l), wq3.at(l), wh.at(l), kc, zc, zkv, zc, zkv, ent, m2);
               m2v.at(l) = m2;
               return l < lim ? v : 0;
             }, okm, und);
@@ -780,7 +824,8 @@ struct TopoEngine {
           }
           if (!found && wn < n) {
             fence(); push();
-            const Accept A = scan_order(kc, zc, zkv);
+            ZChoice zn; zn.vm = 0; zn.off = 0; zn.width = 0; zn.multi = false; zn.on = false; zn.clear = 0;
+            const Accept A = scan_order(kc, zc, zkv, zn, zkv);
             pull();
             if (fast_uniform(bail)) { status = 3; break; }
             if (fast_uniform(A.found)) {
@@ -793,11 +838,11 @@ struct TopoEngine {
         if (!found) {
           // ---- addToNewNodeClaim (scheduler.go:695-790) ----
           bool made = false;
-          if (fast_t >= 0 && n >= 50 && n_claims < max_claims && max_cnt + 2 < kRunMaxCount) {
+          if (!two && fast_t >= 0 && n >= 50 && n_claims < max_claims && max_cnt + 2 < kRunMaxCount) {
             // one template without limits, the order past pdqsort's small-array paths: the claim is opened here. NewNodeClaim draws a
             // hostname number, CanAdd runs on the template's requirement set with nothing requested and every hostname counter zero
             uint64_t m2 = 0;
-            const int v = fast_uniform(lane_test(fast_tv, 0, 0, 0, 0, 0ull, kc, zc, zkv, ent, m2));
+            const int v = fast_uniform(lane_test<false>(fast_tv, 0, 0, 0, 0, 0ull, kc, zc, zkv, zc, zkv, ent, m2));
             m2 = W::uniform(m2);
             if (v == 1) {
               ref += (unsigned long long)n + 1;
@@ -840,7 +885,7 @@ struct TopoEngine {
           }
           if (!made) {
             push();
-            TopoClass tcc; tcc.hlim = kc.hlim; tcc.hinc = hinc; tcc.zsel = zsel; tcc.zg = zg; tcc.zself = zself ? 1u : 0u; tcc.excl = excl; tcc.pad = 0;
+            TopoClass tcc; tcc.hlim = kc.hlim; tcc.hinc = hinc; tcc.zsel = zsel; tcc.zg[0] = (int16_t)zg0; tcc.zg[1] = (int16_t)zg1; tcc.zself = zselfw; tcc.excl = excl; tcc.pad = 0;
             FastSlot csc; csc.cvmask = kc.cvmask; csc.dmask = kc.dmask; csc.size[0] = kc.s0; csc.size[1] = kc.s1; csc.size[2] = kc.s2; csc.size[3] = kc.s3; csc.tmplok = kc.tmplok; csc.kdef = 0;
             fence();
             const int c = fast_uniform(new_claim(tcc, csc));

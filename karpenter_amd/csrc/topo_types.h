@@ -17,16 +17,16 @@ constexpr uint64_t kTopoGuard = 0x8888888888888888ull, kTopoOnes = 0x11111111111
 struct TopoRec { uint64_t vmask; int32_t req[4]; uint64_t hcnt; };   // 32 B: an in-flight claim (requirement set, requests, hostname-group counters)
 // a pod class's topology: limits on the hostname counters it is tested against (field = 8 | limit; 8 | 7 where it has none),
 // the counters and dictionary-key groups a pod of the class is counted by, the dictionary-key group it owns
-struct TopoClass { uint64_t hlim, hinc, zsel; int32_t zg; uint32_t zself; uint32_t excl; uint32_t pad; };   // 48 B
+struct TopoClass { uint64_t hlim, hinc, zsel; int16_t zg[2]; uint32_t zself; uint32_t excl; uint32_t pad; };   // 48 B; zg: up to two dictionary-key groups it is tested against (-1: none), zself bit i: it is selected by zg[i] itself
 struct TopoZg {   // a group on a dictionary key (LDS): sixteen counters and name ranks, then one 16-byte header
   int32_t cnt[kTopoMaxDom];
   uint16_t rank[kTopoMaxDom];
   uint32_t dom;        // registered domains (TopologyGroup.domains)
   int32_t nonzero;     // domains with a positive count
-  int32_t skew;
-  uint8_t type, var, off, width;   // 0 spread / 1 affinity; index of its key among the variable keys (FastMisc::vkey); the key's field inside vmask
+  int16_t skew, min_domains;   // maxSkew; minDomains (-1: nil)
+  uint8_t type, var, off, width;   // 0 spread / 1 affinity / 2 anti-affinity (also the inverse groups); index of its key among the variable keys (FastMisc::vkey); the key's field inside vmask
 };
-struct TopoZgHead { uint32_t dom; int32_t nonzero; int32_t skew; uint8_t type, var, off, width; };   // TopoZg from `dom` on
+struct TopoZgHead { uint32_t dom; int32_t nonzero; int16_t skew, min_domains; uint8_t type, var, off, width; };   // TopoZg from `dom` on
 static_assert(sizeof(TopoZg) == 112 && sizeof(TopoZgHead) == 16, "TopoZg layout");
 struct TopoState {   // LDS
   TopoZg zg[kTopoMaxZg];

@@ -18,7 +18,7 @@ CMD[head]="$B --steps 3 --warmup 1 --topology-pods 0 --sweep-nodes 0"
 CMD[topo]="$B --steps 1 --warmup 0 --pods 20000 --no-parity-pin --topology-pods 1000000 --sweep-nodes 0"
 CMD[big]="python $GRAFT_REPO_ROOT/tests/tools/gpu_check_pin.py $GRAFT_REPO_ROOT/tests/golden/fullsize/config3_p200000_t500_s42.json general"
 CMD[sweep]="$B --steps 1 --warmup 0 --pods 20000 --no-parity-pin --topology-pods 0 --sweep-sample 0 --sweep-topology-sample 0 --sweep-windows 0"
-CMD[exact]="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --pods 20000 --no-parity-pin --topology-pods 0 --batch-problems 0 --components-pods 0 --beyond-lds-pods 0 --whole-batch-pods 0 --sweep-nodes 0 --no-host-engine-baseline --no-cpu-baseline"
+CMD[exact]="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --pods 20000 --no-parity-pin --topology-pods 0 --batch-problems 0 --components-pods 10000000 --beyond-lds-pods 0 --whole-batch-pods 0 --sweep-nodes 0 --no-host-engine-baseline --no-cpu-baseline"
 for leg in $LEGS; do
   C="${CMD[$leg]}"
   (cd /tmp && timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$leg -o bench -- $C > $O/stats_$leg.log 2>&1)
