@@ -171,6 +171,7 @@ static oj::Value solve_doc(const Problem& pr, const std::vector<Pod>* probe_pods
     auto t1 = std::chrono::steady_clock::now();
     Results res = s.solve();
     auto t2 = std::chrono::steady_clock::now();
+    if (getenv("ORACLE_TIMING")) fprintf(stderr, "oracle timing: init %.1f s, solve %.1f s (sort.Slice %.1f s, in-flight scan %.1f s), %d thread(s)\n", std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count(), s.t_sort, s.t_scan, s.threads);
 
     oj::Value out = oj::Value::object();
     oj::Value claims = oj::Value::array();

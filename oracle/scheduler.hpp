@@ -284,6 +284,8 @@ struct Scheduler {
   size_t parallel_min = 512;          // scans shorter than this stay sequential
   struct Pool;
   std::shared_ptr<Pool> pool;
+  double t_sort = 0, t_scan = 0;   // seconds in sort.Slice / in the in-flight scan (ORACLE_TIMING prints them)
+  std::vector<unsigned long long> par_it_evals;   // per-candidate instance-type evaluation counts of the scan in flight
 
   // ---- pod requirement derivation: requirements.go:74-118 --------------------------------------------------
   static Requirements pod_requirements(Pod& p, bool required_only) {
@@ -715,13 +717,18 @@ struct Scheduler {
     if (add_to_existing(pod, queue_pod)) return true;
     // sort.Slice(s.newNodeClaims, len(Pods) asc) — scheduler.go:598, Go pdqsort (unstable)
     ctr.sorts++;
+    const auto tq0 = std::chrono::steady_clock::now();
     {
       auto less = [&](int i, int j) { return claim_pods[(size_t)i] < claim_pods[(size_t)j]; };
       auto swap = [&](int i, int j) { std::swap(new_node_claims[(size_t)i], new_node_claims[(size_t)j]); std::swap(claim_pods[(size_t)i], claim_pods[(size_t)j]); };
       GoSort<decltype(less), decltype(swap)> srt(less, swap);
       srt.sort_slice((int)new_node_claims.size());
     }
-    if (add_to_inflight(pod, queue_pod)) return true;
+    const auto tq1 = std::chrono::steady_clock::now();
+    const bool placed = add_to_inflight(pod, queue_pod);
+    const auto tq2 = std::chrono::steady_clock::now();
+    t_sort += std::chrono::duration<double>(tq1 - tq0).count(); t_scan += std::chrono::duration<double>(tq2 - tq1).count();
+    if (placed) return true;
     if (templates.empty()) { last_err = ERR_NO_TEMPLATES; last_diag = 0; return false; }
     return add_to_new_claim(pod, queue_pod);
   }
@@ -851,6 +858,7 @@ struct Scheduler::Pool {
         int spins = 0;
         while (generation.load(std::memory_order_acquire) == seen) {
           if (stop.load(std::memory_order_relaxed)) return;
+          __builtin_ia32_pause();   // (a spinning sibling hyperthread without it takes issue slots from the one that works)
           if (++spins > 20000) { std::this_thread::yield(); spins = 0; }
         }
         seen = generation.load(std::memory_order_acquire);
@@ -865,40 +873,52 @@ struct Scheduler::Pool {
     pending.store((int)workers.size(), std::memory_order_release);
     generation.fetch_add(1, std::memory_order_acq_rel);
     f(0);
-    while (pending.load(std::memory_order_acquire) != 0) {}
+    while (pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
   }
 };
 
 inline bool Scheduler::add_to_inflight_parallel(Pod& pod, Pod* queue_pod, const PodData& pd) {
   if (!pool) pool = std::make_shared<Pool>(threads);
   const size_t n = new_node_claims.size();
-  std::atomic<size_t> best(n), next(0);
-  std::vector<unsigned long long> it_evals(n, 0);
-  const size_t chunk = 8;
-  pool->run([&](int) {
-    for (;;) {
-      const size_t i0 = next.fetch_add(chunk);
-      if (i0 >= n || i0 > best.load()) return;
+  std::atomic<size_t> best(n);
+  // (every claim below the winner is evaluated exactly once, so the entries read below are all written: no zero-fill per pod)
+  if (par_it_evals.size() < n) par_it_evals.resize(n + n / 2 + 64);
+  unsigned long long* const it_evals = par_it_evals.data();
+  // chunks of eight candidates dealt round-robin (worker t takes chunks t, t + T, ...): no shared cursor to fight over, and a worker
+  // keeps meeting the same claims from pod to pod. A worker stops at the first chunk that starts beyond the best index so far.
+  const size_t chunk = 8, T = (size_t)threads;
+  // a worker keeps the outputs of the lowest candidate IT found to pass: the winner's are among them, no second evaluation
+  struct Found { size_t j; Requirements r; std::vector<const InstanceType*> its; std::vector<const Offering*> ofs; };
+  std::vector<Found> found(T);
+  for (auto& f : found) f.j = n;
+  pool->run([&](int t) {
+    Found& mine = found[(size_t)t];
+    for (size_t i0 = (size_t)t * chunk; i0 < n; i0 += T * chunk) {
+      if (i0 > best.load(std::memory_order_relaxed)) return;
       for (size_t j = i0; j < std::min(n, i0 + chunk); ++j) {
-        if (j > best.load()) return;
+        if (j > best.load(std::memory_order_relaxed)) return;
         EvalCtx cx;
         Requirements r; std::vector<const InstanceType*> its; std::vector<const Offering*> ofs;
         const bool ok = claim_can_add(*new_node_claims[j], pod, pd, false, r, its, ofs, &cx);
         it_evals[j] = (unsigned long long)cx.ctr.it_evaluations;
-        if (ok) { size_t cur = best.load(); while (j < cur && !best.compare_exchange_weak(cur, j)) {} }
+        if (ok) {
+          if (j < mine.j) { mine.j = j; mine.r = std::move(r); mine.its = std::move(its); mine.ofs = std::move(ofs); }
+          size_t cur = best.load(); while (j < cur && !best.compare_exchange_weak(cur, j)) {}
+          return;   // (everything this worker would still look at lies beyond j)
+        }
       }
     }
   });
   const size_t w = best.load();
-  // the sequential scan's counters: every claim up to the winner once
-  const size_t counted = w < n ? w : n;
+  // the sequential scan's counters: every claim up to and including the winner once
+  const size_t counted = w < n ? w + 1 : n;
   ctr.bin_evaluations += (long long)counted;
   for (size_t j = 0; j < counted; ++j) ctr.it_evaluations += (long long)it_evals[j];
   if (w == n) return false;
-  Requirements r; std::vector<const InstanceType*> its; std::vector<const Offering*> ofs;
-  const bool ok = claim_can_add(*new_node_claims[w], pod, pd, false, r, its, ofs);   // the winner again, for its outputs (counts itself)
-  if (!ok) throw std::runtime_error("parallel in-flight scan: the winner does not reproduce");
-  claim_add(*new_node_claims[w], queue_pod, pd, r, its, ofs);
+  Found* win = nullptr;
+  for (auto& f : found) if (f.j == w) win = &f;
+  if (!win) throw std::runtime_error("parallel in-flight scan: the winner's outputs are missing");
+  claim_add(*new_node_claims[w], queue_pod, pd, win->r, win->its, win->ofs);
   claim_pods[w] = (uint32_t)new_node_claims[w]->pods.size();
   return true;
 }

@@ -4,6 +4,7 @@ kube-apiserver in the reference; here only the scheduling decision is checked):
   pkg/controllers/provisioning/scheduling/topology_test.go     zonal / hostname spread :110-653, anti-affinity
   pkg/controllers/provisioning/scheduling/instance_selection_test.go :40-  (cheapest instance type)
 """
+import pytest
 import collections
 
 from karpenter_amd import fixtures as fx
@@ -288,3 +289,22 @@ def test_offering_override_groups_semantics(oracle):
         o["available"] = False
     r, _ = solve(oracle, [fx.pod(requests={"memory": "3Gi"})], its=[t])
     assert not r["podErrors"]
+
+
+@pytest.mark.parametrize("shape", ["config2", "config3", "config4"])
+def test_parallel_in_flight_scan_is_the_sequential_scan(oracle, monkeypatch, shape):
+    """ORACLE_THREADS fans the candidates of addToInflightNode out over a worker pool as the reference's parallelizeUntil does
+    (scheduler.go:939-961, :667-686: the lowest index that succeeds wins) — what the offline pins of the largest configurations are
+    made with. Same Results document, same counters as the sequential scan, with the fan-out forced on from the fourth claim."""
+    prob = {"config2": lambda: fx.config2(pods=3000, n_types=40, seed=5), "config3": lambda: fx.config3(pods=1500, n_types=30, seed=5),
+            "config4": lambda: fx.config4(pods=4000, n_types=60, n_pools=5, seed=5)}[shape]()
+    want = oracle.solve(prob)
+    monkeypatch.setenv("ORACLE_THREADS", "4")
+    monkeypatch.setenv("ORACLE_PAR_MIN", "4")
+    got = oracle.solve(prob)
+    assert len(want["newNodeClaims"]) > 8
+    for k in ("newNodeClaims", "podErrors", "packingCost"):
+        assert got[k] == want[k], k
+    for k in ("binEvaluations", "instanceTypeEvaluations"):
+        if k in want["counters"]:
+            assert got["counters"][k] == want["counters"][k], k
