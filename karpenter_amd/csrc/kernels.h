@@ -677,4 +677,91 @@ KS_FN void claim_gather_body(int i, const ClaimGatherArgs& a) {
   a.out_reserved[i] = a.c_reserved[src];
 }
 
+// A sweep's workspace records, built ON THE DEVICE (round 6). A probe's Workspace is ~600 bytes of pointers into the sweep's arena; built
+// on the host and uploaded they were 6 MB per 10,000 probes — most of the call's upload phase on a host link that moves 3.5 GB/s.
+// The host now sends one 48-byte descriptor per probe (where its block of the arena starts, its pods / removed nodes / claim slots)
+// and this function — the SAME code the host runs to measure a probe's block (arena = null) — lays the record out on the device,
+// one thread per probe (ksolve_sweep_items). Every region is rounded up to 64 bytes as the arena's take() rounds it.
+struct SweepItemDesc { uint64_t off, hl_off; uint32_t pod_b, m, node_b, n_removed, cb, mc, pv_entries, pad; };
+static_assert(sizeof(SweepItemDesc) == 48, "SweepItemDesc layout");
+struct SweepItemArgs {
+  char* arena;                    // null: measure only (the pointers written are meaningless, the sizes returned are exact)
+  const SweepItemDesc* desc;      // [n]
+  Workspace* items;               // [n] out
+  volatile int* const* cancel_each;   // [n] or null: the flag probe i polls where it has one of its own (probe handles in a batch)
+  // regions every probe has a share of
+  uint32_t *d_sorted, *d_removed, *d_slot, *d_last, *d_queue, *d_okey, *d_oord, *d_opos;
+  int64_t* d_limits; int32_t* d_assign; uint8_t *d_err, *d_diag;
+  uint64_t *d_hot, *d_cold, *d_resv, *d_chp;
+  int *d_nclaims, *d_status; Counters* d_ctr;
+  // the base handle's pristine node tables, its cancel flag and options
+  const uint64_t* n_mask0; const uint32_t *n_defined0, *n_complement0; const int64_t* n_remaining0;
+  volatile int* cancel; long long max_steps; int min_values_best_effort, order_cap;
+  // sizes
+  uint32_t ne, nr, T, nc, nk, it_words, req_words, hot_words, cold_words;
+  uint32_t bounds, has_topology, pv_on, hp_on;
+  uint32_t G, dom_words, hg, n_alias, n_key_slots;
+};
+// fills *W for probe p; returns the bytes of the probe's own block (from desc.off) and, through hl_bytes, of its hostname-threshold bitmaps
+KS_FN size_t sweep_item_fill(Workspace* W, const SweepItemArgs& A, const SweepItemDesc& d, uint32_t p, size_t* hl_bytes) {
+  size_t off = d.off;
+  char* const arena = A.arena;
+  auto take = [&](size_t bytes) -> void* { void* q = arena ? (void*)(arena + off) : nullptr; off += (bytes + 63) & ~(size_t)63; return q; };
+  const uint32_t m = d.m, mc = d.mc, cw = (mc + 63) / 64, nr = A.nr, T = A.T;
+  uint32_t oc = 64;
+  { const uint32_t a = m > 1 ? m : 1, b = A.ne > 1 ? A.ne : 1; while (oc < 2 * (a < b ? a : b)) oc <<= 1; }
+  Workspace w = Workspace{};
+  w.c_headroom = (int64_t*)take(((size_t)mc * nr + 64) * 8);
+  w.t_its = (uint64_t*)take((size_t)T * A.it_words * 8);
+  w.t_remaining = (int64_t*)take((size_t)T * (nr + 1) * 8);
+  w.dead = (uint64_t*)take((size_t)A.nc * cw * 8);
+  if (A.ne) {
+    w.ov_key = (uint32_t*)take((size_t)oc * 4); w.pr_revived = (uint32_t*)take((size_t)oc * 4);
+    w.n_mask = (uint64_t*)take((size_t)A.req_words * oc * 8);
+    w.n_defined = (uint32_t*)take((size_t)oc * 4); w.n_complement = (uint32_t*)take((size_t)oc * 4);
+    if (A.bounds) { w.n_hg = (uint32_t*)take((size_t)oc * 4); w.n_hl = (uint32_t*)take((size_t)oc * 4); w.n_gte = (int64_t*)take((size_t)A.nk * oc * 8); w.n_lte = (int64_t*)take((size_t)A.nk * oc * 8); }
+    w.n_remaining = (int64_t*)take((size_t)nr * oc * 8);
+    w.n_npods = (uint32_t*)take((size_t)oc * 4);
+    w.n_hp = A.hp_on ? (uint64_t*)take((size_t)oc * 8) : nullptr;
+    if (A.has_topology) {
+      const size_t G = A.G, dv = (size_t)A.dom_words * 64, hg = A.hg, ks_ = A.n_key_slots;
+      w.tg_domains = (uint64_t*)take(G * A.dom_words * 8); w.tg_counts = (int32_t*)take(G * dv * 4); w.tg_regs = (int32_t*)take(G * dv * 4);
+      w.tg_node_counts = (int32_t*)take(hg * oc * 4); w.tg_claim_counts = (int32_t*)take(hg * mc * 4);   // per overlay slot: what this probe's commits add to the cluster's shared per-node counts
+      w.tg_nonzero = (int32_t*)take(G * 4); w.tg_alias_active = A.n_alias ? (int32_t*)take((size_t)A.n_alias * 4) : nullptr;
+      w.c_keymask = (uint64_t*)take(ks_ * mc * 8);
+      w.kv_claims = (uint64_t*)take(ks_ * 64 * cw * 8);
+    }
+    if (A.pv_on) w.pv_log = (uint64_t*)take((size_t)(d.pv_entries > 1 ? d.pv_entries : 1) * 8);
+  }
+  w.ov_cap = (int)oc;
+  const size_t own = off - d.off;
+  size_t hl = 0;
+  if (A.has_topology) {   // starts as ones (all claims below every threshold): it lives behind the zero-filled regions
+    hl = (((size_t)A.hg * 2 * cw * 8) + 63) & ~(size_t)63;
+    w.host_le = arena ? (uint64_t*)(arena + d.hl_off) : nullptr;
+  }
+  if (hl_bytes) *hl_bytes = hl;
+  if (!W) return own;
+  const uint32_t b = d.pod_b, cb = d.cb;
+  w.max_claims = (int)mc; w.claim_words = (int)cw;
+  w.c_hot = A.d_hot + (size_t)cb * A.hot_words; w.c_cold = A.d_cold + (size_t)cb * A.cold_words;
+  w.c_reserved = A.d_resv + cb; w.c_hp = A.d_chp ? A.d_chp + cb : nullptr;
+  w.o_key = A.d_okey + cb; w.o_ord = A.d_oord + cb; w.o_pos = A.d_opos + cb;
+  w.queue = A.d_queue + b + p; w.last_len = A.d_last + b;
+  w.assign = A.d_assign + b; w.slot = A.d_slot + b; w.err = A.d_err + b; w.diag = A.d_diag + b;
+  w.n_claims_out = A.d_nclaims + p; w.status_out = A.d_status + p; w.counters = A.d_ctr + p;
+  w.cancel_flag = (A.cancel_each && A.cancel_each[p]) ? A.cancel_each[p] : A.cancel;   // ksolve_cancel(base) stops every probe of a ksolve_sweep
+  w.max_steps = A.max_steps;
+  w.min_values_best_effort = A.min_values_best_effort;
+  w.n_mask0 = A.n_mask0; w.n_defined0 = A.n_defined0; w.n_complement0 = A.n_complement0; w.n_remaining0 = A.n_remaining0;
+  w.probe = 1; w.pr_n_pods = (int)m; w.pr_sorted = A.d_sorted + b;
+  w.pr_removed = A.d_removed + d.node_b; w.pr_n_removed = (int)d.n_removed;
+  w.pr_limits = A.d_limits ? A.d_limits + (size_t)p * T * (nr + 1) : nullptr;
+  w.pr_order_cap = A.order_cap;
+  *W = w;
+  return own;
+}
+KS_FN void sweep_items_body(int i, const SweepItemArgs& a) { sweep_item_fill(a.items + i, a, a.desc[i], (uint32_t)i, nullptr); }
+
 }  // namespace ks
+

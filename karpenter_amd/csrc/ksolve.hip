@@ -523,6 +523,11 @@ __global__ void ksolve_claim_gather(int n, ks::ClaimGatherArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ks::claim_gather_body(i, a);
 }
+// a sweep's workspace records from their 48-byte descriptors (kernels.h sweep_item_fill), one thread per probe
+__global__ void ksolve_sweep_items(int n, ks::SweepItemArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ks::sweep_items_body(i, a);
+}
 __global__ void ksolve_fast_queue(int n, ks::FastQueueArgs a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ks::fast_queue_body(i, a);
@@ -621,6 +626,10 @@ static void be_launch_node_dead0(ksolve_handle* h, int n_blocks, const ks::NodeD
 static void be_launch_claim_gather(ksolve_handle* h, int n, const ks::ClaimGatherArgs& a) {
   hipLaunchKernelGGL(ksolve_claim_gather, grid_for(n), dim3(256), 0, HB(h)->stream, n, a);
   hip_check(h, hipGetLastError(), "ksolve_claim_gather launch");
+}
+static void be_launch_sweep_items(ksolve_handle* h, int n, const ks::SweepItemArgs& a) {
+  hipLaunchKernelGGL(ksolve_sweep_items, grid_for(n), dim3(256), 0, HB(h)->stream, n, a);
+  hip_check(h, hipGetLastError(), "ksolve_sweep_items launch");
 }
 static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, ks::Workspace* d_items, int n, const ks::LdsPlan& plan, const uint32_t* d_order, uint32_t* d_next) {
   if (n <= 0) return;

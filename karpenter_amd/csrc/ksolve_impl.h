@@ -142,6 +142,7 @@ static void be_free(ksolve_handle* h, void* p);   // releases one be_alloc'ed bl
 static void be_launch_node_dead0(ksolve_handle* h, int n_blocks, const ks::NodeDeadArgs& a);   // one wavefront per 64 nodes
 static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, ks::Workspace* d_items, int n, const ks::LdsPlan& plan, const uint32_t* d_order, uint32_t* d_next);   // block b = the general engine on probe b; sets T_PACK
 static void be_launch_claim_gather(ksolve_handle* h, int n, const ks::ClaimGatherArgs& a);
+static void be_launch_sweep_items(ksolve_handle* h, int n, const ks::SweepItemArgs& a);
 
 namespace ksi {
 
@@ -1221,14 +1222,19 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
   // ---- validate + queue order per probe (the base queue order, restricted) ----
   // what the launch reads — every probe's workspace record, its pods in queue order, its removed nodes — is written straight into
   // the handle's page-locked staging memory: one DMA each instead of a staged copy out of pageable vectors
-  const size_t st_items = ((size_t)n * sizeof(ks::Workspace) + 63) & ~(size_t)63, st_sorted = ((size_t)total_pods * 4 + 67) & ~(size_t)63, st_removed = ((size_t)total_nodes * 4 + 67) & ~(size_t)63;
+  // (round 6: the workspace records are laid out by the device from one 48-byte descriptor per probe — kernels.h sweep_item_fill)
+  bool any_cancel = false;
+  for (uint32_t p = 0; p < n; ++p) any_cancel = any_cancel || (cancel && cancel[p]);
+  const size_t st_items = ((size_t)n * sizeof(ks::SweepItemDesc) + 63) & ~(size_t)63, st_sorted = ((size_t)total_pods * 4 + 67) & ~(size_t)63, st_removed = ((size_t)total_nodes * 4 + 67) & ~(size_t)63;
   const size_t st_order = ((size_t)n * 4 + 67) & ~(size_t)63;   // the order the compact launch hands the probes out in
-  char* stage = (char*)be_stage(base, st_items + st_sorted + st_removed + st_order);
+  const size_t st_cancel = any_cancel ? ((size_t)n * 8 + 63) & ~(size_t)63 : 0;
+  char* stage = (char*)be_stage(base, st_items + st_sorted + st_removed + st_order + st_cancel);
   if (!stage) return fail(base, KSOLVE_ERR_DEVICE, base->error.empty() ? "host staging allocation failed" : base->error);
-  ks::Workspace* const items = (ks::Workspace*)stage;
+  ks::SweepItemDesc* const descs = (ks::SweepItemDesc*)stage;
   uint32_t* const sorted = (uint32_t*)(stage + st_items);
   uint32_t* const removed = (uint32_t*)(stage + st_items + st_sorted);
   uint32_t* const ord = (uint32_t*)(stage + st_items + st_sorted + st_removed);
+  volatile int** const cancel_h = any_cancel ? (volatile int**)(stage + st_items + st_sorted + st_removed + st_order) : nullptr;
   std::vector<uint32_t> perm(total_pods);   // perm: position in the probe's sorted list -> position in the caller's list
   if (total_nodes) memcpy(removed, nodes, (size_t)total_nodes * 4);
   {
@@ -1330,13 +1336,39 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
   int32_t* d_assign = nullptr; uint32_t* d_slot = nullptr; uint8_t* d_err = nullptr; uint8_t* d_diag = nullptr; uint32_t* d_last = nullptr; uint32_t* d_queue = nullptr;
   uint64_t* d_hot = nullptr; uint64_t* d_cold = nullptr; uint64_t* d_resv = nullptr; uint64_t* d_chp = nullptr; uint32_t* d_okey = nullptr; uint32_t* d_oord = nullptr; uint32_t* d_opos = nullptr;
   int* d_nclaims = nullptr; int* d_status = nullptr; ks::Counters* d_ctr = nullptr; ks::Workspace* d_items = nullptr;
+  ks::SweepItemDesc* d_descs = nullptr; volatile int** d_cancel_each = nullptr;
   uint32_t* d_order = nullptr; uint32_t* d_next = nullptr;   // the compact launch hands out probes largest first through a counter (below)
   size_t zero_from = 0, zero_to = 0, ones_to = 0;
   bool any_limits = false;
   for (uint32_t p = 0; p < n; ++p) any_limits = any_limits || (limits && limits[p]);
+  ks::SweepItemArgs IA{};
+  IA.ne = ne; IA.nr = nr; IA.T = T; IA.nc = nc; IA.nk = nk; IA.it_words = base->it_words; IA.req_words = base->req_words;
+  IA.hot_words = (uint32_t)lay.c_hot_words(); IA.cold_words = (uint32_t)lay.cold_words();
+  IA.bounds = bounds ? 1u : 0u; IA.has_topology = base->has_topology ? 1u : 0u; IA.pv_on = P.pv_on ? 1u : 0u; IA.hp_on = P.hp_on ? 1u : 0u;
+  if (base->has_topology) {
+    const ks::TopoView& Tv = P.topo;
+    IA.G = (uint32_t)Tv.n_groups; IA.dom_words = (uint32_t)Tv.dom_words; IA.hg = (uint32_t)std::max(1, Tv.n_host_groups); IA.n_alias = (uint32_t)Tv.n_alias; IA.n_key_slots = (uint32_t)std::max(1, Tv.n_key_slots);
+  }
+  // every probe's descriptor and the bytes of its own block (the device lays the same block out with the same function)
+  std::vector<size_t> own(n), hlb(n);
+  for (uint32_t p = 0; p < n; ++p) {
+    ks::SweepItemDesc& d = descs[p];
+    d = ks::SweepItemDesc{};
+    d.pod_b = pod_off[p]; d.m = pod_off[p + 1] - pod_off[p]; d.node_b = node_off[p]; d.n_removed = node_off[p + 1] - node_off[p];
+    d.cb = claim_base[p]; d.mc = claim_base[p + 1] - claim_base[p];
+    if (P.pv_on && ne) {
+      size_t entries = 0;
+      for (uint32_t i = pod_off[p]; i < pod_off[p + 1]; ++i) entries += base->h_pod_pv_first[pods[i] + 1] - base->h_pod_pv_first[pods[i]];
+      d.pv_entries = (uint32_t)entries;
+    }
+    own[p] = ks::sweep_item_fill(nullptr, IA, d, p, &hlb[p]);
+    if (cancel_h) cancel_h[p] = cancel[p];
+  }
   auto layout = [&]() {
     off = 0;
     d_items = (ks::Workspace*)take((size_t)n * sizeof(ks::Workspace));
+    d_descs = (ks::SweepItemDesc*)take((size_t)n * sizeof(ks::SweepItemDesc));
+    d_cancel_each = any_cancel ? (volatile int**)take((size_t)n * 8) : nullptr;
     d_sorted = (uint32_t*)take((size_t)total_pods * 4 + 4);
     d_removed = (uint32_t*)take((size_t)total_nodes * 4 + 4);
     d_limits = any_limits ? (int64_t*)take((size_t)n * T * (nr + 1) * 8) : nullptr;
@@ -1349,46 +1381,10 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
     d_resv = (uint64_t*)take((size_t)total_mc * 8); d_chp = P.hp_on ? (uint64_t*)take((size_t)total_mc * 8) : nullptr;
     d_okey = (uint32_t*)take((size_t)total_mc * 4); d_oord = (uint32_t*)take((size_t)total_mc * 4); d_opos = (uint32_t*)take((size_t)total_mc * 4);
     d_nclaims = (int*)take((size_t)n * 4); d_status = (int*)take((size_t)n * 4); d_ctr = (ks::Counters*)take((size_t)n * sizeof(ks::Counters));
-    for (uint32_t p = 0; p < n; ++p) {
-      ks::Workspace& W = items[p];
-      const uint32_t m = pod_off[p + 1] - pod_off[p], mc = claim_base[p + 1] - claim_base[p], cw = (mc + 63) / 64;
-      uint32_t oc = 64;
-      while (oc < 2 * std::min(std::max(1u, m), std::max(1u, ne))) oc <<= 1;
-      W.c_headroom = (int64_t*)take(((size_t)mc * nr + 64) * 8);
-      W.t_its = (uint64_t*)take((size_t)T * base->it_words * 8);
-      W.t_remaining = (int64_t*)take((size_t)T * (nr + 1) * 8);
-      W.dead = (uint64_t*)take((size_t)nc * cw * 8);
-      if (ne) {
-        W.ov_key = (uint32_t*)take((size_t)oc * 4); W.pr_revived = (uint32_t*)take((size_t)oc * 4);
-        W.n_mask = (uint64_t*)take((size_t)base->req_words * oc * 8);
-        W.n_defined = (uint32_t*)take((size_t)oc * 4); W.n_complement = (uint32_t*)take((size_t)oc * 4);
-        if (bounds) { W.n_hg = (uint32_t*)take((size_t)oc * 4); W.n_hl = (uint32_t*)take((size_t)oc * 4); W.n_gte = (int64_t*)take((size_t)nk * oc * 8); W.n_lte = (int64_t*)take((size_t)nk * oc * 8); }
-        W.n_remaining = (int64_t*)take((size_t)nr * oc * 8);
-        W.n_npods = (uint32_t*)take((size_t)oc * 4);
-        W.n_hp = P.hp_on ? (uint64_t*)take((size_t)oc * 8) : nullptr;
-        if (base->has_topology) {
-          const ks::TopoView& T = P.topo;
-          const size_t G = (size_t)T.n_groups, dv = (size_t)T.dom_words * 64, hg = (size_t)std::max(1, T.n_host_groups);
-          W.tg_domains = (uint64_t*)take(G * T.dom_words * 8); W.tg_counts = (int32_t*)take(G * dv * 4); W.tg_regs = (int32_t*)take(G * dv * 4);
-          W.tg_node_counts = (int32_t*)take(hg * oc * 4); W.tg_claim_counts = (int32_t*)take(hg * mc * 4);   // per overlay slot: what this probe's commits add to the cluster's shared per-node counts
-          W.tg_nonzero = (int32_t*)take(G * 4); W.tg_alias_active = T.n_alias ? (int32_t*)take((size_t)T.n_alias * 4) : nullptr;
-          W.c_keymask = (uint64_t*)take((size_t)std::max(1, T.n_key_slots) * mc * 8);
-          W.kv_claims = (uint64_t*)take((size_t)std::max(1, T.n_key_slots) * 64 * cw * 8);
-        }
-        if (P.pv_on) {
-          size_t entries = 0;
-          for (uint32_t i = pod_off[p]; i < pod_off[p + 1]; ++i) entries += base->h_pod_pv_first[pods[i] + 1] - base->h_pod_pv_first[pods[i]];
-          W.pv_log = (uint64_t*)take(std::max<size_t>(1, entries) * 8);
-        }
-      }
-      W.ov_cap = (int)oc;
-    }
+    for (uint32_t p = 0; p < n; ++p) { descs[p].off = off; off += own[p]; }
     zero_to = off;
     d_assign = (int32_t*)take((size_t)total_pods * 4 + 4);   // starts as -1; so do the hostname-group threshold bitmaps (all claims below every threshold)
-    if (base->has_topology) for (uint32_t p = 0; p < n; ++p) {
-      const uint32_t mc = claim_base[p + 1] - claim_base[p], cw = (mc + 63) / 64;
-      items[p].host_le = (uint64_t*)take((size_t)std::max(1, P.topo.n_host_groups) * 2 * cw * 8);
-    }
+    for (uint32_t p = 0; p < n; ++p) { descs[p].hl_off = off; off += hlb[p]; }
     ones_to = off;
   };
 #ifdef KSOLVE_TEST_HOOKS
@@ -1400,7 +1396,6 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
   base->sweep_arena_refused = false;
   arena = sweep_buffer(base, base->sweep_arena, base->sweep_arena_bytes, total, true);
   if (!arena) return fail(base, KSOLVE_ERR_DEVICE, base->error.empty() ? "device allocation failed (sweep arena)" : base->error);
-  for (uint32_t p = 0; p < n; ++p) items[p] = ks::Workspace{};
   layout();
   std::vector<int64_t> lim;
   if (any_limits) {
@@ -1410,29 +1405,20 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
     be_sync(base);
     for (uint32_t p = 0; p < n; ++p) memcpy(lim.data() + (size_t)p * T * (nr + 1), (limits[p] ? limits[p] : base_lim.data()), (size_t)T * (nr + 1) * 8);
   }
-  for (uint32_t p = 0; p < n; ++p) {
-    ks::Workspace& W = items[p];
-    const uint32_t b = pod_off[p], m = pod_off[p + 1] - b, cb = claim_base[p], mc = claim_base[p + 1] - cb;
-    W.max_claims = (int)mc; W.claim_words = (int)((mc + 63) / 64);
-    W.c_hot = d_hot + (size_t)cb * lay.c_hot_words(); W.c_cold = d_cold + (size_t)cb * lay.cold_words();
-    W.c_reserved = d_resv + cb; W.c_hp = d_chp ? d_chp + cb : nullptr;
-    W.o_key = d_okey + cb; W.o_ord = d_oord + cb; W.o_pos = d_opos + cb;
-    W.queue = d_queue + b + p; W.last_len = d_last + b;
-    W.assign = d_assign + b; W.slot = d_slot + b; W.err = d_err + b; W.diag = d_diag + b;
-    W.n_claims_out = d_nclaims + p; W.status_out = d_status + p; W.counters = d_ctr + p;
-    W.cancel_flag = (cancel && cancel[p]) ? cancel[p] : base->d_cancel;   // ksolve_cancel(base) stops every probe of a ksolve_sweep
-    W.max_steps = base->opts.max_steps;
-    W.min_values_best_effort = base->opts.min_values_best_effort ? 1 : 0;
-    W.n_mask0 = base->ws.n_mask0; W.n_defined0 = base->ws.n_defined0; W.n_complement0 = base->ws.n_complement0; W.n_remaining0 = base->ws.n_remaining0;
-    W.probe = 1; W.pr_n_pods = (int)m; W.pr_sorted = d_sorted + b;
-    W.pr_removed = d_removed + node_off[p]; W.pr_n_removed = (int)(node_off[p + 1] - node_off[p]);
-    W.pr_limits = d_limits ? d_limits + (size_t)p * T * (nr + 1) : nullptr;
-    W.pr_order_cap = lp.order_cap;
-  }
+  IA.arena = arena; IA.desc = d_descs; IA.items = d_items; IA.cancel_each = (volatile int* const*)d_cancel_each;
+  IA.d_sorted = d_sorted; IA.d_removed = d_removed; IA.d_slot = d_slot; IA.d_last = d_last; IA.d_queue = d_queue; IA.d_okey = d_okey; IA.d_oord = d_oord; IA.d_opos = d_opos;
+  IA.d_limits = d_limits; IA.d_assign = d_assign; IA.d_err = d_err; IA.d_diag = d_diag;
+  IA.d_hot = d_hot; IA.d_cold = d_cold; IA.d_resv = d_resv; IA.d_chp = d_chp; IA.d_nclaims = d_nclaims; IA.d_status = d_status; IA.d_ctr = d_ctr;
+  IA.n_mask0 = base->ws.n_mask0; IA.n_defined0 = base->ws.n_defined0; IA.n_complement0 = base->ws.n_complement0; IA.n_remaining0 = base->ws.n_remaining0;
+  IA.cancel = base->d_cancel; IA.max_steps = base->opts.max_steps; IA.min_values_best_effort = base->opts.min_values_best_effort ? 1 : 0; IA.order_cap = lp.order_cap;
+  ks::Workspace item0 = ks::Workspace{};   // probe 0's record as the device builds it: the finalize kernel borrows its per-template arrays
+  if (n) ks::sweep_item_fill(&item0, IA, descs[0], 0, nullptr);
 #ifdef KSOLVE_TEST_HOOKS
   auto t_c = tnow();
 #endif
-  be_h2d(base, d_items, items, (size_t)n * sizeof(ks::Workspace));
+  be_h2d(base, d_descs, descs, (size_t)n * sizeof(ks::SweepItemDesc));
+  if (d_cancel_each) be_h2d(base, d_cancel_each, (const void*)cancel_h, (size_t)n * 8);
+  be_launch_sweep_items(base, (int)n, IA);
   if (total_pods) be_h2d(base, d_sorted, sorted, (size_t)total_pods * 4);
   if (total_nodes) be_h2d(base, d_removed, removed, (size_t)total_nodes * 4);
   if (d_limits) be_h2d(base, d_limits, lim.data(), lim.size() * 8);
@@ -1507,7 +1493,7 @@ static ksolve_status sweep_run(ksolve_handle* base, uint32_t n, const uint32_t* 
     flay();
     be_h2d(base, f_slot, slot_of.data(), (size_t)C * 4);
     ks::FinalizeArgs F{P.dict, (int)n_its, (int)base->it_words, P.n_zones, P.n_cts, P.it_off_avail, P.it_off_price, d_hot, d_cold, lay, f_cheap,
-                       P.dg_first, P.dg_ov, P.dg_its, P.dg_nonempty, items[0].t_its, f_dreq,
+                       P.dg_first, P.dg_ov, P.dg_its, P.dg_nonempty, item0.t_its, f_dreq,
                        P.reserved_on ? d_resv : nullptr, P.it_resv_first, P.resv_zone, P.resv_id, P.resv_price,
                        0, 0, P.it_reqs, nullptr, nullptr, nullptr, nullptr, f_slot};
     if (trunc) {
@@ -1583,7 +1569,7 @@ static size_t sweep_probe_bytes(const ksolve_handle* base, uint32_t m, size_t pv
   size_t oc = 64;
   while (oc < 2 * std::min<size_t>(std::max<size_t>(1, m), std::max<size_t>(1, ne))) oc <<= 1;
   auto r = [](size_t b) { return (b + 63) & ~(size_t)63; };
-  size_t b = sizeof(ks::Workspace) + 8 + 4 + sizeof(ks::Counters);                      // + nclaims, status, its place in the hand-out order
+  size_t b = sizeof(ks::Workspace) + sizeof(ks::SweepItemDesc) + 8 + 8 + 4 + sizeof(ks::Counters);   // + its descriptor, its cancel flag's address, nclaims, status, its place in the hand-out order
   b += (size_t)m * (4 + 4 + 1 + 1 + 4 + 4 + 4) + 4;                                     // sorted, slot, err, diag, lastLen, queue, assign
   b += mc * ((size_t)lay.c_hot_words() * 8 + (size_t)lay.cold_words() * 8 + 8 + (P.hp_on ? 8 : 0) + 12);
   if (with_limits) b += T * (nr + 1) * 8;

@@ -10,7 +10,14 @@
 // reads their fields (table pointers, sizes, option flags) all through a probe, and from HBM every such read was a vector load with
 // an L2 round trip in front of its use — the records are wave-uniform, but the compiler cannot scalarise loads through a pointer it
 // cannot prove read-only. ks::kSweepLdsExtra bytes behind the plan's own: the view once per workgroup, a workspace per wavefront.
-__global__ void __launch_bounds__(256, 2) ksolve_pack_sweep4(const ks::ProblemView* pv, ks::Workspace* items, int n, ks::LdsPlan plan, const uint32_t* order, uint32_t* next) {
+// (measurement build -DKSOLVE_SWEEP4_NO_SPILL: one wavefront per SIMD, 512 VGPRs, nothing spilled — what the spills of the shipped form cost
+// in traffic and time is the difference between the two, profiles/round6)
+#ifdef KSOLVE_SWEEP4_NO_SPILL
+#define KS_SWEEP4_BOUNDS __launch_bounds__(256, 1)
+#else
+#define KS_SWEEP4_BOUNDS __launch_bounds__(256, 2)
+#endif
+__global__ void KS_SWEEP4_BOUNDS ksolve_pack_sweep4(const ks::ProblemView* pv, ks::Workspace* items, int n, ks::LdsPlan plan, const uint32_t* order, uint32_t* next) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef ks::Engine<ks::Wave, true, false, ks::ScratchSmall> Eng;
   const int wave = (int)(threadIdx.x >> 6);

@@ -22,10 +22,14 @@
 //     member needs a claim of its own) reads the short list of claims that hold no member yet instead — usually empty: the pod goes
 //     straight to addToNewNodeClaim.
 //
-// Whatever it does not handle (node filters, minDomains, groups created by relaxation, anti-affinity on a dictionary key, affinity
-// on the hostname, several dictionary-key groups owned by one pod, an unschedulable pod, NodePool limits that exclude a type ...)
-// makes it stop with status 3 before it has written a result; the host runs the general engine on the same problem. There is no
-// CPU path.
+// Widened after its first GPU passes (round 6): minDomains (topologygroup.go:318-320), up to TWO groups on dictionary keys per pod
+// (zone + capacity-type spread; spread and affinity on one key — each narrows from the claim's own set, topology.go:226-250; such a
+// pod takes the out-of-line select so that the loop's own step carries neither the code nor the registers), pod anti-affinity on a
+// dictionary key with its inverse groups (every domain the pod could land in is blocked, topology.go:203-206, :213-219).
+//
+// Whatever it does not handle (node filters, groups created by relaxation, affinity on the hostname, three or more dictionary-key
+// groups on one pod, maxSkew beyond a counter's range, an unschedulable pod, NodePool limits that exclude a type ...) makes it stop
+// with status 3 before it has written a result; the host runs the general engine on the same problem. There is no CPU path.
 #pragma once
 #include "fast_engine.h"
 #include "run_order.h"

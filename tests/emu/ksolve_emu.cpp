@@ -166,6 +166,7 @@ static void be_free(ksolve_handle* h, void* p) {
 }
 static void be_launch_node_dead0(ksolve_handle*, int n_blocks, const ks::NodeDeadArgs& a) { for (int b = 0; b < n_blocks; ++b) for (int c = 0; c * ks::kDead0Classes < a.n_classes; ++c) ks::node_dead0_body<ks::Wave>(b, c, a); }
 static void be_launch_claim_gather(ksolve_handle*, int n, const ks::ClaimGatherArgs& a) { for (int i = 0; i < n; ++i) ks::claim_gather_body(i, a); }
+static void be_launch_sweep_items(ksolve_handle*, int n, const ks::SweepItemArgs& a) { for (int i = 0; i < n; ++i) ks::sweep_items_body(i, a); }
 static void be_launch_pack_sweep(ksolve_handle* h, const ks::ProblemView* d_pv, ks::Workspace* d_items, int n, const ks::LdsPlan& plan_in, const uint32_t* d_order, uint32_t* d_next) {
   be_tic(h, ksi::T_PACK);
   if (plan_in.waves == 4) {
