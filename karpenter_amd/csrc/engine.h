@@ -201,6 +201,14 @@ struct Engine {
   int n_pv_log = 0;                 // entries of Workspace::pv_log
   int cur_out = 0;                  // where the pod being placed reports its result: its pod index, or its position in Workspace::pr_sorted (probes)
   int n_revived = 0;                // probes: entries of Workspace::pr_revived
+  // (round 6) a probe's overlay index in a vector register: with ov_cap == 64 (a probe of up to 32 pods — every single-node probe) lane s
+  // holds the node of overlay slot s (node + 1, slots handed out in order), so "is node e overlaid, and where" is a walk over n_ov
+  // readlanes instead of a hash probe into HBM — it was asked three times per pod (the block's lanes, node_merge, ov_touch), each a
+  // dependent L2 round trip of the probe's chain. Larger probes keep the open-addressing table in Workspace::ov_key.
+  LaneVar<uint32_t> ovk_;
+  int n_ov = 0;
+  bool ov_regs = false;
+  bool cur_exempt = false;          // the pod being placed is pending or comes from a deleting node (scheduler.go:628 does not skip nodes for it)
 
   KS_DEV Engine(const ProblemView& p, Workspace& s, const LdsTables& l) : P(p), S(s), L(l), sc(*(SC*)l.scratch), lay(p.lay) {
     if constexpr (BIG) order.init(L.runs, s.o_ring, s.o_cnt, s.o_pos, s.o_key, s.o_ord, s.run_tabs, s.run_off, s.run_log, s.run_kmax);
@@ -1712,6 +1720,11 @@ struct Engine {
   // slot of node e's mutable state: e itself outside probes, its overlay slot or -1 (pristine) in a probe. Per lane.
   KS_DEV int ov_find(int e) const {
     if (!S.probe) return e;
+    if (ov_regs) {
+      int os = -1;
+      for (int s = 0; s < n_ov; ++s) if (ovk_.bcast(s) == (uint32_t)e + 1u) os = s;
+      return os;
+    }
     const uint32_t m = (uint32_t)S.ov_cap - 1;
     for (uint32_t h = (ov_hash(e) >> 8) & m;; h = (h + 1) & m) {
       const uint32_t kx = S.ov_key[h];
@@ -1725,14 +1738,20 @@ struct Engine {
     else { t.mask = S.n_mask0; t.defined = S.n_defined0; t.complement = S.n_complement0; t.hg = nullptr; t.hl = nullptr; t.gte = nullptr; t.lte = nullptr; t.remaining = S.n_remaining0; t.hp = P.node_hp0; t.stride = (size_t)P.n_nodes; }
     return t;
   }
+  // a free overlay slot for node en (not overlaid yet); the caller fills the slot's state
+  KS_DEV int ov_new(int en) {
+    if (ov_regs) { const int os = n_ov; ovk_.set(os, (uint32_t)en + 1u); n_ov++; return os; }
+    const uint32_t m = (uint32_t)S.ov_cap - 1;
+    uint32_t h = (ov_hash(en) >> 8) & m;
+    while (S.ov_key[h]) h = (h + 1) & m;
+    if (W::leader()) S.ov_key[h] = (uint32_t)en + 1u;
+    return (int)h;
+  }
   // the overlay slot of node en, created from the pristine tables when the probe touches the node for the first time
   KS_DEV int ov_touch(int en) {
     int os = ov_find(en);
     if (os >= 0) return os;
-    const uint32_t m = (uint32_t)S.ov_cap - 1;
-    uint32_t h = (ov_hash(en) >> 8) & m;
-    while (S.ov_key[h]) h = (h + 1) & m;
-    os = (int)h;
+    os = ov_new(en);
     const int ne = P.n_nodes, oc = S.ov_cap;
     const Workspace& Sw = S;
     const ProblemView& Pv = P;
@@ -1743,7 +1762,6 @@ struct Engine {
       S.n_defined[os] = S.n_defined0[en]; S.n_complement[os] = S.n_complement0[en]; S.n_npods[os] = 0;
       if (S.n_hg) { S.n_hg[os] = 0; S.n_hl[os] = 0; }
       if (Pv.hp_on) S.n_hp[os] = Pv.node_hp0 ? Pv.node_hp0[en] : 0ull;
-      S.ov_key[os] = (uint32_t)en + 1u;
     }
     W::sync();
     return os;
@@ -1833,7 +1851,7 @@ struct Engine {
     const NodeClassCtx cx = node_class_ctx(d, ly, sc.cls, sc.cls_cold, Pv.hp_on ? cur_hp_conf : 0ull);
     const int64_t* req = cx.req;
     const NodeTabs mut = node_tabs(true), pris = node_tabs(false);
-    const bool exempt_pod = Pv.pod_is_pending[pod] != 0 || (Pv.pod_from_deleting && Pv.pod_from_deleting[pod] != 0);
+    const bool exempt_pod = cur_exempt;   // (fetched with the pod's queue block: pod_is_pending / pod_from_deleting)
     uint64_t* ndead = probe ? nullptr : S.n_dead + (size_t)k * P.node_words;
     int base = -64;
     for (;;) {
@@ -1906,6 +1924,36 @@ struct Engine {
       ctr.bin_evaluations += popc64(todo & (below | (1ull << l)));
       // ---- ExistingNode.Add (existingnode.go:172-185): requirements <- node ∧ pod ∧ topology, remaining -= requests
       const ReqBuf& m = *fin;
+      // A probe's first pod on a node whose requirements the pod leaves as they are (the usual case: the node's labels already say what
+      // the pod asks for): the overlay slot is written straight from what is at hand — the merged set IS the node's, the remaining
+      // resources are the pristine ones less the requests — instead of a copy of the pristine state that is then read back and updated
+      // (two dependent round trips and a fence of the probe's chain).
+      const bool fresh = probe && !changed && !S.n_hg && ov_find(en) < 0;
+      if (fresh) {
+        const int os = ov_new(en);
+        const size_t st = (size_t)nst();
+        uint64_t* nm = S.n_mask; int64_t* nrem = S.n_remaining;
+        const int64_t* rem0 = S.n_remaining0;
+        W::for_n(ly.rw, [&](int w) { nm[(size_t)w * st + os] = m.mask[w]; });
+        W::for_n(nr, [&](int r) { nrem[(size_t)r * st + os] = rem0[(size_t)r * ne + en] - req[r]; });      // resources.SubtractFrom — existingnode.go:175
+        if (W::leader()) {
+          S.n_defined[os] = m.defined; S.n_complement[os] = m.complement; S.n_npods[os] = 1;
+          if (Pv.hp_on) S.n_hp[os] = (Pv.node_hp0 ? Pv.node_hp0[en] : 0ull) | cur_hp_use;                  // existingnode.go:178
+        }
+        if (cur_rec) { W::sync(); topo_record(Pv.node_taints[en], m.ref(), 1, en); }                        // existingnode.go:184
+        if (cur_pv_n && pv_fresh) {   // VolumeUsage.Add — existingnode.go:179
+          const uint64_t fr = pv_fresh;
+          const int at = n_pv_log;
+          const uint32_t pf = cur_pv_first;
+          uint64_t* lg = S.pv_log;
+          W::each([&](int l) { if ((fr >> l) & 1) lg[at + popc64(fr & ((1ull << l) - 1))] = ((uint64_t)(uint32_t)en << 32) | Pv.pod_pvs[pf + l]; });
+          n_pv_log += popc64(fr);
+        }
+        W::store(&S.assign[cur_out], (int32_t)(-2 - en));
+        W::store(&S.slot[cur_out], 0u);
+        W::sync();
+        return true;
+      }
       const int os = probe ? ov_touch(en) : en;     // the node's mutable state (a probe's overlay slot)
       const size_t st = (size_t)nst();
       uint64_t* nm = S.n_mask;
@@ -2246,7 +2294,8 @@ struct Engine {
     if (FULL && P.n_nodes && S.probe) {
       // a probe of a resident cluster: nothing is copied, the overlay starts empty
       Workspace& Sw = S;
-      W::for_n(S.ov_cap, [&](int i) { Sw.ov_key[i] = 0; });
+      ov_regs = S.ov_cap == 64; n_ov = 0;
+      if (!ov_regs) W::for_n(S.ov_cap, [&](int i) { Sw.ov_key[i] = 0; });
       n_revived = 0;
     } else if (FULL && P.n_nodes) {
       // ExistingNodes are mutated by Solve: start from the pristine copies
@@ -2295,10 +2344,11 @@ struct Engine {
         blk_i = 0;
         uint32_t* bp = sc.blk_pod; uint32_t* bc = sc.blk_class; uint32_t* bl = sc.blk_last; uint32_t* bo = sc.blk_out;
         const uint32_t* rc_ = P.row_class; const uint32_t* ll = S.last_len;
+        const uint8_t* pend = (FULL && P.n_nodes) ? P.pod_is_pending : nullptr; const uint8_t* pdel = (FULL && P.n_nodes) ? P.pod_from_deleting : nullptr;
         const int bn = blk_n;
         const uint32_t h0 = head;
         W::for_n(64, [&](int l) {
-          if (l < bn) { const uint32_t q = queue[(h0 + (uint32_t)l) % cap]; const uint32_t p = probe ? sorted[q] : q; bp[l] = p; bo[l] = q; bc[l] = rc_[p]; bl[l] = ll[q]; }
+          if (l < bn) { const uint32_t q = queue[(h0 + (uint32_t)l) % cap]; const uint32_t p = probe ? sorted[q] : q; bp[l] = p; bo[l] = q; bc[l] = rc_[p]; bl[l] = ll[q] | (((pend && pend[p]) || (pdel && pdel[p])) ? 0x80000000u : 0u); }   // (bit 31: exempt from the consolidateAfter skip)
         });
         if (S.cancel_flag) {   // ctx cancellation, polled once per 64 pods (< 0: tests only, see fast_engine.h)
           const int cv = W::poll_flag(S.cancel_flag);
@@ -2309,7 +2359,8 @@ struct Engine {
       const int out = (int)sc.blk_out[blk_i];
       cur_out = out;
       if (FULL && P.pv_on) { cur_pv_first = P.pod_pv_first[pod]; cur_pv_n = P.pod_pv_first[pod + 1] - cur_pv_first; }
-      if (sc.blk_last[blk_i] == qlen) break;                                // queue.go:52-56
+      cur_exempt = (sc.blk_last[blk_i] >> 31) != 0;
+      if ((sc.blk_last[blk_i] & 0x7FFFFFFFu) == qlen) break;                // queue.go:52-56
       if (S.max_steps >= 0 && steps >= S.max_steps) { status = 2; break; }
       int k0 = (int)sc.blk_class[blk_i];
       blk_i++;

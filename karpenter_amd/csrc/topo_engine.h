@@ -223,6 +223,8 @@ struct TopoEngine {
   // narrowed by the pod's selectors and its domain choice.
   struct KClass { uint64_t hlim, cvmask, dmask; int32_t s0, s1, s2, s3; uint32_t tmplok; };
   // one group's choice on the claim's set: the claim's field of the key ∧ the candidates (∧ what an earlier group of the same key left)
+  // FIRST: m2 is still the claim's own set (the first group's choice): the candidates are a subset of its field, nothing to intersect
+  template <bool FIRST>
   KS_DEV bool apply_choice(uint64_t m, uint64_t& m2, const ZChoice& zc, const LaneVar<uint64_t>& zkv) const {
     const uint32_t fm = (1u << zc.width) - 1;
     const uint32_t zf = (uint32_t)(m >> zc.off) & fm;
@@ -231,11 +233,16 @@ struct TopoEngine {
     if (!zc.multi) {
       uint64_t best = ~0ull;
       for (int z = 0; z < zc.width; ++z) { const uint64_t kz = zkv.bcast(z); if (((cand >> z) & 1) && kz < best) best = kz; }
-      nf = cand ? 1u << (best & (kTopoMaxDom - 1)) : 0u;
+      nf = 1u << (best & (kTopoMaxDom - 1));   // (no candidate: whatever — the verdict below says so)
     }
-    nf &= (uint32_t)(m2 >> zc.off) & fm;
-    m2 = (m2 & ~zc.clear) | ((uint64_t)nf << zc.off);
-    return nf != 0;
+    if constexpr (FIRST) {
+      m2 = (m & ~zc.clear) | ((uint64_t)nf << zc.off);
+      return cand != 0;
+    } else {
+      nf = cand ? nf & ((uint32_t)(m2 >> zc.off) & fm) : 0u;
+      m2 = (m2 & ~zc.clear) | ((uint64_t)nf << zc.off);
+      return nf != 0;
+    }
   }
   // TWO = false: the loop's own form — a class with a second group on a dictionary key goes through the out-of-line paths, so that the
   // step of every other class carries neither its code nor its registers
@@ -247,8 +254,8 @@ struct TopoEngine {
     m2 = m;
     bool ok = ((k.tmplok >> t) & 1u) != 0 && fast_fields_ok(m, k.dmask);
     ok = ok && (((k.hlim - hcnt) & kTopoGuard) == kTopoGuard);
-    if (zc.on) ok = apply_choice(m, m2, zc, zkv) && ok;
-    if constexpr (TWO) { if (zd.on) ok = apply_choice(m, m2, zd, zkw) && ok; }
+    if (zc.on) ok = apply_choice<true>(m, m2, zc, zkv) && ok;
+    if constexpr (TWO) { if (zd.on) ok = apply_choice<false>(m, m2, zd, zkw) && ok; }
     const FastEnt e = lds_get16(&ent[fast_hash(m2)]);   // (read whatever `ok` says: no branch in front of the LDS access)
     if (!ok) return 0;
     if (e.vmask != m2) return 2;
