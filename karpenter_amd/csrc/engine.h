@@ -150,6 +150,9 @@ struct Engine {
   uint32_t active_templates = 0;
   int last_err = 0, last_diag = 0;
   Counters ctr{};
+  // a counter stays a wave-uniform scalar whatever it is fed with (a vector-register counter is the first thing the allocator spills, and
+  // every increment of a spilled counter is a load and a store to scratch in the middle of a pod's chain)
+  KS_DEV static void cadd(unsigned long long& c, unsigned long long v) { c = W::uniform(c + W::uniform(v)); }
   // topology: groups that exist so far, and the masks of the class being placed
   // Instance-type tables in registers: lane l owns instance types {j*64 + l}; with up to kRegIw mask words and kRegNr
   // resource dimensions (512 types x 4 dims: every KWOK / benchmark catalogue) the resource-fit test of
@@ -397,7 +400,7 @@ struct Engine {
   KS_DEV bool filter_instance_types(const uint64_t* bin_its, const int64_t* total, bool full, const ReqRef& reqs, bool want_diag, int tmpl) {
     uint64_t cells = ~0ull;
     if (full) {
-      KS_DIAG(ctr.full_filters++);
+      KS_DIAG(cadd(ctr.full_filters, 1));
       compat_mask(reqs);
       cells = offering_cells(reqs);
     } else if (FULL && P.n_xg) {
@@ -520,7 +523,7 @@ struct Engine {
         const uint64_t cm = full ? cmw[w] : ~0ull;
         const uint64_t itfits = in & ((Lt.allocok[w] & fit_and_off) | (nx ? xf[w] : 0ull));
         const uint64_t keep = cm & itfits;
-        KS_DIAG(ctr.it_evaluations += popc64(in));
+        KS_DIAG(cadd(ctr.it_evaluations, (unsigned long long)(popc64(in))));
         if (want_diag) { d_req |= (in & cm) != 0; d_fit |= itfits != 0; d_fo |= (itfits & ~cm) != 0; }
         W::store(&its_out[w], (uint64_t)(accumulate ? (its_out[w] | keep) : keep));
         any |= keep;
@@ -1043,7 +1046,7 @@ struct Engine {
   KS_DEV int can_add(const uint64_t* bin, const uint64_t* bin_cold, bool fresh, bool want_diag, bool* reqs_changed, bool* its_changed, int claim_id) {
     const Dict& d = P.dict;
     const int nr = lay.nr;
-    ctr.bin_evaluations++;
+    cadd(ctr.bin_evaluations, 1);
     topo_reached = false;
     if (FULL && P.hp_on) bin_hp = claim_id >= 0 ? S.c_hp[claim_id] : 0ull;
     unsigned long long ta = W::clock();
@@ -1124,7 +1127,7 @@ struct Engine {
       if (!topo_apply(merged, 0, claim_id, true, &tchanged)) return E_TOPOLOGY;
       if (tchanged) { merged = reqbuf_to_out(sc.topo); changed = true; }
     }
-    KS_DIAG(ctr.full_evaluations++);
+    KS_DIAG(cadd(ctr.full_evaluations, 1));
     unsigned long long tc = W::clock();
     ctr.cycles[12] += tc - tb;
     if (reqs_changed) *reqs_changed = changed;
@@ -1288,7 +1291,7 @@ struct Engine {
     return def_before != def_after || (exists_before & ~exists_after) != 0;
   }
   KS_DEV void reset_column(int c) {
-    KS_DIAG(ctr.column_resets++);
+    KS_DIAG(cadd(ctr.column_resets, 1));
     uint64_t* dead = S.dead;
     const int cw = S.claim_words;
     const uint64_t clr = ~(1ull << (c & 63));
@@ -1321,7 +1324,7 @@ struct Engine {
     ctr.cycles[5] += t2 - t1;
     if (rc != E_OK) return rc;
     const uint32_t tmpl = lo32(sc.claim[ly.c_meta()]), np = hi32(sc.claim[ly.c_meta()]);
-    ctr.ref_bin_evaluations += (unsigned long long)order.position(c) + 1;   // the reference walked every claim up to this position
+    cadd(ctr.ref_bin_evaluations, (unsigned long long)((unsigned long long)order.position(c) + 1));   // the reference walked every claim up to this position
     if (!changed) {
       // requirements untouched: carry masks and flags over from the bin record
       uint64_t* o = sc.out;
@@ -1625,7 +1628,7 @@ struct Engine {
     const int nr = lay.nr, iw = lay.iw, n_its = P.n_its;
     const RecLayout ly = lay;
     int first_err = 0, first_diag = 0;
-    ctr.ref_bin_evaluations += (unsigned long long)n_claims;  // the reference tried every in-flight claim before coming here
+    cadd(ctr.ref_bin_evaluations, (unsigned long long)((unsigned long long)n_claims));  // the reference tried every in-flight claim before coming here
     for (int t = 0; t < P.n_templates; ++t) {
       if (!((active_templates >> t) & 1)) continue;
       const uint64_t* trec = L.tmpl + (size_t)t * ly.c_hot_words();
@@ -1662,7 +1665,7 @@ struct Engine {
       }
       host_seq++;  // NewNodeClaim draws a hostname-placeholder number for every attempt (nodeclaim.go:93)
       bool changed = false;
-      ctr.ref_bin_evaluations++;
+      cadd(ctr.ref_bin_evaluations, 1);
       int rc = can_add(bin, tcold, true, first_err == 0, &changed, nullptr, -1);
       if (rc == E_RESERVED) { last_diag = 0; return E_RESERVED; }   // voids the lower-weight templates (scheduler.go:736-751)
       if (rc != E_OK) { if (!first_err) { first_err = rc; first_diag = (rc == E_INSTANCE_TYPES || rc == E_MIN_VALUES) ? last_diag : 0; } continue; }
@@ -1788,7 +1791,7 @@ struct Engine {
     const uint64_t* skip = exempt_pod ? nullptr : P.node_skip;
     const Workspace& Sw = S;
     for (int w0 = (base >> 6) + 1; w0 < nw; w0 += 64) {
-      ctr.node_block_steps++;
+      cadd(ctr.node_block_steps, 1);
       LaneVar<uint64_t> lv;
       const uint64_t any = W::ballot([&](int l) {
         const int w = w0 + l;
@@ -1866,13 +1869,13 @@ struct Engine {
         const int b0 = base;
         skipped = exempt_pod ? 0ull : W::ballot([&](int l) { return l < cnt && (Pv.node_flags[b0 + l] & 2) != 0; });
         todo = validm & ~deadw & ~skipped;
-        if (!todo) { ctr.ref_bin_evaluations += popc64(validm & ~skipped); continue; }
+        if (!todo) { cadd(ctr.ref_bin_evaluations, (unsigned long long)(popc64(validm & ~skipped))); continue; }
       } else {
         base = probe_next_block(k, base, exempt_pod, n_revived, &todo);
         if (base < 0) break;
       }
       const int b0 = base;
-      ctr.node_evaluations += (unsigned long long)popc64(todo);
+      cadd(ctr.node_evaluations, (unsigned long long)((unsigned long long)popc64(todo)));
       const uint64_t ok = W::ballot([&](int l) {
         if (!((todo >> l) & 1)) return false;
         const int e_ = b0 + l;
@@ -1894,7 +1897,7 @@ struct Engine {
           if (cur_pv_n && node_exceeds_volume_limits(base + cl_, &pv_fresh)) continue;   // VolumeUsage.ExceedsLimits — existingnode.go:88
           const bool ch = node_merge(base + cl_);
           bool tch = false, vch = false, got = false;
-          ctr.bin_evaluations++;
+          cadd(ctr.bin_evaluations, 1);
           if (cur_vol_n) {
             reqbuf_copy(sc.vbase, sc.merged);
             for (uint32_t va = 0; va < cur_vol_n && !got; ++va) {
@@ -1917,11 +1920,11 @@ struct Engine {
       const uint64_t below = l < 0 ? ~0ull : (l == 0 ? 0ull : ((1ull << l) - 1));
       // nodes that failed a check that does not involve topology stay failed until their requirements change
       if (!probe) W::store(&ndead[base >> 6], (uint64_t)(deadw | (todo & ~ok & below)));
-      if (l < 0) { if (!probe) ctr.ref_bin_evaluations += popc64(validm & ~skipped); continue; }
+      if (l < 0) { if (!probe) cadd(ctr.ref_bin_evaluations, (unsigned long long)(popc64(validm & ~skipped))); continue; }
       const int en = base + l;
-      if (!probe) ctr.ref_bin_evaluations += popc64(validm & ~skipped & (below | (1ull << l)));
-      else ctr.ref_bin_evaluations += probe_nodes_before(en, exempt_pod) + 1;
-      ctr.bin_evaluations += popc64(todo & (below | (1ull << l)));
+      if (!probe) cadd(ctr.ref_bin_evaluations, (unsigned long long)(popc64(validm & ~skipped & (below | (1ull << l)))));
+      else cadd(ctr.ref_bin_evaluations, (unsigned long long)(probe_nodes_before(en, exempt_pod) + 1));
+      cadd(ctr.bin_evaluations, (unsigned long long)(popc64(todo & (below | (1ull << l)))));
       // ---- ExistingNode.Add (existingnode.go:172-185): requirements <- node ∧ pod ∧ topology, remaining -= requests
       const ReqBuf& m = *fin;
       // A probe's first pod on a node whose requirements the pod leaves as they are (the usual case: the node's labels already say what
@@ -2002,7 +2005,7 @@ struct Engine {
       W::sync();
       return true;
     }
-    if (probe) ctr.ref_bin_evaluations += probe_nodes_before(ne, exempt_pod);   // the reference evaluated every node of the simulation
+    if (probe) cadd(ctr.ref_bin_evaluations, (unsigned long long)(probe_nodes_before(ne, exempt_pod)));   // the reference evaluated every node of the simulation
     return false;
   }
   // sc.merged <- ExistingNode.requirements ∧ the pod's (existingnode.go:105-108); true when that differs from the node's
@@ -2183,7 +2186,7 @@ struct Engine {
   // add — scheduler.go:582-612
   KS_DEV int add_class(int k, int pod) {
     if (FULL && add_to_existing(k, pod)) return E_OK;  // scheduler.go:594
-    ctr.sorts++;
+    cadd(ctr.sorts, 1);
     unsigned long long t0 = W::clock();
     order.sort();                                      // scheduler.go:598
     if constexpr (BIG) { if (order.overflow) { W::store(S.status_out, 1); return -1; } }   // a claim with more pods than the ring tables provide for: capacity
@@ -2213,7 +2216,7 @@ struct Engine {
       if (nxt < 0) return rc;
       row = nxt;
       k = (int)P.row_class[row];
-      ctr.relaxations++;
+      cadd(ctr.relaxations, 1);
     }
   }
 
@@ -2326,13 +2329,16 @@ struct Engine {
     prefilter_templates(warm != nullptr, warm ? *warm : 0u);
     // The queue holds pod indices; a probe's queue holds positions in its own pod list (Workspace::pr_sorted), which is also
     // how its per-pod outputs are indexed.
-    const bool probe = S.probe != 0;
-    const int np = probe ? S.pr_n_pods : P.n_pods;
+    // (the loop's own state as wave-uniform scalars: read through the view / workspace references — LDS copies in the sweep kernels — these
+    // values come back in vector registers and stayed there across every pod, first in line to be spilled; no division by a run-time
+    // value either: the ring positions wrap with a compare)
+    const bool probe = W::uniform((uint64_t)(S.probe != 0)) != 0;
+    const int np = (int)W::uniform((uint64_t)(uint32_t)(probe ? S.pr_n_pods : P.n_pods));
     const uint32_t cap = (uint32_t)np + 1;
-    const uint32_t* sorted = probe ? S.pr_sorted : P.sorted_pods;
-    uint32_t* queue = S.queue;
+    const uint32_t* sorted = (const uint32_t*)W::uniform((uint64_t)(probe ? S.pr_sorted : P.sorted_pods));
+    uint32_t* queue = (uint32_t*)W::uniform((uint64_t)S.queue);
     W::for_n(np, [&](int i) { queue[i] = probe ? (uint32_t)i : sorted[i]; });
-    uint32_t head = 0, tail = (uint32_t)np % cap, qlen = (uint32_t)np;
+    uint32_t head = 0, tail = (uint32_t)np == cap ? 0u : (uint32_t)np, qlen = (uint32_t)np;
     long long steps = 0;
     int status = 0;
     int blk_n = 0, blk_i = 0;
@@ -2348,25 +2354,31 @@ struct Engine {
         const int bn = blk_n;
         const uint32_t h0 = head;
         W::for_n(64, [&](int l) {
-          if (l < bn) { const uint32_t q = queue[(h0 + (uint32_t)l) % cap]; const uint32_t p = probe ? sorted[q] : q; bp[l] = p; bo[l] = q; bc[l] = rc_[p]; bl[l] = ll[q] | (((pend && pend[p]) || (pdel && pdel[p])) ? 0x80000000u : 0u); }   // (bit 31: exempt from the consolidateAfter skip)
+          if (l < bn) {
+            uint32_t qi = h0 + (uint32_t)l;   // (< 2 cap: head < cap and l < the entries there are < cap)
+            if (qi >= cap) qi -= cap;
+            const uint32_t q = queue[qi]; const uint32_t p = probe ? sorted[q] : q; bp[l] = p; bo[l] = q; bc[l] = rc_[p]; bl[l] = ll[q] | (((pend && pend[p]) || (pdel && pdel[p])) ? 0x80000000u : 0u);   // (bit 31: exempt from the consolidateAfter skip)
+          }
         });
         if (S.cancel_flag) {   // ctx cancellation, polled once per 64 pods (< 0: tests only, see fast_engine.h)
           const int cv = W::poll_flag(S.cancel_flag);
           if (cv > 0 || (cv < 0 && (long long)steps >= -(long long)cv)) { status = 2; break; }
         }
       }
-      int pod = (int)sc.blk_pod[blk_i];
-      const int out = (int)sc.blk_out[blk_i];
+      // (wave-uniform scalars, not the vector registers an LDS read comes back in: they live across the whole placement of the pod)
+      int pod = (int)W::uniform((uint64_t)sc.blk_pod[blk_i]);
+      const int out = (int)W::uniform((uint64_t)sc.blk_out[blk_i]);
+      const uint32_t lastw = (uint32_t)W::uniform((uint64_t)sc.blk_last[blk_i]);
       cur_out = out;
-      if (FULL && P.pv_on) { cur_pv_first = P.pod_pv_first[pod]; cur_pv_n = P.pod_pv_first[pod + 1] - cur_pv_first; }
-      cur_exempt = (sc.blk_last[blk_i] >> 31) != 0;
-      if ((sc.blk_last[blk_i] & 0x7FFFFFFFu) == qlen) break;                // queue.go:52-56
+      if (FULL && P.pv_on) { cur_pv_first = (uint32_t)W::uniform((uint64_t)P.pod_pv_first[pod]); cur_pv_n = (uint32_t)W::uniform((uint64_t)P.pod_pv_first[pod + 1]) - cur_pv_first; }
+      cur_exempt = (lastw >> 31) != 0;
+      if ((lastw & 0x7FFFFFFFu) == qlen) break;                // queue.go:52-56
       if (S.max_steps >= 0 && steps >= S.max_steps) { status = 2; break; }
-      int k0 = (int)sc.blk_class[blk_i];
+      int k0 = (int)W::uniform((uint64_t)sc.blk_class[blk_i]);
       blk_i++;
-      head = (head + 1) % cap; qlen--;
+      head = head + 1 == cap ? 0u : head + 1; qlen--;
       steps++;
-      ctr.queue_pops++;
+      cadd(ctr.queue_pops, 1);
       ctr.cycles[0] += W::clock() - tq;
       unsigned long long ts = W::clock();
       int rc = try_schedule(pod, k0);
@@ -2376,7 +2388,7 @@ struct Engine {
         W::store(&S.err[out], (uint8_t)rc);
         W::store(&S.diag[out], (uint8_t)last_diag);
         W::store(&S.queue[tail], (uint32_t)out);
-        tail = (tail + 1) % cap; qlen++;
+        tail = tail + 1 == cap ? 0u : tail + 1; qlen++;
         W::store(&S.last_len[out], qlen);                                   // queue.go:63-66
         W::sync();
       } else {

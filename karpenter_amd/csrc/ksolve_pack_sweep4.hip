@@ -20,7 +20,9 @@
 __global__ void KS_SWEEP4_BOUNDS ksolve_pack_sweep4(const ks::ProblemView* pv, ks::Workspace* items, int n, ks::LdsPlan plan, const uint32_t* order, uint32_t* next) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef ks::Engine<ks::Wave, true, false, ks::ScratchSmall> Eng;
-  const int wave = (int)(threadIdx.x >> 6);
+  // (readfirstlane: the compiler takes threadIdx.x for divergent, and with it every per-wavefront LDS pointer derived from the wave's index —
+  // a dozen 64-bit pointers held in vector registers across the whole probe, first in line to be spilled)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   ks::LdsTables tables;
   tables.bind(lds, plan, wave);
   uint32_t* misc = (uint32_t*)(lds + plan.off_shared_misc);
