@@ -6,17 +6,18 @@ cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $O
 export TMPDIR=/tmp KSOLVE_BENCH_TEST_HOOK=1
 B="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --pods 20000 --no-parity-pin --topology-pods 0 --batch-problems 0 --components-pods 0 --beyond-lds-pods 0 --whole-batch-exact-pods 0 --whole-batch-pods 0 --no-host-engine-baseline --no-cpu-baseline"
-for v in product sweep4_nospill; do
+VARIANTS="${KSOLVE_AB_VARIANTS:-product sweep4_nospill}"
+for v in $VARIANTS; do
   L=""; [ $v != product ] && L="--solver-lib $GRAFT_REPO_ROOT/karpenter_amd/variants/libksolve_$v.so"
   timeout 600 $B $L 2>$O/bench_$v.err | tail -1 > $O/bench_$v.json
   (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_${v}_fetch -o f -- $B $L --sweep-sample 0 --sweep-topology-sample 0 --sweep-windows 0 > $O/pmc_${v}_fetch.log 2>&1)
   (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_${v}_write -o w -- $B $L --sweep-sample 0 --sweep-topology-sample 0 --sweep-windows 0 > $O/pmc_${v}_write.log 2>&1)
 done
-python - $O <<'PY'
+python - $O "$VARIANTS" <<'PY'
 import json, sys, glob, csv
 O = sys.argv[1]
 out = {}
-for v in ("product", "sweep4_nospill"):
+for v in sys.argv[2].split():
     d = json.load(open(f"{O}/bench_{v}.json"))
     s = d["config4_sweep"]
     row = {"single_node": {k: round(x * 1e3, 3) for k, x in s["seconds"].items()}, "pin": s.get("oracle_pin", {}).get("digest_matches_oracle")}
