@@ -1871,10 +1871,13 @@ struct Engine {
         todo = validm & ~deadw & ~skipped;
         if (!todo) { cadd(ctr.ref_bin_evaluations, (unsigned long long)(popc64(validm & ~skipped))); continue; }
       } else {
+        const unsigned long long tn0 = W::clock();
         base = probe_next_block(k, base, exempt_pod, n_revived, &todo);
+        ctr.cycles[20] += W::clock() - tn0;
         if (base < 0) break;
       }
       const int b0 = base;
+      const unsigned long long tn1 = W::clock();
       cadd(ctr.node_evaluations, (unsigned long long)((unsigned long long)popc64(todo)));
       const uint64_t ok = W::ballot([&](int l) {
         if (!((todo >> l) & 1)) return false;
@@ -1882,6 +1885,8 @@ struct Engine {
         const int os = ov_find(e_);
         return os >= 0 ? node_static_ok(d, ly, cx, Pv.node_taints[e_], mut, (size_t)os) : node_static_ok(d, ly, cx, Pv.node_taints[e_], pris, (size_t)e_);
       });
+      const unsigned long long tn2 = W::clock();
+      ctr.cycles[21] += tn2 - tn1;
       int l = -1;
       bool changed = false;
       ReqBuf* fin = &sc.merged;
@@ -1917,6 +1922,8 @@ struct Engine {
           break;
         }
       }
+      const unsigned long long tn3 = W::clock();
+      ctr.cycles[22] += tn3 - tn2;
       const uint64_t below = l < 0 ? ~0ull : (l == 0 ? 0ull : ((1ull << l) - 1));
       // nodes that failed a check that does not involve topology stay failed until their requirements change
       if (!probe) W::store(&ndead[base >> 6], (uint64_t)(deadw | (todo & ~ok & below)));
@@ -1955,6 +1962,7 @@ struct Engine {
         W::store(&S.assign[cur_out], (int32_t)(-2 - en));
         W::store(&S.slot[cur_out], 0u);
         W::sync();
+        ctr.cycles[23] += W::clock() - tn3;
         return true;
       }
       const int os = probe ? ov_touch(en) : en;     // the node's mutable state (a probe's overlay slot)
@@ -2003,6 +2011,7 @@ struct Engine {
       W::store(&S.assign[cur_out], (int32_t)(-2 - en));
       W::store(&S.slot[cur_out], np_);
       W::sync();
+      ctr.cycles[23] += W::clock() - tn3;
       return true;
     }
     if (probe) cadd(ctr.ref_bin_evaluations, (unsigned long long)(probe_nodes_before(ne, exempt_pod)));   // the reference evaluated every node of the simulation

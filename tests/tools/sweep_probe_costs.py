@@ -14,7 +14,7 @@ from karpenter_amd import disruption as dz  # noqa: E402
 from karpenter_amd.scheduling import SolveBatch  # noqa: E402
 
 NAMES = ["queue", "class_fetch", "sort", "scan", "rec_load", "can_add", "commit", "new_claim", "dead_mark", "try_sched", "total", "ca_pre", "ca_merge", "ca_total",
-         "ca_filter", "f_ballots", "f_combine", "s_stage", "s_headroom", "s_select"]
+         "ca_filter", "f_ballots", "f_combine", "s_stage", "s_headroom", "s_select", "en_next_block", "en_static_ok", "en_merge", "en_commit"]
 
 ap = argparse.ArgumentParser()
 ap.add_argument("nodes", type=int); ap.add_argument("candidates", type=int); ap.add_argument("sample", type=int, nargs="?", default=40)
