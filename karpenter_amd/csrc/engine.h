@@ -1853,8 +1853,9 @@ struct Engine {
     const bool probe = S.probe != 0;
     const NodeClassCtx cx = node_class_ctx(d, ly, sc.cls, sc.cls_cold, Pv.hp_on ? cur_hp_conf : 0ull);
     const int64_t* req = cx.req;
-    const NodeTabs mut = node_tabs(true), pris = node_tabs(false);
+    const NodeTabs mut = node_tabs(true);
     const bool exempt_pod = cur_exempt;   // (fetched with the pod's queue block: pod_is_pending / pod_from_deleting)
+    if (probe) W::sync();                 // behind the stores of the previous pod's commit (its first-pod path does not wait for them)
     uint64_t* ndead = probe ? nullptr : S.n_dead + (size_t)k * P.node_words;
     int base = -64;
     for (;;) {
@@ -1878,29 +1879,53 @@ struct Engine {
       }
       const int b0 = base;
       const unsigned long long tn1 = W::clock();
-      cadd(ctr.node_evaluations, (unsigned long long)((unsigned long long)popc64(todo)));
-      const uint64_t ok = W::ballot([&](int l) {
-        if (!((todo >> l) & 1)) return false;
-        const int e_ = b0 + l;
-        const int os = ov_find(e_);
-        return os >= 0 ? node_static_ok(d, ly, cx, Pv.node_taints[e_], mut, (size_t)os) : node_static_ok(d, ly, cx, Pv.node_taints[e_], pris, (size_t)e_);
-      });
+      uint64_t ok, tov_ = 0;
+      const bool lazy = probe;
+      if (lazy) {
+        // A pristine node of the block that ksolve_node_dead0 left alive for this class PASSES these very checks (nodecheck.h is the
+        // code of both, the class's host-port closure included), and a node a commit revived is an overlaid node: only the block's
+        // overlaid nodes are evaluated (through the overlay) — the others' tables are not read at all until one of them is merged.
+        uint64_t ovm = 0;
+        LaneVar<int> osv;
+        if (ov_regs) {
+          for (int s_ = 0; s_ < n_ov; ++s_) { const uint32_t e1 = ovk_.bcast(s_) - 1u - (uint32_t)b0; if (e1 < 64u) ovm |= 1ull << e1; }
+        } else {
+          ovm = W::ballot([&](int l) { const int os = ((todo >> l) & 1) ? ov_find(b0 + l) : -1; osv.at(l) = os; return os >= 0; });
+        }
+        ok = todo & ~ovm;
+        const uint64_t tov = todo & ovm;
+        tov_ = tov;
+        const bool regs = ov_regs;
+        if (tov) ok |= W::ballot([&](int l) {
+          if (!((tov >> l) & 1)) return false;
+          const int e_ = b0 + l;
+          return node_static_ok(d, ly, cx, Pv.node_taints[e_], mut, (size_t)(regs ? ov_find(e_) : osv.at(l)));
+        });
+      } else {
+        cadd(ctr.node_evaluations, (unsigned long long)popc64(todo));
+        ok = W::ballot([&](int l) {
+          if (!((todo >> l) & 1)) return false;
+          const int e_ = b0 + l;
+          return node_static_ok(d, ly, cx, Pv.node_taints[e_], mut, (size_t)e_);   // (outside probes the solve's own copies)
+        });
+      }
       const unsigned long long tn2 = W::clock();
       ctr.cycles[21] += tn2 - tn1;
       int l = -1;
       bool changed = false;
+      LaneVar<uint64_t> npre; bool npre_ok = false;
       ReqBuf* fin = &sc.merged;
       uint64_t pv_fresh = 0;
       if (!cur_M && !cur_vol_n && !cur_pv_n) {
         if (ok) l = ctz64(ok);
-        if (l >= 0) changed = node_merge(base + l);
+        if (l >= 0) changed = node_merge(base + l, probe ? &npre : nullptr, &npre_ok);
       } else {
         // volume requirement alternatives and topology decide among the nodes that passed everything else
         // (existingnode.go:108-139, tryVolumeAlternative :143-168), lowest index first
         for (uint64_t cand = ok; cand; cand &= cand - 1) {
           const int cl_ = ctz64(cand);
           if (cur_pv_n && node_exceeds_volume_limits(base + cl_, &pv_fresh)) continue;   // VolumeUsage.ExceedsLimits — existingnode.go:88
-          const bool ch = node_merge(base + cl_);
+          const bool ch = node_merge(base + cl_, probe ? &npre : nullptr, &npre_ok);
           bool tch = false, vch = false, got = false;
           cadd(ctr.bin_evaluations, 1);
           if (cur_vol_n) {
@@ -1927,11 +1952,14 @@ struct Engine {
       const uint64_t below = l < 0 ? ~0ull : (l == 0 ? 0ull : ((1ull << l) - 1));
       // nodes that failed a check that does not involve topology stay failed until their requirements change
       if (!probe) W::store(&ndead[base >> 6], (uint64_t)(deadw | (todo & ~ok & below)));
-      if (l < 0) { if (!probe) cadd(ctr.ref_bin_evaluations, (unsigned long long)(popc64(validm & ~skipped))); continue; }
+      if (l < 0) { if (!probe) cadd(ctr.ref_bin_evaluations, (unsigned long long)(popc64(validm & ~skipped))); else if (lazy) { cadd(ctr.node_evaluations, (unsigned long long)popc64(tov_)); cadd(ctr.bin_evaluations, (unsigned long long)popc64(tov_)); } continue; }
       const int en = base + l;
       if (!probe) cadd(ctr.ref_bin_evaluations, (unsigned long long)(popc64(validm & ~skipped & (below | (1ull << l)))));
       else cadd(ctr.ref_bin_evaluations, (unsigned long long)(probe_nodes_before(en, exempt_pod) + 1));
-      cadd(ctr.bin_evaluations, (unsigned long long)(popc64(todo & (below | (1ull << l)))));
+      if (lazy) {   // (what was read: the overlaid nodes up to the winner, and the winner — its tables are read by node_merge)
+        cadd(ctr.node_evaluations, (unsigned long long)(popc64(tov_ & below) + 1));
+        cadd(ctr.bin_evaluations, (unsigned long long)(popc64(tov_ & below) + 1));
+      } else cadd(ctr.bin_evaluations, (unsigned long long)(popc64(todo & (below | (1ull << l)))));
       // ---- ExistingNode.Add (existingnode.go:172-185): requirements <- node ∧ pod ∧ topology, remaining -= requests
       const ReqBuf& m = *fin;
       // A probe's first pod on a node whose requirements the pod leaves as they are (the usual case: the node's labels already say what
@@ -1945,7 +1973,8 @@ struct Engine {
         uint64_t* nm = S.n_mask; int64_t* nrem = S.n_remaining;
         const int64_t* rem0 = S.n_remaining0;
         W::for_n(ly.rw, [&](int w) { nm[(size_t)w * st + os] = m.mask[w]; });
-        W::for_n(nr, [&](int r) { nrem[(size_t)r * st + os] = rem0[(size_t)r * ne + en] - req[r]; });      // resources.SubtractFrom — existingnode.go:175
+        if (npre_ok) { const int r0_ = ly.rw + 2; W::each([&](int l) { if (l >= r0_ && l < r0_ + nr) nrem[(size_t)(l - r0_) * st + os] = (int64_t)npre.at(l) - req[l - r0_]; }); }   // (fetched with the node's requirement set)
+        else W::for_n(nr, [&](int r) { nrem[(size_t)r * st + os] = rem0[(size_t)r * ne + en] - req[r]; });      // resources.SubtractFrom — existingnode.go:175
         if (W::leader()) {
           S.n_defined[os] = m.defined; S.n_complement[os] = m.complement; S.n_npods[os] = 1;
           if (Pv.hp_on) S.n_hp[os] = (Pv.node_hp0 ? Pv.node_hp0[en] : 0ull) | cur_hp_use;                  // existingnode.go:178
@@ -1961,7 +1990,8 @@ struct Engine {
         }
         W::store(&S.assign[cur_out], (int32_t)(-2 - en));
         W::store(&S.slot[cur_out], 0u);
-        W::sync();
+        W::order();   // (the fence stands in front of the next scan's reads of the overlay — the top of this function — where the stores' way to L2
+                      // overlaps with the next pod's class fetch instead of being waited for here)
         ctr.cycles[23] += W::clock() - tn3;
         return true;
       }
@@ -2018,20 +2048,44 @@ struct Engine {
     return false;
   }
   // sc.merged <- ExistingNode.requirements ∧ the pod's (existingnode.go:105-108); true when that differs from the node's
-  KS_DEV bool node_merge(int en) {
+  // pre / pre_ok (probes): a PRISTINE node's remaining resources, fetched in the same round trip as its requirement set (lanes rw + 2 ..)
+  // for the commit that usually follows (add_to_existing's first-pod path)
+  KS_DEV bool node_merge(int en, LaneVar<uint64_t>* pre = nullptr, bool* pre_ok = nullptr) {
     const Dict& d = P.dict;
     ReqBuf& m = sc.merged;
     const int os = ov_find(en);
     const NodeTabs t = node_tabs(os >= 0);
     const size_t i = os >= 0 ? (size_t)os : (size_t)en;
-    W::for_n(lay.rw, [&](int w) { m.mask[w] = t.mask[(size_t)w * t.stride + i]; });
-    if (W::leader()) {
-      m.defined = t.defined[i]; m.complement = t.complement[i]; m.has_minv = 0;
-      m.has_gte = t.hg ? t.hg[i] : 0u; m.has_lte = t.hg ? t.hl[i] : 0u;
-      for (int kk = 0; kk < lay.nk; ++kk) {
-        m.gte[kk] = ((m.has_gte >> kk) & 1u) ? t.gte[(size_t)kk * t.stride + i] : 0;
-        m.lte[kk] = ((m.has_lte >> kk) & 1u) ? t.lte[(size_t)kk * t.stride + i] : 0;
-        m.minv[kk] = -1;
+    const int rw = lay.rw, nr = lay.nr;
+    if (pre_ok) *pre_ok = false;
+    if (pre && os < 0 && !t.hg && rw + 2 + nr <= 64) {
+      // one round trip: the mask words, defined / complement flags and the remaining resources, a lane each
+      LaneVar<uint64_t>& nv = *pre;
+      W::each([&](int l) {
+        uint64_t v = 0;
+        if (l < rw) v = t.mask[(size_t)l * t.stride + i];
+        else if (l == rw) v = t.defined[i];
+        else if (l == rw + 1) v = t.complement[i];
+        else if (l < rw + 2 + nr) v = (uint64_t)t.remaining[(size_t)(l - rw - 2) * t.stride + i];
+        nv.at(l) = v;
+      });
+      W::each([&](int l) { if (l < rw) m.mask[l] = nv.at(l); });
+      const uint32_t df = (uint32_t)nv.bcast(rw), cp = (uint32_t)nv.bcast(rw + 1);
+      if (W::leader()) {
+        m.defined = df; m.complement = cp; m.has_minv = 0; m.has_gte = 0u; m.has_lte = 0u;
+        for (int kk = 0; kk < lay.nk; ++kk) { m.gte[kk] = 0; m.lte[kk] = 0; m.minv[kk] = -1; }
+      }
+      *pre_ok = true;
+    } else {
+      W::for_n(rw, [&](int w) { m.mask[w] = t.mask[(size_t)w * t.stride + i]; });
+      if (W::leader()) {
+        m.defined = t.defined[i]; m.complement = t.complement[i]; m.has_minv = 0;
+        m.has_gte = t.hg ? t.hg[i] : 0u; m.has_lte = t.hg ? t.hl[i] : 0u;
+        for (int kk = 0; kk < lay.nk; ++kk) {
+          m.gte[kk] = ((m.has_gte >> kk) & 1u) ? t.gte[(size_t)kk * t.stride + i] : 0;
+          m.lte[kk] = ((m.has_lte >> kk) & 1u) ? t.lte[(size_t)kk * t.stride + i] : 0;
+          m.minv[kk] = -1;
+        }
       }
     }
     W::sync();
