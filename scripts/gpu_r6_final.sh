@@ -1,4 +1,4 @@
-# round 6, final pass: the default bench line (every in-run gate), the PMC / kernel-stats passes (headline, configs[2] leg, sweep kernels, and
+# round 6, final pass: every GPU parity test and smoke(), the default bench line (every in-run gate), the PMC / kernel-stats passes (headline, configs[2] leg, sweep kernels, and
 # — KSOLVE_PMC_LEGS with "exact" — the exact configs[3] batch), then bench.py once more so that its line quotes the counters of THIS build.
 # usage (GPU box): bash scripts/gpu_r6_final.sh [tag]
 set -x
@@ -6,6 +6,8 @@ cd $GRAFT_REPO_ROOT
 T=${1:-r6final}
 O=$GRAFT_REPO_ROOT/gpurun_out/$T; mkdir -p $O
 export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 | tee $O/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 | tee $O/smoke.log
 KSOLVE_PMC_LEGS="${KSOLVE_PMC_LEGS:-head topo big sweep exact}" timeout 3600 bash scripts/gpu_r6_pmc.sh 2>&1 | tail -14
 mkdir -p profiles/round6
 cp gpurun_out/r6pmc/pmc_traffic.json profiles/round6/pmc_traffic.json
