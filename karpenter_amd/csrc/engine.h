@@ -1851,7 +1851,10 @@ struct Engine {
     const Workspace& Sw = S;
     const ProblemView& Pv = P;
     const bool probe = S.probe != 0;
-    const NodeClassCtx cx = node_class_ctx(d, ly, sc.cls, sc.cls_cold, Pv.hp_on ? cur_hp_conf : 0ull);
+    const bool has_nz = ly.rw <= 64;
+    uint64_t nz = 0;
+    if (has_nz) { const uint64_t* cm_ = sc.cls + ly.k_mask(); const int rw_ = ly.rw; nz = W::ballot([&](int l) { return l < rw_ && cm_[l] != 0; }); }
+    const NodeClassCtx cx = node_class_ctx(d, ly, sc.cls, sc.cls_cold, Pv.hp_on ? cur_hp_conf : 0ull, has_nz, nz);
     const int64_t* req = cx.req;
     const NodeTabs mut = node_tabs(true);
     const bool exempt_pod = cur_exempt;   // (fetched with the pod's queue block: pod_is_pending / pod_from_deleting)
@@ -1899,7 +1902,9 @@ struct Engine {
         if (tov) ok |= W::ballot([&](int l) {
           if (!((tov >> l) & 1)) return false;
           const int e_ = b0 + l;
-          return node_static_ok(d, ly, cx, Pv.node_taints[e_], mut, (size_t)(regs ? ov_find(e_) : osv.at(l)));
+          const size_t os = (size_t)(regs ? ov_find(e_) : osv.at(l));
+          const NodePre n = node_preload(ly, Pv.node_taints[e_], mut, os);   // (the node's scalars in one round trip, not one per check)
+          return node_static_ok_pre(d, ly, cx, n, mut, os);
         });
       } else {
         cadd(ctr.node_evaluations, (unsigned long long)popc64(todo));
@@ -1914,11 +1919,15 @@ struct Engine {
       int l = -1;
       bool changed = false;
       LaneVar<uint64_t> npre; bool npre_ok = false;
+      unsigned long long pnb = 0; bool pnb_ok = false;
       ReqBuf* fin = &sc.merged;
       uint64_t pv_fresh = 0;
       if (!cur_M && !cur_vol_n && !cur_pv_n) {
         if (ok) l = ctz64(ok);
-        if (l >= 0) changed = node_merge(base + l, probe ? &npre : nullptr, &npre_ok);
+        if (l >= 0) {
+          if (probe) { pnb = probe_nodes_before(base + l, exempt_pod); pnb_ok = true; }   // (its loads go out in front of node_merge's: one wait for both)
+          changed = node_merge(base + l, probe ? &npre : nullptr, &npre_ok);
+        }
       } else {
         // volume requirement alternatives and topology decide among the nodes that passed everything else
         // (existingnode.go:108-139, tryVolumeAlternative :143-168), lowest index first
@@ -1955,7 +1964,7 @@ struct Engine {
       if (l < 0) { if (!probe) cadd(ctr.ref_bin_evaluations, (unsigned long long)(popc64(validm & ~skipped))); else if (lazy) { cadd(ctr.node_evaluations, (unsigned long long)popc64(tov_)); cadd(ctr.bin_evaluations, (unsigned long long)popc64(tov_)); } continue; }
       const int en = base + l;
       if (!probe) cadd(ctr.ref_bin_evaluations, (unsigned long long)(popc64(validm & ~skipped & (below | (1ull << l)))));
-      else cadd(ctr.ref_bin_evaluations, (unsigned long long)(probe_nodes_before(en, exempt_pod) + 1));
+      else cadd(ctr.ref_bin_evaluations, (unsigned long long)((pnb_ok ? pnb : probe_nodes_before(en, exempt_pod)) + 1));
       if (lazy) {   // (what was read: the overlaid nodes up to the winner, and the winner — its tables are read by node_merge)
         cadd(ctr.node_evaluations, (unsigned long long)(popc64(tov_ & below) + 1));
         cadd(ctr.bin_evaluations, (unsigned long long)(popc64(tov_ & below) + 1));
@@ -2076,6 +2085,23 @@ struct Engine {
         for (int kk = 0; kk < lay.nk; ++kk) { m.gte[kk] = 0; m.lte[kk] = 0; m.minv[kk] = -1; }
       }
       *pre_ok = true;
+      // The usual outcome, decided wave-wide: the node's labels already say what the pod asks for — every key the pod defines is defined
+      // on the node by a plain value set, no bounds or minValues anywhere, and no word of the node's masks narrows (In: a & b == a,
+      // NotIn: a & ~b == a). Then Add (requirements.go:133-140) leaves the node's set as it is and reqbuf_add's key-by-key walk over
+      // LDS — a chain of dependent reads per key — has nothing to do.
+      const ReqRef q = class_ref(sc.cls, sc.cls_cold);
+      if (!(q.has_gte | q.has_lte) && !q.minv && !(q.defined & ~df) && !(cp & q.defined)) {
+        const uint8_t* wk = sc.word_key; const uint64_t* qm = q.mask;
+        const uint32_t qd = q.defined, qc = q.complement;
+        const uint64_t narrows = W::ballot([&](int l) {
+          if (l >= rw) return false;
+          const int k = wk[l];
+          if (!((qd >> k) & 1)) return false;
+          const uint64_t am = nv.at(l), b = qm[l];
+          return (((qc >> k) & 1) ? (am & ~b) : (am & b)) != am;
+        });
+        if (!narrows) { W::sync(); return false; }
+      }
     } else {
       W::for_n(rw, [&](int w) { m.mask[w] = t.mask[(size_t)w * t.stride + i]; });
       if (W::leader()) {

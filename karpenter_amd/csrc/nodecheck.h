@@ -16,7 +16,9 @@ struct NodeClassCtx {   // the class side, wave-uniform
   const int64_t* req;
 };
 
-KS_FN NodeClassCtx node_class_ctx(const Dict& d, const RecLayout& ly, const uint64_t* cls, const uint64_t* cls_cold, uint64_t hp_conf) {
+// nz (has_nz): bit w = word w of the class's requirement masks is non-zero, when the caller has it at hand (the engine takes it with one
+// ballot, a lane per word; walking the words here is a chain of dependent reads per key)
+KS_FN NodeClassCtx node_class_ctx(const Dict& d, const RecLayout& ly, const uint64_t* cls, const uint64_t* cls_cold, uint64_t hp_conf, bool has_nz = false, uint64_t nz = 0) {
   NodeClassCtx x;
   x.cls = cls; x.cls_cold = cls_cold;
   x.kdef = (uint32_t)cls[ly.k_f0()]; x.kcomp = (uint32_t)(cls[ly.k_f0()] >> 32);
@@ -27,7 +29,9 @@ KS_FN NodeClassCtx node_class_ctx(const Dict& d, const RecLayout& ly, const uint
   for (uint32_t ks_ = x.kdef; ks_; ks_ &= ks_ - 1) {
     const int key = __builtin_ctz(ks_);
     bool ne_ = false;
-    for (uint32_t w = d.key_word_off[key]; w < d.key_word_off[key + 1]; ++w) ne_ = ne_ || cls[ly.k_mask() + w] != 0;
+    const uint32_t w0 = d.key_word_off[key], w1 = d.key_word_off[key + 1];
+    if (has_nz) ne_ = w1 > w0 && ((nz >> w0) & (w1 - w0 >= 64 ? ~0ull : ((1ull << (w1 - w0)) - 1))) != 0;
+    else for (uint32_t w = w0; w < w1; ++w) ne_ = ne_ || cls[ly.k_mask() + w] != 0;
     if (((x.kcomp >> key) & 1) ? ne_ : !ne_) x.kneg |= 1u << key;
   }
   return x;
