@@ -166,6 +166,7 @@ static oj::Value solve_doc(const Problem& pr, const std::vector<Pod>* probe_pods
     // ORACLE_THREADS / ORACLE_PAR_MIN: candidate fan-out of the in-flight scan (parallelizeUntil, scheduler.go:939-961) for the
     // offline pins and the N-thread CPU baseline; the Results and counters are those of the sequential scan
     if (const char* t = getenv("ORACLE_THREADS")) s.threads = std::max(1, atoi(t));
+    if (const char* t = getenv("ORACLE_PROGRESS")) s.progress_every = atoll(t);
     if (const char* t = getenv("ORACLE_PAR_MIN")) s.parallel_min = (size_t)std::max(1, atoi(t));
     s.init(pr, probe_pods, removed);
     auto t1 = std::chrono::steady_clock::now();

@@ -284,7 +284,10 @@ struct Scheduler {
   size_t parallel_min = 512;          // scans shorter than this stay sequential
   struct Pool;
   std::shared_ptr<Pool> pool;
+  long long progress_every = 0;   // ORACLE_PROGRESS: a line on stderr every so many pods (the hour-long offline pins)
   double t_sort = 0, t_scan = 0;   // seconds in sort.Slice / in the in-flight scan (ORACLE_TIMING prints them)
+  struct ParFound { size_t j = 0; Requirements r; std::vector<const InstanceType*> its; std::vector<const Offering*> ofs; };
+  std::vector<ParFound> par_found;   // per worker: the lowest candidate it found to pass, with CanAdd's outputs
   std::vector<unsigned long long> par_it_evals;   // per-candidate instance-type evaluation counts of the scan in flight
 
   // ---- pod requirement derivation: requirements.go:74-118 --------------------------------------------------
@@ -801,6 +804,7 @@ struct Scheduler {
       head++;
       steps++;
       ctr.pops++;
+      if (progress_every > 0 && steps % progress_every == 0) fprintf(stderr, "oracle progress: %lld pods popped, %zu NodeClaims, %.0f s in the in-flight scan, %.0f s in sort.Slice\n", steps, new_node_claims.size(), t_scan, t_sort);
       Pod copy = *p;  // pod.DeepCopy()
       if (try_schedule(copy, p)) {
         res.pod_errors.erase(p->uid);
@@ -888,11 +892,11 @@ inline bool Scheduler::add_to_inflight_parallel(Pod& pod, Pod* queue_pod, const 
   // keeps meeting the same claims from pod to pod. A worker stops at the first chunk that starts beyond the best index so far.
   const size_t chunk = 8, T = (size_t)threads;
   // a worker keeps the outputs of the lowest candidate IT found to pass: the winner's are among them, no second evaluation
-  struct Found { size_t j; Requirements r; std::vector<const InstanceType*> its; std::vector<const Offering*> ofs; };
-  std::vector<Found> found(T);
+  std::vector<ParFound>& found = par_found;   // (kept across pods: no T constructions and destructions per pod)
+  if (found.size() != T) found.resize(T);
   for (auto& f : found) f.j = n;
   pool->run([&](int t) {
-    Found& mine = found[(size_t)t];
+    ParFound& mine = found[(size_t)t];
     for (size_t i0 = (size_t)t * chunk; i0 < n; i0 += T * chunk) {
       if (i0 > best.load(std::memory_order_relaxed)) return;
       for (size_t j = i0; j < std::min(n, i0 + chunk); ++j) {
@@ -915,7 +919,7 @@ inline bool Scheduler::add_to_inflight_parallel(Pod& pod, Pod* queue_pod, const 
   ctr.bin_evaluations += (long long)counted;
   for (size_t j = 0; j < counted; ++j) ctr.it_evaluations += (long long)it_evals[j];
   if (w == n) return false;
-  Found* win = nullptr;
+  ParFound* win = nullptr;
   for (auto& f : found) if (f.j == w) win = &f;
   if (!win) throw std::runtime_error("parallel in-flight scan: the winner's outputs are missing");
   claim_add(*new_node_claims[w], queue_pod, pd, win->r, win->its, win->ofs);

@@ -14,7 +14,7 @@ trap restore EXIT
 g++ $FLAGS -o karpenter_amd/libksched.so karpenter_amd/host/ksched.cpp -ldl
 g++ $FLAGS -pthread -o tests/emu/libksolve_emu.so tests/emu/ksolve_emu.cpp
 LD_PRELOAD="$ASAN $STD" ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 python -m pytest tests/test_device_algorithm.py tests/test_device_topology.py \
-  tests/test_device_fuzz_all.py tests/test_cursor_engine.py tests/test_disruption.py tests/test_reference_known_answers.py -q -s -p no:cacheprovider > /tmp/asan_pytest.log 2>&1 || true
+  tests/test_device_fuzz_all.py tests/test_cursor_engine.py tests/test_spread_engine.py tests/test_disruption.py tests/test_reference_known_answers.py -q -s -p no:cacheprovider > /tmp/asan_pytest.log 2>&1 || true
 tail -1 /tmp/asan_pytest.log
 echo "AddressSanitizer reports: $(grep -c 'ERROR: AddressSanitizer' /tmp/asan_pytest.log)"
 grep SUMMARY /tmp/asan_pytest.log | sort | uniq -c
