@@ -211,6 +211,10 @@ struct Engine {
   LaneVar<uint32_t> ovk_;
   int n_ov = 0;
   bool ov_regs = false;
+  // a probe's removed nodes (ascending; 0xFFFFFFFF behind the last) in two vector registers when there are at most 128 of them — a multi-node
+  // prefix removes up to 101: every scan step and every evaluation count walked the list in HBM, a dependent load per entry
+  LaneVar<uint32_t> prm0_, prm1_;
+  bool prm_regs = false;
   bool cur_exempt = false;          // the pod being placed is pending or comes from a deleting node (scheduler.go:628 does not skip nodes for it)
 
   KS_DEV Engine(const ProblemView& p, Workspace& s, const LdsTables& l) : P(p), S(s), L(l), sc(*(SC*)l.scratch), lay(p.lay) {
@@ -1775,6 +1779,14 @@ struct Engine {
     long long n = upto;
     const int w = upto >> 6, bq = upto & 63;
     if (!exempt_pod && P.node_skip) n -= (long long)P.node_skip_prefix[w] + (bq ? popc64(P.node_skip[w] & ((1ull << bq) - 1)) : 0);
+    if (prm_regs) {
+      const uint64_t* sk = (!exempt_pod && P.node_skip) ? P.node_skip : nullptr;
+      const uint32_t up = (uint32_t)upto;
+      const LaneVar<uint32_t>& a0 = prm0_; const LaneVar<uint32_t>& a1 = prm1_;
+      const uint64_t c0 = W::ballot([&](int l) { const uint32_t r = a0.v_of(l); return r < up && (!sk || !((sk[r >> 6] >> (r & 63)) & 1)); });
+      const uint64_t c1 = W::ballot([&](int l) { const uint32_t r = a1.v_of(l); return r < up && (!sk || !((sk[r >> 6] >> (r & 63)) & 1)); });
+      return (unsigned long long)(n - popc64(c0) - popc64(c1));
+    }
     for (int i = 0; i < S.pr_n_removed; ++i) {
       const int r = (int)S.pr_removed[i];
       if (r >= upto) break;
@@ -1792,7 +1804,21 @@ struct Engine {
     const Workspace& Sw = S;
     for (int w0 = (base >> 6) + 1; w0 < nw; w0 += 64) {
       cadd(ctr.node_block_steps, 1);
-      LaneVar<uint64_t> lv;
+      LaneVar<uint64_t> lv, rmv;
+      const bool rregs = prm_regs;
+      if (rregs) {
+        // the removed nodes that fall into this step's 64 words, each into its word's lane (usually none or a few)
+        W::each([&](int l) { rmv.at(l) = 0; });
+        const uint32_t wlo = (uint32_t)w0;
+        for (int half = 0; half < 2; ++half) {
+          const LaneVar<uint32_t>& a = half ? prm1_ : prm0_;
+          for (uint64_t in = W::ballot([&](int l) { return ((a.v_of(l) >> 6) - wlo) < 64u; }); in; in &= in - 1) {
+            const uint32_t r = a.bcast(ctz64(in));
+            const int t = (int)((r >> 6) - wlo);
+            W::each([&](int l) { if (l == t) rmv.at(l) |= 1ull << (r & 63); });
+          }
+        }
+      }
       const uint64_t any = W::ballot([&](int l) {
         const int w = w0 + l;
         uint64_t live = 0;
@@ -1801,7 +1827,8 @@ struct Engine {
           for (int i = 0; i < n_revived; ++i) { const uint32_t r = Sw.pr_revived[i]; if ((int)(r >> 6) == w) live |= 1ull << (r & 63); }
           if (w == nw - 1 && (ne & 63)) live &= (1ull << (ne & 63)) - 1;
           if (skip) live &= ~skip[w];
-          for (int i = 0; i < Sw.pr_n_removed; ++i) { const uint32_t r = Sw.pr_removed[i]; if ((int)(r >> 6) == w) live &= ~(1ull << (r & 63)); }
+          if (rregs) live &= ~rmv.at(l);
+          else for (int i = 0; i < Sw.pr_n_removed; ++i) { const uint32_t r = Sw.pr_removed[i]; if ((int)(r >> 6) == w) live &= ~(1ull << (r & 63)); }
         }
         lv.at(l) = live;
         return live != 0;
@@ -1884,12 +1911,13 @@ struct Engine {
       const unsigned long long tn1 = W::clock();
       uint64_t ok, tov_ = 0;
       const bool lazy = probe;
+      LaneVar<int> osv;                        // hash-table overlay: the slot of each lane's node (-1: pristine), asked once per block
+      const bool osv_ok = probe && !ov_regs;
       if (lazy) {
         // A pristine node of the block that ksolve_node_dead0 left alive for this class PASSES these very checks (nodecheck.h is the
         // code of both, the class's host-port closure included), and a node a commit revived is an overlaid node: only the block's
         // overlaid nodes are evaluated (through the overlay) — the others' tables are not read at all until one of them is merged.
         uint64_t ovm = 0;
-        LaneVar<int> osv;
         if (ov_regs) {
           for (int s_ = 0; s_ < n_ov; ++s_) { const uint32_t e1 = ovk_.bcast(s_) - 1u - (uint32_t)b0; if (e1 < 64u) ovm |= 1ull << e1; }
         } else {
@@ -1920,13 +1948,15 @@ struct Engine {
       bool changed = false;
       LaneVar<uint64_t> npre; bool npre_ok = false;
       unsigned long long pnb = 0; bool pnb_ok = false;
+      int os_hint = -2;                        // the winner's overlay slot where the block's lanes have looked it up already (-2: not known)
       ReqBuf* fin = &sc.merged;
       uint64_t pv_fresh = 0;
       if (!cur_M && !cur_vol_n && !cur_pv_n) {
         if (ok) l = ctz64(ok);
         if (l >= 0) {
           if (probe) { pnb = probe_nodes_before(base + l, exempt_pod); pnb_ok = true; }   // (its loads go out in front of node_merge's: one wait for both)
-          changed = node_merge(base + l, probe ? &npre : nullptr, &npre_ok);
+          if (osv_ok) os_hint = osv.bcast(l);
+          changed = node_merge(base + l, probe ? &npre : nullptr, &npre_ok, os_hint);
         }
       } else {
         // volume requirement alternatives and topology decide among the nodes that passed everything else
@@ -1934,7 +1964,8 @@ struct Engine {
         for (uint64_t cand = ok; cand; cand &= cand - 1) {
           const int cl_ = ctz64(cand);
           if (cur_pv_n && node_exceeds_volume_limits(base + cl_, &pv_fresh)) continue;   // VolumeUsage.ExceedsLimits — existingnode.go:88
-          const bool ch = node_merge(base + cl_, probe ? &npre : nullptr, &npre_ok);
+          if (osv_ok) os_hint = osv.bcast(cl_);
+          const bool ch = node_merge(base + cl_, probe ? &npre : nullptr, &npre_ok, os_hint);
           bool tch = false, vch = false, got = false;
           cadd(ctr.bin_evaluations, 1);
           if (cur_vol_n) {
@@ -1975,7 +2006,7 @@ struct Engine {
       // the pod asks for): the overlay slot is written straight from what is at hand — the merged set IS the node's, the remaining
       // resources are the pristine ones less the requests — instead of a copy of the pristine state that is then read back and updated
       // (two dependent round trips and a fence of the probe's chain).
-      const bool fresh = probe && !changed && !S.n_hg && ov_find(en) < 0;
+      const bool fresh = probe && !changed && !S.n_hg && (os_hint != -2 ? os_hint : ov_find(en)) < 0;
       if (fresh) {
         const int os = ov_new(en);
         const size_t st = (size_t)nst();
@@ -2004,7 +2035,7 @@ struct Engine {
         ctr.cycles[23] += W::clock() - tn3;
         return true;
       }
-      const int os = probe ? ov_touch(en) : en;     // the node's mutable state (a probe's overlay slot)
+      const int os = probe ? (os_hint >= 0 ? os_hint : ov_touch(en)) : en;     // the node's mutable state (a probe's overlay slot)
       const size_t st = (size_t)nst();
       uint64_t* nm = S.n_mask;
       if (changed) {
@@ -2059,10 +2090,10 @@ struct Engine {
   // sc.merged <- ExistingNode.requirements ∧ the pod's (existingnode.go:105-108); true when that differs from the node's
   // pre / pre_ok (probes): a PRISTINE node's remaining resources, fetched in the same round trip as its requirement set (lanes rw + 2 ..)
   // for the commit that usually follows (add_to_existing's first-pod path)
-  KS_DEV bool node_merge(int en, LaneVar<uint64_t>* pre = nullptr, bool* pre_ok = nullptr) {
+  KS_DEV bool node_merge(int en, LaneVar<uint64_t>* pre = nullptr, bool* pre_ok = nullptr, int os_hint = -2) {
     const Dict& d = P.dict;
     ReqBuf& m = sc.merged;
-    const int os = ov_find(en);
+    const int os = os_hint != -2 ? os_hint : ov_find(en);
     const NodeTabs t = node_tabs(os >= 0);
     const size_t i = os >= 0 ? (size_t)os : (size_t)en;
     const int rw = lay.rw, nr = lay.nr;
@@ -2128,6 +2159,12 @@ struct Engine {
   //     node that passed the group's filter, and in every inverse anti-affinity group it owns;
   //   * the registered domains and the non-empty-domain counts of the dictionary-keyed groups are derived again.
   KS_DEV bool probe_node_removed(int e) const {
+    if (prm_regs) {
+      bool f = false;
+      const int nrm = S.pr_n_removed;
+      for (int i = 0; i < nrm; ++i) f = f || (i < 64 ? prm0_.bcast(i) : prm1_.bcast(i - 64)) == (uint32_t)e;
+      return f;
+    }
     for (int i = 0; i < S.pr_n_removed; ++i) if ((int)S.pr_removed[i] == e) return true;
     return false;
   }
@@ -2387,6 +2424,8 @@ struct Engine {
       // a probe of a resident cluster: nothing is copied, the overlay starts empty
       Workspace& Sw = S;
       ov_regs = S.ov_cap == 64; n_ov = 0;
+      prm_regs = S.pr_n_removed <= 128;
+      if (prm_regs) { const uint32_t* pr = S.pr_removed; const int nrm = S.pr_n_removed; W::each([&](int l) { prm0_.at(l) = l < nrm ? pr[l] : 0xFFFFFFFFu; prm1_.at(l) = 64 + l < nrm ? pr[64 + l] : 0xFFFFFFFFu; }); }
       if (!ov_regs) W::for_n(S.ov_cap, [&](int i) { Sw.ov_key[i] = 0; });
       n_revived = 0;
     } else if (FULL && P.n_nodes) {

@@ -339,6 +339,7 @@ struct LaneVar {
 #if KS_DEVICE
   T v;
   KS_DEV T& at(int) { return v; }
+  KS_DEV T v_of(int) const { return v; }   // this lane's value (const access)
   KS_DEV void set(int lane, T x) {   // a wave-uniform value into one lane (v_writelane)
     static_assert(sizeof(T) == 4, "LaneVar::set: 32-bit values");
     uint32_t w = __builtin_bit_cast(uint32_t, v), m0_saved;
@@ -376,6 +377,7 @@ struct LaneVar {
 #else
   T v[64];
   T& at(int l) { return v[l]; }
+  T v_of(int l) const { return v[l]; }
   void set(int lane, T x) { v[lane] = x; }
   T shuffle(int, int src) const { return v[src & 63]; }   // callers never read a lane the same wave-wide call writes
   T bcast(int lane) const { return v[lane]; }
