@@ -306,8 +306,19 @@ def config4_multi_node(args, cc, rc, rank, world):
     t = time.perf_counter(); rc.decisions(sets, multi_node=True, library_prices=True); first_s = time.perf_counter() - t
     t = time.perf_counter(); cmds = rc.decisions(sets, multi_node=True, library_prices=True); dt = time.perf_counter() - t
     tm = rc.last_sweep["timings"]
+    json_form_s = (tm["descriptors_ms"] + tm["sweep_ms"] + tm["verdicts_ms"]) * 1e-3
+    # the binary form of the call, as in the single-node leg (ksched_sweep_arrays: the prefixes as a CSR of node positions — what a cgo
+    # caller hands over; the JSON form spends most of its descriptor phase parsing 160k node positions): same commands, the faster is quoted
+    for _ in range(2):
+        t = time.perf_counter(); cmds3 = rc.decisions(sets, multi_node=True, library_prices=True, arrays=True); dt3 = time.perf_counter() - t
+        if [(c["decision"], c["replacement"], c.get("replacementCapacityType")) for c in cmds3] != [(c["decision"], c["replacement"], c.get("replacementCapacityType")) for c in cmds]:
+            raise SystemExit("bench.py: the binary form of the multi-node sweep disagrees with the JSON form")
+        tm3 = rc.last_sweep["timings"]
+        if (tm3["descriptors_ms"] + tm3["sweep_ms"] + tm3["verdicts_ms"]) < (tm["descriptors_ms"] + tm["sweep_ms"] + tm["verdicts_ms"]):
+            tm, dt = tm3, min(dt, dt3)
     lib_s = (tm["descriptors_ms"] + tm["sweep_ms"] + tm["verdicts_ms"]) * 1e-3
     out["first_call_python_s"] = first_s
+    out["library_call_json_form_s"] = json_form_s
     by = dict(zip(key, cmds))
     chosen = []
     for w in mine:
