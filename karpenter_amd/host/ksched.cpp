@@ -2224,7 +2224,6 @@ static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas,
         end_probe(n0);
       }
     }
-    const auto t_cands = std::chrono::steady_clock::now();
     const uint32_t n = (uint32_t)node_off.size() - 1;
     // "prices" / "allSpot" may be left out: the session then takes every candidate's price from its own offering (node_price) and
     // its capacity type from its label. "multiNode": the simulations are prefixes of MultiNodeConsolidation's binary search —
@@ -2244,7 +2243,6 @@ static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas,
       for (uint32_t j = node_off[p]; j < node_off[p + 1]; ++j) m += B->node_pod_off[nodes[j] + 1] - B->node_pod_off[nodes[j]];
       pod_off[p + 1] = pod_off[p] + (uint32_t)m;
     }
-    const auto t_sizes = std::chrono::steady_clock::now();
     pods.resize(pod_off[n]);
     std::vector<int64_t> lims;
     const bool limits = !B->tmpl_lim.empty();
@@ -2269,7 +2267,6 @@ static char* sweep_impl(Session* B, const std::vector<ksolve_handle*>& replicas,
     sd.n_probes = n; sd.node_off = node_off.data(); sd.nodes = nodes.data(); sd.pod_off = pod_off.data(); sd.pods = pods.data();
     sd.tmpl_limits = limits ? lims.data() : nullptr;
     const auto t_desc = std::chrono::steady_clock::now();
-    if (getenv("KSCHED_SWEEP_TRACE")) { auto us_ = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); }; fprintf(stderr, "ksched sweep descriptors: candidates %.0f us, sizes %.0f us, pods + limits %.0f us (%u probes, %zu pods)\n", us_(t_begin, t_cands), us_(t_cands, t_sizes), us_(t_sizes, t_desc), n, pods.size()); }
     ksolve_sweep_results res{};
     ksolve_status st = replicas.size() > 1 ? run_replicas(const_cast<ksolve_handle**>(replicas.data()), (uint32_t)replicas.size(), &sd, &res) : run(B->handle, &sd, &res);
     const auto t_solved = std::chrono::steady_clock::now();
