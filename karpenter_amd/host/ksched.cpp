@@ -12,10 +12,13 @@
 // kernels use (csrc/reqalg.h), and anything the device build cannot solve is reported as "unsupported", never solved
 // on the CPU.
 #include <dlfcn.h>
+#include <pthread.h>
 
 #include <algorithm>
 #include <climits>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -192,16 +195,78 @@ struct Dictionary {
 // A table of requirement sets under construction (host memory, ABI layout).
 // fn(i) for i in [0, n) on a few threads, contiguous ranges (the probes of a sweep are independent — descriptors, verdicts — and so
 // are the rows of a million pods)
+// The worker threads are kept (round 6): a 10,000-probe sweep calls this twice — descriptors, verdicts — for a few hundred microseconds
+// of work each, and creating and joining eight threads cost as much as the work. One pool per process, created on first use and never
+// destroyed (its threads sleep on a condition variable; the process's exit ends them); a caller that finds the pool busy — another thread
+// of the process is inside a parallel_for — starts threads of its own as before.
+struct WorkerPool {
+  std::mutex busy;                                   // one parallel_for at a time
+  std::mutex m;
+  std::condition_variable cv_go, cv_done;
+  std::vector<std::thread> workers;
+  const std::function<void(size_t)>* job = nullptr;  // job(t) for t in 1..nt-1 (the caller runs t = 0)
+  size_t nt = 0, generation = 0, pending = 0;
+  explicit WorkerPool(size_t n_workers) {
+    for (size_t w = 0; w < n_workers; ++w) workers.emplace_back([this, w]() {
+      size_t seen = 0;
+      for (;;) {
+        const std::function<void(size_t)>* j = nullptr;
+        {
+          std::unique_lock<std::mutex> lk(m);
+          cv_go.wait(lk, [&] { return generation != seen; });
+          seen = generation;
+          if (w + 1 < nt) j = job;
+        }
+        if (j) {
+          (*j)(w + 1);
+          std::lock_guard<std::mutex> lk(m);
+          if (--pending == 0) cv_done.notify_one();
+        }
+      }
+    });
+    for (auto& t : workers) t.detach();
+  }
+  void run(size_t n_threads, const std::function<void(size_t)>& f) {   // f(t) for t in [0, n_threads), n_threads <= workers + 1
+    {
+      std::lock_guard<std::mutex> lk(m);
+      job = &f; nt = n_threads; pending = n_threads - 1; generation++;
+    }
+    cv_go.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return pending == 0; });
+    job = nullptr;
+  }
+};
+static WorkerPool* g_worker_pool = nullptr;           // leaked on purpose: no destructor runs against sleeping threads at exit
+static std::mutex g_worker_pool_m;
+static WorkerPool* worker_pool() {
+  std::lock_guard<std::mutex> lk(g_worker_pool_m);
+  if (!g_worker_pool) {
+    static bool fork_hook = false;
+    if (!fork_hook) { fork_hook = true; pthread_atfork(nullptr, nullptr, [] { g_worker_pool = nullptr; }); }   // a forked child has none of the threads: it makes its own pool
+    g_worker_pool = new WorkerPool(7);
+  }
+  return g_worker_pool;
+}
 template <class F>
 static void parallel_for(size_t n, F fn) {
   const size_t nt = n < 1024 ? 1 : std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency()));
   if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
-  std::vector<std::thread> pool;
   std::vector<std::string> errors(nt);
-  for (size_t t = 0; t < nt; ++t) pool.emplace_back([&, t]() {
+  auto part = [&](size_t t) {
     try { for (size_t i = n * t / nt, e = n * (t + 1) / nt; i < e; ++i) fn(i); } catch (const std::exception& e) { errors[t] = e.what(); }
-  });
-  for (auto& th : pool) th.join();
+  };
+  WorkerPool* wp = worker_pool();
+  if (wp->busy.try_lock()) {
+    std::lock_guard<std::mutex> hold(wp->busy, std::adopt_lock);
+    const std::function<void(size_t)> f = part;
+    wp->run(nt, f);
+  } else {
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < nt; ++t) pool.emplace_back(part, t);
+    for (auto& th : pool) th.join();
+  }
   for (auto& e : errors) if (!e.empty()) throw std::runtime_error(e);
 }
 
