@@ -660,6 +660,34 @@ def test_multi_node_sets_on_a_compact_cluster_fuzz(oracle, emu, seed, topology):
 
 
 @pytest.mark.parametrize("topology", [False, True])
+def test_large_removed_node_lists(oracle, emu, topology):
+    """A probe's removed nodes live in two vector registers when there are at most 128 of them (engine.h prm0_ / prm1_: the scan's mask of
+    removed nodes and the evaluation count's subtraction are ballots), in the HBM list beyond: sets of 63..65 nodes (the first register's
+    edge), 100 and 127..129 (the second's), 140 and 200 (the list), contiguous in sortCandidates' order and scattered over the cluster —
+    verdict and reference-equivalent evaluation count against the oracle's simulation of the same set."""
+    import random
+    cc = dz.make_resident_cluster(n_nodes=700, seed=31, topology=topology)
+    rc = dz.ResidentCluster.from_compact(cc, solver_lib=emu)
+    full, rng = dz.compact_candidates(cc), random.Random(31)
+    idxs = []
+    for k in (63, 64, 65, 100, 127, 128, 129, 140, 200):
+        off = rng.randrange(0, len(full) - k)
+        idxs.append(full[off:off + k])
+        idxs.append(sorted(rng.sample(full, k)))
+    sets = [[cc["nodes"][i] for i in idx] for idx in idxs]
+    cmds = rc.decisions(sets, multi_node=True, library_prices=True, arrays=True)
+    refs = rc.last_sweep["referenceBinEvaluations"]
+    base = dz.compact_problem(cc, pod_groups=[])
+    if topology:
+        base["clusterPods"] = dz.compact_cluster_pods(cc)
+    probes = [{"removeNodes": [cc["nodes"][i]["name"] for i in idx], "pods": [p for i in idx for p in dz.compact_node_pods(cc, i)]} for idx in idxs]
+    for j, r in enumerate(oracle.sweep(base, probes, threads=4, verdicts=True, multi_node=True)):
+        assert (cmds[j]["decision"], cmds[j]["replacement"], cmds[j].get("replacementCapacityType")) == oracle.verdict_key(r["verdict"]), (j, len(idxs[j]), cmds[j], r["verdict"])
+        assert refs[j] == r["counters"]["binEvaluations"], (j, len(idxs[j]))
+    rc.close()
+
+
+@pytest.mark.parametrize("topology", [False, True])
 def test_compact_sweep_equals_the_one_wavefront_kernel(emu, monkeypatch, topology):
     """ksolve_sweep runs a cluster whose dictionaries fit it through the COMPACT form of the launch (ksolve_pack_sweep4: four
     wavefronts per workgroup share the read-only instance-type tables and the template records that wave 0 prepared once, every
